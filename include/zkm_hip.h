@@ -1,0 +1,221 @@
+/*
+ * zkm_hip.h — C ABI of libzkm_hip.so, the MI355X (gfx950) shard-prover back-end.
+ *
+ * This is the drop-in boundary for Ziren's per-shard STARK proving path
+ *     MachineProver::commit + MachineProver::open      crates/stark/src/prover.rs:30-184
+ *     (CPU impl: commit :258-292, open :298-653)
+ * A Rust shim `HipProver<SC, A>: MachineProver<SC, A>` binds these entry
+ * points 1:1 to the trait's associated types and methods:
+ *
+ *     trait item (prover.rs)                    C ABI
+ *     ----------------------------------------  ---------------------------------------------
+ *     type DeviceMatrix           (:33-36)      zkm_matrix        (column-major, HBM resident)
+ *     type DeviceProverData       (:39)         zkm_pcs_data      (LDEs + Merkle digest layers)
+ *     type DeviceProvingKey       (:42)         zkm_pk
+ *     fn new(machine)             (:48)         zkm_ctx_create
+ *     fn setup / pk_to_device     (:54-66)      zkm_pk_setup      (pcs.commit of machine.rs:406-417)
+ *     pk.observe_into             machine.rs:79-86   zkm_pk_observe_into
+ *     fn commit(record, traces)   (:111-115)    zkm_commit
+ *     fn open(pk, data, chal)     (:118-126)    zkm_open
+ *     fn prove  (one shard)       (:660-693)    zkm_prove_shard
+ *     type Error                  (:45)         int status + zkm_last_error()
+ *
+ * Data representation: every field element crossing this ABI is a KoalaBear
+ * element as Plonky3 holds it in memory — a u32 in Montgomery form, R = 2^32, value < p =
+ * 0x7f000001 (crates/core/machine/include/kb31_t.hpp:458-503). Extension elements are 4 such
+ * words, low coefficient first (crates/stark/src/air/extension.rs:55-74). Host matrices are
+ * row-major (`RowMajorMatrix<KoalaBear>`, prover.rs:225). Digests are 8 words.
+ *
+ * Threading: a zkm_ctx is bound to one GPU and serialises calls internally; use one context
+ * per GPU (prover.rs:30 requires Send + Sync). No function unwinds or calls back.
+ * All functions return 0 on success, non-zero on failure (message via zkm_last_error()).
+ */
+#ifndef ZKM_HIP_H
+#define ZKM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ZKM_DIGEST_ELEMS 8
+#define ZKM_EXT_DEGREE 4
+#define ZKM_PERM_WIDTH 16
+#define ZKM_KOALABEAR_P 0x7f000001u
+
+typedef struct zkm_ctx zkm_ctx;
+typedef struct zkm_matrix zkm_matrix;
+typedef struct zkm_pcs_data zkm_pcs_data;
+typedef struct zkm_pk zkm_pk;
+typedef struct zkm_main_data zkm_main_data;
+
+/* FriConfig { log_blowup, num_queries, proof_of_work_bits } — crates/stark/src/kb31_poseidon2.rs:203-213 */
+typedef struct {
+  uint32_t log_blowup;
+  uint32_t num_queries;
+  uint32_t proof_of_work_bits;
+} zkm_fri_config;
+
+/* DuplexChallenger<KoalaBear, Perm, 16, 8> state; same fields as ChallengerPublicValues,
+ * crates/recursion/circuit/src/challenger.rs:62-66,117-150. */
+typedef struct {
+  uint32_t sponge_state[16];
+  uint32_t num_inputs;
+  uint32_t input_buffer[16];
+  uint32_t num_outputs;
+  uint32_t output_buffer[16];
+} zkm_challenger;
+
+/*
+ * Per-chip metadata `open` reads from `MachineChip` (crates/stark/src/chip.rs:24-175) and
+ * `StarkProvingKey` (machine.rs:58-75).
+ *
+ * lookups: the chip's *Local-scope* sends then receives (permutation.rs:110-116), as u32 words:
+ *     n_sends, n_receives,
+ *     per lookup: kind (LookupKind as usize, lookup/lookup.rs:22-48), n_values,
+ *       then n_values+1 VirtualPairCol (values..., multiplicity), each:
+ *         n_terms, constant (Montgomery),
+ *         n_terms x { (is_main << 31) | column , weight (Montgomery) }
+ *
+ * program: the chip's constraints (`Air::eval` of chip.rs:257-276 *including* the permutation
+ * constraints of permutation.rs:205-347) recorded as straight-line bytecode; see
+ * "Constraint bytecode" below. The Rust shim records it with a symbolic AirBuilder
+ * (same mechanism as lookup/builder.rs:14-112).
+ */
+typedef struct {
+  const char* name;
+  uint32_t main_width;
+  uint32_t prep_width;          /* 0 if the chip has no preprocessed trace */
+  int32_t prep_index;           /* index into the pk's preprocessed traces, -1 if none (pk.chip_ordering) */
+  uint32_t log_quotient_degree; /* chip.rs:81-89 */
+  uint32_t local_only;          /* chip.local_only(): open main/prep at zeta only (prover.rs:526-544) */
+  uint32_t commit_scope_global; /* 1: global_cumulative_sum = last 14 cells of the last main row (prover.rs:352-361) */
+  uint32_t num_constraints;     /* pk.constraints_map[name] (prover.rs:447-456) */
+  const uint32_t* lookups;
+  uint32_t lookups_len;
+  const uint32_t* program;
+  uint32_t program_len;
+} zkm_chip_desc;
+
+/*
+ * Constraint bytecode. Header: { n_instr, n_regs, n_constraints, 0 }, then n_instr
+ * instructions of 2 words: w0 = op | dst<<8 | a<<16 | b<<24 ; w1 = immediate.
+ * Registers hold extension elements; base values occupy coefficient 0.
+ * Loads (dst <- input; imm = column / index; a = row offset 0:local 1:next):
+ */
+enum {
+  ZKM_OP_LD_MAIN = 1,     /* base  main[a][imm]                                  */
+  ZKM_OP_LD_PREP = 2,     /* base  preprocessed[a][imm]                          */
+  ZKM_OP_LD_PERM = 3,     /* ext   permutation[a][imm] (imm = ext column)        */
+  ZKM_OP_LD_CONST = 4,    /* base  constant imm (Montgomery)                     */
+  ZKM_OP_LD_PV = 5,       /* base  public_values[imm]                            */
+  ZKM_OP_LD_CHALLENGE = 6,/* ext   permutation challenge imm (0: alpha, 1: beta) */
+  ZKM_OP_LD_LOCAL_SUM = 7,/* ext   local_cumulative_sum                          */
+  ZKM_OP_LD_GLOBAL_SUM = 8,/* base global_cumulative_sum word imm (0-6: x, 7-13: y) */
+  ZKM_OP_LD_IS_FIRST = 9, /* base  is_first_row selector                         */
+  ZKM_OP_LD_IS_LAST = 10, /* base  is_last_row selector                          */
+  ZKM_OP_LD_IS_TRANS = 11,/* base  is_transition selector                        */
+  /* arithmetic: dst <- a (op) b. "B" = both base, "E" = both ext, "EB" = a ext, b base */
+  ZKM_OP_ADD_B = 16, ZKM_OP_SUB_B = 17, ZKM_OP_MUL_B = 18, ZKM_OP_NEG_B = 19,
+  ZKM_OP_ADD_E = 20, ZKM_OP_SUB_E = 21, ZKM_OP_MUL_E = 22, ZKM_OP_NEG_E = 23,
+  ZKM_OP_ADD_EB = 24, ZKM_OP_SUB_EB = 25, ZKM_OP_MUL_EB = 26,
+  /* constraints, in order (folder.rs:79-102): accumulator += alpha^(C-1-k) * reg a */
+  ZKM_OP_ASSERT_B = 32,
+  ZKM_OP_ASSERT_E = 33
+};
+
+const char* zkm_last_error(void);
+
+/* ---- context ---------------------------------------------------------------------------- */
+int zkm_ctx_create(int device, zkm_ctx** out);
+void zkm_ctx_destroy(zkm_ctx* ctx);
+int zkm_ctx_synchronize(zkm_ctx* ctx);
+/* per-phase GPU time of the last zkm_commit/zkm_open on this context, in milliseconds (HIP
+ * events on the context's stream). names/values arrays of capacity cap; returns the count. */
+int zkm_ctx_last_timings(zkm_ctx* ctx, const char** names, float* ms, int cap);
+
+/* ---- DeviceMatrix ----------------------------------------------------------------------- */
+/* Upload a row-major host matrix (height a power of two) and lay it out column-major in HBM. */
+int zkm_matrix_upload(zkm_ctx* ctx, const uint32_t* host_row_major, size_t height, size_t width,
+                      zkm_matrix** out);
+int zkm_matrix_download(zkm_ctx* ctx, const zkm_matrix* m, uint32_t* host_row_major);
+size_t zkm_matrix_height(const zkm_matrix* m);
+size_t zkm_matrix_width(const zkm_matrix* m);
+void zkm_matrix_free(zkm_ctx* ctx, zkm_matrix* m);
+
+/* ---- Pcs::commit (TwoAdicFriPcs + MerkleTreeMmcs), call sites prover.rs:277,403,497 ------ */
+/* Commits n_mats matrices evaluated over the cosets domain_shift[i] * H_{height_i}
+ * (domain_shifts == NULL: all 1, i.e. natural domains). Each is coset-LDE'd by 2^log_blowup
+ * onto 3 * K, rows bit-reversed, and all are committed under one mixed-height Poseidon2
+ * Merkle tree. root_out receives the 8-word commitment. */
+int zkm_pcs_commit(zkm_ctx* ctx, size_t n_mats, const zkm_matrix* const* mats,
+                   const uint32_t* domain_shifts, uint32_t log_blowup,
+                   uint32_t root_out[ZKM_DIGEST_ELEMS], zkm_pcs_data** out);
+void zkm_pcs_data_free(zkm_ctx* ctx, zkm_pcs_data* d);
+/* test/inspection: copy LDE matrix idx (bit-reversed rows, row-major) to the host. */
+int zkm_pcs_data_get_lde(zkm_ctx* ctx, const zkm_pcs_data* d, size_t idx, uint32_t* host_row_major);
+/* Mmcs::open_batch(index): rows of every matrix at index >> (log_max_h - log_h_i), written
+ * back to back into values_out, and the sibling digests bottom-up into proof_out
+ * (log_max_height digests). Mirrors crates/recursion/circuit/src/fri.rs:363-405. */
+int zkm_pcs_open_batch(zkm_ctx* ctx, const zkm_pcs_data* d, size_t index, uint32_t* values_out,
+                       uint32_t* proof_out);
+
+/* ---- proving key ------------------------------------------------------------------------ */
+/* StarkMachine::setup's commitment to the preprocessed traces (machine.rs:406-417) +
+ * pk_to_device (prover.rs:62-66). n_prep may be 0 (then the opening has no preprocessed round). */
+int zkm_pk_setup(zkm_ctx* ctx, size_t n_prep, const zkm_matrix* const* prep_traces,
+                 const uint32_t* prep_local_only, uint32_t pc_start,
+                 const uint32_t initial_global_cumulative_sum[14], uint32_t log_blowup,
+                 zkm_pk** out);
+int zkm_pk_commitment(const zkm_pk* pk, uint32_t root_out[ZKM_DIGEST_ELEMS]);
+/* StarkProvingKey::observe_into, machine.rs:79-86 */
+int zkm_pk_observe_into(const zkm_pk* pk, zkm_challenger* challenger);
+void zkm_pk_free(zkm_ctx* ctx, zkm_pk* pk);
+
+/* ---- MachineProver::commit / open ------------------------------------------------------- */
+/* commit (prover.rs:258-292): orders chips by (Reverse(height), name), commits the main traces.
+ * The matrices stay owned by the caller but must outlive the returned zkm_main_data.
+ * order_out[i] = caller index of the chip at sorted position i (the chip_ordering). */
+int zkm_commit(zkm_ctx* ctx, size_t n_chips, const char* const* names,
+               const zkm_matrix* const* main_traces, const uint32_t* public_values,
+               size_t n_public_values, uint32_t log_blowup, uint32_t main_commit_out[ZKM_DIGEST_ELEMS],
+               uint32_t* order_out, zkm_main_data** out);
+void zkm_main_data_free(zkm_ctx* ctx, zkm_main_data* d);
+
+/* open (prover.rs:298-653). chips[] is in the caller's order (same order as zkm_commit's
+ * names/main_traces). challenger is the post-`pk.observe_into` clone (prove.rs:496) and is
+ * advanced in place. The proof is written as the flat word stream documented in
+ * INTEGRATION.md ("ShardProof stream", the Appendix-B order of SURVEY.md). If proof_cap is
+ * too small the call fails and *proof_len holds the required length. */
+int zkm_open(zkm_ctx* ctx, const zkm_pk* pk, zkm_main_data* data, const zkm_chip_desc* chips,
+             const zkm_fri_config* fri, uint32_t num_pv_elts, zkm_challenger* challenger,
+             uint32_t* proof_out, size_t proof_cap, size_t* proof_len);
+
+/* commit + open for one shard with device-resident traces (prover.rs:679-690). */
+int zkm_prove_shard(zkm_ctx* ctx, const zkm_pk* pk, size_t n_chips, const zkm_chip_desc* chips,
+                    const zkm_matrix* const* main_traces, const uint32_t* public_values,
+                    size_t n_public_values, const zkm_fri_config* fri, uint32_t num_pv_elts,
+                    zkm_challenger* challenger, uint32_t* proof_out, size_t proof_cap,
+                    size_t* proof_len);
+
+/* ---- fine-grained entry points (parity tests, micro-benchmarks) ------------------------- */
+/* Poseidon2 width-16 permutation on n states (n x 16 words, in place), on the GPU.
+ * zkm_primitives::poseidon2_init, crates/primitives/src/lib.rs:1107-1122. */
+int zkm_poseidon2_permute_batch(zkm_ctx* ctx, uint32_t* states, size_t n);
+/* Radix2Dit::coset_lde_batch + bit_reverse_rows on a host matrix:
+ * out is (height << log_blowup) x width row-major. lde_shift multiplies the evaluation coset
+ * (Pcs::commit passes GENERATOR / domain_shift). */
+int zkm_coset_lde_batch(zkm_ctx* ctx, const uint32_t* host_row_major, size_t height, size_t width,
+                        uint32_t log_blowup, uint32_t lde_shift, uint32_t* out_row_major);
+/* Host-side duplex challenger (DuplexChallenger<KoalaBear,Perm,16,8>), used by zkm_open. */
+void zkm_challenger_init(zkm_challenger* c);
+void zkm_challenger_observe(zkm_challenger* c, const uint32_t* values, size_t n);
+uint32_t zkm_challenger_sample(zkm_challenger* c);
+uint32_t zkm_challenger_sample_bits(zkm_challenger* c, uint32_t bits);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ZKM_HIP_H */

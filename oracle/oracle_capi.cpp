@@ -1,0 +1,337 @@
+// TEST INFRASTRUCTURE — C entry points of the CPU oracle (liboracle.so), loaded with ctypes by
+// tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg only. The product path
+// (ziren_amd/, libzkm_hip.so) never links, imports or executes anything in this directory.
+//
+// The functions take and return exactly the data the product's C ABI (include/zkm_hip.h)
+// does — Montgomery words, row-major host matrices, the same chip descriptors and the same
+// ShardProof word stream — so a parity test feeds both sides identical bytes.
+#include "stark.hpp"
+#include <cstdio>
+#include <omp.h>
+
+using namespace orc;
+
+static thread_local std::string g_err;
+
+static Matrix load_matrix(const uint32_t* p, size_t h, size_t w) {
+  Matrix m(h, w);
+  for (size_t i = 0; i < h * w; i++) m.v[i] = from_monty(p[i]);
+  return m;
+}
+static void put_digest(std::vector<uint32_t>& o, const Digest& d) { for (int i = 0; i < 8; i++) o.push_back(to_monty(d.d[i])); }
+static void put_ext(std::vector<uint32_t>& o, const E& e) { for (int i = 0; i < 4; i++) o.push_back(to_monty(e.c[i])); }
+static void put_exts(std::vector<uint32_t>& o, const std::vector<E>& v) { for (auto& e : v) put_ext(o, e); }
+
+static std::vector<uint32_t> serialize_proof(const ShardProof& p) {
+  std::vector<uint32_t> o;
+  put_digest(o, p.main_commit); put_digest(o, p.perm_commit); put_digest(o, p.quotient_commit);
+  o.push_back((uint32_t)p.chips.size());
+  for (size_t i = 0; i < p.chips.size(); i++) {
+    const ChipOpenedValues& c = p.chips[i];
+    o.push_back((uint32_t)p.order[i]);
+    o.push_back(c.log_degree);
+    o.push_back((uint32_t)c.prep_local.size()); put_exts(o, c.prep_local); put_exts(o, c.prep_next);
+    o.push_back((uint32_t)c.main_local.size()); put_exts(o, c.main_local); put_exts(o, c.main_next);
+    o.push_back((uint32_t)c.perm_local.size()); put_exts(o, c.perm_local); put_exts(o, c.perm_next);
+    o.push_back((uint32_t)c.quotient.size());
+    for (auto& q : c.quotient) put_exts(o, q);
+    for (int k = 0; k < 14; k++) o.push_back(to_monty(c.global_sum[k]));
+    put_ext(o, c.local_sum);
+  }
+  const FriProof& f = p.fri;
+  o.push_back((uint32_t)f.commit_phase_commits.size());
+  for (auto& d : f.commit_phase_commits) put_digest(o, d);
+  o.push_back((uint32_t)f.queries.size());
+  for (auto& q : f.queries) {
+    o.push_back((uint32_t)q.input_proof.size());
+    for (auto& bo : q.input_proof) {
+      o.push_back((uint32_t)bo.opened_values.size());
+      for (auto& row : bo.opened_values) { o.push_back((uint32_t)row.size()); for (F v : row) o.push_back(to_monty(v)); }
+      o.push_back((uint32_t)bo.proof.size());
+      for (auto& d : bo.proof) put_digest(o, d);
+    }
+    o.push_back((uint32_t)q.steps.size());
+    for (auto& s : q.steps) {
+      put_ext(o, s.sibling_value);
+      o.push_back((uint32_t)s.proof.size());
+      for (auto& d : s.proof) put_digest(o, d);
+    }
+  }
+  put_ext(o, f.final_poly);
+  o.push_back(to_monty(f.pow_witness));
+  o.push_back((uint32_t)p.public_values.size());
+  for (F v : p.public_values) o.push_back(to_monty(v));
+  return o;
+}
+
+struct Reader {
+  const uint32_t* p; size_t n, pos = 0;
+  uint32_t u() { if (pos >= n) throw std::runtime_error("proof stream truncated"); return p[pos++]; }
+  F f() { return from_monty(u()); }
+  Digest digest() { Digest d; for (int i = 0; i < 8; i++) d.d[i] = f(); return d; }
+  E ext() { E e; for (int i = 0; i < 4; i++) e.c[i] = f(); return e; }
+  std::vector<E> exts(size_t k) { std::vector<E> v(k); for (auto& e : v) e = ext(); return v; }
+};
+
+static ShardProof parse_proof(const uint32_t* w, size_t n) {
+  Reader r{w, n};
+  ShardProof p;
+  p.main_commit = r.digest(); p.perm_commit = r.digest(); p.quotient_commit = r.digest();
+  size_t nc = r.u();
+  for (size_t i = 0; i < nc; i++) {
+    ChipOpenedValues c;
+    p.order.push_back(r.u());
+    c.log_degree = r.u();
+    size_t k = r.u(); c.prep_local = r.exts(k); c.prep_next = r.exts(k);
+    k = r.u(); c.main_local = r.exts(k); c.main_next = r.exts(k);
+    k = r.u(); c.perm_local = r.exts(k); c.perm_next = r.exts(k);
+    k = r.u(); for (size_t j = 0; j < k; j++) c.quotient.push_back(r.exts(4));
+    for (int j = 0; j < 14; j++) c.global_sum[j] = r.f();
+    c.local_sum = r.ext();
+    p.chips.push_back(std::move(c));
+  }
+  FriProof& f = p.fri;
+  size_t ncp = r.u();
+  for (size_t i = 0; i < ncp; i++) f.commit_phase_commits.push_back(r.digest());
+  size_t nq = r.u();
+  for (size_t q = 0; q < nq; q++) {
+    QueryProof qp;
+    size_t nr = r.u();
+    for (size_t j = 0; j < nr; j++) {
+      BatchOpening bo;
+      size_t nm = r.u();
+      for (size_t m = 0; m < nm; m++) { size_t wd = r.u(); std::vector<F> row(wd); for (auto& v : row) v = r.f(); bo.opened_values.push_back(row); }
+      size_t pl = r.u();
+      for (size_t l = 0; l < pl; l++) bo.proof.push_back(r.digest());
+      qp.input_proof.push_back(std::move(bo));
+    }
+    size_t ns = r.u();
+    for (size_t s = 0; s < ns; s++) {
+      CommitPhaseStep st; st.sibling_value = r.ext();
+      size_t pl = r.u();
+      for (size_t l = 0; l < pl; l++) st.proof.push_back(r.digest());
+      qp.steps.push_back(std::move(st));
+    }
+    f.queries.push_back(std::move(qp));
+  }
+  f.final_poly = r.ext();
+  f.pow_witness = r.f();
+  size_t npv = r.u();
+  for (size_t i = 0; i < npv; i++) p.public_values.push_back(r.f());
+  if (r.pos != n) throw std::runtime_error("proof stream has trailing words");
+  return p;
+}
+
+static Challenger load_challenger(const zkm_challenger* c) {
+  Challenger ch;
+  for (int i = 0; i < 16; i++) ch.state[i] = from_monty(c->sponge_state[i]);
+  for (uint32_t i = 0; i < c->num_inputs; i++) ch.in.push_back(from_monty(c->input_buffer[i]));
+  for (uint32_t i = 0; i < c->num_outputs; i++) ch.out.push_back(from_monty(c->output_buffer[i]));
+  return ch;
+}
+static void store_challenger(const Challenger& ch, zkm_challenger* c) {
+  memset(c, 0, sizeof *c);
+  for (int i = 0; i < 16; i++) c->sponge_state[i] = to_monty(ch.state[i]);
+  c->num_inputs = (uint32_t)ch.in.size();
+  for (size_t i = 0; i < ch.in.size(); i++) c->input_buffer[i] = to_monty(ch.in[i]);
+  c->num_outputs = (uint32_t)ch.out.size();
+  for (size_t i = 0; i < ch.out.size(); i++) c->output_buffer[i] = to_monty(ch.out[i]);
+}
+
+#define ORC_TRY try {
+#define ORC_CATCH } catch (const std::exception& e) { g_err = e.what(); return -1; } return 0;
+
+extern "C" {
+
+const char* orc_last_error(void) { return g_err.c_str(); }
+int orc_num_threads(void) { return omp_get_max_threads(); }
+void orc_set_num_threads(int n) { omp_set_num_threads(n); }
+
+// field / extension vectors (canonical words in, canonical words out) — for the KAT tests
+void orc_field_ops(const uint32_t* a, const uint32_t* b, size_t n, uint32_t* add, uint32_t* sub, uint32_t* mul,
+                   uint32_t* inv, uint32_t* a_monty) {
+  for (size_t i = 0; i < n; i++) {
+    add[i] = fadd(a[i], b[i]); sub[i] = fsub(a[i], b[i]); mul[i] = fmul(a[i], b[i]);
+    inv[i] = a[i] ? finv(a[i]) : 0; a_monty[i] = to_monty(a[i]);
+  }
+}
+void orc_from_monty(const uint32_t* in, uint32_t* out, size_t n) { for (size_t i = 0; i < n; i++) out[i] = from_monty(in[i]); }
+void orc_to_monty(const uint32_t* in, uint32_t* out, size_t n) { for (size_t i = 0; i < n; i++) out[i] = to_monty(in[i]); }
+// ext ops on Montgomery words: out_mul = a*b, out_inv = 1/a
+void orc_ext_ops(const uint32_t* a, const uint32_t* b, size_t n, uint32_t* out_mul, uint32_t* out_inv) {
+  for (size_t i = 0; i < n; i++) {
+    E x, y;
+    for (int k = 0; k < 4; k++) { x.c[k] = from_monty(a[4 * i + k]); y.c[k] = from_monty(b[4 * i + k]); }
+    E m = emul(x, y), iv = eis_zero(x) ? ezero() : einv(x);
+    for (int k = 0; k < 4; k++) { out_mul[4 * i + k] = to_monty(m.c[k]); out_inv[4 * i + k] = to_monty(iv.c[k]); }
+  }
+}
+uint32_t orc_two_adic_generator(int bits) { return to_monty(two_adic_generator(bits)); }
+
+// Poseidon2 on n states of 16 Montgomery words, in place.
+void orc_poseidon2_permute_batch(uint32_t* states, size_t n) {
+#pragma omp parallel for
+  for (size_t i = 0; i < n; i++) {
+    F s[16];
+    for (int k = 0; k < 16; k++) s[k] = from_monty(states[16 * i + k]);
+    poseidon2_permute(s);
+    for (int k = 0; k < 16; k++) states[16 * i + k] = to_monty(s[k]);
+  }
+}
+void orc_hash(const uint32_t* in, size_t len, uint32_t out[8]) {
+  std::vector<F> v(len);
+  for (size_t i = 0; i < len; i++) v[i] = from_monty(in[i]);
+  Digest d = hash_slice(v.data(), len);
+  for (int i = 0; i < 8; i++) out[i] = to_monty(d.d[i]);
+}
+void orc_compress(const uint32_t l[8], const uint32_t r[8], uint32_t out[8]) {
+  Digest a, b;
+  for (int i = 0; i < 8; i++) { a.d[i] = from_monty(l[i]); b.d[i] = from_monty(r[i]); }
+  Digest d = compress(a, b);
+  for (int i = 0; i < 8; i++) out[i] = to_monty(d.d[i]);
+}
+
+void orc_challenger_init(zkm_challenger* c) { memset(c, 0, sizeof *c); }
+void orc_challenger_observe(zkm_challenger* c, const uint32_t* v, size_t n) {
+  Challenger ch = load_challenger(c);
+  for (size_t i = 0; i < n; i++) ch.observe(from_monty(v[i]));
+  store_challenger(ch, c);
+}
+uint32_t orc_challenger_sample(zkm_challenger* c) {
+  Challenger ch = load_challenger(c);
+  F v = ch.sample();
+  store_challenger(ch, c);
+  return to_monty(v);
+}
+uint32_t orc_challenger_sample_bits(zkm_challenger* c, uint32_t bits) {
+  Challenger ch = load_challenger(c);
+  uint32_t v = ch.sample_bits(bits);
+  store_challenger(ch, c);
+  return v;
+}
+uint32_t orc_challenger_grind(zkm_challenger* c, uint32_t bits) {
+  Challenger ch = load_challenger(c);
+  F w = ch.grind(bits);
+  store_challenger(ch, c);
+  return to_monty(w);
+}
+
+int orc_coset_lde_batch(const uint32_t* in, size_t h, size_t w, uint32_t log_blowup, uint32_t lde_shift, uint32_t* out) {
+  ORC_TRY
+  Matrix m = load_matrix(in, h, w);
+  Matrix l = coset_lde_matrix_bitrev(m, log_blowup, from_monty(lde_shift));
+  for (size_t i = 0; i < l.v.size(); i++) out[i] = to_monty(l.v[i]);
+  ORC_CATCH
+}
+
+// Pcs::commit of n matrices; optionally returns every LDE (row-major, bit-reversed rows, back to back)
+// and all digest layers (layer 0 first) back to back.
+int orc_pcs_commit(size_t n_mats, const uint32_t* const* mats, const size_t* heights, const size_t* widths,
+                   const uint32_t* domain_shifts, uint32_t log_blowup, uint32_t root_out[8], uint32_t* ldes_out,
+                   uint32_t* layers_out) {
+  ORC_TRY
+  std::vector<Matrix> ms; std::vector<F> sh;
+  for (size_t i = 0; i < n_mats; i++) { ms.push_back(load_matrix(mats[i], heights[i], widths[i])); sh.push_back(domain_shifts ? from_monty(domain_shifts[i]) : 1); }
+  PcsData d = pcs_commit(ms, sh, log_blowup);
+  for (int i = 0; i < 8; i++) root_out[i] = to_monty(d.tree.root().d[i]);
+  if (ldes_out) { size_t pos = 0; for (auto& l : d.tree.leaves) for (F v : l.v) ldes_out[pos++] = to_monty(v); }
+  if (layers_out) { size_t pos = 0; for (auto& layer : d.tree.layers) for (auto& dg : layer) for (int k = 0; k < 8; k++) layers_out[pos++] = to_monty(dg.d[k]); }
+  ORC_CATCH
+}
+
+// open_batch on a fresh commit of the given matrices (test helper): values then proof.
+int orc_pcs_open_batch(size_t n_mats, const uint32_t* const* mats, const size_t* heights, const size_t* widths,
+                       const uint32_t* domain_shifts, uint32_t log_blowup, size_t index, uint32_t* values_out,
+                       uint32_t* proof_out, int* verify_ok) {
+  ORC_TRY
+  std::vector<Matrix> ms; std::vector<F> sh;
+  for (size_t i = 0; i < n_mats; i++) { ms.push_back(load_matrix(mats[i], heights[i], widths[i])); sh.push_back(domain_shifts ? from_monty(domain_shifts[i]) : 1); }
+  PcsData d = pcs_commit(ms, sh, log_blowup);
+  BatchOpening bo = mmcs_open_batch(d.tree, index);
+  size_t pos = 0;
+  for (auto& row : bo.opened_values) for (F v : row) values_out[pos++] = to_monty(v);
+  pos = 0;
+  for (auto& dg : bo.proof) for (int k = 0; k < 8; k++) proof_out[pos++] = to_monty(dg.d[k]);
+  std::vector<size_t> dims;
+  for (auto& l : d.tree.leaves) dims.push_back(l.h);
+  *verify_ok = mmcs_verify_batch(d.tree.root(), dims, index, bo.opened_values, bo.proof);
+  ORC_CATCH
+}
+
+struct orc_pk { ProvingKey pk; VerifyingKey vk; };
+
+int orc_pk_setup(size_t n_prep, const uint32_t* const* prep, const size_t* heights, const size_t* widths,
+                 const uint32_t* local_only, uint32_t pc_start, const uint32_t igcs[14], uint32_t log_blowup,
+                 orc_pk** out) {
+  ORC_TRY
+  orc_pk* k = new orc_pk();
+  ProvingKey& pk = k->pk;
+  for (size_t i = 0; i < n_prep; i++) { pk.prep_traces.push_back(load_matrix(prep[i], heights[i], widths[i])); pk.prep_local_only.push_back(local_only[i]); }
+  pk.has_prep = n_prep > 0;
+  if (pk.has_prep) { pk.data = pcs_commit(pk.prep_traces, {}, log_blowup); pk.commit = pk.data.tree.root(); }
+  else memset(pk.commit.d, 0, sizeof pk.commit.d);
+  pk.pc_start = from_monty(pc_start);
+  for (int i = 0; i < 14; i++) pk.initial_global_cumulative_sum[i] = from_monty(igcs[i]);
+  k->vk.commit = pk.commit; k->vk.pc_start = pk.pc_start;
+  memcpy(k->vk.initial_global_cumulative_sum, pk.initial_global_cumulative_sum, sizeof pk.initial_global_cumulative_sum);
+  k->vk.has_prep = pk.has_prep;
+  for (auto& t : pk.prep_traces) k->vk.prep_log_heights.push_back(log2_strict(t.h));
+  *out = k;
+  ORC_CATCH
+}
+void orc_pk_commitment(const orc_pk* k, uint32_t out[8]) { for (int i = 0; i < 8; i++) out[i] = to_monty(k->pk.commit.d[i]); }
+void orc_pk_observe_into(const orc_pk* k, zkm_challenger* c) {
+  Challenger ch = load_challenger(c);
+  k->pk.observe_into(ch);
+  store_challenger(ch, c);
+}
+void orc_pk_free(orc_pk* k) { delete k; }
+
+// commit + open of one shard. traces: row-major Montgomery host matrices, caller order.
+// timings_out (nullable): [commit_seconds, open_seconds].
+int orc_prove_shard(const orc_pk* k, size_t n_chips, const zkm_chip_desc* descs, const uint32_t* const* traces,
+                    const size_t* heights, const uint32_t* public_values, size_t n_pv, const zkm_fri_config* fri,
+                    uint32_t num_pv_elts, zkm_challenger* challenger, uint32_t* proof_out, size_t proof_cap,
+                    size_t* proof_len, double* timings_out) {
+  ORC_TRY
+  std::vector<Chip> chips; std::vector<std::string> names; std::vector<Matrix> ms;
+  for (size_t i = 0; i < n_chips; i++) {
+    chips.push_back(parse_chip(descs[i]));
+    names.push_back(descs[i].name);
+    ms.push_back(load_matrix(traces[i], heights[i], descs[i].main_width));
+  }
+  std::vector<F> pv(n_pv);
+  for (size_t i = 0; i < n_pv; i++) pv[i] = from_monty(public_values[i]);
+  FriConfig cfg{(int)fri->log_blowup, (int)fri->num_queries, (int)fri->proof_of_work_bits};
+  Challenger ch = load_challenger(challenger);
+  double t0 = omp_get_wtime();
+  MainData md = shard_commit(names, ms, pv, cfg.log_blowup);
+  double t1 = omp_get_wtime();
+  ShardProof p = shard_open(k->pk, md, chips, cfg, num_pv_elts, ch);
+  double t2 = omp_get_wtime();
+  if (timings_out) { timings_out[0] = t1 - t0; timings_out[1] = t2 - t1; }
+  store_challenger(ch, challenger);
+  std::vector<uint32_t> s = serialize_proof(p);
+  *proof_len = s.size();
+  if (s.size() > proof_cap) throw std::runtime_error("proof buffer too small");
+  memcpy(proof_out, s.data(), s.size() * 4);
+  ORC_CATCH
+}
+
+// Verifier::verify_shard on a proof stream. challenger: post vk.observe_into. *verdict = 0 accept.
+int orc_verify_shard(const orc_pk* k, size_t n_chips, const zkm_chip_desc* descs, const zkm_fri_config* fri,
+                     uint32_t num_pv_elts, zkm_challenger* challenger, const uint32_t* proof, size_t proof_len,
+                     int* verdict) {
+  ORC_TRY
+  std::vector<Chip> chips;
+  for (size_t i = 0; i < n_chips; i++) chips.push_back(parse_chip(descs[i]));
+  FriConfig cfg{(int)fri->log_blowup, (int)fri->num_queries, (int)fri->proof_of_work_bits};
+  Challenger ch = load_challenger(challenger);
+  ShardProof p = parse_proof(proof, proof_len);
+  if (p.chips.size() != n_chips) { *verdict = 1; return 0; }
+  *verdict = verify_shard(k->vk, chips, cfg, num_pv_elts, ch, p);
+  store_challenger(ch, challenger);
+  ORC_CATCH
+}
+
+}  // extern "C"

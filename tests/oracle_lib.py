@@ -1,0 +1,174 @@
+"""ctypes binding of oracle/liboracle.so — TEST INFRASTRUCTURE (see oracle/oracle_capi.cpp)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from ziren_amd import abi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_LIB = None
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "all"])
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(ROOT, "oracle", "liboracle.so")
+        if not os.path.exists(path):
+            build()
+        L = C.CDLL(path)
+        L.orc_last_error.restype = C.c_char_p
+        L.orc_challenger_sample.restype = C.c_uint32
+        L.orc_challenger_sample_bits.restype = C.c_uint32
+        L.orc_challenger_grind.restype = C.c_uint32
+        L.orc_two_adic_generator.restype = C.c_uint32
+        _LIB = L
+    return _LIB
+
+
+def _check(rc):
+    if rc != 0:
+        raise RuntimeError("oracle: " + lib().orc_last_error().decode())
+
+
+def _ptr_array(mats):
+    arr = (abi.u32p * len(mats))()
+    for i, m in enumerate(mats):
+        assert m.dtype == np.uint32 and m.flags["C_CONTIGUOUS"]
+        arr[i] = abi.as_u32p(m)
+    return arr
+
+
+def _sizes(vals):
+    return (C.c_size_t * len(vals))(*vals)
+
+
+def poseidon2_permute_batch(states):
+    s = np.ascontiguousarray(states, dtype=np.uint32).copy()
+    lib().orc_poseidon2_permute_batch(abi.as_u32p(s), C.c_size_t(s.shape[0]))
+    return s
+
+
+def hash_slice(v):
+    v = np.ascontiguousarray(v, dtype=np.uint32)
+    out = np.zeros(8, dtype=np.uint32)
+    lib().orc_hash(abi.as_u32p(v), C.c_size_t(len(v)), abi.as_u32p(out))
+    return out
+
+
+def compress(l, r):
+    out = np.zeros(8, dtype=np.uint32)
+    lib().orc_compress(abi.as_u32p(np.ascontiguousarray(l, dtype=np.uint32)),
+                       abi.as_u32p(np.ascontiguousarray(r, dtype=np.uint32)), abi.as_u32p(out))
+    return out
+
+
+def coset_lde_batch(mat, log_blowup, lde_shift):
+    mat = np.ascontiguousarray(mat, dtype=np.uint32)
+    h, w = mat.shape
+    out = np.zeros((h << log_blowup, w), dtype=np.uint32)
+    _check(lib().orc_coset_lde_batch(abi.as_u32p(mat), C.c_size_t(h), C.c_size_t(w), C.c_uint32(log_blowup),
+                                     C.c_uint32(lde_shift), abi.as_u32p(out)))
+    return out
+
+
+def pcs_commit(mats, log_blowup, domain_shifts=None, want_ldes=False, want_layers=False):
+    mats = [np.ascontiguousarray(m, dtype=np.uint32) for m in mats]
+    root = np.zeros(8, dtype=np.uint32)
+    hs, ws = [m.shape[0] for m in mats], [m.shape[1] for m in mats]
+    ldes = np.zeros(sum((h << log_blowup) * w for h, w in zip(hs, ws)), dtype=np.uint32) if want_ldes else None
+    maxh = max(hs) << log_blowup
+    layers = np.zeros((2 * maxh - 1) * 8, dtype=np.uint32) if want_layers else None
+    sh = None
+    if domain_shifts is not None:
+        sh = np.ascontiguousarray(domain_shifts, dtype=np.uint32)
+    _check(lib().orc_pcs_commit(C.c_size_t(len(mats)), _ptr_array(mats), _sizes(hs), _sizes(ws),
+                                abi.as_u32p(sh) if sh is not None else None, C.c_uint32(log_blowup),
+                                abi.as_u32p(root), abi.as_u32p(ldes) if want_ldes else None,
+                                abi.as_u32p(layers) if want_layers else None))
+    out_ldes = None
+    if want_ldes:
+        out_ldes, pos = [], 0
+        for h, w in zip(hs, ws):
+            H = h << log_blowup
+            out_ldes.append(ldes[pos:pos + H * w].reshape(H, w))
+            pos += H * w
+    return root, out_ldes, layers
+
+
+def pcs_open_batch(mats, log_blowup, index, domain_shifts=None):
+    mats = [np.ascontiguousarray(m, dtype=np.uint32) for m in mats]
+    hs, ws = [m.shape[0] for m in mats], [m.shape[1] for m in mats]
+    values = np.zeros(sum(ws), dtype=np.uint32)
+    logmax = (max(hs) << log_blowup).bit_length() - 1
+    proof = np.zeros(logmax * 8, dtype=np.uint32)
+    ok = C.c_int(0)
+    sh = np.ascontiguousarray(domain_shifts, dtype=np.uint32) if domain_shifts is not None else None
+    _check(lib().orc_pcs_open_batch(C.c_size_t(len(mats)), _ptr_array(mats), _sizes(hs), _sizes(ws),
+                                    abi.as_u32p(sh) if sh is not None else None, C.c_uint32(log_blowup),
+                                    C.c_size_t(index), abi.as_u32p(values), abi.as_u32p(proof), C.byref(ok)))
+    return values, proof.reshape(logmax, 8), bool(ok.value)
+
+
+class Pk:
+    def __init__(self, prep_traces, local_only, pc_start, igcs, log_blowup):
+        prep = [np.ascontiguousarray(m, dtype=np.uint32) for m in prep_traces]
+        self.h = C.c_void_p()
+        lo = np.ascontiguousarray(local_only, dtype=np.uint32) if len(prep) else np.zeros(1, dtype=np.uint32)
+        ig = np.ascontiguousarray(igcs, dtype=np.uint32)
+        _check(lib().orc_pk_setup(C.c_size_t(len(prep)), _ptr_array(prep), _sizes([m.shape[0] for m in prep]),
+                                  _sizes([m.shape[1] for m in prep]), abi.as_u32p(lo), C.c_uint32(pc_start),
+                                  abi.as_u32p(ig), C.c_uint32(log_blowup), C.byref(self.h)))
+
+    def commitment(self):
+        out = np.zeros(8, dtype=np.uint32)
+        lib().orc_pk_commitment(self.h, abi.as_u32p(out))
+        return out
+
+    def observe_into(self, ch):
+        lib().orc_pk_observe_into(self.h, C.byref(ch))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_pk_free(self.h)
+            self.h = None
+
+
+def new_challenger():
+    c = abi.Challenger()
+    lib().orc_challenger_init(C.byref(c))
+    return c
+
+
+def challenger_observe(c, vals):
+    v = np.ascontiguousarray(vals, dtype=np.uint32)
+    lib().orc_challenger_observe(C.byref(c), abi.as_u32p(v), C.c_size_t(len(v)))
+
+
+def prove_shard(pk, chips, traces, public_values, fri, num_pv_elts, challenger, proof_cap=1 << 24):
+    descs, keep = abi.make_chip_descs(chips)
+    traces = [np.ascontiguousarray(t, dtype=np.uint32) for t in traces]
+    pv = np.ascontiguousarray(public_values, dtype=np.uint32)
+    out = np.zeros(proof_cap, dtype=np.uint32)
+    plen = C.c_size_t(0)
+    timings = (C.c_double * 2)()
+    _check(lib().orc_prove_shard(pk.h, C.c_size_t(len(chips)), descs, _ptr_array(traces),
+                                 _sizes([t.shape[0] for t in traces]), abi.as_u32p(pv), C.c_size_t(len(pv)),
+                                 C.byref(fri), C.c_uint32(num_pv_elts), C.byref(challenger), abi.as_u32p(out),
+                                 C.c_size_t(proof_cap), C.byref(plen), timings))
+    return out[:plen.value].copy(), (timings[0], timings[1])
+
+
+def verify_shard(pk, chips, fri, num_pv_elts, challenger, proof):
+    descs, keep = abi.make_chip_descs(chips)
+    proof = np.ascontiguousarray(proof, dtype=np.uint32)
+    verdict = C.c_int(-1)
+    _check(lib().orc_verify_shard(pk.h, C.c_size_t(len(chips)), descs, C.byref(fri), C.c_uint32(num_pv_elts),
+                                  C.byref(challenger), abi.as_u32p(proof), C.c_size_t(len(proof)),
+                                  C.byref(verdict)))
+    return verdict.value
