@@ -1,0 +1,167 @@
+// KoalaBear (p = 2^31 - 2^24 + 1) in Montgomery form, R = 2^32, and its quartic extension
+// F[X]/(X^4 - 3), for gfx950 device code and the host-side transcript.
+//
+// Representation is the one Plonky3's KoalaBear (MontyField31) keeps in memory and the one
+// the reference's kb31_t uses (crates/core/machine/include/kb31_t.hpp:458-503), so trace
+// words cross the ABI untouched. Reduction is written for the CDNA4 integer pipe: one
+// 32x32->64 product (v_mad_u64_u32 / v_mul_hi_u32), the Montgomery quotient as shift-adds
+// (MU = 2^31 + 2^24 + 1), one v_mul_hi_u32 by p and a min-based final correction — no branches.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define KB_HD __host__ __device__ __forceinline__
+
+namespace kb {
+
+constexpr uint32_t P = 0x7f000001u;
+constexpr uint32_t MU = 0x81000001u;    // p^-1 mod 2^32
+constexpr uint32_t ONE = 0x01fffffeu;   // R mod p
+constexpr uint32_t R2 = 0x17f7efe4u;    // R^2 mod p
+constexpr uint32_t GEN = 0x05fffffau;   // 3 * R mod p  (multiplicative generator 3)
+constexpr int TWO_ADICITY = 24;
+
+KB_HD uint32_t umin32(uint32_t a, uint32_t b) { return a < b ? a : b; }
+
+KB_HD uint32_t add(uint32_t a, uint32_t b) {
+  uint32_t s = a + b;
+  return umin32(s, s - P);
+}
+KB_HD uint32_t sub(uint32_t a, uint32_t b) {
+  uint32_t d = a - b;
+  return umin32(d, d + P);
+}
+KB_HD uint32_t neg(uint32_t a) { return a ? P - a : 0u; }
+KB_HD uint32_t dbl(uint32_t a) { return add(a, a); }
+
+// x < 2^32 * p  ->  x * R^-1 mod p, in [0, p)
+KB_HD uint32_t monty_reduce(uint64_t x) {
+  uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
+  uint32_t t = lo + (lo << 24) + (lo << 31);  // lo * MU mod 2^32
+#if defined(__HIP_DEVICE_COMPILE__)
+  uint32_t uhi = __umulhi(t, P);
+#else
+  uint32_t uhi = (uint32_t)(((uint64_t)t * P) >> 32);
+#endif
+  uint32_t r = hi - uhi;  // low words of x and t*p coincide, so no borrow from them
+  return umin32(r, r + P);
+}
+KB_HD uint32_t mul(uint32_t a, uint32_t b) { return monty_reduce((uint64_t)a * b); }
+KB_HD uint32_t sqr(uint32_t a) { return mul(a, a); }
+KB_HD uint32_t to_monty(uint32_t canonical) { return mul(canonical, R2); }
+KB_HD uint32_t from_monty(uint32_t m) { return monty_reduce((uint64_t)m); }
+
+KB_HD uint32_t pow(uint32_t a, uint64_t e) {
+  uint32_t r = ONE;
+  while (e) {
+    if (e & 1) r = mul(r, a);
+    a = sqr(a);
+    e >>= 1;
+  }
+  return r;
+}
+// a^(p-2); p - 2 = 0x7effffff
+KB_HD uint32_t inv(uint32_t a) {
+  // addition chain: a^(2^24 - 1), then a^(127 * 2^24 - 1) = a^(p-2)
+  uint32_t x2 = mul(sqr(a), a);          // 2^2-1
+  uint32_t x3 = mul(sqr(x2), a);         // 2^3-1
+  uint32_t x6 = x3;
+  for (int i = 0; i < 3; i++) x6 = sqr(x6);
+  x6 = mul(x6, x3);                      // 2^6-1
+  uint32_t x12 = x6;
+  for (int i = 0; i < 6; i++) x12 = sqr(x12);
+  x12 = mul(x12, x6);                    // 2^12-1
+  uint32_t x24 = x12;
+  for (int i = 0; i < 12; i++) x24 = sqr(x24);
+  x24 = mul(x24, x12);                   // 2^24-1
+  // p - 2 = (2^7 - 2) * 2^24 + (2^24 - 1) = 0b1111110 followed by 24 ones
+  uint32_t x7m2 = sqr(x6);               // a^(2^7 - 2)  (= (2^6-1)*2)
+  uint32_t r = x7m2;
+  for (int i = 0; i < 24; i++) r = sqr(r);
+  return mul(r, x24);
+}
+
+KB_HD uint32_t two_adic_generator(int bits) { return pow(GEN, (uint64_t)(P - 1) >> bits); }
+
+KB_HD uint32_t bitrev(uint32_t x, int bits) {
+  if (bits == 0) return 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __brev(x) >> (32 - bits);
+#else
+  uint32_t r = 0;
+  for (int i = 0; i < bits; i++) { r = (r << 1) | (x & 1); x >>= 1; }
+  return r;
+#endif
+}
+
+// ---- quartic extension, X^4 = 3 (crates/stark/src/air/extension.rs:55-74) ------------------
+struct alignas(16) E4 {
+  uint32_t c[4];
+};
+
+KB_HD E4 ezero() { return E4{{0, 0, 0, 0}}; }
+KB_HD E4 eone() { return E4{{ONE, 0, 0, 0}}; }
+KB_HD E4 efrom(uint32_t a) { return E4{{a, 0, 0, 0}}; }
+KB_HD bool eq(const E4& a, const E4& b) { return a.c[0] == b.c[0] && a.c[1] == b.c[1] && a.c[2] == b.c[2] && a.c[3] == b.c[3]; }
+KB_HD E4 eadd(const E4& a, const E4& b) { return E4{{add(a.c[0], b.c[0]), add(a.c[1], b.c[1]), add(a.c[2], b.c[2]), add(a.c[3], b.c[3])}}; }
+KB_HD E4 esub(const E4& a, const E4& b) { return E4{{sub(a.c[0], b.c[0]), sub(a.c[1], b.c[1]), sub(a.c[2], b.c[2]), sub(a.c[3], b.c[3])}}; }
+KB_HD E4 eneg(const E4& a) { return E4{{neg(a.c[0]), neg(a.c[1]), neg(a.c[2]), neg(a.c[3])}}; }
+KB_HD E4 escale(const E4& a, uint32_t s) { return E4{{mul(a.c[0], s), mul(a.c[1], s), mul(a.c[2], s), mul(a.c[3], s)}}; }
+KB_HD E4 eadd_base(const E4& a, uint32_t b) { return E4{{add(a.c[0], b), a.c[1], a.c[2], a.c[3]}}; }
+KB_HD E4 esub_base(const E4& a, uint32_t b) { return E4{{sub(a.c[0], b), a.c[1], a.c[2], a.c[3]}}; }
+KB_HD uint32_t mul3(uint32_t a) { return add(dbl(a), a); }
+
+// Products are accumulated in 64 bits two at a time (2 p^2 < 2^32 p) before one reduction.
+KB_HD uint32_t dot2(uint32_t a0, uint32_t b0, uint32_t a1, uint32_t b1) {
+  return monty_reduce((uint64_t)a0 * b0 + (uint64_t)a1 * b1);
+}
+KB_HD E4 emul(const E4& a, const E4& b) {
+  E4 r;
+  // c0 = a0 b0 + 3 (a1 b3 + a2 b2 + a3 b1)
+  uint32_t h0 = add(dot2(a.c[1], b.c[3], a.c[2], b.c[2]), mul(a.c[3], b.c[1]));
+  r.c[0] = add(mul(a.c[0], b.c[0]), mul3(h0));
+  // c1 = a0 b1 + a1 b0 + 3 (a2 b3 + a3 b2)
+  r.c[1] = add(dot2(a.c[0], b.c[1], a.c[1], b.c[0]), mul3(dot2(a.c[2], b.c[3], a.c[3], b.c[2])));
+  // c2 = a0 b2 + a1 b1 + a2 b0 + 3 a3 b3
+  r.c[2] = add(add(dot2(a.c[0], b.c[2], a.c[1], b.c[1]), mul(a.c[2], b.c[0])), mul3(mul(a.c[3], b.c[3])));
+  // c3 = a0 b3 + a1 b2 + a2 b1 + a3 b0
+  r.c[3] = add(dot2(a.c[0], b.c[3], a.c[1], b.c[2]), dot2(a.c[2], b.c[1], a.c[3], b.c[0]));
+  return r;
+}
+KB_HD E4 esqr(const E4& a) { return emul(a, a); }
+// Inverse through the tower F < F[Y]/(Y^2-3) < EF with Y = X^2:
+// a = A + X B, A = a0 + a2 Y, B = a1 + a3 Y;  1/a = (A - X B) / (A^2 - Y B^2).
+KB_HD E4 einv(const E4& a) {
+  uint32_t a0 = a.c[0], a1 = a.c[1], a2 = a.c[2], a3 = a.c[3];
+  // A^2 = (a0^2 + 3 a2^2) + (2 a0 a2) Y ;  B^2 = (a1^2 + 3 a3^2) + (2 a1 a3) Y
+  // Y B^2 = 3 (2 a1 a3) + (a1^2 + 3 a3^2) Y
+  uint32_t d0 = sub(add(sqr(a0), mul3(sqr(a2))), mul3(dbl(mul(a1, a3))));
+  uint32_t d1 = sub(dbl(mul(a0, a2)), add(sqr(a1), mul3(sqr(a3))));
+  // 1/(d0 + d1 Y) = (d0 - d1 Y) / (d0^2 - 3 d1^2)
+  uint32_t nrm = inv(sub(sqr(d0), mul3(sqr(d1))));
+  uint32_t e0 = mul(d0, nrm), e1 = neg(mul(d1, nrm));
+  // (A - X B) * (e0 + e1 Y):
+  //   A (e0 + e1 Y) = (a0 e0 + 3 a2 e1) + (a0 e1 + a2 e0) Y
+  //   B (e0 + e1 Y) = (a1 e0 + 3 a3 e1) + (a1 e1 + a3 e0) Y
+  E4 r;
+  r.c[0] = add(mul(a0, e0), mul3(mul(a2, e1)));
+  r.c[2] = add(mul(a0, e1), mul(a2, e0));
+  r.c[1] = neg(add(mul(a1, e0), mul3(mul(a3, e1))));
+  r.c[3] = neg(add(mul(a1, e1), mul(a3, e0)));
+  return r;
+}
+KB_HD E4 epow(E4 a, uint64_t e) {
+  E4 r = eone();
+  while (e) {
+    if (e & 1) r = emul(r, a);
+    a = esqr(a);
+    e >>= 1;
+  }
+  return r;
+}
+KB_HD E4 epow2k(E4 a, int k) {
+  for (int i = 0; i < k; i++) a = esqr(a);
+  return a;
+}
+
+}  // namespace kb

@@ -1,0 +1,183 @@
+// Coset low-degree extension of column-major trace matrices on gfx950.
+//
+// Replaces p3-dft Radix2DitParallel::coset_lde_batch + bit_reverse_rows as called by
+// TwoAdicFriPcs::commit (call sites crates/stark/src/prover.rs:277,403,497; semantics pinned by
+// the verifier's x formula, crates/recursion/circuit/src/fri.rs:140-150):
+//     out[bitrev(j)] = P(shift * w_N^j),  N = n << log_blowup,  P = interpolant of the column on H_n.
+//
+// Layout: a matrix is column-major in HBM, column c at base + c * height, so every kernel here
+// streams contiguous 4-byte words along a column (coalesced across a wavefront).
+//
+// Algorithm (per column): the 2^bl cosets of H_n inside shift*K_N are 2^bl independent size-n
+// transforms, and coset j lands in the contiguous output block [bitrev_bl(j) * n, +n) in
+// bit-reversed row order. With n = A * B (A = 2^la strided, B = 2^lb <= 8192 contiguous):
+//   1. lde_cols_inverse : A-point inverse DIF down the strided dimension, tile [A][T] in LDS
+//   2. lde_rows         : per contiguous row of B words, all in LDS:
+//        twiddle w_n^(-i0 k1) on load, B-point inverse DIF -> coefficients (bit-reversed),
+//        then for each coset: scale by shift_j^k / n, B-point forward DIT, twiddle w_n^(j0 k1)
+//   3. lde_cols_forward : A-point forward DIT down the strided dimension, then the tile is
+//        written transposed so each column lands as one contiguous A-word bit-reversed segment.
+// For n <= 8192 (A = 1) step 2 alone reads the column once and writes the LDE once.
+#pragma once
+#include "kb31.cuh"
+
+namespace lde {
+
+constexpr int LOG_ROW_MAX = 13;        // B <= 8192 words = 32 KiB of LDS per buffer
+constexpr int COLS_TILE_ELEMS = 16384; // A * T words in LDS for the strided passes (64 KiB)
+constexpr int THREADS = 256;
+
+// In-LDS radix-2 transform over 2^lognb interleaved sequences: element i of sequence t lives at
+// buf[i * istride + t]. tw[j] = w^j for the size-2^logn root w (forward or inverse table).
+// DIF: natural in -> bit-reversed out.  DIT: bit-reversed in -> natural out.
+template <bool DIF>
+__device__ __forceinline__ void lds_ntt(uint32_t* buf, int logn, int lognb, int istride, const uint32_t* __restrict__ tw) {
+  const int half = 1 << (logn - 1);
+  const int total = half << lognb;
+  for (int st = 0; st < logn; st++) {
+    const int s = DIF ? st : (logn - 1 - st);
+    const int logm = logn - 1 - s;  // m = half >> s
+    for (int u = threadIdx.x; u < total; u += blockDim.x) {
+      int t = u & ((1 << lognb) - 1), j = u >> lognb;
+      int off = j & ((1 << logm) - 1);
+      int i0 = ((j >> logm) << (logm + 1)) + off;
+      int i1 = i0 + (1 << logm);
+      uint32_t w = tw[off << s];
+      uint32_t* p0 = buf + i0 * istride + t;
+      uint32_t* p1 = buf + i1 * istride + t;
+      uint32_t a = *p0, b = *p1;
+      if (DIF) {
+        *p0 = kb::add(a, b);
+        *p1 = kb::mul(kb::sub(a, b), w);
+      } else {
+        b = kb::mul(b, w);
+        *p0 = kb::add(a, b);
+        *p1 = kb::sub(a, b);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// Two-level power table of g in LDS: lo[i] = g^i (i < 64), hi[i] = g^(64 i) (i < nhi).
+__device__ __forceinline__ void build_pow_table(uint32_t g, uint32_t* lo, uint32_t* hi, int nhi) {
+  uint32_t g64 = g;
+  for (int i = 0; i < 6; i++) g64 = kb::sqr(g64);
+  for (int i = threadIdx.x; i < 64 + nhi; i += blockDim.x) {
+    if (i < 64) lo[i] = kb::pow(g, (uint64_t)i);
+    else hi[i - 64] = kb::pow(g64, (uint64_t)(i - 64));
+  }
+}
+__device__ __forceinline__ uint32_t pow_lookup(const uint32_t* lo, const uint32_t* hi, uint32_t e) {
+  return kb::mul(lo[e & 63], hi[e >> 6]);
+}
+
+// Step 1 / 3: A-point transforms down the strided dimension of each column.
+// grid = (B / T, width, n_cosets); in/out are column-major with `col_stride` words per column.
+// FORWARD == false: inverse DIF in place layout (tile written back where it was read).
+// FORWARD == true : forward DIT, then element (j1, j0) is written to
+//                   out[c * out_col_stride + out_block(z) * n + bitrev_lb(j0) * A + bitrev_la(j1)].
+template <bool FORWARD>
+__global__ __launch_bounds__(THREADS) void lde_cols(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, int la, int lb,
+                                                    int logT, size_t in_col_stride, size_t in_coset_stride,
+                                                    size_t out_col_stride, int log_blowup,
+                                                    const uint32_t* __restrict__ tw) {
+  extern __shared__ uint32_t lds[];
+  const int A = 1 << la, T = 1 << logT;
+  const size_t B = (size_t)1 << lb;
+  const size_t t0 = (size_t)blockIdx.x << logT;
+  const size_t c = blockIdx.y;
+  const int z = blockIdx.z;
+  const uint32_t* src = in + c * in_col_stride + (size_t)z * in_coset_stride;
+  for (int u = threadIdx.x; u < A * T; u += blockDim.x) {
+    int i1 = u >> logT, t = u & (T - 1);
+    lds[u] = src[(size_t)i1 * B + t0 + t];
+  }
+  __syncthreads();
+  lds_ntt<!FORWARD>(lds, la, logT, T, tw);
+  if (!FORWARD) {
+    uint32_t* dst = out + c * out_col_stride;
+    for (int u = threadIdx.x; u < A * T; u += blockDim.x) {
+      int i1 = u >> logT, t = u & (T - 1);
+      dst[(size_t)i1 * B + t0 + t] = lds[u];
+    }
+  } else {
+    const size_t n = (size_t)A << lb;
+    uint32_t* dst = out + c * out_col_stride + (size_t)kb::bitrev(z, log_blowup) * n;
+    for (int u = threadIdx.x; u < A * T; u += blockDim.x) {
+      int t = u >> la, q = u & (A - 1);
+      size_t j0 = t0 + t;
+      dst[(size_t)kb::bitrev((uint32_t)j0, lb) * A + q] = lds[kb::bitrev(q, la) * T + t];
+    }
+  }
+}
+
+// Step 2: one block per (row k1-position pr, column c).
+//   in : column-major, the column after lde_cols<false> (or the raw trace column when la == 0)
+//   la == 0: writes the finished LDE column to `out` (height n << log_blowup per column)
+//   la  > 0: writes coset j's row to tmp[(j * width + c) * n + pr * B + j0] for lde_cols<true>
+__global__ __launch_bounds__(THREADS) void lde_rows(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, int la, int lb,
+                                                    size_t in_col_stride, size_t out_col_stride, size_t out_coset_stride,
+                                                    int log_blowup, uint32_t shift, uint32_t w_n, uint32_t w_n_inv,
+                                                    uint32_t w_N, uint32_t n_inv, const uint32_t* __restrict__ tw_fwd,
+                                                    const uint32_t* __restrict__ tw_inv) {
+  extern __shared__ uint32_t lds[];
+  const int B = 1 << lb;
+  const int nhi = B > 64 ? (B >> 6) : 1;
+  uint32_t* coef = lds;            // B
+  uint32_t* work = lds + B;        // B
+  uint32_t* lo1 = work + B;        // 64   powers of w_n^(-k1)   (load twiddle)
+  uint32_t* hi1 = lo1 + 64;        // nhi
+  uint32_t* lo2 = hi1 + nhi;       // 64   powers of shift_j^A   (coset scaling)
+  uint32_t* hi2 = lo2 + 64;        // nhi
+  const int pr = blockIdx.x;
+  const size_t c = blockIdx.y;
+  const int k1 = kb::bitrev(pr, la);
+  const int k = la + lb;
+  const uint32_t* src = in + c * in_col_stride + (size_t)pr * B;
+
+  if (la > 0) {
+    build_pow_table(kb::pow(w_n_inv, (uint64_t)k1), lo1, hi1, nhi);
+    __syncthreads();
+    for (int i = threadIdx.x; i < B; i += blockDim.x) coef[i] = kb::mul(src[i], pow_lookup(lo1, hi1, i));
+  } else {
+    for (int i = threadIdx.x; i < B; i += blockDim.x) coef[i] = src[i];
+  }
+  __syncthreads();
+  if (lb > 0) lds_ntt<true>(coef, lb, 0, 1, tw_inv);
+  // coef[pc] = n * c_kk with kk = bitrev_lb(pc) * A + k1
+  if (la > 0) {
+    build_pow_table(kb::pow(w_n, (uint64_t)k1), lo1, hi1, nhi);  // store twiddle w_n^(j0 k1)
+  }
+  const int ncosets = 1 << log_blowup;
+  uint32_t sj = shift;
+  for (int j = 0; j < ncosets; j++) {
+    // shift_j = shift * w_N^j
+    uint32_t sA = sj;
+    for (int i = 0; i < la; i++) sA = kb::sqr(sA);
+    __syncthreads();
+    build_pow_table(sA, lo2, hi2, nhi);
+    uint32_t f = kb::mul(n_inv, kb::pow(sj, (uint64_t)k1));
+    __syncthreads();
+    for (int i = threadIdx.x; i < B; i += blockDim.x)
+      work[i] = kb::mul(kb::mul(coef[i], f), pow_lookup(lo2, hi2, kb::bitrev(i, lb)));
+    __syncthreads();
+    if (lb > 0) lds_ntt<false>(work, lb, 0, 1, tw_fwd);
+    if (la > 0) {
+      uint32_t* dst = out + (size_t)j * out_coset_stride + c * out_col_stride + (size_t)pr * B;
+      for (int i = threadIdx.x; i < B; i += blockDim.x) dst[i] = kb::mul(work[i], pow_lookup(lo1, hi1, i));
+    } else {
+      uint32_t* dst = out + c * out_col_stride + (size_t)kb::bitrev(j, log_blowup) * B;
+      for (int i = threadIdx.x; i < B; i += blockDim.x) dst[i] = work[kb::bitrev(i, lb)];
+    }
+    sj = kb::mul(sj, w_N);
+  }
+}
+
+// tw[j] = w^j, j < count
+__global__ void fill_powers(uint32_t* tw, uint32_t w, size_t count) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < count) tw[i] = kb::pow(w, (uint64_t)i);
+}
+
+}  // namespace lde

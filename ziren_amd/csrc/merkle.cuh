@@ -1,0 +1,126 @@
+// Mixed-height Poseidon2 Merkle commitment (p3 MerkleTreeMmcs semantics) on gfx950.
+//
+// Replaces MerkleTreeMmcs::commit as used by TwoAdicFriPcs::commit and the FRI commit phase
+// (semantics mirrored in-tree by crates/recursion/circuit/src/fri.rs:363-405 and
+// crates/recursion/circuit/src/hash.rs:40-49,75-80):
+//   leaf r      = PaddingFreeSponge(rate 8, overwrite) over row r of every tallest matrix, concatenated
+//   parent      = Poseidon2(left || right)[0..8]
+//   when a layer's length equals a shorter matrix's height: node = compress(node, hash(rows))
+//
+// One thread owns one row / one node: the 16-word sponge state stays in VGPRs, and because the
+// matrices are column-major, lane l of a wavefront reads word (column, r0 + l) — every column
+// read is one coalesced 256-byte transaction. Digests are stored as 8 consecutive words.
+#pragma once
+#include "poseidon2.cuh"
+
+namespace merkle {
+
+constexpr int THREADS = 256;
+
+// Absorb `width` columns (colptrs[g][row]) into the sponge state, 8 per permutation.
+__device__ __forceinline__ void absorb_row(uint32_t s[16], const uint32_t* const* __restrict__ colptrs, int width, size_t row) {
+  for (int g0 = 0; g0 < width; g0 += 8) {
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+      if (g0 + i < width) s[i] = colptrs[g0 + i][row];
+    p2::permute(s);
+  }
+}
+
+__device__ __forceinline__ void store_digest(uint32_t* dst, const uint32_t s[16]) {
+  uint4* d = reinterpret_cast<uint4*>(dst);
+  d[0] = make_uint4(s[0], s[1], s[2], s[3]);
+  d[1] = make_uint4(s[4], s[5], s[6], s[7]);
+}
+__device__ __forceinline__ void load_digest(uint32_t s[8], const uint32_t* src) {
+  const uint4* p = reinterpret_cast<const uint4*>(src);
+  uint4 a = p[0], b = p[1];
+  s[0] = a.x; s[1] = a.y; s[2] = a.z; s[3] = a.w;
+  s[4] = b.x; s[5] = b.y; s[6] = b.z; s[7] = b.w;
+}
+
+// layer 0: digests[r] = hash(row r of all tallest matrices)
+__global__ __launch_bounds__(THREADS) void hash_leaves(const uint32_t* const* __restrict__ colptrs, int width, size_t height,
+                                                       uint32_t* __restrict__ digests) {
+  size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= height) return;
+  uint32_t s[16];
+#pragma unroll
+  for (int i = 0; i < 16; i++) s[i] = 0;
+  absorb_row(s, colptrs, width, r);
+  store_digest(digests + r * 8, s);
+}
+
+// next[i] = compress(prev[2i], prev[2i+1]); optionally inject the rows of matrices of height m.
+__global__ __launch_bounds__(THREADS) void compress_layer(const uint32_t* __restrict__ prev, uint32_t* __restrict__ next, size_t m,
+                                                          const uint32_t* const* __restrict__ inject_cols, int inject_width) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m) return;
+  uint32_t s[16];
+  load_digest(s, prev + 16 * i);
+  load_digest(s + 8, prev + 16 * i + 8);
+  p2::permute(s);
+  if (inject_width > 0) {
+    uint32_t h[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) h[k] = 0;
+    absorb_row(h, inject_cols, inject_width, i);
+#pragma unroll
+    for (int k = 0; k < 8; k++) s[8 + k] = h[k];
+    p2::permute(s);
+  }
+  store_digest(next + 8 * i, s);
+}
+
+// FRI commit-phase leaves: row j = (f[2j], f[2j+1]) as 8 base words (fri.rs:279-306)
+__global__ __launch_bounds__(THREADS) void hash_fri_leaves(const kb::E4* __restrict__ f, size_t m, uint32_t* __restrict__ digests) {
+  size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= m) return;
+  uint32_t s[16];
+  kb::E4 a = f[2 * j], b = f[2 * j + 1];
+#pragma unroll
+  for (int k = 0; k < 4; k++) { s[k] = a.c[k]; s[4 + k] = b.c[k]; }
+#pragma unroll
+  for (int k = 8; k < 16; k++) s[k] = 0;
+  p2::permute(s);
+  store_digest(digests + 8 * j, s);
+}
+
+// n independent permutations (parity / micro-benchmark entry point)
+__global__ __launch_bounds__(THREADS) void permute_batch(uint32_t* __restrict__ states, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint32_t s[16];
+  uint4* p = reinterpret_cast<uint4*>(states + 16 * i);
+  uint4 v[4] = {p[0], p[1], p[2], p[3]};
+#pragma unroll
+  for (int k = 0; k < 4; k++) { s[4 * k] = v[k].x; s[4 * k + 1] = v[k].y; s[4 * k + 2] = v[k].z; s[4 * k + 3] = v[k].w; }
+  p2::permute(s);
+#pragma unroll
+  for (int k = 0; k < 4; k++) p[k] = make_uint4(s[4 * k], s[4 * k + 1], s[4 * k + 2], s[4 * k + 3]);
+}
+
+// Proof-of-work search (DuplexChallenger::grind): the challenger state after observing the
+// witness is fully determined: state[0..n_in) = pending inputs, state[n_in] = witness.
+// Finds the smallest canonical witness in [base, base + total) whose sample has `bits` low zero bits.
+__global__ __launch_bounds__(THREADS) void grind(const uint32_t* __restrict__ sponge_state, const uint32_t* __restrict__ inputs, int n_in,
+                                                 int bits, uint32_t base, uint32_t total, unsigned int* __restrict__ best) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  uint32_t w = base + i;  // canonical witness value
+  if (w >= kb::P) return;
+  uint32_t s[16];
+#pragma unroll
+  for (int k = 0; k < 16; k++) s[k] = sponge_state[k];
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    if (k < n_in) s[k] = inputs[k];
+    else if (k == n_in) s[k] = kb::to_monty(w);
+  }
+  p2::permute(s);
+  // the sample is the last element of the rate (output buffer popped from the back)
+  uint32_t v = kb::from_monty(s[7]);
+  if ((v & ((1u << bits) - 1)) == 0) atomicMin(best, w);
+}
+
+}  // namespace merkle

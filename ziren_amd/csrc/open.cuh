@@ -1,0 +1,146 @@
+// Pcs::open on gfx950: out-of-domain evaluation, reduced openings, FRI folding, query gathers.
+//
+// Replaces p3-fri TwoAdicFriPcs::open + p3-fri prover::prove as called at
+// crates/stark/src/prover.rs:546-556; semantics mirrored in-tree by
+// crates/recursion/circuit/src/fri.rs:71-218 (reduced openings) and :220-361 (fold, queries).
+#pragma once
+#include "kb31.cuh"
+
+namespace open {
+
+constexpr int THREADS = 256;
+
+// Barycentric weights for evaluating, at the extension point z, a polynomial of degree < n
+// given by its values on the coset s * H_n in natural order:
+//   p(z) = sum_i v_i * w_i,   w_i = (u^n - 1)/n * w^i / (u - w^i),   u = z / s.
+// `c` = (u^n - 1)/n is computed on the host. p(z * g) = sum_i v_{i+1} w_i (rotation), so one
+// weight vector serves both opening points of a trace.
+__global__ __launch_bounds__(THREADS) void bary_weights(kb::E4 u, kb::E4 c, uint32_t w_n, size_t n, kb::E4* __restrict__ out) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint32_t wi = kb::pow(w_n, (uint64_t)i);
+  kb::E4 d = kb::einv(kb::esub_base(u, wi));
+  out[i] = kb::emul(kb::escale(d, wi), c);
+}
+
+// Column evaluations: block (bx, by) handles COLS columns starting at 4*bx over rows
+// r = by*THREADS + tid + k * gridDim.y*THREADS, accumulating
+//   acc0[c] += v[c][r] * w[r],   acc1[c] += v[c][(r+1) mod n] * w[r]
+// and writes one partial per block: partials[((by * width) + col) * 2 + {0,1}].
+constexpr int EVAL_COLS = 4;
+__global__ __launch_bounds__(THREADS) void eval_columns(const uint32_t* __restrict__ mat, size_t n, int width,
+                                                        const kb::E4* __restrict__ weights, int two_points,
+                                                        kb::E4* __restrict__ partials) {
+  __shared__ uint32_t red[THREADS];
+  const int c0 = blockIdx.x * EVAL_COLS;
+  kb::E4 acc[EVAL_COLS][2];
+#pragma unroll
+  for (int c = 0; c < EVAL_COLS; c++) { acc[c][0] = kb::ezero(); acc[c][1] = kb::ezero(); }
+  const size_t stride = (size_t)gridDim.y * THREADS;
+  for (size_t r = (size_t)blockIdx.y * THREADS + threadIdx.x; r < n; r += stride) {
+    kb::E4 w = weights[r];
+    size_t rn = r + 1 == n ? 0 : r + 1;
+#pragma unroll
+    for (int c = 0; c < EVAL_COLS; c++) {
+      if (c0 + c < width) {
+        const uint32_t* col = mat + (size_t)(c0 + c) * n;
+        acc[c][0] = kb::eadd(acc[c][0], kb::escale(w, col[r]));
+        if (two_points) acc[c][1] = kb::eadd(acc[c][1], kb::escale(w, col[rn]));
+      }
+    }
+  }
+  // block reduction of 8 * EVAL_COLS words
+#pragma unroll
+  for (int c = 0; c < EVAL_COLS; c++) {
+#pragma unroll
+    for (int pt = 0; pt < 2; pt++) {
+      kb::E4 tot;
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        red[threadIdx.x] = acc[c][pt].c[e];
+        __syncthreads();
+        for (int d = THREADS / 2; d > 0; d >>= 1) {
+          if (threadIdx.x < d) red[threadIdx.x] = kb::add(red[threadIdx.x], red[threadIdx.x + d]);
+          __syncthreads();
+        }
+        tot.c[e] = red[0];
+        __syncthreads();
+      }
+      if (threadIdx.x == 0 && c0 + c < width) partials[((size_t)blockIdx.y * width + c0 + c) * 2 + pt] = tot;
+    }
+  }
+}
+
+// Reduced openings for one LDE height N (fri.rs:103-204). One thread per stored row r
+// (bit-reversed: x_r = 3 * w_N^bitrev(r)). For matrix m with alpha-power offset folded in:
+//   ro[r] += sum_pt (Yc[m][pt] - A[m][pt] * S_m[r]) / (z_pt - x_r),   S_m[r] = sum_col alpha^col L_m[r][col]
+// where A = alpha^offset, Yc = alpha^offset * sum_col alpha^col y_col (host-computed).
+struct ReduceMat {
+  const uint32_t* lde;  // column-major, height N
+  int width;
+  int n_points;         // 1: zeta only, 2: zeta and zeta*g
+  kb::E4 A[2];
+  kb::E4 Yc[2];
+};
+__global__ __launch_bounds__(THREADS) void reduce_openings(const ReduceMat* __restrict__ mats, int n_mats, int log_N,
+                                                           const kb::E4* __restrict__ alpha_pows, kb::E4 z0, kb::E4 z1,
+                                                           uint32_t w_N, kb::E4* __restrict__ ro, int accumulate) {
+  size_t N = (size_t)1 << log_N;
+  size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= N) return;
+  uint32_t x = kb::mul(kb::GEN, kb::pow(w_N, (uint64_t)kb::bitrev((uint32_t)r, log_N)));
+  kb::E4 d0 = kb::einv(kb::esub_base(z0, x));
+  kb::E4 d1 = kb::einv(kb::esub_base(z1, x));
+  kb::E4 acc = accumulate ? ro[r] : kb::ezero();
+  for (int m = 0; m < n_mats; m++) {
+    const ReduceMat& M = mats[m];
+    kb::E4 S = kb::ezero();
+    for (int c = 0; c < M.width; c++) S = kb::eadd(S, kb::escale(alpha_pows[c], M.lde[(size_t)c * N + r]));
+    acc = kb::eadd(acc, kb::emul(kb::esub(M.Yc[0], kb::emul(M.A[0], S)), d0));
+    if (M.n_points > 1) acc = kb::eadd(acc, kb::emul(kb::esub(M.Yc[1], kb::emul(M.A[1], S)), d1));
+  }
+  ro[r] = acc;
+}
+
+// FRI fold (fri.rs:257-358): g[j] = e0 + (beta - x)(e1 - e0)/(-2x) [+ beta^2 * ro_next[j]],
+// (e0, e1) = (f[2j], f[2j+1]), x = w_len^bitrev(2j).
+__global__ __launch_bounds__(THREADS) void fri_fold(const kb::E4* __restrict__ f, int log_len, kb::E4 beta, kb::E4 beta_sq,
+                                                    uint32_t w_len, uint32_t w_len_inv, uint32_t neg_half,
+                                                    const kb::E4* __restrict__ ro_next,
+                                                    kb::E4* __restrict__ g) {
+  size_t half = (size_t)1 << (log_len - 1);
+  size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= half) return;
+  kb::E4 e0 = f[2 * j], e1 = f[2 * j + 1];
+  uint32_t e = kb::bitrev((uint32_t)(2 * j), log_len);
+  uint32_t xinv = kb::pow(w_len_inv, (uint64_t)e);
+  uint32_t x = kb::pow(w_len, (uint64_t)e);
+  // (beta - x) * (e1 - e0) * (-1/2) * x^-1
+  kb::E4 t = kb::emul(kb::esub_base(beta, x), kb::esub(e1, e0));
+  kb::E4 r = kb::eadd(e0, kb::escale(t, kb::mul(neg_half, xinv)));
+  if (ro_next) r = kb::eadd(r, kb::emul(beta_sq, ro_next[j]));
+  g[j] = r;
+}
+
+// dst[i] = *src[i]
+__global__ __launch_bounds__(THREADS) void gather_words(const uint32_t* const* __restrict__ src, size_t count, uint32_t* __restrict__ dst) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < count) dst[i] = *src[i];
+}
+
+// 32x32 tile transpose between row-major [h][w] and column-major [w][h]
+__global__ void transpose(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, size_t rows, size_t cols) {
+  __shared__ uint32_t tile[32][33];
+  size_t bx = (size_t)blockIdx.x * 32, by = (size_t)blockIdx.y * 32;
+  for (int j = threadIdx.y; j < 32; j += blockDim.y) {
+    size_t r = by + j, c = bx + threadIdx.x;
+    if (r < rows && c < cols) tile[j][threadIdx.x] = in[r * cols + c];
+  }
+  __syncthreads();
+  for (int j = threadIdx.y; j < 32; j += blockDim.y) {
+    size_t c = bx + j, r = by + threadIdx.x;
+    if (r < rows && c < cols) out[c * rows + r] = tile[threadIdx.x][j];
+  }
+}
+
+}  // namespace open

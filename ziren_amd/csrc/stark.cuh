@@ -1,0 +1,226 @@
+// LogUp permutation trace and quotient (constraint) evaluation on gfx950.
+//
+// Replaces, for one chip:
+//   generate_permutation_trace / populate_local_permutation_row
+//       crates/stark/src/permutation.rs:29-69,102-196   (caller prover.rs:337-365)
+//   quotient_values + ProverConstraintFolder
+//       crates/stark/src/quotient.rs:19-171, crates/stark/src/folder.rs:19-149
+//
+// Both are one-thread-per-row streaming kernels over column-major matrices: lane l of a
+// wavefront touches row r0 + l of each column, so each column access is one coalesced
+// transaction. Per-chip metadata (lookup linear forms, constraint bytecode, alpha powers) is
+// wave-uniform and comes through the scalar/constant path.
+#pragma once
+#include "kb31.cuh"
+
+namespace stark {
+
+constexpr int THREADS = 256;
+
+// sum_i weight_i * (prep|main)[col_i][row] + constant; advances `pos` past the VirtualPairCol.
+__device__ __forceinline__ uint32_t apply_pair_col(const uint32_t* __restrict__ blob, int& pos, const uint32_t* __restrict__ main,
+                                                   size_t main_stride, const uint32_t* __restrict__ prep, size_t prep_stride,
+                                                   size_t row) {
+  int nt = blob[pos++];
+  uint32_t acc = blob[pos++];
+  for (int t = 0; t < nt; t++) {
+    uint32_t cw = blob[pos++], weight = blob[pos++];
+    uint32_t col = cw & 0x7fffffffu;
+    uint32_t v = (cw >> 31) ? main[col * main_stride + row] : prep[col * prep_stride + row];
+    acc = kb::add(acc, kb::mul(v, weight));
+  }
+  return acc;
+}
+
+// One thread per trace row. Writes the (perm_w - 1) batched columns and, in the last ext
+// column, the row sum (the inclusive scan over rows runs afterwards, see scan kernels).
+// perm is column-major with 4 base columns per ext column (flatten_to_base order).
+__global__ __launch_bounds__(THREADS) void perm_rows(const uint32_t* __restrict__ blob, int n_lookups, int n_sends, int batch,
+                                                     const uint32_t* __restrict__ main, const uint32_t* __restrict__ prep,
+                                                     size_t n, kb::E4 alpha, const kb::E4* __restrict__ beta_pows,
+                                                     uint32_t* __restrict__ perm, int perm_ext_w) {
+  size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  int pos = 2;
+  kb::E4 rowsum = kb::ezero();
+  int k = 0;
+  for (int b = 0; b < perm_ext_w - 1; b++) {
+    kb::E4 val = kb::ezero();
+    for (int q = 0; q < batch && k < n_lookups; q++, k++) {
+      uint32_t kind = blob[pos++];
+      int nv = blob[pos++];
+      kb::E4 denom = kb::eadd_base(alpha, kb::to_monty(kind));  // beta^0 * argument_index
+      for (int v = 0; v < nv; v++) {
+        uint32_t lin = apply_pair_col(blob, pos, main, n, prep, n, r);
+        denom = kb::eadd(denom, kb::escale(beta_pows[v + 1], lin));
+      }
+      uint32_t mult = apply_pair_col(blob, pos, main, n, prep, n, r);
+      if (k >= n_sends) mult = kb::neg(mult);
+      val = kb::eadd(val, kb::escale(kb::einv(denom), mult));
+    }
+#pragma unroll
+    for (int e = 0; e < 4; e++) perm[(size_t)(4 * b + e) * n + r] = val.c[e];
+    rowsum = kb::eadd(rowsum, val);
+  }
+#pragma unroll
+  for (int e = 0; e < 4; e++) perm[(size_t)(4 * (perm_ext_w - 1) + e) * n + r] = rowsum.c[e];
+}
+
+// ---- inclusive prefix sum mod p over each of `ncols` columns of length n --------------------
+constexpr int SCAN_BLOCK = 1024;  // elements per block (256 threads x 4)
+
+__device__ __forceinline__ uint32_t block_inclusive_scan(uint32_t v, uint32_t* lds /*[THREADS]*/) {
+  // Hillis-Steele over the block's per-thread totals; returns the inclusive prefix for this thread
+  int t = threadIdx.x;
+  lds[t] = v;
+  __syncthreads();
+  for (int d = 1; d < THREADS; d <<= 1) {
+    uint32_t add = t >= d ? lds[t - d] : 0;
+    __syncthreads();
+    lds[t] = kb::add(lds[t], add);
+    __syncthreads();
+  }
+  return lds[t];
+}
+
+// phase 1: scan each 1024-chunk in place, emit chunk totals. grid = (chunks, ncols)
+__global__ __launch_bounds__(THREADS) void scan_chunks(uint32_t* __restrict__ data, size_t n, uint32_t* __restrict__ totals, size_t nchunks) {
+  __shared__ uint32_t lds[THREADS];
+  uint32_t* col = data + (size_t)blockIdx.y * n;
+  size_t base = (size_t)blockIdx.x * SCAN_BLOCK + (size_t)threadIdx.x * 4;
+  uint32_t v[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) v[i] = base + i < n ? col[base + i] : 0;
+  v[1] = kb::add(v[1], v[0]); v[2] = kb::add(v[2], v[1]); v[3] = kb::add(v[3], v[2]);
+  uint32_t incl = block_inclusive_scan(v[3], lds);
+  uint32_t excl = kb::sub(incl, v[3]);
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+    if (base + i < n) col[base + i] = kb::add(v[i], excl);
+  if (threadIdx.x == THREADS - 1) totals[(size_t)blockIdx.y * nchunks + blockIdx.x] = incl;
+}
+// phase 2: exclusive scan of the chunk totals, one block per column (serial over 256-wide slabs)
+__global__ __launch_bounds__(THREADS) void scan_totals(uint32_t* __restrict__ totals, size_t nchunks) {
+  __shared__ uint32_t lds[THREADS];
+  uint32_t* t = totals + (size_t)blockIdx.x * nchunks;
+  uint32_t carry = 0;
+  for (size_t base = 0; base < nchunks; base += THREADS) {
+    size_t i = base + threadIdx.x;
+    uint32_t v = i < nchunks ? t[i] : 0;
+    uint32_t incl = block_inclusive_scan(v, lds);
+    if (i < nchunks) t[i] = kb::add(carry, kb::sub(incl, v));
+    uint32_t slab = lds[THREADS - 1];
+    __syncthreads();
+    carry = kb::add(carry, slab);
+  }
+}
+// phase 3: add each chunk's offset. grid = (chunks, ncols)
+__global__ __launch_bounds__(THREADS) void scan_add_offsets(uint32_t* __restrict__ data, size_t n, const uint32_t* __restrict__ totals, size_t nchunks) {
+  uint32_t off = totals[(size_t)blockIdx.y * nchunks + blockIdx.x];
+  uint32_t* col = data + (size_t)blockIdx.y * n;
+  size_t base = (size_t)blockIdx.x * SCAN_BLOCK + (size_t)threadIdx.x * 4;
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+    if (base + i < n) col[base + i] = kb::add(col[base + i], off);
+}
+
+// ---- quotient -------------------------------------------------------------------------------
+struct QuotientArgs {
+  const uint32_t* program;   // 2 words per instruction (header stripped)
+  int n_instr;
+  int n_regs;
+  const uint32_t* main_lde;  // column-major, height N (bit-reversed rows)
+  const uint32_t* prep_lde;
+  const uint32_t* perm_lde;
+  size_t main_stride, prep_stride, perm_stride;  // words per column (= LDE height)
+  int log_n;                 // trace height
+  int lqd;                   // quotient domain = n << lqd
+  const kb::E4* alpha_pows;  // alpha_pows[k] multiplies constraint k (already reversed: alpha^(C-1-k))
+  const uint32_t* public_values;
+  kb::E4 perm_alpha, perm_beta;
+  kb::E4 local_sum;
+  const uint32_t* consts;    // device: [0,14) global_cumulative_sum, [16,24) Z_H by (i mod 2^lqd), [24,32) 1/Z_H
+  uint32_t w_q;              // generator of the quotient domain, order n << lqd
+  uint32_t g_inv;            // inverse of the trace-domain generator
+  uint32_t* out;             // chunk c, coefficient e, row j at out[(c * 4 + e) * n + j]
+};
+
+// Register file in LDS: word e of register r of thread t at regs[(r * 4 + e) * blockDim + t]
+// (conflict-free: consecutive lanes hit consecutive banks).
+#define ZKM_REG(r, e) regs[((r) * 4 + (e)) * bd + tid]
+
+__device__ __forceinline__ kb::E4 reg_load_e(const uint32_t* regs, int bd, int tid, int r) {
+  return kb::E4{{ZKM_REG(r, 0), ZKM_REG(r, 1), ZKM_REG(r, 2), ZKM_REG(r, 3)}};
+}
+__device__ __forceinline__ void reg_store_e(uint32_t* regs, int bd, int tid, int r, const kb::E4& v) {
+  ZKM_REG(r, 0) = v.c[0]; ZKM_REG(r, 1) = v.c[1]; ZKM_REG(r, 2) = v.c[2]; ZKM_REG(r, 3) = v.c[3];
+}
+
+// One thread per stored LDE row p (bit-reversed order): i = bitrev(p) is the natural index on
+// the quotient coset 3 * <w_Q>; local row = p, next row = bitrev(i + 2^lqd) (quotient.rs:44-45,61).
+__global__ void quotient_kernel(QuotientArgs a) {
+  extern __shared__ uint32_t regs[];
+  const int bd = blockDim.x, tid = threadIdx.x;
+  const int lq = a.log_n + a.lqd;
+  const size_t Q = (size_t)1 << lq;
+  size_t p = (size_t)blockIdx.x * bd + tid;
+  if (p >= Q) return;
+  uint32_t i = kb::bitrev((uint32_t)p, lq);
+  size_t pn = kb::bitrev((uint32_t)((i + (1u << a.lqd)) & (Q - 1)), lq);
+
+  // selectors at x = 3 * w_Q^i for the trace domain H_n (domain.rs:46-64)
+  uint32_t x = kb::mul(kb::GEN, kb::pow(a.w_q, (uint64_t)i));
+  uint32_t zh = a.consts[16 + (i & ((1u << a.lqd) - 1))];
+  uint32_t is_first = kb::mul(zh, kb::inv(kb::sub(x, kb::ONE)));
+  uint32_t is_trans = kb::sub(x, a.g_inv);
+  uint32_t is_last = kb::mul(zh, kb::inv(is_trans));
+
+  kb::E4 acc = kb::ezero();
+  int cidx = 0;
+  for (int pc = 0; pc < a.n_instr; pc++) {
+    uint32_t w0 = a.program[2 * pc], imm = a.program[2 * pc + 1];
+    int op = w0 & 0xff, dst = (w0 >> 8) & 0xff, ra = (w0 >> 16) & 0xff, rb = w0 >> 24;
+    switch (op) {
+      case 1: ZKM_REG(dst, 0) = a.main_lde[(size_t)imm * a.main_stride + (ra ? pn : p)]; break;
+      case 2: ZKM_REG(dst, 0) = a.prep_lde[(size_t)imm * a.prep_stride + (ra ? pn : p)]; break;
+      case 3: {
+        const uint32_t* q = a.perm_lde + (size_t)(4 * imm) * a.perm_stride + (ra ? pn : p);
+        ZKM_REG(dst, 0) = q[0]; ZKM_REG(dst, 1) = q[a.perm_stride];
+        ZKM_REG(dst, 2) = q[2 * a.perm_stride]; ZKM_REG(dst, 3) = q[3 * a.perm_stride];
+        break;
+      }
+      case 4: ZKM_REG(dst, 0) = imm; break;
+      case 5: ZKM_REG(dst, 0) = a.public_values[imm]; break;
+      case 6: reg_store_e(regs, bd, tid, dst, imm ? a.perm_beta : a.perm_alpha); break;
+      case 7: reg_store_e(regs, bd, tid, dst, a.local_sum); break;
+      case 8: ZKM_REG(dst, 0) = a.consts[imm]; break;
+      case 9: ZKM_REG(dst, 0) = is_first; break;
+      case 10: ZKM_REG(dst, 0) = is_last; break;
+      case 11: ZKM_REG(dst, 0) = is_trans; break;
+      case 16: ZKM_REG(dst, 0) = kb::add(ZKM_REG(ra, 0), ZKM_REG(rb, 0)); break;
+      case 17: ZKM_REG(dst, 0) = kb::sub(ZKM_REG(ra, 0), ZKM_REG(rb, 0)); break;
+      case 18: ZKM_REG(dst, 0) = kb::mul(ZKM_REG(ra, 0), ZKM_REG(rb, 0)); break;
+      case 19: ZKM_REG(dst, 0) = kb::neg(ZKM_REG(ra, 0)); break;
+      case 20: reg_store_e(regs, bd, tid, dst, kb::eadd(reg_load_e(regs, bd, tid, ra), reg_load_e(regs, bd, tid, rb))); break;
+      case 21: reg_store_e(regs, bd, tid, dst, kb::esub(reg_load_e(regs, bd, tid, ra), reg_load_e(regs, bd, tid, rb))); break;
+      case 22: reg_store_e(regs, bd, tid, dst, kb::emul(reg_load_e(regs, bd, tid, ra), reg_load_e(regs, bd, tid, rb))); break;
+      case 23: reg_store_e(regs, bd, tid, dst, kb::eneg(reg_load_e(regs, bd, tid, ra))); break;
+      case 24: reg_store_e(regs, bd, tid, dst, kb::eadd_base(reg_load_e(regs, bd, tid, ra), ZKM_REG(rb, 0))); break;
+      case 25: reg_store_e(regs, bd, tid, dst, kb::esub_base(reg_load_e(regs, bd, tid, ra), ZKM_REG(rb, 0))); break;
+      case 26: reg_store_e(regs, bd, tid, dst, kb::escale(reg_load_e(regs, bd, tid, ra), ZKM_REG(rb, 0))); break;
+      case 32: acc = kb::eadd(acc, kb::escale(a.alpha_pows[cidx++], ZKM_REG(ra, 0))); break;
+      case 33: acc = kb::eadd(acc, kb::emul(a.alpha_pows[cidx++], reg_load_e(regs, bd, tid, ra))); break;
+      default: break;
+    }
+  }
+  kb::E4 q = kb::escale(acc, a.consts[24 + (i & ((1u << a.lqd) - 1))]);
+  // split_evals (prover.rs:477-488): chunk c = i mod 2^lqd, row j = i >> lqd
+  size_t n = (size_t)1 << a.log_n;
+  uint32_t c = i & ((1u << a.lqd) - 1);
+  size_t j = i >> a.lqd;
+#pragma unroll
+  for (int e = 0; e < 4; e++) a.out[((size_t)c * 4 + e) * n + j] = q.c[e];
+}
+#undef ZKM_REG
+
+}  // namespace stark

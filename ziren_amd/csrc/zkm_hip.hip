@@ -1,0 +1,1156 @@
+// libzkm_hip.so — host side of the MI355X shard prover: context, device memory, the
+// Fiat-Shamir transcript, and the commit/open orchestration behind the C ABI of
+// include/zkm_hip.h. The reference's host side is Rust (CpuProver, crates/stark/src/prover.rs);
+// no Rust toolchain exists in this environment, so this layer is C++ and mirrors
+// CpuProver::commit (:258-292) and CpuProver::open (:298-653) step for step.
+//
+// There is no CPU fallback anywhere in this file: every entry point that computes needs the
+// GPU and fails loudly (non-zero status + zkm_last_error) if HIP is unavailable.
+#include "../../include/zkm_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <array>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <numeric>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "kb31.cuh"
+#include "poseidon2.cuh"
+#include "lde.cuh"
+#include "merkle.cuh"
+#include "stark.cuh"
+#include "open.cuh"
+
+using kb::E4;
+
+static thread_local std::string g_err;
+
+#define HIP_CHECK(expr)                                                                          \
+  do {                                                                                           \
+    hipError_t _e = (expr);                                                                      \
+    if (_e != hipSuccess)                                                                        \
+      throw std::runtime_error(std::string(#expr) + ": " + hipGetErrorString(_e) + " (" + __FILE__ + ":" + \
+                               std::to_string(__LINE__) + ")");                                  \
+  } while (0)
+#define LAUNCH_CHECK() HIP_CHECK(hipGetLastError())
+
+static inline int log2_strict(size_t n) {
+  int k = 0;
+  while (((size_t)1 << k) < n) k++;
+  if (((size_t)1 << k) != n) throw std::runtime_error("height is not a power of two");
+  return k;
+}
+static inline unsigned div_up(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }
+
+// ---- host transcript: DuplexChallenger<KoalaBear, Poseidon2, 16, 8> -----------------------------
+// crates/recursion/circuit/src/challenger.rs:90-114,201-233
+namespace chal {
+static void duplexing(zkm_challenger* c) {
+  for (uint32_t i = 0; i < c->num_inputs; i++) c->sponge_state[i] = c->input_buffer[i];
+  c->num_inputs = 0;
+  p2::permute_host(c->sponge_state);
+  for (int i = 0; i < 8; i++) c->output_buffer[i] = c->sponge_state[i];
+  c->num_outputs = 8;
+}
+static void observe(zkm_challenger* c, uint32_t v) {
+  c->num_outputs = 0;
+  c->input_buffer[c->num_inputs++] = v;
+  if (c->num_inputs == 8) duplexing(c);
+}
+static void observe_slice(zkm_challenger* c, const uint32_t* v, size_t n) {
+  for (size_t i = 0; i < n; i++) observe(c, v[i]);
+}
+static void observe_ext(zkm_challenger* c, const E4& e) { observe_slice(c, e.c, 4); }
+static uint32_t sample(zkm_challenger* c) {
+  if (c->num_inputs != 0 || c->num_outputs == 0) duplexing(c);
+  return c->output_buffer[--c->num_outputs];
+}
+static E4 sample_ext(zkm_challenger* c) {
+  E4 e;
+  for (int i = 0; i < 4; i++) e.c[i] = sample(c);
+  return e;
+}
+static uint32_t sample_bits(zkm_challenger* c, uint32_t bits) {
+  return kb::from_monty(sample(c)) & ((1u << bits) - 1);
+}
+}  // namespace chal
+
+// ---- context -----------------------------------------------------------------------------------
+struct zkm_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::mutex mu;
+  std::multimap<size_t, void*> free_list;  // caching allocator: exact-size reuse
+  std::map<void*, size_t> live;
+  std::map<int, uint32_t*> tw_fwd, tw_inv;  // tw[j] = w^(+-j), j < 2^(log-1), per transform log-size
+  std::vector<std::pair<std::string, hipEvent_t>> marks;
+  std::vector<hipEvent_t> event_pool;
+  std::vector<std::string> timing_names;
+  std::vector<float> timing_ms;
+
+  void* alloc(size_t bytes) {
+    if (bytes == 0) bytes = 4;
+    bytes = (bytes + 255) & ~(size_t)255;
+    auto it = free_list.find(bytes);
+    void* p;
+    if (it != free_list.end()) {
+      p = it->second;
+      free_list.erase(it);
+    } else {
+      HIP_CHECK(hipMalloc(&p, bytes));
+    }
+    live[p] = bytes;
+    return p;
+  }
+  template <class T>
+  T* alloc_n(size_t n) { return (T*)alloc(n * sizeof(T)); }
+  // stream-ordered: buffers are only reused by later work on the same stream
+  void release(void* p) {
+    if (!p) return;
+    auto it = live.find(p);
+    if (it == live.end()) return;
+    free_list.insert({it->second, p});
+    live.erase(it);
+  }
+  void mark(const char* name) {
+    hipEvent_t e;
+    if (!event_pool.empty()) { e = event_pool.back(); event_pool.pop_back(); }
+    else HIP_CHECK(hipEventCreate(&e));
+    HIP_CHECK(hipEventRecord(e, stream));
+    marks.push_back({name, e});
+  }
+  void begin_timing() {
+    for (auto& m : marks) event_pool.push_back(m.second);
+    marks.clear();
+    mark("begin");
+  }
+  void end_timing(bool append) {
+    HIP_CHECK(hipStreamSynchronize(stream));
+    if (!append) { timing_names.clear(); timing_ms.clear(); }
+    for (size_t i = 1; i < marks.size(); i++) {
+      float ms = 0;
+      HIP_CHECK(hipEventElapsedTime(&ms, marks[i - 1].second, marks[i].second));
+      timing_names.push_back(marks[i].first);
+      timing_ms.push_back(ms);
+    }
+  }
+  const uint32_t* twiddles(int log_size, bool inverse) {
+    auto& tab = inverse ? tw_inv : tw_fwd;
+    auto it = tab.find(log_size);
+    if (it != tab.end()) return it->second;
+    size_t count = log_size > 0 ? (size_t)1 << (log_size - 1) : 1;
+    uint32_t* d;
+    HIP_CHECK(hipMalloc(&d, count * 4));
+    uint32_t w = kb::two_adic_generator(log_size);
+    if (inverse) w = kb::inv(w);
+    hipLaunchKernelGGL(lde::fill_powers, dim3(div_up(count, 256)), dim3(256), 0, stream, d, w, count);
+    LAUNCH_CHECK();
+    tab[log_size] = d;
+    return d;
+  }
+};
+
+struct zkm_matrix {
+  uint32_t* d = nullptr;  // column-major: column c at d + c * h
+  size_t h = 0, w = 0;
+  bool owned = true;
+};
+
+struct Tree {
+  uint32_t* digests = nullptr;          // all layers, 8 words per digest
+  std::vector<size_t> layer_off;        // in digests
+  size_t max_height = 0;
+  int log_max = 0;
+  const uint32_t* node(int layer, size_t i) const { return digests + (layer_off[layer] + i) * 8; }
+};
+
+struct zkm_pcs_data {
+  std::vector<zkm_matrix> ldes;           // owned; bit-reversed rows, height = h << log_blowup
+  std::vector<const uint32_t*> evals;     // borrowed: the committed evaluations (column-major, natural order)
+  std::vector<size_t> eval_heights;
+  std::vector<uint32_t> domain_shifts;    // evals[i] live on domain_shifts[i] * H
+  std::vector<zkm_matrix> owned_evals;    // evaluations owned by this object (perm traces, quotient chunks)
+  Tree tree;
+  uint32_t root[8];
+  int log_blowup = 1;
+};
+
+struct zkm_pk {
+  std::vector<zkm_matrix> prep;  // borrowed device matrices
+  std::vector<uint32_t> local_only;
+  zkm_pcs_data* data = nullptr;
+  uint32_t commit[8];
+  uint32_t pc_start;
+  uint32_t igcs[14];
+};
+
+struct zkm_main_data {
+  std::vector<size_t> order;             // sorted position -> caller index
+  std::vector<zkm_matrix> traces;        // borrowed, sorted order
+  zkm_pcs_data* data = nullptr;
+  std::vector<uint32_t> public_values;
+};
+
+// ---- device helpers ------------------------------------------------------------------------------
+static void lde_columns(zkm_ctx* ctx, const uint32_t* in, size_t n, size_t w, int bl, uint32_t lde_shift, uint32_t* out) {
+  if (w == 0) return;
+  int k = log2_strict(n);
+  int lb = std::min(k, lde::LOG_ROW_MAX), la = k - lb;
+  size_t N = n << bl;
+  size_t B = (size_t)1 << lb;
+  uint32_t w_n = kb::two_adic_generator(k), w_n_inv = kb::inv(w_n), w_N = kb::two_adic_generator(k + bl);
+  uint32_t n_inv = kb::inv(kb::to_monty((uint32_t)(n % kb::P)));
+  int nhi = B > 64 ? (int)(B >> 6) : 1;
+  size_t rows_lds = (2 * B + 2 * 64 + 2 * nhi) * 4;
+  const uint32_t* twf = lb > 0 ? ctx->twiddles(lb, false) : nullptr;
+  const uint32_t* twi = lb > 0 ? ctx->twiddles(lb, true) : nullptr;
+  if (la == 0) {
+    hipLaunchKernelGGL(lde::lde_rows, dim3(1, (unsigned)w), dim3(lde::THREADS), rows_lds, ctx->stream, in, out, 0, lb, n, N,
+                       (size_t)0, bl, lde_shift, w_n, w_n_inv, w_N, n_inv, twf, twi);
+    LAUNCH_CHECK();
+    return;
+  }
+  size_t A = (size_t)1 << la;
+  int logT = std::min(std::min(6, 14 - la), lb);
+  size_t T = (size_t)1 << logT;
+  size_t cols_lds = A * T * 4;
+  uint32_t* tmp1 = ctx->alloc_n<uint32_t>(n * w);
+  uint32_t* tmp2 = ctx->alloc_n<uint32_t>((n * w) << bl);
+  hipLaunchKernelGGL(lde::lde_cols<false>, dim3((unsigned)(B / T), (unsigned)w, 1), dim3(lde::THREADS), cols_lds, ctx->stream, in,
+                     tmp1, la, lb, logT, n, (size_t)0, n, bl, ctx->twiddles(la, true));
+  LAUNCH_CHECK();
+  hipLaunchKernelGGL(lde::lde_rows, dim3((unsigned)A, (unsigned)w), dim3(lde::THREADS), rows_lds, ctx->stream, tmp1, tmp2, la, lb,
+                     n, n, n * w, bl, lde_shift, w_n, w_n_inv, w_N, n_inv, twf, twi);
+  LAUNCH_CHECK();
+  hipLaunchKernelGGL(lde::lde_cols<true>, dim3((unsigned)(B / T), (unsigned)w, 1u << bl), dim3(lde::THREADS), cols_lds,
+                     ctx->stream, tmp2, out, la, lb, logT, n, n * w, N, bl, ctx->twiddles(la, false));
+  LAUNCH_CHECK();
+  ctx->release(tmp1);
+  ctx->release(tmp2);
+}
+
+// Upload an array of device pointers (one per column) and return the device copy.
+static const uint32_t** upload_ptrs(zkm_ctx* ctx, const std::vector<const uint32_t*>& ptrs) {
+  const uint32_t** d = (const uint32_t**)ctx->alloc(std::max<size_t>(ptrs.size(), 1) * sizeof(void*));
+  if (!ptrs.empty()) {
+    HIP_CHECK(hipMemcpyAsync(d, ptrs.data(), ptrs.size() * sizeof(void*), hipMemcpyHostToDevice, ctx->stream));
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));  // the host vector dies when the caller returns
+  }
+  return d;
+}
+
+// MerkleTreeMmcs::commit over column-major matrices of power-of-two heights.
+static void build_tree(zkm_ctx* ctx, const std::vector<zkm_matrix>& mats, Tree& t) {
+  size_t maxh = 0;
+  for (auto& m : mats) maxh = std::max(maxh, m.h);
+  t.max_height = maxh;
+  t.log_max = log2_strict(maxh);
+  t.layer_off.clear();
+  size_t off = 0;
+  for (size_t len = maxh; len >= 1; len >>= 1) { t.layer_off.push_back(off); off += len; if (len == 1) break; }
+  t.digests = ctx->alloc_n<uint32_t>(off * 8);
+  auto cols_of_height = [&](size_t h) {
+    std::vector<const uint32_t*> ptrs;
+    for (auto& m : mats)
+      if (m.h == h)
+        for (size_t c = 0; c < m.w; c++) ptrs.push_back(m.d + c * m.h);
+    return ptrs;
+  };
+  std::vector<const uint32_t**> to_free;
+  {
+    auto ptrs = cols_of_height(maxh);
+    const uint32_t** d = upload_ptrs(ctx, ptrs);
+    to_free.push_back(d);
+    hipLaunchKernelGGL(merkle::hash_leaves, dim3(div_up(maxh, merkle::THREADS)), dim3(merkle::THREADS), 0, ctx->stream, d,
+                       (int)ptrs.size(), maxh, t.digests);
+    LAUNCH_CHECK();
+  }
+  int layer = 0;
+  for (size_t len = maxh / 2; len >= 1; len >>= 1, layer++) {
+    auto ptrs = cols_of_height(len);
+    const uint32_t** d = nullptr;
+    if (!ptrs.empty()) { d = upload_ptrs(ctx, ptrs); to_free.push_back(d); }
+    hipLaunchKernelGGL(merkle::compress_layer, dim3(div_up(len, merkle::THREADS)), dim3(merkle::THREADS), 0, ctx->stream,
+                       t.digests + t.layer_off[layer] * 8, t.digests + t.layer_off[layer + 1] * 8, len, d, (int)ptrs.size());
+    LAUNCH_CHECK();
+    if (len == 1) break;
+  }
+  for (auto d : to_free) ctx->release((void*)d);
+}
+
+static void free_pcs_data(zkm_ctx* ctx, zkm_pcs_data* d) {
+  if (!d) return;
+  for (auto& m : d->ldes) ctx->release(m.d);
+  for (auto& m : d->owned_evals) ctx->release(m.d);
+  ctx->release(d->tree.digests);
+  delete d;
+}
+
+// TwoAdicFriPcs::commit: LDE every matrix onto 3 * K (shift = GENERATOR / domain_shift), one tree.
+static zkm_pcs_data* pcs_commit(zkm_ctx* ctx, const std::vector<zkm_matrix>& mats, const std::vector<uint32_t>& shifts,
+                                int log_blowup) {
+  zkm_pcs_data* d = new zkm_pcs_data();
+  try {
+    d->log_blowup = log_blowup;
+    for (size_t i = 0; i < mats.size(); i++) {
+      const zkm_matrix& m = mats[i];
+      zkm_matrix l;
+      l.h = m.h << log_blowup;
+      l.w = m.w;
+      l.d = ctx->alloc_n<uint32_t>(l.h * l.w);
+      uint32_t s = shifts.empty() ? kb::ONE : shifts[i];
+      lde_columns(ctx, m.d, m.h, m.w, log_blowup, kb::mul(kb::GEN, kb::inv(s)), l.d);
+      d->ldes.push_back(l);
+      d->evals.push_back(m.d);
+      d->eval_heights.push_back(m.h);
+      d->domain_shifts.push_back(s);
+    }
+    build_tree(ctx, d->ldes, d->tree);
+    HIP_CHECK(hipMemcpyAsync(d->root, d->tree.node(d->tree.log_max, 0), 32, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  } catch (...) {
+    free_pcs_data(ctx, d);
+    throw;
+  }
+  return d;
+}
+
+static E4 host_pow2k(E4 a, int k) { return kb::epow2k(a, k); }
+
+// ---- proof stream writer ---------------------------------------------------------------------------
+struct Writer {
+  std::vector<uint32_t> w;
+  void u(uint32_t v) { w.push_back(v); }
+  void words(const uint32_t* p, size_t n) { w.insert(w.end(), p, p + n); }
+  void ext(const E4& e) { words(e.c, 4); }
+};
+
+// ---- open --------------------------------------------------------------------------------------
+struct RoundMat {
+  const uint32_t* evals; size_t n; size_t width; uint32_t shift;
+  const zkm_matrix* lde;
+  int n_points;  // 1 or 2
+  std::vector<E4> y[2];
+};
+struct Round { const zkm_pcs_data* data; std::vector<RoundMat> mats; };
+
+static const uint32_t SEPTIC_X[7] = {637514027, 1595065213, 1998064738, 72333738, 1211544370, 822986770, 1518535784};
+static const uint32_t SEPTIC_Y[7] = {1604177449, 90440090, 259343427, 140470264, 1162099742, 941559812, 1064053343};
+
+struct ChipMeta {
+  const zkm_chip_desc* desc;
+  int log_n;
+  size_t n;
+  int n_lookups, n_sends, perm_ext_w, max_values;
+};
+
+static ChipMeta chip_meta(const zkm_chip_desc* d, size_t n) {
+  ChipMeta m;
+  m.desc = d; m.n = n; m.log_n = log2_strict(n);
+  m.n_lookups = m.n_sends = m.max_values = 0;
+  if (d->lookups_len) {
+    const uint32_t* w = d->lookups;
+    size_t pos = 0;
+    uint32_t ns = w[pos++], nr = w[pos++];
+    m.n_sends = ns; m.n_lookups = ns + nr;
+    for (uint32_t i = 0; i < ns + nr; i++) {
+      pos++;  // kind
+      uint32_t nv = w[pos++];
+      m.max_values = std::max<int>(m.max_values, nv);
+      for (uint32_t v = 0; v <= nv; v++) { uint32_t nt = w[pos++]; pos += 1 + 2 * (size_t)nt; }
+    }
+    if (pos != d->lookups_len) throw std::runtime_error(std::string("lookup blob length mismatch for chip ") + d->name);
+  }
+  int batch = 1 << d->log_quotient_degree;
+  m.perm_ext_w = m.n_lookups ? (m.n_lookups + batch - 1) / batch + 1 : 0;
+  if (d->program_len) {
+    if (d->program_len < 4 || d->program_len != 4 + 2 * (size_t)d->program[0]) throw std::runtime_error("program blob length mismatch");
+    if (d->program[2] != d->num_constraints) throw std::runtime_error("program constraint count mismatch");
+  }
+  return m;
+}
+
+static void open_impl(zkm_ctx* ctx, const zkm_pk* pk, zkm_main_data* md, const zkm_chip_desc* chips_in, const zkm_fri_config* fri,
+                      uint32_t num_pv_elts, zkm_challenger* ch, Writer& out) {
+  hipStream_t st = ctx->stream;
+  const int bl = fri->log_blowup;
+  const size_t nc = md->order.size();
+  std::vector<ChipMeta> chips;
+  for (size_t i = 0; i < nc; i++) chips.push_back(chip_meta(&chips_in[md->order[i]], md->traces[i].h));
+  for (size_t i = 0; i < nc; i++) {
+    if (chips[i].desc->main_width != md->traces[i].w) throw std::runtime_error("chip main_width does not match its trace");
+    if ((int)chips[i].desc->log_quotient_degree > bl) throw std::runtime_error("log_quotient_degree > log_blowup unsupported");
+    if (chips[i].desc->prep_index >= 0 && (!pk->data || (size_t)chips[i].desc->prep_index >= pk->prep.size()))
+      throw std::runtime_error("chip references a preprocessed trace the proving key does not hold");
+  }
+  std::vector<void*> scratch;  // released at the end
+  auto salloc = [&](size_t bytes) { void* p = ctx->alloc(bytes); scratch.push_back(p); return p; };
+
+  // --- transcript prelude (prover.rs:321-329)
+  chal::observe_slice(ch, md->public_values.data(), num_pv_elts);
+  chal::observe_slice(ch, md->data->root, 8);
+  E4 perm_ch[2] = {chal::sample_ext(ch), chal::sample_ext(ch)};
+  uint32_t* d_pv = (uint32_t*)salloc(std::max<size_t>(md->public_values.size(), 1) * 4);
+  if (!md->public_values.empty())
+    HIP_CHECK(hipMemcpyAsync(d_pv, md->public_values.data(), md->public_values.size() * 4, hipMemcpyHostToDevice, st));
+
+  // --- permutation traces (prover.rs:337-365)
+  std::vector<zkm_matrix> perm_traces(nc);
+  std::vector<E4> local_sums(nc, kb::ezero());
+  std::vector<std::array<uint32_t, 14>> global_sums(nc);
+  std::vector<uint32_t*> d_blobs(nc, nullptr);
+  {
+    int maxv = 0;
+    for (auto& c : chips) maxv = std::max(maxv, c.max_values);
+    std::vector<E4> bp(maxv + 2);
+    bp[0] = kb::eone();
+    for (int i = 1; i < maxv + 2; i++) bp[i] = kb::emul(bp[i - 1], perm_ch[1]);
+    E4* d_bp = (E4*)salloc(bp.size() * sizeof(E4));
+    HIP_CHECK(hipMemcpyAsync(d_bp, bp.data(), bp.size() * sizeof(E4), hipMemcpyHostToDevice, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    for (size_t i = 0; i < nc; i++) {
+      const ChipMeta& c = chips[i];
+      zkm_matrix& pt = perm_traces[i];
+      pt.h = c.n; pt.w = (size_t)c.perm_ext_w * 4;
+      pt.d = ctx->alloc_n<uint32_t>(std::max<size_t>(pt.h * pt.w, 1));
+      if (c.perm_ext_w > 0) {
+        d_blobs[i] = (uint32_t*)salloc(c.desc->lookups_len * 4);
+        HIP_CHECK(hipMemcpyAsync(d_blobs[i], c.desc->lookups, c.desc->lookups_len * 4, hipMemcpyHostToDevice, st));
+        const uint32_t* prep = c.desc->prep_index >= 0 ? pk->prep[c.desc->prep_index].d : nullptr;
+        hipLaunchKernelGGL(stark::perm_rows, dim3(div_up(c.n, stark::THREADS)), dim3(stark::THREADS), 0, st, d_blobs[i], c.n_lookups,
+                           c.n_sends, 1 << c.desc->log_quotient_degree, md->traces[i].d, prep, c.n, perm_ch[0], d_bp, pt.d,
+                           c.perm_ext_w);
+        LAUNCH_CHECK();
+        // inclusive scan of the last ext column (4 base columns)
+        uint32_t* last = pt.d + (size_t)(c.perm_ext_w - 1) * 4 * c.n;
+        size_t nchunks = (c.n + stark::SCAN_BLOCK - 1) / stark::SCAN_BLOCK;
+        uint32_t* totals = (uint32_t*)salloc(nchunks * 4 * 4);
+        hipLaunchKernelGGL(stark::scan_chunks, dim3((unsigned)nchunks, 4), dim3(stark::THREADS), 0, st, last, c.n, totals, nchunks);
+        LAUNCH_CHECK();
+        if (nchunks > 1) {
+          hipLaunchKernelGGL(stark::scan_totals, dim3(4), dim3(stark::THREADS), 0, st, totals, nchunks);
+          LAUNCH_CHECK();
+          hipLaunchKernelGGL(stark::scan_add_offsets, dim3((unsigned)nchunks, 4), dim3(stark::THREADS), 0, st, last, c.n,
+                             (const uint32_t*)totals, nchunks);
+          LAUNCH_CHECK();
+        }
+        for (int e = 0; e < 4; e++)
+          HIP_CHECK(hipMemcpyAsync(&local_sums[i].c[e], last + (size_t)e * c.n + (c.n - 1), 4, hipMemcpyDeviceToHost, st));
+      }
+      if (c.desc->commit_scope_global) {
+        const zkm_matrix& m = md->traces[i];
+        for (int k = 0; k < 14; k++)
+          HIP_CHECK(hipMemcpyAsync(&global_sums[i][k], m.d + (m.w - 14 + k) * m.h + (m.h - 1), 4, hipMemcpyDeviceToHost, st));
+      } else {
+        for (int k = 0; k < 7; k++) { global_sums[i][k] = kb::to_monty(SEPTIC_X[k]); global_sums[i][7 + k] = kb::to_monty(SEPTIC_Y[k]); }
+      }
+    }
+  }
+  ctx->mark("permutation traces");
+  zkm_pcs_data* perm_data = pcs_commit(ctx, perm_traces, {}, bl);  // synchronises: sums are on the host now
+  perm_data->owned_evals = perm_traces;
+  ctx->mark("commit permutation");
+  struct Guard { zkm_ctx* c; std::vector<zkm_pcs_data*> d; ~Guard() { for (auto p : d) free_pcs_data(c, p); } } guard{ctx, {perm_data}};
+  chal::observe_slice(ch, perm_data->root, 8);
+  for (size_t i = 0; i < nc; i++) {
+    chal::observe_ext(ch, local_sums[i]);
+    chal::observe_slice(ch, global_sums[i].data(), 14);
+  }
+  // --- quotient (prover.rs:416-488)
+  E4 alpha = chal::sample_ext(ch);
+  std::vector<zkm_matrix> qchunks;
+  std::vector<uint32_t> qshifts;
+  for (size_t i = 0; i < nc; i++) {
+    const ChipMeta& c = chips[i];
+    const zkm_chip_desc* d = c.desc;
+    int lqd = d->log_quotient_degree;
+    int lq = c.log_n + lqd;
+    size_t Q = (size_t)1 << lq;
+    size_t nchunks = (size_t)1 << lqd;
+    uint32_t* qbuf = ctx->alloc_n<uint32_t>(Q * 4);
+    // alpha powers, reversed (prover.rs:453-456)
+    size_t C = d->num_constraints;
+    std::vector<E4> ap(std::max<size_t>(C, 1));
+    E4 p = kb::eone();
+    for (size_t k = 0; k < C; k++) { ap[C - 1 - k] = p; p = kb::emul(p, alpha); }
+    E4* d_ap = (E4*)salloc(ap.size() * sizeof(E4));
+    HIP_CHECK(hipMemcpyAsync(d_ap, ap.data(), ap.size() * sizeof(E4), hipMemcpyHostToDevice, st));
+    uint32_t consts[32] = {0};
+    for (int k = 0; k < 14; k++) consts[k] = global_sums[i][k];
+    uint32_t w_q = kb::two_adic_generator(lq);
+    // Z_H(3 w_Q^i) = 3^n * (w_Q^n)^i - 1 depends on i mod 2^lqd (zerofier_coset.rs:22-51)
+    uint32_t s_pow_n = kb::pow(kb::GEN, (uint64_t)c.n);
+    uint32_t wr = kb::two_adic_generator(lqd), wp = kb::ONE;
+    for (size_t k = 0; k < nchunks; k++) {
+      consts[16 + k] = kb::sub(kb::mul(s_pow_n, wp), kb::ONE);
+      consts[24 + k] = kb::inv(consts[16 + k]);
+      wp = kb::mul(wp, wr);
+    }
+    uint32_t* d_consts = (uint32_t*)salloc(sizeof consts);
+    HIP_CHECK(hipMemcpyAsync(d_consts, consts, sizeof consts, hipMemcpyHostToDevice, st));
+    HIP_CHECK(hipStreamSynchronize(st));  // ap / consts are short-lived host buffers
+    uint32_t* d_prog = (uint32_t*)salloc(std::max<size_t>(d->program_len, 4) * 4);
+    if (d->program_len) HIP_CHECK(hipMemcpyAsync(d_prog, d->program, d->program_len * 4, hipMemcpyHostToDevice, st));
+    stark::QuotientArgs a;
+    a.program = d_prog + 4;
+    a.n_instr = d->program_len ? d->program[0] : 0;
+    a.n_regs = d->program_len ? d->program[1] : 1;
+    a.main_lde = md->data->ldes[i].d; a.main_stride = md->data->ldes[i].h;
+    a.prep_lde = d->prep_index >= 0 ? pk->data->ldes[d->prep_index].d : nullptr;
+    a.prep_stride = d->prep_index >= 0 ? pk->data->ldes[d->prep_index].h : 0;
+    a.perm_lde = perm_data->ldes[i].d; a.perm_stride = perm_data->ldes[i].h;
+    a.log_n = c.log_n; a.lqd = lqd;
+    a.alpha_pows = d_ap; a.public_values = d_pv;
+    a.perm_alpha = perm_ch[0]; a.perm_beta = perm_ch[1];
+    a.local_sum = local_sums[i];
+    a.consts = d_consts;
+    a.w_q = w_q; a.g_inv = kb::inv(kb::two_adic_generator(c.log_n));
+    a.out = qbuf;
+    int bd = 128;
+    while ((size_t)a.n_regs * 16 * bd > 160 * 1024 && bd > 64) bd >>= 1;
+    size_t lds = (size_t)a.n_regs * 16 * bd;
+    if (lds > 160 * 1024) throw std::runtime_error(std::string("constraint program of chip ") + d->name + " needs too many registers");
+    hipLaunchKernelGGL(stark::quotient_kernel, dim3(div_up(Q, bd)), dim3(bd), lds, st, a);
+    LAUNCH_CHECK();
+    uint32_t wqp = kb::ONE;
+    for (size_t k = 0; k < nchunks; k++) {
+      zkm_matrix m; m.h = c.n; m.w = 4; m.d = qbuf + k * 4 * c.n; m.owned = (k == 0);
+      qchunks.push_back(m);
+      qshifts.push_back(kb::mul(kb::GEN, wqp));
+      wqp = kb::mul(wqp, w_q);
+    }
+  }
+  ctx->mark("quotient values");
+  zkm_pcs_data* quot_data = pcs_commit(ctx, qchunks, qshifts, bl);
+  for (auto& m : qchunks) if (m.owned) quot_data->owned_evals.push_back(m);
+  guard.d.push_back(quot_data);
+  ctx->mark("commit quotient");
+  chal::observe_slice(ch, quot_data->root, 8);
+  E4 zeta = chal::sample_ext(ch);
+
+  // --- opening rounds (prover.rs:503-556): preprocessed, main, permutation, quotient
+  std::vector<Round> rounds;
+  if (pk->data) {
+    Round r; r.data = pk->data;
+    for (size_t j = 0; j < pk->prep.size(); j++)
+      r.mats.push_back(RoundMat{pk->prep[j].d, pk->prep[j].h, pk->prep[j].w, kb::ONE, &pk->data->ldes[j], pk->local_only[j] ? 1 : 2, {}});
+    rounds.push_back(r);
+  }
+  {
+    Round r; r.data = md->data;
+    for (size_t i = 0; i < nc; i++)
+      r.mats.push_back(RoundMat{md->traces[i].d, md->traces[i].h, md->traces[i].w, kb::ONE, &md->data->ldes[i], chips[i].desc->local_only ? 1 : 2, {}});
+    rounds.push_back(r);
+    Round rp; rp.data = perm_data;
+    for (size_t i = 0; i < nc; i++)
+      rp.mats.push_back(RoundMat{perm_traces[i].d, perm_traces[i].h, perm_traces[i].w, kb::ONE, &perm_data->ldes[i], 2, {}});
+    rounds.push_back(rp);
+    Round rq; rq.data = quot_data;
+    for (size_t i = 0; i < qchunks.size(); i++)
+      rq.mats.push_back(RoundMat{qchunks[i].d, qchunks[i].h, 4, qshifts[i], &quot_data->ldes[i], 1, {}});
+    rounds.push_back(rq);
+  }
+  // (i) evaluate every column at zeta (and zeta * g): barycentric weights shared per (height, shift)
+  {
+    std::map<std::pair<size_t, uint32_t>, E4*> wcache;
+    const unsigned SPLIT = 32;
+    for (auto& r : rounds)
+      for (auto& m : r.mats) {
+        if (m.width == 0) { m.y[0].clear(); m.y[1].clear(); continue; }
+        auto key = std::make_pair(m.n, m.shift);
+        E4* wts;
+        auto it = wcache.find(key);
+        if (it == wcache.end()) {
+          int ln = log2_strict(m.n);
+          E4 u = kb::escale(zeta, kb::inv(m.shift));
+          E4 c = kb::escale(kb::esub_base(host_pow2k(u, ln), kb::ONE), kb::inv(kb::to_monty((uint32_t)(m.n % kb::P))));
+          wts = (E4*)salloc(m.n * sizeof(E4));
+          hipLaunchKernelGGL(open::bary_weights, dim3(div_up(m.n, open::THREADS)), dim3(open::THREADS), 0, st, u, c,
+                             kb::two_adic_generator(ln), m.n, wts);
+          LAUNCH_CHECK();
+          wcache[key] = wts;
+        } else wts = it->second;
+        unsigned split = (unsigned)std::min<size_t>(SPLIT, std::max<size_t>(1, m.n / open::THREADS));
+        E4* partials = (E4*)salloc((size_t)split * m.width * 2 * sizeof(E4));
+        hipLaunchKernelGGL(open::eval_columns, dim3(div_up(m.width, open::EVAL_COLS), split), dim3(open::THREADS), 0, st, m.evals,
+                           m.n, (int)m.width, (const E4*)wts, m.n_points > 1 ? 1 : 0, partials);
+        LAUNCH_CHECK();
+        std::vector<E4> hp((size_t)split * m.width * 2);
+        HIP_CHECK(hipMemcpyAsync(hp.data(), partials, hp.size() * sizeof(E4), hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        for (int pt = 0; pt < m.n_points; pt++) {
+          m.y[pt].assign(m.width, kb::ezero());
+          for (unsigned s = 0; s < split; s++)
+            for (size_t c = 0; c < m.width; c++) m.y[pt][c] = kb::eadd(m.y[pt][c], hp[((size_t)s * m.width + c) * 2 + pt]);
+        }
+      }
+  }
+  ctx->mark("open: evaluations");
+  // (ii) alpha; opened values are not observed (fri.rs:78)
+  E4 fa = chal::sample_ext(ch);
+  // (iii) reduced openings per LDE height
+  int log_max = 0;
+  size_t max_width = 1;
+  for (auto& r : rounds) for (auto& m : r.mats) { log_max = std::max(log_max, log2_strict(m.lde->h)); max_width = std::max(max_width, m.width); }
+  std::vector<E4> fap(max_width + 1);
+  fap[0] = kb::eone();
+  for (size_t i = 1; i <= max_width; i++) fap[i] = kb::emul(fap[i - 1], fa);
+  E4* d_fap = (E4*)salloc(fap.size() * sizeof(E4));
+  HIP_CHECK(hipMemcpyAsync(d_fap, fap.data(), fap.size() * sizeof(E4), hipMemcpyHostToDevice, st));
+  std::vector<E4*> ro(32, nullptr);
+  {
+    std::vector<std::vector<open::ReduceMat>> per_h(32);
+    std::vector<E4> run(32, kb::eone());  // alpha^count per height
+    for (auto& r : rounds)
+      for (auto& m : r.mats) {
+        int lh = log2_strict(m.lde->h);
+        open::ReduceMat rm;
+        rm.lde = m.lde->d; rm.width = (int)m.width; rm.n_points = m.n_points;
+        for (int pt = 0; pt < 2; pt++) { rm.A[pt] = kb::ezero(); rm.Yc[pt] = kb::ezero(); }
+        for (int pt = 0; pt < m.n_points; pt++) {
+          E4 ysum = kb::ezero();
+          for (size_t c = 0; c < m.width; c++) ysum = kb::eadd(ysum, kb::emul(fap[c], m.y[pt][c]));
+          rm.A[pt] = run[lh];
+          rm.Yc[pt] = kb::emul(run[lh], ysum);
+          run[lh] = kb::emul(run[lh], fap[m.width]);
+        }
+        per_h[lh].push_back(rm);
+      }
+    for (int lh = 0; lh < 32; lh++) {
+      if (per_h[lh].empty()) continue;
+      size_t N = (size_t)1 << lh;
+      ro[lh] = (E4*)salloc(N * sizeof(E4));
+      open::ReduceMat* d_rm = (open::ReduceMat*)salloc(per_h[lh].size() * sizeof(open::ReduceMat));
+      HIP_CHECK(hipMemcpyAsync(d_rm, per_h[lh].data(), per_h[lh].size() * sizeof(open::ReduceMat), hipMemcpyHostToDevice, st));
+      HIP_CHECK(hipStreamSynchronize(st));  // per_h storage is pageable host memory
+      E4 z1 = kb::escale(zeta, kb::two_adic_generator(lh - bl));
+      hipLaunchKernelGGL(open::reduce_openings, dim3(div_up(N, open::THREADS)), dim3(open::THREADS), 0, st,
+                         (const open::ReduceMat*)d_rm, (int)per_h[lh].size(), lh, (const E4*)d_fap, zeta, z1,
+                         kb::two_adic_generator(lh), ro[lh], 0);
+      LAUNCH_CHECK();
+    }
+  }
+  ctx->mark("open: reduced openings");
+  // (iv) FRI commit phase (fri.rs:257-358)
+  std::vector<E4*> layers;      // f_t on device
+  std::vector<Tree> ftrees;
+  std::vector<std::array<uint32_t, 8>> commits;
+  E4* f = ro[log_max];
+  int lf = log_max;
+  uint32_t neg_half = kb::neg(kb::inv(kb::to_monty(2)));
+  while (lf > bl) {
+    size_t len = (size_t)1 << lf, half = len / 2;
+    Tree t;
+    t.max_height = half; t.log_max = lf - 1;
+    size_t off = 0;
+    for (size_t l = half; l >= 1; l >>= 1) { t.layer_off.push_back(off); off += l; if (l == 1) break; }
+    t.digests = (uint32_t*)salloc(off * 8 * 4);
+    hipLaunchKernelGGL(merkle::hash_fri_leaves, dim3(div_up(half, merkle::THREADS)), dim3(merkle::THREADS), 0, st, (const E4*)f, half,
+                       t.digests);
+    LAUNCH_CHECK();
+    int layer = 0;
+    for (size_t l = half / 2; l >= 1; l >>= 1, layer++) {
+      hipLaunchKernelGGL(merkle::compress_layer, dim3(div_up(l, merkle::THREADS)), dim3(merkle::THREADS), 0, st,
+                         (const uint32_t*)(t.digests + t.layer_off[layer] * 8), t.digests + t.layer_off[layer + 1] * 8, l,
+                         (const uint32_t* const*)nullptr, 0);
+      LAUNCH_CHECK();
+      if (l == 1) break;
+    }
+    std::array<uint32_t, 8> root;
+    HIP_CHECK(hipMemcpyAsync(root.data(), t.node(t.log_max, 0), 32, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    chal::observe_slice(ch, root.data(), 8);
+    commits.push_back(root);
+    E4 beta = chal::sample_ext(ch);
+    E4* g = (E4*)salloc(half * sizeof(E4));
+    hipLaunchKernelGGL(open::fri_fold, dim3(div_up(half, open::THREADS)), dim3(open::THREADS), 0, st, (const E4*)f, lf, beta,
+                       kb::esqr(beta), kb::two_adic_generator(lf), kb::inv(kb::two_adic_generator(lf)), neg_half,
+                       (const E4*)ro[lf - 1], g);
+    LAUNCH_CHECK();
+    layers.push_back(f);
+    ftrees.push_back(t);
+    f = g;
+    lf--;
+  }
+  std::vector<E4> fin((size_t)1 << lf);
+  HIP_CHECK(hipMemcpyAsync(fin.data(), f, fin.size() * sizeof(E4), hipMemcpyDeviceToHost, st));
+  HIP_CHECK(hipStreamSynchronize(st));
+  for (size_t i = 1; i < fin.size(); i++)
+    if (!kb::eq(fin[i], fin[0])) throw std::runtime_error("FRI final polynomial is not constant (internal error)");
+  E4 final_poly = fin[0];
+  chal::observe_ext(ch, final_poly);
+  ctx->mark("open: FRI commit phase");
+  // proof of work: smallest canonical witness
+  uint32_t pow_witness;
+  {
+    uint32_t* d_state = (uint32_t*)salloc(16 * 4);
+    uint32_t* d_in = (uint32_t*)salloc(16 * 4);
+    unsigned int* d_best = (unsigned int*)salloc(4);
+    HIP_CHECK(hipMemcpyAsync(d_state, ch->sponge_state, 64, hipMemcpyHostToDevice, st));
+    HIP_CHECK(hipMemcpyAsync(d_in, ch->input_buffer, 64, hipMemcpyHostToDevice, st));
+    uint32_t base = 0, found = 0xffffffffu;
+    const uint32_t BATCH = 1u << 20;
+    while (base < kb::P) {
+      unsigned int init = 0xffffffffu;
+      HIP_CHECK(hipMemcpyAsync(d_best, &init, 4, hipMemcpyHostToDevice, st));
+      uint32_t total = std::min<uint64_t>(BATCH, (uint64_t)kb::P - base);
+      hipLaunchKernelGGL(merkle::grind, dim3(div_up(total, merkle::THREADS)), dim3(merkle::THREADS), 0, st, (const uint32_t*)d_state,
+                         (const uint32_t*)d_in, (int)ch->num_inputs, (int)fri->proof_of_work_bits, base, total, d_best);
+      LAUNCH_CHECK();
+      HIP_CHECK(hipMemcpyAsync(&found, d_best, 4, hipMemcpyDeviceToHost, st));
+      HIP_CHECK(hipStreamSynchronize(st));
+      if (found != 0xffffffffu) break;
+      base += total;
+    }
+    if (found == 0xffffffffu) throw std::runtime_error("proof-of-work search exhausted the field");
+    pow_witness = kb::to_monty(found);
+    chal::observe(ch, pow_witness);
+    if (chal::sample_bits(ch, fri->proof_of_work_bits) != 0) throw std::runtime_error("proof-of-work witness rejected by host transcript");
+  }
+  ctx->mark("open: grind");
+  // queries: build one gather list in serialisation order
+  std::vector<size_t> indices(fri->num_queries);
+  for (auto& q : indices) q = chal::sample_bits(ch, log_max);
+  std::vector<const uint32_t*> src;
+  for (size_t q : indices) {
+    for (auto& r : rounds) {
+      const Tree& t = r.data->tree;
+      size_t idx = q >> (log_max - t.log_max);
+      for (auto& m : r.mats) {
+        size_t row = idx >> (t.log_max - log2_strict(m.lde->h));
+        for (size_t c = 0; c < m.width; c++) src.push_back(m.lde->d + c * m.lde->h + row);
+      }
+      for (int l = 0; l < t.log_max; l++) {
+        const uint32_t* nd = t.node(l, (idx >> l) ^ 1);
+        for (int k = 0; k < 8; k++) src.push_back(nd + k);
+      }
+    }
+    for (size_t tI = 0; tI < ftrees.size(); tI++) {
+      size_t i = q >> tI;
+      const uint32_t* sib = (const uint32_t*)(layers[tI] + (i ^ 1));
+      for (int k = 0; k < 4; k++) src.push_back(sib + k);
+      const Tree& t = ftrees[tI];
+      size_t pi = i >> 1;
+      for (int l = 0; l < t.log_max; l++) {
+        const uint32_t* nd = t.node(l, (pi >> l) ^ 1);
+        for (int k = 0; k < 8; k++) src.push_back(nd + k);
+      }
+    }
+  }
+  std::vector<uint32_t> gathered(src.size());
+  if (!src.empty()) {
+    const uint32_t** d_src = (const uint32_t**)salloc(src.size() * sizeof(void*));
+    uint32_t* d_dst = (uint32_t*)salloc(src.size() * 4);
+    HIP_CHECK(hipMemcpyAsync(d_src, src.data(), src.size() * sizeof(void*), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(open::gather_words, dim3(div_up(src.size(), open::THREADS)), dim3(open::THREADS), 0, st,
+                       (const uint32_t* const*)d_src, src.size(), d_dst);
+    LAUNCH_CHECK();
+    HIP_CHECK(hipMemcpyAsync(gathered.data(), d_dst, src.size() * 4, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+  }
+  ctx->mark("open: queries");
+
+  // --- serialise (INTEGRATION.md "ShardProof stream"; prover.rs:558-652)
+  out.words(md->data->root, 8);
+  out.words(perm_data->root, 8);
+  out.words(quot_data->root, 8);
+  out.u((uint32_t)nc);
+  size_t ri = pk->data ? 1 : 0;
+  Round& rmain = rounds[ri];
+  Round& rperm = rounds[ri + 1];
+  Round& rquot = rounds[ri + 2];
+  size_t qpos = 0;
+  auto put_exts = [&](const std::vector<E4>& v) { for (auto& e : v) out.ext(e); };
+  for (size_t i = 0; i < nc; i++) {
+    const zkm_chip_desc* d = chips[i].desc;
+    out.u((uint32_t)md->order[i]);
+    out.u((uint32_t)chips[i].log_n);
+    if (d->prep_index >= 0) {
+      RoundMat& pm = rounds[0].mats[d->prep_index];
+      out.u((uint32_t)pm.width);
+      put_exts(pm.y[0]);
+      if (pm.n_points > 1) put_exts(pm.y[1]); else put_exts(std::vector<E4>(pm.width, kb::ezero()));
+    } else out.u(0);
+    RoundMat& mm = rmain.mats[i];
+    out.u((uint32_t)mm.width);
+    put_exts(mm.y[0]);
+    if (mm.n_points > 1) put_exts(mm.y[1]); else put_exts(std::vector<E4>(mm.width, kb::ezero()));
+    RoundMat& pm = rperm.mats[i];
+    out.u((uint32_t)pm.width);
+    put_exts(pm.y[0]); put_exts(pm.y[1]);
+    size_t nch = (size_t)1 << d->log_quotient_degree;
+    out.u((uint32_t)nch);
+    for (size_t k = 0; k < nch; k++) put_exts(rquot.mats[qpos++].y[0]);
+    out.words(global_sums[i].data(), 14);
+    out.ext(local_sums[i]);
+  }
+  out.u((uint32_t)commits.size());
+  for (auto& c : commits) out.words(c.data(), 8);
+  out.u((uint32_t)indices.size());
+  size_t gp = 0;
+  for (size_t qi = 0; qi < indices.size(); qi++) {
+    out.u((uint32_t)rounds.size());
+    for (auto& r : rounds) {
+      out.u((uint32_t)r.mats.size());
+      for (auto& m : r.mats) { out.u((uint32_t)m.width); out.words(gathered.data() + gp, m.width); gp += m.width; }
+      out.u((uint32_t)r.data->tree.log_max);
+      out.words(gathered.data() + gp, (size_t)r.data->tree.log_max * 8); gp += (size_t)r.data->tree.log_max * 8;
+    }
+    out.u((uint32_t)ftrees.size());
+    for (auto& t : ftrees) {
+      out.words(gathered.data() + gp, 4); gp += 4;
+      out.u((uint32_t)t.log_max);
+      out.words(gathered.data() + gp, (size_t)t.log_max * 8); gp += (size_t)t.log_max * 8;
+    }
+  }
+  out.ext(final_poly);
+  out.u(pow_witness);
+  out.u((uint32_t)md->public_values.size());
+  out.words(md->public_values.data(), md->public_values.size());
+  for (void* p : scratch) ctx->release(p);
+}
+
+// ---- C ABI ---------------------------------------------------------------------------------------
+#define API_BEGIN try {
+#define API_END                              \
+  }                                          \
+  catch (const std::exception& e) {          \
+    g_err = e.what();                        \
+    return -1;                               \
+  }                                          \
+  return 0;
+
+extern "C" {
+
+const char* zkm_last_error(void) { return g_err.c_str(); }
+
+int zkm_ctx_create(int device, zkm_ctx** out) {
+  API_BEGIN
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count == 0)
+    throw std::runtime_error("no HIP device available: libzkm_hip has no CPU fallback (hipGetDeviceCount: " +
+                             std::string(hipGetErrorString(e)) + ")");
+  if (device < 0 || device >= count) throw std::runtime_error("device index out of range");
+  HIP_CHECK(hipSetDevice(device));
+  zkm_ctx* c = new zkm_ctx();
+  c->device = device;
+  HIP_CHECK(hipStreamCreate(&c->stream));
+  HIP_CHECK(p2::upload_tables());
+  HIP_CHECK(hipFuncSetAttribute((const void*)lde::lde_rows, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIP_CHECK(hipFuncSetAttribute((const void*)lde::lde_cols<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIP_CHECK(hipFuncSetAttribute((const void*)lde::lde_cols<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIP_CHECK(hipFuncSetAttribute((const void*)stark::quotient_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  *out = c;
+  API_END
+}
+
+void zkm_ctx_destroy(zkm_ctx* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  for (auto& kv : ctx->free_list) (void)hipFree(kv.second);
+  for (auto& kv : ctx->live) (void)hipFree(kv.first);
+  for (auto& kv : ctx->tw_fwd) (void)hipFree(kv.second);
+  for (auto& kv : ctx->tw_inv) (void)hipFree(kv.second);
+  for (auto& m : ctx->marks) (void)hipEventDestroy(m.second);
+  for (auto& e : ctx->event_pool) (void)hipEventDestroy(e);
+  (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+int zkm_ctx_synchronize(zkm_ctx* ctx) {
+  API_BEGIN
+  HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  API_END
+}
+
+int zkm_ctx_last_timings(zkm_ctx* ctx, const char** names, float* ms, int cap) {
+  int n = (int)ctx->timing_names.size();
+  for (int i = 0; i < n && i < cap; i++) { names[i] = ctx->timing_names[i].c_str(); ms[i] = ctx->timing_ms[i]; }
+  return n;
+}
+
+int zkm_matrix_upload(zkm_ctx* ctx, const uint32_t* host, size_t height, size_t width, zkm_matrix** out) {
+  API_BEGIN
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIP_CHECK(hipSetDevice(ctx->device));
+  log2_strict(height);
+  zkm_matrix* m = new zkm_matrix();
+  m->h = height; m->w = width;
+  m->d = ctx->alloc_n<uint32_t>(std::max<size_t>(height * width, 1));
+  if (height * width) {
+    uint32_t* stage = ctx->alloc_n<uint32_t>(height * width);
+    HIP_CHECK(hipMemcpyAsync(stage, host, height * width * 4, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(open::transpose, dim3(div_up(width, 32), div_up(height, 32)), dim3(32, 8), 0, ctx->stream,
+                       (const uint32_t*)stage, m->d, height, width);
+    LAUNCH_CHECK();
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    ctx->release(stage);
+  }
+  *out = m;
+  API_END
+}
+
+static void download_colmajor(zkm_ctx* ctx, const uint32_t* d, size_t h, size_t w, uint32_t* host) {
+  if (h * w == 0) return;
+  uint32_t* stage = ctx->alloc_n<uint32_t>(h * w);
+  hipLaunchKernelGGL(open::transpose, dim3(div_up(h, 32), div_up(w, 32)), dim3(32, 8), 0, ctx->stream, d, stage, w, h);
+  LAUNCH_CHECK();
+  HIP_CHECK(hipMemcpyAsync(host, stage, h * w * 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  ctx->release(stage);
+}
+
+int zkm_matrix_download(zkm_ctx* ctx, const zkm_matrix* m, uint32_t* host) {
+  API_BEGIN
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIP_CHECK(hipSetDevice(ctx->device));
+  download_colmajor(ctx, m->d, m->h, m->w, host);
+  API_END
+}
+size_t zkm_matrix_height(const zkm_matrix* m) { return m->h; }
+size_t zkm_matrix_width(const zkm_matrix* m) { return m->w; }
+void zkm_matrix_free(zkm_ctx* ctx, zkm_matrix* m) {
+  if (!m) return;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (m->owned) ctx->release(m->d);
+  delete m;
+}
+
+int zkm_pcs_commit(zkm_ctx* ctx, size_t n_mats, const zkm_matrix* const* mats, const uint32_t* domain_shifts, uint32_t log_blowup,
+                   uint32_t root_out[8], zkm_pcs_data** out) {
+  API_BEGIN
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIP_CHECK(hipSetDevice(ctx->device));
+  if (n_mats == 0) throw std::runtime_error("zkm_pcs_commit: empty batch");
+  std::vector<zkm_matrix> ms;
+  std::vector<uint32_t> sh;
+  for (size_t i = 0; i < n_mats; i++) { ms.push_back(*mats[i]); if (domain_shifts) sh.push_back(domain_shifts[i]); }
+  ctx->begin_timing();
+  zkm_pcs_data* d = pcs_commit(ctx, ms, sh, (int)log_blowup);
+  ctx->mark("pcs commit");
+  ctx->end_timing(false);
+  memcpy(root_out, d->root, 32);
+  *out = d;
+  API_END
+}
+void zkm_pcs_data_free(zkm_ctx* ctx, zkm_pcs_data* d) {
+  if (!d) return;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  free_pcs_data(ctx, d);
+}
+int zkm_pcs_data_get_lde(zkm_ctx* ctx, const zkm_pcs_data* d, size_t idx, uint32_t* host) {
+  API_BEGIN
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIP_CHECK(hipSetDevice(ctx->device));
+  if (idx >= d->ldes.size()) throw std::runtime_error("matrix index out of range");
+  download_colmajor(ctx, d->ldes[idx].d, d->ldes[idx].h, d->ldes[idx].w, host);
+  API_END
+}
+int zkm_pcs_open_batch(zkm_ctx* ctx, const zkm_pcs_data* d, size_t index, uint32_t* values_out, uint32_t* proof_out) {
+  API_BEGIN
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIP_CHECK(hipSetDevice(ctx->device));
+  const Tree& t = d->tree;
+  if (index >= t.max_height) throw std::runtime_error("open_batch index out of range");
+  std::vector<const uint32_t*> src;
+  size_t nvals = 0;
+  for (auto& m : d->ldes) {
+    size_t row = index >> (t.log_max - log2_strict(m.h));
+    for (size_t c = 0; c < m.w; c++) src.push_back(m.d + c * m.h + row);
+    nvals += m.w;
+  }
+  for (int l = 0; l < t.log_max; l++)
+    for (int k = 0; k < 8; k++) src.push_back(t.node(l, (index >> l) ^ 1) + k);
+  const uint32_t** d_src = (const uint32_t**)ctx->alloc(src.size() * sizeof(void*));
+  uint32_t* d_dst = ctx->alloc_n<uint32_t>(src.size());
+  HIP_CHECK(hipMemcpyAsync(d_src, src.data(), src.size() * sizeof(void*), hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(open::gather_words, dim3(div_up(src.size(), open::THREADS)), dim3(open::THREADS), 0, ctx->stream,
+                     (const uint32_t* const*)d_src, src.size(), d_dst);
+  LAUNCH_CHECK();
+  std::vector<uint32_t> host(src.size());
+  HIP_CHECK(hipMemcpyAsync(host.data(), d_dst, src.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  memcpy(values_out, host.data(), nvals * 4);
+  memcpy(proof_out, host.data() + nvals, (size_t)t.log_max * 32);
+  ctx->release((void*)d_src);
+  ctx->release(d_dst);
+  API_END
+}
+
+int zkm_pk_setup(zkm_ctx* ctx, size_t n_prep, const zkm_matrix* const* prep_traces, const uint32_t* prep_local_only,
+                 uint32_t pc_start, const uint32_t igcs[14], uint32_t log_blowup, zkm_pk** out) {
+  API_BEGIN
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIP_CHECK(hipSetDevice(ctx->device));
+  zkm_pk* pk = new zkm_pk();
+  pk->pc_start = pc_start;
+  memcpy(pk->igcs, igcs, sizeof pk->igcs);
+  memset(pk->commit, 0, sizeof pk->commit);
+  for (size_t i = 0; i < n_prep; i++) { pk->prep.push_back(*prep_traces[i]); pk->local_only.push_back(prep_local_only[i]); }
+  if (n_prep) {
+    try { pk->data = pcs_commit(ctx, pk->prep, {}, (int)log_blowup); } catch (...) { delete pk; throw; }
+    memcpy(pk->commit, pk->data->root, 32);
+  }
+  *out = pk;
+  API_END
+}
+int zkm_pk_commitment(const zkm_pk* pk, uint32_t root_out[8]) { memcpy(root_out, pk->commit, 32); return 0; }
+int zkm_pk_observe_into(const zkm_pk* pk, zkm_challenger* c) {
+  chal::observe_slice(c, pk->commit, 8);
+  chal::observe(c, pk->pc_start);
+  chal::observe_slice(c, pk->igcs, 14);
+  chal::observe(c, 0);
+  return 0;
+}
+void zkm_pk_free(zkm_ctx* ctx, zkm_pk* pk) {
+  if (!pk) return;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  free_pcs_data(ctx, pk->data);
+  delete pk;
+}
+
+static zkm_main_data* commit_impl(zkm_ctx* ctx, size_t n_chips, const char* const* names, const zkm_matrix* const* traces,
+                                  const uint32_t* pv, size_t n_pv, uint32_t log_blowup) {
+  if (n_chips == 0) throw std::runtime_error("zkm_commit: no chips");
+  zkm_main_data* md = new zkm_main_data();
+  md->order.resize(n_chips);
+  std::iota(md->order.begin(), md->order.end(), 0);
+  // (Reverse(height), name) — prover.rs:264
+  std::sort(md->order.begin(), md->order.end(), [&](size_t a, size_t b) {
+    if (traces[a]->h != traces[b]->h) return traces[a]->h > traces[b]->h;
+    return strcmp(names[a], names[b]) < 0;
+  });
+  for (size_t i : md->order) md->traces.push_back(*traces[i]);
+  md->public_values.assign(pv, pv + n_pv);
+  try { md->data = pcs_commit(ctx, md->traces, {}, (int)log_blowup); } catch (...) { delete md; throw; }
+  return md;
+}
+
+int zkm_commit(zkm_ctx* ctx, size_t n_chips, const char* const* names, const zkm_matrix* const* main_traces,
+               const uint32_t* public_values, size_t n_pv, uint32_t log_blowup, uint32_t main_commit_out[8], uint32_t* order_out,
+               zkm_main_data** out) {
+  API_BEGIN
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIP_CHECK(hipSetDevice(ctx->device));
+  ctx->begin_timing();
+  zkm_main_data* md = commit_impl(ctx, n_chips, names, main_traces, public_values, n_pv, log_blowup);
+  ctx->mark("commit main");
+  ctx->end_timing(false);
+  memcpy(main_commit_out, md->data->root, 32);
+  if (order_out) for (size_t i = 0; i < n_chips; i++) order_out[i] = (uint32_t)md->order[i];
+  *out = md;
+  API_END
+}
+void zkm_main_data_free(zkm_ctx* ctx, zkm_main_data* d) {
+  if (!d) return;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  free_pcs_data(ctx, d->data);
+  delete d;
+}
+
+int zkm_open(zkm_ctx* ctx, const zkm_pk* pk, zkm_main_data* data, const zkm_chip_desc* chips, const zkm_fri_config* fri,
+             uint32_t num_pv_elts, zkm_challenger* challenger, uint32_t* proof_out, size_t proof_cap, size_t* proof_len) {
+  API_BEGIN
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIP_CHECK(hipSetDevice(ctx->device));
+  if (num_pv_elts > data->public_values.size()) throw std::runtime_error("num_pv_elts exceeds public_values length");
+  Writer w;
+  ctx->begin_timing();
+  open_impl(ctx, pk, data, chips, fri, num_pv_elts, challenger, w);
+  ctx->end_timing(true);
+  *proof_len = w.w.size();
+  if (w.w.size() > proof_cap) throw std::runtime_error("proof buffer too small");
+  memcpy(proof_out, w.w.data(), w.w.size() * 4);
+  API_END
+}
+
+int zkm_prove_shard(zkm_ctx* ctx, const zkm_pk* pk, size_t n_chips, const zkm_chip_desc* chips, const zkm_matrix* const* main_traces,
+                    const uint32_t* public_values, size_t n_pv, const zkm_fri_config* fri, uint32_t num_pv_elts,
+                    zkm_challenger* challenger, uint32_t* proof_out, size_t proof_cap, size_t* proof_len) {
+  API_BEGIN
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIP_CHECK(hipSetDevice(ctx->device));
+  if (num_pv_elts > n_pv) throw std::runtime_error("num_pv_elts exceeds public_values length");
+  std::vector<const char*> names;
+  for (size_t i = 0; i < n_chips; i++) names.push_back(chips[i].name);
+  ctx->begin_timing();
+  zkm_main_data* md = commit_impl(ctx, n_chips, names.data(), main_traces, public_values, n_pv, fri->log_blowup);
+  ctx->mark("commit main");
+  Writer w;
+  try {
+    open_impl(ctx, pk, md, chips, fri, num_pv_elts, challenger, w);
+  } catch (...) {
+    free_pcs_data(ctx, md->data);
+    delete md;
+    throw;
+  }
+  free_pcs_data(ctx, md->data);
+  delete md;
+  ctx->end_timing(false);
+  *proof_len = w.w.size();
+  if (w.w.size() > proof_cap) throw std::runtime_error("proof buffer too small");
+  memcpy(proof_out, w.w.data(), w.w.size() * 4);
+  API_END
+}
+
+int zkm_poseidon2_permute_batch(zkm_ctx* ctx, uint32_t* states, size_t n) {
+  API_BEGIN
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIP_CHECK(hipSetDevice(ctx->device));
+  if (n == 0) return 0;
+  uint32_t* d = ctx->alloc_n<uint32_t>(n * 16);
+  HIP_CHECK(hipMemcpyAsync(d, states, n * 64, hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(merkle::permute_batch, dim3(div_up(n, merkle::THREADS)), dim3(merkle::THREADS), 0, ctx->stream, d, n);
+  LAUNCH_CHECK();
+  HIP_CHECK(hipMemcpyAsync(states, d, n * 64, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  ctx->release(d);
+  API_END
+}
+
+int zkm_coset_lde_batch(zkm_ctx* ctx, const uint32_t* host, size_t height, size_t width, uint32_t log_blowup, uint32_t lde_shift,
+                        uint32_t* out) {
+  API_BEGIN
+  zkm_matrix* m = nullptr;
+  if (zkm_matrix_upload(ctx, host, height, width, &m) != 0) throw std::runtime_error(g_err);
+  {
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    size_t N = height << log_blowup;
+    uint32_t* l = ctx->alloc_n<uint32_t>(std::max<size_t>(N * width, 1));
+    lde_columns(ctx, m->d, height, width, (int)log_blowup, lde_shift, l);
+    download_colmajor(ctx, l, N, width, out);
+    ctx->release(l);
+  }
+  zkm_matrix_free(ctx, m);
+  API_END
+}
+
+void zkm_challenger_init(zkm_challenger* c) { memset(c, 0, sizeof *c); }
+void zkm_challenger_observe(zkm_challenger* c, const uint32_t* values, size_t n) { chal::observe_slice(c, values, n); }
+uint32_t zkm_challenger_sample(zkm_challenger* c) { return chal::sample(c); }
+uint32_t zkm_challenger_sample_bits(zkm_challenger* c, uint32_t bits) { return chal::sample_bits(c, bits); }
+
+// host-side arithmetic of the transcript layer, exposed for the CPU-only parity tests
+void zkm_host_poseidon2_permute(uint32_t state[16]) { p2::permute_host(state); }
+void zkm_host_ext_mul(const uint32_t a[4], const uint32_t b[4], uint32_t out[4]) {
+  E4 r = kb::emul(E4{{a[0], a[1], a[2], a[3]}}, E4{{b[0], b[1], b[2], b[3]}});
+  memcpy(out, r.c, 16);
+}
+void zkm_host_ext_inv(const uint32_t a[4], uint32_t out[4]) {
+  E4 r = kb::einv(E4{{a[0], a[1], a[2], a[3]}});
+  memcpy(out, r.c, 16);
+}
+uint32_t zkm_host_field_mul(uint32_t a, uint32_t b) { return kb::mul(a, b); }
+uint32_t zkm_host_field_inv(uint32_t a) { return kb::inv(a); }
+uint32_t zkm_host_two_adic_generator(uint32_t bits) { return kb::two_adic_generator((int)bits); }
+
+}  // extern "C"

@@ -1,0 +1,52 @@
+"""ctypes loader for libzkm_hip.so (the C ABI of include/zkm_hip.h)."""
+import ctypes as C
+import os
+
+from . import abi
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libzkm_hip.so")
+_LIB = None
+
+# every symbol include/zkm_hip.h declares
+EXPORTS = [
+    "zkm_last_error", "zkm_ctx_create", "zkm_ctx_destroy", "zkm_ctx_synchronize", "zkm_ctx_last_timings",
+    "zkm_matrix_upload", "zkm_matrix_download", "zkm_matrix_height", "zkm_matrix_width", "zkm_matrix_free",
+    "zkm_pcs_commit", "zkm_pcs_data_free", "zkm_pcs_data_get_lde", "zkm_pcs_open_batch",
+    "zkm_pk_setup", "zkm_pk_commitment", "zkm_pk_observe_into", "zkm_pk_free",
+    "zkm_commit", "zkm_main_data_free", "zkm_open", "zkm_prove_shard",
+    "zkm_poseidon2_permute_batch", "zkm_coset_lde_batch",
+    "zkm_challenger_init", "zkm_challenger_observe", "zkm_challenger_sample", "zkm_challenger_sample_bits",
+]
+
+
+class ZkmError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the in-tree HIP library. Fails loudly if it has not been built: there is no fallback."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise ZkmError(f"{LIB_PATH} is missing: run `python -m ziren_amd.build` (or __graft_entry__.build())")
+    L = C.CDLL(LIB_PATH)
+    L.zkm_last_error.restype = C.c_char_p
+    L.zkm_matrix_height.restype = C.c_size_t
+    L.zkm_matrix_width.restype = C.c_size_t
+    L.zkm_challenger_sample.restype = C.c_uint32
+    L.zkm_challenger_sample_bits.restype = C.c_uint32
+    L.zkm_host_field_mul.restype = C.c_uint32
+    L.zkm_host_field_inv.restype = C.c_uint32
+    L.zkm_host_two_adic_generator.restype = C.c_uint32
+    for name in ("zkm_ctx_destroy", "zkm_matrix_free", "zkm_pcs_data_free", "zkm_pk_free", "zkm_main_data_free",
+                 "zkm_challenger_init", "zkm_challenger_observe"):
+        getattr(L, name).restype = None
+    _LIB = L
+    return L
+
+
+def check(rc):
+    if rc != 0:
+        raise ZkmError(load().zkm_last_error().decode())

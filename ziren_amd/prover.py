@@ -1,0 +1,247 @@
+"""HipProver — host-side mirror of Ziren's `MachineProver` for the MI355X back-end.
+
+Mirrors the trait of crates/stark/src/prover.rs:30-184 (names, argument meaning, error
+behaviour): `setup` / `pk_to_device`, `commit(record, traces) -> ShardMainData`,
+`open(pk, data, challenger) -> ShardProof`, `prove`. In production the host is Ziren's Rust
+SDK binding the same C ABI; this Python layer exists so parity tests and the
+benchmark read like the reference's own `run_test::<P>` (crates/core/machine/src/utils/prove.rs:614).
+
+Everything numeric runs in libzkm_hip.so on the GPU; this module only marshals.
+"""
+import ctypes as C
+from dataclasses import dataclass
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+from . import abi, lib
+
+
+class DeviceMatrix:
+    """`MachineProver::DeviceMatrix`: a trace resident in HBM, column-major."""
+
+    def __init__(self, ctx: "Context", handle, height, width):
+        self.ctx, self.h, self.height, self.width = ctx, handle, height, width
+
+    def to_host(self) -> np.ndarray:
+        out = np.empty((self.height, self.width), dtype=np.uint32)
+        lib.check(lib.load().zkm_matrix_download(self.ctx.h, self.h, abi.as_u32p(out)))
+        return out
+
+    def free(self):
+        if self.h:
+            lib.load().zkm_matrix_free(self.ctx.h, self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Context:
+    """One per GPU (`zkm_ctx`)."""
+
+    def __init__(self, device: int = 0):
+        self.h = C.c_void_p()
+        lib.check(lib.load().zkm_ctx_create(C.c_int(device), C.byref(self.h)))
+        self.device = device
+
+    def upload(self, host_row_major: np.ndarray) -> DeviceMatrix:
+        m = np.ascontiguousarray(host_row_major, dtype=np.uint32)
+        h = C.c_void_p()
+        lib.check(lib.load().zkm_matrix_upload(self.h, abi.as_u32p(m), C.c_size_t(m.shape[0]), C.c_size_t(m.shape[1]),
+                                               C.byref(h)))
+        return DeviceMatrix(self, h, m.shape[0], m.shape[1])
+
+    def synchronize(self):
+        lib.check(lib.load().zkm_ctx_synchronize(self.h))
+
+    def last_timings(self):
+        names = (C.c_char_p * 64)()
+        ms = (C.c_float * 64)()
+        n = lib.load().zkm_ctx_last_timings(self.h, names, ms, 64)
+        return [(names[i].decode(), float(ms[i])) for i in range(min(n, 64))]
+
+    def close(self):
+        if self.h:
+            lib.load().zkm_ctx_destroy(self.h)
+            self.h = None
+
+
+def _handles(mats: Sequence[DeviceMatrix]):
+    arr = (C.c_void_p * len(mats))()
+    for i, m in enumerate(mats):
+        arr[i] = m.h
+    return arr
+
+
+class PcsData:
+    """`DeviceProverData` (LDEs + Merkle tree)."""
+
+    def __init__(self, ctx, handle, root, mats, log_blowup):
+        self.ctx, self.h, self.root, self.log_blowup = ctx, handle, root, log_blowup
+        self.shapes = [(m.height << log_blowup, m.width) for m in mats]
+        self._keep = list(mats)
+
+    def lde(self, idx) -> np.ndarray:
+        out = np.empty(self.shapes[idx], dtype=np.uint32)
+        lib.check(lib.load().zkm_pcs_data_get_lde(self.ctx.h, self.h, C.c_size_t(idx), abi.as_u32p(out)))
+        return out
+
+    def open_batch(self, index):
+        logmax = max(s[0] for s in self.shapes).bit_length() - 1
+        values = np.zeros(sum(s[1] for s in self.shapes), dtype=np.uint32)
+        proof = np.zeros((logmax, 8), dtype=np.uint32)
+        lib.check(lib.load().zkm_pcs_open_batch(self.ctx.h, self.h, C.c_size_t(index), abi.as_u32p(values),
+                                                abi.as_u32p(proof)))
+        return values, proof
+
+    def free(self):
+        if self.h:
+            lib.load().zkm_pcs_data_free(self.ctx.h, self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def pcs_commit(ctx: Context, mats: Sequence[DeviceMatrix], log_blowup: int, domain_shifts=None) -> PcsData:
+    """`Pcs::commit` (prover.rs:277)."""
+    root = np.zeros(8, dtype=np.uint32)
+    h = C.c_void_p()
+    sh = np.ascontiguousarray(domain_shifts, dtype=np.uint32) if domain_shifts is not None else None
+    lib.check(lib.load().zkm_pcs_commit(ctx.h, C.c_size_t(len(mats)), _handles(mats),
+                                        abi.as_u32p(sh) if sh is not None else None, C.c_uint32(log_blowup),
+                                        abi.as_u32p(root), C.byref(h)))
+    return PcsData(ctx, h, root, mats, log_blowup)
+
+
+@dataclass
+class ShardMainData:
+    """crates/stark/src/types.rs:16-35"""
+    handle: C.c_void_p
+    main_commit: np.ndarray
+    chip_ordering: List[int]
+    public_values: np.ndarray
+    traces: List[DeviceMatrix]
+
+
+class ProvingKey:
+    """`DeviceProvingKey` (StarkProvingKey, crates/stark/src/machine.rs:58-75)."""
+
+    def __init__(self, ctx, handle, prep):
+        self.ctx, self.h, self._prep = ctx, handle, prep
+
+    @property
+    def commit(self):
+        out = np.zeros(8, dtype=np.uint32)
+        lib.load().zkm_pk_commitment(self.h, abi.as_u32p(out))
+        return out
+
+    def observe_into(self, challenger: abi.Challenger):
+        lib.load().zkm_pk_observe_into(self.h, C.byref(challenger))
+
+    def free(self):
+        if self.h:
+            lib.load().zkm_pk_free(self.ctx.h, self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def new_challenger() -> abi.Challenger:
+    """`config.challenger()`"""
+    c = abi.Challenger()
+    lib.load().zkm_challenger_init(C.byref(c))
+    return c
+
+
+class HipProver:
+    """`MachineProver<KoalaBearPoseidon2, A>` over libzkm_hip.
+
+    `chips` plays the role of the `StarkMachine`: per-chip metadata + recorded constraints
+    (objects with the fields of synth.SynChip).
+    """
+
+    def __init__(self, chips, fri: abi.FriConfig, num_pv_elts: int, device: int = 0, ctx: Optional[Context] = None):
+        self.chips = list(chips)
+        self.fri = fri
+        self.num_pv_elts = num_pv_elts
+        self.ctx = ctx or Context(device)
+        self._descs, self._keep = abi.make_chip_descs(self.chips)
+
+    # fn setup / pk_to_device (prover.rs:54-66)
+    def setup(self, prep_traces: Sequence[np.ndarray], prep_local_only, pc_start, initial_global_cumulative_sum) -> ProvingKey:
+        prep = [self.ctx.upload(t) for t in prep_traces]
+        lo = np.ascontiguousarray(prep_local_only if len(prep) else [0], dtype=np.uint32)
+        ig = np.ascontiguousarray(initial_global_cumulative_sum, dtype=np.uint32)
+        h = C.c_void_p()
+        lib.check(lib.load().zkm_pk_setup(self.ctx.h, C.c_size_t(len(prep)), _handles(prep), abi.as_u32p(lo),
+                                          C.c_uint32(int(pc_start)), abi.as_u32p(ig), C.c_uint32(self.fri.log_blowup),
+                                          C.byref(h)))
+        return ProvingKey(self.ctx, h, prep)
+
+    def upload_traces(self, traces: Sequence[np.ndarray]) -> List[DeviceMatrix]:
+        return [self.ctx.upload(t) for t in traces]
+
+    # fn commit (prover.rs:258-292)
+    def commit(self, public_values: np.ndarray, traces: Sequence[DeviceMatrix]) -> ShardMainData:
+        names = (C.c_char_p * len(self.chips))(*[c.name.encode() for c in self.chips])
+        pv = np.ascontiguousarray(public_values, dtype=np.uint32)
+        root = np.zeros(8, dtype=np.uint32)
+        order = np.zeros(len(self.chips), dtype=np.uint32)
+        h = C.c_void_p()
+        lib.check(lib.load().zkm_commit(self.ctx.h, C.c_size_t(len(traces)), names, _handles(traces), abi.as_u32p(pv),
+                                        C.c_size_t(len(pv)), C.c_uint32(self.fri.log_blowup), abi.as_u32p(root),
+                                        abi.as_u32p(order), C.byref(h)))
+        return ShardMainData(h, root, [int(x) for x in order], pv, list(traces))
+
+    # fn open (prover.rs:298-653)
+    def open(self, pk: ProvingKey, data: ShardMainData, challenger: abi.Challenger, proof_cap: int = 1 << 24) -> np.ndarray:
+        out = np.zeros(proof_cap, dtype=np.uint32)
+        plen = C.c_size_t(0)
+        try:
+            lib.check(lib.load().zkm_open(self.ctx.h, pk.h, data.handle, self._descs, C.byref(self.fri),
+                                          C.c_uint32(self.num_pv_elts), C.byref(challenger), abi.as_u32p(out),
+                                          C.c_size_t(proof_cap), C.byref(plen)))
+        finally:
+            lib.load().zkm_main_data_free(self.ctx.h, data.handle)  # `open` consumes ShardMainData
+            data.handle = None
+        return out[:plen.value].copy()
+
+    # commit + open on device-resident traces
+    def prove_shard(self, pk: ProvingKey, public_values: np.ndarray, traces: Sequence[DeviceMatrix],
+                    challenger: abi.Challenger, proof_cap: int = 1 << 24, out: Optional[np.ndarray] = None) -> np.ndarray:
+        pv = np.ascontiguousarray(public_values, dtype=np.uint32)
+        if out is None:
+            out = np.zeros(proof_cap, dtype=np.uint32)
+        plen = C.c_size_t(0)
+        lib.check(lib.load().zkm_prove_shard(self.ctx.h, pk.h, C.c_size_t(len(traces)), self._descs, _handles(traces),
+                                             abi.as_u32p(pv), C.c_size_t(len(pv)), C.byref(self.fri),
+                                             C.c_uint32(self.num_pv_elts), C.byref(challenger), abi.as_u32p(out),
+                                             C.c_size_t(len(out)), C.byref(plen)))
+        return out[:plen.value]
+
+
+# fine-grained entry points ------------------------------------------------------------------
+def poseidon2_permute_batch(ctx: Context, states: np.ndarray) -> np.ndarray:
+    s = np.ascontiguousarray(states, dtype=np.uint32).copy()
+    lib.check(lib.load().zkm_poseidon2_permute_batch(ctx.h, abi.as_u32p(s), C.c_size_t(s.shape[0])))
+    return s
+
+
+def coset_lde_batch(ctx: Context, mat: np.ndarray, log_blowup: int, lde_shift: int) -> np.ndarray:
+    m = np.ascontiguousarray(mat, dtype=np.uint32)
+    out = np.empty((m.shape[0] << log_blowup, m.shape[1]), dtype=np.uint32)
+    lib.check(lib.load().zkm_coset_lde_batch(ctx.h, abi.as_u32p(m), C.c_size_t(m.shape[0]), C.c_size_t(m.shape[1]),
+                                             C.c_uint32(log_blowup), C.c_uint32(int(lde_shift)), abi.as_u32p(out)))
+    return out
