@@ -1,0 +1,161 @@
+#!/usr/bin/env python3
+"""Benchmark of the shard-prover hot path (BASELINE.json metric: shard-proofs/sec, 2^22-row trace).
+
+A "step" is one full shard proof — MachineProver::commit + open (crates/stark/src/prover.rs:258-653) —
+of a SYN-k shard (a Cpu-like chip at 2^k rows plus seven smaller chips, core FRI
+parameters: blowup 2, 84 queries, 16 PoW bits) whose traces are already resident in HBM.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--log-rows 22]
+
+N > 1 is launched by the driver through torch.distributed.run, one process per GPU; shards are
+independent (prove.rs:492-497), so every rank proves its own shards and there is no data-path
+collective: scaling is weak, value = shards proven by all ranks / max-over-ranks time.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+
+from ziren_amd import abi, lib, prover, synth
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def cpu_baseline(log_rows_sample, fri):
+    """Time the CPU restatement (oracle, kind 'port') on a bounded sample of the same workload."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    sh = synth.syn_shard(log_rows_sample)
+    pk = O.Pk([], [], sh.pc_start, sh.initial_global_cumulative_sum, fri.log_blowup)
+    ch = O.new_challenger()
+    pk.observe_into(ch)
+    t0 = time.time()
+    _, (t_commit, t_open) = O.prove_shard(pk, sh.chips, [c.trace for c in sh.chips], sh.public_values, fri,
+                                          synth.NUM_PV_ELTS, ch)
+    wall = time.time() - t0
+    return wall, O.lib().orc_num_threads()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--log-rows", type=int, default=22)
+    ap.add_argument("--cpu-sample-log-rows", type=int, default=16)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist_mod
+        torch.cuda.set_device(local_rank)
+        dist_mod.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        dist = dist_mod
+
+    fri = abi.FriConfig(1, 84, 16)  # core config, crates/stark/src/kb31_poseidon2.rs:203-213
+    k = args.log_rows
+    shard = synth.syn_shard(k, seed=0x5A4B4D00 + 1000 * rank)
+    hp = prover.HipProver(shard.chips, fri, synth.NUM_PV_ELTS, device=local_rank)
+    pk = hp.setup([], [], shard.pc_start, shard.initial_global_cumulative_sum)
+    base_ch = prover.new_challenger()
+    pk.observe_into(base_ch)
+    traces = hp.upload_traces([c.trace for c in shard.chips])  # inputs resident in HBM before timing
+    for c in shard.chips:
+        c.trace = None
+    out = np.zeros(1 << 22, dtype=np.uint32)
+
+    def barrier():
+        hp.ctx.synchronize()
+        if dist is not None:
+            import torch
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    def step():
+        ch = base_ch.copy()  # challenger cloned per shard (prove.rs:496)
+        return hp.prove_shard(pk, shard.public_values, traces, ch, out=out)
+
+    for _ in range(args.warmup):
+        step()
+    phase_acc = {}
+    kern_acc = {}
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        for name, ms in hp.ctx.last_timings():
+            phase_acc[name] = phase_acc.get(name, 0.0) + ms
+        for name, ms, calls, nbytes in hp.ctx.kernel_timings():
+            a = kern_acc.setdefault(name, [0.0, 0, 0.0])
+            a[0] += ms
+            a[1] += calls
+            a[2] += nbytes
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        steps = args.steps
+        ms_per_step = elapsed / steps * 1e3
+        value = world * steps / elapsed
+        alg_bytes = synth.shard_algorithmic_bytes(shard)
+        # dominant kernel by accumulated HIP-event time on the prover's stream
+        roofline = None
+        if kern_acc:
+            dom = max(kern_acc.items(), key=lambda kv: kv[1][0])
+            name, (ms, calls, nbytes) = dom
+            per_launch_ms = ms / max(calls, 1)
+            kbytes = nbytes / max(calls, 1)
+            achieved = kbytes / (per_launch_ms * 1e-3) / 1e9 if per_launch_ms > 0 else 0.0
+            roofline = {"bound": "hbm", "kernel": name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
+                        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                        "launches_per_step": calls // steps, "avg_launch_ms": round(per_launch_ms, 4),
+                        "algorithmic_bytes_per_launch": int(kbytes),
+                        "kernel_share_of_step": round(ms / steps / ms_per_step, 3),
+                        "whole_shard": {"algorithmic_bytes": alg_bytes,
+                                        "achieved": round(alg_bytes / (ms_per_step * 1e-3) / 1e9, 1),
+                                        "frac": round(alg_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}}
+        cpu = None
+        if not args.no_cpu_baseline:
+            ks = min(args.cpu_sample_log_rows, k)
+            wall, threads = cpu_baseline(ks, fri)
+            scale = 1 << (k - ks)
+            cpu = {"value": round(1.0 / (wall * scale), 6), "unit": "shard-proofs/s", "cores": threads, "kind": "port",
+                   "sample": f"oracle (CPU restatement, OpenMP) proving one SYN-{ks} shard in {wall:.2f} s; "
+                             f"extrapolated linearly in rows (x{scale}) to SYN-{k}",
+                   "sample_seconds": round(wall, 3)}
+        line = {"metric": "shard-proofs/sec", "value": round(value, 4), "unit": "shard-proofs/s", "n_gpus": world,
+                "steps": steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
+                "scaling": "weak", "vs_baseline": None, "dtype": "u32 (KoalaBear, Montgomery) / 4xu32 extension",
+                "data": "synthetic",
+                "config": {"workload": f"SYN-{k}: full shard proof (commit+open), Cpu-like chip 2^{k} rows x 67 main "
+                                       f"cols + 7 smaller chips, blowup 2, 84 queries, 16 PoW bits",
+                           "log_rows": k, "parallelism": f"{world} independent shards (one per GPU)"},
+                "phases_ms": {n: round(v / steps, 3) for n, v in phase_acc.items()},
+                "kernels_ms": {n: {"ms": round(v[0] / steps, 3), "launches": v[1] // steps,
+                                   "GBps": round(v[2] / max(v[0], 1e-9) / 1e6, 1)} for n, v in
+                               sorted(kern_acc.items(), key=lambda kv: -kv[1][0])},
+                "roofline": roofline, "cpu_baseline": cpu}
+        print(json.dumps(line))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

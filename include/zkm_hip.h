@@ -135,6 +135,10 @@ int zkm_ctx_synchronize(zkm_ctx* ctx);
 /* per-phase GPU time of the last zkm_commit/zkm_open on this context, in milliseconds (HIP
  * events on the context's stream). names/values arrays of capacity cap; returns the count. */
 int zkm_ctx_last_timings(zkm_ctx* ctx, const char** names, float* ms, int cap);
+/* per-kernel totals of the same call: HIP-event time on the context's stream, launch count and
+ * compulsory HBM bytes (each input/output array of a launch counted once). Returns the count. */
+int zkm_ctx_kernel_timings(zkm_ctx* ctx, const char** names, float* ms, uint32_t* calls, double* bytes, int cap);
+void zkm_ctx_set_kernel_timing(zkm_ctx* ctx, int enabled);
 
 /* ---- DeviceMatrix ----------------------------------------------------------------------- */
 /* Upload a row-major host matrix (height a power of two) and lay it out column-major in HBM. */

@@ -1,0 +1,113 @@
+"""CPU-only: the oracle's prover and verifier (restated from the reference) agree with each other,
+reject corrupted inputs, and satisfy independent big-integer checks of the LDE semantics."""
+import numpy as np
+import pytest
+
+from ziren_amd import abi, synth, field as F
+
+
+def _horner(coeffs, x):
+    acc = 0
+    for c in reversed(coeffs):
+        acc = (acc * x + c) % F.P
+    return acc
+
+
+def test_lde_is_interpolant_on_shifted_coset(oracle):
+    # L[bitrev(j)] = P(3 * w_2n^j) with P(w_n^i) = trace[i]; checked by naive interpolation
+    k, bl = 4, 1
+    n = 1 << k
+    rng = np.random.default_rng(5)
+    col = rng.integers(0, F.P, n, dtype=np.uint64)
+    w = F.two_adic_generator(k)
+    # naive inverse DFT with python ints
+    ninv = F.inv(n)
+    coeffs = [sum(int(col[i]) * pow(w, -i * j % n, F.P) for i in range(n)) * ninv % F.P for j in range(n)]
+    lde = oracle.coset_lde_batch(F.to_monty(col).reshape(n, 1), bl, F.to_monty(3))
+    lde = F.from_monty(lde[:, 0])
+    N = n << bl
+    wN = F.two_adic_generator(k + bl)
+    for j in range(N):
+        r = int(format(j, f"0{k + bl}b")[::-1], 2)
+        assert int(lde[r]) == _horner(coeffs, 3 * pow(wN, j, F.P) % F.P)
+    # first n bit-reversed rows = values on 3H
+    for i in range(n):
+        r = int(format(i, f"0{k}b")[::-1], 2)
+        assert int(lde[r]) == _horner(coeffs, 3 * pow(w, i, F.P) % F.P)
+
+
+def test_mmcs_mixed_heights_open_verify(oracle):
+    # the reference's `size_gaps` case (crates/recursion/circuit/src/fri.rs:580-624), power-of-two heights
+    rng = np.random.default_rng(11)
+    shapes = [(1024, 8)] * 4 + [(64, 8)] * 5 + [(8, 8)] * 6
+    mats = [rng.integers(0, F.P, s, dtype=np.uint64).astype(np.uint32) for s in shapes]
+    for idx in (0, 6, 2047):
+        vals, proof, ok = oracle.pcs_open_batch(mats, 1, idx)
+        assert ok
+
+
+def _prove(oracle, k, with_prep, fri):
+    sh = synth.syn_shard(k, with_prep=with_prep)
+    prep = [c.prep_trace for c in sh.chips if c.prep_width]
+    pk = oracle.Pk(prep, [0] * len(prep), sh.pc_start, sh.initial_global_cumulative_sum, 1)
+    ch = oracle.new_challenger()
+    pk.observe_into(ch)
+    vch = ch.copy()
+    proof, _ = oracle.prove_shard(pk, sh.chips, [c.trace for c in sh.chips], sh.public_values, fri, synth.NUM_PV_ELTS, ch)
+    return sh, pk, ch, vch, proof
+
+
+@pytest.mark.parametrize("k,with_prep", [(5, False), (8, True)])
+def test_prove_then_verify(oracle, k, with_prep):
+    fri = abi.FriConfig(1, 12, 8)
+    sh, pk, ch, vch, proof = _prove(oracle, k, with_prep, fri)
+    assert oracle.verify_shard(pk, sh.chips, fri, synth.NUM_PV_ELTS, vch, proof) == 0
+    assert ch.as_tuple() == vch.as_tuple()  # prover and verifier transcripts end in the same state
+
+
+def test_verifier_rejects_corruption(oracle):
+    fri = abi.FriConfig(1, 12, 8)
+    sh, pk, ch, vch, proof = _prove(oracle, 6, True, fri)
+    base = vch.copy()
+    # wrong public value (reference: stark_testing.rs:150-180 panics on a wrong public value)
+    npv_at = len(proof) - len(sh.public_values)
+    bad = proof.copy()
+    bad[npv_at] = F.to_monty((F.from_monty(int(bad[npv_at])) + 1) % F.P)
+    assert oracle.verify_shard(pk, sh.chips, fri, synth.NUM_PV_ELTS, base.copy(), bad) != 0
+    # one opened value
+    bad = proof.copy()
+    bad[40] = F.to_monty((F.from_monty(int(bad[40])) + 1) % F.P)
+    assert oracle.verify_shard(pk, sh.chips, fri, synth.NUM_PV_ELTS, base.copy(), bad) != 0
+    # commitment
+    bad = proof.copy()
+    bad[3] = F.to_monty((F.from_monty(int(bad[3])) + 1) % F.P)
+    assert oracle.verify_shard(pk, sh.chips, fri, synth.NUM_PV_ELTS, base.copy(), bad) != 0
+    # a trace cell that breaks an arithmetic constraint
+    traces = [c.trace.copy() for c in sh.chips]
+    traces[0][5, sh.chips[0].main_width - 3] ^= 1
+    ch2 = oracle.new_challenger()
+    pk.observe_into(ch2)
+    v2 = ch2.copy()
+    p2, _ = oracle.prove_shard(pk, sh.chips, traces, sh.public_values, fri, synth.NUM_PV_ELTS, ch2)
+    assert oracle.verify_shard(pk, sh.chips, fri, synth.NUM_PV_ELTS, v2, p2) != 0
+
+
+def test_chip_ordering_rule(oracle):
+    # (Reverse(height), name): crates/stark/src/prover.rs:264
+    fri = abi.FriConfig(1, 4, 4)
+    sh, pk, ch, vch, proof = _prove(oracle, 8, False, fri)
+    nchips = int(proof[24])
+    assert nchips == len(sh.chips)
+    # walk the stream to pull (caller_index, log_degree)
+    pos, order = 25, []
+    for _ in range(nchips):
+        idx, logd = int(proof[pos]), int(proof[pos + 1]); pos += 2
+        pw = int(proof[pos]); pos += 1 + 8 * pw
+        mw = int(proof[pos]); pos += 1 + 8 * mw
+        ew = int(proof[pos]); pos += 1 + 8 * ew
+        nq = int(proof[pos]); pos += 1 + 16 * nq
+        pos += 14 + 4
+        order.append((idx, logd))
+    expect = sorted(range(nchips), key=lambda i: (-sh.chips[i].log_height, sh.chips[i].name))
+    assert [o[0] for o in order] == expect
+    assert [o[1] for o in order] == [sh.chips[i].log_height for i in expect]

@@ -40,6 +40,15 @@ static thread_local std::string g_err;
                                std::to_string(__LINE__) + ")");                                  \
   } while (0)
 #define LAUNCH_CHECK() HIP_CHECK(hipGetLastError())
+// launch on the context's stream, bracketed by HIP events; `bytes` = compulsory HBM bytes of this
+// launch (each input and output array counted once) for the roofline report.
+#define KLAUNCH(ctx, name, bytes, kernel, grid, block, lds, ...)                       \
+  do {                                                                                  \
+    (ctx)->kbegin(name, (double)(bytes));                                               \
+    hipLaunchKernelGGL(kernel, grid, block, lds, (ctx)->stream, __VA_ARGS__);           \
+    LAUNCH_CHECK();                                                                     \
+    (ctx)->kend();                                                                      \
+  } while (0)
 
 static inline int log2_strict(size_t n) {
   int k = 0;
@@ -94,6 +103,29 @@ struct zkm_ctx {
   std::vector<hipEvent_t> event_pool;
   std::vector<std::string> timing_names;
   std::vector<float> timing_ms;
+  // per-kernel HIP-event timing on this stream (bench.py's roofline leg reads it)
+  struct KRec { const char* name; double bytes; hipEvent_t start, stop; };
+  struct KStat { double ms = 0, bytes = 0; uint32_t calls = 0; };
+  std::vector<KRec> krecs;
+  std::map<std::string, KStat> kstats;
+  bool kernel_timing = true;
+  hipEvent_t get_event() {
+    hipEvent_t e;
+    if (!event_pool.empty()) { e = event_pool.back(); event_pool.pop_back(); }
+    else HIP_CHECK(hipEventCreate(&e));
+    return e;
+  }
+  void kbegin(const char* name, double bytes) {
+    if (!kernel_timing) return;
+    KRec r{name, bytes, get_event(), nullptr};
+    HIP_CHECK(hipEventRecord(r.start, stream));
+    krecs.push_back(r);
+  }
+  void kend() {
+    if (!kernel_timing) return;
+    krecs.back().stop = get_event();
+    HIP_CHECK(hipEventRecord(krecs.back().stop, stream));
+  }
 
   void* alloc(size_t bytes) {
     if (bytes == 0) bytes = 4;
@@ -120,20 +152,26 @@ struct zkm_ctx {
     live.erase(it);
   }
   void mark(const char* name) {
-    hipEvent_t e;
-    if (!event_pool.empty()) { e = event_pool.back(); event_pool.pop_back(); }
-    else HIP_CHECK(hipEventCreate(&e));
+    hipEvent_t e = get_event();
     HIP_CHECK(hipEventRecord(e, stream));
     marks.push_back({name, e});
   }
   void begin_timing() {
     for (auto& m : marks) event_pool.push_back(m.second);
     marks.clear();
+    for (auto& r : krecs) { event_pool.push_back(r.start); if (r.stop) event_pool.push_back(r.stop); }
+    krecs.clear();
     mark("begin");
   }
   void end_timing(bool append) {
     HIP_CHECK(hipStreamSynchronize(stream));
-    if (!append) { timing_names.clear(); timing_ms.clear(); }
+    if (!append) { timing_names.clear(); timing_ms.clear(); kstats.clear(); }
+    for (auto& r : krecs) {
+      float ms = 0;
+      if (r.stop) HIP_CHECK(hipEventElapsedTime(&ms, r.start, r.stop));
+      KStat& k = kstats[r.name];
+      k.ms += ms; k.bytes += r.bytes; k.calls++;
+    }
     for (size_t i = 1; i < marks.size(); i++) {
       float ms = 0;
       HIP_CHECK(hipEventElapsedTime(&ms, marks[i - 1].second, marks[i].second));
@@ -212,9 +250,8 @@ static void lde_columns(zkm_ctx* ctx, const uint32_t* in, size_t n, size_t w, in
   const uint32_t* twf = lb > 0 ? ctx->twiddles(lb, false) : nullptr;
   const uint32_t* twi = lb > 0 ? ctx->twiddles(lb, true) : nullptr;
   if (la == 0) {
-    hipLaunchKernelGGL(lde::lde_rows, dim3(1, (unsigned)w), dim3(lde::THREADS), rows_lds, ctx->stream, in, out, 0, lb, n, N,
-                       (size_t)0, bl, lde_shift, w_n, w_n_inv, w_N, n_inv, twf, twi);
-    LAUNCH_CHECK();
+    KLAUNCH(ctx, "lde_rows", 4.0 * n * w + 4.0 * N * w, lde::lde_rows, dim3(1, (unsigned)w), dim3(lde::THREADS), rows_lds, in, out, 0,
+            lb, n, N, (size_t)0, bl, lde_shift, w_n, w_n_inv, w_N, n_inv, twf, twi);
     return;
   }
   size_t A = (size_t)1 << la;
@@ -223,15 +260,14 @@ static void lde_columns(zkm_ctx* ctx, const uint32_t* in, size_t n, size_t w, in
   size_t cols_lds = A * T * 4;
   uint32_t* tmp1 = ctx->alloc_n<uint32_t>(n * w);
   uint32_t* tmp2 = ctx->alloc_n<uint32_t>((n * w) << bl);
-  hipLaunchKernelGGL(lde::lde_cols<false>, dim3((unsigned)(B / T), (unsigned)w, 1), dim3(lde::THREADS), cols_lds, ctx->stream, in,
-                     tmp1, la, lb, logT, n, (size_t)0, n, bl, ctx->twiddles(la, true));
-  LAUNCH_CHECK();
-  hipLaunchKernelGGL(lde::lde_rows, dim3((unsigned)A, (unsigned)w), dim3(lde::THREADS), rows_lds, ctx->stream, tmp1, tmp2, la, lb,
-                     n, n, n * w, bl, lde_shift, w_n, w_n_inv, w_N, n_inv, twf, twi);
-  LAUNCH_CHECK();
-  hipLaunchKernelGGL(lde::lde_cols<true>, dim3((unsigned)(B / T), (unsigned)w, 1u << bl), dim3(lde::THREADS), cols_lds,
-                     ctx->stream, tmp2, out, la, lb, logT, n, n * w, N, bl, ctx->twiddles(la, false));
-  LAUNCH_CHECK();
+  const uint32_t* twa_inv = ctx->twiddles(la, true);
+  const uint32_t* twa_fwd = ctx->twiddles(la, false);
+  KLAUNCH(ctx, "lde_cols_inverse", 8.0 * n * w, lde::lde_cols<false>, dim3((unsigned)(B / T), (unsigned)w, 1), dim3(lde::THREADS),
+          cols_lds, in, tmp1, la, lb, logT, n, (size_t)0, n, bl, twa_inv);
+  KLAUNCH(ctx, "lde_rows", 4.0 * n * w + 4.0 * N * w, lde::lde_rows, dim3((unsigned)A, (unsigned)w), dim3(lde::THREADS), rows_lds,
+          (const uint32_t*)tmp1, tmp2, la, lb, n, n, n * w, bl, lde_shift, w_n, w_n_inv, w_N, n_inv, twf, twi);
+  KLAUNCH(ctx, "lde_cols_forward", 8.0 * N * w, lde::lde_cols<true>, dim3((unsigned)(B / T), (unsigned)w, 1u << bl),
+          dim3(lde::THREADS), cols_lds, (const uint32_t*)tmp2, out, la, lb, logT, n, n * w, N, bl, twa_fwd);
   ctx->release(tmp1);
   ctx->release(tmp2);
 }
@@ -268,18 +304,17 @@ static void build_tree(zkm_ctx* ctx, const std::vector<zkm_matrix>& mats, Tree& 
     auto ptrs = cols_of_height(maxh);
     const uint32_t** d = upload_ptrs(ctx, ptrs);
     to_free.push_back(d);
-    hipLaunchKernelGGL(merkle::hash_leaves, dim3(div_up(maxh, merkle::THREADS)), dim3(merkle::THREADS), 0, ctx->stream, d,
-                       (int)ptrs.size(), maxh, t.digests);
-    LAUNCH_CHECK();
+    KLAUNCH(ctx, "hash_leaves", 4.0 * maxh * ptrs.size() + 32.0 * maxh, merkle::hash_leaves, dim3(div_up(maxh, merkle::THREADS)),
+            dim3(merkle::THREADS), 0, d, (int)ptrs.size(), maxh, t.digests);
   }
   int layer = 0;
   for (size_t len = maxh / 2; len >= 1; len >>= 1, layer++) {
     auto ptrs = cols_of_height(len);
     const uint32_t** d = nullptr;
     if (!ptrs.empty()) { d = upload_ptrs(ctx, ptrs); to_free.push_back(d); }
-    hipLaunchKernelGGL(merkle::compress_layer, dim3(div_up(len, merkle::THREADS)), dim3(merkle::THREADS), 0, ctx->stream,
-                       t.digests + t.layer_off[layer] * 8, t.digests + t.layer_off[layer + 1] * 8, len, d, (int)ptrs.size());
-    LAUNCH_CHECK();
+    KLAUNCH(ctx, "compress_layer", 96.0 * len + 4.0 * len * ptrs.size(), merkle::compress_layer, dim3(div_up(len, merkle::THREADS)),
+            dim3(merkle::THREADS), 0, (const uint32_t*)(t.digests + t.layer_off[layer] * 8), t.digests + t.layer_off[layer + 1] * 8,
+            len, (const uint32_t* const*)d, (int)ptrs.size());
     if (len == 1) break;
   }
   for (auto d : to_free) ctx->release((void*)d);
@@ -424,22 +459,20 @@ static void open_impl(zkm_ctx* ctx, const zkm_pk* pk, zkm_main_data* md, const z
         d_blobs[i] = (uint32_t*)salloc(c.desc->lookups_len * 4);
         HIP_CHECK(hipMemcpyAsync(d_blobs[i], c.desc->lookups, c.desc->lookups_len * 4, hipMemcpyHostToDevice, st));
         const uint32_t* prep = c.desc->prep_index >= 0 ? pk->prep[c.desc->prep_index].d : nullptr;
-        hipLaunchKernelGGL(stark::perm_rows, dim3(div_up(c.n, stark::THREADS)), dim3(stark::THREADS), 0, st, d_blobs[i], c.n_lookups,
-                           c.n_sends, 1 << c.desc->log_quotient_degree, md->traces[i].d, prep, c.n, perm_ch[0], d_bp, pt.d,
-                           c.perm_ext_w);
-        LAUNCH_CHECK();
+        KLAUNCH(ctx, "perm_rows", 4.0 * c.n * (c.desc->main_width + c.desc->prep_width + pt.w), stark::perm_rows,
+                dim3(div_up(c.n, stark::THREADS)), dim3(stark::THREADS), 0, (const uint32_t*)d_blobs[i], c.n_lookups, c.n_sends,
+                1 << c.desc->log_quotient_degree, (const uint32_t*)md->traces[i].d, prep, c.n, perm_ch[0], (const E4*)d_bp, pt.d,
+                c.perm_ext_w);
         // inclusive scan of the last ext column (4 base columns)
         uint32_t* last = pt.d + (size_t)(c.perm_ext_w - 1) * 4 * c.n;
         size_t nchunks = (c.n + stark::SCAN_BLOCK - 1) / stark::SCAN_BLOCK;
         uint32_t* totals = (uint32_t*)salloc(nchunks * 4 * 4);
-        hipLaunchKernelGGL(stark::scan_chunks, dim3((unsigned)nchunks, 4), dim3(stark::THREADS), 0, st, last, c.n, totals, nchunks);
-        LAUNCH_CHECK();
+        KLAUNCH(ctx, "scan", 32.0 * c.n, stark::scan_chunks, dim3((unsigned)nchunks, 4), dim3(stark::THREADS), 0, last, c.n, totals,
+                nchunks);
         if (nchunks > 1) {
-          hipLaunchKernelGGL(stark::scan_totals, dim3(4), dim3(stark::THREADS), 0, st, totals, nchunks);
-          LAUNCH_CHECK();
-          hipLaunchKernelGGL(stark::scan_add_offsets, dim3((unsigned)nchunks, 4), dim3(stark::THREADS), 0, st, last, c.n,
-                             (const uint32_t*)totals, nchunks);
-          LAUNCH_CHECK();
+          KLAUNCH(ctx, "scan", 0.0, stark::scan_totals, dim3(4), dim3(stark::THREADS), 0, totals, nchunks);
+          KLAUNCH(ctx, "scan", 32.0 * c.n, stark::scan_add_offsets, dim3((unsigned)nchunks, 4), dim3(stark::THREADS), 0, last, c.n,
+                  (const uint32_t*)totals, nchunks);
         }
         for (int e = 0; e < 4; e++)
           HIP_CHECK(hipMemcpyAsync(&local_sums[i].c[e], last + (size_t)e * c.n + (c.n - 1), 4, hipMemcpyDeviceToHost, st));
@@ -517,8 +550,8 @@ static void open_impl(zkm_ctx* ctx, const zkm_pk* pk, zkm_main_data* md, const z
     while ((size_t)a.n_regs * 16 * bd > 160 * 1024 && bd > 64) bd >>= 1;
     size_t lds = (size_t)a.n_regs * 16 * bd;
     if (lds > 160 * 1024) throw std::runtime_error(std::string("constraint program of chip ") + d->name + " needs too many registers");
-    hipLaunchKernelGGL(stark::quotient_kernel, dim3(div_up(Q, bd)), dim3(bd), lds, st, a);
-    LAUNCH_CHECK();
+    KLAUNCH(ctx, "quotient", 4.0 * Q * (d->main_width + d->prep_width + 4.0 * c.perm_ext_w) + 16.0 * Q, stark::quotient_kernel,
+            dim3(div_up(Q, bd)), dim3(bd), lds, a);
     uint32_t wqp = kb::ONE;
     for (size_t k = 0; k < nchunks; k++) {
       zkm_matrix m; m.h = c.n; m.w = 4; m.d = qbuf + k * 4 * c.n; m.owned = (k == 0);
@@ -572,16 +605,14 @@ static void open_impl(zkm_ctx* ctx, const zkm_pk* pk, zkm_main_data* md, const z
           E4 u = kb::escale(zeta, kb::inv(m.shift));
           E4 c = kb::escale(kb::esub_base(host_pow2k(u, ln), kb::ONE), kb::inv(kb::to_monty((uint32_t)(m.n % kb::P))));
           wts = (E4*)salloc(m.n * sizeof(E4));
-          hipLaunchKernelGGL(open::bary_weights, dim3(div_up(m.n, open::THREADS)), dim3(open::THREADS), 0, st, u, c,
-                             kb::two_adic_generator(ln), m.n, wts);
-          LAUNCH_CHECK();
+          KLAUNCH(ctx, "bary_weights", 16.0 * m.n, open::bary_weights, dim3(div_up(m.n, open::THREADS)), dim3(open::THREADS), 0, u, c,
+                  kb::two_adic_generator(ln), m.n, wts);
           wcache[key] = wts;
         } else wts = it->second;
         unsigned split = (unsigned)std::min<size_t>(SPLIT, std::max<size_t>(1, m.n / open::THREADS));
         E4* partials = (E4*)salloc((size_t)split * m.width * 2 * sizeof(E4));
-        hipLaunchKernelGGL(open::eval_columns, dim3(div_up(m.width, open::EVAL_COLS), split), dim3(open::THREADS), 0, st, m.evals,
-                           m.n, (int)m.width, (const E4*)wts, m.n_points > 1 ? 1 : 0, partials);
-        LAUNCH_CHECK();
+        KLAUNCH(ctx, "eval_columns", 4.0 * m.n * m.width + 16.0 * m.n, open::eval_columns, dim3(div_up(m.width, open::EVAL_COLS), split),
+                dim3(open::THREADS), 0, m.evals, m.n, (int)m.width, (const E4*)wts, m.n_points > 1 ? 1 : 0, partials);
         std::vector<E4> hp((size_t)split * m.width * 2);
         HIP_CHECK(hipMemcpyAsync(hp.data(), partials, hp.size() * sizeof(E4), hipMemcpyDeviceToHost, st));
         HIP_CHECK(hipStreamSynchronize(st));
@@ -631,10 +662,11 @@ static void open_impl(zkm_ctx* ctx, const zkm_pk* pk, zkm_main_data* md, const z
       HIP_CHECK(hipMemcpyAsync(d_rm, per_h[lh].data(), per_h[lh].size() * sizeof(open::ReduceMat), hipMemcpyHostToDevice, st));
       HIP_CHECK(hipStreamSynchronize(st));  // per_h storage is pageable host memory
       E4 z1 = kb::escale(zeta, kb::two_adic_generator(lh - bl));
-      hipLaunchKernelGGL(open::reduce_openings, dim3(div_up(N, open::THREADS)), dim3(open::THREADS), 0, st,
-                         (const open::ReduceMat*)d_rm, (int)per_h[lh].size(), lh, (const E4*)d_fap, zeta, z1,
-                         kb::two_adic_generator(lh), ro[lh], 0);
-      LAUNCH_CHECK();
+      double rbytes = 16.0 * N;
+      for (auto& rm : per_h[lh]) rbytes += 4.0 * N * rm.width;
+      KLAUNCH(ctx, "reduce_openings", rbytes, open::reduce_openings, dim3(div_up(N, open::THREADS)), dim3(open::THREADS), 0,
+              (const open::ReduceMat*)d_rm, (int)per_h[lh].size(), lh, (const E4*)d_fap, zeta, z1, kb::two_adic_generator(lh), ro[lh],
+              0);
     }
   }
   ctx->mark("open: reduced openings");
@@ -652,15 +684,13 @@ static void open_impl(zkm_ctx* ctx, const zkm_pk* pk, zkm_main_data* md, const z
     size_t off = 0;
     for (size_t l = half; l >= 1; l >>= 1) { t.layer_off.push_back(off); off += l; if (l == 1) break; }
     t.digests = (uint32_t*)salloc(off * 8 * 4);
-    hipLaunchKernelGGL(merkle::hash_fri_leaves, dim3(div_up(half, merkle::THREADS)), dim3(merkle::THREADS), 0, st, (const E4*)f, half,
-                       t.digests);
-    LAUNCH_CHECK();
+    KLAUNCH(ctx, "hash_fri_leaves", 64.0 * half, merkle::hash_fri_leaves, dim3(div_up(half, merkle::THREADS)), dim3(merkle::THREADS), 0,
+            (const E4*)f, half, t.digests);
     int layer = 0;
     for (size_t l = half / 2; l >= 1; l >>= 1, layer++) {
-      hipLaunchKernelGGL(merkle::compress_layer, dim3(div_up(l, merkle::THREADS)), dim3(merkle::THREADS), 0, st,
-                         (const uint32_t*)(t.digests + t.layer_off[layer] * 8), t.digests + t.layer_off[layer + 1] * 8, l,
-                         (const uint32_t* const*)nullptr, 0);
-      LAUNCH_CHECK();
+      KLAUNCH(ctx, "compress_layer", 96.0 * l, merkle::compress_layer, dim3(div_up(l, merkle::THREADS)), dim3(merkle::THREADS), 0,
+              (const uint32_t*)(t.digests + t.layer_off[layer] * 8), t.digests + t.layer_off[layer + 1] * 8, l,
+              (const uint32_t* const*)nullptr, 0);
       if (l == 1) break;
     }
     std::array<uint32_t, 8> root;
@@ -670,10 +700,9 @@ static void open_impl(zkm_ctx* ctx, const zkm_pk* pk, zkm_main_data* md, const z
     commits.push_back(root);
     E4 beta = chal::sample_ext(ch);
     E4* g = (E4*)salloc(half * sizeof(E4));
-    hipLaunchKernelGGL(open::fri_fold, dim3(div_up(half, open::THREADS)), dim3(open::THREADS), 0, st, (const E4*)f, lf, beta,
-                       kb::esqr(beta), kb::two_adic_generator(lf), kb::inv(kb::two_adic_generator(lf)), neg_half,
-                       (const E4*)ro[lf - 1], g);
-    LAUNCH_CHECK();
+    KLAUNCH(ctx, "fri_fold", 48.0 * half + (ro[lf - 1] ? 16.0 * half : 0.0), open::fri_fold, dim3(div_up(half, open::THREADS)),
+            dim3(open::THREADS), 0, (const E4*)f, lf, beta, kb::esqr(beta), kb::two_adic_generator(lf),
+            kb::inv(kb::two_adic_generator(lf)), neg_half, (const E4*)ro[lf - 1], g);
     layers.push_back(f);
     ftrees.push_back(t);
     f = g;
@@ -701,9 +730,8 @@ static void open_impl(zkm_ctx* ctx, const zkm_pk* pk, zkm_main_data* md, const z
       unsigned int init = 0xffffffffu;
       HIP_CHECK(hipMemcpyAsync(d_best, &init, 4, hipMemcpyHostToDevice, st));
       uint32_t total = std::min<uint64_t>(BATCH, (uint64_t)kb::P - base);
-      hipLaunchKernelGGL(merkle::grind, dim3(div_up(total, merkle::THREADS)), dim3(merkle::THREADS), 0, st, (const uint32_t*)d_state,
-                         (const uint32_t*)d_in, (int)ch->num_inputs, (int)fri->proof_of_work_bits, base, total, d_best);
-      LAUNCH_CHECK();
+      KLAUNCH(ctx, "grind", 0.0, merkle::grind, dim3(div_up(total, merkle::THREADS)), dim3(merkle::THREADS), 0, (const uint32_t*)d_state,
+              (const uint32_t*)d_in, (int)ch->num_inputs, (int)fri->proof_of_work_bits, base, total, d_best);
       HIP_CHECK(hipMemcpyAsync(&found, d_best, 4, hipMemcpyDeviceToHost, st));
       HIP_CHECK(hipStreamSynchronize(st));
       if (found != 0xffffffffu) break;
@@ -877,6 +905,16 @@ int zkm_ctx_last_timings(zkm_ctx* ctx, const char** names, float* ms, int cap) {
   for (int i = 0; i < n && i < cap; i++) { names[i] = ctx->timing_names[i].c_str(); ms[i] = ctx->timing_ms[i]; }
   return n;
 }
+
+int zkm_ctx_kernel_timings(zkm_ctx* ctx, const char** names, float* ms, uint32_t* calls, double* bytes, int cap) {
+  int i = 0;
+  for (auto& kv : ctx->kstats) {
+    if (i < cap) { names[i] = kv.first.c_str(); ms[i] = (float)kv.second.ms; calls[i] = kv.second.calls; bytes[i] = kv.second.bytes; }
+    i++;
+  }
+  return i;
+}
+void zkm_ctx_set_kernel_timing(zkm_ctx* ctx, int enabled) { ctx->kernel_timing = enabled != 0; }
 
 int zkm_matrix_upload(zkm_ctx* ctx, const uint32_t* host, size_t height, size_t width, zkm_matrix** out) {
   API_BEGIN

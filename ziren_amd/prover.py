@@ -64,6 +64,15 @@ class Context:
         n = lib.load().zkm_ctx_last_timings(self.h, names, ms, 64)
         return [(names[i].decode(), float(ms[i])) for i in range(min(n, 64))]
 
+    def kernel_timings(self):
+        """[(kernel, total ms, launches, compulsory HBM bytes)] of the last commit/open/prove call."""
+        names = (C.c_char_p * 64)()
+        ms = (C.c_float * 64)()
+        calls = (C.c_uint32 * 64)()
+        nbytes = (C.c_double * 64)()
+        n = lib.load().zkm_ctx_kernel_timings(self.h, names, ms, calls, nbytes, 64)
+        return [(names[i].decode(), float(ms[i]), int(calls[i]), float(nbytes[i])) for i in range(min(n, 64))]
+
     def close(self):
         if self.h:
             lib.load().zkm_ctx_destroy(self.h)
