@@ -1,0 +1,109 @@
+// Integer-pipe micro-benchmark for gfx950: issue rate of the instructions a Montgomery multiply is
+// made of. Build: hipcc --offload-arch=gfx950 -O3 tools/ubench_int.hip -o ubench_int ; run on the GPU box.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+#include <vector>
+
+#define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
+
+constexpr int ITERS = 4096;
+constexpr int ILP = 8;
+
+template <int OP>
+__global__ void bench(uint32_t* out, uint32_t seed) {
+  uint32_t a[ILP], b = seed | 1;
+  uint64_t w[ILP];
+  for (int i = 0; i < ILP; i++) { a[i] = threadIdx.x * 2654435761u + i * 40503u + seed; w[i] = a[i]; }
+  for (int it = 0; it < ITERS; it++) {
+#pragma unroll
+    for (int i = 0; i < ILP; i++) {
+      if (OP == 0) asm volatile("v_add_u32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+      if (OP == 1) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+      if (OP == 2) asm volatile("v_mul_hi_u32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+      if (OP == 3) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(w[i]) : "v"(a[i]), "v"(b) : "vcc");
+      if (OP == 4) asm volatile("v_mul_u32_u24 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+      if (OP == 5) asm volatile("v_mad_u32_u24 %0, %0, %1, %0" : "+v"(a[i]) : "v"(b));
+      if (OP == 6) asm volatile("v_lshl_add_u32 %0, %0, 7, %1" : "+v"(a[i]) : "v"(b));
+      if (OP == 7) asm volatile("v_min_u32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+      if (OP == 8) asm volatile("v_mul_hi_u32_u24 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+      if (OP == 9) asm volatile("v_add3_u32 %0, %0, %1, %1" : "+v"(a[i]) : "v"(b));
+      if (OP == 10) asm volatile("v_alignbit_b32 %0, %0, %1, 8" : "+v"(a[i]) : "v"(b));
+      if (OP == 11) asm volatile("v_mad_u32_u16 %0, %0, %1, %0" : "+v"(a[i]) : "v"(b));
+      if (OP == 12) asm volatile("v_fma_f32 %0, %0, %1, %0" : "+v"(a[i]) : "v"(b));
+      if (OP == 13) asm volatile("v_sub_u32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+      if (OP == 14) asm volatile("v_and_b32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+      if (OP == 15) asm volatile("v_lshlrev_b32 %0, 3, %0" : "+v"(a[i]));
+      if (OP == 16) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[i]) : "v"(b));
+      if (OP == 17) asm volatile("v_add_f32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+      if (OP == 18) asm volatile("v_min3_u32 %0, %0, %1, %1" : "+v"(a[i]) : "v"(b));
+      if (OP == 19) asm volatile("v_max_u32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+      if (OP == 20) asm volatile("v_min_i32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+      if (OP == 21) asm volatile("v_add_co_u32 %0, vcc, %0, %1" : "+v"(a[i]) : "v"(b) : "vcc");
+      if (OP == 22) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+      if (OP == 23) asm volatile("v_min_u32 %0, %1, %0" : "+v"(a[i]) : "s"(seed));
+      if (OP == 24) asm volatile("v_add_u32 %0, 0x80ffffff, %0" : "+v"(a[i]));
+      if (OP == 25) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+      if (OP == 26) asm volatile("v_min_f32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+      if (OP == 27) asm volatile("v_mul_lo_u32 %0, %0, %1\n v_add_u32 %2, %2, %1" : "+v"(a[i]), "+v"(b) , "+v"(a[(i+1)%ILP]):);
+    }
+  }
+  uint32_t r = 0;
+  for (int i = 0; i < ILP; i++) r += a[i] + (uint32_t)w[i] + (uint32_t)(w[i] >> 32);
+  out[blockIdx.x * blockDim.x + threadIdx.x] = r;
+}
+
+template <int OP>
+int run(const char* name, uint32_t* d) {
+  const int blocks = 256 * 8, threads = 256;  // 8 blocks x 4 waves per CU = 8 waves / SIMD
+  hipEvent_t e0, e1;
+  CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+  bench<OP><<<blocks, threads>>>(d, 12345);
+  CHECK(hipDeviceSynchronize());
+  CHECK(hipEventRecord(e0));
+  for (int r = 0; r < 5; r++) bench<OP><<<blocks, threads>>>(d, 12345 + r);
+  CHECK(hipEventRecord(e1));
+  CHECK(hipEventSynchronize(e1));
+  float ms;
+  CHECK(hipEventElapsedTime(&ms, e0, e1));
+  double insts = 5.0 * blocks * (threads / 64) * (double)ITERS * ILP;  // wave-instructions
+  double per_simd_per_s = insts / (ms * 1e-3) / (256 * 4);
+  printf("%-18s %8.3f ms  %7.2f Gwave-inst/s/SIMD-equiv  -> %.2f cycles/wave-inst @2.4GHz\n", name, ms, per_simd_per_s / 1e9,
+         2.4e9 / per_simd_per_s);
+  return 0;
+}
+
+int main() {
+  uint32_t* d;
+  CHECK(hipMalloc(&d, 256 * 8 * 256 * 4));
+  run<0>("v_add_u32", d);
+  run<7>("v_min_u32", d);
+  run<6>("v_lshl_add_u32", d);
+  run<9>("v_add3_u32", d);
+  run<10>("v_alignbit_b32", d);
+  run<1>("v_mul_lo_u32", d);
+  run<2>("v_mul_hi_u32", d);
+  run<3>("v_mad_u64_u32", d);
+  run<4>("v_mul_u32_u24", d);
+  run<5>("v_mad_u32_u24", d);
+  run<8>("v_mul_hi_u32_u24", d);
+  run<11>("v_mad_u32_u16", d);
+  run<12>("v_fma_f32", d);
+  run<17>("v_add_f32", d);
+  run<25>("v_mul_f32", d);
+  run<26>("v_min_f32", d);
+  run<13>("v_sub_u32", d);
+  run<14>("v_and_b32", d);
+  run<22>("v_xor_b32", d);
+  run<15>("v_lshlrev_b32", d);
+  run<16>("v_cndmask_b32", d);
+  run<18>("v_min3_u32", d);
+  run<19>("v_max_u32", d);
+  run<20>("v_min_i32", d);
+  run<21>("v_add_co_u32", d);
+  run<23>("v_min_u32 sgpr", d);
+  run<24>("v_add_u32 literal", d);
+  run<0>("v_add_u32 (again)", d);
+  run<7>("v_min_u32 (again)", d);
+  return 0;
+}
