@@ -32,6 +32,8 @@ def cpu_baseline(log_rows_sample, fri):
     """Time the CPU restatement (oracle, kind 'port') on a bounded sample of the same workload."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
+    # the oracle's OpenMP loops stop scaling past ~16 threads (measured on the 2x64-core box)
+    O.lib().orc_set_num_threads(min(16, os.cpu_count() or 1))
     sh = synth.syn_shard(log_rows_sample)
     pk = O.Pk([], [], sh.pc_start, sh.initial_global_cumulative_sum, fri.log_blowup)
     ch = O.new_challenger()

@@ -100,9 +100,10 @@ typedef struct {
 } zkm_chip_desc;
 
 /*
- * Constraint bytecode. Header: { n_instr, n_regs, n_constraints, 0 }, then n_instr
+ * Constraint bytecode. Header: { n_instr, n_ext_regs, n_constraints, n_base_regs }, then n_instr
  * instructions of 2 words: w0 = op | dst<<8 | a<<16 | b<<24 ; w1 = immediate.
- * Registers hold extension elements; base values occupy coefficient 0.
+ * Two register files: base-field registers and extension-field registers; the opcode says which
+ * file each operand lives in ("B": base, "E": extension, "EB": dst and a extension, b base).
  * Loads (dst <- input; imm = column / index; a = row offset 0:local 1:next):
  */
 enum {

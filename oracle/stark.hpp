@@ -55,7 +55,7 @@ struct Chip {
   size_t num_constraints;
   std::vector<Lookup> lookups;  // sends then receives
   std::vector<Instr> program;
-  size_t n_regs = 0;
+  size_t n_regs = 0, n_base_regs = 0;
   size_t batch() const { return (size_t)1 << lqd; }
   size_t perm_ext_width() const { return lookups.empty() ? 0 : (lookups.size() + batch() - 1) / batch() + 1; }
 };
@@ -87,7 +87,7 @@ static inline Chip parse_chip(const zkm_chip_desc& d) {
   }
   if (d.program_len) {
     const uint32_t* p = d.program;
-    uint32_t ni = p[0]; c.n_regs = p[1];
+    uint32_t ni = p[0]; c.n_regs = p[1]; c.n_base_regs = p[3];
     if (p[2] != d.num_constraints) throw std::runtime_error("program constraint count mismatch");
     if (d.program_len != 4 + 2 * (size_t)ni) throw std::runtime_error("program blob length mismatch");
     for (uint32_t i = 0; i < ni; i++) {
@@ -113,27 +113,35 @@ struct EvalInputs {
 // Horner fold as in VerifierConstraintFolder; equal to the prover's sum_k alpha^(C-1-k) c_k
 // (prover.rs:453-456, folder.rs:79-84).
 static inline E eval_constraints(const Chip& chip, const EvalInputs& in) {
-  std::vector<E> reg(chip.n_regs ? chip.n_regs : 1);
+  std::vector<E> re(chip.n_regs ? chip.n_regs : 1), rb(chip.n_base_regs ? chip.n_base_regs : 1);
   E acc = ezero();
   size_t count = 0;
   for (const Instr& i : chip.program) {
     switch (i.op) {
-      case ZKM_OP_LD_MAIN: reg[i.dst] = in.main[i.a][i.imm]; break;
-      case ZKM_OP_LD_PREP: reg[i.dst] = in.prep[i.a][i.imm]; break;
-      case ZKM_OP_LD_PERM: reg[i.dst] = in.perm[i.a][i.imm]; break;
-      case ZKM_OP_LD_CONST: reg[i.dst] = efrom(from_monty(i.imm)); break;
-      case ZKM_OP_LD_PV: reg[i.dst] = efrom(in.public_values[i.imm]); break;
-      case ZKM_OP_LD_CHALLENGE: reg[i.dst] = in.challenges[i.imm]; break;
-      case ZKM_OP_LD_LOCAL_SUM: reg[i.dst] = in.local_sum; break;
-      case ZKM_OP_LD_GLOBAL_SUM: reg[i.dst] = efrom(in.global_sum[i.imm]); break;
-      case ZKM_OP_LD_IS_FIRST: reg[i.dst] = in.is_first; break;
-      case ZKM_OP_LD_IS_LAST: reg[i.dst] = in.is_last; break;
-      case ZKM_OP_LD_IS_TRANS: reg[i.dst] = in.is_trans; break;
-      case ZKM_OP_ADD_B: case ZKM_OP_ADD_E: case ZKM_OP_ADD_EB: reg[i.dst] = eadd(reg[i.a], reg[i.b]); break;
-      case ZKM_OP_SUB_B: case ZKM_OP_SUB_E: case ZKM_OP_SUB_EB: reg[i.dst] = esub(reg[i.a], reg[i.b]); break;
-      case ZKM_OP_MUL_B: case ZKM_OP_MUL_E: case ZKM_OP_MUL_EB: reg[i.dst] = emul(reg[i.a], reg[i.b]); break;
-      case ZKM_OP_NEG_B: case ZKM_OP_NEG_E: reg[i.dst] = eneg(reg[i.a]); break;
-      case ZKM_OP_ASSERT_B: case ZKM_OP_ASSERT_E: acc = eadd(emul(acc, in.alpha), reg[i.a]); count++; break;
+      case ZKM_OP_LD_MAIN: rb[i.dst] = in.main[i.a][i.imm]; break;
+      case ZKM_OP_LD_PREP: rb[i.dst] = in.prep[i.a][i.imm]; break;
+      case ZKM_OP_LD_PERM: re[i.dst] = in.perm[i.a][i.imm]; break;
+      case ZKM_OP_LD_CONST: rb[i.dst] = efrom(from_monty(i.imm)); break;
+      case ZKM_OP_LD_PV: rb[i.dst] = efrom(in.public_values[i.imm]); break;
+      case ZKM_OP_LD_CHALLENGE: re[i.dst] = in.challenges[i.imm]; break;
+      case ZKM_OP_LD_LOCAL_SUM: re[i.dst] = in.local_sum; break;
+      case ZKM_OP_LD_GLOBAL_SUM: rb[i.dst] = efrom(in.global_sum[i.imm]); break;
+      case ZKM_OP_LD_IS_FIRST: rb[i.dst] = in.is_first; break;
+      case ZKM_OP_LD_IS_LAST: rb[i.dst] = in.is_last; break;
+      case ZKM_OP_LD_IS_TRANS: rb[i.dst] = in.is_trans; break;
+      case ZKM_OP_ADD_B: rb[i.dst] = eadd(rb[i.a], rb[i.b]); break;
+      case ZKM_OP_SUB_B: rb[i.dst] = esub(rb[i.a], rb[i.b]); break;
+      case ZKM_OP_MUL_B: rb[i.dst] = emul(rb[i.a], rb[i.b]); break;
+      case ZKM_OP_NEG_B: rb[i.dst] = eneg(rb[i.a]); break;
+      case ZKM_OP_ADD_E: re[i.dst] = eadd(re[i.a], re[i.b]); break;
+      case ZKM_OP_SUB_E: re[i.dst] = esub(re[i.a], re[i.b]); break;
+      case ZKM_OP_MUL_E: re[i.dst] = emul(re[i.a], re[i.b]); break;
+      case ZKM_OP_NEG_E: re[i.dst] = eneg(re[i.a]); break;
+      case ZKM_OP_ADD_EB: re[i.dst] = eadd(re[i.a], rb[i.b]); break;
+      case ZKM_OP_SUB_EB: re[i.dst] = esub(re[i.a], rb[i.b]); break;
+      case ZKM_OP_MUL_EB: re[i.dst] = emul(re[i.a], rb[i.b]); break;
+      case ZKM_OP_ASSERT_B: acc = eadd(emul(acc, in.alpha), rb[i.a]); count++; break;
+      case ZKM_OP_ASSERT_E: acc = eadd(emul(acc, in.alpha), re[i.a]); count++; break;
       default: throw std::runtime_error("bad opcode");
     }
   }

@@ -224,7 +224,7 @@ class AirBuilder:
 
     # --- emission ------------------------------------------------------------------------------
     def assemble(self) -> np.ndarray:
-        """Emit the `program` blob: header {n_instr, n_regs, n_constraints, 0} + 2 words/instr."""
+        """Emit the `program` blob: header {n_instr, n_ext_regs, n_constraints, n_base_regs} + 2 words/instr."""
         # use counts over the whole DAG (each node evaluated once)
         seen = set()
 
@@ -244,14 +244,14 @@ class AirBuilder:
         for a in self.asserts:
             count(a)
         instrs = []
-        free = []
-        self._nregs = 0
+        free = {False: [], True: []}   # separate register files for base and extension values
+        nregs = {False: 0, True: 0}
 
-        def alloc():
-            if free:
-                return free.pop()
-            r = self._nregs
-            self._nregs += 1
+        def alloc(ext):
+            if free[ext]:
+                return free[ext].pop()
+            r = nregs[ext]
+            nregs[ext] += 1
             if r > 255:
                 raise ValueError("constraint program needs more than 256 registers")
             return r
@@ -259,7 +259,7 @@ class AirBuilder:
         def release(x):
             x.uses -= 1
             if x.uses == 0:
-                free.append(x.reg)
+                free[x.ext].append(x.reg)
                 x.reg = None
 
         def emit(e):
@@ -270,7 +270,7 @@ class AirBuilder:
                 if x.reg is not None:
                     continue
                 if x.op < ADD_B:
-                    x.reg = alloc()
+                    x.reg = alloc(x.ext)
                     instrs.append((x.op | x.reg << 8 | (x.a & 0xFF) << 16, x.imm))
                     continue
                 if not ready:
@@ -285,14 +285,14 @@ class AirBuilder:
                 release(x.a)
                 if x.c is not None:
                     release(x.c)
-                x.reg = alloc()
+                x.reg = alloc(x.ext)
                 instrs.append((x.op | x.reg << 8 | ra << 16 | rc << 24, 0))
 
         for a in self.asserts:
             emit(a)
             instrs.append(((ASSERT_E if a.ext else ASSERT_B) | a.reg << 16, 0))
             release(a)
-        words = [len(instrs), max(self._nregs, 1), len(self.asserts), 0]
+        words = [len(instrs), max(nregs[True], 1), len(self.asserts), max(nregs[False], 1)]
         for w0, w1 in instrs:
             words += [w0 & 0xFFFFFFFF, w1 & 0xFFFFFFFF]
         return np.array(words, dtype=np.uint32)

@@ -25,37 +25,77 @@ namespace lde {
 
 constexpr int LOG_ROW_MAX = 13;        // B <= 8192 words = 32 KiB of LDS per buffer
 constexpr int COLS_TILE_ELEMS = 16384; // A * T words in LDS for the strided passes (64 KiB)
-constexpr int THREADS = 256;
+constexpr int THREADS = 512;  // 8 waves per block: two blocks per CU keep 4 waves per SIMD over the barriers
 
-// In-LDS radix-2 transform over 2^lognb interleaved sequences: element i of sequence t lives at
-// buf[i * istride + t]. tw[j] = w^j for the size-2^logn root w (forward or inverse table).
-// DIF: natural in -> bit-reversed out.  DIT: bit-reversed in -> natural out.
-template <bool DIF>
-__device__ __forceinline__ void lds_ntt(uint32_t* buf, int logn, int lognb, int istride, const uint32_t* __restrict__ tw) {
-  const int half = 1 << (logn - 1);
-  const int total = half << lognb;
-  for (int st = 0; st < logn; st++) {
-    const int s = DIF ? st : (logn - 1 - st);
-    const int logm = logn - 1 - s;  // m = half >> s
-    for (int u = threadIdx.x; u < total; u += blockDim.x) {
-      int t = u & ((1 << lognb) - 1), j = u >> lognb;
-      int off = j & ((1 << logm) - 1);
-      int i0 = ((j >> logm) << (logm + 1)) + off;
-      int i1 = i0 + (1 << logm);
-      uint32_t w = tw[off << s];
-      uint32_t* p0 = buf + i0 * istride + t;
-      uint32_t* p1 = buf + i1 * istride + t;
-      uint32_t a = *p0, b = *p1;
-      if (DIF) {
-        *p0 = kb::add(a, b);
-        *p1 = kb::mul(kb::sub(a, b), w);
-      } else {
-        b = kb::mul(b, w);
-        *p0 = kb::add(a, b);
-        *p1 = kb::sub(a, b);
+// ---- in-LDS transforms ---------------------------------------------------------------------------
+// A transform of 2^logn points runs as passes of up to 3 radix-2 stages. In one pass a thread owns a
+// group of 2^R points (R <= 3) that only interact with each other during those stages, keeps them in
+// VGPRs, and touches LDS once to read and once to write them: 13 stages cost 5 LDS round trips and
+// 5 barriers instead of 13.
+//
+// Sequence layout: element i of sequence t lives at buf[phys(i) * istride + t]; 2^lognb sequences are
+// interleaved (strided kernels: t = column inside the tile). PAD inserts one word per 32 so that the
+// power-of-two strides of the late stages spread over the LDS banks (contiguous kernels only).
+//
+// Twiddles are stage-major: for stage s (butterfly span m = n >> (s+1)) the m factors w_{2m}^off sit
+// contiguously at tw[n - (n >> s) + off], so lanes with consecutive `off` read consecutive words.
+// DIF: natural in -> bit-reversed out (stages 0..logn-1).  DIT: bit-reversed in -> natural out.
+template <bool PAD>
+__device__ __forceinline__ int phys(int i) { return PAD ? i + (i >> 5) : i; }
+
+template <bool DIF, int R, bool PAD>
+__device__ __forceinline__ void ntt_pass(uint32_t* buf, int logn, int lognb, int istride, int s0, const uint32_t* __restrict__ tw) {
+  const int n = 1 << logn;
+  const int logm2 = logn - s0 - R;  // points of a group are m2 = 2^logm2 apart
+  const int total = (n >> R) << lognb;
+  for (int u = threadIdx.x; u < total; u += blockDim.x) {
+    const int t = u & ((1 << lognb) - 1), g = u >> lognb;
+    const int lo = g & ((1 << logm2) - 1), hi = g >> logm2;
+    const int base = (hi << (R + logm2)) + lo;
+    uint32_t x[1 << R];
+#pragma unroll
+    for (int j = 0; j < (1 << R); j++) x[j] = buf[phys<PAD>(base + (j << logm2)) * istride + t];
+#pragma unroll
+    for (int qq = 0; qq < R; qq++) {
+      const int q = DIF ? qq : R - 1 - qq;
+      const int s = s0 + q;
+      const int half = 1 << (R - 1 - q);
+      const uint32_t* tws = tw + (n - (n >> s)) + lo;
+#pragma unroll
+      for (int j0 = 0; j0 < (1 << R); j0++) {
+        if (j0 & half) continue;
+        const int j1 = j0 + half;
+        const uint32_t w = tws[(j0 & (half - 1)) << logm2];
+        uint32_t a = x[j0], b = x[j1];
+        if (DIF) {
+          x[j0] = kb::add(a, b);
+          x[j1] = kb::mul(kb::sub(a, b), w);
+        } else {
+          b = kb::mul(b, w);
+          x[j0] = kb::add(a, b);
+          x[j1] = kb::sub(a, b);
+        }
       }
     }
-    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < (1 << R); j++) buf[phys<PAD>(base + (j << logm2)) * istride + t] = x[j];
+  }
+  __syncthreads();
+}
+
+template <bool DIF, bool PAD>
+__device__ __forceinline__ void lds_ntt(uint32_t* buf, int logn, int lognb, int istride, const uint32_t* __restrict__ tw) {
+  const int rem = logn % 3;  // the short pass handles the smallest spans
+  if (DIF) {
+    int s0 = 0;
+    for (; s0 + 3 <= logn; s0 += 3) ntt_pass<true, 3, PAD>(buf, logn, lognb, istride, s0, tw);
+    if (rem == 2) ntt_pass<true, 2, PAD>(buf, logn, lognb, istride, s0, tw);
+    if (rem == 1) ntt_pass<true, 1, PAD>(buf, logn, lognb, istride, s0, tw);
+  } else {
+    int s0 = logn - rem;
+    if (rem == 2) ntt_pass<false, 2, PAD>(buf, logn, lognb, istride, s0, tw);
+    if (rem == 1) ntt_pass<false, 1, PAD>(buf, logn, lognb, istride, s0, tw);
+    for (s0 -= 3; s0 >= 0; s0 -= 3) ntt_pass<false, 3, PAD>(buf, logn, lognb, istride, s0, tw);
   }
 }
 
@@ -94,7 +134,7 @@ __global__ __launch_bounds__(THREADS) void lde_cols(const uint32_t* __restrict__
     lds[u] = src[(size_t)i1 * B + t0 + t];
   }
   __syncthreads();
-  lds_ntt<!FORWARD>(lds, la, logT, T, tw);
+  lds_ntt<!FORWARD, false>(lds, la, logT, T, tw);
   if (!FORWARD) {
     uint32_t* dst = out + c * out_col_stride;
     for (int u = threadIdx.x; u < A * T; u += blockDim.x) {
@@ -124,9 +164,10 @@ __global__ __launch_bounds__(THREADS) void lde_rows(const uint32_t* __restrict__
   extern __shared__ uint32_t lds[];
   const int B = 1 << lb;
   const int nhi = B > 64 ? (B >> 6) : 1;
-  uint32_t* coef = lds;            // B
-  uint32_t* work = lds + B;        // B
-  uint32_t* lo1 = work + B;        // 64   powers of w_n^(-k1)   (load twiddle)
+  const int BP = B + (B >> 5);     // padded length, see phys<>
+  uint32_t* coef = lds;            // BP
+  uint32_t* work = lds + BP;       // BP
+  uint32_t* lo1 = work + BP;       // 64   powers of w_n^(-k1)   (load twiddle)
   uint32_t* hi1 = lo1 + 64;        // nhi
   uint32_t* lo2 = hi1 + nhi;       // 64   powers of shift_j^A   (coset scaling)
   uint32_t* hi2 = lo2 + 64;        // nhi
@@ -139,12 +180,12 @@ __global__ __launch_bounds__(THREADS) void lde_rows(const uint32_t* __restrict__
   if (la > 0) {
     build_pow_table(kb::pow(w_n_inv, (uint64_t)k1), lo1, hi1, nhi);
     __syncthreads();
-    for (int i = threadIdx.x; i < B; i += blockDim.x) coef[i] = kb::mul(src[i], pow_lookup(lo1, hi1, i));
+    for (int i = threadIdx.x; i < B; i += blockDim.x) coef[phys<true>(i)] = kb::mul(src[i], pow_lookup(lo1, hi1, i));
   } else {
-    for (int i = threadIdx.x; i < B; i += blockDim.x) coef[i] = src[i];
+    for (int i = threadIdx.x; i < B; i += blockDim.x) coef[phys<true>(i)] = src[i];
   }
   __syncthreads();
-  if (lb > 0) lds_ntt<true>(coef, lb, 0, 1, tw_inv);
+  if (lb > 0) lds_ntt<true, true>(coef, lb, 0, 1, tw_inv);
   // coef[pc] = n * c_kk with kk = bitrev_lb(pc) * A + k1
   if (la > 0) {
     build_pow_table(kb::pow(w_n, (uint64_t)k1), lo1, hi1, nhi);  // store twiddle w_n^(j0 k1)
@@ -160,24 +201,27 @@ __global__ __launch_bounds__(THREADS) void lde_rows(const uint32_t* __restrict__
     uint32_t f = kb::mul(n_inv, kb::pow(sj, (uint64_t)k1));
     __syncthreads();
     for (int i = threadIdx.x; i < B; i += blockDim.x)
-      work[i] = kb::mul(kb::mul(coef[i], f), pow_lookup(lo2, hi2, kb::bitrev(i, lb)));
+      work[phys<true>(i)] = kb::mul(kb::mul(coef[phys<true>(i)], f), pow_lookup(lo2, hi2, kb::bitrev(i, lb)));
     __syncthreads();
-    if (lb > 0) lds_ntt<false>(work, lb, 0, 1, tw_fwd);
+    if (lb > 0) lds_ntt<false, true>(work, lb, 0, 1, tw_fwd);
     if (la > 0) {
       uint32_t* dst = out + (size_t)j * out_coset_stride + c * out_col_stride + (size_t)pr * B;
-      for (int i = threadIdx.x; i < B; i += blockDim.x) dst[i] = kb::mul(work[i], pow_lookup(lo1, hi1, i));
+      for (int i = threadIdx.x; i < B; i += blockDim.x) dst[i] = kb::mul(work[phys<true>(i)], pow_lookup(lo1, hi1, i));
     } else {
       uint32_t* dst = out + c * out_col_stride + (size_t)kb::bitrev(j, log_blowup) * B;
-      for (int i = threadIdx.x; i < B; i += blockDim.x) dst[i] = work[kb::bitrev(i, lb)];
+      for (int i = threadIdx.x; i < B; i += blockDim.x) dst[i] = work[phys<true>(kb::bitrev(i, lb))];
     }
     sj = kb::mul(sj, w_N);
   }
 }
 
-// tw[j] = w^j, j < count
-__global__ void fill_powers(uint32_t* tw, uint32_t w, size_t count) {
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < count) tw[i] = kb::pow(w, (uint64_t)i);
+// Stage-major twiddles of the size-2^logn transform with root w: tw[n - (n >> s) + off] = w^(off << s)
+// for stage s = blockIdx.y and off < n >> (s + 1).
+__global__ void fill_stage_twiddles(uint32_t* tw, uint32_t w, int logn) {
+  const size_t n = (size_t)1 << logn;
+  const int s = blockIdx.y;
+  size_t off = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (off < (n >> (s + 1))) tw[n - (n >> s) + off] = kb::pow(w, (uint64_t)off << s);
 }
 
 }  // namespace lde

@@ -72,6 +72,27 @@ __global__ __launch_bounds__(THREADS) void compress_layer(const uint32_t* __rest
   store_digest(next + 8 * i, s);
 }
 
+// Top of the tree in one launch: starting from a layer of 2*len0 digests at `prev`, compress down to the
+// root; the layers are contiguous in memory (2*len0, len0, len0/2, ..., 1 digests). One block; a
+// barrier between levels makes the freshly written layer visible to the block.
+__global__ __launch_bounds__(THREADS) void compress_tail(uint32_t* __restrict__ prev, size_t len0) {
+  uint32_t* p = prev;
+  uint32_t* nx = prev + 16 * len0;
+  for (size_t len = len0; len >= 1; len >>= 1) {
+    for (size_t i = threadIdx.x; i < len; i += blockDim.x) {
+      uint32_t s[16];
+      load_digest(s, p + 16 * i);
+      load_digest(s + 8, p + 16 * i + 8);
+      p2::permute(s);
+      store_digest(nx + 8 * i, s);
+    }
+    __syncthreads();
+    p = nx;
+    nx += 8 * len;
+    if (len == 1) break;
+  }
+}
+
 // FRI commit-phase leaves: row j = (f[2j], f[2j+1]) as 8 base words (fri.rs:279-306)
 __global__ __launch_bounds__(THREADS) void hash_fri_leaves(const kb::E4* __restrict__ f, size_t m, uint32_t* __restrict__ digests) {
   size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;

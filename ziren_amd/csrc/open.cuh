@@ -23,33 +23,16 @@ __global__ __launch_bounds__(THREADS) void bary_weights(kb::E4 u, kb::E4 c, uint
   out[i] = kb::emul(kb::escale(d, wi), c);
 }
 
-// Column evaluations: block (bx, by) handles COLS columns starting at 4*bx over rows
-// r = by*THREADS + tid + k * gridDim.y*THREADS, accumulating
-//   acc0[c] += v[c][r] * w[r],   acc1[c] += v[c][(r+1) mod n] * w[r]
-// and writes one partial per block: partials[((by * width) + col) * 2 + {0,1}].
+// Column evaluations. Block (bx, by) owns EVAL_COLS columns starting at EVAL_COLS*bx and the rows
+//   r = 4 * (by * THREADS + tid) + k * 4 * gridDim.y * THREADS,   r .. r+3 per iteration,
+// accumulating  acc0[c] += v[c][r] * w[r]  and (TWO)  acc1[c] += v[c][(r+1) mod n] * w[r].
+// Every load of an iteration (4 weight quads, one 16-byte column quad + 1 word per column) is issued
+// before the first multiply, so a wavefront keeps ~6 KiB in flight. Requires n % 4 == 0.
+// One partial per block: partials[(by * width + col) * 2 + {0,1}].
 constexpr int EVAL_COLS = 4;
-__global__ __launch_bounds__(THREADS) void eval_columns(const uint32_t* __restrict__ mat, size_t n, int width,
-                                                        const kb::E4* __restrict__ weights, int two_points,
-                                                        kb::E4* __restrict__ partials) {
-  __shared__ uint32_t red[THREADS];
-  const int c0 = blockIdx.x * EVAL_COLS;
-  kb::E4 acc[EVAL_COLS][2];
-#pragma unroll
-  for (int c = 0; c < EVAL_COLS; c++) { acc[c][0] = kb::ezero(); acc[c][1] = kb::ezero(); }
-  const size_t stride = (size_t)gridDim.y * THREADS;
-  for (size_t r = (size_t)blockIdx.y * THREADS + threadIdx.x; r < n; r += stride) {
-    kb::E4 w = weights[r];
-    size_t rn = r + 1 == n ? 0 : r + 1;
-#pragma unroll
-    for (int c = 0; c < EVAL_COLS; c++) {
-      if (c0 + c < width) {
-        const uint32_t* col = mat + (size_t)(c0 + c) * n;
-        acc[c][0] = kb::eadd(acc[c][0], kb::escale(w, col[r]));
-        if (two_points) acc[c][1] = kb::eadd(acc[c][1], kb::escale(w, col[rn]));
-      }
-    }
-  }
-  // block reduction of 8 * EVAL_COLS words
+
+__device__ __forceinline__ void block_reduce_store(kb::E4 (&acc)[EVAL_COLS][2], int c0, int width, kb::E4* __restrict__ partials,
+                                                   uint32_t* red) {
 #pragma unroll
   for (int c = 0; c < EVAL_COLS; c++) {
 #pragma unroll
@@ -57,18 +40,89 @@ __global__ __launch_bounds__(THREADS) void eval_columns(const uint32_t* __restri
       kb::E4 tot;
 #pragma unroll
       for (int e = 0; e < 4; e++) {
-        red[threadIdx.x] = acc[c][pt].c[e];
+        // wave reduction through DPP-free shuffles, then one LDS exchange across the 4 waves
+        uint32_t v = acc[c][pt].c[e];
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) v = kb::add(v, __shfl_xor(v, d));
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
         __syncthreads();
-        for (int d = THREADS / 2; d > 0; d >>= 1) {
-          if (threadIdx.x < d) red[threadIdx.x] = kb::add(red[threadIdx.x], red[threadIdx.x + d]);
-          __syncthreads();
-        }
-        tot.c[e] = red[0];
+        uint32_t t = red[0];
+        for (int w = 1; w < THREADS / 64; w++) t = kb::add(t, red[w]);
+        tot.c[e] = t;
         __syncthreads();
       }
       if (threadIdx.x == 0 && c0 + c < width) partials[((size_t)blockIdx.y * width + c0 + c) * 2 + pt] = tot;
     }
   }
+}
+
+template <bool TWO>
+__global__ __launch_bounds__(THREADS) void eval_columns(const uint32_t* __restrict__ mat, size_t n, int width,
+                                                        const kb::E4* __restrict__ weights, kb::E4* __restrict__ partials) {
+  __shared__ uint32_t red[THREADS / 64];
+  const int c0 = blockIdx.x * EVAL_COLS;
+  const uint32_t* cols[EVAL_COLS];
+#pragma unroll
+  for (int c = 0; c < EVAL_COLS; c++) cols[c] = mat + (size_t)min(c0 + c, width - 1) * n;  // clamp: duplicates are not stored
+  kb::E4 acc[EVAL_COLS][2];
+#pragma unroll
+  for (int c = 0; c < EVAL_COLS; c++) { acc[c][0] = kb::ezero(); acc[c][1] = kb::ezero(); }
+  const size_t stride = (size_t)gridDim.y * THREADS * 4;
+  for (size_t r = ((size_t)blockIdx.y * THREADS + threadIdx.x) * 4; r < n; r += stride) {
+    kb::E4 w[4];
+    uint4 v[EVAL_COLS];
+    uint32_t vnext[EVAL_COLS];
+    const size_t rn = r + 4 == n ? 0 : r + 4;
+#pragma unroll
+    for (int k = 0; k < 4; k++) w[k] = weights[r + k];
+#pragma unroll
+    for (int c = 0; c < EVAL_COLS; c++) {
+      v[c] = *reinterpret_cast<const uint4*>(cols[c] + r);
+      if (TWO) vnext[c] = cols[c][rn];
+    }
+#pragma unroll
+    for (int c = 0; c < EVAL_COLS; c++) {
+      const uint32_t x[5] = {v[c].x, v[c].y, v[c].z, v[c].w, TWO ? vnext[c] : 0u};
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        acc[c][0] = kb::eadd(acc[c][0], kb::escale(w[k], x[k]));
+        if (TWO) acc[c][1] = kb::eadd(acc[c][1], kb::escale(w[k], x[k + 1]));
+      }
+    }
+  }
+  block_reduce_store(acc, c0, width, partials, red);
+}
+
+// Small matrices (n < 4 * THREADS): one block per column group, scalar loads.
+__global__ __launch_bounds__(THREADS) void eval_columns_small(const uint32_t* __restrict__ mat, size_t n, int width,
+                                                              const kb::E4* __restrict__ weights, int two_points,
+                                                              kb::E4* __restrict__ partials) {
+  __shared__ uint32_t red[THREADS / 64];
+  const int c0 = blockIdx.x * EVAL_COLS;
+  kb::E4 acc[EVAL_COLS][2];
+#pragma unroll
+  for (int c = 0; c < EVAL_COLS; c++) { acc[c][0] = kb::ezero(); acc[c][1] = kb::ezero(); }
+  for (size_t r = threadIdx.x; r < n; r += THREADS) {
+    kb::E4 w = weights[r];
+    size_t rn = r + 1 == n ? 0 : r + 1;
+#pragma unroll
+    for (int c = 0; c < EVAL_COLS; c++) {
+      const uint32_t* col = mat + (size_t)min(c0 + c, width - 1) * n;
+      acc[c][0] = kb::eadd(acc[c][0], kb::escale(w, col[r]));
+      if (two_points) acc[c][1] = kb::eadd(acc[c][1], kb::escale(w, col[rn]));
+    }
+  }
+  block_reduce_store(acc, c0, width, partials, red);
+}
+
+// out[i] = sum_s partials[s * count + i]
+__global__ __launch_bounds__(THREADS) void reduce_partials(const kb::E4* __restrict__ partials, int split, int count,
+                                                           kb::E4* __restrict__ out) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  kb::E4 acc = kb::ezero();
+  for (int s = 0; s < split; s++) acc = kb::eadd(acc, partials[(size_t)s * count + i]);
+  out[i] = acc;
 }
 
 // Reduced openings for one LDE height N (fri.rs:103-204). One thread per stored row r
@@ -95,7 +149,16 @@ __global__ __launch_bounds__(THREADS) void reduce_openings(const ReduceMat* __re
   for (int m = 0; m < n_mats; m++) {
     const ReduceMat& M = mats[m];
     kb::E4 S = kb::ezero();
-    for (int c = 0; c < M.width; c++) S = kb::eadd(S, kb::escale(alpha_pows[c], M.lde[(size_t)c * N + r]));
+    const uint32_t* col = M.lde + r;
+    int c = 0;
+    for (; c + 8 <= M.width; c += 8) {
+      uint32_t v[8];
+#pragma unroll
+      for (int k = 0; k < 8; k++) v[k] = col[(size_t)(c + k) * N];
+#pragma unroll
+      for (int k = 0; k < 8; k++) S = kb::eadd(S, kb::escale(alpha_pows[c + k], v[k]));
+    }
+    for (; c < M.width; c++) S = kb::eadd(S, kb::escale(alpha_pows[c], col[(size_t)c * N]));
     acc = kb::eadd(acc, kb::emul(kb::esub(M.Yc[0], kb::emul(M.A[0], S)), d0));
     if (M.n_points > 1) acc = kb::eadd(acc, kb::emul(kb::esub(M.Yc[1], kb::emul(M.A[1], S)), d1));
   }

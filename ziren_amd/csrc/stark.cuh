@@ -128,7 +128,8 @@ __global__ __launch_bounds__(THREADS) void scan_add_offsets(uint32_t* __restrict
 struct QuotientArgs {
   const uint32_t* program;   // 2 words per instruction (header stripped)
   int n_instr;
-  int n_regs;
+  int n_regs;                // extension registers
+  int n_base_regs;
   const uint32_t* main_lde;  // column-major, height N (bit-reversed rows)
   const uint32_t* prep_lde;
   const uint32_t* perm_lde;
@@ -145,22 +146,17 @@ struct QuotientArgs {
   uint32_t* out;             // chunk c, coefficient e, row j at out[(c * 4 + e) * n + j]
 };
 
-// Register file in LDS: word e of register r of thread t at regs[(r * 4 + e) * blockDim + t]
-// (conflict-free: consecutive lanes hit consecutive banks).
-#define ZKM_REG(r, e) regs[((r) * 4 + (e)) * bd + tid]
-
-__device__ __forceinline__ kb::E4 reg_load_e(const uint32_t* regs, int bd, int tid, int r) {
-  return kb::E4{{ZKM_REG(r, 0), ZKM_REG(r, 1), ZKM_REG(r, 2), ZKM_REG(r, 3)}};
-}
-__device__ __forceinline__ void reg_store_e(uint32_t* regs, int bd, int tid, int r, const kb::E4& v) {
-  ZKM_REG(r, 0) = v.c[0]; ZKM_REG(r, 1) = v.c[1]; ZKM_REG(r, 2) = v.c[2]; ZKM_REG(r, 3) = v.c[3];
-}
-
+// Register files in LDS, one slot per thread: extension registers as 16-byte words at
+// regs_e[r * blockDim + t] (ds_read/write_b128, conflict-free), base registers at regs_b[r * blockDim + t].
 // One thread per stored LDE row p (bit-reversed order): i = bitrev(p) is the natural index on
 // the quotient coset 3 * <w_Q>; local row = p, next row = bitrev(i + 2^lqd) (quotient.rs:44-45,61).
 __global__ void quotient_kernel(QuotientArgs a) {
-  extern __shared__ uint32_t regs[];
+  extern __shared__ uint4 lds4[];
   const int bd = blockDim.x, tid = threadIdx.x;
+  kb::E4* regs_e = reinterpret_cast<kb::E4*>(lds4);
+  uint32_t* regs_b = reinterpret_cast<uint32_t*>(lds4 + (size_t)a.n_regs * bd);
+#define RE(r) regs_e[(r) * bd + tid]
+#define RB(r) regs_b[(r) * bd + tid]
   const int lq = a.log_n + a.lqd;
   const size_t Q = (size_t)1 << lq;
   size_t p = (size_t)blockIdx.x * bd + tid;
@@ -177,42 +173,46 @@ __global__ void quotient_kernel(QuotientArgs a) {
 
   kb::E4 acc = kb::ezero();
   int cidx = 0;
+  // the next instruction's two words are fetched (scalar loads) while the current one executes
+  uint32_t nw0 = a.n_instr ? a.program[0] : 0, nimm = a.n_instr ? a.program[1] : 0;
   for (int pc = 0; pc < a.n_instr; pc++) {
-    uint32_t w0 = a.program[2 * pc], imm = a.program[2 * pc + 1];
+    const uint32_t w0 = nw0, imm = nimm;
+    if (pc + 1 < a.n_instr) { nw0 = a.program[2 * pc + 2]; nimm = a.program[2 * pc + 3]; }
     int op = w0 & 0xff, dst = (w0 >> 8) & 0xff, ra = (w0 >> 16) & 0xff, rb = w0 >> 24;
     switch (op) {
-      case 1: ZKM_REG(dst, 0) = a.main_lde[(size_t)imm * a.main_stride + (ra ? pn : p)]; break;
-      case 2: ZKM_REG(dst, 0) = a.prep_lde[(size_t)imm * a.prep_stride + (ra ? pn : p)]; break;
+      case 1: RB(dst) = a.main_lde[(size_t)imm * a.main_stride + (ra ? pn : p)]; break;
+      case 2: RB(dst) = a.prep_lde[(size_t)imm * a.prep_stride + (ra ? pn : p)]; break;
       case 3: {
         const uint32_t* q = a.perm_lde + (size_t)(4 * imm) * a.perm_stride + (ra ? pn : p);
-        ZKM_REG(dst, 0) = q[0]; ZKM_REG(dst, 1) = q[a.perm_stride];
-        ZKM_REG(dst, 2) = q[2 * a.perm_stride]; ZKM_REG(dst, 3) = q[3 * a.perm_stride];
+        RE(dst) = kb::E4{{q[0], q[a.perm_stride], q[2 * a.perm_stride], q[3 * a.perm_stride]}};
         break;
       }
-      case 4: ZKM_REG(dst, 0) = imm; break;
-      case 5: ZKM_REG(dst, 0) = a.public_values[imm]; break;
-      case 6: reg_store_e(regs, bd, tid, dst, imm ? a.perm_beta : a.perm_alpha); break;
-      case 7: reg_store_e(regs, bd, tid, dst, a.local_sum); break;
-      case 8: ZKM_REG(dst, 0) = a.consts[imm]; break;
-      case 9: ZKM_REG(dst, 0) = is_first; break;
-      case 10: ZKM_REG(dst, 0) = is_last; break;
-      case 11: ZKM_REG(dst, 0) = is_trans; break;
-      case 16: ZKM_REG(dst, 0) = kb::add(ZKM_REG(ra, 0), ZKM_REG(rb, 0)); break;
-      case 17: ZKM_REG(dst, 0) = kb::sub(ZKM_REG(ra, 0), ZKM_REG(rb, 0)); break;
-      case 18: ZKM_REG(dst, 0) = kb::mul(ZKM_REG(ra, 0), ZKM_REG(rb, 0)); break;
-      case 19: ZKM_REG(dst, 0) = kb::neg(ZKM_REG(ra, 0)); break;
-      case 20: reg_store_e(regs, bd, tid, dst, kb::eadd(reg_load_e(regs, bd, tid, ra), reg_load_e(regs, bd, tid, rb))); break;
-      case 21: reg_store_e(regs, bd, tid, dst, kb::esub(reg_load_e(regs, bd, tid, ra), reg_load_e(regs, bd, tid, rb))); break;
-      case 22: reg_store_e(regs, bd, tid, dst, kb::emul(reg_load_e(regs, bd, tid, ra), reg_load_e(regs, bd, tid, rb))); break;
-      case 23: reg_store_e(regs, bd, tid, dst, kb::eneg(reg_load_e(regs, bd, tid, ra))); break;
-      case 24: reg_store_e(regs, bd, tid, dst, kb::eadd_base(reg_load_e(regs, bd, tid, ra), ZKM_REG(rb, 0))); break;
-      case 25: reg_store_e(regs, bd, tid, dst, kb::esub_base(reg_load_e(regs, bd, tid, ra), ZKM_REG(rb, 0))); break;
-      case 26: reg_store_e(regs, bd, tid, dst, kb::escale(reg_load_e(regs, bd, tid, ra), ZKM_REG(rb, 0))); break;
-      case 32: acc = kb::eadd(acc, kb::escale(a.alpha_pows[cidx++], ZKM_REG(ra, 0))); break;
-      case 33: acc = kb::eadd(acc, kb::emul(a.alpha_pows[cidx++], reg_load_e(regs, bd, tid, ra))); break;
+      case 4: RB(dst) = imm; break;
+      case 5: RB(dst) = a.public_values[imm]; break;
+      case 6: RE(dst) = imm ? a.perm_beta : a.perm_alpha; break;
+      case 7: RE(dst) = a.local_sum; break;
+      case 8: RB(dst) = a.consts[imm]; break;
+      case 9: RB(dst) = is_first; break;
+      case 10: RB(dst) = is_last; break;
+      case 11: RB(dst) = is_trans; break;
+      case 16: RB(dst) = kb::add(RB(ra), RB(rb)); break;
+      case 17: RB(dst) = kb::sub(RB(ra), RB(rb)); break;
+      case 18: RB(dst) = kb::mul(RB(ra), RB(rb)); break;
+      case 19: RB(dst) = kb::neg(RB(ra)); break;
+      case 20: RE(dst) = kb::eadd(RE(ra), RE(rb)); break;
+      case 21: RE(dst) = kb::esub(RE(ra), RE(rb)); break;
+      case 22: RE(dst) = kb::emul(RE(ra), RE(rb)); break;
+      case 23: RE(dst) = kb::eneg(RE(ra)); break;
+      case 24: RE(dst) = kb::eadd_base(RE(ra), RB(rb)); break;
+      case 25: RE(dst) = kb::esub_base(RE(ra), RB(rb)); break;
+      case 26: RE(dst) = kb::escale(RE(ra), RB(rb)); break;
+      case 32: acc = kb::eadd(acc, kb::escale(a.alpha_pows[cidx++], RB(ra))); break;
+      case 33: acc = kb::eadd(acc, kb::emul(a.alpha_pows[cidx++], RE(ra))); break;
       default: break;
     }
   }
+#undef RE
+#undef RB
   kb::E4 q = kb::escale(acc, a.consts[24 + (i & ((1u << a.lqd) - 1))]);
   // split_evals (prover.rs:477-488): chunk c = i mod 2^lqd, row j = i >> lqd
   size_t n = (size_t)1 << a.log_n;
@@ -221,6 +221,5 @@ __global__ void quotient_kernel(QuotientArgs a) {
 #pragma unroll
   for (int e = 0; e < 4; e++) a.out[((size_t)c * 4 + e) * n + j] = q.c[e];
 }
-#undef ZKM_REG
 
 }  // namespace stark

@@ -98,7 +98,7 @@ struct zkm_ctx {
   std::mutex mu;
   std::multimap<size_t, void*> free_list;  // caching allocator: exact-size reuse
   std::map<void*, size_t> live;
-  std::map<int, uint32_t*> tw_fwd, tw_inv;  // tw[j] = w^(+-j), j < 2^(log-1), per transform log-size
+  std::map<int, uint32_t*> tw_fwd, tw_inv;  // stage-major twiddle tables (lde.cuh), per transform log-size
   std::vector<std::pair<std::string, hipEvent_t>> marks;
   std::vector<hipEvent_t> event_pool;
   std::vector<std::string> timing_names;
@@ -183,13 +183,15 @@ struct zkm_ctx {
     auto& tab = inverse ? tw_inv : tw_fwd;
     auto it = tab.find(log_size);
     if (it != tab.end()) return it->second;
-    size_t count = log_size > 0 ? (size_t)1 << (log_size - 1) : 1;
+    size_t count = (size_t)1 << log_size;  // stage-major table: n - 1 entries
     uint32_t* d;
     HIP_CHECK(hipMalloc(&d, count * 4));
     uint32_t w = kb::two_adic_generator(log_size);
     if (inverse) w = kb::inv(w);
-    hipLaunchKernelGGL(lde::fill_powers, dim3(div_up(count, 256)), dim3(256), 0, stream, d, w, count);
-    LAUNCH_CHECK();
+    if (log_size > 0) {
+      hipLaunchKernelGGL(lde::fill_stage_twiddles, dim3(div_up(count / 2, 256), log_size), dim3(256), 0, stream, d, w, log_size);
+      LAUNCH_CHECK();
+    }
     tab[log_size] = d;
     return d;
   }
@@ -246,7 +248,7 @@ static void lde_columns(zkm_ctx* ctx, const uint32_t* in, size_t n, size_t w, in
   uint32_t w_n = kb::two_adic_generator(k), w_n_inv = kb::inv(w_n), w_N = kb::two_adic_generator(k + bl);
   uint32_t n_inv = kb::inv(kb::to_monty((uint32_t)(n % kb::P)));
   int nhi = B > 64 ? (int)(B >> 6) : 1;
-  size_t rows_lds = (2 * B + 2 * 64 + 2 * nhi) * 4;
+  size_t rows_lds = (2 * (B + (B >> 5)) + 2 * 64 + 2 * nhi) * 4;
   const uint32_t* twf = lb > 0 ? ctx->twiddles(lb, false) : nullptr;
   const uint32_t* twi = lb > 0 ? ctx->twiddles(lb, true) : nullptr;
   if (la == 0) {
@@ -307,8 +309,17 @@ static void build_tree(zkm_ctx* ctx, const std::vector<zkm_matrix>& mats, Tree& 
     KLAUNCH(ctx, "hash_leaves", 4.0 * maxh * ptrs.size() + 32.0 * maxh, merkle::hash_leaves, dim3(div_up(maxh, merkle::THREADS)),
             dim3(merkle::THREADS), 0, d, (int)ptrs.size(), maxh, t.digests);
   }
+  // the top of the tree (<= TAIL nodes per layer, no shorter matrix to inject) goes in one launch
+  const size_t TAIL = 512;
+  size_t min_h = maxh;
+  for (auto& m : mats) min_h = std::min(min_h, m.h);
   int layer = 0;
   for (size_t len = maxh / 2; len >= 1; len >>= 1, layer++) {
+    if (len <= TAIL && min_h > len) {
+      KLAUNCH(ctx, "compress_tail", 96.0 * len, merkle::compress_tail, dim3(1), dim3(merkle::THREADS), 0,
+              t.digests + t.layer_off[layer] * 8, len);
+      break;
+    }
     auto ptrs = cols_of_height(len);
     const uint32_t** d = nullptr;
     if (!ptrs.empty()) { d = upload_ptrs(ctx, ptrs); to_free.push_back(d); }
@@ -546,9 +557,11 @@ static void open_impl(zkm_ctx* ctx, const zkm_pk* pk, zkm_main_data* md, const z
     a.consts = d_consts;
     a.w_q = w_q; a.g_inv = kb::inv(kb::two_adic_generator(c.log_n));
     a.out = qbuf;
-    int bd = 128;
-    while ((size_t)a.n_regs * 16 * bd > 160 * 1024 && bd > 64) bd >>= 1;
-    size_t lds = (size_t)a.n_regs * 16 * bd;
+    a.n_base_regs = d->program_len ? std::max<uint32_t>(d->program[3], 1) : 1;
+    size_t per_thread = (size_t)a.n_regs * 16 + (size_t)a.n_base_regs * 4;
+    int bd = 256;
+    while (per_thread * bd > 64 * 1024 && bd > 64) bd >>= 1;
+    size_t lds = per_thread * bd;
     if (lds > 160 * 1024) throw std::runtime_error(std::string("constraint program of chip ") + d->name + " needs too many registers");
     KLAUNCH(ctx, "quotient", 4.0 * Q * (d->main_width + d->prep_width + 4.0 * c.perm_ext_w) + 16.0 * Q, stark::quotient_kernel,
             dim3(div_up(Q, bd)), dim3(bd), lds, a);
@@ -593,10 +606,13 @@ static void open_impl(zkm_ctx* ctx, const zkm_pk* pk, zkm_main_data* md, const z
   // (i) evaluate every column at zeta (and zeta * g): barycentric weights shared per (height, shift)
   {
     std::map<std::pair<size_t, uint32_t>, E4*> wcache;
-    const unsigned SPLIT = 32;
+    size_t total_y = 0;
+    for (auto& r : rounds) for (auto& m : r.mats) total_y += m.width * 2;
+    E4* d_y = (E4*)salloc(std::max<size_t>(total_y, 1) * sizeof(E4));
+    size_t ypos = 0;
     for (auto& r : rounds)
       for (auto& m : r.mats) {
-        if (m.width == 0) { m.y[0].clear(); m.y[1].clear(); continue; }
+        if (m.width == 0) continue;
         auto key = std::make_pair(m.n, m.shift);
         E4* wts;
         auto it = wcache.find(key);
@@ -609,18 +625,41 @@ static void open_impl(zkm_ctx* ctx, const zkm_pk* pk, zkm_main_data* md, const z
                   kb::two_adic_generator(ln), m.n, wts);
           wcache[key] = wts;
         } else wts = it->second;
-        unsigned split = (unsigned)std::min<size_t>(SPLIT, std::max<size_t>(1, m.n / open::THREADS));
-        E4* partials = (E4*)salloc((size_t)split * m.width * 2 * sizeof(E4));
-        KLAUNCH(ctx, "eval_columns", 4.0 * m.n * m.width + 16.0 * m.n, open::eval_columns, dim3(div_up(m.width, open::EVAL_COLS), split),
-                dim3(open::THREADS), 0, m.evals, m.n, (int)m.width, (const E4*)wts, m.n_points > 1 ? 1 : 0, partials);
-        std::vector<E4> hp((size_t)split * m.width * 2);
-        HIP_CHECK(hipMemcpyAsync(hp.data(), partials, hp.size() * sizeof(E4), hipMemcpyDeviceToHost, st));
-        HIP_CHECK(hipStreamSynchronize(st));
-        for (int pt = 0; pt < m.n_points; pt++) {
-          m.y[pt].assign(m.width, kb::ezero());
-          for (unsigned s = 0; s < split; s++)
-            for (size_t c = 0; c < m.width; c++) m.y[pt][c] = kb::eadd(m.y[pt][c], hp[((size_t)s * m.width + c) * 2 + pt]);
+        unsigned groups = div_up(m.width, open::EVAL_COLS);
+        unsigned split = 1;
+        E4* partials;
+        double ebytes = 4.0 * m.n * m.width + 16.0 * m.n;
+        if (m.n >= 4 * open::THREADS) {
+          split = (unsigned)std::min<size_t>(std::max<size_t>(1, 2048 / groups), m.n / (4 * open::THREADS));
+          partials = (E4*)salloc((size_t)split * m.width * 2 * sizeof(E4));
+          if (m.n_points > 1)
+            KLAUNCH(ctx, "eval_columns", ebytes, open::eval_columns<true>, dim3(groups, split), dim3(open::THREADS), 0, m.evals, m.n,
+                    (int)m.width, (const E4*)wts, partials);
+          else
+            KLAUNCH(ctx, "eval_columns", ebytes, open::eval_columns<false>, dim3(groups, split), dim3(open::THREADS), 0, m.evals, m.n,
+                    (int)m.width, (const E4*)wts, partials);
+        } else {
+          partials = (E4*)salloc((size_t)m.width * 2 * sizeof(E4));
+          KLAUNCH(ctx, "eval_columns", ebytes, open::eval_columns_small, dim3(groups, 1), dim3(open::THREADS), 0, m.evals, m.n,
+                  (int)m.width, (const E4*)wts, m.n_points > 1 ? 1 : 0, partials);
         }
+        KLAUNCH(ctx, "eval_columns", 0.0, open::reduce_partials, dim3(div_up(m.width * 2, open::THREADS)), dim3(open::THREADS), 0,
+                (const E4*)partials, (int)split, (int)(m.width * 2), d_y + ypos);
+        ypos += m.width * 2;
+      }
+    std::vector<E4> hy(total_y);
+    if (total_y) HIP_CHECK(hipMemcpyAsync(hy.data(), d_y, total_y * sizeof(E4), hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    ypos = 0;
+    for (auto& r : rounds)
+      for (auto& m : r.mats) {
+        for (int pt = 0; pt < 2; pt++) m.y[pt].clear();
+        if (m.width == 0) continue;
+        for (int pt = 0; pt < m.n_points; pt++) {
+          m.y[pt].resize(m.width);
+          for (size_t c = 0; c < m.width; c++) m.y[pt][c] = hy[ypos + c * 2 + pt];
+        }
+        ypos += m.width * 2;
       }
   }
   ctx->mark("open: evaluations");
@@ -688,6 +727,11 @@ static void open_impl(zkm_ctx* ctx, const zkm_pk* pk, zkm_main_data* md, const z
             (const E4*)f, half, t.digests);
     int layer = 0;
     for (size_t l = half / 2; l >= 1; l >>= 1, layer++) {
+      if (l <= 512) {
+        KLAUNCH(ctx, "compress_tail", 96.0 * l, merkle::compress_tail, dim3(1), dim3(merkle::THREADS), 0,
+                t.digests + t.layer_off[layer] * 8, l);
+        break;
+      }
       KLAUNCH(ctx, "compress_layer", 96.0 * l, merkle::compress_layer, dim3(div_up(l, merkle::THREADS)), dim3(merkle::THREADS), 0,
               (const uint32_t*)(t.digests + t.layer_off[layer] * 8), t.digests + t.layer_off[layer + 1] * 8, l,
               (const uint32_t* const*)nullptr, 0);
