@@ -55,21 +55,16 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    dist = None
-    if world > 1:
-        import torch
-        import torch.distributed as dist_mod
-        torch.cuda.set_device(local_rank)
-        dist_mod.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-        dist = dist_mod
+    from ziren_amd import farm as farm_mod
+    hp_holder = {}
+    farm = farm_mod.Farm(device_sync=lambda: hp_holder["hp"].ctx.synchronize() if "hp" in hp_holder else None)
+    rank, local_rank, world = farm.rank, farm.local_rank, farm.world
 
     fri = abi.FriConfig(1, 84, 16)  # core config, crates/stark/src/kb31_poseidon2.rs:203-213
     k = args.log_rows
     shard = synth.syn_shard(k, seed=0x5A4B4D00 + 1000 * rank)
     hp = prover.HipProver(shard.chips, fri, synth.NUM_PV_ELTS, device=local_rank)
+    hp_holder["hp"] = hp
     pk = hp.setup([], [], shard.pc_start, shard.initial_global_cumulative_sum)
     base_ch = prover.new_challenger()
     pk.observe_into(base_ch)
@@ -78,24 +73,14 @@ def main():
         c.trace = None
     out = np.zeros(1 << 22, dtype=np.uint32)
 
-    def barrier():
-        hp.ctx.synchronize()
-        if dist is not None:
-            import torch
-            dist.barrier()
-            torch.cuda.synchronize()
-
     def step():
         ch = base_ch.copy()  # challenger cloned per shard (prove.rs:496)
         return hp.prove_shard(pk, shard.public_values, traces, ch, out=out)
 
-    for _ in range(args.warmup):
-        step()
     phase_acc = {}
     kern_acc = {}
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
+
+    def timed_step():
         step()
         for name, ms in hp.ctx.last_timings():
             phase_acc[name] = phase_acc.get(name, 0.0) + ms
@@ -104,13 +89,10 @@ def main():
             a[0] += ms
             a[1] += calls
             a[2] += nbytes
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        import torch
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+
+    for _ in range(args.warmup):
+        step()
+    elapsed = farm.timed(timed_step, steps=args.steps, warmup=0)
 
     if rank == 0:
         steps = args.steps
@@ -155,8 +137,7 @@ def main():
                                sorted(kern_acc.items(), key=lambda kv: -kv[1][0])},
                 "roofline": roofline, "cpu_baseline": cpu}
         print(json.dumps(line))
-    if dist is not None:
-        dist.destroy_process_group()
+    farm.close()
 
 
 if __name__ == "__main__":

@@ -96,6 +96,23 @@ def test_pcs_commit_shifted_domains(hip_ctx, oracle):
     assert np.array_equal(d.root, root_o)
 
 
+@pytest.mark.parametrize("log_blowup,queries", [(2, 42), (3, 28)])
+def test_recursion_fri_configs_bit_exact(hip_ctx, oracle, log_blowup, queries):
+    # compress / shrink shards go through the same commit+open with the compressed FRI configs
+    # (crates/stark/src/kb31_poseidon2.rs:215-241: blowup 4 / 42 queries, blowup 8 / 28 queries)
+    sh = synth.syn_shard(8, with_prep=True)
+    fri = abi.FriConfig(log_blowup, queries, 16)
+    pk, start, ch, proof = _gpu_prove(hip_ctx, sh, fri, True)
+    prep = [c.prep_trace for c in sh.chips if c.prep_width]
+    opk = oracle.Pk(prep, [0] * len(prep), sh.pc_start, sh.initial_global_cumulative_sum, log_blowup)
+    och = oracle.new_challenger()
+    opk.observe_into(och)
+    oproof, _ = oracle.prove_shard(opk, sh.chips, [c.trace for c in sh.chips], sh.public_values, fri,
+                                   synth.NUM_PV_ELTS, och)
+    assert np.array_equal(proof, oproof)
+    assert oracle.verify_shard(opk, sh.chips, fri, synth.NUM_PV_ELTS, start.copy(), proof) == 0
+
+
 def _gpu_prove(ctx, sh, fri, use_prove_shard):
     prep = [c.prep_trace for c in sh.chips if c.prep_width]
     hp = prover.HipProver(sh.chips, fri, synth.NUM_PV_ELTS, ctx=ctx)

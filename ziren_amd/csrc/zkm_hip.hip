@@ -630,7 +630,7 @@ static void open_impl(zkm_ctx* ctx, const zkm_pk* pk, zkm_main_data* md, const z
         E4* partials;
         double ebytes = 4.0 * m.n * m.width + 16.0 * m.n;
         if (m.n >= 4 * open::THREADS) {
-          split = (unsigned)std::min<size_t>(std::max<size_t>(1, 2048 / groups), m.n / (4 * open::THREADS));
+          split = (unsigned)std::min<size_t>(std::max<size_t>(1, 8192 / groups), m.n / (4 * open::THREADS));
           partials = (E4*)salloc((size_t)split * m.width * 2 * sizeof(E4));
           if (m.n_points > 1)
             KLAUNCH(ctx, "eval_columns", ebytes, open::eval_columns<true>, dim3(groups, split), dim3(open::THREADS), 0, m.evals, m.n,

@@ -1,5 +1,6 @@
 """ctypes loader for libzkm_hip.so (the C ABI of include/zkm_hip.h)."""
 import ctypes as C
+import importlib.util
 import os
 
 from . import abi
@@ -24,6 +25,25 @@ class ZkmError(RuntimeError):
     pass
 
 
+def _preload_hip_runtime():
+    """One HIP runtime per process. PyTorch-ROCm bundles its own libamdhip64.so (same SONAME as the
+    system one); if our library pulled in /opt/rocm's copy first, a later `import torch` (bench.py uses
+    torch.distributed for N > 1) would load a second runtime and find no GPU. Loading torch's copy first,
+    when torch is installed, makes both bind to the same runtime regardless of import order."""
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    path = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(path):
+        try:
+            C.CDLL(path, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def load():
     """Load the in-tree HIP library. Fails loudly if it has not been built: there is no fallback."""
     global _LIB
@@ -31,6 +51,7 @@ def load():
         return _LIB
     if not os.path.exists(LIB_PATH):
         raise ZkmError(f"{LIB_PATH} is missing: run `python -m ziren_amd.build` (or __graft_entry__.build())")
+    _preload_hip_runtime()
     L = C.CDLL(LIB_PATH)
     L.zkm_last_error.restype = C.c_char_p
     L.zkm_matrix_height.restype = C.c_size_t
