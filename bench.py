@@ -53,6 +53,7 @@ def main():
     ap.add_argument("--log-rows", type=int, default=22)
     ap.add_argument("--cpu-sample-log-rows", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--interpreter", action="store_true", help="use the bytecode interpreter instead of per-chip quotient kernels")
     args = ap.parse_args()
 
     from ziren_amd import farm as farm_mod
@@ -63,7 +64,7 @@ def main():
     fri = abi.FriConfig(1, 84, 16)  # core config, crates/stark/src/kb31_poseidon2.rs:203-213
     k = args.log_rows
     shard = synth.syn_shard(k, seed=0x5A4B4D00 + 1000 * rank)
-    hp = prover.HipProver(shard.chips, fri, synth.NUM_PV_ELTS, device=local_rank)
+    hp = prover.HipProver(shard.chips, fri, synth.NUM_PV_ELTS, device=local_rank, specialize=not args.interpreter)
     hp_holder["hp"] = hp
     pk = hp.setup([], [], shard.pc_start, shard.initial_global_cumulative_sum)
     base_ch = prover.new_challenger()

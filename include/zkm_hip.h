@@ -140,6 +140,12 @@ int zkm_ctx_last_timings(zkm_ctx* ctx, const char** names, float* ms, int cap);
  * compulsory HBM bytes (each input/output array of a launch counted once). Returns the count. */
 int zkm_ctx_kernel_timings(zkm_ctx* ctx, const char** names, float* ms, uint32_t* calls, double* bytes, int cap);
 void zkm_ctx_set_kernel_timing(zkm_ctx* ctx, int enabled);
+/* Register a chip-specialised quotient kernel: a gfx950 code object exporting
+ * `zkm_quotient_specialized(stark::QuotientArgs)` generated from exactly these program words
+ * (ziren_amd/codegen.py; the Rust shim does this once per chip AIR). zkm_open uses it for chips whose
+ * program matches and the bytecode interpreter otherwise; both compute the same values. */
+int zkm_ctx_register_quotient_kernel(zkm_ctx* ctx, const uint32_t* program, uint32_t program_len,
+                                     const void* code_object, size_t code_object_len);
 
 /* ---- DeviceMatrix ----------------------------------------------------------------------- */
 /* Upload a row-major host matrix (height a power of two) and lay it out column-major in HBM. */

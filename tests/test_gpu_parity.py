@@ -113,9 +113,29 @@ def test_recursion_fri_configs_bit_exact(hip_ctx, oracle, log_blowup, queries):
     assert oracle.verify_shard(opk, sh.chips, fri, synth.NUM_PV_ELTS, start.copy(), proof) == 0
 
 
-def _gpu_prove(ctx, sh, fri, use_prove_shard):
+def test_specialized_quotient_kernels_match_interpreter_and_oracle(oracle):
+    # per-chip generated kernels (ziren_amd/codegen.py) vs the bytecode interpreter vs the oracle
+    ctx = prover.Context(0)  # fresh context: nothing registered yet
+    try:
+        sh = synth.syn_shard(10, with_prep=True)
+        fri = abi.FriConfig(1, 16, 8)
+        _, _, _, p_interp = _gpu_prove(ctx, sh, fri, True)
+        _, start, _, p_spec = _gpu_prove(ctx, sh, fri, True, specialize=True)
+        assert np.array_equal(p_interp, p_spec)
+        prep = [c.prep_trace for c in sh.chips if c.prep_width]
+        opk = oracle.Pk(prep, [0] * len(prep), sh.pc_start, sh.initial_global_cumulative_sum, 1)
+        och = oracle.new_challenger()
+        opk.observe_into(och)
+        oproof, _ = oracle.prove_shard(opk, sh.chips, [c.trace for c in sh.chips], sh.public_values, fri,
+                                       synth.NUM_PV_ELTS, och)
+        assert np.array_equal(p_spec, oproof)
+    finally:
+        ctx.close()
+
+
+def _gpu_prove(ctx, sh, fri, use_prove_shard, specialize=False):
     prep = [c.prep_trace for c in sh.chips if c.prep_width]
-    hp = prover.HipProver(sh.chips, fri, synth.NUM_PV_ELTS, ctx=ctx)
+    hp = prover.HipProver(sh.chips, fri, synth.NUM_PV_ELTS, ctx=ctx, specialize=specialize)
     pk = hp.setup(prep, [0] * len(prep), sh.pc_start, sh.initial_global_cumulative_sum)
     ch = prover.new_challenger()
     pk.observe_into(ch)

@@ -31,6 +31,8 @@ KB_HD uint32_t sub(uint32_t a, uint32_t b) {
   uint32_t d = a - b;
   return umin32(d, d + P);
 }
+// a - b + p in (0, 2p): not reduced; valid only as the `a` operand of mul (a < 2^32, b < p suffices)
+KB_HD uint32_t sub_lazy(uint32_t a, uint32_t b) { return a - b + P; }
 KB_HD uint32_t neg(uint32_t a) { return a ? P - a : 0u; }
 KB_HD uint32_t dbl(uint32_t a) { return add(a, a); }
 

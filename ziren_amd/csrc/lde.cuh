@@ -69,7 +69,7 @@ __device__ __forceinline__ void ntt_pass(uint32_t* buf, int logn, int lognb, int
         uint32_t a = x[j0], b = x[j1];
         if (DIF) {
           x[j0] = kb::add(a, b);
-          x[j1] = kb::mul(kb::sub(a, b), w);
+          x[j1] = kb::mul(kb::sub_lazy(a, b), w);
         } else {
           b = kb::mul(b, w);
           x[j0] = kb::add(a, b);

@@ -31,35 +31,42 @@ __global__ __launch_bounds__(THREADS) void bary_weights(kb::E4 u, kb::E4 c, uint
 // One partial per block: partials[(by * width + col) * 2 + {0,1}].
 constexpr int EVAL_COLS = 4;
 
+// Block-wide sum of the 8 * EVAL_COLS accumulator words: every thread parks its words in LDS
+// (word-major, conflict-free), 8 threads per word add 32-entry segments, one thread per word finishes.
+constexpr int EVAL_WORDS = EVAL_COLS * 8;
 __device__ __forceinline__ void block_reduce_store(kb::E4 (&acc)[EVAL_COLS][2], int c0, int width, kb::E4* __restrict__ partials,
-                                                   uint32_t* red) {
+                                                   uint32_t* lds /* EVAL_WORDS * THREADS + EVAL_WORDS * 8 */) {
+  const int tid = threadIdx.x;
 #pragma unroll
-  for (int c = 0; c < EVAL_COLS; c++) {
+  for (int c = 0; c < EVAL_COLS; c++)
 #pragma unroll
-    for (int pt = 0; pt < 2; pt++) {
-      kb::E4 tot;
+    for (int pt = 0; pt < 2; pt++)
 #pragma unroll
-      for (int e = 0; e < 4; e++) {
-        // wave reduction through DPP-free shuffles, then one LDS exchange across the 4 waves
-        uint32_t v = acc[c][pt].c[e];
+      for (int e = 0; e < 4; e++) lds[((c * 2 + pt) * 4 + e) * THREADS + tid] = acc[c][pt].c[e];
+  __syncthreads();
+  uint32_t* seg = lds + EVAL_WORDS * THREADS;
+  {
+    const int word = tid >> 3, part = tid & 7;  // THREADS / 8 == EVAL_WORDS
+    const uint32_t* src = lds + word * THREADS + part * (THREADS / 8);
+    uint32_t t = 0;
+#pragma unroll 8
+    for (int k = 0; k < THREADS / 8; k++) t = kb::add(t, src[k]);
+    seg[word * 8 + part] = t;
+  }
+  __syncthreads();
+  if (tid < EVAL_WORDS) {
+    uint32_t t = 0;
 #pragma unroll
-        for (int d = 32; d > 0; d >>= 1) v = kb::add(v, __shfl_xor(v, d));
-        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-        __syncthreads();
-        uint32_t t = red[0];
-        for (int w = 1; w < THREADS / 64; w++) t = kb::add(t, red[w]);
-        tot.c[e] = t;
-        __syncthreads();
-      }
-      if (threadIdx.x == 0 && c0 + c < width) partials[((size_t)blockIdx.y * width + c0 + c) * 2 + pt] = tot;
-    }
+    for (int k = 0; k < 8; k++) t = kb::add(t, seg[tid * 8 + k]);
+    const int c = tid >> 3, pt = (tid >> 2) & 1, e = tid & 3;
+    if (c0 + c < width) partials[((size_t)blockIdx.y * width + c0 + c) * 2 + pt].c[e] = t;
   }
 }
 
 template <bool TWO>
 __global__ __launch_bounds__(THREADS) void eval_columns(const uint32_t* __restrict__ mat, size_t n, int width,
                                                         const kb::E4* __restrict__ weights, kb::E4* __restrict__ partials) {
-  __shared__ uint32_t red[THREADS / 64];
+  __shared__ uint32_t red[EVAL_WORDS * THREADS + EVAL_WORDS * 8];
   const int c0 = blockIdx.x * EVAL_COLS;
   const uint32_t* cols[EVAL_COLS];
 #pragma unroll
@@ -97,7 +104,7 @@ __global__ __launch_bounds__(THREADS) void eval_columns(const uint32_t* __restri
 __global__ __launch_bounds__(THREADS) void eval_columns_small(const uint32_t* __restrict__ mat, size_t n, int width,
                                                               const kb::E4* __restrict__ weights, int two_points,
                                                               kb::E4* __restrict__ partials) {
-  __shared__ uint32_t red[THREADS / 64];
+  __shared__ uint32_t red[EVAL_WORDS * THREADS + EVAL_WORDS * 8];
   const int c0 = blockIdx.x * EVAL_COLS;
   kb::E4 acc[EVAL_COLS][2];
 #pragma unroll
@@ -115,14 +122,20 @@ __global__ __launch_bounds__(THREADS) void eval_columns_small(const uint32_t* __
   block_reduce_store(acc, c0, width, partials, red);
 }
 
-// out[i] = sum_s partials[s * count + i]
-__global__ __launch_bounds__(THREADS) void reduce_partials(const kb::E4* __restrict__ partials, int split, int count,
-                                                           kb::E4* __restrict__ out) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= count) return;
+// out[i] = sum_s partials[s * count + i]; one 64-lane block per output element
+__global__ __launch_bounds__(64) void reduce_partials(const kb::E4* __restrict__ partials, int split, int count,
+                                                      kb::E4* __restrict__ out) {
+  const int i = blockIdx.x;
   kb::E4 acc = kb::ezero();
-  for (int s = 0; s < split; s++) acc = kb::eadd(acc, partials[(size_t)s * count + i]);
-  out[i] = acc;
+  for (int s = threadIdx.x; s < split; s += 64) acc = kb::eadd(acc, partials[(size_t)s * count + i]);
+#pragma unroll
+  for (int e = 0; e < 4; e++) {
+    uint32_t v = acc.c[e];
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v = kb::add(v, __shfl_xor(v, d));
+    acc.c[e] = v;
+  }
+  if (threadIdx.x == 0) out[i] = acc;
 }
 
 // Reduced openings for one LDE height N (fri.rs:103-204). One thread per stored row r

@@ -12,6 +12,7 @@
 // wave-uniform and comes through the scalar/constant path.
 #pragma once
 #include "kb31.cuh"
+#include "quotient_args.cuh"
 
 namespace stark {
 
@@ -125,26 +126,6 @@ __global__ __launch_bounds__(THREADS) void scan_add_offsets(uint32_t* __restrict
 }
 
 // ---- quotient -------------------------------------------------------------------------------
-struct QuotientArgs {
-  const uint32_t* program;   // 2 words per instruction (header stripped)
-  int n_instr;
-  int n_regs;                // extension registers
-  int n_base_regs;
-  const uint32_t* main_lde;  // column-major, height N (bit-reversed rows)
-  const uint32_t* prep_lde;
-  const uint32_t* perm_lde;
-  size_t main_stride, prep_stride, perm_stride;  // words per column (= LDE height)
-  int log_n;                 // trace height
-  int lqd;                   // quotient domain = n << lqd
-  const kb::E4* alpha_pows;  // alpha_pows[k] multiplies constraint k (already reversed: alpha^(C-1-k))
-  const uint32_t* public_values;
-  kb::E4 perm_alpha, perm_beta;
-  kb::E4 local_sum;
-  const uint32_t* consts;    // device: [0,14) global_cumulative_sum, [16,24) Z_H by (i mod 2^lqd), [24,32) 1/Z_H
-  uint32_t w_q;              // generator of the quotient domain, order n << lqd
-  uint32_t g_inv;            // inverse of the trace-domain generator
-  uint32_t* out;             // chunk c, coefficient e, row j at out[(c * 4 + e) * n + j]
-};
 
 // Register files in LDS, one slot per thread: extension registers as 16-byte words at
 // regs_e[r * blockDim + t] (ds_read/write_b128, conflict-free), base registers at regs_b[r * blockDim + t].
@@ -157,19 +138,10 @@ __global__ void quotient_kernel(QuotientArgs a) {
   uint32_t* regs_b = reinterpret_cast<uint32_t*>(lds4 + (size_t)a.n_regs * bd);
 #define RE(r) regs_e[(r) * bd + tid]
 #define RB(r) regs_b[(r) * bd + tid]
-  const int lq = a.log_n + a.lqd;
-  const size_t Q = (size_t)1 << lq;
-  size_t p = (size_t)blockIdx.x * bd + tid;
-  if (p >= Q) return;
-  uint32_t i = kb::bitrev((uint32_t)p, lq);
-  size_t pn = kb::bitrev((uint32_t)((i + (1u << a.lqd)) & (Q - 1)), lq);
-
-  // selectors at x = 3 * w_Q^i for the trace domain H_n (domain.rs:46-64)
-  uint32_t x = kb::mul(kb::GEN, kb::pow(a.w_q, (uint64_t)i));
-  uint32_t zh = a.consts[16 + (i & ((1u << a.lqd) - 1))];
-  uint32_t is_first = kb::mul(zh, kb::inv(kb::sub(x, kb::ONE)));
-  uint32_t is_trans = kb::sub(x, a.g_inv);
-  uint32_t is_last = kb::mul(zh, kb::inv(is_trans));
+  QuotientPoint qp;
+  if (!quotient_point(a, (size_t)blockIdx.x * bd + tid, qp)) return;
+  const size_t p = qp.p, pn = qp.pn;
+  const uint32_t is_first = qp.is_first, is_last = qp.is_last, is_trans = qp.is_trans;
 
   kb::E4 acc = kb::ezero();
   int cidx = 0;
@@ -213,13 +185,7 @@ __global__ void quotient_kernel(QuotientArgs a) {
   }
 #undef RE
 #undef RB
-  kb::E4 q = kb::escale(acc, a.consts[24 + (i & ((1u << a.lqd) - 1))]);
-  // split_evals (prover.rs:477-488): chunk c = i mod 2^lqd, row j = i >> lqd
-  size_t n = (size_t)1 << a.log_n;
-  uint32_t c = i & ((1u << a.lqd) - 1);
-  size_t j = i >> a.lqd;
-#pragma unroll
-  for (int e = 0; e < 4; e++) a.out[((size_t)c * 4 + e) * n + j] = q.c[e];
+  quotient_store(a, qp, acc);
 }
 
 }  // namespace stark

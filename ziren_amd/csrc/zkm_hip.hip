@@ -57,6 +57,12 @@ static inline int log2_strict(size_t n) {
   return k;
 }
 static inline unsigned div_up(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }
+static inline uint64_t fnv1a(const uint32_t* w, size_t n) {
+  uint64_t h = 1469598103934665603ull;
+  const unsigned char* p = (const unsigned char*)w;
+  for (size_t i = 0; i < n * 4; i++) { h ^= p[i]; h *= 1099511628211ull; }
+  return h;
+}
 
 // ---- host transcript: DuplexChallenger<KoalaBear, Poseidon2, 16, 8> -----------------------------
 // crates/recursion/circuit/src/challenger.rs:90-114,201-233
@@ -109,6 +115,9 @@ struct zkm_ctx {
   std::vector<KRec> krecs;
   std::map<std::string, KStat> kstats;
   bool kernel_timing = true;
+  // per-chip specialised quotient kernels (ziren_amd/codegen.py), keyed by a hash of the program words
+  std::map<uint64_t, hipFunction_t> quotient_fns;
+  std::vector<hipModule_t> modules;
   hipEvent_t get_event() {
     hipEvent_t e;
     if (!event_pool.empty()) { e = event_pool.back(); event_pool.pop_back(); }
@@ -563,8 +572,18 @@ static void open_impl(zkm_ctx* ctx, const zkm_pk* pk, zkm_main_data* md, const z
     while (per_thread * bd > 64 * 1024 && bd > 64) bd >>= 1;
     size_t lds = per_thread * bd;
     if (lds > 160 * 1024) throw std::runtime_error(std::string("constraint program of chip ") + d->name + " needs too many registers");
-    KLAUNCH(ctx, "quotient", 4.0 * Q * (d->main_width + d->prep_width + 4.0 * c.perm_ext_w) + 16.0 * Q, stark::quotient_kernel,
-            dim3(div_up(Q, bd)), dim3(bd), lds, a);
+    double qbytes = 4.0 * Q * (d->main_width + d->prep_width + 4.0 * c.perm_ext_w) + 16.0 * Q;
+    auto fit = d->program_len ? ctx->quotient_fns.find(fnv1a(d->program, d->program_len)) : ctx->quotient_fns.end();
+    if (fit != ctx->quotient_fns.end()) {
+      // chip-specialised kernel: same arithmetic, values in VGPRs
+      size_t arg_size = sizeof(a);
+      void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &arg_size, HIP_LAUNCH_PARAM_END};
+      ctx->kbegin("quotient", qbytes);
+      HIP_CHECK(hipModuleLaunchKernel(fit->second, div_up(Q, 256), 1, 1, 256, 1, 1, 0, st, nullptr, config));
+      ctx->kend();
+    } else {
+      KLAUNCH(ctx, "quotient", qbytes, stark::quotient_kernel, dim3(div_up(Q, bd)), dim3(bd), lds, a);
+    }
     uint32_t wqp = kb::ONE;
     for (size_t k = 0; k < nchunks; k++) {
       zkm_matrix m; m.h = c.n; m.w = 4; m.d = qbuf + k * 4 * c.n; m.owned = (k == 0);
@@ -630,7 +649,7 @@ static void open_impl(zkm_ctx* ctx, const zkm_pk* pk, zkm_main_data* md, const z
         E4* partials;
         double ebytes = 4.0 * m.n * m.width + 16.0 * m.n;
         if (m.n >= 4 * open::THREADS) {
-          split = (unsigned)std::min<size_t>(std::max<size_t>(1, 8192 / groups), m.n / (4 * open::THREADS));
+          split = (unsigned)std::min<size_t>(std::max<size_t>(1, 3072 / groups), m.n / (4 * open::THREADS));
           partials = (E4*)salloc((size_t)split * m.width * 2 * sizeof(E4));
           if (m.n_points > 1)
             KLAUNCH(ctx, "eval_columns", ebytes, open::eval_columns<true>, dim3(groups, split), dim3(open::THREADS), 0, m.evals, m.n,
@@ -643,8 +662,8 @@ static void open_impl(zkm_ctx* ctx, const zkm_pk* pk, zkm_main_data* md, const z
           KLAUNCH(ctx, "eval_columns", ebytes, open::eval_columns_small, dim3(groups, 1), dim3(open::THREADS), 0, m.evals, m.n,
                   (int)m.width, (const E4*)wts, m.n_points > 1 ? 1 : 0, partials);
         }
-        KLAUNCH(ctx, "eval_columns", 0.0, open::reduce_partials, dim3(div_up(m.width * 2, open::THREADS)), dim3(open::THREADS), 0,
-                (const E4*)partials, (int)split, (int)(m.width * 2), d_y + ypos);
+        KLAUNCH(ctx, "reduce_partials", 0.0, open::reduce_partials, dim3((unsigned)(m.width * 2)), dim3(64), 0, (const E4*)partials,
+                (int)split, (int)(m.width * 2), d_y + ypos);
         ypos += m.width * 2;
       }
     std::vector<E4> hy(total_y);
@@ -934,6 +953,7 @@ void zkm_ctx_destroy(zkm_ctx* ctx) {
   for (auto& kv : ctx->tw_inv) (void)hipFree(kv.second);
   for (auto& m : ctx->marks) (void)hipEventDestroy(m.second);
   for (auto& e : ctx->event_pool) (void)hipEventDestroy(e);
+  for (auto& m : ctx->modules) (void)hipModuleUnload(m);
   (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -959,6 +979,23 @@ int zkm_ctx_kernel_timings(zkm_ctx* ctx, const char** names, float* ms, uint32_t
   return i;
 }
 void zkm_ctx_set_kernel_timing(zkm_ctx* ctx, int enabled) { ctx->kernel_timing = enabled != 0; }
+
+int zkm_ctx_register_quotient_kernel(zkm_ctx* ctx, const uint32_t* program, uint32_t program_len, const void* code_object,
+                                     size_t code_object_len) {
+  API_BEGIN
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIP_CHECK(hipSetDevice(ctx->device));
+  if (!program_len || !code_object_len) throw std::runtime_error("empty program or code object");
+  (void)code_object_len;
+  hipModule_t mod;
+  HIP_CHECK(hipModuleLoadData(&mod, code_object));
+  hipFunction_t fn;
+  hipError_t e = hipModuleGetFunction(&fn, mod, "zkm_quotient_specialized");
+  if (e != hipSuccess) { (void)hipModuleUnload(mod); throw std::runtime_error("code object lacks zkm_quotient_specialized"); }
+  ctx->modules.push_back(mod);
+  ctx->quotient_fns[fnv1a(program, program_len)] = fn;
+  API_END
+}
 
 int zkm_matrix_upload(zkm_ctx* ctx, const uint32_t* host, size_t height, size_t width, zkm_matrix** out) {
   API_BEGIN

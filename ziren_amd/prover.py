@@ -181,12 +181,25 @@ class HipProver:
     (objects with the fields of synth.SynChip).
     """
 
-    def __init__(self, chips, fri: abi.FriConfig, num_pv_elts: int, device: int = 0, ctx: Optional[Context] = None):
+    def __init__(self, chips, fri: abi.FriConfig, num_pv_elts: int, device: int = 0, ctx: Optional[Context] = None,
+                 specialize: bool = False):
         self.chips = list(chips)
         self.fri = fri
         self.num_pv_elts = num_pv_elts
         self.ctx = ctx or Context(device)
         self._descs, self._keep = abi.make_chip_descs(self.chips)
+        if specialize:
+            self.specialize_quotient_kernels()
+
+    def specialize_quotient_kernels(self):
+        """Compile (or load from the in-tree cache) one quotient kernel per chip AIR and register it."""
+        from . import codegen
+        for c in self.chips:
+            prog = np.ascontiguousarray(c.program, dtype=np.uint32)
+            co = codegen.specialize(prog)
+            buf = C.create_string_buffer(co, len(co))
+            lib.check(lib.load().zkm_ctx_register_quotient_kernel(self.ctx.h, abi.as_u32p(prog), C.c_uint32(len(prog)), buf,
+                                                                  C.c_size_t(len(co))))
 
     # fn setup / pk_to_device (prover.rs:54-66)
     def setup(self, prep_traces: Sequence[np.ndarray], prep_local_only, pc_start, initial_global_cumulative_sum) -> ProvingKey:
