@@ -136,6 +136,45 @@ struct zkm_ctx {
     HIP_CHECK(hipEventRecord(krecs.back().stop, stream));
   }
 
+  // pinned host ring: short-lived host data goes H2D (and small results come D2H) through it without
+  // a stream synchronisation; it is recycled at the start of every top-level call, when the stream is idle.
+  char* pin = nullptr;
+  size_t pin_cap = (size_t)32 << 20, pin_off = 0;
+  void* pin_alloc(size_t bytes) {
+    if (!pin) HIP_CHECK(hipHostMalloc((void**)&pin, pin_cap, hipHostMallocDefault));
+    size_t off = (pin_off + 63) & ~(size_t)63;
+    if (off + bytes > pin_cap) return nullptr;
+    pin_off = off + bytes;
+    return pin + off;
+  }
+  void begin_call() {
+    HIP_CHECK(hipStreamSynchronize(stream));
+    pin_off = 0;
+  }
+  // copy `bytes` of host data to a fresh device buffer; the source may die as soon as this returns
+  void* upload(const void* src, size_t bytes, std::vector<void*>* scratch) {
+    void* d = alloc(bytes);
+    if (scratch) scratch->push_back(d);
+    if (bytes == 0) return d;
+    void* h = pin_alloc(bytes);
+    if (h) {
+      memcpy(h, src, bytes);
+      HIP_CHECK(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, stream));
+    } else {
+      HIP_CHECK(hipMemcpyAsync(d, src, bytes, hipMemcpyHostToDevice, stream));
+      HIP_CHECK(hipStreamSynchronize(stream));
+    }
+    return d;
+  }
+  // asynchronous D2H into the pinned ring; valid after the next stream synchronisation
+  template <class T>
+  T* download_async(const T* dev, size_t count) {
+    T* h = (T*)pin_alloc(count * sizeof(T));
+    if (!h) throw std::runtime_error("pinned staging ring exhausted");
+    HIP_CHECK(hipMemcpyAsync(h, dev, count * sizeof(T), hipMemcpyDeviceToHost, stream));
+    return h;
+  }
+
   void* alloc(size_t bytes) {
     if (bytes == 0) bytes = 4;
     bytes = (bytes + 255) & ~(size_t)255;
@@ -166,6 +205,7 @@ struct zkm_ctx {
     marks.push_back({name, e});
   }
   void begin_timing() {
+    begin_call();
     for (auto& m : marks) event_pool.push_back(m.second);
     marks.clear();
     for (auto& r : krecs) { event_pool.push_back(r.start); if (r.stop) event_pool.push_back(r.stop); }
@@ -285,12 +325,7 @@ static void lde_columns(zkm_ctx* ctx, const uint32_t* in, size_t n, size_t w, in
 
 // Upload an array of device pointers (one per column) and return the device copy.
 static const uint32_t** upload_ptrs(zkm_ctx* ctx, const std::vector<const uint32_t*>& ptrs) {
-  const uint32_t** d = (const uint32_t**)ctx->alloc(std::max<size_t>(ptrs.size(), 1) * sizeof(void*));
-  if (!ptrs.empty()) {
-    HIP_CHECK(hipMemcpyAsync(d, ptrs.data(), ptrs.size() * sizeof(void*), hipMemcpyHostToDevice, ctx->stream));
-    HIP_CHECK(hipStreamSynchronize(ctx->stream));  // the host vector dies when the caller returns
-  }
-  return d;
+  return (const uint32_t**)ctx->upload(ptrs.data(), ptrs.size() * sizeof(void*), nullptr);
 }
 
 // MerkleTreeMmcs::commit over column-major matrices of power-of-two heights.
@@ -368,8 +403,9 @@ static zkm_pcs_data* pcs_commit(zkm_ctx* ctx, const std::vector<zkm_matrix>& mat
       d->domain_shifts.push_back(s);
     }
     build_tree(ctx, d->ldes, d->tree);
-    HIP_CHECK(hipMemcpyAsync(d->root, d->tree.node(d->tree.log_max, 0), 32, hipMemcpyDeviceToHost, ctx->stream));
+    const uint32_t* h_root = ctx->download_async(d->tree.node(d->tree.log_max, 0), 8);
     HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    memcpy(d->root, h_root, 32);
   } catch (...) {
     free_pcs_data(ctx, d);
     throw;
@@ -452,32 +488,29 @@ static void open_impl(zkm_ctx* ctx, const zkm_pk* pk, zkm_main_data* md, const z
   chal::observe_slice(ch, md->public_values.data(), num_pv_elts);
   chal::observe_slice(ch, md->data->root, 8);
   E4 perm_ch[2] = {chal::sample_ext(ch), chal::sample_ext(ch)};
-  uint32_t* d_pv = (uint32_t*)salloc(std::max<size_t>(md->public_values.size(), 1) * 4);
-  if (!md->public_values.empty())
-    HIP_CHECK(hipMemcpyAsync(d_pv, md->public_values.data(), md->public_values.size() * 4, hipMemcpyHostToDevice, st));
+  uint32_t* d_pv = (uint32_t*)ctx->upload(md->public_values.data(), md->public_values.size() * 4, &scratch);
 
   // --- permutation traces (prover.rs:337-365)
   std::vector<zkm_matrix> perm_traces(nc);
   std::vector<E4> local_sums(nc, kb::ezero());
   std::vector<std::array<uint32_t, 14>> global_sums(nc);
   std::vector<uint32_t*> d_blobs(nc, nullptr);
+  std::vector<const uint32_t*> sum_src;
+  uint32_t* h_sums = nullptr;
   {
     int maxv = 0;
     for (auto& c : chips) maxv = std::max(maxv, c.max_values);
     std::vector<E4> bp(maxv + 2);
     bp[0] = kb::eone();
     for (int i = 1; i < maxv + 2; i++) bp[i] = kb::emul(bp[i - 1], perm_ch[1]);
-    E4* d_bp = (E4*)salloc(bp.size() * sizeof(E4));
-    HIP_CHECK(hipMemcpyAsync(d_bp, bp.data(), bp.size() * sizeof(E4), hipMemcpyHostToDevice, st));
-    HIP_CHECK(hipStreamSynchronize(st));
+    E4* d_bp = (E4*)ctx->upload(bp.data(), bp.size() * sizeof(E4), &scratch);
     for (size_t i = 0; i < nc; i++) {
       const ChipMeta& c = chips[i];
       zkm_matrix& pt = perm_traces[i];
       pt.h = c.n; pt.w = (size_t)c.perm_ext_w * 4;
       pt.d = ctx->alloc_n<uint32_t>(std::max<size_t>(pt.h * pt.w, 1));
       if (c.perm_ext_w > 0) {
-        d_blobs[i] = (uint32_t*)salloc(c.desc->lookups_len * 4);
-        HIP_CHECK(hipMemcpyAsync(d_blobs[i], c.desc->lookups, c.desc->lookups_len * 4, hipMemcpyHostToDevice, st));
+        d_blobs[i] = (uint32_t*)ctx->upload(c.desc->lookups, c.desc->lookups_len * 4, &scratch);
         const uint32_t* prep = c.desc->prep_index >= 0 ? pk->prep[c.desc->prep_index].d : nullptr;
         KLAUNCH(ctx, "perm_rows", 4.0 * c.n * (c.desc->main_width + c.desc->prep_width + pt.w), stark::perm_rows,
                 dim3(div_up(c.n, stark::THREADS)), dim3(stark::THREADS), 0, (const uint32_t*)d_blobs[i], c.n_lookups, c.n_sends,
@@ -494,22 +527,38 @@ static void open_impl(zkm_ctx* ctx, const zkm_pk* pk, zkm_main_data* md, const z
           KLAUNCH(ctx, "scan", 32.0 * c.n, stark::scan_add_offsets, dim3((unsigned)nchunks, 4), dim3(stark::THREADS), 0, last, c.n,
                   (const uint32_t*)totals, nchunks);
         }
-        for (int e = 0; e < 4; e++)
-          HIP_CHECK(hipMemcpyAsync(&local_sums[i].c[e], last + (size_t)e * c.n + (c.n - 1), 4, hipMemcpyDeviceToHost, st));
+        for (int e = 0; e < 4; e++) sum_src.push_back(last + (size_t)e * c.n + (c.n - 1));
+      } else {
+        for (int e = 0; e < 4; e++) sum_src.push_back(nullptr);
       }
       if (c.desc->commit_scope_global) {
         const zkm_matrix& m = md->traces[i];
-        for (int k = 0; k < 14; k++)
-          HIP_CHECK(hipMemcpyAsync(&global_sums[i][k], m.d + (m.w - 14 + k) * m.h + (m.h - 1), 4, hipMemcpyDeviceToHost, st));
+        for (int k = 0; k < 14; k++) sum_src.push_back(m.d + (m.w - 14 + k) * m.h + (m.h - 1));
       } else {
-        for (int k = 0; k < 7; k++) { global_sums[i][k] = kb::to_monty(SEPTIC_X[k]); global_sums[i][7 + k] = kb::to_monty(SEPTIC_Y[k]); }
+        for (int k = 0; k < 14; k++) sum_src.push_back(nullptr);
       }
     }
+    // one gather for every cumulative-sum word (18 per chip), read back after the commit's synchronisation
+    const uint32_t* d_zero = (const uint32_t*)ctx->upload("\0\0\0\0", 4, &scratch);
+    for (auto& p : sum_src) if (!p) p = d_zero;
+    const uint32_t** d_sum_src = (const uint32_t**)ctx->upload(sum_src.data(), sum_src.size() * sizeof(void*), &scratch);
+    uint32_t* d_sums = (uint32_t*)salloc(sum_src.size() * 4);
+    KLAUNCH(ctx, "gather_words", 0.0, open::gather_words, dim3(div_up(sum_src.size(), open::THREADS)), dim3(open::THREADS), 0,
+            (const uint32_t* const*)d_sum_src, sum_src.size(), d_sums);
+    h_sums = ctx->download_async(d_sums, sum_src.size());
   }
   ctx->mark("permutation traces");
   zkm_pcs_data* perm_data = pcs_commit(ctx, perm_traces, {}, bl);  // synchronises: sums are on the host now
   perm_data->owned_evals = perm_traces;
   ctx->mark("commit permutation");
+  for (size_t i = 0; i < nc; i++) {
+    for (int e = 0; e < 4; e++) local_sums[i].c[e] = h_sums[18 * i + e];
+    if (chips[i].desc->commit_scope_global) {
+      for (int k = 0; k < 14; k++) global_sums[i][k] = h_sums[18 * i + 4 + k];
+    } else {
+      for (int k = 0; k < 7; k++) { global_sums[i][k] = kb::to_monty(SEPTIC_X[k]); global_sums[i][7 + k] = kb::to_monty(SEPTIC_Y[k]); }
+    }
+  }
   struct Guard { zkm_ctx* c; std::vector<zkm_pcs_data*> d; ~Guard() { for (auto p : d) free_pcs_data(c, p); } } guard{ctx, {perm_data}};
   chal::observe_slice(ch, perm_data->root, 8);
   for (size_t i = 0; i < nc; i++) {
@@ -533,8 +582,7 @@ static void open_impl(zkm_ctx* ctx, const zkm_pk* pk, zkm_main_data* md, const z
     std::vector<E4> ap(std::max<size_t>(C, 1));
     E4 p = kb::eone();
     for (size_t k = 0; k < C; k++) { ap[C - 1 - k] = p; p = kb::emul(p, alpha); }
-    E4* d_ap = (E4*)salloc(ap.size() * sizeof(E4));
-    HIP_CHECK(hipMemcpyAsync(d_ap, ap.data(), ap.size() * sizeof(E4), hipMemcpyHostToDevice, st));
+    E4* d_ap = (E4*)ctx->upload(ap.data(), ap.size() * sizeof(E4), &scratch);
     uint32_t consts[32] = {0};
     for (int k = 0; k < 14; k++) consts[k] = global_sums[i][k];
     uint32_t w_q = kb::two_adic_generator(lq);
@@ -546,11 +594,9 @@ static void open_impl(zkm_ctx* ctx, const zkm_pk* pk, zkm_main_data* md, const z
       consts[24 + k] = kb::inv(consts[16 + k]);
       wp = kb::mul(wp, wr);
     }
-    uint32_t* d_consts = (uint32_t*)salloc(sizeof consts);
-    HIP_CHECK(hipMemcpyAsync(d_consts, consts, sizeof consts, hipMemcpyHostToDevice, st));
-    HIP_CHECK(hipStreamSynchronize(st));  // ap / consts are short-lived host buffers
-    uint32_t* d_prog = (uint32_t*)salloc(std::max<size_t>(d->program_len, 4) * 4);
-    if (d->program_len) HIP_CHECK(hipMemcpyAsync(d_prog, d->program, d->program_len * 4, hipMemcpyHostToDevice, st));
+    uint32_t* d_consts = (uint32_t*)ctx->upload(consts, sizeof consts, &scratch);
+    static const uint32_t empty_prog[4] = {0, 1, 0, 1};
+    uint32_t* d_prog = (uint32_t*)ctx->upload(d->program_len ? d->program : empty_prog, std::max<size_t>(d->program_len, 4) * 4, &scratch);
     stark::QuotientArgs a;
     a.program = d_prog + 4;
     a.n_instr = d->program_len ? d->program[0] : 0;
@@ -666,8 +712,7 @@ static void open_impl(zkm_ctx* ctx, const zkm_pk* pk, zkm_main_data* md, const z
                 (int)split, (int)(m.width * 2), d_y + ypos);
         ypos += m.width * 2;
       }
-    std::vector<E4> hy(total_y);
-    if (total_y) HIP_CHECK(hipMemcpyAsync(hy.data(), d_y, total_y * sizeof(E4), hipMemcpyDeviceToHost, st));
+    const E4* hy = ctx->download_async(d_y, std::max<size_t>(total_y, 1));
     HIP_CHECK(hipStreamSynchronize(st));
     ypos = 0;
     for (auto& r : rounds)
@@ -691,8 +736,7 @@ static void open_impl(zkm_ctx* ctx, const zkm_pk* pk, zkm_main_data* md, const z
   std::vector<E4> fap(max_width + 1);
   fap[0] = kb::eone();
   for (size_t i = 1; i <= max_width; i++) fap[i] = kb::emul(fap[i - 1], fa);
-  E4* d_fap = (E4*)salloc(fap.size() * sizeof(E4));
-  HIP_CHECK(hipMemcpyAsync(d_fap, fap.data(), fap.size() * sizeof(E4), hipMemcpyHostToDevice, st));
+  E4* d_fap = (E4*)ctx->upload(fap.data(), fap.size() * sizeof(E4), &scratch);
   std::vector<E4*> ro(32, nullptr);
   {
     std::vector<std::vector<open::ReduceMat>> per_h(32);
@@ -716,9 +760,7 @@ static void open_impl(zkm_ctx* ctx, const zkm_pk* pk, zkm_main_data* md, const z
       if (per_h[lh].empty()) continue;
       size_t N = (size_t)1 << lh;
       ro[lh] = (E4*)salloc(N * sizeof(E4));
-      open::ReduceMat* d_rm = (open::ReduceMat*)salloc(per_h[lh].size() * sizeof(open::ReduceMat));
-      HIP_CHECK(hipMemcpyAsync(d_rm, per_h[lh].data(), per_h[lh].size() * sizeof(open::ReduceMat), hipMemcpyHostToDevice, st));
-      HIP_CHECK(hipStreamSynchronize(st));  // per_h storage is pageable host memory
+      open::ReduceMat* d_rm = (open::ReduceMat*)ctx->upload(per_h[lh].data(), per_h[lh].size() * sizeof(open::ReduceMat), &scratch);
       E4 z1 = kb::escale(zeta, kb::two_adic_generator(lh - bl));
       double rbytes = 16.0 * N;
       for (auto& rm : per_h[lh]) rbytes += 4.0 * N * rm.width;
@@ -757,8 +799,9 @@ static void open_impl(zkm_ctx* ctx, const zkm_pk* pk, zkm_main_data* md, const z
       if (l == 1) break;
     }
     std::array<uint32_t, 8> root;
-    HIP_CHECK(hipMemcpyAsync(root.data(), t.node(t.log_max, 0), 32, hipMemcpyDeviceToHost, st));
+    const uint32_t* h_root = ctx->download_async(t.node(t.log_max, 0), 8);
     HIP_CHECK(hipStreamSynchronize(st));
+    memcpy(root.data(), h_root, 32);
     chal::observe_slice(ch, root.data(), 8);
     commits.push_back(root);
     E4 beta = chal::sample_ext(ch);
@@ -771,10 +814,10 @@ static void open_impl(zkm_ctx* ctx, const zkm_pk* pk, zkm_main_data* md, const z
     f = g;
     lf--;
   }
-  std::vector<E4> fin((size_t)1 << lf);
-  HIP_CHECK(hipMemcpyAsync(fin.data(), f, fin.size() * sizeof(E4), hipMemcpyDeviceToHost, st));
+  const size_t nfin = (size_t)1 << lf;
+  const E4* fin = ctx->download_async((const E4*)f, nfin);
   HIP_CHECK(hipStreamSynchronize(st));
-  for (size_t i = 1; i < fin.size(); i++)
+  for (size_t i = 1; i < nfin; i++)
     if (!kb::eq(fin[i], fin[0])) throw std::runtime_error("FRI final polynomial is not constant (internal error)");
   E4 final_poly = fin[0];
   chal::observe_ext(ch, final_poly);
@@ -782,21 +825,19 @@ static void open_impl(zkm_ctx* ctx, const zkm_pk* pk, zkm_main_data* md, const z
   // proof of work: smallest canonical witness
   uint32_t pow_witness;
   {
-    uint32_t* d_state = (uint32_t*)salloc(16 * 4);
-    uint32_t* d_in = (uint32_t*)salloc(16 * 4);
+    uint32_t* d_state = (uint32_t*)ctx->upload(ch->sponge_state, 64, &scratch);
+    uint32_t* d_in = (uint32_t*)ctx->upload(ch->input_buffer, 64, &scratch);
     unsigned int* d_best = (unsigned int*)salloc(4);
-    HIP_CHECK(hipMemcpyAsync(d_state, ch->sponge_state, 64, hipMemcpyHostToDevice, st));
-    HIP_CHECK(hipMemcpyAsync(d_in, ch->input_buffer, 64, hipMemcpyHostToDevice, st));
     uint32_t base = 0, found = 0xffffffffu;
     const uint32_t BATCH = 1u << 20;
     while (base < kb::P) {
-      unsigned int init = 0xffffffffu;
-      HIP_CHECK(hipMemcpyAsync(d_best, &init, 4, hipMemcpyHostToDevice, st));
+      HIP_CHECK(hipMemsetAsync(d_best, 0xff, 4, st));
       uint32_t total = std::min<uint64_t>(BATCH, (uint64_t)kb::P - base);
       KLAUNCH(ctx, "grind", 0.0, merkle::grind, dim3(div_up(total, merkle::THREADS)), dim3(merkle::THREADS), 0, (const uint32_t*)d_state,
               (const uint32_t*)d_in, (int)ch->num_inputs, (int)fri->proof_of_work_bits, base, total, d_best);
-      HIP_CHECK(hipMemcpyAsync(&found, d_best, 4, hipMemcpyDeviceToHost, st));
+      const unsigned int* h_best = ctx->download_async((const unsigned int*)d_best, 1);
       HIP_CHECK(hipStreamSynchronize(st));
+      found = *h_best;
       if (found != 0xffffffffu) break;
       base += total;
     }
@@ -837,9 +878,8 @@ static void open_impl(zkm_ctx* ctx, const zkm_pk* pk, zkm_main_data* md, const z
   }
   std::vector<uint32_t> gathered(src.size());
   if (!src.empty()) {
-    const uint32_t** d_src = (const uint32_t**)salloc(src.size() * sizeof(void*));
+    const uint32_t** d_src = (const uint32_t**)ctx->upload(src.data(), src.size() * sizeof(void*), &scratch);
     uint32_t* d_dst = (uint32_t*)salloc(src.size() * 4);
-    HIP_CHECK(hipMemcpyAsync(d_src, src.data(), src.size() * sizeof(void*), hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(open::gather_words, dim3(div_up(src.size(), open::THREADS)), dim3(open::THREADS), 0, st,
                        (const uint32_t* const*)d_src, src.size(), d_dst);
     LAUNCH_CHECK();
@@ -954,6 +994,7 @@ void zkm_ctx_destroy(zkm_ctx* ctx) {
   for (auto& m : ctx->marks) (void)hipEventDestroy(m.second);
   for (auto& e : ctx->event_pool) (void)hipEventDestroy(e);
   for (auto& m : ctx->modules) (void)hipModuleUnload(m);
+  if (ctx->pin) (void)hipHostFree(ctx->pin);
   (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -1110,6 +1151,7 @@ int zkm_pk_setup(zkm_ctx* ctx, size_t n_prep, const zkm_matrix* const* prep_trac
   API_BEGIN
   std::lock_guard<std::mutex> lk(ctx->mu);
   HIP_CHECK(hipSetDevice(ctx->device));
+  ctx->begin_call();
   zkm_pk* pk = new zkm_pk();
   pk->pc_start = pc_start;
   memcpy(pk->igcs, igcs, sizeof pk->igcs);
