@@ -28,10 +28,10 @@ constexpr int COLS_TILE_ELEMS = 16384; // A * T words in LDS for the strided pas
 constexpr int THREADS = 512;  // 8 waves per block: two blocks per CU keep 4 waves per SIMD over the barriers
 
 // ---- in-LDS transforms ---------------------------------------------------------------------------
-// A transform of 2^logn points runs as passes of up to 3 radix-2 stages. In one pass a thread owns a
-// group of 2^R points (R <= 3) that only interact with each other during those stages, keeps them in
-// VGPRs, and touches LDS once to read and once to write them: 13 stages cost 5 LDS round trips and
-// 5 barriers instead of 13.
+// A transform of 2^logn points runs as passes of up to 4 radix-2 stages. In one pass a thread owns a
+// group of 2^R points (R <= 4) that only interact with each other during those stages, keeps them in
+// VGPRs, and touches LDS once to read and once to write them: 13 stages cost 4 LDS round trips and
+// 4 barriers instead of 13.
 //
 // Sequence layout: element i of sequence t lives at buf[phys(i) * istride + t]; 2^lognb sequences are
 // interleaved (strided kernels: t = column inside the tile). PAD inserts one word per 32 so that the
@@ -85,17 +85,20 @@ __device__ __forceinline__ void ntt_pass(uint32_t* buf, int logn, int lognb, int
 
 template <bool DIF, bool PAD>
 __device__ __forceinline__ void lds_ntt(uint32_t* buf, int logn, int lognb, int istride, const uint32_t* __restrict__ tw) {
-  const int rem = logn % 3;  // the short pass handles the smallest spans
+  // passes of 4 stages (16 points per thread), then one short pass for the remaining 1-3 stages
+  const int rem = logn & 3;
   if (DIF) {
     int s0 = 0;
-    for (; s0 + 3 <= logn; s0 += 3) ntt_pass<true, 3, PAD>(buf, logn, lognb, istride, s0, tw);
+    for (; s0 + 4 <= logn; s0 += 4) ntt_pass<true, 4, PAD>(buf, logn, lognb, istride, s0, tw);
+    if (rem == 3) ntt_pass<true, 3, PAD>(buf, logn, lognb, istride, s0, tw);
     if (rem == 2) ntt_pass<true, 2, PAD>(buf, logn, lognb, istride, s0, tw);
     if (rem == 1) ntt_pass<true, 1, PAD>(buf, logn, lognb, istride, s0, tw);
   } else {
     int s0 = logn - rem;
+    if (rem == 3) ntt_pass<false, 3, PAD>(buf, logn, lognb, istride, s0, tw);
     if (rem == 2) ntt_pass<false, 2, PAD>(buf, logn, lognb, istride, s0, tw);
     if (rem == 1) ntt_pass<false, 1, PAD>(buf, logn, lognb, istride, s0, tw);
-    for (s0 -= 3; s0 >= 0; s0 -= 3) ntt_pass<false, 3, PAD>(buf, logn, lognb, istride, s0, tw);
+    for (s0 -= 4; s0 >= 0; s0 -= 4) ntt_pass<false, 4, PAD>(buf, logn, lognb, istride, s0, tw);
   }
 }
 
@@ -114,40 +117,67 @@ __device__ __forceinline__ uint32_t pow_lookup(const uint32_t* lo, const uint32_
 
 // Step 1 / 3: A-point transforms down the strided dimension of each column.
 // grid = (B / T, width, n_cosets); in/out are column-major with `col_stride` words per column.
-// FORWARD == false: inverse DIF in place layout (tile written back where it was read).
-// FORWARD == true : forward DIT, then element (j1, j0) is written to
-//                   out[c * out_col_stride + out_block(z) * n + bitrev_lb(j0) * A + bitrev_la(j1)].
+// The LDS tile is [A][T + 1] (one pad word per row: the transposed read-out below walks down a column).
+// FORWARD == false: inverse DIF over rows i1 (natural) -> rows in bit-reversed k1 order, written back in place.
+// FORWARD == true : rows arrive in natural k1 order (lde_rows stores row k1 = bitrev(pr)); a forward DIF
+//                   leaves row q holding L[B * bitrev_la(q) + j0], which belongs at
+//                   out[c * out_col_stride + out_block(z) * n + bitrev_lb(j0) * A + q]:
+//                   one contiguous A-word segment per tile column.
 template <bool FORWARD>
 __global__ __launch_bounds__(THREADS) void lde_cols(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, int la, int lb,
                                                     int logT, size_t in_col_stride, size_t in_coset_stride,
                                                     size_t out_col_stride, int log_blowup,
                                                     const uint32_t* __restrict__ tw) {
   extern __shared__ uint32_t lds[];
-  const int A = 1 << la, T = 1 << logT;
+  const int A = 1 << la, T = 1 << logT, TP = T + 1;
   const size_t B = (size_t)1 << lb;
   const size_t t0 = (size_t)blockIdx.x << logT;
   const size_t c = blockIdx.y;
   const int z = blockIdx.z;
-  const uint32_t* src = in + c * in_col_stride + (size_t)z * in_coset_stride;
-  for (int u = threadIdx.x; u < A * T; u += blockDim.x) {
-    int i1 = u >> logT, t = u & (T - 1);
-    lds[u] = src[(size_t)i1 * B + t0 + t];
+  const uint32_t* src = in + c * in_col_stride + (size_t)z * in_coset_stride + t0;
+  // 16-byte global accesses (T >= 8), four in flight per thread
+  const int logTq = logT - 2;
+  const int quads = (A << logT) >> 2;
+  for (int u0 = threadIdx.x; u0 < quads; u0 += 4 * blockDim.x) {
+    uint4 v[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      int u = u0 + k * blockDim.x;
+      if (u < quads) v[k] = *reinterpret_cast<const uint4*>(src + (size_t)(u >> logTq) * B + ((u & ((1 << logTq) - 1)) << 2));
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      int u = u0 + k * blockDim.x;
+      if (u < quads) {
+        uint32_t* d = lds + (u >> logTq) * TP + ((u & ((1 << logTq) - 1)) << 2);
+        d[0] = v[k].x; d[1] = v[k].y; d[2] = v[k].z; d[3] = v[k].w;
+      }
+    }
   }
   __syncthreads();
-  lds_ntt<!FORWARD, false>(lds, la, logT, T, tw);
+  lds_ntt<true, false>(lds, la, logT, TP, tw);  // DIF either way: natural rows in, bit-reversed rows out
   if (!FORWARD) {
-    uint32_t* dst = out + c * out_col_stride;
-    for (int u = threadIdx.x; u < A * T; u += blockDim.x) {
-      int i1 = u >> logT, t = u & (T - 1);
-      dst[(size_t)i1 * B + t0 + t] = lds[u];
+    uint32_t* dst = out + c * out_col_stride + t0;
+    for (int u0 = threadIdx.x; u0 < quads; u0 += blockDim.x) {
+      const uint32_t* sp = lds + (u0 >> logTq) * TP + ((u0 & ((1 << logTq) - 1)) << 2);
+      *reinterpret_cast<uint4*>(dst + (size_t)(u0 >> logTq) * B + ((u0 & ((1 << logTq) - 1)) << 2)) = make_uint4(sp[0], sp[1], sp[2], sp[3]);
     }
   } else {
     const size_t n = (size_t)A << lb;
     uint32_t* dst = out + c * out_col_stride + (size_t)kb::bitrev(z, log_blowup) * n;
-    for (int u = threadIdx.x; u < A * T; u += blockDim.x) {
-      int t = u >> la, q = u & (A - 1);
-      size_t j0 = t0 + t;
-      dst[(size_t)kb::bitrev((uint32_t)j0, lb) * A + q] = lds[kb::bitrev(q, la) * T + t];
+    if (la < 2) {  // A = 2: scalar stores
+      for (int u = threadIdx.x; u < (A << logT); u += blockDim.x) {
+        const int t = u >> la, q = u & (A - 1);
+        dst[(size_t)kb::bitrev((uint32_t)(t0 + t), lb) * A + q] = lds[q * TP + t];
+      }
+      return;
+    }
+    const int logAq = la - 2;
+    for (int u0 = threadIdx.x; u0 < quads; u0 += blockDim.x) {
+      const int t = u0 >> logAq, q = (u0 & ((1 << logAq) - 1)) << 2;
+      const uint32_t* sp = lds + q * TP + t;
+      const size_t j0 = t0 + t;
+      *reinterpret_cast<uint4*>(dst + (size_t)kb::bitrev((uint32_t)j0, lb) * A + q) = make_uint4(sp[0], sp[TP], sp[2 * TP], sp[3 * TP]);
     }
   }
 }
@@ -155,7 +185,7 @@ __global__ __launch_bounds__(THREADS) void lde_cols(const uint32_t* __restrict__
 // Step 2: one block per (row k1-position pr, column c).
 //   in : column-major, the column after lde_cols<false> (or the raw trace column when la == 0)
 //   la == 0: writes the finished LDE column to `out` (height n << log_blowup per column)
-//   la  > 0: writes coset j's row to tmp[(j * width + c) * n + pr * B + j0] for lde_cols<true>
+//   la  > 0: writes coset j's row to tmp[(j * width + c) * n + k1 * B + j0] for lde_cols<true>
 __global__ __launch_bounds__(THREADS) void lde_rows(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, int la, int lb,
                                                     size_t in_col_stride, size_t out_col_stride, size_t out_coset_stride,
                                                     int log_blowup, uint32_t shift, uint32_t w_n, uint32_t w_n_inv,
@@ -180,7 +210,26 @@ __global__ __launch_bounds__(THREADS) void lde_rows(const uint32_t* __restrict__
   if (la > 0) {
     build_pow_table(kb::pow(w_n_inv, (uint64_t)k1), lo1, hi1, nhi);
     __syncthreads();
-    for (int i = threadIdx.x; i < B; i += blockDim.x) coef[phys<true>(i)] = kb::mul(src[i], pow_lookup(lo1, hi1, i));
+    // B = 8192 here: 16-byte loads, four in flight per thread
+    for (int q0 = threadIdx.x; q0 < (B >> 2); q0 += 4 * blockDim.x) {
+      uint4 v[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        int q = q0 + k * blockDim.x;
+        if (q < (B >> 2)) v[k] = *reinterpret_cast<const uint4*>(src + 4 * q);
+      }
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        int q = q0 + k * blockDim.x;
+        if (q < (B >> 2)) {
+          const int i = 4 * q;
+          coef[phys<true>(i)] = kb::mul(v[k].x, pow_lookup(lo1, hi1, i));
+          coef[phys<true>(i + 1)] = kb::mul(v[k].y, pow_lookup(lo1, hi1, i + 1));
+          coef[phys<true>(i + 2)] = kb::mul(v[k].z, pow_lookup(lo1, hi1, i + 2));
+          coef[phys<true>(i + 3)] = kb::mul(v[k].w, pow_lookup(lo1, hi1, i + 3));
+        }
+      }
+    }
   } else {
     for (int i = threadIdx.x; i < B; i += blockDim.x) coef[phys<true>(i)] = src[i];
   }
@@ -205,8 +254,14 @@ __global__ __launch_bounds__(THREADS) void lde_rows(const uint32_t* __restrict__
     __syncthreads();
     if (lb > 0) lds_ntt<false, true>(work, lb, 0, 1, tw_fwd);
     if (la > 0) {
-      uint32_t* dst = out + (size_t)j * out_coset_stride + c * out_col_stride + (size_t)pr * B;
-      for (int i = threadIdx.x; i < B; i += blockDim.x) dst[i] = kb::mul(work[phys<true>(i)], pow_lookup(lo1, hi1, i));
+      uint32_t* dst = out + (size_t)j * out_coset_stride + c * out_col_stride + (size_t)k1 * B;  // row k1: natural order for lde_cols<true>
+      for (int q = threadIdx.x; q < (B >> 2); q += blockDim.x) {
+        const int i = 4 * q;
+        *reinterpret_cast<uint4*>(dst + i) = make_uint4(kb::mul(work[phys<true>(i)], pow_lookup(lo1, hi1, i)),
+                                                         kb::mul(work[phys<true>(i + 1)], pow_lookup(lo1, hi1, i + 1)),
+                                                         kb::mul(work[phys<true>(i + 2)], pow_lookup(lo1, hi1, i + 2)),
+                                                         kb::mul(work[phys<true>(i + 3)], pow_lookup(lo1, hi1, i + 3)));
+      }
     } else {
       uint32_t* dst = out + c * out_col_stride + (size_t)kb::bitrev(j, log_blowup) * B;
       for (int i = threadIdx.x; i < B; i += blockDim.x) dst[i] = work[phys<true>(kb::bitrev(i, lb))];

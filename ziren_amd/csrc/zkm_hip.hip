@@ -306,9 +306,9 @@ static void lde_columns(zkm_ctx* ctx, const uint32_t* in, size_t n, size_t w, in
     return;
   }
   size_t A = (size_t)1 << la;
-  int logT = std::min(std::min(6, 14 - la), lb);
+  int logT = std::min(std::min(6, 14 - la), lb);  // la >= 1 implies lb = 13, so T >= 8
   size_t T = (size_t)1 << logT;
-  size_t cols_lds = A * T * 4;
+  size_t cols_lds = A * (T + 1) * 4;  // padded tile rows
   uint32_t* tmp1 = ctx->alloc_n<uint32_t>(n * w);
   uint32_t* tmp2 = ctx->alloc_n<uint32_t>((n * w) << bl);
   const uint32_t* twa_inv = ctx->twiddles(la, true);
