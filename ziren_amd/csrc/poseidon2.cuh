@@ -53,19 +53,35 @@ KB_HD void external_layer(uint32_t s[16]) {
 
 KB_HD uint32_t sbox(uint32_t x) { return kb::mul(kb::sqr(x), x); }
 
+// acc += x (64-bit accumulate of a 32-bit value): one v_mad_u64_u32 on the device
+KB_HD void acc_add(uint64_t& acc, uint32_t x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm("v_mad_u64_u32 %0, vcc, %1, 1, %0" : "+v"(acc) : "v"(x) : "vcc");
+#else
+  acc += x;
+#endif
+}
+// x / 2 mod p
+KB_HD uint32_t half(uint32_t x) { return (x + ((0u - (x & 1u)) & kb::P)) >> 1; }
+
 template <class DiagFn>
 KB_HD void internal_layer(uint32_t s[16], DiagFn diag) {
-  uint32_t sum = s[0];
+  // sum of the 16 lanes: eight unreduced pair sums (< 2p < 2^32), accumulated in 64 bits, one reduction:
+  // acc = q 2^31 + l  =>  acc - q p = q (2^24 - 1) + l < 2p
+  uint64_t acc = (uint64_t)(s[0] + s[1]);
 #pragma unroll
-  for (int i = 1; i < 16; i++) sum = kb::add(sum, s[i]);
+  for (int i = 2; i < 16; i += 2) acc_add(acc, s[i] + s[i + 1]);
+  uint32_t q = (uint32_t)(acc >> 31);
+  uint32_t r = (uint32_t)acc - q * kb::P;
+  uint32_t sum = kb::umin32(r, r - kb::P);
   // s_i <- s_i * V_i + sum
   s[0] = kb::sub(sum, kb::dbl(s[0]));                 // -2
   s[1] = kb::add(sum, s[1]);                          //  1
   s[2] = kb::add(sum, kb::dbl(s[2]));                 //  2
-  s[3] = kb::add(sum, kb::mul(s[3], diag(3)));        //  1/2
+  s[3] = kb::add(sum, half(s[3]));                    //  1/2
   s[4] = kb::add(sum, kb::mul3(s[4]));                //  3
   s[5] = kb::add(sum, kb::dbl(kb::dbl(s[5])));        //  4
-  s[6] = kb::add(sum, kb::mul(s[6], diag(6)));        // -1/2
+  s[6] = kb::sub(sum, half(s[6]));                    // -1/2
   s[7] = kb::sub(sum, kb::mul3(s[7]));                // -3
   s[8] = kb::sub(sum, kb::dbl(kb::dbl(s[8])));        // -4
 #pragma unroll
