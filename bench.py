@@ -51,7 +51,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--log-rows", type=int, default=22)
-    ap.add_argument("--cpu-sample-log-rows", type=int, default=16)
+    ap.add_argument("--cpu-sample-log-rows", type=int, default=19)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--interpreter", action="store_true", help="use the bytecode interpreter instead of per-chip quotient kernels")
     args = ap.parse_args()
@@ -108,8 +108,17 @@ def main():
             per_launch_ms = ms / max(calls, 1)
             kbytes = nbytes / max(calls, 1)
             achieved = kbytes / (per_launch_ms * 1e-3) / 1e9 if per_launch_ms > 0 else 0.0
+            # HBM bytes per launch from the committed PMC passes of this same command (tools/pmc_traffic.py)
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "r01_syn22_hbm_traffic.json")
+            short = {"compress_layer": "merkle::compress_layer", "hash_leaves": "merkle::hash_leaves",
+                     "lde_rows": "lde::lde_rows"}.get(name)
+            if k == 22 and short and os.path.exists(tpath):
+                tk = json.load(open(tpath))["kernels"].get(short)
+                if tk:
+                    traffic = int(tk["hbm_bytes_per_launch"])
             roofline = {"bound": "hbm", "kernel": name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
-                        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
                         "launches_per_step": calls // steps, "avg_launch_ms": round(per_launch_ms, 4),
                         "algorithmic_bytes_per_launch": int(kbytes),
                         "kernel_share_of_step": round(ms / steps / ms_per_step, 3),
