@@ -126,7 +126,7 @@ def main():
                                         "achieved": round(alg_bytes / (ms_per_step * 1e-3) / 1e9, 1),
                                         "frac": round(alg_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}}
         cpu = None
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # rank 0, N = 1 only
             ks = min(args.cpu_sample_log_rows, k)
             wall, threads = cpu_baseline(ks, fri)
             scale = 1 << (k - ks)
@@ -136,7 +136,7 @@ def main():
                    "sample_seconds": round(wall, 3)}
         line = {"metric": "shard-proofs/sec", "value": round(value, 4), "unit": "shard-proofs/s", "n_gpus": world,
                 "steps": steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
-                "scaling": "weak", "vs_baseline": None, "dtype": "u32 (KoalaBear, Montgomery) / 4xu32 extension",
+                "scaling": "weak", "vs_baseline": None, "dtype": "u32",
                 "data": "synthetic",
                 "config": {"workload": f"SYN-{k}: full shard proof (commit+open), Cpu-like chip 2^{k} rows x 67 main "
                                        f"cols + 7 smaller chips, blowup 2, 84 queries, 16 PoW bits",

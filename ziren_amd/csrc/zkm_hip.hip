@@ -328,6 +328,25 @@ static const uint32_t** upload_ptrs(zkm_ctx* ctx, const std::vector<const uint32
   return (const uint32_t**)ctx->upload(ptrs.data(), ptrs.size() * sizeof(void*), nullptr);
 }
 
+// Layers of at most LANES_MAX nodes without injection: lane-parallel compression; returns true when it
+// finished the tree (tail launch), false when the caller should go on with the next layer.
+static bool compress_small_layer(zkm_ctx* ctx, Tree& t, int layer, size_t len) {
+  const size_t LANES_MAX = 4096, TAIL = 64;
+  if (len > LANES_MAX) {
+    KLAUNCH(ctx, "compress_layer", 96.0 * len, merkle::compress_layer, dim3(div_up(len, merkle::THREADS)), dim3(merkle::THREADS), 0,
+            (const uint32_t*)(t.digests + t.layer_off[layer] * 8), t.digests + t.layer_off[layer + 1] * 8, len,
+            (const uint32_t* const*)nullptr, 0);
+    return false;
+  }
+  if (len <= TAIL) {
+    KLAUNCH(ctx, "compress_tail", 96.0 * len, merkle::compress_tail_lanes, dim3(1), dim3(1024), 0, t.digests + t.layer_off[layer] * 8, len);
+    return true;
+  }
+  KLAUNCH(ctx, "compress_small", 96.0 * len, merkle::compress_layer_lanes, dim3(div_up(len * 16, merkle::THREADS)), dim3(merkle::THREADS),
+          0, (const uint32_t*)(t.digests + t.layer_off[layer] * 8), t.digests + t.layer_off[layer + 1] * 8, len);
+  return false;
+}
+
 // MerkleTreeMmcs::commit over column-major matrices of power-of-two heights.
 static void build_tree(zkm_ctx* ctx, const std::vector<zkm_matrix>& mats, Tree& t) {
   size_t maxh = 0;
@@ -353,16 +372,15 @@ static void build_tree(zkm_ctx* ctx, const std::vector<zkm_matrix>& mats, Tree& 
     KLAUNCH(ctx, "hash_leaves", 4.0 * maxh * ptrs.size() + 32.0 * maxh, merkle::hash_leaves, dim3(div_up(maxh, merkle::THREADS)),
             dim3(merkle::THREADS), 0, d, (int)ptrs.size(), maxh, t.digests);
   }
-  // the top of the tree (<= TAIL nodes per layer, no shorter matrix to inject) goes in one launch
-  const size_t TAIL = 512;
+  // near the root (no shorter matrix left to inject) layers switch to 16 lanes per node, and the last
+  // <= 64-node layers go in one launch
   size_t min_h = maxh;
   for (auto& m : mats) min_h = std::min(min_h, m.h);
   int layer = 0;
   for (size_t len = maxh / 2; len >= 1; len >>= 1, layer++) {
-    if (len <= TAIL && min_h > len) {
-      KLAUNCH(ctx, "compress_tail", 96.0 * len, merkle::compress_tail, dim3(1), dim3(merkle::THREADS), 0,
-              t.digests + t.layer_off[layer] * 8, len);
-      break;
+    if (min_h > len) {
+      if (compress_small_layer(ctx, t, layer, len)) break;
+      continue;
     }
     auto ptrs = cols_of_height(len);
     const uint32_t** d = nullptr;
@@ -787,17 +805,8 @@ static void open_impl(zkm_ctx* ctx, const zkm_pk* pk, zkm_main_data* md, const z
     KLAUNCH(ctx, "hash_fri_leaves", 64.0 * half, merkle::hash_fri_leaves, dim3(div_up(half, merkle::THREADS)), dim3(merkle::THREADS), 0,
             (const E4*)f, half, t.digests);
     int layer = 0;
-    for (size_t l = half / 2; l >= 1; l >>= 1, layer++) {
-      if (l <= 512) {
-        KLAUNCH(ctx, "compress_tail", 96.0 * l, merkle::compress_tail, dim3(1), dim3(merkle::THREADS), 0,
-                t.digests + t.layer_off[layer] * 8, l);
-        break;
-      }
-      KLAUNCH(ctx, "compress_layer", 96.0 * l, merkle::compress_layer, dim3(div_up(l, merkle::THREADS)), dim3(merkle::THREADS), 0,
-              (const uint32_t*)(t.digests + t.layer_off[layer] * 8), t.digests + t.layer_off[layer + 1] * 8, l,
-              (const uint32_t* const*)nullptr, 0);
-      if (l == 1) break;
-    }
+    for (size_t l = half / 2; l >= 1; l >>= 1, layer++)
+      if (compress_small_layer(ctx, t, layer, l)) break;
     std::array<uint32_t, 8> root;
     const uint32_t* h_root = ctx->download_async(t.node(t.log_max, 0), 8);
     HIP_CHECK(hipStreamSynchronize(st));
