@@ -96,6 +96,26 @@ def test_pcs_commit_shifted_domains(hip_ctx, oracle):
     assert np.array_equal(d.root, root_o)
 
 
+def test_edge_shapes_bit_exact(hip_ctx, oracle):
+    # local_only chips, a lookup-free chip (empty permutation trace), global scope, preprocessed local_only
+    sh = synth.edge_shard(7)
+    fri = abi.FriConfig(1, 12, 8)
+    prep = [c.prep_trace for c in sh.chips if c.prep_width]
+    lo = [int(c.local_only) for c in sh.chips if c.prep_width]
+    hp = prover.HipProver(sh.chips, fri, synth.NUM_PV_ELTS, ctx=hip_ctx)
+    pk = hp.setup(prep, lo, sh.pc_start, sh.initial_global_cumulative_sum)
+    ch = prover.new_challenger()
+    pk.observe_into(ch)
+    start = ch.copy()
+    proof = hp.prove_shard(pk, sh.public_values, hp.upload_traces([c.trace for c in sh.chips]), ch).copy()
+    opk = oracle.Pk(prep, lo, sh.pc_start, sh.initial_global_cumulative_sum, 1)
+    och = oracle.new_challenger()
+    opk.observe_into(och)
+    oproof, _ = oracle.prove_shard(opk, sh.chips, [c.trace for c in sh.chips], sh.public_values, fri, synth.NUM_PV_ELTS, och)
+    assert np.array_equal(proof, oproof)
+    assert oracle.verify_shard(opk, sh.chips, fri, synth.NUM_PV_ELTS, start.copy(), proof) == 0
+
+
 @pytest.mark.parametrize("log_blowup,queries", [(2, 42), (3, 28)])
 def test_recursion_fri_configs_bit_exact(hip_ctx, oracle, log_blowup, queries):
     # compress / shrink shards go through the same commit+open with the compressed FRI configs

@@ -65,6 +65,21 @@ def test_prove_then_verify(oracle, k, with_prep):
     assert ch.as_tuple() == vch.as_tuple()  # prover and verifier transcripts end in the same state
 
 
+def test_edge_shapes_prove_then_verify(oracle):
+    # local_only chips (main/preprocessed opened at zeta only), a chip without lookups, equal heights
+    sh = synth.edge_shard(6)
+    fri = abi.FriConfig(1, 10, 6)
+    prep = [c.prep_trace for c in sh.chips if c.prep_width]
+    lo = [int(c.local_only) for c in sh.chips if c.prep_width]
+    pk = oracle.Pk(prep, lo, sh.pc_start, sh.initial_global_cumulative_sum, 1)
+    ch = oracle.new_challenger()
+    pk.observe_into(ch)
+    vch = ch.copy()
+    proof, _ = oracle.prove_shard(pk, sh.chips, [c.trace for c in sh.chips], sh.public_values, fri, synth.NUM_PV_ELTS, ch)
+    assert oracle.verify_shard(pk, sh.chips, fri, synth.NUM_PV_ELTS, vch, proof) == 0
+    assert [c.perm_ext_width for c in sh.chips][2] == 0
+
+
 def test_verifier_rejects_corruption(oracle):
     fri = abi.FriConfig(1, 12, 8)
     sh, pk, ch, vch, proof = _prove(oracle, 6, True, fri)

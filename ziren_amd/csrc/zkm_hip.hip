@@ -1008,6 +1008,17 @@ void zkm_ctx_destroy(zkm_ctx* ctx) {
   delete ctx;
 }
 
+// Return the cached (idle) device buffers of the context's pool to the driver.
+int zkm_ctx_trim(zkm_ctx* ctx) {
+  API_BEGIN
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIP_CHECK(hipSetDevice(ctx->device));
+  HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  for (auto& kv : ctx->free_list) HIP_CHECK(hipFree(kv.second));
+  ctx->free_list.clear();
+  API_END
+}
+
 int zkm_ctx_synchronize(zkm_ctx* ctx) {
   API_BEGIN
   HIP_CHECK(hipStreamSynchronize(ctx->stream));

@@ -58,6 +58,9 @@ class Context:
     def synchronize(self):
         lib.check(lib.load().zkm_ctx_synchronize(self.h))
 
+    def trim(self):
+        lib.check(lib.load().zkm_ctx_trim(self.h))
+
     def last_timings(self):
         names = (C.c_char_p * 64)()
         ms = (C.c_float * 64)()

@@ -145,7 +145,7 @@ def _build_chip(name, log_height, main_width, n_lookups, chip_index, seed, prep_
     first_acc = True
     while budget - next_col[0] >= 3:
         remaining = budget - next_col[0]
-        if first_acc and remaining >= 3:
+        if first_acc and remaining >= 3 and not local_only:
             # accumulator: acc' = acc + a*b on transitions, pinned to public values at both ends
             a, c2 = new_col(), new_col()
             start = int(rng.uniform_field(1)[0]) if with_trace else 0
@@ -246,6 +246,33 @@ def syn_shard(k: int, with_prep: bool = False, with_trace: bool = True, seed: in
     igcs = F.to_monty(rng.uniform_field(14))
     return SynShard(chips=out, public_values=F.to_monty(pv_arr), pc_start=F.to_monty(0x400000),
                     initial_global_cumulative_sum=igcs)
+
+
+def edge_shard(k: int, seed: int = 0xED6E) -> SynShard:
+    """Shapes the reference's machine has but SYN-k lacks: a `local_only` chip (opened at zeta only,
+    prover.rs:526-544), a chip without lookups (empty permutation trace, zero local sum), a global-scope
+    chip, a preprocessed chip, and two chips of equal height (ordering by name, prover.rs:264)."""
+    out, pvs = [], {}
+    specs = [
+        dict(name="Plain", lh=k, m=20, n_lookups=4),
+        dict(name="LocalOnly", lh=k, m=18, n_lookups=2, local_only=True),
+        dict(name="NoLookups", lh=max(k - 1, 1), m=9, n_lookups=0),
+        dict(name="Global", lh=max(k - 2, 1), m=30, n_lookups=3, global_scope=True),
+        dict(name="Byte", lh=max(k - 1, 1), m=12, n_lookups=4, prep_width=6, prep_index=0, local_only=True),
+    ]
+    for i, sp in enumerate(specs):
+        chip, pv = _build_chip(sp["name"], sp["lh"], sp["m"], sp["n_lookups"], i, seed + i,
+                               prep_width=sp.get("prep_width", 0), prep_index=sp.get("prep_index", -1),
+                               global_scope=sp.get("global_scope", False), local_only=sp.get("local_only", False))
+        out.append(chip)
+        pvs.update(pv)
+    pv_arr = np.zeros(PROOF_MAX_NUM_PVS, dtype=np.uint64)
+    rng = F.SplitMix64(seed ^ 0x1234)
+    pv_arr[:NUM_PV_ELTS] = rng.uniform_field(NUM_PV_ELTS)
+    for idx, v in pvs.items():
+        pv_arr[idx] = v
+    return SynShard(chips=out, public_values=F.to_monty(pv_arr), pc_start=F.to_monty(0x400000),
+                    initial_global_cumulative_sum=F.to_monty(rng.uniform_field(14)))
 
 
 def shard_algorithmic_bytes(shard: SynShard) -> int:
