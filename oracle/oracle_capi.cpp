@@ -258,6 +258,26 @@ int orc_pcs_open_batch(size_t n_mats, const uint32_t* const* mats, const size_t*
   ORC_CATCH
 }
 
+// Mmcs::verify_batch (crates/recursion/circuit/src/fri.rs:363-405) on caller-supplied openings.
+int orc_mmcs_verify_batch(const uint32_t root[8], size_t n_mats, const size_t* heights, const size_t* widths, size_t index,
+                          const uint32_t* values, const uint32_t* proof, size_t proof_len, int* ok) {
+  ORC_TRY
+  Digest commit;
+  for (int i = 0; i < 8; i++) commit.d[i] = from_monty(root[i]);
+  std::vector<size_t> dims(heights, heights + n_mats);
+  std::vector<std::vector<F>> opened;
+  size_t pos = 0;
+  for (size_t m = 0; m < n_mats; m++) {
+    std::vector<F> row(widths[m]);
+    for (auto& v : row) v = from_monty(values[pos++]);
+    opened.push_back(row);
+  }
+  std::vector<Digest> path(proof_len);
+  for (size_t l = 0; l < proof_len; l++) for (int k = 0; k < 8; k++) path[l].d[k] = from_monty(proof[8 * l + k]);
+  *ok = mmcs_verify_batch(commit, dims, index, opened, path);
+  ORC_CATCH
+}
+
 struct orc_pk { ProvingKey pk; VerifyingKey vk; };
 
 int orc_pk_setup(size_t n_prep, const uint32_t* const* prep, const size_t* heights, const size_t* widths,

@@ -115,6 +115,17 @@ def pcs_open_batch(mats, log_blowup, index, domain_shifts=None):
     return values, proof.reshape(logmax, 8), bool(ok.value)
 
 
+def mmcs_verify_batch(root, heights, widths, index, values, proof):
+    root = np.ascontiguousarray(root, dtype=np.uint32)
+    values = np.ascontiguousarray(values, dtype=np.uint32)
+    proof = np.ascontiguousarray(proof, dtype=np.uint32)
+    ok = C.c_int(0)
+    _check(lib().orc_mmcs_verify_batch(abi.as_u32p(root), C.c_size_t(len(heights)), _sizes(heights), _sizes(widths),
+                                       C.c_size_t(index), abi.as_u32p(values), abi.as_u32p(proof),
+                                       C.c_size_t(proof.size // 8), C.byref(ok)))
+    return bool(ok.value)
+
+
 class Pk:
     def __init__(self, prep_traces, local_only, pc_start, igcs, log_blowup):
         prep = [np.ascontiguousarray(m, dtype=np.uint32) for m in prep_traces]

@@ -207,6 +207,57 @@ def test_shard_proof_large_verifies(hip_ctx, oracle):
     assert oracle.verify_shard(opk, sh.chips, fri, synth.NUM_PV_ELTS, start3.copy(), proof3) != 0
 
 
+def test_baseline_config_commit_2pow20(hip_ctx, oracle):
+    # BASELINE config 2: 2^20-row traces, LDE + Poseidon2 commit only. Too large for the oracle prover, so:
+    # (1) determinism of the root, (2) every opening the GPU serves verifies against that root with the
+    # restated Mmcs::verify_batch, (3) opened rows equal the LDE of the committed matrix (spot rows, via the
+    # small-size-verified LDE entry point), (4) a one-cell change moves the root.
+    rng = np.random.default_rng(2020)
+    k = 20
+    shapes = [(1 << k, 9), (1 << (k - 1), 5), (1 << (k - 3), 17)]
+    mats = [rand(rng, s) for s in shapes]
+    dm = [hip_ctx.upload(m) for m in mats]
+    d1 = prover.pcs_commit(hip_ctx, dm, 1)
+    d2 = prover.pcs_commit(hip_ctx, dm, 1)
+    assert np.array_equal(d1.root, d2.root)
+    heights = [s[0] * 2 for s in shapes]
+    widths = [s[1] for s in shapes]
+    lde0 = prover.coset_lde_batch(hip_ctx, mats[0], 1, F.to_monty(3))
+    for idx in [0, 1, 12345, (1 << (k + 1)) - 1, 1 << k]:
+        v, pr = d1.open_batch(idx)
+        assert oracle.mmcs_verify_batch(d1.root, heights, widths, idx, v, pr)
+        assert np.array_equal(v[:9], lde0[idx])
+        bad = v.copy()
+        bad[3] ^= 1
+        assert not oracle.mmcs_verify_batch(d1.root, heights, widths, idx, bad, pr)
+    mats[0][777, 2] ^= 1
+    d3 = prover.pcs_commit(hip_ctx, [hip_ctx.upload(mats[0])] + dm[1:], 1)
+    assert not np.array_equal(d3.root, d1.root)
+
+
+def test_baseline_config_full_proof_2pow22(hip_ctx, oracle):
+    # BASELINE config 3: the 2^22-row shard the benchmark times (SYN-22, core FRI parameters, per-chip quotient
+    # kernels): the restated verifier must accept it, and proving twice gives the same bytes.
+    sh = synth.syn_shard(22)
+    fri = abi.FriConfig(1, 84, 16)
+    hp = prover.HipProver(sh.chips, fri, synth.NUM_PV_ELTS, ctx=hip_ctx, specialize=True)
+    pk = hp.setup([], [], sh.pc_start, sh.initial_global_cumulative_sum)
+    ch = prover.new_challenger()
+    pk.observe_into(ch)
+    start = ch.copy()
+    traces = hp.upload_traces([c.trace for c in sh.chips])
+    for c in sh.chips:
+        c.trace = None
+    proof = hp.prove_shard(pk, sh.public_values, traces, ch).copy()
+    opk = oracle.Pk([], [], sh.pc_start, sh.initial_global_cumulative_sum, 1)
+    assert oracle.verify_shard(opk, sh.chips, fri, synth.NUM_PV_ELTS, start.copy(), proof) == 0
+    proof2 = hp.prove_shard(pk, sh.public_values, traces, start.copy()).copy()
+    assert np.array_equal(proof, proof2)
+    for t in traces:
+        t.free()
+    hip_ctx.trim()
+
+
 def test_open_rejects_bad_arguments(hip_ctx):
     sh = synth.syn_shard(4)
     fri = abi.FriConfig(1, 4, 4)
