@@ -134,10 +134,10 @@ __device__ __forceinline__ LaneConsts load_consts(int e) {
 __device__ __forceinline__ uint32_t permute(uint32_t x, const LaneConsts& k) {
   x = external_layer(x);
 #pragma unroll
-  for (int r = 0; r < 4; r++) x = external_layer(p2::sbox(kb::add(x, k.rc[r])));
+  for (int r = 0; r < 4; r++) x = external_layer(p2::sbox_rc(x, k.rc[r]));
 #pragma unroll 1
   for (int r = 0; r < 13; r++) {
-    uint32_t y = p2::sbox(kb::add(x, p2::d_rc_int[r]));
+    uint32_t y = p2::sbox_rc(x, p2::d_rc_int[r]);
     x = k.lane0 ? y : x;
     uint32_t sum = kb::add(x, dpp<ROW_ROR1>(x));
     sum = kb::add(sum, dpp<ROW_ROR2>(sum));
@@ -146,7 +146,7 @@ __device__ __forceinline__ uint32_t permute(uint32_t x, const LaneConsts& k) {
     x = kb::add(kb::mul(x, k.diag), sum);
   }
 #pragma unroll
-  for (int r = 4; r < 8; r++) x = external_layer(p2::sbox(kb::add(x, k.rc[r])));
+  for (int r = 4; r < 8; r++) x = external_layer(p2::sbox_rc(x, k.rc[r]));
   return x;
 }
 }  // namespace lanes

@@ -15,15 +15,11 @@ namespace p2 {
 
 #include "poseidon2_constants.inc"
 
-// device copies live in constant memory (scalar loads: indices are wave-uniform)
+// device copies live in constant memory (scalar loads: indices are wave-uniform); the round constants are
+// stored as rc - p (two's complement), the form sbox_rc() consumes
 __constant__ uint32_t d_rc_ext[8][16];
 __constant__ uint32_t d_rc_int[13];
 __constant__ uint32_t d_diag[16];
-
-struct HostTables {
-  static const uint32_t* rc_row(int r) { return ZKM_RC_16_30_MONTY[r]; }
-  static uint32_t diag(int i) { return ZKM_INTERNAL_DIAG_16_MONTY[i]; }
-};
 
 KB_HD void m4(uint32_t& s0, uint32_t& s1, uint32_t& s2, uint32_t& s3) {
   // [[2,3,1,1],[1,2,3,1],[1,1,2,3],[3,1,1,2]]
@@ -52,6 +48,29 @@ KB_HD void external_layer(uint32_t s[16]) {
 }
 
 KB_HD uint32_t sbox(uint32_t x) { return kb::mul(kb::sqr(x), x); }
+
+KB_HD int32_t mulhi_s32(int32_t a, int32_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __mulhi(a, b);
+#else
+  return (int32_t)(((int64_t)a * b) >> 32);
+#endif
+}
+// (s + rc)^3 with the round-constant addition and both intermediate corrections folded away:
+// `rcm` = rc - p (two's complement), so y = s + rcm lies in [-p, p) as a signed word; a signed Montgomery
+// step maps x in (-p^2, p^2) to (x - t p) / 2^32 in (-p, p) with t = x * p^-1 taken as a signed word,
+// so y^2 and then (y^2) * y stay signed and only the final value is brought back to [0, p).
+// 11 instructions instead of 15 (add-reduce + two full multiplies).
+KB_HD uint32_t sbox_rc(uint32_t s, uint32_t rcm) {
+  const int32_t y = (int32_t)(s + rcm);
+  const int64_t x1 = (int64_t)y * y;
+  const int32_t t1 = (int32_t)((uint32_t)x1 * kb::MU);
+  const int32_t z = (int32_t)(x1 >> 32) - mulhi_s32(t1, (int32_t)kb::P);
+  const int64_t x2 = (int64_t)z * y;
+  const int32_t t2 = (int32_t)((uint32_t)x2 * kb::MU);
+  const uint32_t r = (uint32_t)((int32_t)(x2 >> 32) - mulhi_s32(t2, (int32_t)kb::P));
+  return kb::umin32(r, r + kb::P);
+}
 
 // acc += x (64-bit accumulate of a 32-bit value): one v_mad_u64_u32 on the device
 KB_HD void acc_add(uint64_t& acc, uint32_t x) {
@@ -94,18 +113,18 @@ KB_HD void permute_impl(uint32_t s[16], RcExt rc_ext, RcInt rc_int, DiagFn diag)
 #pragma unroll
   for (int r = 0; r < 4; r++) {
 #pragma unroll
-    for (int i = 0; i < 16; i++) s[i] = sbox(kb::add(s[i], rc_ext(r, i)));
+    for (int i = 0; i < 16; i++) s[i] = sbox_rc(s[i], rc_ext(r, i));
     external_layer(s);
   }
 #pragma unroll 1
   for (int r = 0; r < 13; r++) {
-    s[0] = sbox(kb::add(s[0], rc_int(r)));
+    s[0] = sbox_rc(s[0], rc_int(r));
     internal_layer(s, diag);
   }
 #pragma unroll
   for (int r = 4; r < 8; r++) {
 #pragma unroll
-    for (int i = 0; i < 16; i++) s[i] = sbox(kb::add(s[i], rc_ext(r, i)));
+    for (int i = 0; i < 16; i++) s[i] = sbox_rc(s[i], rc_ext(r, i));
     external_layer(s);
   }
 }
@@ -118,16 +137,16 @@ __device__ __forceinline__ void permute(uint32_t s[16]) {
 
 inline void permute_host(uint32_t s[16]) {
   permute_impl(
-      s, [](int r, int i) { return ZKM_RC_16_30_MONTY[r < 4 ? r : r + 13][i]; },
-      [](int r) { return ZKM_RC_16_30_MONTY[4 + r][0]; }, [](int i) { return ZKM_INTERNAL_DIAG_16_MONTY[i]; });
+      s, [](int r, int i) { return ZKM_RC_16_30_MONTY[r < 4 ? r : r + 13][i] - kb::P; },
+      [](int r) { return ZKM_RC_16_30_MONTY[4 + r][0] - kb::P; }, [](int i) { return ZKM_INTERNAL_DIAG_16_MONTY[i]; });
 }
 
 // upload tables into constant memory (once per process, any device)
 inline hipError_t upload_tables() {
   uint32_t ext[8][16], in[13];
   for (int r = 0; r < 8; r++)
-    for (int i = 0; i < 16; i++) ext[r][i] = ZKM_RC_16_30_MONTY[r < 4 ? r : r + 13][i];
-  for (int r = 0; r < 13; r++) in[r] = ZKM_RC_16_30_MONTY[4 + r][0];
+    for (int i = 0; i < 16; i++) ext[r][i] = ZKM_RC_16_30_MONTY[r < 4 ? r : r + 13][i] - kb::P;
+  for (int r = 0; r < 13; r++) in[r] = ZKM_RC_16_30_MONTY[4 + r][0] - kb::P;
   hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(d_rc_ext), ext, sizeof ext);
   if (e != hipSuccess) return e;
   e = hipMemcpyToSymbol(HIP_SYMBOL(d_rc_int), in, sizeof in);

@@ -45,7 +45,7 @@ static thread_local std::string g_err;
 #define KLAUNCH(ctx, name, bytes, kernel, grid, block, lds, ...)                       \
   do {                                                                                  \
     (ctx)->kbegin(name, (double)(bytes));                                               \
-    hipLaunchKernelGGL(kernel, grid, block, lds, (ctx)->stream, __VA_ARGS__);           \
+    hipLaunchKernelGGL(kernel, grid, block, lds, (ctx)->cur, __VA_ARGS__);              \
     LAUNCH_CHECK();                                                                     \
     (ctx)->kend();                                                                      \
   } while (0)
@@ -100,7 +100,10 @@ static uint32_t sample_bits(zkm_challenger* c, uint32_t bits) {
 // ---- context -----------------------------------------------------------------------------------
 struct zkm_ctx {
   int device = 0;
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr;   // main stream: phases, transcript round trips
+  hipStream_t stream2 = nullptr;  // side stream: Merkle hashing overlapped with the LDEs of the same commit
+  hipStream_t cur = nullptr;      // where KLAUNCH / upload / kernel-timing events go right now
+  bool overlap = false;  // ZKM_OVERLAP=1: measured on SYN-22 it does not pay (both sides are issue-bound)
   std::mutex mu;
   std::multimap<size_t, void*> free_list;  // caching allocator: exact-size reuse
   std::map<void*, size_t> live;
@@ -127,13 +130,13 @@ struct zkm_ctx {
   void kbegin(const char* name, double bytes) {
     if (!kernel_timing) return;
     KRec r{name, bytes, get_event(), nullptr};
-    HIP_CHECK(hipEventRecord(r.start, stream));
+    HIP_CHECK(hipEventRecord(r.start, cur));
     krecs.push_back(r);
   }
   void kend() {
     if (!kernel_timing) return;
     krecs.back().stop = get_event();
-    HIP_CHECK(hipEventRecord(krecs.back().stop, stream));
+    HIP_CHECK(hipEventRecord(krecs.back().stop, cur));
   }
 
   // pinned host ring: short-lived host data goes H2D (and small results come D2H) through it without
@@ -149,6 +152,8 @@ struct zkm_ctx {
   }
   void begin_call() {
     HIP_CHECK(hipStreamSynchronize(stream));
+    HIP_CHECK(hipStreamSynchronize(stream2));
+    cur = stream;
     pin_off = 0;
   }
   // copy `bytes` of host data to a fresh device buffer; the source may die as soon as this returns
@@ -159,10 +164,10 @@ struct zkm_ctx {
     void* h = pin_alloc(bytes);
     if (h) {
       memcpy(h, src, bytes);
-      HIP_CHECK(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, stream));
+      HIP_CHECK(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, cur));
     } else {
-      HIP_CHECK(hipMemcpyAsync(d, src, bytes, hipMemcpyHostToDevice, stream));
-      HIP_CHECK(hipStreamSynchronize(stream));
+      HIP_CHECK(hipMemcpyAsync(d, src, bytes, hipMemcpyHostToDevice, cur));
+      HIP_CHECK(hipStreamSynchronize(cur));
     }
     return d;
   }
@@ -214,6 +219,7 @@ struct zkm_ctx {
   }
   void end_timing(bool append) {
     HIP_CHECK(hipStreamSynchronize(stream));
+    HIP_CHECK(hipStreamSynchronize(stream2));
     if (!append) { timing_names.clear(); timing_ms.clear(); kstats.clear(); }
     for (auto& r : krecs) {
       float ms = 0;
@@ -348,7 +354,13 @@ static bool compress_small_layer(zkm_ctx* ctx, Tree& t, int layer, size_t len) {
 }
 
 // MerkleTreeMmcs::commit over column-major matrices of power-of-two heights.
-static void build_tree(zkm_ctx* ctx, const std::vector<zkm_matrix>& mats, Tree& t) {
+static void build_tree(zkm_ctx* ctx, const std::vector<zkm_matrix>& mats, Tree& t, const std::vector<hipEvent_t>* ready = nullptr) {
+  // when `ready` is given, matrix i is complete once ready[i] has fired (it is being produced on another stream)
+  auto wait_height = [&](size_t h) {
+    if (!ready) return;
+    for (size_t i = 0; i < mats.size(); i++)
+      if (mats[i].h == h) HIP_CHECK(hipStreamWaitEvent(ctx->cur, (*ready)[i], 0));
+  };
   size_t maxh = 0;
   for (auto& m : mats) maxh = std::max(maxh, m.h);
   t.max_height = maxh;
@@ -369,6 +381,7 @@ static void build_tree(zkm_ctx* ctx, const std::vector<zkm_matrix>& mats, Tree& 
     auto ptrs = cols_of_height(maxh);
     const uint32_t** d = upload_ptrs(ctx, ptrs);
     to_free.push_back(d);
+    wait_height(maxh);
     KLAUNCH(ctx, "hash_leaves", 4.0 * maxh * ptrs.size() + 32.0 * maxh, merkle::hash_leaves, dim3(div_up(maxh, merkle::THREADS)),
             dim3(merkle::THREADS), 0, d, (int)ptrs.size(), maxh, t.digests);
   }
@@ -384,7 +397,7 @@ static void build_tree(zkm_ctx* ctx, const std::vector<zkm_matrix>& mats, Tree& 
     }
     auto ptrs = cols_of_height(len);
     const uint32_t** d = nullptr;
-    if (!ptrs.empty()) { d = upload_ptrs(ctx, ptrs); to_free.push_back(d); }
+    if (!ptrs.empty()) { d = upload_ptrs(ctx, ptrs); to_free.push_back(d); wait_height(len); }
     KLAUNCH(ctx, "compress_layer", 96.0 * len + 4.0 * len * ptrs.size(), merkle::compress_layer, dim3(div_up(len, merkle::THREADS)),
             dim3(merkle::THREADS), 0, (const uint32_t*)(t.digests + t.layer_off[layer] * 8), t.digests + t.layer_off[layer + 1] * 8,
             len, (const uint32_t* const*)d, (int)ptrs.size());
@@ -405,6 +418,7 @@ static void free_pcs_data(zkm_ctx* ctx, zkm_pcs_data* d) {
 static zkm_pcs_data* pcs_commit(zkm_ctx* ctx, const std::vector<zkm_matrix>& mats, const std::vector<uint32_t>& shifts,
                                 int log_blowup) {
   zkm_pcs_data* d = new zkm_pcs_data();
+  std::vector<hipEvent_t> ready;
   try {
     d->log_blowup = log_blowup;
     for (size_t i = 0; i < mats.size(); i++) {
@@ -413,18 +427,42 @@ static zkm_pcs_data* pcs_commit(zkm_ctx* ctx, const std::vector<zkm_matrix>& mat
       l.h = m.h << log_blowup;
       l.w = m.w;
       l.d = ctx->alloc_n<uint32_t>(l.h * l.w);
-      uint32_t s = shifts.empty() ? kb::ONE : shifts[i];
-      lde_columns(ctx, m.d, m.h, m.w, log_blowup, kb::mul(kb::GEN, kb::inv(s)), l.d);
       d->ldes.push_back(l);
       d->evals.push_back(m.d);
       d->eval_heights.push_back(m.h);
-      d->domain_shifts.push_back(s);
+      d->domain_shifts.push_back(shifts.empty() ? kb::ONE : shifts[i]);
     }
-    build_tree(ctx, d->ldes, d->tree);
+    // LDEs tallest first on the main stream; the tree is hashed on the side stream as the matrices it needs
+    // complete, so the (VALU-bound) leaf hashing of the tall matrices overlaps the LDEs of the shorter ones.
+    std::vector<size_t> order(mats.size());
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return mats[a].h > mats[b].h; });
+    const bool overlap = ctx->overlap && mats.size() > 1;
+    if (overlap) ready.resize(mats.size());
+    for (size_t i : order) {
+      lde_columns(ctx, mats[i].d, mats[i].h, mats[i].w, log_blowup, kb::mul(kb::GEN, kb::inv(d->domain_shifts[i])), d->ldes[i].d);
+      if (overlap) {
+        ready[i] = ctx->get_event();
+        HIP_CHECK(hipEventRecord(ready[i], ctx->stream));
+      }
+    }
+    if (overlap) {
+      ctx->cur = ctx->stream2;
+      build_tree(ctx, d->ldes, d->tree, &ready);
+      hipEvent_t done = ctx->get_event();
+      HIP_CHECK(hipEventRecord(done, ctx->stream2));
+      ctx->cur = ctx->stream;
+      HIP_CHECK(hipStreamWaitEvent(ctx->stream, done, 0));
+      ready.push_back(done);
+    } else {
+      build_tree(ctx, d->ldes, d->tree);
+    }
     const uint32_t* h_root = ctx->download_async(d->tree.node(d->tree.log_max, 0), 8);
     HIP_CHECK(hipStreamSynchronize(ctx->stream));
     memcpy(d->root, h_root, 32);
+    for (auto e : ready) ctx->event_pool.push_back(e);
   } catch (...) {
+    ctx->cur = ctx->stream;
     free_pcs_data(ctx, d);
     throw;
   }
@@ -983,6 +1021,9 @@ int zkm_ctx_create(int device, zkm_ctx** out) {
   zkm_ctx* c = new zkm_ctx();
   c->device = device;
   HIP_CHECK(hipStreamCreate(&c->stream));
+  HIP_CHECK(hipStreamCreate(&c->stream2));
+  c->cur = c->stream;
+  if (const char* e = getenv("ZKM_OVERLAP")) c->overlap = atoi(e) != 0;
   HIP_CHECK(p2::upload_tables());
   HIP_CHECK(hipFuncSetAttribute((const void*)lde::lde_rows, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIP_CHECK(hipFuncSetAttribute((const void*)lde::lde_cols<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -1005,6 +1046,7 @@ void zkm_ctx_destroy(zkm_ctx* ctx) {
   for (auto& m : ctx->modules) (void)hipModuleUnload(m);
   if (ctx->pin) (void)hipHostFree(ctx->pin);
   (void)hipStreamDestroy(ctx->stream);
+  (void)hipStreamDestroy(ctx->stream2);
   delete ctx;
 }
 
