@@ -54,6 +54,7 @@ def main():
     ap.add_argument("--cpu-sample-log-rows", type=int, default=19)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--inflight", type=int, default=1, help="shards proven concurrently per GPU (one context + host thread each)")
+    ap.add_argument("--kernel-timing", type=int, default=2, help="0 off, 1 every launch, 2 launches >= 256 KiB (default)")
     ap.add_argument("--interpreter", action="store_true", help="use the bytecode interpreter instead of per-chip quotient kernels")
     args = ap.parse_args()
 
@@ -74,6 +75,7 @@ def main():
         chj = prover.new_challenger()
         pkj.observe_into(chj)
         trj = hpj.upload_traces([c.trace for c in shard.chips])  # inputs resident in HBM before timing
+        lib.load().zkm_ctx_set_kernel_timing(hpj.ctx.h, C.c_int(args.kernel_timing))
         lanes.append((hpj, pkj, chj, trj, np.zeros(1 << 22, dtype=np.uint32)))
     hp = lanes[0][0]
     hp_holder["hp"] = hp

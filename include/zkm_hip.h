@@ -141,7 +141,8 @@ int zkm_ctx_last_timings(zkm_ctx* ctx, const char** names, float* ms, int cap);
 /* per-kernel totals of the same call: HIP-event time on the context's stream, launch count and
  * compulsory HBM bytes (each input/output array of a launch counted once). Returns the count. */
 int zkm_ctx_kernel_timings(zkm_ctx* ctx, const char** names, float* ms, uint32_t* calls, double* bytes, int cap);
-void zkm_ctx_set_kernel_timing(zkm_ctx* ctx, int enabled);
+/* mode 0: off; 1: every launch; 2 (default): only launches whose compulsory bytes are >= 256 KiB */
+void zkm_ctx_set_kernel_timing(zkm_ctx* ctx, int mode);
 /* Register a chip-specialised quotient kernel: a gfx950 code object exporting
  * `zkm_quotient_specialized(stark::QuotientArgs)` generated from exactly these program words
  * (ziren_amd/codegen.py; the Rust shim does this once per chip AIR). zkm_open uses it for chips whose

@@ -9,6 +9,7 @@
 #include "../../include/zkm_hip.h"
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <array>
@@ -42,12 +43,16 @@ static thread_local std::string g_err;
 #define LAUNCH_CHECK() HIP_CHECK(hipGetLastError())
 // launch on the context's stream, bracketed by HIP events; `bytes` = compulsory HBM bytes of this
 // launch (each input and output array counted once) for the roofline report.
-#define KLAUNCH(ctx, name, bytes, kernel, grid, block, lds, ...)                       \
-  do {                                                                                  \
-    (ctx)->kbegin(name, (double)(bytes));                                               \
-    hipLaunchKernelGGL(kernel, grid, block, lds, (ctx)->cur, __VA_ARGS__);              \
-    LAUNCH_CHECK();                                                                     \
-    (ctx)->kend();                                                                      \
+#define KLAUNCH(ctx, name, bytes, kernel, grid, block, lds, ...)                                        \
+  do {                                                                                                   \
+    if ((ctx)->kbegin(name, (double)(bytes))) {                                                          \
+      /* start/stop timestamps ride on the dispatch's own completion signal: no extra barrier packets */ \
+      hipExtLaunchKernelGGL(kernel, grid, block, lds, (ctx)->cur, (ctx)->krecs.back().start,             \
+                            (ctx)->krecs.back().stop, 0, __VA_ARGS__);                                   \
+    } else {                                                                                             \
+      hipLaunchKernelGGL(kernel, grid, block, lds, (ctx)->cur, __VA_ARGS__);                             \
+    }                                                                                                    \
+    LAUNCH_CHECK();                                                                                      \
   } while (0)
 
 static inline int log2_strict(size_t n) {
@@ -117,7 +122,9 @@ struct zkm_ctx {
   struct KStat { double ms = 0, bytes = 0; uint32_t calls = 0; };
   std::vector<KRec> krecs;
   std::map<std::string, KStat> kstats;
-  bool kernel_timing = true;
+  // 0: off; 1: every launch; 2 (default): only launches moving >= 256 KiB (the ~300 tiny launches of a proof
+  // are left untimed)
+  int kernel_timing = 2;
   // per-chip specialised quotient kernels (ziren_amd/codegen.py), keyed by a hash of the program words
   std::map<uint64_t, hipFunction_t> quotient_fns;
   std::vector<hipModule_t> modules;
@@ -127,16 +134,12 @@ struct zkm_ctx {
     else HIP_CHECK(hipEventCreate(&e));
     return e;
   }
-  void kbegin(const char* name, double bytes) {
-    if (!kernel_timing) return;
-    KRec r{name, bytes, get_event(), nullptr};
-    HIP_CHECK(hipEventRecord(r.start, cur));
+  // returns true when this launch is to be timed; the record then holds the two events to pass to the launch
+  bool kbegin(const char* name, double bytes) {
+    if (!(kernel_timing == 1 || (kernel_timing == 2 && bytes >= 262144.0))) return false;
+    KRec r{name, bytes, get_event(), get_event()};
     krecs.push_back(r);
-  }
-  void kend() {
-    if (!kernel_timing) return;
-    krecs.back().stop = get_event();
-    HIP_CHECK(hipEventRecord(krecs.back().stop, cur));
+    return true;
   }
 
   // pinned host ring: short-lived host data goes H2D (and small results come D2H) through it without
@@ -680,9 +683,9 @@ static void open_impl(zkm_ctx* ctx, const zkm_pk* pk, zkm_main_data* md, const z
       // chip-specialised kernel: same arithmetic, values in VGPRs
       size_t arg_size = sizeof(a);
       void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &arg_size, HIP_LAUNCH_PARAM_END};
-      ctx->kbegin("quotient", qbytes);
-      HIP_CHECK(hipModuleLaunchKernel(fit->second, div_up(Q, 256), 1, 1, 256, 1, 1, 0, st, nullptr, config));
-      ctx->kend();
+      const bool timed = ctx->kbegin("quotient", qbytes);
+      HIP_CHECK(hipExtModuleLaunchKernel(fit->second, div_up(Q, 256) * 256, 1, 1, 256, 1, 1, 0, st, nullptr, config,
+                                         timed ? ctx->krecs.back().start : nullptr, timed ? ctx->krecs.back().stop : nullptr, 0));
     } else {
       KLAUNCH(ctx, "quotient", qbytes, stark::quotient_kernel, dim3(div_up(Q, bd)), dim3(bd), lds, a);
     }
@@ -1081,7 +1084,7 @@ int zkm_ctx_kernel_timings(zkm_ctx* ctx, const char** names, float* ms, uint32_t
   }
   return i;
 }
-void zkm_ctx_set_kernel_timing(zkm_ctx* ctx, int enabled) { ctx->kernel_timing = enabled != 0; }
+void zkm_ctx_set_kernel_timing(zkm_ctx* ctx, int mode) { ctx->kernel_timing = mode; }
 
 int zkm_ctx_register_quotient_kernel(zkm_ctx* ctx, const uint32_t* program, uint32_t program_len, const void* code_object,
                                      size_t code_object_len) {
