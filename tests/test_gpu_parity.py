@@ -116,6 +116,29 @@ def test_edge_shapes_bit_exact(hip_ctx, oracle):
     assert oracle.verify_shard(opk, sh.chips, fri, synth.NUM_PV_ELTS, start.copy(), proof) == 0
 
 
+@pytest.mark.parametrize("log_blowup,lqd", [(2, 2), (3, 3)])
+def test_higher_quotient_degree_bit_exact(hip_ctx, oracle, log_blowup, lqd):
+    # quotient degree 4 / 8 (recursion-style constraints of degree 2^lqd + 1), LogUp batches of 2^lqd
+    sh = synth.edge_shard(7, lqd=lqd)
+    fri = abi.FriConfig(log_blowup, 10, 8)
+    prep = [c.prep_trace for c in sh.chips if c.prep_width]
+    lo = [int(c.local_only) for c in sh.chips if c.prep_width]
+    for specialize in (False, True):
+        hp = prover.HipProver(sh.chips, fri, synth.NUM_PV_ELTS, ctx=hip_ctx, specialize=specialize)
+        pk = hp.setup(prep, lo, sh.pc_start, sh.initial_global_cumulative_sum)
+        ch = prover.new_challenger()
+        pk.observe_into(ch)
+        start = ch.copy()
+        proof = hp.prove_shard(pk, sh.public_values, hp.upload_traces([c.trace for c in sh.chips]), ch).copy()
+        opk = oracle.Pk(prep, lo, sh.pc_start, sh.initial_global_cumulative_sum, log_blowup)
+        och = oracle.new_challenger()
+        opk.observe_into(och)
+        oproof, _ = oracle.prove_shard(opk, sh.chips, [c.trace for c in sh.chips], sh.public_values, fri,
+                                       synth.NUM_PV_ELTS, och)
+        assert np.array_equal(proof, oproof)
+        assert oracle.verify_shard(opk, sh.chips, fri, synth.NUM_PV_ELTS, start.copy(), proof) == 0
+
+
 @pytest.mark.parametrize("log_blowup,queries", [(2, 42), (3, 28)])
 def test_recursion_fri_configs_bit_exact(hip_ctx, oracle, log_blowup, queries):
     # compress / shrink shards go through the same commit+open with the compressed FRI configs

@@ -80,6 +80,21 @@ def test_edge_shapes_prove_then_verify(oracle):
     assert [c.perm_ext_width for c in sh.chips][2] == 0
 
 
+@pytest.mark.parametrize("log_blowup,lqd", [(2, 2), (3, 3)])
+def test_higher_quotient_degree_prove_then_verify(oracle, log_blowup, lqd):
+    # recursion-style machines: quotient degree 2^lqd (4 / 8 chunks), LogUp batches of 2^lqd, blowup 2^log_blowup
+    sh = synth.edge_shard(6, lqd=lqd)
+    fri = abi.FriConfig(log_blowup, 8, 6)
+    prep = [c.prep_trace for c in sh.chips if c.prep_width]
+    lo = [int(c.local_only) for c in sh.chips if c.prep_width]
+    pk = oracle.Pk(prep, lo, sh.pc_start, sh.initial_global_cumulative_sum, log_blowup)
+    ch = oracle.new_challenger()
+    pk.observe_into(ch)
+    vch = ch.copy()
+    proof, _ = oracle.prove_shard(pk, sh.chips, [c.trace for c in sh.chips], sh.public_values, fri, synth.NUM_PV_ELTS, ch)
+    assert oracle.verify_shard(pk, sh.chips, fri, synth.NUM_PV_ELTS, vch, proof) == 0
+
+
 def test_verifier_rejects_corruption(oracle):
     fri = abi.FriConfig(1, 12, 8)
     sh, pk, ch, vch, proof = _prove(oracle, 6, True, fri)

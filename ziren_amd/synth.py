@@ -59,10 +59,11 @@ class SynChip:
 
 
 def _build_chip(name, log_height, main_width, n_lookups, chip_index, seed, prep_width=0, prep_index=-1,
-                global_scope=False, with_trace=True, local_only=False):
-    """Lay out columns, record lookups + constraints, and (optionally) generate a valid trace."""
+                global_scope=False, with_trace=True, local_only=False, lqd=1):
+    """Lay out columns, record lookups + constraints, and (optionally) generate a valid trace.
+    lqd = log2 of the quotient degree: 1 for the core machine (degree-3 constraints); the recursion
+    machines go higher (chip.rs:81-89), which also widens the LogUp batches to 2^lqd lookups."""
     n = 1 << log_height
-    lqd = 1
     batch = 1 << lqd
     rng = F.SplitMix64(seed)
     cols = {}       # main column -> uint64 canonical array
@@ -165,10 +166,20 @@ def _build_chip(name, log_height, main_width, n_lookups, chip_index, seed, prep_
             b.when_last_row().assert_eq(local[acc], b.public_values(pv1))
             first_acc = False
         elif remaining >= 4 and (next_col[0] % 3 == 0):
-            # degree-3 product d = a*b*c
+            # degree-3 product d = a*b*c (degree 2^lqd + 1 for lqd > 1: d = a^(2^lqd - 1) * b * c)
             a, c2, c3 = new_col(), new_col(), new_col()
-            d = new_col(F.mul(F.mul(cols[a], cols[c2]), cols[c3]) if with_trace else None)
-            b.assert_eq(local[a] * local[c2] * local[c3], local[d])
+            ea = (1 << lqd) - 1
+            if with_trace:
+                pa = cols[a]
+                for _ in range(ea - 1):
+                    pa = F.mul(pa, cols[a])
+                d = new_col(F.mul(F.mul(pa, cols[c2]), cols[c3]))
+            else:
+                d = new_col()
+            expr = local[a]
+            for _ in range(ea - 1):
+                expr = expr * local[a]
+            b.assert_eq(expr * local[c2] * local[c3], local[d])
         elif remaining >= 4 and (next_col[0] % 3 == 1):
             # boolean selector and a select: e = s*a + (1-s)*c
             sv = (rng.uniform_field(n) & np.uint64(1)) if with_trace else None
@@ -248,7 +259,7 @@ def syn_shard(k: int, with_prep: bool = False, with_trace: bool = True, seed: in
                     initial_global_cumulative_sum=igcs)
 
 
-def edge_shard(k: int, seed: int = 0xED6E) -> SynShard:
+def edge_shard(k: int, seed: int = 0xED6E, lqd: int = 1) -> SynShard:
     """Shapes the reference's machine has but SYN-k lacks: a `local_only` chip (opened at zeta only,
     prover.rs:526-544), a chip without lookups (empty permutation trace, zero local sum), a global-scope
     chip, a preprocessed chip, and two chips of equal height (ordering by name, prover.rs:264)."""
@@ -260,10 +271,12 @@ def edge_shard(k: int, seed: int = 0xED6E) -> SynShard:
         dict(name="Global", lh=max(k - 2, 1), m=30, n_lookups=3, global_scope=True),
         dict(name="Byte", lh=max(k - 1, 1), m=12, n_lookups=4, prep_width=6, prep_index=0, local_only=True),
     ]
+    if lqd > 1:  # recursion-style machine: one quotient degree for all chips, wider LogUp batches
+        specs = [dict(sp, n_lookups=sp["n_lookups"] + (3 if sp["n_lookups"] else 0)) for sp in specs]
     for i, sp in enumerate(specs):
         chip, pv = _build_chip(sp["name"], sp["lh"], sp["m"], sp["n_lookups"], i, seed + i,
                                prep_width=sp.get("prep_width", 0), prep_index=sp.get("prep_index", -1),
-                               global_scope=sp.get("global_scope", False), local_only=sp.get("local_only", False))
+                               global_scope=sp.get("global_scope", False), local_only=sp.get("local_only", False), lqd=lqd)
         out.append(chip)
         pvs.update(pv)
     pv_arr = np.zeros(PROOF_MAX_NUM_PVS, dtype=np.uint64)
