@@ -1,7 +1,7 @@
 """Staged GPU-vs-oracle diagnostics (run on the GPU box): prints where parity breaks."""
 import sys, os, time, traceback
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import numpy as np
 import oracle_lib as O
 from ziren_amd import prover, abi, synth, field as F

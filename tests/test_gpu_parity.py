@@ -281,6 +281,44 @@ def test_baseline_config_full_proof_2pow22(hip_ctx, oracle):
     hip_ctx.trim()
 
 
+def test_two_contexts_prove_concurrently(oracle):
+    # MachineProver is Send + Sync and is called from several threads (prove.rs:487-497): two contexts on the
+    # same GPU, one host thread each, must both produce the oracle's bytes.
+    import threading
+    sh = synth.syn_shard(10, with_prep=True)
+    fri = abi.FriConfig(1, 16, 8)
+    prep = [c.prep_trace for c in sh.chips if c.prep_width]
+    opk = oracle.Pk(prep, [0] * len(prep), sh.pc_start, sh.initial_global_cumulative_sum, 1)
+    och = oracle.new_challenger()
+    opk.observe_into(och)
+    oproof, _ = oracle.prove_shard(opk, sh.chips, [c.trace for c in sh.chips], sh.public_values, fri, synth.NUM_PV_ELTS, och)
+    ctxs = [prover.Context(0), prover.Context(0)]
+    results = [None, None]
+
+    def work(j):
+        hp = prover.HipProver(sh.chips, fri, synth.NUM_PV_ELTS, ctx=ctxs[j], specialize=bool(j))
+        pk = hp.setup(prep, [0] * len(prep), sh.pc_start, sh.initial_global_cumulative_sum)
+        traces = hp.upload_traces([c.trace for c in sh.chips])
+        outs = []
+        for _ in range(3):
+            ch = prover.new_challenger()
+            pk.observe_into(ch)
+            outs.append(hp.prove_shard(pk, sh.public_values, traces, ch).copy())
+        results[j] = outs
+
+    ts = [threading.Thread(target=work, args=(j,)) for j in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    for outs in results:
+        assert outs is not None
+        for p in outs:
+            assert np.array_equal(p, oproof)
+    for c in ctxs:
+        c.close()
+
+
 def test_open_rejects_bad_arguments(hip_ctx):
     sh = synth.syn_shard(4)
     fri = abi.FriConfig(1, 4, 4)
