@@ -50,6 +50,19 @@ KB_HD uint32_t monty_reduce(uint64_t x) {
 }
 KB_HD uint32_t mul(uint32_t a, uint32_t b) { return monty_reduce((uint64_t)a * b); }
 KB_HD uint32_t sqr(uint32_t a) { return mul(a, a); }
+// d * b for a signed d in (-p, p) (e.g. a difference of two reduced values, unreduced) and b in [0, p):
+// the Montgomery quotient is taken as a signed word, so (x - t p) / 2^32 lies in (-p, p); one correction.
+KB_HD uint32_t mul_signed(uint32_t d_twos_complement, uint32_t b) {
+  const int64_t x = (int64_t)(int32_t)d_twos_complement * (int64_t)b;
+  const int32_t t = (int32_t)((uint32_t)x * MU);
+#if defined(__HIP_DEVICE_COMPILE__)
+  const int32_t uhi = __mulhi(t, (int32_t)P);
+#else
+  const int32_t uhi = (int32_t)(((int64_t)t * (int64_t)P) >> 32);
+#endif
+  const uint32_t r = (uint32_t)((int32_t)(x >> 32) - uhi);
+  return umin32(r, r + P);
+}
 KB_HD uint32_t to_monty(uint32_t canonical) { return mul(canonical, R2); }
 KB_HD uint32_t from_monty(uint32_t m) { return monty_reduce((uint64_t)m); }
 

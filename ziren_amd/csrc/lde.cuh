@@ -69,7 +69,7 @@ __device__ __forceinline__ void ntt_pass(uint32_t* buf, int logn, int lognb, int
         uint32_t a = x[j0], b = x[j1];
         if (DIF) {
           x[j0] = kb::add(a, b);
-          x[j1] = kb::mul(kb::sub_lazy(a, b), w);
+          x[j1] = kb::mul_signed(a - b, w);
         } else {
           b = kb::mul(b, w);
           x[j0] = kb::add(a, b);
@@ -103,11 +103,12 @@ __device__ __forceinline__ void lds_ntt(uint32_t* buf, int logn, int lognb, int 
 }
 
 // Two-level power table of g in LDS: lo[i] = g^i (i < 64), hi[i] = g^(64 i) (i < nhi).
-__device__ __forceinline__ void build_pow_table(uint32_t g, uint32_t* lo, uint32_t* hi, int nhi) {
+// `scale` is folded into the low table, so pow_lookup() returns scale * g^e.
+__device__ __forceinline__ void build_pow_table(uint32_t g, uint32_t* lo, uint32_t* hi, int nhi, uint32_t scale = kb::ONE) {
   uint32_t g64 = g;
   for (int i = 0; i < 6; i++) g64 = kb::sqr(g64);
   for (int i = threadIdx.x; i < 64 + nhi; i += blockDim.x) {
-    if (i < 64) lo[i] = kb::pow(g, (uint64_t)i);
+    if (i < 64) lo[i] = kb::mul(scale, kb::pow(g, (uint64_t)i));
     else hi[i - 64] = kb::pow(g64, (uint64_t)(i - 64));
   }
 }
@@ -246,11 +247,10 @@ __global__ __launch_bounds__(THREADS) void lde_rows(const uint32_t* __restrict__
     uint32_t sA = sj;
     for (int i = 0; i < la; i++) sA = kb::sqr(sA);
     __syncthreads();
-    build_pow_table(sA, lo2, hi2, nhi);
-    uint32_t f = kb::mul(n_inv, kb::pow(sj, (uint64_t)k1));
+    build_pow_table(sA, lo2, hi2, nhi, kb::mul(n_inv, kb::pow(sj, (uint64_t)k1)));  // 1/n * shift_j^k1 folded in
     __syncthreads();
     for (int i = threadIdx.x; i < B; i += blockDim.x)
-      work[phys<true>(i)] = kb::mul(kb::mul(coef[phys<true>(i)], f), pow_lookup(lo2, hi2, kb::bitrev(i, lb)));
+      work[phys<true>(i)] = kb::mul(coef[phys<true>(i)], pow_lookup(lo2, hi2, kb::bitrev(i, lb)));
     __syncthreads();
     if (lb > 0) lds_ntt<false, true>(work, lb, 0, 1, tw_fwd);
     if (la > 0) {
