@@ -90,10 +90,14 @@ __global__ __launch_bounds__(THREADS) void eval_columns(const uint32_t* __restri
 #pragma unroll
     for (int c = 0; c < EVAL_COLS; c++) {
       const uint32_t x[5] = {v[c].x, v[c].y, v[c].z, v[c].w, TWO ? vnext[c] : 0u};
+      // two products share one Montgomery reduction (2 p^2 < 2^32 p)
 #pragma unroll
-      for (int k = 0; k < 4; k++) {
-        acc[c][0] = kb::eadd(acc[c][0], kb::escale(w[k], x[k]));
-        if (TWO) acc[c][1] = kb::eadd(acc[c][1], kb::escale(w[k], x[k + 1]));
+      for (int k = 0; k < 4; k += 2) {
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          acc[c][0].c[e] = kb::add(acc[c][0].c[e], kb::dot2(w[k].c[e], x[k], w[k + 1].c[e], x[k + 1]));
+          if (TWO) acc[c][1].c[e] = kb::add(acc[c][1].c[e], kb::dot2(w[k].c[e], x[k + 1], w[k + 1].c[e], x[k + 2]));
+        }
       }
     }
   }
@@ -169,7 +173,11 @@ __global__ __launch_bounds__(THREADS) void reduce_openings(const ReduceMat* __re
 #pragma unroll
       for (int k = 0; k < 8; k++) v[k] = col[(size_t)(c + k) * N];
 #pragma unroll
-      for (int k = 0; k < 8; k++) S = kb::eadd(S, kb::escale(alpha_pows[c + k], v[k]));
+      for (int k = 0; k < 8; k += 2) {
+        const kb::E4 a0 = alpha_pows[c + k], a1 = alpha_pows[c + k + 1];
+#pragma unroll
+        for (int e = 0; e < 4; e++) S.c[e] = kb::add(S.c[e], kb::dot2(a0.c[e], v[k], a1.c[e], v[k + 1]));
+      }
     }
     for (; c < M.width; c++) S = kb::eadd(S, kb::escale(alpha_pows[c], col[(size_t)c * N]));
     acc = kb::eadd(acc, kb::emul(kb::esub(M.Yc[0], kb::emul(M.A[0], S)), d0));
