@@ -143,7 +143,7 @@ __device__ __forceinline__ uint32_t permute(uint32_t x, const LaneConsts& k) {
     sum = kb::add(sum, dpp<ROW_ROR2>(sum));
     sum = kb::add(sum, dpp<ROW_ROR4>(sum));
     sum = kb::add(sum, dpp<ROW_ROR8>(sum));
-    x = kb::add(kb::mul(x, k.diag), sum);
+    x = kb::monty_reduce((uint64_t)x * k.diag + (uint64_t)sum * kb::ONE);
   }
 #pragma unroll
   for (int r = 4; r < 8; r++) x = external_layer(p2::sbox_rc(x, k.rc[r]));

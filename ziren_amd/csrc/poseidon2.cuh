@@ -93,18 +93,20 @@ KB_HD void internal_layer(uint32_t s[16], DiagFn diag) {
   uint32_t q = (uint32_t)(acc >> 31);
   uint32_t r = (uint32_t)acc - q * kb::P;
   uint32_t sum = kb::umin32(r, r - kb::P);
-  // s_i <- s_i * V_i + sum
+  // s_i <- s_i * V_i + sum. Where V_i costs more than one doubling, the addition rides inside the Montgomery
+  // reduction: (s_i V_i + sum * R) / R = s_i V_i / R + sum, one 64-bit multiply-add and one reduction.
+  const uint64_t sum_r = (uint64_t)sum * kb::ONE;
   s[0] = kb::sub(sum, kb::dbl(s[0]));                 // -2
   s[1] = kb::add(sum, s[1]);                          //  1
   s[2] = kb::add(sum, kb::dbl(s[2]));                 //  2
   s[3] = kb::add(sum, half(s[3]));                    //  1/2
-  s[4] = kb::add(sum, kb::mul3(s[4]));                //  3
-  s[5] = kb::add(sum, kb::dbl(kb::dbl(s[5])));        //  4
+  s[4] = kb::monty_reduce((uint64_t)s[4] * diag(4) + sum_r);   //  3
+  s[5] = kb::monty_reduce((uint64_t)s[5] * diag(5) + sum_r);   //  4
   s[6] = kb::sub(sum, half(s[6]));                    // -1/2
-  s[7] = kb::sub(sum, kb::mul3(s[7]));                // -3
-  s[8] = kb::sub(sum, kb::dbl(kb::dbl(s[8])));        // -4
+  s[7] = kb::monty_reduce((uint64_t)s[7] * diag(7) + sum_r);   // -3
+  s[8] = kb::monty_reduce((uint64_t)s[8] * diag(8) + sum_r);   // -4
 #pragma unroll
-  for (int i = 9; i < 16; i++) s[i] = kb::add(sum, kb::mul(s[i], diag(i)));
+  for (int i = 9; i < 16; i++) s[i] = kb::monty_reduce((uint64_t)s[i] * diag(i) + sum_r);
 }
 
 template <class RcExt, class RcInt, class DiagFn>
