@@ -65,10 +65,14 @@ KB_HD uint32_t sbox_rc(uint32_t s, uint32_t rcm) {
   const int32_t y = (int32_t)(s + rcm);
   const int64_t x1 = (int64_t)y * y;
   const int32_t t1 = (int32_t)((uint32_t)x1 * kb::MU);
-  const int32_t z = (int32_t)(x1 >> 32) - mulhi_s32(t1, (int32_t)kb::P);
+  uint32_t hi1 = (uint32_t)((uint64_t)x1 >> 32);
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm("" : "+v"(hi1));  // keep the next line a 32-bit subtract (the optimiser otherwise widens it to a borrow chain)
+#endif
+  const int32_t z = (int32_t)(hi1 - (uint32_t)mulhi_s32(t1, (int32_t)kb::P));
   const int64_t x2 = (int64_t)z * y;
   const int32_t t2 = (int32_t)((uint32_t)x2 * kb::MU);
-  const uint32_t r = (uint32_t)((int32_t)(x2 >> 32) - mulhi_s32(t2, (int32_t)kb::P));
+  const uint32_t r = (uint32_t)((uint64_t)x2 >> 32) - (uint32_t)mulhi_s32(t2, (int32_t)kb::P);
   return kb::umin32(r, r + kb::P);
 }
 
@@ -114,8 +118,11 @@ KB_HD void permute_impl(uint32_t s[16], RcExt rc_ext, RcInt rc_int, DiagFn diag)
   external_layer(s);
 #pragma unroll
   for (int r = 0; r < 4; r++) {
+    uint32_t rc[16];
 #pragma unroll
-    for (int i = 0; i < 16; i++) s[i] = sbox_rc(s[i], rc_ext(r, i));
+    for (int i = 0; i < 16; i++) rc[i] = rc_ext(r, i);
+#pragma unroll
+    for (int i = 0; i < 16; i++) s[i] = sbox_rc(s[i], rc[i]);
     external_layer(s);
   }
 #pragma unroll 1
@@ -125,8 +132,11 @@ KB_HD void permute_impl(uint32_t s[16], RcExt rc_ext, RcInt rc_int, DiagFn diag)
   }
 #pragma unroll
   for (int r = 4; r < 8; r++) {
+    uint32_t rc[16];
 #pragma unroll
-    for (int i = 0; i < 16; i++) s[i] = sbox_rc(s[i], rc_ext(r, i));
+    for (int i = 0; i < 16; i++) rc[i] = rc_ext(r, i);
+#pragma unroll
+    for (int i = 0; i < 16; i++) s[i] = sbox_rc(s[i], rc[i]);
     external_layer(s);
   }
 }
