@@ -41,31 +41,34 @@ constexpr int THREADS = 512;  // 8 waves per block: two blocks per CU keep 4 wav
 // contiguously at tw[n - (n >> s) + off], so lanes with consecutive `off` read consecutive words.
 // DIF: natural in -> bit-reversed out (stages 0..logn-1).  DIT: bit-reversed in -> natural out.
 template <bool PAD>
-__device__ __forceinline__ int phys(int i) { return PAD ? i + (i >> 5) : i; }
+__device__ __forceinline__ uint32_t phys(uint32_t i) { return PAD ? i + (i >> 5) : i; }
 
+// All index arithmetic is unsigned 32-bit so that LDS addresses and the twiddle loads (scalar base +
+// 32-bit lane offset) need no sign extension or 64-bit address math.
 template <bool DIF, int R, bool PAD>
-__device__ __forceinline__ void ntt_pass(uint32_t* buf, int logn, int lognb, int istride, int s0, const uint32_t* __restrict__ tw) {
-  const int n = 1 << logn;
-  const int logm2 = logn - s0 - R;  // points of a group are m2 = 2^logm2 apart
-  const int total = (n >> R) << lognb;
-  for (int u = threadIdx.x; u < total; u += blockDim.x) {
-    const int t = u & ((1 << lognb) - 1), g = u >> lognb;
-    const int lo = g & ((1 << logm2) - 1), hi = g >> logm2;
-    const int base = (hi << (R + logm2)) + lo;
+__device__ __forceinline__ void ntt_pass(uint32_t* buf, uint32_t logn, uint32_t lognb, uint32_t istride, uint32_t s0,
+                                         const uint32_t* __restrict__ tw) {
+  const uint32_t n = 1u << logn;
+  const uint32_t logm2 = logn - s0 - R;  // points of a group are m2 = 2^logm2 apart
+  const uint32_t total = (n >> R) << lognb;
+  for (uint32_t u = threadIdx.x; u < total; u += blockDim.x) {
+    const uint32_t t = u & ((1u << lognb) - 1), g = u >> lognb;
+    const uint32_t lo = g & ((1u << logm2) - 1), hi = g >> logm2;
+    const uint32_t base = (hi << (R + logm2)) + lo;
     uint32_t x[1 << R];
 #pragma unroll
-    for (int j = 0; j < (1 << R); j++) x[j] = buf[phys<PAD>(base + (j << logm2)) * istride + t];
+    for (uint32_t j = 0; j < (1u << R); j++) x[j] = buf[phys<PAD>(base + (j << logm2)) * istride + t];
 #pragma unroll
     for (int qq = 0; qq < R; qq++) {
-      const int q = DIF ? qq : R - 1 - qq;
-      const int s = s0 + q;
-      const int half = 1 << (R - 1 - q);
-      const uint32_t* tws = tw + (n - (n >> s)) + lo;
+      const uint32_t q = DIF ? qq : R - 1 - qq;
+      const uint32_t s = s0 + q;
+      const uint32_t half = 1u << (R - 1 - q);
+      const uint32_t tbase = (n - (n >> s)) + lo;
 #pragma unroll
-      for (int j0 = 0; j0 < (1 << R); j0++) {
+      for (uint32_t j0 = 0; j0 < (1u << R); j0++) {
         if (j0 & half) continue;
-        const int j1 = j0 + half;
-        const uint32_t w = tws[(j0 & (half - 1)) << logm2];
+        const uint32_t j1 = j0 + half;
+        const uint32_t w = tw[tbase + ((j0 & (half - 1)) << logm2)];
         uint32_t a = x[j0], b = x[j1];
         if (DIF) {
           x[j0] = kb::add(a, b);
@@ -78,7 +81,7 @@ __device__ __forceinline__ void ntt_pass(uint32_t* buf, int logn, int lognb, int
       }
     }
 #pragma unroll
-    for (int j = 0; j < (1 << R); j++) buf[phys<PAD>(base + (j << logm2)) * istride + t] = x[j];
+    for (uint32_t j = 0; j < (1u << R); j++) buf[phys<PAD>(base + (j << logm2)) * istride + t] = x[j];
   }
   __syncthreads();
 }
