@@ -27,6 +27,8 @@ def lib():
         L.orc_challenger_sample_bits.restype = C.c_uint32
         L.orc_challenger_grind.restype = C.c_uint32
         L.orc_two_adic_generator.restype = C.c_uint32
+        # the oracle's OpenMP loops are fine-grained: beyond ~16 threads they get slower (256-thread hosts: 60x)
+        L.orc_set_num_threads(min(16, os.cpu_count() or 1))
         _LIB = L
     return _LIB
 

@@ -193,7 +193,8 @@ def _gpu_prove(ctx, sh, fri, use_prove_shard, specialize=False):
 
 
 @pytest.mark.parametrize("k,with_prep,queries,pow_bits,one_call", [(4, False, 6, 4, False), (7, True, 10, 8, True),
-                                                                 (11, True, 84, 16, False), (13, False, 20, 10, True)])
+                                                                 (11, True, 84, 16, False), (13, False, 20, 10, True),
+                                                                 (16, True, 84, 16, True), (17, False, 84, 16, False)])
 def test_shard_proof_bit_exact(hip_ctx, oracle, k, with_prep, queries, pow_bits, one_call):
     sh = synth.syn_shard(k, with_prep=with_prep)
     fri = abi.FriConfig(1, queries, pow_bits)
