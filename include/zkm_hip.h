@@ -151,6 +151,10 @@ int zkm_ctx_register_quotient_kernel(zkm_ctx* ctx, const uint32_t* program, uint
                                      const void* code_object, size_t code_object_len);
 
 /* ---- DeviceMatrix ----------------------------------------------------------------------- */
+/* Page-locked host memory for trace buffers (the shim's trace generation writes rows straight into it):
+ * zkm_matrix_upload from such a buffer is pure DMA at PCIe rate. Pageable buffers work too, slower. */
+void* zkm_host_alloc(zkm_ctx* ctx, size_t bytes);
+void zkm_host_free(zkm_ctx* ctx, void* p);
 /* Upload a row-major host matrix (height a power of two) and lay it out column-major in HBM. */
 int zkm_matrix_upload(zkm_ctx* ctx, const uint32_t* host_row_major, size_t height, size_t width,
                       zkm_matrix** out);

@@ -227,4 +227,20 @@ __global__ void transpose(const uint32_t* __restrict__ in, uint32_t* __restrict_
   }
 }
 
+// rows [r0, r0 + rows) of a row-major [.][cols] slab -> column-major matrix of `height` rows
+__global__ void transpose_slab(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, size_t rows, size_t cols, size_t r0,
+                               size_t height) {
+  __shared__ uint32_t tile[32][33];
+  size_t bx = (size_t)blockIdx.x * 32, by = (size_t)blockIdx.y * 32;
+  for (int j = threadIdx.y; j < 32; j += blockDim.y) {
+    size_t r = by + j, c = bx + threadIdx.x;
+    if (r < rows && c < cols) tile[j][threadIdx.x] = in[r * cols + c];
+  }
+  __syncthreads();
+  for (int j = threadIdx.y; j < 32; j += blockDim.y) {
+    size_t c = bx + j, r = by + threadIdx.x;
+    if (r < rows && c < cols) out[c * height + r0 + r] = tile[threadIdx.x][j];
+  }
+}
+
 }  // namespace open

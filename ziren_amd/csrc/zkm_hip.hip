@@ -1103,6 +1103,21 @@ int zkm_ctx_register_quotient_kernel(zkm_ctx* ctx, const uint32_t* program, uint
   API_END
 }
 
+// Pinned host memory for trace buffers: uploads from it are plain DMA (no staging copy on the CPU).
+void* zkm_host_alloc(zkm_ctx* ctx, size_t bytes) {
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  void* p = nullptr;
+  if (hipSetDevice(ctx->device) != hipSuccess) return nullptr;
+  if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) return nullptr;
+  return p;
+}
+void zkm_host_free(zkm_ctx* ctx, void* p) {
+  if (!p) return;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  (void)hipSetDevice(ctx->device);
+  (void)hipHostFree(p);
+}
+
 int zkm_matrix_upload(zkm_ctx* ctx, const uint32_t* host, size_t height, size_t width, zkm_matrix** out) {
   API_BEGIN
   std::lock_guard<std::mutex> lk(ctx->mu);
@@ -1112,13 +1127,31 @@ int zkm_matrix_upload(zkm_ctx* ctx, const uint32_t* host, size_t height, size_t 
   m->h = height; m->w = width;
   m->d = ctx->alloc_n<uint32_t>(std::max<size_t>(height * width, 1));
   if (height * width) {
-    uint32_t* stage = ctx->alloc_n<uint32_t>(height * width);
-    HIP_CHECK(hipMemcpyAsync(stage, host, height * width * 4, hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(open::transpose, dim3(div_up(width, 32), div_up(height, 32)), dim3(32, 8), 0, ctx->stream,
-                       (const uint32_t*)stage, m->d, height, width);
-    LAUNCH_CHECK();
+    // row-major rows [r0, r1) are copied in slabs and transposed into the column-major matrix as they land;
+    // two staging buffers keep the DMA engine and the transpose kernel busy at the same time.
+    const size_t slab_rows = std::max<size_t>(32, std::min<size_t>(height, ((size_t)32 << 20) / (width * 4)) & ~(size_t)31);
+    uint32_t* stage[2] = {ctx->alloc_n<uint32_t>(slab_rows * width), ctx->alloc_n<uint32_t>(slab_rows * width)};
+    hipEvent_t freed[2] = {ctx->get_event(), ctx->get_event()};
+    int k = 0;
+    for (size_t r0 = 0; r0 < height; r0 += slab_rows, k ^= 1) {
+      const size_t rows = std::min(slab_rows, height - r0);
+      if (r0 >= 2 * slab_rows) HIP_CHECK(hipStreamWaitEvent(ctx->stream2, freed[k], 0));
+      HIP_CHECK(hipMemcpyAsync(stage[k], host + r0 * width, rows * width * 4, hipMemcpyHostToDevice, ctx->stream2));
+      hipEvent_t landed = ctx->get_event();
+      HIP_CHECK(hipEventRecord(landed, ctx->stream2));
+      HIP_CHECK(hipStreamWaitEvent(ctx->stream, landed, 0));
+      hipLaunchKernelGGL(open::transpose_slab, dim3(div_up(width, 32), div_up(rows, 32)), dim3(32, 8), 0, ctx->stream,
+                         (const uint32_t*)stage[k], m->d, rows, width, r0, height);
+      LAUNCH_CHECK();
+      HIP_CHECK(hipEventRecord(freed[k], ctx->stream));
+      ctx->event_pool.push_back(landed);
+    }
     HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    ctx->release(stage);
+    HIP_CHECK(hipStreamSynchronize(ctx->stream2));
+    ctx->event_pool.push_back(freed[0]);
+    ctx->event_pool.push_back(freed[1]);
+    ctx->release(stage[0]);
+    ctx->release(stage[1]);
   }
   *out = m;
   API_END

@@ -55,6 +55,22 @@ class Context:
                                                C.byref(h)))
         return DeviceMatrix(self, h, m.shape[0], m.shape[1])
 
+    def host_alloc(self, shape) -> np.ndarray:
+        """uint32 array in page-locked host memory (zkm_host_alloc); free with host_free."""
+        n = int(np.prod(shape))
+        p = lib.load().zkm_host_alloc(self.h, C.c_size_t(max(n, 1) * 4))
+        if not p:
+            raise lib.ZkmError("zkm_host_alloc failed")
+        arr = np.ctypeslib.as_array((C.c_uint32 * max(n, 1)).from_address(p))[:n].reshape(shape)
+        self._pinned = getattr(self, "_pinned", {})
+        self._pinned[arr.ctypes.data] = p
+        return arr
+
+    def host_free(self, arr: np.ndarray):
+        p = getattr(self, "_pinned", {}).pop(arr.ctypes.data, None)
+        if p:
+            lib.load().zkm_host_free(self.h, C.c_void_p(p))
+
     def synchronize(self):
         lib.check(lib.load().zkm_ctx_synchronize(self.h))
 
