@@ -28,6 +28,19 @@ def test_matrix_roundtrip(hip_ctx, h, w):
     assert np.array_equal(hip_ctx.upload(m).to_host(), m)
 
 
+def test_upload_slabs_and_pinned_host_memory(hip_ctx):
+    # multi-slab DMA + transpose (pageable and page-locked sources) round-trips exactly
+    rng = np.random.default_rng(55)
+    m = rand(rng, (1 << 19, 67))          # 140 MB: several 32 MB slabs
+    assert np.array_equal(hip_ctx.upload(m).to_host(), m)
+    pinned = hip_ctx.host_alloc(m.shape)
+    pinned[...] = m
+    d = hip_ctx.upload(pinned)
+    assert np.array_equal(d.to_host(), m)
+    d.free()
+    hip_ctx.host_free(pinned)
+
+
 @pytest.mark.parametrize("k,w,bl", [(0, 1, 1), (1, 2, 1), (3, 3, 1), (5, 4, 2), (8, 5, 1), (10, 3, 3), (13, 2, 1),
                                     (14, 3, 1), (15, 2, 2), (16, 5, 1)])
 def test_coset_lde_matches_oracle(hip_ctx, oracle, k, w, bl):
