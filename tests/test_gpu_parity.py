@@ -345,3 +345,24 @@ def test_open_rejects_bad_arguments(hip_ctx):
         hp.prove_shard(pk, sh.public_values, traces, ch, out=np.zeros(16, dtype=np.uint32))  # buffer too small
     with pytest.raises(lib.ZkmError):
         hip_ctx.upload(np.zeros((3, 2), dtype=np.uint32))  # height not a power of two
+    # malformed descriptors are rejected on the host, before anything is launched
+    import copy
+    for corrupt in ("program_column", "lookup_column", "register", "opcode"):
+        chips = copy.deepcopy(sh.chips)
+        c = chips[0]
+        prog = c.program.copy()
+        if corrupt == "program_column":
+            k = next(i for i in range(int(prog[0])) if (prog[4 + 2 * i] & 0xff) == 1)
+            prog[5 + 2 * k] = c.main_width + 5
+        elif corrupt == "register":
+            prog[4] = (prog[4] & 0xffff00ff) | (250 << 8)
+        elif corrupt == "opcode":
+            prog[4] = (prog[4] & 0xffffff00) | 99
+        else:
+            blob = c.lookups_blob.copy()
+            blob[6] = (1 << 31) | (c.main_width + 1)   # first term of the first lookup's first value
+            c.lookups_blob = blob
+        c.program = prog
+        hp2 = prover.HipProver(chips, fri, synth.NUM_PV_ELTS, ctx=hip_ctx)
+        with pytest.raises(lib.ZkmError):
+            hp2.prove_shard(pk, sh.public_values, traces, prover.new_challenger())

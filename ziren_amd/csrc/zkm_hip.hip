@@ -501,28 +501,81 @@ struct ChipMeta {
   int n_lookups, n_sends, perm_ext_w, max_values;
 };
 
-static ChipMeta chip_meta(const zkm_chip_desc* d, size_t n) {
+// Parse and validate a chip descriptor. The blobs are indices into device arrays: every column, register and
+// table index is checked here so that a malformed descriptor is an error code, never an out-of-bounds access
+// on the GPU.
+static ChipMeta chip_meta(const zkm_chip_desc* d, size_t n, size_t n_public_values) {
   ChipMeta m;
   m.desc = d; m.n = n; m.log_n = log2_strict(n);
   m.n_lookups = m.n_sends = m.max_values = 0;
+  const std::string who = std::string(" (chip ") + (d->name ? d->name : "?") + ")";
+  if (d->log_quotient_degree > 3) throw std::runtime_error("log_quotient_degree > 3 unsupported" + who);
   if (d->lookups_len) {
     const uint32_t* w = d->lookups;
+    const size_t len = d->lookups_len;
     size_t pos = 0;
+    auto need = [&](size_t k) { if (pos + k > len) throw std::runtime_error("lookup blob truncated" + who); };
+    need(2);
     uint32_t ns = w[pos++], nr = w[pos++];
+    if ((uint64_t)ns + nr > 4096) throw std::runtime_error("too many lookups" + who);
     m.n_sends = ns; m.n_lookups = ns + nr;
     for (uint32_t i = 0; i < ns + nr; i++) {
+      need(2);
       pos++;  // kind
       uint32_t nv = w[pos++];
+      if (nv > 64) throw std::runtime_error("lookup with more than 64 values" + who);
       m.max_values = std::max<int>(m.max_values, nv);
-      for (uint32_t v = 0; v <= nv; v++) { uint32_t nt = w[pos++]; pos += 1 + 2 * (size_t)nt; }
+      for (uint32_t v = 0; v <= nv; v++) {
+        need(2);
+        uint32_t nt = w[pos++];
+        if (w[pos++] >= kb::P) throw std::runtime_error("lookup constant not a field element" + who);
+        need(2 * (size_t)nt);
+        for (uint32_t t = 0; t < nt; t++) {
+          uint32_t cw = w[pos++], weight = w[pos++];
+          uint32_t col = cw & 0x7fffffffu;
+          if ((cw >> 31) ? col >= d->main_width : col >= d->prep_width) throw std::runtime_error("lookup column out of range" + who);
+          if (weight >= kb::P) throw std::runtime_error("lookup weight not a field element" + who);
+        }
+      }
     }
-    if (pos != d->lookups_len) throw std::runtime_error(std::string("lookup blob length mismatch for chip ") + d->name);
+    if (pos != len) throw std::runtime_error("lookup blob length mismatch" + who);
   }
   int batch = 1 << d->log_quotient_degree;
   m.perm_ext_w = m.n_lookups ? (m.n_lookups + batch - 1) / batch + 1 : 0;
   if (d->program_len) {
-    if (d->program_len < 4 || d->program_len != 4 + 2 * (size_t)d->program[0]) throw std::runtime_error("program blob length mismatch");
-    if (d->program[2] != d->num_constraints) throw std::runtime_error("program constraint count mismatch");
+    if (d->program_len < 4 || d->program_len != 4 + 2 * (size_t)d->program[0]) throw std::runtime_error("program blob length mismatch" + who);
+    if (d->program[2] != d->num_constraints) throw std::runtime_error("program constraint count mismatch" + who);
+    const uint32_t ne = std::max<uint32_t>(d->program[1], 1), nb = std::max<uint32_t>(d->program[3], 1);
+    if (ne > 256 || nb > 256) throw std::runtime_error("program register count out of range" + who);
+    size_t asserts = 0;
+    for (uint32_t k = 0; k < d->program[0]; k++) {
+      uint32_t w0 = d->program[4 + 2 * k], imm = d->program[5 + 2 * k];
+      uint32_t op = w0 & 0xff, dst = (w0 >> 8) & 0xff, ra = (w0 >> 16) & 0xff, rb = w0 >> 24;
+      bool ok = true;
+      switch (op) {
+        case ZKM_OP_LD_MAIN: ok = dst < nb && ra < 2 && imm < d->main_width; break;
+        case ZKM_OP_LD_PREP: ok = dst < nb && ra < 2 && imm < d->prep_width; break;
+        case ZKM_OP_LD_PERM: ok = dst < ne && ra < 2 && imm < (uint32_t)m.perm_ext_w; break;
+        case ZKM_OP_LD_CONST: ok = dst < nb && imm < kb::P; break;
+        case ZKM_OP_LD_PV: ok = dst < nb && imm < n_public_values; break;
+        case ZKM_OP_LD_CHALLENGE: ok = dst < ne && imm < 2; break;
+        case ZKM_OP_LD_LOCAL_SUM: ok = dst < ne; break;
+        case ZKM_OP_LD_GLOBAL_SUM: ok = dst < nb && imm < 14; break;
+        case ZKM_OP_LD_IS_FIRST: case ZKM_OP_LD_IS_LAST: case ZKM_OP_LD_IS_TRANS: ok = dst < nb; break;
+        case ZKM_OP_ADD_B: case ZKM_OP_SUB_B: case ZKM_OP_MUL_B: ok = dst < nb && ra < nb && rb < nb; break;
+        case ZKM_OP_NEG_B: ok = dst < nb && ra < nb; break;
+        case ZKM_OP_ADD_E: case ZKM_OP_SUB_E: case ZKM_OP_MUL_E: ok = dst < ne && ra < ne && rb < ne; break;
+        case ZKM_OP_NEG_E: ok = dst < ne && ra < ne; break;
+        case ZKM_OP_ADD_EB: case ZKM_OP_SUB_EB: case ZKM_OP_MUL_EB: ok = dst < ne && ra < ne && rb < nb; break;
+        case ZKM_OP_ASSERT_B: ok = ra < nb; asserts++; break;
+        case ZKM_OP_ASSERT_E: ok = ra < ne; asserts++; break;
+        default: ok = false;
+      }
+      if (!ok) throw std::runtime_error("invalid instruction " + std::to_string(k) + " in constraint program" + who);
+    }
+    if (asserts != d->num_constraints) throw std::runtime_error("program asserts do not match num_constraints" + who);
+  } else if (d->num_constraints) {
+    throw std::runtime_error("num_constraints > 0 but no program" + who);
   }
   return m;
 }
@@ -533,7 +586,7 @@ static void open_impl(zkm_ctx* ctx, const zkm_pk* pk, zkm_main_data* md, const z
   const int bl = fri->log_blowup;
   const size_t nc = md->order.size();
   std::vector<ChipMeta> chips;
-  for (size_t i = 0; i < nc; i++) chips.push_back(chip_meta(&chips_in[md->order[i]], md->traces[i].h));
+  for (size_t i = 0; i < nc; i++) chips.push_back(chip_meta(&chips_in[md->order[i]], md->traces[i].h, md->public_values.size()));
   for (size_t i = 0; i < nc; i++) {
     if (chips[i].desc->main_width != md->traces[i].w) throw std::runtime_error("chip main_width does not match its trace");
     if ((int)chips[i].desc->log_quotient_degree > bl) throw std::runtime_error("log_quotient_degree > log_blowup unsupported");
