@@ -11,12 +11,15 @@
 // Algorithm (per column): the 2^bl cosets of H_n inside shift*K_N are 2^bl independent size-n
 // transforms, and coset j lands in the contiguous output block [bitrev_bl(j) * n, +n) in
 // bit-reversed row order. With n = A * B (A = 2^la strided, B = 2^lb <= 8192 contiguous):
-//   1. lde_cols_inverse : A-point inverse DIF down the strided dimension, tile [A][T] in LDS
+//   1. lde_cols<false>  : A-point inverse DIF down the strided dimension, tile [A][T+1] in LDS; row pr of the
+//        result holds frequency k1 = bitrev_la(pr)
 //   2. lde_rows         : per contiguous row of B words, all in LDS:
 //        twiddle w_n^(-i0 k1) on load, B-point inverse DIF -> coefficients (bit-reversed),
-//        then for each coset: scale by shift_j^k / n, B-point forward DIT, twiddle w_n^(j0 k1)
-//   3. lde_cols_forward : A-point forward DIT down the strided dimension, then the tile is
-//        written transposed so each column lands as one contiguous A-word bit-reversed segment.
+//        then for each coset: scale by shift_j^k / n, B-point forward DIT, twiddle w_n^(j0 k1);
+//        the row is stored at row k1 (natural frequency order) of a per-coset scratch matrix
+//   3. lde_cols<true>   : A-point forward DIF down the strided dimension (natural rows in, bit-reversed
+//        rows out), then the padded tile is read out transposed so each tile column lands as one contiguous,
+//        already bit-reversed A-word segment of the output.
 // For n <= 8192 (A = 1) step 2 alone reads the column once and writes the LDE once.
 #pragma once
 #include "kb31.cuh"
@@ -24,7 +27,6 @@
 namespace lde {
 
 constexpr int LOG_ROW_MAX = 13;        // B <= 8192 words = 32 KiB of LDS per buffer
-constexpr int COLS_TILE_ELEMS = 16384; // A * T words in LDS for the strided passes (64 KiB)
 constexpr int THREADS = 512;  // 8 waves per block: two blocks per CU keep 4 waves per SIMD over the barriers
 
 // ---- in-LDS transforms ---------------------------------------------------------------------------

@@ -10,6 +10,11 @@
 // wavefront touches row r0 + l of each column, so each column access is one coalesced
 // transaction. Per-chip metadata (lookup linear forms, constraint bytecode, alpha powers) is
 // wave-uniform and comes through the scalar/constant path.
+//
+// quotient_kernel below is the generic bytecode interpreter (register files in LDS). For chips whose
+// program has been specialised (ziren_amd/codegen.py -> zkm_quotient_specialized, registered through
+// zkm_ctx_register_quotient_kernel) the host launches the generated kernel instead; both share the
+// prologue/epilogue of quotient_args.cuh and compute the same values.
 #pragma once
 #include "kb31.cuh"
 #include "quotient_args.cuh"
