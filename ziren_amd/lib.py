@@ -50,7 +50,12 @@ def load():
     if _LIB is not None:
         return _LIB
     if not os.path.exists(LIB_PATH):
-        raise ZkmError(f"{LIB_PATH} is missing: run `python -m ziren_amd.build` (or __graft_entry__.build())")
+        # not built yet: compile it now if the ROCm toolchain is here; never substitute anything else for it
+        from . import build as _build
+        try:
+            _build.build(verbose=True)
+        except Exception as e:  # noqa: BLE001
+            raise ZkmError(f"{LIB_PATH} is missing and could not be built ({e}): run `python -m ziren_amd.build`") from e
     _preload_hip_runtime()
     L = C.CDLL(LIB_PATH)
     L.zkm_last_error.restype = C.c_char_p
