@@ -47,41 +47,49 @@ __device__ __forceinline__ uint32_t phys(uint32_t i) { return PAD ? i + (i >> 5)
 
 // All index arithmetic is unsigned 32-bit so that LDS addresses and the twiddle loads (scalar base +
 // 32-bit lane offset) need no sign extension or 64-bit address math.
+// R radix-2 stages (s0 .. s0+R-1) on the 2^R points a thread holds in registers; `lo` is the group's offset
+// inside its butterfly span (the low logm2 bits of the group index).
+template <bool DIF, int R>
+__device__ __forceinline__ void butterflies(uint32_t (&x)[1 << R], uint32_t n, uint32_t s0, uint32_t lo, uint32_t logm2,
+                                            const uint32_t* __restrict__ tw) {
+#pragma unroll
+  for (int qq = 0; qq < R; qq++) {
+    const uint32_t q = DIF ? qq : R - 1 - qq;
+    const uint32_t s = s0 + q;
+    const uint32_t half = 1u << (R - 1 - q);
+    const uint32_t tbase = (n - (n >> s)) + lo;
+#pragma unroll
+    for (uint32_t j0 = 0; j0 < (1u << R); j0++) {
+      if (j0 & half) continue;
+      const uint32_t j1 = j0 + half;
+      const uint32_t w = tw[tbase + ((j0 & (half - 1)) << logm2)];
+      uint32_t a = x[j0], b = x[j1];
+      if (DIF) {
+        x[j0] = kb::add(a, b);
+        x[j1] = kb::mul_signed(a - b, w);
+      } else {
+        b = kb::mul(b, w);
+        x[j0] = kb::add(a, b);
+        x[j1] = kb::sub(a, b);
+      }
+    }
+  }
+}
+
 template <bool DIF, int R, bool PAD>
 __device__ __forceinline__ void ntt_pass(uint32_t* buf, uint32_t logn, uint32_t lognb, uint32_t istride, uint32_t s0,
-                                         const uint32_t* __restrict__ tw) {
+                                         const uint32_t* __restrict__ tw, uint32_t tid = threadIdx.x) {
   const uint32_t n = 1u << logn;
   const uint32_t logm2 = logn - s0 - R;  // points of a group are m2 = 2^logm2 apart
   const uint32_t total = (n >> R) << lognb;
-  for (uint32_t u = threadIdx.x; u < total; u += blockDim.x) {
+  for (uint32_t u = tid; u < total; u += blockDim.x) {
     const uint32_t t = u & ((1u << lognb) - 1), g = u >> lognb;
     const uint32_t lo = g & ((1u << logm2) - 1), hi = g >> logm2;
     const uint32_t base = (hi << (R + logm2)) + lo;
     uint32_t x[1 << R];
 #pragma unroll
     for (uint32_t j = 0; j < (1u << R); j++) x[j] = buf[phys<PAD>(base + (j << logm2)) * istride + t];
-#pragma unroll
-    for (int qq = 0; qq < R; qq++) {
-      const uint32_t q = DIF ? qq : R - 1 - qq;
-      const uint32_t s = s0 + q;
-      const uint32_t half = 1u << (R - 1 - q);
-      const uint32_t tbase = (n - (n >> s)) + lo;
-#pragma unroll
-      for (uint32_t j0 = 0; j0 < (1u << R); j0++) {
-        if (j0 & half) continue;
-        const uint32_t j1 = j0 + half;
-        const uint32_t w = tw[tbase + ((j0 & (half - 1)) << logm2)];
-        uint32_t a = x[j0], b = x[j1];
-        if (DIF) {
-          x[j0] = kb::add(a, b);
-          x[j1] = kb::mul_signed(a - b, w);
-        } else {
-          b = kb::mul(b, w);
-          x[j0] = kb::add(a, b);
-          x[j1] = kb::sub(a, b);
-        }
-      }
-    }
+    butterflies<DIF, R>(x, n, s0, lo, logm2, tw);
 #pragma unroll
     for (uint32_t j = 0; j < (1u << R); j++) buf[phys<PAD>(base + (j << logm2)) * istride + t] = x[j];
   }
@@ -192,9 +200,10 @@ __global__ __launch_bounds__(THREADS) void lde_cols(const uint32_t* __restrict__
 //   in : column-major, the column after lde_cols<false> (or the raw trace column when la == 0)
 //   la == 0: writes the finished LDE column to `out` (height n << log_blowup per column)
 //   la  > 0: writes coset j's row to tmp[(j * width + c) * n + k1 * B + j0] for lde_cols<true>
-__global__ __launch_bounds__(THREADS) void lde_rows(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, int la, int lb,
-                                                    size_t in_col_stride, size_t out_col_stride, size_t out_coset_stride,
-                                                    int log_blowup, uint32_t shift, uint32_t w_n, uint32_t w_n_inv,
+// Step 2 when the whole column fits one LDS row (n = B <= 8192, A = 1): grid = (1, width); reads the column once,
+// writes its LDE once, rows already bit-reversed. Taller columns go through lde_rows_big below.
+__global__ __launch_bounds__(THREADS) void lde_rows(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, int lb,
+                                                    size_t in_col_stride, size_t out_col_stride, int log_blowup, uint32_t shift,
                                                     uint32_t w_N, uint32_t n_inv, const uint32_t* __restrict__ tw_fwd,
                                                     const uint32_t* __restrict__ tw_inv) {
   extern __shared__ uint32_t lds[];
@@ -203,73 +212,131 @@ __global__ __launch_bounds__(THREADS) void lde_rows(const uint32_t* __restrict__
   const int BP = B + (B >> 5);     // padded length, see phys<>
   uint32_t* coef = lds;            // BP
   uint32_t* work = lds + BP;       // BP
-  uint32_t* lo1 = work + BP;       // 64   powers of w_n^(-k1)   (load twiddle)
-  uint32_t* hi1 = lo1 + 64;        // nhi
-  uint32_t* lo2 = hi1 + nhi;       // 64   powers of shift_j^A   (coset scaling)
+  uint32_t* lo2 = work + BP;       // 64   powers of shift_j   (coset scaling)
   uint32_t* hi2 = lo2 + 64;        // nhi
-  const int pr = blockIdx.x;
   const size_t c = blockIdx.y;
-  const int k1 = kb::bitrev(pr, la);
-  const int k = la + lb;
-  const uint32_t* src = in + c * in_col_stride + (size_t)pr * B;
-
-  if (la > 0) {
-    build_pow_table(kb::pow(w_n_inv, (uint64_t)k1), lo1, hi1, nhi);
-    __syncthreads();
-    // B = 8192 here: 16-byte loads, four in flight per thread
-    for (int q0 = threadIdx.x; q0 < (B >> 2); q0 += 4 * blockDim.x) {
-      uint4 v[4];
-#pragma unroll
-      for (int k = 0; k < 4; k++) {
-        int q = q0 + k * blockDim.x;
-        if (q < (B >> 2)) v[k] = *reinterpret_cast<const uint4*>(src + 4 * q);
-      }
-#pragma unroll
-      for (int k = 0; k < 4; k++) {
-        int q = q0 + k * blockDim.x;
-        if (q < (B >> 2)) {
-          const int i = 4 * q;
-          coef[phys<true>(i)] = kb::mul(v[k].x, pow_lookup(lo1, hi1, i));
-          coef[phys<true>(i + 1)] = kb::mul(v[k].y, pow_lookup(lo1, hi1, i + 1));
-          coef[phys<true>(i + 2)] = kb::mul(v[k].z, pow_lookup(lo1, hi1, i + 2));
-          coef[phys<true>(i + 3)] = kb::mul(v[k].w, pow_lookup(lo1, hi1, i + 3));
-        }
-      }
-    }
-  } else {
-    for (int i = threadIdx.x; i < B; i += blockDim.x) coef[phys<true>(i)] = src[i];
-  }
+  const uint32_t* src = in + c * in_col_stride;
+  for (int i = threadIdx.x; i < B; i += blockDim.x) coef[phys<true>(i)] = src[i];
   __syncthreads();
   if (lb > 0) lds_ntt<true, true>(coef, lb, 0, 1, tw_inv);
-  // coef[pc] = n * c_kk with kk = bitrev_lb(pc) * A + k1
-  if (la > 0) {
-    build_pow_table(kb::pow(w_n, (uint64_t)k1), lo1, hi1, nhi);  // store twiddle w_n^(j0 k1)
-  }
+  // coef[pc] = n * c_k with k = bitrev_lb(pc)
   const int ncosets = 1 << log_blowup;
   uint32_t sj = shift;
   for (int j = 0; j < ncosets; j++) {
     // shift_j = shift * w_N^j
-    uint32_t sA = sj;
-    for (int i = 0; i < la; i++) sA = kb::sqr(sA);
     __syncthreads();
-    build_pow_table(sA, lo2, hi2, nhi, kb::mul(n_inv, kb::pow(sj, (uint64_t)k1)));  // 1/n * shift_j^k1 folded in
+    build_pow_table(sj, lo2, hi2, nhi, n_inv);  // 1/n folded in
     __syncthreads();
     for (int i = threadIdx.x; i < B; i += blockDim.x)
       work[phys<true>(i)] = kb::mul(coef[phys<true>(i)], pow_lookup(lo2, hi2, kb::bitrev(i, lb)));
     __syncthreads();
     if (lb > 0) lds_ntt<false, true>(work, lb, 0, 1, tw_fwd);
-    if (la > 0) {
-      uint32_t* dst = out + (size_t)j * out_coset_stride + c * out_col_stride + (size_t)k1 * B;  // row k1: natural order for lde_cols<true>
-      for (int q = threadIdx.x; q < (B >> 2); q += blockDim.x) {
-        const int i = 4 * q;
-        *reinterpret_cast<uint4*>(dst + i) = make_uint4(kb::mul(work[phys<true>(i)], pow_lookup(lo1, hi1, i)),
-                                                         kb::mul(work[phys<true>(i + 1)], pow_lookup(lo1, hi1, i + 1)),
-                                                         kb::mul(work[phys<true>(i + 2)], pow_lookup(lo1, hi1, i + 2)),
-                                                         kb::mul(work[phys<true>(i + 3)], pow_lookup(lo1, hi1, i + 3)));
-      }
-    } else {
-      uint32_t* dst = out + c * out_col_stride + (size_t)kb::bitrev(j, log_blowup) * B;
-      for (int i = threadIdx.x; i < B; i += blockDim.x) dst[i] = work[phys<true>(kb::bitrev(i, lb))];
+    uint32_t* dst = out + c * out_col_stride + (size_t)kb::bitrev(j, log_blowup) * B;
+    for (int i = threadIdx.x; i < B; i += blockDim.x) dst[i] = work[phys<true>(kb::bitrev(i, lb))];
+    sj = kb::mul(sj, w_N);
+  }
+}
+
+// Step 2 for n > 8192 (la > 0, B = 8192, 512 threads), grid = (A, width): the data stays in registers wherever
+// two neighbouring steps touch the same points, so one 35 KiB LDS buffer and 9 LDS round trips per row (3 for the
+// inverse transform, 3 per coset) instead of one per four stages plus one for every twiddle / scaling step:
+//   * the load (with its w_n^(-i0 k1) twiddle) feeds the first inverse pass directly: thread g owns i0 = g + 512 j;
+//   * the last inverse stage (pairs 2g, 2g+1) leaves the 16 coefficients of a thread in VGPRs, where they stay
+//     for every coset: scale, the first forward stage (the same pairs) and only then LDS;
+//   * the last forward pass (again i = g + 512 j) goes from registers through the w_n^(j0 k1) twiddle to HBM.
+__global__ __launch_bounds__(THREADS, 4) void lde_rows_big(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, int la,
+                                                        size_t in_col_stride, size_t out_col_stride, size_t out_coset_stride,
+                                                        int log_blowup, uint32_t shift, uint32_t w_n, uint32_t w_n_inv,
+                                                        uint32_t w_N, uint32_t n_inv, const uint32_t* __restrict__ tw_fwd,
+                                                        const uint32_t* __restrict__ tw_inv) {
+  constexpr uint32_t LB = LOG_ROW_MAX, B = 1u << LB, BP = B + (B >> 5), NHI = B >> 6;
+  constexpr uint32_t G = B / THREADS;  // points per thread (16)
+  static_assert(G == 16 && LB == 13, "pass structure below is written for 8192 points on 512 threads");
+  extern __shared__ uint32_t lds[];
+  uint32_t* work = lds;          // BP
+  uint32_t* lo2 = work + BP;     // 64   powers of shift_j^A (coset scaling)
+  uint32_t* hi2 = lo2 + 64;      // NHI
+  const uint32_t tid = threadIdx.x;
+  const uint32_t pr = blockIdx.x;
+  const size_t c = blockIdx.y;
+  const uint32_t k1 = kb::bitrev(pr, la);
+  const uint32_t* src = in + c * in_col_stride + (size_t)pr * B;
+
+  uint32_t x[16];
+#pragma unroll
+  for (uint32_t j = 0; j < 16; j++) x[j] = src[tid + (j << 9)];
+  {
+    // x_j *= w_n^(-k1 (tid + 512 j))
+    uint32_t a = kb::pow(w_n_inv, (uint64_t)k1), t = kb::ONE;
+#pragma unroll
+    for (uint32_t b = 0; b < 9; b++) {
+      if ((tid >> b) & 1) t = kb::mul(t, a);
+      a = kb::sqr(a);
+    }
+#pragma unroll
+    for (uint32_t j = 0; j < 16; j++) {
+      x[j] = kb::mul(x[j], t);
+      t = kb::mul(t, a);
+    }
+  }
+  butterflies<true, 4>(x, B, 0, tid, 9, tw_inv);
+#pragma unroll
+  for (uint32_t j = 0; j < 16; j++) work[phys<true>(tid + (j << 9))] = x[j];
+  __syncthreads();
+  ntt_pass<true, 4, true>(work, LB, 0, 1, 4, tw_inv);
+  ntt_pass<true, 4, true>(work, LB, 0, 1, 8, tw_inv);
+  // last inverse stage (span 1, twiddle 1): coef[2g], coef[2g+1] for g = tid + 512 k stay in registers.
+  // coef[pc] = n * c_kk with kk = bitrev_13(pc) * A + k1
+  uint32_t keep[16];
+#pragma unroll
+  for (uint32_t k = 0; k < 8; k++) {
+    const uint32_t i = 2 * (tid + (k << 9));
+    const uint32_t a = work[phys<true>(i)], b = work[phys<true>(i + 1)];
+    keep[2 * k] = kb::add(a, b);
+    keep[2 * k + 1] = kb::sub(a, b);
+  }
+  // store twiddle w_n^(k1 (tid + 512 j)): first factor and step
+  uint32_t st0 = kb::ONE, st_step = kb::pow(w_n, (uint64_t)k1);
+#pragma unroll
+  for (uint32_t b = 0; b < 9; b++) {
+    if ((tid >> b) & 1) st0 = kb::mul(st0, st_step);
+    st_step = kb::sqr(st_step);
+  }
+  const uint32_t ncosets = 1u << log_blowup;
+  uint32_t sj = shift;
+  for (uint32_t j = 0; j < ncosets; j++) {
+    // shift_j = shift * w_N^j
+    uint32_t sA = sj;
+    for (int i = 0; i < la; i++) sA = kb::sqr(sA);
+    uint32_t sA_half = sA;  // sA^(B/2): bitrev_13(2g + 1) = bitrev_13(2g) + B/2
+    for (uint32_t i = 0; i < LB - 1; i++) sA_half = kb::sqr(sA_half);
+    build_pow_table(sA, lo2, hi2, NHI, kb::mul(n_inv, kb::pow(sj, (uint64_t)k1)));  // 1/n * shift_j^k1 folded in
+    __syncthreads();  // table visible; every reader of `work` from the previous step is done
+    // The LDS/global addresses below are the same for every coset; left alone the optimiser hoists all of them out
+    // of this loop and the kernel needs 160 VGPRs. An opaque copy of the thread index keeps them loop-local.
+    uint32_t lt = tid;
+    asm volatile("" : "+v"(lt));
+#pragma unroll
+    for (uint32_t k = 0; k < 8; k++) {
+      const uint32_t g = lt + (k << 9);
+      const uint32_t p0 = pow_lookup(lo2, hi2, kb::bitrev(g, LB - 1));
+      const uint32_t p1 = kb::mul(p0, sA_half);
+      const uint32_t a = kb::mul(keep[2 * k], p0), b = kb::mul(keep[2 * k + 1], p1);
+      work[phys<true>(2 * g)] = kb::add(a, b);  // first forward stage (span 1, twiddle 1)
+      work[phys<true>(2 * g + 1)] = kb::sub(a, b);
+    }
+    __syncthreads();
+    ntt_pass<false, 4, true>(work, LB, 0, 1, 8, tw_fwd, lt);
+    ntt_pass<false, 4, true>(work, LB, 0, 1, 4, tw_fwd, lt);
+#pragma unroll
+    for (uint32_t q = 0; q < 16; q++) x[q] = work[phys<true>(lt + (q << 9))];
+    butterflies<false, 4>(x, B, 0, lt, 9, tw_fwd);
+    uint32_t* dst = out + (size_t)j * out_coset_stride + c * out_col_stride + (size_t)k1 * B;  // row k1: natural order for lde_cols<true>
+    uint32_t t = st0;
+#pragma unroll
+    for (uint32_t q = 0; q < 16; q++) {
+      dst[lt + (q << 9)] = kb::mul(x[q], t);
+      t = kb::mul(t, st_step);
     }
     sj = kb::mul(sj, w_N);
   }

@@ -306,12 +306,12 @@ static void lde_columns(zkm_ctx* ctx, const uint32_t* in, size_t n, size_t w, in
   uint32_t w_n = kb::two_adic_generator(k), w_n_inv = kb::inv(w_n), w_N = kb::two_adic_generator(k + bl);
   uint32_t n_inv = kb::inv(kb::to_monty((uint32_t)(n % kb::P)));
   int nhi = B > 64 ? (int)(B >> 6) : 1;
-  size_t rows_lds = (2 * (B + (B >> 5)) + 2 * 64 + 2 * nhi) * 4;
+  size_t rows_lds = (2 * (B + (B >> 5)) + 64 + nhi) * 4;
   const uint32_t* twf = lb > 0 ? ctx->twiddles(lb, false) : nullptr;
   const uint32_t* twi = lb > 0 ? ctx->twiddles(lb, true) : nullptr;
   if (la == 0) {
-    KLAUNCH(ctx, "lde_rows", 4.0 * n * w + 4.0 * N * w, lde::lde_rows, dim3(1, (unsigned)w), dim3(lde::THREADS), rows_lds, in, out, 0,
-            lb, n, N, (size_t)0, bl, lde_shift, w_n, w_n_inv, w_N, n_inv, twf, twi);
+    KLAUNCH(ctx, "lde_rows", 4.0 * n * w + 4.0 * N * w, lde::lde_rows, dim3(1, (unsigned)w), dim3(lde::THREADS), rows_lds, in, out,
+            lb, n, N, bl, lde_shift, w_N, n_inv, twf, twi);
     return;
   }
   size_t A = (size_t)1 << la;
@@ -324,8 +324,9 @@ static void lde_columns(zkm_ctx* ctx, const uint32_t* in, size_t n, size_t w, in
   const uint32_t* twa_fwd = ctx->twiddles(la, false);
   KLAUNCH(ctx, "lde_cols_inverse", 8.0 * n * w, lde::lde_cols<false>, dim3((unsigned)(B / T), (unsigned)w, 1), dim3(lde::THREADS),
           cols_lds, in, tmp1, la, lb, logT, n, (size_t)0, n, bl, twa_inv);
-  KLAUNCH(ctx, "lde_rows", 4.0 * n * w + 4.0 * N * w, lde::lde_rows, dim3((unsigned)A, (unsigned)w), dim3(lde::THREADS), rows_lds,
-          (const uint32_t*)tmp1, tmp2, la, lb, n, n, n * w, bl, lde_shift, w_n, w_n_inv, w_N, n_inv, twf, twi);
+  size_t big_lds = (B + (B >> 5) + 64 + nhi) * 4;
+  KLAUNCH(ctx, "lde_rows", 4.0 * n * w + 4.0 * N * w, lde::lde_rows_big, dim3((unsigned)A, (unsigned)w), dim3(lde::THREADS), big_lds,
+          (const uint32_t*)tmp1, tmp2, la, n, n, n * w, bl, lde_shift, w_n, w_n_inv, w_N, n_inv, twf, twi);
   KLAUNCH(ctx, "lde_cols_forward", 8.0 * N * w, lde::lde_cols<true>, dim3((unsigned)(B / T), (unsigned)w, 1u << bl),
           dim3(lde::THREADS), cols_lds, (const uint32_t*)tmp2, out, la, lb, logT, n, n * w, N, bl, twa_fwd);
   ctx->release(tmp1);
@@ -1082,6 +1083,7 @@ int zkm_ctx_create(int device, zkm_ctx** out) {
   if (const char* e = getenv("ZKM_OVERLAP")) c->overlap = atoi(e) != 0;
   HIP_CHECK(p2::upload_tables());
   HIP_CHECK(hipFuncSetAttribute((const void*)lde::lde_rows, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIP_CHECK(hipFuncSetAttribute((const void*)lde::lde_rows_big, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIP_CHECK(hipFuncSetAttribute((const void*)lde::lde_cols<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIP_CHECK(hipFuncSetAttribute((const void*)lde::lde_cols<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIP_CHECK(hipFuncSetAttribute((const void*)stark::quotient_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
