@@ -45,6 +45,10 @@ __global__ void bench(uint32_t* out, uint32_t seed) {
       if (OP == 24) asm volatile("v_add_u32 %0, 0x80ffffff, %0" : "+v"(a[i]));
       if (OP == 25) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
       if (OP == 26) asm volatile("v_min_f32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+      if (OP == 28) asm volatile("v_sub_co_u32 %0, vcc, %0, %1" : "+v"(a[i]) : "v"(b) : "vcc");
+      if (OP == 29) { uint32_t t; asm volatile("v_add_u32 %0, %0, %2\n v_subrev_u32 %1, %3, %0\n v_min_u32 %0, %0, %1" : "+v"(a[i]), "=&v"(t) : "v"(b), "s"(0x7f000001u)); }
+      if (OP == 30) { uint32_t t; asm volatile("v_add_u32 %0, %0, %2\n v_subrev_co_u32 %1, vcc, %3, %0\n v_cndmask_b32 %0, %1, %0, vcc" : "+v"(a[i]), "=&v"(t) : "v"(b), "s"(0x7f000001u) : "vcc"); }
+      if (OP == 31) { uint32_t t; uint64_t m; asm volatile("v_add_u32 %0, %0, %3\n v_subrev_co_u32 %1, %2, %4, %0\n v_cndmask_b32 %0, %1, %0, %2" : "+v"(a[i]), "=&v"(t), "=&s"(m) : "v"(b), "s"(0x7f000001u)); }
       if (OP == 27) asm volatile("v_mul_lo_u32 %0, %0, %1\n v_add_u32 %2, %2, %1" : "+v"(a[i]), "+v"(b) , "+v"(a[(i+1)%ILP]):);
     }
   }
@@ -103,6 +107,10 @@ int main() {
   run<21>("v_add_co_u32", d);
   run<23>("v_min_u32 sgpr", d);
   run<24>("v_add_u32 literal", d);
+  run<28>("v_sub_co_u32 vcc", d);
+  run<29>("modadd add/sub/min", d);
+  run<30>("modadd add/sub_co/cndmask vcc", d);
+  run<31>("modadd add/sub_co/cndmask sgpr", d);
   run<0>("v_add_u32 (again)", d);
   run<7>("v_min_u32 (again)", d);
   return 0;
