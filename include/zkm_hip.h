@@ -218,6 +218,32 @@ int zkm_prove_shard(zkm_ctx* ctx, const zkm_pk* pk, size_t n_chips, const zkm_ch
                     zkm_challenger* challenger, uint32_t* proof_out, size_t proof_cap,
                     size_t* proof_len);
 
+/* ---- device trace generation, ALU chips ------------------- */
+/* One executor event of the AddSub / Bitwise / Lt / ShiftLeft / ShiftRight chips: byte-for-byte
+ * the #[repr(C)] AluEvent of crates/core/executor/src/events/instr.rs:10-26 (opcode numbers:
+ * crates/core/executor/src/opcode.rs:26-48), so the shim passes `record.add_sub_events.as_ptr()`. */
+typedef struct zkm_alu_event {
+  uint32_t pc, next_pc;
+  uint8_t opcode, _pad[3];
+  uint32_t hi, a, b, c;
+} zkm_alu_event;
+enum zkm_alu_chip {
+  ZKM_CHIP_ADD_SUB = 0,     /* crates/core/machine/src/alu/add_sub/mod.rs  (19 columns) */
+  ZKM_CHIP_BITWISE = 1,     /* .../alu/bitwise/mod.rs                      (18) */
+  ZKM_CHIP_LT = 2,          /* .../alu/lt/mod.rs                           (32) */
+  ZKM_CHIP_SHIFT_LEFT = 3,  /* .../alu/sll/mod.rs                          (44) */
+  ZKM_CHIP_SHIFT_RIGHT = 4  /* .../alu/sr/mod.rs                           (67) */
+};
+/* size_of::<Cols<u8>>() of the chip (NUM_*_COLS); 0 for an unknown chip. */
+size_t zkm_tracegen_alu_width(int chip);
+/* MachineAir::generate_trace for one of the chips above, on the device: `events` (host, n_events records) are
+ * copied to HBM and expanded to the padded main trace, returned as a device-resident matrix that
+ * zkm_commit / zkm_prove_shard take directly. fixed_log2_rows is the shape's `fixed_log2_rows` or -1
+ * for next_power_of_two(n_events) with the reference's minimum of 16 rows; rows past the events are the
+ * chip's padding rows. Fails if n_events exceeds the fixed height (the reference panics). */
+int zkm_tracegen_alu(zkm_ctx* ctx, int chip, const zkm_alu_event* events, size_t n_events,
+                     int fixed_log2_rows, zkm_matrix** out);
+
 /* ---- fine-grained entry points (parity tests, micro-benchmarks) ------------------------- */
 /* Poseidon2 width-16 permutation on n states (n x 16 words, in place), on the GPU.
  * zkm_primitives::poseidon2_init, crates/primitives/src/lib.rs:1107-1122. */

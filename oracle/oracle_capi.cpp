@@ -6,6 +6,7 @@
 // does — Montgomery words, row-major host matrices, the same chip descriptors and the same
 // ShardProof word stream — so a parity test feeds both sides identical bytes.
 #include "stark.hpp"
+#include "tracegen.hpp"
 #include <cstdio>
 #include <omp.h>
 
@@ -352,6 +353,34 @@ int orc_verify_shard(const orc_pk* k, size_t n_chips, const zkm_chip_desc* descs
   *verdict = verify_shard(k->vk, chips, cfg, num_pv_elts, ch, p);
   store_challenger(ch, challenger);
   ORC_CATCH
+}
+
+// ---- ALU chip trace generation (tracegen.hpp) ------------------------------------------------------------
+// events: n_events packed 28-byte AluEvent records. out: rows x width row-major Montgomery words, the matrix the
+// reference's generate_trace returns.
+size_t orc_tracegen_alu_width(int chip) { try { return tracegen::chip_width(chip); } catch (...) { return 0; } }
+int orc_tracegen_alu_rows(size_t n_events, int fixed_log2_rows, size_t* rows) {
+  ORC_TRY
+  *rows = tracegen::padded_rows(n_events, fixed_log2_rows);
+  ORC_CATCH
+}
+int orc_tracegen_alu(int chip, const void* events, size_t n_events, int fixed_log2_rows, uint32_t* out, size_t out_cap) {
+  ORC_TRY
+  size_t h;
+  std::vector<F> t = tracegen::generate(chip, (const tracegen::AluEvent*)events, n_events, fixed_log2_rows, &h);
+  if (t.size() > out_cap) throw std::runtime_error("trace buffer too small");
+  for (size_t i = 0; i < t.size(); i++) out[i] = to_monty(t[i]);
+  ORC_CATCH
+}
+// Index of the first event whose row breaks one of the reference's in-line sanity identities, or -1.
+long orc_tracegen_alu_check(int chip, const void* events, size_t n_events) {
+  const tracegen::AluEvent* ev = (const tracegen::AluEvent*)events;
+  size_t h;
+  std::vector<F> t = tracegen::generate(chip, ev, n_events, -1, &h);
+  const size_t w = tracegen::chip_width(chip);
+  for (size_t i = 0; i < n_events; i++)
+    if (!tracegen::check_row(chip, ev[i], t.data() + i * w)) return (long)i;
+  return -1;
 }
 
 }  // extern "C"

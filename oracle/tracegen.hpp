@@ -1,0 +1,255 @@
+// TEST INFRASTRUCTURE ONLY (see oracle/README in DESIGN.md section 2): CPU restatement of the reference's
+// trace generation for the ALU chips that consume `AluEvent`s. Only tests/, __graft_entry__.smoke() and
+// bench.py's cpu_baseline leg may call it; the product path is ziren_amd/csrc/tracegen.cuh.
+//
+// PARITY UNPINNED: the reference holds no golden rows for these chips and its own C++ row builders
+// (crates/core/machine/include/*.hpp) need a cbindgen-generated header that is not in the tree, so they cannot
+// be compiled here. What pins this file instead: (1) the reference's in-line sanity identities, restated as
+// checks in `check_row` below; (2) tests/test_chip_airs.py evaluates the chips' AIR constraints, transcribed from
+// the reference's `eval`, on the generated rows.
+//
+// Follows, per chip (crates/core/machine/src/alu/...):
+//   AddSub      add_sub/mod.rs:44-68 (columns), :161-181 (event_to_row), operations/add.rs:13-57; rows past the
+//               events are zero (:99)
+//   Bitwise     bitwise/mod.rs:36-64, :160-195; zero padding (:110-115)
+//   Lt          lt/mod.rs:36-86, :209-274; zero padding (:127)
+//   ShiftLeft   sll/mod.rs:70-104, :232-287; padding rows are the template of :157-165
+//   ShiftRight  sr/mod.rs:88-137, :232-339; padding rows set shift_by_n_bits[0] = shift_by_n_bytes[0] = 1 (:183-186)
+// Row count: utils/mod.rs next_power_of_two — 2^fixed_log2_rows when the shape fixes it, else the next power of
+// two, at least 16. Event layout: #[repr(C)] AluEvent, crates/core/executor/src/events/instr.rs:10-26; opcode
+// numbers crates/core/executor/src/opcode.rs:26-48.
+#pragma once
+#include <cstdint>
+#include <cstring>
+#include <stdexcept>
+#include <vector>
+#include "field.hpp"
+
+namespace tracegen {
+using namespace orc;
+
+struct AluEvent {  // 28 bytes, as the executor lays it out
+  uint32_t pc, next_pc;
+  uint8_t opcode, _pad[3];
+  uint32_t hi, a, b, c;
+};
+static_assert(sizeof(AluEvent) == 28, "AluEvent is seven words");
+
+enum Opcode : uint8_t { ADD = 0, SUB = 1, SLL = 9, SRL = 10, SRA = 11, ROR = 12, SLT = 13, SLTU = 14, AND = 15, OR = 16, XOR = 17, NOR = 18 };
+enum Chip { ADD_SUB = 0, BITWISE = 1, LT = 2, SHIFT_LEFT = 3, SHIFT_RIGHT = 4, NUM_CHIPS = 5 };
+
+static inline size_t chip_width(int chip) {
+  switch (chip) {
+    case ADD_SUB: return 19;
+    case BITWISE: return 18;
+    case LT: return 32;
+    case SHIFT_LEFT: return 44;
+    case SHIFT_RIGHT: return 67;
+  }
+  throw std::runtime_error("tracegen: unknown chip");
+}
+
+static inline size_t padded_rows(size_t n_events, int fixed_log2_rows) {
+  if (fixed_log2_rows >= 0) {
+    size_t h = (size_t)1 << fixed_log2_rows;
+    if (n_events > h) throw std::runtime_error("tracegen: fixed log2 rows is too small");
+    return h;
+  }
+  size_t h = 16;
+  while (h < n_events) h <<= 1;
+  return h;
+}
+
+// canonical field value of a u32 (from_canonical_u32 of a value that may exceed p wraps, as the Monty form does)
+static inline F fu32(uint32_t x) { return x % P; }
+static inline void word(F* dst, uint32_t v) { for (int i = 0; i < 4; i++) dst[i] = (v >> (8 * i)) & 0xff; }
+
+static inline void add_sub_row(const AluEvent& e, F* r) {
+  r[0] = fu32(e.pc);
+  r[1] = fu32(e.next_pc);
+  const bool is_add = e.opcode == ADD;
+  const uint32_t op1 = is_add ? e.b : e.a, op2 = e.c;
+  const uint32_t sum = op1 + op2;
+  word(r + 2, sum);  // add_operation.value
+  uint32_t carry = 0;
+  for (int i = 0; i < 3; i++) {
+    carry = (((op1 >> (8 * i)) & 0xff) + ((op2 >> (8 * i)) & 0xff) + carry) > 255;
+    r[6 + i] = carry;  // add_operation.carry
+  }
+  word(r + 9, op1);
+  word(r + 13, op2);
+  r[17] = is_add;
+  r[18] = e.opcode == SUB;
+}
+
+static inline void bitwise_row(const AluEvent& e, F* r) {
+  r[0] = fu32(e.pc);
+  r[1] = fu32(e.next_pc);
+  word(r + 2, e.a);
+  word(r + 6, e.b);
+  word(r + 10, e.c);
+  r[14] = e.opcode == NOR;
+  r[15] = e.opcode == XOR;
+  r[16] = e.opcode == OR;
+  r[17] = e.opcode == AND;
+}
+
+static inline void lt_row(const AluEvent& e, F* r) {
+  enum { PC = 0, NEXT_PC = 1, IS_SLT = 2, IS_SLTU = 3, A = 4, B = 8, C = 12, BYTE_FLAGS = 16, B_MASKED = 20, C_MASKED = 21,
+         NOT_EQ_INV = 22, MSB_B = 23, MSB_C = 24, BIT_B = 25, BIT_C = 26, SLTU_ = 27, IS_COMP_EQ = 28, IS_SIGN_EQ = 29, CMP_BYTES = 30 };
+  r[PC] = fu32(e.pc);
+  r[NEXT_PC] = fu32(e.next_pc);
+  word(r + A, e.a);
+  word(r + B, e.b);
+  word(r + C, e.c);
+  uint8_t b[4], c[4];
+  for (int i = 0; i < 4; i++) { b[i] = (e.b >> (8 * i)) & 0xff; c[i] = (e.c >> (8 * i)) & 0xff; }
+  const uint8_t masked_b = b[3] & 0x7f, masked_c = c[3] & 0x7f;
+  r[B_MASKED] = masked_b;
+  r[C_MASKED] = masked_c;
+  uint8_t bc[4], cc[4];
+  memcpy(bc, b, 4); memcpy(cc, c, 4);
+  if (e.opcode == SLT) { bc[3] = masked_b; cc[3] = masked_c; }
+  r[SLTU_] = 0;
+  r[IS_COMP_EQ] = memcmp(bc, cc, 4) == 0;
+  for (int i = 3; i >= 0; i--) {  // most significant differing byte decides
+    if (bc[i] != cc[i]) {
+      r[BYTE_FLAGS + i] = 1;
+      r[SLTU_] = bc[i] < cc[i];
+      r[NOT_EQ_INV] = finv(fsub(bc[i], cc[i]));
+      r[CMP_BYTES] = bc[i];
+      r[CMP_BYTES + 1] = cc[i];
+      break;
+    }
+  }
+  r[MSB_B] = b[3] >> 7;
+  r[MSB_C] = c[3] >> 7;
+  r[IS_SIGN_EQ] = e.opcode == SLT ? (b[3] >> 7) == (c[3] >> 7) : 1;
+  r[IS_SLT] = e.opcode == SLT;
+  r[IS_SLTU] = e.opcode == SLTU;
+  r[BIT_B] = r[MSB_B] * r[IS_SLT];
+  r[BIT_C] = r[MSB_C] * r[IS_SLT];
+}
+
+static inline void shift_left_row(const AluEvent& e, F* r) {
+  enum { PC = 0, NEXT_PC = 1, A = 2, B = 6, C = 10, C_LSB = 14, BY_BITS = 22, MULT = 30, RESULT = 31, CARRY = 35, BY_BYTES = 39, IS_REAL = 43 };
+  r[PC] = fu32(e.pc);
+  r[NEXT_PC] = fu32(e.next_pc);
+  word(r + A, e.a);
+  word(r + B, e.b);
+  word(r + C, e.c);
+  r[IS_REAL] = 1;
+  for (int i = 0; i < 8; i++) r[C_LSB + i] = (e.c >> i) & 1;
+  const uint32_t nbits = e.c % 8;
+  for (uint32_t i = 0; i < 8; i++) r[BY_BITS + i] = nbits == i;
+  const uint32_t mult = 1u << nbits;
+  r[MULT] = mult;
+  uint32_t carry = 0;
+  for (int i = 0; i < 4; i++) {
+    const uint32_t v = ((e.b >> (8 * i)) & 0xff) * mult + carry;
+    carry = v >> 8;
+    r[RESULT + i] = v & 0xff;
+    r[CARRY + i] = carry;
+  }
+  const uint32_t nbytes = (e.c & 31) / 8;
+  for (uint32_t i = 0; i < 4; i++) r[BY_BYTES + i] = nbytes == i;
+}
+static inline void shift_left_padding(F* r) {
+  r[22] = 1;  // shift_by_n_bits[0]
+  r[39] = 1;  // shift_by_n_bytes[0]
+  r[30] = 1;  // bit_shift_multiplier
+}
+
+static inline void shift_right_row(const AluEvent& e, F* r) {
+  enum { PC = 0, NEXT_PC = 1, B = 2, C = 6, BY_BITS = 10, BY_BYTES = 18, BYTE_RES = 22, BIT_RES = 30, SHR_CARRY = 38, SHR_SHIFTED = 46,
+         B_MSB = 54, C_LSB = 55, IS_SRL = 63, IS_ROR = 64, IS_SRA = 65, IS_REAL = 66 };
+  r[PC] = fu32(e.pc);
+  r[NEXT_PC] = fu32(e.next_pc);
+  word(r + B, e.b);
+  word(r + C, e.c);
+  r[B_MSB] = (e.b >> 31) & 1;
+  r[IS_SRL] = e.opcode == SRL;
+  r[IS_SRA] = e.opcode == SRA;
+  r[IS_ROR] = e.opcode == ROR;
+  r[IS_REAL] = 1;
+  for (int i = 0; i < 8; i++) r[C_LSB + i] = (e.c >> i) & 1;
+  const uint32_t nbytes = (e.c % 32) / 8, nbits = (e.c % 32) % 8;
+  for (uint32_t i = 0; i < 4; i++) r[BY_BYTES + i] = nbytes == i;
+  uint64_t ext;
+  if (e.opcode == SRA) ext = (uint64_t)(int64_t)(int32_t)e.b;
+  else if (e.opcode == ROR) ext = ((uint64_t)e.b << 32) | e.b;
+  else ext = e.b;
+  uint8_t byte_res[8] = {0};
+  for (uint32_t i = 0; i < 8; i++)
+    if (i + nbytes < 8) byte_res[i] = (ext >> (8 * (i + nbytes))) & 0xff;
+  for (int i = 0; i < 8; i++) r[BYTE_RES + i] = byte_res[i];
+  for (uint32_t i = 0; i < 8; i++) r[BY_BITS + i] = nbits == i;
+  const uint32_t carry_mult = 1u << (8 - nbits);
+  uint32_t last_carry = 0;
+  for (int i = 7; i >= 0; i--) {
+    uint8_t shifted = byte_res[i], carry = 0;  // shr_carry (crates/core/executor/src/events/utils? restated: utils.hpp:49-60)
+    if (nbits != 0) {
+      shifted = byte_res[i] >> nbits;
+      carry = byte_res[i] & ((1u << nbits) - 1);
+    }
+    r[SHR_CARRY + i] = carry;
+    r[SHR_SHIFTED + i] = shifted;
+    r[BIT_RES + i] = (shifted + last_carry * carry_mult) & 0xff;
+    last_carry = carry;
+  }
+}
+static inline void shift_right_padding(F* r) {
+  r[10] = 1;  // shift_by_n_bits[0]
+  r[18] = 1;  // shift_by_n_bytes[0]
+}
+
+// The reference's own sanity identities (debug_assert / assert in the row builders); returns false when one fails.
+static inline bool check_row(int chip, const AluEvent& e, const F* r) {
+  switch (chip) {
+    case ADD_SUB: {  // operations/add.rs:44-46: the top limb overflows by 0 or 256
+      const uint32_t op1 = e.opcode == ADD ? e.b : e.a, sum = op1 + e.c;
+      const uint32_t ov = (op1 >> 24) + (e.c >> 24) + r[8] - (sum >> 24);
+      return ov == 0 || ov == 256;
+    }
+    case LT:  // lt/mod.rs:266: a[0] = bit_b (1 - bit_c) + is_sign_eq * sltu
+      return r[4] == fadd(fmul(r[25], fsub(1, r[26])), fmul(r[29], r[27]));
+    case SHIFT_LEFT: {  // sll/mod.rs:281-286
+      const uint32_t nbytes = (e.c & 31) / 8;
+      for (uint32_t i = nbytes; i < 4; i++)
+        if (r[31 + i - nbytes] != ((e.a >> (8 * i)) & 0xff)) return false;
+      return true;
+    }
+    case SHIFT_RIGHT:  // sr/mod.rs:327-332
+      for (int i = 0; i < 4; i++)
+        if (r[30 + i] != ((e.a >> (8 * i)) & 0xff)) return false;
+      return true;
+    default: return true;
+  }
+}
+
+// Row-major canonical trace of `chip` over `events`; `height` rows of chip_width(chip) columns.
+static inline std::vector<F> generate(int chip, const AluEvent* events, size_t n_events, int fixed_log2_rows, size_t* height) {
+  const size_t w = chip_width(chip), h = padded_rows(n_events, fixed_log2_rows);
+  std::vector<F> t(h * w, 0);
+#pragma omp parallel for schedule(static)
+  for (size_t i = 0; i < h; i++) {
+    F* r = t.data() + i * w;
+    if (i < n_events) {
+      switch (chip) {
+        case ADD_SUB: add_sub_row(events[i], r); break;
+        case BITWISE: bitwise_row(events[i], r); break;
+        case LT: lt_row(events[i], r); break;
+        case SHIFT_LEFT: shift_left_row(events[i], r); break;
+        case SHIFT_RIGHT: shift_right_row(events[i], r); break;
+      }
+    } else if (chip == SHIFT_LEFT) {
+      shift_left_padding(r);
+    } else if (chip == SHIFT_RIGHT) {
+      shift_right_padding(r);
+    }
+  }
+  *height = h;
+  return t;
+}
+
+}  // namespace tracegen

@@ -27,6 +27,8 @@ def lib():
         L.orc_challenger_sample_bits.restype = C.c_uint32
         L.orc_challenger_grind.restype = C.c_uint32
         L.orc_two_adic_generator.restype = C.c_uint32
+        L.orc_tracegen_alu_width.restype = C.c_size_t
+        L.orc_tracegen_alu_check.restype = C.c_long
         # the oracle's OpenMP loops are fine-grained: beyond ~16 threads they get slower (256-thread hosts: 60x)
         L.orc_set_num_threads(min(16, os.cpu_count() or 1))
         _LIB = L
@@ -185,3 +187,23 @@ def verify_shard(pk, chips, fri, num_pv_elts, challenger, proof):
                                   C.byref(challenger), abi.as_u32p(proof), C.c_size_t(len(proof)),
                                   C.byref(verdict)))
     return verdict.value
+
+
+def tracegen_alu(chip, alu_events, fixed_log2_rows=-1):
+    """Row-major Montgomery trace of an ALU chip (oracle/tracegen.hpp)."""
+    from ziren_amd import events as E
+    ev = np.ascontiguousarray(alu_events, dtype=E.ALU_EVENT)
+    rows = C.c_size_t()
+    _check(lib().orc_tracegen_alu_rows(C.c_size_t(len(ev)), C.c_int(fixed_log2_rows), C.byref(rows)))
+    w = lib().orc_tracegen_alu_width(C.c_int(chip))
+    out = np.zeros((rows.value, w), dtype=np.uint32)
+    _check(lib().orc_tracegen_alu(C.c_int(chip), C.c_void_p(ev.ctypes.data), C.c_size_t(len(ev)), C.c_int(fixed_log2_rows),
+                                  abi.as_u32p(out), C.c_size_t(out.size)))
+    return out
+
+
+def tracegen_alu_check(chip, alu_events):
+    """Index of the first event whose row breaks one of the reference's in-line identities, or -1."""
+    from ziren_amd import events as E
+    ev = np.ascontiguousarray(alu_events, dtype=E.ALU_EVENT)
+    return int(lib().orc_tracegen_alu_check(C.c_int(chip), C.c_void_p(ev.ctypes.data), C.c_size_t(len(ev))))

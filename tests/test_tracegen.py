@@ -1,0 +1,170 @@
+"""ALU-chip trace generation: the oracle's rows against hand-computed rows, the reference's in-line
+identities on the instruction vectors its own chip tests prove (tests/golden/alu_events.json), padding and row counts;
+then (gpu) the HIP kernels bit-exact against the oracle through the C ABI."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from ziren_amd import events as E, field as F
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CHIP_ID = {v: k for k, v in E.CHIP_NAMES.items()}
+
+
+def golden_events():
+    recs = json.load(open(os.path.join(HERE, "golden", "alu_events.json")))["events"]
+    out = {}
+    for chip in E.CHIP_NAMES:
+        rs = [r for r in recs if r["chip"] == E.CHIP_NAMES[chip]]
+        ev = np.zeros(len(rs), dtype=E.ALU_EVENT)
+        ev["pc"] = 0
+        ev["next_pc"] = 4  # AluEvent::new(pc, ..) sets next_pc = pc + 4
+        ev["opcode"] = [r["opcode"] for r in rs]
+        ev["a"] = [r["a"] for r in rs]
+        ev["b"] = [r["b"] for r in rs]
+        ev["c"] = [r["c"] for r in rs]
+        out[chip] = ev
+    return out
+
+
+def canon(m):
+    return F.from_monty(m)
+
+
+def test_event_layout_and_widths(oracle):
+    assert E.ALU_EVENT.itemsize == 28
+    assert [E.ALU_EVENT.fields[k][1] for k in ("pc", "next_pc", "opcode", "hi", "a", "b", "c")] == [0, 4, 8, 12, 16, 20, 24]
+    for chip, w in E.CHIP_WIDTH.items():
+        assert oracle.lib().orc_tracegen_alu_width(chip) == w
+
+
+def test_reference_test_vectors_have_the_stated_results():
+    """`a = b op c` of ziren_amd.events agrees with every vector the reference's chip tests state."""
+    for chip, ev in golden_events().items():
+        got = E.alu_result(ev["opcode"], ev["b"], ev["c"])
+        for e, g in zip(ev, got):
+            if chip == E.CHIP_BITWISE and e["opcode"] == E.NOR:
+                # bitwise/mod.rs:278 states only the low byte of the NOR (228); the upper bytes of its `a` are not the result
+                assert int(g) & 0xff == int(e["a"]) & 0xff
+            else:
+                assert int(g) == int(e["a"]), (E.CHIP_NAMES[chip], e)
+
+
+def test_inline_identities_on_reference_vectors(oracle):
+    for chip, ev in golden_events().items():
+        if chip == E.CHIP_BITWISE:
+            continue  # no identity to check (and see the NOR note above)
+        assert oracle.tracegen_alu_check(chip, ev) == -1, E.CHIP_NAMES[chip]
+
+
+def test_inline_identities_on_synthetic_events(oracle):
+    for chip in E.CHIP_NAMES:
+        ev = E.synthetic_alu_events(chip, 20000, seed=3)
+        assert oracle.tracegen_alu_check(chip, ev) == -1, E.CHIP_NAMES[chip]
+
+
+def test_add_sub_row_by_hand(oracle):
+    # AluEvent::new(0, ADD, 14, 8, 6) (add_sub/mod.rs:282) and a SUB with borrows: 0x100 - 1 = 0xff, checked as 0xff + 1 = 0x100
+    ev = np.zeros(2, dtype=E.ALU_EVENT)
+    ev[0] = (0, 4, E.ADD, [0, 0, 0], 0, 14, 8, 6)
+    ev[1] = (8, 12, E.SUB, [0, 0, 0], 0, 0xff, 0x100, 1)
+    t = canon(oracle.tracegen_alu(E.CHIP_ADD_SUB, ev))
+    assert t.shape == (16, 19)
+    assert t[0].tolist() == [0, 4, 14, 0, 0, 0, 0, 0, 0, 8, 0, 0, 0, 6, 0, 0, 0, 1, 0]
+    # operand_1 = a = 0xff, operand_2 = c = 1, value = 0x100 (= b), carry out of byte 0
+    assert t[1].tolist() == [8, 12, 0, 1, 0, 0, 1, 0, 0, 0xff, 0, 0, 0, 1, 0, 0, 0, 0, 1]
+    assert not t[2:].any()
+
+
+def test_lt_row_by_hand(oracle):
+    # SLT 5 < -3 is false: sign bits differ (b >= 0, c < 0)
+    ev = np.zeros(1, dtype=E.ALU_EVENT)
+    ev[0] = (0, 4, E.SLT, [0, 0, 0], 0, 0, 5, 0xfffffffd)
+    r = canon(oracle.tracegen_alu(E.CHIP_LT, ev))[0]
+    assert r[2] == 1 and r[3] == 0                     # is_slt, is_sltu
+    assert r[8:12].tolist() == [5, 0, 0, 0] and r[12:16].tolist() == [0xfd, 0xff, 0xff, 0xff]
+    assert r[16:20].tolist() == [0, 0, 0, 1]           # masked top bytes 0x00 vs 0x7f differ first
+    assert r[20] == 0 and r[21] == 0x7f
+    assert r[22] == pow(F.P - 0x7f, F.P - 2, F.P)     # 1 / (0 - 0x7f)
+    assert (r[23], r[24], r[25], r[26]) == (0, 1, 0, 1)
+    assert r[27] == 1 and r[28] == 0 and r[29] == 0   # sltu on the masked words, not equal, signs differ
+    assert r[30:32].tolist() == [0, 0x7f]
+    assert r[4] == 0                                   # a[0] = bit_b (1 - bit_c) + is_sign_eq * sltu
+
+
+def test_shift_rows_by_hand(oracle):
+    ev = np.zeros(1, dtype=E.ALU_EVENT)
+    ev[0] = (0, 4, E.SLL, [0, 0, 0], 0, 0x90909080, 0x21212121, 7)   # sll/mod.rs test vector
+    r = canon(oracle.tracegen_alu(E.CHIP_SHIFT_LEFT, ev))
+    assert r[0, 22:30].tolist() == [0, 0, 0, 0, 0, 0, 0, 1] and r[0, 30] == 128
+    assert r[0, 31:35].tolist() == [0x80, 0x90, 0x90, 0x90] and r[0, 35:39].tolist() == [0x10, 0x10, 0x10, 0x10]
+    assert r[0, 39:43].tolist() == [1, 0, 0, 0] and r[0, 43] == 1
+    pad = np.zeros(44, dtype=np.uint32)
+    pad[[22, 30, 39]] = 1
+    assert (r[1:] == pad).all()                                      # sll/mod.rs:157-165
+    ev[0] = (0, 4, E.SRA, [0, 0, 0], 0, 0xff000000, 0x80000000, 7)   # sr/mod.rs test vector
+    r = canon(oracle.tracegen_alu(E.CHIP_SHIFT_RIGHT, ev))
+    assert r[0, 22:30].tolist() == [0, 0, 0, 0x80, 0xff, 0xff, 0xff, 0xff]   # sign-extended b, no byte shift
+    assert r[0, 30:34].tolist() == [0, 0, 0, 0xff]                            # = a
+    assert r[0, 54] == 1 and r[0, 63:67].tolist() == [0, 0, 1, 1]
+    pad = np.zeros(67, dtype=np.uint32)
+    pad[[10, 18]] = 1
+    assert (r[1:] == pad).all()                                      # sr/mod.rs:183-186
+
+
+def test_row_counts(oracle):
+    ev = E.synthetic_alu_events(E.CHIP_BITWISE, 40)
+    assert oracle.tracegen_alu(E.CHIP_BITWISE, ev[:0]).shape == (16, 18)
+    assert oracle.tracegen_alu(E.CHIP_BITWISE, ev[:16]).shape == (16, 18)
+    assert oracle.tracegen_alu(E.CHIP_BITWISE, ev[:17]).shape == (32, 18)
+    assert oracle.tracegen_alu(E.CHIP_BITWISE, ev, fixed_log2_rows=8).shape == (256, 18)
+    with pytest.raises(RuntimeError, match="too small"):
+        oracle.tracegen_alu(E.CHIP_BITWISE, ev, fixed_log2_rows=5)
+
+
+# ---- GPU: HIP kernels against the oracle, through the C ABI ------------------------------------------------------
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("chip", sorted(E.CHIP_NAMES))
+def test_gpu_tracegen_matches_oracle(hip_ctx, oracle, chip):
+    for n, fixed in ((0, -1), (1, -1), (15, -1), (16, -1), (17, -1), (1000, -1), (5000, 13), (70001, -1)):
+        ev = E.synthetic_alu_events(chip, n, seed=n + 1)
+        want = oracle.tracegen_alu(chip, ev, fixed)
+        m = hip_ctx.tracegen_alu(chip, ev, fixed)
+        assert (m.height, m.width) == want.shape
+        got = m.to_host()
+        m.free()
+        assert np.array_equal(got, want), (E.CHIP_NAMES[chip], n, np.argwhere(got != want)[:4])
+
+
+@pytest.mark.gpu
+def test_gpu_tracegen_reference_vectors(hip_ctx, oracle):
+    for chip, ev in golden_events().items():
+        m = hip_ctx.tracegen_alu(chip, ev)
+        assert np.array_equal(m.to_host(), oracle.tracegen_alu(chip, ev)), E.CHIP_NAMES[chip]
+        m.free()
+
+
+@pytest.mark.gpu
+def test_gpu_tracegen_errors(hip_ctx):
+    from ziren_amd import lib
+    ev = E.synthetic_alu_events(E.CHIP_LT, 40)
+    with pytest.raises(lib.ZkmError, match="too small"):
+        hip_ctx.tracegen_alu(E.CHIP_LT, ev, 5)
+    with pytest.raises(lib.ZkmError, match="unknown chip"):
+        hip_ctx.tracegen_alu(9, ev)
+
+
+@pytest.mark.gpu
+def test_gpu_generated_trace_commits_like_an_uploaded_one(hip_ctx, oracle):
+    """The device-born matrix feeds the commit path directly: same root as uploading the oracle's rows."""
+    from ziren_amd import prover
+    ev = E.synthetic_alu_events(E.CHIP_SHIFT_RIGHT, 3000)
+    born = hip_ctx.tracegen_alu(E.CHIP_SHIFT_RIGHT, ev)
+    up = hip_ctx.upload(oracle.tracegen_alu(E.CHIP_SHIFT_RIGHT, ev))
+    a = prover.pcs_commit(hip_ctx, [born], 1)
+    b = prover.pcs_commit(hip_ctx, [up], 1)
+    assert np.array_equal(a.root, b.root)
+    a.free(); b.free(); born.free(); up.free()

@@ -28,6 +28,7 @@
 #include "merkle.cuh"
 #include "stark.cuh"
 #include "open.cuh"
+#include "tracegen.cuh"
 
 using kb::E4;
 
@@ -1053,6 +1054,12 @@ static void open_impl(zkm_ctx* ctx, const zkm_pk* pk, zkm_main_data* md, const z
 }
 
 // ---- C ABI ---------------------------------------------------------------------------------------
+template <int CHIP>
+static void launch_alu_rows(zkm_ctx* ctx, const uint32_t* d_events, size_t n_events, size_t height, uint32_t* out) {
+  KLAUNCH(ctx, "tracegen_alu", 28.0 * n_events + 4.0 * height * tracegen::chip_width(CHIP), tracegen::alu_rows<CHIP>,
+          dim3(div_up(height, tracegen::THREADS)), dim3(tracegen::THREADS), 0, d_events, n_events, height, out);
+}
+
 #define API_BEGIN try {
 #define API_END                              \
   }                                          \
@@ -1445,6 +1452,54 @@ int zkm_coset_lde_batch(zkm_ctx* ctx, const uint32_t* host, size_t height, size_
     ctx->release(l);
   }
   zkm_matrix_free(ctx, m);
+  API_END
+}
+
+// ---- device trace generation (ALU chips) ---------------------------------------------------------------------
+size_t zkm_tracegen_alu_width(int chip) { return (size_t)tracegen::chip_width(chip); }
+
+int zkm_tracegen_alu(zkm_ctx* ctx, int chip, const zkm_alu_event* events, size_t n_events, int fixed_log2_rows, zkm_matrix** out) {
+  API_BEGIN
+  static_assert(sizeof(zkm_alu_event) == 28, "zkm_alu_event mirrors #[repr(C)] AluEvent");
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIP_CHECK(hipSetDevice(ctx->device));
+  if (chip < 0 || chip >= tracegen::NUM_CHIPS) throw std::runtime_error("zkm_tracegen_alu: unknown chip");
+  if (n_events && !events) throw std::runtime_error("zkm_tracegen_alu: null events");
+  // utils::next_power_of_two (crates/core/machine/src/utils/mod.rs): the shape's fixed size, else >= 16
+  size_t height = 16;
+  if (fixed_log2_rows >= 0) {
+    if (fixed_log2_rows > 30) throw std::runtime_error("zkm_tracegen_alu: fixed log2 rows out of range");
+    height = (size_t)1 << fixed_log2_rows;
+    if (n_events > height) throw std::runtime_error("zkm_tracegen_alu: fixed log2 rows is too small");
+  } else {
+    while (height < n_events) height <<= 1;
+  }
+  const size_t w = (size_t)tracegen::chip_width(chip);
+  ctx->begin_timing();
+  zkm_matrix* m = new zkm_matrix();
+  m->h = height; m->w = w;
+  uint32_t* d_events = nullptr;
+  try {
+    m->d = ctx->alloc_n<uint32_t>(height * w);
+    d_events = (uint32_t*)ctx->alloc(std::max<size_t>(n_events * 28, 4));
+    if (n_events) HIP_CHECK(hipMemcpyAsync(d_events, events, n_events * 28, hipMemcpyHostToDevice, ctx->stream));
+    switch (chip) {
+      case tracegen::ADD_SUB: launch_alu_rows<tracegen::ADD_SUB>(ctx, d_events, n_events, height, m->d); break;
+      case tracegen::BITWISE: launch_alu_rows<tracegen::BITWISE>(ctx, d_events, n_events, height, m->d); break;
+      case tracegen::LT: launch_alu_rows<tracegen::LT>(ctx, d_events, n_events, height, m->d); break;
+      case tracegen::SHIFT_LEFT: launch_alu_rows<tracegen::SHIFT_LEFT>(ctx, d_events, n_events, height, m->d); break;
+      case tracegen::SHIFT_RIGHT: launch_alu_rows<tracegen::SHIFT_RIGHT>(ctx, d_events, n_events, height, m->d); break;
+    }
+    ctx->mark("trace generation");
+    ctx->end_timing(false);  // synchronises: the caller's event buffer is free again
+  } catch (...) {
+    if (d_events) ctx->release(d_events);
+    if (m->d) ctx->release(m->d);
+    delete m;
+    throw;
+  }
+  ctx->release(d_events);
+  *out = m;
   API_END
 }
 

@@ -1,0 +1,89 @@
+"""Executor events of the ALU chips, as the reference lays them out in memory, and synthetic event streams.
+
+`ALU_EVENT` is the `#[repr(C)] AluEvent` of crates/core/executor/src/events/instr.rs:10-26 (28 bytes); opcode
+numbers are crates/core/executor/src/opcode.rs:26-48. The executor cannot run here, so shards are
+filled with synthetic instruction streams: operands from SplitMix64 with the corner cases mixed in, results
+computed with the MIPS semantics of the executor's ALU (`a = b op c`).
+"""
+import numpy as np
+
+from . import field as F
+
+ALU_EVENT = np.dtype([("pc", "<u4"), ("next_pc", "<u4"), ("opcode", "u1"), ("_pad", "u1", (3,)), ("hi", "<u4"),
+                      ("a", "<u4"), ("b", "<u4"), ("c", "<u4")])
+assert ALU_EVENT.itemsize == 28
+
+ADD, SUB = 0, 1
+SLL, SRL, SRA, ROR = 9, 10, 11, 12
+SLT, SLTU = 13, 14
+AND, OR, XOR, NOR = 15, 16, 17, 18
+
+# zkm_alu_chip
+CHIP_ADD_SUB, CHIP_BITWISE, CHIP_LT, CHIP_SHIFT_LEFT, CHIP_SHIFT_RIGHT = range(5)
+CHIP_NAMES = {CHIP_ADD_SUB: "AddSub", CHIP_BITWISE: "Bitwise", CHIP_LT: "Lt", CHIP_SHIFT_LEFT: "ShiftLeft",
+              CHIP_SHIFT_RIGHT: "ShiftRight"}
+CHIP_WIDTH = {CHIP_ADD_SUB: 19, CHIP_BITWISE: 18, CHIP_LT: 32, CHIP_SHIFT_LEFT: 44, CHIP_SHIFT_RIGHT: 67}
+CHIP_OPCODES = {CHIP_ADD_SUB: (ADD, SUB), CHIP_BITWISE: (AND, OR, XOR, NOR), CHIP_LT: (SLT, SLTU),
+                CHIP_SHIFT_LEFT: (SLL,), CHIP_SHIFT_RIGHT: (SRL, SRA, ROR)}
+
+_CORNERS = np.array([0, 1, 2, 0x7f, 0x80, 0xff, 0x100, 0xffff, 0x10000, 0x7fffffff, 0x80000000, 0x80000001,
+                     0xfffffffe, 0xffffffff, 0x00ff00ff, 0xff00ff00, 0x01010101], dtype=np.uint64)
+
+
+def alu_result(opcode: np.ndarray, b: np.ndarray, c: np.ndarray) -> np.ndarray:
+    """`a` of `a = b op c` for arrays of opcodes and u32 operands."""
+    b = b.astype(np.uint64)
+    c = c.astype(np.uint64)
+    sh = c & 31
+    sb = b.astype(np.uint32).astype(np.int32).astype(np.int64)
+    sc = c.astype(np.uint32).astype(np.int32).astype(np.int64)
+    M = np.uint64(0xffffffff)
+    out = np.zeros_like(b)
+    sel = lambda op: opcode == op  # noqa: E731
+    out = np.where(sel(ADD), (b + c) & M, out)
+    out = np.where(sel(SUB), (b - c) & M, out)
+    out = np.where(sel(AND), b & c, out)
+    out = np.where(sel(OR), b | c, out)
+    out = np.where(sel(XOR), b ^ c, out)
+    out = np.where(sel(NOR), ~(b | c) & M, out)
+    out = np.where(sel(SLT), (sb < sc).astype(np.uint64), out)
+    out = np.where(sel(SLTU), (b < c).astype(np.uint64), out)
+    out = np.where(sel(SLL), (b << sh) & M, out)
+    out = np.where(sel(SRL), b >> sh, out)
+    out = np.where(sel(SRA), (sb >> sh.astype(np.int64)).astype(np.uint64) & M, out)
+    out = np.where(sel(ROR), ((b >> sh) | (b << (np.uint64(32) - sh))) & M, out)
+    return out.astype(np.uint32)
+
+
+def make_alu_events(opcode, b, c, pc0: int = 0x1000) -> np.ndarray:
+    opcode = np.asarray(opcode, dtype=np.uint8)
+    n = len(opcode)
+    ev = np.zeros(n, dtype=ALU_EVENT)
+    ev["pc"] = (pc0 + 4 * np.arange(n, dtype=np.uint64)) & 0x7ffffffc
+    ev["next_pc"] = ev["pc"] + 4
+    ev["opcode"] = opcode
+    ev["b"] = np.asarray(b, dtype=np.uint32)
+    ev["c"] = np.asarray(c, dtype=np.uint32)
+    ev["a"] = alu_result(opcode, ev["b"], ev["c"])
+    return ev
+
+
+def synthetic_alu_events(chip: int, n: int, seed: int = 1) -> np.ndarray:
+    """n events for `chip`: uniform operands, with about a quarter of them replaced by corner values, equal
+    operands and (for the shift chips) every shift amount, so that each branch of the row builder is taken."""
+    rng = F.SplitMix64(0x414c5500 + 97 * chip + seed)
+    ops = np.array(CHIP_OPCODES[chip], dtype=np.uint8)
+    raw = rng.next_u64(4 * n)
+    r0, r1, r2, r3 = raw[:n], raw[n:2 * n], raw[2 * n:3 * n], raw[3 * n:]
+    opcode = ops[(r0 % np.uint64(len(ops))).astype(np.int64)]
+    b = (r1 & np.uint64(0xffffffff)).astype(np.uint64)
+    c = (r2 & np.uint64(0xffffffff)).astype(np.uint64)
+    kind = (r3 >> np.uint64(8)) % np.uint64(16)
+    pick = lambda r: _CORNERS[(r % np.uint64(len(_CORNERS))).astype(np.int64)]  # noqa: E731
+    b = np.where(kind == 0, pick(r3 >> np.uint64(16)), b)
+    c = np.where(kind == 1, pick(r3 >> np.uint64(24)), c)
+    c = np.where(kind == 2, b, c)                                   # equal operands
+    c = np.where(kind == 3, b ^ (np.uint64(1) << ((r3 >> np.uint64(32)) % np.uint64(32))), c)  # one differing bit
+    if chip in (CHIP_SHIFT_LEFT, CHIP_SHIFT_RIGHT):
+        c = np.where(kind < 8, (r3 >> np.uint64(40)) % np.uint64(32), c)  # small shift amounts, all 32 of them
+    return make_alu_events(opcode, b, c)

@@ -55,8 +55,7 @@ class SplitMix64:
     def __init__(self, seed: int):
         self.state = np.uint64(seed)
 
-    def uniform_field(self, shape):
-        n = int(np.prod(shape))
+    def next_u64(self, n: int) -> np.ndarray:
         with np.errstate(over="ignore"):
             idx = np.arange(1, n + 1, dtype=np.uint64)
             z = self.state + idx * np.uint64(0x9E3779B97F4A7C15)
@@ -64,4 +63,8 @@ class SplitMix64:
             z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
             z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
             z = z ^ (z >> np.uint64(31))
-        return (z % np.uint64(P)).reshape(shape)
+        return z
+
+    def uniform_field(self, shape):
+        n = int(np.prod(shape))
+        return (self.next_u64(n) % np.uint64(P)).reshape(shape)

@@ -55,6 +55,16 @@ class Context:
                                                C.byref(h)))
         return DeviceMatrix(self, h, m.shape[0], m.shape[1])
 
+    def tracegen_alu(self, chip: int, alu_events: np.ndarray, fixed_log2_rows: int = -1) -> DeviceMatrix:
+        """`generate_trace` of an ALU chip on the device (zkm_tracegen_alu); `alu_events` has dtype events.ALU_EVENT."""
+        from . import events as _ev
+        ev = np.ascontiguousarray(alu_events, dtype=_ev.ALU_EVENT)
+        h = C.c_void_p()
+        lib.check(lib.load().zkm_tracegen_alu(self.h, C.c_int(chip), C.c_void_p(ev.ctypes.data if len(ev) else None),
+                                              C.c_size_t(len(ev)), C.c_int(fixed_log2_rows), C.byref(h)))
+        L = lib.load()
+        return DeviceMatrix(self, h, int(L.zkm_matrix_height(h)), int(L.zkm_matrix_width(h)))
+
     def host_alloc(self, shape) -> np.ndarray:
         """uint32 array in page-locked host memory (zkm_host_alloc); free with host_free."""
         n = int(np.prod(shape))
