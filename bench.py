@@ -45,8 +45,73 @@ def cpu_baseline(log_rows_sample, fri):
     return wall, O.lib().orc_num_threads()
 
 
+def tracegen_bench(args):
+    """`python bench.py --tracegen`: device trace generation for the five ALU chips, one chip
+    after the other at 2^log_rows events each. A "step" is one generate_trace call per chip. value = rows per second
+    of kernel time (events resident in HBM); the wall-clock rate including the 28-byte-per-event H2D copy is
+    reported beside it. HBM roofline: algorithmic bytes = 28 n (events) + 4 h w (trace) per chip."""
+    from ziren_amd import events as E
+    ctx = prover.Context(0)
+    lib.load().zkm_ctx_set_kernel_timing(ctx.h, C.c_int(1))
+    n = 1 << args.log_rows
+    per_chip, tot_rows, tot_kernel_ms, tot_wall_ms, tot_bytes = {}, 0, 0.0, 0.0, 0.0
+    for chip in sorted(E.CHIP_NAMES):
+        ev = E.synthetic_alu_events(chip, n)
+        pinned = ctx.host_alloc((n * 7,))
+        pinned[...] = ev.view(np.uint32).reshape(-1)
+        evp = pinned.view(E.ALU_EVENT)
+        kms, wms = [], []
+        for it in range(args.warmup + args.steps):
+            t0 = time.perf_counter()
+            m = ctx.tracegen_alu(chip, evp, args.log_rows)
+            w = (time.perf_counter() - t0) * 1e3
+            k = sum(ms for name, ms, _, _ in ctx.kernel_timings() if name == "tracegen_alu")
+            m.free()
+            if it >= args.warmup:
+                kms.append(k)
+                wms.append(w)
+        ctx.host_free(pinned)
+        nbytes = 28.0 * n + 4.0 * n * E.CHIP_WIDTH[chip]
+        k, w = float(np.mean(kms)), float(np.mean(wms))
+        per_chip[E.CHIP_NAMES[chip]] = {"kernel_ms": round(k, 4), "call_ms": round(w, 3), "GBps": round(nbytes / k / 1e6, 1),
+                                        "width": E.CHIP_WIDTH[chip]}
+        tot_rows += n
+        tot_kernel_ms += k
+        tot_wall_ms += w
+        tot_bytes += nbytes
+    cpu = None
+    if not args.no_cpu_baseline:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_lib as O
+        O.lib().orc_set_num_threads(min(16, os.cpu_count() or 1))
+        ns = 1 << 21
+        rows, t = 0, 0.0
+        for chip in sorted(E.CHIP_NAMES):
+            ev = E.synthetic_alu_events(chip, ns)
+            t0 = time.perf_counter()
+            O.tracegen_alu(chip, ev, 21)
+            t += time.perf_counter() - t0
+            rows += ns
+        cpu = {"value": round(rows / t, 1), "unit": "trace rows/s", "cores": O.lib().orc_num_threads(), "kind": "port",
+               "sample": "the same five chips at 2^21 events each through oracle/tracegen.hpp (row-major Montgomery output, as the reference's generate_trace returns)"}
+    achieved = tot_bytes / tot_kernel_ms / 1e6
+    print(json.dumps({
+        "metric": "trace rows/sec", "value": round(tot_rows / (tot_kernel_ms * 1e-3), 1), "unit": "trace rows/s", "n_gpus": 1,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(tot_kernel_ms, 4), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+        "config": {"workload": f"generate_trace of AddSub, Bitwise, Lt, ShiftLeft, ShiftRight, 2^{args.log_rows} events each, events resident in HBM",
+                   "log_rows": args.log_rows},
+        "pcie_inclusive": {"value": round(tot_rows / (tot_wall_ms * 1e-3), 1), "unit": "trace rows/s", "ms_per_step": round(tot_wall_ms, 3),
+                           "note": "wall clock of zkm_tracegen_alu: pinned-host events -> HBM, kernel, synchronise"},
+        "chips": per_chip,
+        "roofline": {"bound": "hbm", "kernel": "tracegen::alu_rows", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None},
+        "cpu_baseline": cpu}))
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--tracegen", action="store_true", help="benchmark device trace generation of the ALU chips instead of the shard proof")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
@@ -58,6 +123,8 @@ def main():
     ap.add_argument("--from-host", action="store_true", help="time upload (pinned host traces -> HBM) + proof: the PCIe-inclusive rate")
     ap.add_argument("--interpreter", action="store_true", help="use the bytecode interpreter instead of per-chip quotient kernels")
     args = ap.parse_args()
+    if args.tracegen:
+        return tracegen_bench(args)
 
     from ziren_amd import farm as farm_mod
     hp_holder = {}

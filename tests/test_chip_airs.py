@@ -1,0 +1,156 @@
+"""The ALU chips' AIRs, transcribed from the reference's `eval` (ziren_amd/chips.py), against the generated traces:
+every constraint vanishes on every row (events, padding, the wrap-around row), a corrupted cell is caught, and the
+lookups the chips issue have the reference's shape. GPU: a shard of the five real chips, traces born on the device, is
+proved and accepted by the restated verifier, and the proof is bit-identical to the oracle's."""
+import numpy as np
+import pytest
+
+from ziren_amd import abi, air, chips, events as E, field as F
+from test_tracegen import golden_events
+
+
+def rows_for(oracle, chip, n, seed=5, fixed=-1):
+    ev = E.synthetic_alu_events(chip, n, seed=seed)
+    return ev, F.from_monty(oracle.tracegen_alu(chip, ev, fixed))
+
+
+@pytest.mark.parametrize("chip", sorted(E.CHIP_NAMES))
+def test_constraints_hold_on_generated_rows(oracle, chip):
+    rec = chips.record_constraints(chip)
+    _, t = rows_for(oracle, chip, 3000)     # 3000 events + 1096 padding rows
+    assert air.debug_constraints(rec.b, t) == []
+    _, t = rows_for(oracle, chip, 0)        # padding only
+    assert air.debug_constraints(rec.b, t) == []
+    _, t = rows_for(oracle, chip, 64)       # no padding
+    assert air.debug_constraints(rec.b, t) == []
+
+
+def test_constraints_hold_on_reference_vectors(oracle):
+    for chip, ev in golden_events().items():
+        if chip == E.CHIP_BITWISE:
+            continue  # its NOR vector states a truncated result (see test_tracegen); the AIR has no arithmetic on a/b/c anyway
+        rec = chips.record_constraints(chip)
+        t = F.from_monty(oracle.tracegen_alu(chip, ev))
+        assert air.debug_constraints(rec.b, t) == [], E.CHIP_NAMES[chip]
+
+
+@pytest.mark.parametrize("chip,col", [(E.CHIP_ADD_SUB, 6), (E.CHIP_LT, 27), (E.CHIP_SHIFT_LEFT, 31), (E.CHIP_SHIFT_RIGHT, 30),
+                                      (E.CHIP_BITWISE, 14)])
+def test_corrupted_cell_is_caught(oracle, chip, col):
+    rec = chips.record_constraints(chip)
+    _, t = rows_for(oracle, chip, 100)
+    t = t.copy()
+    t[7, col] = (int(t[7, col]) + 1) % F.P
+    bad = air.debug_constraints(rec.b, t)
+    assert bad and all(row == 7 for _, row in bad)
+
+
+def test_lookup_shapes():
+    want = {  # (byte sends, instruction receives): counted from the reference's eval
+        E.CHIP_ADD_SUB: (6, 2), E.CHIP_BITWISE: (4, 1), E.CHIP_LT: (3, 1), E.CHIP_SHIFT_LEFT: (4, 1), E.CHIP_SHIFT_RIGHT: (25, 1)}
+    for chip, (ns, nr) in want.items():
+        rec = chips.record_constraints(chip)
+        assert (len(rec.sends), len(rec.receives)) == (ns, nr)
+        assert all(lk.kind == air.KIND_BYTE and len(lk.values) == 5 for lk in rec.sends)
+        assert all(lk.kind == air.KIND_INSTRUCTION and len(lk.values) == 28 for lk in rec.receives)
+
+
+def test_lookup_values_on_a_row(oracle):
+    """Bitwise, XOR 10 ^ 19 = 25: the byte lookups carry (XOR, a_i, 0, b_i, c_i) and the instruction receive the CPU opcode."""
+    ev = E.make_alu_events([E.XOR], [10], [19], pc0=0x400)
+    t = F.from_monty(oracle.tracegen_alu(E.CHIP_BITWISE, ev))
+    rec = chips.record_constraints(E.CHIP_BITWISE)
+    main = {c: t[:, c].astype(np.uint64) for c in range(t.shape[1])}
+    vals = [int(v.apply_np({}, main)[0]) for v in rec.sends[0].values]
+    assert vals == [chips.B_XOR, 25, 0, 10, 19] and int(rec.sends[0].multiplicity.apply_np({}, main)[0]) == 1
+    recv = [int(v.apply_np({}, main)[0]) for v in rec.receives[0].values]
+    assert recv == [0, 0, 0x400, 0x404, 0x408, 0, E.XOR, 25, 0, 0, 0, 10, 0, 0, 0, 19, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1]
+    assert int(rec.receives[0].multiplicity.apply_np({}, main)[1]) == 0   # padding row: multiplicity 0
+
+
+def test_to_virtual_pair_rejects_products():
+    b = air.AirBuilder(3, 0, 0)
+    l = b.main()[0]
+    with pytest.raises(ValueError):
+        air.to_virtual_pair(l[0] * l[1])
+    with pytest.raises(ValueError):
+        air.to_virtual_pair(b.main()[1][0])
+    vp = air.to_virtual_pair((l[0] - l[2]) * 5 + 7)
+    assert sorted(vp.terms) == [(True, 0, 5), (True, 2, F.P - 5)] and vp.constant == 7
+
+
+# ---- GPU ------------------------------------------------------------------------------------------------------------
+
+def alu_shard(oracle, log_rows, seed=11):
+    """Five real chips; AddSub at 2^log_rows rows, the others smaller; every trace also as oracle rows."""
+    spec = [(E.CHIP_ADD_SUB, log_rows, 0.9), (E.CHIP_BITWISE, log_rows - 1, 1.0), (E.CHIP_LT, log_rows - 1, 0.7),
+            (E.CHIP_SHIFT_LEFT, log_rows - 2, 0.55), (E.CHIP_SHIFT_RIGHT, log_rows - 2, 0.8)]
+    recs, evs = [], []
+    for chip, lh, fill in spec:
+        n = int((1 << lh) * fill)
+        ev = E.synthetic_alu_events(chip, n, seed=seed + chip)
+        rc = chips.record_chip(chip, lh)
+        rc.trace = oracle.tracegen_alu(chip, ev, lh)
+        recs.append(rc)
+        evs.append((chip, ev, lh))
+    return recs, evs
+
+
+def mirror_chip(rec):
+    """A chip that receives exactly what `rec` sends and sends what it receives (one column per lookup value plus a
+    multiplicity column, filled from rec's trace), so that the pair's local cumulative sums cancel. It stands in for
+    the Byte and Cpu chips on the other side of the ALU chips' lookups (bytes/mod.rs, cpu/air), which are not built."""
+    t = F.from_monty(rec.trace)
+    main = {c: t[:, c].astype(np.uint64) for c in range(t.shape[1])}
+    cols, sends, receives = [], [], []
+    for src, dst in ((rec.sends, receives), (rec.receives, sends)):
+        for lk in src:
+            first = len(cols)
+            for v in list(lk.values) + [lk.multiplicity]:
+                cols.append(v.apply_np({}, main))
+            vals = [air.VirtualPairCol.single_main(first + j) for j in range(len(lk.values))]
+            dst.append(air.Lookup(vals, air.VirtualPairCol.single_main(first + len(lk.values)), lk.kind))
+    width = len(cols)
+    b = air.AirBuilder(width, 0, air.local_permutation_trace_width(len(sends) + len(receives), 2))
+    air.eval_permutation_constraints(b, sends, receives, 2, False)
+    program = b.assemble()
+    trace = np.empty((t.shape[0], width), dtype=np.uint32)
+    for c in range(width):
+        trace[:, c] = F.to_monty(cols[c])
+    return chips.RecordedChip(name=rec.name + "Mirror", log_height=rec.log_height, main_width=width, sends=sends,
+                              receives=receives, program=program, lookups_blob=air.encode_lookups(sends, receives),
+                              num_constraints=int(program[2]), trace=trace)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("log_rows,queries,pow_bits", [(6, 20, 8), (12, 84, 16)])
+def test_gpu_alu_shard_proof(hip_ctx, oracle, log_rows, queries, pow_bits):
+    from ziren_amd import prover, synth
+    recs, evs = alu_shard(oracle, log_rows)
+    mirrors = [mirror_chip(r) for r in recs]
+    recs = recs + mirrors
+    fri = abi.FriConfig(1, queries, pow_bits)
+    pv = F.to_monty(F.SplitMix64(3).uniform_field(synth.PROOF_MAX_NUM_PVS))
+    pv[synth.NUM_PV_ELTS:] = 0
+    igcs = F.to_monty(F.SplitMix64(4).uniform_field(14))
+    pc_start = F.to_monty(0x400000)
+    hp = prover.HipProver(recs, fri, synth.NUM_PV_ELTS, ctx=hip_ctx)
+    if log_rows > 8:
+        hp.specialize_quotient_kernels(recs[:5])   # the real chips through generated kernels, the mirrors interpreted
+    pk = hp.setup([], [], pc_start, igcs)
+    ch = prover.new_challenger()
+    pk.observe_into(ch)
+    start = ch.copy()
+    born = [hip_ctx.tracegen_alu(chip, ev, lh) for chip, ev, lh in evs]   # the ALU traces never exist on the host
+    born += [hip_ctx.upload(m.trace) for m in mirrors]
+    proof = hp.prove_shard(pk, pv, born, ch).copy()
+    # oracle: the same recorded chips over the oracle's own rows
+    opk = oracle.Pk([], [], pc_start, igcs, 1)
+    och = oracle.new_challenger()
+    opk.observe_into(och)
+    oproof, _ = oracle.prove_shard(opk, recs, [r.trace for r in recs], pv, fri, synth.NUM_PV_ELTS, och)
+    assert np.array_equal(proof, oproof)
+    assert ch.as_tuple() == och.as_tuple()
+    assert oracle.verify_shard(opk, recs, fri, synth.NUM_PV_ELTS, start.copy(), proof) == 0
+    for m in born:
+        m.free()

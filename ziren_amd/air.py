@@ -147,6 +147,40 @@ def encode_lookups(sends: List[Lookup], receives: List[Lookup]) -> np.ndarray:
     return np.array(w, dtype=np.uint32)
 
 
+def to_virtual_pair(e) -> VirtualPairCol:
+    """symbolic_to_virtual_pair (crates/stark/src/lookup/builder.rs:123-180): an expression that is affine in the
+    current row's main / preprocessed columns becomes column weights + constant; anything else is an error."""
+    if not isinstance(e, Expr):
+        return VirtualPairCol.const(int(e))
+
+    def walk(x):
+        if x.op == LD_CONST:
+            return [], int(F.from_monty(np.uint32(x.imm)))
+        if x.op == LD_MAIN or x.op == LD_PREP:
+            if x.a != 0:
+                raise ValueError("not an affine expression in current row elements")
+            return [(x.op == LD_MAIN, x.imm, 1)], 0
+        if x.op == ADD_B or x.op == SUB_B:
+            vl, cl = walk(x.a)
+            vr, cr = walk(x.c)
+            if x.op == SUB_B:
+                vr, cr = [(m, c, (F.P - w) % F.P) for m, c, w in vr], (F.P - cr) % F.P
+            return vl + vr, (cl + cr) % F.P
+        if x.op == NEG_B:
+            v, c = walk(x.a)
+            return [(m, col, (F.P - w) % F.P) for m, col, w in v], (F.P - c) % F.P
+        if x.op == MUL_B:
+            vl, cl = walk(x.a)
+            vr, cr = walk(x.c)
+            if vl and vr:
+                raise ValueError("not an affine expression")
+            return [(m, c, w * cr % F.P) for m, c, w in vl] + [(m, c, w * cl % F.P) for m, c, w in vr], cl * cr % F.P
+        raise ValueError("not an affine expression in current row elements")
+
+    terms, const = walk(e)
+    return VirtualPairCol(terms, const)
+
+
 class AirBuilder:
     """Symbolic builder that records constraints as bytecode."""
 
@@ -210,8 +244,17 @@ class AirBuilder:
     assert_zero_ext = assert_zero
     assert_eq_ext = assert_eq
 
+    def assert_one(self, e):
+        self.assert_zero(e - 1)
+
+    def assert_bool(self, e):
+        self.assert_zero(e * (e - 1))
+
     def when(self, cond: Expr):
         return _Filtered(self, cond)
+
+    def when_not(self, cond: Expr):
+        return self.when(1 - cond)
 
     def when_first_row(self):
         return self.when(self.is_first_row())
@@ -313,8 +356,17 @@ class _Filtered:
     assert_zero_ext = assert_zero
     assert_eq_ext = assert_eq
 
+    def assert_one(self, e):
+        self.assert_zero(e - 1)
+
+    def assert_bool(self, e):
+        self.assert_zero(e * (e - 1))
+
     def when(self, cond):
         return _Filtered(self.b, self.cond * cond)
+
+    def when_not(self, cond):
+        return self.when(1 - cond)
 
 
 def local_permutation_trace_width(nb_lookups, batch_size):
@@ -380,3 +432,57 @@ def count_permutation_constraints(n_lookups, batch_size, commit_scope_global):
     if commit_scope_global:
         c += 14
     return c
+
+
+def debug_constraints(b: "AirBuilder", main: np.ndarray, public_values=None) -> List[Tuple[int, int]]:
+    """Evaluate the recorded base-field constraints on every row of a trace (canonical values, row-major),
+    row i against row (i + 1) mod n as crates/stark/src/debug.rs:30-120 does. Returns [(constraint, first failing
+    row)]; empty when the trace satisfies the AIR. Extension-field (permutation) constraints are not covered."""
+    n = main.shape[0]
+    cols = [main[:, c].astype(np.uint64) for c in range(main.shape[1])]
+    nxt = [np.roll(c, -1) for c in cols]
+    rows = np.arange(n)
+    memo = {}
+
+    def ev(x):
+        key = id(x)
+        if key in memo:
+            return memo[key]
+        if x.ext:
+            raise ValueError("extension-field expression")
+        if x.op == LD_MAIN:
+            v = (nxt if x.a else cols)[x.imm]
+        elif x.op == LD_CONST:
+            v = np.full(n, int(F.from_monty(np.uint32(x.imm))), dtype=np.uint64)
+        elif x.op == LD_PV:
+            v = np.full(n, int(public_values[x.imm]), dtype=np.uint64)
+        elif x.op == LD_IS_FIRST:
+            v = (rows == 0).astype(np.uint64)
+        elif x.op == LD_IS_LAST:
+            v = (rows == n - 1).astype(np.uint64)
+        elif x.op == LD_IS_TRANS:
+            v = (rows != n - 1).astype(np.uint64)
+        elif x.op == ADD_B:
+            v = F.add(ev(x.a), ev(x.c))
+        elif x.op == SUB_B:
+            v = F.sub(ev(x.a), ev(x.c))
+        elif x.op == MUL_B:
+            v = F.mul(ev(x.a), ev(x.c))
+        elif x.op == NEG_B:
+            v = F.sub(np.zeros(n, dtype=np.uint64), ev(x.a))
+        else:
+            raise ValueError(f"opcode {x.op} not supported by debug_constraints")
+        memo[key] = v
+        return v
+
+    import sys
+    sys.setrecursionlimit(max(sys.getrecursionlimit(), 20000))
+    bad = []
+    for k, a in enumerate(b.asserts):
+        if a.ext:
+            continue
+        v = ev(a)
+        nz = np.nonzero(v)[0]
+        if len(nz):
+            bad.append((k, int(nz[0])))
+    return bad

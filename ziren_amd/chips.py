@@ -1,0 +1,322 @@
+"""The reference's ALU chips as recorded AIRs: `Air::eval` of AddSub, Bitwise, Lt, ShiftLeft and ShiftRight
+transcribed statement by statement onto air.AirBuilder, so the constraint order (hence the alpha powers) and the
+lookup order (hence the permutation columns) are the reference's.
+
+In the Rust integration this file does not exist: the shim runs the chips' own `eval` against a recording builder
+(INTEGRATION.md). Here it stands in for that recorder so that real chips, with traces generated on the device
+(csrc/tracegen.cuh), go through commit/open and the restated verifier. Sources (crates/core/machine/src/):
+  AddSub      alu/add_sub/mod.rs:188-252, operations/add.rs:57-101
+  Bitwise     alu/bitwise/mod.rs:201-257
+  Lt          alu/lt/mod.rs:288-472
+  ShiftLeft   alu/sll/mod.rs:289-415
+  ShiftRight  alu/sr/mod.rs:352-545
+  helpers     air/word.rs:55-80 (slice_range_check_u8), crates/stark/src/air/builder.rs:119-280 (byte and
+              instruction lookups), opcode numbers crates/core/executor/src/opcode.rs:26-48,195-216
+"""
+from dataclasses import dataclass, field as dc_field
+from typing import List, Optional
+
+import numpy as np
+
+from . import air, events as E
+
+# ByteOpcode (crates/core/executor/src/opcode.rs:195-216)
+B_AND, B_OR, B_XOR, B_SLL, B_U8RANGE, B_SHRCARRY, B_LTU, B_MSB, B_U16RANGE, B_NOR = range(10)
+
+
+@dataclass
+class RecordedChip:
+    """The fields HipProver / the oracle read from a chip (same as synth.SynChip)."""
+    name: str
+    log_height: int
+    main_width: int
+    prep_width: int = 0
+    prep_index: int = -1
+    log_quotient_degree: int = 1
+    local_only: bool = True
+    commit_scope_global: bool = False
+    sends: List[air.Lookup] = dc_field(default_factory=list)
+    receives: List[air.Lookup] = dc_field(default_factory=list)
+    program: Optional[np.ndarray] = None
+    lookups_blob: Optional[np.ndarray] = None
+    num_constraints: int = 0
+    trace: Optional[np.ndarray] = None
+    prep_trace: Optional[np.ndarray] = None
+
+    @property
+    def perm_ext_width(self):
+        return air.local_permutation_trace_width(len(self.sends) + len(self.receives), 1 << self.log_quotient_degree)
+
+
+class _Rec:
+    """ZKMAirBuilder surface used by the ALU chips, on top of air.AirBuilder."""
+
+    def __init__(self, width):
+        self.b = air.AirBuilder(width, 0, 0)
+        self.local = self.b.main()[0]
+        self.sends: List[air.Lookup] = []
+        self.receives: List[air.Lookup] = []
+
+    def const(self, v):
+        return self.b.const(v)
+
+    # ByteAirBuilder::send_byte / send_byte_pair (builder.rs:119-150)
+    def send_byte_pair(self, opcode, a1, a2, b, c, mult):
+        vals = [air.to_virtual_pair(v) for v in (opcode, a1, a2, b, c)]
+        self.sends.append(air.Lookup(vals, air.to_virtual_pair(mult), air.KIND_BYTE))
+
+    def send_byte(self, opcode, a, b, c, mult):
+        self.send_byte_pair(opcode, a, 0, b, c, mult)
+
+    # WordAirBuilder::slice_range_check_u8 (air/word.rs:55-80)
+    def slice_range_check_u8(self, cols, mult):
+        i = 0
+        while i + 1 < len(cols):
+            self.send_byte(B_U8RANGE, 0, cols[i], cols[i + 1], mult)
+            i += 2
+        if i < len(cols):
+            self.send_byte(B_U8RANGE, 0, cols[i], 0, mult)
+
+    # InstructionAirBuilder::receive_instruction (builder.rs:237-280) as the ALU chips call it: shard, clk,
+    # num_extra_cycles, hi and the four flags are zero, is_sequential is one
+    def receive_alu_instruction(self, pc, next_pc, opcode, a, b, c, mult):
+        vals = [0, 0, pc, next_pc, next_pc + 4, 0, opcode] + list(a) + list(b) + list(c) + [0, 0, 0, 0] + [0, 0, 0, 0, 1]
+        self.receives.append(air.Lookup([air.to_virtual_pair(v) for v in vals], air.to_virtual_pair(mult), air.KIND_INSTRUCTION))
+
+
+def _add_sub(r: _Rec):
+    l, b = r.local, r.b
+    PC, NEXT_PC, VALUE, CARRY, OP1, OP2, IS_ADD, IS_SUB = 0, 1, 2, 6, 9, 13, 17, 18
+    value, carry = l[VALUE:VALUE + 4], l[CARRY:CARRY + 3]
+    op1, op2 = l[OP1:OP1 + 4], l[OP2:OP2 + 4]
+    is_real = l[IS_ADD] + l[IS_SUB]
+    # AddOperation::eval(builder, operand_1, operand_2, add_operation, is_add + is_sub)
+    real = b.when(is_real)
+    base = 256
+    ov0 = op1[0] + op2[0] - value[0]
+    ov1 = op1[1] + op2[1] - value[1] + carry[0]
+    ov2 = op1[2] + op2[2] - value[2] + carry[1]
+    ov3 = op1[3] + op2[3] - value[3] + carry[2]
+    real.assert_zero(ov3 * (ov3 - base))
+    real.assert_zero(carry[0] * (ov0 - base))
+    real.assert_zero(carry[1] * (ov1 - base))
+    real.assert_zero(carry[2] * (ov2 - base))
+    real.assert_zero((carry[0] - 1) * ov0)
+    real.assert_zero((carry[1] - 1) * ov1)
+    real.assert_zero((carry[2] - 1) * ov2)
+    real.assert_bool(carry[0])
+    real.assert_bool(carry[1])
+    real.assert_bool(carry[2])
+    real.assert_bool(is_real)
+    r.slice_range_check_u8(op1, is_real)
+    r.slice_range_check_u8(op2, is_real)
+    r.slice_range_check_u8(value, is_real)
+    # ADD: a = value, b = operand_1, c = operand_2; SUB: a = operand_1, b = value, c = operand_2
+    r.receive_alu_instruction(l[PC], l[NEXT_PC], E.ADD, value, op1, op2, l[IS_ADD])
+    r.receive_alu_instruction(l[PC], l[NEXT_PC], E.SUB, op1, value, op2, l[IS_SUB])
+    b.assert_bool(l[IS_ADD])
+    b.assert_bool(l[IS_SUB])
+    b.assert_bool(is_real)
+
+
+def _bitwise(r: _Rec):
+    l, b = r.local, r.b
+    PC, NEXT_PC, A, B, C, IS_NOR, IS_XOR, IS_OR, IS_AND = 0, 1, 2, 6, 10, 14, 15, 16, 17
+    opcode = l[IS_XOR] * B_XOR + l[IS_OR] * B_OR + l[IS_AND] * B_AND + l[IS_NOR] * B_NOR
+    mult = l[IS_XOR] + l[IS_OR] + l[IS_AND] + l[IS_NOR]
+    for i in range(4):
+        r.send_byte(opcode, l[A + i], l[B + i], l[C + i], mult)
+    cpu_opcode = l[IS_XOR] * E.XOR + l[IS_OR] * E.OR + l[IS_AND] * E.AND + l[IS_NOR] * E.NOR
+    r.receive_alu_instruction(l[PC], l[NEXT_PC], cpu_opcode, l[A:A + 4], l[B:B + 4], l[C:C + 4],
+                              l[IS_XOR] + l[IS_OR] + l[IS_AND] + l[IS_NOR])
+    is_real = l[IS_XOR] + l[IS_OR] + l[IS_AND] + l[IS_NOR]
+    b.assert_bool(l[IS_XOR])
+    b.assert_bool(l[IS_OR])
+    b.assert_bool(l[IS_AND])
+    b.assert_bool(l[IS_NOR])
+    b.assert_bool(is_real)
+
+
+def _lt(r: _Rec):
+    l, b = r.local, r.b
+    (PC, NEXT_PC, IS_SLT, IS_SLTU, A, B, C, BYTE_FLAGS, B_MASKED, C_MASKED, NOT_EQ_INV, MSB_B, MSB_C, BIT_B, BIT_C, SLTU,
+     IS_COMP_EQ, IS_SIGN_EQ, CMP) = 0, 1, 2, 3, 4, 8, 12, 16, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30
+    is_real = l[IS_SLT] + l[IS_SLTU]
+    b_comp = [l[B + i] for i in range(4)]
+    c_comp = [l[C + i] for i in range(4)]
+    b_comp[3] = l[B + 3] * l[IS_SLTU] + l[B_MASKED] * l[IS_SLT]
+    c_comp[3] = l[C + 3] * l[IS_SLTU] + l[C_MASKED] * l[IS_SLT]
+    r.send_byte(B_AND, l[B_MASKED], l[B + 3], 0x7f, is_real)
+    r.send_byte(B_AND, l[C_MASKED], l[C + 3], 0x7f, is_real)
+    b.assert_eq(l[BIT_B], l[MSB_B] * l[IS_SLT])
+    b.assert_eq(l[BIT_C], l[MSB_C] * l[IS_SLT])
+    inv_128 = pow(128, air.F.P - 2, air.F.P)
+    b.assert_eq(l[MSB_B], (l[B + 3] - l[B_MASKED]) * inv_128)
+    b.assert_eq(l[MSB_C], (l[C + 3] - l[C_MASKED]) * inv_128)
+    b.assert_bool(l[IS_SIGN_EQ])
+    b.when(l[IS_SIGN_EQ]).assert_eq(l[BIT_B], l[BIT_C])
+    b.when(is_real).when_not(l[IS_SIGN_EQ]).assert_one(l[BIT_B] + l[BIT_C])
+    b.assert_eq(l[A], l[BIT_B] * (1 - l[BIT_C]) + l[IS_SIGN_EQ] * l[SLTU])
+    b.assert_zero(l[A + 1])
+    b.assert_zero(l[A + 2])
+    b.assert_zero(l[A + 3])
+    sum_flags = l[BYTE_FLAGS] + l[BYTE_FLAGS + 1] + l[BYTE_FLAGS + 2] + l[BYTE_FLAGS + 3]
+    for i in range(4):
+        b.assert_bool(l[BYTE_FLAGS + i])
+    b.assert_bool(sum_flags)
+    b.when(is_real).assert_eq(1 - l[IS_COMP_EQ], sum_flags)
+    b.assert_bool(l[IS_COMP_EQ])
+    visited = b.const(0)
+    b_cmp = b.const(0)
+    c_cmp = b.const(0)
+    for i in (3, 2, 1, 0):
+        flag = l[BYTE_FLAGS + i]
+        visited = visited + flag
+        b_cmp = b_cmp + b_comp[i] * flag
+        c_cmp = c_cmp + c_comp[i] * flag
+        b.when_not(visited).assert_eq(b_comp[i], c_comp[i])
+        b.when(l[IS_COMP_EQ]).assert_zero(visited)
+    b.assert_eq(l[CMP], b_cmp)
+    b.assert_eq(l[CMP + 1], c_cmp)
+    b.when_not(l[IS_COMP_EQ]).assert_eq(l[NOT_EQ_INV] * (l[CMP] - l[CMP + 1]), is_real)
+    r.send_byte(B_LTU, l[SLTU], l[CMP], l[CMP + 1], is_real)
+    b.assert_bool(l[IS_SLT])
+    b.assert_bool(l[IS_SLTU])
+    b.assert_bool(l[IS_SLT] + l[IS_SLTU])
+    r.receive_alu_instruction(l[PC], l[NEXT_PC], l[IS_SLT] * E.SLT + l[IS_SLTU] * E.SLTU, l[A:A + 4], l[B:B + 4], l[C:C + 4],
+                              is_real)
+
+
+def _shift_left(r: _Rec):
+    l, b = r.local, r.b
+    PC, NEXT_PC, A, B, C, C_LSB, BY_BITS, MULT, RESULT, CARRY, BY_BYTES, IS_REAL = 0, 1, 2, 6, 10, 14, 22, 30, 31, 35, 39, 43
+    base = 256
+    c_byte_sum = b.const(0)
+    for i in range(8):
+        c_byte_sum = c_byte_sum + b.const(1 << i) * l[C_LSB + i]
+    b.assert_eq(c_byte_sum, l[C])
+    nbits = b.const(0)
+    for i in range(3):
+        nbits = nbits + l[C_LSB + i] * (1 << i)
+    for i in range(8):
+        b.when(l[BY_BITS + i]).assert_eq(nbits, b.const(i))
+    for i in range(8):
+        b.when(l[BY_BITS + i]).assert_eq(l[MULT], b.const(1 << i))
+    for i in range(4):
+        v = l[B + i] * l[MULT] - l[CARRY + i] * base
+        if i > 0:
+            v = v + l[CARRY + i - 1]
+        b.assert_eq(l[RESULT + i], v)
+    nbytes = l[C_LSB + 3] + l[C_LSB + 4] * 2
+    for i in range(4):
+        b.when(l[BY_BYTES + i]).assert_eq(nbytes, b.const(i))
+    for k in range(4):
+        shifting = b.when(l[BY_BYTES + k])
+        for i in range(4):
+            if i < k:
+                shifting.assert_eq(l[A + i], b.const(0))
+            else:
+                shifting.assert_eq(l[A + i], l[RESULT + i - k])
+    for i in range(8):
+        b.assert_bool(l[C_LSB + i])
+    for i in range(8):
+        b.assert_bool(l[BY_BITS + i])
+    s = b.const(0)
+    for i in range(8):
+        s = s + l[BY_BITS + i]
+    b.assert_eq(s, b.const(1))
+    r.slice_range_check_u8(l[RESULT:RESULT + 4], l[IS_REAL])
+    r.slice_range_check_u8(l[CARRY:CARRY + 4], l[IS_REAL])
+    for i in range(4):
+        b.assert_bool(l[BY_BYTES + i])
+    s = b.const(0)
+    for i in range(4):
+        s = s + l[BY_BYTES + i]
+    b.assert_eq(s, b.const(1))
+    b.assert_bool(l[IS_REAL])
+    r.receive_alu_instruction(l[PC], l[NEXT_PC], E.SLL, l[A:A + 4], l[B:B + 4], l[C:C + 4], l[IS_REAL])
+
+
+def _shift_right(r: _Rec):
+    l, b = r.local, r.b
+    (PC, NEXT_PC, B, C, BY_BITS, BY_BYTES, BYTE_RES, BIT_RES, SHR_CARRY, SHR_SHIFTED, B_MSB_, C_LSB, IS_SRL, IS_ROR, IS_SRA,
+     IS_REAL) = 0, 1, 2, 6, 10, 18, 22, 30, 38, 46, 54, 55, 63, 64, 65, 66
+    r.send_byte(B_MSB, l[B_MSB_], l[B + 3], 0, l[IS_REAL])
+    c_byte_sum = b.const(0)
+    for i in range(8):
+        c_byte_sum = c_byte_sum + b.const(1 << i) * l[C_LSB + i]
+    b.assert_eq(c_byte_sum, l[C])
+    nbits = b.const(0)
+    for i in range(3):
+        nbits = nbits + l[C_LSB + i] * (1 << i)
+    for i in range(8):
+        b.when(l[BY_BITS + i]).assert_eq(nbits, b.const(i))
+    s = b.const(0)
+    for i in range(8):
+        s = s + l[BY_BITS + i]
+    b.assert_eq(s, b.const(1))
+    nbytes = l[C_LSB + 3] + l[C_LSB + 4] * 2
+    for i in range(4):
+        b.when(l[BY_BYTES + i]).assert_eq(nbytes, b.const(i))
+    s = b.const(0)
+    for i in range(4):
+        s = s + l[BY_BYTES + i]
+    b.assert_eq(s, b.const(1))
+    ext = [l[B + i] for i in range(4)]
+    for i in range(4):
+        ext.append(l[IS_SRA] * l[B_MSB_] * b.const(0xff) + l[IS_ROR] * l[B + i])
+    for k in range(4):
+        for i in range(8 - k):
+            b.when(l[BY_BYTES + k]).assert_eq(l[BYTE_RES + i], ext[i + k])
+    carry_mult = b.const(0)
+    for i in range(8):
+        carry_mult = carry_mult + b.const(1 << (8 - i)) * l[BY_BITS + i]
+    nbits2 = b.const(0)
+    for i in range(3):
+        nbits2 = nbits2 + l[C_LSB + i] * (1 << i)
+    for i in range(7, -1, -1):
+        r.send_byte_pair(B_SHRCARRY, l[SHR_SHIFTED + i], l[SHR_CARRY + i], l[BYTE_RES + i], nbits2, l[IS_REAL])
+    for i in range(7, -1, -1):
+        v = l[SHR_SHIFTED + i]
+        if i + 1 < 8:
+            v = v + l[SHR_CARRY + i + 1] * carry_mult
+        b.assert_eq(v, l[BIT_RES + i])
+    for flag in (IS_SRL, IS_SRA, IS_ROR, IS_REAL, B_MSB_):
+        b.assert_bool(l[flag])
+    for i in range(4):
+        b.assert_bool(l[BY_BYTES + i])
+    for i in range(8):
+        b.assert_bool(l[BY_BITS + i])
+    for i in range(8):
+        b.assert_bool(l[C_LSB + i])
+    for start in (BYTE_RES, BIT_RES, SHR_CARRY, SHR_SHIFTED):
+        r.slice_range_check_u8(l[start:start + 8], l[IS_REAL])
+    b.assert_eq(l[IS_SRL] + l[IS_SRA] + l[IS_ROR], l[IS_REAL])
+    r.receive_alu_instruction(l[PC], l[NEXT_PC], l[IS_SRL] * E.SRL + l[IS_SRA] * E.SRA + l[IS_ROR] * E.ROR,
+                              l[BIT_RES:BIT_RES + 4], l[B:B + 4], l[C:C + 4], l[IS_REAL])
+
+
+_EVAL = {E.CHIP_ADD_SUB: _add_sub, E.CHIP_BITWISE: _bitwise, E.CHIP_LT: _lt, E.CHIP_SHIFT_LEFT: _shift_left,
+         E.CHIP_SHIFT_RIGHT: _shift_right}
+# MachineAir::local_only (add_sub/mod.rs:152, bitwise/mod.rs:154, lt/mod.rs:201, sll/mod.rs:226; ShiftRight keeps the default)
+_LOCAL_ONLY = {E.CHIP_ADD_SUB: True, E.CHIP_BITWISE: True, E.CHIP_LT: True, E.CHIP_SHIFT_LEFT: True, E.CHIP_SHIFT_RIGHT: False}
+
+
+def record_constraints(chip: int) -> _Rec:
+    """The chip's own `eval`, recorded (without the permutation constraints Chip::eval appends)."""
+    r = _Rec(E.CHIP_WIDTH[chip])
+    _EVAL[chip](r)
+    return r
+
+
+def record_chip(chip: int, log_height: int) -> RecordedChip:
+    """`Chip::new` + `Chip::eval` (crates/stark/src/chip.rs:54-96,263-275): lookups collected from `eval`, the chip's
+    constraints followed by the LogUp constraints, quotient degree 2 (all five AIRs have degree 3)."""
+    r = record_constraints(chip)
+    lqd = 1
+    r.b.perm_ext_width = air.local_permutation_trace_width(len(r.sends) + len(r.receives), 1 << lqd)
+    air.eval_permutation_constraints(r.b, r.sends, r.receives, 1 << lqd, False)
+    program = r.b.assemble()
+    return RecordedChip(name=E.CHIP_NAMES[chip], log_height=log_height, main_width=E.CHIP_WIDTH[chip],
+                        log_quotient_degree=lqd, local_only=_LOCAL_ONLY[chip], sends=r.sends, receives=r.receives,
+                        program=program, lookups_blob=air.encode_lookups(r.sends, r.receives), num_constraints=int(program[2]))

@@ -220,10 +220,11 @@ class HipProver:
         if specialize:
             self.specialize_quotient_kernels()
 
-    def specialize_quotient_kernels(self):
-        """Compile (or load from the in-tree cache) one quotient kernel per chip AIR and register it."""
+    def specialize_quotient_kernels(self, chips=None):
+        """Compile (or load from the in-tree cache) one quotient kernel per chip AIR and register it; chips without
+        one go through the bytecode interpreter."""
         from . import codegen
-        for c in self.chips:
+        for c in (self.chips if chips is None else chips):
             prog = np.ascontiguousarray(c.program, dtype=np.uint32)
             co = codegen.specialize(prog)
             buf = C.create_string_buffer(co, len(co))
