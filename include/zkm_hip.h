@@ -244,6 +244,18 @@ size_t zkm_tracegen_alu_width(int chip);
 int zkm_tracegen_alu(zkm_ctx* ctx, int chip, const zkm_alu_event* events, size_t n_events,
                      int fixed_log2_rows, zkm_matrix** out);
 
+/* ByteChip::trace() — the Byte chip's preprocessed table, 65536 x 12, row (b << 8 | c)
+ * (crates/core/machine/src/bytes/mod.rs:31-104, columns bytes/columns.rs:12-46), generated on the device. */
+int zkm_tracegen_byte_table(zkm_ctx* ctx, zkm_matrix** out);
+/* ByteChip::generate_trace (bytes/trace.rs:46-66) over the byte lookups that the given ALU event streams record in
+ * their generate_dependencies (the `blu` of each chip's event_to_row): the 65536 x 10 multiplicity trace, one column
+ * per ByteOpcode. chips[s] is a zkm_alu_chip, events[s] its n_events[s] host events. extra_counts (may be NULL) is a
+ * 65536 x 10 row-major array of plain counts — `record.byte_lookups` of the chips whose dependencies stay on the
+ * host — added before the conversion to field elements. */
+int zkm_tracegen_byte_mults(zkm_ctx* ctx, size_t n_streams, const int* chips,
+                            const zkm_alu_event* const* events, const size_t* n_events,
+                            const uint32_t* extra_counts, zkm_matrix** out);
+
 /* ---- fine-grained entry points (parity tests, micro-benchmarks) ------------------------- */
 /* Poseidon2 width-16 permutation on n states (n x 16 words, in place), on the GPU.
  * zkm_primitives::poseidon2_init, crates/primitives/src/lib.rs:1107-1122. */

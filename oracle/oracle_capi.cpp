@@ -383,4 +383,19 @@ long orc_tracegen_alu_check(int chip, const void* events, size_t n_events) {
   return -1;
 }
 
+// ByteChip::trace() and ByteChip::generate_trace over ALU event streams: row-major Montgomery matrices
+int orc_tracegen_byte_table(uint32_t* out /* 65536 x 12 */) {
+  ORC_TRY
+  std::vector<F> t = tracegen::byte_table();
+  for (size_t i = 0; i < t.size(); i++) out[i] = to_monty(t[i]);
+  ORC_CATCH
+}
+int orc_tracegen_byte_mults(size_t n_streams, const int* chips, const void* const* events, const size_t* n_events,
+                            const uint32_t* extra_counts, uint32_t* out /* 65536 x 10 */) {
+  ORC_TRY
+  std::vector<F> t = tracegen::byte_mults(n_streams, chips, (const tracegen::AluEvent* const*)events, n_events, extra_counts);
+  for (size_t i = 0; i < t.size(); i++) out[i] = to_monty(t[i]);
+  ORC_CATCH
+}
+
 }  // extern "C"

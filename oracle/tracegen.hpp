@@ -187,7 +187,7 @@ static inline void shift_right_row(const AluEvent& e, F* r) {
   const uint32_t carry_mult = 1u << (8 - nbits);
   uint32_t last_carry = 0;
   for (int i = 7; i >= 0; i--) {
-    uint8_t shifted = byte_res[i], carry = 0;  // shr_carry (crates/core/executor/src/events/utils? restated: utils.hpp:49-60)
+    uint8_t shifted = byte_res[i], carry = 0;  // shr_carry, crates/core/machine/src/bytes/utils.rs:2-11
     if (nbits != 0) {
       shifted = byte_res[i] >> nbits;
       carry = byte_res[i] & ((1u << nbits) - 1);
@@ -249,6 +249,92 @@ static inline std::vector<F> generate(int chip, const AluEvent* events, size_t n
     }
   }
   *height = h;
+  return t;
+}
+
+// ---- byte lookups and the Byte chip -----------------------------------------------------------------------------------
+// ByteOpcode (crates/core/executor/src/opcode.rs:195-216); table and multiplicity layout: bytes/columns.rs:12-57,
+// bytes/mod.rs:31-104 (ByteChip::trace), bytes/trace.rs:46-66 (generate_trace).
+enum ByteOp { B_AND = 0, B_OR = 1, B_XOR = 2, B_SLL = 3, B_U8RANGE = 4, B_SHRCARRY = 5, B_LTU = 6, B_MSB = 7, B_U16RANGE = 8, B_NOR = 9 };
+static const size_t NUM_BYTE_OPS = 10, BYTE_ROWS = 1 << 16, BYTE_PREP_COLS = 12;
+
+struct ByteLookup { uint8_t op, b, c; };  // a1 / a2 are functions of (op, b, c); only the table row matters for counting
+
+static inline void range_checks(std::vector<ByteLookup>& out, const F* bytes, int n) {  // events/byte.rs:72-82
+  int i = 0;
+  for (; i + 1 < n; i += 2) out.push_back({B_U8RANGE, (uint8_t)bytes[i], (uint8_t)bytes[i + 1]});
+  if (i < n) out.push_back({B_U8RANGE, (uint8_t)bytes[i], 0});
+}
+
+// The `blu` events of each chip's event_to_row, read off its (canonical) row.
+static inline void row_lookups(int chip, const AluEvent& e, const F* r, std::vector<ByteLookup>& out) {
+  switch (chip) {
+    case ADD_SUB:  // operations/add.rs:48-53
+      range_checks(out, r + 9, 4); range_checks(out, r + 13, 4); range_checks(out, r + 2, 4);
+      break;
+    case BITWISE: {  // bitwise/mod.rs:183-193, ByteOpcode::from(opcode) events/byte.rs:148-160
+      const uint8_t op = e.opcode == AND ? B_AND : e.opcode == OR ? B_OR : e.opcode == XOR ? B_XOR : B_NOR;
+      for (int i = 0; i < 4; i++) out.push_back({op, (uint8_t)r[6 + i], (uint8_t)r[10 + i]});
+      break;
+    }
+    case LT:  // lt/mod.rs:227-241, 268-274
+      out.push_back({B_AND, (uint8_t)r[11], 0x7f});
+      out.push_back({B_AND, (uint8_t)r[15], 0x7f});
+      out.push_back({B_LTU, (uint8_t)r[30], (uint8_t)r[31]});
+      break;
+    case SHIFT_LEFT:  // sll/mod.rs:276-279
+      range_checks(out, r + 31, 4); range_checks(out, r + 35, 4);
+      break;
+    case SHIFT_RIGHT: {  // sr/mod.rs:258-265, 309-316, 334-337
+      out.push_back({B_MSB, (uint8_t)r[5], 0});
+      const uint8_t nbits = (uint8_t)((e.c % 32) % 8);
+      for (int i = 7; i >= 0; i--) out.push_back({B_SHRCARRY, (uint8_t)r[22 + i], nbits});
+      range_checks(out, r + 22, 8); range_checks(out, r + 30, 8); range_checks(out, r + 38, 8); range_checks(out, r + 46, 8);
+      break;
+    }
+  }
+}
+
+// ByteChip::generate_trace over the lookups of the given event streams (+ optional plain counts, row-major 65536 x 10)
+static inline std::vector<F> byte_mults(size_t n_streams, const int* chips, const AluEvent* const* events, const size_t* n_events,
+                                        const uint32_t* extra) {
+  std::vector<uint64_t> cnt(BYTE_ROWS * NUM_BYTE_OPS, 0);
+  std::vector<ByteLookup> lk;
+  for (size_t s = 0; s < n_streams; s++) {
+    const size_t w = chip_width(chips[s]);
+    std::vector<F> row(w);
+    for (size_t i = 0; i < n_events[s]; i++) {
+      std::fill(row.begin(), row.end(), 0);
+      switch (chips[s]) {
+        case ADD_SUB: add_sub_row(events[s][i], row.data()); break;
+        case BITWISE: bitwise_row(events[s][i], row.data()); break;
+        case LT: lt_row(events[s][i], row.data()); break;
+        case SHIFT_LEFT: shift_left_row(events[s][i], row.data()); break;
+        case SHIFT_RIGHT: shift_right_row(events[s][i], row.data()); break;
+      }
+      lk.clear();
+      row_lookups(chips[s], events[s][i], row.data(), lk);
+      for (const ByteLookup& l : lk) cnt[(((size_t)l.b << 8) + l.c) * NUM_BYTE_OPS + l.op]++;
+    }
+  }
+  std::vector<F> t(BYTE_ROWS * NUM_BYTE_OPS);
+  for (size_t i = 0; i < t.size(); i++) t[i] = (F)((cnt[i] + (extra ? extra[i] : 0)) % P);
+  return t;
+}
+
+// ByteChip::trace(): 65536 x 12 row-major canonical
+static inline std::vector<F> byte_table() {
+  std::vector<F> t(BYTE_ROWS * BYTE_PREP_COLS);
+  for (uint32_t b = 0; b < 256; b++)
+    for (uint32_t c = 0; c < 256; c++) {
+      F* r = t.data() + ((size_t)(b << 8) + c) * BYTE_PREP_COLS;
+      const uint32_t k = c & 7;
+      r[0] = b; r[1] = c; r[2] = b & c; r[3] = b | c; r[4] = b ^ c; r[5] = (uint8_t)~(b | c);
+      r[6] = (uint8_t)(b << k);
+      r[7] = k ? b >> k : b;                       // shr_carry(b, c)
+      r[8] = k ? (uint8_t)(b << (8 - k)) >> (8 - k) : 0;
+      r[9] = b < c; r[10] = (b & 0x80) != 0; r[11] = (b << 8) + c;
+    }
   return t;
 }
 

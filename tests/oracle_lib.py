@@ -207,3 +207,23 @@ def tracegen_alu_check(chip, alu_events):
     from ziren_amd import events as E
     ev = np.ascontiguousarray(alu_events, dtype=E.ALU_EVENT)
     return int(lib().orc_tracegen_alu_check(C.c_int(chip), C.c_void_p(ev.ctypes.data), C.c_size_t(len(ev))))
+
+
+def tracegen_byte_table():
+    out = np.zeros((1 << 16, 12), dtype=np.uint32)
+    _check(lib().orc_tracegen_byte_table(abi.as_u32p(out)))
+    return out
+
+
+def tracegen_byte_mults(streams, extra_counts=None):
+    """streams: [(chip, alu_events)]; extra_counts: optional (65536, 10) plain counts."""
+    from ziren_amd import events as E
+    evs = [np.ascontiguousarray(ev, dtype=E.ALU_EVENT) for _, ev in streams]
+    chips = (C.c_int * len(streams))(*[c for c, _ in streams])
+    ptrs = (C.c_void_p * len(streams))(*[ev.ctypes.data for ev in evs])
+    ns = _sizes([len(ev) for ev in evs])
+    out = np.zeros((1 << 16, 10), dtype=np.uint32)
+    ex = np.ascontiguousarray(extra_counts, dtype=np.uint32) if extra_counts is not None else None
+    _check(lib().orc_tracegen_byte_mults(C.c_size_t(len(streams)), chips, ptrs, ns,
+                                         abi.as_u32p(ex) if ex is not None else None, abi.as_u32p(out)))
+    return out

@@ -96,15 +96,18 @@ def alu_shard(oracle, log_rows, seed=11):
     return recs, evs
 
 
-def mirror_chip(rec):
+def mirror_chip(rec, kinds=None):
     """A chip that receives exactly what `rec` sends and sends what it receives (one column per lookup value plus a
     multiplicity column, filled from rec's trace), so that the pair's local cumulative sums cancel. It stands in for
-    the Byte and Cpu chips on the other side of the ALU chips' lookups (bytes/mod.rs, cpu/air), which are not built."""
+    the chips on the other side of the ALU chips' lookups that are not built (Cpu: crates/core/machine/src/cpu/; with
+    kinds=None also Byte). `kinds` restricts the mirror to lookups of those kinds."""
     t = F.from_monty(rec.trace)
     main = {c: t[:, c].astype(np.uint64) for c in range(t.shape[1])}
     cols, sends, receives = [], [], []
     for src, dst in ((rec.sends, receives), (rec.receives, sends)):
         for lk in src:
+            if kinds is not None and lk.kind not in kinds:
+                continue
             first = len(cols)
             for v in list(lk.values) + [lk.multiplicity]:
                 cols.append(v.apply_np({}, main))
@@ -152,5 +155,50 @@ def test_gpu_alu_shard_proof(hip_ctx, oracle, log_rows, queries, pow_bits):
     assert np.array_equal(proof, oproof)
     assert ch.as_tuple() == och.as_tuple()
     assert oracle.verify_shard(opk, recs, fri, synth.NUM_PV_ELTS, start.copy(), proof) == 0
+    for m in born:
+        m.free()
+
+
+@pytest.mark.gpu
+def test_gpu_alu_and_byte_chips_shard(hip_ctx, oracle):
+    """Five ALU chips + the real Byte chip: preprocessed table and multiplicity trace generated on the device from the
+    same events, so the byte side of the LogUp argument balances between real chips; only the instruction lookups
+    (whose sender is the Cpu chip) are mirrored. The pk holds the Byte table: four opening rounds."""
+    from ziren_amd import prover, synth
+    log_rows = 11
+    recs, evs = alu_shard(oracle, log_rows, seed=21)
+    streams = [(chip, ev) for chip, ev, _ in evs]
+    byte = chips.record_byte_chip(prep_index=0)
+    byte.trace = oracle.tracegen_byte_mults(streams)
+    byte.prep_trace = oracle.tracegen_byte_table()
+    mirrors = [mirror_chip(r, kinds=(air.KIND_INSTRUCTION,)) for r in recs]
+    all_chips = recs + [byte] + mirrors
+    fri = abi.FriConfig(1, 84, 16)
+    pv = F.to_monty(F.SplitMix64(3).uniform_field(synth.PROOF_MAX_NUM_PVS))
+    pv[synth.NUM_PV_ELTS:] = 0
+    igcs = F.to_monty(F.SplitMix64(4).uniform_field(14))
+    pc_start = F.to_monty(0x400000)
+    hp = prover.HipProver(all_chips, fri, synth.NUM_PV_ELTS, ctx=hip_ctx)
+    pk = hp.setup([hip_ctx.tracegen_byte_table()], [0], pc_start, igcs)       # device-born preprocessed table
+    opk = oracle.Pk([byte.prep_trace], [0], pc_start, igcs, 1)
+    assert np.array_equal(pk.commit, opk.commitment())
+    ch = prover.new_challenger()
+    pk.observe_into(ch)
+    start = ch.copy()
+    born = [hip_ctx.tracegen_alu(chip, ev, lh) for chip, ev, lh in evs]
+    born.append(hip_ctx.tracegen_byte_mults(streams))
+    born += [hip_ctx.upload(m.trace) for m in mirrors]
+    proof = hp.prove_shard(pk, pv, born, ch).copy()
+    och = oracle.new_challenger()
+    opk.observe_into(och)
+    oproof, _ = oracle.prove_shard(opk, all_chips, [c.trace for c in all_chips], pv, fri, synth.NUM_PV_ELTS, och)
+    assert np.array_equal(proof, oproof)
+    assert oracle.verify_shard(opk, all_chips, fri, synth.NUM_PV_ELTS, start.copy(), proof) == 0
+    # without the Byte chip's multiplicities the byte lookups do not balance: the verifier's cumulative-sum check fails
+    born[5].free()
+    born[5] = hip_ctx.tracegen_byte_mults([])
+    ch2 = start.copy()
+    bad = hp.prove_shard(pk, pv, born, ch2).copy()
+    assert oracle.verify_shard(opk, all_chips, fri, synth.NUM_PV_ELTS, start.copy(), bad) != 0
     for m in born:
         m.free()

@@ -168,3 +168,35 @@ def test_gpu_generated_trace_commits_like_an_uploaded_one(hip_ctx, oracle):
     b = prover.pcs_commit(hip_ctx, [up], 1)
     assert np.array_equal(a.root, b.root)
     a.free(); b.free(); born.free(); up.free()
+
+
+def test_byte_table_and_multiplicities_oracle(oracle):
+    t = canon(oracle.tracegen_byte_table())
+    # row (b, c) = (0x12, 0x34): b, c, and, or, xor, nor, sll, shr, shr_carry, ltu, msb, value_u16
+    assert t[0x1234].tolist() == [0x12, 0x34, 0x10, 0x36, 0x26, 0xc9, 0x20, 1, 2, 1, 0, 0x1234]
+    assert t[0xf305].tolist() == [0xf3, 5, 1, 0xf7, 0xf6, 8, 0x60, 7, 0x13, 0, 1, 0xf305]
+    streams = [(chip, E.synthetic_alu_events(chip, 500, seed=9)) for chip in sorted(E.CHIP_NAMES)]
+    m = canon(oracle.tracegen_byte_mults(streams)).astype(np.int64)
+    # lookups per event: AddSub 6 range checks; Bitwise 4 ops; Lt 2 AND + 1 LTU; ShiftLeft 4 range; ShiftRight 1 MSB + 8 ShrCarry + 16 range
+    assert m[:, 4].sum() == 500 * (6 + 4 + 16) and m[:, 5].sum() == 500 * 8 and m[:, 6].sum() == 500 and m[:, 7].sum() == 500
+    assert m[:, [0, 1, 2, 9]].sum() == 500 * 4 + 2 * 500 and m[:, 3].sum() == 0 and m[:, 8].sum() == 0
+    assert m[:, 7][np.arange(1 << 16) & 0xff != 0].sum() == 0      # MSB lookups sit in the c = 0 rows
+    extra = np.zeros((1 << 16, 10), dtype=np.uint32)
+    extra[77, 8] = 5
+    m2 = canon(oracle.tracegen_byte_mults(streams, extra)).astype(np.int64)
+    assert m2[77, 8] == 5 and (m2 - m).sum() == 5
+
+
+@pytest.mark.gpu
+def test_gpu_byte_table_and_multiplicities(hip_ctx, oracle):
+    t = hip_ctx.tracegen_byte_table()
+    assert np.array_equal(t.to_host(), oracle.tracegen_byte_table())
+    t.free()
+    for n in (0, 1, 3000, 100000):
+        streams = [(chip, E.synthetic_alu_events(chip, n + 13 * chip if n else 0, seed=n + 2)) for chip in sorted(E.CHIP_NAMES)]
+        extra = None
+        if n == 3000:
+            extra = (F.SplitMix64(n).next_u64(10 << 16) % np.uint64(7)).astype(np.uint32).reshape(1 << 16, 10)
+        m = hip_ctx.tracegen_byte_mults(streams, extra)
+        assert np.array_equal(m.to_host(), oracle.tracegen_byte_mults(streams, extra)), n
+        m.free()

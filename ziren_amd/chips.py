@@ -51,9 +51,10 @@ class RecordedChip:
 class _Rec:
     """ZKMAirBuilder surface used by the ALU chips, on top of air.AirBuilder."""
 
-    def __init__(self, width):
-        self.b = air.AirBuilder(width, 0, 0)
+    def __init__(self, width, prep_width=0):
+        self.b = air.AirBuilder(width, prep_width, 0)
         self.local = self.b.main()[0]
+        self.prep = self.b.preprocessed()[0]
         self.sends: List[air.Lookup] = []
         self.receives: List[air.Lookup] = []
 
@@ -67,6 +68,14 @@ class _Rec:
 
     def send_byte(self, opcode, a, b, c, mult):
         self.send_byte_pair(opcode, a, 0, b, c, mult)
+
+    # ByteAirBuilder::receive_byte / receive_byte_pair (builder.rs:152-186)
+    def receive_byte_pair(self, opcode, a1, a2, b, c, mult):
+        vals = [air.to_virtual_pair(v) for v in (opcode, a1, a2, b, c)]
+        self.receives.append(air.Lookup(vals, air.to_virtual_pair(mult), air.KIND_BYTE))
+
+    def receive_byte(self, opcode, a, b, c, mult):
+        self.receive_byte_pair(opcode, a, 0, b, c, mult)
 
     # WordAirBuilder::slice_range_check_u8 (air/word.rs:55-80)
     def slice_range_check_u8(self, cols, mult):
@@ -296,6 +305,22 @@ def _shift_right(r: _Rec):
                               l[BIT_RES:BIT_RES + 4], l[B:B + 4], l[C:C + 4], l[IS_REAL])
 
 
+def _byte(r: _Rec):
+    """ByteChip::eval (bytes/air.rs:20-74): one receive per ByteOpcode, in ByteOpcode::all() order."""
+    m, t = r.local, r.prep
+    B, C, AND, OR, XOR, NOR, SLL, SHR, SHR_CARRY, LTU, MSB, VALUE_U16 = range(12)  # BytePreprocessedCols
+    r.receive_byte(B_AND, t[AND], t[B], t[C], m[B_AND])
+    r.receive_byte(B_OR, t[OR], t[B], t[C], m[B_OR])
+    r.receive_byte(B_XOR, t[XOR], t[B], t[C], m[B_XOR])
+    r.receive_byte(B_SLL, t[SLL], t[B], t[C], m[B_SLL])
+    r.receive_byte(B_U8RANGE, 0, t[B], t[C], m[B_U8RANGE])
+    r.receive_byte_pair(B_SHRCARRY, t[SHR], t[SHR_CARRY], t[B], t[C], m[B_SHRCARRY])
+    r.receive_byte(B_LTU, t[LTU], t[B], t[C], m[B_LTU])
+    r.receive_byte(B_MSB, t[MSB], t[B], 0, m[B_MSB])
+    r.receive_byte(B_U16RANGE, t[VALUE_U16], 0, 0, m[B_U16RANGE])
+    r.receive_byte(B_NOR, t[NOR], t[B], t[C], m[B_NOR])
+
+
 _EVAL = {E.CHIP_ADD_SUB: _add_sub, E.CHIP_BITWISE: _bitwise, E.CHIP_LT: _lt, E.CHIP_SHIFT_LEFT: _shift_left,
          E.CHIP_SHIFT_RIGHT: _shift_right}
 # MachineAir::local_only (add_sub/mod.rs:152, bitwise/mod.rs:154, lt/mod.rs:201, sll/mod.rs:226; ShiftRight keeps the default)
@@ -319,4 +344,21 @@ def record_chip(chip: int, log_height: int) -> RecordedChip:
     program = r.b.assemble()
     return RecordedChip(name=E.CHIP_NAMES[chip], log_height=log_height, main_width=E.CHIP_WIDTH[chip],
                         log_quotient_degree=lqd, local_only=_LOCAL_ONLY[chip], sends=r.sends, receives=r.receives,
+                        program=program, lookups_blob=air.encode_lookups(r.sends, r.receives), num_constraints=int(program[2]))
+
+
+BYTE_LOG_ROWS, BYTE_MULT_COLS, BYTE_PREP_COLS = 16, 10, 12
+
+
+def record_byte_chip(prep_index: int = 0) -> RecordedChip:
+    """The Byte chip (crates/core/machine/src/bytes/): 65536 rows, 12 preprocessed columns (the table), 10 main
+    columns (multiplicities), no constraints of its own, ten byte receives."""
+    r = _Rec(BYTE_MULT_COLS, BYTE_PREP_COLS)
+    _byte(r)
+    lqd = 1
+    r.b.perm_ext_width = air.local_permutation_trace_width(len(r.sends) + len(r.receives), 1 << lqd)
+    air.eval_permutation_constraints(r.b, r.sends, r.receives, 1 << lqd, False)
+    program = r.b.assemble()
+    return RecordedChip(name="Byte", log_height=BYTE_LOG_ROWS, main_width=BYTE_MULT_COLS, prep_width=BYTE_PREP_COLS,
+                        prep_index=prep_index, log_quotient_degree=lqd, local_only=False, sends=r.sends, receives=r.receives,
                         program=program, lookups_blob=air.encode_lookups(r.sends, r.receives), num_constraints=int(program[2]))

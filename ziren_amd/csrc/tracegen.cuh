@@ -31,11 +31,12 @@ __host__ __device__ constexpr int chip_width(int chip) {
 
 constexpr int THREADS = 256;
 
-__device__ __forceinline__ uint32_t fe(uint32_t v) { return kb::to_monty(v); }       // from_canonical_u32 (any u32)
-__device__ __forceinline__ uint32_t fbool(bool b) { return b ? kb::ONE : 0u; }
+// Rows are built as canonical integers (bytes, flags, pcs); alu_rows converts each cell to Montgomery form as it
+// stores it (from_canonical_u32 of any u32), byte_mults reads the same cells to form the byte lookups.
+__device__ __forceinline__ uint32_t fbool(bool b) { return b ? 1u : 0u; }
 __device__ __forceinline__ void word(uint32_t* dst, uint32_t v) {
 #pragma unroll
-  for (int i = 0; i < 4; i++) dst[i] = fe((v >> (8 * i)) & 0xff);
+  for (int i = 0; i < 4; i++) dst[i] = (v >> (8 * i)) & 0xff;
 }
 
 template <int CHIP> __device__ __forceinline__ void event_row(const AluEvent& e, uint32_t* r);
@@ -44,8 +45,8 @@ template <int CHIP> __device__ __forceinline__ void padding_row(uint32_t* r) {}
 template <> __device__ __forceinline__ void event_row<ADD_SUB>(const AluEvent& e, uint32_t* r) {
   const bool is_add = e.opcode == ADD;
   const uint32_t op1 = is_add ? e.b : e.a, op2 = e.c;
-  r[0] = fe(e.pc);
-  r[1] = fe(e.next_pc);
+  r[0] = e.pc;
+  r[1] = e.next_pc;
   word(r + 2, op1 + op2);
   uint32_t carry = 0;
 #pragma unroll
@@ -60,8 +61,8 @@ template <> __device__ __forceinline__ void event_row<ADD_SUB>(const AluEvent& e
 }
 
 template <> __device__ __forceinline__ void event_row<BITWISE>(const AluEvent& e, uint32_t* r) {
-  r[0] = fe(e.pc);
-  r[1] = fe(e.next_pc);
+  r[0] = e.pc;
+  r[1] = e.next_pc;
   word(r + 2, e.a);
   word(r + 6, e.b);
   word(r + 10, e.c);
@@ -75,15 +76,15 @@ template <> __device__ __forceinline__ void event_row<LT>(const AluEvent& e, uin
   enum { PC = 0, NEXT_PC = 1, IS_SLT = 2, IS_SLTU = 3, A = 4, B = 8, C = 12, BYTE_FLAGS = 16, B_MASKED = 20, C_MASKED = 21,
          NOT_EQ_INV = 22, MSB_B = 23, MSB_C = 24, BIT_B = 25, BIT_C = 26, SLTU_ = 27, IS_COMP_EQ = 28, IS_SIGN_EQ = 29, CMP_BYTES = 30 };
   const bool slt = e.opcode == SLT;
-  r[PC] = fe(e.pc);
-  r[NEXT_PC] = fe(e.next_pc);
+  r[PC] = e.pc;
+  r[NEXT_PC] = e.next_pc;
   r[IS_SLT] = fbool(slt);
   r[IS_SLTU] = fbool(e.opcode == SLTU);
   word(r + A, e.a);
   word(r + B, e.b);
   word(r + C, e.c);
-  r[B_MASKED] = fe((e.b >> 24) & 0x7f);
-  r[C_MASKED] = fe((e.c >> 24) & 0x7f);
+  r[B_MASKED] = (e.b >> 24) & 0x7f;
+  r[C_MASKED] = (e.c >> 24) & 0x7f;
   // SLT compares with the sign bits masked off
   const uint32_t bc = slt ? e.b & 0x7fffffffu : e.b, cc = slt ? e.c & 0x7fffffffu : e.c;
   const uint32_t diff = bc ^ cc;
@@ -95,9 +96,9 @@ template <> __device__ __forceinline__ void event_row<LT>(const AluEvent& e, uin
   const bool sltu = top >= 0 && b_byte < c_byte;
   r[SLTU_] = fbool(sltu);
   r[IS_COMP_EQ] = fbool(diff == 0);
-  r[NOT_EQ_INV] = top >= 0 ? kb::inv(kb::sub(fe(b_byte), fe(c_byte))) : 0u;
-  r[CMP_BYTES] = fe(b_byte);
-  r[CMP_BYTES + 1] = fe(c_byte);
+  r[NOT_EQ_INV] = top >= 0 ? kb::from_monty(kb::inv(kb::sub(kb::to_monty(b_byte), kb::to_monty(c_byte)))) : 0u;
+  r[CMP_BYTES] = b_byte;
+  r[CMP_BYTES + 1] = c_byte;
   const uint32_t msb_b = e.b >> 31, msb_c = e.c >> 31;
   r[MSB_B] = fbool(msb_b);
   r[MSB_C] = fbool(msb_c);
@@ -108,8 +109,8 @@ template <> __device__ __forceinline__ void event_row<LT>(const AluEvent& e, uin
 
 template <> __device__ __forceinline__ void event_row<SHIFT_LEFT>(const AluEvent& e, uint32_t* r) {
   enum { PC = 0, NEXT_PC = 1, A = 2, B = 6, C = 10, C_LSB = 14, BY_BITS = 22, MULT = 30, RESULT = 31, CARRY = 35, BY_BYTES = 39, IS_REAL = 43 };
-  r[PC] = fe(e.pc);
-  r[NEXT_PC] = fe(e.next_pc);
+  r[PC] = e.pc;
+  r[NEXT_PC] = e.next_pc;
   word(r + A, e.a);
   word(r + B, e.b);
   word(r + C, e.c);
@@ -119,31 +120,31 @@ template <> __device__ __forceinline__ void event_row<SHIFT_LEFT>(const AluEvent
     r[C_LSB + i] = fbool((e.c >> i) & 1);
     r[BY_BITS + i] = fbool(nbits == (uint32_t)i);
   }
-  r[MULT] = fe(1u << nbits);
+  r[MULT] = (1u << nbits);
   // b * 2^nbits byte by byte: limb i keeps 8 bits, the rest carries into limb i+1
   uint32_t carry = 0;
 #pragma unroll
   for (int i = 0; i < 4; i++) {
     const uint32_t v = (((e.b >> (8 * i)) & 0xff) << nbits) + carry;
     carry = v >> 8;
-    r[RESULT + i] = fe(v & 0xff);
-    r[CARRY + i] = fe(carry);
+    r[RESULT + i] = (v & 0xff);
+    r[CARRY + i] = carry;
   }
 #pragma unroll
   for (int i = 0; i < 4; i++) r[BY_BYTES + i] = fbool(nbytes == (uint32_t)i);
-  r[IS_REAL] = kb::ONE;
+  r[IS_REAL] = 1;
 }
 template <> __device__ __forceinline__ void padding_row<SHIFT_LEFT>(uint32_t* r) {
-  r[22] = kb::ONE;  // shift_by_n_bits[0]
-  r[30] = kb::ONE;  // bit_shift_multiplier
-  r[39] = kb::ONE;  // shift_by_n_bytes[0]
+  r[22] = 1;  // shift_by_n_bits[0]
+  r[30] = 1;  // bit_shift_multiplier
+  r[39] = 1;  // shift_by_n_bytes[0]
 }
 
 template <> __device__ __forceinline__ void event_row<SHIFT_RIGHT>(const AluEvent& e, uint32_t* r) {
   enum { PC = 0, NEXT_PC = 1, B = 2, C = 6, BY_BITS = 10, BY_BYTES = 18, BYTE_RES = 22, BIT_RES = 30, SHR_CARRY = 38, SHR_SHIFTED = 46,
          B_MSB = 54, C_LSB = 55, IS_SRL = 63, IS_ROR = 64, IS_SRA = 65, IS_REAL = 66 };
-  r[PC] = fe(e.pc);
-  r[NEXT_PC] = fe(e.next_pc);
+  r[PC] = e.pc;
+  r[NEXT_PC] = e.next_pc;
   word(r + B, e.b);
   word(r + C, e.c);
   const uint32_t nbits = e.c & 7, nbytes = (e.c & 31) >> 3;
@@ -162,21 +163,21 @@ template <> __device__ __forceinline__ void event_row<SHIFT_RIGHT>(const AluEven
   for (int i = 7; i >= 0; i--) {
     const uint32_t byte = (uint32_t)(bytes >> (8 * i)) & 0xff;
     const uint32_t shifted = byte >> nbits, carry = byte & ((1u << nbits) - 1);  // bytes/utils.rs:2-11 (shr_carry)
-    r[BYTE_RES + i] = fe(byte);
-    r[SHR_CARRY + i] = fe(carry);
-    r[SHR_SHIFTED + i] = fe(shifted);
-    r[BIT_RES + i] = fe((shifted + (last_carry << (8 - nbits))) & 0xff);
+    r[BYTE_RES + i] = byte;
+    r[SHR_CARRY + i] = carry;
+    r[SHR_SHIFTED + i] = shifted;
+    r[BIT_RES + i] = (shifted + (last_carry << (8 - nbits))) & 0xff;
     last_carry = carry;
   }
   r[B_MSB] = fbool(e.b >> 31);
   r[IS_SRL] = fbool(e.opcode == SRL);
   r[IS_ROR] = fbool(e.opcode == ROR);
   r[IS_SRA] = fbool(e.opcode == SRA);
-  r[IS_REAL] = kb::ONE;
+  r[IS_REAL] = 1;
 }
 template <> __device__ __forceinline__ void padding_row<SHIFT_RIGHT>(uint32_t* r) {
-  r[10] = kb::ONE;  // shift_by_n_bits[0]
-  r[18] = kb::ONE;  // shift_by_n_bytes[0]
+  r[10] = 1;  // shift_by_n_bits[0]
+  r[18] = 1;  // shift_by_n_bytes[0]
 }
 
 // events: n_events records of seven words; out: column-major, `height` rows. grid = height / THREADS.
@@ -197,7 +198,93 @@ __global__ __launch_bounds__(THREADS) void alu_rows(const uint32_t* __restrict__
     padding_row<CHIP>(r);
   }
 #pragma unroll
-  for (int c = 0; c < W; c++) out[(size_t)c * height + row] = r[c];
+  for (int c = 0; c < W; c++) out[(size_t)c * height + row] = kb::to_monty(r[c]);
+}
+
+// ---- byte lookups: the ALU chips' generate_dependencies + ByteChip::generate_trace ---------------------------------
+// ByteOpcode, crates/core/executor/src/opcode.rs:195-216
+enum : uint32_t { B_AND = 0, B_OR = 1, B_XOR = 2, B_SLL = 3, B_U8RANGE = 4, B_SHRCARRY = 5, B_LTU = 6, B_MSB = 7, B_U16RANGE = 8, B_NOR = 9 };
+constexpr int NUM_BYTE_OPS = 10, BYTE_ROWS = 1 << 16, BYTE_PREP_COLS = 12;
+
+// counts[op][b << 8 | c] += 1 (bytes/trace.rs:54-66; U16Range is indexed by its value and is not used by these chips)
+__device__ __forceinline__ void lookup(uint32_t* counts, uint32_t op, uint32_t b, uint32_t c) {
+  atomicAdd(counts + op * BYTE_ROWS + ((b & 0xff) << 8 | (c & 0xff)), 1u);
+}
+// ByteRecord::add_u8_range_checks (crates/core/executor/src/events/byte.rs:72-82): bytes in pairs
+__device__ __forceinline__ void range_checks(uint32_t* counts, const uint32_t* bytes, int n) {
+  for (int i = 0; i + 1 < n; i += 2) lookup(counts, B_U8RANGE, bytes[i], bytes[i + 1]);
+  if (n & 1) lookup(counts, B_U8RANGE, bytes[n - 1], 0);
+}
+
+// The byte lookups each chip's event_to_row records (= the `send_byte`s of its AIR with multiplicity 1), read off
+// the row: add_sub/mod.rs:176 -> operations/add.rs:48-53; bitwise/mod.rs:183-193; lt/mod.rs:227-241,268-274;
+// sll/mod.rs:276-279; sr/mod.rs:258-265,309-316,334-337.
+template <int CHIP> __device__ __forceinline__ void row_lookups(const uint32_t* r, uint32_t opcode, uint32_t* counts);
+template <> __device__ __forceinline__ void row_lookups<ADD_SUB>(const uint32_t* r, uint32_t, uint32_t* counts) {
+  range_checks(counts, r + 9, 4);   // operand_1
+  range_checks(counts, r + 13, 4);  // operand_2
+  range_checks(counts, r + 2, 4);   // value
+}
+template <> __device__ __forceinline__ void row_lookups<BITWISE>(const uint32_t* r, uint32_t opcode, uint32_t* counts) {
+  const uint32_t op = opcode == AND ? B_AND : opcode == OR ? B_OR : opcode == XOR ? B_XOR : B_NOR;
+#pragma unroll
+  for (int i = 0; i < 4; i++) lookup(counts, op, r[6 + i], r[10 + i]);
+}
+template <> __device__ __forceinline__ void row_lookups<LT>(const uint32_t* r, uint32_t, uint32_t* counts) {
+  lookup(counts, B_AND, r[8 + 3], 0x7f);
+  lookup(counts, B_AND, r[12 + 3], 0x7f);
+  lookup(counts, B_LTU, r[30], r[31]);
+}
+template <> __device__ __forceinline__ void row_lookups<SHIFT_LEFT>(const uint32_t* r, uint32_t, uint32_t* counts) {
+  range_checks(counts, r + 31, 4);  // bit_shift_result
+  range_checks(counts, r + 35, 4);  // bit_shift_result_carry
+}
+template <> __device__ __forceinline__ void row_lookups<SHIFT_RIGHT>(const uint32_t* r, uint32_t, uint32_t* counts) {
+  lookup(counts, B_MSB, r[2 + 3], 0);
+  uint32_t nbits = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) nbits += r[10 + i] * i;   // shift_by_n_bits is one-hot
+#pragma unroll
+  for (int i = 7; i >= 0; i--) lookup(counts, B_SHRCARRY, r[22 + i], nbits);
+  range_checks(counts, r + 22, 8);
+  range_checks(counts, r + 30, 8);
+  range_checks(counts, r + 38, 8);
+  range_checks(counts, r + 46, 8);
+}
+
+// counts: NUM_BYTE_OPS columns of BYTE_ROWS plain u32 counters (column-major, zeroed by the caller)
+template <int CHIP>
+__global__ __launch_bounds__(THREADS) void byte_mults(const uint32_t* __restrict__ events, size_t n_events, uint32_t* counts) {
+  constexpr int W = chip_width(CHIP);
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_events) return;
+  const uint32_t* p = events + i * 7;
+  AluEvent e{p[0], p[1], p[2] & 0xff, p[3], p[4], p[5], p[6]};
+  uint32_t r[W];
+#pragma unroll
+  for (int c = 0; c < W; c++) r[c] = 0;
+  event_row<CHIP>(e, r);
+  row_lookups<CHIP>(r, e.opcode, counts);
+}
+
+// counts += extra (plain counters from the chips whose dependencies stay on the host), then to Montgomery form in place
+__global__ void byte_mults_finish(uint32_t* counts, const uint32_t* __restrict__ extra_row_major, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint32_t v = counts[i];
+  if (extra_row_major) v += extra_row_major[(i & (BYTE_ROWS - 1)) * NUM_BYTE_OPS + (i >> 16)];
+  counts[i] = kb::to_monty(v);
+}
+
+// ByteChip::trace() (bytes/mod.rs:31-104): row (b << 8 | c) of the preprocessed table, column-major, Montgomery
+__global__ void byte_table(uint32_t* out) {
+  const uint32_t row = blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= BYTE_ROWS) return;
+  const uint32_t b = row >> 8, c = row & 0xff, k = c & 7;
+  const uint32_t v[BYTE_PREP_COLS] = {b, c, b & c, b | c, b ^ c, ~(b | c) & 0xff, (b << k) & 0xff, b >> k, b & ((1u << k) - 1),
+                                      (uint32_t)(b < c), b >> 7, (b << 8) + c};
+#pragma unroll
+  for (int j = 0; j < BYTE_PREP_COLS; j++) out[(size_t)j * BYTE_ROWS + row] = kb::to_monty(v[j]);
 }
 
 }  // namespace tracegen

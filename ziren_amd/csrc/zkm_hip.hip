@@ -1060,6 +1060,13 @@ static void launch_alu_rows(zkm_ctx* ctx, const uint32_t* d_events, size_t n_eve
           dim3(div_up(height, tracegen::THREADS)), dim3(tracegen::THREADS), 0, d_events, n_events, height, out);
 }
 
+template <int CHIP>
+static void launch_byte_mults(zkm_ctx* ctx, const uint32_t* d_events, size_t n_events, uint32_t* counts) {
+  if (n_events == 0) return;
+  KLAUNCH(ctx, "tracegen_byte_mults", 28.0 * n_events, tracegen::byte_mults<CHIP>, dim3(div_up(n_events, tracegen::THREADS)),
+          dim3(tracegen::THREADS), 0, d_events, n_events, counts);
+}
+
 #define API_BEGIN try {
 #define API_END                              \
   }                                          \
@@ -1499,6 +1506,79 @@ int zkm_tracegen_alu(zkm_ctx* ctx, int chip, const zkm_alu_event* events, size_t
     throw;
   }
   ctx->release(d_events);
+  *out = m;
+  API_END
+}
+
+int zkm_tracegen_byte_table(zkm_ctx* ctx, zkm_matrix** out) {
+  API_BEGIN
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIP_CHECK(hipSetDevice(ctx->device));
+  ctx->begin_call();
+  zkm_matrix* m = new zkm_matrix();
+  m->h = tracegen::BYTE_ROWS; m->w = tracegen::BYTE_PREP_COLS;
+  try {
+    m->d = ctx->alloc_n<uint32_t>(m->h * m->w);
+    hipLaunchKernelGGL(tracegen::byte_table, dim3(tracegen::BYTE_ROWS / 256), dim3(256), 0, ctx->stream, m->d);
+    LAUNCH_CHECK();
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  } catch (...) {
+    if (m->d) ctx->release(m->d);
+    delete m;
+    throw;
+  }
+  *out = m;
+  API_END
+}
+
+int zkm_tracegen_byte_mults(zkm_ctx* ctx, size_t n_streams, const int* chips, const zkm_alu_event* const* events,
+                            const size_t* n_events, const uint32_t* extra_counts, zkm_matrix** out) {
+  API_BEGIN
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIP_CHECK(hipSetDevice(ctx->device));
+  for (size_t s = 0; s < n_streams; s++) {
+    if (chips[s] < 0 || chips[s] >= tracegen::NUM_CHIPS) throw std::runtime_error("zkm_tracegen_byte_mults: unknown chip");
+    if (n_events[s] && !events[s]) throw std::runtime_error("zkm_tracegen_byte_mults: null events");
+  }
+  ctx->begin_timing();
+  const size_t cells = (size_t)tracegen::BYTE_ROWS * tracegen::NUM_BYTE_OPS;
+  zkm_matrix* m = new zkm_matrix();
+  m->h = tracegen::BYTE_ROWS; m->w = tracegen::NUM_BYTE_OPS;
+  std::vector<void*> scratch;
+  try {
+    m->d = ctx->alloc_n<uint32_t>(cells);
+    HIP_CHECK(hipMemsetAsync(m->d, 0, cells * 4, ctx->stream));
+    for (size_t s = 0; s < n_streams; s++) {
+      if (n_events[s] == 0) continue;
+      uint32_t* d_ev = (uint32_t*)ctx->alloc(n_events[s] * 28);
+      scratch.push_back(d_ev);
+      HIP_CHECK(hipMemcpyAsync(d_ev, events[s], n_events[s] * 28, hipMemcpyHostToDevice, ctx->stream));
+      switch (chips[s]) {
+        case tracegen::ADD_SUB: launch_byte_mults<tracegen::ADD_SUB>(ctx, d_ev, n_events[s], m->d); break;
+        case tracegen::BITWISE: launch_byte_mults<tracegen::BITWISE>(ctx, d_ev, n_events[s], m->d); break;
+        case tracegen::LT: launch_byte_mults<tracegen::LT>(ctx, d_ev, n_events[s], m->d); break;
+        case tracegen::SHIFT_LEFT: launch_byte_mults<tracegen::SHIFT_LEFT>(ctx, d_ev, n_events[s], m->d); break;
+        case tracegen::SHIFT_RIGHT: launch_byte_mults<tracegen::SHIFT_RIGHT>(ctx, d_ev, n_events[s], m->d); break;
+      }
+    }
+    uint32_t* d_extra = nullptr;
+    if (extra_counts) {
+      d_extra = (uint32_t*)ctx->alloc(cells * 4);
+      scratch.push_back(d_extra);
+      HIP_CHECK(hipMemcpyAsync(d_extra, extra_counts, cells * 4, hipMemcpyHostToDevice, ctx->stream));
+    }
+    hipLaunchKernelGGL(tracegen::byte_mults_finish, dim3(div_up(cells, 256)), dim3(256), 0, ctx->stream, m->d,
+                       (const uint32_t*)d_extra, cells);
+    LAUNCH_CHECK();
+    ctx->mark("byte multiplicities");
+    ctx->end_timing(false);
+  } catch (...) {
+    for (void* p : scratch) ctx->release(p);
+    if (m->d) ctx->release(m->d);
+    delete m;
+    throw;
+  }
+  for (void* p : scratch) ctx->release(p);
   *out = m;
   API_END
 }

@@ -65,6 +65,25 @@ class Context:
         L = lib.load()
         return DeviceMatrix(self, h, int(L.zkm_matrix_height(h)), int(L.zkm_matrix_width(h)))
 
+    def tracegen_byte_table(self) -> DeviceMatrix:
+        """`ByteChip::trace()`: the Byte chip's 65536 x 12 preprocessed table, generated on the device."""
+        h = C.c_void_p()
+        lib.check(lib.load().zkm_tracegen_byte_table(self.h, C.byref(h)))
+        return DeviceMatrix(self, h, 1 << 16, 12)
+
+    def tracegen_byte_mults(self, streams, extra_counts=None) -> DeviceMatrix:
+        """`ByteChip::generate_trace` over the byte lookups of ALU event streams [(chip, events)] (+ optional host counts)."""
+        from . import events as _ev
+        evs = [np.ascontiguousarray(ev, dtype=_ev.ALU_EVENT) for _, ev in streams]
+        chips = (C.c_int * len(streams))(*[c for c, _ in streams])
+        ptrs = (C.c_void_p * len(streams))(*[ev.ctypes.data if len(ev) else None for ev in evs])
+        ns = (C.c_size_t * len(streams))(*[len(ev) for ev in evs])
+        ex = np.ascontiguousarray(extra_counts, dtype=np.uint32) if extra_counts is not None else None
+        h = C.c_void_p()
+        lib.check(lib.load().zkm_tracegen_byte_mults(self.h, C.c_size_t(len(streams)), chips, ptrs, ns,
+                                                     abi.as_u32p(ex) if ex is not None else None, C.byref(h)))
+        return DeviceMatrix(self, h, 1 << 16, 10)
+
     def host_alloc(self, shape) -> np.ndarray:
         """uint32 array in page-locked host memory (zkm_host_alloc); free with host_free."""
         n = int(np.prod(shape))
@@ -233,7 +252,7 @@ class HipProver:
 
     # fn setup / pk_to_device (prover.rs:54-66)
     def setup(self, prep_traces: Sequence[np.ndarray], prep_local_only, pc_start, initial_global_cumulative_sum) -> ProvingKey:
-        prep = [self.ctx.upload(t) for t in prep_traces]
+        prep = [t if isinstance(t, DeviceMatrix) else self.ctx.upload(t) for t in prep_traces]  # device-born tables pass through
         lo = np.ascontiguousarray(prep_local_only if len(prep) else [0], dtype=np.uint32)
         ig = np.ascontiguousarray(initial_global_cumulative_sum, dtype=np.uint32)
         h = C.c_void_p()
