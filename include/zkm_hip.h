@@ -236,25 +236,30 @@ enum zkm_alu_chip {
 };
 /* size_of::<Cols<u8>>() of the chip (NUM_*_COLS); 0 for an unknown chip. */
 size_t zkm_tracegen_alu_width(int chip);
+/* `record.byte_lookups` on the device (crates/core/executor/src/record.rs:62: the HashMap<ByteLookupEvent, usize> that
+ * every chip's generate_dependencies fills and ByteChip::generate_trace reads): one counter per (ByteOpcode, b, c). */
+typedef struct zkm_byte_lookups zkm_byte_lookups;
+int zkm_byte_lookups_create(zkm_ctx* ctx, zkm_byte_lookups** out);
+void zkm_byte_lookups_free(zkm_ctx* ctx, zkm_byte_lookups* blu);
 /* MachineAir::generate_trace for one of the chips above, on the device: `events` (host, n_events records) are
  * copied to HBM and expanded to the padded main trace, returned as a device-resident matrix that
  * zkm_commit / zkm_prove_shard take directly. fixed_log2_rows is the shape's `fixed_log2_rows` or -1
  * for next_power_of_two(n_events) with the reference's minimum of 16 rows; rows past the events are the
- * chip's padding rows. Fails if n_events exceeds the fixed height (the reference panics). */
+ * chip's padding rows. Fails if n_events exceeds the fixed height (the reference panics).
+ * If `blu` is not NULL the same pass also performs the chip's generate_dependencies: the byte lookups each
+ * event's row records (the `blu` argument of the reference's event_to_row) are counted into it. */
 int zkm_tracegen_alu(zkm_ctx* ctx, int chip, const zkm_alu_event* events, size_t n_events,
-                     int fixed_log2_rows, zkm_matrix** out);
+                     int fixed_log2_rows, zkm_byte_lookups* blu, zkm_matrix** out);
 
 /* ByteChip::trace() — the Byte chip's preprocessed table, 65536 x 12, row (b << 8 | c)
  * (crates/core/machine/src/bytes/mod.rs:31-104, columns bytes/columns.rs:12-46), generated on the device. */
 int zkm_tracegen_byte_table(zkm_ctx* ctx, zkm_matrix** out);
-/* ByteChip::generate_trace (bytes/trace.rs:46-66) over the byte lookups that the given ALU event streams record in
- * their generate_dependencies (the `blu` of each chip's event_to_row): the 65536 x 10 multiplicity trace, one column
- * per ByteOpcode. chips[s] is a zkm_alu_chip, events[s] its n_events[s] host events. extra_counts (may be NULL) is a
- * 65536 x 10 row-major array of plain counts — `record.byte_lookups` of the chips whose dependencies stay on the
- * host — added before the conversion to field elements. */
-int zkm_tracegen_byte_mults(zkm_ctx* ctx, size_t n_streams, const int* chips,
-                            const zkm_alu_event* const* events, const size_t* n_events,
-                            const uint32_t* extra_counts, zkm_matrix** out);
+/* ByteChip::generate_trace (bytes/trace.rs:46-66): the 65536 x 10 multiplicity trace, one column per ByteOpcode, from
+ * the lookups counted in `blu`. extra_counts (may be NULL) is a 65536 x 10 row-major array of plain counts —
+ * `record.byte_lookups` of the chips whose dependencies stay on the host — added before the conversion to field
+ * elements. `blu` is left unchanged. */
+int zkm_tracegen_byte_mults(zkm_ctx* ctx, const zkm_byte_lookups* blu, const uint32_t* extra_counts,
+                            zkm_matrix** out);
 
 /* ---- fine-grained entry points (parity tests, micro-benchmarks) ------------------------- */
 /* Poseidon2 width-16 permutation on n states (n x 16 words, in place), on the GPU.

@@ -185,8 +185,9 @@ def test_gpu_alu_and_byte_chips_shard(hip_ctx, oracle):
     ch = prover.new_challenger()
     pk.observe_into(ch)
     start = ch.copy()
-    born = [hip_ctx.tracegen_alu(chip, ev, lh) for chip, ev, lh in evs]
-    born.append(hip_ctx.tracegen_byte_mults(streams))
+    blu = hip_ctx.byte_lookups()
+    born = [hip_ctx.tracegen_alu(chip, ev, lh, blu) for chip, ev, lh in evs]   # traces + byte lookups in one pass
+    born.append(hip_ctx.tracegen_byte_mults(blu))
     born += [hip_ctx.upload(m.trace) for m in mirrors]
     proof = hp.prove_shard(pk, pv, born, ch).copy()
     och = oracle.new_challenger()
@@ -196,7 +197,8 @@ def test_gpu_alu_and_byte_chips_shard(hip_ctx, oracle):
     assert oracle.verify_shard(opk, all_chips, fri, synth.NUM_PV_ELTS, start.copy(), proof) == 0
     # without the Byte chip's multiplicities the byte lookups do not balance: the verifier's cumulative-sum check fails
     born[5].free()
-    born[5] = hip_ctx.tracegen_byte_mults([])
+    empty = hip_ctx.byte_lookups()
+    born[5] = hip_ctx.tracegen_byte_mults(empty)
     ch2 = start.copy()
     bad = hp.prove_shard(pk, pv, born, ch2).copy()
     assert oracle.verify_shard(opk, all_chips, fri, synth.NUM_PV_ELTS, start.copy(), bad) != 0

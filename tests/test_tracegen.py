@@ -197,6 +197,13 @@ def test_gpu_byte_table_and_multiplicities(hip_ctx, oracle):
         extra = None
         if n == 3000:
             extra = (F.SplitMix64(n).next_u64(10 << 16) % np.uint64(7)).astype(np.uint32).reshape(1 << 16, 10)
-        m = hip_ctx.tracegen_byte_mults(streams, extra)
+        blu = hip_ctx.byte_lookups()
+        for chip, ev in streams:   # generate_trace and generate_dependencies in one pass per chip
+            t = hip_ctx.tracegen_alu(chip, ev, -1, blu)
+            assert np.array_equal(t.to_host(), oracle.tracegen_alu(chip, ev)), (n, chip)
+            t.free()
+        m = hip_ctx.tracegen_byte_mults(blu, extra)
         assert np.array_equal(m.to_host(), oracle.tracegen_byte_mults(streams, extra)), n
-        m.free()
+        m2 = hip_ctx.tracegen_byte_mults(blu)   # the accumulator is left unchanged
+        assert np.array_equal(m2.to_host(), oracle.tracegen_byte_mults(streams)), n
+        m.free(); m2.free(); blu.free()

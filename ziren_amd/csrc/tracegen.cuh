@@ -180,38 +180,41 @@ template <> __device__ __forceinline__ void padding_row<SHIFT_RIGHT>(uint32_t* r
   r[18] = 1;  // shift_by_n_bytes[0]
 }
 
-// events: n_events records of seven words; out: column-major, `height` rows. grid = height / THREADS.
-template <int CHIP>
-__global__ __launch_bounds__(THREADS) void alu_rows(const uint32_t* __restrict__ events, size_t n_events, size_t height,
-                                                    uint32_t* __restrict__ out) {
-  constexpr int W = chip_width(CHIP);
-  const size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (row >= height) return;
-  uint32_t r[W];
-#pragma unroll
-  for (int c = 0; c < W; c++) r[c] = 0;
-  if (row < n_events) {
-    const uint32_t* p = events + row * 7;
-    AluEvent e{p[0], p[1], p[2] & 0xff, p[3], p[4], p[5], p[6]};
-    event_row<CHIP>(e, r);
-  } else {
-    padding_row<CHIP>(r);
-  }
-#pragma unroll
-  for (int c = 0; c < W; c++) out[(size_t)c * height + row] = kb::to_monty(r[c]);
-}
-
-// ---- byte lookups: the ALU chips' generate_dependencies + ByteChip::generate_trace ---------------------------------
+// ---- byte lookups: the ALU chips' generate_dependencies, ByteChip::generate_trace and ByteChip::trace -----------------
 // ByteOpcode, crates/core/executor/src/opcode.rs:195-216
 enum : uint32_t { B_AND = 0, B_OR = 1, B_XOR = 2, B_SLL = 3, B_U8RANGE = 4, B_SHRCARRY = 5, B_LTU = 6, B_MSB = 7, B_U16RANGE = 8, B_NOR = 9 };
 constexpr int NUM_BYTE_OPS = 10, BYTE_ROWS = 1 << 16, BYTE_PREP_COLS = 12;
 
-// counts[op][b << 8 | c] += 1 (bytes/trace.rs:54-66; U16Range is indexed by its value and is not used by these chips)
-__device__ __forceinline__ void lookup(uint32_t* counts, uint32_t op, uint32_t b, uint32_t c) {
-  atomicAdd(counts + op * BYTE_ROWS + ((b & 0xff) << 8 | (c & 0xff)), 1u);
+// counts[op][b << 8 | c] += 1 (bytes/trace.rs:54-66; U16Range is indexed by its value and is not used by these chips).
+// Real lookup streams are heavily skewed (range checks of zero upper bytes, carries of 0 / 1, sign-extension bytes):
+// plain global atomics serialise on the hot counters (164 ms for 2^21 ShiftRight events). Each block therefore first
+// combines its lookups in an LDS hash table (open addressing, key = counter index, claimed with atomicCAS) and then
+// issues one global atomicAdd per distinct counter it holds — a hot counter costs one global atomic per block (2048
+// rows); when the table is crowded (many distinct counters, so no hot spot) a lookup goes to its counter directly.
+constexpr uint32_t HASH_EMPTY = 0xffffffffu;
+struct LookupSink {
+  uint32_t* keys;    // LDS, HASH_SLOTS entries
+  uint32_t* vals;
+  uint32_t mask;     // HASH_SLOTS - 1
+  uint32_t* counts;  // global [op][row]
+};
+__device__ __forceinline__ void lookup(const LookupSink& k, uint32_t op, uint32_t b, uint32_t c) {
+  const uint32_t idx = op * BYTE_ROWS + ((b & 0xff) << 8 | (c & 0xff));
+  uint32_t slot = (idx * 2654435761u >> 12) & k.mask;
+  for (int probe = 0; probe < 8; probe++) {
+    const uint32_t prev = atomicCAS(k.keys + slot, HASH_EMPTY, idx);
+    if (prev == HASH_EMPTY || prev == idx) {
+      atomicAdd(k.vals + slot, 1u);
+      return;
+    }
+    slot = (slot + 1) & k.mask;
+  }
+  atomicAdd(k.counts + idx, 1u);  // table crowded (many distinct counters, i.e. no hot spot): count directly
 }
+constexpr int HASH_SLOTS = 8192;   // 64 KiB of LDS: two blocks per CU
+constexpr int TILES_PER_BLOCK = 8; // a block walks 8 x THREADS rows with one table: hot counters cost one global atomic per 2048 rows
 // ByteRecord::add_u8_range_checks (crates/core/executor/src/events/byte.rs:72-82): bytes in pairs
-__device__ __forceinline__ void range_checks(uint32_t* counts, const uint32_t* bytes, int n) {
+__device__ __forceinline__ void range_checks(const LookupSink& counts, const uint32_t* bytes, int n) {
   for (int i = 0; i + 1 < n; i += 2) lookup(counts, B_U8RANGE, bytes[i], bytes[i + 1]);
   if (n & 1) lookup(counts, B_U8RANGE, bytes[n - 1], 0);
 }
@@ -219,27 +222,27 @@ __device__ __forceinline__ void range_checks(uint32_t* counts, const uint32_t* b
 // The byte lookups each chip's event_to_row records (= the `send_byte`s of its AIR with multiplicity 1), read off
 // the row: add_sub/mod.rs:176 -> operations/add.rs:48-53; bitwise/mod.rs:183-193; lt/mod.rs:227-241,268-274;
 // sll/mod.rs:276-279; sr/mod.rs:258-265,309-316,334-337.
-template <int CHIP> __device__ __forceinline__ void row_lookups(const uint32_t* r, uint32_t opcode, uint32_t* counts);
-template <> __device__ __forceinline__ void row_lookups<ADD_SUB>(const uint32_t* r, uint32_t, uint32_t* counts) {
+template <int CHIP> __device__ __forceinline__ void row_lookups(const uint32_t* r, uint32_t opcode, const LookupSink& counts);
+template <> __device__ __forceinline__ void row_lookups<ADD_SUB>(const uint32_t* r, uint32_t, const LookupSink& counts) {
   range_checks(counts, r + 9, 4);   // operand_1
   range_checks(counts, r + 13, 4);  // operand_2
   range_checks(counts, r + 2, 4);   // value
 }
-template <> __device__ __forceinline__ void row_lookups<BITWISE>(const uint32_t* r, uint32_t opcode, uint32_t* counts) {
+template <> __device__ __forceinline__ void row_lookups<BITWISE>(const uint32_t* r, uint32_t opcode, const LookupSink& counts) {
   const uint32_t op = opcode == AND ? B_AND : opcode == OR ? B_OR : opcode == XOR ? B_XOR : B_NOR;
 #pragma unroll
   for (int i = 0; i < 4; i++) lookup(counts, op, r[6 + i], r[10 + i]);
 }
-template <> __device__ __forceinline__ void row_lookups<LT>(const uint32_t* r, uint32_t, uint32_t* counts) {
+template <> __device__ __forceinline__ void row_lookups<LT>(const uint32_t* r, uint32_t, const LookupSink& counts) {
   lookup(counts, B_AND, r[8 + 3], 0x7f);
   lookup(counts, B_AND, r[12 + 3], 0x7f);
   lookup(counts, B_LTU, r[30], r[31]);
 }
-template <> __device__ __forceinline__ void row_lookups<SHIFT_LEFT>(const uint32_t* r, uint32_t, uint32_t* counts) {
+template <> __device__ __forceinline__ void row_lookups<SHIFT_LEFT>(const uint32_t* r, uint32_t, const LookupSink& counts) {
   range_checks(counts, r + 31, 4);  // bit_shift_result
   range_checks(counts, r + 35, 4);  // bit_shift_result_carry
 }
-template <> __device__ __forceinline__ void row_lookups<SHIFT_RIGHT>(const uint32_t* r, uint32_t, uint32_t* counts) {
+template <> __device__ __forceinline__ void row_lookups<SHIFT_RIGHT>(const uint32_t* r, uint32_t, const LookupSink& counts) {
   lookup(counts, B_MSB, r[2 + 3], 0);
   uint32_t nbits = 0;
 #pragma unroll
@@ -252,28 +255,56 @@ template <> __device__ __forceinline__ void row_lookups<SHIFT_RIGHT>(const uint3
   range_checks(counts, r + 46, 8);
 }
 
-// counts: NUM_BYTE_OPS columns of BYTE_ROWS plain u32 counters (column-major, zeroed by the caller)
+// events: n_events records of seven words; out: column-major, `height` rows; grid = height / (tiles * THREADS), with
+// tiles = 1 for the plain row writer (most blocks in flight) and TILES_PER_BLOCK when counting.
+// counts (may be null): NUM_BYTE_OPS columns of BYTE_ROWS plain u32 counters; the byte lookups of every event row are
+// added to them — the chip's generate_dependencies in the same pass that builds its trace.
 template <int CHIP>
-__global__ __launch_bounds__(THREADS) void byte_mults(const uint32_t* __restrict__ events, size_t n_events, uint32_t* counts) {
+__global__ __launch_bounds__(THREADS) void alu_rows(const uint32_t* __restrict__ events, size_t n_events, size_t height,
+                                                    uint32_t* __restrict__ out, uint32_t* counts, int tiles) {
   constexpr int W = chip_width(CHIP);
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_events) return;
-  const uint32_t* p = events + i * 7;
-  AluEvent e{p[0], p[1], p[2] & 0xff, p[3], p[4], p[5], p[6]};
-  uint32_t r[W];
+  extern __shared__ uint32_t hash_lds[];  // 2 * HASH_SLOTS words when counting, nothing otherwise (keeps the pure row writer at full occupancy)
+  uint32_t* hkeys = hash_lds;
+  uint32_t* hvals = hash_lds + HASH_SLOTS;
+  const size_t row0 = (size_t)blockIdx.x * tiles * THREADS;
+  const bool count = counts != nullptr && row0 < n_events;  // block-uniform
+  if (count) {
+    for (int i = threadIdx.x; i < HASH_SLOTS; i += blockDim.x) { hkeys[i] = HASH_EMPTY; hvals[i] = 0; }
+    __syncthreads();
+  }
+  for (int t = 0; t < tiles; t++) {
+    const size_t row = row0 + (size_t)t * THREADS + threadIdx.x;
+    if (row >= height) break;
+    uint32_t r[W];
 #pragma unroll
-  for (int c = 0; c < W; c++) r[c] = 0;
-  event_row<CHIP>(e, r);
-  row_lookups<CHIP>(r, e.opcode, counts);
+    for (int c = 0; c < W; c++) r[c] = 0;
+    if (row < n_events) {
+      const uint32_t* p = events + row * 7;
+      AluEvent e{p[0], p[1], p[2] & 0xff, p[3], p[4], p[5], p[6]};
+      event_row<CHIP>(e, r);
+      if (count) row_lookups<CHIP>(r, e.opcode, LookupSink{hkeys, hvals, HASH_SLOTS - 1, counts});
+    } else {
+      padding_row<CHIP>(r);
+    }
+#pragma unroll
+    for (int c = 0; c < W; c++) out[(size_t)c * height + row] = kb::to_monty(r[c]);
+  }
+  if (count) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < HASH_SLOTS; i += blockDim.x)
+      if (hkeys[i] != HASH_EMPTY) atomicAdd(counts + hkeys[i], hvals[i]);
+  }
 }
 
-// counts += extra (plain counters from the chips whose dependencies stay on the host), then to Montgomery form in place
-__global__ void byte_mults_finish(uint32_t* counts, const uint32_t* __restrict__ extra_row_major, size_t n) {
+// ByteChip::generate_trace: out = to_field(counts + extra); extra (may be null) holds the row-major plain counts of the
+// chips whose dependencies stay on the host
+__global__ void byte_mults_finish(const uint32_t* __restrict__ counts, const uint32_t* __restrict__ extra_row_major,
+                                  uint32_t* __restrict__ out, size_t n) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   uint32_t v = counts[i];
   if (extra_row_major) v += extra_row_major[(i & (BYTE_ROWS - 1)) * NUM_BYTE_OPS + (i >> 16)];
-  counts[i] = kb::to_monty(v);
+  out[i] = kb::to_monty(v);
 }
 
 // ByteChip::trace() (bytes/mod.rs:31-104): row (b << 8 | c) of the preprocessed table, column-major, Montgomery

@@ -262,6 +262,10 @@ struct zkm_matrix {
   bool owned = true;
 };
 
+struct zkm_byte_lookups {
+  uint32_t* counts = nullptr;  // [NUM_BYTE_OPS][BYTE_ROWS] plain counters: record.byte_lookups on the device
+};
+
 struct Tree {
   uint32_t* digests = nullptr;          // all layers, 8 words per digest
   std::vector<size_t> layer_off;        // in digests
@@ -1055,16 +1059,11 @@ static void open_impl(zkm_ctx* ctx, const zkm_pk* pk, zkm_main_data* md, const z
 
 // ---- C ABI ---------------------------------------------------------------------------------------
 template <int CHIP>
-static void launch_alu_rows(zkm_ctx* ctx, const uint32_t* d_events, size_t n_events, size_t height, uint32_t* out) {
+static void launch_alu_rows(zkm_ctx* ctx, const uint32_t* d_events, size_t n_events, size_t height, uint32_t* out, uint32_t* counts) {
   KLAUNCH(ctx, "tracegen_alu", 28.0 * n_events + 4.0 * height * tracegen::chip_width(CHIP), tracegen::alu_rows<CHIP>,
-          dim3(div_up(height, tracegen::THREADS)), dim3(tracegen::THREADS), 0, d_events, n_events, height, out);
-}
-
-template <int CHIP>
-static void launch_byte_mults(zkm_ctx* ctx, const uint32_t* d_events, size_t n_events, uint32_t* counts) {
-  if (n_events == 0) return;
-  KLAUNCH(ctx, "tracegen_byte_mults", 28.0 * n_events, tracegen::byte_mults<CHIP>, dim3(div_up(n_events, tracegen::THREADS)),
-          dim3(tracegen::THREADS), 0, d_events, n_events, counts);
+          dim3(div_up(height, (counts ? tracegen::TILES_PER_BLOCK : 1) * tracegen::THREADS)), dim3(tracegen::THREADS),
+          counts ? 2 * tracegen::HASH_SLOTS * sizeof(uint32_t) : 0, d_events, n_events, height, out, counts,
+          counts ? tracegen::TILES_PER_BLOCK : 1);
 }
 
 #define API_BEGIN try {
@@ -1098,6 +1097,11 @@ int zkm_ctx_create(int device, zkm_ctx** out) {
   HIP_CHECK(p2::upload_tables());
   HIP_CHECK(hipFuncSetAttribute((const void*)lde::lde_rows, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIP_CHECK(hipFuncSetAttribute((const void*)lde::lde_rows_big, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIP_CHECK(hipFuncSetAttribute((const void*)tracegen::alu_rows<tracegen::ADD_SUB>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+  HIP_CHECK(hipFuncSetAttribute((const void*)tracegen::alu_rows<tracegen::BITWISE>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+  HIP_CHECK(hipFuncSetAttribute((const void*)tracegen::alu_rows<tracegen::LT>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+  HIP_CHECK(hipFuncSetAttribute((const void*)tracegen::alu_rows<tracegen::SHIFT_LEFT>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+  HIP_CHECK(hipFuncSetAttribute((const void*)tracegen::alu_rows<tracegen::SHIFT_RIGHT>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
   HIP_CHECK(hipFuncSetAttribute((const void*)lde::lde_cols<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIP_CHECK(hipFuncSetAttribute((const void*)lde::lde_cols<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIP_CHECK(hipFuncSetAttribute((const void*)stark::quotient_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -1465,7 +1469,8 @@ int zkm_coset_lde_batch(zkm_ctx* ctx, const uint32_t* host, size_t height, size_
 // ---- device trace generation (ALU chips) ---------------------------------------------------------------------
 size_t zkm_tracegen_alu_width(int chip) { return (size_t)tracegen::chip_width(chip); }
 
-int zkm_tracegen_alu(zkm_ctx* ctx, int chip, const zkm_alu_event* events, size_t n_events, int fixed_log2_rows, zkm_matrix** out) {
+int zkm_tracegen_alu(zkm_ctx* ctx, int chip, const zkm_alu_event* events, size_t n_events, int fixed_log2_rows,
+                     zkm_byte_lookups* blu, zkm_matrix** out) {
   API_BEGIN
   static_assert(sizeof(zkm_alu_event) == 28, "zkm_alu_event mirrors #[repr(C)] AluEvent");
   std::lock_guard<std::mutex> lk(ctx->mu);
@@ -1490,12 +1495,13 @@ int zkm_tracegen_alu(zkm_ctx* ctx, int chip, const zkm_alu_event* events, size_t
     m->d = ctx->alloc_n<uint32_t>(height * w);
     d_events = (uint32_t*)ctx->alloc(std::max<size_t>(n_events * 28, 4));
     if (n_events) HIP_CHECK(hipMemcpyAsync(d_events, events, n_events * 28, hipMemcpyHostToDevice, ctx->stream));
+    uint32_t* counts = blu ? blu->counts : nullptr;
     switch (chip) {
-      case tracegen::ADD_SUB: launch_alu_rows<tracegen::ADD_SUB>(ctx, d_events, n_events, height, m->d); break;
-      case tracegen::BITWISE: launch_alu_rows<tracegen::BITWISE>(ctx, d_events, n_events, height, m->d); break;
-      case tracegen::LT: launch_alu_rows<tracegen::LT>(ctx, d_events, n_events, height, m->d); break;
-      case tracegen::SHIFT_LEFT: launch_alu_rows<tracegen::SHIFT_LEFT>(ctx, d_events, n_events, height, m->d); break;
-      case tracegen::SHIFT_RIGHT: launch_alu_rows<tracegen::SHIFT_RIGHT>(ctx, d_events, n_events, height, m->d); break;
+      case tracegen::ADD_SUB: launch_alu_rows<tracegen::ADD_SUB>(ctx, d_events, n_events, height, m->d, counts); break;
+      case tracegen::BITWISE: launch_alu_rows<tracegen::BITWISE>(ctx, d_events, n_events, height, m->d, counts); break;
+      case tracegen::LT: launch_alu_rows<tracegen::LT>(ctx, d_events, n_events, height, m->d, counts); break;
+      case tracegen::SHIFT_LEFT: launch_alu_rows<tracegen::SHIFT_LEFT>(ctx, d_events, n_events, height, m->d, counts); break;
+      case tracegen::SHIFT_RIGHT: launch_alu_rows<tracegen::SHIFT_RIGHT>(ctx, d_events, n_events, height, m->d, counts); break;
     }
     ctx->mark("trace generation");
     ctx->end_timing(false);  // synchronises: the caller's event buffer is free again
@@ -1531,54 +1537,57 @@ int zkm_tracegen_byte_table(zkm_ctx* ctx, zkm_matrix** out) {
   API_END
 }
 
-int zkm_tracegen_byte_mults(zkm_ctx* ctx, size_t n_streams, const int* chips, const zkm_alu_event* const* events,
-                            const size_t* n_events, const uint32_t* extra_counts, zkm_matrix** out) {
+int zkm_byte_lookups_create(zkm_ctx* ctx, zkm_byte_lookups** out) {
   API_BEGIN
   std::lock_guard<std::mutex> lk(ctx->mu);
   HIP_CHECK(hipSetDevice(ctx->device));
-  for (size_t s = 0; s < n_streams; s++) {
-    if (chips[s] < 0 || chips[s] >= tracegen::NUM_CHIPS) throw std::runtime_error("zkm_tracegen_byte_mults: unknown chip");
-    if (n_events[s] && !events[s]) throw std::runtime_error("zkm_tracegen_byte_mults: null events");
+  const size_t cells = (size_t)tracegen::BYTE_ROWS * tracegen::NUM_BYTE_OPS;
+  zkm_byte_lookups* b = new zkm_byte_lookups();
+  try {
+    b->counts = ctx->alloc_n<uint32_t>(cells);
+    HIP_CHECK(hipMemsetAsync(b->counts, 0, cells * 4, ctx->stream));
+  } catch (...) {
+    delete b;
+    throw;
   }
+  *out = b;
+  API_END
+}
+void zkm_byte_lookups_free(zkm_ctx* ctx, zkm_byte_lookups* b) {
+  if (!b) return;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  ctx->release(b->counts);
+  delete b;
+}
+
+int zkm_tracegen_byte_mults(zkm_ctx* ctx, const zkm_byte_lookups* blu, const uint32_t* extra_counts, zkm_matrix** out) {
+  API_BEGIN
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIP_CHECK(hipSetDevice(ctx->device));
+  if (!blu) throw std::runtime_error("zkm_tracegen_byte_mults: null byte lookups");
   ctx->begin_timing();
   const size_t cells = (size_t)tracegen::BYTE_ROWS * tracegen::NUM_BYTE_OPS;
   zkm_matrix* m = new zkm_matrix();
   m->h = tracegen::BYTE_ROWS; m->w = tracegen::NUM_BYTE_OPS;
-  std::vector<void*> scratch;
+  uint32_t* d_extra = nullptr;
   try {
     m->d = ctx->alloc_n<uint32_t>(cells);
-    HIP_CHECK(hipMemsetAsync(m->d, 0, cells * 4, ctx->stream));
-    for (size_t s = 0; s < n_streams; s++) {
-      if (n_events[s] == 0) continue;
-      uint32_t* d_ev = (uint32_t*)ctx->alloc(n_events[s] * 28);
-      scratch.push_back(d_ev);
-      HIP_CHECK(hipMemcpyAsync(d_ev, events[s], n_events[s] * 28, hipMemcpyHostToDevice, ctx->stream));
-      switch (chips[s]) {
-        case tracegen::ADD_SUB: launch_byte_mults<tracegen::ADD_SUB>(ctx, d_ev, n_events[s], m->d); break;
-        case tracegen::BITWISE: launch_byte_mults<tracegen::BITWISE>(ctx, d_ev, n_events[s], m->d); break;
-        case tracegen::LT: launch_byte_mults<tracegen::LT>(ctx, d_ev, n_events[s], m->d); break;
-        case tracegen::SHIFT_LEFT: launch_byte_mults<tracegen::SHIFT_LEFT>(ctx, d_ev, n_events[s], m->d); break;
-        case tracegen::SHIFT_RIGHT: launch_byte_mults<tracegen::SHIFT_RIGHT>(ctx, d_ev, n_events[s], m->d); break;
-      }
-    }
-    uint32_t* d_extra = nullptr;
     if (extra_counts) {
       d_extra = (uint32_t*)ctx->alloc(cells * 4);
-      scratch.push_back(d_extra);
       HIP_CHECK(hipMemcpyAsync(d_extra, extra_counts, cells * 4, hipMemcpyHostToDevice, ctx->stream));
     }
-    hipLaunchKernelGGL(tracegen::byte_mults_finish, dim3(div_up(cells, 256)), dim3(256), 0, ctx->stream, m->d,
-                       (const uint32_t*)d_extra, cells);
+    hipLaunchKernelGGL(tracegen::byte_mults_finish, dim3(div_up(cells, 256)), dim3(256), 0, ctx->stream, (const uint32_t*)blu->counts,
+                       (const uint32_t*)d_extra, m->d, cells);
     LAUNCH_CHECK();
     ctx->mark("byte multiplicities");
     ctx->end_timing(false);
   } catch (...) {
-    for (void* p : scratch) ctx->release(p);
+    if (d_extra) ctx->release(d_extra);
     if (m->d) ctx->release(m->d);
     delete m;
     throw;
   }
-  for (void* p : scratch) ctx->release(p);
+  if (d_extra) ctx->release(d_extra);
   *out = m;
   API_END
 }

@@ -16,7 +16,7 @@ EXPORTS = [
     "zkm_pcs_commit", "zkm_pcs_data_free", "zkm_pcs_data_get_lde", "zkm_pcs_open_batch",
     "zkm_pk_setup", "zkm_pk_commitment", "zkm_pk_observe_into", "zkm_pk_free",
     "zkm_commit", "zkm_main_data_free", "zkm_open", "zkm_prove_shard",
-    "zkm_tracegen_alu_width", "zkm_tracegen_alu", "zkm_tracegen_byte_table", "zkm_tracegen_byte_mults",
+    "zkm_tracegen_alu_width", "zkm_byte_lookups_create", "zkm_byte_lookups_free", "zkm_tracegen_alu", "zkm_tracegen_byte_table", "zkm_tracegen_byte_mults",
     "zkm_poseidon2_permute_batch", "zkm_coset_lde_batch",
     "zkm_challenger_init", "zkm_challenger_observe", "zkm_challenger_sample", "zkm_challenger_sample_bits",
 ]
@@ -69,7 +69,7 @@ def load():
     L.zkm_host_field_mul.restype = C.c_uint32
     L.zkm_host_field_inv.restype = C.c_uint32
     L.zkm_host_two_adic_generator.restype = C.c_uint32
-    for name in ("zkm_ctx_destroy", "zkm_host_free", "zkm_ctx_set_kernel_timing", "zkm_matrix_free", "zkm_pcs_data_free", "zkm_pk_free", "zkm_main_data_free",
+    for name in ("zkm_ctx_destroy", "zkm_host_free", "zkm_byte_lookups_free", "zkm_ctx_set_kernel_timing", "zkm_matrix_free", "zkm_pcs_data_free", "zkm_pk_free", "zkm_main_data_free",
                  "zkm_challenger_init", "zkm_challenger_observe"):
         getattr(L, name).restype = None
     _LIB = L

@@ -40,6 +40,24 @@ class DeviceMatrix:
             pass
 
 
+class ByteLookups:
+    """`record.byte_lookups` on the device (zkm_byte_lookups)."""
+
+    def __init__(self, ctx, handle):
+        self.ctx, self.h = ctx, handle
+
+    def free(self):
+        if self.h:
+            lib.load().zkm_byte_lookups_free(self.ctx.h, self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
 class Context:
     """One per GPU (`zkm_ctx`)."""
 
@@ -55,13 +73,22 @@ class Context:
                                                C.byref(h)))
         return DeviceMatrix(self, h, m.shape[0], m.shape[1])
 
-    def tracegen_alu(self, chip: int, alu_events: np.ndarray, fixed_log2_rows: int = -1) -> DeviceMatrix:
-        """`generate_trace` of an ALU chip on the device (zkm_tracegen_alu); `alu_events` has dtype events.ALU_EVENT."""
+    def byte_lookups(self) -> "ByteLookups":
+        """An empty `record.byte_lookups` on the device (zkm_byte_lookups_create)."""
+        h = C.c_void_p()
+        lib.check(lib.load().zkm_byte_lookups_create(self.h, C.byref(h)))
+        return ByteLookups(self, h)
+
+    def tracegen_alu(self, chip: int, alu_events: np.ndarray, fixed_log2_rows: int = -1, blu: "ByteLookups" = None) -> DeviceMatrix:
+        """`generate_trace` of an ALU chip on the device (zkm_tracegen_alu); `alu_events` has dtype events.ALU_EVENT.
+        With `blu`, the chip's `generate_dependencies` runs in the same pass: its byte lookups are counted into it."""
         from . import events as _ev
-        ev = np.ascontiguousarray(alu_events, dtype=_ev.ALU_EVENT)
+        ev = alu_events if (alu_events.dtype == _ev.ALU_EVENT and alu_events.flags["C_CONTIGUOUS"]) else \
+            np.ascontiguousarray(alu_events, dtype=_ev.ALU_EVENT)
         h = C.c_void_p()
         lib.check(lib.load().zkm_tracegen_alu(self.h, C.c_int(chip), C.c_void_p(ev.ctypes.data if len(ev) else None),
-                                              C.c_size_t(len(ev)), C.c_int(fixed_log2_rows), C.byref(h)))
+                                              C.c_size_t(len(ev)), C.c_int(fixed_log2_rows), blu.h if blu is not None else None,
+                                              C.byref(h)))
         L = lib.load()
         return DeviceMatrix(self, h, int(L.zkm_matrix_height(h)), int(L.zkm_matrix_width(h)))
 
@@ -71,17 +98,11 @@ class Context:
         lib.check(lib.load().zkm_tracegen_byte_table(self.h, C.byref(h)))
         return DeviceMatrix(self, h, 1 << 16, 12)
 
-    def tracegen_byte_mults(self, streams, extra_counts=None) -> DeviceMatrix:
-        """`ByteChip::generate_trace` over the byte lookups of ALU event streams [(chip, events)] (+ optional host counts)."""
-        from . import events as _ev
-        evs = [np.ascontiguousarray(ev, dtype=_ev.ALU_EVENT) for _, ev in streams]
-        chips = (C.c_int * len(streams))(*[c for c, _ in streams])
-        ptrs = (C.c_void_p * len(streams))(*[ev.ctypes.data if len(ev) else None for ev in evs])
-        ns = (C.c_size_t * len(streams))(*[len(ev) for ev in evs])
+    def tracegen_byte_mults(self, blu: "ByteLookups", extra_counts=None) -> DeviceMatrix:
+        """`ByteChip::generate_trace` over the lookups counted in `blu` (+ optional (65536, 10) host counts)."""
         ex = np.ascontiguousarray(extra_counts, dtype=np.uint32) if extra_counts is not None else None
         h = C.c_void_p()
-        lib.check(lib.load().zkm_tracegen_byte_mults(self.h, C.c_size_t(len(streams)), chips, ptrs, ns,
-                                                     abi.as_u32p(ex) if ex is not None else None, C.byref(h)))
+        lib.check(lib.load().zkm_tracegen_byte_mults(self.h, blu.h, abi.as_u32p(ex) if ex is not None else None, C.byref(h)))
         return DeviceMatrix(self, h, 1 << 16, 10)
 
     def host_alloc(self, shape) -> np.ndarray:
