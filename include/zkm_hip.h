@@ -219,7 +219,7 @@ int zkm_prove_shard(zkm_ctx* ctx, const zkm_pk* pk, size_t n_chips, const zkm_ch
                     size_t* proof_len);
 
 /* ---- device trace generation, ALU chips ------------------- */
-/* One executor event of the AddSub / Bitwise / Lt / ShiftLeft / ShiftRight chips: byte-for-byte
+/* One executor event of the AddSub / Bitwise / Lt / ShiftLeft / ShiftRight / CloClz chips: byte-for-byte
  * the #[repr(C)] AluEvent of crates/core/executor/src/events/instr.rs:10-26 (opcode numbers:
  * crates/core/executor/src/opcode.rs:26-48), so the shim passes `record.add_sub_events.as_ptr()`. */
 typedef struct zkm_alu_event {
@@ -232,7 +232,8 @@ enum zkm_alu_chip {
   ZKM_CHIP_BITWISE = 1,     /* .../alu/bitwise/mod.rs                      (18) */
   ZKM_CHIP_LT = 2,          /* .../alu/lt/mod.rs                           (32) */
   ZKM_CHIP_SHIFT_LEFT = 3,  /* .../alu/sll/mod.rs                          (44) */
-  ZKM_CHIP_SHIFT_RIGHT = 4  /* .../alu/sr/mod.rs                           (67) */
+  ZKM_CHIP_SHIFT_RIGHT = 4, /* .../alu/sr/mod.rs                           (67) */
+  ZKM_CHIP_CLO_CLZ = 5      /* .../alu/clo_clz/mod.rs                      (17) */
 };
 /* size_of::<Cols<u8>>() of the chip (NUM_*_COLS); 0 for an unknown chip. */
 size_t zkm_tracegen_alu_width(int chip);

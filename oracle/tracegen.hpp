@@ -15,6 +15,7 @@
 //   Lt          lt/mod.rs:36-86, :209-274; zero padding (:127)
 //   ShiftLeft   sll/mod.rs:70-104, :232-287; padding rows are the template of :157-165
 //   ShiftRight  sr/mod.rs:88-137, :232-339; padding rows set shift_by_n_bits[0] = shift_by_n_bytes[0] = 1 (:183-186)
+//   CloClz      clo_clz/mod.rs:41-63, :105-133; padding rows a = 32, is_bb_zero = 1 (:147-163)
 // Row count: utils/mod.rs next_power_of_two — 2^fixed_log2_rows when the shape fixes it, else the next power of
 // two, at least 16. Event layout: #[repr(C)] AluEvent, crates/core/executor/src/events/instr.rs:10-26; opcode
 // numbers crates/core/executor/src/opcode.rs:26-48.
@@ -35,8 +36,8 @@ struct AluEvent {  // 28 bytes, as the executor lays it out
 };
 static_assert(sizeof(AluEvent) == 28, "AluEvent is seven words");
 
-enum Opcode : uint8_t { ADD = 0, SUB = 1, SLL = 9, SRL = 10, SRA = 11, ROR = 12, SLT = 13, SLTU = 14, AND = 15, OR = 16, XOR = 17, NOR = 18 };
-enum Chip { ADD_SUB = 0, BITWISE = 1, LT = 2, SHIFT_LEFT = 3, SHIFT_RIGHT = 4, NUM_CHIPS = 5 };
+enum Opcode : uint8_t { ADD = 0, SUB = 1, SLL = 9, SRL = 10, SRA = 11, ROR = 12, SLT = 13, SLTU = 14, AND = 15, OR = 16, XOR = 17, NOR = 18, CLZ = 19, CLO = 20 };
+enum Chip { ADD_SUB = 0, BITWISE = 1, LT = 2, SHIFT_LEFT = 3, SHIFT_RIGHT = 4, CLO_CLZ = 5, NUM_CHIPS = 6 };
 
 static inline size_t chip_width(int chip) {
   switch (chip) {
@@ -45,6 +46,7 @@ static inline size_t chip_width(int chip) {
     case LT: return 32;
     case SHIFT_LEFT: return 44;
     case SHIFT_RIGHT: return 67;
+    case CLO_CLZ: return 17;
   }
   throw std::runtime_error("tracegen: unknown chip");
 }
@@ -203,6 +205,23 @@ static inline void shift_right_padding(F* r) {
   r[18] = 1;  // shift_by_n_bytes[0]
 }
 
+static inline void clo_clz_row(const AluEvent& e, F* r) {
+  enum { PC = 0, NEXT_PC = 1, A = 2, B = 6, BB = 10, IS_BB_ZERO = 14, IS_CLZ = 15, IS_REAL = 16 };
+  word(r + A, e.a);
+  word(r + B, e.b);
+  r[PC] = fu32(e.pc);
+  r[NEXT_PC] = fu32(e.next_pc);
+  r[IS_REAL] = 1;
+  r[IS_CLZ] = e.opcode == CLZ;
+  const uint32_t bb = e.opcode == CLZ ? e.b : 0xffffffffu - e.b;
+  word(r + BB, bb);
+  r[IS_BB_ZERO] = bb == 0;
+}
+static inline void clo_clz_padding(F* r) {
+  r[2] = 32;  // a = Word::from(32)
+  r[14] = 1;  // is_bb_zero
+}
+
 // The reference's own sanity identities (debug_assert / assert in the row builders); returns false when one fails.
 static inline bool check_row(int chip, const AluEvent& e, const F* r) {
   switch (chip) {
@@ -241,11 +260,14 @@ static inline std::vector<F> generate(int chip, const AluEvent* events, size_t n
         case LT: lt_row(events[i], r); break;
         case SHIFT_LEFT: shift_left_row(events[i], r); break;
         case SHIFT_RIGHT: shift_right_row(events[i], r); break;
+        case CLO_CLZ: clo_clz_row(events[i], r); break;
       }
     } else if (chip == SHIFT_LEFT) {
       shift_left_padding(r);
     } else if (chip == SHIFT_RIGHT) {
       shift_right_padding(r);
+    } else if (chip == CLO_CLZ) {
+      clo_clz_padding(r);
     }
   }
   *height = h;
@@ -292,6 +314,10 @@ static inline void row_lookups(int chip, const AluEvent& e, const F* r, std::vec
       range_checks(out, r + 22, 8); range_checks(out, r + 30, 8); range_checks(out, r + 38, 8); range_checks(out, r + 46, 8);
       break;
     }
+    case CLO_CLZ:  // clo_clz/mod.rs:123-130
+      range_checks(out, r + 10, 4);
+      out.push_back({B_LTU, (uint8_t)e.a, 33});
+      break;
   }
 }
 
@@ -311,6 +337,7 @@ static inline std::vector<F> byte_mults(size_t n_streams, const int* chips, cons
         case LT: lt_row(events[s][i], row.data()); break;
         case SHIFT_LEFT: shift_left_row(events[s][i], row.data()); break;
         case SHIFT_RIGHT: shift_right_row(events[s][i], row.data()); break;
+        case CLO_CLZ: clo_clz_row(events[s][i], row.data()); break;
       }
       lk.clear();
       row_lookups(chips[s], events[s][i], row.data(), lk);

@@ -35,7 +35,7 @@ def test_constraints_hold_on_reference_vectors(oracle):
 
 
 @pytest.mark.parametrize("chip,col", [(E.CHIP_ADD_SUB, 6), (E.CHIP_LT, 27), (E.CHIP_SHIFT_LEFT, 31), (E.CHIP_SHIFT_RIGHT, 30),
-                                      (E.CHIP_BITWISE, 14)])
+                                      (E.CHIP_BITWISE, 14), (E.CHIP_CLO_CLZ, 11)])
 def test_corrupted_cell_is_caught(oracle, chip, col):
     rec = chips.record_constraints(chip)
     _, t = rows_for(oracle, chip, 100)
@@ -47,11 +47,15 @@ def test_corrupted_cell_is_caught(oracle, chip, col):
 
 def test_lookup_shapes():
     want = {  # (byte sends, instruction receives): counted from the reference's eval
-        E.CHIP_ADD_SUB: (6, 2), E.CHIP_BITWISE: (4, 1), E.CHIP_LT: (3, 1), E.CHIP_SHIFT_LEFT: (4, 1), E.CHIP_SHIFT_RIGHT: (25, 1)}
+        E.CHIP_ADD_SUB: (6, 2), E.CHIP_BITWISE: (4, 1), E.CHIP_LT: (3, 1), E.CHIP_SHIFT_LEFT: (4, 1), E.CHIP_SHIFT_RIGHT: (25, 1),
+        E.CHIP_CLO_CLZ: (3, 1)}
     for chip, (ns, nr) in want.items():
         rec = chips.record_constraints(chip)
-        assert (len(rec.sends), len(rec.receives)) == (ns, nr)
-        assert all(lk.kind == air.KIND_BYTE and len(lk.values) == 5 for lk in rec.sends)
+        sends = [lk for lk in rec.sends if lk.kind == air.KIND_BYTE]
+        assert (len(sends), len(rec.receives)) == (ns, nr)
+        assert all(len(lk.values) == 5 for lk in sends)
+        # CloClz also sends one instruction (SRL) to the ShiftRight chip
+        assert [lk.kind for lk in rec.sends if lk.kind != air.KIND_BYTE] == ([air.KIND_INSTRUCTION] if chip == E.CHIP_CLO_CLZ else [])
         assert all(lk.kind == air.KIND_INSTRUCTION and len(lk.values) == 28 for lk in rec.receives)
 
 
@@ -82,17 +86,18 @@ def test_to_virtual_pair_rejects_products():
 # ---- GPU ------------------------------------------------------------------------------------------------------------
 
 def alu_shard(oracle, log_rows, seed=11):
-    """Five real chips; AddSub at 2^log_rows rows, the others smaller; every trace also as oracle rows."""
+    """Six real chips; AddSub at 2^log_rows rows, the others smaller; every trace also as oracle rows. The SRL events
+    the executor derives from the CLO/CLZ instructions go to the ShiftRight chip (dependencies.rs:105-122)."""
     spec = [(E.CHIP_ADD_SUB, log_rows, 0.9), (E.CHIP_BITWISE, log_rows - 1, 1.0), (E.CHIP_LT, log_rows - 1, 0.7),
-            (E.CHIP_SHIFT_LEFT, log_rows - 2, 0.55), (E.CHIP_SHIFT_RIGHT, log_rows - 2, 0.8)]
+            (E.CHIP_SHIFT_LEFT, log_rows - 2, 0.55), (E.CHIP_SHIFT_RIGHT, log_rows - 2, 0.6), (E.CHIP_CLO_CLZ, log_rows - 3, 0.8)]
+    streams = {chip: E.synthetic_alu_events(chip, int((1 << lh) * fill), seed=seed + chip) for chip, lh, fill in spec}
+    streams[E.CHIP_SHIFT_RIGHT] = np.concatenate([streams[E.CHIP_SHIFT_RIGHT], E.cloclz_dependencies(streams[E.CHIP_CLO_CLZ])])
     recs, evs = [], []
-    for chip, lh, fill in spec:
-        n = int((1 << lh) * fill)
-        ev = E.synthetic_alu_events(chip, n, seed=seed + chip)
+    for chip, lh, _ in spec:
         rc = chips.record_chip(chip, lh)
-        rc.trace = oracle.tracegen_alu(chip, ev, lh)
+        rc.trace = oracle.tracegen_alu(chip, streams[chip], lh)
         recs.append(rc)
-        evs.append((chip, ev, lh))
+        evs.append((chip, streams[chip], lh))
     return recs, evs
 
 
@@ -100,17 +105,24 @@ def mirror_chip(rec, kinds=None):
     """A chip that receives exactly what `rec` sends and sends what it receives (one column per lookup value plus a
     multiplicity column, filled from rec's trace), so that the pair's local cumulative sums cancel. It stands in for
     the chips on the other side of the ALU chips' lookups that are not built (Cpu: crates/core/machine/src/cpu/; with
-    kinds=None also Byte). `kinds` restricts the mirror to lookups of those kinds."""
+    kinds=None also Byte). `kinds` restricts the mirror to lookups of those kinds. Lookups between two chips that are
+    both in the shard are left alone: the SRL instructions CloClz sends (its instruction *sends*) and ShiftRight
+    receives (its rows at the placeholder pc UNUSED_PC)."""
     t = F.from_monty(rec.trace)
     main = {c: t[:, c].astype(np.uint64) for c in range(t.shape[1])}
+    from_cpu = (main[0] != E.UNUSED_PC).astype(np.uint64)   # column 0 is `pc` in every ALU chip
     cols, sends, receives = [], [], []
     for src, dst in ((rec.sends, receives), (rec.receives, sends)):
         for lk in src:
             if kinds is not None and lk.kind not in kinds:
                 continue
+            if lk.kind == air.KIND_INSTRUCTION and src is rec.sends:
+                continue
             first = len(cols)
-            for v in list(lk.values) + [lk.multiplicity]:
+            for v in lk.values:
                 cols.append(v.apply_np({}, main))
+            mult = lk.multiplicity.apply_np({}, main)
+            cols.append(mult * from_cpu if lk.kind == air.KIND_INSTRUCTION else mult)
             vals = [air.VirtualPairCol.single_main(first + j) for j in range(len(lk.values))]
             dst.append(air.Lookup(vals, air.VirtualPairCol.single_main(first + len(lk.values)), lk.kind))
     width = len(cols)
@@ -139,7 +151,7 @@ def test_gpu_alu_shard_proof(hip_ctx, oracle, log_rows, queries, pow_bits):
     pc_start = F.to_monty(0x400000)
     hp = prover.HipProver(recs, fri, synth.NUM_PV_ELTS, ctx=hip_ctx)
     if log_rows > 8:
-        hp.specialize_quotient_kernels(recs[:5])   # the real chips through generated kernels, the mirrors interpreted
+        hp.specialize_quotient_kernels(recs[:6])   # the real chips through generated kernels, the mirrors interpreted
     pk = hp.setup([], [], pc_start, igcs)
     ch = prover.new_challenger()
     pk.observe_into(ch)
@@ -196,9 +208,9 @@ def test_gpu_alu_and_byte_chips_shard(hip_ctx, oracle):
     assert np.array_equal(proof, oproof)
     assert oracle.verify_shard(opk, all_chips, fri, synth.NUM_PV_ELTS, start.copy(), proof) == 0
     # without the Byte chip's multiplicities the byte lookups do not balance: the verifier's cumulative-sum check fails
-    born[5].free()
+    born[6].free()
     empty = hip_ctx.byte_lookups()
-    born[5] = hip_ctx.tracegen_byte_mults(empty)
+    born[6] = hip_ctx.tracegen_byte_mults(empty)
     ch2 = start.copy()
     bad = hp.prove_shard(pk, pv, born, ch2).copy()
     assert oracle.verify_shard(opk, all_chips, fri, synth.NUM_PV_ELTS, start.copy(), bad) != 0

@@ -177,8 +177,9 @@ def test_byte_table_and_multiplicities_oracle(oracle):
     assert t[0xf305].tolist() == [0xf3, 5, 1, 0xf7, 0xf6, 8, 0x60, 7, 0x13, 0, 1, 0xf305]
     streams = [(chip, E.synthetic_alu_events(chip, 500, seed=9)) for chip in sorted(E.CHIP_NAMES)]
     m = canon(oracle.tracegen_byte_mults(streams)).astype(np.int64)
-    # lookups per event: AddSub 6 range checks; Bitwise 4 ops; Lt 2 AND + 1 LTU; ShiftLeft 4 range; ShiftRight 1 MSB + 8 ShrCarry + 16 range
-    assert m[:, 4].sum() == 500 * (6 + 4 + 16) and m[:, 5].sum() == 500 * 8 and m[:, 6].sum() == 500 and m[:, 7].sum() == 500
+    # lookups per event: AddSub 6 range checks; Bitwise 4 ops; Lt 2 AND + 1 LTU; ShiftLeft 4 range; ShiftRight 1 MSB + 8 ShrCarry +
+    # 16 range; CloClz 2 range + 1 LTU
+    assert m[:, 4].sum() == 500 * (6 + 4 + 16 + 2) and m[:, 5].sum() == 500 * 8 and m[:, 6].sum() == 2 * 500 and m[:, 7].sum() == 500
     assert m[:, [0, 1, 2, 9]].sum() == 500 * 4 + 2 * 500 and m[:, 3].sum() == 0 and m[:, 8].sum() == 0
     assert m[:, 7][np.arange(1 << 16) & 0xff != 0].sum() == 0      # MSB lookups sit in the c = 0 rows
     extra = np.zeros((1 << 16, 10), dtype=np.uint32)

@@ -10,6 +10,7 @@ In the Rust integration this file does not exist: the shim runs the chips' own `
   Lt          alu/lt/mod.rs:288-472
   ShiftLeft   alu/sll/mod.rs:289-415
   ShiftRight  alu/sr/mod.rs:352-545
+  CloClz      alu/clo_clz/mod.rs:180-283
   helpers     air/word.rs:55-80 (slice_range_check_u8), crates/stark/src/air/builder.rs:119-280 (byte and
               instruction lookups), opcode numbers crates/core/executor/src/opcode.rs:26-48,195-216
 """
@@ -88,6 +89,14 @@ class _Rec:
 
     # InstructionAirBuilder::receive_instruction (builder.rs:237-280) as the ALU chips call it: shard, clk,
     # num_extra_cycles, hi and the four flags are zero, is_sequential is one
+    def send_alu(self, opcode, a, b, c, mult):
+        """InstructionAirBuilder::send_alu (builder.rs:282-326): an instruction sent from one chip to an ALU chip, at
+        the placeholder pc UNUSED_PC."""
+        pc = E.UNUSED_PC
+        vals = [0, 0, pc, pc + E.DEFAULT_PC_INC, pc + 2 * E.DEFAULT_PC_INC, 0, opcode] + list(a) + list(b) + list(c) + \
+               [0, 0, 0, 0] + [0, 0, 0, 0, 1]
+        self.sends.append(air.Lookup([air.to_virtual_pair(v) for v in vals], air.to_virtual_pair(mult), air.KIND_INSTRUCTION))
+
     def receive_alu_instruction(self, pc, next_pc, opcode, a, b, c, mult):
         vals = [0, 0, pc, next_pc, next_pc + 4, 0, opcode] + list(a) + list(b) + list(c) + [0, 0, 0, 0] + [0, 0, 0, 0, 1]
         self.receives.append(air.Lookup([air.to_virtual_pair(v) for v in vals], air.to_virtual_pair(mult), air.KIND_INSTRUCTION))
@@ -305,6 +314,32 @@ def _shift_right(r: _Rec):
                               l[BIT_RES:BIT_RES + 4], l[B:B + 4], l[C:C + 4], l[IS_REAL])
 
 
+def _clo_clz(r: _Rec):
+    l, b = r.local, r.b
+    PC, NEXT_PC, A, B, BB, IS_BB_ZERO, IS_CLZ, IS_REAL = 0, 1, 2, 6, 10, 14, 15, 16
+    is_clo = l[IS_REAL] - l[IS_CLZ]
+    for i in range(4):
+        b.when(is_clo).assert_eq(l[B + i] + l[BB + i], b.const(255))
+        b.when(l[IS_CLZ]).assert_eq(l[B + i], l[BB + i])
+    r.slice_range_check_u8(l[BB:BB + 4], l[IS_REAL])
+    r.send_byte(B_LTU, 1, l[A], 33, l[IS_REAL])
+    b.when(l[IS_REAL]).assert_zero(l[A + 1])
+    b.when(l[IS_REAL]).assert_zero(l[A + 2])
+    b.when(l[IS_REAL]).assert_zero(l[A + 3])
+    cpu_opcode = is_clo * E.CLO + l[IS_CLZ] * E.CLZ
+    r.receive_alu_instruction(l[PC], l[NEXT_PC], cpu_opcode, l[A:A + 4], l[B:B + 4], [0, 0, 0, 0], l[IS_REAL])
+    b.assert_bool(l[IS_BB_ZERO])
+    bb_reduced = b.const(1) * l[BB] + b.const(1 << 8) * l[BB + 1] + b.const(1 << 16) * l[BB + 2] + b.const(1 << 24) * l[BB + 3]
+    b.when(l[IS_BB_ZERO]).assert_zero(bb_reduced)
+    b.when(l[IS_BB_ZERO]).assert_zero(l[BB + 3])
+    b.when(l[IS_BB_ZERO]).assert_eq(l[A], b.const(32))
+    # bb >> (31 - a) = 1: the leading one of bb sits at bit 31 - a (skipped when bb = 0)
+    r.send_alu(E.SRL, [1, 0, 0, 0], l[BB:BB + 4], [31 - l[A], 0, 0, 0], 1 - l[IS_BB_ZERO])
+    b.assert_bool(l[IS_CLZ])
+    b.assert_bool(l[IS_REAL])
+    b.when(l[IS_CLZ]).assert_one(l[IS_REAL])
+
+
 def _byte(r: _Rec):
     """ByteChip::eval (bytes/air.rs:20-74): one receive per ByteOpcode, in ByteOpcode::all() order."""
     m, t = r.local, r.prep
@@ -322,9 +357,10 @@ def _byte(r: _Rec):
 
 
 _EVAL = {E.CHIP_ADD_SUB: _add_sub, E.CHIP_BITWISE: _bitwise, E.CHIP_LT: _lt, E.CHIP_SHIFT_LEFT: _shift_left,
-         E.CHIP_SHIFT_RIGHT: _shift_right}
+         E.CHIP_SHIFT_RIGHT: _shift_right, E.CHIP_CLO_CLZ: _clo_clz}
 # MachineAir::local_only (add_sub/mod.rs:152, bitwise/mod.rs:154, lt/mod.rs:201, sll/mod.rs:226; ShiftRight keeps the default)
-_LOCAL_ONLY = {E.CHIP_ADD_SUB: True, E.CHIP_BITWISE: True, E.CHIP_LT: True, E.CHIP_SHIFT_LEFT: True, E.CHIP_SHIFT_RIGHT: False}
+_LOCAL_ONLY = {E.CHIP_ADD_SUB: True, E.CHIP_BITWISE: True, E.CHIP_LT: True, E.CHIP_SHIFT_LEFT: True, E.CHIP_SHIFT_RIGHT: False,
+               E.CHIP_CLO_CLZ: False}
 
 
 def record_constraints(chip: int) -> _Rec:

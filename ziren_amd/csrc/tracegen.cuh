@@ -9,6 +9,7 @@
 //   Lt          lt/mod.rs:36-86, :209-274
 //   ShiftLeft   sll/mod.rs:70-104, :232-287, padding rows :157-165
 //   ShiftRight  sr/mod.rs:88-137, :232-339, padding rows :183-186
+//   CloClz      clo_clz/mod.rs:41-63, :105-133, padding rows :147-163
 // Values are stored in Montgomery form, the in-memory form of the reference's KoalaBear (RowMajorMatrix<KoalaBear>).
 #pragma once
 #include "kb31.cuh"
@@ -22,11 +23,11 @@ struct AluEvent {  // #[repr(C)] AluEvent, crates/core/executor/src/events/instr
 };
 
 // crates/core/executor/src/opcode.rs:26-48
-enum : uint32_t { ADD = 0, SUB = 1, SLL = 9, SRL = 10, SRA = 11, ROR = 12, SLT = 13, SLTU = 14, AND = 15, OR = 16, XOR = 17, NOR = 18 };
-enum Chip { ADD_SUB = 0, BITWISE = 1, LT = 2, SHIFT_LEFT = 3, SHIFT_RIGHT = 4, NUM_CHIPS = 5 };
+enum : uint32_t { ADD = 0, SUB = 1, SLL = 9, SRL = 10, SRA = 11, ROR = 12, SLT = 13, SLTU = 14, AND = 15, OR = 16, XOR = 17, NOR = 18, CLZ = 19, CLO = 20 };
+enum Chip { ADD_SUB = 0, BITWISE = 1, LT = 2, SHIFT_LEFT = 3, SHIFT_RIGHT = 4, CLO_CLZ = 5, NUM_CHIPS = 6 };
 
 __host__ __device__ constexpr int chip_width(int chip) {
-  return chip == ADD_SUB ? 19 : chip == BITWISE ? 18 : chip == LT ? 32 : chip == SHIFT_LEFT ? 44 : chip == SHIFT_RIGHT ? 67 : 0;
+  return chip == ADD_SUB ? 19 : chip == BITWISE ? 18 : chip == LT ? 32 : chip == SHIFT_LEFT ? 44 : chip == SHIFT_RIGHT ? 67 : chip == CLO_CLZ ? 17 : 0;
 }
 
 constexpr int THREADS = 256;
@@ -180,6 +181,23 @@ template <> __device__ __forceinline__ void padding_row<SHIFT_RIGHT>(uint32_t* r
   r[18] = 1;  // shift_by_n_bytes[0]
 }
 
+template <> __device__ __forceinline__ void event_row<CLO_CLZ>(const AluEvent& e, uint32_t* r) {
+  enum { PC = 0, NEXT_PC = 1, A = 2, B = 6, BB = 10, IS_BB_ZERO = 14, IS_CLZ = 15, IS_REAL = 16 };
+  const uint32_t bb = e.opcode == CLZ ? e.b : ~e.b;
+  r[PC] = e.pc;
+  r[NEXT_PC] = e.next_pc;
+  word(r + A, e.a);
+  word(r + B, e.b);
+  word(r + BB, bb);
+  r[IS_BB_ZERO] = fbool(bb == 0);
+  r[IS_CLZ] = fbool(e.opcode == CLZ);
+  r[IS_REAL] = 1;
+}
+template <> __device__ __forceinline__ void padding_row<CLO_CLZ>(uint32_t* r) {
+  r[2] = 32;  // a = Word::from(32)
+  r[14] = 1;  // is_bb_zero
+}
+
 // ---- byte lookups: the ALU chips' generate_dependencies, ByteChip::generate_trace and ByteChip::trace -----------------
 // ByteOpcode, crates/core/executor/src/opcode.rs:195-216
 enum : uint32_t { B_AND = 0, B_OR = 1, B_XOR = 2, B_SLL = 3, B_U8RANGE = 4, B_SHRCARRY = 5, B_LTU = 6, B_MSB = 7, B_U16RANGE = 8, B_NOR = 9 };
@@ -221,7 +239,7 @@ __device__ __forceinline__ void range_checks(const LookupSink& counts, const uin
 
 // The byte lookups each chip's event_to_row records (= the `send_byte`s of its AIR with multiplicity 1), read off
 // the row: add_sub/mod.rs:176 -> operations/add.rs:48-53; bitwise/mod.rs:183-193; lt/mod.rs:227-241,268-274;
-// sll/mod.rs:276-279; sr/mod.rs:258-265,309-316,334-337.
+// sll/mod.rs:276-279; sr/mod.rs:258-265,309-316,334-337; clo_clz/mod.rs:123-130.
 template <int CHIP> __device__ __forceinline__ void row_lookups(const uint32_t* r, uint32_t opcode, const LookupSink& counts);
 template <> __device__ __forceinline__ void row_lookups<ADD_SUB>(const uint32_t* r, uint32_t, const LookupSink& counts) {
   range_checks(counts, r + 9, 4);   // operand_1
@@ -253,6 +271,11 @@ template <> __device__ __forceinline__ void row_lookups<SHIFT_RIGHT>(const uint3
   range_checks(counts, r + 30, 8);
   range_checks(counts, r + 38, 8);
   range_checks(counts, r + 46, 8);
+}
+
+template <> __device__ __forceinline__ void row_lookups<CLO_CLZ>(const uint32_t* r, uint32_t, const LookupSink& counts) {
+  range_checks(counts, r + 10, 4);       // bb
+  lookup(counts, B_LTU, r[2], 33);       // a < 33
 }
 
 // events: n_events records of seven words; out: column-major, `height` rows; grid = height / (tiles * THREADS), with

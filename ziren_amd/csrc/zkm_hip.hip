@@ -1102,6 +1102,7 @@ int zkm_ctx_create(int device, zkm_ctx** out) {
   HIP_CHECK(hipFuncSetAttribute((const void*)tracegen::alu_rows<tracegen::LT>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
   HIP_CHECK(hipFuncSetAttribute((const void*)tracegen::alu_rows<tracegen::SHIFT_LEFT>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
   HIP_CHECK(hipFuncSetAttribute((const void*)tracegen::alu_rows<tracegen::SHIFT_RIGHT>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+  HIP_CHECK(hipFuncSetAttribute((const void*)tracegen::alu_rows<tracegen::CLO_CLZ>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
   HIP_CHECK(hipFuncSetAttribute((const void*)lde::lde_cols<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIP_CHECK(hipFuncSetAttribute((const void*)lde::lde_cols<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIP_CHECK(hipFuncSetAttribute((const void*)stark::quotient_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -1502,6 +1503,7 @@ int zkm_tracegen_alu(zkm_ctx* ctx, int chip, const zkm_alu_event* events, size_t
       case tracegen::LT: launch_alu_rows<tracegen::LT>(ctx, d_events, n_events, height, m->d, counts); break;
       case tracegen::SHIFT_LEFT: launch_alu_rows<tracegen::SHIFT_LEFT>(ctx, d_events, n_events, height, m->d, counts); break;
       case tracegen::SHIFT_RIGHT: launch_alu_rows<tracegen::SHIFT_RIGHT>(ctx, d_events, n_events, height, m->d, counts); break;
+      case tracegen::CLO_CLZ: launch_alu_rows<tracegen::CLO_CLZ>(ctx, d_events, n_events, height, m->d, counts); break;
     }
     ctx->mark("trace generation");
     ctx->end_timing(false);  // synchronises: the caller's event buffer is free again

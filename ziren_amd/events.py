@@ -17,14 +17,16 @@ ADD, SUB = 0, 1
 SLL, SRL, SRA, ROR = 9, 10, 11, 12
 SLT, SLTU = 13, 14
 AND, OR, XOR, NOR = 15, 16, 17, 18
+CLZ, CLO = 19, 20
+UNUSED_PC, DEFAULT_PC_INC = 1, 4  # crates/core/executor/src/executor.rs:44-47
 
 # zkm_alu_chip
-CHIP_ADD_SUB, CHIP_BITWISE, CHIP_LT, CHIP_SHIFT_LEFT, CHIP_SHIFT_RIGHT = range(5)
+CHIP_ADD_SUB, CHIP_BITWISE, CHIP_LT, CHIP_SHIFT_LEFT, CHIP_SHIFT_RIGHT, CHIP_CLO_CLZ = range(6)
 CHIP_NAMES = {CHIP_ADD_SUB: "AddSub", CHIP_BITWISE: "Bitwise", CHIP_LT: "Lt", CHIP_SHIFT_LEFT: "ShiftLeft",
-              CHIP_SHIFT_RIGHT: "ShiftRight"}
-CHIP_WIDTH = {CHIP_ADD_SUB: 19, CHIP_BITWISE: 18, CHIP_LT: 32, CHIP_SHIFT_LEFT: 44, CHIP_SHIFT_RIGHT: 67}
+              CHIP_SHIFT_RIGHT: "ShiftRight", CHIP_CLO_CLZ: "CloClz"}
+CHIP_WIDTH = {CHIP_ADD_SUB: 19, CHIP_BITWISE: 18, CHIP_LT: 32, CHIP_SHIFT_LEFT: 44, CHIP_SHIFT_RIGHT: 67, CHIP_CLO_CLZ: 17}
 CHIP_OPCODES = {CHIP_ADD_SUB: (ADD, SUB), CHIP_BITWISE: (AND, OR, XOR, NOR), CHIP_LT: (SLT, SLTU),
-                CHIP_SHIFT_LEFT: (SLL,), CHIP_SHIFT_RIGHT: (SRL, SRA, ROR)}
+                CHIP_SHIFT_LEFT: (SLL,), CHIP_SHIFT_RIGHT: (SRL, SRA, ROR), CHIP_CLO_CLZ: (CLZ, CLO)}
 
 _CORNERS = np.array([0, 1, 2, 0x7f, 0x80, 0xff, 0x100, 0xffff, 0x10000, 0x7fffffff, 0x80000000, 0x80000001,
                      0xfffffffe, 0xffffffff, 0x00ff00ff, 0xff00ff00, 0x01010101], dtype=np.uint64)
@@ -52,6 +54,12 @@ def alu_result(opcode: np.ndarray, b: np.ndarray, c: np.ndarray) -> np.ndarray:
     out = np.where(sel(SRL), b >> sh, out)
     out = np.where(sel(SRA), (sb >> sh.astype(np.int64)).astype(np.uint64) & M, out)
     out = np.where(sel(ROR), ((b >> sh) | (b << (np.uint64(32) - sh))) & M, out)
+    if np.any(sel(CLZ) | sel(CLO)):  # leading zeros of b / of !b (crates/core/executor/src/executor.rs:1916-1917)
+        x = np.where(sel(CLO), ~b & M, b)
+        lz = np.full(b.shape, 32, dtype=np.uint64)
+        nz = x != 0
+        lz[nz] = 31 - np.floor(np.log2(x[nz].astype(np.float64))).astype(np.uint64)
+        out = np.where(sel(CLZ) | sel(CLO), lz, out)
     return out.astype(np.uint32)
 
 
@@ -86,4 +94,27 @@ def synthetic_alu_events(chip: int, n: int, seed: int = 1) -> np.ndarray:
     c = np.where(kind == 3, b ^ (np.uint64(1) << ((r3 >> np.uint64(32)) % np.uint64(32))), c)  # one differing bit
     if chip in (CHIP_SHIFT_LEFT, CHIP_SHIFT_RIGHT):
         c = np.where(kind < 8, (r3 >> np.uint64(40)) % np.uint64(32), c)  # small shift amounts, all 32 of them
+    if chip == CHIP_CLO_CLZ:  # every count 0..32: shift the operand down (CLZ) or fill it with ones from the top (CLO)
+        k = (r3 >> np.uint64(40)) % np.uint64(33)
+        low = np.where(k >= 32, np.uint64(0), (b & np.uint64(0xffffffff)) >> np.minimum(k, np.uint64(31)))
+        b = np.where(opcode == CLZ, low, ~low & np.uint64(0xffffffff))
+        c = np.zeros_like(c)
     return make_alu_events(opcode, b, c)
+
+
+def cloclz_dependencies(cloclz_events: np.ndarray) -> np.ndarray:
+    """The SRL events the executor adds to `shift_right_events` for CLO/CLZ instructions
+    (emit_cloclz_dependencies, crates/core/executor/src/dependencies.rs:105-122): they carry the CloClz chip's
+    `send_alu` to the ShiftRight chip."""
+    ev = cloclz_events
+    b = np.where(ev["opcode"] == CLZ, ev["b"], ~ev["b"]).astype(np.uint32)
+    keep = b != 0
+    b, a = b[keep], ev["a"][keep]
+    out = np.zeros(len(b), dtype=ALU_EVENT)
+    out["pc"] = UNUSED_PC
+    out["next_pc"] = UNUSED_PC + DEFAULT_PC_INC
+    out["opcode"] = SRL
+    out["b"] = b
+    out["c"] = 31 - a
+    out["a"] = b >> (31 - a)
+    return out
