@@ -49,6 +49,11 @@ __global__ void bench(uint32_t* out, uint32_t seed) {
       if (OP == 29) { uint32_t t; asm volatile("v_add_u32 %0, %0, %2\n v_subrev_u32 %1, %3, %0\n v_min_u32 %0, %0, %1" : "+v"(a[i]), "=&v"(t) : "v"(b), "s"(0x7f000001u)); }
       if (OP == 30) { uint32_t t; asm volatile("v_add_u32 %0, %0, %2\n v_subrev_co_u32 %1, vcc, %3, %0\n v_cndmask_b32 %0, %1, %0, vcc" : "+v"(a[i]), "=&v"(t) : "v"(b), "s"(0x7f000001u) : "vcc"); }
       if (OP == 31) { uint32_t t; uint64_t m; asm volatile("v_add_u32 %0, %0, %3\n v_subrev_co_u32 %1, %2, %4, %0\n v_cndmask_b32 %0, %1, %0, %2" : "+v"(a[i]), "=&v"(t), "=&s"(m) : "v"(b), "s"(0x7f000001u)); }
+      if (OP == 32) asm volatile("v_mad_i64_i32 %0, vcc, %1, %2, %0" : "+v"(w[i]) : "v"(a[i]), "v"(b) : "vcc");
+      if (OP == 33) asm volatile("v_mul_hi_i32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+      if (OP == 34) asm volatile("v_mad_i64_i32 %0, vcc, %1, 1, %0" : "+v"(w[i]) : "v"(a[i]) : "vcc");
+      if (OP == 35) asm volatile("v_mad_u64_u32 %0, vcc, %1, 1, %0" : "+v"(w[i]) : "v"(a[i]) : "vcc");
+      if (OP == 36) asm volatile("v_lshl_add_u64 %0, %0, 0, %1" : "+v"(w[i]) : "v"(w[(i+1)%ILP]));
       if (OP == 27) asm volatile("v_mul_lo_u32 %0, %0, %1\n v_add_u32 %2, %2, %1" : "+v"(a[i]), "+v"(b) , "+v"(a[(i+1)%ILP]):);
     }
   }
@@ -111,6 +116,11 @@ int main() {
   run<29>("modadd add/sub/min", d);
   run<30>("modadd add/sub_co/cndmask vcc", d);
   run<31>("modadd add/sub_co/cndmask sgpr", d);
+  run<32>("v_mad_i64_i32", d);
+  run<33>("v_mul_hi_i32", d);
+  run<34>("v_mad_i64_i32 x*1+acc", d);
+  run<35>("v_mad_u64_u32 x*1+acc", d);
+  run<36>("v_lshl_add_u64", d);
   run<0>("v_add_u32 (again)", d);
   run<7>("v_min_u32 (again)", d);
   return 0;

@@ -61,7 +61,7 @@ KB_HD int32_t mulhi_s32(int32_t a, int32_t b) {
 // step maps x in (-p^2, p^2) to (x - t p) / 2^32 in (-p, p) with t = x * p^-1 taken as a signed word,
 // so y^2 and then (y^2) * y stay signed and only the final value is brought back to [0, p).
 // 11 instructions instead of 15 (add-reduce + two full multiplies).
-KB_HD uint32_t sbox_rc(uint32_t s, uint32_t rcm) {
+KB_HD int32_t sbox_rc_signed(uint32_t s, uint32_t rcm) {
   const int32_t y = (int32_t)(s + rcm);
   const int64_t x1 = (int64_t)y * y;
   const int32_t t1 = (int32_t)((uint32_t)x1 * kb::MU);
@@ -72,45 +72,69 @@ KB_HD uint32_t sbox_rc(uint32_t s, uint32_t rcm) {
   const int32_t z = (int32_t)(hi1 - (uint32_t)mulhi_s32(t1, (int32_t)kb::P));
   const int64_t x2 = (int64_t)z * y;
   const int32_t t2 = (int32_t)((uint32_t)x2 * kb::MU);
-  const uint32_t r = (uint32_t)((uint64_t)x2 >> 32) - (uint32_t)mulhi_s32(t2, (int32_t)kb::P);
+  return (int32_t)((uint32_t)((uint64_t)x2 >> 32) - (uint32_t)mulhi_s32(t2, (int32_t)kb::P));  // in (-p, p)
+}
+KB_HD uint32_t sbox_rc(uint32_t s, uint32_t rcm) {
+  const uint32_t r = (uint32_t)sbox_rc_signed(s, rcm);
   return kb::umin32(r, r + kb::P);
 }
 
-// acc += x (64-bit accumulate of a 32-bit value): one v_mad_u64_u32 on the device
-KB_HD void acc_add(uint64_t& acc, uint32_t x) {
+// ---- partial rounds in a signed representation ----------------------------------------------------------------
+// Between the 13 partial rounds every lane only feeds (a) the lane sum and (b) its own s_i * V_i + sum, both of which
+// a *signed* Montgomery step accepts: a lane is kept as an int32 congruent to its value, |s_i| < 2^31, and the final
+// correction to [0, p) (two instructions per lane per round) is dropped. One round is then, per lane, a 64-bit
+// multiply-add and a three-instruction reduction; only lane 0 is brought back to [0, p) for its S-box.
+
+// acc += x for a signed 32-bit x: one v_mad_i64_i32 on the device
+KB_HD void acc_add_signed(int64_t& acc, int32_t x) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  asm("v_mad_u64_u32 %0, vcc, %1, 1, %0" : "+v"(acc) : "v"(x) : "vcc");
+  asm("v_mad_i64_i32 %0, vcc, %1, 1, %0" : "+v"(acc) : "v"(x) : "vcc");
 #else
   acc += x;
 #endif
 }
-// x / 2 mod p
-KB_HD uint32_t half(uint32_t x) { return (x + ((0u - (x & 1u)) & kb::P)) >> 1; }
+// a * b + c with a signed 32-bit a, a wave-uniform b in [0, 2^31) and a signed 64-bit c: one v_mad_i64_i32 on the device
+// (left to itself the compiler sometimes expands this into an unsigned multiply plus sign fix-ups: 190 instead of 98
+// instructions per partial round in hash_leaves)
+KB_HD int64_t mad_i64_i32_uniform(int32_t a, uint32_t b_uniform, int64_t c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  int64_t r;
+  asm("v_mad_i64_i32 %0, vcc, %1, %2, %3" : "=v"(r) : "v"(a), "s"(b_uniform), "v"(c) : "vcc");
+  return r;
+#else
+  return (int64_t)a * (int64_t)(int32_t)b_uniform + c;
+#endif
+}
+// x in (-2^31 p, 2^31 p)  ->  (x - t p) / 2^32 with t = x p^-1 mod 2^32 taken as a signed word; |result| <= (|x| / 2^32 + p / 2)
+KB_HD int32_t monty_reduce_signed(int64_t x) {
+  const int32_t t = (int32_t)((uint32_t)x * kb::MU);
+  uint32_t hi = (uint32_t)((uint64_t)x >> 32);
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm("" : "+v"(hi));  // keep the next line a 32-bit subtract
+#endif
+  return (int32_t)(hi - (uint32_t)mulhi_s32(t, (int32_t)kb::P));
+}
+// s in (-2^31, 2^31) congruent to a field value  ->  s or s + p, in (-2^24, 2^31): what sbox_rc and the external layer's
+// first S-boxes accept (they only need |s + rc - p| < 0.996 * 2^31)
+KB_HD uint32_t lift_signed(int32_t s) { return (uint32_t)s + ((uint32_t)(s >> 31) & kb::P); }
 
 template <class DiagFn>
-KB_HD void internal_layer(uint32_t s[16], DiagFn diag) {
-  // sum of the 16 lanes: eight unreduced pair sums (< 2p < 2^32), accumulated in 64 bits, one reduction:
-  // acc = q 2^31 + l  =>  acc - q p = q (2^24 - 1) + l < 2p
-  uint64_t acc = (uint64_t)(s[0] + s[1]);
+KB_HD void internal_layer_signed(int32_t s[16], DiagFn diag) {
+  // S = sum of the 16 lanes, |S| < 2^35. With q = round(S / 2^31): S - q p = (S - q 2^31) + q (2^24 - 1) lies in
+  // (-1.25 * 2^30, 1.25 * 2^30), so it is exact in 32-bit wrap-around arithmetic.
+  int64_t acc = (int64_t)s[0] + (1 << 30);
 #pragma unroll
-  for (int i = 2; i < 16; i += 2) acc_add(acc, s[i] + s[i + 1]);
-  uint32_t q = (uint32_t)(acc >> 31);
-  uint32_t r = (uint32_t)acc - q * kb::P;
-  uint32_t sum = kb::umin32(r, r - kb::P);
-  // s_i <- s_i * V_i + sum. Where V_i costs more than one doubling, the addition rides inside the Montgomery
-  // reduction: (s_i V_i + sum * R) / R = s_i V_i / R + sum, one 64-bit multiply-add and one reduction.
-  const uint64_t sum_r = (uint64_t)sum * kb::ONE;
-  s[0] = kb::sub(sum, kb::dbl(s[0]));                 // -2
-  s[1] = kb::add(sum, s[1]);                          //  1
-  s[2] = kb::add(sum, kb::dbl(s[2]));                 //  2
-  s[3] = kb::add(sum, half(s[3]));                    //  1/2
-  s[4] = kb::monty_reduce((uint64_t)s[4] * diag(4) + sum_r);   //  3
-  s[5] = kb::monty_reduce((uint64_t)s[5] * diag(5) + sum_r);   //  4
-  s[6] = kb::sub(sum, half(s[6]));                    // -1/2
-  s[7] = kb::monty_reduce((uint64_t)s[7] * diag(7) + sum_r);   // -3
-  s[8] = kb::monty_reduce((uint64_t)s[8] * diag(8) + sum_r);   // -4
+  for (int i = 1; i < 16; i++) acc_add_signed(acc, s[i]);
+  const uint32_t q = (uint32_t)(acc >> 31);
+  const int32_t sum = (int32_t)((uint32_t)acc - q * kb::P - (1u << 30));
+  const int64_t sum_r = (int64_t)sum * (int64_t)kb::ONE;  // sum * R: rides inside the reduction below
 #pragma unroll
-  for (int i = 9; i < 16; i++) s[i] = kb::monty_reduce((uint64_t)s[i] * diag(i) + sum_r);
+  for (int i = 0; i < 16; i++) {
+    s[i] = monty_reduce_signed(mad_i64_i32_uniform(s[i], diag(i), sum_r));  // diag(i): wave-uniform table entry
+#if defined(__HIP_DEVICE_COMPILE__)
+    if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // four 64-bit products in flight, not sixteen: 24 fewer VGPRs
+#endif
+  }
 }
 
 template <class RcExt, class RcInt, class DiagFn>
@@ -125,10 +149,17 @@ KB_HD void permute_impl(uint32_t s[16], RcExt rc_ext, RcInt rc_int, DiagFn diag)
     for (int i = 0; i < 16; i++) s[i] = sbox_rc(s[i], rc[i]);
     external_layer(s);
   }
+  {
+    int32_t t[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) t[i] = (int32_t)s[i];
 #pragma unroll 1
-  for (int r = 0; r < 13; r++) {
-    s[0] = sbox_rc(s[0], rc_int(r));
-    internal_layer(s, diag);
+    for (int r = 0; r < 13; r++) {
+      t[0] = sbox_rc_signed(lift_signed(t[0]), rc_int(r));  // stays signed: the layer below takes it as it is
+      internal_layer_signed(t, diag);
+    }
+#pragma unroll
+    for (int i = 0; i < 16; i++) s[i] = lift_signed(t[i]);
   }
 #pragma unroll
   for (int r = 4; r < 8; r++) {
