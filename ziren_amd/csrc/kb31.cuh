@@ -63,6 +63,45 @@ KB_HD uint32_t mul_signed(uint32_t d_twos_complement, uint32_t b) {
   const uint32_t r = (uint32_t)((int32_t)(x >> 32) - uhi);
   return umin32(r, r + P);
 }
+// ---- signed (unreduced) arithmetic: values kept as int32 words congruent to the field element, |v| < 2^31 -----------
+KB_HD int32_t mulhi_s32(int32_t a, int32_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __mulhi(a, b);
+#else
+  return (int32_t)(((int64_t)a * b) >> 32);
+#endif
+}
+// a * b + c, signed 32 x 32 + 64: one v_mad_i64_i32 on the device. Pinned with inline asm: left to itself the compiler
+// sometimes expands the 64-bit product into an unsigned multiply plus sign fix-ups (three to four instructions).
+KB_HD int64_t mad_i64_i32(int32_t a, int32_t b, int64_t c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  int64_t r;
+  asm("v_mad_i64_i32 %0, vcc, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c) : "vcc");
+  return r;
+#else
+  return (int64_t)a * (int64_t)b + c;
+#endif
+}
+// the same with a wave-uniform b in [0, 2^31) (a constant or a table entry with a uniform index): b stays in an SGPR
+KB_HD int64_t mad_i64_i32_uniform(int32_t a, uint32_t b_uniform, int64_t c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  int64_t r;
+  asm("v_mad_i64_i32 %0, vcc, %1, %2, %3" : "=v"(r) : "v"(a), "s"(b_uniform), "v"(c) : "vcc");
+  return r;
+#else
+  return (int64_t)a * (int64_t)(int32_t)b_uniform + c;
+#endif
+}
+// x in (-2^31 p, 2^31 p)  ->  (x - t p) / 2^32 with t = x p^-1 mod 2^32 taken as a signed word: congruent to x / R,
+// |result| <= |x| / 2^32 + p / 2, no correction to [0, p)
+KB_HD int32_t monty_reduce_signed(int64_t x) {
+  const int32_t t = (int32_t)((uint32_t)x * MU);
+  uint32_t hi = (uint32_t)((uint64_t)x >> 32);
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm("" : "+v"(hi));  // keep the next line a 32-bit subtract (the optimiser otherwise widens it to a borrow chain)
+#endif
+  return (int32_t)(hi - (uint32_t)mulhi_s32(t, (int32_t)P));
+}
 KB_HD uint32_t to_monty(uint32_t canonical) { return mul(canonical, R2); }
 KB_HD uint32_t from_monty(uint32_t m) { return monty_reduce((uint64_t)m); }
 

@@ -49,9 +49,15 @@ __device__ __forceinline__ uint32_t phys(uint32_t i) { return PAD ? i + (i >> 5)
 // 32-bit lane offset) need no sign extension or 64-bit address math.
 // R radix-2 stages (s0 .. s0+R-1) on the 2^R points a thread holds in registers; `lo` is the group's offset
 // inside its butterfly span (the low logm2 bits of the group index).
-template <bool DIF, int R>
+// LAZY (DIT only): the points are int32 words congruent to the field elements, |v| < 2^31, and stay that way from
+// stage to stage: a + w b and a - w b are the signed Montgomery reductions of a R + b w and a R - b w (R mod p = ONE),
+// two multiply-adds and two three-instruction reductions per butterfly instead of a full multiply and two modular
+// additions (10 instructions instead of 12). Bound: |out| <= (|a| ONE + |b| w) / 2^32 + p / 2, i.e. in units of 2^31
+// X <- 0.50390625 X + 0.49609375, which stays below 1 for any number of stages when the inputs are reduced.
+template <bool DIF, int R, bool LAZY = false>
 __device__ __forceinline__ void butterflies(uint32_t (&x)[1 << R], uint32_t n, uint32_t s0, uint32_t lo, uint32_t logm2,
                                             const uint32_t* __restrict__ tw) {
+  static_assert(!(DIF && LAZY), "the lazy form exists for the DIT butterfly only");
 #pragma unroll
   for (int qq = 0; qq < R; qq++) {
     const uint32_t q = DIF ? qq : R - 1 - qq;
@@ -67,6 +73,10 @@ __device__ __forceinline__ void butterflies(uint32_t (&x)[1 << R], uint32_t n, u
       if (DIF) {
         x[j0] = kb::add(a, b);
         x[j1] = kb::mul_signed(a - b, w);
+      } else if (LAZY) {
+        const int64_t ar = kb::mad_i64_i32_uniform((int32_t)a, kb::ONE, 0);
+        x[j0] = (uint32_t)kb::monty_reduce_signed(kb::mad_i64_i32((int32_t)b, (int32_t)w, ar));
+        x[j1] = (uint32_t)kb::monty_reduce_signed(kb::mad_i64_i32(-(int32_t)b, (int32_t)w, ar));
       } else {
         b = kb::mul(b, w);
         x[j0] = kb::add(a, b);
@@ -76,7 +86,7 @@ __device__ __forceinline__ void butterflies(uint32_t (&x)[1 << R], uint32_t n, u
   }
 }
 
-template <bool DIF, int R, bool PAD>
+template <bool DIF, int R, bool PAD, bool LAZY = false>
 __device__ __forceinline__ void ntt_pass(uint32_t* buf, uint32_t logn, uint32_t lognb, uint32_t istride, uint32_t s0,
                                          const uint32_t* __restrict__ tw, uint32_t tid = threadIdx.x) {
   const uint32_t n = 1u << logn;
@@ -89,7 +99,7 @@ __device__ __forceinline__ void ntt_pass(uint32_t* buf, uint32_t logn, uint32_t 
     uint32_t x[1 << R];
 #pragma unroll
     for (uint32_t j = 0; j < (1u << R); j++) x[j] = buf[phys<PAD>(base + (j << logm2)) * istride + t];
-    butterflies<DIF, R>(x, n, s0, lo, logm2, tw);
+    butterflies<DIF, R, LAZY>(x, n, s0, lo, logm2, tw);
 #pragma unroll
     for (uint32_t j = 0; j < (1u << R); j++) buf[phys<PAD>(base + (j << logm2)) * istride + t] = x[j];
   }
@@ -326,16 +336,16 @@ __global__ __launch_bounds__(THREADS, 4) void lde_rows_big(const uint32_t* __res
       work[phys<true>(2 * g + 1)] = kb::sub(a, b);
     }
     __syncthreads();
-    ntt_pass<false, 4, true>(work, LB, 0, 1, 8, tw_fwd, lt);
-    ntt_pass<false, 4, true>(work, LB, 0, 1, 4, tw_fwd, lt);
+    ntt_pass<false, 4, true, true>(work, LB, 0, 1, 8, tw_fwd, lt);  // lazy from here to the store
+    ntt_pass<false, 4, true, true>(work, LB, 0, 1, 4, tw_fwd, lt);
 #pragma unroll
     for (uint32_t q = 0; q < 16; q++) x[q] = work[phys<true>(lt + (q << 9))];
-    butterflies<false, 4>(x, B, 0, lt, 9, tw_fwd);
+    butterflies<false, 4, true>(x, B, 0, lt, 9, tw_fwd);
     uint32_t* dst = out + (size_t)j * out_coset_stride + c * out_col_stride + (size_t)k1 * B;  // row k1: natural order for lde_cols<true>
     uint32_t t = st0;
 #pragma unroll
     for (uint32_t q = 0; q < 16; q++) {
-      dst[lt + (q << 9)] = kb::mul(x[q], t);
+      dst[lt + (q << 9)] = kb::mul_signed(x[q], t);  // brings the lazy value back to [0, p)
       t = kb::mul(t, st_step);
     }
     sj = kb::mul(sj, w_N);

@@ -49,13 +49,6 @@ KB_HD void external_layer(uint32_t s[16]) {
 
 KB_HD uint32_t sbox(uint32_t x) { return kb::mul(kb::sqr(x), x); }
 
-KB_HD int32_t mulhi_s32(int32_t a, int32_t b) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  return __mulhi(a, b);
-#else
-  return (int32_t)(((int64_t)a * b) >> 32);
-#endif
-}
 // (s + rc)^3 with the round-constant addition and both intermediate corrections folded away:
 // `rcm` = rc - p (two's complement), so y = s + rcm lies in [-p, p) as a signed word; a signed Montgomery
 // step maps x in (-p^2, p^2) to (x - t p) / 2^32 in (-p, p) with t = x * p^-1 taken as a signed word,
@@ -69,10 +62,10 @@ KB_HD int32_t sbox_rc_signed(uint32_t s, uint32_t rcm) {
 #if defined(__HIP_DEVICE_COMPILE__)
   asm("" : "+v"(hi1));  // keep the next line a 32-bit subtract (the optimiser otherwise widens it to a borrow chain)
 #endif
-  const int32_t z = (int32_t)(hi1 - (uint32_t)mulhi_s32(t1, (int32_t)kb::P));
+  const int32_t z = (int32_t)(hi1 - (uint32_t)kb::mulhi_s32(t1, (int32_t)kb::P));
   const int64_t x2 = (int64_t)z * y;
   const int32_t t2 = (int32_t)((uint32_t)x2 * kb::MU);
-  return (int32_t)((uint32_t)((uint64_t)x2 >> 32) - (uint32_t)mulhi_s32(t2, (int32_t)kb::P));  // in (-p, p)
+  return (int32_t)((uint32_t)((uint64_t)x2 >> 32) - (uint32_t)kb::mulhi_s32(t2, (int32_t)kb::P));  // in (-p, p)
 }
 KB_HD uint32_t sbox_rc(uint32_t s, uint32_t rcm) {
   const uint32_t r = (uint32_t)sbox_rc_signed(s, rcm);
@@ -93,27 +86,6 @@ KB_HD void acc_add_signed(int64_t& acc, int32_t x) {
   acc += x;
 #endif
 }
-// a * b + c with a signed 32-bit a, a wave-uniform b in [0, 2^31) and a signed 64-bit c: one v_mad_i64_i32 on the device
-// (left to itself the compiler sometimes expands this into an unsigned multiply plus sign fix-ups: 190 instead of 98
-// instructions per partial round in hash_leaves)
-KB_HD int64_t mad_i64_i32_uniform(int32_t a, uint32_t b_uniform, int64_t c) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  int64_t r;
-  asm("v_mad_i64_i32 %0, vcc, %1, %2, %3" : "=v"(r) : "v"(a), "s"(b_uniform), "v"(c) : "vcc");
-  return r;
-#else
-  return (int64_t)a * (int64_t)(int32_t)b_uniform + c;
-#endif
-}
-// x in (-2^31 p, 2^31 p)  ->  (x - t p) / 2^32 with t = x p^-1 mod 2^32 taken as a signed word; |result| <= (|x| / 2^32 + p / 2)
-KB_HD int32_t monty_reduce_signed(int64_t x) {
-  const int32_t t = (int32_t)((uint32_t)x * kb::MU);
-  uint32_t hi = (uint32_t)((uint64_t)x >> 32);
-#if defined(__HIP_DEVICE_COMPILE__)
-  asm("" : "+v"(hi));  // keep the next line a 32-bit subtract
-#endif
-  return (int32_t)(hi - (uint32_t)mulhi_s32(t, (int32_t)kb::P));
-}
 // s in (-2^31, 2^31) congruent to a field value  ->  s or s + p, in (-2^24, 2^31): what sbox_rc and the external layer's
 // first S-boxes accept (they only need |s + rc - p| < 0.996 * 2^31)
 KB_HD uint32_t lift_signed(int32_t s) { return (uint32_t)s + ((uint32_t)(s >> 31) & kb::P); }
@@ -130,7 +102,7 @@ KB_HD void internal_layer_signed(int32_t s[16], DiagFn diag) {
   const int64_t sum_r = (int64_t)sum * (int64_t)kb::ONE;  // sum * R: rides inside the reduction below
 #pragma unroll
   for (int i = 0; i < 16; i++) {
-    s[i] = monty_reduce_signed(mad_i64_i32_uniform(s[i], diag(i), sum_r));  // diag(i): wave-uniform table entry
+    s[i] = kb::monty_reduce_signed(kb::mad_i64_i32_uniform(s[i], diag(i), sum_r));  // diag(i): wave-uniform table entry
 #if defined(__HIP_DEVICE_COMPILE__)
     if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // four 64-bit products in flight, not sixteen: 24 fewer VGPRs
 #endif
