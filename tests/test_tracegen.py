@@ -208,3 +208,26 @@ def test_gpu_byte_table_and_multiplicities(hip_ctx, oracle):
         m2 = hip_ctx.tracegen_byte_mults(blu)   # the accumulator is left unchanged
         assert np.array_equal(m2.to_host(), oracle.tracegen_byte_mults(streams)), n
         m.free(); m2.free(); blu.free()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("chip", [E.CHIP_ADD_SUB, E.CHIP_SHIFT_RIGHT])
+def test_gpu_tracegen_full_size(hip_ctx, oracle, chip):
+    """BASELINE-sized traces (2^22 rows): rows and byte-lookup counts against the oracle, from page-locked events."""
+    n = (1 << 22) - 12345
+    ev = E.synthetic_alu_events(chip, n, seed=22)
+    pinned = hip_ctx.host_alloc((n * 7,))
+    pinned[...] = ev.view(np.uint32).reshape(-1)
+    blu = hip_ctx.byte_lookups()
+    m = hip_ctx.tracegen_alu(chip, pinned.view(E.ALU_EVENT), 22, blu)
+    assert (m.height, m.width) == (1 << 22, E.CHIP_WIDTH[chip])
+    got = m.to_host()
+    m.free()
+    want = oracle.tracegen_alu(chip, ev, 22)
+    assert np.array_equal(got, want)
+    del got, want
+    mults = hip_ctx.tracegen_byte_mults(blu)
+    assert np.array_equal(mults.to_host(), oracle.tracegen_byte_mults([(chip, ev)]))
+    mults.free(); blu.free()
+    hip_ctx.host_free(pinned)
+    hip_ctx.trim()
