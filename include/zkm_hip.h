@@ -252,6 +252,18 @@ void zkm_byte_lookups_free(zkm_ctx* ctx, zkm_byte_lookups* blu);
 int zkm_tracegen_alu(zkm_ctx* ctx, int chip, const zkm_alu_event* events, size_t n_events,
                      int fixed_log2_rows, zkm_byte_lookups* blu, zkm_matrix** out);
 
+/* The Jump chip (crates/core/machine/src/control_flow/jump/): its events are JumpEvents, byte-for-byte the
+ * #[repr(C)] struct of crates/core/executor/src/events/instr.rs:200-217. 66 columns (columns.rs:11-39), zero padding
+ * rows, no byte lookups. Same contract as zkm_tracegen_alu otherwise. */
+typedef struct zkm_jump_event {
+  uint32_t pc, next_pc, next_next_pc;
+  uint8_t opcode, _pad[3];
+  uint32_t a, b, c;
+} zkm_jump_event;
+size_t zkm_tracegen_jump_width(void);
+int zkm_tracegen_jump(zkm_ctx* ctx, const zkm_jump_event* events, size_t n_events, int fixed_log2_rows,
+                      zkm_matrix** out);
+
 /* ByteChip::trace() — the Byte chip's preprocessed table, 65536 x 12, row (b << 8 | c)
  * (crates/core/machine/src/bytes/mod.rs:31-104, columns bytes/columns.rs:12-46), generated on the device. */
 int zkm_tracegen_byte_table(zkm_ctx* ctx, zkm_matrix** out);

@@ -398,4 +398,14 @@ int orc_tracegen_byte_mults(size_t n_streams, const int* chips, const void* cons
   ORC_CATCH
 }
 
+// Jump chip (JumpEvent records, 28 bytes): row-major Montgomery trace, 66 columns
+int orc_tracegen_jump(const void* events, size_t n_events, int fixed_log2_rows, uint32_t* out, size_t out_cap) {
+  ORC_TRY
+  size_t h;
+  std::vector<F> t = tracegen::generate_jump((const tracegen::JumpEvent*)events, n_events, fixed_log2_rows, &h);
+  if (t.size() > out_cap) throw std::runtime_error("trace buffer too small");
+  for (size_t i = 0; i < t.size(); i++) out[i] = to_monty(t[i]);
+  ORC_CATCH
+}
+
 }  // extern "C"

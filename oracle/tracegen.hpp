@@ -16,6 +16,8 @@
 //   ShiftLeft   sll/mod.rs:70-104, :232-287; padding rows are the template of :157-165
 //   ShiftRight  sr/mod.rs:88-137, :232-339; padding rows set shift_by_n_bits[0] = shift_by_n_bytes[0] = 1 (:183-186)
 //   CloClz      clo_clz/mod.rs:41-63, :105-133; padding rows a = 32, is_bb_zero = 1 (:147-163)
+//   Jump        crates/core/machine/src/control_flow/jump/columns.rs:11-39, trace.rs:92-113 (JumpEvent, not AluEvent),
+//               operations/koala_bear_word.rs:9-42 (the word range checker); zero padding
 // Row count: utils/mod.rs next_power_of_two — 2^fixed_log2_rows when the shape fixes it, else the next power of
 // two, at least 16. Event layout: #[repr(C)] AluEvent, crates/core/executor/src/events/instr.rs:10-26; opcode
 // numbers crates/core/executor/src/opcode.rs:26-48.
@@ -220,6 +222,47 @@ static inline void clo_clz_row(const AluEvent& e, F* r) {
 static inline void clo_clz_padding(F* r) {
   r[2] = 32;  // a = Word::from(32)
   r[14] = 1;  // is_bb_zero
+}
+
+// ---- Jump chip: JumpEvent (crates/core/executor/src/events/instr.rs:200-217) ---------------------------------------
+struct JumpEvent {
+  uint32_t pc, next_pc, next_next_pc;
+  uint8_t opcode, _pad[3];
+  uint32_t a, b, c;
+};
+static_assert(sizeof(JumpEvent) == 28, "JumpEvent is seven words");
+enum { OP_JUMP = 27, OP_JUMPI = 28, OP_JUMPDIRECT = 29 };
+static const size_t JUMP_WIDTH = 66;
+
+// KoalaBearWordRangeChecker::populate (operations/koala_bear_word.rs:27-42): 14 columns
+static inline void range_checker(F* r, uint32_t value) {
+  for (int i = 0; i < 8; i++) r[i] = (value >> (24 + i)) & 1;
+  r[8] = r[0] * r[1];
+  for (int i = 0; i < 5; i++) r[9 + i] = r[8 + i] * r[2 + i];
+}
+static inline void jump_row(const JumpEvent& e, F* r) {
+  enum { PC = 0, NEXT_PC = 1, NEXT_PC_RC = 5, NEXT_NEXT_PC = 19, NEXT_NEXT_PC_RC = 23, OP_A = 37, OP_B = 41, OP_C = 45, IS_JUMP = 49,
+         IS_JUMPI = 50, IS_JUMPDIRECT = 51, OP_A_RC = 52 };
+  r[PC] = fu32(e.pc);
+  r[IS_JUMP] = e.opcode == OP_JUMP;
+  r[IS_JUMPI] = e.opcode == OP_JUMPI;
+  r[IS_JUMPDIRECT] = e.opcode == OP_JUMPDIRECT;
+  word(r + OP_A, e.a);
+  word(r + OP_B, e.b);
+  word(r + OP_C, e.c);
+  range_checker(r + OP_A_RC, e.a);
+  word(r + NEXT_PC, e.next_pc);
+  range_checker(r + NEXT_PC_RC, e.next_pc);
+  word(r + NEXT_NEXT_PC, e.next_next_pc);
+  range_checker(r + NEXT_NEXT_PC_RC, e.next_next_pc);
+}
+static inline std::vector<F> generate_jump(const JumpEvent* events, size_t n_events, int fixed_log2_rows, size_t* height) {
+  const size_t h = padded_rows(n_events, fixed_log2_rows);
+  std::vector<F> t(h * JUMP_WIDTH, 0);
+#pragma omp parallel for schedule(static)
+  for (size_t i = 0; i < n_events; i++) jump_row(events[i], t.data() + i * JUMP_WIDTH);
+  *height = h;
+  return t;
 }
 
 // The reference's own sanity identities (debug_assert / assert in the row builders); returns false when one fails.

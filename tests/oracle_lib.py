@@ -227,3 +227,14 @@ def tracegen_byte_mults(streams, extra_counts=None):
     _check(lib().orc_tracegen_byte_mults(C.c_size_t(len(streams)), chips, ptrs, ns,
                                          abi.as_u32p(ex) if ex is not None else None, abi.as_u32p(out)))
     return out
+
+
+def tracegen_jump(jump_events, fixed_log2_rows=-1):
+    from ziren_amd import events as E
+    ev = np.ascontiguousarray(jump_events, dtype=E.JUMP_EVENT)
+    rows = C.c_size_t()
+    _check(lib().orc_tracegen_alu_rows(C.c_size_t(len(ev)), C.c_int(fixed_log2_rows), C.byref(rows)))
+    out = np.zeros((rows.value, E.JUMP_WIDTH), dtype=np.uint32)
+    _check(lib().orc_tracegen_jump(C.c_void_p(ev.ctypes.data), C.c_size_t(len(ev)), C.c_int(fixed_log2_rows), abi.as_u32p(out),
+                                   C.c_size_t(out.size)))
+    return out

@@ -25,6 +25,17 @@ def test_constraints_hold_on_generated_rows(oracle, chip):
     assert air.debug_constraints(rec.b, t) == []
 
 
+def test_jump_constraints_hold(oracle):
+    rec = chips.record_jump_constraints()
+    for n in (0, 64, 3000):
+        t = F.from_monty(oracle.tracegen_jump(E.synthetic_jump_events(n, seed=n + 1)))
+        assert air.debug_constraints(rec.b, t) == []
+    t = t.copy()
+    t[5, 23] ^= 1            # a bit of next_next_pc's range checker
+    assert {row for _, row in air.debug_constraints(rec.b, t)} == {5}
+    assert [lk.kind for lk in rec.sends] == [air.KIND_INSTRUCTION] and len(rec.receives) == 1
+
+
 def test_constraints_hold_on_reference_vectors(oracle):
     for chip, ev in golden_events().items():
         if chip == E.CHIP_BITWISE:
@@ -86,19 +97,30 @@ def test_to_virtual_pair_rejects_products():
 # ---- GPU ------------------------------------------------------------------------------------------------------------
 
 def alu_shard(oracle, log_rows, seed=11):
-    """Six real chips; AddSub at 2^log_rows rows, the others smaller; every trace also as oracle rows. The SRL events
-    the executor derives from the CLO/CLZ instructions go to the ShiftRight chip (dependencies.rs:105-122)."""
+    """Seven real chips (six ALU chips + Jump); AddSub at 2^log_rows rows, the others smaller; every trace also as oracle
+    rows. The SRL events the executor derives from CLO/CLZ go to the ShiftRight chip (dependencies.rs:105-122), the ADD
+    events it derives from JumpDirect to the AddSub chip."""
     spec = [(E.CHIP_ADD_SUB, log_rows, 0.9), (E.CHIP_BITWISE, log_rows - 1, 1.0), (E.CHIP_LT, log_rows - 1, 0.7),
             (E.CHIP_SHIFT_LEFT, log_rows - 2, 0.55), (E.CHIP_SHIFT_RIGHT, log_rows - 2, 0.6), (E.CHIP_CLO_CLZ, log_rows - 3, 0.8)]
     streams = {chip: E.synthetic_alu_events(chip, int((1 << lh) * fill), seed=seed + chip) for chip, lh, fill in spec}
+    jumps = E.synthetic_jump_events(int((1 << (log_rows - 3)) * 0.75), seed=seed + 40)
     streams[E.CHIP_SHIFT_RIGHT] = np.concatenate([streams[E.CHIP_SHIFT_RIGHT], E.cloclz_dependencies(streams[E.CHIP_CLO_CLZ])])
+    streams[E.CHIP_ADD_SUB] = np.concatenate([streams[E.CHIP_ADD_SUB], E.jump_dependencies(jumps)])   # dependencies.rs:230-248
     recs, evs = [], []
     for chip, lh, _ in spec:
         rc = chips.record_chip(chip, lh)
         rc.trace = oracle.tracegen_alu(chip, streams[chip], lh)
         recs.append(rc)
         evs.append((chip, streams[chip], lh))
+    jc = chips.record_jump_chip(log_rows - 3)
+    jc.trace = oracle.tracegen_jump(jumps, log_rows - 3)
+    recs.append(jc)
+    evs.append(("jump", jumps, log_rows - 3))
     return recs, evs
+
+
+def device_trace(ctx, chip, ev, lh, blu=None):
+    return ctx.tracegen_jump(ev, lh) if chip == "jump" else ctx.tracegen_alu(chip, ev, lh, blu)
 
 
 def mirror_chip(rec, kinds=None):
@@ -151,12 +173,12 @@ def test_gpu_alu_shard_proof(hip_ctx, oracle, log_rows, queries, pow_bits):
     pc_start = F.to_monty(0x400000)
     hp = prover.HipProver(recs, fri, synth.NUM_PV_ELTS, ctx=hip_ctx)
     if log_rows > 8:
-        hp.specialize_quotient_kernels(recs[:6])   # the real chips through generated kernels, the mirrors interpreted
+        hp.specialize_quotient_kernels(recs[:7])   # the real chips through generated kernels, the mirrors interpreted
     pk = hp.setup([], [], pc_start, igcs)
     ch = prover.new_challenger()
     pk.observe_into(ch)
     start = ch.copy()
-    born = [hip_ctx.tracegen_alu(chip, ev, lh) for chip, ev, lh in evs]   # the ALU traces never exist on the host
+    born = [device_trace(hip_ctx, chip, ev, lh) for chip, ev, lh in evs]   # these traces never exist on the host
     born += [hip_ctx.upload(m.trace) for m in mirrors]
     proof = hp.prove_shard(pk, pv, born, ch).copy()
     # oracle: the same recorded chips over the oracle's own rows
@@ -179,7 +201,7 @@ def test_gpu_alu_and_byte_chips_shard(hip_ctx, oracle):
     from ziren_amd import prover, synth
     log_rows = 11
     recs, evs = alu_shard(oracle, log_rows, seed=21)
-    streams = [(chip, ev) for chip, ev, _ in evs]
+    streams = [(chip, ev) for chip, ev, _ in evs if chip != "jump"]
     byte = chips.record_byte_chip(prep_index=0)
     byte.trace = oracle.tracegen_byte_mults(streams)
     byte.prep_trace = oracle.tracegen_byte_table()
@@ -198,7 +220,7 @@ def test_gpu_alu_and_byte_chips_shard(hip_ctx, oracle):
     pk.observe_into(ch)
     start = ch.copy()
     blu = hip_ctx.byte_lookups()
-    born = [hip_ctx.tracegen_alu(chip, ev, lh, blu) for chip, ev, lh in evs]   # traces + byte lookups in one pass
+    born = [device_trace(hip_ctx, chip, ev, lh, blu) for chip, ev, lh in evs]   # traces + byte lookups in one pass
     born.append(hip_ctx.tracegen_byte_mults(blu))
     born += [hip_ctx.upload(m.trace) for m in mirrors]
     proof = hp.prove_shard(pk, pv, born, ch).copy()
@@ -208,9 +230,9 @@ def test_gpu_alu_and_byte_chips_shard(hip_ctx, oracle):
     assert np.array_equal(proof, oproof)
     assert oracle.verify_shard(opk, all_chips, fri, synth.NUM_PV_ELTS, start.copy(), proof) == 0
     # without the Byte chip's multiplicities the byte lookups do not balance: the verifier's cumulative-sum check fails
-    born[6].free()
+    born[7].free()
     empty = hip_ctx.byte_lookups()
-    born[6] = hip_ctx.tracegen_byte_mults(empty)
+    born[7] = hip_ctx.tracegen_byte_mults(empty)
     ch2 = start.copy()
     bad = hp.prove_shard(pk, pv, born, ch2).copy()
     assert oracle.verify_shard(opk, all_chips, fri, synth.NUM_PV_ELTS, start.copy(), bad) != 0

@@ -231,3 +231,32 @@ def test_gpu_tracegen_full_size(hip_ctx, oracle, chip):
     mults.free(); blu.free()
     hip_ctx.host_free(pinned)
     hip_ctx.trim()
+
+
+def test_jump_rows_by_hand(oracle):
+    ev = np.zeros(1, dtype=E.JUMP_EVENT)
+    ev[0] = (0x400, 0x404, 0x7f000000, E.JUMP, [0, 0, 0], 0x408, 0x7f000000, 7)
+    r = canon(oracle.tracegen_jump(ev))
+    assert r.shape == (16, E.JUMP_WIDTH) and not r[1:].any()
+    r = r[0]
+    assert r[0] == 0x400 and r[1:5].tolist() == [4, 4, 0, 0] and r[19:23].tolist() == [0, 0, 0, 0x7f]
+    assert r[37:41].tolist() == [8, 4, 0, 0] and r[41:45].tolist() == [0, 0, 0, 0x7f] and r[45:49].tolist() == [7, 0, 0, 0]
+    assert r[49:52].tolist() == [1, 0, 0]
+    # range checker of next_next_pc = 0x7f000000: bits 0..6 of the top byte set, bit 7 clear, the and-chain all ones
+    assert r[23:31].tolist() == [1, 1, 1, 1, 1, 1, 1, 0] and r[31:37].tolist() == [1, 1, 1, 1, 1, 1]
+    assert r[5:13].tolist() == [0] * 8 and r[13:19].tolist() == [0] * 6
+    deps = E.jump_dependencies(E.synthetic_jump_events(300))
+    assert (deps["pc"] == 1).all() and (deps["a"] == deps["b"] + deps["c"]).all()   # u32 wrap-around add
+
+
+@pytest.mark.gpu
+def test_gpu_jump_tracegen_matches_oracle(hip_ctx, oracle):
+    from ziren_amd import lib
+    assert lib.load().zkm_tracegen_jump_width() == E.JUMP_WIDTH
+    for n, fixed in ((0, -1), (1, -1), (17, -1), (4000, -1), (70001, 17)):
+        ev = E.synthetic_jump_events(n, seed=n + 5)
+        m = hip_ctx.tracegen_jump(ev, fixed)
+        want = oracle.tracegen_jump(ev, fixed)
+        assert (m.height, m.width) == want.shape
+        assert np.array_equal(m.to_host(), want), n
+        m.free()

@@ -98,7 +98,12 @@ class _Rec:
         self.sends.append(air.Lookup([air.to_virtual_pair(v) for v in vals], air.to_virtual_pair(mult), air.KIND_INSTRUCTION))
 
     def receive_alu_instruction(self, pc, next_pc, opcode, a, b, c, mult):
-        vals = [0, 0, pc, next_pc, next_pc + 4, 0, opcode] + list(a) + list(b) + list(c) + [0, 0, 0, 0] + [0, 0, 0, 0, 1]
+        self.receive_instruction(pc, next_pc, next_pc + 4, opcode, a, b, c, 1, mult)
+
+    def receive_instruction(self, pc, next_pc, next_next_pc, opcode, a, b, c, is_sequential, mult):
+        """InstructionAirBuilder::receive_instruction (builder.rs:237-280) with shard, clk, num_extra_cycles, hi,
+        op_a_immutable, is_rw_a, is_check_memory and is_halt zero, as every chip here calls it."""
+        vals = [0, 0, pc, next_pc, next_next_pc, 0, opcode] + list(a) + list(b) + list(c) + [0, 0, 0, 0] + [0, 0, 0, 0, is_sequential]
         self.receives.append(air.Lookup([air.to_virtual_pair(v) for v in vals], air.to_virtual_pair(mult), air.KIND_INSTRUCTION))
 
 
@@ -340,6 +345,49 @@ def _clo_clz(r: _Rec):
     b.when(l[IS_CLZ]).assert_one(l[IS_REAL])
 
 
+def _reduce(b, w):
+    """Word::reduce (crates/stark/src/word.rs:58-63)."""
+    return b.const(1) * w[0] + b.const(1 << 8) * w[1] + b.const(1 << 16) * w[2] + b.const(1 << 24) * w[3]
+
+
+def _word_range_check(b, value, cols, is_real):
+    """KoalaBearWordRangeChecker::range_check (operations/koala_bear_word.rs:44-100): the word is below p."""
+    decomp, ands = cols[:8], cols[8:14]
+    recomposed = b.const(0)
+    for i in range(8):
+        b.when(is_real).assert_bool(decomp[i])
+        recomposed = recomposed + b.const(1 << i) * decomp[i]
+    b.when(is_real).assert_eq(recomposed, value[3])
+    b.when(is_real).assert_zero(decomp[7])
+    b.when(is_real).assert_eq(ands[0], decomp[0] * decomp[1])
+    for i in range(5):
+        b.when(is_real).assert_eq(ands[1 + i], ands[i] * decomp[2 + i])
+    b.when(is_real).when(ands[5]).assert_zero(value[0] + value[1] + value[2])
+
+
+def _jump(r: _Rec):
+    """JumpChip::eval (control_flow/jump/air.rs:21-114)."""
+    l, b = r.local, r.b
+    (PC, NEXT_PC, NEXT_PC_RC, NEXT_NEXT_PC, NEXT_NEXT_PC_RC, OP_A, OP_B, OP_C, IS_JUMP, IS_JUMPI, IS_JUMPDIRECT,
+     OP_A_RC) = 0, 1, 5, 19, 23, 37, 41, 45, 49, 50, 51, 52
+    next_pc, next_next_pc = l[NEXT_PC:NEXT_PC + 4], l[NEXT_NEXT_PC:NEXT_NEXT_PC + 4]
+    op_a, op_b, op_c = l[OP_A:OP_A + 4], l[OP_B:OP_B + 4], l[OP_C:OP_C + 4]
+    b.assert_bool(l[IS_JUMP])
+    b.assert_bool(l[IS_JUMPI])
+    b.assert_bool(l[IS_JUMPDIRECT])
+    is_real = l[IS_JUMP] + l[IS_JUMPI] + l[IS_JUMPDIRECT]
+    b.assert_bool(is_real)
+    opcode = l[IS_JUMP] * E.JUMP + l[IS_JUMPI] * E.JUMPI + l[IS_JUMPDIRECT] * E.JUMPDIRECT
+    r.receive_instruction(l[PC], _reduce(b, next_pc), _reduce(b, next_next_pc), opcode, op_a, op_b, op_c, 0, is_real)
+    b.when(is_real).assert_eq(_reduce(b, op_a), _reduce(b, next_pc) + 4)
+    _word_range_check(b, op_a, l[OP_A_RC:OP_A_RC + 14], is_real)
+    _word_range_check(b, next_pc, l[NEXT_PC_RC:NEXT_PC_RC + 14], is_real)
+    _word_range_check(b, next_next_pc, l[NEXT_NEXT_PC_RC:NEXT_NEXT_PC_RC + 14], is_real)
+    for i in range(4):   # assert_word_eq under when(is_jump + is_jumpi)
+        b.when(l[IS_JUMP] + l[IS_JUMPI]).assert_eq(next_next_pc[i], op_b[i])
+    r.send_alu(E.ADD, next_next_pc, next_pc, op_b, l[IS_JUMPDIRECT])
+
+
 def _byte(r: _Rec):
     """ByteChip::eval (bytes/air.rs:20-74): one receive per ByteOpcode, in ByteOpcode::all() order."""
     m, t = r.local, r.prep
@@ -398,3 +446,22 @@ def record_byte_chip(prep_index: int = 0) -> RecordedChip:
     return RecordedChip(name="Byte", log_height=BYTE_LOG_ROWS, main_width=BYTE_MULT_COLS, prep_width=BYTE_PREP_COLS,
                         prep_index=prep_index, log_quotient_degree=lqd, local_only=False, sends=r.sends, receives=r.receives,
                         program=program, lookups_blob=air.encode_lookups(r.sends, r.receives), num_constraints=int(program[2]))
+
+
+def record_jump_chip(log_height: int) -> RecordedChip:
+    """The Jump chip (crates/core/machine/src/control_flow/jump/): JumpEvents, 66 columns, local_only (trace.rs:87-89)."""
+    r = _Rec(E.JUMP_WIDTH)
+    _jump(r)
+    lqd = 1
+    r.b.perm_ext_width = air.local_permutation_trace_width(len(r.sends) + len(r.receives), 1 << lqd)
+    air.eval_permutation_constraints(r.b, r.sends, r.receives, 1 << lqd, False)
+    program = r.b.assemble()
+    return RecordedChip(name="Jump", log_height=log_height, main_width=E.JUMP_WIDTH, log_quotient_degree=lqd, local_only=True,
+                        sends=r.sends, receives=r.receives, program=program,
+                        lookups_blob=air.encode_lookups(r.sends, r.receives), num_constraints=int(program[2]))
+
+
+def record_jump_constraints() -> _Rec:
+    r = _Rec(E.JUMP_WIDTH)
+    _jump(r)
+    return r

@@ -10,6 +10,8 @@
 //   ShiftLeft   sll/mod.rs:70-104, :232-287, padding rows :157-165
 //   ShiftRight  sr/mod.rs:88-137, :232-339, padding rows :183-186
 //   CloClz      clo_clz/mod.rs:41-63, :105-133, padding rows :147-163
+// and for the Jump chip (JumpEvents): crates/core/machine/src/control_flow/jump/columns.rs:11-39, trace.rs:92-113,
+// operations/koala_bear_word.rs:27-42.
 // Values are stored in Montgomery form, the in-memory form of the reference's KoalaBear (RowMajorMatrix<KoalaBear>).
 #pragma once
 #include "kb31.cuh"
@@ -24,10 +26,10 @@ struct AluEvent {  // #[repr(C)] AluEvent, crates/core/executor/src/events/instr
 
 // crates/core/executor/src/opcode.rs:26-48
 enum : uint32_t { ADD = 0, SUB = 1, SLL = 9, SRL = 10, SRA = 11, ROR = 12, SLT = 13, SLTU = 14, AND = 15, OR = 16, XOR = 17, NOR = 18, CLZ = 19, CLO = 20 };
-enum Chip { ADD_SUB = 0, BITWISE = 1, LT = 2, SHIFT_LEFT = 3, SHIFT_RIGHT = 4, CLO_CLZ = 5, NUM_CHIPS = 6 };
+enum Chip { ADD_SUB = 0, BITWISE = 1, LT = 2, SHIFT_LEFT = 3, SHIFT_RIGHT = 4, CLO_CLZ = 5, NUM_ALU_CHIPS = 6, JUMP = 6, NUM_CHIPS = 7 };
 
 __host__ __device__ constexpr int chip_width(int chip) {
-  return chip == ADD_SUB ? 19 : chip == BITWISE ? 18 : chip == LT ? 32 : chip == SHIFT_LEFT ? 44 : chip == SHIFT_RIGHT ? 67 : chip == CLO_CLZ ? 17 : 0;
+  return chip == ADD_SUB ? 19 : chip == BITWISE ? 18 : chip == LT ? 32 : chip == SHIFT_LEFT ? 44 : chip == SHIFT_RIGHT ? 67 : chip == CLO_CLZ ? 17 : chip == JUMP ? 66 : 0;
 }
 
 constexpr int THREADS = 256;
@@ -198,6 +200,34 @@ template <> __device__ __forceinline__ void padding_row<CLO_CLZ>(uint32_t* r) {
   r[14] = 1;  // is_bb_zero
 }
 
+// Jump chip. JumpEvent (crates/core/executor/src/events/instr.rs:200-217) is seven words like AluEvent, laid out
+// pc, next_pc, next_next_pc, opcode, a, b, c; alu_rows hands it over in the AluEvent slots (opcode slot = word 2 etc.),
+// so the fields are re-read here by position.
+__device__ __forceinline__ void range_checker(uint32_t* r, uint32_t value) {  // KoalaBearWordRangeChecker::populate
+#pragma unroll
+  for (int i = 0; i < 8; i++) r[i] = (value >> (24 + i)) & 1;
+  r[8] = r[0] & r[1];
+#pragma unroll
+  for (int i = 0; i < 5; i++) r[9 + i] = r[8 + i] & r[2 + i];
+}
+template <> __device__ __forceinline__ void event_row<JUMP>(const AluEvent& e, uint32_t* r) {
+  enum { PC = 0, NEXT_PC = 1, NEXT_PC_RC = 5, NEXT_NEXT_PC = 19, NEXT_NEXT_PC_RC = 23, OP_A = 37, OP_B = 41, OP_C = 45, IS_JUMP = 49,
+         IS_JUMPI = 50, IS_JUMPDIRECT = 51, OP_A_RC = 52 };
+  const uint32_t pc = e.pc, next_pc = e.next_pc, next_next_pc = e.opcode, opcode = e.hi & 0xff, a = e.a, b = e.b, c = e.c;
+  r[PC] = pc;
+  r[IS_JUMP] = fbool(opcode == 27);
+  r[IS_JUMPI] = fbool(opcode == 28);
+  r[IS_JUMPDIRECT] = fbool(opcode == 29);
+  word(r + OP_A, a);
+  word(r + OP_B, b);
+  word(r + OP_C, c);
+  range_checker(r + OP_A_RC, a);
+  word(r + NEXT_PC, next_pc);
+  range_checker(r + NEXT_PC_RC, next_pc);
+  word(r + NEXT_NEXT_PC, next_next_pc);
+  range_checker(r + NEXT_NEXT_PC_RC, next_next_pc);
+}
+
 // ---- byte lookups: the ALU chips' generate_dependencies, ByteChip::generate_trace and ByteChip::trace -----------------
 // ByteOpcode, crates/core/executor/src/opcode.rs:195-216
 enum : uint32_t { B_AND = 0, B_OR = 1, B_XOR = 2, B_SLL = 3, B_U8RANGE = 4, B_SHRCARRY = 5, B_LTU = 6, B_MSB = 7, B_U16RANGE = 8, B_NOR = 9 };
@@ -278,6 +308,8 @@ template <> __device__ __forceinline__ void row_lookups<CLO_CLZ>(const uint32_t*
   lookup(counts, B_LTU, r[2], 33);       // a < 33
 }
 
+template <> __device__ __forceinline__ void row_lookups<JUMP>(const uint32_t*, uint32_t, const LookupSink&) {}  // none
+
 // events: n_events records of seven words; out: column-major, `height` rows; grid = height / (tiles * THREADS), with
 // tiles = 1 for the plain row writer (most blocks in flight) and TILES_PER_BLOCK when counting.
 // counts (may be null): NUM_BYTE_OPS columns of BYTE_ROWS plain u32 counters; the byte lookups of every event row are
@@ -303,7 +335,7 @@ __global__ __launch_bounds__(THREADS) void alu_rows(const uint32_t* __restrict__
     for (int c = 0; c < W; c++) r[c] = 0;
     if (row < n_events) {
       const uint32_t* p = events + row * 7;
-      AluEvent e{p[0], p[1], p[2] & 0xff, p[3], p[4], p[5], p[6]};
+      AluEvent e{p[0], p[1], CHIP == JUMP ? p[2] : (p[2] & 0xff), p[3], p[4], p[5], p[6]};
       event_row<CHIP>(e, r);
       if (count) row_lookups<CHIP>(r, e.opcode, LookupSink{hkeys, hvals, HASH_SLOTS - 1, counts});
     } else {

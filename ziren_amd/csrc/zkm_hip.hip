@@ -1103,6 +1103,7 @@ int zkm_ctx_create(int device, zkm_ctx** out) {
   HIP_CHECK(hipFuncSetAttribute((const void*)tracegen::alu_rows<tracegen::SHIFT_LEFT>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
   HIP_CHECK(hipFuncSetAttribute((const void*)tracegen::alu_rows<tracegen::SHIFT_RIGHT>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
   HIP_CHECK(hipFuncSetAttribute((const void*)tracegen::alu_rows<tracegen::CLO_CLZ>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+  HIP_CHECK(hipFuncSetAttribute((const void*)tracegen::alu_rows<tracegen::JUMP>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
   HIP_CHECK(hipFuncSetAttribute((const void*)lde::lde_cols<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIP_CHECK(hipFuncSetAttribute((const void*)lde::lde_cols<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIP_CHECK(hipFuncSetAttribute((const void*)stark::quotient_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -1468,16 +1469,16 @@ int zkm_coset_lde_batch(zkm_ctx* ctx, const uint32_t* host, size_t height, size_
 }
 
 // ---- device trace generation (ALU chips) ---------------------------------------------------------------------
-size_t zkm_tracegen_alu_width(int chip) { return (size_t)tracegen::chip_width(chip); }
+size_t zkm_tracegen_alu_width(int chip) { return chip >= 0 && chip < tracegen::NUM_ALU_CHIPS ? (size_t)tracegen::chip_width(chip) : 0; }
 
-int zkm_tracegen_alu(zkm_ctx* ctx, int chip, const zkm_alu_event* events, size_t n_events, int fixed_log2_rows,
-                     zkm_byte_lookups* blu, zkm_matrix** out) {
+static int tracegen_events(zkm_ctx* ctx, int chip, const void* events, size_t n_events, int fixed_log2_rows,
+                           zkm_byte_lookups* blu, zkm_matrix** out) {
   API_BEGIN
-  static_assert(sizeof(zkm_alu_event) == 28, "zkm_alu_event mirrors #[repr(C)] AluEvent");
+  static_assert(sizeof(zkm_alu_event) == 28 && sizeof(zkm_jump_event) == 28, "event records mirror the #[repr(C)] executor structs");
   std::lock_guard<std::mutex> lk(ctx->mu);
   HIP_CHECK(hipSetDevice(ctx->device));
-  if (chip < 0 || chip >= tracegen::NUM_CHIPS) throw std::runtime_error("zkm_tracegen_alu: unknown chip");
-  if (n_events && !events) throw std::runtime_error("zkm_tracegen_alu: null events");
+  if (chip < 0 || chip >= tracegen::NUM_CHIPS) throw std::runtime_error("zkm_tracegen: unknown chip");
+  if (n_events && !events) throw std::runtime_error("zkm_tracegen: null events");
   // utils::next_power_of_two (crates/core/machine/src/utils/mod.rs): the shape's fixed size, else >= 16
   size_t height = 16;
   if (fixed_log2_rows >= 0) {
@@ -1504,6 +1505,7 @@ int zkm_tracegen_alu(zkm_ctx* ctx, int chip, const zkm_alu_event* events, size_t
       case tracegen::SHIFT_LEFT: launch_alu_rows<tracegen::SHIFT_LEFT>(ctx, d_events, n_events, height, m->d, counts); break;
       case tracegen::SHIFT_RIGHT: launch_alu_rows<tracegen::SHIFT_RIGHT>(ctx, d_events, n_events, height, m->d, counts); break;
       case tracegen::CLO_CLZ: launch_alu_rows<tracegen::CLO_CLZ>(ctx, d_events, n_events, height, m->d, counts); break;
+      case tracegen::JUMP: launch_alu_rows<tracegen::JUMP>(ctx, d_events, n_events, height, m->d, counts); break;
     }
     ctx->mark("trace generation");
     ctx->end_timing(false);  // synchronises: the caller's event buffer is free again
@@ -1516,6 +1518,16 @@ int zkm_tracegen_alu(zkm_ctx* ctx, int chip, const zkm_alu_event* events, size_t
   ctx->release(d_events);
   *out = m;
   API_END
+}
+
+int zkm_tracegen_alu(zkm_ctx* ctx, int chip, const zkm_alu_event* events, size_t n_events, int fixed_log2_rows,
+                     zkm_byte_lookups* blu, zkm_matrix** out) {
+  if (chip < 0 || chip >= tracegen::NUM_ALU_CHIPS) { g_err = "zkm_tracegen_alu: unknown chip"; return -1; }
+  return tracegen_events(ctx, chip, events, n_events, fixed_log2_rows, blu, out);
+}
+size_t zkm_tracegen_jump_width(void) { return (size_t)tracegen::chip_width(tracegen::JUMP); }
+int zkm_tracegen_jump(zkm_ctx* ctx, const zkm_jump_event* events, size_t n_events, int fixed_log2_rows, zkm_matrix** out) {
+  return tracegen_events(ctx, tracegen::JUMP, events, n_events, fixed_log2_rows, nullptr, out);
 }
 
 int zkm_tracegen_byte_table(zkm_ctx* ctx, zkm_matrix** out) {

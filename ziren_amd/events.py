@@ -18,7 +18,14 @@ SLL, SRL, SRA, ROR = 9, 10, 11, 12
 SLT, SLTU = 13, 14
 AND, OR, XOR, NOR = 15, 16, 17, 18
 CLZ, CLO = 19, 20
+JUMP, JUMPI, JUMPDIRECT = 27, 28, 29
 UNUSED_PC, DEFAULT_PC_INC = 1, 4  # crates/core/executor/src/executor.rs:44-47
+
+# #[repr(C)] JumpEvent, crates/core/executor/src/events/instr.rs:200-217 (28 bytes as well, different fields)
+JUMP_EVENT = np.dtype([("pc", "<u4"), ("next_pc", "<u4"), ("next_next_pc", "<u4"), ("opcode", "u1"), ("_pad", "u1", (3,)),
+                       ("a", "<u4"), ("b", "<u4"), ("c", "<u4")])
+assert JUMP_EVENT.itemsize == 28
+JUMP_WIDTH = 66
 
 # zkm_alu_chip
 CHIP_ADD_SUB, CHIP_BITWISE, CHIP_LT, CHIP_SHIFT_LEFT, CHIP_SHIFT_RIGHT, CHIP_CLO_CLZ = range(6)
@@ -117,4 +124,40 @@ def cloclz_dependencies(cloclz_events: np.ndarray) -> np.ndarray:
     out["b"] = b
     out["c"] = 31 - a
     out["a"] = b >> (31 - a)
+    return out
+
+
+def synthetic_jump_events(n: int, seed: int = 1) -> np.ndarray:
+    """n jump instructions with the executor's semantics: a = next_pc + 4 (the link value); Jump / Jumpi go to b;
+    JumpDirect goes to next_pc + b (b may be negative). All program counters stay below p, as the chip range-checks."""
+    raw = F.SplitMix64(0x4a4d5000 + seed).next_u64(3 * n)
+    r0, r1, r2 = raw[:n], raw[n:2 * n], raw[2 * n:]
+    ev = np.zeros(n, dtype=JUMP_EVENT)
+    pc = ((r0 % np.uint64(0x3fffff00)) & np.uint64(0xfffffffc)).astype(np.uint32)
+    ev["pc"] = pc
+    ev["next_pc"] = pc + 4
+    ev["opcode"] = np.array([JUMP, JUMPI, JUMPDIRECT], dtype=np.uint8)[(r1 % np.uint64(3)).astype(np.int64)]
+    ev["a"] = ev["next_pc"] + 4
+    target = ((r2 % np.uint64(0x7effff00)) & np.uint64(0xfffffffc)).astype(np.uint32)
+    corner = (r2 >> np.uint64(40)) % np.uint64(16)
+    target = np.where(corner == 0, np.uint32(0x7f000000), target)       # the largest value the range checker accepts
+    target = np.where(corner == 1, np.uint32(0), target)
+    direct = ev["opcode"] == JUMPDIRECT
+    ev["b"] = np.where(direct, target - ev["next_pc"], target)           # offset (wrapping) or absolute target
+    ev["next_next_pc"] = target
+    ev["c"] = (r1 >> np.uint64(32)).astype(np.uint32) & np.uint32(0xffff)
+    return ev
+
+
+def jump_dependencies(jump_events: np.ndarray) -> np.ndarray:
+    """The ADD events the executor adds to `add_sub_events` for JumpDirect (emit_jump_dependencies,
+    crates/core/executor/src/dependencies.rs:230-248): they carry the Jump chip's `send_alu` to the AddSub chip."""
+    ev = jump_events[jump_events["opcode"] == JUMPDIRECT]
+    out = np.zeros(len(ev), dtype=ALU_EVENT)
+    out["pc"] = UNUSED_PC
+    out["next_pc"] = UNUSED_PC + DEFAULT_PC_INC
+    out["opcode"] = ADD
+    out["b"] = ev["next_pc"]
+    out["c"] = ev["b"]
+    out["a"] = ev["next_pc"] + ev["b"]
     return out

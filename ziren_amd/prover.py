@@ -92,6 +92,16 @@ class Context:
         L = lib.load()
         return DeviceMatrix(self, h, int(L.zkm_matrix_height(h)), int(L.zkm_matrix_width(h)))
 
+    def tracegen_jump(self, jump_events: np.ndarray, fixed_log2_rows: int = -1) -> DeviceMatrix:
+        """`generate_trace` of the Jump chip on the device (zkm_tracegen_jump); dtype events.JUMP_EVENT."""
+        from . import events as _ev
+        ev = np.ascontiguousarray(jump_events, dtype=_ev.JUMP_EVENT)
+        h = C.c_void_p()
+        lib.check(lib.load().zkm_tracegen_jump(self.h, C.c_void_p(ev.ctypes.data if len(ev) else None), C.c_size_t(len(ev)),
+                                               C.c_int(fixed_log2_rows), C.byref(h)))
+        L = lib.load()
+        return DeviceMatrix(self, h, int(L.zkm_matrix_height(h)), int(L.zkm_matrix_width(h)))
+
     def tracegen_byte_table(self) -> DeviceMatrix:
         """`ByteChip::trace()`: the Byte chip's 65536 x 12 preprocessed table, generated on the device."""
         h = C.c_void_p()
