@@ -27,8 +27,11 @@ KERNEL_NAME = "zkm_quotient_specialized"
 BLOCK = 256
 
 
+TEMPLATE_VERSION = b"4"  # bump when emit_source or quotient_args.cuh change: cached code objects are keyed on it
+
+
 def program_hash(program: np.ndarray) -> str:
-    return hashlib.sha256(np.ascontiguousarray(program, dtype=np.uint32).tobytes()).hexdigest()[:24]
+    return hashlib.sha256(TEMPLATE_VERSION + np.ascontiguousarray(program, dtype=np.uint32).tobytes()).hexdigest()[:24]
 
 
 def emit_source(program: np.ndarray) -> str:
@@ -117,7 +120,7 @@ def emit_source(program: np.ndarray) -> str:
 
 extern "C" __global__ __launch_bounds__({BLOCK}) void {KERNEL_NAME}(stark::QuotientArgs a) {{
   stark::QuotientPoint q;
-  if (!stark::quotient_point(a, (size_t)blockIdx.x * blockDim.x + threadIdx.x, q)) return;
+  if (!stark::quotient_point(a, stark::quotient_row(a), q)) return;
   kb::E4 acc = kb::ezero();
   {body}
   stark::quotient_store(a, q, acc);

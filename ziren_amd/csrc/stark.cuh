@@ -144,7 +144,7 @@ __global__ void quotient_kernel(QuotientArgs a) {
 #define RE(r) regs_e[(r) * bd + tid]
 #define RB(r) regs_b[(r) * bd + tid]
   QuotientPoint qp;
-  if (!quotient_point(a, (size_t)blockIdx.x * bd + tid, qp)) return;
+  if (!quotient_point(a, quotient_row(a), qp)) return;
   const size_t p = qp.p, pn = qp.pn;
   const uint32_t is_first = qp.is_first, is_last = qp.is_last, is_trans = qp.is_trans;
 
