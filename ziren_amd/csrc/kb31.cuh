@@ -148,6 +148,36 @@ KB_HD uint32_t bitrev(uint32_t x, int bits) {
 #endif
 }
 
+// ---- long dot products: 96-bit accumulation, one reduction at the end ------------------------------------------------
+// sum_i a_i b_i with a_i, b_i < 2^32: each term is one v_mad_u64_u32 into the low 64 bits plus the carry into a third
+// word (two instructions per product instead of 3.5 with a Montgomery reduction every second product). Holds 2^32 terms.
+#if defined(__HIPCC__)
+struct Acc96 {
+  uint64_t lo;
+  uint32_t hi;
+};
+__device__ __forceinline__ Acc96 acc96_zero() { return Acc96{0, 0}; }
+__device__ __forceinline__ void acc96_fma(Acc96& acc, uint32_t a, uint32_t b) {
+  asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "+v"(acc.lo), "+v"(acc.hi) : "v"(a), "v"(b) : "vcc");
+}
+// the same with a wave-uniform a (a table entry with a uniform index): it stays in an SGPR
+__device__ __forceinline__ void acc96_fma_uniform(Acc96& acc, uint32_t a_uniform, uint32_t b) {
+  asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "+v"(acc.lo), "+v"(acc.hi) : "s"(a_uniform), "v"(b) : "vcc");
+}
+// (hi 2^64 + lo) / R mod p, in [0, p): the middle word is reduced below p so the low 64 bits satisfy monty_reduce's
+// precondition, and hi 2^64 / R = hi R is one more Montgomery product (2^32 < 2.02 p: two conditional subtractions)
+__device__ __forceinline__ uint32_t acc96_reduce(const Acc96& acc) {
+  uint32_t mid = (uint32_t)(acc.lo >> 32);
+  mid = umin32(mid, mid - P);
+  mid = umin32(mid, mid - P);
+  const uint32_t r_lo = monty_reduce(((uint64_t)mid << 32) | (uint32_t)acc.lo);
+  uint32_t h = acc.hi;            // number of carries: small, but reduce it anyway
+  h = umin32(h, h - P);
+  h = umin32(h, h - P);
+  return add(r_lo, mul(h, R2));   // h * R^2 / R = h * R
+}
+#endif
+
 // ---- quartic extension, X^4 = 3 (crates/stark/src/air/extension.rs:55-74) ------------------
 struct alignas(16) E4 {
   uint32_t c[4];

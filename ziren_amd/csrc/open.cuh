@@ -165,7 +165,8 @@ __global__ __launch_bounds__(THREADS) void reduce_openings(const ReduceMat* __re
   kb::E4 acc = accumulate ? ro[r] : kb::ezero();
   for (int m = 0; m < n_mats; m++) {
     const ReduceMat& M = mats[m];
-    kb::E4 S = kb::ezero();
+    // S = sum_c alpha^c * L[r][c]: four base-field dot products over the matrix's columns, accumulated in 96 bits
+    kb::Acc96 s0 = kb::acc96_zero(), s1 = kb::acc96_zero(), s2 = kb::acc96_zero(), s3 = kb::acc96_zero();
     const uint32_t* col = M.lde + r;
     int c = 0;
     for (; c + 8 <= M.width; c += 8) {
@@ -173,13 +174,23 @@ __global__ __launch_bounds__(THREADS) void reduce_openings(const ReduceMat* __re
 #pragma unroll
       for (int k = 0; k < 8; k++) v[k] = col[(size_t)(c + k) * N];
 #pragma unroll
-      for (int k = 0; k < 8; k += 2) {
-        const kb::E4 a0 = alpha_pows[c + k], a1 = alpha_pows[c + k + 1];
-#pragma unroll
-        for (int e = 0; e < 4; e++) S.c[e] = kb::add(S.c[e], kb::dot2(a0.c[e], v[k], a1.c[e], v[k + 1]));
+      for (int k = 0; k < 8; k++) {
+        const kb::E4 a = alpha_pows[c + k];
+        kb::acc96_fma_uniform(s0, a.c[0], v[k]);
+        kb::acc96_fma_uniform(s1, a.c[1], v[k]);
+        kb::acc96_fma_uniform(s2, a.c[2], v[k]);
+        kb::acc96_fma_uniform(s3, a.c[3], v[k]);
       }
     }
-    for (; c < M.width; c++) S = kb::eadd(S, kb::escale(alpha_pows[c], col[(size_t)c * N]));
+    for (; c < M.width; c++) {
+      const kb::E4 a = alpha_pows[c];
+      const uint32_t v = col[(size_t)c * N];
+      kb::acc96_fma_uniform(s0, a.c[0], v);
+      kb::acc96_fma_uniform(s1, a.c[1], v);
+      kb::acc96_fma_uniform(s2, a.c[2], v);
+      kb::acc96_fma_uniform(s3, a.c[3], v);
+    }
+    const kb::E4 S{{kb::acc96_reduce(s0), kb::acc96_reduce(s1), kb::acc96_reduce(s2), kb::acc96_reduce(s3)}};
     acc = kb::eadd(acc, kb::emul(kb::esub(M.Yc[0], kb::emul(M.A[0], S)), d0));
     if (M.n_points > 1) acc = kb::eadd(acc, kb::emul(kb::esub(M.Yc[1], kb::emul(M.A[1], S)), d1));
   }
