@@ -51,7 +51,10 @@ __global__ __launch_bounds__(THREADS) void perm_rows(const uint32_t* __restrict_
   kb::E4 rowsum = kb::ezero();
   int k = 0;
   for (int b = 0; b < perm_ext_w - 1; b++) {
-    kb::E4 val = kb::ezero();
+    // sum over the batch of mult_q / denom_q as one fraction num / den: one extension inverse per permutation column
+    // instead of one per lookup (each further term costs two extension products instead of an inverse)
+    kb::E4 num = kb::ezero(), den = kb::eone();
+    bool first = true;
     for (int q = 0; q < batch && k < n_lookups; q++, k++) {
       uint32_t kind = blob[pos++];
       int nv = blob[pos++];
@@ -62,8 +65,16 @@ __global__ __launch_bounds__(THREADS) void perm_rows(const uint32_t* __restrict_
       }
       uint32_t mult = apply_pair_col(blob, pos, main, n, prep, n, r);
       if (k >= n_sends) mult = kb::neg(mult);
-      val = kb::eadd(val, kb::escale(kb::einv(denom), mult));
+      if (first) {
+        num = kb::efrom(mult);
+        den = denom;
+        first = false;
+      } else {
+        num = kb::eadd(kb::emul(num, denom), kb::escale(den, mult));
+        den = kb::emul(den, denom);
+      }
     }
+    const kb::E4 val = first ? kb::ezero() : kb::emul(num, kb::einv(den));
 #pragma unroll
     for (int e = 0; e < 4; e++) perm[(size_t)(4 * b + e) * n + r] = val.c[e];
     rowsum = kb::eadd(rowsum, val);
