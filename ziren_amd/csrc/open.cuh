@@ -15,12 +15,29 @@ constexpr int THREADS = 256;
 //   p(z) = sum_i v_i * w_i,   w_i = (u^n - 1)/n * w^i / (u - w^i),   u = z / s.
 // `c` = (u^n - 1)/n is computed on the host. p(z * g) = sum_i v_{i+1} w_i (rotation), so one
 // weight vector serves both opening points of a trace.
+// Four consecutive points per thread: one power of w_n, one extension inverse for the four denominators
+// (Montgomery's trick: 9 products instead of 3 more inverses). grid = ceil(n / 4 / THREADS).
 __global__ __launch_bounds__(THREADS) void bary_weights(kb::E4 u, kb::E4 c, uint32_t w_n, size_t n, kb::E4* __restrict__ out) {
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  uint32_t wi = kb::pow(w_n, (uint64_t)i);
-  kb::E4 d = kb::einv(kb::esub_base(u, wi));
-  out[i] = kb::emul(kb::escale(d, wi), c);
+  const size_t i0 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i0 >= n) return;
+  uint32_t wi[4];
+  wi[0] = kb::pow(w_n, (uint64_t)i0);
+#pragma unroll
+  for (int k = 1; k < 4; k++) wi[k] = kb::mul(wi[k - 1], w_n);
+  kb::E4 d[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) d[k] = i0 + k < n ? kb::esub_base(u, wi[k]) : kb::eone();
+  const kb::E4 p1 = kb::emul(d[0], d[1]), p2 = kb::emul(p1, d[2]), p3 = kb::emul(p2, d[3]);
+  kb::E4 inv = kb::einv(p3), di[4];
+  di[3] = kb::emul(inv, p2);
+  inv = kb::emul(inv, d[3]);
+  di[2] = kb::emul(inv, p1);
+  inv = kb::emul(inv, d[2]);
+  di[1] = kb::emul(inv, d[0]);
+  di[0] = kb::emul(inv, d[1]);
+#pragma unroll
+  for (int k = 0; k < 4; k++)
+    if (i0 + k < n) out[i0 + k] = kb::emul(kb::escale(di[k], wi[k]), c);
 }
 
 // Column evaluations. Block (bx, by) owns EVAL_COLS columns starting at EVAL_COLS*bx and the rows
@@ -160,8 +177,11 @@ __global__ __launch_bounds__(THREADS) void reduce_openings(const ReduceMat* __re
   size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= N) return;
   uint32_t x = kb::mul(kb::GEN, kb::pow(w_N, (uint64_t)kb::bitrev((uint32_t)r, log_N)));
-  kb::E4 d0 = kb::einv(kb::esub_base(z0, x));
-  kb::E4 d1 = kb::einv(kb::esub_base(z1, x));
+  // 1 / (z0 - x) and 1 / (z1 - x) from one inverse
+  const kb::E4 e0 = kb::esub_base(z0, x), e1 = kb::esub_base(z1, x);
+  const kb::E4 e01 = kb::einv(kb::emul(e0, e1));
+  kb::E4 d0 = kb::emul(e01, e1);
+  kb::E4 d1 = kb::emul(e01, e0);
   kb::E4 acc = accumulate ? ro[r] : kb::ezero();
   for (int m = 0; m < n_mats; m++) {
     const ReduceMat& M = mats[m];

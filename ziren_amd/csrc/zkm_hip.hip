@@ -804,7 +804,7 @@ static void open_impl(zkm_ctx* ctx, const zkm_pk* pk, zkm_main_data* md, const z
           E4 u = kb::escale(zeta, kb::inv(m.shift));
           E4 c = kb::escale(kb::esub_base(host_pow2k(u, ln), kb::ONE), kb::inv(kb::to_monty((uint32_t)(m.n % kb::P))));
           wts = (E4*)salloc(m.n * sizeof(E4));
-          KLAUNCH(ctx, "bary_weights", 16.0 * m.n, open::bary_weights, dim3(div_up(m.n, open::THREADS)), dim3(open::THREADS), 0, u, c,
+          KLAUNCH(ctx, "bary_weights", 16.0 * m.n, open::bary_weights, dim3(div_up(div_up(m.n, 4), open::THREADS)), dim3(open::THREADS), 0, u, c,
                   kb::two_adic_generator(ln), m.n, wts);
           wcache[key] = wts;
         } else wts = it->second;
