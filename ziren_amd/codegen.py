@@ -27,7 +27,7 @@ KERNEL_NAME = "zkm_quotient_specialized"
 BLOCK = 256
 
 
-TEMPLATE_VERSION = b"4"  # bump when emit_source or quotient_args.cuh change: cached code objects are keyed on it
+TEMPLATE_VERSION = b"5"  # bump when emit_source or quotient_args.cuh change: cached code objects are keyed on it
 
 
 def program_hash(program: np.ndarray) -> str:
