@@ -4,10 +4,11 @@
 // initial external layer, 4 full rounds, 13 partial rounds on lane 0, 4 full rounds, S-box x^3.
 //
 // The 16-word state lives in VGPRs. The external layer is the add-only circ(2 M4, M4, M4, M4)
-// form; the internal layer multiplies by the diagonal
-//   [-2, 1, 2, 1/2, 3, 4, -1/2, -3, -4, 2^-8, 1/8, 2^-24, -2^-8, -1/8, -1/16, -2^-24]
-// whose small-integer entries are done with adds; only the inverse powers of two use a
-// Montgomery multiply. Round constants come from the reference's table (poseidon2_constants.inc).
+// form; the internal layer is s_i <- s_i * V_i + sum(s) with the diagonal
+//   V = [-2, 1, 2, 1/2, 3, 4, -1/2, -3, -4, 2^-8, 1/8, 2^-24, -2^-8, -1/8, -1/16, -2^-24],
+// computed for all 16 lanes as one 64-bit multiply-add and a signed Montgomery step, the lanes staying unreduced
+// int32 words across the 13 partial rounds (see "partial rounds in a signed representation" below).
+// Round constants come from the reference's table (poseidon2_constants.inc).
 #pragma once
 #include "kb31.cuh"
 
@@ -76,7 +77,10 @@ KB_HD uint32_t sbox_rc(uint32_t s, uint32_t rcm) {
 // Between the 13 partial rounds every lane only feeds (a) the lane sum and (b) its own s_i * V_i + sum, both of which
 // a *signed* Montgomery step accepts: a lane is kept as an int32 congruent to its value, |s_i| < 2^31, and the final
 // correction to [0, p) (two instructions per lane per round) is dropped. One round is then, per lane, a 64-bit
-// multiply-add and a three-instruction reduction; only lane 0 is brought back to [0, p) for its S-box.
+// multiply-add and a three-instruction reduction; only lane 0 is lifted (s or s + p) for its S-box.
+// Bounds: a reduction returns |r| <= |x| / 2^32 + p / 2 with |x| <= |s| V + |sum| R < 2^31 p + 2^56, so
+// |r| < p + 2^23.3 < 0.997 * 2^31 whatever the round: no int32 ever overflows, and a lifted lane lies in (-2^23.3, 0.997 * 2^31),
+// for which the S-box's own signed arithmetic (|s + rc - p| < 2^31, squares below 2^31 p) still holds.
 
 // acc += x for a signed 32-bit x: one v_mad_i64_i32 on the device
 KB_HD void acc_add_signed(int64_t& acc, int32_t x) {
@@ -86,8 +90,8 @@ KB_HD void acc_add_signed(int64_t& acc, int32_t x) {
   acc += x;
 #endif
 }
-// s in (-2^31, 2^31) congruent to a field value  ->  s or s + p, in (-2^24, 2^31): what sbox_rc and the external layer's
-// first S-boxes accept (they only need |s + rc - p| < 0.996 * 2^31)
+// s in (-2^31, 2^31) congruent to a field value  ->  s or s + p: what sbox_rc_signed and the first S-boxes of the next
+// full round accept (see the bounds above)
 KB_HD uint32_t lift_signed(int32_t s) { return (uint32_t)s + ((uint32_t)(s >> 31) & kb::P); }
 
 template <class DiagFn>
