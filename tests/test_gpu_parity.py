@@ -22,6 +22,27 @@ def test_poseidon2_batch(hip_ctx, oracle):
     assert np.array_equal(prover.poseidon2_permute_batch(hip_ctx, st), oracle.poseidon2_permute_batch(st))
 
 
+def test_poseidon2_extreme_states(hip_ctx, oracle):
+    # The partial rounds keep the lanes as unreduced int32 words and the lane sum in 64 bits: states that push the
+    # sums and products towards their bounds (all lanes p - 1, one-hot p - 1, alternating 0 / p - 1, small values,
+    # values around p / 2), and a 2^20-state random batch that is iterated three times.
+    canon = [np.full(16, P - 1), np.zeros(16), np.tile([0, P - 1], 8), np.tile([P - 1, 0], 8), np.arange(16), np.full(16, 1),
+             np.full(16, (P - 1) // 2), np.full(16, (P + 1) // 2), np.concatenate([np.full(8, P - 1), np.arange(8)])]
+    for k in range(16):
+        v = np.zeros(16)
+        v[k] = P - 1
+        canon.append(v)
+        canon.append(np.where(np.arange(16) == k, 0, P - 1))
+    st = F.to_monty(np.array(canon, dtype=np.uint64))
+    assert np.array_equal(prover.poseidon2_permute_batch(hip_ctx, st), oracle.poseidon2_permute_batch(st))
+    big = rand(np.random.default_rng(7), (1 << 20, 16))
+    g, o = big, big
+    for _ in range(3):
+        g = prover.poseidon2_permute_batch(hip_ctx, g)
+        o = oracle.poseidon2_permute_batch(o)
+    assert np.array_equal(g, o)
+
+
 @pytest.mark.parametrize("h,w", [(1, 1), (2, 3), (64, 5), (1024, 67), (8192, 33)])
 def test_matrix_roundtrip(hip_ctx, h, w):
     m = rand(np.random.default_rng(h + w), (h, w))

@@ -61,6 +61,16 @@ def test_host_field_ext_poseidon2_match_oracle(oracle):
         s = (C.c_uint32 * 16)(*map(int, st[i]))
         L.zkm_host_poseidon2_permute(s)
         assert list(s) == list(map(int, exp[i]))
+    # states that push the signed partial rounds (unreduced int32 lanes, 64-bit lane sum) towards their bounds
+    P = F.P
+    ext = [np.full(16, P - 1), np.tile([0, P - 1], 8), np.full(16, (P - 1) // 2)] + \
+          [np.where(np.arange(16) == k, 0, P - 1) for k in range(16)] + [np.where(np.arange(16) == k, P - 1, 0) for k in range(16)]
+    ext = F.to_monty(np.array(ext, dtype=np.uint64))
+    exp = oracle.poseidon2_permute_batch(ext)
+    for i in range(len(ext)):
+        s = (C.c_uint32 * 16)(*map(int, ext[i]))
+        L.zkm_host_poseidon2_permute(s)
+        assert list(s) == list(map(int, exp[i]))
 
 
 def test_challenger_matches_oracle(oracle):
