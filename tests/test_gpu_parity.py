@@ -70,6 +70,19 @@ def test_coset_lde_matches_oracle(hip_ctx, oracle, k, w, bl):
     assert np.array_equal(prover.coset_lde_batch(hip_ctx, m, bl, shift), oracle.coset_lde_batch(m, bl, shift))
 
 
+def test_coset_lde_extreme_columns(hip_ctx, oracle):
+    # The forward stages of lde_rows_big keep their points as unreduced int32 words (|v| <= 2^31 - 1 is the invariant):
+    # columns that maximise magnitudes (all p - 1, alternating 0 / p - 1, a single spike, a constant) at a size that
+    # takes the four-step path (2^15 rows), with blow-up 2 and 4.
+    n, P1 = 1 << 15, P - 1
+    i = np.arange(n)
+    cols = [np.full(n, P1), np.where(i & 1, P1, 0), np.where(i & 1, 0, P1), np.where(i == 0, P1, 0), np.where(i == n - 1, P1, 0),
+            np.full(n, 1), np.where((i >> 3) & 1, P1, 1), (i * 0x9E3779B1) % P]
+    m = F.to_monty(np.stack(cols, axis=1).astype(np.uint64))
+    for bl in (1, 2):
+        assert np.array_equal(prover.coset_lde_batch(hip_ctx, m, bl, F.to_monty(3)), oracle.coset_lde_batch(m, bl, F.to_monty(3)))
+
+
 def test_coset_lde_quotient_chunk_shift(hip_ctx, oracle):
     k = 9
     m = rand(np.random.default_rng(9), (1 << k, 4))
