@@ -274,6 +274,14 @@ int zkm_tracegen_byte_table(zkm_ctx* ctx, zkm_matrix** out);
 int zkm_tracegen_byte_mults(zkm_ctx* ctx, const zkm_byte_lookups* blu, const uint32_t* extra_counts,
                             zkm_matrix** out);
 
+/* generate_trace / generate_preprocessed_trace of the chips whose rows are their event (or instruction) records laid
+ * end to end and zero padded — the recursion machine's BaseAlu and ExtAlu chips
+ * (crates/recursion/core/src/chips/alu_base.rs:99-137,204-222, alu_ext.rs): `words` are n_words field elements
+ * (Montgomery words, as the records lie in memory), `width` the trace width; the height is
+ * next_power_of_two(ceil(n_words / width)) with the minimum of 16 rows, or 2^fixed_log2_rows. */
+int zkm_tracegen_flat(zkm_ctx* ctx, const uint32_t* words, size_t n_words, size_t width,
+                      int fixed_log2_rows, zkm_matrix** out);
+
 /* ---- fine-grained entry points (parity tests, micro-benchmarks) ------------------------- */
 /* Poseidon2 width-16 permutation on n states (n x 16 words, in place), on the GPU.
  * zkm_primitives::poseidon2_init, crates/primitives/src/lib.rs:1107-1122. */

@@ -434,13 +434,15 @@ def count_permutation_constraints(n_lookups, batch_size, commit_scope_global):
     return c
 
 
-def debug_constraints(b: "AirBuilder", main: np.ndarray, public_values=None) -> List[Tuple[int, int]]:
+def debug_constraints(b: "AirBuilder", main: np.ndarray, public_values=None, prep: np.ndarray = None) -> List[Tuple[int, int]]:
     """Evaluate the recorded base-field constraints on every row of a trace (canonical values, row-major),
     row i against row (i + 1) mod n as crates/stark/src/debug.rs:30-120 does. Returns [(constraint, first failing
     row)]; empty when the trace satisfies the AIR. Extension-field (permutation) constraints are not covered."""
     n = main.shape[0]
     cols = [main[:, c].astype(np.uint64) for c in range(main.shape[1])]
     nxt = [np.roll(c, -1) for c in cols]
+    pcols = [prep[:, c].astype(np.uint64) for c in range(prep.shape[1])] if prep is not None else []
+    pnxt = [np.roll(c, -1) for c in pcols]
     rows = np.arange(n)
     memo = {}
 
@@ -452,6 +454,8 @@ def debug_constraints(b: "AirBuilder", main: np.ndarray, public_values=None) -> 
             raise ValueError("extension-field expression")
         if x.op == LD_MAIN:
             v = (nxt if x.a else cols)[x.imm]
+        elif x.op == LD_PREP:
+            v = (pnxt if x.a else pcols)[x.imm]
         elif x.op == LD_CONST:
             v = np.full(n, int(F.from_monty(np.uint32(x.imm))), dtype=np.uint64)
         elif x.op == LD_PV:

@@ -1530,6 +1530,45 @@ int zkm_tracegen_jump(zkm_ctx* ctx, const zkm_jump_event* events, size_t n_event
   return tracegen_events(ctx, tracegen::JUMP, events, n_events, fixed_log2_rows, nullptr, out);
 }
 
+int zkm_tracegen_flat(zkm_ctx* ctx, const uint32_t* words, size_t n_words, size_t width, int fixed_log2_rows, zkm_matrix** out) {
+  API_BEGIN
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIP_CHECK(hipSetDevice(ctx->device));
+  if (width == 0) throw std::runtime_error("zkm_tracegen_flat: zero width");
+  if (n_words && !words) throw std::runtime_error("zkm_tracegen_flat: null records");
+  const size_t rows = (n_words + width - 1) / width;
+  size_t height = 16;
+  if (fixed_log2_rows >= 0) {
+    if (fixed_log2_rows > 30) throw std::runtime_error("zkm_tracegen_flat: fixed log2 rows out of range");
+    height = (size_t)1 << fixed_log2_rows;
+    if (rows > height) throw std::runtime_error("zkm_tracegen_flat: fixed log2 rows is too small");
+  } else {
+    while (height < rows) height <<= 1;
+  }
+  ctx->begin_call();
+  zkm_matrix* m = new zkm_matrix();
+  m->h = height; m->w = width;
+  uint32_t* stage = nullptr;
+  try {
+    m->d = ctx->alloc_n<uint32_t>(height * width);
+    stage = ctx->alloc_n<uint32_t>(height * width);
+    HIP_CHECK(hipMemsetAsync(stage, 0, height * width * 4, ctx->stream));
+    if (n_words) HIP_CHECK(hipMemcpyAsync(stage, words, n_words * 4, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(open::transpose_slab, dim3(div_up(width, 32), div_up(height, 32)), dim3(32, 8), 0, ctx->stream,
+                       (const uint32_t*)stage, m->d, height, width, (size_t)0, height);
+    LAUNCH_CHECK();
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  } catch (...) {
+    if (stage) ctx->release(stage);
+    if (m->d) ctx->release(m->d);
+    delete m;
+    throw;
+  }
+  ctx->release(stage);
+  *out = m;
+  API_END
+}
+
 int zkm_tracegen_byte_table(zkm_ctx* ctx, zkm_matrix** out) {
   API_BEGIN
   std::lock_guard<std::mutex> lk(ctx->mu);

@@ -102,6 +102,15 @@ class Context:
         L = lib.load()
         return DeviceMatrix(self, h, int(L.zkm_matrix_height(h)), int(L.zkm_matrix_width(h)))
 
+    def tracegen_flat(self, words: np.ndarray, width: int, fixed_log2_rows: int = -1) -> DeviceMatrix:
+        """Padded trace of a chip whose rows are its records end to end (zkm_tracegen_flat): recursion BaseAlu / ExtAlu."""
+        w = np.ascontiguousarray(words, dtype=np.uint32).reshape(-1)
+        h = C.c_void_p()
+        lib.check(lib.load().zkm_tracegen_flat(self.h, abi.as_u32p(w) if len(w) else None, C.c_size_t(len(w)), C.c_size_t(width),
+                                               C.c_int(fixed_log2_rows), C.byref(h)))
+        L = lib.load()
+        return DeviceMatrix(self, h, int(L.zkm_matrix_height(h)), int(L.zkm_matrix_width(h)))
+
     def tracegen_byte_table(self) -> DeviceMatrix:
         """`ByteChip::trace()`: the Byte chip's 65536 x 12 preprocessed table, generated on the device."""
         h = C.c_void_p()

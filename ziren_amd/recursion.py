@@ -1,0 +1,171 @@
+"""Two chips of the recursion machine as recorded AIRs, with synthetic programs: BaseAlu and ExtAlu
+(crates/recursion/core/src/chips/alu_base.rs, alu_ext.rs). The compress / shrink provers run the same
+commit + open over these AIRs with the compressed FRI configurations.
+
+A recursion chip splits in two: the *program* fixes, per instruction, the memory addresses, the opcode flags and the
+write multiplicity (preprocessed trace, committed in the proving key), the *execution* supplies the values (main
+trace). Both traces are the instruction / event records laid end to end, four per row, zero padded
+(alu_base.rs:99-137, 204-222; alu_ext.rs likewise), so "trace generation" is a padded upload (zkm_tracegen_flat).
+"""
+from typing import List, Tuple
+
+import numpy as np
+
+from . import air, chips, field as F
+
+ENTRIES_PER_ROW = 4                       # NUM_BASE_ALU_ENTRIES_PER_ROW / NUM_EXT_ALU_ENTRIES_PER_ROW
+ADD, SUB, MUL, DIV = range(4)             # BaseAluOpcode / ExtAluOpcode (runtime/opcode.rs)
+BASE_VALUE_COLS, EXT_VALUE_COLS = 3, 12   # BaseAluIo<F>, ExtAluIo<Block<F>>: out, in1, in2
+ACCESS_COLS = 8                           # addrs.out, addrs.in1, addrs.in2, is_add, is_sub, is_mul, is_div, mult
+W = 3                                     # X^4 = 3 (crates/stark/src/air/extension.rs:55-74)
+
+
+def _ext_mul_expr(b, x, y):
+    """BinomialExtension::mul (extension.rs:58-74), symbolic."""
+    out = [b.const(0)] * 4
+    for i in range(4):
+        for j in range(4):
+            if i + j >= 4:
+                out[i + j - 4] = out[i + j - 4] + b.const(W) * x[i] * y[j]
+            else:
+                out[i + j] = out[i + j] + x[i] * y[j]
+    return out
+
+
+class _RecRec(chips._Rec):
+    """ZKMRecursionAirBuilder's memory lookups (crates/recursion/core/src/builder.rs:19-71): address + a 4-word block."""
+
+    def _mem(self, addr, block, mult):
+        vals = [addr] + list(block)
+        return air.Lookup([air.to_virtual_pair(v) for v in vals], air.to_virtual_pair(mult), air.KIND_MEMORY)
+
+    def send_block(self, addr, block, mult):
+        self.sends.append(self._mem(addr, block, mult))
+
+    def receive_block(self, addr, block, mult):
+        self.receives.append(self._mem(addr, block, mult))
+
+    def send_single(self, addr, val, mult):
+        self.send_block(addr, [val, 0, 0, 0], mult)
+
+    def receive_single(self, addr, val, mult):
+        self.receive_block(addr, [val, 0, 0, 0], mult)
+
+
+def _record(ext: bool) -> _RecRec:
+    vw = EXT_VALUE_COLS if ext else BASE_VALUE_COLS
+    r = _RecRec(ENTRIES_PER_ROW * vw, ENTRIES_PER_ROW * ACCESS_COLS)
+    b, l, p = r.b, r.local, r.prep
+    for k in range(ENTRIES_PER_ROW):
+        v = l[k * vw:(k + 1) * vw]
+        a_out, a_in1, a_in2, is_add, is_sub, is_mul, is_div, mult = p[k * ACCESS_COLS:(k + 1) * ACCESS_COLS]
+        is_real = is_add + is_sub + is_mul + is_div
+        b.assert_bool(is_real)
+        if ext:   # ExtAluChip::eval, alu_ext.rs:272-303
+            out, in1, in2 = v[0:4], v[4:8], v[8:12]
+            for e in range(4):
+                b.when(is_add).assert_eq(in1[e] + in2[e], out[e])
+            for e in range(4):
+                b.when(is_sub).assert_eq(in1[e], in2[e] + out[e])
+            prod = _ext_mul_expr(b, in1, in2)
+            for e in range(4):
+                b.when(is_mul).assert_eq(prod[e], out[e])
+            prod = _ext_mul_expr(b, in2, out)
+            for e in range(4):
+                b.when(is_div).assert_eq(in1[e], prod[e])
+            r.receive_block(a_in1, in1, is_real)
+            r.receive_block(a_in2, in2, is_real)
+            r.send_block(a_out, out, mult)
+        else:     # BaseAluChip::eval, alu_base.rs:279-304
+            out, in1, in2 = v
+            b.when(is_add).assert_eq(in1 + in2, out)
+            b.when(is_sub).assert_eq(in1, in2 + out)
+            b.when(is_mul).assert_eq(out, in1 * in2)
+            b.when(is_div).assert_eq(in2 * out, in1)
+            r.receive_single(a_in1, in1, is_real)
+            r.receive_single(a_in2, in2, is_real)
+            r.send_single(a_out, out, mult)
+    return r
+
+
+def record_constraints(ext: bool) -> _RecRec:
+    return _record(ext)
+
+
+def record_chip(ext: bool, log_height: int, prep_index: int, lqd: int = 1) -> chips.RecordedChip:
+    r = _record(ext)
+    r.b.perm_ext_width = air.local_permutation_trace_width(len(r.sends) + len(r.receives), 1 << lqd)
+    air.eval_permutation_constraints(r.b, r.sends, r.receives, 1 << lqd, False)
+    program = r.b.assemble()
+    return chips.RecordedChip(name="ExtAlu" if ext else "BaseAlu", log_height=log_height, main_width=r.b.main_width,
+                              prep_width=r.b.prep_width, prep_index=prep_index, log_quotient_degree=lqd, local_only=True,
+                              sends=r.sends, receives=r.receives, program=program,
+                              lookups_blob=air.encode_lookups(r.sends, r.receives), num_constraints=int(program[2]))
+
+
+def _ext_mul_np(x, y):
+    out = [np.zeros(len(x[0]), dtype=np.uint64) for _ in range(4)]
+    for i in range(4):
+        for j in range(4):
+            t = F.mul(x[i], y[j])
+            if i + j >= 4:
+                out[i + j - 4] = F.add(out[i + j - 4], F.mul(t, W))
+            else:
+                out[i + j] = F.add(out[i + j], t)
+    return out
+
+
+def synthetic_program(ext: bool, n_instr: int, seed: int = 1) -> Tuple[np.ndarray, np.ndarray]:
+    """n_instr ALU instructions and their execution: (instrs, events), both flat uint32 Montgomery words.
+    instrs: n_instr x 8 (the BaseAluAccessCols / ExtAluAccessCols record of each instruction);
+    events: n_instr x 3 (base) or x 12 (ext) values with out = in1 op in2 (division: out = in1 / in2 is produced as
+    in1 = in2 * out). Addresses are distinct small integers, multiplicities 0..3."""
+    rng = F.SplitMix64(0x52454300 + 17 * int(ext) + seed)
+    op = (rng.next_u64(n_instr) % np.uint64(4)).astype(np.int64)
+    addr = np.arange(3 * n_instr, dtype=np.uint64).reshape(n_instr, 3) + np.uint64(1)
+    mult = rng.next_u64(n_instr) % np.uint64(4)
+    instrs = np.zeros((n_instr, ACCESS_COLS), dtype=np.uint64)
+    instrs[:, 0:3] = addr
+    instrs[np.arange(n_instr), 3 + op] = 1
+    instrs[:, 7] = mult
+    k = 4 if ext else 1
+    a = [rng.uniform_field(n_instr) for _ in range(k)]
+    c = [rng.uniform_field(n_instr) for _ in range(k)]
+    if ext:
+        add = [F.add(a[e], c[e]) for e in range(4)]
+        sub = [F.sub(a[e], c[e]) for e in range(4)]
+        mul = _ext_mul_np(a, c)
+        # per opcode: (out, in1, in2)
+        out = [np.select([op == ADD, op == SUB, op == MUL, op == DIV], [add[e], sub[e], mul[e], c[e]]) for e in range(4)]
+        in1 = [np.select([op == DIV], [mul[e]], a[e]) for e in range(4)]      # DIV: in1 = in2 * out with in2 = a, out = c
+        in2 = [np.select([op == DIV], [a[e]], c[e]) for e in range(4)]
+        events = np.stack(out + in1 + in2, axis=1)
+    else:
+        a, c = a[0], c[0]
+        out = np.select([op == ADD, op == SUB, op == MUL, op == DIV], [F.add(a, c), F.sub(a, c), F.mul(a, c), c])
+        in1 = np.where(op == DIV, F.mul(a, c), a)
+        in2 = np.where(op == DIV, a, c)
+        events = np.stack([out, in1, in2], axis=1)
+    return F.to_monty(instrs).reshape(-1), F.to_monty(events).reshape(-1)
+
+
+def padded_rows(n_records: int, fixed_log2_rows: int = -1) -> int:
+    rows = -(-n_records // ENTRIES_PER_ROW)
+    if fixed_log2_rows >= 0:
+        if rows > (1 << fixed_log2_rows):
+            raise ValueError("fixed log2 rows is too small")
+        return 1 << fixed_log2_rows
+    h = 16
+    while h < rows:
+        h <<= 1
+    return h
+
+
+def flat_trace(words: np.ndarray, width: int, fixed_log2_rows: int = -1) -> np.ndarray:
+    """Host form of the padded trace (what generate_trace / generate_preprocessed_trace return): records end to end,
+    zeros after them."""
+    recs = len(words) // (width // ENTRIES_PER_ROW)
+    h = padded_rows(recs, fixed_log2_rows)
+    out = np.zeros(h * width, dtype=np.uint32)
+    out[:len(words)] = words
+    return out.reshape(h, width)
