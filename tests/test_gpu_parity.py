@@ -260,6 +260,30 @@ def test_shard_proof_bit_exact(hip_ctx, oracle, k, with_prep, queries, pow_bits,
     assert oracle.verify_shard(opk, sh.chips, fri, synth.NUM_PV_ELTS, start.copy(), proof) == 0
 
 
+def test_reference_pcs_test_shapes(hip_ctx, oracle):
+    # The reference checks its PCS against the in-tree verifier on two batches (crates/recursion/circuit/src/fri.rs:626-957):
+    # log-degrees {16, 9, 7, 4, 2} x 10 columns (large gaps between heights: reduced openings join the FRI fold at
+    # sparse layers) and {19, 19} x 100 columns (two wide matrices of equal height). The same shapes as shards:
+    # the first bit-exact against the oracle prover, the second (too large for it) through the restated verifier.
+    gaps = [("G16", 0, 10, 8), ("G09", -7, 10, 8), ("G07", -9, 10, 8), ("G04", -12, 10, 8), ("G02", -14, 10, 8)]
+    sh = synth.syn_shard(16, chips=gaps)
+    assert [c.log_height for c in sh.chips] == [16, 9, 7, 4, 2]
+    fri = abi.FriConfig(1, 84, 16)
+    pk, start, ch, proof = _gpu_prove(hip_ctx, sh, fri, True)
+    opk = oracle.Pk([], [], sh.pc_start, sh.initial_global_cumulative_sum, 1)
+    och = oracle.new_challenger()
+    opk.observe_into(och)
+    oproof, _ = oracle.prove_shard(opk, sh.chips, [c.trace for c in sh.chips], sh.public_values, fri, synth.NUM_PV_ELTS, och)
+    assert np.array_equal(proof, oproof)
+    assert oracle.verify_shard(opk, sh.chips, fri, synth.NUM_PV_ELTS, start.copy(), proof) == 0
+    wide = [("WideA", 0, 100, 12), ("WideB", 0, 100, 12)]
+    sh = synth.syn_shard(19, chips=wide)
+    pk, start, ch, proof = _gpu_prove(hip_ctx, sh, fri, True)
+    opk = oracle.Pk([], [], sh.pc_start, sh.initial_global_cumulative_sum, 1)
+    assert oracle.verify_shard(opk, sh.chips, fri, synth.NUM_PV_ELTS, start.copy(), proof) == 0
+    hip_ctx.trim()
+
+
 def test_shard_proof_large_verifies(hip_ctx, oracle):
     # 2^18-row Cpu chip with the core FRI parameters (84 queries, 16 PoW bits): too slow for the
     # oracle prover, so parity goes through the restated verifier, and determinism through a re-prove.
