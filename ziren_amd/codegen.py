@@ -27,11 +27,21 @@ KERNEL_NAME = "zkm_quotient_specialized"
 BLOCK = 256
 
 
-TEMPLATE_VERSION = b"5"  # bump when emit_source or quotient_args.cuh change: cached code objects are keyed on it
+TEMPLATE_VERSION = b"5"  # bump when emit_source changes
+
+
+def _template_key() -> bytes:
+    """Cached code objects are keyed on the program *and* on everything the generated source pulls in, so an edit to
+    the shared prologue (quotient_args.cuh) or the field arithmetic (kb31.cuh) can never leave a stale kernel behind."""
+    h = hashlib.sha256(TEMPLATE_VERSION)
+    for name in ("quotient_args.cuh", "kb31.cuh"):
+        with open(os.path.join(CSRC, name), "rb") as f:
+            h.update(f.read())
+    return h.digest()
 
 
 def program_hash(program: np.ndarray) -> str:
-    return hashlib.sha256(TEMPLATE_VERSION + np.ascontiguousarray(program, dtype=np.uint32).tobytes()).hexdigest()[:24]
+    return hashlib.sha256(_template_key() + np.ascontiguousarray(program, dtype=np.uint32).tobytes()).hexdigest()[:24]
 
 
 def emit_source(program: np.ndarray) -> str:
