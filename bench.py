@@ -161,7 +161,7 @@ def main():
         hpj, pkj, chj, trj, outj = lanes[j]
         ch = chj.copy()  # challenger cloned per shard (prove.rs:496)
         if args.from_host:
-            dev = [hpj.ctx.upload(h) for h in trj]
+            dev = [hpj.ctx.upload_async(h) for h in trj]   # queued tallest first; the proof waits per matrix on the device
             proof = hpj.prove_shard(pkj, shard.public_values, dev, ch, out=outj)
             for d in dev:
                 d.free()

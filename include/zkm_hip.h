@@ -158,6 +158,15 @@ void zkm_host_free(zkm_ctx* ctx, void* p);
 /* Upload a row-major host matrix (height a power of two) and lay it out column-major in HBM. */
 int zkm_matrix_upload(zkm_ctx* ctx, const uint32_t* host_row_major, size_t height, size_t width,
                       zkm_matrix** out);
+/* The same without waiting: the copy and the transposition are queued on the context's upload streams and the call
+ * returns at once. Every consumer (zkm_commit, zkm_prove_shard, zkm_pk_setup, zkm_pcs_commit, zkm_matrix_download)
+ * waits for the matrix on the device, in stream order, right before its first use — so when a shard's traces are
+ * queued tallest first and then proved, the uploads of the later traces overlap the LDE and hashing of the first ones
+ * (CpuProver::commit receives host matrices, prover.rs:258-292: this is that hand-over, pipelined). The host buffer
+ * must stay valid and unchanged until zkm_matrix_wait returns, or until a consuming call that used the matrix returns. */
+int zkm_matrix_upload_async(zkm_ctx* ctx, const uint32_t* host_row_major, size_t height, size_t width,
+                            zkm_matrix** out);
+int zkm_matrix_wait(zkm_ctx* ctx, const zkm_matrix* m);
 int zkm_matrix_download(zkm_ctx* ctx, const zkm_matrix* m, uint32_t* host_row_major);
 size_t zkm_matrix_height(const zkm_matrix* m);
 size_t zkm_matrix_width(const zkm_matrix* m);

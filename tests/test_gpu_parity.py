@@ -62,6 +62,42 @@ def test_upload_slabs_and_pinned_host_memory(hip_ctx):
     hip_ctx.host_free(pinned)
 
 
+def test_async_upload_then_prove(hip_ctx, oracle):
+    # zkm_matrix_upload_async: traces queued from page-locked memory, consumed without a host-side wait; the proof is
+    # the oracle's, a download waits for the matrix, freeing an in-flight matrix is safe, and many small uploads in a
+    # row (staging slabs reused) stay exact.
+    sh = synth.syn_shard(15)
+    fri = abi.FriConfig(1, 20, 8)
+    hp = prover.HipProver(sh.chips, fri, synth.NUM_PV_ELTS, ctx=hip_ctx)
+    pk = hp.setup([], [], sh.pc_start, sh.initial_global_cumulative_sum)
+    ch = prover.new_challenger()
+    pk.observe_into(ch)
+    och = ch.copy()
+    pinned = []
+    for c in sh.chips:
+        h = hip_ctx.host_alloc(c.trace.shape)
+        h[...] = c.trace
+        pinned.append(h)
+    dev = [hip_ctx.upload_async(h) for h in pinned]
+    proof = hp.prove_shard(pk, sh.public_values, dev, ch).copy()
+    opk = oracle.Pk([], [], sh.pc_start, sh.initial_global_cumulative_sum, 1)
+    oproof, _ = oracle.prove_shard(opk, sh.chips, [c.trace for c in sh.chips], sh.public_values, fri, synth.NUM_PV_ELTS, och)
+    assert np.array_equal(proof, oproof)
+    for d in dev:
+        d.free()
+    d = hip_ctx.upload_async(pinned[0])
+    assert np.array_equal(d.to_host(), sh.chips[0].trace)     # download waits for the upload
+    d.free()
+    hip_ctx.upload_async(pinned[0]).free()                    # freed while in flight
+    smalls = [rand(np.random.default_rng(i), (64, 3 + i)) for i in range(20)]
+    ds = [hip_ctx.upload_async(m) for m in smalls]
+    for m, d in zip(smalls, ds):
+        assert np.array_equal(d.to_host(), m)
+        d.free()
+    for h in pinned:
+        hip_ctx.host_free(h)
+
+
 @pytest.mark.parametrize("k,w,bl", [(0, 1, 1), (1, 2, 1), (3, 3, 1), (5, 4, 2), (8, 5, 1), (10, 3, 3), (13, 2, 1),
                                     (14, 3, 1), (15, 2, 2), (16, 5, 1)])
 def test_coset_lde_matches_oracle(hip_ctx, oracle, k, w, bl):

@@ -15,6 +15,7 @@
 #include <array>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <mutex>
 #include <numeric>
@@ -107,9 +108,15 @@ static uint32_t sample_bits(zkm_challenger* c, uint32_t bits) {
 struct zkm_ctx {
   int device = 0;
   hipStream_t stream = nullptr;   // main stream: phases, transcript round trips
-  hipStream_t stream2 = nullptr;  // side stream: Merkle hashing overlapped with the LDEs of the same commit
+  hipStream_t stream2 = nullptr;  // side stream (kept for experiments: hashing a tree beside the LDEs did not pay)
+  // asynchronous uploads: DMA stream, transpose stream, two persistent staging slabs and their "free again" events
+  hipStream_t up_dma = nullptr, up_tr = nullptr;
+  uint32_t* up_stage[2] = {nullptr, nullptr};
+  hipEvent_t up_freed[2] = {nullptr, nullptr}, up_landed[2] = {nullptr, nullptr};
+  bool up_freed_set[2] = {false, false};
+  int up_next = 0;
+  static constexpr size_t UP_SLAB_BYTES = (size_t)32 << 20;
   hipStream_t cur = nullptr;      // where KLAUNCH / upload / kernel-timing events go right now
-  bool overlap = false;  // ZKM_OVERLAP=1: measured on SYN-22 it does not pay (both sides are issue-bound)
   std::mutex mu;
   std::multimap<size_t, void*> free_list;  // caching allocator: exact-size reuse
   std::map<void*, size_t> live;
@@ -260,7 +267,13 @@ struct zkm_matrix {
   uint32_t* d = nullptr;  // column-major: column c at d + c * h
   size_t h = 0, w = 0;
   bool owned = true;
+  hipEvent_t ready = nullptr;  // set by zkm_matrix_upload_async: fires when the matrix is complete in HBM
 };
+
+// make `stream` wait until an asynchronously uploaded matrix is complete (no-op for any other matrix)
+static inline void wait_ready(hipStream_t stream, const zkm_matrix& m) {
+  if (m.ready) HIP_CHECK(hipStreamWaitEvent(stream, m.ready, 0));
+}
 
 struct zkm_byte_lookups {
   uint32_t* counts = nullptr;  // [NUM_BYTE_OPS][BYTE_ROWS] plain counters: record.byte_lookups on the device
@@ -363,12 +376,13 @@ static bool compress_small_layer(zkm_ctx* ctx, Tree& t, int layer, size_t len) {
 }
 
 // MerkleTreeMmcs::commit over column-major matrices of power-of-two heights.
-static void build_tree(zkm_ctx* ctx, const std::vector<zkm_matrix>& mats, Tree& t, const std::vector<hipEvent_t>* ready = nullptr) {
-  // when `ready` is given, matrix i is complete once ready[i] has fired (it is being produced on another stream)
+static void build_tree(zkm_ctx* ctx, const std::vector<zkm_matrix>& mats, Tree& t,
+                       const std::function<void(size_t)>& prepare_height = nullptr) {
+  // prepare_height(h), when given, is called right before the matrices of height h are first read: pcs_commit extends
+  // them there, so a commit's kernels are queued tallest matrix first, layer by layer (extend, hash, extend the next
+  // height, inject, ...), and whatever is still arriving over PCIe is only waited for when its layer is reached
   auto wait_height = [&](size_t h) {
-    if (!ready) return;
-    for (size_t i = 0; i < mats.size(); i++)
-      if (mats[i].h == h) HIP_CHECK(hipStreamWaitEvent(ctx->cur, (*ready)[i], 0));
+    if (prepare_height) prepare_height(h);
   };
   size_t maxh = 0;
   for (auto& m : mats) maxh = std::max(maxh, m.h);
@@ -427,7 +441,6 @@ static void free_pcs_data(zkm_ctx* ctx, zkm_pcs_data* d) {
 static zkm_pcs_data* pcs_commit(zkm_ctx* ctx, const std::vector<zkm_matrix>& mats, const std::vector<uint32_t>& shifts,
                                 int log_blowup) {
   zkm_pcs_data* d = new zkm_pcs_data();
-  std::vector<hipEvent_t> ready;
   try {
     d->log_blowup = log_blowup;
     for (size_t i = 0; i < mats.size(); i++) {
@@ -441,37 +454,23 @@ static zkm_pcs_data* pcs_commit(zkm_ctx* ctx, const std::vector<zkm_matrix>& mat
       d->eval_heights.push_back(m.h);
       d->domain_shifts.push_back(shifts.empty() ? kb::ONE : shifts[i]);
     }
-    // LDEs tallest first on the main stream; the tree is hashed on the side stream as the matrices it needs
-    // complete, so the (VALU-bound) leaf hashing of the tall matrices overlaps the LDEs of the shorter ones.
-    std::vector<size_t> order(mats.size());
-    std::iota(order.begin(), order.end(), 0);
-    std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return mats[a].h > mats[b].h; });
-    const bool overlap = ctx->overlap && mats.size() > 1;
-    if (overlap) ready.resize(mats.size());
-    for (size_t i : order) {
-      lde_columns(ctx, mats[i].d, mats[i].h, mats[i].w, log_blowup, kb::mul(kb::GEN, kb::inv(d->domain_shifts[i])), d->ldes[i].d);
-      if (overlap) {
-        ready[i] = ctx->get_event();
-        HIP_CHECK(hipEventRecord(ready[i], ctx->stream));
+    // Each height's matrices are extended right before the tree layer that reads them (see build_tree).
+    std::vector<char> extended(mats.size(), 0);
+    auto extend_height = [&](size_t lde_height) {
+      for (size_t i = 0; i < mats.size(); i++) {
+        if (extended[i] || d->ldes[i].h != lde_height) continue;
+        wait_ready(ctx->stream, mats[i]);
+        lde_columns(ctx, mats[i].d, mats[i].h, mats[i].w, log_blowup, kb::mul(kb::GEN, kb::inv(d->domain_shifts[i])), d->ldes[i].d);
+        extended[i] = 1;
       }
-    }
-    if (overlap) {
-      ctx->cur = ctx->stream2;
-      build_tree(ctx, d->ldes, d->tree, &ready);
-      hipEvent_t done = ctx->get_event();
-      HIP_CHECK(hipEventRecord(done, ctx->stream2));
-      ctx->cur = ctx->stream;
-      HIP_CHECK(hipStreamWaitEvent(ctx->stream, done, 0));
-      ready.push_back(done);
-    } else {
-      build_tree(ctx, d->ldes, d->tree);
-    }
+    };
+    build_tree(ctx, d->ldes, d->tree, extend_height);
+    for (size_t i = 0; i < mats.size(); i++)
+      if (!extended[i]) throw std::runtime_error("pcs_commit: a matrix was not reached by the tree (internal error)");
     const uint32_t* h_root = ctx->download_async(d->tree.node(d->tree.log_max, 0), 8);
     HIP_CHECK(hipStreamSynchronize(ctx->stream));
     memcpy(d->root, h_root, 32);
-    for (auto e : ready) ctx->event_pool.push_back(e);
   } catch (...) {
-    ctx->cur = ctx->stream;
     free_pcs_data(ctx, d);
     throw;
   }
@@ -1093,7 +1092,6 @@ int zkm_ctx_create(int device, zkm_ctx** out) {
   HIP_CHECK(hipStreamCreate(&c->stream));
   HIP_CHECK(hipStreamCreate(&c->stream2));
   c->cur = c->stream;
-  if (const char* e = getenv("ZKM_OVERLAP")) c->overlap = atoi(e) != 0;
   HIP_CHECK(p2::upload_tables());
   HIP_CHECK(hipFuncSetAttribute((const void*)lde::lde_rows, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIP_CHECK(hipFuncSetAttribute((const void*)lde::lde_rows_big, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -1125,6 +1123,11 @@ void zkm_ctx_destroy(zkm_ctx* ctx) {
   if (ctx->pin) (void)hipHostFree(ctx->pin);
   (void)hipStreamDestroy(ctx->stream);
   (void)hipStreamDestroy(ctx->stream2);
+  if (ctx->up_dma) {
+    (void)hipStreamDestroy(ctx->up_dma);
+    (void)hipStreamDestroy(ctx->up_tr);
+    for (int k = 0; k < 2; k++) { (void)hipFree(ctx->up_stage[k]); (void)hipEventDestroy(ctx->up_freed[k]); (void)hipEventDestroy(ctx->up_landed[k]); }
+  }
   delete ctx;
 }
 
@@ -1193,41 +1196,74 @@ void zkm_host_free(zkm_ctx* ctx, void* p) {
   (void)hipHostFree(p);
 }
 
+// Row-major host rows are copied in slabs (DMA stream) and transposed into the column-major matrix as they land
+// (transpose stream); two staging slabs keep the DMA engine and the transpose kernel busy at the same time. Nothing
+// here touches the compute stream: a consumer waits for m->ready in-stream right before its first use of the matrix, so
+// the uploads of the later (shorter) traces of a shard overlap the LDE and hashing of the first ones.
+static zkm_matrix* upload_async(zkm_ctx* ctx, const uint32_t* host, size_t height, size_t width) {
+  log2_strict(height);
+  if (!ctx->up_dma) {
+    HIP_CHECK(hipStreamCreateWithFlags(&ctx->up_dma, hipStreamNonBlocking));
+    HIP_CHECK(hipStreamCreateWithFlags(&ctx->up_tr, hipStreamNonBlocking));
+    for (int k = 0; k < 2; k++) {
+      HIP_CHECK(hipMalloc((void**)&ctx->up_stage[k], zkm_ctx::UP_SLAB_BYTES));
+      HIP_CHECK(hipEventCreateWithFlags(&ctx->up_freed[k], hipEventDisableTiming));
+      HIP_CHECK(hipEventCreateWithFlags(&ctx->up_landed[k], hipEventDisableTiming));
+    }
+  }
+  zkm_matrix* m = new zkm_matrix();
+  m->h = height; m->w = width;
+  try {
+    m->d = ctx->alloc_n<uint32_t>(std::max<size_t>(height * width, 1));
+    HIP_CHECK(hipEventCreateWithFlags(&m->ready, hipEventDisableTiming));
+    if (height * width) {
+      if (width * 4 * 32 > zkm_ctx::UP_SLAB_BYTES) throw std::runtime_error("zkm_matrix_upload: matrix too wide for the staging slab");
+      const size_t slab_rows = std::max<size_t>(32, std::min<size_t>(height, zkm_ctx::UP_SLAB_BYTES / (width * 4)) & ~(size_t)31);
+      for (size_t r0 = 0; r0 < height; r0 += slab_rows) {
+        const int k = ctx->up_next;
+        ctx->up_next ^= 1;
+        const size_t rows = std::min(slab_rows, height - r0);
+        if (ctx->up_freed_set[k]) HIP_CHECK(hipStreamWaitEvent(ctx->up_dma, ctx->up_freed[k], 0));
+        HIP_CHECK(hipMemcpyAsync(ctx->up_stage[k], host + r0 * width, rows * width * 4, hipMemcpyHostToDevice, ctx->up_dma));
+        HIP_CHECK(hipEventRecord(ctx->up_landed[k], ctx->up_dma));
+        HIP_CHECK(hipStreamWaitEvent(ctx->up_tr, ctx->up_landed[k], 0));
+        hipLaunchKernelGGL(open::transpose_slab, dim3(div_up(width, 32), div_up(rows, 32)), dim3(32, 8), 0, ctx->up_tr,
+                           (const uint32_t*)ctx->up_stage[k], m->d, rows, width, r0, height);
+        LAUNCH_CHECK();
+        HIP_CHECK(hipEventRecord(ctx->up_freed[k], ctx->up_tr));
+        ctx->up_freed_set[k] = true;
+      }
+    }
+    HIP_CHECK(hipEventRecord(m->ready, ctx->up_tr));
+  } catch (...) {
+    if (m->ready) (void)hipEventDestroy(m->ready);
+    if (m->d) ctx->release(m->d);
+    delete m;
+    throw;
+  }
+  return m;
+}
+
+int zkm_matrix_upload_async(zkm_ctx* ctx, const uint32_t* host, size_t height, size_t width, zkm_matrix** out) {
+  API_BEGIN
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIP_CHECK(hipSetDevice(ctx->device));
+  *out = upload_async(ctx, host, height, width);
+  API_END
+}
+int zkm_matrix_wait(zkm_ctx* ctx, const zkm_matrix* m) {
+  API_BEGIN
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIP_CHECK(hipSetDevice(ctx->device));
+  if (m->ready) HIP_CHECK(hipEventSynchronize(m->ready));
+  API_END
+}
 int zkm_matrix_upload(zkm_ctx* ctx, const uint32_t* host, size_t height, size_t width, zkm_matrix** out) {
   API_BEGIN
   std::lock_guard<std::mutex> lk(ctx->mu);
   HIP_CHECK(hipSetDevice(ctx->device));
-  log2_strict(height);
-  zkm_matrix* m = new zkm_matrix();
-  m->h = height; m->w = width;
-  m->d = ctx->alloc_n<uint32_t>(std::max<size_t>(height * width, 1));
-  if (height * width) {
-    // row-major rows [r0, r1) are copied in slabs and transposed into the column-major matrix as they land;
-    // two staging buffers keep the DMA engine and the transpose kernel busy at the same time.
-    const size_t slab_rows = std::max<size_t>(32, std::min<size_t>(height, ((size_t)32 << 20) / (width * 4)) & ~(size_t)31);
-    uint32_t* stage[2] = {ctx->alloc_n<uint32_t>(slab_rows * width), ctx->alloc_n<uint32_t>(slab_rows * width)};
-    hipEvent_t freed[2] = {ctx->get_event(), ctx->get_event()};
-    int k = 0;
-    for (size_t r0 = 0; r0 < height; r0 += slab_rows, k ^= 1) {
-      const size_t rows = std::min(slab_rows, height - r0);
-      if (r0 >= 2 * slab_rows) HIP_CHECK(hipStreamWaitEvent(ctx->stream2, freed[k], 0));
-      HIP_CHECK(hipMemcpyAsync(stage[k], host + r0 * width, rows * width * 4, hipMemcpyHostToDevice, ctx->stream2));
-      hipEvent_t landed = ctx->get_event();
-      HIP_CHECK(hipEventRecord(landed, ctx->stream2));
-      HIP_CHECK(hipStreamWaitEvent(ctx->stream, landed, 0));
-      hipLaunchKernelGGL(open::transpose_slab, dim3(div_up(width, 32), div_up(rows, 32)), dim3(32, 8), 0, ctx->stream,
-                         (const uint32_t*)stage[k], m->d, rows, width, r0, height);
-      LAUNCH_CHECK();
-      HIP_CHECK(hipEventRecord(freed[k], ctx->stream));
-      ctx->event_pool.push_back(landed);
-    }
-    HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    HIP_CHECK(hipStreamSynchronize(ctx->stream2));
-    ctx->event_pool.push_back(freed[0]);
-    ctx->event_pool.push_back(freed[1]);
-    ctx->release(stage[0]);
-    ctx->release(stage[1]);
-  }
+  zkm_matrix* m = upload_async(ctx, host, height, width);
+  HIP_CHECK(hipEventSynchronize(m->ready));  // the host buffer is free again when this returns
   *out = m;
   API_END
 }
@@ -1246,6 +1282,7 @@ int zkm_matrix_download(zkm_ctx* ctx, const zkm_matrix* m, uint32_t* host) {
   API_BEGIN
   std::lock_guard<std::mutex> lk(ctx->mu);
   HIP_CHECK(hipSetDevice(ctx->device));
+  wait_ready(ctx->stream, *m);
   download_colmajor(ctx, m->d, m->h, m->w, host);
   API_END
 }
@@ -1254,6 +1291,10 @@ size_t zkm_matrix_width(const zkm_matrix* m) { return m->w; }
 void zkm_matrix_free(zkm_ctx* ctx, zkm_matrix* m) {
   if (!m) return;
   std::lock_guard<std::mutex> lk(ctx->mu);
+  if (m->ready) {
+    (void)hipEventSynchronize(m->ready);  // never hand a buffer back to the pool while its upload is in flight
+    (void)hipEventDestroy(m->ready);
+  }
   if (m->owned) ctx->release(m->d);
   delete m;
 }

@@ -23,6 +23,9 @@ class DeviceMatrix:
     def __init__(self, ctx: "Context", handle, height, width):
         self.ctx, self.h, self.height, self.width = ctx, handle, height, width
 
+    def wait(self):
+        lib.check(lib.load().zkm_matrix_wait(self.ctx.h, self.h))
+
     def to_host(self) -> np.ndarray:
         out = np.empty((self.height, self.width), dtype=np.uint32)
         lib.check(lib.load().zkm_matrix_download(self.ctx.h, self.h, abi.as_u32p(out)))
@@ -72,6 +75,18 @@ class Context:
         lib.check(lib.load().zkm_matrix_upload(self.h, abi.as_u32p(m), C.c_size_t(m.shape[0]), C.c_size_t(m.shape[1]),
                                                C.byref(h)))
         return DeviceMatrix(self, h, m.shape[0], m.shape[1])
+
+    def upload_async(self, host_row_major: np.ndarray) -> DeviceMatrix:
+        """zkm_matrix_upload_async: queue the copy and return; consumers wait for the matrix on the device. The array
+        (page-locked for real overlap: host_alloc) must stay alive and unchanged until the matrix has been consumed."""
+        m = host_row_major
+        assert m.dtype == np.uint32 and m.flags["C_CONTIGUOUS"]
+        h = C.c_void_p()
+        lib.check(lib.load().zkm_matrix_upload_async(self.h, abi.as_u32p(m), C.c_size_t(m.shape[0]), C.c_size_t(m.shape[1]),
+                                                     C.byref(h)))
+        dm = DeviceMatrix(self, h, m.shape[0], m.shape[1])
+        dm._host = m
+        return dm
 
     def byte_lookups(self) -> "ByteLookups":
         """An empty `record.byte_lookups` on the device (zkm_byte_lookups_create)."""
