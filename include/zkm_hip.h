@@ -273,6 +273,17 @@ size_t zkm_tracegen_jump_width(void);
 int zkm_tracegen_jump(zkm_ctx* ctx, const zkm_jump_event* events, size_t n_events, int fixed_log2_rows,
                       zkm_matrix** out);
 
+/* The MovCond chip (crates/core/machine/src/misc/mov_cond/mod.rs: MEQ, MNE, WSBH): MovCondEvents, byte-for-byte the
+ * #[repr(C)] struct of crates/core/executor/src/events/instr.rs:286-302. 32 columns, zero padding rows, no byte lookups. */
+typedef struct zkm_mov_cond_event {
+  uint32_t pc, next_pc;
+  uint8_t opcode, _pad[3];
+  uint32_t a, b, c, prev_a;
+} zkm_mov_cond_event;
+size_t zkm_tracegen_mov_cond_width(void);
+int zkm_tracegen_mov_cond(zkm_ctx* ctx, const zkm_mov_cond_event* events, size_t n_events, int fixed_log2_rows,
+                          zkm_matrix** out);
+
 /* ByteChip::trace() — the Byte chip's preprocessed table, 65536 x 12, row (b << 8 | c)
  * (crates/core/machine/src/bytes/mod.rs:31-104, columns bytes/columns.rs:12-46), generated on the device. */
 int zkm_tracegen_byte_table(zkm_ctx* ctx, zkm_matrix** out);

@@ -408,4 +408,13 @@ int orc_tracegen_jump(const void* events, size_t n_events, int fixed_log2_rows, 
   ORC_CATCH
 }
 
+int orc_tracegen_mov_cond(const void* events, size_t n_events, int fixed_log2_rows, uint32_t* out, size_t out_cap) {
+  ORC_TRY
+  size_t h;
+  std::vector<F> t = tracegen::generate_mov_cond((const tracegen::MovCondEvent*)events, n_events, fixed_log2_rows, &h);
+  if (t.size() > out_cap) throw std::runtime_error("trace buffer too small");
+  for (size_t i = 0; i < t.size(); i++) out[i] = to_monty(t[i]);
+  ORC_CATCH
+}
+
 }  // extern "C"

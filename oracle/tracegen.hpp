@@ -265,6 +265,50 @@ static inline std::vector<F> generate_jump(const JumpEvent* events, size_t n_eve
   return t;
 }
 
+// ---- MovCond chip: MovCondEvent (crates/core/executor/src/events/instr.rs:286-302), columns and row builder
+// crates/core/machine/src/misc/mov_cond/mod.rs:38-65, :141-160; IsZeroWordOperation operations/is_zero_word.rs:22-38
+struct MovCondEvent {
+  uint32_t pc, next_pc;
+  uint8_t opcode, _pad[3];
+  uint32_t a, b, c, prev_a;
+};
+static_assert(sizeof(MovCondEvent) == 28, "MovCondEvent is seven words");
+enum { OP_MEQ = 50, OP_MNE = 51, OP_WSBH = 52 };
+static const size_t MOV_COND_WIDTH = 32;
+
+static inline void mov_cond_row(const MovCondEvent& e, F* r) {
+  enum { PC = 0, NEXT_PC = 1, OP_A = 2, PREV_A = 6, OP_B = 10, OP_C = 14, C_EQ_0 = 18, IS_MNE = 29, IS_MEQ = 30, IS_WSBH = 31 };
+  r[PC] = fu32(e.pc);
+  r[NEXT_PC] = fu32(e.next_pc);
+  word(r + OP_A, e.a);
+  word(r + OP_B, e.b);
+  word(r + OP_C, e.c);
+  word(r + PREV_A, e.prev_a);
+  // c_eq_0: per byte (inverse, result), then is_lower_half_zero, is_upper_half_zero, result
+  bool all_zero = true;
+  F res[4];
+  for (int i = 0; i < 4; i++) {
+    const F byte = (e.c >> (8 * i)) & 0xff;
+    r[C_EQ_0 + 2 * i] = byte ? finv(byte) : 0;
+    res[i] = r[C_EQ_0 + 2 * i + 1] = byte == 0;
+    all_zero &= byte == 0;
+  }
+  r[C_EQ_0 + 8] = res[0] * res[1];
+  r[C_EQ_0 + 9] = res[2] * res[3];
+  r[C_EQ_0 + 10] = all_zero;
+  r[IS_MEQ] = e.opcode == OP_MEQ;
+  r[IS_MNE] = e.opcode == OP_MNE;
+  r[IS_WSBH] = e.opcode == OP_WSBH;
+}
+static inline std::vector<F> generate_mov_cond(const MovCondEvent* events, size_t n_events, int fixed_log2_rows, size_t* height) {
+  const size_t h = padded_rows(n_events, fixed_log2_rows);
+  std::vector<F> t(h * MOV_COND_WIDTH, 0);
+#pragma omp parallel for schedule(static)
+  for (size_t i = 0; i < n_events; i++) mov_cond_row(events[i], t.data() + i * MOV_COND_WIDTH);
+  *height = h;
+  return t;
+}
+
 // The reference's own sanity identities (debug_assert / assert in the row builders); returns false when one fails.
 static inline bool check_row(int chip, const AluEvent& e, const F* r) {
   switch (chip) {

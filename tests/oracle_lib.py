@@ -238,3 +238,14 @@ def tracegen_jump(jump_events, fixed_log2_rows=-1):
     _check(lib().orc_tracegen_jump(C.c_void_p(ev.ctypes.data), C.c_size_t(len(ev)), C.c_int(fixed_log2_rows), abi.as_u32p(out),
                                    C.c_size_t(out.size)))
     return out
+
+
+def tracegen_mov_cond(events, fixed_log2_rows=-1):
+    from ziren_amd import events as E
+    ev = np.ascontiguousarray(events, dtype=E.MOV_COND_EVENT)
+    rows = C.c_size_t()
+    _check(lib().orc_tracegen_alu_rows(C.c_size_t(len(ev)), C.c_int(fixed_log2_rows), C.byref(rows)))
+    out = np.zeros((rows.value, E.MOV_COND_WIDTH), dtype=np.uint32)
+    _check(lib().orc_tracegen_mov_cond(C.c_void_p(ev.ctypes.data), C.c_size_t(len(ev)), C.c_int(fixed_log2_rows), abi.as_u32p(out),
+                                       C.c_size_t(out.size)))
+    return out

@@ -36,6 +36,24 @@ def test_jump_constraints_hold(oracle):
     assert [lk.kind for lk in rec.sends] == [air.KIND_INSTRUCTION] and len(rec.receives) == 1
 
 
+def test_mov_cond_constraints_hold(oracle):
+    rec = chips.record_mov_cond_constraints()
+    for n in (0, 64, 3000):
+        t = F.from_monty(oracle.tracegen_mov_cond(E.synthetic_mov_cond_events(n, seed=n + 1)))
+        assert air.debug_constraints(rec.b, t) == []
+    t = t.copy()
+    t[5, 19] ^= 1            # c_eq_0.is_zero_byte[0].result
+    assert {row for _, row in air.debug_constraints(rec.b, t)} == {5}
+    # the instruction lookup carries prev_a in the `hi` word and is_rw_a = is_mne + is_meq
+    ev = E.synthetic_mov_cond_events(8, seed=2)
+    t = F.from_monty(oracle.tracegen_mov_cond(ev))
+    main = {c: t[:, c].astype(np.uint64) for c in range(t.shape[1])}
+    vals = np.array([v.apply_np({}, main) for v in rec.receives[0].values]).T
+    for i, e in enumerate(ev):
+        assert vals[i, 6] == e["opcode"] and vals[i, 19:23].tolist() == [(int(e["prev_a"]) >> (8 * k)) & 0xff for k in range(4)]
+        assert vals[i, 24] == (1 if e["opcode"] in (E.MEQ, E.MNE) else 0) and vals[i, 27] == 1
+
+
 def test_constraints_hold_on_reference_vectors(oracle):
     for chip, ev in golden_events().items():
         if chip == E.CHIP_BITWISE:
@@ -97,7 +115,7 @@ def test_to_virtual_pair_rejects_products():
 # ---- GPU ------------------------------------------------------------------------------------------------------------
 
 def alu_shard(oracle, log_rows, seed=11):
-    """Seven real chips (six ALU chips + Jump); AddSub at 2^log_rows rows, the others smaller; every trace also as oracle
+    """Eight real chips (six ALU chips, Jump, MovCond); AddSub at 2^log_rows rows, the others smaller; every trace also as oracle
     rows. The SRL events the executor derives from CLO/CLZ go to the ShiftRight chip (dependencies.rs:105-122), the ADD
     events it derives from JumpDirect to the AddSub chip."""
     spec = [(E.CHIP_ADD_SUB, log_rows, 0.9), (E.CHIP_BITWISE, log_rows - 1, 1.0), (E.CHIP_LT, log_rows - 1, 0.7),
@@ -116,11 +134,20 @@ def alu_shard(oracle, log_rows, seed=11):
     jc.trace = oracle.tracegen_jump(jumps, log_rows - 3)
     recs.append(jc)
     evs.append(("jump", jumps, log_rows - 3))
+    movs = E.synthetic_mov_cond_events(int((1 << (log_rows - 3)) * 0.6), seed=seed + 50)
+    mc = chips.record_mov_cond_chip(log_rows - 3)
+    mc.trace = oracle.tracegen_mov_cond(movs, log_rows - 3)
+    recs.append(mc)
+    evs.append(("mov_cond", movs, log_rows - 3))
     return recs, evs
 
 
 def device_trace(ctx, chip, ev, lh, blu=None):
-    return ctx.tracegen_jump(ev, lh) if chip == "jump" else ctx.tracegen_alu(chip, ev, lh, blu)
+    if chip == "jump":
+        return ctx.tracegen_jump(ev, lh)
+    if chip == "mov_cond":
+        return ctx.tracegen_mov_cond(ev, lh)
+    return ctx.tracegen_alu(chip, ev, lh, blu)
 
 
 def mirror_chip(rec, kinds=None):
@@ -173,7 +200,7 @@ def test_gpu_alu_shard_proof(hip_ctx, oracle, log_rows, queries, pow_bits):
     pc_start = F.to_monty(0x400000)
     hp = prover.HipProver(recs, fri, synth.NUM_PV_ELTS, ctx=hip_ctx)
     if log_rows > 8:
-        hp.specialize_quotient_kernels(recs[:7])   # the real chips through generated kernels, the mirrors interpreted
+        hp.specialize_quotient_kernels(recs[:8])   # the real chips through generated kernels, the mirrors interpreted
     pk = hp.setup([], [], pc_start, igcs)
     ch = prover.new_challenger()
     pk.observe_into(ch)
@@ -201,7 +228,7 @@ def test_gpu_alu_and_byte_chips_shard(hip_ctx, oracle):
     from ziren_amd import prover, synth
     log_rows = 11
     recs, evs = alu_shard(oracle, log_rows, seed=21)
-    streams = [(chip, ev) for chip, ev, _ in evs if chip != "jump"]
+    streams = [(chip, ev) for chip, ev, _ in evs if not isinstance(chip, str)]
     byte = chips.record_byte_chip(prep_index=0)
     byte.trace = oracle.tracegen_byte_mults(streams)
     byte.prep_trace = oracle.tracegen_byte_table()
@@ -230,9 +257,9 @@ def test_gpu_alu_and_byte_chips_shard(hip_ctx, oracle):
     assert np.array_equal(proof, oproof)
     assert oracle.verify_shard(opk, all_chips, fri, synth.NUM_PV_ELTS, start.copy(), proof) == 0
     # without the Byte chip's multiplicities the byte lookups do not balance: the verifier's cumulative-sum check fails
-    born[7].free()
+    born[8].free()
     empty = hip_ctx.byte_lookups()
-    born[7] = hip_ctx.tracegen_byte_mults(empty)
+    born[8] = hip_ctx.tracegen_byte_mults(empty)
     ch2 = start.copy()
     bad = hp.prove_shard(pk, pv, born, ch2).copy()
     assert oracle.verify_shard(opk, all_chips, fri, synth.NUM_PV_ELTS, start.copy(), bad) != 0

@@ -260,3 +260,30 @@ def test_gpu_jump_tracegen_matches_oracle(hip_ctx, oracle):
         assert (m.height, m.width) == want.shape
         assert np.array_equal(m.to_host(), want), n
         m.free()
+
+
+def test_mov_cond_rows_by_hand(oracle):
+    ev = np.zeros(2, dtype=E.MOV_COND_EVENT)
+    ev[0] = (0x100, 0x104, E.MEQ, [0, 0, 0], 0xaabbccdd, 0xaabbccdd, 0, 0x11223344)          # c == 0: a = b
+    ev[1] = (0x104, 0x108, E.WSBH, [0, 0, 0], 0x33441122, 0x44332211, 0, 0)                   # bytes swapped in halfwords
+    r = canon(oracle.tracegen_mov_cond(ev))
+    assert r.shape == (16, E.MOV_COND_WIDTH) and not r[2:].any()
+    assert r[0, 2:6].tolist() == [0xdd, 0xcc, 0xbb, 0xaa] and r[0, 6:10].tolist() == [0x44, 0x33, 0x22, 0x11]
+    assert r[0, 18:29].tolist() == [0, 1, 0, 1, 0, 1, 0, 1, 1, 1, 1] and r[0, 29:32].tolist() == [0, 1, 0]
+    assert r[1, 2:6].tolist() == [0x22, 0x11, 0x44, 0x33] and r[1, 10:14].tolist() == [0x11, 0x22, 0x33, 0x44] and r[1, 31] == 1
+    ev[0]["c"] = 0x00050000                                                                   # one non-zero byte
+    r = canon(oracle.tracegen_mov_cond(ev[:1]))[0]
+    assert r[22] == pow(5, F.P - 2, F.P) and r[18:29].tolist()[1::2][:4] == [1, 1, 0, 1] and r[26:29].tolist() == [1, 0, 0]
+
+
+@pytest.mark.gpu
+def test_gpu_mov_cond_tracegen_matches_oracle(hip_ctx, oracle):
+    from ziren_amd import lib
+    assert lib.load().zkm_tracegen_mov_cond_width() == E.MOV_COND_WIDTH
+    for n, fixed in ((0, -1), (1, -1), (17, -1), (4000, -1), (70001, 17)):
+        ev = E.synthetic_mov_cond_events(n, seed=n + 5)
+        m = hip_ctx.tracegen_mov_cond(ev, fixed)
+        want = oracle.tracegen_mov_cond(ev, fixed)
+        assert (m.height, m.width) == want.shape
+        assert np.array_equal(m.to_host(), want), n
+        m.free()

@@ -100,10 +100,10 @@ class _Rec:
     def receive_alu_instruction(self, pc, next_pc, opcode, a, b, c, mult):
         self.receive_instruction(pc, next_pc, next_pc + 4, opcode, a, b, c, 1, mult)
 
-    def receive_instruction(self, pc, next_pc, next_next_pc, opcode, a, b, c, is_sequential, mult):
-        """InstructionAirBuilder::receive_instruction (builder.rs:237-280) with shard, clk, num_extra_cycles, hi,
-        op_a_immutable, is_rw_a, is_check_memory and is_halt zero, as every chip here calls it."""
-        vals = [0, 0, pc, next_pc, next_next_pc, 0, opcode] + list(a) + list(b) + list(c) + [0, 0, 0, 0] + [0, 0, 0, 0, is_sequential]
+    def receive_instruction(self, pc, next_pc, next_next_pc, opcode, a, b, c, is_sequential, mult, hi=(0, 0, 0, 0), is_rw_a=0):
+        """InstructionAirBuilder::receive_instruction (builder.rs:237-280) with shard, clk, num_extra_cycles,
+        op_a_immutable, is_check_memory and is_halt zero, as every chip here calls it."""
+        vals = [0, 0, pc, next_pc, next_next_pc, 0, opcode] + list(a) + list(b) + list(c) + list(hi) + [0, is_rw_a, 0, 0, is_sequential]
         self.receives.append(air.Lookup([air.to_virtual_pair(v) for v in vals], air.to_virtual_pair(mult), air.KIND_INSTRUCTION))
 
 
@@ -388,6 +388,57 @@ def _jump(r: _Rec):
     r.send_alu(E.ADD, next_next_pc, next_pc, op_b, l[IS_JUMPDIRECT])
 
 
+def _is_zero_word(b, word, cols, is_real):
+    """IsZeroWordOperation::eval (operations/is_zero_word.rs:40-72) over IsZeroOperation::eval (is_zero.rs:33-49)."""
+    for i in range(4):
+        inverse, result = cols[2 * i], cols[2 * i + 1]
+        is_zero = 1 - inverse * word[i]
+        b.when(is_real).assert_eq(is_zero, result)
+        b.when(is_real).assert_bool(result)
+        b.when(is_real).when(result).assert_zero(word[i])
+    lower, upper, res = cols[8], cols[9], cols[10]
+    b.assert_bool(is_real)
+    real = b.when(is_real)
+    real.assert_bool(lower)
+    real.assert_bool(upper)
+    real.assert_bool(res)
+    real.assert_eq(lower, cols[1] * cols[3])
+    real.assert_eq(upper, cols[5] * cols[7])
+    real.assert_eq(res, lower * upper)
+
+
+def _mov_cond(r: _Rec):
+    """MovCondChip::eval (misc/mov_cond/mod.rs:172-257)."""
+    l, b = r.local, r.b
+    PC, NEXT_PC, OP_A, PREV_A, OP_B, OP_C, C_EQ_0, IS_MNE, IS_MEQ, IS_WSBH = 0, 1, 2, 6, 10, 14, 18, 29, 30, 31
+    op_a, prev_a, op_b, op_c = l[OP_A:OP_A + 4], l[PREV_A:PREV_A + 4], l[OP_B:OP_B + 4], l[OP_C:OP_C + 4]
+    c_eq_0 = l[C_EQ_0:C_EQ_0 + 11]
+    result = c_eq_0[10]
+    is_real = l[IS_MNE] + l[IS_MEQ] + l[IS_WSBH]
+    cpu_opcode = l[IS_WSBH] * E.WSBH + l[IS_MEQ] * E.MEQ + l[IS_MNE] * E.MNE
+    r.receive_instruction(l[PC], l[NEXT_PC], l[NEXT_PC] + 4, cpu_opcode, op_a, op_b, op_c, 1, is_real, hi=prev_a,
+                          is_rw_a=l[IS_MNE] + l[IS_MEQ])
+    _is_zero_word(b, op_c, c_eq_0, is_real)
+    for i in range(4):
+        b.when(l[IS_MEQ]).when(result).assert_eq(op_a[i], op_b[i])
+    for i in range(4):
+        b.when(l[IS_MEQ]).when_not(result).assert_eq(op_a[i], prev_a[i])
+    for i in range(4):
+        b.when(l[IS_MNE]).when_not(result).assert_eq(op_a[i], op_b[i])
+    for i in range(4):
+        b.when(l[IS_MNE]).when(result).assert_eq(op_a[i], prev_a[i])
+    b.when(l[IS_WSBH]).assert_eq(op_a[0], op_b[1])
+    b.when(l[IS_WSBH]).assert_eq(op_a[1], op_b[0])
+    b.when(l[IS_WSBH]).assert_eq(op_a[2], op_b[3])
+    b.when(l[IS_WSBH]).assert_eq(op_a[3], op_b[2])
+    for i in range(4):
+        b.when(l[IS_WSBH]).assert_zero(prev_a[i])
+    b.assert_bool(l[IS_MNE])
+    b.assert_bool(l[IS_MEQ])
+    b.assert_bool(l[IS_WSBH])
+    b.assert_bool(is_real)
+
+
 def _byte(r: _Rec):
     """ByteChip::eval (bytes/air.rs:20-74): one receive per ByteOpcode, in ByteOpcode::all() order."""
     m, t = r.local, r.prep
@@ -465,3 +516,21 @@ def record_jump_constraints() -> _Rec:
     r = _Rec(E.JUMP_WIDTH)
     _jump(r)
     return r
+
+
+def record_mov_cond_constraints() -> _Rec:
+    r = _Rec(E.MOV_COND_WIDTH)
+    _mov_cond(r)
+    return r
+
+
+def record_mov_cond_chip(log_height: int) -> RecordedChip:
+    """The MovCond chip (crates/core/machine/src/misc/mov_cond/mod.rs): MovCondEvents, 32 columns, local_only (:135-137)."""
+    r = record_mov_cond_constraints()
+    lqd = 1
+    r.b.perm_ext_width = air.local_permutation_trace_width(len(r.sends) + len(r.receives), 1 << lqd)
+    air.eval_permutation_constraints(r.b, r.sends, r.receives, 1 << lqd, False)
+    program = r.b.assemble()
+    return RecordedChip(name="MovCond", log_height=log_height, main_width=E.MOV_COND_WIDTH, log_quotient_degree=lqd,
+                        local_only=True, sends=r.sends, receives=r.receives, program=program,
+                        lookups_blob=air.encode_lookups(r.sends, r.receives), num_constraints=int(program[2]))

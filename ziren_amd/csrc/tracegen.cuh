@@ -11,7 +11,8 @@
 //   ShiftRight  sr/mod.rs:88-137, :232-339, padding rows :183-186
 //   CloClz      clo_clz/mod.rs:41-63, :105-133, padding rows :147-163
 // and for the Jump chip (JumpEvents): crates/core/machine/src/control_flow/jump/columns.rs:11-39, trace.rs:92-113,
-// operations/koala_bear_word.rs:27-42.
+// operations/koala_bear_word.rs:27-42; and the MovCond chip (MovCondEvents): misc/mov_cond/mod.rs:38-65, :141-160,
+// operations/is_zero_word.rs:22-38.
 // Values are stored in Montgomery form, the in-memory form of the reference's KoalaBear (RowMajorMatrix<KoalaBear>).
 #pragma once
 #include "kb31.cuh"
@@ -26,10 +27,10 @@ struct AluEvent {  // #[repr(C)] AluEvent, crates/core/executor/src/events/instr
 
 // crates/core/executor/src/opcode.rs:26-48
 enum : uint32_t { ADD = 0, SUB = 1, SLL = 9, SRL = 10, SRA = 11, ROR = 12, SLT = 13, SLTU = 14, AND = 15, OR = 16, XOR = 17, NOR = 18, CLZ = 19, CLO = 20 };
-enum Chip { ADD_SUB = 0, BITWISE = 1, LT = 2, SHIFT_LEFT = 3, SHIFT_RIGHT = 4, CLO_CLZ = 5, NUM_ALU_CHIPS = 6, JUMP = 6, NUM_CHIPS = 7 };
+enum Chip { ADD_SUB = 0, BITWISE = 1, LT = 2, SHIFT_LEFT = 3, SHIFT_RIGHT = 4, CLO_CLZ = 5, NUM_ALU_CHIPS = 6, JUMP = 6, MOV_COND = 7, NUM_CHIPS = 8 };
 
 __host__ __device__ constexpr int chip_width(int chip) {
-  return chip == ADD_SUB ? 19 : chip == BITWISE ? 18 : chip == LT ? 32 : chip == SHIFT_LEFT ? 44 : chip == SHIFT_RIGHT ? 67 : chip == CLO_CLZ ? 17 : chip == JUMP ? 66 : 0;
+  return chip == ADD_SUB ? 19 : chip == BITWISE ? 18 : chip == LT ? 32 : chip == SHIFT_LEFT ? 44 : chip == SHIFT_RIGHT ? 67 : chip == CLO_CLZ ? 17 : chip == JUMP ? 66 : chip == MOV_COND ? 32 : 0;
 }
 
 constexpr int THREADS = 256;
@@ -228,6 +229,32 @@ template <> __device__ __forceinline__ void event_row<JUMP>(const AluEvent& e, u
   range_checker(r + NEXT_NEXT_PC_RC, next_next_pc);
 }
 
+// MovCond chip. MovCondEvent (events/instr.rs:286-302): pc, next_pc, opcode, a, b, c, prev_a — the AluEvent slots
+// (pc, next_pc, opcode, hi, a, b, c) therefore hold a in `hi`, b in `a`, c in `b` and prev_a in `c`.
+template <> __device__ __forceinline__ void event_row<MOV_COND>(const AluEvent& e, uint32_t* r) {
+  enum { PC = 0, NEXT_PC = 1, OP_A = 2, PREV_A = 6, OP_B = 10, OP_C = 14, C_EQ_0 = 18, IS_MNE = 29, IS_MEQ = 30, IS_WSBH = 31 };
+  const uint32_t a = e.hi, b = e.a, c = e.b, prev_a = e.c;
+  r[PC] = e.pc;
+  r[NEXT_PC] = e.next_pc;
+  word(r + OP_A, a);
+  word(r + PREV_A, prev_a);
+  word(r + OP_B, b);
+  word(r + OP_C, c);
+  uint32_t res[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {  // IsZeroOperation per byte: (inverse, result)
+    const uint32_t byte = (c >> (8 * i)) & 0xff;
+    r[C_EQ_0 + 2 * i] = byte ? kb::from_monty(kb::inv(kb::to_monty(byte))) : 0u;
+    res[i] = r[C_EQ_0 + 2 * i + 1] = fbool(byte == 0);
+  }
+  r[C_EQ_0 + 8] = res[0] & res[1];
+  r[C_EQ_0 + 9] = res[2] & res[3];
+  r[C_EQ_0 + 10] = fbool(c == 0);
+  r[IS_MNE] = fbool(e.opcode == 51);
+  r[IS_MEQ] = fbool(e.opcode == 50);
+  r[IS_WSBH] = fbool(e.opcode == 52);
+}
+
 // ---- byte lookups: the ALU chips' generate_dependencies, ByteChip::generate_trace and ByteChip::trace -----------------
 // ByteOpcode, crates/core/executor/src/opcode.rs:195-216
 enum : uint32_t { B_AND = 0, B_OR = 1, B_XOR = 2, B_SLL = 3, B_U8RANGE = 4, B_SHRCARRY = 5, B_LTU = 6, B_MSB = 7, B_U16RANGE = 8, B_NOR = 9 };
@@ -308,7 +335,8 @@ template <> __device__ __forceinline__ void row_lookups<CLO_CLZ>(const uint32_t*
   lookup(counts, B_LTU, r[2], 33);       // a < 33
 }
 
-template <> __device__ __forceinline__ void row_lookups<JUMP>(const uint32_t*, uint32_t, const LookupSink&) {}  // none
+template <> __device__ __forceinline__ void row_lookups<JUMP>(const uint32_t*, uint32_t, const LookupSink&) {}      // none
+template <> __device__ __forceinline__ void row_lookups<MOV_COND>(const uint32_t*, uint32_t, const LookupSink&) {}  // none
 
 // events: n_events records of seven words; out: column-major, `height` rows; grid = height / (tiles * THREADS), with
 // tiles = 1 for the plain row writer (most blocks in flight) and TILES_PER_BLOCK when counting.

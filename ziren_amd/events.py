@@ -19,6 +19,7 @@ SLT, SLTU = 13, 14
 AND, OR, XOR, NOR = 15, 16, 17, 18
 CLZ, CLO = 19, 20
 JUMP, JUMPI, JUMPDIRECT = 27, 28, 29
+MEQ, MNE, WSBH = 50, 51, 52
 UNUSED_PC, DEFAULT_PC_INC = 1, 4  # crates/core/executor/src/executor.rs:44-47
 
 # #[repr(C)] JumpEvent, crates/core/executor/src/events/instr.rs:200-217 (28 bytes as well, different fields)
@@ -26,6 +27,11 @@ JUMP_EVENT = np.dtype([("pc", "<u4"), ("next_pc", "<u4"), ("next_next_pc", "<u4"
                        ("a", "<u4"), ("b", "<u4"), ("c", "<u4")])
 assert JUMP_EVENT.itemsize == 28
 JUMP_WIDTH = 66
+# #[repr(C)] MovCondEvent, crates/core/executor/src/events/instr.rs:286-302
+MOV_COND_EVENT = np.dtype([("pc", "<u4"), ("next_pc", "<u4"), ("opcode", "u1"), ("_pad", "u1", (3,)), ("a", "<u4"), ("b", "<u4"),
+                           ("c", "<u4"), ("prev_a", "<u4")])
+assert MOV_COND_EVENT.itemsize == 28
+MOV_COND_WIDTH = 32
 
 # zkm_alu_chip
 CHIP_ADD_SUB, CHIP_BITWISE, CHIP_LT, CHIP_SHIFT_LEFT, CHIP_SHIFT_RIGHT, CHIP_CLO_CLZ = range(6)
@@ -161,3 +167,28 @@ def jump_dependencies(jump_events: np.ndarray) -> np.ndarray:
     out["c"] = ev["b"]
     out["a"] = ev["next_pc"] + ev["b"]
     return out
+
+
+def synthetic_mov_cond_events(n: int, seed: int = 1) -> np.ndarray:
+    """n conditional-move / byte-swap instructions with the executor's semantics: MEQ a = (c == 0 ? b : prev_a),
+    MNE a = (c != 0 ? b : prev_a), WSBH a = bytes of b swapped within each halfword (prev_a = 0)."""
+    raw = F.SplitMix64(0x4d4f5600 + seed).next_u64(4 * n)
+    r0, r1, r2, r3 = raw[:n], raw[n:2 * n], raw[2 * n:3 * n], raw[3 * n:]
+    ev = np.zeros(n, dtype=MOV_COND_EVENT)
+    ev["pc"] = ((r0 % np.uint64(0x3fffff00)) & np.uint64(0xfffffffc)).astype(np.uint32)
+    ev["next_pc"] = ev["pc"] + 4
+    op = np.array([MEQ, MNE, WSBH], dtype=np.uint8)[(r0 >> np.uint64(40)) % np.uint64(3)]
+    ev["opcode"] = op
+    b = (r1 & np.uint64(0xffffffff)).astype(np.uint32)
+    c = (r2 & np.uint64(0xffffffff)).astype(np.uint32)
+    kind = (r3 >> np.uint64(8)) % np.uint64(8)
+    c = np.where(kind < 3, np.uint32(0), c)                                  # c = 0 often
+    c = np.where(kind == 3, c & np.uint32(0x00ff0000), c)                    # a single non-zero byte (or zero)
+    c = np.where(kind == 4, c & np.uint32(0xff000000), c)
+    prev_a = (r3 >> np.uint64(32)).astype(np.uint32)
+    swapped = ((b & np.uint32(0x00ff00ff)) << np.uint32(8)) | ((b & np.uint32(0xff00ff00)) >> np.uint32(8))
+    cz = c == 0
+    a = np.where(op == MEQ, np.where(cz, b, prev_a), np.where(op == MNE, np.where(cz, prev_a, b), swapped))
+    ev["a"], ev["b"], ev["c"] = a, b, np.where(op == WSBH, np.uint32(0), c)
+    ev["prev_a"] = np.where(op == WSBH, np.uint32(0), prev_a)
+    return ev

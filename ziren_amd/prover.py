@@ -117,6 +117,16 @@ class Context:
         L = lib.load()
         return DeviceMatrix(self, h, int(L.zkm_matrix_height(h)), int(L.zkm_matrix_width(h)))
 
+    def tracegen_mov_cond(self, events: np.ndarray, fixed_log2_rows: int = -1) -> DeviceMatrix:
+        """`generate_trace` of the MovCond chip on the device (zkm_tracegen_mov_cond); dtype events.MOV_COND_EVENT."""
+        from . import events as _ev
+        ev = np.ascontiguousarray(events, dtype=_ev.MOV_COND_EVENT)
+        h = C.c_void_p()
+        lib.check(lib.load().zkm_tracegen_mov_cond(self.h, C.c_void_p(ev.ctypes.data if len(ev) else None), C.c_size_t(len(ev)),
+                                                   C.c_int(fixed_log2_rows), C.byref(h)))
+        L = lib.load()
+        return DeviceMatrix(self, h, int(L.zkm_matrix_height(h)), int(L.zkm_matrix_width(h)))
+
     def tracegen_flat(self, words: np.ndarray, width: int, fixed_log2_rows: int = -1) -> DeviceMatrix:
         """Padded trace of a chip whose rows are its records end to end (zkm_tracegen_flat): recursion BaseAlu / ExtAlu."""
         w = np.ascontiguousarray(words, dtype=np.uint32).reshape(-1)
