@@ -273,6 +273,13 @@ size_t zkm_tracegen_jump_width(void);
 int zkm_tracegen_jump(zkm_ctx* ctx, const zkm_jump_event* events, size_t n_events, int fixed_log2_rows,
                       zkm_matrix** out);
 
+/* The Branch chip (crates/core/machine/src/control_flow/branch/: BEQ, BNE, BLTZ, BLEZ, BGTZ, BGEZ): BranchEvents have the
+ * JumpEvent layout (crates/core/executor/src/events/instr.rs:161-178). 62 columns, zero padding rows; rows of branches
+ * that are not taken record byte lookups (range checks of next_pc and next_next_pc), counted into `blu` if given. */
+typedef zkm_jump_event zkm_branch_event;
+size_t zkm_tracegen_branch_width(void);
+int zkm_tracegen_branch(zkm_ctx* ctx, const zkm_branch_event* events, size_t n_events, int fixed_log2_rows,
+                        zkm_byte_lookups* blu, zkm_matrix** out);
 /* The MovCond chip (crates/core/machine/src/misc/mov_cond/mod.rs: MEQ, MNE, WSBH): MovCondEvents, byte-for-byte the
  * #[repr(C)] struct of crates/core/executor/src/events/instr.rs:286-302. 32 columns, zero padding rows, no byte lookups. */
 typedef struct zkm_mov_cond_event {

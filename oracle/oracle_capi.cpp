@@ -417,4 +417,17 @@ int orc_tracegen_mov_cond(const void* events, size_t n_events, int fixed_log2_ro
   ORC_CATCH
 }
 
+// Branch chip (BranchEvent = JumpEvent layout): row-major Montgomery trace, 62 columns; byte_counts (may be NULL) is a
+// 65536 x 10 row-major array of plain counters that receives the byte lookups of the rows (not-taken branches)
+int orc_tracegen_branch(const void* events, size_t n_events, int fixed_log2_rows, uint32_t* out, size_t out_cap, uint32_t* byte_counts) {
+  ORC_TRY
+  size_t h;
+  std::vector<uint64_t> cnt(byte_counts ? tracegen::BYTE_ROWS * tracegen::NUM_BYTE_OPS : 0, 0);
+  std::vector<F> t = tracegen::generate_branch((const tracegen::JumpEvent*)events, n_events, fixed_log2_rows, &h, byte_counts ? cnt.data() : nullptr);
+  if (t.size() > out_cap) throw std::runtime_error("trace buffer too small");
+  for (size_t i = 0; i < t.size(); i++) out[i] = to_monty(t[i]);
+  for (size_t i = 0; i < cnt.size(); i++) byte_counts[i] += (uint32_t)cnt[i];
+  ORC_CATCH
+}
+
 }  // extern "C"

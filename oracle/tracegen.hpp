@@ -452,4 +452,54 @@ static inline std::vector<F> byte_table() {
   return t;
 }
 
+// ---- Branch chip: BranchEvent has JumpEvent's layout (events/instr.rs:161-178); columns control_flow/branch/columns.rs:11-66,
+// row builder trace.rs:94-141
+static const size_t BRANCH_WIDTH = 62;
+enum { OP_BEQ = 21, OP_BGEZ = 22, OP_BGTZ = 23, OP_BLEZ = 24, OP_BLTZ = 25, OP_BNE = 26 };
+static inline bool branch_row(const JumpEvent& e, F* r) {  // returns `branching`
+  enum { PC = 0, NEXT_PC = 1, NEXT_PC_RC = 5, TARGET_PC = 19, NEXT_NEXT_PC = 23, NEXT_NEXT_PC_RC = 27, OP_A = 41, OP_B = 45, OP_C = 49,
+         IS_BEQ = 53, IS_BNE = 54, IS_BLTZ = 55, IS_BLEZ = 56, IS_BGTZ = 57, IS_BGEZ = 58, IS_BRANCHING = 59, A_GT_B = 60, A_LT_B = 61 };
+  r[PC] = fu32(e.pc);
+  r[IS_BEQ] = e.opcode == OP_BEQ; r[IS_BNE] = e.opcode == OP_BNE; r[IS_BLTZ] = e.opcode == OP_BLTZ;
+  r[IS_BGTZ] = e.opcode == OP_BGTZ; r[IS_BLEZ] = e.opcode == OP_BLEZ; r[IS_BGEZ] = e.opcode == OP_BGEZ;
+  word(r + OP_A, e.a); word(r + OP_B, e.b); word(r + OP_C, e.c);
+  const bool eq = e.a == e.b, lt = (int32_t)e.a < (int32_t)e.b, gt = (int32_t)e.a > (int32_t)e.b;
+  r[A_LT_B] = lt; r[A_GT_B] = gt;
+  bool branching = false;
+  switch (e.opcode) {
+    case OP_BEQ: branching = eq; break;
+    case OP_BNE: branching = !eq; break;
+    case OP_BLTZ: branching = lt; break;
+    case OP_BLEZ: branching = lt || eq; break;
+    case OP_BGTZ: branching = gt; break;
+    case OP_BGEZ: branching = eq || gt; break;
+    default: throw std::runtime_error("tracegen: invalid branch opcode");
+  }
+  word(r + NEXT_PC, e.next_pc);
+  word(r + TARGET_PC, e.next_pc + e.c);
+  word(r + NEXT_NEXT_PC, e.next_next_pc);
+  range_checker(r + NEXT_PC_RC, e.next_pc);
+  range_checker(r + NEXT_NEXT_PC_RC, e.next_next_pc);
+  r[IS_BRANCHING] = branching;
+  return branching;
+}
+static inline std::vector<F> generate_branch(const JumpEvent* events, size_t n_events, int fixed_log2_rows, size_t* height,
+                                             uint64_t* byte_counts /* nullable: [row][op] */) {
+  const size_t h = padded_rows(n_events, fixed_log2_rows);
+  std::vector<F> t(h * BRANCH_WIDTH, 0);
+  for (size_t i = 0; i < n_events; i++) {
+    F* r = t.data() + i * BRANCH_WIDTH;
+    const bool branching = branch_row(events[i], r);
+    if (!branching && byte_counts) {  // trace.rs:137-140: range checks of next_pc and next_next_pc
+      std::vector<ByteLookup> lk;
+      range_checks(lk, r + 1, 4);
+      range_checks(lk, r + 23, 4);
+      for (const ByteLookup& l : lk) byte_counts[(((size_t)l.b << 8) + l.c) * NUM_BYTE_OPS + l.op]++;
+    }
+  }
+  *height = h;
+  return t;
+}
+
+
 }  // namespace tracegen

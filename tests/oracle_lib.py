@@ -249,3 +249,16 @@ def tracegen_mov_cond(events, fixed_log2_rows=-1):
     _check(lib().orc_tracegen_mov_cond(C.c_void_p(ev.ctypes.data), C.c_size_t(len(ev)), C.c_int(fixed_log2_rows), abi.as_u32p(out),
                                        C.c_size_t(out.size)))
     return out
+
+
+def tracegen_branch(events, fixed_log2_rows=-1, byte_counts=None):
+    """Branch chip rows; byte_counts (optional (65536, 10) uint32 array) accumulates the rows' byte lookups in place."""
+    from ziren_amd import events as E
+    ev = np.ascontiguousarray(events, dtype=E.BRANCH_EVENT)
+    rows = C.c_size_t()
+    _check(lib().orc_tracegen_alu_rows(C.c_size_t(len(ev)), C.c_int(fixed_log2_rows), C.byref(rows)))
+    out = np.zeros((rows.value, E.BRANCH_WIDTH), dtype=np.uint32)
+    bc = abi.as_u32p(byte_counts) if byte_counts is not None else None
+    _check(lib().orc_tracegen_branch(C.c_void_p(ev.ctypes.data), C.c_size_t(len(ev)), C.c_int(fixed_log2_rows), abi.as_u32p(out),
+                                     C.c_size_t(out.size), bc))
+    return out

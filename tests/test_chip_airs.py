@@ -36,6 +36,18 @@ def test_jump_constraints_hold(oracle):
     assert [lk.kind for lk in rec.sends] == [air.KIND_INSTRUCTION] and len(rec.receives) == 1
 
 
+def test_branch_constraints_hold(oracle):
+    rec = chips.record_branch_constraints()
+    for n in (0, 64, 3000):
+        t = F.from_monty(oracle.tracegen_branch(E.synthetic_branch_events(n, seed=n + 1)))
+        assert air.debug_constraints(rec.b, t) == []
+    t = t.copy()
+    t[5, 59] ^= 1            # is_branching
+    assert {row for _, row in air.debug_constraints(rec.b, t)} == {5}
+    kinds = [lk.kind for lk in rec.sends]
+    assert kinds.count(air.KIND_INSTRUCTION) == 3 and kinds.count(air.KIND_BYTE) == 4 and len(rec.receives) == 1
+
+
 def test_mov_cond_constraints_hold(oracle):
     rec = chips.record_mov_cond_constraints()
     for n in (0, 64, 3000):
@@ -115,15 +127,18 @@ def test_to_virtual_pair_rejects_products():
 # ---- GPU ------------------------------------------------------------------------------------------------------------
 
 def alu_shard(oracle, log_rows, seed=11):
-    """Eight real chips (six ALU chips, Jump, MovCond); AddSub at 2^log_rows rows, the others smaller; every trace also as oracle
+    """Nine real chips (six ALU chips, Jump, MovCond, Branch); AddSub at 2^log_rows rows, the others smaller; every trace also as oracle
     rows. The SRL events the executor derives from CLO/CLZ go to the ShiftRight chip (dependencies.rs:105-122), the ADD
     events it derives from JumpDirect to the AddSub chip."""
-    spec = [(E.CHIP_ADD_SUB, log_rows, 0.9), (E.CHIP_BITWISE, log_rows - 1, 1.0), (E.CHIP_LT, log_rows - 1, 0.7),
+    spec = [(E.CHIP_ADD_SUB, log_rows, 0.85), (E.CHIP_BITWISE, log_rows - 1, 1.0), (E.CHIP_LT, log_rows - 1, 0.6),
             (E.CHIP_SHIFT_LEFT, log_rows - 2, 0.55), (E.CHIP_SHIFT_RIGHT, log_rows - 2, 0.6), (E.CHIP_CLO_CLZ, log_rows - 3, 0.8)]
     streams = {chip: E.synthetic_alu_events(chip, int((1 << lh) * fill), seed=seed + chip) for chip, lh, fill in spec}
     jumps = E.synthetic_jump_events(int((1 << (log_rows - 3)) * 0.75), seed=seed + 40)
     streams[E.CHIP_SHIFT_RIGHT] = np.concatenate([streams[E.CHIP_SHIFT_RIGHT], E.cloclz_dependencies(streams[E.CHIP_CLO_CLZ])])
-    streams[E.CHIP_ADD_SUB] = np.concatenate([streams[E.CHIP_ADD_SUB], E.jump_dependencies(jumps)])   # dependencies.rs:230-248
+    branches = E.synthetic_branch_events(int((1 << (log_rows - 3)) * 0.7), seed=seed + 60)
+    lt_dep, add_dep = E.branch_dependencies(branches)                                                 # dependencies.rs:181-227
+    streams[E.CHIP_ADD_SUB] = np.concatenate([streams[E.CHIP_ADD_SUB], E.jump_dependencies(jumps), add_dep])   # dependencies.rs:230-248
+    streams[E.CHIP_LT] = np.concatenate([streams[E.CHIP_LT], lt_dep])
     recs, evs = [], []
     for chip, lh, _ in spec:
         rc = chips.record_chip(chip, lh)
@@ -139,6 +154,10 @@ def alu_shard(oracle, log_rows, seed=11):
     mc.trace = oracle.tracegen_mov_cond(movs, log_rows - 3)
     recs.append(mc)
     evs.append(("mov_cond", movs, log_rows - 3))
+    bc = chips.record_branch_chip(log_rows - 3)
+    bc.trace = oracle.tracegen_branch(branches, log_rows - 3)
+    recs.append(bc)
+    evs.append(("branch", branches, log_rows - 3))
     return recs, evs
 
 
@@ -147,6 +166,8 @@ def device_trace(ctx, chip, ev, lh, blu=None):
         return ctx.tracegen_jump(ev, lh)
     if chip == "mov_cond":
         return ctx.tracegen_mov_cond(ev, lh)
+    if chip == "branch":
+        return ctx.tracegen_branch(ev, lh, blu)
     return ctx.tracegen_alu(chip, ev, lh, blu)
 
 
@@ -200,7 +221,7 @@ def test_gpu_alu_shard_proof(hip_ctx, oracle, log_rows, queries, pow_bits):
     pc_start = F.to_monty(0x400000)
     hp = prover.HipProver(recs, fri, synth.NUM_PV_ELTS, ctx=hip_ctx)
     if log_rows > 8:
-        hp.specialize_quotient_kernels(recs[:8])   # the real chips through generated kernels, the mirrors interpreted
+        hp.specialize_quotient_kernels(recs[:9])   # the real chips through generated kernels, the mirrors interpreted
     pk = hp.setup([], [], pc_start, igcs)
     ch = prover.new_challenger()
     pk.observe_into(ch)
@@ -230,7 +251,11 @@ def test_gpu_alu_and_byte_chips_shard(hip_ctx, oracle):
     recs, evs = alu_shard(oracle, log_rows, seed=21)
     streams = [(chip, ev) for chip, ev, _ in evs if not isinstance(chip, str)]
     byte = chips.record_byte_chip(prep_index=0)
-    byte.trace = oracle.tracegen_byte_mults(streams)
+    branch_counts = np.zeros((1 << 16, 10), dtype=np.uint32)   # the Branch chip's range checks (not-taken branches)
+    for chip, ev, lh in evs:
+        if chip == "branch":
+            oracle.tracegen_branch(ev, lh, branch_counts)
+    byte.trace = oracle.tracegen_byte_mults(streams, branch_counts)
     byte.prep_trace = oracle.tracegen_byte_table()
     mirrors = [mirror_chip(r, kinds=(air.KIND_INSTRUCTION,)) for r in recs]
     all_chips = recs + [byte] + mirrors
@@ -257,9 +282,9 @@ def test_gpu_alu_and_byte_chips_shard(hip_ctx, oracle):
     assert np.array_equal(proof, oproof)
     assert oracle.verify_shard(opk, all_chips, fri, synth.NUM_PV_ELTS, start.copy(), proof) == 0
     # without the Byte chip's multiplicities the byte lookups do not balance: the verifier's cumulative-sum check fails
-    born[8].free()
+    born[9].free()
     empty = hip_ctx.byte_lookups()
-    born[8] = hip_ctx.tracegen_byte_mults(empty)
+    born[9] = hip_ctx.tracegen_byte_mults(empty)
     ch2 = start.copy()
     bad = hp.prove_shard(pk, pv, born, ch2).copy()
     assert oracle.verify_shard(opk, all_chips, fri, synth.NUM_PV_ELTS, start.copy(), bad) != 0

@@ -287,3 +287,36 @@ def test_gpu_mov_cond_tracegen_matches_oracle(hip_ctx, oracle):
         assert (m.height, m.width) == want.shape
         assert np.array_equal(m.to_host(), want), n
         m.free()
+
+
+def test_branch_rows_by_hand(oracle):
+    ev = np.zeros(2, dtype=E.BRANCH_EVENT)
+    ev[0] = (0x200, 0x204, 0x184, E.BNE, [0, 0, 0], 7, 9, 0xffffff80)        # taken: next_next_pc = 0x204 - 0x80
+    ev[1] = (0x204, 0x208, 0x20c, E.BGTZ, [0, 0, 0], 0xfffffffb, 0, 0x40)    # -5 > 0 is false: falls through
+    counts = np.zeros((1 << 16, 10), dtype=np.uint32)
+    r = canon(oracle.tracegen_branch(ev, -1, counts))
+    assert r.shape == (16, E.BRANCH_WIDTH) and not r[2:].any()
+    assert r[0, 1:5].tolist() == [4, 2, 0, 0] and r[0, 19:23].tolist() == [0x84, 1, 0, 0] and r[0, 23:27].tolist() == [0x84, 1, 0, 0]
+    assert r[0, 53:62].tolist() == [0, 1, 0, 0, 0, 0, 1, 0, 1]                # is_bne, branching, a_lt_b
+    assert r[1, 53:62].tolist() == [0, 0, 0, 0, 1, 0, 0, 0, 1]                # is_bgtz, not branching, a_lt_b (signed)
+    # only the branch that is not taken records range checks: bytes of 0x208 and of 0x20c, in pairs
+    assert counts.sum() == 4 and counts[(0x08 << 8) | 0x02, 4] == 1 and counts[(0x0c << 8) | 0x02, 4] == 1 and counts[0, 4] == 2
+    lt, add = E.branch_dependencies(ev)
+    assert lt["a"].tolist() == [1, 0, 1, 0] and len(add) == 1 and int(add["a"][0]) == 0x184
+
+
+@pytest.mark.gpu
+def test_gpu_branch_tracegen_matches_oracle(hip_ctx, oracle):
+    from ziren_amd import lib
+    assert lib.load().zkm_tracegen_branch_width() == E.BRANCH_WIDTH
+    for n, fixed in ((0, -1), (1, -1), (17, -1), (4000, -1), (70001, 17)):
+        ev = E.synthetic_branch_events(n, seed=n + 5)
+        counts = np.zeros((1 << 16, 10), dtype=np.uint32)
+        want = oracle.tracegen_branch(ev, fixed, counts)
+        blu = hip_ctx.byte_lookups()
+        m = hip_ctx.tracegen_branch(ev, fixed, blu)
+        assert (m.height, m.width) == want.shape
+        assert np.array_equal(m.to_host(), want), n
+        mults = hip_ctx.tracegen_byte_mults(blu)
+        assert np.array_equal(F.from_monty(mults.to_host()), counts), n
+        m.free(); mults.free(); blu.free()

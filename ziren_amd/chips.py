@@ -100,10 +100,12 @@ class _Rec:
     def receive_alu_instruction(self, pc, next_pc, opcode, a, b, c, mult):
         self.receive_instruction(pc, next_pc, next_pc + 4, opcode, a, b, c, 1, mult)
 
-    def receive_instruction(self, pc, next_pc, next_next_pc, opcode, a, b, c, is_sequential, mult, hi=(0, 0, 0, 0), is_rw_a=0):
+    def receive_instruction(self, pc, next_pc, next_next_pc, opcode, a, b, c, is_sequential, mult, hi=(0, 0, 0, 0), is_rw_a=0,
+                            op_a_immutable=0):
         """InstructionAirBuilder::receive_instruction (builder.rs:237-280) with shard, clk, num_extra_cycles,
-        op_a_immutable, is_check_memory and is_halt zero, as every chip here calls it."""
-        vals = [0, 0, pc, next_pc, next_next_pc, 0, opcode] + list(a) + list(b) + list(c) + list(hi) + [0, is_rw_a, 0, 0, is_sequential]
+        is_check_memory and is_halt zero, as every chip here calls it."""
+        vals = [0, 0, pc, next_pc, next_next_pc, 0, opcode] + list(a) + list(b) + list(c) + list(hi) + \
+               [op_a_immutable, is_rw_a, 0, 0, is_sequential]
         self.receives.append(air.Lookup([air.to_virtual_pair(v) for v in vals], air.to_virtual_pair(mult), air.KIND_INSTRUCTION))
 
 
@@ -388,6 +390,48 @@ def _jump(r: _Rec):
     r.send_alu(E.ADD, next_next_pc, next_pc, op_b, l[IS_JUMPDIRECT])
 
 
+def _branch(r: _Rec):
+    """BranchChip::eval (control_flow/branch/air.rs:22-210)."""
+    l, b = r.local, r.b
+    (PC, NEXT_PC, NEXT_PC_RC, TARGET_PC, NEXT_NEXT_PC, NEXT_NEXT_PC_RC, OP_A, OP_B, OP_C, IS_BEQ, IS_BNE, IS_BLTZ, IS_BLEZ, IS_BGTZ,
+     IS_BGEZ, IS_BRANCHING, A_GT_B, A_LT_B) = 0, 1, 5, 19, 23, 27, 41, 45, 49, 53, 54, 55, 56, 57, 58, 59, 60, 61
+    next_pc, target_pc, next_next_pc = l[NEXT_PC:NEXT_PC + 4], l[TARGET_PC:TARGET_PC + 4], l[NEXT_NEXT_PC:NEXT_NEXT_PC + 4]
+    op_a, op_b, op_c = l[OP_A:OP_A + 4], l[OP_B:OP_B + 4], l[OP_C:OP_C + 4]
+    for f in (IS_BEQ, IS_BNE, IS_BLTZ, IS_BGEZ, IS_BLEZ, IS_BGTZ):
+        b.assert_bool(l[f])
+    is_real = l[IS_BEQ] + l[IS_BNE] + l[IS_BLTZ] + l[IS_BGEZ] + l[IS_BLEZ] + l[IS_BGTZ]
+    b.assert_bool(is_real)
+    opcode = (l[IS_BEQ] * E.BEQ + l[IS_BNE] * E.BNE + l[IS_BLTZ] * E.BLTZ + l[IS_BGEZ] * E.BGEZ + l[IS_BLEZ] * E.BLEZ
+              + l[IS_BGTZ] * E.BGTZ)
+    r.receive_instruction(l[PC], _reduce(b, next_pc), _reduce(b, next_next_pc), opcode, op_a, op_b, op_c, 0, is_real,
+                          op_a_immutable=1)
+    _word_range_check(b, next_pc, l[NEXT_PC_RC:NEXT_PC_RC + 14], is_real)
+    _word_range_check(b, next_next_pc, l[NEXT_NEXT_PC_RC:NEXT_NEXT_PC_RC + 14], is_real)
+    r.send_alu(E.ADD, target_pc, next_pc, op_c, l[IS_BRANCHING])
+    b.when(is_real).when_not(l[IS_BRANCHING]).assert_eq(_reduce(b, next_pc) + 4, _reduce(b, next_next_pc))
+    r.slice_range_check_u8(next_pc, is_real - l[IS_BRANCHING])
+    r.slice_range_check_u8(next_next_pc, is_real - l[IS_BRANCHING])
+    for i in range(4):
+        b.when(is_real).when(l[IS_BRANCHING]).assert_eq(target_pc[i], next_next_pc[i])
+    b.when_not(is_real).assert_zero(l[IS_BRANCHING])
+    b.when(is_real).assert_bool(l[IS_BRANCHING])
+    br, gt, lt = l[IS_BRANCHING], l[A_GT_B], l[A_LT_B]
+    b.when(l[IS_BEQ] * br).assert_zero(gt + lt)
+    b.when(l[IS_BEQ]).when_not(br).assert_one(gt + lt)
+    b.when(l[IS_BNE] * br).assert_one(gt + lt)
+    b.when(l[IS_BNE]).when_not(br).assert_zero(gt + lt)
+    b.when(l[IS_BLTZ] * br).assert_one(lt)
+    b.when(l[IS_BLTZ]).when_not(br).assert_zero(lt)
+    b.when(l[IS_BLEZ] * br).assert_zero(gt)
+    b.when(l[IS_BLEZ]).when_not(br).assert_one(gt)
+    b.when(l[IS_BGTZ] * br).assert_one(gt)
+    b.when(l[IS_BGTZ]).when_not(br).assert_zero(gt)
+    b.when(l[IS_BGEZ] * br).assert_zero(lt)
+    b.when(l[IS_BGEZ]).when_not(br).assert_one(lt)
+    r.send_alu(E.SLT, [lt, 0, 0, 0], op_a, op_b, is_real)    # Word::extend_var
+    r.send_alu(E.SLT, [gt, 0, 0, 0], op_b, op_a, is_real)
+
+
 def _is_zero_word(b, word, cols, is_real):
     """IsZeroWordOperation::eval (operations/is_zero_word.rs:40-72) over IsZeroOperation::eval (is_zero.rs:33-49)."""
     for i in range(4):
@@ -532,5 +576,23 @@ def record_mov_cond_chip(log_height: int) -> RecordedChip:
     air.eval_permutation_constraints(r.b, r.sends, r.receives, 1 << lqd, False)
     program = r.b.assemble()
     return RecordedChip(name="MovCond", log_height=log_height, main_width=E.MOV_COND_WIDTH, log_quotient_degree=lqd,
+                        local_only=True, sends=r.sends, receives=r.receives, program=program,
+                        lookups_blob=air.encode_lookups(r.sends, r.receives), num_constraints=int(program[2]))
+
+
+def record_branch_constraints() -> _Rec:
+    r = _Rec(E.BRANCH_WIDTH)
+    _branch(r)
+    return r
+
+
+def record_branch_chip(log_height: int) -> RecordedChip:
+    """The Branch chip (crates/core/machine/src/control_flow/branch/): BranchEvents, 62 columns, local_only (trace.rs:88-90)."""
+    r = record_branch_constraints()
+    lqd = 1
+    r.b.perm_ext_width = air.local_permutation_trace_width(len(r.sends) + len(r.receives), 1 << lqd)
+    air.eval_permutation_constraints(r.b, r.sends, r.receives, 1 << lqd, False)
+    program = r.b.assemble()
+    return RecordedChip(name="Branch", log_height=log_height, main_width=E.BRANCH_WIDTH, log_quotient_degree=lqd,
                         local_only=True, sends=r.sends, receives=r.receives, program=program,
                         lookups_blob=air.encode_lookups(r.sends, r.receives), num_constraints=int(program[2]))

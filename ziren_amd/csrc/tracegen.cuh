@@ -12,7 +12,7 @@
 //   CloClz      clo_clz/mod.rs:41-63, :105-133, padding rows :147-163
 // and for the Jump chip (JumpEvents): crates/core/machine/src/control_flow/jump/columns.rs:11-39, trace.rs:92-113,
 // operations/koala_bear_word.rs:27-42; and the MovCond chip (MovCondEvents): misc/mov_cond/mod.rs:38-65, :141-160,
-// operations/is_zero_word.rs:22-38.
+// operations/is_zero_word.rs:22-38; and the Branch chip (BranchEvents): control_flow/branch/columns.rs:11-66, trace.rs:94-141.
 // Values are stored in Montgomery form, the in-memory form of the reference's KoalaBear (RowMajorMatrix<KoalaBear>).
 #pragma once
 #include "kb31.cuh"
@@ -27,10 +27,10 @@ struct AluEvent {  // #[repr(C)] AluEvent, crates/core/executor/src/events/instr
 
 // crates/core/executor/src/opcode.rs:26-48
 enum : uint32_t { ADD = 0, SUB = 1, SLL = 9, SRL = 10, SRA = 11, ROR = 12, SLT = 13, SLTU = 14, AND = 15, OR = 16, XOR = 17, NOR = 18, CLZ = 19, CLO = 20 };
-enum Chip { ADD_SUB = 0, BITWISE = 1, LT = 2, SHIFT_LEFT = 3, SHIFT_RIGHT = 4, CLO_CLZ = 5, NUM_ALU_CHIPS = 6, JUMP = 6, MOV_COND = 7, NUM_CHIPS = 8 };
+enum Chip { ADD_SUB = 0, BITWISE = 1, LT = 2, SHIFT_LEFT = 3, SHIFT_RIGHT = 4, CLO_CLZ = 5, NUM_ALU_CHIPS = 6, JUMP = 6, MOV_COND = 7, BRANCH = 8, NUM_CHIPS = 9 };
 
 __host__ __device__ constexpr int chip_width(int chip) {
-  return chip == ADD_SUB ? 19 : chip == BITWISE ? 18 : chip == LT ? 32 : chip == SHIFT_LEFT ? 44 : chip == SHIFT_RIGHT ? 67 : chip == CLO_CLZ ? 17 : chip == JUMP ? 66 : chip == MOV_COND ? 32 : 0;
+  return chip == ADD_SUB ? 19 : chip == BITWISE ? 18 : chip == LT ? 32 : chip == SHIFT_LEFT ? 44 : chip == SHIFT_RIGHT ? 67 : chip == CLO_CLZ ? 17 : chip == JUMP ? 66 : chip == MOV_COND ? 32 : chip == BRANCH ? 62 : 0;
 }
 
 constexpr int THREADS = 256;
@@ -229,6 +229,33 @@ template <> __device__ __forceinline__ void event_row<JUMP>(const AluEvent& e, u
   range_checker(r + NEXT_NEXT_PC_RC, next_next_pc);
 }
 
+// Branch chip. BranchEvent (events/instr.rs:161-178) has JumpEvent's layout: pc, next_pc, next_next_pc, opcode, a, b, c.
+template <> __device__ __forceinline__ void event_row<BRANCH>(const AluEvent& e, uint32_t* r) {
+  enum { PC = 0, NEXT_PC = 1, NEXT_PC_RC = 5, TARGET_PC = 19, NEXT_NEXT_PC = 23, NEXT_NEXT_PC_RC = 27, OP_A = 41, OP_B = 45, OP_C = 49,
+         IS_BEQ = 53, IS_BNE = 54, IS_BLTZ = 55, IS_BLEZ = 56, IS_BGTZ = 57, IS_BGEZ = 58, IS_BRANCHING = 59, A_GT_B = 60, A_LT_B = 61 };
+  const uint32_t pc = e.pc, next_pc = e.next_pc, next_next_pc = e.opcode, opcode = e.hi & 0xff, a = e.a, b = e.b, c = e.c;
+  const bool eq = a == b, lt = (int32_t)a < (int32_t)b, gt = (int32_t)a > (int32_t)b;
+  const bool branching = opcode == 21 ? eq : opcode == 26 ? !eq : opcode == 25 ? lt : opcode == 24 ? (lt || eq) : opcode == 23 ? gt : (eq || gt);
+  r[PC] = pc;
+  r[IS_BEQ] = fbool(opcode == 21);
+  r[IS_BNE] = fbool(opcode == 26);
+  r[IS_BLTZ] = fbool(opcode == 25);
+  r[IS_BLEZ] = fbool(opcode == 24);
+  r[IS_BGTZ] = fbool(opcode == 23);
+  r[IS_BGEZ] = fbool(opcode == 22);
+  word(r + OP_A, a);
+  word(r + OP_B, b);
+  word(r + OP_C, c);
+  r[A_LT_B] = fbool(lt);
+  r[A_GT_B] = fbool(gt);
+  word(r + NEXT_PC, next_pc);
+  word(r + TARGET_PC, next_pc + c);
+  word(r + NEXT_NEXT_PC, next_next_pc);
+  range_checker(r + NEXT_PC_RC, next_pc);
+  range_checker(r + NEXT_NEXT_PC_RC, next_next_pc);
+  r[IS_BRANCHING] = fbool(branching);
+}
+
 // MovCond chip. MovCondEvent (events/instr.rs:286-302): pc, next_pc, opcode, a, b, c, prev_a — the AluEvent slots
 // (pc, next_pc, opcode, hi, a, b, c) therefore hold a in `hi`, b in `a`, c in `b` and prev_a in `c`.
 template <> __device__ __forceinline__ void event_row<MOV_COND>(const AluEvent& e, uint32_t* r) {
@@ -337,6 +364,11 @@ template <> __device__ __forceinline__ void row_lookups<CLO_CLZ>(const uint32_t*
 
 template <> __device__ __forceinline__ void row_lookups<JUMP>(const uint32_t*, uint32_t, const LookupSink&) {}      // none
 template <> __device__ __forceinline__ void row_lookups<MOV_COND>(const uint32_t*, uint32_t, const LookupSink&) {}  // none
+template <> __device__ __forceinline__ void row_lookups<BRANCH>(const uint32_t* r, uint32_t, const LookupSink& counts) {
+  if (r[59]) return;               // taken branches record nothing (control_flow/branch/trace.rs:137-140)
+  range_checks(counts, r + 1, 4);   // next_pc
+  range_checks(counts, r + 23, 4);  // next_next_pc
+}
 
 // events: n_events records of seven words; out: column-major, `height` rows; grid = height / (tiles * THREADS), with
 // tiles = 1 for the plain row writer (most blocks in flight) and TILES_PER_BLOCK when counting.
@@ -363,7 +395,7 @@ __global__ __launch_bounds__(THREADS) void alu_rows(const uint32_t* __restrict__
     for (int c = 0; c < W; c++) r[c] = 0;
     if (row < n_events) {
       const uint32_t* p = events + row * 7;
-      AluEvent e{p[0], p[1], CHIP == JUMP ? p[2] : (p[2] & 0xff), p[3], p[4], p[5], p[6]};
+      AluEvent e{p[0], p[1], (CHIP == JUMP || CHIP == BRANCH) ? p[2] : (p[2] & 0xff), p[3], p[4], p[5], p[6]};
       event_row<CHIP>(e, r);
       if (count) row_lookups<CHIP>(r, e.opcode, LookupSink{hkeys, hvals, HASH_SLOTS - 1, counts});
     } else {

@@ -1103,6 +1103,7 @@ int zkm_ctx_create(int device, zkm_ctx** out) {
   HIP_CHECK(hipFuncSetAttribute((const void*)tracegen::alu_rows<tracegen::CLO_CLZ>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
   HIP_CHECK(hipFuncSetAttribute((const void*)tracegen::alu_rows<tracegen::JUMP>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
   HIP_CHECK(hipFuncSetAttribute((const void*)tracegen::alu_rows<tracegen::MOV_COND>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+  HIP_CHECK(hipFuncSetAttribute((const void*)tracegen::alu_rows<tracegen::BRANCH>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
   HIP_CHECK(hipFuncSetAttribute((const void*)lde::lde_cols<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIP_CHECK(hipFuncSetAttribute((const void*)lde::lde_cols<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIP_CHECK(hipFuncSetAttribute((const void*)stark::quotient_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -1550,6 +1551,7 @@ static int tracegen_events(zkm_ctx* ctx, int chip, const void* events, size_t n_
       case tracegen::CLO_CLZ: launch_alu_rows<tracegen::CLO_CLZ>(ctx, d_events, n_events, height, m->d, counts); break;
       case tracegen::JUMP: launch_alu_rows<tracegen::JUMP>(ctx, d_events, n_events, height, m->d, counts); break;
       case tracegen::MOV_COND: launch_alu_rows<tracegen::MOV_COND>(ctx, d_events, n_events, height, m->d, counts); break;
+      case tracegen::BRANCH: launch_alu_rows<tracegen::BRANCH>(ctx, d_events, n_events, height, m->d, counts); break;
     }
     ctx->mark("trace generation");
     ctx->end_timing(false);  // synchronises: the caller's event buffer is free again
@@ -1613,6 +1615,11 @@ int zkm_tracegen_flat(zkm_ctx* ctx, const uint32_t* words, size_t n_words, size_
   API_END
 }
 
+size_t zkm_tracegen_branch_width(void) { return (size_t)tracegen::chip_width(tracegen::BRANCH); }
+int zkm_tracegen_branch(zkm_ctx* ctx, const zkm_branch_event* events, size_t n_events, int fixed_log2_rows, zkm_byte_lookups* blu,
+                        zkm_matrix** out) {
+  return tracegen_events(ctx, tracegen::BRANCH, events, n_events, fixed_log2_rows, blu, out);
+}
 size_t zkm_tracegen_mov_cond_width(void) { return (size_t)tracegen::chip_width(tracegen::MOV_COND); }
 int zkm_tracegen_mov_cond(zkm_ctx* ctx, const zkm_mov_cond_event* events, size_t n_events, int fixed_log2_rows, zkm_matrix** out) {
   return tracegen_events(ctx, tracegen::MOV_COND, events, n_events, fixed_log2_rows, nullptr, out);

@@ -20,6 +20,7 @@ AND, OR, XOR, NOR = 15, 16, 17, 18
 CLZ, CLO = 19, 20
 JUMP, JUMPI, JUMPDIRECT = 27, 28, 29
 MEQ, MNE, WSBH = 50, 51, 52
+BEQ, BGEZ, BGTZ, BLEZ, BLTZ, BNE = 21, 22, 23, 24, 25, 26
 UNUSED_PC, DEFAULT_PC_INC = 1, 4  # crates/core/executor/src/executor.rs:44-47
 
 # #[repr(C)] JumpEvent, crates/core/executor/src/events/instr.rs:200-217 (28 bytes as well, different fields)
@@ -27,6 +28,8 @@ JUMP_EVENT = np.dtype([("pc", "<u4"), ("next_pc", "<u4"), ("next_next_pc", "<u4"
                        ("a", "<u4"), ("b", "<u4"), ("c", "<u4")])
 assert JUMP_EVENT.itemsize == 28
 JUMP_WIDTH = 66
+BRANCH_EVENT = JUMP_EVENT    # #[repr(C)] BranchEvent, events/instr.rs:161-178: the same seven fields
+BRANCH_WIDTH = 62
 # #[repr(C)] MovCondEvent, crates/core/executor/src/events/instr.rs:286-302
 MOV_COND_EVENT = np.dtype([("pc", "<u4"), ("next_pc", "<u4"), ("opcode", "u1"), ("_pad", "u1", (3,)), ("a", "<u4"), ("b", "<u4"),
                            ("c", "<u4"), ("prev_a", "<u4")])
@@ -192,3 +195,55 @@ def synthetic_mov_cond_events(n: int, seed: int = 1) -> np.ndarray:
     ev["a"], ev["b"], ev["c"] = a, b, np.where(op == WSBH, np.uint32(0), c)
     ev["prev_a"] = np.where(op == WSBH, np.uint32(0), prev_a)
     return ev
+
+
+def branch_taken(ev: np.ndarray) -> np.ndarray:
+    """`branching` of crates/core/machine/src/control_flow/branch/trace.rs:119-127 (a and b compared as signed words)."""
+    a, b, op = ev["a"].astype(np.int32), ev["b"].astype(np.int32), ev["opcode"]
+    eq, lt, gt = a == b, a < b, a > b
+    return np.select([op == BEQ, op == BNE, op == BLTZ, op == BLEZ, op == BGTZ, op == BGEZ], [eq, ~eq, lt, lt | eq, gt, eq | gt],
+                     default=False).astype(bool)
+
+
+def synthetic_branch_events(n: int, seed: int = 1) -> np.ndarray:
+    """n branch instructions: next_next_pc = next_pc + c when the branch is taken, next_pc + 4 otherwise."""
+    raw = F.SplitMix64(0x42524100 + seed).next_u64(4 * n)
+    r0, r1, r2, r3 = raw[:n], raw[n:2 * n], raw[2 * n:3 * n], raw[3 * n:]
+    ev = np.zeros(n, dtype=BRANCH_EVENT)
+    pc = ((r0 % np.uint64(0x3fffff00)) & np.uint64(0xfffffffc)).astype(np.uint32)
+    ev["pc"] = pc
+    ev["next_pc"] = pc + 4
+    ev["opcode"] = np.array([BEQ, BGEZ, BGTZ, BLEZ, BLTZ, BNE], dtype=np.uint8)[(r0 >> np.uint64(40)) % np.uint64(6)]
+    a = (r1 & np.uint64(0xffffffff)).astype(np.uint32)
+    b = (r2 & np.uint64(0xffffffff)).astype(np.uint32)
+    kind = (r3 >> np.uint64(8)) % np.uint64(8)
+    b = np.where(kind < 2, a, b)                            # equal operands
+    b = np.where(kind == 2, np.uint32(0), b)                # the *Z forms compare with register zero
+    a = np.where(kind == 3, np.uint32(0x80000000), a)
+    ev["a"], ev["b"] = a, b
+    off = (((r3 >> np.uint64(32)) % np.uint64(0x20000)).astype(np.int64) - 0x10000) * 4        # +-256 KiB, word aligned
+    ev["c"] = (off & 0xffffffff).astype(np.uint32)
+    taken = branch_taken(ev)
+    ev["next_next_pc"] = np.where(taken, ev["next_pc"] + ev["c"], ev["next_pc"] + 4)
+    return ev
+
+
+def branch_dependencies(branch_events: np.ndarray):
+    """emit_branch_dependencies (crates/core/executor/src/dependencies.rs:181-227): two SLT events per branch for the Lt
+    chip (a < b and b < a, signed) and, for taken branches, one ADD event for the AddSub chip. Returns (lt, add_sub)."""
+    ev = branch_events
+    n = len(ev)
+    a, b = ev["a"].astype(np.int32), ev["b"].astype(np.int32)
+    lt = np.zeros(2 * n, dtype=ALU_EVENT)
+    lt["pc"] = UNUSED_PC
+    lt["next_pc"] = UNUSED_PC + DEFAULT_PC_INC
+    lt["opcode"] = SLT
+    lt["a"][0::2], lt["b"][0::2], lt["c"][0::2] = (a < b), ev["a"], ev["b"]
+    lt["a"][1::2], lt["b"][1::2], lt["c"][1::2] = (a > b), ev["b"], ev["a"]
+    t = ev[branch_taken(ev)]
+    add = np.zeros(len(t), dtype=ALU_EVENT)
+    add["pc"] = UNUSED_PC
+    add["next_pc"] = UNUSED_PC + DEFAULT_PC_INC
+    add["opcode"] = ADD
+    add["a"], add["b"], add["c"] = t["next_next_pc"], t["next_pc"], t["c"]
+    return lt, add

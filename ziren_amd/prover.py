@@ -117,6 +117,16 @@ class Context:
         L = lib.load()
         return DeviceMatrix(self, h, int(L.zkm_matrix_height(h)), int(L.zkm_matrix_width(h)))
 
+    def tracegen_branch(self, events: np.ndarray, fixed_log2_rows: int = -1, blu: "ByteLookups" = None) -> DeviceMatrix:
+        """`generate_trace` of the Branch chip on the device (zkm_tracegen_branch); dtype events.BRANCH_EVENT."""
+        from . import events as _ev
+        ev = np.ascontiguousarray(events, dtype=_ev.BRANCH_EVENT)
+        h = C.c_void_p()
+        lib.check(lib.load().zkm_tracegen_branch(self.h, C.c_void_p(ev.ctypes.data if len(ev) else None), C.c_size_t(len(ev)),
+                                                 C.c_int(fixed_log2_rows), blu.h if blu is not None else None, C.byref(h)))
+        L = lib.load()
+        return DeviceMatrix(self, h, int(L.zkm_matrix_height(h)), int(L.zkm_matrix_width(h)))
+
     def tracegen_mov_cond(self, events: np.ndarray, fixed_log2_rows: int = -1) -> DeviceMatrix:
         """`generate_trace` of the MovCond chip on the device (zkm_tracegen_mov_cond); dtype events.MOV_COND_EVENT."""
         from . import events as _ev
