@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Shard of the reference's real ALU chips + Byte chip (recorded AIRs, ziren_amd/chips.py): events -> device traces ->
+"""Shard of the reference's real chips — six ALU chips, Jump, MovCond, Branch and Byte (recorded AIRs, ziren_amd/chips.py): events -> device traces ->
 commit + open, timed per phase and per kernel. Real constraint programs and lookup shapes instead of the SYN stand-ins.
 
   python tools/bench_alu_shard.py [--log-rows 21] [--steps 3]
@@ -26,15 +26,27 @@ def main():
     ap.add_argument("--interpreter", action="store_true")
     args = ap.parse_args()
     k = args.log_rows
-    spec = [(E.CHIP_ADD_SUB, k), (E.CHIP_BITWISE, k - 1), (E.CHIP_LT, k - 1), (E.CHIP_SHIFT_LEFT, k - 2), (E.CHIP_SHIFT_RIGHT, k - 2)]
-    recs = [chips.record_chip(c, lh) for c, lh in spec] + [chips.record_byte_chip(0)]
+    spec = [(E.CHIP_ADD_SUB, k), (E.CHIP_BITWISE, k - 1), (E.CHIP_LT, k - 1), (E.CHIP_SHIFT_LEFT, k - 2), (E.CHIP_SHIFT_RIGHT, k - 2),
+            (E.CHIP_CLO_CLZ, k - 3)]
+    other = [("jump", k - 3, E.synthetic_jump_events, chips.record_jump_chip), ("mov_cond", k - 3, E.synthetic_mov_cond_events, chips.record_mov_cond_chip),
+             ("branch", k - 3, E.synthetic_branch_events, chips.record_branch_chip)]
+    fill = 0.6
+    streams = {c: E.synthetic_alu_events(c, int((1 << lh) * fill)) for c, lh in spec}
+    ostreams = {name: gen(int((1 << lh) * fill)) for name, lh, gen, _ in other}
+    # the events the executor derives from these instructions (crates/core/executor/src/dependencies.rs)
+    lt_dep, add_dep = E.branch_dependencies(ostreams["branch"])
+    streams[E.CHIP_SHIFT_RIGHT] = np.concatenate([streams[E.CHIP_SHIFT_RIGHT], E.cloclz_dependencies(streams[E.CHIP_CLO_CLZ])])
+    streams[E.CHIP_ADD_SUB] = np.concatenate([streams[E.CHIP_ADD_SUB], E.jump_dependencies(ostreams["jump"]), add_dep])
+    streams[E.CHIP_LT] = np.concatenate([streams[E.CHIP_LT], lt_dep])
+    recs = [chips.record_chip(c, lh) for c, lh in spec] + [rec(lh) for _, lh, _, rec in other] + [chips.record_byte_chip(0)]
     ctx = prover.Context(0)
-    evs = []
-    for c, lh in spec:   # the executor's event vectors, in page-locked host memory
-        ev = E.synthetic_alu_events(c, int((1 << lh) * 0.9))
+
+    def pin(ev):   # the executor's event vectors, in page-locked host memory
         pinned = ctx.host_alloc((len(ev) * 7,))
         pinned[...] = ev.view(np.uint32).reshape(-1)
-        evs.append((c, pinned.view(E.ALU_EVENT), lh))
+        return pinned.view(ev.dtype)
+
+    evs = [(c, pin(streams[c]), lh) for c, lh in spec] + [(name, pin(ostreams[name]), lh) for name, lh, _, _ in other]
     fri = abi.FriConfig(1, 84, 16)
     hp = prover.HipProver(recs, fri, synth.NUM_PV_ELTS, ctx=ctx, specialize=not args.interpreter)
     pv = F.to_monty(F.SplitMix64(3).uniform_field(synth.PROOF_MAX_NUM_PVS))
@@ -48,7 +60,16 @@ def main():
     for it in range(args.steps + 1):
         t0 = time.perf_counter()
         blu = ctx.byte_lookups()
-        born = [ctx.tracegen_alu(c, ev, lh, blu) for c, ev, lh in evs]
+        born = []
+        for c, ev, lh in evs:
+            if c == "jump":
+                born.append(ctx.tracegen_jump(ev, lh))
+            elif c == "mov_cond":
+                born.append(ctx.tracegen_mov_cond(ev, lh))
+            elif c == "branch":
+                born.append(ctx.tracegen_branch(ev, lh, blu))
+            else:
+                born.append(ctx.tracegen_alu(c, ev, lh, blu))
         born.append(ctx.tracegen_byte_mults(blu))
         blu.free()
         t1 = time.perf_counter()
@@ -62,7 +83,8 @@ def main():
             res.append({"tracegen_ms": (t1 - t0) * 1e3, "prove_ms": (t2 - t1) * 1e3, "phases": phases, "kernels": kern})
     r = res[-1]
     cells = sum((1 << c.log_height) * (c.main_width + 4 * c.perm_ext_width + 8) for c in recs)
-    print(json.dumps({"workload": f"ALU-{k}: AddSub 2^{k}, Bitwise/Lt 2^{k-1}, ShiftLeft/ShiftRight 2^{k-2}, Byte 2^16; 90% filled",
+    print(json.dumps({"workload": f"CORE9-{k}: AddSub 2^{k}, Bitwise/Lt 2^{k-1}, ShiftLeft/ShiftRight 2^{k-2}, CloClz/Jump/MovCond/Branch 2^{k-3}, "
+                                  "Byte 2^16; 60% filled plus the executor's dependency events",
                       "tracegen_ms": round(float(np.mean([x["tracegen_ms"] for x in res])), 3),
                       "prove_ms": round(float(np.mean([x["prove_ms"] for x in res])), 3),
                       "committed_cells": cells, "proof_words": int(len(proof)),
