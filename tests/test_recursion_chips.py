@@ -33,29 +33,65 @@ def test_row_counts():
         R.padded_rows(1000, 5)
 
 
-def mirror(rec):
-    """Memory chips on the other side of the ALU chips' lookups (mem/constant.rs, mem/variable.rs), mirrored."""
-    t, pt = F.from_monty(rec.trace), F.from_monty(rec.prep_trace)
-    main = {c: t[:, c].astype(np.uint64) for c in range(t.shape[1])}
-    prep = {c: pt[:, c].astype(np.uint64) for c in range(pt.shape[1])}
-    cols, sends, receives = [], [], []
-    for src, dst in ((rec.sends, receives), (rec.receives, sends)):
-        for lk in src:
-            first = len(cols)
-            for v in list(lk.values) + [lk.multiplicity]:
-                cols.append(v.apply_np(prep, main))
-            vals = [air.VirtualPairCol.single_main(first + j) for j in range(len(lk.values))]
-            dst.append(air.Lookup(vals, air.VirtualPairCol.single_main(first + len(lk.values)), lk.kind))
-    width = len(cols)
-    b = air.AirBuilder(width, 0, air.local_permutation_trace_width(len(sends) + len(receives), 2))
-    air.eval_permutation_constraints(b, sends, receives, 2, False)
-    program = b.assemble()
-    trace = np.empty((t.shape[0], width), dtype=np.uint32)
-    for c in range(width):
-        trace[:, c] = F.to_monty(cols[c])
-    return chips.RecordedChip(name=rec.name + "Memory", log_height=rec.log_height, main_width=width, sends=sends, receives=receives,
-                              program=program, lookups_blob=air.encode_lookups(sends, receives), num_constraints=int(program[2]),
-                              trace=trace)
+def balanced_shard(n_base, n_ext, n_const, seed, heights=(-1, -1, -1)):
+    """BaseAlu + ExtAlu + MemoryConst over one consistent program: (chips with host traces, flat record streams)."""
+    prog = R.balanced_program(n_base, n_ext, n_const, seed)
+    specs = (("base_instrs", "base_events", R.BASE_VALUE_COLS, False), ("ext_instrs", "ext_events", R.EXT_VALUE_COLS, True))
+    recs, streams = [], []
+    for idx, (ik, ek, vw, ext) in enumerate(specs):
+        prep = R.flat_trace(prog[ik], R.ENTRIES_PER_ROW * R.ACCESS_COLS, heights[idx])
+        main = R.flat_trace(prog[ek], R.ENTRIES_PER_ROW * vw, heights[idx])
+        rc = R.record_chip(ext, prep.shape[0].bit_length() - 1, prep_index=idx)
+        rc.trace, rc.prep_trace = main, prep
+        recs.append(rc)
+        streams.append((prog[ik], prog[ek]))
+    prep = R.flat_trace(prog["mem_entries"], R.CONST_MEM_ENTRIES_PER_ROW * R.CONST_MEM_ENTRY_COLS, heights[2], R.CONST_MEM_ENTRIES_PER_ROW)
+    rc = R.record_mem_const(prep.shape[0].bit_length() - 1, prep_index=2)
+    rc.trace, rc.prep_trace = np.zeros((prep.shape[0], 1), dtype=np.uint32), prep
+    recs.append(rc)
+    streams.append((prog["mem_entries"], None))
+    return recs, streams
+
+
+def test_mem_const_and_balance():
+    """MemoryConst has no constraints of its own (constant.rs:152-160); over a consistent program every memory lookup
+    sent is received: the multiset of (address, block) with signed multiplicities sums to zero."""
+    rec = R.record_mem_const(constraints_only=True)
+    assert len(rec.sends) == 2 and not rec.receives and rec.b.assemble()[2] == 0
+    recs, _ = balanced_shard(700, 300, 50, seed=9)
+    assert [r.trace.shape[0] for r in recs] == [256, 128, 128]
+    tally = {}
+    for r in recs:
+        t, pt = F.from_monty(r.trace), F.from_monty(r.prep_trace)
+        main = {c: t[:, c].astype(np.uint64) for c in range(t.shape[1])}
+        prep = {c: pt[:, c].astype(np.uint64) for c in range(pt.shape[1])}
+        for sign, lks in ((1, r.sends), (-1, r.receives)):
+            for lk in lks:
+                vals = np.stack([np.broadcast_to(v.apply_np(prep, main), (t.shape[0],)) for v in lk.values], axis=1)
+                mult = np.broadcast_to(lk.multiplicity.apply_np(prep, main), (t.shape[0],))
+                for row in np.nonzero(mult)[0]:
+                    key = tuple(int(x) for x in vals[row])
+                    tally[key] = (tally.get(key, 0) + sign * int(mult[row])) % F.P
+    assert tally and all(v == 0 for v in tally.values())
+
+
+def test_oracle_proves_balanced_recursion_shard(oracle):
+    """The three real chips alone make a shard the restated verifier accepts (cumulative sum zero); one wrong
+    multiplicity in the constant-memory table and it is rejected."""
+    from ziren_amd import synth
+    fri = abi.FriConfig(2, 42, 16)
+    pv = np.zeros(synth.PROOF_MAX_NUM_PVS, dtype=np.uint32)
+    igcs = F.to_monty(np.zeros(14, dtype=np.uint64))
+    for tamper, want in ((False, True), (True, False)):
+        recs, _ = balanced_shard(500, 300, 40, seed=5)
+        if tamper:
+            recs[2].prep_trace[0, 5] = F.to_monty((int(F.from_monty(recs[2].prep_trace[0, 5])) + 1) % F.P)
+        opk = oracle.Pk([r.prep_trace for r in recs], [1, 1, 1], F.to_monty(0), igcs, 2)
+        ch = oracle.new_challenger()
+        opk.observe_into(ch)
+        start = ch.copy()
+        proof, _ = oracle.prove_shard(opk, recs, [c.trace for c in recs], pv, fri, synth.NUM_PV_ELTS, ch)
+        assert (oracle.verify_shard(opk, recs, fri, synth.NUM_PV_ELTS, start.copy(), proof) == 0) == want
 
 
 @pytest.mark.gpu
@@ -77,36 +113,33 @@ def test_gpu_flat_tracegen(hip_ctx):
 @pytest.mark.gpu
 @pytest.mark.parametrize("log_blowup,queries", [(2, 42), (3, 28)])
 def test_gpu_recursion_alu_shard(hip_ctx, oracle, log_blowup, queries):
-    """BaseAlu + ExtAlu (+ mirrored memory chips) under the compress / shrink FRI configurations
+    """BaseAlu + ExtAlu + MemoryConst over one consistent program under the compress / shrink FRI configurations
     (crates/stark/src/kb31_poseidon2.rs:215-241): device-built traces, preprocessed tables in the proving key,
-    proof bit-identical to the oracle's and accepted by the restated verifier."""
+    memory lookups balancing between the real chips, proof bit-identical to the oracle's and accepted by the
+    restated verifier."""
     from ziren_amd import prover, synth
-    recs, streams = [], []
-    for idx, (ext, lh, n) in enumerate(((False, 10, 3500), (True, 9, 2000))):
-        ins, ev, prep, main = traces(ext, n, seed=40 + idx, fixed=lh)
-        rc = R.record_chip(ext, lh, prep_index=idx)
-        rc.trace, rc.prep_trace = main, prep
-        recs.append(rc)
-        streams.append((ins, ev, prep.shape[1], main.shape[1], lh))
-    all_chips = recs + [mirror(r) for r in recs]
+    recs, streams = balanced_shard(3500, 2000, 200, seed=40, heights=(10, 9, 9))
     fri = abi.FriConfig(log_blowup, queries, 16)
     pv = np.zeros(synth.PROOF_MAX_NUM_PVS, dtype=np.uint32)
-    igcs = F.to_monty(F.SplitMix64(4).uniform_field(14))
-    hp = prover.HipProver(all_chips, fri, synth.NUM_PV_ELTS, ctx=hip_ctx)
+    igcs = F.to_monty(np.zeros(14, dtype=np.uint64))
+    hp = prover.HipProver(recs, fri, synth.NUM_PV_ELTS, ctx=hip_ctx)
     hp.specialize_quotient_kernels(recs)
-    pk = hp.setup([hip_ctx.tracegen_flat(ins, pw, lh) for ins, _, pw, _, lh in streams], [1, 1], F.to_monty(0), igcs)
-    opk = oracle.Pk([r.prep_trace for r in recs], [1, 1], F.to_monty(0), igcs, log_blowup)
+    preps = [hip_ctx.tracegen_flat(ins, r.prep_trace.shape[1], r.log_height) for (ins, _), r in zip(streams, recs)]
+    for m, r in zip(preps, recs):
+        assert np.array_equal(m.to_host(), r.prep_trace)
+    pk = hp.setup(preps, [1, 1, 1], F.to_monty(0), igcs)
+    opk = oracle.Pk([r.prep_trace for r in recs], [1, 1, 1], F.to_monty(0), igcs, log_blowup)
     assert np.array_equal(pk.commit, opk.commitment())
     ch = prover.new_challenger()
     pk.observe_into(ch)
     start = ch.copy()
-    born = [hip_ctx.tracegen_flat(ev, mw, lh) for _, ev, _, mw, lh in streams]
-    born += [hip_ctx.upload(c.trace) for c in all_chips[2:]]
+    born = [hip_ctx.tracegen_flat(ev, r.trace.shape[1], r.log_height) for (_, ev), r in zip(streams[:2], recs[:2])]
+    born.append(hip_ctx.upload(recs[2].trace))
     proof = hp.prove_shard(pk, pv, born, ch).copy()
     och = oracle.new_challenger()
     opk.observe_into(och)
-    oproof, _ = oracle.prove_shard(opk, all_chips, [c.trace for c in all_chips], pv, fri, synth.NUM_PV_ELTS, och)
+    oproof, _ = oracle.prove_shard(opk, recs, [c.trace for c in recs], pv, fri, synth.NUM_PV_ELTS, och)
     assert np.array_equal(proof, oproof)
-    assert oracle.verify_shard(opk, all_chips, fri, synth.NUM_PV_ELTS, start.copy(), proof) == 0
+    assert oracle.verify_shard(opk, recs, fri, synth.NUM_PV_ELTS, start.copy(), proof) == 0
     for m in born:
         m.free()

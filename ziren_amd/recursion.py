@@ -103,6 +103,119 @@ def record_chip(ext: bool, log_height: int, prep_index: int, lqd: int = 1) -> ch
                               lookups_blob=air.encode_lookups(r.sends, r.receives), num_constraints=int(program[2]))
 
 
+CONST_MEM_ENTRIES_PER_ROW = 2   # NUM_CONST_MEM_ENTRIES_PER_ROW (chips/mem/constant.rs:15)
+CONST_MEM_ENTRY_COLS = 6         # (Block<F> value, MemoryAccessCols { addr, mult })
+
+
+def record_mem_const(log_height: int = 10, prep_index: int = 0, lqd: int = 1, constraints_only: bool = False):
+    """MemoryConstChip (crates/recursion/core/src/chips/mem/constant.rs): the program's memory writes (and reads, with
+    negated multiplicity) as a preprocessed table of (value block, address, multiplicity), two per row; the main trace is
+    one unused column; `eval` sends every entry (:152-160)."""
+    r = _RecRec(1, CONST_MEM_ENTRIES_PER_ROW * CONST_MEM_ENTRY_COLS)
+    p = r.prep
+    for k in range(CONST_MEM_ENTRIES_PER_ROW):
+        e = p[k * CONST_MEM_ENTRY_COLS:(k + 1) * CONST_MEM_ENTRY_COLS]
+        r.send_block(e[4], e[0:4], e[5])
+    if constraints_only:
+        return r
+    r.b.perm_ext_width = air.local_permutation_trace_width(len(r.sends) + len(r.receives), 1 << lqd)
+    air.eval_permutation_constraints(r.b, r.sends, r.receives, 1 << lqd, False)
+    program = r.b.assemble()
+    return chips.RecordedChip(name="MemoryConst", log_height=log_height, main_width=1, prep_width=r.b.prep_width,
+                              prep_index=prep_index, log_quotient_degree=lqd, local_only=True, sends=r.sends, receives=r.receives,
+                              program=program, lookups_blob=air.encode_lookups(r.sends, r.receives), num_constraints=int(program[2]))
+
+
+def balanced_program(n_base: int, n_ext: int, n_const: int = 64, seed: int = 1):
+    """A synthetic recursion program whose memory lookups balance exactly, as a real one's do: constants are written by
+    MemoryConst entries, every ALU instruction reads two earlier values (constants or earlier results of its own field)
+    and writes one, and each write's multiplicity is the number of later reads; a few results are read back by
+    MemoryConst `Read` entries (negative multiplicity). Returns a dict of flat Montgomery word arrays:
+    base_instrs, base_events, ext_instrs, ext_events, mem_entries (6 words each), plus the counts."""
+    rng = np.random.default_rng(seed)
+    P = F.P
+    addr = [1]
+
+    def new_addr():
+        addr[0] += 1
+        return addr[0]
+
+    def ext_mul(x, y):
+        out = [0, 0, 0, 0]
+        for i in range(4):
+            for j in range(4):
+                t = x[i] * y[j] % P
+                if i + j >= 4:
+                    out[i + j - 4] = (out[i + j - 4] + W * t) % P
+                else:
+                    out[i + j] = (out[i + j] + t) % P
+        return out
+
+    entries = {}   # addr -> {"val": [4], "reads": int, "kind": "const" | "base" | "ext", "instr": index}
+    pools = {"base": [], "ext": []}
+    for i in range(n_const):
+        a = new_addr()
+        ext = i % 2 == 1
+        v = [int(x) for x in rng.integers(0, P, 4)] if ext else [int(rng.integers(0, P)), 0, 0, 0]
+        entries[a] = {"val": v, "reads": 0, "kind": "const"}
+        pools["ext" if ext else "base"].append(a)
+    base_rows, ext_rows = [], []   # (opcode, addr_out, addr_in1, addr_in2, out, in1, in2)
+    for which, n, rows in (("base", n_base, base_rows), ("ext", n_ext, ext_rows)):
+        for _ in range(n):
+            op = int(rng.integers(0, 4))
+            a1, a2 = (pools[which][int(rng.integers(0, len(pools[which])))] for _ in range(2))
+            x, y = entries[a1]["val"], entries[a2]["val"]
+            if which == "base":
+                if op == DIV and y[0] == 0:
+                    op = ADD
+                o = [[(x[0] + y[0]) % P, (x[0] - y[0]) % P, x[0] * y[0] % P, x[0] * pow(y[0], P - 2, P) % P][op], 0, 0, 0]
+            else:
+                if op == DIV:   # out = in1 / in2 needs an extension inverse: produce it as in1 := in2 * c for a fresh out = c
+                    c = [int(v) for v in rng.integers(0, P, 4)]
+                    # replace in1 by a fresh constant equal to y * c so that the division is exact
+                    a1 = new_addr()
+                    entries[a1] = {"val": ext_mul(y, c), "reads": 0, "kind": "const"}
+                    x = entries[a1]["val"]
+                    o = c
+                else:
+                    o = [[(x[e] + y[e]) % P for e in range(4)], [(x[e] - y[e]) % P for e in range(4)], ext_mul(x, y)][op]
+            ao = new_addr()
+            entries[a1]["reads"] += 1
+            entries[a2]["reads"] += 1
+            entries[ao] = {"val": o, "reads": 0, "kind": which, "row": len(rows)}
+            pools[which].append(ao)
+            rows.append([op, ao, a1, a2, o, x, y])
+    # a few results are read back by the constant-memory table (MemAccessKind::Read: multiplicity negated)
+    mem = []   # (value block, addr, signed multiplicity)
+    results = [a for a, e in entries.items() if e["kind"] != "const"]
+    for a in results[:: max(1, len(results) // 8)]:
+        entries[a]["reads"] += 1
+        mem.append((entries[a]["val"], a, -1))
+    for a, e in entries.items():
+        if e["kind"] == "const":
+            mem.append((e["val"], a, e["reads"]))
+
+    def pack_alu(rows, ext):
+        ins = np.zeros((len(rows), ACCESS_COLS), dtype=np.uint64)
+        ev = np.zeros((len(rows), EXT_VALUE_COLS if ext else BASE_VALUE_COLS), dtype=np.uint64)
+        for i, (op, ao, a1, a2, o, x, y) in enumerate(rows):
+            ins[i, 0:3] = (ao, a1, a2)
+            ins[i, 3 + op] = 1
+            ins[i, 7] = entries[ao]["reads"]
+            ev[i] = (o + x + y) if ext else (o[0], x[0], y[0])
+        return F.to_monty(ins).reshape(-1), F.to_monty(ev).reshape(-1)
+
+    base_instrs, base_events = pack_alu(base_rows, False)
+    ext_instrs, ext_events = pack_alu(ext_rows, True)
+    m = np.zeros((len(mem), CONST_MEM_ENTRY_COLS), dtype=np.uint64)
+    for i, (v, a, mult) in enumerate(mem):
+        m[i, 0:4] = v
+        m[i, 4] = a
+        m[i, 5] = mult % P
+    return {"base_instrs": base_instrs, "base_events": base_events, "ext_instrs": ext_instrs, "ext_events": ext_events,
+            "mem_entries": F.to_monty(m).reshape(-1), "n_mem": len(mem)}
+
+
 def _ext_mul_np(x, y):
     out = [np.zeros(len(x[0]), dtype=np.uint64) for _ in range(4)]
     for i in range(4):
@@ -149,8 +262,8 @@ def synthetic_program(ext: bool, n_instr: int, seed: int = 1) -> Tuple[np.ndarra
     return F.to_monty(instrs).reshape(-1), F.to_monty(events).reshape(-1)
 
 
-def padded_rows(n_records: int, fixed_log2_rows: int = -1) -> int:
-    rows = -(-n_records // ENTRIES_PER_ROW)
+def padded_rows(n_records: int, fixed_log2_rows: int = -1, entries_per_row: int = ENTRIES_PER_ROW) -> int:
+    rows = -(-n_records // entries_per_row)
     if fixed_log2_rows >= 0:
         if rows > (1 << fixed_log2_rows):
             raise ValueError("fixed log2 rows is too small")
@@ -161,11 +274,11 @@ def padded_rows(n_records: int, fixed_log2_rows: int = -1) -> int:
     return h
 
 
-def flat_trace(words: np.ndarray, width: int, fixed_log2_rows: int = -1) -> np.ndarray:
+def flat_trace(words: np.ndarray, width: int, fixed_log2_rows: int = -1, entries_per_row: int = ENTRIES_PER_ROW) -> np.ndarray:
     """Host form of the padded trace (what generate_trace / generate_preprocessed_trace return): records end to end,
     zeros after them."""
-    recs = len(words) // (width // ENTRIES_PER_ROW)
-    h = padded_rows(recs, fixed_log2_rows)
+    recs = len(words) // (width // entries_per_row)
+    h = padded_rows(recs, fixed_log2_rows, entries_per_row)
     out = np.zeros(h * width, dtype=np.uint32)
     out[:len(words)] = words
     return out.reshape(h, width)
