@@ -26,6 +26,7 @@ import numpy as np
 from ziren_amd import abi, lib, prover, synth
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+POSEIDON2_ISSUE_CEILING_GPERMS = 8.3  # integer-issue ceiling of one permutation's instruction mix
 
 
 def cpu_baseline(log_rows_sample, fri):
@@ -249,6 +250,18 @@ def main():
                         "whole_shard": {"algorithmic_bytes": alg_bytes,
                                         "achieved": round(alg_bytes / (ms_per_step * 1e-3) / 1e9, 1),
                                         "frac": round(alg_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}}
+        # SURVEY 8d asks for the VALU side next to the HBM fraction: the hashing kernels are bound by integer
+        # instruction issue (4.66 k VALU instructions per permutation, ~19 k cycles per wavefront
+        # of 64 at the issue costs measured by tools/ubench_int.hip -> 8.3 G permutations/s for the chip)
+        valu = None
+        hashing = [n for n in ("compress_layer", "hash_leaves", "hash_fri_leaves", "compress_small") if n in kern_acc]
+        if hashing and M == 1:
+            perms = synth.shard_poseidon2_permutations(shard, fri.log_blowup)
+            hms = sum(kern_acc[n][0] for n in hashing) / steps
+            valu = {"bound": "valu-issue", "kernels": hashing, "poseidon2_permutations": perms, "ms": round(hms, 3),
+                    "achieved": round(perms / hms / 1e6, 3), "peak": POSEIDON2_ISSUE_CEILING_GPERMS, "unit": "Gperm/s",
+                    "frac": round(perms / hms / 1e6 / POSEIDON2_ISSUE_CEILING_GPERMS, 3), "valu_instr_per_permutation": 4660,
+                    "share_of_step": round(hms / ms_per_step, 3)}
         cpu = None
         if not args.no_cpu_baseline and world == 1:  # rank 0, N = 1 only
             ks = min(args.cpu_sample_log_rows, k)
@@ -269,7 +282,7 @@ def main():
                 "kernels_ms": {n: {"ms": round(v[0] / steps, 3), "launches": v[1] // steps,
                                    "GBps": round(v[2] / max(v[0], 1e-9) / 1e6, 1)} for n, v in
                                sorted(kern_acc.items(), key=lambda kv: -kv[1][0])},
-                "roofline": roofline, "cpu_baseline": cpu}
+                "roofline": roofline, "valu": valu, "cpu_baseline": cpu}
         print(json.dumps(line))
     farm.close()
 

@@ -280,6 +280,24 @@ typedef zkm_jump_event zkm_branch_event;
 size_t zkm_tracegen_branch_width(void);
 int zkm_tracegen_branch(zkm_ctx* ctx, const zkm_branch_event* events, size_t n_events, int fixed_log2_rows,
                         zkm_byte_lookups* blu, zkm_matrix** out);
+/* The Mul chip (crates/core/machine/src/alu/mul/mod.rs: MUL, MULT, MULTU): CompAluEvents, byte-for-byte the #[repr(C)]
+ * struct of crates/core/executor/src/events/instr.rs:50-73 with its MemoryWriteRecord (events/memory.rs:69-82), 64 bytes.
+ * Replaces MulChip::generate_trace (:162-190) and, with `blu`, its generate_dependencies (:192-213): 58 columns
+ * including the HI register's memory-access columns, zero padding rows; byte lookups per row: two MSB, eight U16Range
+ * (carries), four U8Range pairs (product bytes) and, for a real HI write, the two limbs of the timestamp difference. */
+typedef struct zkm_memory_write_record {
+  uint32_t value, shard, timestamp, prev_value, prev_shard, prev_timestamp;
+} zkm_memory_write_record;
+typedef struct zkm_comp_alu_event {
+  uint32_t shard, clk, pc, next_pc;
+  uint8_t opcode, _pad[3];
+  uint32_t hi, a, b, c;
+  zkm_memory_write_record hi_record;
+  uint8_t hi_record_is_real, _pad2[3];
+} zkm_comp_alu_event;
+size_t zkm_tracegen_mul_width(void);
+int zkm_tracegen_mul(zkm_ctx* ctx, const zkm_comp_alu_event* events, size_t n_events, int fixed_log2_rows,
+                     zkm_byte_lookups* blu, zkm_matrix** out);
 /* The MovCond chip (crates/core/machine/src/misc/mov_cond/mod.rs: MEQ, MNE, WSBH): MovCondEvents, byte-for-byte the
  * #[repr(C)] struct of crates/core/executor/src/events/instr.rs:286-302. 32 columns, zero padding rows, no byte lookups. */
 typedef struct zkm_mov_cond_event {

@@ -502,4 +502,97 @@ static inline std::vector<F> generate_branch(const JumpEvent* events, size_t n_e
 }
 
 
+// ---- Mul chip: CompAluEvents (crates/core/executor/src/events/instr.rs:50-73); columns alu/mul/mod.rs:79-141, row builder
+// :221-337, the HI-register access columns memory/consistency/columns.rs:18-45 filled by consistency/trace.rs:43-100
+struct MemoryWriteRecord { uint32_t value, shard, timestamp, prev_value, prev_shard, prev_timestamp; };
+struct CompAluEvent {
+  uint32_t shard, clk, pc, next_pc;
+  uint8_t opcode; uint8_t pad[3];
+  uint32_t hi, a, b, c;
+  MemoryWriteRecord hi_record;
+  uint8_t hi_record_is_real; uint8_t pad2[3];
+};
+static_assert(sizeof(CompAluEvent) == 64, "CompAluEvent is sixteen words");
+static const size_t MUL_WIDTH = 58;
+enum { OP_MUL = 2, OP_MULT = 3, OP_MULTU = 4 };
+enum { B_U8RANGE_OP = 4, B_MSB_OP = 7, B_U16RANGE_OP = 8 };   // ByteOpcode, opcode.rs:195-216
+
+// MemoryAccessCols::populate_access (consistency/trace.rs:69-100) for a write; `r` points at prev_value (13 columns)
+static inline void memory_write_cols(const MemoryWriteRecord& rec, F* r, std::vector<ByteLookup>* lk) {
+  enum { PREV_VALUE = 0, VALUE = 4, PREV_SHARD = 8, PREV_CLK = 9, COMPARE_CLK = 10, DIFF_16 = 11, DIFF_8 = 12 };
+  word(r + PREV_VALUE, rec.prev_value);
+  word(r + VALUE, rec.value);
+  r[PREV_SHARD] = fu32(rec.prev_shard);
+  r[PREV_CLK] = fu32(rec.prev_timestamp);
+  const bool use_clk = rec.prev_shard == rec.shard;
+  r[COMPARE_CLK] = use_clk;
+  const uint32_t prev_t = use_clk ? rec.prev_timestamp : rec.prev_shard, cur_t = use_clk ? rec.timestamp : rec.shard;
+  const uint32_t diff_minus_one = cur_t - prev_t - 1u;   // wrapping_sub
+  const uint32_t d16 = diff_minus_one & 0xffff, d8 = (diff_minus_one >> 16) & 0xff;
+  r[DIFF_16] = d16;
+  r[DIFF_8] = d8;
+  if (lk) {
+    lk->push_back(ByteLookup{B_U16RANGE_OP, (uint8_t)(d16 >> 8), (uint8_t)d16});   // the table row of U16Range is its value
+    lk->push_back(ByteLookup{B_U8RANGE_OP, 0, (uint8_t)d8});
+  }
+}
+
+static inline void mul_row(const CompAluEvent& e, F* r, std::vector<ByteLookup>* lk) {
+  enum { PC = 0, NEXT_PC = 1, HI = 2, A = 6, B = 10, C = 14, CARRY = 18, PRODUCT = 26, B_MSB = 34, C_MSB = 35, B_SIGN_EXTEND = 36,
+         C_SIGN_EXTEND = 37, IS_MUL = 38, IS_MULT = 39, IS_MULTU = 40, IS_REAL = 41, OP_HI_ACCESS = 42, HI_RECORD_IS_REAL = 55,
+         SHARD = 56, CLK = 57 };
+  if (e.opcode != OP_MUL && e.opcode != OP_MULT && e.opcode != OP_MULTU) throw std::runtime_error("tracegen: invalid mul opcode");
+  r[PC] = fu32(e.pc);
+  r[NEXT_PC] = fu32(e.next_pc);
+  r[HI_RECORD_IS_REAL] = e.hi_record_is_real != 0;
+  if (e.hi_record_is_real) {
+    memory_write_cols(e.hi_record, r + OP_HI_ACCESS, lk);
+    r[SHARD] = fu32(e.shard);
+    r[CLK] = fu32(e.clk);
+  }
+  uint8_t b[8], c[8];
+  for (int i = 0; i < 4; i++) { b[i] = (e.b >> (8 * i)) & 0xff; c[i] = (e.c >> (8 * i)) & 0xff; }
+  const uint8_t b_msb = b[3] >> 7, c_msb = c[3] >> 7;
+  r[B_MSB] = b_msb;
+  r[C_MSB] = c_msb;
+  int nb = 4, nc = 4;
+  if (e.opcode == OP_MULT && b_msb) { r[B_SIGN_EXTEND] = 1; for (int i = 4; i < 8; i++) b[i] = 0xff; nb = 8; }
+  if (e.opcode == OP_MULT && c_msb) { r[C_SIGN_EXTEND] = 1; for (int i = 4; i < 8; i++) c[i] = 0xff; nc = 8; }
+  if (lk) {
+    lk->push_back(ByteLookup{B_MSB_OP, b[3], 0});
+    lk->push_back(ByteLookup{B_MSB_OP, c[3], 0});
+  }
+  uint32_t product[8] = {0}, carry[8];
+  for (int i = 0; i < nb; i++)
+    for (int j = 0; j < nc; j++)
+      if (i + j < 8) product[i + j] += (uint32_t)b[i] * c[j];
+  for (int i = 0; i < 8; i++) {
+    carry[i] = product[i] >> 8;
+    product[i] &= 0xff;
+    if (i + 1 < 8) product[i + 1] += carry[i];
+    r[CARRY + i] = carry[i];
+    r[PRODUCT + i] = product[i];
+  }
+  word(r + HI, e.hi); word(r + A, e.a); word(r + B, e.b); word(r + C, e.c);
+  r[IS_REAL] = 1;
+  r[IS_MUL] = e.opcode == OP_MUL; r[IS_MULT] = e.opcode == OP_MULT; r[IS_MULTU] = e.opcode == OP_MULTU;
+  if (lk) {
+    for (int i = 0; i < 8; i++) lk->push_back(ByteLookup{B_U16RANGE_OP, (uint8_t)(carry[i] >> 8), (uint8_t)carry[i]});
+    range_checks(*lk, r + PRODUCT, 8);
+  }
+}
+static inline std::vector<F> generate_mul(const CompAluEvent* events, size_t n_events, int fixed_log2_rows, size_t* height,
+                                          uint64_t* byte_counts /* nullable: [row][op] */) {
+  const size_t h = padded_rows(n_events, fixed_log2_rows);
+  std::vector<F> t(h * MUL_WIDTH, 0);
+  std::vector<ByteLookup> lk;
+  for (size_t i = 0; i < n_events; i++) {
+    lk.clear();
+    mul_row(events[i], t.data() + i * MUL_WIDTH, byte_counts ? &lk : nullptr);
+    for (const ByteLookup& l : lk) byte_counts[(((size_t)l.b << 8) + l.c) * NUM_BYTE_OPS + l.op]++;
+  }
+  *height = h;
+  return t;
+}
+
 }  // namespace tracegen

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Collect the ALU instruction vectors the reference's own chip tests prove and verify
-(crates/core/machine/src/alu/{add_sub,bitwise,lt,sll,sr,clo_clz}/mod.rs, `#[cfg(test)]` modules) into
+(crates/core/machine/src/alu/{add_sub,bitwise,lt,sll,sr,clo_clz,mul}/mod.rs, `#[cfg(test)]` modules) into
 tests/golden/alu_events.json. Each record is data only: (chip, opcode, a, b, c) with a = b op c as the reference
 states it. Run in the build container, where /root/reference exists; the JSON is what travels.
 
@@ -13,8 +13,8 @@ import sys
 
 REF = os.environ.get("ZKM_REFERENCE", "/root/reference")
 ALU = os.path.join(REF, "crates/core/machine/src/alu")
-OPC = {"ADD": 0, "SUB": 1, "SLL": 9, "SRL": 10, "SRA": 11, "ROR": 12, "SLT": 13, "SLTU": 14, "AND": 15, "OR": 16, "XOR": 17, "NOR": 18, "CLZ": 19, "CLO": 20}
-FILES = {"AddSub": "add_sub/mod.rs", "Bitwise": "bitwise/mod.rs", "Lt": "lt/mod.rs", "ShiftLeft": "sll/mod.rs", "ShiftRight": "sr/mod.rs", "CloClz": "clo_clz/mod.rs"}
+OPC = {"ADD": 0, "SUB": 1, "MUL": 2, "MULT": 3, "MULTU": 4, "SLL": 9, "SRL": 10, "SRA": 11, "ROR": 12, "SLT": 13, "SLTU": 14, "AND": 15, "OR": 16, "XOR": 17, "NOR": 18, "CLZ": 19, "CLO": 20}
+FILES = {"AddSub": "add_sub/mod.rs", "Bitwise": "bitwise/mod.rs", "Lt": "lt/mod.rs", "ShiftLeft": "sll/mod.rs", "ShiftRight": "sr/mod.rs", "CloClz": "clo_clz/mod.rs", "Mul": "mul/mod.rs"}
 
 
 def num(tok, consts):
@@ -33,7 +33,8 @@ def main():
         consts = {m.group(1): int(m.group(2).replace("_", ""), 0)
                   for m in re.finditer(r"const (\w+): u32 = (0[bx][0-9a-fA-F_]+|\d+);", tests)}
         seen = set()
-        pats = [r"AluEvent::new\(\s*\w+,\s*Opcode::(\w+),\s*([\w]+),\s*([\w]+),\s*([\w]+)\s*\)",
+        pats = [r"(?<!Comp)AluEvent::new\(\s*\w+,\s*Opcode::(\w+),\s*([\w]+),\s*([\w]+),\s*([\w]+)\s*\)",
+                r"CompAluEvent::new\(\s*\w+,\s*Opcode::(\w+),\s*([\w]+),\s*([\w]+),\s*([\w]+)\s*\)",
                 r"\(Opcode::(\w+),\s*([\w]+),\s*([\w]+),\s*([\w]+)\)"]
         for pat in pats:
             for m in re.finditer(pat, tests):

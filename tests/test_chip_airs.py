@@ -48,6 +48,24 @@ def test_branch_constraints_hold(oracle):
     assert kinds.count(air.KIND_INSTRUCTION) == 3 and kinds.count(air.KIND_BYTE) == 4 and len(rec.receives) == 1
 
 
+def test_mul_constraints_hold(oracle):
+    rec = chips.record_mul_constraints()
+    for n in (0, 64, 3000):
+        t = F.from_monty(oracle.tracegen_mul(E.synthetic_mul_events(n, seed=n + 1)))
+        assert air.debug_constraints(rec.b, t) == []
+    for col in (20, 30, 36, 53, 57):     # a carry, a product byte, b_sign_extend, the 16-bit limb of the clk difference, clk
+        bad = t.copy()
+        rows = np.nonzero(bad[:, 55] * bad[:, 52])[0]     # rows that write HI, previous access in the same shard
+        bad[rows[2], col] = (int(bad[rows[2], col]) + 1) % F.P
+        assert {row for _, row in air.debug_constraints(rec.b, bad)} == {rows[2]}, col
+    kinds = [lk.kind for lk in rec.sends]
+    assert kinds.count(air.KIND_BYTE) == 16 and kinds.count(air.KIND_MEMORY) == 1
+    assert sorted(lk.kind for lk in rec.receives) == sorted([air.KIND_INSTRUCTION, air.KIND_MEMORY])
+    # per-row cost = main + permutation + quotient columns, as pinned in the reference's mips_costs.json (Mul: 110)
+    rc = chips.record_mul_chip(10)
+    assert rc.main_width + 4 * rc.perm_ext_width + 8 == 110
+
+
 def test_mov_cond_constraints_hold(oracle):
     rec = chips.record_mov_cond_constraints()
     for n in (0, 64, 3000):
@@ -127,7 +145,7 @@ def test_to_virtual_pair_rejects_products():
 # ---- GPU ------------------------------------------------------------------------------------------------------------
 
 def alu_shard(oracle, log_rows, seed=11):
-    """Nine real chips (six ALU chips, Jump, MovCond, Branch); AddSub at 2^log_rows rows, the others smaller; every trace also as oracle
+    """Ten real chips (six ALU chips, Jump, MovCond, Branch, Mul); AddSub at 2^log_rows rows, the others smaller; every trace also as oracle
     rows. The SRL events the executor derives from CLO/CLZ go to the ShiftRight chip (dependencies.rs:105-122), the ADD
     events it derives from JumpDirect to the AddSub chip."""
     spec = [(E.CHIP_ADD_SUB, log_rows, 0.85), (E.CHIP_BITWISE, log_rows - 1, 1.0), (E.CHIP_LT, log_rows - 1, 0.6),
@@ -158,6 +176,11 @@ def alu_shard(oracle, log_rows, seed=11):
     bc.trace = oracle.tracegen_branch(branches, log_rows - 3)
     recs.append(bc)
     evs.append(("branch", branches, log_rows - 3))
+    muls = E.synthetic_mul_events(int((1 << (log_rows - 2)) * 0.9), seed=seed + 70)
+    mu = chips.record_mul_chip(log_rows - 2)
+    mu.trace = oracle.tracegen_mul(muls, log_rows - 2)
+    recs.append(mu)
+    evs.append(("mul", muls, log_rows - 2))
     return recs, evs
 
 
@@ -168,6 +191,8 @@ def device_trace(ctx, chip, ev, lh, blu=None):
         return ctx.tracegen_mov_cond(ev, lh)
     if chip == "branch":
         return ctx.tracegen_branch(ev, lh, blu)
+    if chip == "mul":
+        return ctx.tracegen_mul(ev, lh, blu)
     return ctx.tracegen_alu(chip, ev, lh, blu)
 
 
@@ -207,6 +232,54 @@ def mirror_chip(rec, kinds=None):
                               num_constraints=int(program[2]), trace=trace)
 
 
+def lookup_tally(all_chips):
+    """Signed multiset of everything the chips send (+) and receive (-): (kind, values) -> multiplicity mod p."""
+    tally = {}
+    for r in all_chips:
+        t = F.from_monty(r.trace)
+        main = {c: t[:, c].astype(np.uint64) for c in range(t.shape[1])}
+        prep = {}
+        if r.prep_trace is not None:
+            pt = F.from_monty(r.prep_trace)
+            prep = {c: pt[:, c].astype(np.uint64) for c in range(pt.shape[1])}
+        for sign, lks in ((1, r.sends), (-1, r.receives)):
+            for lk in lks:
+                vals = np.stack([np.broadcast_to(v.apply_np(prep, main), (t.shape[0],)) for v in lk.values], axis=1)
+                mult = np.broadcast_to(lk.multiplicity.apply_np(prep, main), (t.shape[0],))
+                for row in np.nonzero(mult)[0]:
+                    key = (lk.kind,) + tuple(int(x) for x in vals[row])
+                    tally[key] = (tally.get(key, 0) + sign * int(mult[row])) % F.P
+    return tally
+
+
+def byte_shard(oracle, log_rows, seed):
+    """alu_shard + the Byte chip (multiplicities from the same events) + mirrors for the chips that are not built (Cpu:
+    instruction lookups; the memory chips: the HI register access of Mul)."""
+    recs, evs = alu_shard(oracle, log_rows, seed=seed)
+    streams = [(chip, ev) for chip, ev, _ in evs if not isinstance(chip, str)]
+    byte = chips.record_byte_chip(prep_index=0)
+    extra = np.zeros((1 << 16, 10), dtype=np.uint32)   # the Branch chip's range checks (not-taken branches), Mul's lookups
+    for chip, ev, lh in evs:
+        if chip == "branch":
+            oracle.tracegen_branch(ev, lh, extra)
+        if chip == "mul":
+            oracle.tracegen_mul(ev, lh, extra)
+    byte.trace = oracle.tracegen_byte_mults(streams, extra)
+    byte.prep_trace = oracle.tracegen_byte_table()
+    mirrors = [mirror_chip(r, kinds=(air.KIND_INSTRUCTION, air.KIND_MEMORY)) for r in recs]
+    return recs, evs, byte, mirrors
+
+
+def test_lookups_balance_between_real_chips(oracle):
+    """Every byte lookup an ALU / control-flow chip sends is received by the Byte chip with the multiplicity counted from
+    the same events; the instructions CloClz, Jump and Branch send are received by ShiftRight, AddSub and Lt. What is left
+    is exactly the traffic with the chips that are not built (instruction receives from Cpu, Mul's HI-register access)."""
+    recs, evs, byte, mirrors = byte_shard(oracle, 8, seed=21)
+    left = {k: v for k, v in lookup_tally(recs + [byte]).items() if v}
+    assert left and {k[0] for k in left} == {air.KIND_INSTRUCTION, air.KIND_MEMORY}
+    assert not any(lookup_tally(recs + [byte] + mirrors).values())
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("log_rows,queries,pow_bits", [(6, 20, 8), (12, 84, 16)])
 def test_gpu_alu_shard_proof(hip_ctx, oracle, log_rows, queries, pow_bits):
@@ -221,7 +294,7 @@ def test_gpu_alu_shard_proof(hip_ctx, oracle, log_rows, queries, pow_bits):
     pc_start = F.to_monty(0x400000)
     hp = prover.HipProver(recs, fri, synth.NUM_PV_ELTS, ctx=hip_ctx)
     if log_rows > 8:
-        hp.specialize_quotient_kernels(recs[:9])   # the real chips through generated kernels, the mirrors interpreted
+        hp.specialize_quotient_kernels(recs[:len(evs)])   # the real chips through generated kernels, the mirrors interpreted
     pk = hp.setup([], [], pc_start, igcs)
     ch = prover.new_challenger()
     pk.observe_into(ch)
@@ -248,16 +321,7 @@ def test_gpu_alu_and_byte_chips_shard(hip_ctx, oracle):
     (whose sender is the Cpu chip) are mirrored. The pk holds the Byte table: four opening rounds."""
     from ziren_amd import prover, synth
     log_rows = 11
-    recs, evs = alu_shard(oracle, log_rows, seed=21)
-    streams = [(chip, ev) for chip, ev, _ in evs if not isinstance(chip, str)]
-    byte = chips.record_byte_chip(prep_index=0)
-    branch_counts = np.zeros((1 << 16, 10), dtype=np.uint32)   # the Branch chip's range checks (not-taken branches)
-    for chip, ev, lh in evs:
-        if chip == "branch":
-            oracle.tracegen_branch(ev, lh, branch_counts)
-    byte.trace = oracle.tracegen_byte_mults(streams, branch_counts)
-    byte.prep_trace = oracle.tracegen_byte_table()
-    mirrors = [mirror_chip(r, kinds=(air.KIND_INSTRUCTION,)) for r in recs]
+    recs, evs, byte, mirrors = byte_shard(oracle, log_rows, seed=21)
     all_chips = recs + [byte] + mirrors
     fri = abi.FriConfig(1, 84, 16)
     pv = F.to_monty(F.SplitMix64(3).uniform_field(synth.PROOF_MAX_NUM_PVS))
@@ -282,9 +346,9 @@ def test_gpu_alu_and_byte_chips_shard(hip_ctx, oracle):
     assert np.array_equal(proof, oproof)
     assert oracle.verify_shard(opk, all_chips, fri, synth.NUM_PV_ELTS, start.copy(), proof) == 0
     # without the Byte chip's multiplicities the byte lookups do not balance: the verifier's cumulative-sum check fails
-    born[9].free()
+    born[len(evs)].free()
     empty = hip_ctx.byte_lookups()
-    born[9] = hip_ctx.tracegen_byte_mults(empty)
+    born[len(evs)] = hip_ctx.tracegen_byte_mults(empty)
     ch2 = start.copy()
     bad = hp.prove_shard(pk, pv, born, ch2).copy()
     assert oracle.verify_shard(opk, all_chips, fri, synth.NUM_PV_ELTS, start.copy(), bad) != 0

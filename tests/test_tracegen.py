@@ -320,3 +320,65 @@ def test_gpu_branch_tracegen_matches_oracle(hip_ctx, oracle):
         mults = hip_ctx.tracegen_byte_mults(blu)
         assert np.array_equal(F.from_monty(mults.to_host()), counts), n
         m.free(); mults.free(); blu.free()
+
+
+def test_mul_rows_by_hand(oracle):
+    """The event of the reference's test_mul_generate_trace_ffi_eq_rust (alu/mul/mod.rs:546-566; a trace-only test: its
+    `hi` is not the product's upper word, the row copies it as given) and a plain MUL."""
+    ev = np.zeros(2, dtype=E.COMP_ALU_EVENT)
+    ev[0] = (5, 790405, 1017624, 1017628, E.MULT, [0, 0, 0], 241306, 1298966409, 274417, 3776743705,
+             (241306, 5, 790409, 3431, 5, 790387), 1, [0, 0, 0])
+    ev[1] = (0, 0, 0, 4, E.MUL, [0, 0, 0], 0, 0x00001200, 0x00007e00, 0xb6db6db7, (0, 0, 0, 0, 0, 0), 0, [0, 0, 0])
+    lo, hi = E.mul_result(ev["opcode"], ev["b"], ev["c"])
+    assert lo.tolist() == [1298966409, 0x1200] and hi.tolist() == [4294934185, 0]   # `a` as the reference states it
+    counts = np.zeros((1 << 16, 10), dtype=np.uint32)
+    r = canon(oracle.tracegen_mul(ev, -1, counts))
+    assert r.shape == (16, E.MUL_WIDTH) and not r[2:].any()
+    word = lambda v: [(v >> (8 * i)) & 0xff for i in range(4)]  # noqa: E731
+    assert r[0, 2:18].tolist() == word(241306) + word(1298966409) + word(274417) + word(3776743705)
+    prod = (274417 * (3776743705 - (1 << 32))) & ((1 << 64) - 1)
+    assert r[0, 26:34].tolist() == [(prod >> (8 * i)) & 0xff for i in range(8)]
+    assert r[0, 34:42].tolist() == [0, 1, 0, 1, 0, 1, 0, 1]       # c is negative and sign-extended; is_mult; is_real
+    # HI access: prev_value, value, prev_shard, prev_clk, compare_clk, the limbs of 790409 - 790387 - 1 = 21
+    assert r[0, 42:55].tolist() == word(3431) + word(241306) + [5, 790387, 1, 21, 0]
+    assert r[0, 55:58].tolist() == [1, 5, 790405]
+    assert r[1, 38:42].tolist() == [1, 0, 0, 1] and not r[1, 42:58].any()
+    # 14 lookups per row + 2 for the HI write: U16Range rows are indexed by their value
+    assert counts.sum() == 30 and counts[21, 8] == 1 and counts[0, 7] == 2 and counts[0xe1 << 8, 7] == 1 and counts[0xb6 << 8, 7] == 1
+
+
+def test_mul_golden_events(oracle):
+    """The MUL vectors the reference's own Mul chip test proves (tests/golden/alu_events.json, from alu/mul/mod.rs)."""
+    evs = [e for e in json.load(open(os.path.join(os.path.dirname(__file__), "golden", "alu_events.json")))["events"] if e["chip"] == "Mul"]
+    # generate_trace_mul (:530-543) only builds a trace from an event whose `a` is not the product; prove_koalabear's 14 are proven
+    unproven = [e for e in evs if (e["a"], e["b"], e["c"]) == (0x80004000, 0x80000000, 0xffff8000)]
+    evs = [e for e in evs if e not in unproven]
+    assert len(evs) == 14 and len(unproven) == 1
+    ev = E.make_mul_events([e["opcode"] for e in evs], [e["b"] for e in evs], [e["c"] for e in evs])
+    assert ev["a"].tolist() == [e["a"] for e in evs]
+    from ziren_amd import air, chips
+    rec = chips.record_mul_constraints()
+    assert air.debug_constraints(rec.b, canon(oracle.tracegen_mul(ev))) == []
+    bad = E.make_mul_events([E.MUL], [unproven[0]["b"]], [unproven[0]["c"]])
+    bad["a"] = unproven[0]["a"]
+    assert {row for _, row in air.debug_constraints(rec.b, canon(oracle.tracegen_mul(bad)))} == {0}
+
+
+@pytest.mark.gpu
+def test_gpu_mul_tracegen_matches_oracle(hip_ctx, oracle):
+    from ziren_amd import lib
+    assert lib.load().zkm_tracegen_mul_width() == E.MUL_WIDTH
+    for n, fixed in ((0, -1), (1, -1), (17, -1), (4000, -1), (70001, 17)):
+        ev = E.synthetic_mul_events(n, seed=n + 5)
+        counts = np.zeros((1 << 16, 10), dtype=np.uint32)
+        want = oracle.tracegen_mul(ev, fixed, counts)
+        blu = hip_ctx.byte_lookups()
+        m = hip_ctx.tracegen_mul(ev, fixed, blu)
+        assert (m.height, m.width) == want.shape
+        assert np.array_equal(m.to_host(), want), n
+        mults = hip_ctx.tracegen_byte_mults(blu)
+        assert np.array_equal(F.from_monty(mults.to_host()), counts), n
+        m.free(); mults.free(); blu.free()
+        m = hip_ctx.tracegen_mul(ev, fixed)      # without counting
+        assert np.array_equal(m.to_host(), want), n
+        m.free()

@@ -87,6 +87,34 @@ class _Rec:
         if i < len(cols):
             self.send_byte(B_U8RANGE, 0, cols[i], 0, mult)
 
+    # WordAirBuilder::slice_range_check_u16 (air/word.rs:83-97)
+    def slice_range_check_u16(self, cols, mult):
+        for c in cols:
+            self.send_byte(B_U16RANGE, c, 0, 0, mult)
+
+    def eval_memory_access(self, shard, clk, addr, cols, do_check):
+        """MemoryAirBuilder::eval_memory_access for MemoryReadWriteCols / MemoryWriteCols (air/memory.rs:18-172):
+        `cols` = prev_value(4), value(4), prev_shard, prev_clk, compare_clk, diff_16bit_limb, diff_8bit_limb."""
+        b = self.b
+        prev_value, value = cols[0:4], cols[4:8]
+        prev_shard, prev_clk, compare_clk, diff16, diff8 = cols[8], cols[9], cols[10], cols[11], cols[12]
+        b.assert_bool(do_check)
+        # eval_memory_access_timestamp
+        b.when(do_check).assert_bool(compare_clk)
+        b.when(do_check).when(compare_clk).assert_eq(shard, prev_shard)
+        prev_comp = compare_clk * prev_clk + (1 - compare_clk) * prev_shard
+        cur_comp = compare_clk * clk + (1 - compare_clk) * shard
+        diff_minus_one = cur_comp - prev_comp - 1
+        # eval_range_check_24bits
+        b.when(do_check).assert_eq(diff_minus_one, diff16 + diff8 * (1 << 16))
+        self.send_byte(B_U16RANGE, diff16, 0, 0, do_check)
+        self.send_byte(B_U8RANGE, 0, 0, diff8, do_check)
+        # the previous access is sent, the current one received
+        self.sends.append(air.Lookup([air.to_virtual_pair(v) for v in [prev_shard, prev_clk, addr] + list(prev_value)],
+                                     air.to_virtual_pair(do_check), air.KIND_MEMORY))
+        self.receives.append(air.Lookup([air.to_virtual_pair(v) for v in [shard, clk, addr] + list(value)],
+                                        air.to_virtual_pair(do_check), air.KIND_MEMORY))
+
     # InstructionAirBuilder::receive_instruction (builder.rs:237-280) as the ALU chips call it: shard, clk,
     # num_extra_cycles, hi and the four flags are zero, is_sequential is one
     def send_alu(self, opcode, a, b, c, mult):
@@ -101,11 +129,11 @@ class _Rec:
         self.receive_instruction(pc, next_pc, next_pc + 4, opcode, a, b, c, 1, mult)
 
     def receive_instruction(self, pc, next_pc, next_next_pc, opcode, a, b, c, is_sequential, mult, hi=(0, 0, 0, 0), is_rw_a=0,
-                            op_a_immutable=0):
-        """InstructionAirBuilder::receive_instruction (builder.rs:237-280) with shard, clk, num_extra_cycles,
-        is_check_memory and is_halt zero, as every chip here calls it."""
-        vals = [0, 0, pc, next_pc, next_next_pc, 0, opcode] + list(a) + list(b) + list(c) + list(hi) + \
-               [op_a_immutable, is_rw_a, 0, 0, is_sequential]
+                            op_a_immutable=0, shard=0, clk=0, is_check_memory=0):
+        """InstructionAirBuilder::receive_instruction (builder.rs:237-280) with num_extra_cycles and is_halt zero, as
+        every chip here calls it."""
+        vals = [shard, clk, pc, next_pc, next_next_pc, 0, opcode] + list(a) + list(b) + list(c) + list(hi) + \
+               [op_a_immutable, is_rw_a, is_check_memory, 0, is_sequential]
         self.receives.append(air.Lookup([air.to_virtual_pair(v) for v in vals], air.to_virtual_pair(mult), air.KIND_INSTRUCTION))
 
 
@@ -432,6 +460,55 @@ def _branch(r: _Rec):
     r.send_alu(E.SLT, [gt, 0, 0, 0], op_b, op_a, is_real)
 
 
+def _mul(r: _Rec):
+    """MulChip::eval (alu/mul/mod.rs:345-499)."""
+    l, b = r.local, r.b
+    (PC, NEXT_PC, HI, A, B, C, CARRY, PRODUCT, MSB_B, MSB_C, B_SE, C_SE, IS_MUL, IS_MULT, IS_MULTU, IS_REAL, OP_HI, HI_REAL, SHARD,
+     CLK) = 0, 1, 2, 6, 10, 14, 18, 26, 34, 35, 36, 37, 38, 39, 40, 41, 42, 55, 56, 57
+    hi, a, wb, wc = l[HI:HI + 4], l[A:A + 4], l[B:B + 4], l[C:C + 4]
+    carry, product = l[CARRY:CARRY + 8], l[PRODUCT:PRODUCT + 8]
+    is_real = l[IS_REAL]
+    r.send_byte(B_MSB, l[MSB_B], wb[3], 0, is_real)
+    r.send_byte(B_MSB, l[MSB_C], wc[3], 0, is_real)
+    b.assert_eq(l[B_SE], l[IS_MULT] * l[MSB_B])
+    b.assert_eq(l[C_SE], l[IS_MULT] * l[MSB_C])
+    bx = [wb[i] if i < 4 else l[B_SE] * 0xff for i in range(8)]
+    cx = [wc[i] if i < 4 else l[C_SE] * 0xff for i in range(8)]
+    m = [b.const(0) for _ in range(8)]
+    for i in range(8):
+        for j in range(8):
+            if i + j < 8:
+                m[i + j] = m[i + j] + bx[i] * cx[j]
+    for i in range(8):
+        if i == 0:
+            b.assert_eq(m[i], carry[i] * 256 + product[i])
+        else:
+            b.assert_eq(product[i] - carry[i - 1] + carry[i] * 256, m[i])
+    has_hi = l[IS_MULT] + l[IS_MULTU]
+    for i in range(4):
+        b.assert_eq(product[i], a[i])
+        b.when(has_hi).assert_eq(product[i + 4], hi[i])
+    for f in (MSB_B, MSB_C, B_SE, C_SE, IS_MUL, IS_MULT, IS_MULTU, IS_REAL, HI_REAL):
+        b.assert_bool(l[f])
+    b.when(l[B_SE]).assert_eq(l[MSB_B], 1)
+    b.when(l[C_SE]).assert_eq(l[MSB_C], 1)
+    b.when(is_real).assert_one(l[IS_MUL] + l[IS_MULT] + l[IS_MULTU])
+    opcode = l[IS_MUL] * E.MUL + l[IS_MULT] * E.MULT + l[IS_MULTU] * E.MULTU
+    r.slice_range_check_u16(carry, is_real)
+    r.slice_range_check_u8(product, is_real)
+    r.receive_instruction(l[PC], l[NEXT_PC], l[NEXT_PC] + 4, opcode, a, wb, wc, 1, is_real, hi=hi, shard=l[SHARD], clk=l[CLK],
+                          is_check_memory=l[HI_REAL])
+    r.eval_memory_access(l[SHARD], l[CLK] + E.MEMORY_ACCESS_POSITION_HI, E.REGISTER_HI, l[OP_HI:OP_HI + 13], l[HI_REAL])
+    b.when_not(is_real).assert_zero(l[HI_REAL])
+    b.when(l[HI_REAL]).assert_one(l[IS_MULT] + l[IS_MULTU])
+    for i in range(4):
+        b.when(l[HI_REAL]).assert_eq(hi[i], l[OP_HI + 4 + i])
+    b.when_not(l[HI_REAL]).assert_zero(l[CLK])
+    b.when_not(l[HI_REAL]).assert_zero(l[SHARD])
+    for i in range(4):
+        b.when(l[IS_MUL]).assert_zero(hi[i])
+
+
 def _is_zero_word(b, word, cols, is_real):
     """IsZeroWordOperation::eval (operations/is_zero_word.rs:40-72) over IsZeroOperation::eval (is_zero.rs:33-49)."""
     for i in range(4):
@@ -576,6 +653,25 @@ def record_mov_cond_chip(log_height: int) -> RecordedChip:
     air.eval_permutation_constraints(r.b, r.sends, r.receives, 1 << lqd, False)
     program = r.b.assemble()
     return RecordedChip(name="MovCond", log_height=log_height, main_width=E.MOV_COND_WIDTH, log_quotient_degree=lqd,
+                        local_only=True, sends=r.sends, receives=r.receives, program=program,
+                        lookups_blob=air.encode_lookups(r.sends, r.receives), num_constraints=int(program[2]))
+
+
+def record_mul_constraints() -> _Rec:
+    r = _Rec(E.MUL_WIDTH)
+    _mul(r)
+    return r
+
+
+def record_mul_chip(log_height: int) -> RecordedChip:
+    """The Mul chip (crates/core/machine/src/alu/mul/mod.rs): CompAluEvents, 58 columns, local_only (:215-217); besides the
+    instruction and byte lookups it carries the HI register's memory access (one send, one receive of kind Memory)."""
+    r = record_mul_constraints()
+    lqd = 1
+    r.b.perm_ext_width = air.local_permutation_trace_width(len(r.sends) + len(r.receives), 1 << lqd)
+    air.eval_permutation_constraints(r.b, r.sends, r.receives, 1 << lqd, False)
+    program = r.b.assemble()
+    return RecordedChip(name="Mul", log_height=log_height, main_width=E.MUL_WIDTH, log_quotient_degree=lqd,
                         local_only=True, sends=r.sends, receives=r.receives, program=program,
                         lookups_blob=air.encode_lookups(r.sends, r.receives), num_constraints=int(program[2]))
 

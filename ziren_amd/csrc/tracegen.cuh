@@ -27,11 +27,13 @@ struct AluEvent {  // #[repr(C)] AluEvent, crates/core/executor/src/events/instr
 
 // crates/core/executor/src/opcode.rs:26-48
 enum : uint32_t { ADD = 0, SUB = 1, SLL = 9, SRL = 10, SRA = 11, ROR = 12, SLT = 13, SLTU = 14, AND = 15, OR = 16, XOR = 17, NOR = 18, CLZ = 19, CLO = 20 };
-enum Chip { ADD_SUB = 0, BITWISE = 1, LT = 2, SHIFT_LEFT = 3, SHIFT_RIGHT = 4, CLO_CLZ = 5, NUM_ALU_CHIPS = 6, JUMP = 6, MOV_COND = 7, BRANCH = 8, NUM_CHIPS = 9 };
+enum Chip { ADD_SUB = 0, BITWISE = 1, LT = 2, SHIFT_LEFT = 3, SHIFT_RIGHT = 4, CLO_CLZ = 5, NUM_ALU_CHIPS = 6, JUMP = 6, MOV_COND = 7, BRANCH = 8, MUL = 9, NUM_CHIPS = 10 };
 
 __host__ __device__ constexpr int chip_width(int chip) {
-  return chip == ADD_SUB ? 19 : chip == BITWISE ? 18 : chip == LT ? 32 : chip == SHIFT_LEFT ? 44 : chip == SHIFT_RIGHT ? 67 : chip == CLO_CLZ ? 17 : chip == JUMP ? 66 : chip == MOV_COND ? 32 : chip == BRANCH ? 62 : 0;
+  return chip == ADD_SUB ? 19 : chip == BITWISE ? 18 : chip == LT ? 32 : chip == SHIFT_LEFT ? 44 : chip == SHIFT_RIGHT ? 67 : chip == CLO_CLZ ? 17 : chip == JUMP ? 66 : chip == MOV_COND ? 32 : chip == BRANCH ? 62 : chip == MUL ? 58 : 0;
 }
+// words per event record: the seven-word AluEvent / JumpEvent / BranchEvent / MovCondEvent, the sixteen-word CompAluEvent
+__host__ __device__ constexpr int event_words(int chip) { return chip == MUL ? 16 : 7; }
 
 constexpr int THREADS = 256;
 
@@ -282,6 +284,76 @@ template <> __device__ __forceinline__ void event_row<MOV_COND>(const AluEvent& 
   r[IS_WSBH] = fbool(e.opcode == 52);
 }
 
+// Mul chip: CompAluEvent (crates/core/executor/src/events/instr.rs:50-73) as sixteen words: shard, clk, pc, next_pc, opcode,
+// hi, a, b, c, hi_record {value, shard, timestamp, prev_value, prev_shard, prev_timestamp}, hi_record_is_real.
+// Columns alu/mul/mod.rs:79-141; row alu/mul/mod.rs:221-337; the HI access columns (prev_value, value, prev_shard,
+// prev_clk, compare_clk, diff_16bit_limb, diff_8bit_limb) memory/consistency/trace.rs:43-100.
+namespace mulcols {
+enum { PC = 0, NEXT_PC = 1, HI = 2, A = 6, B = 10, C = 14, CARRY = 18, PRODUCT = 26, MSB_B = 34, MSB_C = 35, B_SIGN_EXTEND = 36,
+       C_SIGN_EXTEND = 37, IS_MUL = 38, IS_MULT = 39, IS_MULTU = 40, IS_REAL = 41, OP_HI_ACCESS = 42, HI_RECORD_IS_REAL = 55,
+       SHARD = 56, CLK = 57 };
+}
+__device__ __forceinline__ void mul_row(const uint32_t* p, uint32_t* r) {
+  using namespace mulcols;
+  const uint32_t shard = p[0], clk = p[1], opcode = p[4] & 0xff, hi = p[5], a = p[6], b = p[7], c = p[8];
+  const bool real_hi = (p[15] & 0xff) != 0;
+  r[PC] = p[2];
+  r[NEXT_PC] = p[3];
+  r[HI_RECORD_IS_REAL] = fbool(real_hi);
+  if (real_hi) {
+    const uint32_t value = p[9], rshard = p[10], ts = p[11], prev_value = p[12], prev_shard = p[13], prev_ts = p[14];
+    uint32_t* m = r + OP_HI_ACCESS;
+    word(m, prev_value);
+    word(m + 4, value);
+    m[8] = prev_shard;
+    m[9] = prev_ts;
+    const bool use_clk = prev_shard == rshard;
+    m[10] = fbool(use_clk);
+    const uint32_t diff_minus_one = (use_clk ? ts : rshard) - (use_clk ? prev_ts : prev_shard) - 1u;
+    m[11] = diff_minus_one & 0xffff;
+    m[12] = (diff_minus_one >> 16) & 0xff;
+    r[SHARD] = shard;
+    r[CLK] = clk;
+  }
+  const uint32_t b_msb = b >> 31, c_msb = c >> 31;
+  const bool bse = opcode == 3 && b_msb, cse = opcode == 3 && c_msb;   // MULT sign-extends negative operands
+  r[MSB_B] = b_msb;
+  r[MSB_C] = c_msb;
+  r[B_SIGN_EXTEND] = fbool(bse);
+  r[C_SIGN_EXTEND] = fbool(cse);
+  // the low 64 bits of the (sign-extended) product, byte by byte, with the schoolbook carries of the reference:
+  // column k of the uncarried product is sum_{i+j=k} b_i c_j, at most 8 * 255^2 < 2^19
+  uint32_t bb[8], cc[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    bb[i] = i < 4 ? (b >> (8 * i)) & 0xff : (bse ? 0xffu : 0u);
+    cc[i] = i < 4 ? (c >> (8 * i)) & 0xff : (cse ? 0xffu : 0u);
+    // The bytes go through an empty asm so that the compiler sees eight unrelated values: left to itself (ROCm 7.2
+    // clang, gfx950) it fuses the column sums into v_perm_b32 + v_dot4_u32_u8 and gets column 1 wrong
+    // (tests/test_tracegen.py::test_gpu_mul_tracegen_matches_oracle caught it).
+    asm volatile("" : "+v"(bb[i]));
+    asm volatile("" : "+v"(cc[i]));
+  }
+  uint32_t carry = 0;
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    uint32_t m = carry;
+#pragma unroll
+    for (int i = 0; i <= k; i++) m += bb[i] * cc[k - i];
+    carry = m >> 8;
+    r[CARRY + k] = carry;
+    r[PRODUCT + k] = m & 0xff;
+  }
+  word(r + HI, hi);
+  word(r + A, a);
+  word(r + B, b);
+  word(r + C, c);
+  r[IS_REAL] = 1;
+  r[IS_MUL] = fbool(opcode == 2);
+  r[IS_MULT] = fbool(opcode == 3);
+  r[IS_MULTU] = fbool(opcode == 4);
+}
+
 // ---- byte lookups: the ALU chips' generate_dependencies, ByteChip::generate_trace and ByteChip::trace -----------------
 // ByteOpcode, crates/core/executor/src/opcode.rs:195-216
 enum : uint32_t { B_AND = 0, B_OR = 1, B_XOR = 2, B_SLL = 3, B_U8RANGE = 4, B_SHRCARRY = 5, B_LTU = 6, B_MSB = 7, B_U16RANGE = 8, B_NOR = 9 };
@@ -370,7 +442,22 @@ template <> __device__ __forceinline__ void row_lookups<BRANCH>(const uint32_t* 
   range_checks(counts, r + 23, 4);  // next_next_pc
 }
 
-// events: n_events records of seven words; out: column-major, `height` rows; grid = height / (tiles * THREADS), with
+// Mul: two MSB lookups, the u16 range checks of the carries (table row = the value), the u8 range checks of the product
+// bytes, and for a real HI write the two limbs of the timestamp difference (alu/mul/mod.rs:268-283,331-334, trace.rs:95-99)
+template <> __device__ __forceinline__ void row_lookups<MUL>(const uint32_t* r, uint32_t, const LookupSink& counts) {
+  using namespace mulcols;
+  if (r[HI_RECORD_IS_REAL]) {
+    lookup(counts, B_U16RANGE, r[OP_HI_ACCESS + 11] >> 8, r[OP_HI_ACCESS + 11]);
+    lookup(counts, B_U8RANGE, 0, r[OP_HI_ACCESS + 12]);
+  }
+  lookup(counts, B_MSB, r[B + 3], 0);
+  lookup(counts, B_MSB, r[C + 3], 0);
+#pragma unroll
+  for (int i = 0; i < 8; i++) lookup(counts, B_U16RANGE, r[CARRY + i] >> 8, r[CARRY + i]);
+  range_checks(counts, r + PRODUCT, 8);
+}
+
+// events: n_events records of event_words(CHIP) words; out: column-major, `height` rows; grid = height / (tiles * THREADS), with
 // tiles = 1 for the plain row writer (most blocks in flight) and TILES_PER_BLOCK when counting.
 // counts (may be null): NUM_BYTE_OPS columns of BYTE_ROWS plain u32 counters; the byte lookups of every event row are
 // added to them — the chip's generate_dependencies in the same pass that builds its trace.
@@ -394,10 +481,15 @@ __global__ __launch_bounds__(THREADS) void alu_rows(const uint32_t* __restrict__
 #pragma unroll
     for (int c = 0; c < W; c++) r[c] = 0;
     if (row < n_events) {
-      const uint32_t* p = events + row * 7;
-      AluEvent e{p[0], p[1], (CHIP == JUMP || CHIP == BRANCH) ? p[2] : (p[2] & 0xff), p[3], p[4], p[5], p[6]};
-      event_row<CHIP>(e, r);
-      if (count) row_lookups<CHIP>(r, e.opcode, LookupSink{hkeys, hvals, HASH_SLOTS - 1, counts});
+      const uint32_t* p = events + row * event_words(CHIP);
+      if constexpr (CHIP == MUL) {
+        mul_row(p, r);
+        if (count) row_lookups<CHIP>(r, 0, LookupSink{hkeys, hvals, HASH_SLOTS - 1, counts});
+      } else {
+        AluEvent e{p[0], p[1], (CHIP == JUMP || CHIP == BRANCH) ? p[2] : (p[2] & 0xff), p[3], p[4], p[5], p[6]};
+        event_row<CHIP>(e, r);
+        if (count) row_lookups<CHIP>(r, e.opcode, LookupSink{hkeys, hvals, HASH_SLOTS - 1, counts});
+      }
     } else {
       padding_row<CHIP>(r);
     }

@@ -1059,7 +1059,7 @@ static void open_impl(zkm_ctx* ctx, const zkm_pk* pk, zkm_main_data* md, const z
 // ---- C ABI ---------------------------------------------------------------------------------------
 template <int CHIP>
 static void launch_alu_rows(zkm_ctx* ctx, const uint32_t* d_events, size_t n_events, size_t height, uint32_t* out, uint32_t* counts) {
-  KLAUNCH(ctx, "tracegen_alu", 28.0 * n_events + 4.0 * height * tracegen::chip_width(CHIP), tracegen::alu_rows<CHIP>,
+  KLAUNCH(ctx, "tracegen_alu", 4.0 * tracegen::event_words(CHIP) * n_events + 4.0 * height * tracegen::chip_width(CHIP), tracegen::alu_rows<CHIP>,
           dim3(div_up(height, (counts ? tracegen::TILES_PER_BLOCK : 1) * tracegen::THREADS)), dim3(tracegen::THREADS),
           counts ? 2 * tracegen::HASH_SLOTS * sizeof(uint32_t) : 0, d_events, n_events, height, out, counts,
           counts ? tracegen::TILES_PER_BLOCK : 1);
@@ -1103,6 +1103,7 @@ int zkm_ctx_create(int device, zkm_ctx** out) {
   HIP_CHECK(hipFuncSetAttribute((const void*)tracegen::alu_rows<tracegen::CLO_CLZ>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
   HIP_CHECK(hipFuncSetAttribute((const void*)tracegen::alu_rows<tracegen::JUMP>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
   HIP_CHECK(hipFuncSetAttribute((const void*)tracegen::alu_rows<tracegen::MOV_COND>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+  HIP_CHECK(hipFuncSetAttribute((const void*)tracegen::alu_rows<tracegen::MUL>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
   HIP_CHECK(hipFuncSetAttribute((const void*)tracegen::alu_rows<tracegen::BRANCH>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
   HIP_CHECK(hipFuncSetAttribute((const void*)lde::lde_cols<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIP_CHECK(hipFuncSetAttribute((const void*)lde::lde_cols<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -1517,8 +1518,8 @@ size_t zkm_tracegen_alu_width(int chip) { return chip >= 0 && chip < tracegen::N
 static int tracegen_events(zkm_ctx* ctx, int chip, const void* events, size_t n_events, int fixed_log2_rows,
                            zkm_byte_lookups* blu, zkm_matrix** out) {
   API_BEGIN
-  static_assert(sizeof(zkm_alu_event) == 28 && sizeof(zkm_jump_event) == 28 && sizeof(zkm_mov_cond_event) == 28,
-                "event records mirror the #[repr(C)] executor structs");
+  static_assert(sizeof(zkm_alu_event) == 28 && sizeof(zkm_jump_event) == 28 && sizeof(zkm_mov_cond_event) == 28 &&
+                sizeof(zkm_comp_alu_event) == 64, "event records mirror the #[repr(C)] executor structs");
   std::lock_guard<std::mutex> lk(ctx->mu);
   HIP_CHECK(hipSetDevice(ctx->device));
   if (chip < 0 || chip >= tracegen::NUM_CHIPS) throw std::runtime_error("zkm_tracegen: unknown chip");
@@ -1539,8 +1540,9 @@ static int tracegen_events(zkm_ctx* ctx, int chip, const void* events, size_t n_
   uint32_t* d_events = nullptr;
   try {
     m->d = ctx->alloc_n<uint32_t>(height * w);
-    d_events = (uint32_t*)ctx->alloc(std::max<size_t>(n_events * 28, 4));
-    if (n_events) HIP_CHECK(hipMemcpyAsync(d_events, events, n_events * 28, hipMemcpyHostToDevice, ctx->stream));
+    const size_t event_bytes = 4 * (size_t)tracegen::event_words(chip);
+    d_events = (uint32_t*)ctx->alloc(std::max<size_t>(n_events * event_bytes, 4));
+    if (n_events) HIP_CHECK(hipMemcpyAsync(d_events, events, n_events * event_bytes, hipMemcpyHostToDevice, ctx->stream));
     uint32_t* counts = blu ? blu->counts : nullptr;
     switch (chip) {
       case tracegen::ADD_SUB: launch_alu_rows<tracegen::ADD_SUB>(ctx, d_events, n_events, height, m->d, counts); break;
@@ -1552,6 +1554,7 @@ static int tracegen_events(zkm_ctx* ctx, int chip, const void* events, size_t n_
       case tracegen::JUMP: launch_alu_rows<tracegen::JUMP>(ctx, d_events, n_events, height, m->d, counts); break;
       case tracegen::MOV_COND: launch_alu_rows<tracegen::MOV_COND>(ctx, d_events, n_events, height, m->d, counts); break;
       case tracegen::BRANCH: launch_alu_rows<tracegen::BRANCH>(ctx, d_events, n_events, height, m->d, counts); break;
+      case tracegen::MUL: launch_alu_rows<tracegen::MUL>(ctx, d_events, n_events, height, m->d, counts); break;
     }
     ctx->mark("trace generation");
     ctx->end_timing(false);  // synchronises: the caller's event buffer is free again
@@ -1619,6 +1622,11 @@ size_t zkm_tracegen_branch_width(void) { return (size_t)tracegen::chip_width(tra
 int zkm_tracegen_branch(zkm_ctx* ctx, const zkm_branch_event* events, size_t n_events, int fixed_log2_rows, zkm_byte_lookups* blu,
                         zkm_matrix** out) {
   return tracegen_events(ctx, tracegen::BRANCH, events, n_events, fixed_log2_rows, blu, out);
+}
+size_t zkm_tracegen_mul_width(void) { return (size_t)tracegen::chip_width(tracegen::MUL); }
+int zkm_tracegen_mul(zkm_ctx* ctx, const zkm_comp_alu_event* events, size_t n_events, int fixed_log2_rows, zkm_byte_lookups* blu,
+                     zkm_matrix** out) {
+  return tracegen_events(ctx, tracegen::MUL, events, n_events, fixed_log2_rows, blu, out);
 }
 size_t zkm_tracegen_mov_cond_width(void) { return (size_t)tracegen::chip_width(tracegen::MOV_COND); }
 int zkm_tracegen_mov_cond(zkm_ctx* ctx, const zkm_mov_cond_event* events, size_t n_events, int fixed_log2_rows, zkm_matrix** out) {

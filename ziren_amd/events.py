@@ -247,3 +247,79 @@ def branch_dependencies(branch_events: np.ndarray):
     add["opcode"] = ADD
     add["a"], add["b"], add["c"] = t["next_next_pc"], t["next_pc"], t["c"]
     return lt, add
+
+
+# ---- Mul chip: CompAluEvents (crates/core/executor/src/events/instr.rs:50-73, 64 bytes) ------------------------------------------
+MUL, MULT, MULTU = 2, 3, 4
+MEMORY_WRITE_RECORD = np.dtype([("value", "<u4"), ("shard", "<u4"), ("timestamp", "<u4"), ("prev_value", "<u4"),
+                                ("prev_shard", "<u4"), ("prev_timestamp", "<u4")])   # events/memory.rs:69-82
+COMP_ALU_EVENT = np.dtype([("shard", "<u4"), ("clk", "<u4"), ("pc", "<u4"), ("next_pc", "<u4"), ("opcode", "u1"), ("_pad", "u1", (3,)),
+                           ("hi", "<u4"), ("a", "<u4"), ("b", "<u4"), ("c", "<u4"), ("hi_record", MEMORY_WRITE_RECORD),
+                           ("hi_record_is_real", "u1"), ("_pad2", "u1", (3,))])
+assert COMP_ALU_EVENT.itemsize == 64
+MUL_WIDTH = 58
+REGISTER_HI = 33              # the only register op_hi_access writes (alu/mul/mod.rs:478-485)
+MEMORY_ACCESS_POSITION_HI = 4  # events/memory.rs:29-40
+
+
+def mul_result(opcode, b, c):
+    """(lo, hi) of the executor's MUL / MULT / MULTU (executor.rs:1890-1904): MUL keeps the low word and no hi."""
+    b64, c64 = np.asarray(b, dtype=np.uint32).astype(np.uint64), np.asarray(c, dtype=np.uint32).astype(np.uint64)
+    sb = np.asarray(b, dtype=np.uint32).astype(np.int32).astype(np.int64)
+    sc = np.asarray(c, dtype=np.uint32).astype(np.int32).astype(np.int64)
+    unsigned = b64 * c64
+    signed = (sb * sc).astype(np.uint64)
+    prod = np.where(np.asarray(opcode) == MULT, signed, unsigned)
+    lo = (prod & np.uint64(0xffffffff)).astype(np.uint32)
+    hi = np.where(np.asarray(opcode) == MUL, np.uint64(0), prod >> np.uint64(32)).astype(np.uint32)
+    return lo, hi
+
+
+def make_mul_events(opcode, b, c, pc0: int = 0x1000) -> np.ndarray:
+    """`CompAluEvent::new` (instr.rs:78-93): no shard / clk, no HI-register record."""
+    opcode = np.asarray(opcode, dtype=np.uint8)
+    n = len(opcode)
+    ev = np.zeros(n, dtype=COMP_ALU_EVENT)
+    ev["pc"] = (pc0 + 4 * np.arange(n, dtype=np.uint64)) & 0x7ffffffc
+    ev["next_pc"] = ev["pc"] + 4
+    ev["opcode"] = opcode
+    ev["b"], ev["c"] = np.asarray(b, dtype=np.uint32), np.asarray(c, dtype=np.uint32)
+    ev["a"], ev["hi"] = mul_result(opcode, ev["b"], ev["c"])
+    return ev
+
+
+def synthetic_mul_events(n: int, seed: int = 1, shard: int = 3) -> np.ndarray:
+    """n multiplications: MUL (no HI write), and MULT / MULTU of which three quarters write the HI register (the rest
+    are the DivRem chip's dependency events, which carry no record: dependencies.rs). A record's previous access is in an
+    earlier shard or earlier in this one, 1 .. 2^24 ticks back, so every branch of populate_access is taken."""
+    raw = F.SplitMix64(0x4d554c00 + seed).next_u64(5 * n)
+    r0, r1, r2, r3, r4 = (raw[i * n:(i + 1) * n] for i in range(5))
+    opcode = np.array([MUL, MULT, MULTU], dtype=np.uint8)[(r0 % np.uint64(3)).astype(np.int64)]
+    b = (r1 & np.uint64(0xffffffff)).astype(np.uint64)
+    c = (r2 & np.uint64(0xffffffff)).astype(np.uint64)
+    kind = (r3 >> np.uint64(8)) % np.uint64(16)
+    pick = lambda r: _CORNERS[(r % np.uint64(len(_CORNERS))).astype(np.int64)]  # noqa: E731
+    b = np.where(kind == 0, pick(r3 >> np.uint64(16)), b)
+    c = np.where(kind == 1, pick(r3 >> np.uint64(24)), c)
+    c = np.where(kind == 2, b, c)
+    b = np.where(kind == 3, b | np.uint64(0x80000000), b)   # negative operands for MULT
+    c = np.where(kind == 4, c | np.uint64(0x80000000), c)
+    ev = make_mul_events(opcode, b, c)
+    real = (opcode != MUL) & ((r4 & np.uint64(3)) != 0)
+    clk = (np.uint64(1 << 24) + np.uint64(5) * np.arange(n, dtype=np.uint64)).astype(np.uint32)   # room for 2^24 ticks back
+    ev["shard"] = np.where(real, shard, 0)
+    ev["clk"] = np.where(real, clk, 0)
+    rec = ev["hi_record"]
+    same = ((r4 >> np.uint64(2)) & np.uint64(1)) == 1
+    back = 1 + ((r4 >> np.uint64(8)) % np.uint64(1 << 24))                     # diff_minus_one spans all 24 bits
+    back = np.where((r4 >> np.uint64(40)) % np.uint64(8) == 0, np.uint64(1), back)
+    back = np.where((r4 >> np.uint64(40)) % np.uint64(8) == 1, np.uint64(1 << 24), back)
+    ts = clk.astype(np.uint64) + MEMORY_ACCESS_POSITION_HI
+    rec["value"] = np.where(real, ev["hi"], 0)
+    rec["shard"] = np.where(real, shard, 0)
+    rec["timestamp"] = np.where(real, ts, 0)
+    rec["prev_value"] = np.where(real, (r4 >> np.uint64(16)) & np.uint64(0xffffffff), 0)
+    rec["prev_shard"] = np.where(real, np.where(same, shard, (r4 >> np.uint64(48)) % np.uint64(shard)), 0)
+    rec["prev_timestamp"] = np.where(real, np.where(same, ts - back, (r4 >> np.uint64(4)) % np.uint64(1 << 24)), 0)
+    ev["hi_record_is_real"] = real
+    return ev

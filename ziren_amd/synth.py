@@ -298,3 +298,27 @@ def shard_algorithmic_bytes(shard: SynShard) -> int:
         q = 4 << c.log_quotient_degree
         total += n * (36 * c.main_width + 36 * p + 24 * c.prep_width + 12 * q + 672)
     return total
+
+
+def shard_poseidon2_permutations(shard: SynShard, log_blowup: int = 1) -> int:
+    """Poseidon2 permutations of commit+open (SURVEY.md §8d op counts): per commitment, every LDE row of a height is
+    one sponge over the concatenated widths of that height's matrices (⌈w/8⌉ permutations), every shorter height costs
+    one more compression per row where it is injected, and the tree is H_max − 1 compressions; the FRI commit phase
+    hashes len/2 two-element leaves and builds a tree per layer. Proof-of-work (2^16 expected) and queries are left out."""
+    def commit(mats):   # mats: (lde height, width)
+        by_h = {}
+        for h, w in mats:
+            by_h[h] = by_h.get(h, 0) + w
+        hmax = max(by_h)
+        return sum(h * -(-w // 8) + (h if h != hmax else 0) for h, w in by_h.items()) + hmax - 1
+
+    B = 1 << log_blowup
+    main = [((B << c.log_height), c.main_width) for c in shard.chips]
+    perm = [((B << c.log_height), 4 * c.perm_ext_width) for c in shard.chips]
+    quot = [((B << c.log_height), 4 << c.log_quotient_degree) for c in shard.chips]
+    total = commit(main) + commit(perm) + commit(quot)
+    length = max(h for h, _ in main)
+    while length > B:
+        total += length // 2 + length // 2 - 1
+        length //= 2
+    return total
