@@ -298,6 +298,14 @@ typedef struct zkm_comp_alu_event {
 size_t zkm_tracegen_mul_width(void);
 int zkm_tracegen_mul(zkm_ctx* ctx, const zkm_comp_alu_event* events, size_t n_events, int fixed_log2_rows,
                      zkm_byte_lookups* blu, zkm_matrix** out);
+/* The DivRem chip (crates/core/machine/src/alu/divrem/mod.rs: DIV, DIVU, MOD, MODU), CompAluEvents as well: replaces
+ * DivRemChip::generate_trace (:224-381), which also records the chip's byte lookups (counted into `blu` if given). 106
+ * columns: quotient and remainder (get_quotient_and_remainder, crates/core/executor/src/utils.rs:33-43: x / 0 = 2^32 - 1
+ * remainder x; i32::MIN / -1 wraps), absolute values, c * quotient over 64 bits and the carries of adding the remainder,
+ * three IsZeroWord / IsEqualWord blocks (field inverses), sign flags, the HI access of DIV / DIVU. Zero padding rows. */
+size_t zkm_tracegen_divrem_width(void);
+int zkm_tracegen_divrem(zkm_ctx* ctx, const zkm_comp_alu_event* events, size_t n_events, int fixed_log2_rows,
+                        zkm_byte_lookups* blu, zkm_matrix** out);
 /* The MovCond chip (crates/core/machine/src/misc/mov_cond/mod.rs: MEQ, MNE, WSBH): MovCondEvents, byte-for-byte the
  * #[repr(C)] struct of crates/core/executor/src/events/instr.rs:286-302. 32 columns, zero padding rows, no byte lookups. */
 typedef struct zkm_mov_cond_event {

@@ -595,4 +595,101 @@ static inline std::vector<F> generate_mul(const CompAluEvent* events, size_t n_e
   return t;
 }
 
+// ---- DivRem chip: CompAluEvents; columns alu/divrem/mod.rs:106-202, row builder :224-381 (get_quotient_and_remainder:
+// crates/core/executor/src/utils.rs:33-43), IsZeroWordOperation / IsEqualWordOperation: operations/is_zero_word.rs:25-38,
+// is_equal_word.rs:15-28 (inverses of field differences)
+static const size_t DIVREM_WIDTH = 106;
+enum { OP_DIV = 5, OP_DIVU = 6, OP_MOD = 7, OP_MODU = 8 };
+// 11 columns: per byte (inverse, result), is_lower_half_zero, is_upper_half_zero, result
+static inline void is_zero_word_cols(const F a[4], F* r) {
+  bool z[4];
+  for (int i = 0; i < 4; i++) {
+    z[i] = a[i] == 0;
+    r[2 * i] = z[i] ? 0 : finv(a[i]);
+    r[2 * i + 1] = z[i];
+  }
+  r[8] = z[0] && z[1];
+  r[9] = z[2] && z[3];
+  r[10] = z[0] && z[1] && z[2] && z[3];
+}
+static inline void is_equal_word_cols(uint32_t a, uint32_t b, F* r) {
+  F diff[4];
+  for (int i = 0; i < 4; i++) diff[i] = fsub((a >> (8 * i)) & 0xff, (b >> (8 * i)) & 0xff);
+  is_zero_word_cols(diff, r);
+}
+static inline void divrem_row(const CompAluEvent& e, F* r, std::vector<ByteLookup>* lk) {
+  enum { PC = 0, NEXT_PC = 1, B = 2, C = 6, QUOTIENT = 10, REMAINDER = 14, ABS_REMAINDER = 18, ABS_C = 22, MAX_ABS_C_OR_1 = 26,
+         C_TIMES_QUOTIENT = 30, CARRY = 38, IS_C_0 = 46, IS_DIV = 57, IS_DIVU = 58, IS_MOD = 59, IS_MODU = 60, IS_OVERFLOW = 61,
+         IS_OVERFLOW_B = 62, IS_OVERFLOW_C = 73, B_MSB = 84, REM_MSB = 85, C_MSB = 86, B_NEG = 87, REM_NEG = 88, C_NEG = 89,
+         REMAINDER_CHECK_MULTIPLICITY = 90, OP_HI_ACCESS = 91, SHARD = 104, CLK = 105 };
+  if (e.opcode < OP_DIV || e.opcode > OP_MODU) throw std::runtime_error("tracegen: invalid divrem opcode");
+  const bool is_signed = e.opcode == OP_DIV || e.opcode == OP_MOD;
+  word(r + B, e.b); word(r + C, e.c);
+  r[PC] = fu32(e.pc); r[NEXT_PC] = fu32(e.next_pc);
+  r[IS_DIVU] = e.opcode == OP_DIVU; r[IS_DIV] = e.opcode == OP_DIV; r[IS_MODU] = e.opcode == OP_MODU; r[IS_MOD] = e.opcode == OP_MOD;
+  F cw[4]; word(cw, e.c);
+  is_zero_word_cols(cw, r + IS_C_0);
+  if (e.opcode == OP_DIVU || e.opcode == OP_DIV) {
+    memory_write_cols(e.hi_record, r + OP_HI_ACCESS, lk);
+    r[SHARD] = fu32(e.shard);
+    r[CLK] = fu32(e.clk);
+  }
+  uint32_t quotient, remainder;
+  if (e.c == 0) { quotient = 0xffffffffu; remainder = e.b; }
+  else if (is_signed) {
+    const int64_t sb = (int32_t)e.b, sc = (int32_t)e.c;   // 64-bit: i32::MIN / -1 wraps to i32::MIN, remainder 0
+    quotient = (uint32_t)(sb / sc); remainder = (uint32_t)(sb % sc);
+  } else { quotient = e.b / e.c; remainder = e.b % e.c; }
+  word(r + QUOTIENT, quotient); word(r + REMAINDER, remainder);
+  r[REM_MSB] = remainder >> 31; r[B_MSB] = e.b >> 31; r[C_MSB] = e.c >> 31;
+  is_equal_word_cols(e.b, 0x80000000u, r + IS_OVERFLOW_B);
+  is_equal_word_cols(e.c, 0xffffffffu, r + IS_OVERFLOW_C);
+  auto unsigned_abs = [](uint32_t v) { return (v >> 31) ? (uint32_t)(0u - v) : v; };
+  if (is_signed) {
+    const uint32_t abs_c = unsigned_abs(e.c);
+    r[REM_NEG] = r[REM_MSB]; r[B_NEG] = r[B_MSB]; r[C_NEG] = r[C_MSB];
+    r[IS_OVERFLOW] = e.b == 0x80000000u && e.c == 0xffffffffu;
+    word(r + ABS_REMAINDER, unsigned_abs(remainder));
+    word(r + ABS_C, abs_c);
+    word(r + MAX_ABS_C_OR_1, abs_c > 1 ? abs_c : 1);
+  } else {
+    word(r + ABS_REMAINDER, remainder);
+    word(r + ABS_C, e.c);
+    word(r + MAX_ABS_C_OR_1, e.c > 1 ? e.c : 1);
+  }
+  if (lk) {
+    lk->push_back(ByteLookup{B_MSB_OP, (uint8_t)(e.b >> 24), 0});
+    lk->push_back(ByteLookup{B_MSB_OP, (uint8_t)(e.c >> 24), 0});
+    lk->push_back(ByteLookup{B_MSB_OP, (uint8_t)(remainder >> 24), 0});
+  }
+  r[REMAINDER_CHECK_MULTIPLICITY] = e.c != 0;   // 1 - is_c_0.result
+  const uint64_t ctq = is_signed ? (uint64_t)((int64_t)(int32_t)quotient * (int64_t)(int32_t)e.c) : (uint64_t)quotient * e.c;
+  const uint64_t rem64 = is_signed ? (uint64_t)(int64_t)(int32_t)remainder : (uint64_t)remainder;
+  uint32_t carry = 0;
+  for (int i = 0; i < 8; i++) {
+    r[C_TIMES_QUOTIENT + i] = (ctq >> (8 * i)) & 0xff;
+    const uint32_t x = (uint32_t)((ctq >> (8 * i)) & 0xff) + (uint32_t)((rem64 >> (8 * i)) & 0xff) + carry;
+    carry = x >> 8;
+    r[CARRY + i] = carry;
+  }
+  if (lk) {
+    range_checks(*lk, r + QUOTIENT, 4);
+    range_checks(*lk, r + REMAINDER, 4);
+    range_checks(*lk, r + C_TIMES_QUOTIENT, 8);
+  }
+}
+static inline std::vector<F> generate_divrem(const CompAluEvent* events, size_t n_events, int fixed_log2_rows, size_t* height,
+                                             uint64_t* byte_counts /* nullable: [row][op] */) {
+  const size_t h = padded_rows(n_events, fixed_log2_rows);
+  std::vector<F> t(h * DIVREM_WIDTH, 0);
+  std::vector<ByteLookup> lk;
+  for (size_t i = 0; i < n_events; i++) {
+    lk.clear();
+    divrem_row(events[i], t.data() + i * DIVREM_WIDTH, byte_counts ? &lk : nullptr);
+    for (const ByteLookup& l : lk) byte_counts[(((size_t)l.b << 8) + l.c) * NUM_BYTE_OPS + l.op]++;
+  }
+  *height = h;
+  return t;
+}
+
 }  // namespace tracegen

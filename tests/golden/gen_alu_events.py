@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Collect the ALU instruction vectors the reference's own chip tests prove and verify
-(crates/core/machine/src/alu/{add_sub,bitwise,lt,sll,sr,clo_clz,mul}/mod.rs, `#[cfg(test)]` modules) into
+(crates/core/machine/src/alu/{add_sub,bitwise,lt,sll,sr,clo_clz,mul,divrem}/mod.rs, `#[cfg(test)]` modules) into
 tests/golden/alu_events.json. Each record is data only: (chip, opcode, a, b, c) with a = b op c as the reference
 states it. Run in the build container, where /root/reference exists; the JSON is what travels.
 
@@ -13,8 +13,8 @@ import sys
 
 REF = os.environ.get("ZKM_REFERENCE", "/root/reference")
 ALU = os.path.join(REF, "crates/core/machine/src/alu")
-OPC = {"ADD": 0, "SUB": 1, "MUL": 2, "MULT": 3, "MULTU": 4, "SLL": 9, "SRL": 10, "SRA": 11, "ROR": 12, "SLT": 13, "SLTU": 14, "AND": 15, "OR": 16, "XOR": 17, "NOR": 18, "CLZ": 19, "CLO": 20}
-FILES = {"AddSub": "add_sub/mod.rs", "Bitwise": "bitwise/mod.rs", "Lt": "lt/mod.rs", "ShiftLeft": "sll/mod.rs", "ShiftRight": "sr/mod.rs", "CloClz": "clo_clz/mod.rs", "Mul": "mul/mod.rs"}
+OPC = {"ADD": 0, "SUB": 1, "MUL": 2, "MULT": 3, "MULTU": 4, "DIV": 5, "DIVU": 6, "MOD": 7, "MODU": 8, "SLL": 9, "SRL": 10, "SRA": 11, "ROR": 12, "SLT": 13, "SLTU": 14, "AND": 15, "OR": 16, "XOR": 17, "NOR": 18, "CLZ": 19, "CLO": 20}
+FILES = {"AddSub": "add_sub/mod.rs", "Bitwise": "bitwise/mod.rs", "Lt": "lt/mod.rs", "ShiftLeft": "sll/mod.rs", "ShiftRight": "sr/mod.rs", "CloClz": "clo_clz/mod.rs", "Mul": "mul/mod.rs", "DivRem": "divrem/mod.rs"}
 
 
 def num(tok, consts):

@@ -275,3 +275,16 @@ def tracegen_mul(events, fixed_log2_rows=-1, byte_counts=None):
     _check(lib().orc_tracegen_mul(C.c_void_p(ev.ctypes.data), C.c_size_t(len(ev)), C.c_int(fixed_log2_rows), abi.as_u32p(out),
                                   C.c_size_t(out.size), bc))
     return out
+
+
+def tracegen_divrem(events, fixed_log2_rows=-1, byte_counts=None):
+    """DivRem chip rows from CompAluEvents; byte_counts as for tracegen_branch."""
+    from ziren_amd import events as E
+    ev = np.ascontiguousarray(events, dtype=E.COMP_ALU_EVENT)
+    rows = C.c_size_t()
+    _check(lib().orc_tracegen_alu_rows(C.c_size_t(len(ev)), C.c_int(fixed_log2_rows), C.byref(rows)))
+    out = np.zeros((rows.value, E.DIVREM_WIDTH), dtype=np.uint32)
+    bc = abi.as_u32p(byte_counts) if byte_counts is not None else None
+    _check(lib().orc_tracegen_divrem(C.c_void_p(ev.ctypes.data), C.c_size_t(len(ev)), C.c_int(fixed_log2_rows), abi.as_u32p(out),
+                                     C.c_size_t(out.size), bc))
+    return out

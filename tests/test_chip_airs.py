@@ -66,6 +66,31 @@ def test_mul_constraints_hold(oracle):
     assert rc.main_width + 4 * rc.perm_ext_width + 8 == 110
 
 
+def test_divrem_constraints_hold(oracle):
+    rec = chips.record_divrem_constraints()
+    for n in (0, 64, 3000):
+        t = F.from_monty(oracle.tracegen_divrem(E.synthetic_divrem_events(n, seed=n + 1)))
+        assert air.debug_constraints(rec.b, t) == []
+    ev = E.synthetic_divrem_events(3000, seed=3001)
+    row = int(np.nonzero((ev["opcode"] == E.DIV) & (ev["c"] != 0) & (ev["b"] > 0x80000000) & (ev["c"] < 0x80000000))[0][0])
+    # remainder, c * quotient, a carry, is_c_0, rem_neg, the SLTU multiplicity, a HI limb (the quotient is tied only through lookups)
+    for col in (14, 30, 38, 47, 88, 90, 103):
+        bad = t.copy()
+        bad[row, col] = (int(bad[row, col]) + 1) % F.P
+        assert {r for _, r in air.debug_constraints(rec.b, bad)} == {row}, col
+    kinds = [lk.kind for lk in rec.sends]
+    assert kinds.count(air.KIND_INSTRUCTION) == 4 and kinds.count(air.KIND_BYTE) == 13 and kinds.count(air.KIND_MEMORY) == 1
+    assert sorted(lk.kind for lk in rec.receives) == sorted([air.KIND_INSTRUCTION, air.KIND_INSTRUCTION, air.KIND_MEMORY])
+    rc = chips.record_divrem_chip(10)   # mips_costs.json: DivRem 162
+    assert rc.main_width + 4 * rc.perm_ext_width + 8 == 162
+    # the special cases take the reference's values: x / 0 = 2^32 - 1 remainder x; i32::MIN / -1 wraps
+    sp = E.make_divrem_events([E.DIV, E.DIVU, E.MOD, E.DIV, E.MOD], [7, 9, 0x80000000, 0x80000000, 0xfffffff9],
+                              [0, 0, 0xffffffff, 0xffffffff, 0xfffffffe])
+    assert sp["a"].tolist() == [0xffffffff, 0xffffffff, 0, 0x80000000, 0xffffffff] and sp["hi"].tolist() == [7, 9, 0, 0, 0]
+    st = F.from_monty(oracle.tracegen_divrem(sp))
+    assert air.debug_constraints(rec.b, st) == [] and st[:5, 61].tolist() == [0, 0, 1, 1, 0]   # is_overflow
+
+
 def test_mov_cond_constraints_hold(oracle):
     rec = chips.record_mov_cond_constraints()
     for n in (0, 64, 3000):
@@ -145,18 +170,21 @@ def test_to_virtual_pair_rejects_products():
 # ---- GPU ------------------------------------------------------------------------------------------------------------
 
 def alu_shard(oracle, log_rows, seed=11):
-    """Ten real chips (six ALU chips, Jump, MovCond, Branch, Mul); AddSub at 2^log_rows rows, the others smaller; every trace also as oracle
-    rows. The SRL events the executor derives from CLO/CLZ go to the ShiftRight chip (dependencies.rs:105-122), the ADD
-    events it derives from JumpDirect to the AddSub chip."""
-    spec = [(E.CHIP_ADD_SUB, log_rows, 0.85), (E.CHIP_BITWISE, log_rows - 1, 1.0), (E.CHIP_LT, log_rows - 1, 0.6),
+    """Eleven real chips (six ALU chips, Jump, MovCond, Branch, Mul, DivRem); AddSub at 2^log_rows rows, the others smaller; every
+    trace also as oracle rows. The SRL events the executor derives from CLO/CLZ go to the ShiftRight chip
+    (dependencies.rs:105-122), the ADD events it derives from JumpDirect to the AddSub chip, the ADD / MULT / SLTU events it
+    derives from divisions to the AddSub, Mul and Lt chips."""
+    spec = [(E.CHIP_ADD_SUB, log_rows, 0.85), (E.CHIP_BITWISE, log_rows - 1, 1.0), (E.CHIP_LT, log_rows - 1, 0.35),
             (E.CHIP_SHIFT_LEFT, log_rows - 2, 0.55), (E.CHIP_SHIFT_RIGHT, log_rows - 2, 0.6), (E.CHIP_CLO_CLZ, log_rows - 3, 0.8)]
     streams = {chip: E.synthetic_alu_events(chip, int((1 << lh) * fill), seed=seed + chip) for chip, lh, fill in spec}
     jumps = E.synthetic_jump_events(int((1 << (log_rows - 3)) * 0.75), seed=seed + 40)
     streams[E.CHIP_SHIFT_RIGHT] = np.concatenate([streams[E.CHIP_SHIFT_RIGHT], E.cloclz_dependencies(streams[E.CHIP_CLO_CLZ])])
     branches = E.synthetic_branch_events(int((1 << (log_rows - 3)) * 0.7), seed=seed + 60)
     lt_dep, add_dep = E.branch_dependencies(branches)                                                 # dependencies.rs:181-227
-    streams[E.CHIP_ADD_SUB] = np.concatenate([streams[E.CHIP_ADD_SUB], E.jump_dependencies(jumps), add_dep])   # dependencies.rs:230-248
-    streams[E.CHIP_LT] = np.concatenate([streams[E.CHIP_LT], lt_dep])
+    divs = E.synthetic_divrem_events(int((1 << (log_rows - 3)) * 0.9), seed=seed + 80)
+    div_add, mul_dep, div_lt = E.divrem_dependencies(divs)                                            # dependencies.rs:12-103
+    streams[E.CHIP_ADD_SUB] = np.concatenate([streams[E.CHIP_ADD_SUB], E.jump_dependencies(jumps), add_dep, div_add])   # dependencies.rs:230-248
+    streams[E.CHIP_LT] = np.concatenate([streams[E.CHIP_LT], lt_dep, div_lt])
     recs, evs = [], []
     for chip, lh, _ in spec:
         rc = chips.record_chip(chip, lh)
@@ -176,11 +204,15 @@ def alu_shard(oracle, log_rows, seed=11):
     bc.trace = oracle.tracegen_branch(branches, log_rows - 3)
     recs.append(bc)
     evs.append(("branch", branches, log_rows - 3))
-    muls = E.synthetic_mul_events(int((1 << (log_rows - 2)) * 0.9), seed=seed + 70)
+    muls = np.concatenate([E.synthetic_mul_events(int((1 << (log_rows - 2)) * 0.5), seed=seed + 70), mul_dep])
     mu = chips.record_mul_chip(log_rows - 2)
     mu.trace = oracle.tracegen_mul(muls, log_rows - 2)
     recs.append(mu)
     evs.append(("mul", muls, log_rows - 2))
+    dv = chips.record_divrem_chip(log_rows - 3)
+    dv.trace = oracle.tracegen_divrem(divs, log_rows - 3)
+    recs.append(dv)
+    evs.append(("divrem", divs, log_rows - 3))
     return recs, evs
 
 
@@ -193,6 +225,8 @@ def device_trace(ctx, chip, ev, lh, blu=None):
         return ctx.tracegen_branch(ev, lh, blu)
     if chip == "mul":
         return ctx.tracegen_mul(ev, lh, blu)
+    if chip == "divrem":
+        return ctx.tracegen_divrem(ev, lh, blu)
     return ctx.tracegen_alu(chip, ev, lh, blu)
 
 
@@ -264,6 +298,8 @@ def byte_shard(oracle, log_rows, seed):
             oracle.tracegen_branch(ev, lh, extra)
         if chip == "mul":
             oracle.tracegen_mul(ev, lh, extra)
+        if chip == "divrem":
+            oracle.tracegen_divrem(ev, lh, extra)
     byte.trace = oracle.tracegen_byte_mults(streams, extra)
     byte.prep_trace = oracle.tracegen_byte_table()
     mirrors = [mirror_chip(r, kinds=(air.KIND_INSTRUCTION, air.KIND_MEMORY)) for r in recs]
@@ -273,7 +309,8 @@ def byte_shard(oracle, log_rows, seed):
 def test_lookups_balance_between_real_chips(oracle):
     """Every byte lookup an ALU / control-flow chip sends is received by the Byte chip with the multiplicity counted from
     the same events; the instructions CloClz, Jump and Branch send are received by ShiftRight, AddSub and Lt. What is left
-    is exactly the traffic with the chips that are not built (instruction receives from Cpu, Mul's HI-register access)."""
+    is exactly the traffic with the chips that are not built (instruction receives from Cpu, the HI-register accesses of Mul
+    and DivRem); what DivRem sends (MULT / MULTU with the upper word, ADD, SLTU) is received by Mul, AddSub and Lt."""
     recs, evs, byte, mirrors = byte_shard(oracle, 8, seed=21)
     left = {k: v for k, v in lookup_tally(recs + [byte]).items() if v}
     assert left and {k[0] for k in left} == {air.KIND_INSTRUCTION, air.KIND_MEMORY}

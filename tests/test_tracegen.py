@@ -382,3 +382,42 @@ def test_gpu_mul_tracegen_matches_oracle(hip_ctx, oracle):
         m = hip_ctx.tracegen_mul(ev, fixed)      # without counting
         assert np.array_equal(m.to_host(), want), n
         m.free()
+
+
+def test_divrem_rows_by_hand(oracle):
+    """The reference's own trace test event (alu/divrem/mod.rs:783-792: DIVU 17 / 3; its `a` field is not used by the row
+    builder, which divides again) and a signed division with a negative remainder."""
+    ev = np.zeros(2, dtype=E.COMP_ALU_EVENT)
+    ev[0] = (0, 0, 0, 4, E.DIVU, [0, 0, 0], 0, 2, 17, 3, (0, 0, 0, 0, 0, 0), 0, [0, 0, 0])
+    ev[1] = E.make_divrem_events([E.DIV], [0xfffffff9], [2])[0]     # -7 / 2 = -3 remainder -1
+    counts = np.zeros((1 << 16, 10), dtype=np.uint32)
+    r = canon(oracle.tracegen_divrem(ev, -1, counts))
+    assert r.shape == (16, E.DIVREM_WIDTH) and not r[2:].any()
+    assert r[0, 10:18].tolist() == [5, 0, 0, 0, 2, 0, 0, 0] and r[0, 30:38].tolist() == [15, 0, 0, 0, 0, 0, 0, 0]
+    assert r[0, 57:62].tolist() == [0, 1, 0, 0, 0] and r[0, 90] == 1 and r[0, 18:30].tolist() == [2, 0, 0, 0, 3, 0, 0, 0, 3, 0, 0, 0]
+    assert r[1, 10:18].tolist() == [0xfd, 0xff, 0xff, 0xff] + [0xff] * 4                       # quotient -3, remainder -1
+    assert r[1, 18:30].tolist() == [1, 0, 0, 0, 2, 0, 0, 0, 2, 0, 0, 0]                         # abs(remainder), abs(c), max(abs(c), 1)
+    assert r[1, 30:38].tolist() == [0xfa, 0xff, 0xff, 0xff, 0xff, 0xff, 0xff, 0xff]           # c * quotient = -6 over 64 bits
+    assert r[1, 38:46].tolist() == [1] * 8                                                     # -6 + -1: every byte carries
+    assert r[1, 84:90].tolist() == [1, 1, 0, 1, 1, 0]                                          # msb and neg flags of b, rem, c
+    add, mul, lt = E.divrem_dependencies(ev)
+    assert add["b"].tolist() == [0xffffffff] and add["c"].tolist() == [1] and add["a"].tolist() == [0]
+    assert mul["opcode"].tolist() == [E.MULTU, E.MULT] and mul["a"].tolist() == [15, 0xfffffffa] and mul["hi"].tolist() == [0, 0xffffffff]
+    assert lt["b"].tolist() == [2, 1] and lt["c"].tolist() == [3, 2]
+
+
+@pytest.mark.gpu
+def test_gpu_divrem_tracegen_matches_oracle(hip_ctx, oracle):
+    from ziren_amd import lib
+    assert lib.load().zkm_tracegen_divrem_width() == E.DIVREM_WIDTH
+    for n, fixed in ((0, -1), (1, -1), (17, -1), (4000, -1), (70001, 17)):
+        ev = E.synthetic_divrem_events(n, seed=n + 5)
+        counts = np.zeros((1 << 16, 10), dtype=np.uint32)
+        want = oracle.tracegen_divrem(ev, fixed, counts)
+        blu = hip_ctx.byte_lookups()
+        m = hip_ctx.tracegen_divrem(ev, fixed, blu)
+        assert (m.height, m.width) == want.shape
+        assert np.array_equal(m.to_host(), want), n
+        mults = hip_ctx.tracegen_byte_mults(blu)
+        assert np.array_equal(F.from_monty(mults.to_host()), counts), n
+        m.free(); mults.free(); blu.free()

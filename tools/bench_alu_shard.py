@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Shard of the reference's real chips — six ALU chips, Jump, MovCond, Branch, Mul and Byte (recorded AIRs, ziren_amd/chips.py): events -> device traces ->
+"""Shard of the reference's real chips — six ALU chips, Jump, MovCond, Branch, Mul, DivRem and Byte (recorded AIRs, ziren_amd/chips.py): events -> device traces ->
 commit + open, timed per phase and per kernel. Real constraint programs and lookup shapes instead of the SYN stand-ins.
 
   python tools/bench_alu_shard.py [--log-rows 21] [--steps 3]
@@ -29,15 +29,18 @@ def main():
     spec = [(E.CHIP_ADD_SUB, k), (E.CHIP_BITWISE, k - 1), (E.CHIP_LT, k - 1), (E.CHIP_SHIFT_LEFT, k - 2), (E.CHIP_SHIFT_RIGHT, k - 2),
             (E.CHIP_CLO_CLZ, k - 3)]
     other = [("jump", k - 3, E.synthetic_jump_events, chips.record_jump_chip), ("mov_cond", k - 3, E.synthetic_mov_cond_events, chips.record_mov_cond_chip),
-             ("branch", k - 3, E.synthetic_branch_events, chips.record_branch_chip), ("mul", k - 2, E.synthetic_mul_events, chips.record_mul_chip)]
+             ("branch", k - 3, E.synthetic_branch_events, chips.record_branch_chip), ("mul", k - 2, E.synthetic_mul_events, chips.record_mul_chip),
+             ("divrem", k - 3, E.synthetic_divrem_events, chips.record_divrem_chip)]
     fill = 0.6
     streams = {c: E.synthetic_alu_events(c, int((1 << lh) * fill)) for c, lh in spec}
     ostreams = {name: gen(int((1 << lh) * fill)) for name, lh, gen, _ in other}
     # the events the executor derives from these instructions (crates/core/executor/src/dependencies.rs)
     lt_dep, add_dep = E.branch_dependencies(ostreams["branch"])
+    div_add, div_mul, div_lt = E.divrem_dependencies(ostreams["divrem"])
+    ostreams["mul"] = np.concatenate([ostreams["mul"][:int((1 << (k - 2)) * 0.5)], div_mul])
     streams[E.CHIP_SHIFT_RIGHT] = np.concatenate([streams[E.CHIP_SHIFT_RIGHT], E.cloclz_dependencies(streams[E.CHIP_CLO_CLZ])])
-    streams[E.CHIP_ADD_SUB] = np.concatenate([streams[E.CHIP_ADD_SUB], E.jump_dependencies(ostreams["jump"]), add_dep])
-    streams[E.CHIP_LT] = np.concatenate([streams[E.CHIP_LT], lt_dep])
+    streams[E.CHIP_ADD_SUB] = np.concatenate([streams[E.CHIP_ADD_SUB], E.jump_dependencies(ostreams["jump"]), add_dep, div_add])
+    streams[E.CHIP_LT] = np.concatenate([streams[E.CHIP_LT][:int((1 << (k - 1)) * 0.35)], lt_dep, div_lt])
     recs = [chips.record_chip(c, lh) for c, lh in spec] + [rec(lh) for _, lh, _, rec in other] + [chips.record_byte_chip(0)]
     ctx = prover.Context(0)
 
@@ -70,6 +73,8 @@ def main():
                 born.append(ctx.tracegen_branch(ev, lh, blu))
             elif c == "mul":
                 born.append(ctx.tracegen_mul(ev, lh, blu))
+            elif c == "divrem":
+                born.append(ctx.tracegen_divrem(ev, lh, blu))
             else:
                 born.append(ctx.tracegen_alu(c, ev, lh, blu))
         born.append(ctx.tracegen_byte_mults(blu))
@@ -85,7 +90,7 @@ def main():
             res.append({"tracegen_ms": (t1 - t0) * 1e3, "prove_ms": (t2 - t1) * 1e3, "phases": phases, "kernels": kern})
     r = res[-1]
     cells = sum((1 << c.log_height) * (c.main_width + 4 * c.perm_ext_width + 8) for c in recs)
-    print(json.dumps({"workload": f"CORE10-{k}: AddSub 2^{k}, Bitwise/Lt 2^{k-1}, ShiftLeft/ShiftRight/Mul 2^{k-2}, CloClz/Jump/MovCond/Branch 2^{k-3}, "
+    print(json.dumps({"workload": f"CORE11-{k}: AddSub 2^{k}, Bitwise/Lt 2^{k-1}, ShiftLeft/ShiftRight/Mul 2^{k-2}, CloClz/Jump/MovCond/Branch/DivRem 2^{k-3}, "
                                   "Byte 2^16; 60% filled plus the executor's dependency events",
                       "tracegen_ms": round(float(np.mean([x["tracegen_ms"] for x in res])), 3),
                       "prove_ms": round(float(np.mean([x["prove_ms"] for x in res])), 3),

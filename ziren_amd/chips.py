@@ -117,12 +117,12 @@ class _Rec:
 
     # InstructionAirBuilder::receive_instruction (builder.rs:237-280) as the ALU chips call it: shard, clk,
     # num_extra_cycles, hi and the four flags are zero, is_sequential is one
-    def send_alu(self, opcode, a, b, c, mult):
-        """InstructionAirBuilder::send_alu (builder.rs:282-326): an instruction sent from one chip to an ALU chip, at
-        the placeholder pc UNUSED_PC."""
+    def send_alu(self, opcode, a, b, c, mult, hi=(0, 0, 0, 0)):
+        """InstructionAirBuilder::send_alu / send_alu_with_hi (builder.rs:282-326): an instruction sent from one chip to
+        an ALU chip, at the placeholder pc UNUSED_PC."""
         pc = E.UNUSED_PC
         vals = [0, 0, pc, pc + E.DEFAULT_PC_INC, pc + 2 * E.DEFAULT_PC_INC, 0, opcode] + list(a) + list(b) + list(c) + \
-               [0, 0, 0, 0] + [0, 0, 0, 0, 1]
+               list(hi) + [0, 0, 0, 0, 1]
         self.sends.append(air.Lookup([air.to_virtual_pair(v) for v in vals], air.to_virtual_pair(mult), air.KIND_INSTRUCTION))
 
     def receive_alu_instruction(self, pc, next_pc, opcode, a, b, c, mult):
@@ -528,6 +528,79 @@ def _is_zero_word(b, word, cols, is_real):
     real.assert_eq(res, lower * upper)
 
 
+def _divrem(r: _Rec):
+    """DivRemChip::eval (alu/divrem/mod.rs:398-768)."""
+    l, b = r.local, r.b
+    (PC, NEXT_PC, B, C, QUOT, REM, ABS_REM, ABS_C, MAX_ABS_C, CTQ, CARRY, IS_C_0, IS_DIV, IS_DIVU, IS_MOD, IS_MODU, IS_OVERFLOW,
+     IS_OVERFLOW_B, IS_OVERFLOW_C, MSB_B, MSB_REM, MSB_C, B_NEG, REM_NEG, C_NEG, REM_CHECK_MULT, OP_HI, SHARD, CLK) = (
+        0, 1, 2, 6, 10, 14, 18, 22, 26, 30, 38, 46, 57, 58, 59, 60, 61, 62, 73, 84, 85, 86, 87, 88, 89, 90, 91, 104, 105)
+    wb, wc, quot, rem = l[B:B + 4], l[C:C + 4], l[QUOT:QUOT + 4], l[REM:REM + 4]
+    abs_rem, abs_c, max_abs_c = l[ABS_REM:ABS_REM + 4], l[ABS_C:ABS_C + 4], l[MAX_ABS_C:MAX_ABS_C + 4]
+    ctq, carry = l[CTQ:CTQ + 8], l[CARRY:CARRY + 8]
+    is_c_0 = l[IS_C_0:IS_C_0 + 11]
+    is_real = l[IS_DIV] + l[IS_DIVU] + l[IS_MOD] + l[IS_MODU]
+    signed = l[IS_DIV] + l[IS_MOD]
+    for msb, neg in ((MSB_B, B_NEG), (MSB_REM, REM_NEG), (MSB_C, C_NEG)):
+        b.assert_eq(l[msb] * signed, l[neg])
+    r.send_alu(signed * E.MULT + (l[IS_DIVU] + l[IS_MODU]) * E.MULTU, ctq[0:4], quot, wc, is_real, hi=ctq[4:8])
+    # is_overflow = is_equal(b, -2^31) * is_equal(c, -1) * is_signed (IsEqualWordOperation: operations/is_equal_word.rs:30-47)
+    b.assert_bool(is_real)
+    _is_zero_word(b, [wb[0], wb[1], wb[2], wb[3] - 0x80], l[IS_OVERFLOW_B:IS_OVERFLOW_B + 11], is_real)
+    b.assert_bool(is_real)
+    _is_zero_word(b, [wc[i] - 0xff for i in range(4)], l[IS_OVERFLOW_C:IS_OVERFLOW_C + 11], is_real)
+    b.assert_eq(l[IS_OVERFLOW], l[IS_OVERFLOW_B + 10] * l[IS_OVERFLOW_C + 10] * signed)
+    # c * quotient + remainder = b over 64 bits
+    sign_extension = l[REM_NEG] * 0xff
+    total = []
+    for i in range(8):
+        v = ctq[i] + (rem[i] if i < 4 else sign_extension) - carry[i] * 256
+        if i > 0:
+            v = v + carry[i - 1]
+        total.append(v)
+    not_overflow = 1 - l[IS_OVERFLOW]
+    for i in range(8):
+        if i < 4:
+            b.assert_eq(wb[i], total[i])
+        else:
+            b.when(not_overflow).when(l[B_NEG]).assert_eq(total[i], 0xff)
+            b.when(not_overflow).when(1 - l[B_NEG]).assert_zero(total[i])
+            b.when(l[IS_OVERFLOW]).assert_zero(total[i])
+    rem_byte_sum = rem[0] + rem[1] + rem[2] + rem[3]
+    b.when(l[REM_NEG]).assert_one(l[B_NEG])
+    b.when(rem_byte_sum).when(1 - l[REM_NEG]).assert_zero(l[B_NEG])
+    _is_zero_word(b, wc, is_c_0, is_real)
+    for i in range(4):
+        b.when(is_c_0[10]).assert_eq(quot[i], 0xff)
+    for i in range(4):
+        b.when_not(l[C_NEG]).assert_eq(wc[i], abs_c[i])
+        b.when_not(l[REM_NEG]).assert_eq(rem[i], abs_rem[i])
+    r.send_alu(E.ADD, [0, 0, 0, 0], wc, abs_c, l[C_NEG])
+    r.send_alu(E.ADD, [0, 0, 0, 0], rem, abs_rem, l[REM_NEG])
+    want_max = [is_c_0[10] + (1 - is_c_0[10]) * abs_c[0]] + [(1 - is_c_0[10]) * abs_c[i] for i in range(1, 4)]
+    for i in range(4):
+        b.when(is_real).assert_eq(max_abs_c[i], want_max[i])
+    b.assert_eq((1 - is_c_0[10]) * is_real, l[REM_CHECK_MULT])
+    r.send_alu(E.SLTU, [1, 0, 0, 0], abs_rem, max_abs_c, l[REM_CHECK_MULT])
+    for msb, byte in ((MSB_B, wb[3]), (MSB_C, wc[3]), (MSB_REM, rem[3])):
+        r.send_byte(B_MSB, l[msb], byte, 0, is_real)
+    r.slice_range_check_u8(quot, is_real)
+    r.slice_range_check_u8(rem, is_real)
+    for cy in carry:
+        b.assert_bool(cy)
+    r.slice_range_check_u8(ctq, is_real)
+    for f in (IS_DIV, IS_DIVU, IS_MOD, IS_MODU, IS_OVERFLOW, MSB_B, MSB_REM, MSB_C, B_NEG, REM_NEG, C_NEG):
+        b.assert_bool(l[f])
+    b.when(is_real).assert_eq(1, l[IS_DIVU] + l[IS_DIV] + l[IS_MOD] + l[IS_MODU])
+    opcode = l[IS_DIVU] * E.DIVU + l[IS_DIV] * E.DIV + l[IS_MOD] * E.MOD + l[IS_MODU] * E.MODU
+    div = l[IS_DIV] + l[IS_DIVU]
+    r.receive_instruction(l[PC], l[NEXT_PC], l[NEXT_PC] + 4, opcode, quot, wb, wc, 1, div, hi=rem, shard=l[SHARD], clk=l[CLK],
+                          is_check_memory=1)
+    r.receive_instruction(l[PC], l[NEXT_PC], l[NEXT_PC] + 4, opcode, rem, wb, wc, 1, l[IS_MOD] + l[IS_MODU])
+    r.eval_memory_access(l[SHARD], l[CLK] + E.MEMORY_ACCESS_POSITION_HI, E.REGISTER_HI, l[OP_HI:OP_HI + 13], div)
+    for i in range(4):
+        b.when(div).assert_eq(rem[i], l[OP_HI + 4 + i])
+
+
 def _mov_cond(r: _Rec):
     """MovCondChip::eval (misc/mov_cond/mod.rs:172-257)."""
     l, b = r.local, r.b
@@ -672,6 +745,26 @@ def record_mul_chip(log_height: int) -> RecordedChip:
     air.eval_permutation_constraints(r.b, r.sends, r.receives, 1 << lqd, False)
     program = r.b.assemble()
     return RecordedChip(name="Mul", log_height=log_height, main_width=E.MUL_WIDTH, log_quotient_degree=lqd,
+                        local_only=True, sends=r.sends, receives=r.receives, program=program,
+                        lookups_blob=air.encode_lookups(r.sends, r.receives), num_constraints=int(program[2]))
+
+
+def record_divrem_constraints() -> _Rec:
+    r = _Rec(E.DIVREM_WIDTH)
+    _divrem(r)
+    return r
+
+
+def record_divrem_chip(log_height: int) -> RecordedChip:
+    """The DivRem chip (crates/core/machine/src/alu/divrem/mod.rs): CompAluEvents, 106 columns, local_only (:390-392). It
+    proves c * quotient through the Mul chip (a MULT / MULTU sent with the product's upper word), abs(c) and abs(remainder)
+    through the AddSub chip and abs(remainder) < max(abs(c), 1) through the Lt chip; DIV / DIVU write HI."""
+    r = record_divrem_constraints()
+    lqd = 1
+    r.b.perm_ext_width = air.local_permutation_trace_width(len(r.sends) + len(r.receives), 1 << lqd)
+    air.eval_permutation_constraints(r.b, r.sends, r.receives, 1 << lqd, False)
+    program = r.b.assemble()
+    return RecordedChip(name="DivRem", log_height=log_height, main_width=E.DIVREM_WIDTH, log_quotient_degree=lqd,
                         local_only=True, sends=r.sends, receives=r.receives, program=program,
                         lookups_blob=air.encode_lookups(r.sends, r.receives), num_constraints=int(program[2]))
 

@@ -27,13 +27,13 @@ struct AluEvent {  // #[repr(C)] AluEvent, crates/core/executor/src/events/instr
 
 // crates/core/executor/src/opcode.rs:26-48
 enum : uint32_t { ADD = 0, SUB = 1, SLL = 9, SRL = 10, SRA = 11, ROR = 12, SLT = 13, SLTU = 14, AND = 15, OR = 16, XOR = 17, NOR = 18, CLZ = 19, CLO = 20 };
-enum Chip { ADD_SUB = 0, BITWISE = 1, LT = 2, SHIFT_LEFT = 3, SHIFT_RIGHT = 4, CLO_CLZ = 5, NUM_ALU_CHIPS = 6, JUMP = 6, MOV_COND = 7, BRANCH = 8, MUL = 9, NUM_CHIPS = 10 };
+enum Chip { ADD_SUB = 0, BITWISE = 1, LT = 2, SHIFT_LEFT = 3, SHIFT_RIGHT = 4, CLO_CLZ = 5, NUM_ALU_CHIPS = 6, JUMP = 6, MOV_COND = 7, BRANCH = 8, MUL = 9, DIVREM = 10, NUM_CHIPS = 11 };
 
 __host__ __device__ constexpr int chip_width(int chip) {
-  return chip == ADD_SUB ? 19 : chip == BITWISE ? 18 : chip == LT ? 32 : chip == SHIFT_LEFT ? 44 : chip == SHIFT_RIGHT ? 67 : chip == CLO_CLZ ? 17 : chip == JUMP ? 66 : chip == MOV_COND ? 32 : chip == BRANCH ? 62 : chip == MUL ? 58 : 0;
+  return chip == ADD_SUB ? 19 : chip == BITWISE ? 18 : chip == LT ? 32 : chip == SHIFT_LEFT ? 44 : chip == SHIFT_RIGHT ? 67 : chip == CLO_CLZ ? 17 : chip == JUMP ? 66 : chip == MOV_COND ? 32 : chip == BRANCH ? 62 : chip == MUL ? 58 : chip == DIVREM ? 106 : 0;
 }
 // words per event record: the seven-word AluEvent / JumpEvent / BranchEvent / MovCondEvent, the sixteen-word CompAluEvent
-__host__ __device__ constexpr int event_words(int chip) { return chip == MUL ? 16 : 7; }
+__host__ __device__ constexpr int event_words(int chip) { return chip == MUL || chip == DIVREM ? 16 : 7; }
 
 constexpr int THREADS = 256;
 
@@ -354,6 +354,109 @@ __device__ __forceinline__ void mul_row(const uint32_t* p, uint32_t* r) {
   r[IS_MULTU] = fbool(opcode == 4);
 }
 
+// DivRem chip: CompAluEvents; columns alu/divrem/mod.rs:106-202, row :224-381. IsZeroWordOperation = per byte (inverse,
+// result), lower / upper half, result (operations/is_zero_word.rs:25-38); IsEqualWordOperation runs it on the field
+// differences of the bytes (is_equal_word.rs:15-28). Canonical values throughout; alu_rows converts on the store.
+namespace divcols {
+enum { PC = 0, NEXT_PC = 1, B = 2, C = 6, QUOTIENT = 10, REMAINDER = 14, ABS_REMAINDER = 18, ABS_C = 22, MAX_ABS_C_OR_1 = 26,
+       C_TIMES_QUOTIENT = 30, CARRY = 38, IS_C_0 = 46, IS_DIV = 57, IS_DIVU = 58, IS_MOD = 59, IS_MODU = 60, IS_OVERFLOW = 61,
+       IS_OVERFLOW_B = 62, IS_OVERFLOW_C = 73, MSB_B = 84, MSB_REM = 85, MSB_C = 86, B_NEG = 87, REM_NEG = 88, C_NEG = 89,
+       REMAINDER_CHECK_MULTIPLICITY = 90, OP_HI_ACCESS = 91, SHARD = 104, CLK = 105 };
+}
+// bytes of `a` minus bytes of `b` as field elements -> the eleven IsZeroWordOperation columns
+__device__ __forceinline__ void is_equal_word_cols(uint32_t a, uint32_t b, uint32_t* r) {
+  uint32_t z[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const uint32_t x = (a >> (8 * i)) & 0xff, y = (b >> (8 * i)) & 0xff;
+    const uint32_t diff = x >= y ? x - y : x + kb::P - y;   // canonical field difference
+    z[i] = fbool(diff == 0);
+    r[2 * i] = diff ? kb::from_monty(kb::inv(kb::to_monty(diff))) : 0u;
+    r[2 * i + 1] = z[i];
+  }
+  r[8] = z[0] & z[1];
+  r[9] = z[2] & z[3];
+  r[10] = z[0] & z[1] & z[2] & z[3];
+}
+__device__ __forceinline__ void memory_write_cols(const uint32_t* rec, uint32_t* m) {   // rec: the six words of a MemoryWriteRecord
+  const uint32_t value = rec[0], rshard = rec[1], ts = rec[2], prev_value = rec[3], prev_shard = rec[4], prev_ts = rec[5];
+  word(m, prev_value);
+  word(m + 4, value);
+  m[8] = prev_shard;
+  m[9] = prev_ts;
+  const bool use_clk = prev_shard == rshard;
+  m[10] = fbool(use_clk);
+  const uint32_t diff_minus_one = (use_clk ? ts : rshard) - (use_clk ? prev_ts : prev_shard) - 1u;
+  m[11] = diff_minus_one & 0xffff;
+  m[12] = (diff_minus_one >> 16) & 0xff;
+}
+__device__ __forceinline__ void divrem_row(const uint32_t* p, uint32_t* r) {
+  using namespace divcols;
+  const uint32_t shard = p[0], clk = p[1], opcode = p[4] & 0xff, b = p[7], c = p[8];
+  const bool is_signed = opcode == 5 || opcode == 7, is_div = opcode == 5 || opcode == 6;
+  word(r + B, b);
+  word(r + C, c);
+  r[PC] = p[2];
+  r[NEXT_PC] = p[3];
+  r[IS_DIV] = fbool(opcode == 5);
+  r[IS_DIVU] = fbool(opcode == 6);
+  r[IS_MOD] = fbool(opcode == 7);
+  r[IS_MODU] = fbool(opcode == 8);
+  is_equal_word_cols(c, 0, r + IS_C_0);
+  if (is_div) {   // DIV / DIVU always write HI (alu/divrem/mod.rs:246-255)
+    memory_write_cols(p + 9, r + OP_HI_ACCESS);
+    r[SHARD] = shard;
+    r[CLK] = clk;
+  }
+  // get_quotient_and_remainder (crates/core/executor/src/utils.rs:33-43)
+  uint32_t quotient, remainder;
+  if (c == 0) {
+    quotient = 0xffffffffu;
+    remainder = b;
+  } else if (is_signed) {
+    if (b == 0x80000000u && c == 0xffffffffu) {   // wrapping_div / wrapping_rem
+      quotient = 0x80000000u;
+      remainder = 0;
+    } else {
+      quotient = (uint32_t)((int32_t)b / (int32_t)c);
+      remainder = (uint32_t)((int32_t)b % (int32_t)c);
+    }
+  } else {
+    quotient = b / c;
+    remainder = b % c;
+  }
+  word(r + QUOTIENT, quotient);
+  word(r + REMAINDER, remainder);
+  r[MSB_REM] = remainder >> 31;
+  r[MSB_B] = b >> 31;
+  r[MSB_C] = c >> 31;
+  is_equal_word_cols(b, 0x80000000u, r + IS_OVERFLOW_B);
+  is_equal_word_cols(c, 0xffffffffu, r + IS_OVERFLOW_C);
+  uint32_t abs_rem = remainder, abs_c = c;
+  if (is_signed) {
+    r[REM_NEG] = r[MSB_REM];
+    r[B_NEG] = r[MSB_B];
+    r[C_NEG] = r[MSB_C];
+    r[IS_OVERFLOW] = fbool(b == 0x80000000u && c == 0xffffffffu);
+    abs_rem = (remainder >> 31) ? 0u - remainder : remainder;
+    abs_c = (c >> 31) ? 0u - c : c;
+  }
+  word(r + ABS_REMAINDER, abs_rem);
+  word(r + ABS_C, abs_c);
+  word(r + MAX_ABS_C_OR_1, abs_c > 1 ? abs_c : 1u);
+  r[REMAINDER_CHECK_MULTIPLICITY] = fbool(c != 0);
+  const uint64_t ctq = is_signed ? (uint64_t)((int64_t)(int32_t)quotient * (int64_t)(int32_t)c) : (uint64_t)quotient * c;
+  const uint64_t rem64 = is_signed ? (uint64_t)(int64_t)(int32_t)remainder : (uint64_t)remainder;
+  uint32_t carry = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    const uint32_t q = (uint32_t)(ctq >> (8 * i)) & 0xff;
+    r[C_TIMES_QUOTIENT + i] = q;
+    carry = (q + ((uint32_t)(rem64 >> (8 * i)) & 0xff) + carry) >> 8;
+    r[CARRY + i] = carry;
+  }
+}
+
 // ---- byte lookups: the ALU chips' generate_dependencies, ByteChip::generate_trace and ByteChip::trace -----------------
 // ByteOpcode, crates/core/executor/src/opcode.rs:195-216
 enum : uint32_t { B_AND = 0, B_OR = 1, B_XOR = 2, B_SLL = 3, B_U8RANGE = 4, B_SHRCARRY = 5, B_LTU = 6, B_MSB = 7, B_U16RANGE = 8, B_NOR = 9 };
@@ -457,6 +560,22 @@ template <> __device__ __forceinline__ void row_lookups<MUL>(const uint32_t* r, 
   range_checks(counts, r + PRODUCT, 8);
 }
 
+// DivRem: the HI write's two limbs (DIV / DIVU), three MSB lookups, U8Range pairs of quotient, remainder and c * quotient
+// (alu/divrem/mod.rs:250-252,299-313,352-357)
+template <> __device__ __forceinline__ void row_lookups<DIVREM>(const uint32_t* r, uint32_t, const LookupSink& counts) {
+  using namespace divcols;
+  if (r[IS_DIV] | r[IS_DIVU]) {
+    lookup(counts, B_U16RANGE, r[OP_HI_ACCESS + 11] >> 8, r[OP_HI_ACCESS + 11]);
+    lookup(counts, B_U8RANGE, 0, r[OP_HI_ACCESS + 12]);
+  }
+  lookup(counts, B_MSB, r[B + 3], 0);
+  lookup(counts, B_MSB, r[C + 3], 0);
+  lookup(counts, B_MSB, r[REMAINDER + 3], 0);
+  range_checks(counts, r + QUOTIENT, 4);
+  range_checks(counts, r + REMAINDER, 4);
+  range_checks(counts, r + C_TIMES_QUOTIENT, 8);
+}
+
 // events: n_events records of event_words(CHIP) words; out: column-major, `height` rows; grid = height / (tiles * THREADS), with
 // tiles = 1 for the plain row writer (most blocks in flight) and TILES_PER_BLOCK when counting.
 // counts (may be null): NUM_BYTE_OPS columns of BYTE_ROWS plain u32 counters; the byte lookups of every event row are
@@ -482,8 +601,8 @@ __global__ __launch_bounds__(THREADS) void alu_rows(const uint32_t* __restrict__
     for (int c = 0; c < W; c++) r[c] = 0;
     if (row < n_events) {
       const uint32_t* p = events + row * event_words(CHIP);
-      if constexpr (CHIP == MUL) {
-        mul_row(p, r);
+      if constexpr (CHIP == MUL || CHIP == DIVREM) {
+        if constexpr (CHIP == MUL) mul_row(p, r); else divrem_row(p, r);
         if (count) row_lookups<CHIP>(r, 0, LookupSink{hkeys, hvals, HASH_SLOTS - 1, counts});
       } else {
         AluEvent e{p[0], p[1], (CHIP == JUMP || CHIP == BRANCH) ? p[2] : (p[2] & 0xff), p[3], p[4], p[5], p[6]};

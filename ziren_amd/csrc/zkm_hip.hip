@@ -1104,6 +1104,7 @@ int zkm_ctx_create(int device, zkm_ctx** out) {
   HIP_CHECK(hipFuncSetAttribute((const void*)tracegen::alu_rows<tracegen::JUMP>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
   HIP_CHECK(hipFuncSetAttribute((const void*)tracegen::alu_rows<tracegen::MOV_COND>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
   HIP_CHECK(hipFuncSetAttribute((const void*)tracegen::alu_rows<tracegen::MUL>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+  HIP_CHECK(hipFuncSetAttribute((const void*)tracegen::alu_rows<tracegen::DIVREM>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
   HIP_CHECK(hipFuncSetAttribute((const void*)tracegen::alu_rows<tracegen::BRANCH>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
   HIP_CHECK(hipFuncSetAttribute((const void*)lde::lde_cols<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIP_CHECK(hipFuncSetAttribute((const void*)lde::lde_cols<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -1555,6 +1556,7 @@ static int tracegen_events(zkm_ctx* ctx, int chip, const void* events, size_t n_
       case tracegen::MOV_COND: launch_alu_rows<tracegen::MOV_COND>(ctx, d_events, n_events, height, m->d, counts); break;
       case tracegen::BRANCH: launch_alu_rows<tracegen::BRANCH>(ctx, d_events, n_events, height, m->d, counts); break;
       case tracegen::MUL: launch_alu_rows<tracegen::MUL>(ctx, d_events, n_events, height, m->d, counts); break;
+      case tracegen::DIVREM: launch_alu_rows<tracegen::DIVREM>(ctx, d_events, n_events, height, m->d, counts); break;
     }
     ctx->mark("trace generation");
     ctx->end_timing(false);  // synchronises: the caller's event buffer is free again
@@ -1627,6 +1629,11 @@ size_t zkm_tracegen_mul_width(void) { return (size_t)tracegen::chip_width(traceg
 int zkm_tracegen_mul(zkm_ctx* ctx, const zkm_comp_alu_event* events, size_t n_events, int fixed_log2_rows, zkm_byte_lookups* blu,
                      zkm_matrix** out) {
   return tracegen_events(ctx, tracegen::MUL, events, n_events, fixed_log2_rows, blu, out);
+}
+size_t zkm_tracegen_divrem_width(void) { return (size_t)tracegen::chip_width(tracegen::DIVREM); }
+int zkm_tracegen_divrem(zkm_ctx* ctx, const zkm_comp_alu_event* events, size_t n_events, int fixed_log2_rows, zkm_byte_lookups* blu,
+                        zkm_matrix** out) {
+  return tracegen_events(ctx, tracegen::DIVREM, events, n_events, fixed_log2_rows, blu, out);
 }
 size_t zkm_tracegen_mov_cond_width(void) { return (size_t)tracegen::chip_width(tracegen::MOV_COND); }
 int zkm_tracegen_mov_cond(zkm_ctx* ctx, const zkm_mov_cond_event* events, size_t n_events, int fixed_log2_rows, zkm_matrix** out) {

@@ -323,3 +323,119 @@ def synthetic_mul_events(n: int, seed: int = 1, shard: int = 3) -> np.ndarray:
     rec["prev_timestamp"] = np.where(real, np.where(same, ts - back, (r4 >> np.uint64(4)) % np.uint64(1 << 24)), 0)
     ev["hi_record_is_real"] = real
     return ev
+
+
+# ---- DivRem chip: CompAluEvents as well (alu/divrem/mod.rs) --------------------------------------------------------------------------
+DIV, DIVU, MOD, MODU = 5, 6, 7, 8
+DIVREM_WIDTH = 106
+
+
+def quotient_and_remainder(opcode, b, c):
+    """get_quotient_and_remainder (crates/core/executor/src/utils.rs:33-43): division by zero gives (2^32 - 1, b); the signed
+    forms wrap (i32::MIN / -1 = i32::MIN, remainder 0) and truncate towards zero."""
+    opcode = np.asarray(opcode)
+    b = np.asarray(b, dtype=np.uint32)
+    c = np.asarray(c, dtype=np.uint32)
+    signed = (opcode == DIV) | (opcode == MOD)
+    c1 = np.where(c == 0, np.uint32(1), c)
+    uq, ur = b // c1, b % c1
+    sb, sc = b.astype(np.int32).astype(np.int64), c1.astype(np.int32).astype(np.int64)
+    aq = np.abs(sb) // np.abs(sc)
+    sq = np.where((sb < 0) != (sc < 0), -aq, aq)
+    sr = sb - sq * sc
+    q = np.where(signed, sq.astype(np.uint64) & np.uint64(0xffffffff), uq).astype(np.uint32)
+    r = np.where(signed, sr.astype(np.uint64) & np.uint64(0xffffffff), ur).astype(np.uint32)
+    return np.where(c == 0, np.uint32(0xffffffff), q).astype(np.uint32), np.where(c == 0, b, r).astype(np.uint32)
+
+
+def make_divrem_events(opcode, b, c, pc0: int = 0x1000, shard: int = 3, seed: int = 1) -> np.ndarray:
+    """DIV / DIVU: a = quotient, hi = remainder, written to the HI register (the record is always real, alu/divrem/mod.rs:246-255);
+    MOD / MODU: a = remainder, no HI write, shard = clk = 0."""
+    opcode = np.asarray(opcode, dtype=np.uint8)
+    n = len(opcode)
+    ev = np.zeros(n, dtype=COMP_ALU_EVENT)
+    ev["pc"] = (pc0 + 4 * np.arange(n, dtype=np.uint64)) & 0x7ffffffc
+    ev["next_pc"] = ev["pc"] + 4
+    ev["opcode"] = opcode
+    ev["b"], ev["c"] = np.asarray(b, dtype=np.uint32), np.asarray(c, dtype=np.uint32)
+    q, r = quotient_and_remainder(opcode, ev["b"], ev["c"])
+    div = (opcode == DIV) | (opcode == DIVU)
+    ev["a"] = np.where(div, q, r)
+    ev["hi"] = np.where(div, r, 0)
+    r4 = F.SplitMix64(0x44495600 + seed).next_u64(n)
+    clk = (np.uint64(1 << 24) + np.uint64(5) * np.arange(n, dtype=np.uint64)).astype(np.uint32)
+    ts = clk.astype(np.uint64) + MEMORY_ACCESS_POSITION_HI
+    same = ((r4 >> np.uint64(2)) & np.uint64(1)) == 1
+    back = 1 + ((r4 >> np.uint64(8)) % np.uint64(1 << 24))
+    ev["shard"] = np.where(div, shard, 0)
+    ev["clk"] = np.where(div, clk, 0)
+    rec = ev["hi_record"]
+    rec["value"] = np.where(div, r, 0)
+    rec["shard"] = np.where(div, shard, 0)
+    rec["timestamp"] = np.where(div, ts, 0)
+    rec["prev_value"] = np.where(div, (r4 >> np.uint64(16)) & np.uint64(0xffffffff), 0)
+    rec["prev_shard"] = np.where(div, np.where(same, shard, (r4 >> np.uint64(48)) % np.uint64(shard)), 0)
+    rec["prev_timestamp"] = np.where(div, np.where(same, ts - back, (r4 >> np.uint64(4)) % np.uint64(1 << 24)), 0)
+    ev["hi_record_is_real"] = div
+    return ev
+
+
+def synthetic_divrem_events(n: int, seed: int = 1) -> np.ndarray:
+    """n divisions of all four opcodes: uniform operands with the corner cases mixed in — division by zero, i32::MIN / -1,
+    equal operands, small divisors (long quotients), dividends smaller than the divisor, negative operands."""
+    raw = F.SplitMix64(0x44495200 + seed).next_u64(4 * n)
+    r0, r1, r2, r3 = (raw[i * n:(i + 1) * n] for i in range(4))
+    opcode = np.array([DIV, DIVU, MOD, MODU], dtype=np.uint8)[(r0 % np.uint64(4)).astype(np.int64)]
+    b = (r1 & np.uint64(0xffffffff)).astype(np.uint64)
+    c = (r2 & np.uint64(0xffffffff)).astype(np.uint64)
+    kind = (r3 >> np.uint64(8)) % np.uint64(16)
+    pick = lambda r: _CORNERS[(r % np.uint64(len(_CORNERS))).astype(np.int64)]  # noqa: E731
+    b = np.where(kind == 0, pick(r3 >> np.uint64(16)), b)
+    c = np.where(kind == 1, pick(r3 >> np.uint64(24)), c)
+    c = np.where(kind == 2, b, c)
+    c = np.where(kind == 3, np.uint64(0), c)
+    b = np.where(kind == 4, np.uint64(0x80000000), b)
+    c = np.where(kind == 4, np.uint64(0xffffffff), c)
+    c = np.where((kind == 5) | (kind == 6), c & np.uint64(0xff), c)                                   # small divisors
+    c = np.where(kind == 7, (np.uint64(0x100000000) - (c & np.uint64(0xffff))) & np.uint64(0xffffffff), c)   # small negative divisors
+    b = np.where(kind == 8, b & np.uint64(0xffff), b)
+    return make_divrem_events(opcode, b, c, seed=seed)
+
+
+def divrem_dependencies(divrem_events: np.ndarray):
+    """emit_divrem_dependencies (crates/core/executor/src/dependencies.rs:12-103): ADD events proving abs(c) and
+    abs(remainder) for negative values (AddSub chip), one MULT / MULTU event c * quotient without a HI record (Mul chip), one
+    SLTU event abs(remainder) < max(abs(c), 1) unless c = 0 (Lt chip). Returns (add_sub, mul, lt)."""
+    ev = divrem_events
+    n = len(ev)
+    op = ev["opcode"]
+    signed = (op == DIV) | (op == MOD)
+    q, r = quotient_and_remainder(op, ev["b"], ev["c"])
+    c = ev["c"]
+    c_neg = signed & ((c >> 31) == 1)
+    r_neg = signed & ((r >> 31) == 1)
+    abs_c = np.where(c_neg, (~c + np.uint32(1)), c).astype(np.uint32)
+    abs_r = np.where(r_neg, (~r + np.uint32(1)), r).astype(np.uint32)
+    adds = []
+    for i in range(n):   # order of the pushes: c first, then the remainder, event by event
+        if c_neg[i]:
+            adds.append((c[i], abs_c[i]))
+        if r_neg[i]:
+            adds.append((r[i], abs_r[i]))
+    add = np.zeros(len(adds), dtype=ALU_EVENT)
+    add["pc"], add["next_pc"], add["opcode"] = UNUSED_PC, UNUSED_PC + DEFAULT_PC_INC, ADD
+    if adds:
+        add["b"] = [x for x, _ in adds]
+        add["c"] = [y for _, y in adds]
+    mul = np.zeros(n, dtype=COMP_ALU_EVENT)
+    mul["pc"], mul["next_pc"] = UNUSED_PC, UNUSED_PC + DEFAULT_PC_INC
+    mul["opcode"] = np.where(signed, MULT, MULTU)
+    mul["b"], mul["c"] = q, c
+    mul["a"], mul["hi"] = mul_result(mul["opcode"], q, c)
+    keep = c != 0
+    lt = np.zeros(int(keep.sum()), dtype=ALU_EVENT)
+    lt["pc"], lt["next_pc"], lt["opcode"] = UNUSED_PC, UNUSED_PC + DEFAULT_PC_INC, SLTU
+    lt["a"] = 1
+    lt["b"] = abs_r[keep]
+    lt["c"] = np.maximum(abs_c[keep], 1)
+    return add, mul, lt

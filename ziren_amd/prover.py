@@ -138,6 +138,17 @@ class Context:
         L = lib.load()
         return DeviceMatrix(self, h, int(L.zkm_matrix_height(h)), int(L.zkm_matrix_width(h)))
 
+    def tracegen_divrem(self, events: np.ndarray, fixed_log2_rows: int = -1, blu: "ByteLookups" = None) -> DeviceMatrix:
+        """`generate_trace` (which also records the byte lookups, into `blu`) of the DivRem chip on the device
+        (zkm_tracegen_divrem); dtype events.COMP_ALU_EVENT."""
+        from . import events as _ev
+        ev = np.ascontiguousarray(events, dtype=_ev.COMP_ALU_EVENT)
+        h = C.c_void_p()
+        lib.check(lib.load().zkm_tracegen_divrem(self.h, C.c_void_p(ev.ctypes.data if len(ev) else None), C.c_size_t(len(ev)),
+                                                 C.c_int(fixed_log2_rows), blu.h if blu is not None else None, C.byref(h)))
+        L = lib.load()
+        return DeviceMatrix(self, h, int(L.zkm_matrix_height(h)), int(L.zkm_matrix_width(h)))
+
     def tracegen_mov_cond(self, events: np.ndarray, fixed_log2_rows: int = -1) -> DeviceMatrix:
         """`generate_trace` of the MovCond chip on the device (zkm_tracegen_mov_cond); dtype events.MOV_COND_EVENT."""
         from . import events as _ev
