@@ -306,6 +306,47 @@ int zkm_tracegen_mul(zkm_ctx* ctx, const zkm_comp_alu_event* events, size_t n_ev
 size_t zkm_tracegen_divrem_width(void);
 int zkm_tracegen_divrem(zkm_ctx* ctx, const zkm_comp_alu_event* events, size_t n_events, int fixed_log2_rows,
                         zkm_byte_lookups* blu, zkm_matrix** out);
+/* The Cpu chip (crates/core/machine/src/cpu/): replaces CpuChip::generate_trace and generate_dependencies
+ * (cpu/trace.rs:36-115). Events and program are byte-for-byte the reference's own FFI structs: CpuEventFfi
+ * (crates/core/executor/src/events/cpu.rs:46-77, 280 bytes) and InstructionFfi (instruction.rs:22-33, 24 bytes), which it
+ * already hands to its C++ row builder (`cpu_event_to_row_koalabear`, cpu/trace.rs:320-352). `shard` is
+ * public_values.execution_shard; the instruction of an event is program[(pc - pc_base) / 4] (Program::fetch). 67 columns;
+ * padding rows have imm_b = imm_c = is_rw_a = 1. Byte lookups (shard, clk limbs, register accesses, bytes of `a`) are
+ * counted into `blu` if given. Fails if an event's pc lies outside the program. */
+typedef struct zkm_memory_read_record { uint32_t value, shard, timestamp, prev_shard, prev_timestamp; } zkm_memory_read_record;
+typedef struct zkm_option_memory_record {   /* OptionMemoryRecordEnum: tag Read = 0, Write = 1, None = 2 */
+  uint8_t tag, _pad[3];
+  zkm_memory_read_record read;
+  zkm_memory_write_record write;
+} zkm_option_memory_record;
+typedef struct zkm_option_u32 { uint8_t tag, _pad[3]; uint32_t value; } zkm_option_u32;   /* OptionValTag: Some = 0, None = 1 */
+typedef struct zkm_cpu_event {
+  uint32_t clk, pc, next_pc, next_next_pc, a;
+  zkm_option_memory_record a_record;
+  uint32_t b;
+  zkm_option_memory_record b_record;
+  uint32_t c;
+  zkm_option_memory_record c_record;
+  zkm_option_u32 hi;
+  zkm_option_memory_record hi_record, memory_record;
+  uint32_t exit_code;
+} zkm_cpu_event;
+typedef struct zkm_instruction {
+  uint8_t opcode, op_a, _pad0[2];
+  uint32_t op_b, op_c;
+  uint8_t imm_b, imm_c, _pad1[2];
+  zkm_option_u32 raw;
+} zkm_instruction;
+size_t zkm_tracegen_cpu_width(void);
+int zkm_tracegen_cpu(zkm_ctx* ctx, const zkm_cpu_event* events, size_t n_events, const zkm_instruction* program, size_t n_instr,
+                     uint32_t pc_base, uint32_t shard, int fixed_log2_rows, zkm_byte_lookups* blu, zkm_matrix** out);
+/* The Program chip (crates/core/machine/src/program/mod.rs): its preprocessed table (pc, instruction columns; 14 columns,
+ * generate_preprocessed_trace :62-101) for zkm_pk_setup, and its one-column multiplicity trace (generate_trace :113-146:
+ * how many CpuEvents fetched each pc). */
+int zkm_tracegen_program(zkm_ctx* ctx, const zkm_instruction* program, size_t n_instr, uint32_t pc_base, int fixed_log2_rows,
+                         zkm_matrix** out);
+int zkm_tracegen_program_mults(zkm_ctx* ctx, const zkm_cpu_event* events, size_t n_events, size_t n_instr, uint32_t pc_base,
+                               int fixed_log2_rows, zkm_matrix** out);
 /* The MovCond chip (crates/core/machine/src/misc/mov_cond/mod.rs: MEQ, MNE, WSBH): MovCondEvents, byte-for-byte the
  * #[repr(C)] struct of crates/core/executor/src/events/instr.rs:286-302. 32 columns, zero padding rows, no byte lookups. */
 typedef struct zkm_mov_cond_event {

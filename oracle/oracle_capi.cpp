@@ -454,4 +454,29 @@ int orc_tracegen_divrem(const void* events, size_t n_events, int fixed_log2_rows
   ORC_CATCH
 }
 
+// Cpu chip: CpuEventFfi records (280 bytes) + the program's InstructionFfi records (24 bytes); 67 columns
+int orc_tracegen_cpu(const void* events, size_t n_events, const void* program, size_t n_instr, uint32_t pc_base, uint32_t shard,
+                     int fixed_log2_rows, uint32_t* out, size_t out_cap, uint32_t* byte_counts) {
+  ORC_TRY
+  size_t h;
+  std::vector<uint64_t> cnt(byte_counts ? tracegen::BYTE_ROWS * tracegen::NUM_BYTE_OPS : 0, 0);
+  std::vector<F> t = tracegen::generate_cpu((const tracegen::CpuEvent*)events, n_events, (const tracegen::Instruction*)program, n_instr, pc_base,
+                                            shard, fixed_log2_rows, &h, byte_counts ? cnt.data() : nullptr);
+  if (t.size() > out_cap) throw std::runtime_error("trace buffer too small");
+  for (size_t i = 0; i < t.size(); i++) out[i] = to_monty(t[i]);
+  for (size_t i = 0; i < cnt.size(); i++) byte_counts[i] += (uint32_t)cnt[i];
+  ORC_CATCH
+}
+// Program chip: which = 0 preprocessed table (14 columns), 1 multiplicities (1 column)
+int orc_tracegen_program(int which, const void* events, size_t n_events, const void* program, size_t n_instr, uint32_t pc_base,
+                         int fixed_log2_rows, uint32_t* out, size_t out_cap) {
+  ORC_TRY
+  size_t h;
+  std::vector<F> t = which == 0 ? tracegen::generate_program_prep((const tracegen::Instruction*)program, n_instr, pc_base, fixed_log2_rows, &h)
+                                : tracegen::generate_program_mult((const tracegen::CpuEvent*)events, n_events, n_instr, pc_base, fixed_log2_rows, &h);
+  if (t.size() > out_cap) throw std::runtime_error("trace buffer too small");
+  for (size_t i = 0; i < t.size(); i++) out[i] = to_monty(t[i]);
+  ORC_CATCH
+}
+
 }  // extern "C"

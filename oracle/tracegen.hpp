@@ -692,4 +692,157 @@ static inline std::vector<F> generate_divrem(const CompAluEvent* events, size_t 
   return t;
 }
 
+// ---- Cpu chip: CpuEventFfi / InstructionFfi (crates/core/executor/src/events/cpu.rs:46-106, instruction.rs:22-33); columns
+// cpu/columns/mod.rs:16-77 + instruction.rs:12-32; row builder cpu/trace.rs:117-257, padding rows :57-60; the read access
+// columns memory/consistency/trace.rs:22-33
+struct MemoryReadRecord { uint32_t value, shard, timestamp, prev_shard, prev_timestamp; };
+struct OptionMemoryRecord { uint8_t tag; uint8_t pad[3]; MemoryReadRecord read; MemoryWriteRecord write; };   // tag: Read 0, Write 1, None 2
+struct OptionU32 { uint8_t tag; uint8_t pad[3]; uint32_t value; };                                            // tag: Some 0, None 1
+struct CpuEvent {
+  uint32_t clk, pc, next_pc, next_next_pc, a;
+  OptionMemoryRecord a_record;
+  uint32_t b;
+  OptionMemoryRecord b_record;
+  uint32_t c;
+  OptionMemoryRecord c_record;
+  OptionU32 hi;
+  OptionMemoryRecord hi_record, memory_record;
+  uint32_t exit_code;
+};
+static_assert(sizeof(CpuEvent) == 280, "CpuEventFfi is seventy words");
+struct Instruction { uint8_t opcode, op_a; uint8_t pad0[2]; uint32_t op_b, op_c; uint8_t imm_b, imm_c; uint8_t pad1[2]; OptionU32 raw; };
+static_assert(sizeof(Instruction) == 24, "InstructionFfi is six words");
+static const size_t CPU_WIDTH = 67, PROGRAM_PREP_WIDTH = 14;
+
+namespace opc {   // crates/core/executor/src/opcode.rs:26-90 and the predicates of instruction.rs:70-310
+static inline bool is_branch(uint8_t o) { return o >= 21 && o <= 26; }
+static inline bool is_jump(uint8_t o) { return o >= 27 && o <= 29; }
+static inline bool is_syscall(uint8_t o) { return o == 30; }
+static inline bool is_memory(uint8_t o) { return o >= 31 && o <= 44; }
+static inline bool is_store_except_sc(uint8_t o) { return o >= 39 && o <= 43; }
+static inline bool is_mult_div(uint8_t o) { return o == 3 || o == 4 || o == 5 || o == 6; }
+static inline bool is_maddsub(uint8_t o) { return o >= 46 && o <= 49; }
+static inline bool is_check_memory(uint8_t o) { return is_syscall(o) || is_maddsub(o) || is_memory(o); }
+static inline bool is_rw_a(uint8_t o) { return is_syscall(o) || o == 45 || is_maddsub(o) || o == 50 || o == 51 || is_memory(o); }
+}  // namespace opc
+
+// MemoryReadCols::populate: value, prev_shard, prev_clk, compare_clk, diff_16bit_limb, diff_8bit_limb (9 columns at `r`)
+static inline void memory_access_cols(uint32_t value, uint32_t shard, uint32_t ts, uint32_t prev_shard, uint32_t prev_ts, F* r,
+                                      std::vector<ByteLookup>* lk) {
+  word(r, value);
+  r[4] = fu32(prev_shard);
+  r[5] = fu32(prev_ts);
+  const bool use_clk = prev_shard == shard;
+  r[6] = use_clk;
+  const uint32_t diff_minus_one = (use_clk ? ts : shard) - (use_clk ? prev_ts : prev_shard) - 1u;
+  const uint32_t d16 = diff_minus_one & 0xffff, d8 = (diff_minus_one >> 16) & 0xff;
+  r[7] = d16;
+  r[8] = d8;
+  if (lk) {
+    lk->push_back(ByteLookup{B_U16RANGE_OP, (uint8_t)(d16 >> 8), (uint8_t)d16});
+    lk->push_back(ByteLookup{B_U8RANGE_OP, 0, (uint8_t)d8});
+  }
+}
+static inline void instruction_cols(const Instruction& in, F* r) {   // opcode, op_a, op_b[4], op_c[4], op_a_0, imm_b, imm_c
+  r[0] = in.opcode; r[1] = in.op_a;
+  word(r + 2, in.op_b); word(r + 6, in.op_c);
+  r[10] = in.op_a == 0; r[11] = in.imm_b != 0; r[12] = in.imm_c != 0;
+}
+static inline void cpu_row(const CpuEvent& e, uint32_t shard, const Instruction& in, F* r, std::vector<ByteLookup>* lk) {
+  enum { SHARD = 0, CLK_16 = 1, CLK_8 = 2, SHARD_TO_SEND = 3, CLK_TO_SEND = 4, PC = 5, NEXT_PC = 6, NEXT_NEXT_PC = 7, INSTRUCTION = 8,
+         NUM_EXTRA_CYCLES = 21, IS_RW_A = 22, IS_CHECK_MEMORY = 23, IS_HALT = 24, IS_SEQUENTIAL = 25, OP_A_VALUE = 26, HI_OR_PREV_A = 30,
+         OP_A_ACCESS = 34, OP_B_ACCESS = 47, OP_C_ACCESS = 56, IS_REAL = 65, OP_A_IMMUTABLE = 66 };
+  r[SHARD] = fu32(shard);
+  const uint32_t clk16 = e.clk & 0xffff, clk8 = (e.clk >> 16) & 0xff;
+  r[CLK_16] = clk16; r[CLK_8] = clk8;
+  if (lk) {
+    lk->push_back(ByteLookup{B_U16RANGE_OP, (uint8_t)((shard & 0xffff) >> 8), (uint8_t)shard});
+    lk->push_back(ByteLookup{B_U16RANGE_OP, (uint8_t)(clk16 >> 8), (uint8_t)clk16});
+    lk->push_back(ByteLookup{B_U8RANGE_OP, 0, (uint8_t)clk8});
+  }
+  r[PC] = fu32(e.pc); r[NEXT_PC] = fu32(e.next_pc); r[NEXT_NEXT_PC] = fu32(e.next_next_pc);
+  instruction_cols(in, r + INSTRUCTION);
+  const uint8_t o = in.opcode;
+  r[OP_A_IMMUTABLE] = opc::is_store_except_sc(o) || opc::is_branch(o) || o == 54;   // TEQ
+  r[IS_RW_A] = opc::is_rw_a(o);
+  const bool check_memory = opc::is_mult_div(o) || opc::is_check_memory(o);
+  r[IS_CHECK_MEMORY] = check_memory;
+  word(r + OP_A_VALUE, e.a);
+  if (e.hi.tag == 0) word(r + HI_OR_PREV_A, e.hi.value);
+  word(r + OP_A_ACCESS + 4, e.a);        // op_a_access = prev_value(4), access(9)
+  word(r + OP_B_ACCESS, e.b);
+  word(r + OP_C_ACCESS, e.c);
+  r[SHARD_TO_SEND] = check_memory ? r[SHARD] : 0;
+  r[CLK_TO_SEND] = check_memory ? fu32(e.clk) : 0;
+  if (e.a_record.tag == 1) {
+    const MemoryWriteRecord& w = e.a_record.write;
+    word(r + OP_A_ACCESS, w.prev_value);
+    memory_access_cols(w.value, w.shard, w.timestamp, w.prev_shard, w.prev_timestamp, r + OP_A_ACCESS + 4, lk);
+  } else if (e.a_record.tag == 0) {
+    const MemoryReadRecord& rd = e.a_record.read;
+    word(r + OP_A_ACCESS, rd.value);
+    memory_access_cols(rd.value, rd.shard, rd.timestamp, rd.prev_shard, rd.prev_timestamp, r + OP_A_ACCESS + 4, lk);
+  }
+  if (e.b_record.tag == 0) {
+    const MemoryReadRecord& rd = e.b_record.read;
+    memory_access_cols(rd.value, rd.shard, rd.timestamp, rd.prev_shard, rd.prev_timestamp, r + OP_B_ACCESS, lk);
+  }
+  if (e.c_record.tag == 0) {
+    const MemoryReadRecord& rd = e.c_record.read;
+    memory_access_cols(rd.value, rd.shard, rd.timestamp, rd.prev_shard, rd.prev_timestamp, r + OP_C_ACCESS, lk);
+  }
+  bool is_halt = false;
+  if (opc::is_syscall(o)) {   // SyscallCode::HALT = 0, SYS_EXT_GROUP = 4246 (crates/core/executor/src/syscalls/code.rs)
+    const F id0 = r[OP_A_ACCESS], id1 = r[OP_A_ACCESS + 1];
+    is_halt = (id0 == 0 && id1 == 0) || (id0 == (4246 & 0xff) && id1 == (4246 >> 8));
+    r[IS_HALT] = is_halt;
+    r[NUM_EXTRA_CYCLES] = r[OP_A_ACCESS + 3];
+  }
+  r[IS_SEQUENTIAL] = !is_halt && !opc::is_branch(o) && !opc::is_jump(o);
+  if (lk) {
+    lk->push_back(ByteLookup{B_U8RANGE_OP, (uint8_t)r[OP_A_ACCESS + 4], (uint8_t)r[OP_A_ACCESS + 5]});
+    lk->push_back(ByteLookup{B_U8RANGE_OP, (uint8_t)r[OP_A_ACCESS + 6], (uint8_t)r[OP_A_ACCESS + 7]});
+  }
+  r[IS_REAL] = 1;
+}
+static inline std::vector<F> generate_cpu(const CpuEvent* events, size_t n_events, const Instruction* program, size_t n_instr,
+                                          uint32_t pc_base, uint32_t shard, int fixed_log2_rows, size_t* height, uint64_t* byte_counts) {
+  const size_t h = padded_rows(n_events, fixed_log2_rows);
+  std::vector<F> t(h * CPU_WIDTH, 0);
+  std::vector<ByteLookup> lk;
+  for (size_t i = 0; i < h; i++) {
+    F* r = t.data() + i * CPU_WIDTH;
+    if (i >= n_events) { r[8 + 11] = 1; r[8 + 12] = 1; r[22] = 1; continue; }   // imm_b, imm_c, is_rw_a
+    const size_t idx = (events[i].pc - pc_base) / 4;   // Program::fetch
+    if (events[i].pc < pc_base || idx >= n_instr) throw std::runtime_error("tracegen: pc outside the program");
+    lk.clear();
+    cpu_row(events[i], shard, program[idx], r, byte_counts ? &lk : nullptr);
+    for (const ByteLookup& l : lk) byte_counts[(((size_t)l.b << 8) + l.c) * NUM_BYTE_OPS + l.op]++;
+  }
+  *height = h;
+  return t;
+}
+// ProgramChip: preprocessed (pc, instruction) rows (program/mod.rs:62-101) and the multiplicity column (:113-146)
+static inline std::vector<F> generate_program_prep(const Instruction* program, size_t n_instr, uint32_t pc_base, int fixed_log2_rows, size_t* height) {
+  const size_t h = padded_rows(n_instr, fixed_log2_rows);
+  std::vector<F> t(h * PROGRAM_PREP_WIDTH, 0);
+  for (size_t i = 0; i < n_instr; i++) {
+    t[i * PROGRAM_PREP_WIDTH] = fu32(pc_base + 4 * (uint32_t)i);
+    instruction_cols(program[i], t.data() + i * PROGRAM_PREP_WIDTH + 1);
+  }
+  *height = h;
+  return t;
+}
+static inline std::vector<F> generate_program_mult(const CpuEvent* events, size_t n_events, size_t n_instr, uint32_t pc_base, int fixed_log2_rows,
+                                                   size_t* height) {
+  const size_t h = padded_rows(n_instr, fixed_log2_rows);
+  std::vector<F> t(h, 0);
+  for (size_t i = 0; i < n_events; i++) {
+    const size_t idx = (events[i].pc - pc_base) / 4;
+    if (events[i].pc >= pc_base && idx < n_instr) t[idx] = fadd(t[idx], 1);
+  }
+  *height = h;
+  return t;
+}
+
 }  // namespace tracegen

@@ -288,3 +288,31 @@ def tracegen_divrem(events, fixed_log2_rows=-1, byte_counts=None):
     _check(lib().orc_tracegen_divrem(C.c_void_p(ev.ctypes.data), C.c_size_t(len(ev)), C.c_int(fixed_log2_rows), abi.as_u32p(out),
                                      C.c_size_t(out.size), bc))
     return out
+
+
+def tracegen_cpu(events, program, pc_base, shard, fixed_log2_rows=-1, byte_counts=None):
+    """Cpu chip rows from CpuEventFfi records and the program (miniexec.CPU_EVENT / INSTRUCTION)."""
+    from ziren_amd import miniexec as M
+    ev = np.ascontiguousarray(events, dtype=M.CPU_EVENT)
+    prog = np.ascontiguousarray(program, dtype=M.INSTRUCTION)
+    rows = C.c_size_t()
+    _check(lib().orc_tracegen_alu_rows(C.c_size_t(len(ev)), C.c_int(fixed_log2_rows), C.byref(rows)))
+    out = np.zeros((rows.value, M.CPU_WIDTH), dtype=np.uint32)
+    bc = abi.as_u32p(byte_counts) if byte_counts is not None else None
+    _check(lib().orc_tracegen_cpu(C.c_void_p(ev.ctypes.data), C.c_size_t(len(ev)), C.c_void_p(prog.ctypes.data), C.c_size_t(len(prog)),
+                                  C.c_uint32(pc_base), C.c_uint32(shard), C.c_int(fixed_log2_rows), abi.as_u32p(out), C.c_size_t(out.size), bc))
+    return out
+
+
+def tracegen_program(which, events, program, pc_base, fixed_log2_rows=-1):
+    """Program chip: which = 0 the preprocessed (pc, instruction) table, 1 the multiplicity column."""
+    from ziren_amd import miniexec as M
+    ev = np.ascontiguousarray(events, dtype=M.CPU_EVENT)
+    prog = np.ascontiguousarray(program, dtype=M.INSTRUCTION)
+    rows = C.c_size_t()
+    _check(lib().orc_tracegen_alu_rows(C.c_size_t(len(prog)), C.c_int(fixed_log2_rows), C.byref(rows)))
+    out = np.zeros((rows.value, M.PROGRAM_PREP_WIDTH if which == 0 else 1), dtype=np.uint32)
+    _check(lib().orc_tracegen_program(C.c_int(which), C.c_void_p(ev.ctypes.data), C.c_size_t(len(ev)), C.c_void_p(prog.ctypes.data),
+                                      C.c_size_t(len(prog)), C.c_uint32(pc_base), C.c_int(fixed_log2_rows), abi.as_u32p(out),
+                                      C.c_size_t(out.size)))
+    return out

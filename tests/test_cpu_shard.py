@@ -1,0 +1,216 @@
+"""A coherent core shard: a program executed by ziren_amd/miniexec.py, its CpuEvents through the Cpu
+chip, the per-chip events through the ALU / Mul / DivRem / Branch / Jump / MovCond chips, the Program and Byte tables —
+every instruction, program and byte lookup is exchanged between real chips; only the register accesses (kind Memory),
+whose counterpart chips (MemoryLocal / MemoryGlobal) are not built, are mirrored."""
+import numpy as np
+import pytest
+
+from ziren_amd import abi, air, chips, events as E, field as F, miniexec as M
+
+from test_chip_airs import lookup_tally, mirror_chip
+
+PC_BASE, SHARD = 0x1000, 1
+
+
+def log2_rows(n):
+    h = 16
+    while h < n:
+        h <<= 1
+    return h.bit_length() - 1
+
+
+def cpu_shard(oracle, n_cycles, seed=1):
+    """(chips with oracle traces, device work list, byte chip, program chip, public values)."""
+    prog, rec0, pv = M.run(n_cycles, seed=seed, shard=SHARD, pc_base=PC_BASE)
+    rec = M.add_dependencies(rec0)
+    extra = np.zeros((1 << 16, 10), dtype=np.uint32)
+    recs, work = [], []
+    lh = log2_rows(len(rec.cpu))
+    cpu = chips.record_cpu_chip(lh)
+    cpu.trace = oracle.tracegen_cpu(rec.cpu, prog, PC_BASE, SHARD, lh, extra)
+    recs.append(cpu)
+    work.append(("cpu", rec.cpu, lh))
+    for chip in sorted(E.CHIP_NAMES):
+        ev = rec.alu[chip]
+        lh = log2_rows(len(ev))
+        rc = chips.record_chip(chip, lh)
+        rc.trace = oracle.tracegen_alu(chip, ev, lh)
+        recs.append(rc)
+        work.append((chip, ev, lh))
+    for name, ev, record, gen in (("jump", rec.jump, chips.record_jump_chip, oracle.tracegen_jump),
+                                  ("mov_cond", rec.mov_cond, chips.record_mov_cond_chip, oracle.tracegen_mov_cond)):
+        lh = log2_rows(len(ev))
+        rc = record(lh)
+        rc.trace = gen(ev, lh)
+        recs.append(rc)
+        work.append((name, ev, lh))
+    for name, ev, record, gen in (("branch", rec.branch, chips.record_branch_chip, oracle.tracegen_branch),
+                                  ("mul", rec.mul, chips.record_mul_chip, oracle.tracegen_mul),
+                                  ("divrem", rec.divrem, chips.record_divrem_chip, oracle.tracegen_divrem)):
+        lh = log2_rows(len(ev))
+        rc = record(lh)
+        rc.trace = gen(ev, lh, extra)
+        recs.append(rc)
+        work.append((name, ev, lh))
+    byte = chips.record_byte_chip(prep_index=0)
+    byte.trace = oracle.tracegen_byte_mults([(c, ev) for c, ev, _ in work if not isinstance(c, str)], extra)
+    byte.prep_trace = oracle.tracegen_byte_table()
+    plh = log2_rows(len(prog))
+    program = chips.record_program_chip(plh, prep_index=1)
+    program.trace = oracle.tracegen_program(1, rec.cpu, prog, PC_BASE, plh)
+    program.prep_trace = oracle.tracegen_program(0, rec.cpu, prog, PC_BASE, plh)
+    return recs, work, byte, program, prog, pv
+
+
+def test_miniexec_record_is_coherent():
+    prog, rec, pv = M.run(1500, seed=5)
+    cpu = rec.cpu
+    assert len(cpu) == 1500 and pv["start_pc"] == 0x1000 and (np.diff(cpu["clk"].astype(np.int64)) == 5).all()
+    assert (cpu["pc"][1:] == cpu["next_pc"][:-1]).all() and (cpu["next_pc"][1:] == cpu["next_next_pc"][:-1]).all()
+    assert len(np.unique(cpu["pc"])) == 1500                      # forward only: every pc runs once
+    total = sum(len(v) for v in rec.alu.values()) + len(rec.mul) + len(rec.divrem) + len(rec.branch) + len(rec.jump) + len(rec.mov_cond)
+    assert total == 1500                                          # one chip event per cycle (emit_events)
+    assert min(len(v) for v in rec.alu.values()) > 0 and len(rec.jump) > 0 and len(rec.divrem) > 0
+    # register accesses chain: every record's previous (shard, timestamp) is the last access to that register
+    ins = prog[(cpu["pc"] - 0x1000) // 4]
+    last = {}
+    for e, i in zip(cpu, ins):
+        for name, reg, is_reg in (("c_record", int(i["op_c"]), not i["imm_c"]), ("b_record", int(i["op_b"]), not i["imm_b"]),
+                                  ("a_record", int(i["op_a"]), True), ("hi_record", M.REG_HI, True)):
+            r = e[name]
+            if r["tag"] == M.TAG_NONE or not is_reg:
+                continue
+            body = r["read"] if r["tag"] == M.TAG_READ else r["write"]
+            assert (int(body["prev_shard"]), int(body["prev_timestamp"])) == last.get(reg, (0, 0))
+            last[reg] = (int(body["shard"]), int(body["timestamp"]))
+    taken = E.branch_taken(rec.branch)
+    assert taken.any() and (~taken).any()
+
+
+def test_cpu_constraints_hold(oracle):
+    rec = chips.record_cpu_constraints()
+    for n, seed in ((1, 1), (16, 2), (17, 3), (2500, 4)):
+        prog, r, pv = M.run(n, seed=seed)
+        t = F.from_monty(oracle.tracegen_cpu(r.cpu, prog, PC_BASE, SHARD))
+        assert air.debug_constraints(rec.b, t, public_values=F.from_monty(M.public_values(pv))) == []
+    # padding rows: imm_b = imm_c = is_rw_a = 1 (cpu/trace.rs:57-60)
+    assert t[2500:, 19].all() and t[2500:, 20].all() and t[2500:, 22].all() and not t[2500:, 65].any()
+    for col, rows in ((5, {1199, 1200}), (6, {1199, 1200}), (1, {1199, 1200}), (65, {1199, 1200}), (27, {1200}), (40, {1200})):
+        bad = t.copy()     # pc / next_pc / clk limb tie neighbouring rows; op_a_value and the access value only their own
+        bad[1200, col] = (int(bad[1200, col]) + 1) % F.P
+        assert {row for _, row in air.debug_constraints(rec.b, bad, public_values=F.from_monty(M.public_values(pv)))} <= rows | {1200}, col
+        assert air.debug_constraints(rec.b, bad, public_values=F.from_monty(M.public_values(pv))), col
+    wrong = dict(pv, next_pc=pv["next_pc"] + 4)
+    assert {row for _, row in air.debug_constraints(rec.b, t, public_values=F.from_monty(M.public_values(wrong)))} == {2499}
+    c = chips.record_cpu_chip(10)    # mips_costs.json: Cpu 119
+    assert c.main_width + 4 * c.perm_ext_width + 8 == 119
+
+
+def test_shard_lookups_balance(oracle):
+    """Cpu sends every instruction the eleven chips receive, the Program table receives every fetch, the Byte table
+    every byte lookup; only the register accesses are left for the memory chips."""
+    recs, work, byte, program, prog, pv = cpu_shard(oracle, 1200, seed=9)
+    left = {k: v for k, v in lookup_tally(recs + [byte, program]).items() if v}
+    assert left and {k[0] for k in left} == {air.KIND_MEMORY}
+    mirrors = [mirror_chip(r, kinds=(air.KIND_MEMORY,)) for r in recs if any(lk.kind == air.KIND_MEMORY for lk in r.sends)]
+    assert [m.name for m in mirrors] == ["CpuMirror", "MulMirror", "DivRemMirror"]
+    assert not any(lookup_tally(recs + [byte, program] + mirrors).values())
+
+
+def test_oracle_proves_coherent_shard(oracle):
+    """The restated verifier accepts the oracle's proof of the whole shard (cumulative sum zero with only the register
+    accesses mirrored) and rejects one made for a different next_pc (the Cpu chip's boundary constraint)."""
+    from ziren_amd import synth
+    recs, work, byte, program, prog, pv = cpu_shard(oracle, 500, seed=7)
+    mirrors = [mirror_chip(r, kinds=(air.KIND_MEMORY,)) for r in recs if any(lk.kind == air.KIND_MEMORY for lk in r.sends)]
+    all_chips = recs + [byte, program] + mirrors
+    fri = abi.FriConfig(1, 84, 16)
+    igcs = F.to_monty(np.zeros(14, dtype=np.uint64))
+    opk = oracle.Pk([byte.prep_trace, program.prep_trace], [0, 0], F.to_monty(PC_BASE), igcs, 1)
+    start = oracle.new_challenger()
+    opk.observe_into(start)
+    for claimed, ok in ((pv, True), (dict(pv, next_pc=pv["next_pc"] + 4), False)):
+        proof, _ = oracle.prove_shard(opk, all_chips, [c.trace for c in all_chips], M.public_values(claimed), fri, synth.NUM_PV_ELTS, start.copy())
+        assert (oracle.verify_shard(opk, all_chips, fri, synth.NUM_PV_ELTS, start.copy(), proof) == 0) == ok
+
+
+# ---- GPU ------------------------------------------------------------------------------------------------------------
+
+def device_trace(ctx, chip, ev, lh, blu, prog):
+    if chip == "cpu":
+        return ctx.tracegen_cpu(ev, prog, PC_BASE, SHARD, lh, blu)
+    if chip == "jump":
+        return ctx.tracegen_jump(ev, lh)
+    if chip == "mov_cond":
+        return ctx.tracegen_mov_cond(ev, lh)
+    if chip == "branch":
+        return ctx.tracegen_branch(ev, lh, blu)
+    if chip == "mul":
+        return ctx.tracegen_mul(ev, lh, blu)
+    if chip == "divrem":
+        return ctx.tracegen_divrem(ev, lh, blu)
+    return ctx.tracegen_alu(chip, ev, lh, blu)
+
+
+@pytest.mark.gpu
+def test_gpu_cpu_and_program_tracegen_match_oracle(hip_ctx, oracle):
+    from ziren_amd import lib
+    assert lib.load().zkm_tracegen_cpu_width() == M.CPU_WIDTH
+    for n, fixed in ((0, -1), (1, -1), (17, -1), (3000, -1), (5000, 14)):
+        prog, rec, pv = M.run(n, seed=n + 2)
+        counts = np.zeros((1 << 16, 10), dtype=np.uint32)
+        want = oracle.tracegen_cpu(rec.cpu, prog, PC_BASE, SHARD, fixed, counts)
+        blu = hip_ctx.byte_lookups()
+        m = hip_ctx.tracegen_cpu(rec.cpu, prog, PC_BASE, SHARD, fixed, blu)
+        assert (m.height, m.width) == want.shape and np.array_equal(m.to_host(), want), n
+        mults = hip_ctx.tracegen_byte_mults(blu)
+        assert np.array_equal(F.from_monty(mults.to_host()), counts), n
+        m.free(); mults.free(); blu.free()
+        for which, born in ((0, hip_ctx.tracegen_program(prog, PC_BASE)), (1, hip_ctx.tracegen_program_mults(rec.cpu, len(prog), PC_BASE))):
+            want = oracle.tracegen_program(which, rec.cpu, prog, PC_BASE)
+            assert (born.height, born.width) == want.shape and np.array_equal(born.to_host(), want), (n, which)
+            born.free()
+    prog, rec, pv = M.run(50, seed=1)
+    with pytest.raises(lib.ZkmError, match="outside the program"):
+        hip_ctx.tracegen_cpu(rec.cpu, prog[:10], PC_BASE, SHARD)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_cycles", [40, 6000])
+def test_gpu_coherent_shard_proof(hip_ctx, oracle, n_cycles):
+    """Cpu + Program + the eleven instruction chips + Byte over one executed program: every trace and both preprocessed
+    tables born on the device, proof bit-identical to the oracle's and accepted by the restated verifier; the Cpu chip's
+    public values (start_pc, next_pc, execution_shard) are checked by its constraints."""
+    from ziren_amd import prover, synth
+    recs, work, byte, program, prog, pv = cpu_shard(oracle, n_cycles, seed=n_cycles)
+    mirrors = [mirror_chip(r, kinds=(air.KIND_MEMORY,)) for r in recs if any(lk.kind == air.KIND_MEMORY for lk in r.sends)]
+    all_chips = recs + [byte, program] + mirrors
+    fri = abi.FriConfig(1, 84, 16)
+    pvs = M.public_values(pv)
+    igcs = F.to_monty(np.zeros(14, dtype=np.uint64))
+    pc_start = F.to_monty(PC_BASE)
+    hp = prover.HipProver(all_chips, fri, synth.NUM_PV_ELTS, ctx=hip_ctx)
+    hp.specialize_quotient_kernels(recs + [byte, program])
+    pk = hp.setup([hip_ctx.tracegen_byte_table(), hip_ctx.tracegen_program(prog, PC_BASE, program.log_height)], [0, 0], pc_start, igcs)
+    opk = oracle.Pk([byte.prep_trace, program.prep_trace], [0, 0], pc_start, igcs, 1)
+    assert np.array_equal(pk.commit, opk.commitment())
+    ch = prover.new_challenger()
+    pk.observe_into(ch)
+    start = ch.copy()
+    blu = hip_ctx.byte_lookups()
+    born = [device_trace(hip_ctx, chip, ev, lh, blu, prog) for chip, ev, lh in work]
+    born.append(hip_ctx.tracegen_byte_mults(blu))
+    born.append(hip_ctx.tracegen_program_mults(work[0][1], len(prog), PC_BASE, program.log_height))
+    born += [hip_ctx.upload(m.trace) for m in mirrors]
+    proof = hp.prove_shard(pk, pvs, born, ch).copy()
+    och = oracle.new_challenger()
+    opk.observe_into(och)
+    oproof, _ = oracle.prove_shard(opk, all_chips, [c.trace for c in all_chips], pvs, fri, synth.NUM_PV_ELTS, och)
+    assert np.array_equal(proof, oproof)
+    assert oracle.verify_shard(opk, all_chips, fri, synth.NUM_PV_ELTS, start.copy(), proof) == 0
+    # a proof against a different claimed next_pc fails the Cpu chip's boundary constraint
+    wrong = M.public_values(dict(pv, next_pc=pv["next_pc"] + 4))
+    bad = hp.prove_shard(pk, wrong, born, start.copy()).copy()
+    assert oracle.verify_shard(opk, all_chips, fri, synth.NUM_PV_ELTS, start.copy(), bad) != 0
+    for m in born:
+        m.free()

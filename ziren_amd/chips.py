@@ -54,7 +54,7 @@ class _Rec:
 
     def __init__(self, width, prep_width=0):
         self.b = air.AirBuilder(width, prep_width, 0)
-        self.local = self.b.main()[0]
+        self.local, self.next = self.b.main()
         self.prep = self.b.preprocessed()[0]
         self.sends: List[air.Lookup] = []
         self.receives: List[air.Lookup] = []
@@ -92,23 +92,26 @@ class _Rec:
         for c in cols:
             self.send_byte(B_U16RANGE, c, 0, 0, mult)
 
-    def eval_memory_access(self, shard, clk, addr, cols, do_check):
-        """MemoryAirBuilder::eval_memory_access for MemoryReadWriteCols / MemoryWriteCols (air/memory.rs:18-172):
-        `cols` = prev_value(4), value(4), prev_shard, prev_clk, compare_clk, diff_16bit_limb, diff_8bit_limb."""
+    def eval_range_check_24bits(self, value, limb16, limb8, do_check):
+        """MemoryAirBuilder::eval_range_check_24bits (air/memory.rs:142-172)."""
+        self.b.when(do_check).assert_eq(value, limb16 + limb8 * (1 << 16))
+        self.send_byte(B_U16RANGE, limb16, 0, 0, do_check)
+        self.send_byte(B_U8RANGE, 0, 0, limb8, do_check)
+
+    def eval_memory_access(self, shard, clk, addr, prev_value, access, do_check):
+        """MemoryAirBuilder::eval_memory_access (air/memory.rs:18-134): `access` = MemoryAccessCols (value(4), prev_shard,
+        prev_clk, compare_clk, diff_16bit_limb, diff_8bit_limb); `prev_value` = the separate column group of
+        MemoryWriteCols / MemoryReadWriteCols, or the value itself for MemoryReadCols."""
         b = self.b
-        prev_value, value = cols[0:4], cols[4:8]
-        prev_shard, prev_clk, compare_clk, diff16, diff8 = cols[8], cols[9], cols[10], cols[11], cols[12]
+        value = access[0:4]
+        prev_shard, prev_clk, compare_clk, diff16, diff8 = access[4], access[5], access[6], access[7], access[8]
         b.assert_bool(do_check)
         # eval_memory_access_timestamp
         b.when(do_check).assert_bool(compare_clk)
         b.when(do_check).when(compare_clk).assert_eq(shard, prev_shard)
         prev_comp = compare_clk * prev_clk + (1 - compare_clk) * prev_shard
         cur_comp = compare_clk * clk + (1 - compare_clk) * shard
-        diff_minus_one = cur_comp - prev_comp - 1
-        # eval_range_check_24bits
-        b.when(do_check).assert_eq(diff_minus_one, diff16 + diff8 * (1 << 16))
-        self.send_byte(B_U16RANGE, diff16, 0, 0, do_check)
-        self.send_byte(B_U8RANGE, 0, 0, diff8, do_check)
+        self.eval_range_check_24bits(cur_comp - prev_comp - 1, diff16, diff8, do_check)
         # the previous access is sent, the current one received
         self.sends.append(air.Lookup([air.to_virtual_pair(v) for v in [prev_shard, prev_clk, addr] + list(prev_value)],
                                      air.to_virtual_pair(do_check), air.KIND_MEMORY))
@@ -498,7 +501,7 @@ def _mul(r: _Rec):
     r.slice_range_check_u8(product, is_real)
     r.receive_instruction(l[PC], l[NEXT_PC], l[NEXT_PC] + 4, opcode, a, wb, wc, 1, is_real, hi=hi, shard=l[SHARD], clk=l[CLK],
                           is_check_memory=l[HI_REAL])
-    r.eval_memory_access(l[SHARD], l[CLK] + E.MEMORY_ACCESS_POSITION_HI, E.REGISTER_HI, l[OP_HI:OP_HI + 13], l[HI_REAL])
+    r.eval_memory_access(l[SHARD], l[CLK] + E.MEMORY_ACCESS_POSITION_HI, E.REGISTER_HI, l[OP_HI:OP_HI + 4], l[OP_HI + 4:OP_HI + 13], l[HI_REAL])
     b.when_not(is_real).assert_zero(l[HI_REAL])
     b.when(l[HI_REAL]).assert_one(l[IS_MULT] + l[IS_MULTU])
     for i in range(4):
@@ -596,9 +599,83 @@ def _divrem(r: _Rec):
     r.receive_instruction(l[PC], l[NEXT_PC], l[NEXT_PC] + 4, opcode, quot, wb, wc, 1, div, hi=rem, shard=l[SHARD], clk=l[CLK],
                           is_check_memory=1)
     r.receive_instruction(l[PC], l[NEXT_PC], l[NEXT_PC] + 4, opcode, rem, wb, wc, 1, l[IS_MOD] + l[IS_MODU])
-    r.eval_memory_access(l[SHARD], l[CLK] + E.MEMORY_ACCESS_POSITION_HI, E.REGISTER_HI, l[OP_HI:OP_HI + 13], div)
+    r.eval_memory_access(l[SHARD], l[CLK] + E.MEMORY_ACCESS_POSITION_HI, E.REGISTER_HI, l[OP_HI:OP_HI + 4], l[OP_HI + 4:OP_HI + 13], div)
     for i in range(4):
         b.when(div).assert_eq(rem[i], l[OP_HI + 4 + i])
+
+
+def _cpu(r: _Rec):
+    """CpuChip::eval (cpu/air/mod.rs:22-108, eval_registers air/register.rs:12-75, eval_shard_clk / eval_pc / eval_is_real
+    air/mod.rs:110-215). Public values: start_pc, next_pc, execution_shard (crates/stark/src/air/public_values.rs:22-60)."""
+    from . import miniexec as M
+    l, n, b = r.local, r.next, r.b
+    (SHARD, CLK_16, CLK_8, SHARD_TO_SEND, CLK_TO_SEND, PC, NEXT_PC, NEXT_NEXT_PC, INSTR, NUM_EXTRA_CYCLES, IS_RW_A, IS_CHECK_MEMORY, IS_HALT,
+     IS_SEQUENTIAL, OP_A_VALUE, HI_OR_PREV_A, OP_A_ACCESS, OP_B_ACCESS, OP_C_ACCESS, IS_REAL, OP_A_IMMUTABLE) = (
+        0, 1, 2, 3, 4, 5, 6, 7, 8, 21, 22, 23, 24, 25, 26, 30, 34, 47, 56, 65, 66)
+    OPCODE, OP_A, OP_B, OP_C, OP_A_0, IMM_B, IMM_C = INSTR, INSTR + 1, INSTR + 2, INSTR + 6, INSTR + 10, INSTR + 11, INSTR + 12
+    instruction = l[INSTR:INSTR + 13]
+    op_a_value, hi_or_prev_a = l[OP_A_VALUE:OP_A_VALUE + 4], l[HI_OR_PREV_A:HI_OR_PREV_A + 4]
+    a_prev, a_access = l[OP_A_ACCESS:OP_A_ACCESS + 4], l[OP_A_ACCESS + 4:OP_A_ACCESS + 13]
+    b_access, c_access = l[OP_B_ACCESS:OP_B_ACCESS + 9], l[OP_C_ACCESS:OP_C_ACCESS + 9]
+    a_val, b_val, c_val = a_access[0:4], b_access[0:4], c_access[0:4]
+    is_real = l[IS_REAL]
+    clk = l[CLK_8] * (1 << 16) + l[CLK_16]
+    # send_program (air/program.rs:14-26)
+    r.sends.append(air.Lookup([air.to_virtual_pair(v) for v in [l[PC]] + list(instruction)], air.to_virtual_pair(is_real), air.KIND_PROGRAM))
+    # eval_registers
+    for i in range(4):
+        b.when(l[IMM_B]).assert_eq(b_val[i], l[OP_B + i])
+    for i in range(4):
+        b.when(l[IMM_C]).assert_eq(c_val[i], l[OP_C + i])
+    r.eval_memory_access(l[SHARD], clk + M.POS_B, l[OP_B], b_val, b_access, 1 - l[IMM_B])
+    r.eval_memory_access(l[SHARD], clk + M.POS_C, l[OP_C], c_val, c_access, 1 - l[IMM_C])
+    for i in range(4):
+        b.when(l[OP_A_0]).assert_zero(a_val[i])
+    for i in range(4):
+        b.when_not(l[OP_A_0]).assert_eq(op_a_value[i], a_val[i])
+    for i in range(4):
+        b.when(l[IS_RW_A]).assert_eq(hi_or_prev_a[i], a_prev[i])
+    r.eval_memory_access(l[SHARD], clk + M.POS_A, l[OP_A], a_prev, a_access, is_real)
+    r.slice_range_check_u8(a_val, is_real)
+    for i in range(4):
+        b.when(l[OP_A_IMMUTABLE]).assert_eq(a_val[i], a_prev[i])
+    # shard / clk to send
+    b.when(is_real).assert_eq(l[SHARD_TO_SEND], l[IS_CHECK_MEMORY] * l[SHARD] + (1 - l[IS_CHECK_MEMORY]) * 0)
+    b.when(is_real).assert_eq(l[CLK_TO_SEND], l[IS_CHECK_MEMORY] * clk + (1 - l[IS_CHECK_MEMORY]) * 0)
+    vals = [l[SHARD_TO_SEND], l[CLK_TO_SEND], l[PC], l[NEXT_PC], l[NEXT_NEXT_PC], l[NUM_EXTRA_CYCLES], l[OPCODE]] + list(op_a_value) + \
+        list(b_val) + list(c_val) + list(hi_or_prev_a) + [l[OP_A_IMMUTABLE], l[IS_RW_A], l[IS_CHECK_MEMORY], l[IS_HALT], l[IS_SEQUENTIAL]]
+    r.sends.append(air.Lookup([air.to_virtual_pair(v) for v in vals], air.to_virtual_pair(is_real), air.KIND_INSTRUCTION))
+    # eval_shard_clk
+    b.when_transition().when(n[IS_REAL]).assert_eq(l[SHARD], n[SHARD])
+    r.send_byte(B_U16RANGE, l[SHARD], 0, 0, is_real)
+    b.when_first_row().assert_zero(clk)
+    next_clk = n[CLK_8] * (1 << 16) + n[CLK_16]
+    b.when_transition().when(n[IS_REAL]).assert_eq(clk + 5 + l[NUM_EXTRA_CYCLES], next_clk)
+    r.eval_range_check_24bits(clk, l[CLK_16], l[CLK_8], is_real)
+    # eval_pc
+    b.when(is_real).assert_eq(b.public_values(M.PV_EXECUTION_SHARD), l[SHARD])
+    b.when_first_row().assert_eq(b.public_values(M.PV_START_PC), l[PC])
+    b.when_first_row().when_not(l[IS_HALT]).assert_eq(l[PC] + 4, l[NEXT_PC])
+    b.when_transition().when(n[IS_REAL]).assert_eq(l[NEXT_PC], n[PC])
+    b.when_transition().when(n[IS_REAL]).when_not(n[IS_HALT]).assert_eq(l[NEXT_NEXT_PC], n[NEXT_PC])
+    b.when_transition().when(is_real).when(l[IS_SEQUENTIAL]).assert_eq(l[NEXT_NEXT_PC], l[NEXT_PC] + 4)
+    b.when_transition().when(is_real - n[IS_REAL]).assert_eq(b.public_values(M.PV_NEXT_PC), l[NEXT_PC])
+    b.when_last_row().when(is_real).assert_eq(b.public_values(M.PV_NEXT_PC), l[NEXT_PC])
+    # eval_is_real
+    b.assert_bool(is_real)
+    b.when_first_row().assert_one(is_real)
+    b.when_transition().when_not(is_real).assert_zero(n[IS_REAL])
+    b.when_transition().when(l[IS_HALT]).assert_zero(n[IS_REAL])
+    not_real = 1 - is_real
+    b.when(not_real).assert_zero(1 - l[IMM_B])
+    b.when(not_real).assert_zero(1 - l[IMM_C])
+    b.when(not_real).assert_zero(1 - l[IS_RW_A])
+
+
+def _program(r: _Rec):
+    """ProgramChip::eval (program/mod.rs:160-176): one receive of (pc, instruction) with the multiplicity column."""
+    p, l = r.prep, r.local
+    r.receives.append(air.Lookup([air.to_virtual_pair(v) for v in p[0:14]], air.to_virtual_pair(l[0]), air.KIND_PROGRAM))
 
 
 def _mov_cond(r: _Rec):
@@ -767,6 +844,39 @@ def record_divrem_chip(log_height: int) -> RecordedChip:
     return RecordedChip(name="DivRem", log_height=log_height, main_width=E.DIVREM_WIDTH, log_quotient_degree=lqd,
                         local_only=True, sends=r.sends, receives=r.receives, program=program,
                         lookups_blob=air.encode_lookups(r.sends, r.receives), num_constraints=int(program[2]))
+
+
+def record_cpu_constraints() -> _Rec:
+    from . import miniexec as M
+    r = _Rec(M.CPU_WIDTH)
+    _cpu(r)
+    return r
+
+
+def _finish(r: _Rec, name, log_height, width, local_only, prep_width=0, prep_index=-1) -> RecordedChip:
+    lqd = 1
+    r.b.perm_ext_width = air.local_permutation_trace_width(len(r.sends) + len(r.receives), 1 << lqd)
+    air.eval_permutation_constraints(r.b, r.sends, r.receives, 1 << lqd, False)
+    program = r.b.assemble()
+    return RecordedChip(name=name, log_height=log_height, main_width=width, prep_width=prep_width, prep_index=prep_index,
+                        log_quotient_degree=lqd, local_only=local_only, sends=r.sends, receives=r.receives, program=program,
+                        lookups_blob=air.encode_lookups(r.sends, r.receives), num_constraints=int(program[2]))
+
+
+def record_cpu_chip(log_height: int) -> RecordedChip:
+    """The Cpu chip (crates/core/machine/src/cpu/): CpuEvents + the program, 67 columns, constraints between consecutive
+    rows (not local_only). It is the *sender* of every instruction the other chips receive, of the program lookups and of
+    the register accesses."""
+    from . import miniexec as M
+    return _finish(record_cpu_constraints(), "Cpu", log_height, M.CPU_WIDTH, False)
+
+
+def record_program_chip(log_height: int, prep_index: int = 0) -> RecordedChip:
+    """The Program chip (crates/core/machine/src/program/mod.rs): preprocessed (pc, instruction) table, one multiplicity column."""
+    from . import miniexec as M
+    r = _Rec(M.PROGRAM_MULT_WIDTH, M.PROGRAM_PREP_WIDTH)
+    _program(r)
+    return _finish(r, "Program", log_height, M.PROGRAM_MULT_WIDTH, False, M.PROGRAM_PREP_WIDTH, prep_index)
 
 
 def record_branch_constraints() -> _Rec:

@@ -622,6 +622,168 @@ __global__ __launch_bounds__(THREADS) void alu_rows(const uint32_t* __restrict__
   }
 }
 
+// ---- Cpu chip (crates/core/machine/src/cpu/): CpuEventFfi records of 70 words (events/cpu.rs:46-106: clk, pc, next_pc,
+// next_next_pc, a, a_record[12], b, b_record[12], c, c_record[12], hi[2], hi_record[12], memory_record[12], exit_code; an
+// OptionMemoryRecordEnum is tag (Read 0, Write 1, None 2), a five-word read record, a six-word write record) and the
+// program as InstructionFfi records of 6 words (instruction.rs:22-33: opcode u8 | op_a u8, op_b, op_c, imm_b u8 | imm_c u8,
+// raw[2]). Columns cpu/columns/mod.rs:16-77; row cpu/trace.rs:117-257; padding rows :57-60.
+constexpr int CPU_EVENT_WORDS = 70, INSTRUCTION_WORDS = 6, CPU_WIDTH = 67, PROGRAM_PREP_WIDTH = 14;
+namespace cpucols {
+enum { SHARD = 0, CLK_16 = 1, CLK_8 = 2, SHARD_TO_SEND = 3, CLK_TO_SEND = 4, PC = 5, NEXT_PC = 6, NEXT_NEXT_PC = 7, INSTRUCTION = 8,
+       NUM_EXTRA_CYCLES = 21, IS_RW_A = 22, IS_CHECK_MEMORY = 23, IS_HALT = 24, IS_SEQUENTIAL = 25, OP_A_VALUE = 26, HI_OR_PREV_A = 30,
+       OP_A_ACCESS = 34, OP_B_ACCESS = 47, OP_C_ACCESS = 56, IS_REAL = 65, OP_A_IMMUTABLE = 66 };
+}
+// the opcode predicates of crates/core/executor/src/instruction.rs:70-310 (opcode numbers: opcode.rs:26-90)
+__device__ __forceinline__ bool op_is_branch(uint32_t o) { return o >= 21 && o <= 26; }
+__device__ __forceinline__ bool op_is_jump(uint32_t o) { return o >= 27 && o <= 29; }
+__device__ __forceinline__ bool op_is_memory(uint32_t o) { return o >= 31 && o <= 44; }
+__device__ __forceinline__ bool op_is_maddsub(uint32_t o) { return o >= 46 && o <= 49; }
+__device__ __forceinline__ void instruction_cols(const uint32_t* in, uint32_t* r) {   // opcode, op_a, op_b[4], op_c[4], op_a_0, imm_b, imm_c
+  r[0] = in[0] & 0xff;
+  r[1] = (in[0] >> 8) & 0xff;
+  word(r + 2, in[1]);
+  word(r + 6, in[2]);
+  r[10] = fbool(((in[0] >> 8) & 0xff) == 0);
+  r[11] = fbool((in[3] & 0xff) != 0);
+  r[12] = fbool(((in[3] >> 8) & 0xff) != 0);
+}
+// MemoryAccessCols (value, prev_shard, prev_clk, compare_clk, diff limbs) at `m`, from (value, shard, timestamp, prev_shard, prev_timestamp)
+__device__ __forceinline__ void memory_access_cols(uint32_t value, uint32_t shard, uint32_t ts, uint32_t prev_shard, uint32_t prev_ts, uint32_t* m) {
+  word(m, value);
+  m[4] = prev_shard;
+  m[5] = prev_ts;
+  const bool use_clk = prev_shard == shard;
+  m[6] = fbool(use_clk);
+  const uint32_t diff_minus_one = (use_clk ? ts : shard) - (use_clk ? prev_ts : prev_shard) - 1u;
+  m[7] = diff_minus_one & 0xffff;
+  m[8] = (diff_minus_one >> 16) & 0xff;
+}
+__device__ __forceinline__ void access_lookups(const uint32_t* m, const LookupSink& counts) {
+  lookup(counts, B_U16RANGE, m[7] >> 8, m[7]);
+  lookup(counts, B_U8RANGE, 0, m[8]);
+}
+// out: column-major, `height` rows; rows past n_events are the chip's padding rows. counts as in alu_rows.
+__global__ __launch_bounds__(THREADS) void cpu_rows(const uint32_t* __restrict__ events, size_t n_events, const uint32_t* __restrict__ program,
+                                                    size_t n_instr, uint32_t pc_base, uint32_t shard, size_t height,
+                                                    uint32_t* __restrict__ out, uint32_t* counts, int tiles, int* bad_pc) {
+  using namespace cpucols;
+  extern __shared__ uint32_t hash_lds[];
+  uint32_t* hkeys = hash_lds;
+  uint32_t* hvals = hash_lds + HASH_SLOTS;
+  const size_t row0 = (size_t)blockIdx.x * tiles * THREADS;
+  const bool count = counts != nullptr && row0 < n_events;
+  if (count) {
+    for (int i = threadIdx.x; i < HASH_SLOTS; i += blockDim.x) { hkeys[i] = HASH_EMPTY; hvals[i] = 0; }
+    __syncthreads();
+  }
+  const LookupSink sink{hkeys, hvals, HASH_SLOTS - 1, counts};
+  for (int t = 0; t < tiles; t++) {
+    const size_t row = row0 + (size_t)t * THREADS + threadIdx.x;
+    if (row >= height) break;
+    uint32_t r[CPU_WIDTH];
+#pragma unroll
+    for (int c = 0; c < CPU_WIDTH; c++) r[c] = 0;
+    if (row < n_events) {
+      const uint32_t* e = events + row * CPU_EVENT_WORDS;
+      const uint32_t clk = e[0], pc = e[1];
+      const size_t idx = (size_t)(pc - pc_base) >> 2;   // Program::fetch
+      const bool in_program = pc >= pc_base && idx < n_instr;
+      if (!in_program) *bad_pc = 1;
+      const uint32_t* in = program + (in_program ? idx : 0) * INSTRUCTION_WORDS;
+      const uint32_t o = in[0] & 0xff;
+      r[SHARD] = shard;
+      r[CLK_16] = clk & 0xffff;
+      r[CLK_8] = (clk >> 16) & 0xff;
+      r[PC] = pc;
+      r[NEXT_PC] = e[2];
+      r[NEXT_NEXT_PC] = e[3];
+      instruction_cols(in, r + INSTRUCTION);
+      const bool is_syscall = o == 30;
+      const bool check_memory = o == 3 || o == 4 || o == 5 || o == 6 || is_syscall || op_is_maddsub(o) || op_is_memory(o);
+      r[OP_A_IMMUTABLE] = fbool((o >= 39 && o <= 43) || op_is_branch(o) || o == 54);
+      r[IS_RW_A] = fbool(is_syscall || o == 45 || op_is_maddsub(o) || o == 50 || o == 51 || op_is_memory(o));
+      r[IS_CHECK_MEMORY] = fbool(check_memory);
+      const uint32_t* a_rec = e + 5;
+      const uint32_t* b_rec = e + 18;
+      const uint32_t* c_rec = e + 31;
+      word(r + OP_A_VALUE, e[4]);
+      if ((e[43] & 0xff) == 0) word(r + HI_OR_PREV_A, e[44]);   // hi: Some
+      word(r + OP_A_ACCESS + 4, e[4]);
+      word(r + OP_B_ACCESS, e[17]);
+      word(r + OP_C_ACCESS, e[30]);
+      r[SHARD_TO_SEND] = check_memory ? shard : 0u;
+      r[CLK_TO_SEND] = check_memory ? clk : 0u;
+      const uint32_t a_tag = a_rec[0] & 0xff, b_tag = b_rec[0] & 0xff, c_tag = c_rec[0] & 0xff;
+      if (a_tag == 1) {          // write: value, shard, timestamp, prev_value, prev_shard, prev_timestamp at words 6..11
+        word(r + OP_A_ACCESS, a_rec[9]);
+        memory_access_cols(a_rec[6], a_rec[7], a_rec[8], a_rec[10], a_rec[11], r + OP_A_ACCESS + 4);
+      } else if (a_tag == 0) {   // read: value, shard, timestamp, prev_shard, prev_timestamp at words 1..5
+        word(r + OP_A_ACCESS, a_rec[1]);
+        memory_access_cols(a_rec[1], a_rec[2], a_rec[3], a_rec[4], a_rec[5], r + OP_A_ACCESS + 4);
+      }
+      if (b_tag == 0) memory_access_cols(b_rec[1], b_rec[2], b_rec[3], b_rec[4], b_rec[5], r + OP_B_ACCESS);
+      if (c_tag == 0) memory_access_cols(c_rec[1], c_rec[2], c_rec[3], c_rec[4], c_rec[5], r + OP_C_ACCESS);
+      bool is_halt = false;
+      if (is_syscall) {   // HALT = 0, SYS_EXT_GROUP = 4246 in the low two bytes of the previous value of `a`
+        const uint32_t id0 = r[OP_A_ACCESS], id1 = r[OP_A_ACCESS + 1];
+        is_halt = (id0 == 0 && id1 == 0) || (id0 == (4246 & 0xff) && id1 == (4246 >> 8));
+        r[IS_HALT] = fbool(is_halt);
+        r[NUM_EXTRA_CYCLES] = r[OP_A_ACCESS + 3];
+      }
+      r[IS_SEQUENTIAL] = fbool(!is_halt && !op_is_branch(o) && !op_is_jump(o));
+      r[IS_REAL] = 1;
+      if (count) {   // cpu/trace.rs:203-221,240-255 and the three accesses
+        lookup(sink, B_U16RANGE, (shard >> 8) & 0xff, shard);
+        lookup(sink, B_U16RANGE, r[CLK_16] >> 8, r[CLK_16]);
+        lookup(sink, B_U8RANGE, 0, r[CLK_8]);
+        if (a_tag != 2) access_lookups(r + OP_A_ACCESS + 4, sink);
+        if (b_tag == 0) access_lookups(r + OP_B_ACCESS, sink);
+        if (c_tag == 0) access_lookups(r + OP_C_ACCESS, sink);
+        lookup(sink, B_U8RANGE, r[OP_A_ACCESS + 4], r[OP_A_ACCESS + 5]);
+        lookup(sink, B_U8RANGE, r[OP_A_ACCESS + 6], r[OP_A_ACCESS + 7]);
+      }
+    } else {
+      r[INSTRUCTION + 11] = 1;   // imm_b
+      r[INSTRUCTION + 12] = 1;   // imm_c
+      r[IS_RW_A] = 1;
+    }
+#pragma unroll
+    for (int c = 0; c < CPU_WIDTH; c++) out[(size_t)c * height + row] = kb::to_monty(r[c]);
+  }
+  if (count) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < HASH_SLOTS; i += blockDim.x)
+      if (hkeys[i] != HASH_EMPTY) atomicAdd(counts + hkeys[i], hvals[i]);
+  }
+}
+
+// ProgramChip::generate_preprocessed_trace (program/mod.rs:62-101): row i = (pc_base + 4 i, instruction columns), zero padding
+__global__ void program_rows(const uint32_t* __restrict__ program, size_t n_instr, uint32_t pc_base, size_t height, uint32_t* __restrict__ out) {
+  const size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= height) return;
+  uint32_t r[PROGRAM_PREP_WIDTH];
+#pragma unroll
+  for (int c = 0; c < PROGRAM_PREP_WIDTH; c++) r[c] = 0;
+  if (row < n_instr) {
+    r[0] = pc_base + 4u * (uint32_t)row;
+    instruction_cols(program + row * INSTRUCTION_WORDS, r + 1);
+  }
+#pragma unroll
+  for (int c = 0; c < PROGRAM_PREP_WIDTH; c++) out[(size_t)c * height + row] = kb::to_monty(r[c]);
+}
+// ProgramChip::generate_trace (program/mod.rs:113-146): how often each pc was fetched; out starts as plain zero counters
+__global__ void program_count(const uint32_t* __restrict__ events, size_t n_events, size_t n_instr, uint32_t pc_base, uint32_t* out) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_events) return;
+  const uint32_t pc = events[i * CPU_EVENT_WORDS + 1];
+  const size_t idx = (size_t)(pc - pc_base) >> 2;
+  if (pc >= pc_base && idx < n_instr) atomicAdd(out + idx, 1u);
+}
+__global__ void counts_to_field(uint32_t* out, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = kb::to_monty(out[i]);
+}
+
 // ByteChip::generate_trace: out = to_field(counts + extra); extra (may be null) holds the row-major plain counts of the
 // chips whose dependencies stay on the host
 __global__ void byte_mults_finish(const uint32_t* __restrict__ counts, const uint32_t* __restrict__ extra_row_major,

@@ -1105,6 +1105,7 @@ int zkm_ctx_create(int device, zkm_ctx** out) {
   HIP_CHECK(hipFuncSetAttribute((const void*)tracegen::alu_rows<tracegen::MOV_COND>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
   HIP_CHECK(hipFuncSetAttribute((const void*)tracegen::alu_rows<tracegen::MUL>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
   HIP_CHECK(hipFuncSetAttribute((const void*)tracegen::alu_rows<tracegen::DIVREM>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+  HIP_CHECK(hipFuncSetAttribute((const void*)tracegen::cpu_rows, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
   HIP_CHECK(hipFuncSetAttribute((const void*)tracegen::alu_rows<tracegen::BRANCH>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
   HIP_CHECK(hipFuncSetAttribute((const void*)lde::lde_cols<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIP_CHECK(hipFuncSetAttribute((const void*)lde::lde_cols<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -1638,6 +1639,133 @@ int zkm_tracegen_divrem(zkm_ctx* ctx, const zkm_comp_alu_event* events, size_t n
 size_t zkm_tracegen_mov_cond_width(void) { return (size_t)tracegen::chip_width(tracegen::MOV_COND); }
 int zkm_tracegen_mov_cond(zkm_ctx* ctx, const zkm_mov_cond_event* events, size_t n_events, int fixed_log2_rows, zkm_matrix** out) {
   return tracegen_events(ctx, tracegen::MOV_COND, events, n_events, fixed_log2_rows, nullptr, out);
+}
+
+static size_t padded_trace_rows(size_t n_records, int fixed_log2_rows, const char* what) {
+  // utils::next_power_of_two (crates/core/machine/src/utils/mod.rs): the shape's fixed size, else >= 16
+  size_t height = 16;
+  if (fixed_log2_rows >= 0) {
+    if (fixed_log2_rows > 30) throw std::runtime_error(std::string(what) + ": fixed log2 rows out of range");
+    height = (size_t)1 << fixed_log2_rows;
+    if (n_records > height) throw std::runtime_error(std::string(what) + ": fixed log2 rows is too small");
+  } else {
+    while (height < n_records) height <<= 1;
+  }
+  return height;
+}
+
+size_t zkm_tracegen_cpu_width(void) { return (size_t)tracegen::CPU_WIDTH; }
+int zkm_tracegen_cpu(zkm_ctx* ctx, const zkm_cpu_event* events, size_t n_events, const zkm_instruction* program, size_t n_instr,
+                     uint32_t pc_base, uint32_t shard, int fixed_log2_rows, zkm_byte_lookups* blu, zkm_matrix** out) {
+  API_BEGIN
+  static_assert(sizeof(zkm_cpu_event) == 4 * tracegen::CPU_EVENT_WORDS && sizeof(zkm_instruction) == 4 * tracegen::INSTRUCTION_WORDS,
+                "event records mirror the #[repr(C)] executor structs");
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIP_CHECK(hipSetDevice(ctx->device));
+  if (n_events && (!events || !program || !n_instr)) throw std::runtime_error("zkm_tracegen_cpu: null events or program");
+  const size_t height = padded_trace_rows(n_events, fixed_log2_rows, "zkm_tracegen_cpu");
+  ctx->begin_timing();
+  zkm_matrix* m = new zkm_matrix();
+  m->h = height; m->w = tracegen::CPU_WIDTH;
+  uint32_t *d_events = nullptr, *d_program = nullptr;
+  int* d_bad = nullptr;
+  try {
+    m->d = ctx->alloc_n<uint32_t>(height * m->w);
+    d_events = (uint32_t*)ctx->alloc(std::max<size_t>(n_events * sizeof(zkm_cpu_event), 4));
+    d_program = (uint32_t*)ctx->alloc(std::max<size_t>(n_instr * sizeof(zkm_instruction), 4));
+    d_bad = (int*)ctx->alloc(4);
+    HIP_CHECK(hipMemsetAsync(d_bad, 0, 4, ctx->stream));
+    if (n_events) HIP_CHECK(hipMemcpyAsync(d_events, events, n_events * sizeof(zkm_cpu_event), hipMemcpyHostToDevice, ctx->stream));
+    if (n_instr) HIP_CHECK(hipMemcpyAsync(d_program, program, n_instr * sizeof(zkm_instruction), hipMemcpyHostToDevice, ctx->stream));
+    uint32_t* counts = blu ? blu->counts : nullptr;
+    const int tiles = counts ? tracegen::TILES_PER_BLOCK : 1;
+    KLAUNCH(ctx, "tracegen_cpu", 280.0 * n_events + 4.0 * height * tracegen::CPU_WIDTH, tracegen::cpu_rows,
+            dim3(div_up(height, (size_t)tiles * tracegen::THREADS)), dim3(tracegen::THREADS),
+            counts ? 2 * tracegen::HASH_SLOTS * sizeof(uint32_t) : 0, (const uint32_t*)d_events, n_events, (const uint32_t*)d_program, n_instr,
+            pc_base, shard, height, m->d, counts, tiles, d_bad);
+    int bad = 0;
+    HIP_CHECK(hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, ctx->stream));
+    ctx->mark("trace generation");
+    ctx->end_timing(false);
+    if (bad) throw std::runtime_error("zkm_tracegen_cpu: an event's pc lies outside the program");
+  } catch (...) {
+    if (d_events) ctx->release(d_events);
+    if (d_program) ctx->release(d_program);
+    if (d_bad) ctx->release(d_bad);
+    if (m->d) ctx->release(m->d);
+    delete m;
+    throw;
+  }
+  ctx->release(d_events);
+  ctx->release(d_program);
+  ctx->release(d_bad);
+  *out = m;
+  API_END
+}
+
+int zkm_tracegen_program(zkm_ctx* ctx, const zkm_instruction* program, size_t n_instr, uint32_t pc_base, int fixed_log2_rows,
+                         zkm_matrix** out) {
+  API_BEGIN
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIP_CHECK(hipSetDevice(ctx->device));
+  if (n_instr && !program) throw std::runtime_error("zkm_tracegen_program: null program");
+  const size_t height = padded_trace_rows(n_instr, fixed_log2_rows, "zkm_tracegen_program");
+  ctx->begin_call();
+  zkm_matrix* m = new zkm_matrix();
+  m->h = height; m->w = tracegen::PROGRAM_PREP_WIDTH;
+  uint32_t* d_program = nullptr;
+  try {
+    m->d = ctx->alloc_n<uint32_t>(height * m->w);
+    d_program = (uint32_t*)ctx->alloc(std::max<size_t>(n_instr * sizeof(zkm_instruction), 4));
+    if (n_instr) HIP_CHECK(hipMemcpyAsync(d_program, program, n_instr * sizeof(zkm_instruction), hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(tracegen::program_rows, dim3(div_up(height, 256)), dim3(256), 0, ctx->stream, (const uint32_t*)d_program, n_instr,
+                       pc_base, height, m->d);
+    LAUNCH_CHECK();
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  } catch (...) {
+    if (d_program) ctx->release(d_program);
+    if (m->d) ctx->release(m->d);
+    delete m;
+    throw;
+  }
+  ctx->release(d_program);
+  *out = m;
+  API_END
+}
+
+int zkm_tracegen_program_mults(zkm_ctx* ctx, const zkm_cpu_event* events, size_t n_events, size_t n_instr, uint32_t pc_base,
+                               int fixed_log2_rows, zkm_matrix** out) {
+  API_BEGIN
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIP_CHECK(hipSetDevice(ctx->device));
+  if (n_events && !events) throw std::runtime_error("zkm_tracegen_program_mults: null events");
+  const size_t height = padded_trace_rows(n_instr, fixed_log2_rows, "zkm_tracegen_program_mults");
+  ctx->begin_call();
+  zkm_matrix* m = new zkm_matrix();
+  m->h = height; m->w = 1;
+  uint32_t* d_events = nullptr;
+  try {
+    m->d = ctx->alloc_n<uint32_t>(height);
+    HIP_CHECK(hipMemsetAsync(m->d, 0, height * 4, ctx->stream));
+    d_events = (uint32_t*)ctx->alloc(std::max<size_t>(n_events * sizeof(zkm_cpu_event), 4));
+    if (n_events) {
+      HIP_CHECK(hipMemcpyAsync(d_events, events, n_events * sizeof(zkm_cpu_event), hipMemcpyHostToDevice, ctx->stream));
+      hipLaunchKernelGGL(tracegen::program_count, dim3(div_up(n_events, 256)), dim3(256), 0, ctx->stream, (const uint32_t*)d_events, n_events,
+                         n_instr, pc_base, m->d);
+      LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(tracegen::counts_to_field, dim3(div_up(height, 256)), dim3(256), 0, ctx->stream, m->d, height);
+    LAUNCH_CHECK();
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  } catch (...) {
+    if (d_events) ctx->release(d_events);
+    if (m->d) ctx->release(m->d);
+    delete m;
+    throw;
+  }
+  ctx->release(d_events);
+  *out = m;
+  API_END
 }
 
 int zkm_tracegen_byte_table(zkm_ctx* ctx, zkm_matrix** out) {

@@ -149,6 +149,42 @@ class Context:
         L = lib.load()
         return DeviceMatrix(self, h, int(L.zkm_matrix_height(h)), int(L.zkm_matrix_width(h)))
 
+    def _born(self, h) -> DeviceMatrix:
+        L = lib.load()
+        return DeviceMatrix(self, h, int(L.zkm_matrix_height(h)), int(L.zkm_matrix_width(h)))
+
+    def tracegen_cpu(self, events: np.ndarray, program: np.ndarray, pc_base: int, shard: int, fixed_log2_rows: int = -1,
+                     blu: "ByteLookups" = None) -> DeviceMatrix:
+        """`generate_trace` + `generate_dependencies` of the Cpu chip on the device (zkm_tracegen_cpu); dtypes
+        miniexec.CPU_EVENT (CpuEventFfi) and miniexec.INSTRUCTION (InstructionFfi)."""
+        from . import miniexec as _m
+        ev = np.ascontiguousarray(events, dtype=_m.CPU_EVENT)
+        prog = np.ascontiguousarray(program, dtype=_m.INSTRUCTION)
+        h = C.c_void_p()
+        lib.check(lib.load().zkm_tracegen_cpu(self.h, C.c_void_p(ev.ctypes.data if len(ev) else None), C.c_size_t(len(ev)),
+                                              C.c_void_p(prog.ctypes.data if len(prog) else None), C.c_size_t(len(prog)),
+                                              C.c_uint32(pc_base), C.c_uint32(shard), C.c_int(fixed_log2_rows),
+                                              blu.h if blu is not None else None, C.byref(h)))
+        return self._born(h)
+
+    def tracegen_program(self, program: np.ndarray, pc_base: int, fixed_log2_rows: int = -1) -> DeviceMatrix:
+        """The Program chip's preprocessed table on the device (zkm_tracegen_program)."""
+        from . import miniexec as _m
+        prog = np.ascontiguousarray(program, dtype=_m.INSTRUCTION)
+        h = C.c_void_p()
+        lib.check(lib.load().zkm_tracegen_program(self.h, C.c_void_p(prog.ctypes.data if len(prog) else None), C.c_size_t(len(prog)),
+                                                  C.c_uint32(pc_base), C.c_int(fixed_log2_rows), C.byref(h)))
+        return self._born(h)
+
+    def tracegen_program_mults(self, events: np.ndarray, n_instr: int, pc_base: int, fixed_log2_rows: int = -1) -> DeviceMatrix:
+        """The Program chip's multiplicity trace on the device (zkm_tracegen_program_mults)."""
+        from . import miniexec as _m
+        ev = np.ascontiguousarray(events, dtype=_m.CPU_EVENT)
+        h = C.c_void_p()
+        lib.check(lib.load().zkm_tracegen_program_mults(self.h, C.c_void_p(ev.ctypes.data if len(ev) else None), C.c_size_t(len(ev)),
+                                                        C.c_size_t(n_instr), C.c_uint32(pc_base), C.c_int(fixed_log2_rows), C.byref(h)))
+        return self._born(h)
+
     def tracegen_mov_cond(self, events: np.ndarray, fixed_log2_rows: int = -1) -> DeviceMatrix:
         """`generate_trace` of the MovCond chip on the device (zkm_tracegen_mov_cond); dtype events.MOV_COND_EVENT."""
         from . import events as _ev
