@@ -1,0 +1,119 @@
+#!/usr/bin/env python3
+"""A coherent core shard end to end on the device: a program executed by ziren_amd/miniexec.py (the reference's executor is
+Rust and cannot run here) -> CpuEvents + per-chip events in pinned host memory -> device trace generation for Cpu, Program,
+the eleven instruction chips and Byte -> commit + open with the recorded AIRs (generated quotient kernels).
+
+  python tools/bench_core_shard.py [--log-cycles 18] [--steps 3]
+
+The register accesses (kind Memory) have no counterpart chip here, so the proof's cumulative sum is not zero — this tool
+measures; tests/test_cpu_shard.py verifies (with the accesses mirrored)."""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+import numpy as np
+
+from ziren_amd import abi, chips, events as E, field as F, lib, miniexec as M, prover, synth
+
+PC_BASE, SHARD = 0x1000, 1
+
+
+def log2_rows(n):
+    h = 16
+    while h < n:
+        h <<= 1
+    return h.bit_length() - 1
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--log-cycles", type=int, default=18)
+    ap.add_argument("--steps", type=int, default=3)
+    args = ap.parse_args()
+    n = 1 << args.log_cycles
+    t0 = time.perf_counter()
+    prog, rec0, pv = M.run(n, seed=1, shard=SHARD, pc_base=PC_BASE)
+    rec = M.add_dependencies(rec0)
+    exec_s = time.perf_counter() - t0
+    ctx = prover.Context(0)
+
+    def pin(ev):   # the executor's event vectors, in page-locked host memory
+        pinned = ctx.host_alloc((max(len(ev), 1) * (ev.dtype.itemsize // 4),))
+        pinned[:len(ev) * (ev.dtype.itemsize // 4)] = ev.view(np.uint32).reshape(-1)
+        return pinned[:len(ev) * (ev.dtype.itemsize // 4)].view(ev.dtype)
+
+    work = [("cpu", pin(rec.cpu), chips.record_cpu_chip)]
+    work += [(c, pin(rec.alu[c]), None) for c in sorted(E.CHIP_NAMES)]
+    work += [("jump", pin(rec.jump), chips.record_jump_chip), ("mov_cond", pin(rec.mov_cond), chips.record_mov_cond_chip),
+             ("branch", pin(rec.branch), chips.record_branch_chip), ("mul", pin(rec.mul), chips.record_mul_chip),
+             ("divrem", pin(rec.divrem), chips.record_divrem_chip)]
+    heights = [log2_rows(len(ev)) for _, ev, _ in work]
+    recs = [chips.record_chip(c, lh) if rc is None else rc(lh) for (c, _, rc), lh in zip(work, heights)]
+    plh = log2_rows(len(prog))
+    recs += [chips.record_byte_chip(0), chips.record_program_chip(plh, 1)]
+    pprog = pin(prog)
+    fri = abi.FriConfig(1, 84, 16)
+    hp = prover.HipProver(recs, fri, synth.NUM_PV_ELTS, ctx=ctx, specialize=True)
+    pvs = M.public_values(pv)
+    pk = hp.setup([ctx.tracegen_byte_table(), ctx.tracegen_program(pprog, PC_BASE, plh)], [0, 0], F.to_monty(PC_BASE),
+                  F.to_monty(np.zeros(14, dtype=np.uint64)))
+    ch0 = prover.new_challenger()
+    pk.observe_into(ch0)
+    lib.load().zkm_ctx_set_kernel_timing(ctx.h, C.c_int(1))
+    out = np.zeros(1 << 22, dtype=np.uint32)
+    res = []
+    for it in range(args.steps + 1):
+        t0 = time.perf_counter()
+        blu = ctx.byte_lookups()
+        born = []
+        tg_kernel = 0.0
+        for (c, ev, _), lh in zip(work, heights):
+            if c == "cpu":
+                born.append(ctx.tracegen_cpu(ev, pprog, PC_BASE, SHARD, lh, blu))
+            elif c == "jump":
+                born.append(ctx.tracegen_jump(ev, lh))
+            elif c == "mov_cond":
+                born.append(ctx.tracegen_mov_cond(ev, lh))
+            elif c == "branch":
+                born.append(ctx.tracegen_branch(ev, lh, blu))
+            elif c == "mul":
+                born.append(ctx.tracegen_mul(ev, lh, blu))
+            elif c == "divrem":
+                born.append(ctx.tracegen_divrem(ev, lh, blu))
+            else:
+                born.append(ctx.tracegen_alu(c, ev, lh, blu))
+            tg_kernel += sum(ms for name, ms, _, _ in ctx.kernel_timings() if name.startswith("tracegen"))
+        born.append(ctx.tracegen_byte_mults(blu))
+        born.append(ctx.tracegen_program_mults(work[0][1], len(prog), PC_BASE, plh))
+        blu.free()
+        t1 = time.perf_counter()
+        proof = hp.prove_shard(pk, pvs, born, ch0.copy(), out=out)
+        t2 = time.perf_counter()
+        phases = dict(ctx.last_timings())
+        kern = {nm: (round(ms, 3), calls) for nm, ms, calls, _ in ctx.kernel_timings()}
+        for m in born:
+            m.free()
+        if it:
+            res.append({"tracegen_ms": (t1 - t0) * 1e3, "tracegen_kernel_ms": tg_kernel, "prove_ms": (t2 - t1) * 1e3, "phases": phases, "kernels": kern})
+    r = res[-1]
+    cells = sum((1 << c.log_height) * (c.main_width + 4 * c.perm_ext_width + 8) for c in recs)
+    event_bytes = sum(len(ev) * ev.dtype.itemsize for _, ev, _ in work)
+    print(json.dumps({"workload": f"CORE-{args.log_cycles}: 2^{args.log_cycles} executed instructions (Cpu rows) of a generated program; Cpu, Program, "
+                                  "AddSub, Bitwise, Lt, ShiftLeft, ShiftRight, CloClz, Mul, DivRem, Branch, Jump, MovCond, Byte",
+                      "executor_seconds_python": round(exec_s, 1), "program_instructions": int(len(prog)), "event_bytes": int(event_bytes),
+                      "tracegen_ms": round(float(np.mean([x["tracegen_ms"] for x in res])), 3),
+                      "tracegen_kernel_ms": round(float(np.mean([x["tracegen_kernel_ms"] for x in res])), 3),
+                      "prove_ms": round(float(np.mean([x["prove_ms"] for x in res])), 3),
+                      "committed_cells": cells, "proof_words": int(len(proof)),
+                      "chips": {c.name: {"rows": 1 << c.log_height, "main": c.main_width, "perm_ext": c.perm_ext_width,
+                                         "constraints": c.num_constraints, "lookups": len(c.sends) + len(c.receives)} for c in recs},
+                      "phases_ms": {nm: round(v, 3) for nm, v in r["phases"].items()}, "kernels_ms": r["kernels"]}, indent=1))
+
+
+if __name__ == "__main__":
+    main()
