@@ -347,6 +347,13 @@ int zkm_tracegen_program(zkm_ctx* ctx, const zkm_instruction* program, size_t n_
                          zkm_matrix** out);
 int zkm_tracegen_program_mults(zkm_ctx* ctx, const zkm_cpu_event* events, size_t n_events, size_t n_instr, uint32_t pc_base,
                                int fixed_log2_rows, zkm_matrix** out);
+/* The MemoryLocal chip (crates/core/machine/src/memory/local.rs): replaces generate_trace (:147-190). Events are the
+ * #[repr(C)] MemoryLocalEvents of crates/core/executor/src/events/memory.rs:226-237 (ExecutionRecord::get_local_mem_events),
+ * four per row, 56 columns, zero padding. */
+typedef struct zkm_memory_record { uint32_t shard, timestamp, value; } zkm_memory_record;
+typedef struct zkm_memory_local_event { uint32_t addr; zkm_memory_record initial_mem_access, final_mem_access; } zkm_memory_local_event;
+int zkm_tracegen_memory_local(zkm_ctx* ctx, const zkm_memory_local_event* events, size_t n_events, int fixed_log2_rows,
+                              zkm_matrix** out);
 /* The MovCond chip (crates/core/machine/src/misc/mov_cond/mod.rs: MEQ, MNE, WSBH): MovCondEvents, byte-for-byte the
  * #[repr(C)] struct of crates/core/executor/src/events/instr.rs:286-302. 32 columns, zero padding rows, no byte lookups. */
 typedef struct zkm_mov_cond_event {

@@ -479,4 +479,17 @@ int orc_tracegen_program(int which, const void* events, size_t n_events, const v
   ORC_CATCH
 }
 
+// MemoryLocal chip: MemoryLocalEvent records (28 bytes), four per row, 56 columns
+int orc_tracegen_memory_local(const void* events, size_t n_events, int fixed_log2_rows, uint32_t* out, size_t out_cap, size_t* rows) {
+  ORC_TRY
+  size_t h;
+  std::vector<F> t = tracegen::generate_memory_local((const tracegen::MemoryLocalEvent*)events, n_events, fixed_log2_rows, &h);
+  *rows = h;
+  if (out) {
+    if (t.size() > out_cap) throw std::runtime_error("trace buffer too small");
+    for (size_t i = 0; i < t.size(); i++) out[i] = to_monty(t[i]);
+  }
+  ORC_CATCH
+}
+
 }  // extern "C"

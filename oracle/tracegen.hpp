@@ -845,4 +845,24 @@ static inline std::vector<F> generate_program_mult(const CpuEvent* events, size_
   return t;
 }
 
+// ---- MemoryLocal chip (memory/local.rs): MemoryLocalEvents (events/memory.rs:226-237), four per row; columns per entry
+// :30-50 (addr, initial_shard, final_shard, initial_clk, final_clk, initial_value[4], final_value[4], is_real), rows :147-190
+struct MemoryRecordC { uint32_t shard, timestamp, value; };
+struct MemoryLocalEvent { uint32_t addr; MemoryRecordC initial, final_; };
+static_assert(sizeof(MemoryLocalEvent) == 28, "MemoryLocalEvent is seven words");
+static const size_t MEMORY_LOCAL_ENTRIES = 4, MEMORY_LOCAL_ENTRY_COLS = 14, MEMORY_LOCAL_WIDTH = 56;
+static inline std::vector<F> generate_memory_local(const MemoryLocalEvent* events, size_t n_events, int fixed_log2_rows, size_t* height) {
+  const size_t h = padded_rows((n_events + MEMORY_LOCAL_ENTRIES - 1) / MEMORY_LOCAL_ENTRIES, fixed_log2_rows);
+  std::vector<F> t(h * MEMORY_LOCAL_WIDTH, 0);
+  for (size_t i = 0; i < n_events; i++) {
+    F* r = t.data() + i * MEMORY_LOCAL_ENTRY_COLS;   // entry k of row i / 4 is at (i / 4) * 56 + (i % 4) * 14 = i * 14
+    const MemoryLocalEvent& e = events[i];
+    r[0] = fu32(e.addr); r[1] = fu32(e.initial.shard); r[2] = fu32(e.final_.shard); r[3] = fu32(e.initial.timestamp); r[4] = fu32(e.final_.timestamp);
+    word(r + 5, e.initial.value); word(r + 9, e.final_.value);
+    r[13] = 1;
+  }
+  *height = h;
+  return t;
+}
+
 }  // namespace tracegen

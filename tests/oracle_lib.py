@@ -316,3 +316,15 @@ def tracegen_program(which, events, program, pc_base, fixed_log2_rows=-1):
                                       C.c_size_t(len(prog)), C.c_uint32(pc_base), C.c_int(fixed_log2_rows), abi.as_u32p(out),
                                       C.c_size_t(out.size)))
     return out
+
+
+def tracegen_memory_local(events, fixed_log2_rows=-1):
+    """MemoryLocal chip rows from MemoryLocalEvents (miniexec.MEMORY_LOCAL_EVENT), four per row."""
+    from ziren_amd import miniexec as M
+    ev = np.ascontiguousarray(events, dtype=M.MEMORY_LOCAL_EVENT)
+    rows = C.c_size_t()
+    _check(lib().orc_tracegen_memory_local(C.c_void_p(ev.ctypes.data), C.c_size_t(len(ev)), C.c_int(fixed_log2_rows), None, C.c_size_t(0), C.byref(rows)))
+    out = np.zeros((rows.value, M.MEMORY_LOCAL_WIDTH), dtype=np.uint32)
+    _check(lib().orc_tracegen_memory_local(C.c_void_p(ev.ctypes.data), C.c_size_t(len(ev)), C.c_int(fixed_log2_rows), abi.as_u32p(out),
+                                           C.c_size_t(out.size), C.byref(rows)))
+    return out

@@ -1,7 +1,7 @@
 """A coherent core shard: a program executed by ziren_amd/miniexec.py, its CpuEvents through the Cpu
 chip, the per-chip events through the ALU / Mul / DivRem / Branch / Jump / MovCond chips, the Program and Byte tables —
-every instruction, program and byte lookup is exchanged between real chips; only the register accesses (kind Memory),
-whose counterpart chips (MemoryLocal / MemoryGlobal) are not built, are mirrored."""
+every instruction, program, byte and memory lookup is exchanged between real chips (the MemoryLocal chip closes the
+register accesses); only what MemoryLocal forwards to the Global chip (kind Global), which is not built, is mirrored."""
 import numpy as np
 import pytest
 
@@ -52,6 +52,11 @@ def cpu_shard(oracle, n_cycles, seed=1):
         rc.trace = gen(ev, lh, extra)
         recs.append(rc)
         work.append((name, ev, lh))
+    lh = log2_rows(-(-len(rec.memory_local) // M.MEMORY_LOCAL_ENTRIES_PER_ROW))
+    ml = chips.record_memory_local_chip(lh)
+    ml.trace = oracle.tracegen_memory_local(rec.memory_local, lh)
+    recs.append(ml)
+    work.append(("memory_local", rec.memory_local, lh))
     byte = chips.record_byte_chip(prep_index=0)
     byte.trace = oracle.tracegen_byte_mults([(c, ev) for c, ev, _ in work if not isinstance(c, str)], extra)
     byte.prep_trace = oracle.tracegen_byte_table()
@@ -60,6 +65,11 @@ def cpu_shard(oracle, n_cycles, seed=1):
     program.trace = oracle.tracegen_program(1, rec.cpu, prog, PC_BASE, plh)
     program.prep_trace = oracle.tracegen_program(0, rec.cpu, prog, PC_BASE, plh)
     return recs, work, byte, program, prog, pv
+
+
+def global_mirrors(recs):
+    """Stand-in for the Global chip (crates/core/machine/src/global/, not built): receives what MemoryLocal sends to it."""
+    return [mirror_chip(r, kinds=(air.KIND_GLOBAL,)) for r in recs if any(lk.kind == air.KIND_GLOBAL for lk in r.sends)]
 
 
 def test_miniexec_record_is_coherent():
@@ -108,21 +118,25 @@ def test_cpu_constraints_hold(oracle):
 
 def test_shard_lookups_balance(oracle):
     """Cpu sends every instruction the eleven chips receive, the Program table receives every fetch, the Byte table
-    every byte lookup; only the register accesses are left for the memory chips."""
+    every byte lookup, MemoryLocal opens and closes every register's access chain; only its messages to the Global chip
+    (two per touched address) are left."""
     recs, work, byte, program, prog, pv = cpu_shard(oracle, 1200, seed=9)
     left = {k: v for k, v in lookup_tally(recs + [byte, program]).items() if v}
-    assert left and {k[0] for k in left} == {air.KIND_MEMORY}
-    mirrors = [mirror_chip(r, kinds=(air.KIND_MEMORY,)) for r in recs if any(lk.kind == air.KIND_MEMORY for lk in r.sends)]
-    assert [m.name for m in mirrors] == ["CpuMirror", "MulMirror", "DivRemMirror"]
+    n_addr = len(work[-1][1])
+    assert {k[0] for k in left} == {air.KIND_GLOBAL} and len(left) == 2 * n_addr and 30 <= n_addr <= 34
+    without = {k: v for k, v in lookup_tally(recs[:-1] + [byte, program]).items() if v}
+    assert {k[0] for k in without} == {air.KIND_MEMORY}          # without MemoryLocal the access chains stay open
+    mirrors = global_mirrors(recs)
+    assert [m.name for m in mirrors] == ["MemoryLocalMirror"]
     assert not any(lookup_tally(recs + [byte, program] + mirrors).values())
 
 
 def test_oracle_proves_coherent_shard(oracle):
-    """The restated verifier accepts the oracle's proof of the whole shard (cumulative sum zero with only the register
-    accesses mirrored) and rejects one made for a different next_pc (the Cpu chip's boundary constraint)."""
+    """The restated verifier accepts the oracle's proof of the whole shard (cumulative sum zero with only the Global
+    chip's side mirrored) and rejects one made for a different next_pc (the Cpu chip's boundary constraint)."""
     from ziren_amd import synth
     recs, work, byte, program, prog, pv = cpu_shard(oracle, 500, seed=7)
-    mirrors = [mirror_chip(r, kinds=(air.KIND_MEMORY,)) for r in recs if any(lk.kind == air.KIND_MEMORY for lk in r.sends)]
+    mirrors = global_mirrors(recs)
     all_chips = recs + [byte, program] + mirrors
     fri = abi.FriConfig(1, 84, 16)
     igcs = F.to_monty(np.zeros(14, dtype=np.uint64))
@@ -139,6 +153,8 @@ def test_oracle_proves_coherent_shard(oracle):
 def device_trace(ctx, chip, ev, lh, blu, prog):
     if chip == "cpu":
         return ctx.tracegen_cpu(ev, prog, PC_BASE, SHARD, lh, blu)
+    if chip == "memory_local":
+        return ctx.tracegen_memory_local(ev, lh)
     if chip == "jump":
         return ctx.tracegen_jump(ev, lh)
     if chip == "mov_cond":
@@ -170,6 +186,10 @@ def test_gpu_cpu_and_program_tracegen_match_oracle(hip_ctx, oracle):
             want = oracle.tracegen_program(which, rec.cpu, prog, PC_BASE)
             assert (born.height, born.width) == want.shape and np.array_equal(born.to_host(), want), (n, which)
             born.free()
+        want = oracle.tracegen_memory_local(rec.memory_local)
+        born = hip_ctx.tracegen_memory_local(rec.memory_local)
+        assert (born.height, born.width) == want.shape and np.array_equal(born.to_host(), want), n
+        born.free()
     prog, rec, pv = M.run(50, seed=1)
     with pytest.raises(lib.ZkmError, match="outside the program"):
         hip_ctx.tracegen_cpu(rec.cpu, prog[:10], PC_BASE, SHARD)
@@ -183,7 +203,7 @@ def test_gpu_coherent_shard_proof(hip_ctx, oracle, n_cycles):
     public values (start_pc, next_pc, execution_shard) are checked by its constraints."""
     from ziren_amd import prover, synth
     recs, work, byte, program, prog, pv = cpu_shard(oracle, n_cycles, seed=n_cycles)
-    mirrors = [mirror_chip(r, kinds=(air.KIND_MEMORY,)) for r in recs if any(lk.kind == air.KIND_MEMORY for lk in r.sends)]
+    mirrors = global_mirrors(recs)
     all_chips = recs + [byte, program] + mirrors
     fri = abi.FriConfig(1, 84, 16)
     pvs = M.public_values(pv)

@@ -5,8 +5,8 @@ the eleven instruction chips and Byte -> commit + open with the recorded AIRs (g
 
   python tools/bench_core_shard.py [--log-cycles 18] [--steps 3]
 
-The register accesses (kind Memory) have no counterpart chip here, so the proof's cumulative sum is not zero — this tool
-measures; tests/test_cpu_shard.py verifies (with the accesses mirrored)."""
+MemoryLocal's messages to the Global chip (not built) have no receiver here, so the proof's cumulative sum is not zero — this
+tool measures; tests/test_cpu_shard.py verifies (with that side mirrored)."""
 import argparse
 import ctypes as C
 import json
@@ -51,8 +51,8 @@ def main():
     work += [(c, pin(rec.alu[c]), None) for c in sorted(E.CHIP_NAMES)]
     work += [("jump", pin(rec.jump), chips.record_jump_chip), ("mov_cond", pin(rec.mov_cond), chips.record_mov_cond_chip),
              ("branch", pin(rec.branch), chips.record_branch_chip), ("mul", pin(rec.mul), chips.record_mul_chip),
-             ("divrem", pin(rec.divrem), chips.record_divrem_chip)]
-    heights = [log2_rows(len(ev)) for _, ev, _ in work]
+             ("divrem", pin(rec.divrem), chips.record_divrem_chip), ("memory_local", pin(rec.memory_local), chips.record_memory_local_chip)]
+    heights = [log2_rows(-(-len(ev) // 4) if c == "memory_local" else len(ev)) for c, ev, _ in work]
     recs = [chips.record_chip(c, lh) if rc is None else rc(lh) for (c, _, rc), lh in zip(work, heights)]
     plh = log2_rows(len(prog))
     recs += [chips.record_byte_chip(0), chips.record_program_chip(plh, 1)]
@@ -85,6 +85,8 @@ def main():
                 born.append(ctx.tracegen_mul(ev, lh, blu))
             elif c == "divrem":
                 born.append(ctx.tracegen_divrem(ev, lh, blu))
+            elif c == "memory_local":
+                born.append(ctx.tracegen_memory_local(ev, lh))
             else:
                 born.append(ctx.tracegen_alu(c, ev, lh, blu))
             tg_kernel += sum(ms for name, ms, _, _ in ctx.kernel_timings() if name.startswith("tracegen"))
@@ -104,7 +106,7 @@ def main():
     cells = sum((1 << c.log_height) * (c.main_width + 4 * c.perm_ext_width + 8) for c in recs)
     event_bytes = sum(len(ev) * ev.dtype.itemsize for _, ev, _ in work)
     print(json.dumps({"workload": f"CORE-{args.log_cycles}: 2^{args.log_cycles} executed instructions (Cpu rows) of a generated program; Cpu, Program, "
-                                  "AddSub, Bitwise, Lt, ShiftLeft, ShiftRight, CloClz, Mul, DivRem, Branch, Jump, MovCond, Byte",
+                                  "AddSub, Bitwise, Lt, ShiftLeft, ShiftRight, CloClz, Mul, DivRem, Branch, Jump, MovCond, MemoryLocal, Byte",
                       "executor_seconds_python": round(exec_s, 1), "program_instructions": int(len(prog)), "event_bytes": int(event_bytes),
                       "tracegen_ms": round(float(np.mean([x["tracegen_ms"] for x in res])), 3),
                       "tracegen_kernel_ms": round(float(np.mean([x["tracegen_kernel_ms"] for x in res])), 3),

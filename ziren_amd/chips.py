@@ -678,6 +678,22 @@ def _program(r: _Rec):
     r.receives.append(air.Lookup([air.to_virtual_pair(v) for v in p[0:14]], air.to_virtual_pair(l[0]), air.KIND_PROGRAM))
 
 
+def _memory_local(r: _Rec):
+    """MemoryLocalChip::eval (memory/local.rs:213-283): per entry, receive the access the shard starts from, send the one it
+    ends with (kind Memory), and send both to the global table (kind Global: message, is_receive, is_send, kind)."""
+    l, b = r.local, r.b
+    for k in range(4):
+        e = l[14 * k:14 * k + 14]
+        addr, ish, fsh, iclk, fclk, ival, fval, is_real = e[0], e[1], e[2], e[3], e[4], e[5:9], e[9:13], e[13]
+        b.assert_bool(is_real)
+        r.receives.append(air.Lookup([air.to_virtual_pair(v) for v in [ish, iclk, addr] + list(ival)], air.to_virtual_pair(is_real), air.KIND_MEMORY))
+        r.sends.append(air.Lookup([air.to_virtual_pair(v) for v in [ish, iclk, addr] + list(ival) + [is_real * 0, is_real * 1, air.KIND_MEMORY]],
+                                  air.to_virtual_pair(is_real), air.KIND_GLOBAL))
+        r.sends.append(air.Lookup([air.to_virtual_pair(v) for v in [fsh, fclk, addr] + list(fval) + [is_real * 1, is_real * 0, air.KIND_MEMORY]],
+                                  air.to_virtual_pair(is_real), air.KIND_GLOBAL))
+        r.sends.append(air.Lookup([air.to_virtual_pair(v) for v in [fsh, fclk, addr] + list(fval)], air.to_virtual_pair(is_real), air.KIND_MEMORY))
+
+
 def _mov_cond(r: _Rec):
     """MovCondChip::eval (misc/mov_cond/mod.rs:172-257)."""
     l, b = r.local, r.b
@@ -869,6 +885,16 @@ def record_cpu_chip(log_height: int) -> RecordedChip:
     the register accesses."""
     from . import miniexec as M
     return _finish(record_cpu_constraints(), "Cpu", log_height, M.CPU_WIDTH, False)
+
+
+def record_memory_local_chip(log_height: int) -> RecordedChip:
+    """The MemoryLocal chip (crates/core/machine/src/memory/local.rs): MemoryLocalEvents, four per row, 56 columns. It closes
+    the shard's memory argument: receives each touched address's state on entry, sends its state on exit, and forwards both
+    to the Global chip (not built)."""
+    from . import miniexec as M
+    r = _Rec(M.MEMORY_LOCAL_WIDTH)
+    _memory_local(r)
+    return _finish(r, "MemoryLocal", log_height, M.MEMORY_LOCAL_WIDTH, False)
 
 
 def record_program_chip(log_height: int, prep_index: int = 0) -> RecordedChip:

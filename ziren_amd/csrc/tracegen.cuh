@@ -784,6 +784,29 @@ __global__ void counts_to_field(uint32_t* out, size_t n) {
   if (i < n) out[i] = kb::to_monty(out[i]);
 }
 
+// MemoryLocalChip::generate_trace (memory/local.rs:147-190): MemoryLocalEvents of seven words (addr, initial {shard,
+// timestamp, value}, final {...}), four per row; one thread per entry writes its fourteen columns (addr, initial_shard,
+// final_shard, initial_clk, final_clk, initial_value[4], final_value[4], is_real); entries past n_events are zero.
+constexpr int MEMORY_LOCAL_ENTRIES = 4, MEMORY_LOCAL_ENTRY_COLS = 14, MEMORY_LOCAL_WIDTH = 56;
+__global__ void memory_local_rows(const uint32_t* __restrict__ events, size_t n_events, size_t height, uint32_t* __restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // entry index; consecutive threads -> consecutive rows of one entry slot
+  const size_t row = i % height, k = i / height;
+  if (k >= MEMORY_LOCAL_ENTRIES) return;
+  const size_t ev = row * MEMORY_LOCAL_ENTRIES + k;
+  uint32_t r[MEMORY_LOCAL_ENTRY_COLS];
+#pragma unroll
+  for (int c = 0; c < MEMORY_LOCAL_ENTRY_COLS; c++) r[c] = 0;
+  if (ev < n_events) {
+    const uint32_t* e = events + ev * 7;
+    r[0] = e[0]; r[1] = e[1]; r[2] = e[4]; r[3] = e[2]; r[4] = e[5];
+    word(r + 5, e[3]);
+    word(r + 9, e[6]);
+    r[13] = 1;
+  }
+#pragma unroll
+  for (int c = 0; c < MEMORY_LOCAL_ENTRY_COLS; c++) out[(k * MEMORY_LOCAL_ENTRY_COLS + c) * height + row] = kb::to_monty(r[c]);
+}
+
 // ByteChip::generate_trace: out = to_field(counts + extra); extra (may be null) holds the row-major plain counts of the
 // chips whose dependencies stay on the host
 __global__ void byte_mults_finish(const uint32_t* __restrict__ counts, const uint32_t* __restrict__ extra_row_major,

@@ -1768,6 +1768,36 @@ int zkm_tracegen_program_mults(zkm_ctx* ctx, const zkm_cpu_event* events, size_t
   API_END
 }
 
+int zkm_tracegen_memory_local(zkm_ctx* ctx, const zkm_memory_local_event* events, size_t n_events, int fixed_log2_rows, zkm_matrix** out) {
+  API_BEGIN
+  static_assert(sizeof(zkm_memory_local_event) == 28, "event records mirror the #[repr(C)] executor structs");
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIP_CHECK(hipSetDevice(ctx->device));
+  if (n_events && !events) throw std::runtime_error("zkm_tracegen_memory_local: null events");
+  const size_t height = padded_trace_rows(div_up(n_events, (size_t)tracegen::MEMORY_LOCAL_ENTRIES), fixed_log2_rows, "zkm_tracegen_memory_local");
+  ctx->begin_call();
+  zkm_matrix* m = new zkm_matrix();
+  m->h = height; m->w = tracegen::MEMORY_LOCAL_WIDTH;
+  uint32_t* d_events = nullptr;
+  try {
+    m->d = ctx->alloc_n<uint32_t>(height * m->w);
+    d_events = (uint32_t*)ctx->alloc(std::max<size_t>(n_events * sizeof(zkm_memory_local_event), 4));
+    if (n_events) HIP_CHECK(hipMemcpyAsync(d_events, events, n_events * sizeof(zkm_memory_local_event), hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(tracegen::memory_local_rows, dim3(div_up(height * tracegen::MEMORY_LOCAL_ENTRIES, (size_t)256)), dim3(256), 0, ctx->stream,
+                       (const uint32_t*)d_events, n_events, height, m->d);
+    LAUNCH_CHECK();
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  } catch (...) {
+    if (d_events) ctx->release(d_events);
+    if (m->d) ctx->release(m->d);
+    delete m;
+    throw;
+  }
+  ctx->release(d_events);
+  *out = m;
+  API_END
+}
+
 int zkm_tracegen_byte_table(zkm_ctx* ctx, zkm_matrix** out) {
   API_BEGIN
   std::lock_guard<std::mutex> lk(ctx->mu);

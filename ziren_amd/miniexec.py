@@ -36,6 +36,11 @@ CPU_EVENT = np.dtype([("clk", "<u4"), ("pc", "<u4"), ("next_pc", "<u4"), ("next_
                       ("c_record", OPTION_MEMORY_RECORD), ("hi", OPTION_U32), ("hi_record", OPTION_MEMORY_RECORD),
                       ("memory_record", OPTION_MEMORY_RECORD), ("exit_code", "<u4")])
 assert CPU_EVENT.itemsize == 280
+# #[repr(C)] MemoryLocalEvent (events/memory.rs:226-237): addr, initial MemoryRecord {shard, timestamp, value}, final MemoryRecord
+MEMORY_RECORD = np.dtype([("shard", "<u4"), ("timestamp", "<u4"), ("value", "<u4")])
+MEMORY_LOCAL_EVENT = np.dtype([("addr", "<u4"), ("initial", MEMORY_RECORD), ("final", MEMORY_RECORD)])
+assert MEMORY_LOCAL_EVENT.itemsize == 28
+MEMORY_LOCAL_ENTRIES_PER_ROW, MEMORY_LOCAL_WIDTH = 4, 56
 TAG_READ, TAG_WRITE, TAG_NONE = 0, 1, 2
 CPU_WIDTH = 67
 PROGRAM_PREP_WIDTH, PROGRAM_MULT_WIDTH = 14, 1
@@ -55,6 +60,7 @@ class Record:
 
     def __init__(self):
         self.cpu, self.alu, self.mul, self.divrem, self.branch, self.jump, self.mov_cond = [], {c: [] for c in E.CHIP_NAMES}, [], [], [], [], []
+        self.memory_local = []
 
 
 def _alu(op, b, c):
@@ -74,6 +80,7 @@ def run(n_cycles: int, seed: int = 1, shard: int = 1, pc_base: int = 0x1000):
     for i in range(1, 34, 5):     # small and special values so comparisons, shifts and divisions hit their corners
         R[i] = int(E._CORNERS[i % len(E._CORNERS)])
     last = [(0, 0)] * 34           # (shard, timestamp) of the previous access; shard 0 = before this shard
+    first = {}                     # register -> (shard, timestamp, value) on entry to this shard (ExecutionRecord::cpu_local_memory_access)
     program = {}
     rec = Record()
     pc, next_pc = pc_base, pc_base + 4
@@ -81,12 +88,14 @@ def run(n_cycles: int, seed: int = 1, shard: int = 1, pc_base: int = 0x1000):
     pending_jump_reg = None        # a register just loaded with a jump target
 
     def read(reg, clk, pos):
+        first.setdefault(reg, (last[reg][0], last[reg][1], R[reg]))
         r = (TAG_READ, (R[reg], shard, clk + pos, last[reg][0], last[reg][1]), None)
         last[reg] = (shard, clk + pos)
         return r
 
     def write(reg, value, clk, pos):
         value = 0 if reg == 0 else value & 0xffffffff
+        first.setdefault(reg, (last[reg][0], last[reg][1], R[reg]))
         r = (TAG_WRITE, None, (value, shard, clk + pos, R[reg], last[reg][0], last[reg][1]))
         R[reg] = value
         last[reg] = (shard, clk + pos)
@@ -253,6 +262,8 @@ def run(n_cycles: int, seed: int = 1, shard: int = 1, pc_base: int = 0x1000):
     out.branch = np.array(rec.branch, dtype=E.BRANCH_EVENT) if rec.branch else np.zeros(0, dtype=E.BRANCH_EVENT)
     out.jump = np.array(rec.jump, dtype=E.JUMP_EVENT) if rec.jump else np.zeros(0, dtype=E.JUMP_EVENT)
     out.mov_cond = np.array(rec.mov_cond, dtype=E.MOV_COND_EVENT) if rec.mov_cond else np.zeros(0, dtype=E.MOV_COND_EVENT)
+    out.memory_local = np.array([(reg, first[reg], (last[reg][0], last[reg][1], R[reg])) for reg in sorted(first)], dtype=MEMORY_LOCAL_EVENT) \
+        if first else np.zeros(0, dtype=MEMORY_LOCAL_EVENT)
     pv = {"start_pc": pc_base, "next_pc": int(cpu["next_pc"][-1]) if len(cpu) else pc_base, "execution_shard": shard, "shard": shard}
     return prog, out, pv
 
@@ -268,6 +279,7 @@ def add_dependencies(rec: Record) -> Record:
     alu[E.CHIP_LT] = np.concatenate([alu[E.CHIP_LT], lt_dep, div_lt])
     out = Record()
     out.cpu, out.alu, out.branch, out.jump, out.mov_cond, out.divrem = rec.cpu, alu, rec.branch, rec.jump, rec.mov_cond, rec.divrem
+    out.memory_local = rec.memory_local
     out.mul = np.concatenate([rec.mul, div_mul])
     return out
 

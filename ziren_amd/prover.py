@@ -167,6 +167,15 @@ class Context:
                                               blu.h if blu is not None else None, C.byref(h)))
         return self._born(h)
 
+    def tracegen_memory_local(self, events: np.ndarray, fixed_log2_rows: int = -1) -> DeviceMatrix:
+        """`generate_trace` of the MemoryLocal chip on the device (zkm_tracegen_memory_local); dtype miniexec.MEMORY_LOCAL_EVENT."""
+        from . import miniexec as _m
+        ev = np.ascontiguousarray(events, dtype=_m.MEMORY_LOCAL_EVENT)
+        h = C.c_void_p()
+        lib.check(lib.load().zkm_tracegen_memory_local(self.h, C.c_void_p(ev.ctypes.data if len(ev) else None), C.c_size_t(len(ev)),
+                                                       C.c_int(fixed_log2_rows), C.byref(h)))
+        return self._born(h)
+
     def tracegen_program(self, program: np.ndarray, pc_base: int, fixed_log2_rows: int = -1) -> DeviceMatrix:
         """The Program chip's preprocessed table on the device (zkm_tracegen_program)."""
         from . import miniexec as _m
