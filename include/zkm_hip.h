@@ -347,6 +347,23 @@ int zkm_tracegen_program(zkm_ctx* ctx, const zkm_instruction* program, size_t n_
                          zkm_matrix** out);
 int zkm_tracegen_program_mults(zkm_ctx* ctx, const zkm_cpu_event* events, size_t n_events, size_t n_instr, uint32_t pc_base,
                                int fixed_log2_rows, zkm_matrix** out);
+/* The MemoryInstructions chip (crates/core/machine/src/memory/instructions/: LB LBU LH LHU LW LWL LWR LL SB SH SW SWL SWR SC):
+ * replaces generate_trace (trace.rs:44-84), which also records the byte lookups (counted into `blu` if given). Events are the
+ * #[repr(C)] MemInstrEvents of crates/core/executor/src/events/instr.rs:108-136, whose `mem_access` is the #[repr(C)] enum
+ * MemoryRecordEnum (events/memory.rs:88-95): a 4-byte tag (Read = 0, Write = 1) followed by the record (read: value, shard,
+ * timestamp, prev_shard, prev_timestamp; write: value, shard, timestamp, prev_value, prev_shard, prev_timestamp). 79 columns,
+ * zero padding rows. */
+typedef struct zkm_mem_instr_event {
+  uint32_t shard, clk, pc, next_pc;
+  uint8_t opcode, _pad[3];
+  uint32_t a, b, c;
+  uint32_t mem_access_tag;
+  uint32_t mem_access[6];
+  uint32_t prev_a_val;
+} zkm_mem_instr_event;
+size_t zkm_tracegen_memory_instrs_width(void);
+int zkm_tracegen_memory_instrs(zkm_ctx* ctx, const zkm_mem_instr_event* events, size_t n_events, int fixed_log2_rows,
+                               zkm_byte_lookups* blu, zkm_matrix** out);
 /* The MemoryLocal chip (crates/core/machine/src/memory/local.rs): replaces generate_trace (:147-190). Events are the
  * #[repr(C)] MemoryLocalEvents of crates/core/executor/src/events/memory.rs:226-237 (ExecutionRecord::get_local_mem_events),
  * four per row, 56 columns, zero padding. */

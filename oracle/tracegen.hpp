@@ -865,4 +865,82 @@ static inline std::vector<F> generate_memory_local(const MemoryLocalEvent* event
   return t;
 }
 
+// ---- MemoryInstructions chip: MemInstrEvents (crates/core/executor/src/events/instr.rs:108-136; mem_access is the #[repr(C)] enum
+// MemoryRecordEnum: tag Read 0 / Write 1, then the record); columns memory/instructions/columns.rs:12-117, row trace.rs:100-262
+struct MemInstrEvent {
+  uint32_t shard, clk, pc, next_pc;
+  uint8_t opcode; uint8_t pad[3];
+  uint32_t a, b, c;
+  uint32_t mem_tag;
+  uint32_t mem[6];   // Read: value, shard, timestamp, prev_shard, prev_timestamp; Write: value, shard, timestamp, prev_value, prev_shard, prev_timestamp
+  uint32_t prev_a_val;
+};
+static_assert(sizeof(MemInstrEvent) == 64, "MemInstrEvent is sixteen words");
+static const size_t MEMORY_INSTRS_WIDTH = 79;
+enum { B_AND_OP = 0, B_LTU_OP = 6 };
+static inline void memory_instr_row(const MemInstrEvent& e, F* r, std::vector<ByteLookup>* lk) {
+  enum { PC = 0, NEXT_PC = 1, SHARD = 2, CLK = 3, OP_A = 4, OP_B = 8, OP_C = 12, IS_LB = 16, ADDR_WORD = 30, ADDR_ALIGNED = 34, ADDR_LS_TWO_BITS = 35,
+         LS_IS_ONE = 36, LS_IS_TWO = 37, LS_IS_THREE = 38, ADDR_RC = 39, MEMORY_ACCESS = 53, PREV_A_VAL = 66, UNSIGNED_MEM_VAL = 70,
+         MOST_SIG_BIT = 74, MOST_SIG_BYTE = 75, MEM_VALUE_IS_NEG = 76, MOST_SIG_BYTES_ZERO = 77 };
+  const uint8_t o = e.opcode;
+  if (o < 31 || o > 44) throw std::runtime_error("tracegen: invalid memory opcode");
+  if (e.shard == 0) throw std::runtime_error("tracegen: memory instruction in shard 0");
+  r[SHARD] = fu32(e.shard); r[CLK] = fu32(e.clk); r[PC] = fu32(e.pc); r[NEXT_PC] = fu32(e.next_pc);
+  word(r + OP_A, e.a); word(r + OP_B, e.b); word(r + OP_C, e.c);
+  uint32_t mem_value;
+  if (e.mem_tag == 1) {
+    MemoryWriteRecord w{e.mem[0], e.mem[1], e.mem[2], e.mem[3], e.mem[4], e.mem[5]};
+    memory_write_cols(w, r + MEMORY_ACCESS, lk);
+    mem_value = w.value;
+  } else {
+    word(r + MEMORY_ACCESS, e.mem[0]);   // populate_read: prev_value = value
+    memory_access_cols(e.mem[0], e.mem[1], e.mem[2], e.mem[3], e.mem[4], r + MEMORY_ACCESS + 4, lk);
+    mem_value = e.mem[0];
+  }
+  word(r + PREV_A_VAL, e.prev_a_val);
+  const uint32_t addr = e.b + e.c, aligned = addr & ~3u, ls = addr & 3;
+  word(r + ADDR_WORD, addr);
+  range_checker(r + ADDR_RC, addr);
+  r[ADDR_ALIGNED] = fu32(aligned);
+  r[ADDR_LS_TWO_BITS] = ls; r[LS_IS_ONE] = ls == 1; r[LS_IS_TWO] = ls == 2; r[LS_IS_THREE] = ls == 3;
+  if (lk) lk->push_back(ByteLookup{B_AND_OP, (uint8_t)addr, 3});
+  if (o <= 38) {   // loads
+    uint32_t u;
+    switch (o) {
+      case 31: case 32: u = (mem_value >> (8 * ls)) & 0xff; break;                       // LB, LBU
+      case 33: case 34: u = (ls >> 1) ? mem_value >> 16 : mem_value & 0xffff; break;     // LH, LHU
+      case 36: { const uint32_t sh = 24 - 8 * ls; u = (e.prev_a_val & ~(0xffffffffu << sh)) | (mem_value << sh); break; }   // LWL
+      case 37: { const uint32_t sh = 8 * ls; u = (e.prev_a_val & ~(0xffffffffu >> sh)) | (mem_value >> sh); break; }         // LWR
+      default: u = mem_value;                                                            // LW, LL
+    }
+    word(r + UNSIGNED_MEM_VAL, u);
+    if (o == 31 || o == 33) {
+      const uint8_t byte = o == 31 ? (uint8_t)u : (uint8_t)(u >> 8);
+      r[MEM_VALUE_IS_NEG] = byte >> 7;
+      r[MOST_SIG_BYTE] = byte;
+      r[MOST_SIG_BIT] = byte >> 7;
+      if (lk) lk->push_back(ByteLookup{B_MSB_OP, byte, 0});
+    }
+  }
+  r[IS_LB + (o - 31)] = 1;   // is_lb, is_lbu, is_lh, is_lhu, is_lw, is_lwl, is_lwr, is_ll, is_sb, is_sh, is_sw, is_swl, is_swr, is_sc: opcode order
+  if (lk) lk->push_back(ByteLookup{B_U8RANGE_OP, (uint8_t)(addr >> 8), (uint8_t)(addr >> 16)});
+  const F upper = fadd(fadd((addr >> 8) & 0xff, (addr >> 16) & 0xff), addr >> 24);
+  r[MOST_SIG_BYTES_ZERO] = upper ? finv(upper) : 0;
+  r[MOST_SIG_BYTES_ZERO + 1] = upper == 0;
+  if (upper == 0 && lk) lk->push_back(ByteLookup{B_LTU_OP, 35, (uint8_t)addr});   // NUM_REGISTERS - 1 < addr
+}
+static inline std::vector<F> generate_memory_instrs(const MemInstrEvent* events, size_t n_events, int fixed_log2_rows, size_t* height,
+                                                    uint64_t* byte_counts) {
+  const size_t h = padded_rows(n_events, fixed_log2_rows);
+  std::vector<F> t(h * MEMORY_INSTRS_WIDTH, 0);
+  std::vector<ByteLookup> lk;
+  for (size_t i = 0; i < n_events; i++) {
+    lk.clear();
+    memory_instr_row(events[i], t.data() + i * MEMORY_INSTRS_WIDTH, byte_counts ? &lk : nullptr);
+    for (const ByteLookup& l : lk) byte_counts[(((size_t)l.b << 8) + l.c) * NUM_BYTE_OPS + l.op]++;
+  }
+  *height = h;
+  return t;
+}
+
 }  // namespace tracegen

@@ -45,6 +45,7 @@ def cpu_shard(oracle, n_cycles, seed=1):
         recs.append(rc)
         work.append((name, ev, lh))
     for name, ev, record, gen in (("branch", rec.branch, chips.record_branch_chip, oracle.tracegen_branch),
+                                  ("memory_instrs", rec.mem_instr, chips.record_memory_instrs_chip, oracle.tracegen_memory_instrs),
                                   ("mul", rec.mul, chips.record_mul_chip, oracle.tracegen_mul),
                                   ("divrem", rec.divrem, chips.record_divrem_chip, oracle.tracegen_divrem)):
         lh = log2_rows(len(ev))
@@ -78,9 +79,10 @@ def test_miniexec_record_is_coherent():
     assert len(cpu) == 1500 and pv["start_pc"] == 0x1000 and (np.diff(cpu["clk"].astype(np.int64)) == 5).all()
     assert (cpu["pc"][1:] == cpu["next_pc"][:-1]).all() and (cpu["next_pc"][1:] == cpu["next_next_pc"][:-1]).all()
     assert len(np.unique(cpu["pc"])) == 1500                      # forward only: every pc runs once
-    total = sum(len(v) for v in rec.alu.values()) + len(rec.mul) + len(rec.divrem) + len(rec.branch) + len(rec.jump) + len(rec.mov_cond)
+    total = sum(len(v) for v in rec.alu.values()) + len(rec.mul) + len(rec.divrem) + len(rec.branch) + len(rec.jump) + len(rec.mov_cond) + len(rec.mem_instr)
     assert total == 1500                                          # one chip event per cycle (emit_events)
     assert min(len(v) for v in rec.alu.values()) > 0 and len(rec.jump) > 0 and len(rec.divrem) > 0
+    assert set(rec.mem_instr["opcode"].tolist()) == set(range(E.LB, E.SC + 1))     # all fourteen loads and stores
     # register accesses chain: every record's previous (shard, timestamp) is the last access to that register
     ins = prog[(cpu["pc"] - 0x1000) // 4]
     last = {}
@@ -90,11 +92,42 @@ def test_miniexec_record_is_coherent():
             r = e[name]
             if r["tag"] == M.TAG_NONE or not is_reg:
                 continue
+            if name == "a_record" and int(i["opcode"]) in (E.MULT, E.MULTU, E.DIV, E.DIVU):
+                reg = M.REG_LO
             body = r["read"] if r["tag"] == M.TAG_READ else r["write"]
             assert (int(body["prev_shard"]), int(body["prev_timestamp"])) == last.get(reg, (0, 0))
             last[reg] = (int(body["shard"]), int(body["timestamp"]))
     taken = E.branch_taken(rec.branch)
     assert taken.any() and (~taken).any()
+
+
+def test_memory_instrs_constraints_hold(oracle):
+    rec = chips.record_memory_instrs_constraints()
+    prog, r, pv = M.run(8000, seed=11)
+    ev = r.mem_instr
+    assert len(ev) > 800 and (ev["b"] + ev["c"]).min() < 256          # some addresses fit one byte (the LTU lookup)
+    counts = np.zeros((1 << 16, 10), dtype=np.uint32)
+    t = F.from_monty(oracle.tracegen_memory_instrs(ev, -1, counts))
+    assert air.debug_constraints(rec.b, t) == [] and not t[len(ev):].any()
+    # the loaded / stored values are the executor's: a load's `a` and a store's memory word follow events.load_value / store_value
+    for e in ev[:200]:
+        addr = (int(e["b"]) + int(e["c"])) & 0xffffffff
+        if e["mem_tag"] == M.TAG_READ:
+            assert int(e["a"]) == E.load_value(int(e["opcode"]), int(e["mem"][0]), addr, int(e["prev_a_val"]))
+        else:
+            assert int(e["mem"][0]) == E.store_value(int(e["opcode"]), int(e["mem"][3]), addr, int(e["prev_a_val"]))
+    for col in (4, 30, 35, 57, 70):   # op_a byte, addr byte, ls bits, stored / loaded word byte, unsigned_mem_val byte
+        bad = t.copy()
+        bad[7, col] = (int(bad[7, col]) + 1) % F.P
+        assert {row for _, row in air.debug_constraints(rec.b, bad)} == {7}, col
+    kinds = [lk.kind for lk in rec.sends]
+    assert kinds.count(air.KIND_INSTRUCTION) == 2 and kinds.count(air.KIND_BYTE) == 6 and kinds.count(air.KIND_MEMORY) == 1
+    c = chips.record_memory_instrs_chip(10)     # mips_costs.json: MemoryInstrs 115
+    assert c.main_width + 4 * c.perm_ext_width + 8 == 115
+    # dependencies: one ADD per event, one SUB per negative LB / LH
+    dep = E.memory_dependencies(ev)
+    neg = int(t[:len(ev), 76].sum())
+    assert (dep["opcode"] == E.ADD).sum() == len(ev) and (dep["opcode"] == E.SUB).sum() == neg > 0
 
 
 def test_cpu_constraints_hold(oracle):
@@ -123,7 +156,7 @@ def test_shard_lookups_balance(oracle):
     recs, work, byte, program, prog, pv = cpu_shard(oracle, 1200, seed=9)
     left = {k: v for k, v in lookup_tally(recs + [byte, program]).items() if v}
     n_addr = len(work[-1][1])
-    assert {k[0] for k in left} == {air.KIND_GLOBAL} and len(left) == 2 * n_addr and 30 <= n_addr <= 34
+    assert {k[0] for k in left} == {air.KIND_GLOBAL} and len(left) == 2 * n_addr and n_addr > 34    # registers and memory words
     without = {k: v for k, v in lookup_tally(recs[:-1] + [byte, program]).items() if v}
     assert {k[0] for k in without} == {air.KIND_MEMORY}          # without MemoryLocal the access chains stay open
     mirrors = global_mirrors(recs)
@@ -155,6 +188,8 @@ def device_trace(ctx, chip, ev, lh, blu, prog):
         return ctx.tracegen_cpu(ev, prog, PC_BASE, SHARD, lh, blu)
     if chip == "memory_local":
         return ctx.tracegen_memory_local(ev, lh)
+    if chip == "memory_instrs":
+        return ctx.tracegen_memory_instrs(ev, lh, blu)
     if chip == "jump":
         return ctx.tracegen_jump(ev, lh)
     if chip == "mov_cond":
@@ -186,6 +221,14 @@ def test_gpu_cpu_and_program_tracegen_match_oracle(hip_ctx, oracle):
             want = oracle.tracegen_program(which, rec.cpu, prog, PC_BASE)
             assert (born.height, born.width) == want.shape and np.array_equal(born.to_host(), want), (n, which)
             born.free()
+        counts = np.zeros((1 << 16, 10), dtype=np.uint32)
+        want = oracle.tracegen_memory_instrs(rec.mem_instr, -1, counts)
+        blu = hip_ctx.byte_lookups()
+        born = hip_ctx.tracegen_memory_instrs(rec.mem_instr, -1, blu)
+        mults = hip_ctx.tracegen_byte_mults(blu)
+        assert (born.height, born.width) == want.shape and np.array_equal(born.to_host(), want), n
+        assert np.array_equal(F.from_monty(mults.to_host()), counts), n
+        born.free(); mults.free(); blu.free()
         want = oracle.tracegen_memory_local(rec.memory_local)
         born = hip_ctx.tracegen_memory_local(rec.memory_local)
         assert (born.height, born.width) == want.shape and np.array_equal(born.to_host(), want), n

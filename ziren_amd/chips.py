@@ -678,6 +678,119 @@ def _program(r: _Rec):
     r.receives.append(air.Lookup([air.to_virtual_pair(v) for v in p[0:14]], air.to_virtual_pair(l[0]), air.KIND_PROGRAM))
 
 
+def _memory_instrs(r: _Rec):
+    """MemoryInstructionsChip::eval (memory/instructions/air.rs:17-520)."""
+    l, b = r.local, r.b
+    (PC, NEXT_PC, SHARD, CLK, OP_A, OP_B, OP_C, FLAGS, ADDR_WORD, ADDR_ALIGNED, ADDR_LS, LS1, LS2, LS3, ADDR_RC, MEM, PREV_A, UMV, MSBIT, MSBYTE,
+     IS_NEG, MSB_ZERO) = 0, 1, 2, 3, 4, 8, 12, 16, 30, 34, 35, 36, 37, 38, 39, 53, 66, 70, 74, 75, 76, 77
+    is_lb, is_lbu, is_lh, is_lhu, is_lw, is_lwl, is_lwr, is_ll, is_sb, is_sh, is_sw, is_swl, is_swr, is_sc = (l[FLAGS + i] for i in range(14))
+    flags = [is_lb, is_lbu, is_lh, is_lhu, is_lw, is_lwl, is_lwr, is_ll, is_sb, is_sh, is_sw, is_swl, is_swr, is_sc]
+    a_val, b_val, c_val = l[OP_A:OP_A + 4], l[OP_B:OP_B + 4], l[OP_C:OP_C + 4]
+    addr_word, prev_a, umv = l[ADDR_WORD:ADDR_WORD + 4], l[PREV_A:PREV_A + 4], l[UMV:UMV + 4]
+    prev_mem, mem_access = l[MEM:MEM + 4], l[MEM + 4:MEM + 13]
+    mem_val = mem_access[0:4]
+    is_real = flags[0]
+    for f in flags[1:]:
+        is_real = is_real + f
+    for f in flags:
+        b.assert_bool(f)
+    b.assert_bool(is_real)
+    # eval_memory_address_and_access
+    r.send_alu(E.ADD, addr_word, b_val, c_val, is_real)
+    _word_range_check(b, addr_word, l[ADDR_RC:ADDR_RC + 14], is_real)
+    r.slice_range_check_u8(addr_word[1:3], is_real)
+    r.send_byte(B_LTU, 1, E.NUM_REGISTERS - 1, addr_word[0], l[MSB_ZERO + 1])
+    b.when(l[MSB_ZERO + 1]).assert_one(is_real)
+    upper = addr_word[1] + addr_word[2] + addr_word[3]      # IsZeroOperation::eval (operations/is_zero.rs:33-49)
+    b.when(is_real).assert_eq(1 - l[MSB_ZERO] * upper, l[MSB_ZERO + 1])
+    b.when(is_real).assert_bool(l[MSB_ZERO + 1])
+    b.when(is_real).when(l[MSB_ZERO + 1]).assert_zero(upper)
+    off0 = 1 - l[LS1] - l[LS2] - l[LS3]                      # eval_offset_value_flags
+    b.assert_bool(l[LS1])
+    b.assert_bool(l[LS2])
+    b.assert_bool(l[LS3])
+    b.assert_bool(off0)
+    b.when(off0).assert_zero(l[ADDR_LS])
+    b.when(l[LS1]).assert_one(l[ADDR_LS])
+    b.when(l[LS2]).assert_eq(l[ADDR_LS], 2)
+    b.when(l[LS3]).assert_eq(l[ADDR_LS], 3)
+    b.when(is_real).assert_eq(l[ADDR_ALIGNED] + l[ADDR_LS], _reduce(b, addr_word))
+    r.send_byte(B_AND, l[ADDR_LS], addr_word[0], 3, is_real)
+    r.eval_memory_access(l[SHARD], l[CLK] + 0, l[ADDR_ALIGNED], prev_mem, mem_access, is_real)
+    loads = is_lb + is_lbu + is_lh + is_lhu + is_lw + is_lwl + is_lwr + is_ll
+    for i in range(4):
+        b.when(loads).assert_eq(mem_val[i], prev_mem[i])
+    # eval_memory_load: eval_unsigned_mem_value
+    mem_byte = mem_val[0] * off0 + mem_val[1] * l[LS1] + mem_val[2] * l[LS2] + mem_val[3] * l[LS3]
+    for i, want in enumerate([mem_byte, 0, 0, 0]):
+        b.when(is_lb + is_lbu).assert_eq(want, umv[i])
+    b.when(is_lh + is_lhu).assert_zero(l[LS1] + l[LS3])
+    b.when(is_lw).assert_one(off0)
+    half = [off0 * mem_val[0] + l[LS2] * mem_val[2], off0 * mem_val[1] + l[LS2] * mem_val[3], 0, 0]
+    for i in range(4):
+        b.when(is_lh + is_lhu).assert_eq(half[i], umv[i])
+    for i in range(4):
+        b.when(is_lw).assert_eq(mem_val[i], umv[i])
+    lwr = [mem_val[0] * off0 + mem_val[1] * l[LS1] + mem_val[2] * l[LS2] + mem_val[3] * l[LS3],
+           mem_val[1] * off0 + mem_val[2] * l[LS1] + mem_val[3] * l[LS2] + prev_a[1] * l[LS3],
+           mem_val[2] * off0 + mem_val[3] * l[LS1] + prev_a[2] * (1 - l[LS1] - off0),
+           mem_val[3] * off0 + prev_a[3] * (1 - off0)]
+    for i in range(4):
+        b.when(is_lwr).assert_eq(umv[i], lwr[i])
+    lwl = [mem_val[0] * l[LS3] + prev_a[0] * (1 - l[LS3]),
+           mem_val[1] * l[LS3] + mem_val[0] * l[LS2] + prev_a[1] * l[LS1] + prev_a[1] * off0,
+           mem_val[2] * l[LS3] + mem_val[1] * l[LS2] + mem_val[0] * l[LS1] + prev_a[2] * off0,
+           mem_val[3] * l[LS3] + mem_val[2] * l[LS2] + mem_val[1] * l[LS1] + mem_val[0] * off0]
+    for i in range(4):
+        b.when(is_lwl).assert_eq(umv[i], lwl[i])
+    for i in range(4):
+        b.when(is_ll).assert_eq(umv[i], mem_val[i])
+    b.when(is_ll).assert_one(off0)
+    b.assert_eq(l[IS_NEG], (is_lb + is_lh) * l[MSBIT])
+    r.send_byte(B_MSB, l[MSBIT], l[MSBYTE], 0, is_lb + is_lh)
+    b.assert_eq(l[MSBYTE], is_lb * umv[0] + is_lh * umv[1])
+    r.send_alu(E.SUB, a_val, umv, [0, is_lb * 1, is_lh * 1, 0], l[IS_NEG])
+    positive = (is_lb + is_lh - l[IS_NEG]) + is_lbu + is_lhu + is_lw + is_ll + is_lwl + is_lwr
+    for i in range(4):
+        b.when(positive).assert_eq(umv[i], a_val[i])
+    # eval_memory_store
+    sb = [a_val[0] * off0 + (1 - off0) * prev_mem[0], a_val[0] * l[LS1] + (1 - l[LS1]) * prev_mem[1],
+          a_val[0] * l[LS2] + (1 - l[LS2]) * prev_mem[2], a_val[0] * l[LS3] + (1 - l[LS3]) * prev_mem[3]]
+    for i in range(4):
+        b.when(is_sb).assert_eq(mem_val[i], sb[i])
+    b.when(is_sh).assert_zero(l[LS1] + l[LS3])
+    b.when(is_sw).assert_one(off0)
+    sh = [a_val[0] * off0 + (1 - off0) * prev_mem[0], a_val[1] * off0 + (1 - off0) * prev_mem[1],
+          a_val[0] * l[LS2] + (1 - l[LS2]) * prev_mem[2], a_val[1] * l[LS2] + (1 - l[LS2]) * prev_mem[3]]
+    for i in range(4):
+        b.when(is_sh).assert_eq(mem_val[i], sh[i])
+    for i in range(4):
+        b.when(is_sw).assert_eq(mem_val[i], a_val[i])
+    swl = [a_val[3] * off0 + a_val[2] * l[LS1] + a_val[1] * l[LS2] + a_val[0] * l[LS3],
+           prev_mem[1] * off0 + a_val[3] * l[LS1] + a_val[2] * l[LS2] + a_val[1] * l[LS3],
+           prev_mem[2] * (off0 + l[LS1]) + a_val[3] * l[LS2] + a_val[2] * l[LS3],
+           prev_mem[3] * (1 - l[LS3]) + a_val[3] * l[LS3]]
+    for i in range(4):
+        b.when(is_swl).assert_eq(mem_val[i], swl[i])
+    swr = [a_val[0] * off0 + prev_mem[0] * (1 - off0),
+           a_val[1] * off0 + a_val[0] * l[LS1] + prev_mem[1] * (l[LS2] + l[LS3]),
+           a_val[2] * off0 + a_val[1] * l[LS1] + a_val[0] * l[LS2] + prev_mem[2] * l[LS3],
+           a_val[3] * off0 + a_val[2] * l[LS1] + a_val[1] * l[LS2] + a_val[0] * l[LS3]]
+    for i in range(4):
+        b.when(is_swr).assert_eq(mem_val[i], swr[i])
+    b.when(is_sc).assert_one(off0)
+    for i in range(4):
+        b.when(is_sc).assert_eq(prev_a[i], mem_val[i])
+    b.when(is_sc).assert_one(a_val[0])
+    for i in range(1, 4):
+        b.when(is_sc).assert_zero(a_val[i])
+    opcode = flags[0] * E.LB
+    for i in range(1, 14):
+        opcode = opcode + flags[i] * (E.LB + i)
+    r.receive_instruction(l[PC], l[NEXT_PC], l[NEXT_PC] + 4, opcode, a_val, b_val, c_val, 1, is_real, hi=prev_a, is_rw_a=1,
+                          op_a_immutable=is_sb + is_sh + is_sw + is_swl + is_swr, shard=l[SHARD], clk=l[CLK], is_check_memory=1)
+
+
 def _memory_local(r: _Rec):
     """MemoryLocalChip::eval (memory/local.rs:213-283): per entry, receive the access the shard starts from, send the one it
     ends with (kind Memory), and send both to the global table (kind Global: message, is_receive, is_send, kind)."""
@@ -885,6 +998,18 @@ def record_cpu_chip(log_height: int) -> RecordedChip:
     the register accesses."""
     from . import miniexec as M
     return _finish(record_cpu_constraints(), "Cpu", log_height, M.CPU_WIDTH, False)
+
+
+def record_memory_instrs_constraints() -> _Rec:
+    r = _Rec(E.MEMORY_INSTRS_WIDTH)
+    _memory_instrs(r)
+    return r
+
+
+def record_memory_instrs_chip(log_height: int) -> RecordedChip:
+    """The MemoryInstructions chip (crates/core/machine/src/memory/instructions/): the fourteen loads and stores, MemInstrEvents,
+    79 columns, local_only (trace.rs:93-95). Sends the address ADD and the sign-extension SUB to the AddSub chip."""
+    return _finish(record_memory_instrs_constraints(), "MemoryInstrs", log_height, E.MEMORY_INSTRS_WIDTH, True)
 
 
 def record_memory_local_chip(log_height: int) -> RecordedChip:

@@ -27,13 +27,13 @@ struct AluEvent {  // #[repr(C)] AluEvent, crates/core/executor/src/events/instr
 
 // crates/core/executor/src/opcode.rs:26-48
 enum : uint32_t { ADD = 0, SUB = 1, SLL = 9, SRL = 10, SRA = 11, ROR = 12, SLT = 13, SLTU = 14, AND = 15, OR = 16, XOR = 17, NOR = 18, CLZ = 19, CLO = 20 };
-enum Chip { ADD_SUB = 0, BITWISE = 1, LT = 2, SHIFT_LEFT = 3, SHIFT_RIGHT = 4, CLO_CLZ = 5, NUM_ALU_CHIPS = 6, JUMP = 6, MOV_COND = 7, BRANCH = 8, MUL = 9, DIVREM = 10, NUM_CHIPS = 11 };
+enum Chip { ADD_SUB = 0, BITWISE = 1, LT = 2, SHIFT_LEFT = 3, SHIFT_RIGHT = 4, CLO_CLZ = 5, NUM_ALU_CHIPS = 6, JUMP = 6, MOV_COND = 7, BRANCH = 8, MUL = 9, DIVREM = 10, MEMORY_INSTRS = 11, NUM_CHIPS = 12 };
 
 __host__ __device__ constexpr int chip_width(int chip) {
-  return chip == ADD_SUB ? 19 : chip == BITWISE ? 18 : chip == LT ? 32 : chip == SHIFT_LEFT ? 44 : chip == SHIFT_RIGHT ? 67 : chip == CLO_CLZ ? 17 : chip == JUMP ? 66 : chip == MOV_COND ? 32 : chip == BRANCH ? 62 : chip == MUL ? 58 : chip == DIVREM ? 106 : 0;
+  return chip == ADD_SUB ? 19 : chip == BITWISE ? 18 : chip == LT ? 32 : chip == SHIFT_LEFT ? 44 : chip == SHIFT_RIGHT ? 67 : chip == CLO_CLZ ? 17 : chip == JUMP ? 66 : chip == MOV_COND ? 32 : chip == BRANCH ? 62 : chip == MUL ? 58 : chip == DIVREM ? 106 : chip == MEMORY_INSTRS ? 79 : 0;
 }
 // words per event record: the seven-word AluEvent / JumpEvent / BranchEvent / MovCondEvent, the sixteen-word CompAluEvent
-__host__ __device__ constexpr int event_words(int chip) { return chip == MUL || chip == DIVREM ? 16 : 7; }
+__host__ __device__ constexpr int event_words(int chip) { return chip == MUL || chip == DIVREM || chip == MEMORY_INSTRS ? 16 : 7; }
 
 constexpr int THREADS = 256;
 
@@ -457,6 +457,68 @@ __device__ __forceinline__ void divrem_row(const uint32_t* p, uint32_t* r) {
   }
 }
 
+// MemoryInstructions chip: MemInstrEvents of sixteen words (crates/core/executor/src/events/instr.rs:108-136): shard, clk, pc,
+// next_pc, opcode, a, b, c, mem_access tag (Read 0 / Write 1), six record words, prev_a_val. Columns
+// memory/instructions/columns.rs:12-117; row trace.rs:100-262.
+namespace memcols {
+enum { PC = 0, NEXT_PC = 1, SHARD = 2, CLK = 3, OP_A = 4, OP_B = 8, OP_C = 12, IS_LB = 16, ADDR_WORD = 30, ADDR_ALIGNED = 34, ADDR_LS_TWO_BITS = 35,
+       LS_IS_ONE = 36, LS_IS_TWO = 37, LS_IS_THREE = 38, ADDR_RC = 39, MEMORY_ACCESS = 53, PREV_A_VAL = 66, UNSIGNED_MEM_VAL = 70,
+       MOST_SIG_BIT = 74, MOST_SIG_BYTE = 75, MEM_VALUE_IS_NEG = 76, MOST_SIG_BYTES_ZERO = 77 };
+}
+__device__ __forceinline__ void memory_instr_row(const uint32_t* p, uint32_t* r) {
+  using namespace memcols;
+  const uint32_t o = p[4] & 0xff, b = p[6], c = p[7], prev_a = p[15];
+  r[SHARD] = p[0];
+  r[CLK] = p[1];
+  r[PC] = p[2];
+  r[NEXT_PC] = p[3];
+  word(r + OP_A, p[5]);
+  word(r + OP_B, b);
+  word(r + OP_C, c);
+  const uint32_t* rec = p + 9;
+  const uint32_t mem_value = rec[0];
+  uint32_t* m = r + MEMORY_ACCESS;   // prev_value(4), then MemoryAccessCols
+  word(m + 4, mem_value);
+  const bool is_write = p[8] == 1;
+  word(m, is_write ? rec[3] : mem_value);
+  const uint32_t rshard = rec[1], ts = rec[2], prev_shard = is_write ? rec[4] : rec[3], prev_ts = is_write ? rec[5] : rec[4];
+  m[8] = prev_shard;
+  m[9] = prev_ts;
+  const bool use_clk = prev_shard == rshard;
+  m[10] = fbool(use_clk);
+  const uint32_t diff_minus_one = (use_clk ? ts : rshard) - (use_clk ? prev_ts : prev_shard) - 1u;
+  m[11] = diff_minus_one & 0xffff;
+  m[12] = (diff_minus_one >> 16) & 0xff;
+  word(r + PREV_A_VAL, prev_a);
+  const uint32_t addr = b + c, ls = addr & 3;
+  word(r + ADDR_WORD, addr);
+  range_checker(r + ADDR_RC, addr);
+  r[ADDR_ALIGNED] = addr & ~3u;
+  r[ADDR_LS_TWO_BITS] = ls;
+  r[LS_IS_ONE] = fbool(ls == 1);
+  r[LS_IS_TWO] = fbool(ls == 2);
+  r[LS_IS_THREE] = fbool(ls == 3);
+  if (o <= 38) {   // the eight loads
+    uint32_t u = mem_value;                                              // LW, LL
+    if (o == 31 || o == 32) u = (mem_value >> (8 * ls)) & 0xff;          // LB, LBU
+    else if (o == 33 || o == 34) u = (ls >> 1) ? mem_value >> 16 : mem_value & 0xffff;   // LH, LHU
+    else if (o == 36) { const uint32_t sh = 24 - 8 * ls; u = (prev_a & ~(0xffffffffu << sh)) | (mem_value << sh); }   // LWL
+    else if (o == 37) { const uint32_t sh = 8 * ls; u = (prev_a & ~(0xffffffffu >> sh)) | (mem_value >> sh); }         // LWR
+    word(r + UNSIGNED_MEM_VAL, u);
+    if (o == 31 || o == 33) {
+      const uint32_t byte = o == 31 ? u & 0xff : (u >> 8) & 0xff;
+      r[MEM_VALUE_IS_NEG] = byte >> 7;
+      r[MOST_SIG_BYTE] = byte;
+      r[MOST_SIG_BIT] = byte >> 7;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 14; i++) r[IS_LB + i] = fbool(o == 31u + i);
+  const uint32_t upper = ((addr >> 8) & 0xff) + ((addr >> 16) & 0xff) + (addr >> 24);
+  r[MOST_SIG_BYTES_ZERO] = upper ? kb::from_monty(kb::inv(kb::to_monty(upper))) : 0u;
+  r[MOST_SIG_BYTES_ZERO + 1] = fbool(upper == 0);
+}
+
 // ---- byte lookups: the ALU chips' generate_dependencies, ByteChip::generate_trace and ByteChip::trace -----------------
 // ByteOpcode, crates/core/executor/src/opcode.rs:195-216
 enum : uint32_t { B_AND = 0, B_OR = 1, B_XOR = 2, B_SLL = 3, B_U8RANGE = 4, B_SHRCARRY = 5, B_LTU = 6, B_MSB = 7, B_U16RANGE = 8, B_NOR = 9 };
@@ -576,6 +638,18 @@ template <> __device__ __forceinline__ void row_lookups<DIVREM>(const uint32_t* 
   range_checks(counts, r + C_TIMES_QUOTIENT, 8);
 }
 
+// MemoryInstructions: the access's two limbs, AND(addr byte 0, 3), MSB of a signed load, U8Range(addr bytes 1, 2), and
+// LTU(35, addr byte 0) when the address fits one byte (memory/instructions/trace.rs:117,139-146,221-227,246-261)
+template <> __device__ __forceinline__ void row_lookups<MEMORY_INSTRS>(const uint32_t* r, uint32_t, const LookupSink& counts) {
+  using namespace memcols;
+  lookup(counts, B_U16RANGE, r[MEMORY_ACCESS + 11] >> 8, r[MEMORY_ACCESS + 11]);
+  lookup(counts, B_U8RANGE, 0, r[MEMORY_ACCESS + 12]);
+  lookup(counts, B_AND, r[ADDR_WORD], 3);
+  if (r[IS_LB] | r[IS_LB + 2]) lookup(counts, B_MSB, r[MOST_SIG_BYTE], 0);
+  lookup(counts, B_U8RANGE, r[ADDR_WORD + 1], r[ADDR_WORD + 2]);
+  if (r[MOST_SIG_BYTES_ZERO + 1]) lookup(counts, B_LTU, 35, r[ADDR_WORD]);
+}
+
 // events: n_events records of event_words(CHIP) words; out: column-major, `height` rows; grid = height / (tiles * THREADS), with
 // tiles = 1 for the plain row writer (most blocks in flight) and TILES_PER_BLOCK when counting.
 // counts (may be null): NUM_BYTE_OPS columns of BYTE_ROWS plain u32 counters; the byte lookups of every event row are
@@ -601,8 +675,8 @@ __global__ __launch_bounds__(THREADS) void alu_rows(const uint32_t* __restrict__
     for (int c = 0; c < W; c++) r[c] = 0;
     if (row < n_events) {
       const uint32_t* p = events + row * event_words(CHIP);
-      if constexpr (CHIP == MUL || CHIP == DIVREM) {
-        if constexpr (CHIP == MUL) mul_row(p, r); else divrem_row(p, r);
+      if constexpr (CHIP == MUL || CHIP == DIVREM || CHIP == MEMORY_INSTRS) {
+        if constexpr (CHIP == MUL) mul_row(p, r); else if constexpr (CHIP == DIVREM) divrem_row(p, r); else memory_instr_row(p, r);
         if (count) row_lookups<CHIP>(r, 0, LookupSink{hkeys, hvals, HASH_SLOTS - 1, counts});
       } else {
         AluEvent e{p[0], p[1], (CHIP == JUMP || CHIP == BRANCH) ? p[2] : (p[2] & 0xff), p[3], p[4], p[5], p[6]};

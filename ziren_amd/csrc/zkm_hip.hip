@@ -1106,6 +1106,7 @@ int zkm_ctx_create(int device, zkm_ctx** out) {
   HIP_CHECK(hipFuncSetAttribute((const void*)tracegen::alu_rows<tracegen::MUL>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
   HIP_CHECK(hipFuncSetAttribute((const void*)tracegen::alu_rows<tracegen::DIVREM>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
   HIP_CHECK(hipFuncSetAttribute((const void*)tracegen::cpu_rows, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+  HIP_CHECK(hipFuncSetAttribute((const void*)tracegen::alu_rows<tracegen::MEMORY_INSTRS>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
   HIP_CHECK(hipFuncSetAttribute((const void*)tracegen::alu_rows<tracegen::BRANCH>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
   HIP_CHECK(hipFuncSetAttribute((const void*)lde::lde_cols<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIP_CHECK(hipFuncSetAttribute((const void*)lde::lde_cols<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -1558,6 +1559,7 @@ static int tracegen_events(zkm_ctx* ctx, int chip, const void* events, size_t n_
       case tracegen::BRANCH: launch_alu_rows<tracegen::BRANCH>(ctx, d_events, n_events, height, m->d, counts); break;
       case tracegen::MUL: launch_alu_rows<tracegen::MUL>(ctx, d_events, n_events, height, m->d, counts); break;
       case tracegen::DIVREM: launch_alu_rows<tracegen::DIVREM>(ctx, d_events, n_events, height, m->d, counts); break;
+      case tracegen::MEMORY_INSTRS: launch_alu_rows<tracegen::MEMORY_INSTRS>(ctx, d_events, n_events, height, m->d, counts); break;
     }
     ctx->mark("trace generation");
     ctx->end_timing(false);  // synchronises: the caller's event buffer is free again
@@ -1630,6 +1632,12 @@ size_t zkm_tracegen_mul_width(void) { return (size_t)tracegen::chip_width(traceg
 int zkm_tracegen_mul(zkm_ctx* ctx, const zkm_comp_alu_event* events, size_t n_events, int fixed_log2_rows, zkm_byte_lookups* blu,
                      zkm_matrix** out) {
   return tracegen_events(ctx, tracegen::MUL, events, n_events, fixed_log2_rows, blu, out);
+}
+size_t zkm_tracegen_memory_instrs_width(void) { return (size_t)tracegen::chip_width(tracegen::MEMORY_INSTRS); }
+int zkm_tracegen_memory_instrs(zkm_ctx* ctx, const zkm_mem_instr_event* events, size_t n_events, int fixed_log2_rows, zkm_byte_lookups* blu,
+                               zkm_matrix** out) {
+  static_assert(sizeof(zkm_mem_instr_event) == 64, "event records mirror the #[repr(C)] executor structs");
+  return tracegen_events(ctx, tracegen::MEMORY_INSTRS, events, n_events, fixed_log2_rows, blu, out);
 }
 size_t zkm_tracegen_divrem_width(void) { return (size_t)tracegen::chip_width(tracegen::DIVREM); }
 int zkm_tracegen_divrem(zkm_ctx* ctx, const zkm_comp_alu_event* events, size_t n_events, int fixed_log2_rows, zkm_byte_lookups* blu,

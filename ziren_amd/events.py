@@ -439,3 +439,78 @@ def divrem_dependencies(divrem_events: np.ndarray):
     lt["b"] = abs_r[keep]
     lt["c"] = np.maximum(abs_c[keep], 1)
     return add, mul, lt
+
+
+# ---- memory instructions: MemInstrEvent (crates/core/executor/src/events/instr.rs:108-136, #[repr(C)], 64 bytes) -----------------------
+LB, LBU, LH, LHU, LW, LWL, LWR, LL, SB, SH, SW, SWL, SWR, SC = range(31, 45)
+LOADS, STORES = (LB, LBU, LH, LHU, LW, LWL, LWR, LL), (SB, SH, SW, SWL, SWR, SC)
+# mem_access is the #[repr(C)] enum MemoryRecordEnum (events/memory.rs:88-95): a 4-byte tag (Read = 0, Write = 1) and the union of
+# MemoryReadRecord (value, shard, timestamp, prev_shard, prev_timestamp) and MemoryWriteRecord (value, shard, timestamp, prev_value,
+# prev_shard, prev_timestamp)
+MEM_INSTR_EVENT = np.dtype([("shard", "<u4"), ("clk", "<u4"), ("pc", "<u4"), ("next_pc", "<u4"), ("opcode", "u1"), ("_pad", "u1", (3,)),
+                            ("a", "<u4"), ("b", "<u4"), ("c", "<u4"), ("mem_tag", "<u4"), ("mem", "<u4", (6,)), ("prev_a_val", "<u4")])
+assert MEM_INSTR_EVENT.itemsize == 64
+MEMORY_INSTRS_WIDTH = 79
+NUM_REGISTERS = 36      # crates/core/executor/src/register.rs:3
+
+
+def load_value(opcode: int, mem: int, addr: int, rt: int) -> int:
+    """The value a load writes to rt (execute_load, executor.rs:1925-2000)."""
+    i = addr & 3
+    if opcode == LB:
+        v = (mem >> (8 * i)) & 0xff
+        return v | 0xffffff00 if v & 0x80 else v
+    if opcode == LBU:
+        return (mem >> (8 * i)) & 0xff
+    if opcode in (LH, LHU):
+        v = (mem >> (8 * (i & 2))) & 0xffff
+        return v | 0xffff0000 if opcode == LH and v & 0x8000 else v
+    if opcode in (LW, LL):
+        return mem
+    if opcode == LWL:
+        sh = 24 - 8 * i
+        return ((rt & ~(0xffffffff << sh)) | (mem << sh)) & 0xffffffff
+    if opcode == LWR:
+        sh = 8 * i
+        return ((rt & ~(0xffffffff >> sh)) | (mem >> sh)) & 0xffffffff
+    raise ValueError(opcode)
+
+
+def store_value(opcode: int, mem: int, addr: int, rt: int) -> int:
+    """The word a store leaves in memory (execute_store, executor.rs:2002-2088)."""
+    i = addr & 3
+    if opcode == SB:
+        return (mem & ~(0xff << (8 * i)) | ((rt & 0xff) << (8 * i))) & 0xffffffff
+    if opcode == SH:
+        j = i & 2
+        return (mem & ~(0xffff << (8 * j)) | ((rt & 0xffff) << (8 * j))) & 0xffffffff
+    if opcode in (SW, SC):
+        return rt
+    if opcode == SWL:
+        sh = 24 - 8 * i
+        return ((mem & ~(0xffffffff >> sh)) | (rt >> sh)) & 0xffffffff
+    if opcode == SWR:
+        sh = 8 * i
+        return ((mem & ~((0xffffffff << sh) & 0xffffffff)) | ((rt << sh) & 0xffffffff)) & 0xffffffff
+    raise ValueError(opcode)
+
+
+def memory_dependencies(mem_events: np.ndarray) -> np.ndarray:
+    """emit_memory_dependencies (crates/core/executor/src/dependencies.rs:125-178): per event an ADD proving addr = b + c, and
+    for LB / LH of a negative value a SUB proving the sign extension (a = unsigned - 2^8 or 2^16); AddSub chip events in order."""
+    out = []
+    for e in mem_events:
+        addr = (int(e["b"]) + int(e["c"])) & 0xffffffff
+        out.append((UNUSED_PC, UNUSED_PC + DEFAULT_PC_INC, ADD, [0, 0, 0], 0, addr, int(e["b"]), int(e["c"])))
+        op = int(e["opcode"])
+        if op in (LB, LH):
+            mem = int(e["mem"][0])
+            off = addr & 3
+            if op == LB:
+                unsigned, msb, sign = (mem >> (8 * off)) & 0xff, (mem >> (8 * off)) & 0xff, 256
+            else:
+                unsigned = (mem >> (8 * (off & 2))) & 0xffff
+                msb, sign = unsigned >> 8, 65536
+            if msb >> 7:
+                out.append((UNUSED_PC, UNUSED_PC + DEFAULT_PC_INC, SUB, [0, 0, 0], 0, int(e["a"]), unsigned, sign))
+    return np.array(out, dtype=ALU_EVENT) if out else np.zeros(0, dtype=ALU_EVENT)

@@ -13,8 +13,8 @@ the record is what the reference's executor would emit for that program:
   execute_jump*       :2119-2148                  execute_condmov      :1830-1851
   rr_cpu / rw_cpu     :1041-1100 (timestamps clk + MemoryAccessPosition, events/memory.rs:29-40)
 
-Register file: 32 general registers, LO = 32, HI = 33. Not modelled (their chips are not built): loads / stores,
-syscalls, the other misc instructions.
+Register file: 32 general registers, LO = 32, HI = 33; loads and stores go to a small data region (execute_load / execute_store,
+:1925-2088; memory at position Memory = clk + 0). Not modelled (their chips are not built): syscalls, the other misc instructions.
 """
 import numpy as np
 
@@ -60,7 +60,7 @@ class Record:
 
     def __init__(self):
         self.cpu, self.alu, self.mul, self.divrem, self.branch, self.jump, self.mov_cond = [], {c: [] for c in E.CHIP_NAMES}, [], [], [], [], []
-        self.memory_local = []
+        self.memory_local, self.mem_instr = [], []
 
 
 def _alu(op, b, c):
@@ -79,7 +79,9 @@ def run(n_cycles: int, seed: int = 1, shard: int = 1, pc_base: int = 0x1000):
     R[0] = 0
     for i in range(1, 34, 5):     # small and special values so comparisons, shifts and divisions hit their corners
         R[i] = int(E._CORNERS[i % len(E._CORNERS)])
-    last = [(0, 0)] * 34           # (shard, timestamp) of the previous access; shard 0 = before this shard
+    last = {i: (0, 0) for i in range(34)}   # (shard, timestamp) of the previous access to a register / memory word; shard 0 = before this shard
+    R = dict(enumerate(R))         # registers 0..33 and, keyed by their byte address, the memory words that get touched
+    DATA, LOW = 0x00100000, 64     # a data region, and a few words whose address fits one byte (the chip's `addr < 256` branch)
     first = {}                     # register -> (shard, timestamp, value) on entry to this shard (ExecutionRecord::cpu_local_memory_access)
     program = {}
     rec = Record()
@@ -88,6 +90,8 @@ def run(n_cycles: int, seed: int = 1, shard: int = 1, pc_base: int = 0x1000):
     pending_jump_reg = None        # a register just loaded with a jump target
 
     def read(reg, clk, pos):
+        if reg not in R:
+            R[reg], last[reg] = 0, (0, 0)
         first.setdefault(reg, (last[reg][0], last[reg][1], R[reg]))
         r = (TAG_READ, (R[reg], shard, clk + pos, last[reg][0], last[reg][1]), None)
         last[reg] = (shard, clk + pos)
@@ -95,6 +99,8 @@ def run(n_cycles: int, seed: int = 1, shard: int = 1, pc_base: int = 0x1000):
 
     def write(reg, value, clk, pos):
         value = 0 if reg == 0 else value & 0xffffffff
+        if reg not in R:
+            R[reg], last[reg] = 0, (0, 0)
         first.setdefault(reg, (last[reg][0], last[reg][1], R[reg]))
         r = (TAG_WRITE, None, (value, shard, clk + pos, R[reg], last[reg][0], last[reg][1]))
         R[reg] = value
@@ -110,7 +116,7 @@ def run(n_cycles: int, seed: int = 1, shard: int = 1, pc_base: int = 0x1000):
         if pending_jump_reg is not None and not delay_slot:
             ins = (E.JUMP, dst(), pending_jump_reg, 0, 0, 1)
             pending_jump_reg = None
-        elif delay_slot or u < 0.50:
+        elif delay_slot or u < 0.36:
             op = _ALU_RR[int(rng.integers(0, len(_ALU_RR)))]
             form = rng.random()
             if form < 0.55:
@@ -120,6 +126,12 @@ def run(n_cycles: int, seed: int = 1, shard: int = 1, pc_base: int = 0x1000):
                 ins = (op, dst(), reg(), imm, 0, 1)
             else:
                 ins = (op, dst(), int(rng.integers(0, 1 << 32)), int(rng.integers(0, 1 << 16)), 1, 1)
+        elif u < 0.50:
+            op = int(rng.integers(E.LB, E.SC + 1))
+            rs = reg()
+            word_addr = (LOW + 4 * int(rng.integers(0, 40))) if rng.random() < 0.1 else DATA + 4 * int(rng.integers(0, 96))
+            off = 0 if op in (E.LW, E.LL, E.SW, E.SC) else 2 * int(rng.integers(0, 2)) if op in (E.LH, E.LHU, E.SH) else int(rng.integers(0, 4))
+            ins = (op, dst(), rs, (word_addr + off - R[rs]) & 0xffffffff, 0, 1)   # the offset that lands on the chosen address
         elif u < 0.58:
             ins = (E.CLZ if rng.random() < 0.5 else E.CLO, dst(), reg(), 0, 0, 1)
         elif u < 0.66:
@@ -150,7 +162,7 @@ def run(n_cycles: int, seed: int = 1, shard: int = 1, pc_base: int = 0x1000):
         op, op_a, op_b, op_c, imm_b, imm_c = ins
         # ---- execute it
         next_next_pc = next_pc + 4
-        a_rec = b_rec = c_rec = hi_rec = None
+        a_rec = b_rec = c_rec = hi_rec = m_rec = None
         hi = None
         was_delay_slot, delay_slot = delay_slot, False
         if op in _CHIP_OF or op in (E.MUL, E.MULT, E.MULTU, E.DIV, E.DIVU, E.MOD, E.MODU):
@@ -184,6 +196,34 @@ def run(n_cycles: int, seed: int = 1, shard: int = 1, pc_base: int = 0x1000):
                 (rec.mul if op in (E.MUL, E.MULT, E.MULTU) else rec.divrem).append(ev)
             else:
                 rec.alu[_CHIP_OF[op]].append((pc, next_pc, op, [0, 0, 0], 0, a, b, c))
+        elif op in E.LOADS:
+            b_rec = read(op_b, clk, POS_B)
+            b, c = b_rec[1][0], op_c
+            rt = R[op_a]                                   # peeked, no record: the write record's prev_value carries it
+            addr = (b + c) & 0xffffffff
+            m_rec = read(addr & 0xfffffffc, clk, 0)       # MemoryAccessPosition::Memory
+            a = E.load_value(op, m_rec[1][0], addr, rt)
+            a_rec = write(op_a, a, clk, POS_A)
+            hi = rt
+            rec.mem_instr.append((shard, clk, pc, next_pc, op, [0, 0, 0], a, b, c, TAG_READ, list(m_rec[1]) + [0], rt))
+        elif op in E.STORES:
+            b_rec = read(op_b, clk, POS_B)
+            b, c = b_rec[1][0], op_c
+            if op == E.SC:
+                rt = R[op_a]
+            else:
+                a_rec = read(op_a, clk, POS_A)
+                rt = a_rec[1][0]
+            addr = (b + c) & 0xffffffff
+            aligned = addr & 0xfffffffc
+            m_rec = write(aligned, E.store_value(op, R.get(aligned, 0), addr, rt), clk, 0)
+            if op == E.SC:
+                a_rec = write(op_a, 1, clk, POS_A)
+                a = 1
+            else:
+                a = rt
+            hi = rt
+            rec.mem_instr.append((shard, clk, pc, next_pc, op, [0, 0, 0], a, b, c, TAG_WRITE, list(m_rec[2]), rt))
         elif op in _BRANCH:
             if op in _ONE_OPERAND:
                 b = 0
@@ -225,7 +265,7 @@ def run(n_cycles: int, seed: int = 1, shard: int = 1, pc_base: int = 0x1000):
             raise AssertionError(op)
         del was_delay_slot
         # op_a_value of the Cpu row is `a` as computed (a write to $0 stores 0 but the event keeps the result)
-        rec.cpu.append((clk, pc, next_pc, next_next_pc, a, a_rec, b, b_rec, c, c_rec, hi, hi_rec))
+        rec.cpu.append((clk, pc, next_pc, next_next_pc, a, a_rec, b, b_rec, c, c_rec, hi, hi_rec, m_rec))
         pc, next_pc = next_pc, next_next_pc
 
     # ---- pack
@@ -248,11 +288,11 @@ def run(n_cycles: int, seed: int = 1, shard: int = 1, pc_base: int = 0x1000):
 
     cpu = np.zeros(len(rec.cpu), dtype=CPU_EVENT)
     none = opt(None)
-    for i, (clk, p, np_, nnp, a, a_rec, b, b_rec, c, c_rec, hi, hi_rec) in enumerate(rec.cpu):
+    for i, (clk, p, np_, nnp, a, a_rec, b, b_rec, c, c_rec, hi, hi_rec, m_rec) in enumerate(rec.cpu):
         e = cpu[i]
         e["clk"], e["pc"], e["next_pc"], e["next_next_pc"], e["a"], e["b"], e["c"] = clk, p, np_, nnp, a, b, c
         e["a_record"], e["b_record"], e["c_record"], e["hi_record"] = opt(a_rec), opt(b_rec), opt(c_rec), opt(hi_rec)
-        e["memory_record"] = none
+        e["memory_record"] = opt(m_rec) if m_rec is not None else none
         e["hi"]["tag"], e["hi"]["value"] = (0, hi) if hi is not None else (1, 0)
     out = Record()
     out.cpu = cpu
@@ -262,6 +302,7 @@ def run(n_cycles: int, seed: int = 1, shard: int = 1, pc_base: int = 0x1000):
     out.branch = np.array(rec.branch, dtype=E.BRANCH_EVENT) if rec.branch else np.zeros(0, dtype=E.BRANCH_EVENT)
     out.jump = np.array(rec.jump, dtype=E.JUMP_EVENT) if rec.jump else np.zeros(0, dtype=E.JUMP_EVENT)
     out.mov_cond = np.array(rec.mov_cond, dtype=E.MOV_COND_EVENT) if rec.mov_cond else np.zeros(0, dtype=E.MOV_COND_EVENT)
+    out.mem_instr = np.array(rec.mem_instr, dtype=E.MEM_INSTR_EVENT) if rec.mem_instr else np.zeros(0, dtype=E.MEM_INSTR_EVENT)
     out.memory_local = np.array([(reg, first[reg], (last[reg][0], last[reg][1], R[reg])) for reg in sorted(first)], dtype=MEMORY_LOCAL_EVENT) \
         if first else np.zeros(0, dtype=MEMORY_LOCAL_EVENT)
     pv = {"start_pc": pc_base, "next_pc": int(cpu["next_pc"][-1]) if len(cpu) else pc_base, "execution_shard": shard, "shard": shard}
@@ -275,11 +316,11 @@ def add_dependencies(rec: Record) -> Record:
     lt_dep, add_dep = E.branch_dependencies(rec.branch)
     div_add, div_mul, div_lt = E.divrem_dependencies(rec.divrem)
     alu[E.CHIP_SHIFT_RIGHT] = np.concatenate([alu[E.CHIP_SHIFT_RIGHT], E.cloclz_dependencies(alu[E.CHIP_CLO_CLZ])])
-    alu[E.CHIP_ADD_SUB] = np.concatenate([alu[E.CHIP_ADD_SUB], E.jump_dependencies(rec.jump), add_dep, div_add])
+    alu[E.CHIP_ADD_SUB] = np.concatenate([alu[E.CHIP_ADD_SUB], E.jump_dependencies(rec.jump), add_dep, div_add, E.memory_dependencies(rec.mem_instr)])
     alu[E.CHIP_LT] = np.concatenate([alu[E.CHIP_LT], lt_dep, div_lt])
     out = Record()
     out.cpu, out.alu, out.branch, out.jump, out.mov_cond, out.divrem = rec.cpu, alu, rec.branch, rec.jump, rec.mov_cond, rec.divrem
-    out.memory_local = rec.memory_local
+    out.memory_local, out.mem_instr = rec.memory_local, rec.mem_instr
     out.mul = np.concatenate([rec.mul, div_mul])
     return out
 
