@@ -1,0 +1,14 @@
+#!/usr/bin/env python3
+"""Copy the per-row chip costs the reference pins (crates/core/executor/src/artifacts/mips_costs.json, checked by its own
+`core_air_cost_consistency` test, crates/core/machine/src/mips/mod.rs:748-756) for the chips that are recorded here into
+tests/golden/mips_costs.json. Data only. Run in the build container, where /root/reference exists."""
+import json
+import os
+
+REF = os.environ.get("ZKM_REFERENCE", "/root/reference")
+CHIPS = ["Cpu", "Program", "AddSub", "Bitwise", "Lt", "ShiftLeft", "ShiftRight", "CloClz", "Mul", "DivRem", "Branch", "Jump", "MovCond",
+         "MemoryInstrs", "MemoryLocal", "Byte"]
+src = json.load(open(os.path.join(REF, "crates/core/executor/src/artifacts/mips_costs.json")))
+out = {"generated_by": "tests/golden/gen_mips_costs.py", "costs": {c: src[c] for c in CHIPS}}
+json.dump(out, open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "mips_costs.json"), "w"), indent=0)
+print(out["costs"])

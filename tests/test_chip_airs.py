@@ -48,6 +48,21 @@ def test_branch_constraints_hold(oracle):
     assert kinds.count(air.KIND_INSTRUCTION) == 3 and kinds.count(air.KIND_BYTE) == 4 and len(rec.receives) == 1
 
 
+def test_recorded_costs_match_the_reference():
+    """Chip::cost (crates/stark/src/chip.rs:152-163) = preprocessed + main + 4 * permutation + 4 * quotient columns of every
+    recorded chip equals the figure the reference pins in mips_costs.json (its core_air_cost_consistency test): the column
+    layouts, the number of lookups (permutation width) and the constraint degree (quotient width) all enter."""
+    import json
+    import os
+    want = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "mips_costs.json")))["costs"]
+    recs = [chips.record_chip(c, 10) for c in sorted(E.CHIP_NAMES)] + [
+        chips.record_cpu_chip(10), chips.record_program_chip(10), chips.record_mul_chip(10), chips.record_divrem_chip(10),
+        chips.record_branch_chip(10), chips.record_jump_chip(10), chips.record_mov_cond_chip(10), chips.record_memory_instrs_chip(10),
+        chips.record_memory_local_chip(10), chips.record_byte_chip()]
+    got = {r.name: r.prep_width + r.main_width + 4 * r.perm_ext_width + (4 << r.log_quotient_degree) for r in recs}
+    assert got == want
+
+
 def test_mul_constraints_hold(oracle):
     rec = chips.record_mul_constraints()
     for n in (0, 64, 3000):
