@@ -340,6 +340,11 @@ typedef struct zkm_instruction {
 size_t zkm_tracegen_cpu_width(void);
 int zkm_tracegen_cpu(zkm_ctx* ctx, const zkm_cpu_event* events, size_t n_events, const zkm_instruction* program, size_t n_instr,
                      uint32_t pc_base, uint32_t shard, int fixed_log2_rows, zkm_byte_lookups* blu, zkm_matrix** out);
+/* The same, and in the same pass over the events (which are uploaded once) the Program chip's multiplicity trace
+ * (zkm_tracegen_program_mults below) into *program_mults_out, padded to program_fixed_log2_rows. */
+int zkm_tracegen_cpu_and_program(zkm_ctx* ctx, const zkm_cpu_event* events, size_t n_events, const zkm_instruction* program,
+                                 size_t n_instr, uint32_t pc_base, uint32_t shard, int fixed_log2_rows, int program_fixed_log2_rows,
+                                 zkm_byte_lookups* blu, zkm_matrix** out, zkm_matrix** program_mults_out);
 /* The Program chip (crates/core/machine/src/program/mod.rs): its preprocessed table (pc, instruction columns; 14 columns,
  * generate_preprocessed_trace :62-101) for zkm_pk_setup, and its one-column multiplicity trace (generate_trace :113-146:
  * how many CpuEvents fetched each pc). */

@@ -217,7 +217,11 @@ def test_gpu_cpu_and_program_tracegen_match_oracle(hip_ctx, oracle):
         mults = hip_ctx.tracegen_byte_mults(blu)
         assert np.array_equal(F.from_monty(mults.to_host()), counts), n
         m.free(); mults.free(); blu.free()
-        for which, born in ((0, hip_ctx.tracegen_program(prog, PC_BASE)), (1, hip_ctx.tracegen_program_mults(rec.cpu, len(prog), PC_BASE))):
+        both = hip_ctx.tracegen_cpu_and_program(rec.cpu, prog, PC_BASE, SHARD, fixed)     # one upload of the events for both chips
+        assert np.array_equal(both[0].to_host(), want)
+        both[0].free()
+        for which, born in ((0, hip_ctx.tracegen_program(prog, PC_BASE)), (1, hip_ctx.tracegen_program_mults(rec.cpu, len(prog), PC_BASE)),
+                            (1, both[1])):
             want = oracle.tracegen_program(which, rec.cpu, prog, PC_BASE)
             assert (born.height, born.width) == want.shape and np.array_equal(born.to_host(), want), (n, which)
             born.free()

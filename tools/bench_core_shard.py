@@ -75,7 +75,8 @@ def main():
         tg_kernel = 0.0
         for (c, ev, _), lh in zip(work, heights):
             if c == "cpu":
-                born.append(ctx.tracegen_cpu(ev, pprog, PC_BASE, SHARD, lh, blu))
+                cpu_trace, program_mults = ctx.tracegen_cpu_and_program(ev, pprog, PC_BASE, SHARD, lh, plh, blu)
+                born.append(cpu_trace)
             elif c == "jump":
                 born.append(ctx.tracegen_jump(ev, lh))
             elif c == "mov_cond":
@@ -94,7 +95,7 @@ def main():
                 born.append(ctx.tracegen_alu(c, ev, lh, blu))
             tg_kernel += sum(ms for name, ms, _, _ in ctx.kernel_timings() if name.startswith("tracegen"))
         born.append(ctx.tracegen_byte_mults(blu))
-        born.append(ctx.tracegen_program_mults(work[0][1], len(prog), PC_BASE, plh))
+        born.append(program_mults)
         blu.free()
         t1 = time.perf_counter()
         proof = hp.prove_shard(pk, pvs, born, ch0.copy(), out=out)

@@ -739,7 +739,8 @@ __device__ __forceinline__ void access_lookups(const uint32_t* m, const LookupSi
 // out: column-major, `height` rows; rows past n_events are the chip's padding rows. counts as in alu_rows.
 __global__ __launch_bounds__(THREADS) void cpu_rows(const uint32_t* __restrict__ events, size_t n_events, const uint32_t* __restrict__ program,
                                                     size_t n_instr, uint32_t pc_base, uint32_t shard, size_t height,
-                                                    uint32_t* __restrict__ out, uint32_t* counts, int tiles, int* bad_pc) {
+                                                    uint32_t* __restrict__ out, uint32_t* counts, int tiles, int* bad_pc,
+                                                    uint32_t* program_counts /* nullable: plain fetch counters, one per instruction */) {
   using namespace cpucols;
   extern __shared__ uint32_t hash_lds[];
   uint32_t* hkeys = hash_lds;
@@ -763,6 +764,7 @@ __global__ __launch_bounds__(THREADS) void cpu_rows(const uint32_t* __restrict__
       const size_t idx = (size_t)(pc - pc_base) >> 2;   // Program::fetch
       const bool in_program = pc >= pc_base && idx < n_instr;
       if (!in_program) *bad_pc = 1;
+      else if (program_counts) atomicAdd(program_counts + idx, 1u);   // ProgramChip::generate_trace in the same pass
       const uint32_t* in = program + (in_program ? idx : 0) * INSTRUCTION_WORDS;
       const uint32_t o = in[0] & 0xff;
       r[SHARD] = shard;

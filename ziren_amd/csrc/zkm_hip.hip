@@ -1663,8 +1663,9 @@ static size_t padded_trace_rows(size_t n_records, int fixed_log2_rows, const cha
 }
 
 size_t zkm_tracegen_cpu_width(void) { return (size_t)tracegen::CPU_WIDTH; }
-int zkm_tracegen_cpu(zkm_ctx* ctx, const zkm_cpu_event* events, size_t n_events, const zkm_instruction* program, size_t n_instr,
-                     uint32_t pc_base, uint32_t shard, int fixed_log2_rows, zkm_byte_lookups* blu, zkm_matrix** out) {
+int zkm_tracegen_cpu_and_program(zkm_ctx* ctx, const zkm_cpu_event* events, size_t n_events, const zkm_instruction* program, size_t n_instr,
+                                 uint32_t pc_base, uint32_t shard, int fixed_log2_rows, int program_fixed_log2_rows, zkm_byte_lookups* blu,
+                                 zkm_matrix** out, zkm_matrix** program_mults_out) {
   API_BEGIN
   static_assert(sizeof(zkm_cpu_event) == 4 * tracegen::CPU_EVENT_WORDS && sizeof(zkm_instruction) == 4 * tracegen::INSTRUCTION_WORDS,
                 "event records mirror the #[repr(C)] executor structs");
@@ -1672,13 +1673,20 @@ int zkm_tracegen_cpu(zkm_ctx* ctx, const zkm_cpu_event* events, size_t n_events,
   HIP_CHECK(hipSetDevice(ctx->device));
   if (n_events && (!events || !program || !n_instr)) throw std::runtime_error("zkm_tracegen_cpu: null events or program");
   const size_t height = padded_trace_rows(n_events, fixed_log2_rows, "zkm_tracegen_cpu");
+  const size_t pheight = program_mults_out ? padded_trace_rows(n_instr, program_fixed_log2_rows, "zkm_tracegen_cpu (program)") : 0;
   ctx->begin_timing();
   zkm_matrix* m = new zkm_matrix();
+  zkm_matrix* pm = program_mults_out ? new zkm_matrix() : nullptr;
   m->h = height; m->w = tracegen::CPU_WIDTH;
   uint32_t *d_events = nullptr, *d_program = nullptr;
   int* d_bad = nullptr;
   try {
     m->d = ctx->alloc_n<uint32_t>(height * m->w);
+    if (pm) {
+      pm->h = pheight; pm->w = 1;
+      pm->d = ctx->alloc_n<uint32_t>(pheight);
+      HIP_CHECK(hipMemsetAsync(pm->d, 0, pheight * 4, ctx->stream));
+    }
     d_events = (uint32_t*)ctx->alloc(std::max<size_t>(n_events * sizeof(zkm_cpu_event), 4));
     d_program = (uint32_t*)ctx->alloc(std::max<size_t>(n_instr * sizeof(zkm_instruction), 4));
     d_bad = (int*)ctx->alloc(4);
@@ -1690,7 +1698,11 @@ int zkm_tracegen_cpu(zkm_ctx* ctx, const zkm_cpu_event* events, size_t n_events,
     KLAUNCH(ctx, "tracegen_cpu", 280.0 * n_events + 4.0 * height * tracegen::CPU_WIDTH, tracegen::cpu_rows,
             dim3(div_up(height, (size_t)tiles * tracegen::THREADS)), dim3(tracegen::THREADS),
             counts ? 2 * tracegen::HASH_SLOTS * sizeof(uint32_t) : 0, (const uint32_t*)d_events, n_events, (const uint32_t*)d_program, n_instr,
-            pc_base, shard, height, m->d, counts, tiles, d_bad);
+            pc_base, shard, height, m->d, counts, tiles, d_bad, pm ? pm->d : (uint32_t*)nullptr);
+    if (pm) {
+      hipLaunchKernelGGL(tracegen::counts_to_field, dim3(div_up(pheight, 256)), dim3(256), 0, ctx->stream, pm->d, pheight);
+      LAUNCH_CHECK();
+    }
     int bad = 0;
     HIP_CHECK(hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, ctx->stream));
     ctx->mark("trace generation");
@@ -1701,14 +1713,22 @@ int zkm_tracegen_cpu(zkm_ctx* ctx, const zkm_cpu_event* events, size_t n_events,
     if (d_program) ctx->release(d_program);
     if (d_bad) ctx->release(d_bad);
     if (m->d) ctx->release(m->d);
+    if (pm && pm->d) ctx->release(pm->d);
     delete m;
+    delete pm;
     throw;
   }
   ctx->release(d_events);
   ctx->release(d_program);
   ctx->release(d_bad);
   *out = m;
+  if (pm) *program_mults_out = pm;
   API_END
+}
+
+int zkm_tracegen_cpu(zkm_ctx* ctx, const zkm_cpu_event* events, size_t n_events, const zkm_instruction* program, size_t n_instr,
+                     uint32_t pc_base, uint32_t shard, int fixed_log2_rows, zkm_byte_lookups* blu, zkm_matrix** out) {
+  return zkm_tracegen_cpu_and_program(ctx, events, n_events, program, n_instr, pc_base, shard, fixed_log2_rows, -1, blu, out, nullptr);
 }
 
 int zkm_tracegen_program(zkm_ctx* ctx, const zkm_instruction* program, size_t n_instr, uint32_t pc_base, int fixed_log2_rows,

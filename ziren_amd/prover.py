@@ -185,6 +185,20 @@ class Context:
                                                        C.c_int(fixed_log2_rows), C.byref(h)))
         return self._born(h)
 
+    def tracegen_cpu_and_program(self, events: np.ndarray, program: np.ndarray, pc_base: int, shard: int, fixed_log2_rows: int = -1,
+                                 program_fixed_log2_rows: int = -1, blu: "ByteLookups" = None):
+        """The Cpu trace and, from the same upload of the events, the Program chip's multiplicity trace
+        (zkm_tracegen_cpu_and_program). Returns (cpu, program_mults)."""
+        from . import miniexec as _m
+        ev = np.ascontiguousarray(events, dtype=_m.CPU_EVENT)
+        prog = np.ascontiguousarray(program, dtype=_m.INSTRUCTION)
+        h, hp = C.c_void_p(), C.c_void_p()
+        lib.check(lib.load().zkm_tracegen_cpu_and_program(
+            self.h, C.c_void_p(ev.ctypes.data if len(ev) else None), C.c_size_t(len(ev)), C.c_void_p(prog.ctypes.data if len(prog) else None),
+            C.c_size_t(len(prog)), C.c_uint32(pc_base), C.c_uint32(shard), C.c_int(fixed_log2_rows), C.c_int(program_fixed_log2_rows),
+            blu.h if blu is not None else None, C.byref(h), C.byref(hp)))
+        return self._born(h), self._born(hp)
+
     def tracegen_program(self, program: np.ndarray, pc_base: int, fixed_log2_rows: int = -1) -> DeviceMatrix:
         """The Program chip's preprocessed table on the device (zkm_tracegen_program)."""
         from . import miniexec as _m
