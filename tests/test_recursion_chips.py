@@ -33,9 +33,10 @@ def test_row_counts():
         R.padded_rows(1000, 5)
 
 
-def balanced_shard(n_base, n_ext, n_const, seed, heights=(-1, -1, -1)):
-    """BaseAlu + ExtAlu + MemoryConst over one consistent program: (chips with host traces, flat record streams)."""
-    prog = R.balanced_program(n_base, n_ext, n_const, seed)
+def balanced_shard(n_base, n_ext, n_const, seed, heights=(-1, -1, -1), n_var=0, n_select=0):
+    """BaseAlu + ExtAlu + MemoryConst (+ MemoryVar + Select) over one consistent program: (chips with host traces, flat
+    record streams (preprocessed words, main words))."""
+    prog = R.balanced_program(n_base, n_ext, n_const, seed, n_var=n_var, n_select=n_select)
     specs = (("base_instrs", "base_events", R.BASE_VALUE_COLS, False), ("ext_instrs", "ext_events", R.EXT_VALUE_COLS, True))
     recs, streams = [], []
     for idx, (ik, ek, vw, ext) in enumerate(specs):
@@ -50,7 +51,63 @@ def balanced_shard(n_base, n_ext, n_const, seed, heights=(-1, -1, -1)):
     rc.trace, rc.prep_trace = np.zeros((prep.shape[0], 1), dtype=np.uint32), prep
     recs.append(rc)
     streams.append((prog["mem_entries"], None))
+    if n_var:
+        prep = R.flat_trace(prog["var_prep"], 2 * R.VAR_MEM_ENTRIES_PER_ROW, -1, R.VAR_MEM_ENTRIES_PER_ROW)
+        rc = R.record_mem_var(prep.shape[0].bit_length() - 1, prep_index=3)
+        rc.trace, rc.prep_trace = R.flat_trace(prog["var_values"], 4 * R.VAR_MEM_ENTRIES_PER_ROW, -1, R.VAR_MEM_ENTRIES_PER_ROW), prep
+        recs.append(rc)
+        streams.append((prog["var_prep"], prog["var_values"]))
+    if n_select:
+        prep = R.flat_trace(prog["select_prep"], R.SELECT_PREP_COLS, -1, 1)
+        rc = R.record_select(prep.shape[0].bit_length() - 1, prep_index=4)
+        rc.trace, rc.prep_trace = R.flat_trace(prog["select_events"], R.SELECT_COLS, -1, 1), prep
+        recs.append(rc)
+        streams.append((prog["select_prep"], prog["select_events"]))
     return recs, streams
+
+
+def tally_of(recs):
+    tally = {}
+    for r in recs:
+        t, pt = F.from_monty(r.trace), F.from_monty(r.prep_trace)
+        main = {c: t[:, c].astype(np.uint64) for c in range(t.shape[1])}
+        prep = {c: pt[:, c].astype(np.uint64) for c in range(pt.shape[1])}
+        for sign, lks in ((1, r.sends), (-1, r.receives)):
+            for lk in lks:
+                vals = np.stack([np.broadcast_to(v.apply_np(prep, main), (t.shape[0],)) for v in lk.values], axis=1)
+                mult = np.broadcast_to(lk.multiplicity.apply_np(prep, main), (t.shape[0],))
+                for row in np.nonzero(mult)[0]:
+                    key = tuple(int(x) for x in vals[row])
+                    tally[key] = (tally.get(key, 0) + sign * int(mult[row])) % F.P
+    return tally
+
+
+def test_select_and_mem_var(oracle):
+    """Select (out1 = bit ? in2 : in1, out2 the other) and MemoryVar (witnessed values) join the program: constraints hold,
+    a wrong output is caught, and the five chips' memory lookups still cancel exactly; the oracle's proof verifies."""
+    from ziren_amd import synth
+    rs = R.record_select(constraints_only=True)
+    recs, streams = balanced_shard(400, 250, 40, seed=13, n_var=90, n_select=150)
+    assert [r.name for r in recs] == ["BaseAlu", "ExtAlu", "MemoryConst", "MemoryVar", "Select"]
+    sel = recs[4]
+    main, prep = F.from_monty(sel.trace), F.from_monty(sel.prep_trace)
+    assert air.debug_constraints(rs.b, main, prep=prep) == [] and main[:150, 0].max() == 1 and set(main[:150, 0]) == {0, 1}
+    bad = main.copy()
+    bad[7, 1] = (int(bad[7, 1]) + 1) % F.P
+    assert {row for _, row in air.debug_constraints(rs.b, bad, prep=prep)} == {7}
+    assert len(rs.sends) == 2 and len(rs.receives) == 3 and len(R.record_mem_var(constraints_only=True).sends) == 2
+    t = tally_of(recs)
+    assert t and not any(t.values())
+    assert any(tally_of(recs[:3] + recs[4:]).values())      # without MemoryVar the selects' bits are never written
+    fri = abi.FriConfig(2, 42, 16)
+    pv = np.zeros(synth.PROOF_MAX_NUM_PVS, dtype=np.uint32)
+    igcs = F.to_monty(np.zeros(14, dtype=np.uint64))
+    opk = oracle.Pk([r.prep_trace for r in recs], [1] * 5, F.to_monty(0), igcs, 2)
+    ch = oracle.new_challenger()
+    opk.observe_into(ch)
+    start = ch.copy()
+    proof, _ = oracle.prove_shard(opk, recs, [c.trace for c in recs], pv, fri, synth.NUM_PV_ELTS, ch)
+    assert oracle.verify_shard(opk, recs, fri, synth.NUM_PV_ELTS, start.copy(), proof) == 0
 
 
 def test_mem_const_and_balance():
@@ -113,12 +170,12 @@ def test_gpu_flat_tracegen(hip_ctx):
 @pytest.mark.gpu
 @pytest.mark.parametrize("log_blowup,queries", [(2, 42), (3, 28)])
 def test_gpu_recursion_alu_shard(hip_ctx, oracle, log_blowup, queries):
-    """BaseAlu + ExtAlu + MemoryConst over one consistent program under the compress / shrink FRI configurations
+    """BaseAlu + ExtAlu + MemoryConst + MemoryVar + Select over one consistent program under the compress / shrink FRI configurations
     (crates/stark/src/kb31_poseidon2.rs:215-241): device-built traces, preprocessed tables in the proving key,
     memory lookups balancing between the real chips, proof bit-identical to the oracle's and accepted by the
     restated verifier."""
     from ziren_amd import prover, synth
-    recs, streams = balanced_shard(3500, 2000, 200, seed=40, heights=(10, 9, 9))
+    recs, streams = balanced_shard(3500, 2000, 200, seed=40, heights=(10, 9, 9), n_var=300, n_select=400)
     fri = abi.FriConfig(log_blowup, queries, 16)
     pv = np.zeros(synth.PROOF_MAX_NUM_PVS, dtype=np.uint32)
     igcs = F.to_monty(np.zeros(14, dtype=np.uint64))
@@ -127,14 +184,14 @@ def test_gpu_recursion_alu_shard(hip_ctx, oracle, log_blowup, queries):
     preps = [hip_ctx.tracegen_flat(ins, r.prep_trace.shape[1], r.log_height) for (ins, _), r in zip(streams, recs)]
     for m, r in zip(preps, recs):
         assert np.array_equal(m.to_host(), r.prep_trace)
-    pk = hp.setup(preps, [1, 1, 1], F.to_monty(0), igcs)
-    opk = oracle.Pk([r.prep_trace for r in recs], [1, 1, 1], F.to_monty(0), igcs, log_blowup)
+    pk = hp.setup(preps, [1] * len(recs), F.to_monty(0), igcs)
+    opk = oracle.Pk([r.prep_trace for r in recs], [1] * len(recs), F.to_monty(0), igcs, log_blowup)
     assert np.array_equal(pk.commit, opk.commitment())
     ch = prover.new_challenger()
     pk.observe_into(ch)
     start = ch.copy()
-    born = [hip_ctx.tracegen_flat(ev, r.trace.shape[1], r.log_height) for (_, ev), r in zip(streams[:2], recs[:2])]
-    born.append(hip_ctx.upload(recs[2].trace))
+    born = [hip_ctx.tracegen_flat(ev, r.trace.shape[1], r.log_height) if ev is not None else hip_ctx.upload(r.trace)
+            for (_, ev), r in zip(streams, recs)]
     proof = hp.prove_shard(pk, pv, born, ch).copy()
     och = oracle.new_challenger()
     opk.observe_into(och)

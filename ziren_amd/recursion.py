@@ -126,7 +126,47 @@ def record_mem_const(log_height: int = 10, prep_index: int = 0, lqd: int = 1, co
                               program=program, lookups_blob=air.encode_lookups(r.sends, r.receives), num_constraints=int(program[2]))
 
 
-def balanced_program(n_base: int, n_ext: int, n_const: int = 64, seed: int = 1):
+VAR_MEM_ENTRIES_PER_ROW = 2      # NUM_VAR_MEM_ENTRIES_PER_ROW (chips/mem/variable.rs:16)
+SELECT_PREP_COLS, SELECT_COLS = 8, 5   # (is_real, addrs {bit, out1, out2, in1, in2}, mult1, mult2); SelectIo {bit, out1, out2, in1, in2}
+
+
+def _finish_rec(r, name, log_height, main_width, prep_index, lqd=1):
+    r.b.perm_ext_width = air.local_permutation_trace_width(len(r.sends) + len(r.receives), 1 << lqd)
+    air.eval_permutation_constraints(r.b, r.sends, r.receives, 1 << lqd, False)
+    program = r.b.assemble()
+    return chips.RecordedChip(name=name, log_height=log_height, main_width=main_width, prep_width=r.b.prep_width, prep_index=prep_index,
+                              log_quotient_degree=lqd, local_only=True, sends=r.sends, receives=r.receives, program=program,
+                              lookups_blob=air.encode_lookups(r.sends, r.receives), num_constraints=int(program[2]))
+
+
+def record_mem_var(log_height: int = 10, prep_index: int = 0, constraints_only: bool = False):
+    """MemoryVar chip (crates/recursion/core/src/chips/mem/variable.rs): witnessed values — two 4-word blocks per row in the
+    main trace — written to the addresses / with the multiplicities of the preprocessed trace (two (addr, mult) pairs per row);
+    `eval` sends every entry (:157-168)."""
+    r = _RecRec(4 * VAR_MEM_ENTRIES_PER_ROW, 2 * VAR_MEM_ENTRIES_PER_ROW)
+    for k in range(VAR_MEM_ENTRIES_PER_ROW):
+        r.send_block(r.prep[2 * k], r.local[4 * k:4 * k + 4], r.prep[2 * k + 1])
+    return r if constraints_only else _finish_rec(r, "MemoryVar", log_height, 4 * VAR_MEM_ENTRIES_PER_ROW, prep_index)
+
+
+def record_select(log_height: int = 10, prep_index: int = 0, constraints_only: bool = False):
+    """Select chip (crates/recursion/core/src/chips/select.rs:232-257): out1 = bit ? in2 : in1, out2 = bit ? in1 : in2; one
+    instruction per row; reads bit, in1, in2 (multiplicity is_real), writes out1 / out2 with their multiplicities."""
+    r = _RecRec(SELECT_COLS, SELECT_PREP_COLS)
+    p, l, b = r.prep, r.local, r.b
+    is_real, a_bit, a_out1, a_out2, a_in1, a_in2, mult1, mult2 = (p[i] for i in range(8))
+    bit, out1, out2, in1, in2 = (l[i] for i in range(5))
+    r.receive_single(a_bit, bit, is_real)
+    r.receive_single(a_in1, in1, is_real)
+    r.receive_single(a_in2, in2, is_real)
+    r.send_single(a_out1, out1, mult1)
+    r.send_single(a_out2, out2, mult2)
+    b.assert_eq(out1, bit * in2 + (1 - bit) * in1)
+    b.assert_eq(out2, bit * in1 + (1 - bit) * in2)
+    return r if constraints_only else _finish_rec(r, "Select", log_height, SELECT_COLS, prep_index)
+
+
+def balanced_program(n_base: int, n_ext: int, n_const: int = 64, seed: int = 1, n_var: int = 0, n_select: int = 0):
     """A synthetic recursion program whose memory lookups balance exactly, as a real one's do: constants are written by
     MemoryConst entries, every ALU instruction reads two earlier values (constants or earlier results of its own field)
     and writes one, and each write's multiplicity is the number of later reads; a few results are read back by
@@ -159,6 +199,26 @@ def balanced_program(n_base: int, n_ext: int, n_const: int = 64, seed: int = 1):
         v = [int(x) for x in rng.integers(0, P, 4)] if ext else [int(rng.integers(0, P)), 0, 0, 0]
         entries[a] = {"val": v, "reads": 0, "kind": "const"}
         pools["ext" if ext else "base"].append(a)
+    # witnessed values (MemoryVar): base elements, every fourth one a bit; then the selects, whose outputs join the base pool
+    bits, var_rows, select_rows = [], [], []
+    for i in range(n_var):
+        a = new_addr()
+        v = [int(rng.integers(0, 2)) if i % 4 == 0 else int(rng.integers(0, P)), 0, 0, 0]
+        entries[a] = {"val": v, "reads": 0, "kind": "var"}
+        var_rows.append(a)
+        (bits if i % 4 == 0 else pools["base"]).append(a)
+    for _ in range(n_select if bits else 0):
+        ab = bits[int(rng.integers(0, len(bits)))]
+        a1, a2 = (pools["base"][int(rng.integers(0, len(pools["base"])))] for _ in range(2))
+        bit, x, y = entries[ab]["val"][0], entries[a1]["val"][0], entries[a2]["val"][0]
+        o1, o2 = (y, x) if bit else (x, y)
+        ao1, ao2 = new_addr(), new_addr()
+        for a in (ab, a1, a2):
+            entries[a]["reads"] += 1
+        entries[ao1] = {"val": [o1, 0, 0, 0], "reads": 0, "kind": "base"}
+        entries[ao2] = {"val": [o2, 0, 0, 0], "reads": 0, "kind": "base"}
+        pools["base"] += [ao1, ao2]
+        select_rows.append((ab, ao1, ao2, a1, a2, bit, o1, o2, x, y))
     base_rows, ext_rows = [], []   # (opcode, addr_out, addr_in1, addr_in2, out, in1, in2)
     for which, n, rows in (("base", n_base, base_rows), ("ext", n_ext, ext_rows)):
         for _ in range(n):
@@ -187,7 +247,7 @@ def balanced_program(n_base: int, n_ext: int, n_const: int = 64, seed: int = 1):
             rows.append([op, ao, a1, a2, o, x, y])
     # a few results are read back by the constant-memory table (MemAccessKind::Read: multiplicity negated)
     mem = []   # (value block, addr, signed multiplicity)
-    results = [a for a, e in entries.items() if e["kind"] != "const"]
+    results = [a for a, e in entries.items() if e["kind"] in ("base", "ext")]
     for a in results[:: max(1, len(results) // 8)]:
         entries[a]["reads"] += 1
         mem.append((entries[a]["val"], a, -1))
@@ -212,7 +272,15 @@ def balanced_program(n_base: int, n_ext: int, n_const: int = 64, seed: int = 1):
         m[i, 0:4] = v
         m[i, 4] = a
         m[i, 5] = mult % P
-    return {"base_instrs": base_instrs, "base_events": base_events, "ext_instrs": ext_instrs, "ext_events": ext_events,
+    var_prep = np.array([[a, entries[a]["reads"]] for a in var_rows], dtype=np.uint64).reshape(-1, 2)
+    var_values = np.array([entries[a]["val"] for a in var_rows], dtype=np.uint64).reshape(-1, 4)
+    sel_prep = np.array([[1, ab, ao1, ao2, a1, a2, entries[ao1]["reads"], entries[ao2]["reads"]]
+                         for ab, ao1, ao2, a1, a2, *_ in select_rows], dtype=np.uint64).reshape(-1, SELECT_PREP_COLS)
+    sel_events = np.array([[bit, o1, o2, x, y] for *_, bit, o1, o2, x, y in select_rows], dtype=np.uint64).reshape(-1, SELECT_COLS)
+    extra = {"var_prep": F.to_monty(var_prep).reshape(-1), "var_values": F.to_monty(var_values).reshape(-1),
+             "select_prep": F.to_monty(sel_prep).reshape(-1), "select_events": F.to_monty(sel_events).reshape(-1),
+             "n_var": len(var_rows), "n_select": len(select_rows)}
+    return {**extra, "base_instrs": base_instrs, "base_events": base_events, "ext_instrs": ext_instrs, "ext_events": ext_events,
             "mem_entries": F.to_monty(m).reshape(-1), "n_mem": len(mem)}
 
 
