@@ -369,6 +369,11 @@ typedef struct zkm_mem_instr_event {
 size_t zkm_tracegen_memory_instrs_width(void);
 int zkm_tracegen_memory_instrs(zkm_ctx* ctx, const zkm_mem_instr_event* events, size_t n_events, int fixed_log2_rows,
                                zkm_byte_lookups* blu, zkm_matrix** out);
+/* The recursion machine's Poseidon2Wide chip, degree 3 (crates/recursion/core/src/chips/poseidon2_wide/): replaces
+ * generate_trace (trace.rs:66-120). Events are Poseidon2Events — 32 Montgomery words each, input[16] then output[16]
+ * (crates/recursion/core/src/lib.rs, Poseidon2Io) — and every row is one permutation with all the intermediates the AIR
+ * constrains: 313 columns (columns/permutation.rs:20-36). Padding rows are the permutation of the zero state. */
+int zkm_tracegen_poseidon2_wide(zkm_ctx* ctx, const uint32_t* events, size_t n_events, int fixed_log2_rows, zkm_matrix** out);
 /* The MemoryLocal chip (crates/core/machine/src/memory/local.rs): replaces generate_trace (:147-190). Events are the
  * #[repr(C)] MemoryLocalEvents of crates/core/executor/src/events/memory.rs:226-237 (ExecutionRecord::get_local_mem_events),
  * four per row, 56 columns, zero padding. */

@@ -504,4 +504,16 @@ int orc_tracegen_memory_instrs(const void* events, size_t n_events, int fixed_lo
   ORC_CATCH
 }
 
+// recursion Poseidon2Wide chip (degree 3): events = n x 32 Montgomery words (input[16], output[16]); 313 columns
+int orc_tracegen_poseidon2_wide(const uint32_t* events, size_t n_events, int fixed_log2_rows, uint32_t* out, size_t out_cap) {
+  ORC_TRY
+  size_t h;
+  std::vector<F> ev(n_events * 32);
+  for (size_t i = 0; i < ev.size(); i++) ev[i] = from_monty(events[i]);
+  std::vector<F> t = tracegen::generate_poseidon2_wide(ev.data(), n_events, fixed_log2_rows, &h);
+  if (t.size() > out_cap) throw std::runtime_error("trace buffer too small");
+  for (size_t i = 0; i < t.size(); i++) out[i] = to_monty(t[i]);
+  ORC_CATCH
+}
+
 }  // extern "C"

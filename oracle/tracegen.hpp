@@ -28,6 +28,7 @@
 #include <vector>
 #include "field.hpp"
 
+#include "poseidon2.hpp"
 namespace tracegen {
 using namespace orc;
 
@@ -938,6 +939,52 @@ static inline std::vector<F> generate_memory_instrs(const MemInstrEvent* events,
     lk.clear();
     memory_instr_row(events[i], t.data() + i * MEMORY_INSTRS_WIDTH, byte_counts ? &lk : nullptr);
     for (const ByteLookup& l : lk) byte_counts[(((size_t)l.b << 8) + l.c) * NUM_BYTE_OPS + l.op]++;
+  }
+  *height = h;
+  return t;
+}
+
+// ---- recursion Poseidon2Wide chip, degree 3 (crates/recursion/core/src/chips/poseidon2_wide/): columns
+// columns/permutation.rs:20-36 (PermutationSBox: external_rounds_state[8][16], internal_rounds_state[16], internal_rounds_s0[12],
+// output_state[16], external_rounds_sbox_state[8][16], internal_rounds_sbox_state[13]); rows trace.rs:277-420; padding rows are
+// the permutation of the zero state (:99-105)
+static const size_t POSEIDON2_WIDE_WIDTH = 313;
+static inline void poseidon2_wide_row(const F input[16], F* r) {
+  enum { EXT_STATE = 0, INT_STATE = 128, INT_S0 = 144, OUTPUT = 156, EXT_SBOX = 172, INT_SBOX = 300 };
+  F state[16];
+  for (int i = 0; i < 16; i++) r[EXT_STATE + i] = state[i] = input[i];
+  auto external_round = [&](int rd) {
+    if (rd == 0) orc::external_layer(state);
+    const int round = rd < 4 ? rd : rd + 13;
+    for (int i = 0; i < 16; i++) {
+      state[i] = orc::sbox(fadd(state[i], orc::ORC_RC_16_30[round][i]));
+      r[EXT_SBOX + 16 * rd + i] = state[i];
+    }
+    orc::external_layer(state);
+    F* next = rd == 3 ? r + INT_STATE : rd == 7 ? r + OUTPUT : r + EXT_STATE + 16 * (rd + 1);
+    for (int i = 0; i < 16; i++) next[i] = state[i];
+  };
+  for (int rd = 0; rd < 4; rd++) external_round(rd);
+  for (int rd = 0; rd < 13; rd++) {
+    state[0] = orc::sbox(fadd(state[0], orc::ORC_RC_16_30[4 + rd][0]));
+    r[INT_SBOX + rd] = state[0];
+    orc::internal_layer(state);
+    if (rd < 12) r[INT_S0 + rd] = state[0];
+  }
+  for (int i = 0; i < 16; i++) r[EXT_STATE + 64 + i] = state[i];   // external_rounds_state[4]
+  for (int rd = 4; rd < 8; rd++) external_round(rd);
+}
+// events: n_events x 32 canonical words (input[16], output[16]); the row is rebuilt from the input, the output must agree
+static inline std::vector<F> generate_poseidon2_wide(const F* events, size_t n_events, int fixed_log2_rows, size_t* height) {
+  const size_t h = padded_rows(n_events, fixed_log2_rows);
+  std::vector<F> t(h * POSEIDON2_WIDE_WIDTH, 0);
+  const F zero[16] = {0};
+  for (size_t i = 0; i < h; i++) {
+    F* r = t.data() + i * POSEIDON2_WIDE_WIDTH;
+    poseidon2_wide_row(i < n_events ? events + 32 * i : zero, r);
+    if (i < n_events)
+      for (int k = 0; k < 16; k++)
+        if (r[156 + k] != events[32 * i + 16 + k]) throw std::runtime_error("tracegen: Poseidon2 event output is not the permutation of its input");
   }
   *height = h;
   return t;

@@ -341,3 +341,14 @@ def tracegen_memory_instrs(events, fixed_log2_rows=-1, byte_counts=None):
     _check(lib().orc_tracegen_memory_instrs(C.c_void_p(ev.ctypes.data), C.c_size_t(len(ev)), C.c_int(fixed_log2_rows), abi.as_u32p(out),
                                             C.c_size_t(out.size), bc))
     return out
+
+
+def tracegen_poseidon2_wide(events, fixed_log2_rows=-1):
+    """Recursion Poseidon2Wide (degree 3) rows from events of 32 Montgomery words (input[16], output[16])."""
+    from ziren_amd import recursion as R
+    ev = np.ascontiguousarray(events, dtype=np.uint32).reshape(-1, 32)
+    rows = C.c_size_t()
+    _check(lib().orc_tracegen_alu_rows(C.c_size_t(len(ev)), C.c_int(fixed_log2_rows), C.byref(rows)))
+    out = np.zeros((rows.value, R.POSEIDON2_WIDE_WIDTH), dtype=np.uint32)
+    _check(lib().orc_tracegen_poseidon2_wide(abi.as_u32p(ev), C.c_size_t(len(ev)), C.c_int(fixed_log2_rows), abi.as_u32p(out), C.c_size_t(out.size)))
+    return out

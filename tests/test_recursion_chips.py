@@ -33,10 +33,10 @@ def test_row_counts():
         R.padded_rows(1000, 5)
 
 
-def balanced_shard(n_base, n_ext, n_const, seed, heights=(-1, -1, -1), n_var=0, n_select=0):
+def balanced_shard(n_base, n_ext, n_const, seed, heights=(-1, -1, -1), n_var=0, n_select=0, n_poseidon2=0, oracle=None):
     """BaseAlu + ExtAlu + MemoryConst (+ MemoryVar + Select) over one consistent program: (chips with host traces, flat
     record streams (preprocessed words, main words))."""
-    prog = R.balanced_program(n_base, n_ext, n_const, seed, n_var=n_var, n_select=n_select)
+    prog = R.balanced_program(n_base, n_ext, n_const, seed, n_var=n_var, n_select=n_select, n_poseidon2=n_poseidon2)
     specs = (("base_instrs", "base_events", R.BASE_VALUE_COLS, False), ("ext_instrs", "ext_events", R.EXT_VALUE_COLS, True))
     recs, streams = [], []
     for idx, (ik, ek, vw, ext) in enumerate(specs):
@@ -63,6 +63,12 @@ def balanced_shard(n_base, n_ext, n_const, seed, heights=(-1, -1, -1), n_var=0, 
         rc.trace, rc.prep_trace = R.flat_trace(prog["select_events"], R.SELECT_COLS, -1, 1), prep
         recs.append(rc)
         streams.append((prog["select_prep"], prog["select_events"]))
+    if n_poseidon2:
+        prep = R.flat_trace(prog["poseidon2_prep"], R.POSEIDON2_WIDE_PREP_WIDTH, -1, 1)
+        rc = R.record_poseidon2_wide(prep.shape[0].bit_length() - 1, prep_index=5)
+        rc.trace, rc.prep_trace = oracle.tracegen_poseidon2_wide(prog["poseidon2_events"], rc.log_height), prep
+        recs.append(rc)
+        streams.append((prog["poseidon2_prep"], prog["poseidon2_events"]))
     return recs, streams
 
 
@@ -151,6 +157,46 @@ def test_oracle_proves_balanced_recursion_shard(oracle):
         assert (oracle.verify_shard(opk, recs, fri, synth.NUM_PV_ELTS, start.copy(), proof) == 0) == want
 
 
+def test_poseidon2_wide(oracle):
+    """Poseidon2Wide (degree 3): the rows' output columns are the reference permutation (golden vectors), all 298 constraints
+    vanish on them and on the zero-state padding rows, a changed intermediate is caught, and with hashes in the program (their
+    inputs read, their outputs consumed by later instructions) the six chips' lookups cancel."""
+    import json
+    import os
+    kat = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "poseidon2_kat.json")))["vectors"]
+    ev = np.array([list(v["input"]) + list(v["output"]) for v in kat], dtype=np.uint64)
+    rows = F.from_monty(oracle.tracegen_poseidon2_wide(F.to_monty(ev)))
+    assert rows.shape[1] == R.POSEIDON2_WIDE_WIDTH and np.array_equal(rows[:len(kat), 156:172], ev[:, 16:]) and np.array_equal(rows[:len(kat), :16], ev[:, :16])
+    assert R.poseidon2_permute([int(x) for x in ev[0, :16]]) == [int(x) for x in ev[0, 16:]]
+    rp = R.record_poseidon2_wide(constraints_only=True)
+    assert rp.b.assemble()[2] == 298 and len(rp.sends) == 32 and not rp.receives
+    prep = np.zeros((rows.shape[0], R.POSEIDON2_WIDE_PREP_WIDTH), dtype=np.uint64)
+    assert air.debug_constraints(rp.b, rows, prep=prep) == []
+    for col in (3, 130, 150, 160, 200, 305):    # an input lane, the state entering the internal rounds, an s0, an output lane, S-box columns
+        bad = rows.copy()
+        bad[1, col] = (int(bad[1, col]) + 1) % F.P
+        assert {row for _, row in air.debug_constraints(rp.b, bad, prep=prep)} == {1}, col
+    with pytest.raises(RuntimeError, match="not the permutation"):
+        wrong = ev.copy()
+        wrong[0, 20] += 1
+        oracle.tracegen_poseidon2_wide(F.to_monty(wrong))
+    recs, _ = balanced_shard(300, 150, 40, seed=21, n_var=60, n_select=80, n_poseidon2=40, oracle=oracle)
+    assert recs[-1].name == "Poseidon2Wide" and recs[-1].main_width == 313
+    t = tally_of(recs)
+    assert t and not any(t.values())
+
+
+@pytest.mark.gpu
+def test_gpu_poseidon2_wide_tracegen(hip_ctx, oracle):
+    for n, fixed in ((0, -1), (1, -1), (17, -1), (3000, -1), (100, 9)):
+        prog = R.balanced_program(10, 10, 40, seed=n + 1, n_var=20, n_poseidon2=n)
+        ev = prog["poseidon2_events"]
+        want = oracle.tracegen_poseidon2_wide(ev, fixed)
+        m = hip_ctx.tracegen_poseidon2_wide(ev, fixed)
+        assert (m.height, m.width) == want.shape and np.array_equal(m.to_host(), want), n
+        m.free()
+
+
 @pytest.mark.gpu
 def test_gpu_flat_tracegen(hip_ctx):
     for ext in (False, True):
@@ -170,12 +216,12 @@ def test_gpu_flat_tracegen(hip_ctx):
 @pytest.mark.gpu
 @pytest.mark.parametrize("log_blowup,queries", [(2, 42), (3, 28)])
 def test_gpu_recursion_alu_shard(hip_ctx, oracle, log_blowup, queries):
-    """BaseAlu + ExtAlu + MemoryConst + MemoryVar + Select over one consistent program under the compress / shrink FRI configurations
+    """BaseAlu + ExtAlu + MemoryConst + MemoryVar + Select + Poseidon2Wide over one consistent program under the compress / shrink FRI configurations
     (crates/stark/src/kb31_poseidon2.rs:215-241): device-built traces, preprocessed tables in the proving key,
     memory lookups balancing between the real chips, proof bit-identical to the oracle's and accepted by the
     restated verifier."""
     from ziren_amd import prover, synth
-    recs, streams = balanced_shard(3500, 2000, 200, seed=40, heights=(10, 9, 9), n_var=300, n_select=400)
+    recs, streams = balanced_shard(3500, 2000, 200, seed=40, heights=(10, 9, 9), n_var=300, n_select=400, n_poseidon2=200, oracle=oracle)
     fri = abi.FriConfig(log_blowup, queries, 16)
     pv = np.zeros(synth.PROOF_MAX_NUM_PVS, dtype=np.uint32)
     igcs = F.to_monty(np.zeros(14, dtype=np.uint64))
@@ -190,7 +236,8 @@ def test_gpu_recursion_alu_shard(hip_ctx, oracle, log_blowup, queries):
     ch = prover.new_challenger()
     pk.observe_into(ch)
     start = ch.copy()
-    born = [hip_ctx.tracegen_flat(ev, r.trace.shape[1], r.log_height) if ev is not None else hip_ctx.upload(r.trace)
+    born = [hip_ctx.tracegen_poseidon2_wide(ev, r.log_height) if r.name == "Poseidon2Wide" else
+            hip_ctx.tracegen_flat(ev, r.trace.shape[1], r.log_height) if ev is not None else hip_ctx.upload(r.trace)
             for (_, ev), r in zip(streams, recs)]
     proof = hp.prove_shard(pk, pv, born, ch).copy()
     och = oracle.new_challenger()

@@ -16,6 +16,7 @@
 // Values are stored in Montgomery form, the in-memory form of the reference's KoalaBear (RowMajorMatrix<KoalaBear>).
 #pragma once
 #include "kb31.cuh"
+#include "poseidon2.cuh"
 
 namespace tracegen {
 
@@ -881,6 +882,71 @@ __global__ void memory_local_rows(const uint32_t* __restrict__ events, size_t n_
   }
 #pragma unroll
   for (int c = 0; c < MEMORY_LOCAL_ENTRY_COLS; c++) out[(k * MEMORY_LOCAL_ENTRY_COLS + c) * height + row] = kb::to_monty(r[c]);
+}
+
+// ---- recursion Poseidon2Wide chip, degree 3 (crates/recursion/core/src/chips/poseidon2_wide/): one thread runs one
+// permutation and writes every intermediate the AIR constrains as it goes — 313 columns: external_rounds_state[8][16],
+// internal_rounds_state[16], internal_rounds_s0[12], output_state[16], external_rounds_sbox_state[8][16],
+// internal_rounds_sbox_state[13] (columns/permutation.rs:20-36, rows trace.rs:277-420). Events are 32 Montgomery words
+// (Poseidon2Event: input[16], output[16]); rows past n_events are the permutation of the zero state (:99-105). All values
+// stay in Montgomery form, which is what the matrix stores. rc_ext / rc_int / diag: the constant-memory tables of the hashing
+// kernels (poseidon2.cuh; the round constants are kept there minus p, for the folded S-box).
+constexpr int POSEIDON2_WIDE_WIDTH = 313;
+__device__ __forceinline__ void wide_external_layer(uint32_t s[16]) {   // mds_light_permutation, chips/poseidon2_wide/mod.rs:45-71
+#pragma unroll
+  for (int j = 0; j < 16; j += 4) {
+    const uint32_t t01 = kb::add(s[j], s[j + 1]), t23 = kb::add(s[j + 2], s[j + 3]), t0123 = kb::add(t01, t23);
+    const uint32_t t01123 = kb::add(t0123, s[j + 1]), t01233 = kb::add(t0123, s[j + 3]);
+    const uint32_t x0 = s[j], x2 = s[j + 2];
+    s[j + 3] = kb::add(t01233, kb::add(x0, x0));
+    s[j + 1] = kb::add(t01123, kb::add(x2, x2));
+    s[j] = kb::add(t01123, t01);
+    s[j + 2] = kb::add(t01233, t23);
+  }
+  uint32_t sums[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) sums[k] = kb::add(kb::add(s[k], s[4 + k]), kb::add(s[8 + k], s[12 + k]));
+#pragma unroll
+  for (int j = 0; j < 16; j++) s[j] = kb::add(s[j], sums[j & 3]);
+}
+__device__ __forceinline__ uint32_t wide_sbox(uint32_t x) { return kb::mul(kb::mul(x, x), x); }
+__global__ __launch_bounds__(THREADS) void poseidon2_wide_rows(const uint32_t* __restrict__ events, size_t n_events, size_t height,
+                                                               uint32_t* __restrict__ out) {
+  enum { EXT_STATE = 0, INT_STATE = 128, INT_S0 = 144, OUTPUT = 156, EXT_SBOX = 172, INT_SBOX = 300 };
+  const size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= height) return;
+  uint32_t s[16];
+#pragma unroll
+  for (int i = 0; i < 16; i++) s[i] = row < n_events ? events[row * 32 + i] : 0u;
+  auto put = [&](int col, uint32_t v) { out[(size_t)col * height + row] = v; };
+#pragma unroll
+  for (int i = 0; i < 16; i++) put(EXT_STATE + i, s[i]);
+  wide_external_layer(s);
+  for (int rd = 0; rd < 8; rd++) {
+    if (rd == 4) {
+      for (int r = 0; r < 13; r++) {
+        s[0] = wide_sbox(kb::add(s[0], p2::d_rc_int[r] + kb::P));
+        put(INT_SBOX + r, s[0]);
+        uint32_t sum = s[0];
+#pragma unroll
+        for (int i = 1; i < 16; i++) sum = kb::add(sum, s[i]);
+#pragma unroll
+        for (int i = 0; i < 16; i++) s[i] = kb::add(kb::mul(s[i], p2::d_diag[i]), sum);
+        if (r < 12) put(INT_S0 + r, s[0]);
+      }
+#pragma unroll
+      for (int i = 0; i < 16; i++) put(EXT_STATE + 64 + i, s[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      s[i] = wide_sbox(kb::add(s[i], p2::d_rc_ext[rd][i] + kb::P));
+      put(EXT_SBOX + 16 * rd + i, s[i]);
+    }
+    wide_external_layer(s);
+    const int next = rd == 3 ? INT_STATE : rd == 7 ? OUTPUT : EXT_STATE + 16 * (rd + 1);
+#pragma unroll
+    for (int i = 0; i < 16; i++) put(next + i, s[i]);
+  }
 }
 
 // ByteChip::generate_trace: out = to_field(counts + extra); extra (may be null) holds the row-major plain counts of the

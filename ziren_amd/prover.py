@@ -176,6 +176,15 @@ class Context:
                                                         C.c_int(fixed_log2_rows), blu.h if blu is not None else None, C.byref(h)))
         return self._born(h)
 
+    def tracegen_poseidon2_wide(self, events: np.ndarray, fixed_log2_rows: int = -1) -> DeviceMatrix:
+        """`generate_trace` of the recursion Poseidon2Wide chip (degree 3) on the device (zkm_tracegen_poseidon2_wide); events:
+        32 Montgomery words each (input[16], output[16])."""
+        ev = np.ascontiguousarray(events, dtype=np.uint32).reshape(-1, 32)
+        h = C.c_void_p()
+        lib.check(lib.load().zkm_tracegen_poseidon2_wide(self.h, abi.as_u32p(ev) if len(ev) else None, C.c_size_t(len(ev)),
+                                                         C.c_int(fixed_log2_rows), C.byref(h)))
+        return self._born(h)
+
     def tracegen_memory_local(self, events: np.ndarray, fixed_log2_rows: int = -1) -> DeviceMatrix:
         """`generate_trace` of the MemoryLocal chip on the device (zkm_tracegen_memory_local); dtype miniexec.MEMORY_LOCAL_EVENT."""
         from . import miniexec as _m

@@ -166,7 +166,105 @@ def record_select(log_height: int = 10, prep_index: int = 0, constraints_only: b
     return r if constraints_only else _finish_rec(r, "Select", log_height, SELECT_COLS, prep_index)
 
 
-def balanced_program(n_base: int, n_ext: int, n_const: int = 64, seed: int = 1, n_var: int = 0, n_select: int = 0):
+POSEIDON2_WIDE_WIDTH, POSEIDON2_WIDE_PREP_WIDTH = 313, 49
+
+
+def _poseidon2_constants():
+    """Round constants and internal diagonal (canonical) from the tables the kernels use (csrc/poseidon2_constants.inc, pinned
+    against the reference's dump in tests/test_oracle_pins.py)."""
+    import os
+    import re
+    txt = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "poseidon2_constants.inc")).read()
+    tabs = {m.group(1): [int(x) for x in re.findall(r"(\d+)u", m.group(2))]
+            for m in re.finditer(r"static const uint32_t (\w+)\[\d+\](?:\[16\])? = \{(.*?)\};", txt, re.S)}
+    rc = F.from_monty(np.array(tabs["ZKM_RC_16_30_MONTY"], dtype=np.uint32)).reshape(30, 16)
+    diag = F.from_monty(np.array(tabs["ZKM_INTERNAL_DIAG_16_MONTY"], dtype=np.uint32))
+    return [[int(x) for x in row] for row in rc], [int(x) for x in diag]
+
+
+def _external_layer(s):
+    """mds_light_permutation (chips/poseidon2_wide/mod.rs:45-71) over ints or recorded expressions."""
+    s = list(s)
+    for j in range(0, 16, 4):
+        x = s[j:j + 4]
+        t01, t23 = x[0] + x[1], x[2] + x[3]
+        t0123 = t01 + t23
+        t01123, t01233 = t0123 + x[1], t0123 + x[3]
+        s[j + 3] = t01233 + x[0] * 2
+        s[j + 1] = t01123 + x[2] * 2
+        s[j] = t01123 + t01
+        s[j + 2] = t01233 + t23
+    sums = [s[k] + s[4 + k] + s[8 + k] + s[12 + k] for k in range(4)]
+    return [s[j] + sums[j % 4] for j in range(16)]
+
+
+def _internal_layer(s, diag):
+    total = s[0]
+    for x in s[1:]:
+        total = total + x
+    return [s[i] * diag[i] + total for i in range(16)]
+
+
+def poseidon2_permute(state):
+    """The width-16 KoalaBear Poseidon2 permutation over canonical ints (the program generator's executor)."""
+    rc, diag = _poseidon2_constants()
+    P = F.P
+    s = [x % P for x in _external_layer(state)]
+    for r in range(4):
+        s = [x % P for x in _external_layer([pow(s[i] + rc[r][i], 3, P) for i in range(16)])]
+    for r in range(13):
+        s[0] = pow(s[0] + rc[4 + r][0], 3, P)
+        s = [x % P for x in _internal_layer(s, diag)]
+    for r in range(4, 8):
+        s = [x % P for x in _external_layer([pow(s[i] + rc[13 + r][i], 3, P) for i in range(16)])]
+    return s
+
+
+def record_poseidon2_wide(log_height: int = 10, prep_index: int = 0, constraints_only: bool = False):
+    """Poseidon2WideChip<3>::eval (chips/poseidon2_wide/air.rs:34-177): the degree-normalising dummy constraint, sixteen
+    input reads (multiplicity is_real_neg = -1) and sixteen output writes, eight external rounds with their S-box columns
+    (x^3 as a degree-3 constraint, the linear layer folded into the next state's constraint) and the thirteen internal
+    rounds (lane 0 witnessed per round, the other lanes carried as linear expressions)."""
+    rc, diag = _poseidon2_constants()
+    r = _RecRec(POSEIDON2_WIDE_WIDTH, POSEIDON2_WIDE_PREP_WIDTH)
+    l, p, b = r.local, r.prep, r.b
+    EXT_STATE, INT_STATE, INT_S0, OUTPUT, EXT_SBOX, INT_SBOX = 0, 128, 144, 156, 172, 300
+    ext_state = [l[EXT_STATE + 16 * k:EXT_STATE + 16 * k + 16] for k in range(8)]
+    int_state, s0, output = l[INT_STATE:INT_STATE + 16], l[INT_S0:INT_S0 + 12], l[OUTPUT:OUTPUT + 16]
+    ext_sbox = [l[EXT_SBOX + 16 * k:EXT_SBOX + 16 * k + 16] for k in range(8)]
+    int_sbox = l[INT_SBOX:INT_SBOX + 13]
+    x0 = ext_state[0][0]
+    b.assert_eq(x0 * x0 * x0, x0 * x0 * x0)
+    for i in range(16):
+        r.send_single(p[i], ext_state[0][i], p[48])
+    for i in range(16):
+        r.send_single(p[16 + 2 * i], output[i], p[17 + 2 * i])
+    for rd in range(8):
+        state = list(ext_state[rd])
+        if rd == 0:
+            state = _external_layer(state)
+        rnd = rd if rd < 4 else rd + 13
+        for i in range(16):
+            add_rc = state[i] + rc[rnd][i]
+            b.assert_eq(ext_sbox[rd][i], add_rc * add_rc * add_rc)
+        state = _external_layer(list(ext_sbox[rd]))
+        nxt = int_state if rd == 3 else output if rd == 7 else ext_state[rd + 1]
+        for i in range(16):
+            b.assert_eq(nxt[i], state[i])
+    state = list(int_state)     # the internal rounds sit between external rounds 3 and 4; eval lists them after all external rounds
+    for rd in range(13):
+        add_rc = (state[0] if rd == 0 else s0[rd - 1]) + rc[4 + rd][0]
+        b.assert_eq(int_sbox[rd], add_rc * add_rc * add_rc)
+        state[0] = int_sbox[rd]
+        state = _internal_layer(state, diag)
+        if rd < 12:
+            b.assert_eq(s0[rd], state[0])
+    for i in range(16):
+        b.assert_eq(ext_state[4][i], state[i])
+    return r if constraints_only else _finish_rec(r, "Poseidon2Wide", log_height, POSEIDON2_WIDE_WIDTH, prep_index)
+
+
+def balanced_program(n_base: int, n_ext: int, n_const: int = 64, seed: int = 1, n_var: int = 0, n_select: int = 0, n_poseidon2: int = 0):
     """A synthetic recursion program whose memory lookups balance exactly, as a real one's do: constants are written by
     MemoryConst entries, every ALU instruction reads two earlier values (constants or earlier results of its own field)
     and writes one, and each write's multiplicity is the number of later reads; a few results are read back by
@@ -219,6 +317,17 @@ def balanced_program(n_base: int, n_ext: int, n_const: int = 64, seed: int = 1, 
         entries[ao2] = {"val": [o2, 0, 0, 0], "reads": 0, "kind": "base"}
         pools["base"] += [ao1, ao2]
         select_rows.append((ab, ao1, ao2, a1, a2, bit, o1, o2, x, y))
+    poseidon_rows = []
+    for _ in range(n_poseidon2):
+        ins = [pools["base"][int(rng.integers(0, len(pools["base"])))] for _ in range(16)]
+        out = poseidon2_permute([entries[a]["val"][0] for a in ins])
+        outs = [new_addr() for _ in range(16)]
+        for a in ins:
+            entries[a]["reads"] += 1
+        for a, v in zip(outs, out):
+            entries[a] = {"val": [v, 0, 0, 0], "reads": 0, "kind": "base"}
+        pools["base"] += outs
+        poseidon_rows.append((ins, outs))
     base_rows, ext_rows = [], []   # (opcode, addr_out, addr_in1, addr_in2, out, in1, in2)
     for which, n, rows in (("base", n_base, base_rows), ("ext", n_ext, ext_rows)):
         for _ in range(n):
@@ -277,7 +386,12 @@ def balanced_program(n_base: int, n_ext: int, n_const: int = 64, seed: int = 1, 
     sel_prep = np.array([[1, ab, ao1, ao2, a1, a2, entries[ao1]["reads"], entries[ao2]["reads"]]
                          for ab, ao1, ao2, a1, a2, *_ in select_rows], dtype=np.uint64).reshape(-1, SELECT_PREP_COLS)
     sel_events = np.array([[bit, o1, o2, x, y] for *_, bit, o1, o2, x, y in select_rows], dtype=np.uint64).reshape(-1, SELECT_COLS)
-    extra = {"var_prep": F.to_monty(var_prep).reshape(-1), "var_values": F.to_monty(var_values).reshape(-1),
+    pos_prep = np.array([list(ins) + [x for a in outs for x in (a, entries[a]["reads"])] + [P - 1] for ins, outs in poseidon_rows],
+                        dtype=np.uint64).reshape(-1, POSEIDON2_WIDE_PREP_WIDTH)
+    pos_events = np.array([[entries[a]["val"][0] for a in ins] + [entries[a]["val"][0] for a in outs] for ins, outs in poseidon_rows],
+                          dtype=np.uint64).reshape(-1, 32)
+    extra = {"poseidon2_prep": F.to_monty(pos_prep).reshape(-1), "poseidon2_events": F.to_monty(pos_events).reshape(-1),
+             "n_poseidon2": len(poseidon_rows), "var_prep": F.to_monty(var_prep).reshape(-1), "var_values": F.to_monty(var_values).reshape(-1),
              "select_prep": F.to_monty(sel_prep).reshape(-1), "select_events": F.to_monty(sel_events).reshape(-1),
              "n_var": len(var_rows), "n_select": len(select_rows)}
     return {**extra, "base_instrs": base_instrs, "base_events": base_events, "ext_instrs": ext_instrs, "ext_events": ext_events,
