@@ -1,0 +1,90 @@
+#!/usr/bin/env python3
+"""A recursion-machine shard on the device: BaseAlu, ExtAlu, MemoryConst, MemoryVar, Select and Poseidon2Wide
+over one balanced synthetic program (ziren_amd/recursion.py), traces built on the device, commit + open under the compress FRI
+configuration (blow-up 4, 42 queries; `--shrink`: blow-up 8, 28 queries) with generated quotient kernels.
+
+  python tools/bench_recursion_shard.py [--log-hashes 16] [--steps 3]"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+import numpy as np
+
+from ziren_amd import abi, field as F, lib, prover, recursion as R, synth
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--log-hashes", type=int, default=16, help="log2 of the number of Poseidon2 permutations in the program")
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--shrink", action="store_true")
+    args = ap.parse_args()
+    ctx = prover.Context(0)
+    n_hash = 1 << args.log_hashes
+
+    def permute(vals):   # canonical (n, 16) -> canonical, on the device
+        return F.from_monty(prover.poseidon2_permute_batch(ctx, F.to_monty(vals)))
+
+    t0 = time.perf_counter()
+    prog = R.balanced_program(n_hash // 2, n_hash // 4, 512, seed=1, n_var=4096, n_select=n_hash // 8, n_poseidon2=n_hash, permute_batch=permute)
+    gen_s = time.perf_counter() - t0
+    specs = [("base_instrs", "base_events", R.ENTRIES_PER_ROW * R.ACCESS_COLS, R.ENTRIES_PER_ROW * R.BASE_VALUE_COLS, R.ENTRIES_PER_ROW, lambda lh, i: R.record_chip(False, lh, i)),
+             ("ext_instrs", "ext_events", R.ENTRIES_PER_ROW * R.ACCESS_COLS, R.ENTRIES_PER_ROW * R.EXT_VALUE_COLS, R.ENTRIES_PER_ROW, lambda lh, i: R.record_chip(True, lh, i)),
+             ("mem_entries", None, R.CONST_MEM_ENTRIES_PER_ROW * R.CONST_MEM_ENTRY_COLS, 1, R.CONST_MEM_ENTRIES_PER_ROW, R.record_mem_const),
+             ("var_prep", "var_values", 2 * R.VAR_MEM_ENTRIES_PER_ROW, 4 * R.VAR_MEM_ENTRIES_PER_ROW, R.VAR_MEM_ENTRIES_PER_ROW, R.record_mem_var),
+             ("select_prep", "select_events", R.SELECT_PREP_COLS, R.SELECT_COLS, 1, R.record_select),
+             ("poseidon2_prep", "poseidon2_events", R.POSEIDON2_WIDE_PREP_WIDTH, R.POSEIDON2_WIDE_WIDTH, 1, R.record_poseidon2_wide)]
+    recs, preps, mains = [], [], []
+    for idx, (pk_key, ev_key, pw, mw, per_row, record) in enumerate(specs):
+        n_rec = len(prog[pk_key]) // (pw // per_row)
+        lh = (R.padded_rows(n_rec, -1, per_row)).bit_length() - 1
+        recs.append(record(lh, idx))
+        preps.append(ctx.tracegen_flat(prog[pk_key], pw, lh))
+        mains.append((ev_key, mw, lh))
+    fri = abi.FriConfig(3, 28, 16) if args.shrink else abi.FriConfig(2, 42, 16)
+    hp = prover.HipProver(recs, fri, synth.NUM_PV_ELTS, ctx=ctx, specialize=True)
+    pk = hp.setup(preps, [1] * len(recs), F.to_monty(0), F.to_monty(np.zeros(14, dtype=np.uint64)))
+    ch0 = prover.new_challenger()
+    pk.observe_into(ch0)
+    pv = np.zeros(synth.PROOF_MAX_NUM_PVS, dtype=np.uint32)
+    lib.load().zkm_ctx_set_kernel_timing(ctx.h, C.c_int(1))
+    out = np.zeros(1 << 23, dtype=np.uint32)
+    res = []
+    for it in range(args.steps + 1):
+        t0 = time.perf_counter()
+        born = []
+        for (ev_key, mw, lh), r in zip(mains, recs):
+            if r.name == "Poseidon2Wide":
+                born.append(ctx.tracegen_poseidon2_wide(prog[ev_key], lh))
+            elif ev_key is None:
+                born.append(ctx.tracegen_flat(np.zeros(0, dtype=np.uint32), mw, lh))
+            else:
+                born.append(ctx.tracegen_flat(prog[ev_key], mw, lh))
+        t1 = time.perf_counter()
+        proof = hp.prove_shard(pk, pv, born, ch0.copy(), out=out)
+        t2 = time.perf_counter()
+        phases = dict(ctx.last_timings())
+        kern = {nm: (round(ms, 3), calls) for nm, ms, calls, _ in ctx.kernel_timings()}
+        for m in born:
+            m.free()
+        if it:
+            res.append({"tracegen_ms": (t1 - t0) * 1e3, "prove_ms": (t2 - t1) * 1e3, "phases": phases, "kernels": kern})
+    r = res[-1]
+    cells = sum((1 << c.log_height) * (c.prep_width + c.main_width + 4 * c.perm_ext_width + (4 << c.log_quotient_degree)) for c in recs)
+    print(json.dumps({"workload": f"REC-{args.log_hashes}: balanced recursion program, 2^{args.log_hashes} Poseidon2 permutations + ALU / select / memory "
+                                  f"instructions; {'shrink' if args.shrink else 'compress'} FRI configuration (blow-up {1 << fri.log_blowup}, {fri.num_queries} queries)",
+                      "program_generation_seconds_python": round(gen_s, 1),
+                      "tracegen_ms": round(float(np.mean([x["tracegen_ms"] for x in res])), 3),
+                      "prove_ms": round(float(np.mean([x["prove_ms"] for x in res])), 3), "committed_cells": cells, "proof_words": int(len(proof)),
+                      "chips": {c.name: {"rows": 1 << c.log_height, "prep": c.prep_width, "main": c.main_width, "perm_ext": c.perm_ext_width,
+                                         "constraints": c.num_constraints} for c in recs},
+                      "phases_ms": {nm: round(v, 3) for nm, v in r["phases"].items()}, "kernels_ms": r["kernels"]}, indent=1))
+
+
+if __name__ == "__main__":
+    main()

@@ -264,7 +264,8 @@ def record_poseidon2_wide(log_height: int = 10, prep_index: int = 0, constraints
     return r if constraints_only else _finish_rec(r, "Poseidon2Wide", log_height, POSEIDON2_WIDE_WIDTH, prep_index)
 
 
-def balanced_program(n_base: int, n_ext: int, n_const: int = 64, seed: int = 1, n_var: int = 0, n_select: int = 0, n_poseidon2: int = 0):
+def balanced_program(n_base: int, n_ext: int, n_const: int = 64, seed: int = 1, n_var: int = 0, n_select: int = 0, n_poseidon2: int = 0,
+                     permute_batch=None):
     """A synthetic recursion program whose memory lookups balance exactly, as a real one's do: constants are written by
     MemoryConst entries, every ALU instruction reads two earlier values (constants or earlier results of its own field)
     and writes one, and each write's multiplicity is the number of later reads; a few results are read back by
@@ -318,9 +319,19 @@ def balanced_program(n_base: int, n_ext: int, n_const: int = 64, seed: int = 1, 
         pools["base"] += [ao1, ao2]
         select_rows.append((ab, ao1, ao2, a1, a2, bit, o1, o2, x, y))
     poseidon_rows = []
-    for _ in range(n_poseidon2):
-        ins = [pools["base"][int(rng.integers(0, len(pools["base"])))] for _ in range(16)]
-        out = poseidon2_permute([entries[a]["val"][0] for a in ins])
+    batch_out = None
+    if permute_batch is not None and n_poseidon2:   # large programs: every hash reads values that exist already, one batched permutation
+        pool0 = np.array(pools["base"], dtype=np.int64)     # (permute_batch: (n, 16) canonical -> (n, 16) canonical, e.g. on the device)
+        picks = pool0[rng.integers(0, len(pool0), (n_poseidon2, 16))]
+        vals = np.array([entries[a]["val"][0] for a in pool0], dtype=np.uint64)[np.searchsorted(pool0, picks)]
+        batch_out = np.asarray(permute_batch(vals), dtype=np.uint64)
+    for k in range(n_poseidon2):
+        if batch_out is not None:
+            ins = [int(a) for a in picks[k]]
+            out = [int(v) for v in batch_out[k]]
+        else:
+            ins = [pools["base"][int(rng.integers(0, len(pools["base"])))] for _ in range(16)]
+            out = poseidon2_permute([entries[a]["val"][0] for a in ins])
         outs = [new_addr() for _ in range(16)]
         for a in ins:
             entries[a]["reads"] += 1
