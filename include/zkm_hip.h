@@ -374,6 +374,17 @@ int zkm_tracegen_memory_instrs(zkm_ctx* ctx, const zkm_mem_instr_event* events, 
  * (crates/recursion/core/src/lib.rs, Poseidon2Io) — and every row is one permutation with all the intermediates the AIR
  * constrains: 313 columns (columns/permutation.rs:20-36). Padding rows are the permutation of the zero state. */
 int zkm_tracegen_poseidon2_wide(zkm_ctx* ctx, const uint32_t* events, size_t n_events, int fixed_log2_rows, zkm_matrix** out);
+/* The SyscallInstrs chip (crates/core/machine/src/syscall/instructions/): replaces generate_trace (trace.rs:38-86). Events are the
+ * #[repr(C)] SyscallEvents of crates/core/executor/src/events/syscall.rs:7-29 (56 bytes). 77 columns, zero padding rows, no byte
+ * lookups. */
+typedef struct zkm_syscall_event {
+  uint32_t pc, next_pc, shard, clk;
+  zkm_memory_write_record a_record;
+  uint8_t a_record_is_real, _pad[3];
+  uint32_t syscall_id, arg1, arg2;
+} zkm_syscall_event;
+size_t zkm_tracegen_syscall_instrs_width(void);
+int zkm_tracegen_syscall_instrs(zkm_ctx* ctx, const zkm_syscall_event* events, size_t n_events, int fixed_log2_rows, zkm_matrix** out);
 /* The MemoryLocal chip (crates/core/machine/src/memory/local.rs): replaces generate_trace (:147-190). Events are the
  * #[repr(C)] MemoryLocalEvents of crates/core/executor/src/events/memory.rs:226-237 (ExecutionRecord::get_local_mem_events),
  * four per row, 56 columns, zero padding. */

@@ -516,4 +516,14 @@ int orc_tracegen_poseidon2_wide(const uint32_t* events, size_t n_events, int fix
   ORC_CATCH
 }
 
+// SyscallInstrs chip (SyscallEvent, 56 bytes)
+int orc_tracegen_syscall_instrs(const void* events, size_t n_events, int fixed_log2_rows, uint32_t* out, size_t out_cap) {
+  ORC_TRY
+  size_t h;
+  std::vector<F> t = tracegen::generate_syscall_instrs((const tracegen::SyscallEvent*)events, n_events, fixed_log2_rows, &h);
+  if (t.size() > out_cap) throw std::runtime_error("trace buffer too small");
+  for (size_t i = 0; i < t.size(); i++) out[i] = to_monty(t[i]);
+  ORC_CATCH
+}
+
 }  // extern "C"

@@ -990,4 +990,53 @@ static inline std::vector<F> generate_poseidon2_wide(const F* events, size_t n_e
   return t;
 }
 
+// ---- SyscallInstrs chip: SyscallEvents (crates/core/executor/src/events/syscall.rs:7-29); columns syscall/instructions/columns.rs:9-58,
+// row trace.rs:88-176. IsZeroOperation = (inverse, result) of a field element.
+struct SyscallEvent {
+  uint32_t pc, next_pc, shard, clk;
+  MemoryWriteRecord a_record;
+  uint8_t a_record_is_real; uint8_t pad[3];
+  uint32_t syscall_id, arg1, arg2;
+};
+static_assert(sizeof(SyscallEvent) == 56, "SyscallEvent is fourteen words");
+static const size_t SYSCALL_INSTRS_WIDTH = 77;
+static inline void is_zero_cols(F a, F* r) { r[0] = a ? finv(a) : 0; r[1] = a == 0; }
+static inline void syscall_instr_row(const SyscallEvent& e, F* r) {
+  enum { PC = 0, NEXT_PC = 1, SHARD = 2, CLK = 3, NUM_EXTRA_CYCLES = 4, IS_HALT = 5, IS_SYS_LINUX = 6, IS_PREV_A1_ZERO = 7, SYSCALL_ID = 9, OP_A = 10,
+         OP_B = 14, OP_C = 18, PREV_A = 22, IS_ENTER_UNCONSTRAINED = 26, IS_HINT_LEN = 28, IS_HALT_CHECK = 30, IS_EXIT_GROUP_CHECK = 32, IS_COMMIT = 34,
+         IS_COMMIT_DEFERRED = 36, INDEX_BITMAP = 38, OP_B_RC = 46, OP_C_RC = 60, OP_B_CHECK = 74, OP_C_CHECK = 75, IS_REAL = 76 };
+  static_assert(IS_REAL + 1 == 77, "layout");
+  r[IS_REAL] = 1;
+  r[PC] = fu32(e.pc); r[NEXT_PC] = fu32(e.next_pc); r[SHARD] = fu32(e.shard); r[CLK] = fu32(e.clk);
+  const uint32_t prev = e.a_record.prev_value;
+  word(r + OP_A, e.a_record.value); word(r + OP_B, e.arg1); word(r + OP_C, e.arg2); word(r + PREV_A, prev);
+  r[SYSCALL_ID] = fu32(e.syscall_id);
+  const uint32_t id = prev & 0xffff;
+  r[NUM_EXTRA_CYCLES] = (prev >> 24) & 0xff;
+  const bool is_halt = id == 0 || id == 4246;
+  r[IS_HALT] = is_halt;
+  r[IS_SYS_LINUX] = (prev & 0xff00) != 0;
+  const bool send_to_table = ((prev >> 8) & 0xff) != 0 || ((prev >> 16) & 0xff) == 1;
+  is_zero_cols((prev >> 8) & 0xff, r + IS_PREV_A1_ZERO);
+  is_zero_cols(fsub(id, 3), r + IS_ENTER_UNCONSTRAINED);
+  is_zero_cols(fsub(id, 0xf0), r + IS_HINT_LEN);
+  is_zero_cols(fsub(id, 0), r + IS_HALT_CHECK);
+  is_zero_cols(fsub(id, 4246), r + IS_EXIT_GROUP_CHECK);
+  is_zero_cols(fsub(id, 0x10), r + IS_COMMIT);
+  is_zero_cols(fsub(id, 0x1a), r + IS_COMMIT_DEFERRED);
+  if (id == 0x10 || id == 0x1a) {
+    if (e.arg1 >= 8) throw std::runtime_error("tracegen: commit digest index out of range");
+    r[INDEX_BITMAP + e.arg1] = 1;
+  }
+  if (send_to_table || is_halt) { r[OP_B_CHECK] = 1; range_checker(r + OP_B_RC, e.arg1); }
+  if (send_to_table || id == 0x1a) { r[OP_C_CHECK] = 1; range_checker(r + OP_C_RC, e.arg2); }
+}
+static inline std::vector<F> generate_syscall_instrs(const SyscallEvent* events, size_t n_events, int fixed_log2_rows, size_t* height) {
+  const size_t h = padded_rows(n_events, fixed_log2_rows);
+  std::vector<F> t(h * SYSCALL_INSTRS_WIDTH, 0);
+  for (size_t i = 0; i < n_events; i++) syscall_instr_row(events[i], t.data() + i * SYSCALL_INSTRS_WIDTH);
+  *height = h;
+  return t;
+}
+
 }  // namespace tracegen

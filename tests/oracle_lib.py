@@ -352,3 +352,15 @@ def tracegen_poseidon2_wide(events, fixed_log2_rows=-1):
     out = np.zeros((rows.value, R.POSEIDON2_WIDE_WIDTH), dtype=np.uint32)
     _check(lib().orc_tracegen_poseidon2_wide(abi.as_u32p(ev), C.c_size_t(len(ev)), C.c_int(fixed_log2_rows), abi.as_u32p(out), C.c_size_t(out.size)))
     return out
+
+
+def tracegen_syscall_instrs(events, fixed_log2_rows=-1):
+    """SyscallInstrs chip rows from SyscallEvents."""
+    from ziren_amd import events as E
+    ev = np.ascontiguousarray(events, dtype=E.SYSCALL_EVENT)
+    rows = C.c_size_t()
+    _check(lib().orc_tracegen_alu_rows(C.c_size_t(len(ev)), C.c_int(fixed_log2_rows), C.byref(rows)))
+    out = np.zeros((rows.value, E.SYSCALL_INSTRS_WIDTH), dtype=np.uint32)
+    _check(lib().orc_tracegen_syscall_instrs(C.c_void_p(ev.ctypes.data), C.c_size_t(len(ev)), C.c_int(fixed_log2_rows), abi.as_u32p(out),
+                                             C.c_size_t(out.size)))
+    return out

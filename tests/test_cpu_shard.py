@@ -21,7 +21,7 @@ def log2_rows(n):
 
 def cpu_shard(oracle, n_cycles, seed=1):
     """(chips with oracle traces, device work list, byte chip, program chip, public values)."""
-    prog, rec0, pv = M.run(n_cycles, seed=seed, shard=SHARD, pc_base=PC_BASE)
+    prog, rec0, pv = M.run(n_cycles, seed=seed, shard=SHARD, pc_base=PC_BASE, halt=True)   # ... eight COMMITs and HALT at the end
     rec = M.add_dependencies(rec0)
     extra = np.zeros((1 << 16, 10), dtype=np.uint32)
     recs, work = [], []
@@ -37,7 +37,8 @@ def cpu_shard(oracle, n_cycles, seed=1):
         rc.trace = oracle.tracegen_alu(chip, ev, lh)
         recs.append(rc)
         work.append((chip, ev, lh))
-    for name, ev, record, gen in (("jump", rec.jump, chips.record_jump_chip, oracle.tracegen_jump),
+    for name, ev, record, gen in (("syscall_instrs", rec.syscall, chips.record_syscall_instrs_chip, oracle.tracegen_syscall_instrs),
+                                  ("jump", rec.jump, chips.record_jump_chip, oracle.tracegen_jump),
                                   ("mov_cond", rec.mov_cond, chips.record_mov_cond_chip, oracle.tracegen_mov_cond)):
         lh = log2_rows(len(ev))
         rc = record(lh)
@@ -79,7 +80,8 @@ def test_miniexec_record_is_coherent():
     assert len(cpu) == 1500 and pv["start_pc"] == 0x1000 and (np.diff(cpu["clk"].astype(np.int64)) == 5).all()
     assert (cpu["pc"][1:] == cpu["next_pc"][:-1]).all() and (cpu["next_pc"][1:] == cpu["next_next_pc"][:-1]).all()
     assert len(np.unique(cpu["pc"])) == 1500                      # forward only: every pc runs once
-    total = sum(len(v) for v in rec.alu.values()) + len(rec.mul) + len(rec.divrem) + len(rec.branch) + len(rec.jump) + len(rec.mov_cond) + len(rec.mem_instr)
+    total = sum(len(v) for v in rec.alu.values()) + len(rec.mul) + len(rec.divrem) + len(rec.branch) + len(rec.jump) + len(rec.mov_cond) + len(rec.mem_instr) \
+        + len(rec.syscall)
     assert total == 1500                                          # one chip event per cycle (emit_events)
     assert min(len(v) for v in rec.alu.values()) > 0 and len(rec.jump) > 0 and len(rec.divrem) > 0
     assert set(rec.mem_instr["opcode"].tolist()) == set(range(E.LB, E.SC + 1))     # all fourteen loads and stores
@@ -128,6 +130,29 @@ def test_memory_instrs_constraints_hold(oracle):
     dep = E.memory_dependencies(ev)
     neg = int(t[:len(ev), 76].sum())
     assert (dep["opcode"] == E.ADD).sum() == len(ev) and (dep["opcode"] == E.SUB).sum() == neg > 0
+
+
+def test_syscall_instrs_and_halting_program(oracle):
+    """A program that ends as real ones do — eight COMMIT syscalls publishing a value digest, then HALT: the SyscallInstrs rows
+    satisfy the AIR against the public values (committed_value_digest, exit_code), the Cpu chip's halt path holds (is_halt, last
+    real row, public next_pc = 0), and wrong public values are caught by the chip that owns them."""
+    rec = chips.record_syscall_instrs_constraints()
+    prog, r, pv = M.run(400, seed=6, halt=True)
+    assert len(r.syscall) == 9 and r.syscall["syscall_id"].tolist() == [E.SYS_COMMIT] * 8 + [E.SYS_HALT] and pv["next_pc"] == 0
+    assert r.syscall["arg2"][:8].tolist() == pv["committed_value_digest"] and r.syscall["arg1"][:8].tolist() == list(range(8))
+    pvs = F.from_monty(M.public_values(pv))
+    t = F.from_monty(oracle.tracegen_syscall_instrs(r.syscall))
+    assert air.debug_constraints(rec.b, t, public_values=pvs) == [] and not t[9:].any()
+    assert t[:9, 5].tolist() == [0] * 8 + [1] and t[:8, 38:46].tolist() == np.eye(8, dtype=int).tolist()      # is_halt; index_bitmap
+    wrong = dict(pv, committed_value_digest=[w ^ (1 << 9) if i == 3 else w for i, w in enumerate(pv["committed_value_digest"])])
+    assert {row for _, row in air.debug_constraints(rec.b, t, public_values=F.from_monty(M.public_values(wrong)))} == {3}
+    assert {row for _, row in air.debug_constraints(rec.b, t, public_values=F.from_monty(M.public_values(dict(pv, exit_code=1))))} == {8}
+    cpu = chips.record_cpu_constraints()
+    tc = F.from_monty(oracle.tracegen_cpu(r.cpu, prog, PC_BASE, SHARD))
+    n = len(r.cpu)
+    assert air.debug_constraints(cpu.b, tc, public_values=pvs) == [] and tc[n - 1, 24] == 1 and tc[n - 1, 25] == 0 and not tc[n:, 65].any()
+    kinds = sorted(lk.kind for lk in rec.sends)
+    assert kinds == [air.KIND_SYSCALL, air.KIND_SYSCALL_RESULT] and [lk.kind for lk in rec.receives] == [air.KIND_INSTRUCTION]
 
 
 def test_cpu_constraints_hold(oracle):
@@ -188,6 +213,8 @@ def device_trace(ctx, chip, ev, lh, blu, prog):
         return ctx.tracegen_cpu(ev, prog, PC_BASE, SHARD, lh, blu)
     if chip == "memory_local":
         return ctx.tracegen_memory_local(ev, lh)
+    if chip == "syscall_instrs":
+        return ctx.tracegen_syscall_instrs(ev, lh)
     if chip == "memory_instrs":
         return ctx.tracegen_memory_instrs(ev, lh, blu)
     if chip == "jump":
@@ -208,7 +235,7 @@ def test_gpu_cpu_and_program_tracegen_match_oracle(hip_ctx, oracle):
     from ziren_amd import lib
     assert lib.load().zkm_tracegen_cpu_width() == M.CPU_WIDTH
     for n, fixed in ((0, -1), (1, -1), (17, -1), (3000, -1), (5000, 14)):
-        prog, rec, pv = M.run(n, seed=n + 2)
+        prog, rec, pv = M.run(n, seed=n + 2, halt=n > 0)
         counts = np.zeros((1 << 16, 10), dtype=np.uint32)
         want = oracle.tracegen_cpu(rec.cpu, prog, PC_BASE, SHARD, fixed, counts)
         blu = hip_ctx.byte_lookups()
@@ -233,6 +260,10 @@ def test_gpu_cpu_and_program_tracegen_match_oracle(hip_ctx, oracle):
         assert (born.height, born.width) == want.shape and np.array_equal(born.to_host(), want), n
         assert np.array_equal(F.from_monty(mults.to_host()), counts), n
         born.free(); mults.free(); blu.free()
+        want = oracle.tracegen_syscall_instrs(rec.syscall)
+        born = hip_ctx.tracegen_syscall_instrs(rec.syscall)
+        assert (born.height, born.width) == want.shape and np.array_equal(born.to_host(), want), n
+        born.free()
         want = oracle.tracegen_memory_local(rec.memory_local)
         born = hip_ctx.tracegen_memory_local(rec.memory_local)
         assert (born.height, born.width) == want.shape and np.array_equal(born.to_host(), want), n

@@ -132,11 +132,10 @@ class _Rec:
         self.receive_instruction(pc, next_pc, next_pc + 4, opcode, a, b, c, 1, mult)
 
     def receive_instruction(self, pc, next_pc, next_next_pc, opcode, a, b, c, is_sequential, mult, hi=(0, 0, 0, 0), is_rw_a=0,
-                            op_a_immutable=0, shard=0, clk=0, is_check_memory=0):
-        """InstructionAirBuilder::receive_instruction (builder.rs:237-280) with num_extra_cycles and is_halt zero, as
-        every chip here calls it."""
-        vals = [shard, clk, pc, next_pc, next_next_pc, 0, opcode] + list(a) + list(b) + list(c) + list(hi) + \
-               [op_a_immutable, is_rw_a, is_check_memory, 0, is_sequential]
+                            op_a_immutable=0, shard=0, clk=0, is_check_memory=0, num_extra_cycles=0, is_halt=0):
+        """InstructionAirBuilder::receive_instruction (builder.rs:237-280)."""
+        vals = [shard, clk, pc, next_pc, next_next_pc, num_extra_cycles, opcode] + list(a) + list(b) + list(c) + list(hi) + \
+               [op_a_immutable, is_rw_a, is_check_memory, is_halt, is_sequential]
         self.receives.append(air.Lookup([air.to_virtual_pair(v) for v in vals], air.to_virtual_pair(mult), air.KIND_INSTRUCTION))
 
 
@@ -791,6 +790,94 @@ def _memory_instrs(r: _Rec):
                           op_a_immutable=is_sb + is_sh + is_sw + is_swl + is_swr, shard=l[SHARD], clk=l[CLK], is_check_memory=1)
 
 
+def _is_zero(b, a, cols, is_real):
+    """IsZeroOperation::eval (operations/is_zero.rs:33-49): cols = (inverse, result)."""
+    inverse, result = cols[0], cols[1]
+    b.when(is_real).assert_eq(1 - inverse * a, result)
+    b.when(is_real).assert_bool(result)
+    b.when(is_real).when(result).assert_zero(a)
+
+
+def _syscall_instrs(r: _Rec):
+    """SyscallInstrsChip::eval (syscall/instructions/air.rs:22-400). Public values: committed_value_digest (words 0..8 as bytes),
+    deferred_proofs_digest (32..40), exit_code (42)."""
+    l, b = r.local, r.b
+    (PC, NEXT_PC, SHARD, CLK, EXTRA, IS_HALT, IS_LINUX, A1_ZERO, SYSCALL_ID, OP_A, OP_B, OP_C, PREV_A, IS_ENTER, IS_HINT, HALT_CHECK, EXIT_CHECK,
+     IS_COMMIT, IS_DEFERRED, BITMAP, B_RC, C_RC, B_CHECK, C_CHECK, IS_REAL) = (
+        0, 1, 2, 3, 4, 5, 6, 7, 9, 10, 14, 18, 22, 26, 28, 30, 32, 34, 36, 38, 46, 60, 74, 75, 76)
+    a_val, b_val, c_val, prev_a = l[OP_A:OP_A + 4], l[OP_B:OP_B + 4], l[OP_C:OP_C + 4], l[PREV_A:PREV_A + 4]
+    is_real = l[IS_REAL]
+    syscall_id = prev_a[0] + prev_a[1] * 256
+    send_to_table = l[IS_LINUX] + prev_a[2]
+    b.assert_bool(is_real)
+    # eval_is_halt_syscall
+    _is_zero(b, syscall_id - E.SYS_HALT, l[HALT_CHECK:HALT_CHECK + 2], is_real)
+    _is_zero(b, syscall_id - E.SYS_EXT_GROUP, l[EXIT_CHECK:EXIT_CHECK + 2], is_real)
+    b.assert_eq(l[IS_HALT], (l[HALT_CHECK + 1] + l[EXIT_CHECK + 1]) * is_real)
+    r.receive_instruction(l[PC], l[NEXT_PC], l[NEXT_PC] + 4, E.SYSCALL, a_val, b_val, c_val, 1 - l[IS_HALT], is_real, hi=prev_a, is_rw_a=1,
+                          shard=l[SHARD], clk=l[CLK], is_check_memory=1, num_extra_cycles=l[EXTRA], is_halt=l[IS_HALT])
+    b.assert_eq(l[EXTRA], prev_a[3] * is_real)
+    # eval_syscall
+    b.assert_bool(prev_a[2])
+    b.assert_bool(l[IS_LINUX])
+    b.assert_bool(send_to_table)
+    _is_zero(b, prev_a[1], l[A1_ZERO:A1_ZERO + 2], is_real)
+    b.when(is_real).assert_eq(l[IS_LINUX], 1 - l[A1_ZERO + 1])
+    b.when(1 - is_real).assert_zero(send_to_table)
+    b.assert_bool(l[B_CHECK])
+    b.assert_bool(l[C_CHECK])
+    b.when(send_to_table).assert_one(l[B_CHECK])
+    b.when(l[IS_HALT]).assert_one(l[B_CHECK])
+    b.when(send_to_table).assert_one(l[C_CHECK])
+    b.when(l[IS_DEFERRED + 1]).assert_one(l[C_CHECK])
+    b.when_not(is_real).assert_zero(l[B_CHECK])
+    b.when_not(is_real).assert_zero(l[C_CHECK])
+    _word_range_check(b, b_val, l[B_RC:B_RC + 14], l[B_CHECK])
+    _word_range_check(b, c_val, l[C_RC:C_RC + 14], l[C_CHECK])
+    r.sends.append(air.Lookup([air.to_virtual_pair(v) for v in [l[SHARD], l[CLK], syscall_id, _reduce(b, b_val), _reduce(b, c_val)]],
+                              air.to_virtual_pair(send_to_table), air.KIND_SYSCALL))
+    halves = lambda w: [w[0] + w[1] * 256, w[2] + w[3] * 256]   # noqa: E731  (word_to_halves, builder.rs:384-390)
+    r.sends.append(air.Lookup([air.to_virtual_pair(v) for v in [l[SHARD], l[CLK]] + halves(a_val) + halves(b_val) + halves(c_val)],
+                              air.to_virtual_pair(l[IS_LINUX]), air.KIND_SYSCALL_RESULT))
+    _is_zero(b, syscall_id - E.SYS_ENTER_UNCONSTRAINED, l[IS_ENTER:IS_ENTER + 2], is_real)
+    is_enter = l[IS_ENTER + 1]
+    b.when(is_real).when_not(is_enter).assert_eq(l[SYSCALL_ID], syscall_id)
+    b.when(is_real).when(is_enter).assert_eq(l[SYSCALL_ID], E.SYS_EXIT_UNCONSTRAINED)
+    _is_zero(b, syscall_id - E.SYS_HINT_LEN, l[IS_HINT:IS_HINT + 2], is_real)
+    is_hint = l[IS_HINT + 1]
+    for i in range(4):
+        b.when(is_real).when(is_enter).assert_eq(a_val[i], 0)
+    for i in range(4):
+        b.when(is_real).when_not(is_enter + is_hint + l[IS_LINUX]).assert_eq(a_val[i], prev_a[i])
+    # eval_commit
+    _is_zero(b, syscall_id - E.SYS_COMMIT, l[IS_COMMIT:IS_COMMIT + 2], is_real)
+    _is_zero(b, syscall_id - E.SYS_COMMIT_DEFERRED_PROOFS, l[IS_DEFERRED:IS_DEFERRED + 2], is_real)
+    is_commit, is_deferred = l[IS_COMMIT + 1], l[IS_DEFERRED + 1]
+    bitmap = l[BITMAP:BITMAP + 8]
+    bitmap_sum = b.const(0)
+    for bit in bitmap:
+        b.when(is_real).assert_bool(bit)
+        bitmap_sum = bitmap_sum + bit
+    b.when(is_real).when(is_commit + is_deferred).assert_one(bitmap_sum)
+    b.when(is_real).when(1 - (is_commit + is_deferred)).assert_zero(bitmap_sum)
+    for i, bit in enumerate(bitmap):
+        b.when(is_real).when(bit).assert_eq(b_val[0], i)
+    for i in range(3):
+        b.when(is_real).when(is_commit + is_deferred).assert_zero(b_val[i + 1])
+    for k in range(4):      # index_word_array: sum over the bitmap of the digest words' bytes
+        want = b.const(0)
+        for i in range(8):
+            want = want + bitmap[i] * b.public_values(4 * i + k)
+        b.when(is_real).when(is_commit).assert_eq(want, c_val[k])
+    want = b.const(0)
+    for i in range(8):
+        want = want + bitmap[i] * b.public_values(32 + i)
+    b.when(is_real).when(is_deferred).assert_eq(want, _reduce(b, c_val))
+    # eval_halt_unimpl
+    b.when(l[IS_HALT]).assert_zero(l[NEXT_PC])
+    b.when(l[IS_HALT]).assert_eq(_reduce(b, b_val), b.public_values(42))
+
+
 def _memory_local(r: _Rec):
     """MemoryLocalChip::eval (memory/local.rs:213-283): per entry, receive the access the shard starts from, send the one it
     ends with (kind Memory), and send both to the global table (kind Global: message, is_receive, is_send, kind)."""
@@ -1010,6 +1097,18 @@ def record_memory_instrs_chip(log_height: int) -> RecordedChip:
     """The MemoryInstructions chip (crates/core/machine/src/memory/instructions/): the fourteen loads and stores, MemInstrEvents,
     79 columns, local_only (trace.rs:93-95). Sends the address ADD and the sign-extension SUB to the AddSub chip."""
     return _finish(record_memory_instrs_constraints(), "MemoryInstrs", log_height, E.MEMORY_INSTRS_WIDTH, True)
+
+
+def record_syscall_instrs_constraints() -> _Rec:
+    r = _Rec(E.SYSCALL_INSTRS_WIDTH)
+    _syscall_instrs(r)
+    return r
+
+
+def record_syscall_instrs_chip(log_height: int) -> RecordedChip:
+    """The SyscallInstrs chip (crates/core/machine/src/syscall/instructions/): SyscallEvents, 77 columns. HALT (next_pc = 0, exit code
+    public), COMMIT / COMMIT_DEFERRED_PROOFS (the committed word is the public digest's), the bridge to the precompile tables."""
+    return _finish(record_syscall_instrs_constraints(), "SyscallInstrs", log_height, E.SYSCALL_INSTRS_WIDTH, False)
 
 
 def record_memory_local_chip(log_height: int) -> RecordedChip:

@@ -28,13 +28,13 @@ struct AluEvent {  // #[repr(C)] AluEvent, crates/core/executor/src/events/instr
 
 // crates/core/executor/src/opcode.rs:26-48
 enum : uint32_t { ADD = 0, SUB = 1, SLL = 9, SRL = 10, SRA = 11, ROR = 12, SLT = 13, SLTU = 14, AND = 15, OR = 16, XOR = 17, NOR = 18, CLZ = 19, CLO = 20 };
-enum Chip { ADD_SUB = 0, BITWISE = 1, LT = 2, SHIFT_LEFT = 3, SHIFT_RIGHT = 4, CLO_CLZ = 5, NUM_ALU_CHIPS = 6, JUMP = 6, MOV_COND = 7, BRANCH = 8, MUL = 9, DIVREM = 10, MEMORY_INSTRS = 11, NUM_CHIPS = 12 };
+enum Chip { ADD_SUB = 0, BITWISE = 1, LT = 2, SHIFT_LEFT = 3, SHIFT_RIGHT = 4, CLO_CLZ = 5, NUM_ALU_CHIPS = 6, JUMP = 6, MOV_COND = 7, BRANCH = 8, MUL = 9, DIVREM = 10, MEMORY_INSTRS = 11, SYSCALL_INSTRS = 12, NUM_CHIPS = 13 };
 
 __host__ __device__ constexpr int chip_width(int chip) {
-  return chip == ADD_SUB ? 19 : chip == BITWISE ? 18 : chip == LT ? 32 : chip == SHIFT_LEFT ? 44 : chip == SHIFT_RIGHT ? 67 : chip == CLO_CLZ ? 17 : chip == JUMP ? 66 : chip == MOV_COND ? 32 : chip == BRANCH ? 62 : chip == MUL ? 58 : chip == DIVREM ? 106 : chip == MEMORY_INSTRS ? 79 : 0;
+  return chip == ADD_SUB ? 19 : chip == BITWISE ? 18 : chip == LT ? 32 : chip == SHIFT_LEFT ? 44 : chip == SHIFT_RIGHT ? 67 : chip == CLO_CLZ ? 17 : chip == JUMP ? 66 : chip == MOV_COND ? 32 : chip == BRANCH ? 62 : chip == MUL ? 58 : chip == DIVREM ? 106 : chip == MEMORY_INSTRS ? 79 : chip == SYSCALL_INSTRS ? 77 : 0;
 }
 // words per event record: the seven-word AluEvent / JumpEvent / BranchEvent / MovCondEvent, the sixteen-word CompAluEvent
-__host__ __device__ constexpr int event_words(int chip) { return chip == MUL || chip == DIVREM || chip == MEMORY_INSTRS ? 16 : 7; }
+__host__ __device__ constexpr int event_words(int chip) { return chip == MUL || chip == DIVREM || chip == MEMORY_INSTRS ? 16 : chip == SYSCALL_INSTRS ? 14 : 7; }
 
 constexpr int THREADS = 256;
 
@@ -520,6 +520,53 @@ __device__ __forceinline__ void memory_instr_row(const uint32_t* p, uint32_t* r)
   r[MOST_SIG_BYTES_ZERO + 1] = fbool(upper == 0);
 }
 
+// SyscallInstrs chip: SyscallEvents of fourteen words (crates/core/executor/src/events/syscall.rs:7-29): pc, next_pc, shard, clk,
+// a_record (value, shard, timestamp, prev_value, prev_shard, prev_timestamp), a_record_is_real, syscall_id, arg1, arg2. Columns
+// syscall/instructions/columns.rs:9-58; row trace.rs:88-176 (six IsZeroOperations of the syscall id's differences: field inverses).
+namespace syscols {
+enum { PC = 0, NEXT_PC = 1, SHARD = 2, CLK = 3, NUM_EXTRA_CYCLES = 4, IS_HALT = 5, IS_SYS_LINUX = 6, IS_PREV_A1_ZERO = 7, SYSCALL_ID = 9, OP_A = 10,
+       OP_B = 14, OP_C = 18, PREV_A = 22, IS_ENTER_UNCONSTRAINED = 26, IS_HINT_LEN = 28, IS_HALT_CHECK = 30, IS_EXIT_GROUP_CHECK = 32, IS_COMMIT = 34,
+       IS_COMMIT_DEFERRED = 36, INDEX_BITMAP = 38, OP_B_RC = 46, OP_C_RC = 60, OP_B_CHECK = 74, OP_C_CHECK = 75, IS_REAL = 76 };
+}
+__device__ __forceinline__ void is_zero_cols(uint32_t id, uint32_t code, uint32_t* r) {   // IsZeroOperation of (id - code) in the field
+  const uint32_t diff = id >= code ? id - code : id + kb::P - code;
+  r[0] = diff ? kb::from_monty(kb::inv(kb::to_monty(diff))) : 0u;
+  r[1] = fbool(diff == 0);
+}
+__device__ __forceinline__ void syscall_instr_row(const uint32_t* p, uint32_t* r) {
+  using namespace syscols;
+  const uint32_t value = p[4], prev = p[7], arg1 = p[12], arg2 = p[13];
+  r[IS_REAL] = 1;
+  r[PC] = p[0];
+  r[NEXT_PC] = p[1];
+  r[SHARD] = p[2];
+  r[CLK] = p[3];
+  word(r + OP_A, value);
+  word(r + OP_B, arg1);
+  word(r + OP_C, arg2);
+  word(r + PREV_A, prev);
+  r[SYSCALL_ID] = p[11];
+  const uint32_t id = prev & 0xffff;
+  r[NUM_EXTRA_CYCLES] = prev >> 24;
+  const bool is_halt = id == 0 || id == 4246;
+  r[IS_HALT] = fbool(is_halt);
+  r[IS_SYS_LINUX] = fbool((prev & 0xff00) != 0);
+  const bool send_to_table = ((prev >> 8) & 0xff) != 0 || ((prev >> 16) & 0xff) == 1;
+  is_zero_cols((prev >> 8) & 0xff, 0, r + IS_PREV_A1_ZERO);
+  is_zero_cols(id, 3, r + IS_ENTER_UNCONSTRAINED);
+  is_zero_cols(id, 0xf0, r + IS_HINT_LEN);
+  is_zero_cols(id, 0, r + IS_HALT_CHECK);
+  is_zero_cols(id, 4246, r + IS_EXIT_GROUP_CHECK);
+  is_zero_cols(id, 0x10, r + IS_COMMIT);
+  is_zero_cols(id, 0x1a, r + IS_COMMIT_DEFERRED);
+  if (id == 0x10 || id == 0x1a) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) r[INDEX_BITMAP + i] = fbool(arg1 == (uint32_t)i);
+  }
+  if (send_to_table || is_halt) { r[OP_B_CHECK] = 1; range_checker(r + OP_B_RC, arg1); }
+  if (send_to_table || id == 0x1a) { r[OP_C_CHECK] = 1; range_checker(r + OP_C_RC, arg2); }
+}
+
 // ---- byte lookups: the ALU chips' generate_dependencies, ByteChip::generate_trace and ByteChip::trace -----------------
 // ByteOpcode, crates/core/executor/src/opcode.rs:195-216
 enum : uint32_t { B_AND = 0, B_OR = 1, B_XOR = 2, B_SLL = 3, B_U8RANGE = 4, B_SHRCARRY = 5, B_LTU = 6, B_MSB = 7, B_U16RANGE = 8, B_NOR = 9 };
@@ -651,6 +698,8 @@ template <> __device__ __forceinline__ void row_lookups<MEMORY_INSTRS>(const uin
   if (r[MOST_SIG_BYTES_ZERO + 1]) lookup(counts, B_LTU, 35, r[ADDR_WORD]);
 }
 
+template <> __device__ __forceinline__ void row_lookups<SYSCALL_INSTRS>(const uint32_t*, uint32_t, const LookupSink&) {}   // none (trace.rs:88-176)
+
 // events: n_events records of event_words(CHIP) words; out: column-major, `height` rows; grid = height / (tiles * THREADS), with
 // tiles = 1 for the plain row writer (most blocks in flight) and TILES_PER_BLOCK when counting.
 // counts (may be null): NUM_BYTE_OPS columns of BYTE_ROWS plain u32 counters; the byte lookups of every event row are
@@ -676,8 +725,9 @@ __global__ __launch_bounds__(THREADS) void alu_rows(const uint32_t* __restrict__
     for (int c = 0; c < W; c++) r[c] = 0;
     if (row < n_events) {
       const uint32_t* p = events + row * event_words(CHIP);
-      if constexpr (CHIP == MUL || CHIP == DIVREM || CHIP == MEMORY_INSTRS) {
-        if constexpr (CHIP == MUL) mul_row(p, r); else if constexpr (CHIP == DIVREM) divrem_row(p, r); else memory_instr_row(p, r);
+      if constexpr (CHIP == MUL || CHIP == DIVREM || CHIP == MEMORY_INSTRS || CHIP == SYSCALL_INSTRS) {
+        if constexpr (CHIP == MUL) mul_row(p, r); else if constexpr (CHIP == DIVREM) divrem_row(p, r);
+        else if constexpr (CHIP == MEMORY_INSTRS) memory_instr_row(p, r); else syscall_instr_row(p, r);
         if (count) row_lookups<CHIP>(r, 0, LookupSink{hkeys, hvals, HASH_SLOTS - 1, counts});
       } else {
         AluEvent e{p[0], p[1], (CHIP == JUMP || CHIP == BRANCH) ? p[2] : (p[2] & 0xff), p[3], p[4], p[5], p[6]};

@@ -1560,6 +1560,7 @@ static int tracegen_events(zkm_ctx* ctx, int chip, const void* events, size_t n_
       case tracegen::MUL: launch_alu_rows<tracegen::MUL>(ctx, d_events, n_events, height, m->d, counts); break;
       case tracegen::DIVREM: launch_alu_rows<tracegen::DIVREM>(ctx, d_events, n_events, height, m->d, counts); break;
       case tracegen::MEMORY_INSTRS: launch_alu_rows<tracegen::MEMORY_INSTRS>(ctx, d_events, n_events, height, m->d, counts); break;
+      case tracegen::SYSCALL_INSTRS: launch_alu_rows<tracegen::SYSCALL_INSTRS>(ctx, d_events, n_events, height, m->d, counts); break;
     }
     ctx->mark("trace generation");
     ctx->end_timing(false);  // synchronises: the caller's event buffer is free again
@@ -1638,6 +1639,11 @@ int zkm_tracegen_memory_instrs(zkm_ctx* ctx, const zkm_mem_instr_event* events, 
                                zkm_matrix** out) {
   static_assert(sizeof(zkm_mem_instr_event) == 64, "event records mirror the #[repr(C)] executor structs");
   return tracegen_events(ctx, tracegen::MEMORY_INSTRS, events, n_events, fixed_log2_rows, blu, out);
+}
+size_t zkm_tracegen_syscall_instrs_width(void) { return (size_t)tracegen::chip_width(tracegen::SYSCALL_INSTRS); }
+int zkm_tracegen_syscall_instrs(zkm_ctx* ctx, const zkm_syscall_event* events, size_t n_events, int fixed_log2_rows, zkm_matrix** out) {
+  static_assert(sizeof(zkm_syscall_event) == 56, "event records mirror the #[repr(C)] executor structs");
+  return tracegen_events(ctx, tracegen::SYSCALL_INSTRS, events, n_events, fixed_log2_rows, nullptr, out);
 }
 size_t zkm_tracegen_divrem_width(void) { return (size_t)tracegen::chip_width(tracegen::DIVREM); }
 int zkm_tracegen_divrem(zkm_ctx* ctx, const zkm_comp_alu_event* events, size_t n_events, int fixed_log2_rows, zkm_byte_lookups* blu,

@@ -514,3 +514,15 @@ def memory_dependencies(mem_events: np.ndarray) -> np.ndarray:
             if msb >> 7:
                 out.append((UNUSED_PC, UNUSED_PC + DEFAULT_PC_INC, SUB, [0, 0, 0], 0, int(e["a"]), unsigned, sign))
     return np.array(out, dtype=ALU_EVENT) if out else np.zeros(0, dtype=ALU_EVENT)
+
+
+# ---- syscall instructions: SyscallEvent (crates/core/executor/src/events/syscall.rs:7-29, #[repr(C)], 56 bytes) -----------------------
+SYSCALL = 30
+SYSCALL_EVENT = np.dtype([("pc", "<u4"), ("next_pc", "<u4"), ("shard", "<u4"), ("clk", "<u4"), ("a_record", MEMORY_WRITE_RECORD),
+                          ("a_record_is_real", "u1"), ("_pad", "u1", (3,)), ("syscall_id", "<u4"), ("arg1", "<u4"), ("arg2", "<u4")])
+assert SYSCALL_EVENT.itemsize == 56
+SYSCALL_INSTRS_WIDTH = 77
+# SyscallCode (crates/core/executor/src/syscalls/code.rs): byte 0-1 id, byte 2 "has its own table", byte 3 extra cycles
+SYS_HALT, SYS_WRITE, SYS_ENTER_UNCONSTRAINED, SYS_EXIT_UNCONSTRAINED, SYS_COMMIT, SYS_COMMIT_DEFERRED_PROOFS, SYS_HINT_LEN = 0, 2, 3, 4, 0x10, 0x1a, 0xf0
+SYS_EXT_GROUP = 4246
+REG_V0, REG_A0, REG_A1 = 2, 4, 5

@@ -60,7 +60,7 @@ class Record:
 
     def __init__(self):
         self.cpu, self.alu, self.mul, self.divrem, self.branch, self.jump, self.mov_cond = [], {c: [] for c in E.CHIP_NAMES}, [], [], [], [], []
-        self.memory_local, self.mem_instr = [], []
+        self.memory_local, self.mem_instr, self.syscall = [], [], []
 
 
 def _alu(op, b, c):
@@ -70,10 +70,13 @@ def _alu(op, b, c):
 _CHIP_OF = {op: chip for chip, ops in E.CHIP_OPCODES.items() for op in ops}
 
 
-def run(n_cycles: int, seed: int = 1, shard: int = 1, pc_base: int = 0x1000):
+def run(n_cycles: int, seed: int = 1, shard: int = 1, pc_base: int = 0x1000, halt: bool = False):
     """Execute `n_cycles` instructions of a program generated on the way. Returns (program, record, public_values) with
     program: INSTRUCTION array (instructions that were jumped over are `ADD $0, 0, 0` no-ops that never run), record:
-    structured event arrays, public_values: dict of the words the Cpu chip checks (start_pc, next_pc, execution_shard)."""
+    structured event arrays, public_values: dict of the words the Cpu chip checks (start_pc, next_pc, execution_shard).
+    With `halt`, the program ends as a real one does: eight COMMIT syscalls publish the words of a value digest, then HALT
+    (execute_operation's SYSCALL arm, executor.rs:1591-1668): 35 more cycles, next_pc = 0, and the public values carry the
+    committed digest and exit code 0."""
     rng = np.random.default_rng(seed)
     R = [int(x) for x in rng.integers(0, 1 << 32, 34, dtype=np.uint64)]
     R[0] = 0
@@ -107,13 +110,26 @@ def run(n_cycles: int, seed: int = 1, shard: int = 1, pc_base: int = 0x1000):
         last[reg] = (shard, clk + pos)
         return r
 
-    for cyc in range(n_cycles):
+    digest = [int(x) for x in rng.integers(0, 1 << 32, 8, dtype=np.uint64)]
+    epilogue = []
+    if halt:   # li $v0, code; li $a0, arg1; li $a1, arg2; syscall — eight commits, then halt with exit code 0
+        for i, w in enumerate(digest):
+            epilogue += [(E.ADD, E.REG_V0, E.SYS_COMMIT, 0, 1, 1), (E.ADD, E.REG_A0, i, 0, 1, 1), (E.ADD, E.REG_A1, w, 0, 1, 1),
+                         (E.SYSCALL, E.REG_V0, E.REG_A0, E.REG_A1, 0, 0)]
+        epilogue += [(E.ADD, E.REG_V0, E.SYS_HALT, 0, 1, 1), (E.ADD, E.REG_A0, 0, 0, 1, 1), (E.SYSCALL, E.REG_V0, E.REG_A0, E.REG_A1, 0, 0)]
+    cyc = -1
+    while cyc + 1 < n_cycles + len(epilogue):
+        cyc += 1
         clk = 5 * cyc
         u = rng.random()
+        if cyc >= n_cycles and delay_slot:      # a branch's delay slot comes first: one more plain instruction
+            epilogue.insert(cyc - n_cycles, (E.ADD, 1, 0, 0, 1, 1))
         reg = lambda: int(rng.integers(0, 32))       # noqa: E731
         dst = lambda: int(rng.integers(1, 32)) if rng.random() > 0.02 else 0   # noqa: E731  (a few writes to $0)
         # ---- pick the instruction at pc (the program is written as it runs)
-        if pending_jump_reg is not None and not delay_slot:
+        if cyc >= n_cycles:
+            ins = epilogue[cyc - n_cycles]
+        elif pending_jump_reg is not None and not delay_slot:
             ins = (E.JUMP, dst(), pending_jump_reg, 0, 0, 1)
             pending_jump_reg = None
         elif delay_slot or u < 0.36:
@@ -163,7 +179,7 @@ def run(n_cycles: int, seed: int = 1, shard: int = 1, pc_base: int = 0x1000):
         # ---- execute it
         next_next_pc = next_pc + 4
         a_rec = b_rec = c_rec = hi_rec = m_rec = None
-        hi = None
+        hi = syscall_next = None
         was_delay_slot, delay_slot = delay_slot, False
         if op in _CHIP_OF or op in (E.MUL, E.MULT, E.MULTU, E.DIV, E.DIVU, E.MOD, E.MODU):
             if not imm_c:
@@ -224,6 +240,20 @@ def run(n_cycles: int, seed: int = 1, shard: int = 1, pc_base: int = 0x1000):
                 a = rt
             hi = rt
             rec.mem_instr.append((shard, clk, pc, next_pc, op, [0, 0, 0], a, b, c, TAG_WRITE, list(m_rec[2]), rt))
+        elif op == E.SYSCALL:
+            code = R[op_a]                                 # peeked: the write record's prev_value carries it
+            c_rec = read(op_c, clk, POS_C)
+            c = c_rec[1][0]
+            b_rec = read(op_b, clk, POS_B)
+            b = b_rec[1][0]
+            sid = code & 0xffff
+            assert sid in (E.SYS_HALT, E.SYS_COMMIT), sid
+            a = code                                       # neither returns a value: V0 keeps the code
+            a_rec = write(op_a, a, clk, POS_A)
+            hi = code
+            next_pc_after = 0 if sid == E.SYS_HALT else next_pc
+            rec.syscall.append((pc, next_pc_after, shard, clk, a_rec[2], 1, [0, 0, 0], sid, b, c))
+            syscall_next = next_pc_after
         elif op in _BRANCH:
             if op in _ONE_OPERAND:
                 b = 0
@@ -265,6 +295,8 @@ def run(n_cycles: int, seed: int = 1, shard: int = 1, pc_base: int = 0x1000):
             raise AssertionError(op)
         del was_delay_slot
         # op_a_value of the Cpu row is `a` as computed (a write to $0 stores 0 but the event keeps the result)
+        if syscall_next is not None:       # next_pc = precompile_next_pc, next_next_pc = precompile_next_pc + 4 (executor.rs:1660-1661)
+            next_pc, next_next_pc = syscall_next, syscall_next + 4
         rec.cpu.append((clk, pc, next_pc, next_next_pc, a, a_rec, b, b_rec, c, c_rec, hi, hi_rec, m_rec))
         pc, next_pc = next_pc, next_next_pc
 
@@ -303,9 +335,11 @@ def run(n_cycles: int, seed: int = 1, shard: int = 1, pc_base: int = 0x1000):
     out.jump = np.array(rec.jump, dtype=E.JUMP_EVENT) if rec.jump else np.zeros(0, dtype=E.JUMP_EVENT)
     out.mov_cond = np.array(rec.mov_cond, dtype=E.MOV_COND_EVENT) if rec.mov_cond else np.zeros(0, dtype=E.MOV_COND_EVENT)
     out.mem_instr = np.array(rec.mem_instr, dtype=E.MEM_INSTR_EVENT) if rec.mem_instr else np.zeros(0, dtype=E.MEM_INSTR_EVENT)
+    out.syscall = np.array(rec.syscall, dtype=E.SYSCALL_EVENT) if rec.syscall else np.zeros(0, dtype=E.SYSCALL_EVENT)
     out.memory_local = np.array([(reg, first[reg], (last[reg][0], last[reg][1], R[reg])) for reg in sorted(first)], dtype=MEMORY_LOCAL_EVENT) \
         if first else np.zeros(0, dtype=MEMORY_LOCAL_EVENT)
-    pv = {"start_pc": pc_base, "next_pc": int(cpu["next_pc"][-1]) if len(cpu) else pc_base, "execution_shard": shard, "shard": shard}
+    pv = {"start_pc": pc_base, "next_pc": int(cpu["next_pc"][-1]) if len(cpu) else pc_base, "execution_shard": shard, "shard": shard,
+          "exit_code": 0, "committed_value_digest": digest if halt else [0] * 8}
     return prog, out, pv
 
 
@@ -320,7 +354,7 @@ def add_dependencies(rec: Record) -> Record:
     alu[E.CHIP_LT] = np.concatenate([alu[E.CHIP_LT], lt_dep, div_lt])
     out = Record()
     out.cpu, out.alu, out.branch, out.jump, out.mov_cond, out.divrem = rec.cpu, alu, rec.branch, rec.jump, rec.mov_cond, rec.divrem
-    out.memory_local, out.mem_instr = rec.memory_local, rec.mem_instr
+    out.memory_local, out.mem_instr, out.syscall = rec.memory_local, rec.mem_instr, rec.syscall
     out.mul = np.concatenate([rec.mul, div_mul])
     return out
 
@@ -330,4 +364,7 @@ def public_values(pv: dict) -> np.ndarray:
     from . import synth
     v = np.zeros(synth.PROOF_MAX_NUM_PVS, dtype=np.uint64)
     v[PV_START_PC], v[PV_NEXT_PC], v[PV_SHARD], v[PV_EXECUTION_SHARD] = pv["start_pc"], pv["next_pc"], pv["shard"], pv["execution_shard"]
+    v[PV_EXIT_CODE] = pv.get("exit_code", 0)
+    for i, w in enumerate(pv.get("committed_value_digest", [0] * 8)):     # [Word; 8]: one field element per byte
+        v[4 * i:4 * i + 4] = [(w >> (8 * k)) & 0xff for k in range(4)]
     return F.to_monty(v)
