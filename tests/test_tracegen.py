@@ -155,6 +155,23 @@ def test_gpu_tracegen_errors(hip_ctx):
         hip_ctx.tracegen_alu(E.CHIP_LT, ev, 5)
     with pytest.raises(lib.ZkmError, match="unknown chip"):
         hip_ctx.tracegen_alu(9, ev)
+    # every event-driven generator refuses a fixed height its events do not fit in, and a null event pointer with a count
+    import ctypes as C
+    from ziren_amd import miniexec as M
+    prog, rec, _ = M.run(300, seed=2, halt=True)
+    for call in (lambda: hip_ctx.tracegen_mul(E.synthetic_mul_events(40), 5), lambda: hip_ctx.tracegen_divrem(E.synthetic_divrem_events(40), 5),
+                 lambda: hip_ctx.tracegen_branch(E.synthetic_branch_events(40), 5), lambda: hip_ctx.tracegen_jump(E.synthetic_jump_events(40), 5),
+                 lambda: hip_ctx.tracegen_mov_cond(E.synthetic_mov_cond_events(40), 5), lambda: hip_ctx.tracegen_memory_instrs(rec.mem_instr, 4),
+                 lambda: hip_ctx.tracegen_cpu(rec.cpu, prog, 0x1000, 1, 6), lambda: hip_ctx.tracegen_memory_local(rec.memory_local, 2),
+                 lambda: hip_ctx.tracegen_program(prog, 0x1000, 4), lambda: hip_ctx.tracegen_syscall_instrs(rec.syscall, 3),
+                 lambda: hip_ctx.tracegen_poseidon2_wide(np.zeros(32 * 40, dtype=np.uint32), 5)):
+        with pytest.raises(lib.ZkmError, match="too small"):
+            call()
+    L = lib.load()
+    h = C.c_void_p()
+    for fn, extra in ((L.zkm_tracegen_mul, (None,)), (L.zkm_tracegen_divrem, (None,)), (L.zkm_tracegen_memory_instrs, (None,)),
+                      (L.zkm_tracegen_syscall_instrs, ()), (L.zkm_tracegen_memory_local, ()), (L.zkm_tracegen_poseidon2_wide, ())):
+        assert fn(hip_ctx.h, None, C.c_size_t(3), C.c_int(-1), *extra, C.byref(h)) != 0 and b"null" in L.zkm_last_error()
 
 
 @pytest.mark.gpu
