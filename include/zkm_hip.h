@@ -385,6 +385,18 @@ typedef struct zkm_syscall_event {
 } zkm_syscall_event;
 size_t zkm_tracegen_syscall_instrs_width(void);
 int zkm_tracegen_syscall_instrs(zkm_ctx* ctx, const zkm_syscall_event* events, size_t n_events, int fixed_log2_rows, zkm_matrix** out);
+/* The MiscInstrs chip (crates/core/machine/src/misc/others/: SEXT EXT INS MADDU MSUBU MADD MSUB TEQ): replaces generate_trace
+ * (trace.rs:42-84), which also records the byte lookups (counted into `blu` if given). Events are the #[repr(C)] MiscEvents of
+ * crates/core/executor/src/events/instr.rs:239-261 (60 bytes). 72 columns, zero padding rows. */
+typedef struct zkm_misc_event {
+  uint32_t shard, clk, pc, next_pc;
+  uint8_t opcode, _pad[3];
+  uint32_t a, b, c, prev_a;
+  zkm_memory_write_record hi_record;
+} zkm_misc_event;
+size_t zkm_tracegen_misc_instrs_width(void);
+int zkm_tracegen_misc_instrs(zkm_ctx* ctx, const zkm_misc_event* events, size_t n_events, int fixed_log2_rows, zkm_byte_lookups* blu,
+                             zkm_matrix** out);
 /* The MemoryLocal chip (crates/core/machine/src/memory/local.rs): replaces generate_trace (:147-190). Events are the
  * #[repr(C)] MemoryLocalEvents of crates/core/executor/src/events/memory.rs:226-237 (ExecutionRecord::get_local_mem_events),
  * four per row, 56 columns, zero padding. */

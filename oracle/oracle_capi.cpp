@@ -526,4 +526,16 @@ int orc_tracegen_syscall_instrs(const void* events, size_t n_events, int fixed_l
   ORC_CATCH
 }
 
+// MiscInstrs chip (MiscEvent, 60 bytes): 72 columns; byte_counts as for orc_tracegen_branch
+int orc_tracegen_misc_instrs(const void* events, size_t n_events, int fixed_log2_rows, uint32_t* out, size_t out_cap, uint32_t* byte_counts) {
+  ORC_TRY
+  size_t h;
+  std::vector<uint64_t> cnt(byte_counts ? tracegen::BYTE_ROWS * tracegen::NUM_BYTE_OPS : 0, 0);
+  std::vector<F> t = tracegen::generate_misc_instrs((const tracegen::MiscEvent*)events, n_events, fixed_log2_rows, &h, byte_counts ? cnt.data() : nullptr);
+  if (t.size() > out_cap) throw std::runtime_error("trace buffer too small");
+  for (size_t i = 0; i < t.size(); i++) out[i] = to_monty(t[i]);
+  for (size_t i = 0; i < cnt.size(); i++) byte_counts[i] += (uint32_t)cnt[i];
+  ORC_CATCH
+}
+
 }  // extern "C"

@@ -1039,4 +1039,87 @@ static inline std::vector<F> generate_syscall_instrs(const SyscallEvent* events,
   return t;
 }
 
+// ---- MiscInstrs chip: MiscEvents (crates/core/executor/src/events/instr.rs:239-261); columns misc/others/columns/*.rs (a union of four
+// per-opcode layouts in columns 20..63), row misc/others/trace.rs:90-273, AddDoubleOperation operations/adddouble.rs:19-78
+struct MiscEvent {
+  uint32_t shard, clk, pc, next_pc;
+  uint8_t opcode; uint8_t pad[3];
+  uint32_t a, b, c, prev_a;
+  MemoryWriteRecord hi_record;
+};
+static_assert(sizeof(MiscEvent) == 60, "MiscEvent is fifteen words");
+static const size_t MISC_INSTRS_WIDTH = 72;
+static inline void misc_instr_row(const MiscEvent& e, F* r, std::vector<ByteLookup>* lk) {
+  enum { SHARD = 0, CLK = 1, PC = 2, NEXT_PC = 3, OP_A = 4, PREV_A = 8, OP_B = 12, OP_C = 16, SPECIFIC = 20, IS_SEXT = 64, IS_INS = 65, IS_EXT = 66,
+         IS_MADDU = 67, IS_MSUBU = 68, IS_MADD = 69, IS_MSUB = 70, IS_TEQ = 71 };
+  const uint8_t o = e.opcode;
+  r[PC] = fu32(e.pc); r[NEXT_PC] = fu32(e.next_pc); r[SHARD] = fu32(e.shard); r[CLK] = fu32(e.clk);
+  word(r + OP_A, e.a); word(r + OP_B, e.b); word(r + OP_C, e.c); word(r + PREV_A, e.prev_a);
+  r[IS_SEXT] = o == 55; r[IS_EXT] = o == 53; r[IS_INS] = o == 45; r[IS_MADDU] = o == 46; r[IS_MSUBU] = o == 47; r[IS_MADD] = o == 48;
+  r[IS_MSUB] = o == 49; r[IS_TEQ] = o == 54;
+  F* sp = r + SPECIFIC;
+  if (o == 55 || o == 54) {   // SextCols: most_sig_bit, sig_byte, a_eq_b (11), is_seb, is_seh
+    uint32_t bit, byte;
+    if (e.c > 0) { sp[14] = 1; bit = (e.b & 0xffff) >> 15; byte = (e.b >> 8) & 0xff; }
+    else { sp[13] = 1; bit = (e.b & 0xff) >> 7; byte = e.b & 0xff; }
+    sp[0] = bit; sp[1] = byte;
+    is_equal_word_cols(e.a, e.b, sp + 2);
+    if (o == 55 && lk) lk->push_back(ByteLookup{B_MSB_OP, (uint8_t)byte, 0});
+  } else if (o >= 46 && o <= 49) {   // MaddsubCols: mul_lo, mul_hi, add_operation (value, value_hi, carry[7]), src2_hi, src2_lo, op_hi_access
+    const bool is_sign = o == 48 || o == 49, is_add = o == 46 || o == 48;
+    const uint64_t multiply = is_sign ? (uint64_t)((int64_t)(int32_t)e.b * (int64_t)(int32_t)e.c) : (uint64_t)e.b * e.c;
+    word(sp + 0, (uint32_t)multiply); word(sp + 4, (uint32_t)(multiply >> 32));
+    const uint32_t src2_lo = is_add ? e.prev_a : e.a, src2_hi = is_add ? e.hi_record.prev_value : e.hi_record.value;
+    const uint64_t bb = ((uint64_t)src2_hi << 32) + src2_lo, expected = multiply + bb;
+    word(sp + 8, (uint32_t)expected); word(sp + 12, (uint32_t)(expected >> 32));
+    uint32_t carry = 0;
+    for (int i = 0; i < 7; i++) {
+      carry = (((multiply >> (8 * i)) & 0xff) + ((bb >> (8 * i)) & 0xff) + carry) > 255;
+      sp[16 + i] = carry;
+    }
+    if (lk) {
+      F bytes[8];
+      for (uint64_t v : {multiply, bb, expected}) {
+        for (int i = 0; i < 8; i++) bytes[i] = (v >> (8 * i)) & 0xff;
+        range_checks(*lk, bytes, 8);
+      }
+    }
+    word(sp + 23, src2_hi); word(sp + 27, src2_lo);
+    memory_write_cols(e.hi_record, sp + 31, lk);
+  } else if (o == 53) {   // ExtCols: lsb, msbd, sll_val
+    const uint32_t lsb = e.c & 0x1f, msbd = e.c >> 5;
+    sp[0] = lsb; sp[1] = fu32(msbd);
+    word(sp + 2, e.b << (31 - lsb - msbd));
+    if (lk) {
+      lk->push_back(ByteLookup{B_U8RANGE_OP, (uint8_t)lsb, (uint8_t)msbd});
+      lk->push_back(ByteLookup{B_LTU_OP, (uint8_t)(lsb + msbd), 32});
+    }
+  } else if (o == 45) {   // InsCols: lsb, msb, ror_val, srl1_val, srl_val, sll_val, add_val
+    const uint32_t lsb = e.c & 0x1f, msb = e.c >> 5;
+    const uint32_t ror = lsb ? (e.prev_a >> lsb) | (e.prev_a << (32 - lsb)) : e.prev_a, srl1 = ror >> 1, srl = srl1 >> (msb - lsb);
+    const uint32_t sll = e.b << (31 - msb + lsb);
+    sp[0] = lsb; sp[1] = fu32(msb);
+    word(sp + 2, ror); word(sp + 6, srl1); word(sp + 10, srl); word(sp + 14, sll); word(sp + 18, srl + sll);
+    if (lk) {
+      lk->push_back(ByteLookup{B_U8RANGE_OP, (uint8_t)lsb, (uint8_t)msb});
+      lk->push_back(ByteLookup{B_LTU_OP, (uint8_t)lsb, (uint8_t)(msb + 1)});
+      lk->push_back(ByteLookup{B_LTU_OP, (uint8_t)msb, 32});
+    }
+  } else {
+    throw std::runtime_error("tracegen: invalid misc opcode");
+  }
+}
+static inline std::vector<F> generate_misc_instrs(const MiscEvent* events, size_t n_events, int fixed_log2_rows, size_t* height, uint64_t* byte_counts) {
+  const size_t h = padded_rows(n_events, fixed_log2_rows);
+  std::vector<F> t(h * MISC_INSTRS_WIDTH, 0);
+  std::vector<ByteLookup> lk;
+  for (size_t i = 0; i < n_events; i++) {
+    lk.clear();
+    misc_instr_row(events[i], t.data() + i * MISC_INSTRS_WIDTH, byte_counts ? &lk : nullptr);
+    for (const ByteLookup& l : lk) byte_counts[(((size_t)l.b << 8) + l.c) * NUM_BYTE_OPS + l.op]++;
+  }
+  *height = h;
+  return t;
+}
+
 }  // namespace tracegen

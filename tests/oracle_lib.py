@@ -364,3 +364,16 @@ def tracegen_syscall_instrs(events, fixed_log2_rows=-1):
     _check(lib().orc_tracegen_syscall_instrs(C.c_void_p(ev.ctypes.data), C.c_size_t(len(ev)), C.c_int(fixed_log2_rows), abi.as_u32p(out),
                                              C.c_size_t(out.size)))
     return out
+
+
+def tracegen_misc_instrs(events, fixed_log2_rows=-1, byte_counts=None):
+    """MiscInstrs chip rows from MiscEvents; byte_counts as for tracegen_branch."""
+    from ziren_amd import events as E
+    ev = np.ascontiguousarray(events, dtype=E.MISC_EVENT)
+    rows = C.c_size_t()
+    _check(lib().orc_tracegen_alu_rows(C.c_size_t(len(ev)), C.c_int(fixed_log2_rows), C.byref(rows)))
+    out = np.zeros((rows.value, E.MISC_INSTRS_WIDTH), dtype=np.uint32)
+    bc = abi.as_u32p(byte_counts) if byte_counts is not None else None
+    _check(lib().orc_tracegen_misc_instrs(C.c_void_p(ev.ctypes.data), C.c_size_t(len(ev)), C.c_int(fixed_log2_rows), abi.as_u32p(out),
+                                          C.c_size_t(out.size), bc))
+    return out

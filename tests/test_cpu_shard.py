@@ -47,6 +47,7 @@ def cpu_shard(oracle, n_cycles, seed=1):
         work.append((name, ev, lh))
     for name, ev, record, gen in (("branch", rec.branch, chips.record_branch_chip, oracle.tracegen_branch),
                                   ("memory_instrs", rec.mem_instr, chips.record_memory_instrs_chip, oracle.tracegen_memory_instrs),
+                                  ("misc_instrs", rec.misc, chips.record_misc_instrs_chip, oracle.tracegen_misc_instrs),
                                   ("mul", rec.mul, chips.record_mul_chip, oracle.tracegen_mul),
                                   ("divrem", rec.divrem, chips.record_divrem_chip, oracle.tracegen_divrem)):
         lh = log2_rows(len(ev))
@@ -81,7 +82,7 @@ def test_miniexec_record_is_coherent():
     assert (cpu["pc"][1:] == cpu["next_pc"][:-1]).all() and (cpu["next_pc"][1:] == cpu["next_next_pc"][:-1]).all()
     assert len(np.unique(cpu["pc"])) == 1500                      # forward only: every pc runs once
     total = sum(len(v) for v in rec.alu.values()) + len(rec.mul) + len(rec.divrem) + len(rec.branch) + len(rec.jump) + len(rec.mov_cond) + len(rec.mem_instr) \
-        + len(rec.syscall)
+        + len(rec.syscall) + len(rec.misc)
     assert total == 1500                                          # one chip event per cycle (emit_events)
     assert min(len(v) for v in rec.alu.values()) > 0 and len(rec.jump) > 0 and len(rec.divrem) > 0
     assert set(rec.mem_instr["opcode"].tolist()) == set(range(E.LB, E.SC + 1))     # all fourteen loads and stores
@@ -118,10 +119,11 @@ def test_memory_instrs_constraints_hold(oracle):
             assert int(e["a"]) == E.load_value(int(e["opcode"]), int(e["mem"][0]), addr, int(e["prev_a_val"]))
         else:
             assert int(e["mem"][0]) == E.store_value(int(e["opcode"]), int(e["mem"][3]), addr, int(e["prev_a_val"]))
-    for col in (4, 30, 35, 57, 70):   # op_a byte, addr byte, ls bits, stored / loaded word byte, unsigned_mem_val byte
+    lw = int(np.nonzero(ev["opcode"] == E.LW)[0][0])
+    for col in (4, 30, 35, 57, 70):   # op_a byte, addr byte, ls bits, loaded word byte, unsigned_mem_val byte (of a load)
         bad = t.copy()
-        bad[7, col] = (int(bad[7, col]) + 1) % F.P
-        assert {row for _, row in air.debug_constraints(rec.b, bad)} == {7}, col
+        bad[lw, col] = (int(bad[lw, col]) + 1) % F.P
+        assert {row for _, row in air.debug_constraints(rec.b, bad)} == {lw}, col
     kinds = [lk.kind for lk in rec.sends]
     assert kinds.count(air.KIND_INSTRUCTION) == 2 and kinds.count(air.KIND_BYTE) == 6 and kinds.count(air.KIND_MEMORY) == 1
     c = chips.record_memory_instrs_chip(10)     # mips_costs.json: MemoryInstrs 115
@@ -155,6 +157,33 @@ def test_syscall_instrs_and_halting_program(oracle):
     assert kinds == [air.KIND_SYSCALL, air.KIND_SYSCALL_RESULT] and [lk.kind for lk in rec.receives] == [air.KIND_INSTRUCTION]
 
 
+def test_misc_instrs_constraints_hold(oracle):
+    rec = chips.record_misc_instrs_constraints()
+    prog, r, pv = M.run(25000, seed=12)
+    ev = r.misc
+    assert set(ev["opcode"].tolist()) == {E.SEXT, E.EXT, E.INS, E.TEQ, E.MADDU, E.MSUBU, E.MADD, E.MSUB} and len(ev) > 700
+    counts = np.zeros((1 << 16, 10), dtype=np.uint32)
+    t = F.from_monty(oracle.tracegen_misc_instrs(ev, -1, counts))
+    assert air.debug_constraints(rec.b, t) == [] and not t[len(ev):].any()
+    # the reference's own program vectors (misc/others/mod.rs:31-58): SEXT of 0x8f8f, EXT / INS fields
+    assert E.misc_result(E.SEXT, 0x8f8f, 0) == 0xffffff8f and E.misc_result(E.SEXT, 0x8f8f, 1) == 0xffff8f8f and E.misc_result(E.SEXT, 0xf, 0) == 0xf
+    assert E.misc_result(E.EXT, 0x8f8f, 0x21) == (0x8f8f >> 1) & 3 and E.misc_result(E.INS, 0xbeef, 0x3e0, prev_a=0x1234) == 0xbeef
+    assert E.misc_result(E.INS, 0xdead, 0x2e8, prev_a=0xffffffff) == 0xff00adff | 0x00de0000
+    # EXT and INS are proven entirely by the instructions they send (shifts, rotations, one addition): only the split of `c` is a constraint
+    for op, cols in ((E.SEXT, (4, 21)), (E.EXT, (20,)), (E.INS, (21,)), (E.MADDU, (4, 24, 36, 58)), (E.MSUB, (8, 47)), (E.TEQ, (22,))):
+        row = int(np.nonzero(ev["opcode"] == op)[0][1])      # a result byte / an intermediate of that opcode's layout
+        for col in cols:
+            bad = t.copy()
+            bad[row, col] = (int(bad[row, col]) + 1) % F.P
+            assert {x for _, x in air.debug_constraints(rec.b, bad)} == {row}, (op, col)
+    kinds = [lk.kind for lk in rec.sends]
+    assert kinds.count(air.KIND_INSTRUCTION) == 9 and kinds.count(air.KIND_BYTE) == 20 and kinds.count(air.KIND_MEMORY) == 1
+    mul, sll, sr, add = E.misc_dependencies(ev)
+    n = {op: int((ev["opcode"] == op).sum()) for op in (E.EXT, E.INS)}
+    assert len(mul) == int((ev["opcode"] >= E.MADDU).sum() - (ev["opcode"] >= E.MEQ).sum()) and len(sll) == n[E.EXT] + n[E.INS]
+    assert len(sr) == n[E.EXT] + 4 * n[E.INS] and len(add) == n[E.INS]
+
+
 def test_cpu_constraints_hold(oracle):
     rec = chips.record_cpu_constraints()
     for n, seed in ((1, 1), (16, 2), (17, 3), (2500, 4)):
@@ -186,6 +215,7 @@ def test_shard_lookups_balance(oracle):
     assert {k[0] for k in without} == {air.KIND_MEMORY}          # without MemoryLocal the access chains stay open
     mirrors = global_mirrors(recs)
     assert [m.name for m in mirrors] == ["MemoryLocalMirror"]
+    assert {r.name for r in recs} >= {"Cpu", "MiscInstrs", "MemoryInstrs", "SyscallInstrs", "Mul", "DivRem", "MemoryLocal"} and len(recs) == 16
     assert not any(lookup_tally(recs + [byte, program] + mirrors).values())
 
 
@@ -217,6 +247,8 @@ def device_trace(ctx, chip, ev, lh, blu, prog):
         return ctx.tracegen_syscall_instrs(ev, lh)
     if chip == "memory_instrs":
         return ctx.tracegen_memory_instrs(ev, lh, blu)
+    if chip == "misc_instrs":
+        return ctx.tracegen_misc_instrs(ev, lh, blu)
     if chip == "jump":
         return ctx.tracegen_jump(ev, lh)
     if chip == "mov_cond":
@@ -256,6 +288,14 @@ def test_gpu_cpu_and_program_tracegen_match_oracle(hip_ctx, oracle):
         want = oracle.tracegen_memory_instrs(rec.mem_instr, -1, counts)
         blu = hip_ctx.byte_lookups()
         born = hip_ctx.tracegen_memory_instrs(rec.mem_instr, -1, blu)
+        mults = hip_ctx.tracegen_byte_mults(blu)
+        assert (born.height, born.width) == want.shape and np.array_equal(born.to_host(), want), n
+        assert np.array_equal(F.from_monty(mults.to_host()), counts), n
+        born.free(); mults.free(); blu.free()
+        counts = np.zeros((1 << 16, 10), dtype=np.uint32)
+        want = oracle.tracegen_misc_instrs(rec.misc, -1, counts)
+        blu = hip_ctx.byte_lookups()
+        born = hip_ctx.tracegen_misc_instrs(rec.misc, -1, blu)
         mults = hip_ctx.tracegen_byte_mults(blu)
         assert (born.height, born.width) == want.shape and np.array_equal(born.to_host(), want), n
         assert np.array_equal(F.from_monty(mults.to_host()), counts), n

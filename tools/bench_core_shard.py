@@ -53,6 +53,7 @@ def main():
              ("branch", pin(rec.branch), chips.record_branch_chip), ("mul", pin(rec.mul), chips.record_mul_chip),
              ("divrem", pin(rec.divrem), chips.record_divrem_chip),
              ("memory_instrs", pin(rec.mem_instr), chips.record_memory_instrs_chip), ("syscall_instrs", pin(rec.syscall), chips.record_syscall_instrs_chip),
+             ("misc_instrs", pin(rec.misc), chips.record_misc_instrs_chip),
              ("memory_local", pin(rec.memory_local), chips.record_memory_local_chip)]
     heights = [log2_rows(-(-len(ev) // 4) if c == "memory_local" else len(ev)) for c, ev, _ in work]
     recs = [chips.record_chip(c, lh) if rc is None else rc(lh) for (c, _, rc), lh in zip(work, heights)]
@@ -94,6 +95,8 @@ def main():
                 born.append(ctx.tracegen_memory_instrs(ev, lh, blu))
             elif c == "syscall_instrs":
                 born.append(ctx.tracegen_syscall_instrs(ev, lh))
+            elif c == "misc_instrs":
+                born.append(ctx.tracegen_misc_instrs(ev, lh, blu))
             else:
                 born.append(ctx.tracegen_alu(c, ev, lh, blu))
             tg_kernel += sum(ms for name, ms, _, _ in ctx.kernel_timings() if name.startswith("tracegen"))
@@ -113,7 +116,7 @@ def main():
     cells = sum((1 << c.log_height) * (c.main_width + 4 * c.perm_ext_width + 8) for c in recs)
     event_bytes = sum(len(ev) * ev.dtype.itemsize for _, ev, _ in work)
     print(json.dumps({"workload": f"CORE-{args.log_cycles}: 2^{args.log_cycles} executed instructions (Cpu rows) of a generated program; Cpu, Program, "
-                                  "AddSub, Bitwise, Lt, ShiftLeft, ShiftRight, CloClz, Mul, DivRem, Branch, Jump, MovCond, MemoryInstrs, SyscallInstrs, MemoryLocal, Byte",
+                                  "AddSub, Bitwise, Lt, ShiftLeft, ShiftRight, CloClz, Mul, DivRem, Branch, Jump, MovCond, MemoryInstrs, SyscallInstrs, MiscInstrs, MemoryLocal, Byte",
                       "executor_seconds_python": round(exec_s, 1), "program_instructions": int(len(prog)), "event_bytes": int(event_bytes),
                       "tracegen_ms": round(float(np.mean([x["tracegen_ms"] for x in res])), 3),
                       "tracegen_kernel_ms": round(float(np.mean([x["tracegen_kernel_ms"] for x in res])), 3),

@@ -790,6 +790,116 @@ def _memory_instrs(r: _Rec):
                           op_a_immutable=is_sb + is_sh + is_sw + is_swl + is_swr, shard=l[SHARD], clk=l[CLK], is_check_memory=1)
 
 
+def _add_double(r, a, a_hi, bw, b_hi, cols, is_real):
+    """AddDoubleOperation::eval (operations/adddouble.rs:80-150): cols = value(4), value_hi(4), carry(7)."""
+    b = r.b
+    value, value_hi, carry = cols[0:4], cols[4:8], cols[8:15]
+    ov = [a[0] + bw[0] - value[0]] + [a[i] + bw[i] - value[i] + carry[i - 1] for i in range(1, 4)]
+    for i in range(4):
+        b.when(is_real).assert_zero(ov[i] * (ov[i] - 256))
+    for i in range(4):
+        b.when(is_real).assert_zero(carry[i] * (ov[i] - 256))
+    for i in range(4):
+        b.when(is_real).assert_zero((carry[i] - 1) * ov[i])
+    oh = [a_hi[i] + b_hi[i] - value_hi[i] + carry[3 + i] for i in range(4)]
+    for i in range(4):
+        b.when(is_real).assert_zero(oh[i] * (oh[i] - 256))
+    for i in range(3):
+        b.when(is_real).assert_zero(carry[4 + i] * (oh[i] - 256))
+    for i in range(3):
+        b.when(is_real).assert_zero((carry[4 + i] - 1) * oh[i])
+    for i in range(7):
+        b.when(is_real).assert_bool(carry[i])
+    b.when(is_real).assert_bool(is_real)
+    for w in (a, a_hi, bw, b_hi, value, value_hi):
+        r.slice_range_check_u8(w, is_real)
+
+
+def _misc_instrs(r: _Rec):
+    """MiscInstrsChip::eval (misc/others/air.rs:18-446). Columns 20..63 are a union: every opcode's constraints are laid over the
+    same cells and gated by its flag."""
+    l, b = r.local, r.b
+    SHARD, CLK, PC, NEXT_PC, OP_A, PREV_A, OP_B, OP_C, SP = 0, 1, 2, 3, 4, 8, 12, 16, 20
+    is_sext, is_ins, is_ext, is_maddu, is_msubu, is_madd, is_msub, is_teq = (l[64 + i] for i in range(8))
+    a_val, prev_a, b_val, c_val = l[OP_A:OP_A + 4], l[PREV_A:PREV_A + 4], l[OP_B:OP_B + 4], l[OP_C:OP_C + 4]
+    opcode = (is_sext * E.SEXT + is_ins * E.INS + is_ext * E.EXT + is_maddu * E.MADDU + is_msubu * E.MSUBU + is_madd * E.MADD + is_msub * E.MSUB
+              + is_teq * E.TEQ)
+    is_real = is_sext + is_ins + is_ext + is_maddu + is_msubu + is_madd + is_msub + is_teq
+    for f in (is_sext, is_ins, is_ext, is_maddu, is_msubu, is_madd, is_msub, is_teq):
+        b.assert_bool(f)
+    b.assert_bool(is_real)
+    maddsub = is_maddu + is_msubu + is_madd + is_msub
+    is_rw_a = maddsub + is_ins
+    r.receive_instruction(l[PC], l[NEXT_PC], l[NEXT_PC] + 4, opcode, a_val, b_val, c_val, 1, maddsub, hi=prev_a, is_rw_a=is_rw_a,
+                          op_a_immutable=is_teq, shard=l[SHARD], clk=l[CLK], is_check_memory=maddsub)
+    r.receive_instruction(l[PC], l[NEXT_PC], l[NEXT_PC] + 4, opcode, a_val, b_val, c_val, 1, is_sext + is_teq + is_ext + is_ins, hi=prev_a,
+                          is_rw_a=is_rw_a, op_a_immutable=is_teq)
+    # eval_ext: lsb, msbd, sll_val
+    lsb, msbd, sll_val = l[SP], l[SP + 1], l[SP + 2:SP + 6]
+    r.send_alu(E.SLL, sll_val, b_val, [31 - lsb - msbd, 0, 0, 0], is_ext)
+    r.send_alu(E.SRL, a_val, sll_val, [31 - msbd, 0, 0, 0], is_ext)
+    b.when(is_ext).assert_eq(_reduce(b, c_val), lsb + msbd * 32)
+    r.send_byte(B_U8RANGE, 0, lsb, msbd, is_ext)
+    r.send_byte(B_LTU, 1, lsb + msbd, 32, is_ext)
+    # eval_ins: lsb, msb, ror_val, srl1_val, srl_val, sll_val, add_val
+    msb = l[SP + 1]
+    ror_val, srl1_val, srl_val, ins_sll, add_val = (l[SP + 2 + 4 * k:SP + 6 + 4 * k] for k in range(5))
+    r.send_alu(E.ROR, ror_val, prev_a, [0 + lsb, 0, 0, 0], is_ins)
+    r.send_alu(E.SRL, srl1_val, ror_val, [1, 0, 0, 0], is_ins)
+    r.send_alu(E.SRL, srl_val, srl1_val, [0 + msb - lsb, 0, 0, 0], is_ins)
+    r.send_alu(E.SLL, ins_sll, b_val, [31 - msb + lsb, 0, 0, 0], is_ins)
+    r.send_alu(E.ADD, add_val, srl_val, ins_sll, is_ins)
+    r.send_alu(E.ROR, a_val, add_val, [31 - msb, 0, 0, 0], is_ins)
+    b.when(is_ins).assert_eq(_reduce(b, c_val), lsb + msb * 32)
+    r.send_byte(B_U8RANGE, 0, lsb, msb, is_ins)
+    r.send_byte(B_LTU, 1, lsb, msb + 1, is_ins)
+    r.send_byte(B_LTU, 1, msb, 32, is_ins)
+    # eval_maddsub: mul_lo, mul_hi, add_operation (15), src2_hi, src2_lo, op_hi_access (13)
+    mul_lo, mul_hi, add_op = l[SP:SP + 4], l[SP + 4:SP + 8], l[SP + 8:SP + 23]
+    src2_hi, src2_lo = l[SP + 23:SP + 27], l[SP + 27:SP + 31]
+    hi_prev, hi_access = l[SP + 31:SP + 35], l[SP + 35:SP + 44]
+    hi_val = hi_access[0:4]
+    is_add, is_sub = is_maddu + is_madd, is_msubu + is_msub
+    r.send_alu((is_madd + is_msub) * E.MULT + (is_maddu + is_msubu) * E.MULTU, mul_lo, b_val, c_val, maddsub, hi=mul_hi)
+    for i in range(4):
+        b.when(maddsub).assert_eq(src2_hi[i], hi_prev[i] * is_add + hi_val[i] * is_sub)
+        b.when(maddsub).assert_eq(src2_lo[i], prev_a[i] * is_add + a_val[i] * is_sub)
+    _add_double(r, mul_lo, mul_hi, src2_lo, src2_hi, add_op, maddsub)
+    for i in range(4):
+        b.when(is_add).assert_eq(a_val[i], add_op[i])
+    for i in range(4):
+        b.when(is_add).assert_eq(hi_val[i], add_op[4 + i])
+    for i in range(4):
+        b.when(is_sub).assert_eq(prev_a[i], add_op[i])
+    for i in range(4):
+        b.when(is_sub).assert_eq(hi_prev[i], add_op[4 + i])
+    r.eval_memory_access(l[SHARD], l[CLK] + E.MEMORY_ACCESS_POSITION_HI, E.REGISTER_HI, hi_prev, hi_access, maddsub)
+    # eval_sext: most_sig_bit, sig_byte, a_eq_b (11), is_seb, is_seh
+    most_sig_bit, sig_byte, a_eq_b, is_seb, is_seh = l[SP], l[SP + 1], l[SP + 2:SP + 13], l[SP + 13], l[SP + 14]
+    b.assert_bool(is_teq)
+    _is_zero_word(b, [a_val[i] - b_val[i] for i in range(4)], a_eq_b, is_teq)
+    b.when(is_teq).assert_zero(a_eq_b[10])
+    r.send_byte(B_MSB, most_sig_bit, sig_byte, 0, is_sext)
+    b.when(is_sext).assert_bool(c_val[0])
+    b.when(is_sext).assert_bool(is_seb)
+    b.when(is_sext).assert_bool(is_seh)
+    b.when(is_sext).assert_one(is_seh + is_seb)
+    b.when(is_sext).when(is_seb).assert_zero(c_val[0])
+    b.when(is_sext).when(is_seh).assert_one(c_val[0])
+    b.when(is_sext).when(is_seb).assert_eq(b_val[0], sig_byte)
+    b.when(is_sext).when(is_seh).assert_eq(b_val[1], sig_byte)
+    sign_byte = most_sig_bit * 0xff
+    b.when(is_sext).assert_eq(a_val[0], b_val[0])
+    b.when(is_sext).when(is_seb).assert_eq(a_val[1], sign_byte)
+    b.when(is_sext).when(is_seh).assert_eq(a_val[1], b_val[1])
+    b.when(is_sext).assert_eq(a_val[2], sign_byte)
+    b.when(is_sext).assert_eq(a_val[3], sign_byte)
+    for i in range(4):
+        b.when(is_sext + is_ext + is_teq).assert_zero(prev_a[i])
+    b.when(is_ins + is_ext).assert_zero(c_val[2])
+    b.when(is_ins + is_ext).assert_zero(c_val[3])
+
+
 def _is_zero(b, a, cols, is_real):
     """IsZeroOperation::eval (operations/is_zero.rs:33-49): cols = (inverse, result)."""
     inverse, result = cols[0], cols[1]
@@ -1097,6 +1207,19 @@ def record_memory_instrs_chip(log_height: int) -> RecordedChip:
     """The MemoryInstructions chip (crates/core/machine/src/memory/instructions/): the fourteen loads and stores, MemInstrEvents,
     79 columns, local_only (trace.rs:93-95). Sends the address ADD and the sign-extension SUB to the AddSub chip."""
     return _finish(record_memory_instrs_constraints(), "MemoryInstrs", log_height, E.MEMORY_INSTRS_WIDTH, True)
+
+
+def record_misc_instrs_constraints() -> _Rec:
+    r = _Rec(E.MISC_INSTRS_WIDTH)
+    _misc_instrs(r)
+    return r
+
+
+def record_misc_instrs_chip(log_height: int) -> RecordedChip:
+    """The MiscInstrs chip (crates/core/machine/src/misc/others/): SEXT, EXT, INS, MADDU, MSUBU, MADD, MSUB, TEQ; MiscEvents, 72 columns
+    of which 44 are a union of per-opcode layouts. It proves its shifts, rotations, additions and multiplications by sending
+    them to the ShiftLeft / ShiftRight / AddSub / Mul chips."""
+    return _finish(record_misc_instrs_constraints(), "MiscInstrs", log_height, E.MISC_INSTRS_WIDTH, False)
 
 
 def record_syscall_instrs_constraints() -> _Rec:

@@ -28,13 +28,13 @@ struct AluEvent {  // #[repr(C)] AluEvent, crates/core/executor/src/events/instr
 
 // crates/core/executor/src/opcode.rs:26-48
 enum : uint32_t { ADD = 0, SUB = 1, SLL = 9, SRL = 10, SRA = 11, ROR = 12, SLT = 13, SLTU = 14, AND = 15, OR = 16, XOR = 17, NOR = 18, CLZ = 19, CLO = 20 };
-enum Chip { ADD_SUB = 0, BITWISE = 1, LT = 2, SHIFT_LEFT = 3, SHIFT_RIGHT = 4, CLO_CLZ = 5, NUM_ALU_CHIPS = 6, JUMP = 6, MOV_COND = 7, BRANCH = 8, MUL = 9, DIVREM = 10, MEMORY_INSTRS = 11, SYSCALL_INSTRS = 12, NUM_CHIPS = 13 };
+enum Chip { ADD_SUB = 0, BITWISE = 1, LT = 2, SHIFT_LEFT = 3, SHIFT_RIGHT = 4, CLO_CLZ = 5, NUM_ALU_CHIPS = 6, JUMP = 6, MOV_COND = 7, BRANCH = 8, MUL = 9, DIVREM = 10, MEMORY_INSTRS = 11, SYSCALL_INSTRS = 12, MISC_INSTRS = 13, NUM_CHIPS = 14 };
 
 __host__ __device__ constexpr int chip_width(int chip) {
-  return chip == ADD_SUB ? 19 : chip == BITWISE ? 18 : chip == LT ? 32 : chip == SHIFT_LEFT ? 44 : chip == SHIFT_RIGHT ? 67 : chip == CLO_CLZ ? 17 : chip == JUMP ? 66 : chip == MOV_COND ? 32 : chip == BRANCH ? 62 : chip == MUL ? 58 : chip == DIVREM ? 106 : chip == MEMORY_INSTRS ? 79 : chip == SYSCALL_INSTRS ? 77 : 0;
+  return chip == ADD_SUB ? 19 : chip == BITWISE ? 18 : chip == LT ? 32 : chip == SHIFT_LEFT ? 44 : chip == SHIFT_RIGHT ? 67 : chip == CLO_CLZ ? 17 : chip == JUMP ? 66 : chip == MOV_COND ? 32 : chip == BRANCH ? 62 : chip == MUL ? 58 : chip == DIVREM ? 106 : chip == MEMORY_INSTRS ? 79 : chip == SYSCALL_INSTRS ? 77 : chip == MISC_INSTRS ? 72 : 0;
 }
 // words per event record: the seven-word AluEvent / JumpEvent / BranchEvent / MovCondEvent, the sixteen-word CompAluEvent
-__host__ __device__ constexpr int event_words(int chip) { return chip == MUL || chip == DIVREM || chip == MEMORY_INSTRS ? 16 : chip == SYSCALL_INSTRS ? 14 : 7; }
+__host__ __device__ constexpr int event_words(int chip) { return chip == MUL || chip == DIVREM || chip == MEMORY_INSTRS ? 16 : chip == SYSCALL_INSTRS ? 14 : chip == MISC_INSTRS ? 15 : 7; }
 
 constexpr int THREADS = 256;
 
@@ -567,6 +567,76 @@ __device__ __forceinline__ void syscall_instr_row(const uint32_t* p, uint32_t* r
   if (send_to_table || id == 0x1a) { r[OP_C_CHECK] = 1; range_checker(r + OP_C_RC, arg2); }
 }
 
+// MiscInstrs chip: MiscEvents of fifteen words (crates/core/executor/src/events/instr.rs:239-261): shard, clk, pc, next_pc, opcode, a, b,
+// c, prev_a, hi_record (six words). Columns misc/others/columns/*.rs — cells 20..63 are a union of SextCols / ExtCols / InsCols /
+// MaddsubCols; row misc/others/trace.rs:90-273, AddDoubleOperation operations/adddouble.rs:19-78.
+namespace misccols {
+enum { SHARD = 0, CLK = 1, PC = 2, NEXT_PC = 3, OP_A = 4, PREV_A = 8, OP_B = 12, OP_C = 16, SPECIFIC = 20, IS_SEXT = 64, IS_INS = 65, IS_EXT = 66,
+       IS_MADDU = 67, IS_MSUBU = 68, IS_MADD = 69, IS_MSUB = 70, IS_TEQ = 71 };
+}
+__device__ __forceinline__ void misc_instr_row(const uint32_t* p, uint32_t* r) {
+  using namespace misccols;
+  const uint32_t o = p[4] & 0xff, a = p[5], b = p[6], c = p[7], prev_a = p[8];
+  r[SHARD] = p[0];
+  r[CLK] = p[1];
+  r[PC] = p[2];
+  r[NEXT_PC] = p[3];
+  word(r + OP_A, a);
+  word(r + OP_B, b);
+  word(r + OP_C, c);
+  word(r + PREV_A, prev_a);
+  r[IS_SEXT] = fbool(o == 55);
+  r[IS_EXT] = fbool(o == 53);
+  r[IS_INS] = fbool(o == 45);
+  r[IS_MADDU] = fbool(o == 46);
+  r[IS_MSUBU] = fbool(o == 47);
+  r[IS_MADD] = fbool(o == 48);
+  r[IS_MSUB] = fbool(o == 49);
+  r[IS_TEQ] = fbool(o == 54);
+  uint32_t* sp = r + SPECIFIC;
+  if (o == 55 || o == 54) {          // SextCols: most_sig_bit, sig_byte, a_eq_b (11), is_seb, is_seh
+    const bool half = c > 0;
+    sp[half ? 14 : 13] = 1;
+    sp[0] = half ? (b & 0xffff) >> 15 : (b & 0xff) >> 7;
+    sp[1] = half ? (b >> 8) & 0xff : b & 0xff;
+    is_equal_word_cols(a, b, sp + 2);
+  } else if (o >= 46 && o <= 49) {   // MaddsubCols: mul_lo, mul_hi, value, value_hi, carry[7], src2_hi, src2_lo, op_hi_access (13)
+    const bool is_sign = o >= 48, is_add = o == 46 || o == 48;
+    const uint64_t multiply = is_sign ? (uint64_t)((int64_t)(int32_t)b * (int64_t)(int32_t)c) : (uint64_t)b * c;
+    const uint32_t src2_lo = is_add ? prev_a : a, src2_hi = is_add ? p[12] : p[9];   // hi_record.prev_value / .value
+    const uint64_t addend = ((uint64_t)src2_hi << 32) + src2_lo, expected = multiply + addend;
+    word(sp + 0, (uint32_t)multiply);
+    word(sp + 4, (uint32_t)(multiply >> 32));
+    word(sp + 8, (uint32_t)expected);
+    word(sp + 12, (uint32_t)(expected >> 32));
+    uint32_t carry = 0;
+#pragma unroll
+    for (int i = 0; i < 7; i++) {
+      carry = ((uint32_t)((multiply >> (8 * i)) & 0xff) + (uint32_t)((addend >> (8 * i)) & 0xff) + carry) > 255 ? 1u : 0u;
+      sp[16 + i] = carry;
+    }
+    word(sp + 23, src2_hi);
+    word(sp + 27, src2_lo);
+    memory_write_cols(p + 9, sp + 31);
+  } else if (o == 53) {              // ExtCols: lsb, msbd, sll_val
+    const uint32_t lsb = c & 0x1f, msbd = c >> 5;
+    sp[0] = lsb;
+    sp[1] = msbd;
+    word(sp + 2, b << ((31 - lsb - msbd) & 31));
+  } else {                           // INS — InsCols: lsb, msb, ror_val, srl1_val, srl_val, sll_val, add_val
+    const uint32_t lsb = c & 0x1f, msb = c >> 5;
+    const uint32_t ror = (prev_a >> lsb) | (prev_a << ((32 - lsb) & 31)), srl1 = ror >> 1, srl = srl1 >> ((msb - lsb) & 31);
+    const uint32_t sll = b << ((31 - msb + lsb) & 31);
+    sp[0] = lsb;
+    sp[1] = msb;
+    word(sp + 2, ror);
+    word(sp + 6, srl1);
+    word(sp + 10, srl);
+    word(sp + 14, sll);
+    word(sp + 18, srl + sll);
+  }
+}
+
 // ---- byte lookups: the ALU chips' generate_dependencies, ByteChip::generate_trace and ByteChip::trace -----------------
 // ByteOpcode, crates/core/executor/src/opcode.rs:195-216
 enum : uint32_t { B_AND = 0, B_OR = 1, B_XOR = 2, B_SLL = 3, B_U8RANGE = 4, B_SHRCARRY = 5, B_LTU = 6, B_MSB = 7, B_U16RANGE = 8, B_NOR = 9 };
@@ -698,6 +768,29 @@ template <> __device__ __forceinline__ void row_lookups<MEMORY_INSTRS>(const uin
   if (r[MOST_SIG_BYTES_ZERO + 1]) lookup(counts, B_LTU, 35, r[ADDR_WORD]);
 }
 
+// MiscInstrs (misc/others/trace.rs:144-152,192-207,226-273): SEXT: MSB; MADD*: U8Range pairs of the three 64-bit operands of the add,
+// the HI access's two limbs; EXT: U8Range(lsb, msbd), LTU(lsb + msbd, 32); INS: U8Range(lsb, msb), LTU(lsb, msb + 1), LTU(msb, 32)
+template <> __device__ __forceinline__ void row_lookups<MISC_INSTRS>(const uint32_t* r, uint32_t, const LookupSink& counts) {
+  using namespace misccols;
+  const uint32_t* sp = r + SPECIFIC;
+  if (r[IS_SEXT]) {
+    lookup(counts, B_MSB, sp[1], 0);
+  } else if (r[IS_MADDU] | r[IS_MSUBU] | r[IS_MADD] | r[IS_MSUB]) {
+    range_checks(counts, sp + 0, 8);                    // the product: mul_lo, mul_hi
+    range_checks(counts, sp + 27, 4);                   // the addend: src2_lo ...
+    range_checks(counts, sp + 23, 4);                   // ... src2_hi
+    range_checks(counts, sp + 8, 8);                    // the sum: value, value_hi
+    lookup(counts, B_U16RANGE, sp[31 + 11] >> 8, sp[31 + 11]);
+    lookup(counts, B_U8RANGE, 0, sp[31 + 12]);
+  } else if (r[IS_EXT]) {
+    lookup(counts, B_U8RANGE, sp[0], sp[1]);
+    lookup(counts, B_LTU, sp[0] + sp[1], 32);
+  } else if (r[IS_INS]) {
+    lookup(counts, B_U8RANGE, sp[0], sp[1]);
+    lookup(counts, B_LTU, sp[0], sp[1] + 1);
+    lookup(counts, B_LTU, sp[1], 32);
+  }
+}
 template <> __device__ __forceinline__ void row_lookups<SYSCALL_INSTRS>(const uint32_t*, uint32_t, const LookupSink&) {}   // none (trace.rs:88-176)
 
 // events: n_events records of event_words(CHIP) words; out: column-major, `height` rows; grid = height / (tiles * THREADS), with
@@ -725,9 +818,10 @@ __global__ __launch_bounds__(THREADS) void alu_rows(const uint32_t* __restrict__
     for (int c = 0; c < W; c++) r[c] = 0;
     if (row < n_events) {
       const uint32_t* p = events + row * event_words(CHIP);
-      if constexpr (CHIP == MUL || CHIP == DIVREM || CHIP == MEMORY_INSTRS || CHIP == SYSCALL_INSTRS) {
+      if constexpr (CHIP == MUL || CHIP == DIVREM || CHIP == MEMORY_INSTRS || CHIP == SYSCALL_INSTRS || CHIP == MISC_INSTRS) {
         if constexpr (CHIP == MUL) mul_row(p, r); else if constexpr (CHIP == DIVREM) divrem_row(p, r);
-        else if constexpr (CHIP == MEMORY_INSTRS) memory_instr_row(p, r); else syscall_instr_row(p, r);
+        else if constexpr (CHIP == MEMORY_INSTRS) memory_instr_row(p, r); else if constexpr (CHIP == SYSCALL_INSTRS) syscall_instr_row(p, r);
+        else misc_instr_row(p, r);
         if (count) row_lookups<CHIP>(r, 0, LookupSink{hkeys, hvals, HASH_SLOTS - 1, counts});
       } else {
         AluEvent e{p[0], p[1], (CHIP == JUMP || CHIP == BRANCH) ? p[2] : (p[2] & 0xff), p[3], p[4], p[5], p[6]};

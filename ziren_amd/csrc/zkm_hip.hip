@@ -1107,6 +1107,7 @@ int zkm_ctx_create(int device, zkm_ctx** out) {
   HIP_CHECK(hipFuncSetAttribute((const void*)tracegen::alu_rows<tracegen::DIVREM>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
   HIP_CHECK(hipFuncSetAttribute((const void*)tracegen::cpu_rows, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
   HIP_CHECK(hipFuncSetAttribute((const void*)tracegen::alu_rows<tracegen::MEMORY_INSTRS>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+  HIP_CHECK(hipFuncSetAttribute((const void*)tracegen::alu_rows<tracegen::MISC_INSTRS>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
   HIP_CHECK(hipFuncSetAttribute((const void*)tracegen::alu_rows<tracegen::BRANCH>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
   HIP_CHECK(hipFuncSetAttribute((const void*)lde::lde_cols<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIP_CHECK(hipFuncSetAttribute((const void*)lde::lde_cols<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -1561,6 +1562,7 @@ static int tracegen_events(zkm_ctx* ctx, int chip, const void* events, size_t n_
       case tracegen::DIVREM: launch_alu_rows<tracegen::DIVREM>(ctx, d_events, n_events, height, m->d, counts); break;
       case tracegen::MEMORY_INSTRS: launch_alu_rows<tracegen::MEMORY_INSTRS>(ctx, d_events, n_events, height, m->d, counts); break;
       case tracegen::SYSCALL_INSTRS: launch_alu_rows<tracegen::SYSCALL_INSTRS>(ctx, d_events, n_events, height, m->d, counts); break;
+      case tracegen::MISC_INSTRS: launch_alu_rows<tracegen::MISC_INSTRS>(ctx, d_events, n_events, height, m->d, counts); break;
     }
     ctx->mark("trace generation");
     ctx->end_timing(false);  // synchronises: the caller's event buffer is free again
@@ -1644,6 +1646,12 @@ size_t zkm_tracegen_syscall_instrs_width(void) { return (size_t)tracegen::chip_w
 int zkm_tracegen_syscall_instrs(zkm_ctx* ctx, const zkm_syscall_event* events, size_t n_events, int fixed_log2_rows, zkm_matrix** out) {
   static_assert(sizeof(zkm_syscall_event) == 56, "event records mirror the #[repr(C)] executor structs");
   return tracegen_events(ctx, tracegen::SYSCALL_INSTRS, events, n_events, fixed_log2_rows, nullptr, out);
+}
+size_t zkm_tracegen_misc_instrs_width(void) { return (size_t)tracegen::chip_width(tracegen::MISC_INSTRS); }
+int zkm_tracegen_misc_instrs(zkm_ctx* ctx, const zkm_misc_event* events, size_t n_events, int fixed_log2_rows, zkm_byte_lookups* blu,
+                             zkm_matrix** out) {
+  static_assert(sizeof(zkm_misc_event) == 60, "event records mirror the #[repr(C)] executor structs");
+  return tracegen_events(ctx, tracegen::MISC_INSTRS, events, n_events, fixed_log2_rows, blu, out);
 }
 size_t zkm_tracegen_divrem_width(void) { return (size_t)tracegen::chip_width(tracegen::DIVREM); }
 int zkm_tracegen_divrem(zkm_ctx* ctx, const zkm_comp_alu_event* events, size_t n_events, int fixed_log2_rows, zkm_byte_lookups* blu,

@@ -526,3 +526,65 @@ SYSCALL_INSTRS_WIDTH = 77
 SYS_HALT, SYS_WRITE, SYS_ENTER_UNCONSTRAINED, SYS_EXIT_UNCONSTRAINED, SYS_COMMIT, SYS_COMMIT_DEFERRED_PROOFS, SYS_HINT_LEN = 0, 2, 3, 4, 0x10, 0x1a, 0xf0
 SYS_EXT_GROUP = 4246
 REG_V0, REG_A0, REG_A1 = 2, 4, 5
+
+
+# ---- misc instructions: MiscEvent (crates/core/executor/src/events/instr.rs:239-261, #[repr(C)], 60 bytes) ---------------------------
+INS, MADDU, MSUBU, MADD, MSUB = 45, 46, 47, 48, 49
+EXT, TEQ, SEXT = 53, 54, 55
+MISC_EVENT = np.dtype([("shard", "<u4"), ("clk", "<u4"), ("pc", "<u4"), ("next_pc", "<u4"), ("opcode", "u1"), ("_pad", "u1", (3,)),
+                       ("a", "<u4"), ("b", "<u4"), ("c", "<u4"), ("prev_a", "<u4"), ("hi_record", MEMORY_WRITE_RECORD)])
+assert MISC_EVENT.itemsize == 60
+MISC_INSTRS_WIDTH = 72
+
+
+def misc_result(opcode: int, b: int, c: int, prev_a: int = 0, hi_lo=(0, 0)):
+    """The executor's results for the MiscInstrs opcodes (executor.rs:1684-1826): SEXT / EXT / INS return `a`; MADDU / MSUBU / MADD /
+    MSUB return (lo, hi) of HI:LO +- b * c."""
+    M32 = 0xffffffff
+    if opcode == SEXT:
+        v = b & 0xffff if c > 0 else b & 0xff
+        sign = v >> (15 if c > 0 else 7)
+        return (v | (M32 ^ (0xffff if c > 0 else 0xff))) & M32 if sign else v
+    if opcode == EXT:
+        msbd, lsb = c >> 5, c & 0x1f
+        return (b & ((1 << (msbd + lsb + 1)) - 1)) >> lsb
+    if opcode == INS:
+        msb, lsb = c >> 5, c & 0x1f
+        field = (((1 << (msb - lsb + 1)) - 1) << lsb) & M32
+        return (prev_a & ~field & M32) | ((b << lsb) & field)
+    signed = opcode in (MADD, MSUB)
+    sb, sc = (b - (1 << 32) if signed and b >> 31 else b), (c - (1 << 32) if signed and c >> 31 else c)
+    addend = (hi_lo[0] << 32) + hi_lo[1]
+    out = (addend + sb * sc if opcode in (MADDU, MADD) else addend - sb * sc) & ((1 << 64) - 1)
+    return out & M32, out >> 32
+
+
+def misc_dependencies(misc_events: np.ndarray):
+    """emit_misc_dependencies (crates/core/executor/src/dependencies.rs:251-388): MADD* -> one MULT / MULTU event (Mul chip); EXT -> SLL
+    (ShiftLeft) + SRL (ShiftRight); INS -> ROR, SRL, SRL (ShiftRight), SLL (ShiftLeft), ADD (AddSub), ROR (ShiftRight). Returns
+    (mul, shift_left, shift_right, add_sub) event arrays in emission order."""
+    mul, sll, sr, add = [], [], [], []
+    alu = lambda op, a, b, c: (UNUSED_PC, UNUSED_PC + DEFAULT_PC_INC, op, [0, 0, 0], 0, a & 0xffffffff, b, c)   # noqa: E731
+    for e in misc_events:
+        op, a, b, c, prev_a = int(e["opcode"]), int(e["a"]), int(e["b"]), int(e["c"]), int(e["prev_a"])
+        if op in (MADDU, MSUBU, MADD, MSUB):
+            mop = MULTU if op in (MADDU, MSUBU) else MULT
+            lo, hi = mul_result(np.array([mop]), np.array([b], dtype=np.uint32), np.array([c], dtype=np.uint32))
+            mul.append((0, 0, UNUSED_PC, UNUSED_PC + DEFAULT_PC_INC, mop, [0, 0, 0], int(hi[0]), int(lo[0]), b, c, (0, 0, 0, 0, 0, 0), 0, [0, 0, 0]))
+        elif op == EXT:
+            lsb, msbd = c & 0x1f, c >> 5
+            v = (b << (31 - lsb - msbd)) & 0xffffffff
+            sll.append(alu(SLL, v, b, 31 - lsb - msbd))
+            sr.append(alu(SRL, a, v, 31 - msbd))
+        elif op == INS:
+            lsb, msb = c & 0x1f, c >> 5
+            ror = ((prev_a >> lsb) | (prev_a << (32 - lsb))) & 0xffffffff if lsb else prev_a
+            srl1 = ror >> 1
+            srl = srl1 >> (msb - lsb)
+            v = (b << (31 - msb + lsb)) & 0xffffffff
+            sr += [alu(ROR, ror, prev_a, lsb), alu(SRL, srl1, ror, 1), alu(SRL, srl, srl1, msb - lsb)]
+            sll.append(alu(SLL, v, b, 31 - msb + lsb))
+            add.append(alu(ADD, srl + v, srl, v))
+            sr.append(alu(ROR, a, (srl + v) & 0xffffffff, 31 - msb))
+    arr = lambda rows, dt: np.array(rows, dtype=dt) if rows else np.zeros(0, dtype=dt)   # noqa: E731
+    return arr(mul, COMP_ALU_EVENT), arr(sll, ALU_EVENT), arr(sr, ALU_EVENT), arr(add, ALU_EVENT)

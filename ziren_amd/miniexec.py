@@ -14,7 +14,7 @@ the record is what the reference's executor would emit for that program:
   rr_cpu / rw_cpu     :1041-1100 (timestamps clk + MemoryAccessPosition, events/memory.rs:29-40)
 
 Register file: 32 general registers, LO = 32, HI = 33; loads and stores go to a small data region (execute_load / execute_store,
-:1925-2088; memory at position Memory = clk + 0). Not modelled (their chips are not built): syscalls, the other misc instructions.
+:1925-2088; memory at position Memory = clk + 0). Not modelled (their chips are not built): syscalls other than COMMIT and HALT.
 """
 import numpy as np
 
@@ -60,7 +60,7 @@ class Record:
 
     def __init__(self):
         self.cpu, self.alu, self.mul, self.divrem, self.branch, self.jump, self.mov_cond = [], {c: [] for c in E.CHIP_NAMES}, [], [], [], [], []
-        self.memory_local, self.mem_instr, self.syscall = [], [], []
+        self.memory_local, self.mem_instr, self.syscall, self.misc = [], [], [], []
 
 
 def _alu(op, b, c):
@@ -148,8 +148,23 @@ def run(n_cycles: int, seed: int = 1, shard: int = 1, pc_base: int = 0x1000, hal
             word_addr = (LOW + 4 * int(rng.integers(0, 40))) if rng.random() < 0.1 else DATA + 4 * int(rng.integers(0, 96))
             off = 0 if op in (E.LW, E.LL, E.SW, E.SC) else 2 * int(rng.integers(0, 2)) if op in (E.LH, E.LHU, E.SH) else int(rng.integers(0, 4))
             ins = (op, dst(), rs, (word_addr + off - R[rs]) & 0xffffffff, 0, 1)   # the offset that lands on the chosen address
-        elif u < 0.58:
+        elif u < 0.54:
             ins = (E.CLZ if rng.random() < 0.5 else E.CLO, dst(), reg(), 0, 0, 1)
+        elif u < 0.58:    # the MiscInstrs chip's opcodes
+            k = int(rng.integers(0, 8))
+            if k == 0:
+                ins = (E.SEXT, dst(), reg(), int(rng.integers(0, 2)), 0, 1)
+            elif k == 1:
+                lsb = int(rng.integers(0, 32))
+                ins = (E.EXT, dst(), reg(), lsb | int(rng.integers(0, 32 - lsb)) << 5, 0, 1)
+            elif k == 2:
+                lsb = int(rng.integers(0, 32))
+                ins = (E.INS, dst(), reg(), lsb | int(rng.integers(lsb, 32)) << 5, 0, 1)
+            elif k == 3:
+                rs, rt = reg(), reg()
+                ins = (E.TEQ, rs, rt, 0, 0, 1) if R[rs] != R[rt] else (E.SEXT, dst(), rs, 1, 0, 1)   # equal operands trap
+            else:
+                ins = ([E.MADDU, E.MSUBU, E.MADD, E.MSUB][k - 4], REG_LO, reg(), reg(), 0, 0)
         elif u < 0.66:
             ins = (E.MULT if rng.random() < 0.5 else E.MULTU, REG_LO, reg(), reg(), 0, 0)
         elif u < 0.76:
@@ -240,6 +255,31 @@ def run(n_cycles: int, seed: int = 1, shard: int = 1, pc_base: int = 0x1000, hal
                 a = rt
             hi = rt
             rec.mem_instr.append((shard, clk, pc, next_pc, op, [0, 0, 0], a, b, c, TAG_WRITE, list(m_rec[2]), rt))
+        elif op in (E.SEXT, E.EXT, E.INS):
+            b_rec = read(op_b, clk, POS_B)
+            b, c = b_rec[1][0], op_c
+            prev_a = R[op_a] if op == E.INS else 0
+            a = E.misc_result(op, b, c, prev_a)
+            a_rec = write(op_a, a, clk, POS_A)
+            hi = prev_a if op == E.INS else None
+            rec.misc.append((shard, clk, pc, next_pc, op, [0, 0, 0], a, b, c, prev_a, (0, 0, 0, 0, 0, 0)))
+        elif op == E.TEQ:
+            b_rec = read(op_b, clk, POS_B)
+            a_rec = read(op_a, clk, POS_A)
+            a, b, c = a_rec[1][0], b_rec[1][0], 0
+            assert a != b
+            rec.misc.append((shard, clk, pc, next_pc, op, [0, 0, 0], a, b, c, 0, (0, 0, 0, 0, 0, 0)))
+        elif op in (E.MADDU, E.MSUBU, E.MADD, E.MSUB):
+            c_rec = read(op_c, clk, POS_C)
+            c = c_rec[1][0]
+            b_rec = read(op_b, clk, POS_B)
+            b = b_rec[1][0]
+            lo_val = R[REG_LO]
+            a, hv = E.misc_result(op, b, c, hi_lo=(R[REG_HI], lo_val))
+            a_rec = write(REG_LO, a, clk, POS_A)
+            hi_rec = write(REG_HI, hv, clk, POS_HI)
+            hi = lo_val
+            rec.misc.append((shard, clk, pc, next_pc, op, [0, 0, 0], a, b, c, lo_val, hi_rec[2]))
         elif op == E.SYSCALL:
             code = R[op_a]                                 # peeked: the write record's prev_value carries it
             c_rec = read(op_c, clk, POS_C)
@@ -336,6 +376,7 @@ def run(n_cycles: int, seed: int = 1, shard: int = 1, pc_base: int = 0x1000, hal
     out.mov_cond = np.array(rec.mov_cond, dtype=E.MOV_COND_EVENT) if rec.mov_cond else np.zeros(0, dtype=E.MOV_COND_EVENT)
     out.mem_instr = np.array(rec.mem_instr, dtype=E.MEM_INSTR_EVENT) if rec.mem_instr else np.zeros(0, dtype=E.MEM_INSTR_EVENT)
     out.syscall = np.array(rec.syscall, dtype=E.SYSCALL_EVENT) if rec.syscall else np.zeros(0, dtype=E.SYSCALL_EVENT)
+    out.misc = np.array(rec.misc, dtype=E.MISC_EVENT) if rec.misc else np.zeros(0, dtype=E.MISC_EVENT)
     out.memory_local = np.array([(reg, first[reg], (last[reg][0], last[reg][1], R[reg])) for reg in sorted(first)], dtype=MEMORY_LOCAL_EVENT) \
         if first else np.zeros(0, dtype=MEMORY_LOCAL_EVENT)
     pv = {"start_pc": pc_base, "next_pc": int(cpu["next_pc"][-1]) if len(cpu) else pc_base, "execution_shard": shard, "shard": shard,
@@ -349,13 +390,16 @@ def add_dependencies(rec: Record) -> Record:
     alu = dict(rec.alu)
     lt_dep, add_dep = E.branch_dependencies(rec.branch)
     div_add, div_mul, div_lt = E.divrem_dependencies(rec.divrem)
-    alu[E.CHIP_SHIFT_RIGHT] = np.concatenate([alu[E.CHIP_SHIFT_RIGHT], E.cloclz_dependencies(alu[E.CHIP_CLO_CLZ])])
-    alu[E.CHIP_ADD_SUB] = np.concatenate([alu[E.CHIP_ADD_SUB], E.jump_dependencies(rec.jump), add_dep, div_add, E.memory_dependencies(rec.mem_instr)])
+    misc_mul, misc_sll, misc_sr, misc_add = E.misc_dependencies(rec.misc)
+    alu[E.CHIP_SHIFT_RIGHT] = np.concatenate([alu[E.CHIP_SHIFT_RIGHT], E.cloclz_dependencies(alu[E.CHIP_CLO_CLZ]), misc_sr])
+    alu[E.CHIP_SHIFT_LEFT] = np.concatenate([alu[E.CHIP_SHIFT_LEFT], misc_sll])
+    alu[E.CHIP_ADD_SUB] = np.concatenate([alu[E.CHIP_ADD_SUB], E.jump_dependencies(rec.jump), add_dep, div_add, E.memory_dependencies(rec.mem_instr),
+                                          misc_add])
     alu[E.CHIP_LT] = np.concatenate([alu[E.CHIP_LT], lt_dep, div_lt])
     out = Record()
     out.cpu, out.alu, out.branch, out.jump, out.mov_cond, out.divrem = rec.cpu, alu, rec.branch, rec.jump, rec.mov_cond, rec.divrem
-    out.memory_local, out.mem_instr, out.syscall = rec.memory_local, rec.mem_instr, rec.syscall
-    out.mul = np.concatenate([rec.mul, div_mul])
+    out.memory_local, out.mem_instr, out.syscall, out.misc = rec.memory_local, rec.mem_instr, rec.syscall, rec.misc
+    out.mul = np.concatenate([rec.mul, div_mul, misc_mul])
     return out
 
 
