@@ -102,6 +102,9 @@ def test_miniexec_record_is_coherent():
             last[reg] = (int(body["shard"]), int(body["timestamp"]))
     taken = E.branch_taken(rec.branch)
     assert taken.any() and (~taken).any()
+    # a longer run executes every opcode of the instruction set (crates/core/executor/src/opcode.rs:26-87: 0..55)
+    prog, rec, _ = M.run(20000, seed=3, halt=True)
+    assert set(prog["opcode"][(rec.cpu["pc"] - 0x1000) // 4].tolist()) == set(range(56))
 
 
 def test_memory_instrs_constraints_hold(oracle):

@@ -153,7 +153,7 @@ def run(n_cycles: int, seed: int = 1, shard: int = 1, pc_base: int = 0x1000, hal
         elif u < 0.58:    # the MiscInstrs chip's opcodes
             k = int(rng.integers(0, 8))
             if k == 0:
-                ins = (E.SEXT, dst(), reg(), int(rng.integers(0, 2)), 0, 1)
+                ins = (E.SEXT, dst(), reg(), int(rng.integers(0, 2)), 0, 1) if rng.random() < 0.6 else (E.WSBH, dst(), reg(), 0, 0, 1)
             elif k == 1:
                 lsb = int(rng.integers(0, 32))
                 ins = (E.EXT, dst(), reg(), lsb | int(rng.integers(0, 32 - lsb)) << 5, 0, 1)
@@ -263,6 +263,12 @@ def run(n_cycles: int, seed: int = 1, shard: int = 1, pc_base: int = 0x1000, hal
             a_rec = write(op_a, a, clk, POS_A)
             hi = prev_a if op == E.INS else None
             rec.misc.append((shard, clk, pc, next_pc, op, [0, 0, 0], a, b, c, prev_a, (0, 0, 0, 0, 0, 0)))
+        elif op == E.WSBH:      # execute_wsbh (executor.rs:1776-1785): swap the bytes within each halfword; a MovCond chip event
+            b_rec = read(op_b, clk, POS_B)
+            b, c = b_rec[1][0], 0
+            a = ((b >> 16) & 0xff) << 24 | ((b >> 24) & 0xff) << 16 | (b & 0xff) << 8 | (b >> 8) & 0xff
+            a_rec = write(op_a, a, clk, POS_A)
+            rec.mov_cond.append((pc, next_pc, op, [0, 0, 0], a, b, c, 0))
         elif op == E.TEQ:
             b_rec = read(op_b, clk, POS_B)
             a_rec = read(op_a, clk, POS_A)
