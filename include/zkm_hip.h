@@ -397,6 +397,12 @@ typedef struct zkm_misc_event {
 size_t zkm_tracegen_misc_instrs_width(void);
 int zkm_tracegen_misc_instrs(zkm_ctx* ctx, const zkm_misc_event* events, size_t n_events, int fixed_log2_rows, zkm_byte_lookups* blu,
                              zkm_matrix** out);
+/* The recursion machine's ExpReverseBitsLen chip (crates/recursion/core/src/chips/exp_reverse_bits.rs): replaces generate_trace
+ * (:175-226). An ExpReverseBitsEvent is a base and a vector of exponent bits (lib.rs:208-212); here the n bases, all bits end to
+ * end and n + 1 offsets into them (Montgomery words; offsets plain). One row per bit, 7 columns, zero padding. BatchFRI, PublicValues,
+ * Select and the memory chips need no kernel: their traces are their events end to end (zkm_tracegen_flat). */
+int zkm_tracegen_exp_reverse_bits(zkm_ctx* ctx, const uint32_t* bases, const uint32_t* bits, const uint32_t* offsets, size_t n_events,
+                                  int fixed_log2_rows, zkm_matrix** out);
 /* The MemoryLocal chip (crates/core/machine/src/memory/local.rs): replaces generate_trace (:147-190). Events are the
  * #[repr(C)] MemoryLocalEvents of crates/core/executor/src/events/memory.rs:226-237 (ExecutionRecord::get_local_mem_events),
  * four per row, 56 columns, zero padding. */

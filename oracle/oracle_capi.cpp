@@ -538,4 +538,22 @@ int orc_tracegen_misc_instrs(const void* events, size_t n_events, int fixed_log2
   ORC_CATCH
 }
 
+// recursion ExpReverseBitsLen chip: bases (n Montgomery words), bits (Montgomery words, end to end), offsets (n + 1 plain indices)
+int orc_tracegen_exp_reverse_bits(const uint32_t* bases, const uint32_t* bits, const uint32_t* offsets, size_t n_events, int fixed_log2_rows,
+                                  uint32_t* out, size_t out_cap, size_t* rows) {
+  ORC_TRY
+  size_t h;
+  const size_t nb = n_events ? offsets[n_events] : 0;
+  std::vector<F> b(n_events), x(nb);
+  for (size_t i = 0; i < n_events; i++) b[i] = from_monty(bases[i]);
+  for (size_t i = 0; i < nb; i++) x[i] = from_monty(bits[i]);
+  std::vector<F> t = tracegen::generate_exp_reverse_bits(b.data(), x.data(), offsets, n_events, fixed_log2_rows, &h);
+  *rows = h;
+  if (out) {
+    if (t.size() > out_cap) throw std::runtime_error("trace buffer too small");
+    for (size_t i = 0; i < t.size(); i++) out[i] = to_monty(t[i]);
+  }
+  ORC_CATCH
+}
+
 }  // extern "C"

@@ -1122,4 +1122,25 @@ static inline std::vector<F> generate_misc_instrs(const MiscEvent* events, size_
   return t;
 }
 
+// ---- recursion ExpReverseBitsLen chip (crates/recursion/core/src/chips/exp_reverse_bits.rs:175-226): an event is a base and its exponent
+// bits; one row per bit: x, current_bit, prev_accum_squared, prev_accum_squared_times_multiplier, accum, accum_squared, multiplier with
+// accum_i = accum_{i-1}^2 * (bit_i ? x : 1), accum_{-1} = 1. bases: n canonical words; bits: all events' bits end to end; offsets: n + 1.
+static const size_t EXP_REVERSE_BITS_WIDTH = 7;
+static inline std::vector<F> generate_exp_reverse_bits(const F* bases, const F* bits, const uint32_t* offsets, size_t n_events,
+                                                       int fixed_log2_rows, size_t* height) {
+  const size_t rows = n_events ? offsets[n_events] : 0, h = padded_rows(rows, fixed_log2_rows);
+  std::vector<F> t(h * EXP_REVERSE_BITS_WIDTH, 0);
+  for (size_t e = 0; e < n_events; e++) {
+    F accum = 1;
+    for (uint32_t i = offsets[e]; i < offsets[e + 1]; i++) {
+      F* r = t.data() + (size_t)i * EXP_REVERSE_BITS_WIDTH;
+      const F prev_sq = fmul(accum, accum), mult = bits[i] == 1 ? bases[e] : 1;
+      accum = fmul(prev_sq, mult);
+      r[0] = bases[e]; r[1] = bits[i]; r[2] = prev_sq; r[3] = accum; r[4] = accum; r[5] = fmul(accum, accum); r[6] = mult;
+    }
+  }
+  *height = h;
+  return t;
+}
+
 }  // namespace tracegen

@@ -377,3 +377,16 @@ def tracegen_misc_instrs(events, fixed_log2_rows=-1, byte_counts=None):
     _check(lib().orc_tracegen_misc_instrs(C.c_void_p(ev.ctypes.data), C.c_size_t(len(ev)), C.c_int(fixed_log2_rows), abi.as_u32p(out),
                                           C.c_size_t(out.size), bc))
     return out
+
+
+def tracegen_exp_reverse_bits(bases, bits, offsets, fixed_log2_rows=-1):
+    """Recursion ExpReverseBitsLen rows: bases (n), all exponent bits end to end, offsets (n + 1); Montgomery words."""
+    bases, bits = np.ascontiguousarray(bases, dtype=np.uint32), np.ascontiguousarray(bits, dtype=np.uint32)
+    offsets = np.ascontiguousarray(offsets, dtype=np.uint32)
+    rows = C.c_size_t()
+    n = len(bases)
+    args = (abi.as_u32p(bases), abi.as_u32p(bits), abi.as_u32p(offsets), C.c_size_t(n), C.c_int(fixed_log2_rows))
+    _check(lib().orc_tracegen_exp_reverse_bits(*args, None, C.c_size_t(0), C.byref(rows)))
+    out = np.zeros((rows.value, 7), dtype=np.uint32)
+    _check(lib().orc_tracegen_exp_reverse_bits(*args, abi.as_u32p(out), C.c_size_t(out.size), C.byref(rows)))
+    return out

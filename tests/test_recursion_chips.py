@@ -33,10 +33,12 @@ def test_row_counts():
         R.padded_rows(1000, 5)
 
 
-def balanced_shard(n_base, n_ext, n_const, seed, heights=(-1, -1, -1), n_var=0, n_select=0, n_poseidon2=0, oracle=None):
+def balanced_shard(n_base, n_ext, n_const, seed, heights=(-1, -1, -1), n_var=0, n_select=0, n_poseidon2=0, oracle=None, n_exp=0,
+                   n_batch_fri=0, commit_public_values=False):
     """BaseAlu + ExtAlu + MemoryConst (+ MemoryVar + Select) over one consistent program: (chips with host traces, flat
     record streams (preprocessed words, main words))."""
-    prog = R.balanced_program(n_base, n_ext, n_const, seed, n_var=n_var, n_select=n_select, n_poseidon2=n_poseidon2)
+    prog = R.balanced_program(n_base, n_ext, n_const, seed, n_var=n_var, n_select=n_select, n_poseidon2=n_poseidon2, n_exp=n_exp,
+                              n_batch_fri=n_batch_fri, commit_public_values=commit_public_values)
     specs = (("base_instrs", "base_events", R.BASE_VALUE_COLS, False), ("ext_instrs", "ext_events", R.EXT_VALUE_COLS, True))
     recs, streams = [], []
     for idx, (ik, ek, vw, ext) in enumerate(specs):
@@ -69,7 +71,75 @@ def balanced_shard(n_base, n_ext, n_const, seed, heights=(-1, -1, -1), n_var=0, 
         rc.trace, rc.prep_trace = oracle.tracegen_poseidon2_wide(prog["poseidon2_events"], rc.log_height), prep
         recs.append(rc)
         streams.append((prog["poseidon2_prep"], prog["poseidon2_events"]))
+    if n_exp:
+        prep = R.flat_trace(prog["exp_prep"], R.EXP_REVERSE_BITS_PREP_COLS, -1, 1)
+        rc = R.record_exp_reverse_bits(prep.shape[0].bit_length() - 1, prep_index=6)
+        rc.trace, rc.prep_trace = oracle.tracegen_exp_reverse_bits(prog["exp_bases"], prog["exp_bits"], prog["exp_offsets"], rc.log_height), prep
+        assert np.array_equal(rc.trace, R.flat_trace(prog["exp_main"], R.EXP_REVERSE_BITS_COLS, rc.log_height, 1))
+        recs.append(rc)
+        streams.append((prog["exp_prep"], (prog["exp_bases"], prog["exp_bits"], prog["exp_offsets"])))
+    if n_batch_fri:
+        prep = R.flat_trace(prog["batch_fri_prep"], R.BATCH_FRI_PREP_COLS, -1, 1)
+        rc = R.record_batch_fri(prep.shape[0].bit_length() - 1, prep_index=7)
+        rc.trace, rc.prep_trace = R.flat_trace(prog["batch_fri_main"], R.BATCH_FRI_COLS, rc.log_height, 1), prep
+        recs.append(rc)
+        streams.append((prog["batch_fri_prep"], prog["batch_fri_main"]))
+    if commit_public_values:
+        rc = R.record_public_values(prep_index=8)
+        rc.prep_trace = R.flat_trace(prog["pv_prep"], R.PUBLIC_VALUES_PREP_COLS, R.PUBLIC_VALUES_LOG_HEIGHT, 1)
+        rc.trace = R.flat_trace(prog["pv_main"], 1, R.PUBLIC_VALUES_LOG_HEIGHT, 1)
+        recs.append(rc)
+        streams.append((prog["pv_prep"], prog["pv_main"]))
+        streams.append(prog["pv_digest"])
     return recs, streams
+
+
+def recursion_public_values(digest):
+    from ziren_amd import synth
+    pv = np.zeros(synth.PROOF_MAX_NUM_PVS, dtype=np.uint64)
+    pv[R.PV_DIGEST_POS:R.PV_DIGEST_POS + 8] = digest
+    return F.to_monty(pv)
+
+
+def compress_machine_shard(oracle, scale=1, seed=31):
+    """All nine chips of the compress / shrink machine (crates/recursion/core/src/machine.rs:112-132) over one balanced program."""
+    recs, streams = balanced_shard(400 * scale, 250 * scale, 40, seed=seed, n_var=120 * scale, n_select=100 * scale, n_poseidon2=30 * scale,
+                                   oracle=oracle, n_exp=25 * scale, n_batch_fri=30 * scale, commit_public_values=True)
+    digest = streams.pop()
+    return recs, streams, digest
+
+
+def test_compress_machine_is_complete(oracle):
+    """ExpReverseBitsLen, BatchFRI and PublicValues complete the compress machine's chip set: their constraints hold (the first two
+    across consecutive rows), corrupted cells are caught, the nine chips' memory lookups cancel exactly, and the oracle's proof —
+    with the committed digest as public values — verifies; a different claimed digest does not."""
+    from ziren_amd import synth
+    recs, streams, digest = compress_machine_shard(oracle)
+    assert [r.name for r in recs] == ["BaseAlu", "ExtAlu", "MemoryConst", "MemoryVar", "Select", "Poseidon2Wide", "ExpReverseBitsLen", "BatchFRI",
+                                      "PublicValues"]
+    pv = recursion_public_values(digest)
+    by = {r.name: r for r in recs}
+    for name, rec, cols in (("ExpReverseBitsLen", R.record_exp_reverse_bits(constraints_only=True), (0, 4, 5, 6)),
+                            ("BatchFRI", R.record_batch_fri(constraints_only=True), (0, 5, 9, 12)),
+                            ("PublicValues", R.record_public_values(constraints_only=True), (0,))):
+        main, prep = F.from_monty(by[name].trace), F.from_monty(by[name].prep_trace)
+        assert air.debug_constraints(rec.b, main, prep=prep, public_values=F.from_monty(pv)) == [], name
+        for col in cols:
+            bad = main.copy()
+            bad[3, col] = (int(bad[3, col]) + 1) % F.P
+            rows = {row for _, row in air.debug_constraints(rec.b, bad, prep=prep, public_values=F.from_monty(pv))}
+            assert rows and rows <= {2, 3}, (name, col)
+    assert by["PublicValues"].trace.shape == (16, 1) and by["ExpReverseBitsLen"].local_only is False
+    t = tally_of(recs)
+    assert t and not any(t.values())
+    fri = abi.FriConfig(2, 42, 16)
+    igcs = F.to_monty(np.zeros(14, dtype=np.uint64))
+    opk = oracle.Pk([r.prep_trace for r in recs], [int(r.local_only) for r in recs], F.to_monty(0), igcs, 2)
+    start = oracle.new_challenger()
+    opk.observe_into(start)
+    for claimed, ok in ((digest, True), ([digest[0] + 1] + list(digest[1:]), False)):
+        proof, _ = oracle.prove_shard(opk, recs, [c.trace for c in recs], recursion_public_values(claimed), fri, synth.NUM_PV_ELTS, start.copy())
+        assert (oracle.verify_shard(opk, recs, fri, synth.NUM_PV_ELTS, start.copy(), proof) == 0) == ok
 
 
 def tally_of(recs):
@@ -216,29 +286,34 @@ def test_gpu_flat_tracegen(hip_ctx):
 @pytest.mark.gpu
 @pytest.mark.parametrize("log_blowup,queries", [(2, 42), (3, 28)])
 def test_gpu_recursion_alu_shard(hip_ctx, oracle, log_blowup, queries):
-    """BaseAlu + ExtAlu + MemoryConst + MemoryVar + Select + Poseidon2Wide over one consistent program under the compress / shrink FRI configurations
+    """The complete compress machine — BaseAlu, ExtAlu, MemoryConst, MemoryVar, Select, Poseidon2Wide, ExpReverseBitsLen, BatchFRI, PublicValues —
+    over one consistent program under the compress / shrink FRI configurations
     (crates/stark/src/kb31_poseidon2.rs:215-241): device-built traces, preprocessed tables in the proving key,
     memory lookups balancing between the real chips, proof bit-identical to the oracle's and accepted by the
     restated verifier."""
     from ziren_amd import prover, synth
-    recs, streams = balanced_shard(3500, 2000, 200, seed=40, heights=(10, 9, 9), n_var=300, n_select=400, n_poseidon2=200, oracle=oracle)
+    recs, streams, digest = compress_machine_shard(oracle, scale=8, seed=40)
     fri = abi.FriConfig(log_blowup, queries, 16)
-    pv = np.zeros(synth.PROOF_MAX_NUM_PVS, dtype=np.uint32)
+    pv = recursion_public_values(digest)
     igcs = F.to_monty(np.zeros(14, dtype=np.uint64))
     hp = prover.HipProver(recs, fri, synth.NUM_PV_ELTS, ctx=hip_ctx)
     hp.specialize_quotient_kernels(recs)
     preps = [hip_ctx.tracegen_flat(ins, r.prep_trace.shape[1], r.log_height) for (ins, _), r in zip(streams, recs)]
     for m, r in zip(preps, recs):
         assert np.array_equal(m.to_host(), r.prep_trace)
-    pk = hp.setup(preps, [1] * len(recs), F.to_monty(0), igcs)
-    opk = oracle.Pk([r.prep_trace for r in recs], [1] * len(recs), F.to_monty(0), igcs, log_blowup)
+    lo = [int(r.local_only) for r in recs]
+    pk = hp.setup(preps, lo, F.to_monty(0), igcs)
+    opk = oracle.Pk([r.prep_trace for r in recs], lo, F.to_monty(0), igcs, log_blowup)
     assert np.array_equal(pk.commit, opk.commitment())
     ch = prover.new_challenger()
     pk.observe_into(ch)
     start = ch.copy()
     born = [hip_ctx.tracegen_poseidon2_wide(ev, r.log_height) if r.name == "Poseidon2Wide" else
+            hip_ctx.tracegen_exp_reverse_bits(*ev, r.log_height) if r.name == "ExpReverseBitsLen" else
             hip_ctx.tracegen_flat(ev, r.trace.shape[1], r.log_height) if ev is not None else hip_ctx.upload(r.trace)
             for (_, ev), r in zip(streams, recs)]
+    for m, r in zip(born, recs):
+        assert np.array_equal(m.to_host(), r.trace), r.name
     proof = hp.prove_shard(pk, pv, born, ch).copy()
     och = oracle.new_challenger()
     opk.observe_into(och)

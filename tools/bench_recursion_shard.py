@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""A recursion-machine shard on the device: BaseAlu, ExtAlu, MemoryConst, MemoryVar, Select and Poseidon2Wide
-over one balanced synthetic program (ziren_amd/recursion.py), traces built on the device, commit + open under the compress FRI
+"""A recursion-machine shard on the device: the nine chips of the compress machine (BaseAlu, ExtAlu, MemoryConst, MemoryVar, Select, Poseidon2Wide,
+ExpReverseBitsLen, BatchFRI, PublicValues) over one balanced synthetic program (ziren_amd/recursion.py), traces built on the device, commit + open under the compress FRI
 configuration (blow-up 4, 42 queries; `--shrink`: blow-up 8, 28 queries) with generated quotient kernels.
 
   python tools/bench_recursion_shard.py [--log-hashes 16] [--steps 3]"""
@@ -31,27 +31,33 @@ def main():
         return F.from_monty(prover.poseidon2_permute_batch(ctx, F.to_monty(vals)))
 
     t0 = time.perf_counter()
-    prog = R.balanced_program(n_hash // 2, n_hash // 4, 512, seed=1, n_var=4096, n_select=n_hash // 8, n_poseidon2=n_hash, permute_batch=permute)
+    prog = R.balanced_program(n_hash // 2, n_hash // 4, 512, seed=1, n_var=4096, n_select=n_hash // 8, n_poseidon2=n_hash, permute_batch=permute,
+                              n_exp=n_hash // 64, n_batch_fri=n_hash // 32, commit_public_values=True)
     gen_s = time.perf_counter() - t0
     specs = [("base_instrs", "base_events", R.ENTRIES_PER_ROW * R.ACCESS_COLS, R.ENTRIES_PER_ROW * R.BASE_VALUE_COLS, R.ENTRIES_PER_ROW, lambda lh, i: R.record_chip(False, lh, i)),
              ("ext_instrs", "ext_events", R.ENTRIES_PER_ROW * R.ACCESS_COLS, R.ENTRIES_PER_ROW * R.EXT_VALUE_COLS, R.ENTRIES_PER_ROW, lambda lh, i: R.record_chip(True, lh, i)),
              ("mem_entries", None, R.CONST_MEM_ENTRIES_PER_ROW * R.CONST_MEM_ENTRY_COLS, 1, R.CONST_MEM_ENTRIES_PER_ROW, R.record_mem_const),
              ("var_prep", "var_values", 2 * R.VAR_MEM_ENTRIES_PER_ROW, 4 * R.VAR_MEM_ENTRIES_PER_ROW, R.VAR_MEM_ENTRIES_PER_ROW, R.record_mem_var),
              ("select_prep", "select_events", R.SELECT_PREP_COLS, R.SELECT_COLS, 1, R.record_select),
-             ("poseidon2_prep", "poseidon2_events", R.POSEIDON2_WIDE_PREP_WIDTH, R.POSEIDON2_WIDE_WIDTH, 1, R.record_poseidon2_wide)]
+             ("poseidon2_prep", "poseidon2_events", R.POSEIDON2_WIDE_PREP_WIDTH, R.POSEIDON2_WIDE_WIDTH, 1, R.record_poseidon2_wide),
+             ("exp_prep", "exp_main", R.EXP_REVERSE_BITS_PREP_COLS, R.EXP_REVERSE_BITS_COLS, 1, R.record_exp_reverse_bits),
+             ("batch_fri_prep", "batch_fri_main", R.BATCH_FRI_PREP_COLS, R.BATCH_FRI_COLS, 1, R.record_batch_fri),
+             ("pv_prep", "pv_main", R.PUBLIC_VALUES_PREP_COLS, 1, 1, lambda lh, i: R.record_public_values(i))]
     recs, preps, mains = [], [], []
     for idx, (pk_key, ev_key, pw, mw, per_row, record) in enumerate(specs):
         n_rec = len(prog[pk_key]) // (pw // per_row)
-        lh = (R.padded_rows(n_rec, -1, per_row)).bit_length() - 1
+        lh = R.PUBLIC_VALUES_LOG_HEIGHT if pk_key == "pv_prep" else (R.padded_rows(n_rec, -1, per_row)).bit_length() - 1
         recs.append(record(lh, idx))
         preps.append(ctx.tracegen_flat(prog[pk_key], pw, lh))
         mains.append((ev_key, mw, lh))
     fri = abi.FriConfig(3, 28, 16) if args.shrink else abi.FriConfig(2, 42, 16)
     hp = prover.HipProver(recs, fri, synth.NUM_PV_ELTS, ctx=ctx, specialize=True)
-    pk = hp.setup(preps, [1] * len(recs), F.to_monty(0), F.to_monty(np.zeros(14, dtype=np.uint64)))
+    pk = hp.setup(preps, [int(r.local_only) for r in recs], F.to_monty(0), F.to_monty(np.zeros(14, dtype=np.uint64)))
     ch0 = prover.new_challenger()
     pk.observe_into(ch0)
-    pv = np.zeros(synth.PROOF_MAX_NUM_PVS, dtype=np.uint32)
+    pvv = np.zeros(synth.PROOF_MAX_NUM_PVS, dtype=np.uint64)
+    pvv[R.PV_DIGEST_POS:R.PV_DIGEST_POS + 8] = prog["pv_digest"]
+    pv = F.to_monty(pvv)
     lib.load().zkm_ctx_set_kernel_timing(ctx.h, C.c_int(1))
     out = np.zeros(1 << 23, dtype=np.uint32)
     res = []
@@ -61,6 +67,8 @@ def main():
         for (ev_key, mw, lh), r in zip(mains, recs):
             if r.name == "Poseidon2Wide":
                 born.append(ctx.tracegen_poseidon2_wide(prog[ev_key], lh))
+            elif r.name == "ExpReverseBitsLen":
+                born.append(ctx.tracegen_exp_reverse_bits(prog["exp_bases"], prog["exp_bits"], prog["exp_offsets"], lh))
             elif ev_key is None:
                 born.append(ctx.tracegen_flat(np.zeros(0, dtype=np.uint32), mw, lh))
             else:

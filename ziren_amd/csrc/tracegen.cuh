@@ -1093,6 +1093,25 @@ __global__ __launch_bounds__(THREADS) void poseidon2_wide_rows(const uint32_t* _
   }
 }
 
+// recursion ExpReverseBitsLen chip (crates/recursion/core/src/chips/exp_reverse_bits.rs:175-226): one thread walks one event's bits —
+// accum_i = accum_{i-1}^2 * (bit_i ? x : 1) — and writes its rows (x, bit, prev_accum^2, that times the multiplier, accum, accum^2,
+// multiplier); Montgomery words in and out. offsets[e] .. offsets[e + 1] are event e's rows; the rest of the matrix is zeroed first.
+constexpr int EXP_REVERSE_BITS_WIDTH = 7;
+__global__ void exp_reverse_bits_rows(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ bits, const uint32_t* __restrict__ offsets,
+                                      size_t n_events, size_t height, uint32_t* __restrict__ out) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_events) return;
+  const uint32_t x = bases[e];
+  uint32_t accum = kb::ONE;
+  for (uint32_t i = offsets[e]; i < offsets[e + 1]; i++) {
+    const uint32_t bit = bits[i], prev_sq = kb::mul(accum, accum), mult = bit == kb::ONE ? x : kb::ONE;
+    accum = kb::mul(prev_sq, mult);
+    const uint32_t r[EXP_REVERSE_BITS_WIDTH] = {x, bit, prev_sq, accum, accum, kb::mul(accum, accum), mult};
+#pragma unroll
+    for (int c = 0; c < EXP_REVERSE_BITS_WIDTH; c++) out[(size_t)c * height + i] = r[c];
+  }
+}
+
 // ByteChip::generate_trace: out = to_field(counts + extra); extra (may be null) holds the row-major plain counts of the
 // chips whose dependencies stay on the host
 __global__ void byte_mults_finish(const uint32_t* __restrict__ counts, const uint32_t* __restrict__ extra_row_major,

@@ -1869,6 +1869,48 @@ int zkm_tracegen_poseidon2_wide(zkm_ctx* ctx, const uint32_t* events, size_t n_e
   API_END
 }
 
+int zkm_tracegen_exp_reverse_bits(zkm_ctx* ctx, const uint32_t* bases, const uint32_t* bits, const uint32_t* offsets, size_t n_events,
+                                  int fixed_log2_rows, zkm_matrix** out) {
+  API_BEGIN
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIP_CHECK(hipSetDevice(ctx->device));
+  if (n_events && (!bases || !bits || !offsets)) throw std::runtime_error("zkm_tracegen_exp_reverse_bits: null events");
+  const size_t rows = n_events ? offsets[n_events] : 0;
+  for (size_t e = 0; e < n_events; e++)
+    if (offsets[e + 1] < offsets[e]) throw std::runtime_error("zkm_tracegen_exp_reverse_bits: offsets must not decrease");
+  const size_t height = padded_trace_rows(rows, fixed_log2_rows, "zkm_tracegen_exp_reverse_bits");
+  ctx->begin_call();
+  zkm_matrix* m = new zkm_matrix();
+  m->h = height; m->w = tracegen::EXP_REVERSE_BITS_WIDTH;
+  uint32_t *d_bases = nullptr, *d_bits = nullptr, *d_off = nullptr;
+  try {
+    m->d = ctx->alloc_n<uint32_t>(height * m->w);
+    HIP_CHECK(hipMemsetAsync(m->d, 0, height * m->w * 4, ctx->stream));
+    d_bases = ctx->alloc_n<uint32_t>(std::max<size_t>(n_events, 1));
+    d_bits = ctx->alloc_n<uint32_t>(std::max<size_t>(rows, 1));
+    d_off = ctx->alloc_n<uint32_t>(n_events + 1);
+    if (n_events) {
+      HIP_CHECK(hipMemcpyAsync(d_bases, bases, n_events * 4, hipMemcpyHostToDevice, ctx->stream));
+      if (rows) HIP_CHECK(hipMemcpyAsync(d_bits, bits, rows * 4, hipMemcpyHostToDevice, ctx->stream));
+      HIP_CHECK(hipMemcpyAsync(d_off, offsets, (n_events + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+      hipLaunchKernelGGL(tracegen::exp_reverse_bits_rows, dim3(div_up(n_events, (size_t)256)), dim3(256), 0, ctx->stream, (const uint32_t*)d_bases,
+                         (const uint32_t*)d_bits, (const uint32_t*)d_off, n_events, height, m->d);
+      LAUNCH_CHECK();
+    }
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  } catch (...) {
+    for (uint32_t* p : {d_bases, d_bits, d_off, m->d})
+      if (p) ctx->release(p);
+    delete m;
+    throw;
+  }
+  ctx->release(d_bases);
+  ctx->release(d_bits);
+  ctx->release(d_off);
+  *out = m;
+  API_END
+}
+
 int zkm_tracegen_byte_table(zkm_ctx* ctx, zkm_matrix** out) {
   API_BEGIN
   std::lock_guard<std::mutex> lk(ctx->mu);

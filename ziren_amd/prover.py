@@ -203,6 +203,15 @@ class Context:
                                                       C.c_int(fixed_log2_rows), blu.h if blu is not None else None, C.byref(h)))
         return self._born(h)
 
+    def tracegen_exp_reverse_bits(self, bases: np.ndarray, bits: np.ndarray, offsets: np.ndarray, fixed_log2_rows: int = -1) -> DeviceMatrix:
+        """`generate_trace` of the recursion ExpReverseBitsLen chip on the device (zkm_tracegen_exp_reverse_bits)."""
+        bases, bits = np.ascontiguousarray(bases, dtype=np.uint32), np.ascontiguousarray(bits, dtype=np.uint32)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint32)
+        h = C.c_void_p()
+        lib.check(lib.load().zkm_tracegen_exp_reverse_bits(self.h, abi.as_u32p(bases) if len(bases) else None, abi.as_u32p(bits) if len(bits) else None,
+                                                           abi.as_u32p(offsets), C.c_size_t(len(bases)), C.c_int(fixed_log2_rows), C.byref(h)))
+        return self._born(h)
+
     def tracegen_memory_local(self, events: np.ndarray, fixed_log2_rows: int = -1) -> DeviceMatrix:
         """`generate_trace` of the MemoryLocal chip on the device (zkm_tracegen_memory_local); dtype miniexec.MEMORY_LOCAL_EVENT."""
         from . import miniexec as _m

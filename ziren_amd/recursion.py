@@ -130,12 +130,12 @@ VAR_MEM_ENTRIES_PER_ROW = 2      # NUM_VAR_MEM_ENTRIES_PER_ROW (chips/mem/variab
 SELECT_PREP_COLS, SELECT_COLS = 8, 5   # (is_real, addrs {bit, out1, out2, in1, in2}, mult1, mult2); SelectIo {bit, out1, out2, in1, in2}
 
 
-def _finish_rec(r, name, log_height, main_width, prep_index, lqd=1):
+def _finish_rec(r, name, log_height, main_width, prep_index, lqd=1, local_only=True):
     r.b.perm_ext_width = air.local_permutation_trace_width(len(r.sends) + len(r.receives), 1 << lqd)
     air.eval_permutation_constraints(r.b, r.sends, r.receives, 1 << lqd, False)
     program = r.b.assemble()
     return chips.RecordedChip(name=name, log_height=log_height, main_width=main_width, prep_width=r.b.prep_width, prep_index=prep_index,
-                              log_quotient_degree=lqd, local_only=True, sends=r.sends, receives=r.receives, program=program,
+                              log_quotient_degree=lqd, local_only=local_only, sends=r.sends, receives=r.receives, program=program,
                               lookups_blob=air.encode_lookups(r.sends, r.receives), num_constraints=int(program[2]))
 
 
@@ -264,8 +264,73 @@ def record_poseidon2_wide(log_height: int = 10, prep_index: int = 0, constraints
     return r if constraints_only else _finish_rec(r, "Poseidon2Wide", log_height, POSEIDON2_WIDE_WIDTH, prep_index)
 
 
+EXP_REVERSE_BITS_COLS, EXP_REVERSE_BITS_PREP_COLS = 7, 10
+BATCH_FRI_COLS, BATCH_FRI_PREP_COLS = 13, 6
+PUBLIC_VALUES_PREP_COLS, PUBLIC_VALUES_LOG_HEIGHT, DIGEST_SIZE = 10, 4, 8
+PV_DIGEST_POS = 223     # RecursionPublicValues::digest (crates/recursion/core/src/air/public_values.rs:79-145): the last eight of 231 words
+
+
+def record_exp_reverse_bits(log_height: int = 10, prep_index: int = 0, constraints_only: bool = False):
+    """ExpReverseBitsLenChip<3>::eval (chips/exp_reverse_bits.rs:345-405): one row per exponent bit, accum' = accum^2 * (bit ? x : 1);
+    prep = x_mem, exponent_mem, result_mem (addr, mult each), iteration_num, is_first, is_last, is_real; main = x, current_bit,
+    prev_accum_squared, prev_accum_squared_times_multiplier, accum, accum_squared, multiplier."""
+    r = _RecRec(EXP_REVERSE_BITS_COLS, EXP_REVERSE_BITS_PREP_COLS)
+    l, n, p, b = r.local, r.next, r.prep, r.b
+    pn = b.preprocessed()[1]
+    x, bit, prev_sq, prev_sq_mul, accum, accum_sq, mult = (l[i] for i in range(7))
+    is_first, is_last, is_real = p[7], p[8], p[9]
+    r.send_single(p[0], x, p[1])
+    b.when_transition().when(pn[9]).when_not(is_last).assert_eq(x, n[0])
+    r.send_single(p[2], bit, p[3])
+    b.when(is_first).assert_eq(accum, mult)
+    b.when(is_real).when(bit).assert_eq(mult, x)
+    b.when(is_real).when_not(bit).assert_eq(mult, 1)
+    b.when(is_real).assert_eq(prev_sq_mul, prev_sq * mult)
+    b.when(is_real).when_not(is_first).assert_eq(accum, prev_sq_mul)
+    b.when(is_real).assert_eq(accum_sq, accum * accum)
+    b.when_transition().when(pn[9]).when_not(is_last).assert_eq(n[2], accum_sq)
+    r.send_single(p[4], accum, p[5])
+    return r if constraints_only else _finish_rec(r, "ExpReverseBitsLen", log_height, EXP_REVERSE_BITS_COLS, prep_index, local_only=False)
+
+
+def record_batch_fri(log_height: int = 10, prep_index: int = 0, constraints_only: bool = False):
+    """BatchFRIChip<3>::eval (chips/batch_fri.rs:289-350): acc = sum over an instruction's rows of alpha_pow * (p_at_z - p_at_x) in the
+    extension; prep = is_real, is_end, acc / alpha_pow / p_at_z / p_at_x addresses; main = acc(4), alpha_pow(4), p_at_z(4), p_at_x."""
+    r = _RecRec(BATCH_FRI_COLS, BATCH_FRI_PREP_COLS)
+    l, n, p, b = r.local, r.next, r.prep, r.b
+    is_real, is_end = p[0], p[1]
+    b.assert_eq(is_real * is_real * is_real, is_real * is_real * is_real)
+    r.receive_block(p[3], l[4:8], is_real)
+    r.receive_block(p[4], l[8:12], is_real)
+    r.receive_single(p[5], l[12], is_real)
+    r.send_block(p[2], l[0:4], is_end)
+
+    def term(row):    # alpha_pow * (p_at_z - p_at_x) over F[X]/(X^4 - 3)
+        return _ext_mul_expr(b, row[4:8], [row[8] - row[12], row[9], row[10], row[11]])
+
+    for i, t in enumerate(term(l)):
+        b.when_first_row().assert_eq(l[i], t)
+    tn = term(n)
+    for i in range(4):
+        b.when_transition().when(is_end).assert_eq(n[i], tn[i])
+    for i in range(4):
+        b.when_transition().when_not(is_end).assert_eq(n[i], l[i] + tn[i])
+    return r if constraints_only else _finish_rec(r, "BatchFRI", log_height, BATCH_FRI_COLS, prep_index, local_only=False)
+
+
+def record_public_values(prep_index: int = 0, constraints_only: bool = False):
+    """PublicValuesChip::eval (chips/public_values.rs:274-291): sixteen rows, eight real: row i reads digest element i from memory
+    (multiplicity -1) and ties it to public value digest[i]; prep = pv_idx[8] one-hot, (addr, mult); main = pv_element."""
+    r = _RecRec(1, PUBLIC_VALUES_PREP_COLS)
+    l, p, b = r.local, r.prep, r.b
+    r.send_single(p[8], l[0], p[9])
+    for i in range(DIGEST_SIZE):
+        b.when(p[i]).assert_eq(b.public_values(PV_DIGEST_POS + i), l[0])
+    return r if constraints_only else _finish_rec(r, "PublicValues", PUBLIC_VALUES_LOG_HEIGHT, 1, prep_index, local_only=False)
+
+
 def balanced_program(n_base: int, n_ext: int, n_const: int = 64, seed: int = 1, n_var: int = 0, n_select: int = 0, n_poseidon2: int = 0,
-                     permute_batch=None):
+                     permute_batch=None, n_exp: int = 0, n_batch_fri: int = 0, commit_public_values: bool = False):
     """A synthetic recursion program whose memory lookups balance exactly, as a real one's do: constants are written by
     MemoryConst entries, every ALU instruction reads two earlier values (constants or earlier results of its own field)
     and writes one, and each write's multiplicity is the number of later reads; a few results are read back by
@@ -339,6 +404,48 @@ def balanced_program(n_base: int, n_ext: int, n_const: int = 64, seed: int = 1, 
             entries[a] = {"val": [v, 0, 0, 0], "reads": 0, "kind": "base"}
         pools["base"] += outs
         poseidon_rows.append((ins, outs))
+    # ExpReverseBitsLen: result = x^(bit-reversed exponent), one row per bit (accum' = accum^2 * (bit ? x : 1))
+    exp_prep, exp_main = [], []
+    for _ in range(n_exp if bits else 0):
+        ax = pools["base"][int(rng.integers(0, len(pools["base"])))]
+        xv = entries[ax]["val"][0]
+        nbits = int(rng.integers(1, 32))
+        abits = [bits[int(rng.integers(0, len(bits)))] for _ in range(nbits)]
+        ares = new_addr()
+        entries[ax]["reads"] += 1
+        accum, prev = 1, 1
+        rows_here = []
+        for i, ab in enumerate(abits):
+            entries[ab]["reads"] += 1
+            bv = entries[ab]["val"][0]
+            m = xv if bv else 1
+            prev_sq = prev * prev % P
+            accum = prev_sq * m % P
+            exp_main.append([xv, bv, prev_sq, prev_sq * m % P, accum, accum * accum % P, m])
+            rows_here.append([ax, (P - 1) if i == 0 else 0, ab, P - 1, ares, None, i, int(i == 0), int(i == nbits - 1), 1])
+            prev = accum
+        entries[ares] = {"val": [accum, 0, 0, 0], "reads": 0, "kind": "base"}
+        pools["base"].append(ares)
+        exp_prep.append((ares, rows_here))
+    # BatchFRI: acc = sum_k alpha_pow_k * (p_at_z_k - p_at_x_k); one row per k, the accumulator written on the last one
+    fri_prep, fri_main = [], []
+    for _ in range(n_batch_fri):
+        k = int(rng.integers(1, 9))
+        aacc = new_addr()
+        acc = [0, 0, 0, 0]
+        rows_here = []
+        for i in range(k):
+            aal, apz = (pools["ext"][int(rng.integers(0, len(pools["ext"])))] for _ in range(2))
+            apx = pools["base"][int(rng.integers(0, len(pools["base"])))]
+            for a in (aal, apz, apx):
+                entries[a]["reads"] += 1
+            al, pz, px = entries[aal]["val"], entries[apz]["val"], entries[apx]["val"][0]
+            t = ext_mul(al, [(pz[0] - px) % P, pz[1], pz[2], pz[3]])
+            acc = [(acc[e] + t[e]) % P for e in range(4)]
+            fri_main.append(acc + al + pz + [px])
+            rows_here.append([1, int(i == k - 1), aacc, aal, apz, apx])
+        entries[aacc] = {"val": acc, "reads": 1, "kind": "fri_acc"}   # written with multiplicity 1 (acc_mult, batch_fri.rs:103): read exactly once
+        fri_prep += rows_here
     base_rows, ext_rows = [], []   # (opcode, addr_out, addr_in1, addr_in2, out, in1, in2)
     for which, n, rows in (("base", n_base, base_rows), ("ext", n_ext, ext_rows)):
         for _ in range(n):
@@ -365,6 +472,15 @@ def balanced_program(n_base: int, n_ext: int, n_const: int = 64, seed: int = 1, 
             entries[ao] = {"val": o, "reads": 0, "kind": which, "row": len(rows)}
             pools[which].append(ao)
             rows.append([op, ao, a1, a2, o, x, y])
+    # CommitPublicValues: the digest's eight elements are read from memory by the PublicValues chip
+    pv_prep, pv_main, pv_digest = [], [], [0] * DIGEST_SIZE
+    if commit_public_values:
+        for i in range(DIGEST_SIZE):
+            a = pools["base"][int(rng.integers(0, len(pools["base"])))]
+            entries[a]["reads"] += 1
+            pv_digest[i] = entries[a]["val"][0]
+            pv_prep.append([int(j == i) for j in range(DIGEST_SIZE)] + [a, P - 1])
+            pv_main.append([pv_digest[i]])
     # a few results are read back by the constant-memory table (MemAccessKind::Read: multiplicity negated)
     mem = []   # (value block, addr, signed multiplicity)
     results = [a for a, e in entries.items() if e["kind"] in ("base", "ext")]
@@ -374,6 +490,8 @@ def balanced_program(n_base: int, n_ext: int, n_const: int = 64, seed: int = 1, 
     for a, e in entries.items():
         if e["kind"] == "const":
             mem.append((e["val"], a, e["reads"]))
+        elif e["kind"] == "fri_acc":
+            mem.append((e["val"], a, -1))
 
     def pack_alu(rows, ext):
         ins = np.zeros((len(rows), ACCESS_COLS), dtype=np.uint64)
@@ -401,7 +519,20 @@ def balanced_program(n_base: int, n_ext: int, n_const: int = 64, seed: int = 1, 
                         dtype=np.uint64).reshape(-1, POSEIDON2_WIDE_PREP_WIDTH)
     pos_events = np.array([[entries[a]["val"][0] for a in ins] + [entries[a]["val"][0] for a in outs] for ins, outs in poseidon_rows],
                           dtype=np.uint64).reshape(-1, 32)
-    extra = {"poseidon2_prep": F.to_monty(pos_prep).reshape(-1), "poseidon2_events": F.to_monty(pos_events).reshape(-1),
+    for ares, rows_here in exp_prep:      # the result's multiplicity is known only now
+        rows_here[-1][5] = entries[ares]["reads"]
+        for row in rows_here[:-1]:
+            row[5] = 0
+    exp_prep_rows = [row for _, rows_here in exp_prep for row in rows_here]
+    arr = lambda rows, w: F.to_monty(np.array(rows, dtype=np.uint64).reshape(-1, w)).reshape(-1)   # noqa: E731
+    more = {"exp_prep": arr(exp_prep_rows, EXP_REVERSE_BITS_PREP_COLS), "exp_main": arr(exp_main, EXP_REVERSE_BITS_COLS),
+            "batch_fri_prep": arr(fri_prep, BATCH_FRI_PREP_COLS), "batch_fri_main": arr(fri_main, BATCH_FRI_COLS),
+            "pv_prep": arr(pv_prep, PUBLIC_VALUES_PREP_COLS), "pv_main": arr(pv_main, 1), "pv_digest": pv_digest,
+            "exp_bases": arr([entries[rows_here[0][0]]["val"][0] for _, rows_here in exp_prep], 1),
+            "exp_bits": arr([entries[row[2]]["val"][0] for _, rows_here in exp_prep for row in rows_here], 1),
+            "exp_offsets": np.cumsum([0] + [len(rows_here) for _, rows_here in exp_prep]).astype(np.uint32),
+            "n_exp_rows": len(exp_prep_rows), "n_batch_fri_rows": len(fri_prep)}
+    extra = {**more, "poseidon2_prep": F.to_monty(pos_prep).reshape(-1), "poseidon2_events": F.to_monty(pos_events).reshape(-1),
              "n_poseidon2": len(poseidon_rows), "var_prep": F.to_monty(var_prep).reshape(-1), "var_values": F.to_monty(var_values).reshape(-1),
              "select_prep": F.to_monty(sel_prep).reshape(-1), "select_events": F.to_monty(sel_events).reshape(-1),
              "n_var": len(var_rows), "n_select": len(select_rows)}
