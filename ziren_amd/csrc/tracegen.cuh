@@ -38,6 +38,22 @@ __host__ __device__ constexpr int event_words(int chip) { return chip == MUL || 
 
 constexpr int THREADS = 256;
 
+// The IsZero / IsEqual blocks of several chips need the field inverse of a byte, of a difference of two bytes, or of a sum of three
+// bytes: a table of 1/1 .. 1/767 (canonical) in constant memory instead of a 31-bit exponentiation per cell.
+constexpr uint32_t SMALL_INV = 768;
+__constant__ uint32_t d_small_inv[SMALL_INV];
+__device__ __forceinline__ uint32_t small_inverse(uint32_t x) {   // canonical in, canonical out; 0 for 0
+  if (x < SMALL_INV) return d_small_inv[x];
+  if (x > kb::P - SMALL_INV) return kb::P - d_small_inv[kb::P - x];   // 1 / (-d) = -(1 / d)
+  return kb::from_monty(kb::inv(kb::to_monty(x)));
+}
+inline hipError_t upload_tables() {
+  static uint32_t inv[SMALL_INV];
+  inv[0] = 0;
+  for (uint32_t i = 1; i < SMALL_INV; i++) inv[i] = kb::from_monty(kb::inv(kb::to_monty(i)));
+  return hipMemcpyToSymbol(HIP_SYMBOL(d_small_inv), inv, sizeof inv);
+}
+
 // Rows are built as canonical integers (bytes, flags, pcs); alu_rows converts each cell to Montgomery form as it
 // stores it (from_canonical_u32 of any u32), byte_mults reads the same cells to form the byte lookups.
 __device__ __forceinline__ uint32_t fbool(bool b) { return b ? 1u : 0u; }
@@ -274,7 +290,7 @@ template <> __device__ __forceinline__ void event_row<MOV_COND>(const AluEvent& 
 #pragma unroll
   for (int i = 0; i < 4; i++) {  // IsZeroOperation per byte: (inverse, result)
     const uint32_t byte = (c >> (8 * i)) & 0xff;
-    r[C_EQ_0 + 2 * i] = byte ? kb::from_monty(kb::inv(kb::to_monty(byte))) : 0u;
+    r[C_EQ_0 + 2 * i] = small_inverse(byte);
     res[i] = r[C_EQ_0 + 2 * i + 1] = fbool(byte == 0);
   }
   r[C_EQ_0 + 8] = res[0] & res[1];
@@ -372,7 +388,7 @@ __device__ __forceinline__ void is_equal_word_cols(uint32_t a, uint32_t b, uint3
     const uint32_t x = (a >> (8 * i)) & 0xff, y = (b >> (8 * i)) & 0xff;
     const uint32_t diff = x >= y ? x - y : x + kb::P - y;   // canonical field difference
     z[i] = fbool(diff == 0);
-    r[2 * i] = diff ? kb::from_monty(kb::inv(kb::to_monty(diff))) : 0u;
+    r[2 * i] = small_inverse(diff);
     r[2 * i + 1] = z[i];
   }
   r[8] = z[0] & z[1];
@@ -516,7 +532,7 @@ __device__ __forceinline__ void memory_instr_row(const uint32_t* p, uint32_t* r)
 #pragma unroll
   for (int i = 0; i < 14; i++) r[IS_LB + i] = fbool(o == 31u + i);
   const uint32_t upper = ((addr >> 8) & 0xff) + ((addr >> 16) & 0xff) + (addr >> 24);
-  r[MOST_SIG_BYTES_ZERO] = upper ? kb::from_monty(kb::inv(kb::to_monty(upper))) : 0u;
+  r[MOST_SIG_BYTES_ZERO] = small_inverse(upper);
   r[MOST_SIG_BYTES_ZERO + 1] = fbool(upper == 0);
 }
 
@@ -530,7 +546,7 @@ enum { PC = 0, NEXT_PC = 1, SHARD = 2, CLK = 3, NUM_EXTRA_CYCLES = 4, IS_HALT = 
 }
 __device__ __forceinline__ void is_zero_cols(uint32_t id, uint32_t code, uint32_t* r) {   // IsZeroOperation of (id - code) in the field
   const uint32_t diff = id >= code ? id - code : id + kb::P - code;
-  r[0] = diff ? kb::from_monty(kb::inv(kb::to_monty(diff))) : 0u;
+  r[0] = small_inverse(diff);
   r[1] = fbool(diff == 0);
 }
 __device__ __forceinline__ void syscall_instr_row(const uint32_t* p, uint32_t* r) {

@@ -1093,6 +1093,7 @@ int zkm_ctx_create(int device, zkm_ctx** out) {
   HIP_CHECK(hipStreamCreate(&c->stream2));
   c->cur = c->stream;
   HIP_CHECK(p2::upload_tables());
+  HIP_CHECK(tracegen::upload_tables());
   HIP_CHECK(hipFuncSetAttribute((const void*)lde::lde_rows, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIP_CHECK(hipFuncSetAttribute((const void*)lde::lde_rows_big, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIP_CHECK(hipFuncSetAttribute((const void*)tracegen::alu_rows<tracegen::ADD_SUB>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
