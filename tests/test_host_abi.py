@@ -24,6 +24,37 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(L, name), name
 
 
+def _build_c_consumer(tmp_path):
+    import subprocess
+    exe = str(tmp_path / "consumer")
+    subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "c_abi", "consumer.c"),
+                           "-L", os.path.join(ROOT, "ziren_amd"), "-lzkm_hip", "-Wl,-rpath," + os.path.join(ROOT, "ziren_amd"), "-o", exe])
+    return exe
+
+
+def test_plain_c_consumer_links_and_is_refused_without_a_gpu(tmp_path):
+    """include/zkm_hip.h is a C header a foreign-language binding can consume as is: a C11 program compiles against it with -Wall
+    -Werror, links to libzkm_hip.so, and without a GPU gets a refusal (never a CPU fallback)."""
+    import subprocess
+    exe = _build_c_consumer(tmp_path)
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="-1", ROCR_VISIBLE_DEVICES="-1")
+    out = subprocess.run([exe], capture_output=True, text=True, env=env)
+    assert out.returncode == 0 and out.stdout.startswith("refused:") and "no CPU fallback" in out.stdout, (out.returncode, out.stdout, out.stderr)
+
+
+@pytest.mark.gpu
+def test_gpu_plain_c_consumer(tmp_path, hip_ctx, oracle):
+    """The same C program on a GPU: AluEvent -> device trace -> commitment, checked against the oracle's root."""
+    import subprocess
+    from ziren_amd import events as E
+    exe = _build_c_consumer(tmp_path)
+    out = subprocess.run([exe, "gpu"], capture_output=True, text=True)
+    assert out.returncode == 0 and out.stdout.startswith("ok "), (out.returncode, out.stdout, out.stderr)
+    ev = E.make_alu_events([E.ADD], [5], [7], pc0=0x1000)
+    want = oracle.pcs_commit([oracle.tracegen_alu(E.CHIP_ADD_SUB, ev)], 1)[0]
+    assert int(out.stdout.split()[1]) == int(want[0])
+
+
 def test_no_gpu_means_loud_failure():
     import subprocess, sys
     # in a process that cannot see a GPU the context must refuse, not fall back
