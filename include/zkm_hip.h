@@ -397,6 +397,9 @@ typedef struct zkm_misc_event {
 size_t zkm_tracegen_misc_instrs_width(void);
 int zkm_tracegen_misc_instrs(zkm_ctx* ctx, const zkm_misc_event* events, size_t n_events, int fixed_log2_rows, zkm_byte_lookups* blu,
                              zkm_matrix** out);
+/* The wrap machine's hash chip, Poseidon2Skinny (crates/recursion/core/src/chips/poseidon2_skinny/): replaces generate_trace
+ * (trace.rs:62-118). Same Poseidon2Events; eleven rows of 28 columns per permutation, zero padding. */
+int zkm_tracegen_poseidon2_skinny(zkm_ctx* ctx, const uint32_t* events, size_t n_events, int fixed_log2_rows, zkm_matrix** out);
 /* The recursion machine's ExpReverseBitsLen chip (crates/recursion/core/src/chips/exp_reverse_bits.rs): replaces generate_trace
  * (:175-226). An ExpReverseBitsEvent is a base and a vector of exponent bits (lib.rs:208-212); here the n bases, all bits end to
  * end and n + 1 offsets into them (Montgomery words; offsets plain). One row per bit, 7 columns, zero padding. BatchFRI, PublicValues,

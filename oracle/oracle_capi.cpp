@@ -556,4 +556,19 @@ int orc_tracegen_exp_reverse_bits(const uint32_t* bases, const uint32_t* bits, c
   ORC_CATCH
 }
 
+// recursion Poseidon2Skinny chip: events as for orc_tracegen_poseidon2_wide; eleven rows of 28 columns per event
+int orc_tracegen_poseidon2_skinny(const uint32_t* events, size_t n_events, int fixed_log2_rows, uint32_t* out, size_t out_cap, size_t* rows) {
+  ORC_TRY
+  size_t h;
+  std::vector<F> ev(n_events * 32);
+  for (size_t i = 0; i < ev.size(); i++) ev[i] = from_monty(events[i]);
+  std::vector<F> t = tracegen::generate_poseidon2_skinny(ev.data(), n_events, fixed_log2_rows, &h);
+  *rows = h;
+  if (out) {
+    if (t.size() > out_cap) throw std::runtime_error("trace buffer too small");
+    for (size_t i = 0; i < t.size(); i++) out[i] = to_monty(t[i]);
+  }
+  ORC_CATCH
+}
+
 }  // extern "C"

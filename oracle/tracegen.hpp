@@ -1143,4 +1143,42 @@ static inline std::vector<F> generate_exp_reverse_bits(const F* bases, const F* 
   return t;
 }
 
+// ---- recursion Poseidon2Skinny chip (crates/recursion/core/src/chips/poseidon2_skinny/trace.rs:62-118): eleven rows per permutation —
+// the state entering: the initial linear layer, external rounds 0..3, the internal rounds (that row also holds lane 0 after each of the
+// first twelve), external rounds 4..7, and the output row; 28 columns (state_var[16], internal_rounds_s0[12]); zero padding
+static const size_t SKINNY_WIDTH = 28, SKINNY_ROWS = 11;
+static inline void poseidon2_skinny_rows(const F input[16], F* r /* 11 rows */) {
+  F state[16];
+  for (int i = 0; i < 16; i++) r[i] = state[i] = input[i];
+  orc::external_layer(state);
+  for (int row = 1; row <= 10; row++) {
+    F* cur = r + row * SKINNY_WIDTH;
+    for (int i = 0; i < 16; i++) cur[i] = state[i];
+    if (row == 10) break;
+    if (row == 5) {
+      for (int rd = 0; rd < 13; rd++) {
+        state[0] = orc::sbox(fadd(state[0], orc::ORC_RC_16_30[4 + rd][0]));
+        orc::internal_layer(state);
+        if (rd < 12) cur[16 + rd] = state[0];
+      }
+    } else {
+      const int round = row < 5 ? row - 1 : row - 2 + 13;
+      for (int i = 0; i < 16; i++) state[i] = orc::sbox(fadd(state[i], orc::ORC_RC_16_30[round][i]));
+      orc::external_layer(state);
+    }
+  }
+}
+static inline std::vector<F> generate_poseidon2_skinny(const F* events, size_t n_events, int fixed_log2_rows, size_t* height) {
+  const size_t h = padded_rows(n_events * SKINNY_ROWS, fixed_log2_rows);
+  std::vector<F> t(h * SKINNY_WIDTH, 0);
+  for (size_t e = 0; e < n_events; e++) {
+    F* r = t.data() + e * SKINNY_ROWS * SKINNY_WIDTH;
+    poseidon2_skinny_rows(events + 32 * e, r);
+    for (int k = 0; k < 16; k++)
+      if (r[10 * SKINNY_WIDTH + k] != events[32 * e + 16 + k]) throw std::runtime_error("tracegen: Poseidon2 event output is not the permutation of its input");
+  }
+  *height = h;
+  return t;
+}
+
 }  // namespace tracegen

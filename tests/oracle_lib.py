@@ -390,3 +390,14 @@ def tracegen_exp_reverse_bits(bases, bits, offsets, fixed_log2_rows=-1):
     out = np.zeros((rows.value, 7), dtype=np.uint32)
     _check(lib().orc_tracegen_exp_reverse_bits(*args, abi.as_u32p(out), C.c_size_t(out.size), C.byref(rows)))
     return out
+
+
+def tracegen_poseidon2_skinny(events, fixed_log2_rows=-1):
+    """Recursion Poseidon2Skinny rows (eleven per event) from events of 32 Montgomery words (input[16], output[16])."""
+    ev = np.ascontiguousarray(events, dtype=np.uint32).reshape(-1, 32)
+    rows = C.c_size_t()
+    args = (abi.as_u32p(ev), C.c_size_t(len(ev)), C.c_int(fixed_log2_rows))
+    _check(lib().orc_tracegen_poseidon2_skinny(*args, None, C.c_size_t(0), C.byref(rows)))
+    out = np.zeros((rows.value, 28), dtype=np.uint32)
+    _check(lib().orc_tracegen_poseidon2_skinny(*args, abi.as_u32p(out), C.c_size_t(out.size), C.byref(rows)))
+    return out

@@ -34,7 +34,7 @@ def test_row_counts():
 
 
 def balanced_shard(n_base, n_ext, n_const, seed, heights=(-1, -1, -1), n_var=0, n_select=0, n_poseidon2=0, oracle=None, n_exp=0,
-                   n_batch_fri=0, commit_public_values=False):
+                   n_batch_fri=0, commit_public_values=False, wrap=False):
     """BaseAlu + ExtAlu + MemoryConst (+ MemoryVar + Select) over one consistent program: (chips with host traces, flat
     record streams (preprocessed words, main words))."""
     prog = R.balanced_program(n_base, n_ext, n_const, seed, n_var=n_var, n_select=n_select, n_poseidon2=n_poseidon2, n_exp=n_exp,
@@ -65,7 +65,13 @@ def balanced_shard(n_base, n_ext, n_const, seed, heights=(-1, -1, -1), n_var=0, 
         rc.trace, rc.prep_trace = R.flat_trace(prog["select_events"], R.SELECT_COLS, -1, 1), prep
         recs.append(rc)
         streams.append((prog["select_prep"], prog["select_events"]))
-    if n_poseidon2:
+    if n_poseidon2 and wrap:      # the wrap machine hashes with the skinny chip: eleven rows per permutation, degree 9
+        prep = R.flat_trace(F.to_monty(R.poseidon2_skinny_prep(prog["poseidon2_instrs"])).reshape(-1), R.SKINNY_PREP_WIDTH, -1, 1)
+        rc = R.record_poseidon2_skinny(prep.shape[0].bit_length() - 1, prep_index=5, degree=9)
+        rc.trace, rc.prep_trace = oracle.tracegen_poseidon2_skinny(prog["poseidon2_events"], rc.log_height), prep
+        recs.append(rc)
+        streams.append((prep[:len(prog["poseidon2_instrs"]) * R.SKINNY_ROWS].reshape(-1), prog["poseidon2_events"]))
+    elif n_poseidon2:
         prep = R.flat_trace(prog["poseidon2_prep"], R.POSEIDON2_WIDE_PREP_WIDTH, -1, 1)
         rc = R.record_poseidon2_wide(prep.shape[0].bit_length() - 1, prep_index=5)
         rc.trace, rc.prep_trace = oracle.tracegen_poseidon2_wide(prog["poseidon2_events"], rc.log_height), prep
@@ -80,7 +86,7 @@ def balanced_shard(n_base, n_ext, n_const, seed, heights=(-1, -1, -1), n_var=0, 
         streams.append((prog["exp_prep"], (prog["exp_bases"], prog["exp_bits"], prog["exp_offsets"])))
     if n_batch_fri:
         prep = R.flat_trace(prog["batch_fri_prep"], R.BATCH_FRI_PREP_COLS, -1, 1)
-        rc = R.record_batch_fri(prep.shape[0].bit_length() - 1, prep_index=7)
+        rc = R.record_batch_fri(prep.shape[0].bit_length() - 1, prep_index=7, degree=9 if wrap else 3)
         rc.trace, rc.prep_trace = R.flat_trace(prog["batch_fri_main"], R.BATCH_FRI_COLS, rc.log_height, 1), prep
         recs.append(rc)
         streams.append((prog["batch_fri_prep"], prog["batch_fri_main"]))
@@ -107,6 +113,50 @@ def compress_machine_shard(oracle, scale=1, seed=31):
                                    oracle=oracle, n_exp=25 * scale, n_batch_fri=30 * scale, commit_public_values=True)
     digest = streams.pop()
     return recs, streams, digest
+
+
+def wrap_machine_shard(oracle, scale=1, seed=33):
+    """The eight chips of the wrap machine (machine.rs:138-153): the skinny hash chip and BatchFRI at DEGREE 9, no ExpReverseBitsLen."""
+    recs, streams = balanced_shard(300 * scale, 200 * scale, 40, seed=seed, n_var=100 * scale, n_select=80 * scale, n_poseidon2=25 * scale,
+                                   oracle=oracle, n_batch_fri=30 * scale, commit_public_values=True, wrap=True)
+    digest = streams.pop()
+    for i, r in enumerate(recs):
+        r.prep_index = i
+    return recs, streams, digest
+
+
+def test_wrap_machine(oracle):
+    """Poseidon2Skinny<9> completes the wrap machine: eleven rows per permutation whose output row carries the reference's
+    permutation, constraints of degree up to 9 (quotient degree 8 for it and for BatchFRI<9>, 2 for the others, in one shard), lookups
+    that cancel, and an oracle proof under the ultra-compressed FRI configuration (blow-up 8) that verifies."""
+    import json
+    import os
+    from ziren_amd import synth
+    kat = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "poseidon2_kat.json")))["vectors"]
+    ev = np.array([list(v["input"]) + list(v["output"]) for v in kat], dtype=np.uint64)
+    rows = F.from_monty(oracle.tracegen_poseidon2_skinny(F.to_monty(ev)))
+    assert rows.shape == (64, 28) and all(np.array_equal(rows[11 * k + 10, :16], ev[k, 16:]) and np.array_equal(rows[11 * k, :16], ev[k, :16]) for k in range(len(kat)))
+    assert not rows[33:].any()
+    recs, streams, digest = wrap_machine_shard(oracle)
+    assert [r.name for r in recs] == ["BaseAlu", "ExtAlu", "MemoryConst", "MemoryVar", "Select", "Poseidon2SkinnyDeg9", "BatchFRI", "PublicValues"]
+    assert [r.log_quotient_degree for r in recs] == [1, 1, 1, 1, 1, 3, 3, 1]
+    sk = recs[5]
+    rp = R.record_poseidon2_skinny(constraints_only=True)
+    main, prep = F.from_monty(sk.trace), F.from_monty(sk.prep_trace)
+    assert air.debug_constraints(rp.b, main, prep=prep) == []
+    for row, col, hit in ((0, 3, {0}), (3, 7, {2, 3}), (5, 20, {5}), (10, 2, {9})):      # input, an external round, an s0, the output state
+        bad = main.copy()
+        bad[row, col] = (int(bad[row, col]) + 1) % F.P
+        assert {x for _, x in air.debug_constraints(rp.b, bad, prep=prep)} == hit, (row, col)
+    t = tally_of(recs)
+    assert t and not any(t.values())
+    fri = abi.FriConfig(3, 28, 16)
+    igcs = F.to_monty(np.zeros(14, dtype=np.uint64))
+    opk = oracle.Pk([r.prep_trace for r in recs], [int(r.local_only) for r in recs], F.to_monty(0), igcs, 3)
+    start = oracle.new_challenger()
+    opk.observe_into(start)
+    proof, _ = oracle.prove_shard(opk, recs, [c.trace for c in recs], recursion_public_values(digest), fri, synth.NUM_PV_ELTS, start.copy())
+    assert oracle.verify_shard(opk, recs, fri, synth.NUM_PV_ELTS, start.copy(), proof) == 0
 
 
 def test_compress_machine_is_complete(oracle):
@@ -310,6 +360,48 @@ def test_gpu_recursion_alu_shard(hip_ctx, oracle, log_blowup, queries):
     start = ch.copy()
     born = [hip_ctx.tracegen_poseidon2_wide(ev, r.log_height) if r.name == "Poseidon2Wide" else
             hip_ctx.tracegen_exp_reverse_bits(*ev, r.log_height) if r.name == "ExpReverseBitsLen" else
+            hip_ctx.tracegen_flat(ev, r.trace.shape[1], r.log_height) if ev is not None else hip_ctx.upload(r.trace)
+            for (_, ev), r in zip(streams, recs)]
+    for m, r in zip(born, recs):
+        assert np.array_equal(m.to_host(), r.trace), r.name
+    proof = hp.prove_shard(pk, pv, born, ch).copy()
+    och = oracle.new_challenger()
+    opk.observe_into(och)
+    oproof, _ = oracle.prove_shard(opk, recs, [c.trace for c in recs], pv, fri, synth.NUM_PV_ELTS, och)
+    assert np.array_equal(proof, oproof)
+    assert oracle.verify_shard(opk, recs, fri, synth.NUM_PV_ELTS, start.copy(), proof) == 0
+    for m in born:
+        m.free()
+
+
+@pytest.mark.gpu
+def test_gpu_wrap_machine_shard(hip_ctx, oracle):
+    """The wrap machine's eight chips on the device under the ultra-compressed configuration (blow-up 8, 28 queries): quotient degrees
+    2 and 8 in one shard, the skinny hash chip's eleven-row permutations built on the device, proof bit-identical to the oracle's."""
+    from ziren_amd import prover, synth
+    for n in (0, 1, 5, 700):
+        prog = R.balanced_program(10, 10, 40, seed=n + 1, n_var=20, n_poseidon2=n)
+        want = oracle.tracegen_poseidon2_skinny(prog["poseidon2_events"])
+        m = hip_ctx.tracegen_poseidon2_skinny(prog["poseidon2_events"])
+        assert (m.height, m.width) == want.shape and np.array_equal(m.to_host(), want), n
+        m.free()
+    recs, streams, digest = wrap_machine_shard(oracle, scale=6, seed=44)
+    fri = abi.FriConfig(3, 28, 16)
+    pv = recursion_public_values(digest)
+    igcs = F.to_monty(np.zeros(14, dtype=np.uint64))
+    hp = prover.HipProver(recs, fri, synth.NUM_PV_ELTS, ctx=hip_ctx)
+    hp.specialize_quotient_kernels(recs)
+    preps = [hip_ctx.tracegen_flat(ins, r.prep_trace.shape[1], r.log_height) for (ins, _), r in zip(streams, recs)]
+    for m, r in zip(preps, recs):
+        assert np.array_equal(m.to_host(), r.prep_trace), r.name
+    lo = [int(r.local_only) for r in recs]
+    pk = hp.setup(preps, lo, F.to_monty(0), igcs)
+    opk = oracle.Pk([r.prep_trace for r in recs], lo, F.to_monty(0), igcs, 3)
+    assert np.array_equal(pk.commit, opk.commitment())
+    ch = prover.new_challenger()
+    pk.observe_into(ch)
+    start = ch.copy()
+    born = [hip_ctx.tracegen_poseidon2_skinny(ev, r.log_height) if r.name.startswith("Poseidon2Skinny") else
             hip_ctx.tracegen_flat(ev, r.trace.shape[1], r.log_height) if ev is not None else hip_ctx.upload(r.trace)
             for (_, ev), r in zip(streams, recs)]
     for m, r in zip(born, recs):

@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--log-hashes", type=int, default=16, help="log2 of the number of Poseidon2 permutations in the program")
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--shrink", action="store_true")
+    ap.add_argument("--wrap", action="store_true", help="the wrap machine: Poseidon2Skinny and BatchFRI at DEGREE 9, no ExpReverseBitsLen, blow-up 8")
     args = ap.parse_args()
     ctx = prover.Context(0)
     n_hash = 1 << args.log_hashes
@@ -32,7 +33,9 @@ def main():
 
     t0 = time.perf_counter()
     prog = R.balanced_program(n_hash // 2, n_hash // 4, 512, seed=1, n_var=4096, n_select=n_hash // 8, n_poseidon2=n_hash, permute_batch=permute,
-                              n_exp=n_hash // 64, n_batch_fri=n_hash // 32, commit_public_values=True)
+                              n_exp=0 if args.wrap else n_hash // 64, n_batch_fri=n_hash // 32, commit_public_values=True)
+    if args.wrap:
+        prog["skinny_prep"] = F.to_monty(R.poseidon2_skinny_prep(prog["poseidon2_instrs"])).reshape(-1)
     gen_s = time.perf_counter() - t0
     specs = [("base_instrs", "base_events", R.ENTRIES_PER_ROW * R.ACCESS_COLS, R.ENTRIES_PER_ROW * R.BASE_VALUE_COLS, R.ENTRIES_PER_ROW, lambda lh, i: R.record_chip(False, lh, i)),
              ("ext_instrs", "ext_events", R.ENTRIES_PER_ROW * R.ACCESS_COLS, R.ENTRIES_PER_ROW * R.EXT_VALUE_COLS, R.ENTRIES_PER_ROW, lambda lh, i: R.record_chip(True, lh, i)),
@@ -43,6 +46,10 @@ def main():
              ("exp_prep", "exp_main", R.EXP_REVERSE_BITS_PREP_COLS, R.EXP_REVERSE_BITS_COLS, 1, R.record_exp_reverse_bits),
              ("batch_fri_prep", "batch_fri_main", R.BATCH_FRI_PREP_COLS, R.BATCH_FRI_COLS, 1, R.record_batch_fri),
              ("pv_prep", "pv_main", R.PUBLIC_VALUES_PREP_COLS, 1, 1, lambda lh, i: R.record_public_values(i))]
+    if args.wrap:
+        specs = [sp for sp in specs if sp[0] not in ("exp_prep", "poseidon2_prep", "batch_fri_prep")]
+        specs.insert(5, ("skinny_prep", "poseidon2_events", R.SKINNY_PREP_WIDTH, R.SKINNY_WIDTH, 1, lambda lh, i: R.record_poseidon2_skinny(lh, i, degree=9)))
+        specs.insert(6, ("batch_fri_prep", "batch_fri_main", R.BATCH_FRI_PREP_COLS, R.BATCH_FRI_COLS, 1, lambda lh, i: R.record_batch_fri(lh, i, degree=9)))
     recs, preps, mains = [], [], []
     for idx, (pk_key, ev_key, pw, mw, per_row, record) in enumerate(specs):
         n_rec = len(prog[pk_key]) // (pw // per_row)
@@ -50,7 +57,7 @@ def main():
         recs.append(record(lh, idx))
         preps.append(ctx.tracegen_flat(prog[pk_key], pw, lh))
         mains.append((ev_key, mw, lh))
-    fri = abi.FriConfig(3, 28, 16) if args.shrink else abi.FriConfig(2, 42, 16)
+    fri = abi.FriConfig(3, 28, 16) if args.shrink or args.wrap else abi.FriConfig(2, 42, 16)
     hp = prover.HipProver(recs, fri, synth.NUM_PV_ELTS, ctx=ctx, specialize=True)
     pk = hp.setup(preps, [int(r.local_only) for r in recs], F.to_monty(0), F.to_monty(np.zeros(14, dtype=np.uint64)))
     ch0 = prover.new_challenger()
@@ -67,6 +74,8 @@ def main():
         for (ev_key, mw, lh), r in zip(mains, recs):
             if r.name == "Poseidon2Wide":
                 born.append(ctx.tracegen_poseidon2_wide(prog[ev_key], lh))
+            elif r.name.startswith("Poseidon2Skinny"):
+                born.append(ctx.tracegen_poseidon2_skinny(prog[ev_key], lh))
             elif r.name == "ExpReverseBitsLen":
                 born.append(ctx.tracegen_exp_reverse_bits(prog["exp_bases"], prog["exp_bits"], prog["exp_offsets"], lh))
             elif ev_key is None:
@@ -85,7 +94,7 @@ def main():
     r = res[-1]
     cells = sum((1 << c.log_height) * (c.prep_width + c.main_width + 4 * c.perm_ext_width + (4 << c.log_quotient_degree)) for c in recs)
     print(json.dumps({"workload": f"REC-{args.log_hashes}: balanced recursion program, 2^{args.log_hashes} Poseidon2 permutations + ALU / select / memory "
-                                  f"instructions; {'shrink' if args.shrink else 'compress'} FRI configuration (blow-up {1 << fri.log_blowup}, {fri.num_queries} queries)",
+                                  f"instructions; {'wrap machine, ultra-compressed' if args.wrap else 'shrink' if args.shrink else 'compress'} FRI configuration (blow-up {1 << fri.log_blowup}, {fri.num_queries} queries)",
                       "program_generation_seconds_python": round(gen_s, 1),
                       "tracegen_ms": round(float(np.mean([x["tracegen_ms"] for x in res])), 3),
                       "prove_ms": round(float(np.mean([x["prove_ms"] for x in res])), 3), "committed_cells": cells, "proof_words": int(len(proof)),

@@ -1128,6 +1128,46 @@ __global__ void exp_reverse_bits_rows(const uint32_t* __restrict__ bases, const 
   }
 }
 
+// recursion Poseidon2Skinny chip (crates/recursion/core/src/chips/poseidon2_skinny/trace.rs:62-118): the same permutation laid out
+// as eleven rows of 28 columns (the state entering each step; on the internal-rounds row also lane 0 after each of the first twelve
+// internal rounds). One thread per permutation; rows past 11 * n_events are zero (the matrix is cleared first).
+constexpr int SKINNY_WIDTH = 28, SKINNY_ROWS = 11;
+__global__ __launch_bounds__(THREADS) void poseidon2_skinny_rows(const uint32_t* __restrict__ events, size_t n_events, size_t height,
+                                                                 uint32_t* __restrict__ out) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_events) return;
+  uint32_t s[16];
+#pragma unroll
+  for (int i = 0; i < 16; i++) s[i] = events[e * 32 + i];
+  const size_t row0 = e * SKINNY_ROWS;
+  auto put_state = [&](int row) {
+#pragma unroll
+    for (int i = 0; i < 16; i++) out[(size_t)i * height + row0 + row] = s[i];
+  };
+  put_state(0);
+  wide_external_layer(s);
+  for (int row = 1; row <= 10; row++) {
+    put_state(row);
+    if (row == 10) break;
+    if (row == 5) {
+      for (int r = 0; r < 13; r++) {
+        s[0] = wide_sbox(kb::add(s[0], p2::d_rc_int[r] + kb::P));
+        uint32_t sum = s[0];
+#pragma unroll
+        for (int i = 1; i < 16; i++) sum = kb::add(sum, s[i]);
+#pragma unroll
+        for (int i = 0; i < 16; i++) s[i] = kb::add(kb::mul(s[i], p2::d_diag[i]), sum);
+        if (r < 12) out[(size_t)(16 + r) * height + row0 + 5] = s[0];
+      }
+    } else {
+      const int rd = row < 5 ? row - 1 : row - 2;
+#pragma unroll
+      for (int i = 0; i < 16; i++) s[i] = wide_sbox(kb::add(s[i], p2::d_rc_ext[rd][i] + kb::P));
+      wide_external_layer(s);
+    }
+  }
+}
+
 // ByteChip::generate_trace: out = to_field(counts + extra); extra (may be null) holds the row-major plain counts of the
 // chips whose dependencies stay on the host
 __global__ void byte_mults_finish(const uint32_t* __restrict__ counts, const uint32_t* __restrict__ extra_row_major,

@@ -1912,6 +1912,39 @@ int zkm_tracegen_exp_reverse_bits(zkm_ctx* ctx, const uint32_t* bases, const uin
   API_END
 }
 
+int zkm_tracegen_poseidon2_skinny(zkm_ctx* ctx, const uint32_t* events, size_t n_events, int fixed_log2_rows, zkm_matrix** out) {
+  API_BEGIN
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIP_CHECK(hipSetDevice(ctx->device));
+  if (n_events && !events) throw std::runtime_error("zkm_tracegen_poseidon2_skinny: null events");
+  const size_t height = padded_trace_rows(n_events * tracegen::SKINNY_ROWS, fixed_log2_rows, "zkm_tracegen_poseidon2_skinny");
+  ctx->begin_timing();
+  zkm_matrix* m = new zkm_matrix();
+  m->h = height; m->w = tracegen::SKINNY_WIDTH;
+  uint32_t* d_events = nullptr;
+  try {
+    m->d = ctx->alloc_n<uint32_t>(height * m->w);
+    HIP_CHECK(hipMemsetAsync(m->d, 0, height * m->w * 4, ctx->stream));
+    d_events = (uint32_t*)ctx->alloc(std::max<size_t>(n_events * 128, 4));
+    if (n_events) {
+      HIP_CHECK(hipMemcpyAsync(d_events, events, n_events * 128, hipMemcpyHostToDevice, ctx->stream));
+      KLAUNCH(ctx, "tracegen_poseidon2_skinny", 128.0 * n_events + 4.0 * n_events * tracegen::SKINNY_ROWS * tracegen::SKINNY_WIDTH,
+              tracegen::poseidon2_skinny_rows, dim3(div_up(n_events, (size_t)tracegen::THREADS)), dim3(tracegen::THREADS), 0,
+              (const uint32_t*)d_events, n_events, height, m->d);
+    }
+    ctx->mark("trace generation");
+    ctx->end_timing(false);
+  } catch (...) {
+    if (d_events) ctx->release(d_events);
+    if (m->d) ctx->release(m->d);
+    delete m;
+    throw;
+  }
+  ctx->release(d_events);
+  *out = m;
+  API_END
+}
+
 int zkm_tracegen_byte_table(zkm_ctx* ctx, zkm_matrix** out) {
   API_BEGIN
   std::lock_guard<std::mutex> lk(ctx->mu);

@@ -203,6 +203,14 @@ class Context:
                                                       C.c_int(fixed_log2_rows), blu.h if blu is not None else None, C.byref(h)))
         return self._born(h)
 
+    def tracegen_poseidon2_skinny(self, events: np.ndarray, fixed_log2_rows: int = -1) -> DeviceMatrix:
+        """`generate_trace` of the recursion Poseidon2Skinny chip on the device (zkm_tracegen_poseidon2_skinny)."""
+        ev = np.ascontiguousarray(events, dtype=np.uint32).reshape(-1, 32)
+        h = C.c_void_p()
+        lib.check(lib.load().zkm_tracegen_poseidon2_skinny(self.h, abi.as_u32p(ev) if len(ev) else None, C.c_size_t(len(ev)),
+                                                           C.c_int(fixed_log2_rows), C.byref(h)))
+        return self._born(h)
+
     def tracegen_exp_reverse_bits(self, bases: np.ndarray, bits: np.ndarray, offsets: np.ndarray, fixed_log2_rows: int = -1) -> DeviceMatrix:
         """`generate_trace` of the recursion ExpReverseBitsLen chip on the device (zkm_tracegen_exp_reverse_bits)."""
         bases, bits = np.ascontiguousarray(bases, dtype=np.uint32), np.ascontiguousarray(bits, dtype=np.uint32)

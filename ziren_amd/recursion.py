@@ -293,13 +293,13 @@ def record_exp_reverse_bits(log_height: int = 10, prep_index: int = 0, constrain
     return r if constraints_only else _finish_rec(r, "ExpReverseBitsLen", log_height, EXP_REVERSE_BITS_COLS, prep_index, local_only=False)
 
 
-def record_batch_fri(log_height: int = 10, prep_index: int = 0, constraints_only: bool = False):
+def record_batch_fri(log_height: int = 10, prep_index: int = 0, constraints_only: bool = False, degree: int = 3):
     """BatchFRIChip<3>::eval (chips/batch_fri.rs:289-350): acc = sum over an instruction's rows of alpha_pow * (p_at_z - p_at_x) in the
     extension; prep = is_real, is_end, acc / alpha_pow / p_at_z / p_at_x addresses; main = acc(4), alpha_pow(4), p_at_z(4), p_at_x."""
     r = _RecRec(BATCH_FRI_COLS, BATCH_FRI_PREP_COLS)
     l, n, p, b = r.local, r.next, r.prep, r.b
     is_real, is_end = p[0], p[1]
-    b.assert_eq(is_real * is_real * is_real, is_real * is_real * is_real)
+    b.assert_eq(_pow_expr(is_real, degree), _pow_expr(is_real, degree))
     r.receive_block(p[3], l[4:8], is_real)
     r.receive_block(p[4], l[8:12], is_real)
     r.receive_single(p[5], l[12], is_real)
@@ -315,7 +315,68 @@ def record_batch_fri(log_height: int = 10, prep_index: int = 0, constraints_only
         b.when_transition().when(is_end).assert_eq(n[i], tn[i])
     for i in range(4):
         b.when_transition().when_not(is_end).assert_eq(n[i], l[i] + tn[i])
-    return r if constraints_only else _finish_rec(r, "BatchFRI", log_height, BATCH_FRI_COLS, prep_index, local_only=False)
+    lqd = max(1, (degree - 2).bit_length())
+    return r if constraints_only else _finish_rec(r, "BatchFRI", log_height, BATCH_FRI_COLS, prep_index, lqd=lqd, local_only=False)
+
+
+SKINNY_WIDTH, SKINNY_PREP_WIDTH, SKINNY_ROWS = 28, 51, 11    # state_var[16] + internal_rounds_s0[12]; 16 x (addr, mult) + 3 flags + 16 constants
+
+
+def _pow_expr(x, n):
+    out = x
+    for _ in range(n - 1):
+        out = out * x
+    return out
+
+
+def record_poseidon2_skinny(log_height: int = 10, prep_index: int = 0, degree: int = 9, constraints_only: bool = False):
+    """Poseidon2SkinnyChip<DEGREE>::eval (chips/poseidon2_skinny/air.rs:23-160), the hash chip of the wrap machine: eleven rows per
+    permutation (input, four external rounds, one row holding all thirteen internal rounds, four external rounds, output), the state
+    in 16 columns plus lane 0 after each internal round; round type and constants are preprocessed. Nothing but the state is
+    witnessed, so the constraints reach degree 5 (external) and the chip's quotient degree follows the machine's DEGREE (the dummy
+    constraint x^DEGREE = x^DEGREE): 9 -> eight quotient chunks."""
+    _, diag = _poseidon2_constants()
+    r = _RecRec(SKINNY_WIDTH, SKINNY_PREP_WIDTH)
+    l, n, p, b = r.local, r.next, r.prep, r.b
+    state, s0, nxt = l[0:16], l[16:28], n[0:16]
+    is_input, is_external, is_internal, rc = p[32], p[33], p[34], p[35:51]
+    b.assert_eq(_pow_expr(state[0], degree), _pow_expr(state[0], degree))
+    for i in range(16):
+        r.send_single(p[2 * i], state[i], p[2 * i + 1])
+    lin = _external_layer(list(state))
+    for i in range(16):
+        b.when_transition().when(is_input).assert_eq(nxt[i], lin[i])
+    ext = _external_layer([_pow_expr(state[i] + rc[i], 3) for i in range(16)])
+    for i in range(16):
+        b.when_transition().when(is_external).assert_eq(nxt[i], ext[i])
+    st = list(state)
+    for rd in range(13):
+        add_rc = (st[0] if rd == 0 else s0[rd - 1]) + rc[rd]
+        st[0] = _pow_expr(add_rc, 3)
+        st = _internal_layer(st, diag)
+        if rd < 12:
+            b.when(is_internal).assert_eq(s0[rd], st[0])
+    for i in range(16):
+        b.when(is_internal).assert_eq(nxt[i], st[i])
+    lqd = max(1, (degree - 2).bit_length())     # log2_ceil(degree - 1)
+    return r if constraints_only else _finish_rec(r, f"Poseidon2SkinnyDeg{degree}", log_height, SKINNY_WIDTH, prep_index, lqd=lqd, local_only=False)
+
+
+def poseidon2_skinny_prep(instrs) -> np.ndarray:
+    """generate_preprocessed_trace (chips/poseidon2_skinny/trace.rs:177-243): instrs = [(input addrs[16], output addrs[16], output
+    mults[16])]; eleven rows of 51 canonical words each."""
+    rc, _ = _poseidon2_constants()
+    rows = np.zeros((len(instrs) * SKINNY_ROWS, SKINNY_PREP_WIDTH), dtype=np.uint64)
+    for k, (ins, outs, mults) in enumerate(instrs):
+        blk = rows[k * SKINNY_ROWS:(k + 1) * SKINNY_ROWS]
+        blk[0, 32], blk[5, 34] = 1, 1
+        for i in (1, 2, 3, 4, 6, 7, 8, 9):
+            blk[i, 33] = 1
+            blk[i, 35:51] = rc[i - 1 if i < 5 else i - 1 + 12]
+        blk[5, 35:51] = [rc[4 + j][0] for j in range(16)]
+        blk[0, 0:32:2], blk[0, 1:32:2] = ins, F.P - 1
+        blk[10, 0:32:2], blk[10, 1:32:2] = outs, mults
+    return rows
 
 
 def record_public_values(prep_index: int = 0, constraints_only: bool = False):
@@ -532,6 +593,7 @@ def balanced_program(n_base: int, n_ext: int, n_const: int = 64, seed: int = 1, 
             "exp_bits": arr([entries[row[2]]["val"][0] for _, rows_here in exp_prep for row in rows_here], 1),
             "exp_offsets": np.cumsum([0] + [len(rows_here) for _, rows_here in exp_prep]).astype(np.uint32),
             "n_exp_rows": len(exp_prep_rows), "n_batch_fri_rows": len(fri_prep)}
+    more["poseidon2_instrs"] = [(list(ins), list(outs), [entries[a]["reads"] for a in outs]) for ins, outs in poseidon_rows]
     extra = {**more, "poseidon2_prep": F.to_monty(pos_prep).reshape(-1), "poseidon2_events": F.to_monty(pos_events).reshape(-1),
              "n_poseidon2": len(poseidon_rows), "var_prep": F.to_monty(var_prep).reshape(-1), "var_values": F.to_monty(var_values).reshape(-1),
              "select_prep": F.to_monty(sel_prep).reshape(-1), "select_events": F.to_monty(sel_events).reshape(-1),
