@@ -34,11 +34,11 @@ def test_row_counts():
 
 
 def balanced_shard(n_base, n_ext, n_const, seed, heights=(-1, -1, -1), n_var=0, n_select=0, n_poseidon2=0, oracle=None, n_exp=0,
-                   n_batch_fri=0, commit_public_values=False, wrap=False):
+                   n_batch_fri=0, commit_public_values=False, wrap=False, n_fri_fold=0):
     """BaseAlu + ExtAlu + MemoryConst (+ MemoryVar + Select) over one consistent program: (chips with host traces, flat
     record streams (preprocessed words, main words))."""
     prog = R.balanced_program(n_base, n_ext, n_const, seed, n_var=n_var, n_select=n_select, n_poseidon2=n_poseidon2, n_exp=n_exp,
-                              n_batch_fri=n_batch_fri, commit_public_values=commit_public_values)
+                              n_batch_fri=n_batch_fri, commit_public_values=commit_public_values, n_fri_fold=n_fri_fold)
     specs = (("base_instrs", "base_events", R.BASE_VALUE_COLS, False), ("ext_instrs", "ext_events", R.EXT_VALUE_COLS, True))
     recs, streams = [], []
     for idx, (ik, ek, vw, ext) in enumerate(specs):
@@ -90,6 +90,12 @@ def balanced_shard(n_base, n_ext, n_const, seed, heights=(-1, -1, -1), n_var=0, 
         rc.trace, rc.prep_trace = R.flat_trace(prog["batch_fri_main"], R.BATCH_FRI_COLS, rc.log_height, 1), prep
         recs.append(rc)
         streams.append((prog["batch_fri_prep"], prog["batch_fri_main"]))
+    if n_fri_fold:
+        prep = R.flat_trace(prog["fri_fold_prep"], R.FRI_FOLD_PREP_COLS, -1, 1)
+        rc = R.record_fri_fold(prep.shape[0].bit_length() - 1, prep_index=9)
+        rc.trace, rc.prep_trace = R.flat_trace(prog["fri_fold_main"], R.FRI_FOLD_COLS, rc.log_height, 1), prep
+        recs.append(rc)
+        streams.append((prog["fri_fold_prep"], prog["fri_fold_main"]))
     if commit_public_values:
         rc = R.record_public_values(prep_index=8)
         rc.prep_trace = R.flat_trace(prog["pv_prep"], R.PUBLIC_VALUES_PREP_COLS, R.PUBLIC_VALUES_LOG_HEIGHT, 1)
@@ -113,6 +119,44 @@ def compress_machine_shard(oracle, scale=1, seed=31):
                                    oracle=oracle, n_exp=25 * scale, n_batch_fri=30 * scale, commit_public_values=True)
     digest = streams.pop()
     return recs, streams, digest
+
+
+def all_chips_shard(oracle, scale=1, seed=35):
+    """`machine_wide_with_all_chips` (machine.rs:68-87): the compress machine's nine chips plus FriFold."""
+    recs, streams = balanced_shard(300 * scale, 250 * scale, 40, seed=seed, n_var=100 * scale, n_select=80 * scale, n_poseidon2=20 * scale,
+                                   oracle=oracle, n_exp=20 * scale, n_batch_fri=25 * scale, commit_public_values=True, n_fri_fold=30 * scale)
+    digest = streams.pop()
+    for i, r in enumerate(recs):
+        r.prep_index = i
+    return recs, streams, digest
+
+
+def test_fri_fold_and_all_chips_machine(oracle):
+    """FriFold (in the reference only part of its all-chips test machines): constraints across the rows of an instruction, corrupted
+    cells caught, and the ten-chip machine's lookups cancel; the oracle's proof verifies."""
+    from ziren_amd import synth
+    recs, streams, digest = all_chips_shard(oracle)
+    assert [r.name for r in recs] == ["BaseAlu", "ExtAlu", "MemoryConst", "MemoryVar", "Select", "Poseidon2Wide", "ExpReverseBitsLen", "BatchFRI",
+                                      "FriFold", "PublicValues"]
+    ff = recs[8]
+    rec = R.record_fri_fold(constraints_only=True)
+    main, prep = F.from_monty(ff.trace), F.from_monty(ff.prep_trace)
+    assert air.debug_constraints(rec.b, main, prep=prep) == [] and len(rec.sends) == 9
+    multi = int(np.nonzero(prep[1:, 0] == 0)[0][0]) + 1       # a row that continues an instruction
+    for row, col, hit in ((multi, 8, {multi - 1, multi}), (multi, 2, {multi - 1, multi}), (0, 27, {0}), (0, 30, {0}), (0, 10, {0})):
+        bad = main.copy()
+        bad[row, col] = (int(bad[row, col]) + 1) % F.P
+        got = {x for _, x in air.debug_constraints(rec.b, bad, prep=prep)}
+        assert got and got <= hit | {row + 1}, (row, col, got)
+    t = tally_of(recs)
+    assert t and not any(t.values())
+    fri = abi.FriConfig(2, 42, 16)
+    igcs = F.to_monty(np.zeros(14, dtype=np.uint64))
+    opk = oracle.Pk([r.prep_trace for r in recs], [int(r.local_only) for r in recs], F.to_monty(0), igcs, 2)
+    start = oracle.new_challenger()
+    opk.observe_into(start)
+    proof, _ = oracle.prove_shard(opk, recs, [c.trace for c in recs], recursion_public_values(digest), fri, synth.NUM_PV_ELTS, start.copy())
+    assert oracle.verify_shard(opk, recs, fri, synth.NUM_PV_ELTS, start.copy(), proof) == 0
 
 
 def wrap_machine_shard(oracle, scale=1, seed=33):
@@ -342,7 +386,7 @@ def test_gpu_recursion_alu_shard(hip_ctx, oracle, log_blowup, queries):
     memory lookups balancing between the real chips, proof bit-identical to the oracle's and accepted by the
     restated verifier."""
     from ziren_amd import prover, synth
-    recs, streams, digest = compress_machine_shard(oracle, scale=8, seed=40)
+    recs, streams, digest = all_chips_shard(oracle, scale=8, seed=40)      # the compress machine's nine chips + FriFold
     fri = abi.FriConfig(log_blowup, queries, 16)
     pv = recursion_public_values(digest)
     igcs = F.to_monty(np.zeros(14, dtype=np.uint64))

@@ -319,6 +319,66 @@ def record_batch_fri(log_height: int = 10, prep_index: int = 0, constraints_only
     return r if constraints_only else _finish_rec(r, "BatchFRI", log_height, BATCH_FRI_COLS, prep_index, lqd=lqd, local_only=False)
 
 
+FRI_FOLD_COLS, FRI_FOLD_PREP_COLS = 33, 20
+
+
+def record_fri_fold(log_height: int = 10, prep_index: int = 0, degree: int = 3, constraints_only: bool = False):
+    """FriFoldChip<DEGREE>::eval (chips/fri_fold.rs:362-463; part of the reference's all-chips test machines only): per row
+    alpha_pow' = alpha_pow * alpha and (ro' - ro) * (x - z) = (p(x) - p(z)) * alpha_pow over the extension; x, z, alpha are shared by the
+    rows of one instruction. prep = is_first, nine (addr, mult) pairs [z, alpha, x, alpha_pow_in, ro_in, p_at_x, p_at_z, ro_out,
+    alpha_pow_out], is_real; main = z(4), alpha(4), x, p_at_x(4), p_at_z(4), alpha_pow_in(4), ro_in(4), alpha_pow_out(4), ro_out(4)."""
+    r = _RecRec(FRI_FOLD_COLS, FRI_FOLD_PREP_COLS)
+    l, n, p, b = r.local, r.next, r.prep, r.b
+    pn = b.preprocessed()[1]
+    z, alpha, x, p_at_x, p_at_z, ap_in, ro_in, ap_out, ro_out = l[0:4], l[4:8], l[8], l[9:13], l[13:17], l[17:21], l[21:25], l[25:29], l[29:33]
+    mem = lambda k: (p[1 + 2 * k], p[2 + 2 * k])   # noqa: E731
+    b.assert_eq(_pow_expr(p[19], degree), _pow_expr(p[19], degree))
+    cont = lambda: b.when_transition().when(pn[19]).when_not(pn[0])   # noqa: E731  (the next row continues this instruction)
+    r.send_single(mem(2)[0], x, mem(2)[1])
+    cont().assert_eq(x, n[8])
+    r.send_block(mem(0)[0], z, mem(0)[1])
+    for i in range(4):
+        cont().assert_eq(z[i], n[i])
+    r.send_block(mem(1)[0], alpha, mem(1)[1])
+    for i in range(4):
+        cont().assert_eq(alpha[i], n[4 + i])
+    r.send_block(mem(3)[0], ap_in, mem(3)[1])
+    r.send_block(mem(4)[0], ro_in, mem(4)[1])
+    r.send_block(mem(6)[0], p_at_z, mem(6)[1])
+    r.send_block(mem(5)[0], p_at_x, mem(5)[1])
+    r.send_block(mem(8)[0], ap_out, mem(8)[1])
+    r.send_block(mem(7)[0], ro_out, mem(7)[1])
+    for got, want in zip(_ext_mul_expr(b, ap_in, alpha), ap_out):
+        b.assert_eq(got, want)
+    lhs = _ext_mul_expr(b, [ro_out[i] - ro_in[i] for i in range(4)], [x - z[0], 0 - z[1], 0 - z[2], 0 - z[3]])
+    rhs = _ext_mul_expr(b, [p_at_x[i] - p_at_z[i] for i in range(4)], ap_in)
+    for a_, b_ in zip(lhs, rhs):
+        b.assert_eq(a_, b_)
+    lqd = max(1, (degree - 2).bit_length())
+    return r if constraints_only else _finish_rec(r, "FriFold", log_height, FRI_FOLD_COLS, prep_index, lqd=lqd, local_only=False)
+
+
+def _ext_inv(a):
+    """Inverse in F[X]/(X^4 - 3) by solving the 4 x 4 system of multiplication by `a` (a handful of elements: speed is irrelevant)."""
+    P = F.P
+    m = [[0] * 5 for _ in range(4)]
+    for j in range(4):          # column j: a * X^j
+        for i in range(4):
+            k, coef = (i + j) % 4, (W if i + j >= 4 else 1)
+            m[k][j] = (m[k][j] + a[i] * coef) % P
+    m[0][4] = 1
+    for c in range(4):
+        piv = next(r_ for r_ in range(c, 4) if m[r_][c])
+        m[c], m[piv] = m[piv], m[c]
+        inv = pow(m[c][c], P - 2, P)
+        m[c] = [v * inv % P for v in m[c]]
+        for r_ in range(4):
+            if r_ != c and m[r_][c]:
+                f = m[r_][c]
+                m[r_] = [(v - f * w) % P for v, w in zip(m[r_], m[c])]
+    return [m[i][4] for i in range(4)]
+
+
 SKINNY_WIDTH, SKINNY_PREP_WIDTH, SKINNY_ROWS = 28, 51, 11    # state_var[16] + internal_rounds_s0[12]; 16 x (addr, mult) + 3 flags + 16 constants
 
 
@@ -391,7 +451,7 @@ def record_public_values(prep_index: int = 0, constraints_only: bool = False):
 
 
 def balanced_program(n_base: int, n_ext: int, n_const: int = 64, seed: int = 1, n_var: int = 0, n_select: int = 0, n_poseidon2: int = 0,
-                     permute_batch=None, n_exp: int = 0, n_batch_fri: int = 0, commit_public_values: bool = False):
+                     permute_batch=None, n_exp: int = 0, n_batch_fri: int = 0, commit_public_values: bool = False, n_fri_fold: int = 0):
     """A synthetic recursion program whose memory lookups balance exactly, as a real one's do: constants are written by
     MemoryConst entries, every ALU instruction reads two earlier values (constants or earlier results of its own field)
     and writes one, and each write's multiplicity is the number of later reads; a few results are read back by
@@ -507,6 +567,33 @@ def balanced_program(n_base: int, n_ext: int, n_const: int = 64, seed: int = 1, 
             rows_here.append([1, int(i == k - 1), aacc, aal, apz, apx])
         entries[aacc] = {"val": acc, "reads": 1, "kind": "fri_acc"}   # written with multiplicity 1 (acc_mult, batch_fri.rs:103): read exactly once
         fri_prep += rows_here
+    # FriFold: rows of one instruction share x, z, alpha; per row alpha_pow' = alpha_pow * alpha, ro' = ro + (p(x) - p(z)) * alpha_pow / (x - z)
+    ff_prep, ff_main, ff_outs = [], [], []
+    for _ in range(n_fri_fold):
+        k = int(rng.integers(1, 6))
+        az, aal = (pools["ext"][int(rng.integers(0, len(pools["ext"])))] for _ in range(2))
+        ax = pools["base"][int(rng.integers(0, len(pools["base"])))]
+        for a in (az, aal, ax):
+            entries[a]["reads"] += 1
+        zv, alv, xv = entries[az]["val"], entries[aal]["val"], entries[ax]["val"][0]
+        inv_xz = _ext_inv([(xv - zv[0]) % P, (-zv[1]) % P, (-zv[2]) % P, (-zv[3]) % P])
+        for i in range(k):
+            aap, aro, apx, apz = (pools["ext"][int(rng.integers(0, len(pools["ext"])))] for _ in range(4))
+            for a in (aap, aro, apx, apz):
+                entries[a]["reads"] += 1
+            ap, ro, px, pz = (entries[a]["val"] for a in (aap, aro, apx, apz))
+            ap_out = ext_mul(ap, alv)
+            ro_out = [(ro[e] + t) % P for e, t in enumerate(ext_mul(ext_mul([(px[e] - pz[e]) % P for e in range(4)], ap), inv_xz))]
+            aapo, aroo = new_addr(), new_addr()
+            entries[aapo] = {"val": ap_out, "reads": 0, "kind": "ext"}
+            entries[aroo] = {"val": ro_out, "reads": 0, "kind": "ext"}
+            ff_outs.append((aapo, aroo))
+            ff_main.append(zv + alv + [xv] + px + pz + ap + ro + ap_out + ro_out)
+            first = int(i == 0)
+            ff_prep.append([first, az, (P - first) % P, aal, (P - first) % P, ax, (P - first) % P, aap, P - 1, aro, P - 1, apx, P - 1, apz, P - 1,
+                            aroo, None, aapo, None, 1])
+        for aapo, aroo in ff_outs[-k:]:
+            pools["ext"] += [aapo, aroo]
     base_rows, ext_rows = [], []   # (opcode, addr_out, addr_in1, addr_in2, out, in1, in2)
     for which, n, rows in (("base", n_base, base_rows), ("ext", n_ext, ext_rows)):
         for _ in range(n):
@@ -584,9 +671,12 @@ def balanced_program(n_base: int, n_ext: int, n_const: int = 64, seed: int = 1, 
         rows_here[-1][5] = entries[ares]["reads"]
         for row in rows_here[:-1]:
             row[5] = 0
+    for row, (aapo, aroo) in zip(ff_prep, ff_outs):
+        row[16], row[18] = entries[aroo]["reads"], entries[aapo]["reads"]
     exp_prep_rows = [row for _, rows_here in exp_prep for row in rows_here]
     arr = lambda rows, w: F.to_monty(np.array(rows, dtype=np.uint64).reshape(-1, w)).reshape(-1)   # noqa: E731
-    more = {"exp_prep": arr(exp_prep_rows, EXP_REVERSE_BITS_PREP_COLS), "exp_main": arr(exp_main, EXP_REVERSE_BITS_COLS),
+    more = {"fri_fold_prep": arr(ff_prep, FRI_FOLD_PREP_COLS), "fri_fold_main": arr(ff_main, FRI_FOLD_COLS), "n_fri_fold_rows": len(ff_prep),
+            "exp_prep": arr(exp_prep_rows, EXP_REVERSE_BITS_PREP_COLS), "exp_main": arr(exp_main, EXP_REVERSE_BITS_COLS),
             "batch_fri_prep": arr(fri_prep, BATCH_FRI_PREP_COLS), "batch_fri_main": arr(fri_main, BATCH_FRI_COLS),
             "pv_prep": arr(pv_prep, PUBLIC_VALUES_PREP_COLS), "pv_main": arr(pv_main, 1), "pv_digest": pv_digest,
             "exp_bases": arr([entries[rows_here[0][0]]["val"][0] for _, rows_here in exp_prep], 1),
