@@ -25,13 +25,17 @@ def env_rank_world():
 def _stdout_to_stderr():
     """RCCL prints a version banner on stdout when the first communicator is created; bench.py's stdout
     must carry exactly one JSON line, so native-level stdout is pointed at stderr meanwhile."""
+    import ctypes
+    libc = ctypes.CDLL(None)
     sys.stdout.flush()
+    libc.fflush(None)
     saved = os.dup(1)
     try:
         os.dup2(2, 1)
         yield
     finally:
         sys.stdout.flush()
+        libc.fflush(None)   # the banner sits in the C library's stdout buffer: push it out while fd 1 still points at stderr
         os.dup2(saved, 1)
         os.close(saved)
 
@@ -114,5 +118,6 @@ class Farm:
 
     def close(self):
         if self.dist is not None:
-            self.dist.destroy_process_group()
+            with _stdout_to_stderr():   # anything RCCL prints while tearing down stays off stdout as well
+                self.dist.destroy_process_group()
             self.dist = None
