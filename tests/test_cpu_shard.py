@@ -187,6 +187,37 @@ def test_misc_instrs_constraints_hold(oracle):
     assert len(sr) == n[E.EXT] + 4 * n[E.INS] and len(add) == n[E.INS]
 
 
+def test_cpu_row_by_hand(oracle):
+    """The event of the reference's test_generate_cpu_trace_ffi_eq_rust (cpu/trace.rs:283-311; a trace-only test: its records are
+    not a coherent execution) with the program [ADD $29, $0, 1]: every column follows cpu/trace.rs:117-257 by hand."""
+    prog = np.zeros(1, dtype=M.INSTRUCTION)
+    prog[0] = (E.ADD, 29, [0, 0], 0, 1, 0, 1, [0, 0], 1, [0, 0, 0], 0)
+    ev = np.zeros(1, dtype=M.CPU_EVENT)
+    e = ev[0]
+    e["clk"], e["pc"], e["next_pc"], e["next_next_pc"], e["a"], e["b"], e["c"] = 0, 0, 1, 2, 5, 10, 15
+    e["a_record"]["tag"], e["a_record"]["write"] = M.TAG_WRITE, (5, 1, 2, 1, 1, 1)
+    e["b_record"]["tag"], e["b_record"]["read"] = M.TAG_READ, (5, 0, 1, 0, 0)
+    e["c_record"]["tag"], e["c_record"]["read"] = M.TAG_READ, (5, 0, 2, 0, 0)
+    e["hi"]["tag"], e["hi"]["value"] = 0, 1
+    e["hi_record"]["tag"] = M.TAG_NONE
+    e["memory_record"]["tag"], e["memory_record"]["read"] = M.TAG_READ, (5, 0, 3, 0, 0)
+    counts = np.zeros((1 << 16, 10), dtype=np.uint32)
+    r = F.from_monty(oracle.tracegen_cpu(ev, prog, 0, 0, -1, counts))
+    assert r.shape == (16, 67)
+    row = r[0].tolist()
+    assert row[0:8] == [0, 0, 0, 0, 0, 0, 1, 2]                                  # shard, clk limbs, shard/clk to send, pc, next_pc, next_next_pc
+    assert row[8:21] == [E.ADD, 29, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 1]             # opcode, op_a, op_b, op_c, op_a_0, imm_b, imm_c
+    assert row[21:26] == [0, 0, 0, 0, 1]                                         # no extra cycles, not rw_a / check_memory / halt; sequential
+    assert row[26:34] == [5, 0, 0, 0, 1, 0, 0, 0]                                # op_a_value, hi_or_prev_a = hi
+    assert row[34:47] == [1, 0, 0, 0, 5, 0, 0, 0, 1, 1, 1, 0, 0]                 # a: prev_value, value, prev (shard 1, clk 1), same shard, 2 - 1 - 1 = 0
+    assert row[47:56] == [5, 0, 0, 0, 0, 0, 1, 0, 0]                             # b (the record's value, not event.b): prev (0, 0), 1 - 0 - 1 = 0
+    assert row[56:65] == [5, 0, 0, 0, 0, 0, 1, 1, 0]                             # c: 2 - 0 - 1 = 1
+    assert row[65:67] == [1, 0]
+    assert (r[1:, 19] == 1).all() and (r[1:, 20] == 1).all() and (r[1:, 22] == 1).all() and not r[1:, 65].any()    # padding rows
+    # lookups: shard and clk limbs (three), three accesses (two each), the two byte pairs of `a`
+    assert counts.sum() == 11 and counts[0, 8] == 4 and counts[1, 8] == 1 and counts[0, 4] == 5 and counts[5 << 8, 4] == 1
+
+
 def test_cpu_constraints_hold(oracle):
     rec = chips.record_cpu_constraints()
     for n, seed in ((1, 1), (16, 2), (17, 3), (2500, 4)):
