@@ -424,6 +424,17 @@ size_t zkm_tracegen_mov_cond_width(void);
 int zkm_tracegen_mov_cond(zkm_ctx* ctx, const zkm_mov_cond_event* events, size_t n_events, int fixed_log2_rows,
                           zkm_matrix** out);
 
+/* GlobalChip::generate_trace + generate_dependencies (crates/core/machine/src/global/mod.rs:75-197): GlobalLookupEvents (the
+ * #[repr(C)] record of crates/core/executor/src/events/global.rs:6-15) -> the 99-column trace: each message lifted to a point of
+ * the septic curve (operations/global_lookup.rs:26-92), the running sum of the points from the start digest by a parallel scan
+ * (operations/global_accumulation.rs:75-113); the U16Range lookup of message[0] per event is counted into `blu`. The matrix's last
+ * row ends with the shard's global_cumulative_sum (commit_scope_global in zkm_chip_desc). Errors: message[0] >= 2^16; a running sum
+ * that meets the point at infinity or a message's own x-coordinate (the AIR cannot express those rows either). */
+typedef struct { uint32_t message[7]; uint8_t is_receive; uint8_t kind; uint8_t pad[2]; } zkm_global_lookup_event;
+#define ZKM_GLOBAL_WIDTH 99
+int zkm_tracegen_global(zkm_ctx* ctx, const zkm_global_lookup_event* events, size_t n_events, int fixed_log2_rows, zkm_byte_lookups* blu,
+                        zkm_matrix** out);
+
 /* ByteChip::trace() — the Byte chip's preprocessed table, 65536 x 12, row (b << 8 | c)
  * (crates/core/machine/src/bytes/mod.rs:31-104, columns bytes/columns.rs:12-46), generated on the device. */
 int zkm_tracegen_byte_table(zkm_ctx* ctx, zkm_matrix** out);

@@ -504,6 +504,18 @@ int orc_tracegen_memory_instrs(const void* events, size_t n_events, int fixed_lo
   ORC_CATCH
 }
 
+// Global chip (GlobalLookupEvent, 32 bytes): 99 columns; byte_counts as for orc_tracegen_branch
+int orc_tracegen_global(const void* events, size_t n_events, int fixed_log2_rows, uint32_t* out, size_t out_cap, uint32_t* byte_counts) {
+  ORC_TRY
+  size_t h;
+  std::vector<uint64_t> cnt(byte_counts ? tracegen::BYTE_ROWS * tracegen::NUM_BYTE_OPS : 0, 0);
+  std::vector<F> t = tracegen::generate_global((const tracegen::GlobalLookupEvent*)events, n_events, fixed_log2_rows, &h, byte_counts ? cnt.data() : nullptr);
+  if (t.size() > out_cap) throw std::runtime_error("trace buffer too small");
+  for (size_t i = 0; i < t.size(); i++) out[i] = to_monty(t[i]);
+  for (size_t i = 0; i < cnt.size(); i++) byte_counts[i] += (uint32_t)cnt[i];
+  ORC_CATCH
+}
+
 // recursion Poseidon2Wide chip (degree 3): events = n x 32 Montgomery words (input[16], output[16]); 313 columns
 int orc_tracegen_poseidon2_wide(const uint32_t* events, size_t n_events, int fixed_log2_rows, uint32_t* out, size_t out_cap) {
   ORC_TRY

@@ -29,6 +29,7 @@
 #include "field.hpp"
 
 #include "poseidon2.hpp"
+#include "septic.hpp"
 namespace tracegen {
 using namespace orc;
 
@@ -1176,6 +1177,66 @@ static inline std::vector<F> generate_poseidon2_skinny(const F* events, size_t n
     poseidon2_skinny_rows(events + 32 * e, r);
     for (int k = 0; k < 16; k++)
       if (r[10 * SKINNY_WIDTH + k] != events[32 * e + 16 + k]) throw std::runtime_error("tracegen: Poseidon2 event output is not the permutation of its input");
+  }
+  *height = h;
+  return t;
+}
+
+// ---- Global chip (crates/core/machine/src/global/mod.rs): GlobalLookupEvents (crates/core/executor/src/events/global.rs:6-15,
+// #[repr(C)]: message[7], is_receive, kind); columns :54-64 (message[7], kind, GlobalLookupOperation {offset_bits[8], x[7], y[7],
+// y6_bit_decomp[30], range_check_witness}, is_receive, is_send, is_real, GlobalAccumulationOperation<1> {initial_digest[14],
+// sum_checker[7], cumulative_sum[14]}); rows :120-197, operations/global_lookup.rs:26-92, operations/global_accumulation.rs:75-113.
+// The running sum is a plain left-to-right loop (the reference scans in parallel with the complete addition law; two equal x
+// in a row, probability ~2^-217, throw here). Byte lookups: U16Range(message[0]) per event (:75-95).
+struct GlobalLookupEvent { uint32_t message[7]; uint8_t is_receive, kind, pad[2]; };
+static_assert(sizeof(GlobalLookupEvent) == 32, "GlobalLookupEvent is eight words");
+static const size_t GLOBAL_WIDTH = 99;
+static inline std::vector<F> generate_global(const GlobalLookupEvent* events, size_t n_events, int fixed_log2_rows, size_t* height,
+                                             uint64_t* byte_counts) {
+  enum { MESSAGE = 0, KIND = 7, OFFSET_BITS = 8, X = 16, Y = 23, Y6_BITS = 30, RC_WITNESS = 60, IS_RECEIVE = 61, IS_SEND = 62, IS_REAL = 63,
+         INITIAL = 64, SUM_CHECKER = 78, CUMULATIVE = 85 };
+  const size_t h = padded_rows(n_events, fixed_log2_rows);
+  std::vector<F> t(h * GLOBAL_WIDTH, 0);
+  septic::Point sum, dummy;
+  for (int k = 0; k < 7; k++) {
+    sum.x.c[k] = SEPTIC_START_X[k]; sum.y.c[k] = SEPTIC_START_Y[k];
+    dummy.x.c[k] = septic::DUMMY_X[k]; dummy.y.c[k] = septic::DUMMY_Y[k];
+  }
+  for (size_t i = 0; i < n_events; i++) {
+    const GlobalLookupEvent& e = events[i];
+    F* r = t.data() + i * GLOBAL_WIDTH;
+    if (e.message[0] >> 16) throw std::runtime_error("global lookup: message[0] is not a u16");
+    septic::S7 m;
+    for (int k = 0; k < 7; k++) { r[MESSAGE + k] = fu32(e.message[k]); m.c[k] = r[MESSAGE + k]; }
+    m.c[0] = fadd(m.c[0], (F)e.kind << 16);
+    r[KIND] = e.kind;
+    uint8_t offset;
+    septic::Point pt = septic::lift_x(m, &offset);
+    if (!e.is_receive) pt.y = septic::s_neg(pt.y);
+    for (int k = 0; k < 8; k++) r[OFFSET_BITS + k] = (offset >> k) & 1;
+    for (int k = 0; k < 7; k++) { r[X + k] = pt.x.c[k]; r[Y + k] = pt.y.c[k]; }
+    const uint32_t rc = e.is_receive ? pt.y.c[6] - 1 : pt.y.c[6] - (P + 1) / 2;
+    F top = 0;
+    for (int k = 0; k < 30; k++) { r[Y6_BITS + k] = (rc >> k) & 1; if (k >= 23) top = fadd(top, r[Y6_BITS + k]); }
+    r[RC_WITNESS] = finv(fsub(top, 7));
+    r[IS_RECEIVE] = e.is_receive ? 1 : 0; r[IS_SEND] = e.is_receive ? 0 : 1; r[IS_REAL] = 1;
+    septic::Point next = septic::add_incomplete(sum, pt);
+    for (int k = 0; k < 7; k++) {
+      r[INITIAL + k] = sum.x.c[k]; r[INITIAL + 7 + k] = sum.y.c[k];
+      r[CUMULATIVE + k] = next.x.c[k]; r[CUMULATIVE + 7 + k] = next.y.c[k];
+    }
+    sum = next;
+    if (byte_counts) byte_counts[(size_t)e.message[0] * NUM_BYTE_OPS + B_U16RANGE_OP]++;   // the table row of U16Range is its value
+  }
+  const septic::S7 final_checker = septic::sum_checker_x(sum, dummy, sum);
+  for (size_t i = n_events; i < h; i++) {
+    F* r = t.data() + i * GLOBAL_WIDTH;
+    for (int k = 0; k < 7; k++) {
+      r[X + k] = dummy.x.c[k]; r[Y + k] = dummy.y.c[k];
+      r[INITIAL + k] = sum.x.c[k]; r[INITIAL + 7 + k] = sum.y.c[k];
+      r[SUM_CHECKER + k] = final_checker.c[k];
+      r[CUMULATIVE + k] = sum.x.c[k]; r[CUMULATIVE + 7 + k] = sum.y.c[k];
+    }
   }
   *height = h;
   return t;

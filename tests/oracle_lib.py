@@ -343,6 +343,19 @@ def tracegen_memory_instrs(events, fixed_log2_rows=-1, byte_counts=None):
     return out
 
 
+def tracegen_global(events, fixed_log2_rows=-1, byte_counts=None):
+    """Global chip rows from GlobalLookupEvents; byte_counts as for tracegen_branch."""
+    from ziren_amd import miniexec as M
+    ev = np.ascontiguousarray(events, dtype=M.GLOBAL_LOOKUP_EVENT)
+    rows = C.c_size_t()
+    _check(lib().orc_tracegen_alu_rows(C.c_size_t(len(ev)), C.c_int(fixed_log2_rows), C.byref(rows)))
+    out = np.zeros((rows.value, M.GLOBAL_WIDTH), dtype=np.uint32)
+    bc = abi.as_u32p(byte_counts) if byte_counts is not None else None
+    _check(lib().orc_tracegen_global(C.c_void_p(ev.ctypes.data), C.c_size_t(len(ev)), C.c_int(fixed_log2_rows), abi.as_u32p(out),
+                                     C.c_size_t(out.size), bc))
+    return out
+
+
 def tracegen_poseidon2_wide(events, fixed_log2_rows=-1):
     """Recursion Poseidon2Wide (degree 3) rows from events of 32 Montgomery words (input[16], output[16])."""
     from ziren_amd import recursion as R

@@ -60,6 +60,12 @@ def cpu_shard(oracle, n_cycles, seed=1):
     ml.trace = oracle.tracegen_memory_local(rec.memory_local, lh)
     recs.append(ml)
     work.append(("memory_local", rec.memory_local, lh))
+    ge = M.global_lookup_events(rec.memory_local)
+    lh = log2_rows(len(ge))
+    gl = chips.record_global_chip(lh)
+    gl.trace = oracle.tracegen_global(ge, lh, extra)
+    recs.append(gl)
+    work.append(("global", ge, lh))
     byte = chips.record_byte_chip(prep_index=0)
     byte.trace = oracle.tracegen_byte_mults([(c, ev) for c, ev, _ in work if not isinstance(c, str)], extra)
     byte.prep_trace = oracle.tracegen_byte_table()
@@ -70,9 +76,6 @@ def cpu_shard(oracle, n_cycles, seed=1):
     return recs, work, byte, program, prog, pv
 
 
-def global_mirrors(recs):
-    """Stand-in for the Global chip (crates/core/machine/src/global/, not built): receives what MemoryLocal sends to it."""
-    return [mirror_chip(r, kinds=(air.KIND_GLOBAL,)) for r in recs if any(lk.kind == air.KIND_GLOBAL for lk in r.sends)]
 
 
 def test_miniexec_record_is_coherent():
@@ -237,29 +240,74 @@ def test_cpu_constraints_hold(oracle):
     assert c.main_width + 4 * c.perm_ext_width + 8 == 119
 
 
+def random_global_events(n, seed):
+    rng = np.random.default_rng(seed)
+    ev = np.zeros(n, dtype=M.GLOBAL_LOOKUP_EVENT)
+    ev["message"] = rng.integers(0, 1 << 24, size=(n, 7))
+    ev["message"][:, 0] = rng.integers(0, 3, size=n)           # shard numbers: u16
+    ev["message"][:, 3:] = rng.integers(0, 256, size=(n, 4))   # value bytes
+    ev["is_receive"] = rng.integers(0, 2, size=n)
+    ev["kind"] = rng.choice([1, 6], size=n)                    # LookupKind::Memory / Syscall
+    return ev
+
+
+def test_global_constraints_hold(oracle):
+    """The Global chip: rows built by the restated generate_trace satisfy the recorded AIR (message -> curve point, sign of y by
+    direction, running sum from the start digest); the shard's digest does not depend on the order of the messages; cost pinned."""
+    rec = chips.record_global_constraints()
+    prog, r, pv = M.run(300, seed=3, shard=SHARD, pc_base=PC_BASE, halt=True)
+    ge = M.global_lookup_events(r.memory_local)
+    assert len(ge) == 2 * len(r.memory_local) and ge["is_receive"].sum() == len(r.memory_local)
+    counts = np.zeros((1 << 16, 10), dtype=np.uint32)
+    t = F.from_monty(oracle.tracegen_global(ge, -1, counts))
+    assert t.shape == (256, M.GLOBAL_WIDTH) and air.debug_constraints(rec.b, t) == []
+    assert counts.sum() == len(ge) == counts[0, 8] + counts[SHARD, 8]          # U16Range(shard) per message
+    for col in (0, 7, 8, 16, 23, 30, 60, 61, 78, 85, 98):     # message, kind, offset bit, x, y, y6 bit, witness, direction, checker, sum
+        bad = t.copy()
+        bad[5, col] = (int(bad[5, col]) + 1) % F.P
+        assert {row for _, row in air.debug_constraints(rec.b, bad)} == {5}, col
+    bad = t.copy()
+    bad[5, 64] = (int(bad[5, 64]) + 1) % F.P                 # initial digest: also breaks the previous row's hand-over
+    assert {row for _, row in air.debug_constraints(rec.b, bad)} == {4, 5}
+    bad = t.copy()
+    bad[len(ge) + 3, 85] = (int(bad[len(ge) + 3, 85]) + 1) % F.P     # a padding row must carry the sum unchanged
+    assert {row for _, row in air.debug_constraints(rec.b, bad)} == {len(ge) + 3}
+    # the start digest alone (no events) and order independence of the final sum
+    empty = F.from_monty(oracle.tracegen_global(ge[:0], 4))
+    assert air.debug_constraints(rec.b, empty) == [] and list(empty[-1, 85:92]) == list(chips.SEPTIC_START_X)
+    ev = random_global_events(200, 5)
+    a = F.from_monty(oracle.tracegen_global(ev, -1))
+    b = F.from_monty(oracle.tracegen_global(ev[np.random.default_rng(1).permutation(len(ev))], -1))
+    assert air.debug_constraints(rec.b, a) == [] and np.array_equal(a[-1, 85:], b[-1, 85:]) and not np.array_equal(a[100, 85:], b[100, 85:])
+    c = chips.record_global_chip(10)
+    assert c.commit_scope_global and c.main_width + 4 * c.perm_ext_width + 8 == 115
+    with pytest.raises(Exception):
+        bad_ev = ev.copy()
+        bad_ev["message"][3, 0] = 1 << 16
+        oracle.tracegen_global(bad_ev, -1)
+
+
 def test_shard_lookups_balance(oracle):
     """Cpu sends every instruction the eleven chips receive, the Program table receives every fetch, the Byte table
-    every byte lookup, MemoryLocal opens and closes every register's access chain; only its messages to the Global chip
-    (two per touched address) are left."""
+    every byte lookup, MemoryLocal opens and closes every register's access chain and the Global chip receives its two messages
+    per touched address: nothing is left, with no stand-in on any side."""
     recs, work, byte, program, prog, pv = cpu_shard(oracle, 1200, seed=9)
-    left = {k: v for k, v in lookup_tally(recs + [byte, program]).items() if v}
-    n_addr = len(work[-1][1])
-    assert {k[0] for k in left} == {air.KIND_GLOBAL} and len(left) == 2 * n_addr and n_addr > 34    # registers and memory words
-    without = {k: v for k, v in lookup_tally(recs[:-1] + [byte, program]).items() if v}
-    assert {k[0] for k in without} == {air.KIND_MEMORY}          # without MemoryLocal the access chains stay open
-    mirrors = global_mirrors(recs)
-    assert [m.name for m in mirrors] == ["MemoryLocalMirror"]
-    assert {r.name for r in recs} >= {"Cpu", "MiscInstrs", "MemoryInstrs", "SyscallInstrs", "Mul", "DivRem", "MemoryLocal"} and len(recs) == 16
-    assert not any(lookup_tally(recs + [byte, program] + mirrors).values())
+    assert not any(lookup_tally(recs + [byte, program]).values())
+    n_addr = len(work[-2][1])
+    left = {k: v for k, v in lookup_tally(recs[:-1] + [byte, program]).items() if v}      # without the Global chip
+    assert {k[0] for k in left} == {air.KIND_GLOBAL, air.KIND_BYTE} and len(left) == 2 * n_addr + 2 and n_addr > 34    # registers and memory words; U16Range of shard 0 and 1
+    without = {k: v for k, v in lookup_tally(recs[:-2] + [byte, program]).items() if v}
+    assert {k[0] for k in without} == {air.KIND_MEMORY, air.KIND_BYTE}          # without MemoryLocal the access chains stay open
+    assert {r.name for r in recs} >= {"Cpu", "MiscInstrs", "MemoryInstrs", "SyscallInstrs", "Mul", "DivRem", "MemoryLocal", "Global"} and len(recs) == 17
 
 
 def test_oracle_proves_coherent_shard(oracle):
-    """The restated verifier accepts the oracle's proof of the whole shard (cumulative sum zero with only the Global
-    chip's side mirrored) and rejects one made for a different next_pc (the Cpu chip's boundary constraint)."""
+    """The restated verifier accepts the oracle's proof of the whole shard (local cumulative sum zero over real chips only; the
+    Global chip's running curve sum is the proof's global_cumulative_sum) and rejects one made for a different next_pc (the
+    Cpu chip's boundary constraint)."""
     from ziren_amd import synth
     recs, work, byte, program, prog, pv = cpu_shard(oracle, 500, seed=7)
-    mirrors = global_mirrors(recs)
-    all_chips = recs + [byte, program] + mirrors
+    all_chips = recs + [byte, program]
     fri = abi.FriConfig(1, 84, 16)
     igcs = F.to_monty(np.zeros(14, dtype=np.uint64))
     opk = oracle.Pk([byte.prep_trace, program.prep_trace], [0, 0], F.to_monty(PC_BASE), igcs, 1)
@@ -293,6 +341,8 @@ def device_trace(ctx, chip, ev, lh, blu, prog):
         return ctx.tracegen_mul(ev, lh, blu)
     if chip == "divrem":
         return ctx.tracegen_divrem(ev, lh, blu)
+    if chip == "global":
+        return ctx.tracegen_global(ev, lh, blu)
     return ctx.tracegen_alu(chip, ev, lh, blu)
 
 
@@ -348,6 +398,34 @@ def test_gpu_cpu_and_program_tracegen_match_oracle(hip_ctx, oracle):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n", [0, 1, 5, 1023, 1024, 2500, 40000])
+def test_gpu_global_tracegen_matches_oracle(hip_ctx, oracle, n):
+    """zkm_tracegen_global == the restated GlobalChip::generate_trace, bit for bit: lift_x (square roots in the septic extension),
+    the sign by direction, the range-check witness, and the running sum through one, two and three levels of the device scan
+    (n + 1 <= 1024, <= 32768, above); the U16Range counts land in the shared byte-lookup table."""
+    ev = random_global_events(n, 100 + n)
+    want_counts = np.zeros((1 << 16, 10), dtype=np.uint32)
+    want = oracle.tracegen_global(ev, -1, want_counts)
+    blu = hip_ctx.byte_lookups()
+    m = hip_ctx.tracegen_global(ev, -1, blu)
+    got = m.to_host()
+    assert got.shape == want.shape and np.array_equal(got, want)
+    mults = hip_ctx.tracegen_byte_mults(blu)
+    assert np.array_equal(F.from_monty(mults.to_host()), want_counts)
+    mults.free()
+    m.free()
+    if n == 5:
+        from ziren_amd import lib
+        bad = ev.copy()
+        bad["message"][2, 0] = 70000
+        with pytest.raises(lib.ZkmError, match="not a u16"):
+            hip_ctx.tracegen_global(bad, -1, blu)
+        with pytest.raises(lib.ZkmError, match="null byte lookups"):
+            hip_ctx.tracegen_global(ev, -1, None)
+    blu.free()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("n_cycles", [40, 6000])
 def test_gpu_coherent_shard_proof(hip_ctx, oracle, n_cycles):
     """Cpu + Program + the eleven instruction chips + Byte over one executed program: every trace and both preprocessed
@@ -355,8 +433,7 @@ def test_gpu_coherent_shard_proof(hip_ctx, oracle, n_cycles):
     public values (start_pc, next_pc, execution_shard) are checked by its constraints."""
     from ziren_amd import prover, synth
     recs, work, byte, program, prog, pv = cpu_shard(oracle, n_cycles, seed=n_cycles)
-    mirrors = global_mirrors(recs)
-    all_chips = recs + [byte, program] + mirrors
+    all_chips = recs + [byte, program]
     fri = abi.FriConfig(1, 84, 16)
     pvs = M.public_values(pv)
     igcs = F.to_monty(np.zeros(14, dtype=np.uint64))
@@ -373,7 +450,6 @@ def test_gpu_coherent_shard_proof(hip_ctx, oracle, n_cycles):
     born = [device_trace(hip_ctx, chip, ev, lh, blu, prog) for chip, ev, lh in work]
     born.append(hip_ctx.tracegen_byte_mults(blu))
     born.append(hip_ctx.tracegen_program_mults(work[0][1], len(prog), PC_BASE, program.log_height))
-    born += [hip_ctx.upload(m.trace) for m in mirrors]
     proof = hp.prove_shard(pk, pvs, born, ch).copy()
     och = oracle.new_challenger()
     opk.observe_into(och)

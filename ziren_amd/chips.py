@@ -1004,6 +1004,104 @@ def _memory_local(r: _Rec):
         r.sends.append(air.Lookup([air.to_virtual_pair(v) for v in [fsh, fclk, addr] + list(fval)], air.to_virtual_pair(is_real), air.KIND_MEMORY))
 
 
+# septic extension F_p[z] / (z^7 + 2z - 8) over expressions (crates/stark/src/septic_extension.rs) and the curve y^2 = x^3 + 3z x - 3
+# (crates/stark/src/septic_curve.rs:100-122, sum checkers :159-176)
+SEPTIC_START_X = (637514027, 1595065213, 1998064738, 72333738, 1211544370, 822986770, 1518535784)     # septic_digest.rs:9-16
+SEPTIC_START_Y = (1604177449, 90440090, 259343427, 140470264, 1162099742, 941559812, 1064053343)
+
+
+def _s_mul(a, b):
+    t = [None] * 13
+    for i in range(7):
+        for j in range(7):
+            prod = a[i] * b[j]
+            t[i + j] = prod if t[i + j] is None else t[i + j] + prod
+    for k in range(12, 6, -1):          # z^k = z^(k-7) (8 - 2z)
+        t[k - 7] = t[k - 7] + t[k] * 8
+        t[k - 6] = t[k - 6] - t[k] * 2
+    return t[:7]
+
+
+def _s_add(a, b):
+    return [x + y for x, y in zip(a, b)]
+
+
+def _s_sub(a, b):
+    return [x - y for x, y in zip(a, b)]
+
+
+def _curve_formula(b, x):
+    three_z_x = _s_mul(x, [b.const(0), b.const(3)] + [b.const(0)] * 5)
+    cube = _s_add(_s_mul(_s_mul(x, x), x), three_z_x)
+    return [cube[0] - 3] + cube[1:]
+
+
+def _sum_checker_x(p1, p2, p3):
+    dx, dy = _s_sub(p2[0], p1[0]), _s_sub(p2[1], p1[1])
+    return _s_sub(_s_mul(_s_add(_s_add(p1[0], p2[0]), p3[0]), _s_mul(dx, dx)), _s_mul(dy, dy))
+
+
+def _sum_checker_y(p1, p2, p3):
+    return _s_sub(_s_mul(_s_add(p1[1], p3[1]), _s_sub(p2[0], p1[0])), _s_mul(_s_sub(p2[1], p1[1]), _s_sub(p1[0], p3[0])))
+
+
+def _global(r: _Rec):
+    """GlobalChip::eval (crates/core/machine/src/global/mod.rs:214-275) = the receive of every global message of the shard,
+    GlobalLookupOperation::eval_single_digest (operations/global_lookup.rs:96-175: message -> curve point, sign of y by direction)
+    and GlobalAccumulationOperation::<1>::eval_accumulation (operations/global_accumulation.rs:116-223: running sum of the points)."""
+    MESSAGE, KIND, OFFSET_BITS, X, Y, Y6_BITS, RC_WITNESS, IS_RECEIVE, IS_SEND, IS_REAL, INITIAL, SUM_CHECKER, CUMULATIVE = \
+        0, 7, 8, 16, 23, 30, 60, 61, 62, 63, 64, 78, 85
+    l, n, b = r.local, r.next, r.b
+    message, kind, is_real, is_receive, is_send = l[MESSAGE:MESSAGE + 7], l[KIND], l[IS_REAL], l[IS_RECEIVE], l[IS_SEND]
+    r.receives.append(air.Lookup([air.to_virtual_pair(v) for v in list(message) + [is_send, is_receive, kind]], air.to_virtual_pair(is_real),
+                                 air.KIND_GLOBAL))
+    # eval_single_digest
+    b.assert_bool(is_real)
+    offset = b.const(0)
+    for i in range(8):
+        b.assert_bool(l[OFFSET_BITS + i])
+        offset = offset + l[OFFSET_BITS + i] * (1 << i)
+    r.send_byte(B_U16RANGE, message[0], 0, 0, is_real)
+    x, y = list(l[X:X + 7]), list(l[Y:Y + 7])
+    b.when(is_real).assert_eq(x[0], message[0] + kind * 65536)
+    for i in range(1, 6):
+        b.when(is_real).assert_eq(x[i], message[i])
+    b.when(is_real).assert_eq(x[6], message[6] * 256 + offset)
+    for lhs, rhs in zip(_s_mul(y, y), _curve_formula(b, x)):
+        b.assert_eq(lhs, rhs)
+    y6_value, top_7_bits = b.const(0), b.const(0)
+    for i in range(30):
+        b.assert_bool(l[Y6_BITS + i])
+        y6_value = y6_value + l[Y6_BITS + i] * (1 << i)
+        if i >= 23:
+            top_7_bits = top_7_bits + l[Y6_BITS + i]
+    b.when(is_real).assert_eq(l[RC_WITNESS] * (top_7_bits - 7), b.const(1))
+    b.when(is_receive).assert_eq(y[6], y6_value + 1)
+    b.when(is_send).assert_eq(y[6], y6_value + ((1 << 30) - (1 << 23) + 1))
+    # eval_accumulation, N = 1
+    b.assert_bool(is_real)
+    b.when_transition().when_not(is_real).assert_zero(n[IS_REAL])
+    initial = (list(l[INITIAL:INITIAL + 7]), list(l[INITIAL + 7:INITIAL + 14]))
+    total = (list(l[CUMULATIVE:CUMULATIVE + 7]), list(l[CUMULATIVE + 7:CUMULATIVE + 14]))
+    witnessed = list(l[SUM_CHECKER:SUM_CHECKER + 7])
+    for i in range(7):
+        b.when_first_row().assert_eq(initial[0][i], b.const(SEPTIC_START_X[i]))
+    for i in range(7):
+        b.when_first_row().assert_eq(initial[1][i], b.const(SEPTIC_START_Y[i]))
+    for lhs, rhs in zip(_sum_checker_x(initial, (x, y), total), witnessed):
+        b.assert_eq(lhs, rhs)
+    for w in witnessed:
+        b.when(is_real).assert_zero(w)
+    for c in _sum_checker_y(initial, (x, y), total):
+        b.when(is_real).assert_zero(c)
+    for k in range(2):
+        for i in range(7):
+            b.when_not(is_real).assert_eq(initial[k][i], total[k][i])
+    for k in range(2):
+        for i in range(7):
+            b.when_transition().assert_eq(total[k][i], n[INITIAL + 7 * k + i])
+
+
 def _mov_cond(r: _Rec):
     """MovCondChip::eval (misc/mov_cond/mod.rs:172-257)."""
     l, b = r.local, r.b
@@ -1179,13 +1277,14 @@ def record_cpu_constraints() -> _Rec:
     return r
 
 
-def _finish(r: _Rec, name, log_height, width, local_only, prep_width=0, prep_index=-1) -> RecordedChip:
+def _finish(r: _Rec, name, log_height, width, local_only, prep_width=0, prep_index=-1, commit_scope_global=False) -> RecordedChip:
     lqd = 1
     r.b.perm_ext_width = air.local_permutation_trace_width(len(r.sends) + len(r.receives), 1 << lqd)
-    air.eval_permutation_constraints(r.b, r.sends, r.receives, 1 << lqd, False)
+    air.eval_permutation_constraints(r.b, r.sends, r.receives, 1 << lqd, commit_scope_global)
     program = r.b.assemble()
     return RecordedChip(name=name, log_height=log_height, main_width=width, prep_width=prep_width, prep_index=prep_index,
-                        log_quotient_degree=lqd, local_only=local_only, sends=r.sends, receives=r.receives, program=program,
+                        log_quotient_degree=lqd, local_only=local_only, commit_scope_global=commit_scope_global, sends=r.sends, receives=r.receives,
+                        program=program,
                         lookups_blob=air.encode_lookups(r.sends, r.receives), num_constraints=int(program[2]))
 
 
@@ -1242,6 +1341,21 @@ def record_memory_local_chip(log_height: int) -> RecordedChip:
     r = _Rec(M.MEMORY_LOCAL_WIDTH)
     _memory_local(r)
     return _finish(r, "MemoryLocal", log_height, M.MEMORY_LOCAL_WIDTH, False)
+
+
+def record_global_constraints() -> _Rec:
+    from . import miniexec as M
+    r = _Rec(M.GLOBAL_WIDTH)
+    _global(r)
+    return r
+
+
+def record_global_chip(log_height: int) -> RecordedChip:
+    """The Global chip (crates/core/machine/src/global/mod.rs): GlobalLookupEvents, 99 columns, constraints between consecutive rows.
+    Receives every message the shard's chips send across shards (here MemoryLocal's), maps each to a point of the septic curve
+    and accumulates them; commit scope Global: the last row's running sum is the shard proof's global_cumulative_sum."""
+    from . import miniexec as M
+    return _finish(record_global_constraints(), "Global", log_height, M.GLOBAL_WIDTH, False, commit_scope_global=True)
 
 
 def record_program_chip(log_height: int, prep_index: int = 0) -> RecordedChip:

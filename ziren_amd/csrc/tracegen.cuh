@@ -17,6 +17,7 @@
 #pragma once
 #include "kb31.cuh"
 #include "poseidon2.cuh"
+#include "septic.cuh"
 
 namespace tracegen {
 
@@ -1188,6 +1189,152 @@ __global__ void byte_table(uint32_t* out) {
                                       (uint32_t)(b < c), b >> 7, (b << 8) + c};
 #pragma unroll
   for (int j = 0; j < BYTE_PREP_COLS; j++) out[(size_t)j * BYTE_ROWS + row] = kb::to_monty(v[j]);
+}
+
+// ---- Global chip (crates/core/machine/src/global/mod.rs): GlobalLookupEvents of eight words (message[7]; is_receive, kind in the
+// bytes of the eighth), 99 columns (:54-64). Three steps: (1) global_point_rows — one thread per row maps its message to a curve point
+// (GlobalLookupOperation::populate, operations/global_lookup.rs:26-92), writes columns 0..63 and the point into a scan buffer whose
+// element 0 is the start digest; (2) an inclusive scan of that buffer under the curve's complete addition (the reference's parallel
+// scan, mod.rs:163-167) — chunks of SCAN_CHUNK per thread, the chunk sums scanned recursively, one block at the top; (3)
+// global_accum_rows — columns 64..98 from the prefix sums (operations/global_accumulation.rs:75-113). Byte lookups: U16Range(message[0])
+// per event (mod.rs:75-95): message[0] is the shard number, one or two distinct values, so each wave adds its leader's count once.
+constexpr int GLOBAL_WIDTH = 99, SCAN_CHUNK = 32, SCAN_BLOCK = 1024, POINT_WORDS = 16;
+namespace globalcols {
+enum { MESSAGE = 0, KIND = 7, OFFSET_BITS = 8, X = 16, Y = 23, Y6_BITS = 30, RC_WITNESS = 60, IS_RECEIVE = 61, IS_SEND = 62, IS_REAL = 63,
+       INITIAL = 64, SUM_CHECKER = 78, CUMULATIVE = 85 };
+}
+__constant__ uint32_t d_global_consts[28];   // start digest x, y (septic_digest.rs:9-14), dummy point x, y (septic_curve.rs:18-38); Montgomery
+enum : uint32_t { GLOBAL_ERR_NO_POINT = 1, GLOBAL_ERR_INFINITY = 2, GLOBAL_ERR_EQUAL_X = 4 };
+__device__ __forceinline__ septic::Point load_point(const uint32_t* p) {
+  septic::Point r;
+#pragma unroll
+  for (int k = 0; k < 7; k++) { r.x.c[k] = p[k]; r.y.c[k] = p[7 + k]; }
+  r.inf = p[14];
+  return r;
+}
+__device__ __forceinline__ void store_point(uint32_t* p, const septic::Point& v) {
+#pragma unroll
+  for (int k = 0; k < 7; k++) { p[k] = v.x.c[k]; p[7 + k] = v.y.c[k]; }
+  p[14] = v.inf;
+  p[15] = 0;
+}
+__global__ void global_point_rows(const uint32_t* __restrict__ events, size_t n_events, size_t height, uint32_t* __restrict__ out,
+                                  uint32_t* __restrict__ points, uint32_t* __restrict__ counts, uint32_t* __restrict__ err) {
+  using namespace globalcols;
+  const size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (row == 0) {
+    septic::Point s;
+    for (int k = 0; k < 7; k++) { s.x.c[k] = d_global_consts[k]; s.y.c[k] = d_global_consts[7 + k]; }
+    s.inf = 0;
+    store_point(points, s);
+  }
+  if (row >= height) return;
+  auto put = [&](int col, uint32_t monty) { out[(size_t)col * height + row] = monty; };
+  if (row >= n_events) {   // populate_dummy: the dummy point, everything else zero
+    for (int c = 0; c < INITIAL; c++) put(c, (c >= X && c < X + 14) ? d_global_consts[14 + c - X] : 0u);
+    return;
+  }
+  const uint32_t* e = events + row * 8;
+  const uint32_t is_receive = e[7] & 0xff, kind = (e[7] >> 8) & 0xff;
+  septic::S7 m;
+  for (int k = 0; k < 7; k++) { m.c[k] = kb::to_monty(e[k]); put(MESSAGE + k, m.c[k]); }
+  m.c[0] = kb::add(m.c[0], kb::to_monty(kind << 16));
+  put(KIND, kb::to_monty(kind));
+  septic::Point pt;
+  uint32_t offset = 0;
+  if (!septic::lift_x(m, septic::d_frob, &pt, &offset)) {
+    atomicOr(err, GLOBAL_ERR_NO_POINT);
+    pt.x = m; pt.y = septic::s_zero(); pt.inf = 0;
+  }
+  if (!is_receive) pt.y = septic::s_neg(pt.y);
+  for (int k = 0; k < 8; k++) put(OFFSET_BITS + k, (offset >> k) & 1 ? kb::ONE : 0u);
+  for (int k = 0; k < 7; k++) { put(X + k, pt.x.c[k]); put(Y + k, pt.y.c[k]); }
+  const uint32_t y6 = kb::from_monty(pt.y.c[6]);
+  const uint32_t rc = is_receive ? y6 - 1 : y6 - (kb::P + 1) / 2;
+  uint32_t top = 0;
+  for (int k = 0; k < 30; k++) {
+    const uint32_t bit = (rc >> k) & 1;
+    put(Y6_BITS + k, bit ? kb::ONE : 0u);
+    if (k >= 23) top += bit;
+  }
+  put(RC_WITNESS, kb::to_monty(small_inverse(kb::P + top - 7)));
+  put(IS_RECEIVE, is_receive ? kb::ONE : 0u);
+  put(IS_SEND, is_receive ? 0u : kb::ONE);
+  put(IS_REAL, kb::ONE);
+  store_point(points + (row + 1) * POINT_WORDS, pt);
+  // U16Range(message[0]): lanes that agree with the wave's first active lane are counted with one atomic
+  const uint32_t v = e[0] & 0xffff;
+  const uint32_t lead = __builtin_amdgcn_readfirstlane(v);
+  const unsigned long long same = __ballot(v == lead);
+  if (v != lead) atomicAdd(counts + B_U16RANGE * BYTE_ROWS + v, 1u);
+  else if ((same & ((1ull << __lane_id()) - 1)) == 0) atomicAdd(counts + B_U16RANGE * BYTE_ROWS + v, (uint32_t)__popcll(same));
+}
+// sums[t] = pts[t * chunk] + ... (chunk consecutive points)
+__global__ void global_scan_reduce(const uint32_t* __restrict__ pts, size_t n, uint32_t* __restrict__ sums, size_t n_sums) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_sums) return;
+  const size_t lo = t * SCAN_CHUNK, hi = lo + SCAN_CHUNK < n ? lo + SCAN_CHUNK : n;
+  septic::Point acc = load_point(pts + lo * POINT_WORDS);
+  for (size_t i = lo + 1; i < hi; i++) acc = septic::add_complete(acc, load_point(pts + i * POINT_WORDS), septic::d_frob);
+  store_point(sums + t * POINT_WORDS, acc);
+}
+// inclusive scan of n <= SCAN_BLOCK points in place, one block (Hillis-Steele over LDS)
+__global__ void __launch_bounds__(SCAN_BLOCK) global_scan_block(uint32_t* __restrict__ pts, size_t n) {
+  __shared__ uint32_t lds[SCAN_BLOCK * POINT_WORDS];
+  const size_t t = threadIdx.x;
+  septic::Point mine;
+  if (t < n) { mine = load_point(pts + t * POINT_WORDS); store_point(lds + t * POINT_WORDS, mine); }
+  __syncthreads();
+  for (size_t d = 1; d < n; d <<= 1) {
+    septic::Point left;
+    const bool on = t < n && t >= d;
+    if (on) left = load_point(lds + (t - d) * POINT_WORDS);
+    __syncthreads();
+    if (on) { mine = septic::add_complete(left, mine, septic::d_frob); store_point(lds + t * POINT_WORDS, mine); }
+    __syncthreads();
+  }
+  if (t < n) store_point(pts + t * POINT_WORDS, mine);
+}
+// pts[i] <- (scanned sums of the chunks before i's) + pts[lo..=i], in place
+__global__ void global_scan_apply(uint32_t* __restrict__ pts, size_t n, const uint32_t* __restrict__ sums, size_t n_sums) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_sums) return;
+  const size_t lo = t * SCAN_CHUNK, hi = lo + SCAN_CHUNK < n ? lo + SCAN_CHUNK : n;
+  septic::Point acc;
+  acc.inf = 1;
+  acc.x = acc.y = septic::s_zero();
+  if (t) acc = load_point(sums + (t - 1) * POINT_WORDS);
+  for (size_t i = lo; i < hi; i++) {
+    acc = septic::add_complete(acc, load_point(pts + i * POINT_WORDS), septic::d_frob);
+    store_point(pts + i * POINT_WORDS, acc);
+  }
+}
+__global__ void global_accum_rows(const uint32_t* __restrict__ prefix, size_t n_events, size_t height, uint32_t* __restrict__ out,
+                                  uint32_t* __restrict__ err) {
+  using namespace globalcols;
+  const size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= height) return;
+  auto put = [&](int col, uint32_t monty) { out[(size_t)col * height + row] = monty; };
+  const bool real = row < n_events;
+  const septic::Point initial = load_point(prefix + (real ? row : n_events) * POINT_WORDS);
+  septic::Point total = initial;
+  septic::S7 checker = septic::s_zero();
+  if (real) {
+    total = load_point(prefix + (row + 1) * POINT_WORDS);
+    uint32_t same = 0;
+    for (int k = 0; k < 7; k++) same |= initial.x.c[k] ^ out[(size_t)(X + k) * height + row];
+    if (same == 0) atomicOr(err, GLOBAL_ERR_EQUAL_X);    // the AIR's addition is the incomplete one
+  } else {
+    septic::Point dummy;
+    for (int k = 0; k < 7; k++) { dummy.x.c[k] = d_global_consts[14 + k]; dummy.y.c[k] = d_global_consts[21 + k]; }
+    checker = septic::sum_checker_x(initial, dummy, initial);
+  }
+  if (initial.inf | total.inf) atomicOr(err, GLOBAL_ERR_INFINITY);
+  for (int k = 0; k < 7; k++) {
+    put(INITIAL + k, initial.x.c[k]); put(INITIAL + 7 + k, initial.y.c[k]);
+    put(SUM_CHECKER + k, checker.c[k]);
+    put(CUMULATIVE + k, total.x.c[k]); put(CUMULATIVE + 7 + k, total.y.c[k]);
+  }
 }
 
 }  // namespace tracegen

@@ -1094,6 +1094,18 @@ int zkm_ctx_create(int device, zkm_ctx** out) {
   c->cur = c->stream;
   HIP_CHECK(p2::upload_tables());
   HIP_CHECK(tracegen::upload_tables());
+  HIP_CHECK(septic::upload_tables());
+  {
+    // the Global chip's dummy point (crates/stark/src/septic_curve.rs:18-38) next to the start digest
+    static const uint32_t DUMMY_X[7] = {1706420302, 1319108093, 148224806, 26874985, 1766171812, 1645633948, 2028659224};
+    static const uint32_t DUMMY_Y[7] = {942390502, 1239997438, 458866455, 1843332012, 1309764648, 572807436, 74267719};
+    uint32_t consts[28];
+    for (int k = 0; k < 7; k++) {
+      consts[k] = kb::to_monty(SEPTIC_X[k]); consts[7 + k] = kb::to_monty(SEPTIC_Y[k]);
+      consts[14 + k] = kb::to_monty(DUMMY_X[k]); consts[21 + k] = kb::to_monty(DUMMY_Y[k]);
+    }
+    HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(tracegen::d_global_consts), consts, sizeof consts));
+  }
   HIP_CHECK(hipFuncSetAttribute((const void*)lde::lde_rows, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIP_CHECK(hipFuncSetAttribute((const void*)lde::lde_rows_big, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIP_CHECK(hipFuncSetAttribute((const void*)tracegen::alu_rows<tracegen::ADD_SUB>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
@@ -1836,6 +1848,71 @@ int zkm_tracegen_memory_local(zkm_ctx* ctx, const zkm_memory_local_event* events
     delete m;
     throw;
   }
+  ctx->release(d_events);
+  *out = m;
+  API_END
+}
+
+int zkm_tracegen_global(zkm_ctx* ctx, const zkm_global_lookup_event* events, size_t n_events, int fixed_log2_rows, zkm_byte_lookups* blu,
+                        zkm_matrix** out) {
+  API_BEGIN
+  static_assert(sizeof(zkm_global_lookup_event) == 32, "event records mirror the #[repr(C)] executor structs");
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIP_CHECK(hipSetDevice(ctx->device));
+  if (n_events && !events) throw std::runtime_error("zkm_tracegen_global: null events");
+  if (!blu) throw std::runtime_error("zkm_tracegen_global: null byte lookups");
+  for (size_t i = 0; i < n_events; i++)
+    if (events[i].message[0] >> 16) throw std::runtime_error("zkm_tracegen_global: message[0] of event " + std::to_string(i) + " is not a u16");
+  const size_t height = padded_trace_rows(n_events, fixed_log2_rows, "zkm_tracegen_global");
+  ctx->begin_timing();
+  zkm_matrix* m = new zkm_matrix();
+  m->h = height; m->w = tracegen::GLOBAL_WIDTH;
+  uint32_t* d_events = nullptr;
+  uint32_t* d_err = nullptr;
+  std::vector<uint32_t*> levels;     // scan buffers: the points behind the start digest, then the chunk sums of each level
+  std::vector<size_t> sizes;
+  try {
+    m->d = ctx->alloc_n<uint32_t>(height * m->w);
+    d_events = (uint32_t*)ctx->alloc(std::max<size_t>(n_events * sizeof(zkm_global_lookup_event), 4));
+    d_err = ctx->alloc_n<uint32_t>(1);
+    HIP_CHECK(hipMemsetAsync(d_err, 0, 4, ctx->stream));
+    if (n_events) HIP_CHECK(hipMemcpyAsync(d_events, events, n_events * sizeof(zkm_global_lookup_event), hipMemcpyHostToDevice, ctx->stream));
+    for (size_t n = n_events + 1;; n = div_up(n, (size_t)tracegen::SCAN_CHUNK)) {
+      levels.push_back(ctx->alloc_n<uint32_t>(n * tracegen::POINT_WORDS));
+      sizes.push_back(n);
+      if (n <= (size_t)tracegen::SCAN_BLOCK) break;
+    }
+    const double bytes = 32.0 * n_events + 4.0 * height * tracegen::GLOBAL_WIDTH;
+    KLAUNCH(ctx, "tracegen_global_points", bytes, tracegen::global_point_rows, dim3(div_up(height, (size_t)256)), dim3(256), 0,
+            (const uint32_t*)d_events, n_events, height, m->d, levels[0], blu->counts, d_err);
+    for (size_t l = 0; l + 1 < levels.size(); l++)
+      KLAUNCH(ctx, "tracegen_global_scan", 64.0 * sizes[l], tracegen::global_scan_reduce, dim3(div_up(sizes[l + 1], (size_t)64)), dim3(64), 0,
+              (const uint32_t*)levels[l], sizes[l], levels[l + 1], sizes[l + 1]);
+    KLAUNCH(ctx, "tracegen_global_scan", 128.0 * sizes.back(), tracegen::global_scan_block, dim3(1), dim3(tracegen::SCAN_BLOCK), 0, levels.back(),
+            sizes.back());
+    for (size_t l = levels.size() - 1; l-- > 0;)
+      KLAUNCH(ctx, "tracegen_global_scan", 128.0 * sizes[l], tracegen::global_scan_apply, dim3(div_up(sizes[l + 1], (size_t)64)), dim3(64), 0, levels[l],
+              sizes[l], (const uint32_t*)levels[l + 1], sizes[l + 1]);
+    KLAUNCH(ctx, "tracegen_global_accum", bytes, tracegen::global_accum_rows, dim3(div_up(height, (size_t)256)), dim3(256), 0,
+            (const uint32_t*)levels[0], n_events, height, m->d, d_err);
+    uint32_t err = 0;
+    HIP_CHECK(hipMemcpyAsync(&err, d_err, 4, hipMemcpyDeviceToHost, ctx->stream));
+    ctx->mark("trace generation");
+    ctx->end_timing(false);
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (err & tracegen::GLOBAL_ERR_NO_POINT) throw std::runtime_error("zkm_tracegen_global: a message has no curve point within 256 offsets");
+    if (err & tracegen::GLOBAL_ERR_INFINITY) throw std::runtime_error("zkm_tracegen_global: the running sum reached the point at infinity");
+    if (err & tracegen::GLOBAL_ERR_EQUAL_X) throw std::runtime_error("zkm_tracegen_global: a message's point has the running sum's x-coordinate");
+  } catch (...) {
+    for (uint32_t* p : levels) ctx->release(p);
+    if (d_err) ctx->release(d_err);
+    if (d_events) ctx->release(d_events);
+    if (m->d) ctx->release(m->d);
+    delete m;
+    throw;
+  }
+  for (uint32_t* p : levels) ctx->release(p);
+  ctx->release(d_err);
   ctx->release(d_events);
   *out = m;
   API_END

@@ -41,6 +41,10 @@ MEMORY_RECORD = np.dtype([("shard", "<u4"), ("timestamp", "<u4"), ("value", "<u4
 MEMORY_LOCAL_EVENT = np.dtype([("addr", "<u4"), ("initial", MEMORY_RECORD), ("final", MEMORY_RECORD)])
 assert MEMORY_LOCAL_EVENT.itemsize == 28
 MEMORY_LOCAL_ENTRIES_PER_ROW, MEMORY_LOCAL_WIDTH = 4, 56
+# GlobalLookupEvent (crates/core/executor/src/events/global.rs:6-15, #[repr(C)]): message, is_receive, kind (LookupKind as u8)
+GLOBAL_LOOKUP_EVENT = np.dtype([("message", "<u4", (7,)), ("is_receive", "u1"), ("kind", "u1"), ("pad", "u1", (2,))])
+assert GLOBAL_LOOKUP_EVENT.itemsize == 32
+GLOBAL_WIDTH = 99
 TAG_READ, TAG_WRITE, TAG_NONE = 0, 1, 2
 CPU_WIDTH = 67
 PROGRAM_PREP_WIDTH, PROGRAM_MULT_WIDTH = 14, 1
@@ -406,6 +410,21 @@ def add_dependencies(rec: Record) -> Record:
     out.cpu, out.alu, out.branch, out.jump, out.mov_cond, out.divrem = rec.cpu, alu, rec.branch, rec.jump, rec.mov_cond, rec.divrem
     out.memory_local, out.mem_instr, out.syscall, out.misc = rec.memory_local, rec.mem_instr, rec.syscall, rec.misc
     out.mul = np.concatenate([rec.mul, div_mul, misc_mul])
+    return out
+
+
+def global_lookup_events(memory_local: np.ndarray) -> np.ndarray:
+    """MemoryLocalChip::generate_dependencies (crates/core/machine/src/memory/local.rs:98-135): per touched address, the access the shard
+    starts from is *received* from the global table and the one it ends with is *sent* to it; message = (shard, timestamp, addr,
+    the value's four bytes), kind Memory."""
+    out = np.zeros(2 * len(memory_local), dtype=GLOBAL_LOOKUP_EVENT)
+    for half, rec, is_receive in ((0, "initial", 1), (1, "final", 0)):
+        m = out["message"][half::2]
+        m[:, 0], m[:, 1], m[:, 2] = memory_local[rec]["shard"], memory_local[rec]["timestamp"], memory_local["addr"]
+        for k in range(4):
+            m[:, 3 + k] = (memory_local[rec]["value"] >> (8 * k)) & 0xff
+        out["is_receive"][half::2] = is_receive
+    out["kind"] = 1     # LookupKind::Memory
     return out
 
 

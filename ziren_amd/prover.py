@@ -229,6 +229,16 @@ class Context:
                                                        C.c_int(fixed_log2_rows), C.byref(h)))
         return self._born(h)
 
+    def tracegen_global(self, events: np.ndarray, fixed_log2_rows: int = -1, blu: "ByteLookups" = None) -> DeviceMatrix:
+        """`generate_trace` of the Global chip on the device (zkm_tracegen_global); dtype miniexec.GLOBAL_LOOKUP_EVENT. The
+        U16Range lookups of the messages' first words are counted into `blu`."""
+        from . import miniexec as _m
+        ev = np.ascontiguousarray(events, dtype=_m.GLOBAL_LOOKUP_EVENT)
+        h = C.c_void_p()
+        lib.check(lib.load().zkm_tracegen_global(self.h, C.c_void_p(ev.ctypes.data if len(ev) else None), C.c_size_t(len(ev)),
+                                                 C.c_int(fixed_log2_rows), blu.h if blu is not None else None, C.byref(h)))
+        return self._born(h)
+
     def tracegen_cpu_and_program(self, events: np.ndarray, program: np.ndarray, pc_base: int, shard: int, fixed_log2_rows: int = -1,
                                  program_fixed_log2_rows: int = -1, blu: "ByteLookups" = None):
         """The Cpu trace and, from the same upload of the events, the Program chip's multiplicity trace
