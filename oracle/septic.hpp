@@ -1,4 +1,4 @@
-// TEST INFRASTRUCTURE ONLY (see oracle/README or DESIGN.md section 1): CPU restatement of the septic extension and curve behind the
+// TEST INFRASTRUCTURE ONLY (nothing shipped links or calls this): CPU restatement of the septic extension and curve behind the
 // reference's global lookups — F_{p^7} = F_p[z] / (z^7 + 2z - 8) (crates/stark/src/septic_extension.rs:1-16) and the curve
 // y^2 = x^3 + 3z x - 3 over it (crates/stark/src/septic_curve.rs:1-7, curve_formula :100-122, lift_x :126-154, add_incomplete :53-58,
 // sum_checker_x / _y :159-176, dummy point :18-38); is_receive / is_send / is_exception: septic_extension.rs:683-698. The algorithms are

@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
 """A coherent core shard end to end on the device: a program executed by ziren_amd/miniexec.py (the reference's executor is
 Rust and cannot run here) -> CpuEvents + per-chip events in pinned host memory -> device trace generation for Cpu, Program,
-the eleven instruction chips and Byte -> commit + open with the recorded AIRs (generated quotient kernels).
+the instruction chips, MemoryLocal, Global and Byte -> commit + open with the recorded AIRs (generated quotient kernels).
 
   python tools/bench_core_shard.py [--log-cycles 18] [--steps 3]
 
-MemoryLocal's messages to the Global chip (not built) have no receiver here, so the proof's cumulative sum is not zero — this
-tool measures; tests/test_cpu_shard.py verifies (with that side mirrored)."""
+Every lookup of the shard has both of its sides in real chips (the local cumulative sum is zero; the Global chip's curve sum is the
+proof's global_cumulative_sum); tests/test_cpu_shard.py verifies the same shard shape against the oracle."""
 import argparse
 import ctypes as C
 import json
@@ -59,7 +59,8 @@ def main():
                      ("divrem", pin(rec.divrem), chips.record_divrem_chip),
                      ("memory_instrs", pin(rec.mem_instr), chips.record_memory_instrs_chip),
                      ("syscall_instrs", pin(rec.syscall), chips.record_syscall_instrs_chip), ("misc_instrs", pin(rec.misc), chips.record_misc_instrs_chip),
-                     ("memory_local", pin(rec.memory_local), chips.record_memory_local_chip)]
+                     ("memory_local", pin(rec.memory_local), chips.record_memory_local_chip),
+                     ("global", pin(M.global_lookup_events(rec.memory_local)), chips.record_global_chip)]
             self.work = work
             self.heights = [log2_rows(-(-len(ev) // 4) if c == "memory_local" else len(ev)) for c, ev, _ in work]
             self.recs = [chips.record_chip(c, lh) if rc is None else rc(lh) for (c, _, rc), lh in zip(work, self.heights)]
@@ -95,6 +96,8 @@ def main():
                     born.append(ctx.tracegen_divrem(ev, lh, blu))
                 elif c == "memory_local":
                     born.append(ctx.tracegen_memory_local(ev, lh))
+                elif c == "global":
+                    born.append(ctx.tracegen_global(ev, lh, blu))
                 elif c == "memory_instrs":
                     born.append(ctx.tracegen_memory_instrs(ev, lh, blu))
                 elif c == "syscall_instrs":
@@ -142,7 +145,7 @@ def main():
     cells = sum((1 << c.log_height) * (c.main_width + 4 * c.perm_ext_width + 8) for c in recs)
     event_bytes = sum(len(ev) * ev.dtype.itemsize for _, ev, _ in work)
     print(json.dumps({"workload": f"CORE-{args.log_cycles}: 2^{args.log_cycles} executed instructions (Cpu rows) of a generated program; Cpu, Program, "
-                                  "AddSub, Bitwise, Lt, ShiftLeft, ShiftRight, CloClz, Mul, DivRem, Branch, Jump, MovCond, MemoryInstrs, SyscallInstrs, MiscInstrs, MemoryLocal, Byte",
+                                  "AddSub, Bitwise, Lt, ShiftLeft, ShiftRight, CloClz, Mul, DivRem, Branch, Jump, MovCond, MemoryInstrs, SyscallInstrs, MiscInstrs, MemoryLocal, Global, Byte",
                       "executor_seconds_python": round(exec_s, 1), "program_instructions": int(len(prog)), "event_bytes": int(event_bytes),
                       "tracegen_ms": round(float(np.mean([x["tracegen_ms"] for x in res])), 3),
                       "tracegen_kernel_ms": round(float(np.mean([x["tracegen_kernel_ms"] for x in res])), 3),

@@ -2,7 +2,7 @@
 // y^2 = x^3 + 3z x - 3 over it (crates/stark/src/septic_curve.rs) that the Global chip accumulates its messages on; every value in
 // Montgomery form. Frobenius is linear over F_p: x^p = sum_i x_i (z^i)^p with the six (z^i)^p in constant memory, computed once on
 // the host by exponentiation (upload_tables) — no tables copied from the reference. The square root follows the structure of
-// septic_extension.rs:260-290: n^((p+1)/2 (p + p^3 + p^5) + 1) squares to n Norm(n), divided by a root of Norm(n) found in F_p
+// septic_extension.rs:632-660: n^((p+1)/2 (p + p^3 + p^5) + 1) squares to n Norm(n), divided by a root of Norm(n) found in F_p
 // (Tonelli-Shanks, p - 1 = 2^24 * 127); the inverse is the product of the six conjugates over the norm.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -120,7 +120,7 @@ KB_HD S7 curve_formula(const S7& x) {   // x^3 + 3z x - 3
   r.c[0] = kb::sub(r.c[0], kb::to_monty(3));
   return r;
 }
-// SepticCurveComplete's addition (septic_curve.rs:245-283): the identity, opposite points and doubling are handled, which a parallel
+// SepticCurveComplete's addition (septic_curve.rs:198-216): the identity, opposite points and doubling are handled, which a parallel
 // scan needs (a partial sum may hold a message and its own removal)
 KB_HD Point add_complete(const Point& a, const Point& b, const FrobTable& tab) {
   if (a.inf) return b;
