@@ -504,6 +504,21 @@ int orc_tracegen_memory_instrs(const void* events, size_t n_events, int fixed_lo
   ORC_CATCH
 }
 
+// the machine-level check on the global digests (machine.rs:657-671): digests = n x 14 Montgomery words (x, y); out = their SepticDigest sum,
+// *is_zero = it equals the zero digest
+int orc_global_digest_sum(const uint32_t* digests, size_t n, uint32_t out[14], int* is_zero) {
+  ORC_TRY
+  std::vector<septic::Point> pts(n);
+  septic::Point zero;
+  for (int k = 0; k < 7; k++) { zero.x.c[k] = SEPTIC_START_X[k]; zero.y.c[k] = SEPTIC_START_Y[k]; }
+  for (size_t i = 0; i < n; i++)
+    for (int k = 0; k < 7; k++) { pts[i].x.c[k] = from_monty(digests[14 * i + k]); pts[i].y.c[k] = from_monty(digests[14 * i + 7 + k]); }
+  const septic::Point sum = septic::digest_sum(pts.data(), n, zero);
+  for (int k = 0; k < 7; k++) { out[k] = to_monty(sum.x.c[k]); out[7 + k] = to_monty(sum.y.c[k]); }
+  *is_zero = septic::s_eq(sum.x, zero.x) && septic::s_eq(sum.y, zero.y);
+  ORC_CATCH
+}
+
 // Global chip (GlobalLookupEvent, 32 bytes): 99 columns; byte_counts as for orc_tracegen_branch
 int orc_tracegen_global(const void* events, size_t n_events, int fixed_log2_rows, uint32_t* out, size_t out_cap, uint32_t* byte_counts) {
   ORC_TRY

@@ -117,4 +117,19 @@ static inline Point lift_x(const S7& m, uint8_t* offset) {
 static const uint32_t DUMMY_X[7] = {1706420302, 1319108093, 148224806, 26874985, 1766171812, 1645633948, 2028659224};
 static const uint32_t DUMMY_Y[7] = {942390502, 1239997438, 458866455, 1843332012, 1309764648, 572807436, 74267719};
 
+// SepticDigest's Sum (crates/stark/src/septic_digest.rs:60-76) and is_zero (:53-57): what Machine::verify evaluates over the shard
+// proofs' global_cumulative_sums and the key's initial one (crates/stark/src/machine.rs:657-671). Each digest carries the offset
+// `zero` (the cumulative-sum start point); the fold runs from a second fixed point so that no step adds equal x-coordinates.
+static const uint32_t DIGEST_SUM_START_X[7] = {1656788302, 897965284, 874620737, 1581672598, 655804282, 1962911564, 80580607};
+static const uint32_t DIGEST_SUM_START_Y[7] = {1024875409, 218609128, 1856341123, 583920580, 1274441611, 118766316, 81843042};
+static inline Point p_neg(const Point& a) { return Point{a.x, s_neg(a.y)}; }
+static inline Point digest_sum(const Point* digests, size_t n, const Point& zero) {
+  Point start;
+  for (int i = 0; i < 7; i++) { start.x.c[i] = DIGEST_SUM_START_X[i]; start.y.c[i] = DIGEST_SUM_START_Y[i]; }
+  Point acc = start;
+  for (size_t i = 0; i < n; i++) acc = add_incomplete(add_incomplete(acc, digests[i]), p_neg(zero));
+  acc = add_incomplete(acc, zero);
+  return add_incomplete(acc, p_neg(start));
+}
+
 }  // namespace septic

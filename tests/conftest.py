@@ -15,6 +15,7 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def oracle():
     import oracle_lib
+    oracle_lib.build()      # make: a no-op when liboracle.so is newer than its sources
     oracle_lib.lib()
     return oracle_lib
 

@@ -343,6 +343,15 @@ def tracegen_memory_instrs(events, fixed_log2_rows=-1, byte_counts=None):
     return out
 
 
+def global_digest_sum(digests):
+    """Machine::verify's check over global_cumulative_sums ((n, 14) Montgomery words): (their SepticDigest sum, is it the zero digest)."""
+    d = np.ascontiguousarray(digests, dtype=np.uint32).reshape(-1, 14)
+    out = np.zeros(14, dtype=np.uint32)
+    z = C.c_int(0)
+    _check(lib().orc_global_digest_sum(abi.as_u32p(d), C.c_size_t(len(d)), abi.as_u32p(out), C.byref(z)))
+    return out, bool(z.value)
+
+
 def tracegen_global(events, fixed_log2_rows=-1, byte_counts=None):
     """Global chip rows from GlobalLookupEvents; byte_counts as for tracegen_branch."""
     from ziren_amd import miniexec as M

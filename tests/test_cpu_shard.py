@@ -287,6 +287,32 @@ def test_global_constraints_hold(oracle):
         oracle.tracegen_global(bad_ev, -1)
 
 
+def complement(events):
+    """The other side of every message: what the shards (or MemoryGlobalInit / Finalize) at the far end of these lookups put on the
+    global table — same messages, opposite direction."""
+    out = events.copy()
+    out["is_receive"] ^= 1
+    return out
+
+
+def test_global_digests_of_both_sides_sum_to_zero(oracle):
+    """Machine::verify's last check (crates/stark/src/machine.rs:657-671): the shard proofs' global_cumulative_sums and the key's initial
+    one sum (SepticDigest::sum) to the zero digest exactly when every message is received as often as it is sent."""
+    prog, r, pv = M.run(400, seed=2, shard=SHARD, pc_base=PC_BASE, halt=True)
+    ge = M.global_lookup_events(r.memory_local)
+    zero = F.to_monty(np.array(chips.SEPTIC_START_X + chips.SEPTIC_START_Y, dtype=np.uint64))
+    here = oracle.tracegen_global(ge, -1)[-1, 85:]
+    far = complement(ge)
+    split = len(far) // 3                                         # the far side spread over two more shards, in another order
+    there = [oracle.tracegen_global(part[::-1], -1)[-1, 85:] for part in (far[:split], far[split:])]
+    assert oracle.global_digest_sum([here] + there + [zero])[1]
+    assert oracle.global_digest_sum([zero, zero])[1] and oracle.global_digest_sum([zero])[1]
+    assert not oracle.global_digest_sum([here, zero])[1] and not oracle.global_digest_sum([here, there[0], zero])[1]
+    far["message"][7, 3] ^= 1                                      # one value byte differs at the far end
+    there = [oracle.tracegen_global(part, -1)[-1, 85:] for part in (far[:split], far[split:])]
+    assert not oracle.global_digest_sum([here] + there + [zero])[1]
+
+
 def test_shard_lookups_balance(oracle):
     """Cpu sends every instruction the eleven chips receive, the Program table receives every fetch, the Byte table
     every byte lookup, MemoryLocal opens and closes every register's access chain and the Global chip receives its two messages
@@ -456,6 +482,15 @@ def test_gpu_coherent_shard_proof(hip_ctx, oracle, n_cycles):
     oproof, _ = oracle.prove_shard(opk, all_chips, [c.trace for c in all_chips], pvs, fri, synth.NUM_PV_ELTS, och)
     assert np.array_equal(proof, oproof)
     assert oracle.verify_shard(opk, all_chips, fri, synth.NUM_PV_ELTS, start.copy(), proof) == 0
+    # the machine-level check over global digests: this shard's (the last fourteen cells of the device-born Global trace = the proof's
+    # global_cumulative_sum) and that of a shard holding the far side of every message sum to the zero digest
+    gi = [c for c, _, _ in work].index("global")
+    here = born[gi].to_host()[-1, 85:]
+    assert np.array_equal(here, recs[gi].trace[-1, 85:]) and bytes(here) in bytes(proof)
+    far = hip_ctx.tracegen_global(complement(work[gi][1])[::-1].copy(), -1, blu)
+    zero = F.to_monty(np.array(chips.SEPTIC_START_X + chips.SEPTIC_START_Y, dtype=np.uint64))
+    assert oracle.global_digest_sum([here, far.to_host()[-1, 85:], zero])[1] and not oracle.global_digest_sum([here, zero])[1]
+    far.free()
     # a proof against a different claimed next_pc fails the Cpu chip's boundary constraint
     wrong = M.public_values(dict(pv, next_pc=pv["next_pc"] + 4))
     bad = hp.prove_shard(pk, wrong, born, start.copy()).copy()
