@@ -428,7 +428,7 @@ def test_gpu_cpu_and_program_tracegen_match_oracle(hip_ctx, oracle):
 def test_gpu_global_tracegen_matches_oracle(hip_ctx, oracle, n):
     """zkm_tracegen_global == the restated GlobalChip::generate_trace, bit for bit: lift_x (square roots in the septic extension),
     the sign by direction, the range-check witness, and the running sum through one, two and three levels of the device scan
-    (n + 1 <= 1024, <= 32768, above); the U16Range counts land in the shared byte-lookup table."""
+    (n + 1 <= 1024, <= 8192, above); the U16Range counts land in the shared byte-lookup table."""
     ev = random_global_events(n, 100 + n)
     want_counts = np.zeros((1 << 16, 10), dtype=np.uint32)
     want = oracle.tracegen_global(ev, -1, want_counts)

@@ -99,17 +99,18 @@ KB_HD uint32_t f_sqrt(uint32_t a) {   // a is a nonzero square; Tonelli-Shanks w
   }
   return r;
 }
-// a square root of n when it has one (n not in {0, 1}: lift_x skips those, their roots have y6 = 0)
-KB_HD bool s_sqrt(const S7& n, const FrobTable& tab, S7* out) {
+// n has a square root iff its norm is a nonzero square of F_p (n not in {0, 1}: lift_x skips those, their roots have y6 = 0)
+KB_HD bool s_is_square(const S7& n, const FrobTable& tab, uint32_t* norm) {
   S7 cj;
-  uint32_t norm;
-  s_norm(n, tab, &cj, &norm);
-  if (norm == 0 || !f_is_square(norm)) return false;
+  s_norm(n, tab, &cj, norm);
+  return *norm != 0 && f_is_square(*norm);
+}
+// a square root of n, which has one and whose norm is `norm`
+KB_HD S7 s_sqrt(const S7& n, uint32_t norm, const FrobTable& tab) {
   const S7 t = s_pow(n, (kb::P + 1) / 2);
   const S7 f1 = s_frob(t, tab), f3 = s_frob(s_frob(f1, tab), tab), f5 = s_frob(s_frob(f3, tab), tab);
   const S7 d = s_mul(s_mul(s_mul(f1, f3), f5), n);
-  *out = s_scale(d, f_sqrt(kb::inv(norm)));
-  return true;
+  return s_scale(d, f_sqrt(kb::inv(norm)));
 }
 
 struct Point { S7 x, y; uint32_t inf; };
@@ -148,15 +149,23 @@ KB_HD S7 sum_checker_x(const Point& p1, const Point& p2, const Point& p3) {   //
 }
 // SepticCurve::lift_x (septic_curve.rs:126-154): the first offset in 0..255 whose x = (m0, .., m5, 256 m6 + offset) carries a point
 // with y6 != 0; y in the half 1 <= y6 <= (p - 1) / 2 (the "receive" sign). false: no offset works (probability 2^-256).
+// The search for the offset (a norm and an Euler criterion per candidate) runs first and the one square root after it: lanes of a
+// wave need different numbers of candidates, and a root taken inside the search loop would be serialised once per distinct count.
 KB_HD bool lift_x(const S7& m, const FrobTable& tab, Point* out, uint32_t* offset) {
   const uint32_t m6 = kb::mul(m.c[6], kb::to_monty(256));
-  for (uint32_t off = 0; off < 256; off++) {
-    S7 x = m;
-    x.c[6] = kb::add(m6, kb::to_monty(off));
-    S7 y;
-    if (!s_sqrt(curve_formula(x), tab, &y)) continue;
+  uint32_t off = 0;
+  while (off < 256) {
+    S7 x = m, n;
+    uint32_t norm = 0;
+    for (; off < 256; off++) {
+      x.c[6] = kb::add(m6, kb::to_monty(off));
+      n = curve_formula(x);
+      if (s_is_square(n, tab, &norm)) break;
+    }
+    if (off == 256) return false;
+    S7 y = s_sqrt(n, norm, tab);
     const uint32_t y6 = kb::from_monty(y.c[6]);
-    if (y6 == 0) continue;
+    if (y6 == 0) { off++; continue; }   // is_exception (septic_extension.rs:696): next candidate
     if (y6 >= (kb::P + 1) / 2) y = s_neg(y);
     out->x = x; out->y = y; out->inf = 0;
     *offset = off;

@@ -1195,10 +1195,10 @@ __global__ void byte_table(uint32_t* out) {
 // bytes of the eighth), 99 columns (:54-64). Three steps: (1) global_point_rows — one thread per row maps its message to a curve point
 // (GlobalLookupOperation::populate, operations/global_lookup.rs:26-92), writes columns 0..63 and the point into a scan buffer whose
 // element 0 is the start digest; (2) an inclusive scan of that buffer under the curve's complete addition (the reference's parallel
-// scan, mod.rs:163-167) — chunks of SCAN_CHUNK per thread, the chunk sums scanned recursively, one block at the top; (3)
+// scan, mod.rs:163-167) — short chunks of SCAN_CHUNK per thread (an addition is ~800 dependent multiplications: threads, not long chunks), the chunk sums scanned recursively, one block at the top; (3)
 // global_accum_rows — columns 64..98 from the prefix sums (operations/global_accumulation.rs:75-113). Byte lookups: U16Range(message[0])
 // per event (mod.rs:75-95): message[0] is the shard number, one or two distinct values, so each wave adds its leader's count once.
-constexpr int GLOBAL_WIDTH = 99, SCAN_CHUNK = 32, SCAN_BLOCK = 1024, POINT_WORDS = 16;
+constexpr int GLOBAL_WIDTH = 99, SCAN_CHUNK = 8, SCAN_BLOCK = 1024, POINT_WORDS = 16;
 namespace globalcols {
 enum { MESSAGE = 0, KIND = 7, OFFSET_BITS = 8, X = 16, Y = 23, Y6_BITS = 30, RC_WITNESS = 60, IS_RECEIVE = 61, IS_SEND = 62, IS_REAL = 63,
        INITIAL = 64, SUM_CHECKER = 78, CUMULATIVE = 85 };
