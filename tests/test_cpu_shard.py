@@ -452,6 +452,35 @@ def test_gpu_global_tracegen_matches_oracle(hip_ctx, oracle, n):
 
 
 @pytest.mark.gpu
+def test_gpu_global_digest_is_order_independent_at_full_size(hip_ctx, oracle):
+    """2^20 messages (no oracle at this size): the final digest does not depend on the order of the events, both directions of the same
+    messages cancel in the machine-level sum, every row's running sum hands over to the next row, and the byte table holds one U16Range
+    count per event."""
+    n = 1 << 20
+    ev = random_global_events(n, 77)
+    blu = hip_ctx.byte_lookups()
+    a = hip_ctx.tracegen_global(ev, -1, blu)
+    b = hip_ctx.tracegen_global(ev[np.random.default_rng(3).permutation(n)], -1, blu)
+    c = hip_ctx.tracegen_global(complement(ev)[::-1].copy(), -1, blu)
+    ta, tb, tc = a.to_host(), b.to_host(), c.to_host()
+    assert np.array_equal(ta[-1, 85:], tb[-1, 85:]) and not np.array_equal(ta[n // 2, 85:], tb[n // 2, 85:])
+    assert np.array_equal(ta[:-1, 85:], ta[1:, 64:78]) and not ta[:, 78:85].any()      # cumulative_sum -> next initial_digest; sum_checker 0 on real rows
+    zero = F.to_monty(np.array(chips.SEPTIC_START_X + chips.SEPTIC_START_Y, dtype=np.uint64))
+    assert np.array_equal(ta[0, 64:78], zero.astype(np.uint32))
+    assert oracle.global_digest_sum([ta[-1, 85:], tc[-1, 85:], zero])[1] and not oracle.global_digest_sum([ta[-1, 85:], tb[-1, 85:], zero])[1]
+    mults = hip_ctx.tracegen_byte_mults(blu)
+    counts = F.from_monty(mults.to_host())
+    assert int(counts[:, 8].sum()) == 3 * n and int(counts.sum()) == 3 * n
+    # spot-check rows against the oracle: the point of an event does not depend on its neighbours
+    pick = np.array([0, 1, 12345, n - 1])
+    want = oracle.tracegen_global(ev[pick], -1)
+    assert np.array_equal(ta[pick][:, :64], want[:len(pick), :64])
+    for m in (a, b, c, mults):
+        m.free()
+    blu.free()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("n_cycles", [40, 6000])
 def test_gpu_coherent_shard_proof(hip_ctx, oracle, n_cycles):
     """Cpu + Program + the eleven instruction chips + Byte over one executed program: every trace and both preprocessed
