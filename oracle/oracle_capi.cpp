@@ -504,6 +504,27 @@ int orc_tracegen_memory_instrs(const void* events, size_t n_events, int fixed_lo
   ORC_CATCH
 }
 
+// septic extension known answers: out[0..42) = (z^i)^p, out[42..84) = (z^i)^(p^2), i = 1..6 (canonical), by exponentiation; out[84..91) = a * b
+// and out[91..98) = the square root of a^2 normalised to y6 <= (p - 1) / 2 (0 when the root's last coefficient is 0), for canonical a, b
+int orc_septic_known_answers(const uint32_t a[7], const uint32_t b[7], uint32_t out[98]) {
+  ORC_TRY
+  septic::S7 z = septic::s_zero(), x, y;
+  z.c[1] = 1;
+  septic::S7 zi = z;
+  for (int i = 0; i < 6; i++) {
+    const septic::S7 f = septic::s_frob(zi), f2 = septic::s_frob(f);
+    for (int k = 0; k < 7; k++) { out[7 * i + k] = f.c[k]; out[42 + 7 * i + k] = f2.c[k]; }
+    zi = septic::s_mul(zi, z);
+  }
+  for (int k = 0; k < 7; k++) { x.c[k] = a[k] % P; y.c[k] = b[k] % P; }
+  const septic::S7 prod = septic::s_mul(x, y);
+  septic::S7 root;
+  if (!septic::s_sqrt(septic::s_mul(x, x), &root)) throw std::runtime_error("septic: a square has no root");
+  if (root.c[6] >= (P + 1) / 2) root = septic::s_neg(root);
+  for (int k = 0; k < 7; k++) { out[84 + k] = prod.c[k]; out[91 + k] = root.c[k]; }
+  ORC_CATCH
+}
+
 // the machine-level check on the global digests (machine.rs:657-671): digests = n x 14 Montgomery words (x, y); out = their SepticDigest sum,
 // *is_zero = it equals the zero digest
 int orc_global_digest_sum(const uint32_t* digests, size_t n, uint32_t out[14], int* is_zero) {

@@ -343,6 +343,15 @@ def tracegen_memory_instrs(events, fixed_log2_rows=-1, byte_counts=None):
     return out
 
 
+def septic_known_answers(a, b):
+    """((z^i)^p, (z^i)^(p^2) for i = 1..6, a * b, normalised sqrt(a^2)) in the septic extension, canonical words."""
+    a = np.ascontiguousarray(a, dtype=np.uint32)
+    b = np.ascontiguousarray(b, dtype=np.uint32)
+    out = np.zeros(98, dtype=np.uint32)
+    _check(lib().orc_septic_known_answers(abi.as_u32p(a), abi.as_u32p(b), abi.as_u32p(out)))
+    return out[:42].reshape(6, 7), out[42:84].reshape(6, 7), out[84:91], out[91:]
+
+
 def global_digest_sum(digests):
     """Machine::verify's check over global_cumulative_sums ((n, 14) Montgomery words): (their SepticDigest sum, is it the zero digest)."""
     d = np.ascontiguousarray(digests, dtype=np.uint32).reshape(-1, 14)

@@ -251,6 +251,42 @@ def random_global_events(n, seed):
     return ev
 
 
+def test_septic_arithmetic_matches_the_reference_tables(oracle):
+    """The oracle computes Frobenius by exponentiation; the reference keeps (z^i)^p and (z^i)^(p^2) as tables (tests/golden/septic_frobenius.json,
+    copied by gen_septic_frobenius.py). Equal tables pin the reduction polynomial and the product; the square root is checked against
+    an independent Python product."""
+    import json, os
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "septic_frobenius.json")))
+    rng = np.random.default_rng(4)
+    a, b = rng.integers(0, F.P, size=7), rng.integers(0, F.P, size=7)
+    fp, fp2, prod, root = oracle.septic_known_answers(a, b)
+    assert fp.tolist() == gold["z_pow_p"] and fp2.tolist() == gold["z_pow_p2"]
+
+    def mul(x, y):     # schoolbook product modulo z^7 = 8 - 2z, Python integers
+        t = [0] * 13
+        for i in range(7):
+            for j in range(7):
+                t[i + j] += int(x[i]) * int(y[j])
+        for k in range(12, 6, -1):
+            t[k - 7] += 8 * t[k]
+            t[k - 6] -= 2 * t[k]
+        return [v % F.P for v in t[:7]]
+    assert prod.tolist() == mul(a, b)
+    assert mul(root, root) == mul(a, a) and 0 < root[6] <= (F.P - 1) // 2
+    assert root.tolist() in ([int(v) for v in a], [(F.P - int(v)) % F.P for v in a])
+    # Frobenius is the p-th power: applying the table's linear map to a equals a^p computed through the product (p = 2^31 - 2^24 + 1)
+    frob = [int(a[0])] + [0] * 6
+    for i in range(1, 7):
+        frob = [(f + int(a[i]) * g) % F.P for f, g in zip(frob, gold["z_pow_p"][i - 1])]
+    acc, base, e = [1] + [0] * 6, [int(v) for v in a], F.P
+    while e:
+        if e & 1:
+            acc = mul(acc, base)
+        base = mul(base, base)
+        e >>= 1
+    assert acc == frob
+
+
 def test_global_constraints_hold(oracle):
     """The Global chip: rows built by the restated generate_trace satisfy the recorded AIR (message -> curve point, sign of y by
     direction, running sum from the start digest); the shard's digest does not depend on the order of the messages; cost pinned."""
