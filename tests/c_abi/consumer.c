@@ -2,7 +2,8 @@
  * tests/test_host_abi.py with gcc against the header and linked to libzkm_hip.so.
  *
  *   consumer            no GPU expected: zkm_ctx_create must fail loudly (no CPU fallback) -> exit 0 and print the message
- *   consumer gpu        on a GPU: an AddSub event (5 + 7 = 12) -> device trace -> one-matrix commitment; prints "ok <root word>" */
+ *   consumer gpu        on a GPU: an AddSub event (5 + 7 = 12) -> device trace -> one-matrix commitment; prints "ok <root word>", then two
+ *                       GlobalLookupEvents -> the Global chip's trace; prints "global <the fourteen words of the shard's digest>" */
 #include <stdio.h>
 #include <string.h>
 #include "zkm_hip.h"
@@ -35,6 +36,26 @@ int main(int argc, char** argv) {
   printf("ok %u\n", root[0]);
   zkm_pcs_data_free(ctx, data);
   zkm_matrix_free(ctx, trace);
+  /* a register's access chain through one shard: received as the previous shard left it, sent as this one leaves it */
+  zkm_global_lookup_event ge[2];
+  memset(ge, 0, sizeof ge);
+  ge[0].message[0] = 0; ge[0].message[1] = 0; ge[0].message[2] = 8; ge[0].is_receive = 1; ge[0].kind = 1;
+  ge[1].message[0] = 1; ge[1].message[1] = 4003; ge[1].message[2] = 8; ge[1].message[3] = 12; ge[1].is_receive = 0; ge[1].kind = 1;
+  zkm_byte_lookups* blu = NULL;
+  if (zkm_byte_lookups_create(ctx, &blu) != 0) { printf("blu: %s\n", zkm_last_error()); return 9; }
+  zkm_matrix* global = NULL;
+  if (zkm_tracegen_global(ctx, ge, 2, -1, blu, &global) != 0) { printf("global: %s\n", zkm_last_error()); return 10; }
+  if (zkm_matrix_height(global) != 16 || zkm_matrix_width(global) != ZKM_GLOBAL_WIDTH) return 11;
+  static uint32_t grows[16 * ZKM_GLOBAL_WIDTH];
+  if (zkm_matrix_download(ctx, global, grows) != 0) return 12;
+  printf("global");
+  for (int k = 0; k < 14; k++) printf(" %u", grows[15 * ZKM_GLOBAL_WIDTH + 85 + k]);
+  printf("\n");
+  ge[1].message[0] = 1u << 16;   /* not a u16: refused, with a message */
+  zkm_matrix* none = NULL;
+  if (zkm_tracegen_global(ctx, ge, 2, -1, blu, &none) == 0 || !strstr(zkm_last_error(), "not a u16")) return 13;
+  zkm_matrix_free(ctx, global);
+  zkm_byte_lookups_free(ctx, blu);
   zkm_ctx_destroy(ctx);
   return 0;
 }

@@ -53,6 +53,14 @@ def test_gpu_plain_c_consumer(tmp_path, hip_ctx, oracle):
     ev = E.make_alu_events([E.ADD], [5], [7], pc0=0x1000)
     want = oracle.pcs_commit([oracle.tracegen_alu(E.CHIP_ADD_SUB, ev)], 1)[0]
     assert int(out.stdout.split()[1]) == int(want[0])
+    # ... and two GlobalLookupEvents -> the Global chip's trace: the digest the C program printed is the oracle's
+    from ziren_amd import miniexec as M
+    ge = np.zeros(2, dtype=M.GLOBAL_LOOKUP_EVENT)
+    ge["message"][0, :3] = [0, 0, 8]
+    ge["message"][1, :4] = [1, 4003, 8, 12]
+    ge["is_receive"], ge["kind"] = [1, 0], 1
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith("global ")][0]
+    assert [int(w) for w in line.split()[1:]] == oracle.tracegen_global(ge, -1)[-1, 85:].tolist()
 
 
 def test_no_gpu_means_loud_failure():
