@@ -457,6 +457,9 @@ int zkm_tracegen_flat(zkm_ctx* ctx, const uint32_t* words, size_t n_words, size_
 /* Poseidon2 width-16 permutation on n states (n x 16 words, in place), on the GPU.
  * zkm_primitives::poseidon2_init, crates/primitives/src/lib.rs:1107-1122. */
 int zkm_poseidon2_permute_batch(zkm_ctx* ctx, uint32_t* states, size_t n);
+/* The same permutation through the integer-pipe formulation (what the lane-parallel kernels near a tree's root
+ * compute with); the entry point above runs the FP64-pipe formulation every hashing kernel uses. */
+int zkm_poseidon2_permute_batch_int(zkm_ctx* ctx, uint32_t* states, size_t n);
 /* Radix2Dit::coset_lde_batch + bit_reverse_rows on a host matrix:
  * out is (height << log_blowup) x width row-major. lde_shift multiplies the evaluation coset
  * (Pcs::commit passes GENERATOR / domain_shift). */
@@ -467,6 +470,18 @@ void zkm_challenger_init(zkm_challenger* c);
 void zkm_challenger_observe(zkm_challenger* c, const uint32_t* values, size_t n);
 uint32_t zkm_challenger_sample(zkm_challenger* c);
 uint32_t zkm_challenger_sample_bits(zkm_challenger* c, uint32_t bits);
+
+/* ---- host-side arithmetic of the transcript layer (no GPU needed; CPU-only parity tests) --
+ * The duplex challenger above permutes with zkm_host_poseidon2_permute (integer formulation);
+ * zkm_host_poseidon2_permute_f64 is the host build of the FP64 formulation the GPU hashing kernels run
+ * (same IEEE operations), so its exactness can be checked without a GPU. Words are Montgomery form. */
+void zkm_host_poseidon2_permute(uint32_t state[16]);
+void zkm_host_poseidon2_permute_f64(uint32_t state[16]);
+void zkm_host_ext_mul(const uint32_t a[4], const uint32_t b[4], uint32_t out[4]);
+void zkm_host_ext_inv(const uint32_t a[4], uint32_t out[4]);
+uint32_t zkm_host_field_mul(uint32_t a, uint32_t b);
+uint32_t zkm_host_field_inv(uint32_t a);
+uint32_t zkm_host_two_adic_generator(uint32_t bits);
 
 #ifdef __cplusplus
 }

@@ -20,6 +20,7 @@ def test_poseidon2_batch(hip_ctx, oracle):
     st[0] = 0
     st[1] = F.to_monty(P - 1)
     assert np.array_equal(prover.poseidon2_permute_batch(hip_ctx, st), oracle.poseidon2_permute_batch(st))
+    assert np.array_equal(prover.poseidon2_permute_batch_int(hip_ctx, st), oracle.poseidon2_permute_batch(st))
 
 
 def test_poseidon2_extreme_states(hip_ctx, oracle):
@@ -34,6 +35,14 @@ def test_poseidon2_extreme_states(hip_ctx, oracle):
         canon.append(v)
         canon.append(np.where(np.arange(16) == k, 0, P - 1))
     st = F.to_monty(np.array(canon, dtype=np.uint64))
+    assert np.array_equal(prover.poseidon2_permute_batch(hip_ctx, st), oracle.poseidon2_permute_batch(st))
+    assert np.array_equal(prover.poseidon2_permute_batch_int(hip_ctx, st), oracle.poseidon2_permute_batch(st))
+    # the FP64 formulation (exact integers in doubles): values whose squares / cubes sit next to rounding boundaries of the
+    # two-product, i.e. powers of two +- 1, p/2 +- small, and Montgomery words whose canonical value is tiny
+    edge = [(1 << k) + d for k in range(8, 31) for d in (-1, 0, 1)] + [(P - 1) // 2 + d for d in range(-3, 4)] + [P - 1 - d for d in range(8)]
+    rng = np.random.default_rng(11)
+    sel = rng.integers(0, len(edge), (50000, 16))
+    st = F.to_monty(np.array(edge, dtype=np.uint64)[sel] % P)
     assert np.array_equal(prover.poseidon2_permute_batch(hip_ctx, st), oracle.poseidon2_permute_batch(st))
     big = rand(np.random.default_rng(7), (1 << 20, 16))
     g, o = big, big

@@ -4,6 +4,7 @@ duplex challenger) matches the canonical-arithmetic oracle."""
 import ctypes as C
 import os
 import re
+import subprocess
 
 import numpy as np
 import pytest
@@ -20,6 +21,10 @@ def test_library_exports_every_declared_symbol():
     declared = set(re.findall(r"\b(zkm_[a-z0-9_]+)\s*\(", hdr))
     assert declared, "no declarations parsed"
     assert declared == set(lib.EXPORTS)
+    # ... and the library exports nothing beyond the header (dynamic symbol table of the built .so)
+    out = subprocess.run(["nm", "-D", "--defined-only", lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = {ln.split()[-1] for ln in out.splitlines() if ln.split()[-1].startswith("zkm_")}
+    assert exported == declared, (sorted(exported - declared), sorted(declared - exported))
     for name in declared:
         assert hasattr(L, name), name
 
@@ -110,6 +115,32 @@ def test_host_field_ext_poseidon2_match_oracle(oracle):
         s = (C.c_uint32 * 16)(*map(int, ext[i]))
         L.zkm_host_poseidon2_permute(s)
         assert list(s) == list(map(int, exp[i]))
+
+
+def test_fp64_poseidon2_formulation_is_exact(oracle):
+    """The hashing kernels run Poseidon2 on the FP64 pipe (csrc/poseidon2_f64.cuh): exact integers in doubles, two-product +
+    Barrett quotient. This is the host build of the same code (same IEEE operations: fma, round-to-nearest-even), against
+    the oracle's canonical `% p` permutation: random states, states made of values next to the rounding boundaries of the
+    products, and long chains (the output of one permutation feeding the next)."""
+    L = lib.load()
+    P = F.P
+    rng = np.random.default_rng(5)
+    edge = [0, 1, 2, 3, P - 1, P - 2, (P - 1) // 2, (P + 1) // 2, (P - 3) // 2] + [(1 << k) + d for k in range(10, 31) for d in (-1, 0, 1)]
+    edge = np.array(edge, dtype=np.uint64) % P
+    canon = np.concatenate([rng.integers(0, P, (3000, 16), dtype=np.uint64), edge[rng.integers(0, len(edge), (3000, 16))],
+                            np.full((1, 16), P - 1, dtype=np.uint64), np.zeros((1, 16), dtype=np.uint64)])
+    st = F.to_monty(canon)
+    exp = oracle.poseidon2_permute_batch(st)
+    got = st.copy()
+    for i in range(len(got)):
+        L.zkm_host_poseidon2_permute_f64(got[i].ctypes.data_as(C.POINTER(C.c_uint32)))
+    assert np.array_equal(got, exp)
+    chain_g, chain_o = st[:64].copy(), st[:64].copy()
+    for _ in range(20):
+        for i in range(64):
+            L.zkm_host_poseidon2_permute_f64(chain_g[i].ctypes.data_as(C.POINTER(C.c_uint32)))
+        chain_o = oracle.poseidon2_permute_batch(chain_o)
+    assert np.array_equal(chain_g, chain_o)
 
 
 def test_challenger_matches_oracle(oracle):

@@ -14,7 +14,8 @@ template <int OP>
 __global__ void bench(uint32_t* out, uint32_t seed) {
   uint32_t a[ILP], b = seed | 1;
   uint64_t w[ILP];
-  for (int i = 0; i < ILP; i++) { a[i] = threadIdx.x * 2654435761u + i * 40503u + seed; w[i] = a[i]; }
+  double f[ILP]; double g = (double)(seed | 1) * 1.0000001;
+  for (int i = 0; i < ILP; i++) { a[i] = threadIdx.x * 2654435761u + i * 40503u + seed; w[i] = a[i]; f[i] = (double)a[i]; }
   for (int it = 0; it < ITERS; it++) {
 #pragma unroll
     for (int i = 0; i < ILP; i++) {
@@ -54,11 +55,36 @@ __global__ void bench(uint32_t* out, uint32_t seed) {
       if (OP == 34) asm volatile("v_mad_i64_i32 %0, vcc, %1, 1, %0" : "+v"(w[i]) : "v"(a[i]) : "vcc");
       if (OP == 35) asm volatile("v_mad_u64_u32 %0, vcc, %1, 1, %0" : "+v"(w[i]) : "v"(a[i]) : "vcc");
       if (OP == 36) asm volatile("v_lshl_add_u64 %0, %0, 0, %1" : "+v"(w[i]) : "v"(w[(i+1)%ILP]));
+
+      if (OP == 40) asm volatile("v_add_f64 %0, %0, %1" : "+v"(f[i]) : "v"(g));
+      if (OP == 41) asm volatile("v_mul_f64 %0, %0, %1" : "+v"(f[i]) : "v"(g));
+      if (OP == 42) asm volatile("v_fma_f64 %0, %0, %1, %0" : "+v"(f[i]) : "v"(g));
+      if (OP == 43) asm volatile("v_rndne_f64 %0, %0" : "+v"(f[i]));
+      if (OP == 44) { uint32_t t; asm volatile("v_cvt_i32_f64 %0, %1" : "=v"(t) : "v"(f[i])); a[i] ^= t; }
+      if (OP == 45) asm volatile("v_cvt_f64_i32 %0, %1" : "=v"(f[i]) : "v"(a[i]));
+      if (OP == 46) asm volatile("v_cvt_f64_u32 %0, %1" : "=v"(f[i]) : "v"(a[i]));
+      if (OP == 47) asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(f[i]) : "v"(g), "v"(f[(i+1)%ILP]));
+      if (OP == 48) asm volatile("v_add_f64 %0, %0, %1" : "+v"(f[i]) : "s"(g));
+      if (OP == 49) asm volatile("v_trunc_f64 %0, %0" : "+v"(f[i]));
+      if (OP == 50) asm volatile("v_pk_add_u16 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+      if (OP == 51) asm volatile("v_pk_fma_f32 %0, %0, %1, %0" : "+v"(w[i]) : "v"(w[(i+1)%ILP]));
+      if (OP == 52) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(w[i]) : "v"(w[(i+1)%ILP]));
+      if (OP == 53) asm volatile("v_dot4_u32_u8 %0, %0, %1, %0" : "+v"(a[i]) : "v"(b));
+      if (OP == 54) asm volatile("v_ashrrev_i32 %0, 3, %0" : "+v"(a[i]));
+      if (OP == 55) asm volatile("v_bfe_u32 %0, %0, 3, 9" : "+v"(a[i]));
+      if (OP == 56) asm volatile("v_perm_b32 %0, %0, %1, %1" : "+v"(a[i]) : "v"(b));
+      if (OP == 57) asm volatile("v_mul_i32_i24 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+      if (OP == 58) asm volatile("v_ldexp_f64 %0, %0, 3" : "+v"(f[i]));
+      if (OP == 59) asm volatile("v_mov_b32 %0, %1" : "+v"(a[i]) : "v"(a[(i+1)%ILP]));
+      if (OP == 60) asm volatile("v_or_b32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+      if (OP == 61) asm volatile("v_addc_co_u32 %0, vcc, %0, %1, vcc" : "+v"(a[i]) : "v"(b) : "vcc");
+      if (OP == 62) asm volatile("v_min_f64 %0, %0, %1" : "+v"(f[i]) : "v"(g));
+      //if (OP == 63) asm volatile("v_add_nc_u32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
       if (OP == 27) asm volatile("v_mul_lo_u32 %0, %0, %1\n v_add_u32 %2, %2, %1" : "+v"(a[i]), "+v"(b) , "+v"(a[(i+1)%ILP]):);
     }
   }
   uint32_t r = 0;
-  for (int i = 0; i < ILP; i++) r += a[i] + (uint32_t)w[i] + (uint32_t)(w[i] >> 32);
+  for (int i = 0; i < ILP; i++) r += a[i] + (uint32_t)w[i] + (uint32_t)(w[i] >> 32) + (uint32_t)(long long)f[i];
   out[blockIdx.x * blockDim.x + threadIdx.x] = r;
 }
 
@@ -121,6 +147,29 @@ int main() {
   run<34>("v_mad_i64_i32 x*1+acc", d);
   run<35>("v_mad_u64_u32 x*1+acc", d);
   run<36>("v_lshl_add_u64", d);
+  run<40>("v_add_f64", d);
+  run<41>("v_mul_f64", d);
+  run<42>("v_fma_f64", d);
+  run<47>("v_fma_f64 3src", d);
+  run<48>("v_add_f64 sgpr", d);
+  run<43>("v_rndne_f64", d);
+  run<49>("v_trunc_f64", d);
+  run<44>("v_cvt_i32_f64", d);
+  run<45>("v_cvt_f64_i32", d);
+  run<46>("v_cvt_f64_u32", d);
+  run<58>("v_ldexp_f64", d);
+  run<62>("v_min_f64", d);
+  run<50>("v_pk_add_u16", d);
+  run<51>("v_pk_fma_f32", d);
+  run<52>("v_pk_add_f32", d);
+  run<53>("v_dot4_u32_u8", d);
+  run<54>("v_ashrrev_i32", d);
+  run<55>("v_bfe_u32", d);
+  run<56>("v_perm_b32", d);
+  run<57>("v_mul_i32_i24", d);
+  run<59>("v_mov_b32", d);
+  run<60>("v_or_b32", d);
+  run<61>("v_addc_co_u32", d);
   run<0>("v_add_u32 (again)", d);
   run<7>("v_min_u32 (again)", d);
   return 0;

@@ -21,7 +21,7 @@ def build(force=False, verbose=False):
     if not force and not needs_build():
         return OUT
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wl,-rpath,/opt/rocm/lib",
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17", "-fPIC", "-shared", "-Wl,-rpath,/opt/rocm/lib",
            SRC, "-o", OUT]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)

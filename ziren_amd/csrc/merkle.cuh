@@ -7,36 +7,41 @@
 //   parent      = Poseidon2(left || right)[0..8]
 //   when a layer's length equals a shorter matrix's height: node = compress(node, hash(rows))
 //
-// One thread owns one row / one node: the 16-word sponge state stays in VGPRs, and because the
-// matrices are column-major, lane l of a wavefront reads word (column, r0 + l) — every column
-// read is one coalesced 256-byte transaction. Digests are stored as 8 consecutive words.
+// One thread owns one row / one node: the 16-word sponge state stays in VGPRs — as sixteen doubles, the permutation
+// runs on the FP64 vector pipe (poseidon2_f64.cuh) — and because the matrices are column-major, lane l of a wavefront
+// reads word (column, r0 + l): every column read is one coalesced 256-byte transaction. Words are converted on the way in
+// (Montgomery word -> canonical double) and digests on the way out; they are stored as 8 consecutive Montgomery words.
 #pragma once
-#include "poseidon2.cuh"
+#include "poseidon2_f64.cuh"
 
 namespace merkle {
 
 constexpr int THREADS = 256;
 
 // Absorb `width` columns (colptrs[g][row]) into the sponge state, 8 per permutation.
-__device__ __forceinline__ void absorb_row(uint32_t s[16], const uint32_t* const* __restrict__ colptrs, int width, size_t row) {
+__device__ __forceinline__ void absorb_row(double s[16], const uint32_t* const* __restrict__ colptrs, int width, size_t row) {
   for (int g0 = 0; g0 < width; g0 += 8) {
+    uint32_t w[8];
 #pragma unroll
     for (int i = 0; i < 8; i++)
-      if (g0 + i < width) s[i] = colptrs[g0 + i][row];
-    p2::permute(s);
+      if (g0 + i < width) w[i] = colptrs[g0 + i][row];
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+      if (g0 + i < width) s[i] = p2f::load_monty(w[i]);
+    p2f::permute(s);
   }
 }
 
-__device__ __forceinline__ void store_digest(uint32_t* dst, const uint32_t s[16]) {
+__device__ __forceinline__ void store_digest(uint32_t* dst, const double s[16]) {
   uint4* d = reinterpret_cast<uint4*>(dst);
-  d[0] = make_uint4(s[0], s[1], s[2], s[3]);
-  d[1] = make_uint4(s[4], s[5], s[6], s[7]);
+  d[0] = make_uint4(p2f::store_monty(s[0]), p2f::store_monty(s[1]), p2f::store_monty(s[2]), p2f::store_monty(s[3]));
+  d[1] = make_uint4(p2f::store_monty(s[4]), p2f::store_monty(s[5]), p2f::store_monty(s[6]), p2f::store_monty(s[7]));
 }
-__device__ __forceinline__ void load_digest(uint32_t s[8], const uint32_t* src) {
+__device__ __forceinline__ void load_digest(double s[8], const uint32_t* src) {
   const uint4* p = reinterpret_cast<const uint4*>(src);
   uint4 a = p[0], b = p[1];
-  s[0] = a.x; s[1] = a.y; s[2] = a.z; s[3] = a.w;
-  s[4] = b.x; s[5] = b.y; s[6] = b.z; s[7] = b.w;
+  s[0] = p2f::load_monty(a.x); s[1] = p2f::load_monty(a.y); s[2] = p2f::load_monty(a.z); s[3] = p2f::load_monty(a.w);
+  s[4] = p2f::load_monty(b.x); s[5] = p2f::load_monty(b.y); s[6] = p2f::load_monty(b.z); s[7] = p2f::load_monty(b.w);
 }
 
 // layer 0: digests[r] = hash(row r of all tallest matrices)
@@ -44,9 +49,9 @@ __global__ __launch_bounds__(THREADS) void hash_leaves(const uint32_t* const* __
                                                        uint32_t* __restrict__ digests) {
   size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= height) return;
-  uint32_t s[16];
+  double s[16];
 #pragma unroll
-  for (int i = 0; i < 16; i++) s[i] = 0;
+  for (int i = 0; i < 16; i++) s[i] = 0.0;
   absorb_row(s, colptrs, width, r);
   store_digest(digests + r * 8, s);
 }
@@ -56,18 +61,18 @@ __global__ __launch_bounds__(THREADS) void compress_layer(const uint32_t* __rest
                                                           const uint32_t* const* __restrict__ inject_cols, int inject_width) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= m) return;
-  uint32_t s[16];
+  double s[16];
   load_digest(s, prev + 16 * i);
   load_digest(s + 8, prev + 16 * i + 8);
-  p2::permute(s);
+  p2f::permute(s);
   if (inject_width > 0) {
-    uint32_t h[16];
+    double h[16];
 #pragma unroll
-    for (int k = 0; k < 16; k++) h[k] = 0;
+    for (int k = 0; k < 16; k++) h[k] = 0.0;
     absorb_row(h, inject_cols, inject_width, i);
 #pragma unroll
-    for (int k = 0; k < 8; k++) s[8 + k] = h[k];
-    p2::permute(s);
+    for (int k = 0; k < 8; k++) s[8 + k] = h[k];  // both halves stay unreduced doubles (|.| < 2^35.3: permute's input bound)
+    p2f::permute(s);
   }
   store_digest(next + 8 * i, s);
 }
@@ -80,10 +85,10 @@ __global__ __launch_bounds__(THREADS) void compress_tail(uint32_t* __restrict__ 
   uint32_t* nx = prev + 16 * len0;
   for (size_t len = len0; len >= 1; len >>= 1) {
     for (size_t i = threadIdx.x; i < len; i += blockDim.x) {
-      uint32_t s[16];
+      double s[16];
       load_digest(s, p + 16 * i);
       load_digest(s + 8, p + 16 * i + 8);
-      p2::permute(s);
+      p2f::permute(s);
       store_digest(nx + 8 * i, s);
     }
     __syncthreads();
@@ -185,18 +190,37 @@ __global__ __launch_bounds__(1024) void compress_tail_lanes(uint32_t* __restrict
 __global__ __launch_bounds__(THREADS) void hash_fri_leaves(const kb::E4* __restrict__ f, size_t m, uint32_t* __restrict__ digests) {
   size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= m) return;
-  uint32_t s[16];
+  double s[16];
   kb::E4 a = f[2 * j], b = f[2 * j + 1];
 #pragma unroll
-  for (int k = 0; k < 4; k++) { s[k] = a.c[k]; s[4 + k] = b.c[k]; }
+  for (int k = 0; k < 4; k++) { s[k] = p2f::load_monty(a.c[k]); s[4 + k] = p2f::load_monty(b.c[k]); }
 #pragma unroll
-  for (int k = 8; k < 16; k++) s[k] = 0;
-  p2::permute(s);
+  for (int k = 8; k < 16; k++) s[k] = 0.0;
+  p2f::permute(s);
   store_digest(digests + 8 * j, s);
 }
 
 // n independent permutations (parity / micro-benchmark entry point)
 __global__ __launch_bounds__(THREADS) void permute_batch(uint32_t* __restrict__ states, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint32_t w[16];
+  uint4* p = reinterpret_cast<uint4*>(states + 16 * i);
+  uint4 v[4] = {p[0], p[1], p[2], p[3]};
+#pragma unroll
+  for (int k = 0; k < 4; k++) { w[4 * k] = v[k].x; w[4 * k + 1] = v[k].y; w[4 * k + 2] = v[k].z; w[4 * k + 3] = v[k].w; }
+  double s[16];
+#pragma unroll
+  for (int k = 0; k < 16; k++) s[k] = p2f::load_monty(w[k]);
+  p2f::permute(s);
+#pragma unroll
+  for (int k = 0; k < 16; k++) w[k] = p2f::store_monty(s[k]);
+#pragma unroll
+  for (int k = 0; k < 4; k++) p[k] = make_uint4(w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3]);
+}
+// the same through the integer-pipe formulation (poseidon2.cuh): what the lane-parallel kernels near a tree's root and the
+// host transcript compute with; kept as a parity entry point
+__global__ __launch_bounds__(THREADS) void permute_batch_int(uint32_t* __restrict__ states, size_t n) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   uint32_t s[16];
@@ -218,17 +242,17 @@ __global__ __launch_bounds__(THREADS) void grind(const uint32_t* __restrict__ sp
   if (i >= total) return;
   uint32_t w = base + i;  // canonical witness value
   if (w >= kb::P) return;
-  uint32_t s[16];
+  double s[16];
 #pragma unroll
-  for (int k = 0; k < 16; k++) s[k] = sponge_state[k];
+  for (int k = 0; k < 16; k++) s[k] = p2f::load_monty(sponge_state[k]);
 #pragma unroll
   for (int k = 0; k < 8; k++) {
-    if (k < n_in) s[k] = inputs[k];
-    else if (k == n_in) s[k] = kb::to_monty(w);
+    if (k < n_in) s[k] = p2f::load_monty(inputs[k]);
+    else if (k == n_in) s[k] = (double)w;  // the witness is given in canonical form
   }
-  p2::permute(s);
+  p2f::permute(s);
   // the sample is the last element of the rate (output buffer popped from the back)
-  uint32_t v = kb::from_monty(s[7]);
+  uint32_t v = kb::from_monty(p2f::store_monty(s[7]));
   if ((v & ((1u << bits) - 1)) == 0) atomicMin(best, w);
 }
 

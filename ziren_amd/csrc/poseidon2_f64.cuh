@@ -1,0 +1,202 @@
+// Poseidon2 width-16 over KoalaBear on the FP64 vector pipe of gfx950.
+//
+// Same permutation as poseidon2.cuh (zkm_primitives::poseidon2_init, crates/primitives/src/lib.rs:1107-1122;
+// layers crates/recursion/core/include/poseidon2.hpp:21-71), bit for bit, but the state is sixteen *doubles* holding
+// exact integers congruent to the canonical (non-Montgomery) field values. Why: on MI355X v_add/mul/fma/rndne_f64
+// issue at the same rate as the 32-bit integer multiplies (4.3-4.4 cycles per wave64 instruction,
+// profiles/r02_ubench_valu.txt), and a double has 53 bits where an int32 has 31:
+//   * the external MDS layer (coefficient sum 35) is 64 plain additions with no reduction at all
+//     (the integer version: ~70 modular additions of three instructions each);
+//   * a modular product is two-product + Barrett quotient: h = RN(ab), l = fma(a,b,-h) (exact error term),
+//     q = rint(h/p), r = fma(-q,p,h) (exact: an integer below 2^53), result r + l. Six instructions, no carries;
+//   * the internal layer's diagonal (+-2^-k, small integers) is a shift of the exponent plus one fma.
+// Every operation below is exact integer arithmetic as long as the stated magnitude bounds hold; they are
+// re-derived next to each step and hammered by tests/test_poseidon2_f64 (host build of this very code, which uses the
+// same IEEE operations) and by the GPU parity tests against the integer version and the oracle.
+//
+// Interface: load_monty (u32 Montgomery word -> canonical double in (-p, 0]), permute, store_monty (-> [0, p) Montgomery).
+#pragma once
+#include "poseidon2.cuh"
+
+namespace p2f {
+
+constexpr double P = 2130706433.0;
+constexpr double PINV = 1.0 / 2130706433.0;  // RN(1/p): relative error <= 2^-53
+
+KB_HD double fma_(double a, double b, double c) { return __builtin_fma(a, b, c); }
+KB_HD double rne(double x) { return __builtin_rint(x); }  // v_rndne_f64 (round to nearest even, the default mode on the host too)
+
+// canonical tables as balanced doubles (filled by upload_tables / the host mirror below)
+__constant__ double d_rc_ext[8][16];
+__constant__ double d_rc_int[13];
+
+// x integer, |x| < 2^52  ->  congruent integer with |r| <= p/2 + p*2^-20
+KB_HD double reduce(double x) {
+  const double q = rne(x * PINV);
+  return fma_(-q, P, x);
+}
+// a, b integers with |ab| < 2^82  ->  integer congruent to ab, |result| <= p/2 + p*|ab/p|*2^-51 + ulp(ab)/2.
+// h - qp is an integer (h is a multiple of ulp(h) >= 1 or an exact small product) of magnitude < 2^53, so the fma is exact.
+KB_HD double mulmod(double a, double b) {
+  const double h = a * b;
+  const double l = fma_(a, b, -h);
+  const double q = rne(h * PINV);
+  const double r = fma_(-q, P, h);
+  return r + l;
+}
+// (y)^3 for |y| < 2^41: |y^2| < 2^82 -> |z| <= p/2 + p*2^-0.9.. ; for the |y| <= 2^36.3 met in steady state |z| < 2^30.01
+// and |z y| < 2^66.4 -> |w| <= p/2 + 2^15.
+KB_HD double sbox(double y) {
+  const double z = mulmod(y, y);
+  return mulmod(z, y);
+}
+
+KB_HD void m4(double& s0, double& s1, double& s2, double& s3) {
+  // [[2,3,1,1],[1,2,3,1],[1,1,2,3],[3,1,1,2]]
+  const double t01 = s0 + s1, t23 = s2 + s3;
+  const double t0123 = t01 + t23;
+  const double t01123 = t0123 + s1, t01233 = t0123 + s3;
+  const double n3 = fma_(2.0, s0, t01233);
+  const double n1 = fma_(2.0, s2, t01123);
+  const double n0 = t01123 + t01;
+  const double n2 = t01233 + t23;
+  s0 = n0; s1 = n1; s2 = n2; s3 = n3;
+}
+// every output is a combination of the inputs with non-negative coefficients summing to 35
+KB_HD void external_layer(double s[16]) {
+#pragma unroll
+  for (int i = 0; i < 16; i += 4) m4(s[i], s[i + 1], s[i + 2], s[i + 3]);
+  const double c0 = (s[0] + s[4]) + (s[8] + s[12]);
+  const double c1 = (s[1] + s[5]) + (s[9] + s[13]);
+  const double c2 = (s[2] + s[6]) + (s[10] + s[14]);
+  const double c3 = (s[3] + s[7]) + (s[11] + s[15]);
+#pragma unroll
+  for (int i = 0; i < 16; i += 4) {
+    s[i] += c0; s[i + 1] += c1; s[i + 2] += c2; s[i + 3] += c3;
+  }
+}
+
+// x / 2^K + add (SIGN = +1) or -x / 2^K + add (SIGN = -1) modulo p, K <= 24, for an integer |x| < 2^52:
+// x = t 2^K + lo with |lo| <= 2^(K-1); 2^-K = -(p-1)/2^K (mod p) because 2^K (p-1)/2^K = -1; so x/2^K = t - lo (p-1)/2^K.
+// |result - add| <= |x|/2^K + 1/2 + 2^30.
+template <int K, int SIGN>
+KB_HD double div2k_add(double x, double add) {
+  constexpr double INV = 1.0 / (double)(1u << K);
+  constexpr double POW = (double)(1u << K);
+  constexpr double C = (double)((2130706433u - 1u) >> K);
+  const double t = rne(x * INV);
+  const double lo = fma_(-t, POW, x);
+  if (SIGN > 0) return fma_(-lo, C, t + add);
+  return fma_(lo, C, add - t);
+}
+
+// s_i <- V_i s_i + sum(s), V = [-2, 1, 2, 1/2, 3, 4, -1/2, -3, -4, 2^-8, 1/8, 2^-24, -2^-8, -1/8, -1/16, -2^-24]
+KB_HD void internal_layer(double s[16]) {
+  double sum = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+  sum += ((s[8] + s[9]) + (s[10] + s[11])) + ((s[12] + s[13]) + (s[14] + s[15]));
+  sum = reduce(sum);
+  s[0] = fma_(-2.0, s[0], sum);
+  s[1] = s[1] + sum;
+  s[2] = fma_(2.0, s[2], sum);
+  s[3] = div2k_add<1, 1>(s[3], sum);
+  s[4] = fma_(3.0, s[4], sum);
+  s[5] = fma_(4.0, s[5], sum);
+  s[6] = div2k_add<1, -1>(s[6], sum);
+  s[7] = fma_(-3.0, s[7], sum);
+  s[8] = fma_(-4.0, s[8], sum);
+  s[9] = div2k_add<8, 1>(s[9], sum);
+  s[10] = div2k_add<3, 1>(s[10], sum);
+  s[11] = div2k_add<24, 1>(s[11], sum);
+  s[12] = div2k_add<8, -1>(s[12], sum);
+  s[13] = div2k_add<3, -1>(s[13], sum);
+  s[14] = div2k_add<4, -1>(s[14], sum);
+  s[15] = div2k_add<24, -1>(s[15], sum);
+}
+
+// Magnitudes (B = 2^30 + 2^15 bounds an S-box output; inputs of a permutation: |s_i| <= 2^35.3):
+//  first layer: <= 35 * 2^35.3 = 2^40.5 -> first S-boxes see |y| < 2^40.6 (fine for sbox, see there), then every full
+//  round: S-box outputs < B, layer outputs < 35 B < 2^35.2.
+//  partial rounds: lane 0 is an S-box output (< B) before the layer and <= 2 B + |sum| after; the lanes with a 2^-k diagonal
+//  contract (|s|/2 + 2^30 + |sum| + 1); lane 1 grows by |sum| <= p/2 + 2^11 per round; the integer-diagonal lanes 2, 4, 5, 7, 8
+//  grow by at most x4 + |sum| per round and are reduced after rounds 4 and 9, so they stay below 2^35.2 * 4^5 + ... < 2^46,
+//  the lane sum below 2^50, and they leave the last round below 2^30 * 4^3 + 2^33 < 2^37.
+template <class RcExt, class RcInt>
+KB_HD void permute_impl(double s[16], RcExt rc_ext, RcInt rc_int) {
+  external_layer(s);
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+#pragma unroll
+    for (int i = 0; i < 16; i++) s[i] = sbox(s[i] + rc_ext(r, i));
+    external_layer(s);
+  }
+#pragma unroll 1
+  for (int r = 0; r < 13; r++) {
+    s[0] = sbox(s[0] + rc_int(r));
+    internal_layer(s);
+    if (r == 4 || r == 9) {
+      s[2] = reduce(s[2]); s[4] = reduce(s[4]); s[5] = reduce(s[5]); s[7] = reduce(s[7]); s[8] = reduce(s[8]);
+    }
+  }
+#pragma unroll
+  for (int r = 4; r < 8; r++) {
+#pragma unroll
+    for (int i = 0; i < 16; i++) s[i] = sbox(s[i] + rc_ext(r, i));
+    external_layer(s);
+  }
+}
+
+// u32 Montgomery word m < 2^32 -> canonical value in (-p, 0]: m / R = -(m * p^-1 mod R) * p / R (mod p), the integer
+// Montgomery step with a zero high word
+KB_HD double load_monty(uint32_t m) {
+  const uint32_t t = m * kb::MU;
+#if defined(__HIP_DEVICE_COMPILE__)
+  const uint32_t u = __umulhi(t, kb::P);
+#else
+  const uint32_t u = (uint32_t)(((uint64_t)t * kb::P) >> 32);
+#endif
+  // m = t p (mod 2^32), so (m - t p) / 2^32 = -u exactly when m != 0 ... and 0 - u + (m != 0 ? 0 : 0): hi(m) = 0, borrow-free
+  return -(double)u;
+}
+// integer |x| < 2^51 -> x * R mod p as a Montgomery word in [0, p)
+KB_HD uint32_t store_monty(double x) {
+  const double h = x * 4294967296.0;  // exact
+  const double q = rne(h * PINV);
+  const double r = fma_(-q, P, h);  // integer, |r| <= p/2 + p 2^-20
+  const int32_t v = (int32_t)r;
+  return (uint32_t)v + ((uint32_t)(v >> 31) & kb::P);
+}
+
+__device__ __forceinline__ void permute(double s[16]) {
+  permute_impl(
+      s, [](int r, int i) { return d_rc_ext[r][i]; }, [](int r) { return d_rc_int[r]; });
+}
+
+// canonical balanced value of a Montgomery constant
+inline double canonical_balanced(uint32_t monty) {
+  const uint32_t c = kb::from_monty(monty);
+  return c > kb::P / 2 ? (double)c - P : (double)c;
+}
+inline void permute_host(double s[16]) {
+  permute_impl(
+      s, [](int r, int i) { return canonical_balanced(p2::ZKM_RC_16_30_MONTY[r < 4 ? r : r + 13][i]); },
+      [](int r) { return canonical_balanced(p2::ZKM_RC_16_30_MONTY[4 + r][0]); });
+}
+// the integer permutation's interface on top of the FP64 one (host): Montgomery words in, Montgomery words out
+inline void permute_host_words(uint32_t w[16]) {
+  double s[16];
+  for (int i = 0; i < 16; i++) s[i] = load_monty(w[i]);
+  permute_host(s);
+  for (int i = 0; i < 16; i++) w[i] = store_monty(s[i]);
+}
+
+inline hipError_t upload_tables() {
+  double ext[8][16], in[13];
+  for (int r = 0; r < 8; r++)
+    for (int i = 0; i < 16; i++) ext[r][i] = canonical_balanced(p2::ZKM_RC_16_30_MONTY[r < 4 ? r : r + 13][i]);
+  for (int r = 0; r < 13; r++) in[r] = canonical_balanced(p2::ZKM_RC_16_30_MONTY[4 + r][0]);
+  hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(d_rc_ext), ext, sizeof ext);
+  if (e != hipSuccess) return e;
+  return hipMemcpyToSymbol(HIP_SYMBOL(d_rc_int), in, sizeof in);
+}
+
+}  // namespace p2f

@@ -1093,6 +1093,7 @@ int zkm_ctx_create(int device, zkm_ctx** out) {
   HIP_CHECK(hipStreamCreate(&c->stream2));
   c->cur = c->stream;
   HIP_CHECK(p2::upload_tables());
+  HIP_CHECK(p2f::upload_tables());
   HIP_CHECK(tracegen::upload_tables());
   HIP_CHECK(septic::upload_tables());
   {
@@ -1505,6 +1506,21 @@ int zkm_poseidon2_permute_batch(zkm_ctx* ctx, uint32_t* states, size_t n) {
   uint32_t* d = ctx->alloc_n<uint32_t>(n * 16);
   HIP_CHECK(hipMemcpyAsync(d, states, n * 64, hipMemcpyHostToDevice, ctx->stream));
   hipLaunchKernelGGL(merkle::permute_batch, dim3(div_up(n, merkle::THREADS)), dim3(merkle::THREADS), 0, ctx->stream, d, n);
+  LAUNCH_CHECK();
+  HIP_CHECK(hipMemcpyAsync(states, d, n * 64, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  ctx->release(d);
+  API_END
+}
+
+int zkm_poseidon2_permute_batch_int(zkm_ctx* ctx, uint32_t* states, size_t n) {
+  API_BEGIN
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIP_CHECK(hipSetDevice(ctx->device));
+  if (n == 0) return 0;
+  uint32_t* d = ctx->alloc_n<uint32_t>(n * 16);
+  HIP_CHECK(hipMemcpyAsync(d, states, n * 64, hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(merkle::permute_batch_int, dim3(div_up(n, merkle::THREADS)), dim3(merkle::THREADS), 0, ctx->stream, d, n);
   LAUNCH_CHECK();
   HIP_CHECK(hipMemcpyAsync(states, d, n * 64, hipMemcpyDeviceToHost, ctx->stream));
   HIP_CHECK(hipStreamSynchronize(ctx->stream));
@@ -2105,6 +2121,7 @@ uint32_t zkm_challenger_sample_bits(zkm_challenger* c, uint32_t bits) { return c
 
 // host-side arithmetic of the transcript layer, exposed for the CPU-only parity tests
 void zkm_host_poseidon2_permute(uint32_t state[16]) { p2::permute_host(state); }
+void zkm_host_poseidon2_permute_f64(uint32_t state[16]) { p2f::permute_host_words(state); }
 void zkm_host_ext_mul(const uint32_t a[4], const uint32_t b[4], uint32_t out[4]) {
   E4 r = kb::emul(E4{{a[0], a[1], a[2], a[3]}}, E4{{b[0], b[1], b[2], b[3]}});
   memcpy(out, r.c, 16);

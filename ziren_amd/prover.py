@@ -529,6 +529,13 @@ def poseidon2_permute_batch(ctx: Context, states: np.ndarray) -> np.ndarray:
     return s
 
 
+def poseidon2_permute_batch_int(ctx: Context, states: np.ndarray) -> np.ndarray:
+    """The integer-pipe formulation of the same permutation (poseidon2.cuh), kept as a parity entry point."""
+    s = np.ascontiguousarray(states, dtype=np.uint32).copy()
+    lib.check(lib.load().zkm_poseidon2_permute_batch_int(ctx.h, abi.as_u32p(s), C.c_size_t(s.shape[0])))
+    return s
+
+
 def coset_lde_batch(ctx: Context, mat: np.ndarray, log_blowup: int, lde_shift: int) -> np.ndarray:
     m = np.ascontiguousarray(mat, dtype=np.uint32)
     out = np.empty((m.shape[0] << log_blowup, m.shape[1]), dtype=np.uint32)
