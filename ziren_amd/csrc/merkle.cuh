@@ -20,14 +20,19 @@ constexpr int THREADS = 256;
 
 // Absorb `width` columns (colptrs[g][row]) into the sponge state, 8 per permutation.
 __device__ __forceinline__ void absorb_row(double s[16], const uint32_t* const* __restrict__ colptrs, int width, size_t row) {
-  for (int g0 = 0; g0 < width; g0 += 8) {
-    uint32_t w[8];
+  // the next group's eight words are requested before the current group is permuted, so their latency sits under ~3400
+  // instructions of arithmetic instead of in front of them
+  uint32_t w[8];
 #pragma unroll
-    for (int i = 0; i < 8; i++)
-      if (g0 + i < width) w[i] = colptrs[g0 + i][row];
+  for (int i = 0; i < 8; i++)
+    if (i < width) w[i] = colptrs[i][row];
+  for (int g0 = 0; g0 < width; g0 += 8) {
 #pragma unroll
     for (int i = 0; i < 8; i++)
       if (g0 + i < width) s[i] = p2f::load_monty(w[i]);
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+      if (g0 + 8 + i < width) w[i] = colptrs[g0 + 8 + i][row];
     p2f::permute(s);
   }
 }
@@ -56,23 +61,43 @@ __global__ __launch_bounds__(THREADS) void hash_leaves(const uint32_t* const* __
   store_digest(digests + r * 8, s);
 }
 
-// next[i] = compress(prev[2i], prev[2i+1]); optionally inject the rows of matrices of height m.
+// next[i] = compress(prev[2i], prev[2i+1]); optionally inject the rows of matrices of height m:
+// node = compress(node, hash(row i)). All of a node's permutations (1, or 1 + ceil(w/8) + 1) go through ONE call site in a
+// uniform loop — three inlined copies of the permutation would be 64 KiB of code, the size of the instruction cache.
 __global__ __launch_bounds__(THREADS) void compress_layer(const uint32_t* __restrict__ prev, uint32_t* __restrict__ next, size_t m,
                                                           const uint32_t* const* __restrict__ inject_cols, int inject_width) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= m) return;
-  double s[16];
+  double s[16], node[8];
   load_digest(s, prev + 16 * i);
   load_digest(s + 8, prev + 16 * i + 8);
-  p2f::permute(s);
-  if (inject_width > 0) {
-    double h[16];
+  const int groups = (inject_width + 7) / 8;
+  const int last = inject_width > 0 ? groups + 1 : 0;
+  uint32_t w[8];  // the injected row's next eight words, requested one permutation ahead
 #pragma unroll
-    for (int k = 0; k < 16; k++) h[k] = 0.0;
-    absorb_row(h, inject_cols, inject_width, i);
-#pragma unroll
-    for (int k = 0; k < 8; k++) s[8 + k] = h[k];  // both halves stay unreduced doubles (|.| < 2^35.3: permute's input bound)
+  for (int k = 0; k < 8; k++)
+    if (k < inject_width) w[k] = inject_cols[k][i];
+  for (int ph = 0;; ph++) {
     p2f::permute(s);
+    if (ph == last) break;
+    if (ph == 0) {  // the node's digest is set aside, the state becomes the sponge of the injected row
+#pragma unroll
+      for (int k = 0; k < 8; k++) node[k] = s[k];
+#pragma unroll
+      for (int k = 0; k < 16; k++) s[k] = 0.0;
+    }
+    if (ph < groups) {
+      const int g0 = 8 * ph;
+#pragma unroll
+      for (int k = 0; k < 8; k++)
+        if (g0 + k < inject_width) s[k] = p2f::load_monty(w[k]);
+#pragma unroll
+      for (int k = 0; k < 8; k++)
+        if (g0 + 8 + k < inject_width) w[k] = inject_cols[g0 + 8 + k][i];
+    } else {  // compress(node, row hash): both halves stay unreduced doubles (|.| < 2^35.3: permute's input bound)
+#pragma unroll
+      for (int k = 0; k < 8; k++) { s[8 + k] = s[k]; s[k] = node[k]; }
+    }
   }
   store_digest(next + 8 * i, s);
 }

@@ -166,10 +166,22 @@ KB_HD uint32_t store_monty(double x) {
   return (uint32_t)v + ((uint32_t)(v >> 31) & kb::P);
 }
 
+// The 128 + 13 round constants are 282 SGPRs' worth: inside a loop (sponge over a row's columns) the compiler would hoist
+// their scalar loads out of the loop and park them in VGPR lanes (v_writelane / v_readlane: +6 % VALU instructions per
+// permutation). Laundering the table address through an empty asm per call keeps the loads inside the permutation,
+// where they are s_load_dwordx16 running under the VALU work.
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef const double __attribute__((address_space(4))) * const_table;  // constant address space: uniform loads stay scalar
 __device__ __forceinline__ void permute(double s[16]) {
+  uint64_t a_ext = (uint64_t)&d_rc_ext[0][0], a_in = (uint64_t)&d_rc_int[0];
+  asm volatile("" : "+s"(a_ext), "+s"(a_in));
+  const const_table ext = (const_table)a_ext, in = (const_table)a_in;
   permute_impl(
-      s, [](int r, int i) { return d_rc_ext[r][i]; }, [](int r) { return d_rc_int[r]; });
+      s, [ext](int r, int i) { return ext[16 * r + i]; }, [in](int r) { return in[r]; });
 }
+#else
+void permute(double s[16]);  // device only
+#endif
 
 // canonical balanced value of a Montgomery constant
 inline double canonical_balanced(uint32_t monty) {
