@@ -385,6 +385,29 @@ typedef struct zkm_syscall_event {
 } zkm_syscall_event;
 size_t zkm_tracegen_syscall_instrs_width(void);
 int zkm_tracegen_syscall_instrs(zkm_ctx* ctx, const zkm_syscall_event* events, size_t n_events, int fixed_log2_rows, zkm_matrix** out);
+/* The syscall tables SyscallCore (precompile = 0) and SyscallPrecompile (1) (crates/core/machine/src/syscall/chip.rs): replace
+ * generate_trace (:211-276; the C++ twins are syscall_core_event_to_row_koalabear / syscall_precompile_event_to_row_koalabear,
+ * crates/core/machine/src/sys.rs:40-47, include/syscall.hpp). Core takes the shard's syscall events and keeps those whose code has the
+ * send-to-table byte set or names a Linux syscall; Precompile takes the syscall events filed with the shard's precompile events.
+ * 11 columns; the U16Range lookups of the four argument half-words (generate_dependencies :178-183) are counted into `blu` if given. */
+int zkm_tracegen_syscall(zkm_ctx* ctx, const zkm_syscall_event* events, size_t n_events, int precompile, int fixed_log2_rows,
+                         zkm_byte_lookups* blu, zkm_matrix** out);
+/* MemoryGlobalInit / MemoryGlobalFinalize (crates/core/machine/src/memory/global.rs): replaces generate_trace (:113-185; the C++ twin is
+ * memory_global_event_to_row_koalabear, sys.rs:35-39, include/memory_global.hpp). Events are the #[repr(C)]
+ * MemoryInitializeFinalizeEvents of crates/core/executor/src/events/memory.rs:180-209, in any order (sorted by address here as the
+ * reference sorts them); previous_addr is the address in the shard's public values previous_init_addr_bits /
+ * previous_finalize_addr_bits. 111 columns. Addresses that do not strictly increase are an error. */
+typedef struct zkm_memory_init_finalize_event { uint32_t addr, value, shard, timestamp; } zkm_memory_init_finalize_event;
+int zkm_tracegen_memory_global(zkm_ctx* ctx, const zkm_memory_init_finalize_event* events, size_t n_events, uint32_t previous_addr,
+                               int fixed_log2_rows, zkm_matrix** out);
+/* The Poseidon2Permute precompile (crates/core/machine/src/syscall/precompiles/poseidon2/): replaces generate_trace (trace.rs:31-66) and the
+ * byte lookups of generate_dependencies (:68-101, counted into `blu` if given). The reference's Poseidon2PermuteEvent
+ * (crates/core/executor/src/events/precompiles/poseidon2_permute.rs:9-27) holds Vecs; across the ABI it is flattened: shard, clk,
+ * state_addr and the sixteen MemoryWriteRecords of the state words (pre_state[i] = state_records[i].prev_value, post_state[i] = .value,
+ * as syscalls/precompiles/poseidon2/permute.rs:30-47 builds them). 973 columns; padding rows carry the permutation of the zero state. */
+typedef struct zkm_poseidon2_permute_event { uint32_t shard, clk, state_addr; zkm_memory_write_record state_records[16]; } zkm_poseidon2_permute_event;
+int zkm_tracegen_poseidon2_permute(zkm_ctx* ctx, const zkm_poseidon2_permute_event* events, size_t n_events, int fixed_log2_rows,
+                                   zkm_byte_lookups* blu, zkm_matrix** out);
 /* The MiscInstrs chip (crates/core/machine/src/misc/others/: SEXT EXT INS MADDU MSUBU MADD MSUB TEQ): replaces generate_trace
  * (trace.rs:42-84), which also records the byte lookups (counted into `blu` if given). Events are the #[repr(C)] MiscEvents of
  * crates/core/executor/src/events/instr.rs:239-261 (60 bytes). 72 columns, zero padding rows. */

@@ -619,4 +619,52 @@ int orc_tracegen_poseidon2_skinny(const uint32_t* events, size_t n_events, int f
   ORC_CATCH
 }
 
+// MemoryGlobalInit / MemoryGlobalFinalize chips: MemoryInitializeFinalizeEvents (16 bytes), 111 columns; previous_addr = the address the
+// shard's public values carry in previous_init_addr_bits / previous_finalize_addr_bits. Call with out = NULL to get the row count.
+int orc_tracegen_memory_global(const void* events, size_t n_events, uint32_t previous_addr, int fixed_log2_rows, uint32_t* out, size_t out_cap, size_t* rows) {
+  ORC_TRY
+  size_t h;
+  std::vector<F> t = tracegen::generate_memory_global((const tracegen::MemoryInitFinalizeEvent*)events, n_events, previous_addr, fixed_log2_rows, &h);
+  *rows = h;
+  if (out) {
+    if (t.size() > out_cap) throw std::runtime_error("trace buffer too small");
+    for (size_t i = 0; i < t.size(); i++) out[i] = to_monty(t[i]);
+  }
+  ORC_CATCH
+}
+
+// SyscallCore (precompile = 0: the events are filtered as the chip filters them) / SyscallPrecompile (1) chips: SyscallEvents, 11 columns
+int orc_tracegen_syscall(const void* events, size_t n_events, int precompile, int fixed_log2_rows, uint32_t* out, size_t out_cap, size_t* rows,
+                         uint32_t* byte_counts) {
+  ORC_TRY
+  size_t h;
+  std::vector<uint64_t> cnt(byte_counts ? tracegen::BYTE_ROWS * tracegen::NUM_BYTE_OPS : 0, 0);
+  std::vector<F> t = tracegen::generate_syscall((const tracegen::SyscallEvent*)events, n_events, precompile != 0, fixed_log2_rows, &h,
+                                                byte_counts && out ? cnt.data() : nullptr);
+  *rows = h;
+  if (out) {
+    if (t.size() > out_cap) throw std::runtime_error("trace buffer too small");
+    for (size_t i = 0; i < t.size(); i++) out[i] = to_monty(t[i]);
+    for (size_t i = 0; i < cnt.size(); i++) byte_counts[i] += (uint32_t)cnt[i];
+  }
+  ORC_CATCH
+}
+
+// Poseidon2Permute precompile chip: flattened Poseidon2PermuteEvents (99 words), 973 columns
+int orc_tracegen_poseidon2_permute(const void* events, size_t n_events, int fixed_log2_rows, uint32_t* out, size_t out_cap, size_t* rows,
+                                   uint32_t* byte_counts) {
+  ORC_TRY
+  size_t h;
+  std::vector<uint64_t> cnt(byte_counts ? tracegen::BYTE_ROWS * tracegen::NUM_BYTE_OPS : 0, 0);
+  std::vector<F> t = tracegen::generate_poseidon2_permute((const tracegen::Poseidon2PermuteEvent*)events, n_events, fixed_log2_rows, &h,
+                                                          byte_counts && out ? cnt.data() : nullptr);
+  *rows = h;
+  if (out) {
+    if (t.size() > out_cap) throw std::runtime_error("trace buffer too small");
+    for (size_t i = 0; i < t.size(); i++) out[i] = to_monty(t[i]);
+    for (size_t i = 0; i < cnt.size(); i++) byte_counts[i] += (uint32_t)cnt[i];
+  }
+  ORC_CATCH
+}
+
 }  // extern "C"

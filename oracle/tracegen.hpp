@@ -22,6 +22,7 @@
 // two, at least 16. Event layout: #[repr(C)] AluEvent, crates/core/executor/src/events/instr.rs:10-26; opcode
 // numbers crates/core/executor/src/opcode.rs:26-48.
 #pragma once
+#include <algorithm>
 #include <cstdint>
 #include <cstring>
 #include <stdexcept>
@@ -1238,6 +1239,131 @@ static inline std::vector<F> generate_global(const GlobalLookupEvent* events, si
       r[CUMULATIVE + k] = sum.x.c[k]; r[CUMULATIVE + 7 + k] = sum.y.c[k];
     }
   }
+  *height = h;
+  return t;
+}
+
+// ---- MemoryGlobalInit / MemoryGlobalFinalize chips (memory/global.rs): MemoryInitializeFinalizeEvents (crates/core/executor/src/events/
+// memory.rs:180-209: addr, value, shard, timestamp); columns MemoryInitCols :221-259 (shard, timestamp, addr, lt_cols.bit_flags[32],
+// addr_bits: bits[32] + six running products of the top byte's bits, value[32] bits, is_real, is_next_comp, is_prev_addr_zero (inverse,
+// result), is_first_comp, is_last_addr); rows generate_trace :113-185: events sorted by address, row 0 compared with the previous shard's
+// last address (public values), every later row with its predecessor. The C++ twin is include/memory_global.hpp:9-43.
+struct MemoryInitFinalizeEvent { uint32_t addr, value, shard, timestamp; };
+static_assert(sizeof(MemoryInitFinalizeEvent) == 16, "MemoryInitializeFinalizeEvent is four words");
+static const size_t MEMORY_GLOBAL_WIDTH = 111;
+// AssertLtColsBits::populate (operations/cmp.rs:301-319): the flag of the most significant bit where a < b
+static inline void assert_lt_bits(uint32_t a, uint32_t b, F* flags) {
+  if (!(a < b)) throw std::runtime_error("tracegen: memory init/finalize addresses are not strictly increasing");
+  for (int i = 31; i >= 0; i--) {
+    const uint32_t ab = (a >> i) & 1, bb = (b >> i) & 1;
+    if (ab < bb) { flags[i] = 1; break; }
+  }
+}
+static inline std::vector<F> generate_memory_global(const MemoryInitFinalizeEvent* events_in, size_t n_events, uint32_t previous_addr,
+                                                    int fixed_log2_rows, size_t* height) {
+  enum { SHARD = 0, TIMESTAMP = 1, ADDR = 2, LT = 3, ADDR_BITS = 35, AND_DECOMP = 67, VALUE = 73, IS_REAL = 105, IS_NEXT_COMP = 106,
+         IS_PREV_ADDR_ZERO = 107, IS_FIRST_COMP = 109, IS_LAST_ADDR = 110 };
+  static_assert(IS_LAST_ADDR + 1 == 111, "layout");
+  std::vector<MemoryInitFinalizeEvent> events(events_in, events_in + n_events);
+  std::stable_sort(events.begin(), events.end(), [](const MemoryInitFinalizeEvent& a, const MemoryInitFinalizeEvent& b) { return a.addr < b.addr; });
+  const size_t h = padded_rows(n_events, fixed_log2_rows);
+  std::vector<F> t(h * MEMORY_GLOBAL_WIDTH, 0);
+  for (size_t i = 0; i < n_events; i++) {
+    const MemoryInitFinalizeEvent& e = events[i];
+    F* r = t.data() + i * MEMORY_GLOBAL_WIDTH;
+    r[ADDR] = fu32(e.addr);
+    for (int k = 0; k < 32; k++) r[ADDR_BITS + k] = (e.addr >> k) & 1;
+    r[AND_DECOMP] = r[ADDR_BITS + 24] * r[ADDR_BITS + 25];
+    for (int k = 0; k < 5; k++) r[AND_DECOMP + 1 + k] = r[AND_DECOMP + k] * r[ADDR_BITS + 26 + k];
+    r[SHARD] = fu32(e.shard);
+    r[TIMESTAMP] = fu32(e.timestamp);
+    for (int k = 0; k < 32; k++) r[VALUE + k] = (e.value >> k) & 1;
+    r[IS_REAL] = 1;
+    if (i == 0) {
+      is_zero_cols(fu32(previous_addr), r + IS_PREV_ADDR_ZERO);
+      r[IS_FIRST_COMP] = previous_addr != 0;
+      if (previous_addr != 0) assert_lt_bits(previous_addr, e.addr, r + LT);
+    } else {
+      r[IS_NEXT_COMP] = 1;
+      assert_lt_bits(events[i - 1].addr, e.addr, r + LT);
+    }
+    if (i == n_events - 1) r[IS_LAST_ADDR] = 1;
+  }
+  *height = h;
+  return t;
+}
+
+// ---- SyscallCore / SyscallPrecompile chips (syscall/chip.rs): SyscallEvents; columns SyscallCols :71-107 (shard, clk, syscall_id,
+// arg1_lo, arg1_hi, arg2_lo, arg2_hi, result_lo, result_hi, is_linux, is_real); rows generate_trace :211-276. Core: the shard's syscall
+// events whose code (a_record.prev_value) has the send-to-table byte set or names a Linux syscall; Precompile: the syscall events filed
+// with the shard's precompile events (a default a_record; is_linux only for Linux precompile events, which are not built: zero here).
+// The C++ twin is include/syscall.hpp:9-60. Byte lookups (generate_dependencies :115-187): U16Range of the four argument half-words.
+static const size_t SYSCALL_WIDTH = 11;
+static inline bool syscall_goes_to_table(const SyscallEvent& e) {
+  const uint32_t prev = e.a_record.prev_value;
+  return ((prev >> 16) & 0xff) == 1 || ((prev >> 8) & 0xff) != 0;
+}
+static inline std::vector<F> generate_syscall(const SyscallEvent* events, size_t n_events, bool precompile, int fixed_log2_rows, size_t* height,
+                                              uint64_t* byte_counts) {
+  std::vector<const SyscallEvent*> kept;
+  for (size_t i = 0; i < n_events; i++)
+    if (precompile || syscall_goes_to_table(events[i])) kept.push_back(events + i);
+  const size_t h = padded_rows(kept.size(), fixed_log2_rows);
+  std::vector<F> t(h * SYSCALL_WIDTH, 0);
+  for (size_t i = 0; i < kept.size(); i++) {
+    const SyscallEvent& e = *kept[i];
+    F* r = t.data() + i * SYSCALL_WIDTH;
+    r[0] = fu32(e.shard); r[1] = fu32(e.clk); r[2] = fu32(e.syscall_id);
+    r[3] = e.arg1 & 0xffff; r[4] = e.arg1 >> 16; r[5] = e.arg2 & 0xffff; r[6] = e.arg2 >> 16;
+    const bool is_linux = !precompile && ((e.a_record.prev_value >> 8) & 0xff) != 0;
+    r[9] = is_linux;
+    if (is_linux) { r[7] = e.a_record.value & 0xffff; r[8] = e.a_record.value >> 16; }
+    r[10] = 1;
+    if (byte_counts)
+      for (int k = 3; k < 7; k++) byte_counts[(size_t)r[k] * NUM_BYTE_OPS + B_U16RANGE_OP]++;   // the table row of U16Range is its value
+  }
+  *height = h;
+  return t;
+}
+
+// ---- Poseidon2Permute precompile chip (syscall/precompiles/poseidon2/): columns Poseidon2MemCols columns.rs:9-27 = the degree-3
+// permutation columns of operations/poseidon2 (the same 313 as the recursion chip above: permutation.rs:43-80, trace.rs:13-157), shard, clk,
+// state_addr, sixteen MemoryWriteCols (13 each), KoalaBearWordRangeChecker of every pre- and post-state word (14 each), is_real; rows
+// trace.rs:31-128: the padding row carries the permutation of the zero state and nothing else. Event: Poseidon2PermuteEvent
+// (crates/core/executor/src/events/precompiles/poseidon2_permute.rs:9-27) flattened: shard, clk, state_addr, then the sixteen
+// MemoryWriteRecords of the state words (pre_state = their prev_value, post_state = their value, as syscalls/precompiles/poseidon2/
+// permute.rs:30-47 makes them).
+struct Poseidon2PermuteEvent { uint32_t shard, clk, state_addr; MemoryWriteRecord state_records[16]; };
+static_assert(sizeof(Poseidon2PermuteEvent) == 4 * 99, "flattened Poseidon2PermuteEvent is 99 words");
+static const size_t POSEIDON2_PERMUTE_WIDTH = 973;
+static inline std::vector<F> generate_poseidon2_permute(const Poseidon2PermuteEvent* events, size_t n_events, int fixed_log2_rows, size_t* height,
+                                                        uint64_t* byte_counts) {
+  enum { SHARD = 313, CLK = 314, STATE_ADDR = 315, STATE_MEM = 316, PRE_RC = 524, POST_RC = 748, IS_REAL = 972 };
+  const size_t h = padded_rows(n_events, fixed_log2_rows);
+  std::vector<F> t(h * POSEIDON2_PERMUTE_WIDTH, 0);
+  std::vector<ByteLookup> lk;
+  const F zero[16] = {0};
+  for (size_t i = 0; i < h; i++) {
+    F* r = t.data() + i * POSEIDON2_PERMUTE_WIDTH;
+    if (i >= n_events) { poseidon2_wide_row(zero, r); continue; }
+    const Poseidon2PermuteEvent& e = events[i];
+    F input[16];
+    for (int k = 0; k < 16; k++) {
+      if (e.state_records[k].prev_value >= P || e.state_records[k].value >= P) throw std::runtime_error("tracegen: Poseidon2 state word is not a field element");
+      input[k] = e.state_records[k].prev_value;
+    }
+    poseidon2_wide_row(input, r);
+    for (int k = 0; k < 16; k++)
+      if (r[156 + k] != e.state_records[k].value) throw std::runtime_error("tracegen: Poseidon2PermuteEvent post-state is not the permutation of its pre-state");
+    r[SHARD] = fu32(e.shard); r[CLK] = fu32(e.clk); r[STATE_ADDR] = fu32(e.state_addr); r[IS_REAL] = 1;
+    for (int k = 0; k < 16; k++) {
+      memory_write_cols(e.state_records[k], r + STATE_MEM + 13 * k, &lk);
+      range_checker(r + PRE_RC + 14 * k, e.state_records[k].prev_value);
+      range_checker(r + POST_RC + 14 * k, e.state_records[k].value);
+    }
+  }
+  if (byte_counts)
+    for (const ByteLookup& b : lk) byte_counts[((size_t)b.b * 256 + b.c) * NUM_BYTE_OPS + b.op]++;
   *height = h;
   return t;
 }

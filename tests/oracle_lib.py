@@ -343,6 +343,41 @@ def tracegen_memory_instrs(events, fixed_log2_rows=-1, byte_counts=None):
     return out
 
 
+def _rows_then_fill(fn, width, *args, tail=()):
+    rows = C.c_size_t()
+    _check(fn(*args, None, C.c_size_t(0), C.byref(rows), *([None] * len(tail))))
+    out = np.zeros((rows.value, width), dtype=np.uint32)
+    _check(fn(*args, abi.as_u32p(out), C.c_size_t(out.size), C.byref(rows), *tail))
+    return out
+
+
+def tracegen_memory_global(events, previous_addr=0, fixed_log2_rows=-1):
+    """MemoryGlobalInit / MemoryGlobalFinalize rows from MemoryInitializeFinalizeEvents (events.MEMORY_INIT_FINALIZE_EVENT); previous_addr =
+    the last address of the previous shard's chip (public values)."""
+    from ziren_amd import events as E
+    ev = np.ascontiguousarray(events, dtype=E.MEMORY_INIT_FINALIZE_EVENT)
+    return _rows_then_fill(lib().orc_tracegen_memory_global, E.MEMORY_GLOBAL_WIDTH, C.c_void_p(ev.ctypes.data), C.c_size_t(len(ev)),
+                           C.c_uint32(previous_addr), C.c_int(fixed_log2_rows))
+
+
+def tracegen_syscall(events, precompile, fixed_log2_rows=-1, byte_counts=None):
+    """SyscallCore (precompile False: filtered as the chip filters) / SyscallPrecompile rows from SyscallEvents."""
+    from ziren_amd import events as E
+    ev = np.ascontiguousarray(events, dtype=E.SYSCALL_EVENT)
+    bc = (abi.as_u32p(byte_counts),) if byte_counts is not None else (None,)
+    return _rows_then_fill(lib().orc_tracegen_syscall, E.SYSCALL_WIDTH, C.c_void_p(ev.ctypes.data), C.c_size_t(len(ev)), C.c_int(int(precompile)),
+                           C.c_int(fixed_log2_rows), tail=bc)
+
+
+def tracegen_poseidon2_permute(events, fixed_log2_rows=-1, byte_counts=None):
+    """Poseidon2Permute precompile rows from flattened Poseidon2PermuteEvents (events.POSEIDON2_PERMUTE_EVENT)."""
+    from ziren_amd import events as E
+    ev = np.ascontiguousarray(events, dtype=E.POSEIDON2_PERMUTE_EVENT)
+    bc = (abi.as_u32p(byte_counts),) if byte_counts is not None else (None,)
+    return _rows_then_fill(lib().orc_tracegen_poseidon2_permute, E.POSEIDON2_PERMUTE_WIDTH, C.c_void_p(ev.ctypes.data), C.c_size_t(len(ev)),
+                           C.c_int(fixed_log2_rows), tail=bc)
+
+
 def septic_known_answers(a, b):
     """((z^i)^p, (z^i)^(p^2) for i = 1..6, a * b, normalised sqrt(a^2)) in the septic extension, canonical words."""
     a = np.ascontiguousarray(a, dtype=np.uint32)

@@ -1382,3 +1382,208 @@ def record_branch_chip(log_height: int) -> RecordedChip:
     return RecordedChip(name="Branch", log_height=log_height, main_width=E.BRANCH_WIDTH, log_quotient_degree=lqd,
                         local_only=True, sends=r.sends, receives=r.receives, program=program,
                         lookups_blob=air.encode_lookups(r.sends, r.receives), num_constraints=int(program[2]))
+
+
+# ---- the chips that close the machine: memory initialisation / finalisation, the syscall tables, the first precompile ------------------
+
+PV_PREV_INIT_BITS, PV_LAST_INIT_BITS, PV_PREV_FINALIZE_BITS, PV_LAST_FINALIZE_BITS = 45, 77, 109, 141    # public_values.rs:22-60
+
+
+def _assert_lt_bits(b, flags, a, bb, is_real):
+    """AssertLtColsBits::eval (operations/cmp.rs:323-389): `flags` marks the most significant bit where a < b."""
+    total = b.const(0)
+    for f in flags:
+        b.assert_bool(f)
+        total = total + f
+    b.when(is_real).assert_one(total)
+    visited, a_cmp, b_cmp = b.const(0), b.const(0), b.const(0)
+    for a_bit, b_bit, f in zip(reversed(a), reversed(bb), reversed(flags)):
+        visited = visited + f
+        a_cmp = a_cmp + a_bit * f
+        b_cmp = b_cmp + b_bit * f
+        b.when(is_real).when_not(visited).assert_eq(a_bit, b_bit)
+    b.when(is_real).assert_eq(a_cmp, 0)
+    b.when(is_real).assert_eq(b_cmp, 1)
+
+
+def _memory_global(r: _Rec, finalize: bool):
+    """MemoryGlobalChip::eval (memory/global.rs:263-446), kind Initialize / Finalize. Sends one message per address to the global table:
+    Initialize the value every address starts from (shard 0, timestamp 0), Finalize *receives* the last access. Addresses strictly
+    increase down the rows and across shards (public values previous_* / last_*_addr_bits)."""
+    l, n, b = r.local, r.next, r.b
+    SHARD, TIMESTAMP, ADDR, LT, ADDR_BITS, AND_DECOMP, VALUE, IS_REAL, IS_NEXT_COMP, IS_PREV_ZERO, IS_FIRST_COMP, IS_LAST_ADDR = \
+        0, 1, 2, 3, 35, 67, 73, 105, 106, 107, 109, 110
+    is_real = l[IS_REAL]
+    b.assert_bool(is_real)
+    for i in range(32):
+        b.assert_bool(l[VALUE + i])
+    value = []
+    for k in range(4):
+        byte = b.const(0)
+        for i in range(8):
+            byte = byte + l[VALUE + 8 * k + i] * (1 << i)
+        value.append(byte)
+    if not finalize:
+        vals = [b.const(0), b.const(0), l[ADDR]] + value + [is_real * 1, is_real * 0, air.KIND_MEMORY]
+    else:
+        vals = [l[SHARD], l[TIMESTAMP], l[ADDR]] + value + [is_real * 0, is_real * 1, air.KIND_MEMORY]
+    r.sends.append(air.Lookup([air.to_virtual_pair(v) for v in vals], air.to_virtual_pair(is_real), air.KIND_GLOBAL))
+    # KoalaBearBitDecomposition::range_check (operations/koala_bear_range.rs:50-110)
+    bits = list(l[ADDR_BITS:ADDR_BITS + 32])
+    recon = b.const(0)
+    for i, bit in enumerate(bits):
+        b.when(is_real).assert_bool(bit)
+        recon = recon + bit * ((1 << i) % air.F.P)
+    b.when(is_real).assert_eq(recon, l[ADDR])
+    top = bits[24:32]
+    b.when(is_real).assert_zero(top[7])
+    b.when(is_real).assert_eq(l[AND_DECOMP], top[0] * top[1])
+    for i in range(5):
+        b.when(is_real).assert_eq(l[AND_DECOMP + 1 + i], l[AND_DECOMP + i] * top[2 + i])
+    low = b.const(0)
+    for bit in bits[:24]:
+        low = low + bit
+    b.when(is_real).when(l[AND_DECOMP + 5]).assert_zero(low)
+    # addr < next.addr when the next row is real
+    b.when_transition().assert_eq(n[IS_NEXT_COMP], n[IS_REAL])
+    _assert_lt_bits(b, list(n[LT:LT + 32]), bits, list(n[ADDR_BITS:ADDR_BITS + 32]), n[IS_NEXT_COMP])
+    b.when_transition().when_not(is_real).assert_zero(n[IS_REAL])
+    # the first row against the previous shard's last address
+    prev_base, last_base = (PV_PREV_FINALIZE_BITS, PV_LAST_FINALIZE_BITS) if finalize else (PV_PREV_INIT_BITS, PV_LAST_INIT_BITS)
+    prev_bits = [b.public_values(prev_base + i) for i in range(32)]
+    prev_addr = b.const(0)
+    for i, bit in enumerate(prev_bits):
+        prev_addr = prev_addr + bit * ((1 << i) % air.F.P)
+    _is_zero(b, prev_addr, l[IS_PREV_ZERO:IS_PREV_ZERO + 2], b.is_first_row())
+    prev_zero = l[IS_PREV_ZERO + 1]
+    b.assert_bool(l[IS_FIRST_COMP])
+    b.when_first_row().assert_eq(l[IS_FIRST_COMP], 1 - prev_zero)
+    b.when_first_row().assert_one(is_real)
+    _assert_lt_bits(b, list(l[LT:LT + 32]), prev_bits, bits, l[IS_FIRST_COMP])
+    b.when_first_row().when(prev_zero).assert_zero(l[ADDR])
+    b.when_first_row().when(prev_zero).assert_one(n[IS_REAL])
+    b.when_first_row().when(prev_zero).assert_one(n[IS_NEXT_COMP])
+    if not finalize:
+        b.when(is_real).assert_eq(l[TIMESTAMP], 1)
+    for i in range(32):
+        b.when_first_row().when_not(l[IS_FIRST_COMP]).assert_zero(l[VALUE + i])
+    # the last real address is the public one
+    b.when_transition().assert_eq(l[IS_LAST_ADDR], is_real * (1 - n[IS_REAL]))
+    for i in range(32):
+        pub = b.public_values(last_base + i)
+        b.when_last_row().when(is_real).assert_eq(bits[i], pub)
+        b.when_transition().when(l[IS_LAST_ADDR]).assert_eq(bits[i], pub)
+
+
+def _syscall_table(r: _Rec, precompile: bool):
+    """SyscallChip::eval (syscall/chip.rs:308-497), shard kind Core / Precompile. Core receives what the SyscallInstrs chip sends and
+    forwards it to the global table; Precompile receives it there and sends it on to the precompile chip of its shard."""
+    l, b = r.local, r.b
+    SHARD, CLK, ID, A1_LO, A1_HI, A2_LO, A2_HI, R_LO, R_HI, IS_LINUX, IS_REAL = range(11)
+    is_real = l[IS_REAL]
+    b.assert_bool(is_real)
+    b.assert_bool(l[IS_LINUX])
+    b.when(1 - is_real).assert_zero(l[IS_LINUX])
+    b.when_not(l[IS_LINUX]).assert_zero(l[R_LO])
+    b.when_not(l[IS_LINUX]).assert_zero(l[R_HI])
+    arg1 = l[A1_LO] + l[A1_HI] * 65536
+    arg2 = l[A2_LO] + l[A2_HI] * 65536
+    for c in (A1_LO, A1_HI, A2_LO, A2_HI):
+        r.send_byte(B_U16RANGE, l[c], 0, 0, is_real)
+    local_vals = [air.to_virtual_pair(v) for v in [l[SHARD], l[CLK], l[ID], arg1, arg2]]
+    packed = [air.to_virtual_pair(v) for v in [l[SHARD], l[CLK], l[R_LO], l[R_HI], l[A1_LO], l[A1_HI], l[A2_LO], l[A2_HI]]]
+    (r.sends if precompile else r.receives).append(air.Lookup(local_vals, air.to_virtual_pair(is_real), air.KIND_SYSCALL))
+    (r.sends if precompile else r.receives).append(air.Lookup(packed, air.to_virtual_pair(l[IS_LINUX]), air.KIND_SYSCALL_RESULT))
+    is_send, is_recv = (is_real * 0, is_real * 1) if precompile else (is_real * 1, is_real * 0)
+    r.sends.append(air.Lookup([air.to_virtual_pair(v) for v in [l[SHARD], l[CLK], l[ID], l[A1_LO], l[A1_HI], l[A2_LO], l[A2_HI], is_send, is_recv,
+                                                                air.KIND_SYSCALL]], air.to_virtual_pair(is_real), air.KIND_GLOBAL))
+    r.sends.append(air.Lookup([air.to_virtual_pair(v) for v in [l[SHARD], l[CLK], l[ID], l[R_LO], l[R_HI], b.const(0), b.const(0), is_send, is_recv,
+                                                                air.KIND_SYSCALL_RESULT]], air.to_virtual_pair(is_real), air.KIND_GLOBAL))
+
+
+def _poseidon2_permute(r: _Rec):
+    """Poseidon2PermuteChip::eval (syscall/precompiles/poseidon2/air.rs:25-107) with the permutation constraints of
+    operations/poseidon2/air.rs:79-157 (eval_external_round x 8, then eval_internal_rounds)."""
+    from . import recursion as R
+    rc, diag = R._poseidon2_constants()
+    l, b = r.local, r.b
+    EXT_STATE, INT_STATE, INT_S0, OUTPUT, EXT_SBOX, INT_SBOX = 0, 128, 144, 156, 172, 300
+    SHARD, CLK, STATE_ADDR, STATE_MEM, PRE_RC, POST_RC, IS_REAL = 313, 314, 315, 316, 524, 748, 972
+    is_real = l[IS_REAL]
+    ext_state = [l[EXT_STATE + 16 * k:EXT_STATE + 16 * k + 16] for k in range(8)]
+    int_state, s0, output = l[INT_STATE:INT_STATE + 16], l[INT_S0:INT_S0 + 12], l[OUTPUT:OUTPUT + 16]
+    ext_sbox = [l[EXT_SBOX + 16 * k:EXT_SBOX + 16 * k + 16] for k in range(8)]
+    int_sbox = l[INT_SBOX:INT_SBOX + 13]
+    mem = [l[STATE_MEM + 13 * i:STATE_MEM + 13 * i + 13] for i in range(16)]       # MemoryWriteCols: prev_value(4), access(9)
+    b.assert_bool(is_real)
+    for i in range(16):
+        prev = mem[i][0:4]
+        _word_range_check(b, prev, l[PRE_RC + 14 * i:PRE_RC + 14 * i + 14], is_real)
+        b.when(is_real).assert_eq(ext_state[0][i], _reduce(b, prev))
+    for rd in range(8):
+        state = list(ext_state[rd])
+        if rd == 0:
+            state = R._external_layer(state)
+        rnd = rd if rd < 4 else rd + 13
+        for i in range(16):
+            add_rc = state[i] + rc[rnd][i]
+            b.assert_eq(ext_sbox[rd][i], add_rc * add_rc * add_rc)
+        state = R._external_layer(list(ext_sbox[rd]))
+        nxt = int_state if rd == 3 else output if rd == 7 else ext_state[rd + 1]
+        for i in range(16):
+            b.assert_eq(nxt[i], state[i])
+    state = list(int_state)
+    for rd in range(13):
+        add_rc = (state[0] if rd == 0 else s0[rd - 1]) + rc[4 + rd][0]
+        b.assert_eq(int_sbox[rd], add_rc * add_rc * add_rc)
+        state[0] = int_sbox[rd]
+        state = R._internal_layer(state, diag)
+        if rd < 12:
+            b.assert_eq(s0[rd], state[0])
+    for i in range(16):
+        b.assert_eq(ext_state[4][i], state[i])
+    for i in range(16):
+        cur = mem[i][4:8]
+        _word_range_check(b, cur, l[POST_RC + 14 * i:POST_RC + 14 * i + 14], is_real)
+        b.when(is_real).assert_eq(output[i], _reduce(b, cur))
+    for i in range(16):     # eval_memory_access_slice (air/memory.rs:65-82)
+        r.eval_memory_access(l[SHARD], l[CLK], l[STATE_ADDR] + 4 * i, mem[i][0:4], mem[i][4:13], is_real)
+    r.receives.append(air.Lookup([air.to_virtual_pair(v) for v in [l[SHARD], l[CLK], b.const(E.SYS_POSEIDON2_PERMUTE & 0xffff), l[STATE_ADDR], b.const(0)]],
+                                 air.to_virtual_pair(is_real), air.KIND_SYSCALL))
+
+
+def record_memory_global_constraints(finalize: bool) -> _Rec:
+    r = _Rec(E.MEMORY_GLOBAL_WIDTH)
+    _memory_global(r, finalize)
+    return r
+
+
+def record_memory_global_chip(finalize: bool, log_height: int) -> RecordedChip:
+    """MemoryGlobalInit / MemoryGlobalFinalize (crates/core/machine/src/memory/global.rs): MemoryInitializeFinalizeEvents sorted by address,
+    111 columns, constraints between consecutive rows and against the public values."""
+    return _finish(record_memory_global_constraints(finalize), "MemoryGlobalFinalize" if finalize else "MemoryGlobalInit", log_height,
+                   E.MEMORY_GLOBAL_WIDTH, False)
+
+
+def record_syscall_table_constraints(precompile: bool) -> _Rec:
+    r = _Rec(E.SYSCALL_WIDTH)
+    _syscall_table(r, precompile)
+    return r
+
+
+def record_syscall_table_chip(precompile: bool, log_height: int) -> RecordedChip:
+    """SyscallCore / SyscallPrecompile (crates/core/machine/src/syscall/chip.rs): SyscallEvents, 11 columns, local_only is not claimed by the
+    reference (MachineAir::local_only defaults to false)."""
+    return _finish(record_syscall_table_constraints(precompile), "SyscallPrecompile" if precompile else "SyscallCore", log_height, E.SYSCALL_WIDTH, False)
+
+
+def record_poseidon2_permute_constraints() -> _Rec:
+    r = _Rec(E.POSEIDON2_PERMUTE_WIDTH)
+    _poseidon2_permute(r)
+    return r
+
+
+def record_poseidon2_permute_chip(log_height: int) -> RecordedChip:
+    """The Poseidon2Permute precompile (crates/core/machine/src/syscall/precompiles/poseidon2/): one permutation of sixteen memory words per
+    row, 973 columns; receives the syscall the SyscallPrecompile table sends."""
+    return _finish(record_poseidon2_permute_constraints(), "Poseidon2Permute", log_height, E.POSEIDON2_PERMUTE_WIDTH, False)

@@ -29,13 +29,13 @@ struct AluEvent {  // #[repr(C)] AluEvent, crates/core/executor/src/events/instr
 
 // crates/core/executor/src/opcode.rs:26-48
 enum : uint32_t { ADD = 0, SUB = 1, SLL = 9, SRL = 10, SRA = 11, ROR = 12, SLT = 13, SLTU = 14, AND = 15, OR = 16, XOR = 17, NOR = 18, CLZ = 19, CLO = 20 };
-enum Chip { ADD_SUB = 0, BITWISE = 1, LT = 2, SHIFT_LEFT = 3, SHIFT_RIGHT = 4, CLO_CLZ = 5, NUM_ALU_CHIPS = 6, JUMP = 6, MOV_COND = 7, BRANCH = 8, MUL = 9, DIVREM = 10, MEMORY_INSTRS = 11, SYSCALL_INSTRS = 12, MISC_INSTRS = 13, NUM_CHIPS = 14 };
+enum Chip { ADD_SUB = 0, BITWISE = 1, LT = 2, SHIFT_LEFT = 3, SHIFT_RIGHT = 4, CLO_CLZ = 5, NUM_ALU_CHIPS = 6, JUMP = 6, MOV_COND = 7, BRANCH = 8, MUL = 9, DIVREM = 10, MEMORY_INSTRS = 11, SYSCALL_INSTRS = 12, MISC_INSTRS = 13, SYSCALL_CORE = 14, SYSCALL_PRECOMPILE = 15, NUM_CHIPS = 16 };
 
 __host__ __device__ constexpr int chip_width(int chip) {
-  return chip == ADD_SUB ? 19 : chip == BITWISE ? 18 : chip == LT ? 32 : chip == SHIFT_LEFT ? 44 : chip == SHIFT_RIGHT ? 67 : chip == CLO_CLZ ? 17 : chip == JUMP ? 66 : chip == MOV_COND ? 32 : chip == BRANCH ? 62 : chip == MUL ? 58 : chip == DIVREM ? 106 : chip == MEMORY_INSTRS ? 79 : chip == SYSCALL_INSTRS ? 77 : chip == MISC_INSTRS ? 72 : 0;
+  return chip == ADD_SUB ? 19 : chip == BITWISE ? 18 : chip == LT ? 32 : chip == SHIFT_LEFT ? 44 : chip == SHIFT_RIGHT ? 67 : chip == CLO_CLZ ? 17 : chip == JUMP ? 66 : chip == MOV_COND ? 32 : chip == BRANCH ? 62 : chip == MUL ? 58 : chip == DIVREM ? 106 : chip == MEMORY_INSTRS ? 79 : chip == SYSCALL_INSTRS ? 77 : chip == MISC_INSTRS ? 72 : chip == SYSCALL_CORE || chip == SYSCALL_PRECOMPILE ? 11 : 0;
 }
 // words per event record: the seven-word AluEvent / JumpEvent / BranchEvent / MovCondEvent, the sixteen-word CompAluEvent
-__host__ __device__ constexpr int event_words(int chip) { return chip == MUL || chip == DIVREM || chip == MEMORY_INSTRS ? 16 : chip == SYSCALL_INSTRS ? 14 : chip == MISC_INSTRS ? 15 : 7; }
+__host__ __device__ constexpr int event_words(int chip) { return chip == MUL || chip == DIVREM || chip == MEMORY_INSTRS ? 16 : chip == SYSCALL_INSTRS || chip == SYSCALL_CORE || chip == SYSCALL_PRECOMPILE ? 14 : chip == MISC_INSTRS ? 15 : 7; }
 
 constexpr int THREADS = 256;
 
@@ -584,6 +584,19 @@ __device__ __forceinline__ void syscall_instr_row(const uint32_t* p, uint32_t* r
   if (send_to_table || id == 0x1a) { r[OP_C_CHECK] = 1; range_checker(r + OP_C_RC, arg2); }
 }
 
+// SyscallCore / SyscallPrecompile tables (syscall/chip.rs:71-107 columns, :211-276 rows; include/syscall.hpp:9-60): shard, clk, syscall_id,
+// the half-words of arg1 and arg2, the half-words of the result and is_linux (Linux syscalls only: Core reads them off the V0 write
+// record; Linux precompile events are not built, so Precompile rows carry zeros), is_real. Core's events arrive already filtered.
+__device__ __forceinline__ void syscall_table_row(const uint32_t* p, uint32_t* r, bool precompile) {
+  const uint32_t value = p[4], prev = p[7], arg1 = p[12], arg2 = p[13];
+  r[0] = p[2]; r[1] = p[3]; r[2] = p[11];
+  r[3] = arg1 & 0xffff; r[4] = arg1 >> 16; r[5] = arg2 & 0xffff; r[6] = arg2 >> 16;
+  const bool is_linux = !precompile && ((prev >> 8) & 0xff) != 0;
+  r[7] = is_linux ? value & 0xffff : 0; r[8] = is_linux ? value >> 16 : 0;
+  r[9] = fbool(is_linux);
+  r[10] = 1;
+}
+
 // MiscInstrs chip: MiscEvents of fifteen words (crates/core/executor/src/events/instr.rs:239-261): shard, clk, pc, next_pc, opcode, a, b,
 // c, prev_a, hi_record (six words). Columns misc/others/columns/*.rs — cells 20..63 are a union of SextCols / ExtCols / InsCols /
 // MaddsubCols; row misc/others/trace.rs:90-273, AddDoubleOperation operations/adddouble.rs:19-78.
@@ -809,6 +822,12 @@ template <> __device__ __forceinline__ void row_lookups<MISC_INSTRS>(const uint3
   }
 }
 template <> __device__ __forceinline__ void row_lookups<SYSCALL_INSTRS>(const uint32_t*, uint32_t, const LookupSink&) {}   // none (trace.rs:88-176)
+template <> __device__ __forceinline__ void row_lookups<SYSCALL_CORE>(const uint32_t* r, uint32_t, const LookupSink& counts) {   // chip.rs:178-183
+  for (int k = 3; k < 7; k++) lookup(counts, B_U16RANGE, r[k] >> 8, r[k]);
+}
+template <> __device__ __forceinline__ void row_lookups<SYSCALL_PRECOMPILE>(const uint32_t* r, uint32_t, const LookupSink& counts) {
+  for (int k = 3; k < 7; k++) lookup(counts, B_U16RANGE, r[k] >> 8, r[k]);
+}
 
 // events: n_events records of event_words(CHIP) words; out: column-major, `height` rows; grid = height / (tiles * THREADS), with
 // tiles = 1 for the plain row writer (most blocks in flight) and TILES_PER_BLOCK when counting.
@@ -835,9 +854,11 @@ __global__ __launch_bounds__(THREADS) void alu_rows(const uint32_t* __restrict__
     for (int c = 0; c < W; c++) r[c] = 0;
     if (row < n_events) {
       const uint32_t* p = events + row * event_words(CHIP);
-      if constexpr (CHIP == MUL || CHIP == DIVREM || CHIP == MEMORY_INSTRS || CHIP == SYSCALL_INSTRS || CHIP == MISC_INSTRS) {
+      if constexpr (CHIP == MUL || CHIP == DIVREM || CHIP == MEMORY_INSTRS || CHIP == SYSCALL_INSTRS || CHIP == MISC_INSTRS || CHIP == SYSCALL_CORE ||
+                    CHIP == SYSCALL_PRECOMPILE) {
         if constexpr (CHIP == MUL) mul_row(p, r); else if constexpr (CHIP == DIVREM) divrem_row(p, r);
         else if constexpr (CHIP == MEMORY_INSTRS) memory_instr_row(p, r); else if constexpr (CHIP == SYSCALL_INSTRS) syscall_instr_row(p, r);
+        else if constexpr (CHIP == SYSCALL_CORE) syscall_table_row(p, r, false); else if constexpr (CHIP == SYSCALL_PRECOMPILE) syscall_table_row(p, r, true);
         else misc_instr_row(p, r);
         if (count) row_lookups<CHIP>(r, 0, LookupSink{hkeys, hvals, HASH_SLOTS - 1, counts});
       } else {
@@ -1107,6 +1128,128 @@ __global__ __launch_bounds__(THREADS) void poseidon2_wide_rows(const uint32_t* _
     const int next = rd == 3 ? INT_STATE : rd == 7 ? OUTPUT : EXT_STATE + 16 * (rd + 1);
 #pragma unroll
     for (int i = 0; i < 16; i++) put(next + i, s[i]);
+  }
+}
+
+// ---- MemoryGlobalInit / MemoryGlobalFinalize (memory/global.rs:113-185, include/memory_global.hpp:9-43): events (addr, value, shard, timestamp)
+// sorted by address; one thread per row. Row i compares its address with row i - 1's (row 0: with the previous shard's last address,
+// `previous_addr`, when that is not zero): the flag of the most significant differing bit. 111 columns.
+constexpr int MEMORY_GLOBAL_WIDTH = 111;
+__global__ __launch_bounds__(THREADS) void memory_global_rows(const uint32_t* __restrict__ events, size_t n_events, uint32_t previous_addr, size_t height,
+                                                              uint32_t* __restrict__ out, int* __restrict__ bad) {
+  enum { SHARD = 0, TIMESTAMP = 1, ADDR = 2, LT = 3, ADDR_BITS = 35, AND_DECOMP = 67, VALUE = 73, IS_REAL = 105, IS_NEXT_COMP = 106, IS_PREV_ADDR_ZERO = 107,
+         IS_FIRST_COMP = 109, IS_LAST_ADDR = 110 };
+  const size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= height) return;
+  auto put = [&](int col, uint32_t canonical) { out[(size_t)col * height + row] = kb::to_monty(canonical); };
+  if (row >= n_events) {
+    for (int c = 0; c < MEMORY_GLOBAL_WIDTH; c++) out[(size_t)c * height + row] = 0;
+    return;
+  }
+  const uint32_t addr = events[4 * row], value = events[4 * row + 1];
+  put(SHARD, events[4 * row + 2]);
+  put(TIMESTAMP, events[4 * row + 3]);
+  put(ADDR, addr);   // an address is below p (the chip range-checks it; to_monty reduces a larger one like from_canonical would)
+  const bool compare = row > 0 || previous_addr != 0;
+  const uint32_t before = row > 0 ? events[4 * (row - 1)] : previous_addr;
+  if (compare && !(before < addr)) *bad = 1;
+  const int first_lt = compare && before < addr ? 31 - __clz(before ^ addr) : -1;   // the most significant bit where they differ: there before has 0, addr 1
+  for (int k = 0; k < 32; k++) {
+    out[(size_t)(LT + k) * height + row] = k == first_lt ? kb::ONE : 0u;
+    out[(size_t)(ADDR_BITS + k) * height + row] = (addr >> k) & 1 ? kb::ONE : 0u;
+    out[(size_t)(VALUE + k) * height + row] = (value >> k) & 1 ? kb::ONE : 0u;
+  }
+  uint32_t prod = (addr >> 24) & (addr >> 25) & 1;
+  put(AND_DECOMP, prod);
+  for (int k = 0; k < 5; k++) { prod &= (addr >> (26 + k)) & 1; put(AND_DECOMP + 1 + k, prod); }
+  put(IS_REAL, 1);
+  put(IS_NEXT_COMP, row > 0);
+  if (row == 0) {
+    out[(size_t)IS_PREV_ADDR_ZERO * height] = previous_addr ? kb::inv(kb::to_monty(previous_addr)) : 0u;
+    put(IS_PREV_ADDR_ZERO + 1, previous_addr == 0);
+  } else {
+    put(IS_PREV_ADDR_ZERO, 0); put(IS_PREV_ADDR_ZERO + 1, 0);
+  }
+  put(IS_FIRST_COMP, row == 0 && previous_addr != 0);
+  put(IS_LAST_ADDR, row == n_events - 1);
+}
+
+// ---- Poseidon2Permute precompile (syscall/precompiles/poseidon2/: columns.rs:9-27, trace.rs:31-128): flattened events of 99 words (shard, clk,
+// state_addr, sixteen MemoryWriteRecords); one thread per row runs the permutation on the records' previous values and writes every
+// intermediate (the 313 columns of poseidon2_wide_rows above), then the memory columns and the range checkers of the pre- and post-state
+// words; the two byte lookups of each of the sixteen accesses go to the block's LDS table. Padding rows: the permutation of the zero state.
+constexpr int POSEIDON2_PERMUTE_WIDTH = 973, POSEIDON2_PERMUTE_EVENT_WORDS = 99;
+__global__ __launch_bounds__(THREADS) void poseidon2_permute_rows(const uint32_t* __restrict__ events, size_t n_events, size_t height,
+                                                                  uint32_t* __restrict__ out, uint32_t* counts, int* __restrict__ bad) {
+  enum { EXT_STATE = 0, INT_STATE = 128, INT_S0 = 144, OUTPUT = 156, EXT_SBOX = 172, INT_SBOX = 300, SHARD = 313, CLK = 314, STATE_ADDR = 315,
+         STATE_MEM = 316, PRE_RC = 524, POST_RC = 748, IS_REAL = 972 };
+  extern __shared__ uint32_t hash_lds[];
+  uint32_t* hkeys = hash_lds;
+  uint32_t* hvals = hash_lds + HASH_SLOTS;
+  const bool count = counts != nullptr;
+  if (count) {
+    for (int i = threadIdx.x; i < HASH_SLOTS; i += blockDim.x) { hkeys[i] = HASH_EMPTY; hvals[i] = 0; }
+    __syncthreads();
+  }
+  const size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (row < height) {
+    const bool real = row < n_events;
+    const uint32_t* e = events + row * POSEIDON2_PERMUTE_EVENT_WORDS;
+    auto put = [&](int col, uint32_t monty) { out[(size_t)col * height + row] = monty; };
+    uint32_t s[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) s[i] = real ? kb::to_monty(e[3 + 6 * i + 3]) : 0u;   // the record's prev_value
+#pragma unroll
+    for (int i = 0; i < 16; i++) put(EXT_STATE + i, s[i]);
+    wide_external_layer(s);
+    for (int rd = 0; rd < 8; rd++) {
+      if (rd == 4) {
+        for (int r = 0; r < 13; r++) {
+          s[0] = wide_sbox(kb::add(s[0], p2::d_rc_int[r] + kb::P));
+          put(INT_SBOX + r, s[0]);
+          uint32_t sum = s[0];
+#pragma unroll
+          for (int i = 1; i < 16; i++) sum = kb::add(sum, s[i]);
+#pragma unroll
+          for (int i = 0; i < 16; i++) s[i] = kb::add(kb::mul(s[i], p2::d_diag[i]), sum);
+          if (r < 12) put(INT_S0 + r, s[0]);
+        }
+#pragma unroll
+        for (int i = 0; i < 16; i++) put(EXT_STATE + 64 + i, s[i]);
+      }
+#pragma unroll
+      for (int i = 0; i < 16; i++) {
+        s[i] = wide_sbox(kb::add(s[i], p2::d_rc_ext[rd][i] + kb::P));
+        put(EXT_SBOX + 16 * rd + i, s[i]);
+      }
+      wide_external_layer(s);
+      const int next = rd == 3 ? INT_STATE : rd == 7 ? OUTPUT : EXT_STATE + 16 * (rd + 1);
+#pragma unroll
+      for (int i = 0; i < 16; i++) put(next + i, s[i]);
+    }
+    if (real) {
+      put(SHARD, kb::to_monty(e[0])); put(CLK, kb::to_monty(e[1])); put(STATE_ADDR, kb::to_monty(e[2])); put(IS_REAL, kb::ONE);
+      const LookupSink sink{hkeys, hvals, HASH_SLOTS - 1, counts};
+      for (int i = 0; i < 16; i++) {
+        const uint32_t* rec = e + 3 + 6 * i;
+        if (rec[0] >= kb::P || rec[3] >= kb::P || kb::to_monty(rec[0]) != s[i]) *bad = 1;   // post-state = the permutation of the pre-state
+        uint32_t m[13], rc[14];
+        memory_write_cols(rec, m);
+        for (int c = 0; c < 13; c++) put(STATE_MEM + 13 * i + c, kb::to_monty(m[c]));
+        range_checker(rc, rec[3]);
+        for (int c = 0; c < 14; c++) put(PRE_RC + 14 * i + c, kb::to_monty(rc[c]));
+        range_checker(rc, rec[0]);
+        for (int c = 0; c < 14; c++) put(POST_RC + 14 * i + c, kb::to_monty(rc[c]));
+        if (count) { lookup(sink, B_U16RANGE, m[11] >> 8, m[11]); lookup(sink, B_U8RANGE, 0, m[12]); }
+      }
+    } else {
+      for (int c = SHARD; c < POSEIDON2_PERMUTE_WIDTH; c++) put(c, 0u);
+    }
+  }
+  if (count) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < HASH_SLOTS; i += blockDim.x)
+      if (hkeys[i] != HASH_EMPTY) atomicAdd(counts + hkeys[i], hvals[i]);
   }
 }
 

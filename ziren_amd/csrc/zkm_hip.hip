@@ -1592,6 +1592,8 @@ static int tracegen_events(zkm_ctx* ctx, int chip, const void* events, size_t n_
       case tracegen::MEMORY_INSTRS: launch_alu_rows<tracegen::MEMORY_INSTRS>(ctx, d_events, n_events, height, m->d, counts); break;
       case tracegen::SYSCALL_INSTRS: launch_alu_rows<tracegen::SYSCALL_INSTRS>(ctx, d_events, n_events, height, m->d, counts); break;
       case tracegen::MISC_INSTRS: launch_alu_rows<tracegen::MISC_INSTRS>(ctx, d_events, n_events, height, m->d, counts); break;
+      case tracegen::SYSCALL_CORE: launch_alu_rows<tracegen::SYSCALL_CORE>(ctx, d_events, n_events, height, m->d, counts); break;
+      case tracegen::SYSCALL_PRECOMPILE: launch_alu_rows<tracegen::SYSCALL_PRECOMPILE>(ctx, d_events, n_events, height, m->d, counts); break;
     }
     ctx->mark("trace generation");
     ctx->end_timing(false);  // synchronises: the caller's event buffer is free again
@@ -1959,6 +1961,104 @@ int zkm_tracegen_poseidon2_wide(zkm_ctx* ctx, const uint32_t* events, size_t n_e
     throw;
   }
   ctx->release(d_events);
+  *out = m;
+  API_END
+}
+
+int zkm_tracegen_syscall(zkm_ctx* ctx, const zkm_syscall_event* events, size_t n_events, int precompile, int fixed_log2_rows, zkm_byte_lookups* blu,
+                         zkm_matrix** out) {
+  if (precompile) return tracegen_events(ctx, tracegen::SYSCALL_PRECOMPILE, events, n_events, fixed_log2_rows, blu, out);
+  // SyscallCore keeps the events whose code has the send-to-table byte set or names a Linux syscall (syscall/chip.rs:252-259)
+  std::vector<zkm_syscall_event> kept;
+  if (events)
+    for (size_t i = 0; i < n_events; i++) {
+      const uint32_t code = events[i].a_record.prev_value;
+      if (((code >> 16) & 0xff) == 1 || ((code >> 8) & 0xff) != 0) kept.push_back(events[i]);
+    }
+  return tracegen_events(ctx, tracegen::SYSCALL_CORE, n_events ? (events ? (const void*)kept.data() : nullptr) : nullptr, events ? kept.size() : n_events,
+                         fixed_log2_rows, blu, out);
+}
+
+int zkm_tracegen_memory_global(zkm_ctx* ctx, const zkm_memory_init_finalize_event* events, size_t n_events, uint32_t previous_addr, int fixed_log2_rows,
+                               zkm_matrix** out) {
+  API_BEGIN
+  static_assert(sizeof(zkm_memory_init_finalize_event) == 16, "event records mirror the #[repr(C)] executor structs");
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIP_CHECK(hipSetDevice(ctx->device));
+  if (n_events && !events) throw std::runtime_error("zkm_tracegen_memory_global: null events");
+  const size_t height = padded_trace_rows(n_events, fixed_log2_rows, "zkm_tracegen_memory_global");
+  // generate_trace sorts the events by address first (memory/global.rs:131)
+  std::vector<zkm_memory_init_finalize_event> sorted(events, events + n_events);
+  std::stable_sort(sorted.begin(), sorted.end(), [](const zkm_memory_init_finalize_event& a, const zkm_memory_init_finalize_event& b) { return a.addr < b.addr; });
+  ctx->begin_timing();
+  zkm_matrix* m = new zkm_matrix();
+  m->h = height; m->w = tracegen::MEMORY_GLOBAL_WIDTH;
+  uint32_t* d_events = nullptr;
+  int* d_bad = nullptr;
+  try {
+    m->d = ctx->alloc_n<uint32_t>(height * m->w);
+    d_events = (uint32_t*)ctx->alloc(std::max<size_t>(n_events * 16, 4));
+    d_bad = (int*)ctx->alloc(4);
+    HIP_CHECK(hipMemsetAsync(d_bad, 0, 4, ctx->stream));
+    if (n_events) HIP_CHECK(hipMemcpyAsync(d_events, sorted.data(), n_events * 16, hipMemcpyHostToDevice, ctx->stream));
+    KLAUNCH(ctx, "tracegen_memory_global", 16.0 * n_events + 4.0 * height * m->w, tracegen::memory_global_rows, dim3(div_up(height, (size_t)tracegen::THREADS)),
+            dim3(tracegen::THREADS), 0, (const uint32_t*)d_events, n_events, previous_addr, height, m->d, d_bad);
+    int bad = 0;
+    HIP_CHECK(hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, ctx->stream));
+    ctx->mark("trace generation");
+    ctx->end_timing(false);
+    if (bad) throw std::runtime_error("zkm_tracegen_memory_global: addresses are not strictly increasing (from the previous shard's last address on)");
+  } catch (...) {
+    if (d_events) ctx->release(d_events);
+    if (d_bad) ctx->release(d_bad);
+    if (m->d) ctx->release(m->d);
+    delete m;
+    throw;
+  }
+  ctx->release(d_events);
+  ctx->release(d_bad);
+  *out = m;
+  API_END
+}
+
+int zkm_tracegen_poseidon2_permute(zkm_ctx* ctx, const zkm_poseidon2_permute_event* events, size_t n_events, int fixed_log2_rows, zkm_byte_lookups* blu,
+                                   zkm_matrix** out) {
+  API_BEGIN
+  static_assert(sizeof(zkm_poseidon2_permute_event) == 4 * tracegen::POSEIDON2_PERMUTE_EVENT_WORDS, "flattened Poseidon2PermuteEvent is 99 words");
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIP_CHECK(hipSetDevice(ctx->device));
+  if (n_events && !events) throw std::runtime_error("zkm_tracegen_poseidon2_permute: null events");
+  const size_t height = padded_trace_rows(n_events, fixed_log2_rows, "zkm_tracegen_poseidon2_permute");
+  ctx->begin_timing();
+  zkm_matrix* m = new zkm_matrix();
+  m->h = height; m->w = tracegen::POSEIDON2_PERMUTE_WIDTH;
+  uint32_t* d_events = nullptr;
+  int* d_bad = nullptr;
+  try {
+    m->d = ctx->alloc_n<uint32_t>(height * m->w);
+    const size_t ev_bytes = n_events * sizeof(zkm_poseidon2_permute_event);
+    d_events = (uint32_t*)ctx->alloc(std::max<size_t>(ev_bytes, 4));
+    d_bad = (int*)ctx->alloc(4);
+    HIP_CHECK(hipMemsetAsync(d_bad, 0, 4, ctx->stream));
+    if (n_events) HIP_CHECK(hipMemcpyAsync(d_events, events, ev_bytes, hipMemcpyHostToDevice, ctx->stream));
+    uint32_t* counts = blu ? blu->counts : nullptr;
+    KLAUNCH(ctx, "tracegen_poseidon2_permute", (double)ev_bytes + 4.0 * height * m->w, tracegen::poseidon2_permute_rows,
+            dim3(div_up(height, (size_t)tracegen::THREADS)), dim3(tracegen::THREADS), counts ? 2 * tracegen::HASH_SLOTS * sizeof(uint32_t) : 0,
+            (const uint32_t*)d_events, n_events, height, m->d, counts, d_bad);
+    int bad = 0;
+    HIP_CHECK(hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, ctx->stream));
+    ctx->mark("trace generation");
+    ctx->end_timing(false);
+    if (bad) throw std::runtime_error("zkm_tracegen_poseidon2_permute: a state word is not a field element, or the post-state is not the permutation of the pre-state");
+  } catch (...) {
+    if (d_events) ctx->release(d_events);
+    if (d_bad) ctx->release(d_bad);
+    if (m->d) ctx->release(m->d);
+    delete m;
+    throw;
+  }
+  ctx->release(d_events);
+  ctx->release(d_bad);
   *out = m;
   API_END
 }

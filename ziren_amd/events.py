@@ -521,6 +521,17 @@ SYSCALL = 30
 SYSCALL_EVENT = np.dtype([("pc", "<u4"), ("next_pc", "<u4"), ("shard", "<u4"), ("clk", "<u4"), ("a_record", MEMORY_WRITE_RECORD),
                           ("a_record_is_real", "u1"), ("_pad", "u1", (3,)), ("syscall_id", "<u4"), ("arg1", "<u4"), ("arg2", "<u4")])
 assert SYSCALL_EVENT.itemsize == 56
+# the syscall tables: SyscallCore / SyscallPrecompile (crates/core/machine/src/syscall/chip.rs:71-107), eleven columns
+SYSCALL_WIDTH = 11
+SYS_POSEIDON2_PERMUTE = 0x00010030      # SyscallCode::POSEIDON2_PERMUTE (syscalls/code.rs:182): id 0x30, send-to-table byte set, no extra cycles
+# MemoryInitializeFinalizeEvent (crates/core/executor/src/events/memory.rs:180-209, #[repr(C)]): addr, value, shard, timestamp
+MEMORY_INIT_FINALIZE_EVENT = np.dtype([("addr", "<u4"), ("value", "<u4"), ("shard", "<u4"), ("timestamp", "<u4")])
+MEMORY_GLOBAL_WIDTH = 111               # MemoryInitCols (crates/core/machine/src/memory/global.rs:221-259)
+# Poseidon2PermuteEvent (events/precompiles/poseidon2_permute.rs:9-27) flattened for the C ABI: shard, clk, state_addr and the sixteen
+# MemoryWriteRecords of the state words (pre_state = prev_value, post_state = value)
+POSEIDON2_PERMUTE_EVENT = np.dtype([("shard", "<u4"), ("clk", "<u4"), ("state_addr", "<u4"), ("state_records", MEMORY_WRITE_RECORD, (16,))])
+assert POSEIDON2_PERMUTE_EVENT.itemsize == 4 * 99
+POSEIDON2_PERMUTE_WIDTH = 973           # Poseidon2MemCols (syscall/precompiles/poseidon2/columns.rs:9-27)
 SYSCALL_INSTRS_WIDTH = 77
 # SyscallCode (crates/core/executor/src/syscalls/code.rs): byte 0-1 id, byte 2 "has its own table", byte 3 extra cycles
 SYS_HALT, SYS_WRITE, SYS_ENTER_UNCONSTRAINED, SYS_EXIT_UNCONSTRAINED, SYS_COMMIT, SYS_COMMIT_DEFERRED_PROOFS, SYS_HINT_LEN = 0, 2, 3, 4, 0x10, 0x1a, 0xf0

@@ -75,6 +75,37 @@ _CHIP_OF = {op: chip for chip, ops in E.CHIP_OPCODES.items() for op in ops}
 
 
 def run(n_cycles: int, seed: int = 1, shard: int = 1, pc_base: int = 0x1000, halt: bool = False):
+    """One shard of a generated program: (program, record, public values). See _execute."""
+    m = _execute(n_cycles, seed, shard, pc_base, halt)
+    return m.program, m.shards[0].record, m.shards[0].pv
+
+
+class Shard:
+    """One ExecutionRecord of a run: kind "cpu" (instructions), "precompile" (deferred precompile events) or "memory" (global
+    memory initialisation / finalisation), its events and the public values its proof carries."""
+
+    def __init__(self, kind, record, pv):
+        self.kind, self.record, self.pv = kind, record, pv
+
+
+class Machine:
+    def __init__(self, program, shards, pc_base):
+        self.program, self.shards, self.pc_base = program, shards, pc_base
+
+
+def run_machine(n_cycles: int = 0, seed: int = 1, pc_base: int = 0x1000, shard_cycles: int = 1 << 30, program=None, poseidon2_calls: int = 0,
+                memory_chunk: int = 1 << 30) -> Machine:
+    """A whole run as the reference's prover sees it (crates/core/machine/src/utils/prove.rs:255-400): CPU shards of at most `shard_cycles`
+    cycles (never split between a branch and its delay slot, executor.rs:2352-2356), then one shard with the deferred precompile events
+    (ExecutionRecord::split, record.rs:130-218), then the shards that initialise and finalise every touched address
+    (executor.rs:2554-2618, record.rs:220-277; `memory_chunk` events per shard). `program`: a list of (opcode, op_a, op_b, op_c, imm_b, imm_c)
+    to execute until it halts instead of generating one; `poseidon2_calls`: POSEIDON2_PERMUTE precompile calls spread over a generated run."""
+    return _execute(n_cycles, seed, 1, pc_base, True, shard_cycles=shard_cycles, given=program, poseidon2_calls=poseidon2_calls, memory_chunk=memory_chunk,
+                    machine=True)
+
+
+def _execute(n_cycles: int, seed: int = 1, shard: int = 1, pc_base: int = 0x1000, halt: bool = False, shard_cycles: int = 1 << 30, given=None,
+             poseidon2_calls: int = 0, memory_chunk: int = 1 << 30, machine: bool = False) -> Machine:
     """Execute `n_cycles` instructions of a program generated on the way. Returns (program, record, public_values) with
     program: INSTRUCTION array (instructions that were jumped over are `ADD $0, 0, 0` no-ops that never run), record:
     structured event arrays, public_values: dict of the words the Cpu chip checks (start_pc, next_pc, execution_shard).
@@ -90,8 +121,14 @@ def run(n_cycles: int, seed: int = 1, shard: int = 1, pc_base: int = 0x1000, hal
     R = dict(enumerate(R))         # registers 0..33 and, keyed by their byte address, the memory words that get touched
     DATA, LOW = 0x00100000, 64     # a data region, and a few words whose address fits one byte (the chip's `addr < 256` branch)
     first = {}                     # register -> (shard, timestamp, value) on entry to this shard (ExecutionRecord::cpu_local_memory_access)
+    born = {}                      # address -> the value it held before its first access of the whole run (what MemoryGlobalInit sends)
     program = {}
     rec = Record()
+    done_shards = []               # (Record lists, first pc, last next_pc, shard number) of the CPU shards already closed
+    precompile = []                # (syscall event, Poseidon2PermuteEvent tuple, its MemoryLocalEvents) in execution order
+    if given is not None:
+        for i, ins in enumerate(given):
+            program[pc_base + 4 * i] = tuple(ins)
     pc, next_pc = pc_base, pc_base + 4
     delay_slot = False
     pending_jump_reg = None        # a register just loaded with a jump target
@@ -99,6 +136,7 @@ def run(n_cycles: int, seed: int = 1, shard: int = 1, pc_base: int = 0x1000, hal
     def read(reg, clk, pos):
         if reg not in R:
             R[reg], last[reg] = 0, (0, 0)
+        born.setdefault(reg, R[reg])
         first.setdefault(reg, (last[reg][0], last[reg][1], R[reg]))
         r = (TAG_READ, (R[reg], shard, clk + pos, last[reg][0], last[reg][1]), None)
         last[reg] = (shard, clk + pos)
@@ -108,6 +146,7 @@ def run(n_cycles: int, seed: int = 1, shard: int = 1, pc_base: int = 0x1000, hal
         value = 0 if reg == 0 else value & 0xffffffff
         if reg not in R:
             R[reg], last[reg] = 0, (0, 0)
+        born.setdefault(reg, R[reg])
         first.setdefault(reg, (last[reg][0], last[reg][1], R[reg]))
         r = (TAG_WRITE, None, (value, shard, clk + pos, R[reg], last[reg][0], last[reg][1]))
         R[reg] = value
@@ -115,6 +154,7 @@ def run(n_cycles: int, seed: int = 1, shard: int = 1, pc_base: int = 0x1000, hal
         return r
 
     digest = [int(x) for x in rng.integers(0, 1 << 32, 8, dtype=np.uint64)]
+    committed = {}                 # digest index -> word, as the COMMIT syscalls publish them
     epilogue = []
     if halt:   # li $v0, code; li $a0, arg1; li $a1, arg2; syscall — eight commits, then halt with exit code 0
         for i, w in enumerate(digest):
@@ -122,16 +162,51 @@ def run(n_cycles: int, seed: int = 1, shard: int = 1, pc_base: int = 0x1000, hal
                          (E.SYSCALL, E.REG_V0, E.REG_A0, E.REG_A1, 0, 0)]
         epilogue += [(E.ADD, E.REG_V0, E.SYS_HALT, 0, 1, 1), (E.ADD, E.REG_A0, 0, 0, 1, 1), (E.SYSCALL, E.REG_V0, E.REG_A0, E.REG_A1, 0, 0)]
     cyc = -1
-    while cyc + 1 < n_cycles + len(epilogue):
+    shard_start = 0                # global cycle at which the current shard began (its clk is 0 there)
+    halted = False
+    queued = []                    # instructions that must come next (a precompile call's set-up), generated runs only
+    p2_at = set(int(x) for x in np.linspace(n_cycles // 8, max(n_cycles - 40, n_cycles // 8), poseidon2_calls)) if poseidon2_calls else set()
+    p2_seq = 0
+
+    def close_shard():
+        """bump_record (executor.rs:2186-2200): the open access chains become the shard's MemoryLocal events."""
+        nonlocal rec, shard, shard_start
+        rec.memory_local = [(reg, first[reg], (last[reg][0], last[reg][1], R[reg])) for reg in sorted(first)] + rec.memory_local
+        done_shards.append((rec, shard))
+        first.clear()
+        rec = Record()
+        shard += 1
+        shard_start = cyc
+
+    while (not halted) if given is not None else (cyc + 1 < n_cycles + len(epilogue)):
         cyc += 1
-        clk = 5 * cyc
+        if machine and cyc - shard_start >= shard_cycles and not delay_slot and not queued and (given is not None or cyc < n_cycles):
+            close_shard()
+        clk = 5 * (cyc - shard_start)
         u = rng.random()
-        if cyc >= n_cycles and delay_slot:      # a branch's delay slot comes first: one more plain instruction
+        if given is None and cyc >= n_cycles and delay_slot:      # a branch's delay slot comes first: one more plain instruction
             epilogue.insert(cyc - n_cycles, (E.ADD, 1, 0, 0, 1, 1))
         reg = lambda: int(rng.integers(0, 32))       # noqa: E731
         dst = lambda: int(rng.integers(1, 32)) if rng.random() > 0.02 else 0   # noqa: E731  (a few writes to $0)
+        if given is None and cyc in p2_at and cyc < n_cycles:
+            # a POSEIDON2_PERMUTE call as the reference's test program makes it (syscall/precompiles/poseidon2/mod.rs:24-43): sixteen field
+            # elements stored to the state, the code in $v0, the state's address in $a0, zero in $a1, SYSCALL
+            ptr = 0x00200000 + 64 * p2_seq
+            p2_seq += 1
+            for i in range(16):
+                queued += [(E.ADD, 30, int(rng.integers(0, F.P)), 0, 1, 1), (E.SW, 30, 0, ptr + 4 * i, 0, 1)]
+            queued += [(E.ADD, E.REG_V0, E.SYS_POSEIDON2_PERMUTE, 0, 1, 1), (E.ADD, E.REG_A0, ptr, 0, 1, 1), (E.ADD, E.REG_A1, 0, 0, 1, 1),
+                       (E.SYSCALL, E.REG_V0, E.REG_A0, E.REG_A1, 0, 0)]
+            n_cycles += len(queued)        # the body grows by the call; the epilogue still follows it
+            p2_at = set(x + len(queued) if x > cyc else x for x in p2_at)
         # ---- pick the instruction at pc (the program is written as it runs)
-        if cyc >= n_cycles:
+        if given is not None:
+            if pc not in program:
+                raise RuntimeError(f"miniexec: pc {pc:#x} is outside the program")
+            ins = program[pc]
+        elif queued and not delay_slot and pending_jump_reg is None:
+            ins = queued.pop(0)
+        elif cyc >= n_cycles:
             ins = epilogue[cyc - n_cycles]
         elif pending_jump_reg is not None and not delay_slot:
             ins = (E.JUMP, dst(), pending_jump_reg, 0, 0, 1)
@@ -192,7 +267,7 @@ def run(n_cycles: int, seed: int = 1, shard: int = 1, pc_base: int = 0x1000, hal
         else:   # load a forward target into a register (ADD of two immediates); the jump through it comes next
             pending_jump_reg = int(rng.integers(1, 32))
             ins = (E.ADD, pending_jump_reg, next_pc + 4 + 4 * int(rng.integers(3, 10)), 0, 1, 1)
-        assert pc not in program
+        assert given is not None or pc not in program
         program[pc] = ins
         op, op_a, op_b, op_c, imm_b, imm_c = ins
         # ---- execute it
@@ -297,13 +372,37 @@ def run(n_cycles: int, seed: int = 1, shard: int = 1, pc_base: int = 0x1000, hal
             b_rec = read(op_b, clk, POS_B)
             b = b_rec[1][0]
             sid = code & 0xffff
-            assert sid in (E.SYS_HALT, E.SYS_COMMIT), sid
-            a = code                                       # neither returns a value: V0 keeps the code
+            assert code in (E.SYS_HALT, E.SYS_COMMIT, E.SYS_POSEIDON2_PERMUTE), code
+            if code == E.SYS_POSEIDON2_PERMUTE:
+                # Poseidon2PermuteSyscall::execute (syscalls/precompiles/poseidon2/permute.rs:14-71): the sixteen words at $a0 are
+                # replaced by their permutation, written at timestamp clk through the syscall's own local-access map; a CPU access
+                # chain that is open on one of these words is closed first (SyscallContext::postprocess, context.rs:128-147)
+                from .recursion import poseidon2_permute
+                assert c == 0 and b % 4 == 0
+                pre = [R.get(b + 4 * i, 0) for i in range(16)]
+                assert max(pre) < F.P
+                post = poseidon2_permute(pre)
+                records, local = [], []
+                for i in range(16):
+                    addr = b + 4 * i
+                    if addr not in R:
+                        R[addr], last[addr] = 0, (0, 0)
+                    born.setdefault(addr, R[addr])
+                    if addr in first:
+                        rec.memory_local.append((addr, first.pop(addr), (last[addr][0], last[addr][1], R[addr])))
+                    records.append((post[i], shard, clk, pre[i], last[addr][0], last[addr][1]))
+                    local.append((addr, (last[addr][0], last[addr][1], pre[i]), (shard, clk, post[i])))
+                    R[addr], last[addr] = post[i], (shard, clk)
+                precompile.append(((pc, next_pc, shard, clk, (0, 0, 0, 0, 0, 0), 0, [0, 0, 0], sid, b, c), (shard, clk, b, records), local))
+            a = code                                       # none of them returns a value: V0 keeps the code
             a_rec = write(op_a, a, clk, POS_A)
             hi = code
-            next_pc_after = 0 if sid == E.SYS_HALT else next_pc
+            next_pc_after = 0 if code == E.SYS_HALT else next_pc
             rec.syscall.append((pc, next_pc_after, shard, clk, a_rec[2], 1, [0, 0, 0], sid, b, c))
             syscall_next = next_pc_after
+            halted = code == E.SYS_HALT
+            if code == E.SYS_COMMIT:
+                committed[b] = c
         elif op in _BRANCH:
             if op in _ONE_OPERAND:
                 b = 0
@@ -368,30 +467,71 @@ def run(n_cycles: int, seed: int = 1, shard: int = 1, pc_base: int = 0x1000, hal
                 o["write"] = r[2]
         return o
 
-    cpu = np.zeros(len(rec.cpu), dtype=CPU_EVENT)
-    none = opt(None)
-    for i, (clk, p, np_, nnp, a, a_rec, b, b_rec, c, c_rec, hi, hi_rec, m_rec) in enumerate(rec.cpu):
-        e = cpu[i]
-        e["clk"], e["pc"], e["next_pc"], e["next_next_pc"], e["a"], e["b"], e["c"] = clk, p, np_, nnp, a, b, c
-        e["a_record"], e["b_record"], e["c_record"], e["hi_record"] = opt(a_rec), opt(b_rec), opt(c_rec), opt(hi_rec)
-        e["memory_record"] = opt(m_rec) if m_rec is not None else none
-        e["hi"]["tag"], e["hi"]["value"] = (0, hi) if hi is not None else (1, 0)
-    out = Record()
-    out.cpu = cpu
-    out.alu = {chip: np.array(v, dtype=E.ALU_EVENT) if v else np.zeros(0, dtype=E.ALU_EVENT) for chip, v in rec.alu.items()}
-    out.mul = np.array(rec.mul, dtype=E.COMP_ALU_EVENT) if rec.mul else np.zeros(0, dtype=E.COMP_ALU_EVENT)
-    out.divrem = np.array(rec.divrem, dtype=E.COMP_ALU_EVENT) if rec.divrem else np.zeros(0, dtype=E.COMP_ALU_EVENT)
-    out.branch = np.array(rec.branch, dtype=E.BRANCH_EVENT) if rec.branch else np.zeros(0, dtype=E.BRANCH_EVENT)
-    out.jump = np.array(rec.jump, dtype=E.JUMP_EVENT) if rec.jump else np.zeros(0, dtype=E.JUMP_EVENT)
-    out.mov_cond = np.array(rec.mov_cond, dtype=E.MOV_COND_EVENT) if rec.mov_cond else np.zeros(0, dtype=E.MOV_COND_EVENT)
-    out.mem_instr = np.array(rec.mem_instr, dtype=E.MEM_INSTR_EVENT) if rec.mem_instr else np.zeros(0, dtype=E.MEM_INSTR_EVENT)
-    out.syscall = np.array(rec.syscall, dtype=E.SYSCALL_EVENT) if rec.syscall else np.zeros(0, dtype=E.SYSCALL_EVENT)
-    out.misc = np.array(rec.misc, dtype=E.MISC_EVENT) if rec.misc else np.zeros(0, dtype=E.MISC_EVENT)
-    out.memory_local = np.array([(reg, first[reg], (last[reg][0], last[reg][1], R[reg])) for reg in sorted(first)], dtype=MEMORY_LOCAL_EVENT) \
-        if first else np.zeros(0, dtype=MEMORY_LOCAL_EVENT)
-    pv = {"start_pc": pc_base, "next_pc": int(cpu["next_pc"][-1]) if len(cpu) else pc_base, "execution_shard": shard, "shard": shard,
-          "exit_code": 0, "committed_value_digest": digest if halt else [0] * 8}
-    return prog, out, pv
+    def arr(v, dt):
+        return np.array(v, dtype=dt) if len(v) else np.zeros(0, dtype=dt)
+
+    def pack(rec):
+        cpu = np.zeros(len(rec.cpu), dtype=CPU_EVENT)
+        none = opt(None)
+        for i, (clk, p, np_, nnp, a, a_rec, b, b_rec, c, c_rec, hi, hi_rec, m_rec) in enumerate(rec.cpu):
+            e = cpu[i]
+            e["clk"], e["pc"], e["next_pc"], e["next_next_pc"], e["a"], e["b"], e["c"] = clk, p, np_, nnp, a, b, c
+            e["a_record"], e["b_record"], e["c_record"], e["hi_record"] = opt(a_rec), opt(b_rec), opt(c_rec), opt(hi_rec)
+            e["memory_record"] = opt(m_rec) if m_rec is not None else none
+            e["hi"]["tag"], e["hi"]["value"] = (0, hi) if hi is not None else (1, 0)
+        out = Record()
+        out.cpu = cpu
+        out.alu = {chip: arr(v, E.ALU_EVENT) for chip, v in rec.alu.items()}
+        out.mul, out.divrem = arr(rec.mul, E.COMP_ALU_EVENT), arr(rec.divrem, E.COMP_ALU_EVENT)
+        out.branch, out.jump, out.mov_cond = arr(rec.branch, E.BRANCH_EVENT), arr(rec.jump, E.JUMP_EVENT), arr(rec.mov_cond, E.MOV_COND_EVENT)
+        out.mem_instr, out.syscall, out.misc = arr(rec.mem_instr, E.MEM_INSTR_EVENT), arr(rec.syscall, E.SYSCALL_EVENT), arr(rec.misc, E.MISC_EVENT)
+        out.memory_local = arr(rec.memory_local, MEMORY_LOCAL_EVENT)
+        return out
+
+    rec.memory_local = [(reg, first[reg], (last[reg][0], last[reg][1], R[reg])) for reg in sorted(first)] + rec.memory_local
+    done_shards.append((rec, shard))
+    final_digest = [committed.get(i, 0) for i in range(8)] if given is not None else (digest if halt else [0] * 8)
+    shards = []
+    for k, (r, sh) in enumerate(done_shards):
+        o = pack(r)
+        # the public values every shard of a batch carries are the run's final ones (executor.rs:2381-2400): the committed digest
+        # is the same in all of them; start_pc / next_pc are the shard's own
+        pv = {"start_pc": int(o.cpu["pc"][0]) if len(o.cpu) else pc_base, "next_pc": int(o.cpu["next_pc"][-1]) if len(o.cpu) else pc_base,
+              "execution_shard": sh, "shard": sh, "exit_code": 0, "committed_value_digest": final_digest}
+        shards.append(Shard("cpu", o, pv))
+    if not machine:
+        return Machine(prog, shards, pc_base)
+    # ---- the deferred shards (prove.rs:283-400): precompile events first, then memory initialisation / finalisation
+    last_pv = shards[-1].pv
+    n_shard = shards[-1].pv["shard"]
+    if precompile:
+        n_shard += 1
+        o = Record()
+        o.cpu = np.zeros(0, dtype=CPU_EVENT)
+        o.precompile_syscall = arr([e[0] for e in precompile], E.SYSCALL_EVENT)
+        o.poseidon2_permute = arr([e[1] for e in precompile], E.POSEIDON2_PERMUTE_EVENT)
+        o.memory_local = arr([ev for e in precompile for ev in e[2]], MEMORY_LOCAL_EVENT)
+        pv = dict(last_pv, start_pc=last_pv["next_pc"], shard=n_shard)
+        shards.append(Shard("precompile", o, pv))
+    touched = sorted(a for a in born if last[a] != (0, 0))
+    assert touched and touched[0] == 0, "register $0 is always touched (executor.rs:2561-2574 handles the other case separately)"
+    init = arr([(a, born[a], 1, 1) for a in touched], E.MEMORY_INIT_FINALIZE_EVENT)
+    fin = arr([(a, R[a], last[a][0], last[a][1]) for a in touched], E.MEMORY_INIT_FINALIZE_EVENT)
+    prev_addr = 0
+    for k in range(0, len(touched), memory_chunk):
+        n_shard += 1
+        o = Record()
+        o.cpu = np.zeros(0, dtype=CPU_EVENT)
+        o.memory_init, o.memory_finalize = init[k:k + memory_chunk], fin[k:k + memory_chunk]
+        last_addr = int(o.memory_init["addr"][-1])
+        pv = dict(last_pv, start_pc=last_pv["next_pc"], shard=n_shard, previous_init_addr=prev_addr, last_init_addr=last_addr,
+                  previous_finalize_addr=prev_addr, last_finalize_addr=last_addr)
+        prev_addr = last_addr
+        shards.append(Shard("memory", o, pv))
+    for sh in shards:      # shards before the memory ones: previous = last = 0 (verify.rs:207-245)
+        for key in ("previous_init_addr", "last_init_addr", "previous_finalize_addr", "last_finalize_addr"):
+            sh.pv.setdefault(key, 0)
+    return Machine(prog, shards, pc_base)
 
 
 def add_dependencies(rec: Record) -> Record:
@@ -436,4 +576,7 @@ def public_values(pv: dict) -> np.ndarray:
     v[PV_EXIT_CODE] = pv.get("exit_code", 0)
     for i, w in enumerate(pv.get("committed_value_digest", [0] * 8)):     # [Word; 8]: one field element per byte
         v[4 * i:4 * i + 4] = [(w >> (8 * k)) & 0xff for k in range(4)]
+    for base, key in ((45, "previous_init_addr"), (77, "last_init_addr"), (109, "previous_finalize_addr"), (141, "last_finalize_addr")):
+        a = pv.get(key, 0)
+        v[base:base + 32] = [(a >> k) & 1 for k in range(32)]
     return F.to_monty(v)

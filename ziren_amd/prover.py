@@ -194,6 +194,34 @@ class Context:
                                                          C.c_int(fixed_log2_rows), C.byref(h)))
         return self._born(h)
 
+    def tracegen_syscall(self, events: np.ndarray, precompile: bool, fixed_log2_rows: int = -1, blu: "ByteLookups" = None) -> DeviceMatrix:
+        """`generate_trace` of the SyscallCore / SyscallPrecompile tables on the device (zkm_tracegen_syscall); dtype events.SYSCALL_EVENT."""
+        from . import events as _ev
+        ev = np.ascontiguousarray(events, dtype=_ev.SYSCALL_EVENT)
+        h = C.c_void_p()
+        lib.check(lib.load().zkm_tracegen_syscall(self.h, C.c_void_p(ev.ctypes.data if len(ev) else None), C.c_size_t(len(ev)), C.c_int(int(precompile)),
+                                                  C.c_int(fixed_log2_rows), blu.h if blu is not None else None, C.byref(h)))
+        return self._born(h)
+
+    def tracegen_memory_global(self, events: np.ndarray, previous_addr: int = 0, fixed_log2_rows: int = -1) -> DeviceMatrix:
+        """`generate_trace` of MemoryGlobalInit / MemoryGlobalFinalize on the device (zkm_tracegen_memory_global); dtype
+        events.MEMORY_INIT_FINALIZE_EVENT; previous_addr = the previous shard's last address (public values)."""
+        from . import events as _ev
+        ev = np.ascontiguousarray(events, dtype=_ev.MEMORY_INIT_FINALIZE_EVENT)
+        h = C.c_void_p()
+        lib.check(lib.load().zkm_tracegen_memory_global(self.h, C.c_void_p(ev.ctypes.data if len(ev) else None), C.c_size_t(len(ev)),
+                                                        C.c_uint32(previous_addr), C.c_int(fixed_log2_rows), C.byref(h)))
+        return self._born(h)
+
+    def tracegen_poseidon2_permute(self, events: np.ndarray, fixed_log2_rows: int = -1, blu: "ByteLookups" = None) -> DeviceMatrix:
+        """`generate_trace` of the Poseidon2Permute precompile on the device (zkm_tracegen_poseidon2_permute); dtype events.POSEIDON2_PERMUTE_EVENT."""
+        from . import events as _ev
+        ev = np.ascontiguousarray(events, dtype=_ev.POSEIDON2_PERMUTE_EVENT)
+        h = C.c_void_p()
+        lib.check(lib.load().zkm_tracegen_poseidon2_permute(self.h, C.c_void_p(ev.ctypes.data if len(ev) else None), C.c_size_t(len(ev)),
+                                                            C.c_int(fixed_log2_rows), blu.h if blu is not None else None, C.byref(h)))
+        return self._born(h)
+
     def tracegen_misc_instrs(self, events: np.ndarray, fixed_log2_rows: int = -1, blu: "ByteLookups" = None) -> DeviceMatrix:
         """`generate_trace` of the MiscInstrs chip on the device (zkm_tracegen_misc_instrs); dtype events.MISC_EVENT."""
         from . import events as _ev
