@@ -181,3 +181,118 @@ def test_oracle_proves_and_verifies_a_machine(oracle):
     bad_pv = dict(m.shards[-1].pv, last_init_addr=m.shards[-1].pv["last_init_addr"] ^ 4)
     bad, _ = oracle.prove_shard(opk, shards[-1], [c.trace for c in shards[-1]], M.public_values(bad_pv), fri, synth.NUM_PV_ELTS, start.copy())
     assert ok(shards, proofs[:-1] + [bad]) == f"shard {len(proofs)}: invalid shard proof (code {oracle.verify_shard(opk, shards[-1], fri, synth.NUM_PV_ELTS, start.copy(), bad)})"
+
+
+# ---- GPU ------------------------------------------------------------------------------------------------------------------------------
+
+@pytest.mark.gpu
+def test_gpu_new_chip_tracegen_matches_oracle(hip_ctx, oracle):
+    """zkm_tracegen_memory_global / _syscall / _poseidon2_permute against the restated generate_trace, bit for bit, with the byte lookups
+    they record; unsorted memory events are sorted as the reference sorts them; bad inputs are errors, not silent rows."""
+    from ziren_amd import lib
+    m = M.run_machine(3000, seed=12, shard_cycles=1 << 20, poseidon2_calls=5)
+    mem, pre, cpu = m.shards[-1].record, m.shards[-2].record, m.shards[0].record
+    rng = np.random.default_rng(3)
+    for ev in (mem.memory_init, mem.memory_finalize):
+        for sub, prev, fixed in ((ev, 0, -1), (ev[7:], int(ev["addr"][6]), -1), (ev[:1], 0, -1), (ev[rng.permutation(len(ev))], 0, 9), (ev[:0], 0, -1)):
+            if len(sub) == 0:
+                born = hip_ctx.tracegen_memory_global(sub, prev, fixed)
+                assert born.height == 16 and not born.to_host().any()
+                born.free()
+                continue
+            want = oracle.tracegen_memory_global(sub, prev, fixed)
+            born = hip_ctx.tracegen_memory_global(sub, prev, fixed)
+            assert (born.height, born.width) == want.shape and np.array_equal(born.to_host(), want), (len(sub), prev)
+            born.free()
+        with pytest.raises(lib.ZkmError, match="strictly increasing"):
+            hip_ctx.tracegen_memory_global(ev[3:], int(ev["addr"][5]))
+        with pytest.raises(lib.ZkmError, match="strictly increasing"):
+            hip_ctx.tracegen_memory_global(np.concatenate([ev[:4], ev[3:6]]), 0)
+    for precompile, ev in ((False, cpu.syscall), (True, pre.precompile_syscall), (False, cpu.syscall[:0]), (True, np.tile(pre.precompile_syscall, 300))):
+        counts = np.zeros((1 << 16, 10), dtype=np.uint32)
+        want = oracle.tracegen_syscall(ev, precompile, -1, counts)
+        blu = hip_ctx.byte_lookups()
+        born = hip_ctx.tracegen_syscall(ev, precompile, -1, blu)
+        mults = hip_ctx.tracegen_byte_mults(blu)
+        assert (born.height, born.width) == want.shape and np.array_equal(born.to_host(), want), (precompile, len(ev))
+        assert np.array_equal(F.from_monty(mults.to_host()), counts)
+        born.free(); mults.free(); blu.free()
+    assert int(F.from_monty(oracle.tracegen_syscall(cpu.syscall, False))[:, 10].sum()) == 5      # of 14 syscalls only the precompile calls go to the table
+    for ev, fixed in ((pre.poseidon2_permute, -1), (pre.poseidon2_permute[:1], -1), (pre.poseidon2_permute[:0], -1), (np.tile(pre.poseidon2_permute, 70), 9)):
+        counts = np.zeros((1 << 16, 10), dtype=np.uint32)
+        want = oracle.tracegen_poseidon2_permute(ev, fixed, counts)
+        blu = hip_ctx.byte_lookups()
+        born = hip_ctx.tracegen_poseidon2_permute(ev, fixed, blu)
+        mults = hip_ctx.tracegen_byte_mults(blu)
+        assert (born.height, born.width) == want.shape and np.array_equal(born.to_host(), want), len(ev)
+        assert np.array_equal(F.from_monty(mults.to_host()), counts) and counts.sum() == 32 * len(ev)
+        born.free(); mults.free(); blu.free()
+    bad = pre.poseidon2_permute.copy()
+    bad["state_records"][2, 5]["value"] ^= 1
+    with pytest.raises(lib.ZkmError, match="permutation of the pre-state"):
+        hip_ctx.tracegen_poseidon2_permute(bad)
+
+
+def gpu_prove_machine(hip_ctx, oracle, m, fri):
+    """Every shard of the run: traces born on the device (equal to the oracle's rows), proven by the HIP prover and by the oracle."""
+    from ziren_amd import prover
+    oshards = check_machine_airs(oracle, m)
+    byte_prep, prog_prep = oshards[0][-2].prep_trace, oshards[0][-1].prep_trace
+    pc_start = F.to_monty(m.pc_base)
+    opk = oracle.Pk([byte_prep, prog_prep], [0, 0], pc_start, ZERO_DIGEST, fri.log_blowup)
+    pk = None
+    proofs, oproofs = [], []
+    for k, (ocs, sh) in enumerate(zip(oshards, m.shards)):
+        dev = ML.Device(hip_ctx)
+        dcs = ML.build_shard(dev, m, k)
+        assert [c.name for c in dcs] == [c.name for c in ocs]
+        for d, o in zip(dcs, ocs):
+            assert np.array_equal(d.trace.to_host(), o.trace), (k, d.name)
+        hp = prover.HipProver(ocs, fri, synth.NUM_PV_ELTS, ctx=hip_ctx)
+        hp.specialize_quotient_kernels(ocs)
+        if pk is None:
+            pk = hp.setup([hip_ctx.tracegen_byte_table(), hip_ctx.tracegen_program(m.program, m.pc_base, ocs[-1].log_height)], [0, 0], pc_start, ZERO_DIGEST)
+            assert np.array_equal(pk.commit, opk.commitment())
+        ch = prover.new_challenger()
+        pk.observe_into(ch)
+        och = oracle.new_challenger()
+        opk.observe_into(och)
+        pvs = ML.shard_public_values(sh)
+        proofs.append(hp.prove_shard(pk, pvs, [c.trace for c in dcs], ch).copy())
+        oproofs.append(oracle.prove_shard(opk, ocs, [c.trace for c in ocs], pvs, fri, synth.NUM_PV_ELTS, och)[0])
+        assert np.array_equal(proofs[-1], oproofs[-1]), f"shard {k + 1}: GPU proof differs from the oracle's"
+        for c in dcs:
+            c.trace.free()
+        dev.blu.free()
+    return opk, oshards, proofs
+
+
+@pytest.mark.gpu
+def test_gpu_machine_with_precompile_proves_and_verifies(hip_ctx, oracle):
+    """BASELINE config 4's shape at test size (a program with precompile calls, several shards): CPU shards, the precompile shard and the
+    memory shard proven on the GPU from device-born traces, bit-identical to the oracle's proofs, accepted by the restated machine
+    verifier; without the memory shard the global digests do not cancel."""
+    m = M.run_machine(5000, seed=21, shard_cycles=2048, poseidon2_calls=4)
+    assert [s.kind for s in m.shards] == ["cpu", "cpu", "cpu", "precompile", "memory"]
+    fri = abi.FriConfig(1, 84, 16)
+    opk, oshards, proofs = gpu_prove_machine(hip_ctx, oracle, m, fri)
+    ok = lambda sc, pf: ML.verify_machine(oracle, opk, sc, pf, fri, synth.NUM_PV_ELTS, m.pc_base, ZERO_DIGEST)   # noqa: E731
+    assert ok(oshards, proofs) is None
+    assert ok(oshards[:-1], proofs[:-1]) == "global cumulative sum is not zero"
+    assert ok(oshards[:3] + oshards[4:], proofs[:3] + proofs[4:]) is not None
+
+
+@pytest.mark.gpu
+def test_gpu_fibonacci_n1000(hip_ctx, oracle):
+    """BASELINE config 1 (examples/fibonacci, n = 1000) through the HIP prover: the hand-assembled guest, three CPU shards and the memory
+    shard, every proof bit-identical to the oracle's, the machine verifies, and the committed digest is (n, fib(n - 1), fib(n)) mod 7919
+    as Python computes it."""
+    n = 1000
+    m = M.run_machine(program=fibonacci_program(n), shard_cycles=2048)
+    fri = abi.FriConfig(1, 84, 16)
+    opk, oshards, proofs = gpu_prove_machine(hip_ctx, oracle, m, fri)
+    assert ML.verify_machine(oracle, opk, oshards, proofs, fri, synth.NUM_PV_ELTS, m.pc_base, ZERO_DIGEST) is None
+    a, b = fib(n)
+    pv = F.from_monty(ML.decode_shard_proof(proofs[-1])["public_values"])
+    words = [int(sum(int(pv[4 * i + k]) << (8 * k) for k in range(4))) for i in range(8)]
+    assert words == [n, a, b, 0, 0, 0, 0, 0]

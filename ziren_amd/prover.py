@@ -513,6 +513,9 @@ class HipProver:
 
     # fn commit (prover.rs:258-292)
     def commit(self, public_values: np.ndarray, traces: Sequence[DeviceMatrix]) -> ShardMainData:
+        # a HipProver is built for one shard's chip list (the reference's shard_chips_ordered): traces pair with self.chips one to one
+        if len(traces) != len(self.chips):
+            raise ValueError(f"commit: {len(traces)} traces for {len(self.chips)} chips — build the prover with the chips this shard includes")
         names = (C.c_char_p * len(self.chips))(*[c.name.encode() for c in self.chips])
         pv = np.ascontiguousarray(public_values, dtype=np.uint32)
         root = np.zeros(8, dtype=np.uint32)
