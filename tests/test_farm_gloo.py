@@ -39,6 +39,21 @@ WORKER = textwrap.dedent("""
     assert [int(table[i, 0]) for i in range(n_shards)] == [1000 * i + 7 for i in range(n_shards)]
     total = f.sum_over_ranks(float(len(mine)))
     assert total == n_shards
+    # the work queue: shards go to whoever is free; rank 1 is three times slower, so rank 0 proves more of them; every shard exactly once;
+    # whole proof streams (different lengths) arrive at rank 0 in shard order
+    def prove(i):
+        time.sleep(0.01 * (1 + 2 * f.rank))
+        return np.arange(100 + 7 * i, dtype=np.uint32) + 1000 * i
+    f.barrier()
+    ids, proofs = f.run_queue(12, prove)
+    counts = f.sum_over_ranks(float(len(ids)))
+    assert counts == 12
+    got = f.gather_proofs(ids, proofs, 12)
+    if f.rank == 0:
+        assert len(ids) > 6, ids
+        assert all(np.array_equal(got[i], np.arange(100 + 7 * i, dtype=np.uint32) + 1000 * i) for i in range(12))
+    else:
+        assert got is None and 0 < len(ids) < 6
     if f.rank == 0:
         print(json.dumps({"elapsed": elapsed, "ok": True}))
     f.close()

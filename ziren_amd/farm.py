@@ -1,11 +1,12 @@
 """Shard farm: independent shards dealt to one prover process per GPU.
 
 Each shard's commit+open depends only on (pk, its traces, a clone of the post-pk challenger)
-(crates/core/machine/src/utils/prove.rs:208-209,492-497), so there is no data-path collective:
-rank r proves shards r, r + world, r + 2*world, ... The process group is used only for the
-barrier around the timed region, the max-over-ranks time, and (optionally) gathering the small
-per-shard commitments so rank 0 can hand the proofs to the recursion tree
-(crates/prover/src/lib.rs:617-957) in shard order.
+(crates/core/machine/src/utils/prove.rs:208-209,492-497), so there is no data-path collective. Shards are dealt the way the
+reference's phase-2 channel deals records to the next free prover thread (prove.rs:484): every rank claims the next
+unclaimed shard from one shared counter when it becomes free (`Farm.claim` — an atomic add on the process group's store; a
+static round-robin, `shards_for_rank`, is kept for equal-cost benchmark shards). The process group is otherwise used for the
+barrier around the timed region, the max-over-ranks time, and gathering the finished ShardProof streams to rank 0, which
+hands them to the recursion tree (crates/prover/src/lib.rs:617-957) in shard order.
 """
 import contextlib
 import os
@@ -104,6 +105,72 @@ class Farm:
         t = self.torch.from_numpy(table).to(self.device)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)  # disjoint rows: sum == union
         return t.cpu().numpy().astype(np.uint32)
+
+    # ---- dealing shards to the next free rank (prove.rs:484) ---------------------------------------------------------------
+    def claim(self, queue: str = "shards") -> int:
+        """The index of the next unclaimed shard: an atomic fetch-and-add on a counter every rank shares (the process group's
+        key-value store; a plain counter without one). Whoever is free first gets the next shard."""
+        if self.dist is None:
+            self._local_counters = getattr(self, "_local_counters", {})
+            self._local_counters[queue] = self._local_counters.get(queue, 0) + 1
+            return self._local_counters[queue] - 1
+        store = self.dist.distributed_c10d._get_default_store()
+        return int(store.add(f"zkm_farm_{queue}", 1)) - 1
+
+    def run_queue(self, n_shards: int, prove: Callable[[int], np.ndarray], queue: str = "shards"):
+        """Prove shards until the queue is empty; returns ([shard ids this rank proved], [their proof streams])."""
+        ids, proofs = [], []
+        while True:
+            i = self.claim(queue)
+            if i >= n_shards:
+                break
+            ids.append(i)
+            proofs.append(np.asarray(prove(i), dtype=np.uint32).copy())
+        return ids, proofs
+
+    def gather_proofs(self, shard_ids: Sequence[int], proofs: Sequence[np.ndarray], n_shards: int) -> Optional[List[np.ndarray]]:
+        """Whole ShardProof streams to rank 0, in shard order (the input of the recursion tree, lib.rs:617-641). Streams differ in
+        length: lengths are exchanged first, then one padded buffer per rank (a few MB per proof; over xGMI this is far below a
+        link's bandwidth and happens once per batch). Returns the list on rank 0, None elsewhere."""
+        if self.dist is None:
+            out = [None] * n_shards
+            for i, p in zip(shard_ids, proofs):
+                out[i] = np.asarray(p, dtype=np.uint32)
+            return out
+        torch, dist = self.torch, self.dist
+        lens = np.zeros(n_shards, dtype=np.int64)
+        for i, p in zip(shard_ids, proofs):
+            lens[i] = len(p)
+        t = torch.from_numpy(lens).to(self.device)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)           # disjoint entries: every rank learns every length
+        lens = t.cpu().numpy()
+        per_rank = torch.zeros(self.world, dtype=torch.int64, device=self.device)
+        per_rank[self.rank] = int(sum(len(p) for p in proofs))
+        dist.all_reduce(per_rank, op=dist.ReduceOp.SUM)
+        cap = int(per_rank.max().item())
+        mine = np.zeros(cap + n_shards, dtype=np.int64)     # [ids this rank holds (-1 padded)] ++ [their words, concatenated]
+        mine[:n_shards] = -1
+        mine[:len(shard_ids)] = shard_ids
+        off = n_shards
+        for p in proofs:
+            mine[off:off + len(p)] = np.asarray(p, dtype=np.uint32)
+            off += len(p)
+        buf = torch.from_numpy(mine).to(self.device)
+        bufs = [torch.empty_like(buf) for _ in range(self.world)]
+        dist.all_gather(bufs, buf)
+        if self.rank != 0:
+            return None
+        out = [None] * n_shards
+        for b in bufs:
+            b = b.cpu().numpy()
+            off = n_shards
+            for i in b[:n_shards]:
+                if i < 0:
+                    break
+                out[int(i)] = b[off:off + int(lens[i])].astype(np.uint32)
+                off += int(lens[i])
+        assert all(p is not None for p in out), "a shard was proven by no rank"
+        return out
 
     def timed(self, step: Callable[[], None], steps: int, warmup: int) -> float:
         """W untimed warm-up steps, then exactly K steps between barriers; max over ranks (seconds)."""
