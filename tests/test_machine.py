@@ -296,3 +296,66 @@ def test_gpu_fibonacci_n1000(hip_ctx, oracle):
     pv = F.from_monty(ML.decode_shard_proof(proofs[-1])["public_values"])
     words = [int(sum(int(pv[4 * i + k]) << (8 * k) for k in range(4))) for i in range(8)]
     assert words == [n, a, b, 0, 0, 0, 0, 0]
+
+
+@pytest.mark.gpu
+def test_gpu_core_proofs_feed_a_compress_shaped_shard(hip_ctx, oracle):
+    """BASELINE config 5's shape (core + recursion) as a two-level DAG at test size: level 1 = the core shard proofs of the fibonacci run
+    (proven on the GPU, gathered in shard order through the farm's interface); level 2 = one shard of the compress machine's nine chips
+    whose program witnesses the level-1 commitments (24 words per core proof), absorbs them with Poseidon2 and commits the resulting digest
+    as its public value — proven under the compress FRI configuration (blow-up 4, 42 queries; kb31_poseidon2.rs:215-227), bit-identical
+    to the oracle's proof and accepted by the restated verifier. The digest is recomputed independently from the gathered proofs; a
+    different core proof gives a different digest. (The real reduce programs come from the reference's recursion compiler; the chips,
+    FRI configuration and data flow are the reference's, the program is a stand-in.)"""
+    from ziren_amd import farm, prover, recursion as R
+    from test_recursion_chips import balanced_shard, recursion_public_values
+    m = M.run_machine(program=fibonacci_program(150), shard_cycles=512)
+    core_fri = abi.FriConfig(1, 84, 16)
+    opk, oshards, proofs = gpu_prove_machine(hip_ctx, oracle, m, core_fri)
+    f = farm.Farm()
+    gathered = f.gather_proofs(list(range(len(proofs))), proofs, len(proofs))
+    inputs = [int(w) for p in gathered for w in F.from_monty(p[:24])]
+
+    def digest_of(words):
+        st = np.zeros(16, dtype=np.uint64)
+        words = list(words) + [0] * (-len(words) % 8)
+        for k in range(0, len(words), 8):
+            st[:8] = words[k:k + 8]
+            st = F.from_monty(oracle.poseidon2_permute_batch(F.to_monty(st.reshape(1, 16)))[0]).astype(np.uint64)
+        return [int(x) for x in st[:8]]
+
+    recs, streams = balanced_shard(300, 200, 40, seed=77, n_var=64, n_select=40, n_poseidon2=10, oracle=oracle, n_exp=10, n_batch_fri=12,
+                                   commit_public_values=True, inputs=inputs)
+    digest = streams.pop()
+    assert digest == digest_of(inputs)
+    other = list(inputs)
+    other[30] ^= 1
+    assert digest_of(other) != digest
+    fri = abi.FriConfig(2, 42, 16)
+    pv = recursion_public_values(digest)
+    igcs = F.to_monty(np.zeros(14, dtype=np.uint64))
+    for i, r in enumerate(recs):
+        r.prep_index = i
+    hp = prover.HipProver(recs, fri, synth.NUM_PV_ELTS, ctx=hip_ctx)
+    hp.specialize_quotient_kernels(recs)
+    preps = [hip_ctx.tracegen_flat(ins, r.prep_trace.shape[1], r.log_height) for (ins, _), r in zip(streams, recs)]
+    lo = [int(r.local_only) for r in recs]
+    pk = hp.setup(preps, lo, F.to_monty(0), igcs)
+    ropk = oracle.Pk([r.prep_trace for r in recs], lo, F.to_monty(0), igcs, fri.log_blowup)
+    assert np.array_equal(pk.commit, ropk.commitment())
+    ch = prover.new_challenger()
+    pk.observe_into(ch)
+    start = ch.copy()
+    born = [hip_ctx.tracegen_poseidon2_wide(ev, r.log_height) if r.name == "Poseidon2Wide" else
+            hip_ctx.tracegen_exp_reverse_bits(*ev, r.log_height) if r.name == "ExpReverseBitsLen" else
+            hip_ctx.tracegen_flat(ev, r.trace.shape[1], r.log_height) if ev is not None else hip_ctx.upload(r.trace)
+            for (_, ev), r in zip(streams, recs)]
+    proof = hp.prove_shard(pk, pv, born, ch).copy()
+    och = oracle.new_challenger()
+    ropk.observe_into(och)
+    oproof, _ = oracle.prove_shard(ropk, recs, [c.trace for c in recs], pv, fri, synth.NUM_PV_ELTS, och)
+    assert np.array_equal(proof, oproof)
+    assert oracle.verify_shard(ropk, recs, fri, synth.NUM_PV_ELTS, start.copy(), proof) == 0
+    assert oracle.verify_shard(ropk, recs, fri, synth.NUM_PV_ELTS, start.copy(), np.concatenate([proof[:-8], proof[-8:] ^ 1])) != 0
+    for t in born:
+        t.free()

@@ -34,11 +34,13 @@ def test_row_counts():
 
 
 def balanced_shard(n_base, n_ext, n_const, seed, heights=(-1, -1, -1), n_var=0, n_select=0, n_poseidon2=0, oracle=None, n_exp=0,
-                   n_batch_fri=0, commit_public_values=False, wrap=False, n_fri_fold=0):
+                   n_batch_fri=0, commit_public_values=False, wrap=False, n_fri_fold=0, inputs=None):
     """BaseAlu + ExtAlu + MemoryConst (+ MemoryVar + Select) over one consistent program: (chips with host traces, flat
     record streams (preprocessed words, main words))."""
     prog = R.balanced_program(n_base, n_ext, n_const, seed, n_var=n_var, n_select=n_select, n_poseidon2=n_poseidon2, n_exp=n_exp,
-                              n_batch_fri=n_batch_fri, commit_public_values=commit_public_values, n_fri_fold=n_fri_fold)
+                              n_batch_fri=n_batch_fri, commit_public_values=commit_public_values, n_fri_fold=n_fri_fold, inputs=inputs)
+    n_var = prog["n_var"]
+    n_poseidon2 = prog["n_poseidon2"]
     specs = (("base_instrs", "base_events", R.BASE_VALUE_COLS, False), ("ext_instrs", "ext_events", R.EXT_VALUE_COLS, True))
     recs, streams = [], []
     for idx, (ik, ek, vw, ext) in enumerate(specs):

@@ -451,12 +451,17 @@ def record_public_values(prep_index: int = 0, constraints_only: bool = False):
 
 
 def balanced_program(n_base: int, n_ext: int, n_const: int = 64, seed: int = 1, n_var: int = 0, n_select: int = 0, n_poseidon2: int = 0,
-                     permute_batch=None, n_exp: int = 0, n_batch_fri: int = 0, commit_public_values: bool = False, n_fri_fold: int = 0):
+                     permute_batch=None, n_exp: int = 0, n_batch_fri: int = 0, commit_public_values: bool = False, n_fri_fold: int = 0,
+                     inputs=None):
     """A synthetic recursion program whose memory lookups balance exactly, as a real one's do: constants are written by
     MemoryConst entries, every ALU instruction reads two earlier values (constants or earlier results of its own field)
     and writes one, and each write's multiplicity is the number of later reads; a few results are read back by
     MemoryConst `Read` entries (negative multiplicity). Returns a dict of flat Montgomery word arrays:
-    base_instrs, base_events, ext_instrs, ext_events, mem_entries (6 words each), plus the counts."""
+    base_instrs, base_events, ext_instrs, ext_events, mem_entries (6 words each), plus the counts.
+    `inputs` (canonical field words, e.g. the commitments of the core shard proofs a compress program verifies) are witnessed through
+    MemoryVar, absorbed eight at a time by a chain of Poseidon2 permutations (overwrite-mode sponge from the zero state), and the
+    chain's final eight words become the committed public-values digest: the shard's public output is bound to those inputs the way
+    a reduce program binds its output to the proofs it consumed (crates/prover/src/lib.rs:617-641)."""
     rng = np.random.default_rng(seed)
     P = F.P
     addr = [1]
@@ -505,6 +510,30 @@ def balanced_program(n_base: int, n_ext: int, n_const: int = 64, seed: int = 1, 
         pools["base"] += [ao1, ao2]
         select_rows.append((ab, ao1, ao2, a1, a2, bit, o1, o2, x, y))
     poseidon_rows = []
+    input_digest = None
+    if inputs is not None and len(inputs):
+        az = new_addr()
+        entries[az] = {"val": [0, 0, 0, 0], "reads": 0, "kind": "const"}
+        words = [int(w) % P for w in inputs] + [0] * (-len(inputs) % 8)
+        in_addrs = []
+        for w in words:
+            a = new_addr()
+            entries[a] = {"val": [w, 0, 0, 0], "reads": 0, "kind": "var"}
+            var_rows.append(a)
+            in_addrs.append(a)
+        state = [az] * 16
+        for k in range(0, len(in_addrs), 8):
+            ins = in_addrs[k:k + 8] + state[8:]
+            out = poseidon2_permute([entries[a]["val"][0] for a in ins])
+            outs = [new_addr() for _ in range(16)]
+            for a in ins:
+                entries[a]["reads"] += 1
+            for a, v in zip(outs, out):
+                entries[a] = {"val": [v, 0, 0, 0], "reads": 0, "kind": "base"}
+            poseidon_rows.append((ins, outs))
+            state = outs
+        input_digest = state[:8]
+        pools["base"] += state
     batch_out = None
     if permute_batch is not None and n_poseidon2:   # large programs: every hash reads values that exist already, one batched permutation
         pool0 = np.array(pools["base"], dtype=np.int64)     # (permute_batch: (n, 16) canonical -> (n, 16) canonical, e.g. on the device)
@@ -624,7 +653,7 @@ def balanced_program(n_base: int, n_ext: int, n_const: int = 64, seed: int = 1, 
     pv_prep, pv_main, pv_digest = [], [], [0] * DIGEST_SIZE
     if commit_public_values:
         for i in range(DIGEST_SIZE):
-            a = pools["base"][int(rng.integers(0, len(pools["base"])))]
+            a = input_digest[i] if input_digest is not None else pools["base"][int(rng.integers(0, len(pools["base"])))]
             entries[a]["reads"] += 1
             pv_digest[i] = entries[a]["val"][0]
             pv_prep.append([int(j == i) for j in range(DIGEST_SIZE)] + [a, P - 1])
