@@ -469,3 +469,60 @@ def test_open_rejects_bad_arguments(hip_ctx):
         hp2 = prover.HipProver(chips, fri, synth.NUM_PV_ELTS, ctx=hip_ctx)
         with pytest.raises(lib.ZkmError):
             hp2.prove_shard(pk, sh.public_values, traces, prover.new_challenger())
+
+
+def _free_main_data(ctx, data):
+    from ziren_amd import lib as _lib
+    _lib.load().zkm_main_data_free(ctx.h, data.handle)
+
+
+def _sorted_traces(sh):
+    """commit's order rule (prover.rs:264): height descending, then name."""
+    order = sorted(range(len(sh.chips)), key=lambda i: (-sh.chips[i].log_height, sh.chips[i].name))
+    return [sh.chips[i].trace for i in order]
+
+
+def test_baseline_config2_syn20_commit_bit_exact(hip_ctx, oracle):
+    """BASELINE config 2 as written: the 2^20-row trace, LDE + Poseidon2 commitment only, bit-exact against the CPU — the main-trace
+    commitment of SYN-20 through MachineProver::commit equals the oracle's root over the same matrices."""
+    sh = synth.syn_shard(20)
+    hp = prover.HipProver(sh.chips, abi.FriConfig(1, 84, 16), synth.NUM_PV_ELTS, ctx=hip_ctx)
+    tr = hp.upload_traces([c.trace for c in sh.chips])
+    data = hp.commit(sh.public_values, tr)
+    want, _, _ = oracle.pcs_commit(_sorted_traces(sh), 1)
+    assert np.array_equal(data.main_commit, want)
+    _free_main_data(hip_ctx, data)
+    for t in tr:
+        t.free()
+    hip_ctx.trim()
+
+
+def test_baseline_syn20_full_proof_bit_exact(hip_ctx, oracle):
+    """A full SYN-20 shard proof (commit + open, core FRI parameters), every word equal to the oracle's; the largest shard the oracle
+    proves inside the GPU-test budget."""
+    sh = synth.syn_shard(20)
+    fri = abi.FriConfig(1, 84, 16)
+    pk, start, ch, proof = _gpu_prove(hip_ctx, sh, fri, True)
+    opk = oracle.Pk([], [], sh.pc_start, sh.initial_global_cumulative_sum, 1)
+    och = oracle.new_challenger()
+    opk.observe_into(och)
+    oproof, _ = oracle.prove_shard(opk, sh.chips, [c.trace for c in sh.chips], sh.public_values, fri, synth.NUM_PV_ELTS, och)
+    assert np.array_equal(proof, oproof) and ch.as_tuple() == och.as_tuple()
+    hip_ctx.trim()
+
+
+def test_baseline_config3_syn22_main_commit_bit_exact(hip_ctx, oracle):
+    """The SYN-22 main-trace commitment (2^22 x 67 and seven smaller matrices: 2.4 GB of traces, 2^23-leaf tree) bit-exact against the
+    oracle — the commit half of BASELINE config 3 at full size; the open half is covered at full size by the restated verifier
+    (test_full_size_shard_verifies) and bit-exactly up to SYN-20 above."""
+    sh = synth.syn_shard(22)
+    hp = prover.HipProver(sh.chips, abi.FriConfig(1, 84, 16), synth.NUM_PV_ELTS, ctx=hip_ctx)
+    tr = hp.upload_traces([c.trace for c in sh.chips])
+    data = hp.commit(sh.public_values, tr)
+    got = data.main_commit.copy()
+    _free_main_data(hip_ctx, data)
+    for t in tr:
+        t.free()
+    hip_ctx.trim()
+    want, _, _ = oracle.pcs_commit(_sorted_traces(sh), 1)
+    assert np.array_equal(got, want)
