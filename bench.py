@@ -26,24 +26,54 @@ import numpy as np
 from ziren_amd import abi, lib, prover, synth
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
-POSEIDON2_ISSUE_CEILING_GPERMS = 8.3  # integer-issue ceiling of one permutation's instruction mix
+FP64_VECTOR_TFLOPS = 78.6  # MI355X FP64 vector peak: 256 CUs x 4 SIMDs x 16 lanes x 2 flop x 2.4 GHz (MI355X_MICROARCH.md)
+
+
+def poseidon2_isa():
+    """Dynamic VALU instructions per permutation as the hardware counts them (SQ_INSTS_VALU over tools/ubench_p2's kernels,
+    profiles/r02_poseidon2_isa.json, written by tools/profile_r02.sh -> tools/pmc_poseidon2.py); None when the profile is missing."""
+    path = os.path.join(ROOT, "profiles", "r02_poseidon2_isa.json")
+    if not os.path.exists(path):
+        return None
+    return json.load(open(path))
+
+
+def csrc_digest():
+    """sha256 over the kernel sources: PMC profiles record it, so a traffic figure is only quoted for the code it was measured on."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "ziren_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        with open(os.path.join(d, name), "rb") as f:
+            h.update(name.encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
 
 
 def cpu_baseline(log_rows_sample, fri):
-    """Time the CPU restatement (oracle, kind 'port') on a bounded sample of the same workload."""
+    """Time the CPU restatement (oracle, kind 'port') on a bounded sample of the same workload: first a small shard with all cores and
+    with fewer threads (the oracle's OpenMP loops stop scaling at some point: the best count is used and reported), then the sample."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
-    # the oracle's OpenMP loops stop scaling past ~16 threads (measured on the 2x64-core box)
-    O.lib().orc_set_num_threads(min(16, os.cpu_count() or 1))
-    sh = synth.syn_shard(log_rows_sample)
-    pk = O.Pk([], [], sh.pc_start, sh.initial_global_cumulative_sum, fri.log_blowup)
-    ch = O.new_challenger()
-    pk.observe_into(ch)
-    t0 = time.time()
-    _, (t_commit, t_open) = O.prove_shard(pk, sh.chips, [c.trace for c in sh.chips], sh.public_values, fri,
-                                          synth.NUM_PV_ELTS, ch)
-    wall = time.time() - t0
-    return wall, O.lib().orc_num_threads()
+    L = O.lib()
+    L.orc_lde_seconds.restype = C.c_double
+
+    def prove(k, threads):
+        L.orc_set_num_threads(threads)
+        sh = synth.syn_shard(k)
+        pk = O.Pk([], [], sh.pc_start, sh.initial_global_cumulative_sum, fri.log_blowup)
+        ch = O.new_challenger()
+        pk.observe_into(ch)
+        L.orc_lde_seconds(C.c_int(1))
+        t0 = time.time()
+        O.prove_shard(pk, sh.chips, [c.trace for c in sh.chips], sh.public_values, fri, synth.NUM_PV_ELTS, ch)
+        return time.time() - t0, float(L.orc_lde_seconds(C.c_int(0)))
+
+    avail = os.cpu_count() or 1
+    tries = sorted({avail, min(avail, 64), min(avail, 32), min(avail, 16)}, reverse=True)
+    probe_k = min(log_rows_sample, 16)
+    best = min(tries, key=lambda t: prove(probe_k, t)[0])
+    wall, lde = prove(log_rows_sample, best)
+    return wall, lde, best, avail
 
 
 def tracegen_bench(args):
@@ -136,7 +166,8 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--log-rows", type=int, default=22)
-    ap.add_argument("--cpu-sample-log-rows", type=int, default=19)
+    ap.add_argument("--cpu-sample-log-rows", type=int, default=20)
+    ap.add_argument("--no-pcie", action="store_true", help="skip the PCIe-inclusive measurement that follows the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--inflight", type=int, default=1, help="shards proven concurrently per GPU (one context + host thread each)")
     ap.add_argument("--kernel-timing", type=int, default=2, help="0 off, 1 every launch, 2 launches >= 256 KiB (default)")
@@ -252,44 +283,89 @@ def main():
             per_launch_ms = ms / max(calls, 1)
             kbytes = nbytes / max(calls, 1)
             achieved = kbytes / (per_launch_ms * 1e-3) / 1e9 if per_launch_ms > 0 else 0.0
-            # HBM bytes per launch from the committed PMC passes of this same command (tools/pmc_traffic.py)
-            traffic = None
-            tpath = os.path.join(ROOT, "profiles", "r01_syn22_hbm_traffic.json")
-            short = {"compress_layer": "merkle::compress_layer", "hash_leaves": "merkle::hash_leaves",
-                     "lde_rows": "lde::lde_rows"}.get(name)
+            # HBM bytes per launch: PMC counters cannot be read from inside this process, so the figure comes from the rocprofv3 --pmc
+            # passes of this same command kept under profiles/ (tools/profile_r02.sh) — and only if they were taken on these very
+            # kernel sources (the profile records their digest); otherwise null, never a stale number
+            traffic, traffic_source = None, None
+            tpath = os.path.join(ROOT, "profiles", "r02_syn22_hbm_traffic.json")
+            short = {"compress_layer": "merkle::compress_layer", "hash_leaves": "merkle::hash_leaves", "hash_leaves_tree": "merkle::hash_leaves_tree",
+                     "lde_rows": "lde::lde_rows_big"}.get(name)
             if k == 22 and short and os.path.exists(tpath):
-                tk = json.load(open(tpath))["kernels"].get(short)
-                if tk:
+                tj = json.load(open(tpath))
+                tk = tj["kernels"].get(short)
+                if tk and tj.get("csrc_digest") == csrc_digest():
                     traffic = int(tk["hbm_bytes_per_launch"])
+                    traffic_source = {"file": "profiles/r02_syn22_hbm_traffic.json", "commit": tj.get("commit"), "csrc_digest": tj.get("csrc_digest")}
+                else:
+                    traffic_source = {"file": "profiles/r02_syn22_hbm_traffic.json", "stale": True,
+                                      "note": "taken on other kernel sources (csrc digest differs): not quoted"}
             roofline = {"bound": "hbm", "kernel": name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
-                        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_source,
                         "launches_per_step": calls // steps, "avg_launch_ms": round(per_launch_ms, 4),
                         "algorithmic_bytes_per_launch": int(kbytes),
                         "kernel_share_of_step": round(ms / steps / ms_per_step, 3),
                         "whole_shard": {"algorithmic_bytes": alg_bytes,
                                         "achieved": round(alg_bytes / (ms_per_step * 1e-3) / 1e9, 1),
                                         "frac": round(alg_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}}
-        # SURVEY 8d asks for the VALU side next to the HBM fraction: the hashing kernels are bound by integer
-        # instruction issue (4.66 k VALU instructions per permutation, ~19 k cycles per wavefront
-        # of 64 at the issue costs measured by tools/ubench_int.hip -> 8.3 G permutations/s for the chip)
+        # SURVEY 8d asks for the VALU side next to the HBM fraction: the hashing kernels are bound by instruction issue, not by bytes.
+        # Poseidon2 runs on the FP64 vector pipe (csrc/poseidon2_f64.cuh); its ceiling is the chip's FP64 vector issue rate divided by
+        # the permutation's dynamic instruction count as the hardware counted it (SQ_INSTS_VALU, profiles/r02_poseidon2_isa.json)
         valu = None
-        hashing = [n for n in ("compress_layer", "hash_leaves", "hash_fri_leaves", "compress_small") if n in kern_acc]
+        hashing = [n for n in ("compress_layer", "hash_leaves", "hash_leaves_tree", "hash_fri_leaves", "compress_small") if n in kern_acc]
         if hashing and M == 1:
             perms = synth.shard_poseidon2_permutations(shard, fri.log_blowup)
             hms = sum(kern_acc[n][0] for n in hashing) / steps
-            valu = {"bound": "valu-issue", "kernels": hashing, "poseidon2_permutations": perms, "ms": round(hms, 3),
-                    "achieved": round(perms / hms / 1e6, 3), "peak": POSEIDON2_ISSUE_CEILING_GPERMS, "unit": "Gperm/s",
-                    "frac": round(perms / hms / 1e6 / POSEIDON2_ISSUE_CEILING_GPERMS, 3), "valu_instr_per_permutation": 4660,
+            isa = poseidon2_isa()
+            per_perm = isa["fp64"]["valu_instr_per_permutation"] if isa else None
+            # one wave64 FP64 instruction = 64 lanes; the vector peak counts an FMA as 2 flop: instructions/s = TFLOPS / 2 / 64 per ... lane-instr
+            peak = FP64_VECTOR_TFLOPS * 1e12 / 2 / per_perm / 1e9 if per_perm else None
+            valu = {"bound": "fp64-vector-issue", "kernels": hashing, "poseidon2_permutations": perms, "ms": round(hms, 3),
+                    "achieved": round(perms / hms / 1e6, 3), "peak": round(peak, 2) if peak else None, "unit": "Gperm/s",
+                    "frac": round(perms / hms / 1e6 / peak, 3) if peak else None, "valu_instr_per_permutation": per_perm,
+                    "valu_instr_source": "profiles/r02_poseidon2_isa.json (SQ_INSTS_VALU / permutations, tools/ubench_p2)" if isa else None,
                     "share_of_step": round(hms / ms_per_step, 3)}
         cpu = None
         if not args.no_cpu_baseline and world == 1:  # rank 0, N = 1 only
             ks = min(args.cpu_sample_log_rows, k)
-            wall, threads = cpu_baseline(ks, fri)
-            scale = 1 << (k - ks)
-            cpu = {"value": round(1.0 / (wall * scale), 6), "unit": "shard-proofs/s", "cores": threads, "kind": "port",
-                   "sample": f"oracle (CPU restatement, OpenMP) proving one SYN-{ks} shard in {wall:.2f} s; "
-                             f"extrapolated linearly in rows (x{scale}) to SYN-{k}",
-                   "sample_seconds": round(wall, 3)}
+            wall, lde, threads, avail = cpu_baseline(ks, fri)
+            # everything but the LDEs is linear in the rows; the LDEs (n log n) grow by (k + 1) / (ks + 1) on top (rows of the extended domain)
+            lin = 1 << (k - ks)
+            est = (wall - lde) * lin + lde * lin * (k + 1) / (ks + 1)
+            cpu = {"value": round(1.0 / est, 6), "unit": "shard-proofs/s", "cores": threads, "cores_available": avail, "kind": "port",
+                   "sample": f"oracle (CPU restatement, OpenMP, {threads} threads: the fastest of all cores / 64 / 32 / 16 on a SYN-{min(ks, 16)} probe) "
+                             f"proving one SYN-{ks} shard in {wall:.2f} s ({lde:.2f} s of it coset LDEs); scaled to SYN-{k}: x{lin} for the linear "
+                             f"phases, x{lin}*{k + 1}/{ks + 1} for the LDEs",
+                   "sample_seconds": round(wall, 3), "estimated_seconds_full_size": round(est, 2)}
+        pcie = None
+        if world == 1 and M == 1 and not args.from_host and not args.no_pcie:
+            # the boundary hands over host buffers (commit(record, traces)): the same step with the traces re-uploaded from page-locked
+            # host memory every time (slabbed DMA + transpose on their own streams). Reported beside `value`, never as `value`.
+            hpj, pkj, chj, trj, outj = lanes[0]
+            host = []
+            for t in trj:      # the resident traces go back to (page-locked) host memory, row-major as the reference holds them
+                h = hpj.ctx.host_alloc((t.height, t.width))
+                h[...] = t.to_host()
+                host.append(h)
+                t.free()
+
+            def from_host_step():
+                dev = [hpj.ctx.upload_async(h) for h in host]
+                hpj.prove_shard(pkj, shard.public_values, dev, chj.copy(), out=outj)
+                for d in dev:
+                    d.free()
+            from_host_step()
+            hpj.ctx.synchronize()
+            t0 = time.perf_counter()
+            n_host = min(3, steps)
+            for _ in range(n_host):
+                from_host_step()
+            hpj.ctx.synchronize()
+            dt = (time.perf_counter() - t0) / n_host
+            pcie = {"value": round(1.0 / dt, 4), "unit": "shard-proofs/s", "ms_per_step": round(dt * 1e3, 3), "steps": n_host,
+                    "host_bytes_per_step": int(sum(h.nbytes for h in host)),
+                    "note": "traces in page-locked host memory handed over every step (zkm_matrix_upload_async), upload overlapped with commit"}
+            for h in host:
+                hpj.ctx.host_free(h)
         line = {"metric": "shard-proofs/sec", "value": round(value, 4), "unit": "shard-proofs/s", "n_gpus": world,
                 "steps": steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
                 "scaling": "weak", "vs_baseline": None, "dtype": "u32",
@@ -301,7 +377,7 @@ def main():
                 "kernels_ms": {n: {"ms": round(v[0] / steps, 3), "launches": v[1] // steps,
                                    "GBps": round(v[2] / max(v[0], 1e-9) / 1e6, 1)} for n, v in
                                sorted(kern_acc.items(), key=lambda kv: -kv[1][0])},
-                "roofline": roofline, "valu": valu, "cpu_baseline": cpu}
+                "roofline": roofline, "valu": valu, "pcie_inclusive": pcie, "cpu_baseline": cpu}
         print(json.dumps(line))
     farm.close()
 

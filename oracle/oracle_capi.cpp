@@ -308,6 +308,9 @@ void orc_pk_observe_into(const orc_pk* k, zkm_challenger* c) {
 }
 void orc_pk_free(orc_pk* k) { delete k; }
 
+// seconds spent in coset LDEs since the last call with reset != 0 (bench.py: the n log n share of the CPU baseline)
+double orc_lde_seconds(int reset) { double t = lde_seconds(); if (reset) lde_seconds() = 0; return t; }
+
 // commit + open of one shard. traces: row-major Montgomery host matrices, caller order.
 // timings_out (nullable): [commit_seconds, open_seconds].
 int orc_prove_shard(const orc_pk* k, size_t n_chips, const zkm_chip_desc* descs, const uint32_t* const* traces,

@@ -15,6 +15,7 @@
 // (SURVEY.md F6); it is pinned structurally — proofs produced here are accepted by
 // verify_* below, which follow the in-tree verifier line by line.
 #pragma once
+#include <omp.h>
 #include "poseidon2.hpp"
 #include <algorithm>
 #include <numeric>
@@ -80,7 +81,10 @@ static inline std::vector<F> coset_lde(std::vector<F> evals, int added_bits, F l
   return evals;
 }
 
+// wall-clock seconds spent in coset LDEs since the last reset (the one n log n phase: bench.py scales it separately)
+static inline double& lde_seconds() { static double t = 0; return t; }
 static inline Matrix coset_lde_matrix_bitrev(const Matrix& m, int added_bits, F lde_shift) {
+  struct Timer { double t0 = omp_get_wtime(); ~Timer() { lde_seconds() += omp_get_wtime() - t0; } } timer;
   size_t H = m.h << added_bits;
   int logH = log2_strict(H);
   Matrix out(H, m.w);

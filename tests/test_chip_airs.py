@@ -59,7 +59,8 @@ def test_recorded_costs_match_the_reference():
         chips.record_cpu_chip(10), chips.record_program_chip(10), chips.record_mul_chip(10), chips.record_divrem_chip(10),
         chips.record_branch_chip(10), chips.record_jump_chip(10), chips.record_mov_cond_chip(10), chips.record_memory_instrs_chip(10),
         chips.record_memory_local_chip(10), chips.record_syscall_instrs_chip(10), chips.record_misc_instrs_chip(10), chips.record_byte_chip(),
-        chips.record_global_chip(10)]
+        chips.record_global_chip(10), chips.record_memory_global_chip(False, 10), chips.record_memory_global_chip(True, 10),
+        chips.record_syscall_table_chip(False, 10), chips.record_syscall_table_chip(True, 10), chips.record_poseidon2_permute_chip(10)]
     got = {r.name: r.prep_width + r.main_width + 4 * r.perm_ext_width + (4 << r.log_quotient_degree) for r in recs}
     assert got == want
 

@@ -444,8 +444,19 @@ def test_open_rejects_bad_arguments(hip_ctx):
     traces = hp.upload_traces([c.trace for c in sh.chips])
     ch = prover.new_challenger()
     from ziren_amd import lib
-    with pytest.raises(lib.ZkmError):
-        hp.prove_shard(pk, sh.public_values, traces, ch, out=np.zeros(16, dtype=np.uint32))  # buffer too small
+    before = ch.as_tuple()
+    with pytest.raises(lib.ZkmError, match="proof buffer too small"):
+        hp.prove_shard(pk, sh.public_values, traces, ch, out=np.zeros(16, dtype=np.uint32))
+    assert ch.as_tuple() == before       # a call that delivers no proof leaves the caller's transcript where it was: it can be retried
+    proof = hp.prove_shard(pk, sh.public_values, traces, ch).copy()
+    assert len(proof) > 16 and ch.as_tuple() != before
+    for bad_fri, what in ((abi.FriConfig(0, 4, 4), "log_blowup"), (abi.FriConfig(9, 4, 4), "log_blowup"), (abi.FriConfig(1, 0, 4), "num_queries"),
+                          (abi.FriConfig(1, 4, 31), "proof_of_work_bits")):
+        hp_bad = prover.HipProver(sh.chips, bad_fri, synth.NUM_PV_ELTS, ctx=hip_ctx)
+        with pytest.raises(lib.ZkmError, match=what):
+            hp_bad.prove_shard(pk, sh.public_values, traces, prover.new_challenger())
+    with pytest.raises(ValueError, match="traces for"):
+        hp.commit(sh.public_values, traces[:-1])     # a shard that leaves a chip out needs a prover built for its chip list
     with pytest.raises(lib.ZkmError):
         hip_ctx.upload(np.zeros((3, 2), dtype=np.uint32))  # height not a power of two
     # malformed descriptors are rejected on the host, before anything is launched

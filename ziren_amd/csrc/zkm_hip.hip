@@ -598,7 +598,21 @@ static void open_impl(zkm_ctx* ctx, const zkm_pk* pk, zkm_main_data* md, const z
     if (chips[i].desc->prep_index >= 0 && (!pk->data || (size_t)chips[i].desc->prep_index >= pk->prep.size()))
       throw std::runtime_error("chip references a preprocessed trace the proving key does not hold");
   }
-  std::vector<void*> scratch;  // released at the end
+  // FRI parameters as the reference's configurations use them (kb31_poseidon2.rs:203-241: blow-up 1..3 bits, 28..84 queries, 16 PoW
+  // bits); anything outside a sane envelope is an error at the boundary, not an out-of-range shift further down
+  if (bl < 1 || bl > 4) throw std::runtime_error("fri.log_blowup out of range (1..4)");
+  if (fri->proof_of_work_bits > 30) throw std::runtime_error("fri.proof_of_work_bits out of range (0..30)");
+  if (fri->num_queries < 1 || fri->num_queries > 1024) throw std::runtime_error("fri.num_queries out of range (1..1024)");
+  if (num_pv_elts > md->public_values.size()) throw std::runtime_error("num_pv_elts exceeds public_values length");
+  // Every device buffer this call allocates and has not handed to an owner yet goes back to the pool when the call unwinds:
+  // a bad shard in a long-running farm must not leak HBM (the pool only frees at zkm_ctx_destroy).
+  struct Loose {
+    zkm_ctx* ctx;
+    std::vector<void*> v;
+    void disown(void* p) { v.erase(std::remove(v.begin(), v.end(), p), v.end()); }
+    ~Loose() { for (void* p : v) ctx->release(p); }
+  } loose{ctx, {}};
+  std::vector<void*>& scratch = loose.v;
   auto salloc = [&](size_t bytes) { void* p = ctx->alloc(bytes); scratch.push_back(p); return p; };
 
   // --- transcript prelude (prover.rs:321-329)
@@ -626,6 +640,7 @@ static void open_impl(zkm_ctx* ctx, const zkm_pk* pk, zkm_main_data* md, const z
       zkm_matrix& pt = perm_traces[i];
       pt.h = c.n; pt.w = (size_t)c.perm_ext_w * 4;
       pt.d = ctx->alloc_n<uint32_t>(std::max<size_t>(pt.h * pt.w, 1));
+      scratch.push_back(pt.d);   // until the permutation commitment owns it
       if (c.perm_ext_w > 0) {
         d_blobs[i] = (uint32_t*)ctx->upload(c.desc->lookups, c.desc->lookups_len * 4, &scratch);
         const uint32_t* prep = c.desc->prep_index >= 0 ? pk->prep[c.desc->prep_index].d : nullptr;
@@ -667,6 +682,7 @@ static void open_impl(zkm_ctx* ctx, const zkm_pk* pk, zkm_main_data* md, const z
   ctx->mark("permutation traces");
   zkm_pcs_data* perm_data = pcs_commit(ctx, perm_traces, {}, bl);  // synchronises: sums are on the host now
   perm_data->owned_evals = perm_traces;
+  for (auto& m : perm_traces) loose.disown(m.d);
   ctx->mark("commit permutation");
   for (size_t i = 0; i < nc; i++) {
     for (int e = 0; e < 4; e++) local_sums[i].c[e] = h_sums[18 * i + e];
@@ -694,6 +710,7 @@ static void open_impl(zkm_ctx* ctx, const zkm_pk* pk, zkm_main_data* md, const z
     size_t Q = (size_t)1 << lq;
     size_t nchunks = (size_t)1 << lqd;
     uint32_t* qbuf = ctx->alloc_n<uint32_t>(Q * 4);
+    scratch.push_back(qbuf);   // until the quotient commitment owns it
     // alpha powers, reversed (prover.rs:453-456)
     size_t C = d->num_constraints;
     std::vector<E4> ap(std::max<size_t>(C, 1));
@@ -757,7 +774,7 @@ static void open_impl(zkm_ctx* ctx, const zkm_pk* pk, zkm_main_data* md, const z
   }
   ctx->mark("quotient values");
   zkm_pcs_data* quot_data = pcs_commit(ctx, qchunks, qshifts, bl);
-  for (auto& m : qchunks) if (m.owned) quot_data->owned_evals.push_back(m);
+  for (auto& m : qchunks) if (m.owned) { quot_data->owned_evals.push_back(m); loose.disown(m.d); }
   guard.d.push_back(quot_data);
   ctx->mark("commit quotient");
   chal::observe_slice(ch, quot_data->root, 8);
@@ -1053,7 +1070,6 @@ static void open_impl(zkm_ctx* ctx, const zkm_pk* pk, zkm_main_data* md, const z
   out.u(pow_witness);
   out.u((uint32_t)md->public_values.size());
   out.words(md->public_values.data(), md->public_values.size());
-  for (void* p : scratch) ctx->release(p);
 }
 
 // ---- C ABI ---------------------------------------------------------------------------------------
@@ -1461,11 +1477,15 @@ int zkm_open(zkm_ctx* ctx, const zkm_pk* pk, zkm_main_data* data, const zkm_chip
   if (num_pv_elts > data->public_values.size()) throw std::runtime_error("num_pv_elts exceeds public_values length");
   Writer w;
   ctx->begin_timing();
-  open_impl(ctx, pk, data, chips, fri, num_pv_elts, challenger, w);
+  // the transcript runs on a copy: the caller's challenger only advances once the proof has been handed over, so a call that
+  // fails (a proof buffer that is too small: *proof_len says how many words it takes) leaves it where it was
+  zkm_challenger ch = *challenger;
+  open_impl(ctx, pk, data, chips, fri, num_pv_elts, &ch, w);
   ctx->end_timing(true);
   *proof_len = w.w.size();
   if (w.w.size() > proof_cap) throw std::runtime_error("proof buffer too small");
   memcpy(proof_out, w.w.data(), w.w.size() * 4);
+  *challenger = ch;
   API_END
 }
 
@@ -1482,8 +1502,9 @@ int zkm_prove_shard(zkm_ctx* ctx, const zkm_pk* pk, size_t n_chips, const zkm_ch
   zkm_main_data* md = commit_impl(ctx, n_chips, names.data(), main_traces, public_values, n_pv, fri->log_blowup);
   ctx->mark("commit main");
   Writer w;
+  zkm_challenger ch = *challenger;   // as in zkm_open: the caller's transcript advances only with a delivered proof
   try {
-    open_impl(ctx, pk, md, chips, fri, num_pv_elts, challenger, w);
+    open_impl(ctx, pk, md, chips, fri, num_pv_elts, &ch, w);
   } catch (...) {
     free_pcs_data(ctx, md->data);
     delete md;
@@ -1495,6 +1516,7 @@ int zkm_prove_shard(zkm_ctx* ctx, const zkm_pk* pk, size_t n_chips, const zkm_ch
   *proof_len = w.w.size();
   if (w.w.size() > proof_cap) throw std::runtime_error("proof buffer too small");
   memcpy(proof_out, w.w.data(), w.w.size() * 4);
+  *challenger = ch;
   API_END
 }
 
