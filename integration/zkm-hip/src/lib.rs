@@ -1,0 +1,284 @@
+//! `HipProver`: Ziren's `MachineProver` (crates/stark/src/prover.rs:30-184) on an MI355X through libzkm_hip.so.
+//!
+//! Plug-in points, nothing else in Ziren changes:
+//!   * `ZKMProverComponents::CoreProver = HipProver<CoreSC, MipsAir<..>>` (crates/prover/src/components.rs:6-35) — `HipProverComponents` below;
+//!   * `run_test::<HipProver<_, _>>(program)` in the core machine's tests (crates/core/machine/src/utils/prove.rs:614-656).
+//!
+//! NOT compiled where it was written (no Rust toolchain in that image); the C ABI underneath is exercised call for call by
+//! tests/c_abi/consumer.c and by the Python mirror ziren_amd/prover.py. ffi.rs is generated from include/zkm_hip.h.
+
+pub mod decode;
+pub mod ffi;
+pub mod recorder;
+
+use std::ffi::{c_int, CStr};
+use std::ptr::null_mut;
+
+use hashbrown::HashMap;
+use p3_air::Air;
+use p3_challenger::DuplexChallenger;
+use p3_field::PrimeField32;
+use p3_koala_bear::KoalaBear;
+use p3_matrix::{dense::RowMajorMatrix, Matrix};
+use p3_uni_stark::SymbolicAirBuilder;
+use zkm_stark::{
+    air::MachineAir, koala_bear_poseidon2::KoalaBearPoseidon2, MachineProver, MachineProvingKey, MachineRecord, ShardMainData, ShardProof,
+    Challenger, Com, StarkGenericConfig, StarkMachine, StarkProvingKey, StarkVerifyingKey, Val,
+};
+
+use recorder::RecordedChip;
+
+type SC = KoalaBearPoseidon2;
+type F = KoalaBear;
+
+#[derive(Debug, thiserror::Error)]
+#[error("libzkm_hip: {0}")]
+pub struct HipProverError(pub String);
+
+fn last_error() -> HipProverError {
+    HipProverError(unsafe { CStr::from_ptr(ffi::zkm_last_error()) }.to_string_lossy().into_owned())
+}
+fn check(rc: c_int) -> Result<(), HipProverError> { if rc == 0 { Ok(()) } else { Err(last_error()) } }
+
+/// One GPU: a `zkm_ctx` (its own stream, memory pool and kernels). `Send + Sync`: the library serialises calls on a context.
+pub struct HipContext(*mut ffi::ZkmCtx);
+unsafe impl Send for HipContext {}
+unsafe impl Sync for HipContext {}
+impl Drop for HipContext { fn drop(&mut self) { unsafe { ffi::zkm_ctx_destroy(self.0) } } }
+
+/// `DeviceMatrix`: a column-major matrix resident in HBM.
+pub struct HipMatrix { ctx: *mut ffi::ZkmCtx, h: *mut ffi::ZkmMatrix, height: usize, width: usize }
+unsafe impl Send for HipMatrix {}
+unsafe impl Sync for HipMatrix {}
+impl Drop for HipMatrix { fn drop(&mut self) { unsafe { ffi::zkm_matrix_free(self.ctx, self.h) } } }
+impl Matrix<F> for HipMatrix {
+    fn width(&self) -> usize { self.width }
+    fn height(&self) -> usize { self.height }
+    type Row<'a> = std::vec::IntoIter<F>;
+    // Rows of a device matrix are not read on the host on the proving path; debugging reads go through zkm_matrix_download.
+    fn row(&self, r: usize) -> Self::Row<'_> {
+        let mut host = vec![0u32; self.height * self.width];
+        unsafe { ffi::zkm_matrix_download(self.ctx, self.h, host.as_mut_ptr()) };
+        host[r * self.width..(r + 1) * self.width].iter().map(|&w| unsafe { core::mem::transmute::<u32, F>(w) }).collect::<Vec<_>>().into_iter()
+    }
+}
+
+/// `DeviceProverData`: owned by the library inside zkm_main_data; the Rust side only carries the handle.
+pub struct HipMainData {
+    ctx: *mut ffi::ZkmCtx,
+    h: *mut ffi::ZkmMainData,
+    /// chip names in the order `zkm_commit` received them: `zkm_open` wants the descriptors in that same order
+    caller_names: Vec<String>,
+}
+unsafe impl Send for HipMainData {}
+unsafe impl Sync for HipMainData {}
+impl Drop for HipMainData { fn drop(&mut self) { if !self.h.is_null() { unsafe { ffi::zkm_main_data_free(self.ctx, self.h) } } } }
+
+/// `DeviceProvingKey`: the host key (vk fields, chip ordering) plus the preprocessed traces / LDEs / tree on the device.
+pub struct HipProvingKey { host: StarkProvingKey<SC>, ctx: *mut ffi::ZkmCtx, h: *mut ffi::ZkmPk, _prep: Vec<HipMatrix> }
+unsafe impl Send for HipProvingKey {}
+unsafe impl Sync for HipProvingKey {}
+impl Drop for HipProvingKey { fn drop(&mut self) { unsafe { ffi::zkm_pk_free(self.ctx, self.h) } } }
+impl MachineProvingKey<SC> for HipProvingKey {
+    fn preprocessed_commit(&self) -> Com<SC> { self.host.commit.clone() }
+    fn pc_start(&self) -> Val<SC> { self.host.pc_start }
+    fn initial_global_cumulative_sum(&self) -> zkm_stark::septic_digest::SepticDigest<Val<SC>> { self.host.initial_global_cumulative_sum }
+    fn observe_into(&self, challenger: &mut Challenger<SC>) {
+        // host-side, as StarkProvingKey::observe_into (machine.rs:79-86); zkm_pk_observe_into is its twin on a ZkmChallenger
+        self.host.observe_into(challenger)
+    }
+}
+
+pub struct HipProver<A> where A: MachineAir<F> {
+    machine: StarkMachine<SC, A>,
+    ctx: HipContext,
+    /// every chip of the machine, recorded once: name -> bytecode + lookups (the memory ZkmChipDesc points into)
+    recorded: HashMap<String, RecordedChip>,
+}
+
+impl<A> HipProver<A>
+where
+    A: MachineAir<F> + for<'a> Air<SymbolicAirBuilder<F>>,
+{
+    fn desc(&self, name: &str, prep_index: i32) -> ffi::ZkmChipDesc {
+        let c = &self.recorded[name];
+        ffi::ZkmChipDesc {
+            name: c.name.as_ptr(), main_width: c.main_width, prep_width: c.prep_width, prep_index,
+            log_quotient_degree: c.log_quotient_degree, local_only: c.local_only as u32, commit_scope_global: c.commit_scope_global as u32,
+            num_constraints: c.num_constraints, lookups: c.lookups.as_ptr(), lookups_len: c.lookups.len() as u32,
+            program: c.program.as_ptr(), program_len: c.program.len() as u32,
+        }
+    }
+
+    fn upload(&self, m: &RowMajorMatrix<F>) -> Result<HipMatrix, HipProverError> {
+        let mut h = null_mut();
+        // asynchronous: slabbed DMA + transpose on the library's upload streams; consumers wait per matrix on the device
+        check(unsafe { ffi::zkm_matrix_upload_async(self.ctx.0, m.values.as_ptr() as *const u32, m.height(), m.width(), &mut h) })?;
+        Ok(HipMatrix { ctx: self.ctx.0, h, height: m.height(), width: m.width() })
+    }
+
+    /// The ahead-of-time compiled quotient kernel of a chip, if one was shipped (tools/aot_quotient_kernels.py writes
+    /// `<ZKM_HIP_KERNEL_DIR>/manifest.json`: sha256 of the program words -> code object). Without one the library interprets
+    /// the bytecode (4x slower on the quotient phase, same field values): no compiler is needed at run time either way.
+    fn register_aot_kernels(&self) {
+        use sha2::{Digest, Sha256};
+        let dir = std::path::PathBuf::from(env!("ZKM_HIP_KERNEL_DIR"));
+        let Ok(manifest) = std::fs::read_to_string(dir.join("manifest.json")) else { return };
+        for c in self.recorded.values() {
+            let bytes: Vec<u8> = c.program.iter().flat_map(|w| w.to_le_bytes()).collect();
+            let key = Sha256::digest(&bytes).iter().map(|b| format!("{b:02x}")).collect::<String>();
+            // manifest lines: "<sha256 of program words>": "<file>.hsaco"
+            if let Some(pos) = manifest.find(&key) {
+                let rest = &manifest[pos + key.len()..];
+                if let Some(file) = rest.split('"').nth(2) {
+                    if let Ok(obj) = std::fs::read(dir.join(file)) {
+                        unsafe { ffi::zkm_ctx_register_quotient_kernel(self.ctx.0, c.program.as_ptr(), c.program.len(), obj.as_ptr() as *const _, obj.len()) };
+                    }
+                }
+            }
+        }
+    }
+}
+
+impl<A> MachineProver<SC, A> for HipProver<A>
+where
+    A: MachineAir<F> + for<'a> Air<SymbolicAirBuilder<F>> + 'static,
+    // ... plus the bounds CpuProver carries (prover.rs:210-221): Air<ProverConstraintFolder>, Air<VerifierConstraintFolder>, Air<LookupBuilder>
+    A::Record: MachineRecord,
+{
+    type DeviceMatrix = HipMatrix;
+    type DeviceProverData = HipMainData;
+    type DeviceProvingKey = HipProvingKey;
+    type Error = HipProverError;
+
+    fn new(machine: StarkMachine<SC, A>) -> Self {
+        let device = std::env::var("ZKM_HIP_DEVICE").ok().and_then(|s| s.parse().ok()).unwrap_or(0);
+        let mut ctx = null_mut();
+        check(unsafe { ffi::zkm_ctx_create(device, &mut ctx) }).expect("zkm_ctx_create (there is no CPU fallback)");
+        let recorded = machine.chips().iter().map(|chip| (chip.name(), recorder::record_chip(chip))).collect();
+        let p = Self { machine, ctx: HipContext(ctx), recorded };
+        p.register_aot_kernels();
+        p
+    }
+
+    fn machine(&self) -> &StarkMachine<SC, A> { &self.machine }
+
+    fn setup(&self, program: &A::Program) -> (Self::DeviceProvingKey, StarkVerifyingKey<SC>) {
+        let (pk, vk) = self.machine.setup(program);      // host side, as CpuProver::setup (prover.rs:238-243)
+        (self.pk_to_device(&pk), vk)
+    }
+
+    fn pk_from_vk(&self, program: &A::Program, vk: &StarkVerifyingKey<SC>) -> Self::DeviceProvingKey {
+        self.pk_to_device(&self.machine.setup_core(program, vk.initial_global_cumulative_sum).0)
+    }
+
+    fn pk_to_device(&self, pk: &StarkProvingKey<SC>) -> Self::DeviceProvingKey {
+        let prep: Vec<HipMatrix> = pk.traces.iter().map(|t| self.upload(t).expect("upload")).collect();
+        let handles: Vec<*const ffi::ZkmMatrix> = prep.iter().map(|m| m.h as *const _).collect();
+        let local_only: Vec<u32> = pk.local_only.iter().map(|&b| b as u32).collect();
+        let igcs: Vec<u32> = pk.initial_global_cumulative_sum.0.x.0.iter().chain(pk.initial_global_cumulative_sum.0.y.0.iter())
+            .map(|&w| unsafe { core::mem::transmute::<F, u32>(w) }).collect();
+        let mut h = null_mut();
+        check(unsafe {
+            ffi::zkm_pk_setup(self.ctx.0, prep.len(), handles.as_ptr(), local_only.as_ptr(), core::mem::transmute::<F, u32>(pk.pc_start), igcs.as_ptr(),
+                              self.config().pcs().fri_config().log_blowup as u32, &mut h)
+        }).expect("zkm_pk_setup");
+        let mut root = [0u32; 8];
+        unsafe { ffi::zkm_pk_commitment(h, root.as_mut_ptr()) };
+        debug_assert_eq!(root.map(|w| unsafe { core::mem::transmute::<u32, F>(w) }), <[F; 8]>::from(pk.commit.clone()), "device and host preprocessed commitments differ");
+        HipProvingKey { host: pk.clone(), ctx: self.ctx.0, h, _prep: prep }
+    }
+
+    fn pk_to_host(&self, pk: &Self::DeviceProvingKey) -> StarkProvingKey<SC> { pk.host.clone() }
+
+    /// prover.rs:111-115 / :258-292. Traces go to the device tallest first so their upload overlaps the commit's kernels.
+    fn commit(&self, record: &A::Record, traces: Vec<(String, RowMajorMatrix<Val<SC>>)>) -> ShardMainData<SC, Self::DeviceMatrix, Self::DeviceProverData> {
+        let mut order: Vec<usize> = (0..traces.len()).collect();
+        order.sort_by_key(|&i| std::cmp::Reverse(traces[i].1.height()));
+        let mut dev: Vec<Option<HipMatrix>> = (0..traces.len()).map(|_| None).collect();
+        for i in order { dev[i] = Some(self.upload(&traces[i].1).expect("upload")); }
+        let dev: Vec<HipMatrix> = dev.into_iter().map(Option::unwrap).collect();
+        let names: Vec<std::ffi::CString> = traces.iter().map(|(n, _)| std::ffi::CString::new(n.as_str()).unwrap()).collect();
+        let name_ptrs: Vec<*const std::ffi::c_char> = names.iter().map(|n| n.as_ptr()).collect();
+        let handles: Vec<*const ffi::ZkmMatrix> = dev.iter().map(|m| m.h as *const _).collect();
+        let public_values: Vec<F> = record.public_values();
+        let (mut root, mut order_out, mut h) = ([0u32; 8], vec![0u32; traces.len()], null_mut());
+        check(unsafe {
+            ffi::zkm_commit(self.ctx.0, traces.len(), name_ptrs.as_ptr(), handles.as_ptr(), public_values.as_ptr() as *const u32, public_values.len(),
+                            self.config().pcs().fri_config().log_blowup as u32, root.as_mut_ptr(), order_out.as_mut_ptr(), &mut h)
+        }).expect("zkm_commit");
+        let caller_names: Vec<String> = traces.iter().map(|(n, _)| n.clone()).collect();
+        // chip_ordering: name -> position in commit order (prover.rs:264-271); order_out[position] = caller index
+        let chip_ordering = order_out.iter().enumerate().map(|(pos, &idx)| (traces[idx as usize].0.clone(), pos)).collect();
+        // ShardMainData.traces are in commit order (prover.rs:283-291)
+        let mut by_caller: Vec<Option<HipMatrix>> = dev.into_iter().map(Some).collect();
+        let sorted = order_out.iter().map(|&i| by_caller[i as usize].take().unwrap()).collect();
+        ShardMainData::new(sorted, root.map(|w| unsafe { core::mem::transmute::<u32, F>(w) }).into(), HipMainData { ctx: self.ctx.0, h, caller_names }, chip_ordering, public_values)
+    }
+
+    /// prover.rs:118-126 / :298-653: everything between the main commitment and the ShardProof happens inside zkm_open.
+    fn open(&self, pk: &Self::DeviceProvingKey, mut data: ShardMainData<SC, Self::DeviceMatrix, Self::DeviceProverData>,
+            challenger: &mut Challenger<SC>) -> Result<ShardProof<SC>, Self::Error> {
+        // descriptors in the caller order of zkm_commit (the library maps them through its own chip_ordering), each with the key's
+        // preprocessed index of its chip (pk.chip_ordering, machine.rs:58-75)
+        let caller_names = std::mem::take(&mut data.main_data.caller_names);
+        let descs: Vec<ffi::ZkmChipDesc> = caller_names.iter()
+            .map(|n| self.desc(n, pk.host.chip_ordering.get(n).map(|&i| i as i32).unwrap_or(-1))).collect();
+        let fri = self.config().pcs().fri_config();
+        let cfg = ffi::ZkmFriConfig { log_blowup: fri.log_blowup as u32, num_queries: fri.num_queries as u32, proof_of_work_bits: fri.proof_of_work_bits as u32 };
+        let mut ch = challenger_to_ffi(challenger);
+        let mut cap = 1usize << 22;
+        let mut proof = vec![0u32; cap];
+        let mut len = 0usize;
+        let h = std::mem::replace(&mut data.main_data.h, null_mut());    // zkm_open consumes the main data
+        let rc = unsafe {
+            ffi::zkm_open(self.ctx.0, pk.h, h, descs.as_ptr(), &cfg, self.machine.num_pv_elts() as u32, &mut ch, proof.as_mut_ptr(), cap, &mut len)
+        };
+        if rc != 0 && len > cap {
+            // the only retryable failure: the stream did not fit (the transcript was not advanced); the main data is gone, so the shim
+            // sizes the buffer generously up front and treats this as an error
+            cap = len;
+        }
+        check(rc)?;
+        proof.truncate(len);
+        challenger_from_ffi(&ch, challenger);
+        Ok(decode::decode_shard_proof(&proof, &caller_names))
+    }
+}
+
+/// DuplexChallenger<KoalaBear, Perm, 16, 8> <-> zkm_challenger (same fields as ChallengerPublicValues,
+/// crates/recursion/circuit/src/challenger.rs:62-66,117-150).
+fn challenger_to_ffi(c: &Challenger<SC>) -> ffi::ZkmChallenger {
+    let mut out = ffi::ZkmChallenger { sponge_state: [0; 16], num_inputs: 0, input_buffer: [0; 16], num_outputs: 0, output_buffer: [0; 16] };
+    let w = |x: F| unsafe { core::mem::transmute::<F, u32>(x) };
+    for (d, s) in out.sponge_state.iter_mut().zip(c.sponge_state.iter()) { *d = w(*s); }
+    out.num_inputs = c.input_buffer.len() as u32;
+    for (d, s) in out.input_buffer.iter_mut().zip(c.input_buffer.iter()) { *d = w(*s); }
+    out.num_outputs = c.output_buffer.len() as u32;
+    for (d, s) in out.output_buffer.iter_mut().zip(c.output_buffer.iter()) { *d = w(*s); }
+    out
+}
+fn challenger_from_ffi(src: &ffi::ZkmChallenger, c: &mut Challenger<SC>) {
+    let f = |x: u32| unsafe { core::mem::transmute::<u32, F>(x) };
+    for (d, s) in c.sponge_state.iter_mut().zip(src.sponge_state.iter()) { *d = f(*s); }
+    c.input_buffer = src.input_buffer[..src.num_inputs as usize].iter().map(|&x| f(x)).collect();
+    c.output_buffer = src.output_buffer[..src.num_outputs as usize].iter().map(|&x| f(x)).collect();
+}
+
+/// crates/prover/src/components.rs:28-35 gets a sibling: the core prover on the GPU, the recursion provers as they are (the recursion
+/// machine's chips go through the same library — SURVEY.md 8f N2 — once their provers are switched the same way).
+pub mod components {
+    // pub struct HipProverComponents;
+    // impl ZKMProverComponents for HipProverComponents {
+    //     type CoreProver = crate::HipProver<MipsAir<<CoreSC as StarkGenericConfig>::Val>>;
+    //     type CompressProver = CpuProver<InnerSC, CompressAir<<InnerSC as StarkGenericConfig>::Val>>;
+    //     type ShrinkProver = CpuProver<InnerSC, ShrinkAir<<InnerSC as StarkGenericConfig>::Val>>;
+    //     type WrapProver = CpuProver<OuterSC, WrapAir<<OuterSC as StarkGenericConfig>::Val>>;
+    // }
+    // It has to live in crates/prover (the trait and the Air types are there); it is four lines once `zkm-hip` is a dependency.
+}
+
+#[allow(dead_code)]
+fn _duplex_is_the_challenger(_: &DuplexChallenger<F, zkm_stark::koala_bear_poseidon2::InnerPerm, 16, 8>) {}
+#[allow(dead_code)]
+fn _canonical(x: F) -> u32 { x.as_canonical_u32() }

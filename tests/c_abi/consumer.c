@@ -3,10 +3,72 @@
  *
  *   consumer            no GPU expected: zkm_ctx_create must fail loudly (no CPU fallback) -> exit 0 and print the message
  *   consumer gpu        on a GPU: an AddSub event (5 + 7 = 12) -> device trace -> one-matrix commitment; prints "ok <root word>", then two
- *                       GlobalLookupEvents -> the Global chip's trace; prints "global <the fourteen words of the shard's digest>" */
+ *                       GlobalLookupEvents -> the Global chip's trace; prints "global <the fourteen words of the shard's digest>"
+ *   consumer prove      on a GPU, the whole hot path as the Rust shim would drive it: zkm_chip_desc of the AddSub chip (constraint bytecode and
+ *                       lookups from a header the test generates with the recorder: tests/c_abi/addsub_desc.h), forty AluEvents -> device trace,
+ *                       zkm_pk_setup (no preprocessed trace) -> zkm_challenger_init + zkm_pk_observe_into -> zkm_commit -> zkm_open with the
+ *                       too-small-buffer retry -> prints "proof <words> <fnv1a of the stream> <main commitment word 0> <transcript word>" */
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include "zkm_hip.h"
+#ifdef ZKM_HAVE_ADDSUB_DESC
+#include "addsub_desc.h"   /* ADDSUB_PROGRAM[], ADDSUB_LOOKUPS[], ADDSUB_NUM_CONSTRAINTS, ADDSUB_LQD, N_PUBLIC_VALUES, NUM_PV_ELTS */
+
+static int prove(zkm_ctx* ctx) {
+  enum { N = 40 };
+  zkm_alu_event ev[N];
+  memset(ev, 0, sizeof ev);
+  for (int i = 0; i < N; i++) {
+    ev[i].pc = 0x1000 + 4 * i; ev[i].next_pc = ev[i].pc + 4;
+    ev[i].opcode = i & 1;                                   /* ADD, SUB */
+    ev[i].b = 0x01020304u * (uint32_t)(i + 1); ev[i].c = 0xfffefdfcu - 77u * (uint32_t)i;
+    ev[i].a = ev[i].opcode ? ev[i].b - ev[i].c : ev[i].b + ev[i].c;
+  }
+  zkm_matrix* trace = NULL;
+  if (zkm_tracegen_alu(ctx, ZKM_CHIP_ADD_SUB, ev, N, -1, NULL, &trace) != 0) { printf("tracegen: %s\n", zkm_last_error()); return 20; }
+  zkm_chip_desc chip;
+  memset(&chip, 0, sizeof chip);
+  chip.name = "AddSub";
+  chip.main_width = (uint32_t)zkm_tracegen_alu_width(ZKM_CHIP_ADD_SUB);
+  chip.prep_index = -1;
+  chip.log_quotient_degree = ADDSUB_LQD;
+  chip.local_only = 1;
+  chip.num_constraints = ADDSUB_NUM_CONSTRAINTS;
+  chip.lookups = ADDSUB_LOOKUPS; chip.lookups_len = sizeof ADDSUB_LOOKUPS / 4;
+  chip.program = ADDSUB_PROGRAM; chip.program_len = sizeof ADDSUB_PROGRAM / 4;
+  const zkm_fri_config fri = {1, 84, 16};                   /* core configuration, kb31_poseidon2.rs:203-213 */
+  uint32_t igcs[14] = {0};
+  zkm_pk* pk = NULL;
+  if (zkm_pk_setup(ctx, 0, NULL, NULL, 0, igcs, fri.log_blowup, &pk) != 0) { printf("pk: %s\n", zkm_last_error()); return 21; }
+  zkm_challenger ch;
+  zkm_challenger_init(&ch);
+  if (zkm_pk_observe_into(pk, &ch) != 0) return 22;
+  static uint32_t pv[N_PUBLIC_VALUES];
+  const char* names[1] = {"AddSub"};
+  const zkm_matrix* traces[1] = {trace};
+  uint32_t main_commit[ZKM_DIGEST_ELEMS], order[1];
+  zkm_main_data* data = NULL;
+  if (zkm_commit(ctx, 1, names, traces, pv, N_PUBLIC_VALUES, fri.log_blowup, main_commit, order, &data) != 0) { printf("commit: %s\n", zkm_last_error()); return 23; }
+  /* first with a buffer that is too small: the call fails, says how many words it takes, and leaves the transcript untouched */
+  uint32_t tiny[8];
+  size_t need = 0;
+  const zkm_challenger before = ch;
+  if (zkm_prove_shard(ctx, pk, 1, &chip, traces, pv, N_PUBLIC_VALUES, &fri, NUM_PV_ELTS, &ch, tiny, 8, &need) == 0) return 24;
+  if (need <= 8 || memcmp(&before, &ch, sizeof ch) != 0 || !strstr(zkm_last_error(), "too small")) return 25;
+  uint32_t* proof = (uint32_t*)malloc(need * 4);
+  size_t len = 0;
+  if (zkm_open(ctx, pk, data, &chip, &fri, NUM_PV_ELTS, &ch, proof, need, &len) != 0) { printf("open: %s\n", zkm_last_error()); return 26; }
+  if (len != need || memcmp(proof, main_commit, 32) != 0) return 27;
+  uint32_t h = 2166136261u;
+  for (size_t i = 0; i < len; i++) { h ^= proof[i]; h *= 16777619u; }
+  printf("proof %zu %u %u %u\n", len, h, main_commit[0], zkm_challenger_sample(&ch));
+  free(proof);
+  zkm_pk_free(ctx, pk);
+  zkm_matrix_free(ctx, trace);
+  return 0;
+}
+#endif
 
 int main(int argc, char** argv) {
   zkm_ctx* ctx = NULL;
@@ -17,6 +79,9 @@ int main(int argc, char** argv) {
     return strstr(zkm_last_error(), "no CPU fallback") ? 0 : 2;
   }
   if (rc != 0) { printf("ctx: %s\n", zkm_last_error()); return 3; }
+#ifdef ZKM_HAVE_ADDSUB_DESC
+  if (!strcmp(argv[1], "prove")) { rc = prove(ctx); zkm_ctx_destroy(ctx); return rc; }
+#endif
   zkm_alu_event ev;
   memset(&ev, 0, sizeof ev);
   ev.pc = 0x1000; ev.next_pc = 0x1004; ev.opcode = 0; ev.a = 12; ev.b = 5; ev.c = 7;   /* ADD */

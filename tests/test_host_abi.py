@@ -29,12 +29,42 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(L, name), name
 
 
-def _build_c_consumer(tmp_path):
+def _addsub_chip():
+    from ziren_amd import chips, events as E
+    return chips.record_chip(E.CHIP_ADD_SUB, 6)
+
+
+def _build_c_consumer(tmp_path, with_desc=False):
     import subprocess
     exe = str(tmp_path / "consumer")
-    subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "c_abi", "consumer.c"),
-                           "-L", os.path.join(ROOT, "ziren_amd"), "-lzkm_hip", "-Wl,-rpath," + os.path.join(ROOT, "ziren_amd"), "-o", exe])
+    extra = []
+    if with_desc:     # the AddSub chip's descriptor as the recorder emits it, as C arrays: what the Rust shim would hand to zkm_open
+        c = _addsub_chip()
+        arr = lambda name, a: f"static const uint32_t {name}[] = {{" + ", ".join(f"{int(x)}u" for x in a) + "};\n"   # noqa: E731
+        (tmp_path / "addsub_desc.h").write_text(
+            arr("ADDSUB_PROGRAM", c.program) + arr("ADDSUB_LOOKUPS", c.lookups_blob) +
+            f"enum {{ ADDSUB_NUM_CONSTRAINTS = {c.num_constraints}, ADDSUB_LQD = {c.log_quotient_degree}, N_PUBLIC_VALUES = {synth.PROOF_MAX_NUM_PVS}, "
+            f"NUM_PV_ELTS = {synth.NUM_PV_ELTS} }};\n")
+        extra = ["-DZKM_HAVE_ADDSUB_DESC", "-I", str(tmp_path)]
+    subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include")] + extra +
+                          [os.path.join(ROOT, "tests", "c_abi", "consumer.c"), "-L", os.path.join(ROOT, "ziren_amd"), "-lzkm_hip",
+                           "-Wl,-rpath," + os.path.join(ROOT, "ziren_amd"), "-o", exe])
     return exe
+
+
+def test_rust_ffi_is_generated_from_the_header():
+    """integration/zkm-hip/src/ffi.rs (the Rust side of the boundary) is generated from include/zkm_hip.h: regenerating it gives the
+    committed file, and it declares every entry point the library exports."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("gen_rust_ffi", os.path.join(ROOT, "tools", "gen_rust_ffi.py"))
+    g = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(g)
+    text, names = g.gen(os.path.join(ROOT, "include", "zkm_hip.h"))
+    assert text == open(os.path.join(ROOT, "integration", "zkm-hip", "src", "ffi.rs")).read(), "run python tools/gen_rust_ffi.py"
+    assert set(names) == set(lib.EXPORTS)
+    for f in ("lib.rs", "recorder.rs", "decode.rs"):
+        src = open(os.path.join(ROOT, "integration", "zkm-hip", "src", f)).read()
+        assert src.count("{") == src.count("}") and src.count("(") == src.count(")"), f      # not compiled here: at least balanced
 
 
 def test_plain_c_consumer_links_and_is_refused_without_a_gpu(tmp_path):
@@ -76,6 +106,36 @@ def test_no_gpu_means_loud_failure():
     env = dict(os.environ, HIP_VISIBLE_DEVICES="-1", ROCR_VISIBLE_DEVICES="-1", PYTHONPATH=ROOT)
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=ROOT).stdout
     assert out.startswith("-1 ") and "no CPU fallback" in out, out
+
+
+@pytest.mark.gpu
+def test_gpu_plain_c_consumer_proves_a_shard(tmp_path, oracle):
+    """A C program with no Python in the process drives the whole hot path through the ABI — descriptor, device trace generation,
+    zkm_pk_setup, transcript, zkm_commit, zkm_open (with the too-small-buffer retry) — and its proof stream is the oracle's, word for
+    word (compared through length, FNV-1a hash, the main commitment and the next transcript sample)."""
+    import subprocess
+    from ziren_amd import events as E
+    exe = _build_c_consumer(tmp_path, with_desc=True)
+    out = subprocess.run([exe, "prove"], capture_output=True, text=True)
+    assert out.returncode == 0 and out.stdout.startswith("proof "), (out.returncode, out.stdout, out.stderr)
+    n_words, fnv, commit0, sample = (int(x) for x in out.stdout.split()[1:5])
+    i = np.arange(40, dtype=np.uint64)
+    b = (0x01020304 * (i + 1)) & 0xffffffff
+    c = (0xfffefdfc - 77 * i) & 0xffffffff
+    ev = E.make_alu_events([E.ADD if k % 2 == 0 else E.SUB for k in range(40)], [int(x) for x in b], [int(x) for x in c], pc0=0x1000)
+    chip = _addsub_chip()
+    chip.trace = oracle.tracegen_alu(E.CHIP_ADD_SUB, ev)
+    fri = abi.FriConfig(1, 84, 16)
+    opk = oracle.Pk([], [], 0, np.zeros(14, dtype=np.uint32), 1)
+    ch = oracle.new_challenger()
+    opk.observe_into(ch)
+    pv = np.zeros(synth.PROOF_MAX_NUM_PVS, dtype=np.uint32)
+    proof, _ = oracle.prove_shard(opk, [chip], [chip.trace], pv, fri, synth.NUM_PV_ELTS, ch)
+    h = 2166136261
+    for w in proof.tolist():
+        h = ((h ^ w) * 16777619) & 0xffffffff
+    assert (n_words, fnv, commit0) == (len(proof), h, int(proof[0]))
+    assert sample == oracle.lib().orc_challenger_sample(C.byref(ch))
 
 
 def test_host_field_ext_poseidon2_match_oracle(oracle):

@@ -155,5 +155,27 @@ def specialize(program: np.ndarray, force: bool = False, verbose: bool = False) 
                 print(" ".join(cmd))
             subprocess.check_call(cmd)
         os.replace(out + ".tmp", out)
+    _note_in_manifest(program, os.path.basename(out))
     with open(out, "rb") as f:
         return f.read()
+
+
+def _note_in_manifest(program: np.ndarray, filename: str):
+    """Ahead-of-time story for a host with no compiler at run time (the Rust shim): `_jit/manifest.json` maps the sha256
+    of a chip's program words (little-endian bytes — a key any host language can compute) to its code object. `__graft_entry__.build()`
+    specialises every recorded chip, so the manifest and the code objects ship with the build; an unknown program falls back to the
+    bytecode interpreter inside the library."""
+    import json
+    key = hashlib.sha256(np.ascontiguousarray(program, dtype="<u4").tobytes()).hexdigest()
+    path = os.path.join(CACHE, "manifest.json")
+    try:
+        with open(path) as f:
+            m = json.load(f)
+    except (OSError, ValueError):
+        m = {}
+    if m.get(key) != filename:
+        m[key] = filename
+        tmp = path + f".{os.getpid()}.tmp"
+        with open(tmp, "w") as f:
+            json.dump(m, f, indent=0, sort_keys=True)
+        os.replace(tmp, path)
