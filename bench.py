@@ -311,7 +311,8 @@ def main():
         # Poseidon2 runs on the FP64 vector pipe (csrc/poseidon2_f64.cuh); its ceiling is the chip's FP64 vector issue rate divided by
         # the permutation's dynamic instruction count as the hardware counted it (SQ_INSTS_VALU, profiles/r02_poseidon2_isa.json)
         valu = None
-        hashing = [n for n in ("compress_layer", "hash_leaves", "hash_leaves_tree", "hash_fri_leaves", "compress_small") if n in kern_acc]
+        hashing = [n for n in ("compress_layer", "hash_leaves", "hash_leaves_tree", "hash_fri_leaves", "hash_fri_leaves_tree", "compress_small", "compress_tail")
+                   if n in kern_acc]
         if hashing and M == 1:
             perms = synth.shard_poseidon2_permutations(shard, fri.log_blowup)
             hms = sum(kern_acc[n][0] for n in hashing) / steps

@@ -123,6 +123,90 @@ __global__ __launch_bounds__(THREADS) void compress_tail(uint32_t* __restrict__ 
   }
 }
 
+// ---- fused leaf hashing + in-block tree (north_star: "Poseidon2 Merkle-tree commitment as a fused permutation+tree kernel") ----------
+// One block hashes FUSE_LEAVES = 1024 consecutive leaves (one per thread, sponge state in VGPRs) and then reduces them through up to
+// FUSE_MAX_LEVELS = 4 tree levels without going back to HBM for its inputs: a level's digests are handed over in LDS (two 32 KiB
+// buffers), every level is also written to its place in the tree (openings read all of them later). With 1024 leaves the four levels
+// have 512, 256, 128 and 64 nodes — whole wavefronts, so no lane idles inside a permutation; deeper in-block levels would run
+// part-filled waves on an issue-bound kernel and are left to compress_layer / the lane-parallel kernels. Applies where no shorter
+// matrix is injected into those levels: every FRI commit-phase tree, and commits whose next matrix is at least 2^levels shorter.
+constexpr int FUSE_LEAVES = 1024, FUSE_MAX_LEVELS = 4;
+
+__device__ __forceinline__ void tree_levels_in_block(double s[16], uint32_t* lds, size_t leaf0, size_t n_leaves, uint32_t* __restrict__ tree, int levels) {
+  // s[0..8): this thread's leaf digest (doubles, unreduced). Layer l of the tree starts at digest index n_leaves * (2 - 2^(1-l)).
+  uint32_t* cur = lds;                       // [FUSE_LEAVES][8] words
+  uint32_t* nxt = lds + FUSE_LEAVES * 8;     // [FUSE_LEAVES / 2][8]
+  const int t = threadIdx.x;
+  {
+    uint32_t w[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) w[k] = p2f::store_monty(s[k]);
+    uint4* g = reinterpret_cast<uint4*>(tree + (leaf0 + t) * 8);
+    g[0] = make_uint4(w[0], w[1], w[2], w[3]);
+    g[1] = make_uint4(w[4], w[5], w[6], w[7]);
+    uint4* l = reinterpret_cast<uint4*>(cur + t * 8);
+    l[0] = make_uint4(w[0], w[1], w[2], w[3]);
+    l[1] = make_uint4(w[4], w[5], w[6], w[7]);
+  }
+  size_t layer_off = n_leaves;               // digest index where layer 1 starts
+  size_t layer_len = n_leaves >> 1;
+  size_t node0 = leaf0 >> 1;
+  int nodes = FUSE_LEAVES >> 1;
+  for (int lvl = 1; lvl <= levels; lvl++) {
+    __syncthreads();
+    if (t < nodes) {
+      const uint4* c = reinterpret_cast<const uint4*>(cur + 16 * t);
+      const uint4 a0 = c[0], a1 = c[1], b0 = c[2], b1 = c[3];
+      s[0] = p2f::load_monty(a0.x); s[1] = p2f::load_monty(a0.y); s[2] = p2f::load_monty(a0.z); s[3] = p2f::load_monty(a0.w);
+      s[4] = p2f::load_monty(a1.x); s[5] = p2f::load_monty(a1.y); s[6] = p2f::load_monty(a1.z); s[7] = p2f::load_monty(a1.w);
+      s[8] = p2f::load_monty(b0.x); s[9] = p2f::load_monty(b0.y); s[10] = p2f::load_monty(b0.z); s[11] = p2f::load_monty(b0.w);
+      s[12] = p2f::load_monty(b1.x); s[13] = p2f::load_monty(b1.y); s[14] = p2f::load_monty(b1.z); s[15] = p2f::load_monty(b1.w);
+      p2f::permute(s);
+      uint32_t w[8];
+#pragma unroll
+      for (int k = 0; k < 8; k++) w[k] = p2f::store_monty(s[k]);
+      uint4* g = reinterpret_cast<uint4*>(tree + (layer_off + node0 + t) * 8);
+      g[0] = make_uint4(w[0], w[1], w[2], w[3]);
+      g[1] = make_uint4(w[4], w[5], w[6], w[7]);
+      uint4* l = reinterpret_cast<uint4*>(nxt + t * 8);
+      l[0] = make_uint4(w[0], w[1], w[2], w[3]);
+      l[1] = make_uint4(w[4], w[5], w[6], w[7]);
+    }
+    uint32_t* tmp = cur; cur = nxt; nxt = tmp;
+    layer_off += layer_len;
+    layer_len >>= 1;
+    node0 >>= 1;
+    nodes >>= 1;
+  }
+}
+
+// leaves = rows of the tallest matrices (hash_leaves) + `levels` tree levels; height is a multiple of FUSE_LEAVES
+__global__ __launch_bounds__(FUSE_LEAVES) void hash_leaves_tree(const uint32_t* const* __restrict__ colptrs, int width, size_t height,
+                                                                uint32_t* __restrict__ tree, int levels) {
+  extern __shared__ uint32_t fuse_lds[];
+  const size_t leaf0 = (size_t)blockIdx.x * FUSE_LEAVES;
+  double s[16];
+#pragma unroll
+  for (int i = 0; i < 16; i++) s[i] = 0.0;
+  absorb_row(s, colptrs, width, leaf0 + threadIdx.x);
+  tree_levels_in_block(s, fuse_lds, leaf0, height, tree, levels);
+}
+
+// FRI commit-phase leaves (row j = (f[2j], f[2j+1]), as hash_fri_leaves) + `levels` tree levels; m is a multiple of FUSE_LEAVES
+__global__ __launch_bounds__(FUSE_LEAVES) void hash_fri_leaves_tree(const kb::E4* __restrict__ f, size_t m, uint32_t* __restrict__ tree, int levels) {
+  extern __shared__ uint32_t fuse_lds[];
+  const size_t leaf0 = (size_t)blockIdx.x * FUSE_LEAVES;
+  const size_t j = leaf0 + threadIdx.x;
+  double s[16];
+  const kb::E4 a = f[2 * j], b = f[2 * j + 1];
+#pragma unroll
+  for (int k = 0; k < 4; k++) { s[k] = p2f::load_monty(a.c[k]); s[4 + k] = p2f::load_monty(b.c[k]); }
+#pragma unroll
+  for (int k = 8; k < 16; k++) s[k] = 0.0;
+  p2f::permute(s);
+  tree_levels_in_block(s, fuse_lds, leaf0, m, tree, levels);
+}
+
 // ---- lane-parallel Poseidon2 for the small layers near the root ------------------------------------
 // A layer with few nodes cannot fill the chip with one thread per node and pays the full ~11 us latency
 // of a serial permutation per level. Here 16 lanes (one DPP row) share one permutation, lane e holding

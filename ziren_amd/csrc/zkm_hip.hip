@@ -400,20 +400,35 @@ static void build_tree(zkm_ctx* ctx, const std::vector<zkm_matrix>& mats, Tree& 
     return ptrs;
   };
   std::vector<const uint32_t**> to_free;
+  // the tree levels right above the leaves that no shorter matrix is injected into can be reduced inside the leaf kernel's blocks
+  int fuse = 0;
+  if (maxh >= (size_t)merkle::FUSE_LEAVES) {
+    while (fuse < merkle::FUSE_MAX_LEVELS && (maxh >> (fuse + 1)) >= 1) {
+      bool injected = false;
+      for (auto& m : mats) injected |= m.h == (maxh >> (fuse + 1));
+      if (injected) break;
+      fuse++;
+    }
+  }
   {
     auto ptrs = cols_of_height(maxh);
     const uint32_t** d = upload_ptrs(ctx, ptrs);
     to_free.push_back(d);
     wait_height(maxh);
-    KLAUNCH(ctx, "hash_leaves", 4.0 * maxh * ptrs.size() + 32.0 * maxh, merkle::hash_leaves, dim3(div_up(maxh, merkle::THREADS)),
-            dim3(merkle::THREADS), 0, d, (int)ptrs.size(), maxh, t.digests);
+    if (fuse > 0)
+      KLAUNCH(ctx, "hash_leaves_tree", 4.0 * maxh * ptrs.size() + 32.0 * maxh * (2.0 - 1.0 / (1 << fuse)), merkle::hash_leaves_tree,
+              dim3(maxh / merkle::FUSE_LEAVES), dim3(merkle::FUSE_LEAVES), merkle::FUSE_LEAVES * 12 * sizeof(uint32_t), d, (int)ptrs.size(), maxh,
+              t.digests, fuse);
+    else
+      KLAUNCH(ctx, "hash_leaves", 4.0 * maxh * ptrs.size() + 32.0 * maxh, merkle::hash_leaves, dim3(div_up(maxh, merkle::THREADS)),
+              dim3(merkle::THREADS), 0, d, (int)ptrs.size(), maxh, t.digests);
   }
   // near the root (no shorter matrix left to inject) layers switch to 16 lanes per node, and the last
   // <= 64-node layers go in one launch
   size_t min_h = maxh;
   for (auto& m : mats) min_h = std::min(min_h, m.h);
-  int layer = 0;
-  for (size_t len = maxh / 2; len >= 1; len >>= 1, layer++) {
+  int layer = fuse;
+  for (size_t len = maxh >> (fuse + 1); len >= 1; len >>= 1, layer++) {
     if (min_h > len) {
       if (compress_small_layer(ctx, t, layer, len)) break;
       continue;
@@ -918,10 +933,16 @@ static void open_impl(zkm_ctx* ctx, const zkm_pk* pk, zkm_main_data* md, const z
     size_t off = 0;
     for (size_t l = half; l >= 1; l >>= 1) { t.layer_off.push_back(off); off += l; if (l == 1) break; }
     t.digests = (uint32_t*)salloc(off * 8 * 4);
-    KLAUNCH(ctx, "hash_fri_leaves", 64.0 * half, merkle::hash_fri_leaves, dim3(div_up(half, merkle::THREADS)), dim3(merkle::THREADS), 0,
-            (const E4*)f, half, t.digests);
-    int layer = 0;
-    for (size_t l = half / 2; l >= 1; l >>= 1, layer++)
+    int fuse = 0;   // FRI trees have one matrix: the first levels are reduced inside the leaf kernel's blocks
+    if (half >= (size_t)merkle::FUSE_LEAVES) fuse = std::min(merkle::FUSE_MAX_LEVELS, lf - 1);
+    if (fuse > 0)
+      KLAUNCH(ctx, "hash_fri_leaves_tree", 32.0 * half + 32.0 * half * (2.0 - 1.0 / (1 << fuse)), merkle::hash_fri_leaves_tree,
+              dim3(half / merkle::FUSE_LEAVES), dim3(merkle::FUSE_LEAVES), merkle::FUSE_LEAVES * 12 * sizeof(uint32_t), (const E4*)f, half, t.digests, fuse);
+    else
+      KLAUNCH(ctx, "hash_fri_leaves", 64.0 * half, merkle::hash_fri_leaves, dim3(div_up(half, merkle::THREADS)), dim3(merkle::THREADS), 0,
+              (const E4*)f, half, t.digests);
+    int layer = fuse;
+    for (size_t l = half >> (fuse + 1); l >= 1; l >>= 1, layer++)
       if (compress_small_layer(ctx, t, layer, l)) break;
     std::array<uint32_t, 8> root;
     const uint32_t* h_root = ctx->download_async(t.node(t.log_max, 0), 8);
