@@ -1,0 +1,671 @@
+// Part of libzkm_hip.so's host side (one translation unit: csrc/zkm_hip.hip includes this file). The zkm_tracegen_* entry points (device trace generation); included inside the extern "C" block.
+#pragma once
+// ---- device trace generation (ALU chips) ---------------------------------------------------------------------
+size_t zkm_tracegen_alu_width(int chip) { return chip >= 0 && chip < tracegen::NUM_ALU_CHIPS ? (size_t)tracegen::chip_width(chip) : 0; }
+
+static int tracegen_events(zkm_ctx* ctx, int chip, const void* events, size_t n_events, int fixed_log2_rows,
+                           zkm_byte_lookups* blu, zkm_matrix** out) {
+  API_BEGIN
+  static_assert(sizeof(zkm_alu_event) == 28 && sizeof(zkm_jump_event) == 28 && sizeof(zkm_mov_cond_event) == 28 &&
+                sizeof(zkm_comp_alu_event) == 64, "event records mirror the #[repr(C)] executor structs");
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIP_CHECK(hipSetDevice(ctx->device));
+  if (chip < 0 || chip >= tracegen::NUM_CHIPS) throw std::runtime_error("zkm_tracegen: unknown chip");
+  if (n_events && !events) throw std::runtime_error("zkm_tracegen: null events");
+  // utils::next_power_of_two (crates/core/machine/src/utils/mod.rs): the shape's fixed size, else >= 16
+  size_t height = 16;
+  if (fixed_log2_rows >= 0) {
+    if (fixed_log2_rows > 30) throw std::runtime_error("zkm_tracegen_alu: fixed log2 rows out of range");
+    height = (size_t)1 << fixed_log2_rows;
+    if (n_events > height) throw std::runtime_error("zkm_tracegen_alu: fixed log2 rows is too small");
+  } else {
+    while (height < n_events) height <<= 1;
+  }
+  const size_t w = (size_t)tracegen::chip_width(chip);
+  ctx->begin_timing();
+  zkm_matrix* m = new zkm_matrix();
+  m->h = height; m->w = w;
+  uint32_t* d_events = nullptr;
+  try {
+    m->d = ctx->alloc_n<uint32_t>(height * w);
+    const size_t event_bytes = 4 * (size_t)tracegen::event_words(chip);
+    d_events = (uint32_t*)ctx->alloc(std::max<size_t>(n_events * event_bytes, 4));
+    if (n_events) HIP_CHECK(hipMemcpyAsync(d_events, events, n_events * event_bytes, hipMemcpyHostToDevice, ctx->stream));
+    uint32_t* counts = blu ? blu->counts : nullptr;
+    switch (chip) {
+      case tracegen::ADD_SUB: launch_alu_rows<tracegen::ADD_SUB>(ctx, d_events, n_events, height, m->d, counts); break;
+      case tracegen::BITWISE: launch_alu_rows<tracegen::BITWISE>(ctx, d_events, n_events, height, m->d, counts); break;
+      case tracegen::LT: launch_alu_rows<tracegen::LT>(ctx, d_events, n_events, height, m->d, counts); break;
+      case tracegen::SHIFT_LEFT: launch_alu_rows<tracegen::SHIFT_LEFT>(ctx, d_events, n_events, height, m->d, counts); break;
+      case tracegen::SHIFT_RIGHT: launch_alu_rows<tracegen::SHIFT_RIGHT>(ctx, d_events, n_events, height, m->d, counts); break;
+      case tracegen::CLO_CLZ: launch_alu_rows<tracegen::CLO_CLZ>(ctx, d_events, n_events, height, m->d, counts); break;
+      case tracegen::JUMP: launch_alu_rows<tracegen::JUMP>(ctx, d_events, n_events, height, m->d, counts); break;
+      case tracegen::MOV_COND: launch_alu_rows<tracegen::MOV_COND>(ctx, d_events, n_events, height, m->d, counts); break;
+      case tracegen::BRANCH: launch_alu_rows<tracegen::BRANCH>(ctx, d_events, n_events, height, m->d, counts); break;
+      case tracegen::MUL: launch_alu_rows<tracegen::MUL>(ctx, d_events, n_events, height, m->d, counts); break;
+      case tracegen::DIVREM: launch_alu_rows<tracegen::DIVREM>(ctx, d_events, n_events, height, m->d, counts); break;
+      case tracegen::MEMORY_INSTRS: launch_alu_rows<tracegen::MEMORY_INSTRS>(ctx, d_events, n_events, height, m->d, counts); break;
+      case tracegen::SYSCALL_INSTRS: launch_alu_rows<tracegen::SYSCALL_INSTRS>(ctx, d_events, n_events, height, m->d, counts); break;
+      case tracegen::MISC_INSTRS: launch_alu_rows<tracegen::MISC_INSTRS>(ctx, d_events, n_events, height, m->d, counts); break;
+      case tracegen::SYSCALL_CORE: launch_alu_rows<tracegen::SYSCALL_CORE>(ctx, d_events, n_events, height, m->d, counts); break;
+      case tracegen::SYSCALL_PRECOMPILE: launch_alu_rows<tracegen::SYSCALL_PRECOMPILE>(ctx, d_events, n_events, height, m->d, counts); break;
+    }
+    ctx->mark("trace generation");
+    ctx->end_timing(false);  // synchronises: the caller's event buffer is free again
+  } catch (...) {
+    if (d_events) ctx->release(d_events);
+    if (m->d) ctx->release(m->d);
+    delete m;
+    throw;
+  }
+  ctx->release(d_events);
+  *out = m;
+  API_END
+}
+
+int zkm_tracegen_alu(zkm_ctx* ctx, int chip, const zkm_alu_event* events, size_t n_events, int fixed_log2_rows,
+                     zkm_byte_lookups* blu, zkm_matrix** out) {
+  if (chip < 0 || chip >= tracegen::NUM_ALU_CHIPS) { g_err = "zkm_tracegen_alu: unknown chip"; return -1; }
+  return tracegen_events(ctx, chip, events, n_events, fixed_log2_rows, blu, out);
+}
+size_t zkm_tracegen_jump_width(void) { return (size_t)tracegen::chip_width(tracegen::JUMP); }
+int zkm_tracegen_jump(zkm_ctx* ctx, const zkm_jump_event* events, size_t n_events, int fixed_log2_rows, zkm_matrix** out) {
+  return tracegen_events(ctx, tracegen::JUMP, events, n_events, fixed_log2_rows, nullptr, out);
+}
+
+int zkm_tracegen_flat(zkm_ctx* ctx, const uint32_t* words, size_t n_words, size_t width, int fixed_log2_rows, zkm_matrix** out) {
+  API_BEGIN
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIP_CHECK(hipSetDevice(ctx->device));
+  if (width == 0) throw std::runtime_error("zkm_tracegen_flat: zero width");
+  if (n_words && !words) throw std::runtime_error("zkm_tracegen_flat: null records");
+  const size_t rows = (n_words + width - 1) / width;
+  size_t height = 16;
+  if (fixed_log2_rows >= 0) {
+    if (fixed_log2_rows > 30) throw std::runtime_error("zkm_tracegen_flat: fixed log2 rows out of range");
+    height = (size_t)1 << fixed_log2_rows;
+    if (rows > height) throw std::runtime_error("zkm_tracegen_flat: fixed log2 rows is too small");
+  } else {
+    while (height < rows) height <<= 1;
+  }
+  ctx->begin_call();
+  zkm_matrix* m = new zkm_matrix();
+  m->h = height; m->w = width;
+  uint32_t* stage = nullptr;
+  try {
+    m->d = ctx->alloc_n<uint32_t>(height * width);
+    stage = ctx->alloc_n<uint32_t>(height * width);
+    HIP_CHECK(hipMemsetAsync(stage, 0, height * width * 4, ctx->stream));
+    if (n_words) HIP_CHECK(hipMemcpyAsync(stage, words, n_words * 4, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(open::transpose_slab, dim3(div_up(width, 32), div_up(height, 32)), dim3(32, 8), 0, ctx->stream,
+                       (const uint32_t*)stage, m->d, height, width, (size_t)0, height);
+    LAUNCH_CHECK();
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  } catch (...) {
+    if (stage) ctx->release(stage);
+    if (m->d) ctx->release(m->d);
+    delete m;
+    throw;
+  }
+  ctx->release(stage);
+  *out = m;
+  API_END
+}
+
+size_t zkm_tracegen_branch_width(void) { return (size_t)tracegen::chip_width(tracegen::BRANCH); }
+int zkm_tracegen_branch(zkm_ctx* ctx, const zkm_branch_event* events, size_t n_events, int fixed_log2_rows, zkm_byte_lookups* blu,
+                        zkm_matrix** out) {
+  return tracegen_events(ctx, tracegen::BRANCH, events, n_events, fixed_log2_rows, blu, out);
+}
+size_t zkm_tracegen_mul_width(void) { return (size_t)tracegen::chip_width(tracegen::MUL); }
+int zkm_tracegen_mul(zkm_ctx* ctx, const zkm_comp_alu_event* events, size_t n_events, int fixed_log2_rows, zkm_byte_lookups* blu,
+                     zkm_matrix** out) {
+  return tracegen_events(ctx, tracegen::MUL, events, n_events, fixed_log2_rows, blu, out);
+}
+size_t zkm_tracegen_memory_instrs_width(void) { return (size_t)tracegen::chip_width(tracegen::MEMORY_INSTRS); }
+int zkm_tracegen_memory_instrs(zkm_ctx* ctx, const zkm_mem_instr_event* events, size_t n_events, int fixed_log2_rows, zkm_byte_lookups* blu,
+                               zkm_matrix** out) {
+  static_assert(sizeof(zkm_mem_instr_event) == 64, "event records mirror the #[repr(C)] executor structs");
+  return tracegen_events(ctx, tracegen::MEMORY_INSTRS, events, n_events, fixed_log2_rows, blu, out);
+}
+size_t zkm_tracegen_syscall_instrs_width(void) { return (size_t)tracegen::chip_width(tracegen::SYSCALL_INSTRS); }
+int zkm_tracegen_syscall_instrs(zkm_ctx* ctx, const zkm_syscall_event* events, size_t n_events, int fixed_log2_rows, zkm_matrix** out) {
+  static_assert(sizeof(zkm_syscall_event) == 56, "event records mirror the #[repr(C)] executor structs");
+  return tracegen_events(ctx, tracegen::SYSCALL_INSTRS, events, n_events, fixed_log2_rows, nullptr, out);
+}
+size_t zkm_tracegen_misc_instrs_width(void) { return (size_t)tracegen::chip_width(tracegen::MISC_INSTRS); }
+int zkm_tracegen_misc_instrs(zkm_ctx* ctx, const zkm_misc_event* events, size_t n_events, int fixed_log2_rows, zkm_byte_lookups* blu,
+                             zkm_matrix** out) {
+  static_assert(sizeof(zkm_misc_event) == 60, "event records mirror the #[repr(C)] executor structs");
+  return tracegen_events(ctx, tracegen::MISC_INSTRS, events, n_events, fixed_log2_rows, blu, out);
+}
+size_t zkm_tracegen_divrem_width(void) { return (size_t)tracegen::chip_width(tracegen::DIVREM); }
+int zkm_tracegen_divrem(zkm_ctx* ctx, const zkm_comp_alu_event* events, size_t n_events, int fixed_log2_rows, zkm_byte_lookups* blu,
+                        zkm_matrix** out) {
+  return tracegen_events(ctx, tracegen::DIVREM, events, n_events, fixed_log2_rows, blu, out);
+}
+size_t zkm_tracegen_mov_cond_width(void) { return (size_t)tracegen::chip_width(tracegen::MOV_COND); }
+int zkm_tracegen_mov_cond(zkm_ctx* ctx, const zkm_mov_cond_event* events, size_t n_events, int fixed_log2_rows, zkm_matrix** out) {
+  return tracegen_events(ctx, tracegen::MOV_COND, events, n_events, fixed_log2_rows, nullptr, out);
+}
+
+static size_t padded_trace_rows(size_t n_records, int fixed_log2_rows, const char* what) {
+  // utils::next_power_of_two (crates/core/machine/src/utils/mod.rs): the shape's fixed size, else >= 16
+  size_t height = 16;
+  if (fixed_log2_rows >= 0) {
+    if (fixed_log2_rows > 30) throw std::runtime_error(std::string(what) + ": fixed log2 rows out of range");
+    height = (size_t)1 << fixed_log2_rows;
+    if (n_records > height) throw std::runtime_error(std::string(what) + ": fixed log2 rows is too small");
+  } else {
+    while (height < n_records) height <<= 1;
+  }
+  return height;
+}
+
+size_t zkm_tracegen_cpu_width(void) { return (size_t)tracegen::CPU_WIDTH; }
+int zkm_tracegen_cpu_and_program(zkm_ctx* ctx, const zkm_cpu_event* events, size_t n_events, const zkm_instruction* program, size_t n_instr,
+                                 uint32_t pc_base, uint32_t shard, int fixed_log2_rows, int program_fixed_log2_rows, zkm_byte_lookups* blu,
+                                 zkm_matrix** out, zkm_matrix** program_mults_out) {
+  API_BEGIN
+  static_assert(sizeof(zkm_cpu_event) == 4 * tracegen::CPU_EVENT_WORDS && sizeof(zkm_instruction) == 4 * tracegen::INSTRUCTION_WORDS,
+                "event records mirror the #[repr(C)] executor structs");
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIP_CHECK(hipSetDevice(ctx->device));
+  if (n_events && (!events || !program || !n_instr)) throw std::runtime_error("zkm_tracegen_cpu: null events or program");
+  const size_t height = padded_trace_rows(n_events, fixed_log2_rows, "zkm_tracegen_cpu");
+  const size_t pheight = program_mults_out ? padded_trace_rows(n_instr, program_fixed_log2_rows, "zkm_tracegen_cpu (program)") : 0;
+  ctx->begin_timing();
+  zkm_matrix* m = new zkm_matrix();
+  zkm_matrix* pm = program_mults_out ? new zkm_matrix() : nullptr;
+  m->h = height; m->w = tracegen::CPU_WIDTH;
+  uint32_t *d_events = nullptr, *d_program = nullptr;
+  int* d_bad = nullptr;
+  try {
+    m->d = ctx->alloc_n<uint32_t>(height * m->w);
+    if (pm) {
+      pm->h = pheight; pm->w = 1;
+      pm->d = ctx->alloc_n<uint32_t>(pheight);
+      HIP_CHECK(hipMemsetAsync(pm->d, 0, pheight * 4, ctx->stream));
+    }
+    d_events = (uint32_t*)ctx->alloc(std::max<size_t>(n_events * sizeof(zkm_cpu_event), 4));
+    d_program = (uint32_t*)ctx->alloc(std::max<size_t>(n_instr * sizeof(zkm_instruction), 4));
+    d_bad = (int*)ctx->alloc(4);
+    HIP_CHECK(hipMemsetAsync(d_bad, 0, 4, ctx->stream));
+    if (n_events) HIP_CHECK(hipMemcpyAsync(d_events, events, n_events * sizeof(zkm_cpu_event), hipMemcpyHostToDevice, ctx->stream));
+    if (n_instr) HIP_CHECK(hipMemcpyAsync(d_program, program, n_instr * sizeof(zkm_instruction), hipMemcpyHostToDevice, ctx->stream));
+    uint32_t* counts = blu ? blu->counts : nullptr;
+    const int tiles = counts ? tracegen::TILES_PER_BLOCK : 1;
+    KLAUNCH(ctx, "tracegen_cpu", 280.0 * n_events + 4.0 * height * tracegen::CPU_WIDTH, tracegen::cpu_rows,
+            dim3(div_up(height, (size_t)tiles * tracegen::THREADS)), dim3(tracegen::THREADS),
+            counts ? 2 * tracegen::HASH_SLOTS * sizeof(uint32_t) : 0, (const uint32_t*)d_events, n_events, (const uint32_t*)d_program, n_instr,
+            pc_base, shard, height, m->d, counts, tiles, d_bad, pm ? pm->d : (uint32_t*)nullptr);
+    if (pm) {
+      hipLaunchKernelGGL(tracegen::counts_to_field, dim3(div_up(pheight, 256)), dim3(256), 0, ctx->stream, pm->d, pheight);
+      LAUNCH_CHECK();
+    }
+    int bad = 0;
+    HIP_CHECK(hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, ctx->stream));
+    ctx->mark("trace generation");
+    ctx->end_timing(false);
+    if (bad) throw std::runtime_error("zkm_tracegen_cpu: an event's pc lies outside the program");
+  } catch (...) {
+    if (d_events) ctx->release(d_events);
+    if (d_program) ctx->release(d_program);
+    if (d_bad) ctx->release(d_bad);
+    if (m->d) ctx->release(m->d);
+    if (pm && pm->d) ctx->release(pm->d);
+    delete m;
+    delete pm;
+    throw;
+  }
+  ctx->release(d_events);
+  ctx->release(d_program);
+  ctx->release(d_bad);
+  *out = m;
+  if (pm) *program_mults_out = pm;
+  API_END
+}
+
+int zkm_tracegen_cpu(zkm_ctx* ctx, const zkm_cpu_event* events, size_t n_events, const zkm_instruction* program, size_t n_instr,
+                     uint32_t pc_base, uint32_t shard, int fixed_log2_rows, zkm_byte_lookups* blu, zkm_matrix** out) {
+  return zkm_tracegen_cpu_and_program(ctx, events, n_events, program, n_instr, pc_base, shard, fixed_log2_rows, -1, blu, out, nullptr);
+}
+
+int zkm_tracegen_program(zkm_ctx* ctx, const zkm_instruction* program, size_t n_instr, uint32_t pc_base, int fixed_log2_rows,
+                         zkm_matrix** out) {
+  API_BEGIN
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIP_CHECK(hipSetDevice(ctx->device));
+  if (n_instr && !program) throw std::runtime_error("zkm_tracegen_program: null program");
+  const size_t height = padded_trace_rows(n_instr, fixed_log2_rows, "zkm_tracegen_program");
+  ctx->begin_call();
+  zkm_matrix* m = new zkm_matrix();
+  m->h = height; m->w = tracegen::PROGRAM_PREP_WIDTH;
+  uint32_t* d_program = nullptr;
+  try {
+    m->d = ctx->alloc_n<uint32_t>(height * m->w);
+    d_program = (uint32_t*)ctx->alloc(std::max<size_t>(n_instr * sizeof(zkm_instruction), 4));
+    if (n_instr) HIP_CHECK(hipMemcpyAsync(d_program, program, n_instr * sizeof(zkm_instruction), hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(tracegen::program_rows, dim3(div_up(height, 256)), dim3(256), 0, ctx->stream, (const uint32_t*)d_program, n_instr,
+                       pc_base, height, m->d);
+    LAUNCH_CHECK();
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  } catch (...) {
+    if (d_program) ctx->release(d_program);
+    if (m->d) ctx->release(m->d);
+    delete m;
+    throw;
+  }
+  ctx->release(d_program);
+  *out = m;
+  API_END
+}
+
+int zkm_tracegen_program_mults(zkm_ctx* ctx, const zkm_cpu_event* events, size_t n_events, size_t n_instr, uint32_t pc_base,
+                               int fixed_log2_rows, zkm_matrix** out) {
+  API_BEGIN
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIP_CHECK(hipSetDevice(ctx->device));
+  if (n_events && !events) throw std::runtime_error("zkm_tracegen_program_mults: null events");
+  const size_t height = padded_trace_rows(n_instr, fixed_log2_rows, "zkm_tracegen_program_mults");
+  ctx->begin_call();
+  zkm_matrix* m = new zkm_matrix();
+  m->h = height; m->w = 1;
+  uint32_t* d_events = nullptr;
+  try {
+    m->d = ctx->alloc_n<uint32_t>(height);
+    HIP_CHECK(hipMemsetAsync(m->d, 0, height * 4, ctx->stream));
+    d_events = (uint32_t*)ctx->alloc(std::max<size_t>(n_events * sizeof(zkm_cpu_event), 4));
+    if (n_events) {
+      HIP_CHECK(hipMemcpyAsync(d_events, events, n_events * sizeof(zkm_cpu_event), hipMemcpyHostToDevice, ctx->stream));
+      hipLaunchKernelGGL(tracegen::program_count, dim3(div_up(n_events, 256)), dim3(256), 0, ctx->stream, (const uint32_t*)d_events, n_events,
+                         n_instr, pc_base, m->d);
+      LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(tracegen::counts_to_field, dim3(div_up(height, 256)), dim3(256), 0, ctx->stream, m->d, height);
+    LAUNCH_CHECK();
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  } catch (...) {
+    if (d_events) ctx->release(d_events);
+    if (m->d) ctx->release(m->d);
+    delete m;
+    throw;
+  }
+  ctx->release(d_events);
+  *out = m;
+  API_END
+}
+
+int zkm_tracegen_memory_local(zkm_ctx* ctx, const zkm_memory_local_event* events, size_t n_events, int fixed_log2_rows, zkm_matrix** out) {
+  API_BEGIN
+  static_assert(sizeof(zkm_memory_local_event) == 28, "event records mirror the #[repr(C)] executor structs");
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIP_CHECK(hipSetDevice(ctx->device));
+  if (n_events && !events) throw std::runtime_error("zkm_tracegen_memory_local: null events");
+  const size_t height = padded_trace_rows(div_up(n_events, (size_t)tracegen::MEMORY_LOCAL_ENTRIES), fixed_log2_rows, "zkm_tracegen_memory_local");
+  ctx->begin_call();
+  zkm_matrix* m = new zkm_matrix();
+  m->h = height; m->w = tracegen::MEMORY_LOCAL_WIDTH;
+  uint32_t* d_events = nullptr;
+  try {
+    m->d = ctx->alloc_n<uint32_t>(height * m->w);
+    d_events = (uint32_t*)ctx->alloc(std::max<size_t>(n_events * sizeof(zkm_memory_local_event), 4));
+    if (n_events) HIP_CHECK(hipMemcpyAsync(d_events, events, n_events * sizeof(zkm_memory_local_event), hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(tracegen::memory_local_rows, dim3(div_up(height * tracegen::MEMORY_LOCAL_ENTRIES, (size_t)256)), dim3(256), 0, ctx->stream,
+                       (const uint32_t*)d_events, n_events, height, m->d);
+    LAUNCH_CHECK();
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  } catch (...) {
+    if (d_events) ctx->release(d_events);
+    if (m->d) ctx->release(m->d);
+    delete m;
+    throw;
+  }
+  ctx->release(d_events);
+  *out = m;
+  API_END
+}
+
+int zkm_tracegen_global(zkm_ctx* ctx, const zkm_global_lookup_event* events, size_t n_events, int fixed_log2_rows, zkm_byte_lookups* blu,
+                        zkm_matrix** out) {
+  API_BEGIN
+  static_assert(sizeof(zkm_global_lookup_event) == 32, "event records mirror the #[repr(C)] executor structs");
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIP_CHECK(hipSetDevice(ctx->device));
+  if (n_events && !events) throw std::runtime_error("zkm_tracegen_global: null events");
+  if (!blu) throw std::runtime_error("zkm_tracegen_global: null byte lookups");
+  for (size_t i = 0; i < n_events; i++)
+    if (events[i].message[0] >> 16) throw std::runtime_error("zkm_tracegen_global: message[0] of event " + std::to_string(i) + " is not a u16");
+  const size_t height = padded_trace_rows(n_events, fixed_log2_rows, "zkm_tracegen_global");
+  ctx->begin_timing();
+  zkm_matrix* m = new zkm_matrix();
+  m->h = height; m->w = tracegen::GLOBAL_WIDTH;
+  uint32_t* d_events = nullptr;
+  uint32_t* d_err = nullptr;
+  std::vector<uint32_t*> levels;     // scan buffers: the points behind the start digest, then the chunk sums of each level
+  std::vector<size_t> sizes;
+  try {
+    m->d = ctx->alloc_n<uint32_t>(height * m->w);
+    d_events = (uint32_t*)ctx->alloc(std::max<size_t>(n_events * sizeof(zkm_global_lookup_event), 4));
+    d_err = ctx->alloc_n<uint32_t>(1);
+    HIP_CHECK(hipMemsetAsync(d_err, 0, 4, ctx->stream));
+    if (n_events) HIP_CHECK(hipMemcpyAsync(d_events, events, n_events * sizeof(zkm_global_lookup_event), hipMemcpyHostToDevice, ctx->stream));
+    for (size_t n = n_events + 1;; n = div_up(n, (size_t)tracegen::SCAN_CHUNK)) {
+      levels.push_back(ctx->alloc_n<uint32_t>(n * tracegen::POINT_WORDS));
+      sizes.push_back(n);
+      if (n <= (size_t)tracegen::SCAN_BLOCK) break;
+    }
+    const double bytes = 32.0 * n_events + 4.0 * height * tracegen::GLOBAL_WIDTH;
+    KLAUNCH(ctx, "tracegen_global_points", bytes, tracegen::global_point_rows, dim3(div_up(height, (size_t)256)), dim3(256), 0,
+            (const uint32_t*)d_events, n_events, height, m->d, levels[0], blu->counts, d_err);
+    for (size_t l = 0; l + 1 < levels.size(); l++)
+      KLAUNCH(ctx, "tracegen_global_scan", 64.0 * sizes[l], tracegen::global_scan_reduce, dim3(div_up(sizes[l + 1], (size_t)64)), dim3(64), 0,
+              (const uint32_t*)levels[l], sizes[l], levels[l + 1], sizes[l + 1]);
+    KLAUNCH(ctx, "tracegen_global_scan", 128.0 * sizes.back(), tracegen::global_scan_block, dim3(1), dim3(tracegen::SCAN_BLOCK), 0, levels.back(),
+            sizes.back());
+    for (size_t l = levels.size() - 1; l-- > 0;)
+      KLAUNCH(ctx, "tracegen_global_scan", 128.0 * sizes[l], tracegen::global_scan_apply, dim3(div_up(sizes[l + 1], (size_t)64)), dim3(64), 0, levels[l],
+              sizes[l], (const uint32_t*)levels[l + 1], sizes[l + 1]);
+    KLAUNCH(ctx, "tracegen_global_accum", bytes, tracegen::global_accum_rows, dim3(div_up(height, (size_t)256)), dim3(256), 0,
+            (const uint32_t*)levels[0], n_events, height, m->d, d_err);
+    uint32_t err = 0;
+    HIP_CHECK(hipMemcpyAsync(&err, d_err, 4, hipMemcpyDeviceToHost, ctx->stream));
+    ctx->mark("trace generation");
+    ctx->end_timing(false);
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (err & tracegen::GLOBAL_ERR_NO_POINT) throw std::runtime_error("zkm_tracegen_global: a message has no curve point within 256 offsets");
+    if (err & tracegen::GLOBAL_ERR_INFINITY) throw std::runtime_error("zkm_tracegen_global: the running sum reached the point at infinity");
+    if (err & tracegen::GLOBAL_ERR_EQUAL_X) throw std::runtime_error("zkm_tracegen_global: a message's point has the running sum's x-coordinate");
+  } catch (...) {
+    for (uint32_t* p : levels) ctx->release(p);
+    if (d_err) ctx->release(d_err);
+    if (d_events) ctx->release(d_events);
+    if (m->d) ctx->release(m->d);
+    delete m;
+    throw;
+  }
+  for (uint32_t* p : levels) ctx->release(p);
+  ctx->release(d_err);
+  ctx->release(d_events);
+  *out = m;
+  API_END
+}
+
+int zkm_tracegen_poseidon2_wide(zkm_ctx* ctx, const uint32_t* events, size_t n_events, int fixed_log2_rows, zkm_matrix** out) {
+  API_BEGIN
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIP_CHECK(hipSetDevice(ctx->device));
+  if (n_events && !events) throw std::runtime_error("zkm_tracegen_poseidon2_wide: null events");
+  const size_t height = padded_trace_rows(n_events, fixed_log2_rows, "zkm_tracegen_poseidon2_wide");
+  ctx->begin_timing();
+  zkm_matrix* m = new zkm_matrix();
+  m->h = height; m->w = tracegen::POSEIDON2_WIDE_WIDTH;
+  uint32_t* d_events = nullptr;
+  try {
+    m->d = ctx->alloc_n<uint32_t>(height * m->w);
+    d_events = (uint32_t*)ctx->alloc(std::max<size_t>(n_events * 128, 4));
+    if (n_events) HIP_CHECK(hipMemcpyAsync(d_events, events, n_events * 128, hipMemcpyHostToDevice, ctx->stream));
+    KLAUNCH(ctx, "tracegen_poseidon2_wide", 128.0 * n_events + 4.0 * height * tracegen::POSEIDON2_WIDE_WIDTH, tracegen::poseidon2_wide_rows,
+            dim3(div_up(height, (size_t)tracegen::THREADS)), dim3(tracegen::THREADS), 0, (const uint32_t*)d_events, n_events, height, m->d);
+    ctx->mark("trace generation");
+    ctx->end_timing(false);
+  } catch (...) {
+    if (d_events) ctx->release(d_events);
+    if (m->d) ctx->release(m->d);
+    delete m;
+    throw;
+  }
+  ctx->release(d_events);
+  *out = m;
+  API_END
+}
+
+int zkm_tracegen_syscall(zkm_ctx* ctx, const zkm_syscall_event* events, size_t n_events, int precompile, int fixed_log2_rows, zkm_byte_lookups* blu,
+                         zkm_matrix** out) {
+  if (precompile) return tracegen_events(ctx, tracegen::SYSCALL_PRECOMPILE, events, n_events, fixed_log2_rows, blu, out);
+  // SyscallCore keeps the events whose code has the send-to-table byte set or names a Linux syscall (syscall/chip.rs:252-259)
+  std::vector<zkm_syscall_event> kept;
+  if (events)
+    for (size_t i = 0; i < n_events; i++) {
+      const uint32_t code = events[i].a_record.prev_value;
+      if (((code >> 16) & 0xff) == 1 || ((code >> 8) & 0xff) != 0) kept.push_back(events[i]);
+    }
+  return tracegen_events(ctx, tracegen::SYSCALL_CORE, n_events ? (events ? (const void*)kept.data() : nullptr) : nullptr, events ? kept.size() : n_events,
+                         fixed_log2_rows, blu, out);
+}
+
+int zkm_tracegen_memory_global(zkm_ctx* ctx, const zkm_memory_init_finalize_event* events, size_t n_events, uint32_t previous_addr, int fixed_log2_rows,
+                               zkm_matrix** out) {
+  API_BEGIN
+  static_assert(sizeof(zkm_memory_init_finalize_event) == 16, "event records mirror the #[repr(C)] executor structs");
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIP_CHECK(hipSetDevice(ctx->device));
+  if (n_events && !events) throw std::runtime_error("zkm_tracegen_memory_global: null events");
+  const size_t height = padded_trace_rows(n_events, fixed_log2_rows, "zkm_tracegen_memory_global");
+  // generate_trace sorts the events by address first (memory/global.rs:131)
+  std::vector<zkm_memory_init_finalize_event> sorted(events, events + n_events);
+  std::stable_sort(sorted.begin(), sorted.end(), [](const zkm_memory_init_finalize_event& a, const zkm_memory_init_finalize_event& b) { return a.addr < b.addr; });
+  ctx->begin_timing();
+  zkm_matrix* m = new zkm_matrix();
+  m->h = height; m->w = tracegen::MEMORY_GLOBAL_WIDTH;
+  uint32_t* d_events = nullptr;
+  int* d_bad = nullptr;
+  try {
+    m->d = ctx->alloc_n<uint32_t>(height * m->w);
+    d_events = (uint32_t*)ctx->alloc(std::max<size_t>(n_events * 16, 4));
+    d_bad = (int*)ctx->alloc(4);
+    HIP_CHECK(hipMemsetAsync(d_bad, 0, 4, ctx->stream));
+    if (n_events) HIP_CHECK(hipMemcpyAsync(d_events, sorted.data(), n_events * 16, hipMemcpyHostToDevice, ctx->stream));
+    KLAUNCH(ctx, "tracegen_memory_global", 16.0 * n_events + 4.0 * height * m->w, tracegen::memory_global_rows, dim3(div_up(height, (size_t)tracegen::THREADS)),
+            dim3(tracegen::THREADS), 0, (const uint32_t*)d_events, n_events, previous_addr, height, m->d, d_bad);
+    int bad = 0;
+    HIP_CHECK(hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, ctx->stream));
+    ctx->mark("trace generation");
+    ctx->end_timing(false);
+    if (bad) throw std::runtime_error("zkm_tracegen_memory_global: addresses are not strictly increasing (from the previous shard's last address on)");
+  } catch (...) {
+    if (d_events) ctx->release(d_events);
+    if (d_bad) ctx->release(d_bad);
+    if (m->d) ctx->release(m->d);
+    delete m;
+    throw;
+  }
+  ctx->release(d_events);
+  ctx->release(d_bad);
+  *out = m;
+  API_END
+}
+
+int zkm_tracegen_poseidon2_permute(zkm_ctx* ctx, const zkm_poseidon2_permute_event* events, size_t n_events, int fixed_log2_rows, zkm_byte_lookups* blu,
+                                   zkm_matrix** out) {
+  API_BEGIN
+  static_assert(sizeof(zkm_poseidon2_permute_event) == 4 * tracegen::POSEIDON2_PERMUTE_EVENT_WORDS, "flattened Poseidon2PermuteEvent is 99 words");
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIP_CHECK(hipSetDevice(ctx->device));
+  if (n_events && !events) throw std::runtime_error("zkm_tracegen_poseidon2_permute: null events");
+  const size_t height = padded_trace_rows(n_events, fixed_log2_rows, "zkm_tracegen_poseidon2_permute");
+  ctx->begin_timing();
+  zkm_matrix* m = new zkm_matrix();
+  m->h = height; m->w = tracegen::POSEIDON2_PERMUTE_WIDTH;
+  uint32_t* d_events = nullptr;
+  int* d_bad = nullptr;
+  try {
+    m->d = ctx->alloc_n<uint32_t>(height * m->w);
+    const size_t ev_bytes = n_events * sizeof(zkm_poseidon2_permute_event);
+    d_events = (uint32_t*)ctx->alloc(std::max<size_t>(ev_bytes, 4));
+    d_bad = (int*)ctx->alloc(4);
+    HIP_CHECK(hipMemsetAsync(d_bad, 0, 4, ctx->stream));
+    if (n_events) HIP_CHECK(hipMemcpyAsync(d_events, events, ev_bytes, hipMemcpyHostToDevice, ctx->stream));
+    uint32_t* counts = blu ? blu->counts : nullptr;
+    KLAUNCH(ctx, "tracegen_poseidon2_permute", (double)ev_bytes + 4.0 * height * m->w, tracegen::poseidon2_permute_rows,
+            dim3(div_up(height, (size_t)tracegen::THREADS)), dim3(tracegen::THREADS), counts ? 2 * tracegen::HASH_SLOTS * sizeof(uint32_t) : 0,
+            (const uint32_t*)d_events, n_events, height, m->d, counts, d_bad);
+    int bad = 0;
+    HIP_CHECK(hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, ctx->stream));
+    ctx->mark("trace generation");
+    ctx->end_timing(false);
+    if (bad) throw std::runtime_error("zkm_tracegen_poseidon2_permute: a state word is not a field element, or the post-state is not the permutation of the pre-state");
+  } catch (...) {
+    if (d_events) ctx->release(d_events);
+    if (d_bad) ctx->release(d_bad);
+    if (m->d) ctx->release(m->d);
+    delete m;
+    throw;
+  }
+  ctx->release(d_events);
+  ctx->release(d_bad);
+  *out = m;
+  API_END
+}
+
+int zkm_tracegen_exp_reverse_bits(zkm_ctx* ctx, const uint32_t* bases, const uint32_t* bits, const uint32_t* offsets, size_t n_events,
+                                  int fixed_log2_rows, zkm_matrix** out) {
+  API_BEGIN
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIP_CHECK(hipSetDevice(ctx->device));
+  if (n_events && (!bases || !bits || !offsets)) throw std::runtime_error("zkm_tracegen_exp_reverse_bits: null events");
+  const size_t rows = n_events ? offsets[n_events] : 0;
+  for (size_t e = 0; e < n_events; e++)
+    if (offsets[e + 1] < offsets[e]) throw std::runtime_error("zkm_tracegen_exp_reverse_bits: offsets must not decrease");
+  const size_t height = padded_trace_rows(rows, fixed_log2_rows, "zkm_tracegen_exp_reverse_bits");
+  ctx->begin_call();
+  zkm_matrix* m = new zkm_matrix();
+  m->h = height; m->w = tracegen::EXP_REVERSE_BITS_WIDTH;
+  uint32_t *d_bases = nullptr, *d_bits = nullptr, *d_off = nullptr;
+  try {
+    m->d = ctx->alloc_n<uint32_t>(height * m->w);
+    HIP_CHECK(hipMemsetAsync(m->d, 0, height * m->w * 4, ctx->stream));
+    d_bases = ctx->alloc_n<uint32_t>(std::max<size_t>(n_events, 1));
+    d_bits = ctx->alloc_n<uint32_t>(std::max<size_t>(rows, 1));
+    d_off = ctx->alloc_n<uint32_t>(n_events + 1);
+    if (n_events) {
+      HIP_CHECK(hipMemcpyAsync(d_bases, bases, n_events * 4, hipMemcpyHostToDevice, ctx->stream));
+      if (rows) HIP_CHECK(hipMemcpyAsync(d_bits, bits, rows * 4, hipMemcpyHostToDevice, ctx->stream));
+      HIP_CHECK(hipMemcpyAsync(d_off, offsets, (n_events + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+      hipLaunchKernelGGL(tracegen::exp_reverse_bits_rows, dim3(div_up(n_events, (size_t)256)), dim3(256), 0, ctx->stream, (const uint32_t*)d_bases,
+                         (const uint32_t*)d_bits, (const uint32_t*)d_off, n_events, height, m->d);
+      LAUNCH_CHECK();
+    }
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  } catch (...) {
+    for (uint32_t* p : {d_bases, d_bits, d_off, m->d})
+      if (p) ctx->release(p);
+    delete m;
+    throw;
+  }
+  ctx->release(d_bases);
+  ctx->release(d_bits);
+  ctx->release(d_off);
+  *out = m;
+  API_END
+}
+
+int zkm_tracegen_poseidon2_skinny(zkm_ctx* ctx, const uint32_t* events, size_t n_events, int fixed_log2_rows, zkm_matrix** out) {
+  API_BEGIN
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIP_CHECK(hipSetDevice(ctx->device));
+  if (n_events && !events) throw std::runtime_error("zkm_tracegen_poseidon2_skinny: null events");
+  const size_t height = padded_trace_rows(n_events * tracegen::SKINNY_ROWS, fixed_log2_rows, "zkm_tracegen_poseidon2_skinny");
+  ctx->begin_timing();
+  zkm_matrix* m = new zkm_matrix();
+  m->h = height; m->w = tracegen::SKINNY_WIDTH;
+  uint32_t* d_events = nullptr;
+  try {
+    m->d = ctx->alloc_n<uint32_t>(height * m->w);
+    HIP_CHECK(hipMemsetAsync(m->d, 0, height * m->w * 4, ctx->stream));
+    d_events = (uint32_t*)ctx->alloc(std::max<size_t>(n_events * 128, 4));
+    if (n_events) {
+      HIP_CHECK(hipMemcpyAsync(d_events, events, n_events * 128, hipMemcpyHostToDevice, ctx->stream));
+      KLAUNCH(ctx, "tracegen_poseidon2_skinny", 128.0 * n_events + 4.0 * n_events * tracegen::SKINNY_ROWS * tracegen::SKINNY_WIDTH,
+              tracegen::poseidon2_skinny_rows, dim3(div_up(n_events, (size_t)tracegen::THREADS)), dim3(tracegen::THREADS), 0,
+              (const uint32_t*)d_events, n_events, height, m->d);
+    }
+    ctx->mark("trace generation");
+    ctx->end_timing(false);
+  } catch (...) {
+    if (d_events) ctx->release(d_events);
+    if (m->d) ctx->release(m->d);
+    delete m;
+    throw;
+  }
+  ctx->release(d_events);
+  *out = m;
+  API_END
+}
+
+int zkm_tracegen_byte_table(zkm_ctx* ctx, zkm_matrix** out) {
+  API_BEGIN
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIP_CHECK(hipSetDevice(ctx->device));
+  ctx->begin_call();
+  zkm_matrix* m = new zkm_matrix();
+  m->h = tracegen::BYTE_ROWS; m->w = tracegen::BYTE_PREP_COLS;
+  try {
+    m->d = ctx->alloc_n<uint32_t>(m->h * m->w);
+    hipLaunchKernelGGL(tracegen::byte_table, dim3(tracegen::BYTE_ROWS / 256), dim3(256), 0, ctx->stream, m->d);
+    LAUNCH_CHECK();
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  } catch (...) {
+    if (m->d) ctx->release(m->d);
+    delete m;
+    throw;
+  }
+  *out = m;
+  API_END
+}
+
+int zkm_byte_lookups_create(zkm_ctx* ctx, zkm_byte_lookups** out) {
+  API_BEGIN
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIP_CHECK(hipSetDevice(ctx->device));
+  const size_t cells = (size_t)tracegen::BYTE_ROWS * tracegen::NUM_BYTE_OPS;
+  zkm_byte_lookups* b = new zkm_byte_lookups();
+  try {
+    b->counts = ctx->alloc_n<uint32_t>(cells);
+    HIP_CHECK(hipMemsetAsync(b->counts, 0, cells * 4, ctx->stream));
+  } catch (...) {
+    delete b;
+    throw;
+  }
+  *out = b;
+  API_END
+}
+void zkm_byte_lookups_free(zkm_ctx* ctx, zkm_byte_lookups* b) {
+  if (!b) return;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  ctx->release(b->counts);
+  delete b;
+}
+
+int zkm_tracegen_byte_mults(zkm_ctx* ctx, const zkm_byte_lookups* blu, const uint32_t* extra_counts, zkm_matrix** out) {
+  API_BEGIN
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIP_CHECK(hipSetDevice(ctx->device));
+  if (!blu) throw std::runtime_error("zkm_tracegen_byte_mults: null byte lookups");
+  ctx->begin_timing();
+  const size_t cells = (size_t)tracegen::BYTE_ROWS * tracegen::NUM_BYTE_OPS;
+  zkm_matrix* m = new zkm_matrix();
+  m->h = tracegen::BYTE_ROWS; m->w = tracegen::NUM_BYTE_OPS;
+  uint32_t* d_extra = nullptr;
+  try {
+    m->d = ctx->alloc_n<uint32_t>(cells);
+    if (extra_counts) {
+      d_extra = (uint32_t*)ctx->alloc(cells * 4);
+      HIP_CHECK(hipMemcpyAsync(d_extra, extra_counts, cells * 4, hipMemcpyHostToDevice, ctx->stream));
+    }
+    hipLaunchKernelGGL(tracegen::byte_mults_finish, dim3(div_up(cells, 256)), dim3(256), 0, ctx->stream, (const uint32_t*)blu->counts,
+                       (const uint32_t*)d_extra, m->d, cells);
+    LAUNCH_CHECK();
+    ctx->mark("byte multiplicities");
+    ctx->end_timing(false);
+  } catch (...) {
+    if (d_extra) ctx->release(d_extra);
+    if (m->d) ctx->release(m->d);
+    delete m;
+    throw;
+  }
+  if (d_extra) ctx->release(d_extra);
+  *out = m;
+  API_END
+}
+

@@ -1,0 +1,283 @@
+// Part of libzkm_hip.so's host side (one translation unit: csrc/zkm_hip.hip includes this file). The context: error reporting, launch / timing macros, the host-side duplex challenger, the device memory pool and pinned staging ring, and the handle types of the C ABI.
+#pragma once
+static thread_local std::string g_err;
+
+#define HIP_CHECK(expr)                                                                          \
+  do {                                                                                           \
+    hipError_t _e = (expr);                                                                      \
+    if (_e != hipSuccess)                                                                        \
+      throw std::runtime_error(std::string(#expr) + ": " + hipGetErrorString(_e) + " (" + __FILE__ + ":" + \
+                               std::to_string(__LINE__) + ")");                                  \
+  } while (0)
+#define LAUNCH_CHECK() HIP_CHECK(hipGetLastError())
+// launch on the context's stream, bracketed by HIP events; `bytes` = compulsory HBM bytes of this
+// launch (each input and output array counted once) for the roofline report.
+#define KLAUNCH(ctx, name, bytes, kernel, grid, block, lds, ...)                                        \
+  do {                                                                                                   \
+    if ((ctx)->kbegin(name, (double)(bytes))) {                                                          \
+      /* start/stop timestamps ride on the dispatch's own completion signal: no extra barrier packets */ \
+      hipExtLaunchKernelGGL(kernel, grid, block, lds, (ctx)->cur, (ctx)->krecs.back().start,             \
+                            (ctx)->krecs.back().stop, 0, __VA_ARGS__);                                   \
+    } else {                                                                                             \
+      hipLaunchKernelGGL(kernel, grid, block, lds, (ctx)->cur, __VA_ARGS__);                             \
+    }                                                                                                    \
+    LAUNCH_CHECK();                                                                                      \
+  } while (0)
+
+static inline int log2_strict(size_t n) {
+  int k = 0;
+  while (((size_t)1 << k) < n) k++;
+  if (((size_t)1 << k) != n) throw std::runtime_error("height is not a power of two");
+  return k;
+}
+static inline unsigned div_up(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }
+static inline uint64_t fnv1a(const uint32_t* w, size_t n) {
+  uint64_t h = 1469598103934665603ull;
+  const unsigned char* p = (const unsigned char*)w;
+  for (size_t i = 0; i < n * 4; i++) { h ^= p[i]; h *= 1099511628211ull; }
+  return h;
+}
+
+// ---- host transcript: DuplexChallenger<KoalaBear, Poseidon2, 16, 8> -----------------------------
+// crates/recursion/circuit/src/challenger.rs:90-114,201-233
+namespace chal {
+static void duplexing(zkm_challenger* c) {
+  for (uint32_t i = 0; i < c->num_inputs; i++) c->sponge_state[i] = c->input_buffer[i];
+  c->num_inputs = 0;
+  p2::permute_host(c->sponge_state);
+  for (int i = 0; i < 8; i++) c->output_buffer[i] = c->sponge_state[i];
+  c->num_outputs = 8;
+}
+static void observe(zkm_challenger* c, uint32_t v) {
+  c->num_outputs = 0;
+  c->input_buffer[c->num_inputs++] = v;
+  if (c->num_inputs == 8) duplexing(c);
+}
+static void observe_slice(zkm_challenger* c, const uint32_t* v, size_t n) {
+  for (size_t i = 0; i < n; i++) observe(c, v[i]);
+}
+static void observe_ext(zkm_challenger* c, const E4& e) { observe_slice(c, e.c, 4); }
+static uint32_t sample(zkm_challenger* c) {
+  if (c->num_inputs != 0 || c->num_outputs == 0) duplexing(c);
+  return c->output_buffer[--c->num_outputs];
+}
+static E4 sample_ext(zkm_challenger* c) {
+  E4 e;
+  for (int i = 0; i < 4; i++) e.c[i] = sample(c);
+  return e;
+}
+static uint32_t sample_bits(zkm_challenger* c, uint32_t bits) {
+  return kb::from_monty(sample(c)) & ((1u << bits) - 1);
+}
+}  // namespace chal
+
+// ---- context -----------------------------------------------------------------------------------
+struct zkm_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;   // main stream: phases, transcript round trips
+  hipStream_t stream2 = nullptr;  // side stream (kept for experiments: hashing a tree beside the LDEs did not pay)
+  // asynchronous uploads: DMA stream, transpose stream, two persistent staging slabs and their "free again" events
+  hipStream_t up_dma = nullptr, up_tr = nullptr;
+  uint32_t* up_stage[2] = {nullptr, nullptr};
+  hipEvent_t up_freed[2] = {nullptr, nullptr}, up_landed[2] = {nullptr, nullptr};
+  bool up_freed_set[2] = {false, false};
+  int up_next = 0;
+  static constexpr size_t UP_SLAB_BYTES = (size_t)32 << 20;
+  hipStream_t cur = nullptr;      // where KLAUNCH / upload / kernel-timing events go right now
+  std::mutex mu;
+  std::multimap<size_t, void*> free_list;  // caching allocator: exact-size reuse
+  std::map<void*, size_t> live;
+  std::map<int, uint32_t*> tw_fwd, tw_inv;  // stage-major twiddle tables (lde.cuh), per transform log-size
+  std::vector<std::pair<std::string, hipEvent_t>> marks;
+  std::vector<hipEvent_t> event_pool;
+  std::vector<std::string> timing_names;
+  std::vector<float> timing_ms;
+  // per-kernel HIP-event timing on this stream (bench.py's roofline leg reads it)
+  struct KRec { const char* name; double bytes; hipEvent_t start, stop; };
+  struct KStat { double ms = 0, bytes = 0; uint32_t calls = 0; };
+  std::vector<KRec> krecs;
+  std::map<std::string, KStat> kstats;
+  // 0: off; 1: every launch; 2 (default): only launches moving >= 256 KiB (the ~300 tiny launches of a proof
+  // are left untimed)
+  int kernel_timing = 2;
+  // per-chip specialised quotient kernels (ziren_amd/codegen.py), keyed by a hash of the program words
+  std::map<uint64_t, hipFunction_t> quotient_fns;
+  std::vector<hipModule_t> modules;
+  hipEvent_t get_event() {
+    hipEvent_t e;
+    if (!event_pool.empty()) { e = event_pool.back(); event_pool.pop_back(); }
+    else HIP_CHECK(hipEventCreate(&e));
+    return e;
+  }
+  // returns true when this launch is to be timed; the record then holds the two events to pass to the launch
+  bool kbegin(const char* name, double bytes) {
+    if (!(kernel_timing == 1 || (kernel_timing == 2 && bytes >= 262144.0))) return false;
+    KRec r{name, bytes, get_event(), get_event()};
+    krecs.push_back(r);
+    return true;
+  }
+
+  // pinned host ring: short-lived host data goes H2D (and small results come D2H) through it without
+  // a stream synchronisation; it is recycled at the start of every top-level call, when the stream is idle.
+  char* pin = nullptr;
+  size_t pin_cap = (size_t)32 << 20, pin_off = 0;
+  void* pin_alloc(size_t bytes) {
+    if (!pin) HIP_CHECK(hipHostMalloc((void**)&pin, pin_cap, hipHostMallocDefault));
+    size_t off = (pin_off + 63) & ~(size_t)63;
+    if (off + bytes > pin_cap) return nullptr;
+    pin_off = off + bytes;
+    return pin + off;
+  }
+  void begin_call() {
+    HIP_CHECK(hipStreamSynchronize(stream));
+    HIP_CHECK(hipStreamSynchronize(stream2));
+    cur = stream;
+    pin_off = 0;
+  }
+  // copy `bytes` of host data to a fresh device buffer; the source may die as soon as this returns
+  void* upload(const void* src, size_t bytes, std::vector<void*>* scratch) {
+    void* d = alloc(bytes);
+    if (scratch) scratch->push_back(d);
+    if (bytes == 0) return d;
+    void* h = pin_alloc(bytes);
+    if (h) {
+      memcpy(h, src, bytes);
+      HIP_CHECK(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, cur));
+    } else {
+      HIP_CHECK(hipMemcpyAsync(d, src, bytes, hipMemcpyHostToDevice, cur));
+      HIP_CHECK(hipStreamSynchronize(cur));
+    }
+    return d;
+  }
+  // asynchronous D2H into the pinned ring; valid after the next stream synchronisation
+  template <class T>
+  T* download_async(const T* dev, size_t count) {
+    T* h = (T*)pin_alloc(count * sizeof(T));
+    if (!h) throw std::runtime_error("pinned staging ring exhausted");
+    HIP_CHECK(hipMemcpyAsync(h, dev, count * sizeof(T), hipMemcpyDeviceToHost, stream));
+    return h;
+  }
+
+  void* alloc(size_t bytes) {
+    if (bytes == 0) bytes = 4;
+    bytes = (bytes + 255) & ~(size_t)255;
+    auto it = free_list.find(bytes);
+    void* p;
+    if (it != free_list.end()) {
+      p = it->second;
+      free_list.erase(it);
+    } else {
+      HIP_CHECK(hipMalloc(&p, bytes));
+    }
+    live[p] = bytes;
+    return p;
+  }
+  template <class T>
+  T* alloc_n(size_t n) { return (T*)alloc(n * sizeof(T)); }
+  // stream-ordered: buffers are only reused by later work on the same stream
+  void release(void* p) {
+    if (!p) return;
+    auto it = live.find(p);
+    if (it == live.end()) return;
+    free_list.insert({it->second, p});
+    live.erase(it);
+  }
+  void mark(const char* name) {
+    hipEvent_t e = get_event();
+    HIP_CHECK(hipEventRecord(e, stream));
+    marks.push_back({name, e});
+  }
+  void begin_timing() {
+    begin_call();
+    for (auto& m : marks) event_pool.push_back(m.second);
+    marks.clear();
+    for (auto& r : krecs) { event_pool.push_back(r.start); if (r.stop) event_pool.push_back(r.stop); }
+    krecs.clear();
+    mark("begin");
+  }
+  void end_timing(bool append) {
+    HIP_CHECK(hipStreamSynchronize(stream));
+    HIP_CHECK(hipStreamSynchronize(stream2));
+    if (!append) { timing_names.clear(); timing_ms.clear(); kstats.clear(); }
+    for (auto& r : krecs) {
+      float ms = 0;
+      if (r.stop) HIP_CHECK(hipEventElapsedTime(&ms, r.start, r.stop));
+      KStat& k = kstats[r.name];
+      k.ms += ms; k.bytes += r.bytes; k.calls++;
+    }
+    for (size_t i = 1; i < marks.size(); i++) {
+      float ms = 0;
+      HIP_CHECK(hipEventElapsedTime(&ms, marks[i - 1].second, marks[i].second));
+      timing_names.push_back(marks[i].first);
+      timing_ms.push_back(ms);
+    }
+  }
+  const uint32_t* twiddles(int log_size, bool inverse) {
+    auto& tab = inverse ? tw_inv : tw_fwd;
+    auto it = tab.find(log_size);
+    if (it != tab.end()) return it->second;
+    size_t count = (size_t)1 << log_size;  // stage-major table: n - 1 entries
+    uint32_t* d;
+    HIP_CHECK(hipMalloc(&d, count * 4));
+    uint32_t w = kb::two_adic_generator(log_size);
+    if (inverse) w = kb::inv(w);
+    if (log_size > 0) {
+      hipLaunchKernelGGL(lde::fill_stage_twiddles, dim3(div_up(count / 2, 256), log_size), dim3(256), 0, stream, d, w, log_size);
+      LAUNCH_CHECK();
+    }
+    tab[log_size] = d;
+    return d;
+  }
+};
+
+struct zkm_matrix {
+  uint32_t* d = nullptr;  // column-major: column c at d + c * h
+  size_t h = 0, w = 0;
+  bool owned = true;
+  hipEvent_t ready = nullptr;  // set by zkm_matrix_upload_async: fires when the matrix is complete in HBM
+};
+
+// make `stream` wait until an asynchronously uploaded matrix is complete (no-op for any other matrix)
+static inline void wait_ready(hipStream_t stream, const zkm_matrix& m) {
+  if (m.ready) HIP_CHECK(hipStreamWaitEvent(stream, m.ready, 0));
+}
+
+struct zkm_byte_lookups {
+  uint32_t* counts = nullptr;  // [NUM_BYTE_OPS][BYTE_ROWS] plain counters: record.byte_lookups on the device
+};
+
+struct Tree {
+  uint32_t* digests = nullptr;          // all layers, 8 words per digest
+  std::vector<size_t> layer_off;        // in digests
+  size_t max_height = 0;
+  int log_max = 0;
+  const uint32_t* node(int layer, size_t i) const { return digests + (layer_off[layer] + i) * 8; }
+};
+
+struct zkm_pcs_data {
+  std::vector<zkm_matrix> ldes;           // owned; bit-reversed rows, height = h << log_blowup
+  std::vector<const uint32_t*> evals;     // borrowed: the committed evaluations (column-major, natural order)
+  std::vector<size_t> eval_heights;
+  std::vector<uint32_t> domain_shifts;    // evals[i] live on domain_shifts[i] * H
+  std::vector<zkm_matrix> owned_evals;    // evaluations owned by this object (perm traces, quotient chunks)
+  Tree tree;
+  uint32_t root[8];
+  int log_blowup = 1;
+};
+
+struct zkm_pk {
+  std::vector<zkm_matrix> prep;  // borrowed device matrices
+  std::vector<uint32_t> local_only;
+  zkm_pcs_data* data = nullptr;
+  uint32_t commit[8];
+  uint32_t pc_start;
+  uint32_t igcs[14];
+};
+
+struct zkm_main_data {
+  std::vector<size_t> order;             // sorted position -> caller index
+  std::vector<zkm_matrix> traces;        // borrowed, sorted order
+  zkm_pcs_data* data = nullptr;
+  std::vector<uint32_t> public_values;
+};
+

@@ -1,0 +1,671 @@
+// Part of libzkm_hip.so's host side (one translation unit: csrc/zkm_hip.hip includes this file). MachineProver::open (crates/stark/src/prover.rs:298-653): permutation traces, quotient, openings, FRI, queries, the proof stream.
+#pragma once
+static E4 host_pow2k(E4 a, int k) { return kb::epow2k(a, k); }
+
+// ---- proof stream writer ---------------------------------------------------------------------------
+struct Writer {
+  std::vector<uint32_t> w;
+  void u(uint32_t v) { w.push_back(v); }
+  void words(const uint32_t* p, size_t n) { w.insert(w.end(), p, p + n); }
+  void ext(const E4& e) { words(e.c, 4); }
+};
+
+// ---- open --------------------------------------------------------------------------------------
+struct RoundMat {
+  const uint32_t* evals; size_t n; size_t width; uint32_t shift;
+  const zkm_matrix* lde;
+  int n_points;  // 1 or 2
+  std::vector<E4> y[2];
+};
+struct Round { const zkm_pcs_data* data; std::vector<RoundMat> mats; };
+
+static const uint32_t SEPTIC_X[7] = {637514027, 1595065213, 1998064738, 72333738, 1211544370, 822986770, 1518535784};
+static const uint32_t SEPTIC_Y[7] = {1604177449, 90440090, 259343427, 140470264, 1162099742, 941559812, 1064053343};
+
+struct ChipMeta {
+  const zkm_chip_desc* desc;
+  int log_n;
+  size_t n;
+  int n_lookups, n_sends, perm_ext_w, max_values;
+};
+
+// Parse and validate a chip descriptor. The blobs are indices into device arrays: every column, register and
+// table index is checked here so that a malformed descriptor is an error code, never an out-of-bounds access
+// on the GPU.
+static ChipMeta chip_meta(const zkm_chip_desc* d, size_t n, size_t n_public_values) {
+  ChipMeta m;
+  m.desc = d; m.n = n; m.log_n = log2_strict(n);
+  m.n_lookups = m.n_sends = m.max_values = 0;
+  const std::string who = std::string(" (chip ") + (d->name ? d->name : "?") + ")";
+  if (d->log_quotient_degree > 3) throw std::runtime_error("log_quotient_degree > 3 unsupported" + who);
+  if (d->lookups_len) {
+    const uint32_t* w = d->lookups;
+    const size_t len = d->lookups_len;
+    size_t pos = 0;
+    auto need = [&](size_t k) { if (pos + k > len) throw std::runtime_error("lookup blob truncated" + who); };
+    need(2);
+    uint32_t ns = w[pos++], nr = w[pos++];
+    if ((uint64_t)ns + nr > 4096) throw std::runtime_error("too many lookups" + who);
+    m.n_sends = ns; m.n_lookups = ns + nr;
+    for (uint32_t i = 0; i < ns + nr; i++) {
+      need(2);
+      pos++;  // kind
+      uint32_t nv = w[pos++];
+      if (nv > 64) throw std::runtime_error("lookup with more than 64 values" + who);
+      m.max_values = std::max<int>(m.max_values, nv);
+      for (uint32_t v = 0; v <= nv; v++) {
+        need(2);
+        uint32_t nt = w[pos++];
+        if (w[pos++] >= kb::P) throw std::runtime_error("lookup constant not a field element" + who);
+        need(2 * (size_t)nt);
+        for (uint32_t t = 0; t < nt; t++) {
+          uint32_t cw = w[pos++], weight = w[pos++];
+          uint32_t col = cw & 0x7fffffffu;
+          if ((cw >> 31) ? col >= d->main_width : col >= d->prep_width) throw std::runtime_error("lookup column out of range" + who);
+          if (weight >= kb::P) throw std::runtime_error("lookup weight not a field element" + who);
+        }
+      }
+    }
+    if (pos != len) throw std::runtime_error("lookup blob length mismatch" + who);
+  }
+  int batch = 1 << d->log_quotient_degree;
+  m.perm_ext_w = m.n_lookups ? (m.n_lookups + batch - 1) / batch + 1 : 0;
+  if (d->program_len) {
+    if (d->program_len < 4 || d->program_len != 4 + 2 * (size_t)d->program[0]) throw std::runtime_error("program blob length mismatch" + who);
+    if (d->program[2] != d->num_constraints) throw std::runtime_error("program constraint count mismatch" + who);
+    const uint32_t ne = std::max<uint32_t>(d->program[1], 1), nb = std::max<uint32_t>(d->program[3], 1);
+    if (ne > 256 || nb > 256) throw std::runtime_error("program register count out of range" + who);
+    size_t asserts = 0;
+    for (uint32_t k = 0; k < d->program[0]; k++) {
+      uint32_t w0 = d->program[4 + 2 * k], imm = d->program[5 + 2 * k];
+      uint32_t op = w0 & 0xff, dst = (w0 >> 8) & 0xff, ra = (w0 >> 16) & 0xff, rb = w0 >> 24;
+      bool ok = true;
+      switch (op) {
+        case ZKM_OP_LD_MAIN: ok = dst < nb && ra < 2 && imm < d->main_width; break;
+        case ZKM_OP_LD_PREP: ok = dst < nb && ra < 2 && imm < d->prep_width; break;
+        case ZKM_OP_LD_PERM: ok = dst < ne && ra < 2 && imm < (uint32_t)m.perm_ext_w; break;
+        case ZKM_OP_LD_CONST: ok = dst < nb && imm < kb::P; break;
+        case ZKM_OP_LD_PV: ok = dst < nb && imm < n_public_values; break;
+        case ZKM_OP_LD_CHALLENGE: ok = dst < ne && imm < 2; break;
+        case ZKM_OP_LD_LOCAL_SUM: ok = dst < ne; break;
+        case ZKM_OP_LD_GLOBAL_SUM: ok = dst < nb && imm < 14; break;
+        case ZKM_OP_LD_IS_FIRST: case ZKM_OP_LD_IS_LAST: case ZKM_OP_LD_IS_TRANS: ok = dst < nb; break;
+        case ZKM_OP_ADD_B: case ZKM_OP_SUB_B: case ZKM_OP_MUL_B: ok = dst < nb && ra < nb && rb < nb; break;
+        case ZKM_OP_NEG_B: ok = dst < nb && ra < nb; break;
+        case ZKM_OP_ADD_E: case ZKM_OP_SUB_E: case ZKM_OP_MUL_E: ok = dst < ne && ra < ne && rb < ne; break;
+        case ZKM_OP_NEG_E: ok = dst < ne && ra < ne; break;
+        case ZKM_OP_ADD_EB: case ZKM_OP_SUB_EB: case ZKM_OP_MUL_EB: ok = dst < ne && ra < ne && rb < nb; break;
+        case ZKM_OP_ASSERT_B: ok = ra < nb; asserts++; break;
+        case ZKM_OP_ASSERT_E: ok = ra < ne; asserts++; break;
+        default: ok = false;
+      }
+      if (!ok) throw std::runtime_error("invalid instruction " + std::to_string(k) + " in constraint program" + who);
+    }
+    if (asserts != d->num_constraints) throw std::runtime_error("program asserts do not match num_constraints" + who);
+  } else if (d->num_constraints) {
+    throw std::runtime_error("num_constraints > 0 but no program" + who);
+  }
+  return m;
+}
+
+// One `open` call: the state that crosses Fiat-Shamir phases and one method per phase, in the order of prover.rs:298-653. Every device
+// buffer allocated on the way and not yet handed to an owner is in `loose` and goes back to the pool when the object dies (also on an
+// exception): a bad shard in a long-running farm must not leak HBM.
+struct ShardOpening {
+  struct Loose {
+    zkm_ctx* ctx;
+    std::vector<void*> v;
+    void disown(void* p) { v.erase(std::remove(v.begin(), v.end(), p), v.end()); }
+    ~Loose() { for (void* p : v) ctx->release(p); }
+  };
+  struct Guard { zkm_ctx* c; std::vector<zkm_pcs_data*> d; ~Guard() { for (auto p : d) free_pcs_data(c, p); } };
+
+  zkm_ctx* ctx;
+  const zkm_pk* pk;
+  zkm_main_data* md;
+  const zkm_fri_config* fri;
+  uint32_t num_pv_elts;
+  zkm_challenger* ch;
+  hipStream_t st;
+  const int bl;
+  const size_t nc;
+  std::vector<ChipMeta> chips;
+  Loose loose;
+  std::vector<void*>& scratch;
+  Guard guard;
+  // permutation phase
+  E4 perm_ch[2];
+  uint32_t* d_pv = nullptr;
+  std::vector<zkm_matrix> perm_traces;
+  std::vector<E4> local_sums;
+  std::vector<std::array<uint32_t, 14>> global_sums;
+  zkm_pcs_data* perm_data = nullptr;
+  // quotient phase
+  std::vector<zkm_matrix> qchunks;
+  std::vector<uint32_t> qshifts;
+  zkm_pcs_data* quot_data = nullptr;
+  E4 zeta;
+  // openings
+  std::vector<Round> rounds;
+  int log_max = 0;
+  std::vector<E4*> ro = std::vector<E4*>(32, nullptr);
+  // FRI
+  std::vector<E4*> layers;      // f_t on device
+  std::vector<Tree> ftrees;
+  std::vector<std::array<uint32_t, 8>> commits;
+  E4 final_poly;
+  uint32_t pow_witness = 0;
+  std::vector<size_t> indices;
+  const uint32_t* gathered = nullptr;
+  std::vector<uint32_t> gathered_big;
+
+  void* salloc(size_t bytes) { void* p = ctx->alloc(bytes); scratch.push_back(p); return p; }
+
+  ShardOpening(zkm_ctx* ctx_, const zkm_pk* pk_, zkm_main_data* md_, const zkm_chip_desc* chips_in, const zkm_fri_config* fri_, uint32_t num_pv_elts_,
+               zkm_challenger* ch_)
+      : ctx(ctx_), pk(pk_), md(md_), fri(fri_), num_pv_elts(num_pv_elts_), ch(ch_), st(ctx_->stream), bl((int)fri_->log_blowup), nc(md_->order.size()),
+        loose{ctx_, {}}, scratch(loose.v), guard{ctx_, {}} {
+  for (size_t i = 0; i < nc; i++) chips.push_back(chip_meta(&chips_in[md->order[i]], md->traces[i].h, md->public_values.size()));
+  for (size_t i = 0; i < nc; i++) {
+    if (chips[i].desc->main_width != md->traces[i].w) throw std::runtime_error("chip main_width does not match its trace");
+    if ((int)chips[i].desc->log_quotient_degree > bl) throw std::runtime_error("log_quotient_degree > log_blowup unsupported");
+    if (chips[i].desc->prep_index >= 0 && (!pk->data || (size_t)chips[i].desc->prep_index >= pk->prep.size()))
+      throw std::runtime_error("chip references a preprocessed trace the proving key does not hold");
+  }
+  // FRI parameters as the reference's configurations use them (kb31_poseidon2.rs:203-241: blow-up 1..3 bits, 28..84 queries, 16 PoW
+  // bits); anything outside a sane envelope is an error at the boundary, not an out-of-range shift further down
+  if (bl < 1 || bl > 4) throw std::runtime_error("fri.log_blowup out of range (1..4)");
+  if (fri->proof_of_work_bits > 30) throw std::runtime_error("fri.proof_of_work_bits out of range (0..30)");
+  if (fri->num_queries < 1 || fri->num_queries > 1024) throw std::runtime_error("fri.num_queries out of range (1..1024)");
+  if (num_pv_elts > md->public_values.size()) throw std::runtime_error("num_pv_elts exceeds public_values length");
+  // --- transcript prelude (prover.rs:321-329)
+  chal::observe_slice(ch, md->public_values.data(), num_pv_elts);
+  chal::observe_slice(ch, md->data->root, 8);
+  perm_ch[0] = chal::sample_ext(ch);
+  perm_ch[1] = chal::sample_ext(ch);
+  d_pv = (uint32_t*)ctx->upload(md->public_values.data(), md->public_values.size() * 4, &scratch);
+  }
+
+  // --- permutation traces (prover.rs:337-365), their commitment, the cumulative sums into the transcript (:366-414)
+  void permutation_phase() {
+  perm_traces.assign(nc, zkm_matrix());
+  local_sums.assign(nc, kb::ezero());
+  global_sums.assign(nc, std::array<uint32_t, 14>());
+  std::vector<uint32_t*> d_blobs(nc, nullptr);
+  std::vector<const uint32_t*> sum_src;
+  uint32_t* h_sums = nullptr;
+  {
+    int maxv = 0;
+    for (auto& c : chips) maxv = std::max(maxv, c.max_values);
+    std::vector<E4> bp(maxv + 2);
+    bp[0] = kb::eone();
+    for (int i = 1; i < maxv + 2; i++) bp[i] = kb::emul(bp[i - 1], perm_ch[1]);
+    E4* d_bp = (E4*)ctx->upload(bp.data(), bp.size() * sizeof(E4), &scratch);
+    for (size_t i = 0; i < nc; i++) {
+      const ChipMeta& c = chips[i];
+      zkm_matrix& pt = perm_traces[i];
+      pt.h = c.n; pt.w = (size_t)c.perm_ext_w * 4;
+      pt.d = ctx->alloc_n<uint32_t>(std::max<size_t>(pt.h * pt.w, 1));
+      scratch.push_back(pt.d);   // until the permutation commitment owns it
+      if (c.perm_ext_w > 0) {
+        d_blobs[i] = (uint32_t*)ctx->upload(c.desc->lookups, c.desc->lookups_len * 4, &scratch);
+        const uint32_t* prep = c.desc->prep_index >= 0 ? pk->prep[c.desc->prep_index].d : nullptr;
+        KLAUNCH(ctx, "perm_rows", 4.0 * c.n * (c.desc->main_width + c.desc->prep_width + pt.w), stark::perm_rows,
+                dim3(div_up(c.n, stark::THREADS)), dim3(stark::THREADS), 0, (const uint32_t*)d_blobs[i], c.n_lookups, c.n_sends,
+                1 << c.desc->log_quotient_degree, (const uint32_t*)md->traces[i].d, prep, c.n, perm_ch[0], (const E4*)d_bp, pt.d,
+                c.perm_ext_w);
+        // inclusive scan of the last ext column (4 base columns)
+        uint32_t* last = pt.d + (size_t)(c.perm_ext_w - 1) * 4 * c.n;
+        size_t nchunks = (c.n + stark::SCAN_BLOCK - 1) / stark::SCAN_BLOCK;
+        uint32_t* totals = (uint32_t*)salloc(nchunks * 4 * 4);
+        KLAUNCH(ctx, "scan", 32.0 * c.n, stark::scan_chunks, dim3((unsigned)nchunks, 4), dim3(stark::THREADS), 0, last, c.n, totals,
+                nchunks);
+        if (nchunks > 1) {
+          KLAUNCH(ctx, "scan", 0.0, stark::scan_totals, dim3(4), dim3(stark::THREADS), 0, totals, nchunks);
+          KLAUNCH(ctx, "scan", 32.0 * c.n, stark::scan_add_offsets, dim3((unsigned)nchunks, 4), dim3(stark::THREADS), 0, last, c.n,
+                  (const uint32_t*)totals, nchunks);
+        }
+        for (int e = 0; e < 4; e++) sum_src.push_back(last + (size_t)e * c.n + (c.n - 1));
+      } else {
+        for (int e = 0; e < 4; e++) sum_src.push_back(nullptr);
+      }
+      if (c.desc->commit_scope_global) {
+        const zkm_matrix& m = md->traces[i];
+        for (int k = 0; k < 14; k++) sum_src.push_back(m.d + (m.w - 14 + k) * m.h + (m.h - 1));
+      } else {
+        for (int k = 0; k < 14; k++) sum_src.push_back(nullptr);
+      }
+    }
+    // one gather for every cumulative-sum word (18 per chip), read back after the commit's synchronisation
+    const uint32_t* d_zero = (const uint32_t*)ctx->upload("\0\0\0\0", 4, &scratch);
+    for (auto& p : sum_src) if (!p) p = d_zero;
+    const uint32_t** d_sum_src = (const uint32_t**)ctx->upload(sum_src.data(), sum_src.size() * sizeof(void*), &scratch);
+    uint32_t* d_sums = (uint32_t*)salloc(sum_src.size() * 4);
+    KLAUNCH(ctx, "gather_words", 0.0, open::gather_words, dim3(div_up(sum_src.size(), open::THREADS)), dim3(open::THREADS), 0,
+            (const uint32_t* const*)d_sum_src, sum_src.size(), d_sums);
+    h_sums = ctx->download_async(d_sums, sum_src.size());
+  }
+  ctx->mark("permutation traces");
+  perm_data = pcs_commit(ctx, perm_traces, {}, bl);  // synchronises: sums are on the host now
+  guard.d.push_back(perm_data);
+  perm_data->owned_evals = perm_traces;
+  for (auto& m : perm_traces) loose.disown(m.d);
+  ctx->mark("commit permutation");
+  for (size_t i = 0; i < nc; i++) {
+    for (int e = 0; e < 4; e++) local_sums[i].c[e] = h_sums[18 * i + e];
+    if (chips[i].desc->commit_scope_global) {
+      for (int k = 0; k < 14; k++) global_sums[i][k] = h_sums[18 * i + 4 + k];
+    } else {
+      for (int k = 0; k < 7; k++) { global_sums[i][k] = kb::to_monty(SEPTIC_X[k]); global_sums[i][7 + k] = kb::to_monty(SEPTIC_Y[k]); }
+    }
+  }
+  chal::observe_slice(ch, perm_data->root, 8);
+  for (size_t i = 0; i < nc; i++) {
+    chal::observe_ext(ch, local_sums[i]);
+    chal::observe_slice(ch, global_sums[i].data(), 14);
+  }
+  }
+
+  // --- quotient values and their commitment (prover.rs:416-498); ends with zeta
+  void quotient_phase() {
+  E4 alpha = chal::sample_ext(ch);
+  for (size_t i = 0; i < nc; i++) {
+    const ChipMeta& c = chips[i];
+    const zkm_chip_desc* d = c.desc;
+    int lqd = d->log_quotient_degree;
+    int lq = c.log_n + lqd;
+    size_t Q = (size_t)1 << lq;
+    size_t nchunks = (size_t)1 << lqd;
+    uint32_t* qbuf = ctx->alloc_n<uint32_t>(Q * 4);
+    scratch.push_back(qbuf);   // until the quotient commitment owns it
+    // alpha powers, reversed (prover.rs:453-456)
+    size_t C = d->num_constraints;
+    std::vector<E4> ap(std::max<size_t>(C, 1));
+    E4 p = kb::eone();
+    for (size_t k = 0; k < C; k++) { ap[C - 1 - k] = p; p = kb::emul(p, alpha); }
+    E4* d_ap = (E4*)ctx->upload(ap.data(), ap.size() * sizeof(E4), &scratch);
+    uint32_t consts[32] = {0};
+    for (int k = 0; k < 14; k++) consts[k] = global_sums[i][k];
+    uint32_t w_q = kb::two_adic_generator(lq);
+    // Z_H(3 w_Q^i) = 3^n * (w_Q^n)^i - 1 depends on i mod 2^lqd (zerofier_coset.rs:22-51)
+    uint32_t s_pow_n = kb::pow(kb::GEN, (uint64_t)c.n);
+    uint32_t wr = kb::two_adic_generator(lqd), wp = kb::ONE;
+    for (size_t k = 0; k < nchunks; k++) {
+      consts[16 + k] = kb::sub(kb::mul(s_pow_n, wp), kb::ONE);
+      consts[24 + k] = kb::inv(consts[16 + k]);
+      wp = kb::mul(wp, wr);
+    }
+    uint32_t* d_consts = (uint32_t*)ctx->upload(consts, sizeof consts, &scratch);
+    static const uint32_t empty_prog[4] = {0, 1, 0, 1};
+    uint32_t* d_prog = (uint32_t*)ctx->upload(d->program_len ? d->program : empty_prog, std::max<size_t>(d->program_len, 4) * 4, &scratch);
+    stark::QuotientArgs a;
+    a.program = d_prog + 4;
+    a.n_instr = d->program_len ? d->program[0] : 0;
+    a.n_regs = d->program_len ? d->program[1] : 1;
+    a.main_lde = md->data->ldes[i].d; a.main_stride = md->data->ldes[i].h;
+    a.prep_lde = d->prep_index >= 0 ? pk->data->ldes[d->prep_index].d : nullptr;
+    a.prep_stride = d->prep_index >= 0 ? pk->data->ldes[d->prep_index].h : 0;
+    a.perm_lde = perm_data->ldes[i].d; a.perm_stride = perm_data->ldes[i].h;
+    a.log_n = c.log_n; a.lqd = lqd;
+    a.alpha_pows = d_ap; a.public_values = d_pv;
+    a.perm_alpha = perm_ch[0]; a.perm_beta = perm_ch[1];
+    a.local_sum = local_sums[i];
+    a.consts = d_consts;
+    a.w_q = w_q; a.g_inv = kb::inv(kb::two_adic_generator(c.log_n));
+    a.out = qbuf;
+    a.n_base_regs = d->program_len ? std::max<uint32_t>(d->program[3], 1) : 1;
+    size_t per_thread = (size_t)a.n_regs * 16 + (size_t)a.n_base_regs * 4;
+    int bd = 256;
+    while (per_thread * bd > 64 * 1024 && bd > 64) bd >>= 1;
+    size_t lds = per_thread * bd;
+    if (lds > 160 * 1024) throw std::runtime_error(std::string("constraint program of chip ") + d->name + " needs too many registers");
+    double qbytes = 4.0 * Q * (d->main_width + d->prep_width + 4.0 * c.perm_ext_w) + 16.0 * Q;
+    auto fit = d->program_len ? ctx->quotient_fns.find(fnv1a(d->program, d->program_len)) : ctx->quotient_fns.end();
+    if (fit != ctx->quotient_fns.end()) {
+      // chip-specialised kernel: same arithmetic, values in VGPRs
+      size_t arg_size = sizeof(a);
+      void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &arg_size, HIP_LAUNCH_PARAM_END};
+      const bool timed = ctx->kbegin("quotient", qbytes);
+      HIP_CHECK(hipExtModuleLaunchKernel(fit->second, div_up(Q, 256) * 256, 1, 1, 256, 1, 1, 0, st, nullptr, config,
+                                         timed ? ctx->krecs.back().start : nullptr, timed ? ctx->krecs.back().stop : nullptr, 0));
+    } else {
+      KLAUNCH(ctx, "quotient", qbytes, stark::quotient_kernel, dim3(div_up(Q, bd)), dim3(bd), lds, a);
+    }
+    uint32_t wqp = kb::ONE;
+    for (size_t k = 0; k < nchunks; k++) {
+      zkm_matrix m; m.h = c.n; m.w = 4; m.d = qbuf + k * 4 * c.n; m.owned = (k == 0);
+      qchunks.push_back(m);
+      qshifts.push_back(kb::mul(kb::GEN, wqp));
+      wqp = kb::mul(wqp, w_q);
+    }
+  }
+  ctx->mark("quotient values");
+  quot_data = pcs_commit(ctx, qchunks, qshifts, bl);
+  for (auto& m : qchunks) if (m.owned) { quot_data->owned_evals.push_back(m); loose.disown(m.d); }
+  guard.d.push_back(quot_data);
+  ctx->mark("commit quotient");
+  chal::observe_slice(ch, quot_data->root, 8);
+  zeta = chal::sample_ext(ch);
+  }
+
+  // --- opening rounds (prover.rs:503-556): preprocessed, main, permutation, quotient; every column evaluated at zeta (and zeta g)
+  void opened_values() {
+  if (pk->data) {
+    Round r; r.data = pk->data;
+    for (size_t j = 0; j < pk->prep.size(); j++)
+      r.mats.push_back(RoundMat{pk->prep[j].d, pk->prep[j].h, pk->prep[j].w, kb::ONE, &pk->data->ldes[j], pk->local_only[j] ? 1 : 2, {}});
+    rounds.push_back(r);
+  }
+  {
+    Round r; r.data = md->data;
+    for (size_t i = 0; i < nc; i++)
+      r.mats.push_back(RoundMat{md->traces[i].d, md->traces[i].h, md->traces[i].w, kb::ONE, &md->data->ldes[i], chips[i].desc->local_only ? 1 : 2, {}});
+    rounds.push_back(r);
+    Round rp; rp.data = perm_data;
+    for (size_t i = 0; i < nc; i++)
+      rp.mats.push_back(RoundMat{perm_traces[i].d, perm_traces[i].h, perm_traces[i].w, kb::ONE, &perm_data->ldes[i], 2, {}});
+    rounds.push_back(rp);
+    Round rq; rq.data = quot_data;
+    for (size_t i = 0; i < qchunks.size(); i++)
+      rq.mats.push_back(RoundMat{qchunks[i].d, qchunks[i].h, 4, qshifts[i], &quot_data->ldes[i], 1, {}});
+    rounds.push_back(rq);
+  }
+  // (i) evaluate every column at zeta (and zeta * g): barycentric weights shared per (height, shift)
+  {
+    std::map<std::pair<size_t, uint32_t>, E4*> wcache;
+    size_t total_y = 0;
+    for (auto& r : rounds) for (auto& m : r.mats) total_y += m.width * 2;
+    E4* d_y = (E4*)salloc(std::max<size_t>(total_y, 1) * sizeof(E4));
+    size_t ypos = 0;
+    for (auto& r : rounds)
+      for (auto& m : r.mats) {
+        if (m.width == 0) continue;
+        auto key = std::make_pair(m.n, m.shift);
+        E4* wts;
+        auto it = wcache.find(key);
+        if (it == wcache.end()) {
+          int ln = log2_strict(m.n);
+          E4 u = kb::escale(zeta, kb::inv(m.shift));
+          E4 c = kb::escale(kb::esub_base(host_pow2k(u, ln), kb::ONE), kb::inv(kb::to_monty((uint32_t)(m.n % kb::P))));
+          wts = (E4*)salloc(m.n * sizeof(E4));
+          KLAUNCH(ctx, "bary_weights", 16.0 * m.n, open::bary_weights, dim3(div_up(div_up(m.n, 4), open::THREADS)), dim3(open::THREADS), 0, u, c,
+                  kb::two_adic_generator(ln), m.n, wts);
+          wcache[key] = wts;
+        } else wts = it->second;
+        unsigned groups = div_up(m.width, open::EVAL_COLS);
+        unsigned split = 1;
+        E4* partials;
+        double ebytes = 4.0 * m.n * m.width + 16.0 * m.n;
+        if (m.n >= 4 * open::THREADS) {
+          split = (unsigned)std::min<size_t>(std::max<size_t>(1, 3072 / groups), m.n / (4 * open::THREADS));
+          partials = (E4*)salloc((size_t)split * m.width * 2 * sizeof(E4));
+          if (m.n_points > 1)
+            KLAUNCH(ctx, "eval_columns", ebytes, open::eval_columns<true>, dim3(groups, split), dim3(open::THREADS), 0, m.evals, m.n,
+                    (int)m.width, (const E4*)wts, partials);
+          else
+            KLAUNCH(ctx, "eval_columns", ebytes, open::eval_columns<false>, dim3(groups, split), dim3(open::THREADS), 0, m.evals, m.n,
+                    (int)m.width, (const E4*)wts, partials);
+        } else {
+          partials = (E4*)salloc((size_t)m.width * 2 * sizeof(E4));
+          KLAUNCH(ctx, "eval_columns", ebytes, open::eval_columns_small, dim3(groups, 1), dim3(open::THREADS), 0, m.evals, m.n,
+                  (int)m.width, (const E4*)wts, m.n_points > 1 ? 1 : 0, partials);
+        }
+        KLAUNCH(ctx, "reduce_partials", 0.0, open::reduce_partials, dim3((unsigned)(m.width * 2)), dim3(64), 0, (const E4*)partials,
+                (int)split, (int)(m.width * 2), d_y + ypos);
+        ypos += m.width * 2;
+      }
+    const E4* hy = ctx->download_async(d_y, std::max<size_t>(total_y, 1));
+    HIP_CHECK(hipStreamSynchronize(st));
+    ypos = 0;
+    for (auto& r : rounds)
+      for (auto& m : r.mats) {
+        for (int pt = 0; pt < 2; pt++) m.y[pt].clear();
+        if (m.width == 0) continue;
+        for (int pt = 0; pt < m.n_points; pt++) {
+          m.y[pt].resize(m.width);
+          for (size_t c = 0; c < m.width; c++) m.y[pt][c] = hy[ypos + c * 2 + pt];
+        }
+        ypos += m.width * 2;
+      }
+  }
+  ctx->mark("open: evaluations");
+  }
+
+  // (ii) alpha — opened values are not observed (fri.rs:78) — and (iii) the reduced openings per LDE height (fri.rs:103-204)
+  void reduced_openings() {
+  E4 fa = chal::sample_ext(ch);
+  log_max = 0;
+  size_t max_width = 1;
+  for (auto& r : rounds) for (auto& m : r.mats) { log_max = std::max(log_max, log2_strict(m.lde->h)); max_width = std::max(max_width, m.width); }
+  std::vector<E4> fap(max_width + 1);
+  fap[0] = kb::eone();
+  for (size_t i = 1; i <= max_width; i++) fap[i] = kb::emul(fap[i - 1], fa);
+  E4* d_fap = (E4*)ctx->upload(fap.data(), fap.size() * sizeof(E4), &scratch);
+  {
+    std::vector<std::vector<open::ReduceMat>> per_h(32);
+    std::vector<E4> run(32, kb::eone());  // alpha^count per height
+    for (auto& r : rounds)
+      for (auto& m : r.mats) {
+        int lh = log2_strict(m.lde->h);
+        open::ReduceMat rm;
+        rm.lde = m.lde->d; rm.width = (int)m.width; rm.n_points = m.n_points;
+        for (int pt = 0; pt < 2; pt++) { rm.A[pt] = kb::ezero(); rm.Yc[pt] = kb::ezero(); }
+        for (int pt = 0; pt < m.n_points; pt++) {
+          E4 ysum = kb::ezero();
+          for (size_t c = 0; c < m.width; c++) ysum = kb::eadd(ysum, kb::emul(fap[c], m.y[pt][c]));
+          rm.A[pt] = run[lh];
+          rm.Yc[pt] = kb::emul(run[lh], ysum);
+          run[lh] = kb::emul(run[lh], fap[m.width]);
+        }
+        per_h[lh].push_back(rm);
+      }
+    for (int lh = 0; lh < 32; lh++) {
+      if (per_h[lh].empty()) continue;
+      size_t N = (size_t)1 << lh;
+      ro[lh] = (E4*)salloc(N * sizeof(E4));
+      open::ReduceMat* d_rm = (open::ReduceMat*)ctx->upload(per_h[lh].data(), per_h[lh].size() * sizeof(open::ReduceMat), &scratch);
+      E4 z1 = kb::escale(zeta, kb::two_adic_generator(lh - bl));
+      double rbytes = 16.0 * N;
+      for (auto& rm : per_h[lh]) rbytes += 4.0 * N * rm.width;
+      KLAUNCH(ctx, "reduce_openings", rbytes, open::reduce_openings, dim3(div_up(N, open::THREADS)), dim3(open::THREADS), 0,
+              (const open::ReduceMat*)d_rm, (int)per_h[lh].size(), lh, (const E4*)d_fap, zeta, z1, kb::two_adic_generator(lh), ro[lh],
+              0);
+    }
+  }
+  ctx->mark("open: reduced openings");
+  }
+
+  // (iv) FRI commit phase (fri.rs:257-358): per layer a tree over the pairs, its root into the transcript, beta out, fold
+  void fri_commit_phase() {
+  E4* f = ro[log_max];
+  int lf = log_max;
+  uint32_t neg_half = kb::neg(kb::inv(kb::to_monty(2)));
+  while (lf > bl) {
+    size_t len = (size_t)1 << lf, half = len / 2;
+    Tree t;
+    t.max_height = half; t.log_max = lf - 1;
+    size_t off = 0;
+    for (size_t l = half; l >= 1; l >>= 1) { t.layer_off.push_back(off); off += l; if (l == 1) break; }
+    t.digests = (uint32_t*)salloc(off * 8 * 4);
+    int fuse = 0;   // FRI trees have one matrix: the first levels are reduced inside the leaf kernel's blocks
+    if (half >= (size_t)merkle::FUSE_LEAVES) fuse = std::min(merkle::FUSE_MAX_LEVELS, lf - 1);
+    if (fuse > 0)
+      KLAUNCH(ctx, "hash_fri_leaves_tree", 32.0 * half + 32.0 * half * (2.0 - 1.0 / (1 << fuse)), merkle::hash_fri_leaves_tree,
+              dim3(half / merkle::FUSE_LEAVES), dim3(merkle::FUSE_LEAVES), merkle::FUSE_LEAVES * 12 * sizeof(uint32_t), (const E4*)f, half, t.digests, fuse);
+    else
+      KLAUNCH(ctx, "hash_fri_leaves", 64.0 * half, merkle::hash_fri_leaves, dim3(div_up(half, merkle::THREADS)), dim3(merkle::THREADS), 0,
+              (const E4*)f, half, t.digests);
+    int layer = fuse;
+    for (size_t l = half >> (fuse + 1); l >= 1; l >>= 1, layer++)
+      if (compress_small_layer(ctx, t, layer, l)) break;
+    std::array<uint32_t, 8> root;
+    const uint32_t* h_root = ctx->download_async(t.node(t.log_max, 0), 8);
+    HIP_CHECK(hipStreamSynchronize(st));
+    memcpy(root.data(), h_root, 32);
+    chal::observe_slice(ch, root.data(), 8);
+    commits.push_back(root);
+    E4 beta = chal::sample_ext(ch);
+    E4* g = (E4*)salloc(half * sizeof(E4));
+    KLAUNCH(ctx, "fri_fold", 48.0 * half + (ro[lf - 1] ? 16.0 * half : 0.0), open::fri_fold, dim3(div_up(half, open::THREADS)),
+            dim3(open::THREADS), 0, (const E4*)f, lf, beta, kb::esqr(beta), kb::two_adic_generator(lf),
+            kb::inv(kb::two_adic_generator(lf)), neg_half, (const E4*)ro[lf - 1], g);
+    layers.push_back(f);
+    ftrees.push_back(t);
+    f = g;
+    lf--;
+  }
+  const size_t nfin = (size_t)1 << lf;
+  const E4* fin = ctx->download_async((const E4*)f, nfin);
+  HIP_CHECK(hipStreamSynchronize(st));
+  for (size_t i = 1; i < nfin; i++)
+    if (!kb::eq(fin[i], fin[0])) throw std::runtime_error("FRI final polynomial is not constant (internal error)");
+  final_poly = fin[0];
+  chal::observe_ext(ch, final_poly);
+  ctx->mark("open: FRI commit phase");
+  }
+
+  // proof of work: the smallest canonical witness
+  void grind() {
+  {
+    uint32_t* d_state = (uint32_t*)ctx->upload(ch->sponge_state, 64, &scratch);
+    uint32_t* d_in = (uint32_t*)ctx->upload(ch->input_buffer, 64, &scratch);
+    unsigned int* d_best = (unsigned int*)salloc(4);
+    uint32_t base = 0, found = 0xffffffffu;
+    const uint32_t BATCH = 1u << 20;
+    while (base < kb::P) {
+      HIP_CHECK(hipMemsetAsync(d_best, 0xff, 4, st));
+      uint32_t total = std::min<uint64_t>(BATCH, (uint64_t)kb::P - base);
+      KLAUNCH(ctx, "grind", 0.0, merkle::grind, dim3(div_up(total, merkle::THREADS)), dim3(merkle::THREADS), 0, (const uint32_t*)d_state,
+              (const uint32_t*)d_in, (int)ch->num_inputs, (int)fri->proof_of_work_bits, base, total, d_best);
+      const unsigned int* h_best = ctx->download_async((const unsigned int*)d_best, 1);
+      HIP_CHECK(hipStreamSynchronize(st));
+      found = *h_best;
+      if (found != 0xffffffffu) break;
+      base += total;
+    }
+    if (found == 0xffffffffu) throw std::runtime_error("proof-of-work search exhausted the field");
+    pow_witness = kb::to_monty(found);
+    chal::observe(ch, pow_witness);
+    if (chal::sample_bits(ch, fri->proof_of_work_bits) != 0) throw std::runtime_error("proof-of-work witness rejected by host transcript");
+  }
+  ctx->mark("open: grind");
+  }
+
+  // query indices out of the transcript; every word the queries open is fetched by one gather in serialisation order
+  void query_phase() {
+  indices.assign(fri->num_queries, 0);
+  for (auto& q : indices) q = chal::sample_bits(ch, log_max);
+  // one template entry per word of a query, in serialisation order (open::QueryWord): the positions depend on the index only through shifts
+  std::vector<open::QueryWord> tmpl;
+  for (auto& r : rounds) {
+    const Tree& t = r.data->tree;
+    const uint32_t tree_shift = (uint32_t)(log_max - t.log_max);
+    for (auto& m : r.mats) {
+      const uint32_t sh = tree_shift + (uint32_t)(t.log_max - log2_strict(m.lde->h));
+      for (size_t c = 0; c < m.width; c++) tmpl.push_back(open::QueryWord{m.lde->d + c * m.lde->h, sh, 0, 1, 0});
+    }
+    for (int l = 0; l < t.log_max; l++)
+      for (uint32_t k = 0; k < 8; k++) tmpl.push_back(open::QueryWord{t.node(l, 0), tree_shift + (uint32_t)l, 1, 8, k});
+  }
+  for (size_t tI = 0; tI < ftrees.size(); tI++) {
+    for (uint32_t k = 0; k < 4; k++) tmpl.push_back(open::QueryWord{(const uint32_t*)layers[tI], (uint32_t)tI, 1, 4, k});
+    const Tree& t = ftrees[tI];
+    for (int l = 0; l < t.log_max; l++)
+      for (uint32_t k = 0; k < 8; k++) tmpl.push_back(open::QueryWord{t.node(l, 0), (uint32_t)(tI + 1 + l), 1, 8, k});
+  }
+  const size_t per_query = tmpl.size(), n_gather = per_query * indices.size();
+  if (n_gather) {
+    std::vector<uint32_t> idx32(indices.begin(), indices.end());
+    const open::QueryWord* d_tmpl = (const open::QueryWord*)ctx->upload(tmpl.data(), tmpl.size() * sizeof(open::QueryWord), &scratch);
+    const uint32_t* d_idx = (const uint32_t*)ctx->upload(idx32.data(), idx32.size() * 4, &scratch);
+    uint32_t* d_dst = (uint32_t*)salloc(n_gather * 4);
+    hipLaunchKernelGGL(open::gather_queries, dim3(div_up(n_gather, open::THREADS)), dim3(open::THREADS), 0, st, d_tmpl, per_query, d_idx, indices.size(), d_dst);
+    LAUNCH_CHECK();
+    uint32_t* h = (uint32_t*)ctx->pin_alloc(n_gather * 4);      // through the pinned ring when it fits: no staged pageable copy
+    if (h) {
+      HIP_CHECK(hipMemcpyAsync(h, d_dst, n_gather * 4, hipMemcpyDeviceToHost, st));
+      gathered = h;
+    } else {
+      gathered_big.resize(n_gather);
+      HIP_CHECK(hipMemcpyAsync(gathered_big.data(), d_dst, n_gather * 4, hipMemcpyDeviceToHost, st));
+      gathered = gathered_big.data();
+    }
+    HIP_CHECK(hipStreamSynchronize(st));
+  }
+  ctx->mark("open: queries");
+  }
+
+  // --- serialise (INTEGRATION.md "ShardProof stream"; prover.rs:558-652)
+  void serialise(Writer& out) {
+  out.words(md->data->root, 8);
+  out.words(perm_data->root, 8);
+  out.words(quot_data->root, 8);
+  out.u((uint32_t)nc);
+  size_t ri = pk->data ? 1 : 0;
+  Round& rmain = rounds[ri];
+  Round& rperm = rounds[ri + 1];
+  Round& rquot = rounds[ri + 2];
+  size_t qpos = 0;
+  auto put_exts = [&](const std::vector<E4>& v) { for (auto& e : v) out.ext(e); };
+  for (size_t i = 0; i < nc; i++) {
+    const zkm_chip_desc* d = chips[i].desc;
+    out.u((uint32_t)md->order[i]);
+    out.u((uint32_t)chips[i].log_n);
+    if (d->prep_index >= 0) {
+      RoundMat& pm = rounds[0].mats[d->prep_index];
+      out.u((uint32_t)pm.width);
+      put_exts(pm.y[0]);
+      if (pm.n_points > 1) put_exts(pm.y[1]); else put_exts(std::vector<E4>(pm.width, kb::ezero()));
+    } else out.u(0);
+    RoundMat& mm = rmain.mats[i];
+    out.u((uint32_t)mm.width);
+    put_exts(mm.y[0]);
+    if (mm.n_points > 1) put_exts(mm.y[1]); else put_exts(std::vector<E4>(mm.width, kb::ezero()));
+    RoundMat& pm = rperm.mats[i];
+    out.u((uint32_t)pm.width);
+    put_exts(pm.y[0]); put_exts(pm.y[1]);
+    size_t nch = (size_t)1 << d->log_quotient_degree;
+    out.u((uint32_t)nch);
+    for (size_t k = 0; k < nch; k++) put_exts(rquot.mats[qpos++].y[0]);
+    out.words(global_sums[i].data(), 14);
+    out.ext(local_sums[i]);
+  }
+  out.u((uint32_t)commits.size());
+  for (auto& c : commits) out.words(c.data(), 8);
+  out.u((uint32_t)indices.size());
+  size_t gp = 0;
+  for (size_t qi = 0; qi < indices.size(); qi++) {
+    out.u((uint32_t)rounds.size());
+    for (auto& r : rounds) {
+      out.u((uint32_t)r.mats.size());
+      for (auto& m : r.mats) { out.u((uint32_t)m.width); out.words(gathered + gp, m.width); gp += m.width; }
+      out.u((uint32_t)r.data->tree.log_max);
+      out.words(gathered + gp, (size_t)r.data->tree.log_max * 8); gp += (size_t)r.data->tree.log_max * 8;
+    }
+    out.u((uint32_t)ftrees.size());
+    for (auto& t : ftrees) {
+      out.words(gathered + gp, 4); gp += 4;
+      out.u((uint32_t)t.log_max);
+      out.words(gathered + gp, (size_t)t.log_max * 8); gp += (size_t)t.log_max * 8;
+    }
+  }
+  out.ext(final_poly);
+  out.u(pow_witness);
+  out.u((uint32_t)md->public_values.size());
+  out.words(md->public_values.data(), md->public_values.size());
+  }
+};
+
+static void open_impl(zkm_ctx* ctx, const zkm_pk* pk, zkm_main_data* md, const zkm_chip_desc* chips_in, const zkm_fri_config* fri,
+                      uint32_t num_pv_elts, zkm_challenger* ch, Writer& out) {
+  ShardOpening o(ctx, pk, md, chips_in, fri, num_pv_elts, ch);
+  o.permutation_phase();
+  o.quotient_phase();
+  o.opened_values();
+  o.reduced_openings();
+  o.fri_commit_phase();
+  o.grind();
+  o.query_phase();
+  o.serialise(out);
+}
+

@@ -237,6 +237,24 @@ __global__ __launch_bounds__(THREADS) void fri_fold(const kb::E4* __restrict__ f
   g[j] = r;
 }
 
+// The query phase's gather (fri.rs:110-128, 279-306): every query reads the same *shape* of words — the opened row of every committed
+// matrix, the sibling digests up each input tree, the FRI sibling values and their paths — at positions that depend on the query index only
+// through shifts. One template entry per word of a query: the word is base[(((q >> shift) ^ flip) * step) + k]. The host uploads the
+// template once (a few thousand entries) instead of one pointer per word per query (84 x as many).
+struct QueryWord {
+  const uint32_t* base;
+  uint32_t shift, flip, step, k;
+};
+__global__ __launch_bounds__(THREADS) void gather_queries(const QueryWord* __restrict__ tmpl, size_t per_query, const uint32_t* __restrict__ indices,
+                                                          size_t n_queries, uint32_t* __restrict__ dst) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= per_query * n_queries) return;
+  const size_t qi = i / per_query;
+  const QueryWord w = tmpl[i - qi * per_query];
+  const size_t q = indices[qi];
+  dst[i] = w.base[(((q >> w.shift) ^ w.flip) * w.step) + w.k];
+}
+
 // dst[i] = *src[i]
 __global__ __launch_bounds__(THREADS) void gather_words(const uint32_t* const* __restrict__ src, size_t count, uint32_t* __restrict__ dst) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -33,1065 +33,9 @@
 
 using kb::E4;
 
-static thread_local std::string g_err;
-
-#define HIP_CHECK(expr)                                                                          \
-  do {                                                                                           \
-    hipError_t _e = (expr);                                                                      \
-    if (_e != hipSuccess)                                                                        \
-      throw std::runtime_error(std::string(#expr) + ": " + hipGetErrorString(_e) + " (" + __FILE__ + ":" + \
-                               std::to_string(__LINE__) + ")");                                  \
-  } while (0)
-#define LAUNCH_CHECK() HIP_CHECK(hipGetLastError())
-// launch on the context's stream, bracketed by HIP events; `bytes` = compulsory HBM bytes of this
-// launch (each input and output array counted once) for the roofline report.
-#define KLAUNCH(ctx, name, bytes, kernel, grid, block, lds, ...)                                        \
-  do {                                                                                                   \
-    if ((ctx)->kbegin(name, (double)(bytes))) {                                                          \
-      /* start/stop timestamps ride on the dispatch's own completion signal: no extra barrier packets */ \
-      hipExtLaunchKernelGGL(kernel, grid, block, lds, (ctx)->cur, (ctx)->krecs.back().start,             \
-                            (ctx)->krecs.back().stop, 0, __VA_ARGS__);                                   \
-    } else {                                                                                             \
-      hipLaunchKernelGGL(kernel, grid, block, lds, (ctx)->cur, __VA_ARGS__);                             \
-    }                                                                                                    \
-    LAUNCH_CHECK();                                                                                      \
-  } while (0)
-
-static inline int log2_strict(size_t n) {
-  int k = 0;
-  while (((size_t)1 << k) < n) k++;
-  if (((size_t)1 << k) != n) throw std::runtime_error("height is not a power of two");
-  return k;
-}
-static inline unsigned div_up(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }
-static inline uint64_t fnv1a(const uint32_t* w, size_t n) {
-  uint64_t h = 1469598103934665603ull;
-  const unsigned char* p = (const unsigned char*)w;
-  for (size_t i = 0; i < n * 4; i++) { h ^= p[i]; h *= 1099511628211ull; }
-  return h;
-}
-
-// ---- host transcript: DuplexChallenger<KoalaBear, Poseidon2, 16, 8> -----------------------------
-// crates/recursion/circuit/src/challenger.rs:90-114,201-233
-namespace chal {
-static void duplexing(zkm_challenger* c) {
-  for (uint32_t i = 0; i < c->num_inputs; i++) c->sponge_state[i] = c->input_buffer[i];
-  c->num_inputs = 0;
-  p2::permute_host(c->sponge_state);
-  for (int i = 0; i < 8; i++) c->output_buffer[i] = c->sponge_state[i];
-  c->num_outputs = 8;
-}
-static void observe(zkm_challenger* c, uint32_t v) {
-  c->num_outputs = 0;
-  c->input_buffer[c->num_inputs++] = v;
-  if (c->num_inputs == 8) duplexing(c);
-}
-static void observe_slice(zkm_challenger* c, const uint32_t* v, size_t n) {
-  for (size_t i = 0; i < n; i++) observe(c, v[i]);
-}
-static void observe_ext(zkm_challenger* c, const E4& e) { observe_slice(c, e.c, 4); }
-static uint32_t sample(zkm_challenger* c) {
-  if (c->num_inputs != 0 || c->num_outputs == 0) duplexing(c);
-  return c->output_buffer[--c->num_outputs];
-}
-static E4 sample_ext(zkm_challenger* c) {
-  E4 e;
-  for (int i = 0; i < 4; i++) e.c[i] = sample(c);
-  return e;
-}
-static uint32_t sample_bits(zkm_challenger* c, uint32_t bits) {
-  return kb::from_monty(sample(c)) & ((1u << bits) - 1);
-}
-}  // namespace chal
-
-// ---- context -----------------------------------------------------------------------------------
-struct zkm_ctx {
-  int device = 0;
-  hipStream_t stream = nullptr;   // main stream: phases, transcript round trips
-  hipStream_t stream2 = nullptr;  // side stream (kept for experiments: hashing a tree beside the LDEs did not pay)
-  // asynchronous uploads: DMA stream, transpose stream, two persistent staging slabs and their "free again" events
-  hipStream_t up_dma = nullptr, up_tr = nullptr;
-  uint32_t* up_stage[2] = {nullptr, nullptr};
-  hipEvent_t up_freed[2] = {nullptr, nullptr}, up_landed[2] = {nullptr, nullptr};
-  bool up_freed_set[2] = {false, false};
-  int up_next = 0;
-  static constexpr size_t UP_SLAB_BYTES = (size_t)32 << 20;
-  hipStream_t cur = nullptr;      // where KLAUNCH / upload / kernel-timing events go right now
-  std::mutex mu;
-  std::multimap<size_t, void*> free_list;  // caching allocator: exact-size reuse
-  std::map<void*, size_t> live;
-  std::map<int, uint32_t*> tw_fwd, tw_inv;  // stage-major twiddle tables (lde.cuh), per transform log-size
-  std::vector<std::pair<std::string, hipEvent_t>> marks;
-  std::vector<hipEvent_t> event_pool;
-  std::vector<std::string> timing_names;
-  std::vector<float> timing_ms;
-  // per-kernel HIP-event timing on this stream (bench.py's roofline leg reads it)
-  struct KRec { const char* name; double bytes; hipEvent_t start, stop; };
-  struct KStat { double ms = 0, bytes = 0; uint32_t calls = 0; };
-  std::vector<KRec> krecs;
-  std::map<std::string, KStat> kstats;
-  // 0: off; 1: every launch; 2 (default): only launches moving >= 256 KiB (the ~300 tiny launches of a proof
-  // are left untimed)
-  int kernel_timing = 2;
-  // per-chip specialised quotient kernels (ziren_amd/codegen.py), keyed by a hash of the program words
-  std::map<uint64_t, hipFunction_t> quotient_fns;
-  std::vector<hipModule_t> modules;
-  hipEvent_t get_event() {
-    hipEvent_t e;
-    if (!event_pool.empty()) { e = event_pool.back(); event_pool.pop_back(); }
-    else HIP_CHECK(hipEventCreate(&e));
-    return e;
-  }
-  // returns true when this launch is to be timed; the record then holds the two events to pass to the launch
-  bool kbegin(const char* name, double bytes) {
-    if (!(kernel_timing == 1 || (kernel_timing == 2 && bytes >= 262144.0))) return false;
-    KRec r{name, bytes, get_event(), get_event()};
-    krecs.push_back(r);
-    return true;
-  }
-
-  // pinned host ring: short-lived host data goes H2D (and small results come D2H) through it without
-  // a stream synchronisation; it is recycled at the start of every top-level call, when the stream is idle.
-  char* pin = nullptr;
-  size_t pin_cap = (size_t)32 << 20, pin_off = 0;
-  void* pin_alloc(size_t bytes) {
-    if (!pin) HIP_CHECK(hipHostMalloc((void**)&pin, pin_cap, hipHostMallocDefault));
-    size_t off = (pin_off + 63) & ~(size_t)63;
-    if (off + bytes > pin_cap) return nullptr;
-    pin_off = off + bytes;
-    return pin + off;
-  }
-  void begin_call() {
-    HIP_CHECK(hipStreamSynchronize(stream));
-    HIP_CHECK(hipStreamSynchronize(stream2));
-    cur = stream;
-    pin_off = 0;
-  }
-  // copy `bytes` of host data to a fresh device buffer; the source may die as soon as this returns
-  void* upload(const void* src, size_t bytes, std::vector<void*>* scratch) {
-    void* d = alloc(bytes);
-    if (scratch) scratch->push_back(d);
-    if (bytes == 0) return d;
-    void* h = pin_alloc(bytes);
-    if (h) {
-      memcpy(h, src, bytes);
-      HIP_CHECK(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, cur));
-    } else {
-      HIP_CHECK(hipMemcpyAsync(d, src, bytes, hipMemcpyHostToDevice, cur));
-      HIP_CHECK(hipStreamSynchronize(cur));
-    }
-    return d;
-  }
-  // asynchronous D2H into the pinned ring; valid after the next stream synchronisation
-  template <class T>
-  T* download_async(const T* dev, size_t count) {
-    T* h = (T*)pin_alloc(count * sizeof(T));
-    if (!h) throw std::runtime_error("pinned staging ring exhausted");
-    HIP_CHECK(hipMemcpyAsync(h, dev, count * sizeof(T), hipMemcpyDeviceToHost, stream));
-    return h;
-  }
-
-  void* alloc(size_t bytes) {
-    if (bytes == 0) bytes = 4;
-    bytes = (bytes + 255) & ~(size_t)255;
-    auto it = free_list.find(bytes);
-    void* p;
-    if (it != free_list.end()) {
-      p = it->second;
-      free_list.erase(it);
-    } else {
-      HIP_CHECK(hipMalloc(&p, bytes));
-    }
-    live[p] = bytes;
-    return p;
-  }
-  template <class T>
-  T* alloc_n(size_t n) { return (T*)alloc(n * sizeof(T)); }
-  // stream-ordered: buffers are only reused by later work on the same stream
-  void release(void* p) {
-    if (!p) return;
-    auto it = live.find(p);
-    if (it == live.end()) return;
-    free_list.insert({it->second, p});
-    live.erase(it);
-  }
-  void mark(const char* name) {
-    hipEvent_t e = get_event();
-    HIP_CHECK(hipEventRecord(e, stream));
-    marks.push_back({name, e});
-  }
-  void begin_timing() {
-    begin_call();
-    for (auto& m : marks) event_pool.push_back(m.second);
-    marks.clear();
-    for (auto& r : krecs) { event_pool.push_back(r.start); if (r.stop) event_pool.push_back(r.stop); }
-    krecs.clear();
-    mark("begin");
-  }
-  void end_timing(bool append) {
-    HIP_CHECK(hipStreamSynchronize(stream));
-    HIP_CHECK(hipStreamSynchronize(stream2));
-    if (!append) { timing_names.clear(); timing_ms.clear(); kstats.clear(); }
-    for (auto& r : krecs) {
-      float ms = 0;
-      if (r.stop) HIP_CHECK(hipEventElapsedTime(&ms, r.start, r.stop));
-      KStat& k = kstats[r.name];
-      k.ms += ms; k.bytes += r.bytes; k.calls++;
-    }
-    for (size_t i = 1; i < marks.size(); i++) {
-      float ms = 0;
-      HIP_CHECK(hipEventElapsedTime(&ms, marks[i - 1].second, marks[i].second));
-      timing_names.push_back(marks[i].first);
-      timing_ms.push_back(ms);
-    }
-  }
-  const uint32_t* twiddles(int log_size, bool inverse) {
-    auto& tab = inverse ? tw_inv : tw_fwd;
-    auto it = tab.find(log_size);
-    if (it != tab.end()) return it->second;
-    size_t count = (size_t)1 << log_size;  // stage-major table: n - 1 entries
-    uint32_t* d;
-    HIP_CHECK(hipMalloc(&d, count * 4));
-    uint32_t w = kb::two_adic_generator(log_size);
-    if (inverse) w = kb::inv(w);
-    if (log_size > 0) {
-      hipLaunchKernelGGL(lde::fill_stage_twiddles, dim3(div_up(count / 2, 256), log_size), dim3(256), 0, stream, d, w, log_size);
-      LAUNCH_CHECK();
-    }
-    tab[log_size] = d;
-    return d;
-  }
-};
-
-struct zkm_matrix {
-  uint32_t* d = nullptr;  // column-major: column c at d + c * h
-  size_t h = 0, w = 0;
-  bool owned = true;
-  hipEvent_t ready = nullptr;  // set by zkm_matrix_upload_async: fires when the matrix is complete in HBM
-};
-
-// make `stream` wait until an asynchronously uploaded matrix is complete (no-op for any other matrix)
-static inline void wait_ready(hipStream_t stream, const zkm_matrix& m) {
-  if (m.ready) HIP_CHECK(hipStreamWaitEvent(stream, m.ready, 0));
-}
-
-struct zkm_byte_lookups {
-  uint32_t* counts = nullptr;  // [NUM_BYTE_OPS][BYTE_ROWS] plain counters: record.byte_lookups on the device
-};
-
-struct Tree {
-  uint32_t* digests = nullptr;          // all layers, 8 words per digest
-  std::vector<size_t> layer_off;        // in digests
-  size_t max_height = 0;
-  int log_max = 0;
-  const uint32_t* node(int layer, size_t i) const { return digests + (layer_off[layer] + i) * 8; }
-};
-
-struct zkm_pcs_data {
-  std::vector<zkm_matrix> ldes;           // owned; bit-reversed rows, height = h << log_blowup
-  std::vector<const uint32_t*> evals;     // borrowed: the committed evaluations (column-major, natural order)
-  std::vector<size_t> eval_heights;
-  std::vector<uint32_t> domain_shifts;    // evals[i] live on domain_shifts[i] * H
-  std::vector<zkm_matrix> owned_evals;    // evaluations owned by this object (perm traces, quotient chunks)
-  Tree tree;
-  uint32_t root[8];
-  int log_blowup = 1;
-};
-
-struct zkm_pk {
-  std::vector<zkm_matrix> prep;  // borrowed device matrices
-  std::vector<uint32_t> local_only;
-  zkm_pcs_data* data = nullptr;
-  uint32_t commit[8];
-  uint32_t pc_start;
-  uint32_t igcs[14];
-};
-
-struct zkm_main_data {
-  std::vector<size_t> order;             // sorted position -> caller index
-  std::vector<zkm_matrix> traces;        // borrowed, sorted order
-  zkm_pcs_data* data = nullptr;
-  std::vector<uint32_t> public_values;
-};
-
-// ---- device helpers ------------------------------------------------------------------------------
-static void lde_columns(zkm_ctx* ctx, const uint32_t* in, size_t n, size_t w, int bl, uint32_t lde_shift, uint32_t* out) {
-  if (w == 0) return;
-  int k = log2_strict(n);
-  int lb = std::min(k, lde::LOG_ROW_MAX), la = k - lb;
-  size_t N = n << bl;
-  size_t B = (size_t)1 << lb;
-  uint32_t w_n = kb::two_adic_generator(k), w_n_inv = kb::inv(w_n), w_N = kb::two_adic_generator(k + bl);
-  uint32_t n_inv = kb::inv(kb::to_monty((uint32_t)(n % kb::P)));
-  int nhi = B > 64 ? (int)(B >> 6) : 1;
-  size_t rows_lds = (2 * (B + (B >> 5)) + 64 + nhi) * 4;
-  const uint32_t* twf = lb > 0 ? ctx->twiddles(lb, false) : nullptr;
-  const uint32_t* twi = lb > 0 ? ctx->twiddles(lb, true) : nullptr;
-  if (la == 0) {
-    KLAUNCH(ctx, "lde_rows", 4.0 * n * w + 4.0 * N * w, lde::lde_rows, dim3(1, (unsigned)w), dim3(lde::THREADS), rows_lds, in, out,
-            lb, n, N, bl, lde_shift, w_N, n_inv, twf, twi);
-    return;
-  }
-  size_t A = (size_t)1 << la;
-  int logT = std::min(std::min(6, 14 - la), lb);  // la >= 1 implies lb = 13, so T >= 8
-  size_t T = (size_t)1 << logT;
-  size_t cols_lds = A * (T + 1) * 4;  // padded tile rows
-  uint32_t* tmp1 = ctx->alloc_n<uint32_t>(n * w);
-  uint32_t* tmp2 = ctx->alloc_n<uint32_t>((n * w) << bl);
-  const uint32_t* twa_inv = ctx->twiddles(la, true);
-  const uint32_t* twa_fwd = ctx->twiddles(la, false);
-  KLAUNCH(ctx, "lde_cols_inverse", 8.0 * n * w, lde::lde_cols<false>, dim3((unsigned)(B / T), (unsigned)w, 1), dim3(lde::THREADS),
-          cols_lds, in, tmp1, la, lb, logT, n, (size_t)0, n, bl, twa_inv);
-  size_t big_lds = (B + (B >> 5) + 64 + nhi) * 4;
-  KLAUNCH(ctx, "lde_rows", 4.0 * n * w + 4.0 * N * w, lde::lde_rows_big, dim3((unsigned)A, (unsigned)w), dim3(lde::THREADS), big_lds,
-          (const uint32_t*)tmp1, tmp2, la, n, n, n * w, bl, lde_shift, w_n, w_n_inv, w_N, n_inv, twf, twi);
-  KLAUNCH(ctx, "lde_cols_forward", 8.0 * N * w, lde::lde_cols<true>, dim3((unsigned)(B / T), (unsigned)w, 1u << bl),
-          dim3(lde::THREADS), cols_lds, (const uint32_t*)tmp2, out, la, lb, logT, n, n * w, N, bl, twa_fwd);
-  ctx->release(tmp1);
-  ctx->release(tmp2);
-}
-
-// Upload an array of device pointers (one per column) and return the device copy.
-static const uint32_t** upload_ptrs(zkm_ctx* ctx, const std::vector<const uint32_t*>& ptrs) {
-  return (const uint32_t**)ctx->upload(ptrs.data(), ptrs.size() * sizeof(void*), nullptr);
-}
-
-// Layers of at most LANES_MAX nodes without injection: lane-parallel compression; returns true when it
-// finished the tree (tail launch), false when the caller should go on with the next layer.
-static bool compress_small_layer(zkm_ctx* ctx, Tree& t, int layer, size_t len) {
-  const size_t LANES_MAX = 4096, TAIL = 64;
-  if (len > LANES_MAX) {
-    KLAUNCH(ctx, "compress_layer", 96.0 * len, merkle::compress_layer, dim3(div_up(len, merkle::THREADS)), dim3(merkle::THREADS), 0,
-            (const uint32_t*)(t.digests + t.layer_off[layer] * 8), t.digests + t.layer_off[layer + 1] * 8, len,
-            (const uint32_t* const*)nullptr, 0);
-    return false;
-  }
-  if (len <= TAIL) {
-    KLAUNCH(ctx, "compress_tail", 96.0 * len, merkle::compress_tail_lanes, dim3(1), dim3(1024), 0, t.digests + t.layer_off[layer] * 8, len);
-    return true;
-  }
-  KLAUNCH(ctx, "compress_small", 96.0 * len, merkle::compress_layer_lanes, dim3(div_up(len * 16, merkle::THREADS)), dim3(merkle::THREADS),
-          0, (const uint32_t*)(t.digests + t.layer_off[layer] * 8), t.digests + t.layer_off[layer + 1] * 8, len);
-  return false;
-}
-
-// MerkleTreeMmcs::commit over column-major matrices of power-of-two heights.
-static void build_tree(zkm_ctx* ctx, const std::vector<zkm_matrix>& mats, Tree& t,
-                       const std::function<void(size_t)>& prepare_height = nullptr) {
-  // prepare_height(h), when given, is called right before the matrices of height h are first read: pcs_commit extends
-  // them there, so a commit's kernels are queued tallest matrix first, layer by layer (extend, hash, extend the next
-  // height, inject, ...), and whatever is still arriving over PCIe is only waited for when its layer is reached
-  auto wait_height = [&](size_t h) {
-    if (prepare_height) prepare_height(h);
-  };
-  size_t maxh = 0;
-  for (auto& m : mats) maxh = std::max(maxh, m.h);
-  t.max_height = maxh;
-  t.log_max = log2_strict(maxh);
-  t.layer_off.clear();
-  size_t off = 0;
-  for (size_t len = maxh; len >= 1; len >>= 1) { t.layer_off.push_back(off); off += len; if (len == 1) break; }
-  t.digests = ctx->alloc_n<uint32_t>(off * 8);
-  auto cols_of_height = [&](size_t h) {
-    std::vector<const uint32_t*> ptrs;
-    for (auto& m : mats)
-      if (m.h == h)
-        for (size_t c = 0; c < m.w; c++) ptrs.push_back(m.d + c * m.h);
-    return ptrs;
-  };
-  std::vector<const uint32_t**> to_free;
-  // the tree levels right above the leaves that no shorter matrix is injected into can be reduced inside the leaf kernel's blocks
-  int fuse = 0;
-  if (maxh >= (size_t)merkle::FUSE_LEAVES) {
-    while (fuse < merkle::FUSE_MAX_LEVELS && (maxh >> (fuse + 1)) >= 1) {
-      bool injected = false;
-      for (auto& m : mats) injected |= m.h == (maxh >> (fuse + 1));
-      if (injected) break;
-      fuse++;
-    }
-  }
-  {
-    auto ptrs = cols_of_height(maxh);
-    const uint32_t** d = upload_ptrs(ctx, ptrs);
-    to_free.push_back(d);
-    wait_height(maxh);
-    if (fuse > 0)
-      KLAUNCH(ctx, "hash_leaves_tree", 4.0 * maxh * ptrs.size() + 32.0 * maxh * (2.0 - 1.0 / (1 << fuse)), merkle::hash_leaves_tree,
-              dim3(maxh / merkle::FUSE_LEAVES), dim3(merkle::FUSE_LEAVES), merkle::FUSE_LEAVES * 12 * sizeof(uint32_t), d, (int)ptrs.size(), maxh,
-              t.digests, fuse);
-    else
-      KLAUNCH(ctx, "hash_leaves", 4.0 * maxh * ptrs.size() + 32.0 * maxh, merkle::hash_leaves, dim3(div_up(maxh, merkle::THREADS)),
-              dim3(merkle::THREADS), 0, d, (int)ptrs.size(), maxh, t.digests);
-  }
-  // near the root (no shorter matrix left to inject) layers switch to 16 lanes per node, and the last
-  // <= 64-node layers go in one launch
-  size_t min_h = maxh;
-  for (auto& m : mats) min_h = std::min(min_h, m.h);
-  int layer = fuse;
-  for (size_t len = maxh >> (fuse + 1); len >= 1; len >>= 1, layer++) {
-    if (min_h > len) {
-      if (compress_small_layer(ctx, t, layer, len)) break;
-      continue;
-    }
-    auto ptrs = cols_of_height(len);
-    const uint32_t** d = nullptr;
-    if (!ptrs.empty()) { d = upload_ptrs(ctx, ptrs); to_free.push_back(d); wait_height(len); }
-    KLAUNCH(ctx, "compress_layer", 96.0 * len + 4.0 * len * ptrs.size(), merkle::compress_layer, dim3(div_up(len, merkle::THREADS)),
-            dim3(merkle::THREADS), 0, (const uint32_t*)(t.digests + t.layer_off[layer] * 8), t.digests + t.layer_off[layer + 1] * 8,
-            len, (const uint32_t* const*)d, (int)ptrs.size());
-    if (len == 1) break;
-  }
-  for (auto d : to_free) ctx->release((void*)d);
-}
-
-static void free_pcs_data(zkm_ctx* ctx, zkm_pcs_data* d) {
-  if (!d) return;
-  for (auto& m : d->ldes) ctx->release(m.d);
-  for (auto& m : d->owned_evals) ctx->release(m.d);
-  ctx->release(d->tree.digests);
-  delete d;
-}
-
-// TwoAdicFriPcs::commit: LDE every matrix onto 3 * K (shift = GENERATOR / domain_shift), one tree.
-static zkm_pcs_data* pcs_commit(zkm_ctx* ctx, const std::vector<zkm_matrix>& mats, const std::vector<uint32_t>& shifts,
-                                int log_blowup) {
-  zkm_pcs_data* d = new zkm_pcs_data();
-  try {
-    d->log_blowup = log_blowup;
-    for (size_t i = 0; i < mats.size(); i++) {
-      const zkm_matrix& m = mats[i];
-      zkm_matrix l;
-      l.h = m.h << log_blowup;
-      l.w = m.w;
-      l.d = ctx->alloc_n<uint32_t>(l.h * l.w);
-      d->ldes.push_back(l);
-      d->evals.push_back(m.d);
-      d->eval_heights.push_back(m.h);
-      d->domain_shifts.push_back(shifts.empty() ? kb::ONE : shifts[i]);
-    }
-    // Each height's matrices are extended right before the tree layer that reads them (see build_tree).
-    std::vector<char> extended(mats.size(), 0);
-    auto extend_height = [&](size_t lde_height) {
-      for (size_t i = 0; i < mats.size(); i++) {
-        if (extended[i] || d->ldes[i].h != lde_height) continue;
-        wait_ready(ctx->stream, mats[i]);
-        lde_columns(ctx, mats[i].d, mats[i].h, mats[i].w, log_blowup, kb::mul(kb::GEN, kb::inv(d->domain_shifts[i])), d->ldes[i].d);
-        extended[i] = 1;
-      }
-    };
-    build_tree(ctx, d->ldes, d->tree, extend_height);
-    for (size_t i = 0; i < mats.size(); i++)
-      if (!extended[i]) throw std::runtime_error("pcs_commit: a matrix was not reached by the tree (internal error)");
-    const uint32_t* h_root = ctx->download_async(d->tree.node(d->tree.log_max, 0), 8);
-    HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    memcpy(d->root, h_root, 32);
-  } catch (...) {
-    free_pcs_data(ctx, d);
-    throw;
-  }
-  return d;
-}
-
-static E4 host_pow2k(E4 a, int k) { return kb::epow2k(a, k); }
-
-// ---- proof stream writer ---------------------------------------------------------------------------
-struct Writer {
-  std::vector<uint32_t> w;
-  void u(uint32_t v) { w.push_back(v); }
-  void words(const uint32_t* p, size_t n) { w.insert(w.end(), p, p + n); }
-  void ext(const E4& e) { words(e.c, 4); }
-};
-
-// ---- open --------------------------------------------------------------------------------------
-struct RoundMat {
-  const uint32_t* evals; size_t n; size_t width; uint32_t shift;
-  const zkm_matrix* lde;
-  int n_points;  // 1 or 2
-  std::vector<E4> y[2];
-};
-struct Round { const zkm_pcs_data* data; std::vector<RoundMat> mats; };
-
-static const uint32_t SEPTIC_X[7] = {637514027, 1595065213, 1998064738, 72333738, 1211544370, 822986770, 1518535784};
-static const uint32_t SEPTIC_Y[7] = {1604177449, 90440090, 259343427, 140470264, 1162099742, 941559812, 1064053343};
-
-struct ChipMeta {
-  const zkm_chip_desc* desc;
-  int log_n;
-  size_t n;
-  int n_lookups, n_sends, perm_ext_w, max_values;
-};
-
-// Parse and validate a chip descriptor. The blobs are indices into device arrays: every column, register and
-// table index is checked here so that a malformed descriptor is an error code, never an out-of-bounds access
-// on the GPU.
-static ChipMeta chip_meta(const zkm_chip_desc* d, size_t n, size_t n_public_values) {
-  ChipMeta m;
-  m.desc = d; m.n = n; m.log_n = log2_strict(n);
-  m.n_lookups = m.n_sends = m.max_values = 0;
-  const std::string who = std::string(" (chip ") + (d->name ? d->name : "?") + ")";
-  if (d->log_quotient_degree > 3) throw std::runtime_error("log_quotient_degree > 3 unsupported" + who);
-  if (d->lookups_len) {
-    const uint32_t* w = d->lookups;
-    const size_t len = d->lookups_len;
-    size_t pos = 0;
-    auto need = [&](size_t k) { if (pos + k > len) throw std::runtime_error("lookup blob truncated" + who); };
-    need(2);
-    uint32_t ns = w[pos++], nr = w[pos++];
-    if ((uint64_t)ns + nr > 4096) throw std::runtime_error("too many lookups" + who);
-    m.n_sends = ns; m.n_lookups = ns + nr;
-    for (uint32_t i = 0; i < ns + nr; i++) {
-      need(2);
-      pos++;  // kind
-      uint32_t nv = w[pos++];
-      if (nv > 64) throw std::runtime_error("lookup with more than 64 values" + who);
-      m.max_values = std::max<int>(m.max_values, nv);
-      for (uint32_t v = 0; v <= nv; v++) {
-        need(2);
-        uint32_t nt = w[pos++];
-        if (w[pos++] >= kb::P) throw std::runtime_error("lookup constant not a field element" + who);
-        need(2 * (size_t)nt);
-        for (uint32_t t = 0; t < nt; t++) {
-          uint32_t cw = w[pos++], weight = w[pos++];
-          uint32_t col = cw & 0x7fffffffu;
-          if ((cw >> 31) ? col >= d->main_width : col >= d->prep_width) throw std::runtime_error("lookup column out of range" + who);
-          if (weight >= kb::P) throw std::runtime_error("lookup weight not a field element" + who);
-        }
-      }
-    }
-    if (pos != len) throw std::runtime_error("lookup blob length mismatch" + who);
-  }
-  int batch = 1 << d->log_quotient_degree;
-  m.perm_ext_w = m.n_lookups ? (m.n_lookups + batch - 1) / batch + 1 : 0;
-  if (d->program_len) {
-    if (d->program_len < 4 || d->program_len != 4 + 2 * (size_t)d->program[0]) throw std::runtime_error("program blob length mismatch" + who);
-    if (d->program[2] != d->num_constraints) throw std::runtime_error("program constraint count mismatch" + who);
-    const uint32_t ne = std::max<uint32_t>(d->program[1], 1), nb = std::max<uint32_t>(d->program[3], 1);
-    if (ne > 256 || nb > 256) throw std::runtime_error("program register count out of range" + who);
-    size_t asserts = 0;
-    for (uint32_t k = 0; k < d->program[0]; k++) {
-      uint32_t w0 = d->program[4 + 2 * k], imm = d->program[5 + 2 * k];
-      uint32_t op = w0 & 0xff, dst = (w0 >> 8) & 0xff, ra = (w0 >> 16) & 0xff, rb = w0 >> 24;
-      bool ok = true;
-      switch (op) {
-        case ZKM_OP_LD_MAIN: ok = dst < nb && ra < 2 && imm < d->main_width; break;
-        case ZKM_OP_LD_PREP: ok = dst < nb && ra < 2 && imm < d->prep_width; break;
-        case ZKM_OP_LD_PERM: ok = dst < ne && ra < 2 && imm < (uint32_t)m.perm_ext_w; break;
-        case ZKM_OP_LD_CONST: ok = dst < nb && imm < kb::P; break;
-        case ZKM_OP_LD_PV: ok = dst < nb && imm < n_public_values; break;
-        case ZKM_OP_LD_CHALLENGE: ok = dst < ne && imm < 2; break;
-        case ZKM_OP_LD_LOCAL_SUM: ok = dst < ne; break;
-        case ZKM_OP_LD_GLOBAL_SUM: ok = dst < nb && imm < 14; break;
-        case ZKM_OP_LD_IS_FIRST: case ZKM_OP_LD_IS_LAST: case ZKM_OP_LD_IS_TRANS: ok = dst < nb; break;
-        case ZKM_OP_ADD_B: case ZKM_OP_SUB_B: case ZKM_OP_MUL_B: ok = dst < nb && ra < nb && rb < nb; break;
-        case ZKM_OP_NEG_B: ok = dst < nb && ra < nb; break;
-        case ZKM_OP_ADD_E: case ZKM_OP_SUB_E: case ZKM_OP_MUL_E: ok = dst < ne && ra < ne && rb < ne; break;
-        case ZKM_OP_NEG_E: ok = dst < ne && ra < ne; break;
-        case ZKM_OP_ADD_EB: case ZKM_OP_SUB_EB: case ZKM_OP_MUL_EB: ok = dst < ne && ra < ne && rb < nb; break;
-        case ZKM_OP_ASSERT_B: ok = ra < nb; asserts++; break;
-        case ZKM_OP_ASSERT_E: ok = ra < ne; asserts++; break;
-        default: ok = false;
-      }
-      if (!ok) throw std::runtime_error("invalid instruction " + std::to_string(k) + " in constraint program" + who);
-    }
-    if (asserts != d->num_constraints) throw std::runtime_error("program asserts do not match num_constraints" + who);
-  } else if (d->num_constraints) {
-    throw std::runtime_error("num_constraints > 0 but no program" + who);
-  }
-  return m;
-}
-
-static void open_impl(zkm_ctx* ctx, const zkm_pk* pk, zkm_main_data* md, const zkm_chip_desc* chips_in, const zkm_fri_config* fri,
-                      uint32_t num_pv_elts, zkm_challenger* ch, Writer& out) {
-  hipStream_t st = ctx->stream;
-  const int bl = fri->log_blowup;
-  const size_t nc = md->order.size();
-  std::vector<ChipMeta> chips;
-  for (size_t i = 0; i < nc; i++) chips.push_back(chip_meta(&chips_in[md->order[i]], md->traces[i].h, md->public_values.size()));
-  for (size_t i = 0; i < nc; i++) {
-    if (chips[i].desc->main_width != md->traces[i].w) throw std::runtime_error("chip main_width does not match its trace");
-    if ((int)chips[i].desc->log_quotient_degree > bl) throw std::runtime_error("log_quotient_degree > log_blowup unsupported");
-    if (chips[i].desc->prep_index >= 0 && (!pk->data || (size_t)chips[i].desc->prep_index >= pk->prep.size()))
-      throw std::runtime_error("chip references a preprocessed trace the proving key does not hold");
-  }
-  // FRI parameters as the reference's configurations use them (kb31_poseidon2.rs:203-241: blow-up 1..3 bits, 28..84 queries, 16 PoW
-  // bits); anything outside a sane envelope is an error at the boundary, not an out-of-range shift further down
-  if (bl < 1 || bl > 4) throw std::runtime_error("fri.log_blowup out of range (1..4)");
-  if (fri->proof_of_work_bits > 30) throw std::runtime_error("fri.proof_of_work_bits out of range (0..30)");
-  if (fri->num_queries < 1 || fri->num_queries > 1024) throw std::runtime_error("fri.num_queries out of range (1..1024)");
-  if (num_pv_elts > md->public_values.size()) throw std::runtime_error("num_pv_elts exceeds public_values length");
-  // Every device buffer this call allocates and has not handed to an owner yet goes back to the pool when the call unwinds:
-  // a bad shard in a long-running farm must not leak HBM (the pool only frees at zkm_ctx_destroy).
-  struct Loose {
-    zkm_ctx* ctx;
-    std::vector<void*> v;
-    void disown(void* p) { v.erase(std::remove(v.begin(), v.end(), p), v.end()); }
-    ~Loose() { for (void* p : v) ctx->release(p); }
-  } loose{ctx, {}};
-  std::vector<void*>& scratch = loose.v;
-  auto salloc = [&](size_t bytes) { void* p = ctx->alloc(bytes); scratch.push_back(p); return p; };
-
-  // --- transcript prelude (prover.rs:321-329)
-  chal::observe_slice(ch, md->public_values.data(), num_pv_elts);
-  chal::observe_slice(ch, md->data->root, 8);
-  E4 perm_ch[2] = {chal::sample_ext(ch), chal::sample_ext(ch)};
-  uint32_t* d_pv = (uint32_t*)ctx->upload(md->public_values.data(), md->public_values.size() * 4, &scratch);
-
-  // --- permutation traces (prover.rs:337-365)
-  std::vector<zkm_matrix> perm_traces(nc);
-  std::vector<E4> local_sums(nc, kb::ezero());
-  std::vector<std::array<uint32_t, 14>> global_sums(nc);
-  std::vector<uint32_t*> d_blobs(nc, nullptr);
-  std::vector<const uint32_t*> sum_src;
-  uint32_t* h_sums = nullptr;
-  {
-    int maxv = 0;
-    for (auto& c : chips) maxv = std::max(maxv, c.max_values);
-    std::vector<E4> bp(maxv + 2);
-    bp[0] = kb::eone();
-    for (int i = 1; i < maxv + 2; i++) bp[i] = kb::emul(bp[i - 1], perm_ch[1]);
-    E4* d_bp = (E4*)ctx->upload(bp.data(), bp.size() * sizeof(E4), &scratch);
-    for (size_t i = 0; i < nc; i++) {
-      const ChipMeta& c = chips[i];
-      zkm_matrix& pt = perm_traces[i];
-      pt.h = c.n; pt.w = (size_t)c.perm_ext_w * 4;
-      pt.d = ctx->alloc_n<uint32_t>(std::max<size_t>(pt.h * pt.w, 1));
-      scratch.push_back(pt.d);   // until the permutation commitment owns it
-      if (c.perm_ext_w > 0) {
-        d_blobs[i] = (uint32_t*)ctx->upload(c.desc->lookups, c.desc->lookups_len * 4, &scratch);
-        const uint32_t* prep = c.desc->prep_index >= 0 ? pk->prep[c.desc->prep_index].d : nullptr;
-        KLAUNCH(ctx, "perm_rows", 4.0 * c.n * (c.desc->main_width + c.desc->prep_width + pt.w), stark::perm_rows,
-                dim3(div_up(c.n, stark::THREADS)), dim3(stark::THREADS), 0, (const uint32_t*)d_blobs[i], c.n_lookups, c.n_sends,
-                1 << c.desc->log_quotient_degree, (const uint32_t*)md->traces[i].d, prep, c.n, perm_ch[0], (const E4*)d_bp, pt.d,
-                c.perm_ext_w);
-        // inclusive scan of the last ext column (4 base columns)
-        uint32_t* last = pt.d + (size_t)(c.perm_ext_w - 1) * 4 * c.n;
-        size_t nchunks = (c.n + stark::SCAN_BLOCK - 1) / stark::SCAN_BLOCK;
-        uint32_t* totals = (uint32_t*)salloc(nchunks * 4 * 4);
-        KLAUNCH(ctx, "scan", 32.0 * c.n, stark::scan_chunks, dim3((unsigned)nchunks, 4), dim3(stark::THREADS), 0, last, c.n, totals,
-                nchunks);
-        if (nchunks > 1) {
-          KLAUNCH(ctx, "scan", 0.0, stark::scan_totals, dim3(4), dim3(stark::THREADS), 0, totals, nchunks);
-          KLAUNCH(ctx, "scan", 32.0 * c.n, stark::scan_add_offsets, dim3((unsigned)nchunks, 4), dim3(stark::THREADS), 0, last, c.n,
-                  (const uint32_t*)totals, nchunks);
-        }
-        for (int e = 0; e < 4; e++) sum_src.push_back(last + (size_t)e * c.n + (c.n - 1));
-      } else {
-        for (int e = 0; e < 4; e++) sum_src.push_back(nullptr);
-      }
-      if (c.desc->commit_scope_global) {
-        const zkm_matrix& m = md->traces[i];
-        for (int k = 0; k < 14; k++) sum_src.push_back(m.d + (m.w - 14 + k) * m.h + (m.h - 1));
-      } else {
-        for (int k = 0; k < 14; k++) sum_src.push_back(nullptr);
-      }
-    }
-    // one gather for every cumulative-sum word (18 per chip), read back after the commit's synchronisation
-    const uint32_t* d_zero = (const uint32_t*)ctx->upload("\0\0\0\0", 4, &scratch);
-    for (auto& p : sum_src) if (!p) p = d_zero;
-    const uint32_t** d_sum_src = (const uint32_t**)ctx->upload(sum_src.data(), sum_src.size() * sizeof(void*), &scratch);
-    uint32_t* d_sums = (uint32_t*)salloc(sum_src.size() * 4);
-    KLAUNCH(ctx, "gather_words", 0.0, open::gather_words, dim3(div_up(sum_src.size(), open::THREADS)), dim3(open::THREADS), 0,
-            (const uint32_t* const*)d_sum_src, sum_src.size(), d_sums);
-    h_sums = ctx->download_async(d_sums, sum_src.size());
-  }
-  ctx->mark("permutation traces");
-  zkm_pcs_data* perm_data = pcs_commit(ctx, perm_traces, {}, bl);  // synchronises: sums are on the host now
-  perm_data->owned_evals = perm_traces;
-  for (auto& m : perm_traces) loose.disown(m.d);
-  ctx->mark("commit permutation");
-  for (size_t i = 0; i < nc; i++) {
-    for (int e = 0; e < 4; e++) local_sums[i].c[e] = h_sums[18 * i + e];
-    if (chips[i].desc->commit_scope_global) {
-      for (int k = 0; k < 14; k++) global_sums[i][k] = h_sums[18 * i + 4 + k];
-    } else {
-      for (int k = 0; k < 7; k++) { global_sums[i][k] = kb::to_monty(SEPTIC_X[k]); global_sums[i][7 + k] = kb::to_monty(SEPTIC_Y[k]); }
-    }
-  }
-  struct Guard { zkm_ctx* c; std::vector<zkm_pcs_data*> d; ~Guard() { for (auto p : d) free_pcs_data(c, p); } } guard{ctx, {perm_data}};
-  chal::observe_slice(ch, perm_data->root, 8);
-  for (size_t i = 0; i < nc; i++) {
-    chal::observe_ext(ch, local_sums[i]);
-    chal::observe_slice(ch, global_sums[i].data(), 14);
-  }
-  // --- quotient (prover.rs:416-488)
-  E4 alpha = chal::sample_ext(ch);
-  std::vector<zkm_matrix> qchunks;
-  std::vector<uint32_t> qshifts;
-  for (size_t i = 0; i < nc; i++) {
-    const ChipMeta& c = chips[i];
-    const zkm_chip_desc* d = c.desc;
-    int lqd = d->log_quotient_degree;
-    int lq = c.log_n + lqd;
-    size_t Q = (size_t)1 << lq;
-    size_t nchunks = (size_t)1 << lqd;
-    uint32_t* qbuf = ctx->alloc_n<uint32_t>(Q * 4);
-    scratch.push_back(qbuf);   // until the quotient commitment owns it
-    // alpha powers, reversed (prover.rs:453-456)
-    size_t C = d->num_constraints;
-    std::vector<E4> ap(std::max<size_t>(C, 1));
-    E4 p = kb::eone();
-    for (size_t k = 0; k < C; k++) { ap[C - 1 - k] = p; p = kb::emul(p, alpha); }
-    E4* d_ap = (E4*)ctx->upload(ap.data(), ap.size() * sizeof(E4), &scratch);
-    uint32_t consts[32] = {0};
-    for (int k = 0; k < 14; k++) consts[k] = global_sums[i][k];
-    uint32_t w_q = kb::two_adic_generator(lq);
-    // Z_H(3 w_Q^i) = 3^n * (w_Q^n)^i - 1 depends on i mod 2^lqd (zerofier_coset.rs:22-51)
-    uint32_t s_pow_n = kb::pow(kb::GEN, (uint64_t)c.n);
-    uint32_t wr = kb::two_adic_generator(lqd), wp = kb::ONE;
-    for (size_t k = 0; k < nchunks; k++) {
-      consts[16 + k] = kb::sub(kb::mul(s_pow_n, wp), kb::ONE);
-      consts[24 + k] = kb::inv(consts[16 + k]);
-      wp = kb::mul(wp, wr);
-    }
-    uint32_t* d_consts = (uint32_t*)ctx->upload(consts, sizeof consts, &scratch);
-    static const uint32_t empty_prog[4] = {0, 1, 0, 1};
-    uint32_t* d_prog = (uint32_t*)ctx->upload(d->program_len ? d->program : empty_prog, std::max<size_t>(d->program_len, 4) * 4, &scratch);
-    stark::QuotientArgs a;
-    a.program = d_prog + 4;
-    a.n_instr = d->program_len ? d->program[0] : 0;
-    a.n_regs = d->program_len ? d->program[1] : 1;
-    a.main_lde = md->data->ldes[i].d; a.main_stride = md->data->ldes[i].h;
-    a.prep_lde = d->prep_index >= 0 ? pk->data->ldes[d->prep_index].d : nullptr;
-    a.prep_stride = d->prep_index >= 0 ? pk->data->ldes[d->prep_index].h : 0;
-    a.perm_lde = perm_data->ldes[i].d; a.perm_stride = perm_data->ldes[i].h;
-    a.log_n = c.log_n; a.lqd = lqd;
-    a.alpha_pows = d_ap; a.public_values = d_pv;
-    a.perm_alpha = perm_ch[0]; a.perm_beta = perm_ch[1];
-    a.local_sum = local_sums[i];
-    a.consts = d_consts;
-    a.w_q = w_q; a.g_inv = kb::inv(kb::two_adic_generator(c.log_n));
-    a.out = qbuf;
-    a.n_base_regs = d->program_len ? std::max<uint32_t>(d->program[3], 1) : 1;
-    size_t per_thread = (size_t)a.n_regs * 16 + (size_t)a.n_base_regs * 4;
-    int bd = 256;
-    while (per_thread * bd > 64 * 1024 && bd > 64) bd >>= 1;
-    size_t lds = per_thread * bd;
-    if (lds > 160 * 1024) throw std::runtime_error(std::string("constraint program of chip ") + d->name + " needs too many registers");
-    double qbytes = 4.0 * Q * (d->main_width + d->prep_width + 4.0 * c.perm_ext_w) + 16.0 * Q;
-    auto fit = d->program_len ? ctx->quotient_fns.find(fnv1a(d->program, d->program_len)) : ctx->quotient_fns.end();
-    if (fit != ctx->quotient_fns.end()) {
-      // chip-specialised kernel: same arithmetic, values in VGPRs
-      size_t arg_size = sizeof(a);
-      void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &arg_size, HIP_LAUNCH_PARAM_END};
-      const bool timed = ctx->kbegin("quotient", qbytes);
-      HIP_CHECK(hipExtModuleLaunchKernel(fit->second, div_up(Q, 256) * 256, 1, 1, 256, 1, 1, 0, st, nullptr, config,
-                                         timed ? ctx->krecs.back().start : nullptr, timed ? ctx->krecs.back().stop : nullptr, 0));
-    } else {
-      KLAUNCH(ctx, "quotient", qbytes, stark::quotient_kernel, dim3(div_up(Q, bd)), dim3(bd), lds, a);
-    }
-    uint32_t wqp = kb::ONE;
-    for (size_t k = 0; k < nchunks; k++) {
-      zkm_matrix m; m.h = c.n; m.w = 4; m.d = qbuf + k * 4 * c.n; m.owned = (k == 0);
-      qchunks.push_back(m);
-      qshifts.push_back(kb::mul(kb::GEN, wqp));
-      wqp = kb::mul(wqp, w_q);
-    }
-  }
-  ctx->mark("quotient values");
-  zkm_pcs_data* quot_data = pcs_commit(ctx, qchunks, qshifts, bl);
-  for (auto& m : qchunks) if (m.owned) { quot_data->owned_evals.push_back(m); loose.disown(m.d); }
-  guard.d.push_back(quot_data);
-  ctx->mark("commit quotient");
-  chal::observe_slice(ch, quot_data->root, 8);
-  E4 zeta = chal::sample_ext(ch);
-
-  // --- opening rounds (prover.rs:503-556): preprocessed, main, permutation, quotient
-  std::vector<Round> rounds;
-  if (pk->data) {
-    Round r; r.data = pk->data;
-    for (size_t j = 0; j < pk->prep.size(); j++)
-      r.mats.push_back(RoundMat{pk->prep[j].d, pk->prep[j].h, pk->prep[j].w, kb::ONE, &pk->data->ldes[j], pk->local_only[j] ? 1 : 2, {}});
-    rounds.push_back(r);
-  }
-  {
-    Round r; r.data = md->data;
-    for (size_t i = 0; i < nc; i++)
-      r.mats.push_back(RoundMat{md->traces[i].d, md->traces[i].h, md->traces[i].w, kb::ONE, &md->data->ldes[i], chips[i].desc->local_only ? 1 : 2, {}});
-    rounds.push_back(r);
-    Round rp; rp.data = perm_data;
-    for (size_t i = 0; i < nc; i++)
-      rp.mats.push_back(RoundMat{perm_traces[i].d, perm_traces[i].h, perm_traces[i].w, kb::ONE, &perm_data->ldes[i], 2, {}});
-    rounds.push_back(rp);
-    Round rq; rq.data = quot_data;
-    for (size_t i = 0; i < qchunks.size(); i++)
-      rq.mats.push_back(RoundMat{qchunks[i].d, qchunks[i].h, 4, qshifts[i], &quot_data->ldes[i], 1, {}});
-    rounds.push_back(rq);
-  }
-  // (i) evaluate every column at zeta (and zeta * g): barycentric weights shared per (height, shift)
-  {
-    std::map<std::pair<size_t, uint32_t>, E4*> wcache;
-    size_t total_y = 0;
-    for (auto& r : rounds) for (auto& m : r.mats) total_y += m.width * 2;
-    E4* d_y = (E4*)salloc(std::max<size_t>(total_y, 1) * sizeof(E4));
-    size_t ypos = 0;
-    for (auto& r : rounds)
-      for (auto& m : r.mats) {
-        if (m.width == 0) continue;
-        auto key = std::make_pair(m.n, m.shift);
-        E4* wts;
-        auto it = wcache.find(key);
-        if (it == wcache.end()) {
-          int ln = log2_strict(m.n);
-          E4 u = kb::escale(zeta, kb::inv(m.shift));
-          E4 c = kb::escale(kb::esub_base(host_pow2k(u, ln), kb::ONE), kb::inv(kb::to_monty((uint32_t)(m.n % kb::P))));
-          wts = (E4*)salloc(m.n * sizeof(E4));
-          KLAUNCH(ctx, "bary_weights", 16.0 * m.n, open::bary_weights, dim3(div_up(div_up(m.n, 4), open::THREADS)), dim3(open::THREADS), 0, u, c,
-                  kb::two_adic_generator(ln), m.n, wts);
-          wcache[key] = wts;
-        } else wts = it->second;
-        unsigned groups = div_up(m.width, open::EVAL_COLS);
-        unsigned split = 1;
-        E4* partials;
-        double ebytes = 4.0 * m.n * m.width + 16.0 * m.n;
-        if (m.n >= 4 * open::THREADS) {
-          split = (unsigned)std::min<size_t>(std::max<size_t>(1, 3072 / groups), m.n / (4 * open::THREADS));
-          partials = (E4*)salloc((size_t)split * m.width * 2 * sizeof(E4));
-          if (m.n_points > 1)
-            KLAUNCH(ctx, "eval_columns", ebytes, open::eval_columns<true>, dim3(groups, split), dim3(open::THREADS), 0, m.evals, m.n,
-                    (int)m.width, (const E4*)wts, partials);
-          else
-            KLAUNCH(ctx, "eval_columns", ebytes, open::eval_columns<false>, dim3(groups, split), dim3(open::THREADS), 0, m.evals, m.n,
-                    (int)m.width, (const E4*)wts, partials);
-        } else {
-          partials = (E4*)salloc((size_t)m.width * 2 * sizeof(E4));
-          KLAUNCH(ctx, "eval_columns", ebytes, open::eval_columns_small, dim3(groups, 1), dim3(open::THREADS), 0, m.evals, m.n,
-                  (int)m.width, (const E4*)wts, m.n_points > 1 ? 1 : 0, partials);
-        }
-        KLAUNCH(ctx, "reduce_partials", 0.0, open::reduce_partials, dim3((unsigned)(m.width * 2)), dim3(64), 0, (const E4*)partials,
-                (int)split, (int)(m.width * 2), d_y + ypos);
-        ypos += m.width * 2;
-      }
-    const E4* hy = ctx->download_async(d_y, std::max<size_t>(total_y, 1));
-    HIP_CHECK(hipStreamSynchronize(st));
-    ypos = 0;
-    for (auto& r : rounds)
-      for (auto& m : r.mats) {
-        for (int pt = 0; pt < 2; pt++) m.y[pt].clear();
-        if (m.width == 0) continue;
-        for (int pt = 0; pt < m.n_points; pt++) {
-          m.y[pt].resize(m.width);
-          for (size_t c = 0; c < m.width; c++) m.y[pt][c] = hy[ypos + c * 2 + pt];
-        }
-        ypos += m.width * 2;
-      }
-  }
-  ctx->mark("open: evaluations");
-  // (ii) alpha; opened values are not observed (fri.rs:78)
-  E4 fa = chal::sample_ext(ch);
-  // (iii) reduced openings per LDE height
-  int log_max = 0;
-  size_t max_width = 1;
-  for (auto& r : rounds) for (auto& m : r.mats) { log_max = std::max(log_max, log2_strict(m.lde->h)); max_width = std::max(max_width, m.width); }
-  std::vector<E4> fap(max_width + 1);
-  fap[0] = kb::eone();
-  for (size_t i = 1; i <= max_width; i++) fap[i] = kb::emul(fap[i - 1], fa);
-  E4* d_fap = (E4*)ctx->upload(fap.data(), fap.size() * sizeof(E4), &scratch);
-  std::vector<E4*> ro(32, nullptr);
-  {
-    std::vector<std::vector<open::ReduceMat>> per_h(32);
-    std::vector<E4> run(32, kb::eone());  // alpha^count per height
-    for (auto& r : rounds)
-      for (auto& m : r.mats) {
-        int lh = log2_strict(m.lde->h);
-        open::ReduceMat rm;
-        rm.lde = m.lde->d; rm.width = (int)m.width; rm.n_points = m.n_points;
-        for (int pt = 0; pt < 2; pt++) { rm.A[pt] = kb::ezero(); rm.Yc[pt] = kb::ezero(); }
-        for (int pt = 0; pt < m.n_points; pt++) {
-          E4 ysum = kb::ezero();
-          for (size_t c = 0; c < m.width; c++) ysum = kb::eadd(ysum, kb::emul(fap[c], m.y[pt][c]));
-          rm.A[pt] = run[lh];
-          rm.Yc[pt] = kb::emul(run[lh], ysum);
-          run[lh] = kb::emul(run[lh], fap[m.width]);
-        }
-        per_h[lh].push_back(rm);
-      }
-    for (int lh = 0; lh < 32; lh++) {
-      if (per_h[lh].empty()) continue;
-      size_t N = (size_t)1 << lh;
-      ro[lh] = (E4*)salloc(N * sizeof(E4));
-      open::ReduceMat* d_rm = (open::ReduceMat*)ctx->upload(per_h[lh].data(), per_h[lh].size() * sizeof(open::ReduceMat), &scratch);
-      E4 z1 = kb::escale(zeta, kb::two_adic_generator(lh - bl));
-      double rbytes = 16.0 * N;
-      for (auto& rm : per_h[lh]) rbytes += 4.0 * N * rm.width;
-      KLAUNCH(ctx, "reduce_openings", rbytes, open::reduce_openings, dim3(div_up(N, open::THREADS)), dim3(open::THREADS), 0,
-              (const open::ReduceMat*)d_rm, (int)per_h[lh].size(), lh, (const E4*)d_fap, zeta, z1, kb::two_adic_generator(lh), ro[lh],
-              0);
-    }
-  }
-  ctx->mark("open: reduced openings");
-  // (iv) FRI commit phase (fri.rs:257-358)
-  std::vector<E4*> layers;      // f_t on device
-  std::vector<Tree> ftrees;
-  std::vector<std::array<uint32_t, 8>> commits;
-  E4* f = ro[log_max];
-  int lf = log_max;
-  uint32_t neg_half = kb::neg(kb::inv(kb::to_monty(2)));
-  while (lf > bl) {
-    size_t len = (size_t)1 << lf, half = len / 2;
-    Tree t;
-    t.max_height = half; t.log_max = lf - 1;
-    size_t off = 0;
-    for (size_t l = half; l >= 1; l >>= 1) { t.layer_off.push_back(off); off += l; if (l == 1) break; }
-    t.digests = (uint32_t*)salloc(off * 8 * 4);
-    int fuse = 0;   // FRI trees have one matrix: the first levels are reduced inside the leaf kernel's blocks
-    if (half >= (size_t)merkle::FUSE_LEAVES) fuse = std::min(merkle::FUSE_MAX_LEVELS, lf - 1);
-    if (fuse > 0)
-      KLAUNCH(ctx, "hash_fri_leaves_tree", 32.0 * half + 32.0 * half * (2.0 - 1.0 / (1 << fuse)), merkle::hash_fri_leaves_tree,
-              dim3(half / merkle::FUSE_LEAVES), dim3(merkle::FUSE_LEAVES), merkle::FUSE_LEAVES * 12 * sizeof(uint32_t), (const E4*)f, half, t.digests, fuse);
-    else
-      KLAUNCH(ctx, "hash_fri_leaves", 64.0 * half, merkle::hash_fri_leaves, dim3(div_up(half, merkle::THREADS)), dim3(merkle::THREADS), 0,
-              (const E4*)f, half, t.digests);
-    int layer = fuse;
-    for (size_t l = half >> (fuse + 1); l >= 1; l >>= 1, layer++)
-      if (compress_small_layer(ctx, t, layer, l)) break;
-    std::array<uint32_t, 8> root;
-    const uint32_t* h_root = ctx->download_async(t.node(t.log_max, 0), 8);
-    HIP_CHECK(hipStreamSynchronize(st));
-    memcpy(root.data(), h_root, 32);
-    chal::observe_slice(ch, root.data(), 8);
-    commits.push_back(root);
-    E4 beta = chal::sample_ext(ch);
-    E4* g = (E4*)salloc(half * sizeof(E4));
-    KLAUNCH(ctx, "fri_fold", 48.0 * half + (ro[lf - 1] ? 16.0 * half : 0.0), open::fri_fold, dim3(div_up(half, open::THREADS)),
-            dim3(open::THREADS), 0, (const E4*)f, lf, beta, kb::esqr(beta), kb::two_adic_generator(lf),
-            kb::inv(kb::two_adic_generator(lf)), neg_half, (const E4*)ro[lf - 1], g);
-    layers.push_back(f);
-    ftrees.push_back(t);
-    f = g;
-    lf--;
-  }
-  const size_t nfin = (size_t)1 << lf;
-  const E4* fin = ctx->download_async((const E4*)f, nfin);
-  HIP_CHECK(hipStreamSynchronize(st));
-  for (size_t i = 1; i < nfin; i++)
-    if (!kb::eq(fin[i], fin[0])) throw std::runtime_error("FRI final polynomial is not constant (internal error)");
-  E4 final_poly = fin[0];
-  chal::observe_ext(ch, final_poly);
-  ctx->mark("open: FRI commit phase");
-  // proof of work: smallest canonical witness
-  uint32_t pow_witness;
-  {
-    uint32_t* d_state = (uint32_t*)ctx->upload(ch->sponge_state, 64, &scratch);
-    uint32_t* d_in = (uint32_t*)ctx->upload(ch->input_buffer, 64, &scratch);
-    unsigned int* d_best = (unsigned int*)salloc(4);
-    uint32_t base = 0, found = 0xffffffffu;
-    const uint32_t BATCH = 1u << 20;
-    while (base < kb::P) {
-      HIP_CHECK(hipMemsetAsync(d_best, 0xff, 4, st));
-      uint32_t total = std::min<uint64_t>(BATCH, (uint64_t)kb::P - base);
-      KLAUNCH(ctx, "grind", 0.0, merkle::grind, dim3(div_up(total, merkle::THREADS)), dim3(merkle::THREADS), 0, (const uint32_t*)d_state,
-              (const uint32_t*)d_in, (int)ch->num_inputs, (int)fri->proof_of_work_bits, base, total, d_best);
-      const unsigned int* h_best = ctx->download_async((const unsigned int*)d_best, 1);
-      HIP_CHECK(hipStreamSynchronize(st));
-      found = *h_best;
-      if (found != 0xffffffffu) break;
-      base += total;
-    }
-    if (found == 0xffffffffu) throw std::runtime_error("proof-of-work search exhausted the field");
-    pow_witness = kb::to_monty(found);
-    chal::observe(ch, pow_witness);
-    if (chal::sample_bits(ch, fri->proof_of_work_bits) != 0) throw std::runtime_error("proof-of-work witness rejected by host transcript");
-  }
-  ctx->mark("open: grind");
-  // queries: build one gather list in serialisation order
-  std::vector<size_t> indices(fri->num_queries);
-  for (auto& q : indices) q = chal::sample_bits(ch, log_max);
-  std::vector<const uint32_t*> src;
-  for (size_t q : indices) {
-    for (auto& r : rounds) {
-      const Tree& t = r.data->tree;
-      size_t idx = q >> (log_max - t.log_max);
-      for (auto& m : r.mats) {
-        size_t row = idx >> (t.log_max - log2_strict(m.lde->h));
-        for (size_t c = 0; c < m.width; c++) src.push_back(m.lde->d + c * m.lde->h + row);
-      }
-      for (int l = 0; l < t.log_max; l++) {
-        const uint32_t* nd = t.node(l, (idx >> l) ^ 1);
-        for (int k = 0; k < 8; k++) src.push_back(nd + k);
-      }
-    }
-    for (size_t tI = 0; tI < ftrees.size(); tI++) {
-      size_t i = q >> tI;
-      const uint32_t* sib = (const uint32_t*)(layers[tI] + (i ^ 1));
-      for (int k = 0; k < 4; k++) src.push_back(sib + k);
-      const Tree& t = ftrees[tI];
-      size_t pi = i >> 1;
-      for (int l = 0; l < t.log_max; l++) {
-        const uint32_t* nd = t.node(l, (pi >> l) ^ 1);
-        for (int k = 0; k < 8; k++) src.push_back(nd + k);
-      }
-    }
-  }
-  std::vector<uint32_t> gathered(src.size());
-  if (!src.empty()) {
-    const uint32_t** d_src = (const uint32_t**)ctx->upload(src.data(), src.size() * sizeof(void*), &scratch);
-    uint32_t* d_dst = (uint32_t*)salloc(src.size() * 4);
-    hipLaunchKernelGGL(open::gather_words, dim3(div_up(src.size(), open::THREADS)), dim3(open::THREADS), 0, st,
-                       (const uint32_t* const*)d_src, src.size(), d_dst);
-    LAUNCH_CHECK();
-    HIP_CHECK(hipMemcpyAsync(gathered.data(), d_dst, src.size() * 4, hipMemcpyDeviceToHost, st));
-    HIP_CHECK(hipStreamSynchronize(st));
-  }
-  ctx->mark("open: queries");
-
-  // --- serialise (INTEGRATION.md "ShardProof stream"; prover.rs:558-652)
-  out.words(md->data->root, 8);
-  out.words(perm_data->root, 8);
-  out.words(quot_data->root, 8);
-  out.u((uint32_t)nc);
-  size_t ri = pk->data ? 1 : 0;
-  Round& rmain = rounds[ri];
-  Round& rperm = rounds[ri + 1];
-  Round& rquot = rounds[ri + 2];
-  size_t qpos = 0;
-  auto put_exts = [&](const std::vector<E4>& v) { for (auto& e : v) out.ext(e); };
-  for (size_t i = 0; i < nc; i++) {
-    const zkm_chip_desc* d = chips[i].desc;
-    out.u((uint32_t)md->order[i]);
-    out.u((uint32_t)chips[i].log_n);
-    if (d->prep_index >= 0) {
-      RoundMat& pm = rounds[0].mats[d->prep_index];
-      out.u((uint32_t)pm.width);
-      put_exts(pm.y[0]);
-      if (pm.n_points > 1) put_exts(pm.y[1]); else put_exts(std::vector<E4>(pm.width, kb::ezero()));
-    } else out.u(0);
-    RoundMat& mm = rmain.mats[i];
-    out.u((uint32_t)mm.width);
-    put_exts(mm.y[0]);
-    if (mm.n_points > 1) put_exts(mm.y[1]); else put_exts(std::vector<E4>(mm.width, kb::ezero()));
-    RoundMat& pm = rperm.mats[i];
-    out.u((uint32_t)pm.width);
-    put_exts(pm.y[0]); put_exts(pm.y[1]);
-    size_t nch = (size_t)1 << d->log_quotient_degree;
-    out.u((uint32_t)nch);
-    for (size_t k = 0; k < nch; k++) put_exts(rquot.mats[qpos++].y[0]);
-    out.words(global_sums[i].data(), 14);
-    out.ext(local_sums[i]);
-  }
-  out.u((uint32_t)commits.size());
-  for (auto& c : commits) out.words(c.data(), 8);
-  out.u((uint32_t)indices.size());
-  size_t gp = 0;
-  for (size_t qi = 0; qi < indices.size(); qi++) {
-    out.u((uint32_t)rounds.size());
-    for (auto& r : rounds) {
-      out.u((uint32_t)r.mats.size());
-      for (auto& m : r.mats) { out.u((uint32_t)m.width); out.words(gathered.data() + gp, m.width); gp += m.width; }
-      out.u((uint32_t)r.data->tree.log_max);
-      out.words(gathered.data() + gp, (size_t)r.data->tree.log_max * 8); gp += (size_t)r.data->tree.log_max * 8;
-    }
-    out.u((uint32_t)ftrees.size());
-    for (auto& t : ftrees) {
-      out.words(gathered.data() + gp, 4); gp += 4;
-      out.u((uint32_t)t.log_max);
-      out.words(gathered.data() + gp, (size_t)t.log_max * 8); gp += (size_t)t.log_max * 8;
-    }
-  }
-  out.ext(final_poly);
-  out.u(pow_witness);
-  out.u((uint32_t)md->public_values.size());
-  out.words(md->public_values.data(), md->public_values.size());
-}
+#include "host_ctx.hpp"
+#include "host_pcs.hpp"
+#include "host_open.hpp"
 
 // ---- C ABI ---------------------------------------------------------------------------------------
 template <int CHIP>
@@ -1588,674 +532,7 @@ int zkm_coset_lde_batch(zkm_ctx* ctx, const uint32_t* host, size_t height, size_
   API_END
 }
 
-// ---- device trace generation (ALU chips) ---------------------------------------------------------------------
-size_t zkm_tracegen_alu_width(int chip) { return chip >= 0 && chip < tracegen::NUM_ALU_CHIPS ? (size_t)tracegen::chip_width(chip) : 0; }
-
-static int tracegen_events(zkm_ctx* ctx, int chip, const void* events, size_t n_events, int fixed_log2_rows,
-                           zkm_byte_lookups* blu, zkm_matrix** out) {
-  API_BEGIN
-  static_assert(sizeof(zkm_alu_event) == 28 && sizeof(zkm_jump_event) == 28 && sizeof(zkm_mov_cond_event) == 28 &&
-                sizeof(zkm_comp_alu_event) == 64, "event records mirror the #[repr(C)] executor structs");
-  std::lock_guard<std::mutex> lk(ctx->mu);
-  HIP_CHECK(hipSetDevice(ctx->device));
-  if (chip < 0 || chip >= tracegen::NUM_CHIPS) throw std::runtime_error("zkm_tracegen: unknown chip");
-  if (n_events && !events) throw std::runtime_error("zkm_tracegen: null events");
-  // utils::next_power_of_two (crates/core/machine/src/utils/mod.rs): the shape's fixed size, else >= 16
-  size_t height = 16;
-  if (fixed_log2_rows >= 0) {
-    if (fixed_log2_rows > 30) throw std::runtime_error("zkm_tracegen_alu: fixed log2 rows out of range");
-    height = (size_t)1 << fixed_log2_rows;
-    if (n_events > height) throw std::runtime_error("zkm_tracegen_alu: fixed log2 rows is too small");
-  } else {
-    while (height < n_events) height <<= 1;
-  }
-  const size_t w = (size_t)tracegen::chip_width(chip);
-  ctx->begin_timing();
-  zkm_matrix* m = new zkm_matrix();
-  m->h = height; m->w = w;
-  uint32_t* d_events = nullptr;
-  try {
-    m->d = ctx->alloc_n<uint32_t>(height * w);
-    const size_t event_bytes = 4 * (size_t)tracegen::event_words(chip);
-    d_events = (uint32_t*)ctx->alloc(std::max<size_t>(n_events * event_bytes, 4));
-    if (n_events) HIP_CHECK(hipMemcpyAsync(d_events, events, n_events * event_bytes, hipMemcpyHostToDevice, ctx->stream));
-    uint32_t* counts = blu ? blu->counts : nullptr;
-    switch (chip) {
-      case tracegen::ADD_SUB: launch_alu_rows<tracegen::ADD_SUB>(ctx, d_events, n_events, height, m->d, counts); break;
-      case tracegen::BITWISE: launch_alu_rows<tracegen::BITWISE>(ctx, d_events, n_events, height, m->d, counts); break;
-      case tracegen::LT: launch_alu_rows<tracegen::LT>(ctx, d_events, n_events, height, m->d, counts); break;
-      case tracegen::SHIFT_LEFT: launch_alu_rows<tracegen::SHIFT_LEFT>(ctx, d_events, n_events, height, m->d, counts); break;
-      case tracegen::SHIFT_RIGHT: launch_alu_rows<tracegen::SHIFT_RIGHT>(ctx, d_events, n_events, height, m->d, counts); break;
-      case tracegen::CLO_CLZ: launch_alu_rows<tracegen::CLO_CLZ>(ctx, d_events, n_events, height, m->d, counts); break;
-      case tracegen::JUMP: launch_alu_rows<tracegen::JUMP>(ctx, d_events, n_events, height, m->d, counts); break;
-      case tracegen::MOV_COND: launch_alu_rows<tracegen::MOV_COND>(ctx, d_events, n_events, height, m->d, counts); break;
-      case tracegen::BRANCH: launch_alu_rows<tracegen::BRANCH>(ctx, d_events, n_events, height, m->d, counts); break;
-      case tracegen::MUL: launch_alu_rows<tracegen::MUL>(ctx, d_events, n_events, height, m->d, counts); break;
-      case tracegen::DIVREM: launch_alu_rows<tracegen::DIVREM>(ctx, d_events, n_events, height, m->d, counts); break;
-      case tracegen::MEMORY_INSTRS: launch_alu_rows<tracegen::MEMORY_INSTRS>(ctx, d_events, n_events, height, m->d, counts); break;
-      case tracegen::SYSCALL_INSTRS: launch_alu_rows<tracegen::SYSCALL_INSTRS>(ctx, d_events, n_events, height, m->d, counts); break;
-      case tracegen::MISC_INSTRS: launch_alu_rows<tracegen::MISC_INSTRS>(ctx, d_events, n_events, height, m->d, counts); break;
-      case tracegen::SYSCALL_CORE: launch_alu_rows<tracegen::SYSCALL_CORE>(ctx, d_events, n_events, height, m->d, counts); break;
-      case tracegen::SYSCALL_PRECOMPILE: launch_alu_rows<tracegen::SYSCALL_PRECOMPILE>(ctx, d_events, n_events, height, m->d, counts); break;
-    }
-    ctx->mark("trace generation");
-    ctx->end_timing(false);  // synchronises: the caller's event buffer is free again
-  } catch (...) {
-    if (d_events) ctx->release(d_events);
-    if (m->d) ctx->release(m->d);
-    delete m;
-    throw;
-  }
-  ctx->release(d_events);
-  *out = m;
-  API_END
-}
-
-int zkm_tracegen_alu(zkm_ctx* ctx, int chip, const zkm_alu_event* events, size_t n_events, int fixed_log2_rows,
-                     zkm_byte_lookups* blu, zkm_matrix** out) {
-  if (chip < 0 || chip >= tracegen::NUM_ALU_CHIPS) { g_err = "zkm_tracegen_alu: unknown chip"; return -1; }
-  return tracegen_events(ctx, chip, events, n_events, fixed_log2_rows, blu, out);
-}
-size_t zkm_tracegen_jump_width(void) { return (size_t)tracegen::chip_width(tracegen::JUMP); }
-int zkm_tracegen_jump(zkm_ctx* ctx, const zkm_jump_event* events, size_t n_events, int fixed_log2_rows, zkm_matrix** out) {
-  return tracegen_events(ctx, tracegen::JUMP, events, n_events, fixed_log2_rows, nullptr, out);
-}
-
-int zkm_tracegen_flat(zkm_ctx* ctx, const uint32_t* words, size_t n_words, size_t width, int fixed_log2_rows, zkm_matrix** out) {
-  API_BEGIN
-  std::lock_guard<std::mutex> lk(ctx->mu);
-  HIP_CHECK(hipSetDevice(ctx->device));
-  if (width == 0) throw std::runtime_error("zkm_tracegen_flat: zero width");
-  if (n_words && !words) throw std::runtime_error("zkm_tracegen_flat: null records");
-  const size_t rows = (n_words + width - 1) / width;
-  size_t height = 16;
-  if (fixed_log2_rows >= 0) {
-    if (fixed_log2_rows > 30) throw std::runtime_error("zkm_tracegen_flat: fixed log2 rows out of range");
-    height = (size_t)1 << fixed_log2_rows;
-    if (rows > height) throw std::runtime_error("zkm_tracegen_flat: fixed log2 rows is too small");
-  } else {
-    while (height < rows) height <<= 1;
-  }
-  ctx->begin_call();
-  zkm_matrix* m = new zkm_matrix();
-  m->h = height; m->w = width;
-  uint32_t* stage = nullptr;
-  try {
-    m->d = ctx->alloc_n<uint32_t>(height * width);
-    stage = ctx->alloc_n<uint32_t>(height * width);
-    HIP_CHECK(hipMemsetAsync(stage, 0, height * width * 4, ctx->stream));
-    if (n_words) HIP_CHECK(hipMemcpyAsync(stage, words, n_words * 4, hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(open::transpose_slab, dim3(div_up(width, 32), div_up(height, 32)), dim3(32, 8), 0, ctx->stream,
-                       (const uint32_t*)stage, m->d, height, width, (size_t)0, height);
-    LAUNCH_CHECK();
-    HIP_CHECK(hipStreamSynchronize(ctx->stream));
-  } catch (...) {
-    if (stage) ctx->release(stage);
-    if (m->d) ctx->release(m->d);
-    delete m;
-    throw;
-  }
-  ctx->release(stage);
-  *out = m;
-  API_END
-}
-
-size_t zkm_tracegen_branch_width(void) { return (size_t)tracegen::chip_width(tracegen::BRANCH); }
-int zkm_tracegen_branch(zkm_ctx* ctx, const zkm_branch_event* events, size_t n_events, int fixed_log2_rows, zkm_byte_lookups* blu,
-                        zkm_matrix** out) {
-  return tracegen_events(ctx, tracegen::BRANCH, events, n_events, fixed_log2_rows, blu, out);
-}
-size_t zkm_tracegen_mul_width(void) { return (size_t)tracegen::chip_width(tracegen::MUL); }
-int zkm_tracegen_mul(zkm_ctx* ctx, const zkm_comp_alu_event* events, size_t n_events, int fixed_log2_rows, zkm_byte_lookups* blu,
-                     zkm_matrix** out) {
-  return tracegen_events(ctx, tracegen::MUL, events, n_events, fixed_log2_rows, blu, out);
-}
-size_t zkm_tracegen_memory_instrs_width(void) { return (size_t)tracegen::chip_width(tracegen::MEMORY_INSTRS); }
-int zkm_tracegen_memory_instrs(zkm_ctx* ctx, const zkm_mem_instr_event* events, size_t n_events, int fixed_log2_rows, zkm_byte_lookups* blu,
-                               zkm_matrix** out) {
-  static_assert(sizeof(zkm_mem_instr_event) == 64, "event records mirror the #[repr(C)] executor structs");
-  return tracegen_events(ctx, tracegen::MEMORY_INSTRS, events, n_events, fixed_log2_rows, blu, out);
-}
-size_t zkm_tracegen_syscall_instrs_width(void) { return (size_t)tracegen::chip_width(tracegen::SYSCALL_INSTRS); }
-int zkm_tracegen_syscall_instrs(zkm_ctx* ctx, const zkm_syscall_event* events, size_t n_events, int fixed_log2_rows, zkm_matrix** out) {
-  static_assert(sizeof(zkm_syscall_event) == 56, "event records mirror the #[repr(C)] executor structs");
-  return tracegen_events(ctx, tracegen::SYSCALL_INSTRS, events, n_events, fixed_log2_rows, nullptr, out);
-}
-size_t zkm_tracegen_misc_instrs_width(void) { return (size_t)tracegen::chip_width(tracegen::MISC_INSTRS); }
-int zkm_tracegen_misc_instrs(zkm_ctx* ctx, const zkm_misc_event* events, size_t n_events, int fixed_log2_rows, zkm_byte_lookups* blu,
-                             zkm_matrix** out) {
-  static_assert(sizeof(zkm_misc_event) == 60, "event records mirror the #[repr(C)] executor structs");
-  return tracegen_events(ctx, tracegen::MISC_INSTRS, events, n_events, fixed_log2_rows, blu, out);
-}
-size_t zkm_tracegen_divrem_width(void) { return (size_t)tracegen::chip_width(tracegen::DIVREM); }
-int zkm_tracegen_divrem(zkm_ctx* ctx, const zkm_comp_alu_event* events, size_t n_events, int fixed_log2_rows, zkm_byte_lookups* blu,
-                        zkm_matrix** out) {
-  return tracegen_events(ctx, tracegen::DIVREM, events, n_events, fixed_log2_rows, blu, out);
-}
-size_t zkm_tracegen_mov_cond_width(void) { return (size_t)tracegen::chip_width(tracegen::MOV_COND); }
-int zkm_tracegen_mov_cond(zkm_ctx* ctx, const zkm_mov_cond_event* events, size_t n_events, int fixed_log2_rows, zkm_matrix** out) {
-  return tracegen_events(ctx, tracegen::MOV_COND, events, n_events, fixed_log2_rows, nullptr, out);
-}
-
-static size_t padded_trace_rows(size_t n_records, int fixed_log2_rows, const char* what) {
-  // utils::next_power_of_two (crates/core/machine/src/utils/mod.rs): the shape's fixed size, else >= 16
-  size_t height = 16;
-  if (fixed_log2_rows >= 0) {
-    if (fixed_log2_rows > 30) throw std::runtime_error(std::string(what) + ": fixed log2 rows out of range");
-    height = (size_t)1 << fixed_log2_rows;
-    if (n_records > height) throw std::runtime_error(std::string(what) + ": fixed log2 rows is too small");
-  } else {
-    while (height < n_records) height <<= 1;
-  }
-  return height;
-}
-
-size_t zkm_tracegen_cpu_width(void) { return (size_t)tracegen::CPU_WIDTH; }
-int zkm_tracegen_cpu_and_program(zkm_ctx* ctx, const zkm_cpu_event* events, size_t n_events, const zkm_instruction* program, size_t n_instr,
-                                 uint32_t pc_base, uint32_t shard, int fixed_log2_rows, int program_fixed_log2_rows, zkm_byte_lookups* blu,
-                                 zkm_matrix** out, zkm_matrix** program_mults_out) {
-  API_BEGIN
-  static_assert(sizeof(zkm_cpu_event) == 4 * tracegen::CPU_EVENT_WORDS && sizeof(zkm_instruction) == 4 * tracegen::INSTRUCTION_WORDS,
-                "event records mirror the #[repr(C)] executor structs");
-  std::lock_guard<std::mutex> lk(ctx->mu);
-  HIP_CHECK(hipSetDevice(ctx->device));
-  if (n_events && (!events || !program || !n_instr)) throw std::runtime_error("zkm_tracegen_cpu: null events or program");
-  const size_t height = padded_trace_rows(n_events, fixed_log2_rows, "zkm_tracegen_cpu");
-  const size_t pheight = program_mults_out ? padded_trace_rows(n_instr, program_fixed_log2_rows, "zkm_tracegen_cpu (program)") : 0;
-  ctx->begin_timing();
-  zkm_matrix* m = new zkm_matrix();
-  zkm_matrix* pm = program_mults_out ? new zkm_matrix() : nullptr;
-  m->h = height; m->w = tracegen::CPU_WIDTH;
-  uint32_t *d_events = nullptr, *d_program = nullptr;
-  int* d_bad = nullptr;
-  try {
-    m->d = ctx->alloc_n<uint32_t>(height * m->w);
-    if (pm) {
-      pm->h = pheight; pm->w = 1;
-      pm->d = ctx->alloc_n<uint32_t>(pheight);
-      HIP_CHECK(hipMemsetAsync(pm->d, 0, pheight * 4, ctx->stream));
-    }
-    d_events = (uint32_t*)ctx->alloc(std::max<size_t>(n_events * sizeof(zkm_cpu_event), 4));
-    d_program = (uint32_t*)ctx->alloc(std::max<size_t>(n_instr * sizeof(zkm_instruction), 4));
-    d_bad = (int*)ctx->alloc(4);
-    HIP_CHECK(hipMemsetAsync(d_bad, 0, 4, ctx->stream));
-    if (n_events) HIP_CHECK(hipMemcpyAsync(d_events, events, n_events * sizeof(zkm_cpu_event), hipMemcpyHostToDevice, ctx->stream));
-    if (n_instr) HIP_CHECK(hipMemcpyAsync(d_program, program, n_instr * sizeof(zkm_instruction), hipMemcpyHostToDevice, ctx->stream));
-    uint32_t* counts = blu ? blu->counts : nullptr;
-    const int tiles = counts ? tracegen::TILES_PER_BLOCK : 1;
-    KLAUNCH(ctx, "tracegen_cpu", 280.0 * n_events + 4.0 * height * tracegen::CPU_WIDTH, tracegen::cpu_rows,
-            dim3(div_up(height, (size_t)tiles * tracegen::THREADS)), dim3(tracegen::THREADS),
-            counts ? 2 * tracegen::HASH_SLOTS * sizeof(uint32_t) : 0, (const uint32_t*)d_events, n_events, (const uint32_t*)d_program, n_instr,
-            pc_base, shard, height, m->d, counts, tiles, d_bad, pm ? pm->d : (uint32_t*)nullptr);
-    if (pm) {
-      hipLaunchKernelGGL(tracegen::counts_to_field, dim3(div_up(pheight, 256)), dim3(256), 0, ctx->stream, pm->d, pheight);
-      LAUNCH_CHECK();
-    }
-    int bad = 0;
-    HIP_CHECK(hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, ctx->stream));
-    ctx->mark("trace generation");
-    ctx->end_timing(false);
-    if (bad) throw std::runtime_error("zkm_tracegen_cpu: an event's pc lies outside the program");
-  } catch (...) {
-    if (d_events) ctx->release(d_events);
-    if (d_program) ctx->release(d_program);
-    if (d_bad) ctx->release(d_bad);
-    if (m->d) ctx->release(m->d);
-    if (pm && pm->d) ctx->release(pm->d);
-    delete m;
-    delete pm;
-    throw;
-  }
-  ctx->release(d_events);
-  ctx->release(d_program);
-  ctx->release(d_bad);
-  *out = m;
-  if (pm) *program_mults_out = pm;
-  API_END
-}
-
-int zkm_tracegen_cpu(zkm_ctx* ctx, const zkm_cpu_event* events, size_t n_events, const zkm_instruction* program, size_t n_instr,
-                     uint32_t pc_base, uint32_t shard, int fixed_log2_rows, zkm_byte_lookups* blu, zkm_matrix** out) {
-  return zkm_tracegen_cpu_and_program(ctx, events, n_events, program, n_instr, pc_base, shard, fixed_log2_rows, -1, blu, out, nullptr);
-}
-
-int zkm_tracegen_program(zkm_ctx* ctx, const zkm_instruction* program, size_t n_instr, uint32_t pc_base, int fixed_log2_rows,
-                         zkm_matrix** out) {
-  API_BEGIN
-  std::lock_guard<std::mutex> lk(ctx->mu);
-  HIP_CHECK(hipSetDevice(ctx->device));
-  if (n_instr && !program) throw std::runtime_error("zkm_tracegen_program: null program");
-  const size_t height = padded_trace_rows(n_instr, fixed_log2_rows, "zkm_tracegen_program");
-  ctx->begin_call();
-  zkm_matrix* m = new zkm_matrix();
-  m->h = height; m->w = tracegen::PROGRAM_PREP_WIDTH;
-  uint32_t* d_program = nullptr;
-  try {
-    m->d = ctx->alloc_n<uint32_t>(height * m->w);
-    d_program = (uint32_t*)ctx->alloc(std::max<size_t>(n_instr * sizeof(zkm_instruction), 4));
-    if (n_instr) HIP_CHECK(hipMemcpyAsync(d_program, program, n_instr * sizeof(zkm_instruction), hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(tracegen::program_rows, dim3(div_up(height, 256)), dim3(256), 0, ctx->stream, (const uint32_t*)d_program, n_instr,
-                       pc_base, height, m->d);
-    LAUNCH_CHECK();
-    HIP_CHECK(hipStreamSynchronize(ctx->stream));
-  } catch (...) {
-    if (d_program) ctx->release(d_program);
-    if (m->d) ctx->release(m->d);
-    delete m;
-    throw;
-  }
-  ctx->release(d_program);
-  *out = m;
-  API_END
-}
-
-int zkm_tracegen_program_mults(zkm_ctx* ctx, const zkm_cpu_event* events, size_t n_events, size_t n_instr, uint32_t pc_base,
-                               int fixed_log2_rows, zkm_matrix** out) {
-  API_BEGIN
-  std::lock_guard<std::mutex> lk(ctx->mu);
-  HIP_CHECK(hipSetDevice(ctx->device));
-  if (n_events && !events) throw std::runtime_error("zkm_tracegen_program_mults: null events");
-  const size_t height = padded_trace_rows(n_instr, fixed_log2_rows, "zkm_tracegen_program_mults");
-  ctx->begin_call();
-  zkm_matrix* m = new zkm_matrix();
-  m->h = height; m->w = 1;
-  uint32_t* d_events = nullptr;
-  try {
-    m->d = ctx->alloc_n<uint32_t>(height);
-    HIP_CHECK(hipMemsetAsync(m->d, 0, height * 4, ctx->stream));
-    d_events = (uint32_t*)ctx->alloc(std::max<size_t>(n_events * sizeof(zkm_cpu_event), 4));
-    if (n_events) {
-      HIP_CHECK(hipMemcpyAsync(d_events, events, n_events * sizeof(zkm_cpu_event), hipMemcpyHostToDevice, ctx->stream));
-      hipLaunchKernelGGL(tracegen::program_count, dim3(div_up(n_events, 256)), dim3(256), 0, ctx->stream, (const uint32_t*)d_events, n_events,
-                         n_instr, pc_base, m->d);
-      LAUNCH_CHECK();
-    }
-    hipLaunchKernelGGL(tracegen::counts_to_field, dim3(div_up(height, 256)), dim3(256), 0, ctx->stream, m->d, height);
-    LAUNCH_CHECK();
-    HIP_CHECK(hipStreamSynchronize(ctx->stream));
-  } catch (...) {
-    if (d_events) ctx->release(d_events);
-    if (m->d) ctx->release(m->d);
-    delete m;
-    throw;
-  }
-  ctx->release(d_events);
-  *out = m;
-  API_END
-}
-
-int zkm_tracegen_memory_local(zkm_ctx* ctx, const zkm_memory_local_event* events, size_t n_events, int fixed_log2_rows, zkm_matrix** out) {
-  API_BEGIN
-  static_assert(sizeof(zkm_memory_local_event) == 28, "event records mirror the #[repr(C)] executor structs");
-  std::lock_guard<std::mutex> lk(ctx->mu);
-  HIP_CHECK(hipSetDevice(ctx->device));
-  if (n_events && !events) throw std::runtime_error("zkm_tracegen_memory_local: null events");
-  const size_t height = padded_trace_rows(div_up(n_events, (size_t)tracegen::MEMORY_LOCAL_ENTRIES), fixed_log2_rows, "zkm_tracegen_memory_local");
-  ctx->begin_call();
-  zkm_matrix* m = new zkm_matrix();
-  m->h = height; m->w = tracegen::MEMORY_LOCAL_WIDTH;
-  uint32_t* d_events = nullptr;
-  try {
-    m->d = ctx->alloc_n<uint32_t>(height * m->w);
-    d_events = (uint32_t*)ctx->alloc(std::max<size_t>(n_events * sizeof(zkm_memory_local_event), 4));
-    if (n_events) HIP_CHECK(hipMemcpyAsync(d_events, events, n_events * sizeof(zkm_memory_local_event), hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(tracegen::memory_local_rows, dim3(div_up(height * tracegen::MEMORY_LOCAL_ENTRIES, (size_t)256)), dim3(256), 0, ctx->stream,
-                       (const uint32_t*)d_events, n_events, height, m->d);
-    LAUNCH_CHECK();
-    HIP_CHECK(hipStreamSynchronize(ctx->stream));
-  } catch (...) {
-    if (d_events) ctx->release(d_events);
-    if (m->d) ctx->release(m->d);
-    delete m;
-    throw;
-  }
-  ctx->release(d_events);
-  *out = m;
-  API_END
-}
-
-int zkm_tracegen_global(zkm_ctx* ctx, const zkm_global_lookup_event* events, size_t n_events, int fixed_log2_rows, zkm_byte_lookups* blu,
-                        zkm_matrix** out) {
-  API_BEGIN
-  static_assert(sizeof(zkm_global_lookup_event) == 32, "event records mirror the #[repr(C)] executor structs");
-  std::lock_guard<std::mutex> lk(ctx->mu);
-  HIP_CHECK(hipSetDevice(ctx->device));
-  if (n_events && !events) throw std::runtime_error("zkm_tracegen_global: null events");
-  if (!blu) throw std::runtime_error("zkm_tracegen_global: null byte lookups");
-  for (size_t i = 0; i < n_events; i++)
-    if (events[i].message[0] >> 16) throw std::runtime_error("zkm_tracegen_global: message[0] of event " + std::to_string(i) + " is not a u16");
-  const size_t height = padded_trace_rows(n_events, fixed_log2_rows, "zkm_tracegen_global");
-  ctx->begin_timing();
-  zkm_matrix* m = new zkm_matrix();
-  m->h = height; m->w = tracegen::GLOBAL_WIDTH;
-  uint32_t* d_events = nullptr;
-  uint32_t* d_err = nullptr;
-  std::vector<uint32_t*> levels;     // scan buffers: the points behind the start digest, then the chunk sums of each level
-  std::vector<size_t> sizes;
-  try {
-    m->d = ctx->alloc_n<uint32_t>(height * m->w);
-    d_events = (uint32_t*)ctx->alloc(std::max<size_t>(n_events * sizeof(zkm_global_lookup_event), 4));
-    d_err = ctx->alloc_n<uint32_t>(1);
-    HIP_CHECK(hipMemsetAsync(d_err, 0, 4, ctx->stream));
-    if (n_events) HIP_CHECK(hipMemcpyAsync(d_events, events, n_events * sizeof(zkm_global_lookup_event), hipMemcpyHostToDevice, ctx->stream));
-    for (size_t n = n_events + 1;; n = div_up(n, (size_t)tracegen::SCAN_CHUNK)) {
-      levels.push_back(ctx->alloc_n<uint32_t>(n * tracegen::POINT_WORDS));
-      sizes.push_back(n);
-      if (n <= (size_t)tracegen::SCAN_BLOCK) break;
-    }
-    const double bytes = 32.0 * n_events + 4.0 * height * tracegen::GLOBAL_WIDTH;
-    KLAUNCH(ctx, "tracegen_global_points", bytes, tracegen::global_point_rows, dim3(div_up(height, (size_t)256)), dim3(256), 0,
-            (const uint32_t*)d_events, n_events, height, m->d, levels[0], blu->counts, d_err);
-    for (size_t l = 0; l + 1 < levels.size(); l++)
-      KLAUNCH(ctx, "tracegen_global_scan", 64.0 * sizes[l], tracegen::global_scan_reduce, dim3(div_up(sizes[l + 1], (size_t)64)), dim3(64), 0,
-              (const uint32_t*)levels[l], sizes[l], levels[l + 1], sizes[l + 1]);
-    KLAUNCH(ctx, "tracegen_global_scan", 128.0 * sizes.back(), tracegen::global_scan_block, dim3(1), dim3(tracegen::SCAN_BLOCK), 0, levels.back(),
-            sizes.back());
-    for (size_t l = levels.size() - 1; l-- > 0;)
-      KLAUNCH(ctx, "tracegen_global_scan", 128.0 * sizes[l], tracegen::global_scan_apply, dim3(div_up(sizes[l + 1], (size_t)64)), dim3(64), 0, levels[l],
-              sizes[l], (const uint32_t*)levels[l + 1], sizes[l + 1]);
-    KLAUNCH(ctx, "tracegen_global_accum", bytes, tracegen::global_accum_rows, dim3(div_up(height, (size_t)256)), dim3(256), 0,
-            (const uint32_t*)levels[0], n_events, height, m->d, d_err);
-    uint32_t err = 0;
-    HIP_CHECK(hipMemcpyAsync(&err, d_err, 4, hipMemcpyDeviceToHost, ctx->stream));
-    ctx->mark("trace generation");
-    ctx->end_timing(false);
-    HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    if (err & tracegen::GLOBAL_ERR_NO_POINT) throw std::runtime_error("zkm_tracegen_global: a message has no curve point within 256 offsets");
-    if (err & tracegen::GLOBAL_ERR_INFINITY) throw std::runtime_error("zkm_tracegen_global: the running sum reached the point at infinity");
-    if (err & tracegen::GLOBAL_ERR_EQUAL_X) throw std::runtime_error("zkm_tracegen_global: a message's point has the running sum's x-coordinate");
-  } catch (...) {
-    for (uint32_t* p : levels) ctx->release(p);
-    if (d_err) ctx->release(d_err);
-    if (d_events) ctx->release(d_events);
-    if (m->d) ctx->release(m->d);
-    delete m;
-    throw;
-  }
-  for (uint32_t* p : levels) ctx->release(p);
-  ctx->release(d_err);
-  ctx->release(d_events);
-  *out = m;
-  API_END
-}
-
-int zkm_tracegen_poseidon2_wide(zkm_ctx* ctx, const uint32_t* events, size_t n_events, int fixed_log2_rows, zkm_matrix** out) {
-  API_BEGIN
-  std::lock_guard<std::mutex> lk(ctx->mu);
-  HIP_CHECK(hipSetDevice(ctx->device));
-  if (n_events && !events) throw std::runtime_error("zkm_tracegen_poseidon2_wide: null events");
-  const size_t height = padded_trace_rows(n_events, fixed_log2_rows, "zkm_tracegen_poseidon2_wide");
-  ctx->begin_timing();
-  zkm_matrix* m = new zkm_matrix();
-  m->h = height; m->w = tracegen::POSEIDON2_WIDE_WIDTH;
-  uint32_t* d_events = nullptr;
-  try {
-    m->d = ctx->alloc_n<uint32_t>(height * m->w);
-    d_events = (uint32_t*)ctx->alloc(std::max<size_t>(n_events * 128, 4));
-    if (n_events) HIP_CHECK(hipMemcpyAsync(d_events, events, n_events * 128, hipMemcpyHostToDevice, ctx->stream));
-    KLAUNCH(ctx, "tracegen_poseidon2_wide", 128.0 * n_events + 4.0 * height * tracegen::POSEIDON2_WIDE_WIDTH, tracegen::poseidon2_wide_rows,
-            dim3(div_up(height, (size_t)tracegen::THREADS)), dim3(tracegen::THREADS), 0, (const uint32_t*)d_events, n_events, height, m->d);
-    ctx->mark("trace generation");
-    ctx->end_timing(false);
-  } catch (...) {
-    if (d_events) ctx->release(d_events);
-    if (m->d) ctx->release(m->d);
-    delete m;
-    throw;
-  }
-  ctx->release(d_events);
-  *out = m;
-  API_END
-}
-
-int zkm_tracegen_syscall(zkm_ctx* ctx, const zkm_syscall_event* events, size_t n_events, int precompile, int fixed_log2_rows, zkm_byte_lookups* blu,
-                         zkm_matrix** out) {
-  if (precompile) return tracegen_events(ctx, tracegen::SYSCALL_PRECOMPILE, events, n_events, fixed_log2_rows, blu, out);
-  // SyscallCore keeps the events whose code has the send-to-table byte set or names a Linux syscall (syscall/chip.rs:252-259)
-  std::vector<zkm_syscall_event> kept;
-  if (events)
-    for (size_t i = 0; i < n_events; i++) {
-      const uint32_t code = events[i].a_record.prev_value;
-      if (((code >> 16) & 0xff) == 1 || ((code >> 8) & 0xff) != 0) kept.push_back(events[i]);
-    }
-  return tracegen_events(ctx, tracegen::SYSCALL_CORE, n_events ? (events ? (const void*)kept.data() : nullptr) : nullptr, events ? kept.size() : n_events,
-                         fixed_log2_rows, blu, out);
-}
-
-int zkm_tracegen_memory_global(zkm_ctx* ctx, const zkm_memory_init_finalize_event* events, size_t n_events, uint32_t previous_addr, int fixed_log2_rows,
-                               zkm_matrix** out) {
-  API_BEGIN
-  static_assert(sizeof(zkm_memory_init_finalize_event) == 16, "event records mirror the #[repr(C)] executor structs");
-  std::lock_guard<std::mutex> lk(ctx->mu);
-  HIP_CHECK(hipSetDevice(ctx->device));
-  if (n_events && !events) throw std::runtime_error("zkm_tracegen_memory_global: null events");
-  const size_t height = padded_trace_rows(n_events, fixed_log2_rows, "zkm_tracegen_memory_global");
-  // generate_trace sorts the events by address first (memory/global.rs:131)
-  std::vector<zkm_memory_init_finalize_event> sorted(events, events + n_events);
-  std::stable_sort(sorted.begin(), sorted.end(), [](const zkm_memory_init_finalize_event& a, const zkm_memory_init_finalize_event& b) { return a.addr < b.addr; });
-  ctx->begin_timing();
-  zkm_matrix* m = new zkm_matrix();
-  m->h = height; m->w = tracegen::MEMORY_GLOBAL_WIDTH;
-  uint32_t* d_events = nullptr;
-  int* d_bad = nullptr;
-  try {
-    m->d = ctx->alloc_n<uint32_t>(height * m->w);
-    d_events = (uint32_t*)ctx->alloc(std::max<size_t>(n_events * 16, 4));
-    d_bad = (int*)ctx->alloc(4);
-    HIP_CHECK(hipMemsetAsync(d_bad, 0, 4, ctx->stream));
-    if (n_events) HIP_CHECK(hipMemcpyAsync(d_events, sorted.data(), n_events * 16, hipMemcpyHostToDevice, ctx->stream));
-    KLAUNCH(ctx, "tracegen_memory_global", 16.0 * n_events + 4.0 * height * m->w, tracegen::memory_global_rows, dim3(div_up(height, (size_t)tracegen::THREADS)),
-            dim3(tracegen::THREADS), 0, (const uint32_t*)d_events, n_events, previous_addr, height, m->d, d_bad);
-    int bad = 0;
-    HIP_CHECK(hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, ctx->stream));
-    ctx->mark("trace generation");
-    ctx->end_timing(false);
-    if (bad) throw std::runtime_error("zkm_tracegen_memory_global: addresses are not strictly increasing (from the previous shard's last address on)");
-  } catch (...) {
-    if (d_events) ctx->release(d_events);
-    if (d_bad) ctx->release(d_bad);
-    if (m->d) ctx->release(m->d);
-    delete m;
-    throw;
-  }
-  ctx->release(d_events);
-  ctx->release(d_bad);
-  *out = m;
-  API_END
-}
-
-int zkm_tracegen_poseidon2_permute(zkm_ctx* ctx, const zkm_poseidon2_permute_event* events, size_t n_events, int fixed_log2_rows, zkm_byte_lookups* blu,
-                                   zkm_matrix** out) {
-  API_BEGIN
-  static_assert(sizeof(zkm_poseidon2_permute_event) == 4 * tracegen::POSEIDON2_PERMUTE_EVENT_WORDS, "flattened Poseidon2PermuteEvent is 99 words");
-  std::lock_guard<std::mutex> lk(ctx->mu);
-  HIP_CHECK(hipSetDevice(ctx->device));
-  if (n_events && !events) throw std::runtime_error("zkm_tracegen_poseidon2_permute: null events");
-  const size_t height = padded_trace_rows(n_events, fixed_log2_rows, "zkm_tracegen_poseidon2_permute");
-  ctx->begin_timing();
-  zkm_matrix* m = new zkm_matrix();
-  m->h = height; m->w = tracegen::POSEIDON2_PERMUTE_WIDTH;
-  uint32_t* d_events = nullptr;
-  int* d_bad = nullptr;
-  try {
-    m->d = ctx->alloc_n<uint32_t>(height * m->w);
-    const size_t ev_bytes = n_events * sizeof(zkm_poseidon2_permute_event);
-    d_events = (uint32_t*)ctx->alloc(std::max<size_t>(ev_bytes, 4));
-    d_bad = (int*)ctx->alloc(4);
-    HIP_CHECK(hipMemsetAsync(d_bad, 0, 4, ctx->stream));
-    if (n_events) HIP_CHECK(hipMemcpyAsync(d_events, events, ev_bytes, hipMemcpyHostToDevice, ctx->stream));
-    uint32_t* counts = blu ? blu->counts : nullptr;
-    KLAUNCH(ctx, "tracegen_poseidon2_permute", (double)ev_bytes + 4.0 * height * m->w, tracegen::poseidon2_permute_rows,
-            dim3(div_up(height, (size_t)tracegen::THREADS)), dim3(tracegen::THREADS), counts ? 2 * tracegen::HASH_SLOTS * sizeof(uint32_t) : 0,
-            (const uint32_t*)d_events, n_events, height, m->d, counts, d_bad);
-    int bad = 0;
-    HIP_CHECK(hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, ctx->stream));
-    ctx->mark("trace generation");
-    ctx->end_timing(false);
-    if (bad) throw std::runtime_error("zkm_tracegen_poseidon2_permute: a state word is not a field element, or the post-state is not the permutation of the pre-state");
-  } catch (...) {
-    if (d_events) ctx->release(d_events);
-    if (d_bad) ctx->release(d_bad);
-    if (m->d) ctx->release(m->d);
-    delete m;
-    throw;
-  }
-  ctx->release(d_events);
-  ctx->release(d_bad);
-  *out = m;
-  API_END
-}
-
-int zkm_tracegen_exp_reverse_bits(zkm_ctx* ctx, const uint32_t* bases, const uint32_t* bits, const uint32_t* offsets, size_t n_events,
-                                  int fixed_log2_rows, zkm_matrix** out) {
-  API_BEGIN
-  std::lock_guard<std::mutex> lk(ctx->mu);
-  HIP_CHECK(hipSetDevice(ctx->device));
-  if (n_events && (!bases || !bits || !offsets)) throw std::runtime_error("zkm_tracegen_exp_reverse_bits: null events");
-  const size_t rows = n_events ? offsets[n_events] : 0;
-  for (size_t e = 0; e < n_events; e++)
-    if (offsets[e + 1] < offsets[e]) throw std::runtime_error("zkm_tracegen_exp_reverse_bits: offsets must not decrease");
-  const size_t height = padded_trace_rows(rows, fixed_log2_rows, "zkm_tracegen_exp_reverse_bits");
-  ctx->begin_call();
-  zkm_matrix* m = new zkm_matrix();
-  m->h = height; m->w = tracegen::EXP_REVERSE_BITS_WIDTH;
-  uint32_t *d_bases = nullptr, *d_bits = nullptr, *d_off = nullptr;
-  try {
-    m->d = ctx->alloc_n<uint32_t>(height * m->w);
-    HIP_CHECK(hipMemsetAsync(m->d, 0, height * m->w * 4, ctx->stream));
-    d_bases = ctx->alloc_n<uint32_t>(std::max<size_t>(n_events, 1));
-    d_bits = ctx->alloc_n<uint32_t>(std::max<size_t>(rows, 1));
-    d_off = ctx->alloc_n<uint32_t>(n_events + 1);
-    if (n_events) {
-      HIP_CHECK(hipMemcpyAsync(d_bases, bases, n_events * 4, hipMemcpyHostToDevice, ctx->stream));
-      if (rows) HIP_CHECK(hipMemcpyAsync(d_bits, bits, rows * 4, hipMemcpyHostToDevice, ctx->stream));
-      HIP_CHECK(hipMemcpyAsync(d_off, offsets, (n_events + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
-      hipLaunchKernelGGL(tracegen::exp_reverse_bits_rows, dim3(div_up(n_events, (size_t)256)), dim3(256), 0, ctx->stream, (const uint32_t*)d_bases,
-                         (const uint32_t*)d_bits, (const uint32_t*)d_off, n_events, height, m->d);
-      LAUNCH_CHECK();
-    }
-    HIP_CHECK(hipStreamSynchronize(ctx->stream));
-  } catch (...) {
-    for (uint32_t* p : {d_bases, d_bits, d_off, m->d})
-      if (p) ctx->release(p);
-    delete m;
-    throw;
-  }
-  ctx->release(d_bases);
-  ctx->release(d_bits);
-  ctx->release(d_off);
-  *out = m;
-  API_END
-}
-
-int zkm_tracegen_poseidon2_skinny(zkm_ctx* ctx, const uint32_t* events, size_t n_events, int fixed_log2_rows, zkm_matrix** out) {
-  API_BEGIN
-  std::lock_guard<std::mutex> lk(ctx->mu);
-  HIP_CHECK(hipSetDevice(ctx->device));
-  if (n_events && !events) throw std::runtime_error("zkm_tracegen_poseidon2_skinny: null events");
-  const size_t height = padded_trace_rows(n_events * tracegen::SKINNY_ROWS, fixed_log2_rows, "zkm_tracegen_poseidon2_skinny");
-  ctx->begin_timing();
-  zkm_matrix* m = new zkm_matrix();
-  m->h = height; m->w = tracegen::SKINNY_WIDTH;
-  uint32_t* d_events = nullptr;
-  try {
-    m->d = ctx->alloc_n<uint32_t>(height * m->w);
-    HIP_CHECK(hipMemsetAsync(m->d, 0, height * m->w * 4, ctx->stream));
-    d_events = (uint32_t*)ctx->alloc(std::max<size_t>(n_events * 128, 4));
-    if (n_events) {
-      HIP_CHECK(hipMemcpyAsync(d_events, events, n_events * 128, hipMemcpyHostToDevice, ctx->stream));
-      KLAUNCH(ctx, "tracegen_poseidon2_skinny", 128.0 * n_events + 4.0 * n_events * tracegen::SKINNY_ROWS * tracegen::SKINNY_WIDTH,
-              tracegen::poseidon2_skinny_rows, dim3(div_up(n_events, (size_t)tracegen::THREADS)), dim3(tracegen::THREADS), 0,
-              (const uint32_t*)d_events, n_events, height, m->d);
-    }
-    ctx->mark("trace generation");
-    ctx->end_timing(false);
-  } catch (...) {
-    if (d_events) ctx->release(d_events);
-    if (m->d) ctx->release(m->d);
-    delete m;
-    throw;
-  }
-  ctx->release(d_events);
-  *out = m;
-  API_END
-}
-
-int zkm_tracegen_byte_table(zkm_ctx* ctx, zkm_matrix** out) {
-  API_BEGIN
-  std::lock_guard<std::mutex> lk(ctx->mu);
-  HIP_CHECK(hipSetDevice(ctx->device));
-  ctx->begin_call();
-  zkm_matrix* m = new zkm_matrix();
-  m->h = tracegen::BYTE_ROWS; m->w = tracegen::BYTE_PREP_COLS;
-  try {
-    m->d = ctx->alloc_n<uint32_t>(m->h * m->w);
-    hipLaunchKernelGGL(tracegen::byte_table, dim3(tracegen::BYTE_ROWS / 256), dim3(256), 0, ctx->stream, m->d);
-    LAUNCH_CHECK();
-    HIP_CHECK(hipStreamSynchronize(ctx->stream));
-  } catch (...) {
-    if (m->d) ctx->release(m->d);
-    delete m;
-    throw;
-  }
-  *out = m;
-  API_END
-}
-
-int zkm_byte_lookups_create(zkm_ctx* ctx, zkm_byte_lookups** out) {
-  API_BEGIN
-  std::lock_guard<std::mutex> lk(ctx->mu);
-  HIP_CHECK(hipSetDevice(ctx->device));
-  const size_t cells = (size_t)tracegen::BYTE_ROWS * tracegen::NUM_BYTE_OPS;
-  zkm_byte_lookups* b = new zkm_byte_lookups();
-  try {
-    b->counts = ctx->alloc_n<uint32_t>(cells);
-    HIP_CHECK(hipMemsetAsync(b->counts, 0, cells * 4, ctx->stream));
-  } catch (...) {
-    delete b;
-    throw;
-  }
-  *out = b;
-  API_END
-}
-void zkm_byte_lookups_free(zkm_ctx* ctx, zkm_byte_lookups* b) {
-  if (!b) return;
-  std::lock_guard<std::mutex> lk(ctx->mu);
-  ctx->release(b->counts);
-  delete b;
-}
-
-int zkm_tracegen_byte_mults(zkm_ctx* ctx, const zkm_byte_lookups* blu, const uint32_t* extra_counts, zkm_matrix** out) {
-  API_BEGIN
-  std::lock_guard<std::mutex> lk(ctx->mu);
-  HIP_CHECK(hipSetDevice(ctx->device));
-  if (!blu) throw std::runtime_error("zkm_tracegen_byte_mults: null byte lookups");
-  ctx->begin_timing();
-  const size_t cells = (size_t)tracegen::BYTE_ROWS * tracegen::NUM_BYTE_OPS;
-  zkm_matrix* m = new zkm_matrix();
-  m->h = tracegen::BYTE_ROWS; m->w = tracegen::NUM_BYTE_OPS;
-  uint32_t* d_extra = nullptr;
-  try {
-    m->d = ctx->alloc_n<uint32_t>(cells);
-    if (extra_counts) {
-      d_extra = (uint32_t*)ctx->alloc(cells * 4);
-      HIP_CHECK(hipMemcpyAsync(d_extra, extra_counts, cells * 4, hipMemcpyHostToDevice, ctx->stream));
-    }
-    hipLaunchKernelGGL(tracegen::byte_mults_finish, dim3(div_up(cells, 256)), dim3(256), 0, ctx->stream, (const uint32_t*)blu->counts,
-                       (const uint32_t*)d_extra, m->d, cells);
-    LAUNCH_CHECK();
-    ctx->mark("byte multiplicities");
-    ctx->end_timing(false);
-  } catch (...) {
-    if (d_extra) ctx->release(d_extra);
-    if (m->d) ctx->release(m->d);
-    delete m;
-    throw;
-  }
-  if (d_extra) ctx->release(d_extra);
-  *out = m;
-  API_END
-}
+#include "api_tracegen.hpp"
 
 void zkm_challenger_init(zkm_challenger* c) { memset(c, 0, sizeof *c); }
 void zkm_challenger_observe(zkm_challenger* c, const uint32_t* values, size_t n) { chal::observe_slice(c, values, n); }
