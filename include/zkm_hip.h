@@ -408,6 +408,25 @@ int zkm_tracegen_memory_global(zkm_ctx* ctx, const zkm_memory_init_finalize_even
 typedef struct zkm_poseidon2_permute_event { uint32_t shard, clk, state_addr; zkm_memory_write_record state_records[16]; } zkm_poseidon2_permute_event;
 int zkm_tracegen_poseidon2_permute(zkm_ctx* ctx, const zkm_poseidon2_permute_event* events, size_t n_events, int fixed_log2_rows,
                                    zkm_byte_lookups* blu, zkm_matrix** out);
+
+/* The KeccakSponge precompile (crates/core/machine/src/syscall/precompiles/keccak_sponge/): replaces generate_trace (trace.rs:59-100) and the
+ * byte lookups of generate_dependencies (:33-57, counted into `blu` if given). The reference's KeccakSpongeEvent
+ * (crates/core/executor/src/events/precompiles/keccak_sponge.rs:15-46) holds Vecs; across the ABI it is cut into its 36-word blocks, in
+ * order, one record per block (twenty-four trace rows each): the state after the block is xored in (xored_state_list[block_index], every
+ * u64 as low word, high word), the block's read records (their values are the input words), and — read on the call's first / last block
+ * only — the record of the input length (the word at output_addr + 64) and the sixteen output write records. The round columns are those
+ * of p3-keccak-air's generate_trace_rows (a git dependency of the reference, restated from the published crate: DESIGN.md). Fails when a
+ * call's blocks do not chain through keccak-f or its output records are not the squeezed state. */
+typedef struct zkm_keccak_sponge_block {
+  uint32_t shard, clk, input_addr, output_addr, input_len_u32s, block_index;
+  uint32_t xored_state[50];
+  zkm_memory_read_record input_read_records[36];
+  zkm_memory_read_record input_length_record;
+  zkm_memory_write_record output_write_records[16];
+} zkm_keccak_sponge_block;
+#define ZKM_KECCAK_SPONGE_WIDTH 3531
+int zkm_tracegen_keccak_sponge(zkm_ctx* ctx, const zkm_keccak_sponge_block* blocks, size_t n_blocks, int fixed_log2_rows,
+                               zkm_byte_lookups* blu, zkm_matrix** out);
 /* The MiscInstrs chip (crates/core/machine/src/misc/others/: SEXT EXT INS MADDU MSUBU MADD MSUB TEQ): replaces generate_trace
  * (trace.rs:42-84), which also records the byte lookups (counted into `blu` if given). Events are the #[repr(C)] MiscEvents of
  * crates/core/executor/src/events/instr.rs:239-261 (60 bytes). 72 columns, zero padding rows. */

@@ -670,4 +670,21 @@ int orc_tracegen_poseidon2_permute(const void* events, size_t n_events, int fixe
   ORC_CATCH
 }
 
+// KeccakSponge precompile chip: KeccakSpongeEvents cut into 36-word blocks (337 words each), 24 rows per block, 3531 columns
+int orc_tracegen_keccak_sponge(const void* blocks, size_t n_blocks, int fixed_log2_rows, uint32_t* out, size_t out_cap, size_t* rows,
+                               uint32_t* byte_counts) {
+  ORC_TRY
+  size_t h;
+  std::vector<uint64_t> cnt(byte_counts ? tracegen::BYTE_ROWS * tracegen::NUM_BYTE_OPS : 0, 0);
+  std::vector<F> t = tracegen::generate_keccak_sponge((const tracegen::KeccakSpongeBlock*)blocks, n_blocks, fixed_log2_rows, &h,
+                                                      byte_counts && out ? cnt.data() : nullptr);
+  *rows = h;
+  if (out) {
+    if (t.size() > out_cap) throw std::runtime_error("trace buffer too small");
+    for (size_t i = 0; i < t.size(); i++) out[i] = to_monty(t[i]);
+    for (size_t i = 0; i < cnt.size(); i++) byte_counts[i] += (uint32_t)cnt[i];
+  }
+  ORC_CATCH
+}
+
 }  // extern "C"

@@ -1368,4 +1368,152 @@ static inline std::vector<F> generate_poseidon2_permute(const Poseidon2PermuteEv
   return t;
 }
 
+
+// ---- KeccakSponge precompile chip (syscall/precompiles/keccak_sponge/): columns KeccakSpongeCols columns.rs:17-37 = the 2633 KeccakCols of
+// p3-keccak-air, thirty-six MemoryReadCols of the block (9 each), shard, clk, is_real, read_block, input_address, output_address, input_len,
+// already_absorbed_u32s, is_absorbed, receive_syscall, write_output, is_first_input_block, is_final_input_block, the fifty words of the state
+// the block is absorbed into, thirty-six XorOperations, the MemoryReadCols of the input length and sixteen MemoryWriteCols of the output:
+// 3531 columns, twenty-four rows per 36-word block (trace.rs:102-195); padding rows are the rounds of the permutation of the zero state,
+// row i carrying round i mod 24 (trace.rs:79-93).
+//
+// p3-keccak-air (git dependency github.com/ProjectZKM/Plonky3, not vendored under /root/reference: Cargo.toml:62) is restated here from the
+// published crate (columns.rs, generate.rs, constants.rs): KeccakCols = step_flags[24], export, preimage[5][5][4], a[5][5][4], c[5][64],
+// c_prime[5][64], a_prime[5][5][64], a_prime_prime[5][5][4], a_prime_prime_0_0_bits[64], a_prime_prime_prime_0_0_limbs[4], arrays indexed
+// [y][x], 16-bit limbs. Its column count is pinned by the reference's cost table (mips_costs.json: KeccakSponge 102216 = 24 x 4259, which
+// only a 2633-column KeccakCols gives), its values by Keccak-256 known answers (tests); `export` is left 0 as generate_trace_rows leaves it.
+// PARITY UNPINNED for anything else the fork may have changed in that crate.
+static const uint64_t KECCAK_RC[24] = {
+    0x0000000000000001ull, 0x0000000000008082ull, 0x800000000000808aull, 0x8000000080008000ull, 0x000000000000808bull, 0x0000000080000001ull,
+    0x8000000080008081ull, 0x8000000000008009ull, 0x000000000000008aull, 0x0000000000000088ull, 0x0000000080008009ull, 0x000000008000000aull,
+    0x000000008000808bull, 0x800000000000008bull, 0x8000000000008089ull, 0x8000000000008003ull, 0x8000000000008002ull, 0x8000000000000080ull,
+    0x000000000000800aull, 0x800000008000000aull, 0x8000000080008081ull, 0x8000000000008080ull, 0x0000000080000001ull, 0x8000000080008008ull};
+static const int KECCAK_ROT[5][5] = {{0, 36, 3, 41, 18}, {1, 44, 10, 45, 2}, {62, 6, 43, 15, 61}, {28, 55, 25, 21, 56}, {27, 20, 39, 8, 14}};   // [x][y]
+static inline uint64_t rotl64(uint64_t v, int r) { return r ? (v << r) | (v >> (64 - r)) : v; }
+enum { KC_STEP = 0, KC_EXPORT = 24, KC_PREIMAGE = 25, KC_A = 125, KC_C = 225, KC_C_PRIME = 545, KC_A_PRIME = 865, KC_A_PP = 2465, KC_A_PP_00_BITS = 2565,
+       KC_A_PPP_00 = 2629, NUM_KECCAK_COLS = 2633 };
+// One round of keccak-f[1600] on a[y * 5 + x], writing the round's KeccakCols at r (generate_trace_row_for_round); returns with `a` = the next round's input.
+static inline void keccak_round_cols(uint64_t a[25], const uint64_t preimage[25], int round, F* r) {
+  r[KC_STEP + round] = 1;
+  for (int i = 0; i < 25; i++)
+    for (int l = 0; l < 4; l++) {
+      r[KC_PREIMAGE + 4 * i + l] = (preimage[i] >> (16 * l)) & 0xffff;
+      r[KC_A + 4 * i + l] = (a[i] >> (16 * l)) & 0xffff;
+    }
+  uint64_t c[5], cp[5], ap[25], app[25];
+  for (int x = 0; x < 5; x++) c[x] = a[x] ^ a[5 + x] ^ a[10 + x] ^ a[15 + x] ^ a[20 + x];
+  for (int x = 0; x < 5; x++) {
+    const uint64_t d = c[(x + 4) % 5] ^ rotl64(c[(x + 1) % 5], 1);     // bit z of rotl(c, 1) is bit z - 1 of c
+    cp[x] = c[x] ^ d;
+    for (int y = 0; y < 5; y++) ap[5 * y + x] = a[5 * y + x] ^ d;
+  }
+  for (int x = 0; x < 5; x++)
+    for (int z = 0; z < 64; z++) {
+      r[KC_C + 64 * x + z] = (c[x] >> z) & 1;
+      r[KC_C_PRIME + 64 * x + z] = (cp[x] >> z) & 1;
+    }
+  for (int i = 0; i < 25; i++)
+    for (int z = 0; z < 64; z++) r[KC_A_PRIME + 64 * i + z] = (ap[i] >> z) & 1;
+  // B[x, y] = rotl(A'[(x + 3y) mod 5, x], R[(x + 3y) mod 5][x]);  A''[x, y] = B[x, y] ^ (~B[x + 1, y] & B[x + 2, y])
+  auto b = [&](int x, int y) { const int xa = (x + 3 * y) % 5; return rotl64(ap[5 * x + xa], KECCAK_ROT[xa][x]); };
+  for (int y = 0; y < 5; y++)
+    for (int x = 0; x < 5; x++) app[5 * y + x] = b(x, y) ^ (~b((x + 1) % 5, y) & b((x + 2) % 5, y));
+  for (int i = 0; i < 25; i++)
+    for (int l = 0; l < 4; l++) r[KC_A_PP + 4 * i + l] = (app[i] >> (16 * l)) & 0xffff;
+  for (int z = 0; z < 64; z++) r[KC_A_PP_00_BITS + z] = (app[0] >> z) & 1;
+  app[0] ^= KECCAK_RC[round];
+  for (int l = 0; l < 4; l++) r[KC_A_PPP_00 + l] = (app[0] >> (16 * l)) & 0xffff;
+  for (int i = 0; i < 25; i++) a[i] = app[i];
+}
+// One 36-word block of a KeccakSpongeEvent (crates/core/executor/src/events/precompiles/keccak_sponge.rs:15-46), the event's Vecs cut per
+// block for the C ABI: the state after the block is xored in (xored_state_list[block_index] as u32 pairs), the block's read records
+// (their values are the input words), and — used on the first / last block only — the record of the input length and the output writes.
+struct KeccakSpongeBlock {
+  uint32_t shard, clk, input_addr, output_addr, input_len_u32s, block_index;
+  uint32_t xored_state[50];
+  MemoryReadRecord input_read_records[36];
+  MemoryReadRecord input_length_record;
+  MemoryWriteRecord output_write_records[16];
+};
+static_assert(sizeof(KeccakSpongeBlock) == 4 * 337, "flattened KeccakSpongeEvent block is 337 words");
+static const size_t KECCAK_SPONGE_WIDTH = 3531;
+static inline std::vector<F> generate_keccak_sponge(const KeccakSpongeBlock* blocks, size_t n_blocks, int fixed_log2_rows, size_t* height,
+                                                    uint64_t* byte_counts) {
+  enum { BLOCK_MEM = 2633, SHARD = 2957, CLK = 2958, IS_REAL = 2959, READ_BLOCK = 2960, INPUT_ADDRESS = 2961, OUTPUT_ADDRESS = 2962, INPUT_LEN = 2963,
+         ALREADY_ABSORBED = 2964, IS_ABSORBED = 2965, RECEIVE_SYSCALL = 2966, WRITE_OUTPUT = 2967, IS_FIRST = 2968, IS_FINAL = 2969, ORIGINAL_STATE = 2970,
+         XORED_RATE = 3170, INPUT_LENGTH_MEM = 3314, OUTPUT_MEM = 3323 };
+  static_assert(OUTPUT_MEM + 16 * 13 == 3531, "layout");
+  const size_t h = padded_rows(24 * n_blocks, fixed_log2_rows);
+  std::vector<F> t(h * KECCAK_SPONGE_WIDTH, 0);
+  std::vector<ByteLookup> lk;
+  for (size_t k = 0; k < n_blocks; k++) {
+    const KeccakSpongeBlock& e = blocks[k];
+    if (e.input_len_u32s == 0 || e.input_len_u32s % 36 != 0 || e.block_index >= e.input_len_u32s / 36)
+      throw std::runtime_error("tracegen: KeccakSponge block index / input length");
+    const uint32_t n_ev_blocks = e.input_len_u32s / 36;
+    const bool first = e.block_index == 0, final = e.block_index == n_ev_blocks - 1;
+    uint32_t before[50];                      // the state the block is absorbed into
+    for (int j = 0; j < 50; j++) before[j] = e.xored_state[j] ^ (j < 36 ? e.input_read_records[j].value : 0u);
+    if (first)
+      for (int j = 0; j < 50; j++)
+        if (before[j]) throw std::runtime_error("tracegen: KeccakSponge first block is not absorbed into the zero state");
+    if (first && e.input_length_record.value != e.input_len_u32s) throw std::runtime_error("tracegen: KeccakSponge input length record");
+    uint64_t a[25], pre[25];
+    for (int i = 0; i < 25; i++) a[i] = pre[i] = (uint64_t)e.xored_state[2 * i] | ((uint64_t)e.xored_state[2 * i + 1] << 32);
+    for (int round = 0; round < 24; round++) {
+      F* r = t.data() + (24 * k + round) * KECCAK_SPONGE_WIDTH;
+      keccak_round_cols(a, pre, round, r);
+      r[SHARD] = fu32(e.shard); r[CLK] = fu32(e.clk); r[IS_REAL] = 1;
+      r[INPUT_LEN] = fu32(e.input_len_u32s);
+      r[ALREADY_ABSORBED] = fu32(36 * e.block_index);
+      r[IS_ABSORBED] = round == 23 && !final;
+      r[IS_FIRST] = first; r[IS_FINAL] = final;
+      r[READ_BLOCK] = round == 0;
+      r[RECEIVE_SYSCALL] = first && round == 0;
+      r[WRITE_OUTPUT] = final && round == 23;
+      r[OUTPUT_ADDRESS] = fu32(e.output_addr);
+      r[INPUT_ADDRESS] = fu32(e.input_addr + e.block_index * 144);
+      for (int j = 0; j < 50; j++) word(r + ORIGINAL_STATE + 4 * j, before[j]);
+      if (round == 0)
+        for (int j = 0; j < 36; j++) {
+          const MemoryReadRecord& m = e.input_read_records[j];
+          memory_access_cols(m.value, m.shard, m.timestamp, m.prev_shard, m.prev_timestamp, r + BLOCK_MEM + 9 * j, &lk);
+        }
+      if (round == 0)
+        for (int j = 0; j < 36; j++) {       // XorOperation::populate (operations/xor.rs:19-37)
+          word(r + XORED_RATE + 4 * j, e.xored_state[j]);
+          for (int b = 0; b < 4; b++) lk.push_back(ByteLookup{B_XOR, (uint8_t)(before[j] >> (8 * b)), (uint8_t)(e.input_read_records[j].value >> (8 * b))});
+        }
+      if (first && round == 0) {
+        const MemoryReadRecord& m = e.input_length_record;
+        memory_access_cols(m.value, m.shard, m.timestamp, m.prev_shard, m.prev_timestamp, r + INPUT_LENGTH_MEM, &lk);
+      }
+      if (final && round == 23)
+        for (int j = 0; j < 16; j++) {
+          if (e.output_write_records[j].value != (uint32_t)(a[j / 2] >> (32 * (j & 1)))) throw std::runtime_error("tracegen: KeccakSponge output is not the squeezed state");
+          memory_write_cols(e.output_write_records[j], r + OUTPUT_MEM + 13 * j, &lk);
+        }
+    }
+    if (!final) {      // the next block of the event follows and is absorbed into this block's permuted state
+      if (k + 1 >= n_blocks) throw std::runtime_error("tracegen: KeccakSponge event is cut short");
+      const KeccakSpongeBlock& nx = blocks[k + 1];
+      bool ok = nx.block_index == e.block_index + 1 && nx.input_len_u32s == e.input_len_u32s && nx.shard == e.shard && nx.clk == e.clk;
+      for (int j = 0; j < 50 && ok; j++)
+        ok = (nx.xored_state[j] ^ (j < 36 ? nx.input_read_records[j].value : 0u)) == (uint32_t)(a[j / 2] >> (32 * (j & 1)));
+      if (!ok) throw std::runtime_error("tracegen: KeccakSponge blocks of one event do not chain");
+    }
+  }
+  const uint64_t zero[25] = {0};
+  std::vector<F> dummy(24 * NUM_KECCAK_COLS, 0);
+  {
+    uint64_t a[25] = {0};
+    for (int round = 0; round < 24; round++) keccak_round_cols(a, zero, round, dummy.data() + round * NUM_KECCAK_COLS);
+  }
+  for (size_t i = 24 * n_blocks; i < h; i++)
+    std::copy(dummy.begin() + (i % 24) * NUM_KECCAK_COLS, dummy.begin() + (i % 24 + 1) * NUM_KECCAK_COLS, t.begin() + i * KECCAK_SPONGE_WIDTH);
+  if (byte_counts)
+    for (const ByteLookup& b : lk) byte_counts[((size_t)b.b * 256 + b.c) * NUM_BYTE_OPS + b.op]++;
+  *height = h;
+  return t;
+}
+
 }  // namespace tracegen

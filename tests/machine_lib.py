@@ -76,7 +76,8 @@ class Oracle:
         if what in fn:
             return fn[what](a[0], a[1])
         fn = {"branch": O.tracegen_branch, "memory_instrs": O.tracegen_memory_instrs, "misc_instrs": O.tracegen_misc_instrs, "mul": O.tracegen_mul,
-              "divrem": O.tracegen_divrem, "global": O.tracegen_global, "poseidon2_permute": O.tracegen_poseidon2_permute}
+              "divrem": O.tracegen_divrem, "global": O.tracegen_global, "poseidon2_permute": O.tracegen_poseidon2_permute,
+              "keccak_sponge": O.tracegen_keccak_sponge}
         if what in fn:
             return fn[what](a[0], a[1], c)
         if what == "syscall_table":
@@ -110,7 +111,8 @@ class Device:
         if what in fn:
             return fn[what](a[0], a[1])
         fn = {"branch": ctx.tracegen_branch, "memory_instrs": ctx.tracegen_memory_instrs, "misc_instrs": ctx.tracegen_misc_instrs, "mul": ctx.tracegen_mul,
-              "divrem": ctx.tracegen_divrem, "global": ctx.tracegen_global, "poseidon2_permute": ctx.tracegen_poseidon2_permute}
+              "divrem": ctx.tracegen_divrem, "global": ctx.tracegen_global, "poseidon2_permute": ctx.tracegen_poseidon2_permute,
+              "keccak_sponge": ctx.tracegen_keccak_sponge}
         if what in fn:
             return fn[what](a[0], a[1], blu)
         if what == "syscall_table":
@@ -165,8 +167,12 @@ def build_shard(src, machine, k):
         lh = log2_rows(len(rec.precompile_syscall))
         add(chips.record_syscall_table_chip(True, lh), src.trace("syscall_table", rec.precompile_syscall, True, lh))
         glob.append(syscall_global_events(rec.precompile_syscall, True))
-        lh = log2_rows(len(rec.poseidon2_permute))
-        add(chips.record_poseidon2_permute_chip(lh), src.trace("poseidon2_permute", rec.poseidon2_permute, lh))
+        if len(rec.poseidon2_permute):
+            lh = log2_rows(len(rec.poseidon2_permute))
+            add(chips.record_poseidon2_permute_chip(lh), src.trace("poseidon2_permute", rec.poseidon2_permute, lh))
+        if len(rec.keccak_sponge):
+            lh = log2_rows(24 * len(rec.keccak_sponge))
+            add(chips.record_keccak_sponge_chip(lh), src.trace("keccak_sponge", rec.keccak_sponge, lh))
     else:
         for finalize, ev, prev in ((False, rec.memory_init, sh.pv["previous_init_addr"]), (True, rec.memory_finalize, sh.pv["previous_finalize_addr"])):
             if len(ev):

@@ -378,6 +378,15 @@ def tracegen_poseidon2_permute(events, fixed_log2_rows=-1, byte_counts=None):
                            C.c_int(fixed_log2_rows), tail=bc)
 
 
+def tracegen_keccak_sponge(blocks, fixed_log2_rows=-1, byte_counts=None):
+    """KeccakSponge precompile rows from KeccakSpongeEvents cut into 36-word blocks (events.KECCAK_SPONGE_BLOCK), 24 rows per block."""
+    from ziren_amd import events as E
+    ev = np.ascontiguousarray(blocks, dtype=E.KECCAK_SPONGE_BLOCK)
+    bc = (abi.as_u32p(byte_counts),) if byte_counts is not None else (None,)
+    return _rows_then_fill(lib().orc_tracegen_keccak_sponge, E.KECCAK_SPONGE_WIDTH, C.c_void_p(ev.ctypes.data), C.c_size_t(len(ev)),
+                           C.c_int(fixed_log2_rows), tail=bc)
+
+
 def septic_known_answers(a, b):
     """((z^i)^p, (z^i)^(p^2) for i = 1..6, a * b, normalised sqrt(a^2)) in the septic extension, canonical words."""
     a = np.ascontiguousarray(a, dtype=np.uint32)

@@ -48,7 +48,7 @@ def main():
             d = prover.pcs_commit(ctx, [dm], 1)
             wall.append((time.perf_counter() - t0) * 1e3)
             lde_ms.append(kernel_ms(ctx, ["lde_rows", "lde_cols_inverse", "lde_cols_forward"]))
-            tree_ms.append(kernel_ms(ctx, ["hash_leaves", "compress_layer", "compress_small", "compress_tail"]))
+            tree_ms.append(kernel_ms(ctx, ["hash_leaves", "hash_leaves_tree", "compress_layer", "compress_small", "compress_tail"]))
             d.free()
         lde, tree = float(np.median(lde_ms[1:])), float(np.median(tree_ms[1:]))
         lde_bytes, tree_bytes = 12.0 * n * w, 8.0 * n * w + 128.0 * n

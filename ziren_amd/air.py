@@ -267,9 +267,34 @@ class AirBuilder:
 
     # --- emission ------------------------------------------------------------------------------
     def assemble(self) -> np.ndarray:
-        """Emit the `program` blob: header {n_instr, n_ext_regs, n_constraints, n_base_regs} + 2 words/instr."""
+        """Emit the `program` blob: header {n_instr, n_ext_regs, n_constraints, n_base_regs} + 2 words/instr. A value is computed once and
+        kept in its register until its last use. When that needs more than the 256 registers an instruction can name (a chip whose columns
+        are each read by constraints far apart: KeccakSponge), the inputs are loaded again at every use instead of being kept."""
+        try:
+            return self._assemble(False)
+        except ValueError:
+            return self._assemble(True)
+
+    def _assemble(self, reload_inputs: bool) -> np.ndarray:
         # use counts over the whole DAG (each node evaluated once)
         seen = set()
+
+        def reset(e):
+            stack = [e]
+            while stack:
+                x = stack.pop()
+                if id(x) in seen:
+                    continue
+                seen.add(id(x))
+                x.uses, x.reg = 0, None
+                if x.op >= ADD_B:
+                    stack.append(x.a)
+                    if x.c is not None:
+                        stack.append(x.c)
+
+        for a in self.asserts:
+            reset(a)
+        seen.clear()
 
         def count(e):
             stack = [e]
@@ -299,11 +324,22 @@ class AirBuilder:
                 raise ValueError("constraint program needs more than 256 registers")
             return r
 
+        def is_input(x):
+            return x.op < ADD_B
+
         def release(x):
             x.uses -= 1
-            if x.uses == 0:
+            if reload_inputs and is_input(x):
+                if x.reg is not None:
+                    free[x.ext].append(x.reg)
+                    x.reg = None
+            elif x.uses == 0:
                 free[x.ext].append(x.reg)
                 x.reg = None
+
+        def load(x):
+            x.reg = alloc(x.ext)
+            instrs.append((x.op | x.reg << 8 | (x.a & 0xFF) << 16, x.imm))
 
         def emit(e):
             # iterative post-order
@@ -312,17 +348,21 @@ class AirBuilder:
                 x, ready = stack.pop()
                 if x.reg is not None:
                     continue
-                if x.op < ADD_B:
-                    x.reg = alloc(x.ext)
-                    instrs.append((x.op | x.reg << 8 | (x.a & 0xFF) << 16, x.imm))
+                if is_input(x):
+                    if not reload_inputs or x is e:
+                        load(x)
                     continue
                 if not ready:
                     stack.append((x, True))
-                    if x.c is not None and x.c.reg is None:
+                    if x.c is not None and x.c.reg is None and not (reload_inputs and is_input(x.c)):
                         stack.append((x.c, False))
-                    if x.a.reg is None:
+                    if x.a.reg is None and not (reload_inputs and is_input(x.a)):
                         stack.append((x.a, False))
                     continue
+                if reload_inputs:       # inputs are loaded right where they are consumed
+                    for ch in (x.a, x.c):
+                        if ch is not None and is_input(ch) and ch.reg is None:
+                            load(ch)
                 ra = x.a.reg
                 rc = x.c.reg if x.c is not None else 0
                 release(x.a)
@@ -434,10 +474,8 @@ def count_permutation_constraints(n_lookups, batch_size, commit_scope_global):
     return c
 
 
-def debug_constraints(b: "AirBuilder", main: np.ndarray, public_values=None, prep: np.ndarray = None) -> List[Tuple[int, int]]:
-    """Evaluate the recorded base-field constraints on every row of a trace (canonical values, row-major),
-    row i against row (i + 1) mod n as crates/stark/src/debug.rs:30-120 does. Returns [(constraint, first failing
-    row)]; empty when the trace satisfies the AIR. Extension-field (permutation) constraints are not covered."""
+def _constraint_values(b: "AirBuilder", main: np.ndarray, public_values=None, prep: np.ndarray = None):
+    """Yield (k, values over the rows) for every recorded base-field constraint k; row i is evaluated against row (i + 1) mod n."""
     n = main.shape[0]
     cols = [main[:, c].astype(np.uint64) for c in range(main.shape[1])]
     nxt = [np.roll(c, -1) for c in cols]
@@ -453,10 +491,10 @@ def debug_constraints(b: "AirBuilder", main: np.ndarray, public_values=None, pre
         if x.ext:
             raise ValueError("extension-field expression")
         if x.op == LD_MAIN:
-            v = (nxt if x.a else cols)[x.imm]
-        elif x.op == LD_PREP:
-            v = (pnxt if x.a else pcols)[x.imm]
-        elif x.op == LD_CONST:
+            return (nxt if x.a else cols)[x.imm]
+        if x.op == LD_PREP:
+            return (pnxt if x.a else pcols)[x.imm]
+        if x.op == LD_CONST:
             v = np.full(n, int(F.from_monty(np.uint32(x.imm))), dtype=np.uint64)
         elif x.op == LD_PV:
             v = np.full(n, int(public_values[x.imm]), dtype=np.uint64)
@@ -481,12 +519,29 @@ def debug_constraints(b: "AirBuilder", main: np.ndarray, public_values=None, pre
 
     import sys
     sys.setrecursionlimit(max(sys.getrecursionlimit(), 20000))
-    bad = []
     for k, a in enumerate(b.asserts):
         if a.ext:
             continue
-        v = ev(a)
+        yield k, ev(a)
+        if len(memo) * n * 8 > (1 << 30):     # values shared between constraints are kept, up to a gigabyte of them
+            memo.clear()
+
+
+def debug_constraints(b: "AirBuilder", main: np.ndarray, public_values=None, prep: np.ndarray = None) -> List[Tuple[int, int]]:
+    """Evaluate the recorded base-field constraints on every row of a trace (canonical values, row-major),
+    row i against row (i + 1) mod n as crates/stark/src/debug.rs:30-120 does. Returns [(constraint, first failing
+    row)]; empty when the trace satisfies the AIR. Extension-field (permutation) constraints are not covered."""
+    bad = []
+    for k, v in _constraint_values(b, main, public_values, prep):
         nz = np.nonzero(v)[0]
         if len(nz):
             bad.append((k, int(nz[0])))
     return bad
+
+
+def violated_rows(b: "AirBuilder", main: np.ndarray, public_values=None, prep: np.ndarray = None) -> np.ndarray:
+    """Per row: does any recorded base-field constraint fail there (the row as `local`, the next one as `next`)."""
+    out = np.zeros(main.shape[0], dtype=bool)
+    for _, v in _constraint_values(b, main, public_values, prep):
+        out |= v != 0
+    return out

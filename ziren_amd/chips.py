@@ -1552,6 +1552,159 @@ def _poseidon2_permute(r: _Rec):
                                  air.to_virtual_pair(is_real), air.KIND_SYSCALL))
 
 
+def _keccak_air(b, l, n):
+    """KeccakAir::eval of p3-keccak-air on the first 2633 columns, as SubAirBuilder hands them over (keccak_sponge/air.rs:121-124). The crate
+    is a git dependency that is not under /root/reference (Cargo.toml:62); this restates its published air.rs / round_flags.rs / columns.rs:
+    one row per round of keccak-f[1600], the state in 16-bit limbs, theta through the bits of C / C1 / A1 (the crate's c, c_prime, a_prime),
+    rho and pi as an index map into A1 (`b`), chi into A2 (a_prime_prime), iota on the bits of A2[0][0]; arrays are indexed [y][x]."""
+    STEP, EXPORT, PRE, A, C, CP, AP, APP, APP00, APPP00 = 0, 24, 25, 125, 225, 545, 865, 2465, 2565, 2629
+    xor = lambda x, y: x + y - x * y * 2                   # noqa: E731
+    xor3 = lambda x, y, z: xor(x, xor(y, z))               # noqa: E731
+    # round_flags.rs: step 0 on the first row, then the flags rotate
+    b.when_first_row().assert_one(l[STEP])
+    for i in range(1, 24):
+        b.when_first_row().assert_zero(l[STEP + i])
+    for i in range(24):
+        b.when_transition().assert_eq(n[STEP + (i + 1) % 24], l[STEP + i])
+    first_step, final_step = l[STEP], l[STEP + 23]
+    not_final = 1 - final_step
+    for i in range(100):                                   # on the first step the input is the preimage
+        b.when(first_step).assert_eq(l[PRE + i], l[A + i])
+    for i in range(100):                                   # the preimage stays while the permutation runs
+        b.when(not_final).when(b.is_transition()).assert_eq(l[PRE + i], n[PRE + i])
+    b.assert_bool(l[EXPORT])
+    b.when(not_final).assert_zero(l[EXPORT])
+    # C1[x, z] = C[x, z] ^ C[x - 1, z] ^ C[x + 1, z - 1]
+    for x in range(5):
+        for z in range(64):
+            b.assert_bool(l[C + 64 * x + z])
+            b.assert_eq(l[CP + 64 * x + z], xor3(l[C + 64 * x + z], l[C + 64 * ((x + 4) % 5) + z], l[C + 64 * ((x + 1) % 5) + (z + 63) % 64]))
+    # A[x, y, z] = A1[x, y, z] ^ C[x, z] ^ C1[x, z], limb by limb
+    for y in range(5):
+        for x in range(5):
+            for limb in range(4):
+                acc = b.const(0)
+                for z in reversed(range(16 * limb, 16 * limb + 16)):
+                    bit = l[AP + 64 * (5 * y + x) + z]
+                    b.assert_bool(bit)
+                    acc = acc * 2 + xor3(bit, l[C + 64 * x + z], l[CP + 64 * x + z])
+                b.assert_eq(acc, l[A + 4 * (5 * y + x) + limb])
+    # the column parity of A1 is C1: sum - C1 is 0, 2 or 4
+    for x in range(5):
+        for z in range(64):
+            total = l[AP + 64 * x + z]
+            for y in range(1, 5):
+                total = total + l[AP + 64 * (5 * y + x) + z]
+            diff = total - l[CP + 64 * x + z]
+            b.assert_zero(diff * (diff - 2) * (diff - 4))
+
+    def rho_pi(x, y, z):          # KeccakCols::b: B[x, y] = rot(A1[(x + 3y) mod 5, x], R[(x + 3y) mod 5][x])
+        xa = (x + 3 * y) % 5
+        return l[AP + 64 * (5 * x + xa) + (z + 64 - E.KECCAK_ROT[xa][x]) % 64]
+
+    # A2[x, y] = B[x, y] ^ (~B[x + 1, y] & B[x + 2, y])
+    for y in range(5):
+        for x in range(5):
+            for limb in range(4):
+                acc = b.const(0)
+                for z in reversed(range(16 * limb, 16 * limb + 16)):
+                    acc = acc * 2 + xor(rho_pi(x, y, z), (1 - rho_pi((x + 1) % 5, y, z)) * rho_pi((x + 2) % 5, y, z))
+                b.assert_eq(acc, l[APP + 4 * (5 * y + x) + limb])
+    # A3[0, 0] = A2[0, 0] ^ RC: the bits of A2[0][0], then the round constant chosen by the step flags
+    for limb in range(4):
+        acc = b.const(0)
+        for z in reversed(range(16 * limb, 16 * limb + 16)):
+            b.assert_bool(l[APP00 + z])
+            acc = acc * 2 + l[APP00 + z]
+        b.assert_eq(acc, l[APP + limb])
+    for limb in range(4):
+        acc = b.const(0)
+        for z in reversed(range(16 * limb, 16 * limb + 16)):
+            rc_bit = b.const(0)
+            for rd in range(24):
+                rc_bit = rc_bit + l[STEP + rd] * ((E.KECCAK_RC[rd] >> z) & 1)
+            acc = acc * 2 + xor(l[APP00 + z], rc_bit)
+        b.assert_eq(acc, l[APPP00 + limb])
+    # this round's output is the next round's input
+    for x in range(5):
+        for y in range(5):
+            for limb in range(4):
+                out = l[APPP00 + limb] if x == 0 and y == 0 else l[APP + 4 * (5 * y + x) + limb]
+                b.when(b.is_transition()).when(not_final).assert_eq(out, n[A + 4 * (5 * y + x) + limb])
+
+
+def _keccak_sponge(r: _Rec):
+    """KeccakSpongeChip::eval (syscall/precompiles/keccak_sponge/air.rs:27-285): twenty-four rows per 36-word block; the block is read and
+    xored into the running state on the first of them, the permuted state is handed to the next block (is_absorbed) or written out
+    (write_output) on the last."""
+    l, n, b = r.local, r.next, r.b
+    NK = E.NUM_KECCAK_COLS
+    (BLOCK_MEM, SHARD, CLK, IS_REAL, READ_BLOCK, INPUT_ADDRESS, OUTPUT_ADDRESS, INPUT_LEN, ALREADY_ABSORBED, IS_ABSORBED, RECEIVE_SYSCALL, WRITE_OUTPUT,
+     IS_FIRST, IS_FINAL, ORIGINAL_STATE, XORED_RATE, INPUT_LENGTH_MEM, OUTPUT_MEM) = (NK, 2957, 2958, 2959, 2960, 2961, 2962, 2963, 2964, 2965, 2966,
+                                                                                      2967, 2968, 2969, 2970, 3170, 3314, 3323)
+    STEP, A, APP, APPP00 = 0, 125, 2465, 2629
+    is_real, first_block, final_block = l[IS_REAL], l[IS_FIRST], l[IS_FINAL]
+    first_step, final_step = l[STEP], l[STEP + 23]
+    not_final_step = 1 - final_step
+    not_final_sponge = 1 - l[WRITE_OUTPUT]
+    block_mem = [l[BLOCK_MEM + 9 * i:BLOCK_MEM + 9 * i + 9] for i in range(36)]
+    output_mem = [l[OUTPUT_MEM + 13 * i:OUTPUT_MEM + 13 * i + 13] for i in range(16)]
+    length_mem = l[INPUT_LENGTH_MEM:INPUT_LENGTH_MEM + 9]
+    # eval_flags (:126-145)
+    b.assert_eq(first_block * first_step * is_real, l[RECEIVE_SYSCALL])
+    b.assert_eq(final_block * final_step * is_real, l[WRITE_OUTPUT])
+    b.assert_eq(l[IS_ABSORBED], final_step * (1 - final_block) * is_real)
+    # eval_memory_access (:147-192); MemoryReadCols::prev_value is its value (memory/consistency/columns.rs:77-79), so "the input has not
+    # changed" compares a word with itself: constraints that are identically zero but still take their place in the random combination
+    r.eval_memory_access(l[SHARD], l[CLK], l[OUTPUT_ADDRESS] + 64, length_mem[0:4], length_mem, l[RECEIVE_SYSCALL])
+    for k in range(4):
+        b.when(is_real).assert_eq(length_mem[k], length_mem[k])
+    for i in range(36):
+        r.eval_memory_access(l[SHARD], l[CLK], l[INPUT_ADDRESS] + 4 * i, block_mem[i][0:4], block_mem[i], l[READ_BLOCK])
+    for i in range(36):
+        for k in range(4):
+            b.when(is_real).assert_eq(block_mem[i][k], block_mem[i][k])
+    for i in range(16):
+        r.eval_memory_access(l[SHARD], l[CLK] + 1, l[OUTPUT_ADDRESS] + 4 * i, output_mem[i][0:4], output_mem[i][4:13], l[WRITE_OUTPUT])
+
+    # eval_state_keccakf (:193-284): memory words against the permutation's 16-bit limbs
+    def limbs(lo, hi):
+        return [lo[0] + lo[1] * 256, lo[2] + lo[3] * 256, hi[0] + hi[1] * 256, hi[2] + hi[3] * 256]
+
+    def word_cols(row, base, i):
+        return row[base + 4 * i:base + 4 * i + 4]
+
+    def appp(i, j):
+        return l[APPP00 + j] if i == 0 else l[APP + 4 * i + j]
+
+    for i in range(25):
+        src = XORED_RATE if i < 18 else ORIGINAL_STATE      # the rate part after the block is xored in, the capacity part as it was
+        mem = limbs(word_cols(l, src, 2 * i), word_cols(l, src, 2 * i + 1))
+        for j in range(4):
+            b.when(first_step * is_real).assert_eq(mem[j], l[A + 4 * i + j])
+        mem = limbs(word_cols(n, ORIGINAL_STATE, 2 * i), word_cols(n, ORIGINAL_STATE, 2 * i + 1))
+        for j in range(4):
+            b.when(l[IS_ABSORBED]).assert_eq(mem[j], appp(i, j))
+    for i in range(8):
+        mem = limbs(output_mem[2 * i][4:8], output_mem[2 * i + 1][4:8])
+        for j in range(4):
+            b.when(l[WRITE_OUTPUT]).assert_eq(mem[j], appp(i, j))
+    r.receives.append(air.Lookup([air.to_virtual_pair(v) for v in [l[SHARD], l[CLK], b.const(E.SYS_KECCAK_SPONGE & 0xffff), l[INPUT_ADDRESS],
+                                                                   l[OUTPUT_ADDRESS]]], air.to_virtual_pair(l[RECEIVE_SYSCALL]), air.KIND_SYSCALL))
+    for c in (SHARD, CLK, IS_REAL, INPUT_LEN, OUTPUT_ADDRESS):       # a call's inputs stay the same down its rows
+        b.when_transition().when(not_final_sponge).assert_eq(l[c], n[c])
+    b.when_last_row().assert_zero(is_real)        # 24 is not a power of two: the table cannot end on a real row
+    for i in range(36):                           # XorOperation::eval (operations/xor.rs:39-57)
+        for k in range(4):
+            r.send_byte(B_XOR, l[XORED_RATE + 4 * i + k], l[ORIGINAL_STATE + 4 * i + k], block_mem[i][k], l[READ_BLOCK])
+    b.when_transition().when(not_final_step).assert_eq(l[ALREADY_ABSORBED], n[ALREADY_ABSORBED])
+    b.when(first_block).assert_eq(l[ALREADY_ABSORBED], b.const(0))
+    b.when(final_block).assert_eq(l[ALREADY_ABSORBED], l[INPUT_LEN] - 36)
+    b.when(l[IS_ABSORBED]).assert_eq(l[ALREADY_ABSORBED], n[ALREADY_ABSORBED] - 36)
+    b.when(l[IS_ABSORBED]).assert_eq(l[INPUT_ADDRESS], n[INPUT_ADDRESS] - 144)
+    _keccak_air(b, l, n)
+
+
 def record_memory_global_constraints(finalize: bool) -> _Rec:
     r = _Rec(E.MEMORY_GLOBAL_WIDTH)
     _memory_global(r, finalize)
@@ -1575,6 +1728,19 @@ def record_syscall_table_chip(precompile: bool, log_height: int) -> RecordedChip
     """SyscallCore / SyscallPrecompile (crates/core/machine/src/syscall/chip.rs): SyscallEvents, 11 columns, local_only is not claimed by the
     reference (MachineAir::local_only defaults to false)."""
     return _finish(record_syscall_table_constraints(precompile), "SyscallPrecompile" if precompile else "SyscallCore", log_height, E.SYSCALL_WIDTH, False)
+
+
+def record_keccak_sponge_constraints() -> _Rec:
+    r = _Rec(E.KECCAK_SPONGE_WIDTH)
+    _keccak_sponge(r)
+    return r
+
+
+def record_keccak_sponge_chip(log_height: int) -> RecordedChip:
+    """The KeccakSponge precompile (crates/core/machine/src/syscall/precompiles/keccak_sponge/): 24 rows per 36-word block of a call, 3531
+    columns (2633 of them the round columns of p3-keccak-air), constraints between consecutive rows; receives the syscall the
+    SyscallPrecompile table sends."""
+    return _finish(record_keccak_sponge_constraints(), "KeccakSponge", log_height, E.KECCAK_SPONGE_WIDTH, False)
 
 
 def record_poseidon2_permute_constraints() -> _Rec:

@@ -15,6 +15,7 @@ import hashlib
 import os
 import subprocess
 import tempfile
+from typing import Optional
 
 import numpy as np
 
@@ -138,8 +139,14 @@ extern "C" __global__ __launch_bounds__({BLOCK}) void {KERNEL_NAME}(stark::Quoti
 """
 
 
-def specialize(program: np.ndarray, force: bool = False, verbose: bool = False) -> bytes:
-    """Return the gfx950 code object for `program`, compiling it on first use (cached in-tree)."""
+MAX_SPECIALIZED_INSTRS = 40000   # straight-line code beyond this takes hipcc tens of minutes (KeccakSponge: 114 324 instructions)
+
+
+def specialize(program: np.ndarray, force: bool = False, verbose: bool = False) -> Optional[bytes]:
+    """Return the gfx950 code object for `program`, compiling it on first use (cached in-tree); None for a program too long to be worth a
+    straight-line kernel — the library's bytecode interpreter evaluates it."""
+    if int(np.asarray(program)[0]) > MAX_SPECIALIZED_INSTRS:
+        return None
     os.makedirs(CACHE, exist_ok=True)
     h = program_hash(program)
     out = os.path.join(CACHE, f"q_{h}.hsaco")

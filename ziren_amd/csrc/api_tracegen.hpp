@@ -518,6 +518,51 @@ int zkm_tracegen_poseidon2_permute(zkm_ctx* ctx, const zkm_poseidon2_permute_eve
   API_END
 }
 
+int zkm_tracegen_keccak_sponge(zkm_ctx* ctx, const zkm_keccak_sponge_block* blocks, size_t n_blocks, int fixed_log2_rows, zkm_byte_lookups* blu,
+                               zkm_matrix** out) {
+  API_BEGIN
+  static_assert(sizeof(zkm_keccak_sponge_block) == 4 * tracegen::KECCAK_SPONGE_BLOCK_WORDS, "a KeccakSpongeEvent block is 337 words");
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIP_CHECK(hipSetDevice(ctx->device));
+  if (n_blocks && !blocks) throw std::runtime_error("zkm_tracegen_keccak_sponge: null blocks");
+  const size_t height = padded_trace_rows(24 * n_blocks, fixed_log2_rows, "zkm_tracegen_keccak_sponge");
+  ctx->begin_timing();
+  zkm_matrix* m = new zkm_matrix();
+  m->h = height; m->w = tracegen::KECCAK_SPONGE_WIDTH;
+  uint32_t* d_blocks = nullptr;
+  int* d_bad = nullptr;
+  try {
+    m->d = ctx->alloc_n<uint32_t>(height * m->w);
+    const size_t ev_bytes = n_blocks * sizeof(zkm_keccak_sponge_block);
+    d_blocks = (uint32_t*)ctx->alloc(std::max<size_t>(ev_bytes, 4));
+    d_bad = (int*)ctx->alloc(4);
+    HIP_CHECK(hipMemsetAsync(d_bad, 0, 4, ctx->stream));
+    if (n_blocks) HIP_CHECK(hipMemcpyAsync(d_blocks, blocks, ev_bytes, hipMemcpyHostToDevice, ctx->stream));
+    uint32_t* counts = blu ? blu->counts : nullptr;
+    KLAUNCH(ctx, "tracegen_keccak_sponge", (double)ev_bytes + 4.0 * height * m->w, tracegen::keccak_sponge_rows,
+            dim3(div_up(height, (size_t)tracegen::THREADS)), dim3(tracegen::THREADS), counts ? 2 * tracegen::HASH_SLOTS * sizeof(uint32_t) : 0,
+            (const uint32_t*)d_blocks, n_blocks, height, m->d, counts, d_bad);
+    int bad = 0;
+    HIP_CHECK(hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, ctx->stream));
+    ctx->mark("trace generation");
+    ctx->end_timing(false);
+    static const char* const why[] = {"", "input length is not a positive multiple of 36 words, or the block index is past it",
+                                      "the first block of a call is not absorbed into the zero state", "the input length record does not hold the input length",
+                                      "the output records are not the squeezed state", "the blocks of one call do not follow each other and chain"};
+    if (bad) throw std::runtime_error(std::string("zkm_tracegen_keccak_sponge: ") + why[bad < 6 ? bad : 0]);
+  } catch (...) {
+    if (d_blocks) ctx->release(d_blocks);
+    if (d_bad) ctx->release(d_bad);
+    if (m->d) ctx->release(m->d);
+    delete m;
+    throw;
+  }
+  ctx->release(d_blocks);
+  ctx->release(d_bad);
+  *out = m;
+  API_END
+}
+
 int zkm_tracegen_exp_reverse_bits(zkm_ctx* ctx, const uint32_t* bases, const uint32_t* bits, const uint32_t* offsets, size_t n_events,
                                   int fixed_log2_rows, zkm_matrix** out) {
   API_BEGIN

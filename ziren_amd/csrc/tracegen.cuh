@@ -1253,6 +1253,196 @@ __global__ __launch_bounds__(THREADS) void poseidon2_permute_rows(const uint32_t
   }
 }
 
+// ---- KeccakSponge precompile (syscall/precompiles/keccak_sponge/: columns.rs:17-37, trace.rs:102-195): KeccakSpongeEvents cut into their
+// 36-word blocks (337 words each, include/zkm_hip.h zkm_keccak_sponge_block), twenty-four rows per block. One thread per row: it runs
+// keccak-f from the block's xored state up to its round (twelve rounds on average, a few hundred 64-bit operations each — small next to the
+// 3531 cells it then stores), and writes the round's KeccakCols (the layout of p3-keccak-air: step flags, export, preimage and A in 16-bit
+// limbs, the bits of C, C' and A', A'' in limbs, the bits of A''[0][0], A'''[0][0] in limbs) and the sponge's own columns, which are zero
+// except on a block's first row (the block is read and xored in, the call is received) and last row (the state goes on or is written out).
+// Rows past the last block are rounds of the permutation of the zero state, row i carrying round i mod 24 (trace.rs:79-93).
+constexpr int KECCAK_SPONGE_WIDTH = 3531, KECCAK_SPONGE_BLOCK_WORDS = 337, NUM_KECCAK_COLS = 2633;
+__constant__ uint64_t d_keccak_rc[24] = {
+    0x0000000000000001ull, 0x0000000000008082ull, 0x800000000000808aull, 0x8000000080008000ull, 0x000000000000808bull, 0x0000000080000001ull,
+    0x8000000080008081ull, 0x8000000000008009ull, 0x000000000000008aull, 0x0000000000000088ull, 0x0000000080008009ull, 0x000000008000000aull,
+    0x000000008000808bull, 0x800000000000008bull, 0x8000000000008089ull, 0x8000000000008003ull, 0x8000000000008002ull, 0x8000000000000080ull,
+    0x000000000000800aull, 0x800000008000000aull, 0x8000000080008081ull, 0x8000000000008080ull, 0x0000000080000001ull, 0x8000000080008008ull};
+template <int R> __device__ __forceinline__ uint64_t rotl64(uint64_t v) {
+  if constexpr (R == 0) return v;
+  else return (v << R) | (v >> (64 - R));
+}
+// rotation offsets r[x][y] of rho, as template arguments so that every rotation is by an immediate
+template <int X, int Y> struct KeccakRot {
+  static constexpr int T[5][5] = {{0, 36, 3, 41, 18}, {1, 44, 10, 45, 2}, {62, 6, 43, 15, 61}, {28, 55, 25, 21, 56}, {27, 20, 39, 8, 14}};
+  static constexpr int value = T[X][Y];
+};
+// B[x, y] = rot(A'[(x + 3y) mod 5, x], r[(x + 3y) mod 5][x]) with A' stored [y][x]
+template <int X, int Y> __device__ __forceinline__ uint64_t keccak_b(const uint64_t* ap) {
+  constexpr int XA = (X + 3 * Y) % 5;
+  return rotl64<KeccakRot<XA, X>::value>(ap[5 * X + XA]);
+}
+template <int X, int Y> __device__ __forceinline__ void keccak_chi_lane(const uint64_t* ap, uint64_t* app) {
+  app[5 * Y + X] = keccak_b<X, Y>(ap) ^ (~keccak_b<(X + 1) % 5, Y>(ap) & keccak_b<(X + 2) % 5, Y>(ap));
+}
+template <int Y> __device__ __forceinline__ void keccak_chi_row(const uint64_t* ap, uint64_t* app) {
+  keccak_chi_lane<0, Y>(ap, app); keccak_chi_lane<1, Y>(ap, app); keccak_chi_lane<2, Y>(ap, app); keccak_chi_lane<3, Y>(ap, app); keccak_chi_lane<4, Y>(ap, app);
+}
+// one round on a[5 * y + x]: c = column parities, cp = C', ap = A' (after theta), app = A'' (after chi, before iota)
+__device__ __forceinline__ void keccak_round_parts(const uint64_t* a, uint64_t* c, uint64_t* cp, uint64_t* ap, uint64_t* app) {
+#pragma unroll
+  for (int x = 0; x < 5; x++) c[x] = a[x] ^ a[5 + x] ^ a[10 + x] ^ a[15 + x] ^ a[20 + x];
+#pragma unroll
+  for (int x = 0; x < 5; x++) {
+    const uint64_t d = c[(x + 4) % 5] ^ rotl64<1>(c[(x + 1) % 5]);
+    cp[x] = c[x] ^ d;
+#pragma unroll
+    for (int y = 0; y < 5; y++) ap[5 * y + x] = a[5 * y + x] ^ d;
+  }
+  keccak_chi_row<0>(ap, app); keccak_chi_row<1>(ap, app); keccak_chi_row<2>(ap, app); keccak_chi_row<3>(ap, app); keccak_chi_row<4>(ap, app);
+}
+__global__ __launch_bounds__(THREADS) void keccak_sponge_rows(const uint32_t* __restrict__ blocks, size_t n_blocks, size_t height,
+                                                              uint32_t* __restrict__ out, uint32_t* counts, int* __restrict__ bad) {
+  enum { STEP = 0, EXPORT = 24, PREIMAGE = 25, A = 125, C = 225, C_PRIME = 545, A_PRIME = 865, A_PP = 2465, A_PP_00_BITS = 2565, A_PPP_00 = 2629,
+         BLOCK_MEM = 2633, SHARD = 2957, CLK = 2958, IS_REAL = 2959, READ_BLOCK = 2960, INPUT_ADDRESS = 2961, OUTPUT_ADDRESS = 2962, INPUT_LEN = 2963,
+         ALREADY_ABSORBED = 2964, IS_ABSORBED = 2965, RECEIVE_SYSCALL = 2966, WRITE_OUTPUT = 2967, IS_FIRST = 2968, IS_FINAL = 2969, ORIGINAL_STATE = 2970,
+         XORED_RATE = 3170, INPUT_LENGTH_MEM = 3314, OUTPUT_MEM = 3323 };
+  enum { E_SHARD = 0, E_CLK = 1, E_INPUT_ADDR = 2, E_OUTPUT_ADDR = 3, E_INPUT_LEN = 4, E_BLOCK_INDEX = 5, E_XORED = 6, E_READS = 56, E_LEN_RECORD = 236,
+         E_WRITES = 241 };
+  extern __shared__ uint32_t hash_lds[];
+  uint32_t* hkeys = hash_lds;
+  uint32_t* hvals = hash_lds + HASH_SLOTS;
+  const bool count = counts != nullptr;
+  if (count) {
+    for (int i = threadIdx.x; i < HASH_SLOTS; i += blockDim.x) { hkeys[i] = HASH_EMPTY; hvals[i] = 0; }
+    __syncthreads();
+  }
+  const size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (row < height) {
+    const size_t blk = row / 24;
+    const int round = (int)(row % 24);
+    const bool real = blk < n_blocks;
+    const uint32_t* e = blocks + blk * KECCAK_SPONGE_BLOCK_WORDS;
+    auto put = [&](int col, uint32_t monty) { out[(size_t)col * height + row] = monty; };
+    auto put_bits = [&](int col, uint64_t v) {
+      for (int z = 0; z < 64; z++) put(col + z, (v >> z) & 1 ? kb::ONE : 0u);
+    };
+    auto put_limbs = [&](int col, uint64_t v) {
+#pragma unroll
+      for (int l = 0; l < 4; l++) put(col + l, kb::to_monty((uint32_t)(v >> (16 * l)) & 0xffffu));
+    };
+    uint64_t a[25], c[5], cp[5], ap[25], app[25];
+#pragma unroll
+    for (int i = 0; i < 25; i++) a[i] = real ? (uint64_t)e[E_XORED + 2 * i] | ((uint64_t)e[E_XORED + 2 * i + 1] << 32) : 0ull;
+#pragma unroll
+    for (int i = 0; i < 25; i++) put_limbs(PREIMAGE + 4 * i, a[i]);
+    for (int r = 0; r < round; r++) {
+      keccak_round_parts(a, c, cp, ap, app);
+#pragma unroll
+      for (int i = 0; i < 25; i++) a[i] = app[i];
+      a[0] ^= d_keccak_rc[r];
+    }
+    keccak_round_parts(a, c, cp, ap, app);
+    for (int i = 0; i < 24; i++) put(STEP + i, i == round ? kb::ONE : 0u);
+    put(EXPORT, 0u);
+#pragma unroll
+    for (int i = 0; i < 25; i++) put_limbs(A + 4 * i, a[i]);
+#pragma unroll
+    for (int x = 0; x < 5; x++) { put_bits(C + 64 * x, c[x]); put_bits(C_PRIME + 64 * x, cp[x]); }
+#pragma unroll
+    for (int i = 0; i < 25; i++) put_bits(A_PRIME + 64 * i, ap[i]);
+#pragma unroll
+    for (int i = 0; i < 25; i++) put_limbs(A_PP + 4 * i, app[i]);
+    put_bits(A_PP_00_BITS, app[0]);
+    const uint64_t out00 = app[0] ^ d_keccak_rc[round];
+    put_limbs(A_PPP_00, out00);
+    // ---- the sponge's own columns
+    if (!real) {
+      for (int col = BLOCK_MEM; col < KECCAK_SPONGE_WIDTH; col++) put(col, 0u);
+    } else {
+      const uint32_t len = e[E_INPUT_LEN], index = e[E_BLOCK_INDEX];
+      const uint32_t n_ev_blocks = len / 36;
+      if (len == 0 || len % 36 != 0 || index >= n_ev_blocks) { *bad = 1; }
+      const bool first = index == 0, final = index + 1 == n_ev_blocks;
+      const LookupSink sink{hkeys, hvals, HASH_SLOTS - 1, counts};
+      put(SHARD, kb::to_monty(e[E_SHARD])); put(CLK, kb::to_monty(e[E_CLK])); put(IS_REAL, kb::ONE);
+      put(READ_BLOCK, round == 0 ? kb::ONE : 0u);
+      put(INPUT_ADDRESS, kb::to_monty(e[E_INPUT_ADDR] + index * 144u));
+      put(OUTPUT_ADDRESS, kb::to_monty(e[E_OUTPUT_ADDR]));
+      put(INPUT_LEN, kb::to_monty(len));
+      put(ALREADY_ABSORBED, kb::to_monty(36u * index));
+      put(IS_ABSORBED, round == 23 && !final ? kb::ONE : 0u);
+      put(RECEIVE_SYSCALL, first && round == 0 ? kb::ONE : 0u);
+      put(WRITE_OUTPUT, final && round == 23 ? kb::ONE : 0u);
+      put(IS_FIRST, first ? kb::ONE : 0u);
+      put(IS_FINAL, final ? kb::ONE : 0u);
+      for (int j = 0; j < 50; j++) {           // the state the block is absorbed into: xored ^ block on the rate part
+        const uint32_t before = e[E_XORED + j] ^ (j < 36 ? e[E_READS + 5 * j] : 0u);
+        if (first && before) *bad = 2;
+        for (int k = 0; k < 4; k++) put(ORIGINAL_STATE + 4 * j + k, kb::to_monty((before >> (8 * k)) & 0xff));
+      }
+      if (round == 0) {
+        for (int j = 0; j < 36; j++) {
+          const uint32_t* rec = e + E_READS + 5 * j;
+          uint32_t m[9];
+          memory_access_cols(rec[0], rec[1], rec[2], rec[3], rec[4], m);
+          for (int k = 0; k < 9; k++) put(BLOCK_MEM + 9 * j + k, kb::to_monty(m[k]));
+          const uint32_t xored = e[E_XORED + j], before = xored ^ rec[0];
+          for (int k = 0; k < 4; k++) put(XORED_RATE + 4 * j + k, kb::to_monty((xored >> (8 * k)) & 0xff));
+          if (count) {
+            access_lookups(m, sink);
+            for (int k = 0; k < 4; k++) lookup(sink, B_XOR, before >> (8 * k), rec[0] >> (8 * k));
+          }
+        }
+      } else {
+        for (int col = BLOCK_MEM; col < SHARD; col++) put(col, 0u);
+        for (int col = XORED_RATE; col < INPUT_LENGTH_MEM; col++) put(col, 0u);
+      }
+      if (first && round == 0) {
+        const uint32_t* rec = e + E_LEN_RECORD;
+        if (rec[0] != len) *bad = 3;
+        uint32_t m[9];
+        memory_access_cols(rec[0], rec[1], rec[2], rec[3], rec[4], m);
+        for (int k = 0; k < 9; k++) put(INPUT_LENGTH_MEM + k, kb::to_monty(m[k]));
+        if (count) access_lookups(m, sink);
+      } else {
+        for (int k = 0; k < 9; k++) put(INPUT_LENGTH_MEM + k, 0u);
+      }
+      if (final && round == 23) {
+        uint64_t squeezed[8] = {out00, app[1], app[2], app[3], app[4], app[5], app[6], app[7]};
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+          const uint32_t* rec = e + E_WRITES + 6 * j;
+          if (rec[0] != (uint32_t)(squeezed[j / 2] >> (32 * (j & 1)))) *bad = 4;
+          uint32_t m[13];
+          memory_write_cols(rec, m);
+          for (int k = 0; k < 13; k++) put(OUTPUT_MEM + 13 * j + k, kb::to_monty(m[k]));
+          if (count) { lookup(sink, B_U16RANGE, m[11] >> 8, m[11]); lookup(sink, B_U8RANGE, 0, m[12]); }
+        }
+      } else {
+        for (int col = OUTPUT_MEM; col < KECCAK_SPONGE_WIDTH; col++) put(col, 0u);
+      }
+      if (round == 23 && !final) {     // the call's next block follows and is absorbed into this block's permuted state
+        if (blk + 1 >= n_blocks) {
+          *bad = 5;
+        } else {
+          const uint32_t* nx = e + KECCAK_SPONGE_BLOCK_WORDS;
+          bool ok = nx[E_BLOCK_INDEX] == index + 1 && nx[E_INPUT_LEN] == len && nx[E_SHARD] == e[E_SHARD] && nx[E_CLK] == e[E_CLK];
+#pragma unroll
+          for (int j = 0; j < 50; j++) {
+            const uint64_t lane = j / 2 == 0 ? out00 : app[j / 2];
+            ok = ok && (nx[E_XORED + j] ^ (j < 36 ? nx[E_READS + 5 * j] : 0u)) == (uint32_t)(lane >> (32 * (j & 1)));
+          }
+          if (!ok) *bad = 5;
+        }
+      }
+    }
+  }
+  if (count) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < HASH_SLOTS; i += blockDim.x)
+      if (hkeys[i] != HASH_EMPTY) atomicAdd(counts + hkeys[i], hvals[i]);
+  }
+}
+
 // recursion ExpReverseBitsLen chip (crates/recursion/core/src/chips/exp_reverse_bits.rs:175-226): one thread walks one event's bits —
 // accum_i = accum_{i-1}^2 * (bit_i ? x : 1) — and writes its rows (x, bit, prev_accum^2, that times the multiplier, accum, accum^2,
 // multiplier); Montgomery words in and out. offsets[e] .. offsets[e + 1] are event e's rows; the rest of the matrix is zeroed first.

@@ -532,6 +532,59 @@ MEMORY_GLOBAL_WIDTH = 111               # MemoryInitCols (crates/core/machine/sr
 POSEIDON2_PERMUTE_EVENT = np.dtype([("shard", "<u4"), ("clk", "<u4"), ("state_addr", "<u4"), ("state_records", MEMORY_WRITE_RECORD, (16,))])
 assert POSEIDON2_PERMUTE_EVENT.itemsize == 4 * 99
 POSEIDON2_PERMUTE_WIDTH = 973           # Poseidon2MemCols (syscall/precompiles/poseidon2/columns.rs:9-27)
+# KeccakSpongeEvent (events/precompiles/keccak_sponge.rs:15-46) holds Vecs; across the C ABI it is cut into its 36-word blocks, one record
+# per block (24 trace rows each): the state after the block is xored in (xored_state_list[block_index], as u32 pairs), the block's
+# MemoryReadRecords (their values are the input words) and, used by the first / last block only, the record of the input length (read at
+# output_addr + 64) and the sixteen output MemoryWriteRecords.
+SYS_KECCAK_SPONGE = 0x01010009          # SyscallCode::KECCAK_SPONGE (syscalls/code.rs:57): id 9, own table, one extra cycle
+MEMORY_READ_RECORD = np.dtype([("value", "<u4"), ("shard", "<u4"), ("timestamp", "<u4"), ("prev_shard", "<u4"), ("prev_timestamp", "<u4")])
+KECCAK_SPONGE_BLOCK = np.dtype([("shard", "<u4"), ("clk", "<u4"), ("input_addr", "<u4"), ("output_addr", "<u4"), ("input_len_u32s", "<u4"),
+                                ("block_index", "<u4"), ("xored_state", "<u4", (50,)), ("input_read_records", MEMORY_READ_RECORD, (36,)),
+                                ("input_length_record", MEMORY_READ_RECORD), ("output_write_records", MEMORY_WRITE_RECORD, (16,))])
+assert KECCAK_SPONGE_BLOCK.itemsize == 4 * 337
+KECCAK_SPONGE_WIDTH = 3531              # KeccakSpongeCols (syscall/precompiles/keccak_sponge/columns.rs:17-37): 2633 KeccakCols + 898
+KECCAK_RATE_U32S, KECCAK_OUTPUT_U32S, NUM_KECCAK_COLS = 36, 16, 2633
+KECCAK_RC = [0x0000000000000001, 0x0000000000008082, 0x800000000000808a, 0x8000000080008000, 0x000000000000808b, 0x0000000080000001,
+             0x8000000080008081, 0x8000000000008009, 0x000000000000008a, 0x0000000000000088, 0x0000000080008009, 0x000000008000000a,
+             0x000000008000808b, 0x800000000000008b, 0x8000000000008089, 0x8000000000008003, 0x8000000000008002, 0x8000000000000080,
+             0x000000000000800a, 0x800000008000000a, 0x8000000080008081, 0x8000000000008080, 0x0000000080000001, 0x8000000080008008]
+KECCAK_ROT = [[0, 36, 3, 41, 18], [1, 44, 10, 45, 2], [62, 6, 43, 15, 61], [28, 55, 25, 21, 56], [27, 20, 39, 8, 14]]   # [x][y]
+
+
+def keccak_f(state):
+    """keccak-f[1600] on 25 u64 lanes state[x + 5 * y] (tiny-keccak's keccakf, which KeccakSpongeSyscall::execute calls)."""
+    M = (1 << 64) - 1
+    rotl = lambda v, r: ((v << r) | (v >> (64 - r))) & M if r else v   # noqa: E731
+    a = list(state)
+    for rc in KECCAK_RC:
+        c = [a[x] ^ a[x + 5] ^ a[x + 10] ^ a[x + 15] ^ a[x + 20] for x in range(5)]
+        d = [c[(x + 4) % 5] ^ rotl(c[(x + 1) % 5], 1) for x in range(5)]
+        a = [a[i] ^ d[i % 5] for i in range(25)]
+        b = [0] * 25
+        for x in range(5):
+            for y in range(5):
+                b[y + 5 * ((2 * x + 3 * y) % 5)] = rotl(a[x + 5 * y], KECCAK_ROT[x][y])
+        a = [b[x + 5 * y] ^ (~b[(x + 1) % 5 + 5 * y] & M & b[(x + 2) % 5 + 5 * y]) for y in range(5) for x in range(5)]
+        a[0] ^= rc
+    return a
+
+
+def keccak256_words(data: bytes):
+    """The guest library's keccak256 (crates/zkvm/lib/src/keccak256.rs:3-57) up to the syscall: pad10*1 to the 136-byte rate, little-endian
+    words, every 34-word block extended by two zero words to the precompile's general 36-word rate."""
+    n = len(data)
+    padded = bytearray(data) + bytearray(136 - n % 136)
+    if n % 136 == 135:
+        padded[-1] = 0x81
+    else:
+        padded[n] = 1
+        padded[-1] = 0x80
+    words = []
+    for k in range(0, len(padded), 136):
+        words += [int.from_bytes(padded[k + 4 * i:k + 4 * i + 4], "little") for i in range(34)] + [0, 0]
+    return words
+
+
 SYSCALL_INSTRS_WIDTH = 77
 # SyscallCode (crates/core/executor/src/syscalls/code.rs): byte 0-1 id, byte 2 "has its own table", byte 3 extra cycles
 SYS_HALT, SYS_WRITE, SYS_ENTER_UNCONSTRAINED, SYS_EXIT_UNCONSTRAINED, SYS_COMMIT, SYS_COMMIT_DEFERRED_PROOFS, SYS_HINT_LEN = 0, 2, 3, 4, 0x10, 0x1a, 0xf0

@@ -94,18 +94,19 @@ class Machine:
 
 
 def run_machine(n_cycles: int = 0, seed: int = 1, pc_base: int = 0x1000, shard_cycles: int = 1 << 30, program=None, poseidon2_calls: int = 0,
-                memory_chunk: int = 1 << 30) -> Machine:
+                memory_chunk: int = 1 << 30, keccak_calls: int = 0) -> Machine:
     """A whole run as the reference's prover sees it (crates/core/machine/src/utils/prove.rs:255-400): CPU shards of at most `shard_cycles`
     cycles (never split between a branch and its delay slot, executor.rs:2352-2356), then one shard with the deferred precompile events
     (ExecutionRecord::split, record.rs:130-218), then the shards that initialise and finalise every touched address
     (executor.rs:2554-2618, record.rs:220-277; `memory_chunk` events per shard). `program`: a list of (opcode, op_a, op_b, op_c, imm_b, imm_c)
-    to execute until it halts instead of generating one; `poseidon2_calls`: POSEIDON2_PERMUTE precompile calls spread over a generated run."""
+    to execute until it halts instead of generating one; `poseidon2_calls` / `keccak_calls`: POSEIDON2_PERMUTE / KECCAK_SPONGE precompile calls
+    spread over a generated run (each kind is deferred to a precompile shard of its own, record.rs:150-185)."""
     return _execute(n_cycles, seed, 1, pc_base, True, shard_cycles=shard_cycles, given=program, poseidon2_calls=poseidon2_calls, memory_chunk=memory_chunk,
-                    machine=True)
+                    machine=True, keccak_calls=keccak_calls)
 
 
 def _execute(n_cycles: int, seed: int = 1, shard: int = 1, pc_base: int = 0x1000, halt: bool = False, shard_cycles: int = 1 << 30, given=None,
-             poseidon2_calls: int = 0, memory_chunk: int = 1 << 30, machine: bool = False) -> Machine:
+             poseidon2_calls: int = 0, memory_chunk: int = 1 << 30, machine: bool = False, keccak_calls: int = 0) -> Machine:
     """Execute `n_cycles` instructions of a program generated on the way. Returns (program, record, public_values) with
     program: INSTRUCTION array (instructions that were jumped over are `ADD $0, 0, 0` no-ops that never run), record:
     structured event arrays, public_values: dict of the words the Cpu chip checks (start_pc, next_pc, execution_shard).
@@ -125,7 +126,7 @@ def _execute(n_cycles: int, seed: int = 1, shard: int = 1, pc_base: int = 0x1000
     program = {}
     rec = Record()
     done_shards = []               # (Record lists, first pc, last next_pc, shard number) of the CPU shards already closed
-    precompile = []                # (syscall event, Poseidon2PermuteEvent tuple, its MemoryLocalEvents) in execution order
+    precompile = []                # (kind, syscall event, the precompile's event(s), its MemoryLocalEvents) in execution order
     if given is not None:
         for i, ins in enumerate(given):
             program[pc_base + 4 * i] = tuple(ins)
@@ -167,22 +168,26 @@ def _execute(n_cycles: int, seed: int = 1, shard: int = 1, pc_base: int = 0x1000
     queued = []                    # instructions that must come next (a precompile call's set-up), generated runs only
     p2_at = set(int(x) for x in np.linspace(n_cycles // 8, max(n_cycles - 40, n_cycles // 8), poseidon2_calls)) if poseidon2_calls else set()
     p2_seq = 0
+    k_at = set(int(x) for x in np.linspace(n_cycles // 6, max(n_cycles - 60, n_cycles // 6), keccak_calls)) - p2_at if keccak_calls else set()
+    k_seq = 0
+    clk_extra = 0                  # the extra cycles of the shard's syscalls so far (Syscall::num_extra_cycles, executor.rs:1641)
 
     def close_shard():
         """bump_record (executor.rs:2186-2200): the open access chains become the shard's MemoryLocal events."""
-        nonlocal rec, shard, shard_start
+        nonlocal rec, shard, shard_start, clk_extra
         rec.memory_local = [(reg, first[reg], (last[reg][0], last[reg][1], R[reg])) for reg in sorted(first)] + rec.memory_local
         done_shards.append((rec, shard))
         first.clear()
         rec = Record()
         shard += 1
         shard_start = cyc
+        clk_extra = 0
 
     while (not halted) if given is not None else (cyc + 1 < n_cycles + len(epilogue)):
         cyc += 1
         if machine and cyc - shard_start >= shard_cycles and not delay_slot and not queued and (given is not None or cyc < n_cycles):
             close_shard()
-        clk = 5 * (cyc - shard_start)
+        clk = 5 * (cyc - shard_start) + clk_extra
         u = rng.random()
         if given is None and cyc >= n_cycles and delay_slot:      # a branch's delay slot comes first: one more plain instruction
             epilogue.insert(cyc - n_cycles, (E.ADD, 1, 0, 0, 1, 1))
@@ -191,14 +196,32 @@ def _execute(n_cycles: int, seed: int = 1, shard: int = 1, pc_base: int = 0x1000
         if given is None and cyc in p2_at and cyc < n_cycles:
             # a POSEIDON2_PERMUTE call as the reference's test program makes it (syscall/precompiles/poseidon2/mod.rs:24-43): sixteen field
             # elements stored to the state, the code in $v0, the state's address in $a0, zero in $a1, SYSCALL
+            had = len(queued)
             ptr = 0x00200000 + 64 * p2_seq
             p2_seq += 1
             for i in range(16):
                 queued += [(E.ADD, 30, int(rng.integers(0, F.P)), 0, 1, 1), (E.SW, 30, 0, ptr + 4 * i, 0, 1)]
             queued += [(E.ADD, E.REG_V0, E.SYS_POSEIDON2_PERMUTE, 0, 1, 1), (E.ADD, E.REG_A0, ptr, 0, 1, 1), (E.ADD, E.REG_A1, 0, 0, 1, 1),
                        (E.SYSCALL, E.REG_V0, E.REG_A0, E.REG_A1, 0, 0)]
-            n_cycles += len(queued)        # the body grows by the call; the epilogue still follows it
-            p2_at = set(x + len(queued) if x > cyc else x for x in p2_at)
+            n_cycles += len(queued) - had  # the body grows by the call; the epilogue still follows it
+            p2_at = set(x + len(queued) - had if x > cyc else x for x in p2_at)
+            k_at = set(x + len(queued) - had if x > cyc else x for x in k_at)
+        if given is None and cyc in k_at and cyc < n_cycles:
+            # a KECCAK_SPONGE call as the guest library's keccak256 makes it (crates/zkvm/lib/src/keccak256.rs:3-57): the padded message as
+            # 36-word blocks, its length in words at result + 64, the code in $v0, input and result pointers in $a0 / $a1
+            had = len(queued)
+            msg = bytes(rng.integers(0, 256, int(rng.integers(1, 300)), dtype=np.uint8))
+            words = E.keccak256_words(msg)
+            in_ptr, out_ptr = 0x00300000 + 0x1000 * k_seq, 0x00380000 + 0x100 * k_seq
+            k_seq += 1
+            for i, w in enumerate(words):
+                queued += [(E.ADD, 30, w, 0, 1, 1), (E.SW, 30, 0, in_ptr + 4 * i, 0, 1)]
+            queued += [(E.ADD, 30, len(words), 0, 1, 1), (E.SW, 30, 0, out_ptr + 64, 0, 1),
+                       (E.ADD, E.REG_V0, E.SYS_KECCAK_SPONGE, 0, 1, 1), (E.ADD, E.REG_A0, in_ptr, 0, 1, 1), (E.ADD, E.REG_A1, out_ptr, 0, 1, 1),
+                       (E.SYSCALL, E.REG_V0, E.REG_A0, E.REG_A1, 0, 0)]
+            n_cycles += len(queued) - had
+            p2_at = set(x + len(queued) - had if x > cyc else x for x in p2_at)
+            k_at = set(x + len(queued) - had if x > cyc else x for x in k_at)
         # ---- pick the instruction at pc (the program is written as it runs)
         if given is not None:
             if pc not in program:
@@ -372,7 +395,7 @@ def _execute(n_cycles: int, seed: int = 1, shard: int = 1, pc_base: int = 0x1000
             b_rec = read(op_b, clk, POS_B)
             b = b_rec[1][0]
             sid = code & 0xffff
-            assert code in (E.SYS_HALT, E.SYS_COMMIT, E.SYS_POSEIDON2_PERMUTE), code
+            assert code in (E.SYS_HALT, E.SYS_COMMIT, E.SYS_POSEIDON2_PERMUTE, E.SYS_KECCAK_SPONGE), code
             if code == E.SYS_POSEIDON2_PERMUTE:
                 # Poseidon2PermuteSyscall::execute (syscalls/precompiles/poseidon2/permute.rs:14-71): the sixteen words at $a0 are
                 # replaced by their permutation, written at timestamp clk through the syscall's own local-access map; a CPU access
@@ -393,7 +416,49 @@ def _execute(n_cycles: int, seed: int = 1, shard: int = 1, pc_base: int = 0x1000
                     records.append((post[i], shard, clk, pre[i], last[addr][0], last[addr][1]))
                     local.append((addr, (last[addr][0], last[addr][1], pre[i]), (shard, clk, post[i])))
                     R[addr], last[addr] = post[i], (shard, clk)
-                precompile.append(((pc, next_pc, shard, clk, (0, 0, 0, 0, 0, 0), 0, [0, 0, 0], sid, b, c), (shard, clk, b, records), local))
+                precompile.append(("poseidon2", (pc, next_pc, shard, clk, (0, 0, 0, 0, 0, 0), 0, [0, 0, 0], sid, b, c), [(shard, clk, b, records)], local))
+            if code == E.SYS_KECCAK_SPONGE:
+                # KeccakSpongeSyscall::execute (syscalls/precompiles/keccak/sponge.rs:20-104): the input length is read from result + 64 and
+                # the input from $a0 at timestamp clk, every 36-word block is xored into the state and permuted, the first sixteen words of
+                # the state are written to the result at clk + 1; the call takes one extra cycle
+                touched = {}                               # address -> [initial (shard, timestamp, value), final]: SyscallContext's local map
+
+                def mem(addr, ts, value=None):
+                    if addr not in R:
+                        R[addr], last[addr] = 0, (0, 0)
+                    born.setdefault(addr, R[addr])
+                    if addr in first:                      # an open CPU access chain is closed first (SyscallContext::postprocess)
+                        rec.memory_local.append((addr, first.pop(addr), (last[addr][0], last[addr][1], R[addr])))
+                    prev = (last[addr][0], last[addr][1], R[addr])
+                    touched.setdefault(addr, [prev, None])
+                    if value is None:
+                        out = (R[addr], shard, ts, prev[0], prev[1])
+                    else:
+                        out = (value, shard, ts, prev[2], prev[0], prev[1])
+                        R[addr] = value
+                    last[addr] = (shard, ts)
+                    touched[addr][1] = (shard, ts, R[addr])
+                    return out
+
+                assert b % 4 == 0 and c % 4 == 0
+                len_rec = mem(c + 64, clk)
+                n_words = len_rec[0]
+                assert n_words and n_words % E.KECCAK_RATE_U32S == 0
+                reads = [mem(b + 4 * j, clk) for j in range(n_words)]
+                state, xored = [0] * 25, []
+                for k in range(0, n_words, 36):
+                    for i in range(18):
+                        state[i] ^= reads[k + 2 * i][0] | (reads[k + 2 * i + 1][0] << 32)
+                    xored.append([w for lane in state for w in (lane & 0xffffffff, lane >> 32)])
+                    state = E.keccak_f(state)
+                writes = [mem(c + 4 * j, clk + 1, (state[j // 2] >> (32 * (j & 1))) & 0xffffffff) for j in range(16)]
+                nb = n_words // 36
+                no_read, no_write = (0, 0, 0, 0, 0), (0, 0, 0, 0, 0, 0)
+                blocks = [(shard, clk, b, c, n_words, k, xored[k], reads[36 * k:36 * k + 36], len_rec if k == 0 else no_read,
+                           writes if k == nb - 1 else [no_write] * 16) for k in range(nb)]
+                local = [(addr, v[0], v[1]) for addr, v in sorted(touched.items())]
+                precompile.append(("keccak", (pc, next_pc, shard, clk, (0, 0, 0, 0, 0, 0), 0, [0, 0, 0], sid, b, c), blocks, local))
+                clk_extra += 1
             a = code                                       # none of them returns a value: V0 keeps the code
             a_rec = write(op_a, a, clk, POS_A)
             hi = code
@@ -504,13 +569,17 @@ def _execute(n_cycles: int, seed: int = 1, shard: int = 1, pc_base: int = 0x1000
     # ---- the deferred shards (prove.rs:283-400): precompile events first, then memory initialisation / finalisation
     last_pv = shards[-1].pv
     n_shard = shards[-1].pv["shard"]
-    if precompile:
+    for kind, dt in (("poseidon2", E.POSEIDON2_PERMUTE_EVENT), ("keccak", E.KECCAK_SPONGE_BLOCK)):
+        mine = [e for e in precompile if e[0] == kind]
+        if not mine:
+            continue
         n_shard += 1
         o = Record()
         o.cpu = np.zeros(0, dtype=CPU_EVENT)
-        o.precompile_syscall = arr([e[0] for e in precompile], E.SYSCALL_EVENT)
-        o.poseidon2_permute = arr([e[1] for e in precompile], E.POSEIDON2_PERMUTE_EVENT)
-        o.memory_local = arr([ev for e in precompile for ev in e[2]], MEMORY_LOCAL_EVENT)
+        o.precompile_syscall = arr([e[1] for e in mine], E.SYSCALL_EVENT)
+        o.poseidon2_permute = arr([ev for e in mine for ev in e[2]] if kind == "poseidon2" else [], E.POSEIDON2_PERMUTE_EVENT)
+        o.keccak_sponge = arr([ev for e in mine for ev in e[2]] if kind == "keccak" else [], E.KECCAK_SPONGE_BLOCK)
+        o.memory_local = arr([ev for e in mine for ev in e[3]], MEMORY_LOCAL_EVENT)
         pv = dict(last_pv, start_pc=last_pv["next_pc"], shard=n_shard)
         shards.append(Shard("precompile", o, pv))
     touched = sorted(a for a in born if last[a] != (0, 0))

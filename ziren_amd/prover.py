@@ -222,6 +222,16 @@ class Context:
                                                             C.c_int(fixed_log2_rows), blu.h if blu is not None else None, C.byref(h)))
         return self._born(h)
 
+    def tracegen_keccak_sponge(self, blocks: np.ndarray, fixed_log2_rows: int = -1, blu: "ByteLookups" = None) -> DeviceMatrix:
+        """`generate_trace` of the KeccakSponge precompile on the device (zkm_tracegen_keccak_sponge); dtype events.KECCAK_SPONGE_BLOCK, the
+        calls' 36-word blocks in order, 24 rows each."""
+        from . import events as _ev
+        ev = np.ascontiguousarray(blocks, dtype=_ev.KECCAK_SPONGE_BLOCK)
+        h = C.c_void_p()
+        lib.check(lib.load().zkm_tracegen_keccak_sponge(self.h, C.c_void_p(ev.ctypes.data if len(ev) else None), C.c_size_t(len(ev)),
+                                                        C.c_int(fixed_log2_rows), blu.h if blu is not None else None, C.byref(h)))
+        return self._born(h)
+
     def tracegen_misc_instrs(self, events: np.ndarray, fixed_log2_rows: int = -1, blu: "ByteLookups" = None) -> DeviceMatrix:
         """`generate_trace` of the MiscInstrs chip on the device (zkm_tracegen_misc_instrs); dtype events.MISC_EVENT."""
         from . import events as _ev
@@ -493,6 +503,8 @@ class HipProver:
         for c in (self.chips if chips is None else chips):
             prog = np.ascontiguousarray(c.program, dtype=np.uint32)
             co = codegen.specialize(prog)
+            if co is None:          # too long for a straight-line kernel: the interpreter evaluates it
+                continue
             buf = C.create_string_buffer(co, len(co))
             lib.check(lib.load().zkm_ctx_register_quotient_kernel(self.ctx.h, abi.as_u32p(prog), C.c_uint32(len(prog)), buf,
                                                                   C.c_size_t(len(co))))
