@@ -146,7 +146,10 @@ void zkm_ctx_set_kernel_timing(zkm_ctx* ctx, int mode);
 /* Register a chip-specialised quotient kernel: a gfx950 code object exporting
  * `zkm_quotient_specialized(stark::QuotientArgs)` generated from exactly these program words
  * (ziren_amd/codegen.py; the Rust shim does this once per chip AIR). zkm_open uses it for chips whose
- * program matches and the bytecode interpreter otherwise; both compute the same values. */
+ * program matches and the bytecode interpreter otherwise; both compute the same values. A long program
+ * (KeccakSponge: 114 324 instructions) is cut into several kernels, handed over as one container: "ZKMQPART",
+ * u32 count, u32 zero, count x u64 lengths, the code objects; the first stores its share of the quotient
+ * values, the others add theirs. Registering a program again replaces its kernels. */
 int zkm_ctx_register_quotient_kernel(zkm_ctx* ctx, const uint32_t* program, uint32_t program_len,
                                      const void* code_object, size_t code_object_len);
 

@@ -97,7 +97,7 @@ def test_keccak_sponge_rows_satisfy_the_air_and_cost_what_the_reference_says(ora
     ref = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "mips_costs.json")))["costs"]
     perm_width = air.local_permutation_trace_width(len(chip.sends) + len(chip.receives), 2)
     assert (len(chip.sends), len(chip.receives), perm_width, chip.log_quotient_degree) == (303, 54, 180, 1)
-    # MipsAir::costs multiplies a precompile's row cost by its rows per event (mips/mod.rs:593: KeccakSponge => 24)
+    # MipsAir::costs multiplies a precompile's row cost by its rows per event (mips/mod.rs:588-595: KeccakSponge => 24)
     assert 24 * (chip.main_width + 4 * perm_width + 4 * 2) == ref["KeccakSponge"] == 102216
     # a call cut short, blocks out of order, a forged output: errors, not rows
     with pytest.raises(RuntimeError, match="cut short|chain"):

@@ -45,12 +45,13 @@ def program_hash(program: np.ndarray) -> str:
     return hashlib.sha256(_template_key() + np.ascontiguousarray(program, dtype=np.uint32).tobytes()).hexdigest()[:24]
 
 
-def emit_source(program: np.ndarray) -> str:
-    """Straight-line HIP for one chip. Every register write becomes a fresh SSA value."""
+def _ssa_lines(program: np.ndarray):
+    """The program as straight-line HIP statements, every register write a fresh SSA value: (lines, meta) with meta[k] = (the value line
+    k defines — None for an assert —, the values it reads)."""
     prog = np.asarray(program, dtype=np.uint32)
     n_instr = int(prog[0])
     cur_b, cur_e = {}, {}   # register -> current variable name
-    lines = []
+    lines, meta = [], []
     nv = [0]
 
     def fresh(prefix):
@@ -65,68 +66,88 @@ def emit_source(program: np.ndarray) -> str:
         if op == air.LD_MAIN:
             v = fresh("b"); cur_b[dst] = v
             lines.append(f"const uint32_t {v} = a.main_lde[(size_t){imm} * a.main_stride + {row}];")
+            meta.append((v, ()))
         elif op == air.LD_PREP:
             v = fresh("b"); cur_b[dst] = v
             lines.append(f"const uint32_t {v} = a.prep_lde[(size_t){imm} * a.prep_stride + {row}];")
+            meta.append((v, ()))
         elif op == air.LD_PERM:
             v = fresh("e"); cur_e[dst] = v
             base = f"a.perm_lde + (size_t){4 * imm} * a.perm_stride + {row}"
             lines.append(f"const kb::E4 {v} = kb::E4{{{{({base})[0], ({base})[a.perm_stride], ({base})[2 * a.perm_stride], "
                          f"({base})[3 * a.perm_stride]}}}};")
+            meta.append((v, ()))
         elif op == air.LD_CONST:
             v = fresh("b"); cur_b[dst] = v
             lines.append(f"const uint32_t {v} = {imm}u;")
+            meta.append((v, ()))
         elif op == air.LD_PV:
             v = fresh("b"); cur_b[dst] = v
             lines.append(f"const uint32_t {v} = a.public_values[{imm}];")
+            meta.append((v, ()))
         elif op == air.LD_CHALLENGE:
             v = fresh("e"); cur_e[dst] = v
             lines.append(f"const kb::E4 {v} = {'a.perm_beta' if imm else 'a.perm_alpha'};")
+            meta.append((v, ()))
         elif op == air.LD_LOCAL_SUM:
             v = fresh("e"); cur_e[dst] = v
             lines.append(f"const kb::E4 {v} = a.local_sum;")
+            meta.append((v, ()))
         elif op == air.LD_GLOBAL_SUM:
             v = fresh("b"); cur_b[dst] = v
             lines.append(f"const uint32_t {v} = a.consts[{imm}];")
+            meta.append((v, ()))
         elif op in (air.LD_IS_FIRST, air.LD_IS_LAST, air.LD_IS_TRANS):
             v = fresh("b"); cur_b[dst] = v
             sel = {air.LD_IS_FIRST: "q.is_first", air.LD_IS_LAST: "q.is_last", air.LD_IS_TRANS: "q.is_trans"}[op]
             lines.append(f"const uint32_t {v} = {sel};")
+            meta.append((v, ()))
         elif op in (air.ADD_B, air.SUB_B, air.MUL_B):
             fn = {air.ADD_B: "add", air.SUB_B: "sub", air.MUL_B: "mul"}[op]
             x, y = cur_b[ra], cur_b[rb]
             v = fresh("b"); cur_b[dst] = v
             lines.append(f"const uint32_t {v} = kb::{fn}({x}, {y});")
+            meta.append((v, (x, y)))
         elif op == air.NEG_B:
             x = cur_b[ra]
             v = fresh("b"); cur_b[dst] = v
             lines.append(f"const uint32_t {v} = kb::neg({x});")
+            meta.append((v, (x,)))
         elif op in (air.ADD_E, air.SUB_E, air.MUL_E):
             fn = {air.ADD_E: "eadd", air.SUB_E: "esub", air.MUL_E: "emul"}[op]
             x, y = cur_e[ra], cur_e[rb]
             v = fresh("e"); cur_e[dst] = v
             lines.append(f"const kb::E4 {v} = kb::{fn}({x}, {y});")
+            meta.append((v, (x, y)))
         elif op == air.NEG_E:
             x = cur_e[ra]
             v = fresh("e"); cur_e[dst] = v
             lines.append(f"const kb::E4 {v} = kb::eneg({x});")
+            meta.append((v, (x,)))
         elif op in (air.ADD_EB, air.SUB_EB, air.MUL_EB):
             fn = {air.ADD_EB: "eadd_base", air.SUB_EB: "esub_base", air.MUL_EB: "escale"}[op]
             x, y = cur_e[ra], cur_b[rb]
             v = fresh("e"); cur_e[dst] = v
             lines.append(f"const kb::E4 {v} = kb::{fn}({x}, {y});")
+            meta.append((v, (x, y)))
         elif op == air.ASSERT_B:
             lines.append(f"acc = kb::eadd(acc, kb::escale(a.alpha_pows[{cidx}], {cur_b[ra]}));")
+            meta.append((None, (cur_b[ra],)))
             cidx += 1
         elif op == air.ASSERT_E:
             lines.append(f"acc = kb::eadd(acc, kb::emul(a.alpha_pows[{cidx}], {cur_e[ra]}));")
+            meta.append((None, (cur_e[ra],)))
             cidx += 1
         else:
             raise ValueError(f"bad opcode {op}")
-    assert cidx == int(prog[2])
+    assert cidx == int(prog[2]) and len(meta) == len(lines)
+    return lines, meta
+
+
+def _kernel_source(lines, n_instr, n_constraints, accumulate=False, part="") -> str:
     body = "\n  ".join(lines)
     return f"""// GENERATED by ziren_amd/codegen.py from a chip's constraint bytecode ({n_instr} instructions,
-// {cidx} constraints). Same arithmetic as stark::quotient_kernel (the interpreter), values in VGPRs.
+// {n_constraints} constraints{part}). Same arithmetic as stark::quotient_kernel (the interpreter), values in VGPRs.
 #include "quotient_args.cuh"
 
 extern "C" __global__ __launch_bounds__({BLOCK}) void {KERNEL_NAME}(stark::QuotientArgs a) {{
@@ -134,37 +155,114 @@ extern "C" __global__ __launch_bounds__({BLOCK}) void {KERNEL_NAME}(stark::Quoti
   if (!stark::quotient_point(a, stark::quotient_row(a), q)) return;
   kb::E4 acc = kb::ezero();
   {body}
-  stark::quotient_store(a, q, acc);
+  stark::{'quotient_accumulate' if accumulate else 'quotient_store'}(a, q, acc);
 }}
 """
 
 
-MAX_SPECIALIZED_INSTRS = 40000   # straight-line code beyond this takes hipcc tens of minutes (KeccakSponge: 114 324 instructions)
+def emit_source(program: np.ndarray) -> str:
+    """Straight-line HIP for one chip, one kernel."""
+    prog = np.asarray(program, dtype=np.uint32)
+    lines, _ = _ssa_lines(prog)
+    return _kernel_source(lines, int(prog[0]), int(prog[2]))
+
+
+PART_INSTRS = 6000             # a long program is cut into kernels of about this many instructions
+SINGLE_KERNEL_INSTRS = 12000   # ... when it is longer than this (KeccakSponge: 114 324; every other recorded chip is below 10 000)
+
+
+def emit_part_sources(program: np.ndarray):
+    """A long program as several kernels. The folded constraint sum is linear in the constraints, so the program is cut at assert
+    boundaries: the first kernel stores its partial quotient, the others add theirs to it. A value computed before a cut and used after
+    it is recomputed by the later kernel (the statements that define it, transitively, are put in front of the part)."""
+    prog = np.asarray(program, dtype=np.uint32)
+    lines, meta = _ssa_lines(prog)
+    defined_at = {v: k for k, (v, _) in enumerate(meta) if v is not None}
+    cuts, start = [], 0
+    for k, (v, _) in enumerate(meta):
+        if v is None and k + 1 - start >= PART_INSTRS:
+            cuts.append((start, k + 1))
+            start = k + 1
+    if start < len(lines):
+        if cuts and not any(v is None for v, _ in meta[start:]):
+            cuts[-1] = (cuts[-1][0], len(lines))      # trailing statements without an assert belong to the last part
+        else:
+            cuts.append((start, len(lines)))
+    sources = []
+    for n, (lo, hi) in enumerate(cuts):
+        need, stack = set(), [u for _, uses in meta[lo:hi] for u in uses if defined_at[u] < lo]
+        while stack:
+            u = stack.pop()
+            if u in need:
+                continue
+            need.add(u)
+            stack += list(meta[defined_at[u]][1])
+        prelude = [lines[k] for k in sorted(defined_at[u] for u in need)]
+        sources.append(_kernel_source(prelude + lines[lo:hi], int(prog[0]), int(prog[2]), accumulate=n > 0,
+                                      part=f"; part {n + 1} of {len(cuts)}: statements {lo}..{hi - 1}"))
+    return sources
+
+
+MAX_SPECIALIZED_INSTRS = 1 << 20   # beyond this the interpreter evaluates the program (no recorded chip comes near)
+PARTS_MAGIC = b"ZKMQPART"         # container of a multi-kernel program: magic, u32 count, u32 pad, count x u64 lengths, the code objects
+
+
+def _compile(src: str, out: str, verbose: bool = False):
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, os.path.basename(out) + ".hip")
+        with open(path, "w") as f:
+            f.write(src)
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "--genco", "-I", CSRC, path, "-o", out + ".tmp"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    os.replace(out + ".tmp", out)
 
 
 def specialize(program: np.ndarray, force: bool = False, verbose: bool = False) -> Optional[bytes]:
-    """Return the gfx950 code object for `program`, compiling it on first use (cached in-tree); None for a program too long to be worth a
-    straight-line kernel — the library's bytecode interpreter evaluates it."""
-    if int(np.asarray(program)[0]) > MAX_SPECIALIZED_INSTRS:
+    """Return the gfx950 code object for `program`, compiling it on first use (cached in-tree). A program of more than
+    SINGLE_KERNEL_INSTRS instructions comes back as a container of several code objects (emit_part_sources; hipcc's time grows much
+    faster than the length of a straight-line kernel: 114 324 instructions in one kernel do not finish in half an hour, in nineteen
+    kernels they take seconds each), which zkm_ctx_register_quotient_kernel takes just the same. None for a program beyond
+    MAX_SPECIALIZED_INSTRS — the library's bytecode interpreter evaluates it."""
+    n_instr = int(np.asarray(program)[0])
+    if n_instr > MAX_SPECIALIZED_INSTRS:
         return None
     os.makedirs(CACHE, exist_ok=True)
     h = program_hash(program)
-    out = os.path.join(CACHE, f"q_{h}.hsaco")
-    if force or not os.path.exists(out):
-        src = emit_source(program)
-        hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-        with tempfile.TemporaryDirectory() as td:
-            path = os.path.join(td, f"q_{h}.hip")
-            with open(path, "w") as f:
-                f.write(src)
-            cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "--genco", "-I", CSRC, path, "-o", out + ".tmp"]
-            if verbose:
-                print(" ".join(cmd))
-            subprocess.check_call(cmd)
-        os.replace(out + ".tmp", out)
+    if n_instr <= SINGLE_KERNEL_INSTRS:
+        out = os.path.join(CACHE, f"q_{h}.hsaco")
+        if force or not os.path.exists(out):
+            _compile(emit_source(program), out, verbose)
+    else:
+        out = os.path.join(CACHE, f"q_{h}.parts")
+        if force or not os.path.exists(out):
+            from concurrent.futures import ThreadPoolExecutor
+            sources = emit_part_sources(program)
+            with tempfile.TemporaryDirectory() as td:
+                outs = [os.path.join(td, f"q_{h}_{n}.hsaco") for n in range(len(sources))]
+                with ThreadPoolExecutor(max_workers=min(len(sources), os.cpu_count() or 1)) as pool:
+                    list(pool.map(lambda so: _compile(so[0], so[1], verbose), zip(sources, outs)))
+                blobs = [open(o, "rb").read() for o in outs]
+            blob = PARTS_MAGIC + np.array([len(blobs), 0], dtype="<u4").tobytes() + np.array([len(b) for b in blobs], dtype="<u8").tobytes()
+            blob += b"".join(blobs)
+            with open(out + ".tmp", "wb") as f:
+                f.write(blob)
+            os.replace(out + ".tmp", out)
     _note_in_manifest(program, os.path.basename(out))
     with open(out, "rb") as f:
         return f.read()
+
+
+def specialize_many(programs, verbose: bool = False):
+    """specialize() for a list of programs, compiling the missing ones side by side (the build step: every recorded chip)."""
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=os.cpu_count() or 1) as pool:
+        return list(pool.map(lambda prog: specialize(prog, verbose=verbose), programs))
+
+
+_manifest_lock = __import__("threading").Lock()
 
 
 def _note_in_manifest(program: np.ndarray, filename: str):
@@ -175,6 +273,12 @@ def _note_in_manifest(program: np.ndarray, filename: str):
     import json
     key = hashlib.sha256(np.ascontiguousarray(program, dtype="<u4").tobytes()).hexdigest()
     path = os.path.join(CACHE, "manifest.json")
+    with _manifest_lock:
+        _update_manifest(path, key, filename)
+
+
+def _update_manifest(path, key, filename):
+    import json
     try:
         with open(path) as f:
             m = json.load(f)

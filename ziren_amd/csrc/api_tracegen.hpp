@@ -549,7 +549,7 @@ int zkm_tracegen_keccak_sponge(zkm_ctx* ctx, const zkm_keccak_sponge_block* bloc
     static const char* const why[] = {"", "input length is not a positive multiple of 36 words, or the block index is past it",
                                       "the first block of a call is not absorbed into the zero state", "the input length record does not hold the input length",
                                       "the output records are not the squeezed state", "the blocks of one call do not follow each other and chain"};
-    if (bad) throw std::runtime_error(std::string("zkm_tracegen_keccak_sponge: ") + why[bad < 6 ? bad : 0]);
+    if (bad) throw std::runtime_error(std::string("zkm_tracegen_keccak_sponge: ") + why[16 - bad >= 1 && 16 - bad < 6 ? 16 - bad : 0]);
   } catch (...) {
     if (d_blocks) ctx->release(d_blocks);
     if (d_bad) ctx->release(d_bad);

@@ -101,7 +101,7 @@ struct zkm_ctx {
   // are left untimed)
   int kernel_timing = 2;
   // per-chip specialised quotient kernels (ziren_amd/codegen.py), keyed by a hash of the program words
-  std::map<uint64_t, hipFunction_t> quotient_fns;
+  std::map<uint64_t, std::vector<hipFunction_t>> quotient_fns;   // a program's specialised kernel(s), in launch order
   std::vector<hipModule_t> modules;
   hipEvent_t get_event() {
     hipEvent_t e;

@@ -325,9 +325,11 @@ struct ShardOpening {
       // chip-specialised kernel: same arithmetic, values in VGPRs
       size_t arg_size = sizeof(a);
       void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &arg_size, HIP_LAUNCH_PARAM_END};
-      const bool timed = ctx->kbegin("quotient", qbytes);
-      HIP_CHECK(hipExtModuleLaunchKernel(fit->second, div_up(Q, 256) * 256, 1, 1, 256, 1, 1, 0, st, nullptr, config,
-                                         timed ? ctx->krecs.back().start : nullptr, timed ? ctx->krecs.back().stop : nullptr, 0));
+      for (hipFunction_t fn : fit->second) {       // several for a long program: the first stores, the others accumulate
+        const bool timed = ctx->kbegin("quotient", qbytes);
+        HIP_CHECK(hipExtModuleLaunchKernel(fn, div_up(Q, 256) * 256, 1, 1, 256, 1, 1, 0, st, nullptr, config,
+                                           timed ? ctx->krecs.back().start : nullptr, timed ? ctx->krecs.back().stop : nullptr, 0));
+      }
     } else {
       KLAUNCH(ctx, "quotient", qbytes, stark::quotient_kernel, dim3(div_up(Q, bd)), dim3(bd), lds, a);
     }

@@ -1322,6 +1322,7 @@ __global__ __launch_bounds__(THREADS) void keccak_sponge_rows(const uint32_t* __
     const bool real = blk < n_blocks;
     const uint32_t* e = blocks + blk * KECCAK_SPONGE_BLOCK_WORDS;
     auto put = [&](int col, uint32_t monty) { out[(size_t)col * height + row] = monty; };
+    auto fail = [&](int why) { atomicMax(bad, 16 - why); };     // the lowest code is reported: 16 - *bad on the host
     auto put_bits = [&](int col, uint64_t v) {
       for (int z = 0; z < 64; z++) put(col + z, (v >> z) & 1 ? kb::ONE : 0u);
     };
@@ -1360,7 +1361,7 @@ __global__ __launch_bounds__(THREADS) void keccak_sponge_rows(const uint32_t* __
     } else {
       const uint32_t len = e[E_INPUT_LEN], index = e[E_BLOCK_INDEX];
       const uint32_t n_ev_blocks = len / 36;
-      if (len == 0 || len % 36 != 0 || index >= n_ev_blocks) { *bad = 1; }
+      if (len == 0 || len % 36 != 0 || index >= n_ev_blocks) fail(1);
       const bool first = index == 0, final = index + 1 == n_ev_blocks;
       const LookupSink sink{hkeys, hvals, HASH_SLOTS - 1, counts};
       put(SHARD, kb::to_monty(e[E_SHARD])); put(CLK, kb::to_monty(e[E_CLK])); put(IS_REAL, kb::ONE);
@@ -1376,7 +1377,7 @@ __global__ __launch_bounds__(THREADS) void keccak_sponge_rows(const uint32_t* __
       put(IS_FINAL, final ? kb::ONE : 0u);
       for (int j = 0; j < 50; j++) {           // the state the block is absorbed into: xored ^ block on the rate part
         const uint32_t before = e[E_XORED + j] ^ (j < 36 ? e[E_READS + 5 * j] : 0u);
-        if (first && before) *bad = 2;
+        if (first && before) fail(2);
         for (int k = 0; k < 4; k++) put(ORIGINAL_STATE + 4 * j + k, kb::to_monty((before >> (8 * k)) & 0xff));
       }
       if (round == 0) {
@@ -1398,7 +1399,7 @@ __global__ __launch_bounds__(THREADS) void keccak_sponge_rows(const uint32_t* __
       }
       if (first && round == 0) {
         const uint32_t* rec = e + E_LEN_RECORD;
-        if (rec[0] != len) *bad = 3;
+        if (rec[0] != len) fail(3);
         uint32_t m[9];
         memory_access_cols(rec[0], rec[1], rec[2], rec[3], rec[4], m);
         for (int k = 0; k < 9; k++) put(INPUT_LENGTH_MEM + k, kb::to_monty(m[k]));
@@ -1411,7 +1412,7 @@ __global__ __launch_bounds__(THREADS) void keccak_sponge_rows(const uint32_t* __
 #pragma unroll
         for (int j = 0; j < 16; j++) {
           const uint32_t* rec = e + E_WRITES + 6 * j;
-          if (rec[0] != (uint32_t)(squeezed[j / 2] >> (32 * (j & 1)))) *bad = 4;
+          if (rec[0] != (uint32_t)(squeezed[j / 2] >> (32 * (j & 1)))) fail(4);
           uint32_t m[13];
           memory_write_cols(rec, m);
           for (int k = 0; k < 13; k++) put(OUTPUT_MEM + 13 * j + k, kb::to_monty(m[k]));
@@ -1422,7 +1423,7 @@ __global__ __launch_bounds__(THREADS) void keccak_sponge_rows(const uint32_t* __
       }
       if (round == 23 && !final) {     // the call's next block follows and is absorbed into this block's permuted state
         if (blk + 1 >= n_blocks) {
-          *bad = 5;
+          fail(5);
         } else {
           const uint32_t* nx = e + KECCAK_SPONGE_BLOCK_WORDS;
           bool ok = nx[E_BLOCK_INDEX] == index + 1 && nx[E_INPUT_LEN] == len && nx[E_SHARD] == e[E_SHARD] && nx[E_CLK] == e[E_CLK];
@@ -1431,7 +1432,7 @@ __global__ __launch_bounds__(THREADS) void keccak_sponge_rows(const uint32_t* __
             const uint64_t lane = j / 2 == 0 ? out00 : app[j / 2];
             ok = ok && (nx[E_XORED + j] ^ (j < 36 ? nx[E_READS + 5 * j] : 0u)) == (uint32_t)(lane >> (32 * (j & 1)));
           }
-          if (!ok) *bad = 5;
+          if (!ok) fail(5);
         }
       }
     }

@@ -172,14 +172,45 @@ int zkm_ctx_register_quotient_kernel(zkm_ctx* ctx, const uint32_t* program, uint
   std::lock_guard<std::mutex> lk(ctx->mu);
   HIP_CHECK(hipSetDevice(ctx->device));
   if (!program_len || !code_object_len) throw std::runtime_error("empty program or code object");
-  (void)code_object_len;
-  hipModule_t mod;
-  HIP_CHECK(hipModuleLoadData(&mod, code_object));
-  hipFunction_t fn;
-  hipError_t e = hipModuleGetFunction(&fn, mod, "zkm_quotient_specialized");
-  if (e != hipSuccess) { (void)hipModuleUnload(mod); throw std::runtime_error("code object lacks zkm_quotient_specialized"); }
-  ctx->modules.push_back(mod);
-  ctx->quotient_fns[fnv1a(program, program_len)] = fn;
+  // one gfx950 code object, or — for a program long enough to be cut into several kernels (ziren_amd/codegen.py) — a container of them:
+  // "ZKMQPART", u32 count, u32 zero, count x u64 lengths, then the code objects back to back. The first kernel stores its share of the
+  // quotient, the others add theirs; they are launched in this order.
+  std::vector<std::pair<const char*, size_t>> parts;
+  std::vector<std::vector<char>> copies;
+  const char* bytes = (const char*)code_object;
+  if (code_object_len >= 16 && memcmp(bytes, "ZKMQPART", 8) == 0) {
+    uint32_t count;
+    memcpy(&count, bytes + 8, 4);
+    size_t at = 16 + 8 * (size_t)count;
+    if (count == 0 || count > 4096 || at > code_object_len) throw std::runtime_error("malformed quotient kernel container");
+    for (uint32_t i = 0; i < count; i++) {
+      uint64_t len;
+      memcpy(&len, bytes + 16 + 8 * (size_t)i, 8);
+      if (len == 0 || len > code_object_len - at) throw std::runtime_error("malformed quotient kernel container");
+      copies.emplace_back(bytes + at, bytes + at + len);     // its own (aligned) allocation: hipModuleLoadData parses an ELF image
+      at += len;
+    }
+    for (auto& c : copies) parts.push_back({c.data(), c.size()});
+  } else {
+    parts.push_back({bytes, code_object_len});
+  }
+  std::vector<hipFunction_t> fns;
+  std::vector<hipModule_t> mods;
+  try {
+    for (auto& part : parts) {
+      hipModule_t mod;
+      HIP_CHECK(hipModuleLoadData(&mod, part.first));
+      mods.push_back(mod);
+      hipFunction_t fn;
+      if (hipModuleGetFunction(&fn, mod, "zkm_quotient_specialized") != hipSuccess) throw std::runtime_error("code object lacks zkm_quotient_specialized");
+      fns.push_back(fn);
+    }
+  } catch (...) {
+    for (hipModule_t m : mods) (void)hipModuleUnload(m);
+    throw;
+  }
+  for (hipModule_t m : mods) ctx->modules.push_back(m);
+  ctx->quotient_fns[fnv1a(program, program_len)] = fns;
   API_END
 }
 
