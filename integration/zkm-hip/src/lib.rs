@@ -127,7 +127,8 @@ where
         for c in self.recorded.values() {
             let bytes: Vec<u8> = c.program.iter().flat_map(|w| w.to_le_bytes()).collect();
             let key = Sha256::digest(&bytes).iter().map(|b| format!("{b:02x}")).collect::<String>();
-            // manifest lines: "<sha256 of program words>": "<file>.hsaco"
+            // manifest lines: "<sha256 of program words>": "<file>" — one code object (.hsaco) or, for a program long enough to be cut into
+            // several kernels (KeccakSponge), their container (.parts); zkm_ctx_register_quotient_kernel takes either
             if let Some(pos) = manifest.find(&key) {
                 let rest = &manifest[pos + key.len()..];
                 if let Some(file) = rest.split('"').nth(2) {
