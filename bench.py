@@ -38,12 +38,18 @@ def poseidon2_isa():
     return json.load(open(path))
 
 
+PROVER_SOURCES = ("kb31.cuh", "lde.cuh", "merkle.cuh", "open.cuh", "poseidon2.cuh", "poseidon2_constants.inc", "poseidon2_f64.cuh", "quotient_args.cuh",
+                  "stark.cuh", "host_pcs.hpp", "host_open.hpp")
+
+
 def csrc_digest():
-    """sha256 over the kernel sources: PMC profiles record it, so a traffic figure is only quoted for the code it was measured on."""
+    """sha256 over the sources a shard proof runs: the kernels (field, LDE, Merkle / Poseidon2, quotient, opening) and the host code that
+    decides their launches (commit, open). PMC profiles record it, so a traffic figure is only quoted for the code it was measured on.
+    The trace generators and the API glue are not part of it: they launch nothing inside a proof."""
     import hashlib
     h = hashlib.sha256()
     d = os.path.join(ROOT, "ziren_amd", "csrc")
-    for name in sorted(os.listdir(d)):
+    for name in PROVER_SOURCES:
         with open(os.path.join(d, name), "rb") as f:
             h.update(name.encode() + b"\0" + f.read())
     return h.hexdigest()[:16]

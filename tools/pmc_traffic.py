@@ -23,18 +23,15 @@ def load(path, counter):
 
 def main(fetch_db, write_db, out_path):
     f, w = load(fetch_db, "FETCH_SIZE"), load(write_db, "WRITE_SIZE")
-    import hashlib, os, subprocess
+    import os, subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    h = hashlib.sha256()
-    d = os.path.join(root, "ziren_amd", "csrc")
-    for name in sorted(os.listdir(d)):
-        with open(os.path.join(d, name), "rb") as fh:
-            h.update(name.encode() + b"\0" + fh.read())
+    sys.path.insert(0, root)
+    import bench              # the same digest bench.py checks before it quotes a figure from this file
     try:
         commit = subprocess.run(["git", "-C", root, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or None
     except OSError:
         commit = None
-    out = {"workload": "SYN-22, one shard proof (bench.py --log-rows 22 --steps 1 --warmup 0)", "csrc_digest": h.hexdigest()[:16], "commit": commit,
+    out = {"workload": "SYN-22, one shard proof (bench.py --log-rows 22 --steps 1 --warmup 0)", "csrc_digest": bench.csrc_digest(), "commit": commit,
            "correction": "read bytes = 2 * FETCH_SIZE * 1024, write bytes = WRITE_SIZE * 1024", "kernels": {}}
     for k in sorted(set(f) | set(w)):
         fv, fn = f.get(k, (0, 0))

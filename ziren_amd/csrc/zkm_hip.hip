@@ -250,6 +250,13 @@ static zkm_matrix* upload_async(zkm_ctx* ctx, const uint32_t* host, size_t heigh
     m->d = ctx->alloc_n<uint32_t>(std::max<size_t>(height * width, 1));
     HIP_CHECK(hipEventCreateWithFlags(&m->ready, hipEventDisableTiming));
     if (height * width) {
+      // the pool hands buffers back in compute-stream order (release()); this one is written from the transpose stream, so that stream
+      // first waits for whatever the compute stream still has queued — nothing, when every entry point has synchronised, but the
+      // ordering no longer rests on that
+      hipEvent_t reuse = ctx->get_event();
+      HIP_CHECK(hipEventRecord(reuse, ctx->stream));
+      HIP_CHECK(hipStreamWaitEvent(ctx->up_tr, reuse, 0));
+      ctx->event_pool.push_back(reuse);
       if (width * 4 * 32 > zkm_ctx::UP_SLAB_BYTES) throw std::runtime_error("zkm_matrix_upload: matrix too wide for the staging slab");
       const size_t slab_rows = std::max<size_t>(32, std::min<size_t>(height, zkm_ctx::UP_SLAB_BYTES / (width * 4)) & ~(size_t)31);
       for (size_t r0 = 0; r0 < height; r0 += slab_rows) {
