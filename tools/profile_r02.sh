@@ -10,7 +10,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/r02prof
 rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-B="python $R/bench.py --log-rows 22 --no-cpu-baseline --no-pcie"
+B="python $R/bench.py --log-rows 22 --no-cpu-baseline --no-pcie --no-inflight2"
 db() { find "$1" -name '*_results.db' | head -1; }
 python $R/bench.py --log-rows 22 --steps 10 --warmup 2 > $OUT/bench_unprofiled.json 2> $OUT/bench_unprofiled.err
 rocprofv3 --kernel-trace --stats -d $OUT/stats -o stats -- $B --steps 5 --warmup 1 > $OUT/bench_profiled.json 2> $OUT/stats.err
