@@ -430,6 +430,28 @@ typedef struct zkm_keccak_sponge_block {
 #define ZKM_KECCAK_SPONGE_WIDTH 3531
 int zkm_tracegen_keccak_sponge(zkm_ctx* ctx, const zkm_keccak_sponge_block* blocks, size_t n_blocks, int fixed_log2_rows,
                                zkm_byte_lookups* blu, zkm_matrix** out);
+
+/* The SHA-256 precompiles (crates/core/machine/src/syscall/precompiles/sha256/): replace generate_trace of ShaExtendChip
+ * (extend/trace.rs:31-63; 48 rows per call) and ShaCompressChip (compress/trace.rs:32-91; 80 rows per call) and the byte lookups of their
+ * generate_dependencies (counted into `blu` if given). The reference's events (crates/core/executor/src/events/precompiles/
+ * sha256_extend.rs:9-24, sha256_compress.rs:9-25) hold Vecs of fixed length; across the ABI they are flattened. ShaCompressEvent's `w`
+ * and `h` are the values of its read records and are not repeated. Fails when a write record does not hold what its reads give. */
+typedef struct zkm_sha_extend_event {
+  uint32_t shard, clk, w_ptr;
+  zkm_memory_read_record w_i_minus_15_reads[48], w_i_minus_2_reads[48], w_i_minus_16_reads[48], w_i_minus_7_reads[48];
+  zkm_memory_write_record w_i_writes[48];
+} zkm_sha_extend_event;
+typedef struct zkm_sha_compress_event {
+  uint32_t shard, clk, w_ptr, h_ptr;
+  zkm_memory_read_record h_read_records[8], w_i_read_records[64];
+  zkm_memory_write_record h_write_records[8];
+} zkm_sha_compress_event;
+#define ZKM_SHA_EXTEND_WIDTH 176
+#define ZKM_SHA_COMPRESS_WIDTH 262
+int zkm_tracegen_sha_extend(zkm_ctx* ctx, const zkm_sha_extend_event* events, size_t n_events, int fixed_log2_rows, zkm_byte_lookups* blu,
+                            zkm_matrix** out);
+int zkm_tracegen_sha_compress(zkm_ctx* ctx, const zkm_sha_compress_event* events, size_t n_events, int fixed_log2_rows,
+                              zkm_byte_lookups* blu, zkm_matrix** out);
 /* The MiscInstrs chip (crates/core/machine/src/misc/others/: SEXT EXT INS MADDU MSUBU MADD MSUB TEQ): replaces generate_trace
  * (trace.rs:42-84), which also records the byte lookups (counted into `blu` if given). Events are the #[repr(C)] MiscEvents of
  * crates/core/executor/src/events/instr.rs:239-261 (60 bytes). 72 columns, zero padding rows. */

@@ -687,4 +687,36 @@ int orc_tracegen_keccak_sponge(const void* blocks, size_t n_blocks, int fixed_lo
   ORC_CATCH
 }
 
+// SHA-256 precompile chips: flattened ShaExtendEvents (1251 words, 48 rows each, 176 columns), ShaCompressEvents (412 words, 80 rows, 262)
+int orc_tracegen_sha_extend(const void* events, size_t n_events, int fixed_log2_rows, uint32_t* out, size_t out_cap, size_t* rows,
+                            uint32_t* byte_counts) {
+  ORC_TRY
+  size_t h;
+  std::vector<uint64_t> cnt(byte_counts ? tracegen::BYTE_ROWS * tracegen::NUM_BYTE_OPS : 0, 0);
+  std::vector<F> t = tracegen::generate_sha_extend((const tracegen::ShaExtendEvent*)events, n_events, fixed_log2_rows, &h,
+                                                   byte_counts && out ? cnt.data() : nullptr);
+  *rows = h;
+  if (out) {
+    if (t.size() > out_cap) throw std::runtime_error("trace buffer too small");
+    for (size_t i = 0; i < t.size(); i++) out[i] = to_monty(t[i]);
+    for (size_t i = 0; i < cnt.size(); i++) byte_counts[i] += (uint32_t)cnt[i];
+  }
+  ORC_CATCH
+}
+int orc_tracegen_sha_compress(const void* events, size_t n_events, int fixed_log2_rows, uint32_t* out, size_t out_cap, size_t* rows,
+                              uint32_t* byte_counts) {
+  ORC_TRY
+  size_t h;
+  std::vector<uint64_t> cnt(byte_counts ? tracegen::BYTE_ROWS * tracegen::NUM_BYTE_OPS : 0, 0);
+  std::vector<F> t = tracegen::generate_sha_compress((const tracegen::ShaCompressEvent*)events, n_events, fixed_log2_rows, &h,
+                                                     byte_counts && out ? cnt.data() : nullptr);
+  *rows = h;
+  if (out) {
+    if (t.size() > out_cap) throw std::runtime_error("trace buffer too small");
+    for (size_t i = 0; i < t.size(); i++) out[i] = to_monty(t[i]);
+    for (size_t i = 0; i < cnt.size(); i++) byte_counts[i] += (uint32_t)cnt[i];
+  }
+  ORC_CATCH
+}
+
 }  // extern "C"

@@ -1516,4 +1516,226 @@ static inline std::vector<F> generate_keccak_sponge(const KeccakSpongeBlock* blo
   return t;
 }
 
+// ---- SHA-256 precompile chips (syscall/precompiles/sha256/): ShaExtend (48 rows per call: one message-schedule word each) and
+// ShaCompress (80 rows per call: 8 that load the state, 64 rounds, 8 that add and store). Operation column groups (operations/):
+// FixedRotateRightOperation / FixedShiftRightOperation = value, shift, carry words (fixed_rotate_right.rs:13-22, fixed_shift_right.rs);
+// Xor / And / Not = the result word; Add4 / Add5 = value, one-hot carry flags per byte, carry (add4.rs:13-28, add5.rs); AddOperation =
+// value + three carries (add.rs). Byte lookups as each populate() records them.
+struct ShaOps {
+  std::vector<ByteLookup>* lk;
+  void range(uint32_t v) const {       // ByteRecord::add_u8_range_checks of a word: two lookups of byte pairs
+    lk->push_back(ByteLookup{B_U8RANGE, (uint8_t)v, (uint8_t)(v >> 8)});
+    lk->push_back(ByteLookup{B_U8RANGE, (uint8_t)(v >> 16), (uint8_t)(v >> 24)});
+  }
+  // fixed_rotate_right.rs:37-88 / fixed_shift_right.rs:37-84: bytes moved by rotation / 8, then every byte shifted by rotation % 8 with
+  // the bits that fall out carried into the byte below
+  uint32_t shift_or_rotate(F* r, uint32_t x, int rotation, bool rotate) const {
+    const int nbytes = rotation / 8, nbits = rotation % 8;
+    uint8_t in[4];
+    for (int i = 0; i < 4; i++) in[i] = rotate ? (uint8_t)(x >> (8 * ((i + nbytes) % 4))) : (i + nbytes < 4 ? (uint8_t)(x >> (8 * (i + nbytes))) : 0);
+    uint32_t first_shift = 0, last_carry = 0;
+    for (int i = 3; i >= 0; i--) {
+      const uint32_t shift = nbits ? in[i] >> nbits : in[i], carry = nbits ? in[i] & ((1u << nbits) - 1) : 0;
+      lk->push_back(ByteLookup{B_SHRCARRY, in[i], (uint8_t)nbits});
+      r[4 + i] = shift; r[8 + i] = carry;
+      if (i == 3) first_shift = shift; else r[i] = shift + last_carry * (1u << (8 - nbits));
+      last_carry = carry;
+    }
+    r[3] = rotate ? first_shift + last_carry * (1u << (8 - nbits)) : first_shift;
+    const uint32_t out = (uint32_t)r[0] | ((uint32_t)r[1] << 8) | ((uint32_t)r[2] << 16) | ((uint32_t)r[3] << 24);
+    if (out != (rotate ? (x >> rotation) | (x << (32 - rotation)) : x >> rotation)) throw std::runtime_error("tracegen: fixed rotate / shift");
+    return out;
+  }
+  uint32_t bitwise(F* r, int op, uint32_t x, uint32_t y) const {    // xor.rs / and.rs: the result word, one lookup per byte
+    const uint32_t out = op == B_XOR ? x ^ y : x & y;
+    word(r, out);
+    for (int i = 0; i < 4; i++) lk->push_back(ByteLookup{(uint8_t)op, (uint8_t)(x >> (8 * i)), (uint8_t)(y >> (8 * i))});
+    return out;
+  }
+  uint32_t not_(F* r, uint32_t x) const { word(r, ~x); range(x); return ~x; }     // not.rs:16-25
+  // add4.rs:31-73 / add5.rs: value, is_carry_0..k (one-hot per byte), carry
+  uint32_t add_many(F* r, const uint32_t* v, int n) const {
+    uint32_t sum = 0;
+    for (int k = 0; k < n; k++) sum += v[k];
+    word(r, sum);
+    uint32_t carry = 0;
+    for (int i = 0; i < 4; i++) {
+      uint32_t res = carry;
+      for (int k = 0; k < n; k++) res += (v[k] >> (8 * i)) & 0xff;
+      carry = res >> 8;
+      for (int c = 0; c < n; c++) r[4 + 4 * c + i] = carry == (uint32_t)c;
+      r[4 + 4 * n + i] = carry;
+    }
+    for (int k = 0; k < n; k++) range(v[k]);
+    range(sum);
+    return sum;
+  }
+  uint32_t add(F* r, uint32_t a, uint32_t b) const {                // add.rs:21-57: value, three carries
+    word(r, a + b);
+    uint32_t carry = 0;
+    for (int i = 0; i < 3; i++) {
+      carry = (((a >> (8 * i)) & 0xff) + ((b >> (8 * i)) & 0xff) + carry) > 255;
+      r[4 + i] = carry;
+    }
+    range(a); range(b); range(a + b);
+    return a + b;
+  }
+};
+
+// ShaExtendEvent (crates/core/executor/src/events/precompiles/sha256_extend.rs:9-24) with its Vecs at their fixed length of 48
+struct ShaExtendEvent {
+  uint32_t shard, clk, w_ptr;
+  MemoryReadRecord w_i_minus_15_reads[48], w_i_minus_2_reads[48], w_i_minus_16_reads[48], w_i_minus_7_reads[48];
+  MemoryWriteRecord w_i_writes[48];
+};
+static_assert(sizeof(ShaExtendEvent) == 4 * 1251, "flattened ShaExtendEvent is 1251 words");
+static const size_t SHA_EXTEND_WIDTH = 176;
+// ShaExtendCols::populate_flags (extend/flags.rs:13-38): g = the generator of the order-16 subgroup
+static inline void sha_extend_flags(F* r, size_t i, bool is_real) {
+  enum { I = 3, CYCLE_16 = 4, CYCLE_16_START = 5, CYCLE_16_END = 7, CYCLE_48 = 9, CYCLE_48_START = 12, CYCLE_48_END = 13 };
+  const F g = two_adic_generator(4);
+  r[CYCLE_16] = fpow(g, (i + 1) % 16);
+  is_zero_cols(fsub(r[CYCLE_16], g), r + CYCLE_16_START);
+  is_zero_cols(fsub(r[CYCLE_16], 1), r + CYCLE_16_END);
+  const size_t j = 16 + (i % 48);
+  r[I] = j;
+  r[CYCLE_48] = j < 32; r[CYCLE_48 + 1] = j >= 32 && j < 48; r[CYCLE_48 + 2] = j >= 48;
+  r[CYCLE_48_START] = r[CYCLE_48] * r[CYCLE_16_START + 1] * is_real;
+  r[CYCLE_48_END] = r[CYCLE_48 + 2] * r[CYCLE_16_END + 1] * is_real;
+}
+static inline std::vector<F> generate_sha_extend(const ShaExtendEvent* events, size_t n_events, int fixed_log2_rows, size_t* height,
+                                                 uint64_t* byte_counts) {
+  enum { SHARD = 0, CLK = 1, W_PTR = 2, W_I_MINUS_15 = 14, RR_7 = 23, RR_18 = 35, RS_3 = 47, S0_INTERMEDIATE = 59, S0 = 63, W_I_MINUS_2 = 67, RR_17 = 76,
+         RR_19 = 88, RS_10 = 100, S1_INTERMEDIATE = 112, S1 = 116, W_I_MINUS_16 = 120, W_I_MINUS_7 = 129, S2 = 138, W_I = 162, IS_REAL = 175 };
+  const size_t h = padded_rows(48 * n_events, fixed_log2_rows);
+  std::vector<F> t(h * SHA_EXTEND_WIDTH, 0);
+  std::vector<ByteLookup> lk;
+  const ShaOps ops{&lk};
+  auto read = [&](const MemoryReadRecord& m, F* r) { memory_access_cols(m.value, m.shard, m.timestamp, m.prev_shard, m.prev_timestamp, r, &lk); };
+  for (size_t row = 0; row < h; row++) {
+    F* r = t.data() + row * SHA_EXTEND_WIDTH;
+    if (row >= 48 * n_events) { sha_extend_flags(r, row, false); continue; }
+    const ShaExtendEvent& e = events[row / 48];
+    const size_t j = row % 48;
+    r[IS_REAL] = 1;
+    sha_extend_flags(r, j, true);
+    r[SHARD] = fu32(e.shard); r[CLK] = fu32(e.clk); r[W_PTR] = fu32(e.w_ptr);
+    read(e.w_i_minus_15_reads[j], r + W_I_MINUS_15);
+    read(e.w_i_minus_2_reads[j], r + W_I_MINUS_2);
+    read(e.w_i_minus_16_reads[j], r + W_I_MINUS_16);
+    read(e.w_i_minus_7_reads[j], r + W_I_MINUS_7);
+    const uint32_t w15 = e.w_i_minus_15_reads[j].value, w2 = e.w_i_minus_2_reads[j].value;
+    const uint32_t s0 = ops.bitwise(r + S0, B_XOR, ops.bitwise(r + S0_INTERMEDIATE, B_XOR, ops.shift_or_rotate(r + RR_7, w15, 7, true),
+                                                               ops.shift_or_rotate(r + RR_18, w15, 18, true)),
+                                    ops.shift_or_rotate(r + RS_3, w15, 3, false));
+    const uint32_t s1 = ops.bitwise(r + S1, B_XOR, ops.bitwise(r + S1_INTERMEDIATE, B_XOR, ops.shift_or_rotate(r + RR_17, w2, 17, true),
+                                                               ops.shift_or_rotate(r + RR_19, w2, 19, true)),
+                                    ops.shift_or_rotate(r + RS_10, w2, 10, false));
+    const uint32_t four[4] = {e.w_i_minus_16_reads[j].value, s0, e.w_i_minus_7_reads[j].value, s1};
+    const uint32_t w_i = ops.add_many(r + S2, four, 4);
+    if (e.w_i_writes[j].value != w_i) throw std::runtime_error("tracegen: ShaExtendEvent write is not the schedule word");
+    memory_write_cols(e.w_i_writes[j], r + W_I, &lk);
+  }
+  if (byte_counts)
+    for (const ByteLookup& b : lk) byte_counts[((size_t)b.b * 256 + b.c) * NUM_BYTE_OPS + b.op]++;
+  *height = h;
+  return t;
+}
+
+// ShaCompressEvent (events/precompiles/sha256_compress.rs:9-25) flattened: w and h are the values of the read records
+struct ShaCompressEvent {
+  uint32_t shard, clk, w_ptr, h_ptr;
+  MemoryReadRecord h_read_records[8], w_i_read_records[64];
+  MemoryWriteRecord h_write_records[8];
+};
+static_assert(sizeof(ShaCompressEvent) == 4 * 412, "flattened ShaCompressEvent is 412 words");
+static const size_t SHA_COMPRESS_WIDTH = 262;
+static const uint32_t SHA_COMPRESS_K[64] = {
+    0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98, 0x12835b01, 0x243185be, 0x550c7dc3,
+    0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174, 0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc, 0x2de92c6f, 0x4a7484aa, 0x5cb0a9dc, 0x76f988da,
+    0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147, 0x06ca6351, 0x14292967, 0x27b70a85, 0x2e1b2138, 0x4d2c6dfc, 0x53380d13,
+    0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85, 0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3, 0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070,
+    0x19a4c116, 0x1e376c08, 0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f, 0x682e6ff3, 0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208,
+    0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
+static inline std::vector<F> generate_sha_compress(const ShaCompressEvent* events, size_t n_events, int fixed_log2_rows, size_t* height,
+                                                   uint64_t* byte_counts) {
+  enum { SHARD = 0, CLK = 1, W_PTR = 2, H_PTR = 3, START = 4, OCTET = 5, OCTET_NUM = 13, MEM = 23, MEM_ADDR = 36, A = 37, K = 69, E_RR_6 = 73, E_RR_11 = 85,
+         E_RR_25 = 97, S1_INTERMEDIATE = 109, S1 = 113, E_AND_F = 117, E_NOT = 121, E_NOT_AND_G = 125, CH = 129, TEMP1 = 133, A_RR_2 = 161, A_RR_13 = 173,
+         A_RR_22 = 185, S0_INTERMEDIATE = 197, S0 = 201, A_AND_B = 205, A_AND_C = 209, B_AND_C = 213, MAJ_INTERMEDIATE = 217, MAJ = 221, TEMP2 = 225,
+         D_ADD_TEMP1 = 232, TEMP1_ADD_TEMP2 = 239, FINALIZED_OPERAND = 246, FINALIZE_ADD = 250, IS_INITIALIZE = 257, IS_COMPRESSION = 258,
+         IS_FINALIZE = 259, IS_LAST_ROW = 260, IS_REAL = 261 };
+  const size_t h = padded_rows(80 * n_events, fixed_log2_rows);
+  std::vector<F> t(h * SHA_COMPRESS_WIDTH, 0);
+  std::vector<ByteLookup> lk;
+  const ShaOps ops{&lk};
+  for (size_t ev = 0; ev < n_events; ev++) {
+    const ShaCompressEvent& e = events[ev];
+    uint32_t v[8], og[8];
+    for (int i = 0; i < 8; i++) v[i] = og[i] = e.h_read_records[i].value;
+    for (int step = 0; step < 80; step++) {
+      F* r = t.data() + (80 * ev + step) * SHA_COMPRESS_WIDTH;
+      const int octet = step % 8, octet_num = step / 8;
+      r[SHARD] = fu32(e.shard); r[CLK] = fu32(e.clk); r[W_PTR] = fu32(e.w_ptr); r[H_PTR] = fu32(e.h_ptr);
+      r[OCTET + octet] = 1; r[OCTET_NUM + octet_num] = 1; r[IS_REAL] = 1;
+      r[START] = step == 0;
+      if (octet_num == 0) {              // the state words are read (trace.rs:138-168)
+        r[IS_INITIALIZE] = 1;
+        const MemoryReadRecord& m = e.h_read_records[octet];
+        word(r + MEM, m.value);
+        memory_access_cols(m.value, m.shard, m.timestamp, m.prev_shard, m.prev_timestamp, r + MEM + 4, &lk);
+        r[MEM_ADDR] = fu32(e.h_ptr + 4 * octet);
+        for (int i = 0; i < 8; i++) word(r + A + 4 * i, v[i]);
+      } else if (octet_num < 9) {        // one round (:171-246)
+        const int j = step - 8;
+        word(r + K, SHA_COMPRESS_K[j]);
+        r[IS_COMPRESSION] = 1;
+        const MemoryReadRecord& m = e.w_i_read_records[j];
+        word(r + MEM, m.value);
+        memory_access_cols(m.value, m.shard, m.timestamp, m.prev_shard, m.prev_timestamp, r + MEM + 4, &lk);
+        r[MEM_ADDR] = fu32(e.w_ptr + 4 * j);
+        for (int i = 0; i < 8; i++) word(r + A + 4 * i, v[i]);
+        const uint32_t a = v[0], b = v[1], c = v[2], d = v[3], ee = v[4], f = v[5], g = v[6], hh = v[7];
+        const uint32_t s1 = ops.bitwise(r + S1, B_XOR, ops.bitwise(r + S1_INTERMEDIATE, B_XOR, ops.shift_or_rotate(r + E_RR_6, ee, 6, true),
+                                                                   ops.shift_or_rotate(r + E_RR_11, ee, 11, true)),
+                                        ops.shift_or_rotate(r + E_RR_25, ee, 25, true));
+        const uint32_t e_and_f = ops.bitwise(r + E_AND_F, B_AND, ee, f);
+        const uint32_t e_not = ops.not_(r + E_NOT, ee);
+        const uint32_t ch = ops.bitwise(r + CH, B_XOR, e_and_f, ops.bitwise(r + E_NOT_AND_G, B_AND, e_not, g));
+        const uint32_t five[5] = {hh, s1, ch, m.value, SHA_COMPRESS_K[j]};
+        const uint32_t temp1 = ops.add_many(r + TEMP1, five, 5);
+        const uint32_t s0 = ops.bitwise(r + S0, B_XOR, ops.bitwise(r + S0_INTERMEDIATE, B_XOR, ops.shift_or_rotate(r + A_RR_2, a, 2, true),
+                                                                   ops.shift_or_rotate(r + A_RR_13, a, 13, true)),
+                                        ops.shift_or_rotate(r + A_RR_22, a, 22, true));
+        const uint32_t a_and_b = ops.bitwise(r + A_AND_B, B_AND, a, b), a_and_c = ops.bitwise(r + A_AND_C, B_AND, a, c);
+        const uint32_t b_and_c = ops.bitwise(r + B_AND_C, B_AND, b, c);
+        const uint32_t maj = ops.bitwise(r + MAJ, B_XOR, ops.bitwise(r + MAJ_INTERMEDIATE, B_XOR, a_and_b, a_and_c), b_and_c);
+        const uint32_t temp2 = ops.add(r + TEMP2, s0, maj);
+        const uint32_t new_e = ops.add(r + D_ADD_TEMP1, d, temp1), new_a = ops.add(r + TEMP1_ADD_TEMP2, temp1, temp2);
+        v[7] = g; v[6] = f; v[5] = ee; v[4] = new_e; v[3] = c; v[2] = b; v[1] = a; v[0] = new_a;
+      } else {                           // the state is added to what was read and written back (:252-302)
+        r[IS_FINALIZE] = 1;
+        const uint32_t out = ops.add(r + FINALIZE_ADD, og[octet], v[octet]);
+        const MemoryWriteRecord& m = e.h_write_records[octet];
+        if (m.value != out || m.prev_value != og[octet]) throw std::runtime_error("tracegen: ShaCompressEvent write is not state + digest");
+        memory_write_cols(m, r + MEM, &lk);
+        r[MEM_ADDR] = fu32(e.h_ptr + 4 * octet);
+        for (int i = 0; i < 8; i++) word(r + A + 4 * i, v[i]);
+        word(r + FINALIZED_OPERAND, v[octet]);
+        r[IS_LAST_ROW] = octet == 7;
+      }
+    }
+  }
+  for (size_t row = 80 * n_events; row < h; row++) {       // padding rows keep the octet counters and k going (trace.rs:58-80)
+    F* r = t.data() + row * SHA_COMPRESS_WIDTH;
+    const size_t step = (row - 80 * n_events) % 80, octet = step % 8, octet_num = step / 8;
+    r[OCTET + octet] = 1; r[OCTET_NUM + octet_num] = 1;
+    if (octet_num != 0 && octet_num != 9) word(r + K, SHA_COMPRESS_K[(octet_num - 1) * 8 + octet]);
+    r[IS_LAST_ROW] = octet == 7 && octet_num == 9;
+  }
+  if (byte_counts)
+    for (const ByteLookup& b : lk) byte_counts[((size_t)b.b * 256 + b.c) * NUM_BYTE_OPS + b.op]++;
+  *height = h;
+  return t;
+}
+
 }  // namespace tracegen

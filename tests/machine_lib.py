@@ -77,7 +77,7 @@ class Oracle:
             return fn[what](a[0], a[1])
         fn = {"branch": O.tracegen_branch, "memory_instrs": O.tracegen_memory_instrs, "misc_instrs": O.tracegen_misc_instrs, "mul": O.tracegen_mul,
               "divrem": O.tracegen_divrem, "global": O.tracegen_global, "poseidon2_permute": O.tracegen_poseidon2_permute,
-              "keccak_sponge": O.tracegen_keccak_sponge}
+              "keccak_sponge": O.tracegen_keccak_sponge, "sha_extend": O.tracegen_sha_extend, "sha_compress": O.tracegen_sha_compress}
         if what in fn:
             return fn[what](a[0], a[1], c)
         if what == "syscall_table":
@@ -112,7 +112,7 @@ class Device:
             return fn[what](a[0], a[1])
         fn = {"branch": ctx.tracegen_branch, "memory_instrs": ctx.tracegen_memory_instrs, "misc_instrs": ctx.tracegen_misc_instrs, "mul": ctx.tracegen_mul,
               "divrem": ctx.tracegen_divrem, "global": ctx.tracegen_global, "poseidon2_permute": ctx.tracegen_poseidon2_permute,
-              "keccak_sponge": ctx.tracegen_keccak_sponge}
+              "keccak_sponge": ctx.tracegen_keccak_sponge, "sha_extend": ctx.tracegen_sha_extend, "sha_compress": ctx.tracegen_sha_compress}
         if what in fn:
             return fn[what](a[0], a[1], blu)
         if what == "syscall_table":
@@ -173,6 +173,12 @@ def build_shard(src, machine, k):
         if len(rec.keccak_sponge):
             lh = log2_rows(24 * len(rec.keccak_sponge))
             add(chips.record_keccak_sponge_chip(lh), src.trace("keccak_sponge", rec.keccak_sponge, lh))
+        if len(rec.sha_extend):
+            lh = log2_rows(48 * len(rec.sha_extend))
+            add(chips.record_sha_extend_chip(lh), src.trace("sha_extend", rec.sha_extend, lh))
+        if len(rec.sha_compress):
+            lh = log2_rows(80 * len(rec.sha_compress))
+            add(chips.record_sha_compress_chip(lh), src.trace("sha_compress", rec.sha_compress, lh))
     else:
         for finalize, ev, prev in ((False, rec.memory_init, sh.pv["previous_init_addr"]), (True, rec.memory_finalize, sh.pv["previous_finalize_addr"])):
             if len(ev):

@@ -387,6 +387,24 @@ def tracegen_keccak_sponge(blocks, fixed_log2_rows=-1, byte_counts=None):
                            C.c_int(fixed_log2_rows), tail=bc)
 
 
+def tracegen_sha_extend(events, fixed_log2_rows=-1, byte_counts=None):
+    """ShaExtend precompile rows from flattened ShaExtendEvents (events.SHA_EXTEND_EVENT), 48 rows per event."""
+    from ziren_amd import events as E
+    ev = np.ascontiguousarray(events, dtype=E.SHA_EXTEND_EVENT)
+    bc = (abi.as_u32p(byte_counts),) if byte_counts is not None else (None,)
+    return _rows_then_fill(lib().orc_tracegen_sha_extend, E.SHA_EXTEND_WIDTH, C.c_void_p(ev.ctypes.data), C.c_size_t(len(ev)),
+                           C.c_int(fixed_log2_rows), tail=bc)
+
+
+def tracegen_sha_compress(events, fixed_log2_rows=-1, byte_counts=None):
+    """ShaCompress precompile rows from flattened ShaCompressEvents (events.SHA_COMPRESS_EVENT), 80 rows per event."""
+    from ziren_amd import events as E
+    ev = np.ascontiguousarray(events, dtype=E.SHA_COMPRESS_EVENT)
+    bc = (abi.as_u32p(byte_counts),) if byte_counts is not None else (None,)
+    return _rows_then_fill(lib().orc_tracegen_sha_compress, E.SHA_COMPRESS_WIDTH, C.c_void_p(ev.ctypes.data), C.c_size_t(len(ev)),
+                           C.c_int(fixed_log2_rows), tail=bc)
+
+
 def septic_known_answers(a, b):
     """((z^i)^p, (z^i)^(p^2) for i = 1..6, a * b, normalised sqrt(a^2)) in the septic extension, canonical words."""
     a = np.ascontiguousarray(a, dtype=np.uint32)

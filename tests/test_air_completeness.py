@@ -86,6 +86,36 @@ def sweep(oracle, m):
     return seen, holes
 
 
+def windowed_sweep(rec, chip, t, rows, chunk=512):
+    """The same question for a chip whose rows come many to an event (KeccakSponge, ShaExtend, ShaCompress): every column, changed on one of
+    `rows`, must be noticed by a constraint or by the chip's lookups. The constraints only look at a row and its successor, so all variants
+    of a row are evaluated in one pass over a stack of three-row windows (`rows` must not contain the first or the last row of the table:
+    the boundary selectors are not reproduced in the stack). Returns the columns nothing noticed."""
+    t = t.astype(np.uint64)
+    w = t.shape[1]
+    caught = np.zeros(w, dtype=bool)
+    for r in rows:
+        todo = np.nonzero(~caught)[0]
+        if not len(todo):
+            break
+        for lo in range(0, len(todo), chunk):
+            cols = todo[lo:lo + chunk]
+            stack = np.concatenate([t[r + 1:r + 2], np.tile(t[r - 1:r + 2], (len(cols), 1))])
+            at = 2 + 3 * np.arange(len(cols))
+            stack[at, cols] = (stack[at, cols] + 1) % F.P
+            bad = air.violated_rows(rec.b, stack)
+            caught[cols] |= bad[at - 1] | bad[at]          # the changed row as `next`, then as `local`
+        one = chips.RecordedChip(name=chip.name, log_height=0, main_width=w, sends=chip.sends, receives=chip.receives)
+        one.trace, one.prep_trace = F.to_monty(t[r:r + 1]), None
+        base = lookup_tally([one])
+        for col in np.nonzero(~caught)[0]:
+            row = t[r:r + 1].copy()
+            row[0, col] = (row[0, col] + 1) % F.P
+            one.trace = F.to_monty(row)
+            caught[col] = lookup_tally([one]) != base
+    return [int(c) for c in np.nonzero(~caught)[0]]
+
+
 def test_every_column_of_every_core_chip_is_bound(oracle):
     m = M.run_machine(2500, seed=15, shard_cycles=1 << 20, poseidon2_calls=1)
     seen, holes = sweep(oracle, m)

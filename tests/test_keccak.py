@@ -16,7 +16,6 @@ import pytest
 from ziren_amd import abi, air, chips, events as E, field as F, miniexec as M, synth
 
 import machine_lib as ML
-from test_chip_airs import lookup_tally
 from test_machine import ZERO_DIGEST, check_machine_airs, global_digests, gpu_prove_machine
 
 # Keccak-256 of b"abc" and of the empty string's neighbour cases, from the Keccak team's test vectors (also what the guest library's
@@ -118,34 +117,12 @@ def test_every_keccak_sponge_column_is_bound(oracle):
     """The completeness sweep of tests/test_air_completeness.py for this chip: every one of the 3531 columns, changed on one of six rows
     (first row of a call, of a later block, a middle round, the last round of a block that is absorbed on, of a call's last block, of the
     whole table), must be noticed by a constraint or by the chip's lookups. The constraints only look at a row and its successor, so all
-    3531 variants of a row are evaluated in one pass over a stack of three-row windows."""
+    3531 variants of a row are evaluated in one pass over a stack of three-row windows (test_air_completeness.windowed_sweep)."""
+    from test_air_completeness import windowed_sweep
     blocks, _ = two_calls()
-    t = F.from_monty(oracle.tracegen_keccak_sponge(blocks)).astype(np.uint64)
-    rec = chips.record_keccak_sponge_constraints()
-    chip = chips.record_keccak_sponge_chip(7)
-    w = t.shape[1]
-    caught = np.zeros(w, dtype=bool)
-    for r in (72, 24, 31, 23, 71, 95):
-        todo = np.nonzero(~caught)[0]
-        if not len(todo):
-            break
-        for lo in range(0, len(todo), 512):
-            cols = todo[lo:lo + 512]
-            stack = np.concatenate([t[r + 1:r + 2], np.tile(t[r - 1:r + 2], (len(cols), 1))])
-            at = 2 + 3 * np.arange(len(cols))
-            stack[at, cols] = (stack[at, cols] + 1) % F.P
-            bad = air.violated_rows(rec.b, stack)
-            caught[cols] |= bad[at - 1] | bad[at]          # the changed row as `next`, then as `local`
-        one = chips.RecordedChip(name="KeccakSponge", log_height=0, main_width=w, sends=chip.sends, receives=chip.receives)
-        one.trace, one.prep_trace = F.to_monty(t[r:r + 1]), None
-        base = lookup_tally([one])
-        for col in np.nonzero(~caught)[0]:
-            row = t[r:r + 1].copy()
-            row[0, col] = (row[0, col] + 1) % F.P
-            one.trace = F.to_monty(row)
-            caught[col] = lookup_tally([one]) != base
-    holes = [int(c) for c in np.nonzero(~caught)[0] if int(c) not in KECCAK_FREE]
-    assert holes == [], holes
+    t = F.from_monty(oracle.tracegen_keccak_sponge(blocks))
+    holes = windowed_sweep(chips.record_keccak_sponge_constraints(), chips.record_keccak_sponge_chip(7), t, (72, 24, 31, 23, 71, 95))
+    assert [c for c in holes if c not in KECCAK_FREE] == [], holes
 
 
 def keccak_machine():

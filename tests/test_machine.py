@@ -52,7 +52,8 @@ def check_machine_airs(oracle, m):
             rec = {"Cpu": chips.record_cpu_constraints, "SyscallInstrs": chips.record_syscall_instrs_constraints, "Global": chips.record_global_constraints,
                    "MemoryGlobalInit": lambda: chips.record_memory_global_constraints(False), "MemoryGlobalFinalize": lambda: chips.record_memory_global_constraints(True),
                    "SyscallCore": lambda: chips.record_syscall_table_constraints(False), "SyscallPrecompile": lambda: chips.record_syscall_table_constraints(True),
-                   "Poseidon2Permute": chips.record_poseidon2_permute_constraints, "KeccakSponge": chips.record_keccak_sponge_constraints}.get(c.name)
+                   "Poseidon2Permute": chips.record_poseidon2_permute_constraints, "KeccakSponge": chips.record_keccak_sponge_constraints,
+                   "ShaExtend": chips.record_sha_extend_constraints, "ShaCompress": chips.record_sha_compress_constraints}.get(c.name)
             if rec is not None:
                 assert air.debug_constraints(rec().b, F.from_monty(c.trace), public_values=pv) == [], (k, c.name)
         assert not any(lookup_tally(cs).values()), (k, sh.kind)

@@ -1705,6 +1705,295 @@ def _keccak_sponge(r: _Rec):
     _keccak_air(b, l, n)
 
 
+# ---- SHA-256 precompiles: the operation gadgets of crates/core/machine/src/operations/ they are built from ------------------------------
+
+def _fixed_shift_or_rotate(r: _Rec, x, rotation, cols, is_real, rotate):
+    """FixedRotateRightOperation::eval (fixed_rotate_right.rs:90-136) / FixedShiftRightOperation::eval (fixed_shift_right.rs:86-134):
+    cols = value(4), shift(4), carry(4)."""
+    b = r.b
+    nbytes, nbits = rotation // 8, rotation % 8
+    mult = 1 << (8 - nbits)
+    value, shift, carry = cols[0:4], cols[4:8], cols[8:12]
+    moved = [x[(i + nbytes) % 4] if rotate or i + nbytes < 4 else b.const(0) for i in range(4)]
+    first_shift = last_carry = None
+    for i in (3, 2, 1, 0):
+        r.send_byte_pair(B_SHRCARRY, shift[i], carry[i], moved[i], nbits, is_real)
+        if i == 3:
+            first_shift = shift[i]
+        else:
+            b.assert_eq(value[i], shift[i] + last_carry * mult)
+        last_carry = carry[i]
+    b.assert_eq(value[3], first_shift + last_carry * mult if rotate else first_shift)
+
+
+def _bitwise_op(r: _Rec, op, x, y, value, is_real):
+    """XorOperation::eval (xor.rs:39-57) / AndOperation::eval (and.rs:42-60)."""
+    for i in range(4):
+        r.send_byte(op, value[i], x[i], y[i], is_real)
+
+
+def _not_op(r: _Rec, x, value, is_real):
+    """NotOperation::eval (not.rs:28-52)."""
+    for i in (0, 2):
+        r.send_byte_pair(B_U8RANGE, 0, 0, x[i], x[i + 1], is_real)
+    for i in range(4):
+        r.b.when(is_real).assert_eq(value[i] + x[i], 255)
+
+
+def _add_many(r: _Rec, words, cols, is_real, range_checks_first):
+    """Add4Operation::eval (add4.rs:76-145) / Add5Operation::eval (add5.rs:83-153): cols = value(4), is_carry_0..n-1 (4 each), carry(4).
+    Add4 range-checks before it asserts is_real boolean, Add5 after."""
+    b, n = r.b, len(words)
+    value, carry = cols[0:4], cols[4 + 4 * n:8 + 4 * n]
+    flags = [cols[4 + 4 * c:8 + 4 * c] for c in range(n)]
+
+    def ranges():
+        for w in words:
+            r.slice_range_check_u8(w, is_real)
+        r.slice_range_check_u8(value, is_real)
+
+    if range_checks_first:
+        ranges()
+    b.assert_bool(is_real)
+    if not range_checks_first:
+        ranges()
+    real = b.when(is_real)
+    for i in range(4):
+        total = b.const(0)
+        for c in range(n):
+            real.assert_bool(flags[c][i])
+        for c in range(n):
+            total = flags[c][i] if c == 0 else total + flags[c][i]
+        real.assert_eq(total, 1)
+    for i in range(4):
+        acc = flags[1][i] * 1
+        for c in range(2, n):
+            acc = acc + flags[c][i] * c
+        real.assert_eq(carry[i], acc)
+    for i in range(4):
+        overflow = b.const(0) if n == 5 else None
+        for w in words:
+            overflow = w[i] if overflow is None else overflow + w[i]
+        overflow = overflow - value[i]
+        if i > 0:
+            overflow = overflow + carry[i - 1]
+        real.assert_eq(carry[i] * 256, overflow)
+
+
+def _add_op(r: _Rec, x, y, cols, is_real):
+    """AddOperation::eval (add.rs:59-106): cols = value(4), carry(3)."""
+    b = r.b
+    value, carry = cols[0:4], cols[4:7]
+    real = b.when(is_real)
+    ov = [x[0] + y[0] - value[0]] + [x[i] + y[i] - value[i] + carry[i - 1] for i in (1, 2, 3)]
+    real.assert_zero(ov[3] * (ov[3] - 256))
+    for i in range(3):
+        real.assert_zero(carry[i] * (ov[i] - 256))
+    for i in range(3):
+        real.assert_zero((carry[i] - 1) * ov[i])
+    for i in range(3):
+        real.assert_bool(carry[i])
+    real.assert_bool(is_real)
+    r.slice_range_check_u8(x, is_real)
+    r.slice_range_check_u8(y, is_real)
+    r.slice_range_check_u8(value, is_real)
+
+
+def _sha_extend(r: _Rec):
+    """ShaExtendChip::eval (syscall/precompiles/sha256/extend/air.rs:27-221) with eval_flags (extend/flags.rs:41-116): 48 rows per call,
+    row j computes w[16 + j] = w[j] + s0(w[j + 1]) + w[j + 9] + s1(w[j + 14]) at timestamp clk + j. The counters: cycle_16 walks the
+    order-16 subgroup, cycle_48 counts its laps."""
+    l, n, b = r.local, r.next, r.b
+    (SHARD, CLK, W_PTR, I, CYCLE_16, C16_START, C16_END, CYCLE_48, C48_START, C48_END, W15, RR_7, RR_18, RS_3, S0_INT, S0, W2, RR_17, RR_19, RS_10,
+     S1_INT, S1, W16, W7, S2, W_I, IS_REAL) = (0, 1, 2, 3, 4, 5, 7, 9, 12, 13, 14, 23, 35, 47, 59, 63, 67, 76, 88, 100, 112, 116, 120, 129, 138, 162, 175)
+    is_real = l[IS_REAL]
+    g = air.F.two_adic_generator(4)
+    # eval_flags
+    b.when_first_row().assert_eq(l[CYCLE_16], g)
+    b.when_first_row().assert_eq(l[I], 16)
+    b.when_transition().assert_eq(l[CYCLE_16] * g, n[CYCLE_16])
+    _is_zero(b, l[CYCLE_16] - g, l[C16_START:C16_START + 2], b.const(1))
+    _is_zero(b, l[CYCLE_16] - 1, l[C16_END:C16_END + 2], b.const(1))
+    start16, end16 = l[C16_START + 1], l[C16_END + 1]
+    b.when_first_row().assert_eq(l[CYCLE_48], 1)
+    b.when_first_row().assert_eq(l[CYCLE_48 + 1], 0)
+    b.when_first_row().assert_eq(l[CYCLE_48 + 2], 0)
+    for i in range(3):
+        b.when_transition().when(end16).assert_eq(l[CYCLE_48 + i], n[CYCLE_48 + (i + 1) % 3])
+        b.when_transition().when(1 - end16).assert_eq(l[CYCLE_48 + i], n[CYCLE_48 + i])
+        b.assert_bool(l[CYCLE_48 + i])
+    b.assert_eq(start16 * l[CYCLE_48] * is_real, l[C48_START])
+    b.assert_eq(end16 * l[CYCLE_48 + 2] * is_real, l[C48_END])
+    b.when_transition().when(end16 * l[CYCLE_48 + 2]).assert_eq(n[I], 16)
+    b.when_transition().when_not(end16 * l[CYCLE_48 + 2]).assert_eq(l[I] + 1, n[I])
+    # the inputs stay until the 48 rows are done
+    for c in (SHARD, CLK, W_PTR):
+        b.when_transition().when_not(end16 * l[CYCLE_48 + 2]).assert_eq(l[c], n[c])
+    clk = l[CLK] + (l[I] - 16)
+    reads = {W15: 15, W2: 2, W16: 16, W7: 7}
+    for base in (W15, W2, W16, W7):
+        mem = l[base:base + 9]
+        r.eval_memory_access(l[SHARD], clk, l[W_PTR] + (l[I] - reads[base]) * 4, mem[0:4], mem, is_real)
+    w15, w2, w16, w7 = l[W15:W15 + 4], l[W2:W2 + 4], l[W16:W16 + 4], l[W7:W7 + 4]
+    _fixed_shift_or_rotate(r, w15, 7, l[RR_7:RR_7 + 12], is_real, True)
+    _fixed_shift_or_rotate(r, w15, 18, l[RR_18:RR_18 + 12], is_real, True)
+    _fixed_shift_or_rotate(r, w15, 3, l[RS_3:RS_3 + 12], is_real, False)
+    _bitwise_op(r, B_XOR, l[RR_7:RR_7 + 4], l[RR_18:RR_18 + 4], l[S0_INT:S0_INT + 4], is_real)
+    _bitwise_op(r, B_XOR, l[S0_INT:S0_INT + 4], l[RS_3:RS_3 + 4], l[S0:S0 + 4], is_real)
+    _fixed_shift_or_rotate(r, w2, 17, l[RR_17:RR_17 + 12], is_real, True)
+    _fixed_shift_or_rotate(r, w2, 19, l[RR_19:RR_19 + 12], is_real, True)
+    _fixed_shift_or_rotate(r, w2, 10, l[RS_10:RS_10 + 12], is_real, False)
+    _bitwise_op(r, B_XOR, l[RR_17:RR_17 + 4], l[RR_19:RR_19 + 4], l[S1_INT:S1_INT + 4], is_real)
+    _bitwise_op(r, B_XOR, l[S1_INT:S1_INT + 4], l[RS_10:RS_10 + 4], l[S1:S1 + 4], is_real)
+    _add_many(r, [w16, l[S0:S0 + 4], w7, l[S1:S1 + 4]], l[S2:S2 + 24], is_real, True)
+    w_i = l[W_I:W_I + 13]
+    r.eval_memory_access(l[SHARD], clk, l[W_PTR] + l[I] * 4, w_i[0:4], w_i[4:13], is_real)
+    for k in range(4):
+        b.assert_eq(w_i[4 + k], l[S2 + k])
+    r.receives.append(air.Lookup([air.to_virtual_pair(v) for v in [l[SHARD], l[CLK], b.const(E.SYS_SHA_EXTEND & 0xffff), l[W_PTR], b.const(0)]],
+                                 air.to_virtual_pair(l[C48_START]), air.KIND_SYSCALL))
+    b.assert_bool(is_real)
+    b.when_transition().when_not(l[C48_END]).assert_eq(is_real, n[IS_REAL])
+    b.when_last_row().assert_zero(is_real)
+
+
+def _sha_compress(r: _Rec):
+    """ShaCompressChip::eval (syscall/precompiles/sha256/compress/air.rs:33-506): 80 rows per call, counted by octet (row within eight) and
+    octet_num (which eight): octet_num 0 reads the state words, 1..8 run the 64 rounds (one w[i] read each), 9 adds the result to the words
+    read and writes them back at clk + 1."""
+    l, n, b = r.local, r.next, r.b
+    (SHARD, CLK, W_PTR, H_PTR, START, OCTET, OCTET_NUM, MEM, MEM_ADDR, A, K, E_RR_6, E_RR_11, E_RR_25, S1_INT, S1, E_AND_F, E_NOT, E_NOT_AND_G, CH, TEMP1,
+     A_RR_2, A_RR_13, A_RR_22, S0_INT, S0, A_AND_B, A_AND_C, B_AND_C, MAJ_INT, MAJ, TEMP2, D_ADD_TEMP1, TEMP1_ADD_TEMP2, FIN_OPERAND, FIN_ADD, IS_INIT,
+     IS_COMP, IS_FIN, IS_LAST, IS_REAL) = (0, 1, 2, 3, 4, 5, 13, 23, 36, 37, 69, 73, 85, 97, 109, 113, 117, 121, 125, 129, 133, 161, 173, 185, 197, 201,
+                                           205, 209, 213, 217, 221, 225, 232, 239, 246, 250, 257, 258, 259, 260, 261)
+    is_real = l[IS_REAL]
+    octet, octet_num = l[OCTET:OCTET + 8], l[OCTET_NUM:OCTET_NUM + 10]
+    word_at = lambda row, i: row[A + 4 * i:A + 4 * i + 4]      # noqa: E731   a..h
+    mem_prev, mem_value = l[MEM:MEM + 4], l[MEM + 4:MEM + 8]
+    # eval_control_flow_flags (:60-208)
+    for i in range(8):
+        b.assert_bool(octet[i])
+    total = b.const(0)
+    for i in range(8):
+        total = total + octet[i]
+    b.assert_one(total)
+    b.when_first_row().assert_one(octet[0])
+    for i in range(8):
+        b.when_transition().when(octet[i]).assert_one(n[OCTET + (i + 1) % 8])
+    for i in range(10):
+        b.assert_bool(octet_num[i])
+    total = b.const(0)
+    for i in range(10):
+        total = total + octet_num[i]
+    b.assert_one(total)
+    b.when_first_row().assert_one(octet_num[0])
+    for i in range(10):
+        b.when_transition().when_not(octet[7]).assert_eq(octet_num[i], n[OCTET_NUM + i])
+    for i in range(10):
+        b.when_transition().when(octet[7]).assert_eq(octet_num[i], n[OCTET_NUM + (i + 1) % 10])
+    for i in range(8):
+        for k in range(4):
+            b.when_transition().when(octet_num[0] + octet_num[9] * (1 - octet[7])).assert_eq(word_at(l, i)[k], word_at(n, i)[k])
+        for k in range(4):
+            b.when_transition().when(octet_num[0] * octet[i]).assert_eq(word_at(l, i)[k], mem_value[k])
+    b.assert_eq(l[IS_INIT], octet_num[0] * is_real)
+    b.assert_eq(l[IS_COMP], (octet_num[1] + octet_num[2] + octet_num[3] + octet_num[4] + octet_num[5] + octet_num[6] + octet_num[7] + octet_num[8]) * is_real)
+    b.assert_eq(l[IS_FIN], octet_num[9] * is_real)
+    b.assert_eq(l[IS_LAST], octet[7] * octet_num[9])
+    for c in (SHARD, CLK, W_PTR, H_PTR):
+        b.when_transition().when(is_real).when_not(l[IS_LAST]).assert_eq(l[c], n[c])
+    b.assert_bool(is_real)
+    b.when_transition().when(is_real).when_not(l[IS_LAST]).assert_one(n[IS_REAL])
+    b.when_transition().when_not(is_real).assert_zero(n[IS_REAL])
+    b.when_last_row().assert_zero(is_real)
+    # eval_memory (:210-271)
+    r.eval_memory_access(l[SHARD], l[CLK] + l[IS_FIN], l[MEM_ADDR], mem_prev, l[MEM + 4:MEM + 13], l[IS_INIT] + l[IS_COMP] + l[IS_FIN])
+    cycle_num = b.const(0)
+    for i in range(10):
+        cycle_num = cycle_num + octet_num[i] * i
+    cycle_step = b.const(0)
+    for i in range(8):
+        cycle_step = cycle_step + octet[i] * i
+    b.when(l[IS_INIT]).assert_eq(l[MEM_ADDR], l[H_PTR] + cycle_step * 4)
+    b.when(l[IS_COMP]).assert_eq(l[MEM_ADDR], l[W_PTR] + ((cycle_num - 1) * 8 + cycle_step) * 4)
+    b.when(l[IS_FIN]).assert_eq(l[MEM_ADDR], l[H_PTR] + cycle_step * 4)
+    for i in range(8):
+        for k in range(4):
+            b.when(l[IS_INIT]).when(octet[i]).assert_eq(word_at(l, i)[k], mem_prev[k])
+        for k in range(4):
+            b.when(l[IS_INIT]).when(octet[i]).assert_eq(word_at(l, i)[k], mem_value[k])
+    for k in range(4):
+        b.when(l[IS_COMP]).assert_eq(mem_prev[k], mem_value[k])
+    for k in range(4):
+        b.when(l[IS_FIN]).assert_eq(mem_value[k], l[FIN_ADD + k])
+    # eval_compression_ops (:273-469)
+    for i in range(64):
+        for k in range(4):
+            b.when(octet_num[i // 8 + 1] * octet[i % 8]).assert_eq(l[K + k], (E.SHA_COMPRESS_K[i] >> (8 * k)) & 0xff)
+    comp = l[IS_COMP]
+    a_, b_, c_, d_, e_, f_, g_, h_ = (word_at(l, i) for i in range(8))
+    grp = lambda base, w=4: l[base:base + w]      # noqa: E731
+    _fixed_shift_or_rotate(r, e_, 6, grp(E_RR_6, 12), comp, True)
+    _fixed_shift_or_rotate(r, e_, 11, grp(E_RR_11, 12), comp, True)
+    _fixed_shift_or_rotate(r, e_, 25, grp(E_RR_25, 12), comp, True)
+    _bitwise_op(r, B_XOR, grp(E_RR_6), grp(E_RR_11), grp(S1_INT), comp)
+    _bitwise_op(r, B_XOR, grp(S1_INT), grp(E_RR_25), grp(S1), comp)
+    _bitwise_op(r, B_AND, e_, f_, grp(E_AND_F), comp)
+    _not_op(r, e_, grp(E_NOT), comp)
+    _bitwise_op(r, B_AND, grp(E_NOT), g_, grp(E_NOT_AND_G), comp)
+    _bitwise_op(r, B_XOR, grp(E_AND_F), grp(E_NOT_AND_G), grp(CH), comp)
+    _add_many(r, [h_, grp(S1), grp(CH), grp(K), mem_value], grp(TEMP1, 28), comp, False)
+    _fixed_shift_or_rotate(r, a_, 2, grp(A_RR_2, 12), comp, True)
+    _fixed_shift_or_rotate(r, a_, 13, grp(A_RR_13, 12), comp, True)
+    _fixed_shift_or_rotate(r, a_, 22, grp(A_RR_22, 12), comp, True)
+    _bitwise_op(r, B_XOR, grp(A_RR_2), grp(A_RR_13), grp(S0_INT), comp)
+    _bitwise_op(r, B_XOR, grp(S0_INT), grp(A_RR_22), grp(S0), comp)
+    _bitwise_op(r, B_AND, a_, b_, grp(A_AND_B), comp)
+    _bitwise_op(r, B_AND, a_, c_, grp(A_AND_C), comp)
+    _bitwise_op(r, B_AND, b_, c_, grp(B_AND_C), comp)
+    _bitwise_op(r, B_XOR, grp(A_AND_B), grp(A_AND_C), grp(MAJ_INT), comp)
+    _bitwise_op(r, B_XOR, grp(MAJ_INT), grp(B_AND_C), grp(MAJ), comp)
+    _add_op(r, grp(S0), grp(MAJ), grp(TEMP2, 7), comp)
+    _add_op(r, d_, grp(TEMP1), grp(D_ADD_TEMP1, 7), comp)
+    _add_op(r, grp(TEMP1), grp(TEMP2), grp(TEMP1_ADD_TEMP2, 7), comp)
+    moves = [(7, g_), (6, f_), (5, e_), (4, grp(D_ADD_TEMP1)), (3, c_), (2, b_), (1, a_), (0, grp(TEMP1_ADD_TEMP2))]
+    for i, src in moves:
+        for k in range(4):
+            b.when_transition().when(comp).assert_eq(word_at(n, i)[k], src[k])
+    # eval_finalize_ops (:471-505)
+    for k in range(4):
+        picked = b.const(0)
+        for i in range(8):
+            picked = picked + octet[i] * word_at(l, i)[k]
+        b.when(l[IS_FIN]).assert_eq(picked, l[FIN_OPERAND + k])
+    _add_op(r, mem_prev, grp(FIN_OPERAND), grp(FIN_ADD, 7), l[IS_FIN])
+    b.assert_eq(l[START], is_real * octet[0] * octet_num[0])
+    r.receives.append(air.Lookup([air.to_virtual_pair(v) for v in [l[SHARD], l[CLK], b.const(E.SYS_SHA_COMPRESS & 0xffff), l[W_PTR], l[H_PTR]]],
+                                 air.to_virtual_pair(l[START]), air.KIND_SYSCALL))
+
+
+def record_sha_extend_constraints() -> _Rec:
+    r = _Rec(E.SHA_EXTEND_WIDTH)
+    _sha_extend(r)
+    return r
+
+
+def record_sha_extend_chip(log_height: int) -> RecordedChip:
+    """The ShaExtend precompile (crates/core/machine/src/syscall/precompiles/sha256/extend/): 48 rows per call, 176 columns."""
+    return _finish(record_sha_extend_constraints(), "ShaExtend", log_height, E.SHA_EXTEND_WIDTH, False)
+
+
+def record_sha_compress_constraints() -> _Rec:
+    r = _Rec(E.SHA_COMPRESS_WIDTH)
+    _sha_compress(r)
+    return r
+
+
+def record_sha_compress_chip(log_height: int) -> RecordedChip:
+    """The ShaCompress precompile (crates/core/machine/src/syscall/precompiles/sha256/compress/): 80 rows per call, 262 columns."""
+    return _finish(record_sha_compress_constraints(), "ShaCompress", log_height, E.SHA_COMPRESS_WIDTH, False)
+
+
 def record_memory_global_constraints(finalize: bool) -> _Rec:
     r = _Rec(E.MEMORY_GLOBAL_WIDTH)
     _memory_global(r, finalize)

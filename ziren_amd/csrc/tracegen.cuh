@@ -1444,6 +1444,247 @@ __global__ __launch_bounds__(THREADS) void keccak_sponge_rows(const uint32_t* __
   }
 }
 
+// ---- SHA-256 precompiles (syscall/precompiles/sha256/): ShaExtend — 48 rows per call, row j holds w[16 + j] = w[j] + s0(w[j + 1]) +
+// w[j + 9] + s1(w[j + 14]) with every rotate / shift / xor / add spelled out in byte columns (extend/columns.rs:17-73, trace.rs:103-150) —
+// and ShaCompress — 80 rows per call: eight that read the state, the 64 rounds, eight that add the result to the words read and write
+// them back (compress/columns.rs:17-108, trace.rs:127-302). One thread per row builds the row as canonical integers in registers /
+// scratch and stores it column by column; a ShaCompress thread first re-runs the rounds before its own (at most 63, a few dozen integer
+// operations each). The operation gadgets (operations/fixed_rotate_right.rs, fixed_shift_right.rs, xor.rs, and.rs, not.rs, add.rs,
+// add4.rs, add5.rs) are the ShaOps methods: each fills its columns and records the byte lookups its populate() records.
+constexpr int SHA_EXTEND_WIDTH = 176, SHA_EXTEND_EVENT_WORDS = 1251, SHA_COMPRESS_WIDTH = 262, SHA_COMPRESS_EVENT_WORDS = 412;
+// the order-16 subgroup g^k (g = two_adic_generator(4)) and the inverses of g^k - g and g^k - 1 (0 where that is 0): ShaExtendCols::populate_flags
+__constant__ uint32_t d_sha_cycle16[16] = {1u, 148625052u, 1748172362u, 665723362u, 2113994754u, 982097957u, 391001680u, 668978722u, 2130706432u,
+                                           1982081381u, 382534071u, 1464983071u, 16711679u, 1148608476u, 1739704753u, 1461727711u};
+__constant__ uint32_t d_sha_inv_start[16] = {1228590512u, 0u, 1571094643u, 501619392u, 497113253u, 1627680u, 962112900u, 1167342754u, 1236834581u,
+                                             334489361u, 1562850574u, 1632342401u, 1837572255u, 667351042u, 171865469u, 167359330u};
+__constant__ uint32_t d_sha_inv_end[16] = {0u, 902115921u, 1069475251u, 1703008016u, 8355839u, 1728187304u, 1052763572u, 893871851u, 1065353216u,
+                                           1236834581u, 1077942860u, 402519128u, 2122350593u, 427698416u, 1061231181u, 1228590511u};
+__constant__ uint32_t d_sha_k[64] = {
+    0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98, 0x12835b01, 0x243185be, 0x550c7dc3,
+    0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174, 0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc, 0x2de92c6f, 0x4a7484aa, 0x5cb0a9dc, 0x76f988da,
+    0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147, 0x06ca6351, 0x14292967, 0x27b70a85, 0x2e1b2138, 0x4d2c6dfc, 0x53380d13,
+    0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85, 0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3, 0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070,
+    0x19a4c116, 0x1e376c08, 0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f, 0x682e6ff3, 0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208,
+    0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
+struct ShaOps {
+  const LookupSink& sink;
+  bool count;
+  __device__ __forceinline__ void range(uint32_t v) const {
+    if (count) { lookup(sink, B_U8RANGE, v, v >> 8); lookup(sink, B_U8RANGE, v >> 16, v >> 24); }
+  }
+  // value(4), shift(4), carry(4): bytes moved by rotation / 8, then shifted by rotation % 8 with the bits that fall out carried down
+  __device__ __forceinline__ uint32_t shift_or_rotate(uint32_t* r, uint32_t x, int rotation, bool rotate) const {
+    const int nbytes = rotation / 8, nbits = rotation % 8;
+    uint32_t first_shift = 0, last_carry = 0;
+    for (int i = 3; i >= 0; i--) {
+      const uint32_t in = rotate ? (x >> (8 * ((i + nbytes) % 4))) & 0xff : (i + nbytes < 4 ? (x >> (8 * (i + nbytes))) & 0xff : 0u);
+      const uint32_t shift = in >> nbits, carry = in & ((1u << nbits) - 1);
+      if (count) lookup(sink, B_SHRCARRY, in, nbits);
+      r[4 + i] = shift; r[8 + i] = carry;
+      if (i == 3) first_shift = shift; else r[i] = shift + (last_carry << (8 - nbits));
+      last_carry = carry;
+    }
+    r[3] = rotate ? first_shift + (last_carry << (8 - nbits)) : first_shift;
+    return rotate ? (x >> rotation) | (x << (32 - rotation)) : x >> rotation;
+  }
+  __device__ __forceinline__ uint32_t bitwise(uint32_t* r, uint32_t op, uint32_t x, uint32_t y) const {
+    const uint32_t out = op == B_XOR ? x ^ y : x & y;
+    word(r, out);
+    if (count)
+      for (int i = 0; i < 4; i++) lookup(sink, op, x >> (8 * i), y >> (8 * i));
+    return out;
+  }
+  __device__ __forceinline__ uint32_t not_(uint32_t* r, uint32_t x) const { word(r, ~x); range(x); return ~x; }
+  // value(4), is_carry_0..n-1 (4 each, one-hot per byte), carry(4)
+  __device__ __forceinline__ uint32_t add_many(uint32_t* r, const uint32_t* v, int n) const {
+    uint32_t sum = 0;
+    for (int k = 0; k < n; k++) sum += v[k];
+    word(r, sum);
+    uint32_t carry = 0;
+    for (int i = 0; i < 4; i++) {
+      uint32_t res = carry;
+      for (int k = 0; k < n; k++) res += (v[k] >> (8 * i)) & 0xff;
+      carry = res >> 8;
+      for (int c = 0; c < n; c++) r[4 + 4 * c + i] = fbool(carry == (uint32_t)c);
+      r[4 + 4 * n + i] = carry;
+    }
+    for (int k = 0; k < n; k++) range(v[k]);
+    range(sum);
+    return sum;
+  }
+  __device__ __forceinline__ uint32_t add(uint32_t* r, uint32_t a, uint32_t b) const {     // value(4), carry(3)
+    word(r, a + b);
+    uint32_t carry = 0;
+    for (int i = 0; i < 3; i++) {
+      carry = fbool((((a >> (8 * i)) & 0xff) + ((b >> (8 * i)) & 0xff) + carry) > 255);
+      r[4 + i] = carry;
+    }
+    range(a); range(b); range(a + b);
+    return a + b;
+  }
+  __device__ __forceinline__ void read(uint32_t* r, const uint32_t* rec) const {            // MemoryReadCols from a five-word record
+    memory_access_cols(rec[0], rec[1], rec[2], rec[3], rec[4], r);
+    if (count) access_lookups(r, sink);
+  }
+  __device__ __forceinline__ void write(uint32_t* r, const uint32_t* rec) const {           // MemoryWriteCols from a six-word record
+    memory_write_cols(rec, r);
+    if (count) { lookup(sink, B_U16RANGE, r[11] >> 8, r[11]); lookup(sink, B_U8RANGE, 0, r[12]); }
+  }
+};
+
+__global__ __launch_bounds__(THREADS) void sha_extend_rows(const uint32_t* __restrict__ events, size_t n_events, size_t height, uint32_t* __restrict__ out,
+                                                           uint32_t* counts, int* __restrict__ bad) {
+  enum { SHARD = 0, CLK = 1, W_PTR = 2, I = 3, CYCLE_16 = 4, CYCLE_16_START = 5, CYCLE_16_END = 7, CYCLE_48 = 9, CYCLE_48_START = 12, CYCLE_48_END = 13,
+         W_I_MINUS_15 = 14, RR_7 = 23, RR_18 = 35, RS_3 = 47, S0_INTERMEDIATE = 59, S0 = 63, W_I_MINUS_2 = 67, RR_17 = 76, RR_19 = 88, RS_10 = 100,
+         S1_INTERMEDIATE = 112, S1 = 116, W_I_MINUS_16 = 120, W_I_MINUS_7 = 129, S2 = 138, W_I = 162, IS_REAL = 175 };
+  enum { E_READS_15 = 3, E_READS_2 = 3 + 240, E_READS_16 = 3 + 480, E_READS_7 = 3 + 720, E_WRITES = 3 + 960 };
+  extern __shared__ uint32_t hash_lds[];
+  uint32_t* hkeys = hash_lds;
+  uint32_t* hvals = hash_lds + HASH_SLOTS;
+  const bool count = counts != nullptr;
+  if (count) {
+    for (int i = threadIdx.x; i < HASH_SLOTS; i += blockDim.x) { hkeys[i] = HASH_EMPTY; hvals[i] = 0; }
+    __syncthreads();
+  }
+  const size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (row < height) {
+    uint32_t r[SHA_EXTEND_WIDTH];
+    for (int c = 0; c < SHA_EXTEND_WIDTH; c++) r[c] = 0;
+    const bool real = row < 48 * n_events;
+    const size_t j = row % 48;               // a call's row; padding rows count on from the real ones (a multiple of 48)
+    const int k16 = (int)((j + 1) % 16);
+    r[CYCLE_16] = d_sha_cycle16[k16];
+    r[CYCLE_16_START] = d_sha_inv_start[k16]; r[CYCLE_16_START + 1] = fbool(k16 == 1);
+    r[CYCLE_16_END] = d_sha_inv_end[k16]; r[CYCLE_16_END + 1] = fbool(k16 == 0);
+    r[I] = 16 + (uint32_t)j;
+    r[CYCLE_48] = fbool(j < 16); r[CYCLE_48 + 1] = fbool(j >= 16 && j < 32); r[CYCLE_48 + 2] = fbool(j >= 32);
+    if (real) {
+      const uint32_t* e = events + (row / 48) * SHA_EXTEND_EVENT_WORDS;
+      const LookupSink sink{hkeys, hvals, HASH_SLOTS - 1, counts};
+      const ShaOps ops{sink, count};
+      r[IS_REAL] = 1;
+      r[CYCLE_48_START] = fbool(j == 0); r[CYCLE_48_END] = fbool(j == 47);
+      r[SHARD] = e[0]; r[CLK] = e[1]; r[W_PTR] = e[2];
+      const uint32_t *m15 = e + E_READS_15 + 5 * j, *m2 = e + E_READS_2 + 5 * j, *m16 = e + E_READS_16 + 5 * j, *m7 = e + E_READS_7 + 5 * j;
+      ops.read(r + W_I_MINUS_15, m15); ops.read(r + W_I_MINUS_2, m2); ops.read(r + W_I_MINUS_16, m16); ops.read(r + W_I_MINUS_7, m7);
+      const uint32_t w15 = m15[0], w2 = m2[0];
+      const uint32_t s0 = ops.bitwise(r + S0, B_XOR, ops.bitwise(r + S0_INTERMEDIATE, B_XOR, ops.shift_or_rotate(r + RR_7, w15, 7, true),
+                                                                 ops.shift_or_rotate(r + RR_18, w15, 18, true)),
+                                      ops.shift_or_rotate(r + RS_3, w15, 3, false));
+      const uint32_t s1 = ops.bitwise(r + S1, B_XOR, ops.bitwise(r + S1_INTERMEDIATE, B_XOR, ops.shift_or_rotate(r + RR_17, w2, 17, true),
+                                                                 ops.shift_or_rotate(r + RR_19, w2, 19, true)),
+                                      ops.shift_or_rotate(r + RS_10, w2, 10, false));
+      const uint32_t four[4] = {m16[0], s0, m7[0], s1};
+      const uint32_t w_i = ops.add_many(r + S2, four, 4);
+      const uint32_t* wr = e + E_WRITES + 6 * j;
+      if (wr[0] != w_i) *bad = 1;
+      ops.write(r + W_I, wr);
+    }
+    for (int c = 0; c < SHA_EXTEND_WIDTH; c++) out[(size_t)c * height + row] = kb::to_monty(r[c]);
+  }
+  if (count) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < HASH_SLOTS; i += blockDim.x)
+      if (hkeys[i] != HASH_EMPTY) atomicAdd(counts + hkeys[i], hvals[i]);
+  }
+}
+
+__global__ __launch_bounds__(THREADS) void sha_compress_rows(const uint32_t* __restrict__ events, size_t n_events, size_t height, uint32_t* __restrict__ out,
+                                                             uint32_t* counts, int* __restrict__ bad) {
+  enum { SHARD = 0, CLK = 1, W_PTR = 2, H_PTR = 3, START = 4, OCTET = 5, OCTET_NUM = 13, MEM = 23, MEM_ADDR = 36, A = 37, K = 69, E_RR_6 = 73, E_RR_11 = 85,
+         E_RR_25 = 97, S1_INTERMEDIATE = 109, S1 = 113, E_AND_F = 117, E_NOT = 121, E_NOT_AND_G = 125, CH = 129, TEMP1 = 133, A_RR_2 = 161, A_RR_13 = 173,
+         A_RR_22 = 185, S0_INTERMEDIATE = 197, S0 = 201, A_AND_B = 205, A_AND_C = 209, B_AND_C = 213, MAJ_INTERMEDIATE = 217, MAJ = 221, TEMP2 = 225,
+         D_ADD_TEMP1 = 232, TEMP1_ADD_TEMP2 = 239, FINALIZED_OPERAND = 246, FINALIZE_ADD = 250, IS_INITIALIZE = 257, IS_COMPRESSION = 258,
+         IS_FINALIZE = 259, IS_LAST_ROW = 260, IS_REAL = 261 };
+  enum { E_H_READS = 4, E_W_READS = 44, E_H_WRITES = 364 };
+  extern __shared__ uint32_t hash_lds[];
+  uint32_t* hkeys = hash_lds;
+  uint32_t* hvals = hash_lds + HASH_SLOTS;
+  const bool count = counts != nullptr;
+  if (count) {
+    for (int i = threadIdx.x; i < HASH_SLOTS; i += blockDim.x) { hkeys[i] = HASH_EMPTY; hvals[i] = 0; }
+    __syncthreads();
+  }
+  const size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (row < height) {
+    uint32_t r[SHA_COMPRESS_WIDTH];
+    for (int c = 0; c < SHA_COMPRESS_WIDTH; c++) r[c] = 0;
+    const bool real = row < 80 * n_events;
+    const int step = (int)(row % 80), octet = step % 8, octet_num = step / 8;
+    r[OCTET + octet] = 1; r[OCTET_NUM + octet_num] = 1;
+    r[IS_LAST_ROW] = fbool(step == 79);
+    if (!real) {
+      if (octet_num != 0 && octet_num != 9) word(r + K, d_sha_k[step - 8]);
+    } else {
+      const uint32_t* e = events + (row / 80) * SHA_COMPRESS_EVENT_WORDS;
+      const LookupSink sink{hkeys, hvals, HASH_SLOTS - 1, counts};
+      const ShaOps ops{sink, count};
+      r[IS_REAL] = 1;
+      r[SHARD] = e[0]; r[CLK] = e[1]; r[W_PTR] = e[2]; r[H_PTR] = e[3];
+      r[START] = fbool(step == 0);
+      uint32_t v[8], og[8];
+      for (int i = 0; i < 8; i++) v[i] = og[i] = e[E_H_READS + 5 * i];
+      const int rounds_before = octet_num == 0 ? 0 : octet_num == 9 ? 64 : step - 8;
+      for (int j = 0; j < rounds_before; j++) {     // Sha256CompressSyscall::execute's round (syscalls/precompiles/sha256/compress.rs:63-85)
+        const uint32_t a = v[0], b = v[1], c = v[2], d = v[3], ee = v[4], f = v[5], g = v[6], hh = v[7];
+        const uint32_t s1 = ((ee >> 6) | (ee << 26)) ^ ((ee >> 11) | (ee << 21)) ^ ((ee >> 25) | (ee << 7));
+        const uint32_t temp1 = hh + s1 + ((ee & f) ^ (~ee & g)) + d_sha_k[j] + e[E_W_READS + 5 * j];
+        const uint32_t s0 = ((a >> 2) | (a << 30)) ^ ((a >> 13) | (a << 19)) ^ ((a >> 22) | (a << 10));
+        const uint32_t temp2 = s0 + ((a & b) ^ (a & c) ^ (b & c));
+        v[7] = g; v[6] = f; v[5] = ee; v[4] = d + temp1; v[3] = c; v[2] = b; v[1] = a; v[0] = temp1 + temp2;
+      }
+      for (int i = 0; i < 8; i++) word(r + A + 4 * i, v[i]);
+      if (octet_num == 0) {
+        r[IS_INITIALIZE] = 1;
+        const uint32_t* m = e + E_H_READS + 5 * octet;
+        word(r + MEM, m[0]);
+        ops.read(r + MEM + 4, m);
+        r[MEM_ADDR] = e[3] + 4u * octet;
+      } else if (octet_num < 9) {
+        const int j = step - 8;
+        r[IS_COMPRESSION] = 1;
+        word(r + K, d_sha_k[j]);
+        const uint32_t* m = e + E_W_READS + 5 * j;
+        word(r + MEM, m[0]);
+        ops.read(r + MEM + 4, m);
+        r[MEM_ADDR] = e[2] + 4u * j;
+        const uint32_t a = v[0], b = v[1], c = v[2], d = v[3], ee = v[4], f = v[5], g = v[6], hh = v[7];
+        const uint32_t s1 = ops.bitwise(r + S1, B_XOR, ops.bitwise(r + S1_INTERMEDIATE, B_XOR, ops.shift_or_rotate(r + E_RR_6, ee, 6, true),
+                                                                   ops.shift_or_rotate(r + E_RR_11, ee, 11, true)),
+                                        ops.shift_or_rotate(r + E_RR_25, ee, 25, true));
+        const uint32_t e_and_f = ops.bitwise(r + E_AND_F, B_AND, ee, f);
+        const uint32_t e_not = ops.not_(r + E_NOT, ee);
+        const uint32_t ch = ops.bitwise(r + CH, B_XOR, e_and_f, ops.bitwise(r + E_NOT_AND_G, B_AND, e_not, g));
+        const uint32_t five[5] = {hh, s1, ch, m[0], d_sha_k[j]};
+        const uint32_t temp1 = ops.add_many(r + TEMP1, five, 5);
+        const uint32_t s0 = ops.bitwise(r + S0, B_XOR, ops.bitwise(r + S0_INTERMEDIATE, B_XOR, ops.shift_or_rotate(r + A_RR_2, a, 2, true),
+                                                                   ops.shift_or_rotate(r + A_RR_13, a, 13, true)),
+                                        ops.shift_or_rotate(r + A_RR_22, a, 22, true));
+        const uint32_t a_and_b = ops.bitwise(r + A_AND_B, B_AND, a, b), a_and_c = ops.bitwise(r + A_AND_C, B_AND, a, c);
+        const uint32_t b_and_c = ops.bitwise(r + B_AND_C, B_AND, b, c);
+        const uint32_t maj = ops.bitwise(r + MAJ, B_XOR, ops.bitwise(r + MAJ_INTERMEDIATE, B_XOR, a_and_b, a_and_c), b_and_c);
+        const uint32_t temp2 = ops.add(r + TEMP2, s0, maj);
+        ops.add(r + D_ADD_TEMP1, d, temp1);
+        ops.add(r + TEMP1_ADD_TEMP2, temp1, temp2);
+      } else {
+        r[IS_FINALIZE] = 1;
+        const uint32_t sum = ops.add(r + FINALIZE_ADD, og[octet], v[octet]);
+        const uint32_t* m = e + E_H_WRITES + 6 * octet;
+        if (m[0] != sum || m[3] != og[octet]) *bad = 1;
+        ops.write(r + MEM, m);
+        r[MEM_ADDR] = e[3] + 4u * octet;
+        word(r + FINALIZED_OPERAND, v[octet]);
+      }
+    }
+    for (int c = 0; c < SHA_COMPRESS_WIDTH; c++) out[(size_t)c * height + row] = kb::to_monty(r[c]);
+  }
+  if (count) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < HASH_SLOTS; i += blockDim.x)
+      if (hkeys[i] != HASH_EMPTY) atomicAdd(counts + hkeys[i], hvals[i]);
+  }
+}
+
 // recursion ExpReverseBitsLen chip (crates/recursion/core/src/chips/exp_reverse_bits.rs:175-226): one thread walks one event's bits —
 // accum_i = accum_{i-1}^2 * (bit_i ? x : 1) — and writes its rows (x, bit, prev_accum^2, that times the multiplier, accum, accum^2,
 // multiplier); Montgomery words in and out. offsets[e] .. offsets[e + 1] are event e's rows; the rest of the matrix is zeroed first.

@@ -585,6 +585,55 @@ def keccak256_words(data: bytes):
     return words
 
 
+# The SHA-256 precompiles (syscall/precompiles/sha256/): SHA_EXTEND fills w[16..64] of a message schedule in place (48 extra cycles, one
+# per word), SHA_COMPRESS runs the 64 rounds on the state at h_ptr (one extra cycle). Their events hold Vecs of fixed length: flattened.
+SYS_SHA_EXTEND, SYS_SHA_COMPRESS = 0x30010005, 0x01010006     # syscalls/code.rs:45,48
+SHA_EXTEND_EVENT = np.dtype([("shard", "<u4"), ("clk", "<u4"), ("w_ptr", "<u4"), ("w_i_minus_15_reads", MEMORY_READ_RECORD, (48,)),
+                             ("w_i_minus_2_reads", MEMORY_READ_RECORD, (48,)), ("w_i_minus_16_reads", MEMORY_READ_RECORD, (48,)),
+                             ("w_i_minus_7_reads", MEMORY_READ_RECORD, (48,)), ("w_i_writes", MEMORY_WRITE_RECORD, (48,))])
+assert SHA_EXTEND_EVENT.itemsize == 4 * 1251
+SHA_COMPRESS_EVENT = np.dtype([("shard", "<u4"), ("clk", "<u4"), ("w_ptr", "<u4"), ("h_ptr", "<u4"), ("h_read_records", MEMORY_READ_RECORD, (8,)),
+                               ("w_i_read_records", MEMORY_READ_RECORD, (64,)), ("h_write_records", MEMORY_WRITE_RECORD, (8,))])
+assert SHA_COMPRESS_EVENT.itemsize == 4 * 412
+SHA_EXTEND_WIDTH, SHA_COMPRESS_WIDTH = 176, 262         # ShaExtendCols (extend/columns.rs:17-73), ShaCompressCols (compress/columns.rs:17-108)
+SHA_COMPRESS_K = [
+    0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98, 0x12835b01, 0x243185be, 0x550c7dc3,
+    0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174, 0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc, 0x2de92c6f, 0x4a7484aa, 0x5cb0a9dc, 0x76f988da,
+    0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147, 0x06ca6351, 0x14292967, 0x27b70a85, 0x2e1b2138, 0x4d2c6dfc, 0x53380d13,
+    0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85, 0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3, 0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070,
+    0x19a4c116, 0x1e376c08, 0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f, 0x682e6ff3, 0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208,
+    0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2]
+SHA256_IV = [0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19]
+
+
+def sha_extend(w):
+    """sha_extend (extend/mod.rs:19-25): w[16..64] of the message schedule from w[0..16]."""
+    M = 0xffffffff
+    rr = lambda x, n: ((x >> n) | (x << (32 - n))) & M   # noqa: E731
+    w = list(w[:16]) + [0] * 48
+    for i in range(16, 64):
+        s0 = rr(w[i - 15], 7) ^ rr(w[i - 15], 18) ^ (w[i - 15] >> 3)
+        s1 = rr(w[i - 2], 17) ^ rr(w[i - 2], 19) ^ (w[i - 2] >> 10)
+        w[i] = (w[i - 16] + s0 + w[i - 7] + s1) & M
+    return w
+
+
+def sha_compress(h, w):
+    """Sha256CompressSyscall::execute's arithmetic (syscalls/precompiles/sha256/compress.rs:52-91): the state after 64 rounds, added to h."""
+    M = 0xffffffff
+    rr = lambda x, n: ((x >> n) | (x << (32 - n))) & M   # noqa: E731
+    a, b, c, d, e, f, g, hh = h
+    for i in range(64):
+        s1 = rr(e, 6) ^ rr(e, 11) ^ rr(e, 25)
+        ch = (e & f) ^ (~e & M & g)
+        temp1 = (hh + s1 + ch + SHA_COMPRESS_K[i] + w[i]) & M
+        s0 = rr(a, 2) ^ rr(a, 13) ^ rr(a, 22)
+        maj = (a & b) ^ (a & c) ^ (b & c)
+        temp2 = (s0 + maj) & M
+        hh, g, f, e, d, c, b, a = g, f, e, (d + temp1) & M, c, b, a, (temp1 + temp2) & M
+    return [(x + y) & M for x, y in zip(h, [a, b, c, d, e, f, g, hh])]
+
+
 SYSCALL_INSTRS_WIDTH = 77
 # SyscallCode (crates/core/executor/src/syscalls/code.rs): byte 0-1 id, byte 2 "has its own table", byte 3 extra cycles
 SYS_HALT, SYS_WRITE, SYS_ENTER_UNCONSTRAINED, SYS_EXIT_UNCONSTRAINED, SYS_COMMIT, SYS_COMMIT_DEFERRED_PROOFS, SYS_HINT_LEN = 0, 2, 3, 4, 0x10, 0x1a, 0xf0

@@ -94,7 +94,7 @@ class Machine:
 
 
 def run_machine(n_cycles: int = 0, seed: int = 1, pc_base: int = 0x1000, shard_cycles: int = 1 << 30, program=None, poseidon2_calls: int = 0,
-                memory_chunk: int = 1 << 30, keccak_calls: int = 0) -> Machine:
+                memory_chunk: int = 1 << 30, keccak_calls: int = 0, sha_calls: int = 0) -> Machine:
     """A whole run as the reference's prover sees it (crates/core/machine/src/utils/prove.rs:255-400): CPU shards of at most `shard_cycles`
     cycles (never split between a branch and its delay slot, executor.rs:2352-2356), then one shard with the deferred precompile events
     (ExecutionRecord::split, record.rs:130-218), then the shards that initialise and finalise every touched address
@@ -102,11 +102,11 @@ def run_machine(n_cycles: int = 0, seed: int = 1, pc_base: int = 0x1000, shard_c
     to execute until it halts instead of generating one; `poseidon2_calls` / `keccak_calls`: POSEIDON2_PERMUTE / KECCAK_SPONGE precompile calls
     spread over a generated run (each kind is deferred to a precompile shard of its own, record.rs:150-185)."""
     return _execute(n_cycles, seed, 1, pc_base, True, shard_cycles=shard_cycles, given=program, poseidon2_calls=poseidon2_calls, memory_chunk=memory_chunk,
-                    machine=True, keccak_calls=keccak_calls)
+                    machine=True, keccak_calls=keccak_calls, sha_calls=sha_calls)
 
 
 def _execute(n_cycles: int, seed: int = 1, shard: int = 1, pc_base: int = 0x1000, halt: bool = False, shard_cycles: int = 1 << 30, given=None,
-             poseidon2_calls: int = 0, memory_chunk: int = 1 << 30, machine: bool = False, keccak_calls: int = 0) -> Machine:
+             poseidon2_calls: int = 0, memory_chunk: int = 1 << 30, machine: bool = False, keccak_calls: int = 0, sha_calls: int = 0) -> Machine:
     """Execute `n_cycles` instructions of a program generated on the way. Returns (program, record, public_values) with
     program: INSTRUCTION array (instructions that were jumped over are `ADD $0, 0, 0` no-ops that never run), record:
     structured event arrays, public_values: dict of the words the Cpu chip checks (start_pc, next_pc, execution_shard).
@@ -170,6 +170,8 @@ def _execute(n_cycles: int, seed: int = 1, shard: int = 1, pc_base: int = 0x1000
     p2_seq = 0
     k_at = set(int(x) for x in np.linspace(n_cycles // 6, max(n_cycles - 60, n_cycles // 6), keccak_calls)) - p2_at if keccak_calls else set()
     k_seq = 0
+    s_at = set(int(x) for x in np.linspace(n_cycles // 5, max(n_cycles - 80, n_cycles // 5), sha_calls)) - p2_at - k_at if sha_calls else set()
+    s_seq = 0
     clk_extra = 0                  # the extra cycles of the shard's syscalls so far (Syscall::num_extra_cycles, executor.rs:1641)
 
     def close_shard():
@@ -206,6 +208,7 @@ def _execute(n_cycles: int, seed: int = 1, shard: int = 1, pc_base: int = 0x1000
             n_cycles += len(queued) - had  # the body grows by the call; the epilogue still follows it
             p2_at = set(x + len(queued) - had if x > cyc else x for x in p2_at)
             k_at = set(x + len(queued) - had if x > cyc else x for x in k_at)
+            s_at = set(x + len(queued) - had if x > cyc else x for x in s_at)
         if given is None and cyc in k_at and cyc < n_cycles:
             # a KECCAK_SPONGE call as the guest library's keccak256 makes it (crates/zkvm/lib/src/keccak256.rs:3-57): the padded message as
             # 36-word blocks, its length in words at result + 64, the code in $v0, input and result pointers in $a0 / $a1
@@ -222,6 +225,25 @@ def _execute(n_cycles: int, seed: int = 1, shard: int = 1, pc_base: int = 0x1000
             n_cycles += len(queued) - had
             p2_at = set(x + len(queued) - had if x > cyc else x for x in p2_at)
             k_at = set(x + len(queued) - had if x > cyc else x for x in k_at)
+            s_at = set(x + len(queued) - had if x > cyc else x for x in s_at)
+        if given is None and cyc in s_at and cyc < n_cycles:
+            # one SHA-256 block as the reference's test programs lay the calls out (sha256/extend/mod.rs:44-61, compress/mod.rs:52-78): sixteen
+            # message words at w_ptr, SHA_EXTEND(w_ptr, 0), the eight state words at h_ptr, SHA_COMPRESS(w_ptr, h_ptr)
+            had = len(queued)
+            w_ptr, h_ptr = 0x00400000 + 0x200 * s_seq, 0x00480000 + 0x40 * s_seq
+            s_seq += 1
+            for i in range(16):
+                queued += [(E.ADD, 30, int(rng.integers(0, 1 << 32)), 0, 1, 1), (E.SW, 30, 0, w_ptr + 4 * i, 0, 1)]
+            queued += [(E.ADD, E.REG_V0, E.SYS_SHA_EXTEND, 0, 1, 1), (E.ADD, E.REG_A0, w_ptr, 0, 1, 1), (E.ADD, E.REG_A1, 0, 0, 1, 1),
+                       (E.SYSCALL, E.REG_V0, E.REG_A0, E.REG_A1, 0, 0)]
+            for i, word in enumerate(E.SHA256_IV):
+                queued += [(E.ADD, 30, word, 0, 1, 1), (E.SW, 30, 0, h_ptr + 4 * i, 0, 1)]
+            queued += [(E.ADD, E.REG_V0, E.SYS_SHA_COMPRESS, 0, 1, 1), (E.ADD, E.REG_A0, w_ptr, 0, 1, 1), (E.ADD, E.REG_A1, h_ptr, 0, 1, 1),
+                       (E.SYSCALL, E.REG_V0, E.REG_A0, E.REG_A1, 0, 0)]
+            n_cycles += len(queued) - had
+            p2_at = set(x + len(queued) - had if x > cyc else x for x in p2_at)
+            k_at = set(x + len(queued) - had if x > cyc else x for x in k_at)
+            s_at = set(x + len(queued) - had if x > cyc else x for x in s_at)
         # ---- pick the instruction at pc (the program is written as it runs)
         if given is not None:
             if pc not in program:
@@ -395,7 +417,26 @@ def _execute(n_cycles: int, seed: int = 1, shard: int = 1, pc_base: int = 0x1000
             b_rec = read(op_b, clk, POS_B)
             b = b_rec[1][0]
             sid = code & 0xffff
-            assert code in (E.SYS_HALT, E.SYS_COMMIT, E.SYS_POSEIDON2_PERMUTE, E.SYS_KECCAK_SPONGE), code
+            assert code in (E.SYS_HALT, E.SYS_COMMIT, E.SYS_POSEIDON2_PERMUTE, E.SYS_KECCAK_SPONGE, E.SYS_SHA_EXTEND, E.SYS_SHA_COMPRESS), code
+            touched = {}                               # address -> [initial (shard, timestamp, value), final]: SyscallContext's local map
+
+            def mem(addr, ts, value=None):
+                if addr not in R:
+                    R[addr], last[addr] = 0, (0, 0)
+                born.setdefault(addr, R[addr])
+                if addr in first:                      # an open CPU access chain is closed first (SyscallContext::postprocess)
+                    rec.memory_local.append((addr, first.pop(addr), (last[addr][0], last[addr][1], R[addr])))
+                prev = (last[addr][0], last[addr][1], R[addr])
+                touched.setdefault(addr, [prev, None])
+                if value is None:
+                    out = (R[addr], shard, ts, prev[0], prev[1])
+                else:
+                    out = (value, shard, ts, prev[2], prev[0], prev[1])
+                    R[addr] = value
+                last[addr] = (shard, ts)
+                touched[addr][1] = (shard, ts, R[addr])
+                return out
+
             if code == E.SYS_POSEIDON2_PERMUTE:
                 # Poseidon2PermuteSyscall::execute (syscalls/precompiles/poseidon2/permute.rs:14-71): the sixteen words at $a0 are
                 # replaced by their permutation, written at timestamp clk through the syscall's own local-access map; a CPU access
@@ -421,25 +462,6 @@ def _execute(n_cycles: int, seed: int = 1, shard: int = 1, pc_base: int = 0x1000
                 # KeccakSpongeSyscall::execute (syscalls/precompiles/keccak/sponge.rs:20-104): the input length is read from result + 64 and
                 # the input from $a0 at timestamp clk, every 36-word block is xored into the state and permuted, the first sixteen words of
                 # the state are written to the result at clk + 1; the call takes one extra cycle
-                touched = {}                               # address -> [initial (shard, timestamp, value), final]: SyscallContext's local map
-
-                def mem(addr, ts, value=None):
-                    if addr not in R:
-                        R[addr], last[addr] = 0, (0, 0)
-                    born.setdefault(addr, R[addr])
-                    if addr in first:                      # an open CPU access chain is closed first (SyscallContext::postprocess)
-                        rec.memory_local.append((addr, first.pop(addr), (last[addr][0], last[addr][1], R[addr])))
-                    prev = (last[addr][0], last[addr][1], R[addr])
-                    touched.setdefault(addr, [prev, None])
-                    if value is None:
-                        out = (R[addr], shard, ts, prev[0], prev[1])
-                    else:
-                        out = (value, shard, ts, prev[2], prev[0], prev[1])
-                        R[addr] = value
-                    last[addr] = (shard, ts)
-                    touched[addr][1] = (shard, ts, R[addr])
-                    return out
-
                 assert b % 4 == 0 and c % 4 == 0
                 len_rec = mem(c + 64, clk)
                 n_words = len_rec[0]
@@ -458,6 +480,36 @@ def _execute(n_cycles: int, seed: int = 1, shard: int = 1, pc_base: int = 0x1000
                            writes if k == nb - 1 else [no_write] * 16) for k in range(nb)]
                 local = [(addr, v[0], v[1]) for addr, v in sorted(touched.items())]
                 precompile.append(("keccak", (pc, next_pc, shard, clk, (0, 0, 0, 0, 0, 0), 0, [0, 0, 0], sid, b, c), blocks, local))
+                clk_extra += 1
+            if code == E.SYS_SHA_EXTEND:
+                # Sha256ExtendSyscall::execute (syscalls/precompiles/sha256/extend.rs:16-74): w[16..64] of the schedule at $a0, one word per
+                # cycle — four reads and the write at timestamp clk + (i - 16); 48 extra cycles
+                assert c == 0 and b % 4 == 0
+                r15, r2, r16, r7, wr = [], [], [], [], []
+                M32 = 0xffffffff
+                rr = lambda x, k: ((x >> k) | (x << (32 - k))) & M32      # noqa: E731
+                for i in range(16, 64):
+                    ts = clk + i - 16
+                    r15.append(mem(b + 4 * (i - 15), ts)); w15 = r15[-1][0]
+                    r2.append(mem(b + 4 * (i - 2), ts)); w2 = r2[-1][0]
+                    r16.append(mem(b + 4 * (i - 16), ts))
+                    r7.append(mem(b + 4 * (i - 7), ts))
+                    s0 = rr(w15, 7) ^ rr(w15, 18) ^ (w15 >> 3)
+                    s1 = rr(w2, 17) ^ rr(w2, 19) ^ (w2 >> 10)
+                    wr.append(mem(b + 4 * i, ts, (s1 + r16[-1][0] + s0 + r7[-1][0]) & M32))
+                local = [(addr, v[0], v[1]) for addr, v in sorted(touched.items())]
+                precompile.append(("sha_extend", (pc, next_pc, shard, clk, (0, 0, 0, 0, 0, 0), 0, [0, 0, 0], sid, b, c), [(shard, clk, b, r15, r2, r16, r7, wr)], local))
+                clk_extra += 48
+            if code == E.SYS_SHA_COMPRESS:
+                # Sha256CompressSyscall::execute (syscalls/precompiles/sha256/compress.rs:34-118): the state at $a1 and the 64 schedule words
+                # at $a0 are read at clk, the compressed state is added and written back at clk + 1; one extra cycle
+                assert b != c and b % 4 == 0 and c % 4 == 0
+                hr = [mem(c + 4 * i, clk) for i in range(8)]
+                wr_ = [mem(b + 4 * i, clk) for i in range(64)]
+                out = E.sha_compress([x[0] for x in hr], [x[0] for x in wr_])
+                hw = [mem(c + 4 * i, clk + 1, out[i]) for i in range(8)]
+                local = [(addr, v[0], v[1]) for addr, v in sorted(touched.items())]
+                precompile.append(("sha_compress", (pc, next_pc, shard, clk, (0, 0, 0, 0, 0, 0), 0, [0, 0, 0], sid, b, c), [(shard, clk, b, c, hr, wr_, hw)], local))
                 clk_extra += 1
             a = code                                       # none of them returns a value: V0 keeps the code
             a_rec = write(op_a, a, clk, POS_A)
@@ -569,7 +621,8 @@ def _execute(n_cycles: int, seed: int = 1, shard: int = 1, pc_base: int = 0x1000
     # ---- the deferred shards (prove.rs:283-400): precompile events first, then memory initialisation / finalisation
     last_pv = shards[-1].pv
     n_shard = shards[-1].pv["shard"]
-    for kind, dt in (("poseidon2", E.POSEIDON2_PERMUTE_EVENT), ("keccak", E.KECCAK_SPONGE_BLOCK)):
+    for kind, dt in (("poseidon2", E.POSEIDON2_PERMUTE_EVENT), ("keccak", E.KECCAK_SPONGE_BLOCK), ("sha_extend", E.SHA_EXTEND_EVENT),
+                     ("sha_compress", E.SHA_COMPRESS_EVENT)):
         mine = [e for e in precompile if e[0] == kind]
         if not mine:
             continue
@@ -579,6 +632,8 @@ def _execute(n_cycles: int, seed: int = 1, shard: int = 1, pc_base: int = 0x1000
         o.precompile_syscall = arr([e[1] for e in mine], E.SYSCALL_EVENT)
         o.poseidon2_permute = arr([ev for e in mine for ev in e[2]] if kind == "poseidon2" else [], E.POSEIDON2_PERMUTE_EVENT)
         o.keccak_sponge = arr([ev for e in mine for ev in e[2]] if kind == "keccak" else [], E.KECCAK_SPONGE_BLOCK)
+        o.sha_extend = arr([ev for e in mine for ev in e[2]] if kind == "sha_extend" else [], E.SHA_EXTEND_EVENT)
+        o.sha_compress = arr([ev for e in mine for ev in e[2]] if kind == "sha_compress" else [], E.SHA_COMPRESS_EVENT)
         o.memory_local = arr([ev for e in mine for ev in e[3]], MEMORY_LOCAL_EVENT)
         pv = dict(last_pv, start_pc=last_pv["next_pc"], shard=n_shard)
         shards.append(Shard("precompile", o, pv))

@@ -232,6 +232,24 @@ class Context:
                                                         C.c_int(fixed_log2_rows), blu.h if blu is not None else None, C.byref(h)))
         return self._born(h)
 
+    def tracegen_sha_extend(self, events: np.ndarray, fixed_log2_rows: int = -1, blu: "ByteLookups" = None) -> DeviceMatrix:
+        """`generate_trace` of the ShaExtend precompile on the device (zkm_tracegen_sha_extend); dtype events.SHA_EXTEND_EVENT, 48 rows each."""
+        from . import events as _ev
+        ev = np.ascontiguousarray(events, dtype=_ev.SHA_EXTEND_EVENT)
+        h = C.c_void_p()
+        lib.check(lib.load().zkm_tracegen_sha_extend(self.h, C.c_void_p(ev.ctypes.data if len(ev) else None), C.c_size_t(len(ev)),
+                                                     C.c_int(fixed_log2_rows), blu.h if blu is not None else None, C.byref(h)))
+        return self._born(h)
+
+    def tracegen_sha_compress(self, events: np.ndarray, fixed_log2_rows: int = -1, blu: "ByteLookups" = None) -> DeviceMatrix:
+        """`generate_trace` of the ShaCompress precompile on the device (zkm_tracegen_sha_compress); dtype events.SHA_COMPRESS_EVENT, 80 rows each."""
+        from . import events as _ev
+        ev = np.ascontiguousarray(events, dtype=_ev.SHA_COMPRESS_EVENT)
+        h = C.c_void_p()
+        lib.check(lib.load().zkm_tracegen_sha_compress(self.h, C.c_void_p(ev.ctypes.data if len(ev) else None), C.c_size_t(len(ev)),
+                                                       C.c_int(fixed_log2_rows), blu.h if blu is not None else None, C.byref(h)))
+        return self._born(h)
+
     def tracegen_misc_instrs(self, events: np.ndarray, fixed_log2_rows: int = -1, blu: "ByteLookups" = None) -> DeviceMatrix:
         """`generate_trace` of the MiscInstrs chip on the device (zkm_tracegen_misc_instrs); dtype events.MISC_EVENT."""
         from . import events as _ev
