@@ -452,6 +452,19 @@ int zkm_tracegen_sha_extend(zkm_ctx* ctx, const zkm_sha_extend_event* events, si
                             zkm_matrix** out);
 int zkm_tracegen_sha_compress(zkm_ctx* ctx, const zkm_sha_compress_event* events, size_t n_events, int fixed_log2_rows,
                               zkm_byte_lookups* blu, zkm_matrix** out);
+
+/* The EdAddAssign precompile (crates/core/machine/src/syscall/precompiles/edwards/ed_add.rs): replaces generate_trace (:108-153) and the byte
+ * lookups of generate_dependencies (:155-186): one Ed25519 point addition per row, the eight big-field gadgets (operations/field/) computed
+ * on the device. EllipticCurveAddEvent (crates/core/executor/src/events/precompiles/ec.rs:24-47) flattened: its `p` and `q` are the previous
+ * values of the p write records and the values of the q read records. Fails when the words written to p are not p + q. */
+typedef struct zkm_ed_add_event {
+  uint32_t shard, clk, p_ptr, q_ptr;
+  zkm_memory_write_record p_memory_records[16];
+  zkm_memory_read_record q_memory_records[16];
+} zkm_ed_add_event;
+#define ZKM_ED_ADD_WIDTH 1861
+int zkm_tracegen_ed_add(zkm_ctx* ctx, const zkm_ed_add_event* events, size_t n_events, int fixed_log2_rows, zkm_byte_lookups* blu,
+                        zkm_matrix** out);
 /* The MiscInstrs chip (crates/core/machine/src/misc/others/: SEXT EXT INS MADDU MSUBU MADD MSUB TEQ): replaces generate_trace
  * (trace.rs:42-84), which also records the byte lookups (counted into `blu` if given). Events are the #[repr(C)] MiscEvents of
  * crates/core/executor/src/events/instr.rs:239-261 (60 bytes). 72 columns, zero padding rows. */

@@ -23,6 +23,7 @@
 // numbers crates/core/executor/src/opcode.rs:26-48.
 #pragma once
 #include <algorithm>
+#include "bigfield.hpp"
 #include <cstdint>
 #include <cstring>
 #include <stdexcept>
@@ -1731,6 +1732,125 @@ static inline std::vector<F> generate_sha_compress(const ShaCompressEvent* event
     r[OCTET + octet] = 1; r[OCTET_NUM + octet_num] = 1;
     if (octet_num != 0 && octet_num != 9) word(r + K, SHA_COMPRESS_K[(octet_num - 1) * 8 + octet]);
     r[IS_LAST_ROW] = octet == 7 && octet_num == 9;
+  }
+  if (byte_counts)
+    for (const ByteLookup& b : lk) byte_counts[((size_t)b.b * 256 + b.c) * NUM_BYTE_OPS + b.op]++;
+  *height = h;
+  return t;
+}
+
+// ---- EdAddAssign precompile (syscall/precompiles/edwards/ed_add.rs): one Ed25519 point addition per row. Columns EdAddAssignCols :41-57 =
+// is_real, shard, clk, p_ptr, q_ptr, sixteen MemoryWriteCols of p, sixteen MemoryReadCols of q, then eight field gadgets of 188 columns
+// (result 32, carry 32, witness_low 62, witness_high 62): x3_numerator and y3_numerator (FieldInnerProductCols), x1_mul_y1, x2_mul_y2, f,
+// d_mul_f (FieldOpCols, Mul), x3_ins, y3_ins (FieldDenCols). A gadget checks op = result + carry * p as a polynomial identity in x = 2^8:
+// the difference vanishes at 256, its quotient by (x - 256), shifted by WITNESS_OFFSET = 2^14, is the witness
+// (operations/field/util.rs:21-66). Padding rows hold the gadgets of the all-zero inputs (:130-147): the witness of zero is the offset.
+struct EdAddEvent { uint32_t shard, clk, p_ptr, q_ptr; MemoryWriteRecord p_memory_records[16]; MemoryReadRecord q_memory_records[16]; };
+static_assert(sizeof(EdAddEvent) == 4 * 180, "flattened EllipticCurveAddEvent is 180 words");
+static const size_t ED_ADD_WIDTH = 1861;
+static const uint8_t ED25519_MODULUS[32] = {237, 255, 255, 255, 255, 255, 255, 255, 255, 255, 255, 255, 255, 255, 255, 255,
+                                            255, 255, 255, 255, 255, 255, 255, 255, 255, 255, 255, 255, 255, 255, 255, 127};
+static const uint8_t ED25519_D[32] = {163, 120, 89, 19, 202, 77, 235, 117, 171, 216, 65, 65, 77, 10, 112, 0,
+                                      152, 232, 121, 119, 121, 64, 199, 140, 115, 254, 111, 43, 238, 108, 3, 82};
+// result, carry, witness_low, witness_high at r, from `lhs_minus_rhs` (the identity's polynomial before the carry term) and the two integers
+static inline void field_gadget_cols(F* r, const bigfield::Poly& lhs_minus_rhs, const bigfield::Big& result, const bigfield::Big& carry,
+                                     const bigfield::Big& p, int n_limbs, int64_t offset, std::vector<ByteLookup>* lk) {
+  using namespace bigfield;
+  const int nw = 2 * n_limbs - 2;
+  Poly van = padd(lhs_minus_rhs, pmul(poly(carry, n_limbs), poly(p, n_limbs)), -1);
+  van.resize(nw + 1, 0);
+  std::vector<int64_t> w(nw, 0);          // van = w * (x - 256): w[k - 1] = van[k] + 256 * w[k] from the top down, and the constant term closes
+  int64_t above = 0;
+  for (int k = nw; k >= 1; k--) { w[k - 1] = van[k] + 256 * above; above = w[k - 1]; }
+  if (van[0] + 256 * w[0] != 0) throw std::runtime_error("tracegen: field gadget identity does not hold");
+  for (int i = 0; i < n_limbs; i++) { r[i] = limb(result, i); r[n_limbs + i] = limb(carry, i); }
+  if (limb(result, n_limbs) || limb(carry, n_limbs)) throw std::runtime_error("tracegen: field gadget result / carry does not fit its limbs");
+  for (int i = 0; i < nw; i++) {
+    const int64_t shifted = w[i] + offset;
+    if (shifted < 0 || shifted >= 65536) throw std::runtime_error("tracegen: field gadget witness out of range");
+    r[2 * n_limbs + i] = shifted & 0xff;
+    r[2 * n_limbs + nw + i] = shifted >> 8;
+  }
+  if (lk) {
+    auto ranges = [&](const F* c, int n) {
+      for (int i = 0; i + 1 < n; i += 2) lk->push_back(ByteLookup{B_U8RANGE, (uint8_t)c[i], (uint8_t)c[i + 1]});
+      if (n & 1) lk->push_back(ByteLookup{B_U8RANGE, (uint8_t)c[n - 1], 0});
+    };
+    ranges(r, n_limbs); ranges(r + n_limbs, n_limbs); ranges(r + 2 * n_limbs, nw); ranges(r + 2 * n_limbs + nw, nw);
+  }
+}
+struct FieldGadgets {
+  bigfield::Big p;
+  int n;
+  int64_t offset;
+  std::vector<ByteLookup>* lk;
+  // FieldOpCols::populate, Mul (field_op.rs:97-152): a * b = result + carry * p
+  bigfield::Big mul(F* r, const bigfield::Big& a, const bigfield::Big& b) const {
+    using namespace bigfield;
+    Big q, res;
+    divmod(bigfield::mul(a, b), p, q, res);
+    field_gadget_cols(r, padd(pmul(poly(a, n), poly(b, n)), poly(res, n), -1), res, q, p, n, offset, lk);
+    return res;
+  }
+  // FieldInnerProductCols::populate (field_inner_product.rs:27-79): a0 * b0 + a1 * b1 = result + carry * p
+  bigfield::Big inner_product(F* r, const bigfield::Big& a0, const bigfield::Big& b0, const bigfield::Big& a1, const bigfield::Big& b1) const {
+    using namespace bigfield;
+    Big q, res;
+    divmod(add(bigfield::mul(a0, b0), bigfield::mul(a1, b1)), p, q, res);
+    field_gadget_cols(r, padd(padd(pmul(poly(a0, n), poly(b0, n)), pmul(poly(a1, n), poly(b1, n))), poly(res, n), -1), res, q, p, n, offset, lk);
+    return res;
+  }
+  // FieldDenCols::populate (field_den.rs:27-81): result = a / (1 + b) (sign) or a / (1 - b)
+  bigfield::Big den(F* r, const bigfield::Big& a, const bigfield::Big& b, bool sign) const {
+    using namespace bigfield;
+    const Big denominator = mod(add(sign ? b : sub(p, mod(b, p)), from_u64(1)), p);
+    const Big res = is_zero(a) ? Big() : mod(bigfield::mul(a, inv_mod(denominator, p)), p);
+    const Big lhs = add(bigfield::mul(b, res), sign ? res : a), rhs = sign ? a : res;
+    Big q, rem;
+    divmod(sub(lhs, rhs), p, q, rem);
+    if (!is_zero(rem)) throw std::runtime_error("tracegen: FieldDen identity");
+    Poly lhs_p = padd(pmul(poly(b, n), poly(res, n)), poly(sign ? res : a, n));
+    field_gadget_cols(r, padd(lhs_p, poly(rhs, n), -1), res, q, p, n, offset, lk);
+    return res;
+  }
+};
+static inline std::vector<F> generate_ed_add(const EdAddEvent* events, size_t n_events, int fixed_log2_rows, size_t* height, uint64_t* byte_counts) {
+  using bigfield::Big;
+  enum { IS_REAL = 0, SHARD = 1, CLK = 2, P_PTR = 3, Q_PTR = 4, P_ACCESS = 5, Q_ACCESS = 5 + 16 * 13, GADGETS = 5 + 16 * 13 + 16 * 9, G = 188 };
+  static_assert(GADGETS + 8 * G == 1861, "layout");
+  const size_t h = padded_rows(n_events, fixed_log2_rows);
+  std::vector<F> t(h * ED_ADD_WIDTH, 0);
+  std::vector<ByteLookup> lk;
+  const Big d = bigfield::from_bytes(ED25519_D, 32);
+  auto fill = [&](F* r, const Big& x1, const Big& y1, const Big& x2, const Big& y2, std::vector<ByteLookup>* sink) {   // populate_field_ops :68-95
+    const FieldGadgets g{bigfield::from_bytes(ED25519_MODULUS, 32), 32, 1 << 14, sink};
+    const Big x3n = g.inner_product(r + GADGETS, x1, y2, x2, y1);
+    const Big y3n = g.inner_product(r + GADGETS + G, y1, y2, x1, x2);
+    const Big x1y1 = g.mul(r + GADGETS + 2 * G, x1, y1), x2y2 = g.mul(r + GADGETS + 3 * G, x2, y2);
+    const Big f = g.mul(r + GADGETS + 4 * G, x1y1, x2y2);
+    const Big df = g.mul(r + GADGETS + 5 * G, f, d);
+    g.den(r + GADGETS + 6 * G, x3n, df, true);
+    g.den(r + GADGETS + 7 * G, y3n, df, false);
+  };
+  std::vector<F> padding(ED_ADD_WIDTH, 0);
+  fill(padding.data(), Big(), Big(), Big(), Big(), nullptr);
+  for (size_t i = 0; i < h; i++) {
+    F* r = t.data() + i * ED_ADD_WIDTH;
+    if (i >= n_events) { std::copy(padding.begin(), padding.end(), r); continue; }
+    const EdAddEvent& e = events[i];
+    uint32_t p[16], q[16];
+    for (int k = 0; k < 16; k++) { p[k] = e.p_memory_records[k].prev_value; q[k] = e.q_memory_records[k].value; }
+    r[IS_REAL] = 1; r[SHARD] = fu32(e.shard); r[CLK] = fu32(e.clk); r[P_PTR] = fu32(e.p_ptr); r[Q_PTR] = fu32(e.q_ptr);
+    fill(r, bigfield::from_words(p, 8), bigfield::from_words(p + 8, 8), bigfield::from_words(q, 8), bigfield::from_words(q + 8, 8), &lk);
+    for (int k = 0; k < 16; k++) {
+      const MemoryReadRecord& m = e.q_memory_records[k];
+      memory_access_cols(m.value, m.shard, m.timestamp, m.prev_shard, m.prev_timestamp, r + Q_ACCESS + 9 * k, &lk);
+    }
+    for (int k = 0; k < 16; k++) {
+      memory_write_cols(e.p_memory_records[k], r + P_ACCESS + 13 * k, &lk);
+      for (int c = 0; c < 4; c++)      // the words written are the sum's limbs (ed_add.rs:299-307)
+        if (r[P_ACCESS + 13 * k + 4 + c] != r[GADGETS + (k < 8 ? 6 : 7) * G + 4 * (k % 8) + c]) throw std::runtime_error("tracegen: EdAdd event does not write p + q");
+    }
   }
   if (byte_counts)
     for (const ByteLookup& b : lk) byte_counts[((size_t)b.b * 256 + b.c) * NUM_BYTE_OPS + b.op]++;

@@ -1994,6 +1994,127 @@ def record_sha_compress_chip(log_height: int) -> RecordedChip:
     return _finish(record_sha_compress_constraints(), "ShaCompress", log_height, E.SHA_COMPRESS_WIDTH, False)
 
 
+# ---- big-field gadgets (crates/core/machine/src/operations/field/): a 256-bit (or 384-bit) field element is a polynomial in x = 2^8 with byte
+# coefficients; an identity op(a, b, ...) = result + carry * p over the integers is checked as a polynomial identity: the difference vanishes
+# at x = 256, so it is (x - 256) * witness(x), with the witness coefficients shifted by WITNESS_OFFSET and split into two byte columns.
+
+def _poly_add(x, y):
+    n = max(len(x), len(y))
+    return [(x[i] if i < len(x) else None) if i >= len(y) else (y[i] if i >= len(x) else x[i] + y[i]) for i in range(n)]
+
+
+def _poly_sub(b, x, y):
+    n = max(len(x), len(y))
+    return [x[i] if i >= len(y) else (b.const(0) - y[i] if i >= len(x) else x[i] - y[i]) for i in range(n)]
+
+
+def _poly_mul(x, y):
+    out = [None] * (len(x) + len(y) - 1)
+    for i, xi in enumerate(x):
+        for j, yj in enumerate(y):
+            t = xi * yj
+            out[i + j] = t if out[i + j] is None else out[i + j] + t
+    return out
+
+
+def _field_gadget(r: _Rec, p_vanishing, cols, n_limbs, witness_offset, is_real):
+    """eval_field_operation (operations/field/util_air.rs:5-29) and the range checks every gadget ends with (field_op.rs:333-336):
+    cols = result(N), carry(N), witness_low(2N - 2), witness_high(2N - 2)."""
+    b = r.b
+    nw = 2 * n_limbs - 2
+    result, carry = cols[0:n_limbs], cols[n_limbs:2 * n_limbs]
+    w_low, w_high = cols[2 * n_limbs:2 * n_limbs + nw], cols[2 * n_limbs + nw:2 * n_limbs + 2 * nw]
+    witness = [w_low[i] + w_high[i] * 256 - witness_offset for i in range(nw)]
+    # witness(x) * (x - 256)
+    prod = [None] * (nw + 1)
+    for i in range(nw):
+        lo = witness[i] * (air.F.P - 256)
+        prod[i] = lo if prod[i] is None else prod[i] + lo
+        prod[i + 1] = witness[i] * 1
+    for c in _poly_sub(b, p_vanishing, prod):
+        b.assert_zero(c)
+    r.slice_range_check_u8(result, is_real)
+    r.slice_range_check_u8(carry, is_real)
+    r.slice_range_check_u8(w_low, is_real)
+    r.slice_range_check_u8(w_high, is_real)
+
+
+def _limbs_of_const(b, value, n):
+    return [b.const((value >> (8 * i)) & 0xff) for i in range(n)]
+
+
+ED25519_P = (1 << 255) - 19
+ED25519_D = int.from_bytes(bytes([163, 120, 89, 19, 202, 77, 235, 117, 171, 216, 65, 65, 77, 10, 112, 0, 152, 232, 121, 119, 121, 64, 199, 140, 115, 254,
+                                  111, 43, 238, 108, 3, 82]), "little")      # EdwardsParameters::D of Ed25519Parameters (curves/src/edwards/ed25519.rs:47-50)
+
+
+def _ed_add(r: _Rec):
+    """EdAddAssignChip::eval (syscall/precompiles/edwards/ed_add.rs:247-335): (x3, y3) = ((x1 y2 + x2 y1) / (1 + d f), (y1 y2 + x1 x2) / (1 - d f))
+    with f = x1 x2 y1 y2, through two FieldInnerProductCols, four FieldOpCols (Mul) and two FieldDenCols; p is overwritten at clk + 1."""
+    l, b = r.local, r.b
+    N, G = 32, 188
+    IS_REAL, SHARD, CLK, P_PTR, Q_PTR, P_ACCESS, Q_ACCESS, GADGETS = 0, 1, 2, 3, 4, 5, 5 + 16 * 13, 5 + 16 * 13 + 16 * 9
+    is_real = l[IS_REAL]
+    p_access = [l[P_ACCESS + 13 * i:P_ACCESS + 13 * i + 13] for i in range(16)]      # MemoryWriteCols: prev_value(4), access(9)
+    q_access = [l[Q_ACCESS + 9 * i:Q_ACCESS + 9 * i + 9] for i in range(16)]
+    gadget = [l[GADGETS + G * k:GADGETS + G * k + G] for k in range(8)]
+    x3_num, y3_num, x1_mul_y1, x2_mul_y2, f, d_mul_f, x3_ins, y3_ins = gadget
+    prev_limbs = lambda acc, lo, hi: [c for a in acc[lo:hi] for c in a[0:4]]          # noqa: E731   limbs_from_prev_access
+    x1, y1 = prev_limbs(p_access, 0, 8), prev_limbs(p_access, 8, 16)
+    x2, y2 = prev_limbs(q_access, 0, 8), prev_limbs(q_access, 8, 16)                  # a read's previous value is its value
+    modulus = _limbs_of_const(b, ED25519_P, N)
+
+    def inner_product(cols, xs, ys):          # FieldInnerProductCols::eval (field_inner_product.rs:82-120)
+        acc = [b.const(0)]
+        for x, y in zip(xs, ys):
+            acc = _poly_add(acc, _poly_mul(x, y))
+        van = _poly_sub(b, _poly_sub(b, acc, cols[0:N]), _poly_mul(cols[N:2 * N], modulus))
+        _field_gadget(r, van, cols, N, 1 << 14, is_real)
+
+    def mul(cols, x, y):                      # FieldOpCols::eval, FieldOperation::Mul (field_op.rs:296-331)
+        van = _poly_sub(b, _poly_sub(b, _poly_mul(x, y), cols[0:N]), _poly_mul(cols[N:2 * N], modulus))
+        _field_gadget(r, van, cols, N, 1 << 14, is_real)
+
+    def den(cols, a, bb, sign):               # FieldDenCols::eval (field_den.rs:84-125): result * (1 +- b) = a
+        result = cols[0:N]
+        lhs = _poly_add(_poly_mul(bb, result), result if sign else a)
+        rhs = a if sign else result
+        van = _poly_sub(b, _poly_sub(b, lhs, rhs), _poly_mul(cols[N:2 * N], modulus))
+        _field_gadget(r, van, cols, N, 1 << 14, is_real)
+
+    inner_product(x3_num, [x1, x2], [y2, y1])
+    inner_product(y3_num, [y1, x1], [y2, x2])
+    mul(x1_mul_y1, x1, y1)
+    mul(x2_mul_y2, x2, y2)
+    mul(f, x1_mul_y1[0:N], x2_mul_y2[0:N])
+    mul(d_mul_f, f[0:N], _limbs_of_const(b, ED25519_D, N))
+    den(x3_ins, x3_num[0:N], d_mul_f[0:N], True)
+    den(y3_ins, y3_num[0:N], d_mul_f[0:N], False)
+    value_limbs = [c for a in p_access for c in a[4:8]]                               # value_as_limbs
+    for i in range(N):
+        b.when(is_real).assert_eq(x3_ins[i], value_limbs[i])
+    for i in range(N):
+        b.when(is_real).assert_eq(y3_ins[i], value_limbs[N + i])
+    for i in range(16):      # eval_memory_access_slice (air/memory.rs:65-82)
+        r.eval_memory_access(l[SHARD], l[CLK], l[Q_PTR] + 4 * i, q_access[i][0:4], q_access[i], is_real)
+    for i in range(16):
+        r.eval_memory_access(l[SHARD], l[CLK] + 1, l[P_PTR] + 4 * i, p_access[i][0:4], p_access[i][4:13], is_real)
+    r.receives.append(air.Lookup([air.to_virtual_pair(v) for v in [l[SHARD], l[CLK], b.const(E.SYS_ED_ADD & 0xffff), l[P_PTR], l[Q_PTR]]],
+                                 air.to_virtual_pair(is_real), air.KIND_SYSCALL))
+
+
+def record_ed_add_constraints() -> _Rec:
+    r = _Rec(E.ED_ADD_WIDTH)
+    _ed_add(r)
+    return r
+
+
+def record_ed_add_chip(log_height: int) -> RecordedChip:
+    """The EdAddAssign precompile (crates/core/machine/src/syscall/precompiles/edwards/ed_add.rs): one Ed25519 point addition per row, 1861
+    columns; local_only as the reference declares it (:206-208)."""
+    return _finish(record_ed_add_constraints(), "EdAddAssign", log_height, E.ED_ADD_WIDTH, True)
+
+
 def record_memory_global_constraints(finalize: bool) -> _Rec:
     r = _Rec(E.MEMORY_GLOBAL_WIDTH)
     _memory_global(r, finalize)

@@ -18,6 +18,7 @@
 #include "kb31.cuh"
 #include "poseidon2.cuh"
 #include "septic.cuh"
+#include "bigfield.cuh"
 
 namespace tracegen {
 
@@ -1677,6 +1678,158 @@ __global__ __launch_bounds__(THREADS) void sha_compress_rows(const uint32_t* __r
       }
     }
     for (int c = 0; c < SHA_COMPRESS_WIDTH; c++) out[(size_t)c * height + row] = kb::to_monty(r[c]);
+  }
+  if (count) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < HASH_SLOTS; i += blockDim.x)
+      if (hkeys[i] != HASH_EMPTY) atomicAdd(counts + hkeys[i], hvals[i]);
+  }
+}
+
+// ---- EdAddAssign precompile (syscall/precompiles/edwards/ed_add.rs:41-57, :68-95, :210-243): one Ed25519 point addition per row, 1861 columns:
+// the memory columns of p (written at clk + 1) and q, and eight 188-column field gadgets (result 32, carry 32, witness_low 62, witness_high
+// 62 byte limbs; operations/field/field_inner_product.rs, field_op.rs, field_den.rs). One thread per row: the integers with bigfield.cuh
+// (32-bit limbs, Barrett, Fermat inverse for the two denominators), then per gadget the witness of the polynomial identity in x = 2^8 —
+// op(x) - result(x) - carry(x) p(x) = (x - 256) w(x), w shifted by 2^14 and split into bytes (operations/field/util.rs:21-66) — straight
+// into the columns. Padding rows hold the gadgets of the zero inputs: zero everywhere except witness_high = 2^14 >> 8.
+constexpr int ED_ADD_WIDTH = 1861, ED_ADD_EVENT_WORDS = 180, ED_LIMBS = 32, ED_GADGET = 188;
+__constant__ bigfield::Modulus<8> d_ed25519 = {
+    {0xffffffedu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0x7fffffffu},
+    // floor(2^512 / (2^255 - 19)) = 2^257 + 76 (the next term, 19^2 * 4 / 2^255, is below one)
+    {76u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 2u}};
+__constant__ uint32_t d_ed25519_d[8] = {0x135978a3u, 0x75eb4dcau, 0x4141d8abu, 0x00700a4du, 0x7779e898u, 0x8cc74079u, 0x2b6ffe73u, 0x52036ceeu};
+struct EdRow {
+  uint32_t* out; size_t height, row; const LookupSink& sink; bool count;
+  __device__ __forceinline__ void put(int col, uint32_t canonical) const { out[(size_t)col * height + row] = kb::to_monty(canonical); }
+  // columns of one gadget at `base` from the identity's polynomial before the carry term (63 coefficients) and the two integers
+  __device__ void gadget(int base, int32_t* van, const uint32_t* result, const uint32_t* carry) const {
+    constexpr int N = ED_LIMBS, NW = 2 * ED_LIMBS - 2;
+    for (int i = 0; i < N; i++) {
+      const int32_t c = (int32_t)bigfield::byte_of(carry, i);
+      for (int j = 0; j < N; j++) van[i + j] -= c * (int32_t)bigfield::byte_of(d_ed25519.p, j);
+    }
+    uint32_t prev_low = 0, prev_high = 0;
+    int32_t above = 0;
+    for (int k = NW; k >= 1; k--) {          // w[k - 1] = van[k] + 256 w[k]
+      above = van[k] + 256 * above;
+      const uint32_t shifted = (uint32_t)(above + (1 << 14));
+      put(base + 2 * N + k - 1, shifted & 0xff);
+      put(base + 2 * N + NW + k - 1, shifted >> 8);
+      if (count) {                           // slice_range_check_u8 pairs (i, i + 1) for even i
+        if ((k - 1) % 2 == 0) { lookup(sink, B_U8RANGE, shifted & 0xff, prev_low); lookup(sink, B_U8RANGE, shifted >> 8, prev_high); }
+        prev_low = shifted & 0xff; prev_high = shifted >> 8;
+      }
+    }
+    for (int i = 0; i < N; i++) { put(base + i, bigfield::byte_of(result, i)); put(base + N + i, bigfield::byte_of(carry, i)); }
+    if (count)
+      for (int i = 0; i < N; i += 2) {
+        lookup(sink, B_U8RANGE, bigfield::byte_of(result, i), bigfield::byte_of(result, i + 1));
+        lookup(sink, B_U8RANGE, bigfield::byte_of(carry, i), bigfield::byte_of(carry, i + 1));
+      }
+  }
+};
+__device__ __forceinline__ void ed_poly_mac(int32_t* acc, const uint32_t* a, const uint32_t* b) {      // acc(x) += a(x) b(x) over byte limbs
+  for (int i = 0; i < ED_LIMBS; i++) {
+    const int32_t ai = (int32_t)bigfield::byte_of(a, i);
+    for (int j = 0; j < ED_LIMBS; j++) acc[i + j] += ai * (int32_t)bigfield::byte_of(b, j);
+  }
+}
+__device__ __forceinline__ void ed_poly_add(int32_t* acc, const uint32_t* a, int sign) {
+  for (int i = 0; i < ED_LIMBS; i++) acc[i] += sign * (int32_t)bigfield::byte_of(a, i);
+}
+__global__ __launch_bounds__(64) void ed_add_rows(const uint32_t* __restrict__ events, size_t n_events, size_t height, uint32_t* __restrict__ out,
+                                                  uint32_t* counts, int* __restrict__ bad) {
+  enum { IS_REAL = 0, SHARD = 1, CLK = 2, P_PTR = 3, Q_PTR = 4, P_ACCESS = 5, Q_ACCESS = 5 + 16 * 13, GADGETS = 5 + 16 * 13 + 16 * 9, G = ED_GADGET };
+  enum { E_P_RECORDS = 4, E_Q_RECORDS = 4 + 96 };
+  extern __shared__ uint32_t hash_lds[];
+  uint32_t* hkeys = hash_lds;
+  uint32_t* hvals = hash_lds + HASH_SLOTS;
+  const bool count = counts != nullptr;
+  if (count) {
+    for (int i = threadIdx.x; i < HASH_SLOTS; i += blockDim.x) { hkeys[i] = HASH_EMPTY; hvals[i] = 0; }
+    __syncthreads();
+  }
+  const size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (row < height) {
+    const bool real = row < n_events;
+    const uint32_t* e = events + row * ED_ADD_EVENT_WORDS;
+    const LookupSink sink{hkeys, hvals, HASH_SLOTS - 1, counts};
+    const EdRow R{out, height, row, sink, count && real};
+    const bigfield::Modulus<8>& m = d_ed25519;
+    uint32_t x1[8], y1[8], x2[8], y2[8];
+    for (int k = 0; k < 8; k++) {
+      x1[k] = real ? e[E_P_RECORDS + 6 * k + 3] : 0u;            // p = the previous values of the p write records
+      y1[k] = real ? e[E_P_RECORDS + 6 * (8 + k) + 3] : 0u;
+      x2[k] = real ? e[E_Q_RECORDS + 5 * k] : 0u;
+      y2[k] = real ? e[E_Q_RECORDS + 5 * (8 + k)] : 0u;
+    }
+    int32_t van[2 * ED_LIMBS - 1];
+    uint32_t t[16], t2[16], q[9], x3n[8], y3n[8], a[8], b[8], f[8], df[8], res[8];
+    auto clear = [&]() { for (int i = 0; i < 2 * ED_LIMBS - 1; i++) van[i] = 0; };
+    // x3_numerator = x1 y2 + x2 y1, y3_numerator = y1 y2 + x1 x2 (FieldInnerProductCols)
+    auto inner = [&](int base, const uint32_t* a0, const uint32_t* b0, const uint32_t* a1, const uint32_t* b1, uint32_t* result) {
+      bigfield::mul<8, 8>(a0, b0, t); bigfield::mul<8, 8>(a1, b1, t2);
+      bigfield::add<16>(t, t2);                        // below 2 p^2 < 2^511
+      bigfield::divmod<8>(t, m, q, result);
+      clear(); ed_poly_mac(van, a0, b0); ed_poly_mac(van, a1, b1); ed_poly_add(van, result, -1);
+      R.gadget(base, van, result, q);
+    };
+    auto product = [&](int base, const uint32_t* a0, const uint32_t* b0, uint32_t* result) {      // FieldOpCols, Mul
+      bigfield::mul<8, 8>(a0, b0, t);
+      bigfield::divmod<8>(t, m, q, result);
+      clear(); ed_poly_mac(van, a0, b0); ed_poly_add(van, result, -1);
+      R.gadget(base, van, result, q);
+    };
+    auto den = [&](int base, const uint32_t* num, const uint32_t* bb, bool sign, uint32_t* result) {   // FieldDenCols: result (1 +- b) = a
+      uint32_t dn[8], inv[8];
+      const uint32_t one[8] = {1};
+      if (sign) { for (int i = 0; i < 8; i++) dn[i] = bb[i]; } else { for (int i = 0; i < 8; i++) dn[i] = m.p[i]; bigfield::sub<8>(dn, bb); }
+      bigfield::add<8>(dn, one);
+      if (bigfield::cmp<8>(dn, m.p) >= 0) bigfield::sub<8>(dn, m.p);
+      bool zero = true;
+      for (int i = 0; i < 8; i++) zero = zero && num[i] == 0;
+      if (zero) { for (int i = 0; i < 8; i++) result[i] = 0; } else { bigfield::inverse<8>(dn, m, inv); bigfield::mulmod<8>(num, inv, m, result); }
+      // carry = (b result + (sign ? result : a) - (sign ? a : result)) / p
+      bigfield::mul<8, 8>(bb, result, t);
+      for (int i = 0; i < 16; i++) t2[i] = i < 8 ? (sign ? result[i] : num[i]) : 0u;
+      bigfield::add<16>(t, t2);
+      for (int i = 0; i < 16; i++) t2[i] = i < 8 ? (sign ? num[i] : result[i]) : 0u;
+      bigfield::sub<16>(t, t2);
+      uint32_t rem[8];
+      bigfield::divmod<8>(t, m, q, rem);
+      clear(); ed_poly_mac(van, bb, result); ed_poly_add(van, sign ? result : num, 1); ed_poly_add(van, sign ? num : result, -1);
+      R.gadget(base, van, result, q);
+    };
+    inner(GADGETS, x1, y2, x2, y1, x3n);
+    inner(GADGETS + G, y1, y2, x1, x2, y3n);
+    product(GADGETS + 2 * G, x1, y1, a);
+    product(GADGETS + 3 * G, x2, y2, b);
+    product(GADGETS + 4 * G, a, b, f);
+    product(GADGETS + 5 * G, f, d_ed25519_d, df);
+    den(GADGETS + 6 * G, x3n, df, true, res);
+    bool ok = true;
+    if (real)
+      for (int k = 0; k < 8; k++) ok = ok && e[E_P_RECORDS + 6 * k] == res[k];
+    den(GADGETS + 7 * G, y3n, df, false, res);
+    if (real)
+      for (int k = 0; k < 8; k++) ok = ok && e[E_P_RECORDS + 6 * (8 + k)] == res[k];
+    if (!ok) *bad = 1;
+    R.put(IS_REAL, real ? 1u : 0u);
+    R.put(SHARD, real ? e[0] : 0u); R.put(CLK, real ? e[1] : 0u); R.put(P_PTR, real ? e[2] : 0u); R.put(Q_PTR, real ? e[3] : 0u);
+    for (int k = 0; k < 16; k++) {
+      uint32_t mw[13], mr[9];
+      if (real) {
+        memory_write_cols(e + E_P_RECORDS + 6 * k, mw);
+        const uint32_t* rec = e + E_Q_RECORDS + 5 * k;
+        memory_access_cols(rec[0], rec[1], rec[2], rec[3], rec[4], mr);
+        if (count) { access_lookups(mr, sink); lookup(sink, B_U16RANGE, mw[11] >> 8, mw[11]); lookup(sink, B_U8RANGE, 0, mw[12]); }
+      } else {
+        for (int c = 0; c < 13; c++) mw[c] = 0;
+        for (int c = 0; c < 9; c++) mr[c] = 0;
+      }
+      for (int c = 0; c < 13; c++) R.put(P_ACCESS + 13 * k + c, mw[c]);
+      for (int c = 0; c < 9; c++) R.put(Q_ACCESS + 9 * k + c, mr[c]);
+    }
   }
   if (count) {
     __syncthreads();

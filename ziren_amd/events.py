@@ -634,6 +634,27 @@ def sha_compress(h, w):
     return [(x + y) & M for x, y in zip(h, [a, b, c, d, e, f, g, hh])]
 
 
+# EdAddAssign (syscall/precompiles/edwards/ed_add.rs): EllipticCurveAddEvent (events/precompiles/ec.rs:24-47) flattened — p and q are the previous
+# values of the p write records and the values of the q read records
+SYS_ED_ADD = 0x01010007                 # syscalls/code.rs:51: one extra cycle (p is written at clk + 1)
+ED_ADD_EVENT = np.dtype([("shard", "<u4"), ("clk", "<u4"), ("p_ptr", "<u4"), ("q_ptr", "<u4"), ("p_memory_records", MEMORY_WRITE_RECORD, (16,)),
+                         ("q_memory_records", MEMORY_READ_RECORD, (16,))])
+assert ED_ADD_EVENT.itemsize == 4 * 180
+ED_ADD_WIDTH = 5 + 16 * 13 + 16 * 9 + 8 * 188       # EdAddAssignCols (ed_add.rs:41-57): 1861
+ED25519_P = (1 << 255) - 19
+ED25519_D = 37095705934669439343138083508754565189542113879843219016388785533085940283555
+
+
+def ed25519_add(p, q):
+    """AffinePoint<Ed25519> + AffinePoint (curves/src/edwards/mod.rs ed_add): the complete twisted-Edwards addition, a = -1."""
+    P, D = ED25519_P, ED25519_D
+    (x1, y1), (x2, y2) = p, q
+    f = x1 * x2 * y1 * y2 % P
+    x3 = (x1 * y2 + x2 * y1) * pow(1 + D * f, P - 2, P) % P
+    y3 = (y1 * y2 + x1 * x2) * pow(1 - D * f, P - 2, P) % P
+    return x3, y3
+
+
 SYSCALL_INSTRS_WIDTH = 77
 # SyscallCode (crates/core/executor/src/syscalls/code.rs): byte 0-1 id, byte 2 "has its own table", byte 3 extra cycles
 SYS_HALT, SYS_WRITE, SYS_ENTER_UNCONSTRAINED, SYS_EXIT_UNCONSTRAINED, SYS_COMMIT, SYS_COMMIT_DEFERRED_PROOFS, SYS_HINT_LEN = 0, 2, 3, 4, 0x10, 0x1a, 0xf0

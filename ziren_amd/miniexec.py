@@ -94,7 +94,7 @@ class Machine:
 
 
 def run_machine(n_cycles: int = 0, seed: int = 1, pc_base: int = 0x1000, shard_cycles: int = 1 << 30, program=None, poseidon2_calls: int = 0,
-                memory_chunk: int = 1 << 30, keccak_calls: int = 0, sha_calls: int = 0) -> Machine:
+                memory_chunk: int = 1 << 30, keccak_calls: int = 0, sha_calls: int = 0, ed_calls: int = 0) -> Machine:
     """A whole run as the reference's prover sees it (crates/core/machine/src/utils/prove.rs:255-400): CPU shards of at most `shard_cycles`
     cycles (never split between a branch and its delay slot, executor.rs:2352-2356), then one shard with the deferred precompile events
     (ExecutionRecord::split, record.rs:130-218), then the shards that initialise and finalise every touched address
@@ -102,11 +102,11 @@ def run_machine(n_cycles: int = 0, seed: int = 1, pc_base: int = 0x1000, shard_c
     to execute until it halts instead of generating one; `poseidon2_calls` / `keccak_calls`: POSEIDON2_PERMUTE / KECCAK_SPONGE precompile calls
     spread over a generated run (each kind is deferred to a precompile shard of its own, record.rs:150-185)."""
     return _execute(n_cycles, seed, 1, pc_base, True, shard_cycles=shard_cycles, given=program, poseidon2_calls=poseidon2_calls, memory_chunk=memory_chunk,
-                    machine=True, keccak_calls=keccak_calls, sha_calls=sha_calls)
+                    machine=True, keccak_calls=keccak_calls, sha_calls=sha_calls, ed_calls=ed_calls)
 
 
 def _execute(n_cycles: int, seed: int = 1, shard: int = 1, pc_base: int = 0x1000, halt: bool = False, shard_cycles: int = 1 << 30, given=None,
-             poseidon2_calls: int = 0, memory_chunk: int = 1 << 30, machine: bool = False, keccak_calls: int = 0, sha_calls: int = 0) -> Machine:
+             poseidon2_calls: int = 0, memory_chunk: int = 1 << 30, machine: bool = False, keccak_calls: int = 0, sha_calls: int = 0, ed_calls: int = 0) -> Machine:
     """Execute `n_cycles` instructions of a program generated on the way. Returns (program, record, public_values) with
     program: INSTRUCTION array (instructions that were jumped over are `ADD $0, 0, 0` no-ops that never run), record:
     structured event arrays, public_values: dict of the words the Cpu chip checks (start_pc, next_pc, execution_shard).
@@ -172,6 +172,7 @@ def _execute(n_cycles: int, seed: int = 1, shard: int = 1, pc_base: int = 0x1000
     k_seq = 0
     s_at = set(int(x) for x in np.linspace(n_cycles // 5, max(n_cycles - 80, n_cycles // 5), sha_calls)) - p2_at - k_at if sha_calls else set()
     s_seq = 0
+    e_at = {n_cycles // 4} - p2_at - k_at - s_at if ed_calls else set()
     clk_extra = 0                  # the extra cycles of the shard's syscalls so far (Syscall::num_extra_cycles, executor.rs:1641)
 
     def close_shard():
@@ -209,6 +210,7 @@ def _execute(n_cycles: int, seed: int = 1, shard: int = 1, pc_base: int = 0x1000
             p2_at = set(x + len(queued) - had if x > cyc else x for x in p2_at)
             k_at = set(x + len(queued) - had if x > cyc else x for x in k_at)
             s_at = set(x + len(queued) - had if x > cyc else x for x in s_at)
+            e_at = set(x + len(queued) - had if x > cyc else x for x in e_at)
         if given is None and cyc in k_at and cyc < n_cycles:
             # a KECCAK_SPONGE call as the guest library's keccak256 makes it (crates/zkvm/lib/src/keccak256.rs:3-57): the padded message as
             # 36-word blocks, its length in words at result + 64, the code in $v0, input and result pointers in $a0 / $a1
@@ -226,6 +228,7 @@ def _execute(n_cycles: int, seed: int = 1, shard: int = 1, pc_base: int = 0x1000
             p2_at = set(x + len(queued) - had if x > cyc else x for x in p2_at)
             k_at = set(x + len(queued) - had if x > cyc else x for x in k_at)
             s_at = set(x + len(queued) - had if x > cyc else x for x in s_at)
+            e_at = set(x + len(queued) - had if x > cyc else x for x in e_at)
         if given is None and cyc in s_at and cyc < n_cycles:
             # one SHA-256 block as the reference's test programs lay the calls out (sha256/extend/mod.rs:44-61, compress/mod.rs:52-78): sixteen
             # message words at w_ptr, SHA_EXTEND(w_ptr, 0), the eight state words at h_ptr, SHA_COMPRESS(w_ptr, h_ptr)
@@ -240,6 +243,25 @@ def _execute(n_cycles: int, seed: int = 1, shard: int = 1, pc_base: int = 0x1000
                 queued += [(E.ADD, 30, word, 0, 1, 1), (E.SW, 30, 0, h_ptr + 4 * i, 0, 1)]
             queued += [(E.ADD, E.REG_V0, E.SYS_SHA_COMPRESS, 0, 1, 1), (E.ADD, E.REG_A0, w_ptr, 0, 1, 1), (E.ADD, E.REG_A1, h_ptr, 0, 1, 1),
                        (E.SYSCALL, E.REG_V0, E.REG_A0, E.REG_A1, 0, 0)]
+            n_cycles += len(queued) - had
+            p2_at = set(x + len(queued) - had if x > cyc else x for x in p2_at)
+            k_at = set(x + len(queued) - had if x > cyc else x for x in k_at)
+            s_at = set(x + len(queued) - had if x > cyc else x for x in s_at)
+            e_at = set(x + len(queued) - had if x > cyc else x for x in e_at)
+        if given is None and cyc in e_at and cyc < n_cycles:
+            # Ed25519 additions the way a scalar multiplication makes them: p = B and q = 2B stored once, then `ed_calls` times p <- p + q
+            # (ED_ADD(p_ptr, q_ptr), the reference's ed_add test program: syscall/precompiles/edwards/ed_add.rs tests)
+            had = len(queued)
+            p_ptr, q_ptr = 0x00500000, 0x00500100
+            base = (15112221349535400772501151409588531511454012693041857206046113283949847762202,
+                    46316835694926478169428394003475163141307993866256225615783033603165251855960)
+            dbl = E.ed25519_add(base, base)
+            for ptr, pt in ((p_ptr, base), (q_ptr, dbl)):
+                for i in range(16):
+                    queued += [(E.ADD, 30, (pt[i // 8] >> (32 * (i % 8))) & 0xffffffff, 0, 1, 1), (E.SW, 30, 0, ptr + 4 * i, 0, 1)]
+            for _ in range(ed_calls):
+                queued += [(E.ADD, E.REG_V0, E.SYS_ED_ADD, 0, 1, 1), (E.ADD, E.REG_A0, p_ptr, 0, 1, 1), (E.ADD, E.REG_A1, q_ptr, 0, 1, 1),
+                           (E.SYSCALL, E.REG_V0, E.REG_A0, E.REG_A1, 0, 0)]
             n_cycles += len(queued) - had
             p2_at = set(x + len(queued) - had if x > cyc else x for x in p2_at)
             k_at = set(x + len(queued) - had if x > cyc else x for x in k_at)
@@ -417,7 +439,7 @@ def _execute(n_cycles: int, seed: int = 1, shard: int = 1, pc_base: int = 0x1000
             b_rec = read(op_b, clk, POS_B)
             b = b_rec[1][0]
             sid = code & 0xffff
-            assert code in (E.SYS_HALT, E.SYS_COMMIT, E.SYS_POSEIDON2_PERMUTE, E.SYS_KECCAK_SPONGE, E.SYS_SHA_EXTEND, E.SYS_SHA_COMPRESS), code
+            assert code in (E.SYS_HALT, E.SYS_COMMIT, E.SYS_POSEIDON2_PERMUTE, E.SYS_KECCAK_SPONGE, E.SYS_SHA_EXTEND, E.SYS_SHA_COMPRESS, E.SYS_ED_ADD), code
             touched = {}                               # address -> [initial (shard, timestamp, value), final]: SyscallContext's local map
 
             def mem(addr, ts, value=None):
@@ -510,6 +532,19 @@ def _execute(n_cycles: int, seed: int = 1, shard: int = 1, pc_base: int = 0x1000
                 hw = [mem(c + 4 * i, clk + 1, out[i]) for i in range(8)]
                 local = [(addr, v[0], v[1]) for addr, v in sorted(touched.items())]
                 precompile.append(("sha_compress", (pc, next_pc, shard, clk, (0, 0, 0, 0, 0, 0), 0, [0, 0, 0], sid, b, c), [(shard, clk, b, c, hr, wr_, hw)], local))
+                clk_extra += 1
+            if code == E.SYS_ED_ADD:
+                # create_ec_add_event (events/precompiles/ec.rs:96-139) for Ed25519: p is peeked, q is read at clk, p + q is written over p at
+                # clk + 1 (p and q may be the same words); one extra cycle
+                assert b % 4 == 0 and c % 4 == 0
+                pw = [R.get(b + 4 * i, 0) for i in range(16)]
+                qr = [mem(c + 4 * i, clk) for i in range(16)]
+                as_int = lambda ws: sum(w << (32 * i) for i, w in enumerate(ws))      # noqa: E731
+                x3, y3 = E.ed25519_add((as_int(pw[:8]), as_int(pw[8:])), (as_int([x[0] for x in qr[:8]]), as_int([x[0] for x in qr[8:]])))
+                out = [(x3 >> (32 * i)) & 0xffffffff for i in range(8)] + [(y3 >> (32 * i)) & 0xffffffff for i in range(8)]
+                pwr = [mem(b + 4 * i, clk + 1, out[i]) for i in range(16)]
+                local = [(addr, v[0], v[1]) for addr, v in sorted(touched.items())]
+                precompile.append(("ed_add", (pc, next_pc, shard, clk, (0, 0, 0, 0, 0, 0), 0, [0, 0, 0], sid, b, c), [(shard, clk, b, c, pwr, qr)], local))
                 clk_extra += 1
             a = code                                       # none of them returns a value: V0 keeps the code
             a_rec = write(op_a, a, clk, POS_A)
@@ -622,7 +657,7 @@ def _execute(n_cycles: int, seed: int = 1, shard: int = 1, pc_base: int = 0x1000
     last_pv = shards[-1].pv
     n_shard = shards[-1].pv["shard"]
     for kind, dt in (("poseidon2", E.POSEIDON2_PERMUTE_EVENT), ("keccak", E.KECCAK_SPONGE_BLOCK), ("sha_extend", E.SHA_EXTEND_EVENT),
-                     ("sha_compress", E.SHA_COMPRESS_EVENT)):
+                     ("sha_compress", E.SHA_COMPRESS_EVENT), ("ed_add", E.ED_ADD_EVENT)):
         mine = [e for e in precompile if e[0] == kind]
         if not mine:
             continue
@@ -634,6 +669,7 @@ def _execute(n_cycles: int, seed: int = 1, shard: int = 1, pc_base: int = 0x1000
         o.keccak_sponge = arr([ev for e in mine for ev in e[2]] if kind == "keccak" else [], E.KECCAK_SPONGE_BLOCK)
         o.sha_extend = arr([ev for e in mine for ev in e[2]] if kind == "sha_extend" else [], E.SHA_EXTEND_EVENT)
         o.sha_compress = arr([ev for e in mine for ev in e[2]] if kind == "sha_compress" else [], E.SHA_COMPRESS_EVENT)
+        o.ed_add = arr([ev for e in mine for ev in e[2]] if kind == "ed_add" else [], E.ED_ADD_EVENT)
         o.memory_local = arr([ev for e in mine for ev in e[3]], MEMORY_LOCAL_EVENT)
         pv = dict(last_pv, start_pc=last_pv["next_pc"], shard=n_shard)
         shards.append(Shard("precompile", o, pv))
