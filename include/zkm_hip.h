@@ -465,6 +465,19 @@ typedef struct zkm_ed_add_event {
 #define ZKM_ED_ADD_WIDTH 1861
 int zkm_tracegen_ed_add(zkm_ctx* ctx, const zkm_ed_add_event* events, size_t n_events, int fixed_log2_rows, zkm_byte_lookups* blu,
                         zkm_matrix** out);
+
+/* The EdDecompress precompile (crates/core/machine/src/syscall/precompiles/edwards/ed_decompress.rs): replaces generate_trace (:217-252), byte
+ * lookups into `blu`. EdDecompressEvent (crates/core/executor/src/events/precompiles/edwards.rs:13-32) flattened: y_bytes and
+ * decompressed_x_bytes are the values of the y read records (at ptr + 32) and of the x write records (at ptr). Fails when y is not below
+ * 2^255 - 19, when it is not the y of a curve point, or when the x written is not the root the sign bit selects. */
+typedef struct zkm_ed_decompress_event {
+  uint32_t shard, clk, ptr, sign;
+  zkm_memory_write_record x_memory_records[8];
+  zkm_memory_read_record y_memory_records[8];
+} zkm_ed_decompress_event;
+#define ZKM_ED_DECOMPRESS_WIDTH 1566
+int zkm_tracegen_ed_decompress(zkm_ctx* ctx, const zkm_ed_decompress_event* events, size_t n_events, int fixed_log2_rows,
+                               zkm_byte_lookups* blu, zkm_matrix** out);
 /* The MiscInstrs chip (crates/core/machine/src/misc/others/: SEXT EXT INS MADDU MSUBU MADD MSUB TEQ): replaces generate_trace
  * (trace.rs:42-84), which also records the byte lookups (counted into `blu` if given). Events are the #[repr(C)] MiscEvents of
  * crates/core/executor/src/events/instr.rs:239-261 (60 bytes). 72 columns, zero padding rows. */

@@ -68,16 +68,34 @@ static inline void halve(Big& a) {
   for (size_t i = a.size(); i-- > 0;) { const uint32_t v = a[i] | (carry << 8); a[i] = v >> 1; carry = v & 1; }
   trim(a);
 }
-// num = q * den + r, 0 <= r < den: one bit of the quotient at a time
-static inline void divmod(const Big& num, const Big& den, Big& q, Big& r) {
-  if (is_zero(den)) throw std::runtime_error("bigfield: division by zero");
+// num = q * den + r, 0 <= r < den: one bit of the quotient at a time; the running remainder lives in eight 64-bit words (den below 2^448)
+static inline void divmod(const Big& num, const Big& den_in, Big& q, Big& r) {
+  Big den = den_in;
+  trim(den);
+  if (den.empty()) throw std::runtime_error("bigfield: division by zero");
+  if (den.size() > 56) throw std::runtime_error("bigfield: divisor too wide");
+  uint64_t d[8] = {0}, rem[8] = {0};
+  for (size_t i = 0; i < den.size(); i++) d[i / 8] |= (uint64_t)den[i] << (8 * (i % 8));
   q.assign(num.size() + 1, 0);
-  r.clear();
   for (size_t k = 8 * num.size(); k-- > 0;) {
-    r = add(r, r);
-    if (bit(num, k)) r = add(r, from_u64(1));
-    if (cmp(r, den) >= 0) { r = sub(r, den); q[k / 8] |= 1u << (k % 8); }
+    for (int w = 7; w > 0; w--) rem[w] = (rem[w] << 1) | (rem[w - 1] >> 63);
+    rem[0] = (rem[0] << 1) | (bit(num, k) ? 1u : 0u);
+    bool ge = true;
+    for (int w = 7; w >= 0; w--)
+      if (rem[w] != d[w]) { ge = rem[w] > d[w]; break; }
+    if (ge) {
+      uint64_t borrow = 0;
+      for (int w = 0; w < 8; w++) {
+        const uint64_t x = rem[w], y = d[w];
+        rem[w] = x - y - borrow;
+        borrow = (x < y) || (x == y && borrow);
+      }
+      q[k / 8] |= 1u << (k % 8);
+    }
   }
+  r.assign(64, 0);
+  for (size_t i = 0; i < 64; i++) r[i] = (rem[i / 8] >> (8 * (i % 8))) & 0xff;
+  trim(r);
   trim(q);
 }
 static inline Big mod(const Big& a, const Big& p) { Big q, r; divmod(a, p, q, r); return r; }
@@ -94,6 +112,14 @@ static inline Big inv_mod(const Big& a_in, const Big& p) {
     if (cmp(u, v) >= 0) { u = sub(u, v); x1 = sub_mod(x1, x2); } else { v = sub(v, u); x2 = sub_mod(x2, x1); }
   }
   return cmp(u, one) == 0 ? x1 : x2;
+}
+static inline Big pow_mod(const Big& a, const Big& e, const Big& p) {      // right-to-left square and multiply
+  Big acc = from_u64(1), base = mod(a, p);
+  for (size_t k = 0; k < 8 * e.size(); k++) {
+    if (bit(e, k)) acc = mod(mul(acc, base), p);
+    base = mod(mul(base, base), p);
+  }
+  return acc;
 }
 static inline uint32_t limb(const Big& a, size_t i) { return i < a.size() ? a[i] : 0; }
 

@@ -734,4 +734,21 @@ int orc_tracegen_ed_add(const void* events, size_t n_events, int fixed_log2_rows
   ORC_CATCH
 }
 
+// EdDecompress precompile chip: flattened EdDecompressEvents (92 words), one row each, 1566 columns
+int orc_tracegen_ed_decompress(const void* events, size_t n_events, int fixed_log2_rows, uint32_t* out, size_t out_cap, size_t* rows,
+                               uint32_t* byte_counts) {
+  ORC_TRY
+  size_t h;
+  std::vector<uint64_t> cnt(byte_counts ? tracegen::BYTE_ROWS * tracegen::NUM_BYTE_OPS : 0, 0);
+  std::vector<F> t = tracegen::generate_ed_decompress((const tracegen::EdDecompressEvent*)events, n_events, fixed_log2_rows, &h,
+                                                      byte_counts && out ? cnt.data() : nullptr);
+  *rows = h;
+  if (out) {
+    if (t.size() > out_cap) throw std::runtime_error("trace buffer too small");
+    for (size_t i = 0; i < t.size(); i++) out[i] = to_monty(t[i]);
+    for (size_t i = 0; i < cnt.size(); i++) byte_counts[i] += (uint32_t)cnt[i];
+  }
+  ORC_CATCH
+}
+
 }  // extern "C"

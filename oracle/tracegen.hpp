@@ -1858,4 +1858,123 @@ static inline std::vector<F> generate_ed_add(const EdAddEvent* events, size_t n_
   return t;
 }
 
+// ---- EdDecompress precompile (syscall/precompiles/edwards/ed_decompress.rs): x from y and a sign bit. Columns EdDecompressCols :39-57 = is_real,
+// shard, clk, ptr, sign, eight MemoryWriteCols of x, eight MemoryReadCols of y, y_range (FieldLtCols: 32 byte flags + the two compared bytes),
+// yy, u, dyy, v, u_div_v (FieldOpCols), x (FieldSqrtCols = a FieldOpCols whose result columns hold the root, a FieldLtCols, the root's low
+// bit), neg_x (FieldOpCols): 1566 columns. Padding rows hold the field operations of y = 0 (:239-249), whose root is sqrt(-1).
+struct EdDecompressEvent { uint32_t shard, clk, ptr, sign; MemoryWriteRecord x_memory_records[8]; MemoryReadRecord y_memory_records[8]; };
+static_assert(sizeof(EdDecompressEvent) == 4 * 92, "flattened EdDecompressEvent is 92 words");
+static const size_t ED_DECOMPRESS_WIDTH = 1566;
+enum FieldOpKind { FOP_ADD, FOP_SUB, FOP_MUL, FOP_DIV };
+// FieldOpCols::populate_with_modulus (field_op.rs:154-224): Sub and Div fill carry and witness from the reversed identity result op' b = a
+static inline bigfield::Big field_op_cols(const FieldGadgets& g, F* r, const bigfield::Big& a, const bigfield::Big& b, FieldOpKind op) {
+  using namespace bigfield;
+  const int n = g.n;
+  Big res, lhs_value, rhs = a;
+  Poly lhs_poly;
+  switch (op) {
+    case FOP_ADD: res = mod(add(a, b), g.p); break;
+    case FOP_MUL: res = mod(bigfield::mul(a, b), g.p); break;
+    case FOP_SUB: res = mod(sub(add(g.p, a), mod(b, g.p)), g.p); break;
+    case FOP_DIV:
+      if (is_zero(b) && !is_zero(a)) throw std::runtime_error("tracegen: division by zero is allowed only when dividing zero");
+      res = is_zero(a) ? Big() : mod(bigfield::mul(a, inv_mod(b, g.p)), g.p);
+      break;
+  }
+  if (op == FOP_ADD || op == FOP_MUL) {           // a op b = res + carry p
+    lhs_value = op == FOP_ADD ? add(a, b) : bigfield::mul(a, b);
+    lhs_poly = op == FOP_ADD ? padd(poly(a, n), poly(b, n)) : pmul(poly(a, n), poly(b, n));
+    rhs = res;
+  } else {                                        // res op' b = a + carry p
+    lhs_value = op == FOP_SUB ? add(res, b) : bigfield::mul(res, b);
+    lhs_poly = op == FOP_SUB ? padd(poly(res, n), poly(b, n)) : pmul(poly(res, n), poly(b, n));
+  }
+  Big q, rem;
+  divmod(sub(lhs_value, rhs), g.p, q, rem);
+  if (!is_zero(rem)) throw std::runtime_error("tracegen: field operation identity");
+  field_gadget_cols(r, padd(lhs_poly, poly(rhs, n), -1), res, q, g.p, n, g.offset, g.lk);
+  return res;
+}
+// FieldLtCols::populate (range.rs:27-60): the flag of the most significant byte where lhs < rhs, and the two bytes
+static inline void field_lt_cols(F* r, const bigfield::Big& lhs, const bigfield::Big& rhs, int n, std::vector<ByteLookup>* lk) {
+  if (bigfield::cmp(lhs, rhs) >= 0) throw std::runtime_error("tracegen: field element is not below the modulus");
+  for (int i = n - 1; i >= 0; i--) {
+    const uint32_t a = bigfield::limb(lhs, i), b = bigfield::limb(rhs, i);
+    if (a < b) {
+      r[i] = 1; r[n] = a; r[n + 1] = b;
+      if (lk) lk->push_back(ByteLookup{B_LTU_OP, (uint8_t)a, (uint8_t)b});
+      return;
+    }
+  }
+}
+static inline std::vector<F> generate_ed_decompress(const EdDecompressEvent* events, size_t n_events, int fixed_log2_rows, size_t* height,
+                                                    uint64_t* byte_counts) {
+  using namespace bigfield;
+  enum { IS_REAL = 0, SHARD = 1, CLK = 2, PTR = 3, SIGN = 4, X_ACCESS = 5, Y_ACCESS = 109, Y_RANGE = 181, YY = 215, U = 403, DYY = 591, V = 779, U_DIV_V = 967,
+         X_MULT = 1155, X_RANGE = 1343, X_LSB = 1377, NEG_X = 1378 };
+  static_assert(NEG_X + 188 == 1566, "layout");
+  const size_t h = padded_rows(n_events, fixed_log2_rows);
+  std::vector<F> t(h * ED_DECOMPRESS_WIDTH, 0);
+  std::vector<ByteLookup> lk;
+  const Big p = from_bytes(ED25519_MODULUS, 32), d = from_bytes(ED25519_D, 32), one = from_u64(1);
+  // ed25519_sqrt (curves/src/edwards/ed25519.rs:75-113): a^((p + 3) / 8), times sqrt(-1) when that squares to -a; the even root
+  auto sqrt = [&](const Big& a) {
+    Big e, rem;
+    divmod(add(p, from_u64(3)), from_u64(8), e, rem);
+    Big beta = pow_mod(a, e, p);
+    const Big sq = mod(bigfield::mul(beta, beta), p), neg_a = mod(sub(p, a), p);
+    if (cmp(sq, neg_a) == 0 && cmp(sq, a) != 0) {
+      const Big e4 = [&] { Big q2, r2; divmod(sub(p, one), from_u64(4), q2, r2); return q2; }();
+      beta = mod(bigfield::mul(beta, pow_mod(from_u64(2), e4, p)), p);        // 2^((p - 1) / 4) is a square root of -1
+    } else if (cmp(sq, a) != 0) {
+      throw std::runtime_error("tracegen: EdDecompress: not a square");
+    }
+    if (bit(beta, 0)) beta = mod(sub(p, beta), p);
+    return beta;
+  };
+  auto fill = [&](F* r, const Big& y, std::vector<ByteLookup>* sink) {      // populate_field_ops :85-101; returns the even root
+    const FieldGadgets g{p, 32, 1 << 14, sink};
+    field_lt_cols(r + Y_RANGE, y, p, 32, sink);
+    const Big yy = field_op_cols(g, r + YY, y, y, FOP_MUL);
+    const Big u = field_op_cols(g, r + U, yy, one, FOP_SUB);
+    const Big dyy = field_op_cols(g, r + DYY, d, yy, FOP_MUL);
+    const Big v = field_op_cols(g, r + V, one, dyy, FOP_ADD);
+    const Big u_div_v = field_op_cols(g, r + U_DIV_V, u, v, FOP_DIV);
+    const Big x = sqrt(u_div_v);                                           // FieldSqrtCols::populate (field_sqrt.rs:34-85)
+    if (cmp(field_op_cols(g, r + X_MULT, x, x, FOP_MUL), u_div_v) != 0) throw std::runtime_error("tracegen: EdDecompress: root");
+    for (int i = 0; i < 32; i++) r[X_MULT + i] = limb(x, i);               // the result columns are overwritten with the root
+    field_lt_cols(r + X_RANGE, x, p, 32, sink);
+    r[X_LSB] = limb(x, 0) & 1;
+    if (sink) {
+      sink->push_back(ByteLookup{B_AND_OP, (uint8_t)limb(x, 0), 1});
+      for (int i = 0; i < 32; i += 2) sink->push_back(ByteLookup{B_U8RANGE, (uint8_t)limb(x, i), (uint8_t)limb(x, i + 1)});
+    }
+    field_op_cols(g, r + NEG_X, Big(), x, FOP_SUB);
+    return x;
+  };
+  std::vector<F> padding(ED_DECOMPRESS_WIDTH, 0);
+  fill(padding.data(), Big(), nullptr);
+  for (size_t i = 0; i < h; i++) {
+    F* r = t.data() + i * ED_DECOMPRESS_WIDTH;
+    if (i >= n_events) { std::copy(padding.begin(), padding.end(), r); continue; }
+    const EdDecompressEvent& e = events[i];
+    if (e.sign > 1) throw std::runtime_error("tracegen: EdDecompress sign bit");
+    r[IS_REAL] = 1; r[SHARD] = fu32(e.shard); r[CLK] = fu32(e.clk); r[PTR] = fu32(e.ptr); r[SIGN] = e.sign;
+    uint32_t yw[8];
+    for (int k = 0; k < 8; k++) {
+      memory_write_cols(e.x_memory_records[k], r + X_ACCESS + 13 * k, &lk);
+      const MemoryReadRecord& m = e.y_memory_records[k];
+      memory_access_cols(m.value, m.shard, m.timestamp, m.prev_shard, m.prev_timestamp, r + Y_ACCESS + 9 * k, &lk);
+      yw[k] = m.value;
+    }
+    const Big x = fill(r, from_words(yw, 8), &lk);
+    for (int k = 0; k < 32; k++)        // what is written is the root, or its negative when the sign bit is set (:170-176)
+      if (r[X_ACCESS + 13 * (k / 4) + 4 + k % 4] != (e.sign ? r[NEG_X + k] : r[X_MULT + k])) throw std::runtime_error("tracegen: EdDecompress event does not write x");
+  }
+  if (byte_counts)
+    for (const ByteLookup& b : lk) byte_counts[((size_t)b.b * 256 + b.c) * NUM_BYTE_OPS + b.op]++;
+  *height = h;
+  return t;
+}
+
 }  // namespace tracegen

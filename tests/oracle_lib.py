@@ -413,6 +413,14 @@ def tracegen_ed_add(events, fixed_log2_rows=-1, byte_counts=None):
     return _rows_then_fill(lib().orc_tracegen_ed_add, E.ED_ADD_WIDTH, C.c_void_p(ev.ctypes.data), C.c_size_t(len(ev)), C.c_int(fixed_log2_rows), tail=bc)
 
 
+def tracegen_ed_decompress(events, fixed_log2_rows=-1, byte_counts=None):
+    """EdDecompress precompile rows from flattened EdDecompressEvents (events.ED_DECOMPRESS_EVENT), one row per event."""
+    from ziren_amd import events as E
+    ev = np.ascontiguousarray(events, dtype=E.ED_DECOMPRESS_EVENT)
+    bc = (abi.as_u32p(byte_counts),) if byte_counts is not None else (None,)
+    return _rows_then_fill(lib().orc_tracegen_ed_decompress, E.ED_DECOMPRESS_WIDTH, C.c_void_p(ev.ctypes.data), C.c_size_t(len(ev)), C.c_int(fixed_log2_rows), tail=bc)
+
+
 def septic_known_answers(a, b):
     """((z^i)^p, (z^i)^(p^2) for i = 1..6, a * b, normalised sqrt(a^2)) in the septic extension, canonical words."""
     a = np.ascontiguousarray(a, dtype=np.uint32)

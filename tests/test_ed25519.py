@@ -1,9 +1,11 @@
-"""The EdAddAssign precompile (crates/core/machine/src/syscall/precompiles/edwards/ed_add.rs): Ed25519 point addition, the operation a
-signature verification (BASELINE config 5: the tendermint light client) spends its precompile rows on. One row per addition, 1861 columns:
-eight big-field gadgets (operations/field/: two FieldInnerProductCols, four FieldOpCols, two FieldDenCols) over 32 byte limbs. Everything
-is in the reference tree; pinned by its cost table (3637 per row: 1861 columns, 881 lookups, degree 3) and by three independent
-computations of the same sums: Python integers (events.ed25519_add), the oracle's byte-vector arithmetic with binary long division and the
-binary extended Euclid (oracle/bigfield.hpp), and the device's 32-bit limbs with Barrett reduction and Fermat inversion (csrc/bigfield.cuh)."""
+"""The Ed25519 precompiles (crates/core/machine/src/syscall/precompiles/edwards/): EdAddAssign — point addition, the operation a signature
+verification (BASELINE config 5: the tendermint light client) spends its precompile rows on; one row per addition, 1861 columns: eight
+big-field gadgets (operations/field/: two FieldInnerProductCols, four FieldOpCols, two FieldDenCols) over 32 byte limbs — and EdDecompress
+— x from y and a sign bit, once per public key and per signature; 1566 columns: a less-than gadget, six field operations including a
+division, a square root. Everything is in the reference tree; pinned by its cost table (3637 and 3062 per row: column counts, lookup
+counts, degree 3) and by three independent computations of the same numbers: Python integers (events.ed25519_add / _decompress), the
+oracle's byte-vector arithmetic with binary long division and the binary extended Euclid (oracle/bigfield.hpp), and the device's 32-bit
+limbs with Barrett reduction, Fermat inversion and the (p + 3) / 8 power for the root (csrc/bigfield.cuh)."""
 import json
 import os
 
@@ -108,17 +110,90 @@ def test_every_ed_add_column_is_bound(oracle):
     assert [c for c in holes if c not in ED_ADD_FREE] == [], holes
 
 
+def test_ed_decompress_rows_satisfy_the_air_and_cost_what_the_reference_says(oracle):
+    evs, xs = some_decompressions()
+    counts = np.zeros((1 << 16, 10), dtype=np.uint32)
+    t = oracle.tracegen_ed_decompress(evs, -1, counts)      # refuses events whose x records do not hold the root their sign selects
+    assert t.shape == (16, E.ED_DECOMPRESS_WIDTH)
+    # per row: seven gadgets x 94, the root's 16 range checks + AND + LTU, y's LTU, sixteen memory accesses x 2
+    assert counts.sum() == len(evs) * (7 * 94 + 18 + 1 + 32)
+    tc = F.from_monty(t)
+    assert air.debug_constraints(chips.record_ed_decompress_constraints().b, tc) == []
+    for i, x in enumerate(xs):
+        root = sum(int(tc[i, 1155 + k]) << (8 * k) for k in range(32))
+        neg = sum(int(tc[i, 1378 + k]) << (8 * k) for k in range(32))
+        assert root % 2 == 0 and x in (root, neg) and (root + neg) % P == 0 and int(tc[i, 1377]) == 0
+    chip = chips.record_ed_decompress_chip(4)
+    ref = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "mips_costs.json")))["costs"]
+    assert len(chip.sends) + len(chip.receives) == 742 and chip.main_width + 4 * chip.perm_ext_width + 8 == ref["EdDecompress"] == 3062
+    assert E.ed25519_decompress(2, 0) is None               # y = 2 is not on the curve
+    forged = evs.copy()
+    forged["x_memory_records"][1, 0]["value"] ^= 1
+    with pytest.raises(RuntimeError, match="does not write x"):
+        oracle.tracegen_ed_decompress(forged)
+    off_curve = evs[:1].copy()
+    off_curve["y_memory_records"][0]["value"] = words(2)
+    with pytest.raises(RuntimeError, match="not a square"):
+        oracle.tracegen_ed_decompress(off_curve)
+
+
+ED_DECOMPRESS_FREE = {}
+
+
+def test_every_ed_decompress_column_is_bound(oracle):
+    evs, _ = some_decompressions()
+    t = F.from_monty(oracle.tracegen_ed_decompress(evs))
+    holes = windowed_sweep(chips.record_ed_decompress_constraints(), chips.record_ed_decompress_chip(4), t, (1, 2, 14))
+    assert [c for c in holes if c not in ED_DECOMPRESS_FREE] == [], holes
+
+
 def ed_machine():
     return M.run_machine(1500, seed=3, shard_cycles=1024, ed_calls=6)
+
+
+def precompile_record(m, name):
+    return [s.record for s in m.shards if s.kind == "precompile" and len(getattr(s.record, name))][0]
+
+
+def dec_event(y, sign, shard=2, clk=300, ptr=0x700000, seed=0):
+    """The EdDecompressEvent of ED_DECOMPRESS(ptr, sign) (syscalls/precompiles/edwards/decompress.rs:33-83)."""
+    rng = np.random.default_rng(seed)
+    e = np.zeros(1, dtype=E.ED_DECOMPRESS_EVENT)[0]
+    e["shard"], e["clk"], e["ptr"], e["sign"] = shard, clk, ptr, sign
+    x = E.ed25519_decompress(y, sign)
+    for k in range(8):
+        prev = (shard, int(rng.integers(0, clk))) if rng.random() < 0.7 else (int(rng.integers(0, shard)), int(rng.integers(0, 1 << 20)))
+        e["y_memory_records"][k] = (words(y)[k], shard, clk) + prev
+        prev = (shard, int(rng.integers(0, clk))) if rng.random() < 0.7 else (int(rng.integers(0, shard)), int(rng.integers(0, 1 << 20)))
+        e["x_memory_records"][k] = (words(x)[k], shard, clk, int(rng.integers(0, 1 << 32))) + prev
+    return e, x
+
+
+def some_decompressions():
+    """B .. 7B with the sign of their x, each also with the other sign, and the neutral element (y = 1, x = 0)."""
+    pts, evs, xs = [BASE], [], []
+    for _ in range(6):
+        pts.append(E.ed25519_add(pts[-1], BASE))
+    for i, (x, y) in enumerate(pts):
+        for flip in (0, 1):
+            e, got = dec_event(y, (x & 1) ^ flip, clk=300 + 20 * i + flip, seed=2 * i + flip)
+            assert got == (x if not flip else P - x)
+            evs.append(e); xs.append(got)
+    e, got = dec_event(1, 0, clk=900)
+    assert got == 0
+    return np.array(evs + [e]), xs + [got]
 
 
 def test_machine_with_ed_add_calls_is_coherent(oracle):
     """A run that adds 2B to B six times with the precompile: CPU shards, the EdAddAssign precompile shard, the memory shard; constraints,
     lookups and global digests as for the other precompiles, and the point left in memory is 13 B."""
     m = ed_machine()
-    assert [s.kind for s in m.shards][-2:] == ["precompile", "memory"]
-    ev = m.shards[-2].record.ed_add
-    assert len(ev) == 6
+    assert [s.kind for s in m.shards][-3:] == ["precompile", "precompile", "memory"]
+    ev = precompile_record(m, "ed_add").ed_add
+    dec = precompile_record(m, "ed_decompress").ed_decompress
+    assert len(ev) == 6 and len(dec) == 2          # B and 2B are decompressed from their y and sign first, as a verifier gets A and R
+    two = E.ed25519_add(BASE, BASE)
+    assert [int(x) for x in dec["x_memory_records"]["value"][0]] == words(BASE[0]) and [int(x) for x in dec["x_memory_records"]["value"][1]] == words(two[0])
     pt = BASE
     for _ in range(6):
         pt = E.ed25519_add(pt, E.ed25519_add(BASE, BASE))
@@ -129,7 +204,9 @@ def test_machine_with_ed_add_calls_is_coherent(oracle):
         thirteen = E.ed25519_add(thirteen, BASE)
     assert pt == thirteen
     shards = check_machine_airs(oracle, m)
-    assert {c.name for c in shards[-2]} == {"SyscallPrecompile", "EdAddAssign", "MemoryLocal", "Global", "Byte", "Program"}
+    names = [{c.name for c in cs} for cs in shards]
+    assert {"SyscallPrecompile", "EdAddAssign", "MemoryLocal", "Global", "Byte", "Program"} in names
+    assert {"SyscallPrecompile", "EdDecompress", "MemoryLocal", "Global", "Byte", "Program"} in names
     d = global_digests(shards)
     assert oracle.global_digest_sum(d + [ZERO_DIGEST])[1]
 
@@ -142,7 +219,7 @@ def test_gpu_ed_add_tracegen_matches_oracle(hip_ctx, oracle):
     doubling, a point and its negative), a run's additions, one, none, 300 random multiples in a fixed table; a forged sum is an error."""
     from ziren_amd import lib
     evs, _ = some_additions()
-    run = ed_machine().shards[-2].record.ed_add
+    run = precompile_record(ed_machine(), "ed_add").ed_add
     rng = np.random.default_rng(5)
     pts = [BASE]
     for _ in range(40):
@@ -163,6 +240,42 @@ def test_gpu_ed_add_tracegen_matches_oracle(hip_ctx, oracle):
     forged["p_memory_records"][2, 9]["value"] ^= 1
     with pytest.raises(lib.ZkmError, match="p \\+ q"):
         hip_ctx.tracegen_ed_add(forged)
+
+
+@pytest.mark.gpu
+def test_gpu_ed_decompress_tracegen_matches_oracle(hip_ctx, oracle):
+    """zkm_tracegen_ed_decompress against the restated generate_trace, bit for bit, with its byte lookups; a y that is no point's, a y not
+    below p and a forged x are errors."""
+    from ziren_amd import lib
+    evs, _ = some_decompressions()
+    run = precompile_record(ed_machine(), "ed_decompress").ed_decompress
+    pts = [BASE]
+    for _ in range(60):
+        pts.append(E.ed25519_add(pts[-1], BASE))
+    many = np.array([dec_event(y, x & 1, clk=100 + 3 * i, seed=i)[0] for i, (x, y) in enumerate(pts * 4)])
+    for ev, fixed in ((evs, -1), (run, -1), (evs[:1], -1), (evs[:0], -1), (many, 8)):
+        counts = np.zeros((1 << 16, 10), dtype=np.uint32)
+        want = oracle.tracegen_ed_decompress(ev, fixed, counts)
+        blu = hip_ctx.byte_lookups()
+        born = hip_ctx.tracegen_ed_decompress(ev, fixed, blu)
+        mults = hip_ctx.tracegen_byte_mults(blu)
+        assert (born.height, born.width) == want.shape
+        got = born.to_host()
+        assert np.array_equal(got, want), (len(ev), np.argwhere(got != want)[:5])
+        assert np.array_equal(F.from_monty(mults.to_host()), counts)
+        born.free(); mults.free(); blu.free()
+    forged = evs.copy()
+    forged["x_memory_records"][1, 0]["value"] ^= 1
+    with pytest.raises(lib.ZkmError, match="not the x"):
+        hip_ctx.tracegen_ed_decompress(forged)
+    off_curve = evs[:1].copy()
+    off_curve["y_memory_records"][0]["value"] = words(2)
+    with pytest.raises(lib.ZkmError, match="not a square"):
+        hip_ctx.tracegen_ed_decompress(off_curve)
+    too_big = evs[:1].copy()
+    too_big["y_memory_records"][0]["value"] = words(P + 1)
+    with pytest.raises(lib.ZkmError, match="not below"):
+        hip_ctx.tracegen_ed_decompress(too_big)
 
 
 @pytest.mark.gpu

@@ -54,7 +54,7 @@ def check_machine_airs(oracle, m):
                    "SyscallCore": lambda: chips.record_syscall_table_constraints(False), "SyscallPrecompile": lambda: chips.record_syscall_table_constraints(True),
                    "Poseidon2Permute": chips.record_poseidon2_permute_constraints, "KeccakSponge": chips.record_keccak_sponge_constraints,
                    "ShaExtend": chips.record_sha_extend_constraints, "ShaCompress": chips.record_sha_compress_constraints,
-                   "EdAddAssign": chips.record_ed_add_constraints}.get(c.name)
+                   "EdAddAssign": chips.record_ed_add_constraints, "EdDecompress": chips.record_ed_decompress_constraints}.get(c.name)
             if rec is not None:
                 assert air.debug_constraints(rec().b, F.from_monty(c.trace), public_values=pv) == [], (k, c.name)
         assert not any(lookup_tally(cs).values()), (k, sh.kind)

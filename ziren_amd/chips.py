@@ -2103,6 +2103,96 @@ def _ed_add(r: _Rec):
                                  air.to_virtual_pair(is_real), air.KIND_SYSCALL))
 
 
+def _field_op(r: _Rec, cols, a, bb, op, modulus, n_limbs, witness_offset, is_real):
+    """FieldOpCols::eval_with_modulus (operations/field/field_op.rs:296-331): Add / Mul check a op b = result; Sub / Div swap the roles —
+    result op' b = a with op' = Add / Mul — so `a` is what the identity's right-hand side holds. Operands may be shorter than a field
+    element (the constant polynomials [0] and [1])."""
+    b = r.b
+    result = cols[0:n_limbs]
+    lhs, rhs = (a, result) if op in ("add", "mul") else (result, a)
+    p_op = _poly_add(lhs, bb) if op in ("add", "sub") else _poly_mul(lhs, bb)
+    van = _poly_sub(b, _poly_sub(b, p_op, rhs), _poly_mul(cols[n_limbs:2 * n_limbs], modulus))
+    _field_gadget(r, van, cols, n_limbs, witness_offset, is_real)
+
+
+def _field_lt(r: _Rec, cols, lhs, rhs, n_limbs, is_real):
+    """FieldLtCols::eval (operations/field/range.rs:63-139): cols = byte_flags(N), lhs_comparison_byte, rhs_comparison_byte; the flag marks
+    the most significant byte where lhs < rhs, every byte above it is equal."""
+    b = r.b
+    flags, lhs_byte, rhs_byte = cols[0:n_limbs], cols[n_limbs], cols[n_limbs + 1]
+    total = b.const(0)
+    for f in flags:
+        b.when(is_real).assert_bool(f)
+        total = total + f
+    b.when(is_real).assert_one(total)
+    visited, lhs_cmp, rhs_cmp = b.const(0), b.const(0), b.const(0)
+    for i in reversed(range(n_limbs)):
+        visited = visited + flags[i]
+        lhs_cmp = lhs_cmp + lhs[i] * flags[i]
+        rhs_cmp = rhs_cmp + flags[i] * rhs[i]
+        b.when(is_real).when_not(visited).assert_eq(lhs[i], rhs[i])
+    b.when(is_real).assert_eq(lhs_byte, lhs_cmp)
+    b.when(is_real).assert_eq(rhs_byte, rhs_cmp)
+    r.send_byte(B_LTU, 1, lhs_byte, rhs_byte, is_real)
+
+
+def _ed_decompress(r: _Rec):
+    """EdDecompressCols::eval (syscall/precompiles/edwards/ed_decompress.rs:104-190): x = sqrt((y^2 - 1) / (d y^2 + 1)), the even root, negated
+    when the sign bit asks for the odd one; y is read at ptr + 32, x is written at ptr, both at clk."""
+    l, b = r.local, r.b
+    N, G = 32, 188
+    IS_REAL, SHARD, CLK, PTR, SIGN, X_ACCESS, Y_ACCESS, Y_RANGE, YY, U, DYY, V, U_DIV_V, X_MULT, X_RANGE, X_LSB, NEG_X = (
+        0, 1, 2, 3, 4, 5, 109, 181, 215, 403, 591, 779, 967, 1155, 1343, 1377, 1378)
+    is_real, sign = l[IS_REAL], l[SIGN]
+    x_access = [l[X_ACCESS + 13 * i:X_ACCESS + 13 * i + 13] for i in range(8)]
+    y_access = [l[Y_ACCESS + 9 * i:Y_ACCESS + 9 * i + 9] for i in range(8)]
+    modulus = _limbs_of_const(b, ED25519_P, N)
+    d_const = _limbs_of_const(b, ED25519_D, N)
+    one, zero = [b.const(1)], [b.const(0)]
+    grp = lambda base: l[base:base + G]      # noqa: E731
+    b.assert_bool(sign)
+    y = [c for a in y_access for c in a[0:4]]
+    _field_lt(r, l[Y_RANGE:Y_RANGE + 34], y, modulus, N, is_real)
+    _field_op(r, grp(YY), y, y, "mul", modulus, N, 1 << 14, is_real)
+    _field_op(r, grp(U), l[YY:YY + N], one, "sub", modulus, N, 1 << 14, is_real)
+    _field_op(r, grp(DYY), d_const, l[YY:YY + N], "mul", modulus, N, 1 << 14, is_real)
+    _field_op(r, grp(V), one, l[DYY:DYY + N], "add", modulus, N, 1 << 14, is_real)
+    _field_op(r, grp(U_DIV_V), l[U:U + N], l[V:V + N], "div", modulus, N, 1 << 14, is_real)
+    # FieldSqrtCols::eval (operations/field/field_sqrt.rs:88-131): the multiplication's result columns hold the root; its product is the input
+    sqrt = l[X_MULT:X_MULT + N]
+    mult = list(l[U_DIV_V:U_DIV_V + N]) + list(l[X_MULT + N:X_MULT + G])          # `multiplication.result = *a`
+    _field_op(r, mult, sqrt, sqrt, "mul", modulus, N, 1 << 14, is_real)
+    _field_lt(r, l[X_RANGE:X_RANGE + 34], sqrt, modulus, N, is_real)
+    r.slice_range_check_u8(sqrt, is_real)
+    b.assert_bool(l[X_LSB])
+    b.when(is_real).assert_eq(l[X_LSB], 0)
+    r.send_byte(B_AND, l[X_LSB], sqrt[0], 1, is_real)
+    _field_op(r, grp(NEG_X), zero, sqrt, "sub", modulus, N, 1 << 14, is_real)
+    for i in range(8):      # eval_memory_access_slice
+        r.eval_memory_access(l[SHARD], l[CLK], l[PTR] + 4 * i, x_access[i][0:4], x_access[i][4:13], is_real)
+    for i in range(8):
+        r.eval_memory_access(l[SHARD], l[CLK], l[PTR] + 32 + 4 * i, y_access[i][0:4], y_access[i], is_real)
+    x_limbs = [c for a in x_access for c in a[4:8]]
+    for i in range(N):
+        b.when(is_real).when(sign).assert_eq(l[NEG_X + i], x_limbs[i])
+    for i in range(N):
+        b.when(is_real).when_not(sign).assert_eq(sqrt[i], x_limbs[i])
+    r.receives.append(air.Lookup([air.to_virtual_pair(v) for v in [l[SHARD], l[CLK], b.const(E.SYS_ED_DECOMPRESS & 0xffff), l[PTR], sign]],
+                                 air.to_virtual_pair(is_real), air.KIND_SYSCALL))
+
+
+def record_ed_decompress_constraints() -> _Rec:
+    r = _Rec(E.ED_DECOMPRESS_WIDTH)
+    _ed_decompress(r)
+    return r
+
+
+def record_ed_decompress_chip(log_height: int) -> RecordedChip:
+    """The EdDecompress precompile (crates/core/machine/src/syscall/precompiles/edwards/ed_decompress.rs): one Ed25519 point decompression per
+    row, 1566 columns; local_only (:262-264)."""
+    return _finish(record_ed_decompress_constraints(), "EdDecompress", log_height, E.ED_DECOMPRESS_WIDTH, True)
+
+
 def record_ed_add_constraints() -> _Rec:
     r = _Rec(E.ED_ADD_WIDTH)
     _ed_add(r)

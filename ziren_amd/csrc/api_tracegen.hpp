@@ -683,6 +683,48 @@ int zkm_tracegen_ed_add(zkm_ctx* ctx, const zkm_ed_add_event* events, size_t n_e
   API_END
 }
 
+int zkm_tracegen_ed_decompress(zkm_ctx* ctx, const zkm_ed_decompress_event* events, size_t n_events, int fixed_log2_rows, zkm_byte_lookups* blu, zkm_matrix** out) {
+  API_BEGIN
+  static_assert(sizeof(zkm_ed_decompress_event) == 4 * tracegen::ED_DECOMPRESS_EVENT_WORDS, "flattened EdDecompressEvent is 92 words");
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIP_CHECK(hipSetDevice(ctx->device));
+  if (n_events && !events) throw std::runtime_error("zkm_tracegen_ed_decompress: null events");
+  const size_t height = padded_trace_rows(n_events, fixed_log2_rows, "zkm_tracegen_ed_decompress");
+  ctx->begin_timing();
+  zkm_matrix* m = new zkm_matrix();
+  m->h = height; m->w = tracegen::ED_DECOMPRESS_WIDTH;
+  uint32_t* d_events = nullptr;
+  int* d_bad = nullptr;
+  try {
+    m->d = ctx->alloc_n<uint32_t>(height * m->w);
+    const size_t ev_bytes = n_events * sizeof(zkm_ed_decompress_event);
+    d_events = (uint32_t*)ctx->alloc(std::max<size_t>(ev_bytes, 4));
+    d_bad = (int*)ctx->alloc(4);
+    HIP_CHECK(hipMemsetAsync(d_bad, 0, 4, ctx->stream));
+    if (n_events) HIP_CHECK(hipMemcpyAsync(d_events, events, ev_bytes, hipMemcpyHostToDevice, ctx->stream));
+    uint32_t* counts = blu ? blu->counts : nullptr;
+    KLAUNCH(ctx, "tracegen_ed_decompress", (double)ev_bytes + 4.0 * height * m->w, tracegen::ed_decompress_rows, dim3(div_up(height, (size_t)64)), dim3(64),
+            counts ? 2 * tracegen::HASH_SLOTS * sizeof(uint32_t) : 0, (const uint32_t*)d_events, n_events, height, m->d, counts, d_bad);
+    int bad = 0;
+    HIP_CHECK(hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, ctx->stream));
+    ctx->mark("trace generation");
+    ctx->end_timing(false);
+    static const char* const why[] = {"", "y is not below the field modulus, or the sign is not a bit", "(y^2 - 1) / (d y^2 + 1) is not a square: no such point",
+                                      "the words an event writes are not the x its y and sign give"};
+    if (bad) throw std::runtime_error(std::string("zkm_tracegen_ed_decompress: ") + why[16 - bad >= 1 && 16 - bad <= 3 ? 16 - bad : 0]);
+  } catch (...) {
+    if (d_events) ctx->release(d_events);
+    if (d_bad) ctx->release(d_bad);
+    if (m->d) ctx->release(m->d);
+    delete m;
+    throw;
+  }
+  ctx->release(d_events);
+  ctx->release(d_bad);
+  *out = m;
+  API_END
+}
+
 int zkm_tracegen_exp_reverse_bits(zkm_ctx* ctx, const uint32_t* bases, const uint32_t* bits, const uint32_t* offsets, size_t n_events,
                                   int fixed_log2_rows, zkm_matrix** out) {
   API_BEGIN

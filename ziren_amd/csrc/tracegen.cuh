@@ -1838,6 +1838,150 @@ __global__ __launch_bounds__(64) void ed_add_rows(const uint32_t* __restrict__ e
   }
 }
 
+// ---- EdDecompress precompile (syscall/precompiles/edwards/ed_decompress.rs:39-57, :85-101): x = sqrt((y^2 - 1) / (d y^2 + 1)) from y and a sign bit,
+// one row per call, 1566 columns: memory columns of x (written) and y (read), a FieldLtCols of y against p, five FieldOpCols (yy, u, dyy, v,
+// u_div_v), a FieldSqrtCols (a FieldOpCols whose result columns hold the even root, the root's FieldLtCols, its low bit), and neg_x.
+// The root is a^((p + 3) / 8), times sqrt(-1) when that squares to -a (curves/src/edwards/ed25519.rs:75-113).
+constexpr int ED_DECOMPRESS_WIDTH = 1566, ED_DECOMPRESS_EVENT_WORDS = 92;
+__constant__ uint32_t d_ed25519_sqrt_exp[8] = {0xfffffffeu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0x0fffffffu};
+__constant__ uint32_t d_ed25519_sqrt_m1[8] = {0x4a0ea0b0u, 0xc4ee1b27u, 0xad2fe478u, 0x2f431806u, 0x3dfbd7a7u, 0x2b4d0099u, 0x4fc1df0bu, 0x2b832480u};
+enum { FOP_ADD = 0, FOP_SUB = 1, FOP_MUL = 2, FOP_DIV = 3 };
+// FieldOpCols::populate_with_modulus (operations/field/field_op.rs:154-224) for a, b below p: the columns at `base`, the result in `res`
+__device__ void ed_field_op(const EdRow& R, int base, const uint32_t* a, const uint32_t* b, int op, uint32_t* res, int32_t* van) {
+  const bigfield::Modulus<8>& m = d_ed25519;
+  uint32_t t[16], t2[16], q[9] = {0};
+  for (int i = 0; i < 2 * ED_LIMBS - 1; i++) van[i] = 0;
+  if (op == FOP_ADD || op == FOP_SUB) {
+    if (op == FOP_ADD) {
+      for (int i = 0; i < 8; i++) res[i] = a[i];
+      const uint32_t carry_out = bigfield::add<8>(res, b);        // below 2^256: no carry out for a, b < p < 2^255
+      (void)carry_out;
+      if (bigfield::cmp<8>(res, m.p) >= 0) { bigfield::sub<8>(res, m.p); q[0] = 1; }
+      ed_poly_add(van, a, 1); ed_poly_add(van, b, 1); ed_poly_add(van, res, -1);
+    } else {                                                       // result + b = a + carry p
+      for (int i = 0; i < 8; i++) res[i] = a[i];
+      if (bigfield::sub<8>(res, b)) { bigfield::add<8>(res, m.p); q[0] = 1; }
+      ed_poly_add(van, res, 1); ed_poly_add(van, b, 1); ed_poly_add(van, a, -1);
+    }
+  } else if (op == FOP_MUL) {
+    bigfield::mul<8, 8>(a, b, t);
+    bigfield::divmod<8>(t, m, q, res);
+    ed_poly_mac(van, a, b); ed_poly_add(van, res, -1);
+  } else {                                                         // result * b = a + carry p
+    bool zero = true;
+    for (int i = 0; i < 8; i++) zero = zero && a[i] == 0;
+    if (zero) { for (int i = 0; i < 8; i++) res[i] = 0; } else { uint32_t inv[8]; bigfield::inverse<8>(b, m, inv); bigfield::mulmod<8>(a, inv, m, res); }
+    bigfield::mul<8, 8>(res, b, t);
+    for (int i = 0; i < 16; i++) t2[i] = i < 8 ? a[i] : 0u;
+    bigfield::sub<16>(t, t2);
+    uint32_t rem[8];
+    bigfield::divmod<8>(t, m, q, rem);
+    ed_poly_mac(van, res, b); ed_poly_add(van, a, -1);
+  }
+  R.gadget(base, van, res, q);
+}
+// FieldLtCols::populate (operations/field/range.rs:27-60) of a value below p against p
+__device__ void ed_field_lt(const EdRow& R, int base, const uint32_t* lhs) {
+  int at = -1;
+  for (int i = ED_LIMBS - 1; i >= 0 && at < 0; i--)
+    if (bigfield::byte_of(lhs, i) < bigfield::byte_of(d_ed25519.p, i)) at = i;
+  for (int i = 0; i < ED_LIMBS; i++) R.put(base + i, i == at ? 1u : 0u);
+  const uint32_t a = at >= 0 ? bigfield::byte_of(lhs, at) : 0u, b = at >= 0 ? bigfield::byte_of(d_ed25519.p, at) : 0u;
+  R.put(base + ED_LIMBS, a); R.put(base + ED_LIMBS + 1, b);
+  if (R.count && at >= 0) lookup(R.sink, B_LTU, a, b);
+}
+__global__ __launch_bounds__(64) void ed_decompress_rows(const uint32_t* __restrict__ events, size_t n_events, size_t height, uint32_t* __restrict__ out,
+                                                         uint32_t* counts, int* __restrict__ bad) {
+  enum { IS_REAL = 0, SHARD = 1, CLK = 2, PTR = 3, SIGN = 4, X_ACCESS = 5, Y_ACCESS = 109, Y_RANGE = 181, YY = 215, U = 403, DYY = 591, V = 779, U_DIV_V = 967,
+         X_MULT = 1155, X_RANGE = 1343, X_LSB = 1377, NEG_X = 1378 };
+  enum { E_X_RECORDS = 4, E_Y_RECORDS = 52 };
+  extern __shared__ uint32_t hash_lds[];
+  uint32_t* hkeys = hash_lds;
+  uint32_t* hvals = hash_lds + HASH_SLOTS;
+  const bool count = counts != nullptr;
+  if (count) {
+    for (int i = threadIdx.x; i < HASH_SLOTS; i += blockDim.x) { hkeys[i] = HASH_EMPTY; hvals[i] = 0; }
+    __syncthreads();
+  }
+  const size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (row < height) {
+    const bool real = row < n_events;
+    const uint32_t* e = events + row * ED_DECOMPRESS_EVENT_WORDS;
+    const LookupSink sink{hkeys, hvals, HASH_SLOTS - 1, counts};
+    const EdRow R{out, height, row, sink, count && real};
+    const bigfield::Modulus<8>& m = d_ed25519;
+    int why = 0;
+    uint32_t y[8];
+    for (int k = 0; k < 8; k++) y[k] = real ? e[E_Y_RECORDS + 5 * k] : 0u;
+    if (bigfield::cmp<8>(y, m.p) >= 0) { why = 1; for (int k = 0; k < 8; k++) y[k] = 0; }
+    if (real && e[3] > 1) why = 1;
+    int32_t van[2 * ED_LIMBS - 1];
+    uint32_t yy[8], u[8], dyy[8], v[8], udv[8], x[8], sq[8], neg[8];
+    const uint32_t one[8] = {1}, zero[8] = {0};
+    ed_field_lt(R, Y_RANGE, y);
+    ed_field_op(R, YY, y, y, FOP_MUL, yy, van);
+    ed_field_op(R, U, yy, one, FOP_SUB, u, van);
+    ed_field_op(R, DYY, d_ed25519_d, yy, FOP_MUL, dyy, van);
+    ed_field_op(R, V, one, dyy, FOP_ADD, v, van);
+    ed_field_op(R, U_DIV_V, u, v, FOP_DIV, udv, van);
+    // the even square root of u / v
+    {
+      uint32_t acc[8] = {1};
+      bool started = false;
+      for (int bit = 255; bit >= 0; bit--) {
+        if (started) bigfield::mulmod<8>(acc, acc, m, acc);
+        if ((d_ed25519_sqrt_exp[bit / 32] >> (bit % 32)) & 1) {
+          if (started) bigfield::mulmod<8>(acc, udv, m, acc);
+          else { for (int i = 0; i < 8; i++) acc[i] = udv[i]; started = true; }
+        }
+      }
+      for (int i = 0; i < 8; i++) x[i] = acc[i];
+      bigfield::mulmod<8>(x, x, m, sq);
+      if (bigfield::cmp<8>(sq, udv) != 0) {
+        uint32_t neg_a[8];
+        for (int i = 0; i < 8; i++) neg_a[i] = m.p[i];
+        bigfield::sub<8>(neg_a, udv);
+        if (bigfield::cmp<8>(neg_a, m.p) >= 0) bigfield::sub<8>(neg_a, m.p);
+        if (bigfield::cmp<8>(sq, neg_a) == 0) bigfield::mulmod<8>(x, d_ed25519_sqrt_m1, m, x); else why = 2;
+      }
+      if (x[0] & 1) { uint32_t tmp[8]; for (int i = 0; i < 8; i++) tmp[i] = m.p[i]; bigfield::sub<8>(tmp, x); for (int i = 0; i < 8; i++) x[i] = tmp[i]; }
+    }
+    // FieldSqrtCols: x * x = u_div_v in the multiplication's carry / witness columns, the root itself in its result columns
+    ed_field_op(R, X_MULT, x, x, FOP_MUL, sq, van);
+    for (int i = 0; i < ED_LIMBS; i++) R.put(X_MULT + i, bigfield::byte_of(x, i));
+    ed_field_lt(R, X_RANGE, x);
+    R.put(X_LSB, x[0] & 1);
+    if (R.count) {
+      lookup(sink, B_AND, x[0], 1);
+      for (int i = 0; i < ED_LIMBS; i += 2) lookup(sink, B_U8RANGE, bigfield::byte_of(x, i), bigfield::byte_of(x, i + 1));
+    }
+    ed_field_op(R, NEG_X, zero, x, FOP_SUB, neg, van);
+    R.put(IS_REAL, real ? 1u : 0u);
+    R.put(SHARD, real ? e[0] : 0u); R.put(CLK, real ? e[1] : 0u); R.put(PTR, real ? e[2] : 0u); R.put(SIGN, real ? e[3] : 0u);
+    for (int k = 0; k < 8; k++) {
+      uint32_t mw[13], mr[9];
+      if (real) {
+        memory_write_cols(e + E_X_RECORDS + 6 * k, mw);
+        const uint32_t* rec = e + E_Y_RECORDS + 5 * k;
+        memory_access_cols(rec[0], rec[1], rec[2], rec[3], rec[4], mr);
+        if (count) { access_lookups(mr, sink); lookup(sink, B_U16RANGE, mw[11] >> 8, mw[11]); lookup(sink, B_U8RANGE, 0, mw[12]); }
+        if (e[E_X_RECORDS + 6 * k] != (e[3] ? neg[k] : x[k])) why = why ? why : 3;
+      } else {
+        for (int c = 0; c < 13; c++) mw[c] = 0;
+        for (int c = 0; c < 9; c++) mr[c] = 0;
+      }
+      for (int c = 0; c < 13; c++) R.put(X_ACCESS + 13 * k + c, mw[c]);
+      for (int c = 0; c < 9; c++) R.put(Y_ACCESS + 9 * k + c, mr[c]);
+    }
+    if (real && why) atomicMax(bad, 16 - why);
+  }
+  if (count) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < HASH_SLOTS; i += blockDim.x)
+      if (hkeys[i] != HASH_EMPTY) atomicAdd(counts + hkeys[i], hvals[i]);
+  }
+}
+
 // recursion ExpReverseBitsLen chip (crates/recursion/core/src/chips/exp_reverse_bits.rs:175-226): one thread walks one event's bits —
 // accum_i = accum_{i-1}^2 * (bit_i ? x : 1) — and writes its rows (x, bit, prev_accum^2, that times the multiplier, accum, accum^2,
 // multiplier); Montgomery words in and out. offsets[e] .. offsets[e + 1] are event e's rows; the rest of the matrix is zeroed first.

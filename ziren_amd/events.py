@@ -655,6 +655,38 @@ def ed25519_add(p, q):
     return x3, y3
 
 
+# EdDecompress (syscall/precompiles/edwards/ed_decompress.rs): EdDecompressEvent (events/precompiles/edwards.rs:13-32) flattened — y_bytes and
+# decompressed_x_bytes are the values of the y read records and of the x write records
+SYS_ED_DECOMPRESS = 0x00010008          # syscalls/code.rs:54: no extra cycle
+ED_DECOMPRESS_EVENT = np.dtype([("shard", "<u4"), ("clk", "<u4"), ("ptr", "<u4"), ("sign", "<u4"), ("x_memory_records", MEMORY_WRITE_RECORD, (8,)),
+                                ("y_memory_records", MEMORY_READ_RECORD, (8,))])
+assert ED_DECOMPRESS_EVENT.itemsize == 4 * 92
+ED_DECOMPRESS_WIDTH = 1566              # EdDecompressCols (ed_decompress.rs:39-57)
+ED25519_SQRT_M1 = 19681161376707505956807079304988542015446066515923890162744021073123829784752
+
+
+def ed25519_sqrt(a):
+    """ed25519_sqrt (curves/src/edwards/ed25519.rs:75-113): the even square root of a, None when there is none."""
+    P = ED25519_P
+    beta = pow(a, (P + 3) // 8, P)
+    sq = beta * beta % P
+    if sq == (P - a) % P:
+        beta = beta * ED25519_SQRT_M1 % P
+    elif sq != a:
+        return None
+    return (P - beta) % P if beta & 1 else beta
+
+
+def ed25519_decompress(y, sign):
+    """decompress (curves/src/edwards/ed25519.rs:115-141): x from y and the sign bit."""
+    P, D = ED25519_P, ED25519_D
+    yy = y * y % P
+    x = ed25519_sqrt((yy - 1) * pow(D * yy + 1, P - 2, P) % P)
+    if x is None:
+        return None
+    return (P - x) % P if sign else x
+
+
 SYSCALL_INSTRS_WIDTH = 77
 # SyscallCode (crates/core/executor/src/syscalls/code.rs): byte 0-1 id, byte 2 "has its own table", byte 3 extra cycles
 SYS_HALT, SYS_WRITE, SYS_ENTER_UNCONSTRAINED, SYS_EXIT_UNCONSTRAINED, SYS_COMMIT, SYS_COMMIT_DEFERRED_PROOFS, SYS_HINT_LEN = 0, 2, 3, 4, 0x10, 0x1a, 0xf0

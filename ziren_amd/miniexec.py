@@ -256,9 +256,11 @@ def _execute(n_cycles: int, seed: int = 1, shard: int = 1, pc_base: int = 0x1000
             base = (15112221349535400772501151409588531511454012693041857206046113283949847762202,
                     46316835694926478169428394003475163141307993866256225615783033603165251855960)
             dbl = E.ed25519_add(base, base)
-            for ptr, pt in ((p_ptr, base), (q_ptr, dbl)):
-                for i in range(16):
-                    queued += [(E.ADD, 30, (pt[i // 8] >> (32 * (i % 8))) & 0xffffffff, 0, 1, 1), (E.SW, 30, 0, ptr + 4 * i, 0, 1)]
+            for ptr, pt in ((p_ptr, base), (q_ptr, dbl)):      # only y is stored; x comes from ED_DECOMPRESS(ptr, sign) as a verifier gets A and R
+                for i in range(8, 16):
+                    queued += [(E.ADD, 30, (pt[1] >> (32 * (i % 8))) & 0xffffffff, 0, 1, 1), (E.SW, 30, 0, ptr + 4 * i, 0, 1)]
+                queued += [(E.ADD, E.REG_V0, E.SYS_ED_DECOMPRESS, 0, 1, 1), (E.ADD, E.REG_A0, ptr, 0, 1, 1), (E.ADD, E.REG_A1, pt[0] & 1, 0, 1, 1),
+                           (E.SYSCALL, E.REG_V0, E.REG_A0, E.REG_A1, 0, 0)]
             for _ in range(ed_calls):
                 queued += [(E.ADD, E.REG_V0, E.SYS_ED_ADD, 0, 1, 1), (E.ADD, E.REG_A0, p_ptr, 0, 1, 1), (E.ADD, E.REG_A1, q_ptr, 0, 1, 1),
                            (E.SYSCALL, E.REG_V0, E.REG_A0, E.REG_A1, 0, 0)]
@@ -439,7 +441,7 @@ def _execute(n_cycles: int, seed: int = 1, shard: int = 1, pc_base: int = 0x1000
             b_rec = read(op_b, clk, POS_B)
             b = b_rec[1][0]
             sid = code & 0xffff
-            assert code in (E.SYS_HALT, E.SYS_COMMIT, E.SYS_POSEIDON2_PERMUTE, E.SYS_KECCAK_SPONGE, E.SYS_SHA_EXTEND, E.SYS_SHA_COMPRESS, E.SYS_ED_ADD), code
+            assert code in (E.SYS_HALT, E.SYS_COMMIT, E.SYS_POSEIDON2_PERMUTE, E.SYS_KECCAK_SPONGE, E.SYS_SHA_EXTEND, E.SYS_SHA_COMPRESS, E.SYS_ED_ADD, E.SYS_ED_DECOMPRESS), code
             touched = {}                               # address -> [initial (shard, timestamp, value), final]: SyscallContext's local map
 
             def mem(addr, ts, value=None):
@@ -546,6 +548,16 @@ def _execute(n_cycles: int, seed: int = 1, shard: int = 1, pc_base: int = 0x1000
                 local = [(addr, v[0], v[1]) for addr, v in sorted(touched.items())]
                 precompile.append(("ed_add", (pc, next_pc, shard, clk, (0, 0, 0, 0, 0, 0), 0, [0, 0, 0], sid, b, c), [(shard, clk, b, c, pwr, qr)], local))
                 clk_extra += 1
+            if code == E.SYS_ED_DECOMPRESS:
+                # EdwardsDecompressSyscall::execute (syscalls/precompiles/edwards/decompress.rs:33-83): y is read at ptr + 32, the x its sign
+                # bit ($a1) selects is written at ptr, both at clk; no extra cycle
+                assert b % 4 == 0 and c <= 1
+                yr = [mem(b + 32 + 4 * i, clk) for i in range(8)]
+                x = E.ed25519_decompress(sum(rec_[0] << (32 * i) for i, rec_ in enumerate(yr)), c)
+                assert x is not None
+                xw = [mem(b + 4 * i, clk, (x >> (32 * i)) & 0xffffffff) for i in range(8)]
+                local = [(addr, v[0], v[1]) for addr, v in sorted(touched.items())]
+                precompile.append(("ed_decompress", (pc, next_pc, shard, clk, (0, 0, 0, 0, 0, 0), 0, [0, 0, 0], sid, b, c), [(shard, clk, b, c, xw, yr)], local))
             a = code                                       # none of them returns a value: V0 keeps the code
             a_rec = write(op_a, a, clk, POS_A)
             hi = code
@@ -657,7 +669,8 @@ def _execute(n_cycles: int, seed: int = 1, shard: int = 1, pc_base: int = 0x1000
     last_pv = shards[-1].pv
     n_shard = shards[-1].pv["shard"]
     for kind, dt in (("poseidon2", E.POSEIDON2_PERMUTE_EVENT), ("keccak", E.KECCAK_SPONGE_BLOCK), ("sha_extend", E.SHA_EXTEND_EVENT),
-                     ("sha_compress", E.SHA_COMPRESS_EVENT), ("ed_add", E.ED_ADD_EVENT)):
+                     ("sha_compress", E.SHA_COMPRESS_EVENT), ("ed_add", E.ED_ADD_EVENT),
+                     ("ed_decompress", E.ED_DECOMPRESS_EVENT)):
         mine = [e for e in precompile if e[0] == kind]
         if not mine:
             continue
@@ -670,6 +683,7 @@ def _execute(n_cycles: int, seed: int = 1, shard: int = 1, pc_base: int = 0x1000
         o.sha_extend = arr([ev for e in mine for ev in e[2]] if kind == "sha_extend" else [], E.SHA_EXTEND_EVENT)
         o.sha_compress = arr([ev for e in mine for ev in e[2]] if kind == "sha_compress" else [], E.SHA_COMPRESS_EVENT)
         o.ed_add = arr([ev for e in mine for ev in e[2]] if kind == "ed_add" else [], E.ED_ADD_EVENT)
+        o.ed_decompress = arr([ev for e in mine for ev in e[2]] if kind == "ed_decompress" else [], E.ED_DECOMPRESS_EVENT)
         o.memory_local = arr([ev for e in mine for ev in e[3]], MEMORY_LOCAL_EVENT)
         pv = dict(last_pv, start_pc=last_pv["next_pc"], shard=n_shard)
         shards.append(Shard("precompile", o, pv))

@@ -259,6 +259,15 @@ class Context:
                                                  C.c_int(fixed_log2_rows), blu.h if blu is not None else None, C.byref(h)))
         return self._born(h)
 
+    def tracegen_ed_decompress(self, events: np.ndarray, fixed_log2_rows: int = -1, blu: "ByteLookups" = None) -> DeviceMatrix:
+        """`generate_trace` of the EdDecompress precompile on the device (zkm_tracegen_ed_decompress); dtype events.ED_DECOMPRESS_EVENT."""
+        from . import events as _ev
+        ev = np.ascontiguousarray(events, dtype=_ev.ED_DECOMPRESS_EVENT)
+        h = C.c_void_p()
+        lib.check(lib.load().zkm_tracegen_ed_decompress(self.h, C.c_void_p(ev.ctypes.data if len(ev) else None), C.c_size_t(len(ev)),
+                                                        C.c_int(fixed_log2_rows), blu.h if blu is not None else None, C.byref(h)))
+        return self._born(h)
+
     def tracegen_misc_instrs(self, events: np.ndarray, fixed_log2_rows: int = -1, blu: "ByteLookups" = None) -> DeviceMatrix:
         """`generate_trace` of the MiscInstrs chip on the device (zkm_tracegen_misc_instrs); dtype events.MISC_EVENT."""
         from . import events as _ev
