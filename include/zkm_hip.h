@@ -478,6 +478,20 @@ typedef struct zkm_ed_decompress_event {
 #define ZKM_ED_DECOMPRESS_WIDTH 1566
 int zkm_tracegen_ed_decompress(zkm_ctx* ctx, const zkm_ed_decompress_event* events, size_t n_events, int fixed_log2_rows,
                                zkm_byte_lookups* blu, zkm_matrix** out);
+
+/* The short-Weierstrass precompiles (crates/core/machine/src/syscall/precompiles/weierstrass/weierstrass_add.rs, weierstrass_double.rs): the
+ * eight chips Secp256k1 / Secp256r1 / Bn254 / Bls12381 x AddAssign / DoubleAssign; replace their generate_trace (weierstrass_add.rs:182-247,
+ * weierstrass_double.rs:202-266), byte lookups into `blu`. `events`: the curve's EllipticCurveAddEvent / EllipticCurveDoubleEvent
+ * (crates/core/executor/src/events/precompiles/ec.rs:24-72) flattened, W = 16 words per point (Bls12381: 24):
+ *   add:    shard, clk, p_ptr, q_ptr, W zkm_memory_write_record of p, W zkm_memory_read_record of q      (4 + 11 W words)
+ *   double: shard, clk, p_ptr, W zkm_memory_write_record of p                                              (3 + 6 W words)
+ * p (and q) are the previous values of the p records (the values of the q records). Fails when a coordinate is not below the base-field
+ * modulus or the words written to p are not the result. */
+enum { ZKM_CURVE_SECP256K1 = 0, ZKM_CURVE_SECP256R1 = 1, ZKM_CURVE_BN254 = 2, ZKM_CURVE_BLS12381 = 3 };
+int zkm_tracegen_weierstrass_add(zkm_ctx* ctx, int curve, const void* events, size_t n_events, int fixed_log2_rows, zkm_byte_lookups* blu,
+                                 zkm_matrix** out);
+int zkm_tracegen_weierstrass_double(zkm_ctx* ctx, int curve, const void* events, size_t n_events, int fixed_log2_rows, zkm_byte_lookups* blu,
+                                    zkm_matrix** out);
 /* The MiscInstrs chip (crates/core/machine/src/misc/others/: SEXT EXT INS MADDU MSUBU MADD MSUB TEQ): replaces generate_trace
  * (trace.rs:42-84), which also records the byte lookups (counted into `blu` if given). Events are the #[repr(C)] MiscEvents of
  * crates/core/executor/src/events/instr.rs:239-261 (60 bytes). 72 columns, zero padding rows. */

@@ -751,4 +751,21 @@ int orc_tracegen_ed_decompress(const void* events, size_t n_events, int fixed_lo
   ORC_CATCH
 }
 
+// Short-Weierstrass add / double chips of any curve: flattened events (4 + 11 W or 3 + 6 W words, W = n_limbs / 2), one row each
+int orc_tracegen_weierstrass(const uint32_t* events, size_t n_events, int is_double, int n_limbs, const uint8_t* modulus, const uint8_t* a,
+                             uint32_t witness_offset, int fixed_log2_rows, uint32_t* out, size_t out_cap, size_t* rows, uint32_t* byte_counts) {
+  ORC_TRY
+  size_t h;
+  std::vector<uint64_t> cnt(byte_counts ? tracegen::BYTE_ROWS * tracegen::NUM_BYTE_OPS : 0, 0);
+  std::vector<F> t = tracegen::generate_weierstrass(events, n_events, is_double != 0, n_limbs, modulus, a, witness_offset, fixed_log2_rows, &h,
+                                                    byte_counts && out ? cnt.data() : nullptr);
+  *rows = h;
+  if (out) {
+    if (t.size() > out_cap) throw std::runtime_error("trace buffer too small");
+    for (size_t i = 0; i < t.size(); i++) out[i] = to_monty(t[i]);
+    for (size_t i = 0; i < cnt.size(); i++) byte_counts[i] += (uint32_t)cnt[i];
+  }
+  ORC_CATCH
+}
+
 }  // extern "C"

@@ -1977,4 +1977,87 @@ static inline std::vector<F> generate_ed_decompress(const EdDecompressEvent* eve
   return t;
 }
 
+// ---- Short-Weierstrass precompiles (syscall/precompiles/weierstrass/weierstrass_add.rs:43-62, :75-129; weierstrass_double.rs:43-62, :75-150) for
+// any of the four curves: the curve's base field comes in as its modulus bytes, limb count and witness offset, a doubling also needs `a`.
+// Events are the flattened EllipticCurveAddEvent (shard, clk, p_ptr, q_ptr, W write records of p, W read records of q) or
+// EllipticCurveDoubleEvent (shard, clk, p_ptr, W write records of p), W = n_limbs / 2 words per point. Padding rows of an addition: the
+// operations of the zero inputs (0 / 0 = 0 is the one division by zero FieldOpCols allows); of a doubling: see below.
+static inline std::vector<F> generate_weierstrass(const uint32_t* events, size_t n_events, bool dbl, int n_limbs, const uint8_t* modulus_bytes,
+                                                  const uint8_t* a_bytes, int64_t offset, int fixed_log2_rows, size_t* height, uint64_t* byte_counts) {
+  using namespace bigfield;
+  const int W = n_limbs / 2, G = 6 * n_limbs - 4;
+  const int P_ACCESS = dbl ? 4 : 5, Q_ACCESS = P_ACCESS + 13 * W, GADGETS = P_ACCESS + 13 * W + (dbl ? 0 : 9 * W);
+  const size_t width = GADGETS + (dbl ? 11 : 9) * G, ev_words = dbl ? 3 + 6 * W : 4 + 11 * W;
+  const size_t h = padded_rows(n_events, fixed_log2_rows);
+  std::vector<F> t(h * width, 0);
+  std::vector<ByteLookup> lk;
+  const Big p = from_bytes(modulus_bytes, n_limbs), a = from_bytes(a_bytes, n_limbs);
+  auto fill = [&](F* r, const Big& px, const Big& py, const Big& qx, const Big& qy, std::vector<ByteLookup>* sink, Big& x3, Big& y3) {
+    const FieldGadgets g{p, n_limbs, offset, sink};
+    auto col = [&](int k) { return r + GADGETS + G * k; };
+    Big slope, slope_sq, sum_x;
+    if (!dbl) {          // gadget order: slope_denominator, slope_numerator, slope, slope_squared, p_x_plus_q_x, x3_ins, p_x_minus_x, y3_ins, slope_times_p_x_minus_x
+      const Big num = field_op_cols(g, col(1), qy, py, FOP_SUB), den = field_op_cols(g, col(0), qx, px, FOP_SUB);
+      slope = field_op_cols(g, col(2), num, den, FOP_DIV);
+      slope_sq = field_op_cols(g, col(3), slope, slope, FOP_MUL);
+      sum_x = field_op_cols(g, col(4), px, qx, FOP_ADD);
+      x3 = field_op_cols(g, col(5), slope_sq, sum_x, FOP_SUB);
+      const Big dx = field_op_cols(g, col(6), px, x3, FOP_SUB);
+      const Big prod = field_op_cols(g, col(8), slope, dx, FOP_MUL);
+      y3 = field_op_cols(g, col(7), prod, py, FOP_SUB);
+    } else {             // slope_denominator, slope_numerator, slope, p_x_squared, p_x_squared_times_3, slope_squared, p_x_plus_p_x, x3_ins, p_x_minus_x, y3_ins, slope_times_p_x_minus_x
+      const Big sq = field_op_cols(g, col(3), px, px, FOP_MUL);
+      const Big sq3 = field_op_cols(g, col(4), sq, from_u64(3), FOP_MUL);
+      const Big num = field_op_cols(g, col(1), a, sq3, FOP_ADD);
+      const Big den = field_op_cols(g, col(0), from_u64(2), py, FOP_MUL);
+      slope = field_op_cols(g, col(2), num, den, FOP_DIV);
+      slope_sq = field_op_cols(g, col(5), slope, slope, FOP_MUL);
+      sum_x = field_op_cols(g, col(6), px, px, FOP_ADD);
+      x3 = field_op_cols(g, col(7), slope_sq, sum_x, FOP_SUB);
+      const Big dx = field_op_cols(g, col(8), px, x3, FOP_SUB);
+      const Big prod = field_op_cols(g, col(10), slope, dx, FOP_MUL);
+      y3 = field_op_cols(g, col(9), prod, py, FOP_SUB);
+    }
+  };
+  std::vector<F> padding(width, 0);
+  Big x3, y3;
+  if (dbl) {      // the doubling's padding row is the point (0, 1) — a / 0 would not be allowed — with a dummy write record on the first word of y
+                  // (weierstrass_double.rs:225-239: value 1, shard 0, timestamp 1, previous value 1 at (0, 0))
+    fill(padding.data(), Big(), from_u64(1), Big(), Big(), nullptr, x3, y3);
+    const MemoryWriteRecord dummy{1, 0, 1, 1, 0, 0};
+    memory_write_cols(dummy, padding.data() + P_ACCESS + 13 * (W / 2), nullptr);
+  } else {
+    fill(padding.data(), Big(), Big(), Big(), Big(), nullptr, x3, y3);
+  }
+  std::vector<uint32_t> pw(W), qw(W);
+  for (size_t i = 0; i < h; i++) {
+    F* r = t.data() + i * width;
+    if (i >= n_events) { std::copy(padding.begin(), padding.end(), r); continue; }
+    const uint32_t* e = events + i * ev_words;
+    const MemoryWriteRecord* prec = (const MemoryWriteRecord*)(e + (dbl ? 3 : 4));
+    const MemoryReadRecord* qrec = (const MemoryReadRecord*)(e + 4 + 6 * W);
+    r[0] = 1; r[1] = fu32(e[0]); r[2] = fu32(e[1]); r[3] = fu32(e[2]);
+    if (!dbl) r[4] = fu32(e[3]);
+    for (int k = 0; k < W; k++) { pw[k] = prec[k].prev_value; qw[k] = dbl ? 0u : qrec[k].value; }
+    const Big px = from_words(pw.data(), W / 2), py = from_words(pw.data() + W / 2, W / 2);
+    if (cmp(px, p) >= 0 || cmp(py, p) >= 0) throw std::runtime_error("tracegen: Weierstrass point coordinate is not below the modulus");
+    fill(r, px, py, from_words(qw.data(), W / 2), from_words(qw.data() + W / 2, W / 2), &lk, x3, y3);
+    if (!dbl)
+      for (int k = 0; k < W; k++) {
+        const MemoryReadRecord& m = qrec[k];
+        memory_access_cols(m.value, m.shard, m.timestamp, m.prev_shard, m.prev_timestamp, r + Q_ACCESS + 9 * k, &lk);
+      }
+    for (int k = 0; k < W; k++) {
+      memory_write_cols(prec[k], r + P_ACCESS + 13 * k, &lk);
+      const Big& coord = k < W / 2 ? x3 : y3;
+      for (int c = 0; c < 4; c++)
+        if (r[P_ACCESS + 13 * k + 4 + c] != limb(coord, 4 * (k % (W / 2)) + c)) throw std::runtime_error("tracegen: Weierstrass event does not write the result point");
+    }
+  }
+  if (byte_counts)
+    for (const ByteLookup& b : lk) byte_counts[((size_t)b.b * 256 + b.c) * NUM_BYTE_OPS + b.op]++;
+  *height = h;
+  return t;
+}
+
 }  // namespace tracegen

@@ -81,6 +81,8 @@ class Oracle:
               "ed_add": O.tracegen_ed_add, "ed_decompress": O.tracegen_ed_decompress}
         if what in fn:
             return fn[what](a[0], a[1], c)
+        if what == "weierstrass":
+            return O.tracegen_weierstrass(a[0], a[1], a[2], a[3], c)
         if what == "syscall_table":
             return O.tracegen_syscall(a[0], a[1], a[2], c)
         if what == "memory_global":
@@ -117,6 +119,8 @@ class Device:
               "ed_add": ctx.tracegen_ed_add, "ed_decompress": ctx.tracegen_ed_decompress}
         if what in fn:
             return fn[what](a[0], a[1], blu)
+        if what == "weierstrass":
+            return ctx.tracegen_weierstrass(a[0], a[1], a[2], a[3], blu)
         if what == "syscall_table":
             return ctx.tracegen_syscall(a[0], a[1], a[2], blu)
         if what == "memory_global":
@@ -187,6 +191,11 @@ def build_shard(src, machine, k):
         if len(rec.ed_decompress):
             lh = log2_rows(len(rec.ed_decompress))
             add(chips.record_ed_decompress_chip(lh), src.trace("ed_decompress", rec.ed_decompress, lh))
+        if rec.weierstrass is not None:
+            kind, ev = rec.weierstrass
+            curve, double = kind.split("_")[0], kind.endswith("_double")
+            lh = log2_rows(len(ev))
+            add(chips.record_weierstrass_chip(curve, double, lh), src.trace("weierstrass", curve, double, ev, lh))
     else:
         for finalize, ev, prev in ((False, rec.memory_init, sh.pv["previous_init_addr"]), (True, rec.memory_finalize, sh.pv["previous_finalize_addr"])):
             if len(ev):

@@ -421,6 +421,20 @@ def tracegen_ed_decompress(events, fixed_log2_rows=-1, byte_counts=None):
     return _rows_then_fill(lib().orc_tracegen_ed_decompress, E.ED_DECOMPRESS_WIDTH, C.c_void_p(ev.ctypes.data), C.c_size_t(len(ev)), C.c_int(fixed_log2_rows), tail=bc)
 
 
+def tracegen_weierstrass(curve, double, events, fixed_log2_rows=-1, byte_counts=None):
+    """<Curve>AddAssign / <Curve>DoubleAssign rows from flattened EllipticCurveAddEvents / EllipticCurveDoubleEvents (events.weierstrass_event_dtypes)."""
+    from ziren_amd import events as E
+    c = E.WEIERSTRASS_CURVES[curve]
+    dt = E.weierstrass_event_dtypes(curve)[1 if double else 0]
+    ev = np.ascontiguousarray(events, dtype=dt)
+    n = c["n_limbs"]
+    mod = (C.c_uint8 * n)(*c["p"].to_bytes(n, "little"))
+    a = (C.c_uint8 * n)(*c["a"].to_bytes(n, "little"))
+    bc = (abi.as_u32p(byte_counts),) if byte_counts is not None else (None,)
+    return _rows_then_fill(lib().orc_tracegen_weierstrass, E.weierstrass_widths(curve)[1 if double else 0], C.c_void_p(ev.ctypes.data), C.c_size_t(len(ev)),
+                           C.c_int(int(double)), C.c_int(n), mod, a, C.c_uint32(c["witness_offset"]), C.c_int(fixed_log2_rows), tail=bc)
+
+
 def septic_known_answers(a, b):
     """((z^i)^p, (z^i)^(p^2) for i = 1..6, a * b, normalised sqrt(a^2)) in the septic extension, canonical words."""
     a = np.ascontiguousarray(a, dtype=np.uint32)

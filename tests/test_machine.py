@@ -55,6 +55,9 @@ def check_machine_airs(oracle, m):
                    "Poseidon2Permute": chips.record_poseidon2_permute_constraints, "KeccakSponge": chips.record_keccak_sponge_constraints,
                    "ShaExtend": chips.record_sha_extend_constraints, "ShaCompress": chips.record_sha_compress_constraints,
                    "EdAddAssign": chips.record_ed_add_constraints, "EdDecompress": chips.record_ed_decompress_constraints}.get(c.name)
+            if rec is None and c.name.endswith(("AddAssign", "DoubleAssign")):
+                curve, double = c.name.replace("DoubleAssign", "").replace("AddAssign", ""), c.name.endswith("DoubleAssign")
+                rec = lambda curve=curve, double=double: chips.record_weierstrass_constraints(curve, double)      # noqa: E731
             if rec is not None:
                 assert air.debug_constraints(rec().b, F.from_monty(c.trace), public_values=pv) == [], (k, c.name)
         assert not any(lookup_tally(cs).values()), (k, sh.kind)

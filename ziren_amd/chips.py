@@ -2193,6 +2193,76 @@ def record_ed_decompress_chip(log_height: int) -> RecordedChip:
     return _finish(record_ed_decompress_constraints(), "EdDecompress", log_height, E.ED_DECOMPRESS_WIDTH, True)
 
 
+def _weierstrass(r: _Rec, curve: str, double: bool):
+    """WeierstrassAddAssignChip::eval (syscall/precompiles/weierstrass/weierstrass_add.rs:283-404) / WeierstrassDoubleAssignChip::eval
+    (weierstrass_double.rs:318-462) over the curve's base field: slope = (q.y - p.y) / (q.x - p.x), or (3 p.x^2 + a) / (2 p.y) for a doubling;
+    x3 = slope^2 - p.x - q.x; y3 = slope (p.x - x3) - p.y; every step a FieldOpCols. p is overwritten (at clk + 1 for an addition, at clk for
+    a doubling)."""
+    c = E.WEIERSTRASS_CURVES[curve]
+    l, b = r.local, r.b
+    N, W, off = c["n_limbs"], c["n_limbs"] // 2, c["witness_offset"]
+    G = 6 * N - 4
+    modulus = _limbs_of_const(b, c["p"], N)
+    IS_REAL, SHARD, CLK, P_PTR = 0, 1, 2, 3
+    Q_PTR = None if double else 4
+    P_ACCESS = 4 if double else 5
+    Q_ACCESS = None if double else P_ACCESS + 13 * W
+    GADGETS = P_ACCESS + 13 * W + (0 if double else 9 * W)
+    is_real = l[IS_REAL]
+    p_access = [l[P_ACCESS + 13 * i:P_ACCESS + 13 * i + 13] for i in range(W)]
+    px, py = [x for a in p_access[:W // 2] for x in a[0:4]], [x for a in p_access[W // 2:] for x in a[0:4]]
+    col = lambda k: l[GADGETS + G * k:GADGETS + G * k + G]      # noqa: E731
+    res = lambda k: l[GADGETS + G * k:GADGETS + G * k + N]      # noqa: E731
+    op = lambda k, a, bb, kind: _field_op(r, col(k), a, bb, kind, modulus, N, off, is_real)      # noqa: E731
+    if not double:
+        q_access = [l[Q_ACCESS + 9 * i:Q_ACCESS + 9 * i + 9] for i in range(W)]
+        qx, qy = [x for a in q_access[:W // 2] for x in a[0:4]], [x for a in q_access[W // 2:] for x in a[0:4]]
+        SLOPE_DEN, SLOPE_NUM, SLOPE, SLOPE_SQ, PX_PLUS_QX, X3, PX_MINUS_X, Y3, SLOPE_TIMES = range(9)
+        op(SLOPE_NUM, qy, py, "sub")
+        op(SLOPE_DEN, qx, px, "sub")
+        op(SLOPE, res(SLOPE_NUM), res(SLOPE_DEN), "div")
+        op(SLOPE_SQ, res(SLOPE), res(SLOPE), "mul")
+        op(PX_PLUS_QX, px, qx, "add")
+        op(X3, res(SLOPE_SQ), res(PX_PLUS_QX), "sub")
+    else:
+        SLOPE_DEN, SLOPE_NUM, SLOPE, PX_SQ, PX_SQ_3, SLOPE_SQ, PX_PLUS_QX, X3, PX_MINUS_X, Y3, SLOPE_TIMES = range(11)
+        op(PX_SQ, px, px, "mul")
+        op(PX_SQ_3, res(PX_SQ), _limbs_of_const(b, 3, N), "mul")
+        op(SLOPE_NUM, _limbs_of_const(b, c["a"], N), res(PX_SQ_3), "add")
+        op(SLOPE_DEN, _limbs_of_const(b, 2, N), py, "mul")
+        op(SLOPE, res(SLOPE_NUM), res(SLOPE_DEN), "div")
+        op(SLOPE_SQ, res(SLOPE), res(SLOPE), "mul")
+        op(PX_PLUS_QX, px, px, "add")
+        op(X3, res(SLOPE_SQ), res(PX_PLUS_QX), "sub")
+    op(PX_MINUS_X, px, res(X3), "sub")
+    op(SLOPE_TIMES, res(SLOPE), res(PX_MINUS_X), "mul")
+    op(Y3, res(SLOPE_TIMES), py, "sub")
+    for i in range(N):
+        b.when(is_real).assert_eq(res(X3)[i], p_access[i // 4][4 + i % 4])
+        b.when(is_real).assert_eq(res(Y3)[i], p_access[W // 2 + i // 4][4 + i % 4])
+    if not double:
+        for i in range(W):
+            r.eval_memory_access(l[SHARD], l[CLK], l[Q_PTR] + 4 * i, q_access[i][0:4], q_access[i], is_real)
+    for i in range(W):
+        r.eval_memory_access(l[SHARD], l[CLK] + (0 if double else 1), l[P_PTR] + 4 * i, p_access[i][0:4], p_access[i][4:13], is_real)
+    code = c["double" if double else "add"] & 0xffff
+    r.receives.append(air.Lookup([air.to_virtual_pair(v) for v in [l[SHARD], l[CLK], b.const(code), l[P_PTR], b.const(0) if double else l[Q_PTR]]],
+                                 air.to_virtual_pair(is_real), air.KIND_SYSCALL))
+
+
+def record_weierstrass_constraints(curve: str, double: bool) -> _Rec:
+    r = _Rec(E.weierstrass_widths(curve)[1 if double else 0])
+    _weierstrass(r, curve, double)
+    return r
+
+
+def record_weierstrass_chip(curve: str, double: bool, log_height: int) -> RecordedChip:
+    """<Curve>AddAssign / <Curve>DoubleAssign for Secp256k1, Secp256r1, Bn254, Bls12381 (crates/core/machine/src/syscall/precompiles/weierstrass/):
+    one point operation per row; local_only as the reference declares them."""
+    name = curve + ("DoubleAssign" if double else "AddAssign")
+    return _finish(record_weierstrass_constraints(curve, double), name, log_height, E.weierstrass_widths(curve)[1 if double else 0], True)
+
+
 def record_ed_add_constraints() -> _Rec:
     r = _Rec(E.ED_ADD_WIDTH)
     _ed_add(r)

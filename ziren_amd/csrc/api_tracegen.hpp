@@ -725,6 +725,93 @@ int zkm_tracegen_ed_decompress(zkm_ctx* ctx, const zkm_ed_decompress_event* even
   API_END
 }
 
+// Base fields of the short-Weierstrass curves (crates/curves/src/weierstrass/{secp256k1,secp256r1,bn254,bls12_381}.rs): modulus, its Barrett
+// constant, the curve's `a`, as 32-bit limbs (generated from the reference's MODULUS bytes; tests compare the widths and costs they give)
+struct Curve8 { bigfield::Modulus<8> m; uint32_t a[8]; };
+struct Curve12 { bigfield::Modulus<12> m; uint32_t a[12]; };
+static const Curve8 k_curves8[3] = {
+  // Secp256k1: p, floor(2^512 / p), a
+  {{{0xfffffc2fu, 0xfffffffeu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu}, {0x000003d1u, 0x00000001u, 0x00000000u, 0x00000000u, 0x00000000u, 0x00000000u, 0x00000000u, 0x00000000u, 0x00000001u}}, {0x00000000u, 0x00000000u, 0x00000000u, 0x00000000u, 0x00000000u, 0x00000000u, 0x00000000u, 0x00000000u}},
+  // Secp256r1: p, floor(2^512 / p), a
+  {{{0xffffffffu, 0xffffffffu, 0xffffffffu, 0x00000000u, 0x00000000u, 0x00000000u, 0x00000001u, 0xffffffffu}, {0x00000003u, 0x00000000u, 0xffffffffu, 0xfffffffeu, 0xfffffffeu, 0xfffffffeu, 0xffffffffu, 0x00000000u, 0x00000001u}}, {0xfffffffcu, 0xffffffffu, 0xffffffffu, 0x00000000u, 0x00000000u, 0x00000000u, 0x00000001u, 0xffffffffu}},
+  // Bn254: p, floor(2^512 / p), a
+  {{{0xd87cfd47u, 0x3c208c16u, 0x6871ca8du, 0x97816a91u, 0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u}, {0x9bf90e51u, 0xf3aed8a1u, 0x7cd4c086u, 0xe965e176u, 0x8073013au, 0xb074a586u, 0x23a04a7au, 0x4a474626u, 0x00000005u}}, {0x00000000u, 0x00000000u, 0x00000000u, 0x00000000u, 0x00000000u, 0x00000000u, 0x00000000u, 0x00000000u}},
+};
+// Bls12381: p, floor(2^768 / p), a
+static const Curve12 k_curve_bls12381 = {{{0xffffaaabu, 0xb9feffffu, 0xb153ffffu, 0x1eabfffeu, 0xf6b0f624u, 0x6730d2a0u, 0xf38512bfu, 0x64774b84u, 0x434bacd7u, 0x4b1ba7b6u, 0x397fe69au, 0x1a0111eau}, {0x6591ba2eu, 0x13e207f5u, 0x58f1c07bu, 0x997167a0u, 0x286779d3u, 0xdf4771e0u, 0xf6a0a94bu, 0x1b82741fu, 0xc7a6ba29u, 0x28101b0cu, 0xcc9e45ceu, 0xd835d2f3u, 0x00000009u}}, {0x00000000u, 0x00000000u, 0x00000000u, 0x00000000u, 0x00000000u, 0x00000000u, 0x00000000u, 0x00000000u, 0x00000000u, 0x00000000u, 0x00000000u, 0x00000000u}};
+extern "C++" {
+template <int NL, bool DOUBLE>
+static void launch_weierstrass(zkm_ctx* ctx, const tracegen::CurveField<NL>& field, const uint32_t* d_events, size_t n_events, size_t height, uint32_t* out,
+                               uint32_t* counts, int* d_bad, double bytes) {
+  KLAUNCH(ctx, DOUBLE ? "tracegen_weierstrass_double" : "tracegen_weierstrass_add", bytes, (tracegen::weierstrass_rows<NL, DOUBLE>),
+          dim3(div_up(height, (size_t)64)), dim3(64), counts ? 2 * tracegen::HASH_SLOTS * sizeof(uint32_t) : 0, d_events, n_events, height, out, counts,
+          d_bad, field);
+}
+}  // extern "C++"
+static int tracegen_weierstrass(zkm_ctx* ctx, int curve, bool dbl, const void* events, size_t n_events, int fixed_log2_rows, zkm_byte_lookups* blu,
+                                zkm_matrix** out, const char* who) {
+  API_BEGIN
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIP_CHECK(hipSetDevice(ctx->device));
+  if (curve < 0 || curve > 3) throw std::runtime_error(std::string(who) + ": unknown curve");
+  if (n_events && !events) throw std::runtime_error(std::string(who) + ": null events");
+  const int nl = curve == 3 ? 12 : 8, W = 2 * nl, G = 6 * 4 * nl - 4;
+  const size_t ev_words = dbl ? 3 + 6 * W : 4 + 11 * W, width = (dbl ? 4 + 13 * W + 11 * G : 5 + 22 * W + 9 * G);
+  const size_t height = padded_trace_rows(n_events, fixed_log2_rows, who);
+  ctx->begin_timing();
+  zkm_matrix* m = new zkm_matrix();
+  m->h = height; m->w = width;
+  uint32_t* d_events = nullptr;
+  int* d_bad = nullptr;
+  try {
+    m->d = ctx->alloc_n<uint32_t>(height * m->w);
+    const size_t ev_bytes = n_events * ev_words * 4;
+    d_events = (uint32_t*)ctx->alloc(std::max<size_t>(ev_bytes, 4));
+    d_bad = (int*)ctx->alloc(4);
+    HIP_CHECK(hipMemsetAsync(d_bad, 0, 4, ctx->stream));
+    if (n_events) HIP_CHECK(hipMemcpyAsync(d_events, events, ev_bytes, hipMemcpyHostToDevice, ctx->stream));
+    uint32_t* counts = blu ? blu->counts : nullptr;
+    const double bytes = (double)ev_bytes + 4.0 * height * m->w;
+    if (nl == 8) {
+      tracegen::CurveField<8> f;
+      f.m = k_curves8[curve].m;
+      memcpy(f.a, k_curves8[curve].a, sizeof f.a);
+      f.witness_offset = 1 << 14;
+      if (dbl) launch_weierstrass<8, true>(ctx, f, d_events, n_events, height, m->d, counts, d_bad, bytes);
+      else launch_weierstrass<8, false>(ctx, f, d_events, n_events, height, m->d, counts, d_bad, bytes);
+    } else {
+      tracegen::CurveField<12> f;
+      f.m = k_curve_bls12381.m;
+      memcpy(f.a, k_curve_bls12381.a, sizeof f.a);
+      f.witness_offset = 1 << 15;
+      if (dbl) launch_weierstrass<12, true>(ctx, f, d_events, n_events, height, m->d, counts, d_bad, bytes);
+      else launch_weierstrass<12, false>(ctx, f, d_events, n_events, height, m->d, counts, d_bad, bytes);
+    }
+    int bad = 0;
+    HIP_CHECK(hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, ctx->stream));
+    ctx->mark("trace generation");
+    ctx->end_timing(false);
+    if (bad) throw std::runtime_error(std::string(who) + ": a coordinate is not below the field modulus, or the words written to p are not the result point");
+  } catch (...) {
+    if (d_events) ctx->release(d_events);
+    if (d_bad) ctx->release(d_bad);
+    if (m->d) ctx->release(m->d);
+    delete m;
+    throw;
+  }
+  ctx->release(d_events);
+  ctx->release(d_bad);
+  *out = m;
+  API_END
+}
+int zkm_tracegen_weierstrass_add(zkm_ctx* ctx, int curve, const void* events, size_t n_events, int fixed_log2_rows, zkm_byte_lookups* blu, zkm_matrix** out) {
+  return tracegen_weierstrass(ctx, curve, false, events, n_events, fixed_log2_rows, blu, out, "zkm_tracegen_weierstrass_add");
+}
+int zkm_tracegen_weierstrass_double(zkm_ctx* ctx, int curve, const void* events, size_t n_events, int fixed_log2_rows, zkm_byte_lookups* blu,
+                                    zkm_matrix** out) {
+  return tracegen_weierstrass(ctx, curve, true, events, n_events, fixed_log2_rows, blu, out, "zkm_tracegen_weierstrass_double");
+}
+
 int zkm_tracegen_exp_reverse_bits(zkm_ctx* ctx, const uint32_t* bases, const uint32_t* bits, const uint32_t* offsets, size_t n_events,
                                   int fixed_log2_rows, zkm_matrix** out) {
   API_BEGIN

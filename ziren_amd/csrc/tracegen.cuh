@@ -1982,6 +1982,176 @@ __global__ __launch_bounds__(64) void ed_decompress_rows(const uint32_t* __restr
   }
 }
 
+// ---- Short-Weierstrass precompiles (syscall/precompiles/weierstrass/weierstrass_add.rs, weierstrass_double.rs) for Secp256k1, Secp256r1, Bn254
+// (32 byte limbs, eight 32-bit limbs here) and Bls12381 (48 / twelve): nine / eleven FieldOpCols per row. The curve's base field arrives as
+// a kernel argument (modulus, its Barrett constant, `a`, the witness offset); the gadget code is the Ed25519 one with the limb count as a
+// template parameter. Padding rows: an addition's are the operations of the zero inputs; a doubling's are those of the point (0, 1) with the
+// dummy write record of weierstrass_double.rs:225-239 on the first word of y.
+template <int NL> struct CurveField { bigfield::Modulus<NL> m; uint32_t a[NL]; int32_t witness_offset; };
+template <int NL> struct FieldRow {
+  static constexpr int N = 4 * NL, NW = 2 * N - 2, G = 2 * N + 2 * NW;
+  uint32_t* out; size_t height, row; const LookupSink& sink; bool count; const CurveField<NL>& f;
+  __device__ __forceinline__ void put(int col, uint32_t canonical) const { out[(size_t)col * height + row] = kb::to_monty(canonical); }
+  static __device__ __forceinline__ void poly_mac(int32_t* acc, const uint32_t* a, const uint32_t* b) {
+    for (int i = 0; i < N; i++) {
+      const int32_t ai = (int32_t)bigfield::byte_of(a, i);
+      for (int j = 0; j < N; j++) acc[i + j] += ai * (int32_t)bigfield::byte_of(b, j);
+    }
+  }
+  static __device__ __forceinline__ void poly_add(int32_t* acc, const uint32_t* a, int sign) {
+    for (int i = 0; i < N; i++) acc[i] += sign * (int32_t)bigfield::byte_of(a, i);
+  }
+  __device__ void gadget(int base, int32_t* van, const uint32_t* result, const uint32_t* carry) const {
+    for (int i = 0; i < N; i++) {
+      const int32_t c = (int32_t)bigfield::byte_of(carry, i);
+      for (int j = 0; j < N; j++) van[i + j] -= c * (int32_t)bigfield::byte_of(f.m.p, j);
+    }
+    uint32_t prev_low = 0, prev_high = 0;
+    int32_t above = 0;
+    for (int k = NW; k >= 1; k--) {
+      above = van[k] + 256 * above;
+      const uint32_t shifted = (uint32_t)(above + f.witness_offset);
+      put(base + 2 * N + k - 1, shifted & 0xff);
+      put(base + 2 * N + NW + k - 1, shifted >> 8);
+      if (count) {
+        if ((k - 1) % 2 == 0) { lookup(sink, B_U8RANGE, shifted & 0xff, prev_low); lookup(sink, B_U8RANGE, shifted >> 8, prev_high); }
+        prev_low = shifted & 0xff; prev_high = shifted >> 8;
+      }
+    }
+    for (int i = 0; i < N; i++) { put(base + i, bigfield::byte_of(result, i)); put(base + N + i, bigfield::byte_of(carry, i)); }
+    if (count)
+      for (int i = 0; i < N; i += 2) {
+        lookup(sink, B_U8RANGE, bigfield::byte_of(result, i), bigfield::byte_of(result, i + 1));
+        lookup(sink, B_U8RANGE, bigfield::byte_of(carry, i), bigfield::byte_of(carry, i + 1));
+      }
+  }
+  // FieldOpCols::populate_with_modulus (operations/field/field_op.rs:154-224) for a, b below p
+  __device__ void op(int base, const uint32_t* a, const uint32_t* b, int kind, uint32_t* res, int32_t* van) const {
+    const bigfield::Modulus<NL>& m = f.m;
+    uint32_t t[2 * NL], t2[2 * NL], q[NL + 1];
+    for (int i = 0; i <= NL; i++) q[i] = 0;
+    for (int i = 0; i < 2 * N - 1; i++) van[i] = 0;
+    if (kind == FOP_ADD) {
+      for (int i = 0; i < NL; i++) res[i] = a[i];
+      const uint32_t carry_out = bigfield::add<NL>(res, b);
+      if (carry_out || bigfield::cmp<NL>(res, m.p) >= 0) { bigfield::sub<NL>(res, m.p); q[0] = 1; }
+      poly_add(van, a, 1); poly_add(van, b, 1); poly_add(van, res, -1);
+    } else if (kind == FOP_SUB) {                 // result + b = a + carry p
+      for (int i = 0; i < NL; i++) res[i] = a[i];
+      if (bigfield::sub<NL>(res, b)) { bigfield::add<NL>(res, m.p); q[0] = 1; }
+      poly_add(van, res, 1); poly_add(van, b, 1); poly_add(van, a, -1);
+    } else if (kind == FOP_MUL) {
+      bigfield::mul<NL, NL>(a, b, t);
+      bigfield::divmod<NL>(t, m, q, res);
+      poly_mac(van, a, b); poly_add(van, res, -1);
+    } else {                                      // result * b = a + carry p
+      bool zero = true;
+      for (int i = 0; i < NL; i++) zero = zero && a[i] == 0;
+      if (zero) { for (int i = 0; i < NL; i++) res[i] = 0; } else { uint32_t inv[NL]; bigfield::inverse<NL>(b, m, inv); bigfield::mulmod<NL>(a, inv, m, res); }
+      bigfield::mul<NL, NL>(res, b, t);
+      for (int i = 0; i < 2 * NL; i++) t2[i] = i < NL ? a[i] : 0u;
+      bigfield::sub<2 * NL>(t, t2);
+      uint32_t rem[NL];
+      bigfield::divmod<NL>(t, m, q, rem);
+      poly_mac(van, res, b); poly_add(van, a, -1);
+    }
+    gadget(base, van, res, q);
+  }
+};
+template <int NL, bool DOUBLE>
+__global__ __launch_bounds__(64) void weierstrass_rows(const uint32_t* __restrict__ events, size_t n_events, size_t height, uint32_t* __restrict__ out,
+                                                       uint32_t* counts, int* __restrict__ bad, const CurveField<NL> field) {
+  constexpr int N = 4 * NL, W = 2 * NL, G = FieldRow<NL>::G;
+  constexpr int P_ACCESS = DOUBLE ? 4 : 5, Q_ACCESS = P_ACCESS + 13 * W, GADGETS = P_ACCESS + 13 * W + (DOUBLE ? 0 : 9 * W);
+  constexpr int EV_WORDS = DOUBLE ? 3 + 6 * W : 4 + 11 * W, E_P = DOUBLE ? 3 : 4, E_Q = 4 + 6 * W;
+  extern __shared__ uint32_t hash_lds[];
+  uint32_t* hkeys = hash_lds;
+  uint32_t* hvals = hash_lds + HASH_SLOTS;
+  const bool count = counts != nullptr;
+  if (count) {
+    for (int i = threadIdx.x; i < HASH_SLOTS; i += blockDim.x) { hkeys[i] = HASH_EMPTY; hvals[i] = 0; }
+    __syncthreads();
+  }
+  const size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (row < height) {
+    const bool real = row < n_events;
+    const uint32_t* e = events + row * EV_WORDS;
+    const LookupSink sink{hkeys, hvals, HASH_SLOTS - 1, counts};
+    const FieldRow<NL> R{out, height, row, sink, count && real, field};
+    uint32_t px[NL], py[NL], qx[NL], qy[NL];
+    bool ok = true;
+    for (int k = 0; k < NL; k++) {
+      px[k] = real ? e[E_P + 6 * k + 3] : 0u;
+      py[k] = real ? e[E_P + 6 * (NL + k) + 3] : (DOUBLE && k == 0 ? 1u : 0u);      // a doubling's padding point is (0, 1)
+      qx[k] = real && !DOUBLE ? e[E_Q + 5 * k] : 0u;
+      qy[k] = real && !DOUBLE ? e[E_Q + 5 * (NL + k)] : 0u;
+    }
+    if (bigfield::cmp<NL>(px, field.m.p) >= 0 || bigfield::cmp<NL>(py, field.m.p) >= 0 || bigfield::cmp<NL>(qx, field.m.p) >= 0 ||
+        bigfield::cmp<NL>(qy, field.m.p) >= 0) {
+      ok = false;
+      for (int k = 0; k < NL; k++) px[k] = py[k] = qx[k] = qy[k] = 0;
+    }
+    int32_t van[2 * N - 1];
+    uint32_t num[NL], den[NL], slope[NL], sq[NL], sum[NL], x3[NL], dx[NL], prod[NL], y3[NL];
+    auto col = [&](int k) { return GADGETS + G * k; };
+    if (!DOUBLE) {
+      R.op(col(1), qy, py, FOP_SUB, num, van);
+      R.op(col(0), qx, px, FOP_SUB, den, van);
+      R.op(col(2), num, den, FOP_DIV, slope, van);
+      R.op(col(3), slope, slope, FOP_MUL, sq, van);
+      R.op(col(4), px, qx, FOP_ADD, sum, van);
+      R.op(col(5), sq, sum, FOP_SUB, x3, van);
+      R.op(col(6), px, x3, FOP_SUB, dx, van);
+      R.op(col(8), slope, dx, FOP_MUL, prod, van);
+      R.op(col(7), prod, py, FOP_SUB, y3, van);
+    } else {
+      uint32_t xx[NL], xx3[NL], three[NL], two[NL];
+      for (int k = 0; k < NL; k++) { three[k] = k == 0 ? 3u : 0u; two[k] = k == 0 ? 2u : 0u; }
+      R.op(col(3), px, px, FOP_MUL, xx, van);
+      R.op(col(4), xx, three, FOP_MUL, xx3, van);
+      R.op(col(1), field.a, xx3, FOP_ADD, num, van);
+      R.op(col(0), two, py, FOP_MUL, den, van);
+      R.op(col(2), num, den, FOP_DIV, slope, van);
+      R.op(col(5), slope, slope, FOP_MUL, sq, van);
+      R.op(col(6), px, px, FOP_ADD, sum, van);
+      R.op(col(7), sq, sum, FOP_SUB, x3, van);
+      R.op(col(8), px, x3, FOP_SUB, dx, van);
+      R.op(col(10), slope, dx, FOP_MUL, prod, van);
+      R.op(col(9), prod, py, FOP_SUB, y3, van);
+    }
+    R.put(0, real ? 1u : 0u);
+    R.put(1, real ? e[0] : 0u); R.put(2, real ? e[1] : 0u); R.put(3, real ? e[2] : 0u);
+    if (!DOUBLE) R.put(4, real ? e[3] : 0u);
+    for (int k = 0; k < W; k++) {
+      uint32_t mw[13], mr[9];
+      for (int c = 0; c < 13; c++) mw[c] = 0;
+      for (int c = 0; c < 9; c++) mr[c] = 0;
+      if (real) {
+        memory_write_cols(e + E_P + 6 * k, mw);
+        if (count) { lookup(sink, B_U16RANGE, mw[11] >> 8, mw[11]); lookup(sink, B_U8RANGE, 0, mw[12]); }
+        if (e[E_P + 6 * k] != (k < NL ? x3[k] : y3[k - NL])) ok = false;
+        if (!DOUBLE) {
+          const uint32_t* rec = e + E_Q + 5 * k;
+          memory_access_cols(rec[0], rec[1], rec[2], rec[3], rec[4], mr);
+          if (count) access_lookups(mr, sink);
+        }
+      } else if (DOUBLE && k == NL) {
+        const uint32_t dummy[6] = {1, 0, 1, 1, 0, 0};
+        memory_write_cols(dummy, mw);
+      }
+      for (int c = 0; c < 13; c++) R.put(P_ACCESS + 13 * k + c, mw[c]);
+      if (!DOUBLE)
+        for (int c = 0; c < 9; c++) R.put(Q_ACCESS + 9 * k + c, mr[c]);
+    }
+    if (real && !ok) *bad = 1;
+  }
+  if (count) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < HASH_SLOTS; i += blockDim.x)
+      if (hkeys[i] != HASH_EMPTY) atomicAdd(counts + hkeys[i], hvals[i]);
+  }
+}
+
 // recursion ExpReverseBitsLen chip (crates/recursion/core/src/chips/exp_reverse_bits.rs:175-226): one thread walks one event's bits —
 // accum_i = accum_{i-1}^2 * (bit_i ? x : 1) — and writes its rows (x, bit, prev_accum^2, that times the multiplier, accum, accum^2,
 // multiplier); Montgomery words in and out. offsets[e] .. offsets[e + 1] are event e's rows; the rest of the matrix is zeroed first.

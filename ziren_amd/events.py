@@ -687,6 +687,61 @@ def ed25519_decompress(y, sign):
     return (P - x) % P if sign else x
 
 
+# The short-Weierstrass precompiles (syscall/precompiles/weierstrass/weierstrass_add.rs, weierstrass_double.rs), one chip per curve and operation
+# (MipsAir variants Secp256k1Add .. Bls12381Double, mips/mod.rs:137-158): parameters as crates/curves/src/weierstrass/{secp256k1,secp256r1,bn254,
+# bls12_381}.rs give them; `index` is the curve number across the C ABI (ZKM_CURVE_*).
+WEIERSTRASS_CURVES = {
+    "Secp256k1": dict(index=0, p=(1 << 256) - (1 << 32) - 977, a=0, b=7, n_limbs=32, witness_offset=1 << 14, add=0x0101000A, double=0x0001000B,
+                      generator=(55066263022277343669578718895168534326250603453777594175500187360389116729240,
+                                 32670510020758816978083085130507043184471273380659243275938904335757337482424)),
+    "Secp256r1": dict(index=1, p=(1 << 256) - (1 << 224) + (1 << 192) + (1 << 96) - 1, a=(1 << 256) - (1 << 224) + (1 << 192) + (1 << 96) - 4,
+                      b=0x5AC635D8AA3A93E7B3EBBD55769886BC651D06B0CC53B0F63BCE3C3E27D2604B, n_limbs=32, witness_offset=1 << 14, add=0x0101002C, double=0x0001002D,
+                      generator=(48439561293906451759052585252797914202762949526041747995844080717082404635286,
+                                 36134250956749795798585127919587881956611106672985015071877198253568414405109)),
+    "Bn254": dict(index=2, p=21888242871839275222246405745257275088696311157297823662689037894645226208583, a=0, b=3, n_limbs=32, witness_offset=1 << 14,
+                  add=0x0101000E, double=0x0001000F, generator=(1, 2)),
+    "Bls12381": dict(index=3, p=0x1a0111ea397fe69a4b1ba7b6434bacd764774b84f38512bf6730d2a0f6b0f6241eabfffeb153ffffb9feffffffffaaab, a=0, b=4, n_limbs=48,
+                     witness_offset=1 << 15, add=0x0101001E, double=0x0001001F,
+                     generator=(3685416753713387016781088315183077757961620795782546409894578378688607592378376318836054947676345821548104185464507,
+                                1339506544944476473020471379941921221584933875938349620426543736416511423956333506472724655353366534992391756441569)),
+}
+
+
+def weierstrass_event_dtypes(curve):
+    """EllipticCurveAddEvent / EllipticCurveDoubleEvent (events/precompiles/ec.rs:24-72) flattened for a curve: p (and q) are the previous values of
+    the p write records (the values of the q read records)."""
+    w = WEIERSTRASS_CURVES[curve]["n_limbs"] // 2
+    add = np.dtype([("shard", "<u4"), ("clk", "<u4"), ("p_ptr", "<u4"), ("q_ptr", "<u4"), ("p_memory_records", MEMORY_WRITE_RECORD, (w,)),
+                    ("q_memory_records", MEMORY_READ_RECORD, (w,))])
+    double = np.dtype([("shard", "<u4"), ("clk", "<u4"), ("p_ptr", "<u4"), ("p_memory_records", MEMORY_WRITE_RECORD, (w,))])
+    return add, double
+
+
+def weierstrass_widths(curve):
+    """WeierstrassAddAssignCols (weierstrass_add.rs:43-62): 5 + W * 13 + W * 9 + 9 gadgets; WeierstrassDoubleAssignCols (weierstrass_double.rs:43-62):
+    4 + W * 13 + 11 gadgets; a gadget is 2 N + 2 (2 N - 2) columns."""
+    n = WEIERSTRASS_CURVES[curve]["n_limbs"]
+    w, g = n // 2, 6 * n - 4
+    return 5 + 22 * w + 9 * g, 4 + 13 * w + 11 * g
+
+
+def weierstrass_add(curve, p, q):
+    """AffinePoint + AffinePoint on a short Weierstrass curve (curves/src/weierstrass/mod.rs sw_add): distinct x coordinates."""
+    P = WEIERSTRASS_CURVES[curve]["p"]
+    (x1, y1), (x2, y2) = p, q
+    slope = (y2 - y1) * pow(x2 - x1, P - 2, P) % P
+    x3 = (slope * slope - x1 - x2) % P
+    return x3, (slope * (x1 - x3) - y1) % P
+
+
+def weierstrass_double(curve, p):
+    c = WEIERSTRASS_CURVES[curve]
+    P, (x1, y1) = c["p"], p
+    slope = (3 * x1 * x1 + c["a"]) * pow(2 * y1, P - 2, P) % P
+    x3 = (slope * slope - 2 * x1) % P
+    return x3, (slope * (x1 - x3) - y1) % P
+
+
 SYSCALL_INSTRS_WIDTH = 77
 # SyscallCode (crates/core/executor/src/syscalls/code.rs): byte 0-1 id, byte 2 "has its own table", byte 3 extra cycles
 SYS_HALT, SYS_WRITE, SYS_ENTER_UNCONSTRAINED, SYS_EXIT_UNCONSTRAINED, SYS_COMMIT, SYS_COMMIT_DEFERRED_PROOFS, SYS_HINT_LEN = 0, 2, 3, 4, 0x10, 0x1a, 0xf0

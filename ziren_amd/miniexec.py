@@ -94,7 +94,8 @@ class Machine:
 
 
 def run_machine(n_cycles: int = 0, seed: int = 1, pc_base: int = 0x1000, shard_cycles: int = 1 << 30, program=None, poseidon2_calls: int = 0,
-                memory_chunk: int = 1 << 30, keccak_calls: int = 0, sha_calls: int = 0, ed_calls: int = 0) -> Machine:
+                memory_chunk: int = 1 << 30, keccak_calls: int = 0, sha_calls: int = 0, ed_calls: int = 0,
+                curve_calls=None) -> Machine:
     """A whole run as the reference's prover sees it (crates/core/machine/src/utils/prove.rs:255-400): CPU shards of at most `shard_cycles`
     cycles (never split between a branch and its delay slot, executor.rs:2352-2356), then one shard with the deferred precompile events
     (ExecutionRecord::split, record.rs:130-218), then the shards that initialise and finalise every touched address
@@ -102,11 +103,12 @@ def run_machine(n_cycles: int = 0, seed: int = 1, pc_base: int = 0x1000, shard_c
     to execute until it halts instead of generating one; `poseidon2_calls` / `keccak_calls`: POSEIDON2_PERMUTE / KECCAK_SPONGE precompile calls
     spread over a generated run (each kind is deferred to a precompile shard of its own, record.rs:150-185)."""
     return _execute(n_cycles, seed, 1, pc_base, True, shard_cycles=shard_cycles, given=program, poseidon2_calls=poseidon2_calls, memory_chunk=memory_chunk,
-                    machine=True, keccak_calls=keccak_calls, sha_calls=sha_calls, ed_calls=ed_calls)
+                    machine=True, keccak_calls=keccak_calls, sha_calls=sha_calls, ed_calls=ed_calls, curve_calls=curve_calls)
 
 
 def _execute(n_cycles: int, seed: int = 1, shard: int = 1, pc_base: int = 0x1000, halt: bool = False, shard_cycles: int = 1 << 30, given=None,
-             poseidon2_calls: int = 0, memory_chunk: int = 1 << 30, machine: bool = False, keccak_calls: int = 0, sha_calls: int = 0, ed_calls: int = 0) -> Machine:
+             poseidon2_calls: int = 0, memory_chunk: int = 1 << 30, machine: bool = False, keccak_calls: int = 0, sha_calls: int = 0, ed_calls: int = 0,
+             curve_calls=None) -> Machine:
     """Execute `n_cycles` instructions of a program generated on the way. Returns (program, record, public_values) with
     program: INSTRUCTION array (instructions that were jumped over are `ADD $0, 0, 0` no-ops that never run), record:
     structured event arrays, public_values: dict of the words the Cpu chip checks (start_pc, next_pc, execution_shard).
@@ -173,6 +175,7 @@ def _execute(n_cycles: int, seed: int = 1, shard: int = 1, pc_base: int = 0x1000
     s_at = set(int(x) for x in np.linspace(n_cycles // 5, max(n_cycles - 80, n_cycles // 5), sha_calls)) - p2_at - k_at if sha_calls else set()
     s_seq = 0
     e_at = {n_cycles // 4} - p2_at - k_at - s_at if ed_calls else set()
+    w_at = {n_cycles // 3} - p2_at - k_at - s_at - e_at if curve_calls else set()
     clk_extra = 0                  # the extra cycles of the shard's syscalls so far (Syscall::num_extra_cycles, executor.rs:1641)
 
     def close_shard():
@@ -211,6 +214,7 @@ def _execute(n_cycles: int, seed: int = 1, shard: int = 1, pc_base: int = 0x1000
             k_at = set(x + len(queued) - had if x > cyc else x for x in k_at)
             s_at = set(x + len(queued) - had if x > cyc else x for x in s_at)
             e_at = set(x + len(queued) - had if x > cyc else x for x in e_at)
+            w_at = set(x + len(queued) - had if x > cyc else x for x in w_at)
         if given is None and cyc in k_at and cyc < n_cycles:
             # a KECCAK_SPONGE call as the guest library's keccak256 makes it (crates/zkvm/lib/src/keccak256.rs:3-57): the padded message as
             # 36-word blocks, its length in words at result + 64, the code in $v0, input and result pointers in $a0 / $a1
@@ -229,6 +233,7 @@ def _execute(n_cycles: int, seed: int = 1, shard: int = 1, pc_base: int = 0x1000
             k_at = set(x + len(queued) - had if x > cyc else x for x in k_at)
             s_at = set(x + len(queued) - had if x > cyc else x for x in s_at)
             e_at = set(x + len(queued) - had if x > cyc else x for x in e_at)
+            w_at = set(x + len(queued) - had if x > cyc else x for x in w_at)
         if given is None and cyc in s_at and cyc < n_cycles:
             # one SHA-256 block as the reference's test programs lay the calls out (sha256/extend/mod.rs:44-61, compress/mod.rs:52-78): sixteen
             # message words at w_ptr, SHA_EXTEND(w_ptr, 0), the eight state words at h_ptr, SHA_COMPRESS(w_ptr, h_ptr)
@@ -248,6 +253,7 @@ def _execute(n_cycles: int, seed: int = 1, shard: int = 1, pc_base: int = 0x1000
             k_at = set(x + len(queued) - had if x > cyc else x for x in k_at)
             s_at = set(x + len(queued) - had if x > cyc else x for x in s_at)
             e_at = set(x + len(queued) - had if x > cyc else x for x in e_at)
+            w_at = set(x + len(queued) - had if x > cyc else x for x in w_at)
         if given is None and cyc in e_at and cyc < n_cycles:
             # Ed25519 additions the way a scalar multiplication makes them: p = B and q = 2B stored once, then `ed_calls` times p <- p + q
             # (ED_ADD(p_ptr, q_ptr), the reference's ed_add test program: syscall/precompiles/edwards/ed_add.rs tests)
@@ -268,6 +274,28 @@ def _execute(n_cycles: int, seed: int = 1, shard: int = 1, pc_base: int = 0x1000
             p2_at = set(x + len(queued) - had if x > cyc else x for x in p2_at)
             k_at = set(x + len(queued) - had if x > cyc else x for x in k_at)
             s_at = set(x + len(queued) - had if x > cyc else x for x in s_at)
+            w_at = set(x + len(queued) - had if x > cyc else x for x in w_at)
+        if given is None and cyc in w_at and cyc < n_cycles:
+            # per curve in `curve_calls`: the generator stored at p and at q, q doubled with <CURVE>_DOUBLE(q), then `count` times p <- p + q
+            # with <CURVE>_ADD(p, q): p runs through G, 3G, 5G, ... and never meets q = 2G
+            had = len(queued)
+            for k, (curve, calls) in enumerate(curve_calls.items()):
+                cv = E.WEIERSTRASS_CURVES[curve]
+                W = cv["n_limbs"] // 2
+                p_ptr, q_ptr = 0x00600000 + 0x400 * k, 0x00600200 + 0x400 * k
+                for ptr in (p_ptr, q_ptr):
+                    for i in range(W):
+                        queued += [(E.ADD, 30, (cv["generator"][i // (W // 2)] >> (32 * (i % (W // 2)))) & 0xffffffff, 0, 1, 1), (E.SW, 30, 0, ptr + 4 * i, 0, 1)]
+                queued += [(E.ADD, E.REG_V0, cv["double"], 0, 1, 1), (E.ADD, E.REG_A0, q_ptr, 0, 1, 1), (E.ADD, E.REG_A1, 0, 0, 1, 1),
+                           (E.SYSCALL, E.REG_V0, E.REG_A0, E.REG_A1, 0, 0)]
+                for _ in range(calls):
+                    queued += [(E.ADD, E.REG_V0, cv["add"], 0, 1, 1), (E.ADD, E.REG_A0, p_ptr, 0, 1, 1), (E.ADD, E.REG_A1, q_ptr, 0, 1, 1),
+                               (E.SYSCALL, E.REG_V0, E.REG_A0, E.REG_A1, 0, 0)]
+            n_cycles += len(queued) - had
+            p2_at = set(x + len(queued) - had if x > cyc else x for x in p2_at)
+            k_at = set(x + len(queued) - had if x > cyc else x for x in k_at)
+            s_at = set(x + len(queued) - had if x > cyc else x for x in s_at)
+            e_at = set(x + len(queued) - had if x > cyc else x for x in e_at)
         # ---- pick the instruction at pc (the program is written as it runs)
         if given is not None:
             if pc not in program:
@@ -441,7 +469,9 @@ def _execute(n_cycles: int, seed: int = 1, shard: int = 1, pc_base: int = 0x1000
             b_rec = read(op_b, clk, POS_B)
             b = b_rec[1][0]
             sid = code & 0xffff
-            assert code in (E.SYS_HALT, E.SYS_COMMIT, E.SYS_POSEIDON2_PERMUTE, E.SYS_KECCAK_SPONGE, E.SYS_SHA_EXTEND, E.SYS_SHA_COMPRESS, E.SYS_ED_ADD, E.SYS_ED_DECOMPRESS), code
+            w_curve = {c[k]: (name, k == "double") for name, c in E.WEIERSTRASS_CURVES.items() for k in ("add", "double")}.get(code)
+            assert w_curve or code in (E.SYS_HALT, E.SYS_COMMIT, E.SYS_POSEIDON2_PERMUTE, E.SYS_KECCAK_SPONGE, E.SYS_SHA_EXTEND, E.SYS_SHA_COMPRESS, E.SYS_ED_ADD,
+                                        E.SYS_ED_DECOMPRESS), code
             touched = {}                               # address -> [initial (shard, timestamp, value), final]: SyscallContext's local map
 
             def mem(addr, ts, value=None):
@@ -558,6 +588,24 @@ def _execute(n_cycles: int, seed: int = 1, shard: int = 1, pc_base: int = 0x1000
                 xw = [mem(b + 4 * i, clk, (x >> (32 * i)) & 0xffffffff) for i in range(8)]
                 local = [(addr, v[0], v[1]) for addr, v in sorted(touched.items())]
                 precompile.append(("ed_decompress", (pc, next_pc, shard, clk, (0, 0, 0, 0, 0, 0), 0, [0, 0, 0], sid, b, c), [(shard, clk, b, c, xw, yr)], local))
+            if w_curve:
+                # create_ec_add_event / create_ec_double_event (events/precompiles/ec.rs:96-176) for a short-Weierstrass curve: p is peeked; an
+                # addition reads q at clk and writes p + q over p at clk + 1 (one extra cycle), a doubling writes 2 p over p at clk
+                curve, dbl = w_curve
+                W = E.WEIERSTRASS_CURVES[curve]["n_limbs"] // 2
+                as_pt = lambda ws: (sum(w << (32 * i) for i, w in enumerate(ws[:W // 2])), sum(w << (32 * i) for i, w in enumerate(ws[W // 2:])))      # noqa: E731
+                pw = [R.get(b + 4 * i, 0) for i in range(W)]
+                if dbl:
+                    out_pt, qr = E.weierstrass_double(curve, as_pt(pw)), []
+                else:
+                    qr = [mem(c + 4 * i, clk) for i in range(W)]
+                    out_pt = E.weierstrass_add(curve, as_pt(pw), as_pt([x[0] for x in qr]))
+                out = [(out_pt[i // (W // 2)] >> (32 * (i % (W // 2)))) & 0xffffffff for i in range(W)]
+                pwr = [mem(b + 4 * i, clk + (0 if dbl else 1), out[i]) for i in range(W)]
+                local = [(addr, v[0], v[1]) for addr, v in sorted(touched.items())]
+                event = (shard, clk, b, pwr) if dbl else (shard, clk, b, c, pwr, qr)
+                precompile.append((curve + ("_double" if dbl else "_add"), (pc, next_pc, shard, clk, (0, 0, 0, 0, 0, 0), 0, [0, 0, 0], sid, b, c), [event], local))
+                clk_extra += 0 if dbl else 1
             a = code                                       # none of them returns a value: V0 keeps the code
             a_rec = write(op_a, a, clk, POS_A)
             hi = code
@@ -670,7 +718,8 @@ def _execute(n_cycles: int, seed: int = 1, shard: int = 1, pc_base: int = 0x1000
     n_shard = shards[-1].pv["shard"]
     for kind, dt in (("poseidon2", E.POSEIDON2_PERMUTE_EVENT), ("keccak", E.KECCAK_SPONGE_BLOCK), ("sha_extend", E.SHA_EXTEND_EVENT),
                      ("sha_compress", E.SHA_COMPRESS_EVENT), ("ed_add", E.ED_ADD_EVENT),
-                     ("ed_decompress", E.ED_DECOMPRESS_EVENT)):
+                     ("ed_decompress", E.ED_DECOMPRESS_EVENT)) + tuple(
+            (curve + suffix, E.weierstrass_event_dtypes(curve)[k]) for curve in E.WEIERSTRASS_CURVES for k, suffix in ((0, "_add"), (1, "_double"))):
         mine = [e for e in precompile if e[0] == kind]
         if not mine:
             continue
@@ -684,6 +733,7 @@ def _execute(n_cycles: int, seed: int = 1, shard: int = 1, pc_base: int = 0x1000
         o.sha_compress = arr([ev for e in mine for ev in e[2]] if kind == "sha_compress" else [], E.SHA_COMPRESS_EVENT)
         o.ed_add = arr([ev for e in mine for ev in e[2]] if kind == "ed_add" else [], E.ED_ADD_EVENT)
         o.ed_decompress = arr([ev for e in mine for ev in e[2]] if kind == "ed_decompress" else [], E.ED_DECOMPRESS_EVENT)
+        o.weierstrass = (kind, arr([ev for e in mine for ev in e[2]], dt)) if kind.endswith(("_add", "_double")) and kind.split("_")[0] in E.WEIERSTRASS_CURVES else None
         o.memory_local = arr([ev for e in mine for ev in e[3]], MEMORY_LOCAL_EVENT)
         pv = dict(last_pv, start_pc=last_pv["next_pc"], shard=n_shard)
         shards.append(Shard("precompile", o, pv))

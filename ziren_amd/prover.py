@@ -268,6 +268,17 @@ class Context:
                                                         C.c_int(fixed_log2_rows), blu.h if blu is not None else None, C.byref(h)))
         return self._born(h)
 
+    def tracegen_weierstrass(self, curve: str, double: bool, events: np.ndarray, fixed_log2_rows: int = -1, blu: "ByteLookups" = None) -> DeviceMatrix:
+        """`generate_trace` of <Curve>AddAssign / <Curve>DoubleAssign on the device (zkm_tracegen_weierstrass_add / _double); curve one of
+        events.WEIERSTRASS_CURVES, dtype events.weierstrass_event_dtypes(curve)."""
+        from . import events as _ev
+        ev = np.ascontiguousarray(events, dtype=_ev.weierstrass_event_dtypes(curve)[1 if double else 0])
+        h = C.c_void_p()
+        fn = lib.load().zkm_tracegen_weierstrass_double if double else lib.load().zkm_tracegen_weierstrass_add
+        lib.check(fn(self.h, C.c_int(_ev.WEIERSTRASS_CURVES[curve]["index"]), C.c_void_p(ev.ctypes.data if len(ev) else None), C.c_size_t(len(ev)),
+                     C.c_int(fixed_log2_rows), blu.h if blu is not None else None, C.byref(h)))
+        return self._born(h)
+
     def tracegen_misc_instrs(self, events: np.ndarray, fixed_log2_rows: int = -1, blu: "ByteLookups" = None) -> DeviceMatrix:
         """`generate_trace` of the MiscInstrs chip on the device (zkm_tracegen_misc_instrs); dtype events.MISC_EVENT."""
         from . import events as _ev
