@@ -1854,9 +1854,10 @@ __device__ void ed_field_op(const EdRow& R, int base, const uint32_t* a, const u
   if (op == FOP_ADD || op == FOP_SUB) {
     if (op == FOP_ADD) {
       for (int i = 0; i < 8; i++) res[i] = a[i];
-      const uint32_t carry_out = bigfield::add<8>(res, b);        // below 2^256: no carry out for a, b < p < 2^255
-      (void)carry_out;
-      if (bigfield::cmp<8>(res, m.p) >= 0) { bigfield::sub<8>(res, m.p); q[0] = 1; }
+      bigfield::add<8>(res, b);                                   // below 2^256: no carry out for a, b < p < 2^255
+      const uint32_t wraps = bigfield::cmp<8>(res, m.p) >= 0 ? 1u : 0u;
+      if (wraps) bigfield::sub<8>(res, m.p);
+      q[0] = wraps;
       ed_poly_add(van, a, 1); ed_poly_add(van, b, 1); ed_poly_add(van, res, -1);
     } else {                                                       // result + b = a + carry p
       for (int i = 0; i < 8; i++) res[i] = a[i];
@@ -2034,7 +2035,9 @@ template <int NL> struct FieldRow {
     if (kind == FOP_ADD) {
       for (int i = 0; i < NL; i++) res[i] = a[i];
       const uint32_t carry_out = bigfield::add<NL>(res, b);
-      if (carry_out || bigfield::cmp<NL>(res, m.p) >= 0) { bigfield::sub<NL>(res, m.p); q[0] = 1; }
+      const uint32_t wraps = carry_out | (bigfield::cmp<NL>(res, m.p) >= 0 ? 1u : 0u);
+      if (wraps) bigfield::sub<NL>(res, m.p);
+      q[0] = wraps;
       poly_add(van, a, 1); poly_add(van, b, 1); poly_add(van, res, -1);
     } else if (kind == FOP_SUB) {                 // result + b = a + carry p
       for (int i = 0; i < NL; i++) res[i] = a[i];
