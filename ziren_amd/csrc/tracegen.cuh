@@ -1693,6 +1693,9 @@ __global__ __launch_bounds__(THREADS) void sha_compress_rows(const uint32_t* __r
 // op(x) - result(x) - carry(x) p(x) = (x - 256) w(x), w shifted by 2^14 and split into bytes (operations/field/util.rs:21-66) — straight
 // into the columns. Padding rows hold the gadgets of the zero inputs: zero everywhere except witness_high = 2^14 >> 8.
 constexpr int ED_ADD_WIDTH = 1861, ED_ADD_EVENT_WORDS = 180, ED_LIMBS = 32, ED_GADGET = 188;
+// the big-field kernels run 64 threads per block; their lookups (≈ 800 per row, many of them range checks of zero bytes) need the full
+// LDS table: with 1024 slots it crowds, lookups fall through to global atomics on a few hot counters and EdDecompress runs 5x slower
+constexpr int BF_HASH_SLOTS = HASH_SLOTS;
 __constant__ bigfield::Modulus<8> d_ed25519 = {
     {0xffffffedu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0x7fffffffu},
     // floor(2^512 / (2^255 - 19)) = 2^257 + 76 (the next term, 19^2 * 4 / 2^255, is below one)
@@ -1743,17 +1746,17 @@ __global__ __launch_bounds__(64) void ed_add_rows(const uint32_t* __restrict__ e
   enum { E_P_RECORDS = 4, E_Q_RECORDS = 4 + 96 };
   extern __shared__ uint32_t hash_lds[];
   uint32_t* hkeys = hash_lds;
-  uint32_t* hvals = hash_lds + HASH_SLOTS;
+  uint32_t* hvals = hash_lds + BF_HASH_SLOTS;
   const bool count = counts != nullptr;
   if (count) {
-    for (int i = threadIdx.x; i < HASH_SLOTS; i += blockDim.x) { hkeys[i] = HASH_EMPTY; hvals[i] = 0; }
+    for (int i = threadIdx.x; i < BF_HASH_SLOTS; i += blockDim.x) { hkeys[i] = HASH_EMPTY; hvals[i] = 0; }
     __syncthreads();
   }
   const size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (row < height) {
     const bool real = row < n_events;
     const uint32_t* e = events + row * ED_ADD_EVENT_WORDS;
-    const LookupSink sink{hkeys, hvals, HASH_SLOTS - 1, counts};
+    const LookupSink sink{hkeys, hvals, BF_HASH_SLOTS - 1, counts};
     const EdRow R{out, height, row, sink, count && real};
     const bigfield::Modulus<8>& m = d_ed25519;
     uint32_t x1[8], y1[8], x2[8], y2[8];
@@ -1780,15 +1783,24 @@ __global__ __launch_bounds__(64) void ed_add_rows(const uint32_t* __restrict__ e
       clear(); ed_poly_mac(van, a0, b0); ed_poly_add(van, result, -1);
       R.gadget(base, van, result, q);
     };
-    auto den = [&](int base, const uint32_t* num, const uint32_t* bb, bool sign, uint32_t* result) {   // FieldDenCols: result (1 +- b) = a
-      uint32_t dn[8], inv[8];
+    // FieldDenCols: result (1 +- b) = a. The two denominators 1 + d f and 1 - d f are inverted together: one Fermat inverse of their product
+    // (Montgomery's trick), then one product each
+    uint32_t inv_plus[8], inv_minus[8];
+    auto denominators = [&](const uint32_t* bb) {
+      uint32_t dp[8], dm[8], prod[8], inv[8];
       const uint32_t one[8] = {1};
-      if (sign) { for (int i = 0; i < 8; i++) dn[i] = bb[i]; } else { for (int i = 0; i < 8; i++) dn[i] = m.p[i]; bigfield::sub<8>(dn, bb); }
-      bigfield::add<8>(dn, one);
-      if (bigfield::cmp<8>(dn, m.p) >= 0) bigfield::sub<8>(dn, m.p);
-      bool zero = true;
-      for (int i = 0; i < 8; i++) zero = zero && num[i] == 0;
-      if (zero) { for (int i = 0; i < 8; i++) result[i] = 0; } else { bigfield::inverse<8>(dn, m, inv); bigfield::mulmod<8>(num, inv, m, result); }
+      for (int i = 0; i < 8; i++) { dp[i] = bb[i]; dm[i] = m.p[i]; }
+      bigfield::sub<8>(dm, bb);
+      bigfield::add<8>(dp, one); bigfield::add<8>(dm, one);
+      if (bigfield::cmp<8>(dp, m.p) >= 0) bigfield::sub<8>(dp, m.p);
+      if (bigfield::cmp<8>(dm, m.p) >= 0) bigfield::sub<8>(dm, m.p);
+      bigfield::mulmod<8>(dp, dm, m, prod);
+      bigfield::inverse<8>(prod, m, inv);            // 1 - (d f)^2 is not zero for points of the curve (d is not a square)
+      bigfield::mulmod<8>(inv, dm, m, inv_plus);
+      bigfield::mulmod<8>(inv, dp, m, inv_minus);
+    };
+    auto den = [&](int base, const uint32_t* num, const uint32_t* bb, bool sign, uint32_t* result) {
+      bigfield::mulmod<8>(num, sign ? inv_plus : inv_minus, m, result);
       // carry = (b result + (sign ? result : a) - (sign ? a : result)) / p
       bigfield::mul<8, 8>(bb, result, t);
       for (int i = 0; i < 16; i++) t2[i] = i < 8 ? (sign ? result[i] : num[i]) : 0u;
@@ -1806,6 +1818,7 @@ __global__ __launch_bounds__(64) void ed_add_rows(const uint32_t* __restrict__ e
     product(GADGETS + 3 * G, x2, y2, b);
     product(GADGETS + 4 * G, a, b, f);
     product(GADGETS + 5 * G, f, d_ed25519_d, df);
+    denominators(df);
     den(GADGETS + 6 * G, x3n, df, true, res);
     bool ok = true;
     if (real)
@@ -1833,7 +1846,7 @@ __global__ __launch_bounds__(64) void ed_add_rows(const uint32_t* __restrict__ e
   }
   if (count) {
     __syncthreads();
-    for (int i = threadIdx.x; i < HASH_SLOTS; i += blockDim.x)
+    for (int i = threadIdx.x; i < BF_HASH_SLOTS; i += blockDim.x)
       if (hkeys[i] != HASH_EMPTY) atomicAdd(counts + hkeys[i], hvals[i]);
   }
 }
@@ -1898,17 +1911,17 @@ __global__ __launch_bounds__(64) void ed_decompress_rows(const uint32_t* __restr
   enum { E_X_RECORDS = 4, E_Y_RECORDS = 52 };
   extern __shared__ uint32_t hash_lds[];
   uint32_t* hkeys = hash_lds;
-  uint32_t* hvals = hash_lds + HASH_SLOTS;
+  uint32_t* hvals = hash_lds + BF_HASH_SLOTS;
   const bool count = counts != nullptr;
   if (count) {
-    for (int i = threadIdx.x; i < HASH_SLOTS; i += blockDim.x) { hkeys[i] = HASH_EMPTY; hvals[i] = 0; }
+    for (int i = threadIdx.x; i < BF_HASH_SLOTS; i += blockDim.x) { hkeys[i] = HASH_EMPTY; hvals[i] = 0; }
     __syncthreads();
   }
   const size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (row < height) {
     const bool real = row < n_events;
     const uint32_t* e = events + row * ED_DECOMPRESS_EVENT_WORDS;
-    const LookupSink sink{hkeys, hvals, HASH_SLOTS - 1, counts};
+    const LookupSink sink{hkeys, hvals, BF_HASH_SLOTS - 1, counts};
     const EdRow R{out, height, row, sink, count && real};
     const bigfield::Modulus<8>& m = d_ed25519;
     int why = 0;
@@ -1978,7 +1991,7 @@ __global__ __launch_bounds__(64) void ed_decompress_rows(const uint32_t* __restr
   }
   if (count) {
     __syncthreads();
-    for (int i = threadIdx.x; i < HASH_SLOTS; i += blockDim.x)
+    for (int i = threadIdx.x; i < BF_HASH_SLOTS; i += blockDim.x)
       if (hkeys[i] != HASH_EMPTY) atomicAdd(counts + hkeys[i], hvals[i]);
   }
 }
@@ -2069,17 +2082,17 @@ __global__ __launch_bounds__(64) void weierstrass_rows(const uint32_t* __restric
   constexpr int EV_WORDS = DOUBLE ? 3 + 6 * W : 4 + 11 * W, E_P = DOUBLE ? 3 : 4, E_Q = 4 + 6 * W;
   extern __shared__ uint32_t hash_lds[];
   uint32_t* hkeys = hash_lds;
-  uint32_t* hvals = hash_lds + HASH_SLOTS;
+  uint32_t* hvals = hash_lds + BF_HASH_SLOTS;
   const bool count = counts != nullptr;
   if (count) {
-    for (int i = threadIdx.x; i < HASH_SLOTS; i += blockDim.x) { hkeys[i] = HASH_EMPTY; hvals[i] = 0; }
+    for (int i = threadIdx.x; i < BF_HASH_SLOTS; i += blockDim.x) { hkeys[i] = HASH_EMPTY; hvals[i] = 0; }
     __syncthreads();
   }
   const size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (row < height) {
     const bool real = row < n_events;
     const uint32_t* e = events + row * EV_WORDS;
-    const LookupSink sink{hkeys, hvals, HASH_SLOTS - 1, counts};
+    const LookupSink sink{hkeys, hvals, BF_HASH_SLOTS - 1, counts};
     const FieldRow<NL> R{out, height, row, sink, count && real, field};
     uint32_t px[NL], py[NL], qx[NL], qy[NL];
     bool ok = true;
@@ -2150,7 +2163,7 @@ __global__ __launch_bounds__(64) void weierstrass_rows(const uint32_t* __restric
   }
   if (count) {
     __syncthreads();
-    for (int i = threadIdx.x; i < HASH_SLOTS; i += blockDim.x)
+    for (int i = threadIdx.x; i < BF_HASH_SLOTS; i += blockDim.x)
       if (hkeys[i] != HASH_EMPTY) atomicAdd(counts + hkeys[i], hvals[i]);
   }
 }
