@@ -1,7 +1,14 @@
-"""BASELINE config 4 (multi-shard fan-out) on one GPU: N = 8 distinct SYN-21 shards (SURVEY.md 8d's mapping of the keccak multi-shard
+"""BASELINE config 4 (multi-shard fan-out) on one GPU, twice: the synthetic mapping and the real workload.
+
+(1) N = 8 distinct SYN-21 shards (SURVEY.md 8d's mapping of the keccak multi-shard
 workload) go through ziren_amd.farm.Farm — process group on RCCL (ZKM_FORCE_DIST=1, world 1), shards claimed from the shared work queue,
 whole proof streams gathered to rank 0 — and every gathered proof is accepted by the restated shard verifier; the gathered table is in
-shard order. The N > 1 ranks path of the same code runs over gloo in tests/test_farm_gloo.py."""
+shard order. The N > 1 ranks path of the same code runs over gloo in tests/test_farm_gloo.py.
+
+(2) The workload config 4 names — a guest that hashes with the KECCAK_SPONGE precompile, several shards (examples/keccak-precompile): every
+shard of such a run (CPU shards, the Poseidon2 and Keccak precompile shards, the memory shard) is claimed from the farm's queue, generated on
+the device from its events and proven; the gathered proofs pass the restated machine verifier (public values chain, global digests sum to
+zero)."""
 import os
 import socket
 import subprocess
@@ -74,3 +81,63 @@ def test_gpu_eight_shard_farm_over_rccl(tmp_path):
     r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=1100)
     assert r.returncode == 0, r.stderr[-3000:]
     assert '"ok": true' in r.stdout
+
+
+MACHINE_WORKER = textwrap.dedent("""
+    import sys, json
+    import numpy as np
+    sys.path.insert(0, %r)
+    sys.path.insert(0, %r)
+    from ziren_amd import abi, farm, field as F, miniexec as M, prover, synth
+    import oracle_lib as O
+    import machine_lib as ML
+    from test_machine import ZERO_DIGEST, check_machine_airs
+    m = M.run_machine(3000, seed=5, shard_cycles=1024, poseidon2_calls=1, keccak_calls=2)
+    N = len(m.shards)
+    f = farm.Farm()
+    assert f.dist is not None and f.device.type == "cuda", "the farm must be on RCCL here"
+    fri = abi.FriConfig(1, 84, 16)
+    ctx = prover.Context(f.local_rank)
+    pc_start = F.to_monty(m.pc_base)
+    state = {}
+    def prove(k):
+        dev = ML.Device(ctx)
+        dcs = ML.build_shard(dev, m, k)                       # traces born on the device from the shard's events
+        hp = prover.HipProver(dcs, fri, synth.NUM_PV_ELTS, ctx=ctx)
+        hp.specialize_quotient_kernels(dcs)
+        if "pk" not in state:
+            state["pk"] = hp.setup([ctx.tracegen_byte_table(), ctx.tracegen_program(m.program, m.pc_base, dcs[-1].log_height)], [0, 0], pc_start, ZERO_DIGEST)
+        ch = prover.new_challenger()
+        state["pk"].observe_into(ch)
+        proof = hp.prove_shard(state["pk"], ML.shard_public_values(m.shards[k]), [c.trace for c in dcs], ch).copy()
+        for c in dcs:
+            c.trace.free()
+        dev.blu.free()
+        return proof
+    f.barrier()
+    ids, proofs = f.run_queue(N, prove)
+    got = f.gather_proofs(ids, proofs, N)
+    assert len(got) == N
+    oshards = check_machine_airs(O, m)
+    opk = O.Pk([oshards[0][-2].prep_trace, oshards[0][-1].prep_trace], [0, 0], pc_start, ZERO_DIGEST, fri.log_blowup)
+    assert ML.verify_machine(O, opk, oshards, got, fri, synth.NUM_PV_ELTS, m.pc_base, ZERO_DIGEST) is None
+    assert ML.verify_machine(O, opk, oshards[:-2] + oshards[-1:], got[:-2] + got[-1:], fri, synth.NUM_PV_ELTS, m.pc_base, ZERO_DIGEST) is not None
+    kinds = [s.kind for s in m.shards]
+    print(json.dumps({"ok": True, "shards": N, "kinds": kinds, "keccak_blocks": int(len(m.shards[-2].record.keccak_sponge))}))
+    f.close()
+""")
+
+
+@pytest.mark.gpu
+def test_gpu_keccak_machine_through_the_farm(tmp_path):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    script = tmp_path / "farm_machine_worker.py"
+    script.write_text(MACHINE_WORKER % (ROOT, os.path.join(ROOT, "tests")))
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), ZKM_FORCE_DIST="1",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=1100)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert '"ok": true' in r.stdout and '"precompile"' in r.stdout
