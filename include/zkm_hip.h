@@ -492,6 +492,16 @@ int zkm_tracegen_weierstrass_add(zkm_ctx* ctx, int curve, const void* events, si
                                  zkm_matrix** out);
 int zkm_tracegen_weierstrass_double(zkm_ctx* ctx, int curve, const void* events, size_t n_events, int fixed_log2_rows, zkm_byte_lookups* blu,
                                     zkm_matrix** out);
+
+/* The field-tower precompiles (crates/core/machine/src/syscall/precompiles/fptower/fp.rs, fp2_addsub.rs, fp2_mul.rs): Bn254 / Bls12381 x FpOpAssign,
+ * Fp2AddSubAssign, Fp2MulAssign; replace their generate_trace, byte lookups into `blu`. `field` is ZKM_CURVE_BN254 or ZKM_CURVE_BLS12381. Events:
+ * FpOpEvent / Fp2AddSubEvent / Fp2MulEvent (crates/core/executor/src/events/precompiles/fptower.rs:23-94) flattened — shard, clk, x_ptr, y_ptr,
+ * [op: FieldOperation as a word, Add 0, Mul 1, Sub 2; not for Fp2Mul], W zkm_memory_write_record of x, W zkm_memory_read_record of y, W = 8 / 12
+ * words for FpOp, 16 / 24 for the Fp2 chips. Fails when an operand is not below the modulus or the words written to x are not the result. */
+int zkm_tracegen_fp_op(zkm_ctx* ctx, int field, const void* events, size_t n_events, int fixed_log2_rows, zkm_byte_lookups* blu, zkm_matrix** out);
+int zkm_tracegen_fp2_addsub(zkm_ctx* ctx, int field, const void* events, size_t n_events, int fixed_log2_rows, zkm_byte_lookups* blu,
+                            zkm_matrix** out);
+int zkm_tracegen_fp2_mul(zkm_ctx* ctx, int field, const void* events, size_t n_events, int fixed_log2_rows, zkm_byte_lookups* blu, zkm_matrix** out);
 /* The MiscInstrs chip (crates/core/machine/src/misc/others/: SEXT EXT INS MADDU MSUBU MADD MSUB TEQ): replaces generate_trace
  * (trace.rs:42-84), which also records the byte lookups (counted into `blu` if given). Events are the #[repr(C)] MiscEvents of
  * crates/core/executor/src/events/instr.rs:239-261 (60 bytes). 72 columns, zero padding rows. */

@@ -2060,4 +2060,77 @@ static inline std::vector<F> generate_weierstrass(const uint32_t* events, size_t
   return t;
 }
 
+// ---- Field-tower precompiles (syscall/precompiles/fptower/): FpOp (kind 0: one FieldOpCols, the operation chosen per event), Fp2AddSub (kind 1: two,
+// add or subtract per event), Fp2Mul (kind 2: four products, a difference, a sum) over the base field of Bn254 or Bls12381. Events: shard, clk,
+// x_ptr, y_ptr, [op — FieldOperation as a word: Add 0, Mul 1, Sub 2 —] W write records of x, W read records of y (W = N / 4 for FpOp, N / 2 for
+// the Fp2 chips; no op word for Fp2Mul). x is the records' previous values, y their values. Padding rows: the operations of the zero inputs with
+// the flag is_add set (fp.rs:150-166, fp2_addsub.rs:158-178; Fp2Mul has no flag: fp2_mul.rs:186-204).
+static inline std::vector<F> generate_fp_tower(const uint32_t* events, size_t n_events, int kind, int n_limbs, const uint8_t* modulus_bytes, int64_t offset,
+                                               int fixed_log2_rows, size_t* height, uint64_t* byte_counts) {
+  using namespace bigfield;
+  const int W = kind == 0 ? n_limbs / 4 : n_limbs / 2, G = 6 * n_limbs - 4, HEAD = kind == 0 ? 8 : kind == 1 ? 6 : 5;
+  const int X_ACCESS = HEAD, Y_ACCESS = HEAD + 13 * W, GADGETS = HEAD + 22 * W, NG = kind == 0 ? 1 : kind == 1 ? 2 : 6;
+  const size_t width = GADGETS + NG * G, ev_words = (kind == 2 ? 4 : 5) + 11 * W;
+  const size_t h = padded_rows(n_events, fixed_log2_rows);
+  std::vector<F> t(h * width, 0);
+  std::vector<ByteLookup> lk;
+  const Big p = from_bytes(modulus_bytes, n_limbs);
+  auto kind_of = [](uint32_t op) { return op == 0 ? FOP_ADD : op == 1 ? FOP_MUL : FOP_SUB; };
+  auto fill = [&](F* r, const Big* x, const Big* y, uint32_t op, std::vector<ByteLookup>* sink, Big* out) {
+    const FieldGadgets g{p, n_limbs, offset, sink};
+    auto col = [&](int k) { return r + GADGETS + G * k; };
+    if (kind == 0) {
+      out[0] = field_op_cols(g, col(0), x[0], y[0], kind_of(op));
+    } else if (kind == 1) {
+      out[0] = field_op_cols(g, col(0), x[0], y[0], kind_of(op));
+      out[1] = field_op_cols(g, col(1), x[1], y[1], kind_of(op));
+    } else {        // a0_mul_b0, a1_mul_b1, a0_mul_b1, a1_mul_b0, c0, c1
+      const Big a0b0 = field_op_cols(g, col(0), x[0], y[0], FOP_MUL), a1b1 = field_op_cols(g, col(1), x[1], y[1], FOP_MUL);
+      const Big a0b1 = field_op_cols(g, col(2), x[0], y[1], FOP_MUL), a1b0 = field_op_cols(g, col(3), x[1], y[0], FOP_MUL);
+      out[0] = field_op_cols(g, col(4), a0b0, a1b1, FOP_SUB);
+      out[1] = field_op_cols(g, col(5), a0b1, a1b0, FOP_ADD);
+    }
+  };
+  std::vector<F> padding(width, 0);
+  Big zero2[2], out[2];
+  fill(padding.data(), zero2, zero2, 0, nullptr, out);
+  if (kind != 2) padding[3] = 1;              // is_add
+  std::vector<uint32_t> xw(W), yw(W);
+  for (size_t i = 0; i < h; i++) {
+    F* r = t.data() + i * width;
+    if (i >= n_events) { std::copy(padding.begin(), padding.end(), r); continue; }
+    const uint32_t* e = events + i * ev_words;
+    const uint32_t op = kind == 2 ? 1u : e[4];
+    if (kind == 0 ? op > 2 : (kind == 1 && op != 0 && op != 2)) throw std::runtime_error("tracegen: field-tower operation");
+    const MemoryWriteRecord* xrec = (const MemoryWriteRecord*)(e + (kind == 2 ? 4 : 5));
+    const MemoryReadRecord* yrec = (const MemoryReadRecord*)(e + (kind == 2 ? 4 : 5) + 6 * W);
+    r[0] = 1; r[1] = fu32(e[0]); r[2] = fu32(e[1]);
+    if (kind == 0) { r[3] = op == 0; r[4] = op == 2; r[5] = op == 1; r[6] = fu32(e[2]); r[7] = fu32(e[3]); }
+    else if (kind == 1) { r[3] = op == 0; r[4] = fu32(e[2]); r[5] = fu32(e[3]); }
+    else { r[3] = fu32(e[2]); r[4] = fu32(e[3]); }
+    for (int k = 0; k < W; k++) { xw[k] = xrec[k].prev_value; yw[k] = yrec[k].value; }
+    const int per = n_limbs / 4;
+    Big x[2], y[2];
+    x[0] = from_words(xw.data(), per); y[0] = from_words(yw.data(), per);
+    if (kind != 0) { x[1] = from_words(xw.data() + per, per); y[1] = from_words(yw.data() + per, per); }
+    for (int k = 0; k < (kind == 0 ? 1 : 2); k++)
+      if (cmp(x[k], p) >= 0 || cmp(y[k], p) >= 0) throw std::runtime_error("tracegen: field-tower operand is not below the modulus");
+    fill(r, x, y, op, &lk, out);
+    for (int k = 0; k < W; k++) {
+      const MemoryReadRecord& m = yrec[k];
+      memory_access_cols(m.value, m.shard, m.timestamp, m.prev_shard, m.prev_timestamp, r + Y_ACCESS + 9 * k, &lk);
+    }
+    for (int k = 0; k < W; k++) {
+      memory_write_cols(xrec[k], r + X_ACCESS + 13 * k, &lk);
+      const Big& coord = out[k / per];
+      for (int c = 0; c < 4; c++)
+        if (r[X_ACCESS + 13 * k + 4 + c] != limb(coord, 4 * (k % per) + c)) throw std::runtime_error("tracegen: field-tower event does not write the result");
+    }
+  }
+  if (byte_counts)
+    for (const ByteLookup& b : lk) byte_counts[((size_t)b.b * 256 + b.c) * NUM_BYTE_OPS + b.op]++;
+  *height = h;
+  return t;
+}
+
 }  // namespace tracegen

@@ -83,6 +83,8 @@ class Oracle:
             return fn[what](a[0], a[1], c)
         if what == "weierstrass":
             return O.tracegen_weierstrass(a[0], a[1], a[2], a[3], c)
+        if what == "fp_tower":
+            return O.tracegen_fp_tower(a[0], a[1], a[2], a[3], c)
         if what == "syscall_table":
             return O.tracegen_syscall(a[0], a[1], a[2], c)
         if what == "memory_global":
@@ -121,6 +123,8 @@ class Device:
             return fn[what](a[0], a[1], blu)
         if what == "weierstrass":
             return ctx.tracegen_weierstrass(a[0], a[1], a[2], a[3], blu)
+        if what == "fp_tower":
+            return ctx.tracegen_fp_tower(a[0], a[1], a[2], a[3], blu)
         if what == "syscall_table":
             return ctx.tracegen_syscall(a[0], a[1], a[2], blu)
         if what == "memory_global":
@@ -196,6 +200,11 @@ def build_shard(src, machine, k):
             curve, double = kind.split("_")[0], kind.endswith("_double")
             lh = log2_rows(len(ev))
             add(chips.record_weierstrass_chip(curve, double, lh), src.trace("weierstrass", curve, double, ev, lh))
+        if getattr(rec, "fp_tower", None) is not None:
+            kind_key, ev = rec.fp_tower
+            field, kind = kind_key.split("_", 1)
+            lh = log2_rows(len(ev))
+            add(chips.record_fp_tower_chip(field, kind, lh), src.trace("fp_tower", field, kind, ev, lh))
     else:
         for finalize, ev, prev in ((False, rec.memory_init, sh.pv["previous_init_addr"]), (True, rec.memory_finalize, sh.pv["previous_finalize_addr"])):
             if len(ev):

@@ -435,6 +435,21 @@ def tracegen_weierstrass(curve, double, events, fixed_log2_rows=-1, byte_counts=
                            C.c_int(int(double)), C.c_int(n), mod, a, C.c_uint32(c["witness_offset"]), C.c_int(fixed_log2_rows), tail=bc)
 
 
+FP_TOWER_KINDS = {"fp": 0, "fp2_addsub": 1, "fp2_mul": 2}
+
+
+def tracegen_fp_tower(field, kind, events, fixed_log2_rows=-1, byte_counts=None):
+    """<Field>FpOpAssign / Fp2AddSubAssign / Fp2MulAssign rows from flattened FpOpEvents / Fp2AddSubEvents / Fp2MulEvents (events.fp_tower_event_dtype)."""
+    from ziren_amd import events as E
+    c = E.WEIERSTRASS_CURVES[field]
+    ev = np.ascontiguousarray(events, dtype=E.fp_tower_event_dtype(field, kind))
+    n = c["n_limbs"]
+    mod = (C.c_uint8 * n)(*c["p"].to_bytes(n, "little"))
+    bc = (abi.as_u32p(byte_counts),) if byte_counts is not None else (None,)
+    return _rows_then_fill(lib().orc_tracegen_fp_tower, E.fp_tower_width(field, kind), C.c_void_p(ev.ctypes.data), C.c_size_t(len(ev)),
+                           C.c_int(FP_TOWER_KINDS[kind]), C.c_int(n), mod, C.c_uint32(c["witness_offset"]), C.c_int(fixed_log2_rows), tail=bc)
+
+
 def septic_known_answers(a, b):
     """((z^i)^p, (z^i)^(p^2) for i = 1..6, a * b, normalised sqrt(a^2)) in the septic extension, canonical words."""
     a = np.ascontiguousarray(a, dtype=np.uint32)

@@ -55,6 +55,10 @@ def check_machine_airs(oracle, m):
                    "Poseidon2Permute": chips.record_poseidon2_permute_constraints, "KeccakSponge": chips.record_keccak_sponge_constraints,
                    "ShaExtend": chips.record_sha_extend_constraints, "ShaCompress": chips.record_sha_compress_constraints,
                    "EdAddAssign": chips.record_ed_add_constraints, "EdDecompress": chips.record_ed_decompress_constraints}.get(c.name)
+            if rec is None and ("FpOpAssign" in c.name or "Fp2" in c.name):
+                field = "Bn254" if c.name.startswith("Bn254") else "Bls12381"
+                kind = "fp" if "FpOp" in c.name else "fp2_mul" if "Fp2Mul" in c.name else "fp2_addsub"
+                rec = lambda field=field, kind=kind: chips.record_fp_tower_constraints(field, kind)      # noqa: E731
             if rec is None and c.name.endswith(("AddAssign", "DoubleAssign")):
                 curve, double = c.name.replace("DoubleAssign", "").replace("AddAssign", ""), c.name.endswith("DoubleAssign")
                 rec = lambda curve=curve, double=double: chips.record_weierstrass_constraints(curve, double)      # noqa: E731

@@ -2263,6 +2263,89 @@ def record_weierstrass_chip(curve: str, double: bool, log_height: int) -> Record
     return _finish(record_weierstrass_constraints(curve, double), name, log_height, E.weierstrass_widths(curve)[1 if double else 0], True)
 
 
+def _field_op_variable(r: _Rec, cols, a, bb, modulus, n_limbs, witness_offset, is_add, is_sub, is_mul, is_real):
+    """FieldOpCols::eval_variable (operations/field/field_op.rs:227-261) with is_div = 0: the operation is chosen by flags, so the identity
+    is the flag-weighted sum of the three."""
+    b = r.b
+    result = cols[0:n_limbs]
+    scale = lambda poly, k: [x * k for x in poly]      # noqa: E731
+    p_result = _poly_add(scale(result, is_add + is_mul), scale(a, is_sub))
+    p_op = _poly_add(_poly_add(scale(_poly_add(a, bb), is_add), scale(_poly_add(result, bb), is_sub)), scale(_poly_mul(a, bb), is_mul))
+    van = _poly_sub(b, _poly_sub(b, p_op, p_result), _poly_mul(cols[n_limbs:2 * n_limbs], modulus))
+    _field_gadget(r, van, cols, n_limbs, witness_offset, is_real)
+
+
+def _fp_tower(r: _Rec, field: str, kind: str):
+    """FpOpChip::eval (syscall/precompiles/fptower/fp.rs:203-289), Fp2AddSubAssignChip::eval (fp2_addsub.rs:227-320), Fp2MulAssignChip::eval
+    (fp2_mul.rs:244-360) over the base field of Bn254 or Bls12381; x is overwritten at clk + 1, y read at clk."""
+    c = E.WEIERSTRASS_CURVES[field]
+    l, b = r.local, r.b
+    N, off = c["n_limbs"], c["witness_offset"]
+    G = 6 * N - 4
+    modulus = _limbs_of_const(b, c["p"], N)
+    words = N // 4 if kind == "fp" else N // 2
+    head = {"fp": 8, "fp2_addsub": 6, "fp2_mul": 5}[kind]
+    X_ACCESS, Y_ACCESS, GADGETS = head, head + 13 * words, head + 22 * words
+    is_real = l[0]
+    x_access = [l[X_ACCESS + 13 * i:X_ACCESS + 13 * i + 13] for i in range(words)]
+    y_access = [l[Y_ACCESS + 9 * i:Y_ACCESS + 9 * i + 9] for i in range(words)]
+    prev = lambda acc, lo, hi: [x for a in acc[lo:hi] for x in a[0:4]]      # noqa: E731
+    col = lambda k: l[GADGETS + G * k:GADGETS + G * k + G]                  # noqa: E731
+    res = lambda k: l[GADGETS + G * k:GADGETS + G * k + N]                  # noqa: E731
+    codes = E.FP_TOWER_CODES[field]
+    if kind == "fp":
+        SHARD, CLK, IS_ADD, IS_SUB, IS_MUL, X_PTR, Y_PTR = 1, 2, 3, 4, 5, 6, 7
+        for f in (IS_ADD, IS_SUB, IS_MUL):
+            b.assert_bool(l[f])
+        b.assert_eq(l[IS_ADD] + l[IS_SUB] + l[IS_MUL], 1)
+        _field_op_variable(r, col(0), prev(x_access, 0, words), prev(y_access, 0, words), modulus, N, off, l[IS_ADD], l[IS_SUB], l[IS_MUL], is_real)
+        outs = [(0, 0)]
+        syscall = l[IS_ADD] * (codes["fp_add"] & 0xffff) + l[IS_SUB] * (codes["fp_sub"] & 0xffff) + l[IS_MUL] * (codes["fp_mul"] & 0xffff)
+    elif kind == "fp2_addsub":
+        SHARD, CLK, IS_ADD, X_PTR, Y_PTR = 1, 2, 3, 4, 5
+        b.assert_bool(l[IS_ADD])
+        h = words // 2
+        for k, (lo, hi) in enumerate(((0, h), (h, words))):
+            _field_op_variable(r, col(k), prev(x_access, lo, hi), prev(y_access, lo, hi), modulus, N, off, l[IS_ADD], 1 - l[IS_ADD], b.const(0), is_real)
+        outs = [(0, 0), (1, h)]
+        syscall = l[IS_ADD] * (codes["fp2_add"] & 0xffff) + (1 - l[IS_ADD]) * (codes["fp2_sub"] & 0xffff)
+    else:
+        SHARD, CLK, X_PTR, Y_PTR = 1, 2, 3, 4
+        h = words // 2
+        px, py, qx, qy = prev(x_access, 0, h), prev(x_access, h, words), prev(y_access, 0, h), prev(y_access, h, words)
+        A0B0, A1B1, A0B1, A1B0, C0, C1 = range(6)
+        op = lambda k, a, bb, o: _field_op(r, col(k), a, bb, o, modulus, N, off, is_real)      # noqa: E731
+        op(A0B0, px, qx, "mul")
+        op(A1B1, py, qy, "mul")
+        op(C0, res(A0B0), res(A1B1), "sub")
+        op(A0B1, px, qy, "mul")
+        op(A1B0, py, qx, "mul")
+        op(C1, res(A0B1), res(A1B0), "add")
+        outs = [(C0, 0), (C1, h)]
+        syscall = b.const(codes["fp2_mul"] & 0xffff)
+    for k, first_word in outs:       # the result is what is written (assert_all_eq of result and value_as_limbs)
+        for i in range(N):
+            b.when(is_real).assert_eq(res(k)[i], x_access[first_word + i // 4][4 + i % 4])
+    for i in range(words):
+        r.eval_memory_access(l[SHARD], l[CLK], l[Y_PTR] + 4 * i, y_access[i][0:4], y_access[i], is_real)
+    for i in range(words):
+        r.eval_memory_access(l[SHARD], l[CLK] + 1, l[X_PTR] + 4 * i, x_access[i][0:4], x_access[i][4:13], is_real)
+    r.receives.append(air.Lookup([air.to_virtual_pair(v) for v in [l[SHARD], l[CLK], syscall, l[X_PTR], l[Y_PTR]]], air.to_virtual_pair(is_real), air.KIND_SYSCALL))
+
+
+def record_fp_tower_constraints(field: str, kind: str) -> _Rec:
+    r = _Rec(E.fp_tower_width(field, kind))
+    _fp_tower(r, field, kind)
+    return r
+
+
+def record_fp_tower_chip(field: str, kind: str, log_height: int) -> RecordedChip:
+    """<Field>FpOpAssign, <Field>Fp2AddSubAssign, <Field>Fp2MulAssign for Bn254 and Bls12381 (crates/core/machine/src/syscall/precompiles/fptower/);
+    local_only as the reference declares them."""
+    name = {"Bn254": "Bn254", "Bls12381": "Bls12831" if kind != "fp" else "Bls12381"}[field] + {"fp": "FpOpAssign", "fp2_addsub": "Fp2AddSubAssign", "fp2_mul": "Fp2MulAssign"}[kind]
+    return _finish(record_fp_tower_constraints(field, kind), name, log_height, E.fp_tower_width(field, kind), True)
+
+
 def record_ed_add_constraints() -> _Rec:
     r = _Rec(E.ED_ADD_WIDTH)
     _ed_add(r)

@@ -812,6 +812,83 @@ int zkm_tracegen_weierstrass_double(zkm_ctx* ctx, int curve, const void* events,
   return tracegen_weierstrass(ctx, curve, true, events, n_events, fixed_log2_rows, blu, out, "zkm_tracegen_weierstrass_double");
 }
 
+extern "C++" {
+template <int NL, int KIND>
+static void launch_fp_tower(zkm_ctx* ctx, const tracegen::CurveField<NL>& field, const uint32_t* d_events, size_t n_events, size_t height, uint32_t* out,
+                            uint32_t* counts, int* d_bad, double bytes) {
+  KLAUNCH(ctx, KIND == 0 ? "tracegen_fp_op" : KIND == 1 ? "tracegen_fp2_addsub" : "tracegen_fp2_mul", bytes, (tracegen::fp_tower_rows<NL, KIND>),
+          dim3(div_up(height, (size_t)64)), dim3(64), counts ? 2 * tracegen::BF_HASH_SLOTS * sizeof(uint32_t) : 0, d_events, n_events, height, out, counts,
+          d_bad, field);
+}
+}  // extern "C++"
+static int tracegen_fp_tower(zkm_ctx* ctx, int field, int kind, const void* events, size_t n_events, int fixed_log2_rows, zkm_byte_lookups* blu,
+                             zkm_matrix** out, const char* who) {
+  API_BEGIN
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIP_CHECK(hipSetDevice(ctx->device));
+  if (field != 2 && field != 3) throw std::runtime_error(std::string(who) + ": the field is ZKM_CURVE_BN254 or ZKM_CURVE_BLS12381");
+  if (n_events && !events) throw std::runtime_error(std::string(who) + ": null events");
+  const int nl = field == 3 ? 12 : 8, W = kind == 0 ? nl : 2 * nl, G = 6 * 4 * nl - 4;
+  const size_t ev_words = (kind == 2 ? 4 : 5) + 11 * W, width = (kind == 0 ? 8 : kind == 1 ? 6 : 5) + 22 * W + (kind == 0 ? 1 : kind == 1 ? 2 : 6) * G;
+  const size_t height = padded_trace_rows(n_events, fixed_log2_rows, who);
+  ctx->begin_timing();
+  zkm_matrix* m = new zkm_matrix();
+  m->h = height; m->w = width;
+  uint32_t* d_events = nullptr;
+  int* d_bad = nullptr;
+  try {
+    m->d = ctx->alloc_n<uint32_t>(height * m->w);
+    const size_t ev_bytes = n_events * ev_words * 4;
+    d_events = (uint32_t*)ctx->alloc(std::max<size_t>(ev_bytes, 4));
+    d_bad = (int*)ctx->alloc(4);
+    HIP_CHECK(hipMemsetAsync(d_bad, 0, 4, ctx->stream));
+    if (n_events) HIP_CHECK(hipMemcpyAsync(d_events, events, ev_bytes, hipMemcpyHostToDevice, ctx->stream));
+    uint32_t* counts = blu ? blu->counts : nullptr;
+    const double bytes = (double)ev_bytes + 4.0 * height * m->w;
+    if (nl == 8) {
+      tracegen::CurveField<8> f;
+      f.m = k_curves8[2].m;
+      memcpy(f.a, k_curves8[2].a, sizeof f.a);
+      f.witness_offset = 1 << 14;
+      if (kind == 0) launch_fp_tower<8, 0>(ctx, f, d_events, n_events, height, m->d, counts, d_bad, bytes);
+      else if (kind == 1) launch_fp_tower<8, 1>(ctx, f, d_events, n_events, height, m->d, counts, d_bad, bytes);
+      else launch_fp_tower<8, 2>(ctx, f, d_events, n_events, height, m->d, counts, d_bad, bytes);
+    } else {
+      tracegen::CurveField<12> f;
+      f.m = k_curve_bls12381.m;
+      memcpy(f.a, k_curve_bls12381.a, sizeof f.a);
+      f.witness_offset = 1 << 15;
+      if (kind == 0) launch_fp_tower<12, 0>(ctx, f, d_events, n_events, height, m->d, counts, d_bad, bytes);
+      else if (kind == 1) launch_fp_tower<12, 1>(ctx, f, d_events, n_events, height, m->d, counts, d_bad, bytes);
+      else launch_fp_tower<12, 2>(ctx, f, d_events, n_events, height, m->d, counts, d_bad, bytes);
+    }
+    int bad = 0;
+    HIP_CHECK(hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, ctx->stream));
+    ctx->mark("trace generation");
+    ctx->end_timing(false);
+    if (bad) throw std::runtime_error(std::string(who) + ": an operand is not below the field modulus, the operation is not one this chip has, or the words written to x are not the result");
+  } catch (...) {
+    if (d_events) ctx->release(d_events);
+    if (d_bad) ctx->release(d_bad);
+    if (m->d) ctx->release(m->d);
+    delete m;
+    throw;
+  }
+  ctx->release(d_events);
+  ctx->release(d_bad);
+  *out = m;
+  API_END
+}
+int zkm_tracegen_fp_op(zkm_ctx* ctx, int field, const void* events, size_t n_events, int fixed_log2_rows, zkm_byte_lookups* blu, zkm_matrix** out) {
+  return tracegen_fp_tower(ctx, field, 0, events, n_events, fixed_log2_rows, blu, out, "zkm_tracegen_fp_op");
+}
+int zkm_tracegen_fp2_addsub(zkm_ctx* ctx, int field, const void* events, size_t n_events, int fixed_log2_rows, zkm_byte_lookups* blu, zkm_matrix** out) {
+  return tracegen_fp_tower(ctx, field, 1, events, n_events, fixed_log2_rows, blu, out, "zkm_tracegen_fp2_addsub");
+}
+int zkm_tracegen_fp2_mul(zkm_ctx* ctx, int field, const void* events, size_t n_events, int fixed_log2_rows, zkm_byte_lookups* blu, zkm_matrix** out) {
+  return tracegen_fp_tower(ctx, field, 2, events, n_events, fixed_log2_rows, blu, out, "zkm_tracegen_fp2_mul");
+}
+
 int zkm_tracegen_exp_reverse_bits(zkm_ctx* ctx, const uint32_t* bases, const uint32_t* bits, const uint32_t* offsets, size_t n_events,
                                   int fixed_log2_rows, zkm_matrix** out) {
   API_BEGIN

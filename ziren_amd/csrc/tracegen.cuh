@@ -2168,6 +2168,92 @@ __global__ __launch_bounds__(64) void weierstrass_rows(const uint32_t* __restric
   }
 }
 
+// ---- Field-tower precompiles (syscall/precompiles/fptower/fp.rs, fp2_addsub.rs, fp2_mul.rs) over the base field of Bn254 (NL = 8) or Bls12381
+// (NL = 12): KIND 0 FpOp (one FieldOpCols, the operation — FieldOperation as a word: Add 0, Mul 1, Sub 2 — per event), 1 Fp2AddSub (two), 2 Fp2Mul
+// (four products, a difference, a sum). x is overwritten at clk + 1, y is read at clk. Padding rows: zero inputs with is_add set.
+template <int NL, int KIND>
+__global__ __launch_bounds__(64) void fp_tower_rows(const uint32_t* __restrict__ events, size_t n_events, size_t height, uint32_t* __restrict__ out,
+                                                    uint32_t* counts, int* __restrict__ bad, const CurveField<NL> field) {
+  constexpr int N = 4 * NL, G = FieldRow<NL>::G, W = KIND == 0 ? NL : 2 * NL, HEAD = KIND == 0 ? 8 : KIND == 1 ? 6 : 5;
+  constexpr int X_ACCESS = HEAD, Y_ACCESS = HEAD + 13 * W, GADGETS = HEAD + 22 * W, E_HEAD = KIND == 2 ? 4 : 5, EV_WORDS = E_HEAD + 11 * W;
+  extern __shared__ uint32_t hash_lds[];
+  uint32_t* hkeys = hash_lds;
+  uint32_t* hvals = hash_lds + BF_HASH_SLOTS;
+  const bool count = counts != nullptr;
+  if (count) {
+    for (int i = threadIdx.x; i < BF_HASH_SLOTS; i += blockDim.x) { hkeys[i] = HASH_EMPTY; hvals[i] = 0; }
+    __syncthreads();
+  }
+  const size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (row < height) {
+    const bool real = row < n_events;
+    const uint32_t* e = events + row * EV_WORDS;
+    const LookupSink sink{hkeys, hvals, BF_HASH_SLOTS - 1, counts};
+    const FieldRow<NL> R{out, height, row, sink, count && real, field};
+    const uint32_t op = KIND == 2 ? 1u : (real ? e[4] : 0u);
+    bool ok = KIND == 0 ? op <= 2 : (KIND == 1 ? op == 0 || op == 2 : true);
+    const int fop = op == 0 ? FOP_ADD : op == 1 ? FOP_MUL : FOP_SUB;
+    uint32_t x0[NL], x1[NL], y0[NL], y1[NL];
+    for (int k = 0; k < NL; k++) {
+      x0[k] = real ? e[E_HEAD + 6 * k + 3] : 0u;
+      y0[k] = real ? e[E_HEAD + 6 * W + 5 * k] : 0u;
+      x1[k] = real && KIND != 0 ? e[E_HEAD + 6 * (NL + k) + 3] : 0u;
+      y1[k] = real && KIND != 0 ? e[E_HEAD + 6 * W + 5 * (NL + k)] : 0u;
+    }
+    if (bigfield::cmp<NL>(x0, field.m.p) >= 0 || bigfield::cmp<NL>(y0, field.m.p) >= 0 || bigfield::cmp<NL>(x1, field.m.p) >= 0 ||
+        bigfield::cmp<NL>(y1, field.m.p) >= 0) {
+      ok = false;
+      for (int k = 0; k < NL; k++) x0[k] = x1[k] = y0[k] = y1[k] = 0;
+    }
+    int32_t van[2 * N - 1];
+    uint32_t out0[NL], out1[NL];
+    auto col = [&](int k) { return GADGETS + G * k; };
+    if (KIND == 0) {
+      R.op(col(0), x0, y0, fop, out0, van);
+    } else if (KIND == 1) {
+      R.op(col(0), x0, y0, fop, out0, van);
+      R.op(col(1), x1, y1, fop, out1, van);
+    } else {
+      uint32_t a0b0[NL], a1b1[NL], a0b1[NL], a1b0[NL];
+      R.op(col(0), x0, y0, FOP_MUL, a0b0, van);
+      R.op(col(1), x1, y1, FOP_MUL, a1b1, van);
+      R.op(col(2), x0, y1, FOP_MUL, a0b1, van);
+      R.op(col(3), x1, y0, FOP_MUL, a1b0, van);
+      R.op(col(4), a0b0, a1b1, FOP_SUB, out0, van);
+      R.op(col(5), a0b1, a1b0, FOP_ADD, out1, van);
+    }
+    R.put(0, real ? 1u : 0u); R.put(1, real ? e[0] : 0u); R.put(2, real ? e[1] : 0u);
+    if (KIND == 0) {
+      R.put(3, !real || op == 0 ? 1u : 0u); R.put(4, real && op == 2 ? 1u : 0u); R.put(5, real && op == 1 ? 1u : 0u);
+      R.put(6, real ? e[2] : 0u); R.put(7, real ? e[3] : 0u);
+    } else if (KIND == 1) {
+      R.put(3, !real || op == 0 ? 1u : 0u); R.put(4, real ? e[2] : 0u); R.put(5, real ? e[3] : 0u);
+    } else {
+      R.put(3, real ? e[2] : 0u); R.put(4, real ? e[3] : 0u);
+    }
+    for (int k = 0; k < W; k++) {
+      uint32_t mw[13], mr[9];
+      for (int c = 0; c < 13; c++) mw[c] = 0;
+      for (int c = 0; c < 9; c++) mr[c] = 0;
+      if (real) {
+        memory_write_cols(e + E_HEAD + 6 * k, mw);
+        const uint32_t* rec = e + E_HEAD + 6 * W + 5 * k;
+        memory_access_cols(rec[0], rec[1], rec[2], rec[3], rec[4], mr);
+        if (count) { access_lookups(mr, sink); lookup(sink, B_U16RANGE, mw[11] >> 8, mw[11]); lookup(sink, B_U8RANGE, 0, mw[12]); }
+        if (e[E_HEAD + 6 * k] != (k < NL ? out0[k] : out1[k - NL])) ok = false;
+      }
+      for (int c = 0; c < 13; c++) R.put(X_ACCESS + 13 * k + c, mw[c]);
+      for (int c = 0; c < 9; c++) R.put(Y_ACCESS + 9 * k + c, mr[c]);
+    }
+    if (real && !ok) *bad = 1;
+  }
+  if (count) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < BF_HASH_SLOTS; i += blockDim.x)
+      if (hkeys[i] != HASH_EMPTY) atomicAdd(counts + hkeys[i], hvals[i]);
+  }
+}
+
 // recursion ExpReverseBitsLen chip (crates/recursion/core/src/chips/exp_reverse_bits.rs:175-226): one thread walks one event's bits —
 // accum_i = accum_{i-1}^2 * (bit_i ? x : 1) — and writes its rows (x, bit, prev_accum^2, that times the multiplier, accum, accum^2,
 // multiplier); Montgomery words in and out. offsets[e] .. offsets[e + 1] are event e's rows; the rest of the matrix is zeroed first.

@@ -742,6 +742,39 @@ def weierstrass_double(curve, p):
     return x3, (slope * (x1 - x3) - y1) % P
 
 
+# The field-tower precompiles (syscall/precompiles/fptower/fp.rs, fp2_addsub.rs, fp2_mul.rs) over the base fields of Bn254 and Bls12381: FpOpEvent,
+# Fp2AddSubEvent, Fp2MulEvent (events/precompiles/fptower.rs:23-94) flattened; `op` is FieldOperation as a word (Add 0, Mul 1, Sub 2).
+FP_TOWER_CODES = {"Bn254": dict(fp_add=0x01010026, fp_sub=0x01010027, fp_mul=0x01010028, fp2_add=0x01010029, fp2_sub=0x0101002A, fp2_mul=0x0101002B),
+                  "Bls12381": dict(fp_add=0x01010020, fp_sub=0x01010021, fp_mul=0x01010022, fp2_add=0x01010023, fp2_sub=0x01010024, fp2_mul=0x01010025)}
+FIELD_OP_ADD, FIELD_OP_MUL, FIELD_OP_SUB = 0, 1, 2
+
+
+def fp_tower_event_dtype(field, kind):
+    n = WEIERSTRASS_CURVES[field]["n_limbs"]
+    w = n // 4 if kind == "fp" else n // 2
+    head = [("shard", "<u4"), ("clk", "<u4"), ("x_ptr", "<u4"), ("y_ptr", "<u4")] + ([] if kind == "fp2_mul" else [("op", "<u4")])
+    return np.dtype(head + [("x_memory_records", MEMORY_WRITE_RECORD, (w,)), ("y_memory_records", MEMORY_READ_RECORD, (w,))])
+
+
+def fp_tower_width(field, kind):
+    """FpOpCols (fp.rs:40-54): 8 + 22 W + G with W = N / 4 words; Fp2AddSubAssignCols (fp2_addsub.rs:40-51): 6 + 22 W + 2 G, Fp2MulAssignCols
+    (fp2_mul.rs:40-54): 5 + 22 W + 6 G with W = N / 2."""
+    n = WEIERSTRASS_CURVES[field]["n_limbs"]
+    g = 6 * n - 4
+    return {"fp": 8 + 22 * (n // 4) + g, "fp2_addsub": 6 + 22 * (n // 2) + 2 * g, "fp2_mul": 5 + 22 * (n // 2) + 6 * g}[kind]
+
+
+def fp_tower_result(field, kind, op, x, y):
+    """What the syscalls write (syscalls/precompiles/fptower/fp.rs:52-59, fp2_addsub.rs:52-70, fp2_mul.rs:52-75): x and y are ints (fp) or pairs."""
+    P = WEIERSTRASS_CURVES[field]["p"]
+    f = {FIELD_OP_ADD: lambda a, b: (a + b) % P, FIELD_OP_SUB: lambda a, b: (a - b) % P, FIELD_OP_MUL: lambda a, b: a * b % P}
+    if kind == "fp":
+        return f[op](x, y)
+    if kind == "fp2_addsub":
+        return f[op](x[0], y[0]), f[op](x[1], y[1])
+    return (x[0] * y[0] - x[1] * y[1]) % P, (x[0] * y[1] + x[1] * y[0]) % P
+
+
 SYSCALL_INSTRS_WIDTH = 77
 # SyscallCode (crates/core/executor/src/syscalls/code.rs): byte 0-1 id, byte 2 "has its own table", byte 3 extra cycles
 SYS_HALT, SYS_WRITE, SYS_ENTER_UNCONSTRAINED, SYS_EXIT_UNCONSTRAINED, SYS_COMMIT, SYS_COMMIT_DEFERRED_PROOFS, SYS_HINT_LEN = 0, 2, 3, 4, 0x10, 0x1a, 0xf0

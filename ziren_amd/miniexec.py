@@ -95,7 +95,7 @@ class Machine:
 
 def run_machine(n_cycles: int = 0, seed: int = 1, pc_base: int = 0x1000, shard_cycles: int = 1 << 30, program=None, poseidon2_calls: int = 0,
                 memory_chunk: int = 1 << 30, keccak_calls: int = 0, sha_calls: int = 0, ed_calls: int = 0,
-                curve_calls=None) -> Machine:
+                curve_calls=None, fp_calls=None) -> Machine:
     """A whole run as the reference's prover sees it (crates/core/machine/src/utils/prove.rs:255-400): CPU shards of at most `shard_cycles`
     cycles (never split between a branch and its delay slot, executor.rs:2352-2356), then one shard with the deferred precompile events
     (ExecutionRecord::split, record.rs:130-218), then the shards that initialise and finalise every touched address
@@ -103,12 +103,12 @@ def run_machine(n_cycles: int = 0, seed: int = 1, pc_base: int = 0x1000, shard_c
     to execute until it halts instead of generating one; `poseidon2_calls` / `keccak_calls`: POSEIDON2_PERMUTE / KECCAK_SPONGE precompile calls
     spread over a generated run (each kind is deferred to a precompile shard of its own, record.rs:150-185)."""
     return _execute(n_cycles, seed, 1, pc_base, True, shard_cycles=shard_cycles, given=program, poseidon2_calls=poseidon2_calls, memory_chunk=memory_chunk,
-                    machine=True, keccak_calls=keccak_calls, sha_calls=sha_calls, ed_calls=ed_calls, curve_calls=curve_calls)
+                    machine=True, keccak_calls=keccak_calls, sha_calls=sha_calls, ed_calls=ed_calls, curve_calls=curve_calls, fp_calls=fp_calls)
 
 
 def _execute(n_cycles: int, seed: int = 1, shard: int = 1, pc_base: int = 0x1000, halt: bool = False, shard_cycles: int = 1 << 30, given=None,
              poseidon2_calls: int = 0, memory_chunk: int = 1 << 30, machine: bool = False, keccak_calls: int = 0, sha_calls: int = 0, ed_calls: int = 0,
-             curve_calls=None) -> Machine:
+             curve_calls=None, fp_calls=None) -> Machine:
     """Execute `n_cycles` instructions of a program generated on the way. Returns (program, record, public_values) with
     program: INSTRUCTION array (instructions that were jumped over are `ADD $0, 0, 0` no-ops that never run), record:
     structured event arrays, public_values: dict of the words the Cpu chip checks (start_pc, next_pc, execution_shard).
@@ -176,6 +176,7 @@ def _execute(n_cycles: int, seed: int = 1, shard: int = 1, pc_base: int = 0x1000
     s_seq = 0
     e_at = {n_cycles // 4} - p2_at - k_at - s_at if ed_calls else set()
     w_at = {n_cycles // 3} - p2_at - k_at - s_at - e_at if curve_calls else set()
+    f_at = {n_cycles // 2} - p2_at - k_at - s_at - e_at - w_at if fp_calls else set()
     clk_extra = 0                  # the extra cycles of the shard's syscalls so far (Syscall::num_extra_cycles, executor.rs:1641)
 
     def close_shard():
@@ -215,6 +216,7 @@ def _execute(n_cycles: int, seed: int = 1, shard: int = 1, pc_base: int = 0x1000
             s_at = set(x + len(queued) - had if x > cyc else x for x in s_at)
             e_at = set(x + len(queued) - had if x > cyc else x for x in e_at)
             w_at = set(x + len(queued) - had if x > cyc else x for x in w_at)
+            f_at = set(x + len(queued) - had if x > cyc else x for x in f_at)
         if given is None and cyc in k_at and cyc < n_cycles:
             # a KECCAK_SPONGE call as the guest library's keccak256 makes it (crates/zkvm/lib/src/keccak256.rs:3-57): the padded message as
             # 36-word blocks, its length in words at result + 64, the code in $v0, input and result pointers in $a0 / $a1
@@ -234,6 +236,7 @@ def _execute(n_cycles: int, seed: int = 1, shard: int = 1, pc_base: int = 0x1000
             s_at = set(x + len(queued) - had if x > cyc else x for x in s_at)
             e_at = set(x + len(queued) - had if x > cyc else x for x in e_at)
             w_at = set(x + len(queued) - had if x > cyc else x for x in w_at)
+            f_at = set(x + len(queued) - had if x > cyc else x for x in f_at)
         if given is None and cyc in s_at and cyc < n_cycles:
             # one SHA-256 block as the reference's test programs lay the calls out (sha256/extend/mod.rs:44-61, compress/mod.rs:52-78): sixteen
             # message words at w_ptr, SHA_EXTEND(w_ptr, 0), the eight state words at h_ptr, SHA_COMPRESS(w_ptr, h_ptr)
@@ -254,6 +257,7 @@ def _execute(n_cycles: int, seed: int = 1, shard: int = 1, pc_base: int = 0x1000
             s_at = set(x + len(queued) - had if x > cyc else x for x in s_at)
             e_at = set(x + len(queued) - had if x > cyc else x for x in e_at)
             w_at = set(x + len(queued) - had if x > cyc else x for x in w_at)
+            f_at = set(x + len(queued) - had if x > cyc else x for x in f_at)
         if given is None and cyc in e_at and cyc < n_cycles:
             # Ed25519 additions the way a scalar multiplication makes them: p = B and q = 2B stored once, then `ed_calls` times p <- p + q
             # (ED_ADD(p_ptr, q_ptr), the reference's ed_add test program: syscall/precompiles/edwards/ed_add.rs tests)
@@ -275,6 +279,7 @@ def _execute(n_cycles: int, seed: int = 1, shard: int = 1, pc_base: int = 0x1000
             k_at = set(x + len(queued) - had if x > cyc else x for x in k_at)
             s_at = set(x + len(queued) - had if x > cyc else x for x in s_at)
             w_at = set(x + len(queued) - had if x > cyc else x for x in w_at)
+            f_at = set(x + len(queued) - had if x > cyc else x for x in f_at)
         if given is None and cyc in w_at and cyc < n_cycles:
             # per curve in `curve_calls`: the generator stored at p and at q, q doubled with <CURVE>_DOUBLE(q), then `count` times p <- p + q
             # with <CURVE>_ADD(p, q): p runs through G, 3G, 5G, ... and never meets q = 2G
@@ -296,6 +301,30 @@ def _execute(n_cycles: int, seed: int = 1, shard: int = 1, pc_base: int = 0x1000
             k_at = set(x + len(queued) - had if x > cyc else x for x in k_at)
             s_at = set(x + len(queued) - had if x > cyc else x for x in s_at)
             e_at = set(x + len(queued) - had if x > cyc else x for x in e_at)
+            f_at = set(x + len(queued) - had if x > cyc else x for x in f_at)
+        if given is None and cyc in f_at and cyc < n_cycles:
+            # per field in `fp_calls`: two random Fp2 elements x, y stored, then `count` calls cycling through FP_ADD, FP_SUB, FP_MUL (on the first
+            # components), FP2_ADD, FP2_SUB, FP2_MUL; every call overwrites x with its result
+            had = len(queued)
+            for k, (field, calls) in enumerate(fp_calls.items()):
+                cv = E.WEIERSTRASS_CURVES[field]
+                per = cv["n_limbs"] // 4
+                x_ptr, y_ptr = 0x00700000 + 0x400 * k, 0x00700200 + 0x400 * k
+                for ptr in (x_ptr, y_ptr):
+                    for comp in range(2):
+                        v = int.from_bytes(rng.bytes(cv["n_limbs"]), "little") % cv["p"]
+                        for i in range(per):
+                            queued += [(E.ADD, 30, (v >> (32 * i)) & 0xffffffff, 0, 1, 1), (E.SW, 30, 0, ptr + 4 * (comp * per + i), 0, 1)]
+                names = ["fp_add", "fp_sub", "fp_mul", "fp2_add", "fp2_sub", "fp2_mul"]
+                for j in range(calls):
+                    queued += [(E.ADD, E.REG_V0, E.FP_TOWER_CODES[field][names[j % 6]], 0, 1, 1), (E.ADD, E.REG_A0, x_ptr, 0, 1, 1),
+                               (E.ADD, E.REG_A1, y_ptr, 0, 1, 1), (E.SYSCALL, E.REG_V0, E.REG_A0, E.REG_A1, 0, 0)]
+            n_cycles += len(queued) - had
+            p2_at = set(x + len(queued) - had if x > cyc else x for x in p2_at)
+            k_at = set(x + len(queued) - had if x > cyc else x for x in k_at)
+            s_at = set(x + len(queued) - had if x > cyc else x for x in s_at)
+            e_at = set(x + len(queued) - had if x > cyc else x for x in e_at)
+            w_at = set(x + len(queued) - had if x > cyc else x for x in w_at)
         # ---- pick the instruction at pc (the program is written as it runs)
         if given is not None:
             if pc not in program:
@@ -470,7 +499,8 @@ def _execute(n_cycles: int, seed: int = 1, shard: int = 1, pc_base: int = 0x1000
             b = b_rec[1][0]
             sid = code & 0xffff
             w_curve = {c[k]: (name, k == "double") for name, c in E.WEIERSTRASS_CURVES.items() for k in ("add", "double")}.get(code)
-            assert w_curve or code in (E.SYS_HALT, E.SYS_COMMIT, E.SYS_POSEIDON2_PERMUTE, E.SYS_KECCAK_SPONGE, E.SYS_SHA_EXTEND, E.SYS_SHA_COMPRESS, E.SYS_ED_ADD,
+            fp_call = {c: (field, name) for field, codes in E.FP_TOWER_CODES.items() for name, c in codes.items()}.get(code)
+            assert w_curve or fp_call or code in (E.SYS_HALT, E.SYS_COMMIT, E.SYS_POSEIDON2_PERMUTE, E.SYS_KECCAK_SPONGE, E.SYS_SHA_EXTEND, E.SYS_SHA_COMPRESS, E.SYS_ED_ADD,
                                         E.SYS_ED_DECOMPRESS), code
             touched = {}                               # address -> [initial (shard, timestamp, value), final]: SyscallContext's local map
 
@@ -606,6 +636,29 @@ def _execute(n_cycles: int, seed: int = 1, shard: int = 1, pc_base: int = 0x1000
                 event = (shard, clk, b, pwr) if dbl else (shard, clk, b, c, pwr, qr)
                 precompile.append((curve + ("_double" if dbl else "_add"), (pc, next_pc, shard, clk, (0, 0, 0, 0, 0, 0), 0, [0, 0, 0], sid, b, c), [event], local))
                 clk_extra += 0 if dbl else 1
+            if fp_call:
+                # FpOpSyscall / Fp2AddSubSyscall / Fp2MulSyscall::execute (syscalls/precompiles/fptower/fp.rs:30-120, fp2_addsub.rs, fp2_mul.rs): x is
+                # peeked, y read at clk, the result written over x at clk + 1; one extra cycle. The three Fp codes of a field file their events
+                # together (under the field's FP_ADD), the two Fp2 add / sub codes likewise
+                field, name = fp_call
+                kind = "fp" if name.startswith("fp_") else "fp2_mul" if name == "fp2_mul" else "fp2_addsub"
+                op = {"add": E.FIELD_OP_ADD, "sub": E.FIELD_OP_SUB, "mul": E.FIELD_OP_MUL}[name.split("_")[1]]
+                per = E.WEIERSTRASS_CURVES[field]["n_limbs"] // 4
+                W = per if kind == "fp" else 2 * per
+                as_int = lambda ws: sum(w << (32 * i) for i, w in enumerate(ws))      # noqa: E731
+                xw = [R.get(b + 4 * i, 0) for i in range(W)]
+                yr = [mem(c + 4 * i, clk) for i in range(W)]
+                yw = [x[0] for x in yr]
+                if kind == "fp":
+                    res = (E.fp_tower_result(field, kind, op, as_int(xw), as_int(yw)),)
+                else:
+                    res = E.fp_tower_result(field, kind, op, (as_int(xw[:per]), as_int(xw[per:])), (as_int(yw[:per]), as_int(yw[per:])))
+                out = [(v >> (32 * i)) & 0xffffffff for v in res for i in range(per)]
+                xwr = [mem(b + 4 * i, clk + 1, out[i]) for i in range(W)]
+                local = [(addr, v[0], v[1]) for addr, v in sorted(touched.items())]
+                event = (shard, clk, b, c, xwr, yr) if kind == "fp2_mul" else (shard, clk, b, c, op, xwr, yr)
+                precompile.append((field + "_" + kind, (pc, next_pc, shard, clk, (0, 0, 0, 0, 0, 0), 0, [0, 0, 0], sid, b, c), [event], local))
+                clk_extra += 1
             a = code                                       # none of them returns a value: V0 keeps the code
             a_rec = write(op_a, a, clk, POS_A)
             hi = code
@@ -719,7 +772,8 @@ def _execute(n_cycles: int, seed: int = 1, shard: int = 1, pc_base: int = 0x1000
     for kind, dt in (("poseidon2", E.POSEIDON2_PERMUTE_EVENT), ("keccak", E.KECCAK_SPONGE_BLOCK), ("sha_extend", E.SHA_EXTEND_EVENT),
                      ("sha_compress", E.SHA_COMPRESS_EVENT), ("ed_add", E.ED_ADD_EVENT),
                      ("ed_decompress", E.ED_DECOMPRESS_EVENT)) + tuple(
-            (curve + suffix, E.weierstrass_event_dtypes(curve)[k]) for curve in E.WEIERSTRASS_CURVES for k, suffix in ((0, "_add"), (1, "_double"))):
+            (curve + suffix, E.weierstrass_event_dtypes(curve)[k]) for curve in E.WEIERSTRASS_CURVES for k, suffix in ((0, "_add"), (1, "_double"))) + tuple(
+            (field + "_" + kind, E.fp_tower_event_dtype(field, kind)) for field in E.FP_TOWER_CODES for kind in ("fp", "fp2_addsub", "fp2_mul")):
         mine = [e for e in precompile if e[0] == kind]
         if not mine:
             continue
@@ -734,6 +788,7 @@ def _execute(n_cycles: int, seed: int = 1, shard: int = 1, pc_base: int = 0x1000
         o.ed_add = arr([ev for e in mine for ev in e[2]] if kind == "ed_add" else [], E.ED_ADD_EVENT)
         o.ed_decompress = arr([ev for e in mine for ev in e[2]] if kind == "ed_decompress" else [], E.ED_DECOMPRESS_EVENT)
         o.weierstrass = (kind, arr([ev for e in mine for ev in e[2]], dt)) if kind.endswith(("_add", "_double")) and kind.split("_")[0] in E.WEIERSTRASS_CURVES else None
+        o.fp_tower = (kind, arr([ev for e in mine for ev in e[2]], dt)) if kind.split("_")[0] in E.FP_TOWER_CODES and "_fp" in kind else None
         o.memory_local = arr([ev for e in mine for ev in e[3]], MEMORY_LOCAL_EVENT)
         pv = dict(last_pv, start_pc=last_pv["next_pc"], shard=n_shard)
         shards.append(Shard("precompile", o, pv))

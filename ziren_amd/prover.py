@@ -279,6 +279,18 @@ class Context:
                      C.c_int(fixed_log2_rows), blu.h if blu is not None else None, C.byref(h)))
         return self._born(h)
 
+    def tracegen_fp_tower(self, field: str, kind: str, events: np.ndarray, fixed_log2_rows: int = -1, blu: "ByteLookups" = None) -> DeviceMatrix:
+        """`generate_trace` of <Field>FpOpAssign / Fp2AddSubAssign / Fp2MulAssign on the device (zkm_tracegen_fp_op / _fp2_addsub / _fp2_mul); field
+        "Bn254" or "Bls12381", kind "fp" / "fp2_addsub" / "fp2_mul", dtype events.fp_tower_event_dtype(field, kind)."""
+        from . import events as _ev
+        ev = np.ascontiguousarray(events, dtype=_ev.fp_tower_event_dtype(field, kind))
+        h = C.c_void_p()
+        L = lib.load()
+        fn = {"fp": L.zkm_tracegen_fp_op, "fp2_addsub": L.zkm_tracegen_fp2_addsub, "fp2_mul": L.zkm_tracegen_fp2_mul}[kind]
+        lib.check(fn(self.h, C.c_int(_ev.WEIERSTRASS_CURVES[field]["index"]), C.c_void_p(ev.ctypes.data if len(ev) else None), C.c_size_t(len(ev)),
+                     C.c_int(fixed_log2_rows), blu.h if blu is not None else None, C.byref(h)))
+        return self._born(h)
+
     def tracegen_misc_instrs(self, events: np.ndarray, fixed_log2_rows: int = -1, blu: "ByteLookups" = None) -> DeviceMatrix:
         """`generate_trace` of the MiscInstrs chip on the device (zkm_tracegen_misc_instrs); dtype events.MISC_EVENT."""
         from . import events as _ev
