@@ -10,6 +10,7 @@
 pub mod decode;
 pub mod ffi;
 pub mod recorder;
+pub mod tracegen;
 
 use std::ffi::{c_int, CStr};
 use std::ptr::null_mut;
@@ -192,12 +193,41 @@ where
 
     fn pk_to_host(&self, pk: &Self::DeviceProvingKey) -> StarkProvingKey<SC> { pk.host.clone() }
 
-    /// prover.rs:111-115 / :258-292. Traces go to the device tallest first so their upload overlaps the commit's kernels.
+    /// prover.rs:70-109, with one difference: a chip the library builds from events (tracegen::device_trace) gets no host trace — an empty
+    /// matrix of its width stands in, and `commit` builds the real one on the device. Only for the core machine (A::Record = ExecutionRecord).
+    fn generate_traces(&self, record: &A::Record) -> Result<Vec<(String, RowMajorMatrix<Val<SC>>)>, A::Error> {
+        let on_device = (record as &dyn std::any::Any).downcast_ref::<zkm_core_executor::ExecutionRecord>().is_some();
+        self.shard_chips(record)
+            .map(|chip| {
+                let name = chip.name();
+                if on_device && tracegen::DEVICE_BUILT.contains(&name.as_str()) {
+                    Ok((name, RowMajorMatrix::new(vec![], chip.width())))
+                } else {
+                    chip.generate_trace(record, &mut A::Record::default()).map(|t| (name, t))
+                }
+            })
+            .collect()
+    }
+
+    /// prover.rs:111-115 / :258-292. Device-built chips are generated from the record's events; the others' host traces go up tallest first
+    /// so their upload overlaps the commit's kernels. Byte lookups keep the reference's flow (generate_dependencies has counted every chip's
+    /// into record.byte_lookups, the Byte chip's trace is a host trace), so the device generators are not asked to count them again.
     fn commit(&self, record: &A::Record, traces: Vec<(String, RowMajorMatrix<Val<SC>>)>) -> ShardMainData<SC, Self::DeviceMatrix, Self::DeviceProverData> {
+        let core = (record as &dyn std::any::Any).downcast_ref::<zkm_core_executor::ExecutionRecord>();
         let mut order: Vec<usize> = (0..traces.len()).collect();
         order.sort_by_key(|&i| std::cmp::Reverse(traces[i].1.height()));
         let mut dev: Vec<Option<HipMatrix>> = (0..traces.len()).map(|_| None).collect();
-        for i in order { dev[i] = Some(self.upload(&traces[i].1).expect("upload")); }
+        for i in order {
+            let (name, host) = &traces[i];
+            let born = match core {
+                Some(r) if host.values.is_empty() => {
+                    let fixed = r.shape.as_ref().and_then(|s| s.log2_height_by_name(name)).map(|h| h as i32).unwrap_or(-1);
+                    tracegen::device_trace(self.ctx.0, name, r, fixed, null_mut()).expect("device trace generation")
+                }
+                _ => None,
+            };
+            dev[i] = Some(match born { Some(m) => m, None => self.upload(host).expect("upload") });
+        }
         let dev: Vec<HipMatrix> = dev.into_iter().map(Option::unwrap).collect();
         let names: Vec<std::ffi::CString> = traces.iter().map(|(n, _)| std::ffi::CString::new(n.as_str()).unwrap()).collect();
         let name_ptrs: Vec<*const std::ffi::c_char> = names.iter().map(|n| n.as_ptr()).collect();
