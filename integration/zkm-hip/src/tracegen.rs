@@ -7,8 +7,11 @@
 //! SyscallEvent, CpuEvent, MemoryLocalEvent, GlobalLookupEvent, MemoryInitializeFinalizeEvent, MemoryReadRecord, MemoryWriteRecord) cross the
 //! boundary by pointer cast. Precompile events hold `Vec`s and are flattened into the fixed layouts of `include/zkm_hip.h` first.
 //!
-//! Byte lookups: the reference's chips add their `ByteLookupEvent`s to the record in `generate_dependencies`; here every device generator
-//! counts its own into one `ZkmByteLookups` per shard, and the Byte chip's multiplicity trace comes from `zkm_tracegen_byte_mults`.
+//! Byte lookups: the reference's chips add their `ByteLookupEvent`s to the record in `generate_dependencies`, which runs over every chip before
+//! proving; the Byte chip's trace therefore stays a host trace built from `record.byte_lookups`, and `commit` passes a null `blu` so that
+//! the device generators do not count the same lookups again. (With `generate_dependencies` skipped for the device-built chips, one
+//! `ZkmByteLookups` per shard would collect them and `zkm_tracegen_byte_mults` would give the Byte chip's multiplicities — the path the Python
+//! mirror and the tests use.)
 //!
 //! Written against the reference's types; never compiled (no Rust toolchain in the build image) — see INTEGRATION.md.
 use std::ptr::null_mut;
