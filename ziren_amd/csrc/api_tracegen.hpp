@@ -663,7 +663,7 @@ int zkm_tracegen_ed_add(zkm_ctx* ctx, const zkm_ed_add_event* events, size_t n_e
     HIP_CHECK(hipMemsetAsync(d_bad, 0, 4, ctx->stream));
     if (n_events) HIP_CHECK(hipMemcpyAsync(d_events, events, ev_bytes, hipMemcpyHostToDevice, ctx->stream));
     uint32_t* counts = blu ? blu->counts : nullptr;
-    KLAUNCH(ctx, "tracegen_ed_add", (double)ev_bytes + 4.0 * height * m->w, tracegen::ed_add_rows, dim3(div_up(height, (size_t)64)), dim3(64),
+    KLAUNCH(ctx, "tracegen_ed_add", (double)ev_bytes + 4.0 * height * m->w, tracegen::ed_add_rows, dim3(div_up(height, (size_t)tracegen::BF_THREADS)), dim3(tracegen::BF_THREADS),
             counts ? 2 * tracegen::BF_HASH_SLOTS * sizeof(uint32_t) : 0, (const uint32_t*)d_events, n_events, height, m->d, counts, d_bad);
     int bad = 0;
     HIP_CHECK(hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -703,7 +703,7 @@ int zkm_tracegen_ed_decompress(zkm_ctx* ctx, const zkm_ed_decompress_event* even
     HIP_CHECK(hipMemsetAsync(d_bad, 0, 4, ctx->stream));
     if (n_events) HIP_CHECK(hipMemcpyAsync(d_events, events, ev_bytes, hipMemcpyHostToDevice, ctx->stream));
     uint32_t* counts = blu ? blu->counts : nullptr;
-    KLAUNCH(ctx, "tracegen_ed_decompress", (double)ev_bytes + 4.0 * height * m->w, tracegen::ed_decompress_rows, dim3(div_up(height, (size_t)64)), dim3(64),
+    KLAUNCH(ctx, "tracegen_ed_decompress", (double)ev_bytes + 4.0 * height * m->w, tracegen::ed_decompress_rows, dim3(div_up(height, (size_t)tracegen::BF_THREADS)), dim3(tracegen::BF_THREADS),
             counts ? 2 * tracegen::BF_HASH_SLOTS * sizeof(uint32_t) : 0, (const uint32_t*)d_events, n_events, height, m->d, counts, d_bad);
     int bad = 0;
     HIP_CHECK(hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -744,7 +744,7 @@ template <int NL, bool DOUBLE>
 static void launch_weierstrass(zkm_ctx* ctx, const tracegen::CurveField<NL>& field, const uint32_t* d_events, size_t n_events, size_t height, uint32_t* out,
                                uint32_t* counts, int* d_bad, double bytes) {
   KLAUNCH(ctx, DOUBLE ? "tracegen_weierstrass_double" : "tracegen_weierstrass_add", bytes, (tracegen::weierstrass_rows<NL, DOUBLE>),
-          dim3(div_up(height, (size_t)64)), dim3(64), counts ? 2 * tracegen::BF_HASH_SLOTS * sizeof(uint32_t) : 0, d_events, n_events, height, out, counts,
+          dim3(div_up(height, (size_t)tracegen::BF_THREADS)), dim3(tracegen::BF_THREADS), counts ? 2 * tracegen::BF_HASH_SLOTS * sizeof(uint32_t) : 0, d_events, n_events, height, out, counts,
           d_bad, field);
 }
 }  // extern "C++"
@@ -817,7 +817,7 @@ template <int NL, int KIND>
 static void launch_fp_tower(zkm_ctx* ctx, const tracegen::CurveField<NL>& field, const uint32_t* d_events, size_t n_events, size_t height, uint32_t* out,
                             uint32_t* counts, int* d_bad, double bytes) {
   KLAUNCH(ctx, KIND == 0 ? "tracegen_fp_op" : KIND == 1 ? "tracegen_fp2_addsub" : "tracegen_fp2_mul", bytes, (tracegen::fp_tower_rows<NL, KIND>),
-          dim3(div_up(height, (size_t)64)), dim3(64), counts ? 2 * tracegen::BF_HASH_SLOTS * sizeof(uint32_t) : 0, d_events, n_events, height, out, counts,
+          dim3(div_up(height, (size_t)tracegen::BF_THREADS)), dim3(tracegen::BF_THREADS), counts ? 2 * tracegen::BF_HASH_SLOTS * sizeof(uint32_t) : 0, d_events, n_events, height, out, counts,
           d_bad, field);
 }
 }  // extern "C++"

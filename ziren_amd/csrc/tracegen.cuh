@@ -1696,6 +1696,8 @@ constexpr int ED_ADD_WIDTH = 1861, ED_ADD_EVENT_WORDS = 180, ED_LIMBS = 32, ED_G
 // the big-field kernels run 64 threads per block; their lookups (≈ 800 per row, many of them range checks of zero bytes) need the full
 // LDS table: with 1024 slots it crowds, lookups fall through to global atomics on a few hot counters and EdDecompress runs 5x slower
 constexpr int BF_HASH_SLOTS = HASH_SLOTS;
+// rows per block: the 64 KiB lookup table allows two blocks per CU, so a block brings four waves (one per SIMD) rather than one
+constexpr int BF_THREADS = 256;
 __constant__ bigfield::Modulus<8> d_ed25519 = {
     {0xffffffedu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0x7fffffffu},
     // floor(2^512 / (2^255 - 19)) = 2^257 + 76 (the next term, 19^2 * 4 / 2^255, is below one)
@@ -1740,7 +1742,7 @@ __device__ __forceinline__ void ed_poly_mac(int32_t* acc, const uint32_t* a, con
 __device__ __forceinline__ void ed_poly_add(int32_t* acc, const uint32_t* a, int sign) {
   for (int i = 0; i < ED_LIMBS; i++) acc[i] += sign * (int32_t)bigfield::byte_of(a, i);
 }
-__global__ __launch_bounds__(64) void ed_add_rows(const uint32_t* __restrict__ events, size_t n_events, size_t height, uint32_t* __restrict__ out,
+__global__ __launch_bounds__(BF_THREADS) void ed_add_rows(const uint32_t* __restrict__ events, size_t n_events, size_t height, uint32_t* __restrict__ out,
                                                   uint32_t* counts, int* __restrict__ bad) {
   enum { IS_REAL = 0, SHARD = 1, CLK = 2, P_PTR = 3, Q_PTR = 4, P_ACCESS = 5, Q_ACCESS = 5 + 16 * 13, GADGETS = 5 + 16 * 13 + 16 * 9, G = ED_GADGET };
   enum { E_P_RECORDS = 4, E_Q_RECORDS = 4 + 96 };
@@ -1904,7 +1906,7 @@ __device__ void ed_field_lt(const EdRow& R, int base, const uint32_t* lhs) {
   R.put(base + ED_LIMBS, a); R.put(base + ED_LIMBS + 1, b);
   if (R.count && at >= 0) lookup(R.sink, B_LTU, a, b);
 }
-__global__ __launch_bounds__(64) void ed_decompress_rows(const uint32_t* __restrict__ events, size_t n_events, size_t height, uint32_t* __restrict__ out,
+__global__ __launch_bounds__(BF_THREADS) void ed_decompress_rows(const uint32_t* __restrict__ events, size_t n_events, size_t height, uint32_t* __restrict__ out,
                                                          uint32_t* counts, int* __restrict__ bad) {
   enum { IS_REAL = 0, SHARD = 1, CLK = 2, PTR = 3, SIGN = 4, X_ACCESS = 5, Y_ACCESS = 109, Y_RANGE = 181, YY = 215, U = 403, DYY = 591, V = 779, U_DIV_V = 967,
          X_MULT = 1155, X_RANGE = 1343, X_LSB = 1377, NEG_X = 1378 };
@@ -2075,7 +2077,7 @@ template <int NL> struct FieldRow {
   }
 };
 template <int NL, bool DOUBLE>
-__global__ __launch_bounds__(64) void weierstrass_rows(const uint32_t* __restrict__ events, size_t n_events, size_t height, uint32_t* __restrict__ out,
+__global__ __launch_bounds__(BF_THREADS) void weierstrass_rows(const uint32_t* __restrict__ events, size_t n_events, size_t height, uint32_t* __restrict__ out,
                                                        uint32_t* counts, int* __restrict__ bad, const CurveField<NL> field) {
   constexpr int N = 4 * NL, W = 2 * NL, G = FieldRow<NL>::G;
   constexpr int P_ACCESS = DOUBLE ? 4 : 5, Q_ACCESS = P_ACCESS + 13 * W, GADGETS = P_ACCESS + 13 * W + (DOUBLE ? 0 : 9 * W);
@@ -2172,7 +2174,7 @@ __global__ __launch_bounds__(64) void weierstrass_rows(const uint32_t* __restric
 // (NL = 12): KIND 0 FpOp (one FieldOpCols, the operation — FieldOperation as a word: Add 0, Mul 1, Sub 2 — per event), 1 Fp2AddSub (two), 2 Fp2Mul
 // (four products, a difference, a sum). x is overwritten at clk + 1, y is read at clk. Padding rows: zero inputs with is_add set.
 template <int NL, int KIND>
-__global__ __launch_bounds__(64) void fp_tower_rows(const uint32_t* __restrict__ events, size_t n_events, size_t height, uint32_t* __restrict__ out,
+__global__ __launch_bounds__(BF_THREADS) void fp_tower_rows(const uint32_t* __restrict__ events, size_t n_events, size_t height, uint32_t* __restrict__ out,
                                                     uint32_t* counts, int* __restrict__ bad, const CurveField<NL> field) {
   constexpr int N = 4 * NL, G = FieldRow<NL>::G, W = KIND == 0 ? NL : 2 * NL, HEAD = KIND == 0 ? 8 : KIND == 1 ? 6 : 5;
   constexpr int X_ACCESS = HEAD, Y_ACCESS = HEAD + 13 * W, GADGETS = HEAD + 22 * W, E_HEAD = KIND == 2 ? 4 : 5, EV_WORDS = E_HEAD + 11 * W;
