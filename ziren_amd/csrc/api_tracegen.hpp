@@ -643,6 +643,30 @@ int zkm_tracegen_sha_compress(zkm_ctx* ctx, const zkm_sha_compress_event* events
   API_END
 }
 
+// The U8Range lookups of the byte-limb columns of a big-field table's real rows (tracegen::u8_pair_histogram), added to the lookup counters
+static void count_u8_pairs(zkm_ctx* ctx, const zkm_matrix* m, size_t n_real, const tracegen::U8Segments& seg, uint32_t* counts) {
+  if (!counts || !n_real) return;
+  int log_slab_rows = 8;
+  while (div_up(n_real, (size_t)1 << log_slab_rows) > (size_t)tracegen::U8H_MAX_SLABS) log_slab_rows++;
+  const size_t slabs = div_up(n_real, (size_t)1 << log_slab_rows);
+  size_t columns = 0;
+  for (int k = 0; k < seg.n; k++) {
+    if (seg.cols[k] % 2 || seg.start[k] < 0 || (size_t)(seg.start[k] + seg.cols[k]) > m->w) throw std::runtime_error("count_u8_pairs: bad column segment");
+    columns += seg.cols[k];
+  }
+  uint32_t* partial = ctx->alloc_n<uint32_t>(slabs * 65536);
+  try {
+    KLAUNCH(ctx, "tracegen_u8_pairs", 4.0 * tracegen::U8H_RANGES * n_real * columns, tracegen::u8_pair_histogram, dim3(slabs * tracegen::U8H_RANGES),
+            dim3(tracegen::U8H_THREADS), 0, (const uint32_t*)m->d, m->h, n_real, seg, log_slab_rows, partial);
+    KLAUNCH(ctx, "tracegen_u8_pairs_reduce", 4.0 * slabs * 65536, tracegen::u8_pair_reduce, dim3(65536 / 256), dim3(256), 0, (const uint32_t*)partial, (int)slabs,
+            counts + (size_t)tracegen::B_U8RANGE * tracegen::BYTE_ROWS);
+  } catch (...) {
+    ctx->release(partial);
+    throw;
+  }
+  ctx->release(partial);
+}
+
 int zkm_tracegen_ed_add(zkm_ctx* ctx, const zkm_ed_add_event* events, size_t n_events, int fixed_log2_rows, zkm_byte_lookups* blu, zkm_matrix** out) {
   API_BEGIN
   static_assert(sizeof(zkm_ed_add_event) == 4 * tracegen::ED_ADD_EVENT_WORDS, "flattened EllipticCurveAddEvent is 180 words");
@@ -663,8 +687,9 @@ int zkm_tracegen_ed_add(zkm_ctx* ctx, const zkm_ed_add_event* events, size_t n_e
     HIP_CHECK(hipMemsetAsync(d_bad, 0, 4, ctx->stream));
     if (n_events) HIP_CHECK(hipMemcpyAsync(d_events, events, ev_bytes, hipMemcpyHostToDevice, ctx->stream));
     uint32_t* counts = blu ? blu->counts : nullptr;
-    KLAUNCH(ctx, "tracegen_ed_add", (double)ev_bytes + 4.0 * height * m->w, tracegen::ed_add_rows, dim3(div_up(height, (size_t)tracegen::BF_THREADS)), dim3(tracegen::BF_THREADS),
-            counts ? 2 * tracegen::BF_HASH_SLOTS * sizeof(uint32_t) : 0, (const uint32_t*)d_events, n_events, height, m->d, counts, d_bad);
+    KLAUNCH(ctx, "tracegen_ed_add", (double)ev_bytes + 4.0 * height * m->w, tracegen::ed_add_rows, dim3(div_up(height, (size_t)tracegen::bf_threads(8))),
+            dim3(tracegen::bf_threads(8)), tracegen::bf_lds_bytes(8, counts != nullptr), (const uint32_t*)d_events, n_events, height, m->d, counts, d_bad);
+    count_u8_pairs(ctx, m, n_events, tracegen::U8Segments{1, {5 + 16 * 13 + 16 * 9}, {8 * tracegen::ED_GADGET}}, counts);      // the eight gadgets
     int bad = 0;
     HIP_CHECK(hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, ctx->stream));
     ctx->mark("trace generation");
@@ -703,8 +728,11 @@ int zkm_tracegen_ed_decompress(zkm_ctx* ctx, const zkm_ed_decompress_event* even
     HIP_CHECK(hipMemsetAsync(d_bad, 0, 4, ctx->stream));
     if (n_events) HIP_CHECK(hipMemcpyAsync(d_events, events, ev_bytes, hipMemcpyHostToDevice, ctx->stream));
     uint32_t* counts = blu ? blu->counts : nullptr;
-    KLAUNCH(ctx, "tracegen_ed_decompress", (double)ev_bytes + 4.0 * height * m->w, tracegen::ed_decompress_rows, dim3(div_up(height, (size_t)tracegen::BF_THREADS)), dim3(tracegen::BF_THREADS),
-            counts ? 2 * tracegen::BF_HASH_SLOTS * sizeof(uint32_t) : 0, (const uint32_t*)d_events, n_events, height, m->d, counts, d_bad);
+    KLAUNCH(ctx, "tracegen_ed_decompress", (double)ev_bytes + 4.0 * height * m->w, tracegen::ed_decompress_rows,
+            dim3(div_up(height, (size_t)tracegen::bf_threads(8))), dim3(tracegen::bf_threads(8)), tracegen::bf_lds_bytes(8, counts != nullptr), (const uint32_t*)d_events, n_events, height, m->d, counts, d_bad);
+    // yy .. x's multiplication (six gadgets; the last one's result columns hold the root, FieldSqrtCols range-checks both the root and the
+    // product — the product's bytes are u_div_v's result columns), neg_x
+    count_u8_pairs(ctx, m, n_events, tracegen::U8Segments{3, {215, 1378, 967}, {6 * tracegen::ED_GADGET, tracegen::ED_GADGET, tracegen::ED_LIMBS}}, counts);
     int bad = 0;
     HIP_CHECK(hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, ctx->stream));
     ctx->mark("trace generation");
@@ -744,7 +772,8 @@ template <int NL, bool DOUBLE>
 static void launch_weierstrass(zkm_ctx* ctx, const tracegen::CurveField<NL>& field, const uint32_t* d_events, size_t n_events, size_t height, uint32_t* out,
                                uint32_t* counts, int* d_bad, double bytes) {
   KLAUNCH(ctx, DOUBLE ? "tracegen_weierstrass_double" : "tracegen_weierstrass_add", bytes, (tracegen::weierstrass_rows<NL, DOUBLE>),
-          dim3(div_up(height, (size_t)tracegen::BF_THREADS)), dim3(tracegen::BF_THREADS), counts ? 2 * tracegen::BF_HASH_SLOTS * sizeof(uint32_t) : 0, d_events, n_events, height, out, counts,
+          dim3(div_up(height, (size_t)tracegen::bf_threads(NL))), dim3(tracegen::bf_threads(NL)), tracegen::bf_lds_bytes(NL, counts != nullptr), d_events, n_events,
+          height, out, counts,
           d_bad, field);
 }
 }  // extern "C++"
@@ -787,6 +816,7 @@ static int tracegen_weierstrass(zkm_ctx* ctx, int curve, bool dbl, const void* e
       if (dbl) launch_weierstrass<12, true>(ctx, f, d_events, n_events, height, m->d, counts, d_bad, bytes);
       else launch_weierstrass<12, false>(ctx, f, d_events, n_events, height, m->d, counts, d_bad, bytes);
     }
+    count_u8_pairs(ctx, m, n_events, tracegen::U8Segments{1, {(dbl ? 4 : 5) + 13 * W + (dbl ? 0 : 9 * W)}, {(dbl ? 11 : 9) * G}}, counts);
     int bad = 0;
     HIP_CHECK(hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, ctx->stream));
     ctx->mark("trace generation");
@@ -817,7 +847,8 @@ template <int NL, int KIND>
 static void launch_fp_tower(zkm_ctx* ctx, const tracegen::CurveField<NL>& field, const uint32_t* d_events, size_t n_events, size_t height, uint32_t* out,
                             uint32_t* counts, int* d_bad, double bytes) {
   KLAUNCH(ctx, KIND == 0 ? "tracegen_fp_op" : KIND == 1 ? "tracegen_fp2_addsub" : "tracegen_fp2_mul", bytes, (tracegen::fp_tower_rows<NL, KIND>),
-          dim3(div_up(height, (size_t)tracegen::BF_THREADS)), dim3(tracegen::BF_THREADS), counts ? 2 * tracegen::BF_HASH_SLOTS * sizeof(uint32_t) : 0, d_events, n_events, height, out, counts,
+          dim3(div_up(height, (size_t)tracegen::bf_threads(NL))), dim3(tracegen::bf_threads(NL)), tracegen::bf_lds_bytes(NL, counts != nullptr), d_events, n_events,
+          height, out, counts,
           d_bad, field);
 }
 }  // extern "C++"
@@ -862,6 +893,7 @@ static int tracegen_fp_tower(zkm_ctx* ctx, int field, int kind, const void* even
       else if (kind == 1) launch_fp_tower<12, 1>(ctx, f, d_events, n_events, height, m->d, counts, d_bad, bytes);
       else launch_fp_tower<12, 2>(ctx, f, d_events, n_events, height, m->d, counts, d_bad, bytes);
     }
+    count_u8_pairs(ctx, m, n_events, tracegen::U8Segments{1, {(kind == 0 ? 8 : kind == 1 ? 6 : 5) + 22 * W}, {(kind == 0 ? 1 : kind == 1 ? 2 : 6) * G}}, counts);
     int bad = 0;
     HIP_CHECK(hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, ctx->stream));
     ctx->mark("trace generation");

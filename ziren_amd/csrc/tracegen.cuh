@@ -1686,81 +1686,229 @@ __global__ __launch_bounds__(THREADS) void sha_compress_rows(const uint32_t* __r
   }
 }
 
-// ---- EdAddAssign precompile (syscall/precompiles/edwards/ed_add.rs:41-57, :68-95, :210-243): one Ed25519 point addition per row, 1861 columns:
-// the memory columns of p (written at clk + 1) and q, and eight 188-column field gadgets (result 32, carry 32, witness_low 62, witness_high
-// 62 byte limbs; operations/field/field_inner_product.rs, field_op.rs, field_den.rs). One thread per row: the integers with bigfield.cuh
-// (32-bit limbs, Barrett, Fermat inverse for the two denominators), then per gadget the witness of the polynomial identity in x = 2^8 —
-// op(x) - result(x) - carry(x) p(x) = (x - 256) w(x), w shifted by 2^14 and split into bytes (operations/field/util.rs:21-66) — straight
-// into the columns. Padding rows hold the gadgets of the zero inputs: zero everywhere except witness_high = 2^14 >> 8.
-constexpr int ED_ADD_WIDTH = 1861, ED_ADD_EVENT_WORDS = 180, ED_LIMBS = 32, ED_GADGET = 188;
-// the big-field kernels run 64 threads per block; their lookups (≈ 800 per row, many of them range checks of zero bytes) need the full
-// LDS table: with 1024 slots it crowds, lookups fall through to global atomics on a few hot counters and EdDecompress runs 5x slower
-constexpr int BF_HASH_SLOTS = HASH_SLOTS;
-// rows per block: the 64 KiB lookup table allows two blocks per CU, so a block brings four waves (one per SIMD) rather than one
-constexpr int BF_THREADS = 256;
-__constant__ bigfield::Modulus<8> d_ed25519 = {
-    {0xffffffedu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0x7fffffffu},
-    // floor(2^512 / (2^255 - 19)) = 2^257 + 76 (the next term, 19^2 * 4 / 2^255, is below one)
-    {76u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 2u}};
-__constant__ uint32_t d_ed25519_d[8] = {0x135978a3u, 0x75eb4dcau, 0x4141d8abu, 0x00700a4du, 0x7779e898u, 0x8cc74079u, 0x2b6ffe73u, 0x52036ceeu};
-struct EdRow {
-  uint32_t* out; size_t height, row; const LookupSink& sink; bool count;
+// ==== Big-field precompiles: the Ed25519 chips, the short-Weierstrass chips, the field-tower chips ====================================================
+// (syscall/precompiles/edwards/, weierstrass/, fptower/ over the gadgets of operations/field/). A row holds a handful of *field gadgets*: result,
+// carry, witness_low, witness_high of an identity op = result + carry p over the integers, checked as a polynomial identity in x = 2^8 on byte
+// limbs: op(x) - result(x) - carry(x) p(x) vanishes at 256, its quotient by (x - 256), shifted by the field's witness offset and split into two
+// bytes, is the witness (operations/field/util.rs:21-66). One thread per row. The integers are bigfield.cuh's (32-bit limbs in registers,
+// Barrett, Fermat inverse); the byte-limb polynomials live in LDS — one accumulator of 2 N - 1 words and two staged operands per thread, laid
+// out [element][thread] so that a wavefront's accesses never conflict. (In scratch memory, where the compiler puts a dynamically indexed local
+// array, the same loops made EdAddAssign twenty milliseconds per 2^16 rows.)
+// Byte lookups. A row range-checks ≈ 1500 limb bytes in pairs, and witness bytes are uniformly random: 2^16 rows make 5 * 10^7 increments
+// spread evenly over the 65536 U8Range counters. No per-block table combines those (a block of 256 rows meets every key about three times),
+// and as device-scope atomics they cost 20 ms per 2^16 rows — ten times the rows themselves. So the row kernels count only their skewed
+// lookups (memory timestamps, comparisons) in the block's LDS table, and u8_pair_histogram below counts the range checks from the columns.
+constexpr int BF_HASH_SLOTS = 2048;
+__host__ __device__ constexpr int bf_threads(int nl) { return nl == 8 ? 256 : 128; }                    // rows per block
+__host__ __device__ constexpr int bf_words_per_thread(int nl) { return (8 * nl - 1) + 2 * nl; }         // accumulator + two operands
+__host__ __device__ constexpr size_t bf_lds_bytes(int nl, bool count) {
+  return (count ? 2 * (size_t)BF_HASH_SLOTS * 4 : 0) + (size_t)bf_threads(nl) * bf_words_per_thread(nl) * 4;
+}
+enum { FOP_ADD = 0, FOP_SUB = 1, FOP_MUL = 2, FOP_DIV = 3 };
+template <int NL> struct CurveField { bigfield::Modulus<NL> m; uint32_t a[NL]; int32_t witness_offset; };
+template <int NL> struct FieldRow {
+  static constexpr int N = 4 * NL, NW = 2 * N - 2, G = 2 * N + 2 * NW, T = bf_threads(NL);
+  uint32_t* out; size_t height, row; const LookupSink& sink; bool count; const CurveField<NL>& f;
+  int32_t* van;          // LDS: 2 N - 1 coefficients, stride T
+  uint32_t *opa, *opb;   // LDS: NL limbs each, stride T
+  // the block's LDS after the lookup table (if any): accumulators, then the operands
+  __device__ static FieldRow make(uint32_t* out, size_t height, size_t row, const LookupSink& sink, bool count, const CurveField<NL>& f, uint32_t* lds) {
+    int32_t* van = (int32_t*)lds + threadIdx.x;
+    uint32_t* opa = lds + (size_t)T * (2 * N - 1) + threadIdx.x;
+    return FieldRow{out, height, row, sink, count, f, van, opa, opa + (size_t)T * NL};
+  }
   __device__ __forceinline__ void put(int col, uint32_t canonical) const { out[(size_t)col * height + row] = kb::to_monty(canonical); }
-  // columns of one gadget at `base` from the identity's polynomial before the carry term (63 coefficients) and the two integers
-  __device__ void gadget(int base, int32_t* van, const uint32_t* result, const uint32_t* carry) const {
-    constexpr int N = ED_LIMBS, NW = 2 * ED_LIMBS - 2;
-    for (int i = 0; i < N; i++) {
-      const int32_t c = (int32_t)bigfield::byte_of(carry, i);
-      for (int j = 0; j < N; j++) van[i + j] -= c * (int32_t)bigfield::byte_of(d_ed25519.p, j);
+  __device__ __forceinline__ int32_t& V(int k) const { return van[(size_t)k * T]; }
+  __device__ __forceinline__ int32_t A(int i) const { return (int32_t)((opa[(size_t)(i >> 2) * T] >> (8 * (i & 3))) & 0xff); }
+  __device__ __forceinline__ int32_t B(int i) const { return (int32_t)((opb[(size_t)(i >> 2) * T] >> (8 * (i & 3))) & 0xff); }
+  __device__ __forceinline__ void stage_a(const uint32_t* x) const {
+#pragma unroll
+    for (int l = 0; l < NL; l++) opa[(size_t)l * T] = x[l];
+  }
+  __device__ __forceinline__ void stage_b(const uint32_t* x) const {
+#pragma unroll
+    for (int l = 0; l < NL; l++) opb[(size_t)l * T] = x[l];
+  }
+  __device__ void clear() const { for (int k = 0; k < 2 * N - 1; k++) V(k) = 0; }
+  // accumulator += sign * (staged a)(x) * (staged b)(x): one coefficient at a time, summed in a register
+  __device__ void mac_staged(int sign) const {
+    for (int k = 0; k < 2 * N - 1; k++) {
+      const int lo = k < N ? 0 : k - N + 1, hi = k < N ? k : N - 1;
+      int32_t acc = 0;
+      for (int i = lo; i <= hi; i++) acc += A(i) * B(k - i);
+      V(k) += sign * acc;
     }
-    uint32_t prev_low = 0, prev_high = 0;
+  }
+  __device__ void mac(const uint32_t* x, const uint32_t* y) const { stage_a(x); stage_b(y); mac_staged(1); }
+  __device__ void add(const uint32_t* x, int sign) const {
+    stage_a(x);
+    for (int i = 0; i < N; i++) V(i) += sign * A(i);
+  }
+  // the gadget's columns at `base` from the accumulator (the identity's polynomial before the carry term) and the two integers. Its byte
+  // lookups — the range checks of all four limb vectors in pairs (i, i + 1), even i — are not counted here: u8_pair_histogram reads them
+  // off the finished columns
+  __device__ void gadget(int base, const uint32_t* result, const uint32_t* carry) const {
+    stage_a(carry); stage_b(f.m.p); mac_staged(-1);
     int32_t above = 0;
     for (int k = NW; k >= 1; k--) {          // w[k - 1] = van[k] + 256 w[k]
-      above = van[k] + 256 * above;
-      const uint32_t shifted = (uint32_t)(above + (1 << 14));
+      above = V(k) + 256 * above;
+      const uint32_t shifted = (uint32_t)(above + f.witness_offset);
       put(base + 2 * N + k - 1, shifted & 0xff);
       put(base + 2 * N + NW + k - 1, shifted >> 8);
-      if (count) {                           // slice_range_check_u8 pairs (i, i + 1) for even i
-        if ((k - 1) % 2 == 0) { lookup(sink, B_U8RANGE, shifted & 0xff, prev_low); lookup(sink, B_U8RANGE, shifted >> 8, prev_high); }
-        prev_low = shifted & 0xff; prev_high = shifted >> 8;
-      }
     }
-    for (int i = 0; i < N; i++) { put(base + i, bigfield::byte_of(result, i)); put(base + N + i, bigfield::byte_of(carry, i)); }
-    if (count)
-      for (int i = 0; i < N; i += 2) {
-        lookup(sink, B_U8RANGE, bigfield::byte_of(result, i), bigfield::byte_of(result, i + 1));
-        lookup(sink, B_U8RANGE, bigfield::byte_of(carry, i), bigfield::byte_of(carry, i + 1));
-      }
+#pragma unroll
+    for (int l = 0; l < NL; l++)
+#pragma unroll
+      for (int j = 0; j < 4; j++) { put(base + 4 * l + j, (result[l] >> (8 * j)) & 0xff); put(base + N + 4 * l + j, (carry[l] >> (8 * j)) & 0xff); }
+  }
+  // FieldOpCols::populate_with_modulus (operations/field/field_op.rs:154-224) for a, b below p; Sub and Div through the reversed identities
+  __device__ void op(int base, const uint32_t* a, const uint32_t* b, int kind, uint32_t* res) const {
+    const bigfield::Modulus<NL>& m = f.m;
+    uint32_t t[2 * NL], t2[2 * NL], q[NL + 1];
+    for (int i = 0; i <= NL; i++) q[i] = 0;
+    clear();
+    if (kind == FOP_ADD) {
+      for (int i = 0; i < NL; i++) res[i] = a[i];
+      const uint32_t carry_out = bigfield::add<NL>(res, b);
+      const uint32_t wraps = carry_out | (bigfield::cmp<NL>(res, m.p) >= 0 ? 1u : 0u);
+      if (wraps) bigfield::sub<NL>(res, m.p);
+      q[0] = wraps;
+      add(a, 1); add(b, 1); add(res, -1);
+    } else if (kind == FOP_SUB) {                 // result + b = a + carry p
+      for (int i = 0; i < NL; i++) res[i] = a[i];
+      const uint32_t borrows = bigfield::sub<NL>(res, b);
+      if (borrows) bigfield::add<NL>(res, m.p);
+      q[0] = borrows;
+      add(res, 1); add(b, 1); add(a, -1);
+    } else if (kind == FOP_MUL) {
+      bigfield::mul<NL, NL>(a, b, t);
+      bigfield::divmod<NL>(t, m, q, res);
+      mac(a, b); add(res, -1);
+    } else {                                      // result * b = a + carry p
+      bool zero = true;
+      for (int i = 0; i < NL; i++) zero = zero && a[i] == 0;
+      if (zero) { for (int i = 0; i < NL; i++) res[i] = 0; } else { uint32_t inv[NL]; bigfield::inverse<NL>(b, m, inv); bigfield::mulmod<NL>(a, inv, m, res); }
+      bigfield::mul<NL, NL>(res, b, t);
+      for (int i = 0; i < 2 * NL; i++) t2[i] = i < NL ? a[i] : 0u;
+      bigfield::sub<2 * NL>(t, t2);
+      uint32_t rem[NL];
+      bigfield::divmod<NL>(t, m, q, rem);
+      mac(res, b); add(a, -1);
+    }
+    gadget(base, res, q);
+  }
+  // FieldLtCols::populate (operations/field/range.rs:27-60) of a value below p against p: N flags, the two compared bytes
+  __device__ void lt(int base, const uint32_t* lhs) const {
+    stage_a(lhs); stage_b(f.m.p);
+    int at = -1;
+    for (int i = N - 1; i >= 0 && at < 0; i--)
+      if (A(i) < B(i)) at = i;
+    for (int i = 0; i < N; i++) put(base + i, i == at ? 1u : 0u);
+    const uint32_t a = at >= 0 ? (uint32_t)A(at) : 0u, b = at >= 0 ? (uint32_t)B(at) : 0u;
+    put(base + N, a); put(base + N + 1, b);
+    if (count && at >= 0) lookup(sink, B_LTU, a, b);
+  }
+  // the memory columns of a W-word write slice (6-word records) and read slice (5-word records); zero for a padding row
+  __device__ void write_cols(int base, const uint32_t* rec) const {
+    uint32_t mw[13];
+    for (int c = 0; c < 13; c++) mw[c] = 0;
+    if (rec) {
+      memory_write_cols(rec, mw);
+      if (count) { lookup(sink, B_U16RANGE, mw[11] >> 8, mw[11]); lookup(sink, B_U8RANGE, 0, mw[12]); }
+    }
+    for (int c = 0; c < 13; c++) put(base + c, mw[c]);
+  }
+  __device__ void read_cols(int base, const uint32_t* rec) const {
+    uint32_t mr[9];
+    for (int c = 0; c < 9; c++) mr[c] = 0;
+    if (rec) {
+      memory_access_cols(rec[0], rec[1], rec[2], rec[3], rec[4], mr);
+      if (count) access_lookups(mr, sink);
+    }
+    for (int c = 0; c < 9; c++) put(base + c, mr[c]);
   }
 };
-__device__ __forceinline__ void ed_poly_mac(int32_t* acc, const uint32_t* a, const uint32_t* b) {      // acc(x) += a(x) b(x) over byte limbs
-  for (int i = 0; i < ED_LIMBS; i++) {
-    const int32_t ai = (int32_t)bigfield::byte_of(a, i);
-    for (int j = 0; j < ED_LIMBS; j++) acc[i + j] += ai * (int32_t)bigfield::byte_of(b, j);
+// every big-field kernel starts and ends the same way: the block's lookup table in LDS, flushed into the global counters at the end
+struct BfBlock {
+  uint32_t *hkeys, *hvals, *scratch;
+  bool count;
+  __device__ BfBlock(uint32_t* lds, uint32_t* counts) : hkeys(lds), hvals(lds + BF_HASH_SLOTS), scratch(counts ? lds + 2 * BF_HASH_SLOTS : lds), count(counts != nullptr) {
+    if (count) {
+      for (int i = threadIdx.x; i < BF_HASH_SLOTS; i += blockDim.x) { hkeys[i] = HASH_EMPTY; hvals[i] = 0; }
+      __syncthreads();
+    }
   }
+  __device__ void flush(uint32_t* counts) const {
+    if (count) {
+      __syncthreads();
+      for (int i = threadIdx.x; i < BF_HASH_SLOTS; i += blockDim.x)
+        if (hkeys[i] != HASH_EMPTY) atomicAdd(counts + hkeys[i], hvals[i]);
+    }
+  }
+};
+
+// The U8Range lookups of adjacent byte columns, counted from the trace: for every real row and every pair of columns (start + 2 j,
+// start + 2 j + 1) of the given segments, one lookup (U8Range, b, c). A block takes a slab of rows and a quarter of the key space (the
+// top two bits of b), reads the slab's byte columns (coalesced along the rows; the other three quarters' blocks read them again, out of
+// the memory-side cache) and counts in a dense LDS histogram of 16384 counters — no probing, no overflow. It leaves its counters in its
+// own part of `partial` [slab][key]; u8_pair_reduce adds the slabs up into the lookup counters. Rows per slab: a power of two >= 256.
+struct U8Segments { int n; int start[4]; int cols[4]; };
+constexpr int U8H_RANGES = 4, U8H_KEYS = 65536 / U8H_RANGES, U8H_THREADS = 512, U8H_MAX_SLABS = 64;
+__global__ __launch_bounds__(U8H_THREADS) void u8_pair_histogram(const uint32_t* __restrict__ trace, size_t height, size_t n_real, const U8Segments seg,
+                                                                 int log_slab_rows, uint32_t* __restrict__ partial) {
+  __shared__ uint32_t hist[U8H_KEYS];
+  const uint32_t slab = blockIdx.x / U8H_RANGES, range = blockIdx.x % U8H_RANGES;
+  for (int i = threadIdx.x; i < U8H_KEYS; i += U8H_THREADS) hist[i] = 0;
+  __syncthreads();
+  const size_t row0 = (size_t)slab << log_slab_rows;
+  const uint32_t slab_rows = 1u << log_slab_rows;
+  for (int sg = 0; sg < seg.n; sg++) {
+    const uint32_t* base = trace + (size_t)seg.start[sg] * height + row0;
+    const uint32_t items = (uint32_t)(seg.cols[sg] / 2) << log_slab_rows;      // (pair, row) with the row fastest: a wavefront shares the pair
+#pragma unroll 4
+    for (uint32_t idx = threadIdx.x; idx < items; idx += U8H_THREADS) {
+      const uint32_t pair = idx >> log_slab_rows, r = idx & (slab_rows - 1);
+      if (row0 + r < n_real) {
+        const uint32_t* at = base + (size_t)(2 * pair) * height + r;
+        const uint32_t b = kb::from_monty(at[0]), c = kb::from_monty(at[height]);
+        if ((b >> 6) == range) atomicAdd(&hist[(b & 0x3f) << 8 | (c & 0xff)], 1u);
+      }
+    }
+  }
+  __syncthreads();
+  uint32_t* mine = partial + (size_t)slab * 65536 + (size_t)range * U8H_KEYS;
+  for (int i = threadIdx.x; i < U8H_KEYS; i += U8H_THREADS) mine[i] = hist[i];
 }
-__device__ __forceinline__ void ed_poly_add(int32_t* acc, const uint32_t* a, int sign) {
-  for (int i = 0; i < ED_LIMBS; i++) acc[i] += sign * (int32_t)bigfield::byte_of(a, i);
+__global__ __launch_bounds__(256) void u8_pair_reduce(const uint32_t* __restrict__ partial, int slabs, uint32_t* __restrict__ u8range_counts) {
+  const uint32_t key = blockIdx.x * 256 + threadIdx.x;
+  uint32_t sum = 0;
+  for (int s = 0; s < slabs; s++) sum += partial[(size_t)s * 65536 + key];
+  if (sum) atomicAdd(u8range_counts + key, sum);
 }
-__global__ __launch_bounds__(BF_THREADS) void ed_add_rows(const uint32_t* __restrict__ events, size_t n_events, size_t height, uint32_t* __restrict__ out,
-                                                  uint32_t* counts, int* __restrict__ bad) {
+
+// ---- EdAddAssign (syscall/precompiles/edwards/ed_add.rs:41-57, :68-95, :210-243): one Ed25519 point addition per row, 1861 columns: the memory
+// columns of p (written at clk + 1) and q, and eight gadgets: x3_numerator, y3_numerator (FieldInnerProductCols), x1_mul_y1, x2_mul_y2, f, d_mul_f
+// (FieldOpCols), x3_ins, y3_ins (FieldDenCols). Padding rows hold the gadgets of the zero inputs: zero except witness_high = 2^14 >> 8.
+constexpr int ED_ADD_WIDTH = 1861, ED_ADD_EVENT_WORDS = 180, ED_LIMBS = 32, ED_GADGET = 188;
+__constant__ CurveField<8> d_ed25519 = {
+    {{0xffffffedu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0x7fffffffu},
+     {76u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 2u}},      // floor(2^512 / (2^255 - 19)) = 2^257 + 76 (the next term, 19^2 * 4 / 2^255, is below one)
+    {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u},              // not a Weierstrass curve: `a` is unused
+    1 << 14};
+__constant__ uint32_t d_ed25519_d[8] = {0x135978a3u, 0x75eb4dcau, 0x4141d8abu, 0x00700a4du, 0x7779e898u, 0x8cc74079u, 0x2b6ffe73u, 0x52036ceeu};
+__global__ __launch_bounds__(bf_threads(8)) void ed_add_rows(const uint32_t* __restrict__ events, size_t n_events, size_t height, uint32_t* __restrict__ out,
+                                                             uint32_t* counts, int* __restrict__ bad) {
   enum { IS_REAL = 0, SHARD = 1, CLK = 2, P_PTR = 3, Q_PTR = 4, P_ACCESS = 5, Q_ACCESS = 5 + 16 * 13, GADGETS = 5 + 16 * 13 + 16 * 9, G = ED_GADGET };
   enum { E_P_RECORDS = 4, E_Q_RECORDS = 4 + 96 };
-  extern __shared__ uint32_t hash_lds[];
-  uint32_t* hkeys = hash_lds;
-  uint32_t* hvals = hash_lds + BF_HASH_SLOTS;
-  const bool count = counts != nullptr;
-  if (count) {
-    for (int i = threadIdx.x; i < BF_HASH_SLOTS; i += blockDim.x) { hkeys[i] = HASH_EMPTY; hvals[i] = 0; }
-    __syncthreads();
-  }
+  extern __shared__ uint32_t bf_lds[];
+  const BfBlock blk(bf_lds, counts);
   const size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (row < height) {
     const bool real = row < n_events;
     const uint32_t* e = events + row * ED_ADD_EVENT_WORDS;
-    const LookupSink sink{hkeys, hvals, BF_HASH_SLOTS - 1, counts};
-    const EdRow R{out, height, row, sink, count && real};
-    const bigfield::Modulus<8>& m = d_ed25519;
+    const LookupSink sink{blk.hkeys, blk.hvals, BF_HASH_SLOTS - 1, counts};
+    const FieldRow<8> R = FieldRow<8>::make(out, height, row, sink, blk.count && real, d_ed25519, blk.scratch);
+    const bigfield::Modulus<8>& m = d_ed25519.m;
     uint32_t x1[8], y1[8], x2[8], y2[8];
     for (int k = 0; k < 8; k++) {
       x1[k] = real ? e[E_P_RECORDS + 6 * k + 3] : 0u;            // p = the previous values of the p write records
@@ -1768,25 +1916,17 @@ __global__ __launch_bounds__(BF_THREADS) void ed_add_rows(const uint32_t* __rest
       x2[k] = real ? e[E_Q_RECORDS + 5 * k] : 0u;
       y2[k] = real ? e[E_Q_RECORDS + 5 * (8 + k)] : 0u;
     }
-    int32_t van[2 * ED_LIMBS - 1];
     uint32_t t[16], t2[16], q[9], x3n[8], y3n[8], a[8], b[8], f[8], df[8], res[8];
-    auto clear = [&]() { for (int i = 0; i < 2 * ED_LIMBS - 1; i++) van[i] = 0; };
-    // x3_numerator = x1 y2 + x2 y1, y3_numerator = y1 y2 + x1 x2 (FieldInnerProductCols)
+    // x3_numerator = x1 y2 + x2 y1, y3_numerator = y1 y2 + x1 x2 (FieldInnerProductCols::populate, field_inner_product.rs:27-79)
     auto inner = [&](int base, const uint32_t* a0, const uint32_t* b0, const uint32_t* a1, const uint32_t* b1, uint32_t* result) {
       bigfield::mul<8, 8>(a0, b0, t); bigfield::mul<8, 8>(a1, b1, t2);
       bigfield::add<16>(t, t2);                        // below 2 p^2 < 2^511
       bigfield::divmod<8>(t, m, q, result);
-      clear(); ed_poly_mac(van, a0, b0); ed_poly_mac(van, a1, b1); ed_poly_add(van, result, -1);
-      R.gadget(base, van, result, q);
+      R.clear(); R.mac(a0, b0); R.mac(a1, b1); R.add(result, -1);
+      R.gadget(base, result, q);
     };
-    auto product = [&](int base, const uint32_t* a0, const uint32_t* b0, uint32_t* result) {      // FieldOpCols, Mul
-      bigfield::mul<8, 8>(a0, b0, t);
-      bigfield::divmod<8>(t, m, q, result);
-      clear(); ed_poly_mac(van, a0, b0); ed_poly_add(van, result, -1);
-      R.gadget(base, van, result, q);
-    };
-    // FieldDenCols: result (1 +- b) = a. The two denominators 1 + d f and 1 - d f are inverted together: one Fermat inverse of their product
-    // (Montgomery's trick), then one product each
+    // FieldDenCols::populate (field_den.rs:27-81): result (1 +- b) = a. The two denominators 1 + d f and 1 - d f are inverted together: one
+    // Fermat inverse of their product (Montgomery's trick), then one product each
     uint32_t inv_plus[8], inv_minus[8];
     auto denominators = [&](const uint32_t* bb) {
       uint32_t dp[8], dm[8], prod[8], inv[8];
@@ -1811,15 +1951,15 @@ __global__ __launch_bounds__(BF_THREADS) void ed_add_rows(const uint32_t* __rest
       bigfield::sub<16>(t, t2);
       uint32_t rem[8];
       bigfield::divmod<8>(t, m, q, rem);
-      clear(); ed_poly_mac(van, bb, result); ed_poly_add(van, sign ? result : num, 1); ed_poly_add(van, sign ? num : result, -1);
-      R.gadget(base, van, result, q);
+      R.clear(); R.mac(bb, result); R.add(sign ? result : num, 1); R.add(sign ? num : result, -1);
+      R.gadget(base, result, q);
     };
     inner(GADGETS, x1, y2, x2, y1, x3n);
     inner(GADGETS + G, y1, y2, x1, x2, y3n);
-    product(GADGETS + 2 * G, x1, y1, a);
-    product(GADGETS + 3 * G, x2, y2, b);
-    product(GADGETS + 4 * G, a, b, f);
-    product(GADGETS + 5 * G, f, d_ed25519_d, df);
+    R.op(GADGETS + 2 * G, x1, y1, FOP_MUL, a);
+    R.op(GADGETS + 3 * G, x2, y2, FOP_MUL, b);
+    R.op(GADGETS + 4 * G, a, b, FOP_MUL, f);
+    R.op(GADGETS + 5 * G, f, d_ed25519_d, FOP_MUL, df);
     denominators(df);
     den(GADGETS + 6 * G, x3n, df, true, res);
     bool ok = true;
@@ -1832,116 +1972,48 @@ __global__ __launch_bounds__(BF_THREADS) void ed_add_rows(const uint32_t* __rest
     R.put(IS_REAL, real ? 1u : 0u);
     R.put(SHARD, real ? e[0] : 0u); R.put(CLK, real ? e[1] : 0u); R.put(P_PTR, real ? e[2] : 0u); R.put(Q_PTR, real ? e[3] : 0u);
     for (int k = 0; k < 16; k++) {
-      uint32_t mw[13], mr[9];
-      if (real) {
-        memory_write_cols(e + E_P_RECORDS + 6 * k, mw);
-        const uint32_t* rec = e + E_Q_RECORDS + 5 * k;
-        memory_access_cols(rec[0], rec[1], rec[2], rec[3], rec[4], mr);
-        if (count) { access_lookups(mr, sink); lookup(sink, B_U16RANGE, mw[11] >> 8, mw[11]); lookup(sink, B_U8RANGE, 0, mw[12]); }
-      } else {
-        for (int c = 0; c < 13; c++) mw[c] = 0;
-        for (int c = 0; c < 9; c++) mr[c] = 0;
-      }
-      for (int c = 0; c < 13; c++) R.put(P_ACCESS + 13 * k + c, mw[c]);
-      for (int c = 0; c < 9; c++) R.put(Q_ACCESS + 9 * k + c, mr[c]);
+      R.write_cols(P_ACCESS + 13 * k, real ? e + E_P_RECORDS + 6 * k : nullptr);
+      R.read_cols(Q_ACCESS + 9 * k, real ? e + E_Q_RECORDS + 5 * k : nullptr);
     }
   }
-  if (count) {
-    __syncthreads();
-    for (int i = threadIdx.x; i < BF_HASH_SLOTS; i += blockDim.x)
-      if (hkeys[i] != HASH_EMPTY) atomicAdd(counts + hkeys[i], hvals[i]);
-  }
+  blk.flush(counts);
 }
 
-// ---- EdDecompress precompile (syscall/precompiles/edwards/ed_decompress.rs:39-57, :85-101): x = sqrt((y^2 - 1) / (d y^2 + 1)) from y and a sign bit,
-// one row per call, 1566 columns: memory columns of x (written) and y (read), a FieldLtCols of y against p, five FieldOpCols (yy, u, dyy, v,
-// u_div_v), a FieldSqrtCols (a FieldOpCols whose result columns hold the even root, the root's FieldLtCols, its low bit), and neg_x.
-// The root is a^((p + 3) / 8), times sqrt(-1) when that squares to -a (curves/src/edwards/ed25519.rs:75-113).
+// ---- EdDecompress (syscall/precompiles/edwards/ed_decompress.rs:39-57, :85-101): x = sqrt((y^2 - 1) / (d y^2 + 1)) from y and a sign bit, one row
+// per call, 1566 columns: memory columns of x (written) and y (read), a FieldLtCols of y against p, five FieldOpCols (yy, u, dyy, v, u_div_v), a
+// FieldSqrtCols (a FieldOpCols whose result columns hold the even root, the root's FieldLtCols, its low bit), and neg_x. The root is
+// a^((p + 3) / 8), times sqrt(-1) when that squares to -a (curves/src/edwards/ed25519.rs:75-113). Padding rows: y = 0.
 constexpr int ED_DECOMPRESS_WIDTH = 1566, ED_DECOMPRESS_EVENT_WORDS = 92;
 __constant__ uint32_t d_ed25519_sqrt_exp[8] = {0xfffffffeu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0x0fffffffu};
 __constant__ uint32_t d_ed25519_sqrt_m1[8] = {0x4a0ea0b0u, 0xc4ee1b27u, 0xad2fe478u, 0x2f431806u, 0x3dfbd7a7u, 0x2b4d0099u, 0x4fc1df0bu, 0x2b832480u};
-enum { FOP_ADD = 0, FOP_SUB = 1, FOP_MUL = 2, FOP_DIV = 3 };
-// FieldOpCols::populate_with_modulus (operations/field/field_op.rs:154-224) for a, b below p: the columns at `base`, the result in `res`
-__device__ void ed_field_op(const EdRow& R, int base, const uint32_t* a, const uint32_t* b, int op, uint32_t* res, int32_t* van) {
-  const bigfield::Modulus<8>& m = d_ed25519;
-  uint32_t t[16], t2[16], q[9] = {0};
-  for (int i = 0; i < 2 * ED_LIMBS - 1; i++) van[i] = 0;
-  if (op == FOP_ADD || op == FOP_SUB) {
-    if (op == FOP_ADD) {
-      for (int i = 0; i < 8; i++) res[i] = a[i];
-      bigfield::add<8>(res, b);                                   // below 2^256: no carry out for a, b < p < 2^255
-      const uint32_t wraps = bigfield::cmp<8>(res, m.p) >= 0 ? 1u : 0u;
-      if (wraps) bigfield::sub<8>(res, m.p);
-      q[0] = wraps;
-      ed_poly_add(van, a, 1); ed_poly_add(van, b, 1); ed_poly_add(van, res, -1);
-    } else {                                                       // result + b = a + carry p
-      for (int i = 0; i < 8; i++) res[i] = a[i];
-      if (bigfield::sub<8>(res, b)) { bigfield::add<8>(res, m.p); q[0] = 1; }
-      ed_poly_add(van, res, 1); ed_poly_add(van, b, 1); ed_poly_add(van, a, -1);
-    }
-  } else if (op == FOP_MUL) {
-    bigfield::mul<8, 8>(a, b, t);
-    bigfield::divmod<8>(t, m, q, res);
-    ed_poly_mac(van, a, b); ed_poly_add(van, res, -1);
-  } else {                                                         // result * b = a + carry p
-    bool zero = true;
-    for (int i = 0; i < 8; i++) zero = zero && a[i] == 0;
-    if (zero) { for (int i = 0; i < 8; i++) res[i] = 0; } else { uint32_t inv[8]; bigfield::inverse<8>(b, m, inv); bigfield::mulmod<8>(a, inv, m, res); }
-    bigfield::mul<8, 8>(res, b, t);
-    for (int i = 0; i < 16; i++) t2[i] = i < 8 ? a[i] : 0u;
-    bigfield::sub<16>(t, t2);
-    uint32_t rem[8];
-    bigfield::divmod<8>(t, m, q, rem);
-    ed_poly_mac(van, res, b); ed_poly_add(van, a, -1);
-  }
-  R.gadget(base, van, res, q);
-}
-// FieldLtCols::populate (operations/field/range.rs:27-60) of a value below p against p
-__device__ void ed_field_lt(const EdRow& R, int base, const uint32_t* lhs) {
-  int at = -1;
-  for (int i = ED_LIMBS - 1; i >= 0 && at < 0; i--)
-    if (bigfield::byte_of(lhs, i) < bigfield::byte_of(d_ed25519.p, i)) at = i;
-  for (int i = 0; i < ED_LIMBS; i++) R.put(base + i, i == at ? 1u : 0u);
-  const uint32_t a = at >= 0 ? bigfield::byte_of(lhs, at) : 0u, b = at >= 0 ? bigfield::byte_of(d_ed25519.p, at) : 0u;
-  R.put(base + ED_LIMBS, a); R.put(base + ED_LIMBS + 1, b);
-  if (R.count && at >= 0) lookup(R.sink, B_LTU, a, b);
-}
-__global__ __launch_bounds__(BF_THREADS) void ed_decompress_rows(const uint32_t* __restrict__ events, size_t n_events, size_t height, uint32_t* __restrict__ out,
-                                                         uint32_t* counts, int* __restrict__ bad) {
+__global__ __launch_bounds__(bf_threads(8)) void ed_decompress_rows(const uint32_t* __restrict__ events, size_t n_events, size_t height,
+                                                                    uint32_t* __restrict__ out, uint32_t* counts, int* __restrict__ bad) {
   enum { IS_REAL = 0, SHARD = 1, CLK = 2, PTR = 3, SIGN = 4, X_ACCESS = 5, Y_ACCESS = 109, Y_RANGE = 181, YY = 215, U = 403, DYY = 591, V = 779, U_DIV_V = 967,
          X_MULT = 1155, X_RANGE = 1343, X_LSB = 1377, NEG_X = 1378 };
   enum { E_X_RECORDS = 4, E_Y_RECORDS = 52 };
-  extern __shared__ uint32_t hash_lds[];
-  uint32_t* hkeys = hash_lds;
-  uint32_t* hvals = hash_lds + BF_HASH_SLOTS;
-  const bool count = counts != nullptr;
-  if (count) {
-    for (int i = threadIdx.x; i < BF_HASH_SLOTS; i += blockDim.x) { hkeys[i] = HASH_EMPTY; hvals[i] = 0; }
-    __syncthreads();
-  }
+  extern __shared__ uint32_t bf_lds[];
+  const BfBlock blk(bf_lds, counts);
   const size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (row < height) {
     const bool real = row < n_events;
     const uint32_t* e = events + row * ED_DECOMPRESS_EVENT_WORDS;
-    const LookupSink sink{hkeys, hvals, BF_HASH_SLOTS - 1, counts};
-    const EdRow R{out, height, row, sink, count && real};
-    const bigfield::Modulus<8>& m = d_ed25519;
+    const LookupSink sink{blk.hkeys, blk.hvals, BF_HASH_SLOTS - 1, counts};
+    const FieldRow<8> R = FieldRow<8>::make(out, height, row, sink, blk.count && real, d_ed25519, blk.scratch);
+    const bigfield::Modulus<8>& m = d_ed25519.m;
     int why = 0;
     uint32_t y[8];
     for (int k = 0; k < 8; k++) y[k] = real ? e[E_Y_RECORDS + 5 * k] : 0u;
     if (bigfield::cmp<8>(y, m.p) >= 0) { why = 1; for (int k = 0; k < 8; k++) y[k] = 0; }
     if (real && e[3] > 1) why = 1;
-    int32_t van[2 * ED_LIMBS - 1];
     uint32_t yy[8], u[8], dyy[8], v[8], udv[8], x[8], sq[8], neg[8];
     const uint32_t one[8] = {1}, zero[8] = {0};
-    ed_field_lt(R, Y_RANGE, y);
-    ed_field_op(R, YY, y, y, FOP_MUL, yy, van);
-    ed_field_op(R, U, yy, one, FOP_SUB, u, van);
-    ed_field_op(R, DYY, d_ed25519_d, yy, FOP_MUL, dyy, van);
-    ed_field_op(R, V, one, dyy, FOP_ADD, v, van);
-    ed_field_op(R, U_DIV_V, u, v, FOP_DIV, udv, van);
-    // the even square root of u / v
-    {
+    R.lt(Y_RANGE, y);
+    R.op(YY, y, y, FOP_MUL, yy);
+    R.op(U, yy, one, FOP_SUB, u);
+    R.op(DYY, d_ed25519_d, yy, FOP_MUL, dyy);
+    R.op(V, one, dyy, FOP_ADD, v);
+    R.op(U_DIV_V, u, v, FOP_DIV, udv);
+    {      // the even square root of u / v
       uint32_t acc[8] = {1};
       bool started = false;
       for (int bit = 255; bit >= 0; bit--) {
@@ -1962,140 +2034,45 @@ __global__ __launch_bounds__(BF_THREADS) void ed_decompress_rows(const uint32_t*
       }
       if (x[0] & 1) { uint32_t tmp[8]; for (int i = 0; i < 8; i++) tmp[i] = m.p[i]; bigfield::sub<8>(tmp, x); for (int i = 0; i < 8; i++) x[i] = tmp[i]; }
     }
-    // FieldSqrtCols: x * x = u_div_v in the multiplication's carry / witness columns, the root itself in its result columns
-    ed_field_op(R, X_MULT, x, x, FOP_MUL, sq, van);
-    for (int i = 0; i < ED_LIMBS; i++) R.put(X_MULT + i, bigfield::byte_of(x, i));
-    ed_field_lt(R, X_RANGE, x);
+    // FieldSqrtCols (field_sqrt.rs:34-85): x * x = u_div_v in the multiplication's carry / witness columns, the root itself in its result columns
+    R.op(X_MULT, x, x, FOP_MUL, sq);
+    R.stage_a(x);
+    for (int i = 0; i < ED_LIMBS; i++) R.put(X_MULT + i, (uint32_t)R.A(i));
+    if (R.count) lookup(sink, B_AND, x[0], 1);      // the range checks of the product's and the root's bytes: u8_pair_histogram
+    R.lt(X_RANGE, x);
     R.put(X_LSB, x[0] & 1);
-    if (R.count) {
-      lookup(sink, B_AND, x[0], 1);
-      for (int i = 0; i < ED_LIMBS; i += 2) lookup(sink, B_U8RANGE, bigfield::byte_of(x, i), bigfield::byte_of(x, i + 1));
-    }
-    ed_field_op(R, NEG_X, zero, x, FOP_SUB, neg, van);
+    R.op(NEG_X, zero, x, FOP_SUB, neg);
     R.put(IS_REAL, real ? 1u : 0u);
     R.put(SHARD, real ? e[0] : 0u); R.put(CLK, real ? e[1] : 0u); R.put(PTR, real ? e[2] : 0u); R.put(SIGN, real ? e[3] : 0u);
     for (int k = 0; k < 8; k++) {
-      uint32_t mw[13], mr[9];
-      if (real) {
-        memory_write_cols(e + E_X_RECORDS + 6 * k, mw);
-        const uint32_t* rec = e + E_Y_RECORDS + 5 * k;
-        memory_access_cols(rec[0], rec[1], rec[2], rec[3], rec[4], mr);
-        if (count) { access_lookups(mr, sink); lookup(sink, B_U16RANGE, mw[11] >> 8, mw[11]); lookup(sink, B_U8RANGE, 0, mw[12]); }
-        if (e[E_X_RECORDS + 6 * k] != (e[3] ? neg[k] : x[k])) why = why ? why : 3;
-      } else {
-        for (int c = 0; c < 13; c++) mw[c] = 0;
-        for (int c = 0; c < 9; c++) mr[c] = 0;
-      }
-      for (int c = 0; c < 13; c++) R.put(X_ACCESS + 13 * k + c, mw[c]);
-      for (int c = 0; c < 9; c++) R.put(Y_ACCESS + 9 * k + c, mr[c]);
+      R.write_cols(X_ACCESS + 13 * k, real ? e + E_X_RECORDS + 6 * k : nullptr);
+      R.read_cols(Y_ACCESS + 9 * k, real ? e + E_Y_RECORDS + 5 * k : nullptr);
+      if (real && e[E_X_RECORDS + 6 * k] != (e[3] ? neg[k] : x[k])) why = why ? why : 3;
     }
     if (real && why) atomicMax(bad, 16 - why);
   }
-  if (count) {
-    __syncthreads();
-    for (int i = threadIdx.x; i < BF_HASH_SLOTS; i += blockDim.x)
-      if (hkeys[i] != HASH_EMPTY) atomicAdd(counts + hkeys[i], hvals[i]);
-  }
+  blk.flush(counts);
 }
 
-// ---- Short-Weierstrass precompiles (syscall/precompiles/weierstrass/weierstrass_add.rs, weierstrass_double.rs) for Secp256k1, Secp256r1, Bn254
-// (32 byte limbs, eight 32-bit limbs here) and Bls12381 (48 / twelve): nine / eleven FieldOpCols per row. The curve's base field arrives as
-// a kernel argument (modulus, its Barrett constant, `a`, the witness offset); the gadget code is the Ed25519 one with the limb count as a
-// template parameter. Padding rows: an addition's are the operations of the zero inputs; a doubling's are those of the point (0, 1) with the
-// dummy write record of weierstrass_double.rs:225-239 on the first word of y.
-template <int NL> struct CurveField { bigfield::Modulus<NL> m; uint32_t a[NL]; int32_t witness_offset; };
-template <int NL> struct FieldRow {
-  static constexpr int N = 4 * NL, NW = 2 * N - 2, G = 2 * N + 2 * NW;
-  uint32_t* out; size_t height, row; const LookupSink& sink; bool count; const CurveField<NL>& f;
-  __device__ __forceinline__ void put(int col, uint32_t canonical) const { out[(size_t)col * height + row] = kb::to_monty(canonical); }
-  static __device__ __forceinline__ void poly_mac(int32_t* acc, const uint32_t* a, const uint32_t* b) {
-    for (int i = 0; i < N; i++) {
-      const int32_t ai = (int32_t)bigfield::byte_of(a, i);
-      for (int j = 0; j < N; j++) acc[i + j] += ai * (int32_t)bigfield::byte_of(b, j);
-    }
-  }
-  static __device__ __forceinline__ void poly_add(int32_t* acc, const uint32_t* a, int sign) {
-    for (int i = 0; i < N; i++) acc[i] += sign * (int32_t)bigfield::byte_of(a, i);
-  }
-  __device__ void gadget(int base, int32_t* van, const uint32_t* result, const uint32_t* carry) const {
-    for (int i = 0; i < N; i++) {
-      const int32_t c = (int32_t)bigfield::byte_of(carry, i);
-      for (int j = 0; j < N; j++) van[i + j] -= c * (int32_t)bigfield::byte_of(f.m.p, j);
-    }
-    uint32_t prev_low = 0, prev_high = 0;
-    int32_t above = 0;
-    for (int k = NW; k >= 1; k--) {
-      above = van[k] + 256 * above;
-      const uint32_t shifted = (uint32_t)(above + f.witness_offset);
-      put(base + 2 * N + k - 1, shifted & 0xff);
-      put(base + 2 * N + NW + k - 1, shifted >> 8);
-      if (count) {
-        if ((k - 1) % 2 == 0) { lookup(sink, B_U8RANGE, shifted & 0xff, prev_low); lookup(sink, B_U8RANGE, shifted >> 8, prev_high); }
-        prev_low = shifted & 0xff; prev_high = shifted >> 8;
-      }
-    }
-    for (int i = 0; i < N; i++) { put(base + i, bigfield::byte_of(result, i)); put(base + N + i, bigfield::byte_of(carry, i)); }
-    if (count)
-      for (int i = 0; i < N; i += 2) {
-        lookup(sink, B_U8RANGE, bigfield::byte_of(result, i), bigfield::byte_of(result, i + 1));
-        lookup(sink, B_U8RANGE, bigfield::byte_of(carry, i), bigfield::byte_of(carry, i + 1));
-      }
-  }
-  // FieldOpCols::populate_with_modulus (operations/field/field_op.rs:154-224) for a, b below p
-  __device__ void op(int base, const uint32_t* a, const uint32_t* b, int kind, uint32_t* res, int32_t* van) const {
-    const bigfield::Modulus<NL>& m = f.m;
-    uint32_t t[2 * NL], t2[2 * NL], q[NL + 1];
-    for (int i = 0; i <= NL; i++) q[i] = 0;
-    for (int i = 0; i < 2 * N - 1; i++) van[i] = 0;
-    if (kind == FOP_ADD) {
-      for (int i = 0; i < NL; i++) res[i] = a[i];
-      const uint32_t carry_out = bigfield::add<NL>(res, b);
-      const uint32_t wraps = carry_out | (bigfield::cmp<NL>(res, m.p) >= 0 ? 1u : 0u);
-      if (wraps) bigfield::sub<NL>(res, m.p);
-      q[0] = wraps;
-      poly_add(van, a, 1); poly_add(van, b, 1); poly_add(van, res, -1);
-    } else if (kind == FOP_SUB) {                 // result + b = a + carry p
-      for (int i = 0; i < NL; i++) res[i] = a[i];
-      if (bigfield::sub<NL>(res, b)) { bigfield::add<NL>(res, m.p); q[0] = 1; }
-      poly_add(van, res, 1); poly_add(van, b, 1); poly_add(van, a, -1);
-    } else if (kind == FOP_MUL) {
-      bigfield::mul<NL, NL>(a, b, t);
-      bigfield::divmod<NL>(t, m, q, res);
-      poly_mac(van, a, b); poly_add(van, res, -1);
-    } else {                                      // result * b = a + carry p
-      bool zero = true;
-      for (int i = 0; i < NL; i++) zero = zero && a[i] == 0;
-      if (zero) { for (int i = 0; i < NL; i++) res[i] = 0; } else { uint32_t inv[NL]; bigfield::inverse<NL>(b, m, inv); bigfield::mulmod<NL>(a, inv, m, res); }
-      bigfield::mul<NL, NL>(res, b, t);
-      for (int i = 0; i < 2 * NL; i++) t2[i] = i < NL ? a[i] : 0u;
-      bigfield::sub<2 * NL>(t, t2);
-      uint32_t rem[NL];
-      bigfield::divmod<NL>(t, m, q, rem);
-      poly_mac(van, res, b); poly_add(van, a, -1);
-    }
-    gadget(base, van, res, q);
-  }
-};
+// ---- Short-Weierstrass AddAssign / DoubleAssign (syscall/precompiles/weierstrass/weierstrass_add.rs, weierstrass_double.rs) for Secp256k1,
+// Secp256r1, Bn254 (NL = 8) and Bls12381 (NL = 12): nine / eleven FieldOpCols per row. The curve's base field arrives as a kernel argument
+// (modulus, its Barrett constant, `a`, the witness offset). Padding rows: an addition's are the operations of the zero inputs; a doubling's
+// are those of the point (0, 1) with the dummy write record of weierstrass_double.rs:225-239 on the first word of y.
 template <int NL, bool DOUBLE>
-__global__ __launch_bounds__(BF_THREADS) void weierstrass_rows(const uint32_t* __restrict__ events, size_t n_events, size_t height, uint32_t* __restrict__ out,
-                                                       uint32_t* counts, int* __restrict__ bad, const CurveField<NL> field) {
-  constexpr int N = 4 * NL, W = 2 * NL, G = FieldRow<NL>::G;
+__global__ __launch_bounds__(bf_threads(NL)) void weierstrass_rows(const uint32_t* __restrict__ events, size_t n_events, size_t height,
+                                                                   uint32_t* __restrict__ out, uint32_t* counts, int* __restrict__ bad,
+                                                                   const CurveField<NL> field) {
+  constexpr int W = 2 * NL, G = FieldRow<NL>::G;
   constexpr int P_ACCESS = DOUBLE ? 4 : 5, Q_ACCESS = P_ACCESS + 13 * W, GADGETS = P_ACCESS + 13 * W + (DOUBLE ? 0 : 9 * W);
   constexpr int EV_WORDS = DOUBLE ? 3 + 6 * W : 4 + 11 * W, E_P = DOUBLE ? 3 : 4, E_Q = 4 + 6 * W;
-  extern __shared__ uint32_t hash_lds[];
-  uint32_t* hkeys = hash_lds;
-  uint32_t* hvals = hash_lds + BF_HASH_SLOTS;
-  const bool count = counts != nullptr;
-  if (count) {
-    for (int i = threadIdx.x; i < BF_HASH_SLOTS; i += blockDim.x) { hkeys[i] = HASH_EMPTY; hvals[i] = 0; }
-    __syncthreads();
-  }
+  extern __shared__ uint32_t bf_lds[];
+  const BfBlock blk(bf_lds, counts);
   const size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (row < height) {
     const bool real = row < n_events;
     const uint32_t* e = events + row * EV_WORDS;
-    const LookupSink sink{hkeys, hvals, BF_HASH_SLOTS - 1, counts};
-    const FieldRow<NL> R{out, height, row, sink, count && real, field};
+    const LookupSink sink{blk.hkeys, blk.hvals, BF_HASH_SLOTS - 1, counts};
+    const FieldRow<NL> R = FieldRow<NL>::make(out, height, row, sink, blk.count && real, field, blk.scratch);
     uint32_t px[NL], py[NL], qx[NL], qy[NL];
     bool ok = true;
     for (int k = 0; k < NL; k++) {
@@ -2109,89 +2086,64 @@ __global__ __launch_bounds__(BF_THREADS) void weierstrass_rows(const uint32_t* _
       ok = false;
       for (int k = 0; k < NL; k++) px[k] = py[k] = qx[k] = qy[k] = 0;
     }
-    int32_t van[2 * N - 1];
     uint32_t num[NL], den[NL], slope[NL], sq[NL], sum[NL], x3[NL], dx[NL], prod[NL], y3[NL];
     auto col = [&](int k) { return GADGETS + G * k; };
-    if (!DOUBLE) {
-      R.op(col(1), qy, py, FOP_SUB, num, van);
-      R.op(col(0), qx, px, FOP_SUB, den, van);
-      R.op(col(2), num, den, FOP_DIV, slope, van);
-      R.op(col(3), slope, slope, FOP_MUL, sq, van);
-      R.op(col(4), px, qx, FOP_ADD, sum, van);
-      R.op(col(5), sq, sum, FOP_SUB, x3, van);
-      R.op(col(6), px, x3, FOP_SUB, dx, van);
-      R.op(col(8), slope, dx, FOP_MUL, prod, van);
-      R.op(col(7), prod, py, FOP_SUB, y3, van);
-    } else {
+    if (!DOUBLE) {      // slope_denominator, slope_numerator, slope, slope_squared, p_x_plus_q_x, x3_ins, p_x_minus_x, y3_ins, slope_times_p_x_minus_x
+      R.op(col(1), qy, py, FOP_SUB, num);
+      R.op(col(0), qx, px, FOP_SUB, den);
+      R.op(col(2), num, den, FOP_DIV, slope);
+      R.op(col(3), slope, slope, FOP_MUL, sq);
+      R.op(col(4), px, qx, FOP_ADD, sum);
+      R.op(col(5), sq, sum, FOP_SUB, x3);
+      R.op(col(6), px, x3, FOP_SUB, dx);
+      R.op(col(8), slope, dx, FOP_MUL, prod);
+      R.op(col(7), prod, py, FOP_SUB, y3);
+    } else {            // ..., p_x_squared, p_x_squared_times_3, slope_squared, p_x_plus_p_x, x3_ins, p_x_minus_x, y3_ins, slope_times_p_x_minus_x
       uint32_t xx[NL], xx3[NL], three[NL], two[NL];
       for (int k = 0; k < NL; k++) { three[k] = k == 0 ? 3u : 0u; two[k] = k == 0 ? 2u : 0u; }
-      R.op(col(3), px, px, FOP_MUL, xx, van);
-      R.op(col(4), xx, three, FOP_MUL, xx3, van);
-      R.op(col(1), field.a, xx3, FOP_ADD, num, van);
-      R.op(col(0), two, py, FOP_MUL, den, van);
-      R.op(col(2), num, den, FOP_DIV, slope, van);
-      R.op(col(5), slope, slope, FOP_MUL, sq, van);
-      R.op(col(6), px, px, FOP_ADD, sum, van);
-      R.op(col(7), sq, sum, FOP_SUB, x3, van);
-      R.op(col(8), px, x3, FOP_SUB, dx, van);
-      R.op(col(10), slope, dx, FOP_MUL, prod, van);
-      R.op(col(9), prod, py, FOP_SUB, y3, van);
+      R.op(col(3), px, px, FOP_MUL, xx);
+      R.op(col(4), xx, three, FOP_MUL, xx3);
+      R.op(col(1), field.a, xx3, FOP_ADD, num);
+      R.op(col(0), two, py, FOP_MUL, den);
+      R.op(col(2), num, den, FOP_DIV, slope);
+      R.op(col(5), slope, slope, FOP_MUL, sq);
+      R.op(col(6), px, px, FOP_ADD, sum);
+      R.op(col(7), sq, sum, FOP_SUB, x3);
+      R.op(col(8), px, x3, FOP_SUB, dx);
+      R.op(col(10), slope, dx, FOP_MUL, prod);
+      R.op(col(9), prod, py, FOP_SUB, y3);
     }
     R.put(0, real ? 1u : 0u);
     R.put(1, real ? e[0] : 0u); R.put(2, real ? e[1] : 0u); R.put(3, real ? e[2] : 0u);
     if (!DOUBLE) R.put(4, real ? e[3] : 0u);
+    const uint32_t dummy[6] = {1, 0, 1, 1, 0, 0};
     for (int k = 0; k < W; k++) {
-      uint32_t mw[13], mr[9];
-      for (int c = 0; c < 13; c++) mw[c] = 0;
-      for (int c = 0; c < 9; c++) mr[c] = 0;
-      if (real) {
-        memory_write_cols(e + E_P + 6 * k, mw);
-        if (count) { lookup(sink, B_U16RANGE, mw[11] >> 8, mw[11]); lookup(sink, B_U8RANGE, 0, mw[12]); }
-        if (e[E_P + 6 * k] != (k < NL ? x3[k] : y3[k - NL])) ok = false;
-        if (!DOUBLE) {
-          const uint32_t* rec = e + E_Q + 5 * k;
-          memory_access_cols(rec[0], rec[1], rec[2], rec[3], rec[4], mr);
-          if (count) access_lookups(mr, sink);
-        }
-      } else if (DOUBLE && k == NL) {
-        const uint32_t dummy[6] = {1, 0, 1, 1, 0, 0};
-        memory_write_cols(dummy, mw);
-      }
-      for (int c = 0; c < 13; c++) R.put(P_ACCESS + 13 * k + c, mw[c]);
-      if (!DOUBLE)
-        for (int c = 0; c < 9; c++) R.put(Q_ACCESS + 9 * k + c, mr[c]);
+      R.write_cols(P_ACCESS + 13 * k, real ? e + E_P + 6 * k : (DOUBLE && k == NL ? dummy : nullptr));
+      if (!DOUBLE) R.read_cols(Q_ACCESS + 9 * k, real ? e + E_Q + 5 * k : nullptr);
+      if (real && e[E_P + 6 * k] != (k < NL ? x3[k] : y3[k - NL])) ok = false;
     }
     if (real && !ok) *bad = 1;
   }
-  if (count) {
-    __syncthreads();
-    for (int i = threadIdx.x; i < BF_HASH_SLOTS; i += blockDim.x)
-      if (hkeys[i] != HASH_EMPTY) atomicAdd(counts + hkeys[i], hvals[i]);
-  }
+  blk.flush(counts);
 }
 
-// ---- Field-tower precompiles (syscall/precompiles/fptower/fp.rs, fp2_addsub.rs, fp2_mul.rs) over the base field of Bn254 (NL = 8) or Bls12381
-// (NL = 12): KIND 0 FpOp (one FieldOpCols, the operation — FieldOperation as a word: Add 0, Mul 1, Sub 2 — per event), 1 Fp2AddSub (two), 2 Fp2Mul
-// (four products, a difference, a sum). x is overwritten at clk + 1, y is read at clk. Padding rows: zero inputs with is_add set.
+// ---- Field tower (syscall/precompiles/fptower/fp.rs, fp2_addsub.rs, fp2_mul.rs) over the base field of Bn254 (NL = 8) or Bls12381 (NL = 12):
+// KIND 0 FpOp (one FieldOpCols, the operation — FieldOperation as a word: Add 0, Mul 1, Sub 2 — per event), 1 Fp2AddSub (two), 2 Fp2Mul (four
+// products, a difference, a sum). x is overwritten at clk + 1, y is read at clk. Padding rows: zero inputs with is_add set.
 template <int NL, int KIND>
-__global__ __launch_bounds__(BF_THREADS) void fp_tower_rows(const uint32_t* __restrict__ events, size_t n_events, size_t height, uint32_t* __restrict__ out,
-                                                    uint32_t* counts, int* __restrict__ bad, const CurveField<NL> field) {
-  constexpr int N = 4 * NL, G = FieldRow<NL>::G, W = KIND == 0 ? NL : 2 * NL, HEAD = KIND == 0 ? 8 : KIND == 1 ? 6 : 5;
+__global__ __launch_bounds__(bf_threads(NL)) void fp_tower_rows(const uint32_t* __restrict__ events, size_t n_events, size_t height,
+                                                                uint32_t* __restrict__ out, uint32_t* counts, int* __restrict__ bad,
+                                                                const CurveField<NL> field) {
+  constexpr int G = FieldRow<NL>::G, W = KIND == 0 ? NL : 2 * NL, HEAD = KIND == 0 ? 8 : KIND == 1 ? 6 : 5;
   constexpr int X_ACCESS = HEAD, Y_ACCESS = HEAD + 13 * W, GADGETS = HEAD + 22 * W, E_HEAD = KIND == 2 ? 4 : 5, EV_WORDS = E_HEAD + 11 * W;
-  extern __shared__ uint32_t hash_lds[];
-  uint32_t* hkeys = hash_lds;
-  uint32_t* hvals = hash_lds + BF_HASH_SLOTS;
-  const bool count = counts != nullptr;
-  if (count) {
-    for (int i = threadIdx.x; i < BF_HASH_SLOTS; i += blockDim.x) { hkeys[i] = HASH_EMPTY; hvals[i] = 0; }
-    __syncthreads();
-  }
+  extern __shared__ uint32_t bf_lds[];
+  const BfBlock blk(bf_lds, counts);
   const size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (row < height) {
     const bool real = row < n_events;
     const uint32_t* e = events + row * EV_WORDS;
-    const LookupSink sink{hkeys, hvals, BF_HASH_SLOTS - 1, counts};
-    const FieldRow<NL> R{out, height, row, sink, count && real, field};
+    const LookupSink sink{blk.hkeys, blk.hvals, BF_HASH_SLOTS - 1, counts};
+    const FieldRow<NL> R = FieldRow<NL>::make(out, height, row, sink, blk.count && real, field, blk.scratch);
     const uint32_t op = KIND == 2 ? 1u : (real ? e[4] : 0u);
     bool ok = KIND == 0 ? op <= 2 : (KIND == 1 ? op == 0 || op == 2 : true);
     const int fop = op == 0 ? FOP_ADD : op == 1 ? FOP_MUL : FOP_SUB;
@@ -2207,22 +2159,21 @@ __global__ __launch_bounds__(BF_THREADS) void fp_tower_rows(const uint32_t* __re
       ok = false;
       for (int k = 0; k < NL; k++) x0[k] = x1[k] = y0[k] = y1[k] = 0;
     }
-    int32_t van[2 * N - 1];
     uint32_t out0[NL], out1[NL];
     auto col = [&](int k) { return GADGETS + G * k; };
     if (KIND == 0) {
-      R.op(col(0), x0, y0, fop, out0, van);
+      R.op(col(0), x0, y0, fop, out0);
     } else if (KIND == 1) {
-      R.op(col(0), x0, y0, fop, out0, van);
-      R.op(col(1), x1, y1, fop, out1, van);
-    } else {
+      R.op(col(0), x0, y0, fop, out0);
+      R.op(col(1), x1, y1, fop, out1);
+    } else {            // a0_mul_b0, a1_mul_b1, a0_mul_b1, a1_mul_b0, c0, c1
       uint32_t a0b0[NL], a1b1[NL], a0b1[NL], a1b0[NL];
-      R.op(col(0), x0, y0, FOP_MUL, a0b0, van);
-      R.op(col(1), x1, y1, FOP_MUL, a1b1, van);
-      R.op(col(2), x0, y1, FOP_MUL, a0b1, van);
-      R.op(col(3), x1, y0, FOP_MUL, a1b0, van);
-      R.op(col(4), a0b0, a1b1, FOP_SUB, out0, van);
-      R.op(col(5), a0b1, a1b0, FOP_ADD, out1, van);
+      R.op(col(0), x0, y0, FOP_MUL, a0b0);
+      R.op(col(1), x1, y1, FOP_MUL, a1b1);
+      R.op(col(2), x0, y1, FOP_MUL, a0b1);
+      R.op(col(3), x1, y0, FOP_MUL, a1b0);
+      R.op(col(4), a0b0, a1b1, FOP_SUB, out0);
+      R.op(col(5), a0b1, a1b0, FOP_ADD, out1);
     }
     R.put(0, real ? 1u : 0u); R.put(1, real ? e[0] : 0u); R.put(2, real ? e[1] : 0u);
     if (KIND == 0) {
@@ -2234,26 +2185,13 @@ __global__ __launch_bounds__(BF_THREADS) void fp_tower_rows(const uint32_t* __re
       R.put(3, real ? e[2] : 0u); R.put(4, real ? e[3] : 0u);
     }
     for (int k = 0; k < W; k++) {
-      uint32_t mw[13], mr[9];
-      for (int c = 0; c < 13; c++) mw[c] = 0;
-      for (int c = 0; c < 9; c++) mr[c] = 0;
-      if (real) {
-        memory_write_cols(e + E_HEAD + 6 * k, mw);
-        const uint32_t* rec = e + E_HEAD + 6 * W + 5 * k;
-        memory_access_cols(rec[0], rec[1], rec[2], rec[3], rec[4], mr);
-        if (count) { access_lookups(mr, sink); lookup(sink, B_U16RANGE, mw[11] >> 8, mw[11]); lookup(sink, B_U8RANGE, 0, mw[12]); }
-        if (e[E_HEAD + 6 * k] != (k < NL ? out0[k] : out1[k - NL])) ok = false;
-      }
-      for (int c = 0; c < 13; c++) R.put(X_ACCESS + 13 * k + c, mw[c]);
-      for (int c = 0; c < 9; c++) R.put(Y_ACCESS + 9 * k + c, mr[c]);
+      R.write_cols(X_ACCESS + 13 * k, real ? e + E_HEAD + 6 * k : nullptr);
+      R.read_cols(Y_ACCESS + 9 * k, real ? e + E_HEAD + 6 * W + 5 * k : nullptr);
+      if (real && e[E_HEAD + 6 * k] != (k < NL ? out0[k] : out1[k - NL])) ok = false;
     }
     if (real && !ok) *bad = 1;
   }
-  if (count) {
-    __syncthreads();
-    for (int i = threadIdx.x; i < BF_HASH_SLOTS; i += blockDim.x)
-      if (hkeys[i] != HASH_EMPTY) atomicAdd(counts + hkeys[i], hvals[i]);
-  }
+  blk.flush(counts);
 }
 
 // recursion ExpReverseBitsLen chip (crates/recursion/core/src/chips/exp_reverse_bits.rs:175-226): one thread walks one event's bits —

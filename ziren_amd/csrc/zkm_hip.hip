@@ -104,6 +104,15 @@ int zkm_ctx_create(int device, zkm_ctx** out) {
   HIP_CHECK(hipFuncSetAttribute((const void*)tracegen::alu_rows<tracegen::MEMORY_INSTRS>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
   HIP_CHECK(hipFuncSetAttribute((const void*)tracegen::alu_rows<tracegen::MISC_INSTRS>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
   HIP_CHECK(hipFuncSetAttribute((const void*)tracegen::alu_rows<tracegen::BRANCH>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+  {      // the big-field precompile kernels keep their byte-limb polynomials next to the lookup table
+    const void* big_field_kernels[] = {
+        (const void*)tracegen::ed_add_rows, (const void*)tracegen::ed_decompress_rows,
+        (const void*)tracegen::weierstrass_rows<8, false>, (const void*)tracegen::weierstrass_rows<8, true>,
+        (const void*)tracegen::weierstrass_rows<12, false>, (const void*)tracegen::weierstrass_rows<12, true>,
+        (const void*)tracegen::fp_tower_rows<8, 0>, (const void*)tracegen::fp_tower_rows<8, 1>, (const void*)tracegen::fp_tower_rows<8, 2>,
+        (const void*)tracegen::fp_tower_rows<12, 0>, (const void*)tracegen::fp_tower_rows<12, 1>, (const void*)tracegen::fp_tower_rows<12, 2>};
+    for (const void* k : big_field_kernels) HIP_CHECK(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  }
   HIP_CHECK(hipFuncSetAttribute((const void*)lde::lde_cols<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIP_CHECK(hipFuncSetAttribute((const void*)lde::lde_cols<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIP_CHECK(hipFuncSetAttribute((const void*)stark::quotient_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
