@@ -493,6 +493,15 @@ int zkm_tracegen_weierstrass_add(zkm_ctx* ctx, int curve, const void* events, si
 int zkm_tracegen_weierstrass_double(zkm_ctx* ctx, int curve, const void* events, size_t n_events, int fixed_log2_rows, zkm_byte_lookups* blu,
                                     zkm_matrix** out);
 
+/* Secp256k1Decompress / Secp256r1Decompress / Bls12381Decompress (crates/core/machine/src/syscall/precompiles/weierstrass/weierstrass_decompress.rs):
+ * replaces generate_trace (:163-285), byte lookups into `blu`. `curve` is ZKM_CURVE_SECP256K1, _SECP256R1 (the sign bit is y's parity) or
+ * _BLS12381 (the bit says y > p - y). `events`: EllipticCurveDecompressEvent (crates/core/executor/src/events/precompiles/ec.rs:74-94) flattened,
+ * W = 8 words per field element (Bls12381: 12):
+ *   shard, clk, ptr, sign_bit, W zkm_memory_read_record of x (read at ptr + 4 W), W zkm_memory_write_record of y (written at ptr)   (4 + 11 W words)
+ * Fails when the bit is not 0 / 1, x is not below the modulus or not on the curve, or the words written are not the root the bit asks for. */
+int zkm_tracegen_weierstrass_decompress(zkm_ctx* ctx, int curve, const void* events, size_t n_events, int fixed_log2_rows, zkm_byte_lookups* blu,
+                                        zkm_matrix** out);
+
 /* The field-tower precompiles (crates/core/machine/src/syscall/precompiles/fptower/fp.rs, fp2_addsub.rs, fp2_mul.rs): Bn254 / Bls12381 x FpOpAssign,
  * Fp2AddSubAssign, Fp2MulAssign; replace their generate_trace, byte lookups into `blu`. `field` is ZKM_CURVE_BN254 or ZKM_CURVE_BLS12381. Events:
  * FpOpEvent / Fp2AddSubEvent / Fp2MulEvent (crates/core/executor/src/events/precompiles/fptower.rs:23-94) flattened — shard, clk, x_ptr, y_ptr,

@@ -17,7 +17,7 @@
 use std::ptr::null_mut;
 
 use zkm_core_executor::events::{
-    EdDecompressEvent, EllipticCurveAddEvent, EllipticCurveDoubleEvent, Fp2AddSubEvent, Fp2MulEvent, FpOpEvent, FieldOperation, KeccakSpongeEvent,
+    EdDecompressEvent, EllipticCurveAddEvent, EllipticCurveDecompressEvent, EllipticCurveDoubleEvent, Fp2AddSubEvent, Fp2MulEvent, FpOpEvent, FieldOperation, KeccakSpongeEvent,
     MemoryReadRecord, MemoryWriteRecord, Poseidon2PermuteEvent, PrecompileEvent, ShaCompressEvent, ShaExtendEvent, SyscallEvent,
 };
 use zkm_core_executor::{syscalls::SyscallCode, ExecutionRecord};
@@ -31,7 +31,8 @@ pub(crate) const DEVICE_BUILT: &[&str] = &[
     "Global", "MemoryLocal", "Cpu", "Program", "SyscallCore", "SyscallPrecompile", "MemoryGlobalInit", "MemoryGlobalFinalize", "Poseidon2Permute",
     "KeccakSponge", "ShaExtend", "ShaCompress", "EdAddAssign", "EdDecompress", "Secp256k1AddAssign", "Secp256k1DoubleAssign", "Secp256r1AddAssign",
     "Secp256r1DoubleAssign", "Bn254AddAssign", "Bn254DoubleAssign", "Bls12381AddAssign", "Bls12381DoubleAssign", "Bn254FpOpAssign", "Bn254Fp2AddSubAssign",
-    "Bn254Fp2MulAssign", "Bls12381FpOpAssign", "Bls12831Fp2AddSubAssign", "Bls12831Fp2MulAssign",
+    "Bn254Fp2MulAssign", "Bls12381FpOpAssign", "Bls12831Fp2AddSubAssign", "Bls12831Fp2MulAssign", "Secp256k1Decompress", "Secp256r1Decompress",
+    "Bls12381Decompress",
 ];
 
 /// ZKM_CURVE_* of include/zkm_hip.h
@@ -109,6 +110,13 @@ pub(crate) fn device_trace(
     }}; }
     let add = |e: &EllipticCurveAddEvent| flat(&[e.shard, e.clk, e.p_ptr, e.q_ptr], &e.p_memory_records, &e.q_memory_records);
     let dbl = |e: &EllipticCurveDoubleEvent| flat(&[e.shard, e.clk, e.p_ptr], &e.p_memory_records, &[]);
+    // a decompression lists its reads (x) before its writes (y): include/zkm_hip.h, zkm_tracegen_weierstrass_decompress
+    let dec = |e: &EllipticCurveDecompressEvent| {
+        let mut v = vec![e.shard, e.clk, e.ptr, e.sign_bit as u32];
+        v.extend(flat(&[], &[], &e.x_memory_records));
+        v.extend(flat(&[], &e.y_memory_records, &[]));
+        v
+    };
     let fp = |e: &FpOpEvent| flat(&[e.shard, e.clk, e.x_ptr, e.y_ptr, field_op_word(e.op)], &e.x_memory_records, &e.y_memory_records);
     let fp2 = |e: &Fp2AddSubEvent| flat(&[e.shard, e.clk, e.x_ptr, e.y_ptr, field_op_word(e.op)], &e.x_memory_records, &e.y_memory_records);
     let fp2m = |e: &Fp2MulEvent| flat(&[e.shard, e.clk, e.x_ptr, e.y_ptr], &e.x_memory_records, &e.y_memory_records);
@@ -211,6 +219,9 @@ pub(crate) fn device_trace(
         "Bn254DoubleAssign" => curve_events!(BN254_DOUBLE, Bn254Double, zkm_tracegen_weierstrass_double, BN254, dbl),
         "Bls12381AddAssign" => curve_events!(BLS12381_ADD, Bls12381Add, zkm_tracegen_weierstrass_add, BLS12381, add),
         "Bls12381DoubleAssign" => curve_events!(BLS12381_DOUBLE, Bls12381Double, zkm_tracegen_weierstrass_double, BLS12381, dbl),
+        "Secp256k1Decompress" => curve_events!(SECP256K1_DECOMPRESS, Secp256k1Decompress, zkm_tracegen_weierstrass_decompress, SECP256K1, dec),
+        "Secp256r1Decompress" => curve_events!(SECP256R1_DECOMPRESS, Secp256r1Decompress, zkm_tracegen_weierstrass_decompress, SECP256R1, dec),
+        "Bls12381Decompress" => curve_events!(BLS12381_DECOMPRESS, Bls12381Decompress, zkm_tracegen_weierstrass_decompress, BLS12381, dec),
         // the three Fp codes of a field are filed under FP_ADD, FP2_ADD and FP2_SUB under FP2_ADD (syscalls/precompiles/fptower/)
         "Bn254FpOpAssign" => curve_events!(BN254_FP_ADD, Bn254Fp, zkm_tracegen_fp_op, BN254, fp),
         "Bn254Fp2AddSubAssign" => curve_events!(BN254_FP2_ADD, Bn254Fp2AddSub, zkm_tracegen_fp2_addsub, BN254, fp2),

@@ -2060,6 +2060,97 @@ static inline std::vector<F> generate_weierstrass(const uint32_t* events, size_t
   return t;
 }
 
+// ---- <Curve>Decompress (syscall/precompiles/weierstrass/weierstrass_decompress.rs:52-79, :121-142, :163-285): y = sqrt(x^3 + a x + b) from x and a
+// sign bit. Events: shard, clk, ptr, sign_bit, W read records of x, W write records of y (W = N / 4). Columns: is_real, shard, clk, ptr,
+// sign_bit, x_access (W x 9), y_access (W x 13), range_x (FieldLtCols), x_2, x_3 (FieldOpCols), ax_plus_b (FieldInnerProductCols),
+// x_3_plus_b_plus_ax, y (FieldSqrtCols), neg_y; with the lexicographic rule (Bls12381) also comparison_lt_cols, neg_y_range_check and three
+// flags. The root is a^((p + 1) / 4) — what k256 / p256 / amcl compute for these p = 3 (mod 4); those crates are not in the tree (unpinned).
+// Padding rows: the field operations of the generator's x, which also sits in the value columns of x_access (:254-271).
+static inline std::vector<F> generate_weierstrass_decompress(const uint32_t* events, size_t n_events, int n_limbs, const uint8_t* modulus_bytes,
+                                                             const uint8_t* a_bytes, const uint8_t* b_bytes, const uint8_t* generator_x_bytes, int64_t offset,
+                                                             bool lexicographic, int fixed_log2_rows, size_t* height, uint64_t* byte_counts) {
+  using namespace bigfield;
+  const int N = n_limbs, W = N / 4, G = 6 * N - 4;
+  const int X_ACCESS = 5, Y_ACCESS = X_ACCESS + 9 * W, RANGE_X = Y_ACCESS + 13 * W, X_2 = RANGE_X + N + 2, X_3 = X_2 + G, AX_PLUS_B = X_2 + 2 * G,
+            X_3_PLUS = X_2 + 3 * G, Y_MULT = X_2 + 4 * G, Y_RANGE = Y_MULT + G, Y_LSB = Y_RANGE + N + 2, NEG_Y = Y_LSB + 1, CHOICE = NEG_Y + G;
+  const size_t width = CHOICE + (lexicographic ? 2 * (N + 2) + 3 : 0), ev_words = 4 + 11 * W;
+  const size_t h = padded_rows(n_events, fixed_log2_rows);
+  std::vector<F> t(h * width, 0);
+  std::vector<ByteLookup> lk;
+  const Big p = from_bytes(modulus_bytes, N), a = from_bytes(a_bytes, N), b = from_bytes(b_bytes, N), one = from_u64(1);
+  Big sqrt_exp, rem;
+  divmod(add(p, one), from_u64(4), sqrt_exp, rem);
+  if (!is_zero(rem)) throw std::runtime_error("tracegen: decompress needs p = 3 (mod 4)");
+  auto fill = [&](F* r, const Big& x, std::vector<ByteLookup>* sink) {          // populate_field_ops :121-142; returns the root
+    const FieldGadgets g{p, N, offset, sink};
+    field_lt_cols(r + RANGE_X, x, p, N, sink);
+    const Big x2 = field_op_cols(g, r + X_2, x, x, FOP_MUL);
+    const Big x3 = field_op_cols(g, r + X_3, x2, x, FOP_MUL);
+    const Big ax_b = g.inner_product(r + AX_PLUS_B, a, x, b, one);
+    const Big rhs = field_op_cols(g, r + X_3_PLUS, x3, ax_b, FOP_ADD);
+    const Big y = pow_mod(rhs, sqrt_exp, p);                                    // FieldSqrtCols::populate (field_sqrt.rs:34-85)
+    if (cmp(field_op_cols(g, r + Y_MULT, y, y, FOP_MUL), rhs) != 0) throw std::runtime_error("tracegen: decompress: x is not on the curve");
+    for (int i = 0; i < N; i++) r[Y_MULT + i] = limb(y, i);
+    field_lt_cols(r + Y_RANGE, y, p, N, sink);
+    r[Y_LSB] = limb(y, 0) & 1;
+    if (sink) {
+      sink->push_back(ByteLookup{B_AND_OP, (uint8_t)limb(y, 0), 1});
+      for (int i = 0; i < N; i += 2) sink->push_back(ByteLookup{B_U8RANGE, (uint8_t)limb(y, i), (uint8_t)limb(y, i + 1)});
+    }
+    field_op_cols(g, r + NEG_Y, Big(), y, FOP_SUB);
+    return y;
+  };
+  std::vector<F> padding(width, 0);
+  {
+    const Big gx = from_bytes(generator_x_bytes, N);
+    for (int i = 0; i < N; i++) padding[X_ACCESS + 9 * (i / 4) + i % 4] = limb(gx, i);
+    fill(padding.data(), gx, nullptr);
+  }
+  std::vector<uint32_t> xw(W), yw(W);
+  for (size_t i = 0; i < h; i++) {
+    F* r = t.data() + i * width;
+    if (i >= n_events) { std::copy(padding.begin(), padding.end(), r); continue; }
+    const uint32_t* e = events + i * ev_words;
+    const MemoryReadRecord* xrec = (const MemoryReadRecord*)(e + 4);
+    const MemoryWriteRecord* yrec = (const MemoryWriteRecord*)(e + 4 + 5 * W);
+    if (e[3] > 1) throw std::runtime_error("tracegen: decompress sign bit");
+    r[0] = 1; r[1] = fu32(e[0]); r[2] = fu32(e[1]); r[3] = fu32(e[2]); r[4] = e[3];
+    for (int k = 0; k < W; k++) {
+      const MemoryReadRecord& m = xrec[k];
+      memory_access_cols(m.value, m.shard, m.timestamp, m.prev_shard, m.prev_timestamp, r + X_ACCESS + 9 * k, &lk);
+      memory_write_cols(yrec[k], r + Y_ACCESS + 13 * k, &lk);
+      xw[k] = m.value; yw[k] = yrec[k].value;
+    }
+    const Big x = from_words(xw.data(), W), decompressed = from_words(yw.data(), W);
+    if (cmp(x, p) >= 0) throw std::runtime_error("tracegen: decompress: x is not below the modulus");
+    const Big y = fill(r, x, &lk);
+    const Big neg = mod(sub(p, y), p);
+    const bool wrote_root = cmp(decompressed, y) == 0;
+    if (!wrote_root && cmp(decompressed, neg) != 0) throw std::runtime_error("tracegen: decompress event does not write a root");
+    if (!lexicographic) {
+      if ((limb(decompressed, 0) & 1) != e[3]) throw std::runtime_error("tracegen: decompress event does not write the root the sign bit asks for");
+    } else {        // LexicographicChoiceCols :196-246: comparison_lt_cols, neg_y_range_check, is_y_eq_sqrt_y_result, when_sqrt_y_res_is_lt, when_neg_y_res_is_lt
+      const Big other = mod(sub(p, decompressed), p);                           // `neg_y` of :201
+      const bool larger = cmp(other, decompressed) < 0;
+      if (larger != (e[3] != 0) || cmp(other, decompressed) == 0) throw std::runtime_error("tracegen: decompress event does not write the root the sign bit asks for");
+      const int CMP = CHOICE, NEG_RANGE = CHOICE + N + 2, FLAGS = CHOICE + 2 * (N + 2);
+      r[FLAGS] = wrote_root ? 1 : 0;
+      field_lt_cols(r + NEG_RANGE, wrote_root ? other : decompressed, p, N, &lk);      // either way: the root's negative
+      if (e[3]) {
+        r[FLAGS + 1] = !wrote_root; r[FLAGS + 2] = wrote_root;
+        field_lt_cols(r + CMP, other, decompressed, N, &lk);
+      } else {
+        r[FLAGS + 1] = wrote_root; r[FLAGS + 2] = !wrote_root;
+        field_lt_cols(r + CMP, decompressed, other, N, &lk);
+      }
+    }
+  }
+  if (byte_counts)
+    for (const ByteLookup& bl : lk) byte_counts[((size_t)bl.b * 256 + bl.c) * NUM_BYTE_OPS + bl.op]++;
+  *height = h;
+  return t;
+}
+
 // ---- Field-tower precompiles (syscall/precompiles/fptower/): FpOp (kind 0: one FieldOpCols, the operation chosen per event), Fp2AddSub (kind 1: two,
 // add or subtract per event), Fp2Mul (kind 2: four products, a difference, a sum) over the base field of Bn254 or Bls12381. Events: shard, clk,
 // x_ptr, y_ptr, [op — FieldOperation as a word: Add 0, Mul 1, Sub 2 —] W write records of x, W read records of y (W = N / 4 for FpOp, N / 2 for

@@ -83,6 +83,8 @@ class Oracle:
             return fn[what](a[0], a[1], c)
         if what == "weierstrass":
             return O.tracegen_weierstrass(a[0], a[1], a[2], a[3], c)
+        if what == "weierstrass_decompress":
+            return O.tracegen_weierstrass_decompress(a[0], a[1], a[2], c)
         if what == "fp_tower":
             return O.tracegen_fp_tower(a[0], a[1], a[2], a[3], c)
         if what == "syscall_table":
@@ -123,6 +125,8 @@ class Device:
             return fn[what](a[0], a[1], blu)
         if what == "weierstrass":
             return ctx.tracegen_weierstrass(a[0], a[1], a[2], a[3], blu)
+        if what == "weierstrass_decompress":
+            return ctx.tracegen_weierstrass_decompress(a[0], a[1], a[2], blu)
         if what == "fp_tower":
             return ctx.tracegen_fp_tower(a[0], a[1], a[2], a[3], blu)
         if what == "syscall_table":
@@ -200,6 +204,10 @@ def build_shard(src, machine, k):
             curve, double = kind.split("_")[0], kind.endswith("_double")
             lh = log2_rows(len(ev))
             add(chips.record_weierstrass_chip(curve, double, lh), src.trace("weierstrass", curve, double, ev, lh))
+        if getattr(rec, "weierstrass_decompress", None) is not None:
+            curve, ev = rec.weierstrass_decompress
+            lh = log2_rows(len(ev))
+            add(chips.record_weierstrass_decompress_chip(curve, lh), src.trace("weierstrass_decompress", curve, ev, lh))
         if getattr(rec, "fp_tower", None) is not None:
             kind_key, ev = rec.fp_tower
             field, kind = kind_key.split("_", 1)

@@ -435,6 +435,19 @@ def tracegen_weierstrass(curve, double, events, fixed_log2_rows=-1, byte_counts=
                            C.c_int(int(double)), C.c_int(n), mod, a, C.c_uint32(c["witness_offset"]), C.c_int(fixed_log2_rows), tail=bc)
 
 
+def tracegen_weierstrass_decompress(curve, events, fixed_log2_rows=-1, byte_counts=None):
+    """<Curve>Decompress rows from flattened EllipticCurveDecompressEvents (events.weierstrass_decompress_event_dtype)."""
+    from ziren_amd import events as E
+    c = E.WEIERSTRASS_CURVES[curve]
+    ev = np.ascontiguousarray(events, dtype=E.weierstrass_decompress_event_dtype(curve))
+    n = c["n_limbs"]
+    as_bytes = lambda v: (C.c_uint8 * n)(*v.to_bytes(n, "little"))      # noqa: E731
+    bc = (abi.as_u32p(byte_counts),) if byte_counts is not None else (None,)
+    return _rows_then_fill(lib().orc_tracegen_weierstrass_decompress, E.weierstrass_decompress_width(curve), C.c_void_p(ev.ctypes.data), C.c_size_t(len(ev)),
+                           C.c_int(n), as_bytes(c["p"]), as_bytes(c["a"]), as_bytes(c["b"]), as_bytes(c["generator"][0]), C.c_uint32(c["witness_offset"]),
+                           C.c_int(int(E.WEIERSTRASS_DECOMPRESS[curve]["lexicographic"])), C.c_int(fixed_log2_rows), tail=bc)
+
+
 FP_TOWER_KINDS = {"fp": 0, "fp2_addsub": 1, "fp2_mul": 2}
 
 

@@ -64,6 +64,7 @@ def test_recorded_costs_match_the_reference():
         chips.record_keccak_sponge_chip(10), chips.record_sha_extend_chip(10), chips.record_sha_compress_chip(10),
         chips.record_ed_add_chip(10), chips.record_ed_decompress_chip(10)] + [
         chips.record_weierstrass_chip(curve, double, 10) for curve in E.WEIERSTRASS_CURVES for double in (False, True)] + [
+        chips.record_weierstrass_decompress_chip(curve, 10) for curve in E.WEIERSTRASS_DECOMPRESS] + [
         chips.record_fp_tower_chip(field, kind, 10) for field in E.FP_TOWER_CODES for kind in ("fp", "fp2_addsub", "fp2_mul")]
     rows_per_event = {"KeccakSponge": 24, "ShaExtend": 48, "ShaCompress": 80}      # MipsAir::costs scales a multi-row precompile by its rows per event (mips/mod.rs:588-595, applied where the cost table is built)
     got = {r.name: rows_per_event.get(r.name, 1) * (r.prep_width + r.main_width + 4 * r.perm_ext_width + (4 << r.log_quotient_degree)) for r in recs}

@@ -59,6 +59,8 @@ def check_machine_airs(oracle, m):
                 field = "Bn254" if c.name.startswith("Bn254") else "Bls12381"
                 kind = "fp" if "FpOp" in c.name else "fp2_mul" if "Fp2Mul" in c.name else "fp2_addsub"
                 rec = lambda field=field, kind=kind: chips.record_fp_tower_constraints(field, kind)      # noqa: E731
+            if rec is None and c.name.endswith("Decompress"):
+                rec = lambda curve=c.name.replace("Decompress", ""): chips.record_weierstrass_decompress_constraints(curve)      # noqa: E731
             if rec is None and c.name.endswith(("AddAssign", "DoubleAssign")):
                 curve, double = c.name.replace("DoubleAssign", "").replace("AddAssign", ""), c.name.endswith("DoubleAssign")
                 rec = lambda curve=curve, double=double: chips.record_weierstrass_constraints(curve, double)      # noqa: E731

@@ -2263,6 +2263,94 @@ def record_weierstrass_chip(curve: str, double: bool, log_height: int) -> Record
     return _finish(record_weierstrass_constraints(curve, double), name, log_height, E.weierstrass_widths(curve)[1 if double else 0], True)
 
 
+def _weierstrass_decompress(r: _Rec, curve: str):
+    """WeierstrassDecompressChip::eval (syscall/precompiles/weierstrass/weierstrass_decompress.rs:305-527): y = sqrt(x^3 + a x + b) — a FieldLtCols
+    of x, two products, an inner product (a, b) . (x, 1), a sum, a FieldSqrtCols, the root's negative — and the choice between the root and its
+    negative: by parity of the root against the sign bit (Secp256k1, Secp256r1), or by comparing the two as integers (Bls12381:
+    LexicographicChoiceCols). x is read at ptr + N, y written at ptr, both at clk."""
+    c = E.WEIERSTRASS_CURVES[curve]
+    lexicographic = E.WEIERSTRASS_DECOMPRESS[curve]["lexicographic"]
+    l, b = r.local, r.b
+    N, W, off = c["n_limbs"], c["n_limbs"] // 4, c["witness_offset"]
+    G = 6 * N - 4
+    modulus = _limbs_of_const(b, c["p"], N)
+    IS_REAL, SHARD, CLK, PTR, SIGN, X_ACCESS = 0, 1, 2, 3, 4, 5
+    Y_ACCESS = X_ACCESS + 9 * W
+    RANGE_X = Y_ACCESS + 13 * W
+    X_2 = RANGE_X + N + 2
+    X_3, AX_PLUS_B, X_3_PLUS = X_2 + G, X_2 + 2 * G, X_2 + 3 * G
+    Y_MULT = X_2 + 4 * G
+    Y_RANGE, Y_LSB, NEG_Y = Y_MULT + G, Y_MULT + G + N + 2, Y_MULT + G + N + 3
+    CHOICE = NEG_Y + G
+    is_real, sign = l[IS_REAL], l[SIGN]
+    x_access = [l[X_ACCESS + 9 * i:X_ACCESS + 9 * i + 9] for i in range(W)]
+    y_access = [l[Y_ACCESS + 13 * i:Y_ACCESS + 13 * i + 13] for i in range(W)]
+    grp = lambda base: l[base:base + G]      # noqa: E731
+    b.assert_bool(sign)
+    x = [v for a in x_access for v in a[0:4]]                                   # limbs_from_prev_access of a read: its value
+    _field_lt(r, l[RANGE_X:RANGE_X + N + 2], x, modulus, N, is_real)
+    _field_op(r, grp(X_2), x, x, "mul", modulus, N, off, is_real)
+    _field_op(r, grp(X_3), l[X_2:X_2 + N], x, "mul", modulus, N, off, is_real)
+    # FieldInnerProductCols::eval (field_inner_product.rs:82-120) of (a, b) and (x, 1)
+    cols = grp(AX_PLUS_B)
+    inner = _poly_add(_poly_mul(_limbs_of_const(b, c["a"], N), x), _poly_mul(_limbs_of_const(b, c["b"], N), _limbs_of_const(b, 1, N)))
+    _field_gadget(r, _poly_sub(b, _poly_sub(b, inner, cols[0:N]), _poly_mul(cols[N:2 * N], modulus)), cols, N, off, is_real)
+    _field_op(r, grp(X_3_PLUS), l[X_3:X_3 + N], l[AX_PLUS_B:AX_PLUS_B + N], "add", modulus, N, off, is_real)
+    sqrt, neg_y = l[Y_MULT:Y_MULT + N], l[NEG_Y:NEG_Y + N]
+    _field_op(r, grp(NEG_Y), [b.const(0)], sqrt, "sub", modulus, N, off, is_real)
+    # FieldSqrtCols::eval (field_sqrt.rs:88-131): the multiplication's result columns hold the root, its product is the input
+    mult = list(l[X_3_PLUS:X_3_PLUS + N]) + list(l[Y_MULT + N:Y_MULT + G])
+    _field_op(r, mult, sqrt, sqrt, "mul", modulus, N, off, is_real)
+    _field_lt(r, l[Y_RANGE:Y_RANGE + N + 2], sqrt, modulus, N, is_real)
+    r.slice_range_check_u8(sqrt, is_real)
+    b.assert_bool(l[Y_LSB])
+    b.when(is_real).assert_eq(l[Y_LSB], l[Y_LSB])                               # `is_odd` is the column itself here (:372)
+    r.send_byte(B_AND, l[Y_LSB], sqrt[0], 1, is_real)
+    y_limbs = [v for a in y_access for v in a[4:8]]                             # limbs_from_access of the write: the new value
+    if not lexicographic:
+        for i in range(N):
+            b.when(is_real).when(l[Y_LSB] - (b.const(1) - sign)).assert_eq(sqrt[i], y_limbs[i])
+        for i in range(N):
+            b.when(is_real).when(l[Y_LSB] - sign).assert_eq(neg_y[i], y_limbs[i])
+    else:
+        CMP, NEG_RANGE = CHOICE, CHOICE + N + 2
+        is_eq, when_sqrt_lt, when_neg_lt = l[CHOICE + 2 * (N + 2)], l[CHOICE + 2 * (N + 2) + 1], l[CHOICE + 2 * (N + 2) + 2]
+        _field_lt(r, l[NEG_RANGE:NEG_RANGE + N + 2], neg_y, modulus, N, is_real)
+        b.assert_bool(is_eq)
+        b.assert_bool(when_sqrt_lt)
+        b.assert_bool(when_neg_lt)
+        b.when(is_real).assert_one(when_sqrt_lt + when_neg_lt)
+        for i in range(N):
+            b.when(is_real).when(is_eq).assert_eq(sqrt[i], y_limbs[i])
+        for i in range(N):
+            b.when(is_real).when_not(is_eq).assert_eq(neg_y[i], y_limbs[i])
+        b.when_not(is_real).assert_zero(when_sqrt_lt)
+        b.when_not(is_real).assert_zero(when_neg_lt)
+        b.when(is_real).when(sign).assert_eq(is_eq, when_neg_lt)
+        b.when(is_real).when_not(sign).assert_eq(is_eq, when_sqrt_lt)
+        _field_lt(r, l[CMP:CMP + N + 2], sqrt, neg_y, N, when_sqrt_lt)
+        _field_lt(r, l[CMP:CMP + N + 2], neg_y, sqrt, N, when_neg_lt)
+    for i in range(W):
+        r.eval_memory_access(l[SHARD], l[CLK], l[PTR] + (4 * i + N), x_access[i][0:4], x_access[i], is_real)
+    for i in range(W):
+        r.eval_memory_access(l[SHARD], l[CLK], l[PTR] + 4 * i, y_access[i][0:4], y_access[i][4:13], is_real)
+    code = E.WEIERSTRASS_DECOMPRESS[curve]["code"] & 0xffff
+    r.receives.append(air.Lookup([air.to_virtual_pair(v) for v in [l[SHARD], l[CLK], b.const(code), l[PTR], sign]],
+                                 air.to_virtual_pair(is_real), air.KIND_SYSCALL))
+
+
+def record_weierstrass_decompress_constraints(curve: str) -> _Rec:
+    r = _Rec(E.weierstrass_decompress_width(curve))
+    _weierstrass_decompress(r, curve)
+    return r
+
+
+def record_weierstrass_decompress_chip(curve: str, log_height: int) -> RecordedChip:
+    """Secp256k1Decompress / Secp256r1Decompress / Bls12381Decompress (crates/core/machine/src/syscall/precompiles/weierstrass/weierstrass_decompress.rs):
+    one decompression per row; local_only (:299-301)."""
+    return _finish(record_weierstrass_decompress_constraints(curve), curve + "Decompress", log_height, E.weierstrass_decompress_width(curve), True)
+
+
 def _field_op_variable(r: _Rec, cols, a, bb, modulus, n_limbs, witness_offset, is_add, is_sub, is_mul, is_real):
     """FieldOpCols::eval_variable (operations/field/field_op.rs:227-261) with is_div = 0: the operation is chosen by flags, so the identity
     is the flag-weighted sum of the three."""

@@ -842,6 +842,94 @@ int zkm_tracegen_weierstrass_double(zkm_ctx* ctx, int curve, const void* events,
   return tracegen_weierstrass(ctx, curve, true, events, n_events, fixed_log2_rows, blu, out, "zkm_tracegen_weierstrass_double");
 }
 
+// <Curve>Decompress: the curve's b and the generator's x (the padding rows' input) as 32-bit limbs (crates/curves/src/weierstrass/secp256k1.rs,
+// secp256r1.rs, bls12_381.rs: WeierstrassParameters::B, GENERATOR); indexed like k_curves8 (Bn254 has no decompress chip)
+static const uint32_t k_decompress_b8[2][8] = {
+  {0x00000007u, 0x00000000u, 0x00000000u, 0x00000000u, 0x00000000u, 0x00000000u, 0x00000000u, 0x00000000u},
+  {0x27d2604bu, 0x3bce3c3eu, 0xcc53b0f6u, 0x651d06b0u, 0x769886bcu, 0xb3ebbd55u, 0xaa3a93e7u, 0x5ac635d8u}};
+static const uint32_t k_decompress_gx8[2][8] = {
+  {0x16f81798u, 0x59f2815bu, 0x2dce28d9u, 0x029bfcdbu, 0xce870b07u, 0x55a06295u, 0xf9dcbbacu, 0x79be667eu},
+  {0xd898c296u, 0xf4a13945u, 0x2deb33a0u, 0x77037d81u, 0x63a440f2u, 0xf8bce6e5u, 0xe12c4247u, 0x6b17d1f2u}};
+static const uint32_t k_decompress_b12[12] = {4u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+static const uint32_t k_decompress_gx12[12] = {0xdb22c6bbu, 0xfb3af00au, 0xf97a1aefu, 0x6c55e83fu, 0x171bac58u, 0xa14e3a3fu,
+                                               0x9774b905u, 0xc3688c4fu, 0x4fa9ac0fu, 0x2695638cu, 0x3197d794u, 0x17f1d3a7u};
+extern "C++" {
+template <int NL>
+static tracegen::DecompressCurve<NL> decompress_curve(const bigfield::Modulus<NL>& m, const uint32_t* a, const uint32_t* b, const uint32_t* gx, int32_t offset) {
+  tracegen::DecompressCurve<NL> c;
+  c.f.m = m;
+  c.f.witness_offset = offset;
+  uint64_t carry = 1;      // (p + 1) / 4: the exponent of the square root for p = 3 (mod 4)
+  uint32_t plus[NL + 1];
+  for (int i = 0; i < NL; i++) { carry += m.p[i]; plus[i] = (uint32_t)carry; carry >>= 32; }
+  plus[NL] = (uint32_t)carry;
+  if ((m.p[0] & 3) != 3) throw std::runtime_error("decompress: the modulus is not 3 (mod 4)");
+  for (int i = 0; i < NL; i++) { c.f.a[i] = a[i]; c.b[i] = b[i]; c.generator_x[i] = gx[i]; c.sqrt_exp[i] = plus[i] >> 2 | plus[i + 1] << 30; }
+  return c;
+}
+template <int NL, bool LEX>
+static void launch_weierstrass_decompress(zkm_ctx* ctx, const tracegen::DecompressCurve<NL>& curve, const uint32_t* d_events, size_t n_events, size_t height,
+                                          uint32_t* out, uint32_t* counts, int* d_bad, double bytes) {
+  KLAUNCH(ctx, "tracegen_weierstrass_decompress", bytes, (tracegen::weierstrass_decompress_rows<NL, LEX>), dim3(div_up(height, (size_t)tracegen::bf_threads(NL))),
+          dim3(tracegen::bf_threads(NL)), tracegen::bf_lds_bytes(NL, counts != nullptr), d_events, n_events, height, out, counts, d_bad, curve);
+}
+}  // extern "C++"
+int zkm_tracegen_weierstrass_decompress(zkm_ctx* ctx, int curve, const void* events, size_t n_events, int fixed_log2_rows, zkm_byte_lookups* blu,
+                                        zkm_matrix** out) {
+  API_BEGIN
+  const char* who = "zkm_tracegen_weierstrass_decompress";
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIP_CHECK(hipSetDevice(ctx->device));
+  if (curve != 0 && curve != 1 && curve != 3) throw std::runtime_error(std::string(who) + ": the curve is ZKM_CURVE_SECP256K1, ZKM_CURVE_SECP256R1 or ZKM_CURVE_BLS12381");
+  if (n_events && !events) throw std::runtime_error(std::string(who) + ": null events");
+  const int nl = curve == 3 ? 12 : 8, N = 4 * nl, W = nl, G = 6 * N - 4;
+  const bool lex = curve == 3;
+  const size_t ev_words = 4 + 11 * W, width = 5 + 22 * W + (N + 2) + 4 * G + (G + N + 3) + G + (lex ? 2 * (N + 2) + 3 : 0);
+  const size_t height = padded_trace_rows(n_events, fixed_log2_rows, who);
+  ctx->begin_timing();
+  zkm_matrix* m = new zkm_matrix();
+  m->h = height; m->w = width;
+  uint32_t* d_events = nullptr;
+  int* d_bad = nullptr;
+  try {
+    m->d = ctx->alloc_n<uint32_t>(height * m->w);
+    const size_t ev_bytes = n_events * ev_words * 4;
+    d_events = (uint32_t*)ctx->alloc(std::max<size_t>(ev_bytes, 4));
+    d_bad = (int*)ctx->alloc(4);
+    HIP_CHECK(hipMemsetAsync(d_bad, 0, 4, ctx->stream));
+    if (n_events) HIP_CHECK(hipMemcpyAsync(d_events, events, ev_bytes, hipMemcpyHostToDevice, ctx->stream));
+    uint32_t* counts = blu ? blu->counts : nullptr;
+    const double bytes = (double)ev_bytes + 4.0 * height * m->w;
+    if (nl == 8)
+      launch_weierstrass_decompress<8, false>(ctx, decompress_curve<8>(k_curves8[curve].m, k_curves8[curve].a, k_decompress_b8[curve], k_decompress_gx8[curve], 1 << 14),
+                                              d_events, n_events, height, m->d, counts, d_bad, bytes);
+    else
+      launch_weierstrass_decompress<12, true>(ctx, decompress_curve<12>(k_curve_bls12381.m, k_curve_bls12381.a, k_decompress_b12, k_decompress_gx12, 1 << 15),
+                                              d_events, n_events, height, m->d, counts, d_bad, bytes);
+    // x_2 .. x_3_plus_b_plus_ax, the root's multiplication (its result columns hold the root; FieldSqrtCols also range-checks the product's
+    // bytes, which are x_3_plus_b_plus_ax's result columns), neg_y
+    const int x_2 = 5 + 22 * W + N + 2;
+    count_u8_pairs(ctx, m, n_events, tracegen::U8Segments{4, {x_2, x_2 + 4 * G, x_2 + 5 * G + N + 3, x_2 + 3 * G}, {4 * G, G, G, N}}, counts);
+    int bad = 0;
+    HIP_CHECK(hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, ctx->stream));
+    ctx->mark("trace generation");
+    ctx->end_timing(false);
+    static const char* reasons[] = {"", "the sign bit is not 0 or 1, or x is not below the field modulus", "x is not on the curve",
+                                    "the words written to y do not write a root of x^3 + a x + b", "the words written to y are not the root the sign bit asks for"};
+    if (bad) throw std::runtime_error(std::string(who) + ": " + reasons[std::min(std::max(16 - bad, 1), 4)]);
+  } catch (...) {
+    if (d_events) ctx->release(d_events);
+    if (d_bad) ctx->release(d_bad);
+    if (m->d) ctx->release(m->d);
+    delete m;
+    throw;
+  }
+  ctx->release(d_events);
+  ctx->release(d_bad);
+  *out = m;
+  API_END
+}
+
 extern "C++" {
 template <int NL, int KIND>
 static void launch_fp_tower(zkm_ctx* ctx, const tracegen::CurveField<NL>& field, const uint32_t* d_events, size_t n_events, size_t height, uint32_t* out,

@@ -1797,16 +1797,31 @@ template <int NL> struct FieldRow {
     }
     gadget(base, res, q);
   }
-  // FieldLtCols::populate (operations/field/range.rs:27-60) of a value below p against p: N flags, the two compared bytes
-  __device__ void lt(int base, const uint32_t* lhs) const {
-    stage_a(lhs); stage_b(f.m.p);
+  // FieldLtCols::populate (operations/field/range.rs:27-60): the flag of the most significant byte where lhs < rhs, the two compared bytes
+  __device__ void lt(int base, const uint32_t* lhs, const uint32_t* rhs) const {
+    stage_a(lhs); stage_b(rhs);
     int at = -1;
-    for (int i = N - 1; i >= 0 && at < 0; i--)
-      if (A(i) < B(i)) at = i;
+    for (int i = N - 1; i >= 0 && at < 0; i--) {
+      const int32_t x = A(i), y = B(i);
+      if (x < y) at = i;
+      else if (x > y) break;        // not below: no flag (callers report the error)
+    }
     for (int i = 0; i < N; i++) put(base + i, i == at ? 1u : 0u);
     const uint32_t a = at >= 0 ? (uint32_t)A(at) : 0u, b = at >= 0 ? (uint32_t)B(at) : 0u;
     put(base + N, a); put(base + N + 1, b);
     if (count && at >= 0) lookup(sink, B_LTU, a, b);
+  }
+  __device__ void lt(int base, const uint32_t* lhs) const { lt(base, lhs, f.m.p); }      // against the modulus
+  __device__ void zeros(int base, int n) const { for (int i = 0; i < n; i++) put(base + i, 0u); }
+  // FieldInnerProductCols::populate (operations/field/field_inner_product.rs:27-79) of (a0, a1) . (b0, 1): a0 b0 + a1 = result + carry p
+  __device__ void inner_with_one(int base, const uint32_t* a0, const uint32_t* b0, const uint32_t* a1, uint32_t* res) const {
+    uint32_t t[2 * NL], t2[2 * NL], q[NL + 1];
+    bigfield::mul<NL, NL>(a0, b0, t);
+    for (int i = 0; i < 2 * NL; i++) t2[i] = i < NL ? a1[i] : 0u;
+    bigfield::add<2 * NL>(t, t2);
+    bigfield::divmod<NL>(t, f.m, q, res);
+    clear(); mac(a0, b0); add(a1, 1); add(res, -1);
+    gadget(base, res, q);
   }
   // the memory columns of a W-word write slice (6-word records) and read slice (5-word records); zero for a padding row
   __device__ void write_cols(int base, const uint32_t* rec) const {
@@ -2123,6 +2138,94 @@ __global__ __launch_bounds__(bf_threads(NL)) void weierstrass_rows(const uint32_
       if (real && e[E_P + 6 * k] != (k < NL ? x3[k] : y3[k - NL])) ok = false;
     }
     if (real && !ok) *bad = 1;
+  }
+  blk.flush(counts);
+}
+
+// ---- <Curve>Decompress (syscall/precompiles/weierstrass/weierstrass_decompress.rs:52-79, :121-142, :163-285) for Secp256k1, Secp256r1 (the sign bit is
+// y's parity) and Bls12381 (LEX: the bit says y > p - y; three flags and two more FieldLtCols): y = sqrt(x^3 + a x + b), the root
+// (x^3 + a x + b)^((p + 1) / 4). x is read at ptr + N, y written at ptr. Padding rows hold the operations of the generator's x.
+// Error codes (the lowest wins): 1 sign bit / x not below p, 2 x not on the curve, 3 the y written is not a root, 4 not the root asked for.
+template <int NL> struct DecompressCurve { CurveField<NL> f; uint32_t b[NL], generator_x[NL], sqrt_exp[NL]; };
+template <int NL, bool LEX>
+__global__ __launch_bounds__(bf_threads(NL)) void weierstrass_decompress_rows(const uint32_t* __restrict__ events, size_t n_events, size_t height,
+                                                                              uint32_t* __restrict__ out, uint32_t* counts, int* __restrict__ bad,
+                                                                              const DecompressCurve<NL> curve) {
+  constexpr int N = 4 * NL, W = NL, G = FieldRow<NL>::G;
+  constexpr int X_ACCESS = 5, Y_ACCESS = X_ACCESS + 9 * W, RANGE_X = Y_ACCESS + 13 * W, X_2 = RANGE_X + N + 2, X_3 = X_2 + G, AX_PLUS_B = X_2 + 2 * G,
+                X_3_PLUS = X_2 + 3 * G, Y_MULT = X_2 + 4 * G, Y_RANGE = Y_MULT + G, Y_LSB = Y_RANGE + N + 2, NEG_Y = Y_LSB + 1, CHOICE = NEG_Y + G;
+  constexpr int EV_WORDS = 4 + 11 * W, E_X = 4, E_Y = 4 + 5 * W;
+  extern __shared__ uint32_t bf_lds[];
+  const BfBlock blk(bf_lds, counts);
+  const size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (row < height) {
+    const bool real = row < n_events;
+    const uint32_t* e = events + row * EV_WORDS;
+    const LookupSink sink{blk.hkeys, blk.hvals, BF_HASH_SLOTS - 1, counts};
+    const FieldRow<NL> R = FieldRow<NL>::make(out, height, row, sink, blk.count && real, curve.f, blk.scratch);
+    const bigfield::Modulus<NL>& m = curve.f.m;
+    int why = 0;
+    uint32_t x[NL];
+    for (int k = 0; k < NL; k++) x[k] = real ? e[E_X + 5 * k] : curve.generator_x[k];
+    if (bigfield::cmp<NL>(x, m.p) >= 0 || (real && e[3] > 1)) { why = 1; for (int k = 0; k < NL; k++) x[k] = curve.generator_x[k]; }
+    uint32_t x2[NL], x3[NL], axb[NL], rhs[NL], y[NL], sq[NL], neg[NL], zero[NL];
+    for (int k = 0; k < NL; k++) zero[k] = 0;
+    R.lt(RANGE_X, x);
+    R.op(X_2, x, x, FOP_MUL, x2);
+    R.op(X_3, x2, x, FOP_MUL, x3);
+    R.inner_with_one(AX_PLUS_B, curve.f.a, x, curve.b, axb);
+    R.op(X_3_PLUS, x3, axb, FOP_ADD, rhs);
+    {      // the root rhs^((p + 1) / 4)
+      bool started = false;
+      for (int k = 0; k < NL; k++) y[k] = k == 0 ? 1u : 0u;
+      for (int bit = 32 * NL - 1; bit >= 0; bit--) {
+        if (started) bigfield::mulmod<NL>(y, y, m, y);
+        if ((curve.sqrt_exp[bit / 32] >> (bit % 32)) & 1) {
+          if (started) bigfield::mulmod<NL>(y, rhs, m, y);
+          else { for (int i = 0; i < NL; i++) y[i] = rhs[i]; started = true; }
+        }
+      }
+      bigfield::mulmod<NL>(y, y, m, sq);
+      if (bigfield::cmp<NL>(sq, rhs) != 0) why = why ? why : 2;
+    }
+    // FieldSqrtCols (field_sqrt.rs:34-85): y * y = rhs in the multiplication's carry / witness columns, the root itself in its result columns
+    R.op(Y_MULT, y, y, FOP_MUL, sq);
+    R.stage_a(y);
+    for (int i = 0; i < N; i++) R.put(Y_MULT + i, (uint32_t)R.A(i));
+    if (R.count) lookup(sink, B_AND, y[0], 1);      // the range checks of the product's and the root's bytes: u8_pair_histogram
+    R.lt(Y_RANGE, y);
+    R.put(Y_LSB, y[0] & 1);
+    R.op(NEG_Y, zero, y, FOP_SUB, neg);
+    R.put(0, real ? 1u : 0u);
+    R.put(1, real ? e[0] : 0u); R.put(2, real ? e[1] : 0u); R.put(3, real ? e[2] : 0u); R.put(4, real ? e[3] : 0u);
+    uint32_t d[NL];
+    for (int k = 0; k < W; k++) {
+      R.read_cols(X_ACCESS + 9 * k, real ? e + E_X + 5 * k : nullptr);
+      R.write_cols(Y_ACCESS + 13 * k, real ? e + E_Y + 6 * k : nullptr);
+      d[k] = real ? e[E_Y + 6 * k] : 0u;
+    }
+    if (!real)      // the padding rows show the generator's x as the value read
+      for (int i = 0; i < N; i++) R.put(X_ACCESS + 9 * (i / 4) + i % 4, (curve.generator_x[i / 4] >> (8 * (i % 4))) & 0xff);
+    const bool wrote_root = bigfield::cmp<NL>(d, y) == 0;
+    if (real && !wrote_root && bigfield::cmp<NL>(d, neg) != 0) why = why ? why : 3;
+    if (!LEX) {
+      if (real && (d[0] & 1) != e[3]) why = why ? why : 4;
+    } else {      // LexicographicChoiceCols :196-246: comparison_lt_cols, neg_y_range_check, is_y_eq_sqrt_y_result, when_sqrt_y_res_is_lt, when_neg_y_res_is_lt
+      constexpr int CMP = CHOICE, NEG_RANGE = CHOICE + N + 2, FLAGS = CHOICE + 2 * (N + 2);
+      if (real && !why) {
+        const uint32_t* other = wrote_root ? neg : y;      // p - d
+        const int order = bigfield::cmp<NL>(other, d);
+        if (order == 0 || (order < 0) != (e[3] != 0)) why = 4;
+        R.put(FLAGS, wrote_root ? 1u : 0u);
+        R.put(FLAGS + 1, (e[3] != 0) != wrote_root ? 1u : 0u);      // sign: !wrote_root; no sign: wrote_root
+        R.put(FLAGS + 2, (e[3] != 0) == wrote_root ? 1u : 0u);
+        R.lt(NEG_RANGE, neg);
+        if (e[3]) R.lt(CMP, other, d); else R.lt(CMP, d, other);
+      } else {
+        R.zeros(CHOICE, 2 * (N + 2) + 3);
+      }
+    }
+    if (real && why) atomicMax(bad, 16 - why);
   }
   blk.flush(counts);
 }

@@ -742,6 +742,49 @@ def weierstrass_double(curve, p):
     return x3, (slope * (x1 - x3) - y1) % P
 
 
+# <Curve>Decompress (syscall/precompiles/weierstrass/weierstrass_decompress.rs): y from x and a sign bit on Secp256k1, Secp256r1 (the bit is y's
+# parity: SignChoiceRule::LeastSignificantBit) and Bls12381 (the bit says y > p - y: Lexicographic, mips/mod.rs:240,259,347). The syscall reads x at
+# ptr + N and writes y at ptr, both at clk (create_ec_decompress_event, events/precompiles/ec.rs:181-228).
+WEIERSTRASS_DECOMPRESS = {"Secp256k1": dict(code=0x0001000C, lexicographic=False), "Secp256r1": dict(code=0x0001002E, lexicographic=False),
+                          "Bls12381": dict(code=0x0001001C, lexicographic=True)}
+
+
+def weierstrass_decompress_event_dtype(curve):
+    """EllipticCurveDecompressEvent (events/precompiles/ec.rs:74-94) flattened: x is the values of the x read records, the decompressed y the
+    values of the y write records."""
+    w = WEIERSTRASS_CURVES[curve]["n_limbs"] // 4
+    return np.dtype([("shard", "<u4"), ("clk", "<u4"), ("ptr", "<u4"), ("sign_bit", "<u4"), ("x_memory_records", MEMORY_READ_RECORD, (w,)),
+                     ("y_memory_records", MEMORY_WRITE_RECORD, (w,))])
+
+
+def weierstrass_decompress_width(curve):
+    """WeierstrassDecompressCols (weierstrass_decompress.rs:52-68): 5 + 9 W + 13 W, range_x (N + 2), x_2, x_3, ax_plus_b, x_3_plus_b_plus_ax (G each),
+    y (FieldSqrtCols: G + N + 2 + 1), neg_y (G); the lexicographic rule adds LexicographicChoiceCols (:73-79): two FieldLtCols and three flags."""
+    n = WEIERSTRASS_CURVES[curve]["n_limbs"]
+    w, g = n // 4, 6 * n - 4
+    return 5 + 22 * w + (n + 2) + 4 * g + (g + n + 3) + g + (2 * (n + 2) + 3 if WEIERSTRASS_DECOMPRESS[curve]["lexicographic"] else 0)
+
+
+def weierstrass_sqrt(curve, a):
+    """secp256k1_sqrt / secp256r1_sqrt / bls12381_sqrt (curves/src/weierstrass/*.rs): the root the k256 / p256 / amcl field types return. Those
+    crates are not in the tree; for all three moduli p = 3 (mod 4) and the root is a^((p + 1) / 4) (unpinned: either root satisfies the AIR)."""
+    P = WEIERSTRASS_CURVES[curve]["p"]
+    r = pow(a, (P + 1) // 4, P)
+    if r * r % P != a % P:
+        raise ValueError("not a square")
+    return r
+
+
+def weierstrass_decompress(curve, x, sign_bit):
+    """The y the syscall writes: the root whose parity is the bit (Secp256k1 / Secp256r1), or the larger of y, p - y when the bit is set (Bls12381)."""
+    c = WEIERSTRASS_CURVES[curve]
+    P = c["p"]
+    r = weierstrass_sqrt(curve, (x * x * x + c["a"] * x + c["b"]) % P)
+    if WEIERSTRASS_DECOMPRESS[curve]["lexicographic"]:
+        return max(r, P - r) if sign_bit else min(r, P - r)
+    return r if (r & 1) == sign_bit else P - r
+
+
 # The field-tower precompiles (syscall/precompiles/fptower/fp.rs, fp2_addsub.rs, fp2_mul.rs) over the base fields of Bn254 and Bls12381: FpOpEvent,
 # Fp2AddSubEvent, Fp2MulEvent (events/precompiles/fptower.rs:23-94) flattened; `op` is FieldOperation as a word (Add 0, Mul 1, Sub 2).
 FP_TOWER_CODES = {"Bn254": dict(fp_add=0x01010026, fp_sub=0x01010027, fp_mul=0x01010028, fp2_add=0x01010029, fp2_sub=0x0101002A, fp2_mul=0x0101002B),

@@ -95,7 +95,7 @@ class Machine:
 
 def run_machine(n_cycles: int = 0, seed: int = 1, pc_base: int = 0x1000, shard_cycles: int = 1 << 30, program=None, poseidon2_calls: int = 0,
                 memory_chunk: int = 1 << 30, keccak_calls: int = 0, sha_calls: int = 0, ed_calls: int = 0,
-                curve_calls=None, fp_calls=None) -> Machine:
+                curve_calls=None, fp_calls=None, decompress_calls=None) -> Machine:
     """A whole run as the reference's prover sees it (crates/core/machine/src/utils/prove.rs:255-400): CPU shards of at most `shard_cycles`
     cycles (never split between a branch and its delay slot, executor.rs:2352-2356), then one shard with the deferred precompile events
     (ExecutionRecord::split, record.rs:130-218), then the shards that initialise and finalise every touched address
@@ -103,12 +103,12 @@ def run_machine(n_cycles: int = 0, seed: int = 1, pc_base: int = 0x1000, shard_c
     to execute until it halts instead of generating one; `poseidon2_calls` / `keccak_calls`: POSEIDON2_PERMUTE / KECCAK_SPONGE precompile calls
     spread over a generated run (each kind is deferred to a precompile shard of its own, record.rs:150-185)."""
     return _execute(n_cycles, seed, 1, pc_base, True, shard_cycles=shard_cycles, given=program, poseidon2_calls=poseidon2_calls, memory_chunk=memory_chunk,
-                    machine=True, keccak_calls=keccak_calls, sha_calls=sha_calls, ed_calls=ed_calls, curve_calls=curve_calls, fp_calls=fp_calls)
+                    machine=True, keccak_calls=keccak_calls, sha_calls=sha_calls, ed_calls=ed_calls, curve_calls=curve_calls, fp_calls=fp_calls, decompress_calls=decompress_calls)
 
 
 def _execute(n_cycles: int, seed: int = 1, shard: int = 1, pc_base: int = 0x1000, halt: bool = False, shard_cycles: int = 1 << 30, given=None,
              poseidon2_calls: int = 0, memory_chunk: int = 1 << 30, machine: bool = False, keccak_calls: int = 0, sha_calls: int = 0, ed_calls: int = 0,
-             curve_calls=None, fp_calls=None) -> Machine:
+             curve_calls=None, fp_calls=None, decompress_calls=None) -> Machine:
     """Execute `n_cycles` instructions of a program generated on the way. Returns (program, record, public_values) with
     program: INSTRUCTION array (instructions that were jumped over are `ADD $0, 0, 0` no-ops that never run), record:
     structured event arrays, public_values: dict of the words the Cpu chip checks (start_pc, next_pc, execution_shard).
@@ -175,7 +175,7 @@ def _execute(n_cycles: int, seed: int = 1, shard: int = 1, pc_base: int = 0x1000
     s_at = set(int(x) for x in np.linspace(n_cycles // 5, max(n_cycles - 80, n_cycles // 5), sha_calls)) - p2_at - k_at if sha_calls else set()
     s_seq = 0
     e_at = {n_cycles // 4} - p2_at - k_at - s_at if ed_calls else set()
-    w_at = {n_cycles // 3} - p2_at - k_at - s_at - e_at if curve_calls else set()
+    w_at = {n_cycles // 3} - p2_at - k_at - s_at - e_at if curve_calls or decompress_calls else set()
     f_at = {n_cycles // 2} - p2_at - k_at - s_at - e_at - w_at if fp_calls else set()
     clk_extra = 0                  # the extra cycles of the shard's syscalls so far (Syscall::num_extra_cycles, executor.rs:1641)
 
@@ -284,7 +284,7 @@ def _execute(n_cycles: int, seed: int = 1, shard: int = 1, pc_base: int = 0x1000
             # per curve in `curve_calls`: the generator stored at p and at q, q doubled with <CURVE>_DOUBLE(q), then `count` times p <- p + q
             # with <CURVE>_ADD(p, q): p runs through G, 3G, 5G, ... and never meets q = 2G
             had = len(queued)
-            for k, (curve, calls) in enumerate(curve_calls.items()):
+            for k, (curve, calls) in enumerate((curve_calls or {}).items()):
                 cv = E.WEIERSTRASS_CURVES[curve]
                 W = cv["n_limbs"] // 2
                 p_ptr, q_ptr = 0x00600000 + 0x400 * k, 0x00600200 + 0x400 * k
@@ -295,6 +295,16 @@ def _execute(n_cycles: int, seed: int = 1, shard: int = 1, pc_base: int = 0x1000
                            (E.SYSCALL, E.REG_V0, E.REG_A0, E.REG_A1, 0, 0)]
                 for _ in range(calls):
                     queued += [(E.ADD, E.REG_V0, cv["add"], 0, 1, 1), (E.ADD, E.REG_A0, p_ptr, 0, 1, 1), (E.ADD, E.REG_A1, q_ptr, 0, 1, 1),
+                               (E.SYSCALL, E.REG_V0, E.REG_A0, E.REG_A1, 0, 0)]
+            # per curve in `decompress_calls`: the generator's x stored at ptr + N, then `count` times <CURVE>_DECOMPRESS(ptr, sign) with the sign
+            # bit alternating: y at ptr is the generator's y or its negative
+            for k, (curve, calls) in enumerate((decompress_calls or {}).items()):
+                cv = E.WEIERSTRASS_CURVES[curve]
+                ptr = 0x00680000 + 0x400 * k
+                for i in range(cv["n_limbs"] // 4):
+                    queued += [(E.ADD, 30, (cv["generator"][0] >> (32 * i)) & 0xffffffff, 0, 1, 1), (E.SW, 30, 0, ptr + cv["n_limbs"] + 4 * i, 0, 1)]
+                for j in range(calls):
+                    queued += [(E.ADD, E.REG_V0, E.WEIERSTRASS_DECOMPRESS[curve]["code"], 0, 1, 1), (E.ADD, E.REG_A0, ptr, 0, 1, 1), (E.ADD, E.REG_A1, j & 1, 0, 1, 1),
                                (E.SYSCALL, E.REG_V0, E.REG_A0, E.REG_A1, 0, 0)]
             n_cycles += len(queued) - had
             p2_at = set(x + len(queued) - had if x > cyc else x for x in p2_at)
@@ -500,7 +510,8 @@ def _execute(n_cycles: int, seed: int = 1, shard: int = 1, pc_base: int = 0x1000
             sid = code & 0xffff
             w_curve = {c[k]: (name, k == "double") for name, c in E.WEIERSTRASS_CURVES.items() for k in ("add", "double")}.get(code)
             fp_call = {c: (field, name) for field, codes in E.FP_TOWER_CODES.items() for name, c in codes.items()}.get(code)
-            assert w_curve or fp_call or code in (E.SYS_HALT, E.SYS_COMMIT, E.SYS_POSEIDON2_PERMUTE, E.SYS_KECCAK_SPONGE, E.SYS_SHA_EXTEND, E.SYS_SHA_COMPRESS, E.SYS_ED_ADD,
+            w_decompress = {d["code"]: name for name, d in E.WEIERSTRASS_DECOMPRESS.items()}.get(code)
+            assert w_curve or fp_call or w_decompress or code in (E.SYS_HALT, E.SYS_COMMIT, E.SYS_POSEIDON2_PERMUTE, E.SYS_KECCAK_SPONGE, E.SYS_SHA_EXTEND, E.SYS_SHA_COMPRESS, E.SYS_ED_ADD,
                                         E.SYS_ED_DECOMPRESS), code
             touched = {}                               # address -> [initial (shard, timestamp, value), final]: SyscallContext's local map
 
@@ -636,6 +647,16 @@ def _execute(n_cycles: int, seed: int = 1, shard: int = 1, pc_base: int = 0x1000
                 event = (shard, clk, b, pwr) if dbl else (shard, clk, b, c, pwr, qr)
                 precompile.append((curve + ("_double" if dbl else "_add"), (pc, next_pc, shard, clk, (0, 0, 0, 0, 0, 0), 0, [0, 0, 0], sid, b, c), [event], local))
                 clk_extra += 0 if dbl else 1
+            if w_decompress:
+                # create_ec_decompress_event (events/precompiles/ec.rs:181-228): x is read at ptr + N, the y the sign bit ($a1) selects is written at
+                # ptr, both at clk; no extra cycle
+                n_words = E.WEIERSTRASS_CURVES[w_decompress]["n_limbs"] // 4
+                assert b % 4 == 0 and c <= 1
+                xr = [mem(b + 4 * n_words + 4 * i, clk) for i in range(n_words)]
+                y = E.weierstrass_decompress(w_decompress, sum(rec_[0] << (32 * i) for i, rec_ in enumerate(xr)), c)
+                yw = [mem(b + 4 * i, clk, (y >> (32 * i)) & 0xffffffff) for i in range(n_words)]
+                local = [(addr, v[0], v[1]) for addr, v in sorted(touched.items())]
+                precompile.append((w_decompress + "_decompress", (pc, next_pc, shard, clk, (0, 0, 0, 0, 0, 0), 0, [0, 0, 0], sid, b, c), [(shard, clk, b, c, xr, yw)], local))
             if fp_call:
                 # FpOpSyscall / Fp2AddSubSyscall / Fp2MulSyscall::execute (syscalls/precompiles/fptower/fp.rs:30-120, fp2_addsub.rs, fp2_mul.rs): x is
                 # peeked, y read at clk, the result written over x at clk + 1; one extra cycle. The three Fp codes of a field file their events
@@ -773,6 +794,7 @@ def _execute(n_cycles: int, seed: int = 1, shard: int = 1, pc_base: int = 0x1000
                      ("sha_compress", E.SHA_COMPRESS_EVENT), ("ed_add", E.ED_ADD_EVENT),
                      ("ed_decompress", E.ED_DECOMPRESS_EVENT)) + tuple(
             (curve + suffix, E.weierstrass_event_dtypes(curve)[k]) for curve in E.WEIERSTRASS_CURVES for k, suffix in ((0, "_add"), (1, "_double"))) + tuple(
+            (curve + "_decompress", E.weierstrass_decompress_event_dtype(curve)) for curve in E.WEIERSTRASS_DECOMPRESS) + tuple(
             (field + "_" + kind, E.fp_tower_event_dtype(field, kind)) for field in E.FP_TOWER_CODES for kind in ("fp", "fp2_addsub", "fp2_mul")):
         mine = [e for e in precompile if e[0] == kind]
         if not mine:
@@ -788,6 +810,7 @@ def _execute(n_cycles: int, seed: int = 1, shard: int = 1, pc_base: int = 0x1000
         o.ed_add = arr([ev for e in mine for ev in e[2]] if kind == "ed_add" else [], E.ED_ADD_EVENT)
         o.ed_decompress = arr([ev for e in mine for ev in e[2]] if kind == "ed_decompress" else [], E.ED_DECOMPRESS_EVENT)
         o.weierstrass = (kind, arr([ev for e in mine for ev in e[2]], dt)) if kind.endswith(("_add", "_double")) and kind.split("_")[0] in E.WEIERSTRASS_CURVES else None
+        o.weierstrass_decompress = (kind.split("_")[0], arr([ev for e in mine for ev in e[2]], dt)) if kind.endswith("_decompress") and kind != "ed_decompress" else None
         o.fp_tower = (kind, arr([ev for e in mine for ev in e[2]], dt)) if kind.split("_")[0] in E.FP_TOWER_CODES and "_fp" in kind else None
         o.memory_local = arr([ev for e in mine for ev in e[3]], MEMORY_LOCAL_EVENT)
         pv = dict(last_pv, start_pc=last_pv["next_pc"], shard=n_shard)

@@ -279,6 +279,18 @@ class Context:
                      C.c_int(fixed_log2_rows), blu.h if blu is not None else None, C.byref(h)))
         return self._born(h)
 
+    def tracegen_weierstrass_decompress(self, curve: str, events: np.ndarray, fixed_log2_rows: int = -1, blu: "ByteLookups" = None) -> DeviceMatrix:
+        """`generate_trace` of Secp256k1Decompress / Secp256r1Decompress / Bls12381Decompress on the device (zkm_tracegen_weierstrass_decompress);
+        dtype events.weierstrass_decompress_event_dtype(curve)."""
+        from . import events as _ev
+        ev = np.ascontiguousarray(events, dtype=_ev.weierstrass_decompress_event_dtype(curve))
+        if curve not in _ev.WEIERSTRASS_DECOMPRESS:
+            raise ValueError("no decompress chip for " + curve)
+        h = C.c_void_p()
+        lib.check(lib.load().zkm_tracegen_weierstrass_decompress(self.h, C.c_int(_ev.WEIERSTRASS_CURVES[curve]["index"]), C.c_void_p(ev.ctypes.data if len(ev) else None),
+                                                                 C.c_size_t(len(ev)), C.c_int(fixed_log2_rows), blu.h if blu is not None else None, C.byref(h)))
+        return self._born(h)
+
     def tracegen_fp_tower(self, field: str, kind: str, events: np.ndarray, fixed_log2_rows: int = -1, blu: "ByteLookups" = None) -> DeviceMatrix:
         """`generate_trace` of <Field>FpOpAssign / Fp2AddSubAssign / Fp2MulAssign on the device (zkm_tracegen_fp_op / _fp2_addsub / _fp2_mul); field
         "Bn254" or "Bls12381", kind "fp" / "fp2_addsub" / "fp2_mul", dtype events.fp_tower_event_dtype(field, kind)."""
