@@ -502,6 +502,18 @@ int zkm_tracegen_weierstrass_double(zkm_ctx* ctx, int curve, const void* events,
 int zkm_tracegen_weierstrass_decompress(zkm_ctx* ctx, int curve, const void* events, size_t n_events, int fixed_log2_rows, zkm_byte_lookups* blu,
                                         zkm_matrix** out);
 
+/* Uint256MulMod (crates/core/machine/src/syscall/precompiles/uint256/air.rs): replaces generate_trace (:104-203), byte lookups into `blu`. An event is
+ * Uint256MulEvent (crates/core/executor/src/events/precompiles/uint256.rs:12-35) flattened: x is the previous values of the x write records (the
+ * result is their values, written at clk + 1), y and the modulus the values of their read records (read at clk from y_ptr, contiguous); a
+ * zero modulus stands for 2^256. Fails when the words written are not x * y mod modulus, or when x * y / modulus does not fit 256 bits. */
+typedef struct {
+  uint32_t shard, clk, x_ptr, y_ptr;
+  zkm_memory_write_record x_memory_records[8];
+  zkm_memory_read_record y_memory_records[8], modulus_memory_records[8];
+} zkm_uint256_mul_event;
+int zkm_tracegen_uint256_mul(zkm_ctx* ctx, const zkm_uint256_mul_event* events, size_t n_events, int fixed_log2_rows, zkm_byte_lookups* blu,
+                             zkm_matrix** out);
+
 /* The field-tower precompiles (crates/core/machine/src/syscall/precompiles/fptower/fp.rs, fp2_addsub.rs, fp2_mul.rs): Bn254 / Bls12381 x FpOpAssign,
  * Fp2AddSubAssign, Fp2MulAssign; replace their generate_trace, byte lookups into `blu`. `field` is ZKM_CURVE_BN254 or ZKM_CURVE_BLS12381. Events:
  * FpOpEvent / Fp2AddSubEvent / Fp2MulEvent (crates/core/executor/src/events/precompiles/fptower.rs:23-94) flattened — shard, clk, x_ptr, y_ptr,

@@ -32,7 +32,7 @@ pub(crate) const DEVICE_BUILT: &[&str] = &[
     "KeccakSponge", "ShaExtend", "ShaCompress", "EdAddAssign", "EdDecompress", "Secp256k1AddAssign", "Secp256k1DoubleAssign", "Secp256r1AddAssign",
     "Secp256r1DoubleAssign", "Bn254AddAssign", "Bn254DoubleAssign", "Bls12381AddAssign", "Bls12381DoubleAssign", "Bn254FpOpAssign", "Bn254Fp2AddSubAssign",
     "Bn254Fp2MulAssign", "Bls12381FpOpAssign", "Bls12831Fp2AddSubAssign", "Bls12831Fp2MulAssign", "Secp256k1Decompress", "Secp256r1Decompress",
-    "Bls12381Decompress",
+    "Bls12381Decompress", "Uint256MulMod",
 ];
 
 /// ZKM_CURVE_* of include/zkm_hip.h
@@ -219,6 +219,20 @@ pub(crate) fn device_trace(
         "Bn254DoubleAssign" => curve_events!(BN254_DOUBLE, Bn254Double, zkm_tracegen_weierstrass_double, BN254, dbl),
         "Bls12381AddAssign" => curve_events!(BLS12381_ADD, Bls12381Add, zkm_tracegen_weierstrass_add, BLS12381, add),
         "Bls12381DoubleAssign" => curve_events!(BLS12381_DOUBLE, Bls12381Double, zkm_tracegen_weierstrass_double, BLS12381, dbl),
+        "Uint256MulMod" => {
+            let ev: Vec<ffi::ZkmUint256MulEvent> = precompile(r, SyscallCode::UINT256_MUL)
+                .map(|e| match e {
+                    PrecompileEvent::Uint256Mul(e) => ffi::ZkmUint256MulEvent {
+                        shard: e.shard, clk: e.clk, x_ptr: e.x_ptr, y_ptr: e.y_ptr,
+                        x_memory_records: core::array::from_fn(|i| wr(&e.x_memory_records[i])),
+                        y_memory_records: core::array::from_fn(|i| rd(&e.y_memory_records[i])),
+                        modulus_memory_records: core::array::from_fn(|i| rd(&e.modulus_memory_records[i])),
+                    },
+                    _ => unreachable!(),
+                })
+                .collect();
+            check(unsafe { ffi::zkm_tracegen_uint256_mul(ctx, ev.as_ptr(), ev.len(), fixed, blu, &mut m) })?
+        }
         "Secp256k1Decompress" => curve_events!(SECP256K1_DECOMPRESS, Secp256k1Decompress, zkm_tracegen_weierstrass_decompress, SECP256K1, dec),
         "Secp256r1Decompress" => curve_events!(SECP256R1_DECOMPRESS, Secp256r1Decompress, zkm_tracegen_weierstrass_decompress, SECP256R1, dec),
         "Bls12381Decompress" => curve_events!(BLS12381_DECOMPRESS, Bls12381Decompress, zkm_tracegen_weierstrass_decompress, BLS12381, dec),

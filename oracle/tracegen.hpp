@@ -1753,18 +1753,21 @@ static const uint8_t ED25519_MODULUS[32] = {237, 255, 255, 255, 255, 255, 255, 2
 static const uint8_t ED25519_D[32] = {163, 120, 89, 19, 202, 77, 235, 117, 171, 216, 65, 65, 77, 10, 112, 0,
                                       152, 232, 121, 119, 121, 64, 199, 140, 115, 254, 111, 43, 238, 108, 3, 82};
 // result, carry, witness_low, witness_high at r, from `lhs_minus_rhs` (the identity's polynomial before the carry term) and the two integers
+// (`nw`: the witness length, 2 N - 2 for the fields and 2 N - 1 for U256Field, whose modulus 2^256 has N + 1 limbs: curves/src/uint256.rs:31-36)
 static inline void field_gadget_cols(F* r, const bigfield::Poly& lhs_minus_rhs, const bigfield::Big& result, const bigfield::Big& carry,
-                                     const bigfield::Big& p, int n_limbs, int64_t offset, std::vector<ByteLookup>* lk) {
+                                     const bigfield::Big& p, int n_limbs, int64_t offset, std::vector<ByteLookup>* lk, int nw = -1) {
   using namespace bigfield;
-  const int nw = 2 * n_limbs - 2;
-  Poly van = padd(lhs_minus_rhs, pmul(poly(carry, n_limbs), poly(p, n_limbs)), -1);
+  const int modulus_limbs = nw < 0 ? n_limbs : n_limbs + 1;
+  if (nw < 0) nw = 2 * n_limbs - 2;
+  Poly van = padd(lhs_minus_rhs, pmul(poly(carry, n_limbs), poly(p, modulus_limbs)), -1);
   van.resize(nw + 1, 0);
   std::vector<int64_t> w(nw, 0);          // van = w * (x - 256): w[k - 1] = van[k] + 256 * w[k] from the top down, and the constant term closes
   int64_t above = 0;
   for (int k = nw; k >= 1; k--) { w[k - 1] = van[k] + 256 * above; above = w[k - 1]; }
   if (van[0] + 256 * w[0] != 0) throw std::runtime_error("tracegen: field gadget identity does not hold");
   for (int i = 0; i < n_limbs; i++) { r[i] = limb(result, i); r[n_limbs + i] = limb(carry, i); }
-  if (limb(result, n_limbs) || limb(carry, n_limbs)) throw std::runtime_error("tracegen: field gadget result / carry does not fit its limbs");
+  for (size_t i = n_limbs; i < std::max(result.size(), carry.size()); i++)
+    if (limb(result, i) || limb(carry, i)) throw std::runtime_error("tracegen: field gadget result / carry does not fit its limbs");
   for (int i = 0; i < nw; i++) {
     const int64_t shifted = w[i] + offset;
     if (shifted < 0 || shifted >= 65536) throw std::runtime_error("tracegen: field gadget witness out of range");
@@ -2144,6 +2147,59 @@ static inline std::vector<F> generate_weierstrass_decompress(const uint32_t* eve
         field_lt_cols(r + CMP, decompressed, other, N, &lk);
       }
     }
+  }
+  if (byte_counts)
+    for (const ByteLookup& bl : lk) byte_counts[((size_t)bl.b * 256 + bl.c) * NUM_BYTE_OPS + bl.op]++;
+  *height = h;
+  return t;
+}
+
+// ---- Uint256MulMod (syscall/precompiles/uint256/air.rs:57-91, :104-203): x <- x * y mod m, m = 0 standing for 2^256. Columns: shard, clk, x_ptr, y_ptr,
+// eight MemoryWriteCols of x, eight MemoryReadCols of y, eight of the modulus, modulus_is_zero (IsZeroOperation of the sum of the modulus' bytes),
+// modulus_is_not_zero, output (FieldOpCols over U256Field: 32 + 32 + 63 + 63), output_range_check (FieldLtCols, filled only when there is a
+// modulus), is_real: 480 columns. Padding rows: the product of zeros (witness_high = 2^14 >> 8).
+struct Uint256MulEvent { uint32_t shard, clk, x_ptr, y_ptr; MemoryWriteRecord x_memory_records[8]; MemoryReadRecord y_memory_records[8], modulus_memory_records[8]; };
+static_assert(sizeof(Uint256MulEvent) == 4 * 132, "flattened Uint256MulEvent is 132 words");
+static const size_t UINT256_MUL_WIDTH = 480;
+static inline std::vector<F> generate_uint256_mul(const Uint256MulEvent* events, size_t n_events, int fixed_log2_rows, size_t* height, uint64_t* byte_counts) {
+  using namespace bigfield;
+  enum { SHARD = 0, CLK = 1, X_PTR = 2, Y_PTR = 3, X_MEM = 4, Y_MEM = 108, M_MEM = 180, IS_ZERO = 252, NOT_ZERO = 254, OUTPUT = 255, RANGE = 445, IS_REAL = 479, N = 32, NW = 63 };
+  const size_t h = padded_rows(n_events, fixed_log2_rows);
+  std::vector<F> t(h * UINT256_MUL_WIDTH, 0);
+  std::vector<ByteLookup> lk;
+  Big two_256(33, 0);
+  two_256[32] = 1;
+  auto product = [&](F* r, const Big& x, const Big& y, const Big& modulus, std::vector<ByteLookup>* sink) {      // populate_with_modulus, Mul (field_op.rs:154-224)
+    Big q, res;
+    divmod(bigfield::mul(x, y), modulus, q, res);
+    field_gadget_cols(r + OUTPUT, padd(pmul(poly(x, N), poly(y, N)), poly(res, N), -1), res, q, modulus, N, 1 << 14, sink, NW);
+    return res;
+  };
+  std::vector<F> padding(UINT256_MUL_WIDTH, 0);
+  product(padding.data(), Big(), Big(), two_256, nullptr);
+  for (size_t i = 0; i < h; i++) {
+    F* r = t.data() + i * UINT256_MUL_WIDTH;
+    if (i >= n_events) { std::copy(padding.begin(), padding.end(), r); continue; }
+    const Uint256MulEvent& e = events[i];
+    r[IS_REAL] = 1; r[SHARD] = fu32(e.shard); r[CLK] = fu32(e.clk); r[X_PTR] = fu32(e.x_ptr); r[Y_PTR] = fu32(e.y_ptr);
+    uint32_t xw[8], yw[8], mw[8], byte_sum = 0;
+    for (int k = 0; k < 8; k++) {
+      memory_write_cols(e.x_memory_records[k], r + X_MEM + 13 * k, &lk);
+      const MemoryReadRecord& y = e.y_memory_records[k];
+      memory_access_cols(y.value, y.shard, y.timestamp, y.prev_shard, y.prev_timestamp, r + Y_MEM + 9 * k, &lk);
+      const MemoryReadRecord& m = e.modulus_memory_records[k];
+      memory_access_cols(m.value, m.shard, m.timestamp, m.prev_shard, m.prev_timestamp, r + M_MEM + 9 * k, &lk);
+      xw[k] = e.x_memory_records[k].prev_value; yw[k] = y.value; mw[k] = m.value;
+      for (int c = 0; c < 4; c++) byte_sum += (m.value >> (8 * c)) & 0xff;
+    }
+    is_zero_cols(byte_sum, r + IS_ZERO);
+    const Big modulus = from_words(mw, 8);
+    const bool no_modulus = is_zero(modulus);
+    const Big res = product(r, from_words(xw, 8), from_words(yw, 8), no_modulus ? two_256 : modulus, &lk);
+    r[NOT_ZERO] = no_modulus ? 0 : 1;
+    if (!no_modulus) field_lt_cols(r + RANGE, res, modulus, N, &lk);
+    for (int k = 0; k < N; k++)
+      if (r[X_MEM + 13 * (k / 4) + 4 + k % 4] != r[OUTPUT + k]) throw std::runtime_error("tracegen: Uint256Mul event does not write x * y mod m");
   }
   if (byte_counts)
     for (const ByteLookup& bl : lk) byte_counts[((size_t)bl.b * 256 + bl.c) * NUM_BYTE_OPS + bl.op]++;

@@ -2017,11 +2017,11 @@ def _poly_mul(x, y):
     return out
 
 
-def _field_gadget(r: _Rec, p_vanishing, cols, n_limbs, witness_offset, is_real):
+def _field_gadget(r: _Rec, p_vanishing, cols, n_limbs, witness_offset, is_real, n_witness=None):
     """eval_field_operation (operations/field/util_air.rs:5-29) and the range checks every gadget ends with (field_op.rs:333-336):
-    cols = result(N), carry(N), witness_low(2N - 2), witness_high(2N - 2)."""
+    cols = result(N), carry(N), witness_low(NW), witness_high(NW); NW = 2N - 2 for the fields, 2N - 1 for U256Field (curves/src/uint256.rs:31-36)."""
     b = r.b
-    nw = 2 * n_limbs - 2
+    nw = 2 * n_limbs - 2 if n_witness is None else n_witness
     result, carry = cols[0:n_limbs], cols[n_limbs:2 * n_limbs]
     w_low, w_high = cols[2 * n_limbs:2 * n_limbs + nw], cols[2 * n_limbs + nw:2 * n_limbs + 2 * nw]
     witness = [w_low[i] + w_high[i] * 256 - witness_offset for i in range(nw)]
@@ -2349,6 +2349,54 @@ def record_weierstrass_decompress_chip(curve: str, log_height: int) -> RecordedC
     """Secp256k1Decompress / Secp256r1Decompress / Bls12381Decompress (crates/core/machine/src/syscall/precompiles/weierstrass/weierstrass_decompress.rs):
     one decompression per row; local_only (:299-301)."""
     return _finish(record_weierstrass_decompress_constraints(curve), curve + "Decompress", log_height, E.weierstrass_decompress_width(curve), True)
+
+
+def _uint256_mul(r: _Rec):
+    """Uint256MulChip::eval (syscall/precompiles/uint256/air.rs:216-328): output = x * y mod m through one FieldOpCols over U256Field whose modulus
+    polynomial is the limbs read from memory, or x^32 (2^256) when an IsZeroOperation on the sum of those limbs says they are all zero; the
+    result is below the modulus (FieldLtCols) when there is one. x is written at clk + 1, y and the modulus (contiguous at y_ptr) are read at clk."""
+    l, b = r.local, r.b
+    N, NW = 32, 63
+    SHARD, CLK, X_PTR, Y_PTR, X_MEM, Y_MEM, M_MEM, IS_ZERO, NOT_ZERO, OUTPUT, RANGE, IS_REAL = 0, 1, 2, 3, 4, 108, 180, 252, 254, 255, 445, 479
+    is_real = l[IS_REAL]
+    x_mem = [l[X_MEM + 13 * i:X_MEM + 13 * i + 13] for i in range(8)]
+    y_mem = [l[Y_MEM + 9 * i:Y_MEM + 9 * i + 9] for i in range(8)]
+    m_mem = [l[M_MEM + 9 * i:M_MEM + 9 * i + 9] for i in range(8)]
+    x = [v for a in x_mem for v in a[0:4]]              # limbs_from_prev_access
+    y = [v for a in y_mem for v in a[0:4]]
+    m = [v for a in m_mem for v in a[0:4]]
+    byte_sum = b.const(0)
+    for limb in m:
+        byte_sum = byte_sum + limb
+    _is_zero(b, byte_sum, l[IS_ZERO:IS_ZERO + 2], is_real)
+    is_zero = l[IS_ZERO + 1]
+    p_modulus = [limb * (b.const(1) - is_zero) for limb in m] + [b.const(1) * is_zero]      # the limbs, or x^32
+    cols = l[OUTPUT:OUTPUT + 2 * N + 2 * NW]
+    van = _poly_sub(b, _poly_sub(b, _poly_mul(x, y), cols[0:N]), _poly_mul(cols[N:2 * N], p_modulus))
+    _field_gadget(r, van, cols, N, 1 << 14, is_real, NW)
+    _field_lt(r, l[RANGE:RANGE + N + 2], cols[0:N], m, N, l[NOT_ZERO])
+    b.assert_eq(l[NOT_ZERO], is_real * (b.const(1) - is_zero))
+    value_limbs = [v for a in x_mem for v in a[4:8]]
+    for i in range(N):
+        b.when(is_real).assert_eq(cols[i], value_limbs[i])
+    for i in range(8):
+        r.eval_memory_access(l[SHARD], l[CLK] + 1, l[X_PTR] + 4 * i, x_mem[i][0:4], x_mem[i][4:13], is_real)
+    for i, acc in enumerate(y_mem + m_mem):
+        r.eval_memory_access(l[SHARD], l[CLK], l[Y_PTR] + 4 * i, acc[0:4], acc, is_real)
+    r.receives.append(air.Lookup([air.to_virtual_pair(v) for v in [l[SHARD], l[CLK], b.const(E.SYS_UINT256_MUL & 0xffff), l[X_PTR], l[Y_PTR]]],
+                                 air.to_virtual_pair(is_real), air.KIND_SYSCALL))
+    b.assert_bool(is_real)
+
+
+def record_uint256_mul_constraints() -> _Rec:
+    r = _Rec(E.UINT256_MUL_WIDTH)
+    _uint256_mul(r)
+    return r
+
+
+def record_uint256_mul_chip(log_height: int) -> RecordedChip:
+    """Uint256MulMod (crates/core/machine/src/syscall/precompiles/uint256/air.rs): one modular multiplication of 256-bit integers per row; local_only (:205-207)."""
+    return _finish(record_uint256_mul_constraints(), "Uint256MulMod", log_height, E.UINT256_MUL_WIDTH, True)
 
 
 def _field_op_variable(r: _Rec, cols, a, bb, modulus, n_limbs, witness_offset, is_add, is_sub, is_mul, is_real):

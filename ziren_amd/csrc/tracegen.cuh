@@ -1706,18 +1706,42 @@ __host__ __device__ constexpr size_t bf_lds_bytes(int nl, bool count) {
 }
 enum { FOP_ADD = 0, FOP_SUB = 1, FOP_MUL = 2, FOP_DIV = 3 };
 template <int NL> struct CurveField { bigfield::Modulus<NL> m; uint32_t a[NL]; int32_t witness_offset; };
-template <int NL> struct FieldRow {
+// a row's column writers: canonical value -> Montgomery word of the column-major matrix; the memory columns of a precompile's records
+struct RowCols {
+  uint32_t* out; size_t height, row; const LookupSink& sink; bool count;
+  __device__ __forceinline__ void put(int col, uint32_t canonical) const { out[(size_t)col * height + row] = kb::to_monty(canonical); }
+  __device__ void zeros(int base, int n) const { for (int i = 0; i < n; i++) put(base + i, 0u); }
+  // the columns of a 6-word write record (MemoryWriteCols, 13) and of a 5-word read record (MemoryReadCols, 9); zero for a padding row
+  __device__ void write_cols(int base, const uint32_t* rec) const {
+    uint32_t mw[13];
+    for (int c = 0; c < 13; c++) mw[c] = 0;
+    if (rec) {
+      memory_write_cols(rec, mw);
+      if (count) { lookup(sink, B_U16RANGE, mw[11] >> 8, mw[11]); lookup(sink, B_U8RANGE, 0, mw[12]); }
+    }
+    for (int c = 0; c < 13; c++) put(base + c, mw[c]);
+  }
+  __device__ void read_cols(int base, const uint32_t* rec) const {
+    uint32_t mr[9];
+    for (int c = 0; c < 9; c++) mr[c] = 0;
+    if (rec) {
+      memory_access_cols(rec[0], rec[1], rec[2], rec[3], rec[4], mr);
+      if (count) access_lookups(mr, sink);
+    }
+    for (int c = 0; c < 9; c++) put(base + c, mr[c]);
+  }
+};
+template <int NL> struct FieldRow : RowCols {
   static constexpr int N = 4 * NL, NW = 2 * N - 2, G = 2 * N + 2 * NW, T = bf_threads(NL);
-  uint32_t* out; size_t height, row; const LookupSink& sink; bool count; const CurveField<NL>& f;
+  const CurveField<NL>& f;
   int32_t* van;          // LDS: 2 N - 1 coefficients, stride T
   uint32_t *opa, *opb;   // LDS: NL limbs each, stride T
   // the block's LDS after the lookup table (if any): accumulators, then the operands
   __device__ static FieldRow make(uint32_t* out, size_t height, size_t row, const LookupSink& sink, bool count, const CurveField<NL>& f, uint32_t* lds) {
     int32_t* van = (int32_t*)lds + threadIdx.x;
     uint32_t* opa = lds + (size_t)T * (2 * N - 1) + threadIdx.x;
-    return FieldRow{out, height, row, sink, count, f, van, opa, opa + (size_t)T * NL};
+    return FieldRow{{out, height, row, sink, count}, f, van, opa, opa + (size_t)T * NL};
   }
-  __device__ __forceinline__ void put(int col, uint32_t canonical) const { out[(size_t)col * height + row] = kb::to_monty(canonical); }
   __device__ __forceinline__ int32_t& V(int k) const { return van[(size_t)k * T]; }
   __device__ __forceinline__ int32_t A(int i) const { return (int32_t)((opa[(size_t)(i >> 2) * T] >> (8 * (i & 3))) & 0xff); }
   __device__ __forceinline__ int32_t B(int i) const { return (int32_t)((opb[(size_t)(i >> 2) * T] >> (8 * (i & 3))) & 0xff); }
@@ -1812,7 +1836,6 @@ template <int NL> struct FieldRow {
     if (count && at >= 0) lookup(sink, B_LTU, a, b);
   }
   __device__ void lt(int base, const uint32_t* lhs) const { lt(base, lhs, f.m.p); }      // against the modulus
-  __device__ void zeros(int base, int n) const { for (int i = 0; i < n; i++) put(base + i, 0u); }
   // FieldInnerProductCols::populate (operations/field/field_inner_product.rs:27-79) of (a0, a1) . (b0, 1): a0 b0 + a1 = result + carry p
   __device__ void inner_with_one(int base, const uint32_t* a0, const uint32_t* b0, const uint32_t* a1, uint32_t* res) const {
     uint32_t t[2 * NL], t2[2 * NL], q[NL + 1];
@@ -1822,25 +1845,6 @@ template <int NL> struct FieldRow {
     bigfield::divmod<NL>(t, f.m, q, res);
     clear(); mac(a0, b0); add(a1, 1); add(res, -1);
     gadget(base, res, q);
-  }
-  // the memory columns of a W-word write slice (6-word records) and read slice (5-word records); zero for a padding row
-  __device__ void write_cols(int base, const uint32_t* rec) const {
-    uint32_t mw[13];
-    for (int c = 0; c < 13; c++) mw[c] = 0;
-    if (rec) {
-      memory_write_cols(rec, mw);
-      if (count) { lookup(sink, B_U16RANGE, mw[11] >> 8, mw[11]); lookup(sink, B_U8RANGE, 0, mw[12]); }
-    }
-    for (int c = 0; c < 13; c++) put(base + c, mw[c]);
-  }
-  __device__ void read_cols(int base, const uint32_t* rec) const {
-    uint32_t mr[9];
-    for (int c = 0; c < 9; c++) mr[c] = 0;
-    if (rec) {
-      memory_access_cols(rec[0], rec[1], rec[2], rec[3], rec[4], mr);
-      if (count) access_lookups(mr, sink);
-    }
-    for (int c = 0; c < 9; c++) put(base + c, mr[c]);
   }
 };
 // every big-field kernel starts and ends the same way: the block's lookup table in LDS, flushed into the global counters at the end
@@ -1863,7 +1867,7 @@ struct BfBlock {
 };
 
 // The U8Range lookups of adjacent byte columns, counted from the trace: for every real row and every pair of columns (start + 2 j,
-// start + 2 j + 1) of the given segments, one lookup (U8Range, b, c). A block takes a slab of rows and a quarter of the key space (the
+// start + 2 j + 1) of the given segments (a segment's odd last column pairs with zero), one lookup (U8Range, b, c). A block takes a slab of rows and a quarter of the key space (the
 // top two bits of b), reads the slab's byte columns (coalesced along the rows; the other three quarters' blocks read them again, out of
 // the memory-side cache) and counts in a dense LDS histogram of 16384 counters — no probing, no overflow. It leaves its counters in its
 // own part of `partial` [slab][key]; u8_pair_reduce adds the slabs up into the lookup counters. Rows per slab: a power of two >= 256.
@@ -1879,13 +1883,14 @@ __global__ __launch_bounds__(U8H_THREADS) void u8_pair_histogram(const uint32_t*
   const uint32_t slab_rows = 1u << log_slab_rows;
   for (int sg = 0; sg < seg.n; sg++) {
     const uint32_t* base = trace + (size_t)seg.start[sg] * height + row0;
-    const uint32_t items = (uint32_t)(seg.cols[sg] / 2) << log_slab_rows;      // (pair, row) with the row fastest: a wavefront shares the pair
+    const uint32_t items = (uint32_t)((seg.cols[sg] + 1) / 2) << log_slab_rows;      // (pair, row) with the row fastest: a wavefront shares the pair
 #pragma unroll 4
     for (uint32_t idx = threadIdx.x; idx < items; idx += U8H_THREADS) {
       const uint32_t pair = idx >> log_slab_rows, r = idx & (slab_rows - 1);
       if (row0 + r < n_real) {
         const uint32_t* at = base + (size_t)(2 * pair) * height + r;
-        const uint32_t b = kb::from_monty(at[0]), c = kb::from_monty(at[height]);
+        const bool alone = 2 * pair + 1 >= (uint32_t)seg.cols[sg];      // the last column of an odd segment is checked with a zero (ByteRecord::add_u8_range_checks)
+        const uint32_t b = kb::from_monty(at[0]), c = alone ? 0u : kb::from_monty(at[height]);
         if ((b >> 6) == range) atomicAdd(&hist[(b & 0x3f) << 8 | (c & 0xff)], 1u);
       }
     }
@@ -2224,6 +2229,102 @@ __global__ __launch_bounds__(bf_threads(NL)) void weierstrass_decompress_rows(co
       } else {
         R.zeros(CHOICE, 2 * (N + 2) + 3);
       }
+    }
+    if (real && why) atomicMax(bad, 16 - why);
+  }
+  blk.flush(counts);
+}
+
+// ---- Uint256MulMod (syscall/precompiles/uint256/air.rs:57-91, :104-203): x <- x * y mod m, m = 0 standing for 2^256; 480 columns, one FieldOpCols over
+// U256Field (63 witness limbs: the modulus polynomial may have 33). The modulus changes from row to row, so the quotient comes from a
+// binary long division (512 shift-compare-subtract steps) instead of Barrett. The vanishing polynomial x(t) y(t) - result(t) - carry(t) m(t)
+// is produced one coefficient at a time from the top, which is the order the witness recurrence consumes them; the five operands' limbs
+// are staged in LDS ([word][thread]). Error codes: 1 the quotient does not fit 256 bits, 2 the words written to x are not the result.
+constexpr int UINT256_MUL_WIDTH = 480, UINT256_MUL_EVENT_WORDS = 132, U256_THREADS = 256, U256_LDS_WORDS = 40;
+__host__ __device__ constexpr size_t uint256_lds_bytes(bool count) { return (count ? 2 * (size_t)BF_HASH_SLOTS * 4 : 0) + (size_t)U256_THREADS * U256_LDS_WORDS * 4; }
+__global__ __launch_bounds__(U256_THREADS) void uint256_mul_rows(const uint32_t* __restrict__ events, size_t n_events, size_t height, uint32_t* __restrict__ out,
+                                                                 uint32_t* counts, int* __restrict__ bad) {
+  enum { SHARD = 0, CLK = 1, X_PTR = 2, Y_PTR = 3, X_MEM = 4, Y_MEM = 108, M_MEM = 180, IS_ZERO = 252, NOT_ZERO = 254, OUTPUT = 255, RANGE = 445, IS_REAL = 479,
+         N = 32, NW = 63, T = U256_THREADS };
+  enum { E_X = 4, E_Y = 4 + 48, E_M = 4 + 48 + 40 };
+  extern __shared__ uint32_t bf_lds[];
+  const BfBlock blk(bf_lds, counts);
+  const size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (row < height) {
+    const bool real = row < n_events;
+    const uint32_t* e = events + row * UINT256_MUL_EVENT_WORDS;
+    const LookupSink sink{blk.hkeys, blk.hvals, BF_HASH_SLOTS - 1, counts};
+    const RowCols R{out, height, row, sink, blk.count && real};
+    uint32_t* lds = blk.scratch + threadIdx.x;      // five operands of eight words, stride T
+    auto byte = [&](int operand, int i) { return (int32_t)((lds[(size_t)(8 * operand + (i >> 2)) * T] >> (8 * (i & 3))) & 0xff); };
+    enum { OX = 0, OY = 1, OQ = 2, OM = 3, OR = 4 };
+    uint32_t x[8], y[8], m[8], t[16], q[16], rem[9];
+    bool no_modulus = true;
+    uint32_t byte_sum = 0;
+    for (int k = 0; k < 8; k++) {
+      x[k] = real ? e[E_X + 6 * k + 3] : 0u;
+      y[k] = real ? e[E_Y + 5 * k] : 0u;
+      m[k] = real ? e[E_M + 5 * k] : 0u;
+      no_modulus = no_modulus && m[k] == 0;
+      byte_sum += (m[k] & 0xff) + ((m[k] >> 8) & 0xff) + ((m[k] >> 16) & 0xff) + (m[k] >> 24);
+    }
+    bigfield::mul<8, 8>(x, y, t);
+    int why = 0;
+    if (no_modulus) {        // modulo 2^256: the low half, carry the high half
+      for (int k = 0; k < 8; k++) { rem[k] = t[k]; q[k] = t[8 + k]; q[8 + k] = 0; }
+    } else {
+      for (int k = 0; k < 9; k++) rem[k] = 0;
+#pragma unroll
+      for (int l = 15; l >= 0; l--) {
+        uint32_t w = t[l], qw = 0;
+        for (int b = 0; b < 32; b++) {
+          for (int k = 8; k > 0; k--) rem[k] = rem[k] << 1 | rem[k - 1] >> 31;
+          rem[0] = rem[0] << 1 | w >> 31;
+          w <<= 1;
+          const bool ge = rem[8] != 0 || bigfield::cmp<8>(rem, m) >= 0;
+          if (ge) { const uint32_t borrow = bigfield::sub<8>(rem, m); rem[8] -= borrow; }
+          qw = qw << 1 | (ge ? 1u : 0u);
+        }
+        q[l] = qw;
+      }
+      for (int k = 8; k < 16; k++) if (q[k]) why = 1;
+    }
+    for (int k = 0; k < 8; k++) {
+      lds[(size_t)(8 * OX + k) * T] = x[k]; lds[(size_t)(8 * OY + k) * T] = y[k]; lds[(size_t)(8 * OQ + k) * T] = q[k];
+      lds[(size_t)(8 * OM + k) * T] = m[k]; lds[(size_t)(8 * OR + k) * T] = rem[k];
+    }
+    // the witness, from the top coefficient down: w[k - 1] = van[k] + 256 w[k] (operations/field/util.rs:21-66), shifted by 2^14
+    int32_t above = 0;
+    for (int k = NW; k >= 1; k--) {
+      int32_t van = k < N ? -byte(OR, k) : 0;
+      for (int i = k < N ? 0 : k - N + 1; i <= (k < N ? k : N - 1); i++) van += byte(OX, i) * byte(OY, k - i) - byte(OQ, i) * byte(OM, k - i);
+      if (no_modulus && real && k >= N) van -= byte(OQ, k - N);      // the modulus polynomial is t^32
+      above = van + 256 * above;
+      const uint32_t shifted = (uint32_t)(above + (1 << 14));
+      R.put(OUTPUT + 2 * N + k - 1, shifted & 0xff);
+      R.put(OUTPUT + 2 * N + NW + k - 1, shifted >> 8);
+    }
+    for (int i = 0; i < N; i++) { R.put(OUTPUT + i, (uint32_t)byte(OR, i)); R.put(OUTPUT + N + i, (uint32_t)byte(OQ, i)); }
+    // IsZeroOperation of the sum of the modulus' bytes, modulus_is_not_zero, the range check of the result against the modulus
+    R.put(IS_ZERO, real ? small_inverse(byte_sum) : 0u); R.put(IS_ZERO + 1, real && no_modulus ? 1u : 0u);
+    R.put(NOT_ZERO, real && !no_modulus ? 1u : 0u);
+    {
+      int at = -1;
+      if (real && !no_modulus)
+        for (int i = N - 1; i >= 0 && at < 0; i--)
+          if (byte(OR, i) < byte(OM, i)) at = i;      // the remainder is below the modulus: the first difference from the top decides
+      for (int i = 0; i < N; i++) R.put(RANGE + i, i == at ? 1u : 0u);
+      const uint32_t a = at >= 0 ? (uint32_t)byte(OR, at) : 0u, b = at >= 0 ? (uint32_t)byte(OM, at) : 0u;
+      R.put(RANGE + N, a); R.put(RANGE + N + 1, b);
+      if (R.count && at >= 0) lookup(sink, B_LTU, a, b);
+    }
+    R.put(IS_REAL, real ? 1u : 0u);
+    R.put(SHARD, real ? e[0] : 0u); R.put(CLK, real ? e[1] : 0u); R.put(X_PTR, real ? e[2] : 0u); R.put(Y_PTR, real ? e[3] : 0u);
+    for (int k = 0; k < 8; k++) {
+      R.write_cols(X_MEM + 13 * k, real ? e + E_X + 6 * k : nullptr);
+      R.read_cols(Y_MEM + 9 * k, real ? e + E_Y + 5 * k : nullptr);
+      R.read_cols(M_MEM + 9 * k, real ? e + E_M + 5 * k : nullptr);
+      if (real && e[E_X + 6 * k] != rem[k]) why = why ? why : 2;
     }
     if (real && why) atomicMax(bad, 16 - why);
   }

@@ -785,6 +785,20 @@ def weierstrass_decompress(curve, x, sign_bit):
     return r if (r & 1) == sign_bit else P - r
 
 
+# Uint256MulMod (syscall/precompiles/uint256/air.rs): x <- x * y mod m for 256-bit integers, m = 0 meaning 2^256. The syscall reads y and, right
+# after it, the modulus at clk and writes x at clk + 1 (syscalls/precompiles/uint256.rs:14-97); Uint256MulEvent (events/precompiles/uint256.rs:12-35)
+# flattened: x is the previous values of the x write records, y and the modulus the values of their read records.
+SYS_UINT256_MUL = 0x0101001D
+UINT256_MUL_EVENT = np.dtype([("shard", "<u4"), ("clk", "<u4"), ("x_ptr", "<u4"), ("y_ptr", "<u4"), ("x_memory_records", MEMORY_WRITE_RECORD, (8,)),
+                              ("y_memory_records", MEMORY_READ_RECORD, (8,)), ("modulus_memory_records", MEMORY_READ_RECORD, (8,))])
+assert UINT256_MUL_EVENT.itemsize == 4 * 132
+UINT256_MUL_WIDTH = 480      # Uint256MulCols (uint256/air.rs:57-91): 4 + 8 * 13 + 2 * 8 * 9 + IsZero 2 + 1 + FieldOpCols<U256Field> (32 + 32 + 63 + 63) + FieldLtCols 34 + 1
+
+
+def uint256_mulmod(x, y, modulus):
+    return x * y % (modulus if modulus else 1 << 256)
+
+
 # The field-tower precompiles (syscall/precompiles/fptower/fp.rs, fp2_addsub.rs, fp2_mul.rs) over the base fields of Bn254 and Bls12381: FpOpEvent,
 # Fp2AddSubEvent, Fp2MulEvent (events/precompiles/fptower.rs:23-94) flattened; `op` is FieldOperation as a word (Add 0, Mul 1, Sub 2).
 FP_TOWER_CODES = {"Bn254": dict(fp_add=0x01010026, fp_sub=0x01010027, fp_mul=0x01010028, fp2_add=0x01010029, fp2_sub=0x0101002A, fp2_mul=0x0101002B),
