@@ -514,6 +514,18 @@ typedef struct {
 int zkm_tracegen_uint256_mul(zkm_ctx* ctx, const zkm_uint256_mul_event* events, size_t n_events, int fixed_log2_rows, zkm_byte_lookups* blu,
                              zkm_matrix** out);
 
+/* U256XU2048Mul (crates/core/machine/src/syscall/precompiles/u256x2048_mul/air.rs): replaces generate_trace (:101-229), byte lookups into `blu`. An
+ * event is U256xU2048MulEvent (crates/core/executor/src/events/precompiles/u256x2048_mul.rs:9-44) flattened: a and b are the values of their read
+ * records (read at clk), lo_ptr / hi_ptr the values of the reads of registers $a2 / $a3, lo (the low 2048 bits of a * b) and hi (the high 256)
+ * the values of their write records (written at clk + 1). Fails when the words written are not the product or the pointers do not match. */
+typedef struct {
+  uint32_t shard, clk, a_ptr, b_ptr, lo_ptr, hi_ptr;
+  zkm_memory_read_record lo_ptr_memory, hi_ptr_memory, a_memory_records[8], b_memory_records[64];
+  zkm_memory_write_record lo_memory_records[64], hi_memory_records[8];
+} zkm_u256x2048_mul_event;
+int zkm_tracegen_u256x2048_mul(zkm_ctx* ctx, const zkm_u256x2048_mul_event* events, size_t n_events, int fixed_log2_rows, zkm_byte_lookups* blu,
+                               zkm_matrix** out);
+
 /* The field-tower precompiles (crates/core/machine/src/syscall/precompiles/fptower/fp.rs, fp2_addsub.rs, fp2_mul.rs): Bn254 / Bls12381 x FpOpAssign,
  * Fp2AddSubAssign, Fp2MulAssign; replace their generate_trace, byte lookups into `blu`. `field` is ZKM_CURVE_BN254 or ZKM_CURVE_BLS12381. Events:
  * FpOpEvent / Fp2AddSubEvent / Fp2MulEvent (crates/core/executor/src/events/precompiles/fptower.rs:23-94) flattened — shard, clk, x_ptr, y_ptr,

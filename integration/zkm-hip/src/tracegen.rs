@@ -32,7 +32,7 @@ pub(crate) const DEVICE_BUILT: &[&str] = &[
     "KeccakSponge", "ShaExtend", "ShaCompress", "EdAddAssign", "EdDecompress", "Secp256k1AddAssign", "Secp256k1DoubleAssign", "Secp256r1AddAssign",
     "Secp256r1DoubleAssign", "Bn254AddAssign", "Bn254DoubleAssign", "Bls12381AddAssign", "Bls12381DoubleAssign", "Bn254FpOpAssign", "Bn254Fp2AddSubAssign",
     "Bn254Fp2MulAssign", "Bls12381FpOpAssign", "Bls12831Fp2AddSubAssign", "Bls12831Fp2MulAssign", "Secp256k1Decompress", "Secp256r1Decompress",
-    "Bls12381Decompress", "Uint256MulMod",
+    "Bls12381Decompress", "Uint256MulMod", "U256XU2048Mul",
 ];
 
 /// ZKM_CURVE_* of include/zkm_hip.h
@@ -232,6 +232,22 @@ pub(crate) fn device_trace(
                 })
                 .collect();
             check(unsafe { ffi::zkm_tracegen_uint256_mul(ctx, ev.as_ptr(), ev.len(), fixed, blu, &mut m) })?
+        }
+        "U256XU2048Mul" => {
+            let ev: Vec<ffi::ZkmU256x2048MulEvent> = precompile(r, SyscallCode::U256XU2048_MUL)
+                .map(|e| match e {
+                    PrecompileEvent::U256xU2048Mul(e) => ffi::ZkmU256x2048MulEvent {
+                        shard: e.shard, clk: e.clk, a_ptr: e.a_ptr, b_ptr: e.b_ptr, lo_ptr: e.lo_ptr, hi_ptr: e.hi_ptr,
+                        lo_ptr_memory: rd(&e.lo_ptr_memory), hi_ptr_memory: rd(&e.hi_ptr_memory),
+                        a_memory_records: core::array::from_fn(|i| rd(&e.a_memory_records[i])),
+                        b_memory_records: core::array::from_fn(|i| rd(&e.b_memory_records[i])),
+                        lo_memory_records: core::array::from_fn(|i| wr(&e.lo_memory_records[i])),
+                        hi_memory_records: core::array::from_fn(|i| wr(&e.hi_memory_records[i])),
+                    },
+                    _ => unreachable!(),
+                })
+                .collect();
+            check(unsafe { ffi::zkm_tracegen_u256x2048_mul(ctx, ev.as_ptr(), ev.len(), fixed, blu, &mut m) })?
         }
         "Secp256k1Decompress" => curve_events!(SECP256K1_DECOMPRESS, Secp256k1Decompress, zkm_tracegen_weierstrass_decompress, SECP256K1, dec),
         "Secp256r1Decompress" => curve_events!(SECP256R1_DECOMPRESS, Secp256r1Decompress, zkm_tracegen_weierstrass_decompress, SECP256R1, dec),

@@ -2207,6 +2207,63 @@ static inline std::vector<F> generate_uint256_mul(const Uint256MulEvent* events,
   return t;
 }
 
+// ---- U256XU2048Mul (syscall/precompiles/u256x2048_mul/air.rs:52-87, :101-229): a (256 bits) times b (2048 bits); eight FieldOpCols over U256Field chained
+// through their carries (populate_mul_and_carry, field_op.rs:47-95): a * b_i + carry_{i-1} = result_i + carry_i 2^256. Columns: shard, clk, a_ptr,
+// b_ptr, lo_ptr, hi_ptr, the reads of registers $a2 / $a3 (lo_ptr_memory, hi_ptr_memory), 8 + 64 MemoryReadCols of a, b, 64 + 8 MemoryWriteCols
+// of lo, hi, the eight gadgets, is_real: 3129. Padding rows: products of zeros.
+struct U256x2048MulEvent {
+  uint32_t shard, clk, a_ptr, b_ptr, lo_ptr, hi_ptr;
+  MemoryReadRecord lo_ptr_memory, hi_ptr_memory, a_memory_records[8], b_memory_records[64];
+  MemoryWriteRecord lo_memory_records[64], hi_memory_records[8];
+};
+static_assert(sizeof(U256x2048MulEvent) == 4 * 808, "flattened U256xU2048MulEvent is 808 words");
+static const size_t U256X2048_MUL_WIDTH = 3129;
+static inline std::vector<F> generate_u256x2048_mul(const U256x2048MulEvent* events, size_t n_events, int fixed_log2_rows, size_t* height, uint64_t* byte_counts) {
+  using namespace bigfield;
+  enum { SHARD = 0, CLK = 1, A_PTR = 2, B_PTR = 3, LO_PTR = 4, HI_PTR = 5, LO_PTR_MEM = 6, HI_PTR_MEM = 15, A_MEM = 24, B_MEM = 96, LO_MEM = 672, HI_MEM = 1504,
+         GADGETS = 1608, IS_REAL = 3128, N = 32, NW = 63, G = 190 };
+  const size_t h = padded_rows(n_events, fixed_log2_rows);
+  std::vector<F> t(h * U256X2048_MUL_WIDTH, 0);
+  std::vector<ByteLookup> lk;
+  Big two_256(33, 0);
+  two_256[32] = 1;
+  auto gadgets = [&](F* r, const Big& a, const uint32_t* b_words, std::vector<ByteLookup>* sink) {
+    Big carry;
+    for (int g = 0; g < 8; g++) {
+      const Big b = b_words ? from_words(b_words + 8 * g, 8) : Big();
+      Big q, res;
+      divmod(add(bigfield::mul(a, b), carry), two_256, q, res);
+      field_gadget_cols(r + GADGETS + G * g, padd(padd(pmul(poly(a, N), poly(b, N)), poly(carry, N)), poly(res, N), -1), res, q, two_256, N, 1 << 14, sink, NW);
+      carry = q;
+    }
+  };
+  std::vector<F> padding(U256X2048_MUL_WIDTH, 0);
+  gadgets(padding.data(), Big(), nullptr, nullptr);
+  auto read = [&](const MemoryReadRecord& m, F* r) { memory_access_cols(m.value, m.shard, m.timestamp, m.prev_shard, m.prev_timestamp, r, &lk); };
+  for (size_t i = 0; i < h; i++) {
+    F* r = t.data() + i * U256X2048_MUL_WIDTH;
+    if (i >= n_events) { std::copy(padding.begin(), padding.end(), r); continue; }
+    const U256x2048MulEvent& e = events[i];
+    r[IS_REAL] = 1; r[SHARD] = fu32(e.shard); r[CLK] = fu32(e.clk); r[A_PTR] = fu32(e.a_ptr); r[B_PTR] = fu32(e.b_ptr); r[LO_PTR] = fu32(e.lo_ptr); r[HI_PTR] = fu32(e.hi_ptr);
+    if (e.lo_ptr_memory.value != e.lo_ptr || e.hi_ptr_memory.value != e.hi_ptr) throw std::runtime_error("tracegen: U256x2048Mul: lo_ptr / hi_ptr are not what the registers hold");
+    read(e.lo_ptr_memory, r + LO_PTR_MEM); read(e.hi_ptr_memory, r + HI_PTR_MEM);
+    uint32_t aw[8], bw[64];
+    for (int k = 0; k < 8; k++) { read(e.a_memory_records[k], r + A_MEM + 9 * k); aw[k] = e.a_memory_records[k].value; }
+    for (int k = 0; k < 64; k++) { read(e.b_memory_records[k], r + B_MEM + 9 * k); bw[k] = e.b_memory_records[k].value; }
+    for (int k = 0; k < 64; k++) memory_write_cols(e.lo_memory_records[k], r + LO_MEM + 13 * k, &lk);
+    for (int k = 0; k < 8; k++) memory_write_cols(e.hi_memory_records[k], r + HI_MEM + 13 * k, &lk);
+    gadgets(r, from_words(aw, 8), bw, &lk);
+    for (int k = 0; k < 256; k++)
+      if (r[LO_MEM + 13 * (k / 4) + 4 + k % 4] != r[GADGETS + G * (k / 32) + k % 32]) throw std::runtime_error("tracegen: U256x2048Mul event does not write the product");
+    for (int k = 0; k < 32; k++)
+      if (r[HI_MEM + 13 * (k / 4) + 4 + k % 4] != r[GADGETS + G * 7 + N + k]) throw std::runtime_error("tracegen: U256x2048Mul event does not write the product");
+  }
+  if (byte_counts)
+    for (const ByteLookup& bl : lk) byte_counts[((size_t)bl.b * 256 + bl.c) * NUM_BYTE_OPS + bl.op]++;
+  *height = h;
+  return t;
+}
+
 // ---- Field-tower precompiles (syscall/precompiles/fptower/): FpOp (kind 0: one FieldOpCols, the operation chosen per event), Fp2AddSub (kind 1: two,
 // add or subtract per event), Fp2Mul (kind 2: four products, a difference, a sum) over the base field of Bn254 or Bls12381. Events: shard, clk,
 // x_ptr, y_ptr, [op — FieldOperation as a word: Add 0, Mul 1, Sub 2 —] W write records of x, W read records of y (W = N / 4 for FpOp, N / 2 for

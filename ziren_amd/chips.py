@@ -2399,6 +2399,65 @@ def record_uint256_mul_chip(log_height: int) -> RecordedChip:
     return _finish(record_uint256_mul_constraints(), "Uint256MulMod", log_height, E.UINT256_MUL_WIDTH, True)
 
 
+def _u256x2048_mul(r: _Rec):
+    """U256x2048MulChip::eval (syscall/precompiles/u256x2048_mul/air.rs:250-398): eight FieldOpCols over U256Field with the modulus t^32, chained
+    through their carries — a * b_i + carry_{i-1} = result_i + carry_i 2^256 — so that the results are the low 2048 bits and the last carry the
+    high 256. lo_ptr and hi_ptr are read from registers $a2 and $a3; a and b are read at clk, lo and hi written at clk + 1."""
+    l, b = r.local, r.b
+    N, NW, G = 32, 63, 190
+    SHARD, CLK, A_PTR, B_PTR, LO_PTR, HI_PTR, LO_PTR_MEM, HI_PTR_MEM, A_MEM, B_MEM, LO_MEM, HI_MEM, GADGETS, IS_REAL = 0, 1, 2, 3, 4, 5, 6, 15, 24, 96, 672, 1504, 1608, 3128
+    is_real = l[IS_REAL]
+    reads = lambda base, n: [l[base + 9 * i:base + 9 * i + 9] for i in range(n)]          # noqa: E731
+    writes = lambda base, n: [l[base + 13 * i:base + 13 * i + 13] for i in range(n)]      # noqa: E731
+    lo_ptr_mem, hi_ptr_mem = l[LO_PTR_MEM:LO_PTR_MEM + 9], l[HI_PTR_MEM:HI_PTR_MEM + 9]
+    a_mem, b_mem, lo_mem, hi_mem = reads(A_MEM, 8), reads(B_MEM, 64), writes(LO_MEM, 64), writes(HI_MEM, 8)
+    b.assert_bool(is_real)
+    r.receives.append(air.Lookup([air.to_virtual_pair(v) for v in [l[SHARD], l[CLK], b.const(E.SYS_U256XU2048_MUL & 0xffff), l[A_PTR], l[B_PTR]]],
+                                 air.to_virtual_pair(is_real), air.KIND_SYSCALL))
+    r.eval_memory_access(l[SHARD], l[CLK], b.const(E.REG_A2), lo_ptr_mem[0:4], lo_ptr_mem, is_real)
+    r.eval_memory_access(l[SHARD], l[CLK], b.const(E.REG_A3), hi_ptr_mem[0:4], hi_ptr_mem, is_real)
+    for i in range(8):
+        r.eval_memory_access(l[SHARD], l[CLK], l[A_PTR] + 4 * i, a_mem[i][0:4], a_mem[i], is_real)
+    for i in range(64):
+        r.eval_memory_access(l[SHARD], l[CLK], l[B_PTR] + 4 * i, b_mem[i][0:4], b_mem[i], is_real)
+    for i in range(64):
+        r.eval_memory_access(l[SHARD], l[CLK] + 1, l[LO_PTR] + 4 * i, lo_mem[i][0:4], lo_mem[i][4:13], is_real)
+    for i in range(8):
+        r.eval_memory_access(l[SHARD], l[CLK] + 1, l[HI_PTR] + 4 * i, hi_mem[i][0:4], hi_mem[i][4:13], is_real)
+    a = [v for acc in a_mem for v in acc[0:4]]
+    modulus = [b.const(0)] * N + [b.const(1)]
+    carry = [b.const(0)]
+    for g in range(8):      # FieldOpCols::eval_mul_and_carry (field_op.rs:281-301)
+        cols = l[GADGETS + G * g:GADGETS + G * g + G]
+        b_g = [v for acc in b_mem[8 * g:8 * g + 8] for v in acc[0:4]]
+        op = _poly_add(_poly_mul(a, b_g), carry)
+        van = _poly_sub(b, _poly_sub(b, op, cols[0:N]), _poly_mul(cols[N:2 * N], modulus))
+        _field_gadget(r, van, cols, N, 1 << 14, is_real, NW)
+        carry = cols[N:2 * N]
+    hi_limbs = [v for acc in hi_mem for v in acc[4:8]]
+    for i in range(N):
+        b.when(is_real).assert_eq(carry[i], hi_limbs[i])
+    for g in range(8):
+        lo_limbs = [v for acc in lo_mem[8 * g:8 * g + 8] for v in acc[4:8]]
+        for i in range(N):
+            b.when(is_real).assert_eq(l[GADGETS + G * g + i], lo_limbs[i])
+    reduce = lambda w: w[0] + w[1] * 256 + w[2] * 65536 + w[3] * 16777216      # noqa: E731
+    b.when(is_real).assert_eq(l[LO_PTR], reduce(lo_ptr_mem[0:4]))
+    b.when(is_real).assert_eq(l[HI_PTR], reduce(hi_ptr_mem[0:4]))
+
+
+def record_u256x2048_mul_constraints() -> _Rec:
+    r = _Rec(E.U256X2048_MUL_WIDTH)
+    _u256x2048_mul(r)
+    return r
+
+
+def record_u256x2048_mul_chip(log_height: int) -> RecordedChip:
+    """U256XU2048Mul (crates/core/machine/src/syscall/precompiles/u256x2048_mul/air.rs): one 256 x 2048-bit product per row. The reference does not
+    override local_only for this chip (:231-240), so it is not."""
+    return _finish(record_u256x2048_mul_constraints(), "U256XU2048Mul", log_height, E.U256X2048_MUL_WIDTH, False)
+
+
 def _field_op_variable(r: _Rec, cols, a, bb, modulus, n_limbs, witness_offset, is_add, is_sub, is_mul, is_real):
     """FieldOpCols::eval_variable (operations/field/field_op.rs:227-261) with is_div = 0: the operation is chosen by flags, so the identity
     is the flag-weighted sum of the three."""

@@ -651,8 +651,10 @@ static void count_u8_pairs(zkm_ctx* ctx, const zkm_matrix* m, size_t n_real, con
   const size_t slabs = div_up(n_real, (size_t)1 << log_slab_rows);
   size_t columns = 0;
   for (int k = 0; k < seg.n; k++) {
-    if (seg.cols[k] < 0 || seg.start[k] < 0 || (size_t)(seg.start[k] + seg.cols[k]) > m->w) throw std::runtime_error("count_u8_pairs: bad column segment");
-    columns += seg.cols[k];
+    const int reps = seg.reps[k] > 1 ? seg.reps[k] : 1;
+    if (seg.cols[k] < 0 || seg.start[k] < 0 || seg.stride[k] < 0 || (size_t)(seg.start[k] + (reps - 1) * seg.stride[k] + seg.cols[k]) > m->w)
+      throw std::runtime_error("count_u8_pairs: bad column segment");
+    columns += (size_t)seg.cols[k] * reps;
   }
   uint32_t* partial = ctx->alloc_n<uint32_t>(slabs * 65536);
   try {
@@ -774,7 +776,7 @@ int zkm_tracegen_uint256_mul(zkm_ctx* ctx, const zkm_uint256_mul_event* events, 
     if (n_events) HIP_CHECK(hipMemcpyAsync(d_events, events, ev_bytes, hipMemcpyHostToDevice, ctx->stream));
     uint32_t* counts = blu ? blu->counts : nullptr;
     KLAUNCH(ctx, "tracegen_uint256_mul", (double)ev_bytes + 4.0 * height * m->w, tracegen::uint256_mul_rows, dim3(div_up(height, (size_t)tracegen::U256_THREADS)),
-            dim3(tracegen::U256_THREADS), tracegen::uint256_lds_bytes(counts != nullptr), (const uint32_t*)d_events, n_events, height, m->d, counts, d_bad);
+            dim3(tracegen::U256_THREADS), tracegen::u256_lds_bytes(counts != nullptr), (const uint32_t*)d_events, n_events, height, m->d, counts, d_bad);
     // output: result and carry (32 + 32), witness_low, witness_high (63 each: the last limb is checked alone)
     count_u8_pairs(ctx, m, n_events, tracegen::U8Segments{3, {255, 255 + 64, 255 + 64 + 63}, {64, 63, 63}}, counts);
     int bad = 0;
@@ -783,6 +785,50 @@ int zkm_tracegen_uint256_mul(zkm_ctx* ctx, const zkm_uint256_mul_event* events, 
     ctx->end_timing(false);
     if (bad == 15) throw std::runtime_error("zkm_tracegen_uint256_mul: x * y / modulus does not fit 256 bits (the carry columns hold 32 bytes)");
     if (bad) throw std::runtime_error("zkm_tracegen_uint256_mul: the words an event writes to x are not x * y mod modulus");
+  } catch (...) {
+    if (d_events) ctx->release(d_events);
+    if (d_bad) ctx->release(d_bad);
+    if (m->d) ctx->release(m->d);
+    delete m;
+    throw;
+  }
+  ctx->release(d_events);
+  ctx->release(d_bad);
+  *out = m;
+  API_END
+}
+
+int zkm_tracegen_u256x2048_mul(zkm_ctx* ctx, const zkm_u256x2048_mul_event* events, size_t n_events, int fixed_log2_rows, zkm_byte_lookups* blu, zkm_matrix** out) {
+  API_BEGIN
+  static_assert(sizeof(zkm_u256x2048_mul_event) == 4 * tracegen::U256X2048_MUL_EVENT_WORDS, "flattened U256xU2048MulEvent is 808 words");
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIP_CHECK(hipSetDevice(ctx->device));
+  if (n_events && !events) throw std::runtime_error("zkm_tracegen_u256x2048_mul: null events");
+  const size_t height = padded_trace_rows(n_events, fixed_log2_rows, "zkm_tracegen_u256x2048_mul");
+  ctx->begin_timing();
+  zkm_matrix* m = new zkm_matrix();
+  m->h = height; m->w = tracegen::U256X2048_MUL_WIDTH;
+  uint32_t* d_events = nullptr;
+  int* d_bad = nullptr;
+  try {
+    m->d = ctx->alloc_n<uint32_t>(height * m->w);
+    const size_t ev_bytes = n_events * sizeof(zkm_u256x2048_mul_event);
+    d_events = (uint32_t*)ctx->alloc(std::max<size_t>(ev_bytes, 4));
+    d_bad = (int*)ctx->alloc(4);
+    HIP_CHECK(hipMemsetAsync(d_bad, 0, 4, ctx->stream));
+    if (n_events) HIP_CHECK(hipMemcpyAsync(d_events, events, ev_bytes, hipMemcpyHostToDevice, ctx->stream));
+    uint32_t* counts = blu ? blu->counts : nullptr;
+    KLAUNCH(ctx, "tracegen_u256x2048_mul", (double)ev_bytes + 4.0 * height * m->w, tracegen::u256x2048_mul_rows, dim3(div_up(height, (size_t)tracegen::U256_THREADS)),
+            dim3(tracegen::U256_THREADS), tracegen::u256_lds_bytes(counts != nullptr), (const uint32_t*)d_events, n_events, height, m->d, counts, d_bad);
+    // per gadget: result and carry (32 + 32), witness_low, witness_high (63 each); eight gadgets 190 columns apart
+    const int G = tracegen::U256_GADGET, g0 = 1608;
+    count_u8_pairs(ctx, m, n_events, tracegen::U8Segments{3, {g0, g0 + 64, g0 + 127}, {64, 63, 63}, {8, 8, 8}, {G, G, G}}, counts);
+    int bad = 0;
+    HIP_CHECK(hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, ctx->stream));
+    ctx->mark("trace generation");
+    ctx->end_timing(false);
+    if (bad == 15) throw std::runtime_error("zkm_tracegen_u256x2048_mul: lo_ptr / hi_ptr are not what the register records hold");
+    if (bad) throw std::runtime_error("zkm_tracegen_u256x2048_mul: the words an event writes to lo and hi are not a * b");
   } catch (...) {
     if (d_events) ctx->release(d_events);
     if (d_bad) ctx->release(d_bad);

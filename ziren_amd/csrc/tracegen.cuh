@@ -1871,7 +1871,7 @@ struct BfBlock {
 // top two bits of b), reads the slab's byte columns (coalesced along the rows; the other three quarters' blocks read them again, out of
 // the memory-side cache) and counts in a dense LDS histogram of 16384 counters — no probing, no overflow. It leaves its counters in its
 // own part of `partial` [slab][key]; u8_pair_reduce adds the slabs up into the lookup counters. Rows per slab: a power of two >= 256.
-struct U8Segments { int n; int start[4]; int cols[4]; };
+struct U8Segments { int n; int start[4]; int cols[4]; int reps[4]; int stride[4]; };      // reps = 0 or 1: once; else `reps` copies `stride` columns apart
 constexpr int U8H_RANGES = 4, U8H_KEYS = 65536 / U8H_RANGES, U8H_THREADS = 512, U8H_MAX_SLABS = 64;
 __global__ __launch_bounds__(U8H_THREADS) void u8_pair_histogram(const uint32_t* __restrict__ trace, size_t height, size_t n_real, const U8Segments seg,
                                                                  int log_slab_rows, uint32_t* __restrict__ partial) {
@@ -1883,12 +1883,14 @@ __global__ __launch_bounds__(U8H_THREADS) void u8_pair_histogram(const uint32_t*
   const uint32_t slab_rows = 1u << log_slab_rows;
   for (int sg = 0; sg < seg.n; sg++) {
     const uint32_t* base = trace + (size_t)seg.start[sg] * height + row0;
-    const uint32_t items = (uint32_t)((seg.cols[sg] + 1) / 2) << log_slab_rows;      // (pair, row) with the row fastest: a wavefront shares the pair
+    const uint32_t pairs = (uint32_t)(seg.cols[sg] + 1) / 2, reps = seg.reps[sg] > 1 ? (uint32_t)seg.reps[sg] : 1u;
+    const uint32_t items = (pairs * reps) << log_slab_rows;      // (pair, row) with the row fastest: a wavefront shares the pair
 #pragma unroll 4
     for (uint32_t idx = threadIdx.x; idx < items; idx += U8H_THREADS) {
-      const uint32_t pair = idx >> log_slab_rows, r = idx & (slab_rows - 1);
+      const uint32_t p = idx >> log_slab_rows, r = idx & (slab_rows - 1);
+      const uint32_t rep = p / pairs, pair = p - rep * pairs;      // the same for a whole wavefront
       if (row0 + r < n_real) {
-        const uint32_t* at = base + (size_t)(2 * pair) * height + r;
+        const uint32_t* at = base + ((size_t)rep * seg.stride[sg] + 2 * pair) * height + r;
         const bool alone = 2 * pair + 1 >= (uint32_t)seg.cols[sg];      // the last column of an odd segment is checked with a zero (ByteRecord::add_u8_range_checks)
         const uint32_t b = kb::from_monty(at[0]), c = alone ? 0u : kb::from_monty(at[height]);
         if ((b >> 6) == range) atomicAdd(&hist[(b & 0x3f) << 8 | (c & 0xff)], 1u);
@@ -2235,17 +2237,43 @@ __global__ __launch_bounds__(bf_threads(NL)) void weierstrass_decompress_rows(co
   blk.flush(counts);
 }
 
-// ---- Uint256MulMod (syscall/precompiles/uint256/air.rs:57-91, :104-203): x <- x * y mod m, m = 0 standing for 2^256; 480 columns, one FieldOpCols over
-// U256Field (63 witness limbs: the modulus polynomial may have 33). The modulus changes from row to row, so the quotient comes from a
-// binary long division (512 shift-compare-subtract steps) instead of Barrett. The vanishing polynomial x(t) y(t) - result(t) - carry(t) m(t)
-// is produced one coefficient at a time from the top, which is the order the witness recurrence consumes them; the five operands' limbs
-// are staged in LDS ([word][thread]). Error codes: 1 the quotient does not fit 256 bits, 2 the words written to x are not the result.
-constexpr int UINT256_MUL_WIDTH = 480, UINT256_MUL_EVENT_WORDS = 132, U256_THREADS = 256, U256_LDS_WORDS = 40;
-__host__ __device__ constexpr size_t uint256_lds_bytes(bool count) { return (count ? 2 * (size_t)BF_HASH_SLOTS * 4 : 0) + (size_t)U256_THREADS * U256_LDS_WORDS * 4; }
+// ---- U256Field gadgets: Uint256MulMod and U256XU2048Mul. FieldOpCols over U256Field (curves/src/uint256.rs) has 63 witness limbs, because its
+// modulus polynomial may have 33 (2^256 = t^32). The identity is x(t) y(t) + addend(t) - result(t) - carry(t) m(t), with m either 32 limbs or
+// t^32. Its coefficients are produced one at a time from the top, which is the order the witness recurrence w[k - 1] = van[k] + 256 w[k]
+// (operations/field/util.rs:21-66) consumes them; the six operands' limbs are staged in LDS ([word][thread]).
+constexpr int U256_THREADS = 256, U256_LDS_WORDS = 48, U256_GADGET = 190;
+__host__ __device__ constexpr size_t u256_lds_bytes(bool count) { return (count ? 2 * (size_t)BF_HASH_SLOTS * 4 : 0) + (size_t)U256_THREADS * U256_LDS_WORDS * 4; }
+struct U256Operands {
+  enum { X = 0, Y = 1, CARRY = 2, MODULUS = 3, RESULT = 4, ADDEND = 5, T = U256_THREADS };
+  uint32_t* lds;      // this thread's first word
+  __device__ __forceinline__ int32_t byte(int operand, int i) const { return (int32_t)((lds[(size_t)(8 * operand + (i >> 2)) * T] >> (8 * (i & 3))) & 0xff); }
+  __device__ __forceinline__ void stage(int operand, const uint32_t* v) const {
+#pragma unroll
+    for (int k = 0; k < 8; k++) lds[(size_t)(8 * operand + k) * T] = v[k];
+  }
+  // result(32), carry(32), witness_low(63), witness_high(63) at `base`; their range checks are counted by u8_pair_histogram
+  __device__ void gadget(const RowCols& R, int base, bool modulus_is_t32) const {
+    constexpr int N = 32, NW = 63;
+    int32_t above = 0;
+    for (int k = NW; k >= 1; k--) {
+      int32_t van = k < N ? byte(ADDEND, k) - byte(RESULT, k) : (modulus_is_t32 ? -byte(CARRY, k - N) : 0);
+      for (int i = k < N ? 0 : k - N + 1; i <= (k < N ? k : N - 1); i++) van += byte(X, i) * byte(Y, k - i) - byte(CARRY, i) * byte(MODULUS, k - i);
+      above = van + 256 * above;
+      const uint32_t shifted = (uint32_t)(above + (1 << 14));
+      R.put(base + 2 * N + k - 1, shifted & 0xff);
+      R.put(base + 2 * N + NW + k - 1, shifted >> 8);
+    }
+    for (int i = 0; i < N; i++) { R.put(base + i, (uint32_t)byte(RESULT, i)); R.put(base + N + i, (uint32_t)byte(CARRY, i)); }
+  }
+};
+
+// Uint256MulMod (syscall/precompiles/uint256/air.rs:57-91, :104-203): x <- x * y mod m, m = 0 standing for 2^256; 480 columns. The modulus changes
+// from row to row, so the quotient comes from a binary long division (512 shift-compare-subtract steps) instead of Barrett.
+// Error codes: 1 the quotient does not fit 256 bits, 2 the words written to x are not the result.
+constexpr int UINT256_MUL_WIDTH = 480, UINT256_MUL_EVENT_WORDS = 132;
 __global__ __launch_bounds__(U256_THREADS) void uint256_mul_rows(const uint32_t* __restrict__ events, size_t n_events, size_t height, uint32_t* __restrict__ out,
                                                                  uint32_t* counts, int* __restrict__ bad) {
-  enum { SHARD = 0, CLK = 1, X_PTR = 2, Y_PTR = 3, X_MEM = 4, Y_MEM = 108, M_MEM = 180, IS_ZERO = 252, NOT_ZERO = 254, OUTPUT = 255, RANGE = 445, IS_REAL = 479,
-         N = 32, NW = 63, T = U256_THREADS };
+  enum { SHARD = 0, CLK = 1, X_PTR = 2, Y_PTR = 3, X_MEM = 4, Y_MEM = 108, M_MEM = 180, IS_ZERO = 252, NOT_ZERO = 254, OUTPUT = 255, RANGE = 445, IS_REAL = 479, N = 32 };
   enum { E_X = 4, E_Y = 4 + 48, E_M = 4 + 48 + 40 };
   extern __shared__ uint32_t bf_lds[];
   const BfBlock blk(bf_lds, counts);
@@ -2255,16 +2283,15 @@ __global__ __launch_bounds__(U256_THREADS) void uint256_mul_rows(const uint32_t*
     const uint32_t* e = events + row * UINT256_MUL_EVENT_WORDS;
     const LookupSink sink{blk.hkeys, blk.hvals, BF_HASH_SLOTS - 1, counts};
     const RowCols R{out, height, row, sink, blk.count && real};
-    uint32_t* lds = blk.scratch + threadIdx.x;      // five operands of eight words, stride T
-    auto byte = [&](int operand, int i) { return (int32_t)((lds[(size_t)(8 * operand + (i >> 2)) * T] >> (8 * (i & 3))) & 0xff); };
-    enum { OX = 0, OY = 1, OQ = 2, OM = 3, OR = 4 };
-    uint32_t x[8], y[8], m[8], t[16], q[16], rem[9];
+    const U256Operands ops{blk.scratch + threadIdx.x};
+    uint32_t x[8], y[8], m[8], t[16], q[16], rem[9], zero[8];
     bool no_modulus = true;
     uint32_t byte_sum = 0;
     for (int k = 0; k < 8; k++) {
       x[k] = real ? e[E_X + 6 * k + 3] : 0u;
       y[k] = real ? e[E_Y + 5 * k] : 0u;
       m[k] = real ? e[E_M + 5 * k] : 0u;
+      zero[k] = 0;
       no_modulus = no_modulus && m[k] == 0;
       byte_sum += (m[k] & 0xff) + ((m[k] >> 8) & 0xff) + ((m[k] >> 16) & 0xff) + (m[k] >> 24);
     }
@@ -2289,22 +2316,9 @@ __global__ __launch_bounds__(U256_THREADS) void uint256_mul_rows(const uint32_t*
       }
       for (int k = 8; k < 16; k++) if (q[k]) why = 1;
     }
-    for (int k = 0; k < 8; k++) {
-      lds[(size_t)(8 * OX + k) * T] = x[k]; lds[(size_t)(8 * OY + k) * T] = y[k]; lds[(size_t)(8 * OQ + k) * T] = q[k];
-      lds[(size_t)(8 * OM + k) * T] = m[k]; lds[(size_t)(8 * OR + k) * T] = rem[k];
-    }
-    // the witness, from the top coefficient down: w[k - 1] = van[k] + 256 w[k] (operations/field/util.rs:21-66), shifted by 2^14
-    int32_t above = 0;
-    for (int k = NW; k >= 1; k--) {
-      int32_t van = k < N ? -byte(OR, k) : 0;
-      for (int i = k < N ? 0 : k - N + 1; i <= (k < N ? k : N - 1); i++) van += byte(OX, i) * byte(OY, k - i) - byte(OQ, i) * byte(OM, k - i);
-      if (no_modulus && real && k >= N) van -= byte(OQ, k - N);      // the modulus polynomial is t^32
-      above = van + 256 * above;
-      const uint32_t shifted = (uint32_t)(above + (1 << 14));
-      R.put(OUTPUT + 2 * N + k - 1, shifted & 0xff);
-      R.put(OUTPUT + 2 * N + NW + k - 1, shifted >> 8);
-    }
-    for (int i = 0; i < N; i++) { R.put(OUTPUT + i, (uint32_t)byte(OR, i)); R.put(OUTPUT + N + i, (uint32_t)byte(OQ, i)); }
+    ops.stage(U256Operands::X, x); ops.stage(U256Operands::Y, y); ops.stage(U256Operands::CARRY, q); ops.stage(U256Operands::MODULUS, m);
+    ops.stage(U256Operands::RESULT, rem); ops.stage(U256Operands::ADDEND, zero);
+    ops.gadget(R, OUTPUT, no_modulus);
     // IsZeroOperation of the sum of the modulus' bytes, modulus_is_not_zero, the range check of the result against the modulus
     R.put(IS_ZERO, real ? small_inverse(byte_sum) : 0u); R.put(IS_ZERO + 1, real && no_modulus ? 1u : 0u);
     R.put(NOT_ZERO, real && !no_modulus ? 1u : 0u);
@@ -2312,9 +2326,9 @@ __global__ __launch_bounds__(U256_THREADS) void uint256_mul_rows(const uint32_t*
       int at = -1;
       if (real && !no_modulus)
         for (int i = N - 1; i >= 0 && at < 0; i--)
-          if (byte(OR, i) < byte(OM, i)) at = i;      // the remainder is below the modulus: the first difference from the top decides
+          if (ops.byte(U256Operands::RESULT, i) < ops.byte(U256Operands::MODULUS, i)) at = i;      // the remainder is below the modulus: the first difference from the top decides
       for (int i = 0; i < N; i++) R.put(RANGE + i, i == at ? 1u : 0u);
-      const uint32_t a = at >= 0 ? (uint32_t)byte(OR, at) : 0u, b = at >= 0 ? (uint32_t)byte(OM, at) : 0u;
+      const uint32_t a = at >= 0 ? (uint32_t)ops.byte(U256Operands::RESULT, at) : 0u, b = at >= 0 ? (uint32_t)ops.byte(U256Operands::MODULUS, at) : 0u;
       R.put(RANGE + N, a); R.put(RANGE + N + 1, b);
       if (R.count && at >= 0) lookup(sink, B_LTU, a, b);
     }
@@ -2326,6 +2340,59 @@ __global__ __launch_bounds__(U256_THREADS) void uint256_mul_rows(const uint32_t*
       R.read_cols(M_MEM + 9 * k, real ? e + E_M + 5 * k : nullptr);
       if (real && e[E_X + 6 * k] != rem[k]) why = why ? why : 2;
     }
+    if (real && why) atomicMax(bad, 16 - why);
+  }
+  blk.flush(counts);
+}
+
+// U256XU2048Mul (syscall/precompiles/u256x2048_mul/air.rs:52-87, :101-229): a (256 bits) times b (2048 bits), as eight gadgets chained through their
+// carries — a * b_i + carry_{i-1} = result_i + carry_i 2^256 (the schoolbook product, one 256-bit digit of b at a time): 3129 columns. Event
+// words: shard, clk, a_ptr, b_ptr, lo_ptr, hi_ptr, the read records of $a2 and $a3, 8 + 64 read records of a and b, 64 + 8 write records
+// of lo and hi. Error codes: 1 lo_ptr / hi_ptr are not the registers' values, 2 the words written are not the product.
+constexpr int U256X2048_MUL_WIDTH = 3129, U256X2048_MUL_EVENT_WORDS = 808;
+__global__ __launch_bounds__(U256_THREADS) void u256x2048_mul_rows(const uint32_t* __restrict__ events, size_t n_events, size_t height, uint32_t* __restrict__ out,
+                                                                   uint32_t* counts, int* __restrict__ bad) {
+  enum { SHARD = 0, CLK = 1, A_PTR = 2, B_PTR = 3, LO_PTR = 4, HI_PTR = 5, LO_PTR_MEM = 6, HI_PTR_MEM = 15, A_MEM = 24, B_MEM = 96, LO_MEM = 672, HI_MEM = 1504,
+         GADGETS = 1608, IS_REAL = 3128, G = U256_GADGET };
+  enum { E_LO_PTR = 6, E_HI_PTR = 11, E_A = 16, E_B = 16 + 40, E_LO = 16 + 40 + 320, E_HI = 16 + 40 + 320 + 384 };
+  extern __shared__ uint32_t bf_lds[];
+  const BfBlock blk(bf_lds, counts);
+  const size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (row < height) {
+    const bool real = row < n_events;
+    const uint32_t* e = events + row * U256X2048_MUL_EVENT_WORDS;
+    const LookupSink sink{blk.hkeys, blk.hvals, BF_HASH_SLOTS - 1, counts};
+    const RowCols R{out, height, row, sink, blk.count && real};
+    const U256Operands ops{blk.scratch + threadIdx.x};
+    uint32_t a[8], b[8], carry[8], t[16], zero[8];
+    int why = 0;
+    for (int k = 0; k < 8; k++) { a[k] = real ? e[E_A + 5 * k] : 0u; carry[k] = 0; zero[k] = 0; }
+    ops.stage(U256Operands::X, a); ops.stage(U256Operands::MODULUS, zero);
+    for (int g = 0; g < 8; g++) {
+      for (int k = 0; k < 8; k++) b[k] = real ? e[E_B + 5 * (8 * g + k)] : 0u;
+      bigfield::mul<8, 8>(a, b, t);
+      uint32_t addend[16];
+      for (int k = 0; k < 16; k++) addend[k] = k < 8 ? carry[k] : 0u;
+      bigfield::add<16>(t, addend);                       // a * b_g + carry < 2^512
+      ops.stage(U256Operands::Y, b); ops.stage(U256Operands::ADDEND, carry); ops.stage(U256Operands::RESULT, t); ops.stage(U256Operands::CARRY, t + 8);
+      ops.gadget(R, GADGETS + G * g, true);
+      for (int k = 0; k < 8; k++) {
+        carry[k] = t[8 + k];
+        if (real && e[E_LO + 6 * (8 * g + k)] != t[k]) why = 2;
+      }
+    }
+    for (int k = 0; k < 8; k++)
+      if (real && e[E_HI + 6 * k] != carry[k]) why = 2;
+    if (real && (e[E_LO_PTR] != e[4] || e[E_HI_PTR] != e[5])) why = 1;
+    R.put(IS_REAL, real ? 1u : 0u);
+    R.put(SHARD, real ? e[0] : 0u); R.put(CLK, real ? e[1] : 0u); R.put(A_PTR, real ? e[2] : 0u); R.put(B_PTR, real ? e[3] : 0u);
+    R.put(LO_PTR, real ? e[4] : 0u); R.put(HI_PTR, real ? e[5] : 0u);
+    R.read_cols(LO_PTR_MEM, real ? e + E_LO_PTR : nullptr);
+    R.read_cols(HI_PTR_MEM, real ? e + E_HI_PTR : nullptr);
+    for (int k = 0; k < 8; k++) R.read_cols(A_MEM + 9 * k, real ? e + E_A + 5 * k : nullptr);
+    for (int k = 0; k < 64; k++) R.read_cols(B_MEM + 9 * k, real ? e + E_B + 5 * k : nullptr);
+    for (int k = 0; k < 64; k++) R.write_cols(LO_MEM + 13 * k, real ? e + E_LO + 6 * k : nullptr);
+    for (int k = 0; k < 8; k++) R.write_cols(HI_MEM + 13 * k, real ? e + E_HI + 6 * k : nullptr);
     if (real && why) atomicMax(bad, 16 - why);
   }
   blk.flush(counts);

@@ -109,7 +109,7 @@ int zkm_ctx_create(int device, zkm_ctx** out) {
         (const void*)tracegen::ed_add_rows, (const void*)tracegen::ed_decompress_rows,
         (const void*)tracegen::weierstrass_rows<8, false>, (const void*)tracegen::weierstrass_rows<8, true>,
         (const void*)tracegen::weierstrass_rows<12, false>, (const void*)tracegen::weierstrass_rows<12, true>,
-        (const void*)tracegen::uint256_mul_rows, (const void*)tracegen::weierstrass_decompress_rows<8, false>, (const void*)tracegen::weierstrass_decompress_rows<12, true>,
+        (const void*)tracegen::uint256_mul_rows, (const void*)tracegen::u256x2048_mul_rows, (const void*)tracegen::weierstrass_decompress_rows<8, false>, (const void*)tracegen::weierstrass_decompress_rows<12, true>,
         (const void*)tracegen::fp_tower_rows<8, 0>, (const void*)tracegen::fp_tower_rows<8, 1>, (const void*)tracegen::fp_tower_rows<8, 2>,
         (const void*)tracegen::fp_tower_rows<12, 0>, (const void*)tracegen::fp_tower_rows<12, 1>, (const void*)tracegen::fp_tower_rows<12, 2>};
     for (const void* k : big_field_kernels) HIP_CHECK(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));

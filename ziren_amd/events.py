@@ -799,6 +799,19 @@ def uint256_mulmod(x, y, modulus):
     return x * y % (modulus if modulus else 1 << 256)
 
 
+# U256XU2048Mul (syscall/precompiles/u256x2048_mul/air.rs): a 256-bit a times a 2048-bit b; the low 2048 bits go to the address in $a2, the high 256
+# to the address in $a3. The syscall reads the two registers, a and b at clk and writes lo and hi at clk + 1
+# (syscalls/precompiles/u256x2048_mul.rs:20-93); U256xU2048MulEvent (events/precompiles/u256x2048_mul.rs:9-44) flattened.
+SYS_U256XU2048_MUL = 0x0101002F
+REG_A2, REG_A3 = 6, 7
+U256X2048_MUL_EVENT = np.dtype([("shard", "<u4"), ("clk", "<u4"), ("a_ptr", "<u4"), ("b_ptr", "<u4"), ("lo_ptr", "<u4"), ("hi_ptr", "<u4"),
+                                ("lo_ptr_memory", MEMORY_READ_RECORD), ("hi_ptr_memory", MEMORY_READ_RECORD), ("a_memory_records", MEMORY_READ_RECORD, (8,)),
+                                ("b_memory_records", MEMORY_READ_RECORD, (64,)), ("lo_memory_records", MEMORY_WRITE_RECORD, (64,)),
+                                ("hi_memory_records", MEMORY_WRITE_RECORD, (8,))])
+assert U256X2048_MUL_EVENT.itemsize == 4 * 808
+U256X2048_MUL_WIDTH = 3129   # U256x2048MulCols (u256x2048_mul/air.rs:52-87): 6 + 2 * 9 + 8 * 9 + 64 * 9 + 64 * 13 + 8 * 13 + 8 FieldOpCols<U256Field> (190) + 1
+
+
 # The field-tower precompiles (syscall/precompiles/fptower/fp.rs, fp2_addsub.rs, fp2_mul.rs) over the base fields of Bn254 and Bls12381: FpOpEvent,
 # Fp2AddSubEvent, Fp2MulEvent (events/precompiles/fptower.rs:23-94) flattened; `op` is FieldOperation as a word (Add 0, Mul 1, Sub 2).
 FP_TOWER_CODES = {"Bn254": dict(fp_add=0x01010026, fp_sub=0x01010027, fp_mul=0x01010028, fp2_add=0x01010029, fp2_sub=0x0101002A, fp2_mul=0x0101002B),

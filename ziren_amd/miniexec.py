@@ -95,7 +95,7 @@ class Machine:
 
 def run_machine(n_cycles: int = 0, seed: int = 1, pc_base: int = 0x1000, shard_cycles: int = 1 << 30, program=None, poseidon2_calls: int = 0,
                 memory_chunk: int = 1 << 30, keccak_calls: int = 0, sha_calls: int = 0, ed_calls: int = 0,
-                curve_calls=None, fp_calls=None, decompress_calls=None, uint256_calls: int = 0) -> Machine:
+                curve_calls=None, fp_calls=None, decompress_calls=None, uint256_calls: int = 0, u2048_calls: int = 0) -> Machine:
     """A whole run as the reference's prover sees it (crates/core/machine/src/utils/prove.rs:255-400): CPU shards of at most `shard_cycles`
     cycles (never split between a branch and its delay slot, executor.rs:2352-2356), then one shard with the deferred precompile events
     (ExecutionRecord::split, record.rs:130-218), then the shards that initialise and finalise every touched address
@@ -104,12 +104,12 @@ def run_machine(n_cycles: int = 0, seed: int = 1, pc_base: int = 0x1000, shard_c
     spread over a generated run (each kind is deferred to a precompile shard of its own, record.rs:150-185)."""
     return _execute(n_cycles, seed, 1, pc_base, True, shard_cycles=shard_cycles, given=program, poseidon2_calls=poseidon2_calls, memory_chunk=memory_chunk,
                     machine=True, keccak_calls=keccak_calls, sha_calls=sha_calls, ed_calls=ed_calls, curve_calls=curve_calls, fp_calls=fp_calls, decompress_calls=decompress_calls,
-                    uint256_calls=uint256_calls)
+                    uint256_calls=uint256_calls, u2048_calls=u2048_calls)
 
 
 def _execute(n_cycles: int, seed: int = 1, shard: int = 1, pc_base: int = 0x1000, halt: bool = False, shard_cycles: int = 1 << 30, given=None,
              poseidon2_calls: int = 0, memory_chunk: int = 1 << 30, machine: bool = False, keccak_calls: int = 0, sha_calls: int = 0, ed_calls: int = 0,
-             curve_calls=None, fp_calls=None, decompress_calls=None, uint256_calls: int = 0) -> Machine:
+             curve_calls=None, fp_calls=None, decompress_calls=None, uint256_calls: int = 0, u2048_calls: int = 0) -> Machine:
     """Execute `n_cycles` instructions of a program generated on the way. Returns (program, record, public_values) with
     program: INSTRUCTION array (instructions that were jumped over are `ADD $0, 0, 0` no-ops that never run), record:
     structured event arrays, public_values: dict of the words the Cpu chip checks (start_pc, next_pc, execution_shard).
@@ -176,7 +176,7 @@ def _execute(n_cycles: int, seed: int = 1, shard: int = 1, pc_base: int = 0x1000
     s_at = set(int(x) for x in np.linspace(n_cycles // 5, max(n_cycles - 80, n_cycles // 5), sha_calls)) - p2_at - k_at if sha_calls else set()
     s_seq = 0
     e_at = {n_cycles // 4} - p2_at - k_at - s_at if ed_calls else set()
-    w_at = {n_cycles // 3} - p2_at - k_at - s_at - e_at if curve_calls or decompress_calls or uint256_calls else set()
+    w_at = {n_cycles // 3} - p2_at - k_at - s_at - e_at if curve_calls or decompress_calls or uint256_calls or u2048_calls else set()
     f_at = {n_cycles // 2} - p2_at - k_at - s_at - e_at - w_at if fp_calls else set()
     clk_extra = 0                  # the extra cycles of the shard's syscalls so far (Syscall::num_extra_cycles, executor.rs:1641)
 
@@ -320,6 +320,15 @@ def _execute(n_cycles: int, seed: int = 1, shard: int = 1, pc_base: int = 0x1000
                         queued += [(E.ADD, 30, ((0 if j & 1 else big) >> (32 * i)) & 0xffffffff, 0, 1, 1), (E.SW, 30, 0, y_ptr + 32 + 4 * i, 0, 1)]
                     queued += [(E.ADD, E.REG_V0, E.SYS_UINT256_MUL, 0, 1, 1), (E.ADD, E.REG_A0, x_ptr, 0, 1, 1), (E.ADD, E.REG_A1, y_ptr, 0, 1, 1),
                                (E.SYSCALL, E.REG_V0, E.REG_A0, E.REG_A1, 0, 0)]
+            # `u2048_calls` times U256XU2048_MUL(a_ptr, b_ptr) with $a2 = lo_ptr, $a3 = hi_ptr: a random a (256 bits) and b (2048 bits) each time
+            for j in range(u2048_calls):
+                a_ptr, b_ptr, lo_ptr, hi_ptr = 0x006d0000, 0x006d0100, 0x006d0400, 0x006d0800
+                for ptr, n_words in ((a_ptr, 8), (b_ptr, 64)):
+                    v = int.from_bytes(rng.bytes(4 * n_words), "little")
+                    for i in range(n_words):
+                        queued += [(E.ADD, 30, (v >> (32 * i)) & 0xffffffff, 0, 1, 1), (E.SW, 30, 0, ptr + 4 * i, 0, 1)]
+                queued += [(E.ADD, E.REG_A2, lo_ptr, 0, 1, 1), (E.ADD, E.REG_A3, hi_ptr, 0, 1, 1), (E.ADD, E.REG_V0, E.SYS_U256XU2048_MUL, 0, 1, 1),
+                           (E.ADD, E.REG_A0, a_ptr, 0, 1, 1), (E.ADD, E.REG_A1, b_ptr, 0, 1, 1), (E.SYSCALL, E.REG_V0, E.REG_A0, E.REG_A1, 0, 0)]
             n_cycles += len(queued) - had
             p2_at = set(x + len(queued) - had if x > cyc else x for x in p2_at)
             k_at = set(x + len(queued) - had if x > cyc else x for x in k_at)
@@ -525,7 +534,7 @@ def _execute(n_cycles: int, seed: int = 1, shard: int = 1, pc_base: int = 0x1000
             w_curve = {c[k]: (name, k == "double") for name, c in E.WEIERSTRASS_CURVES.items() for k in ("add", "double")}.get(code)
             fp_call = {c: (field, name) for field, codes in E.FP_TOWER_CODES.items() for name, c in codes.items()}.get(code)
             w_decompress = {d["code"]: name for name, d in E.WEIERSTRASS_DECOMPRESS.items()}.get(code)
-            assert w_curve or fp_call or w_decompress or code == E.SYS_UINT256_MUL or code in (E.SYS_HALT, E.SYS_COMMIT, E.SYS_POSEIDON2_PERMUTE, E.SYS_KECCAK_SPONGE, E.SYS_SHA_EXTEND, E.SYS_SHA_COMPRESS, E.SYS_ED_ADD,
+            assert w_curve or fp_call or w_decompress or code in (E.SYS_UINT256_MUL, E.SYS_U256XU2048_MUL) or code in (E.SYS_HALT, E.SYS_COMMIT, E.SYS_POSEIDON2_PERMUTE, E.SYS_KECCAK_SPONGE, E.SYS_SHA_EXTEND, E.SYS_SHA_COMPRESS, E.SYS_ED_ADD,
                                         E.SYS_ED_DECOMPRESS), code
             touched = {}                               # address -> [initial (shard, timestamp, value), final]: SyscallContext's local map
 
@@ -674,6 +683,21 @@ def _execute(n_cycles: int, seed: int = 1, shard: int = 1, pc_base: int = 0x1000
                 local = [(addr, v[0], v[1]) for addr, v in sorted(touched.items())]
                 precompile.append(("uint256_mul", (pc, next_pc, shard, clk, (0, 0, 0, 0, 0, 0), 0, [0, 0, 0], sid, b, c), [(shard, clk, b, c, xwr, yr, mr)], local))
                 clk_extra += 1
+            if code == E.SYS_U256XU2048_MUL:
+                # U256xU2048MulSyscall::execute (syscalls/precompiles/u256x2048_mul.rs:20-93): $a2 and $a3 (lo_ptr, hi_ptr), a and b are read at clk; the
+                # low 2048 bits of a * b are written at lo_ptr and the high 256 at hi_ptr at clk + 1; one extra cycle
+                assert b % 4 == 0 and c % 4 == 0
+                as_int = lambda ws: sum(w << (32 * i) for i, w in enumerate(ws))      # noqa: E731
+                lo_reg, hi_reg = mem(E.REG_A2, clk), mem(E.REG_A3, clk)
+                ar = [mem(b + 4 * i, clk) for i in range(8)]
+                br = [mem(c + 4 * i, clk) for i in range(64)]
+                prod = as_int([x[0] for x in ar]) * as_int([x[0] for x in br])
+                low = [mem(lo_reg[0] + 4 * i, clk + 1, (prod >> (32 * i)) & 0xffffffff) for i in range(64)]
+                high = [mem(hi_reg[0] + 4 * i, clk + 1, (prod >> (2048 + 32 * i)) & 0xffffffff) for i in range(8)]
+                local = [(addr, v[0], v[1]) for addr, v in sorted(touched.items())]
+                precompile.append(("u256x2048_mul", (pc, next_pc, shard, clk, (0, 0, 0, 0, 0, 0), 0, [0, 0, 0], sid, b, c),
+                                   [(shard, clk, b, c, lo_reg[0], hi_reg[0], lo_reg, hi_reg, ar, br, low, high)], local))
+                clk_extra += 1
             if w_decompress:
                 # create_ec_decompress_event (events/precompiles/ec.rs:181-228): x is read at ptr + N, the y the sign bit ($a1) selects is written at
                 # ptr, both at clk; no extra cycle
@@ -819,7 +843,7 @@ def _execute(n_cycles: int, seed: int = 1, shard: int = 1, pc_base: int = 0x1000
     n_shard = shards[-1].pv["shard"]
     for kind, dt in (("poseidon2", E.POSEIDON2_PERMUTE_EVENT), ("keccak", E.KECCAK_SPONGE_BLOCK), ("sha_extend", E.SHA_EXTEND_EVENT),
                      ("sha_compress", E.SHA_COMPRESS_EVENT), ("ed_add", E.ED_ADD_EVENT),
-                     ("ed_decompress", E.ED_DECOMPRESS_EVENT), ("uint256_mul", E.UINT256_MUL_EVENT)) + tuple(
+                     ("ed_decompress", E.ED_DECOMPRESS_EVENT), ("uint256_mul", E.UINT256_MUL_EVENT), ("u256x2048_mul", E.U256X2048_MUL_EVENT)) + tuple(
             (curve + suffix, E.weierstrass_event_dtypes(curve)[k]) for curve in E.WEIERSTRASS_CURVES for k, suffix in ((0, "_add"), (1, "_double"))) + tuple(
             (curve + "_decompress", E.weierstrass_decompress_event_dtype(curve)) for curve in E.WEIERSTRASS_DECOMPRESS) + tuple(
             (field + "_" + kind, E.fp_tower_event_dtype(field, kind)) for field in E.FP_TOWER_CODES for kind in ("fp", "fp2_addsub", "fp2_mul")):
@@ -837,6 +861,7 @@ def _execute(n_cycles: int, seed: int = 1, shard: int = 1, pc_base: int = 0x1000
         o.ed_add = arr([ev for e in mine for ev in e[2]] if kind == "ed_add" else [], E.ED_ADD_EVENT)
         o.ed_decompress = arr([ev for e in mine for ev in e[2]] if kind == "ed_decompress" else [], E.ED_DECOMPRESS_EVENT)
         o.uint256_mul = arr([ev for e in mine for ev in e[2]] if kind == "uint256_mul" else [], E.UINT256_MUL_EVENT)
+        o.u256x2048_mul = arr([ev for e in mine for ev in e[2]] if kind == "u256x2048_mul" else [], E.U256X2048_MUL_EVENT)
         o.weierstrass = (kind, arr([ev for e in mine for ev in e[2]], dt)) if kind.endswith(("_add", "_double")) and kind.split("_")[0] in E.WEIERSTRASS_CURVES else None
         o.weierstrass_decompress = (kind.split("_")[0], arr([ev for e in mine for ev in e[2]], dt)) if kind.endswith("_decompress") and kind != "ed_decompress" else None
         o.fp_tower = (kind, arr([ev for e in mine for ev in e[2]], dt)) if kind.split("_")[0] in E.FP_TOWER_CODES and "_fp" in kind else None
