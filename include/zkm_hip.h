@@ -526,6 +526,22 @@ typedef struct {
 int zkm_tracegen_u256x2048_mul(zkm_ctx* ctx, const zkm_u256x2048_mul_event* events, size_t n_events, int fixed_log2_rows, zkm_byte_lookups* blu,
                                zkm_matrix** out);
 
+/* BooleanCircuitGarble (crates/core/machine/src/syscall/precompiles/boolean_circuit_garble/): replaces generate_trace + generate_dependencies
+ * (trace.rs:32-98), byte lookups into `blu`. A call takes 1 + num_gates rows; the BooleanCircuitGarbleEvent
+ * (crates/core/executor/src/events/precompiles/boolean_circuit_garble.rs:12-45, Vecs inside) crosses the ABI cut into those rows, in order: a header
+ * row (is_gate 0; reads[0] = num_gates_read_record, reads[1..5] = delta_read_records; input_address = input_addr) and a row per gate
+ * (is_gate 1; reads = the gate's seventeen gates_read_records; input_address = input_addr + 20 + 68 gate_id; pre_check = 1 when every gate
+ * before this one checked; `write` = output_write_record on the last gate's row). Fails when a row does not continue the row before it, a
+ * call is cut short, a gate type is not 0 / 7, or the value written is not the conjunction of the checks. The table is padded like the others
+ * (at least 16 rows unless fixed_log2_rows says otherwise; the reference pads this chip to the next power of two without that floor). */
+typedef struct {
+  uint32_t shard, clk, input_address, output_address, is_gate, gate_id, gates_num, pre_check, delta[4];
+  zkm_memory_read_record reads[17];
+  zkm_memory_write_record write;
+} zkm_garble_row;
+int zkm_tracegen_boolean_circuit_garble(zkm_ctx* ctx, const zkm_garble_row* rows, size_t n_rows, int fixed_log2_rows, zkm_byte_lookups* blu,
+                                        zkm_matrix** out);
+
 /* The field-tower precompiles (crates/core/machine/src/syscall/precompiles/fptower/fp.rs, fp2_addsub.rs, fp2_mul.rs): Bn254 / Bls12381 x FpOpAssign,
  * Fp2AddSubAssign, Fp2MulAssign; replace their generate_trace, byte lookups into `blu`. `field` is ZKM_CURVE_BN254 or ZKM_CURVE_BLS12381. Events:
  * FpOpEvent / Fp2AddSubEvent / Fp2MulEvent (crates/core/executor/src/events/precompiles/fptower.rs:23-94) flattened — shard, clk, x_ptr, y_ptr,

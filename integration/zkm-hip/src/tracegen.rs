@@ -32,7 +32,7 @@ pub(crate) const DEVICE_BUILT: &[&str] = &[
     "KeccakSponge", "ShaExtend", "ShaCompress", "EdAddAssign", "EdDecompress", "Secp256k1AddAssign", "Secp256k1DoubleAssign", "Secp256r1AddAssign",
     "Secp256r1DoubleAssign", "Bn254AddAssign", "Bn254DoubleAssign", "Bls12381AddAssign", "Bls12381DoubleAssign", "Bn254FpOpAssign", "Bn254Fp2AddSubAssign",
     "Bn254Fp2MulAssign", "Bls12381FpOpAssign", "Bls12831Fp2AddSubAssign", "Bls12831Fp2MulAssign", "Secp256k1Decompress", "Secp256r1Decompress",
-    "Bls12381Decompress", "Uint256MulMod", "U256XU2048Mul",
+    "Bls12381Decompress", "Uint256MulMod", "U256XU2048Mul", "BooleanCircuitGarble",
 ];
 
 /// ZKM_CURVE_* of include/zkm_hip.h
@@ -248,6 +248,34 @@ pub(crate) fn device_trace(
                 })
                 .collect();
             check(unsafe { ffi::zkm_tracegen_u256x2048_mul(ctx, ev.as_ptr(), ev.len(), fixed, blu, &mut m) })?
+        }
+        "BooleanCircuitGarble" => {
+            // one record per row: a header row and a row per gate (include/zkm_hip.h, zkm_garble_row)
+            let mut rows: Vec<ffi::ZkmGarbleRow> = Vec::new();
+            let none = ffi::ZkmMemoryReadRecord { value: 0, shard: 0, timestamp: 0, prev_shard: 0, prev_timestamp: 0 };
+            let no_write = ffi::ZkmMemoryWriteRecord { value: 0, shard: 0, timestamp: 0, prev_value: 0, prev_shard: 0, prev_timestamp: 0 };
+            for e in precompile(r, SyscallCode::BOOLEAN_CIRCUIT_GARBLE) {
+                let e = match e { PrecompileEvent::BooleanCircuitGarble(e) => e, _ => unreachable!() };
+                let n = e.num_gates();
+                let mut reads = [none; 17];
+                reads[0] = rd(&e.num_gates_read_record);
+                for i in 0..4 { reads[1 + i] = rd(&e.delta_read_records[i]); }
+                rows.push(ffi::ZkmGarbleRow { shard: e.shard, clk: e.clk, input_address: e.input_addr, output_address: e.output_addr, is_gate: 0, gate_id: 0,
+                                              gates_num: n as u32, pre_check: 0, delta: e.delta, reads, write: no_write });
+                let mut running = true;
+                for g in 0..n {
+                    let info = &e.gates_info[17 * g..17 * g + 17];
+                    let ok = (0..4).all(|i| info[1 + i] ^ info[5 + i] ^ info[9 + i] ^ (if info[0] != 0 { e.delta[i] } else { 0 }) == info[13 + i]);
+                    rows.push(ffi::ZkmGarbleRow {
+                        shard: e.shard, clk: e.clk, input_address: e.input_addr + 20 + 68 * g as u32, output_address: e.output_addr, is_gate: 1, gate_id: g as u32,
+                        gates_num: n as u32, pre_check: running as u32, delta: e.delta,
+                        reads: core::array::from_fn(|i| rd(&e.gates_read_records[17 * g + i])),
+                        write: if g + 1 == n { wr(&e.output_write_record) } else { no_write },
+                    });
+                    running = running && ok;
+                }
+            }
+            check(unsafe { ffi::zkm_tracegen_boolean_circuit_garble(ctx, rows.as_ptr(), rows.len(), fixed, blu, &mut m) })?
         }
         "Secp256k1Decompress" => curve_events!(SECP256K1_DECOMPRESS, Secp256k1Decompress, zkm_tracegen_weierstrass_decompress, SECP256K1, dec),
         "Secp256r1Decompress" => curve_events!(SECP256R1_DECOMPRESS, Secp256r1Decompress, zkm_tracegen_weierstrass_decompress, SECP256R1, dec),

@@ -2264,6 +2264,90 @@ static inline std::vector<F> generate_u256x2048_mul(const U256x2048MulEvent* eve
   return t;
 }
 
+// ---- BooleanCircuitGarble (syscall/precompiles/boolean_circuit_garble/columns.rs:10-35, trace.rs:100-223): a call is a header row (the reads of the
+// gate count and of delta in gates_input_mem[0..5]) and one row per gate (seventeen reads: type, h0, h1, label_b, expected; aux1 = h0 ^ h1,
+// aux2 = aux1 ^ label_b, aux3 = aux2 ^ delta; is_equal_words of aux2 (AND gate, type 0) or aux3 (OR gate, type 7) with the expected words;
+// checks = the conjunctions of those, checks[3] also of all the gates before; the last gate's row holds the write of the result). Input: one
+// GarbleRow per row, cut from the BooleanCircuitGarbleEvent. The reference pads this table to the next power of two with no floor of 16
+// (trace.rs:84-85) when no shape fixes its size; here the floor is 16 as for every other table, and fixed_log2_rows gives any size.
+struct GarbleRow { uint32_t shard, clk, input_address, output_address, is_gate, gate_id, gates_num, pre_check, delta[4]; MemoryReadRecord reads[17]; MemoryWriteRecord write; };
+static_assert(sizeof(GarbleRow) == 4 * 103, "a BooleanCircuitGarble row record is 103 words");
+static const size_t GARBLE_WIDTH = 292;
+static inline bool garble_gate_ok(const GarbleRow& g) {
+  bool ok = true;
+  for (int i = 0; i < 4; i++) {
+    const uint32_t v = g.reads[1 + i].value ^ g.reads[5 + i].value ^ g.reads[9 + i].value ^ (g.reads[0].value ? g.delta[i] : 0u);
+    ok = ok && v == g.reads[13 + i].value;
+  }
+  return ok;
+}
+static inline std::vector<F> generate_boolean_circuit_garble(const GarbleRow* rows, size_t n_rows, int fixed_log2_rows, size_t* height, uint64_t* byte_counts) {
+  enum { SHARD = 0, CLK = 1, IS_REAL = 2, INPUT = 3, OUTPUT = 4, IS_FIRST_ROW = 5, IS_GATE = 6, IS_FIRST_GATE = 7, IS_LAST_GATE = 8, NOT_LAST_GATE = 9, GATE_TYPE = 10,
+         GATE_ID = 12, GATES_NUM = 13, DELTA = 14, MEM = 30, RESULT_MEM = 183, AUX1 = 196, AUX2 = 212, AUX3 = 228, IS_EQ = 244, CHECKS = 288 };
+  const size_t h = padded_rows(n_rows, fixed_log2_rows);
+  std::vector<F> t(h * GARBLE_WIDTH, 0);
+  std::vector<ByteLookup> lk;
+  auto read = [&](const MemoryReadRecord& m, F* r) { memory_access_cols(m.value, m.shard, m.timestamp, m.prev_shard, m.prev_timestamp, r, &lk); };
+  auto xor_word = [&](uint32_t x, uint32_t y, F* r) {      // XorOperation::populate (operations/xor.rs:22-37)
+    for (int k = 0; k < 4; k++) {
+      r[k] = ((x ^ y) >> (8 * k)) & 0xff;
+      lk.push_back(ByteLookup{B_XOR, (uint8_t)(x >> (8 * k)), (uint8_t)(y >> (8 * k))});
+    }
+    return x ^ y;
+  };
+  for (size_t i = 0; i < n_rows; i++) {
+    const GarbleRow& g = rows[i];
+    F* r = t.data() + i * GARBLE_WIDTH;
+    r[SHARD] = fu32(g.shard); r[CLK] = fu32(g.clk); r[IS_REAL] = 1; r[INPUT] = fu32(g.input_address); r[OUTPUT] = fu32(g.output_address);
+    r[GATES_NUM] = fu32(g.gates_num);
+    for (int k = 0; k < 16; k++) r[DELTA + k] = (g.delta[k / 4] >> (8 * (k % 4))) & 0xff;
+    if (!g.is_gate) {
+      if (g.reads[0].value != g.gates_num || g.gates_num == 0) throw std::runtime_error("tracegen: garble: the header row does not read the gate count");
+      for (int k = 0; k < 4; k++)
+        if (g.reads[1 + k].value != g.delta[k]) throw std::runtime_error("tracegen: garble: the header row does not read delta");
+      r[IS_FIRST_ROW] = 1;
+      for (int k = 0; k < 5; k++) read(g.reads[k], r + MEM + 9 * k);
+      continue;
+    }
+    // a gate row continues the row before it
+    if (i == 0) throw std::runtime_error("tracegen: garble: a gate row without a header row");
+    const GarbleRow& prev = rows[i - 1];
+    const bool chained = prev.shard == g.shard && prev.clk == g.clk && prev.gates_num == g.gates_num && prev.output_address == g.output_address &&
+                         std::equal(g.delta, g.delta + 4, prev.delta) &&
+                         (g.gate_id == 0 ? !prev.is_gate && g.input_address == prev.input_address + 20 && g.pre_check == 1
+                                         : prev.is_gate && prev.gate_id + 1 == g.gate_id && g.input_address == prev.input_address + 68 &&
+                                               g.pre_check == (prev.pre_check && garble_gate_ok(prev) ? 1u : 0u));
+    if (!chained || g.gate_id >= g.gates_num) throw std::runtime_error("tracegen: garble: a gate row does not continue the row before it");
+    const uint32_t type = g.reads[0].value;
+    if (type != 0 && type != 7) throw std::runtime_error("tracegen: garble: gate type");
+    const bool last = g.gate_id + 1 == g.gates_num;
+    r[IS_GATE] = 1; r[IS_FIRST_GATE] = g.gate_id == 0; r[IS_LAST_GATE] = last; r[NOT_LAST_GATE] = !last; r[GATE_TYPE + (type ? 1 : 0)] = 1; r[GATE_ID] = fu32(g.gate_id);
+    for (int k = 0; k < 17; k++) read(g.reads[k], r + MEM + 9 * k);
+    uint32_t running = 1, check[4];
+    for (int k = 0; k < 4; k++) {
+      const uint32_t inter1 = xor_word(g.reads[1 + k].value, g.reads[5 + k].value, r + AUX1 + 4 * k);
+      const uint32_t inter2 = xor_word(inter1, g.reads[9 + k].value, r + AUX2 + 4 * k);
+      const uint32_t inter3 = xor_word(inter2, g.delta[k], r + AUX3 + 4 * k);
+      is_equal_word_cols(type ? inter3 : inter2, g.reads[13 + k].value, r + IS_EQ + 11 * k);
+      running = running && (type ? inter3 : inter2) == g.reads[13 + k].value;
+      check[k] = running;
+    }
+    r[CHECKS] = check[1]; r[CHECKS + 1] = check[2]; r[CHECKS + 2] = check[3]; r[CHECKS + 3] = check[3] && g.pre_check;
+    if (last) {
+      if (g.write.value != (check[3] && g.pre_check ? 1u : 0u)) throw std::runtime_error("tracegen: garble: the last gate's row does not write the result");
+      memory_write_cols(g.write, r + RESULT_MEM, &lk);
+    }
+  }
+  if (n_rows && rows[n_rows - 1].is_gate && rows[n_rows - 1].gate_id + 1 != rows[n_rows - 1].gates_num) throw std::runtime_error("tracegen: garble: the last call is cut short");
+  if (n_rows && !rows[n_rows - 1].is_gate) throw std::runtime_error("tracegen: garble: the last call is cut short");
+  for (size_t i = 0; i + 1 < n_rows; i++)
+    if (!rows[i + 1].is_gate && (!rows[i].is_gate || rows[i].gate_id + 1 != rows[i].gates_num)) throw std::runtime_error("tracegen: garble: a call is cut short");
+  if (byte_counts)
+    for (const ByteLookup& bl : lk) byte_counts[((size_t)bl.b * 256 + bl.c) * NUM_BYTE_OPS + bl.op]++;
+  *height = h;
+  return t;
+}
+
 // ---- Field-tower precompiles (syscall/precompiles/fptower/): FpOp (kind 0: one FieldOpCols, the operation chosen per event), Fp2AddSub (kind 1: two,
 // add or subtract per event), Fp2Mul (kind 2: four products, a difference, a sum) over the base field of Bn254 or Bls12381. Events: shard, clk,
 // x_ptr, y_ptr, [op — FieldOperation as a word: Add 0, Mul 1, Sub 2 —] W write records of x, W read records of y (W = N / 4 for FpOp, N / 2 for

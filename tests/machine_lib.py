@@ -78,7 +78,8 @@ class Oracle:
         fn = {"branch": O.tracegen_branch, "memory_instrs": O.tracegen_memory_instrs, "misc_instrs": O.tracegen_misc_instrs, "mul": O.tracegen_mul,
               "divrem": O.tracegen_divrem, "global": O.tracegen_global, "poseidon2_permute": O.tracegen_poseidon2_permute,
               "keccak_sponge": O.tracegen_keccak_sponge, "sha_extend": O.tracegen_sha_extend, "sha_compress": O.tracegen_sha_compress,
-              "ed_add": O.tracegen_ed_add, "ed_decompress": O.tracegen_ed_decompress, "uint256_mul": O.tracegen_uint256_mul, "u256x2048_mul": O.tracegen_u256x2048_mul}
+              "ed_add": O.tracegen_ed_add, "ed_decompress": O.tracegen_ed_decompress, "uint256_mul": O.tracegen_uint256_mul, "u256x2048_mul": O.tracegen_u256x2048_mul,
+              "garble": O.tracegen_boolean_circuit_garble}
         if what in fn:
             return fn[what](a[0], a[1], c)
         if what == "weierstrass":
@@ -120,7 +121,8 @@ class Device:
         fn = {"branch": ctx.tracegen_branch, "memory_instrs": ctx.tracegen_memory_instrs, "misc_instrs": ctx.tracegen_misc_instrs, "mul": ctx.tracegen_mul,
               "divrem": ctx.tracegen_divrem, "global": ctx.tracegen_global, "poseidon2_permute": ctx.tracegen_poseidon2_permute,
               "keccak_sponge": ctx.tracegen_keccak_sponge, "sha_extend": ctx.tracegen_sha_extend, "sha_compress": ctx.tracegen_sha_compress,
-              "ed_add": ctx.tracegen_ed_add, "ed_decompress": ctx.tracegen_ed_decompress, "uint256_mul": ctx.tracegen_uint256_mul, "u256x2048_mul": ctx.tracegen_u256x2048_mul}
+              "ed_add": ctx.tracegen_ed_add, "ed_decompress": ctx.tracegen_ed_decompress, "uint256_mul": ctx.tracegen_uint256_mul, "u256x2048_mul": ctx.tracegen_u256x2048_mul,
+              "garble": ctx.tracegen_boolean_circuit_garble}
         if what in fn:
             return fn[what](a[0], a[1], blu)
         if what == "weierstrass":
@@ -205,6 +207,9 @@ def build_shard(src, machine, k):
         if len(getattr(rec, "u256x2048_mul", ())):
             lh = log2_rows(len(rec.u256x2048_mul))
             add(chips.record_u256x2048_mul_chip(lh), src.trace("u256x2048_mul", rec.u256x2048_mul, lh))
+        if len(getattr(rec, "garble", ())):
+            lh = log2_rows(len(rec.garble))
+            add(chips.record_boolean_circuit_garble_chip(lh), src.trace("garble", rec.garble, lh))
         if rec.weierstrass is not None:
             kind, ev = rec.weierstrass
             curve, double = kind.split("_")[0], kind.endswith("_double")

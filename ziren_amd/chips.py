@@ -2458,6 +2458,84 @@ def record_u256x2048_mul_chip(log_height: int) -> RecordedChip:
     return _finish(record_u256x2048_mul_constraints(), "U256XU2048Mul", log_height, E.U256X2048_MUL_WIDTH, False)
 
 
+def _boolean_circuit_garble(r: _Rec):
+    """BooleanCircuitGarbleChip::eval (syscall/precompiles/boolean_circuit_garble/air.rs:25-231): a call is a header row (the reads of the gate count
+    and of delta) followed by one row per gate (seventeen reads; three chained XorOperations per ciphertext word; IsEqualWordOperations against the
+    expected ciphertext, selected by the gate type; a running conjunction in checks[3]); the last gate's row writes the result. Transcribed as
+    written, including what it leaves open (the running conjunction is not tied to the value written; gates_num and delta are tied to memory
+    on the table's first row only)."""
+    l, n, b = r.local, r.next, r.b
+    (SHARD, CLK, IS_REAL, INPUT, OUTPUT, IS_FIRST_ROW, IS_GATE, IS_FIRST_GATE, IS_LAST_GATE, NOT_LAST_GATE, GATE_TYPE, GATE_ID, GATES_NUM, DELTA, MEM, RESULT_MEM,
+     AUX1, AUX2, AUX3, IS_EQ, CHECKS) = (0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 12, 13, 14, 30, 183, 196, 212, 228, 244, 288)
+    mem = [l[MEM + 9 * i:MEM + 9 * i + 9] for i in range(17)]
+    delta = [l[DELTA + 4 * i:DELTA + 4 * i + 4] for i in range(4)]
+    word = lambda base, i: l[base + 4 * i:base + 4 * i + 4]      # noqa: E731
+    r.receives.append(air.Lookup([air.to_virtual_pair(v) for v in [l[SHARD], l[CLK], b.const(E.SYS_BOOLEAN_CIRCUIT_GARBLE & 0xffff), l[INPUT], l[OUTPUT]]],
+                                 air.to_virtual_pair(l[IS_FIRST_ROW]), air.KIND_SYSCALL))
+    # eval_flags (:50-65)
+    b.assert_bool(l[IS_REAL])
+    b.assert_bool(l[IS_FIRST_GATE])
+    b.assert_bool(l[NOT_LAST_GATE])
+    b.assert_bool(l[IS_GATE])
+    b.assert_zero(l[IS_LAST_GATE] * l[IS_FIRST_GATE])
+    b.when(l[IS_GATE]).assert_one(l[IS_LAST_GATE] + l[NOT_LAST_GATE])
+    b.assert_bool(l[GATE_TYPE])
+    b.assert_bool(l[GATE_TYPE + 1])
+    b.assert_eq(l[GATE_TYPE] + l[GATE_TYPE + 1], l[IS_GATE])
+    b.when(l[IS_REAL]).assert_one(l[IS_FIRST_ROW] + l[IS_GATE])
+    # eval_memory_access (:67-113)
+    r.eval_memory_access(l[SHARD], l[CLK], l[INPUT], mem[0][0:4], mem[0], l[IS_FIRST_ROW])
+    for i in range(4):
+        r.eval_memory_access(l[SHARD], l[CLK], l[INPUT] + (4 + 4 * i), mem[i + 1][0:4], mem[i + 1], l[IS_FIRST_ROW])
+    for i in range(17):
+        r.eval_memory_access(l[SHARD], l[CLK], l[INPUT] + 4 * i, mem[i][0:4], mem[i], l[IS_GATE])
+    res = l[RESULT_MEM:RESULT_MEM + 13]
+    r.eval_memory_access(l[SHARD], l[CLK], l[OUTPUT], res[0:4], res[4:13], l[IS_LAST_GATE])
+    # eval_logic_check (:115-180)
+    for i in range(4):
+        _bitwise_op(r, B_XOR, mem[1 + i][0:4], mem[5 + i][0:4], word(AUX1, i), l[IS_GATE])
+        _bitwise_op(r, B_XOR, word(AUX1, i), mem[9 + i][0:4], word(AUX2, i), l[IS_GATE])
+        _bitwise_op(r, B_XOR, word(AUX2, i), delta[i], word(AUX3, i), l[IS_GATE])
+    for i in range(4):
+        want, cols = mem[13 + i][0:4], l[IS_EQ + 11 * i:IS_EQ + 11 * i + 11]
+        for aux, flag in ((AUX2, l[GATE_TYPE]), (AUX3, l[GATE_TYPE + 1])):
+            b.assert_bool(flag)                                            # IsEqualWordOperation::eval (is_equal_word.rs:31-47)
+            _is_zero_word(b, [word(aux, i)[k] - want[k] for k in range(4)], cols, flag)
+    eq = lambda i: l[IS_EQ + 11 * i + 10]      # noqa: E731
+    b.when(l[IS_GATE]).assert_eq(l[CHECKS], eq(0) * eq(1))
+    b.when(l[IS_GATE]).assert_eq(l[CHECKS + 1], eq(2) * l[CHECKS])
+    b.when(l[IS_GATE]).assert_eq(l[CHECKS + 2], eq(3) * l[CHECKS + 1])
+    b.when(l[NOT_LAST_GATE]).assert_eq(n[CHECKS + 3], l[CHECKS + 3] * n[CHECKS + 2])
+    # eval_transition (:182-230)
+    num_gates = mem[0][0] + mem[0][1] * 256 + mem[0][2] * 65536 + mem[0][3] * 16777216
+    b.when_first_row().assert_eq(l[GATES_NUM], num_gates)
+    for i in range(4):
+        for j in range(4):
+            b.when_first_row().assert_eq(delta[i][j], mem[i + 1][j])
+    gate_type_value = l[GATE_TYPE] * 0 + l[GATE_TYPE + 1]
+    b.when(l[IS_GATE]).assert_eq(gate_type_value * E.GARBLE_OR_GATE, num_gates)
+    b.when(l[IS_FIRST_GATE]).assert_zero(l[GATE_ID])
+    b.when(l[IS_LAST_GATE]).assert_eq(l[GATES_NUM] - 1, l[GATE_ID])
+    b.when(l[NOT_LAST_GATE]).assert_eq(l[GATE_ID] + 1, n[GATE_ID])
+    b.when(l[NOT_LAST_GATE] * l[IS_GATE]).assert_eq(l[INPUT] + 68, n[INPUT])
+    b.when(l[NOT_LAST_GATE] * l[IS_GATE]).assert_eq(l[GATES_NUM], n[GATES_NUM])
+    for i in range(4):
+        for j in range(4):
+            b.when(l[NOT_LAST_GATE] * l[IS_GATE]).assert_eq(delta[i][j], n[DELTA + 4 * i + j])
+
+
+def record_boolean_circuit_garble_constraints() -> _Rec:
+    r = _Rec(E.GARBLE_WIDTH)
+    _boolean_circuit_garble(r)
+    return r
+
+
+def record_boolean_circuit_garble_chip(log_height: int) -> RecordedChip:
+    """BooleanCircuitGarble (crates/core/machine/src/syscall/precompiles/boolean_circuit_garble/): 1 + num_gates rows per call, 292 columns; constraints
+    between consecutive rows, not local_only (the reference does not override it)."""
+    return _finish(record_boolean_circuit_garble_constraints(), "BooleanCircuitGarble", log_height, E.GARBLE_WIDTH, False)
+
+
 def _field_op_variable(r: _Rec, cols, a, bb, modulus, n_limbs, witness_offset, is_add, is_sub, is_mul, is_real):
     """FieldOpCols::eval_variable (operations/field/field_op.rs:227-261) with is_div = 0: the operation is chosen by flags, so the identity
     is the flag-weighted sum of the three."""

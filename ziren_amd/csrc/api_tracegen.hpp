@@ -842,6 +842,48 @@ int zkm_tracegen_u256x2048_mul(zkm_ctx* ctx, const zkm_u256x2048_mul_event* even
   API_END
 }
 
+int zkm_tracegen_boolean_circuit_garble(zkm_ctx* ctx, const zkm_garble_row* rows, size_t n_rows, int fixed_log2_rows, zkm_byte_lookups* blu, zkm_matrix** out) {
+  API_BEGIN
+  static_assert(sizeof(zkm_garble_row) == 4 * tracegen::GARBLE_ROW_WORDS, "a BooleanCircuitGarble row record is 103 words");
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIP_CHECK(hipSetDevice(ctx->device));
+  if (n_rows && !rows) throw std::runtime_error("zkm_tracegen_boolean_circuit_garble: null rows");
+  const size_t height = padded_trace_rows(n_rows, fixed_log2_rows, "zkm_tracegen_boolean_circuit_garble");
+  ctx->begin_timing();
+  zkm_matrix* m = new zkm_matrix();
+  m->h = height; m->w = tracegen::GARBLE_WIDTH;
+  uint32_t* d_rows = nullptr;
+  int* d_bad = nullptr;
+  try {
+    m->d = ctx->alloc_n<uint32_t>(height * m->w);
+    const size_t bytes_in = n_rows * sizeof(zkm_garble_row);
+    d_rows = (uint32_t*)ctx->alloc(std::max<size_t>(bytes_in, 4));
+    d_bad = (int*)ctx->alloc(4);
+    HIP_CHECK(hipMemsetAsync(d_bad, 0, 4, ctx->stream));
+    if (n_rows) HIP_CHECK(hipMemcpyAsync(d_rows, rows, bytes_in, hipMemcpyHostToDevice, ctx->stream));
+    uint32_t* counts = blu ? blu->counts : nullptr;
+    KLAUNCH(ctx, "tracegen_boolean_circuit_garble", (double)bytes_in + 4.0 * height * m->w, tracegen::garble_rows, dim3(div_up(height, (size_t)256)), dim3(256),
+            counts ? 2 * tracegen::BF_HASH_SLOTS * sizeof(uint32_t) : 0, (const uint32_t*)d_rows, n_rows, height, m->d, counts, d_bad);
+    int bad = 0;
+    HIP_CHECK(hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, ctx->stream));
+    ctx->mark("trace generation");
+    ctx->end_timing(false);
+    static const char* reasons[] = {"", "a header row does not read the gate count and delta", "a gate row does not continue the row before it",
+                                    "a gate type is neither 0 (AND) nor 7 (OR)", "the last gate's row does not write the result", "a call is cut short"};
+    if (bad) throw std::runtime_error(std::string("zkm_tracegen_boolean_circuit_garble: ") + reasons[std::min(std::max(16 - bad, 1), 5)]);
+  } catch (...) {
+    if (d_rows) ctx->release(d_rows);
+    if (d_bad) ctx->release(d_bad);
+    if (m->d) ctx->release(m->d);
+    delete m;
+    throw;
+  }
+  ctx->release(d_rows);
+  ctx->release(d_bad);
+  *out = m;
+  API_END
+}
+
 // Base fields of the short-Weierstrass curves (crates/curves/src/weierstrass/{secp256k1,secp256r1,bn254,bls12_381}.rs): modulus, its Barrett
 // constant, the curve's `a`, as 32-bit limbs (generated from the reference's MODULUS bytes; tests compare the widths and costs they give)
 struct Curve8 { bigfield::Modulus<8> m; uint32_t a[8]; };

@@ -2398,6 +2398,99 @@ __global__ __launch_bounds__(U256_THREADS) void u256x2048_mul_rows(const uint32_
   blk.flush(counts);
 }
 
+// ---- BooleanCircuitGarble (syscall/precompiles/boolean_circuit_garble/columns.rs:10-35, trace.rs:100-223): 1 + num_gates rows per call, 292 columns; one
+// thread per row from its 103-word record (shard, clk, input_address, output_address, is_gate, gate_id, gates_num, pre_check, delta[4], seventeen
+// read records, a write record). A gate row is checked against the record before it (same call, next gate, next address, pre_check = the
+// conjunction so far — recomputed from that record), so the rows stay independent. Error codes: 1 a header row that does not read the gate
+// count / delta, 2 a gate row that does not continue the row before it, 3 a gate type other than 0 / 7, 4 a wrong result, 5 a call cut short.
+constexpr int GARBLE_WIDTH = 292, GARBLE_ROW_WORDS = 103;
+__device__ __forceinline__ bool garble_gate_ok(const uint32_t* g) {      // g: a gate row's record
+  bool ok = true;
+  for (int i = 0; i < 4; i++) {
+    const uint32_t v = g[12 + 5 * (1 + i)] ^ g[12 + 5 * (5 + i)] ^ g[12 + 5 * (9 + i)] ^ (g[12] ? g[8 + i] : 0u);
+    ok = ok && v == g[12 + 5 * (13 + i)];
+  }
+  return ok;
+}
+__global__ __launch_bounds__(256) void garble_rows(const uint32_t* __restrict__ records, size_t n_rows, size_t height, uint32_t* __restrict__ out, uint32_t* counts,
+                                                   int* __restrict__ bad) {
+  enum { SHARD = 0, CLK = 1, IS_REAL = 2, INPUT = 3, OUTPUT = 4, IS_FIRST_ROW = 5, IS_GATE = 6, IS_FIRST_GATE = 7, IS_LAST_GATE = 8, NOT_LAST_GATE = 9, GATE_TYPE = 10,
+         GATE_ID = 12, GATES_NUM = 13, DELTA = 14, MEM = 30, RESULT_MEM = 183, AUX1 = 196, AUX2 = 212, AUX3 = 228, IS_EQ = 244, CHECKS = 288 };
+  enum { R_INPUT = 2, R_OUTPUT = 3, R_IS_GATE = 4, R_GATE_ID = 5, R_GATES_NUM = 6, R_PRE_CHECK = 7, R_DELTA = 8, R_READS = 12, R_WRITE = 12 + 85 };
+  extern __shared__ uint32_t bf_lds[];
+  const BfBlock blk(bf_lds, counts);
+  const size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (row < height) {
+    const bool real = row < n_rows;
+    const uint32_t* g = records + row * GARBLE_ROW_WORDS;
+    const LookupSink sink{blk.hkeys, blk.hvals, BF_HASH_SLOTS - 1, counts};
+    const RowCols R{out, height, row, sink, blk.count && real};
+    if (!real) {
+      R.zeros(0, GARBLE_WIDTH);
+    } else {
+      const uint32_t* prev = row ? g - GARBLE_ROW_WORDS : nullptr;
+      const bool gate = g[R_IS_GATE] != 0;
+      const uint32_t type = gate ? g[R_READS] : 0u;
+      const bool last = gate && g[R_GATE_ID] + 1 == g[R_GATES_NUM];
+      int why = 0;
+      if (!gate) {
+        bool ok = g[R_READS] == g[R_GATES_NUM] && g[R_GATES_NUM] != 0;
+        for (int k = 0; k < 4; k++) ok = ok && g[R_READS + 5 * (1 + k)] == g[R_DELTA + k];
+        if (!ok) why = 1;
+        if (prev && !(prev[R_IS_GATE] && prev[R_GATE_ID] + 1 == prev[R_GATES_NUM])) why = why ? why : 5;
+        if (row + 1 == n_rows) why = why ? why : 5;
+      } else {
+        bool chained = prev != nullptr;
+        if (chained) {
+          chained = prev[0] == g[0] && prev[1] == g[1] && prev[R_GATES_NUM] == g[R_GATES_NUM] && prev[R_OUTPUT] == g[R_OUTPUT] && g[R_GATE_ID] < g[R_GATES_NUM];
+          for (int k = 0; k < 4; k++) chained = chained && prev[R_DELTA + k] == g[R_DELTA + k];
+          if (g[R_GATE_ID] == 0) chained = chained && !prev[R_IS_GATE] && g[R_INPUT] == prev[R_INPUT] + 20 && g[R_PRE_CHECK] == 1;
+          else chained = chained && prev[R_IS_GATE] && prev[R_GATE_ID] + 1 == g[R_GATE_ID] && g[R_INPUT] == prev[R_INPUT] + 68 &&
+                         g[R_PRE_CHECK] == (prev[R_PRE_CHECK] && garble_gate_ok(prev) ? 1u : 0u);
+        }
+        if (!chained) why = 2;
+        if (type != 0 && type != 7) why = why ? why : 3;
+        if (!last && row + 1 == n_rows) why = why ? why : 5;
+      }
+      R.put(SHARD, g[0]); R.put(CLK, g[1]); R.put(IS_REAL, 1u); R.put(INPUT, g[R_INPUT]); R.put(OUTPUT, g[R_OUTPUT]);
+      R.put(IS_FIRST_ROW, gate ? 0u : 1u); R.put(IS_GATE, gate ? 1u : 0u);
+      R.put(IS_FIRST_GATE, gate && g[R_GATE_ID] == 0 ? 1u : 0u); R.put(IS_LAST_GATE, last ? 1u : 0u); R.put(NOT_LAST_GATE, gate && !last ? 1u : 0u);
+      R.put(GATE_TYPE, gate && type == 0 ? 1u : 0u); R.put(GATE_TYPE + 1, gate && type != 0 ? 1u : 0u);
+      R.put(GATE_ID, gate ? g[R_GATE_ID] : 0u); R.put(GATES_NUM, g[R_GATES_NUM]);
+      for (int k = 0; k < 16; k++) R.put(DELTA + k, (g[R_DELTA + k / 4] >> (8 * (k % 4))) & 0xff);
+      for (int k = 0; k < 17; k++) R.read_cols(MEM + 9 * k, k < (gate ? 17 : 5) ? g + R_READS + 5 * k : nullptr);
+      R.write_cols(RESULT_MEM, last ? g + R_WRITE : nullptr);
+      if (!gate) {
+        R.zeros(AUX1, GARBLE_WIDTH - AUX1);
+      } else {
+        uint32_t running = 1, check[4];
+        for (int k = 0; k < 4; k++) {
+          uint32_t v[3];
+          v[0] = g[R_READS + 5 * (1 + k)] ^ g[R_READS + 5 * (5 + k)];
+          v[1] = v[0] ^ g[R_READS + 5 * (9 + k)];
+          v[2] = v[1] ^ g[R_DELTA + k];
+          const uint32_t lhs[3] = {g[R_READS + 5 * (1 + k)], v[0], v[1]}, rhs[3] = {g[R_READS + 5 * (5 + k)], g[R_READS + 5 * (9 + k)], g[R_DELTA + k]};
+          for (int a = 0; a < 3; a++)
+            for (int c = 0; c < 4; c++) {
+              R.put((a == 0 ? AUX1 : a == 1 ? AUX2 : AUX3) + 4 * k + c, (v[a] >> (8 * c)) & 0xff);
+              if (R.count) lookup(sink, B_XOR, lhs[a] >> (8 * c), rhs[a] >> (8 * c));
+            }
+          const uint32_t computed = type ? v[2] : v[1], want = g[R_READS + 5 * (13 + k)];
+          uint32_t eq[11];
+          is_equal_word_cols(computed, want, eq);
+          for (int c = 0; c < 11; c++) R.put(IS_EQ + 11 * k + c, eq[c]);
+          running = running && computed == want;
+          check[k] = running;
+        }
+        R.put(CHECKS, check[1]); R.put(CHECKS + 1, check[2]); R.put(CHECKS + 2, check[3]); R.put(CHECKS + 3, check[3] && g[R_PRE_CHECK] ? 1u : 0u);
+        if (last && g[R_WRITE] != (check[3] && g[R_PRE_CHECK] ? 1u : 0u)) why = why ? why : 4;
+      }
+      if (why) atomicMax(bad, 16 - why);
+    }
+  }
+  blk.flush(counts);
+}
+
 // ---- Field tower (syscall/precompiles/fptower/fp.rs, fp2_addsub.rs, fp2_mul.rs) over the base field of Bn254 (NL = 8) or Bls12381 (NL = 12):
 // KIND 0 FpOp (one FieldOpCols, the operation — FieldOperation as a word: Add 0, Mul 1, Sub 2 — per event), 1 Fp2AddSub (two), 2 Fp2Mul (four
 // products, a difference, a sum). x is overwritten at clk + 1, y is read at clk. Padding rows: zero inputs with is_add set.

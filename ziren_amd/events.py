@@ -812,6 +812,27 @@ assert U256X2048_MUL_EVENT.itemsize == 4 * 808
 U256X2048_MUL_WIDTH = 3129   # U256x2048MulCols (u256x2048_mul/air.rs:52-87): 6 + 2 * 9 + 8 * 9 + 64 * 9 + 64 * 13 + 8 * 13 + 8 FieldOpCols<U256Field> (190) + 1
 
 
+# BooleanCircuitGarble (syscall/precompiles/boolean_circuit_garble/): checks the ciphertexts of the non-free gates of a garbled circuit. At
+# input_ptr: the number of gates, delta (4 words), then 17 words per gate (gate type — 0 AND, 7 OR —, h0, h1, label_b, expected, 4 words each);
+# 1 is written to output_ptr when every gate's h0 ^ h1 ^ label_b (^ delta for OR) equals its expected ciphertext, else 0; everything at clk
+# (syscalls/precompiles/boolean_circuit/garble.rs:10-95). A call takes 1 + num_gates rows. Across the ABI the BooleanCircuitGarbleEvent
+# (events/precompiles/boolean_circuit_garble.rs:12-45, Vecs inside) is cut into its rows: the header row (is_gate 0: the reads of num_gates and
+# delta in the first five records) and one per gate (its seventeen reads; the write record counts on the last gate). `pre_check` is the
+# conjunction of the gates before this one.
+SYS_BOOLEAN_CIRCUIT_GARBLE = 0x00010031
+GARBLE_OR_GATE = 7
+GARBLE_ROW = np.dtype([("shard", "<u4"), ("clk", "<u4"), ("input_address", "<u4"), ("output_address", "<u4"), ("is_gate", "<u4"), ("gate_id", "<u4"),
+                       ("gates_num", "<u4"), ("pre_check", "<u4"), ("delta", "<u4", (4,)), ("reads", MEMORY_READ_RECORD, (17,)), ("write", MEMORY_WRITE_RECORD)])
+assert GARBLE_ROW.itemsize == 4 * 103
+GARBLE_WIDTH = 292      # BooleanCircuitGarbleCols (boolean_circuit_garble/columns.rs:10-35)
+
+
+def garble_gate_ok(gate_words, delta):
+    """One gate's check: gate_words = [type, h0 x 4, h1 x 4, label_b x 4, expected x 4]."""
+    t, h0, h1, lb, want = gate_words[0], gate_words[1:5], gate_words[5:9], gate_words[9:13], gate_words[13:17]
+    return all((h0[i] ^ h1[i] ^ lb[i] ^ (delta[i] if t else 0)) == want[i] for i in range(4))
+
+
 # The field-tower precompiles (syscall/precompiles/fptower/fp.rs, fp2_addsub.rs, fp2_mul.rs) over the base fields of Bn254 and Bls12381: FpOpEvent,
 # Fp2AddSubEvent, Fp2MulEvent (events/precompiles/fptower.rs:23-94) flattened; `op` is FieldOperation as a word (Add 0, Mul 1, Sub 2).
 FP_TOWER_CODES = {"Bn254": dict(fp_add=0x01010026, fp_sub=0x01010027, fp_mul=0x01010028, fp2_add=0x01010029, fp2_sub=0x0101002A, fp2_mul=0x0101002B),

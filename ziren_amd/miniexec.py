@@ -95,7 +95,8 @@ class Machine:
 
 def run_machine(n_cycles: int = 0, seed: int = 1, pc_base: int = 0x1000, shard_cycles: int = 1 << 30, program=None, poseidon2_calls: int = 0,
                 memory_chunk: int = 1 << 30, keccak_calls: int = 0, sha_calls: int = 0, ed_calls: int = 0,
-                curve_calls=None, fp_calls=None, decompress_calls=None, uint256_calls: int = 0, u2048_calls: int = 0) -> Machine:
+                curve_calls=None, fp_calls=None, decompress_calls=None, uint256_calls: int = 0, u2048_calls: int = 0,
+                garble_calls=()) -> Machine:
     """A whole run as the reference's prover sees it (crates/core/machine/src/utils/prove.rs:255-400): CPU shards of at most `shard_cycles`
     cycles (never split between a branch and its delay slot, executor.rs:2352-2356), then one shard with the deferred precompile events
     (ExecutionRecord::split, record.rs:130-218), then the shards that initialise and finalise every touched address
@@ -104,12 +105,13 @@ def run_machine(n_cycles: int = 0, seed: int = 1, pc_base: int = 0x1000, shard_c
     spread over a generated run (each kind is deferred to a precompile shard of its own, record.rs:150-185)."""
     return _execute(n_cycles, seed, 1, pc_base, True, shard_cycles=shard_cycles, given=program, poseidon2_calls=poseidon2_calls, memory_chunk=memory_chunk,
                     machine=True, keccak_calls=keccak_calls, sha_calls=sha_calls, ed_calls=ed_calls, curve_calls=curve_calls, fp_calls=fp_calls, decompress_calls=decompress_calls,
-                    uint256_calls=uint256_calls, u2048_calls=u2048_calls)
+                    uint256_calls=uint256_calls, u2048_calls=u2048_calls, garble_calls=garble_calls)
 
 
 def _execute(n_cycles: int, seed: int = 1, shard: int = 1, pc_base: int = 0x1000, halt: bool = False, shard_cycles: int = 1 << 30, given=None,
              poseidon2_calls: int = 0, memory_chunk: int = 1 << 30, machine: bool = False, keccak_calls: int = 0, sha_calls: int = 0, ed_calls: int = 0,
-             curve_calls=None, fp_calls=None, decompress_calls=None, uint256_calls: int = 0, u2048_calls: int = 0) -> Machine:
+             curve_calls=None, fp_calls=None, decompress_calls=None, uint256_calls: int = 0, u2048_calls: int = 0,
+             garble_calls=()) -> Machine:
     """Execute `n_cycles` instructions of a program generated on the way. Returns (program, record, public_values) with
     program: INSTRUCTION array (instructions that were jumped over are `ADD $0, 0, 0` no-ops that never run), record:
     structured event arrays, public_values: dict of the words the Cpu chip checks (start_pc, next_pc, execution_shard).
@@ -176,7 +178,7 @@ def _execute(n_cycles: int, seed: int = 1, shard: int = 1, pc_base: int = 0x1000
     s_at = set(int(x) for x in np.linspace(n_cycles // 5, max(n_cycles - 80, n_cycles // 5), sha_calls)) - p2_at - k_at if sha_calls else set()
     s_seq = 0
     e_at = {n_cycles // 4} - p2_at - k_at - s_at if ed_calls else set()
-    w_at = {n_cycles // 3} - p2_at - k_at - s_at - e_at if curve_calls or decompress_calls or uint256_calls or u2048_calls else set()
+    w_at = {n_cycles // 3} - p2_at - k_at - s_at - e_at if curve_calls or decompress_calls or uint256_calls or u2048_calls or garble_calls else set()
     f_at = {n_cycles // 2} - p2_at - k_at - s_at - e_at - w_at if fp_calls else set()
     clk_extra = 0                  # the extra cycles of the shard's syscalls so far (Syscall::num_extra_cycles, executor.rs:1641)
 
@@ -329,6 +331,23 @@ def _execute(n_cycles: int, seed: int = 1, shard: int = 1, pc_base: int = 0x1000
                         queued += [(E.ADD, 30, (v >> (32 * i)) & 0xffffffff, 0, 1, 1), (E.SW, 30, 0, ptr + 4 * i, 0, 1)]
                 queued += [(E.ADD, E.REG_A2, lo_ptr, 0, 1, 1), (E.ADD, E.REG_A3, hi_ptr, 0, 1, 1), (E.ADD, E.REG_V0, E.SYS_U256XU2048_MUL, 0, 1, 1),
                            (E.ADD, E.REG_A0, a_ptr, 0, 1, 1), (E.ADD, E.REG_A1, b_ptr, 0, 1, 1), (E.SYSCALL, E.REG_V0, E.REG_A0, E.REG_A1, 0, 0)]
+            # per entry of `garble_calls` (a gate count; negative: one expected ciphertext of that many gates is wrong): the gate count, a random
+            # delta and the gates (type, h0, h1, label_b, expected) stored at input_ptr, then BOOLEAN_CIRCUIT_GARBLE(input_ptr, output_ptr)
+            for j, n_gates in enumerate(garble_calls):
+                input_ptr, output_ptr = 0x006e0000 + 0x1000 * j, 0x006f0000 + 4 * j
+                delta = [int(rng.integers(0, 1 << 32)) for _ in range(4)]
+                words = [abs(n_gates)] + delta
+                for g in range(abs(n_gates)):
+                    t = E.GARBLE_OR_GATE if rng.random() < 0.5 else 0
+                    h0, h1, lb = ([int(rng.integers(0, 1 << 32)) for _ in range(4)] for _ in range(3))
+                    want = [h0[i] ^ h1[i] ^ lb[i] ^ (delta[i] if t else 0) for i in range(4)]
+                    if n_gates < 0 and g == abs(n_gates) // 2:
+                        want[1] ^= 0x00010000
+                    words += [t] + h0 + h1 + lb + want
+                for i, w in enumerate(words):
+                    queued += [(E.ADD, 30, w, 0, 1, 1), (E.SW, 30, 0, input_ptr + 4 * i, 0, 1)]
+                queued += [(E.ADD, E.REG_V0, E.SYS_BOOLEAN_CIRCUIT_GARBLE, 0, 1, 1), (E.ADD, E.REG_A0, input_ptr, 0, 1, 1), (E.ADD, E.REG_A1, output_ptr, 0, 1, 1),
+                           (E.SYSCALL, E.REG_V0, E.REG_A0, E.REG_A1, 0, 0)]
             n_cycles += len(queued) - had
             p2_at = set(x + len(queued) - had if x > cyc else x for x in p2_at)
             k_at = set(x + len(queued) - had if x > cyc else x for x in k_at)
@@ -534,7 +553,7 @@ def _execute(n_cycles: int, seed: int = 1, shard: int = 1, pc_base: int = 0x1000
             w_curve = {c[k]: (name, k == "double") for name, c in E.WEIERSTRASS_CURVES.items() for k in ("add", "double")}.get(code)
             fp_call = {c: (field, name) for field, codes in E.FP_TOWER_CODES.items() for name, c in codes.items()}.get(code)
             w_decompress = {d["code"]: name for name, d in E.WEIERSTRASS_DECOMPRESS.items()}.get(code)
-            assert w_curve or fp_call or w_decompress or code in (E.SYS_UINT256_MUL, E.SYS_U256XU2048_MUL) or code in (E.SYS_HALT, E.SYS_COMMIT, E.SYS_POSEIDON2_PERMUTE, E.SYS_KECCAK_SPONGE, E.SYS_SHA_EXTEND, E.SYS_SHA_COMPRESS, E.SYS_ED_ADD,
+            assert w_curve or fp_call or w_decompress or code in (E.SYS_UINT256_MUL, E.SYS_U256XU2048_MUL, E.SYS_BOOLEAN_CIRCUIT_GARBLE) or code in (E.SYS_HALT, E.SYS_COMMIT, E.SYS_POSEIDON2_PERMUTE, E.SYS_KECCAK_SPONGE, E.SYS_SHA_EXTEND, E.SYS_SHA_COMPRESS, E.SYS_ED_ADD,
                                         E.SYS_ED_DECOMPRESS), code
             touched = {}                               # address -> [initial (shard, timestamp, value), final]: SyscallContext's local map
 
@@ -698,6 +717,24 @@ def _execute(n_cycles: int, seed: int = 1, shard: int = 1, pc_base: int = 0x1000
                 precompile.append(("u256x2048_mul", (pc, next_pc, shard, clk, (0, 0, 0, 0, 0, 0), 0, [0, 0, 0], sid, b, c),
                                    [(shard, clk, b, c, lo_reg[0], hi_reg[0], lo_reg, hi_reg, ar, br, low, high)], local))
                 clk_extra += 1
+            if code == E.SYS_BOOLEAN_CIRCUIT_GARBLE:
+                # BooleanCircuitGarbleSyscall::execute (syscalls/precompiles/boolean_circuit/garble.rs:10-95): the gate count, delta and 17 words per gate
+                # are read from $a0, 1 is written to $a1 when every gate checks, else 0; all at clk, no extra cycle. The event is filed as its rows
+                assert b % 4 == 0 and c % 4 == 0
+                count_rec = mem(b, clk)
+                n_gates = count_rec[0]
+                delta_recs = [mem(b + 4 + 4 * i, clk) for i in range(4)]
+                delta = tuple(x[0] for x in delta_recs)
+                no_read, no_write = (0, 0, 0, 0, 0), (0, 0, 0, 0, 0, 0)
+                rows_ = [(shard, clk, b, c, 0, 0, n_gates, 0, delta, [count_rec] + delta_recs + [no_read] * 12, no_write)]
+                running = True
+                for g in range(n_gates):
+                    recs = [mem(b + 20 + 68 * g + 4 * i, clk) for i in range(17)]
+                    rows_.append([shard, clk, b + 20 + 68 * g, c, 1, g, n_gates, int(running), delta, recs, no_write])
+                    running = running and E.garble_gate_ok([x[0] for x in recs], delta)
+                rows_[-1][10] = mem(c, clk, int(running))
+                local = [(addr, v[0], v[1]) for addr, v in sorted(touched.items())]
+                precompile.append(("garble", (pc, next_pc, shard, clk, (0, 0, 0, 0, 0, 0), 0, [0, 0, 0], sid, b, c), [tuple(x) for x in rows_], local))
             if w_decompress:
                 # create_ec_decompress_event (events/precompiles/ec.rs:181-228): x is read at ptr + N, the y the sign bit ($a1) selects is written at
                 # ptr, both at clk; no extra cycle
@@ -843,7 +880,7 @@ def _execute(n_cycles: int, seed: int = 1, shard: int = 1, pc_base: int = 0x1000
     n_shard = shards[-1].pv["shard"]
     for kind, dt in (("poseidon2", E.POSEIDON2_PERMUTE_EVENT), ("keccak", E.KECCAK_SPONGE_BLOCK), ("sha_extend", E.SHA_EXTEND_EVENT),
                      ("sha_compress", E.SHA_COMPRESS_EVENT), ("ed_add", E.ED_ADD_EVENT),
-                     ("ed_decompress", E.ED_DECOMPRESS_EVENT), ("uint256_mul", E.UINT256_MUL_EVENT), ("u256x2048_mul", E.U256X2048_MUL_EVENT)) + tuple(
+                     ("ed_decompress", E.ED_DECOMPRESS_EVENT), ("uint256_mul", E.UINT256_MUL_EVENT), ("u256x2048_mul", E.U256X2048_MUL_EVENT), ("garble", E.GARBLE_ROW)) + tuple(
             (curve + suffix, E.weierstrass_event_dtypes(curve)[k]) for curve in E.WEIERSTRASS_CURVES for k, suffix in ((0, "_add"), (1, "_double"))) + tuple(
             (curve + "_decompress", E.weierstrass_decompress_event_dtype(curve)) for curve in E.WEIERSTRASS_DECOMPRESS) + tuple(
             (field + "_" + kind, E.fp_tower_event_dtype(field, kind)) for field in E.FP_TOWER_CODES for kind in ("fp", "fp2_addsub", "fp2_mul")):
@@ -862,6 +899,7 @@ def _execute(n_cycles: int, seed: int = 1, shard: int = 1, pc_base: int = 0x1000
         o.ed_decompress = arr([ev for e in mine for ev in e[2]] if kind == "ed_decompress" else [], E.ED_DECOMPRESS_EVENT)
         o.uint256_mul = arr([ev for e in mine for ev in e[2]] if kind == "uint256_mul" else [], E.UINT256_MUL_EVENT)
         o.u256x2048_mul = arr([ev for e in mine for ev in e[2]] if kind == "u256x2048_mul" else [], E.U256X2048_MUL_EVENT)
+        o.garble = arr([ev for e in mine for ev in e[2]] if kind == "garble" else [], E.GARBLE_ROW)
         o.weierstrass = (kind, arr([ev for e in mine for ev in e[2]], dt)) if kind.endswith(("_add", "_double")) and kind.split("_")[0] in E.WEIERSTRASS_CURVES else None
         o.weierstrass_decompress = (kind.split("_")[0], arr([ev for e in mine for ev in e[2]], dt)) if kind.endswith("_decompress") and kind != "ed_decompress" else None
         o.fp_tower = (kind, arr([ev for e in mine for ev in e[2]], dt)) if kind.split("_")[0] in E.FP_TOWER_CODES and "_fp" in kind else None

@@ -309,6 +309,16 @@ class Context:
                                                         C.c_int(fixed_log2_rows), blu.h if blu is not None else None, C.byref(h)))
         return self._born(h)
 
+    def tracegen_boolean_circuit_garble(self, rows: np.ndarray, fixed_log2_rows: int = -1, blu: "ByteLookups" = None) -> DeviceMatrix:
+        """`generate_trace` of the BooleanCircuitGarble precompile on the device (zkm_tracegen_boolean_circuit_garble); dtype events.GARBLE_ROW, one
+        record per row (a header row and a row per gate for every call)."""
+        from . import events as _ev
+        ev = np.ascontiguousarray(rows, dtype=_ev.GARBLE_ROW)
+        h = C.c_void_p()
+        lib.check(lib.load().zkm_tracegen_boolean_circuit_garble(self.h, C.c_void_p(ev.ctypes.data if len(ev) else None), C.c_size_t(len(ev)),
+                                                                 C.c_int(fixed_log2_rows), blu.h if blu is not None else None, C.byref(h)))
+        return self._born(h)
+
     def tracegen_fp_tower(self, field: str, kind: str, events: np.ndarray, fixed_log2_rows: int = -1, blu: "ByteLookups" = None) -> DeviceMatrix:
         """`generate_trace` of <Field>FpOpAssign / Fp2AddSubAssign / Fp2MulAssign on the device (zkm_tracegen_fp_op / _fp2_addsub / _fp2_mul); field
         "Bn254" or "Bls12381", kind "fp" / "fp2_addsub" / "fp2_mul", dtype events.fp_tower_event_dtype(field, kind)."""
