@@ -392,7 +392,10 @@ int zkm_tracegen_syscall_instrs(zkm_ctx* ctx, const zkm_syscall_event* events, s
  * generate_trace (:211-276; the C++ twins are syscall_core_event_to_row_koalabear / syscall_precompile_event_to_row_koalabear,
  * crates/core/machine/src/sys.rs:40-47, include/syscall.hpp). Core takes the shard's syscall events and keeps those whose code has the
  * send-to-table byte set or names a Linux syscall; Precompile takes the syscall events filed with the shard's precompile events.
- * 11 columns; the U16Range lookups of the four argument half-words (generate_dependencies :178-183) are counted into `blu` if given. */
+ * 11 columns; the U16Range lookups of the four argument half-words (generate_dependencies :178-183) are counted into `blu` if given.
+ * Linux syscalls (a code whose second byte is not zero): is_linux and the result half-words come from the event's a_record (prev_value = the
+ * code, value = the value returned in $v0). Core's events hold that record already; for the Precompile table, where the reference reads both
+ * off the LinuxEvent filed with the syscall event (:223-238), the caller copies syscall_code and v0 into the a_record. */
 int zkm_tracegen_syscall(zkm_ctx* ctx, const zkm_syscall_event* events, size_t n_events, int precompile, int fixed_log2_rows,
                          zkm_byte_lookups* blu, zkm_matrix** out);
 /* MemoryGlobalInit / MemoryGlobalFinalize (crates/core/machine/src/memory/global.rs): replaces generate_trace (:113-185; the C++ twin is
@@ -541,6 +544,17 @@ typedef struct {
 } zkm_garble_row;
 int zkm_tracegen_boolean_circuit_garble(zkm_ctx* ctx, const zkm_garble_row* rows, size_t n_rows, int fixed_log2_rows, zkm_byte_lookups* blu,
                                         zkm_matrix** out);
+
+/* SysLinux (crates/core/machine/src/syscall/precompiles/sys_linux/): replaces generate_trace + generate_dependencies (trace.rs:32-102), byte lookups
+ * into `blu`. An event is LinuxEvent (crates/core/executor/src/events/precompiles/linux.rs:9-28) flattened: read_record = read_records[0] (brk: the
+ * BRK register; write: $a2), a3_record = write_records[0], heap_record = write_records[1] (mmap / mmap2 with a0 = 0); records an event does not
+ * have are zero. Fails when v0, the value written to $a3 or the new heap are not what the syscall returns. */
+typedef struct {
+  uint32_t shard, clk, a0, a1, v0, syscall_code;
+  zkm_memory_read_record read_record;
+  zkm_memory_write_record a3_record, heap_record;
+} zkm_linux_event;
+int zkm_tracegen_sys_linux(zkm_ctx* ctx, const zkm_linux_event* events, size_t n_events, int fixed_log2_rows, zkm_byte_lookups* blu, zkm_matrix** out);
 
 /* The field-tower precompiles (crates/core/machine/src/syscall/precompiles/fptower/fp.rs, fp2_addsub.rs, fp2_mul.rs): Bn254 / Bls12381 x FpOpAssign,
  * Fp2AddSubAssign, Fp2MulAssign; replace their generate_trace, byte lookups into `blu`. `field` is ZKM_CURVE_BN254 or ZKM_CURVE_BLS12381. Events:

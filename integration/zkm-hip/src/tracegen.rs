@@ -32,7 +32,7 @@ pub(crate) const DEVICE_BUILT: &[&str] = &[
     "KeccakSponge", "ShaExtend", "ShaCompress", "EdAddAssign", "EdDecompress", "Secp256k1AddAssign", "Secp256k1DoubleAssign", "Secp256r1AddAssign",
     "Secp256r1DoubleAssign", "Bn254AddAssign", "Bn254DoubleAssign", "Bls12381AddAssign", "Bls12381DoubleAssign", "Bn254FpOpAssign", "Bn254Fp2AddSubAssign",
     "Bn254Fp2MulAssign", "Bls12381FpOpAssign", "Bls12831Fp2AddSubAssign", "Bls12831Fp2MulAssign", "Secp256k1Decompress", "Secp256r1Decompress",
-    "Bls12381Decompress", "Uint256MulMod", "U256XU2048Mul", "BooleanCircuitGarble",
+    "Bls12381Decompress", "Uint256MulMod", "U256XU2048Mul", "BooleanCircuitGarble", "SysLinux",
 ];
 
 /// ZKM_CURVE_* of include/zkm_hip.h
@@ -152,7 +152,13 @@ pub(crate) fn device_trace(
             ffi::zkm_tracegen_syscall(ctx, r.syscall_events.as_ptr() as *const ffi::ZkmSyscallEvent, r.syscall_events.len(), 0, fixed, blu, &mut m)      // filtered inside, as the chip filters
         })?,
         "SyscallPrecompile" => {
-            let ev: Vec<SyscallEvent> = r.precompile_events.all_events().map(|(e, _)| *e).collect();
+            // a Linux call's code and result reach the table through its syscall event's a_record (include/zkm_hip.h, zkm_tracegen_syscall):
+            // the reference reads them off the LinuxEvent (syscall/chip.rs:223-238)
+            let ev: Vec<SyscallEvent> = r.precompile_events.all_events().map(|(e, p)| {
+                let mut e = *e;
+                if let PrecompileEvent::Linux(l) = p { e.a_record.prev_value = l.syscall_code; e.a_record.value = l.v0; }
+                e
+            }).collect();
             check(unsafe { ffi::zkm_tracegen_syscall(ctx, ev.as_ptr() as *const ffi::ZkmSyscallEvent, ev.len(), 1, fixed, blu, &mut m) })?
         }
         "MemoryGlobalInit" | "MemoryGlobalFinalize" => {
@@ -276,6 +282,22 @@ pub(crate) fn device_trace(
                 }
             }
             check(unsafe { ffi::zkm_tracegen_boolean_circuit_garble(ctx, rows.as_ptr(), rows.len(), fixed, blu, &mut m) })?
+        }
+        "SysLinux" => {
+            let none = ffi::ZkmMemoryReadRecord { value: 0, shard: 0, timestamp: 0, prev_shard: 0, prev_timestamp: 0 };
+            let no_write = ffi::ZkmMemoryWriteRecord { value: 0, shard: 0, timestamp: 0, prev_value: 0, prev_shard: 0, prev_timestamp: 0 };
+            let ev: Vec<ffi::ZkmLinuxEvent> = precompile(r, SyscallCode::SYS_LINUX)
+                .map(|e| match e {
+                    PrecompileEvent::Linux(e) => ffi::ZkmLinuxEvent {
+                        shard: e.shard, clk: e.clk, a0: e.a0, a1: e.a1, v0: e.v0, syscall_code: e.syscall_code,
+                        read_record: e.read_records.first().map(rd).unwrap_or(none),
+                        a3_record: wr(&e.write_records[0]),
+                        heap_record: e.write_records.get(1).map(wr).unwrap_or(no_write),
+                    },
+                    _ => unreachable!(),
+                })
+                .collect();
+            check(unsafe { ffi::zkm_tracegen_sys_linux(ctx, ev.as_ptr(), ev.len(), fixed, blu, &mut m) })?
         }
         "Secp256k1Decompress" => curve_events!(SECP256K1_DECOMPRESS, Secp256k1Decompress, zkm_tracegen_weierstrass_decompress, SECP256K1, dec),
         "Secp256r1Decompress" => curve_events!(SECP256R1_DECOMPRESS, Secp256r1Decompress, zkm_tracegen_weierstrass_decompress, SECP256R1, dec),

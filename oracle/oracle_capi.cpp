@@ -831,6 +831,21 @@ int orc_tracegen_boolean_circuit_garble(const void* rows_in, size_t n_rows, int 
   ORC_CATCH
 }
 
+// SysLinux chip: flattened LinuxEvents (23 words), one row each
+int orc_tracegen_sys_linux(const void* events, size_t n_events, int fixed_log2_rows, uint32_t* out, size_t out_cap, size_t* rows, uint32_t* byte_counts) {
+  ORC_TRY
+  size_t h;
+  std::vector<uint64_t> cnt(byte_counts ? tracegen::BYTE_ROWS * tracegen::NUM_BYTE_OPS : 0, 0);
+  std::vector<F> t = tracegen::generate_sys_linux((const tracegen::LinuxEvent*)events, n_events, fixed_log2_rows, &h, byte_counts && out ? cnt.data() : nullptr);
+  *rows = h;
+  if (out) {
+    if (t.size() > out_cap) throw std::runtime_error("trace buffer too small");
+    for (size_t i = 0; i < t.size(); i++) out[i] = to_monty(t[i]);
+    for (size_t i = 0; i < cnt.size(); i++) byte_counts[i] += (uint32_t)cnt[i];
+  }
+  ORC_CATCH
+}
+
 // Field-tower chips (kind 0 FpOp, 1 Fp2AddSub, 2 Fp2Mul) over a base field given by its modulus bytes
 int orc_tracegen_fp_tower(const uint32_t* events, size_t n_events, int kind, int n_limbs, const uint8_t* modulus, uint32_t witness_offset,
                           int fixed_log2_rows, uint32_t* out, size_t out_cap, size_t* rows, uint32_t* byte_counts) {

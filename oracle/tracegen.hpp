@@ -1297,7 +1297,8 @@ static inline std::vector<F> generate_memory_global(const MemoryInitFinalizeEven
 // ---- SyscallCore / SyscallPrecompile chips (syscall/chip.rs): SyscallEvents; columns SyscallCols :71-107 (shard, clk, syscall_id,
 // arg1_lo, arg1_hi, arg2_lo, arg2_hi, result_lo, result_hi, is_linux, is_real); rows generate_trace :211-276. Core: the shard's syscall
 // events whose code (a_record.prev_value) has the send-to-table byte set or names a Linux syscall; Precompile: the syscall events filed
-// with the shard's precompile events (a default a_record; is_linux only for Linux precompile events, which are not built: zero here).
+// with the shard's precompile events (a default a_record — except for Linux events, chip.rs:223-238: is_linux and the result come from the LinuxEvent;
+// across this boundary the syscall event of a Linux call carries them in its a_record: prev_value = the code, value = v0).
 // The C++ twin is include/syscall.hpp:9-60. Byte lookups (generate_dependencies :115-187): U16Range of the four argument half-words.
 static const size_t SYSCALL_WIDTH = 11;
 static inline bool syscall_goes_to_table(const SyscallEvent& e) {
@@ -1316,7 +1317,7 @@ static inline std::vector<F> generate_syscall(const SyscallEvent* events, size_t
     F* r = t.data() + i * SYSCALL_WIDTH;
     r[0] = fu32(e.shard); r[1] = fu32(e.clk); r[2] = fu32(e.syscall_id);
     r[3] = e.arg1 & 0xffff; r[4] = e.arg1 >> 16; r[5] = e.arg2 & 0xffff; r[6] = e.arg2 >> 16;
-    const bool is_linux = !precompile && ((e.a_record.prev_value >> 8) & 0xff) != 0;
+    const bool is_linux = ((e.a_record.prev_value >> 8) & 0xff) != 0;      // Precompile: the a_record of a Linux event's syscall event carries its code and v0
     r[9] = is_linux;
     if (is_linux) { r[7] = e.a_record.value & 0xffff; r[8] = e.a_record.value >> 16; }
     r[10] = 1;
@@ -2342,6 +2343,112 @@ static inline std::vector<F> generate_boolean_circuit_garble(const GarbleRow* ro
   if (n_rows && !rows[n_rows - 1].is_gate) throw std::runtime_error("tracegen: garble: the last call is cut short");
   for (size_t i = 0; i + 1 < n_rows; i++)
     if (!rows[i + 1].is_gate && (!rows[i].is_gate || rows[i].gate_id + 1 != rows[i].gates_num)) throw std::runtime_error("tracegen: garble: a call is cut short");
+  if (byte_counts)
+    for (const ByteLookup& bl : lk) byte_counts[((size_t)bl.b * 256 + bl.c) * NUM_BYTE_OPS + bl.op]++;
+  *height = h;
+  return t;
+}
+
+// ---- SysLinux (syscall/precompiles/sys_linux/columns.rs:20-82, trace.rs:104-233): one Linux syscall per row, 103 columns: shard, clk, syscall_id, a0, a1,
+// result (words), inorout and output (MemoryReadWriteCols: the branch's own access — register BRK, $a2 or HEAP — and the write of $a3), eight
+// IsZeroOperations decoding the syscall id, is_mmap, five decoding a0 / a1, three composite flags, the mmap columns (the two nibbles of a1's
+// second byte as bits, IsZero of the page offset, the size as a word, two carries, an AddOperation for the new heap), GtColsBytes for brk,
+// is_real. Padding rows are zero.
+struct LinuxEvent { uint32_t shard, clk, a0, a1, v0, syscall_code; MemoryReadRecord read_record; MemoryWriteRecord a3_record, heap_record; };
+static_assert(sizeof(LinuxEvent) == 4 * 23, "flattened LinuxEvent is 23 words");
+static const size_t SYS_LINUX_WIDTH = 103;
+static inline std::vector<F> generate_sys_linux(const LinuxEvent* events, size_t n_events, int fixed_log2_rows, size_t* height, uint64_t* byte_counts) {
+  enum { SHARD = 0, CLK = 1, ID = 2, A0 = 3, A1 = 7, RESULT = 11, INOROUT = 15, OUTPUT = 28, D_MMAP = 41, D_MMAP2 = 43, D_CLONE = 45, D_EXIT = 47, D_BRK = 49, D_FCNTL = 51,
+         D_READ = 53, D_WRITE = 55, IS_MMAP = 57, D_A0_0 = 58, D_A0_1 = 60, D_A0_2 = 62, D_A1_1 = 64, D_A1_3 = 66, IS_MMAP_A0_0 = 68, IS_FCNTL_A1_1 = 69, IS_FCNTL_A1_3 = 70,
+         LO_BITS = 71, HI_BITS = 75, PAGE_ZERO = 79, MMAP_SIZE = 81, SIZE_CARRY = 85, HEAP_ADD = 87, GT = 94, IS_REAL = 102 };
+  enum { MMAP = 4210, MMAP2 = 4090, CLONE = 4120, EXIT_GROUP = 4246, BRK = 4045, FCNTL = 4055, READ = 4003, WRITE = 4004 };
+  const size_t h = padded_rows(n_events, fixed_log2_rows);
+  std::vector<F> t(h * SYS_LINUX_WIDTH, 0);
+  std::vector<ByteLookup> lk;
+  auto range = [&](uint32_t v) {
+    lk.push_back(ByteLookup{B_U8RANGE, (uint8_t)v, (uint8_t)(v >> 8)});
+    lk.push_back(ByteLookup{B_U8RANGE, (uint8_t)(v >> 16), (uint8_t)(v >> 24)});
+  };
+  for (size_t i = 0; i < n_events; i++) {
+    const LinuxEvent& e = events[i];
+    F* r = t.data() + i * SYS_LINUX_WIDTH;
+    const uint32_t code = e.syscall_code;
+    // what the executor would have done (syscalls/precompiles/sys_linux/*.rs): the value returned and the value written to $a3
+    uint32_t v0 = 0, a3 = 0;
+    const bool mmap = code == MMAP || code == MMAP2, fd = e.a0 <= 2;
+    if (code == BRK) v0 = std::max(e.a0, e.read_record.value);
+    else if (mmap) v0 = e.a0 == 0 ? e.heap_record.prev_value : e.a0;
+    else if (code == CLONE) v0 = 1;
+    else if (code == FCNTL) {
+      if (e.a1 == 3) v0 = e.a0 == 0 ? 0 : fd ? 1 : 0xffffffffu;
+      else if (e.a1 == 1) v0 = fd ? e.a0 : 0xffffffffu;
+      else v0 = 0xffffffffu;
+      a3 = v0 == 0xffffffffu ? 9 : 0;
+    } else if (code == READ) { v0 = e.a0 == 0 ? 0 : 0xffffffffu; a3 = e.a0 == 0 ? 0 : 9; }
+    else if (code == WRITE) v0 = e.read_record.value;
+    if (v0 != e.v0 || a3 != e.a3_record.value) throw std::runtime_error("tracegen: SysLinux event does not return what the syscall returns");
+    word(r + A0, e.a0); word(r + A1, e.a1); word(r + RESULT, e.v0);
+    r[SHARD] = fu32(e.shard); r[CLK] = fu32(e.clk); r[ID] = fu32(code); r[IS_REAL] = 1;
+    memory_write_cols(e.a3_record, r + OUTPUT, &lk);
+    const F sid = fu32(code);
+    const int decoders[8][2] = {{MMAP, D_MMAP}, {MMAP2, D_MMAP2}, {CLONE, D_CLONE}, {EXIT_GROUP, D_EXIT}, {BRK, D_BRK}, {FCNTL, D_FCNTL}, {READ, D_READ}, {WRITE, D_WRITE}};
+    for (auto& d : decoders) is_zero_cols(fsub(sid, d[0]), r + d[1]);
+    r[IS_MMAP] = mmap;
+    const F a0f = fu32(e.a0), a1f = fu32(e.a1);
+    is_zero_cols(a0f, r + D_A0_0); is_zero_cols(fsub(a0f, 1), r + D_A0_1); is_zero_cols(fsub(a0f, 2), r + D_A0_2);
+    is_zero_cols(fsub(a1f, 1), r + D_A1_1); is_zero_cols(fsub(a1f, 3), r + D_A1_3);
+    r[IS_MMAP_A0_0] = mmap && e.a0 == 0;
+    r[IS_FCNTL_A1_1] = code == FCNTL && e.a1 == 1;
+    r[IS_FCNTL_A1_3] = code == FCNTL && e.a1 == 3;
+    auto read_inorout = [&]() {      // MemoryReadWriteCols::populate_read: the previous value is the value
+      const MemoryReadRecord& m = e.read_record;
+      word(r + INOROUT, m.value);
+      memory_access_cols(m.value, m.shard, m.timestamp, m.prev_shard, m.prev_timestamp, r + INOROUT + 4, &lk);
+    };
+    if (code == BRK) {
+      // GtColsBytes::populate (operations/cmp.rs:34-93) of a0 against the BRK register
+      const uint32_t a = e.a0, bb = e.read_record.value;
+      uint32_t res = 0, a_byte = 0, b_byte = 0;
+      bool flagged = false;
+      for (int k = 3; k >= 0 && !flagged; k--) {
+        const uint32_t x = (a >> (8 * k)) & 0xff, y = (bb >> (8 * k)) & 0xff;
+        if (x != y) { r[GT + k] = 1; a_byte = x; b_byte = y; res = x > y; flagged = true; }
+      }
+      r[GT + 4] = a_byte; r[GT + 5] = b_byte; r[GT + 6] = res; r[GT + 7] = flagged;
+      lk.push_back(ByteLookup{B_LTU, (uint8_t)b_byte, (uint8_t)a_byte});
+      if (flagged) lk.push_back(ByteLookup{B_LTU, (uint8_t)a_byte, (uint8_t)b_byte});
+      range(a); range(bb);
+      read_inorout();
+    } else if (mmap) {
+      range(e.a0); range(e.a1);
+      const uint32_t byte1 = (e.a1 >> 8) & 0xff, lo = byte1 & 15, hi = byte1 >> 4;
+      for (int bit = 0; bit < 4; bit++) { r[LO_BITS + bit] = (lo >> bit) & 1; r[HI_BITS + bit] = (hi >> bit) & 1; }
+      const uint32_t page_off = e.a1 & 0xfff, upper = (e.a1 >> 12) << 12;
+      is_zero_cols(page_off, r + PAGE_ZERO);
+      if (e.a0 == 0) {
+        memory_write_cols(e.heap_record, r + INOROUT, &lk);
+        const uint32_t size = page_off == 0 ? upper : upper + 0x1000;
+        word(r + MMAP_SIZE, size);
+        range(size);
+        if (page_off != 0 && hi == 15) {
+          r[SIZE_CARRY] = 1;
+          if (((e.a1 >> 16) & 0xff) == 255) r[SIZE_CARRY + 1] = 1;
+        }
+        // AddOperation::populate (operations/add.rs:23-57) of the old heap and the size
+        const uint32_t old_heap = e.heap_record.prev_value, sum = old_heap + size;
+        if (e.heap_record.value != sum) throw std::runtime_error("tracegen: SysLinux mmap does not move the heap by the rounded size");
+        word(r + HEAP_ADD, sum);
+        uint32_t carry = 0;
+        for (int k = 0; k < 3; k++) {
+          carry = (((old_heap >> (8 * k)) & 0xff) + ((size >> (8 * k)) & 0xff) + carry) >> 8;
+          r[HEAP_ADD + 4 + k] = carry;
+        }
+        range(old_heap); range(size); range(sum);
+      }
+    } else if (code == WRITE) {
+      read_inorout();
+    }
+  }
   if (byte_counts)
     for (const ByteLookup& bl : lk) byte_counts[((size_t)bl.b * 256 + bl.c) * NUM_BYTE_OPS + bl.op]++;
   *height = h;

@@ -27,7 +27,7 @@ def halves(x):
 
 def syscall_global_events(syscall_events, precompile):
     """SyscallChip::generate_dependencies (syscall/chip.rs:115-187): per event two messages — the arguments as half-words (kind Syscall) and
-    the result half-words (kind SyscallResult; zero for the syscalls built here) — sent by Core, received by Precompile."""
+    the result half-words (kind SyscallResult; zero unless the call is a Linux syscall) — sent by Core, received by Precompile."""
     ev = syscall_events
     if not precompile:
         code = ev["a_record"]["prev_value"]
@@ -36,7 +36,9 @@ def syscall_global_events(syscall_events, precompile):
     for i, e in enumerate(ev):
         a1, a2 = halves(int(e["arg1"])), halves(int(e["arg2"]))
         out["message"][2 * i] = [e["shard"], e["clk"], e["syscall_id"], a1[0], a1[1], a2[0], a2[1]]
-        out["message"][2 * i + 1] = [e["shard"], e["clk"], e["syscall_id"], 0, 0, 0, 0]
+        linux = (int(e["a_record"]["prev_value"]) >> 8) & 0xff != 0      # a Linux syscall: the result's half-words (chip.rs:134-157)
+        res = halves(int(e["a_record"]["value"])) if linux else (0, 0)
+        out["message"][2 * i + 1] = [e["shard"], e["clk"], e["syscall_id"], res[0], res[1], 0, 0]
         out["kind"][2 * i], out["kind"][2 * i + 1] = KIND_SYSCALL, KIND_SYSCALL_RESULT
     out["is_receive"] = 1 if precompile else 0
     return out
@@ -79,7 +81,7 @@ class Oracle:
               "divrem": O.tracegen_divrem, "global": O.tracegen_global, "poseidon2_permute": O.tracegen_poseidon2_permute,
               "keccak_sponge": O.tracegen_keccak_sponge, "sha_extend": O.tracegen_sha_extend, "sha_compress": O.tracegen_sha_compress,
               "ed_add": O.tracegen_ed_add, "ed_decompress": O.tracegen_ed_decompress, "uint256_mul": O.tracegen_uint256_mul, "u256x2048_mul": O.tracegen_u256x2048_mul,
-              "garble": O.tracegen_boolean_circuit_garble}
+              "garble": O.tracegen_boolean_circuit_garble, "linux": O.tracegen_sys_linux}
         if what in fn:
             return fn[what](a[0], a[1], c)
         if what == "weierstrass":
@@ -122,7 +124,7 @@ class Device:
               "divrem": ctx.tracegen_divrem, "global": ctx.tracegen_global, "poseidon2_permute": ctx.tracegen_poseidon2_permute,
               "keccak_sponge": ctx.tracegen_keccak_sponge, "sha_extend": ctx.tracegen_sha_extend, "sha_compress": ctx.tracegen_sha_compress,
               "ed_add": ctx.tracegen_ed_add, "ed_decompress": ctx.tracegen_ed_decompress, "uint256_mul": ctx.tracegen_uint256_mul, "u256x2048_mul": ctx.tracegen_u256x2048_mul,
-              "garble": ctx.tracegen_boolean_circuit_garble}
+              "garble": ctx.tracegen_boolean_circuit_garble, "linux": ctx.tracegen_sys_linux}
         if what in fn:
             return fn[what](a[0], a[1], blu)
         if what == "weierstrass":
@@ -210,6 +212,9 @@ def build_shard(src, machine, k):
         if len(getattr(rec, "garble", ())):
             lh = log2_rows(len(rec.garble))
             add(chips.record_boolean_circuit_garble_chip(lh), src.trace("garble", rec.garble, lh))
+        if len(getattr(rec, "linux", ())):
+            lh = log2_rows(len(rec.linux))
+            add(chips.record_sys_linux_chip(lh), src.trace("linux", rec.linux, lh))
         if rec.weierstrass is not None:
             kind, ev = rec.weierstrass
             curve, double = kind.split("_")[0], kind.endswith("_double")

@@ -459,6 +459,14 @@ def tracegen_boolean_circuit_garble(rows, fixed_log2_rows=-1, byte_counts=None):
     return _rows_then_fill(lib().orc_tracegen_boolean_circuit_garble, E.GARBLE_WIDTH, C.c_void_p(ev.ctypes.data), C.c_size_t(len(ev)), C.c_int(fixed_log2_rows), tail=bc)
 
 
+def tracegen_sys_linux(events, fixed_log2_rows=-1, byte_counts=None):
+    """SysLinux rows from flattened LinuxEvents (events.LINUX_EVENT)."""
+    from ziren_amd import events as E
+    ev = np.ascontiguousarray(events, dtype=E.LINUX_EVENT)
+    bc = (abi.as_u32p(byte_counts),) if byte_counts is not None else (None,)
+    return _rows_then_fill(lib().orc_tracegen_sys_linux, E.SYS_LINUX_WIDTH, C.c_void_p(ev.ctypes.data), C.c_size_t(len(ev)), C.c_int(fixed_log2_rows), tail=bc)
+
+
 def tracegen_weierstrass_decompress(curve, events, fixed_log2_rows=-1, byte_counts=None):
     """<Curve>Decompress rows from flattened EllipticCurveDecompressEvents (events.weierstrass_decompress_event_dtype)."""
     from ziren_amd import events as E

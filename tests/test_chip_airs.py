@@ -62,7 +62,7 @@ def test_recorded_costs_match_the_reference():
         chips.record_global_chip(10), chips.record_memory_global_chip(False, 10), chips.record_memory_global_chip(True, 10),
         chips.record_syscall_table_chip(False, 10), chips.record_syscall_table_chip(True, 10), chips.record_poseidon2_permute_chip(10),
         chips.record_keccak_sponge_chip(10), chips.record_sha_extend_chip(10), chips.record_sha_compress_chip(10),
-        chips.record_ed_add_chip(10), chips.record_ed_decompress_chip(10), chips.record_uint256_mul_chip(10), chips.record_u256x2048_mul_chip(10), chips.record_boolean_circuit_garble_chip(10)] + [
+        chips.record_ed_add_chip(10), chips.record_ed_decompress_chip(10), chips.record_uint256_mul_chip(10), chips.record_u256x2048_mul_chip(10), chips.record_boolean_circuit_garble_chip(10), chips.record_sys_linux_chip(10)] + [
         chips.record_weierstrass_chip(curve, double, 10) for curve in E.WEIERSTRASS_CURVES for double in (False, True)] + [
         chips.record_weierstrass_decompress_chip(curve, 10) for curve in E.WEIERSTRASS_DECOMPRESS] + [
         chips.record_fp_tower_chip(field, kind, 10) for field in E.FP_TOWER_CODES for kind in ("fp", "fp2_addsub", "fp2_mul")]

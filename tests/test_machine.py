@@ -56,7 +56,7 @@ def check_machine_airs(oracle, m):
                    "ShaExtend": chips.record_sha_extend_constraints, "ShaCompress": chips.record_sha_compress_constraints,
                    "EdAddAssign": chips.record_ed_add_constraints, "EdDecompress": chips.record_ed_decompress_constraints,
                    "Uint256MulMod": chips.record_uint256_mul_constraints, "U256XU2048Mul": chips.record_u256x2048_mul_constraints,
-                   "BooleanCircuitGarble": chips.record_boolean_circuit_garble_constraints}.get(c.name)
+                   "BooleanCircuitGarble": chips.record_boolean_circuit_garble_constraints, "SysLinux": chips.record_sys_linux_constraints}.get(c.name)
             if rec is None and ("FpOpAssign" in c.name or "Fp2" in c.name):
                 field = "Bn254" if c.name.startswith("Bn254") else "Bls12381"
                 kind = "fp" if "FpOp" in c.name else "fp2_mul" if "Fp2Mul" in c.name else "fp2_addsub"

@@ -2536,6 +2536,158 @@ def record_boolean_circuit_garble_chip(log_height: int) -> RecordedChip:
     return _finish(record_boolean_circuit_garble_constraints(), "BooleanCircuitGarble", log_height, E.GARBLE_WIDTH, False)
 
 
+def _gt_bytes(r: _Rec, a, bw, is_real, cols):
+    """GtColsBytes::eval (operations/cmp.rs:95-169): cols = byte_flags(4), a_comparison_byte, b_comparison_byte, result, has_comparison."""
+    b = r.b
+    flags, a_byte, b_byte, result, has = cols[0:4], cols[4], cols[5], cols[6], cols[7]
+    r.slice_range_check_u8(a, is_real)
+    r.slice_range_check_u8(bw, is_real)
+    total = b.const(0)
+    for f in flags:
+        b.when(is_real).assert_bool(f)
+        total = total + f
+    b.when(is_real).assert_bool(total)
+    b.when(is_real).assert_eq(has, total)
+    b.when(is_real).assert_bool(has)
+    visited, first_gt, b_cmp = b.const(0), b.const(0), b.const(0)
+    for i in reversed(range(4)):
+        visited = visited + flags[i]
+        first_gt = first_gt + a[i] * flags[i]
+        b_cmp = b_cmp + bw[i] * flags[i]
+        b.when_not(visited).when(is_real).assert_eq(a[i], bw[i])
+    b.when(is_real).assert_eq(a_byte, first_gt)
+    b.when(is_real).assert_eq(b_byte, b_cmp)
+    r.send_byte(B_LTU, result, b_byte, a_byte, is_real)
+    r.send_byte(B_LTU, 1 - result, a_byte, b_byte, has)
+
+
+def _sys_linux(r: _Rec):
+    """SysLinuxChip::eval (syscall/precompiles/sys_linux/air.rs:29-477): the syscall id and a0 / a1 are decoded with IsZeroOperations into branch
+    selectors (mmap / mmap2, clone, exit_group, brk, fcntl, read, write; anything else is a no-op); each branch fixes `result` (the new $v0) and
+    the value written to $a3; brk, write and mmap(0) share one memory access (`inorout`: register BRK, $a2, register HEAP)."""
+    l, b = r.local, r.b
+    (SHARD, CLK, ID, A0, A1, RESULT, INOROUT, OUTPUT, D_MMAP, D_MMAP2, D_CLONE, D_EXIT, D_BRK, D_FCNTL, D_READ, D_WRITE, IS_MMAP, D_A0_0, D_A0_1, D_A0_2, D_A1_1, D_A1_3,
+     IS_MMAP_A0_0, IS_FCNTL_A1_1, IS_FCNTL_A1_3, LO_BITS, HI_BITS, PAGE_ZERO, MMAP_SIZE, SIZE_CARRY, HEAP_ADD, GT, IS_REAL) = (
+        0, 1, 2, 3, 7, 11, 15, 28, 41, 43, 45, 47, 49, 51, 53, 55, 57, 58, 60, 62, 64, 66, 68, 69, 70, 71, 75, 79, 81, 85, 87, 94, 102)
+    is_real = l[IS_REAL]
+    a0, a1, result = l[A0:A0 + 4], l[A1:A1 + 4], l[RESULT:RESULT + 4]
+    inorout, output = l[INOROUT:INOROUT + 13], l[OUTPUT:OUTPUT + 13]
+    in_prev, in_value, out_value = inorout[0:4], inorout[4:8], output[4:8]
+    sid = l[ID]
+    for code, col in ((E.SYS_MMAP, D_MMAP), (E.SYS_MMAP2, D_MMAP2), (E.SYS_CLONE, D_CLONE), (E.SYS_EXT_GROUP, D_EXIT), (E.SYS_BRK, D_BRK), (E.SYS_FCNTL, D_FCNTL),
+                      (E.SYS_READ, D_READ), (E.SYS_WRITE_LINUX, D_WRITE)):
+        _is_zero(b, sid - code, l[col:col + 2], is_real)
+    is_clone, is_exit, is_brk, is_fcntl, is_read, is_write = (l[c + 1] for c in (D_CLONE, D_EXIT, D_BRK, D_FCNTL, D_READ, D_WRITE))
+    is_mmap = l[IS_MMAP]
+    b.when(is_real).assert_eq(is_mmap, l[D_MMAP + 1] + l[D_MMAP2 + 1])
+    b.assert_bool(is_mmap)
+    is_nop = is_real - (is_mmap + is_clone + is_exit + is_brk + is_fcntl + is_read + is_write)
+    b.when(is_real).assert_bool(is_nop)
+    reduce = lambda w: w[0] + w[1] * 256 + w[2] * 65536 + w[3] * 16777216      # noqa: E731
+    _is_zero(b, reduce(a0), l[D_A0_0:D_A0_0 + 2], is_real)
+    _is_zero(b, reduce(a0) - 1, l[D_A0_1:D_A0_1 + 2], is_real)
+    _is_zero(b, reduce(a0) - 2, l[D_A0_2:D_A0_2 + 2], is_real)
+    _is_zero(b, reduce(a1) - 1, l[D_A1_1:D_A1_1 + 2], is_real)
+    _is_zero(b, reduce(a1) - 3, l[D_A1_3:D_A1_3 + 2], is_real)
+    is_a0_0, is_a0_1, is_a0_2, is_a1_1, is_a1_3 = (l[c + 1] for c in (D_A0_0, D_A0_1, D_A0_2, D_A1_1, D_A1_3))
+    b.assert_eq(l[IS_MMAP_A0_0], is_mmap * is_a0_0)
+    b.assert_eq(l[IS_FCNTL_A1_1], is_fcntl * is_a1_1)
+    b.assert_eq(l[IS_FCNTL_A1_3], is_fcntl * is_a1_3)
+    word_eq = lambda cond, x, y: [cond.assert_eq(x[i], y[i]) for i in range(4)]      # noqa: E731
+    word_zero = lambda cond, x: [cond.assert_zero(x[i]) for i in range(4)]          # noqa: E731
+    const_word = lambda v: [b.const((v >> (8 * i)) & 0xff) for i in range(4)]       # noqa: E731
+    word_eq(b.when(is_brk + is_write), in_value, in_prev)
+    # eval_brk (:213-241)
+    r.eval_memory_access(l[SHARD], l[CLK], b.const(E.REG_BRK), in_prev, inorout[4:13], is_brk)
+    _gt_bytes(r, a0, in_value, is_brk, l[GT:GT + 8])
+    gt = l[GT + 6]
+    word_eq(b.when(is_brk).when(gt), result, a0)
+    word_eq(b.when(is_brk).when_not(gt), result, in_prev)
+    word_zero(b.when(is_brk), out_value)
+    # eval_clone (:243-254)
+    word_zero(b.when(is_clone), out_value)
+    b.when(is_clone).assert_one(result[0])
+    for i in (1, 2, 3):
+        b.when(is_clone).assert_zero(result[i])
+    # eval_exit_group (:373-381)
+    word_zero(b.when(is_exit), out_value)
+    word_zero(b.when(is_exit), result)
+    # eval_fnctl (:383-436)
+    any_fd = is_a0_0 + is_a0_1 + is_a0_2
+    f11, f13 = l[IS_FCNTL_A1_1], l[IS_FCNTL_A1_3]
+    word_zero(b.when(f11).when(is_a0_0), result)
+    word_eq(b.when(f11).when(is_a0_1), result, const_word(1))
+    word_eq(b.when(f11).when(is_a0_2), result, const_word(2))
+    word_eq(b.when(f11).when_not(any_fd), result, const_word(0xffffffff))
+    word_zero(b.when(f13).when(is_a0_0), result)
+    word_eq(b.when(f13).when(is_a0_1 + is_a0_2), result, const_word(1))
+    word_eq(b.when(f13).when_not(any_fd), result, const_word(0xffffffff))
+    word_eq(b.when(is_fcntl).when_not(is_a1_3 + is_a1_1), result, const_word(0xffffffff))
+    word_zero(b.when(f13 + f11).when(any_fd), out_value)
+    word_eq(b.when(f13 + f11).when_not(any_fd), out_value, const_word(9))
+    word_eq(b.when(is_fcntl).when_not(is_a1_3 + is_a1_1), out_value, const_word(9))
+    # eval_read (:438-455)
+    word_zero(b.when(is_read).when(is_a0_0), result)
+    word_zero(b.when(is_read).when(is_a0_0), out_value)
+    word_eq(b.when(is_read).when_not(is_a0_0), result, const_word(0xffffffff))
+    word_eq(b.when(is_read).when_not(is_a0_0), out_value, const_word(9))
+    # eval_write (:457-471)
+    r.eval_memory_access(l[SHARD], l[CLK], b.const(E.REG_A2), in_prev, inorout[4:13], is_write)
+    word_eq(b.when(is_write), result, in_value)
+    word_zero(b.when(is_write), out_value)
+    # eval_mmap (:256-371)
+    r.slice_range_check_u8(a0, is_mmap)
+    r.slice_range_check_u8(a1, is_mmap)
+    lo = b.const(0)
+    for bit in range(4):
+        b.when(is_mmap).assert_bool(l[LO_BITS + bit])
+        lo = lo + l[LO_BITS + bit] * (1 << bit)
+    hi = b.const(0)
+    for bit in range(4):
+        b.when(is_mmap).assert_bool(l[HI_BITS + bit])
+        hi = hi + l[HI_BITS + bit] * (1 << bit)
+    b.when(is_mmap).assert_eq(a1[1], lo + hi * 16)
+    page_offset = a1[0] + lo * 256
+    _is_zero(b, page_offset, l[PAGE_ZERO:PAGE_ZERO + 2], is_mmap)
+    is_offset_0 = l[PAGE_ZERO + 1]
+    mm = l[IS_MMAP_A0_0]
+    not_aligned = mm * (1 - is_offset_0)
+    size, carry = l[MMAP_SIZE:MMAP_SIZE + 4], l[SIZE_CARRY:SIZE_CARRY + 2]
+    b.when(mm).assert_bool(carry[0])
+    b.when(mm).assert_bool(carry[1])
+    b.when(mm).assert_zero(size[0])
+    b.when(mm).assert_eq(size[1], hi * 16 + not_aligned * 16 - carry[0] * 256)
+    b.when(mm).assert_eq(size[2], a1[2] + carry[0] - carry[1] * 256)
+    b.when(mm).assert_eq(size[3], a1[3] + carry[1])
+    r.slice_range_check_u8(size, mm)
+    _add_op(r, in_prev, size, l[HEAP_ADD:HEAP_ADD + 7], mm)
+    word_eq(b.when(mm), in_value, l[HEAP_ADD:HEAP_ADD + 4])
+    r.eval_memory_access(l[SHARD], l[CLK], b.const(E.REG_HEAP), in_prev, inorout[4:13], mm)
+    word_eq(b.when(mm), in_prev, result)
+    word_eq(b.when(is_mmap).when_not(is_a0_0), a0, result)
+    word_zero(b.when(is_mmap), out_value)
+    # eval_nop (:473-476)
+    word_zero(b.when(is_nop), out_value)
+    word_zero(b.when(is_nop), result)
+    # the write of $a3, the syscall and its result
+    r.eval_memory_access(l[SHARD], l[CLK], b.const(E.REG_A3), output[0:4], output[4:13], is_real)
+    r.receives.append(air.Lookup([air.to_virtual_pair(v) for v in [l[SHARD], l[CLK], sid, reduce(a0), reduce(a1)]], air.to_virtual_pair(is_real), air.KIND_SYSCALL))
+    halves = lambda w: [w[0] + w[1] * 256, w[2] + w[3] * 256]      # noqa: E731
+    r.receives.append(air.Lookup([air.to_virtual_pair(v) for v in [l[SHARD], l[CLK]] + halves(result) + halves(a0) + halves(a1)],
+                                 air.to_virtual_pair(is_real), air.KIND_SYSCALL_RESULT))
+
+
+def record_sys_linux_constraints() -> _Rec:
+    r = _Rec(E.SYS_LINUX_WIDTH)
+    _sys_linux(r)
+    return r
+
+
+def record_sys_linux_chip(log_height: int) -> RecordedChip:
+    """SysLinux (crates/core/machine/src/syscall/precompiles/sys_linux/): one Linux syscall per row, 103 columns; not local_only (mod.rs leaves the default)."""
+    return _finish(record_sys_linux_constraints(), "SysLinux", log_height, E.SYS_LINUX_WIDTH, False)
+
+
 def _field_op_variable(r: _Rec, cols, a, bb, modulus, n_limbs, witness_offset, is_add, is_sub, is_mul, is_real):
     """FieldOpCols::eval_variable (operations/field/field_op.rs:227-261) with is_div = 0: the operation is chosen by flags, so the identity
     is the flag-weighted sum of the three."""

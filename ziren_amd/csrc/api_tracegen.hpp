@@ -884,6 +884,46 @@ int zkm_tracegen_boolean_circuit_garble(zkm_ctx* ctx, const zkm_garble_row* rows
   API_END
 }
 
+int zkm_tracegen_sys_linux(zkm_ctx* ctx, const zkm_linux_event* events, size_t n_events, int fixed_log2_rows, zkm_byte_lookups* blu, zkm_matrix** out) {
+  API_BEGIN
+  static_assert(sizeof(zkm_linux_event) == 4 * tracegen::LINUX_EVENT_WORDS, "flattened LinuxEvent is 23 words");
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIP_CHECK(hipSetDevice(ctx->device));
+  if (n_events && !events) throw std::runtime_error("zkm_tracegen_sys_linux: null events");
+  const size_t height = padded_trace_rows(n_events, fixed_log2_rows, "zkm_tracegen_sys_linux");
+  ctx->begin_timing();
+  zkm_matrix* m = new zkm_matrix();
+  m->h = height; m->w = tracegen::SYS_LINUX_WIDTH;
+  uint32_t* d_events = nullptr;
+  int* d_bad = nullptr;
+  try {
+    m->d = ctx->alloc_n<uint32_t>(height * m->w);
+    const size_t ev_bytes = n_events * sizeof(zkm_linux_event);
+    d_events = (uint32_t*)ctx->alloc(std::max<size_t>(ev_bytes, 4));
+    d_bad = (int*)ctx->alloc(4);
+    HIP_CHECK(hipMemsetAsync(d_bad, 0, 4, ctx->stream));
+    if (n_events) HIP_CHECK(hipMemcpyAsync(d_events, events, ev_bytes, hipMemcpyHostToDevice, ctx->stream));
+    uint32_t* counts = blu ? blu->counts : nullptr;
+    KLAUNCH(ctx, "tracegen_sys_linux", (double)ev_bytes + 4.0 * height * m->w, tracegen::sys_linux_rows, dim3(div_up(height, (size_t)256)), dim3(256),
+            counts ? 2 * tracegen::BF_HASH_SLOTS * sizeof(uint32_t) : 0, (const uint32_t*)d_events, n_events, height, m->d, counts, d_bad);
+    int bad = 0;
+    HIP_CHECK(hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, ctx->stream));
+    ctx->mark("trace generation");
+    ctx->end_timing(false);
+    if (bad) throw std::runtime_error("zkm_tracegen_sys_linux: an event does not return what its syscall returns (v0, the value written to $a3, the new heap)");
+  } catch (...) {
+    if (d_events) ctx->release(d_events);
+    if (d_bad) ctx->release(d_bad);
+    if (m->d) ctx->release(m->d);
+    delete m;
+    throw;
+  }
+  ctx->release(d_events);
+  ctx->release(d_bad);
+  *out = m;
+  API_END
+}
+
 // Base fields of the short-Weierstrass curves (crates/curves/src/weierstrass/{secp256k1,secp256r1,bn254,bls12_381}.rs): modulus, its Barrett
 // constant, the curve's `a`, as 32-bit limbs (generated from the reference's MODULUS bytes; tests compare the widths and costs they give)
 struct Curve8 { bigfield::Modulus<8> m; uint32_t a[8]; };

@@ -592,7 +592,7 @@ __device__ __forceinline__ void syscall_table_row(const uint32_t* p, uint32_t* r
   const uint32_t value = p[4], prev = p[7], arg1 = p[12], arg2 = p[13];
   r[0] = p[2]; r[1] = p[3]; r[2] = p[11];
   r[3] = arg1 & 0xffff; r[4] = arg1 >> 16; r[5] = arg2 & 0xffff; r[6] = arg2 >> 16;
-  const bool is_linux = !precompile && ((prev >> 8) & 0xff) != 0;
+  const bool is_linux = ((prev >> 8) & 0xff) != 0;      // Precompile: a Linux event's syscall event carries its code and v0 in the a_record
   r[7] = is_linux ? value & 0xffff : 0; r[8] = is_linux ? value >> 16 : 0;
   r[9] = fbool(is_linux);
   r[10] = 1;
@@ -2486,6 +2486,106 @@ __global__ __launch_bounds__(256) void garble_rows(const uint32_t* __restrict__ 
         if (last && g[R_WRITE] != (check[3] && g[R_PRE_CHECK] ? 1u : 0u)) why = why ? why : 4;
       }
       if (why) atomicMax(bad, 16 - why);
+    }
+  }
+  blk.flush(counts);
+}
+
+// ---- SysLinux (syscall/precompiles/sys_linux/columns.rs:20-82, trace.rs:104-233): one Linux syscall per row, 103 columns, from the flattened LinuxEvent
+// (shard, clk, a0, a1, v0, syscall_code, the read record of brk / write, the write record of $a3, the write record of HEAP for mmap with
+// a0 = 0). Refused (code 1): an event whose v0 / $a3 value is not what the syscall returns, or whose heap does not move by the rounded size.
+constexpr int SYS_LINUX_WIDTH = 103, LINUX_EVENT_WORDS = 23;
+__global__ __launch_bounds__(256) void sys_linux_rows(const uint32_t* __restrict__ events, size_t n_events, size_t height, uint32_t* __restrict__ out, uint32_t* counts,
+                                                      int* __restrict__ bad) {
+  enum { SHARD = 0, CLK = 1, ID = 2, A0 = 3, A1 = 7, RESULT = 11, INOROUT = 15, OUTPUT = 28, D_MMAP = 41, D_MMAP2 = 43, D_CLONE = 45, D_EXIT = 47, D_BRK = 49, D_FCNTL = 51,
+         D_READ = 53, D_WRITE = 55, IS_MMAP = 57, D_A0_0 = 58, D_A0_1 = 60, D_A0_2 = 62, D_A1_1 = 64, D_A1_3 = 66, IS_MMAP_A0_0 = 68, IS_FCNTL_A1_1 = 69, IS_FCNTL_A1_3 = 70,
+         LO_BITS = 71, HI_BITS = 75, PAGE_ZERO = 79, MMAP_SIZE = 81, SIZE_CARRY = 85, HEAP_ADD = 87, GT = 94, IS_REAL = 102 };
+  enum { MMAP = 4210, MMAP2 = 4090, CLONE = 4120, EXIT_GROUP = 4246, BRK = 4045, FCNTL = 4055, READ = 4003, WRITE = 4004 };
+  enum { E_A0 = 2, E_A1 = 3, E_V0 = 4, E_CODE = 5, E_READ = 6, E_A3 = 11, E_HEAP = 17 };
+  extern __shared__ uint32_t bf_lds[];
+  const BfBlock blk(bf_lds, counts);
+  const size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (row < height) {
+    const bool real = row < n_events;
+    const LookupSink sink{blk.hkeys, blk.hvals, BF_HASH_SLOTS - 1, counts};
+    const RowCols R{out, height, row, sink, blk.count && real};
+    if (!real) {
+      R.zeros(0, SYS_LINUX_WIDTH);
+    } else {
+      const uint32_t* e = events + row * LINUX_EVENT_WORDS;
+      const uint32_t code = e[E_CODE], a0 = e[E_A0], a1 = e[E_A1];
+      const bool mmap = code == MMAP || code == MMAP2, fd = a0 <= 2;
+      uint32_t r[SYS_LINUX_WIDTH];
+      for (int c = 0; c < SYS_LINUX_WIDTH; c++) r[c] = 0;
+      uint32_t v0 = 0, a3 = 0;
+      if (code == BRK) v0 = a0 > e[E_READ] ? a0 : e[E_READ];
+      else if (mmap) v0 = a0 == 0 ? e[E_HEAP + 3] : a0;
+      else if (code == CLONE) v0 = 1;
+      else if (code == FCNTL) {
+        if (a1 == 3) v0 = a0 == 0 ? 0u : fd ? 1u : 0xffffffffu;
+        else if (a1 == 1) v0 = fd ? a0 : 0xffffffffu;
+        else v0 = 0xffffffffu;
+        a3 = v0 == 0xffffffffu ? 9u : 0u;
+      } else if (code == READ) { v0 = a0 == 0 ? 0u : 0xffffffffu; a3 = a0 == 0 ? 0u : 9u; }
+      else if (code == WRITE) v0 = e[E_READ];
+      bool ok = v0 == e[E_V0] && a3 == e[E_A3];
+      auto lookups = [&](uint32_t v) { if (R.count) { lookup(sink, B_U8RANGE, v, v >> 8); lookup(sink, B_U8RANGE, v >> 16, v >> 24); } };
+      word(r + A0, a0); word(r + A1, a1); word(r + RESULT, e[E_V0]);
+      r[SHARD] = e[0] % kb::P; r[CLK] = e[1] % kb::P; r[ID] = code % kb::P; r[IS_REAL] = 1;
+      const uint32_t sid = code % kb::P, a0f = a0 % kb::P, a1f = a1 % kb::P;
+      is_zero_cols(sid, MMAP, r + D_MMAP); is_zero_cols(sid, MMAP2, r + D_MMAP2); is_zero_cols(sid, CLONE, r + D_CLONE); is_zero_cols(sid, EXIT_GROUP, r + D_EXIT);
+      is_zero_cols(sid, BRK, r + D_BRK); is_zero_cols(sid, FCNTL, r + D_FCNTL); is_zero_cols(sid, READ, r + D_READ); is_zero_cols(sid, WRITE, r + D_WRITE);
+      r[IS_MMAP] = mmap;
+      is_zero_cols(a0f, 0, r + D_A0_0); is_zero_cols(a0f, 1, r + D_A0_1); is_zero_cols(a0f, 2, r + D_A0_2);
+      is_zero_cols(a1f, 1, r + D_A1_1); is_zero_cols(a1f, 3, r + D_A1_3);
+      r[IS_MMAP_A0_0] = mmap && a0 == 0;
+      r[IS_FCNTL_A1_1] = code == FCNTL && a1 == 1;
+      r[IS_FCNTL_A1_3] = code == FCNTL && a1 == 3;
+      if (code == BRK) {        // GtColsBytes::populate (operations/cmp.rs:34-93) of a0 against the BRK register
+        const uint32_t bb = e[E_READ];
+        uint32_t res = 0, a_byte = 0, b_byte = 0;
+        bool flagged = false;
+        for (int k = 3; k >= 0 && !flagged; k--) {
+          const uint32_t x = (a0 >> (8 * k)) & 0xff, y = (bb >> (8 * k)) & 0xff;
+          if (x != y) { r[GT + k] = 1; a_byte = x; b_byte = y; res = x > y; flagged = true; }
+        }
+        r[GT + 4] = a_byte; r[GT + 5] = b_byte; r[GT + 6] = res; r[GT + 7] = flagged;
+        if (R.count) { lookup(sink, B_LTU, b_byte, a_byte); if (flagged) lookup(sink, B_LTU, a_byte, b_byte); }
+        lookups(a0); lookups(bb);
+      } else if (mmap) {
+        lookups(a0); lookups(a1);
+        const uint32_t byte1 = (a1 >> 8) & 0xff, lo = byte1 & 15, hi = byte1 >> 4;
+        for (int bit = 0; bit < 4; bit++) { r[LO_BITS + bit] = (lo >> bit) & 1; r[HI_BITS + bit] = (hi >> bit) & 1; }
+        const uint32_t page_off = a1 & 0xfff, upper = (a1 >> 12) << 12;
+        is_zero_cols(page_off, 0, r + PAGE_ZERO);
+        if (a0 == 0) {
+          const uint32_t size = page_off == 0 ? upper : upper + 0x1000;
+          word(r + MMAP_SIZE, size);
+          lookups(size);
+          if (page_off != 0 && hi == 15) { r[SIZE_CARRY] = 1; if (((a1 >> 16) & 0xff) == 255) r[SIZE_CARRY + 1] = 1; }
+          const uint32_t old_heap = e[E_HEAP + 3], sum = old_heap + size;      // AddOperation::populate (operations/add.rs:23-57)
+          ok = ok && e[E_HEAP] == sum;
+          word(r + HEAP_ADD, sum);
+          uint32_t carry = 0;
+          for (int k = 0; k < 3; k++) { carry = (((old_heap >> (8 * k)) & 0xff) + ((size >> (8 * k)) & 0xff) + carry) >> 8; r[HEAP_ADD + 4 + k] = carry; }
+          lookups(old_heap); lookups(size); lookups(sum);
+        }
+      }
+      for (int c = 0; c < SYS_LINUX_WIDTH; c++)
+        if (!(c >= INOROUT && c < OUTPUT + 13)) R.put(c, r[c]);
+      // inorout: the read of BRK / $a2 (the previous value is the value), or the write of HEAP; output: the write of $a3
+      if (code == BRK || code == WRITE) {
+        uint32_t w4[4];
+        word(w4, e[E_READ]);
+        for (int c = 0; c < 4; c++) R.put(INOROUT + c, w4[c]);
+        R.read_cols(INOROUT + 4, e + E_READ);
+      } else if (mmap && a0 == 0) {
+        R.write_cols(INOROUT, e + E_HEAP);
+      } else {
+        R.zeros(INOROUT, 13);
+      }
+      R.write_cols(OUTPUT, e + E_A3);
+      if (!ok) *bad = 1;
     }
   }
   blk.flush(counts);

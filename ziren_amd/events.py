@@ -833,6 +833,43 @@ def garble_gate_ok(gate_words, delta):
     return all((h0[i] ^ h1[i] ^ lb[i] ^ (delta[i] if t else 0)) == want[i] for i in range(4))
 
 
+# SysLinux (syscall/precompiles/sys_linux/): the Linux syscalls a MIPS guest's runtime makes — the codes with a non-zero second byte (4003 read, 4004
+# write, 4045 brk, 4055 fcntl, 4090 mmap2, 4120 clone, 4210 mmap, 4246 exit_group; every other one is a no-op returning 0). Each returns a value
+# in $v0 and writes $a3 (0, or 9 = EBADF); brk reads register BRK (34), write reads $a2, mmap with a0 = 0 bumps register HEAP (35)
+# (syscalls/precompiles/sys_linux/*.rs). LinuxEvent (events/precompiles/linux.rs:9-28) flattened: its one read record (brk, write) and its
+# write records (the $a3 write, and HEAP's for mmap with a0 = 0); the ones an event does not have are zero.
+SYS_READ, SYS_WRITE_LINUX, SYS_BRK, SYS_FCNTL, SYS_MMAP2, SYS_CLONE, SYS_MMAP, SYS_OPEN = 4003, 4004, 4045, 4055, 4090, 4120, 4210, 4005
+REG_BRK, REG_HEAP = 34, 35
+LINUX_EVENT = np.dtype([("shard", "<u4"), ("clk", "<u4"), ("a0", "<u4"), ("a1", "<u4"), ("v0", "<u4"), ("syscall_code", "<u4"), ("read_record", MEMORY_READ_RECORD),
+                        ("a3_record", MEMORY_WRITE_RECORD), ("heap_record", MEMORY_WRITE_RECORD)])
+assert LINUX_EVENT.itemsize == 4 * 23
+SYS_LINUX_WIDTH = 103      # SysLinuxCols (sys_linux/columns.rs:20-82)
+
+
+def linux_syscall(code, a0, a1, brk=0, heap=0, a2=0):
+    """What a Linux syscall does (syscalls/precompiles/sys_linux/): returns (v0, the value written to $a3, the new HEAP or None)."""
+    if code == SYS_BRK:
+        return max(a0, brk), 0, None
+    if code in (SYS_MMAP, SYS_MMAP2):
+        size = a1 if a1 & 0xfff == 0 else (a1 + 0x1000 - (a1 & 0xfff)) & 0xffffffff
+        return (heap, 0, (heap + size) & 0xffffffff) if a0 == 0 else (a0, 0, None)
+    if code == SYS_CLONE:
+        return 1, 0, None
+    if code == SYS_EXT_GROUP:
+        return 0, 0, None
+    if code == SYS_FCNTL:
+        if a1 == 3:
+            return (0, 0, None) if a0 == 0 else (1, 0, None) if a0 in (1, 2) else (0xffffffff, 9, None)
+        if a1 == 1:
+            return (a0, 0, None) if a0 in (0, 1, 2) else (0xffffffff, 9, None)
+        return 0xffffffff, 9, None
+    if code == SYS_READ:
+        return (0, 0, None) if a0 == 0 else (0xffffffff, 9, None)
+    if code == SYS_WRITE_LINUX:
+        return a2, 0, None
+    return 0, 0, None
+
+
 # The field-tower precompiles (syscall/precompiles/fptower/fp.rs, fp2_addsub.rs, fp2_mul.rs) over the base fields of Bn254 and Bls12381: FpOpEvent,
 # Fp2AddSubEvent, Fp2MulEvent (events/precompiles/fptower.rs:23-94) flattened; `op` is FieldOperation as a word (Add 0, Mul 1, Sub 2).
 FP_TOWER_CODES = {"Bn254": dict(fp_add=0x01010026, fp_sub=0x01010027, fp_mul=0x01010028, fp2_add=0x01010029, fp2_sub=0x0101002A, fp2_mul=0x0101002B),

@@ -96,7 +96,7 @@ class Machine:
 def run_machine(n_cycles: int = 0, seed: int = 1, pc_base: int = 0x1000, shard_cycles: int = 1 << 30, program=None, poseidon2_calls: int = 0,
                 memory_chunk: int = 1 << 30, keccak_calls: int = 0, sha_calls: int = 0, ed_calls: int = 0,
                 curve_calls=None, fp_calls=None, decompress_calls=None, uint256_calls: int = 0, u2048_calls: int = 0,
-                garble_calls=()) -> Machine:
+                garble_calls=(), linux_calls=()) -> Machine:
     """A whole run as the reference's prover sees it (crates/core/machine/src/utils/prove.rs:255-400): CPU shards of at most `shard_cycles`
     cycles (never split between a branch and its delay slot, executor.rs:2352-2356), then one shard with the deferred precompile events
     (ExecutionRecord::split, record.rs:130-218), then the shards that initialise and finalise every touched address
@@ -105,13 +105,14 @@ def run_machine(n_cycles: int = 0, seed: int = 1, pc_base: int = 0x1000, shard_c
     spread over a generated run (each kind is deferred to a precompile shard of its own, record.rs:150-185)."""
     return _execute(n_cycles, seed, 1, pc_base, True, shard_cycles=shard_cycles, given=program, poseidon2_calls=poseidon2_calls, memory_chunk=memory_chunk,
                     machine=True, keccak_calls=keccak_calls, sha_calls=sha_calls, ed_calls=ed_calls, curve_calls=curve_calls, fp_calls=fp_calls, decompress_calls=decompress_calls,
-                    uint256_calls=uint256_calls, u2048_calls=u2048_calls, garble_calls=garble_calls)
+                    uint256_calls=uint256_calls, u2048_calls=u2048_calls, garble_calls=garble_calls,
+                    linux_calls=linux_calls)
 
 
 def _execute(n_cycles: int, seed: int = 1, shard: int = 1, pc_base: int = 0x1000, halt: bool = False, shard_cycles: int = 1 << 30, given=None,
              poseidon2_calls: int = 0, memory_chunk: int = 1 << 30, machine: bool = False, keccak_calls: int = 0, sha_calls: int = 0, ed_calls: int = 0,
              curve_calls=None, fp_calls=None, decompress_calls=None, uint256_calls: int = 0, u2048_calls: int = 0,
-             garble_calls=()) -> Machine:
+             garble_calls=(), linux_calls=()) -> Machine:
     """Execute `n_cycles` instructions of a program generated on the way. Returns (program, record, public_values) with
     program: INSTRUCTION array (instructions that were jumped over are `ADD $0, 0, 0` no-ops that never run), record:
     structured event arrays, public_values: dict of the words the Cpu chip checks (start_pc, next_pc, execution_shard).
@@ -178,7 +179,7 @@ def _execute(n_cycles: int, seed: int = 1, shard: int = 1, pc_base: int = 0x1000
     s_at = set(int(x) for x in np.linspace(n_cycles // 5, max(n_cycles - 80, n_cycles // 5), sha_calls)) - p2_at - k_at if sha_calls else set()
     s_seq = 0
     e_at = {n_cycles // 4} - p2_at - k_at - s_at if ed_calls else set()
-    w_at = {n_cycles // 3} - p2_at - k_at - s_at - e_at if curve_calls or decompress_calls or uint256_calls or u2048_calls or garble_calls else set()
+    w_at = {n_cycles // 3} - p2_at - k_at - s_at - e_at if curve_calls or decompress_calls or uint256_calls or u2048_calls or garble_calls or linux_calls else set()
     f_at = {n_cycles // 2} - p2_at - k_at - s_at - e_at - w_at if fp_calls else set()
     clk_extra = 0                  # the extra cycles of the shard's syscalls so far (Syscall::num_extra_cycles, executor.rs:1641)
 
@@ -347,6 +348,12 @@ def _execute(n_cycles: int, seed: int = 1, shard: int = 1, pc_base: int = 0x1000
                 for i, w in enumerate(words):
                     queued += [(E.ADD, 30, w, 0, 1, 1), (E.SW, 30, 0, input_ptr + 4 * i, 0, 1)]
                 queued += [(E.ADD, E.REG_V0, E.SYS_BOOLEAN_CIRCUIT_GARBLE, 0, 1, 1), (E.ADD, E.REG_A0, input_ptr, 0, 1, 1), (E.ADD, E.REG_A1, output_ptr, 0, 1, 1),
+                           (E.SYSCALL, E.REG_V0, E.REG_A0, E.REG_A1, 0, 0)]
+            # per entry of `linux_calls` — (code, a0, a1) or (code, a0, a1, a2) — a Linux syscall: $v0 = code, $a0, $a1 (and $a2) set, SYSCALL
+            for call in linux_calls:
+                if len(call) > 3:
+                    queued += [(E.ADD, E.REG_A2, call[3], 0, 1, 1)]
+                queued += [(E.ADD, E.REG_V0, call[0], 0, 1, 1), (E.ADD, E.REG_A0, call[1], 0, 1, 1), (E.ADD, E.REG_A1, call[2], 0, 1, 1),
                            (E.SYSCALL, E.REG_V0, E.REG_A0, E.REG_A1, 0, 0)]
             n_cycles += len(queued) - had
             p2_at = set(x + len(queued) - had if x > cyc else x for x in p2_at)
@@ -553,7 +560,8 @@ def _execute(n_cycles: int, seed: int = 1, shard: int = 1, pc_base: int = 0x1000
             w_curve = {c[k]: (name, k == "double") for name, c in E.WEIERSTRASS_CURVES.items() for k in ("add", "double")}.get(code)
             fp_call = {c: (field, name) for field, codes in E.FP_TOWER_CODES.items() for name, c in codes.items()}.get(code)
             w_decompress = {d["code"]: name for name, d in E.WEIERSTRASS_DECOMPRESS.items()}.get(code)
-            assert w_curve or fp_call or w_decompress or code in (E.SYS_UINT256_MUL, E.SYS_U256XU2048_MUL, E.SYS_BOOLEAN_CIRCUIT_GARBLE) or code in (E.SYS_HALT, E.SYS_COMMIT, E.SYS_POSEIDON2_PERMUTE, E.SYS_KECCAK_SPONGE, E.SYS_SHA_EXTEND, E.SYS_SHA_COMPRESS, E.SYS_ED_ADD,
+            is_linux = (code >> 8) & 0xff != 0 and code < 0x10000
+            assert is_linux or w_curve or fp_call or w_decompress or code in (E.SYS_UINT256_MUL, E.SYS_U256XU2048_MUL, E.SYS_BOOLEAN_CIRCUIT_GARBLE) or code in (E.SYS_HALT, E.SYS_COMMIT, E.SYS_POSEIDON2_PERMUTE, E.SYS_KECCAK_SPONGE, E.SYS_SHA_EXTEND, E.SYS_SHA_COMPRESS, E.SYS_ED_ADD,
                                         E.SYS_ED_DECOMPRESS), code
             touched = {}                               # address -> [initial (shard, timestamp, value), final]: SyscallContext's local map
 
@@ -735,6 +743,20 @@ def _execute(n_cycles: int, seed: int = 1, shard: int = 1, pc_base: int = 0x1000
                 rows_[-1][10] = mem(c, clk, int(running))
                 local = [(addr, v[0], v[1]) for addr, v in sorted(touched.items())]
                 precompile.append(("garble", (pc, next_pc, shard, clk, (0, 0, 0, 0, 0, 0), 0, [0, 0, 0], sid, b, c), [tuple(x) for x in rows_], local))
+            returned = None
+            if is_linux:
+                # the Linux syscalls (syscalls/precompiles/sys_linux/*.rs): brk reads register BRK, write reads $a2, mmap with a0 = 0 moves register
+                # HEAP; every one writes $a3 (0, or 9 = EBADF) and returns a value for $v0; all at clk, no extra cycle. Filed under SYS_LINUX; the
+                # SyscallPrecompile table learns of the call's code and result through the syscall event's a_record (prev_value, value)
+                assert code != E.SYS_EXT_GROUP, "exit_group halts: not generated"
+                no_read, no_write = (0, 0, 0, 0, 0), (0, 0, 0, 0, 0, 0)
+                read_rec = mem(E.REG_BRK, clk) if code == E.SYS_BRK else mem(E.REG_A2, clk) if code == E.SYS_WRITE_LINUX else no_read
+                v0, a3, new_heap = E.linux_syscall(code, b, c, brk=read_rec[0], heap=R.get(E.REG_HEAP, 0), a2=read_rec[0])
+                a3_rec = mem(E.REG_A3, clk, a3)
+                heap_rec = mem(E.REG_HEAP, clk, new_heap) if new_heap is not None else no_write
+                local = [(addr, v[0], v[1]) for addr, v in sorted(touched.items())]
+                precompile.append(("linux", (pc, next_pc, shard, clk, (v0, 0, 0, code, 0, 0), 0, [0, 0, 0], sid, b, c), [(shard, clk, b, c, v0, code, read_rec, a3_rec, heap_rec)], local))
+                returned = v0
             if w_decompress:
                 # create_ec_decompress_event (events/precompiles/ec.rs:181-228): x is read at ptr + N, the y the sign bit ($a1) selects is written at
                 # ptr, both at clk; no extra cycle
@@ -768,7 +790,7 @@ def _execute(n_cycles: int, seed: int = 1, shard: int = 1, pc_base: int = 0x1000
                 event = (shard, clk, b, c, xwr, yr) if kind == "fp2_mul" else (shard, clk, b, c, op, xwr, yr)
                 precompile.append((field + "_" + kind, (pc, next_pc, shard, clk, (0, 0, 0, 0, 0, 0), 0, [0, 0, 0], sid, b, c), [event], local))
                 clk_extra += 1
-            a = code                                       # none of them returns a value: V0 keeps the code
+            a = code if returned is None else returned     # only the Linux syscalls return a value; otherwise $v0 keeps the code
             a_rec = write(op_a, a, clk, POS_A)
             hi = code
             next_pc_after = 0 if code == E.SYS_HALT else next_pc
@@ -880,7 +902,7 @@ def _execute(n_cycles: int, seed: int = 1, shard: int = 1, pc_base: int = 0x1000
     n_shard = shards[-1].pv["shard"]
     for kind, dt in (("poseidon2", E.POSEIDON2_PERMUTE_EVENT), ("keccak", E.KECCAK_SPONGE_BLOCK), ("sha_extend", E.SHA_EXTEND_EVENT),
                      ("sha_compress", E.SHA_COMPRESS_EVENT), ("ed_add", E.ED_ADD_EVENT),
-                     ("ed_decompress", E.ED_DECOMPRESS_EVENT), ("uint256_mul", E.UINT256_MUL_EVENT), ("u256x2048_mul", E.U256X2048_MUL_EVENT), ("garble", E.GARBLE_ROW)) + tuple(
+                     ("ed_decompress", E.ED_DECOMPRESS_EVENT), ("uint256_mul", E.UINT256_MUL_EVENT), ("u256x2048_mul", E.U256X2048_MUL_EVENT), ("garble", E.GARBLE_ROW), ("linux", E.LINUX_EVENT)) + tuple(
             (curve + suffix, E.weierstrass_event_dtypes(curve)[k]) for curve in E.WEIERSTRASS_CURVES for k, suffix in ((0, "_add"), (1, "_double"))) + tuple(
             (curve + "_decompress", E.weierstrass_decompress_event_dtype(curve)) for curve in E.WEIERSTRASS_DECOMPRESS) + tuple(
             (field + "_" + kind, E.fp_tower_event_dtype(field, kind)) for field in E.FP_TOWER_CODES for kind in ("fp", "fp2_addsub", "fp2_mul")):
@@ -900,6 +922,7 @@ def _execute(n_cycles: int, seed: int = 1, shard: int = 1, pc_base: int = 0x1000
         o.uint256_mul = arr([ev for e in mine for ev in e[2]] if kind == "uint256_mul" else [], E.UINT256_MUL_EVENT)
         o.u256x2048_mul = arr([ev for e in mine for ev in e[2]] if kind == "u256x2048_mul" else [], E.U256X2048_MUL_EVENT)
         o.garble = arr([ev for e in mine for ev in e[2]] if kind == "garble" else [], E.GARBLE_ROW)
+        o.linux = arr([ev for e in mine for ev in e[2]] if kind == "linux" else [], E.LINUX_EVENT)
         o.weierstrass = (kind, arr([ev for e in mine for ev in e[2]], dt)) if kind.endswith(("_add", "_double")) and kind.split("_")[0] in E.WEIERSTRASS_CURVES else None
         o.weierstrass_decompress = (kind.split("_")[0], arr([ev for e in mine for ev in e[2]], dt)) if kind.endswith("_decompress") and kind != "ed_decompress" else None
         o.fp_tower = (kind, arr([ev for e in mine for ev in e[2]], dt)) if kind.split("_")[0] in E.FP_TOWER_CODES and "_fp" in kind else None

@@ -319,6 +319,15 @@ class Context:
                                                                  C.c_int(fixed_log2_rows), blu.h if blu is not None else None, C.byref(h)))
         return self._born(h)
 
+    def tracegen_sys_linux(self, events: np.ndarray, fixed_log2_rows: int = -1, blu: "ByteLookups" = None) -> DeviceMatrix:
+        """`generate_trace` of the SysLinux chip on the device (zkm_tracegen_sys_linux); dtype events.LINUX_EVENT, one row each."""
+        from . import events as _ev
+        ev = np.ascontiguousarray(events, dtype=_ev.LINUX_EVENT)
+        h = C.c_void_p()
+        lib.check(lib.load().zkm_tracegen_sys_linux(self.h, C.c_void_p(ev.ctypes.data if len(ev) else None), C.c_size_t(len(ev)),
+                                                    C.c_int(fixed_log2_rows), blu.h if blu is not None else None, C.byref(h)))
+        return self._born(h)
+
     def tracegen_fp_tower(self, field: str, kind: str, events: np.ndarray, fixed_log2_rows: int = -1, blu: "ByteLookups" = None) -> DeviceMatrix:
         """`generate_trace` of <Field>FpOpAssign / Fp2AddSubAssign / Fp2MulAssign on the device (zkm_tracegen_fp_op / _fp2_addsub / _fp2_mul); field
         "Bn254" or "Bls12381", kind "fp" / "fp2_addsub" / "fp2_mul", dtype events.fp_tower_event_dtype(field, kind)."""
