@@ -86,7 +86,7 @@ def sweep(oracle, m):
     return seen, holes
 
 
-def windowed_sweep(rec, chip, t, rows, chunk=512):
+def windowed_sweep(rec, chip, t, rows, chunk=4096):
     """The same question for a chip whose rows come many to an event (KeccakSponge, ShaExtend, ShaCompress): every column, changed on one of
     `rows`, must be noticed by a constraint or by the chip's lookups. The constraints only look at a row and its successor, so all variants
     of a row are evaluated in one pass over a stack of three-row windows (`rows` must not contain the first or the last row of the table:
@@ -105,14 +105,28 @@ def windowed_sweep(rec, chip, t, rows, chunk=512):
             stack[at, cols] = (stack[at, cols] + 1) % F.P
             bad = air.violated_rows(rec.b, stack)
             caught[cols] |= bad[at - 1] | bad[at]          # the changed row as `next`, then as `local`
-        one = chips.RecordedChip(name=chip.name, log_height=0, main_width=w, sends=chip.sends, receives=chip.receives)
-        one.trace, one.prep_trace = F.to_monty(t[r:r + 1]), None
-        base = lookup_tally([one])
-        for col in np.nonzero(~caught)[0]:
-            row = t[r:r + 1].copy()
-            row[0, col] = (row[0, col] + 1) % F.P
-            one.trace = F.to_monty(row)
-            caught[col] = lookup_tally([one]) != base
+        # the lookups of the row: for every column nothing has noticed yet, the exact difference between the signed multiset the changed row
+        # sends / receives and the honest row's (all candidates in one pass per lookup: row 0 of the stack is the honest row)
+        cand = np.nonzero(~caught)[0]
+        if not len(cand):
+            continue
+        n = len(cand) + 1
+        stack = np.tile(t[r:r + 1], (n, 1))
+        stack[1 + np.arange(len(cand)), cand] = (stack[1 + np.arange(len(cand)), cand] + 1) % F.P
+        main = {c: stack[:, c] for c in range(w)}
+        delta = [dict() for _ in range(n)]
+        for sign, lks in ((1, chip.sends), (-1, chip.receives)):
+            for lk in lks:
+                vals = np.stack([np.broadcast_to(v.apply_np({}, main), (n,)) for v in lk.values], axis=1)
+                mult = np.broadcast_to(lk.multiplicity.apply_np({}, main), (n,))
+                for i in np.nonzero((vals != vals[0]).any(axis=1) | (mult != mult[0]))[0]:
+                    d = delta[i]
+                    for which, weight in ((0, -sign), (i, sign)):
+                        if mult[which]:
+                            key = (lk.kind,) + tuple(int(x) for x in vals[which])
+                            d[key] = (d.get(key, 0) + weight * int(mult[which])) % F.P
+        for k, col in enumerate(cand):
+            caught[col] = any(delta[1 + k].values())
     return [int(c) for c in np.nonzero(~caught)[0]]
 
 
