@@ -645,6 +645,14 @@ int zkm_poseidon2_permute_batch_int(zkm_ctx* ctx, uint32_t* states, size_t n);
  * (Pcs::commit passes GENERATOR / domain_shift). */
 int zkm_coset_lde_batch(zkm_ctx* ctx, const uint32_t* host_row_major, size_t height, size_t width,
                         uint32_t log_blowup, uint32_t lde_shift, uint32_t* out_row_major);
+
+/* generate_permutation_trace of one chip (crates/stark/src/permutation.rs:102-196; called from prover.rs:337-365 inside `open`): the LogUp columns —
+ * per batch of lookups the sum of multiplicity / (alpha + kind + sum beta^k value_k) — and the running sum in the last extension column, from the
+ * chip's main (and preprocessed, may be null when prep_width is 0) trace and the two permutation challenges (alpha, beta: 8 Montgomery words).
+ * `*out`: height x 4 perm_ext_width; local_sum: the cumulative sum (4 words). A test entry point; `zkm_open` does this itself. */
+int zkm_permutation_trace(zkm_ctx* ctx, const zkm_chip_desc* chip, const zkm_matrix* main, const zkm_matrix* prep, const uint32_t challenges[8],
+                          zkm_matrix** out, uint32_t local_sum[4]);
+
 /* Host-side duplex challenger (DuplexChallenger<KoalaBear,Perm,16,8>), used by zkm_open. */
 void zkm_challenger_init(zkm_challenger* c);
 void zkm_challenger_observe(zkm_challenger* c, const uint32_t* values, size_t n);

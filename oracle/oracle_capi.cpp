@@ -342,6 +342,25 @@ int orc_prove_shard(const orc_pk* k, size_t n_chips, const zkm_chip_desc* descs,
   ORC_CATCH
 }
 
+// generate_permutation_trace (crates/stark/src/permutation.rs:102-196) of one chip on its own: main (and prep, nullable) row-major Montgomery, the two
+// permutation challenges as 8 Montgomery words (alpha, beta); out: height x 4 * perm_ext_width row-major Montgomery, local_sum: 4 words.
+int orc_permutation_trace(const zkm_chip_desc* desc, const uint32_t* main, const uint32_t* prep, size_t height, const uint32_t challenges[8], uint32_t* out,
+                          size_t out_cap, uint32_t local_sum[4]) {
+  ORC_TRY
+  const Chip chip = parse_chip(*desc);
+  const Matrix m = load_matrix(main, height, desc->main_width);
+  Matrix pm;
+  if (prep) pm = load_matrix(prep, height, desc->prep_width);
+  E alpha, beta, sum;
+  for (int c = 0; c < 4; c++) { alpha.c[c] = from_monty(challenges[c]); beta.c[c] = from_monty(challenges[4 + c]); }
+  const Matrix t = generate_permutation_trace(chip, prep ? &pm : nullptr, m, alpha, beta, sum);
+  if (t.h * t.w > out_cap) throw std::runtime_error("permutation trace buffer too small");
+  for (size_t r = 0; r < t.h; r++)
+    for (size_t c = 0; c < t.w; c++) out[r * t.w + c] = to_monty(t.at(r, c));
+  for (int c = 0; c < 4; c++) local_sum[c] = to_monty(sum.c[c]);
+  ORC_CATCH
+}
+
 // Verifier::verify_shard on a proof stream. challenger: post vk.observe_into. *verdict = 0 accept.
 int orc_verify_shard(const orc_pk* k, size_t n_chips, const zkm_chip_desc* descs, const zkm_fri_config* fri,
                      uint32_t num_pv_elts, zkm_challenger* challenger, const uint32_t* proof, size_t proof_len,

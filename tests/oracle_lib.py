@@ -179,6 +179,20 @@ def prove_shard(pk, chips, traces, public_values, fri, num_pv_elts, challenger, 
     return out[:plen.value].copy(), (timings[0], timings[1])
 
 
+def permutation_trace(chip, main, prep, alpha, beta):
+    """generate_permutation_trace of one chip (oracle/stark.hpp): main / prep row-major Montgomery, alpha / beta four Montgomery words each.
+    Returns (height x 4 perm_ext_width, the cumulative sum)."""
+    descs, keep = abi.make_chip_descs([chip])
+    main = np.ascontiguousarray(main, dtype=np.uint32)
+    prep = None if prep is None else np.ascontiguousarray(prep, dtype=np.uint32)
+    ch = np.ascontiguousarray(list(alpha) + list(beta), dtype=np.uint32)
+    out = np.zeros((main.shape[0], 4 * chip.perm_ext_width), dtype=np.uint32)
+    total = np.zeros(4, dtype=np.uint32)
+    _check(lib().orc_permutation_trace(descs, abi.as_u32p(main), abi.as_u32p(prep) if prep is not None else None, C.c_size_t(main.shape[0]), abi.as_u32p(ch),
+                                       abi.as_u32p(out), C.c_size_t(out.size), abi.as_u32p(total)))
+    return out, total
+
+
 def verify_shard(pk, chips, fri, num_pv_elts, challenger, proof):
     descs, keep = abi.make_chip_descs(chips)
     proof = np.ascontiguousarray(proof, dtype=np.uint32)

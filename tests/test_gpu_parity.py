@@ -537,3 +537,41 @@ def test_baseline_config3_syn22_main_commit_bit_exact(hip_ctx, oracle):
     hip_ctx.trim()
     want, _, _ = oracle.pcs_commit(_sorted_traces(sh), 1)
     assert np.array_equal(got, want)
+
+
+@pytest.mark.gpu
+def test_permutation_trace_matches_oracle_on_its_own(hip_ctx, oracle):
+    """zkm_permutation_trace (the LogUp step `open` runs between the main and the permutation commitments) against the restated
+    generate_permutation_trace (crates/stark/src/permutation.rs:102-196), cell by cell and with the cumulative sum: the synthetic chips of a
+    shard (with and without preprocessed columns, tall and short), and recorded core chips on executor traces — among them the Global chip
+    (lookups whose multiplicities are expressions) and the Byte chip (65536 rows, preprocessed table, ten receives per row)."""
+    from ziren_amd import chips as CH, miniexec as M
+    import machine_lib as ML
+    rng = np.random.default_rng(21)
+    challenge = lambda: [int(x) for x in F.to_monty(rng.integers(0, F.P, 4, dtype=np.uint64).astype(np.uint32))]      # noqa: E731
+    cases = [(c, c.trace, c.prep_trace) for c in synth.syn_shard(12, with_prep=True).chips]
+    m = M.run_machine(1500, seed=3, shard_cycles=1 << 20, poseidon2_calls=1)
+    byte_prep = oracle.tracegen_byte_table()
+    prog_prep = oracle.tracegen_program(0, m.shards[0].record.cpu, m.program, m.pc_base, ML.log2_rows(len(m.program)))
+    for k in range(len(m.shards)):
+        cs = ML.build_shard(ML.Oracle(oracle), m, k)
+        cs[-2].prep_trace, cs[-1].prep_trace = byte_prep, prog_prep
+        cases += [(c, c.trace, c.prep_trace) for c in cs if k == 0 or c.name not in ("Byte", "Program")]
+    assert len(cases) >= 8
+    checked = 0
+    for chip, trace, prep in cases:
+        if chip.prep_width and prep is None:
+            continue
+        alpha, beta = challenge(), challenge()
+        want, want_sum = oracle.permutation_trace(chip, trace, prep, alpha, beta)
+        main_d = hip_ctx.upload(trace)
+        prep_d = hip_ctx.upload(prep) if chip.prep_width else None
+        got, got_sum = hip_ctx.permutation_trace(chip, main_d, prep_d, alpha, beta)
+        assert (got.height, got.width) == want.shape, chip.name
+        assert np.array_equal(got.to_host(), want), chip.name
+        assert np.array_equal(got_sum, want_sum) and np.array_equal(want_sum, want[-1, -4:] if want.shape[1] else np.zeros(4, dtype=np.uint32)), chip.name
+        got.free(); main_d.free()
+        if prep_d is not None:
+            prep_d.free()
+        checked += 1
+    assert checked >= 25 and {"Global", "Byte", "Cpu", "Poseidon2Permute", "MemoryGlobalInit"} <= {c.name for c, _, _ in cases}

@@ -111,6 +111,24 @@ static ChipMeta chip_meta(const zkm_chip_desc* d, size_t n, size_t n_public_valu
 // One `open` call: the state that crosses Fiat-Shamir phases and one method per phase, in the order of prover.rs:298-653. Every device
 // buffer allocated on the way and not yet handed to an owner is in `loose` and goes back to the pool when the object dies (also on an
 // exception): a bad shard in a long-running farm must not leak HBM.
+// One chip's permutation trace (crates/stark/src/permutation.rs:102-196) into `pt` (allocated, n x 4 perm_ext_w): perm_rows fills the batched
+// reciprocal columns and the per-row sums, the three-phase scan turns the last extension column into the running sum. `salloc` hands out
+// scratch that lives until the caller's stream has passed.
+template <typename Alloc>
+static void launch_permutation_trace(zkm_ctx* ctx, const ChipMeta& c, const uint32_t* d_blob, const uint32_t* trace, const uint32_t* prep, const E4& alpha,
+                                     const E4* d_beta_powers, zkm_matrix& pt, Alloc&& salloc) {
+  KLAUNCH(ctx, "perm_rows", 4.0 * c.n * (c.desc->main_width + c.desc->prep_width + pt.w), stark::perm_rows, dim3(div_up(c.n, stark::THREADS)), dim3(stark::THREADS), 0,
+          d_blob, c.n_lookups, c.n_sends, 1 << c.desc->log_quotient_degree, trace, prep, c.n, alpha, d_beta_powers, pt.d, c.perm_ext_w);
+  uint32_t* last = pt.d + (size_t)(c.perm_ext_w - 1) * 4 * c.n;      // inclusive scan of the last ext column (4 base columns)
+  const size_t nchunks = (c.n + stark::SCAN_BLOCK - 1) / stark::SCAN_BLOCK;
+  uint32_t* totals = (uint32_t*)salloc(nchunks * 4 * 4);
+  KLAUNCH(ctx, "scan", 32.0 * c.n, stark::scan_chunks, dim3((unsigned)nchunks, 4), dim3(stark::THREADS), 0, last, c.n, totals, nchunks);
+  if (nchunks > 1) {
+    KLAUNCH(ctx, "scan", 0.0, stark::scan_totals, dim3(4), dim3(stark::THREADS), 0, totals, nchunks);
+    KLAUNCH(ctx, "scan", 32.0 * c.n, stark::scan_add_offsets, dim3((unsigned)nchunks, 4), dim3(stark::THREADS), 0, last, c.n, (const uint32_t*)totals, nchunks);
+  }
+}
+
 struct ShardOpening {
   struct Loose {
     zkm_ctx* ctx;
@@ -210,21 +228,9 @@ struct ShardOpening {
       if (c.perm_ext_w > 0) {
         d_blobs[i] = (uint32_t*)ctx->upload(c.desc->lookups, c.desc->lookups_len * 4, &scratch);
         const uint32_t* prep = c.desc->prep_index >= 0 ? pk->prep[c.desc->prep_index].d : nullptr;
-        KLAUNCH(ctx, "perm_rows", 4.0 * c.n * (c.desc->main_width + c.desc->prep_width + pt.w), stark::perm_rows,
-                dim3(div_up(c.n, stark::THREADS)), dim3(stark::THREADS), 0, (const uint32_t*)d_blobs[i], c.n_lookups, c.n_sends,
-                1 << c.desc->log_quotient_degree, (const uint32_t*)md->traces[i].d, prep, c.n, perm_ch[0], (const E4*)d_bp, pt.d,
-                c.perm_ext_w);
-        // inclusive scan of the last ext column (4 base columns)
+        launch_permutation_trace(ctx, c, (const uint32_t*)d_blobs[i], (const uint32_t*)md->traces[i].d, prep, perm_ch[0], (const E4*)d_bp, pt,
+                                 [&](size_t bytes) { return salloc(bytes); });
         uint32_t* last = pt.d + (size_t)(c.perm_ext_w - 1) * 4 * c.n;
-        size_t nchunks = (c.n + stark::SCAN_BLOCK - 1) / stark::SCAN_BLOCK;
-        uint32_t* totals = (uint32_t*)salloc(nchunks * 4 * 4);
-        KLAUNCH(ctx, "scan", 32.0 * c.n, stark::scan_chunks, dim3((unsigned)nchunks, 4), dim3(stark::THREADS), 0, last, c.n, totals,
-                nchunks);
-        if (nchunks > 1) {
-          KLAUNCH(ctx, "scan", 0.0, stark::scan_totals, dim3(4), dim3(stark::THREADS), 0, totals, nchunks);
-          KLAUNCH(ctx, "scan", 32.0 * c.n, stark::scan_add_offsets, dim3((unsigned)nchunks, 4), dim3(stark::THREADS), 0, last, c.n,
-                  (const uint32_t*)totals, nchunks);
-        }
         for (int e = 0; e < 4; e++) sum_src.push_back(last + (size_t)e * c.n + (c.n - 1));
       } else {
         for (int e = 0; e < 4; e++) sum_src.push_back(nullptr);

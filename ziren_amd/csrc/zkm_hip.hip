@@ -580,6 +580,48 @@ int zkm_coset_lde_batch(zkm_ctx* ctx, const uint32_t* host, size_t height, size_
   API_END
 }
 
+// One chip's permutation trace on its own (the step `open` runs between the main and the permutation commitments): a fine-grained entry point
+// for parity tests, like zkm_coset_lde_batch.
+int zkm_permutation_trace(zkm_ctx* ctx, const zkm_chip_desc* chip, const zkm_matrix* main, const zkm_matrix* prep, const uint32_t challenges[8], zkm_matrix** out,
+                          uint32_t local_sum[4]) {
+  API_BEGIN
+  if (!chip || !main || !challenges || !out || !local_sum) throw std::runtime_error("zkm_permutation_trace: null argument");
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIP_CHECK(hipSetDevice(ctx->device));
+  if (main->w != chip->main_width) throw std::runtime_error("zkm_permutation_trace: chip main_width does not match its trace");
+  if (chip->prep_width && (!prep || prep->w != chip->prep_width || prep->h != main->h)) throw std::runtime_error("zkm_permutation_trace: the chip's preprocessed trace is missing or of another shape");
+  const ChipMeta c = chip_meta(chip, main->h, (size_t)-1);
+  zkm_matrix* pt = new zkm_matrix();
+  pt->h = c.n; pt->w = (size_t)c.perm_ext_w * 4;
+  std::vector<void*> scratch;
+  try {
+    pt->d = ctx->alloc_n<uint32_t>(std::max<size_t>(pt->h * pt->w, 1));
+    for (int e = 0; e < 4; e++) local_sum[e] = 0;
+    if (c.perm_ext_w > 0) {
+      E4 alpha, beta;
+      memcpy(alpha.c, challenges, 16); memcpy(beta.c, challenges + 4, 16);
+      std::vector<E4> bp(c.max_values + 2);
+      bp[0] = kb::eone();
+      for (size_t i = 1; i < bp.size(); i++) bp[i] = kb::emul(bp[i - 1], beta);
+      const E4* d_bp = (const E4*)ctx->upload(bp.data(), bp.size() * sizeof(E4), &scratch);
+      const uint32_t* d_blob = (const uint32_t*)ctx->upload(chip->lookups, chip->lookups_len * 4, &scratch);
+      launch_permutation_trace(ctx, c, d_blob, (const uint32_t*)main->d, chip->prep_width ? (const uint32_t*)prep->d : nullptr, alpha, d_bp, *pt,
+                               [&](size_t bytes) { void* p = ctx->alloc(bytes); scratch.push_back(p); return p; });
+      const uint32_t* last = pt->d + (size_t)(c.perm_ext_w - 1) * 4 * c.n;
+      for (int e = 0; e < 4; e++) HIP_CHECK(hipMemcpyAsync(local_sum + e, last + (size_t)e * c.n + (c.n - 1), 4, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  } catch (...) {
+    for (void* p : scratch) ctx->release(p);
+    if (pt->d) ctx->release(pt->d);
+    delete pt;
+    throw;
+  }
+  for (void* p : scratch) ctx->release(p);
+  *out = pt;
+  API_END
+}
+
 #include "api_tracegen.hpp"
 
 void zkm_challenger_init(zkm_challenger* c) { memset(c, 0, sizeof *c); }

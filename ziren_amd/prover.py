@@ -88,6 +88,16 @@ class Context:
         dm._host = m
         return dm
 
+    def permutation_trace(self, chip, main: DeviceMatrix, prep: Optional[DeviceMatrix], alpha, beta):
+        """generate_permutation_trace of one chip on the device (zkm_permutation_trace, a test entry point): returns (DeviceMatrix of
+        height x 4 perm_ext_width, the cumulative sum as four Montgomery words)."""
+        descs, keep = abi.make_chip_descs([chip])
+        ch = np.ascontiguousarray(list(alpha) + list(beta), dtype=np.uint32)
+        total = np.zeros(4, dtype=np.uint32)
+        h = C.c_void_p()
+        lib.check(lib.load().zkm_permutation_trace(self.h, descs, main.h, prep.h if prep is not None else None, abi.as_u32p(ch), C.byref(h), abi.as_u32p(total)))
+        return self._born(h), total
+
     def byte_lookups(self) -> "ByteLookups":
         """An empty `record.byte_lookups` on the device (zkm_byte_lookups_create)."""
         h = C.c_void_p()
