@@ -58,6 +58,27 @@ def main():
     for field in ("Bn254", "Bls12381"):
         ev = np.concatenate([TF.some_events(field, "fp2_mul", n=119, seed=k)[0] for k in range(distinct // 128 + 1)])[:distinct]
         curve_tables.append((field + "Fp2MulAssign", tile(ev), functools.partial(lambda f, ev, h, blu: ctx.tracegen_fp_tower(f, "fp2_mul", ev, h, blu), field), 1))
+    # the U256Field chips, the decompressions, the garbled-circuit checks and the Linux syscalls: distinct events repeated to the row count
+    import random
+    import test_garble as TG
+    import test_sys_linux as TL
+    import test_uint256 as TU
+    rnd = random.Random(11)
+    moduli = [rnd.choice([0, TU.BIG, rnd.randrange(1 << 255, 1 << 256)]) for _ in range(distinct)]      # y below the modulus: the quotient fits 256 bits
+    u256 = np.array([TU.uevent(rnd.randrange(1 << 256), rnd.randrange(m or 1 << 256), m, clk=100 + 7 * i, seed=i)[0] for i, m in enumerate(moduli)])
+    u2048 = np.array([TU.xevent(rnd.randrange(1 << 256), rnd.randrange(1 << 2048), clk=100 + 7 * i, seed=i)[0] for i in range(min(distinct, 256))])
+    curve_tables.append(("Uint256MulMod", tile(u256), lambda ev, h, blu: ctx.tracegen_uint256_mul(ev, h, blu), 1))
+    curve_tables.append(("U256XU2048Mul", tile(u2048), lambda ev, h, blu: ctx.tracegen_u256x2048_mul(ev, h, blu), 1))
+    for curve in ("Secp256k1", "Bls12381"):
+        pts_w = TW.multiples(curve, 64)
+        dec = np.array([TW.devent(curve, pts_w[int(rng.integers(0, 64))][0], int(rng.integers(0, 2)), clk=300 + 10 * i, seed=i)[0] for i in range(distinct)])
+        curve_tables.append((curve + "Decompress", tile(dec), functools.partial(lambda c, ev, h, blu: ctx.tracegen_weierstrass_decompress(c, ev, h, blu), curve), 1))
+    calls, _ = TG.some_calls(seed=5, sizes=tuple([31] * (n // 32)))      # calls of 31 gates: 32 rows each
+    curve_tables.append(("BooleanCircuitGarble", calls, lambda ev, h, blu: ctx.tracegen_boolean_circuit_garble(ev, h, blu), 1))
+    codes = [E.SYS_BRK, E.SYS_MMAP, E.SYS_MMAP2, E.SYS_CLONE, E.SYS_FCNTL, E.SYS_READ, E.SYS_WRITE_LINUX, E.SYS_OPEN]
+    linux = np.array([TL.levent(codes[i % 8], int(rng.integers(0, 4)), int(rng.integers(0, 1 << 24)), brk=int(rng.integers(0, 1 << 32)), heap=int(rng.integers(0, 1 << 31)),
+                                clk=100 + 7 * i, seed=i) for i in range(distinct)])
+    curve_tables.append(("SysLinux", tile(linux), lambda ev, h, blu: ctx.tracegen_sys_linux(ev, h, blu), 1))
     gen_s = time.perf_counter() - t0
     ctx = prover.Context(0)
     lib.load().zkm_ctx_set_kernel_timing(ctx.h, C.c_int(1))

@@ -1,6 +1,7 @@
 // Big-field arithmetic for the precompile chips whose rows hold 256-bit field elements as byte limbs (crates/core/machine/src/operations/field/:
 // the reference computes them with num::BigUint on the host). Numbers are little-endian 32-bit limbs; a modulus comes with its Barrett constant
-// mu = floor(2^(64 NL) / p); a product is reduced with two multiplications and at most two subtractions, an inverse is a^(p - 2).
+// mu = floor(2^(64 NL) / p); a product is reduced with two multiplications and at most two subtractions, an inverse is a^(p - 2). Every loop over limbs is
+// unrolled and no limb array is indexed by a run-time value, so the numbers live in registers (the 12-limb kernels spilled 336 bytes per lane before).
 // The polynomial side of a gadget — the witness of op(x) - result(x) - carry(x) p(x) = (x - 256) w(x) over byte limbs — is in tracegen.cuh.
 #pragma once
 #include <cstdint>
@@ -10,9 +11,12 @@ namespace bigfield {
 template <int NL> struct Modulus { uint32_t p[NL]; uint32_t mu[NL + 1]; };
 
 template <int NA, int NB> __device__ __forceinline__ void mul(const uint32_t* a, const uint32_t* b, uint32_t* out /* NA + NB */) {
+#pragma unroll
   for (int i = 0; i < NA + NB; i++) out[i] = 0;
+#pragma unroll
   for (int i = 0; i < NA; i++) {
     uint64_t carry = 0;
+#pragma unroll
     for (int j = 0; j < NB; j++) {
       const uint64_t t = (uint64_t)a[i] * b[j] + out[i + j] + carry;
       out[i + j] = (uint32_t)t;
@@ -22,17 +26,20 @@ template <int NA, int NB> __device__ __forceinline__ void mul(const uint32_t* a,
   }
 }
 template <int N> __device__ __forceinline__ int cmp(const uint32_t* a, const uint32_t* b) {
-  for (int i = N - 1; i >= 0; i--)
-    if (a[i] != b[i]) return a[i] < b[i] ? -1 : 1;
-  return 0;
+  int order = 0;      // branch-free over the limbs, so that they stay in registers
+#pragma unroll
+  for (int i = 0; i < N; i++) order = a[i] != b[i] ? (a[i] < b[i] ? -1 : 1) : order;
+  return order;
 }
 template <int N> __device__ __forceinline__ uint32_t add(uint32_t* a, const uint32_t* b) {     // a += b, returns the carry out
   uint64_t carry = 0;
+#pragma unroll
   for (int i = 0; i < N; i++) { const uint64_t t = (uint64_t)a[i] + b[i] + carry; a[i] = (uint32_t)t; carry = t >> 32; }
   return (uint32_t)carry;
 }
 template <int N> __device__ __forceinline__ uint32_t sub(uint32_t* a, const uint32_t* b) {     // a -= b, returns the borrow out
   uint64_t borrow = 0;
+#pragma unroll
   for (int i = 0; i < N; i++) { const uint64_t t = (uint64_t)a[i] - b[i] - borrow; a[i] = (uint32_t)t; borrow = (t >> 32) & 1; }
   return (uint32_t)borrow;
 }
@@ -68,7 +75,10 @@ template <int NL> __device__ __forceinline__ void inverse(const uint32_t* a, con
   bool started = false;
   for (int bit = 32 * NL - 1; bit >= 0; bit--) {
     if (started) mulmod<NL>(acc, acc, m, acc);
-    if ((e[bit / 32] >> (bit % 32)) & 1) {
+    uint32_t word = 0;      // e[bit / 32] without indexing the array dynamically (that would put it in scratch memory)
+#pragma unroll
+    for (int l = 0; l < NL; l++) word = l == bit / 32 ? e[l] : word;
+    if ((word >> (bit % 32)) & 1) {
       if (started) mulmod<NL>(acc, a, m, acc);
       else { for (int i = 0; i < NL; i++) acc[i] = a[i]; started = true; }
     }

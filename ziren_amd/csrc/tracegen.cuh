@@ -2187,7 +2187,10 @@ __global__ __launch_bounds__(bf_threads(NL)) void weierstrass_decompress_rows(co
       for (int k = 0; k < NL; k++) y[k] = k == 0 ? 1u : 0u;
       for (int bit = 32 * NL - 1; bit >= 0; bit--) {
         if (started) bigfield::mulmod<NL>(y, y, m, y);
-        if ((curve.sqrt_exp[bit / 32] >> (bit % 32)) & 1) {
+        uint32_t word = 0;
+#pragma unroll
+        for (int l = 0; l < NL; l++) word = l == bit / 32 ? curve.sqrt_exp[l] : word;
+        if ((word >> (bit % 32)) & 1) {
           if (started) bigfield::mulmod<NL>(y, rhs, m, y);
           else { for (int i = 0; i < NL; i++) y[i] = rhs[i]; started = true; }
         }
