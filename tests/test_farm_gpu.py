@@ -9,6 +9,7 @@ shard order. The N > 1 ranks path of the same code runs over gloo in tests/test_
 shard of such a run (CPU shards, the Poseidon2 and Keccak precompile shards, the memory shard) is claimed from the farm's queue, generated on
 the device from its events and proven; the gathered proofs pass the restated machine verifier (public values chain, global digests sum to
 zero)."""
+import json
 import os
 import socket
 import subprocess
@@ -92,7 +93,7 @@ MACHINE_WORKER = textwrap.dedent("""
     import oracle_lib as O
     import machine_lib as ML
     from test_machine import ZERO_DIGEST, check_machine_airs
-    m = M.run_machine(3000, seed=5, shard_cycles=1024, poseidon2_calls=1, keccak_calls=2)
+    m = %s
     N = len(m.shards)
     f = farm.Farm()
     assert f.dist is not None and f.device.type == "cuda", "the farm must be on RCCL here"
@@ -123,7 +124,7 @@ MACHINE_WORKER = textwrap.dedent("""
     assert ML.verify_machine(O, opk, oshards, got, fri, synth.NUM_PV_ELTS, m.pc_base, ZERO_DIGEST) is None
     assert ML.verify_machine(O, opk, oshards[:-2] + oshards[-1:], got[:-2] + got[-1:], fri, synth.NUM_PV_ELTS, m.pc_base, ZERO_DIGEST) is not None
     kinds = [s.kind for s in m.shards]
-    print(json.dumps({"ok": True, "shards": N, "kinds": kinds, "keccak_blocks": int(len(m.shards[-2].record.keccak_sponge))}))
+    print(json.dumps({"ok": True, "shards": N, "kinds": kinds, "chips": sorted({c.name for cs in oshards for c in cs})}))
     f.close()
 """)
 
@@ -135,9 +136,27 @@ def test_gpu_keccak_machine_through_the_farm(tmp_path):
     port = s.getsockname()[1]
     s.close()
     script = tmp_path / "farm_machine_worker.py"
-    script.write_text(MACHINE_WORKER % (ROOT, os.path.join(ROOT, "tests")))
+    script.write_text(MACHINE_WORKER % (ROOT, os.path.join(ROOT, "tests"), "M.run_machine(3000, seed=5, shard_cycles=1024, poseidon2_calls=1, keccak_calls=2)"))
     env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), ZKM_FORCE_DIST="1",
                HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=1100)
     assert r.returncode == 0, r.stderr[-3000:]
-    assert '"ok": true' in r.stdout and '"precompile"' in r.stdout
+    assert '"ok": true' in r.stdout and '"precompile"' in r.stdout and '"KeccakSponge"' in r.stdout
+
+
+@pytest.mark.gpu
+def test_gpu_run_with_every_chip_through_the_farm(tmp_path):
+    """The run of tests/test_all_chips.py — thirty-odd shards of very different shapes, all fifty chips — dealt out by the farm's work queue over
+    RCCL (world 1), gathered as proof streams and verified as a machine."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    script = tmp_path / "farm_all_chips_worker.py"
+    script.write_text(MACHINE_WORKER % (ROOT, os.path.join(ROOT, "tests"), "__import__('test_all_chips').everything_machine()"))
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), ZKM_FORCE_DIST="1",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=1100)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["ok"] and len(out["chips"]) == 50 and out["kinds"].count("precompile") == 27
