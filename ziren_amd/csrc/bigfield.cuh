@@ -65,25 +65,63 @@ template <int NL> __device__ __forceinline__ void mulmod(const uint32_t* a, cons
   mul<NL, NL>(a, b, t);
   divmod<NL>(t, m, q, out);
 }
-// a^(p - 2) mod p, a in [1, p): left-to-right square and multiply over the bits of p - 2 (p odd, p > 2)
+// a^e mod p, a in [0, p), e > 0: left to right over two-bit digits of the exponent with a, a^2, a^3 at hand — the exponents here (p - 2,
+// (p + 1) / 4, (p + 3) / 8 of pseudo-Mersenne primes) are mostly ones, where the plain binary method multiplies at every bit
+template <int NL> __device__ __forceinline__ void pow(const uint32_t* a, const uint32_t* e, const Modulus<NL>& m, uint32_t* out) {
+  if constexpr (NL > 8) {      // twelve limbs: the kernels are at the register limit already; the plain binary method keeps a and the accumulator only
+    uint32_t acc[NL];
+    bool started = false;
+    for (int bit = 32 * NL - 1; bit >= 0; bit--) {
+      if (started) mulmod<NL>(acc, acc, m, acc);
+      uint32_t word = 0;
+#pragma unroll
+      for (int l = 0; l < NL; l++) word = l == bit / 32 ? e[l] : word;
+      if ((word >> (bit % 32)) & 1) {
+        if (started) mulmod<NL>(acc, a, m, acc);
+        else {
+#pragma unroll
+          for (int i = 0; i < NL; i++) acc[i] = a[i];
+          started = true;
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NL; i++) out[i] = acc[i];
+    return;
+  }
+  uint32_t a2[NL], a3[NL], acc[NL];
+  mulmod<NL>(a, a, m, a2);
+  mulmod<NL>(a2, a, m, a3);
+  bool started = false;
+  for (int digit = 16 * NL - 1; digit >= 0; digit--) {
+    uint32_t word = 0;      // e[digit / 16] without indexing the array dynamically (that would put it in scratch memory)
+#pragma unroll
+    for (int l = 0; l < NL; l++) word = l == digit / 16 ? e[l] : word;
+    const uint32_t d = (word >> (2 * (digit % 16))) & 3;
+    if (started) { mulmod<NL>(acc, acc, m, acc); mulmod<NL>(acc, acc, m, acc); }
+    if (d) {
+      uint32_t f[NL];
+#pragma unroll
+      for (int i = 0; i < NL; i++) f[i] = d == 1 ? a[i] : d == 2 ? a2[i] : a3[i];
+      if (started) mulmod<NL>(acc, f, m, acc);
+      else {
+#pragma unroll
+        for (int i = 0; i < NL; i++) acc[i] = f[i];
+        started = true;
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NL; i++) out[i] = acc[i];
+}
+// a^(p - 2) mod p, a in [1, p) (p odd, p > 2)
 template <int NL> __device__ __forceinline__ void inverse(const uint32_t* a, const Modulus<NL>& m, uint32_t* out) {
   uint32_t e[NL];
+#pragma unroll
   for (int i = 0; i < NL; i++) e[i] = m.p[i];
   const uint32_t two[NL] = {2};
   sub<NL>(e, two);
-  uint32_t acc[NL] = {1};
-  bool started = false;
-  for (int bit = 32 * NL - 1; bit >= 0; bit--) {
-    if (started) mulmod<NL>(acc, acc, m, acc);
-    uint32_t word = 0;      // e[bit / 32] without indexing the array dynamically (that would put it in scratch memory)
-#pragma unroll
-    for (int l = 0; l < NL; l++) word = l == bit / 32 ? e[l] : word;
-    if ((word >> (bit % 32)) & 1) {
-      if (started) mulmod<NL>(acc, a, m, acc);
-      else { for (int i = 0; i < NL; i++) acc[i] = a[i]; started = true; }
-    }
-  }
-  for (int i = 0; i < NL; i++) out[i] = acc[i];
+  pow<NL>(a, e, m, out);
 }
 __device__ __forceinline__ uint32_t byte_of(const uint32_t* a, int i) { return (a[i / 4] >> (8 * (i % 4))) & 0xff; }
 

@@ -2036,16 +2036,12 @@ __global__ __launch_bounds__(bf_threads(8)) void ed_decompress_rows(const uint32
     R.op(V, one, dyy, FOP_ADD, v);
     R.op(U_DIV_V, u, v, FOP_DIV, udv);
     {      // the even square root of u / v
-      uint32_t acc[8] = {1};
-      bool started = false;
-      for (int bit = 255; bit >= 0; bit--) {
-        if (started) bigfield::mulmod<8>(acc, acc, m, acc);
-        if ((d_ed25519_sqrt_exp[bit / 32] >> (bit % 32)) & 1) {
-          if (started) bigfield::mulmod<8>(acc, udv, m, acc);
-          else { for (int i = 0; i < 8; i++) acc[i] = udv[i]; started = true; }
-        }
-      }
-      for (int i = 0; i < 8; i++) x[i] = acc[i];
+      uint32_t exponent[8];
+#pragma unroll
+      for (int i = 0; i < 8; i++) exponent[i] = d_ed25519_sqrt_exp[i];
+      bool zero = true;
+      for (int i = 0; i < 8; i++) zero = zero && udv[i] == 0;
+      if (zero) { for (int i = 0; i < 8; i++) x[i] = 0; } else bigfield::pow<8>(udv, exponent, m, x);
       bigfield::mulmod<8>(x, x, m, sq);
       if (bigfield::cmp<8>(sq, udv) != 0) {
         uint32_t neg_a[8];
@@ -2183,18 +2179,9 @@ __global__ __launch_bounds__(bf_threads(NL)) void weierstrass_decompress_rows(co
     R.inner_with_one(AX_PLUS_B, curve.f.a, x, curve.b, axb);
     R.op(X_3_PLUS, x3, axb, FOP_ADD, rhs);
     {      // the root rhs^((p + 1) / 4)
-      bool started = false;
-      for (int k = 0; k < NL; k++) y[k] = k == 0 ? 1u : 0u;
-      for (int bit = 32 * NL - 1; bit >= 0; bit--) {
-        if (started) bigfield::mulmod<NL>(y, y, m, y);
-        uint32_t word = 0;
-#pragma unroll
-        for (int l = 0; l < NL; l++) word = l == bit / 32 ? curve.sqrt_exp[l] : word;
-        if ((word >> (bit % 32)) & 1) {
-          if (started) bigfield::mulmod<NL>(y, rhs, m, y);
-          else { for (int i = 0; i < NL; i++) y[i] = rhs[i]; started = true; }
-        }
-      }
+      bool zero = true;
+      for (int k = 0; k < NL; k++) zero = zero && rhs[k] == 0;
+      if (zero) { for (int k = 0; k < NL; k++) y[k] = 0; } else bigfield::pow<NL>(rhs, curve.sqrt_exp, m, y);
       bigfield::mulmod<NL>(y, y, m, sq);
       if (bigfield::cmp<NL>(sq, rhs) != 0) why = why ? why : 2;
     }
