@@ -68,27 +68,6 @@ template <int NL> __device__ __forceinline__ void mulmod(const uint32_t* a, cons
 // a^e mod p, a in [0, p), e > 0: left to right over two-bit digits of the exponent with a, a^2, a^3 at hand — the exponents here (p - 2,
 // (p + 1) / 4, (p + 3) / 8 of pseudo-Mersenne primes) are mostly ones, where the plain binary method multiplies at every bit
 template <int NL> __device__ __forceinline__ void pow(const uint32_t* a, const uint32_t* e, const Modulus<NL>& m, uint32_t* out) {
-  if constexpr (NL > 8) {      // twelve limbs: the kernels are at the register limit already; the plain binary method keeps a and the accumulator only
-    uint32_t acc[NL];
-    bool started = false;
-    for (int bit = 32 * NL - 1; bit >= 0; bit--) {
-      if (started) mulmod<NL>(acc, acc, m, acc);
-      uint32_t word = 0;
-#pragma unroll
-      for (int l = 0; l < NL; l++) word = l == bit / 32 ? e[l] : word;
-      if ((word >> (bit % 32)) & 1) {
-        if (started) mulmod<NL>(acc, a, m, acc);
-        else {
-#pragma unroll
-          for (int i = 0; i < NL; i++) acc[i] = a[i];
-          started = true;
-        }
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < NL; i++) out[i] = acc[i];
-    return;
-  }
   uint32_t a2[NL], a3[NL], acc[NL];
   mulmod<NL>(a, a, m, a2);
   mulmod<NL>(a2, a, m, a3);
@@ -122,6 +101,24 @@ template <int NL> __device__ __forceinline__ void inverse(const uint32_t* a, con
   const uint32_t two[NL] = {2};
   sub<NL>(e, two);
   pow<NL>(a, e, m, out);
+}
+// The same two out of line: for the twelve-limb fields, whose kernels are at the register limit, the long dependent chain of an inverse or
+// a root is better off with a register allocation of its own than inlined into every field operation of its caller
+template <int NL> __device__ __noinline__ void inverse_call(const uint32_t* a, const Modulus<NL>* m, uint32_t* out) {
+  uint32_t x[NL], y[NL];
+#pragma unroll
+  for (int i = 0; i < NL; i++) x[i] = a[i];
+  inverse<NL>(x, *m, y);
+#pragma unroll
+  for (int i = 0; i < NL; i++) out[i] = y[i];
+}
+template <int NL> __device__ __noinline__ void pow_call(const uint32_t* a, const uint32_t* e, const Modulus<NL>* m, uint32_t* out) {
+  uint32_t x[NL], ex[NL], y[NL];
+#pragma unroll
+  for (int i = 0; i < NL; i++) { x[i] = a[i]; ex[i] = e[i]; }
+  pow<NL>(x, ex, *m, y);
+#pragma unroll
+  for (int i = 0; i < NL; i++) out[i] = y[i];
 }
 __device__ __forceinline__ uint32_t byte_of(const uint32_t* a, int i) { return (a[i / 4] >> (8 * (i % 4))) & 0xff; }
 

@@ -1811,7 +1811,11 @@ template <int NL> struct FieldRow : RowCols {
     } else {                                      // result * b = a + carry p
       bool zero = true;
       for (int i = 0; i < NL; i++) zero = zero && a[i] == 0;
-      if (zero) { for (int i = 0; i < NL; i++) res[i] = 0; } else { uint32_t inv[NL]; bigfield::inverse<NL>(b, m, inv); bigfield::mulmod<NL>(a, inv, m, res); }
+      if (zero) { for (int i = 0; i < NL; i++) res[i] = 0; } else {
+        uint32_t inv[NL];
+        if constexpr (NL > 8) bigfield::inverse_call<NL>(b, &m, inv); else bigfield::inverse<NL>(b, m, inv);
+        bigfield::mulmod<NL>(a, inv, m, res);
+      }
       bigfield::mul<NL, NL>(res, b, t);
       for (int i = 0; i < 2 * NL; i++) t2[i] = i < NL ? a[i] : 0u;
       bigfield::sub<2 * NL>(t, t2);
@@ -2181,7 +2185,9 @@ __global__ __launch_bounds__(bf_threads(NL)) void weierstrass_decompress_rows(co
     {      // the root rhs^((p + 1) / 4)
       bool zero = true;
       for (int k = 0; k < NL; k++) zero = zero && rhs[k] == 0;
-      if (zero) { for (int k = 0; k < NL; k++) y[k] = 0; } else bigfield::pow<NL>(rhs, curve.sqrt_exp, m, y);
+      if (zero) { for (int k = 0; k < NL; k++) y[k] = 0; }
+      else if constexpr (NL > 8) bigfield::pow_call<NL>(rhs, curve.sqrt_exp, &m, y);
+      else bigfield::pow<NL>(rhs, curve.sqrt_exp, m, y);
       bigfield::mulmod<NL>(y, y, m, sq);
       if (bigfield::cmp<NL>(sq, rhs) != 0) why = why ? why : 2;
     }
