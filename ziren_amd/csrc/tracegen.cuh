@@ -1889,15 +1889,26 @@ __global__ __launch_bounds__(U8H_THREADS) void u8_pair_histogram(const uint32_t*
     const uint32_t* base = trace + (size_t)seg.start[sg] * height + row0;
     const uint32_t pairs = (uint32_t)(seg.cols[sg] + 1) / 2, reps = seg.reps[sg] > 1 ? (uint32_t)seg.reps[sg] : 1u;
     const uint32_t items = (pairs * reps) << log_slab_rows;      // (pair, row) with the row fastest: a wavefront shares the pair
-#pragma unroll 4
-    for (uint32_t idx = threadIdx.x; idx < items; idx += U8H_THREADS) {
-      const uint32_t p = idx >> log_slab_rows, r = idx & (slab_rows - 1);
-      const uint32_t rep = p / pairs, pair = p - rep * pairs;      // the same for a whole wavefront
-      if (row0 + r < n_real) {
-        const uint32_t* at = base + ((size_t)rep * seg.stride[sg] + 2 * pair) * height + r;
-        const bool alone = 2 * pair + 1 >= (uint32_t)seg.cols[sg];      // the last column of an odd segment is checked with a zero (ByteRecord::add_u8_range_checks)
-        const uint32_t b = kb::from_monty(at[0]), c = alone ? 0u : kb::from_monty(at[height]);
-        if ((b >> 6) == range) atomicAdd(&hist[(b & 0x3f) << 8 | (c & 0xff)], 1u);
+    // four (pair, row) items per thread and step, their eight loads issued before any is used: an out-of-range item reads the slab's first
+    // word instead (always there) and is dropped afterwards, so no load sits behind a branch
+    for (uint32_t first = threadIdx.x; first < items; first += 4 * U8H_THREADS) {
+      uint32_t bw[4], cw[4];
+      bool keep[4], alone[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const uint32_t idx = first + u * U8H_THREADS;
+        const uint32_t p = idx >> log_slab_rows, r = idx & (slab_rows - 1);
+        const uint32_t rep = p / pairs, pair = p - rep * pairs;      // the same for a whole wavefront
+        keep[u] = idx < items && row0 + r < n_real;
+        alone[u] = 2 * pair + 1 >= (uint32_t)seg.cols[sg];      // the last column of an odd segment is checked with a zero (ByteRecord::add_u8_range_checks)
+        const uint32_t* at = keep[u] ? base + ((size_t)rep * seg.stride[sg] + 2 * pair) * height + r : base;
+        bw[u] = at[0];
+        cw[u] = at[keep[u] && !alone[u] ? height : 0];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const uint32_t b = kb::from_monty(bw[u]), c = alone[u] ? 0u : kb::from_monty(cw[u]);
+        if (keep[u] && (b >> 6) == range) atomicAdd(&hist[(b & 0x3f) << 8 | (c & 0xff)], 1u);
       }
     }
   }
