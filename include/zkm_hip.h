@@ -143,6 +143,9 @@ int zkm_ctx_last_timings(zkm_ctx* ctx, const char** names, float* ms, int cap);
 int zkm_ctx_kernel_timings(zkm_ctx* ctx, const char** names, float* ms, uint32_t* calls, double* bytes, int cap);
 /* mode 0: off; 1: every launch; 2 (default): only launches whose compulsory bytes are >= 256 KiB */
 void zkm_ctx_set_kernel_timing(zkm_ctx* ctx, int mode);
+/* mode 3: only launches of the kernel `name` (as zkm_ctx_kernel_timings reports it) are timed. A timed launch costs a few microseconds of
+ * dispatch latency; a shard proof is ~500 launches, so timing them all slows it by ~2.5 %. A benchmark times the kernel it reports on. */
+void zkm_ctx_set_kernel_timing_only(zkm_ctx* ctx, const char* name);
 /* Register a chip-specialised quotient kernel: a gfx950 code object exporting
  * `zkm_quotient_specialized(stark::QuotientArgs)` generated from exactly these program words
  * (ziren_amd/codegen.py; the Rust shim does this once per chip AIR). zkm_open uses it for chips whose

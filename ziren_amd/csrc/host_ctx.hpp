@@ -110,8 +110,9 @@ struct zkm_ctx {
     return e;
   }
   // returns true when this launch is to be timed; the record then holds the two events to pass to the launch
+  std::string timing_only;      // kernel_timing == 3: the one kernel name that is timed
   bool kbegin(const char* name, double bytes) {
-    if (!(kernel_timing == 1 || (kernel_timing == 2 && bytes >= 262144.0))) return false;
+    if (!(kernel_timing == 1 || (kernel_timing == 2 && bytes >= 262144.0) || (kernel_timing == 3 && timing_only == name))) return false;
     KRec r{name, bytes, get_event(), get_event()};
     krecs.push_back(r);
     return true;

@@ -175,6 +175,7 @@ int zkm_ctx_kernel_timings(zkm_ctx* ctx, const char** names, float* ms, uint32_t
   return i;
 }
 void zkm_ctx_set_kernel_timing(zkm_ctx* ctx, int mode) { ctx->kernel_timing = mode; }
+void zkm_ctx_set_kernel_timing_only(zkm_ctx* ctx, const char* name) { ctx->timing_only = name ? name : ""; ctx->kernel_timing = 3; }
 
 int zkm_ctx_register_quotient_kernel(zkm_ctx* ctx, const uint32_t* program, uint32_t program_len, const void* code_object,
                                      size_t code_object_len) {
