@@ -646,7 +646,7 @@ int zkm_tracegen_sha_compress(zkm_ctx* ctx, const zkm_sha_compress_event* events
 // The U8Range lookups of the byte-limb columns of a big-field table's real rows (tracegen::u8_pair_histogram), added to the lookup counters
 static void count_u8_pairs(zkm_ctx* ctx, const zkm_matrix* m, size_t n_real, const tracegen::U8Segments& seg, uint32_t* counts) {
   if (!counts || !n_real) return;
-  int log_slab_rows = 8;
+  int log_slab_rows = n_real > 16384 ? 10 : 8;      // 1024-row slabs (a slab's byte columns: a few MB) until there would be more than U8H_MAX_SLABS of them
   while (div_up(n_real, (size_t)1 << log_slab_rows) > (size_t)tracegen::U8H_MAX_SLABS) log_slab_rows++;
   const size_t slabs = div_up(n_real, (size_t)1 << log_slab_rows);
   size_t columns = 0;
@@ -659,7 +659,7 @@ static void count_u8_pairs(zkm_ctx* ctx, const zkm_matrix* m, size_t n_real, con
   uint32_t* partial = ctx->alloc_n<uint32_t>(slabs * 65536);
   try {
     KLAUNCH(ctx, "tracegen_u8_pairs", 4.0 * tracegen::U8H_RANGES * n_real * columns, tracegen::u8_pair_histogram, dim3(slabs * tracegen::U8H_RANGES),
-            dim3(tracegen::U8H_THREADS), 0, (const uint32_t*)m->d, m->h, n_real, seg, log_slab_rows, partial);
+            dim3(tracegen::U8H_THREADS), (size_t)tracegen::U8H_KEYS * 4, (const uint32_t*)m->d, m->h, n_real, seg, log_slab_rows, partial);
     KLAUNCH(ctx, "tracegen_u8_pairs_reduce", 4.0 * slabs * 65536, tracegen::u8_pair_reduce, dim3(65536 / 256), dim3(256), 0, (const uint32_t*)partial, (int)slabs,
             counts + (size_t)tracegen::B_U8RANGE * tracegen::BYTE_ROWS);
   } catch (...) {

@@ -1871,15 +1871,15 @@ struct BfBlock {
 };
 
 // The U8Range lookups of adjacent byte columns, counted from the trace: for every real row and every pair of columns (start + 2 j,
-// start + 2 j + 1) of the given segments (a segment's odd last column pairs with zero), one lookup (U8Range, b, c). A block takes a slab of rows and a quarter of the key space (the
-// top two bits of b), reads the slab's byte columns (coalesced along the rows; the other three quarters' blocks read them again, out of
-// the memory-side cache) and counts in a dense LDS histogram of 16384 counters — no probing, no overflow. It leaves its counters in its
+// start + 2 j + 1) of the given segments (a segment's odd last column pairs with zero), one lookup (U8Range, b, c). A block takes a slab of rows and half of the key space (the
+// top bit of b), reads the slab's byte columns (coalesced along the rows; the other half's block reads them again, out of
+// the memory-side cache) and counts in a dense LDS histogram of 32768 counters — no probing, no overflow. It leaves its counters in its
 // own part of `partial` [slab][key]; u8_pair_reduce adds the slabs up into the lookup counters. Rows per slab: a power of two >= 256.
 struct U8Segments { int n; int start[4]; int cols[4]; int reps[4]; int stride[4]; };      // reps = 0 or 1: once; else `reps` copies `stride` columns apart
-constexpr int U8H_RANGES = 4, U8H_KEYS = 65536 / U8H_RANGES, U8H_THREADS = 512, U8H_MAX_SLABS = 64;
+constexpr int U8H_RANGES = 2, U8H_KEYS = 65536 / U8H_RANGES, U8H_THREADS = 1024, U8H_MAX_SLABS = 256;      // 128 KiB of counters: one block of sixteen waves per CU
 __global__ __launch_bounds__(U8H_THREADS) void u8_pair_histogram(const uint32_t* __restrict__ trace, size_t height, size_t n_real, const U8Segments seg,
                                                                  int log_slab_rows, uint32_t* __restrict__ partial) {
-  __shared__ uint32_t hist[U8H_KEYS];
+  extern __shared__ uint32_t hist[];      // U8H_KEYS counters
   const uint32_t slab = blockIdx.x / U8H_RANGES, range = blockIdx.x % U8H_RANGES;
   for (int i = threadIdx.x; i < U8H_KEYS; i += U8H_THREADS) hist[i] = 0;
   __syncthreads();
@@ -1908,7 +1908,7 @@ __global__ __launch_bounds__(U8H_THREADS) void u8_pair_histogram(const uint32_t*
 #pragma unroll
       for (int u = 0; u < 4; u++) {
         const uint32_t b = kb::from_monty(bw[u]), c = alone[u] ? 0u : kb::from_monty(cw[u]);
-        if (keep[u] && (b >> 6) == range) atomicAdd(&hist[(b & 0x3f) << 8 | (c & 0xff)], 1u);
+        if (keep[u] && (b >> 7) == range) atomicAdd(&hist[(b & 0x7f) << 8 | (c & 0xff)], 1u);
       }
     }
   }

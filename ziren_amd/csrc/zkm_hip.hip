@@ -106,7 +106,7 @@ int zkm_ctx_create(int device, zkm_ctx** out) {
   HIP_CHECK(hipFuncSetAttribute((const void*)tracegen::alu_rows<tracegen::BRANCH>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
   {      // the big-field precompile kernels keep their byte-limb polynomials next to the lookup table
     const void* big_field_kernels[] = {
-        (const void*)tracegen::ed_add_rows, (const void*)tracegen::ed_decompress_rows,
+        (const void*)tracegen::u8_pair_histogram, (const void*)tracegen::ed_add_rows, (const void*)tracegen::ed_decompress_rows,
         (const void*)tracegen::weierstrass_rows<8, false>, (const void*)tracegen::weierstrass_rows<8, true>,
         (const void*)tracegen::weierstrass_rows<12, false>, (const void*)tracegen::weierstrass_rows<12, true>,
         (const void*)tracegen::uint256_mul_rows, (const void*)tracegen::u256x2048_mul_rows, (const void*)tracegen::weierstrass_decompress_rows<8, false>, (const void*)tracegen::weierstrass_decompress_rows<12, true>,
