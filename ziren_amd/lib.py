@@ -58,6 +58,9 @@ def load():
             _build.build(verbose=True)
         except Exception as e:  # noqa: BLE001
             raise ZkmError(f"{LIB_PATH} is missing and could not be built ({e}): run `python -m ziren_amd.build`") from e
+    # a proof is ~525 dependent launches; with the kernel arguments in device memory each dispatch is ~1 microsecond shorter (0.6 ms per
+    # SYN-22 proof, measured: DESIGN.md section 4). The runtime reads this when it initialises, so it has to be in place before the first HIP call
+    os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
     _preload_hip_runtime()
     L = C.CDLL(LIB_PATH)
     L.zkm_last_error.restype = C.c_char_p
