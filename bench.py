@@ -23,6 +23,8 @@ sys.path.insert(0, ROOT)
 
 import numpy as np
 
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")      # before anything initialises the HIP runtime (torch.distributed for N > 1 would): ziren_amd/lib.py
+
 from ziren_amd import abi, lib, prover, synth
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
