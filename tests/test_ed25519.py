@@ -284,3 +284,33 @@ def test_gpu_machine_with_ed_add_calls_proves_and_verifies(hip_ctx, oracle):
     fri = abi.FriConfig(1, 84, 16)
     opk, oshards, proofs = gpu_prove_machine(hip_ctx, oracle, m, fri)
     assert ML.verify_machine(oracle, opk, oshards, proofs, fri, synth.NUM_PV_ELTS, m.pc_base, ZERO_DIGEST) is None
+
+
+@pytest.mark.gpu
+def test_gpu_range_check_histogram_at_scale(hip_ctx):
+    """The U8Range lookups of the big-field tables are counted from the finished columns by a pass of its own (tracegen::u8_pair_histogram, many
+    slabs of rows, two halves of the key space, a reduction). At 2^14 + 100 rows — seventeen slabs, the last one ragged — its counters must
+    equal a numpy recount over the downloaded trace: every gadget's columns in pairs, real rows only, plus the one kind of U8Range lookup the
+    row kernel records itself (the 8-bit limb of each memory record's timestamp difference, checked next to a zero)."""
+    n = (1 << 14) + 100
+    pts = [BASE]
+    for _ in range(63):
+        pts.append(E.ed25519_add(pts[-1], BASE))
+    rng = np.random.default_rng(4)
+    distinct = np.array([ed_event(pts[int(rng.integers(0, 64))], pts[int(rng.integers(0, 64))], clk=100 + 3 * i, seed=i)[0] for i in range(512)])
+    evs = np.tile(distinct, n // 512 + 1)[:n]
+    blu = hip_ctx.byte_lookups()
+    born = hip_ctx.tracegen_ed_add(evs, 15, blu)
+    mults = F.from_monty(hip_ctx.tracegen_byte_mults(blu).to_host())
+    t = F.from_monty(born.to_host())[:n]
+    assert born.height == 1 << 15
+    want = np.zeros(1 << 16, dtype=np.int64)
+    g = t[:, GADGETS:GADGETS + 8 * 188].astype(np.int64)
+    np.add.at(want, (g[:, 0::2] << 8 | g[:, 1::2]).ravel(), 1)                       # the eight gadgets: 94 pairs each, all of even length
+    # the other U8Range lookups of a row: the 8-bit limb of every memory record's timestamp difference, checked next to a zero
+    for k in range(16):
+        np.add.at(want, t[:, 5 + 13 * k + 12].astype(np.int64), 1)                   # p: MemoryWriteCols, diff_8bit_limb (the key is 0 << 8 | limb)
+        np.add.at(want, t[:, 5 + 16 * 13 + 9 * k + 8].astype(np.int64), 1)           # q: MemoryReadCols
+    got = mults[:, 4].astype(np.int64)                                               # ByteOpcode::U8Range is column 4
+    assert got.sum() == n * (8 * 94 + 32) and np.array_equal(got, want)
+    born.free(); blu.free()
