@@ -251,3 +251,32 @@ def test_gpu_machine_with_u256x2048_calls_proves_and_verifies(hip_ctx, oracle):
     fri = abi.FriConfig(1, 84, 16)
     opk, oshards, proofs = gpu_prove_machine(hip_ctx, oracle, m, fri)
     assert ML.verify_machine(oracle, opk, oshards, proofs, fri, synth.NUM_PV_ELTS, m.pc_base, ZERO_DIGEST) is None
+
+
+@pytest.mark.gpu
+def test_gpu_u256x2048_range_check_histogram_at_scale(hip_ctx):
+    """The histogram pass with strided, odd-length segments (eight gadgets 190 columns apart; 63-limb witnesses whose last limb is checked next to
+    a zero) over several slabs with a ragged end: its U8Range counters equal a numpy recount of the downloaded trace."""
+    n = (1 << 12) + 37
+    rnd = random.Random(13)
+    distinct = np.array([xevent(rnd.randrange(1 << 256), rnd.randrange(1 << 2048), clk=100 + 7 * i, seed=i)[0] for i in range(64)])
+    evs = np.tile(distinct, n // 64 + 1)[:n]
+    blu = hip_ctx.byte_lookups()
+    born = hip_ctx.tracegen_u256x2048_mul(evs, 13, blu)
+    mults = F.from_monty(hip_ctx.tracegen_byte_mults(blu).to_host())
+    t = F.from_monty(born.to_host())[:n].astype(np.int64)
+    want = np.zeros(1 << 16, dtype=np.int64)
+    for g in range(8):
+        base = 1608 + 190 * g
+        both = t[:, base:base + 64]                                                  # result and carry: 32 + 32 limbs
+        np.add.at(want, (both[:, 0::2] << 8 | both[:, 1::2]).ravel(), 1)
+        for w0 in (base + 64, base + 127):                                           # witness_low, witness_high: 63 limbs each
+            w = t[:, w0:w0 + 63]
+            np.add.at(want, (w[:, 0:62:2] << 8 | w[:, 1:62:2]).ravel(), 1)
+            np.add.at(want, (w[:, 62] << 8).ravel(), 1)
+    for base, count, stride, limb in ((6, 2, 9, 8), (24, 8, 9, 8), (96, 64, 9, 8), (672, 64, 13, 12), (1504, 8, 13, 12)):      # the memory records' 8-bit limbs
+        for k in range(count):
+            np.add.at(want, t[:, base + stride * k + limb], 1)
+    got = mults[:, 4].astype(np.int64)
+    assert got.sum() == n * (8 * 96 + 146) and np.array_equal(got, want)
+    born.free(); blu.free()
