@@ -575,3 +575,29 @@ def test_permutation_trace_matches_oracle_on_its_own(hip_ctx, oracle):
             prep_d.free()
         checked += 1
     assert checked >= 25 and {"Global", "Byte", "Cpu", "Poseidon2Permute", "MemoryGlobalInit"} <= {c.name for c, _, _ in cases}
+
+
+@pytest.mark.gpu
+def test_kernel_timing_modes(hip_ctx, oracle):
+    """zkm_ctx_set_kernel_timing / _only: with one kernel named, only its launches carry HIP events (what bench.py does inside its timed region);
+    mode 2 times every launch of at least 256 KiB; mode 0 none. The proof is the same bytes in every mode."""
+    import ctypes as C
+    from ziren_amd import lib, prover
+    shard = synth.syn_shard(12)
+    fri = abi.FriConfig(1, 84, 16)
+    hp = prover.HipProver(shard.chips, fri, synth.NUM_PV_ELTS, ctx=hip_ctx)
+    pk = hp.setup([], [], shard.pc_start, shard.initial_global_cumulative_sum)
+    traces = hp.upload_traces([c.trace for c in shard.chips])
+    seen, proofs = {}, []
+    for mode in ("only", 2, 0):
+        if mode == "only":
+            lib.load().zkm_ctx_set_kernel_timing_only(hip_ctx.h, b"compress_layer")
+        else:
+            lib.load().zkm_ctx_set_kernel_timing(hip_ctx.h, C.c_int(mode))
+        ch = prover.new_challenger()
+        pk.observe_into(ch)
+        proofs.append(hp.prove_shard(pk, shard.public_values, traces, ch).copy())
+        seen[mode] = {name for name, ms, calls, nbytes in hip_ctx.kernel_timings() if calls}
+    lib.load().zkm_ctx_set_kernel_timing(hip_ctx.h, C.c_int(2))
+    assert seen["only"] == {"compress_layer"} and seen[0] == set() and {"compress_layer", "hash_leaves", "quotient"} <= seen[2]
+    assert np.array_equal(proofs[0], proofs[1]) and np.array_equal(proofs[0], proofs[2])
