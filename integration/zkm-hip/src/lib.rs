@@ -4,6 +4,8 @@
 //!   * `ZKMProverComponents::CoreProver = HipProver<CoreSC, MipsAir<..>>` (crates/prover/src/components.rs:6-35) — `HipProverComponents` below;
 //!   * `run_test::<HipProver<_, _>>(program)` in the core machine's tests (crates/core/machine/src/utils/prove.rs:614-656).
 //!
+//! The SDK-facing pieces (`HipProverComponents`, the `ZKM_PROVER=hip` client) live in integration/sdk-hip/, which depends on this crate.
+//!
 //! NOT compiled where it was written (no Rust toolchain in that image); the C ABI underneath is exercised call for call by
 //! tests/c_abi/consumer.c and by the Python mirror ziren_amd/prover.py. ffi.rs is generated from include/zkm_hip.h.
 
@@ -23,7 +25,8 @@ use p3_koala_bear::KoalaBear;
 use p3_matrix::{dense::RowMajorMatrix, Matrix};
 use p3_uni_stark::SymbolicAirBuilder;
 use zkm_stark::{
-    air::MachineAir, koala_bear_poseidon2::KoalaBearPoseidon2, MachineProver, MachineProvingKey, MachineRecord, ShardMainData, ShardProof,
+    air::MachineAir, koala_bear_poseidon2::KoalaBearPoseidon2, DebugConstraintBuilder, MachineProof, MachineProver, MachineProvingKey, MachineRecord,
+    ShardMainData, ShardProof,
     Challenger, Com, StarkGenericConfig, StarkMachine, StarkProvingKey, StarkVerifyingKey, Val,
 };
 
@@ -48,18 +51,34 @@ unsafe impl Sync for HipContext {}
 impl Drop for HipContext { fn drop(&mut self) { unsafe { ffi::zkm_ctx_destroy(self.0) } } }
 
 /// `DeviceMatrix`: a column-major matrix resident in HBM.
-pub struct HipMatrix { ctx: *mut ffi::ZkmCtx, h: *mut ffi::ZkmMatrix, height: usize, width: usize }
+pub struct HipMatrix {
+    ctx: *mut ffi::ZkmCtx,
+    h: *mut ffi::ZkmMatrix,
+    height: usize,
+    width: usize,
+    /// host copy for `Matrix::row` (debugging reads only): downloaded once, on the first row asked for
+    host: std::sync::OnceLock<Vec<u32>>,
+}
 unsafe impl Send for HipMatrix {}
 unsafe impl Sync for HipMatrix {}
 impl Drop for HipMatrix { fn drop(&mut self) { unsafe { ffi::zkm_matrix_free(self.ctx, self.h) } } }
+impl HipMatrix {
+    pub(crate) fn from_handle(ctx: *mut ffi::ZkmCtx, h: *mut ffi::ZkmMatrix, height: usize, width: usize) -> Self {
+        Self { ctx, h, height, width, host: std::sync::OnceLock::new() }
+    }
+}
 impl Matrix<F> for HipMatrix {
     fn width(&self) -> usize { self.width }
     fn height(&self) -> usize { self.height }
     type Row<'a> = std::vec::IntoIter<F>;
-    // Rows of a device matrix are not read on the host on the proving path; debugging reads go through zkm_matrix_download.
+    // Rows of a device matrix are not read on the host on the proving path (`open` works on the handles). A debugging read downloads the
+    // matrix once and serves every later row from that copy; a failed download panics like an out-of-range row would.
     fn row(&self, r: usize) -> Self::Row<'_> {
-        let mut host = vec![0u32; self.height * self.width];
-        unsafe { ffi::zkm_matrix_download(self.ctx, self.h, host.as_mut_ptr()) };
+        let host = self.host.get_or_init(|| {
+            let mut host = vec![0u32; self.height * self.width];
+            check(unsafe { ffi::zkm_matrix_download(self.ctx, self.h, host.as_mut_ptr()) }).expect("zkm_matrix_download");
+            host
+        });
         host[r * self.width..(r + 1) * self.width].iter().map(|&w| unsafe { core::mem::transmute::<u32, F>(w) }).collect::<Vec<_>>().into_iter()
     }
 }
@@ -115,30 +134,29 @@ where
         let mut h = null_mut();
         // asynchronous: slabbed DMA + transpose on the library's upload streams; consumers wait per matrix on the device
         check(unsafe { ffi::zkm_matrix_upload_async(self.ctx.0, m.values.as_ptr() as *const u32, m.height(), m.width(), &mut h) })?;
-        Ok(HipMatrix { ctx: self.ctx.0, h, height: m.height(), width: m.width() })
+        Ok(HipMatrix::from_handle(self.ctx.0, h, m.height(), m.width()))
     }
 
-    /// The ahead-of-time compiled quotient kernel of a chip, if one was shipped (tools/aot_quotient_kernels.py writes
-    /// `<ZKM_HIP_KERNEL_DIR>/manifest.json`: sha256 of the program words -> code object). Without one the library interprets
-    /// the bytecode (4x slower on the quotient phase, same field values): no compiler is needed at run time either way.
-    fn register_aot_kernels(&self) {
+    /// The ahead-of-time compiled quotient kernel of a chip, if one was shipped: `ziren_amd/codegen.py` (`specialize_many`, run by
+    /// `__graft_entry__.build()`) keeps `<ZKM_HIP_KERNEL_DIR>/manifest.json`, a JSON object {sha256 of the program words: file name}; the
+    /// file is one code object (.hsaco) or, for a program long enough to be cut into several kernels (KeccakSponge), their container
+    /// (.parts) — zkm_ctx_register_quotient_kernel takes either. A chip without one runs through the library's bytecode interpreter
+    /// (4x slower on the quotient phase, same field values): no compiler is needed at run time either way. A kernel the library
+    /// refuses is an error, not a silent fall-back.
+    fn register_aot_kernels(&self) -> Result<(), HipProverError> {
         use sha2::{Digest, Sha256};
         let dir = std::path::PathBuf::from(env!("ZKM_HIP_KERNEL_DIR"));
-        let Ok(manifest) = std::fs::read_to_string(dir.join("manifest.json")) else { return };
+        let Ok(text) = std::fs::read_to_string(dir.join("manifest.json")) else { return Ok(()) };
+        let manifest: std::collections::HashMap<String, String> =
+            serde_json::from_str(&text).map_err(|e| HipProverError(format!("{}: {e}", dir.join("manifest.json").display())))?;
         for c in self.recorded.values() {
             let bytes: Vec<u8> = c.program.iter().flat_map(|w| w.to_le_bytes()).collect();
             let key = Sha256::digest(&bytes).iter().map(|b| format!("{b:02x}")).collect::<String>();
-            // manifest lines: "<sha256 of program words>": "<file>" — one code object (.hsaco) or, for a program long enough to be cut into
-            // several kernels (KeccakSponge), their container (.parts); zkm_ctx_register_quotient_kernel takes either
-            if let Some(pos) = manifest.find(&key) {
-                let rest = &manifest[pos + key.len()..];
-                if let Some(file) = rest.split('"').nth(2) {
-                    if let Ok(obj) = std::fs::read(dir.join(file)) {
-                        unsafe { ffi::zkm_ctx_register_quotient_kernel(self.ctx.0, c.program.as_ptr(), c.program.len(), obj.as_ptr() as *const _, obj.len()) };
-                    }
-                }
-            }
+            let Some(file) = manifest.get(&key) else { continue };
+            let obj = std::fs::read(dir.join(file)).map_err(|e| HipProverError(format!("{file}: {e}")))?;
+            check(unsafe { ffi::zkm_ctx_register_quotient_kernel(self.ctx.0, c.program.as_ptr(), c.program.len() as u32, obj.as_ptr() as *const _, obj.len()) })?;
         }
+        Ok(())
     }
 }
 
@@ -159,7 +177,7 @@ where
         check(unsafe { ffi::zkm_ctx_create(device, &mut ctx) }).expect("zkm_ctx_create (there is no CPU fallback)");
         let recorded = machine.chips().iter().map(|chip| (chip.name(), recorder::record_chip(chip))).collect();
         let p = Self { machine, ctx: HipContext(ctx), recorded };
-        p.register_aot_kernels();
+        p.register_aot_kernels().expect("registering the shipped quotient kernels");
         p
     }
 
@@ -258,22 +276,46 @@ where
         let fri = self.config().pcs().fri_config();
         let cfg = ffi::ZkmFriConfig { log_blowup: fri.log_blowup as u32, num_queries: fri.num_queries as u32, proof_of_work_bits: fri.proof_of_work_bits as u32 };
         let mut ch = challenger_to_ffi(challenger);
-        let mut cap = 1usize << 22;
-        let mut proof = vec![0u32; cap];
+        // zkm_open neither frees the main data nor advances the transcript when the stream does not fit (it reports the length it
+        // needs in `len`), so that one failure is retried once with the right size; `data` frees the handle when it drops
+        let mut proof = vec![0u32; 1usize << 22];
         let mut len = 0usize;
-        let h = std::mem::replace(&mut data.main_data.h, null_mut());    // zkm_open consumes the main data
-        let rc = unsafe {
-            ffi::zkm_open(self.ctx.0, pk.h, h, descs.as_ptr(), &cfg, self.machine.num_pv_elts() as u32, &mut ch, proof.as_mut_ptr(), cap, &mut len)
+        let mut rc = unsafe {
+            ffi::zkm_open(self.ctx.0, pk.h, data.main_data.h, descs.as_ptr(), &cfg, self.machine.num_pv_elts() as u32, &mut ch,
+                          proof.as_mut_ptr(), proof.len(), &mut len)
         };
-        if rc != 0 && len > cap {
-            // the only retryable failure: the stream did not fit (the transcript was not advanced); the main data is gone, so the shim
-            // sizes the buffer generously up front and treats this as an error
-            cap = len;
+        if rc != 0 && len > proof.len() {
+            proof.resize(len, 0);
+            ch = challenger_to_ffi(challenger);
+            rc = unsafe {
+                ffi::zkm_open(self.ctx.0, pk.h, data.main_data.h, descs.as_ptr(), &cfg, self.machine.num_pv_elts() as u32, &mut ch,
+                              proof.as_mut_ptr(), proof.len(), &mut len)
+            };
         }
         check(rc)?;
         proof.truncate(len);
         challenger_from_ffi(&ch, challenger);
         Ok(decode::decode_shard_proof(&proof, &caller_names))
+    }
+
+    /// prover.rs:140-148, CPU body :660-693: dependencies, the key into the transcript, then per record `generate_traces` -> `commit`
+    /// -> `open` on a clone of the challenger. The records go through one after the other, not through rayon: a `zkm_ctx` serialises
+    /// its calls anyway (one context per GPU; `ZKMProverOpts::gpu` sets shard_batch_size = 1 for the same reason, opts.rs:83-110),
+    /// and inside `commit` the upload of the next trace already overlaps the kernels of the previous one.
+    fn prove(&self, pk: &Self::DeviceProvingKey, mut records: Vec<A::Record>, challenger: &mut Challenger<SC>,
+             opts: <A::Record as MachineRecord>::Config) -> Result<MachineProof<SC>, Self::Error>
+    where
+        A: for<'a> Air<DebugConstraintBuilder<'a, Val<SC>, <SC as StarkGenericConfig>::Challenge>>,
+    {
+        self.machine.generate_dependencies(&mut records, &opts, None).map_err(|e| HipProverError(format!("generate_dependencies: {e:?}")))?;
+        pk.observe_into(challenger);
+        let mut shard_proofs = Vec::with_capacity(records.len());
+        for record in records {
+            let named_traces = self.generate_traces(&record).map_err(|e| HipProverError(format!("generate_traces: {e:?}")))?;
+            let shard_data = self.commit(&record, named_traces);
+            shard_proofs.push(self.open(pk, shard_data, &mut challenger.clone())?);
+        }
+        Ok(MachineProof { shard_proofs })
     }
 }
 
@@ -294,19 +336,6 @@ fn challenger_from_ffi(src: &ffi::ZkmChallenger, c: &mut Challenger<SC>) {
     for (d, s) in c.sponge_state.iter_mut().zip(src.sponge_state.iter()) { *d = f(*s); }
     c.input_buffer = src.input_buffer[..src.num_inputs as usize].iter().map(|&x| f(x)).collect();
     c.output_buffer = src.output_buffer[..src.num_outputs as usize].iter().map(|&x| f(x)).collect();
-}
-
-/// crates/prover/src/components.rs:28-35 gets a sibling: the core prover on the GPU, the recursion provers as they are (the recursion
-/// machine's chips go through the same library — SURVEY.md 8f N2 — once their provers are switched the same way).
-pub mod components {
-    // pub struct HipProverComponents;
-    // impl ZKMProverComponents for HipProverComponents {
-    //     type CoreProver = crate::HipProver<MipsAir<<CoreSC as StarkGenericConfig>::Val>>;
-    //     type CompressProver = CpuProver<InnerSC, CompressAir<<InnerSC as StarkGenericConfig>::Val>>;
-    //     type ShrinkProver = CpuProver<InnerSC, ShrinkAir<<InnerSC as StarkGenericConfig>::Val>>;
-    //     type WrapProver = CpuProver<OuterSC, WrapAir<<OuterSC as StarkGenericConfig>::Val>>;
-    // }
-    // It has to live in crates/prover (the trait and the Air types are there); it is four lines once `zkm-hip` is a dependency.
 }
 
 #[allow(dead_code)]

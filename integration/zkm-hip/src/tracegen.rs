@@ -312,7 +312,7 @@ pub(crate) fn device_trace(
         _ => return Ok(None),
     };
     let (height, width) = unsafe { (ffi::zkm_matrix_height(m), ffi::zkm_matrix_width(m)) };
-    Ok(Some(HipMatrix { ctx, h: m, height, width }))
+    Ok(Some(HipMatrix::from_handle(ctx, m, height, width)))
 }
 
 fn poseidon2_event(e: &Poseidon2PermuteEvent) -> ffi::ZkmPoseidon2PermuteEvent {

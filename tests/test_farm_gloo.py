@@ -54,22 +54,66 @@ WORKER = textwrap.dedent("""
         assert all(np.array_equal(got[i], np.arange(100 + 7 * i, dtype=np.uint32) + 1000 * i) for i in range(12))
     else:
         assert got is None and 0 < len(ids) < 6
+    # a second batch on the same farm and queue name: a fresh counter, every shard dealt again (one run_queue per batch of records)
+    ids2, proofs2 = f.run_queue(7, lambda i: np.full(3 + i, 50 + i, dtype=np.uint32))
+    assert f.sum_over_ranks(float(len(ids2))) == 7
+    got2 = f.gather_proofs(ids2, proofs2, 7)
+    if f.rank == 0:
+        assert [len(p) for p in got2] == [3 + i for i in range(7)] and all(int(p[0]) == 50 + i for i, p in enumerate(got2))
+    assert len(f.host_ms) == len(ids2) and all(ms >= 0 for ms in f.host_ms)
+    # a shard nobody proved is an error on every rank (not a hang of the ranks that wait in the gather)
+    try:
+        f.gather_proofs(ids2, proofs2, 8)
+        raise SystemExit("a missing shard went unnoticed")
+    except RuntimeError as e:
+        assert "no rank" in str(e)
+    # words above 2^31 survive the 32-bit transport
+    hi = f.gather_proofs([f.rank], [np.array([0xFFFFFFFE - f.rank, 0x80000000], dtype=np.uint32)], 2)
+    if f.rank == 0:
+        assert [int(x) for x in hi[1]] == [0xFFFFFFFD, 0x80000000]
     if f.rank == 0:
         print(json.dumps({"elapsed": elapsed, "ok": True}))
     f.close()
 """)
 
+STRAGGLER = textwrap.dedent("""
+    import sys, time, json
+    import numpy as np
+    sys.path.insert(0, %r)
+    from ziren_amd import farm
+    f = farm.Farm(backend="gloo")
+    assert f.world == 4
+    # sixteen shards (4 per rank if dealt statically), rank 3 ten times slower than the others: the queue gives it fewer
+    def prove(i):
+        time.sleep(0.1 if f.rank == 3 else 0.01)
+        return np.full(10 + i, i, dtype=np.uint32)
+    f.barrier()
+    t0 = time.perf_counter()
+    ids, proofs = f.run_queue(16, prove)
+    f.barrier()
+    elapsed = f.max_over_ranks(time.perf_counter() - t0)
+    got = f.gather_proofs(ids, proofs, 16)
+    n3 = f.sum_over_ranks(float(len(ids)) if f.rank == 3 else 0.0)
+    assert f.sum_over_ranks(float(len(ids))) == 16
+    assert n3 <= 2, n3
+    assert elapsed < 0.35, elapsed                 # a static deal would take 4 x 0.1 s on the slow rank
+    if f.rank == 0:
+        assert all(len(got[i]) == 10 + i and (got[i] == i).all() for i in range(16))
+        print(json.dumps({"ok": True, "elapsed": elapsed, "slow_rank_shards": n3}))
+    f.close()
+""")
 
-def test_two_rank_farm_over_gloo(tmp_path):
+
+def _run_world(tmp_path, source, world):
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     script = tmp_path / "worker.py"
-    script.write_text(WORKER % ROOT)
+    script.write_text(source % ROOT)
     procs = []
-    for rank in range(2):
-        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port))
         procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
                                       text=True))
@@ -77,3 +121,20 @@ def test_two_rank_farm_over_gloo(tmp_path):
     for p, (o, e) in zip(procs, outs):
         assert p.returncode == 0, e[-2000:]
     assert '"ok": true' in outs[0][0]
+
+
+def test_two_rank_farm_over_gloo(tmp_path):
+    _run_world(tmp_path, WORKER, 2)
+
+
+def test_four_rank_farm_with_a_straggler_over_gloo(tmp_path):
+    """The claim queue against a static deal: one of four ranks is ten times slower (prove.rs:484: records go to the next free prover)."""
+    _run_world(tmp_path, STRAGGLER, 4)
+
+
+def test_a_second_batch_without_a_process_group_gets_a_fresh_counter():
+    f = farm.Farm()
+    assert f.dist is None
+    for n in (5, 3):
+        ids, proofs = f.run_queue(n, lambda i: [i, i + 1])
+        assert ids == list(range(n)) and [int(p[0]) for p in f.gather_proofs(ids, proofs, n)] == list(range(n))

@@ -231,10 +231,11 @@ def test_higher_quotient_degree_bit_exact(hip_ctx, oracle, log_blowup, lqd):
         assert oracle.verify_shard(opk, sh.chips, fri, synth.NUM_PV_ELTS, start.copy(), proof) == 0
 
 
-@pytest.mark.parametrize("log_blowup,queries", [(2, 42), (3, 28)])
+@pytest.mark.parametrize("log_blowup,queries", [(2, 42), (3, 28)], ids=["shrink-2-42", "ultra-compressed-3-28"])
 def test_recursion_fri_configs_bit_exact(hip_ctx, oracle, log_blowup, queries):
-    # compress / shrink shards go through the same commit+open with the compressed FRI configs
-    # (crates/stark/src/kb31_poseidon2.rs:215-241: blowup 4 / 42 queries, blowup 8 / 28 queries)
+    # the other two KoalaBear FRI configurations go through the same commit+open: `compressed` (shrink prover,
+    # crates/prover/src/lib.rs:196) = blowup 4 / 42 queries, `ultra_compressed` = blowup 8 / 28 queries
+    # (crates/stark/src/kb31_poseidon2.rs:215-241); the compress prover runs the default (1, 84) of every other test here (:192)
     sh = synth.syn_shard(8, with_prep=True)
     fri = abi.FriConfig(log_blowup, queries, 16)
     pk, start, ch, proof = _gpu_prove(hip_ctx, sh, fri, True)

@@ -316,7 +316,8 @@ def test_gpu_core_proofs_feed_a_compress_shaped_shard(hip_ctx, oracle):
     """BASELINE config 5's shape (core + recursion) as a two-level DAG at test size: level 1 = the core shard proofs of the fibonacci run
     (proven on the GPU, gathered in shard order through the farm's interface); level 2 = one shard of the compress machine's nine chips
     whose program witnesses the level-1 commitments (24 words per core proof), absorbs them with Poseidon2 and commits the resulting digest
-    as its public value — proven under the compress FRI configuration (blow-up 4, 42 queries; kb31_poseidon2.rs:215-227), bit-identical
+    as its public value — proven under the compress prover's FRI configuration (`InnerSC::default()`: log_blowup 1, 84 queries;
+    crates/prover/src/lib.rs:192, kb31_poseidon2.rs:203-213), bit-identical
     to the oracle's proof and accepted by the restated verifier. The digest is recomputed independently from the gathered proofs; a
     different core proof gives a different digest. (The real reduce programs come from the reference's recursion compiler; the chips,
     FRI configuration and data flow are the reference's, the program is a stand-in.)"""
@@ -344,7 +345,7 @@ def test_gpu_core_proofs_feed_a_compress_shaped_shard(hip_ctx, oracle):
     other = list(inputs)
     other[30] ^= 1
     assert digest_of(other) != digest
-    fri = abi.FriConfig(2, 42, 16)
+    fri = abi.FriConfig(1, 84, 16)
     pv = recursion_public_values(digest)
     igcs = F.to_monty(np.zeros(14, dtype=np.uint64))
     for i, r in enumerate(recs):

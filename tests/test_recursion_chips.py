@@ -1,5 +1,6 @@
 """Recursion-machine chips: BaseAlu and ExtAlu recorded from the reference's `eval`
-(ziren_amd/recursion.py), their traces as padded record streams, proved with the compress FRI configuration."""
+(ziren_amd/recursion.py), their traces as padded record streams, proved under the recursion provers' FRI configurations
+(compress = log_blowup 1 / 84 queries, shrink = 2 / 42: crates/prover/src/lib.rs:192-196)."""
 import numpy as np
 import pytest
 
@@ -174,7 +175,8 @@ def wrap_machine_shard(oracle, scale=1, seed=33):
 def test_wrap_machine(oracle):
     """Poseidon2Skinny<9> completes the wrap machine: eleven rows per permutation whose output row carries the reference's
     permutation, constraints of degree up to 9 (quotient degree 8 for it and for BatchFRI<9>, 2 for the others, in one shard), lookups
-    that cancel, and an oracle proof under the ultra-compressed FRI configuration (blow-up 8) that verifies."""
+    that cancel, and an oracle proof under the ultra-compressed KoalaBear FRI configuration (blow-up 8; the reference's wrap prover itself
+    commits with a BN254 hasher, crates/prover/src/lib.rs:199 — not this path) that verifies."""
     import json
     import os
     from ziren_amd import synth
@@ -380,11 +382,14 @@ def test_gpu_flat_tracegen(hip_ctx):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("log_blowup,queries", [(2, 42), (3, 28)])
+@pytest.mark.parametrize("log_blowup,queries", [(1, 84), (2, 42), (3, 28)],
+                         ids=["compress-1-84", "shrink-2-42", "ultra-compressed-3-28"])
 def test_gpu_recursion_alu_shard(hip_ctx, oracle, log_blowup, queries):
     """The complete compress machine — BaseAlu, ExtAlu, MemoryConst, MemoryVar, Select, Poseidon2Wide, ExpReverseBitsLen, BatchFRI, PublicValues —
-    over one consistent program under the compress / shrink FRI configurations
-    (crates/stark/src/kb31_poseidon2.rs:215-241): device-built traces, preprocessed tables in the proving key,
+    over one consistent program under the FRI configurations the reference builds its recursion provers with
+    (crates/prover/src/lib.rs:192-196): **compress** = `InnerSC::default()` = log_blowup 1 / 84 queries / 16 PoW bits
+    (crates/stark/src/kb31_poseidon2.rs:203-213), **shrink** = `InnerSC::compressed()` = 2 / 42 (:215-227); (3, 28) is the
+    ultra-compressed KoalaBear configuration (:229-241), which no prover of the reference is built with today. Device-built traces, preprocessed tables in the proving key,
     memory lookups balancing between the real chips, proof bit-identical to the oracle's and accepted by the
     restated verifier."""
     from ziren_amd import prover, synth
@@ -421,9 +426,13 @@ def test_gpu_recursion_alu_shard(hip_ctx, oracle, log_blowup, queries):
 
 
 @pytest.mark.gpu
-def test_gpu_wrap_machine_shard(hip_ctx, oracle):
-    """The wrap machine's eight chips on the device under the ultra-compressed configuration (blow-up 8, 28 queries): quotient degrees
-    2 and 8 in one shard, the skinny hash chip's eleven-row permutations built on the device, proof bit-identical to the oracle's."""
+def test_gpu_wrap_chips_under_ultra_compressed_koalabear_config(hip_ctx, oracle):
+    """The eight chips of the wrap machine (Poseidon2Skinny, BatchFRI at DEGREE 9; crates/recursion/core/src/machine.rs:138-153) on the device
+    under the ultra-compressed *KoalaBear* configuration (log_blowup 3, 28 queries; kb31_poseidon2.rs:229-241): quotient degrees 2 and 8
+    in one shard, the skinny hash chip's eleven-row permutations built on the device, proof bit-identical to the oracle's. This is NOT the
+    reference's wrap prover: that one commits under OuterSC — a BN254 Poseidon2 Merkle tree, log_blowup 4
+    (crates/prover/src/lib.rs:199, crates/recursion/core/src/stark/config.rs:70-83) — a different hasher, outside this path; what is
+    exercised here is that chip set's constraints (degree 9, quotient degree 8) through the KoalaBear commit + open."""
     from ziren_amd import prover, synth
     for n in (0, 1, 5, 700):
         prog = R.balanced_program(10, 10, 40, seed=n + 1, n_var=20, n_poseidon2=n)

@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """A recursion-machine shard on the device: the nine chips of the compress machine (BaseAlu, ExtAlu, MemoryConst, MemoryVar, Select, Poseidon2Wide,
-ExpReverseBitsLen, BatchFRI, PublicValues) over one balanced synthetic program (ziren_amd/recursion.py), traces built on the device, commit + open under the compress FRI
-configuration (blow-up 4, 42 queries; `--shrink`: blow-up 8, 28 queries) with generated quotient kernels.
+ExpReverseBitsLen, BatchFRI, PublicValues) over one balanced synthetic program (ziren_amd/recursion.py), traces built on the device, commit + open under the FRI
+configuration of the reference's compress prover (`InnerSC::default()`: log_blowup 1, 84 queries; crates/prover/src/lib.rs:192), `--shrink`: the shrink prover's
+(`InnerSC::compressed()`: 2 / 42; :196), `--ultra`: the ultra-compressed KoalaBear configuration (3 / 28; kb31_poseidon2.rs:229-241), with generated quotient kernels.
+`--wrap-chips` swaps in the wrap machine's chip set (Poseidon2Skinny, BatchFRI at DEGREE 9) under the ultra-compressed configuration — the chips, not the reference's wrap
+prover, which commits with a BN254 hasher (lib.rs:199).
 
   python tools/bench_recursion_shard.py [--log-hashes 16] [--steps 3]"""
 import argparse
@@ -22,8 +25,10 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--log-hashes", type=int, default=16, help="log2 of the number of Poseidon2 permutations in the program")
     ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--shrink", action="store_true")
-    ap.add_argument("--wrap", action="store_true", help="the wrap machine: Poseidon2Skinny and BatchFRI at DEGREE 9, no ExpReverseBitsLen, blow-up 8")
+    ap.add_argument("--shrink", action="store_true", help="shrink prover's configuration: log_blowup 2, 42 queries")
+    ap.add_argument("--ultra", action="store_true", help="ultra-compressed KoalaBear configuration: log_blowup 3, 28 queries")
+    ap.add_argument("--wrap-chips", dest="wrap", action="store_true",
+                    help="the wrap machine's chips (Poseidon2Skinny and BatchFRI at DEGREE 9, no ExpReverseBitsLen) under the ultra-compressed KoalaBear configuration")
     args = ap.parse_args()
     ctx = prover.Context(0)
     n_hash = 1 << args.log_hashes
@@ -57,7 +62,7 @@ def main():
         recs.append(record(lh, idx))
         preps.append(ctx.tracegen_flat(prog[pk_key], pw, lh))
         mains.append((ev_key, mw, lh))
-    fri = abi.FriConfig(3, 28, 16) if args.shrink or args.wrap else abi.FriConfig(2, 42, 16)
+    fri = abi.FriConfig(3, 28, 16) if args.ultra or args.wrap else abi.FriConfig(2, 42, 16) if args.shrink else abi.FriConfig(1, 84, 16)
     hp = prover.HipProver(recs, fri, synth.NUM_PV_ELTS, ctx=ctx, specialize=True)
     pk = hp.setup(preps, [int(r.local_only) for r in recs], F.to_monty(0), F.to_monty(np.zeros(14, dtype=np.uint64)))
     ch0 = prover.new_challenger()
@@ -94,7 +99,7 @@ def main():
     r = res[-1]
     cells = sum((1 << c.log_height) * (c.prep_width + c.main_width + 4 * c.perm_ext_width + (4 << c.log_quotient_degree)) for c in recs)
     print(json.dumps({"workload": f"REC-{args.log_hashes}: balanced recursion program, 2^{args.log_hashes} Poseidon2 permutations + ALU / select / memory "
-                                  f"instructions; {'wrap machine, ultra-compressed' if args.wrap else 'shrink' if args.shrink else 'compress'} FRI configuration (blow-up {1 << fri.log_blowup}, {fri.num_queries} queries)",
+                                  f"instructions; {"wrap machine's chips, ultra-compressed KoalaBear" if args.wrap else 'ultra-compressed KoalaBear' if args.ultra else 'shrink prover' if args.shrink else 'compress prover'} FRI configuration (blow-up {1 << fri.log_blowup}, {fri.num_queries} queries)",
                       "program_generation_seconds_python": round(gen_s, 1),
                       "tracegen_ms": round(float(np.mean([x["tracegen_ms"] for x in res])), 3),
                       "prove_ms": round(float(np.mean([x["prove_ms"] for x in res])), 3), "committed_cells": cells, "proof_words": int(len(proof)),

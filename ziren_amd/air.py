@@ -34,6 +34,10 @@ KIND_MEMORY, KIND_PROGRAM, KIND_INSTRUCTION, KIND_BYTE = 1, 2, 3, 4
 KIND_RANGE, KIND_SYSCALL, KIND_GLOBAL, KIND_SYSCALL_RESULT = 5, 6, 7, 8
 
 
+class RegisterPressure(Exception):
+    """A constraint program that keeps every value in a register until its last use needs more than the 256 registers an instruction can name."""
+
+
 class Expr:
     """Node of the recorded expression DAG. ext=False: base field, True: extension field."""
 
@@ -272,7 +276,9 @@ class AirBuilder:
         are each read by constraints far apart: KeccakSponge), the inputs are loaded again at every use instead of being kept."""
         try:
             return self._assemble(False)
-        except ValueError:
+        except RegisterPressure as e:
+            import logging
+            logging.getLogger(__name__).info("%s: assembling again with inputs reloaded at every use (a longer program)", e)
             return self._assemble(True)
 
     def _assemble(self, reload_inputs: bool) -> np.ndarray:
@@ -321,7 +327,7 @@ class AirBuilder:
             r = nregs[ext]
             nregs[ext] += 1
             if r > 255:
-                raise ValueError("constraint program needs more than 256 registers")
+                raise RegisterPressure("constraint program needs more than 256 registers")
             return r
 
         def is_input(x):

@@ -207,17 +207,23 @@ MAX_SPECIALIZED_INSTRS = 1 << 20   # beyond this the interpreter evaluates the p
 PARTS_MAGIC = b"ZKMQPART"         # container of a multi-kernel program: magic, u32 count, u32 pad, count x u64 lengths, the code objects
 
 
+def _private_tmp(out: str) -> str:
+    """A temporary name next to `out` that no other process or thread uses (os.replace publishes the finished file atomically)."""
+    return f"{out}.{os.getpid()}.{__import__('threading').get_ident()}.tmp"
+
+
 def _compile(src: str, out: str, verbose: bool = False):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     with tempfile.TemporaryDirectory() as td:
         path = os.path.join(td, os.path.basename(out) + ".hip")
         with open(path, "w") as f:
             f.write(src)
-        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "--genco", "-I", CSRC, path, "-o", out + ".tmp"]
+        tmp = _private_tmp(out)   # farm ranks (one process per GPU) may compile the same chip on a cold cache: no shared temporary
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "--genco", "-I", CSRC, path, "-o", tmp]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
-    os.replace(out + ".tmp", out)
+    os.replace(tmp, out)
 
 
 def specialize(program: np.ndarray, force: bool = False, verbose: bool = False) -> Optional[bytes]:
@@ -247,9 +253,10 @@ def specialize(program: np.ndarray, force: bool = False, verbose: bool = False) 
                 blobs = [open(o, "rb").read() for o in outs]
             blob = PARTS_MAGIC + np.array([len(blobs), 0], dtype="<u4").tobytes() + np.array([len(b) for b in blobs], dtype="<u8").tobytes()
             blob += b"".join(blobs)
-            with open(out + ".tmp", "wb") as f:
+            tmp = _private_tmp(out)
+            with open(tmp, "wb") as f:
                 f.write(blob)
-            os.replace(out + ".tmp", out)
+            os.replace(tmp, out)
     _note_in_manifest(program, os.path.basename(out))
     with open(out, "rb") as f:
         return f.read()
@@ -273,7 +280,9 @@ def _note_in_manifest(program: np.ndarray, filename: str):
     import json
     key = hashlib.sha256(np.ascontiguousarray(program, dtype="<u4").tobytes()).hexdigest()
     path = os.path.join(CACHE, "manifest.json")
-    with _manifest_lock:
+    import fcntl
+    with _manifest_lock, open(path + ".lock", "w") as lk:   # threads of this process, then the other processes (farm ranks)
+        fcntl.flock(lk, fcntl.LOCK_EX)
         _update_manifest(path, key, filename)
 
 

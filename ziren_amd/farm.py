@@ -107,69 +107,87 @@ class Farm:
         return t.cpu().numpy().astype(np.uint32)
 
     # ---- dealing shards to the next free rank (prove.rs:484) ---------------------------------------------------------------
+    def _queue_key(self, queue: str) -> str:
+        """One counter per batch: `run_queue` opens a new epoch of `queue` every time it is called (every rank calls it the same
+        number of times, so the epochs agree without a message), and a key nobody has added to yet counts from zero."""
+        self._epochs = getattr(self, "_epochs", {})
+        return f"zkm_farm_{queue}_{self._epochs.get(queue, 0)}"
+
     def claim(self, queue: str = "shards") -> int:
-        """The index of the next unclaimed shard: an atomic fetch-and-add on a counter every rank shares (the process group's
-        key-value store; a plain counter without one). Whoever is free first gets the next shard."""
+        """The index of the next unclaimed shard of the queue's current batch: an atomic fetch-and-add on a counter every rank shares
+        (the process group's key-value store; a plain counter without one). Whoever is free first gets the next shard."""
+        key = self._queue_key(queue)
         if self.dist is None:
             self._local_counters = getattr(self, "_local_counters", {})
-            self._local_counters[queue] = self._local_counters.get(queue, 0) + 1
-            return self._local_counters[queue] - 1
+            self._local_counters[key] = self._local_counters.get(key, 0) + 1
+            return self._local_counters[key] - 1
         store = self.dist.distributed_c10d._get_default_store()
-        return int(store.add(f"zkm_farm_{queue}", 1)) - 1
+        return int(store.add(key, 1)) - 1
 
     def run_queue(self, n_shards: int, prove: Callable[[int], np.ndarray], queue: str = "shards"):
-        """Prove shards until the queue is empty; returns ([shard ids this rank proved], [their proof streams])."""
+        """Prove shards of one batch until its queue is empty; returns ([shard ids this rank proved], [their proof streams]). Calling
+        it again deals a new batch (a fresh counter). `self.host_ms` collects, per shard proven here, the wall-clock milliseconds of
+        its `prove` call (what a rank spends per shard including host work: the number that limits an 8-GPU node once events, not
+        resident traces, are the input)."""
         ids, proofs = [], []
-        while True:
-            i = self.claim(queue)
-            if i >= n_shards:
-                break
-            ids.append(i)
-            proofs.append(np.asarray(prove(i), dtype=np.uint32).copy())
+        self.host_ms = []
+        try:
+            while True:
+                i = self.claim(queue)
+                if i >= n_shards:
+                    break
+                t0 = time.perf_counter()
+                ids.append(i)
+                proofs.append(np.asarray(prove(i), dtype=np.uint32).copy())
+                self.host_ms.append(1e3 * (time.perf_counter() - t0))
+        finally:
+            self._epochs[queue] = self._epochs.get(queue, 0) + 1
         return ids, proofs
 
     def gather_proofs(self, shard_ids: Sequence[int], proofs: Sequence[np.ndarray], n_shards: int) -> Optional[List[np.ndarray]]:
         """Whole ShardProof streams to rank 0, in shard order (the input of the recursion tree, lib.rs:617-641). Streams differ in
-        length: lengths are exchanged first, then one padded buffer per rank (a few MB per proof; over xGMI this is far below a
-        link's bandwidth and happens once per batch). Returns the list on rank 0, None elsewhere."""
+        length: the lengths are exchanged first (one small all-reduce), then every rank sends one buffer — the ids it holds and their
+        words end to end, as 32-bit words — to rank 0 only (`gather`; a few MB per proof, far below one xGMI link's bandwidth, once
+        per batch). Returns the list on rank 0, None elsewhere; every rank raises if some shard was proven by nobody."""
         if self.dist is None:
             out = [None] * n_shards
             for i, p in zip(shard_ids, proofs):
                 out[i] = np.asarray(p, dtype=np.uint32)
+            if any(p is None for p in out):
+                raise RuntimeError("a shard was proven by no rank")
             return out
         torch, dist = self.torch, self.dist
-        lens = np.zeros(n_shards, dtype=np.int64)
+        lens = np.zeros(n_shards + self.world, dtype=np.int64)     # [length of every shard's stream] ++ [words held per rank]
         for i, p in zip(shard_ids, proofs):
             lens[i] = len(p)
+        lens[n_shards + self.rank] = int(sum(len(p) for p in proofs))
         t = torch.from_numpy(lens).to(self.device)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)           # disjoint entries: every rank learns every length
         lens = t.cpu().numpy()
-        per_rank = torch.zeros(self.world, dtype=torch.int64, device=self.device)
-        per_rank[self.rank] = int(sum(len(p) for p in proofs))
-        dist.all_reduce(per_rank, op=dist.ReduceOp.SUM)
-        cap = int(per_rank.max().item())
-        mine = np.zeros(cap + n_shards, dtype=np.int64)     # [ids this rank holds (-1 padded)] ++ [their words, concatenated]
-        mine[:n_shards] = -1
+        if (lens[:n_shards] == 0).any():                   # known on every rank: nobody is left waiting in the gather
+            raise RuntimeError("a shard was proven by no rank")
+        cap = int(lens[n_shards:].max())
+        mine = np.zeros(cap + n_shards, dtype=np.uint32)    # [ids this rank holds (0xffffffff padded)] ++ [their words, concatenated]
+        mine[:n_shards] = 0xFFFFFFFF
         mine[:len(shard_ids)] = shard_ids
         off = n_shards
         for p in proofs:
             mine[off:off + len(p)] = np.asarray(p, dtype=np.uint32)
             off += len(p)
-        buf = torch.from_numpy(mine).to(self.device)
-        bufs = [torch.empty_like(buf) for _ in range(self.world)]
-        dist.all_gather(bufs, buf)
+        buf = torch.from_numpy(mine.view(np.int32)).to(self.device)
+        bufs = [torch.empty_like(buf) for _ in range(self.world)] if self.rank == 0 else None
+        dist.gather(buf, bufs, dst=0)
         if self.rank != 0:
             return None
         out = [None] * n_shards
         for b in bufs:
-            b = b.cpu().numpy()
+            b = b.cpu().numpy().view(np.uint32)
             off = n_shards
             for i in b[:n_shards]:
-                if i < 0:
+                if i == 0xFFFFFFFF:
                     break
-                out[int(i)] = b[off:off + int(lens[i])].astype(np.uint32)
+                out[int(i)] = b[off:off + int(lens[i])].copy()
                 off += int(lens[i])
-        assert all(p is not None for p in out), "a shard was proven by no rank"
         return out
 
     def timed(self, step: Callable[[], None], steps: int, warmup: int) -> float:
