@@ -668,6 +668,17 @@ uint32_t zkm_challenger_sample_bits(zkm_challenger* c, uint32_t bits);
  * (same IEEE operations), so its exactness can be checked without a GPU. Words are Montgomery form. */
 void zkm_host_poseidon2_permute(uint32_t state[16]);
 void zkm_host_poseidon2_permute_f64(uint32_t state[16]);
+/* Host mirrors of the hashing kernels' data flow, state kept in doubles between permutations exactly as on the device:
+ * PaddingFreeSponge over n words (hash_leaves / absorb_row: the capacity is carried on unreduced), and one tree node
+ * compress(left, right) followed, when n > 0, by compress(node, hash(row)) with both halves handed over as unreduced doubles
+ * (compress_layer). */
+void zkm_host_poseidon2_f64_sponge(const uint32_t* words, size_t n, uint32_t digest[8]);
+void zkm_host_poseidon2_f64_compress_inject(const uint32_t left[8], const uint32_t right[8], const uint32_t* row, size_t n,
+                                            uint32_t out[8]);
+/* The largest magnitudes the host build of the FP64 permutation has met on this thread since the last reset, at the points
+ * its exactness argument rests on: out[0] a permutation input, out[1] the sum of lane magnitudes in a partial round,
+ * out[2] an S-box input, out[3] a lane after a partial round. (The device build has no probes.) */
+void zkm_host_poseidon2_f64_audit(double out[4], int reset);
 void zkm_host_ext_mul(const uint32_t a[4], const uint32_t b[4], uint32_t out[4]);
 void zkm_host_ext_inv(const uint32_t a[4], uint32_t out[4]);
 uint32_t zkm_host_field_mul(uint32_t a, uint32_t b);

@@ -203,6 +203,50 @@ def test_fp64_poseidon2_formulation_is_exact(oracle):
     assert np.array_equal(chain_g, chain_o)
 
 
+def test_fp64_poseidon2_unreduced_flows_are_exact_and_within_their_bounds(oracle):
+    """What the hashing kernels actually do with the FP64 permutation, on the host build of the same code: a sponge whose capacity is
+    carried from permutation to permutation as unreduced doubles (hash_leaves), and compress(node, hash(row)) with both halves handed
+    over unreduced (compress_layer) — on random and on adversarial words (values next to every rounding boundary, all p - 1, all zero),
+    every digest equal to the oracle's `% p` hashing. The host build records the largest magnitude it meets at each point the exactness
+    argument rests on; they must stay inside the bounds documented in csrc/poseidon2_f64.cuh."""
+    L = lib.load()
+    P = F.P
+    rng = np.random.default_rng(11)
+    edge = np.array([0, 1, 2, P - 1, P - 2, (P - 1) // 2, (P + 1) // 2] + [(1 << k) + d for k in range(20, 31) for d in (-1, 0, 1)], dtype=np.uint64) % P
+    audit = (C.c_double * 4)()
+    L.zkm_host_poseidon2_f64_audit(audit, 1)
+
+    def words(n, kind):
+        if kind == 0:
+            return rng.integers(0, P, n, dtype=np.uint64)
+        if kind == 1:
+            return edge[rng.integers(0, len(edge), n)]
+        return np.full(n, P - 1 if kind == 2 else 0, dtype=np.uint64)
+
+    u32p = lambda a: a.ctypes.data_as(C.POINTER(C.c_uint32))
+    for trial in range(160):
+        kind = trial % 4
+        n = int(rng.integers(1, 200)) if trial % 8 else [8, 16, 64, 7, 9, 1, 333, 128][trial // 8 % 8]
+        row = F.to_monty(words(n, kind))
+        got = np.zeros(8, dtype=np.uint32)
+        L.zkm_host_poseidon2_f64_sponge(u32p(row), C.c_size_t(n), u32p(got))
+        assert np.array_equal(got, oracle.hash_slice(row)), (trial, n, kind)
+        left, right = F.to_monty(words(8, (kind + 1) % 4)), F.to_monty(words(8, kind))
+        for inj in (0, n):
+            out = np.zeros(8, dtype=np.uint32)
+            L.zkm_host_poseidon2_f64_compress_inject(u32p(left), u32p(right), u32p(row), C.c_size_t(inj), u32p(out))
+            want = oracle.compress(left, right)
+            if inj:
+                want = oracle.compress(want, oracle.hash_slice(row))
+            assert np.array_equal(out, want), (trial, n, kind, inj)
+    L.zkm_host_poseidon2_f64_audit(audit, 1)
+    perm_in, lane_sum, sbox_in, lane = [float(x) for x in audit]
+    assert 2.0 ** 30 < perm_in <= 2.0 ** 35.3          # unreduced capacity / node halves did flow in, and within the input bound
+    assert lane_sum < 2.0 ** 50.4                       # reduce() takes |x| < 2^52
+    assert sbox_in < 2.0 ** 40.6                        # sbox(): |y| < 2^41
+    assert lane < 2.0 ** 49.3
+
+
 def test_challenger_matches_oracle(oracle):
     # the reference's own challenger test observes 1,2,2,2 then samples (recursion/circuit/src/challenger.rs:462-500)
     L = lib.load()

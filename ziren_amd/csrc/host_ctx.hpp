@@ -229,6 +229,54 @@ struct zkm_ctx {
     tab[log_size] = d;
     return d;
   }
+  // w_n^e by two lookups (lde::Group::pw_lo / pw_hi), per log2 n >= 10
+  std::map<int, std::pair<uint32_t*, uint32_t*>> pow_tabs;
+  std::pair<const uint32_t*, const uint32_t*> pow_tables(int k) {
+    auto it = pow_tabs.find(k);
+    if (it != pow_tabs.end()) return {it->second.first, it->second.second};
+    const uint32_t n_hi = (uint32_t)(((size_t)1 << k) >> 10);
+    uint32_t *lo, *hi;
+    HIP_CHECK(hipMalloc(&lo, 1024 * 4));
+    HIP_CHECK(hipMalloc(&hi, std::max<uint32_t>(n_hi, 1) * 4));
+    hipLaunchKernelGGL(lde::fill_pow_tables, dim3(div_up(std::max<uint32_t>(1024, n_hi), 256)), dim3(256), 0, stream, lo, hi,
+                       kb::two_adic_generator(k), n_hi);
+    LAUNCH_CHECK();
+    pow_tabs[k] = {lo, hi};
+    return {lo, hi};
+  }
+  // the tables of lde_rows_big that depend on the coset shift: per coset the scaled forward stage twiddles of the B-point row
+  // transform and the row constants shift_j^k1 / n; keyed by (log2 n, log_blowup, shift of coset 0). A prover meets a handful of
+  // (height, shift) pairs — traces are extended onto 3 K, quotient chunks onto 3 w_2n^-i K — so the cache stays small; zkm_ctx_trim clears it.
+  struct CosetTabs { uint32_t* twf; uint32_t* cs; };
+  std::map<std::tuple<int, int, uint32_t>, CosetTabs> coset_tabs;
+  CosetTabs coset_tables(int k, int bl, uint32_t shift) {
+    auto key = std::make_tuple(k, bl, shift);
+    auto it = coset_tabs.find(key);
+    if (it != coset_tabs.end()) return it->second;
+    const int lb = lde::LOG_ROW_MAX, la = k - lb;
+    const size_t B = (size_t)1 << lb, A = (size_t)1 << la, cosets = (size_t)1 << bl;
+    CosetTabs t;
+    HIP_CHECK(hipMalloc(&t.twf, cosets * B * 4));
+    HIP_CHECK(hipMalloc(&t.cs, cosets * A * 4));
+    const uint32_t w_N = kb::two_adic_generator(k + bl), w_B = kb::two_adic_generator(lb);
+    const uint32_t n_inv = kb::inv(kb::to_monty((uint32_t)(((size_t)1 << k) % kb::P)));
+    uint32_t sj = shift;
+    for (size_t j = 0; j < cosets; j++) {
+      uint32_t sA = sj;
+      for (int i = 0; i < la; i++) sA = kb::sqr(sA);
+      hipLaunchKernelGGL(lde::fill_scaled_stage_twiddles, dim3(div_up(B / 2, 256), lb), dim3(256), 0, stream, t.twf + j * B, w_B, lb, sA);
+      LAUNCH_CHECK();
+      sj = kb::mul(sj, w_N);
+    }
+    hipLaunchKernelGGL(lde::fill_row_scales, dim3(div_up(A * cosets, 256)), dim3(256), 0, stream, t.cs, shift, w_N, n_inv, (uint32_t)A, (uint32_t)cosets);
+    LAUNCH_CHECK();
+    coset_tabs[key] = t;
+    return t;
+  }
+  void drop_coset_tables() {   // stream must be idle
+    for (auto& kv : coset_tabs) { (void)hipFree(kv.second.twf); (void)hipFree(kv.second.cs); }
+    coset_tabs.clear();
+  }
 };
 
 struct zkm_matrix {

@@ -1,40 +1,106 @@
 // Part of libzkm_hip.so's host side (one translation unit: csrc/zkm_hip.hip includes this file). Pcs::commit on the device: coset LDE dispatch, Merkle tree construction (mixed heights, fused leaf kernel, lane-parallel top), pcs_commit.
 #pragma once
 // ---- device helpers ------------------------------------------------------------------------------
-static void lde_columns(zkm_ctx* ctx, const uint32_t* in, size_t n, size_t w, int bl, uint32_t lde_shift, uint32_t* out) {
-  if (w == 0) return;
-  int k = log2_strict(n);
-  int lb = std::min(k, lde::LOG_ROW_MAX), la = k - lb;
-  size_t N = n << bl;
-  size_t B = (size_t)1 << lb;
-  uint32_t w_n = kb::two_adic_generator(k), w_n_inv = kb::inv(w_n), w_N = kb::two_adic_generator(k + bl);
-  uint32_t n_inv = kb::inv(kb::to_monty((uint32_t)(n % kb::P)));
-  int nhi = B > 64 ? (int)(B >> 6) : 1;
-  size_t rows_lds = (2 * (B + (B >> 5)) + 64 + nhi) * 4;
-  const uint32_t* twf = lb > 0 ? ctx->twiddles(lb, false) : nullptr;
-  const uint32_t* twi = lb > 0 ? ctx->twiddles(lb, true) : nullptr;
-  if (la == 0) {
-    KLAUNCH(ctx, "lde_rows", 4.0 * n * w + 4.0 * N * w, lde::lde_rows, dim3(1, (unsigned)w), dim3(lde::THREADS), rows_lds, in, out,
-            lb, n, N, bl, lde_shift, w_N, n_inv, twf, twi);
-    return;
+// Coset LDE of a batch of column-major matrices (any heights), one launch per kernel for the whole batch (lde.cuh: Batch).
+struct LdeJob { const uint32_t* in; size_t n, w; uint32_t lde_shift; uint32_t* out; };
+
+static void lde_batch_chunk(zkm_ctx* ctx, const std::vector<LdeJob>& jobs, int bl) {
+  // groups = distinct heights, tallest first (the biggest blocks are queued first)
+  std::vector<size_t> order(jobs.size());
+  std::iota(order.begin(), order.end(), 0);
+  std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return jobs[a].n > jobs[b].n; });
+  std::vector<lde::Batch> hb(1);
+  lde::Batch& b = hb[0];
+  memset(&b, 0, sizeof b);
+  b.log_blowup = bl;
+  const size_t cosets = (size_t)1 << bl;
+  size_t tmp1_words = 0, tmp2_words = 0;
+  for (size_t oi : order) if (jobs[oi].n > ((size_t)1 << lde::LOG_ROW_MAX)) { tmp1_words += jobs[oi].n * jobs[oi].w; tmp2_words += (jobs[oi].n * jobs[oi].w) << bl; }
+  uint32_t* tmp1 = tmp1_words ? ctx->alloc_n<uint32_t>(tmp1_words) : nullptr;
+  uint32_t* tmp2 = tmp2_words ? ctx->alloc_n<uint32_t>(tmp2_words) : nullptr;
+  size_t t1 = 0, t2 = 0;
+  uint32_t blk[4] = {0, 0, 0, 0};
+  size_t lds_cols = 0, lds_small = 0;
+  double bytes_inv = 0, bytes_rows = 0, bytes_fwd = 0, bytes_small = 0;
+  int nm = 0;
+  for (size_t p = 0; p < order.size();) {
+    const size_t n = jobs[order[p]].n;
+    const int k = log2_strict(n);
+    const int lb = std::min(k, lde::LOG_ROW_MAX), la = k - lb;
+    lde::Group& g = b.g[b.n_groups];
+    g.la = la; g.lb = lb;
+    g.logT = la ? std::min(std::min(6, 14 - la), lb) : 0;  // la >= 1 implies lb = 13, so T >= 8
+    g.first_mat = nm;
+    g.w_N = kb::two_adic_generator(k + bl);
+    g.n_inv = kb::inv(kb::to_monty((uint32_t)(n % kb::P)));
+    g.twb_inv = lb > 0 ? ctx->twiddles(lb, true) : nullptr;
+    g.twb_fwd = lb > 0 ? ctx->twiddles(lb, false) : nullptr;
+    if (la) {
+      g.twa_inv = ctx->twiddles(la, true);
+      g.twa_fwd = ctx->twiddles(la, false);
+      auto pw = ctx->pow_tables(k);
+      g.pw_lo = pw.first; g.pw_hi = pw.second;
+    }
+    uint32_t cols = 0;
+    for (; p < order.size() && jobs[order[p]].n == n; p++) {
+      const LdeJob& j = jobs[order[p]];
+      lde::Mat& m = b.m[nm++];
+      m.in = j.in; m.out = j.out; m.col0 = cols; m.w = (uint32_t)j.w; m.shift = j.lde_shift;
+      if (la) {
+        m.tmp1 = tmp1 + t1; t1 += n * j.w;
+        m.tmp2 = tmp2 + t2; t2 += (n * j.w) << bl;
+        auto ct = ctx->coset_tables(k, bl, j.lde_shift);
+        m.twf = ct.twf; m.cs = ct.cs;
+      }
+      cols += (uint32_t)j.w;
+    }
+    g.n_cols = cols;
+    g.n_mats = nm - g.first_mat;
+    const double cells = (double)n * cols;
+    if (la) {
+      const size_t per_col = ((size_t)1 << lb) >> g.logT;
+      blk[lde::K_COLS_INV] += (uint32_t)(per_col * cols);
+      blk[lde::K_ROWS_BIG] += (uint32_t)(((size_t)1 << la) * cols);
+      blk[lde::K_COLS_FWD] += (uint32_t)(per_col * cols * cosets);
+      lds_cols = std::max(lds_cols, ((size_t)1 << la) * (((size_t)1 << g.logT) + 1) * 4);
+      bytes_inv += 8.0 * cells; bytes_rows += 4.0 * cells * (1 + cosets); bytes_fwd += 8.0 * cells * cosets;
+    } else {
+      blk[lde::K_ROWS_SMALL] += cols;
+      const size_t B = (size_t)1 << lb;
+      lds_small = std::max(lds_small, (2 * (B + (B >> 5)) + 64 + (B > 64 ? (B >> 6) : 1)) * 4);
+      bytes_small += 4.0 * cells * (1 + cosets);
+    }
+    for (int q = 0; q < 4; q++) g.blk_end[q] = blk[q];
+    b.n_groups++;
   }
-  size_t A = (size_t)1 << la;
-  int logT = std::min(std::min(6, 14 - la), lb);  // la >= 1 implies lb = 13, so T >= 8
-  size_t T = (size_t)1 << logT;
-  size_t cols_lds = A * (T + 1) * 4;  // padded tile rows
-  uint32_t* tmp1 = ctx->alloc_n<uint32_t>(n * w);
-  uint32_t* tmp2 = ctx->alloc_n<uint32_t>((n * w) << bl);
-  const uint32_t* twa_inv = ctx->twiddles(la, true);
-  const uint32_t* twa_fwd = ctx->twiddles(la, false);
-  KLAUNCH(ctx, "lde_cols_inverse", 8.0 * n * w, lde::lde_cols<false>, dim3((unsigned)(B / T), (unsigned)w, 1), dim3(lde::THREADS),
-          cols_lds, in, tmp1, la, lb, logT, n, (size_t)0, n, bl, twa_inv);
-  size_t big_lds = (B + (B >> 5) + 64 + nhi) * 4;
-  KLAUNCH(ctx, "lde_rows", 4.0 * n * w + 4.0 * N * w, lde::lde_rows_big, dim3((unsigned)A, (unsigned)w), dim3(lde::THREADS), big_lds,
-          (const uint32_t*)tmp1, tmp2, la, n, n, n * w, bl, lde_shift, w_n, w_n_inv, w_N, n_inv, twf, twi);
-  KLAUNCH(ctx, "lde_cols_forward", 8.0 * N * w, lde::lde_cols<true>, dim3((unsigned)(B / T), (unsigned)w, 1u << bl),
-          dim3(lde::THREADS), cols_lds, (const uint32_t*)tmp2, out, la, lb, logT, n, n * w, N, bl, twa_fwd);
+  const lde::Batch* d = (const lde::Batch*)ctx->upload(&b, sizeof b, nullptr);
+  if (blk[lde::K_COLS_INV]) {
+    constexpr size_t B = (size_t)1 << lde::LOG_ROW_MAX;
+    const size_t big_lds = (B + (B >> 5)) * 4;
+    KLAUNCH(ctx, "lde_cols_inverse", bytes_inv, lde::lde_cols<false>, dim3(blk[lde::K_COLS_INV]), dim3(lde::THREADS), lds_cols, d);
+    KLAUNCH(ctx, "lde_rows", bytes_rows, lde::lde_rows_big, dim3(blk[lde::K_ROWS_BIG]), dim3(lde::THREADS), big_lds, d);
+    KLAUNCH(ctx, "lde_cols_forward", bytes_fwd, lde::lde_cols<true>, dim3(blk[lde::K_COLS_FWD]), dim3(lde::THREADS), lds_cols, d);
+  }
+  if (blk[lde::K_ROWS_SMALL])
+    KLAUNCH(ctx, "lde_rows", bytes_small, lde::lde_rows, dim3(blk[lde::K_ROWS_SMALL]), dim3(lde::THREADS), lds_small, d);
   ctx->release(tmp1);
   ctx->release(tmp2);
+  ctx->release((void*)d);
+}
+
+static void lde_batch(zkm_ctx* ctx, const std::vector<LdeJob>& all, int bl) {
+  // a descriptor holds MAX_MATS matrices and MAX_GROUPS heights (24 covers every power of two up to the field's two-adicity minus the blow-up)
+  std::vector<LdeJob> jobs;
+  for (auto& j : all) {
+    if (j.w == 0) continue;
+    jobs.push_back(j);
+    if ((int)jobs.size() == lde::MAX_MATS) { lde_batch_chunk(ctx, jobs, bl); jobs.clear(); }
+  }
+  if (!jobs.empty()) lde_batch_chunk(ctx, jobs, bl);
+}
+
+static void lde_columns(zkm_ctx* ctx, const uint32_t* in, size_t n, size_t w, int bl, uint32_t lde_shift, uint32_t* out) {
+  lde_batch(ctx, {LdeJob{in, n, w, lde_shift, out}}, bl);
 }
 
 // Upload an array of device pointers (one per column) and return the device copy.
@@ -155,15 +221,29 @@ static zkm_pcs_data* pcs_commit(zkm_ctx* ctx, const std::vector<zkm_matrix>& mat
       d->eval_heights.push_back(m.h);
       d->domain_shifts.push_back(shifts.empty() ? kb::ONE : shifts[i]);
     }
-    // Each height's matrices are extended right before the tree layer that reads them (see build_tree).
+    // Matrices that are complete in HBM are all extended up front, one launch per kernel for the whole commit. A matrix still
+    // arriving over PCIe (zkm_matrix_upload_async) is extended right before the tree layer that reads it (see build_tree), so only
+    // the tallest trace's upload is exposed.
     std::vector<char> extended(mats.size(), 0);
+    auto shift_of = [&](size_t i) { return kb::mul(kb::GEN, kb::inv(d->domain_shifts[i])); };
+    {
+      std::vector<LdeJob> jobs;
+      for (size_t i = 0; i < mats.size(); i++)
+        if (!mats[i].ready || hipEventQuery(mats[i].ready) == hipSuccess) {   // never uploaded asynchronously, or landed already
+          jobs.push_back(LdeJob{mats[i].d, mats[i].h, mats[i].w, shift_of(i), d->ldes[i].d});
+          extended[i] = 1;
+        }
+      lde_batch(ctx, jobs, log_blowup);
+    }
     auto extend_height = [&](size_t lde_height) {
+      std::vector<LdeJob> jobs;
       for (size_t i = 0; i < mats.size(); i++) {
         if (extended[i] || d->ldes[i].h != lde_height) continue;
         wait_ready(ctx->stream, mats[i]);
-        lde_columns(ctx, mats[i].d, mats[i].h, mats[i].w, log_blowup, kb::mul(kb::GEN, kb::inv(d->domain_shifts[i])), d->ldes[i].d);
+        jobs.push_back(LdeJob{mats[i].d, mats[i].h, mats[i].w, shift_of(i), d->ldes[i].d});
         extended[i] = 1;
       }
+      lde_batch(ctx, jobs, log_blowup);
     };
     build_tree(ctx, d->ldes, d->tree, extend_height);
     for (size_t i = 0; i < mats.size(); i++)

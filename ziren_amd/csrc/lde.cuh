@@ -139,26 +139,79 @@ __device__ __forceinline__ uint32_t pow_lookup(const uint32_t* lo, const uint32_
   return kb::mul(lo[e & 63], hi[e >> 6]);
 }
 
+// ---- batch descriptors ------------------------------------------------------------------------------
+// One launch per kernel covers every matrix of a commit (round 3; before, each matrix had its own three launches and a
+// SYN-22 proof spent 96 dispatches and their ~8 us gaps on the LDEs alone). The matrices are grouped by height; a flat
+// blockIdx.x is mapped to (group, block inside the group) through the groups' cumulative block counts and then to
+// (matrix, column) through the matrices' first-column indices. The descriptor lives in device memory (one small upload per
+// commit); every index into it is wave-uniform, so the reads are scalar loads.
+constexpr int MAX_GROUPS = 24, MAX_MATS = 64;
+enum { K_COLS_INV = 0, K_ROWS_BIG = 1, K_COLS_FWD = 2, K_ROWS_SMALL = 3 };
+
+struct Mat {
+  const uint32_t* in;   // n x w evaluations, column-major
+  uint32_t* out;        // N x w LDE, column-major, rows bit-reversed
+  uint32_t* tmp1;       // n x w            (la > 0): the column after the strided inverse pass
+  uint32_t* tmp2;       // cosets x n x w   (la > 0): coset j's rows, natural frequency order, at tmp2 + j n w
+  const uint32_t* twf;  // la > 0: per coset the forward stage twiddles of the B-point row transform with the coset scaling folded in
+                        //         (cosets x B words, see fill_scaled_stage_twiddles); la == 0: unused
+  const uint32_t* cs;   // la > 0: cs[j A + k1] = shift_j^k1 / n
+  uint32_t col0, w;     // first column inside the group, width
+  uint32_t shift, pad;  // shift of coset 0 (shift_j = shift w_N^j)
+};
+struct Group {
+  int la, lb, logT, pad;
+  uint32_t n_cols, first_mat, n_mats, pad2;
+  uint32_t blk_end[4];                     // cumulative number of blocks up to and including this group, per kernel
+  const uint32_t *twb_fwd, *twb_inv;       // stage-major twiddles of the B-point transform (la == 0 uses both, la > 0 the inverse)
+  const uint32_t *twa_fwd, *twa_inv;       // of the A-point transform
+  const uint32_t *pw_lo, *pw_hi;           // w_n^e = pw_lo[e & 1023] * pw_hi[e >> 10]
+  uint32_t w_N, n_inv, pad3[2];
+};
+struct Batch {
+  int n_groups, log_blowup;
+  Group g[MAX_GROUPS];
+  Mat m[MAX_MATS];
+};
+
+__device__ __forceinline__ const Group& find_group(const Batch* __restrict__ d, int which, uint32_t& local) {
+  uint32_t gi = 0, start = 0;
+  const uint32_t b = blockIdx.x;
+  while (b >= d->g[gi].blk_end[which]) { start = d->g[gi].blk_end[which]; gi++; }
+  local = b - start;
+  return d->g[gi];
+}
+__device__ __forceinline__ const Mat& find_mat(const Batch* __restrict__ d, const Group& g, uint32_t col) {
+  uint32_t mi = g.first_mat;
+  while (col >= d->m[mi].col0 + d->m[mi].w) mi++;
+  return d->m[mi];
+}
+
 // Step 1 / 3: A-point transforms down the strided dimension of each column.
-// grid = (B / T, width, n_cosets); in/out are column-major with `col_stride` words per column.
+// Blocks of a group: (B / T) x columns (x cosets for FORWARD), x fastest. in/out are column-major.
 // The LDS tile is [A][T + 1] (one pad word per row: the transposed read-out below walks down a column).
-// FORWARD == false: inverse DIF over rows i1 (natural) -> rows in bit-reversed k1 order, written back in place.
-// FORWARD == true : rows arrive in natural k1 order (lde_rows stores row k1 = bitrev(pr)); a forward DIF
+// FORWARD == false: inverse DIF over rows i1 (natural) -> rows in bit-reversed k1 order, written to tmp1.
+// FORWARD == true : rows arrive in natural k1 order (lde_rows_big stores row k1 = bitrev(pr)); a forward DIF
 //                   leaves row q holding L[B * bitrev_la(q) + j0], which belongs at
-//                   out[c * out_col_stride + out_block(z) * n + bitrev_lb(j0) * A + q]:
+//                   out[c * N + out_block(z) * n + bitrev_lb(j0) * A + q]:
 //                   one contiguous A-word segment per tile column.
 template <bool FORWARD>
-__global__ __launch_bounds__(THREADS) void lde_cols(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, int la, int lb,
-                                                    int logT, size_t in_col_stride, size_t in_coset_stride,
-                                                    size_t out_col_stride, int log_blowup,
-                                                    const uint32_t* __restrict__ tw) {
+__global__ __launch_bounds__(THREADS) void lde_cols(const Batch* __restrict__ d) {
   extern __shared__ uint32_t lds[];
+  uint32_t local;
+  const Group& g = find_group(d, FORWARD ? K_COLS_FWD : K_COLS_INV, local);
+  const int la = g.la, lb = g.lb, logT = g.logT, log_blowup = d->log_blowup;
   const int A = 1 << la, T = 1 << logT, TP = T + 1;
-  const size_t B = (size_t)1 << lb;
-  const size_t t0 = (size_t)blockIdx.x << logT;
-  const size_t c = blockIdx.y;
-  const int z = blockIdx.z;
-  const uint32_t* src = in + c * in_col_stride + (size_t)z * in_coset_stride + t0;
+  const size_t B = (size_t)1 << lb, n = (size_t)A << lb;
+  const uint32_t xb = local & ((1u << (lb - logT)) - 1);
+  const uint32_t rest = local >> (lb - logT);
+  const uint32_t col = FORWARD ? rest % g.n_cols : rest;
+  const int z = FORWARD ? (int)(rest / g.n_cols) : 0;
+  const Mat& m = find_mat(d, g, col);
+  const size_t c = col - m.col0;
+  const size_t t0 = (size_t)xb << logT;
+  const uint32_t* src = (FORWARD ? m.tmp2 + (size_t)z * n * m.w : m.in) + c * n + t0;
+  const uint32_t* __restrict__ tw = FORWARD ? g.twa_fwd : g.twa_inv;
   // 16-byte global accesses (T >= 8), four in flight per thread
   const int logTq = logT - 2;
   const int quads = (A << logT) >> 2;
@@ -173,22 +226,21 @@ __global__ __launch_bounds__(THREADS) void lde_cols(const uint32_t* __restrict__
     for (int k = 0; k < 4; k++) {
       int u = u0 + k * blockDim.x;
       if (u < quads) {
-        uint32_t* d = lds + (u >> logTq) * TP + ((u & ((1 << logTq) - 1)) << 2);
-        d[0] = v[k].x; d[1] = v[k].y; d[2] = v[k].z; d[3] = v[k].w;
+        uint32_t* dd = lds + (u >> logTq) * TP + ((u & ((1 << logTq) - 1)) << 2);
+        dd[0] = v[k].x; dd[1] = v[k].y; dd[2] = v[k].z; dd[3] = v[k].w;
       }
     }
   }
   __syncthreads();
   lds_ntt<true, false>(lds, la, logT, TP, tw);  // DIF either way: natural rows in, bit-reversed rows out
   if (!FORWARD) {
-    uint32_t* dst = out + c * out_col_stride + t0;
+    uint32_t* dst = m.tmp1 + c * n + t0;
     for (int u0 = threadIdx.x; u0 < quads; u0 += blockDim.x) {
       const uint32_t* sp = lds + (u0 >> logTq) * TP + ((u0 & ((1 << logTq) - 1)) << 2);
       *reinterpret_cast<uint4*>(dst + (size_t)(u0 >> logTq) * B + ((u0 & ((1 << logTq) - 1)) << 2)) = make_uint4(sp[0], sp[1], sp[2], sp[3]);
     }
   } else {
-    const size_t n = (size_t)A << lb;
-    uint32_t* dst = out + c * out_col_stride + (size_t)kb::bitrev(z, log_blowup) * n;
+    uint32_t* dst = m.out + c * (n << log_blowup) + (size_t)kb::bitrev(z, log_blowup) * n;
     if (la < 2) {  // A = 2: scalar stores
       for (int u = threadIdx.x; u < (A << logT); u += blockDim.x) {
         const int t = u >> la, q = u & (A - 1);
@@ -206,17 +258,14 @@ __global__ __launch_bounds__(THREADS) void lde_cols(const uint32_t* __restrict__
   }
 }
 
-// Step 2: one block per (row k1-position pr, column c).
-//   in : column-major, the column after lde_cols<false> (or the raw trace column when la == 0)
-//   la == 0: writes the finished LDE column to `out` (height n << log_blowup per column)
-//   la  > 0: writes coset j's row to tmp[(j * width + c) * n + k1 * B + j0] for lde_cols<true>
-// Step 2 when the whole column fits one LDS row (n = B <= 8192, A = 1): grid = (1, width); reads the column once,
+// Step 2 when the whole column fits one LDS row (n = B <= 8192, A = 1): one block per column; reads the column once,
 // writes its LDE once, rows already bit-reversed. Taller columns go through lde_rows_big below.
-__global__ __launch_bounds__(THREADS) void lde_rows(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, int lb,
-                                                    size_t in_col_stride, size_t out_col_stride, int log_blowup, uint32_t shift,
-                                                    uint32_t w_N, uint32_t n_inv, const uint32_t* __restrict__ tw_fwd,
-                                                    const uint32_t* __restrict__ tw_inv) {
+__global__ __launch_bounds__(THREADS) void lde_rows(const Batch* __restrict__ d) {
   extern __shared__ uint32_t lds[];
+  uint32_t col;
+  const Group& g = find_group(d, K_ROWS_SMALL, col);
+  const Mat& m = find_mat(d, g, col);
+  const int lb = g.lb, log_blowup = d->log_blowup;
   const int B = 1 << lb;
   const int nhi = B > 64 ? (B >> 6) : 1;
   const int BP = B + (B >> 5);     // padded length, see phys<>
@@ -224,65 +273,75 @@ __global__ __launch_bounds__(THREADS) void lde_rows(const uint32_t* __restrict__
   uint32_t* work = lds + BP;       // BP
   uint32_t* lo2 = work + BP;       // 64   powers of shift_j   (coset scaling)
   uint32_t* hi2 = lo2 + 64;        // nhi
-  const size_t c = blockIdx.y;
-  const uint32_t* src = in + c * in_col_stride;
+  const size_t c = col - m.col0;
+  const uint32_t* src = m.in + c * B;
+  const uint32_t* __restrict__ tw_fwd = g.twb_fwd;
+  const uint32_t* __restrict__ tw_inv = g.twb_inv;
   for (int i = threadIdx.x; i < B; i += blockDim.x) coef[phys<true>(i)] = src[i];
   __syncthreads();
   if (lb > 0) lds_ntt<true, true>(coef, lb, 0, 1, tw_inv);
   // coef[pc] = n * c_k with k = bitrev_lb(pc)
   const int ncosets = 1 << log_blowup;
-  uint32_t sj = shift;
+  uint32_t sj = m.shift;
   for (int j = 0; j < ncosets; j++) {
     // shift_j = shift * w_N^j
     __syncthreads();
-    build_pow_table(sj, lo2, hi2, nhi, n_inv);  // 1/n folded in
+    build_pow_table(sj, lo2, hi2, nhi, g.n_inv);  // 1/n folded in
     __syncthreads();
     for (int i = threadIdx.x; i < B; i += blockDim.x)
       work[phys<true>(i)] = kb::mul(coef[phys<true>(i)], pow_lookup(lo2, hi2, kb::bitrev(i, lb)));
     __syncthreads();
     if (lb > 0) lds_ntt<false, true>(work, lb, 0, 1, tw_fwd);
-    uint32_t* dst = out + c * out_col_stride + (size_t)kb::bitrev(j, log_blowup) * B;
+    uint32_t* dst = m.out + c * ((size_t)B << log_blowup) + (size_t)kb::bitrev(j, log_blowup) * B;
     for (int i = threadIdx.x; i < B; i += blockDim.x) dst[i] = work[phys<true>(kb::bitrev(i, lb))];
-    sj = kb::mul(sj, w_N);
+    sj = kb::mul(sj, g.w_N);
   }
 }
 
-// Step 2 for n > 8192 (la > 0, B = 8192, 512 threads), grid = (A, width): the data stays in registers wherever
-// two neighbouring steps touch the same points, so one 35 KiB LDS buffer and 9 LDS round trips per row (3 for the
-// inverse transform, 3 per coset) instead of one per four stages plus one for every twiddle / scaling step:
+// Step 2 for n > 8192 (la > 0, B = 8192, 512 threads), blocks of a group = A x columns (row position fastest): the data stays
+// in registers wherever two neighbouring steps touch the same points, so one 33 KiB LDS buffer and 9 LDS round trips per row
+// (3 for the inverse transform, 3 per coset) instead of one per four stages plus one for every twiddle / scaling step:
 //   * the load (with its w_n^(-i0 k1) twiddle) feeds the first inverse pass directly: thread g owns i0 = g + 512 j;
 //   * the last inverse stage (pairs 2g, 2g+1) leaves the 16 coefficients of a thread in VGPRs, where they stay
-//     for every coset: scale, the first forward stage (the same pairs) and only then LDS;
+//     for every coset;
+//   * per coset the scaling by shift_j^k is NOT a step of its own (round 3): a forward DIT whose stage twiddles are
+//     (shift_j^A w_B^off)^(2^s) instead of w_B^(off 2^s) evaluates on the shifted coset directly (P(z) = Pe(z^2) + z Po(z^2)
+//     with z = shift_j^A w^off), so the first forward stage works straight from the kept coefficients as a lazy butterfly
+//     with one wave-uniform twiddle; what is left of the scaling, the row's constant shift_j^k1 / n, rides on the store twiddle;
 //   * the last forward pass (again i = g + 512 j) goes from registers through the w_n^(j0 k1) twiddle to HBM.
-__global__ __launch_bounds__(THREADS, 4) void lde_rows_big(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, int la,
-                                                        size_t in_col_stride, size_t out_col_stride, size_t out_coset_stride,
-                                                        int log_blowup, uint32_t shift, uint32_t w_n, uint32_t w_n_inv,
-                                                        uint32_t w_N, uint32_t n_inv, const uint32_t* __restrict__ tw_fwd,
-                                                        const uint32_t* __restrict__ tw_inv) {
-  constexpr uint32_t LB = LOG_ROW_MAX, B = 1u << LB, BP = B + (B >> 5), NHI = B >> 6;
+// Everything a block needs that depends only on its row k1 — w_n^(+-k1 tid), w_n^(+-512 k1), shift_j^k1 / n — comes from
+// small tables (two multiplications per lookup) instead of square-and-multiply chains run redundantly by every thread:
+// those chains were ~76 of the kernel's 336 VALU instructions per point.
+__global__ __launch_bounds__(THREADS, 4) void lde_rows_big(const Batch* __restrict__ d) {
+  constexpr uint32_t LB = LOG_ROW_MAX, B = 1u << LB, BP = B + (B >> 5);
   constexpr uint32_t G = B / THREADS;  // points per thread (16)
   static_assert(G == 16 && LB == 13, "pass structure below is written for 8192 points on 512 threads");
   extern __shared__ uint32_t lds[];
   uint32_t* work = lds;          // BP
-  uint32_t* lo2 = work + BP;     // 64   powers of shift_j^A (coset scaling)
-  uint32_t* hi2 = lo2 + 64;      // NHI
+  uint32_t local;
+  const Group& g = find_group(d, K_ROWS_BIG, local);
+  const uint32_t la = g.la;
   const uint32_t tid = threadIdx.x;
-  const uint32_t pr = blockIdx.x;
-  const size_t c = blockIdx.y;
+  const uint32_t pr = local & ((1u << la) - 1);
+  const uint32_t col = local >> la;
+  const Mat& m = find_mat(d, g, col);
+  const size_t c = col - m.col0;
+  const size_t n = (size_t)B << la;
+  const uint32_t nmask = (uint32_t)n - 1;
   const uint32_t k1 = kb::bitrev(pr, la);
-  const uint32_t* src = in + c * in_col_stride + (size_t)pr * B;
+  const uint32_t* src = m.tmp1 + c * n + (size_t)pr * B;
+  const uint32_t* __restrict__ tw_inv = g.twb_inv;
+  const uint32_t* __restrict__ pw_lo = g.pw_lo;
+  const uint32_t* __restrict__ pw_hi = g.pw_hi;
+  auto pw = [&](uint32_t e) { return kb::mul(pw_lo[e & 1023], pw_hi[e >> 10]); };  // w_n^e, e < n
 
   uint32_t x[16];
 #pragma unroll
   for (uint32_t j = 0; j < 16; j++) x[j] = src[tid + (j << 9)];
   {
     // x_j *= w_n^(-k1 (tid + 512 j))
-    uint32_t a = kb::pow(w_n_inv, (uint64_t)k1), t = kb::ONE;
-#pragma unroll
-    for (uint32_t b = 0; b < 9; b++) {
-      if ((tid >> b) & 1) t = kb::mul(t, a);
-      a = kb::sqr(a);
-    }
+    uint32_t t = pw((0u - k1 * tid) & nmask);
+    const uint32_t a = pw((0u - (k1 << 9)) & nmask);
 #pragma unroll
     for (uint32_t j = 0; j < 16; j++) {
       x[j] = kb::mul(x[j], t);
@@ -306,49 +365,38 @@ __global__ __launch_bounds__(THREADS, 4) void lde_rows_big(const uint32_t* __res
     keep[2 * k + 1] = kb::sub(a, b);
   }
   // store twiddle w_n^(k1 (tid + 512 j)): first factor and step
-  uint32_t st0 = kb::ONE, st_step = kb::pow(w_n, (uint64_t)k1);
-#pragma unroll
-  for (uint32_t b = 0; b < 9; b++) {
-    if ((tid >> b) & 1) st0 = kb::mul(st0, st_step);
-    st_step = kb::sqr(st_step);
-  }
-  const uint32_t ncosets = 1u << log_blowup;
-  uint32_t sj = shift;
+  const uint32_t st0 = pw((k1 * tid) & nmask), st_step = pw((k1 << 9) & nmask);
+  const uint32_t ncosets = 1u << d->log_blowup;
   for (uint32_t j = 0; j < ncosets; j++) {
-    // shift_j = shift * w_N^j
-    uint32_t sA = sj;
-    for (int i = 0; i < la; i++) sA = kb::sqr(sA);
-    uint32_t sA_half = sA;  // sA^(B/2): bitrev_13(2g + 1) = bitrev_13(2g) + B/2
-    for (uint32_t i = 0; i < LB - 1; i++) sA_half = kb::sqr(sA_half);
-    build_pow_table(sA, lo2, hi2, NHI, kb::mul(n_inv, kb::pow(sj, (uint64_t)k1)));  // 1/n * shift_j^k1 folded in
-    __syncthreads();  // table visible; every reader of `work` from the previous step is done
+    const uint32_t* __restrict__ tw_fwd = m.twf + (size_t)j * B;  // stage twiddles (shift_j^A w_B^off)^(2^s)
+    const uint32_t t_first = tw_fwd[B - 2];                       // stage 12 (span 1): shift_j^(A B / 2)
+    const uint32_t cj = m.cs[(j << la) + k1];                     // shift_j^k1 / n
+    __syncthreads();  // every reader of `work` from the previous step is done
     // The LDS/global addresses below are the same for every coset; left alone the optimiser hoists all of them out
     // of this loop and the kernel needs 160 VGPRs. An opaque copy of the thread index keeps them loop-local.
     uint32_t lt = tid;
     asm volatile("" : "+v"(lt));
 #pragma unroll
     for (uint32_t k = 0; k < 8; k++) {
-      const uint32_t g = lt + (k << 9);
-      const uint32_t p0 = pow_lookup(lo2, hi2, kb::bitrev(g, LB - 1));
-      const uint32_t p1 = kb::mul(p0, sA_half);
-      const uint32_t a = kb::mul(keep[2 * k], p0), b = kb::mul(keep[2 * k + 1], p1);
-      work[phys<true>(2 * g)] = kb::add(a, b);  // first forward stage (span 1, twiddle 1)
-      work[phys<true>(2 * g + 1)] = kb::sub(a, b);
+      const uint32_t gg = lt + (k << 9);
+      // first forward stage (span 1) as a lazy butterfly: a + t b, a - t b, kept as signed words from here to the store
+      const int64_t ar = kb::mad_i64_i32_uniform((int32_t)keep[2 * k], kb::ONE, 0);
+      work[phys<true>(2 * gg)] = (uint32_t)kb::monty_reduce_signed(kb::mad_i64_i32_uniform((int32_t)keep[2 * k + 1], t_first, ar));
+      work[phys<true>(2 * gg + 1)] = (uint32_t)kb::monty_reduce_signed(kb::mad_i64_i32_uniform(-(int32_t)keep[2 * k + 1], t_first, ar));
     }
     __syncthreads();
-    ntt_pass<false, 4, true, true>(work, LB, 0, 1, 8, tw_fwd, lt);  // lazy from here to the store
+    ntt_pass<false, 4, true, true>(work, LB, 0, 1, 8, tw_fwd, lt);
     ntt_pass<false, 4, true, true>(work, LB, 0, 1, 4, tw_fwd, lt);
 #pragma unroll
     for (uint32_t q = 0; q < 16; q++) x[q] = work[phys<true>(lt + (q << 9))];
     butterflies<false, 4, true>(x, B, 0, lt, 9, tw_fwd);
-    uint32_t* dst = out + (size_t)j * out_coset_stride + c * out_col_stride + (size_t)k1 * B;  // row k1: natural order for lde_cols<true>
-    uint32_t t = st0;
+    uint32_t* dst = m.tmp2 + (size_t)j * n * m.w + c * n + (size_t)k1 * B;  // row k1: natural order for lde_cols<true>
+    uint32_t t = kb::mul(st0, cj);
 #pragma unroll
     for (uint32_t q = 0; q < 16; q++) {
       dst[lt + (q << 9)] = kb::mul_signed(x[q], t);  // brings the lazy value back to [0, p)
       t = kb::mul(t, st_step);
     }
-    sj = kb::mul(sj, w_N);
   }
 }
 
@@ -359,6 +407,33 @@ __global__ void fill_stage_twiddles(uint32_t* tw, uint32_t w, int logn) {
   const int s = blockIdx.y;
   size_t off = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (off < (n >> (s + 1))) tw[n - (n >> s) + off] = kb::pow(w, (uint64_t)off << s);
+}
+
+// The same table with a coset shift folded in: tw[n - (n >> s) + off] = (g w^off)^(2^s) = g^(2^s) w^(off << s). A forward DIT run
+// with it evaluates the polynomial on g <w> instead of <w>: the sub-transform of stage s works in the variable y = z^(2^s), and
+// P(y) = Pe(y^2) + y Po(y^2) makes y itself the butterfly's twiddle.
+__global__ void fill_scaled_stage_twiddles(uint32_t* tw, uint32_t w, int logn, uint32_t g) {
+  const size_t n = (size_t)1 << logn;
+  const int s = blockIdx.y;
+  size_t off = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (off < (n >> (s + 1))) {
+    uint32_t gs = g;
+    for (int i = 0; i < s; i++) gs = kb::sqr(gs);
+    tw[n - (n >> s) + off] = kb::mul(gs, kb::pow(w, (uint64_t)off << s));
+  }
+}
+// lo[i] = w^i (i < 1024), hi[i] = w^(1024 i) (i < n_hi): w^e = lo[e & 1023] * hi[e >> 10]
+__global__ void fill_pow_tables(uint32_t* lo, uint32_t* hi, uint32_t w, uint32_t n_hi) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < 1024) lo[i] = kb::pow(w, (uint64_t)i);
+  if (i < n_hi) hi[i] = kb::pow(w, (uint64_t)i << 10);
+}
+// cs[j A + k1] = (shift w_N^j)^k1 / n for j < cosets, k1 < A
+__global__ void fill_row_scales(uint32_t* cs, uint32_t shift, uint32_t w_N, uint32_t n_inv, uint32_t A, uint32_t cosets) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= A * cosets) return;
+  const uint32_t j = i / A, k1 = i % A;
+  cs[i] = kb::mul(n_inv, kb::pow(kb::mul(shift, kb::pow(w_N, (uint64_t)j)), (uint64_t)k1));
 }
 
 }  // namespace lde

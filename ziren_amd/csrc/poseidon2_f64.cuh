@@ -11,8 +11,10 @@
 //     q = rint(h/p), r = fma(-q,p,h) (exact: an integer below 2^53), result r + l. Six instructions, no carries;
 //   * the internal layer's diagonal (+-2^-k, small integers) is a shift of the exponent plus one fma.
 // Every operation below is exact integer arithmetic as long as the stated magnitude bounds hold; they are
-// re-derived next to each step and hammered by tests/test_poseidon2_f64 (host build of this very code, which uses the
-// same IEEE operations) and by the GPU parity tests against the integer version and the oracle.
+// re-derived next to each step and hammered by tests/test_host_abi.py::test_fp64_poseidon2_* (host build of this very code, which
+// uses the same IEEE operations: plain words, unreduced sponges and compress-with-injection chains on adversarial states, with the
+// magnitudes below *measured* by the probes of the host build and held against the documented bounds) and by the GPU parity
+// tests against the integer version and the oracle.
 //
 // Interface: load_monty (u32 Montgomery word -> canonical double in (-p, 0]), permute, store_monty (-> [0, p) Montgomery).
 #pragma once
@@ -25,6 +27,17 @@ constexpr double PINV = 1.0 / 2130706433.0;  // RN(1/p): relative error <= 2^-53
 
 KB_HD double fma_(double a, double b, double c) { return __builtin_fma(a, b, c); }
 KB_HD double rne(double x) { return __builtin_rint(x); }  // v_rndne_f64 (round to nearest even, the default mode on the host too)
+
+// Host build only: the largest magnitudes seen at the points the exactness argument rests on (a permutation's inputs, the lane sum
+// of a partial round before its reduction, an S-box input, any lane after a partial round). The device build compiles them away.
+struct Audit { double in = 0, lane_sum = 0, sbox_in = 0, lane = 0; };
+inline Audit& audit() { static thread_local Audit a; return a; }
+inline void probe(double& slot, double v) { v = v < 0 ? -v : v; if (v > slot) slot = v; }
+#if !defined(__HIP_DEVICE_COMPILE__)
+#define P2F_PROBE(slot, v) probe(audit().slot, (v))
+#else
+#define P2F_PROBE(slot, v) ((void)0)
+#endif
 
 // canonical tables as balanced doubles (filled by upload_tables / the host mirror below)
 __constant__ double d_rc_ext[8][16];
@@ -47,6 +60,7 @@ KB_HD double mulmod(double a, double b) {
 // (y)^3 for |y| < 2^41: |y^2| < 2^82 -> |z| <= p/2 + p*2^-0.9.. ; for the |y| <= 2^36.3 met in steady state |z| < 2^30.01
 // and |z y| < 2^66.4 -> |w| <= p/2 + 2^15.
 KB_HD double sbox(double y) {
+  P2F_PROBE(sbox_in, y);
   const double z = mulmod(y, y);
   return mulmod(z, y);
 }
@@ -91,9 +105,14 @@ KB_HD double div2k_add(double x, double add) {
 }
 
 // s_i <- V_i s_i + sum(s), V = [-2, 1, 2, 1/2, 3, 4, -1/2, -3, -4, 2^-8, 1/8, 2^-24, -2^-8, -1/8, -1/16, -2^-24]
+// The two 2^-24 entries are the small integers -+127 modulo p (p - 1 = 127 * 2^24), one fma each instead of the five
+// instructions of div2k_add; those two lanes then grow by 2^7 per round and are reduced every other round (permute_impl).
 KB_HD void internal_layer(double s[16]) {
   double sum = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
   sum += ((s[8] + s[9]) + (s[10] + s[11])) + ((s[12] + s[13]) + (s[14] + s[15]));
+#if !defined(__HIP_DEVICE_COMPILE__)
+  { double a = 0; for (int i = 0; i < 16; i++) a += s[i] < 0 ? -s[i] : s[i]; P2F_PROBE(lane_sum, a); }  // sum of magnitudes: no order of the additions can exceed it
+#endif
   sum = reduce(sum);
   s[0] = fma_(-2.0, s[0], sum);
   s[1] = s[1] + sum;
@@ -106,11 +125,11 @@ KB_HD void internal_layer(double s[16]) {
   s[8] = fma_(-4.0, s[8], sum);
   s[9] = div2k_add<8, 1>(s[9], sum);
   s[10] = div2k_add<3, 1>(s[10], sum);
-  s[11] = div2k_add<24, 1>(s[11], sum);
+  s[11] = fma_(-127.0, s[11], sum);  // 2^-24 = -127 (mod p): 127 * 2^24 = p - 1
   s[12] = div2k_add<8, -1>(s[12], sum);
   s[13] = div2k_add<3, -1>(s[13], sum);
   s[14] = div2k_add<4, -1>(s[14], sum);
-  s[15] = div2k_add<24, -1>(s[15], sum);
+  s[15] = fma_(127.0, s[15], sum);   // -2^-24 = 127
 }
 
 // Magnitudes (B = 2^30 + 2^15 bounds an S-box output; inputs of a permutation: |s_i| <= 2^35.3):
@@ -119,9 +138,14 @@ KB_HD void internal_layer(double s[16]) {
 //  partial rounds: lane 0 is an S-box output (< B) before the layer and <= 2 B + |sum| after; the lanes with a 2^-k diagonal
 //  contract (|s|/2 + 2^30 + |sum| + 1); lane 1 grows by |sum| <= p/2 + 2^11 per round; the integer-diagonal lanes 2, 4, 5, 7, 8
 //  grow by at most x4 + |sum| per round and are reduced after rounds 4 and 9, so they stay below 2^35.2 * 4^5 + ... < 2^46,
-//  the lane sum below 2^50, and they leave the last round below 2^30 * 4^3 + 2^33 < 2^37.
+//  and they leave the last round below 2^30 * 4^3 + 2^33 < 2^37; lanes 11 and 15 (diagonal -+127) grow by x127 + |sum| per round and
+//  are reduced after every odd round: 2^35.2 -> 2^42.2 -> 2^49.2 once at the start, afterwards 2^30 -> 2^37 -> 2^44, and they leave the
+//  last (even) round below 2^37.1. The lane sum stays below 2 * 2^49.2 + 5 * 2^46 + 9 * 2^36 < 2^50.4 (reduce() takes |x| < 2^52).
 template <class RcExt, class RcInt>
 KB_HD void permute_impl(double s[16], RcExt rc_ext, RcInt rc_int) {
+#if !defined(__HIP_DEVICE_COMPILE__)
+  for (int i = 0; i < 16; i++) P2F_PROBE(in, s[i]);
+#endif
   external_layer(s);
 #pragma unroll
   for (int r = 0; r < 4; r++) {
@@ -136,6 +160,10 @@ KB_HD void permute_impl(double s[16], RcExt rc_ext, RcInt rc_int) {
     if (r == 4 || r == 9) {
       s[2] = reduce(s[2]); s[4] = reduce(s[4]); s[5] = reduce(s[5]); s[7] = reduce(s[7]); s[8] = reduce(s[8]);
     }
+    if (r & 1) { s[11] = reduce(s[11]); s[15] = reduce(s[15]); }
+#if !defined(__HIP_DEVICE_COMPILE__)
+    for (int i = 0; i < 16; i++) P2F_PROBE(lane, s[i]);
+#endif
   }
 #pragma unroll
   for (int r = 4; r < 8; r++) {
@@ -199,6 +227,36 @@ inline void permute_host_words(uint32_t w[16]) {
   for (int i = 0; i < 16; i++) s[i] = load_monty(w[i]);
   permute_host(s);
   for (int i = 0; i < 16; i++) w[i] = store_monty(s[i]);
+}
+
+// Host mirrors of the hashing kernels' data flow (merkle.cuh), state kept in doubles exactly as there:
+// absorb_row / hash_leaves: overwrite the rate with the next <= 8 words, permute, capacity carried on unreduced
+inline void sponge_host(const uint32_t* words, size_t n, uint32_t digest[8]) {
+  double s[16];
+  for (int i = 0; i < 16; i++) s[i] = 0.0;
+  for (size_t g0 = 0; g0 < n; g0 += 8) {
+    for (size_t i = 0; i < 8 && g0 + i < n; i++) s[i] = load_monty(words[g0 + i]);
+    permute_host(s);
+  }
+  for (int i = 0; i < 8; i++) digest[i] = store_monty(s[i]);
+}
+// compress_layer: node = compress(left, right); with an injected row: node = compress(node, hash(row)), both halves handed over
+// as unreduced doubles
+inline void compress_inject_host(const uint32_t left[8], const uint32_t right[8], const uint32_t* row, size_t n, uint32_t out[8]) {
+  double s[16], node[8];
+  for (int i = 0; i < 8; i++) { s[i] = load_monty(left[i]); s[8 + i] = load_monty(right[i]); }
+  permute_host(s);
+  if (n > 0) {
+    for (int i = 0; i < 8; i++) node[i] = s[i];
+    for (int i = 0; i < 16; i++) s[i] = 0.0;
+    for (size_t g0 = 0; g0 < n; g0 += 8) {
+      for (size_t i = 0; i < 8 && g0 + i < n; i++) s[i] = load_monty(row[g0 + i]);
+      permute_host(s);
+    }
+    for (int i = 0; i < 8; i++) { s[8 + i] = s[i]; s[i] = node[i]; }
+    permute_host(s);
+  }
+  for (int i = 0; i < 8; i++) out[i] = store_monty(s[i]);
 }
 
 inline hipError_t upload_tables() {

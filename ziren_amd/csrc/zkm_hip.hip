@@ -129,6 +129,8 @@ void zkm_ctx_destroy(zkm_ctx* ctx) {
   for (auto& kv : ctx->live) (void)hipFree(kv.first);
   for (auto& kv : ctx->tw_fwd) (void)hipFree(kv.second);
   for (auto& kv : ctx->tw_inv) (void)hipFree(kv.second);
+  for (auto& kv : ctx->pow_tabs) { (void)hipFree(kv.second.first); (void)hipFree(kv.second.second); }
+  ctx->drop_coset_tables();
   for (auto& m : ctx->marks) (void)hipEventDestroy(m.second);
   for (auto& e : ctx->event_pool) (void)hipEventDestroy(e);
   for (auto& m : ctx->modules) (void)hipModuleUnload(m);
@@ -151,6 +153,7 @@ int zkm_ctx_trim(zkm_ctx* ctx) {
   HIP_CHECK(hipStreamSynchronize(ctx->stream));
   for (auto& kv : ctx->free_list) HIP_CHECK(hipFree(kv.second));
   ctx->free_list.clear();
+  ctx->drop_coset_tables();
   API_END
 }
 
@@ -633,6 +636,15 @@ uint32_t zkm_challenger_sample_bits(zkm_challenger* c, uint32_t bits) { return c
 // host-side arithmetic of the transcript layer, exposed for the CPU-only parity tests
 void zkm_host_poseidon2_permute(uint32_t state[16]) { p2::permute_host(state); }
 void zkm_host_poseidon2_permute_f64(uint32_t state[16]) { p2f::permute_host_words(state); }
+void zkm_host_poseidon2_f64_sponge(const uint32_t* words, size_t n, uint32_t digest[8]) { p2f::sponge_host(words, n, digest); }
+void zkm_host_poseidon2_f64_compress_inject(const uint32_t left[8], const uint32_t right[8], const uint32_t* row, size_t n, uint32_t out[8]) {
+  p2f::compress_inject_host(left, right, row, n, out);
+}
+void zkm_host_poseidon2_f64_audit(double out[4], int reset) {
+  p2f::Audit& a = p2f::audit();
+  out[0] = a.in; out[1] = a.lane_sum; out[2] = a.sbox_in; out[3] = a.lane;
+  if (reset) a = p2f::Audit();
+}
 void zkm_host_ext_mul(const uint32_t a[4], const uint32_t b[4], uint32_t out[4]) {
   E4 r = kb::emul(E4{{a[0], a[1], a[2], a[3]}}, E4{{b[0], b[1], b[2], b[3]}});
   memcpy(out, r.c, 16);

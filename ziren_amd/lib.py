@@ -19,7 +19,8 @@ EXPORTS = [
     "zkm_tracegen_alu_width", "zkm_byte_lookups_create", "zkm_byte_lookups_free", "zkm_tracegen_alu", "zkm_tracegen_jump_width", "zkm_tracegen_jump", "zkm_tracegen_branch_width", "zkm_tracegen_branch", "zkm_tracegen_mov_cond_width", "zkm_tracegen_mov_cond", "zkm_tracegen_mul_width", "zkm_tracegen_mul", "zkm_tracegen_divrem_width", "zkm_tracegen_divrem", "zkm_tracegen_cpu_width", "zkm_tracegen_cpu", "zkm_tracegen_cpu_and_program", "zkm_tracegen_program", "zkm_tracegen_program_mults", "zkm_tracegen_memory_local", "zkm_tracegen_global", "zkm_tracegen_misc_instrs_width", "zkm_tracegen_misc_instrs", "zkm_tracegen_syscall_instrs_width", "zkm_tracegen_syscall_instrs", "zkm_tracegen_syscall", "zkm_tracegen_memory_global", "zkm_tracegen_poseidon2_permute", "zkm_tracegen_keccak_sponge", "zkm_tracegen_sha_extend", "zkm_tracegen_sha_compress", "zkm_tracegen_ed_add", "zkm_tracegen_ed_decompress", "zkm_tracegen_weierstrass_add", "zkm_tracegen_weierstrass_double", "zkm_tracegen_weierstrass_decompress", "zkm_tracegen_uint256_mul", "zkm_tracegen_u256x2048_mul", "zkm_tracegen_boolean_circuit_garble", "zkm_tracegen_sys_linux", "zkm_tracegen_fp_op", "zkm_tracegen_fp2_addsub", "zkm_tracegen_fp2_mul", "zkm_tracegen_poseidon2_wide", "zkm_tracegen_poseidon2_skinny", "zkm_tracegen_exp_reverse_bits", "zkm_tracegen_memory_instrs_width", "zkm_tracegen_memory_instrs", "zkm_tracegen_flat", "zkm_tracegen_byte_table", "zkm_tracegen_byte_mults",
     "zkm_poseidon2_permute_batch", "zkm_poseidon2_permute_batch_int", "zkm_coset_lde_batch", "zkm_permutation_trace",
     "zkm_challenger_init", "zkm_challenger_observe", "zkm_challenger_sample", "zkm_challenger_sample_bits",
-    "zkm_host_poseidon2_permute", "zkm_host_poseidon2_permute_f64", "zkm_host_ext_mul", "zkm_host_ext_inv", "zkm_host_field_mul", "zkm_host_field_inv", "zkm_host_two_adic_generator",
+    "zkm_host_poseidon2_permute", "zkm_host_poseidon2_permute_f64", "zkm_host_poseidon2_f64_sponge", "zkm_host_poseidon2_f64_compress_inject", "zkm_host_poseidon2_f64_audit",
+    "zkm_host_ext_mul", "zkm_host_ext_inv", "zkm_host_field_mul", "zkm_host_field_inv", "zkm_host_two_adic_generator",
 ]
 
 
@@ -83,7 +84,8 @@ def load():
     L.zkm_host_field_inv.restype = C.c_uint32
     L.zkm_host_two_adic_generator.restype = C.c_uint32
     for name in ("zkm_ctx_destroy", "zkm_host_free", "zkm_byte_lookups_free", "zkm_ctx_set_kernel_timing", "zkm_ctx_set_kernel_timing_only", "zkm_matrix_free", "zkm_pcs_data_free", "zkm_pk_free", "zkm_main_data_free",
-                 "zkm_challenger_init", "zkm_challenger_observe", "zkm_host_poseidon2_permute", "zkm_host_poseidon2_permute_f64", "zkm_host_ext_mul", "zkm_host_ext_inv"):
+                 "zkm_challenger_init", "zkm_challenger_observe", "zkm_host_poseidon2_permute", "zkm_host_poseidon2_permute_f64", "zkm_host_poseidon2_f64_sponge",
+                 "zkm_host_poseidon2_f64_compress_inject", "zkm_host_poseidon2_f64_audit", "zkm_host_ext_mul", "zkm_host_ext_inv"):
         getattr(L, name).restype = None
     _LIB = L
     return L
