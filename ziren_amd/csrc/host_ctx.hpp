@@ -14,6 +14,7 @@ static thread_local std::string g_err;
 // launch (each input and output array counted once) for the roofline report.
 #define KLAUNCH(ctx, name, bytes, kernel, grid, block, lds, ...)                                        \
   do {                                                                                                   \
+    (ctx)->flush_staged();                                                                               \
     if ((ctx)->kbegin(name, (double)(bytes))) {                                                          \
       /* start/stop timestamps ride on the dispatch's own completion signal: no extra barrier packets */ \
       hipExtLaunchKernelGGL(kernel, grid, block, lds, (ctx)->cur, (ctx)->krecs.back().start,             \
@@ -134,6 +135,30 @@ struct zkm_ctx {
     HIP_CHECK(hipStreamSynchronize(stream2));
     cur = stream;
     pin_off = 0;
+    dirty_lo = SIZE_MAX; dirty_hi = 0;
+  }
+  // Small phase-local host tables (challenge powers, per-chip constants, descriptor and pointer arrays: ~100 per proof) are staged:
+  // written into the pinned ring, handed out as addresses in a device mirror of the ring, and copied over in ONE transfer per run of
+  // uploads, right before the next kernel launch (KLAUNCH flushes; the few direct launch sites call flush_staged themselves). One copy
+  // dispatch per phase instead of one per table. The address stays valid until the next top-level call (begin_call rewinds the ring);
+  // release() ignores it.
+  char* arena = nullptr;
+  size_t dirty_lo = SIZE_MAX, dirty_hi = 0;
+  void* upload_staged(const void* src, size_t bytes, std::vector<void*>* scratch = nullptr) {
+    if (bytes == 0) bytes = 4;
+    void* h = bytes <= ((size_t)1 << 20) ? pin_alloc(bytes) : nullptr;
+    if (!h) return upload(src, bytes, scratch);        // too large for the ring: its own buffer and copy
+    if (!arena) HIP_CHECK(hipMalloc((void**)&arena, pin_cap));
+    memcpy(h, src, bytes);
+    const size_t off = (char*)h - pin;
+    dirty_lo = std::min(dirty_lo, off);
+    dirty_hi = std::max(dirty_hi, off + bytes);
+    return arena + off;
+  }
+  void flush_staged() {
+    if (dirty_hi <= dirty_lo) return;
+    HIP_CHECK(hipMemcpyAsync(arena + dirty_lo, pin + dirty_lo, dirty_hi - dirty_lo, hipMemcpyHostToDevice, cur));
+    dirty_lo = SIZE_MAX; dirty_hi = 0;
   }
   // copy `bytes` of host data to a fresh device buffer; the source may die as soon as this returns
   void* upload(const void* src, size_t bytes, std::vector<void*>* scratch) {
@@ -296,6 +321,7 @@ struct zkm_byte_lookups {
 };
 
 struct Tree {
+  const uint32_t* h_root = nullptr;     // set when the kernel that finished the tree wrote the root to page-locked host memory itself
   uint32_t* digests = nullptr;          // all layers, 8 words per digest
   std::vector<size_t> layer_off;        // in digests
   size_t max_height = 0;

@@ -116,16 +116,29 @@ static ChipMeta chip_meta(const zkm_chip_desc* d, size_t n, size_t n_public_valu
 // scratch that lives until the caller's stream has passed.
 template <typename Alloc>
 static void launch_permutation_trace(zkm_ctx* ctx, const ChipMeta& c, const uint32_t* d_blob, const uint32_t* trace, const uint32_t* prep, const E4& alpha,
-                                     const E4* d_beta_powers, zkm_matrix& pt, Alloc&& salloc) {
+                                     const E4* d_beta_powers, zkm_matrix& pt, Alloc&& salloc, std::vector<stark::ScanJob>& scans) {
   KLAUNCH(ctx, "perm_rows", 4.0 * c.n * (c.desc->main_width + c.desc->prep_width + pt.w), stark::perm_rows, dim3(div_up(c.n, stark::THREADS)), dim3(stark::THREADS), 0,
           d_blob, c.n_lookups, c.n_sends, 1 << c.desc->log_quotient_degree, trace, prep, c.n, alpha, d_beta_powers, pt.d, c.perm_ext_w);
-  uint32_t* last = pt.d + (size_t)(c.perm_ext_w - 1) * 4 * c.n;      // inclusive scan of the last ext column (4 base columns)
-  const size_t nchunks = (c.n + stark::SCAN_BLOCK - 1) / stark::SCAN_BLOCK;
-  uint32_t* totals = (uint32_t*)salloc(nchunks * 4 * 4);
-  KLAUNCH(ctx, "scan", 32.0 * c.n, stark::scan_chunks, dim3((unsigned)nchunks, 4), dim3(stark::THREADS), 0, last, c.n, totals, nchunks);
-  if (nchunks > 1) {
-    KLAUNCH(ctx, "scan", 0.0, stark::scan_totals, dim3(4), dim3(stark::THREADS), 0, totals, nchunks);
-    KLAUNCH(ctx, "scan", 32.0 * c.n, stark::scan_add_offsets, dim3((unsigned)nchunks, 4), dim3(stark::THREADS), 0, last, c.n, (const uint32_t*)totals, nchunks);
+  stark::ScanJob j;
+  j.data = pt.d + (size_t)(c.perm_ext_w - 1) * 4 * c.n;      // inclusive scan of the last ext column (4 base columns)
+  j.n = c.n;
+  j.nchunks = (c.n + stark::SCAN_BLOCK - 1) / stark::SCAN_BLOCK;
+  j.totals = (uint32_t*)salloc(j.nchunks * 4 * 4);
+  j.blk_end = (scans.empty() ? 0 : scans.back().blk_end) + (uint32_t)(j.nchunks * 4);
+  j.pad = 0;
+  scans.push_back(j);
+}
+// the three scan phases over every queued chip: three launches for the shard
+static void launch_scans(zkm_ctx* ctx, const std::vector<stark::ScanJob>& scans, std::vector<void*>* scratch) {
+  if (scans.empty()) return;
+  const stark::ScanJob* d = (const stark::ScanJob*)ctx->upload_staged(scans.data(), scans.size() * sizeof(stark::ScanJob), scratch);
+  double bytes = 0;
+  bool multi = false;
+  for (auto& j : scans) { bytes += 32.0 * j.n; multi |= j.nchunks > 1; }
+  KLAUNCH(ctx, "scan", bytes, stark::scan_chunks, dim3(scans.back().blk_end), dim3(stark::THREADS), 0, d);
+  if (multi) {
+    KLAUNCH(ctx, "scan", 0.0, stark::scan_totals, dim3((unsigned)(4 * scans.size())), dim3(stark::THREADS), 0, d);
+    KLAUNCH(ctx, "scan", bytes, stark::scan_add_offsets, dim3(scans.back().blk_end), dim3(stark::THREADS), 0, d);
   }
 }
 
@@ -201,7 +214,7 @@ struct ShardOpening {
   chal::observe_slice(ch, md->data->root, 8);
   perm_ch[0] = chal::sample_ext(ch);
   perm_ch[1] = chal::sample_ext(ch);
-  d_pv = (uint32_t*)ctx->upload(md->public_values.data(), md->public_values.size() * 4, &scratch);
+  d_pv = (uint32_t*)ctx->upload_staged(md->public_values.data(), md->public_values.size() * 4, &scratch);
   }
 
   // --- permutation traces (prover.rs:337-365), their commitment, the cumulative sums into the transcript (:366-414)
@@ -210,6 +223,7 @@ struct ShardOpening {
   local_sums.assign(nc, kb::ezero());
   global_sums.assign(nc, std::array<uint32_t, 14>());
   std::vector<uint32_t*> d_blobs(nc, nullptr);
+  std::vector<stark::ScanJob> scans;
   std::vector<const uint32_t*> sum_src;
   uint32_t* h_sums = nullptr;
   {
@@ -218,7 +232,10 @@ struct ShardOpening {
     std::vector<E4> bp(maxv + 2);
     bp[0] = kb::eone();
     for (int i = 1; i < maxv + 2; i++) bp[i] = kb::emul(bp[i - 1], perm_ch[1]);
-    E4* d_bp = (E4*)ctx->upload(bp.data(), bp.size() * sizeof(E4), &scratch);
+    E4* d_bp = (E4*)ctx->upload_staged(bp.data(), bp.size() * sizeof(E4), &scratch);
+    // every chip's lookup table is staged before the first launch: one transfer for the whole phase
+    for (size_t i = 0; i < nc; i++)
+      if (chips[i].perm_ext_w > 0) d_blobs[i] = (uint32_t*)ctx->upload_staged(chips[i].desc->lookups, chips[i].desc->lookups_len * 4, &scratch);
     for (size_t i = 0; i < nc; i++) {
       const ChipMeta& c = chips[i];
       zkm_matrix& pt = perm_traces[i];
@@ -226,10 +243,9 @@ struct ShardOpening {
       pt.d = ctx->alloc_n<uint32_t>(std::max<size_t>(pt.h * pt.w, 1));
       scratch.push_back(pt.d);   // until the permutation commitment owns it
       if (c.perm_ext_w > 0) {
-        d_blobs[i] = (uint32_t*)ctx->upload(c.desc->lookups, c.desc->lookups_len * 4, &scratch);
         const uint32_t* prep = c.desc->prep_index >= 0 ? pk->prep[c.desc->prep_index].d : nullptr;
         launch_permutation_trace(ctx, c, (const uint32_t*)d_blobs[i], (const uint32_t*)md->traces[i].d, prep, perm_ch[0], (const E4*)d_bp, pt,
-                                 [&](size_t bytes) { return salloc(bytes); });
+                                 [&](size_t bytes) { return salloc(bytes); }, scans);
         uint32_t* last = pt.d + (size_t)(c.perm_ext_w - 1) * 4 * c.n;
         for (int e = 0; e < 4; e++) sum_src.push_back(last + (size_t)e * c.n + (c.n - 1));
       } else {
@@ -242,10 +258,11 @@ struct ShardOpening {
         for (int k = 0; k < 14; k++) sum_src.push_back(nullptr);
       }
     }
+    launch_scans(ctx, scans, &scratch);
     // one gather for every cumulative-sum word (18 per chip), read back after the commit's synchronisation
-    const uint32_t* d_zero = (const uint32_t*)ctx->upload("\0\0\0\0", 4, &scratch);
+    const uint32_t* d_zero = (const uint32_t*)ctx->upload_staged("\0\0\0\0", 4, &scratch);
     for (auto& p : sum_src) if (!p) p = d_zero;
-    const uint32_t** d_sum_src = (const uint32_t**)ctx->upload(sum_src.data(), sum_src.size() * sizeof(void*), &scratch);
+    const uint32_t** d_sum_src = (const uint32_t**)ctx->upload_staged(sum_src.data(), sum_src.size() * sizeof(void*), &scratch);
     uint32_t* d_sums = (uint32_t*)salloc(sum_src.size() * 4);
     KLAUNCH(ctx, "gather_words", 0.0, open::gather_words, dim3(div_up(sum_src.size(), open::THREADS)), dim3(open::THREADS), 0,
             (const uint32_t* const*)d_sum_src, sum_src.size(), d_sums);
@@ -275,6 +292,8 @@ struct ShardOpening {
   // --- quotient values and their commitment (prover.rs:416-498); ends with zeta
   void quotient_phase() {
   E4 alpha = chal::sample_ext(ch);
+  // every chip's tables (alpha powers, constants, program) are staged first and the kernels queued after the loop: one transfer for the phase
+  std::vector<std::function<void()>> launches;
   for (size_t i = 0; i < nc; i++) {
     const ChipMeta& c = chips[i];
     const zkm_chip_desc* d = c.desc;
@@ -289,7 +308,7 @@ struct ShardOpening {
     std::vector<E4> ap(std::max<size_t>(C, 1));
     E4 p = kb::eone();
     for (size_t k = 0; k < C; k++) { ap[C - 1 - k] = p; p = kb::emul(p, alpha); }
-    E4* d_ap = (E4*)ctx->upload(ap.data(), ap.size() * sizeof(E4), &scratch);
+    E4* d_ap = (E4*)ctx->upload_staged(ap.data(), ap.size() * sizeof(E4), &scratch);
     uint32_t consts[32] = {0};
     for (int k = 0; k < 14; k++) consts[k] = global_sums[i][k];
     uint32_t w_q = kb::two_adic_generator(lq);
@@ -301,9 +320,9 @@ struct ShardOpening {
       consts[24 + k] = kb::inv(consts[16 + k]);
       wp = kb::mul(wp, wr);
     }
-    uint32_t* d_consts = (uint32_t*)ctx->upload(consts, sizeof consts, &scratch);
+    uint32_t* d_consts = (uint32_t*)ctx->upload_staged(consts, sizeof consts, &scratch);
     static const uint32_t empty_prog[4] = {0, 1, 0, 1};
-    uint32_t* d_prog = (uint32_t*)ctx->upload(d->program_len ? d->program : empty_prog, std::max<size_t>(d->program_len, 4) * 4, &scratch);
+    uint32_t* d_prog = (uint32_t*)ctx->upload_staged(d->program_len ? d->program : empty_prog, std::max<size_t>(d->program_len, 4) * 4, &scratch);
     stark::QuotientArgs a;
     a.program = d_prog + 4;
     a.n_instr = d->program_len ? d->program[0] : 0;
@@ -327,18 +346,23 @@ struct ShardOpening {
     if (lds > 160 * 1024) throw std::runtime_error(std::string("constraint program of chip ") + d->name + " needs too many registers");
     double qbytes = 4.0 * Q * (d->main_width + d->prep_width + 4.0 * c.perm_ext_w) + 16.0 * Q;
     auto fit = d->program_len ? ctx->quotient_fns.find(fnv1a(d->program, d->program_len)) : ctx->quotient_fns.end();
-    if (fit != ctx->quotient_fns.end()) {
-      // chip-specialised kernel: same arithmetic, values in VGPRs
-      size_t arg_size = sizeof(a);
-      void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &arg_size, HIP_LAUNCH_PARAM_END};
-      for (hipFunction_t fn : fit->second) {       // several for a long program: the first stores, the others accumulate
-        const bool timed = ctx->kbegin("quotient", qbytes);
-        HIP_CHECK(hipExtModuleLaunchKernel(fn, div_up(Q, 256) * 256, 1, 1, 256, 1, 1, 0, st, nullptr, config,
-                                           timed ? ctx->krecs.back().start : nullptr, timed ? ctx->krecs.back().stop : nullptr, 0));
+    const bool special = fit != ctx->quotient_fns.end();
+    const std::vector<hipFunction_t>* fns = special ? &fit->second : nullptr;
+    launches.push_back([this, a, fns, Q, bd, lds, qbytes]() mutable {
+      if (fns) {
+        // chip-specialised kernel: same arithmetic, values in VGPRs
+        size_t arg_size = sizeof(a);
+        void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &arg_size, HIP_LAUNCH_PARAM_END};
+        ctx->flush_staged();
+        for (hipFunction_t fn : *fns) {       // several for a long program: the first stores, the others accumulate
+          const bool timed = ctx->kbegin("quotient", qbytes);
+          HIP_CHECK(hipExtModuleLaunchKernel(fn, div_up(Q, 256) * 256, 1, 1, 256, 1, 1, 0, st, nullptr, config,
+                                             timed ? ctx->krecs.back().start : nullptr, timed ? ctx->krecs.back().stop : nullptr, 0));
+        }
+      } else {
+        KLAUNCH(ctx, "quotient", qbytes, stark::quotient_kernel, dim3(div_up(Q, bd)), dim3(bd), lds, a);
       }
-    } else {
-      KLAUNCH(ctx, "quotient", qbytes, stark::quotient_kernel, dim3(div_up(Q, bd)), dim3(bd), lds, a);
-    }
+    });
     uint32_t wqp = kb::ONE;
     for (size_t k = 0; k < nchunks; k++) {
       zkm_matrix m; m.h = c.n; m.w = 4; m.d = qbuf + k * 4 * c.n; m.owned = (k == 0);
@@ -347,6 +371,7 @@ struct ShardOpening {
       wqp = kb::mul(wqp, w_q);
     }
   }
+  for (auto& l : launches) l();
   ctx->mark("quotient values");
   quot_data = pcs_commit(ctx, qchunks, qshifts, bl);
   for (auto& m : qchunks) if (m.owned) { quot_data->owned_evals.push_back(m); loose.disown(m.d); }
@@ -384,6 +409,12 @@ struct ShardOpening {
     size_t total_y = 0;
     for (auto& r : rounds) for (auto& m : r.mats) total_y += m.width * 2;
     E4* d_y = (E4*)salloc(std::max<size_t>(total_y, 1) * sizeof(E4));
+    // one launch each for all weight vectors, all column evaluations and all partial sums (job tables: open.cuh)
+    std::vector<open::WeightJob> wjobs;
+    std::vector<open::EvalJob> ejobs;
+    std::vector<open::SumJob> sjobs;
+    uint32_t wblk = 0, eblk = 0, sblk = 0;
+    double wbytes = 0, ebytes = 0;
     size_t ypos = 0;
     for (auto& r : rounds)
       for (auto& m : r.mats) {
@@ -393,35 +424,44 @@ struct ShardOpening {
         auto it = wcache.find(key);
         if (it == wcache.end()) {
           int ln = log2_strict(m.n);
-          E4 u = kb::escale(zeta, kb::inv(m.shift));
-          E4 c = kb::escale(kb::esub_base(host_pow2k(u, ln), kb::ONE), kb::inv(kb::to_monty((uint32_t)(m.n % kb::P))));
+          open::WeightJob wj;
+          wj.u = kb::escale(zeta, kb::inv(m.shift));
+          wj.c = kb::escale(kb::esub_base(host_pow2k(wj.u, ln), kb::ONE), kb::inv(kb::to_monty((uint32_t)(m.n % kb::P))));
           wts = (E4*)salloc(m.n * sizeof(E4));
-          KLAUNCH(ctx, "bary_weights", 16.0 * m.n, open::bary_weights, dim3(div_up(div_up(m.n, 4), open::THREADS)), dim3(open::THREADS), 0, u, c,
-                  kb::two_adic_generator(ln), m.n, wts);
+          wj.w_n = kb::two_adic_generator(ln); wj.n = m.n; wj.out = wts;
+          wblk += div_up(div_up(m.n, 4), open::THREADS);
+          wj.blk_end = wblk;
+          wjobs.push_back(wj);
+          wbytes += 16.0 * m.n;
           wcache[key] = wts;
         } else wts = it->second;
-        unsigned groups = div_up(m.width, open::EVAL_COLS);
-        unsigned split = 1;
-        E4* partials;
-        double ebytes = 4.0 * m.n * m.width + 16.0 * m.n;
+        open::EvalJob ej;
+        ej.mat = m.evals; ej.weights = wts; ej.n = m.n; ej.width = (int)m.width;
+        ej.groups = (int)div_up(m.width, open::EVAL_COLS);
+        ej.split = 1;
         if (m.n >= 4 * open::THREADS) {
-          split = (unsigned)std::min<size_t>(std::max<size_t>(1, 3072 / groups), m.n / (4 * open::THREADS));
-          partials = (E4*)salloc((size_t)split * m.width * 2 * sizeof(E4));
-          if (m.n_points > 1)
-            KLAUNCH(ctx, "eval_columns", ebytes, open::eval_columns<true>, dim3(groups, split), dim3(open::THREADS), 0, m.evals, m.n,
-                    (int)m.width, (const E4*)wts, partials);
-          else
-            KLAUNCH(ctx, "eval_columns", ebytes, open::eval_columns<false>, dim3(groups, split), dim3(open::THREADS), 0, m.evals, m.n,
-                    (int)m.width, (const E4*)wts, partials);
+          ej.split = (int)std::min<size_t>(std::max<size_t>(1, 3072 / ej.groups), m.n / (4 * open::THREADS));
+          ej.kind = m.n_points > 1 ? 1 : 0;
         } else {
-          partials = (E4*)salloc((size_t)m.width * 2 * sizeof(E4));
-          KLAUNCH(ctx, "eval_columns", ebytes, open::eval_columns_small, dim3(groups, 1), dim3(open::THREADS), 0, m.evals, m.n,
-                  (int)m.width, (const E4*)wts, m.n_points > 1 ? 1 : 0, partials);
+          ej.kind = m.n_points > 1 ? 3 : 2;
         }
-        KLAUNCH(ctx, "reduce_partials", 0.0, open::reduce_partials, dim3((unsigned)(m.width * 2)), dim3(64), 0, (const E4*)partials,
-                (int)split, (int)(m.width * 2), d_y + ypos);
+        ej.partials = (E4*)salloc((size_t)ej.split * m.width * 2 * sizeof(E4));
+        eblk += (uint32_t)ej.groups * (uint32_t)ej.split;
+        ej.blk_end = eblk; ej.pad = 0;
+        ejobs.push_back(ej);
+        ebytes += 4.0 * m.n * m.width + 16.0 * m.n;
+        sblk += (uint32_t)(m.width * 2);
+        sjobs.push_back(open::SumJob{ej.partials, ej.split, (int)(m.width * 2), (uint32_t)ypos, sblk});
         ypos += m.width * 2;
       }
+    if (!ejobs.empty()) {
+      const open::WeightJob* d_w = (const open::WeightJob*)ctx->upload_staged(wjobs.data(), wjobs.size() * sizeof(open::WeightJob), &scratch);
+      const open::EvalJob* d_e = (const open::EvalJob*)ctx->upload_staged(ejobs.data(), ejobs.size() * sizeof(open::EvalJob), &scratch);
+      const open::SumJob* d_s = (const open::SumJob*)ctx->upload_staged(sjobs.data(), sjobs.size() * sizeof(open::SumJob), &scratch);
+      KLAUNCH(ctx, "bary_weights", wbytes, open::bary_weights_batch, dim3(wblk), dim3(open::THREADS), 0, d_w);
+      KLAUNCH(ctx, "eval_columns", ebytes, open::eval_columns_batch, dim3(eblk), dim3(open::THREADS), 0, d_e);
+      KLAUNCH(ctx, "reduce_partials", 0.0, open::reduce_partials_batch, dim3(sblk), dim3(64), 0, d_s, d_y);
+    }
     const E4* hy = ctx->download_async(d_y, std::max<size_t>(total_y, 1));
     HIP_CHECK(hipStreamSynchronize(st));
     ypos = 0;
@@ -448,7 +488,7 @@ struct ShardOpening {
   std::vector<E4> fap(max_width + 1);
   fap[0] = kb::eone();
   for (size_t i = 1; i <= max_width; i++) fap[i] = kb::emul(fap[i - 1], fa);
-  E4* d_fap = (E4*)ctx->upload(fap.data(), fap.size() * sizeof(E4), &scratch);
+  E4* d_fap = (E4*)ctx->upload_staged(fap.data(), fap.size() * sizeof(E4), &scratch);
   {
     std::vector<std::vector<open::ReduceMat>> per_h(32);
     std::vector<E4> run(32, kb::eone());  // alpha^count per height
@@ -467,11 +507,14 @@ struct ShardOpening {
         }
         per_h[lh].push_back(rm);
       }
+    std::vector<open::ReduceMat*> d_rms(32, nullptr);
+    for (int lh = 0; lh < 32; lh++)
+      if (!per_h[lh].empty()) d_rms[lh] = (open::ReduceMat*)ctx->upload_staged(per_h[lh].data(), per_h[lh].size() * sizeof(open::ReduceMat), &scratch);
     for (int lh = 0; lh < 32; lh++) {
       if (per_h[lh].empty()) continue;
       size_t N = (size_t)1 << lh;
       ro[lh] = (E4*)salloc(N * sizeof(E4));
-      open::ReduceMat* d_rm = (open::ReduceMat*)ctx->upload(per_h[lh].data(), per_h[lh].size() * sizeof(open::ReduceMat), &scratch);
+      open::ReduceMat* d_rm = d_rms[lh];
       E4 z1 = kb::escale(zeta, kb::two_adic_generator(lh - bl));
       double rbytes = 16.0 * N;
       for (auto& rm : per_h[lh]) rbytes += 4.0 * N * rm.width;
@@ -507,8 +550,9 @@ struct ShardOpening {
     for (size_t l = half >> (fuse + 1); l >= 1; l >>= 1, layer++)
       if (compress_small_layer(ctx, t, layer, l)) break;
     std::array<uint32_t, 8> root;
-    const uint32_t* h_root = ctx->download_async(t.node(t.log_max, 0), 8);
+    const uint32_t* h_root = t.h_root ? t.h_root : ctx->download_async(t.node(t.log_max, 0), 8);
     HIP_CHECK(hipStreamSynchronize(st));
+    t.h_root = nullptr;
     memcpy(root.data(), h_root, 32);
     chal::observe_slice(ch, root.data(), 8);
     commits.push_back(root);
@@ -535,8 +579,8 @@ struct ShardOpening {
   // proof of work: the smallest canonical witness
   void grind() {
   {
-    uint32_t* d_state = (uint32_t*)ctx->upload(ch->sponge_state, 64, &scratch);
-    uint32_t* d_in = (uint32_t*)ctx->upload(ch->input_buffer, 64, &scratch);
+    uint32_t* d_state = (uint32_t*)ctx->upload_staged(ch->sponge_state, 64, &scratch);
+    uint32_t* d_in = (uint32_t*)ctx->upload_staged(ch->input_buffer, 64, &scratch);
     unsigned int* d_best = (unsigned int*)salloc(4);
     uint32_t base = 0, found = 0xffffffffu;
     const uint32_t BATCH = 1u << 20;
@@ -584,9 +628,10 @@ struct ShardOpening {
   const size_t per_query = tmpl.size(), n_gather = per_query * indices.size();
   if (n_gather) {
     std::vector<uint32_t> idx32(indices.begin(), indices.end());
-    const open::QueryWord* d_tmpl = (const open::QueryWord*)ctx->upload(tmpl.data(), tmpl.size() * sizeof(open::QueryWord), &scratch);
-    const uint32_t* d_idx = (const uint32_t*)ctx->upload(idx32.data(), idx32.size() * 4, &scratch);
+    const open::QueryWord* d_tmpl = (const open::QueryWord*)ctx->upload_staged(tmpl.data(), tmpl.size() * sizeof(open::QueryWord), &scratch);
+    const uint32_t* d_idx = (const uint32_t*)ctx->upload_staged(idx32.data(), idx32.size() * 4, &scratch);
     uint32_t* d_dst = (uint32_t*)salloc(n_gather * 4);
+    ctx->flush_staged();
     hipLaunchKernelGGL(open::gather_queries, dim3(div_up(n_gather, open::THREADS)), dim3(open::THREADS), 0, st, d_tmpl, per_query, d_idx, indices.size(), d_dst);
     LAUNCH_CHECK();
     uint32_t* h = (uint32_t*)ctx->pin_alloc(n_gather * 4);      // through the pinned ring when it fits: no staged pageable copy

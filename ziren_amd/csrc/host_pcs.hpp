@@ -29,7 +29,9 @@ static void lde_batch_chunk(zkm_ctx* ctx, const std::vector<LdeJob>& jobs, int b
     const int lb = std::min(k, lde::LOG_ROW_MAX), la = k - lb;
     lde::Group& g = b.g[b.n_groups];
     g.la = la; g.lb = lb;
-    g.logT = la ? std::min(std::min(6, 14 - la), lb) : 0;  // la >= 1 implies lb = 13, so T >= 8
+    // every block of the strided passes takes a tile of 2^14 points (A x T), whatever the height: one LDS size (~66 KiB, two blocks per
+    // CU) and one amount of work per block for the whole batch; shorter columns get wider tiles (longer contiguous segments)
+    g.logT = la ? std::min(14 - la, lb) : 0;  // la >= 1 implies lb = 13, so T >= 8
     g.first_mat = nm;
     g.w_N = kb::two_adic_generator(k + bl);
     g.n_inv = kb::inv(kb::to_monty((uint32_t)(n % kb::P)));
@@ -73,7 +75,7 @@ static void lde_batch_chunk(zkm_ctx* ctx, const std::vector<LdeJob>& jobs, int b
     for (int q = 0; q < 4; q++) g.blk_end[q] = blk[q];
     b.n_groups++;
   }
-  const lde::Batch* d = (const lde::Batch*)ctx->upload(&b, sizeof b, nullptr);
+  const lde::Batch* d = (const lde::Batch*)ctx->upload_staged(&b, sizeof b);
   if (blk[lde::K_COLS_INV]) {
     constexpr size_t B = (size_t)1 << lde::LOG_ROW_MAX;
     const size_t big_lds = (B + (B >> 5)) * 4;
@@ -105,11 +107,12 @@ static void lde_columns(zkm_ctx* ctx, const uint32_t* in, size_t n, size_t w, in
 
 // Upload an array of device pointers (one per column) and return the device copy.
 static const uint32_t** upload_ptrs(zkm_ctx* ctx, const std::vector<const uint32_t*>& ptrs) {
-  return (const uint32_t**)ctx->upload(ptrs.data(), ptrs.size() * sizeof(void*), nullptr);
+  return (const uint32_t**)ctx->upload_staged(ptrs.data(), ptrs.size() * sizeof(void*));
 }
 
 // Layers of at most LANES_MAX nodes without injection: lane-parallel compression; returns true when it
-// finished the tree (tail launch), false when the caller should go on with the next layer.
+// finished the tree (tail launch, which also writes the root to pinned host memory: t.h_root, valid after the next stream
+// synchronisation), false when the caller should go on with the next layer.
 static bool compress_small_layer(zkm_ctx* ctx, Tree& t, int layer, size_t len) {
   const size_t LANES_MAX = 4096, TAIL = 64;
   if (len > LANES_MAX) {
@@ -119,7 +122,9 @@ static bool compress_small_layer(zkm_ctx* ctx, Tree& t, int layer, size_t len) {
     return false;
   }
   if (len <= TAIL) {
-    KLAUNCH(ctx, "compress_tail", 96.0 * len, merkle::compress_tail_lanes, dim3(1), dim3(1024), 0, t.digests + t.layer_off[layer] * 8, len);
+    uint32_t* h_root = (uint32_t*)ctx->pin_alloc(32);
+    KLAUNCH(ctx, "compress_tail", 96.0 * len, merkle::compress_tail_lanes, dim3(1), dim3(1024), 0, t.digests + t.layer_off[layer] * 8, len, h_root);
+    t.h_root = h_root;
     return true;
   }
   KLAUNCH(ctx, "compress_small", 96.0 * len, merkle::compress_layer_lanes, dim3(div_up(len * 16, merkle::THREADS)), dim3(merkle::THREADS),
@@ -152,6 +157,15 @@ static void build_tree(zkm_ctx* ctx, const std::vector<zkm_matrix>& mats, Tree& 
     return ptrs;
   };
   std::vector<const uint32_t**> to_free;
+  // the column-pointer table of every height is staged before the first launch (the LDE buffers exist already): one transfer per tree
+  std::map<size_t, std::pair<const uint32_t**, size_t>> tables;
+  for (auto& m : mats)
+    if (!tables.count(m.h)) {
+      auto ptrs = cols_of_height(m.h);
+      const uint32_t** d = ptrs.empty() ? nullptr : upload_ptrs(ctx, ptrs);
+      if (d) to_free.push_back(d);
+      tables[m.h] = {d, ptrs.size()};
+    }
   // the tree levels right above the leaves that no shorter matrix is injected into can be reduced inside the leaf kernel's blocks
   int fuse = 0;
   if (maxh >= (size_t)merkle::FUSE_LEAVES) {
@@ -163,9 +177,8 @@ static void build_tree(zkm_ctx* ctx, const std::vector<zkm_matrix>& mats, Tree& 
     }
   }
   {
-    auto ptrs = cols_of_height(maxh);
-    const uint32_t** d = upload_ptrs(ctx, ptrs);
-    to_free.push_back(d);
+    const uint32_t** d = tables[maxh].first;
+    struct { size_t n; size_t size() const { return n; } } ptrs{tables[maxh].second};
     wait_height(maxh);
     if (fuse > 0)
       KLAUNCH(ctx, "hash_leaves_tree", 4.0 * maxh * ptrs.size() + 32.0 * maxh * (2.0 - 1.0 / (1 << fuse)), merkle::hash_leaves_tree,
@@ -185,9 +198,9 @@ static void build_tree(zkm_ctx* ctx, const std::vector<zkm_matrix>& mats, Tree& 
       if (compress_small_layer(ctx, t, layer, len)) break;
       continue;
     }
-    auto ptrs = cols_of_height(len);
-    const uint32_t** d = nullptr;
-    if (!ptrs.empty()) { d = upload_ptrs(ctx, ptrs); to_free.push_back(d); wait_height(len); }
+    const uint32_t** d = tables.count(len) ? tables[len].first : nullptr;
+    struct { size_t n; size_t size() const { return n; } } ptrs{tables.count(len) ? tables[len].second : 0};
+    if (d) wait_height(len);
     KLAUNCH(ctx, "compress_layer", 96.0 * len + 4.0 * len * ptrs.size(), merkle::compress_layer, dim3(div_up(len, merkle::THREADS)),
             dim3(merkle::THREADS), 0, (const uint32_t*)(t.digests + t.layer_off[layer] * 8), t.digests + t.layer_off[layer + 1] * 8,
             len, (const uint32_t* const*)d, (int)ptrs.size());
@@ -248,8 +261,9 @@ static zkm_pcs_data* pcs_commit(zkm_ctx* ctx, const std::vector<zkm_matrix>& mat
     build_tree(ctx, d->ldes, d->tree, extend_height);
     for (size_t i = 0; i < mats.size(); i++)
       if (!extended[i]) throw std::runtime_error("pcs_commit: a matrix was not reached by the tree (internal error)");
-    const uint32_t* h_root = ctx->download_async(d->tree.node(d->tree.log_max, 0), 8);
+    const uint32_t* h_root = d->tree.h_root ? d->tree.h_root : ctx->download_async(d->tree.node(d->tree.log_max, 0), 8);
     HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    d->tree.h_root = nullptr;   // the pinned ring is rewound at the next top-level call
     memcpy(d->root, h_root, 32);
   } catch (...) {
     free_pcs_data(ctx, d);

@@ -276,8 +276,12 @@ __global__ __launch_bounds__(THREADS) void compress_layer_lanes(const uint32_t* 
   if (e < 8) next[8 * node + e] = x;
 }
 
-// Root of the tree in one launch, 16 lanes per node: from 2*len0 digests at `prev` (len0 <= 64) down to 1.
-__global__ __launch_bounds__(1024) void compress_tail_lanes(uint32_t* __restrict__ prev, size_t len0) {
+// Root of the tree in one launch, 16 lanes per node: from 2*len0 digests at `prev` (len0 <= 64) down to 1. The root also goes straight
+// to `root_host` (page-locked host memory, may be null): the transcript reads it after the stream synchronisation, no copy dispatch.
+// (Tried and removed, round 3: ONE launch from 4096 nodes down, len0 / 64 blocks with grid barriers between levels — 72 dispatches fewer
+// per proof, bit-exact, but 0.8 ms slower per SYN-22 proof: an agent-scope release is a whole-L2 write-back on gfx950, and a level is
+// latency-bound at ~3 us either way.)
+__global__ __launch_bounds__(1024) void compress_tail_lanes(uint32_t* __restrict__ prev, size_t len0, uint32_t* root_host) {
   const int e = threadIdx.x & 15;
   lanes::LaneConsts k = lanes::load_consts(e);
   uint32_t* p = prev;
@@ -286,7 +290,10 @@ __global__ __launch_bounds__(1024) void compress_tail_lanes(uint32_t* __restrict
     const size_t node = threadIdx.x >> 4;
     if (node < len) {
       uint32_t x = lanes::permute(p[16 * node + e], k);
-      if (e < 8) nx[8 * node + e] = x;
+      if (e < 8) {
+        nx[8 * node + e] = x;
+        if (len == 1 && root_host) root_host[e] = x;
+      }
     }
     __syncthreads();
     p = nx;

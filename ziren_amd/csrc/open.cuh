@@ -17,8 +17,28 @@ constexpr int THREADS = 256;
 // weight vector serves both opening points of a trace.
 // Four consecutive points per thread: one power of w_n, one extension inverse for the four denominators
 // (Montgomery's trick: 9 products instead of 3 more inverses). grid = ceil(n / 4 / THREADS).
-__global__ __launch_bounds__(THREADS) void bary_weights(kb::E4 u, kb::E4 c, uint32_t w_n, size_t n, kb::E4* __restrict__ out) {
-  const size_t i0 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+// The opening phase of a shard evaluates ~4 matrices per chip: one launch per kernel covers all of them (round 3; before, each matrix
+// had its own bary_weights / eval_columns / reduce_partials launches: ~80 dispatches per proof). A flat blockIdx.x is mapped to
+// (job, block inside the job) through the jobs' cumulative block counts; the job tables live in device memory, indices are wave-uniform.
+struct WeightJob { kb::E4 u, c; uint32_t w_n, blk_end; size_t n; kb::E4* out; };
+struct EvalJob {
+  const uint32_t* mat; const kb::E4* weights; kb::E4* partials;
+  size_t n;
+  int width, groups, split, kind;   // kind 0: one point, 1: two points, 2: small one point, 3: small two points
+  uint32_t blk_end, pad;
+};
+struct SumJob { const kb::E4* partials; int split, count; uint32_t out0, blk_end; };
+template <class J>
+__device__ __forceinline__ const J& find_job(const J* __restrict__ jobs, uint32_t& local) {
+  uint32_t j = 0, start = 0;
+  const uint32_t b = blockIdx.x;
+  while (b >= jobs[j].blk_end) { start = jobs[j].blk_end; j++; }
+  local = b - start;
+  return jobs[j];
+}
+
+__device__ __forceinline__ void bary_weights_body(kb::E4 u, kb::E4 c, uint32_t w_n, size_t n, kb::E4* __restrict__ out, uint32_t bx) {
+  const size_t i0 = ((size_t)bx * blockDim.x + threadIdx.x) * 4;
   if (i0 >= n) return;
   uint32_t wi[4];
   wi[0] = kb::pow(w_n, (uint64_t)i0);
@@ -39,6 +59,14 @@ __global__ __launch_bounds__(THREADS) void bary_weights(kb::E4 u, kb::E4 c, uint
   for (int k = 0; k < 4; k++)
     if (i0 + k < n) out[i0 + k] = kb::emul(kb::escale(di[k], wi[k]), c);
 }
+__global__ __launch_bounds__(THREADS) void bary_weights(kb::E4 u, kb::E4 c, uint32_t w_n, size_t n, kb::E4* __restrict__ out) {
+  bary_weights_body(u, c, w_n, n, out, blockIdx.x);
+}
+__global__ __launch_bounds__(THREADS) void bary_weights_batch(const WeightJob* __restrict__ jobs) {
+  uint32_t bx;
+  const WeightJob& j = find_job(jobs, bx);
+  bary_weights_body(j.u, j.c, j.w_n, j.n, j.out, bx);
+}
 
 // Column evaluations. Block (bx, by) owns EVAL_COLS columns starting at EVAL_COLS*bx and the rows
 //   r = 4 * (by * THREADS + tid) + k * 4 * gridDim.y * THREADS,   r .. r+3 per iteration,
@@ -52,7 +80,7 @@ constexpr int EVAL_COLS = 4;
 // (word-major, conflict-free), 8 threads per word add 32-entry segments, one thread per word finishes.
 constexpr int EVAL_WORDS = EVAL_COLS * 8;
 __device__ __forceinline__ void block_reduce_store(kb::E4 (&acc)[EVAL_COLS][2], int c0, int width, kb::E4* __restrict__ partials,
-                                                   uint32_t* lds /* EVAL_WORDS * THREADS + EVAL_WORDS * 8 */) {
+                                                   uint32_t* lds /* EVAL_WORDS * THREADS + EVAL_WORDS * 8 */, uint32_t by) {
   const int tid = threadIdx.x;
 #pragma unroll
   for (int c = 0; c < EVAL_COLS; c++)
@@ -76,23 +104,22 @@ __device__ __forceinline__ void block_reduce_store(kb::E4 (&acc)[EVAL_COLS][2], 
 #pragma unroll
     for (int k = 0; k < 8; k++) t = kb::add(t, seg[tid * 8 + k]);
     const int c = tid >> 3, pt = (tid >> 2) & 1, e = tid & 3;
-    if (c0 + c < width) partials[((size_t)blockIdx.y * width + c0 + c) * 2 + pt].c[e] = t;
+    if (c0 + c < width) partials[((size_t)by * width + c0 + c) * 2 + pt].c[e] = t;
   }
 }
 
 template <bool TWO>
-__global__ __launch_bounds__(THREADS) void eval_columns(const uint32_t* __restrict__ mat, size_t n, int width,
-                                                        const kb::E4* __restrict__ weights, kb::E4* __restrict__ partials) {
-  __shared__ uint32_t red[EVAL_WORDS * THREADS + EVAL_WORDS * 8];
-  const int c0 = blockIdx.x * EVAL_COLS;
+__device__ __forceinline__ void eval_columns_body(const uint32_t* __restrict__ mat, size_t n, int width, const kb::E4* __restrict__ weights,
+                                                  kb::E4* __restrict__ partials, uint32_t* red, uint32_t bx, uint32_t by, uint32_t ny) {
+  const int c0 = bx * EVAL_COLS;
   const uint32_t* cols[EVAL_COLS];
 #pragma unroll
   for (int c = 0; c < EVAL_COLS; c++) cols[c] = mat + (size_t)min(c0 + c, width - 1) * n;  // clamp: duplicates are not stored
   kb::E4 acc[EVAL_COLS][2];
 #pragma unroll
   for (int c = 0; c < EVAL_COLS; c++) { acc[c][0] = kb::ezero(); acc[c][1] = kb::ezero(); }
-  const size_t stride = (size_t)gridDim.y * THREADS * 4;
-  for (size_t r = ((size_t)blockIdx.y * THREADS + threadIdx.x) * 4; r < n; r += stride) {
+  const size_t stride = (size_t)ny * THREADS * 4;
+  for (size_t r = ((size_t)by * THREADS + threadIdx.x) * 4; r < n; r += stride) {
     kb::E4 w[4];
     uint4 v[EVAL_COLS];
     uint32_t vnext[EVAL_COLS];
@@ -118,15 +145,13 @@ __global__ __launch_bounds__(THREADS) void eval_columns(const uint32_t* __restri
       }
     }
   }
-  block_reduce_store(acc, c0, width, partials, red);
+  block_reduce_store(acc, c0, width, partials, red, by);
 }
 
 // Small matrices (n < 4 * THREADS): one block per column group, scalar loads.
-__global__ __launch_bounds__(THREADS) void eval_columns_small(const uint32_t* __restrict__ mat, size_t n, int width,
-                                                              const kb::E4* __restrict__ weights, int two_points,
-                                                              kb::E4* __restrict__ partials) {
-  __shared__ uint32_t red[EVAL_WORDS * THREADS + EVAL_WORDS * 8];
-  const int c0 = blockIdx.x * EVAL_COLS;
+__device__ __forceinline__ void eval_columns_small_body(const uint32_t* __restrict__ mat, size_t n, int width, const kb::E4* __restrict__ weights,
+                                                        int two_points, kb::E4* __restrict__ partials, uint32_t* red, uint32_t bx) {
+  const int c0 = bx * EVAL_COLS;
   kb::E4 acc[EVAL_COLS][2];
 #pragma unroll
   for (int c = 0; c < EVAL_COLS; c++) { acc[c][0] = kb::ezero(); acc[c][1] = kb::ezero(); }
@@ -140,13 +165,21 @@ __global__ __launch_bounds__(THREADS) void eval_columns_small(const uint32_t* __
       if (two_points) acc[c][1] = kb::eadd(acc[c][1], kb::escale(w, col[rn]));
     }
   }
-  block_reduce_store(acc, c0, width, partials, red);
+  block_reduce_store(acc, c0, width, partials, red, 0);
+}
+// every matrix of an opening in one launch: block -> (job, column group, row split)
+__global__ __launch_bounds__(THREADS) void eval_columns_batch(const EvalJob* __restrict__ jobs) {
+  __shared__ uint32_t red[EVAL_WORDS * THREADS + EVAL_WORDS * 8];
+  uint32_t local;
+  const EvalJob& j = find_job(jobs, local);
+  const uint32_t bx = local % (uint32_t)j.groups, by = local / (uint32_t)j.groups;
+  if (j.kind == 0) eval_columns_body<false>(j.mat, j.n, j.width, j.weights, j.partials, red, bx, by, (uint32_t)j.split);
+  else if (j.kind == 1) eval_columns_body<true>(j.mat, j.n, j.width, j.weights, j.partials, red, bx, by, (uint32_t)j.split);
+  else eval_columns_small_body(j.mat, j.n, j.width, j.weights, j.kind == 3, j.partials, red, bx);
 }
 
 // out[i] = sum_s partials[s * count + i]; one 64-lane block per output element
-__global__ __launch_bounds__(64) void reduce_partials(const kb::E4* __restrict__ partials, int split, int count,
-                                                      kb::E4* __restrict__ out) {
-  const int i = blockIdx.x;
+__device__ __forceinline__ void reduce_partials_body(const kb::E4* __restrict__ partials, int split, int count, kb::E4* __restrict__ out, int i) {
   kb::E4 acc = kb::ezero();
   for (int s = threadIdx.x; s < split; s += 64) acc = kb::eadd(acc, partials[(size_t)s * count + i]);
 #pragma unroll
@@ -157,6 +190,11 @@ __global__ __launch_bounds__(64) void reduce_partials(const kb::E4* __restrict__
     acc.c[e] = v;
   }
   if (threadIdx.x == 0) out[i] = acc;
+}
+__global__ __launch_bounds__(64) void reduce_partials_batch(const SumJob* __restrict__ jobs, kb::E4* __restrict__ out) {
+  uint32_t i;
+  const SumJob& j = find_job(jobs, i);
+  reduce_partials_body(j.partials, j.split, j.count, out + j.out0, (int)i);
 }
 
 // Reduced openings for one LDE height N (fri.rs:103-204). One thread per stored row r

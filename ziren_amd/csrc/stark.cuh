@@ -100,11 +100,25 @@ __device__ __forceinline__ uint32_t block_inclusive_scan(uint32_t v, uint32_t* l
   return lds[t];
 }
 
-// phase 1: scan each 1024-chunk in place, emit chunk totals. grid = (chunks, ncols)
-__global__ __launch_bounds__(THREADS) void scan_chunks(uint32_t* __restrict__ data, size_t n, uint32_t* __restrict__ totals, size_t nchunks) {
+// The running sums of all chips of a shard are scanned by the same three launches (round 3; before: three launches per chip). A job is
+// one chip's last extension column (four base columns of n words, `data + e n`); blocks are dealt through the jobs' cumulative counts.
+struct ScanJob { uint32_t* data; uint32_t* totals; size_t n, nchunks; uint32_t blk_end, pad; };
+__device__ __forceinline__ const ScanJob& find_scan_job(const ScanJob* __restrict__ jobs, uint32_t& local) {
+  uint32_t j = 0, start = 0;
+  const uint32_t b = blockIdx.x;
+  while (b >= jobs[j].blk_end) { start = jobs[j].blk_end; j++; }
+  local = b - start;
+  return jobs[j];
+}
+// phase 1: scan each 1024-chunk in place, emit chunk totals. blocks of a job = chunks x 4 columns
+__global__ __launch_bounds__(THREADS) void scan_chunks(const ScanJob* __restrict__ jobs) {
   __shared__ uint32_t lds[THREADS];
-  uint32_t* col = data + (size_t)blockIdx.y * n;
-  size_t base = (size_t)blockIdx.x * SCAN_BLOCK + (size_t)threadIdx.x * 4;
+  uint32_t local;
+  const ScanJob& j = find_scan_job(jobs, local);
+  const size_t n = j.n, nchunks = j.nchunks;
+  const uint32_t bx = local % (uint32_t)nchunks, by = local / (uint32_t)nchunks;
+  uint32_t* col = j.data + (size_t)by * n;
+  size_t base = (size_t)bx * SCAN_BLOCK + (size_t)threadIdx.x * 4;
   uint32_t v[4];
 #pragma unroll
   for (int i = 0; i < 4; i++) v[i] = base + i < n ? col[base + i] : 0;
@@ -114,12 +128,14 @@ __global__ __launch_bounds__(THREADS) void scan_chunks(uint32_t* __restrict__ da
 #pragma unroll
   for (int i = 0; i < 4; i++)
     if (base + i < n) col[base + i] = kb::add(v[i], excl);
-  if (threadIdx.x == THREADS - 1) totals[(size_t)blockIdx.y * nchunks + blockIdx.x] = incl;
+  if (threadIdx.x == THREADS - 1) j.totals[(size_t)by * nchunks + bx] = incl;
 }
-// phase 2: exclusive scan of the chunk totals, one block per column (serial over 256-wide slabs)
-__global__ __launch_bounds__(THREADS) void scan_totals(uint32_t* __restrict__ totals, size_t nchunks) {
+// phase 2: exclusive scan of the chunk totals, one block per (job, column) (serial over 256-wide slabs)
+__global__ __launch_bounds__(THREADS) void scan_totals(const ScanJob* __restrict__ jobs) {
   __shared__ uint32_t lds[THREADS];
-  uint32_t* t = totals + (size_t)blockIdx.x * nchunks;
+  const ScanJob& j = jobs[blockIdx.x >> 2];
+  const size_t nchunks = j.nchunks;
+  uint32_t* t = j.totals + (size_t)(blockIdx.x & 3) * nchunks;
   uint32_t carry = 0;
   for (size_t base = 0; base < nchunks; base += THREADS) {
     size_t i = base + threadIdx.x;
@@ -131,11 +147,15 @@ __global__ __launch_bounds__(THREADS) void scan_totals(uint32_t* __restrict__ to
     carry = kb::add(carry, slab);
   }
 }
-// phase 3: add each chunk's offset. grid = (chunks, ncols)
-__global__ __launch_bounds__(THREADS) void scan_add_offsets(uint32_t* __restrict__ data, size_t n, const uint32_t* __restrict__ totals, size_t nchunks) {
-  uint32_t off = totals[(size_t)blockIdx.y * nchunks + blockIdx.x];
-  uint32_t* col = data + (size_t)blockIdx.y * n;
-  size_t base = (size_t)blockIdx.x * SCAN_BLOCK + (size_t)threadIdx.x * 4;
+// phase 3: add each chunk's offset
+__global__ __launch_bounds__(THREADS) void scan_add_offsets(const ScanJob* __restrict__ jobs) {
+  uint32_t local;
+  const ScanJob& j = find_scan_job(jobs, local);
+  const size_t n = j.n, nchunks = j.nchunks;
+  const uint32_t bx = local % (uint32_t)nchunks, by = local / (uint32_t)nchunks;
+  uint32_t off = j.totals[(size_t)by * nchunks + bx];
+  uint32_t* col = j.data + (size_t)by * n;
+  size_t base = (size_t)bx * SCAN_BLOCK + (size_t)threadIdx.x * 4;
 #pragma unroll
   for (int i = 0; i < 4; i++)
     if (base + i < n) col[base + i] = kb::add(col[base + i], off);

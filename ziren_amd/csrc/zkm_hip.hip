@@ -135,6 +135,7 @@ void zkm_ctx_destroy(zkm_ctx* ctx) {
   for (auto& e : ctx->event_pool) (void)hipEventDestroy(e);
   for (auto& m : ctx->modules) (void)hipModuleUnload(m);
   if (ctx->pin) (void)hipHostFree(ctx->pin);
+  if (ctx->arena) (void)hipFree(ctx->arena);
   (void)hipStreamDestroy(ctx->stream);
   (void)hipStreamDestroy(ctx->stream2);
   if (ctx->up_dma) {
@@ -603,6 +604,7 @@ int zkm_permutation_trace(zkm_ctx* ctx, const zkm_chip_desc* chip, const zkm_mat
     for (int e = 0; e < 4; e++) local_sum[e] = 0;
     if (c.perm_ext_w > 0) {
       E4 alpha, beta;
+      std::vector<stark::ScanJob> scans;
       memcpy(alpha.c, challenges, 16); memcpy(beta.c, challenges + 4, 16);
       std::vector<E4> bp(c.max_values + 2);
       bp[0] = kb::eone();
@@ -610,7 +612,8 @@ int zkm_permutation_trace(zkm_ctx* ctx, const zkm_chip_desc* chip, const zkm_mat
       const E4* d_bp = (const E4*)ctx->upload(bp.data(), bp.size() * sizeof(E4), &scratch);
       const uint32_t* d_blob = (const uint32_t*)ctx->upload(chip->lookups, chip->lookups_len * 4, &scratch);
       launch_permutation_trace(ctx, c, d_blob, (const uint32_t*)main->d, chip->prep_width ? (const uint32_t*)prep->d : nullptr, alpha, d_bp, *pt,
-                               [&](size_t bytes) { void* p = ctx->alloc(bytes); scratch.push_back(p); return p; });
+                               [&](size_t bytes) { void* p = ctx->alloc(bytes); scratch.push_back(p); return p; }, scans);
+      launch_scans(ctx, scans, &scratch);
       const uint32_t* last = pt->d + (size_t)(c.perm_ext_w - 1) * 4 * c.n;
       for (int e = 0; e < 4; e++) HIP_CHECK(hipMemcpyAsync(local_sum + e, last + (size_t)e * c.n + (c.n - 1), 4, hipMemcpyDeviceToHost, ctx->stream));
     }

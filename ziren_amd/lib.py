@@ -6,7 +6,8 @@ import os
 from . import abi
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libzkm_hip.so")
+# ZKM_HIP_LIB: another build of the same library (A/B timing of two kernel versions on one box); never anything but a libzkm_hip build
+LIB_PATH = os.environ.get("ZKM_HIP_LIB") or os.path.join(HERE, "libzkm_hip.so")
 _LIB = None
 
 # every symbol include/zkm_hip.h declares
@@ -86,7 +87,8 @@ def load():
     for name in ("zkm_ctx_destroy", "zkm_host_free", "zkm_byte_lookups_free", "zkm_ctx_set_kernel_timing", "zkm_ctx_set_kernel_timing_only", "zkm_matrix_free", "zkm_pcs_data_free", "zkm_pk_free", "zkm_main_data_free",
                  "zkm_challenger_init", "zkm_challenger_observe", "zkm_host_poseidon2_permute", "zkm_host_poseidon2_permute_f64", "zkm_host_poseidon2_f64_sponge",
                  "zkm_host_poseidon2_f64_compress_inject", "zkm_host_poseidon2_f64_audit", "zkm_host_ext_mul", "zkm_host_ext_inv"):
-        getattr(L, name).restype = None
+        if hasattr(L, name) or "ZKM_HIP_LIB" not in os.environ:   # an older build under A/B comparison may lack the newest entry points
+            getattr(L, name).restype = None
     _LIB = L
     return L
 
