@@ -84,6 +84,65 @@ def cpu_baseline(log_rows_sample, fri):
     return wall, lde, best, avail
 
 
+def fib_leg(device, fri, log_cycles, steps, specialize=True):
+    """BASELINE.json's own workload beside the synthetic default: a full shard of the fibonacci guest (examples/fibonacci; the loop's
+    closed-form events, ziren_amd/fibfast.py — event for event what the executor restatement gives), real chips (Cpu, AddSub, Lt, Mul,
+    Branch, DivRem, MemoryLocal, Global, Byte, Program with the recorded AIRs), 2^log_cycles cycles. Two rates: `prove` = commit + open with
+    the traces resident in HBM (what `value` of the main line means for SYN), and `events_to_proof` = device trace generation from the
+    executor's events in (pageable) host memory + the proof, the reference's prove-a-record step (crates/core/machine/src/utils/prove.rs:484-497)."""
+    from ziren_amd import fibfast, field as F, chips as CH
+    t0 = time.perf_counter()
+    mach = fibfast.full_shard(log_cycles)
+    ds = fibfast.DeviceShard(mach)
+    gen_s = time.perf_counter() - t0
+    ctx = prover.Context(device)
+    hp = prover.HipProver(ds.chips, fri, synth.NUM_PV_ELTS, ctx=ctx, specialize=specialize)
+    zero_digest = F.to_monty(np.array(CH.SEPTIC_START_X + CH.SEPTIC_START_Y, dtype=np.uint64)).astype(np.uint32)
+    pk = hp.setup(ds.preprocessed(ctx), [0, 0], F.to_monty(mach.pc_base), zero_digest)
+    ch0 = prover.new_challenger()
+    pk.observe_into(ch0)
+    out = np.zeros(1 << 22, dtype=np.uint32)
+    lib.load().zkm_ctx_set_kernel_timing(ctx.h, C.c_int(2))
+    born = ds.traces(ctx)
+    hp.prove_shard(pk, ds.public_values, born, ch0.copy(), out=out)          # warm-up
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        proof = hp.prove_shard(pk, ds.public_values, born, ch0.copy(), out=out)
+    ctx.synchronize()
+    prove_ms = (time.perf_counter() - t0) / steps * 1e3
+    phases = {n: round(ms, 3) for n, ms in ctx.last_timings()}
+    kernels = {n: {"ms": round(ms, 3), "launches": calls} for n, ms, calls, _ in sorted(ctx.kernel_timings(), key=lambda t: -t[1])}
+    n_words = int(len(proof))
+    for t in born:
+        t.free()
+    t0 = time.perf_counter()
+    tg = 0.0
+    for _ in range(steps):
+        t1 = time.perf_counter()
+        born = ds.traces(ctx)
+        ctx.synchronize()
+        tg += time.perf_counter() - t1
+        hp.prove_shard(pk, ds.public_values, born, ch0.copy(), out=out)
+        for t in born:
+            t.free()
+    ctx.synchronize()
+    e2p_ms = (time.perf_counter() - t0) / steps * 1e3
+    alg = synth.shard_algorithmic_bytes(ds)
+    rec = mach.shards[0].record
+    event_bytes = int(sum(a.nbytes for a in [rec.cpu, rec.divrem, rec.branch, rec.memory_local] + list(rec.alu.values())))
+    return {"workload": f"FIB-{log_cycles}: a middle shard of examples/fibonacci, {len(rec.cpu)} cycles, full shard proof (commit+open), blowup 2, 84 queries, 16 PoW bits",
+            "chips": {c.name: c.log_height for c in ds.chips}, "committed_cells": ds.committed_cells(), "proof_words": n_words,
+            "prove": {"ms_per_proof": round(prove_ms, 3), "value": round(1e3 / prove_ms, 4), "unit": "shard-proofs/s", "steps": steps,
+                      "note": "traces resident in HBM (device-born), as `value` of the main line"},
+            "events_to_proof": {"ms_per_shard": round(e2p_ms, 3), "value": round(1e3 / e2p_ms, 4), "unit": "shard-proofs/s",
+                                "tracegen_ms": round(tg / steps * 1e3, 3), "event_bytes": event_bytes,
+                                "note": "device trace generation of every chip from the shard's events in pageable host memory, then the proof"},
+            "whole_shard": {"algorithmic_bytes": alg, "achieved": round(alg / (prove_ms * 1e-3) / 1e9, 1), "unit": "GB/s",
+                            "frac": round(alg / (prove_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)},
+            "phases_ms": phases, "kernels_ms": kernels, "event_generation_s": round(gen_s, 2)}
+
+
 def tracegen_bench(args):
     """`python bench.py --tracegen`: device trace generation, chip after chip, 2^log_rows events each, events
     resident in pinned host memory. A "step" is one generate_trace call per chip. value = rows per second of kernel time; the
@@ -184,6 +243,10 @@ def main():
                          "is quoted on) is timed, and the per-kernel table comes from an extra pass with mode 2 after it — timing every launch costs ~2.5 %% of a step")
     ap.add_argument("--from-host", action="store_true", help="time upload (pinned host traces -> HBM) + proof: the PCIe-inclusive rate")
     ap.add_argument("--interpreter", action="store_true", help="use the bytecode interpreter instead of per-chip quotient kernels")
+    ap.add_argument("--fib", type=str, default="21,22", help="log2 cycles of the fibonacci-guest shards proven after the timed region (the `fib` object of "
+                    "the line: BASELINE.json's own workload beside SYN); empty string to skip")
+    ap.add_argument("--workload", choices=["syn", "fib"], default="syn", help="fib: only the fibonacci-guest leg at --log-rows, printed as the line's `fib` object "
+                    "with value / ms_per_step taken from it")
     args = ap.parse_args()
     if args.tracegen:
         return tracegen_bench(args)
@@ -195,6 +258,20 @@ def main():
 
     fri = abi.FriConfig(1, 84, 16)  # core config, crates/stark/src/kb31_poseidon2.rs:203-213
     k = args.log_rows
+    if args.workload == "fib":
+        # the fibonacci guest's shard as the whole job: every rank proves its own copy (weak scaling), rank 0 prints
+        farm.barrier()
+        leg = fib_leg(local_rank, fri, k, max(1, args.steps), not args.interpreter)
+        farm.barrier()
+        slowest = farm.max_over_ranks(leg["prove"]["ms_per_proof"])
+        if rank == 0:
+            print(json.dumps({"metric": "shard-proofs/sec", "value": round(world * 1e3 / slowest, 4), "unit": "shard-proofs/s", "n_gpus": world,
+                              "steps": args.steps, "warmup": 1, "ms_per_step": round(slowest, 3), "higher_is_better": True, "scaling": "weak",
+                              "vs_baseline": None, "dtype": "u32", "data": "synthetic (the guest's events in closed form, ziren_amd/fibfast.py)",
+                              "config": {"workload": leg["workload"], "log_rows": k, "parallelism": f"{world} GPU(s) x 1 shard in flight, independent shards, no collective"},
+                              "fib": leg}))
+        farm.close()
+        return
     shard = synth.syn_shard(k, seed=0x5A4B4D00 + 1000 * rank)
     import threading
     M = max(1, args.inflight)
@@ -433,6 +510,14 @@ def main():
                     "note": "traces in page-locked host memory handed over every step (zkm_matrix_upload_async), upload overlapped with commit"}
             for h in host:
                 hpj.ctx.host_free(h)
+        fib = None
+        if world == 1 and M == 1 and not args.from_host and args.fib:
+            for t in lanes[0][3]:          # the SYN traces are not needed any more
+                try:
+                    t.free()
+                except Exception:           # noqa: BLE001  (already handed back by the PCIe leg)
+                    pass
+            fib = {f"FIB-{kk}": fib_leg(local_rank, fri, int(kk), 3, not args.interpreter) for kk in args.fib.split(",")}
         line = {"metric": "shard-proofs/sec", "value": round(value, 4), "unit": "shard-proofs/s", "n_gpus": world,
                 "steps": steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
                 "scaling": "weak", "vs_baseline": None, "dtype": "u32",
@@ -447,7 +532,7 @@ def main():
                 "kernels_ms_source": (f"a pass of {inst_steps} steps after the timed region with every launch >= 256 KiB timed ({inst_ms:.3f} ms per step: a timed "
                                       f"launch costs a few microseconds of dispatch latency, ~500 launches per proof); inside the timed region only "
                                       f"{dominant} is timed, and the roofline is computed from those launches") if inst_acc else "the timed region",
-                "roofline": roofline, "valu": valu, "two_in_flight": two, "pcie_inclusive": pcie, "cpu_baseline": cpu}
+                "roofline": roofline, "valu": valu, "two_in_flight": two, "pcie_inclusive": pcie, "cpu_baseline": cpu, "fib": fib}
         print(json.dumps(line))
     farm.close()
 

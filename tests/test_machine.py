@@ -16,27 +16,7 @@ PC_BASE = 0x1000
 ZERO_DIGEST = F.to_monty(np.array(chips.SEPTIC_START_X + chips.SEPTIC_START_Y, dtype=np.uint64)).astype(np.uint32)
 
 
-def fibonacci_program(n):
-    """examples/fibonacci/guest/src/main.rs:12-40 by hand: a, b = 0, 1; n times (c = (a + b) % 7919; a = b; b = c); the words n, a, b are
-    committed (digest words 0..2, the other five words zero), then HALT. The loop branches backwards; `b = c` sits in the delay slot."""
-    T0, T1, T2, T3, T4, T5 = 8, 9, 10, 11, 12, 13
-    p = [(E.ADD, T0, 0, n, 0, 1), (E.ADD, T1, 0, 0, 0, 1), (E.ADD, T2, 0, 1, 0, 1), (E.ADD, T4, 0, 0, 0, 1), (E.ADD, T5, 0, 7919, 0, 1)]
-    loop = len(p)
-    p += [(E.ADD, T3, T1, T2, 0, 0), (E.MODU, T3, T3, T5, 0, 0), (E.ADD, T1, T2, 0, 0, 1), (E.ADD, T4, T4, 1, 0, 1)]
-    branch = len(p)
-    p += [(E.BNE, T4, T0, (4 * loop - 4 * (branch + 1)) & 0xffffffff, 0, 1),      # target = next_pc + offset
-          (E.ADD, T2, T3, 0, 0, 1)]                                                 # delay slot: b = c
-    for idx, reg in enumerate([T0, T1, T2, 0, 0, 0, 0, 0]):
-        p += [(E.ADD, E.REG_V0, 0, E.SYS_COMMIT, 0, 1), (E.ADD, E.REG_A0, 0, idx, 0, 1), (E.ADD, E.REG_A1, reg, 0, 0, 1), (E.SYSCALL, E.REG_V0, E.REG_A0, E.REG_A1, 0, 0)]
-    p += [(E.ADD, E.REG_V0, 0, E.SYS_HALT, 0, 1), (E.ADD, E.REG_A0, 0, 0, 0, 1), (E.SYSCALL, E.REG_V0, E.REG_A0, E.REG_A1, 0, 0)]
-    return p
-
-
-def fib(n):
-    a, b = 0, 1
-    for _ in range(n):
-        a, b = b, (a + b) % 7919
-    return a, b
+from ziren_amd.fibfast import fib, fibonacci_program  # noqa: E402,F401  (the guest lives with its closed-form shard generator)
 
 
 def check_machine_airs(oracle, m):

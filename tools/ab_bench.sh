@@ -6,8 +6,8 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 A=$R/$1; N=${2:-2}
 mkdir -p $R/gpurun_out/ab
 for i in $(seq 1 $N); do
-  ZKM_HIP_LIB=$A python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-pcie --no-inflight2 > $R/gpurun_out/ab/a$i.json 2>/dev/null
-  python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-pcie --no-inflight2 > $R/gpurun_out/ab/b$i.json 2>/dev/null
+  ZKM_HIP_LIB=$A python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-pcie --no-inflight2 --fib= > $R/gpurun_out/ab/a$i.json 2>/dev/null
+  python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-pcie --no-inflight2 --fib= > $R/gpurun_out/ab/b$i.json 2>/dev/null
 done
 python - <<PY
 import json, glob

@@ -12,7 +12,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/r03prof
 rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-B="python $R/bench.py --log-rows 22 --no-cpu-baseline --no-pcie --no-inflight2"
+B="python $R/bench.py --log-rows 22 --no-cpu-baseline --no-pcie --no-inflight2 --fib="
 db() { find "$1" -name '*_results.db' | head -1; }
 python $R/bench.py --log-rows 22 --steps 10 --warmup 2 --no-cpu-baseline > $OUT/r03_syn22_bench_unprofiled.json 2> $OUT/bench_unprofiled.err
 rocprofv3 --kernel-trace --stats -d $OUT/stats -o stats -- $B --steps 5 --warmup 1 > $OUT/r03_syn22_bench.json 2> $OUT/stats.err
