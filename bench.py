@@ -57,31 +57,52 @@ def csrc_digest():
     return h.hexdigest()[:16]
 
 
+def usable_cores():
+    """(cores this process may actually use, logical CPUs the host shows, why they differ). A container sees every logical CPU of the host
+    (os.cpu_count) but is scheduled under a cgroup CPU quota: on the GPU boxes of this pool cpu.max is 16 CPUs' worth of time on a
+    256-thread host, and running more threads than the quota makes every OpenMP loop slower (measured: SYN-18 on the restatement takes
+    4.5 s with 16 threads, 6.5 s with 64, 58.8 s with 256 — profiles/r03_cpu_scaling.json), so the quota is the core count."""
+    shown = os.cpu_count() or 1
+    n, why = shown, None
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            q = max(1, int(int(quota) / int(period)))
+            if q < n:
+                n, why = q, f"cgroup cpu.max = {quota}/{period}: {q} CPUs of the host's {shown} logical CPUs"
+    except (OSError, ValueError):
+        try:
+            quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota > 0 and quota // period < n:
+                n, why = max(1, quota // period), f"cgroup cfs quota {quota}/{period}"
+        except (OSError, ValueError):
+            pass
+    return n, shown, why
+
+
 def cpu_baseline(log_rows_sample, fri):
-    """Time the CPU restatement (oracle, kind 'port') on a bounded sample of the same workload: first a small shard with all cores and
-    with fewer threads (the oracle's OpenMP loops stop scaling at some point: the best count is used and reported), then the sample."""
+    """Time the CPU restatement (oracle, kind 'port') proving one SYN shard of the sample size, on every core this process may use
+    (usable_cores: the cgroup quota, not the host's CPU count)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
     L = O.lib()
     L.orc_lde_seconds.restype = C.c_double
-
-    def prove(k, threads):
-        L.orc_set_num_threads(threads)
-        sh = synth.syn_shard(k)
-        pk = O.Pk([], [], sh.pc_start, sh.initial_global_cumulative_sum, fri.log_blowup)
-        ch = O.new_challenger()
-        pk.observe_into(ch)
-        L.orc_lde_seconds(C.c_int(1))
-        t0 = time.time()
-        O.prove_shard(pk, sh.chips, [c.trace for c in sh.chips], sh.public_values, fri, synth.NUM_PV_ELTS, ch)
-        return time.time() - t0, float(L.orc_lde_seconds(C.c_int(0)))
-
-    avail = os.cpu_count() or 1
-    tries = sorted({avail, min(avail, 64), min(avail, 32), min(avail, 16)}, reverse=True)
-    probe_k = min(log_rows_sample, 16)
-    best = min(tries, key=lambda t: prove(probe_k, t)[0])
-    wall, lde = prove(log_rows_sample, best)
-    return wall, lde, best, avail
+    threads, shown, why = usable_cores()
+    L.orc_set_num_threads(threads)
+    sh = synth.syn_shard(log_rows_sample)
+    pk = O.Pk([], [], sh.pc_start, sh.initial_global_cumulative_sum, fri.log_blowup)
+    ch = O.new_challenger()
+    pk.observe_into(ch)
+    L.orc_lde_seconds(C.c_int(1))
+    t0 = time.time()
+    O.prove_shard(pk, sh.chips, [c.trace for c in sh.chips], sh.public_values, fri, synth.NUM_PV_ELTS, ch)
+    wall = time.time() - t0
+    return wall, float(L.orc_lde_seconds(C.c_int(0))), threads, shown, why
 
 
 def fib_leg(device, fri, log_cycles, steps, specialize=True):
@@ -236,6 +257,7 @@ def main():
     ap.add_argument("--cpu-sample-log-rows", type=int, default=20)
     ap.add_argument("--no-pcie", action="store_true", help="skip the PCIe-inclusive measurement that follows the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-full", action="store_true", help="time the CPU baseline at the full size (SYN-22: ~80 s on 16 cores) instead of on the SYN-20 sample")
     ap.add_argument("--no-inflight2", action="store_true", help="skip the two-shards-in-flight measurement that follows the timed region")
     ap.add_argument("--inflight", type=int, default=1, help="shards proven concurrently per GPU (one context + host thread each)")
     ap.add_argument("--kernel-timing", type=int, default=3,
@@ -243,6 +265,9 @@ def main():
                          "is quoted on) is timed, and the per-kernel table comes from an extra pass with mode 2 after it — timing every launch costs ~2.5 %% of a step")
     ap.add_argument("--from-host", action="store_true", help="time upload (pinned host traces -> HBM) + proof: the PCIe-inclusive rate")
     ap.add_argument("--interpreter", action="store_true", help="use the bytecode interpreter instead of per-chip quotient kernels")
+    ap.add_argument("--queue", type=int, default=0, metavar="SHARDS", help="deal SHARDS distinct shards (0: off; the default with --queue -1 is 4 per GPU) "
+                    "through the farm's claim queue (Farm.run_queue: whichever rank is free takes the next shard, crates/core/machine/src/utils/prove.rs:484) "
+                    "and gather the proof streams to rank 0, instead of K identical steps per rank; value = shards / max-over-ranks time")
     ap.add_argument("--fib", type=str, default="21,22", help="log2 cycles of the fibonacci-guest shards proven after the timed region (the `fib` object of "
                     "the line: BASELINE.json's own workload beside SYN); empty string to skip")
     ap.add_argument("--workload", choices=["syn", "fib"], default="syn", help="fib: only the fibonacci-guest leg at --log-rows, printed as the line's `fib` object "
@@ -330,6 +355,40 @@ def main():
             a[1] += calls
             a[2] += nbytes
 
+    if args.queue:
+        # the farm as the reference runs it: distinct shards from one queue. The traces are this rank's resident set; what makes shard i its
+        # own shard is its transcript (the index is observed after the key), so every proof differs and every proof verifies
+        n_shards = args.queue if args.queue > 0 else 4 * world
+        hpj, pkj, chj, trj, outj = lanes[0]
+
+        def prove_shard_i(i):
+            ch = chj.copy()
+            idx = np.array([i + 1], dtype=np.uint32)
+            lib.load().zkm_challenger_observe(C.byref(ch), abi.as_u32p(idx), C.c_size_t(1))
+            return hpj.prove_shard(pkj, shard.public_values, trj, ch, out=outj)
+
+        for _ in range(max(1, args.warmup)):
+            prove_shard_i(0)
+        farm.barrier()
+        t0 = time.perf_counter()
+        ids, proofs = farm.run_queue(n_shards, prove_shard_i)
+        gathered = farm.gather_proofs(ids, proofs, n_shards)
+        farm.barrier()
+        elapsed = farm.max_over_ranks(time.perf_counter() - t0)
+        mine = float(np.mean(farm.host_ms)) if farm.host_ms else 0.0
+        slowest = farm.max_over_ranks(mine)
+        proved = farm.sum_over_ranks(float(len(ids)))
+        if rank == 0:
+            assert len(gathered) == n_shards and len({p.tobytes() for p in gathered}) == n_shards, "the gathered proofs are not distinct"
+            print(json.dumps({"metric": "shard-proofs/sec", "value": round(n_shards / elapsed, 4), "unit": "shard-proofs/s", "n_gpus": world,
+                              "steps": n_shards, "warmup": max(1, args.warmup), "ms_per_step": round(elapsed / n_shards * 1e3, 3),
+                              "higher_is_better": True, "scaling": "strong" if args.queue > 0 else "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+                              "config": {"workload": f"SYN-{k}: {n_shards} distinct full shard proofs dealt from one queue (Farm.run_queue), proof streams gathered to rank 0 inside the timed region",
+                                         "log_rows": k, "parallelism": f"{world} GPU(s), claim queue, RCCL gather of {sum(len(p) for p in gathered) * 4} proof bytes"},
+                              "host_ms_per_shard": {"rank0_mean": round(mine, 3), "max_over_ranks_of_means": round(slowest, 3)},
+                              "shards_proved": int(proved), "shards_proved_by_rank0": len(ids)}))
+        farm.close()
+        return
     for _ in range(args.warmup):
         step()
     # which kernel the roofline will be quoted on: the one with the most HIP-event time in the last warm-up step (every launch >= 256 KiB timed)
@@ -437,16 +496,17 @@ def main():
                     "share_of_step": round(hms / table_step_ms, 3)}
         cpu = None
         if not args.no_cpu_baseline and world == 1:  # rank 0, N = 1 only
-            ks = min(args.cpu_sample_log_rows, k)
-            wall, lde, threads, avail = cpu_baseline(ks, fri)
+            ks = k if args.cpu_full else min(args.cpu_sample_log_rows, k)
+            wall, lde, threads, shown, why = cpu_baseline(ks, fri)
             # everything but the LDEs is linear in the rows; the LDEs (n log n) grow by (k + 1) / (ks + 1) on top (rows of the extended domain)
             lin = 1 << (k - ks)
             est = (wall - lde) * lin + lde * lin * (k + 1) / (ks + 1)
-            cpu = {"value": round(1.0 / est, 6), "unit": "shard-proofs/s", "cores": threads, "cores_available": avail, "kind": "port",
-                   "sample": f"oracle (CPU restatement, OpenMP, {threads} threads: the fastest of all cores / 64 / 32 / 16 on a SYN-{min(ks, 16)} probe) "
-                             f"proving one SYN-{ks} shard in {wall:.2f} s ({lde:.2f} s of it coset LDEs); scaled to SYN-{k}: x{lin} for the linear "
-                             f"phases, x{lin}*{k + 1}/{ks + 1} for the LDEs",
-                   "sample_seconds": round(wall, 3), "estimated_seconds_full_size": round(est, 2)}
+            cpu = {"value": round(1.0 / est, 6), "unit": "shard-proofs/s", "cores": threads, "cores_available": threads, "host_logical_cpus": shown,
+                   "cores_note": why, "kind": "port",
+                   "sample": (f"oracle (CPU restatement, canonical `% p` arithmetic, OpenMP, {threads} threads) proving one SYN-{ks} shard in {wall:.2f} s "
+                              f"({lde:.2f} s of it coset LDEs)" + ("" if ks == k else f"; scaled to SYN-{k}: x{lin} for the linear phases, x{lin}*{k + 1}/{ks + 1} for the LDEs")),
+                   "measured_at_full_size": ks == k, "sample_seconds": round(wall, 3), "estimated_seconds_full_size": round(est, 2),
+                   "full_size_measurement": "profiles/r03_cpu_baseline_full.json (bench.py --cpu-full, the same proof at SYN-22 timed directly)"}
         two = None
         if world == 1 and M == 1 and not args.from_host and not args.no_inflight2:
             # the same GPU with two shards in flight (a second context + host thread, its own copy of the traces): the launch gaps and

@@ -88,12 +88,19 @@ static inline Matrix coset_lde_matrix_bitrev(const Matrix& m, int added_bits, F 
   size_t H = m.h << added_bits;
   int logH = log2_strict(H);
   Matrix out(H, m.w);
+  // columns are extended side by side, each into a vector of its own; the row-major result is then written row by row (a thread owns
+  // whole rows: no two threads share a cache line of `out`, which is what kept this loop from scaling past a few threads before)
+  std::vector<std::vector<F>> cols(m.w);
 #pragma omp parallel for schedule(dynamic)
   for (size_t c = 0; c < m.w; c++) {
     std::vector<F> col(m.h);
     for (size_t r = 0; r < m.h; r++) col[r] = m.at(r, c);
-    std::vector<F> l = coset_lde(std::move(col), added_bits, lde_shift);
-    for (size_t j = 0; j < H; j++) out.at(bitrev((uint32_t)j, logH), c) = l[j];
+    cols[c] = coset_lde(std::move(col), added_bits, lde_shift);
+  }
+#pragma omp parallel for schedule(static)
+  for (size_t r = 0; r < H; r++) {
+    const size_t j = bitrev((uint32_t)r, logH);
+    for (size_t c = 0; c < m.w; c++) out.at(r, c) = cols[c][j];
   }
   return out;
 }
