@@ -269,6 +269,21 @@ struct zkm_ctx {
     pow_tabs[k] = {lo, hi};
     return {lo, hi};
   }
+  // per row of the four-step decomposition the twiddles of the inverse row transform (lde::fill_row_twiddles): n words per height
+  std::map<int, uint32_t*> row_tabs;
+  const uint32_t* row_twiddles(int k) {
+    auto it = row_tabs.find(k);
+    if (it != row_tabs.end()) return it->second;
+    const int lb = lde::LOG_ROW_MAX, la = k - lb;
+    const size_t n = (size_t)1 << k;
+    uint32_t* d;
+    HIP_CHECK(hipMalloc(&d, n * 4));
+    auto pw = pow_tables(k);
+    hipLaunchKernelGGL(lde::fill_row_twiddles, dim3(div_up(n, 256)), dim3(256), 0, stream, d, la, lb, pw.first, pw.second);
+    LAUNCH_CHECK();
+    row_tabs[k] = d;
+    return d;
+  }
   // the tables of lde_rows_big that depend on the coset shift: per coset the scaled forward stage twiddles of the B-point row
   // transform and the row constants shift_j^k1 / n; keyed by (log2 n, log_blowup, shift of coset 0). A prover meets a handful of
   // (height, shift) pairs — traces are extended onto 3 K, quotient chunks onto 3 w_2n^-i K — so the cache stays small; zkm_ctx_trim clears it.

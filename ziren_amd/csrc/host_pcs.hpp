@@ -42,6 +42,7 @@ static void lde_batch_chunk(zkm_ctx* ctx, const std::vector<LdeJob>& jobs, int b
       g.twa_fwd = ctx->twiddles(la, false);
       auto pw = ctx->pow_tables(k);
       g.pw_lo = pw.first; g.pw_hi = pw.second;
+      g.tw_rows = ctx->row_twiddles(k);
     }
     uint32_t cols = 0;
     for (; p < order.size() && jobs[order[p]].n == n; p++) {

@@ -125,6 +125,55 @@ __device__ __forceinline__ void lds_ntt(uint32_t* buf, int logn, int lognb, int 
   }
 }
 
+// ---- natural in -> bit-reversed out with the twiddle BEFORE the add (Cooley-Tukey butterflies on a decimation-in-frequency geometry) ----
+// Stage s splits sub-problem r (positions [r M, (r + 1) M), M = n >> s) into its halves: a' = a + c b, b' = a - c b for the pairs
+// (p, p + M/2), with ONE factor c per sub-problem: c = shift(s, r)^(M/2), shift(s, r) = g w^bitrev_s(r) the coset the sub-problem is
+// evaluated on (even outputs keep the shift, odd outputs multiply it by the current root). Two things follow. (i) A pre-scaling of the
+// inputs by g^i is absorbed: the table tw[(1 << s) - 1 + r] = (g w^bitrev_s(r))^(M/2) simply starts from g instead of 1 — this is how
+// lde_rows_big's inverse row transform takes its w_n^(-i0 k1) twiddle without one multiplication (round 3; the table is per row k1:
+// n words per height). (ii) The butterfly has the lazy form of the forward passes (ten instructions, signed unreduced words).
+// `hi` = the group's sub-problem index at stage s0 (its position >> (logn - s0)).
+template <int R, bool UNIFORM>
+__device__ __forceinline__ void butterflies_ct(uint32_t (&x)[1 << R], uint32_t s0, uint32_t hi, const uint32_t* __restrict__ tw) {
+#pragma unroll
+  for (int q = 0; q < R; q++) {
+    const uint32_t half = 1u << (R - 1 - q);
+    const uint32_t tbase = (1u << (s0 + q)) - 1 + (hi << q);
+#pragma unroll
+    for (uint32_t j0 = 0; j0 < (1u << R); j0++) {
+      if (j0 & half) continue;
+      const uint32_t j1 = j0 + half;
+      const uint32_t w = tw[tbase + (j0 >> (R - q))];
+      const int32_t a = (int32_t)x[j0], b = (int32_t)x[j1];
+      const int64_t ar = kb::mad_i64_i32_uniform(a, kb::ONE, 0);
+      if (UNIFORM) {
+        x[j0] = (uint32_t)kb::monty_reduce_signed(kb::mad_i64_i32_uniform(b, w, ar));
+        x[j1] = (uint32_t)kb::monty_reduce_signed(kb::mad_i64_i32_uniform(-b, w, ar));
+      } else {
+        x[j0] = (uint32_t)kb::monty_reduce_signed(kb::mad_i64_i32(b, (int32_t)w, ar));
+        x[j1] = (uint32_t)kb::monty_reduce_signed(kb::mad_i64_i32(-b, (int32_t)w, ar));
+      }
+    }
+  }
+}
+// one pass of R such stages over an LDS buffer of 2^logn points (PAD as in ntt_pass); a thread's 2^R points are 2^logm2 apart
+template <int R, bool PAD>
+__device__ __forceinline__ void ntt_pass_ct(uint32_t* buf, uint32_t logn, uint32_t s0, const uint32_t* __restrict__ tw, uint32_t tid = threadIdx.x) {
+  const uint32_t logm2 = logn - s0 - R;
+  const uint32_t total = (1u << logn) >> R;
+  for (uint32_t u = tid; u < total; u += blockDim.x) {
+    const uint32_t lo = u & ((1u << logm2) - 1), hi = u >> logm2;
+    const uint32_t base = (hi << (R + logm2)) + lo;
+    uint32_t x[1 << R];
+#pragma unroll
+    for (uint32_t j = 0; j < (1u << R); j++) x[j] = buf[phys<PAD>(base + (j << logm2))];
+    butterflies_ct<R, false>(x, s0, hi, tw);
+#pragma unroll
+    for (uint32_t j = 0; j < (1u << R); j++) buf[phys<PAD>(base + (j << logm2))] = x[j];
+  }
+  __syncthreads();
+}
+
 // Two-level power table of g in LDS: lo[i] = g^i (i < 64), hi[i] = g^(64 i) (i < nhi).
 // `scale` is folded into the low table, so pow_lookup() returns scale * g^e.
 __device__ __forceinline__ void build_pow_table(uint32_t g, uint32_t* lo, uint32_t* hi, int nhi, uint32_t scale = kb::ONE) {
@@ -166,6 +215,7 @@ struct Group {
   const uint32_t *twb_fwd, *twb_inv;       // stage-major twiddles of the B-point transform (la == 0 uses both, la > 0 the inverse)
   const uint32_t *twa_fwd, *twa_inv;       // of the A-point transform
   const uint32_t *pw_lo, *pw_hi;           // w_n^e = pw_lo[e & 1023] * pw_hi[e >> 10]
+  const uint32_t* tw_rows;                 // la > 0: per row k1 the B - 1 sub-problem twiddles of the inverse row transform (fill_row_twiddles)
   uint32_t w_N, n_inv, pad3[2];
 };
 struct Batch {
@@ -312,7 +362,7 @@ __global__ __launch_bounds__(THREADS) void lde_rows(const Batch* __restrict__ d)
 // Everything a block needs that depends only on its row k1 — w_n^(+-k1 tid), w_n^(+-512 k1), shift_j^k1 / n — comes from
 // small tables (two multiplications per lookup) instead of square-and-multiply chains run redundantly by every thread:
 // those chains were ~76 of the kernel's 336 VALU instructions per point.
-__global__ __launch_bounds__(THREADS, 4) void lde_rows_big(const Batch* __restrict__ d) {
+__global__ __launch_bounds__(THREADS, 6) void lde_rows_big(const Batch* __restrict__ d) {
   constexpr uint32_t LB = LOG_ROW_MAX, B = 1u << LB, BP = B + (B >> 5);
   constexpr uint32_t G = B / THREADS;  // points per thread (16)
   static_assert(G == 16 && LB == 13, "pass structure below is written for 8192 points on 512 threads");
@@ -322,47 +372,43 @@ __global__ __launch_bounds__(THREADS, 4) void lde_rows_big(const Batch* __restri
   const Group& g = find_group(d, K_ROWS_BIG, local);
   const uint32_t la = g.la;
   const uint32_t tid = threadIdx.x;
-  const uint32_t pr = local & ((1u << la) - 1);
-  const uint32_t col = local >> la;
+  // column fastest: the blocks in flight at one time share their row position, hence the row's twiddle table (32 KiB, L2-resident)
+  const uint32_t pr = local / g.n_cols;
+  const uint32_t col = local - pr * g.n_cols;
   const Mat& m = find_mat(d, g, col);
   const size_t c = col - m.col0;
   const size_t n = (size_t)B << la;
   const uint32_t nmask = (uint32_t)n - 1;
   const uint32_t k1 = kb::bitrev(pr, la);
   const uint32_t* src = m.tmp1 + c * n + (size_t)pr * B;
-  const uint32_t* __restrict__ tw_inv = g.twb_inv;
   const uint32_t* __restrict__ pw_lo = g.pw_lo;
   const uint32_t* __restrict__ pw_hi = g.pw_hi;
   auto pw = [&](uint32_t e) { return kb::mul(pw_lo[e & 1023], pw_hi[e >> 10]); };  // w_n^e, e < n
 
+  // inverse row transform, natural in -> bit-reversed out, with the row's table of sub-problem twiddles (butterflies_ct): the
+  // w_n^(-i0 k1) twiddle of the four-step decomposition is inside the table. First four stages in registers (thread g owns i0 = g + 512 j:
+  // the sub-problem index of those stages is made of j's top bits, so their fifteen twiddles are the same for the whole block: scalar
+  // loads), two passes through LDS, last stage (pairs 2g, 2g+1) into the registers where the coefficients stay for every coset.
+  const uint32_t* __restrict__ twr = g.tw_rows + (size_t)k1 * B;
   uint32_t x[16];
 #pragma unroll
   for (uint32_t j = 0; j < 16; j++) x[j] = src[tid + (j << 9)];
-  {
-    // x_j *= w_n^(-k1 (tid + 512 j))
-    uint32_t t = pw((0u - k1 * tid) & nmask);
-    const uint32_t a = pw((0u - (k1 << 9)) & nmask);
-#pragma unroll
-    for (uint32_t j = 0; j < 16; j++) {
-      x[j] = kb::mul(x[j], t);
-      t = kb::mul(t, a);
-    }
-  }
-  butterflies<true, 4>(x, B, 0, tid, 9, tw_inv);
+  butterflies_ct<4, true>(x, 0, 0, twr);
 #pragma unroll
   for (uint32_t j = 0; j < 16; j++) work[phys<true>(tid + (j << 9))] = x[j];
   __syncthreads();
-  ntt_pass<true, 4, true>(work, LB, 0, 1, 4, tw_inv);
-  ntt_pass<true, 4, true>(work, LB, 0, 1, 8, tw_inv);
-  // last inverse stage (span 1, twiddle 1): coef[2g], coef[2g+1] for g = tid + 512 k stay in registers.
-  // coef[pc] = n * c_kk with kk = bitrev_13(pc) * A + k1
+  ntt_pass_ct<4, true>(work, LB, 4, twr);
+  ntt_pass_ct<4, true>(work, LB, 8, twr);
+  // coef[pc] = n * c_kk with kk = bitrev_13(pc) * A + k1, as signed unreduced words (the forward passes are lazy as well)
   uint32_t keep[16];
 #pragma unroll
   for (uint32_t k = 0; k < 8; k++) {
-    const uint32_t i = 2 * (tid + (k << 9));
-    const uint32_t a = work[phys<true>(i)], b = work[phys<true>(i + 1)];
-    keep[2 * k] = kb::add(a, b);
-    keep[2 * k + 1] = kb::sub(a, b);
+    const uint32_t gg = tid + (k << 9);
+    const int32_t a = (int32_t)work[phys<true>(2 * gg)], b = (int32_t)work[phys<true>(2 * gg + 1)];
+    const uint32_t w = twr[(1u << 12) - 1 + gg];
+    const int64_t ar = kb::mad_i64_i32_uniform(a, kb::ONE, 0);
+    keep[2 * k] = (uint32_t)kb::monty_reduce_signed(kb::mad_i64_i32(b, (int32_t)w, ar));
+    keep[2 * k + 1] = (uint32_t)kb::monty_reduce_signed(kb::mad_i64_i32(-b, (int32_t)w, ar));
   }
   // store twiddle w_n^(k1 (tid + 512 j)): first factor and step
   const uint32_t st0 = pw((k1 * tid) & nmask), st_step = pw((k1 << 9) & nmask);
@@ -421,6 +467,21 @@ __global__ void fill_scaled_stage_twiddles(uint32_t* tw, uint32_t w, int logn, u
     for (int i = 0; i < s; i++) gs = kb::sqr(gs);
     tw[n - (n >> s) + off] = kb::mul(gs, kb::pow(w, (uint64_t)off << s));
   }
+}
+// Per row k1 < A of the four-step decomposition, the sub-problem twiddles of the inverse B-point row transform with the w_n^(-i0 k1)
+// twiddle folded in (butterflies_ct): tw[k1 B + (1 << s) - 1 + r] = (g w^bitrev_s(r))^(B >> (s + 1)) with g = w_n^-k1, w = w_B^-1 = w_n^-A,
+// i.e. w_n^(-(B >> (s + 1)) (k1 + A bitrev_s(r))). One thread per entry; w_n^e through the two-level power table.
+__global__ void fill_row_twiddles(uint32_t* tw, int la, int lb, const uint32_t* __restrict__ pw_lo, const uint32_t* __restrict__ pw_hi) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t B = (size_t)1 << lb, n = B << la;
+  if (idx >= n) return;
+  const uint32_t k1 = (uint32_t)(idx >> lb), e = (uint32_t)(idx & (B - 1));
+  if (e == B - 1) { tw[idx] = 0; return; }        // B - 1 entries per row
+  const int s = 31 - __clz(e + 1);
+  const uint32_t r = e + 1 - (1u << s);
+  const uint64_t ex = ((uint64_t)(B >> (s + 1)) * ((uint64_t)k1 + ((uint64_t)kb::bitrev(r, s) << la))) & (n - 1);
+  const uint32_t en = (uint32_t)((n - ex) & (n - 1));
+  tw[idx] = kb::mul(pw_lo[en & 1023], pw_hi[en >> 10]);
 }
 // lo[i] = w^i (i < 1024), hi[i] = w^(1024 i) (i < n_hi): w^e = lo[e & 1023] * hi[e >> 10]
 __global__ void fill_pow_tables(uint32_t* lo, uint32_t* hi, uint32_t w, uint32_t n_hi) {
