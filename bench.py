@@ -33,8 +33,8 @@ FP64_VECTOR_TFLOPS = 78.6  # MI355X FP64 vector peak: 256 CUs x 4 SIMDs x 16 lan
 
 def poseidon2_isa():
     """Dynamic VALU instructions per permutation as the hardware counts them (SQ_INSTS_VALU over tools/ubench_p2's kernels,
-    profiles/r02_poseidon2_isa.json, written by tools/profile_r02.sh -> tools/pmc_poseidon2.py); None when the profile is missing."""
-    path = os.path.join(ROOT, "profiles", "r02_poseidon2_isa.json")
+    profiles/r03_poseidon2_isa.json, written by tools/profile_r03.sh -> tools/pmc_poseidon2.py); None when the profile is missing."""
+    path = os.path.join(ROOT, "profiles", "r03_poseidon2_isa.json")
     if not os.path.exists(path):
         return None
     return json.load(open(path))
@@ -451,10 +451,10 @@ def main():
             kbytes = nbytes / max(calls, 1)
             achieved = kbytes / (per_launch_ms * 1e-3) / 1e9 if per_launch_ms > 0 else 0.0
             # HBM bytes per launch: PMC counters cannot be read from inside this process, so the figure comes from the rocprofv3 --pmc
-            # passes of this same command kept under profiles/ (tools/profile_r02.sh) — and only if they were taken on these very
+            # passes of this same command kept under profiles/ (tools/profile_r03.sh) — and only if they were taken on these very
             # kernel sources (the profile records their digest); otherwise null, never a stale number
             traffic, traffic_source = None, None
-            tpath = os.path.join(ROOT, "profiles", "r02_syn22_hbm_traffic.json")
+            tpath = os.path.join(ROOT, "profiles", "r03_syn22_hbm_traffic.json")
             short = {"compress_layer": "merkle::compress_layer", "hash_leaves": "merkle::hash_leaves", "hash_leaves_tree": "merkle::hash_leaves_tree",
                      "lde_rows": "lde::lde_rows_big"}.get(name)
             if k == 22 and short and os.path.exists(tpath):
@@ -462,9 +462,9 @@ def main():
                 tk = tj["kernels"].get(short)
                 if tk and tj.get("csrc_digest") == csrc_digest():
                     traffic = int(tk["hbm_bytes_per_launch"])
-                    traffic_source = {"file": "profiles/r02_syn22_hbm_traffic.json", "commit": tj.get("commit"), "csrc_digest": tj.get("csrc_digest")}
+                    traffic_source = {"file": "profiles/r03_syn22_hbm_traffic.json", "commit": tj.get("commit"), "csrc_digest": tj.get("csrc_digest")}
                 else:
-                    traffic_source = {"file": "profiles/r02_syn22_hbm_traffic.json", "stale": True,
+                    traffic_source = {"file": "profiles/r03_syn22_hbm_traffic.json", "stale": True,
                                       "note": "taken on other kernel sources (csrc digest differs): not quoted"}
             roofline = {"bound": "hbm", "kernel": name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_source,
@@ -476,7 +476,7 @@ def main():
                                         "frac": round(alg_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}}
         # SURVEY 8d asks for the VALU side next to the HBM fraction: the hashing kernels are bound by instruction issue, not by bytes.
         # Poseidon2 runs on the FP64 vector pipe (csrc/poseidon2_f64.cuh); its ceiling is the chip's FP64 vector issue rate divided by
-        # the permutation's dynamic instruction count as the hardware counted it (SQ_INSTS_VALU, profiles/r02_poseidon2_isa.json)
+        # the permutation's dynamic instruction count as the hardware counted it (SQ_INSTS_VALU, profiles/r03_poseidon2_isa.json)
         valu = None
         # the per-kernel table: from the timed region itself, or — when only the dominant kernel was timed there — from the pass after it
         table, table_steps, table_step_ms = (inst_acc, inst_steps, inst_ms) if inst_acc else (kern_acc, steps, ms_per_step)
@@ -492,8 +492,35 @@ def main():
             valu = {"bound": "fp64-vector-issue", "kernels": hashing, "poseidon2_permutations": perms, "ms": round(hms, 3),
                     "achieved": round(perms / hms / 1e6, 3), "peak": round(peak, 2) if peak else None, "unit": "Gperm/s",
                     "frac": round(perms / hms / 1e6 / peak, 3) if peak else None, "valu_instr_per_permutation": per_perm,
-                    "valu_instr_source": "profiles/r02_poseidon2_isa.json (SQ_INSTS_VALU / permutations, tools/ubench_p2)" if isa else None,
+                    "valu_instr_source": "profiles/r03_poseidon2_isa.json (SQ_INSTS_VALU / permutations, tools/ubench_p2)" if isa else None,
                     "share_of_step": round(hms / table_step_ms, 3)}
+        # the coset LDE as a group: its three kernels' time, the algorithmic bytes 12 n w (read n w words, write 2 n w)
+        # of every committed column, and — from the PMC profile of these very sources — the bytes they really move through HBM
+        lde = None
+        lde_names = [n for n in ("lde_rows", "lde_cols_forward", "lde_cols_inverse") if n in table]
+        if lde_names and M == 1:
+            lde_ms = sum(table[n][0] for n in lde_names) / table_steps
+            cells = sum((1 << c.log_height) * (c.main_width + 4 * c.perm_ext_width + (4 << c.log_quotient_degree)) for c in shard.chips)
+            alg = 12.0 * cells
+            tr = None
+            tpath = os.path.join(ROOT, "profiles", "r03_syn22_hbm_traffic.json")
+            if k == 22 and os.path.exists(tpath):
+                tj = json.load(open(tpath))
+                if tj.get("csrc_digest") == csrc_digest():
+                    tr = sum(tj["kernels"][n]["hbm_bytes_total"] for n in ("lde::lde_rows_big", "lde::lde_cols<true>", "lde::lde_cols<false>") if n in tj["kernels"])
+            lde = {"ms": round(lde_ms, 3), "alg_GB": round(alg / 1e9, 3), "alg_GBps": round(alg / lde_ms / 1e6, 1), "frac_of_hbm_peak": round(alg / lde_ms / 1e6 / HBM_PEAK_GBPS, 4),
+                   "traffic_GB": round(tr / 1e9, 3) if tr else None, "ratio": round(tr / alg, 2) if tr else None,
+                   "structural_floor": "36 n w: a two-level split reads and writes the column three times (strided inverse, rows, strided forward)"}
+        # hardware-measured vector-pipe occupancy of the hashing kernels (rocprofv3 --pmc SQ_ACTIVE_INST_VALU / GRBM_GUI_ACTIVE over this
+        # command: tools/profile_r03.sh, definitions in tools/pmc_sq_summary.py), next to the derived valu.frac
+        if valu is not None:
+            spath = os.path.join(ROOT, "profiles", "r03_syn22_sq_counters.csv")
+            if os.path.exists(spath):
+                import csv
+                rows = {r["Name"]: r for r in csv.DictReader(open(spath))}
+                valu["valu_pipe_busy_pct_measured"] = {n: float(rows[n]["ValuPipeBusyPct(of SIMD time)"]) for n in ("merkle::compress_layer", "merkle::hash_leaves")
+                                                       if n in rows and rows[n].get("ValuPipeBusyPct(of SIMD time)")}
+                valu["valu_pipe_busy_source"] = "profiles/r03_syn22_sq_counters.csv"
         cpu = None
         if not args.no_cpu_baseline and world == 1:  # rank 0, N = 1 only
             ks = k if args.cpu_full else min(args.cpu_sample_log_rows, k)
@@ -592,7 +619,7 @@ def main():
                 "kernels_ms_source": (f"a pass of {inst_steps} steps after the timed region with every launch >= 256 KiB timed ({inst_ms:.3f} ms per step: a timed "
                                       f"launch costs a few microseconds of dispatch latency, ~500 launches per proof); inside the timed region only "
                                       f"{dominant} is timed, and the roofline is computed from those launches") if inst_acc else "the timed region",
-                "roofline": roofline, "valu": valu, "two_in_flight": two, "pcie_inclusive": pcie, "cpu_baseline": cpu, "fib": fib}
+                "roofline": roofline, "valu": valu, "lde": lde, "two_in_flight": two, "pcie_inclusive": pcie, "cpu_baseline": cpu, "fib": fib}
         print(json.dumps(line))
     farm.close()
 

@@ -269,6 +269,21 @@ struct zkm_ctx {
     pow_tabs[k] = {lo, hi};
     return {lo, hi};
   }
+  // the quotient kernels' selector table per (log2 n, log quotient degree): stark::fill_selectors, 3 Q words
+  std::map<std::pair<int, int>, uint32_t*> selector_tabs;
+  const uint32_t* selectors(int log_n, int lqd, uint32_t w_q, uint32_t g_inv, const uint32_t* d_consts) {
+    auto key = std::make_pair(log_n, lqd);
+    auto it = selector_tabs.find(key);
+    if (it != selector_tabs.end()) return it->second;
+    const size_t Q = (size_t)1 << (log_n + lqd);
+    uint32_t* d;
+    HIP_CHECK(hipMalloc(&d, 3 * Q * 4));
+    flush_staged();
+    hipLaunchKernelGGL(stark::fill_selectors, dim3(div_up(Q, 256)), dim3(256), 0, cur, d, log_n + lqd, lqd, w_q, g_inv, d_consts);
+    LAUNCH_CHECK();
+    selector_tabs[key] = d;
+    return d;
+  }
   // per row of the four-step decomposition the twiddles of the inverse row transform (lde::fill_row_twiddles): n words per height
   std::map<int, uint32_t*> row_tabs;
   const uint32_t* row_twiddles(int k) {

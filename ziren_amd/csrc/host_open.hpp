@@ -338,6 +338,7 @@ struct ShardOpening {
     a.consts = d_consts;
     a.w_q = w_q; a.g_inv = kb::inv(kb::two_adic_generator(c.log_n));
     a.out = qbuf;
+    a.selectors = ctx->selectors(c.log_n, lqd, w_q, a.g_inv, d_consts);
     a.n_base_regs = d->program_len ? std::max<uint32_t>(d->program[3], 1) : 1;
     size_t per_thread = (size_t)a.n_regs * 16 + (size_t)a.n_base_regs * 4;
     int bd = 256;
@@ -483,27 +484,35 @@ struct ShardOpening {
   void reduced_openings() {
   E4 fa = chal::sample_ext(ch);
   log_max = 0;
-  size_t max_width = 1;
-  for (auto& r : rounds) for (auto& m : r.mats) { log_max = std::max(log_max, log2_strict(m.lde->h)); max_width = std::max(max_width, m.width); }
-  std::vector<E4> fap(max_width + 1);
+  // one table of alpha powers long enough for the largest per-height column count (a matrix's powers are a window of it)
+  std::vector<size_t> count(32, 0);
+  size_t max_count = 1;
+  for (auto& r : rounds) for (auto& m : r.mats) {
+    int lh = log2_strict(m.lde->h);
+    log_max = std::max(log_max, lh);
+    count[lh] += m.width * m.n_points;
+    max_count = std::max(max_count, count[lh]);
+  }
+  std::vector<E4> fap(max_count + 1);
   fap[0] = kb::eone();
-  for (size_t i = 1; i <= max_width; i++) fap[i] = kb::emul(fap[i - 1], fa);
+  for (size_t i = 1; i <= max_count; i++) fap[i] = kb::emul(fap[i - 1], fa);
   E4* d_fap = (E4*)ctx->upload_staged(fap.data(), fap.size() * sizeof(E4), &scratch);
   {
     std::vector<std::vector<open::ReduceMat>> per_h(32);
-    std::vector<E4> run(32, kb::eone());  // alpha^count per height
+    std::vector<size_t> off(32, 0);                     // columns counted so far per height (fri.rs: per (point, column))
+    std::vector<std::array<E4, 2>> Y(32, {kb::ezero(), kb::ezero()});
     for (auto& r : rounds)
       for (auto& m : r.mats) {
         int lh = log2_strict(m.lde->h);
         open::ReduceMat rm;
         rm.lde = m.lde->d; rm.width = (int)m.width; rm.n_points = m.n_points;
-        for (int pt = 0; pt < 2; pt++) { rm.A[pt] = kb::ezero(); rm.Yc[pt] = kb::ezero(); }
+        rm.apow_off = (uint32_t)off[lh]; rm.pad = 0;
+        rm.A1 = fap[m.width];
         for (int pt = 0; pt < m.n_points; pt++) {
           E4 ysum = kb::ezero();
-          for (size_t c = 0; c < m.width; c++) ysum = kb::eadd(ysum, kb::emul(fap[c], m.y[pt][c]));
-          rm.A[pt] = run[lh];
-          rm.Yc[pt] = kb::emul(run[lh], ysum);
-          run[lh] = kb::emul(run[lh], fap[m.width]);
+          for (size_t c = 0; c < m.width; c++) ysum = kb::eadd(ysum, kb::emul(fap[off[lh] + c], m.y[pt][c]));
+          Y[lh][pt] = kb::eadd(Y[lh][pt], ysum);
+          off[lh] += m.width;
         }
         per_h[lh].push_back(rm);
       }
@@ -518,9 +527,11 @@ struct ShardOpening {
       E4 z1 = kb::escale(zeta, kb::two_adic_generator(lh - bl));
       double rbytes = 16.0 * N;
       for (auto& rm : per_h[lh]) rbytes += 4.0 * N * rm.width;
+      std::pair<const uint32_t*, const uint32_t*> pw{nullptr, nullptr};
+      if (lh >= 12) pw = ctx->pow_tables(lh);
       KLAUNCH(ctx, "reduce_openings", rbytes, open::reduce_openings, dim3(div_up(N, open::THREADS)), dim3(open::THREADS), 0,
-              (const open::ReduceMat*)d_rm, (int)per_h[lh].size(), lh, (const E4*)d_fap, zeta, z1, kb::two_adic_generator(lh), ro[lh],
-              0);
+              (const open::ReduceMat*)d_rm, (int)per_h[lh].size(), lh, (const E4*)d_fap, Y[lh][0], Y[lh][1], zeta, z1, kb::two_adic_generator(lh),
+              pw.first, pw.second, ro[lh]);
     }
   }
   ctx->mark("open: reduced openings");

@@ -215,6 +215,49 @@ KB_HD E4 emul(const E4& a, const E4& b) {
 KB_HD E4 esqr(const E4& a) { return emul(a, a); }
 // Inverse through the tower F < F[Y]/(Y^2-3) < EF with Y = X^2:
 // a = A + X B, A = a0 + a2 Y, B = a1 + a3 Y;  1/a = (A - X B) / (A^2 - Y B^2).
+// The extension inverse in two halves around its one base-field inversion (54 of its 74 multiplications), so that a kernel with several
+// inverses per thread can take all the base inversions in one (Montgomery's trick: inv_batch below): einv_norm gives the element's norm
+// down to the base field and the two intermediate words, einv_finish takes the norm's inverse.
+KB_HD uint32_t einv_norm(const E4& a, uint32_t& d0, uint32_t& d1) {
+  uint32_t a0 = a.c[0], a1 = a.c[1], a2 = a.c[2], a3 = a.c[3];
+  // A^2 = (a0^2 + 3 a2^2) + (2 a0 a2) Y ;  B^2 = (a1^2 + 3 a3^2) + (2 a1 a3) Y
+  // Y B^2 = 3 (2 a1 a3) + (a1^2 + 3 a3^2) Y
+  d0 = sub(add(sqr(a0), mul3(sqr(a2))), mul3(dbl(mul(a1, a3))));
+  d1 = sub(dbl(mul(a0, a2)), add(sqr(a1), mul3(sqr(a3))));
+  // 1/(d0 + d1 Y) = (d0 - d1 Y) / (d0^2 - 3 d1^2)
+  return sub(sqr(d0), mul3(sqr(d1)));
+}
+KB_HD E4 einv_finish(const E4& a, uint32_t d0, uint32_t d1, uint32_t nrm_inv) {
+  uint32_t a0 = a.c[0], a1 = a.c[1], a2 = a.c[2], a3 = a.c[3];
+  uint32_t e0 = mul(d0, nrm_inv), e1 = neg(mul(d1, nrm_inv));
+  E4 r;
+  r.c[0] = add(mul(a0, e0), mul3(mul(a2, e1)));
+  r.c[2] = add(mul(a0, e1), mul(a2, e0));
+  r.c[1] = neg(add(mul(a1, e0), mul3(mul(a3, e1))));
+  r.c[3] = neg(add(mul(a1, e1), mul(a3, e0)));
+  return r;
+}
+// x[i] <- 1 / x[i] for N base-field words with ONE inversion (prefix products, invert, peel back: 3 (N - 1) multiplications); a zero
+// stays zero, as inv(0) = 0 does
+template <int N>
+KB_HD void inv_batch(uint32_t (&x)[N]) {
+  uint32_t nz[N], pre[N];
+#pragma unroll
+  for (int i = 0; i < N; i++) { nz[i] = x[i] != 0; x[i] = nz[i] ? x[i] : ONE; }
+  pre[0] = x[0];
+#pragma unroll
+  for (int i = 1; i < N; i++) pre[i] = mul(pre[i - 1], x[i]);
+  uint32_t iv = inv(pre[N - 1]);
+#pragma unroll
+  for (int i = N - 1; i > 0; i--) {
+    const uint32_t xi = x[i];
+    x[i] = mul(iv, pre[i - 1]);
+    iv = mul(iv, xi);
+  }
+  x[0] = iv;
+#pragma unroll
+  for (int i = 0; i < N; i++) x[i] = nz[i] ? x[i] : 0u;
+}
 KB_HD E4 einv(const E4& a) {
   uint32_t a0 = a.c[0], a1 = a.c[1], a2 = a.c[2], a3 = a.c[3];
   // A^2 = (a0^2 + 3 a2^2) + (2 a0 a2) Y ;  B^2 = (a1^2 + 3 a3^2) + (2 a1 a3) Y

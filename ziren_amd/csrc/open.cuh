@@ -197,33 +197,45 @@ __global__ __launch_bounds__(64) void reduce_partials_batch(const SumJob* __rest
   reduce_partials_body(j.partials, j.split, j.count, out + j.out0, (int)i);
 }
 
-// Reduced openings for one LDE height N (fri.rs:103-204). One thread per stored row r
-// (bit-reversed: x_r = 3 * w_N^bitrev(r)). For matrix m with alpha-power offset folded in:
-//   ro[r] += sum_pt (Yc[m][pt] - A[m][pt] * S_m[r]) / (z_pt - x_r),   S_m[r] = sum_col alpha^col L_m[r][col]
-// where A = alpha^offset, Yc = alpha^offset * sum_col alpha^col y_col (host-computed).
+// Reduced openings for one LDE height N (fri.rs:103-204). One thread per stored row r (bit-reversed: x_r = 3 * w_N^bitrev(r)).
+//   ro[r] = sum_m sum_pt (Yc[m][pt] - alpha^off(m,pt) * S_m[r]) / (z_pt - x_r),   S_m[r] = sum_col alpha^col L_m[r][col],
+// off(m, 0) = the height's running column count before matrix m, off(m, 1) = off(m, 0) + width (fri.rs counts per (point, column)).
+// Rearranged so that a row's fixed cost does not grow with the number of matrices (round 3: the kernel was 4 269 instructions per
+// row of which ~1 200 were the columns themselves): the alpha powers come from ONE table indexed from off(m, 0), so
+// S'_m = alpha^off(m,0) S_m falls out of the dot products directly (no product by A); the point-0 terms are summed as T0 = sum S'_m,
+// the point-1 terms as T1 = sum alpha^width S'_m (one extension product per two-point matrix), and
+//   ro[r] = (Y0 - T0) / (z0 - x) + (Y1 - T1) / (z1 - x)     with Y_pt = sum_m Yc[m][pt] (host).
+// x_r comes from the two-level power table of w_N (two loads and a product instead of a 23-step square-and-multiply).
 struct ReduceMat {
   const uint32_t* lde;  // column-major, height N
   int width;
   int n_points;         // 1: zeta only, 2: zeta and zeta*g
-  kb::E4 A[2];
-  kb::E4 Yc[2];
+  uint32_t apow_off;    // off(m, 0)
+  uint32_t pad;
+  kb::E4 A1;            // alpha^width
 };
+
 __global__ __launch_bounds__(THREADS) void reduce_openings(const ReduceMat* __restrict__ mats, int n_mats, int log_N,
-                                                           const kb::E4* __restrict__ alpha_pows, kb::E4 z0, kb::E4 z1,
-                                                           uint32_t w_N, kb::E4* __restrict__ ro, int accumulate) {
+                                                           const kb::E4* __restrict__ alpha_pows, kb::E4 Y0, kb::E4 Y1, kb::E4 z0, kb::E4 z1,
+                                                           uint32_t w_N, const uint32_t* __restrict__ pw_lo, const uint32_t* __restrict__ pw_hi,
+                                                           kb::E4* __restrict__ ro) {
   size_t N = (size_t)1 << log_N;
   size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= N) return;
-  uint32_t x = kb::mul(kb::GEN, kb::pow(w_N, (uint64_t)kb::bitrev((uint32_t)r, log_N)));
+  const uint32_t ex = kb::bitrev((uint32_t)r, log_N);
+  const uint32_t wp = pw_lo ? kb::mul(pw_lo[ex & 1023], pw_hi[ex >> 10]) : kb::pow(w_N, (uint64_t)ex);
+  uint32_t x = kb::mul(kb::GEN, wp);
   // 1 / (z0 - x) and 1 / (z1 - x) from one inverse
   const kb::E4 e0 = kb::esub_base(z0, x), e1 = kb::esub_base(z1, x);
   const kb::E4 e01 = kb::einv(kb::emul(e0, e1));
   kb::E4 d0 = kb::emul(e01, e1);
   kb::E4 d1 = kb::emul(e01, e0);
-  kb::E4 acc = accumulate ? ro[r] : kb::ezero();
+  kb::E4 T0 = kb::ezero(), T1 = kb::ezero();
+  bool two = false;
   for (int m = 0; m < n_mats; m++) {
     const ReduceMat& M = mats[m];
-    // S = sum_c alpha^c * L[r][c]: four base-field dot products over the matrix's columns, accumulated in 96 bits
+    const kb::E4* __restrict__ ap = alpha_pows + M.apow_off;
+    // S' = sum_c alpha^(off + c) * L[r][c]: four base-field dot products over the matrix's columns, accumulated in 96 bits
     kb::Acc96 s0 = kb::acc96_zero(), s1 = kb::acc96_zero(), s2 = kb::acc96_zero(), s3 = kb::acc96_zero();
     const uint32_t* col = M.lde + r;
     int c = 0;
@@ -233,7 +245,7 @@ __global__ __launch_bounds__(THREADS) void reduce_openings(const ReduceMat* __re
       for (int k = 0; k < 8; k++) v[k] = col[(size_t)(c + k) * N];
 #pragma unroll
       for (int k = 0; k < 8; k++) {
-        const kb::E4 a = alpha_pows[c + k];
+        const kb::E4 a = ap[c + k];
         kb::acc96_fma_uniform(s0, a.c[0], v[k]);
         kb::acc96_fma_uniform(s1, a.c[1], v[k]);
         kb::acc96_fma_uniform(s2, a.c[2], v[k]);
@@ -241,7 +253,7 @@ __global__ __launch_bounds__(THREADS) void reduce_openings(const ReduceMat* __re
       }
     }
     for (; c < M.width; c++) {
-      const kb::E4 a = alpha_pows[c];
+      const kb::E4 a = ap[c];
       const uint32_t v = col[(size_t)c * N];
       kb::acc96_fma_uniform(s0, a.c[0], v);
       kb::acc96_fma_uniform(s1, a.c[1], v);
@@ -249,11 +261,14 @@ __global__ __launch_bounds__(THREADS) void reduce_openings(const ReduceMat* __re
       kb::acc96_fma_uniform(s3, a.c[3], v);
     }
     const kb::E4 S{{kb::acc96_reduce(s0), kb::acc96_reduce(s1), kb::acc96_reduce(s2), kb::acc96_reduce(s3)}};
-    acc = kb::eadd(acc, kb::emul(kb::esub(M.Yc[0], kb::emul(M.A[0], S)), d0));
-    if (M.n_points > 1) acc = kb::eadd(acc, kb::emul(kb::esub(M.Yc[1], kb::emul(M.A[1], S)), d1));
+    T0 = kb::eadd(T0, S);
+    if (M.n_points > 1) { T1 = kb::eadd(T1, kb::emul(M.A1, S)); two = true; }
   }
+  kb::E4 acc = kb::emul(kb::esub(Y0, T0), d0);
+  if (two) acc = kb::eadd(acc, kb::emul(kb::esub(Y1, T1), d1));
   ro[r] = acc;
 }
+
 
 // FRI fold (fri.rs:257-358): g[j] = e0 + (beta - x)(e1 - e0)/(-2x) [+ beta^2 * ro_next[j]],
 // (e0, e1) = (f[2j], f[2j+1]), x = w_len^bitrev(2j).

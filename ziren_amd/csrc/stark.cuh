@@ -50,34 +50,52 @@ __global__ __launch_bounds__(THREADS) void perm_rows(const uint32_t* __restrict_
   int pos = 2;
   kb::E4 rowsum = kb::ezero();
   int k = 0;
-  for (int b = 0; b < perm_ext_w - 1; b++) {
-    // sum over the batch of mult_q / denom_q as one fraction num / den: one extension inverse per permutation column
-    // instead of one per lookup (each further term costs two extension products instead of an inverse)
-    kb::E4 num = kb::ezero(), den = kb::eone();
-    bool first = true;
-    for (int q = 0; q < batch && k < n_lookups; q++, k++) {
-      uint32_t kind = blob[pos++];
-      int nv = blob[pos++];
-      kb::E4 denom = kb::eadd_base(alpha, kb::to_monty(kind));  // beta^0 * argument_index
-      for (int v = 0; v < nv; v++) {
-        uint32_t lin = apply_pair_col(blob, pos, main, n, prep, n, r);
-        denom = kb::eadd(denom, kb::escale(beta_pows[v + 1], lin));
+  // Columns go in groups of PERM_GROUP: each column's batch of lookups is summed as one fraction num / den (two extension products per
+  // further term instead of an inverse), and the group's denominators are inverted with ONE base-field inversion between them
+  // (einv_norm / inv_batch / einv_finish: the base inversion is 54 of an extension inverse's 74 multiplications; round 3 — a Cpu row
+  // has ten of them).
+  constexpr int PERM_GROUP = 2;   // 4 halves the inversions again but takes 98 registers (3 waves per SIMD: the kernel turns latency-bound and gets slower); 2 takes 50
+  for (int b0 = 0; b0 < perm_ext_w - 1; b0 += PERM_GROUP) {
+    kb::E4 num[PERM_GROUP], den[PERM_GROUP];
+    uint32_t d0[PERM_GROUP], d1[PERM_GROUP], nrm[PERM_GROUP];
+#pragma unroll
+    for (int g = 0; g < PERM_GROUP; g++) {
+      num[g] = kb::ezero();
+      den[g] = kb::eone();
+      if (b0 + g < perm_ext_w - 1) {
+        bool first = true;
+        for (int q = 0; q < batch && k < n_lookups; q++, k++) {
+          uint32_t kind = blob[pos++];
+          int nv = blob[pos++];
+          kb::E4 denom = kb::eadd_base(alpha, kb::to_monty(kind));  // beta^0 * argument_index
+          for (int v = 0; v < nv; v++) {
+            uint32_t lin = apply_pair_col(blob, pos, main, n, prep, n, r);
+            denom = kb::eadd(denom, kb::escale(beta_pows[v + 1], lin));
+          }
+          uint32_t mult = apply_pair_col(blob, pos, main, n, prep, n, r);
+          if (k >= n_sends) mult = kb::neg(mult);
+          if (first) {
+            num[g] = kb::efrom(mult);
+            den[g] = denom;
+            first = false;
+          } else {
+            num[g] = kb::eadd(kb::emul(num[g], denom), kb::escale(den[g], mult));
+            den[g] = kb::emul(den[g], denom);
+          }
+        }
       }
-      uint32_t mult = apply_pair_col(blob, pos, main, n, prep, n, r);
-      if (k >= n_sends) mult = kb::neg(mult);
-      if (first) {
-        num = kb::efrom(mult);
-        den = denom;
-        first = false;
-      } else {
-        num = kb::eadd(kb::emul(num, denom), kb::escale(den, mult));
-        den = kb::emul(den, denom);
+      nrm[g] = kb::einv_norm(den[g], d0[g], d1[g]);
+    }
+    kb::inv_batch<PERM_GROUP>(nrm);
+#pragma unroll
+    for (int g = 0; g < PERM_GROUP; g++) {
+      if (b0 + g < perm_ext_w - 1) {
+        const kb::E4 val = kb::emul(num[g], kb::einv_finish(den[g], d0[g], d1[g], nrm[g]));
+#pragma unroll
+        for (int e = 0; e < 4; e++) perm[(size_t)(4 * (b0 + g) + e) * n + r] = val.c[e];
+        rowsum = kb::eadd(rowsum, val);
       }
     }
-    const kb::E4 val = first ? kb::ezero() : kb::emul(num, kb::einv(den));
-#pragma unroll
-    for (int e = 0; e < 4; e++) perm[(size_t)(4 * b + e) * n + r] = val.c[e];
-    rowsum = kb::eadd(rowsum, val);
   }
 #pragma unroll
   for (int e = 0; e < 4; e++) perm[(size_t)(4 * (perm_ext_w - 1) + e) * n + r] = rowsum.c[e];
@@ -162,6 +180,25 @@ __global__ __launch_bounds__(THREADS) void scan_add_offsets(const ScanJob* __res
 }
 
 // ---- quotient -------------------------------------------------------------------------------
+
+// The table quotient_point reads: for stored row p (i = bitrev(p)), x = 3 w_Q^i:
+//   is_first = Z_H(x) / (x - 1), is_last = Z_H(x) / (x - g^-1), is_transition = x - g^-1,  Z_H(x) = zh[i mod 2^lqd] (zerofier_coset.rs:22-51)
+__global__ void fill_selectors(uint32_t* __restrict__ out, int lq, int lqd, uint32_t w_q, uint32_t g_inv, const uint32_t* __restrict__ consts) {
+  const size_t Q = (size_t)1 << lq;
+  const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= Q) return;
+  const uint32_t i = kb::bitrev((uint32_t)p, lq);
+  const uint32_t x = kb::mul(kb::GEN, kb::pow(w_q, (uint64_t)i));
+  const uint32_t zh = consts[16 + (i & ((1u << lqd) - 1))];
+  // both inverses from one
+  const uint32_t xm1 = kb::sub(x, kb::ONE);
+  const uint32_t is_trans = kb::sub(x, g_inv);
+  const uint32_t both = kb::mul(zh, kb::inv(kb::mul(xm1, is_trans)));
+  out[p] = kb::mul(both, is_trans);
+  out[Q + p] = kb::mul(both, xm1);
+  out[2 * Q + p] = is_trans;
+}
+
 
 // Register files in LDS, one slot per thread: extension registers as 16-byte words at
 // regs_e[r * blockDim + t] (ds_read/write_b128, conflict-free), base registers at regs_b[r * blockDim + t].
