@@ -699,6 +699,23 @@ __device__ __forceinline__ void lookup(const LookupSink& k, uint32_t op, uint32_
   }
   atomicAdd(k.counts + idx, 1u);  // table crowded (many distinct counters, i.e. no hot spot): count directly
 }
+// The Program chip's fetch counters go through the same table under keys with bit 31 set (a loop's handful of program counters are as
+// hot as any byte counter: 2^21 cycles of a six-instruction loop were six addresses taking 350 000 global atomics each — 6 ms of an
+// otherwise 1.5 ms kernel).
+constexpr uint32_t HASH_PROGRAM_KEY = 0x80000000u;
+__device__ __forceinline__ void count_fetch(const LookupSink& k, uint32_t instr_index, uint32_t* program_counts) {
+  const uint32_t key = HASH_PROGRAM_KEY | instr_index;
+  uint32_t slot = (instr_index * 2654435761u >> 12) & k.mask;
+  for (int probe = 0; probe < 8; probe++) {
+    const uint32_t prev = atomicCAS(k.keys + slot, HASH_EMPTY, key);
+    if (prev == HASH_EMPTY || prev == key) {
+      atomicAdd(k.vals + slot, 1u);
+      return;
+    }
+    slot = (slot + 1) & k.mask;
+  }
+  atomicAdd(program_counts + instr_index, 1u);
+}
 constexpr int HASH_SLOTS = 8192;   // 64 KiB of LDS: two blocks per CU
 constexpr int TILES_PER_BLOCK = 8; // a block walks 8 x THREADS rows with one table: hot counters cost one global atomic per 2048 rows
 // ByteRecord::add_u8_range_checks (crates/core/executor/src/events/byte.rs:72-82): bytes in pairs
@@ -948,7 +965,10 @@ __global__ __launch_bounds__(THREADS) void cpu_rows(const uint32_t* __restrict__
       const size_t idx = (size_t)(pc - pc_base) >> 2;   // Program::fetch
       const bool in_program = pc >= pc_base && idx < n_instr;
       if (!in_program) *bad_pc = 1;
-      else if (program_counts) atomicAdd(program_counts + idx, 1u);   // ProgramChip::generate_trace in the same pass
+      else if (program_counts) {   // ProgramChip::generate_trace in the same pass
+        if (count && idx < 0x7fffffffu) count_fetch(LookupSink{hkeys, hvals, HASH_SLOTS - 1, counts}, (uint32_t)idx, program_counts);
+        else atomicAdd(program_counts + idx, 1u);
+      }
       const uint32_t* in = program + (in_program ? idx : 0) * INSTRUCTION_WORDS;
       const uint32_t o = in[0] & 0xff;
       r[SHARD] = shard;
@@ -1012,8 +1032,12 @@ __global__ __launch_bounds__(THREADS) void cpu_rows(const uint32_t* __restrict__
   }
   if (count) {
     __syncthreads();
-    for (int i = threadIdx.x; i < HASH_SLOTS; i += blockDim.x)
-      if (hkeys[i] != HASH_EMPTY) atomicAdd(counts + hkeys[i], hvals[i]);
+    for (int i = threadIdx.x; i < HASH_SLOTS; i += blockDim.x) {
+      const uint32_t key = hkeys[i];
+      if (key == HASH_EMPTY) continue;
+      if (key & HASH_PROGRAM_KEY) atomicAdd(program_counts + (key & ~HASH_PROGRAM_KEY), hvals[i]);
+      else atomicAdd(counts + key, hvals[i]);
+    }
   }
 }
 

@@ -239,6 +239,20 @@ class DeviceShard:
         self.chips += [chips.record_byte_chip(prep_index=0), chips.record_program_chip(self.plh, prep_index=1)]
         self.public_values = M.public_values(sh.pv)
 
+    def pin(self, ctx):
+        """Move the shard's event vectors into page-locked host memory (zkm_host_alloc): where a host that feeds a GPU keeps them, the
+        upload inside every zkm_tracegen_* call is then plain DMA at PCIe rate. Returns the bytes pinned."""
+        total = 0
+        pinned = []
+        for name, ev, lh, record in self.work:
+            words = max(len(ev), 1) * (ev.dtype.itemsize // 4)
+            buf = ctx.host_alloc((words,))
+            buf[:len(ev) * (ev.dtype.itemsize // 4)] = ev.view(np.uint32).reshape(-1)
+            pinned.append((name, buf[:len(ev) * (ev.dtype.itemsize // 4)].view(ev.dtype), lh, record))
+            total += ev.nbytes
+        self.work = pinned
+        return total
+
     def preprocessed(self, ctx):
         return [ctx.tracegen_byte_table(), ctx.tracegen_program(self.machine.program, self.machine.pc_base, self.plh)]
 
