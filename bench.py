@@ -541,14 +541,14 @@ def main():
         cpu = None
         if not args.no_cpu_baseline and world == 1:  # rank 0, N = 1 only
             ks = k if args.cpu_full else min(args.cpu_sample_log_rows, k)
-            wall, lde, threads, shown, why = cpu_baseline(ks, fri)
+            wall, lde_s, threads, shown, why = cpu_baseline(ks, fri)
             # everything but the LDEs is linear in the rows; the LDEs (n log n) grow by (k + 1) / (ks + 1) on top (rows of the extended domain)
             lin = 1 << (k - ks)
-            est = (wall - lde) * lin + lde * lin * (k + 1) / (ks + 1)
+            est = (wall - lde_s) * lin + lde_s * lin * (k + 1) / (ks + 1)
             cpu = {"value": round(1.0 / est, 6), "unit": "shard-proofs/s", "cores": threads, "cores_available": threads, "host_logical_cpus": shown,
                    "cores_note": why, "kind": "port",
                    "sample": (f"oracle (CPU restatement, canonical `% p` arithmetic, OpenMP, {threads} threads) proving one SYN-{ks} shard in {wall:.2f} s "
-                              f"({lde:.2f} s of it coset LDEs)" + ("" if ks == k else f"; scaled to SYN-{k}: x{lin} for the linear phases, x{lin}*{k + 1}/{ks + 1} for the LDEs")),
+                              f"({lde_s:.2f} s of it coset LDEs)" + ("" if ks == k else f"; scaled to SYN-{k}: x{lin} for the linear phases, x{lin}*{k + 1}/{ks + 1} for the LDEs")),
                    "measured_at_full_size": ks == k, "sample_seconds": round(wall, 3), "estimated_seconds_full_size": round(est, 2),
                    "full_size_measurement": "profiles/r03_cpu_baseline_full.json (bench.py --cpu-full, the same proof at SYN-22 timed directly)"}
         two = None
