@@ -188,6 +188,26 @@ def test_pcs_commit_shifted_domains(hip_ctx, oracle):
     assert np.array_equal(d.root, root_o)
 
 
+@pytest.mark.parametrize("bl", [1, 2])
+def test_batched_lde_many_matrices_mixed_heights_and_shifts(hip_ctx, oracle, bl):
+    """One commitment of 70 matrices (more than one lde::Batch descriptor holds: the host cuts it in two), heights 2^0 .. 2^15 so that the
+    single-block path (n <= 8192), the four-step path and the height grouping are all in one launch set, widths 1 .. 9, three different
+    domain shifts (a scaled-twiddle table per shift): every LDE equals the oracle's coset LDE of that matrix alone, the root the oracle's."""
+    rng = np.random.default_rng(1234 + bl)
+    heights = [15, 14, 14, 13, 12, 15, 9, 3, 0, 1, 2, 14, 7, 13, 15] * 5
+    heights = heights[:70]
+    shifts_c = [3, 3 * F.two_adic_generator(16) % P, 3 * F.two_adic_generator(15) % P]
+    mats = [rand(rng, (1 << k, 1 + (i * 5) % 9)) for i, k in enumerate(heights)]
+    sc = [shifts_c[i % 3] if heights[i] >= 3 else 3 for i in range(len(mats))]
+    sh = [F.to_monty(c) for c in sc]
+    d = prover.pcs_commit(hip_ctx, [hip_ctx.upload(m) for m in mats], bl, domain_shifts=sh)
+    for i, m in enumerate(mats):
+        lde_shift = F.to_monty(3 * F.inv(sc[i]) % P)    # Pcs::commit passes GENERATOR / domain_shift
+        assert np.array_equal(d.lde(i), oracle.coset_lde_batch(m, bl, lde_shift)), (i, heights[i], m.shape)
+    root_o, _, _ = oracle.pcs_commit(mats, bl, domain_shifts=sh)
+    assert np.array_equal(d.root, root_o)
+
+
 def test_edge_shapes_bit_exact(hip_ctx, oracle):
     # local_only chips, a lookup-free chip (empty permutation trace), global scope, preprocessed local_only
     sh = synth.edge_shard(7)
