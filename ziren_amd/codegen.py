@@ -28,7 +28,7 @@ KERNEL_NAME = "zkm_quotient_specialized"
 BLOCK = 256
 
 
-TEMPLATE_VERSION = b"5"  # bump when emit_source changes
+TEMPLATE_VERSION = b"6"  # bump when emit_source changes
 
 
 def _template_key() -> bytes:
@@ -131,11 +131,11 @@ def _ssa_lines(program: np.ndarray):
             lines.append(f"const kb::E4 {v} = kb::{fn}({x}, {y});")
             meta.append((v, (x, y)))
         elif op == air.ASSERT_B:
-            lines.append(f"acc = kb::eadd(acc, kb::escale(a.alpha_pows[{cidx}], {cur_b[ra]}));")
+            lines.append(f"kb::fold_base(acc, a.alpha_pows[{cidx}], {cur_b[ra]});")
             meta.append((None, (cur_b[ra],)))
             cidx += 1
         elif op == air.ASSERT_E:
-            lines.append(f"acc = kb::eadd(acc, kb::emul(a.alpha_pows[{cidx}], {cur_e[ra]}));")
+            lines.append(f"kb::fold_ext(acc, a.alpha_pows[{cidx}], {cur_e[ra]});")
             meta.append((None, (cur_e[ra],)))
             cidx += 1
         else:
@@ -153,9 +153,9 @@ def _kernel_source(lines, n_instr, n_constraints, accumulate=False, part="") -> 
 extern "C" __global__ __launch_bounds__({BLOCK}) void {KERNEL_NAME}(stark::QuotientArgs a) {{
   stark::QuotientPoint q;
   if (!stark::quotient_point(a, stark::quotient_row(a), q)) return;
-  kb::E4 acc = kb::ezero();
+  kb::FoldAcc acc = kb::fold_zero();
   {body}
-  stark::{'quotient_accumulate' if accumulate else 'quotient_store'}(a, q, acc);
+  stark::{'quotient_accumulate' if accumulate else 'quotient_store'}(a, q, kb::fold_finish(acc));
 }}
 """
 

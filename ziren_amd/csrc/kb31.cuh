@@ -277,6 +277,30 @@ KB_HD E4 einv(const E4& a) {
   r.c[3] = neg(add(mul(a1, e1), mul(a3, e0)));
   return r;
 }
+#if defined(__HIP_DEVICE_COMPILE__)
+// The folded constraint sum of a quotient kernel, acc = sum_k alpha^(C-1-k) * constraint_k (folder.rs:79-102), kept as four 96-bit
+// integer accumulators (one per extension coefficient) of unreduced 64-bit products and reduced once at the end: a base-field
+// constraint costs four v_mad_u64_u32 + carry instead of four Montgomery products and four modular additions (8 instructions
+// instead of 44), an extension-field one sixteen. alpha's powers are wave-uniform (SGPR operands). Room: a product is below 2^62,
+// a chip has at most a few thousand constraints.
+struct FoldAcc { Acc96 c[4]; };
+__device__ __forceinline__ FoldAcc fold_zero() { return FoldAcc{{acc96_zero(), acc96_zero(), acc96_zero(), acc96_zero()}}; }
+__device__ __forceinline__ void fold_base(FoldAcc& f, const E4& alpha_pow_uniform, uint32_t v) {
+#pragma unroll
+  for (int i = 0; i < 4; i++) acc96_fma_uniform(f.c[i], alpha_pow_uniform.c[i], v);
+}
+__device__ __forceinline__ void fold_ext(FoldAcc& f, const E4& a /* uniform */, const E4& e) {
+  // (a0 + a1 X + a2 X^2 + a3 X^3)(e0 + ...) with X^4 = 3
+  const uint32_t t1 = mul3(a.c[1]), t2 = mul3(a.c[2]), t3 = mul3(a.c[3]);
+  acc96_fma_uniform(f.c[0], a.c[0], e.c[0]); acc96_fma_uniform(f.c[0], t1, e.c[3]); acc96_fma_uniform(f.c[0], t2, e.c[2]); acc96_fma_uniform(f.c[0], t3, e.c[1]);
+  acc96_fma_uniform(f.c[1], a.c[0], e.c[1]); acc96_fma_uniform(f.c[1], a.c[1], e.c[0]); acc96_fma_uniform(f.c[1], t2, e.c[3]); acc96_fma_uniform(f.c[1], t3, e.c[2]);
+  acc96_fma_uniform(f.c[2], a.c[0], e.c[2]); acc96_fma_uniform(f.c[2], a.c[1], e.c[1]); acc96_fma_uniform(f.c[2], a.c[2], e.c[0]); acc96_fma_uniform(f.c[2], t3, e.c[3]);
+  acc96_fma_uniform(f.c[3], a.c[0], e.c[3]); acc96_fma_uniform(f.c[3], a.c[1], e.c[2]); acc96_fma_uniform(f.c[3], a.c[2], e.c[1]); acc96_fma_uniform(f.c[3], a.c[3], e.c[0]);
+}
+__device__ __forceinline__ E4 fold_finish(const FoldAcc& f) {
+  return E4{{acc96_reduce(f.c[0]), acc96_reduce(f.c[1]), acc96_reduce(f.c[2]), acc96_reduce(f.c[3])}};
+}
+#endif
 KB_HD E4 epow(E4 a, uint64_t e) {
   E4 r = eone();
   while (e) {
