@@ -28,7 +28,7 @@ KERNEL_NAME = "zkm_quotient_specialized"
 BLOCK = 256
 
 
-TEMPLATE_VERSION = b"6"  # bump when emit_source changes
+TEMPLATE_VERSION = b"7"  # bump when emit_source changes
 
 
 def _template_key() -> bytes:
@@ -53,10 +53,32 @@ def _ssa_lines(program: np.ndarray):
     cur_b, cur_e = {}, {}   # register -> current variable name
     lines, meta = [], []
     nv = [0]
+    # Linear forms (round 3). A LogUp denominator is alpha + kind + sum_k beta^k * value_k: in the bytecode a chain of
+    # ADD_E(previous, MUL_EB(beta^k, value_k)) whose extension operands beta^k are the same for every row ("uniform": they depend on
+    # the challenges, constants and public values only — the compiler keeps them in SGPRs). Such a chain is not emitted step by step
+    # (a Montgomery product per coefficient and term plus a modular addition: 38 instructions per term) but kept as a list of
+    # (uniform extension value, base value) terms and, when something first needs the sum, emitted as 96-bit dot products
+    # (kb::fold_base: 8 instructions per term, one reduction per coefficient at the end).
+    uniform = set()          # SSA values that are the same for every row
+    deferred = {}            # SSA extension value -> {"terms": [(uniform ext, base)], "consts": [uniform ext], "extras": [ext]} not emitted yet
 
     def fresh(prefix):
         nv[0] += 1
         return f"{prefix}{nv[0]}"
+
+    def use(name):
+        """The name of a value about to be read: a deferred linear form is emitted first (one line, one meta entry)."""
+        form = deferred.pop(name, None)
+        if form is None:
+            return name
+        acc = f"l_{name}"
+        stmts = [f"kb::FoldAcc {acc} = kb::fold_zero();"] + [f"kb::fold_base({acc}, {u}, {b});" for u, b in form["terms"]]
+        expr = f"kb::fold_finish({acc})"
+        for c in form["consts"] + form["extras"]:
+            expr = f"kb::eadd({expr}, {c})"
+        lines.append(" ".join(stmts) + f" const kb::E4 {name} = {expr};")
+        meta.append((name, tuple(x for t in form["terms"] for x in t) + tuple(form["consts"]) + tuple(form["extras"])))
+        return name
 
     cidx = 0
     for k in range(n_instr):
@@ -81,22 +103,27 @@ def _ssa_lines(program: np.ndarray):
             v = fresh("b"); cur_b[dst] = v
             lines.append(f"const uint32_t {v} = {imm}u;")
             meta.append((v, ()))
+            uniform.add(v)
         elif op == air.LD_PV:
             v = fresh("b"); cur_b[dst] = v
             lines.append(f"const uint32_t {v} = a.public_values[{imm}];")
             meta.append((v, ()))
+            uniform.add(v)
         elif op == air.LD_CHALLENGE:
             v = fresh("e"); cur_e[dst] = v
             lines.append(f"const kb::E4 {v} = {'a.perm_beta' if imm else 'a.perm_alpha'};")
             meta.append((v, ()))
+            uniform.add(v)
         elif op == air.LD_LOCAL_SUM:
             v = fresh("e"); cur_e[dst] = v
             lines.append(f"const kb::E4 {v} = a.local_sum;")
             meta.append((v, ()))
+            uniform.add(v)
         elif op == air.LD_GLOBAL_SUM:
             v = fresh("b"); cur_b[dst] = v
             lines.append(f"const uint32_t {v} = a.consts[{imm}];")
             meta.append((v, ()))
+            uniform.add(v)
         elif op in (air.LD_IS_FIRST, air.LD_IS_LAST, air.LD_IS_TRANS):
             v = fresh("b"); cur_b[dst] = v
             sel = {air.LD_IS_FIRST: "q.is_first", air.LD_IS_LAST: "q.is_last", air.LD_IS_TRANS: "q.is_trans"}[op]
@@ -108,35 +135,67 @@ def _ssa_lines(program: np.ndarray):
             v = fresh("b"); cur_b[dst] = v
             lines.append(f"const uint32_t {v} = kb::{fn}({x}, {y});")
             meta.append((v, (x, y)))
+            if x in uniform and y in uniform:
+                uniform.add(v)
         elif op == air.NEG_B:
             x = cur_b[ra]
             v = fresh("b"); cur_b[dst] = v
             lines.append(f"const uint32_t {v} = kb::neg({x});")
             meta.append((v, (x,)))
+            if x in uniform:
+                uniform.add(v)
         elif op in (air.ADD_E, air.SUB_E, air.MUL_E):
             fn = {air.ADD_E: "eadd", air.SUB_E: "esub", air.MUL_E: "emul"}[op]
             x, y = cur_e[ra], cur_e[rb]
+            if op == air.ADD_E and (x in deferred or y in deferred) and x != y:
+                # a sum with a linear form stays a linear form: the other side joins as more terms, as a uniform constant or as an extra addend
+                form = {"terms": [], "consts": [], "extras": []}
+                for z in (x, y):
+                    if z in deferred:
+                        f2 = deferred.pop(z)
+                        for key in form:
+                            form[key] += f2[key]
+                    elif z in uniform:
+                        form["consts"].append(z)
+                    else:
+                        form["extras"].append(z)
+                v = fresh("e"); cur_e[dst] = v
+                deferred[v] = form
+                continue
+            x, y = use(x), use(y)
             v = fresh("e"); cur_e[dst] = v
             lines.append(f"const kb::E4 {v} = kb::{fn}({x}, {y});")
             meta.append((v, (x, y)))
+            if x in uniform and y in uniform:
+                uniform.add(v)
         elif op == air.NEG_E:
-            x = cur_e[ra]
+            x = use(cur_e[ra])
             v = fresh("e"); cur_e[dst] = v
             lines.append(f"const kb::E4 {v} = kb::eneg({x});")
             meta.append((v, (x,)))
+            if x in uniform:
+                uniform.add(v)
         elif op in (air.ADD_EB, air.SUB_EB, air.MUL_EB):
             fn = {air.ADD_EB: "eadd_base", air.SUB_EB: "esub_base", air.MUL_EB: "escale"}[op]
             x, y = cur_e[ra], cur_b[rb]
+            if op == air.MUL_EB and x in uniform and x not in deferred and y not in uniform:
+                v = fresh("e"); cur_e[dst] = v
+                deferred[v] = {"terms": [(x, y)], "consts": [], "extras": []}      # uniform extension value x row value: a term
+                continue
+            x = use(x)
             v = fresh("e"); cur_e[dst] = v
             lines.append(f"const kb::E4 {v} = kb::{fn}({x}, {y});")
             meta.append((v, (x, y)))
+            if x in uniform and y in uniform:
+                uniform.add(v)
         elif op == air.ASSERT_B:
             lines.append(f"kb::fold_base(acc, a.alpha_pows[{cidx}], {cur_b[ra]});")
             meta.append((None, (cur_b[ra],)))
             cidx += 1
         elif op == air.ASSERT_E:
-            lines.append(f"kb::fold_ext(acc, a.alpha_pows[{cidx}], {cur_e[ra]});")
-            meta.append((None, (cur_e[ra],)))
+            x = use(cur_e[ra])
+            lines.append(f"kb::fold_ext(acc, a.alpha_pows[{cidx}], {x});")
+            meta.append((None, (x,)))
             cidx += 1
         else:
             raise ValueError(f"bad opcode {op}")

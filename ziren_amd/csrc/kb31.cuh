@@ -199,17 +199,33 @@ KB_HD uint32_t mul3(uint32_t a) { return add(dbl(a), a); }
 KB_HD uint32_t dot2(uint32_t a0, uint32_t b0, uint32_t a1, uint32_t b1) {
   return monty_reduce((uint64_t)a0 * b0 + (uint64_t)a1 * b1);
 }
+// x < 4 p^2 (a sum of up to four products of reduced words: four v_mad_u64_u32 into one 64-bit accumulator) -> x / R mod p in [0, p).
+// (x - t p) / 2^32 lies in (-p, 2p): the borrow of the high words tells which side of zero, then one conditional subtraction.
+KB_HD uint32_t monty_reduce_wide(uint64_t x) {
+  uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
+  uint32_t t = lo + (lo << 24) + (lo << 31);  // lo * MU mod 2^32
+#if defined(__HIP_DEVICE_COMPILE__)
+  uint32_t uhi = __umulhi(t, P);
+#else
+  uint32_t uhi = (uint32_t)(((uint64_t)t * P) >> 32);
+#endif
+  uint32_t r = hi - uhi;
+  r += hi < uhi ? P : 0u;
+  return umin32(r, r - P);
+}
+// Every coefficient is four products summed in 64 bits and reduced once (round 3: 77 instructions instead of 103 with a reduction
+// every second product); the X^4 = 3 wrap-around is taken on a's side first (three modular triplings).
 KB_HD E4 emul(const E4& a, const E4& b) {
+  const uint32_t t1 = mul3(a.c[1]), t2 = mul3(a.c[2]), t3 = mul3(a.c[3]);
   E4 r;
   // c0 = a0 b0 + 3 (a1 b3 + a2 b2 + a3 b1)
-  uint32_t h0 = add(dot2(a.c[1], b.c[3], a.c[2], b.c[2]), mul(a.c[3], b.c[1]));
-  r.c[0] = add(mul(a.c[0], b.c[0]), mul3(h0));
+  r.c[0] = monty_reduce_wide((uint64_t)a.c[0] * b.c[0] + (uint64_t)t1 * b.c[3] + (uint64_t)t2 * b.c[2] + (uint64_t)t3 * b.c[1]);
   // c1 = a0 b1 + a1 b0 + 3 (a2 b3 + a3 b2)
-  r.c[1] = add(dot2(a.c[0], b.c[1], a.c[1], b.c[0]), mul3(dot2(a.c[2], b.c[3], a.c[3], b.c[2])));
+  r.c[1] = monty_reduce_wide((uint64_t)a.c[0] * b.c[1] + (uint64_t)a.c[1] * b.c[0] + (uint64_t)t2 * b.c[3] + (uint64_t)t3 * b.c[2]);
   // c2 = a0 b2 + a1 b1 + a2 b0 + 3 a3 b3
-  r.c[2] = add(add(dot2(a.c[0], b.c[2], a.c[1], b.c[1]), mul(a.c[2], b.c[0])), mul3(mul(a.c[3], b.c[3])));
+  r.c[2] = monty_reduce_wide((uint64_t)a.c[0] * b.c[2] + (uint64_t)a.c[1] * b.c[1] + (uint64_t)a.c[2] * b.c[0] + (uint64_t)t3 * b.c[3]);
   // c3 = a0 b3 + a1 b2 + a2 b1 + a3 b0
-  r.c[3] = add(dot2(a.c[0], b.c[3], a.c[1], b.c[2]), dot2(a.c[2], b.c[1], a.c[3], b.c[0]));
+  r.c[3] = monty_reduce_wide((uint64_t)a.c[0] * b.c[3] + (uint64_t)a.c[1] * b.c[2] + (uint64_t)a.c[2] * b.c[1] + (uint64_t)a.c[3] * b.c[0]);
   return r;
 }
 KB_HD E4 esqr(const E4& a) { return emul(a, a); }
