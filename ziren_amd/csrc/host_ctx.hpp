@@ -254,6 +254,22 @@ struct zkm_ctx {
     tab[log_size] = d;
     return d;
   }
+  // sub-problem twiddles (lde::fill_ct_twiddles) of the strided passes' A-point transforms
+  std::map<int, uint32_t*> ct_fwd, ct_inv;
+  const uint32_t* twiddles_ct(int log_size, bool inverse) {
+    auto& tab = inverse ? ct_inv : ct_fwd;
+    auto it = tab.find(log_size);
+    if (it != tab.end()) return it->second;
+    const size_t count = (size_t)1 << log_size;
+    uint32_t* d;
+    HIP_CHECK(hipMalloc(&d, count * 4));
+    uint32_t w = kb::two_adic_generator(log_size);
+    if (inverse) w = kb::inv(w);
+    hipLaunchKernelGGL(lde::fill_ct_twiddles, dim3(div_up(count, 256)), dim3(256), 0, stream, d, w, log_size);
+    LAUNCH_CHECK();
+    tab[log_size] = d;
+    return d;
+  }
   // w_n^e by two lookups (lde::Group::pw_lo / pw_hi), per log2 n >= 10
   std::map<int, std::pair<uint32_t*, uint32_t*>> pow_tabs;
   std::pair<const uint32_t*, const uint32_t*> pow_tables(int k) {

@@ -38,8 +38,8 @@ static void lde_batch_chunk(zkm_ctx* ctx, const std::vector<LdeJob>& jobs, int b
     g.twb_inv = lb > 0 ? ctx->twiddles(lb, true) : nullptr;
     g.twb_fwd = lb > 0 ? ctx->twiddles(lb, false) : nullptr;
     if (la) {
-      g.twa_inv = ctx->twiddles(la, true);
-      g.twa_fwd = ctx->twiddles(la, false);
+      g.twa_inv = ctx->twiddles_ct(la, true);
+      g.twa_fwd = ctx->twiddles_ct(la, false);
       auto pw = ctx->pow_tables(k);
       g.pw_lo = pw.first; g.pw_hi = pw.second;
       g.tw_rows = ctx->row_twiddles(k);

@@ -293,7 +293,7 @@ KB_HD E4 einv(const E4& a) {
   r.c[3] = neg(add(mul(a1, e1), mul(a3, e0)));
   return r;
 }
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIPCC__)
 // The folded constraint sum of a quotient kernel, acc = sum_k alpha^(C-1-k) * constraint_k (folder.rs:79-102), kept as four 96-bit
 // integer accumulators (one per extension coefficient) of unreduced 64-bit products and reduced once at the end: a base-field
 // constraint costs four v_mad_u64_u32 + carry instead of four Montgomery products and four modular additions (8 instructions

@@ -157,21 +157,40 @@ __device__ __forceinline__ void butterflies_ct(uint32_t (&x)[1 << R], uint32_t s
   }
 }
 // one pass of R such stages over an LDS buffer of 2^logn points (PAD as in ntt_pass); a thread's 2^R points are 2^logm2 apart
+// (2^lognb sequences interleaved, element i of sequence t at buf[phys(i) * istride + t], as in ntt_pass)
 template <int R, bool PAD>
-__device__ __forceinline__ void ntt_pass_ct(uint32_t* buf, uint32_t logn, uint32_t s0, const uint32_t* __restrict__ tw, uint32_t tid = threadIdx.x) {
+__device__ __forceinline__ void ntt_pass_ct(uint32_t* buf, uint32_t logn, uint32_t s0, const uint32_t* __restrict__ tw, uint32_t tid = threadIdx.x,
+                                            uint32_t lognb = 0, uint32_t istride = 1) {
   const uint32_t logm2 = logn - s0 - R;
-  const uint32_t total = (1u << logn) >> R;
+  const uint32_t total = ((1u << logn) >> R) << lognb;
   for (uint32_t u = tid; u < total; u += blockDim.x) {
-    const uint32_t lo = u & ((1u << logm2) - 1), hi = u >> logm2;
+    const uint32_t t = u & ((1u << lognb) - 1), g = u >> lognb;
+    const uint32_t lo = g & ((1u << logm2) - 1), hi = g >> logm2;
     const uint32_t base = (hi << (R + logm2)) + lo;
     uint32_t x[1 << R];
 #pragma unroll
-    for (uint32_t j = 0; j < (1u << R); j++) x[j] = buf[phys<PAD>(base + (j << logm2))];
+    for (uint32_t j = 0; j < (1u << R); j++) x[j] = buf[phys<PAD>(base + (j << logm2)) * istride + t];
     butterflies_ct<R, false>(x, s0, hi, tw);
 #pragma unroll
-    for (uint32_t j = 0; j < (1u << R); j++) buf[phys<PAD>(base + (j << logm2))] = x[j];
+    for (uint32_t j = 0; j < (1u << R); j++) buf[phys<PAD>(base + (j << logm2)) * istride + t] = x[j];
   }
   __syncthreads();
+}
+// a whole transform of 2^logn points that way: passes of four stages from stage 0 up, one shorter pass for the last 1-3 stages. In: reduced
+// or lazy words; out: lazy signed words (|v| < 2^31, congruent to the result), bit-reversed order.
+template <bool PAD>
+__device__ __forceinline__ void lds_ntt_ct(uint32_t* buf, int logn, int lognb, int istride, const uint32_t* __restrict__ tw) {
+  int s0 = 0;
+  for (; s0 + 4 <= logn; s0 += 4) ntt_pass_ct<4, PAD>(buf, logn, s0, tw, threadIdx.x, lognb, istride);
+  const int rem = logn - s0;
+  if (rem == 3) ntt_pass_ct<3, PAD>(buf, logn, s0, tw, threadIdx.x, lognb, istride);
+  if (rem == 2) ntt_pass_ct<2, PAD>(buf, logn, s0, tw, threadIdx.x, lognb, istride);
+  if (rem == 1) ntt_pass_ct<1, PAD>(buf, logn, s0, tw, threadIdx.x, lognb, istride);
+}
+// a lazy word back to [0, p): v in (-2^31, 2^31) -> v + 2p if negative (in (p - 2^24, 2p)), then one conditional subtraction
+__device__ __forceinline__ uint32_t canonical(uint32_t lazy) {
+  const uint32_t w = lazy + ((uint32_t)((int32_t)lazy >> 31) & (2u * kb::P));
+  return kb::umin32(w, w - kb::P);
 }
 
 // Two-level power table of g in LDS: lo[i] = g^i (i < 64), hi[i] = g^(64 i) (i < nhi).
@@ -213,7 +232,7 @@ struct Group {
   uint32_t n_cols, first_mat, n_mats, pad2;
   uint32_t blk_end[4];                     // cumulative number of blocks up to and including this group, per kernel
   const uint32_t *twb_fwd, *twb_inv;       // stage-major twiddles of the B-point transform (la == 0 uses both, la > 0 the inverse)
-  const uint32_t *twa_fwd, *twa_inv;       // of the A-point transform
+  const uint32_t *twa_fwd, *twa_inv;       // of the A-point transform, by sub-problem (fill_ct_twiddles)
   const uint32_t *pw_lo, *pw_hi;           // w_n^e = pw_lo[e & 1023] * pw_hi[e >> 10]
   const uint32_t* tw_rows;                 // la > 0: per row k1 the B - 1 sub-problem twiddles of the inverse row transform (fill_row_twiddles)
   uint32_t w_N, n_inv, pad3[2];
@@ -261,7 +280,7 @@ __global__ __launch_bounds__(THREADS) void lde_cols(const Batch* __restrict__ d)
   const size_t c = col - m.col0;
   const size_t t0 = (size_t)xb << logT;
   const uint32_t* src = (FORWARD ? m.tmp2 + (size_t)z * n * m.w : m.in) + c * n + t0;
-  const uint32_t* __restrict__ tw = FORWARD ? g.twa_fwd : g.twa_inv;
+  const uint32_t* __restrict__ tw = FORWARD ? g.twa_fwd : g.twa_inv;   // sub-problem twiddles (fill_ct_twiddles)
   // 16-byte global accesses (T >= 8), four in flight per thread
   const int logTq = logT - 2;
   const int quads = (A << logT) >> 2;
@@ -282,7 +301,10 @@ __global__ __launch_bounds__(THREADS) void lde_cols(const Batch* __restrict__ d)
     }
   }
   __syncthreads();
-  lds_ntt<true, false>(lds, la, logT, TP, tw);  // DIF either way: natural rows in, bit-reversed rows out
+  // natural rows in, bit-reversed rows out either way, lazy Cooley-Tukey butterflies (ten instructions instead of twelve). The inverse
+  // pass hands its lazy words on as they are (lde_rows_big's first butterflies take signed words); the forward pass writes the
+  // committed LDE and brings them back to [0, p) on the way out.
+  lds_ntt_ct<false>(lds, la, logT, TP, tw);
   if (!FORWARD) {
     uint32_t* dst = m.tmp1 + c * n + t0;
     for (int u0 = threadIdx.x; u0 < quads; u0 += blockDim.x) {
@@ -294,7 +316,7 @@ __global__ __launch_bounds__(THREADS) void lde_cols(const Batch* __restrict__ d)
     if (la < 2) {  // A = 2: scalar stores
       for (int u = threadIdx.x; u < (A << logT); u += blockDim.x) {
         const int t = u >> la, q = u & (A - 1);
-        dst[(size_t)kb::bitrev((uint32_t)(t0 + t), lb) * A + q] = lds[q * TP + t];
+        dst[(size_t)kb::bitrev((uint32_t)(t0 + t), lb) * A + q] = canonical(lds[q * TP + t]);
       }
       return;
     }
@@ -303,7 +325,8 @@ __global__ __launch_bounds__(THREADS) void lde_cols(const Batch* __restrict__ d)
       const int t = u0 >> logAq, q = (u0 & ((1 << logAq) - 1)) << 2;
       const uint32_t* sp = lds + q * TP + t;
       const size_t j0 = t0 + t;
-      *reinterpret_cast<uint4*>(dst + (size_t)kb::bitrev((uint32_t)j0, lb) * A + q) = make_uint4(sp[0], sp[TP], sp[2 * TP], sp[3 * TP]);
+      *reinterpret_cast<uint4*>(dst + (size_t)kb::bitrev((uint32_t)j0, lb) * A + q) =
+          make_uint4(canonical(sp[0]), canonical(sp[TP]), canonical(sp[2 * TP]), canonical(sp[3 * TP]));
     }
   }
 }
@@ -467,6 +490,15 @@ __global__ void fill_scaled_stage_twiddles(uint32_t* tw, uint32_t w, int logn, u
     for (int i = 0; i < s; i++) gs = kb::sqr(gs);
     tw[n - (n >> s) + off] = kb::mul(gs, kb::pow(w, (uint64_t)off << s));
   }
+}
+// Sub-problem twiddles of a plain size-2^logn transform run as butterflies_ct: tw[(1 << s) - 1 + r] = w^(bitrev_s(r) * (n >> (s + 1)))
+__global__ void fill_ct_twiddles(uint32_t* tw, uint32_t w, int logn) {
+  const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t n = 1u << logn;
+  if (e + 1 >= n) { if (e + 1 == n) tw[e] = 0; return; }
+  const int s = 31 - __clz(e + 1);
+  const uint32_t r = e + 1 - (1u << s);
+  tw[e] = kb::pow(w, (uint64_t)kb::bitrev(r, s) * (n >> (s + 1)));
 }
 // Per row k1 < A of the four-step decomposition, the sub-problem twiddles of the inverse B-point row transform with the w_n^(-i0 k1)
 // twiddle folded in (butterflies_ct): tw[k1 B + (1 << s) - 1 + r] = (g w^bitrev_s(r))^(B >> (s + 1)) with g = w_n^-k1, w = w_B^-1 = w_n^-A,

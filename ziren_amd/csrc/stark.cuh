@@ -67,10 +67,22 @@ __global__ __launch_bounds__(THREADS) void perm_rows(const uint32_t* __restrict_
         for (int q = 0; q < batch && k < n_lookups; q++, k++) {
           uint32_t kind = blob[pos++];
           int nv = blob[pos++];
-          kb::E4 denom = kb::eadd_base(alpha, kb::to_monty(kind));  // beta^0 * argument_index
-          for (int v = 0; v < nv; v++) {
-            uint32_t lin = apply_pair_col(blob, pos, main, n, prep, n, r);
-            denom = kb::eadd(denom, kb::escale(beta_pows[v + 1], lin));
+          // alpha + beta^0 * argument_index + sum_v beta^(v+1) * value_v: the sum as four 96-bit dot products with the (row-uniform)
+          // powers of beta, reduced once (8 instructions per value instead of a Montgomery product and a modular addition per coefficient)
+          // (pays from four values on: the four reductions at the end cost as much as three terms the other way)
+          kb::E4 denom = kb::eadd_base(alpha, kb::to_monty(kind));
+          if (nv >= 4) {
+            kb::FoldAcc dsum = kb::fold_zero();
+            for (int v = 0; v < nv; v++) {
+              uint32_t lin = apply_pair_col(blob, pos, main, n, prep, n, r);
+              kb::fold_base(dsum, beta_pows[v + 1], lin);
+            }
+            denom = kb::eadd(denom, kb::fold_finish(dsum));
+          } else {
+            for (int v = 0; v < nv; v++) {
+              uint32_t lin = apply_pair_col(blob, pos, main, n, prep, n, r);
+              denom = kb::eadd(denom, kb::escale(beta_pows[v + 1], lin));
+            }
           }
           uint32_t mult = apply_pair_col(blob, pos, main, n, prep, n, r);
           if (k >= n_sends) mult = kb::neg(mult);

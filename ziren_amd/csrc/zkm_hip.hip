@@ -132,6 +132,8 @@ void zkm_ctx_destroy(zkm_ctx* ctx) {
   for (auto& kv : ctx->pow_tabs) { (void)hipFree(kv.second.first); (void)hipFree(kv.second.second); }
   ctx->drop_coset_tables();
   for (auto& kv : ctx->row_tabs) (void)hipFree(kv.second);
+  for (auto& kv : ctx->ct_fwd) (void)hipFree(kv.second);
+  for (auto& kv : ctx->ct_inv) (void)hipFree(kv.second);
   for (auto& kv : ctx->selector_tabs) (void)hipFree(kv.second);
   for (auto& m : ctx->marks) (void)hipEventDestroy(m.second);
   for (auto& e : ctx->event_pool) (void)hipEventDestroy(e);
