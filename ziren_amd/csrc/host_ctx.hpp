@@ -145,11 +145,12 @@ struct zkm_ctx {
   char* arena = nullptr;
   size_t dirty_lo = SIZE_MAX, dirty_hi = 0;
   void* upload_staged(const void* src, size_t bytes, std::vector<void*>* scratch = nullptr) {
-    if (bytes == 0) bytes = 4;
-    void* h = bytes <= ((size_t)1 << 20) ? pin_alloc(bytes) : nullptr;
+    const size_t room = bytes ? bytes : 4;             // an empty table still gets an address of its own
+    void* h = room <= ((size_t)1 << 20) ? pin_alloc(room) : nullptr;
     if (!h) return upload(src, bytes, scratch);        // too large for the ring: its own buffer and copy
     if (!arena) HIP_CHECK(hipMalloc((void**)&arena, pin_cap));
-    memcpy(h, src, bytes);
+    if (bytes) memcpy(h, src, bytes);
+    bytes = room;
     const size_t off = (char*)h - pin;
     dirty_lo = std::min(dirty_lo, off);
     dirty_hi = std::max(dirty_hi, off + bytes);
