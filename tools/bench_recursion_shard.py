@@ -97,9 +97,11 @@ def main():
         if it:
             res.append({"tracegen_ms": (t1 - t0) * 1e3, "prove_ms": (t2 - t1) * 1e3, "phases": phases, "kernels": kern})
     r = res[-1]
+    label = ("the wrap machine's chips, ultra-compressed KoalaBear" if args.wrap else "ultra-compressed KoalaBear" if args.ultra else
+             "shrink prover's" if args.shrink else "compress prover's")
     cells = sum((1 << c.log_height) * (c.prep_width + c.main_width + 4 * c.perm_ext_width + (4 << c.log_quotient_degree)) for c in recs)
     print(json.dumps({"workload": f"REC-{args.log_hashes}: balanced recursion program, 2^{args.log_hashes} Poseidon2 permutations + ALU / select / memory "
-                                  f"instructions; {"wrap machine's chips, ultra-compressed KoalaBear" if args.wrap else 'ultra-compressed KoalaBear' if args.ultra else 'shrink prover' if args.shrink else 'compress prover'} FRI configuration (blow-up {1 << fri.log_blowup}, {fri.num_queries} queries)",
+                                  f"instructions; {label} FRI configuration (blow-up {1 << fri.log_blowup}, {fri.num_queries} queries)",
                       "program_generation_seconds_python": round(gen_s, 1),
                       "tracegen_ms": round(float(np.mean([x["tracegen_ms"] for x in res])), 3),
                       "prove_ms": round(float(np.mean([x["prove_ms"] for x in res])), 3), "committed_cells": cells, "proof_words": int(len(proof)),
