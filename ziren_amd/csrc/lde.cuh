@@ -76,7 +76,7 @@ __device__ __forceinline__ void butterflies(uint32_t (&x)[1 << R], uint32_t n, u
       } else if (LAZY) {
         const int64_t ar = kb::mad_i64_i32_uniform((int32_t)a, kb::ONE, 0);
         x[j0] = (uint32_t)kb::monty_reduce_signed(kb::mad_i64_i32((int32_t)b, (int32_t)w, ar));
-        x[j1] = (uint32_t)kb::monty_reduce_signed(kb::mad_i64_i32(-(int32_t)b, (int32_t)w, ar));
+        x[j1] = (uint32_t)kb::monty_reduce_signed(kb::mad_i64_i32((int32_t)b, -(int32_t)w, ar));  // -w, not -b: shared by the butterflies of a twiddle
       } else {
         b = kb::mul(b, w);
         x[j0] = kb::add(a, b);
@@ -148,10 +148,10 @@ __device__ __forceinline__ void butterflies_ct(uint32_t (&x)[1 << R], uint32_t s
       const int64_t ar = kb::mad_i64_i32_uniform(a, kb::ONE, 0);
       if (UNIFORM) {
         x[j0] = (uint32_t)kb::monty_reduce_signed(kb::mad_i64_i32_uniform(b, w, ar));
-        x[j1] = (uint32_t)kb::monty_reduce_signed(kb::mad_i64_i32_uniform(-b, w, ar));
+        x[j1] = (uint32_t)kb::monty_reduce_signed(kb::mad_i64_i32_uniform(b, 0u - w, ar));  // the negation is scalar work
       } else {
         x[j0] = (uint32_t)kb::monty_reduce_signed(kb::mad_i64_i32(b, (int32_t)w, ar));
-        x[j1] = (uint32_t)kb::monty_reduce_signed(kb::mad_i64_i32(-b, (int32_t)w, ar));
+        x[j1] = (uint32_t)kb::monty_reduce_signed(kb::mad_i64_i32(b, -(int32_t)w, ar));  // one negation per twiddle (15 per 32 butterflies)
       }
     }
   }
@@ -451,7 +451,7 @@ __global__ __launch_bounds__(THREADS, 6) void lde_rows_big(const Batch* __restri
       // first forward stage (span 1) as a lazy butterfly: a + t b, a - t b, kept as signed words from here to the store
       const int64_t ar = kb::mad_i64_i32_uniform((int32_t)keep[2 * k], kb::ONE, 0);
       work[phys<true>(2 * gg)] = (uint32_t)kb::monty_reduce_signed(kb::mad_i64_i32_uniform((int32_t)keep[2 * k + 1], t_first, ar));
-      work[phys<true>(2 * gg + 1)] = (uint32_t)kb::monty_reduce_signed(kb::mad_i64_i32_uniform(-(int32_t)keep[2 * k + 1], t_first, ar));
+      work[phys<true>(2 * gg + 1)] = (uint32_t)kb::monty_reduce_signed(kb::mad_i64_i32_uniform((int32_t)keep[2 * k + 1], 0u - t_first, ar));
     }
     __syncthreads();
     ntt_pass<false, 4, true, true>(work, LB, 0, 1, 8, tw_fwd, lt);
