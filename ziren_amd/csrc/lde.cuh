@@ -463,8 +463,13 @@ __global__ __launch_bounds__(THREADS, 6) void lde_rows_big(const Batch* __restri
     uint32_t t = kb::mul(st0, cj);
 #pragma unroll
     for (uint32_t q = 0; q < 16; q++) {
-      dst[lt + (q << 9)] = kb::mul_signed(x[q], t);  // brings the lazy value back to [0, p)
-      t = kb::mul(t, st_step);
+      {  // x t with both factors signed words; the one correction brings the product back to [0, p)
+        const uint32_t r = (uint32_t)kb::monty_reduce_signed(kb::mad_i64_i32((int32_t)x[q], (int32_t)t, 0));
+        dst[lt + (q << 9)] = min(r, r + kb::P);
+      }
+      // the running twiddle stays a signed unreduced word (four instructions, st_step is block-uniform): in units of 2^31
+      // T <- 0.4961 T + 0.4961 <= 0.985, so |x t| / 2^32 + p / 2 < p and one correction is enough
+      t = (uint32_t)kb::monty_reduce_signed(kb::mad_i64_i32_uniform((int32_t)t, st_step, 0));
     }
   }
 }
