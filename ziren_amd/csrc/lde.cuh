@@ -179,13 +179,20 @@ __device__ __forceinline__ void ntt_pass_ct(uint32_t* buf, uint32_t logn, uint32
 // a whole transform of 2^logn points that way: passes of four stages from stage 0 up, one shorter pass for the last 1-3 stages. In: reduced
 // or lazy words; out: lazy signed words (|v| < 2^31, congruent to the result), bit-reversed order.
 template <bool PAD>
-__device__ __forceinline__ void lds_ntt_ct(uint32_t* buf, int logn, int lognb, int istride, const uint32_t* __restrict__ tw) {
+__device__ __forceinline__ void lds_ntt_ct(uint32_t* buf, int logn, int lognb, int istride, const uint32_t* __restrict__ tw, bool leave_single = false) {
   int s0 = 0;
   for (; s0 + 4 <= logn; s0 += 4) ntt_pass_ct<4, PAD>(buf, logn, s0, tw, threadIdx.x, lognb, istride);
   const int rem = logn - s0;
   if (rem == 3) ntt_pass_ct<3, PAD>(buf, logn, s0, tw, threadIdx.x, lognb, istride);
   if (rem == 2) ntt_pass_ct<2, PAD>(buf, logn, s0, tw, threadIdx.x, lognb, istride);
-  if (rem == 1) ntt_pass_ct<1, PAD>(buf, logn, s0, tw, threadIdx.x, lognb, istride);
+  if (rem == 1 && !leave_single) ntt_pass_ct<1, PAD>(buf, logn, s0, tw, threadIdx.x, lognb, istride);  // leave_single: the caller's read-out does it
+}
+// the last stage of such a transform (pairs of adjacent positions 2 g, 2 g + 1; one twiddle per pair) on values already in registers
+__device__ __forceinline__ void last_stage_ct(uint32_t& x0, uint32_t& x1, uint32_t w) {
+  const int32_t a = (int32_t)x0, b = (int32_t)x1;
+  const int64_t ar = kb::mad_i64_i32_uniform(a, kb::ONE, 0);
+  x0 = (uint32_t)kb::monty_reduce_signed(kb::mad_i64_i32(b, (int32_t)w, ar));
+  x1 = (uint32_t)kb::monty_reduce_signed(kb::mad_i64_i32(b, -(int32_t)w, ar));
 }
 // a lazy word back to [0, p): v in (-2^31, 2^31) -> v + 2p if negative (in (p - 2^24, 2p)), then one conditional subtraction
 __device__ __forceinline__ uint32_t canonical(uint32_t lazy) {
@@ -304,9 +311,26 @@ __global__ __launch_bounds__(THREADS) void lde_cols(const Batch* __restrict__ d)
   // natural rows in, bit-reversed rows out either way, lazy Cooley-Tukey butterflies (ten instructions instead of twelve). The inverse
   // pass hands its lazy words on as they are (lde_rows_big's first butterflies take signed words); the forward pass writes the
   // committed LDE and brings them back to [0, p) on the way out.
-  lds_ntt_ct<false>(lds, la, logT, TP, tw);
+  // When the stage count leaves a single last stage (la = 5, 9, 13) it is not a pass of its own over LDS: it pairs adjacent rows, and
+  // the read-out below has both rows of a pair in hand (round 3: one LDS round trip and barrier fewer).
+  const bool fused_last = la >= 2 && (la & 3) == 1;
+  lds_ntt_ct<false>(lds, la, logT, TP, tw, fused_last);
+  const uint32_t* __restrict__ tw_last = tw + ((1u << (la - 1)) - 1);  // stage la - 1: sub-problem g = pair g
   if (!FORWARD) {
     uint32_t* dst = m.tmp1 + c * n + t0;
+    if (fused_last) {
+      for (int u0 = threadIdx.x; u0 < (quads >> 1); u0 += blockDim.x) {
+        const int rp = u0 >> logTq, qd = (u0 & ((1 << logTq) - 1)) << 2;
+        const uint32_t* sp = lds + (2 * rp) * TP + qd;
+        uint32_t x[4] = {sp[0], sp[1], sp[2], sp[3]}, y[4] = {sp[TP], sp[TP + 1], sp[TP + 2], sp[TP + 3]};
+        const uint32_t w = tw_last[rp];
+#pragma unroll
+        for (int k = 0; k < 4; k++) last_stage_ct(x[k], y[k], w);
+        *reinterpret_cast<uint4*>(dst + (size_t)(2 * rp) * B + qd) = make_uint4(x[0], x[1], x[2], x[3]);
+        *reinterpret_cast<uint4*>(dst + (size_t)(2 * rp + 1) * B + qd) = make_uint4(y[0], y[1], y[2], y[3]);
+      }
+      return;
+    }
     for (int u0 = threadIdx.x; u0 < quads; u0 += blockDim.x) {
       const uint32_t* sp = lds + (u0 >> logTq) * TP + ((u0 & ((1 << logTq) - 1)) << 2);
       *reinterpret_cast<uint4*>(dst + (size_t)(u0 >> logTq) * B + ((u0 & ((1 << logTq) - 1)) << 2)) = make_uint4(sp[0], sp[1], sp[2], sp[3]);
@@ -325,8 +349,13 @@ __global__ __launch_bounds__(THREADS) void lde_cols(const Batch* __restrict__ d)
       const int t = u0 >> logAq, q = (u0 & ((1 << logAq) - 1)) << 2;
       const uint32_t* sp = lds + q * TP + t;
       const size_t j0 = t0 + t;
+      uint32_t x[4] = {sp[0], sp[TP], sp[2 * TP], sp[3 * TP]};
+      if (fused_last) {
+        last_stage_ct(x[0], x[1], tw_last[q >> 1]);
+        last_stage_ct(x[2], x[3], tw_last[(q >> 1) + 1]);
+      }
       *reinterpret_cast<uint4*>(dst + (size_t)kb::bitrev((uint32_t)j0, lb) * A + q) =
-          make_uint4(canonical(sp[0]), canonical(sp[TP]), canonical(sp[2 * TP]), canonical(sp[3 * TP]));
+          make_uint4(canonical(x[0]), canonical(x[1]), canonical(x[2]), canonical(x[3]));
     }
   }
 }
