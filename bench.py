@@ -652,7 +652,7 @@ def main():
                                    "GBps": round(v[2] / max(v[0], 1e-9) / 1e6, 1)} for n, v in
                                sorted(table.items(), key=lambda kv: -kv[1][0])},
                 "kernels_ms_source": (f"a pass of {inst_steps} steps after the timed region with every launch >= 256 KiB timed ({inst_ms:.3f} ms per step: a timed "
-                                      f"launch costs a few microseconds of dispatch latency, ~500 launches per proof); inside the timed region only "
+                                      f"launch costs a few microseconds of dispatch latency, ~250 launches per proof); inside the timed region only "
                                       f"{dominant} is timed, and the roofline is computed from those launches") if inst_acc else "the timed region",
                 "roofline": roofline, "valu": valu, "lde": lde, "two_in_flight": two, "pcie_inclusive": pcie, "cpu_baseline": cpu, "fib": fib}
         print(json.dumps(line))
