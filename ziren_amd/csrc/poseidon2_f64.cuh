@@ -90,18 +90,20 @@ KB_HD void external_layer(double s[16]) {
   }
 }
 
-// x / 2^K + add (SIGN = +1) or -x / 2^K + add (SIGN = -1) modulo p, K <= 24, for an integer |x| < 2^52:
-// x = t 2^K + lo with |lo| <= 2^(K-1); 2^-K = -(p-1)/2^K (mod p) because 2^K (p-1)/2^K = -1; so x/2^K = t - lo (p-1)/2^K.
-// |result - add| <= |x|/2^K + 1/2 + 2^30.
+// x / 2^K + add (SIGN = +1) or -x / 2^K + add (SIGN = -1) modulo p, K <= 24, for integers |x| < 2^44, |add| < 2^44.
+// Z[1/2] -> F_p is a ring homomorphism (2 is invertible), so the real number w = add +- x / 2^K — exact in a double: K fractional
+// bits under at most 45 integer ones — already *is* the result; what is left is to make it an integer again. w = t + lo with
+// t = rint(w), lo = j / 2^K, |lo| <= 1/2, and 2^-K = -(p-1)/2^K (mod p) because 2^K (p-1)/2^K = -1, so lo stands for
+// -j (p-1)/2^K = -lo (p-1), an integer of magnitude <= (p-1)/2 (2^24 divides p - 1). Four instructions (round 3; before: split x
+// first, five). |result - add| <= |x|/2^K + 1/2 + 2^30.
 template <int K, int SIGN>
 KB_HD double div2k_add(double x, double add) {
-  constexpr double INV = 1.0 / (double)(1u << K);
-  constexpr double POW = (double)(1u << K);
-  constexpr double C = (double)((2130706433u - 1u) >> K);
-  const double t = rne(x * INV);
-  const double lo = fma_(-t, POW, x);
-  if (SIGN > 0) return fma_(-lo, C, t + add);
-  return fma_(lo, C, add - t);
+  constexpr double SCALE = (SIGN > 0 ? 1.0 : -1.0) / (double)(1u << K);
+  constexpr double PM1 = 2130706432.0;
+  const double w = fma_(x, SCALE, add);
+  const double t = rne(w);
+  const double lo = w - t;
+  return fma_(-lo, PM1, t);
 }
 
 // s_i <- V_i s_i + sum(s), V = [-2, 1, 2, 1/2, 3, 4, -1/2, -3, -4, 2^-8, 1/8, 2^-24, -2^-8, -1/8, -1/16, -2^-24]
