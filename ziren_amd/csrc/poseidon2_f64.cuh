@@ -27,6 +27,16 @@ constexpr double PINV = 1.0 / 2130706433.0;  // RN(1/p): relative error <= 2^-53
 
 KB_HD double fma_(double a, double b, double c) { return __builtin_fma(a, b, c); }
 KB_HD double rne(double x) { return __builtin_rint(x); }  // v_rndne_f64 (round to nearest even, the default mode on the host too)
+// A constant that is not one of the inline operands (+-0.5, 1, 2, 4), held in a scalar register pair. As a literal it can only be
+// encoded in the two-address v_fmac_f64, whose addend is overwritten — and the addend of the internal layer's lanes is the lane sum,
+// which every lane needs: the compiler copies it first (v_mov_b64, nine per partial round). An opaque scalar operand makes it the
+// three-address v_fma_f64 instead.
+KB_HD double sconst(double c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm("" : "+s"(c));
+#endif
+  return c;
+}
 
 // Host build only: the largest magnitudes seen at the points the exactness argument rests on (a permutation's inputs, the lane sum
 // of a partial round before its reduction, an S-box input, any lane after a partial round). The device build compiles them away.
@@ -100,7 +110,7 @@ template <int K, int SIGN>
 KB_HD double div2k_add(double x, double add) {
   constexpr double SCALE = (SIGN > 0 ? 1.0 : -1.0) / (double)(1u << K);
   constexpr double PM1 = 2130706432.0;
-  const double w = fma_(x, SCALE, add);
+  const double w = (K == 1) ? fma_(x, SCALE, add) : fma_(x, sconst(SCALE), add);
   const double t = rne(w);
   const double lo = w - t;
   return fma_(-lo, PM1, t);
@@ -120,18 +130,18 @@ KB_HD void internal_layer(double s[16]) {
   s[1] = s[1] + sum;
   s[2] = fma_(2.0, s[2], sum);
   s[3] = div2k_add<1, 1>(s[3], sum);
-  s[4] = fma_(3.0, s[4], sum);
+  s[4] = fma_(sconst(3.0), s[4], sum);
   s[5] = fma_(4.0, s[5], sum);
   s[6] = div2k_add<1, -1>(s[6], sum);
-  s[7] = fma_(-3.0, s[7], sum);
+  s[7] = fma_(sconst(-3.0), s[7], sum);
   s[8] = fma_(-4.0, s[8], sum);
   s[9] = div2k_add<8, 1>(s[9], sum);
   s[10] = div2k_add<3, 1>(s[10], sum);
-  s[11] = fma_(-127.0, s[11], sum);  // 2^-24 = -127 (mod p): 127 * 2^24 = p - 1
+  s[11] = fma_(sconst(-127.0), s[11], sum);  // 2^-24 = -127 (mod p): 127 * 2^24 = p - 1
   s[12] = div2k_add<8, -1>(s[12], sum);
   s[13] = div2k_add<3, -1>(s[13], sum);
   s[14] = div2k_add<4, -1>(s[14], sum);
-  s[15] = fma_(127.0, s[15], sum);   // -2^-24 = 127
+  s[15] = fma_(sconst(127.0), s[15], sum);   // -2^-24 = 127
 }
 
 // Magnitudes (B = 2^30 + 2^15 bounds an S-box output; inputs of a permutation: |s_i| <= 2^35.3):
