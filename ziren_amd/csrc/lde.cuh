@@ -23,6 +23,7 @@
 // For n <= 8192 (A = 1) step 2 alone reads the column once and writes the LDE once.
 #pragma once
 #include "kb31.cuh"
+#include "gptr.cuh"
 
 namespace lde {
 
@@ -68,7 +69,7 @@ __device__ __forceinline__ void butterflies(uint32_t (&x)[1 << R], uint32_t n, u
     for (uint32_t j0 = 0; j0 < (1u << R); j0++) {
       if (j0 & half) continue;
       const uint32_t j1 = j0 + half;
-      const uint32_t w = tw[tbase + ((j0 & (half - 1)) << logm2)];
+      const uint32_t w = gp::load(tw + tbase + ((j0 & (half - 1)) << logm2));
       uint32_t a = x[j0], b = x[j1];
       if (DIF) {
         x[j0] = kb::add(a, b);
@@ -143,7 +144,7 @@ __device__ __forceinline__ void butterflies_ct(uint32_t (&x)[1 << R], uint32_t s
     for (uint32_t j0 = 0; j0 < (1u << R); j0++) {
       if (j0 & half) continue;
       const uint32_t j1 = j0 + half;
-      const uint32_t w = tw[tbase + (j0 >> (R - q))];
+      const uint32_t w = gp::load(tw + tbase + (j0 >> (R - q)));
       const int32_t a = (int32_t)x[j0], b = (int32_t)x[j1];
       const int64_t ar = kb::mad_i64_i32_uniform(a, kb::ONE, 0);
       if (UNIFORM) {
@@ -296,7 +297,7 @@ __global__ __launch_bounds__(THREADS) void lde_cols(const Batch* __restrict__ d)
 #pragma unroll
     for (int k = 0; k < 4; k++) {
       int u = u0 + k * blockDim.x;
-      if (u < quads) v[k] = *reinterpret_cast<const uint4*>(src + (size_t)(u >> logTq) * B + ((u & ((1 << logTq) - 1)) << 2));
+      if (u < quads) v[k] = gp::load(reinterpret_cast<const uint4*>(src + (size_t)(u >> logTq) * B + ((u & ((1 << logTq) - 1)) << 2)));
     }
 #pragma unroll
     for (int k = 0; k < 4; k++) {
@@ -323,24 +324,24 @@ __global__ __launch_bounds__(THREADS) void lde_cols(const Batch* __restrict__ d)
         const int rp = u0 >> logTq, qd = (u0 & ((1 << logTq) - 1)) << 2;
         const uint32_t* sp = lds + (2 * rp) * TP + qd;
         uint32_t x[4] = {sp[0], sp[1], sp[2], sp[3]}, y[4] = {sp[TP], sp[TP + 1], sp[TP + 2], sp[TP + 3]};
-        const uint32_t w = tw_last[rp];
+        const uint32_t w = gp::load(tw_last + rp);
 #pragma unroll
         for (int k = 0; k < 4; k++) last_stage_ct(x[k], y[k], w);
-        *reinterpret_cast<uint4*>(dst + (size_t)(2 * rp) * B + qd) = make_uint4(x[0], x[1], x[2], x[3]);
-        *reinterpret_cast<uint4*>(dst + (size_t)(2 * rp + 1) * B + qd) = make_uint4(y[0], y[1], y[2], y[3]);
+        gp::store(reinterpret_cast<uint4*>(dst + (size_t)(2 * rp) * B + qd), make_uint4(x[0], x[1], x[2], x[3]));
+        gp::store(reinterpret_cast<uint4*>(dst + (size_t)(2 * rp + 1) * B + qd), make_uint4(y[0], y[1], y[2], y[3]));
       }
       return;
     }
     for (int u0 = threadIdx.x; u0 < quads; u0 += blockDim.x) {
       const uint32_t* sp = lds + (u0 >> logTq) * TP + ((u0 & ((1 << logTq) - 1)) << 2);
-      *reinterpret_cast<uint4*>(dst + (size_t)(u0 >> logTq) * B + ((u0 & ((1 << logTq) - 1)) << 2)) = make_uint4(sp[0], sp[1], sp[2], sp[3]);
+      gp::store(reinterpret_cast<uint4*>(dst + (size_t)(u0 >> logTq) * B + ((u0 & ((1 << logTq) - 1)) << 2)), make_uint4(sp[0], sp[1], sp[2], sp[3]));
     }
   } else {
     uint32_t* dst = m.out + c * (n << log_blowup) + (size_t)kb::bitrev(z, log_blowup) * n;
     if (la < 2) {  // A = 2: scalar stores
       for (int u = threadIdx.x; u < (A << logT); u += blockDim.x) {
         const int t = u >> la, q = u & (A - 1);
-        dst[(size_t)kb::bitrev((uint32_t)(t0 + t), lb) * A + q] = canonical(lds[q * TP + t]);
+        gp::store(dst + (size_t)kb::bitrev((uint32_t)(t0 + t), lb) * A + q, canonical(lds[q * TP + t]));
       }
       return;
     }
@@ -351,11 +352,11 @@ __global__ __launch_bounds__(THREADS) void lde_cols(const Batch* __restrict__ d)
       const size_t j0 = t0 + t;
       uint32_t x[4] = {sp[0], sp[TP], sp[2 * TP], sp[3 * TP]};
       if (fused_last) {
-        last_stage_ct(x[0], x[1], tw_last[q >> 1]);
-        last_stage_ct(x[2], x[3], tw_last[(q >> 1) + 1]);
+        last_stage_ct(x[0], x[1], gp::load(tw_last + (q >> 1)));
+        last_stage_ct(x[2], x[3], gp::load(tw_last + (q >> 1) + 1));
       }
-      *reinterpret_cast<uint4*>(dst + (size_t)kb::bitrev((uint32_t)j0, lb) * A + q) =
-          make_uint4(canonical(x[0]), canonical(x[1]), canonical(x[2]), canonical(x[3]));
+      gp::store(reinterpret_cast<uint4*>(dst + (size_t)kb::bitrev((uint32_t)j0, lb) * A + q),
+                make_uint4(canonical(x[0]), canonical(x[1]), canonical(x[2]), canonical(x[3])));
     }
   }
 }
@@ -379,7 +380,7 @@ __global__ __launch_bounds__(THREADS) void lde_rows(const Batch* __restrict__ d)
   const uint32_t* src = m.in + c * B;
   const uint32_t* __restrict__ tw_fwd = g.twb_fwd;
   const uint32_t* __restrict__ tw_inv = g.twb_inv;
-  for (int i = threadIdx.x; i < B; i += blockDim.x) coef[phys<true>(i)] = src[i];
+  for (int i = threadIdx.x; i < B; i += blockDim.x) coef[phys<true>(i)] = gp::load(src + i);
   __syncthreads();
   if (lb > 0) lds_ntt<true, true>(coef, lb, 0, 1, tw_inv);
   // coef[pc] = n * c_k with k = bitrev_lb(pc)
@@ -395,7 +396,7 @@ __global__ __launch_bounds__(THREADS) void lde_rows(const Batch* __restrict__ d)
     __syncthreads();
     if (lb > 0) lds_ntt<false, true>(work, lb, 0, 1, tw_fwd);
     uint32_t* dst = m.out + c * ((size_t)B << log_blowup) + (size_t)kb::bitrev(j, log_blowup) * B;
-    for (int i = threadIdx.x; i < B; i += blockDim.x) dst[i] = work[phys<true>(kb::bitrev(i, lb))];
+    for (int i = threadIdx.x; i < B; i += blockDim.x) gp::store(dst + i, work[phys<true>(kb::bitrev(i, lb))]);
     sj = kb::mul(sj, g.w_N);
   }
 }
@@ -435,7 +436,7 @@ __global__ __launch_bounds__(THREADS, 6) void lde_rows_big(const Batch* __restri
   const uint32_t* src = m.tmp1 + c * n + (size_t)pr * B;
   const uint32_t* __restrict__ pw_lo = g.pw_lo;
   const uint32_t* __restrict__ pw_hi = g.pw_hi;
-  auto pw = [&](uint32_t e) { return kb::mul(pw_lo[e & 1023], pw_hi[e >> 10]); };  // w_n^e, e < n
+  auto pw = [&](uint32_t e) { return kb::mul(gp::load(pw_lo + (e & 1023)), gp::load(pw_hi + (e >> 10))); };  // w_n^e, e < n
 
   // inverse row transform, natural in -> bit-reversed out, with the row's table of sub-problem twiddles (butterflies_ct): the
   // w_n^(-i0 k1) twiddle of the four-step decomposition is inside the table. First four stages in registers (thread g owns i0 = g + 512 j:
@@ -444,7 +445,7 @@ __global__ __launch_bounds__(THREADS, 6) void lde_rows_big(const Batch* __restri
   const uint32_t* __restrict__ twr = g.tw_rows + (size_t)k1 * B;
   uint32_t x[16];
 #pragma unroll
-  for (uint32_t j = 0; j < 16; j++) x[j] = src[tid + (j << 9)];
+  for (uint32_t j = 0; j < 16; j++) x[j] = gp::load(src + tid + (j << 9));
   butterflies_ct<4, true>(x, 0, 0, twr);
 #pragma unroll
   for (uint32_t j = 0; j < 16; j++) work[phys<true>(tid + (j << 9))] = x[j];
@@ -457,7 +458,7 @@ __global__ __launch_bounds__(THREADS, 6) void lde_rows_big(const Batch* __restri
   for (uint32_t k = 0; k < 8; k++) {
     const uint32_t gg = tid + (k << 9);
     const int32_t a = (int32_t)work[phys<true>(2 * gg)], b = (int32_t)work[phys<true>(2 * gg + 1)];
-    const uint32_t w = twr[(1u << 12) - 1 + gg];
+    const uint32_t w = gp::load(twr + (1u << 12) - 1 + gg);
     const int64_t ar = kb::mad_i64_i32_uniform(a, kb::ONE, 0);
     keep[2 * k] = (uint32_t)kb::monty_reduce_signed(kb::mad_i64_i32(b, (int32_t)w, ar));
     keep[2 * k + 1] = (uint32_t)kb::monty_reduce_signed(kb::mad_i64_i32(-b, (int32_t)w, ar));
@@ -467,8 +468,8 @@ __global__ __launch_bounds__(THREADS, 6) void lde_rows_big(const Batch* __restri
   const uint32_t ncosets = 1u << d->log_blowup;
   for (uint32_t j = 0; j < ncosets; j++) {
     const uint32_t* __restrict__ tw_fwd = m.twf + (size_t)j * B;  // stage twiddles (shift_j^A w_B^off)^(2^s)
-    const uint32_t t_first = tw_fwd[B - 2];                       // stage 12 (span 1): shift_j^(A B / 2)
-    const uint32_t cj = m.cs[(j << la) + k1];                     // shift_j^k1 / n
+    const uint32_t t_first = gp::load(tw_fwd + B - 2);                       // stage 12 (span 1): shift_j^(A B / 2)
+    const uint32_t cj = gp::load(m.cs + (j << la) + k1);                     // shift_j^k1 / n
     __syncthreads();  // every reader of `work` from the previous step is done
     // The LDS/global addresses below are the same for every coset; left alone the optimiser hoists all of them out
     // of this loop and the kernel needs 160 VGPRs. An opaque copy of the thread index keeps them loop-local.
@@ -494,7 +495,7 @@ __global__ __launch_bounds__(THREADS, 6) void lde_rows_big(const Batch* __restri
     for (uint32_t q = 0; q < 16; q++) {
       {  // x t with both factors signed words; the one correction brings the product back to [0, p)
         const uint32_t r = (uint32_t)kb::monty_reduce_signed(kb::mad_i64_i32((int32_t)x[q], (int32_t)t, 0));
-        dst[lt + (q << 9)] = min(r, r + kb::P);
+        gp::store(dst + lt + (q << 9), min(r, r + kb::P));
       }
       // the running twiddle stays a signed unreduced word (four instructions, st_step is block-uniform): in units of 2^31
       // T <- 0.4961 T + 0.4961 <= 0.985, so |x t| / 2^32 + p / 2 < p and one correction is enough

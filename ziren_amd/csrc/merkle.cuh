@@ -13,6 +13,7 @@
 // (Montgomery word -> canonical double) and digests on the way out; they are stored as 8 consecutive Montgomery words.
 #pragma once
 #include "poseidon2_f64.cuh"
+#include "gptr.cuh"
 
 namespace merkle {
 
@@ -25,14 +26,14 @@ __device__ __forceinline__ void absorb_row(double s[16], const uint32_t* const* 
   uint32_t w[8];
 #pragma unroll
   for (int i = 0; i < 8; i++)
-    if (i < width) w[i] = colptrs[i][row];
+    if (i < width) w[i] = gp::load(colptrs[i] + row);
   for (int g0 = 0; g0 < width; g0 += 8) {
 #pragma unroll
     for (int i = 0; i < 8; i++)
       if (g0 + i < width) s[i] = p2f::load_monty(w[i]);
 #pragma unroll
     for (int i = 0; i < 8; i++)
-      if (g0 + 8 + i < width) w[i] = colptrs[g0 + 8 + i][row];
+      if (g0 + 8 + i < width) w[i] = gp::load(colptrs[g0 + 8 + i] + row);
     p2f::permute(s);
   }
 }
@@ -76,7 +77,7 @@ __global__ __launch_bounds__(THREADS) void compress_layer(const uint32_t* __rest
   uint32_t w[8];  // the injected row's next eight words, requested one permutation ahead
 #pragma unroll
   for (int k = 0; k < 8; k++)
-    if (k < inject_width) w[k] = inject_cols[k][i];
+    if (k < inject_width) w[k] = gp::load(inject_cols[k] + i);
   for (int ph = 0;; ph++) {
     p2f::permute(s);
     if (ph == last) break;
@@ -93,7 +94,7 @@ __global__ __launch_bounds__(THREADS) void compress_layer(const uint32_t* __rest
         if (g0 + k < inject_width) s[k] = p2f::load_monty(w[k]);
 #pragma unroll
       for (int k = 0; k < 8; k++)
-        if (g0 + 8 + k < inject_width) w[k] = inject_cols[g0 + 8 + k][i];
+        if (g0 + 8 + k < inject_width) w[k] = gp::load(inject_cols[g0 + 8 + k] + i);
     } else {  // compress(node, row hash): both halves stay unreduced doubles (|.| < 2^35.3: permute's input bound)
 #pragma unroll
       for (int k = 0; k < 8; k++) { s[8 + k] = s[k]; s[k] = node[k]; }
