@@ -25,4 +25,17 @@ __device__ __forceinline__ void store(uint4* p, const uint4& v) {
   u32x4 w; w.x = v.x; w.y = v.y; w.z = v.z; w.w = v.w;
   *(u32x4 GP_AS1*)p = w;
 }
+// a quartic-extension element (four words, 16-byte aligned) through one 16-byte access; E is kb::E4 (kept a template so that this
+// header does not depend on kb31.cuh)
+template <class E>
+__device__ __forceinline__ E load_e4(const E* p) {
+  const u32x4 v = *(const u32x4 GP_AS1*)p;
+  E e; e.c[0] = v.x; e.c[1] = v.y; e.c[2] = v.z; e.c[3] = v.w;
+  return e;
+}
+template <class E>
+__device__ __forceinline__ void store_e4(E* p, const E& e) {
+  u32x4 w; w.x = e.c[0]; w.y = e.c[1]; w.z = e.c[2]; w.w = e.c[3];
+  *(u32x4 GP_AS1*)p = w;
+}
 }  // namespace gp

@@ -5,6 +5,7 @@
 // crates/recursion/circuit/src/fri.rs:71-218 (reduced openings) and :220-361 (fold, queries).
 #pragma once
 #include "kb31.cuh"
+#include "gptr.cuh"
 
 namespace open {
 
@@ -125,11 +126,11 @@ __device__ __forceinline__ void eval_columns_body(const uint32_t* __restrict__ m
     uint32_t vnext[EVAL_COLS];
     const size_t rn = r + 4 == n ? 0 : r + 4;
 #pragma unroll
-    for (int k = 0; k < 4; k++) w[k] = weights[r + k];
+    for (int k = 0; k < 4; k++) w[k] = gp::load_e4(weights + r + k);
 #pragma unroll
     for (int c = 0; c < EVAL_COLS; c++) {
-      v[c] = *reinterpret_cast<const uint4*>(cols[c] + r);
-      if (TWO) vnext[c] = cols[c][rn];
+      v[c] = gp::load(reinterpret_cast<const uint4*>(cols[c] + r));
+      if (TWO) vnext[c] = gp::load(cols[c] + rn);
     }
 #pragma unroll
     for (int c = 0; c < EVAL_COLS; c++) {
@@ -242,7 +243,7 @@ __global__ __launch_bounds__(THREADS) void reduce_openings(const ReduceMat* __re
     for (; c + 8 <= M.width; c += 8) {
       uint32_t v[8];
 #pragma unroll
-      for (int k = 0; k < 8; k++) v[k] = col[(size_t)(c + k) * N];
+      for (int k = 0; k < 8; k++) v[k] = gp::load(col + (size_t)(c + k) * N);
 #pragma unroll
       for (int k = 0; k < 8; k++) {
         const kb::E4 a = ap[c + k];
@@ -254,7 +255,7 @@ __global__ __launch_bounds__(THREADS) void reduce_openings(const ReduceMat* __re
     }
     for (; c < M.width; c++) {
       const kb::E4 a = ap[c];
-      const uint32_t v = col[(size_t)c * N];
+      const uint32_t v = gp::load(col + (size_t)c * N);
       kb::acc96_fma_uniform(s0, a.c[0], v);
       kb::acc96_fma_uniform(s1, a.c[1], v);
       kb::acc96_fma_uniform(s2, a.c[2], v);
