@@ -221,7 +221,8 @@ void zkm_main_data_free(zkm_ctx* ctx, zkm_main_data* d);
  * names/main_traces). challenger is the post-`pk.observe_into` clone (prove.rs:496) and is
  * advanced in place. The proof is written as the flat word stream documented in
  * INTEGRATION.md ("ShardProof stream", the Appendix-B order of SURVEY.md). If proof_cap is
- * too small the call fails and *proof_len holds the required length. */
+ * too small the call fails, *proof_len holds the required length, and proof_out holds an
+ * unspecified prefix of the stream (it is written in place, not copied at the end). */
 int zkm_open(zkm_ctx* ctx, const zkm_pk* pk, zkm_main_data* data, const zkm_chip_desc* chips,
              const zkm_fri_config* fri, uint32_t num_pv_elts, zkm_challenger* challenger,
              uint32_t* proof_out, size_t proof_cap, size_t* proof_len);

@@ -3,11 +3,20 @@
 static E4 host_pow2k(E4 a, int k) { return kb::epow2k(a, k); }
 
 // ---- proof stream writer ---------------------------------------------------------------------------
+// The proof stream goes straight into the caller's buffer (no growing vector and final copy: ~0.2 ms of host time per 1.2 MB proof
+// during which the GPU had nothing to do). Words beyond the capacity are counted, not written, so that the length a too-small buffer
+// would have needed can still be reported.
 struct Writer {
-  std::vector<uint32_t> w;
-  void u(uint32_t v) { w.push_back(v); }
-  void words(const uint32_t* p, size_t n) { w.insert(w.end(), p, p + n); }
+  uint32_t* dst;
+  size_t cap, n = 0;
+  Writer(uint32_t* d, size_t c) : dst(d), cap(d ? c : 0) {}
+  void u(uint32_t v) { if (n < cap) dst[n] = v; n++; }
+  void words(const uint32_t* p, size_t cnt) {
+    if (n < cap) memcpy(dst + n, p, std::min(cnt, cap - n) * 4);
+    n += cnt;
+  }
   void ext(const E4& e) { words(e.c, 4); }
+  size_t size() const { return n; }
 };
 
 // ---- open --------------------------------------------------------------------------------------

@@ -497,16 +497,15 @@ int zkm_open(zkm_ctx* ctx, const zkm_pk* pk, zkm_main_data* data, const zkm_chip
   std::lock_guard<std::mutex> lk(ctx->mu);
   HIP_CHECK(hipSetDevice(ctx->device));
   if (num_pv_elts > data->public_values.size()) throw std::runtime_error("num_pv_elts exceeds public_values length");
-  Writer w;
+  Writer w(proof_out, proof_cap);
   ctx->begin_timing();
   // the transcript runs on a copy: the caller's challenger only advances once the proof has been handed over, so a call that
   // fails (a proof buffer that is too small: *proof_len says how many words it takes) leaves it where it was
   zkm_challenger ch = *challenger;
   open_impl(ctx, pk, data, chips, fri, num_pv_elts, &ch, w);
   ctx->end_timing(true);
-  *proof_len = w.w.size();
-  if (w.w.size() > proof_cap) throw std::runtime_error("proof buffer too small");
-  memcpy(proof_out, w.w.data(), w.w.size() * 4);
+  *proof_len = w.size();
+  if (w.size() > proof_cap) throw std::runtime_error("proof buffer too small");
   *challenger = ch;
   API_END
 }
@@ -523,7 +522,7 @@ int zkm_prove_shard(zkm_ctx* ctx, const zkm_pk* pk, size_t n_chips, const zkm_ch
   ctx->begin_timing();
   zkm_main_data* md = commit_impl(ctx, n_chips, names.data(), main_traces, public_values, n_pv, fri->log_blowup);
   ctx->mark("commit main");
-  Writer w;
+  Writer w(proof_out, proof_cap);
   zkm_challenger ch = *challenger;   // as in zkm_open: the caller's transcript advances only with a delivered proof
   try {
     open_impl(ctx, pk, md, chips, fri, num_pv_elts, &ch, w);
@@ -535,9 +534,8 @@ int zkm_prove_shard(zkm_ctx* ctx, const zkm_pk* pk, size_t n_chips, const zkm_ch
   free_pcs_data(ctx, md->data);
   delete md;
   ctx->end_timing(false);
-  *proof_len = w.w.size();
-  if (w.w.size() > proof_cap) throw std::runtime_error("proof buffer too small");
-  memcpy(proof_out, w.w.data(), w.w.size() * 4);
+  *proof_len = w.size();
+  if (w.size() > proof_cap) throw std::runtime_error("proof buffer too small");
   *challenger = ch;
   API_END
 }
