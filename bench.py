@@ -1,20 +1,27 @@
 #!/usr/bin/env python3
-"""Benchmark of the shard-prover hot path (BASELINE.json metric: shard-proofs/sec, 2^22-row trace).
+"""Benchmark of the shard-prover hot path (BASELINE.json metric: shard-proofs/sec, fibonacci 2^22-row trace).
 
-A "step" is one full shard proof — MachineProver::commit + open (crates/stark/src/prover.rs:258-653) —
-of a SYN-k shard (a Cpu-like chip at 2^k rows plus seven smaller chips, core FRI
-parameters: blowup 2, 84 queries, 16 PoW bits) whose traces are already resident in HBM.
+A "step" is one full shard proof — MachineProver::commit + open (crates/stark/src/prover.rs:258-653), core FRI parameters (blowup 2,
+84 queries, 16 PoW bits) — of a shard whose traces are already resident in HBM. The default workload is BASELINE.json's own: a middle
+shard of the fibonacci guest as the reference cuts and shapes it (the executor's shape check closes the shard, `CoreShapeConfig::fix_shape`
+pads it: ziren_amd/shape.py) at SHARD_SIZE = 2^21 — 1 569 808 cycles in a Cpu trace of 2^22 rows, 16 core chips + Byte + Program.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--log-rows 22]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload fib|fib-tight|syn] [--log-rows 22]
 
-N > 1 is launched by the driver through torch.distributed.run, one process per GPU; shards are
-independent (prove.rs:492-497), so every rank proves its own shards and there is no data-path
-collective: scaling is weak, value = shards proven by all ranks / max-over-ranks time.
+Every number this file prints belongs to a proof the restated verifier (oracle verify_shard, outside the timed region) accepted: a leg
+whose proof is rejected raises instead of printing.
+
+N > 1: one process per GPU (launched by the driver through torch.distributed.run, or by this script itself when WORLD_SIZE is not set:
+`python bench.py --gpus 8` starts 8 ranks). Shards are independent (crates/core/machine/src/utils/prove.rs:492-497): the ranks take
+distinct shards from one claim queue, each from the executor's events in page-locked host memory (events -> device traces -> proof, the
+next shard's events crossing PCIe under the current proof), the proof streams are gathered to rank 0 over RCCL inside the timed region;
+there is no data-path collective. Per-GPU work is fixed (4 shards per GPU): scaling is weak, value = shards / max-over-ranks time.
 """
 import argparse
 import ctypes as C
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -25,20 +32,13 @@ import numpy as np
 
 os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")      # before anything initialises the HIP runtime (torch.distributed for N > 1 would): ziren_amd/lib.py
 
-from ziren_amd import abi, lib, prover, synth
-
-HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+HBM_PEAK_GBPS = 8000.0     # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 FP64_VECTOR_TFLOPS = 78.6  # MI355X FP64 vector peak: 256 CUs x 4 SIMDs x 16 lanes x 2 flop x 2.4 GHz (MI355X_MICROARCH.md)
-
-
-def poseidon2_isa():
-    """Dynamic VALU instructions per permutation as the hardware counts them (SQ_INSTS_VALU over tools/ubench_p2's kernels,
-    profiles/r03_poseidon2_isa.json, written by tools/profile_r03.sh -> tools/pmc_poseidon2.py); None when the profile is missing."""
-    path = os.path.join(ROOT, "profiles", "r03_poseidon2_isa.json")
-    if not os.path.exists(path):
-        return None
-    return json.load(open(path))
-
+PROFILE_ROUND = "r04"
+HASHING_KERNELS = ("compress_layer", "hash_leaves", "hash_leaves_tree", "hash_fri_leaves", "hash_fri_leaves_tree", "compress_small", "compress_tail")
+LDE_KERNELS = ("lde_rows", "lde_cols_forward", "lde_cols_inverse")
+ROCPROF_NAMES = {"compress_layer": "merkle::compress_layer", "hash_leaves": "merkle::hash_leaves", "hash_leaves_tree": "merkle::hash_leaves_tree",
+                 "lde_rows": "lde::lde_rows_big", "lde_cols_forward": "lde::lde_cols<true>", "lde_cols_inverse": "lde::lde_cols<false>"}
 
 PROVER_SOURCES = ("kb31.cuh", "lde.cuh", "merkle.cuh", "open.cuh", "poseidon2.cuh", "poseidon2_constants.inc", "poseidon2_f64.cuh", "quotient_args.cuh",
                   "stark.cuh", "host_pcs.hpp", "host_open.hpp")
@@ -57,11 +57,21 @@ def csrc_digest():
     return h.hexdigest()[:16]
 
 
+def poseidon2_isa():
+    """Dynamic VALU instructions per permutation as the hardware counts them (SQ_INSTS_VALU over tools/ubench_p2's kernels, written by
+    tools/profile_r04.sh -> tools/pmc_poseidon2.py); the newest profile kept; None when there is none."""
+    for rnd in (PROFILE_ROUND, "r03"):
+        path = os.path.join(ROOT, "profiles", f"{rnd}_poseidon2_isa.json")
+        if os.path.exists(path):
+            return json.load(open(path)), f"profiles/{rnd}_poseidon2_isa.json"
+    return None, None
+
+
 def usable_cores():
     """(cores this process may actually use, logical CPUs the host shows, why they differ). A container sees every logical CPU of the host
     (os.cpu_count) but is scheduled under a cgroup CPU quota: on the GPU boxes of this pool cpu.max is 16 CPUs' worth of time on a
-    256-thread host, and running more threads than the quota makes every OpenMP loop slower (measured: SYN-18 on the restatement takes
-    4.5 s with 16 threads, 6.5 s with 64, 58.8 s with 256 — profiles/r03_cpu_scaling.json), so the quota is the core count."""
+    256-thread host, and running more threads than the quota makes every OpenMP loop slower (profiles/r03_cpu_scaling.json), so the quota
+    is the core count."""
     shown = os.cpu_count() or 1
     n, why = shown, None
     try:
@@ -85,91 +95,296 @@ def usable_cores():
     return n, shown, why
 
 
-def cpu_baseline(log_rows_sample, fri):
-    """Time the CPU restatement (oracle, kind 'port') proving one SYN shard of the sample size, on every core this process may use
-    (usable_cores: the cgroup quota, not the host's CPU count)."""
+def oracle():
+    """The CPU restatement (tests/oracle_lib.py over oracle/liboracle.so): the checker of every leg's last proof and the `cpu_baseline`
+    leg — never inside a timed region."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
-    L = O.lib()
-    L.orc_lde_seconds.restype = C.c_double
-    threads, shown, why = usable_cores()
-    L.orc_set_num_threads(threads)
-    sh = synth.syn_shard(log_rows_sample)
-    pk = O.Pk([], [], sh.pc_start, sh.initial_global_cumulative_sum, fri.log_blowup)
-    ch = O.new_challenger()
-    pk.observe_into(ch)
-    L.orc_lde_seconds(C.c_int(1))
-    t0 = time.time()
-    O.prove_shard(pk, sh.chips, [c.trace for c in sh.chips], sh.public_values, fri, synth.NUM_PV_ELTS, ch)
-    wall = time.time() - t0
-    return wall, float(L.orc_lde_seconds(C.c_int(0))), threads, shown, why
+    return O
 
 
-def fib_leg(device, fri, log_cycles, steps, specialize=True):
-    """BASELINE.json's own workload beside the synthetic default: a full shard of the fibonacci guest (examples/fibonacci; the loop's
-    closed-form events, ziren_amd/fibfast.py — event for event what the executor restatement gives), real chips (Cpu, AddSub, Lt, Mul,
-    Branch, DivRem, MemoryLocal, Global, Byte, Program with the recorded AIRs), 2^log_cycles cycles. Two rates: `prove` = commit + open with
-    the traces resident in HBM (what `value` of the main line means for SYN), and `events_to_proof` = device trace generation from the
-    executor's events in (pageable) host memory + the proof, the reference's prove-a-record step (crates/core/machine/src/utils/prove.rs:484-497)."""
-    from ziren_amd import fibfast, field as F, chips as CH
-    t0 = time.perf_counter()
-    mach = fibfast.full_shard(log_cycles)
-    ds = fibfast.DeviceShard(mach)
-    gen_s = time.perf_counter() - t0
-    ctx = prover.Context(device)
-    hp = prover.HipProver(ds.chips, fri, synth.NUM_PV_ELTS, ctx=ctx, specialize=specialize)
-    zero_digest = F.to_monty(np.array(CH.SEPTIC_START_X + CH.SEPTIC_START_Y, dtype=np.uint64)).astype(np.uint32)
-    pk = hp.setup(ds.preprocessed(ctx), [0, 0], F.to_monty(mach.pc_base), zero_digest)
-    ch0 = prover.new_challenger()
-    pk.observe_into(ch0)
+# ---- self-launch ---------------------------------------------------------------------------------------------------------------------------
+
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this very command (one process per GPU, RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_* set as torch.distributed.run would), rank 0 inheriting stdout — its one JSON line is the output — and fail
+    if any rank fails."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), ZKM_BENCH_SELF_LAUNCHED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rcs = []
+    deadline = time.time() + float(os.environ.get("ZKM_BENCH_LAUNCH_TIMEOUT", "3000"))
+    for p in procs:
+        try:
+            rcs.append(p.wait(timeout=max(1.0, deadline - time.time())))
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                if q.poll() is None:
+                    q.kill()                 # exactly the processes this function started
+            rcs.append(-9)
+    if any(rcs):
+        sys.stderr.write(f"bench.py --gpus {n}: rank exit codes {rcs}\n")
+        return 1
+    return 0
+
+
+# ---- workloads ---------------------------------------------------------------------------------------------------------------------------
+
+class FibWorkload:
+    """A middle shard of the fibonacci guest (examples/fibonacci; the loop's events in closed form, ziren_amd/fibfast.py — event for event
+    what the executor restatement gives), the real chips with their recorded AIRs. kind "shaped": cut and padded as the reference does by
+    default (fibfast.shaped_shard + shape.fix_shape); kind "tight": 2^k cycles, every chip padded to its next power of two."""
+
+    def __init__(self, kind, log_size, shard_no=2):
+        from ziren_amd import fibfast, shape as SH
+        self.kind, self.log_size = kind, log_size
+        t0 = time.perf_counter()
+        if kind == "shaped":
+            cycles, why = SH.executor_shard_cycles(1 << log_size, fibfast.loop_event_estimate)
+            n = ((shard_no + 1) * cycles) // fibfast.LOOP + 8
+            self.machine = fibfast.fib_shard(n, cycles, shard_no)
+            self.ds = fibfast.DeviceShard(self.machine, shape="fix")
+            self.cut = why
+            self.tag = f"fibs{log_size}"
+        else:
+            assert shard_no == 2
+            self.machine = fibfast.full_shard(log_size)
+            self.ds = fibfast.DeviceShard(self.machine)
+            self.cut = None
+            self.tag = f"fib{log_size}"
+        self.event_generation_s = time.perf_counter() - t0
+        self.chips, self.public_values = self.ds.chips, self.ds.public_values
+        self.cycles = len(self.machine.shards[0].record.cpu)
+        self.data = "synthetic (the fibonacci guest's events in closed form, ziren_amd/fibfast.py; no executor or ELF in this environment)"
+
+    @property
+    def label(self):
+        heights = {c.name: c.log_height for c in self.chips}
+        if self.kind == "shaped":
+            return (f"FIB-S{self.log_size}: a middle shard of examples/fibonacci as the reference cuts and shapes it at SHARD_SIZE = 2^{self.log_size} "
+                    f"({self.cycles} cycles: the executor's shape check closes the shard; fix_shape pads it to the covering shape of least area — Cpu 2^{heights['Cpu']} rows, "
+                    f"{len(self.chips)} chips), full shard proof (commit+open), blowup 2, 84 queries, 16 PoW bits")
+        return (f"FIB-{self.log_size}: a middle shard of examples/fibonacci, {self.cycles} cycles, tight heights (no shape), {len(self.chips)} chips, "
+                f"full shard proof (commit+open), blowup 2, 84 queries, 16 PoW bits")
+
+    def setup(self, ctx, fri, specialize=True):
+        from ziren_amd import chips as CH, field as F, prover, synth
+        hp = prover.HipProver(self.chips, fri, synth.NUM_PV_ELTS, ctx=ctx, specialize=specialize)
+        self.zero_digest = F.to_monty(np.array(CH.SEPTIC_START_X + CH.SEPTIC_START_Y, dtype=np.uint64)).astype(np.uint32)
+        self.pc_start = F.to_monty(self.machine.pc_base)
+        prep = self.ds.preprocessed(ctx)
+        self.prep_host = [p.to_host() for p in prep]
+        pk = hp.setup(prep, [0, 0], self.pc_start, self.zero_digest)
+        ch0 = prover.new_challenger()
+        pk.observe_into(ch0)
+        return hp, pk, ch0
+
+    def resident_traces(self, ctx):
+        return self.ds.traces(ctx)
+
+    def oracle_pk(self, O, fri):
+        return O.Pk(self.prep_host, [0, 0], self.pc_start, self.zero_digest, fri.log_blowup)
+
+
+class SynWorkload:
+    """SYN-k: a Cpu-like chip at 2^k rows plus seven smaller chips, synthetic constraints; round 1-3's headline, kept for
+    continuity."""
+
+    def __init__(self, k, seed=0x5A4B4D00):
+        from ziren_amd import synth
+        self.kind, self.log_size, self.tag = "syn", k, f"syn{k}"
+        self.shard = synth.syn_shard(k, seed=seed)
+        self.chips, self.public_values = self.shard.chips, self.shard.public_values
+        self.label = (f"SYN-{k}: full shard proof (commit+open), Cpu-like chip 2^{k} rows x 67 main cols + 7 smaller chips, blowup 2, 84 queries, 16 PoW bits")
+        self.data = "synthetic"
+
+    def setup(self, ctx, fri, specialize=True):
+        from ziren_amd import prover, synth
+        hp = prover.HipProver(self.chips, fri, synth.NUM_PV_ELTS, ctx=ctx, specialize=specialize)
+        pk = hp.setup([], [], self.shard.pc_start, self.shard.initial_global_cumulative_sum)
+        ch0 = prover.new_challenger()
+        pk.observe_into(ch0)
+        return hp, pk, ch0
+
+    def resident_traces(self, ctx):
+        out = [ctx.upload(c.trace) for c in self.chips]
+        return out
+
+    def host_traces(self):
+        return [c.trace for c in self.chips]
+
+    def oracle_pk(self, O, fri):
+        return O.Pk([], [], self.shard.pc_start, self.shard.initial_global_cumulative_sum, fri.log_blowup)
+
+
+def verify_or_die(wl, fri, ch0, proof, what):
+    """The restated verifier (oracle verify_shard: constraints at zeta against the quotient, FRI queries, Merkle paths, proof of work) on a
+    leg's last proof, outside every timed region. A rejected proof ends the run: no number is printed for it."""
+    from ziren_amd import synth
+    O = oracle()
+    rc = O.verify_shard(wl.oracle_pk(O, fri), wl.chips, fri, synth.NUM_PV_ELTS, ch0.copy(), np.ascontiguousarray(proof, dtype=np.uint32).copy())
+    if rc != 0:
+        raise SystemExit(f"bench.py: the verifier REJECTED the {what} proof (code {rc}); nothing is reported for it")
+    return True
+
+
+# ---- legs --------------------------------------------------------------------------------------------------------------------------------
+
+def accumulate(acc, ctx):
+    for name, ms, calls, nbytes in ctx.kernel_timings():
+        a = acc.setdefault(name, [0.0, 0, 0.0])
+        a[0] += ms
+        a[1] += calls
+        a[2] += nbytes
+
+
+def resident_leg(farm, wl, hp, pk, ch0, traces, steps, warmup, kernel_timing):
+    """W warm-up proofs, then exactly K timed proofs between barriers, traces resident in HBM. Inside the timed region only the dominant
+    kernel (the one the roofline is quoted on: the kernel with the most HIP-event time in the last warm-up proof) is timed; the per-kernel
+    table comes from a pass after it (timing every launch >= 256 KiB costs ~2.5 % of a step)."""
+    from ziren_amd import lib
+    L = lib.load()
+    ctx = hp.ctx
     out = np.zeros(1 << 22, dtype=np.uint32)
-    lib.load().zkm_ctx_set_kernel_timing(ctx.h, C.c_int(2))
-    born = ds.traces(ctx)
-    hp.prove_shard(pk, ds.public_values, born, ch0.copy(), out=out)          # warm-up
-    ctx.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        proof = hp.prove_shard(pk, ds.public_values, born, ch0.copy(), out=out)
-    ctx.synchronize()
-    prove_ms = (time.perf_counter() - t0) / steps * 1e3
-    phases = {n: round(ms, 3) for n, ms in ctx.last_timings()}
-    kernels = {n: {"ms": round(ms, 3), "launches": calls} for n, ms, calls, _ in sorted(ctx.kernel_timings(), key=lambda t: -t[1])}
-    n_words = int(len(proof))
-    for t in born:
-        t.free()
-    pageable = None
-    for pinned in (False, True):
-        if pinned:
-            pageable = (e2p_ms, tg / steps * 1e3)
-            ds.pin(ctx)
-            for t in ds.traces(ctx):
-                t.free()
-        e2p_ms, tg = _events_to_proof(ctx, hp, pk, ds, ch0, out, steps)
-    # two lanes (a context + host thread each, the same pinned events): one lane's event upload and trace generation run under the
-    # other's proof — how a host that feeds a GPU from the executor's record channel would drive it (prove.rs:484-497)
-    import threading
-    ctx2 = prover.Context(device)
-    hp2 = prover.HipProver(ds.chips, fri, synth.NUM_PV_ELTS, ctx=ctx2, specialize=specialize)
-    pk2 = hp2.setup(ds.preprocessed(ctx2), [0, 0], F.to_monty(mach.pc_base), zero_digest)
-    out2 = np.zeros(1 << 22, dtype=np.uint32)
-    _events_to_proof(ctx2, hp2, pk2, ds, ch0, out2, 1)
-    n2 = max(2, steps)
-    t0 = time.perf_counter()
-    th = threading.Thread(target=_events_to_proof, args=(ctx2, hp2, pk2, ds, ch0, out2, n2))
-    th.start()
-    _events_to_proof(ctx, hp, pk, ds, ch0, out, n2)
-    th.join()
-    two_lane_ms = (time.perf_counter() - t0) / (2 * n2) * 1e3
-    alg = synth.shard_algorithmic_bytes(ds)
-    rec = mach.shards[0].record
-    event_bytes = int(sum(a.nbytes for a in [rec.cpu, rec.divrem, rec.branch, rec.memory_local] + list(rec.alu.values())))
-    res = _fib_result(log_cycles, rec, ds, n_words, prove_ms, steps, e2p_ms, tg, pageable, event_bytes, alg, phases, kernels, gen_s)
-    res["events_to_proof"]["two_lanes"] = {"ms_per_shard": round(two_lane_ms, 3), "value": round(1e3 / two_lane_ms, 4), "unit": "shard-proofs/s",
-                                           "note": "two contexts + host threads on the one GPU, each running events -> traces -> proof back to back"}
-    return res
+    L.zkm_ctx_set_kernel_timing(ctx.h, C.c_int(2 if kernel_timing == 3 else kernel_timing))
+    state = {}
+
+    def step():
+        state["proof"] = hp.prove_shard(pk, wl.public_values, traces, ch0.copy(), out=out)     # challenger cloned per shard (prove.rs:496)
+
+    for _ in range(max(1, warmup)):
+        step()
+    dominant = None
+    if kernel_timing == 3:
+        last = ctx.kernel_timings()
+        if last:
+            dominant = max(last, key=lambda t: t[1])[0]
+            L.zkm_ctx_set_kernel_timing_only(ctx.h, dominant.encode())
+    phase_acc, kern_acc = {}, {}
+
+    def timed_step():
+        step()
+        for name, ms in ctx.last_timings():
+            phase_acc[name] = phase_acc.get(name, 0.0) + ms
+        accumulate(kern_acc, ctx)
+
+    elapsed = farm.timed(timed_step, steps=steps, warmup=0)
+    table, table_steps, table_ms = kern_acc, steps, elapsed / steps * 1e3
+    if dominant is not None:
+        L.zkm_ctx_set_kernel_timing(ctx.h, C.c_int(2))
+        table, table_steps = {}, min(steps, 5)
+        t0 = time.perf_counter()
+        for _ in range(table_steps):
+            step()
+            accumulate(table, ctx)
+        table_ms = (time.perf_counter() - t0) / table_steps * 1e3
+    return {"elapsed": elapsed, "phases": {n: v / steps for n, v in phase_acc.items()}, "kern_timed": kern_acc, "table": table,
+            "table_steps": table_steps, "table_ms": table_ms, "dominant": dominant, "proof": state["proof"].copy(), "out": out}
 
 
-def _events_to_proof(ctx, hp, pk, ds, ch0, out, steps):
+def traffic_profile(tag):
+    """The rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE summary of this workload kept under profiles/ (tools/profile_r04.sh), only if it was
+    taken on these very kernel sources (it records their digest); PMC counters cannot be read from inside this process."""
+    path = os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_{tag}_hbm_traffic.json")
+    rel = os.path.relpath(path, ROOT)
+    if not os.path.exists(path):
+        return None, {"file": rel, "missing": True}
+    tj = json.load(open(path))
+    if tj.get("csrc_digest") != csrc_digest():
+        return None, {"file": rel, "stale": True, "note": "taken on other kernel sources (csrc digest differs): not quoted"}
+    return tj, {"file": rel, "commit": tj.get("commit"), "csrc_digest": tj.get("csrc_digest")}
+
+
+def roofline_objects(wl, fri, leg, steps):
+    """`roofline` (dominant kernel: algorithmic bytes per launch from the launch site / its average HIP-event duration, measured inside the
+    timed region), `valu` (the hashing kernels against the FP64 vector issue rate) and `lde` (the three LDE kernels as a group)."""
+    from ziren_amd import synth
+    ms_per_step = leg["elapsed"] / steps * 1e3
+    alg_bytes = synth.shard_algorithmic_bytes(wl)
+    tj, tsrc = traffic_profile(wl.tag)
+    roofline = None
+    if leg["kern_timed"]:
+        name, (ms, calls, nbytes) = max(leg["kern_timed"].items(), key=lambda kv: kv[1][0])
+        per_launch_ms = ms / max(calls, 1)
+        kbytes = nbytes / max(calls, 1)
+        achieved = kbytes / (per_launch_ms * 1e-3) / 1e9 if per_launch_ms > 0 else 0.0
+        traffic = None
+        if tj is not None:
+            tk = tj["kernels"].get(ROCPROF_NAMES.get(name, name))
+            traffic = int(tk["hbm_bytes_per_launch"]) if tk else None
+        roofline = {"bound": "hbm", "kernel": name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": tsrc,
+                    "launches_per_step": calls // steps, "avg_launch_ms": round(per_launch_ms, 4), "algorithmic_bytes_per_launch": int(kbytes),
+                    "kernel_share_of_step": round(ms / steps / ms_per_step, 3),
+                    "whole_shard": {"algorithmic_bytes": alg_bytes, "achieved": round(alg_bytes / (ms_per_step * 1e-3) / 1e9, 1),
+                                    "frac": round(alg_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}}
+    table, table_steps, table_ms = leg["table"], leg["table_steps"], leg["table_ms"]
+    valu = None
+    hashing = [n for n in HASHING_KERNELS if n in table]
+    if hashing:
+        perms = synth.shard_poseidon2_permutations(wl, fri.log_blowup)
+        hms = sum(table[n][0] for n in hashing) / table_steps
+        isa, isa_src = poseidon2_isa()
+        per_perm = isa["fp64"]["valu_instr_per_permutation"] if isa else None
+        # one wave64 FP64 instruction = 64 lanes; the vector peak counts an FMA as 2 flop: lane-instructions/s = TFLOPS / 2
+        peak = FP64_VECTOR_TFLOPS * 1e12 / 2 / per_perm / 1e9 if per_perm else None
+        valu = {"bound": "fp64-vector-issue", "kernels": hashing, "poseidon2_permutations": perms, "ms": round(hms, 3),
+                "achieved": round(perms / hms / 1e6, 3), "peak": round(peak, 2) if peak else None, "unit": "Gperm/s",
+                "frac": round(perms / hms / 1e6 / peak, 3) if peak else None, "valu_instr_per_permutation": per_perm,
+                "valu_instr_source": (isa_src + " (SQ_INSTS_VALU / permutations, tools/ubench_p2)") if isa else None,
+                "share_of_step": round(hms / table_ms, 3)}
+        spath = os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_{wl.tag}_sq_counters.csv")
+        if os.path.exists(spath):
+            import csv
+            rows = {r["Name"]: r for r in csv.DictReader(open(spath))}
+            valu["valu_pipe_busy_pct_measured"] = {n: float(rows[n]["ValuPipeBusyPct(of SIMD time)"]) for n in ("merkle::compress_layer", "merkle::hash_leaves")
+                                                   if n in rows and rows[n].get("ValuPipeBusyPct(of SIMD time)")}
+            valu["valu_pipe_busy_source"] = os.path.relpath(spath, ROOT)
+    lde = None
+    lde_names = [n for n in LDE_KERNELS if n in table]
+    if lde_names:
+        lde_ms = sum(table[n][0] for n in lde_names) / table_steps
+        cells = sum((1 << c.log_height) * (c.main_width + 4 * c.perm_ext_width + (4 << c.log_quotient_degree)) for c in wl.chips)
+        alg = 12.0 * cells
+        tr = None
+        if tj is not None:
+            tr = sum(tj["kernels"][ROCPROF_NAMES[n]]["hbm_bytes_total"] for n in LDE_KERNELS if ROCPROF_NAMES[n] in tj["kernels"]) / max(tj.get("steps", 1), 1)
+        lde = {"ms": round(lde_ms, 3), "alg_GB": round(alg / 1e9, 3), "alg_GBps": round(alg / lde_ms / 1e6, 1), "frac_of_hbm_peak": round(alg / lde_ms / 1e6 / HBM_PEAK_GBPS, 4),
+               "traffic_GB": round(tr / 1e9, 3) if tr else None, "ratio": round(tr / alg, 2) if tr else None,
+               "structural_floor": "36 n w: a two-level split reads and writes the column three times (strided inverse, rows, strided forward)"}
+    kernels_ms = {n: {"ms": round(v[0] / table_steps, 3), "launches": v[1] // table_steps, "GBps": round(v[2] / max(v[0], 1e-9) / 1e6, 1)}
+                  for n, v in sorted(table.items(), key=lambda kv: -kv[1][0])}
+    source = (f"a pass of {table_steps} steps after the timed region with every launch >= 256 KiB timed ({table_ms:.3f} ms per step); inside the timed "
+              f"region only {leg['dominant']} is timed, and the roofline is computed from those launches") if leg["dominant"] else "the timed region"
+    return roofline, valu, lde, kernels_ms, source
+
+
+def events_leg(wl, hp, pk, ch0, out, steps):
+    """events -> device traces -> proof, the reference's prove-a-record step (crates/core/machine/src/utils/prove.rs:484-497), fib only.
+    `serial`: one shard at a time, every generator uploading its own events (page-locked). `pipelined`: one context, one host thread —
+    the next shard's events are queued on the DMA stream (zkm_events_upload_async) right before the current shard's proof, so they cross
+    PCIe under its kernels; trace generation then finds them in HBM."""
+    ctx, ds = hp.ctx, wl.ds
+    ds.pin(ctx)
+    event_bytes = ds.event_bytes()
+
+    def one(pre=None):
+        born = ds.traces(ctx, pre)
+        proof = hp.prove_shard(pk, wl.public_values, born, ch0.copy(), out=out)
+        for t in born:
+            t.free()
+        return proof
+
+    one()
+    ctx.synchronize()
     t0 = time.perf_counter()
     tg = 0.0
     for _ in range(steps):
@@ -177,486 +392,404 @@ def _events_to_proof(ctx, hp, pk, ds, ch0, out, steps):
         born = ds.traces(ctx)
         ctx.synchronize()
         tg += time.perf_counter() - t1
-        hp.prove_shard(pk, ds.public_values, born, ch0.copy(), out=out)
+        hp.prove_shard(pk, wl.public_values, born, ch0.copy(), out=out)
         for t in born:
             t.free()
     ctx.synchronize()
-    return (time.perf_counter() - t0) / steps * 1e3, tg
+    serial_ms = (time.perf_counter() - t0) / steps * 1e3
+    # upload rate on its own: the whole shard's events, page-locked host -> HBM, nothing else running
+    t1 = time.perf_counter()
+    pre = ds.prefetch(ctx)
+    for d in pre.values():
+        d.free()                   # waits for the copy
+    h2d_s = time.perf_counter() - t1
+    pre = ds.prefetch(ctx)
+    one(pre)                       # warm the pipelined path
+    ctx.synchronize()
+    pre = ds.prefetch(ctx)
+    t0 = time.perf_counter()
+    for i in range(steps):
+        nxt = ds.prefetch(ctx) if i + 1 < steps else None      # shard i + 1's events start crossing PCIe now
+        proof = one(pre)
+        pre = nxt
+    ctx.synchronize()
+    pipe_ms = (time.perf_counter() - t0) / steps * 1e3
+    return {"event_bytes": event_bytes, "h2d_GBps_alone": round(event_bytes / h2d_s / 1e9, 2),
+            "serial": {"ms_per_shard": round(serial_ms, 3), "value": round(1e3 / serial_ms, 4), "tracegen_ms": round(tg / steps * 1e3, 3),
+                       "note": "one shard at a time: every generator uploads its events (page-locked) and runs, then the proof; nothing overlapped"},
+            "pipelined": {"ms_per_shard": round(pipe_ms, 3), "value": round(1e3 / pipe_ms, 4), "steps": steps,
+                          "note": "one context, one host thread: shard i+1's events are queued on the DMA stream right before shard i's proof"},
+            "unit": "shard-proofs/s"}, proof.copy()
 
 
-def _fib_result(log_cycles, rec, ds, n_words, prove_ms, steps, e2p_ms, tg, pageable, event_bytes, alg, phases, kernels, gen_s):
-    return {"workload": f"FIB-{log_cycles}: a middle shard of examples/fibonacci, {len(rec.cpu)} cycles, full shard proof (commit+open), blowup 2, 84 queries, 16 PoW bits",
-            "chips": {c.name: c.log_height for c in ds.chips}, "committed_cells": ds.committed_cells(), "proof_words": n_words,
-            "prove": {"ms_per_proof": round(prove_ms, 3), "value": round(1e3 / prove_ms, 4), "unit": "shard-proofs/s", "steps": steps,
-                      "note": "traces resident in HBM (device-born), as `value` of the main line"},
-            "events_to_proof": {"ms_per_shard": round(e2p_ms, 3), "value": round(1e3 / e2p_ms, 4), "unit": "shard-proofs/s",
-                                "tracegen_ms": round(tg / steps * 1e3, 3), "event_bytes": event_bytes,
-                                "from_pageable_memory": {"ms_per_shard": round(pageable[0], 3), "tracegen_ms": round(pageable[1], 3)},
-                                "note": "device trace generation of every chip from the shard's events in page-locked host memory (the events' upload is part of "
-                                        "it), then the proof; one shard at a time, nothing overlapped"},
-            "whole_shard": {"algorithmic_bytes": alg, "achieved": round(alg / (prove_ms * 1e-3) / 1e9, 1), "unit": "GB/s",
-                            "frac": round(alg / (prove_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)},
-            "phases_ms": phases, "kernels_ms": kernels, "event_generation_s": round(gen_s, 2)}
+def two_in_flight_leg(wl, fri, device, lane0, specialize, steps):
+    """The same GPU with two shards in flight (a second context + host thread, its own copy of the traces): the launch gaps and host round
+    trips of one proof are filled by the other's kernels. Throughput beside `value`; latency per proof doubles."""
+    import threading
+    from ziren_amd import prover
+    hp0, pk0, ch0, tr0, out0 = lane0
+    ctx1 = prover.Context(device)
+    hp1, pk1, ch1 = wl.setup(ctx1, fri, specialize)
+    tr1 = wl.resident_traces(ctx1)
+    out1 = np.zeros(1 << 22, dtype=np.uint32)
+    both = ((hp0, pk0, ch0, tr0, out0), (hp1, pk1, ch1, tr1, out1))
+
+    def loop(lane, n):
+        hpj, pkj, chj, trj, outj = lane
+        for _ in range(n):
+            hpj.prove_shard(pkj, wl.public_values, trj, chj.copy(), out=outj)
+
+    loop(both[1], 1)
+    n2 = max(2, min(steps, 8))
+    hp0.ctx.synchronize(); hp1.ctx.synchronize()
+    t0 = time.perf_counter()
+    th = threading.Thread(target=loop, args=(both[1], n2))
+    th.start()
+    loop(both[0], n2)
+    th.join()
+    hp0.ctx.synchronize(); hp1.ctx.synchronize()
+    dt = time.perf_counter() - t0
+    for t in tr1:
+        t.free()
+    return {"value": round(2 * n2 / dt, 4), "unit": "shard-proofs/s", "shards": 2 * n2, "ms_per_shard": round(dt / (2 * n2) * 1e3, 3),
+            "note": "two contexts on the one GPU, each proving back to back; the default line keeps one shard in flight (lowest latency)"}
 
 
-def tracegen_bench(args):
-    """`python bench.py --tracegen`: device trace generation, chip after chip, 2^log_rows events each, events
-    resident in pinned host memory. A "step" is one generate_trace call per chip. value = rows per second of kernel time; the
-    wall-clock rate including the H2D copy of the events is reported beside it. HBM roofline per chip: algorithmic bytes =
-    event bytes + 4 h w (the column-major trace) over the kernel time. The six AluEvent chips, Mul, DivRem, Branch, Jump and
-    MovCond use the synthetic per-chip streams of ziren_amd/events.py; Cpu, MemoryInstrs, MiscInstrs and SyscallInstrs a record of
-    ziren_amd/miniexec.py repeated to size (the row builders do not look across rows)."""
-    from ziren_amd import events as E, miniexec as M
-    ctx = prover.Context(0)
-    lib.load().zkm_ctx_set_kernel_timing(ctx.h, C.c_int(1))
-    n = 1 << args.log_rows
-    prog, rec, _ = M.run(1 << 13, seed=1)
+def pcie_leg(wl, hp, pk, ch0, out, steps):
+    """SYN only (for fib the events leg is the boundary's PCIe-inclusive figure): the traces handed over as page-locked host buffers every
+    step (zkm_matrix_upload_async: slabbed DMA + transpose on their own streams, overlapped with commit). Never `value`."""
+    ctx = hp.ctx
+    host = []
+    for t in wl.host_traces():
+        h = ctx.host_alloc(t.shape)
+        h[...] = t
+        host.append(h)
 
-    def tile(ev):
-        return np.tile(ev, -(-n // len(ev)))[:n]
+    def step():
+        dev = [ctx.upload_async(h) for h in host]
+        hp.prove_shard(pk, wl.public_values, dev, ch0.copy(), out=out)
+        for d in dev:
+            d.free()
+    step()
+    ctx.synchronize()
+    n = min(3, steps)
+    t0 = time.perf_counter()
+    for _ in range(n):
+        step()
+    ctx.synchronize()
+    dt = (time.perf_counter() - t0) / n
+    res = {"value": round(1.0 / dt, 4), "unit": "shard-proofs/s", "ms_per_step": round(dt * 1e3, 3), "steps": n, "host_bytes_per_step": int(sum(h.nbytes for h in host)),
+           "note": "traces in page-locked host memory handed over every step (zkm_matrix_upload_async), upload overlapped with commit"}
+    for h in host:
+        ctx.host_free(h)
+    return res
 
-    chips_todo = [(E.CHIP_NAMES[c], E.synthetic_alu_events(c, n), (lambda ev, c=c: ctx.tracegen_alu(c, ev, args.log_rows))) for c in sorted(E.CHIP_NAMES)]
-    chips_todo += [
-        ("Mul", E.synthetic_mul_events(n), lambda ev: ctx.tracegen_mul(ev, args.log_rows)),
-        ("DivRem", E.synthetic_divrem_events(n), lambda ev: ctx.tracegen_divrem(ev, args.log_rows)),
-        ("Branch", E.synthetic_branch_events(n), lambda ev: ctx.tracegen_branch(ev, args.log_rows)),
-        ("Jump", E.synthetic_jump_events(n), lambda ev: ctx.tracegen_jump(ev, args.log_rows)),
-        ("MovCond", E.synthetic_mov_cond_events(n), lambda ev: ctx.tracegen_mov_cond(ev, args.log_rows)),
-        ("Cpu", tile(rec.cpu), lambda ev: ctx.tracegen_cpu(ev, prog, 0x1000, 1, args.log_rows)),
-        ("MemoryInstrs", tile(rec.mem_instr), lambda ev: ctx.tracegen_memory_instrs(ev, args.log_rows)),
-        ("MiscInstrs", tile(rec.misc), lambda ev: ctx.tracegen_misc_instrs(ev, args.log_rows)),
-    ]
-    per_chip, tot_rows, tot_kernel_ms, tot_wall_ms, tot_bytes = {}, 0, 0.0, 0.0, 0.0
-    for name, ev, gen in chips_todo:
-        words = ev.dtype.itemsize // 4
-        pinned = ctx.host_alloc((n * words,))
-        pinned[...] = ev.view(np.uint32).reshape(-1)
-        evp = pinned.view(ev.dtype)
-        kms, wms, width = [], [], 0
-        for it in range(args.warmup + args.steps):
-            t0 = time.perf_counter()
-            m = gen(evp)
-            w = (time.perf_counter() - t0) * 1e3
-            k = sum(ms for nm, ms, _, _ in ctx.kernel_timings() if nm.startswith("tracegen"))
-            width = m.width
-            m.free()
-            if it >= args.warmup:
-                kms.append(k)
-                wms.append(w)
-        ctx.host_free(pinned)
-        nbytes = float(ev.dtype.itemsize) * n + 4.0 * n * width
-        k, w = float(np.mean(kms)), float(np.mean(wms))
-        per_chip[name] = {"kernel_ms": round(k, 4), "call_ms": round(w, 3), "GBps": round(nbytes / k / 1e6, 1), "width": width,
-                          "event_bytes": ev.dtype.itemsize, "Grows_per_s": round(n / k / 1e6, 2)}
-        tot_rows += n
-        tot_kernel_ms += k
-        tot_wall_ms += w
-        tot_bytes += nbytes
-    cpu = None
-    if not args.no_cpu_baseline:
-        sys.path.insert(0, os.path.join(ROOT, "tests"))
-        import oracle_lib as O
-        O.lib().orc_set_num_threads(min(16, os.cpu_count() or 1))
-        ns = 1 << 21
-        rows, t = 0, 0.0
-        for chip in sorted(E.CHIP_NAMES):
-            ev = E.synthetic_alu_events(chip, ns)
-            t0 = time.perf_counter()
-            O.tracegen_alu(chip, ev, 21)
-            t += time.perf_counter() - t0
-            rows += ns
-        cpu = {"value": round(rows / t, 1), "unit": "trace rows/s", "cores": O.lib().orc_num_threads(), "kind": "port",
-               "sample": "the six AluEvent chips at 2^21 events each through oracle/tracegen.hpp (row-major Montgomery output, as the reference's generate_trace returns)"}
-    achieved = tot_bytes / tot_kernel_ms / 1e6
-    print(json.dumps({
-        "metric": "trace rows/sec", "value": round(tot_rows / (tot_kernel_ms * 1e-3), 1), "unit": "trace rows/s", "n_gpus": 1,
-        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(tot_kernel_ms, 4), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
-        "config": {"workload": f"generate_trace of {len(chips_todo)} core chips ({', '.join(nm for nm, _, _ in chips_todo)}), 2^{args.log_rows} events each, "
-                               "events resident in HBM", "log_rows": args.log_rows},
-        "pcie_inclusive": {"value": round(tot_rows / (tot_wall_ms * 1e-3), 1), "unit": "trace rows/s", "ms_per_step": round(tot_wall_ms, 3),
-                           "note": "wall clock of the zkm_tracegen_* calls: pinned-host events -> HBM, kernel, synchronise"},
-        "chips": per_chip,
-        "roofline": {"bound": "hbm", "kernel": "tracegen::alu_rows / cpu_rows", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None},
-        "cpu_baseline": cpu}))
 
+def cpu_baseline_leg(wl, fri, full, sample_log):
+    """The CPU restatement (oracle, kind "port": canonical `% p` arithmetic, OpenMP) proving a bounded sample of the same workload on the
+    cores this process may use — rank 0, N = 1 only, after the timed region. fib: the same guest's shard cut and shaped at a smaller
+    SHARD_SIZE (traces from the oracle's row builders, not timed); syn: SYN-k' . Scaled to the full size: the linear phases by the ratio
+    of committed cells, the LDEs by an extra (k + 1) / (k' + 1)."""
+    from ziren_amd import synth
+    O = oracle()
+    L = O.lib()
+    L.orc_lde_seconds.restype = C.c_double
+    threads, shown, why = usable_cores()
+    L.orc_set_num_threads(threads)
+
+    def cells(chips):
+        return sum((1 << c.log_height) * (c.prep_width + c.main_width + 4 * c.perm_ext_width + (4 << c.log_quotient_degree)) for c in chips)
+
+    if wl.kind == "syn":
+        ks = wl.log_size if full else min(sample_log, wl.log_size)
+        sh = synth.syn_shard(ks)
+        opk = O.Pk([], [], sh.pc_start, sh.initial_global_cumulative_sum, fri.log_blowup)
+        chips, traces, pv = sh.chips, [c.trace for c in sh.chips], sh.public_values
+        what = f"SYN-{ks}"
+        k_full, k_s = wl.log_size, ks
+    else:
+        import machine_lib as ML
+        from ziren_amd import fibfast
+        sample = wl if full else FibWorkload(wl.kind, min(sample_log, wl.log_size))
+        chips = ML.build_shard(ML.Oracle(O), sample.machine, 0, shape=sample.ds.shape)
+        chips[-2].prep_trace = O.tracegen_byte_table()
+        chips[-1].prep_trace = O.tracegen_program(0, sample.machine.shards[0].record.cpu, sample.machine.program, sample.machine.pc_base, sample.ds.plh)
+        from ziren_amd import chips as CH, field as F
+        zero = F.to_monty(np.array(CH.SEPTIC_START_X + CH.SEPTIC_START_Y, dtype=np.uint64)).astype(np.uint32)
+        opk = O.Pk([chips[-2].prep_trace, chips[-1].prep_trace], [0, 0], F.to_monty(sample.machine.pc_base), zero, fri.log_blowup)
+        traces, pv = [c.trace for c in chips], sample.ds.public_values
+        what = f"FIB-S{sample.log_size}" if wl.kind == "shaped" else f"FIB-{sample.log_size}"
+        what += f" ({sample.cycles} cycles, Cpu 2^{chips[0].log_height} rows)"
+        k_full, k_s = wl.chips[0].log_height, chips[0].log_height
+    ch = O.new_challenger()
+    opk.observe_into(ch)
+    L.orc_lde_seconds(C.c_int(1))
+    t0 = time.time()
+    O.prove_shard(opk, chips, traces, pv, fri, synth.NUM_PV_ELTS, ch)
+    wall = time.time() - t0
+    lde_s = float(L.orc_lde_seconds(C.c_int(0)))
+    ratio = cells(wl.chips) / cells(chips)
+    est = (wall - lde_s) * ratio + lde_s * ratio * (k_full + 1) / (k_s + 1)
+    return {"value": round(1.0 / est, 6), "unit": "shard-proofs/s", "cores": threads, "host_logical_cpus": shown, "cores_note": why, "kind": "port",
+            "sample": (f"oracle (CPU restatement, canonical `% p` arithmetic, OpenMP, {threads} threads) proving one {what} shard in {wall:.2f} s ({lde_s:.2f} s of it coset LDEs)"
+                       + ("" if full else f"; scaled to the benchmarked shard by committed cells (x{ratio:.2f}), the LDEs by a further ({k_full} + 1) / ({k_s} + 1)")),
+            "measured_at_full_size": bool(full), "sample_seconds": round(wall, 3), "estimated_seconds_full_size": round(est, 2),
+            "full_size_measurement": f"profiles/{PROFILE_ROUND}_cpu_baseline_full.json (bench.py --cpu-full)"}
+
+
+# ---- N > 1: the claim queue over events -> traces -> proof ---------------------------------------------------------------------------------
+
+class StubLane:
+    """tests/test_bench_cli.py only (ZKM_BENCH_STUB_PROVER=1, CPU, gloo): stands in for the GPU lane so that the launch / queue / gather /
+    line logic of `--gpus N` runs without a GPU. Its "proofs" are labelled words; the line says "stub": true and carries no rate claim."""
+
+    def __init__(self, rank):
+        self.rank = rank
+        self.event_bytes = 1 << 20
+
+    def prefetch(self, i):
+        return ("events", i)
+
+    def prove(self, i, handle):
+        assert handle == ("events", i)
+        time.sleep(0.01)
+        return np.array([0x5AFE, i, self.rank] + [i] * (8 + i % 3), dtype=np.uint32)
+
+    def verify_last(self):
+        return True
+
+    def sync(self):
+        pass
+
+
+class FibQueueLane:
+    """One rank's side of the farm: a pool of distinct middle shards of the guest (their events page-locked), one context, the key."""
+
+    def __init__(self, device, rank, fri, log_size, specialize, pool=2):
+        from ziren_amd import lib, prover
+        self.fri = fri
+        self.wls = [FibWorkload("shaped", log_size, shard_no=2 + (2 * rank + j) % 6) for j in range(pool)]
+        self.ctx = prover.Context(device)
+        self.hp, self.pk, self.ch0 = self.wls[0].setup(self.ctx, fri, specialize)       # one program, one shape: one key for every shard
+        lib.load().zkm_ctx_set_kernel_timing(self.ctx.h, C.c_int(0))
+        for w in self.wls:
+            assert [c.name for c in w.chips] == [c.name for c in self.wls[0].chips] and [c.log_height for c in w.chips] == [c.log_height for c in self.wls[0].chips]
+            w.ds.pin(self.ctx)
+        self.event_bytes = self.wls[0].ds.event_bytes()
+        self.out = np.zeros(1 << 22, dtype=np.uint32)
+        self.last = None
+
+    def challenger(self, i):
+        """Shard i's transcript: the key, then its index in the batch — what makes every queue entry its own proof even where two entries
+        share a pool shard's events."""
+        from ziren_amd import abi, lib
+        ch = self.ch0.copy()
+        idx = np.array([i + 1], dtype=np.uint32)
+        lib.load().zkm_challenger_observe(C.byref(ch), abi.as_u32p(idx), C.c_size_t(1))
+        return ch
+
+    def prefetch(self, i):
+        return self.wls[i % len(self.wls)].ds.prefetch(self.ctx)
+
+    def prove(self, i, handle):
+        w = self.wls[i % len(self.wls)]
+        born = w.ds.traces(self.ctx, handle)
+        proof = self.hp.prove_shard(self.pk, w.public_values, born, self.challenger(i), out=self.out)
+        for t in born:
+            t.free()
+        self.last = (i, w, proof.copy())
+        return proof
+
+    def verify_last(self):
+        i, w, proof = self.last
+        return verify_or_die(w, self.fri, self.challenger(i), proof, f"queue shard {i}")
+
+    def sync(self):
+        self.ctx.synchronize()
+
+
+def queue_main(args, farm, fri):
+    rank, local_rank, world = farm.rank, farm.local_rank, farm.world
+    stub = os.environ.get("ZKM_BENCH_STUB_PROVER") == "1"
+    lane = StubLane(rank) if stub else FibQueueLane(local_rank, rank, fri, args.shard_size_log, not args.interpreter)
+    farm.device_sync = lane.sync
+    n_shards = args.queue if args.queue > 0 else 4 * world
+    for _ in range(max(1, args.warmup)):
+        lane.prove(0, lane.prefetch(0))
+    farm.barrier()
+    t0 = time.perf_counter()
+    ids, proofs = farm.run_queue(n_shards, lane.prove, prefetch=lane.prefetch)
+    gathered = farm.gather_proofs(ids, proofs, n_shards)
+    farm.barrier()
+    elapsed = farm.max_over_ranks(time.perf_counter() - t0)
+    mine = float(np.mean(farm.host_ms)) if farm.host_ms else 0.0
+    slowest = farm.max_over_ranks(mine)
+    proved = farm.sum_over_ranks(float(len(ids)))
+    fewest = -farm.max_over_ranks(-float(len(ids)))
+    ok = 1.0
+    if ids:
+        ok = 1.0 if lane.verify_last() else 0.0         # every rank checks the last proof it made (outside the timed region)
+    all_ok = -farm.max_over_ranks(-ok)
+    ranks_in_group = farm.dist.get_world_size() if farm.dist is not None else 1
+    if all_ok != 1.0 or int(proved) != n_shards:
+        raise SystemExit("bench.py: a rank's proof was rejected or a shard was proven by nobody")
+    if rank == 0:
+        assert len(gathered) == n_shards and len({p.tobytes() for p in gathered}) == n_shards, "the gathered proofs are not distinct"
+        ms = elapsed / n_shards * 1e3
+        print(json.dumps({
+            "metric": "shard-proofs/sec", "value": round(n_shards / elapsed, 4), "unit": "shard-proofs/s", "n_gpus": world, "steps": n_shards,
+            "warmup": max(1, args.warmup), "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "strong" if args.queue > 0 else "weak",
+            "vs_baseline": None, "dtype": "u32", "verified": True, "stub": stub or None,
+            "data": "synthetic (the fibonacci guest's events in closed form, ziren_amd/fibfast.py; two pool shards per rank, page-locked)",
+            "config": {"workload": (f"FIB-S{args.shard_size_log}: {n_shards} distinct shards of examples/fibonacci (cut and shaped as the reference does at SHARD_SIZE = 2^{args.shard_size_log}, "
+                                    f"Cpu 2^22 rows) dealt from one claim queue; per shard: executor events in page-locked host memory -> device traces -> full shard "
+                                    f"proof (commit+open, blowup 2, 84 queries, 16 PoW bits); proof streams gathered to rank 0 inside the timed region"),
+                       "parallelism": f"{world} GPU(s), one process each, claim queue (one shard claimed ahead: its events cross PCIe under the current proof), "
+                                      f"{'gloo' if stub else 'RCCL'} gather of {sum(len(p) for p in gathered) * 4} proof bytes, no data-path collective",
+                       "ranks_in_process_group": ranks_in_group, "backend": "gloo" if stub else "nccl (RCCL)"},
+            "host_ms_per_shard": {"rank0_mean": round(mine, 3), "max_over_ranks_of_means": round(slowest, 3)},
+            "event_bytes_per_shard": lane.event_bytes,
+            "h2d_GBps_per_rank_needed": round(lane.event_bytes / (slowest * 1e-3) / 1e9, 2) if slowest > 0 else None,
+            "shards_proved": int(proved), "shards_proved_by_rank0": len(ids), "fewest_shards_on_a_rank": int(fewest)}))
+    farm.close()
+
+
+# ---- main ----------------------------------------------------------------------------------------------------------------------------------
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--tracegen", action="store_true", help="benchmark device trace generation of the ALU chips instead of the shard proof")
+    ap.add_argument("--tracegen", action="store_true", help="benchmark device trace generation of the core chips instead of the shard proof (tools/bench_tracegen.py)")
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", choices=["fib", "fib-tight", "syn"], default="fib",
+                    help="fib (default): the fibonacci shard as the reference cuts and shapes it at SHARD_SIZE = 2^--shard-size-log; fib-tight: 2^--log-rows cycles, "
+                         "tight heights; syn: SYN---log-rows")
+    ap.add_argument("--shard-size-log", type=int, default=21, help="log2 of the reference's SHARD_SIZE for --workload fib (MAX_SHARD_SIZE = 2^21, crates/stark/src/opts.rs:6; "
+                    "at 2^22 this guest's shard has no covering shape: fix_shape fails in the reference too)")
     ap.add_argument("--log-rows", type=int, default=22)
-    ap.add_argument("--cpu-sample-log-rows", type=int, default=20)
-    ap.add_argument("--no-pcie", action="store_true", help="skip the PCIe-inclusive measurement that follows the timed region")
+    ap.add_argument("--cpu-sample-log", type=int, default=None, help="size of the cpu_baseline sample (fib: log2 SHARD_SIZE, default 18; syn: log rows, default 20)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-full", action="store_true", help="time the CPU baseline at the full size (SYN-22: ~80 s on 16 cores) instead of on the SYN-20 sample")
-    ap.add_argument("--no-inflight2", action="store_true", help="skip the two-shards-in-flight measurement that follows the timed region")
-    ap.add_argument("--inflight", type=int, default=1, help="shards proven concurrently per GPU (one context + host thread each)")
+    ap.add_argument("--cpu-full", action="store_true", help="time the CPU baseline on the benchmarked shard itself instead of a sample (minutes)")
+    ap.add_argument("--no-extra", action="store_true", help="only the timed region, its verification and the roofline objects (profiling runs)")
+    ap.add_argument("--no-syn", action="store_true", help="skip the SYN-22 continuity leg after a fib run")
+    ap.add_argument("--also", type=str, default="", help="comma-separated extra resident legs after the main one: fib21, fib22 (tight), fibs20 ...")
     ap.add_argument("--kernel-timing", type=int, default=3,
-                    help="0 off, 1 every launch, 2 launches >= 256 KiB, 3 (default): inside the timed region only the dominant kernel (the one the roofline "
-                         "is quoted on) is timed, and the per-kernel table comes from an extra pass with mode 2 after it — timing every launch costs ~2.5 %% of a step")
-    ap.add_argument("--from-host", action="store_true", help="time upload (pinned host traces -> HBM) + proof: the PCIe-inclusive rate")
+                    help="0 off, 1 every launch, 2 launches >= 256 KiB, 3 (default): inside the timed region only the dominant kernel is timed")
     ap.add_argument("--interpreter", action="store_true", help="use the bytecode interpreter instead of per-chip quotient kernels")
-    ap.add_argument("--queue", type=int, default=0, metavar="SHARDS", help="deal SHARDS distinct shards (0: off; the default with --queue -1 is 4 per GPU) "
-                    "through the farm's claim queue (Farm.run_queue: whichever rank is free takes the next shard, crates/core/machine/src/utils/prove.rs:484) "
-                    "and gather the proof streams to rank 0, instead of K identical steps per rank; value = shards / max-over-ranks time")
-    ap.add_argument("--fib", type=str, default="21,22", help="log2 cycles of the fibonacci-guest shards proven after the timed region (the `fib` object of "
-                    "the line: BASELINE.json's own workload beside SYN); empty string to skip")
-    ap.add_argument("--workload", choices=["syn", "fib"], default="syn", help="fib: only the fibonacci-guest leg at --log-rows, printed as the line's `fib` object "
-                    "with value / ms_per_step taken from it")
+    ap.add_argument("--queue", type=int, default=0, metavar="SHARDS", help="N = 1 too: deal SHARDS distinct shards through the claim queue (events -> traces -> proof); "
+                    "-1: 4 per GPU. The default for N > 1.")
     args = ap.parse_args()
     if args.tracegen:
-        return tracegen_bench(args)
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import bench_tracegen
+        args.log_rows = min(args.log_rows, 21)
+        return bench_tracegen.tracegen_bench(args)
 
-    from ziren_amd import farm as farm_mod
-    hp_holder = {}
-    farm = farm_mod.Farm(device_sync=lambda: hp_holder["hp"].ctx.synchronize() if "hp" in hp_holder else None)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))
+
+    from ziren_amd import abi, farm as farm_mod, prover
+    farm = farm_mod.Farm(backend="gloo" if os.environ.get("ZKM_BENCH_STUB_PROVER") == "1" else None)
     rank, local_rank, world = farm.rank, farm.local_rank, farm.world
-
+    if world != args.gpus:
+        farm.close()
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the process group has {world} rank(s) (WORLD_SIZE): refusing to print a line for another N")
     fri = abi.FriConfig(1, 84, 16)  # core config, crates/stark/src/kb31_poseidon2.rs:203-213
-    k = args.log_rows
-    if args.workload == "fib":
-        # the fibonacci guest's shard as the whole job: every rank proves its own copy (weak scaling), rank 0 prints
-        farm.barrier()
-        leg = fib_leg(local_rank, fri, k, max(1, args.steps), not args.interpreter)
-        farm.barrier()
-        slowest = farm.max_over_ranks(leg["prove"]["ms_per_proof"])
-        if rank == 0:
-            print(json.dumps({"metric": "shard-proofs/sec", "value": round(world * 1e3 / slowest, 4), "unit": "shard-proofs/s", "n_gpus": world,
-                              "steps": args.steps, "warmup": 1, "ms_per_step": round(slowest, 3), "higher_is_better": True, "scaling": "weak",
-                              "vs_baseline": None, "dtype": "u32", "data": "synthetic (the guest's events in closed form, ziren_amd/fibfast.py)",
-                              "config": {"workload": leg["workload"], "log_rows": k, "parallelism": f"{world} GPU(s) x 1 shard in flight, independent shards, no collective"},
-                              "fib": leg}))
-        farm.close()
-        return
-    shard = synth.syn_shard(k, seed=0x5A4B4D00 + 1000 * rank)
-    import threading
-    M = max(1, args.inflight)
-    lanes = []
-    for j in range(M):
-        hpj = prover.HipProver(shard.chips, fri, synth.NUM_PV_ELTS, device=local_rank, specialize=not args.interpreter)
-        pkj = hpj.setup([], [], shard.pc_start, shard.initial_global_cumulative_sum)
-        chj = prover.new_challenger()
-        pkj.observe_into(chj)
-        if args.from_host:  # traces live in page-locked host memory; every step uploads them again
-            trj = []
-            for c in shard.chips:
-                h = hpj.ctx.host_alloc(c.trace.shape)
-                h[...] = c.trace
-                trj.append(h)
+    if world > 1 or args.queue:
+        return queue_main(args, farm, fri)
+
+    # ---- N = 1: the resident-trace line ------------------------------------------------------------------------------------------------
+    wl = {"fib": lambda: FibWorkload("shaped", args.shard_size_log), "fib-tight": lambda: FibWorkload("tight", args.log_rows),
+          "syn": lambda: SynWorkload(args.log_rows)}[args.workload]()
+    ctx = prover.Context(local_rank)
+    farm.device_sync = ctx.synchronize
+    specialize = not args.interpreter
+    hp, pk, ch0 = wl.setup(ctx, fri, specialize)
+    traces = wl.resident_traces(ctx)            # inputs resident in HBM before timing
+    leg = resident_leg(farm, wl, hp, pk, ch0, traces, args.steps, args.warmup, args.kernel_timing)
+    verify_or_die(wl, fri, ch0, leg["proof"], wl.tag)
+    steps = args.steps
+    ms_per_step = leg["elapsed"] / steps * 1e3
+    roofline, valu, lde, kernels_ms, ksource = roofline_objects(wl, fri, leg, steps)
+    line = {"metric": "shard-proofs/sec", "value": round(steps / leg["elapsed"], 4), "unit": "shard-proofs/s", "n_gpus": 1, "steps": steps, "warmup": max(1, args.warmup),
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": wl.data, "verified": True,
+            "config": {"workload": wl.label, "chips": {c.name: c.log_height for c in wl.chips},
+                       "committed_cells": int(sum((1 << c.log_height) * (c.prep_width + c.main_width + 4 * c.perm_ext_width + (4 << c.log_quotient_degree)) for c in wl.chips)),
+                       "proof_words": int(len(leg["proof"])), "parallelism": "1 GPU x 1 shard in flight"},
+            "phases_ms": {n: round(v, 3) for n, v in leg["phases"].items()}, "kernels_ms": kernels_ms, "kernels_ms_source": ksource,
+            "roofline": roofline, "valu": valu, "lde": lde}
+    if wl.kind != "syn":
+        line["config"]["cycles"] = wl.cycles
+        line["config"]["event_generation_s"] = round(wl.event_generation_s, 2)
+        if wl.kind == "shaped":
+            line["config"]["shape"] = {"registered_under_log2_shard_size": wl.ds.shape_key[0], "cluster": wl.ds.shape_key[1], "shard_closed_by": wl.cut,
+                                       "reference": "crates/core/machine/src/shape/mod.rs:139-191, crates/core/executor/src/executor.rs:2429-2516"}
+    if not args.no_extra:
+        from ziren_amd import lib
+        lib.load().zkm_ctx_set_kernel_timing(ctx.h, C.c_int(0))
+        line["two_in_flight"] = two_in_flight_leg(wl, fri, local_rank, (hp, pk, ch0, traces, leg["out"]), specialize, steps)
+        for t in traces:
+            t.free()
+        traces = None
+        if wl.kind == "syn":
+            line["pcie_inclusive"] = pcie_leg(wl, hp, pk, ch0, leg["out"], steps)
         else:
-            trj = hpj.upload_traces([c.trace for c in shard.chips])  # inputs resident in HBM before timing
-        lib.load().zkm_ctx_set_kernel_timing(hpj.ctx.h, C.c_int(2 if args.kernel_timing == 3 else args.kernel_timing))
-        lanes.append((hpj, pkj, chj, trj, np.zeros(1 << 22, dtype=np.uint32)))
-    hp = lanes[0][0]
-    hp_holder["hp"] = hp
-    for c in shard.chips:
-        c.trace = None
-
-    def prove_on(j):
-        hpj, pkj, chj, trj, outj = lanes[j]
-        ch = chj.copy()  # challenger cloned per shard (prove.rs:496)
-        if args.from_host:
-            dev = [hpj.ctx.upload_async(h) for h in trj]   # queued tallest first; the proof waits per matrix on the device
-            proof = hpj.prove_shard(pkj, shard.public_values, dev, ch, out=outj)
-            for d in dev:
-                d.free()
-            return proof
-        return hpj.prove_shard(pkj, shard.public_values, trj, ch, out=outj)
-
-    def step():
-        if M == 1:
-            return prove_on(0)
-        ts = [threading.Thread(target=prove_on, args=(j,)) for j in range(1, M)]
-        for t in ts:
-            t.start()
-        prove_on(0)
-        for t in ts:
-            t.join()
-
-    phase_acc = {}
-    kern_acc = {}
-
-    def timed_step():
-        step()
-        for name, ms in hp.ctx.last_timings():
-            phase_acc[name] = phase_acc.get(name, 0.0) + ms
-        for name, ms, calls, nbytes in hp.ctx.kernel_timings():
-            a = kern_acc.setdefault(name, [0.0, 0, 0.0])
-            a[0] += ms
-            a[1] += calls
-            a[2] += nbytes
-
-    if args.queue:
-        # the farm as the reference runs it: distinct shards from one queue. The traces are this rank's resident set; what makes shard i its
-        # own shard is its transcript (the index is observed after the key), so every proof differs and every proof verifies
-        n_shards = args.queue if args.queue > 0 else 4 * world
-        hpj, pkj, chj, trj, outj = lanes[0]
-
-        def prove_shard_i(i):
-            ch = chj.copy()
-            idx = np.array([i + 1], dtype=np.uint32)
-            lib.load().zkm_challenger_observe(C.byref(ch), abi.as_u32p(idx), C.c_size_t(1))
-            return hpj.prove_shard(pkj, shard.public_values, trj, ch, out=outj)
-
-        for _ in range(max(1, args.warmup)):
-            prove_shard_i(0)
-        farm.barrier()
-        t0 = time.perf_counter()
-        ids, proofs = farm.run_queue(n_shards, prove_shard_i)
-        gathered = farm.gather_proofs(ids, proofs, n_shards)
-        farm.barrier()
-        elapsed = farm.max_over_ranks(time.perf_counter() - t0)
-        mine = float(np.mean(farm.host_ms)) if farm.host_ms else 0.0
-        slowest = farm.max_over_ranks(mine)
-        proved = farm.sum_over_ranks(float(len(ids)))
-        if rank == 0:
-            assert len(gathered) == n_shards and len({p.tobytes() for p in gathered}) == n_shards, "the gathered proofs are not distinct"
-            print(json.dumps({"metric": "shard-proofs/sec", "value": round(n_shards / elapsed, 4), "unit": "shard-proofs/s", "n_gpus": world,
-                              "steps": n_shards, "warmup": max(1, args.warmup), "ms_per_step": round(elapsed / n_shards * 1e3, 3),
-                              "higher_is_better": True, "scaling": "strong" if args.queue > 0 else "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
-                              "config": {"workload": f"SYN-{k}: {n_shards} distinct full shard proofs dealt from one queue (Farm.run_queue), proof streams gathered to rank 0 inside the timed region",
-                                         "log_rows": k, "parallelism": f"{world} GPU(s), claim queue, RCCL gather of {sum(len(p) for p in gathered) * 4} proof bytes"},
-                              "host_ms_per_shard": {"rank0_mean": round(mine, 3), "max_over_ranks_of_means": round(slowest, 3)},
-                              "shards_proved": int(proved), "shards_proved_by_rank0": len(ids)}))
-        farm.close()
-        return
-    for _ in range(args.warmup):
-        step()
-    # which kernel the roofline will be quoted on: the one with the most HIP-event time in the last warm-up step (every launch >= 256 KiB timed)
-    dominant, inst_acc, inst_steps, inst_ms = None, None, 0, None
-    if args.kernel_timing == 3 and M == 1 and args.warmup > 0:
-        last = hp.ctx.kernel_timings()
-        if last:
-            dominant = max(last, key=lambda t: t[1])[0]
-            lib.load().zkm_ctx_set_kernel_timing_only(hp.ctx.h, dominant.encode())
-    if M == 1:
-        elapsed = farm.timed(timed_step, steps=args.steps, warmup=0)
-        if dominant is not None:
-            # the per-kernel table: an extra pass with every launch >= 256 KiB timed, outside the timed region
-            lib.load().zkm_ctx_set_kernel_timing(hp.ctx.h, C.c_int(2))
-            inst_acc, inst_steps = {}, min(args.steps, 5)
-            t0 = time.perf_counter()
-            for _ in range(inst_steps):
-                step()
-                for name, ms, calls, nbytes in hp.ctx.kernel_timings():
-                    a = inst_acc.setdefault(name, [0.0, 0, 0.0])
-                    a[0] += ms
-                    a[1] += calls
-                    a[2] += nbytes
-            inst_ms = (time.perf_counter() - t0) / inst_steps * 1e3
+            ev, proof = events_leg(wl, hp, pk, ch0, leg["out"], min(steps, 6))
+            verify_or_die(wl, fri, ch0, proof, wl.tag + " events->proof")
+            ev["verified"] = True
+            line["events_to_proof"] = ev
+        extra = {}
+        also = [a for a in args.also.split(",") if a]
+        if wl.kind != "syn" and not args.no_syn:
+            also.append("syn22")
+        ctx.trim()
+        for name in also:
+            if name.startswith("syn"):
+                w2 = SynWorkload(int(name[3:]))
+            elif name.startswith("fibs"):
+                w2 = FibWorkload("shaped", int(name[4:]))
+            else:
+                w2 = FibWorkload("tight", int(name[3:]))
+            ctx2 = prover.Context(local_rank)
+            hp2, pk2, ch2 = w2.setup(ctx2, fri, specialize)
+            tr2 = w2.resident_traces(ctx2)
+            n2 = max(3, min(steps, 5))
+            leg2 = resident_leg(_LocalTimer(ctx2), w2, hp2, pk2, ch2, tr2, n2, 1, 2)
+            verify_or_die(w2, fri, ch2, leg2["proof"], w2.tag)
+            t = leg2["table"]
+            extra[name.upper() if name.startswith("syn") else name] = {
+                "workload": w2.label, "ms_per_step": round(leg2["elapsed"] / n2 * 1e3, 3), "value": round(n2 / leg2["elapsed"], 4), "unit": "shard-proofs/s", "steps": n2,
+                "verified": True, "kernels_ms": {k: round(v[0] / leg2["table_steps"], 3) for k, v in sorted(t.items(), key=lambda kv: -kv[1][0])[:8]}}
+            for x in tr2:
+                x.free()
+            ctx2.close()
+        if extra:
+            line["other_workloads"] = extra
+    if not args.no_cpu_baseline:
+        sample = args.cpu_sample_log if args.cpu_sample_log is not None else (20 if wl.kind == "syn" else 18 if wl.kind == "shaped" else 18)
+        line["cpu_baseline"] = cpu_baseline_leg(wl, fri, args.cpu_full, sample)
     else:
-        # M independent lanes, each proving K shards back to back (free-running: one lane's upload and
-        # transcript round trips overlap another lane's kernels); the timed region ends when all are done.
-        def run_all():
-            def loop(j):
-                time.sleep(0.04 * j)
-                for _ in range(args.steps):
-                    prove_on(j)
-            ts = [threading.Thread(target=loop, args=(j,)) for j in range(1, M)]
-            for t in ts:
-                t.start()
-            for _ in range(args.steps):
-                prove_on(0)
-                for name, ms in hp.ctx.last_timings():
-                    phase_acc[name] = phase_acc.get(name, 0.0) + ms
-                for name, ms, calls, nbytes in hp.ctx.kernel_timings():
-                    a = kern_acc.setdefault(name, [0.0, 0, 0.0])
-                    a[0] += ms
-                    a[1] += calls
-                    a[2] += nbytes
-            for t in ts:
-                t.join()
-        elapsed = farm.timed(run_all, steps=1, warmup=0)
-
-    if rank == 0:
-        steps = args.steps
-        ms_per_step = elapsed / steps * 1e3
-        value = world * M * steps / elapsed
-        alg_bytes = synth.shard_algorithmic_bytes(shard)
-        # dominant kernel by accumulated HIP-event time on the prover's stream
-        roofline = None
-        if kern_acc:
-            dom = max(kern_acc.items(), key=lambda kv: kv[1][0])
-            name, (ms, calls, nbytes) = dom
-            per_launch_ms = ms / max(calls, 1)
-            kbytes = nbytes / max(calls, 1)
-            achieved = kbytes / (per_launch_ms * 1e-3) / 1e9 if per_launch_ms > 0 else 0.0
-            # HBM bytes per launch: PMC counters cannot be read from inside this process, so the figure comes from the rocprofv3 --pmc
-            # passes of this same command kept under profiles/ (tools/profile_r03.sh) — and only if they were taken on these very
-            # kernel sources (the profile records their digest); otherwise null, never a stale number
-            traffic, traffic_source = None, None
-            tpath = os.path.join(ROOT, "profiles", "r03_syn22_hbm_traffic.json")
-            short = {"compress_layer": "merkle::compress_layer", "hash_leaves": "merkle::hash_leaves", "hash_leaves_tree": "merkle::hash_leaves_tree",
-                     "lde_rows": "lde::lde_rows_big"}.get(name)
-            if k == 22 and short and os.path.exists(tpath):
-                tj = json.load(open(tpath))
-                tk = tj["kernels"].get(short)
-                if tk and tj.get("csrc_digest") == csrc_digest():
-                    traffic = int(tk["hbm_bytes_per_launch"])
-                    traffic_source = {"file": "profiles/r03_syn22_hbm_traffic.json", "commit": tj.get("commit"), "csrc_digest": tj.get("csrc_digest")}
-                else:
-                    traffic_source = {"file": "profiles/r03_syn22_hbm_traffic.json", "stale": True,
-                                      "note": "taken on other kernel sources (csrc digest differs): not quoted"}
-            roofline = {"bound": "hbm", "kernel": name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
-                        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_source,
-                        "launches_per_step": calls // steps, "avg_launch_ms": round(per_launch_ms, 4),
-                        "algorithmic_bytes_per_launch": int(kbytes),
-                        "kernel_share_of_step": round(ms / steps / ms_per_step, 3),
-                        "whole_shard": {"algorithmic_bytes": alg_bytes,
-                                        "achieved": round(alg_bytes / (ms_per_step * 1e-3) / 1e9, 1),
-                                        "frac": round(alg_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}}
-        # SURVEY 8d asks for the VALU side next to the HBM fraction: the hashing kernels are bound by instruction issue, not by bytes.
-        # Poseidon2 runs on the FP64 vector pipe (csrc/poseidon2_f64.cuh); its ceiling is the chip's FP64 vector issue rate divided by
-        # the permutation's dynamic instruction count as the hardware counted it (SQ_INSTS_VALU, profiles/r03_poseidon2_isa.json)
-        valu = None
-        # the per-kernel table: from the timed region itself, or — when only the dominant kernel was timed there — from the pass after it
-        table, table_steps, table_step_ms = (inst_acc, inst_steps, inst_ms) if inst_acc else (kern_acc, steps, ms_per_step)
-        hashing = [n for n in ("compress_layer", "hash_leaves", "hash_leaves_tree", "hash_fri_leaves", "hash_fri_leaves_tree", "compress_small", "compress_tail")
-                   if n in table]
-        if hashing and M == 1:
-            perms = synth.shard_poseidon2_permutations(shard, fri.log_blowup)
-            hms = sum(table[n][0] for n in hashing) / table_steps
-            isa = poseidon2_isa()
-            per_perm = isa["fp64"]["valu_instr_per_permutation"] if isa else None
-            # one wave64 FP64 instruction = 64 lanes; the vector peak counts an FMA as 2 flop: instructions/s = TFLOPS / 2 / 64 per ... lane-instr
-            peak = FP64_VECTOR_TFLOPS * 1e12 / 2 / per_perm / 1e9 if per_perm else None
-            valu = {"bound": "fp64-vector-issue", "kernels": hashing, "poseidon2_permutations": perms, "ms": round(hms, 3),
-                    "achieved": round(perms / hms / 1e6, 3), "peak": round(peak, 2) if peak else None, "unit": "Gperm/s",
-                    "frac": round(perms / hms / 1e6 / peak, 3) if peak else None, "valu_instr_per_permutation": per_perm,
-                    "valu_instr_source": "profiles/r03_poseidon2_isa.json (SQ_INSTS_VALU / permutations, tools/ubench_p2)" if isa else None,
-                    "share_of_step": round(hms / table_step_ms, 3)}
-        # the coset LDE as a group (VERDICT r02 item 4): its three kernels' time, the algorithmic bytes 12 n w (read n w words, write 2 n w)
-        # of every committed column, and — from the PMC profile of these very sources — the bytes they really move through HBM
-        lde = None
-        lde_names = [n for n in ("lde_rows", "lde_cols_forward", "lde_cols_inverse") if n in table]
-        if lde_names and M == 1:
-            lde_ms = sum(table[n][0] for n in lde_names) / table_steps
-            cells = sum((1 << c.log_height) * (c.main_width + 4 * c.perm_ext_width + (4 << c.log_quotient_degree)) for c in shard.chips)
-            alg = 12.0 * cells
-            tr = None
-            tpath = os.path.join(ROOT, "profiles", "r03_syn22_hbm_traffic.json")
-            if k == 22 and os.path.exists(tpath):
-                tj = json.load(open(tpath))
-                if tj.get("csrc_digest") == csrc_digest():
-                    tr = sum(tj["kernels"][n]["hbm_bytes_total"] for n in ("lde::lde_rows_big", "lde::lde_cols<true>", "lde::lde_cols<false>") if n in tj["kernels"])
-            lde = {"ms": round(lde_ms, 3), "alg_GB": round(alg / 1e9, 3), "alg_GBps": round(alg / lde_ms / 1e6, 1), "frac_of_hbm_peak": round(alg / lde_ms / 1e6 / HBM_PEAK_GBPS, 4),
-                   "traffic_GB": round(tr / 1e9, 3) if tr else None, "ratio": round(tr / alg, 2) if tr else None,
-                   "structural_floor": "36 n w: a two-level split reads and writes the column three times (strided inverse, rows, strided forward)"}
-        # hardware-measured vector-pipe occupancy of the hashing kernels (rocprofv3 --pmc SQ_ACTIVE_INST_VALU / GRBM_GUI_ACTIVE over this
-        # command: tools/profile_r03.sh, definitions in tools/pmc_sq_summary.py), next to the derived valu.frac
-        if valu is not None:
-            spath = os.path.join(ROOT, "profiles", "r03_syn22_sq_counters.csv")
-            if os.path.exists(spath):
-                import csv
-                rows = {r["Name"]: r for r in csv.DictReader(open(spath))}
-                valu["valu_pipe_busy_pct_measured"] = {n: float(rows[n]["ValuPipeBusyPct(of SIMD time)"]) for n in ("merkle::compress_layer", "merkle::hash_leaves")
-                                                       if n in rows and rows[n].get("ValuPipeBusyPct(of SIMD time)")}
-                valu["valu_pipe_busy_source"] = "profiles/r03_syn22_sq_counters.csv"
-        cpu = None
-        if not args.no_cpu_baseline and world == 1:  # rank 0, N = 1 only
-            ks = k if args.cpu_full else min(args.cpu_sample_log_rows, k)
-            wall, lde_s, threads, shown, why = cpu_baseline(ks, fri)
-            # everything but the LDEs is linear in the rows; the LDEs (n log n) grow by (k + 1) / (ks + 1) on top (rows of the extended domain)
-            lin = 1 << (k - ks)
-            est = (wall - lde_s) * lin + lde_s * lin * (k + 1) / (ks + 1)
-            cpu = {"value": round(1.0 / est, 6), "unit": "shard-proofs/s", "cores": threads, "cores_available": threads, "host_logical_cpus": shown,
-                   "cores_note": why, "kind": "port",
-                   "sample": (f"oracle (CPU restatement, canonical `% p` arithmetic, OpenMP, {threads} threads) proving one SYN-{ks} shard in {wall:.2f} s "
-                              f"({lde_s:.2f} s of it coset LDEs)" + ("" if ks == k else f"; scaled to SYN-{k}: x{lin} for the linear phases, x{lin}*{k + 1}/{ks + 1} for the LDEs")),
-                   "measured_at_full_size": ks == k, "sample_seconds": round(wall, 3), "estimated_seconds_full_size": round(est, 2),
-                   "full_size_measurement": "profiles/r03_cpu_baseline_full.json (bench.py --cpu-full, the same proof at SYN-22 timed directly)"}
-        two = None
-        if world == 1 and M == 1 and not args.from_host and not args.no_inflight2:
-            # the same GPU with two shards in flight (a second context + host thread, its own copy of the traces): the launch gaps and
-            # host round trips of one proof are filled by the other's kernels. Throughput beside `value`; latency per proof doubles.
-            hp0, pk0, ch0, tr0, out0 = lanes[0]
-            hp1 = prover.HipProver(shard.chips, fri, synth.NUM_PV_ELTS, device=local_rank, specialize=not args.interpreter)
-            pk1 = hp1.setup([], [], shard.pc_start, shard.initial_global_cumulative_sum)
-            ch1 = prover.new_challenger()
-            pk1.observe_into(ch1)
-            tr1 = hp1.upload_traces([t.to_host() for t in tr0])
-            lib.load().zkm_ctx_set_kernel_timing(hp1.ctx.h, C.c_int(args.kernel_timing))
-            out1 = np.zeros(1 << 22, dtype=np.uint32)
-            both = ((hp0, pk0, ch0, tr0, out0), (hp1, pk1, ch1, tr1, out1))
-
-            def loop(lane, n):
-                hpj, pkj, chj, trj, outj = lane
-                for _ in range(n):
-                    hpj.prove_shard(pkj, shard.public_values, trj, chj.copy(), out=outj)
-
-            loop(both[1], 1)                       # warm the second context
-            n2 = max(2, min(steps, 8))
-            hp0.ctx.synchronize(); hp1.ctx.synchronize()
-            t0 = time.perf_counter()
-            th = threading.Thread(target=loop, args=(both[1], n2))
-            th.start()
-            loop(both[0], n2)
-            th.join()
-            hp0.ctx.synchronize(); hp1.ctx.synchronize()
-            dt = time.perf_counter() - t0
-            two = {"value": round(2 * n2 / dt, 4), "unit": "shard-proofs/s", "shards": 2 * n2, "ms_per_shard": round(dt / (2 * n2) * 1e3, 3),
-                   "note": "two contexts on the one GPU, each proving back to back; the default line keeps one shard in flight (lowest latency)"}
-            for t in tr1:
-                t.free()
-        pcie = None
-        if world == 1 and M == 1 and not args.from_host and not args.no_pcie:
-            # the boundary hands over host buffers (commit(record, traces)): the same step with the traces re-uploaded from page-locked
-            # host memory every time (slabbed DMA + transpose on their own streams). Reported beside `value`, never as `value`.
-            hpj, pkj, chj, trj, outj = lanes[0]
-            host = []
-            for t in trj:      # the resident traces go back to (page-locked) host memory, row-major as the reference holds them
-                h = hpj.ctx.host_alloc((t.height, t.width))
-                h[...] = t.to_host()
-                host.append(h)
-                t.free()
-
-            def from_host_step():
-                dev = [hpj.ctx.upload_async(h) for h in host]
-                hpj.prove_shard(pkj, shard.public_values, dev, chj.copy(), out=outj)
-                for d in dev:
-                    d.free()
-            from_host_step()
-            hpj.ctx.synchronize()
-            t0 = time.perf_counter()
-            n_host = min(3, steps)
-            for _ in range(n_host):
-                from_host_step()
-            hpj.ctx.synchronize()
-            dt = (time.perf_counter() - t0) / n_host
-            pcie = {"value": round(1.0 / dt, 4), "unit": "shard-proofs/s", "ms_per_step": round(dt * 1e3, 3), "steps": n_host,
-                    "host_bytes_per_step": int(sum(h.nbytes for h in host)),
-                    "note": "traces in page-locked host memory handed over every step (zkm_matrix_upload_async), upload overlapped with commit"}
-            for h in host:
-                hpj.ctx.host_free(h)
-        fib = None
-        if world == 1 and M == 1 and not args.from_host and args.fib:
-            for t in lanes[0][3]:          # the SYN traces are not needed any more
-                try:
-                    t.free()
-                except Exception:           # noqa: BLE001  (already handed back by the PCIe leg)
-                    pass
-            fib = {f"FIB-{kk}": fib_leg(local_rank, fri, int(kk), 3, not args.interpreter) for kk in args.fib.split(",")}
-        line = {"metric": "shard-proofs/sec", "value": round(value, 4), "unit": "shard-proofs/s", "n_gpus": world,
-                "steps": steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
-                "scaling": "weak", "vs_baseline": None, "dtype": "u32",
-                "data": "synthetic" + (" (traces re-uploaded from pinned host memory every step)" if args.from_host else ""),
-                "config": {"workload": f"SYN-{k}: full shard proof (commit+open), Cpu-like chip 2^{k} rows x 67 main "
-                                       f"cols + 7 smaller chips, blowup 2, 84 queries, 16 PoW bits",
-                           "log_rows": k, "parallelism": f"{world} GPU(s) x {M} shard(s) in flight, independent shards, no collective"},
-                "phases_ms": {n: round(v / steps, 3) for n, v in phase_acc.items()},
-                "kernels_ms": {n: {"ms": round(v[0] / table_steps, 3), "launches": v[1] // table_steps,
-                                   "GBps": round(v[2] / max(v[0], 1e-9) / 1e6, 1)} for n, v in
-                               sorted(table.items(), key=lambda kv: -kv[1][0])},
-                "kernels_ms_source": (f"a pass of {inst_steps} steps after the timed region with every launch >= 256 KiB timed ({inst_ms:.3f} ms per step: a timed "
-                                      f"launch costs a few microseconds of dispatch latency, ~250 launches per proof); inside the timed region only "
-                                      f"{dominant} is timed, and the roofline is computed from those launches") if inst_acc else "the timed region",
-                "roofline": roofline, "valu": valu, "lde": lde, "two_in_flight": two, "pcie_inclusive": pcie, "cpu_baseline": cpu, "fib": fib}
-        print(json.dumps(line))
+        line["cpu_baseline"] = None
+    print(json.dumps(line))
     farm.close()
+
+
+class _LocalTimer:
+    """farm.timed for a leg outside the main timed region (one process, no barrier)."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+
+    def timed(self, step, steps, warmup):
+        for _ in range(warmup):
+            step()
+        self.ctx.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        self.ctx.synchronize()
+        return time.perf_counter() - t0
 
 
 if __name__ == "__main__":

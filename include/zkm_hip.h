@@ -173,6 +173,17 @@ int zkm_matrix_upload(zkm_ctx* ctx, const uint32_t* host_row_major, size_t heigh
 int zkm_matrix_upload_async(zkm_ctx* ctx, const uint32_t* host_row_major, size_t height, size_t width,
                             zkm_matrix** out);
 int zkm_matrix_wait(zkm_ctx* ctx, const zkm_matrix* m);
+/* Executor events ahead of their trace generation. Queues the copy of `bytes` bytes of event records (any of the zkm_*_event arrays,
+ * page-locked for a true asynchronous copy) on the context's DMA stream and returns a device address at once. That address may be passed
+ * to the core-shard trace generators whose rows are a function of one event each (zkm_tracegen_alu / _jump / _mov_cond / _branch / _mul /
+ * _divrem / _memory_instrs / _misc_instrs / _syscall_instrs / _cpu / _cpu_and_program / _program_mults / _memory_local) in place of the host
+ * pointer: they then wait for the copy on the device instead of making their own. (zkm_tracegen_global and zkm_tracegen_syscall read their
+ * events on the host first and take host pointers only.) Called for shard i + 1 right before zkm_prove_shard of shard i, the transfer
+ * runs under that proof (the reference's prove-a-record loop hands records to the prover while the previous one is proving:
+ * crates/core/machine/src/utils/prove.rs:484-497). The host buffer must stay unchanged until a trace generator that used the address has
+ * returned, or zkm_events_free has. */
+int zkm_events_upload_async(zkm_ctx* ctx, const void* host_events, size_t bytes, void** device_events_out);
+void zkm_events_free(zkm_ctx* ctx, void* device_events);
 int zkm_matrix_download(zkm_ctx* ctx, const zkm_matrix* m, uint32_t* host_row_major);
 size_t zkm_matrix_height(const zkm_matrix* m);
 size_t zkm_matrix_width(const zkm_matrix* m);

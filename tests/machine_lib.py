@@ -146,9 +146,11 @@ class Device:
         return self.ctx.tracegen_program_mults(cpu, len(prog), pc_base, lh)
 
 
-def build_shard(src, machine, k):
+def build_shard(src, machine, k, shape=None):
     """The chips shard k includes (MachineAir::included: a chip with no events is left out; Program and Byte are always in) with their
-    traces from `src`. Returns the RecordedChips in machine order, Byte and Program last (prep indices 0 and 1 of the key)."""
+    traces from `src`. Returns the RecordedChips in machine order, Byte and Program last (prep indices 0 and 1 of the key).
+    `shape` ({MipsAirId name: log2 height}, a cpu shard only): the record's fixed shape (CoreShapeConfig::fix_shape) — a chip is in when the
+    shape names it, events or not, and every trace is padded to the shape's height."""
     sh = machine.shards[k]
     prog, pc_base, shard_no = machine.program, machine.pc_base, sh.pv["shard"]
     rec = sh.record
@@ -159,28 +161,41 @@ def build_shard(src, machine, k):
         chip.trace = trace
         out.append(chip)
 
+    def height(name, rows):
+        """log2 height of a chip, or None when the shard leaves it out."""
+        if shape is None:
+            return log2_rows(rows) if rows else None
+        if name not in shape:
+            assert not rows, (name, rows)
+            return None
+        assert rows <= (1 << shape[name]), (name, rows)
+        return shape[name]
+
+    assert shape is None or sh.kind == "cpu"
     if sh.kind == "cpu":
         rec = M.add_dependencies(rec)
-        lh = log2_rows(len(rec.cpu))
+        lh = height("Cpu", len(rec.cpu))
         add(chips.record_cpu_chip(lh), src.trace("cpu", rec.cpu, prog, pc_base, shard_no, lh))
         for chip in sorted(E.CHIP_NAMES):
             ev = rec.alu[chip]
-            if len(ev):
-                lh = log2_rows(len(ev))
+            lh = height(E.CHIP_NAMES[chip], len(ev))
+            if lh is not None:
                 add(chips.record_chip(chip, lh), src.trace("alu", chip, ev, lh))
                 alu_streams.append((chip, ev))
-        for name, ev, record in (("syscall_instrs", rec.syscall, chips.record_syscall_instrs_chip), ("jump", rec.jump, chips.record_jump_chip),
-                                 ("mov_cond", rec.mov_cond, chips.record_mov_cond_chip), ("branch", rec.branch, chips.record_branch_chip),
-                                 ("memory_instrs", rec.mem_instr, chips.record_memory_instrs_chip), ("misc_instrs", rec.misc, chips.record_misc_instrs_chip),
-                                 ("mul", rec.mul, chips.record_mul_chip), ("divrem", rec.divrem, chips.record_divrem_chip)):
-            if len(ev):
-                lh = log2_rows(len(ev))
+        for name, air, ev, record in (("syscall_instrs", "SyscallInstrs", rec.syscall, chips.record_syscall_instrs_chip), ("jump", "Jump", rec.jump, chips.record_jump_chip),
+                                      ("mov_cond", "MovCond", rec.mov_cond, chips.record_mov_cond_chip), ("branch", "Branch", rec.branch, chips.record_branch_chip),
+                                      ("memory_instrs", "MemoryInstrs", rec.mem_instr, chips.record_memory_instrs_chip),
+                                      ("misc_instrs", "MiscInstrs", rec.misc, chips.record_misc_instrs_chip),
+                                      ("mul", "Mul", rec.mul, chips.record_mul_chip), ("divrem", "DivRem", rec.divrem, chips.record_divrem_chip)):
+            lh = height(air, len(ev))
+            if lh is not None:
                 add(record(lh), src.trace(name, ev, lh))
         to_table = syscall_global_events(rec.syscall, False)
-        if len(to_table):
-            lh = log2_rows(len(to_table) // 2)
+        lh = height("SyscallCore", len(to_table) // 2)
+        if lh is not None:
             add(chips.record_syscall_table_chip(False, lh), src.trace("syscall_table", rec.syscall, False, lh))
-            glob.append(to_table)
+            if len(to_table):
+                glob.append(to_table)
     elif sh.kind == "precompile":
         lh = log2_rows(len(rec.precompile_syscall))
         add(chips.record_syscall_table_chip(True, lh), src.trace("syscall_table", rec.precompile_syscall, True, lh))
@@ -235,17 +250,18 @@ def build_shard(src, machine, k):
                 lh = log2_rows(len(ev))
                 add(chips.record_memory_global_chip(finalize, lh), src.trace("memory_global", ev, prev, lh))
                 glob.append(memory_global_events(ev, finalize))
-    if sh.kind != "memory" and len(rec.memory_local):
-        lh = log2_rows(-(-len(rec.memory_local) // M.MEMORY_LOCAL_ENTRIES_PER_ROW))
+    if sh.kind != "memory" and (len(rec.memory_local) or (shape is not None and "MemoryLocal" in shape)):
+        rows = -(-len(rec.memory_local) // M.MEMORY_LOCAL_ENTRIES_PER_ROW)
+        lh = log2_rows(rows) if shape is None else height("MemoryLocal", rows)
         add(chips.record_memory_local_chip(lh), src.trace("memory_local", rec.memory_local, lh))
         glob.insert(0, M.global_lookup_events(rec.memory_local))
     ge = np.concatenate(glob) if glob else np.zeros(0, dtype=M.GLOBAL_LOOKUP_EVENT)
-    if len(ge):
-        lh = log2_rows(len(ge))
+    if len(ge) or (shape is not None and "Global" in shape):
+        lh = log2_rows(len(ge)) if shape is None else height("Global", len(ge))
         add(chips.record_global_chip(lh), src.trace("global", ge, lh))
     byte = chips.record_byte_chip(prep_index=0)
     byte.trace = src.byte_trace(alu_streams)
-    plh = log2_rows(len(prog))
+    plh = log2_rows(len(prog)) if shape is None else shape["Program"]
     program = chips.record_program_chip(plh, prep_index=1)
     program.trace = src.program_mults(rec.cpu, prog, pc_base, plh)
     return out + [byte, program]

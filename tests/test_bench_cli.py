@@ -1,0 +1,55 @@
+"""bench.py's command line where it does not need a GPU: `--gpus N` must mean N.
+
+The prover is stubbed (ZKM_BENCH_STUB_PROVER=1 -> bench.StubLane, gloo): what runs is the real launch, claim queue with one shard claimed
+ahead, gather to rank 0 and the JSON line."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(args, env_extra, timeout=240):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def test_gpus_2_without_a_launcher_starts_two_ranks_and_prints_one_line():
+    r = _run(["--gpus", "2"], {"ZKM_BENCH_STUB_PROVER": "1"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["config"]["ranks_in_process_group"] == 2 and line["stub"] is True
+    assert line["steps"] == 8 and line["shards_proved"] == 8 and line["scaling"] == "weak"          # 4 shards per GPU
+    assert line["fewest_shards_on_a_rank"] >= 1 and line["verified"] is True
+    assert "claim queue" in line["config"]["parallelism"]
+
+
+def test_gpus_must_agree_with_the_process_group():
+    """A launcher that sets WORLD_SIZE=1 for a `--gpus 2` command gets an error, never a line that says n_gpus 1."""
+    r = _run(["--gpus", "2"], {"ZKM_BENCH_STUB_PROVER": "1", "WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and not r.stdout.strip()
+    assert "refusing" in r.stderr
+
+
+def test_under_torchrun_style_env_the_queue_runs_with_three_ranks():
+    """The driver's way: every rank started by a launcher with RANK / WORLD_SIZE / MASTER_* set (here by hand, world 3, strong scaling
+    over 7 shards: the ranks cannot all get the same number)."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for rank in range(3):
+        env = {k: v for k, v in os.environ.items()}
+        env.update({"ZKM_BENCH_STUB_PROVER": "1", "RANK": str(rank), "LOCAL_RANK": str(rank), "WORLD_SIZE": "3", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--queue", "7"], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=240) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [o[1][-1500:] for o in outs]
+    line = json.loads(outs[0][0].strip().splitlines()[-1])
+    assert not outs[1][0].strip() and not outs[2][0].strip()           # only rank 0 prints
+    assert line["n_gpus"] == 3 and line["steps"] == 7 and line["shards_proved"] == 7 and line["scaling"] == "strong"

@@ -80,17 +80,9 @@ def test_gpu_fibonacci_loop_shard_bit_exact_and_verified(hip_ctx, oracle):
         t.free()
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize("log_cycles", [20])
-def test_gpu_fibonacci_full_size_shard_is_accepted_by_the_verifier(hip_ctx, oracle, log_cycles):
-    """The same at the size the benchmark runs (2^20 here; bench.py's fib leg proves 2^21 = MAX_SHARD_SIZE and 2^22): too large for the
-    oracle to prove in a test, so the size-independent check is the verifier's: the restated verify_shard (constraints at zeta against the
-    quotient, FRI queries, Merkle paths, proof of work) accepts the GPU proof and rejects it with one opened value changed."""
+def _gpu_prove_fib(hip_ctx, oracle, m, ds, keep_traces=False):
     from ziren_amd import abi, field as F, prover, synth
     from test_machine import ZERO_DIGEST
-    m = fibfast.full_shard(log_cycles)
-    ds = fibfast.DeviceShard(m)
-    assert ds.chips[0].name == "Cpu" and ds.chips[0].log_height == log_cycles
     fri = abi.FriConfig(1, 84, 16)
     hp = prover.HipProver(ds.chips, fri, synth.NUM_PV_ELTS, ctx=hip_ctx)
     hp.specialize_quotient_kernels(ds.chips)
@@ -104,9 +96,115 @@ def test_gpu_fibonacci_full_size_shard_is_accepted_by_the_verifier(hip_ctx, orac
     start = ch.copy()
     born = ds.traces(hip_ctx)
     proof = hp.prove_shard(pk, ds.public_values, born, ch).copy()
+    host = [t.to_host() for t in born] if keep_traces else None
     for t in born:
         t.free()
-    assert oracle.verify_shard(opk, ds.chips, fri, synth.NUM_PV_ELTS, start.copy(), proof) == 0
+    hip_ctx.trim()
+    return fri, opk, start, ch, proof, host
+
+
+def _accepts_and_rejects(oracle, opk, chips, fri, start, proof):
+    from ziren_amd import synth
+    assert oracle.verify_shard(opk, chips, fri, synth.NUM_PV_ELTS, start.copy(), proof) == 0
     bad = proof.copy()
     bad[40] ^= 1
-    assert oracle.verify_shard(opk, ds.chips, fri, synth.NUM_PV_ELTS, start.copy(), bad) != 0
+    assert oracle.verify_shard(opk, chips, fri, synth.NUM_PV_ELTS, start.copy(), bad) != 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("log_cycles", [20, 21, 22])
+def test_gpu_fibonacci_full_size_shard_is_accepted_by_the_verifier(hip_ctx, oracle, log_cycles):
+    """The tight shards at the sizes bench.py can run (--workload fib-tight; 2^21 = MAX_SHARD_SIZE, 2^22 = BASELINE's row count): too large
+    for the oracle to prove in a test, so the size-independent check is the verifier's: the restated verify_shard (constraints at zeta
+    against the quotient, FRI queries, Merkle paths, proof of work) accepts the GPU proof and rejects it with one opened value changed."""
+    m = fibfast.full_shard(log_cycles)
+    ds = fibfast.DeviceShard(m)
+    assert ds.chips[0].name == "Cpu" and ds.chips[0].log_height == log_cycles
+    fri, opk, start, _, proof, _ = _gpu_prove_fib(hip_ctx, oracle, m, ds)
+    _accepts_and_rejects(oracle, opk, ds.chips, fri, start, proof)
+
+
+@pytest.mark.gpu
+def test_gpu_fibonacci_2pow18_shard_bit_exact(hip_ctx, oracle):
+    """2^18 cycles of the guest: device-born traces of every chip equal to the oracle's rows, and the whole GPU proof word for word equal to
+    the oracle's (the largest fibonacci shard the oracle proves inside the GPU-test budget)."""
+    from ziren_amd import synth
+    m = fibfast.full_shard(18)
+    ds = fibfast.DeviceShard(m)
+    ocs = _oracle_side(oracle, m)
+    fri, opk, start, ch, proof, host = _gpu_prove_fib(hip_ctx, oracle, m, ds, keep_traces=True)
+    for t, o in zip(host, ocs):
+        assert np.array_equal(t, o.trace), o.name
+    och = oracle.new_challenger()
+    opk.observe_into(och)
+    oproof, _ = oracle.prove_shard(opk, ocs, [c.trace for c in ocs], ds.public_values, fri, synth.NUM_PV_ELTS, och)
+    assert len(proof) == len(oproof) and np.array_equal(proof, oproof) and ch.as_tuple() == och.as_tuple()
+
+
+# ---- the shard as the reference shapes it (ziren_amd/shape.py) ----------------------------------------------------------------------------
+
+def _oracle_side_shaped(oracle, m, ds):
+    import machine_lib as ML
+    ocs = ML.build_shard(ML.Oracle(oracle), m, 0, shape=ds.shape)
+    ocs[-2].prep_trace = oracle.tracegen_byte_table()
+    ocs[-1].prep_trace = oracle.tracegen_program(0, m.shards[0].record.cpu, m.program, m.pc_base, ds.plh)
+    return ocs
+
+
+def test_shape_fixed_shard_on_the_oracle_proves_and_verifies(oracle):
+    """CPU only: a shard cut and shaped as the reference does (SHARD_SIZE 2^13 here) — every chip the shape names is in, with or without
+    events, at the shape's height, Program at 2^19 — proved and verified by the restatement: the zero-event chips' padded traces satisfy
+    their AIRs and the LogUp sums still cancel."""
+    from ziren_amd import abi, field as F, synth
+    from test_machine import ZERO_DIGEST
+    m, cycles, why = fibfast.shaped_shard(1 << 13)
+    ds = fibfast.DeviceShard(m, shape="fix")
+    assert ds.shape["Program"] == 19 and ds.shape["Byte"] == 16 and ds.plh == 19
+    zero_event = [n for n, ev, _, _ in ds.work if not len(ev)]
+    assert {"Bitwise", "ShiftLeft", "ShiftRight", "Jump", "MemoryInstrs"} <= set(zero_event)
+    ocs = _oracle_side_shaped(oracle, m, ds)
+    assert [c.name for c in ds.chips] == [c.name for c in ocs] and [c.log_height for c in ds.chips] == [c.log_height for c in ocs]
+    fri = abi.FriConfig(1, 20, 8)
+    pc_start = F.to_monty(m.pc_base)
+    opk = oracle.Pk([ocs[-2].prep_trace, ocs[-1].prep_trace], [0, 0], pc_start, ZERO_DIGEST, 1)
+    ch = oracle.new_challenger()
+    opk.observe_into(ch)
+    start = ch.copy()
+    proof, _ = oracle.prove_shard(opk, ocs, [c.trace for c in ocs], ds.public_values, fri, synth.NUM_PV_ELTS, ch)
+    assert oracle.verify_shard(opk, ocs, fri, synth.NUM_PV_ELTS, start, proof) == 0
+
+
+@pytest.mark.gpu
+def test_gpu_shape_fixed_shard_bit_exact(hip_ctx, oracle):
+    """The shaped shard at SHARD_SIZE 2^15: device-born traces (zero-event chips included) equal to the oracle's, GPU proof word for word
+    equal to the oracle's, accepted by the verifier; and the same events through `prefetch` (zkm_events_upload_async) give the same traces."""
+    from ziren_amd import synth
+    m, cycles, why = fibfast.shaped_shard(1 << 15)
+    ds = fibfast.DeviceShard(m, shape="fix")
+    ocs = _oracle_side_shaped(oracle, m, ds)
+    fri, opk, start, ch, proof, host = _gpu_prove_fib(hip_ctx, oracle, m, ds, keep_traces=True)
+    for t, o in zip(host, ocs):
+        assert np.array_equal(t, o.trace), o.name
+    och = oracle.new_challenger()
+    opk.observe_into(och)
+    oproof, _ = oracle.prove_shard(opk, ocs, [c.trace for c in ocs], ds.public_values, fri, synth.NUM_PV_ELTS, och)
+    assert np.array_equal(proof, oproof) and ch.as_tuple() == och.as_tuple()
+    _accepts_and_rejects(oracle, opk, ocs, fri, start, proof)
+    ds.pin(hip_ctx)
+    pre = ds.prefetch(hip_ctx)
+    assert {"Cpu", "AddSub", "Lt", "Mul", "DivRem", "Branch", "MemoryLocal"} <= set(pre)
+    again = ds.traces(hip_ctx, pre)
+    for t, want in zip(again, host):
+        assert np.array_equal(t.to_host(), want)
+        t.free()
+
+
+@pytest.mark.gpu
+def test_gpu_benchmarked_shape_fixed_shard_is_accepted_by_the_verifier(hip_ctx, oracle):
+    """bench.py's default workload at full size: SHARD_SIZE = 2^21 -> 1 569 808 cycles, Cpu padded to 2^22 rows, 16 core chips + Byte +
+    Program(2^19): accepted by the restated verifier, rejected with one opened value changed."""
+    m, cycles, why = fibfast.shaped_shard(1 << 21)
+    ds = fibfast.DeviceShard(m, shape="fix")
+    assert why == "shape" and ds.shape["Cpu"] == 22 and len(ds.chips) == 18
+    fri, opk, start, _, proof, _ = _gpu_prove_fib(hip_ctx, oracle, m, ds)
+    _accepts_and_rejects(oracle, opk, ds.chips, fri, start, proof)

@@ -29,26 +29,25 @@ static int tracegen_events(zkm_ctx* ctx, int chip, const void* events, size_t n_
   try {
     m->d = ctx->alloc_n<uint32_t>(height * w);
     const size_t event_bytes = 4 * (size_t)tracegen::event_words(chip);
-    d_events = (uint32_t*)ctx->alloc(std::max<size_t>(n_events * event_bytes, 4));
-    if (n_events) HIP_CHECK(hipMemcpyAsync(d_events, events, n_events * event_bytes, hipMemcpyHostToDevice, ctx->stream));
+    const uint32_t* dev_events = ctx->events_on_device(events, n_events * event_bytes, &d_events);
     uint32_t* counts = blu ? blu->counts : nullptr;
     switch (chip) {
-      case tracegen::ADD_SUB: launch_alu_rows<tracegen::ADD_SUB>(ctx, d_events, n_events, height, m->d, counts); break;
-      case tracegen::BITWISE: launch_alu_rows<tracegen::BITWISE>(ctx, d_events, n_events, height, m->d, counts); break;
-      case tracegen::LT: launch_alu_rows<tracegen::LT>(ctx, d_events, n_events, height, m->d, counts); break;
-      case tracegen::SHIFT_LEFT: launch_alu_rows<tracegen::SHIFT_LEFT>(ctx, d_events, n_events, height, m->d, counts); break;
-      case tracegen::SHIFT_RIGHT: launch_alu_rows<tracegen::SHIFT_RIGHT>(ctx, d_events, n_events, height, m->d, counts); break;
-      case tracegen::CLO_CLZ: launch_alu_rows<tracegen::CLO_CLZ>(ctx, d_events, n_events, height, m->d, counts); break;
-      case tracegen::JUMP: launch_alu_rows<tracegen::JUMP>(ctx, d_events, n_events, height, m->d, counts); break;
-      case tracegen::MOV_COND: launch_alu_rows<tracegen::MOV_COND>(ctx, d_events, n_events, height, m->d, counts); break;
-      case tracegen::BRANCH: launch_alu_rows<tracegen::BRANCH>(ctx, d_events, n_events, height, m->d, counts); break;
-      case tracegen::MUL: launch_alu_rows<tracegen::MUL>(ctx, d_events, n_events, height, m->d, counts); break;
-      case tracegen::DIVREM: launch_alu_rows<tracegen::DIVREM>(ctx, d_events, n_events, height, m->d, counts); break;
-      case tracegen::MEMORY_INSTRS: launch_alu_rows<tracegen::MEMORY_INSTRS>(ctx, d_events, n_events, height, m->d, counts); break;
-      case tracegen::SYSCALL_INSTRS: launch_alu_rows<tracegen::SYSCALL_INSTRS>(ctx, d_events, n_events, height, m->d, counts); break;
-      case tracegen::MISC_INSTRS: launch_alu_rows<tracegen::MISC_INSTRS>(ctx, d_events, n_events, height, m->d, counts); break;
-      case tracegen::SYSCALL_CORE: launch_alu_rows<tracegen::SYSCALL_CORE>(ctx, d_events, n_events, height, m->d, counts); break;
-      case tracegen::SYSCALL_PRECOMPILE: launch_alu_rows<tracegen::SYSCALL_PRECOMPILE>(ctx, d_events, n_events, height, m->d, counts); break;
+      case tracegen::ADD_SUB: launch_alu_rows<tracegen::ADD_SUB>(ctx, dev_events, n_events, height, m->d, counts); break;
+      case tracegen::BITWISE: launch_alu_rows<tracegen::BITWISE>(ctx, dev_events, n_events, height, m->d, counts); break;
+      case tracegen::LT: launch_alu_rows<tracegen::LT>(ctx, dev_events, n_events, height, m->d, counts); break;
+      case tracegen::SHIFT_LEFT: launch_alu_rows<tracegen::SHIFT_LEFT>(ctx, dev_events, n_events, height, m->d, counts); break;
+      case tracegen::SHIFT_RIGHT: launch_alu_rows<tracegen::SHIFT_RIGHT>(ctx, dev_events, n_events, height, m->d, counts); break;
+      case tracegen::CLO_CLZ: launch_alu_rows<tracegen::CLO_CLZ>(ctx, dev_events, n_events, height, m->d, counts); break;
+      case tracegen::JUMP: launch_alu_rows<tracegen::JUMP>(ctx, dev_events, n_events, height, m->d, counts); break;
+      case tracegen::MOV_COND: launch_alu_rows<tracegen::MOV_COND>(ctx, dev_events, n_events, height, m->d, counts); break;
+      case tracegen::BRANCH: launch_alu_rows<tracegen::BRANCH>(ctx, dev_events, n_events, height, m->d, counts); break;
+      case tracegen::MUL: launch_alu_rows<tracegen::MUL>(ctx, dev_events, n_events, height, m->d, counts); break;
+      case tracegen::DIVREM: launch_alu_rows<tracegen::DIVREM>(ctx, dev_events, n_events, height, m->d, counts); break;
+      case tracegen::MEMORY_INSTRS: launch_alu_rows<tracegen::MEMORY_INSTRS>(ctx, dev_events, n_events, height, m->d, counts); break;
+      case tracegen::SYSCALL_INSTRS: launch_alu_rows<tracegen::SYSCALL_INSTRS>(ctx, dev_events, n_events, height, m->d, counts); break;
+      case tracegen::MISC_INSTRS: launch_alu_rows<tracegen::MISC_INSTRS>(ctx, dev_events, n_events, height, m->d, counts); break;
+      case tracegen::SYSCALL_CORE: launch_alu_rows<tracegen::SYSCALL_CORE>(ctx, dev_events, n_events, height, m->d, counts); break;
+      case tracegen::SYSCALL_PRECOMPILE: launch_alu_rows<tracegen::SYSCALL_PRECOMPILE>(ctx, dev_events, n_events, height, m->d, counts); break;
     }
     ctx->mark("trace generation");
     ctx->end_timing(false);  // synchronises: the caller's event buffer is free again
@@ -187,17 +186,16 @@ int zkm_tracegen_cpu_and_program(zkm_ctx* ctx, const zkm_cpu_event* events, size
       pm->d = ctx->alloc_n<uint32_t>(pheight);
       HIP_CHECK(hipMemsetAsync(pm->d, 0, pheight * 4, ctx->stream));
     }
-    d_events = (uint32_t*)ctx->alloc(std::max<size_t>(n_events * sizeof(zkm_cpu_event), 4));
+    const uint32_t* dev_events = ctx->events_on_device(events, n_events * sizeof(zkm_cpu_event), &d_events);
     d_program = (uint32_t*)ctx->alloc(std::max<size_t>(n_instr * sizeof(zkm_instruction), 4));
     d_bad = (int*)ctx->alloc(4);
     HIP_CHECK(hipMemsetAsync(d_bad, 0, 4, ctx->stream));
-    if (n_events) HIP_CHECK(hipMemcpyAsync(d_events, events, n_events * sizeof(zkm_cpu_event), hipMemcpyHostToDevice, ctx->stream));
     if (n_instr) HIP_CHECK(hipMemcpyAsync(d_program, program, n_instr * sizeof(zkm_instruction), hipMemcpyHostToDevice, ctx->stream));
     uint32_t* counts = blu ? blu->counts : nullptr;
     const int tiles = counts ? tracegen::TILES_PER_BLOCK : 1;
     KLAUNCH(ctx, "tracegen_cpu", 280.0 * n_events + 4.0 * height * tracegen::CPU_WIDTH, tracegen::cpu_rows,
             dim3(div_up(height, (size_t)tiles * tracegen::THREADS)), dim3(tracegen::THREADS),
-            counts ? 2 * tracegen::HASH_SLOTS * sizeof(uint32_t) : 0, (const uint32_t*)d_events, n_events, (const uint32_t*)d_program, n_instr,
+            counts ? 2 * tracegen::HASH_SLOTS * sizeof(uint32_t) : 0, dev_events, n_events, (const uint32_t*)d_program, n_instr,
             pc_base, shard, height, m->d, counts, tiles, d_bad, pm ? pm->d : (uint32_t*)nullptr);
     if (pm) {
       hipLaunchKernelGGL(tracegen::counts_to_field, dim3(div_up(pheight, 256)), dim3(256), 0, ctx->stream, pm->d, pheight);
@@ -275,10 +273,9 @@ int zkm_tracegen_program_mults(zkm_ctx* ctx, const zkm_cpu_event* events, size_t
   try {
     m->d = ctx->alloc_n<uint32_t>(height);
     HIP_CHECK(hipMemsetAsync(m->d, 0, height * 4, ctx->stream));
-    d_events = (uint32_t*)ctx->alloc(std::max<size_t>(n_events * sizeof(zkm_cpu_event), 4));
+    const uint32_t* dev_events = ctx->events_on_device(events, n_events * sizeof(zkm_cpu_event), &d_events);
     if (n_events) {
-      HIP_CHECK(hipMemcpyAsync(d_events, events, n_events * sizeof(zkm_cpu_event), hipMemcpyHostToDevice, ctx->stream));
-      hipLaunchKernelGGL(tracegen::program_count, dim3(div_up(n_events, 256)), dim3(256), 0, ctx->stream, (const uint32_t*)d_events, n_events,
+      hipLaunchKernelGGL(tracegen::program_count, dim3(div_up(n_events, 256)), dim3(256), 0, ctx->stream, dev_events, n_events,
                          n_instr, pc_base, m->d);
       LAUNCH_CHECK();
     }
@@ -309,10 +306,9 @@ int zkm_tracegen_memory_local(zkm_ctx* ctx, const zkm_memory_local_event* events
   uint32_t* d_events = nullptr;
   try {
     m->d = ctx->alloc_n<uint32_t>(height * m->w);
-    d_events = (uint32_t*)ctx->alloc(std::max<size_t>(n_events * sizeof(zkm_memory_local_event), 4));
-    if (n_events) HIP_CHECK(hipMemcpyAsync(d_events, events, n_events * sizeof(zkm_memory_local_event), hipMemcpyHostToDevice, ctx->stream));
+    const uint32_t* dev_events = ctx->events_on_device(events, n_events * sizeof(zkm_memory_local_event), &d_events);
     hipLaunchKernelGGL(tracegen::memory_local_rows, dim3(div_up(height * tracegen::MEMORY_LOCAL_ENTRIES, (size_t)256)), dim3(256), 0, ctx->stream,
-                       (const uint32_t*)d_events, n_events, height, m->d);
+                       dev_events, n_events, height, m->d);
     LAUNCH_CHECK();
     HIP_CHECK(hipStreamSynchronize(ctx->stream));
   } catch (...) {

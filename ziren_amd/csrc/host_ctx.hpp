@@ -85,6 +85,25 @@ struct zkm_ctx {
   int up_next = 0;
   static constexpr size_t UP_SLAB_BYTES = (size_t)32 << 20;
   hipStream_t cur = nullptr;      // where KLAUNCH / upload / kernel-timing events go right now
+  // executor events copied ahead of their trace generation (zkm_events_upload_async): device address -> (bytes, "landed" event)
+  struct Prefetched { size_t bytes; hipEvent_t landed; };
+  std::map<const void*, Prefetched> prefetched;
+  // The device copy of a chip's events for a zkm_tracegen_* call. `events` is either a host pointer — copied now, on the compute
+  // stream, into a pool buffer the caller releases (`owned` = true) — or an address zkm_events_upload_async returned: the compute
+  // stream then only waits for that copy to have landed (the upload ran on the DMA stream, typically under the previous shard's proof).
+  const uint32_t* events_on_device(const void* events, size_t bytes, uint32_t** owned) {
+    *owned = nullptr;
+    auto it = prefetched.find(events);
+    if (it != prefetched.end()) {
+      if (bytes > it->second.bytes) throw std::runtime_error("zkm_tracegen: more events asked for than zkm_events_upload_async copied");
+      HIP_CHECK(hipStreamWaitEvent(stream, it->second.landed, 0));
+      return (const uint32_t*)events;
+    }
+    uint32_t* d = (uint32_t*)alloc(std::max<size_t>(bytes, 4));
+    *owned = d;
+    if (bytes) HIP_CHECK(hipMemcpyAsync(d, events, bytes, hipMemcpyHostToDevice, stream));
+    return d;
+  }
   std::mutex mu;
   std::multimap<size_t, void*> free_list;  // caching allocator: exact-size reuse
   std::map<void*, size_t> live;

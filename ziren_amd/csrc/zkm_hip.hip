@@ -358,6 +358,47 @@ void zkm_matrix_free(zkm_ctx* ctx, zkm_matrix* m) {
   delete m;
 }
 
+// Executor events ahead of time: the copy is queued on the DMA stream and the call returns; a later zkm_tracegen_* call that is given the
+// returned address instead of a host pointer finds the events in HBM. Issued right before zkm_prove_shard of shard i for the events of
+// shard i + 1, the PCIe transfer runs under shard i's kernels (one context, one host thread; the copy engine and the compute queue do
+// not contend). `host` should be page-locked (zkm_host_alloc) — a pageable source makes the runtime stage the copy synchronously.
+int zkm_events_upload_async(zkm_ctx* ctx, const void* host, size_t bytes, void** device_out) {
+  API_BEGIN
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIP_CHECK(hipSetDevice(ctx->device));
+  if (bytes && !host) throw std::runtime_error("zkm_events_upload_async: null events");
+  if (!ctx->up_dma) HIP_CHECK(hipStreamCreateWithFlags(&ctx->up_dma, hipStreamNonBlocking));
+  void* d = ctx->alloc(std::max<size_t>(bytes, 4));
+  hipEvent_t landed = nullptr;
+  try {
+    HIP_CHECK(hipEventCreateWithFlags(&landed, hipEventDisableTiming));
+    // pool buffers come back in compute-stream order: the DMA stream first waits for what the compute stream has queued so far
+    hipEvent_t reuse = ctx->get_event();
+    HIP_CHECK(hipEventRecord(reuse, ctx->stream));
+    HIP_CHECK(hipStreamWaitEvent(ctx->up_dma, reuse, 0));
+    ctx->event_pool.push_back(reuse);
+    if (bytes) HIP_CHECK(hipMemcpyAsync(d, host, bytes, hipMemcpyHostToDevice, ctx->up_dma));
+    HIP_CHECK(hipEventRecord(landed, ctx->up_dma));
+  } catch (...) {
+    if (landed) (void)hipEventDestroy(landed);
+    ctx->release(d);
+    throw;
+  }
+  ctx->prefetched[d] = {bytes, landed};
+  *device_out = d;
+  API_END
+}
+void zkm_events_free(zkm_ctx* ctx, void* device_events) {
+  if (!device_events) return;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  auto it = ctx->prefetched.find(device_events);
+  if (it == ctx->prefetched.end()) return;
+  (void)hipEventSynchronize(it->second.landed);   // never hand a buffer back to the pool while its upload is in flight
+  (void)hipEventDestroy(it->second.landed);
+  ctx->prefetched.erase(it);
+  ctx->release(device_events);
+}
+
 int zkm_pcs_commit(zkm_ctx* ctx, size_t n_mats, const zkm_matrix* const* mats, const uint32_t* domain_shifts, uint32_t log_blowup,
                    uint32_t root_out[8], zkm_pcs_data** out) {
   API_BEGIN

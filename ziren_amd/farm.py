@@ -69,7 +69,9 @@ class Farm:
                     torch.cuda.synchronize()
             else:
                 self.device = torch.device("cpu")
-                dist.init_process_group(backend=backend)
+                with _stdout_to_stderr():       # gloo announces its peers on stdout
+                    dist.init_process_group(backend=backend)
+                    dist.barrier()
             self.dist = dist
             self.torch = torch
 
@@ -124,22 +126,34 @@ class Farm:
         store = self.dist.distributed_c10d._get_default_store()
         return int(store.add(key, 1)) - 1
 
-    def run_queue(self, n_shards: int, prove: Callable[[int], np.ndarray], queue: str = "shards"):
+    def run_queue(self, n_shards: int, prove: Callable, queue: str = "shards", prefetch: Optional[Callable] = None):
         """Prove shards of one batch until its queue is empty; returns ([shard ids this rank proved], [their proof streams]). Calling
         it again deals a new batch (a fresh counter). `self.host_ms` collects, per shard proven here, the wall-clock milliseconds of
         its `prove` call (what a rank spends per shard including host work: the number that limits an 8-GPU node once events, not
-        resident traces, are the input)."""
+        resident traces, are the input).
+
+        With `prefetch`, the rank claims one shard ahead: `prefetch(j)` is called for the next shard before `prove(i, handle_i)` of the
+        current one, so the next shard's input (the executor's events) crosses PCIe while the current one is proven — the records and
+        traces channel of the reference holds one record ahead of the prover the same way (crates/stark/src/opts.rs:11,
+        DEFAULT_RECORDS_AND_TRACES_CHANNEL_CAPACITY = 1)."""
         ids, proofs = [], []
         self.host_ms = []
         try:
-            while True:
-                i = self.claim(queue)
-                if i >= n_shards:
-                    break
+            cur = self.claim(queue)
+            handle = prefetch(cur) if (prefetch is not None and cur < n_shards) else None
+            while cur < n_shards:
                 t0 = time.perf_counter()
-                ids.append(i)
-                proofs.append(np.asarray(prove(i), dtype=np.uint32).copy())
+                nxt, nxt_handle = n_shards, None
+                if prefetch is not None:
+                    nxt = self.claim(queue)
+                    if nxt < n_shards:
+                        nxt_handle = prefetch(nxt)
+                ids.append(cur)
+                proofs.append(np.asarray(prove(cur, handle) if prefetch is not None else prove(cur), dtype=np.uint32).copy())
                 self.host_ms.append(1e3 * (time.perf_counter() - t0))
+                if prefetch is None:
+                    nxt = self.claim(queue)
+                cur, handle = nxt, nxt_handle
         finally:
             self._epochs[queue] = self._epochs.get(queue, 0) + 1
         return ids, proofs

@@ -191,6 +191,28 @@ def fib_shard(n, shard_cycles, shard_no, pc_base=0x1000):
     return M.Machine(program_array(n, pc_base), [M.Shard("cpu", rec, pv)], pc_base)
 
 
+def loop_event_estimate(cycles):
+    """estimate_mips_event_counts (crates/core/executor/src/cost.rs:96-195) after `cycles` cycles of the loop: opcode counts (four ADDs, a MODU
+    — counted under DivRem — and a BNE per six cycles), Mul and Lt raised by the DivRem count (:189-190), the six registers as touched
+    addresses (MemoryLocal rows of four, two Global messages each); the other dependency events are not estimated (:192-193)."""
+    it = cycles // LOOP
+    return {"Cpu": cycles, "AddSub": 4 * it, "DivRem": it, "Mul": it, "Lt": it, "Branch": it, "MemoryLocal": 2, "Global": 12}
+
+
+def shaped_shard(shard_size=1 << 21, pc_base=0x1000):
+    """A middle shard of a long run as the reference's executor cuts it when shapes are on (the default: crates/prover/src/lib.rs:210-213,
+    crates/core/machine/src/utils/prove.rs:146-148): every 16 cycles it checks that some maximal shape of the configured shard size still
+    holds the estimated event counts with a margin, and closes the shard when none does (executor.rs:2429-2516) — for this loop after
+    about three quarters of `shard_size` cycles, when the DivRem / Mul count reaches the tallest height any maximal shape allows.
+    Returns (machine with that one shard, cycles, "shape" | "clock")."""
+    from . import shape as SH
+    cycles, why = SH.executor_shard_cycles(shard_size, loop_event_estimate)
+    n = (3 * cycles) // LOOP + 8
+    m = fib_shard(n, cycles, 2, pc_base)
+    assert cycles <= len(m.shards[0].record.cpu) <= cycles + 1
+    return m, cycles, why
+
+
 def full_shard(log_cycles, pc_base=0x1000):
     """The second shard of a run long enough to fill it: 2^log_cycles cycles of the loop (Cpu 2^k rows, AddSub 2^k, DivRem and Branch
     2^(k-2) after padding): the shape every middle shard of a long fibonacci run has."""
@@ -210,14 +232,37 @@ def _log2_rows(n):
     return h.bit_length() - 1
 
 
-class DeviceShard:
-    """The chips a CPU shard of this guest includes — Cpu, AddSub, Lt, Mul (the executor's dependency events of the branches and of the
-    division: crates/core/executor/src/dependencies.rs), Branch, DivRem, MemoryLocal, Global, Byte, Program — recorded once, and their
-    traces generated on the device from the shard's events as often as asked: the step before `commit`. Same chips,
-    heights and traces as tests/machine_lib.py::build_shard gives for the shard (tests/test_fibfast.py holds the two against each other)."""
+# MipsAirId name -> (work-list key, chips.py recorder name or ALU chip id); the order is the machine's (tests/machine_lib.py::build_shard)
+_ALU = {"AddSub": E.CHIP_ADD_SUB, "Bitwise": E.CHIP_BITWISE, "Lt": E.CHIP_LT, "ShiftLeft": E.CHIP_SHIFT_LEFT, "ShiftRight": E.CHIP_SHIFT_RIGHT,
+        "CloClz": E.CHIP_CLO_CLZ}
 
-    def __init__(self, machine, k=0):
-        from . import chips
+
+def core_heights(rec, glob):
+    """MipsAir::core_heights (crates/core/machine/src/mips/mod.rs:456-487) of a record with its dependency events added: rows per chip."""
+    h = {"Cpu": len(rec.cpu), "Branch": len(rec.branch), "Jump": len(rec.jump), "MovCond": len(rec.mov_cond), "MiscInstrs": len(rec.misc),
+         "MemoryInstrs": len(rec.mem_instr), "SyscallInstrs": len(rec.syscall), "DivRem": len(rec.divrem), "Mul": len(rec.mul),
+         "MemoryLocal": -(-len(rec.memory_local) // M.MEMORY_LOCAL_ENTRIES_PER_ROW), "Global": 2 * len(rec.memory_local) + 2 * len(rec.syscall),
+         "SyscallCore": len(rec.syscall)}
+    for name, chip in _ALU.items():
+        h[name] = len(rec.alu[chip])
+    return h
+
+
+class DeviceShard:
+    """The chips a CPU shard of this guest includes, recorded once, and their traces generated on the device from the shard's events as
+    often as asked: the step before `commit`.
+
+    shape=None: the tight shard — a chip is in when it has events (MachineAir::included), every trace padded to the next power of two
+    (at least 16 rows): Cpu, AddSub, Lt, Mul (the executor's dependency events of the branches and of the division:
+    crates/core/executor/src/dependencies.rs), Branch, DivRem, MemoryLocal, Global, Byte, Program. Same chips, heights and traces as
+    tests/machine_lib.py::build_shard gives for the shard (tests/test_fibfast.py holds the two against each other).
+
+    shape="fix": the shard as the reference proves it by default — `CoreShapeConfig::fix_shape` (ziren_amd/shape.py) picks the allowed shape
+    of least area that covers the record; every chip the shape names is in, events or not, padded to the shape's height
+    (`fixed_log2_rows`), and Program takes its allowed height (2^19 at least). A dict {chip: log2 height} fixes the shape directly."""
+
+    def __init__(self, machine, k=0, shape=None):
+        from . import chips, shape as SH
         sh = machine.shards[k]
         assert sh.kind == "cpu"
         self.machine, self.shard = machine, sh
@@ -225,17 +270,43 @@ class DeviceShard:
         self.shard_no = sh.pv["shard"]
         self.glob = M.global_lookup_events(rec.memory_local)
         assert not len(rec.jump) and not len(rec.mov_cond) and not len(rec.mem_instr) and not len(rec.syscall) and not len(rec.misc)
-        self.work = [("cpu", rec.cpu, _log2_rows(len(rec.cpu)), chips.record_cpu_chip)]
-        for chip in sorted(E.CHIP_NAMES):
-            if len(rec.alu[chip]):
-                self.work.append((chip, rec.alu[chip], _log2_rows(len(rec.alu[chip])), None))
-        for name, ev, record in (("branch", rec.branch, chips.record_branch_chip), ("mul", rec.mul, chips.record_mul_chip), ("divrem", rec.divrem, chips.record_divrem_chip)):
-            if len(ev):
-                self.work.append((name, ev, _log2_rows(len(ev)), record))
-        self.work.append(("memory_local", rec.memory_local, _log2_rows(-(-len(rec.memory_local) // M.MEMORY_LOCAL_ENTRIES_PER_ROW)), chips.record_memory_local_chip))
-        self.work.append(("global", self.glob, _log2_rows(len(self.glob)), chips.record_global_chip))
-        self.plh = _log2_rows(len(machine.program))
-        self.chips = [chips.record_chip(name, lh) if record is None else record(lh) for name, _, lh, record in self.work]
+        self.heights = core_heights(rec, self.glob)
+        self.shape_key = None
+        if isinstance(shape, str):
+            assert shape == "fix"
+            shape, key, cluster = SH.fix_shape(self.heights)
+            self.shape_key = (key, cluster)
+            plen = len(machine.program)
+            shape = dict(shape, Byte=16, Program=next(h for h in SH.PREPROCESSED_ALLOWED["Program"] if plen <= (1 << h)))
+        self.shape = shape
+        events = {"Cpu": rec.cpu, "Branch": rec.branch, "Jump": rec.jump, "MovCond": rec.mov_cond, "MiscInstrs": rec.misc, "MemoryInstrs": rec.mem_instr,
+                  "SyscallInstrs": rec.syscall, "SyscallCore": rec.syscall, "DivRem": rec.divrem, "Mul": rec.mul, "MemoryLocal": rec.memory_local,
+                  "Global": self.glob}
+        events.update({name: rec.alu[chip] for name, chip in _ALU.items()})
+        recorders = {"Cpu": chips.record_cpu_chip, "Branch": chips.record_branch_chip, "Jump": chips.record_jump_chip, "MovCond": chips.record_mov_cond_chip,
+                     "MiscInstrs": chips.record_misc_instrs_chip, "MemoryInstrs": chips.record_memory_instrs_chip,
+                     "SyscallInstrs": chips.record_syscall_instrs_chip, "SyscallCore": lambda lh: chips.record_syscall_table_chip(False, lh),
+                     "DivRem": chips.record_divrem_chip, "Mul": chips.record_mul_chip, "MemoryLocal": chips.record_memory_local_chip,
+                     "Global": chips.record_global_chip}
+        recorders.update({name: (lambda lh, chip=chip: chips.record_chip(chip, lh)) for name, chip in _ALU.items()})
+        order = ["Cpu"] + [E.CHIP_NAMES[c] for c in sorted(E.CHIP_NAMES)] + ["SyscallInstrs", "Jump", "MovCond", "Branch", "MemoryInstrs", "MiscInstrs", "Mul",
+                                                                               "DivRem", "SyscallCore", "MemoryLocal", "Global"]
+        self.work = []
+        for name in order:
+            rows = self.heights[name]
+            if shape is None:
+                if not rows:
+                    continue
+                lh = _log2_rows(rows)
+            else:
+                if name not in shape:
+                    assert not rows, f"the shape leaves {name} out but the record has {rows} rows for it"
+                    continue
+                lh = shape[name]
+                assert rows <= (1 << lh), (name, rows, lh)
+            self.work.append((name, events[name], lh, recorders[name]))
+        self.plh = _log2_rows(len(machine.program)) if shape is None else shape["Program"]
+        self.chips = [record(lh) for _, _, lh, record in self.work]
         self.chips += [chips.record_byte_chip(prep_index=0), chips.record_program_chip(self.plh, prep_index=1)]
         self.public_values = M.public_values(sh.pv)
 
@@ -253,32 +324,61 @@ class DeviceShard:
         self.work = pinned
         return total
 
+    def event_bytes(self):
+        """Bytes of the executor's events this shard's traces are generated from (what crosses PCIe per shard)."""
+        return int(sum(ev.nbytes for name, ev, _, _ in self.work if name != "SyscallCore"))
+
     def preprocessed(self, ctx):
         return [ctx.tracegen_byte_table(), ctx.tracegen_program(self.machine.program, self.machine.pc_base, self.plh)]
 
-    def traces(self, ctx):
-        """generate_traces on the device: one DeviceMatrix per chip of `self.chips`, in that order."""
+    def prefetch(self, ctx):
+        """Queue the copy of this shard's event vectors to the device (zkm_events_upload_async, the DMA stream) and return at once:
+        {chip: DeviceEvents} for `traces`. Called right before the previous shard's proof, the transfer runs under that proof. The vectors
+        should be page-locked (`pin`). Global's and SyscallCore's events (a handful here) are read on the host and stay there."""
+        return {name: ctx.events_upload_async(ev) for name, ev, _, _ in self.work if len(ev) and name not in ("Global", "SyscallCore")}
+
+    def traces(self, ctx, prefetched=None):
+        """generate_traces on the device: one DeviceMatrix per chip of `self.chips`, in that order. `prefetched` = what `prefetch` returned
+        (freed here); without it every generator uploads its own events."""
         blu = ctx.byte_lookups()
         born, program_mults = [], None
+        pre = prefetched or {}
         for name, ev, lh, _ in self.work:
-            if name == "cpu":
+            ev = pre.get(name, ev)
+            if name == "Cpu":
                 cpu, program_mults = ctx.tracegen_cpu_and_program(ev, self.machine.program, self.machine.pc_base, self.shard_no, lh, self.plh, blu)
                 born.append(cpu)
-            elif name == "branch":
+            elif name in _ALU:
+                born.append(ctx.tracegen_alu(_ALU[name], ev, lh, blu))
+            elif name == "Branch":
                 born.append(ctx.tracegen_branch(ev, lh, blu))
-            elif name == "mul":
+            elif name == "Mul":
                 born.append(ctx.tracegen_mul(ev, lh, blu))
-            elif name == "divrem":
+            elif name == "DivRem":
                 born.append(ctx.tracegen_divrem(ev, lh, blu))
-            elif name == "memory_local":
+            elif name == "MemoryLocal":
                 born.append(ctx.tracegen_memory_local(ev, lh))
-            elif name == "global":
+            elif name == "Global":
                 born.append(ctx.tracegen_global(ev, lh, blu))
+            elif name == "Jump":
+                born.append(ctx.tracegen_jump(ev, lh))
+            elif name == "MovCond":
+                born.append(ctx.tracegen_mov_cond(ev, lh))
+            elif name == "MemoryInstrs":
+                born.append(ctx.tracegen_memory_instrs(ev, lh, blu))
+            elif name == "MiscInstrs":
+                born.append(ctx.tracegen_misc_instrs(ev, lh, blu))
+            elif name == "SyscallInstrs":
+                born.append(ctx.tracegen_syscall_instrs(ev, lh))
+            elif name == "SyscallCore":
+                born.append(ctx.tracegen_syscall(ev, False, lh, blu))
             else:
-                born.append(ctx.tracegen_alu(name, ev, lh, blu))
+                raise KeyError(name)
         born.append(ctx.tracegen_byte_mults(blu))
         born.append(program_mults)
         blu.free()
+        for d in pre.values():
+            d.free()
         return born
 
     def committed_cells(self):

@@ -61,6 +61,38 @@ class ByteLookups:
             pass
 
 
+class DeviceEvents:
+    """Executor events copied to the device ahead of their trace generation (zkm_events_upload_async). Pass it to a core-shard
+    `Context.tracegen_*` call in place of the numpy array; `host` (page-locked for a true asynchronous copy) is kept alive with it."""
+
+    def __init__(self, ctx, ptr, host):
+        self.ctx, self.ptr, self.host, self.dtype = ctx, ptr, host, host.dtype
+
+    def __len__(self):
+        return len(self.host)
+
+    def free(self):
+        if self.ptr:
+            lib.load().zkm_events_free(self.ctx.h, C.c_void_p(self.ptr))
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def _evptr(events, dtype):
+    """(address, count, keep-alive) of an event vector: a numpy array (host pointer) or a DeviceEvents (device address)."""
+    if isinstance(events, DeviceEvents):
+        if events.dtype != dtype:
+            raise TypeError(f"events of dtype {events.dtype} handed to a chip that reads {dtype}")
+        return C.c_void_p(events.ptr if len(events) else None), len(events), events
+    ev = events if (isinstance(events, np.ndarray) and events.dtype == dtype and events.flags["C_CONTIGUOUS"]) else np.ascontiguousarray(events, dtype=dtype)
+    return C.c_void_p(ev.ctypes.data if len(ev) else None), len(ev), ev
+
+
 class Context:
     """One per GPU (`zkm_ctx`)."""
 
@@ -88,6 +120,13 @@ class Context:
         dm._host = m
         return dm
 
+    def events_upload_async(self, events: np.ndarray) -> DeviceEvents:
+        """zkm_events_upload_async: queue the copy of an event vector (page-locked: host_alloc / fibfast.DeviceShard.pin) on the DMA stream."""
+        assert events.flags["C_CONTIGUOUS"]
+        d = C.c_void_p()
+        lib.check(lib.load().zkm_events_upload_async(self.h, C.c_void_p(events.ctypes.data if len(events) else None), C.c_size_t(events.nbytes), C.byref(d)))
+        return DeviceEvents(self, d.value, events)
+
     def permutation_trace(self, chip, main: DeviceMatrix, prep: Optional[DeviceMatrix], alpha, beta):
         """generate_permutation_trace of one chip on the device (zkm_permutation_trace, a test entry point): returns (DeviceMatrix of
         height x 4 perm_ext_width, the cumulative sum as four Montgomery words)."""
@@ -104,25 +143,23 @@ class Context:
         lib.check(lib.load().zkm_byte_lookups_create(self.h, C.byref(h)))
         return ByteLookups(self, h)
 
-    def tracegen_alu(self, chip: int, alu_events: np.ndarray, fixed_log2_rows: int = -1, blu: "ByteLookups" = None) -> DeviceMatrix:
-        """`generate_trace` of an ALU chip on the device (zkm_tracegen_alu); `alu_events` has dtype events.ALU_EVENT.
+    def tracegen_alu(self, chip: int, events: np.ndarray, fixed_log2_rows: int = -1, blu: "ByteLookups" = None) -> DeviceMatrix:
+        """`generate_trace` of an ALU chip on the device (zkm_tracegen_alu); `events` has dtype events.ALU_EVENT.
         With `blu`, the chip's `generate_dependencies` runs in the same pass: its byte lookups are counted into it."""
         from . import events as _ev
-        ev = alu_events if (alu_events.dtype == _ev.ALU_EVENT and alu_events.flags["C_CONTIGUOUS"]) else \
-            np.ascontiguousarray(alu_events, dtype=_ev.ALU_EVENT)
+        p_ev, n_ev, _keep = _evptr(events, _ev.ALU_EVENT)
         h = C.c_void_p()
-        lib.check(lib.load().zkm_tracegen_alu(self.h, C.c_int(chip), C.c_void_p(ev.ctypes.data if len(ev) else None),
-                                              C.c_size_t(len(ev)), C.c_int(fixed_log2_rows), blu.h if blu is not None else None,
+        lib.check(lib.load().zkm_tracegen_alu(self.h, C.c_int(chip), p_ev, C.c_size_t(n_ev), C.c_int(fixed_log2_rows), blu.h if blu is not None else None,
                                               C.byref(h)))
         L = lib.load()
         return DeviceMatrix(self, h, int(L.zkm_matrix_height(h)), int(L.zkm_matrix_width(h)))
 
-    def tracegen_jump(self, jump_events: np.ndarray, fixed_log2_rows: int = -1) -> DeviceMatrix:
+    def tracegen_jump(self, events: np.ndarray, fixed_log2_rows: int = -1) -> DeviceMatrix:
         """`generate_trace` of the Jump chip on the device (zkm_tracegen_jump); dtype events.JUMP_EVENT."""
         from . import events as _ev
-        ev = np.ascontiguousarray(jump_events, dtype=_ev.JUMP_EVENT)
+        p_ev, n_ev, _keep = _evptr(events, _ev.JUMP_EVENT)
         h = C.c_void_p()
-        lib.check(lib.load().zkm_tracegen_jump(self.h, C.c_void_p(ev.ctypes.data if len(ev) else None), C.c_size_t(len(ev)),
+        lib.check(lib.load().zkm_tracegen_jump(self.h, p_ev, C.c_size_t(n_ev),
                                                C.c_int(fixed_log2_rows), C.byref(h)))
         L = lib.load()
         return DeviceMatrix(self, h, int(L.zkm_matrix_height(h)), int(L.zkm_matrix_width(h)))
@@ -130,9 +167,9 @@ class Context:
     def tracegen_branch(self, events: np.ndarray, fixed_log2_rows: int = -1, blu: "ByteLookups" = None) -> DeviceMatrix:
         """`generate_trace` of the Branch chip on the device (zkm_tracegen_branch); dtype events.BRANCH_EVENT."""
         from . import events as _ev
-        ev = np.ascontiguousarray(events, dtype=_ev.BRANCH_EVENT)
+        p_ev, n_ev, _keep = _evptr(events, _ev.BRANCH_EVENT)
         h = C.c_void_p()
-        lib.check(lib.load().zkm_tracegen_branch(self.h, C.c_void_p(ev.ctypes.data if len(ev) else None), C.c_size_t(len(ev)),
+        lib.check(lib.load().zkm_tracegen_branch(self.h, p_ev, C.c_size_t(n_ev),
                                                  C.c_int(fixed_log2_rows), blu.h if blu is not None else None, C.byref(h)))
         L = lib.load()
         return DeviceMatrix(self, h, int(L.zkm_matrix_height(h)), int(L.zkm_matrix_width(h)))
@@ -141,9 +178,9 @@ class Context:
         """`generate_trace` (+ `generate_dependencies` into `blu`) of the Mul chip on the device (zkm_tracegen_mul); dtype
         events.COMP_ALU_EVENT."""
         from . import events as _ev
-        ev = np.ascontiguousarray(events, dtype=_ev.COMP_ALU_EVENT)
+        p_ev, n_ev, _keep = _evptr(events, _ev.COMP_ALU_EVENT)
         h = C.c_void_p()
-        lib.check(lib.load().zkm_tracegen_mul(self.h, C.c_void_p(ev.ctypes.data if len(ev) else None), C.c_size_t(len(ev)),
+        lib.check(lib.load().zkm_tracegen_mul(self.h, p_ev, C.c_size_t(n_ev),
                                               C.c_int(fixed_log2_rows), blu.h if blu is not None else None, C.byref(h)))
         L = lib.load()
         return DeviceMatrix(self, h, int(L.zkm_matrix_height(h)), int(L.zkm_matrix_width(h)))
@@ -152,9 +189,9 @@ class Context:
         """`generate_trace` (which also records the byte lookups, into `blu`) of the DivRem chip on the device
         (zkm_tracegen_divrem); dtype events.COMP_ALU_EVENT."""
         from . import events as _ev
-        ev = np.ascontiguousarray(events, dtype=_ev.COMP_ALU_EVENT)
+        p_ev, n_ev, _keep = _evptr(events, _ev.COMP_ALU_EVENT)
         h = C.c_void_p()
-        lib.check(lib.load().zkm_tracegen_divrem(self.h, C.c_void_p(ev.ctypes.data if len(ev) else None), C.c_size_t(len(ev)),
+        lib.check(lib.load().zkm_tracegen_divrem(self.h, p_ev, C.c_size_t(n_ev),
                                                  C.c_int(fixed_log2_rows), blu.h if blu is not None else None, C.byref(h)))
         L = lib.load()
         return DeviceMatrix(self, h, int(L.zkm_matrix_height(h)), int(L.zkm_matrix_width(h)))
@@ -168,10 +205,10 @@ class Context:
         """`generate_trace` + `generate_dependencies` of the Cpu chip on the device (zkm_tracegen_cpu); dtypes
         miniexec.CPU_EVENT (CpuEventFfi) and miniexec.INSTRUCTION (InstructionFfi)."""
         from . import miniexec as _m
-        ev = np.ascontiguousarray(events, dtype=_m.CPU_EVENT)
+        p_ev, n_ev, _keep = _evptr(events, _m.CPU_EVENT)
         prog = np.ascontiguousarray(program, dtype=_m.INSTRUCTION)
         h = C.c_void_p()
-        lib.check(lib.load().zkm_tracegen_cpu(self.h, C.c_void_p(ev.ctypes.data if len(ev) else None), C.c_size_t(len(ev)),
+        lib.check(lib.load().zkm_tracegen_cpu(self.h, p_ev, C.c_size_t(n_ev),
                                               C.c_void_p(prog.ctypes.data if len(prog) else None), C.c_size_t(len(prog)),
                                               C.c_uint32(pc_base), C.c_uint32(shard), C.c_int(fixed_log2_rows),
                                               blu.h if blu is not None else None, C.byref(h)))
@@ -180,9 +217,9 @@ class Context:
     def tracegen_memory_instrs(self, events: np.ndarray, fixed_log2_rows: int = -1, blu: "ByteLookups" = None) -> DeviceMatrix:
         """`generate_trace` of the MemoryInstructions chip on the device (zkm_tracegen_memory_instrs); dtype events.MEM_INSTR_EVENT."""
         from . import events as _ev
-        ev = np.ascontiguousarray(events, dtype=_ev.MEM_INSTR_EVENT)
+        p_ev, n_ev, _keep = _evptr(events, _ev.MEM_INSTR_EVENT)
         h = C.c_void_p()
-        lib.check(lib.load().zkm_tracegen_memory_instrs(self.h, C.c_void_p(ev.ctypes.data if len(ev) else None), C.c_size_t(len(ev)),
+        lib.check(lib.load().zkm_tracegen_memory_instrs(self.h, p_ev, C.c_size_t(n_ev),
                                                         C.c_int(fixed_log2_rows), blu.h if blu is not None else None, C.byref(h)))
         return self._born(h)
 
@@ -198,9 +235,9 @@ class Context:
     def tracegen_syscall_instrs(self, events: np.ndarray, fixed_log2_rows: int = -1) -> DeviceMatrix:
         """`generate_trace` of the SyscallInstrs chip on the device (zkm_tracegen_syscall_instrs); dtype events.SYSCALL_EVENT."""
         from . import events as _ev
-        ev = np.ascontiguousarray(events, dtype=_ev.SYSCALL_EVENT)
+        p_ev, n_ev, _keep = _evptr(events, _ev.SYSCALL_EVENT)
         h = C.c_void_p()
-        lib.check(lib.load().zkm_tracegen_syscall_instrs(self.h, C.c_void_p(ev.ctypes.data if len(ev) else None), C.c_size_t(len(ev)),
+        lib.check(lib.load().zkm_tracegen_syscall_instrs(self.h, p_ev, C.c_size_t(n_ev),
                                                          C.c_int(fixed_log2_rows), C.byref(h)))
         return self._born(h)
 
@@ -353,9 +390,9 @@ class Context:
     def tracegen_misc_instrs(self, events: np.ndarray, fixed_log2_rows: int = -1, blu: "ByteLookups" = None) -> DeviceMatrix:
         """`generate_trace` of the MiscInstrs chip on the device (zkm_tracegen_misc_instrs); dtype events.MISC_EVENT."""
         from . import events as _ev
-        ev = np.ascontiguousarray(events, dtype=_ev.MISC_EVENT)
+        p_ev, n_ev, _keep = _evptr(events, _ev.MISC_EVENT)
         h = C.c_void_p()
-        lib.check(lib.load().zkm_tracegen_misc_instrs(self.h, C.c_void_p(ev.ctypes.data if len(ev) else None), C.c_size_t(len(ev)),
+        lib.check(lib.load().zkm_tracegen_misc_instrs(self.h, p_ev, C.c_size_t(n_ev),
                                                       C.c_int(fixed_log2_rows), blu.h if blu is not None else None, C.byref(h)))
         return self._born(h)
 
@@ -379,9 +416,9 @@ class Context:
     def tracegen_memory_local(self, events: np.ndarray, fixed_log2_rows: int = -1) -> DeviceMatrix:
         """`generate_trace` of the MemoryLocal chip on the device (zkm_tracegen_memory_local); dtype miniexec.MEMORY_LOCAL_EVENT."""
         from . import miniexec as _m
-        ev = np.ascontiguousarray(events, dtype=_m.MEMORY_LOCAL_EVENT)
+        p_ev, n_ev, _keep = _evptr(events, _m.MEMORY_LOCAL_EVENT)
         h = C.c_void_p()
-        lib.check(lib.load().zkm_tracegen_memory_local(self.h, C.c_void_p(ev.ctypes.data if len(ev) else None), C.c_size_t(len(ev)),
+        lib.check(lib.load().zkm_tracegen_memory_local(self.h, p_ev, C.c_size_t(n_ev),
                                                        C.c_int(fixed_log2_rows), C.byref(h)))
         return self._born(h)
 
@@ -400,11 +437,11 @@ class Context:
         """The Cpu trace and, from the same upload of the events, the Program chip's multiplicity trace
         (zkm_tracegen_cpu_and_program). Returns (cpu, program_mults)."""
         from . import miniexec as _m
-        ev = np.ascontiguousarray(events, dtype=_m.CPU_EVENT)
+        p_ev, n_ev, _keep = _evptr(events, _m.CPU_EVENT)
         prog = np.ascontiguousarray(program, dtype=_m.INSTRUCTION)
         h, hp = C.c_void_p(), C.c_void_p()
         lib.check(lib.load().zkm_tracegen_cpu_and_program(
-            self.h, C.c_void_p(ev.ctypes.data if len(ev) else None), C.c_size_t(len(ev)), C.c_void_p(prog.ctypes.data if len(prog) else None),
+            self.h, p_ev, C.c_size_t(n_ev), C.c_void_p(prog.ctypes.data if len(prog) else None),
             C.c_size_t(len(prog)), C.c_uint32(pc_base), C.c_uint32(shard), C.c_int(fixed_log2_rows), C.c_int(program_fixed_log2_rows),
             blu.h if blu is not None else None, C.byref(h), C.byref(hp)))
         return self._born(h), self._born(hp)
@@ -421,18 +458,18 @@ class Context:
     def tracegen_program_mults(self, events: np.ndarray, n_instr: int, pc_base: int, fixed_log2_rows: int = -1) -> DeviceMatrix:
         """The Program chip's multiplicity trace on the device (zkm_tracegen_program_mults)."""
         from . import miniexec as _m
-        ev = np.ascontiguousarray(events, dtype=_m.CPU_EVENT)
+        p_ev, n_ev, _keep = _evptr(events, _m.CPU_EVENT)
         h = C.c_void_p()
-        lib.check(lib.load().zkm_tracegen_program_mults(self.h, C.c_void_p(ev.ctypes.data if len(ev) else None), C.c_size_t(len(ev)),
+        lib.check(lib.load().zkm_tracegen_program_mults(self.h, p_ev, C.c_size_t(n_ev),
                                                         C.c_size_t(n_instr), C.c_uint32(pc_base), C.c_int(fixed_log2_rows), C.byref(h)))
         return self._born(h)
 
     def tracegen_mov_cond(self, events: np.ndarray, fixed_log2_rows: int = -1) -> DeviceMatrix:
         """`generate_trace` of the MovCond chip on the device (zkm_tracegen_mov_cond); dtype events.MOV_COND_EVENT."""
         from . import events as _ev
-        ev = np.ascontiguousarray(events, dtype=_ev.MOV_COND_EVENT)
+        p_ev, n_ev, _keep = _evptr(events, _ev.MOV_COND_EVENT)
         h = C.c_void_p()
-        lib.check(lib.load().zkm_tracegen_mov_cond(self.h, C.c_void_p(ev.ctypes.data if len(ev) else None), C.c_size_t(len(ev)),
+        lib.check(lib.load().zkm_tracegen_mov_cond(self.h, p_ev, C.c_size_t(n_ev),
                                                    C.c_int(fixed_log2_rows), C.byref(h)))
         L = lib.load()
         return DeviceMatrix(self, h, int(L.zkm_matrix_height(h)), int(L.zkm_matrix_width(h)))
