@@ -667,7 +667,7 @@ def main():
                          "tight heights; syn: SYN---log-rows")
     ap.add_argument("--shard-size-log", type=int, default=21, help="log2 of the reference's SHARD_SIZE for --workload fib (MAX_SHARD_SIZE = 2^21, crates/stark/src/opts.rs:6; "
                     "at 2^22 this guest's shard has no covering shape: fix_shape fails in the reference too)")
-    ap.add_argument("--log-rows", type=int, default=22)
+    ap.add_argument("--log-rows", type=int, default=None, help="fib-tight: log2 cycles (default 21, the most a shard's 24-bit clock holds); syn: log2 rows of the tallest chip (default 22)")
     ap.add_argument("--cpu-sample-log", type=int, default=None, help="size of the cpu_baseline sample (fib: log2 SHARD_SIZE, default 18; syn: log rows, default 20)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-full", action="store_true", help="time the CPU baseline on the benchmarked shard itself instead of a sample (minutes)")
@@ -680,10 +680,11 @@ def main():
     ap.add_argument("--queue", type=int, default=0, metavar="SHARDS", help="N = 1 too: deal SHARDS distinct shards through the claim queue (events -> traces -> proof); "
                     "-1: 4 per GPU. The default for N > 1.")
     args = ap.parse_args()
+    if args.log_rows is None:
+        args.log_rows = 21 if (args.workload == "fib-tight" or args.tracegen) else 22
     if args.tracegen:
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import bench_tracegen
-        args.log_rows = min(args.log_rows, 21)
         return bench_tracegen.tracegen_bench(args)
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -763,6 +764,8 @@ def main():
                 "verified": True, "kernels_ms": {k: round(v[0] / leg2["table_steps"], 3) for k, v in sorted(t.items(), key=lambda kv: -kv[1][0])[:8]}}
             for x in tr2:
                 x.free()
+            pk2.free()                     # before its context goes
+            del hp2, pk2, tr2, leg2, w2
             ctx2.close()
         if extra:
             line["other_workloads"] = extra
@@ -771,7 +774,7 @@ def main():
         line["cpu_baseline"] = cpu_baseline_leg(wl, fri, args.cpu_full, sample)
     else:
         line["cpu_baseline"] = None
-    print(json.dumps(line))
+    print(json.dumps(line), flush=True)
     farm.close()
 
 

@@ -21,7 +21,7 @@ def load(path, counter):
     return {k.split("(")[0].replace("void ", ""): (v, n) for k, v, n in rows}
 
 
-def main(fetch_db, write_db, out_path):
+def main(fetch_db, write_db, out_path, tag="syn22", proofs=1):
     f, w = load(fetch_db, "FETCH_SIZE"), load(write_db, "WRITE_SIZE")
     import os, subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -31,7 +31,8 @@ def main(fetch_db, write_db, out_path):
         commit = subprocess.run(["git", "-C", root, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or None
     except OSError:
         commit = None
-    out = {"workload": "SYN-22, one shard proof (bench.py --log-rows 22 --steps 1 --warmup 0)", "csrc_digest": bench.csrc_digest(), "commit": commit,
+    proofs = int(proofs)
+    out = {"workload": f"{tag}: {proofs} shard proof(s) of bench.py's workload of that tag (tools/profile_r04.sh)", "steps": proofs, "csrc_digest": bench.csrc_digest(), "commit": commit,
            "correction": "read bytes = 2 * FETCH_SIZE * 1024, write bytes = WRITE_SIZE * 1024", "kernels": {}}
     for k in sorted(set(f) | set(w)):
         fv, fn = f.get(k, (0, 0))
@@ -45,4 +46,4 @@ def main(fetch_db, write_db, out_path):
 
 
 if __name__ == "__main__":
-    main(*sys.argv[1:4])
+    main(*sys.argv[1:6])

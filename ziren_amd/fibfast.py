@@ -216,6 +216,11 @@ def shaped_shard(shard_size=1 << 21, pc_base=0x1000):
 def full_shard(log_cycles, pc_base=0x1000):
     """The second shard of a run long enough to fill it: 2^log_cycles cycles of the loop (Cpu 2^k rows, AddSub 2^k, DivRem and Branch
     2^(k-2) after padding): the shape every middle shard of a long fibonacci run has."""
+    if 5 << log_cycles >= 1 << 24:
+        # the shard's clock advances 5 per cycle (executor.rs:1682) and the Cpu chip range-checks it to 24 bits (cpu/air/mod.rs:39,131-138):
+        # no shard of the reference holds 2^22 cycles (it closes one at 0.8 SHARD_SIZE cycles at the latest, executor.rs:325,2423), and a
+        # trace that did would not satisfy the AIR — the verifier rejects such a proof (found by verifying round 3's "FIB-22" shard)
+        raise ValueError(f"a shard of 2^{log_cycles} cycles overflows the 24-bit shard clock")
     S = (1 << log_cycles) - 1       # a shard that would end on a delay slot runs one cycle longer: 2^k - 1 or 2^k cycles, never 2^k + 1
     n = (3 * S) // LOOP + 8
     m = fib_shard(n, S, 2, pc_base)
