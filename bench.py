@@ -15,7 +15,7 @@ N > 1: one process per GPU (launched by the driver through torch.distributed.run
 `python bench.py --gpus 8` starts 8 ranks). Shards are independent (crates/core/machine/src/utils/prove.rs:492-497): the ranks take
 distinct shards from one claim queue, each from the executor's events in page-locked host memory (events -> device traces -> proof, the
 next shard's events crossing PCIe under the current proof), the proof streams are gathered to rank 0 over RCCL inside the timed region;
-there is no data-path collective. Per-GPU work is fixed (4 shards per GPU): scaling is weak, value = shards / max-over-ranks time.
+there is no data-path collective. Per-GPU work is fixed (8 shards per GPU): scaling is weak, value = shards / max-over-ranks time.
 """
 import argparse
 import ctypes as C
@@ -35,6 +35,7 @@ os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")      # before anything initi
 HBM_PEAK_GBPS = 8000.0     # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 FP64_VECTOR_TFLOPS = 78.6  # MI355X FP64 vector peak: 256 CUs x 4 SIMDs x 16 lanes x 2 flop x 2.4 GHz (MI355X_MICROARCH.md)
 PROFILE_ROUND = "r04"
+SHARDS_PER_GPU = 8        # N > 1 default: shards dealt per GPU (weak scaling); one shard is claimed ahead, so the tail costs at most 1/8
 HASHING_KERNELS = ("compress_layer", "hash_leaves", "hash_leaves_tree", "hash_fri_leaves", "hash_fri_leaves_tree", "compress_small", "compress_tail")
 LDE_KERNELS = ("lde_rows", "lde_cols_forward", "lde_cols_inverse")
 ROCPROF_NAMES = {"compress_layer": "merkle::compress_layer", "hash_leaves": "merkle::hash_leaves", "hash_leaves_tree": "merkle::hash_leaves_tree",
@@ -100,6 +101,9 @@ def oracle():
     leg — never inside a timed region."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
+    # OpenMP would start one thread per logical CPU of the host in every rank: the cores this process may use, shared among the node's ranks
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
+    O.lib().orc_set_num_threads(max(1, usable_cores()[0] // max(1, local_world)))
     return O
 
 
@@ -565,16 +569,19 @@ class StubLane:
 class FibQueueLane:
     """One rank's side of the farm: a pool of distinct middle shards of the guest (their events page-locked), one context, the key."""
 
-    def __init__(self, device, rank, fri, log_size, specialize, pool=2):
+    def __init__(self, device, rank, fri, log_size, specialize, pool=2, share=None):
         from ziren_amd import lib, prover
         self.fri = fri
-        self.wls = [FibWorkload("shaped", log_size, shard_no=2 + (2 * rank + j) % 6) for j in range(pool)]
+        # a second lane of the same rank proves from the same page-locked pool
+        self.wls = share.wls if share is not None else [FibWorkload("shaped", log_size, shard_no=2 + (2 * rank + j) % 6) for j in range(pool)]
         self.ctx = prover.Context(device)
         self.hp, self.pk, self.ch0 = self.wls[0].setup(self.ctx, fri, specialize)       # one program, one shape: one key for every shard
         lib.load().zkm_ctx_set_kernel_timing(self.ctx.h, C.c_int(0))
-        for w in self.wls:
-            assert [c.name for c in w.chips] == [c.name for c in self.wls[0].chips] and [c.log_height for c in w.chips] == [c.log_height for c in self.wls[0].chips]
-            w.ds.pin(self.ctx)
+        if share is None:
+            for w in self.wls:
+                w.prep_host, w.pc_start, w.zero_digest = self.wls[0].prep_host, self.wls[0].pc_start, self.wls[0].zero_digest     # one program: one key
+                assert [c.name for c in w.chips] == [c.name for c in self.wls[0].chips] and [c.log_height for c in w.chips] == [c.log_height for c in self.wls[0].chips]
+                w.ds.pin(self.ctx)
         self.event_bytes = self.wls[0].ds.event_bytes()
         self.out = np.zeros(1 << 22, dtype=np.uint32)
         self.last = None
@@ -611,14 +618,21 @@ class FibQueueLane:
 def queue_main(args, farm, fri):
     rank, local_rank, world = farm.rank, farm.local_rank, farm.world
     stub = os.environ.get("ZKM_BENCH_STUB_PROVER") == "1"
+    M = max(1, args.inflight)
     lane = StubLane(rank) if stub else FibQueueLane(local_rank, rank, fri, args.shard_size_log, not args.interpreter)
-    farm.device_sync = lane.sync
-    n_shards = args.queue if args.queue > 0 else 4 * world
-    for _ in range(max(1, args.warmup)):
-        lane.prove(0, lane.prefetch(0))
+    lanes = [lane] + [StubLane(rank) if stub else FibQueueLane(local_rank, rank, fri, args.shard_size_log, not args.interpreter, share=lane) for _ in range(M - 1)]
+
+    def sync_all():
+        for l in lanes:
+            l.sync()
+    farm.device_sync = sync_all
+    n_shards = args.queue if args.queue > 0 else SHARDS_PER_GPU * world
+    for l in lanes:
+        for _ in range(max(1, args.warmup)):
+            l.prove(0, l.prefetch(0))
     farm.barrier()
     t0 = time.perf_counter()
-    ids, proofs = farm.run_queue(n_shards, lane.prove, prefetch=lane.prefetch)
+    ids, proofs = farm.run_queue(n_shards, lanes=[(l.prove, l.prefetch) for l in lanes])
     gathered = farm.gather_proofs(ids, proofs, n_shards)
     farm.barrier()
     elapsed = farm.max_over_ranks(time.perf_counter() - t0)
@@ -627,8 +641,9 @@ def queue_main(args, farm, fri):
     proved = farm.sum_over_ranks(float(len(ids)))
     fewest = -farm.max_over_ranks(-float(len(ids)))
     ok = 1.0
-    if ids:
-        ok = 1.0 if lane.verify_last() else 0.0         # every rank checks the last proof it made (outside the timed region)
+    for l in lanes:
+        if getattr(l, "last", True) is not None and ids:
+            ok = min(ok, 1.0 if l.verify_last() else 0.0)         # every lane of every rank checks the last proof it made (outside the timed region)
     all_ok = -farm.max_over_ranks(-ok)
     ranks_in_group = farm.dist.get_world_size() if farm.dist is not None else 1
     if all_ok != 1.0 or int(proved) != n_shards:
@@ -644,12 +659,14 @@ def queue_main(args, farm, fri):
             "config": {"workload": (f"FIB-S{args.shard_size_log}: {n_shards} distinct shards of examples/fibonacci (cut and shaped as the reference does at SHARD_SIZE = 2^{args.shard_size_log}, "
                                     f"Cpu 2^22 rows) dealt from one claim queue; per shard: executor events in page-locked host memory -> device traces -> full shard "
                                     f"proof (commit+open, blowup 2, 84 queries, 16 PoW bits); proof streams gathered to rank 0 inside the timed region"),
-                       "parallelism": f"{world} GPU(s), one process each, claim queue (one shard claimed ahead: its events cross PCIe under the current proof), "
-                                      f"{'gloo' if stub else 'RCCL'} gather of {sum(len(p) for p in gathered) * 4} proof bytes, no data-path collective",
-                       "ranks_in_process_group": ranks_in_group, "backend": "gloo" if stub else "nccl (RCCL)"},
+                       "parallelism": f"{world} GPU(s), one process each, {M} shard(s) in flight per GPU (a context + host thread each), claim queue (every lane claims one shard "
+                                      f"ahead: its events cross PCIe under the current proof), {'gloo' if stub else 'RCCL'} gather of {sum(len(p) for p in gathered) * 4} proof bytes, "
+                                      f"no data-path collective",
+                       "shards_in_flight_per_gpu": M, "ranks_in_process_group": ranks_in_group,
+                       "backend": "none (one process)" if farm.dist is None else "gloo" if stub else "nccl (RCCL)"},
             "host_ms_per_shard": {"rank0_mean": round(mine, 3), "max_over_ranks_of_means": round(slowest, 3)},
             "event_bytes_per_shard": lane.event_bytes,
-            "h2d_GBps_per_rank_needed": round(lane.event_bytes / (slowest * 1e-3) / 1e9, 2) if slowest > 0 else None,
+            "h2d_GBps_per_rank": round(lane.event_bytes * len(ids) / elapsed / 1e9, 2),      # rank 0's events over the timed region: what its PCIe link carried
             "shards_proved": int(proved), "shards_proved_by_rank0": len(ids), "fewest_shards_on_a_rank": int(fewest)}))
     farm.close()
 
@@ -677,8 +694,10 @@ def main():
     ap.add_argument("--kernel-timing", type=int, default=3,
                     help="0 off, 1 every launch, 2 launches >= 256 KiB, 3 (default): inside the timed region only the dominant kernel is timed")
     ap.add_argument("--interpreter", action="store_true", help="use the bytecode interpreter instead of per-chip quotient kernels")
+    ap.add_argument("--inflight", type=int, default=2, help="queue path: shards in flight per GPU (a context + host thread each); 2 fills one proof's transcript "
+                    "round trips and launch gaps with the other's kernels (the N = 1 resident line always keeps one in flight and reports two beside it)")
     ap.add_argument("--queue", type=int, default=0, metavar="SHARDS", help="N = 1 too: deal SHARDS distinct shards through the claim queue (events -> traces -> proof); "
-                    "-1: 4 per GPU. The default for N > 1.")
+                    "-1: 8 per GPU. The default for N > 1.")
     args = ap.parse_args()
     if args.log_rows is None:
         args.log_rows = 21 if (args.workload == "fib-tight" or args.tracegen) else 22

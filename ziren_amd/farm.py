@@ -55,6 +55,9 @@ class Farm:
         self.dist = None
         self.device = None
         self.device_sync = device_sync or (lambda: None)
+        import threading
+        self._claim_lock = threading.Lock()
+        self._epochs = {}
         if self.world > 1 or os.environ.get("ZKM_FORCE_DIST") == "1":
             import torch
             import torch.distributed as dist
@@ -112,21 +115,21 @@ class Farm:
     def _queue_key(self, queue: str) -> str:
         """One counter per batch: `run_queue` opens a new epoch of `queue` every time it is called (every rank calls it the same
         number of times, so the epochs agree without a message), and a key nobody has added to yet counts from zero."""
-        self._epochs = getattr(self, "_epochs", {})
         return f"zkm_farm_{queue}_{self._epochs.get(queue, 0)}"
 
     def claim(self, queue: str = "shards") -> int:
         """The index of the next unclaimed shard of the queue's current batch: an atomic fetch-and-add on a counter every rank shares
         (the process group's key-value store; a plain counter without one). Whoever is free first gets the next shard."""
         key = self._queue_key(queue)
-        if self.dist is None:
-            self._local_counters = getattr(self, "_local_counters", {})
-            self._local_counters[key] = self._local_counters.get(key, 0) + 1
-            return self._local_counters[key] - 1
-        store = self.dist.distributed_c10d._get_default_store()
-        return int(store.add(key, 1)) - 1
+        with self._claim_lock:                 # several lanes (host threads) of this rank may claim
+            if self.dist is None:
+                self._local_counters = getattr(self, "_local_counters", {})
+                self._local_counters[key] = self._local_counters.get(key, 0) + 1
+                return self._local_counters[key] - 1
+            store = self.dist.distributed_c10d._get_default_store()
+            return int(store.add(key, 1)) - 1
 
-    def run_queue(self, n_shards: int, prove: Callable, queue: str = "shards", prefetch: Optional[Callable] = None):
+    def run_queue(self, n_shards: int, prove: Optional[Callable] = None, queue: str = "shards", prefetch: Optional[Callable] = None, lanes=None):
         """Prove shards of one batch until its queue is empty; returns ([shard ids this rank proved], [their proof streams]). Calling
         it again deals a new batch (a fresh counter). `self.host_ms` collects, per shard proven here, the wall-clock milliseconds of
         its `prove` call (what a rank spends per shard including host work: the number that limits an 8-GPU node once events, not
@@ -135,28 +138,54 @@ class Farm:
         With `prefetch`, the rank claims one shard ahead: `prefetch(j)` is called for the next shard before `prove(i, handle_i)` of the
         current one, so the next shard's input (the executor's events) crosses PCIe while the current one is proven — the records and
         traces channel of the reference holds one record ahead of the prover the same way (crates/stark/src/opts.rs:11,
-        DEFAULT_RECORDS_AND_TRACES_CHANNEL_CAPACITY = 1)."""
-        ids, proofs = [], []
-        self.host_ms = []
+        DEFAULT_RECORDS_AND_TRACES_CHANNEL_CAPACITY = 1).
+
+        `lanes` = [(prove, prefetch), ...]: several shards in flight on this rank's GPU, one host thread per lane (each lane its own
+        context), all claiming from the same queue — the reference's `shard_batch_size` prover threads (prove.rs:487-497) on one device:
+        one lane's transcript round trips and launch gaps are filled by the other's kernels."""
+        import threading
+        lanes = lanes or [(prove, prefetch)]
+        results = [None] * len(lanes)
+        errors = []
+
+        def work(j):
+            pv, pf = lanes[j]
+            ids, proofs, ms = [], [], []
+            results[j] = (ids, proofs, ms)
+            try:
+                cur = self.claim(queue)
+                handle = pf(cur) if (pf is not None and cur < n_shards) else None
+                while cur < n_shards:
+                    t0 = time.perf_counter()
+                    nxt, nxt_handle = n_shards, None
+                    if pf is not None:
+                        nxt = self.claim(queue)
+                        if nxt < n_shards:
+                            nxt_handle = pf(nxt)
+                    ids.append(cur)
+                    proofs.append(np.asarray(pv(cur, handle) if pf is not None else pv(cur), dtype=np.uint32).copy())
+                    ms.append(1e3 * (time.perf_counter() - t0))
+                    if pf is None:
+                        nxt = self.claim(queue)
+                    cur, handle = nxt, nxt_handle
+            except BaseException as e:  # noqa: BLE001  (re-raised on the calling thread)
+                errors.append(e)
+
         try:
-            cur = self.claim(queue)
-            handle = prefetch(cur) if (prefetch is not None and cur < n_shards) else None
-            while cur < n_shards:
-                t0 = time.perf_counter()
-                nxt, nxt_handle = n_shards, None
-                if prefetch is not None:
-                    nxt = self.claim(queue)
-                    if nxt < n_shards:
-                        nxt_handle = prefetch(nxt)
-                ids.append(cur)
-                proofs.append(np.asarray(prove(cur, handle) if prefetch is not None else prove(cur), dtype=np.uint32).copy())
-                self.host_ms.append(1e3 * (time.perf_counter() - t0))
-                if prefetch is None:
-                    nxt = self.claim(queue)
-                cur, handle = nxt, nxt_handle
+            if len(lanes) == 1:
+                work(0)
+            else:
+                ts = [threading.Thread(target=work, args=(j,)) for j in range(len(lanes))]
+                for t in ts:
+                    t.start()
+                for t in ts:
+                    t.join()
         finally:
             self._epochs[queue] = self._epochs.get(queue, 0) + 1
-        return ids, proofs
+        if errors:
+            raise errors[0]
+        self.host_ms = [m for r in results for m in r[2]]
+        return [i for r in results for i in r[0]], [p for r in results for p in r[1]]
 
     def gather_proofs(self, shard_ids: Sequence[int], proofs: Sequence[np.ndarray], n_shards: int) -> Optional[List[np.ndarray]]:
         """Whole ShardProof streams to rank 0, in shard order (the input of the recursion tree, lib.rs:617-641). Streams differ in
