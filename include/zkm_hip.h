@@ -133,7 +133,8 @@ const char* zkm_last_error(void);
 int zkm_ctx_create(int device, zkm_ctx** out);
 void zkm_ctx_destroy(zkm_ctx* ctx);
 int zkm_ctx_synchronize(zkm_ctx* ctx);
-/* Device buffers are recycled through an exact-size pool; trim returns the idle ones to the driver. */
+/* Device buffers are recycled through an exact-size pool; trim returns the idle ones to the driver, and drops the per-height tables
+ * (coset twiddles, quotient selectors, row twiddles) a long-lived prover accumulates: they are rebuilt on the next use of a height. */
 int zkm_ctx_trim(zkm_ctx* ctx);
 /* per-phase GPU time of the last zkm_commit/zkm_open on this context, in milliseconds (HIP
  * events on the context's stream). names/values arrays of capacity cap; returns the count. */

@@ -152,9 +152,11 @@ def _ssa_lines(program: np.ndarray):
                 form = {"terms": [], "consts": [], "extras": []}
                 for z in (x, y):
                     if z in deferred:
-                        f2 = deferred.pop(z)
+                        # copied, not taken: z stays a deferred form of its own, so a second reader of the same value (the same
+                        # beta * column product added into two different sums) still finds it and `use` can emit it
+                        f2 = deferred[z]
                         for key in form:
-                            form[key] += f2[key]
+                            form[key] += list(f2[key])
                     elif z in uniform:
                         form["consts"].append(z)
                     else:

@@ -177,6 +177,9 @@ struct zkm_ctx {
   }
   void flush_staged() {
     if (dirty_hi <= dirty_lo) return;
+    // the span [dirty_lo, dirty_hi) may also cover ring blocks that are not staged tables (download_async destinations, upload() staging):
+    // copying them to the arena is harmless only while everything that touches the ring runs on the one main stream
+    if (cur != stream) throw std::runtime_error("flush_staged: staged tables are only flushed on the main stream");
     HIP_CHECK(hipMemcpyAsync(arena + dirty_lo, pin + dirty_lo, dirty_hi - dirty_lo, hipMemcpyHostToDevice, cur));
     dirty_lo = SIZE_MAX; dirty_hi = 0;
   }

@@ -93,11 +93,19 @@ static void lde_batch_chunk(zkm_ctx* ctx, const std::vector<LdeJob>& jobs, int b
 
 static void lde_batch(zkm_ctx* ctx, const std::vector<LdeJob>& all, int bl) {
   // a descriptor holds MAX_MATS matrices and MAX_GROUPS heights (24 covers every power of two up to the field's two-adicity minus the blow-up)
+  // ... and a chunk's scratch (the four-step matrices' intermediates: n w words after the inverse strided pass, n w << bl before the
+  // forward one) stays under a budget: batching exists to fill the GPU with one launch per kernel, which a few GB of cells already do,
+  // while the scratch of a whole commit of several billion cells (1.5x its LDE bytes, cached by the exact-size pool afterwards) would
+  // not be small beside the LDEs themselves. A single matrix larger than the budget still goes alone.
+  constexpr size_t SCRATCH_BUDGET_WORDS = ((size_t)12 << 30) / 4;
   std::vector<LdeJob> jobs;
+  size_t scratch = 0;
   for (auto& j : all) {
     if (j.w == 0) continue;
+    const size_t need = j.n > ((size_t)1 << lde::LOG_ROW_MAX) ? j.n * j.w + ((j.n * j.w) << bl) : 0;
+    if (!jobs.empty() && ((int)jobs.size() == lde::MAX_MATS || scratch + need > SCRATCH_BUDGET_WORDS)) { lde_batch_chunk(ctx, jobs, bl); jobs.clear(); scratch = 0; }
     jobs.push_back(j);
-    if ((int)jobs.size() == lde::MAX_MATS) { lde_batch_chunk(ctx, jobs, bl); jobs.clear(); }
+    scratch += need;
   }
   if (!jobs.empty()) lde_batch_chunk(ctx, jobs, bl);
 }

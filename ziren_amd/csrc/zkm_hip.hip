@@ -159,6 +159,12 @@ int zkm_ctx_trim(zkm_ctx* ctx) {
   for (auto& kv : ctx->free_list) HIP_CHECK(hipFree(kv.second));
   ctx->free_list.clear();
   ctx->drop_coset_tables();
+  // per-height tables a long-lived prover accumulates (12 B per quotient-domain row per (height, degree); n words per height): rebuilt on
+  // the next use of that height
+  for (auto& kv : ctx->selector_tabs) HIP_CHECK(hipFree(kv.second));
+  ctx->selector_tabs.clear();
+  for (auto& kv : ctx->row_tabs) HIP_CHECK(hipFree(kv.second));
+  ctx->row_tabs.clear();
   API_END
 }
 

@@ -657,7 +657,12 @@ class HipProver:
         from . import codegen
         for c in (self.chips if chips is None else chips):
             prog = np.ascontiguousarray(c.program, dtype=np.uint32)
-            co = codegen.specialize(prog)
+            try:
+                co = codegen.specialize(prog)
+            except Exception as e:  # noqa: BLE001  the generator or hipcc failed on this AIR: the library's bytecode interpreter evaluates it (same arithmetic, slower)
+                import warnings
+                warnings.warn(f"no specialised quotient kernel for chip {getattr(c, 'name', '?')} ({type(e).__name__}: {e}); the interpreter evaluates it")
+                continue
             if co is None:          # too long for a straight-line kernel: the interpreter evaluates it
                 continue
             buf = C.create_string_buffer(co, len(co))
