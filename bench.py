@@ -651,13 +651,14 @@ def queue_main(args, farm, fri):
     if rank == 0:
         assert len(gathered) == n_shards and len({p.tobytes() for p in gathered}) == n_shards, "the gathered proofs are not distinct"
         ms = elapsed / n_shards * 1e3
+        cpu_log = 22 if stub else lane.wls[0].chips[0].log_height
         print(json.dumps({
             "metric": "shard-proofs/sec", "value": round(n_shards / elapsed, 4), "unit": "shard-proofs/s", "n_gpus": world, "steps": n_shards,
             "warmup": max(1, args.warmup), "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "strong" if args.queue > 0 else "weak",
             "vs_baseline": None, "dtype": "u32", "verified": True, "stub": stub or None,
             "data": "synthetic (the fibonacci guest's events in closed form, ziren_amd/fibfast.py; two pool shards per rank, page-locked)",
             "config": {"workload": (f"FIB-S{args.shard_size_log}: {n_shards} distinct shards of examples/fibonacci (cut and shaped as the reference does at SHARD_SIZE = 2^{args.shard_size_log}, "
-                                    f"Cpu 2^22 rows) dealt from one claim queue; per shard: executor events in page-locked host memory -> device traces -> full shard "
+                                    f"Cpu 2^{cpu_log} rows) dealt from one claim queue; per shard: executor events in page-locked host memory -> device traces -> full shard "
                                     f"proof (commit+open, blowup 2, 84 queries, 16 PoW bits); proof streams gathered to rank 0 inside the timed region"),
                        "parallelism": f"{world} GPU(s), one process each, {M} shard(s) in flight per GPU (a context + host thread each), claim queue (every lane claims one shard "
                                       f"ahead: its events cross PCIe under the current proof), {'gloo' if stub else 'RCCL'} gather of {sum(len(p) for p in gathered) * 4} proof bytes, "

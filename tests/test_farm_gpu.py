@@ -164,8 +164,9 @@ def test_gpu_run_with_every_chip_through_the_farm(tmp_path):
 
 @pytest.mark.gpu
 def test_gpu_bench_queue_mode_over_rccl():
-    """`bench.py --gpus N --queue`: the benchmark's multi-GPU line through the code path the farm tests cover (claim queue, RCCL gather to
-    rank 0), here with world size 1 on RCCL: six distinct SYN-16 shards, one JSON line, per-rank host milliseconds per shard."""
+    """`bench.py --gpus N --queue`: the benchmark's multi-GPU line through the code path the farm tests cover (claim queue with one shard
+    claimed ahead per lane, two lanes, events prefetched, RCCL gather to rank 0), here with world size 1 on RCCL: six distinct shaped
+    fibonacci shards (SHARD_SIZE 2^16), one JSON line, every lane's last proof verified."""
     import json
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -173,10 +174,12 @@ def test_gpu_bench_queue_mode_over_rccl():
     s.close()
     env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), ZKM_FORCE_DIST="1",
                HSA_ENABLE_IPC_MODE_LEGACY="0")
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--queue", "6", "--log-rows", "16", "--warmup", "1"], env=env,
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--queue", "6", "--shard-size-log", "16", "--warmup", "1"], env=env,
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
+    assert d["verified"] is True and d["config"]["shards_in_flight_per_gpu"] == 2 and d["config"]["ranks_in_process_group"] == 1
+    assert "nccl" in d["config"]["backend"] and d["event_bytes_per_shard"] > 0
     assert d["steps"] == 6 and d["shards_proved"] == 6 and d["value"] > 0 and d["host_ms_per_shard"]["rank0_mean"] > 0

@@ -128,6 +128,30 @@ def test_coset_lde_extreme_columns(hip_ctx, oracle):
         assert np.array_equal(prover.coset_lde_batch(hip_ctx, m, bl, F.to_monty(3)), oracle.coset_lde_batch(m, bl, F.to_monty(3)))
 
 
+@pytest.mark.parametrize("k,bl", [(14, 1), (15, 2), (18, 1)])
+def test_coset_lde_constant_and_nearly_constant_columns(hip_ctx, oracle, k, bl):
+    """The four-step LDE does not transform a column whose words are all equal (lde::Mat::cflag: the constant polynomial — what the shape
+    step's zero-event chips and a trace's unused selectors look like). Constant columns (zero, one, p - 1, a random word) next to random
+    ones and to columns that differ from a constant in exactly one word — the first, the last, one in the middle of a tile, the second
+    word — which must take the full transform: every cell equal to the oracle's."""
+    n = 1 << k
+    rng = np.random.default_rng(900 + k)
+    r = int(rng.integers(1, P - 1))
+    cols = [np.zeros(n, dtype=np.uint64), np.full(n, 1, dtype=np.uint64), np.full(n, P - 1, dtype=np.uint64), np.full(n, r, dtype=np.uint64),
+            rng.integers(0, P, n, dtype=np.uint64)]
+    for pos in (0, 1, n - 1, n // 2 + 37, (1 << 13) + 5, n - (1 << 13)):
+        c = np.full(n, r, dtype=np.uint64)
+        c[pos] = (r + 1) % P
+        cols.append(c)
+    cols.append(rng.integers(0, P, n, dtype=np.uint64))
+    m = F.to_monty(np.stack(cols, axis=1))
+    shift = F.to_monty(3)
+    got = prover.coset_lde_batch(hip_ctx, m, bl, shift)
+    assert np.array_equal(got, oracle.coset_lde_batch(m, bl, shift))
+    for c in range(4):
+        assert (got[:, c] == m[0, c]).all()          # and the constant columns come back as the constant
+
+
 def test_coset_lde_quotient_chunk_shift(hip_ctx, oracle):
     k = 9
     m = rand(np.random.default_rng(9), (1 << k, 4))

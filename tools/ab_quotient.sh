@@ -1,0 +1,19 @@
+#!/bin/bash
+# A/B of generated-quotient-kernel variants on ONE box (ziren_amd/codegen.py's experiment knobs): for each variant the default bench
+# workload's quotient time and step time.   gpurun --timeout 1500 -- 'bash tools/ab_quotient.sh'
+set -u
+R=${GRAFT_REPO_ROOT:-$(pwd)}; cd $R
+run() {  # label, env...
+  local L=$1; shift
+  for rep in 1 2; do
+    env "$@" python bench.py --no-extra --no-cpu-baseline --steps 8 --warmup 2 2>/dev/null | python -c "
+import json,sys
+l=json.loads(sys.stdin.read()); k=l['kernels_ms']
+print('$L rep $rep: step %.3f ms  quotient %.3f ms  perm_rows %.3f  verified %s' % (l['ms_per_step'], k['quotient']['ms'], k['perm_rows']['ms'], l['verified']))"
+  done
+}
+run default ZKM_X=0
+run waves5 ZKM_Q_WAVES=5
+run waves6 ZKM_Q_WAVES=6
+run split700 ZKM_Q_SINGLE=700 ZKM_Q_PART=480
+run default_again ZKM_X=0

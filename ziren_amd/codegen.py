@@ -26,15 +26,23 @@ CSRC = os.path.join(HERE, "csrc")
 CACHE = os.path.join(HERE, "_jit")
 KERNEL_NAME = "zkm_quotient_specialized"
 BLOCK = 256
+PART_INSTRS = int(os.environ.get("ZKM_Q_PART", "6000"))              # a long program is cut into kernels of about this many statements
+SINGLE_KERNEL_INSTRS = int(os.environ.get("ZKM_Q_SINGLE", "12000"))  # ... when it is longer than this (KeccakSponge: 114 324; every other recorded chip is below 10 000)
 
 
 TEMPLATE_VERSION = b"7"  # bump when emit_source changes
+
+
+# Experiment knobs (tools/ab_quotient.sh; unset in production): waves per SIMD the compiler is told to fit the kernel into, and where a
+# program is cut into several kernels. They are part of the cache key.
+Q_WAVES = int(os.environ.get("ZKM_Q_WAVES", "0"))
 
 
 def _template_key() -> bytes:
     """Cached code objects are keyed on the program *and* on everything the generated source pulls in, so an edit to
     the shared prologue (quotient_args.cuh) or the field arithmetic (kb31.cuh) can never leave a stale kernel behind."""
     h = hashlib.sha256(TEMPLATE_VERSION)
+    h.update(f"{Q_WAVES},{SINGLE_KERNEL_INSTRS},{PART_INSTRS}".encode())
     for name in ("quotient_args.cuh", "kb31.cuh"):
         with open(os.path.join(CSRC, name), "rb") as f:
             h.update(f.read())
@@ -211,7 +219,7 @@ def _kernel_source(lines, n_instr, n_constraints, accumulate=False, part="") -> 
 // {n_constraints} constraints{part}). Same arithmetic as stark::quotient_kernel (the interpreter), values in VGPRs.
 #include "quotient_args.cuh"
 
-extern "C" __global__ __launch_bounds__({BLOCK}) void {KERNEL_NAME}(stark::QuotientArgs a) {{
+extern "C" __global__ {f"__attribute__((amdgpu_waves_per_eu({Q_WAVES},{Q_WAVES}))) " if Q_WAVES else ""}__launch_bounds__({BLOCK}) void {KERNEL_NAME}(stark::QuotientArgs a) {{
   stark::QuotientPoint q;
   if (!stark::quotient_point(a, stark::quotient_row(a), q)) return;
   kb::FoldAcc acc = kb::fold_zero();
@@ -228,8 +236,6 @@ def emit_source(program: np.ndarray) -> str:
     return _kernel_source(lines, int(prog[0]), int(prog[2]))
 
 
-PART_INSTRS = 6000             # a long program is cut into kernels of about this many instructions
-SINGLE_KERNEL_INSTRS = 12000   # ... when it is longer than this (KeccakSponge: 114 324; every other recorded chip is below 10 000)
 
 
 def emit_part_sources(program: np.ndarray):

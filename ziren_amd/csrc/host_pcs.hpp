@@ -19,6 +19,11 @@ static void lde_batch_chunk(zkm_ctx* ctx, const std::vector<LdeJob>& jobs, int b
   uint32_t* tmp1 = tmp1_words ? ctx->alloc_n<uint32_t>(tmp1_words) : nullptr;
   uint32_t* tmp2 = tmp2_words ? ctx->alloc_n<uint32_t>(tmp2_words) : nullptr;
   size_t t1 = 0, t2 = 0;
+  // constant-column flags of the four-step matrices (lde::Mat::cflag): two words per column, zero = "constant so far"
+  size_t big_cols = 0, fc = 0;
+  for (size_t oi : order) if (jobs[oi].n > ((size_t)1 << lde::LOG_ROW_MAX)) big_cols += jobs[oi].w;
+  uint32_t* cflags = big_cols ? ctx->alloc_n<uint32_t>(2 * big_cols) : nullptr;
+  if (cflags) HIP_CHECK(hipMemsetAsync(cflags, 0, 2 * big_cols * sizeof(uint32_t), ctx->cur));
   uint32_t blk[4] = {0, 0, 0, 0};
   size_t lds_cols = 0, lds_small = 0;
   double bytes_inv = 0, bytes_rows = 0, bytes_fwd = 0, bytes_small = 0;
@@ -52,6 +57,7 @@ static void lde_batch_chunk(zkm_ctx* ctx, const std::vector<LdeJob>& jobs, int b
       if (la) {
         m.tmp1 = tmp1 + t1; t1 += n * j.w;
         m.tmp2 = tmp2 + t2; t2 += (n * j.w) << bl;
+        m.cflag = cflags + fc; fc += 2 * j.w;
         auto ct = ctx->coset_tables(k, bl, j.lde_shift);
         m.twf = ct.twf; m.cs = ct.cs;
       }
@@ -88,6 +94,7 @@ static void lde_batch_chunk(zkm_ctx* ctx, const std::vector<LdeJob>& jobs, int b
     KLAUNCH(ctx, "lde_rows", bytes_small, lde::lde_rows, dim3(blk[lde::K_ROWS_SMALL]), dim3(lde::THREADS), lds_small, d);
   ctx->release(tmp1);
   ctx->release(tmp2);
+  ctx->release(cflags);
   ctx->release((void*)d);
 }
 

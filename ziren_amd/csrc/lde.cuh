@@ -234,6 +234,12 @@ struct Mat {
   const uint32_t* cs;   // la > 0: cs[j A + k1] = shift_j^k1 / n
   uint32_t col0, w;     // first column inside the group, width
   uint32_t shift, pad;  // shift of coset 0 (shift_j = shift w_N^j)
+  uint32_t* cflag;      // la > 0: per column two words, zeroed before the batch: [2c] != 0 once some tile of column c was seen to hold two
+                        //         different values (lde_cols<false>), [2c + 1] = the column's first word. A column whose words are all equal
+                        //         is the constant polynomial: its LDE is that word on every row of every coset, so the two later passes do
+                        //         not transform it (lde_rows_big returns, lde_cols<true> fills its output tile). The shape step pads every
+                        //         shard with chips that have no events at all (constant rows: 14 % of the benchmarked shard's cells),
+                        //         and real traces hold columns that never change (unused selectors)
 };
 struct Group {
   int la, lb, logT, pad;
@@ -292,6 +298,25 @@ __global__ __launch_bounds__(THREADS) void lde_cols(const Batch* __restrict__ d)
   // 16-byte global accesses (T >= 8), four in flight per thread
   const int logTq = logT - 2;
   const int quads = (A << logT) >> 2;
+  if (FORWARD && gp::load(m.cflag + 2 * c) == 0) {
+    // a constant column (see Mat::cflag): every word of this block's output tile is the column's word
+    const uint32_t v0 = gp::load(m.cflag + 2 * c + 1);
+    const uint32_t v = kb::umin32(v0, v0 - kb::P);
+    uint32_t* dst = m.out + c * (n << log_blowup) + (size_t)kb::bitrev(z, log_blowup) * n;
+    if (la < 2) {
+      for (int u = threadIdx.x; u < (A << logT); u += blockDim.x)
+        gp::store(dst + (size_t)kb::bitrev((uint32_t)(t0 + (u >> la)), lb) * A + (u & (A - 1)), v);
+      return;
+    }
+    const int logAq = la - 2;
+    for (int u0 = threadIdx.x; u0 < quads; u0 += blockDim.x) {
+      const int t = u0 >> logAq, q = (u0 & ((1 << logAq) - 1)) << 2;
+      gp::store(reinterpret_cast<uint4*>(dst + (size_t)kb::bitrev((uint32_t)(t0 + t), lb) * A + q), make_uint4(v, v, v, v));
+    }
+    return;
+  }
+  const uint32_t first_word = FORWARD ? 0u : gp::load(m.in + c * n);   // the column's first word: what a constant column holds everywhere
+  uint32_t differs = 0;
   for (int u0 = threadIdx.x; u0 < quads; u0 += 4 * blockDim.x) {
     uint4 v[4];
 #pragma unroll
@@ -305,8 +330,14 @@ __global__ __launch_bounds__(THREADS) void lde_cols(const Batch* __restrict__ d)
       if (u < quads) {
         uint32_t* dd = lds + (u >> logTq) * TP + ((u & ((1 << logTq) - 1)) << 2);
         dd[0] = v[k].x; dd[1] = v[k].y; dd[2] = v[k].z; dd[3] = v[k].w;
+        if (!FORWARD) differs |= (v[k].x ^ first_word) | (v[k].y ^ first_word) | (v[k].z ^ first_word) | (v[k].w ^ first_word);
       }
     }
+  }
+  if (!FORWARD) {
+    // a wave that saw a word different from the column's first one marks the column (every writer writes the same word)
+    if (__any(differs != 0) && (threadIdx.x & 63) == 0) gp::store(m.cflag + 2 * c, 1u);
+    if (xb == 0 && threadIdx.x == 0) gp::store(m.cflag + 2 * c + 1, first_word);
   }
   __syncthreads();
   // natural rows in, bit-reversed rows out either way, lazy Cooley-Tukey butterflies (ten instructions instead of twelve). The inverse
@@ -433,6 +464,7 @@ __global__ __launch_bounds__(THREADS, 6) void lde_rows_big(const Batch* __restri
   const size_t n = (size_t)B << la;
   const uint32_t nmask = (uint32_t)n - 1;
   const uint32_t k1 = kb::bitrev(pr, la);
+  if (gp::load(m.cflag + 2 * c) == 0) return;   // a constant column: nothing to transform (lde_cols<true> fills the output), whole block
   const uint32_t* src = m.tmp1 + c * n + (size_t)pr * B;
   const uint32_t* __restrict__ pw_lo = g.pw_lo;
   const uint32_t* __restrict__ pw_hi = g.pw_hi;
