@@ -56,6 +56,32 @@ __global__ __launch_bounds__(THREADS) void perm_rows(const uint32_t* __restrict_
   // has ten of them).
   constexpr int PERM_GROUP = 2;   // 4 halves the inversions again but takes 98 registers (3 waves per SIMD: the kernel turns latency-bound and gets slower); 2 takes 50
   for (int b0 = 0; b0 < perm_ext_w - 1; b0 += PERM_GROUP) {
+    // Rows whose lookups all have multiplicity zero — the padding rows behind a chip's events (62 % of the benchmarked shard's Cpu rows),
+    // every row of a chip the shape step added without events, table rows nobody looked up — contribute the fraction 0 / den = 0 to
+    // every column: when that holds for all 64 rows of a wavefront, the group's denominators and inversion are not computed at all
+    // (round 4). The multiplicities are evaluated first (their linear forms are one or two terms); the walk over the blob is scalar.
+    {
+      int p2 = pos, k2 = k;
+      uint32_t any_mult = 0;
+      for (int g = 0; g < PERM_GROUP; g++)
+        if (b0 + g < perm_ext_w - 1)
+          for (int q = 0; q < batch && k2 < n_lookups; q++, k2++) {
+            const int nv = blob[p2 + 1];
+            p2 += 2;
+            for (int v = 0; v < nv; v++) p2 += 2 + 2 * (int)blob[p2];     // skip the value forms: {terms, constant, terms x (column, weight)}
+            any_mult |= apply_pair_col(blob, p2, main, n, prep, n, r);
+          }
+      if (__all(any_mult == 0)) {
+#pragma unroll
+        for (int g = 0; g < PERM_GROUP; g++)
+          if (b0 + g < perm_ext_w - 1)
+#pragma unroll
+            for (int e = 0; e < 4; e++) perm[(size_t)(4 * (b0 + g) + e) * n + r] = 0;
+        pos = p2;
+        k = k2;
+        continue;
+      }
+    }
     kb::E4 num[PERM_GROUP], den[PERM_GROUP];
     uint32_t d0[PERM_GROUP], d1[PERM_GROUP], nrm[PERM_GROUP];
 #pragma unroll
