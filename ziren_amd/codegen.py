@@ -336,6 +336,21 @@ def specialize_many(programs, verbose: bool = False):
         return list(pool.map(lambda prog: specialize(prog, verbose=verbose), programs))
 
 
+def prune_cache():
+    """Remove code objects the manifest no longer names (left behind when the template key changes: every kernel gets a new file name).
+    Called at the end of `__graft_entry__.build()`; the cache travels to the GPU box with the snapshot."""
+    import json
+    try:
+        with open(os.path.join(CACHE, "manifest.json")) as f:
+            keep = set(json.load(f).values()) | {"manifest.json", "manifest.json.lock"}
+    except (OSError, ValueError):
+        return 0
+    stale = [f for f in os.listdir(CACHE) if f not in keep and not f.endswith(".tmp")]
+    for f in stale:
+        os.remove(os.path.join(CACHE, f))
+    return len(stale)
+
+
 _manifest_lock = __import__("threading").Lock()
 
 
