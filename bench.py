@@ -759,6 +759,9 @@ def main():
             ev, proof = events_leg(wl, hp, pk, ch0, leg["out"], min(steps, 6))
             verify_or_die(wl, fri, ch0, proof, wl.tag + " events->proof")
             ev["verified"] = True
+            ev["proof_identical_to_resident_leg"] = bool(np.array_equal(proof, leg["proof"]))     # same events, same transcript: the same words
+            if not ev["proof_identical_to_resident_leg"]:
+                raise SystemExit("bench.py: the proof made from prefetched events differs from the one made from resident traces")
             line["events_to_proof"] = ev
         extra = {}
         also = [a for a in args.also.split(",") if a]
