@@ -15,7 +15,7 @@ N > 1: one process per GPU (launched by the driver through torch.distributed.run
 `python bench.py --gpus 8` starts 8 ranks). Shards are independent (crates/core/machine/src/utils/prove.rs:492-497): the ranks take
 distinct shards from one claim queue, each from the executor's events in page-locked host memory (events -> device traces -> proof, the
 next shard's events crossing PCIe under the current proof), the proof streams are gathered to rank 0 over RCCL inside the timed region;
-there is no data-path collective. Per-GPU work is fixed (8 shards per GPU): scaling is weak, value = shards / max-over-ranks time.
+there is no data-path collective. Per-GPU work is fixed (--steps K shards per GPU, K N in the queue): scaling is weak, value = shards / max-over-ranks time.
 """
 import argparse
 import ctypes as C
@@ -35,7 +35,6 @@ os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")      # before anything initi
 HBM_PEAK_GBPS = 8000.0     # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 FP64_VECTOR_TFLOPS = 78.6  # MI355X FP64 vector peak: 256 CUs x 4 SIMDs x 16 lanes x 2 flop x 2.4 GHz (MI355X_MICROARCH.md)
 PROFILE_ROUND = "r04"
-SHARDS_PER_GPU = 8        # N > 1 default: shards dealt per GPU (weak scaling); one shard is claimed ahead, so the tail costs at most 1/8
 HASHING_KERNELS = ("compress_layer", "hash_leaves", "hash_leaves_tree", "hash_fri_leaves", "hash_fri_leaves_tree", "compress_small", "compress_tail")
 LDE_KERNELS = ("lde_rows", "lde_cols_forward", "lde_cols_inverse")
 ROCPROF_NAMES = {"compress_layer": "merkle::compress_layer", "hash_leaves": "merkle::hash_leaves", "hash_leaves_tree": "merkle::hash_leaves_tree",
@@ -626,7 +625,9 @@ def queue_main(args, farm, fri):
         for l in lanes:
             l.sync()
     farm.device_sync = sync_all
-    n_shards = args.queue if args.queue > 0 else SHARDS_PER_GPU * world
+    # default (and --queue -1): --steps K shards per GPU, K N in the queue (weak scaling: per-GPU work fixed); --queue S: S shards in all
+    per_gpu = max(args.steps, 2 * M)
+    n_shards = args.queue if args.queue > 0 else per_gpu * world
     for l in lanes:
         for _ in range(max(1, args.warmup)):
             l.prove(0, l.prefetch(0))
@@ -653,11 +654,13 @@ def queue_main(args, farm, fri):
         ms = elapsed / n_shards * 1e3
         cpu_log = 22 if stub else lane.wls[0].chips[0].log_height
         print(json.dumps({
-            "metric": "shard-proofs/sec", "value": round(n_shards / elapsed, 4), "unit": "shard-proofs/s", "n_gpus": world, "steps": n_shards,
-            "warmup": max(1, args.warmup), "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "strong" if args.queue > 0 else "weak",
+            "metric": "shard-proofs/sec", "value": round(n_shards / elapsed, 4), "unit": "shard-proofs/s", "n_gpus": world,
+            "steps": n_shards if args.queue > 0 else per_gpu, "shards": n_shards,
+            "warmup": max(1, args.warmup), "ms_per_step": round(ms if args.queue > 0 else elapsed / per_gpu * 1e3, 3), "ms_per_shard": round(ms, 3),
+            "higher_is_better": True, "scaling": "strong" if args.queue > 0 else "weak",
             "vs_baseline": None, "dtype": "u32", "verified": True, "stub": stub or None,
             "data": "synthetic (the fibonacci guest's events in closed form, ziren_amd/fibfast.py; two pool shards per rank, page-locked)",
-            "config": {"workload": (f"FIB-S{args.shard_size_log}: {n_shards} distinct shards of examples/fibonacci (cut and shaped as the reference does at SHARD_SIZE = 2^{args.shard_size_log}, "
+            "config": {"workload": (f"FIB-S{args.shard_size_log}: {n_shards} distinct shards ({'as given' if args.queue > 0 else str(per_gpu) + ' per GPU'}) of examples/fibonacci (cut and shaped as the reference does at SHARD_SIZE = 2^{args.shard_size_log}, "
                                     f"Cpu 2^{cpu_log} rows) dealt from one claim queue; per shard: executor events in page-locked host memory -> device traces -> full shard "
                                     f"proof (commit+open, blowup 2, 84 queries, 16 PoW bits); proof streams gathered to rank 0 inside the timed region"),
                        "parallelism": f"{world} GPU(s), one process each, {M} shard(s) in flight per GPU (a context + host thread each), claim queue (every lane claims one shard "
@@ -698,7 +701,7 @@ def main():
     ap.add_argument("--inflight", type=int, default=2, help="queue path: shards in flight per GPU (a context + host thread each); 2 fills one proof's transcript "
                     "round trips and launch gaps with the other's kernels (the N = 1 resident line always keeps one in flight and reports two beside it)")
     ap.add_argument("--queue", type=int, default=0, metavar="SHARDS", help="N = 1 too: deal SHARDS distinct shards through the claim queue (events -> traces -> proof); "
-                    "-1: 8 per GPU. The default for N > 1.")
+                    "-1 (the default for N > 1): --steps per GPU.")
     args = ap.parse_args()
     if args.log_rows is None:
         args.log_rows = 21 if (args.workload == "fib-tight" or args.tracegen) else 22

@@ -23,7 +23,7 @@ def test_gpus_2_without_a_launcher_starts_two_ranks_and_prints_one_line():
     assert len(lines) == 1, r.stdout
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["config"]["ranks_in_process_group"] == 2 and line["stub"] is True
-    assert line["steps"] == 16 and line["shards_proved"] == 16 and line["scaling"] == "weak"          # 8 shards per GPU
+    assert line["steps"] == 10 and line["shards"] == 20 and line["shards_proved"] == 20 and line["scaling"] == "weak"          # --steps (10) shards per GPU
     assert line["fewest_shards_on_a_rank"] >= 1 and line["verified"] is True
     assert "claim queue" in line["config"]["parallelism"]
 
