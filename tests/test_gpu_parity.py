@@ -107,6 +107,38 @@ def test_async_upload_then_prove(hip_ctx, oracle):
         hip_ctx.host_free(h)
 
 
+def test_events_prefetch_and_matrix_upload_share_a_context():
+    """zkm_events_upload_async first, zkm_matrix_upload_async afterwards, in a fresh context (each has its own DMA stream: the matrix
+    uploads create theirs together with their staging slabs), then trace generation from the prefetched address: rows equal to the ones
+    generated from the host pointer; freeing the events twice and destroying the context with a prefetch outstanding are harmless."""
+    from ziren_amd import events as E
+    ctx = prover.Context(0)
+    try:
+        ev = E.synthetic_alu_events(E.CHIP_ADD_SUB, 5000)
+        pinned = ctx.host_alloc((len(ev) * (ev.dtype.itemsize // 4),))
+        pinned[...] = ev.view(np.uint32).reshape(-1)
+        pev = pinned.view(ev.dtype)
+        d = ctx.events_upload_async(pev)
+        m = rand(np.random.default_rng(5), (1024, 7))
+        hm = ctx.host_alloc(m.shape)
+        hm[...] = m
+        dm = ctx.upload_async(hm)
+        assert np.array_equal(dm.to_host(), m)
+        want = ctx.tracegen_alu(E.CHIP_ADD_SUB, ev, 13)
+        got = ctx.tracegen_alu(E.CHIP_ADD_SUB, d, 13)
+        assert np.array_equal(got.to_host(), want.to_host())
+        with pytest.raises(TypeError):
+            ctx.tracegen_jump(d, 13)              # events of another chip's record type
+        d.free()
+        d.free()
+        for x in (dm, want, got):
+            x.free()
+        left = ctx.events_upload_async(pev)       # left outstanding on purpose: the context's destruction waits for the copy
+    finally:
+        ctx.close()
+    left.free()                                   # after the context is gone: nothing to do, no crash
+
+
 @pytest.mark.parametrize("k,w,bl", [(0, 1, 1), (1, 2, 1), (3, 3, 1), (5, 4, 2), (8, 5, 1), (10, 3, 3), (13, 2, 1),
                                     (14, 3, 1), (15, 2, 2), (16, 5, 1), (17, 1, 1), (18, 3, 1), (18, 1, 2), (19, 1, 1)])   # 18: la = 5, the strided passes' fused last stage
 def test_coset_lde_matches_oracle(hip_ctx, oracle, k, w, bl):

@@ -86,6 +86,7 @@ struct zkm_ctx {
   static constexpr size_t UP_SLAB_BYTES = (size_t)32 << 20;
   hipStream_t cur = nullptr;      // where KLAUNCH / upload / kernel-timing events go right now
   // executor events copied ahead of their trace generation (zkm_events_upload_async): device address -> (bytes, "landed" event)
+  hipStream_t ev_dma = nullptr;   // the DMA stream of zkm_events_upload_async (its own: the matrix uploads' streams come and go with their staging slabs)
   struct Prefetched { size_t bytes; hipEvent_t landed; };
   std::map<const void*, Prefetched> prefetched;
   // The device copy of a chip's events for a zkm_tracegen_* call. `events` is either a host pointer — copied now, on the compute

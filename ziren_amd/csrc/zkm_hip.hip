@@ -125,6 +125,7 @@ void zkm_ctx_destroy(zkm_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
+  for (auto& kv : ctx->prefetched) { (void)hipEventSynchronize(kv.second.landed); (void)hipEventDestroy(kv.second.landed); }   // their buffers are in `live`
   for (auto& kv : ctx->free_list) (void)hipFree(kv.second);
   for (auto& kv : ctx->live) (void)hipFree(kv.first);
   for (auto& kv : ctx->tw_fwd) (void)hipFree(kv.second);
@@ -140,6 +141,7 @@ void zkm_ctx_destroy(zkm_ctx* ctx) {
   for (auto& m : ctx->modules) (void)hipModuleUnload(m);
   if (ctx->pin) (void)hipHostFree(ctx->pin);
   if (ctx->arena) (void)hipFree(ctx->arena);
+  if (ctx->ev_dma) (void)hipStreamDestroy(ctx->ev_dma);
   (void)hipStreamDestroy(ctx->stream);
   (void)hipStreamDestroy(ctx->stream2);
   if (ctx->up_dma) {
@@ -373,7 +375,7 @@ int zkm_events_upload_async(zkm_ctx* ctx, const void* host, size_t bytes, void**
   std::lock_guard<std::mutex> lk(ctx->mu);
   HIP_CHECK(hipSetDevice(ctx->device));
   if (bytes && !host) throw std::runtime_error("zkm_events_upload_async: null events");
-  if (!ctx->up_dma) HIP_CHECK(hipStreamCreateWithFlags(&ctx->up_dma, hipStreamNonBlocking));
+  if (!ctx->ev_dma) HIP_CHECK(hipStreamCreateWithFlags(&ctx->ev_dma, hipStreamNonBlocking));
   void* d = ctx->alloc(std::max<size_t>(bytes, 4));
   hipEvent_t landed = nullptr;
   try {
@@ -381,10 +383,10 @@ int zkm_events_upload_async(zkm_ctx* ctx, const void* host, size_t bytes, void**
     // pool buffers come back in compute-stream order: the DMA stream first waits for what the compute stream has queued so far
     hipEvent_t reuse = ctx->get_event();
     HIP_CHECK(hipEventRecord(reuse, ctx->stream));
-    HIP_CHECK(hipStreamWaitEvent(ctx->up_dma, reuse, 0));
+    HIP_CHECK(hipStreamWaitEvent(ctx->ev_dma, reuse, 0));
     ctx->event_pool.push_back(reuse);
-    if (bytes) HIP_CHECK(hipMemcpyAsync(d, host, bytes, hipMemcpyHostToDevice, ctx->up_dma));
-    HIP_CHECK(hipEventRecord(landed, ctx->up_dma));
+    if (bytes) HIP_CHECK(hipMemcpyAsync(d, host, bytes, hipMemcpyHostToDevice, ctx->ev_dma));
+    HIP_CHECK(hipEventRecord(landed, ctx->ev_dma));
   } catch (...) {
     if (landed) (void)hipEventDestroy(landed);
     ctx->release(d);
@@ -395,7 +397,7 @@ int zkm_events_upload_async(zkm_ctx* ctx, const void* host, size_t bytes, void**
   API_END
 }
 void zkm_events_free(zkm_ctx* ctx, void* device_events) {
-  if (!device_events) return;
+  if (!ctx || !device_events) return;
   std::lock_guard<std::mutex> lk(ctx->mu);
   auto it = ctx->prefetched.find(device_events);
   if (it == ctx->prefetched.end()) return;

@@ -32,9 +32,9 @@ class DeviceMatrix:
         return out
 
     def free(self):
-        if self.h:
+        if self.h and self.ctx.h:             # a closed context has already released everything it owned
             lib.load().zkm_matrix_free(self.ctx.h, self.h)
-            self.h = None
+        self.h = None
 
     def __del__(self):
         try:
@@ -50,9 +50,9 @@ class ByteLookups:
         self.ctx, self.h = ctx, handle
 
     def free(self):
-        if self.h:
+        if self.h and self.ctx.h:
             lib.load().zkm_byte_lookups_free(self.ctx.h, self.h)
-            self.h = None
+        self.h = None
 
     def __del__(self):
         try:
@@ -72,9 +72,9 @@ class DeviceEvents:
         return len(self.host)
 
     def free(self):
-        if self.ptr:
+        if self.ptr and self.ctx.h:           # a closed context has already released everything it owned
             lib.load().zkm_events_free(self.ctx.h, C.c_void_p(self.ptr))
-            self.ptr = None
+        self.ptr = None
 
     def __del__(self):
         try:
@@ -568,9 +568,9 @@ class PcsData:
         return values, proof
 
     def free(self):
-        if self.h:
+        if self.h and self.ctx.h:
             lib.load().zkm_pcs_data_free(self.ctx.h, self.h)
-            self.h = None
+        self.h = None
 
     def __del__(self):
         try:
@@ -616,9 +616,9 @@ class ProvingKey:
         lib.load().zkm_pk_observe_into(self.h, C.byref(challenger))
 
     def free(self):
-        if self.h:
+        if self.h and self.ctx.h:
             lib.load().zkm_pk_free(self.ctx.h, self.h)
-            self.h = None
+        self.h = None
 
     def __del__(self):
         try:
