@@ -667,7 +667,7 @@ def queue_main(args, farm, fri):
                                       f"ahead: its events cross PCIe under the current proof), {'gloo' if stub else 'RCCL'} gather of {sum(len(p) for p in gathered) * 4} proof bytes, "
                                       f"no data-path collective",
                        "shards_in_flight_per_gpu": M, "ranks_in_process_group": ranks_in_group,
-                       "backend": "none (one process)" if farm.dist is None else "gloo" if stub else "nccl (RCCL)"},
+                       "backend": "none (one process)" if farm.dist is None else "gloo" if (stub or os.environ.get("ZKM_BENCH_ONE_DEVICE") == "1") else "nccl (RCCL)"},
             "host_ms_per_shard": {"rank0_mean": round(mine, 3), "max_over_ranks_of_means": round(slowest, 3)},
             "event_bytes_per_shard": lane.event_bytes,
             "h2d_GBps_per_rank": round(lane.event_bytes * len(ids) / elapsed / 1e9, 2),      # rank 0's events over the timed region: what its PCIe link carried
@@ -714,8 +714,13 @@ def main():
         sys.exit(self_launch(args.gpus))
 
     from ziren_amd import abi, farm as farm_mod, prover
-    farm = farm_mod.Farm(backend="gloo" if os.environ.get("ZKM_BENCH_STUB_PROVER") == "1" else None)
+    # tests only: ZKM_BENCH_STUB_PROVER=1 (no GPU at all: gloo, stub lanes) and ZKM_BENCH_ONE_DEVICE=1 (a 1-GPU box standing in for N: every
+    # rank proves on device 0 and the process group runs over gloo — RCCL refuses two ranks on one device)
+    one_device = os.environ.get("ZKM_BENCH_ONE_DEVICE") == "1"
+    farm = farm_mod.Farm(backend="gloo" if (os.environ.get("ZKM_BENCH_STUB_PROVER") == "1" or one_device) else None)
     rank, local_rank, world = farm.rank, farm.local_rank, farm.world
+    if one_device:
+        farm.local_rank = local_rank = 0
     if world != args.gpus:
         farm.close()
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the process group has {world} rank(s) (WORLD_SIZE): refusing to print a line for another N")

@@ -183,3 +183,21 @@ def test_gpu_bench_queue_mode_over_rccl():
     assert d["verified"] is True and d["config"]["shards_in_flight_per_gpu"] == 2 and d["config"]["ranks_in_process_group"] == 1
     assert "nccl" in d["config"]["backend"] and d["event_bytes_per_shard"] > 0
     assert d["steps"] == 6 and d["shards_proved"] == 6 and d["value"] > 0 and d["host_ms_per_shard"]["rank0_mean"] > 0
+
+
+@pytest.mark.gpu
+def test_gpu_bench_two_ranks_on_one_device_share_the_queue():
+    """`bench.py --gpus 2` self-launching two ranks that both prove on this box's one GPU (ZKM_BENCH_ONE_DEVICE: process group over gloo, since
+    RCCL wants a device per rank): two processes, four lanes, one claim counter in the store, events prefetched, proofs gathered to rank 0,
+    every lane's last proof verified — the N > 1 line's code path with real proofs."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(ZKM_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--shard-size-log", "16", "--steps", "4", "--warmup", "1"], env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["ranks_in_process_group"] == 2 and d["shards"] == 8 and d["shards_proved"] == 8 and d["steps"] == 4
+    assert d["verified"] is True and d["fewest_shards_on_a_rank"] >= 1 and d["config"]["shards_in_flight_per_gpu"] == 2
