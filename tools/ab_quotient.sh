@@ -12,8 +12,10 @@ l=json.loads(sys.stdin.read()); k=l['kernels_ms']
 print('$L rep $rep: step %.3f ms  quotient %.3f ms  perm_rows %.3f  verified %s' % (l['ms_per_step'], k['quotient']['ms'], k['perm_rows']['ms'], l['verified']))"
   done
 }
-run default ZKM_X=0
-run waves5 ZKM_Q_WAVES=5
-run waves6 ZKM_Q_WAVES=6
-run split700 ZKM_Q_SINGLE=700 ZKM_Q_PART=480
-run default_again ZKM_X=0
+run prefetch4 ZKM_Q_PREFETCH=4
+run prefetch2 ZKM_Q_PREFETCH=2
+run prefetch6 ZKM_Q_PREFETCH=6
+run prefetch4_ahead2 ZKM_Q_PREFETCH=4 ZKM_Q_AHEAD=2
+run prefetch2_ahead2 ZKM_Q_PREFETCH=2 ZKM_Q_AHEAD=2
+run prefetch4_again ZKM_Q_PREFETCH=4
+# round 4, measured and not kept (EXPERIMENTS.md): ZKM_Q_WAVES=5 / 6, ZKM_Q_SINGLE=700 ZKM_Q_PART=480
