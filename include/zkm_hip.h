@@ -157,6 +157,12 @@ void zkm_ctx_set_kernel_timing_only(zkm_ctx* ctx, const char* name);
 int zkm_ctx_register_quotient_kernel(zkm_ctx* ctx, const uint32_t* program, uint32_t program_len,
                                      const void* code_object, size_t code_object_len);
 
+/* The same for a chip's permutation trace: a gfx950 code object exporting `zkm_perm_rows_specialized(stark::PermArgs)` generated from
+ * exactly these lookups words and this log_quotient_degree (ziren_amd/codegen.py emit_perm_source). zkm_open / zkm_permutation_trace use
+ * it for chips whose lookups match and the generic kernel (which walks the blob) otherwise; both compute the same values. */
+int zkm_ctx_register_perm_kernel(zkm_ctx* ctx, const uint32_t* lookups, uint32_t lookups_len, uint32_t log_quotient_degree,
+                                 const void* code_object, size_t code_object_len);
+
 /* ---- DeviceMatrix ----------------------------------------------------------------------- */
 /* Page-locked host memory for trace buffers (the shim's trace generation writes rows straight into it):
  * zkm_matrix_upload from such a buffer is pure DMA at PCIe rate. Pageable buffers work too, slower. */

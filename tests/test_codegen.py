@@ -100,3 +100,66 @@ def test_gpu_shared_term_chip_specialised_equals_interpreter_and_oracle(oracle):
     opk.observe_into(och)
     oproof, _ = oracle.prove_shard(opk, sh.chips, [x.trace for x in sh.chips], sh.public_values, fri, synth.NUM_PV_ELTS, och)
     assert np.array_equal(proofs[1], oproof)
+
+
+# ---- permutation-trace kernels -----------------------------------------------------------------------------------------------------------
+
+def test_perm_source_loads_every_column_once_and_parses_the_blob_back():
+    from ziren_amd import chips
+    c = chips.record_cpu_chip(10)
+    n_sends, lookups = codegen.parse_lookups(c.lookups_blob)
+    assert n_sends == len(c.sends) and len(lookups) == len(c.sends) + len(c.receives)
+    assert np.array_equal(air.encode_lookups(c.sends, c.receives), c.lookups_blob)
+    src = codegen.emit_perm_source(c.lookups_blob, c.log_quotient_degree)
+    loads = re.findall(r"const uint32_t ([mp]\d+) = a\.(?:main|prep)\[", src)
+    assert len(loads) == len(set(loads)) > 10
+    assert src.count("kb::inv_batch<") == -(-(c.perm_ext_width - 1) // 2)
+    assert codegen.specialize_perm(chips.record_keccak_sponge_chip(10).lookups_blob, 1) is None      # too many lookups: the generic kernel
+
+
+def test_perm_kernels_compile_for_gfx950():
+    from ziren_amd import chips
+    for c in (chips.record_cpu_chip(10), chips.record_global_chip(10), chips.record_byte_chip(), synth.syn_shard(8, with_prep=True, with_trace=False).chips[0]):
+        co = codegen.specialize_perm(c.lookups_blob, c.log_quotient_degree)
+        assert co is not None and len(co) > 1000
+
+
+@pytest.mark.gpu
+def test_gpu_generated_permutation_kernels_equal_the_generic_one_and_the_oracle(oracle):
+    """zkm_permutation_trace of recorded core chips on executor traces and of synthetic chips (with preprocessed columns, batches of 2 and 4):
+    the generic kernel (a context with nothing registered), the generated kernel (registered) and the oracle give the same cells and sums."""
+    from ziren_amd import chips as CH, field as F, miniexec as M, prover
+    import machine_lib as ML
+    rng = np.random.default_rng(77)
+    challenge = lambda: [int(x) for x in F.to_monty(rng.integers(0, F.P, 4, dtype=np.uint64).astype(np.uint32))]      # noqa: E731
+    cases = [(c, c.trace, c.prep_trace) for c in synth.syn_shard(11, with_prep=True).chips[:4]]
+    cases += [(c, c.trace, c.prep_trace) for c in synth.edge_shard(9, lqd=2).chips[:3]]
+    m = M.run_machine(1200, seed=5, shard_cycles=1 << 20)
+    cs = ML.build_shard(ML.Oracle(oracle), m, 0)
+    cs[-2].prep_trace = oracle.tracegen_byte_table()
+    cs[-1].prep_trace = oracle.tracegen_program(0, m.shards[0].record.cpu, m.program, m.pc_base, ML.log2_rows(len(m.program)))
+    cases += [(c, c.trace, c.prep_trace) for c in cs]
+    plain, special = prover.Context(0), prover.Context(0)
+    try:
+        hp = prover.HipProver([c for c, _, _ in cases], __import__("ziren_amd.abi", fromlist=["abi"]).FriConfig(1, 8, 4), synth.NUM_PV_ELTS, ctx=special)
+        hp.specialize_perm_kernels()
+        checked = 0
+        for chip, trace, prep in cases:
+            if chip.prep_width and prep is None:
+                continue
+            alpha, beta = challenge(), challenge()
+            want, want_sum = oracle.permutation_trace(chip, trace, prep, alpha, beta)
+            for ctx in (plain, special):
+                main_d = ctx.upload(trace)
+                prep_d = ctx.upload(prep) if chip.prep_width else None
+                got, got_sum = ctx.permutation_trace(chip, main_d, prep_d, alpha, beta)
+                assert np.array_equal(got.to_host(), want), (chip.name, ctx is special)
+                assert np.array_equal(got_sum, want_sum), chip.name
+                got.free(); main_d.free()
+                if prep_d is not None:
+                    prep_d.free()
+            checked += 1
+        assert checked >= 12 and {"Cpu", "Global", "Byte", "Program"} <= {c.name for c, _, _ in cases}
+    finally:
+        plain.close()
+        special.close()

@@ -235,7 +235,7 @@ extern "C" __global__ {f"__attribute__((amdgpu_waves_per_eu({Q_WAVES},{Q_WAVES})
 
 def _is_load(line: str) -> int:
     """Words a statement loads from the trace LDEs (0: not a load)."""
-    if "= a.main_lde[" in line or "= a.prep_lde[" in line:
+    if "= a.main_lde[" in line or "= a.prep_lde[" in line or "= a.main[" in line or "= a.prep[" in line:
         return 1
     return 4 if "a.perm_lde + " in line else 0
 
@@ -379,6 +379,173 @@ def specialize_many(programs, verbose: bool = False):
     from concurrent.futures import ThreadPoolExecutor
     with ThreadPoolExecutor(max_workers=os.cpu_count() or 1) as pool:
         return list(pool.map(lambda prog: specialize(prog, verbose=verbose), programs))
+
+
+# ---- permutation-trace kernels -----------------------------------------------------------------------------------------------------------
+PERM_KERNEL_NAME = "zkm_perm_rows_specialized"
+MAX_PERM_LOOKUPS = 64      # beyond this (the precompiles: ShaCompress 115 lookups, KeccakSponge 357, EdAddAssign 881) the straight-line kernel is
+                           # megabytes of code; those chips keep the generic kernel, which walks the blob
+
+
+def parse_lookups(blob):
+    """The `lookups` blob of zkm_chip_desc (air.encode_lookups) back into (n_sends, [(kind, [value forms], multiplicity form)]) with a form =
+    (constant word, [(is_main, column, weight word)])."""
+    b = [int(x) for x in np.asarray(blob, dtype=np.uint32)]
+    n_sends, n_receives = b[0], b[1]
+    pos, out = 2, []
+
+    def form():
+        nonlocal pos
+        nt, const = b[pos], b[pos + 1]
+        pos += 2
+        terms = []
+        for _ in range(nt):
+            cw, weight = b[pos], b[pos + 1]
+            pos += 2
+            terms.append((cw >> 31, cw & 0x7FFFFFFF, weight))
+        return const, terms
+
+    for _ in range(n_sends + n_receives):
+        kind, nv = b[pos], b[pos + 1]
+        pos += 2
+        values = [form() for _ in range(nv)]
+        out.append((kind, values, form()))
+    assert pos == len(b), "trailing words in the lookups blob"
+    return n_sends, out
+
+
+def emit_perm_source(blob, log_quotient_degree: int) -> str:
+    """stark::perm_rows (csrc/stark.cuh) for ONE chip as straight-line HIP: the generic kernel walks the blob with scalar instructions
+    (as many as its vector ones), reloads a column every time a lookup names it, and has about one load in flight per wave. Here the
+    walk is done at generation time, every column is loaded once per row, weights of one and zero constants cost nothing, and the
+    loads are issued in groups ahead of their use (prefetch_order). Same values: every operation is exact field arithmetic with
+    canonical results, so the order of additions and the batching of the inversions do not show. A row's multiplicities come first; a
+    wavefront whose 64 rows all have none (padding rows) writes zeros and leaves."""
+    n_sends, lookups = parse_lookups(blob)
+    batch = 1 << log_quotient_degree
+    n = len(lookups)
+    ncols = -(-n // batch)                      # fraction columns; the running-sum column follows
+    ONE = 0x01FFFFFE
+    pre, body = [], []                          # statements before / after the all-padding exit
+    loaded = {}
+
+    def col(is_main, c, lines):
+        key = (is_main, c)
+        if key not in loaded:
+            name = f"{'m' if is_main else 'p'}{c}"
+            lines.append(f"const uint32_t {name} = a.{'main' if is_main else 'prep'}[(size_t){c} * a.n + r];")
+            loaded[key] = name
+        return loaded[key]
+
+    tmp = [0]
+
+    def form(f, lines):
+        const, terms = f
+        acc = None if const == 0 else f"{const}u"
+        for is_main, c, w in terms:
+            v = col(is_main, c, lines)
+            t = v if w == ONE else f"kb::mul({v}, {w}u)"
+            acc = t if acc is None else f"kb::add({acc}, {t})"
+        if acc is None:
+            return "0u"
+        tmp[0] += 1
+        name = f"f{tmp[0]}"
+        lines.append(f"const uint32_t {name} = {acc};")
+        return name
+
+    mults = []
+    for k, (kind, values, mult) in enumerate(lookups):
+        m = form(mult, pre)
+        if k >= n_sends and m != "0u":
+            tmp[0] += 1
+            pre.append(f"const uint32_t f{tmp[0]} = kb::neg({m});")
+            m = f"f{tmp[0]}"
+        mults.append(m)
+    live = [m for m in mults if m != "0u"]
+    zero_stores = " ".join(f"a.perm[(size_t){j} * a.n + r] = 0;" for j in range(4 * (ncols + 1)))
+    exit_line = f"if (__all(({' | '.join(live) if live else '0u'}) == 0)) {{ {zero_stores} return; }}"
+    body.append("kb::E4 rowsum = kb::ezero();")
+    G = 2
+    for b0 in range(0, ncols, G):
+        cols_here = [b for b in range(b0, min(b0 + G, ncols))]
+        for g, b in enumerate(cols_here):
+            first = True
+            for k in range(b * batch, min((b + 1) * batch, n)):
+                kind, values, _ = lookups[k]
+                body.append(f"kb::E4 d{k} = kb::eadd_base(a.alpha, kb::to_monty({kind}u));")
+                if len(values) >= 4:
+                    body.append(f"kb::FoldAcc fa{k} = kb::fold_zero();")
+                    for v, f in enumerate(values):
+                        lin = form(f, body)
+                        if lin != "0u":
+                            body.append(f"kb::fold_base(fa{k}, a.beta_pows[{v + 1}], {lin});")
+                    body.append(f"d{k} = kb::eadd(d{k}, kb::fold_finish(fa{k}));")
+                else:
+                    for v, f in enumerate(values):
+                        lin = form(f, body)
+                        if lin != "0u":
+                            body.append(f"d{k} = kb::eadd(d{k}, kb::escale(a.beta_pows[{v + 1}], {lin}));")
+                if first:
+                    body.append(f"kb::E4 num{b} = kb::efrom({mults[k]}); kb::E4 den{b} = d{k};")
+                    first = False
+                else:
+                    body.append(f"num{b} = kb::eadd(kb::emul(num{b}, d{k}), kb::escale(den{b}, {mults[k]})); den{b} = kb::emul(den{b}, d{k});")
+        names = [f"den{b}" for b in cols_here]
+        body.append(f"uint32_t x{b0}[{len(names)}], y{b0}[{len(names)}], z{b0}[{len(names)}];")
+        for g, b in enumerate(cols_here):
+            body.append(f"z{b0}[{g}] = kb::einv_norm(den{b}, x{b0}[{g}], y{b0}[{g}]);")
+        body.append(f"kb::inv_batch<{len(names)}>(z{b0});")
+        for g, b in enumerate(cols_here):
+            body.append(f"{{ const kb::E4 val = kb::emul(num{b}, kb::einv_finish(den{b}, x{b0}[{g}], y{b0}[{g}], z{b0}[{g}])); "
+                        + " ".join(f"a.perm[(size_t){4 * b + e} * a.n + r] = val.c[{e}];" for e in range(4)) + " rowsum = kb::eadd(rowsum, val); }")
+    body.append(" ".join(f"a.perm[(size_t){4 * ncols + e} * a.n + r] = rowsum.c[{e}];" for e in range(4)))
+    if Q_PREFETCH:
+        body = prefetch_order(body, Q_PREFETCH)
+    text = "\n  ".join(pre + [exit_line] + body)
+    return f"""// GENERATED by ziren_amd/codegen.py from a chip's lookups blob ({n} lookups, {n_sends} sends, batches of {batch}). Same values as
+// stark::perm_rows.
+#include "perm_args.cuh"
+
+extern "C" __global__ __launch_bounds__({BLOCK}) void {PERM_KERNEL_NAME}(stark::PermArgs a) {{
+  const size_t r = (size_t)blockIdx.x * {BLOCK} + threadIdx.x;
+  if (r >= a.n) return;
+  {text}
+}}
+"""
+
+
+def perm_hash(blob, log_quotient_degree: int) -> str:
+    h = hashlib.sha256(_template_key() + b"perm1")
+    with open(os.path.join(CSRC, "perm_args.cuh"), "rb") as f:
+        h.update(f.read())
+    h.update(np.ascontiguousarray(blob, dtype=np.uint32).tobytes() + bytes([log_quotient_degree]))
+    return h.hexdigest()[:24]
+
+
+def specialize_perm(blob, log_quotient_degree: int, force: bool = False, verbose: bool = False) -> Optional[bytes]:
+    """The gfx950 code object of a chip's permutation-trace kernel (compiled on first use, cached in-tree like the quotient kernels);
+    None for a chip without lookups (nothing to specialise)."""
+    blob = np.ascontiguousarray(blob, dtype=np.uint32)
+    if len(blob) < 2 or int(blob[0]) + int(blob[1]) == 0 or int(blob[0]) + int(blob[1]) > MAX_PERM_LOOKUPS:
+        return None
+    os.makedirs(CACHE, exist_ok=True)
+    out = os.path.join(CACHE, f"p_{perm_hash(blob, log_quotient_degree)}.hsaco")
+    if force or not os.path.exists(out):
+        _compile(emit_perm_source(blob, log_quotient_degree), out, verbose)
+    key = hashlib.sha256(np.ascontiguousarray(blob, dtype="<u4").tobytes() + bytes([log_quotient_degree])).hexdigest()
+    import fcntl
+    path = os.path.join(CACHE, "manifest.json")
+    with _manifest_lock, open(path + ".lock", "w") as lk:
+        fcntl.flock(lk, fcntl.LOCK_EX)
+        _update_manifest(path, "perm:" + key, os.path.basename(out))
+    with open(out, "rb") as f:
+        return f.read()
+
+
+def specialize_perm_many(chips, verbose: bool = False):
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=os.cpu_count() or 1) as pool:
+        return list(pool.map(lambda c: specialize_perm(c.lookups_blob, c.log_quotient_degree, verbose=verbose), chips))
 
 
 def prune_cache():

@@ -32,6 +32,11 @@ static inline int log2_strict(size_t n) {
   return k;
 }
 static inline unsigned div_up(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }
+static inline uint64_t fnv1a(const uint32_t* w, size_t n);
+// registry key of a chip's permutation-trace kernel: its lookups blob and the batch size (2^log_quotient_degree lookups per column)
+static inline uint64_t perm_key(const uint32_t* lookups, size_t len, uint32_t log_quotient_degree) {
+  return fnv1a(lookups, len) * 1099511628211ull + log_quotient_degree + 1;
+}
 static inline uint64_t fnv1a(const uint32_t* w, size_t n) {
   uint64_t h = 1469598103934665603ull;
   const unsigned char* p = (const unsigned char*)w;
@@ -123,6 +128,7 @@ struct zkm_ctx {
   int kernel_timing = 2;
   // per-chip specialised quotient kernels (ziren_amd/codegen.py), keyed by a hash of the program words
   std::map<uint64_t, std::vector<hipFunction_t>> quotient_fns;   // a program's specialised kernel(s), in launch order
+  std::map<uint64_t, hipFunction_t> perm_fns;                    // a lookups blob's specialised permutation-trace kernel (key: perm_key)
   std::vector<hipModule_t> modules;
   hipEvent_t get_event() {
     hipEvent_t e;

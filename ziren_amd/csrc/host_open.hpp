@@ -126,8 +126,22 @@ static ChipMeta chip_meta(const zkm_chip_desc* d, size_t n, size_t n_public_valu
 template <typename Alloc>
 static void launch_permutation_trace(zkm_ctx* ctx, const ChipMeta& c, const uint32_t* d_blob, const uint32_t* trace, const uint32_t* prep, const E4& alpha,
                                      const E4* d_beta_powers, zkm_matrix& pt, Alloc&& salloc, std::vector<stark::ScanJob>& scans) {
-  KLAUNCH(ctx, "perm_rows", 4.0 * c.n * (c.desc->main_width + c.desc->prep_width + pt.w), stark::perm_rows, dim3(div_up(c.n, stark::THREADS)), dim3(stark::THREADS), 0,
-          d_blob, c.n_lookups, c.n_sends, 1 << c.desc->log_quotient_degree, trace, prep, c.n, alpha, d_beta_powers, pt.d, c.perm_ext_w);
+  const double pbytes = 4.0 * c.n * (c.desc->main_width + c.desc->prep_width + pt.w);
+  auto fit = c.desc->lookups_len ? ctx->perm_fns.find(perm_key(c.desc->lookups, c.desc->lookups_len, c.desc->log_quotient_degree)) : ctx->perm_fns.end();
+  if (fit != ctx->perm_fns.end()) {
+    // chip-specialised kernel (ziren_amd/codegen.py emit_perm_source): the blob walked at generation time, same values
+    stark::PermArgs a;
+    a.main = trace; a.prep = prep; a.n = c.n; a.alpha = alpha; a.beta_pows = d_beta_powers; a.perm = pt.d;
+    size_t arg_size = sizeof(a);
+    void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &arg_size, HIP_LAUNCH_PARAM_END};
+    ctx->flush_staged();
+    const bool timed = ctx->kbegin("perm_rows", pbytes);
+    HIP_CHECK(hipExtModuleLaunchKernel(fit->second, div_up(c.n, 256) * 256, 1, 1, 256, 1, 1, 0, ctx->cur, nullptr, config,
+                                       timed ? ctx->krecs.back().start : nullptr, timed ? ctx->krecs.back().stop : nullptr, 0));
+  } else {
+    KLAUNCH(ctx, "perm_rows", pbytes, stark::perm_rows, dim3(div_up(c.n, stark::THREADS)), dim3(stark::THREADS), 0,
+            d_blob, c.n_lookups, c.n_sends, 1 << c.desc->log_quotient_degree, trace, prep, c.n, alpha, d_beta_powers, pt.d, c.perm_ext_w);
+  }
   stark::ScanJob j;
   j.data = pt.d + (size_t)(c.perm_ext_w - 1) * 4 * c.n;      // inclusive scan of the last ext column (4 base columns)
   j.n = c.n;

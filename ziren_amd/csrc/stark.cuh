@@ -18,6 +18,7 @@
 #pragma once
 #include "kb31.cuh"
 #include "quotient_args.cuh"
+#include "perm_args.cuh"
 
 namespace stark {
 

@@ -241,6 +241,25 @@ int zkm_ctx_register_quotient_kernel(zkm_ctx* ctx, const uint32_t* program, uint
   API_END
 }
 
+int zkm_ctx_register_perm_kernel(zkm_ctx* ctx, const uint32_t* lookups, uint32_t lookups_len, uint32_t log_quotient_degree,
+                                 const void* code_object, size_t code_object_len) {
+  API_BEGIN
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIP_CHECK(hipSetDevice(ctx->device));
+  if (lookups_len < 2 || !code_object_len) throw std::runtime_error("empty lookups blob or code object");
+  std::vector<char> copy((const char*)code_object, (const char*)code_object + code_object_len);   // an aligned allocation of its own
+  hipModule_t mod;
+  HIP_CHECK(hipModuleLoadData(&mod, copy.data()));
+  hipFunction_t fn;
+  if (hipModuleGetFunction(&fn, mod, "zkm_perm_rows_specialized") != hipSuccess) {
+    (void)hipModuleUnload(mod);
+    throw std::runtime_error("code object lacks zkm_perm_rows_specialized");
+  }
+  ctx->modules.push_back(mod);
+  ctx->perm_fns[perm_key(lookups, lookups_len, log_quotient_degree)] = fn;
+  API_END
+}
+
 // Pinned host memory for trace buffers: uploads from it are plain DMA (no staging copy on the CPU).
 void* zkm_host_alloc(zkm_ctx* ctx, size_t bytes) {
   std::lock_guard<std::mutex> lk(ctx->mu);

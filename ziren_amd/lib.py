@@ -12,7 +12,7 @@ _LIB = None
 
 # every symbol include/zkm_hip.h declares
 EXPORTS = [
-    "zkm_last_error", "zkm_ctx_create", "zkm_ctx_destroy", "zkm_ctx_synchronize", "zkm_ctx_trim", "zkm_ctx_last_timings", "zkm_ctx_kernel_timings", "zkm_ctx_set_kernel_timing", "zkm_ctx_set_kernel_timing_only", "zkm_ctx_register_quotient_kernel",
+    "zkm_last_error", "zkm_ctx_create", "zkm_ctx_destroy", "zkm_ctx_synchronize", "zkm_ctx_trim", "zkm_ctx_last_timings", "zkm_ctx_kernel_timings", "zkm_ctx_set_kernel_timing", "zkm_ctx_set_kernel_timing_only", "zkm_ctx_register_quotient_kernel", "zkm_ctx_register_perm_kernel",
     "zkm_host_alloc", "zkm_host_free", "zkm_matrix_upload", "zkm_matrix_upload_async", "zkm_matrix_wait", "zkm_events_upload_async", "zkm_events_free", "zkm_matrix_download", "zkm_matrix_height", "zkm_matrix_width", "zkm_matrix_free",
     "zkm_pcs_commit", "zkm_pcs_data_free", "zkm_pcs_data_get_lde", "zkm_pcs_open_batch",
     "zkm_pk_setup", "zkm_pk_commitment", "zkm_pk_observe_into", "zkm_pk_free",

@@ -9,6 +9,7 @@ benchmark read like the reference's own `run_test::<P>` (crates/core/machine/src
 Everything numeric runs in libzkm_hip.so on the GPU; this module only marshals.
 """
 import ctypes as C
+import os
 from dataclasses import dataclass
 from typing import List, Optional, Sequence
 
@@ -668,6 +669,26 @@ class HipProver:
             buf = C.create_string_buffer(co, len(co))
             lib.check(lib.load().zkm_ctx_register_quotient_kernel(self.ctx.h, abi.as_u32p(prog), C.c_uint32(len(prog)), buf,
                                                                   C.c_size_t(len(co))))
+        if os.environ.get("ZKM_NO_PERM_KERNELS") != "1":
+            self.specialize_perm_kernels(chips)
+
+    def specialize_perm_kernels(self, chips=None):
+        """The same for the permutation traces: one generated kernel per chip's lookups (zkm_ctx_register_perm_kernel); chips without one
+        go through the generic kernel."""
+        from . import codegen
+        for c in (self.chips if chips is None else chips):
+            blob = np.ascontiguousarray(c.lookups_blob, dtype=np.uint32)
+            try:
+                co = codegen.specialize_perm(blob, c.log_quotient_degree)
+            except Exception as e:  # noqa: BLE001
+                import warnings
+                warnings.warn(f"no specialised permutation kernel for chip {getattr(c, 'name', '?')} ({type(e).__name__}: {e}); the generic kernel runs")
+                continue
+            if co is None:
+                continue
+            buf = C.create_string_buffer(co, len(co))
+            lib.check(lib.load().zkm_ctx_register_perm_kernel(self.ctx.h, abi.as_u32p(blob), C.c_uint32(len(blob)), C.c_uint32(c.log_quotient_degree),
+                                                              buf, C.c_size_t(len(co))))
 
     # fn setup / pk_to_device (prover.rs:54-66)
     def setup(self, prep_traces: Sequence[np.ndarray], prep_local_only, pc_start, initial_global_cumulative_sum) -> ProvingKey:
