@@ -132,6 +132,7 @@ const char* zkm_last_error(void);
 /* ---- context ---------------------------------------------------------------------------- */
 int zkm_ctx_create(int device, zkm_ctx** out);
 void zkm_ctx_destroy(zkm_ctx* ctx);
+/* Waits for everything queued on the context: the compute stream and every zkm_events_upload_async copy. */
 int zkm_ctx_synchronize(zkm_ctx* ctx);
 /* Device buffers are recycled through an exact-size pool; trim returns the idle ones to the driver, and drops the per-height tables
  * (coset twiddles, quotient selectors, row twiddles) a long-lived prover accumulates: they are rebuilt on the next use of a height. */

@@ -173,6 +173,7 @@ int zkm_ctx_trim(zkm_ctx* ctx) {
 int zkm_ctx_synchronize(zkm_ctx* ctx) {
   API_BEGIN
   HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  if (ctx->ev_dma) HIP_CHECK(hipStreamSynchronize(ctx->ev_dma));   // and every event prefetch queued so far has landed
   API_END
 }
 
