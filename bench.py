@@ -150,13 +150,14 @@ class FibWorkload:
         from ziren_amd import fibfast, shape as SH
         self.kind, self.log_size = kind, log_size
         t0 = time.perf_counter()
-        if kind == "shaped":
+        if kind in ("shaped", "cut"):
             cycles, why = SH.executor_shard_cycles(1 << log_size, fibfast.loop_event_estimate)
             n = ((shard_no + 1) * cycles) // fibfast.LOOP + 8
             self.machine = fibfast.fib_shard(n, cycles, shard_no)
-            self.ds = fibfast.DeviceShard(self.machine, shape="fix")
+            # "cut": the same record without the shape step — chips with events only, every trace padded to its next power of two
+            self.ds = fibfast.DeviceShard(self.machine, shape="fix" if kind == "shaped" else None)
             self.cut = why
-            self.tag = f"fibs{log_size}"
+            self.tag = f"fibs{log_size}" if kind == "shaped" else f"fibc{log_size}"
         else:
             assert shard_no == 2
             self.machine = fibfast.full_shard(log_size)
@@ -175,6 +176,9 @@ class FibWorkload:
             return (f"FIB-S{self.log_size}: a middle shard of examples/fibonacci as the reference cuts and shapes it at SHARD_SIZE = 2^{self.log_size} "
                     f"({self.cycles} cycles: the executor's shape check closes the shard; fix_shape pads it to the covering shape of least area — Cpu 2^{heights['Cpu']} rows, "
                     f"{len(self.chips)} chips), full shard proof (commit+open), blowup 2, 84 queries, 16 PoW bits")
+        if self.kind == "cut":
+            return (f"FIB-C{self.log_size}: the same record as FIB-S{self.log_size} ({self.cycles} cycles) without the shape step: the {len(self.chips)} chips that have events, "
+                    f"tight heights (Cpu 2^{heights['Cpu']}), full shard proof (commit+open), blowup 2, 84 queries, 16 PoW bits")
         return (f"FIB-{self.log_size}: a middle shard of examples/fibonacci, {self.cycles} cycles, tight heights (no shape), {len(self.chips)} chips, "
                 f"full shard proof (commit+open), blowup 2, 84 queries, 16 PoW bits")
 
@@ -787,6 +791,8 @@ def main():
             line["events_to_proof"] = ev
         extra = {}
         also = [a for a in args.also.split(",") if a]
+        if wl.kind == "shaped":
+            also.append(f"fibc{wl.log_size}")          # the same record, tight: what the shape step costs
         if wl.kind != "syn" and not args.no_syn:
             also.append("syn22")
         ctx.trim()
@@ -795,6 +801,8 @@ def main():
                 w2 = SynWorkload(int(name[3:]))
             elif name.startswith("fibs"):
                 w2 = FibWorkload("shaped", int(name[4:]))
+            elif name.startswith("fibc"):
+                w2 = FibWorkload("cut", int(name[4:]))
             else:
                 w2 = FibWorkload("tight", int(name[3:]))
             ctx2 = prover.Context(local_rank)
@@ -804,9 +812,11 @@ def main():
             leg2 = resident_leg(_LocalTimer(ctx2), w2, hp2, pk2, ch2, tr2, n2, 1, 2)
             verify_or_die(w2, fri, ch2, leg2["proof"], w2.tag)
             t = leg2["table"]
-            extra[name.upper() if name.startswith("syn") else name] = {
+            extra[name.upper()] = {
                 "workload": w2.label, "ms_per_step": round(leg2["elapsed"] / n2 * 1e3, 3), "value": round(n2 / leg2["elapsed"], 4), "unit": "shard-proofs/s", "steps": n2,
-                "verified": True, "kernels_ms": {k: round(v[0] / leg2["table_steps"], 3) for k, v in sorted(t.items(), key=lambda kv: -kv[1][0])[:8]}}
+                "verified": True, "chips": {c.name: c.log_height for c in w2.chips},
+                "committed_cells": int(sum((1 << c.log_height) * (c.prep_width + c.main_width + 4 * c.perm_ext_width + (4 << c.log_quotient_degree)) for c in w2.chips)),
+                "kernels_ms": {k: round(v[0] / leg2["table_steps"], 3) for k, v in sorted(t.items(), key=lambda kv: -kv[1][0])[:8]}}
             for x in tr2:
                 x.free()
             pk2.free()                     # before its context goes
