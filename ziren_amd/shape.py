@@ -147,7 +147,7 @@ def executor_shard_cycles(shard_size, counts_at, first_check=0):
     (estimate_mips_event_counts: opcode counts, Mul and Lt raised by the DivRem count, no other dependency — cost.rs:96-195): the smaller of
     the clock limit (`max_syscall_cycles + clk >= shard_size * 4`, executor.rs:325,2423; clk advances 5 per cycle) and the first shape check
     — made when the global clock is a multiple of 16, `first_check` being the shard's first such cycle — at which no maximal shape fits."""
-    shapes = maximal_core_shapes(max(shard_size - 1, 0).bit_length() if shard_size & (shard_size - 1) else shard_size.bit_length() - 1)
+    shapes = maximal_core_shapes(shard_size.bit_length() - 1)          # opts.shard_size.ilog2(), utils/prove.rs:147
     limit = -(-4 * shard_size // 5)                       # first c with 5 c >= 4 shard_size
     lo, hi = 0, (limit - first_check) // SHAPE_CHECK_FREQUENCY + 1
     if executor_fits(shapes, 5 * limit, counts_at(limit)):
