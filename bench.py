@@ -712,10 +712,10 @@ def main():
     ap.add_argument("--cpu-full", action="store_true", help="time the CPU baseline on the benchmarked shard itself instead of a sample (minutes)")
     ap.add_argument("--no-extra", action="store_true", help="only the timed region, its verification and the roofline objects (profiling runs)")
     ap.add_argument("--no-syn", action="store_true", help="skip the SYN-22 continuity leg after a fib run")
-    ap.add_argument("--also", type=str, default="", help="comma-separated extra resident legs after the main one: fib21, fib22 (tight), fibs20 ...")
+    ap.add_argument("--also", type=str, default="", help="comma-separated extra resident legs after the main one: fib21 (2^21 cycles, tight), fibs20 (shaped at SHARD_SIZE 2^20), fibc20 (the same record, tight), syn20 ...")
     ap.add_argument("--kernel-timing", type=int, default=3,
                     help="0 off, 1 every launch, 2 launches >= 256 KiB, 3 (default): inside the timed region only the dominant kernel is timed")
-    ap.add_argument("--interpreter", action="store_true", help="use the bytecode interpreter instead of per-chip quotient kernels")
+    ap.add_argument("--interpreter", action="store_true", help="no generated kernels: the bytecode interpreter for the quotient, the generic kernel for the permutation traces")
     ap.add_argument("--inflight", type=int, default=2, help="queue path: shards in flight per GPU (a context + host thread each); 2 fills one proof's transcript "
                     "round trips and launch gaps with the other's kernels (the N = 1 resident line always keeps one in flight and reports two beside it)")
     ap.add_argument("--queue", type=int, default=0, metavar="SHARDS", help="N = 1 too: deal SHARDS distinct shards through the claim queue (events -> traces -> proof); "
