@@ -214,3 +214,18 @@ def test_gpu_benchmarked_shape_fixed_shard_is_accepted_by_the_verifier(hip_ctx, 
     assert why == "shape" and ds.shape["Cpu"] == 22 and len(ds.chips) == 18
     fri, opk, start, _, proof, _ = _gpu_prove_fib(hip_ctx, oracle, m, ds)
     _accepts_and_rejects(oracle, opk, ds.chips, fri, start, proof)
+
+
+@pytest.mark.gpu
+def test_gpu_cpu_trace_generation_refuses_a_clock_beyond_24_bits(hip_ctx):
+    """What round 3's unverified "2^22 cycles" shard would have met: the Cpu chip range-checks the shard clock as a 16-bit and an 8-bit limb, so
+    an event with clk >= 2^24 cannot be laid out as a valid row — the generator fails loudly instead of truncating it."""
+    from ziren_amd import lib
+    m = fibfast.full_shard(12)
+    rec = m.shards[0].record
+    good = hip_ctx.tracegen_cpu(rec.cpu, m.program, m.pc_base, 2, 12)
+    good.free()
+    ev = rec.cpu.copy()
+    ev["clk"][7] = 1 << 24
+    with pytest.raises(lib.ZkmError, match="24 bits"):
+        hip_ctx.tracegen_cpu(ev, m.program, m.pc_base, 2, 12)

@@ -205,7 +205,8 @@ int zkm_tracegen_cpu_and_program(zkm_ctx* ctx, const zkm_cpu_event* events, size
     HIP_CHECK(hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, ctx->stream));
     ctx->mark("trace generation");
     ctx->end_timing(false);
-    if (bad) throw std::runtime_error("zkm_tracegen_cpu: an event's pc lies outside the program");
+    if (bad & 1) throw std::runtime_error("zkm_tracegen_cpu: an event's pc lies outside the program");
+    if (bad & 2) throw std::runtime_error("zkm_tracegen_cpu: an event's clock does not fit 24 bits (a shard holds fewer than 2^24 / 5 cycles)");
   } catch (...) {
     if (d_events) ctx->release(d_events);
     if (d_program) ctx->release(d_program);

@@ -965,7 +965,10 @@ __global__ __launch_bounds__(THREADS) void cpu_rows(const uint32_t* __restrict__
       const size_t idx = (size_t)(pc - pc_base) >> 2;   // Program::fetch
       const bool in_program = pc >= pc_base && idx < n_instr;
       if (!in_program) *bad_pc = 1;
-      else if (program_counts) {   // ProgramChip::generate_trace in the same pass
+      // the shard clock is range-checked as a 16-bit and an 8-bit limb (cpu/air/mod.rs:39,131-138): a clock of 2^24 or more would be
+      // truncated into a trace that satisfies no verifier (the executor closes a shard long before: executor.rs:325,2423)
+      if (clk >> 24) atomicOr(bad_pc, 2);
+      if (in_program && program_counts) {   // ProgramChip::generate_trace in the same pass
         if (count && idx < 0x7fffffffu) count_fetch(LookupSink{hkeys, hvals, HASH_SLOTS - 1, counts}, (uint32_t)idx, program_counts);
         else atomicAdd(program_counts + idx, 1u);
       }
