@@ -671,6 +671,9 @@ def queue_main(args, farm, fri):
         assert len(gathered) == n_shards and len({p.tobytes() for p in gathered}) == n_shards, "the gathered proofs are not distinct"
         ms = elapsed / n_shards * 1e3
         cpu_log = 22 if stub else lane.wls[0].chips[0].log_height
+        if not stub:
+            from ziren_amd import synth
+            alg = synth.shard_algorithmic_bytes(lane.wls[0])
         print(json.dumps({
             "metric": "shard-proofs/sec", "value": round(n_shards / elapsed, 4), "unit": "shard-proofs/s", "n_gpus": world,
             "steps": n_shards if args.queue > 0 else per_gpu, "shards": n_shards,
@@ -686,6 +689,12 @@ def queue_main(args, farm, fri):
                                       f"no data-path collective",
                        "shards_in_flight_per_gpu": M, "ranks_in_process_group": ranks_in_group,
                        "backend": "none (one process)" if farm.dist is None else "gloo" if (stub or os.environ.get("ZKM_BENCH_ONE_DEVICE") == "1") else "nccl (RCCL)"},
+            "roofline": None if stub else {
+                "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBPS * world,
+                "whole_shard": {"algorithmic_bytes_per_shard": alg, "achieved": round(alg * n_shards / elapsed / 1e9, 1),
+                                "frac": round(alg * n_shards / elapsed / 1e9 / (HBM_PEAK_GBPS * world), 4)},
+                "note": "SURVEY 8(d)'s algorithmic bytes of one shard x shards / time against N x 8 TB/s; the per-kernel roofline, counters and the CPU baseline "
+                        "are on the N = 1 line (this path runs with kernel timing off)"},
             "host_ms_per_shard": {"rank0_mean": round(mine, 3), "max_over_ranks_of_means": round(slowest, 3)},
             "event_bytes_per_shard": lane.event_bytes,
             "h2d_GBps_per_rank": round(lane.event_bytes * len(ids) / elapsed / 1e9, 2),      # rank 0's events over the timed region: what its PCIe link carried
