@@ -163,3 +163,22 @@ def test_gpu_generated_permutation_kernels_equal_the_generic_one_and_the_oracle(
     finally:
         plain.close()
         special.close()
+
+
+def test_prefetch_order_moves_loads_up_and_loses_nothing():
+    """codegen.prefetch_order: every statement of the program appears exactly once, no load moves down, every value is still declared
+    before its first use, and group k + 1's loads sit in front of group k's first use."""
+    from ziren_amd import chips
+    for prog in (chips.record_cpu_chip(10).program, chips.record_divrem_chip(10).program, shared_term_program()):
+        lines, _ = codegen._ssa_lines(np.asarray(prog, dtype=np.uint32))
+        out = codegen.prefetch_order(lines, 4)
+        body = [ln for ln in out if "sched_barrier" not in ln]
+        assert sorted(body) == sorted(lines) and len(out) - len(body) >= 1
+        pos_before = {ln: k for k, ln in enumerate(lines)}
+        seen_non_load = 0
+        for k, ln in enumerate(body):
+            if codegen._is_load(ln):
+                assert seen_non_load <= sum(1 for x in lines[:pos_before[ln]] if not codegen._is_load(x)), "a load moved down"
+            else:
+                seen_non_load += 1
+        _check_defined_before_use("kb::FoldAcc acc;\n" + "\n".join(body))
