@@ -184,6 +184,27 @@ def test_coset_lde_constant_and_nearly_constant_columns(hip_ctx, oracle, k, bl):
         assert (got[:, c] == m[0, c]).all()          # and the constant columns come back as the constant
 
 
+def test_coset_lde_random_shapes_shifts_and_column_kinds(hip_ctx, oracle):
+    """Sixteen random (height 2^14..2^19, width, blow-up 1..3, shift) cases whose columns are drawn from: constant, zero, constant but for one
+    word, a step (constant up to a random row, another constant after it), random — against the oracle."""
+    rng = np.random.default_rng(4242)
+    for trial in range(16):
+        k, w, bl = int(rng.integers(14, 20)), int(rng.integers(1, 10)), int(rng.integers(1, 4))
+        n = 1 << k
+        cols = []
+        for _ in range(w):
+            mode = int(rng.integers(0, 5))
+            col = rng.integers(0, P, n, dtype=np.uint64) if mode == 4 else np.full(n, 0 if mode == 1 else int(rng.integers(0, P)), dtype=np.uint64)
+            if mode == 2:
+                col[int(rng.integers(0, n))] = int(rng.integers(0, P))
+            if mode == 3:
+                col[int(rng.integers(0, n)):] = int(rng.integers(0, P))
+            cols.append(col)
+        m = F.to_monty(np.stack(cols, axis=1))
+        shift = F.to_monty(int(rng.integers(1, P)))
+        assert np.array_equal(prover.coset_lde_batch(hip_ctx, m, bl, shift), oracle.coset_lde_batch(m, bl, shift)), (trial, k, w, bl)
+
+
 def test_coset_lde_quotient_chunk_shift(hip_ctx, oracle):
     k = 9
     m = rand(np.random.default_rng(9), (1 << k, 4))
