@@ -160,6 +160,7 @@ struct zkm_ctx {
     HIP_CHECK(hipStreamSynchronize(stream));
     HIP_CHECK(hipStreamSynchronize(stream2));
     cur = stream;
+    side_join();               // both streams are idle here: only the deferred scratch is left to hand back
     pin_off = 0;
     dirty_lo = SIZE_MAX; dirty_hi = 0;
   }
@@ -185,10 +186,41 @@ struct zkm_ctx {
   void flush_staged() {
     if (dirty_hi <= dirty_lo) return;
     // the span [dirty_lo, dirty_hi) may also cover ring blocks that are not staged tables (download_async destinations, upload() staging):
-    // copying them to the arena is harmless only while everything that touches the ring runs on the one main stream
-    if (cur != stream) throw std::runtime_error("flush_staged: staged tables are only flushed on the main stream");
-    HIP_CHECK(hipMemcpyAsync(arena + dirty_lo, pin + dirty_lo, dirty_hi - dirty_lo, hipMemcpyHostToDevice, cur));
+    // copying them to the arena is harmless only while everything that touches the ring runs on the one main stream — so the copy is
+    // always made there. When the launch that needs the tables goes to the side stream (pcs_commit extends a commit's shorter matrices
+    // there), that stream then waits for the main stream up to this point: the copy, the first-use table fills and whatever produced
+    // the kernel's inputs are all in front of it.
+    HIP_CHECK(hipMemcpyAsync(arena + dirty_lo, pin + dirty_lo, dirty_hi - dirty_lo, hipMemcpyHostToDevice, stream));
     dirty_lo = SIZE_MAX; dirty_hi = 0;
+    if (cur != stream) {
+      hipEvent_t e = get_event();
+      HIP_CHECK(hipEventRecord(e, stream));
+      HIP_CHECK(hipStreamWaitEvent(cur, e, 0));
+      event_pool.push_back(e);
+    }
+  }
+  // Work queued on the side stream and not yet joined: scratch it uses goes back to the pool (which hands buffers out in main-stream
+  // order) only after the main stream has waited for it.
+  std::vector<void*> side_deferred;
+  hipEvent_t side_done = nullptr;
+  bool side_pending = false;
+  void release_here(void* p) {            // release() for scratch of a launch sequence that may run on the side stream
+    if (cur != stream) side_deferred.push_back(p);
+    else release(p);
+  }
+  void side_begin() { cur = stream2; }
+  void side_end() {
+    if (!side_done) HIP_CHECK(hipEventCreateWithFlags(&side_done, hipEventDisableTiming));
+    HIP_CHECK(hipEventRecord(side_done, stream2));
+    cur = stream;
+    side_pending = true;
+  }
+  void side_join() {
+    if (!side_pending) return;
+    HIP_CHECK(hipStreamWaitEvent(stream, side_done, 0));
+    for (void* p : side_deferred) release(p);
+    side_deferred.clear();
+    side_pending = false;
   }
   // copy `bytes` of host data to a fresh device buffer; the source may die as soon as this returns
   void* upload(const void* src, size_t bytes, std::vector<void*>* scratch) {

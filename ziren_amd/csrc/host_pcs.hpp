@@ -92,10 +92,10 @@ static void lde_batch_chunk(zkm_ctx* ctx, const std::vector<LdeJob>& jobs, int b
   }
   if (blk[lde::K_ROWS_SMALL])
     KLAUNCH(ctx, "lde_rows", bytes_small, lde::lde_rows, dim3(blk[lde::K_ROWS_SMALL]), dim3(lde::THREADS), lds_small, d);
-  ctx->release(tmp1);
-  ctx->release(tmp2);
-  ctx->release(cflags);
-  ctx->release((void*)d);
+  ctx->release_here(tmp1);
+  ctx->release_here(tmp2);
+  ctx->release_here(cflags);
+  ctx->release_here((void*)d);
 }
 
 static void lde_batch(zkm_ctx* ctx, const std::vector<LdeJob>& all, int bl) {
@@ -255,16 +255,34 @@ static zkm_pcs_data* pcs_commit(zkm_ctx* ctx, const std::vector<zkm_matrix>& mat
     // the tallest trace's upload is exposed.
     std::vector<char> extended(mats.size(), 0);
     auto shift_of = [&](size_t i) { return kb::mul(kb::GEN, kb::inv(d->domain_shifts[i])); };
+    size_t top = 0;
+    for (auto& l : d->ldes) top = std::max(top, l.h);
     {
-      std::vector<LdeJob> jobs;
+      // The tallest matrices first, on the main stream: the leaf hashing that follows needs only them. The shorter ones are extended on
+      // the side stream while the leaves are hashed (ZKM_LDE_OVERLAP, default on): the strided LDE passes run at the memory system's
+      // pace and leave issue slots free, the leaf hashing is bound by issue and leaves the memory system idle. The tree joins the
+      // side stream right before the first layer that reads a shorter matrix (extend_height below).
+      static const bool overlap = !(getenv("ZKM_LDE_OVERLAP") && atoi(getenv("ZKM_LDE_OVERLAP")) == 0);
+      std::vector<LdeJob> tall, rest;
+      size_t rest_cells = 0;
       for (size_t i = 0; i < mats.size(); i++)
         if (!mats[i].ready || hipEventQuery(mats[i].ready) == hipSuccess) {   // never uploaded asynchronously, or landed already
-          jobs.push_back(LdeJob{mats[i].d, mats[i].h, mats[i].w, shift_of(i), d->ldes[i].d});
+          (d->ldes[i].h == top ? tall : rest).push_back(LdeJob{mats[i].d, mats[i].h, mats[i].w, shift_of(i), d->ldes[i].d});
+          if (d->ldes[i].h != top) rest_cells += mats[i].h * mats[i].w;
           extended[i] = 1;
         }
-      lde_batch(ctx, jobs, log_blowup);
+      if (overlap && !tall.empty() && rest_cells >= ((size_t)1 << 22)) {
+        lde_batch(ctx, tall, log_blowup);
+        ctx->side_begin();
+        try { lde_batch(ctx, rest, log_blowup); } catch (...) { ctx->side_end(); ctx->side_join(); throw; }
+        ctx->side_end();
+      } else {
+        tall.insert(tall.end(), rest.begin(), rest.end());
+        lde_batch(ctx, tall, log_blowup);
+      }
     }
     auto extend_height = [&](size_t lde_height) {
+      if (lde_height < top) ctx->side_join();
       std::vector<LdeJob> jobs;
       for (size_t i = 0; i < mats.size(); i++) {
         if (extended[i] || d->ldes[i].h != lde_height) continue;
@@ -275,6 +293,7 @@ static zkm_pcs_data* pcs_commit(zkm_ctx* ctx, const std::vector<zkm_matrix>& mat
       lde_batch(ctx, jobs, log_blowup);
     };
     build_tree(ctx, d->ldes, d->tree, extend_height);
+    ctx->side_join();
     for (size_t i = 0; i < mats.size(); i++)
       if (!extended[i]) throw std::runtime_error("pcs_commit: a matrix was not reached by the tree (internal error)");
     const uint32_t* h_root = d->tree.h_root ? d->tree.h_root : ctx->download_async(d->tree.node(d->tree.log_max, 0), 8);
@@ -282,6 +301,8 @@ static zkm_pcs_data* pcs_commit(zkm_ctx* ctx, const std::vector<zkm_matrix>& mat
     d->tree.h_root = nullptr;   // the pinned ring is rewound at the next top-level call
     memcpy(d->root, h_root, 32);
   } catch (...) {
+    ctx->cur = ctx->stream;
+    try { ctx->side_join(); } catch (...) {}   // nothing of this commit may still be running on the side stream when its buffers go back
     free_pcs_data(ctx, d);
     throw;
   }
