@@ -394,6 +394,9 @@ struct ShardOpening {
       qshifts.push_back(kb::mul(kb::GEN, wqp));
       wqp = kb::mul(wqp, w_q);
     }
+    // the first (tallest) chip's kernel goes out as soon as its own tables are staged: the host prepares the other chips' tables
+    // (alpha powers, zerofier inverses: ~0.15 ms for a core shard) while it runs, instead of in front of an idle GPU
+    if (i == 0) { launches[0](); launches[0] = [] {}; }
   }
   for (auto& l : launches) l();
   ctx->mark("quotient values");
