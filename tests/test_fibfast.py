@@ -181,11 +181,14 @@ def test_shape_fixed_shard_on_the_oracle_proves_and_verifies(oracle):
 
 
 @pytest.mark.gpu
-def test_gpu_shape_fixed_shard_bit_exact(hip_ctx, oracle):
-    """The shaped shard at SHARD_SIZE 2^15: device-born traces (zero-event chips included) equal to the oracle's, GPU proof word for word
-    equal to the oracle's, accepted by the verifier; and the same events through `prefetch` (zkm_events_upload_async) give the same traces."""
+@pytest.mark.parametrize("log_shard_size", [15, 18])
+def test_gpu_shape_fixed_shard_bit_exact(hip_ctx, oracle, log_shard_size):
+    """The shaped shard at SHARD_SIZE 2^15 and 2^18 (Cpu 2^19 rows: the four-step LDE with its constant-column shortcut, the shorter matrices
+    extended on the side stream, the generated quotient and permutation kernels — everything the benchmarked shard goes through, at a size
+    the oracle proves in 15 s): device-born traces (zero-event chips included) equal to the oracle's, GPU proof word for word equal to the
+    oracle's, accepted by the verifier; and the same events through `prefetch` (zkm_events_upload_async) give the same traces."""
     from ziren_amd import synth
-    m, cycles, why = fibfast.shaped_shard(1 << 15)
+    m, cycles, why = fibfast.shaped_shard(1 << log_shard_size)
     ds = fibfast.DeviceShard(m, shape="fix")
     ocs = _oracle_side_shaped(oracle, m, ds)
     fri, opk, start, ch, proof, host = _gpu_prove_fib(hip_ctx, oracle, m, ds, keep_traces=True)
