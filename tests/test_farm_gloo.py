@@ -138,3 +138,47 @@ def test_a_second_batch_without_a_process_group_gets_a_fresh_counter():
     for n in (5, 3):
         ids, proofs = f.run_queue(n, lambda i: [i, i + 1])
         assert ids == list(range(n)) and [int(p[0]) for p in f.gather_proofs(ids, proofs, n)] == list(range(n))
+
+
+def test_lanes_share_one_queue_claim_ahead_and_surface_a_lane_s_failure():
+    """Several lanes (host threads) of one rank: every shard proven exactly once, each lane's `prefetch(j)` called for shard j before its
+    `prove(j, handle)` and handed over unchanged; a lane that raises ends the batch with that exception (not a hang, not a silent loss) and
+    the next batch still gets a fresh counter."""
+    import threading
+    import time
+    import numpy as np
+    f = farm.Farm()
+    lock = threading.Lock()
+    prefetched, proved = [], []
+
+    def make_lane(tag, delay):
+        def prefetch(i):
+            with lock:
+                prefetched.append(i)
+            return (tag, i)
+
+        def prove(i, handle):
+            assert handle == (tag, i)
+            with lock:
+                assert i in prefetched
+                proved.append(i)
+            time.sleep(delay)
+            return np.array([i, i + 1], dtype=np.uint32)
+        return prove, prefetch
+
+    ids, proofs = f.run_queue(17, lanes=[make_lane("a", 0.002), make_lane("b", 0.005), make_lane("c", 0.0)])
+    assert sorted(ids) == list(range(17)) and sorted(proved) == list(range(17)) and len(f.host_ms) == 17
+    assert all(int(p[0]) == i for i, p in zip(ids, proofs))
+
+    def bad_prove(i, handle):
+        if i == 3:
+            raise RuntimeError("shard 3 is broken")
+        return np.array([i], dtype=np.uint32)
+
+    try:
+        f.run_queue(8, lanes=[(bad_prove, lambda i: i), (bad_prove, lambda i: i)])
+        raise AssertionError("the lane's failure was swallowed")
+    except RuntimeError as e:
+        assert "shard 3" in str(e)
+    ids, _ = f.run_queue(4, lanes=[(lambda i, h: np.array([i], dtype=np.uint32), lambda i: i)])
+    assert sorted(ids) == [0, 1, 2, 3]
