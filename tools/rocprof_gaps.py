@@ -36,16 +36,21 @@ def main(db_path, out_path, n_last=None):
     gaps, total_gap, busy, ndisp = {}, 0, 0, 0
     for pr in sel:
         ndisp += len(pr)
-        busy += sum(e - s for _, s, e in pr)
-        for (n0, s0, e0), (n1, s1, e1) in zip(pr, pr[1:]):
-            g = s1 - e0
-            if g <= 0:
-                continue
-            rec = gaps.setdefault(short(n0), {"count": 0, "total_us": 0.0, "max_us": 0.0})
-            rec["count"] += 1
-            rec["total_us"] += g / 1e3
-            rec["max_us"] = max(rec["max_us"], g / 1e3)
-            total_gap += g
+        # kernels of the main and the side stream overlap (round 4): busy = the union of the dispatch intervals, a gap = time no kernel runs,
+        # charged to the kernel that ended last before it
+        cur_end, last = pr[0][1], pr[0][0]
+        for n1, s1, e1 in pr:
+            if s1 > cur_end:
+                g = s1 - cur_end
+                rec = gaps.setdefault(short(last), {"count": 0, "total_us": 0.0, "max_us": 0.0})
+                rec["count"] += 1
+                rec["total_us"] += g / 1e3
+                rec["max_us"] = max(rec["max_us"], g / 1e3)
+                total_gap += g
+                busy += 0
+            if e1 > cur_end:
+                busy += e1 - max(cur_end, s1)
+                cur_end, last = e1, n1
     k = len(sel)
     counts = {}
     for pr in sel:
