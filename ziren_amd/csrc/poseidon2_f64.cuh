@@ -9,7 +9,8 @@
 //     (the integer version: ~70 modular additions of three instructions each);
 //   * a modular product is two-product + Barrett quotient: h = RN(ab), l = fma(a,b,-h) (exact error term),
 //     q = rint(h/p), r = fma(-q,p,h) (exact: an integer below 2^53), result r + l. Six instructions, no carries;
-//   * the internal layer's diagonal (+-2^-k, small integers) is a shift of the exponent plus one fma.
+//   * the internal layer's diagonal (+-2^-k, small integers) is one fma per lane: the lanes with a 2^-k entry stay dyadic
+//     rationals (exact in a double) between the rounds and are made integers again only every few rounds.
 // Every operation below is exact integer arithmetic as long as the stated magnitude bounds hold; they are
 // re-derived next to each step and hammered by tests/test_host_abi.py::test_fp64_poseidon2_* (host build of this very code, which
 // uses the same IEEE operations: plain words, unreduced sponges and compress-with-injection chains on adversarial states, with the
@@ -39,8 +40,9 @@ KB_HD double sconst(double c) {
 }
 
 // Host build only: the largest magnitudes seen at the points the exactness argument rests on (a permutation's inputs, the lane sum
-// of a partial round before its reduction, an S-box input, any lane after a partial round). The device build compiles them away.
-struct Audit { double in = 0, lane_sum = 0, sbox_in = 0, lane = 0; };
+// of a partial round before its reduction, an S-box input, any lane after a partial round, the sum of the fractional lanes), and the
+// number of fractional-lane operations that lost a bit (must be zero). The device build compiles them away.
+struct Audit { double in = 0, lane_sum = 0, sbox_in = 0, lane = 0, frac_sum = 0, inexact = 0; };
 inline Audit& audit() { static thread_local Audit a; return a; }
 inline void probe(double& slot, double v) { v = v < 0 ? -v : v; if (v > slot) slot = v; }
 #if !defined(__HIP_DEVICE_COMPILE__)
@@ -100,59 +102,86 @@ KB_HD void external_layer(double s[16]) {
   }
 }
 
-// x / 2^K + add (SIGN = +1) or -x / 2^K + add (SIGN = -1) modulo p, K <= 24, for integers |x| < 2^44, |add| < 2^44.
-// Z[1/2] -> F_p is a ring homomorphism (2 is invertible), so the real number w = add +- x / 2^K — exact in a double: K fractional
-// bits under at most 45 integer ones — already *is* the result; what is left is to make it an integer again. w = t + lo with
-// t = rint(w), lo = j / 2^K, |lo| <= 1/2, and 2^-K = -(p-1)/2^K (mod p) because 2^K (p-1)/2^K = -1, so lo stands for
-// -j (p-1)/2^K = -lo (p-1), an integer of magnitude <= (p-1)/2 (2^24 divides p - 1). Four instructions (round 3; before: split x
-// first, five). |result - add| <= |x|/2^K + 1/2 + 2^30.
-template <int K, int SIGN>
-KB_HD double div2k_add(double x, double add) {
-  constexpr double SCALE = (SIGN > 0 ? 1.0 : -1.0) / (double)(1u << K);
+// The internal layer's diagonal has seven entries +-2^-K (K = 1, 1, 8, 3, 8, 3, 4 for lanes 3, 6, 9, 10, 12, 13, 14). Z[1/2] -> F_p is a ring
+// homomorphism (2 is invertible), so the real number x / 2^K + sum — exact in a double while its fractional bits fit under the integer
+// ones — already *is* the lane's new value: those seven lanes are left as dyadic rationals (one fma per lane and round), and only made
+// integers again ("integerize") when their fractional bits run out or an S-box is about to read them (round 4: before, every such lane
+// was made an integer in every round, four instructions instead of one). What a round needs from them is their sum, and that is
+// integerized once per round instead.
+// w = t + lo with t = rint(w), lo = j / 2^f, |lo| <= 1/2, f <= 24; 2^-f = -(p-1)/2^f (mod p) because 2^f (p-1)/2^f = -1, so lo stands for
+// -j (p-1)/2^f = -lo (p-1), an integer of magnitude <= (p-1)/2 (2^24 divides p - 1). |result| <= |w| + 1/2 + 2^30.
+KB_HD double integerize(double w) {
   constexpr double PM1 = 2130706432.0;
-  const double w = (K == 1) ? fma_(x, SCALE, add) : fma_(x, sconst(SCALE), add);
   const double t = rne(w);
   const double lo = w - t;
   return fma_(-lo, PM1, t);
 }
+// scale * x + sum with scale = +-2^-K, x a dyadic rational, sum an integer; the host build checks that no bit is lost
+KB_HD double frac_lane(double scale, double x, double sum) {
+  const double w = fma_(scale, x, sum);
+#if !defined(__HIP_DEVICE_COMPILE__)
+  if ((long double)w != (long double)scale * (long double)x + (long double)sum) audit().inexact += 1;   // 64-bit significands: the right side is exact
+#endif
+  return w;
+}
 
 // s_i <- V_i s_i + sum(s), V = [-2, 1, 2, 1/2, 3, 4, -1/2, -3, -4, 2^-8, 1/8, 2^-24, -2^-8, -1/8, -1/16, -2^-24]
-// The two 2^-24 entries are the small integers -+127 modulo p (p - 1 = 127 * 2^24), one fma each instead of the five
-// instructions of div2k_add; those two lanes then grow by 2^7 per round and are reduced every other round (permute_impl).
+// The two 2^-24 entries are the small integers -+127 modulo p (p - 1 = 127 * 2^24), one fma each; those two lanes then grow by 2^7 per
+// round and are reduced every other round (permute_impl).
 KB_HD void internal_layer(double s[16]) {
-  double sum = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
-  sum += ((s[8] + s[9]) + (s[10] + s[11])) + ((s[12] + s[13]) + (s[14] + s[15]));
+  // integer lanes and fractional lanes are summed apart: the integer part may reach 2^50.4, the fractional one carries up to 16 bits
+  // below the point and stays under 2^36 (bounds below)
+  double si = ((s[0] + s[1]) + (s[2] + s[4])) + ((s[5] + s[7]) + (s[8] + s[11])) + s[15];
+  const double sf = ((s[3] + s[6]) + (s[9] + s[10])) + ((s[12] + s[13]) + s[14]);
 #if !defined(__HIP_DEVICE_COMPILE__)
-  { double a = 0; for (int i = 0; i < 16; i++) a += s[i] < 0 ? -s[i] : s[i]; P2F_PROBE(lane_sum, a); }  // sum of magnitudes: no order of the additions can exceed it
+  {
+    double a = 0, f = 0;
+    for (int i = 0; i < 16; i++) a += s[i] < 0 ? -s[i] : s[i];
+    P2F_PROBE(lane_sum, a);  // sum of magnitudes: no order of the additions can exceed it
+    const int fl[7] = {3, 6, 9, 10, 12, 13, 14};
+    long double e = 0;
+    bool fractional = false;
+    for (int i : fl) { f += s[i] < 0 ? -s[i] : s[i]; e += (long double)s[i]; fractional |= s[i] != rne(s[i]); }
+    if (fractional) P2F_PROBE(frac_sum, f);   // (in the first partial round they are still integers, below 7 * 2^35.2)
+    if ((long double)sf != e) audit().inexact += 1;
+  }
 #endif
-  sum = reduce(sum);
+  double sum = reduce(si + integerize(sf));
   s[0] = fma_(-2.0, s[0], sum);
   s[1] = s[1] + sum;
   s[2] = fma_(2.0, s[2], sum);
-  s[3] = div2k_add<1, 1>(s[3], sum);
+  s[3] = frac_lane(0.5, s[3], sum);
   s[4] = fma_(sconst(3.0), s[4], sum);
   s[5] = fma_(4.0, s[5], sum);
-  s[6] = div2k_add<1, -1>(s[6], sum);
+  s[6] = frac_lane(-0.5, s[6], sum);
   s[7] = fma_(sconst(-3.0), s[7], sum);
   s[8] = fma_(-4.0, s[8], sum);
-  s[9] = div2k_add<8, 1>(s[9], sum);
-  s[10] = div2k_add<3, 1>(s[10], sum);
+  s[9] = frac_lane(sconst(1.0 / 256), s[9], sum);
+  s[10] = frac_lane(sconst(0.125), s[10], sum);
   s[11] = fma_(sconst(-127.0), s[11], sum);  // 2^-24 = -127 (mod p): 127 * 2^24 = p - 1
-  s[12] = div2k_add<8, -1>(s[12], sum);
-  s[13] = div2k_add<3, -1>(s[13], sum);
-  s[14] = div2k_add<4, -1>(s[14], sum);
+  s[12] = frac_lane(sconst(-1.0 / 256), s[12], sum);
+  s[13] = frac_lane(sconst(-0.125), s[13], sum);
+  s[14] = frac_lane(sconst(-0.0625), s[14], sum);
   s[15] = fma_(sconst(127.0), s[15], sum);   // -2^-24 = 127
 }
 
 // Magnitudes (B = 2^30 + 2^15 bounds an S-box output; inputs of a permutation: |s_i| <= 2^35.3):
 //  first layer: <= 35 * 2^35.3 = 2^40.5 -> first S-boxes see |y| < 2^40.6 (fine for sbox, see there), then every full
 //  round: S-box outputs < B, layer outputs < 35 B < 2^35.2.
-//  partial rounds: lane 0 is an S-box output (< B) before the layer and <= 2 B + |sum| after; the lanes with a 2^-k diagonal
-//  contract (|s|/2 + 2^30 + |sum| + 1); lane 1 grows by |sum| <= p/2 + 2^11 per round; the integer-diagonal lanes 2, 4, 5, 7, 8
-//  grow by at most x4 + |sum| per round and are reduced after rounds 4 and 9, so they stay below 2^35.2 * 4^5 + ... < 2^46,
-//  and they leave the last round below 2^30 * 4^3 + 2^33 < 2^37; lanes 11 and 15 (diagonal -+127) grow by x127 + |sum| per round and
-//  are reduced after every odd round: 2^35.2 -> 2^42.2 -> 2^49.2 once at the start, afterwards 2^30 -> 2^37 -> 2^44, and they leave the
-//  last (even) round below 2^37.1. The lane sum stays below 2 * 2^49.2 + 5 * 2^46 + 9 * 2^36 < 2^50.4 (reduce() takes |x| < 2^52).
+//  partial rounds: lane 0 is an S-box output (< B) before the layer and <= 2 B + |sum| after; lane 1 grows by |sum| <= p/2 + 2^11 per
+//  round; the integer-diagonal lanes 2, 4, 5, 7, 8 grow by at most x4 + |sum| per round and are reduced after rounds 4 and 9, so they
+//  stay below 2^35.2 * 4^5 + ... < 2^46, and they leave the last round below 2^30 * 4^3 + 2^33 < 2^37; lanes 11 and 15 (diagonal -+127)
+//  grow by x127 + |sum| per round and are reduced after every odd round: 2^35.2 -> 2^42.2 -> 2^49.2 once at the start, afterwards
+//  2^30 -> 2^37 -> 2^44, and they leave the last (even) round below 2^37.1. The lane sum stays below 2 * 2^49.2 + 5 * 2^46 + 9 * 2^36
+//  < 2^50.4 (reduce() takes |x| < 2^52).
+//  The fractional lanes (diagonal +-2^-K) contract: |s| <- |s| / 2^K + |sum|, from < 2^35.2 to < 2^34.3 (K = 1) / 2^32.5 (K = 3) / 2^31.8
+//  (K = 4) / 2^30.1 (K = 8) after the first round and towards 2 |sum| < 2^31.1 after that; an integerization adds at most 2^30 + 1/2.
+//  They gain K bits below the point per round: lanes 9 and 12 (K = 8) are integerized after every odd round (16 bits at that moment, 8
+//  when a sum reads them), lanes 10, 13 (K = 3) and 14 (K = 4) after rounds 4 and 9 (15 / 20 bits at that moment — a lane below 2^32 has
+//  21 to spare — and 12 / 16 when a sum reads them), lanes 3 and 6 (K = 1) only at the end (13 bits). All seven are integerized after
+//  the last partial round, before the S-boxes of the full rounds read them. Their sum is below 2^35.8 in round 1 (8 bits below the
+//  point) and below 2^35 from round 2 on (at most 16 bits): exact in a double. The host build checks every one of these operations
+//  against 64-bit significands (Audit::inexact) and records the largest sum of their magnitudes (Audit::frac_sum).
 template <class RcExt, class RcInt>
 KB_HD void permute_impl(double s[16], RcExt rc_ext, RcInt rc_int) {
 #if !defined(__HIP_DEVICE_COMPILE__)
@@ -171,12 +200,18 @@ KB_HD void permute_impl(double s[16], RcExt rc_ext, RcInt rc_int) {
     internal_layer(s);
     if (r == 4 || r == 9) {
       s[2] = reduce(s[2]); s[4] = reduce(s[4]); s[5] = reduce(s[5]); s[7] = reduce(s[7]); s[8] = reduce(s[8]);
+      s[10] = integerize(s[10]); s[13] = integerize(s[13]); s[14] = integerize(s[14]);
     }
-    if (r & 1) { s[11] = reduce(s[11]); s[15] = reduce(s[15]); }
+    if (r & 1) {
+      s[11] = reduce(s[11]); s[15] = reduce(s[15]);
+      s[9] = integerize(s[9]); s[12] = integerize(s[12]);
+    }
 #if !defined(__HIP_DEVICE_COMPILE__)
     for (int i = 0; i < 16; i++) P2F_PROBE(lane, s[i]);
 #endif
   }
+  s[3] = integerize(s[3]); s[6] = integerize(s[6]); s[9] = integerize(s[9]); s[10] = integerize(s[10]);
+  s[12] = integerize(s[12]); s[13] = integerize(s[13]); s[14] = integerize(s[14]);
 #pragma unroll
   for (int r = 4; r < 8; r++) {
 #pragma unroll
