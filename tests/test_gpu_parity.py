@@ -263,6 +263,37 @@ def test_pcs_commit_and_open_batch(hip_ctx, oracle, shapes):
         assert ok and np.array_equal(v, vo) and np.array_equal(pr, po)
 
 
+@pytest.mark.parametrize("bl", [1, 2])
+def test_pcs_commit_rows_that_start_with_constant_columns(hip_ctx, oracle, bl):
+    """The shape step pads a shard with chips that have no events: all rows of such a trace are equal. Where the row injected at a tree
+    layer starts with constant columns, the sponge over them is computed once (merkle::sponge_prefix) and every node starts from that
+    state. Roots, LDEs and openings against the oracle for: constant matrices in front of a random one (three whole groups skipped),
+    a layer made of one constant matrix whose width is not a multiple of eight (the whole row hash is the same), a constant matrix with
+    one different cell in its thirteenth column (one group skipped), five constant columns in front (nothing skipped), a nearly
+    constant first column (nothing skipped); enough cells below the top for the side-stream LDE to be used."""
+    rng = np.random.default_rng(4040 + bl)
+    const = lambda h, w: np.repeat(rand(rng, (1, w)), h, axis=0)
+    one_off = const(1 << 14, 16)
+    one_off[777, 12] ^= 1
+    five = np.concatenate([const(1 << 15, 5), rand(rng, (1 << 15, 4))], axis=1)
+    nearly = const(1 << 14, 9)
+    nearly[(1 << 14) - 1, 0] ^= 1
+    for mats in ([rand(rng, (1 << 17, 3)), const(1 << 16, 40), const(1 << 16, 16), rand(rng, (1 << 16, 20)), const(1 << 15, 9), one_off, rand(rng, (1 << 14, 3))],
+                 [rand(rng, (1 << 16, 2)), five, const(1 << 15, 8), nearly, const(1 << 14, 8), const(1 << 13, 8)]):
+        mats = [np.ascontiguousarray(m) for m in mats]
+        root_o, ldes_o, _ = oracle.pcs_commit(mats, bl, want_ldes=True)
+        d = prover.pcs_commit(hip_ctx, [hip_ctx.upload(m) for m in mats], bl)
+        assert np.array_equal(d.root, root_o)
+        for i in range(len(mats)):
+            assert np.array_equal(d.lde(i), ldes_o[i])
+        maxh = max(m.shape[0] for m in mats) << bl
+        for idx in (0, 1, maxh // 2 + 5, maxh - 1):
+            v, pr = d.open_batch(idx)
+            vo, po, ok = oracle.pcs_open_batch(mats, bl, idx)
+            assert ok and np.array_equal(v, vo) and np.array_equal(pr, po)
+        d.free()
+
+
 def test_pcs_commit_shifted_domains(hip_ctx, oracle):
     rng = np.random.default_rng(77)
     mats = [rand(rng, (256, 4)), rand(rng, (256, 4))]

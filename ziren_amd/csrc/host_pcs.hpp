@@ -2,7 +2,11 @@
 #pragma once
 // ---- device helpers ------------------------------------------------------------------------------
 // Coset LDE of a batch of column-major matrices (any heights), one launch per kernel for the whole batch (lde.cuh: Batch).
-struct LdeJob { const uint32_t* in; size_t n, w; uint32_t lde_shift; uint32_t* out; };
+struct LdeJob {
+  const uint32_t* in; size_t n, w; uint32_t lde_shift; uint32_t* out;
+  uint32_t* cflag = nullptr;   // optional: 2 w words, zeroed by the caller, that keep the constant-column flags (lde::Mat::cflag) after the batch — written
+                               // only for four-step matrices (n > 2^LOG_ROW_MAX); without it the batch uses scratch of its own
+};
 
 static void lde_batch_chunk(zkm_ctx* ctx, const std::vector<LdeJob>& jobs, int bl) {
   // groups = distinct heights, tallest first (the biggest blocks are queued first)
@@ -21,7 +25,7 @@ static void lde_batch_chunk(zkm_ctx* ctx, const std::vector<LdeJob>& jobs, int b
   size_t t1 = 0, t2 = 0;
   // constant-column flags of the four-step matrices (lde::Mat::cflag): two words per column, zero = "constant so far"
   size_t big_cols = 0, fc = 0;
-  for (size_t oi : order) if (jobs[oi].n > ((size_t)1 << lde::LOG_ROW_MAX)) big_cols += jobs[oi].w;
+  for (size_t oi : order) if (jobs[oi].n > ((size_t)1 << lde::LOG_ROW_MAX) && !jobs[oi].cflag) big_cols += jobs[oi].w;
   uint32_t* cflags = big_cols ? ctx->alloc_n<uint32_t>(2 * big_cols) : nullptr;
   if (cflags) HIP_CHECK(hipMemsetAsync(cflags, 0, 2 * big_cols * sizeof(uint32_t), ctx->cur));
   uint32_t blk[4] = {0, 0, 0, 0};
@@ -57,7 +61,8 @@ static void lde_batch_chunk(zkm_ctx* ctx, const std::vector<LdeJob>& jobs, int b
       if (la) {
         m.tmp1 = tmp1 + t1; t1 += n * j.w;
         m.tmp2 = tmp2 + t2; t2 += (n * j.w) << bl;
-        m.cflag = cflags + fc; fc += 2 * j.w;
+        if (j.cflag) m.cflag = j.cflag;
+        else { m.cflag = cflags + fc; fc += 2 * j.w; }
         auto ct = ctx->coset_tables(k, bl, j.lde_shift);
         m.twf = ct.twf; m.cs = ct.cs;
       }
@@ -134,7 +139,7 @@ static bool compress_small_layer(zkm_ctx* ctx, Tree& t, int layer, size_t len) {
   if (len > LANES_MAX) {
     KLAUNCH(ctx, "compress_layer", 96.0 * len, merkle::compress_layer, dim3(div_up(len, merkle::THREADS)), dim3(merkle::THREADS), 0,
             (const uint32_t*)(t.digests + t.layer_off[layer] * 8), t.digests + t.layer_off[layer + 1] * 8, len,
-            (const uint32_t* const*)nullptr, 0);
+            (const uint32_t* const*)nullptr, 0, (const uint32_t*)nullptr);
     return false;
   }
   if (len <= TAIL) {
@@ -150,7 +155,9 @@ static bool compress_small_layer(zkm_ctx* ctx, Tree& t, int layer, size_t len) {
 
 // MerkleTreeMmcs::commit over column-major matrices of power-of-two heights.
 static void build_tree(zkm_ctx* ctx, const std::vector<zkm_matrix>& mats, Tree& t,
-                       const std::function<void(size_t)>& prepare_height = nullptr) {
+                       const std::function<void(size_t)>& prepare_height = nullptr, const std::vector<const uint32_t*>* col_flags = nullptr) {
+  // col_flags (pcs_commit): per matrix the constant-column flags its LDE left (two words per column, lde::Mat::cflag), or null. Where
+  // the row injected at a layer starts with constant columns, the sponge over them is computed once (merkle::sponge_prefix).
   // prepare_height(h), when given, is called right before the matrices of height h are first read: pcs_commit extends
   // them there, so a commit's kernels are queued tallest matrix first, layer by layer (extend, hash, extend the next
   // height, inject, ...), and whatever is still arriving over PCIe is only waited for when its layer is reached
@@ -173,6 +180,28 @@ static void build_tree(zkm_ctx* ctx, const std::vector<zkm_matrix>& mats, Tree& 
     return ptrs;
   };
   std::vector<const uint32_t**> to_free;
+  // the flag-pointer table of a height below the top whose first matrix kept flags (one entry per column of the concatenated row)
+  std::map<size_t, const uint32_t**> flag_tables;
+  uint32_t* prefixes = nullptr;   // 32 words per such height: sponge_prefix's output
+  if (col_flags) {
+    size_t n_tab = 0;
+    for (size_t i = 0; i < mats.size(); i++) {
+      const size_t h = mats[i].h;
+      if (h == maxh || flag_tables.count(h)) continue;
+      size_t first = 0;
+      while (mats[first].h != h) first++;
+      if (!(*col_flags)[first]) { flag_tables[h] = nullptr; continue; }
+      std::vector<const uint32_t*> fp;
+      for (size_t j = 0; j < mats.size(); j++)
+        if (mats[j].h == h)
+          for (size_t c = 0; c < mats[j].w; c++) fp.push_back((*col_flags)[j] ? (*col_flags)[j] + 2 * c : nullptr);
+      flag_tables[h] = upload_ptrs(ctx, fp);
+      to_free.push_back(flag_tables[h]);
+      n_tab++;
+    }
+    if (n_tab) prefixes = ctx->alloc_n<uint32_t>(32 * n_tab);
+  }
+  size_t prefix_no = 0;
   // the column-pointer table of every height is staged before the first launch (the LDE buffers exist already): one transfer per tree
   std::map<size_t, std::pair<const uint32_t**, size_t>> tables;
   for (auto& m : mats)
@@ -217,12 +246,19 @@ static void build_tree(zkm_ctx* ctx, const std::vector<zkm_matrix>& mats, Tree& 
     const uint32_t** d = tables.count(len) ? tables[len].first : nullptr;
     struct { size_t n; size_t size() const { return n; } } ptrs{tables.count(len) ? tables[len].second : 0};
     if (d) wait_height(len);
+    const uint32_t* prefix = nullptr;
+    if (d && flag_tables.count(len) && flag_tables[len]) {   // after wait_height: the flags are final once the matrices' LDE is queued
+      uint32_t* out = prefixes + 32 * prefix_no++;
+      KLAUNCH(ctx, "sponge_prefix", 0.0, merkle::sponge_prefix, dim3(1), dim3(64), 0, (const uint32_t* const*)flag_tables[len], (int)ptrs.size(), out);
+      prefix = out;
+    }
     KLAUNCH(ctx, "compress_layer", 96.0 * len + 4.0 * len * ptrs.size(), merkle::compress_layer, dim3(div_up(len, merkle::THREADS)),
             dim3(merkle::THREADS), 0, (const uint32_t*)(t.digests + t.layer_off[layer] * 8), t.digests + t.layer_off[layer + 1] * 8,
-            len, (const uint32_t* const*)d, (int)ptrs.size());
+            len, (const uint32_t* const*)d, (int)ptrs.size(), prefix);
     if (len == 1) break;
   }
   for (auto d : to_free) ctx->release((void*)d);
+  ctx->release(prefixes);
 }
 
 static void free_pcs_data(zkm_ctx* ctx, zkm_pcs_data* d) {
@@ -237,6 +273,7 @@ static void free_pcs_data(zkm_ctx* ctx, zkm_pcs_data* d) {
 static zkm_pcs_data* pcs_commit(zkm_ctx* ctx, const std::vector<zkm_matrix>& mats, const std::vector<uint32_t>& shifts,
                                 int log_blowup) {
   zkm_pcs_data* d = new zkm_pcs_data();
+  uint32_t* cflags = nullptr;
   try {
     d->log_blowup = log_blowup;
     for (size_t i = 0; i < mats.size(); i++) {
@@ -253,8 +290,20 @@ static zkm_pcs_data* pcs_commit(zkm_ctx* ctx, const std::vector<zkm_matrix>& mat
     // Matrices that are complete in HBM are all extended up front, one launch per kernel for the whole commit. A matrix still
     // arriving over PCIe (zkm_matrix_upload_async) is extended right before the tree layer that reads it (see build_tree), so only
     // the tallest trace's upload is exposed.
-    std::vector<char> extended(mats.size(), 0);
     auto shift_of = [&](size_t i) { return kb::mul(kb::GEN, kb::inv(d->domain_shifts[i])); };
+    // constant-column flags of the four-step matrices, kept until the tree is built (build_tree: col_flags)
+    size_t flag_words = 0;
+    for (auto& m : mats) if (m.h > ((size_t)1 << lde::LOG_ROW_MAX)) flag_words += 2 * m.w;
+    cflags = flag_words ? ctx->alloc_n<uint32_t>(flag_words) : nullptr;
+    if (cflags) HIP_CHECK(hipMemsetAsync(cflags, 0, flag_words * sizeof(uint32_t), ctx->stream));
+    std::vector<const uint32_t*> col_flags(mats.size(), nullptr);
+    {
+      size_t off = 0;
+      for (size_t i = 0; i < mats.size(); i++)
+        if (mats[i].h > ((size_t)1 << lde::LOG_ROW_MAX)) { col_flags[i] = cflags + off; off += 2 * mats[i].w; }
+    }
+    auto job_of = [&](size_t i) { return LdeJob{mats[i].d, mats[i].h, mats[i].w, shift_of(i), d->ldes[i].d, const_cast<uint32_t*>(col_flags[i])}; };
+    std::vector<char> extended(mats.size(), 0);
     size_t top = 0;
     for (auto& l : d->ldes) top = std::max(top, l.h);
     {
@@ -267,7 +316,7 @@ static zkm_pcs_data* pcs_commit(zkm_ctx* ctx, const std::vector<zkm_matrix>& mat
       size_t rest_cells = 0;
       for (size_t i = 0; i < mats.size(); i++)
         if (!mats[i].ready || hipEventQuery(mats[i].ready) == hipSuccess) {   // never uploaded asynchronously, or landed already
-          (d->ldes[i].h == top ? tall : rest).push_back(LdeJob{mats[i].d, mats[i].h, mats[i].w, shift_of(i), d->ldes[i].d});
+          (d->ldes[i].h == top ? tall : rest).push_back(job_of(i));
           if (d->ldes[i].h != top) rest_cells += mats[i].h * mats[i].w;
           extended[i] = 1;
         }
@@ -287,13 +336,15 @@ static zkm_pcs_data* pcs_commit(zkm_ctx* ctx, const std::vector<zkm_matrix>& mat
       for (size_t i = 0; i < mats.size(); i++) {
         if (extended[i] || d->ldes[i].h != lde_height) continue;
         wait_ready(ctx->stream, mats[i]);
-        jobs.push_back(LdeJob{mats[i].d, mats[i].h, mats[i].w, shift_of(i), d->ldes[i].d});
+        jobs.push_back(job_of(i));
         extended[i] = 1;
       }
       lde_batch(ctx, jobs, log_blowup);
     };
-    build_tree(ctx, d->ldes, d->tree, extend_height);
+    build_tree(ctx, d->ldes, d->tree, extend_height, &col_flags);
     ctx->side_join();
+    ctx->release(cflags);
+    cflags = nullptr;
     for (size_t i = 0; i < mats.size(); i++)
       if (!extended[i]) throw std::runtime_error("pcs_commit: a matrix was not reached by the tree (internal error)");
     const uint32_t* h_root = d->tree.h_root ? d->tree.h_root : ctx->download_async(d->tree.node(d->tree.log_max, 0), 8);
@@ -303,6 +354,7 @@ static zkm_pcs_data* pcs_commit(zkm_ctx* ctx, const std::vector<zkm_matrix>& mat
   } catch (...) {
     ctx->cur = ctx->stream;
     try { ctx->side_join(); } catch (...) {}   // nothing of this commit may still be running on the side stream when its buffers go back
+    ctx->release(cflags);
     free_pcs_data(ctx, d);
     throw;
   }

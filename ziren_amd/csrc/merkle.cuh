@@ -65,15 +65,22 @@ __global__ __launch_bounds__(THREADS) void hash_leaves(const uint32_t* const* __
 // next[i] = compress(prev[2i], prev[2i+1]); optionally inject the rows of matrices of height m:
 // node = compress(node, hash(row i)). All of a node's permutations (1, or 1 + ceil(w/8) + 1) go through ONE call site in a
 // uniform loop — three inlined copies of the permutation would be 64 KiB of code, the size of the instruction cache.
+// `prefix` (may be null; written by sponge_prefix below): prefix[16] = P, the number of leading eight-column groups of the injected
+// row whose columns are constant over all rows, prefix[0..16) = the sponge state after absorbing them (Montgomery words) — the same
+// for every row, so a node's sponge starts from it and absorbs the groups from P on.
 __global__ __launch_bounds__(THREADS) void compress_layer(const uint32_t* __restrict__ prev, uint32_t* __restrict__ next, size_t m,
-                                                          const uint32_t* const* __restrict__ inject_cols, int inject_width) {
+                                                          const uint32_t* const* __restrict__ inject_cols, int inject_width,
+                                                          const uint32_t* __restrict__ prefix) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= m) return;
   double s[16], node[8];
   load_digest(s, prev + 16 * i);
   load_digest(s + 8, prev + 16 * i + 8);
-  const int groups = (inject_width + 7) / 8;
+  const int skip = prefix ? (int)gp::load(prefix + 16) : 0;
+  const int groups = (inject_width + 7) / 8 - skip;   // the groups this node absorbs itself
   const int last = inject_width > 0 ? groups + 1 : 0;
+  inject_cols += 8 * skip;
+  inject_width -= 8 * skip;
   uint32_t w[8];  // the injected row's next eight words, requested one permutation ahead
 #pragma unroll
   for (int k = 0; k < 8; k++)
@@ -84,8 +91,13 @@ __global__ __launch_bounds__(THREADS) void compress_layer(const uint32_t* __rest
     if (ph == 0) {  // the node's digest is set aside, the state becomes the sponge of the injected row
 #pragma unroll
       for (int k = 0; k < 8; k++) node[k] = s[k];
+      if (skip) {
 #pragma unroll
-      for (int k = 0; k < 16; k++) s[k] = 0.0;
+        for (int k = 0; k < 16; k++) s[k] = p2f::load_monty(gp::load(prefix + k));
+      } else {
+#pragma unroll
+        for (int k = 0; k < 16; k++) s[k] = 0.0;
+      }
     }
     if (ph < groups) {
       const int g0 = 8 * ph;
@@ -301,6 +313,31 @@ __global__ __launch_bounds__(1024) void compress_tail_lanes(uint32_t* __restrict
     nx += 8 * len;
     if (len == 1) break;
   }
+}
+
+// The part of an injected row's sponge that is the same for every row (round 4). The shape step pads a shard with chips that have no
+// events: every row of such a trace is the same, its LDE is that row again, and when such matrices come first among the matrices of a
+// height, every row's sponge spends its first permutations on the same words. flags[c] -> the two words lde::Mat::cflag keeps for column
+// c of the concatenated row ([0] != 0: the column is not constant, [1]: its first word), or null where no flags were kept. One
+// wavefront, sixteen lanes per permutation (lanes::permute): out[16] = P, the number of leading whole groups of eight constant columns
+// (all groups when every column is constant, the last one possibly short), out[0..16) = the sponge state after them.
+__global__ __launch_bounds__(64) void sponge_prefix(const uint32_t* const* __restrict__ flags, int width, uint32_t* __restrict__ out) {
+  const int e = threadIdx.x & 15;
+  int nc = 0;
+  while (nc < width) {
+    const uint32_t* f = flags[nc];
+    if (!f || f[0] != 0) break;
+    nc++;
+  }
+  const int P = nc == width ? (width + 7) / 8 : nc / 8;
+  const lanes::LaneConsts k = lanes::load_consts(e);
+  uint32_t x = 0;
+  for (int g = 0; g < P; g++) {
+    if (e < 8 && 8 * g + e < width) x = flags[8 * g + e][1];
+    x = lanes::permute(x, k);
+  }
+  if (threadIdx.x < 16) out[e] = x;
+  if (threadIdx.x == 0) out[16] = (uint32_t)P;
 }
 
 // FRI commit-phase leaves: row j = (f[2j], f[2j+1]) as 8 base words (fri.rs:279-306)
