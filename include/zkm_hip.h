@@ -697,10 +697,11 @@ void zkm_host_poseidon2_f64_compress_inject(const uint32_t left[8], const uint32
                                             uint32_t out[8]);
 /* The largest magnitudes the host build of the FP64 permutation has met on this thread since the last reset, at the points
  * its exactness argument rests on: out[0] a permutation input, out[1] the sum of lane magnitudes in a partial round,
- * out[2] an S-box input, out[3] a lane after a partial round, out[4] the sum of the magnitudes of the lanes held as dyadic rationals
- * in a partial round; out[5] = how many operations on those lanes lost a bit (checked against 64-bit significands: must be 0).
- * (The device build has no probes.) */
-void zkm_host_poseidon2_f64_audit(double out[6], int reset);
+ * out[2] an input of the first sixteen (wide) S-boxes, out[3] a lane after a partial round, out[4] the sum of the magnitudes of the lanes held as dyadic rationals
+ * in a partial round; out[5] = how many operations on those lanes lost a bit (checked against 64-bit significands) plus how many
+ * four-instruction modular products were not exact, not congruent or out of range (checked against 128-bit integers): must be 0;
+ * out[6] an input of the other (nine-instruction) S-boxes. (The device build has no probes.) */
+void zkm_host_poseidon2_f64_audit(double out[7], int reset);
 void zkm_host_ext_mul(const uint32_t a[4], const uint32_t b[4], uint32_t out[4]);
 void zkm_host_ext_inv(const uint32_t a[4], uint32_t out[4]);
 uint32_t zkm_host_field_mul(uint32_t a, uint32_t b);

@@ -213,7 +213,7 @@ def test_fp64_poseidon2_unreduced_flows_are_exact_and_within_their_bounds(oracle
     P = F.P
     rng = np.random.default_rng(11)
     edge = np.array([0, 1, 2, P - 1, P - 2, (P - 1) // 2, (P + 1) // 2] + [(1 << k) + d for k in range(20, 31) for d in (-1, 0, 1)], dtype=np.uint64) % P
-    audit = (C.c_double * 6)()
+    audit = (C.c_double * 7)()
     L.zkm_host_poseidon2_f64_audit(audit, 1)
 
     def words(n, kind):
@@ -240,13 +240,14 @@ def test_fp64_poseidon2_unreduced_flows_are_exact_and_within_their_bounds(oracle
                 want = oracle.compress(want, oracle.hash_slice(row))
             assert np.array_equal(out, want), (trial, n, kind, inj)
     L.zkm_host_poseidon2_f64_audit(audit, 1)
-    perm_in, lane_sum, sbox_in, lane, frac_sum, inexact = [float(x) for x in audit]
+    perm_in, lane_sum, sbox_in, lane, frac_sum, inexact, sbox_fast_in = [float(x) for x in audit]
     assert 2.0 ** 30 < perm_in <= 2.0 ** 35.3          # unreduced capacity / node halves did flow in, and within the input bound
     assert lane_sum < 2.0 ** 50.4                       # reduce() takes |x| < 2^52
-    assert sbox_in < 2.0 ** 40.6                        # sbox(): |y| < 2^41
+    assert sbox_in < 2.0 ** 40.6                        # sbox_wide() (the first sixteen S-boxes): |y| < 2^41
+    assert 2.0 ** 31 < sbox_fast_in < 2.0 ** 37.3       # sbox() (nine instructions): |y| < 2^38.5
     assert lane < 2.0 ** 49.3
     assert 2.0 ** 31 < frac_sum < 2.0 ** 35.8           # the lanes kept as dyadic rationals between rounds: their sum is exact below 2^36
-    assert inexact == 0                                 # no fractional-lane operation lost a bit
+    assert inexact == 0                                 # no fractional-lane operation lost a bit; every four-instruction product exact
 
 
 def test_challenger_matches_oracle(oracle):

@@ -38,11 +38,19 @@ KB_HD double sconst(double c) {
 #endif
   return c;
 }
+// ... and one held in a vector register pair: an instruction of this family reads at most one scalar operand, so the second constant of
+// fma(x, p - 1, -M p) sits in VGPRs (as a literal it would again be v_fmac_f64 with a v_mov_b64 of the addend in front).
+KB_HD double vconst(double c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm("" : "+v"(c));
+#endif
+  return c;
+}
 
 // Host build only: the largest magnitudes seen at the points the exactness argument rests on (a permutation's inputs, the lane sum
 // of a partial round before its reduction, an S-box input, any lane after a partial round, the sum of the fractional lanes), and the
 // number of fractional-lane operations that lost a bit (must be zero). The device build compiles them away.
-struct Audit { double in = 0, lane_sum = 0, sbox_in = 0, lane = 0, frac_sum = 0, inexact = 0; };
+struct Audit { double in = 0, lane_sum = 0, sbox_in = 0, lane = 0, frac_sum = 0, inexact = 0, sbox_fast_in = 0; };
 inline Audit& audit() { static thread_local Audit a; return a; }
 inline void probe(double& slot, double v) { v = v < 0 ? -v : v; if (v > slot) slot = v; }
 #if !defined(__HIP_DEVICE_COMPILE__)
@@ -69,12 +77,52 @@ KB_HD double mulmod(double a, double b) {
   const double r = fma_(-q, P, h);
   return r + l;
 }
-// (y)^3 for |y| < 2^41: |y^2| < 2^82 -> |z| <= p/2 + p*2^-0.9.. ; for the |y| <= 2^36.3 met in steady state |z| < 2^30.01
-// and |z y| < 2^66.4 -> |w| <= p/2 + 2^15.
-KB_HD double sbox(double y) {
+// (y)^3 for |y| < 2^41: |y^2| < 2^82 -> |z| <= p/2 + p*2^-0.9.. ; the wide form, used where the input is the output of two linear
+// layers in a row (the first S-boxes of a permutation: |y| < 2^40.6). Twelve instructions.
+KB_HD double sbox_wide(double y) {
   P2F_PROBE(sbox_in, y);
   const double z = mulmod(y, y);
   return mulmod(z, y);
+}
+
+// ---- the four-instruction modular product (round 4) ----
+// a b - q p for the integer q nearest to a * bp, bp = RN(b / p), without ever forming the product's high part:
+//   qm = fma(a, bp, M)         M = 1.5 * 2^52: the sum lands in [2^52, 2^53) where a double's ulp is 1, so qm = M + q exactly, q the
+//                              integer nearest to a*bp (|q| < 2^51); |q - ab/p| <= 1/2 + |ab/p| 2^-52
+//   tm = fma(qm, p - 1, -M p)  = (M + q)(p - 1) - M p = q (p - 1) - M exactly: p - 1 = 127 * 2^24, so q (p - 1) is 127 q shifted —
+//                              representable while |127 q| < 2^53, i.e. |q| < 2^46 — and M is a multiple of 2^24 as well;
+//                              M p = 3 p * 2^51 is a double (3 p has 33 bits)
+//   rm = fma(a, b, -tm)        = (ab - q p) + q + M exactly: an integer in [2^52, 2^53) again (|ab - q p| <= p (1/2 + 2^-6), |q| < 2^46)
+//   rm - qm                    = ab - q p exactly.
+// Bounds: |ab| < 2^77 (so |q| < 2^46); result |r| <= p (1/2 + |ab/p| 2^-52) — for |ab| < 2^66.4 (an S-box's second product) that is
+// p/2 + 2^15. The quotient's multiplier bp is shared by the two products of a cube (both multiply by y), so an S-box is
+// 1 + 4 + 4 = nine instructions instead of twelve. The host build checks every such product against 128-bit integers.
+constexpr double MAGIC = 6755399441055744.0;        // 1.5 * 2^52
+constexpr double PM1 = 2130706432.0;                 // p - 1 = 127 * 2^24
+constexpr double MAGIC_P = MAGIC * P;                // exact: 3 p * 2^51
+KB_HD double mulmod_q(double a, double b, double bp) {
+  const double qm = fma_(a, bp, vconst(MAGIC));
+  const double tm = fma_(qm, sconst(PM1), vconst(-MAGIC_P));
+  const double rm = fma_(a, b, -tm);
+  const double r = rm - qm;
+#if !defined(__HIP_DEVICE_COMPILE__)
+  {
+    const __int128 ab = (__int128)(long long)a * (__int128)(long long)b, ri = (__int128)(long long)r;
+    const double lim = P * (0.5 + 1.0 / 32);
+    if ((double)(long long)a != a || (double)(long long)b != b || (ab - ri) % (__int128)2130706433LL != 0 || r > lim || r < -lim ||
+        (a < 0 ? -a : a) * (b < 0 ? -b : b) >= 0x1p77)
+      audit().inexact += 1;
+  }
+#endif
+  return r;
+}
+// (y)^3 for |y| < 2^38.5 (y^2 < 2^77): every S-box but the first sixteen of a permutation (steady state |y| <= 2^37.2).
+// |z| <= p (1/2 + 2^-6) < 2^30.05, |z y| < 2^68.6; for |y| <= 2^36.3: |w| <= p/2 + 2^15.4.
+KB_HD double sbox(double y) {
+  P2F_PROBE(sbox_fast_in, y);
+  const double yp = y * PINV;
+  const double z = mulmod_q(y, y, yp);
+  return mulmod_q(z, y, yp);
 }
 
 KB_HD void m4(double& s0, double& s1, double& s2, double& s3) {
@@ -189,7 +237,10 @@ KB_HD void permute_impl(double s[16], RcExt rc_ext, RcInt rc_int) {
 #endif
   external_layer(s);
 #pragma unroll
-  for (int r = 0; r < 4; r++) {
+  for (int i = 0; i < 16; i++) s[i] = sbox_wide(s[i] + rc_ext(0, i));   // two linear layers in a row behind these: |y| < 2^40.6
+  external_layer(s);
+#pragma unroll
+  for (int r = 1; r < 4; r++) {
 #pragma unroll
     for (int i = 0; i < 16; i++) s[i] = sbox(s[i] + rc_ext(r, i));
     external_layer(s);

@@ -714,9 +714,9 @@ void zkm_host_poseidon2_f64_sponge(const uint32_t* words, size_t n, uint32_t dig
 void zkm_host_poseidon2_f64_compress_inject(const uint32_t left[8], const uint32_t right[8], const uint32_t* row, size_t n, uint32_t out[8]) {
   p2f::compress_inject_host(left, right, row, n, out);
 }
-void zkm_host_poseidon2_f64_audit(double out[6], int reset) {
+void zkm_host_poseidon2_f64_audit(double out[7], int reset) {
   p2f::Audit& a = p2f::audit();
-  out[0] = a.in; out[1] = a.lane_sum; out[2] = a.sbox_in; out[3] = a.lane; out[4] = a.frac_sum; out[5] = a.inexact;
+  out[0] = a.in; out[1] = a.lane_sum; out[2] = a.sbox_in; out[3] = a.lane; out[4] = a.frac_sum; out[5] = a.inexact; out[6] = a.sbox_fast_in;
   if (reset) a = p2f::Audit();
 }
 void zkm_host_ext_mul(const uint32_t a[4], const uint32_t b[4], uint32_t out[4]) {
