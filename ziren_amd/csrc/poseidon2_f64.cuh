@@ -101,7 +101,7 @@ constexpr double MAGIC = 6755399441055744.0;        // 1.5 * 2^52
 constexpr double PM1 = 2130706432.0;                 // p - 1 = 127 * 2^24
 constexpr double MAGIC_P = MAGIC * P;                // exact: 3 p * 2^51
 KB_HD double mulmod_q(double a, double b, double bp) {
-  const double qm = fma_(a, bp, vconst(MAGIC));
+  const double qm = fma_(a, bp, sconst(MAGIC));
   const double tm = fma_(qm, sconst(PM1), vconst(-MAGIC_P));
   const double rm = fma_(a, b, -tm);
   const double r = rm - qm;
