@@ -7,8 +7,8 @@
 // profiles/r02_ubench_valu.txt), and a double has 53 bits where an int32 has 31:
 //   * the external MDS layer (coefficient sum 35) is 64 plain additions with no reduction at all
 //     (the integer version: ~70 modular additions of three instructions each);
-//   * a modular product is two-product + Barrett quotient: h = RN(ab), l = fma(a,b,-h) (exact error term),
-//     q = rint(h/p), r = fma(-q,p,h) (exact: an integer below 2^53), result r + l. Six instructions, no carries;
+//   * a modular product a b - q p is four instructions (mulmod_q below: the quotient by the magic-number rounding, q (p - 1) exact
+//     because p - 1 = 127 * 2^24, the residue recovered next to 1.5 * 2^52), no carries; a cube is nine;
 //   * the internal layer's diagonal (+-2^-k, small integers) is one fma per lane: the lanes with a 2^-k entry stay dyadic
 //     rationals (exact in a double) between the rounds and are made integers again only every few rounds.
 // Every operation below is exact integer arithmetic as long as the stated magnitude bounds hold; they are
@@ -47,6 +47,14 @@ KB_HD double vconst(double c) {
   return c;
 }
 
+// ... made where it stands (not hoisted, not kept alive): for a constant that only the first round of a permutation reads
+KB_HD double vconst_here(double c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("" : "+v"(c));
+#endif
+  return c;
+}
+
 // Host build only: the largest magnitudes seen at the points the exactness argument rests on (a permutation's inputs, the lane sum
 // of a partial round before its reduction, an S-box input, any lane after a partial round, the sum of the fractional lanes), and the
 // number of fractional-lane operations that lost a bit (must be zero). The device build compiles them away.
@@ -68,23 +76,6 @@ KB_HD double reduce(double x) {
   const double q = rne(x * PINV);
   return fma_(-q, P, x);
 }
-// a, b integers with |ab| < 2^82  ->  integer congruent to ab, |result| <= p/2 + p*|ab/p|*2^-51 + ulp(ab)/2.
-// h - qp is an integer (h is a multiple of ulp(h) >= 1 or an exact small product) of magnitude < 2^53, so the fma is exact.
-KB_HD double mulmod(double a, double b) {
-  const double h = a * b;
-  const double l = fma_(a, b, -h);
-  const double q = rne(h * PINV);
-  const double r = fma_(-q, P, h);
-  return r + l;
-}
-// (y)^3 for |y| < 2^41: |y^2| < 2^82 -> |z| <= p/2 + p*2^-0.9.. ; the wide form, used where the input is the output of two linear
-// layers in a row (the first S-boxes of a permutation: |y| < 2^40.6). Twelve instructions.
-KB_HD double sbox_wide(double y) {
-  P2F_PROBE(sbox_in, y);
-  const double z = mulmod(y, y);
-  return mulmod(z, y);
-}
-
 // ---- the four-instruction modular product (round 4) ----
 // a b - q p for the integer q nearest to a * bp, bp = RN(b / p), without ever forming the product's high part:
 //   qm = fma(a, bp, M)         M = 1.5 * 2^52: the sum lands in [2^52, 2^53) where a double's ulp is 1, so qm = M + q exactly, q the
@@ -122,6 +113,35 @@ KB_HD double sbox(double y) {
   P2F_PROBE(sbox_fast_in, y);
   const double yp = y * PINV;
   const double z = mulmod_q(y, y, yp);
+  return mulmod_q(z, y, yp);
+}
+
+// The same for |y| < 2^40.6 — the first sixteen S-boxes of a permutation, which sit behind two linear layers in a row (inputs up to
+// 2^35.3, first layer x 35). y^2 / p reaches 2^50.2, too many bits for 127 q; so the first product takes a quotient that is a multiple
+// of 32 (the magic constant one binade up per factor of two: at 1.5 * 2^57 a double's ulp is 32) and leaves a residue below 16 p:
+//   Qm = fma(y, yp, M32)             = M32 + Q, Q the multiple of 32 nearest to y yp; |Q - y^2 / p| <= 16 + 2^-2
+//   tm = fma(Qm, p - 1, -(M32 (p - 1) + M))   = Q (p - 1) - M exactly: 127 Q = 32 * (127 Q / 32) with 127 Q / 32 < 2^52.2, and the constant
+//                                    is 2^51 (381 * 2^29 + 3)
+//   rm = fma(y, y, -tm)              = (y^2 - Q p) + Q + M exactly: an integer in [2^52, 2^53) (|Q| < 2^51)
+//   z  = rm - (Qm - (M32 - M))       = y^2 - Q p exactly, |z| <= p (16 + 2^-2) < 2^35.03
+// five instructions; then z y (|z y| < 2^75.7 < 2^77) is an ordinary four-instruction product: ten instructions instead of twelve.
+constexpr double MAGIC32 = 216172782113783808.0;                  // 1.5 * 2^57
+constexpr double WIDE_C = MAGIC32 * PM1 + MAGIC;                   // exact: 2^51 (381 * 2^29 + 3)
+constexpr double WIDE_D = MAGIC32 - MAGIC;                         // exact: 31 * 1.5 * 2^52
+KB_HD double sbox_wide(double y, double neg_wide_c) {   // neg_wide_c = -WIDE_C in a vector register pair (one scalar operand per instruction)
+  P2F_PROBE(sbox_in, y);
+  const double yp = y * PINV;
+  const double Qm = fma_(y, yp, sconst(MAGIC32));
+  const double tm = fma_(Qm, sconst(PM1), neg_wide_c);
+  const double rm = fma_(y, y, -tm);
+  const double z = rm - (Qm - sconst(WIDE_D));
+#if !defined(__HIP_DEVICE_COMPILE__)
+  {
+    const __int128 yy = (__int128)(long long)y * (__int128)(long long)y, zi = (__int128)(long long)z;
+    const double lim = P * 16.5;
+    if ((double)(long long)y != y || (yy - zi) % (__int128)2130706433LL != 0 || z > lim || z < -lim || (y < 0 ? -y : y) >= 1.6668e12) audit().inexact += 1;
+  }
+#endif
   return mulmod_q(z, y, yp);
 }
 
@@ -236,8 +256,11 @@ KB_HD void permute_impl(double s[16], RcExt rc_ext, RcInt rc_int) {
   for (int i = 0; i < 16; i++) P2F_PROBE(in, s[i]);
 #endif
   external_layer(s);
+  {
+    const double neg_wide_c = vconst_here(-WIDE_C);
 #pragma unroll
-  for (int i = 0; i < 16; i++) s[i] = sbox_wide(s[i] + rc_ext(0, i));   // two linear layers in a row behind these: |y| < 2^40.6
+    for (int i = 0; i < 16; i++) s[i] = sbox_wide(s[i] + rc_ext(0, i), neg_wide_c);   // two linear layers in a row behind these: |y| < 2^40.6
+  }
   external_layer(s);
 #pragma unroll
   for (int r = 1; r < 4; r++) {
