@@ -47,14 +47,6 @@ KB_HD double vconst(double c) {
   return c;
 }
 
-// ... made where it stands (not hoisted, not kept alive): for a constant that only the first round of a permutation reads
-KB_HD double vconst_here(double c) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  asm volatile("" : "+v"(c));
-#endif
-  return c;
-}
-
 // Host build only: the largest magnitudes seen at the points the exactness argument rests on (a permutation's inputs, the lane sum
 // of a partial round before its reduction, an S-box input, any lane after a partial round, the sum of the fractional lanes), and the
 // number of fractional-lane operations that lost a bit (must be zero). The device build compiles them away.
@@ -119,22 +111,23 @@ KB_HD double sbox(double y) {
 // The same for |y| < 2^40.6 — the first sixteen S-boxes of a permutation, which sit behind two linear layers in a row (inputs up to
 // 2^35.3, first layer x 35). y^2 / p reaches 2^50.2, too many bits for 127 q; so the first product takes a quotient that is a multiple
 // of 32 (the magic constant one binade up per factor of two: at 1.5 * 2^57 a double's ulp is 32) and leaves a residue below 16 p:
-//   Qm = fma(y, yp, M32)             = M32 + Q, Q the multiple of 32 nearest to y yp; |Q - y^2 / p| <= 16 + 2^-2
-//   tm = fma(Qm, p - 1, -(M32 (p - 1) + M))   = Q (p - 1) - M exactly: 127 Q = 32 * (127 Q / 32) with 127 Q / 32 < 2^52.2, and the constant
-//                                    is 2^51 (381 * 2^29 + 3)
-//   rm = fma(y, y, -tm)              = (y^2 - Q p) + Q + M exactly: an integer in [2^52, 2^53) (|Q| < 2^51)
-//   z  = rm - (Qm - (M32 - M))       = y^2 - Q p exactly, |z| <= p (16 + 2^-2) < 2^35.03
-// five instructions; then z y (|z y| < 2^75.7 < 2^77) is an ordinary four-instruction product: ten instructions instead of twelve.
+//   Qm = fma(y, yp, M32)    = M32 + Q, Q the multiple of 32 nearest to y yp; |Q - y^2 / p| <= 16 + 2^-2
+//   Q  = Qm - M32           exact
+//   tm = Q (p - 1)          exact: 127 Q = 32 * (127 Q / 32) with |127 Q / 32| < 2^52.2
+//   rm = fma(y, y, -tm)     = (y^2 - Q p) + Q exactly: an integer below 2^51
+//   z  = rm - Q             = y^2 - Q p, |z| <= p (16 + 2^-2) < 2^35.03
+// five instructions with scalar constants only (the four-instruction form would want a second constant in vector registers, and
+// compress_layer sits at 128 of them); then z y (|z y| < 2^75.7 < 2^77) is an ordinary four-instruction product: ten instead of twelve.
 constexpr double MAGIC32 = 216172782113783808.0;                  // 1.5 * 2^57
-constexpr double WIDE_C = MAGIC32 * PM1 + MAGIC;                   // exact: 2^51 (381 * 2^29 + 3)
-constexpr double WIDE_D = MAGIC32 - MAGIC;                         // exact: 31 * 1.5 * 2^52
-KB_HD double sbox_wide(double y, double neg_wide_c) {   // neg_wide_c = -WIDE_C in a vector register pair (one scalar operand per instruction)
+KB_HD double sbox_wide(double y) {
   P2F_PROBE(sbox_in, y);
   const double yp = y * PINV;
-  const double Qm = fma_(y, yp, sconst(MAGIC32));
-  const double tm = fma_(Qm, sconst(PM1), neg_wide_c);
+  const double m32 = sconst(MAGIC32);
+  const double Qm = fma_(y, yp, m32);
+  const double Q = Qm - m32;
+  const double tm = Q * sconst(PM1);
   const double rm = fma_(y, y, -tm);
-  const double z = rm - (Qm - sconst(WIDE_D));
+  const double z = rm - Q;
 #if !defined(__HIP_DEVICE_COMPILE__)
   {
     const __int128 yy = (__int128)(long long)y * (__int128)(long long)y, zi = (__int128)(long long)z;
@@ -256,11 +249,8 @@ KB_HD void permute_impl(double s[16], RcExt rc_ext, RcInt rc_int) {
   for (int i = 0; i < 16; i++) P2F_PROBE(in, s[i]);
 #endif
   external_layer(s);
-  {
-    const double neg_wide_c = vconst_here(-WIDE_C);
 #pragma unroll
-    for (int i = 0; i < 16; i++) s[i] = sbox_wide(s[i] + rc_ext(0, i), neg_wide_c);   // two linear layers in a row behind these: |y| < 2^40.6
-  }
+  for (int i = 0; i < 16; i++) s[i] = sbox_wide(s[i] + rc_ext(0, i));   // two linear layers in a row behind these: |y| < 2^40.6
   external_layer(s);
 #pragma unroll
   for (int r = 1; r < 4; r++) {
