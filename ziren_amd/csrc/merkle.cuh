@@ -144,11 +144,23 @@ __global__ __launch_bounds__(THREADS) void compress_tail(uint32_t* __restrict__ 
 // part-filled waves on an issue-bound kernel and are left to compress_layer / the lane-parallel kernels. Applies where no shorter
 // matrix is injected into those levels: every FRI commit-phase tree, and commits whose next matrix is at least 2^levels shorter.
 constexpr int FUSE_LEAVES = 1024, FUSE_MAX_LEVELS = 4;
+// The FRI commit-phase trees (one permutation per leaf) use smaller blocks: a 1024-thread block owns its CU (70 registers x 16 waves),
+// and while it walks its four tree levels with 8, 4, 2, 1 waves the CU's issue slots idle — 61 % of the permutation rate over the
+// kernel. With 256 leaves per block (levels of 128 and 64 nodes: whole wavefronts again) seven blocks share a CU and one block's
+// sparse levels run under the other blocks' leaves; the levels below go to compress_layer, which fills the chip.
+#ifndef ZKM_FRI_FUSE_LEAVES
+#define ZKM_FRI_FUSE_LEAVES 256
+#endif
+#ifndef ZKM_FRI_FUSE_LEVELS
+#define ZKM_FRI_FUSE_LEVELS 2
+#endif
+constexpr int FRI_FUSE_LEAVES = ZKM_FRI_FUSE_LEAVES, FRI_FUSE_MAX_LEVELS = ZKM_FRI_FUSE_LEVELS;
 
+template <int LEAVES>
 __device__ __forceinline__ void tree_levels_in_block(double s[16], uint32_t* lds, size_t leaf0, size_t n_leaves, uint32_t* __restrict__ tree, int levels) {
   // s[0..8): this thread's leaf digest (doubles, unreduced). Layer l of the tree starts at digest index n_leaves * (2 - 2^(1-l)).
-  uint32_t* cur = lds;                       // [FUSE_LEAVES][8] words
-  uint32_t* nxt = lds + FUSE_LEAVES * 8;     // [FUSE_LEAVES / 2][8]
+  uint32_t* cur = lds;                       // [LEAVES][8] words
+  uint32_t* nxt = lds + LEAVES * 8;          // [LEAVES / 2][8]
   const int t = threadIdx.x;
   {
     uint32_t w[8];
@@ -164,7 +176,7 @@ __device__ __forceinline__ void tree_levels_in_block(double s[16], uint32_t* lds
   size_t layer_off = n_leaves;               // digest index where layer 1 starts
   size_t layer_len = n_leaves >> 1;
   size_t node0 = leaf0 >> 1;
-  int nodes = FUSE_LEAVES >> 1;
+  int nodes = LEAVES >> 1;
   for (int lvl = 1; lvl <= levels; lvl++) {
     __syncthreads();
     if (t < nodes) {
@@ -202,13 +214,13 @@ __global__ __launch_bounds__(FUSE_LEAVES) void hash_leaves_tree(const uint32_t* 
 #pragma unroll
   for (int i = 0; i < 16; i++) s[i] = 0.0;
   absorb_row(s, colptrs, width, leaf0 + threadIdx.x);
-  tree_levels_in_block(s, fuse_lds, leaf0, height, tree, levels);
+  tree_levels_in_block<FUSE_LEAVES>(s, fuse_lds, leaf0, height, tree, levels);
 }
 
-// FRI commit-phase leaves (row j = (f[2j], f[2j+1]), as hash_fri_leaves) + `levels` tree levels; m is a multiple of FUSE_LEAVES
-__global__ __launch_bounds__(FUSE_LEAVES) void hash_fri_leaves_tree(const kb::E4* __restrict__ f, size_t m, uint32_t* __restrict__ tree, int levels) {
+// FRI commit-phase leaves (row j = (f[2j], f[2j+1]), as hash_fri_leaves) + `levels` tree levels; m is a multiple of FRI_FUSE_LEAVES
+__global__ __launch_bounds__(FRI_FUSE_LEAVES) void hash_fri_leaves_tree(const kb::E4* __restrict__ f, size_t m, uint32_t* __restrict__ tree, int levels) {
   extern __shared__ uint32_t fuse_lds[];
-  const size_t leaf0 = (size_t)blockIdx.x * FUSE_LEAVES;
+  const size_t leaf0 = (size_t)blockIdx.x * FRI_FUSE_LEAVES;
   const size_t j = leaf0 + threadIdx.x;
   double s[16];
   const kb::E4 a = f[2 * j], b = f[2 * j + 1];
@@ -217,7 +229,7 @@ __global__ __launch_bounds__(FUSE_LEAVES) void hash_fri_leaves_tree(const kb::E4
 #pragma unroll
   for (int k = 8; k < 16; k++) s[k] = 0.0;
   p2f::permute(s);
-  tree_levels_in_block(s, fuse_lds, leaf0, m, tree, levels);
+  tree_levels_in_block<FRI_FUSE_LEAVES>(s, fuse_lds, leaf0, m, tree, levels);
 }
 
 // ---- lane-parallel Poseidon2 for the small layers near the root ------------------------------------
