@@ -8,11 +8,12 @@ run() {
     env "$@" python bench.py --no-extra --no-cpu-baseline --steps 10 --warmup 2 2>/dev/null | python -c "
 import json,sys
 l=json.loads(sys.stdin.read()); p=l['phases_ms']
-print('$L rep $rep: step %.3f ms  commit main %.3f  commit perm %.3f  commit quotient %.3f  verified %s' % (l['ms_per_step'], p['commit main'], p['commit permutation'], p['commit quotient'], l['verified']))"
+print('$L rep $rep: step %.3f ms  commit main %.3f  commit perm %.3f  commit quotient %.3f  FRI commit phase %.3f  verified %s' % (l['ms_per_step'], p['commit main'], p['commit permutation'], p['commit quotient'], p['open: FRI commit phase'], l['verified']))"
   done
 }
-run overlap_off ZKM_LDE_OVERLAP=0
-run overlap_on ZKM_LDE_OVERLAP=1
-run overlap_off_again ZKM_LDE_OVERLAP=0
-run overlap_on_again ZKM_LDE_OVERLAP=1
+run poll_off ZKM_ROOT_POLL=0
+run poll_on ZKM_ROOT_POLL=1
+run poll_off_again ZKM_ROOT_POLL=0
+run poll_on_again ZKM_ROOT_POLL=1
+# measured before with the same script: ZKM_LDE_OVERLAP=0 / 1 (the side stream at all: 55.0 -> 54.3 ms); the side stream at the greatest priority (no difference)
 # measured, no difference: HSA_ENABLE_INTERRUPT=0

@@ -587,8 +587,9 @@ struct ShardOpening {
     for (size_t l = half >> (fuse + 1); l >= 1; l >>= 1, layer++)
       if (compress_small_layer(ctx, t, layer, l)) break;
     std::array<uint32_t, 8> root;
+    const bool pollable = t.h_root != nullptr;
     const uint32_t* h_root = t.h_root ? t.h_root : ctx->download_async(t.node(t.log_max, 0), 8);
-    HIP_CHECK(hipStreamSynchronize(st));
+    wait_root(ctx, h_root, pollable);
     t.h_root = nullptr;
     memcpy(root.data(), h_root, 32);
     chal::observe_slice(ch, root.data(), 8);

@@ -144,6 +144,7 @@ static bool compress_small_layer(zkm_ctx* ctx, Tree& t, int layer, size_t len) {
   }
   if (len <= TAIL) {
     uint32_t* h_root = (uint32_t*)ctx->pin_alloc(32);
+    if (h_root) for (int k = 0; k < 8; k++) ((volatile uint32_t*)h_root)[k] = 0xffffffffu;   // not a field word: wait_root can watch the root arrive
     KLAUNCH(ctx, "compress_tail", 96.0 * len, merkle::compress_tail_lanes, dim3(1), dim3(1024), 0, t.digests + t.layer_off[layer] * 8, len, h_root);
     t.h_root = h_root;
     return true;
@@ -151,6 +152,26 @@ static bool compress_small_layer(zkm_ctx* ctx, Tree& t, int layer, size_t len) {
   KLAUNCH(ctx, "compress_small", 96.0 * len, merkle::compress_layer_lanes, dim3(div_up(len * 16, merkle::THREADS)), dim3(merkle::THREADS),
           0, (const uint32_t*)(t.digests + t.layer_off[layer] * 8), t.digests + t.layer_off[layer + 1] * 8, len);
   return false;
+}
+
+// The root a tail launch writes to page-locked host memory, read without a stream synchronisation (ZKM_ROOT_POLL=0: with one): the host watches the
+// eight words change from the 0xffffffff they were set to before the launch (a Montgomery word is below 2^31; each word is one 32-bit
+// store to coherent host memory) and goes on queueing the next kernels behind the still-finishing launch — the completion signal, the
+// wake-up and the return through hipStreamSynchronize stay off the critical path of the 22 dependent FRI layers. Falls back to the
+// synchronisation after a second (a failed launch must still surface).
+static void wait_root(zkm_ctx* ctx, const uint32_t* h_root, bool pollable) {
+  static const bool poll = [] { const char* e = getenv("ZKM_ROOT_POLL"); return !e || atoi(e) != 0; }();
+  if (poll && pollable) {
+    const volatile uint32_t* v = h_root;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int spins = 0;; spins++) {
+      bool all = true;
+      for (int k = 0; k < 8; k++) all &= v[k] != 0xffffffffu;
+      if (all) { std::atomic_thread_fence(std::memory_order_acquire); return; }
+      if ((spins & 4095) == 4095 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(1)) break;
+    }
+  }
+  HIP_CHECK(hipStreamSynchronize(ctx->stream));
 }
 
 // MerkleTreeMmcs::commit over column-major matrices of power-of-two heights.
