@@ -169,6 +169,7 @@ static void wait_root(zkm_ctx* ctx, const uint32_t* h_root, bool pollable) {
       for (int k = 0; k < 8; k++) all &= v[k] != 0xffffffffu;
       if (all) { std::atomic_thread_fence(std::memory_order_acquire); return; }
       if ((spins & 4095) == 4095 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(1)) break;
+      __builtin_ia32_pause();
     }
   }
   HIP_CHECK(hipStreamSynchronize(ctx->stream));
