@@ -744,3 +744,19 @@ def test_kernel_timing_modes(hip_ctx, oracle):
     lib.load().zkm_ctx_set_kernel_timing(hip_ctx.h, C.c_int(2))
     assert seen["only"] == {"compress_layer"} and seen[0] == set() and {"compress_layer", "hash_leaves", "quotient"} <= seen[2]
     assert np.array_equal(proofs[0], proofs[1]) and np.array_equal(proofs[0], proofs[2])
+
+
+@pytest.mark.gpu
+def test_fri_layer_roots_with_and_without_polling():
+    """The FRI commit phase reads each layer's root either by watching the page-locked words the tail launch writes (default, wait_root in
+    csrc/host_pcs.hpp) or after a stream synchronisation (ZKM_ROOT_POLL=0; also the fallback of the first). The switch is read once per
+    process, so each setting gets a process of its own: both must produce the smoke shard's proof word for word as the oracle does
+    (__graft_entry__.smoke compares the whole stream and runs the restated verifier)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for poll in ("0", "1"):
+        r = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.smoke()"], cwd=root, env=dict(os.environ, ZKM_ROOT_POLL=poll),
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, (poll, r.stdout[-2000:], r.stderr[-2000:])
