@@ -128,6 +128,10 @@ enum {
 };
 
 const char* zkm_last_error(void);
+/* What this binary was built from: "ZKM_SOURCES_DIGEST=<16 hex>;hipcc=<version>;arch=gfx950". The digest is sha256 over every file of
+ * ziren_amd/csrc plus this header, in name order (ziren_amd/build.py sources_digest); the build script compares it with the tree's before
+ * deciding not to compile, and a benchmark refuses a library whose digest is not the tree's. */
+const char* zkm_build_info(void);
 
 /* ---- context ---------------------------------------------------------------------------- */
 int zkm_ctx_create(int device, zkm_ctx** out);
@@ -148,6 +152,10 @@ void zkm_ctx_set_kernel_timing(zkm_ctx* ctx, int mode);
 /* mode 3: only launches of the kernel `name` (as zkm_ctx_kernel_timings reports it) are timed. A timed launch costs a few microseconds of
  * dispatch latency; a shard proof is ~500 launches, so timing them all slows it by ~2.5 %. A benchmark times the kernel it reports on. */
 void zkm_ctx_set_kernel_timing_only(zkm_ctx* ctx, const char* name);
+/* on (default): pcs_commit extends a commit's shorter matrices on the context's side stream, under the leaf hashing of the tallest.
+ * off: every kernel of a proof runs alone on the main stream, so per-kernel HIP-event durations add up to the proof's busy time
+ * (a measurement mode: the proof is the same words, ~0.7 ms slower). The environment's ZKM_LDE_OVERLAP=0 sets the default to off. */
+void zkm_ctx_set_lde_overlap(zkm_ctx* ctx, int on);
 /* Register a chip-specialised quotient kernel: a gfx950 code object exporting
  * `zkm_quotient_specialized(stark::QuotientArgs)` generated from exactly these program words
  * (ziren_amd/codegen.py; the Rust shim does this once per chip AIR). zkm_open uses it for chips whose
@@ -184,9 +192,10 @@ int zkm_matrix_wait(zkm_ctx* ctx, const zkm_matrix* m);
 /* Executor events ahead of their trace generation. Queues the copy of `bytes` bytes of event records (any of the zkm_*_event arrays,
  * page-locked for a true asynchronous copy) on the context's DMA stream and returns a device address at once. That address may be passed
  * to the core-shard trace generators whose rows are a function of one event each (zkm_tracegen_alu / _jump / _mov_cond / _branch / _mul /
- * _divrem / _memory_instrs / _misc_instrs / _syscall_instrs / _cpu / _cpu_and_program / _program_mults / _memory_local) in place of the host
- * pointer: they then wait for the copy on the device instead of making their own. (zkm_tracegen_global and zkm_tracegen_syscall read their
- * events on the host first and take host pointers only.) Called for shard i + 1 right before zkm_prove_shard of shard i, the transfer
+ * _divrem / _memory_instrs / _misc_instrs / _syscall_instrs / _syscall / _cpu / _cpu_and_program / _program_mults / _memory_local / _global)
+ * and in zkm_tracegen_shard's descriptors in place of the host pointer: they then wait for the copy on the device instead of making their
+ * own, and read nothing on the host (SyscallCore's filter and Global's u16 check of message[0] run on the device; a SyscallCore trace
+ * without a fixed height costs one round trip for the kept count). Called for shard i + 1 right before zkm_prove_shard of shard i, the transfer
  * runs under that proof (the reference's prove-a-record loop hands records to the prover while the previous one is proving:
  * crates/core/machine/src/utils/prove.rs:484-497). The host buffer must stay unchanged until a trace generator that used the address has
  * returned, or zkm_events_free has. */
@@ -647,6 +656,35 @@ int zkm_tracegen_byte_table(zkm_ctx* ctx, zkm_matrix** out);
  * elements. `blu` is left unchanged. */
 int zkm_tracegen_byte_mults(zkm_ctx* ctx, const zkm_byte_lookups* blu, const uint32_t* extra_counts,
                             zkm_matrix** out);
+
+/* ---- generate_traces of a whole core shard in one call (crates/stark/src/prover.rs:70-108) ------------------------------------------
+ * One descriptor per chip of the shard; out[i] receives descriptor i's trace. Every generator is queued on the context's stream behind
+ * the copy of its events — `events` is a host pointer (copied in front of the kernel) or an address zkm_events_upload_async returned (the
+ * stream waits for that copy; nothing is read on the host, SyscallCore's filter and Global's range check included) — and the call
+ * synchronises once, at the end. Byte lookups of all chips are counted into `blu` (NULL: a table that lives for the call);
+ * ZKM_TG_BYTE_MULTS yields the Byte chip's multiplicity trace over it after every other generator has run, wherever it stands in the list;
+ * ZKM_TG_PROGRAM_MULTS yields the Program chip's multiplicities, counted by the ZKM_TG_CPU descriptor's pass (its fixed_log2_rows is the
+ * Program chip's height). On failure no matrix is returned (out[] all NULL). */
+enum zkm_tracegen_kind {
+  ZKM_TG_ALU = 0,            /* `chip` = enum zkm_alu_chip; zkm_alu_event */
+  ZKM_TG_CPU = 1,            /* zkm_cpu_event; program, n_instr, pc_base, shard */
+  ZKM_TG_BRANCH = 2, ZKM_TG_JUMP = 3, ZKM_TG_MOV_COND = 4, ZKM_TG_MUL = 5, ZKM_TG_DIVREM = 6, ZKM_TG_MEMORY_INSTRS = 7, ZKM_TG_MISC_INSTRS = 8,
+  ZKM_TG_SYSCALL_INSTRS = 9, ZKM_TG_SYSCALL_CORE = 10, ZKM_TG_SYSCALL_PRECOMPILE = 11, ZKM_TG_MEMORY_LOCAL = 12, ZKM_TG_GLOBAL = 13,
+  ZKM_TG_BYTE_MULTS = 14,    /* no events */
+  ZKM_TG_PROGRAM_MULTS = 15  /* no events: needs a ZKM_TG_CPU descriptor in the same call */
+};
+typedef struct zkm_tracegen_desc {
+  uint32_t kind;             /* enum zkm_tracegen_kind */
+  int32_t chip;              /* ZKM_TG_ALU only */
+  const void* events;
+  size_t n_events;
+  int32_t fixed_log2_rows;   /* the shape's height, or -1: next power of two (>= 16) */
+  uint32_t no_byte_lookups;  /* 1: this chip's generate_dependencies is not run (its byte lookups are not counted) */
+  const zkm_instruction* program;   /* ZKM_TG_CPU only, host memory */
+  size_t n_instr;
+  uint32_t pc_base, shard;
+} zkm_tracegen_desc;
+int zkm_tracegen_shard(zkm_ctx* ctx, const zkm_tracegen_desc* descs, size_t n, zkm_byte_lookups* blu, zkm_matrix** out);
 
 /* generate_trace / generate_preprocessed_trace of the chips whose rows are their event (or instruction) records laid
  * end to end and zero padded — the recursion machine's BaseAlu and ExtAlu chips

@@ -34,6 +34,17 @@ class ChipDesc(C.Structure):
                 ("program", u32p), ("program_len", C.c_uint32)]
 
 
+# enum zkm_tracegen_kind
+(TG_ALU, TG_CPU, TG_BRANCH, TG_JUMP, TG_MOV_COND, TG_MUL, TG_DIVREM, TG_MEMORY_INSTRS, TG_MISC_INSTRS, TG_SYSCALL_INSTRS, TG_SYSCALL_CORE,
+ TG_SYSCALL_PRECOMPILE, TG_MEMORY_LOCAL, TG_GLOBAL, TG_BYTE_MULTS, TG_PROGRAM_MULTS) = range(16)
+
+
+class TracegenDesc(C.Structure):
+    """zkm_tracegen_desc: one chip of a zkm_tracegen_shard call."""
+    _fields_ = [("kind", C.c_uint32), ("chip", C.c_int32), ("events", C.c_void_p), ("n_events", C.c_size_t), ("fixed_log2_rows", C.c_int32),
+                ("no_byte_lookups", C.c_uint32), ("program", C.c_void_p), ("n_instr", C.c_size_t), ("pc_base", C.c_uint32), ("shard", C.c_uint32)]
+
+
 def as_u32p(a: np.ndarray):
     assert a.dtype == np.uint32 and a.flags["C_CONTIGUOUS"]
     return a.ctypes.data_as(u32p)

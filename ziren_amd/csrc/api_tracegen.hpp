@@ -3,63 +3,155 @@
 // ---- device trace generation (ALU chips) ---------------------------------------------------------------------
 size_t zkm_tracegen_alu_width(int chip) { return chip >= 0 && chip < tracegen::NUM_ALU_CHIPS ? (size_t)tracegen::chip_width(chip) : 0; }
 
-static int tracegen_events(zkm_ctx* ctx, int chip, const void* events, size_t n_events, int fixed_log2_rows,
-                           zkm_byte_lookups* blu, zkm_matrix** out) {
-  API_BEGIN
-  static_assert(sizeof(zkm_alu_event) == 28 && sizeof(zkm_jump_event) == 28 && sizeof(zkm_mov_cond_event) == 28 &&
-                sizeof(zkm_comp_alu_event) == 64, "event records mirror the #[repr(C)] executor structs");
-  std::lock_guard<std::mutex> lk(ctx->mu);
-  HIP_CHECK(hipSetDevice(ctx->device));
-  if (chip < 0 || chip >= tracegen::NUM_CHIPS) throw std::runtime_error("zkm_tracegen: unknown chip");
-  if (n_events && !events) throw std::runtime_error("zkm_tracegen: null events");
+static size_t padded_trace_rows(size_t n_records, int fixed_log2_rows, const char* what) {
   // utils::next_power_of_two (crates/core/machine/src/utils/mod.rs): the shape's fixed size, else >= 16
   size_t height = 16;
   if (fixed_log2_rows >= 0) {
-    if (fixed_log2_rows > 30) throw std::runtime_error("zkm_tracegen_alu: fixed log2 rows out of range");
+    if (fixed_log2_rows > 30) throw std::runtime_error(std::string(what) + ": fixed log2 rows out of range");
     height = (size_t)1 << fixed_log2_rows;
-    if (n_events > height) throw std::runtime_error("zkm_tracegen_alu: fixed log2 rows is too small");
+    if (n_records > height) throw std::runtime_error(std::string(what) + ": fixed log2 rows is too small");
   } else {
-    while (height < n_events) height <<= 1;
+    while (height < n_records) height <<= 1;
   }
-  const size_t w = (size_t)tracegen::chip_width(chip);
-  ctx->begin_timing();
-  zkm_matrix* m = new zkm_matrix();
-  m->h = height; m->w = w;
-  uint32_t* d_events = nullptr;
-  try {
-    m->d = ctx->alloc_n<uint32_t>(height * w);
-    const size_t event_bytes = 4 * (size_t)tracegen::event_words(chip);
-    const uint32_t* dev_events = ctx->events_on_device(events, n_events * event_bytes, &d_events);
-    uint32_t* counts = blu ? blu->counts : nullptr;
-    switch (chip) {
-      case tracegen::ADD_SUB: launch_alu_rows<tracegen::ADD_SUB>(ctx, dev_events, n_events, height, m->d, counts); break;
-      case tracegen::BITWISE: launch_alu_rows<tracegen::BITWISE>(ctx, dev_events, n_events, height, m->d, counts); break;
-      case tracegen::LT: launch_alu_rows<tracegen::LT>(ctx, dev_events, n_events, height, m->d, counts); break;
-      case tracegen::SHIFT_LEFT: launch_alu_rows<tracegen::SHIFT_LEFT>(ctx, dev_events, n_events, height, m->d, counts); break;
-      case tracegen::SHIFT_RIGHT: launch_alu_rows<tracegen::SHIFT_RIGHT>(ctx, dev_events, n_events, height, m->d, counts); break;
-      case tracegen::CLO_CLZ: launch_alu_rows<tracegen::CLO_CLZ>(ctx, dev_events, n_events, height, m->d, counts); break;
-      case tracegen::JUMP: launch_alu_rows<tracegen::JUMP>(ctx, dev_events, n_events, height, m->d, counts); break;
-      case tracegen::MOV_COND: launch_alu_rows<tracegen::MOV_COND>(ctx, dev_events, n_events, height, m->d, counts); break;
-      case tracegen::BRANCH: launch_alu_rows<tracegen::BRANCH>(ctx, dev_events, n_events, height, m->d, counts); break;
-      case tracegen::MUL: launch_alu_rows<tracegen::MUL>(ctx, dev_events, n_events, height, m->d, counts); break;
-      case tracegen::DIVREM: launch_alu_rows<tracegen::DIVREM>(ctx, dev_events, n_events, height, m->d, counts); break;
-      case tracegen::MEMORY_INSTRS: launch_alu_rows<tracegen::MEMORY_INSTRS>(ctx, dev_events, n_events, height, m->d, counts); break;
-      case tracegen::SYSCALL_INSTRS: launch_alu_rows<tracegen::SYSCALL_INSTRS>(ctx, dev_events, n_events, height, m->d, counts); break;
-      case tracegen::MISC_INSTRS: launch_alu_rows<tracegen::MISC_INSTRS>(ctx, dev_events, n_events, height, m->d, counts); break;
-      case tracegen::SYSCALL_CORE: launch_alu_rows<tracegen::SYSCALL_CORE>(ctx, dev_events, n_events, height, m->d, counts); break;
-      case tracegen::SYSCALL_PRECOMPILE: launch_alu_rows<tracegen::SYSCALL_PRECOMPILE>(ctx, dev_events, n_events, height, m->d, counts); break;
+  return height;
+}
+
+// Trace generators queued back to back on the compute stream, with no host synchronisation between them: every generator below is an
+// `enqueue_*` function that allocates its matrix, finds its events in HBM (a prefetched address: the stream waits for the copy; a host
+// pointer: the copy is queued in front of the kernel) and launches. `finish` makes the one synchronisation of the batch, reads the error
+// words the kernels may have set, and hands scratch back to the pool. The single-chip entry points are batches of one;
+// zkm_tracegen_shard is a batch of a whole shard's chips (crates/stark/src/prover.rs:70-108, generate_traces).
+struct TraceBatch {
+  zkm_ctx* ctx;
+  std::vector<void*> scratch;                 // event copies, programs, scan levels: released by finish / abort
+  std::vector<zkm_matrix*> made;              // matrices of this batch: deleted by abort
+  std::vector<std::vector<zkm_syscall_event>> host_keep;   // host-side filtered events: alive until the copy has run
+  enum { F_CPU, F_GLOBAL, F_SYSCALL_CORE };
+  static constexpr int MAX_FLAGS = 256;
+  uint32_t* d_flags = nullptr;
+  std::vector<int> flag_kind;
+  explicit TraceBatch(zkm_ctx* c) : ctx(c) {}
+  zkm_matrix* matrix(size_t h, size_t w) {
+    zkm_matrix* m = new zkm_matrix();
+    made.push_back(m);
+    m->h = h; m->w = w;
+    m->d = ctx->alloc_n<uint32_t>(std::max<size_t>(h * w, 1));
+    return m;
+  }
+  void* temp(size_t bytes) { void* p = ctx->alloc(bytes); scratch.push_back(p); return p; }
+  const uint32_t* events(const void* ev, size_t bytes) {
+    uint32_t* owned = nullptr;
+    const uint32_t* d = ctx->events_on_device(ev, bytes, &owned);
+    if (owned) scratch.push_back(owned);
+    return d;
+  }
+  uint32_t* flag(int kind) {     // a zeroed device word a kernel of this batch may set; read back by finish
+    if (!d_flags) {
+      d_flags = (uint32_t*)temp(MAX_FLAGS * 4);
+      HIP_CHECK(hipMemsetAsync(d_flags, 0, MAX_FLAGS * 4, ctx->stream));
     }
-    ctx->mark("trace generation");
-    ctx->end_timing(false);  // synchronises: the caller's event buffer is free again
+    if ((int)flag_kind.size() == MAX_FLAGS) throw std::runtime_error("zkm_tracegen: too many generators in one batch");
+    flag_kind.push_back(kind);
+    return d_flags + flag_kind.size() - 1;
+  }
+  void finish(const char* mark) {
+    const uint32_t* h_flags = flag_kind.empty() ? nullptr : ctx->download_async(d_flags, flag_kind.size());
+    ctx->mark(mark);
+    ctx->end_timing(false);     // synchronises: the callers' event buffers are free again, the flags are on the host
+    for (size_t i = 0; i < flag_kind.size(); i++) {
+      const uint32_t f = h_flags[i];
+      if (!f) continue;
+      if (flag_kind[i] == F_CPU) {
+        if (f & 1) throw std::runtime_error("zkm_tracegen_cpu: an event's pc lies outside the program");
+        throw std::runtime_error("zkm_tracegen_cpu: an event's clock does not fit 24 bits (a shard holds fewer than 2^24 / 5 cycles)");
+      }
+      if (flag_kind[i] == F_GLOBAL) {
+        if (f & tracegen::GLOBAL_ERR_NOT_U16) throw std::runtime_error("zkm_tracegen_global: message[0] of an event is not a u16");
+        if (f & tracegen::GLOBAL_ERR_NO_POINT) throw std::runtime_error("zkm_tracegen_global: a message has no curve point within 256 offsets");
+        if (f & tracegen::GLOBAL_ERR_INFINITY) throw std::runtime_error("zkm_tracegen_global: the running sum reached the point at infinity");
+        throw std::runtime_error("zkm_tracegen_global: a message's point has the running sum's x-coordinate");
+      }
+      throw std::runtime_error("zkm_tracegen_syscall: fixed log2 rows is too small");
+    }
+    for (void* p : scratch) ctx->release(p);
+    scratch.clear();
+    made.clear();
+    host_keep.clear();
+  }
+  void abort() {     // a generator threw, or a kernel flagged an error: nothing of the batch survives
+    (void)hipStreamSynchronize(ctx->stream);
+    for (void* p : scratch) ctx->release(p);
+    for (zkm_matrix* m : made) { if (m->d) ctx->release(m->d); delete m; }
+    scratch.clear(); made.clear(); host_keep.clear();
+  }
+};
+
+// the chips whose rows are a function of one event each (tracegen::alu_rows<CHIP>). n_dev: the event count in device memory
+// (syscall_core_compact), n_events then being its upper bound
+static zkm_matrix* enqueue_rows(TraceBatch& b, int chip, const void* events, size_t n_events, int fixed_log2_rows, zkm_byte_lookups* blu,
+                                const uint32_t* n_dev = nullptr, const uint32_t* dev_events_given = nullptr, size_t height_given = 0) {
+  static_assert(sizeof(zkm_alu_event) == 28 && sizeof(zkm_jump_event) == 28 && sizeof(zkm_mov_cond_event) == 28 &&
+                sizeof(zkm_comp_alu_event) == 64, "event records mirror the #[repr(C)] executor structs");
+  zkm_ctx* ctx = b.ctx;
+  if (chip < 0 || chip >= tracegen::NUM_CHIPS) throw std::runtime_error("zkm_tracegen: unknown chip");
+  if (n_events && !events && !dev_events_given) throw std::runtime_error("zkm_tracegen: null events");
+  const size_t height = height_given ? height_given : padded_trace_rows(n_events, fixed_log2_rows, "zkm_tracegen_alu");
+  const size_t w = (size_t)tracegen::chip_width(chip);
+  zkm_matrix* m = b.matrix(height, w);
+  const size_t event_bytes = 4 * (size_t)tracegen::event_words(chip);
+  const uint32_t* dev_events = dev_events_given ? dev_events_given : b.events(events, n_events * event_bytes);
+  uint32_t* counts = blu ? blu->counts : nullptr;
+  if (n_dev) {
+    if (chip != tracegen::SYSCALL_CORE) throw std::runtime_error("zkm_tracegen: a device-side event count is for SyscallCore only");
+    const int tiles = counts ? tracegen::TILES_PER_BLOCK : 1;
+    KLAUNCH(ctx, "tracegen_alu", event_bytes * n_events + 4.0 * height * w, tracegen::alu_rows_counted<tracegen::SYSCALL_CORE>,
+            dim3(div_up(height, (size_t)tiles * tracegen::THREADS)), dim3(tracegen::THREADS), counts ? 2 * tracegen::HASH_SLOTS * sizeof(uint32_t) : 0,
+            dev_events, n_dev, height, m->d, counts, tiles);
+    return m;
+  }
+  switch (chip) {
+    case tracegen::ADD_SUB: launch_alu_rows<tracegen::ADD_SUB>(ctx, dev_events, n_events, height, m->d, counts); break;
+    case tracegen::BITWISE: launch_alu_rows<tracegen::BITWISE>(ctx, dev_events, n_events, height, m->d, counts); break;
+    case tracegen::LT: launch_alu_rows<tracegen::LT>(ctx, dev_events, n_events, height, m->d, counts); break;
+    case tracegen::SHIFT_LEFT: launch_alu_rows<tracegen::SHIFT_LEFT>(ctx, dev_events, n_events, height, m->d, counts); break;
+    case tracegen::SHIFT_RIGHT: launch_alu_rows<tracegen::SHIFT_RIGHT>(ctx, dev_events, n_events, height, m->d, counts); break;
+    case tracegen::CLO_CLZ: launch_alu_rows<tracegen::CLO_CLZ>(ctx, dev_events, n_events, height, m->d, counts); break;
+    case tracegen::JUMP: launch_alu_rows<tracegen::JUMP>(ctx, dev_events, n_events, height, m->d, counts); break;
+    case tracegen::MOV_COND: launch_alu_rows<tracegen::MOV_COND>(ctx, dev_events, n_events, height, m->d, counts); break;
+    case tracegen::BRANCH: launch_alu_rows<tracegen::BRANCH>(ctx, dev_events, n_events, height, m->d, counts); break;
+    case tracegen::MUL: launch_alu_rows<tracegen::MUL>(ctx, dev_events, n_events, height, m->d, counts); break;
+    case tracegen::DIVREM: launch_alu_rows<tracegen::DIVREM>(ctx, dev_events, n_events, height, m->d, counts); break;
+    case tracegen::MEMORY_INSTRS: launch_alu_rows<tracegen::MEMORY_INSTRS>(ctx, dev_events, n_events, height, m->d, counts); break;
+    case tracegen::SYSCALL_INSTRS: launch_alu_rows<tracegen::SYSCALL_INSTRS>(ctx, dev_events, n_events, height, m->d, counts); break;
+    case tracegen::MISC_INSTRS: launch_alu_rows<tracegen::MISC_INSTRS>(ctx, dev_events, n_events, height, m->d, counts); break;
+    case tracegen::SYSCALL_CORE: launch_alu_rows<tracegen::SYSCALL_CORE>(ctx, dev_events, n_events, height, m->d, counts); break;
+    case tracegen::SYSCALL_PRECOMPILE: launch_alu_rows<tracegen::SYSCALL_PRECOMPILE>(ctx, dev_events, n_events, height, m->d, counts); break;
+  }
+  return m;
+}
+
+// a batch of one generator behind a public entry point
+static int tracegen_single(zkm_ctx* ctx, zkm_matrix** out, const std::function<zkm_matrix*(TraceBatch&)>& enqueue) {
+  API_BEGIN
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIP_CHECK(hipSetDevice(ctx->device));
+  ctx->begin_timing();
+  TraceBatch b(ctx);
+  zkm_matrix* m = nullptr;
+  try {
+    m = enqueue(b);
+    b.finish("trace generation");
   } catch (...) {
-    if (d_events) ctx->release(d_events);
-    if (m->d) ctx->release(m->d);
-    delete m;
+    b.abort();
     throw;
   }
-  ctx->release(d_events);
   *out = m;
   API_END
+}
+
+static int tracegen_events(zkm_ctx* ctx, int chip, const void* events, size_t n_events, int fixed_log2_rows,
+                           zkm_byte_lookups* blu, zkm_matrix** out) {
+  return tracegen_single(ctx, out, [&](TraceBatch& b) { return enqueue_rows(b, chip, events, n_events, fixed_log2_rows, blu); });
 }
 
 int zkm_tracegen_alu(zkm_ctx* ctx, int chip, const zkm_alu_event* events, size_t n_events, int fixed_log2_rows,
@@ -148,81 +240,46 @@ int zkm_tracegen_mov_cond(zkm_ctx* ctx, const zkm_mov_cond_event* events, size_t
   return tracegen_events(ctx, tracegen::MOV_COND, events, n_events, fixed_log2_rows, nullptr, out);
 }
 
-static size_t padded_trace_rows(size_t n_records, int fixed_log2_rows, const char* what) {
-  // utils::next_power_of_two (crates/core/machine/src/utils/mod.rs): the shape's fixed size, else >= 16
-  size_t height = 16;
-  if (fixed_log2_rows >= 0) {
-    if (fixed_log2_rows > 30) throw std::runtime_error(std::string(what) + ": fixed log2 rows out of range");
-    height = (size_t)1 << fixed_log2_rows;
-    if (n_records > height) throw std::runtime_error(std::string(what) + ": fixed log2 rows is too small");
-  } else {
-    while (height < n_records) height <<= 1;
-  }
-  return height;
-}
-
 size_t zkm_tracegen_cpu_width(void) { return (size_t)tracegen::CPU_WIDTH; }
-int zkm_tracegen_cpu_and_program(zkm_ctx* ctx, const zkm_cpu_event* events, size_t n_events, const zkm_instruction* program, size_t n_instr,
-                                 uint32_t pc_base, uint32_t shard, int fixed_log2_rows, int program_fixed_log2_rows, zkm_byte_lookups* blu,
-                                 zkm_matrix** out, zkm_matrix** program_mults_out) {
-  API_BEGIN
+static zkm_matrix* enqueue_cpu(TraceBatch& b, const zkm_cpu_event* events, size_t n_events, const zkm_instruction* program, size_t n_instr,
+                               uint32_t pc_base, uint32_t shard, int fixed_log2_rows, int program_fixed_log2_rows, zkm_byte_lookups* blu,
+                               zkm_matrix** program_mults_out) {
   static_assert(sizeof(zkm_cpu_event) == 4 * tracegen::CPU_EVENT_WORDS && sizeof(zkm_instruction) == 4 * tracegen::INSTRUCTION_WORDS,
                 "event records mirror the #[repr(C)] executor structs");
-  std::lock_guard<std::mutex> lk(ctx->mu);
-  HIP_CHECK(hipSetDevice(ctx->device));
+  zkm_ctx* ctx = b.ctx;
   if (n_events && (!events || !program || !n_instr)) throw std::runtime_error("zkm_tracegen_cpu: null events or program");
   const size_t height = padded_trace_rows(n_events, fixed_log2_rows, "zkm_tracegen_cpu");
   const size_t pheight = program_mults_out ? padded_trace_rows(n_instr, program_fixed_log2_rows, "zkm_tracegen_cpu (program)") : 0;
-  ctx->begin_timing();
-  zkm_matrix* m = new zkm_matrix();
-  zkm_matrix* pm = program_mults_out ? new zkm_matrix() : nullptr;
-  m->h = height; m->w = tracegen::CPU_WIDTH;
-  uint32_t *d_events = nullptr, *d_program = nullptr;
-  int* d_bad = nullptr;
-  try {
-    m->d = ctx->alloc_n<uint32_t>(height * m->w);
-    if (pm) {
-      pm->h = pheight; pm->w = 1;
-      pm->d = ctx->alloc_n<uint32_t>(pheight);
-      HIP_CHECK(hipMemsetAsync(pm->d, 0, pheight * 4, ctx->stream));
-    }
-    const uint32_t* dev_events = ctx->events_on_device(events, n_events * sizeof(zkm_cpu_event), &d_events);
-    d_program = (uint32_t*)ctx->alloc(std::max<size_t>(n_instr * sizeof(zkm_instruction), 4));
-    d_bad = (int*)ctx->alloc(4);
-    HIP_CHECK(hipMemsetAsync(d_bad, 0, 4, ctx->stream));
-    if (n_instr) HIP_CHECK(hipMemcpyAsync(d_program, program, n_instr * sizeof(zkm_instruction), hipMemcpyHostToDevice, ctx->stream));
-    uint32_t* counts = blu ? blu->counts : nullptr;
-    const int tiles = counts ? tracegen::TILES_PER_BLOCK : 1;
-    KLAUNCH(ctx, "tracegen_cpu", 280.0 * n_events + 4.0 * height * tracegen::CPU_WIDTH, tracegen::cpu_rows,
-            dim3(div_up(height, (size_t)tiles * tracegen::THREADS)), dim3(tracegen::THREADS),
-            counts ? 2 * tracegen::HASH_SLOTS * sizeof(uint32_t) : 0, dev_events, n_events, (const uint32_t*)d_program, n_instr,
-            pc_base, shard, height, m->d, counts, tiles, d_bad, pm ? pm->d : (uint32_t*)nullptr);
-    if (pm) {
-      hipLaunchKernelGGL(tracegen::counts_to_field, dim3(div_up(pheight, 256)), dim3(256), 0, ctx->stream, pm->d, pheight);
-      LAUNCH_CHECK();
-    }
-    int bad = 0;
-    HIP_CHECK(hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, ctx->stream));
-    ctx->mark("trace generation");
-    ctx->end_timing(false);
-    if (bad & 1) throw std::runtime_error("zkm_tracegen_cpu: an event's pc lies outside the program");
-    if (bad & 2) throw std::runtime_error("zkm_tracegen_cpu: an event's clock does not fit 24 bits (a shard holds fewer than 2^24 / 5 cycles)");
-  } catch (...) {
-    if (d_events) ctx->release(d_events);
-    if (d_program) ctx->release(d_program);
-    if (d_bad) ctx->release(d_bad);
-    if (m->d) ctx->release(m->d);
-    if (pm && pm->d) ctx->release(pm->d);
-    delete m;
-    delete pm;
-    throw;
+  zkm_matrix* m = b.matrix(height, tracegen::CPU_WIDTH);
+  zkm_matrix* pm = program_mults_out ? b.matrix(pheight, 1) : nullptr;
+  if (pm) HIP_CHECK(hipMemsetAsync(pm->d, 0, pheight * 4, ctx->stream));
+  const uint32_t* dev_events = b.events(events, n_events * sizeof(zkm_cpu_event));
+  // the program goes through the staged ring when it fits (one copy with the batch's other small tables), else its own buffer
+  const uint32_t* d_program = (const uint32_t*)ctx->upload_staged(program, n_instr * sizeof(zkm_instruction), &b.scratch);
+  uint32_t* d_bad = b.flag(TraceBatch::F_CPU);
+  uint32_t* counts = blu ? blu->counts : nullptr;
+  const int tiles = counts ? tracegen::TILES_PER_BLOCK : 1;
+  KLAUNCH(ctx, "tracegen_cpu", 280.0 * n_events + 4.0 * height * tracegen::CPU_WIDTH, tracegen::cpu_rows,
+          dim3(div_up(height, (size_t)tiles * tracegen::THREADS)), dim3(tracegen::THREADS),
+          counts ? 2 * tracegen::HASH_SLOTS * sizeof(uint32_t) : 0, dev_events, n_events, d_program, n_instr,
+          pc_base, shard, height, m->d, counts, tiles, (int*)d_bad, pm ? pm->d : (uint32_t*)nullptr);
+  if (pm) {
+    hipLaunchKernelGGL(tracegen::counts_to_field, dim3(div_up(pheight, 256)), dim3(256), 0, ctx->stream, pm->d, pheight);
+    LAUNCH_CHECK();
+    *program_mults_out = pm;
   }
-  ctx->release(d_events);
-  ctx->release(d_program);
-  ctx->release(d_bad);
-  *out = m;
-  if (pm) *program_mults_out = pm;
-  API_END
+  return m;
+}
+
+int zkm_tracegen_cpu_and_program(zkm_ctx* ctx, const zkm_cpu_event* events, size_t n_events, const zkm_instruction* program, size_t n_instr,
+                                 uint32_t pc_base, uint32_t shard, int fixed_log2_rows, int program_fixed_log2_rows, zkm_byte_lookups* blu,
+                                 zkm_matrix** out, zkm_matrix** program_mults_out) {
+  zkm_matrix* pm = nullptr;
+  const int rc = tracegen_single(ctx, out, [&](TraceBatch& b) {
+    return enqueue_cpu(b, events, n_events, program, n_instr, pc_base, shard, fixed_log2_rows, program_fixed_log2_rows, blu, program_mults_out ? &pm : nullptr);
+  });
+  if (rc == 0 && program_mults_out) *program_mults_out = pm;
+  return rc;
 }
 
 int zkm_tracegen_cpu(zkm_ctx* ctx, const zkm_cpu_event* events, size_t n_events, const zkm_instruction* program, size_t n_instr,
@@ -294,98 +351,60 @@ int zkm_tracegen_program_mults(zkm_ctx* ctx, const zkm_cpu_event* events, size_t
   API_END
 }
 
-int zkm_tracegen_memory_local(zkm_ctx* ctx, const zkm_memory_local_event* events, size_t n_events, int fixed_log2_rows, zkm_matrix** out) {
-  API_BEGIN
+static zkm_matrix* enqueue_memory_local(TraceBatch& b, const zkm_memory_local_event* events, size_t n_events, int fixed_log2_rows) {
   static_assert(sizeof(zkm_memory_local_event) == 28, "event records mirror the #[repr(C)] executor structs");
-  std::lock_guard<std::mutex> lk(ctx->mu);
-  HIP_CHECK(hipSetDevice(ctx->device));
+  zkm_ctx* ctx = b.ctx;
   if (n_events && !events) throw std::runtime_error("zkm_tracegen_memory_local: null events");
   const size_t height = padded_trace_rows(div_up(n_events, (size_t)tracegen::MEMORY_LOCAL_ENTRIES), fixed_log2_rows, "zkm_tracegen_memory_local");
-  ctx->begin_call();
-  zkm_matrix* m = new zkm_matrix();
-  m->h = height; m->w = tracegen::MEMORY_LOCAL_WIDTH;
-  uint32_t* d_events = nullptr;
-  try {
-    m->d = ctx->alloc_n<uint32_t>(height * m->w);
-    const uint32_t* dev_events = ctx->events_on_device(events, n_events * sizeof(zkm_memory_local_event), &d_events);
-    hipLaunchKernelGGL(tracegen::memory_local_rows, dim3(div_up(height * tracegen::MEMORY_LOCAL_ENTRIES, (size_t)256)), dim3(256), 0, ctx->stream,
-                       dev_events, n_events, height, m->d);
-    LAUNCH_CHECK();
-    HIP_CHECK(hipStreamSynchronize(ctx->stream));
-  } catch (...) {
-    if (d_events) ctx->release(d_events);
-    if (m->d) ctx->release(m->d);
-    delete m;
-    throw;
+  zkm_matrix* m = b.matrix(height, tracegen::MEMORY_LOCAL_WIDTH);
+  const uint32_t* dev_events = b.events(events, n_events * sizeof(zkm_memory_local_event));
+  ctx->flush_staged();
+  hipLaunchKernelGGL(tracegen::memory_local_rows, dim3(div_up(height * tracegen::MEMORY_LOCAL_ENTRIES, (size_t)256)), dim3(256), 0, ctx->stream,
+                     dev_events, n_events, height, m->d);
+  LAUNCH_CHECK();
+  return m;
+}
+
+int zkm_tracegen_memory_local(zkm_ctx* ctx, const zkm_memory_local_event* events, size_t n_events, int fixed_log2_rows, zkm_matrix** out) {
+  return tracegen_single(ctx, out, [&](TraceBatch& b) { return enqueue_memory_local(b, events, n_events, fixed_log2_rows); });
+}
+
+static zkm_matrix* enqueue_global(TraceBatch& b, const zkm_global_lookup_event* events, size_t n_events, int fixed_log2_rows, zkm_byte_lookups* blu) {
+  static_assert(sizeof(zkm_global_lookup_event) == 32, "event records mirror the #[repr(C)] executor structs");
+  zkm_ctx* ctx = b.ctx;
+  if (n_events && !events) throw std::runtime_error("zkm_tracegen_global: null events");
+  if (!blu) throw std::runtime_error("zkm_tracegen_global: null byte lookups");
+  const size_t height = padded_trace_rows(n_events, fixed_log2_rows, "zkm_tracegen_global");
+  zkm_matrix* m = b.matrix(height, tracegen::GLOBAL_WIDTH);
+  // the events are read on the device only (the u16 check of message[0] included: GLOBAL_ERR_NOT_U16), so a prefetched address does as well
+  const uint32_t* d_events = b.events(events, n_events * sizeof(zkm_global_lookup_event));
+  uint32_t* d_err = b.flag(TraceBatch::F_GLOBAL);
+  std::vector<uint32_t*> levels;     // scan buffers: the points behind the start digest, then the chunk sums of each level
+  std::vector<size_t> sizes;
+  for (size_t n = n_events + 1;; n = div_up(n, (size_t)tracegen::SCAN_CHUNK)) {
+    levels.push_back((uint32_t*)b.temp(n * tracegen::POINT_WORDS * sizeof(uint32_t)));
+    sizes.push_back(n);
+    if (n <= (size_t)tracegen::SCAN_BLOCK) break;
   }
-  ctx->release(d_events);
-  *out = m;
-  API_END
+  const double bytes = 32.0 * n_events + 4.0 * height * tracegen::GLOBAL_WIDTH;
+  KLAUNCH(ctx, "tracegen_global_points", bytes, tracegen::global_point_rows, dim3(div_up(height, (size_t)256)), dim3(256), 0,
+          d_events, n_events, height, m->d, levels[0], blu->counts, d_err);
+  for (size_t l = 0; l + 1 < levels.size(); l++)
+    KLAUNCH(ctx, "tracegen_global_scan", 64.0 * sizes[l], tracegen::global_scan_reduce, dim3(div_up(sizes[l + 1], (size_t)64)), dim3(64), 0,
+            (const uint32_t*)levels[l], sizes[l], levels[l + 1], sizes[l + 1]);
+  KLAUNCH(ctx, "tracegen_global_scan", 128.0 * sizes.back(), tracegen::global_scan_block, dim3(1), dim3(tracegen::SCAN_BLOCK), 0, levels.back(),
+          sizes.back());
+  for (size_t l = levels.size() - 1; l-- > 0;)
+    KLAUNCH(ctx, "tracegen_global_scan", 128.0 * sizes[l], tracegen::global_scan_apply, dim3(div_up(sizes[l + 1], (size_t)64)), dim3(64), 0, levels[l],
+            sizes[l], (const uint32_t*)levels[l + 1], sizes[l + 1]);
+  KLAUNCH(ctx, "tracegen_global_accum", bytes, tracegen::global_accum_rows, dim3(div_up(height, (size_t)256)), dim3(256), 0,
+          (const uint32_t*)levels[0], n_events, height, m->d, d_err);
+  return m;
 }
 
 int zkm_tracegen_global(zkm_ctx* ctx, const zkm_global_lookup_event* events, size_t n_events, int fixed_log2_rows, zkm_byte_lookups* blu,
                         zkm_matrix** out) {
-  API_BEGIN
-  static_assert(sizeof(zkm_global_lookup_event) == 32, "event records mirror the #[repr(C)] executor structs");
-  std::lock_guard<std::mutex> lk(ctx->mu);
-  HIP_CHECK(hipSetDevice(ctx->device));
-  if (n_events && !events) throw std::runtime_error("zkm_tracegen_global: null events");
-  if (!blu) throw std::runtime_error("zkm_tracegen_global: null byte lookups");
-  for (size_t i = 0; i < n_events; i++)
-    if (events[i].message[0] >> 16) throw std::runtime_error("zkm_tracegen_global: message[0] of event " + std::to_string(i) + " is not a u16");
-  const size_t height = padded_trace_rows(n_events, fixed_log2_rows, "zkm_tracegen_global");
-  ctx->begin_timing();
-  zkm_matrix* m = new zkm_matrix();
-  m->h = height; m->w = tracegen::GLOBAL_WIDTH;
-  uint32_t* d_events = nullptr;
-  uint32_t* d_err = nullptr;
-  std::vector<uint32_t*> levels;     // scan buffers: the points behind the start digest, then the chunk sums of each level
-  std::vector<size_t> sizes;
-  try {
-    m->d = ctx->alloc_n<uint32_t>(height * m->w);
-    d_events = (uint32_t*)ctx->alloc(std::max<size_t>(n_events * sizeof(zkm_global_lookup_event), 4));
-    d_err = ctx->alloc_n<uint32_t>(1);
-    HIP_CHECK(hipMemsetAsync(d_err, 0, 4, ctx->stream));
-    if (n_events) HIP_CHECK(hipMemcpyAsync(d_events, events, n_events * sizeof(zkm_global_lookup_event), hipMemcpyHostToDevice, ctx->stream));
-    for (size_t n = n_events + 1;; n = div_up(n, (size_t)tracegen::SCAN_CHUNK)) {
-      levels.push_back(ctx->alloc_n<uint32_t>(n * tracegen::POINT_WORDS));
-      sizes.push_back(n);
-      if (n <= (size_t)tracegen::SCAN_BLOCK) break;
-    }
-    const double bytes = 32.0 * n_events + 4.0 * height * tracegen::GLOBAL_WIDTH;
-    KLAUNCH(ctx, "tracegen_global_points", bytes, tracegen::global_point_rows, dim3(div_up(height, (size_t)256)), dim3(256), 0,
-            (const uint32_t*)d_events, n_events, height, m->d, levels[0], blu->counts, d_err);
-    for (size_t l = 0; l + 1 < levels.size(); l++)
-      KLAUNCH(ctx, "tracegen_global_scan", 64.0 * sizes[l], tracegen::global_scan_reduce, dim3(div_up(sizes[l + 1], (size_t)64)), dim3(64), 0,
-              (const uint32_t*)levels[l], sizes[l], levels[l + 1], sizes[l + 1]);
-    KLAUNCH(ctx, "tracegen_global_scan", 128.0 * sizes.back(), tracegen::global_scan_block, dim3(1), dim3(tracegen::SCAN_BLOCK), 0, levels.back(),
-            sizes.back());
-    for (size_t l = levels.size() - 1; l-- > 0;)
-      KLAUNCH(ctx, "tracegen_global_scan", 128.0 * sizes[l], tracegen::global_scan_apply, dim3(div_up(sizes[l + 1], (size_t)64)), dim3(64), 0, levels[l],
-              sizes[l], (const uint32_t*)levels[l + 1], sizes[l + 1]);
-    KLAUNCH(ctx, "tracegen_global_accum", bytes, tracegen::global_accum_rows, dim3(div_up(height, (size_t)256)), dim3(256), 0,
-            (const uint32_t*)levels[0], n_events, height, m->d, d_err);
-    uint32_t err = 0;
-    HIP_CHECK(hipMemcpyAsync(&err, d_err, 4, hipMemcpyDeviceToHost, ctx->stream));
-    ctx->mark("trace generation");
-    ctx->end_timing(false);
-    HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    if (err & tracegen::GLOBAL_ERR_NO_POINT) throw std::runtime_error("zkm_tracegen_global: a message has no curve point within 256 offsets");
-    if (err & tracegen::GLOBAL_ERR_INFINITY) throw std::runtime_error("zkm_tracegen_global: the running sum reached the point at infinity");
-    if (err & tracegen::GLOBAL_ERR_EQUAL_X) throw std::runtime_error("zkm_tracegen_global: a message's point has the running sum's x-coordinate");
-  } catch (...) {
-    for (uint32_t* p : levels) ctx->release(p);
-    if (d_err) ctx->release(d_err);
-    if (d_events) ctx->release(d_events);
-    if (m->d) ctx->release(m->d);
-    delete m;
-    throw;
-  }
-  for (uint32_t* p : levels) ctx->release(p);
-  ctx->release(d_err);
-  ctx->release(d_events);
-  *out = m;
-  API_END
+  return tracegen_single(ctx, out, [&](TraceBatch& b) { return enqueue_global(b, events, n_events, fixed_log2_rows, blu); });
 }
 
 int zkm_tracegen_poseidon2_wide(zkm_ctx* ctx, const uint32_t* events, size_t n_events, int fixed_log2_rows, zkm_matrix** out) {
@@ -417,18 +436,44 @@ int zkm_tracegen_poseidon2_wide(zkm_ctx* ctx, const uint32_t* events, size_t n_e
   API_END
 }
 
+// SyscallCore keeps the events whose code has the send-to-table byte set or names a Linux syscall (syscall/chip.rs:252-259): host events are
+// filtered here, events that are already in HBM (zkm_events_upload_async) by tracegen::syscall_core_compact, the row kernel then reading
+// the count from device memory — no host read either way for a prefetched shard.
+static zkm_matrix* enqueue_syscall(TraceBatch& b, const zkm_syscall_event* events, size_t n_events, int precompile, int fixed_log2_rows, zkm_byte_lookups* blu) {
+  static_assert(sizeof(zkm_syscall_event) == 56, "event records mirror the #[repr(C)] executor structs");
+  zkm_ctx* ctx = b.ctx;
+  if (precompile) return enqueue_rows(b, tracegen::SYSCALL_PRECOMPILE, events, n_events, fixed_log2_rows, blu);
+  if (n_events && !events) throw std::runtime_error("zkm_tracegen: null events");
+  if (n_events && ctx->prefetched.count(events)) {
+    const uint32_t* d_all = b.events(events, n_events * sizeof(zkm_syscall_event));
+    const size_t cap = fixed_log2_rows >= 0 ? std::min(n_events, padded_trace_rows(0, fixed_log2_rows, "zkm_tracegen_syscall")) : n_events;
+    uint32_t* d_kept = (uint32_t*)b.temp(cap * sizeof(zkm_syscall_event));
+    uint32_t* d_n = (uint32_t*)b.temp(4);
+    uint32_t* d_flag = b.flag(TraceBatch::F_SYSCALL_CORE);
+    KLAUNCH(ctx, "tracegen_syscall_compact", 2.0 * n_events * sizeof(zkm_syscall_event), tracegen::syscall_core_compact, dim3(1), dim3(1024), 0,
+            d_all, n_events, d_kept, d_n, cap, d_flag);
+    if (fixed_log2_rows < 0) {
+      // no shape: the trace's height is the next power of two of the kept count, which the host has to learn first (one round trip; a
+      // shaped shard — the reference's default — fixes the height and takes the branch below)
+      const uint32_t* h_n = ctx->download_async(d_n, 1);
+      HIP_CHECK(hipStreamSynchronize(ctx->stream));
+      return enqueue_rows(b, tracegen::SYSCALL_CORE, nullptr, *h_n, -1, blu, nullptr, d_kept);
+    }
+    // the kept count stays on the device: the row kernel reads it there
+    return enqueue_rows(b, tracegen::SYSCALL_CORE, nullptr, cap, fixed_log2_rows, blu, d_n, d_kept, (size_t)1 << fixed_log2_rows);
+  }
+  b.host_keep.emplace_back();
+  std::vector<zkm_syscall_event>& kept = b.host_keep.back();
+  for (size_t i = 0; i < n_events; i++) {
+    const uint32_t code = events[i].a_record.prev_value;
+    if (((code >> 16) & 0xff) == 1 || ((code >> 8) & 0xff) != 0) kept.push_back(events[i]);
+  }
+  return enqueue_rows(b, tracegen::SYSCALL_CORE, kept.empty() ? nullptr : (const void*)kept.data(), kept.size(), fixed_log2_rows, blu);
+}
+
 int zkm_tracegen_syscall(zkm_ctx* ctx, const zkm_syscall_event* events, size_t n_events, int precompile, int fixed_log2_rows, zkm_byte_lookups* blu,
                          zkm_matrix** out) {
-  if (precompile) return tracegen_events(ctx, tracegen::SYSCALL_PRECOMPILE, events, n_events, fixed_log2_rows, blu, out);
-  // SyscallCore keeps the events whose code has the send-to-table byte set or names a Linux syscall (syscall/chip.rs:252-259)
-  std::vector<zkm_syscall_event> kept;
-  if (events)
-    for (size_t i = 0; i < n_events; i++) {
-      const uint32_t code = events[i].a_record.prev_value;
-      if (((code >> 16) & 0xff) == 1 || ((code >> 8) & 0xff) != 0) kept.push_back(events[i]);
-    }
-  return tracegen_events(ctx, tracegen::SYSCALL_CORE, n_events ? (events ? (const void*)kept.data() : nullptr) : nullptr, events ? kept.size() : n_events,
-                         fixed_log2_rows, blu, out);
+  return tracegen_single(ctx, out, [&](TraceBatch& b) { return enqueue_syscall(b, events, n_events, precompile, fixed_log2_rows, blu); });
 }
 
 int zkm_tracegen_memory_global(zkm_ctx* ctx, const zkm_memory_init_finalize_event* events, size_t n_events, uint32_t previous_addr, int fixed_log2_rows,
@@ -1296,35 +1341,89 @@ void zkm_byte_lookups_free(zkm_ctx* ctx, zkm_byte_lookups* b) {
   delete b;
 }
 
+static zkm_matrix* enqueue_byte_mults(TraceBatch& b, const zkm_byte_lookups* blu, const uint32_t* extra_counts) {
+  zkm_ctx* ctx = b.ctx;
+  if (!blu) throw std::runtime_error("zkm_tracegen_byte_mults: null byte lookups");
+  const size_t cells = (size_t)tracegen::BYTE_ROWS * tracegen::NUM_BYTE_OPS;
+  zkm_matrix* m = b.matrix(tracegen::BYTE_ROWS, tracegen::NUM_BYTE_OPS);
+  uint32_t* d_extra = nullptr;
+  if (extra_counts) {
+    d_extra = (uint32_t*)b.temp(cells * 4);
+    HIP_CHECK(hipMemcpyAsync(d_extra, extra_counts, cells * 4, hipMemcpyHostToDevice, ctx->stream));
+  }
+  ctx->flush_staged();
+  hipLaunchKernelGGL(tracegen::byte_mults_finish, dim3(div_up(cells, 256)), dim3(256), 0, ctx->stream, (const uint32_t*)blu->counts,
+                     (const uint32_t*)d_extra, m->d, cells);
+  LAUNCH_CHECK();
+  return m;
+}
+
 int zkm_tracegen_byte_mults(zkm_ctx* ctx, const zkm_byte_lookups* blu, const uint32_t* extra_counts, zkm_matrix** out) {
+  return tracegen_single(ctx, out, [&](TraceBatch& b) { return enqueue_byte_mults(b, blu, extra_counts); });
+}
+
+// generate_traces of a core shard (crates/stark/src/prover.rs:70-108) in one call: every descriptor's generator is queued on the compute
+// stream behind the prefetch of its events, none waits for the host, and the call synchronises once at the end. Byte lookups of all the
+// chips are counted into one table (the caller's, or one that lives for the call); a ZKM_TG_BYTE_MULTS descriptor reads it after every
+// other generator, wherever it stands in the list; ZKM_TG_PROGRAM_MULTS is filled by the ZKM_TG_CPU descriptor's pass over the events.
+int zkm_tracegen_shard(zkm_ctx* ctx, const zkm_tracegen_desc* descs, size_t n, zkm_byte_lookups* blu, zkm_matrix** out) {
   API_BEGIN
   std::lock_guard<std::mutex> lk(ctx->mu);
   HIP_CHECK(hipSetDevice(ctx->device));
-  if (!blu) throw std::runtime_error("zkm_tracegen_byte_mults: null byte lookups");
+  if (n && (!descs || !out)) throw std::runtime_error("zkm_tracegen_shard: null descriptors");
   ctx->begin_timing();
-  const size_t cells = (size_t)tracegen::BYTE_ROWS * tracegen::NUM_BYTE_OPS;
-  zkm_matrix* m = new zkm_matrix();
-  m->h = tracegen::BYTE_ROWS; m->w = tracegen::NUM_BYTE_OPS;
-  uint32_t* d_extra = nullptr;
+  TraceBatch b(ctx);
+  zkm_byte_lookups own;
   try {
-    m->d = ctx->alloc_n<uint32_t>(cells);
-    if (extra_counts) {
-      d_extra = (uint32_t*)ctx->alloc(cells * 4);
-      HIP_CHECK(hipMemcpyAsync(d_extra, extra_counts, cells * 4, hipMemcpyHostToDevice, ctx->stream));
+    if (!blu) {
+      const size_t cells = (size_t)tracegen::BYTE_ROWS * tracegen::NUM_BYTE_OPS;
+      own.counts = (uint32_t*)b.temp(cells * 4);
+      HIP_CHECK(hipMemsetAsync(own.counts, 0, cells * 4, ctx->stream));
+      blu = &own;
     }
-    hipLaunchKernelGGL(tracegen::byte_mults_finish, dim3(div_up(cells, 256)), dim3(256), 0, ctx->stream, (const uint32_t*)blu->counts,
-                       (const uint32_t*)d_extra, m->d, cells);
-    LAUNCH_CHECK();
-    ctx->mark("byte multiplicities");
-    ctx->end_timing(false);
+    long cpu_at = -1, pm_at = -1;
+    for (size_t i = 0; i < n; i++) {
+      out[i] = nullptr;
+      if (descs[i].kind == ZKM_TG_CPU) { if (cpu_at >= 0) throw std::runtime_error("zkm_tracegen_shard: two Cpu descriptors"); cpu_at = (long)i; }
+      if (descs[i].kind == ZKM_TG_PROGRAM_MULTS) { if (pm_at >= 0) throw std::runtime_error("zkm_tracegen_shard: two Program descriptors"); pm_at = (long)i; }
+    }
+    if (pm_at >= 0 && cpu_at < 0) throw std::runtime_error("zkm_tracegen_shard: the Program multiplicities come from the Cpu descriptor's events, and there is none");
+    for (size_t i = 0; i < n; i++) {
+      const zkm_tracegen_desc& d = descs[i];
+      zkm_byte_lookups* use = d.no_byte_lookups ? nullptr : blu;
+      switch (d.kind) {
+        case ZKM_TG_ALU:
+          if (d.chip < 0 || d.chip >= tracegen::NUM_ALU_CHIPS) throw std::runtime_error("zkm_tracegen_shard: unknown ALU chip");
+          out[i] = enqueue_rows(b, d.chip, d.events, d.n_events, d.fixed_log2_rows, use);
+          break;
+        case ZKM_TG_JUMP: out[i] = enqueue_rows(b, tracegen::JUMP, d.events, d.n_events, d.fixed_log2_rows, nullptr); break;
+        case ZKM_TG_MOV_COND: out[i] = enqueue_rows(b, tracegen::MOV_COND, d.events, d.n_events, d.fixed_log2_rows, nullptr); break;
+        case ZKM_TG_BRANCH: out[i] = enqueue_rows(b, tracegen::BRANCH, d.events, d.n_events, d.fixed_log2_rows, use); break;
+        case ZKM_TG_MUL: out[i] = enqueue_rows(b, tracegen::MUL, d.events, d.n_events, d.fixed_log2_rows, use); break;
+        case ZKM_TG_DIVREM: out[i] = enqueue_rows(b, tracegen::DIVREM, d.events, d.n_events, d.fixed_log2_rows, use); break;
+        case ZKM_TG_MEMORY_INSTRS: out[i] = enqueue_rows(b, tracegen::MEMORY_INSTRS, d.events, d.n_events, d.fixed_log2_rows, use); break;
+        case ZKM_TG_MISC_INSTRS: out[i] = enqueue_rows(b, tracegen::MISC_INSTRS, d.events, d.n_events, d.fixed_log2_rows, use); break;
+        case ZKM_TG_SYSCALL_INSTRS: out[i] = enqueue_rows(b, tracegen::SYSCALL_INSTRS, d.events, d.n_events, d.fixed_log2_rows, nullptr); break;
+        case ZKM_TG_SYSCALL_CORE: out[i] = enqueue_syscall(b, (const zkm_syscall_event*)d.events, d.n_events, 0, d.fixed_log2_rows, use); break;
+        case ZKM_TG_SYSCALL_PRECOMPILE: out[i] = enqueue_syscall(b, (const zkm_syscall_event*)d.events, d.n_events, 1, d.fixed_log2_rows, use); break;
+        case ZKM_TG_MEMORY_LOCAL: out[i] = enqueue_memory_local(b, (const zkm_memory_local_event*)d.events, d.n_events, d.fixed_log2_rows); break;
+        case ZKM_TG_GLOBAL: out[i] = enqueue_global(b, (const zkm_global_lookup_event*)d.events, d.n_events, d.fixed_log2_rows, blu); break;
+        case ZKM_TG_CPU:
+          out[i] = enqueue_cpu(b, (const zkm_cpu_event*)d.events, d.n_events, d.program, d.n_instr, d.pc_base, d.shard, d.fixed_log2_rows,
+                               pm_at >= 0 ? descs[pm_at].fixed_log2_rows : -1, use, pm_at >= 0 ? &out[pm_at] : nullptr);
+          break;
+        case ZKM_TG_PROGRAM_MULTS: case ZKM_TG_BYTE_MULTS: break;
+        default: throw std::runtime_error("zkm_tracegen_shard: unknown descriptor kind");
+      }
+    }
+    for (size_t i = 0; i < n; i++)
+      if (descs[i].kind == ZKM_TG_BYTE_MULTS) out[i] = enqueue_byte_mults(b, blu, nullptr);
+    b.finish("trace generation");
   } catch (...) {
-    if (d_extra) ctx->release(d_extra);
-    if (m->d) ctx->release(m->d);
-    delete m;
+    b.abort();
+    for (size_t i = 0; i < n; i++) out[i] = nullptr;
     throw;
   }
-  if (d_extra) ctx->release(d_extra);
-  *out = m;
   API_END
 }
 

@@ -126,6 +126,12 @@ struct zkm_ctx {
   // 0: off; 1: every launch; 2 (default): only launches moving >= 256 KiB (the ~300 tiny launches of a proof
   // are left untimed)
   int kernel_timing = 2;
+  // pcs_commit extends a commit's shorter matrices on the side stream under the leaf hashing of the tallest (zkm_ctx_set_lde_overlap;
+  // ZKM_LDE_OVERLAP=0 turns it off for every context of the process). Off, every kernel of a proof runs alone on the main stream and
+  // the per-kernel HIP-event durations add up to the busy time.
+  bool lde_overlap = !(getenv("ZKM_LDE_OVERLAP") && atoi(getenv("ZKM_LDE_OVERLAP")) == 0);
+  bool root_poll = !(getenv("ZKM_ROOT_POLL") && atoi(getenv("ZKM_ROOT_POLL")) == 0);   // wait_root; cleared for good by its first timeout
+  int root_spin_before_yield = getenv("ZKM_ROOT_SPIN") ? atoi(getenv("ZKM_ROOT_SPIN")) : 4096;   // wait_root: spins before it starts yielding the core
   // per-chip specialised quotient kernels (ziren_amd/codegen.py), keyed by a hash of the program words
   std::map<uint64_t, std::vector<hipFunction_t>> quotient_fns;   // a program's specialised kernel(s), in launch order
   std::map<uint64_t, hipFunction_t> perm_fns;                    // a lookups blob's specialised permutation-trace kernel (key: perm_key)
@@ -150,7 +156,8 @@ struct zkm_ctx {
   char* pin = nullptr;
   size_t pin_cap = (size_t)32 << 20, pin_off = 0;
   void* pin_alloc(size_t bytes) {
-    if (!pin) HIP_CHECK(hipHostMalloc((void**)&pin, pin_cap, hipHostMallocDefault));
+    // coherent (fine-grained) whatever HIP_HOST_COHERENT says: wait_root watches words a running kernel stores into this ring
+    if (!pin) HIP_CHECK(hipHostMalloc((void**)&pin, pin_cap, hipHostMallocCoherent));
     size_t off = (pin_off + 63) & ~(size_t)63;
     if (off + bytes > pin_cap) return nullptr;
     pin_off = off + bytes;
@@ -208,7 +215,15 @@ struct zkm_ctx {
     if (cur != stream) side_deferred.push_back(p);
     else release(p);
   }
-  void side_begin() { cur = stream2; }
+  // Everything queued on the main stream so far is in front of the side stream's work: the producers of its inputs (cflags memset,
+  // perm_rows / scan kernels, first-use table fills), pool buffers released in main-stream order, and any staged table copy.
+  void side_begin() {
+    hipEvent_t e = get_event();
+    HIP_CHECK(hipEventRecord(e, stream));
+    HIP_CHECK(hipStreamWaitEvent(stream2, e, 0));
+    event_pool.push_back(e);
+    cur = stream2;
+  }
   void side_end() {
     if (!side_done) HIP_CHECK(hipEventCreateWithFlags(&side_done, hipEventDisableTiming));
     HIP_CHECK(hipEventRecord(side_done, stream2));

@@ -154,22 +154,37 @@ static bool compress_small_layer(zkm_ctx* ctx, Tree& t, int layer, size_t len) {
   return false;
 }
 
+static inline void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+  __builtin_ia32_pause();
+#elif defined(__aarch64__)
+  __asm__ __volatile__("yield");
+#endif
+}
+
 // The root a tail launch writes to page-locked host memory, read without a stream synchronisation (ZKM_ROOT_POLL=0: with one): the host watches the
 // eight words change from the 0xffffffff they were set to before the launch (a Montgomery word is below 2^31; each word is one 32-bit
 // store to coherent host memory) and goes on queueing the next kernels behind the still-finishing launch — the completion signal, the
 // wake-up and the return through hipStreamSynchronize stay off the critical path of the 22 dependent FRI layers. Falls back to the
 // synchronisation after a second (a failed launch must still surface).
 static void wait_root(zkm_ctx* ctx, const uint32_t* h_root, bool pollable) {
-  static const bool poll = [] { const char* e = getenv("ZKM_ROOT_POLL"); return !e || atoi(e) != 0; }();
-  if (poll && pollable) {
+  if (ctx->root_poll && pollable) {
     const volatile uint32_t* v = h_root;
     const auto t0 = std::chrono::steady_clock::now();
     for (int spins = 0;; spins++) {
       bool all = true;
       for (int k = 0; k < 8; k++) all &= v[k] != 0xffffffffu;
       if (all) { std::atomic_thread_fence(std::memory_order_acquire); return; }
-      if ((spins & 4095) == 4095 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(1)) break;
-      __builtin_ia32_pause();
+      if ((spins & 4095) == 4095 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(1)) {
+        // the stores of a running kernel are not visible to the host here (non-coherent host memory?): every further root would cost
+        // the same second, so this context synchronises from now on, and says so once
+        ctx->root_poll = false;
+        fprintf(stderr, "libzkm_hip: a tree root did not become visible in page-locked memory within 1 s; root polling is off for this context (stream synchronisation instead)\n");
+        break;
+      }
+      // after a short burst of spinning give the core away: a lane's host thread shares its CPUs with the other lanes and ranks of the node
+      if (spins >= ctx->root_spin_before_yield) sched_yield();
+      else cpu_relax();
     }
   }
   HIP_CHECK(hipStreamSynchronize(ctx->stream));
@@ -333,7 +348,7 @@ static zkm_pcs_data* pcs_commit(zkm_ctx* ctx, const std::vector<zkm_matrix>& mat
       // the side stream while the leaves are hashed (ZKM_LDE_OVERLAP, default on): the strided LDE passes run at the memory system's
       // pace and leave issue slots free, the leaf hashing is bound by issue and leaves the memory system idle. The tree joins the
       // side stream right before the first layer that reads a shorter matrix (extend_height below).
-      static const bool overlap = !(getenv("ZKM_LDE_OVERLAP") && atoi(getenv("ZKM_LDE_OVERLAP")) == 0);
+      const bool overlap = ctx->lde_overlap;
       std::vector<LdeJob> tall, rest;
       size_t rest_cells = 0;
       for (size_t i = 0; i < mats.size(); i++)

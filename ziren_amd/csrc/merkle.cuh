@@ -345,7 +345,8 @@ __global__ __launch_bounds__(64) void sponge_prefix(const uint32_t* const* __res
   const lanes::LaneConsts k = lanes::load_consts(e);
   uint32_t x = 0;
   for (int g = 0; g < P; g++) {
-    if (e < 8 && 8 * g + e < width) x = flags[8 * g + e][1];
+    // the canonical word, as lde_cols<true> writes it into the LDE (an input word may be any u32 congruent to the value)
+    if (e < 8 && 8 * g + e < width) { const uint32_t v = flags[8 * g + e][1]; x = kb::umin32(v, v - kb::P); }
     x = lanes::permute(x, k);
   }
   if (threadIdx.x < 16) out[e] = x;

@@ -852,8 +852,8 @@ template <> __device__ __forceinline__ void row_lookups<SYSCALL_PRECOMPILE>(cons
 // counts (may be null): NUM_BYTE_OPS columns of BYTE_ROWS plain u32 counters; the byte lookups of every event row are
 // added to them — the chip's generate_dependencies in the same pass that builds its trace.
 template <int CHIP>
-__global__ __launch_bounds__(THREADS) void alu_rows(const uint32_t* __restrict__ events, size_t n_events, size_t height,
-                                                    uint32_t* __restrict__ out, uint32_t* counts, int tiles) {
+__device__ __forceinline__ void alu_rows_body(const uint32_t* __restrict__ events, size_t n_events, size_t height,
+                                              uint32_t* __restrict__ out, uint32_t* counts, int tiles) {
   constexpr int W = chip_width(CHIP);
   extern __shared__ uint32_t hash_lds[];  // 2 * HASH_SLOTS words when counting, nothing otherwise (keeps the pure row writer at full occupancy)
   uint32_t* hkeys = hash_lds;
@@ -894,6 +894,56 @@ __global__ __launch_bounds__(THREADS) void alu_rows(const uint32_t* __restrict__
     __syncthreads();
     for (int i = threadIdx.x; i < HASH_SLOTS; i += blockDim.x)
       if (hkeys[i] != HASH_EMPTY) atomicAdd(counts + hkeys[i], hvals[i]);
+  }
+}
+
+template <int CHIP>
+__global__ __launch_bounds__(THREADS) void alu_rows(const uint32_t* __restrict__ events, size_t n_events, size_t height,
+                                                    uint32_t* __restrict__ out, uint32_t* counts, int tiles) {
+  alu_rows_body<CHIP>(events, n_events, height, out, counts, tiles);
+}
+
+// The same with the event count in device memory: the rows of events a device-side pass selected (syscall_core_compact).
+template <int CHIP>
+__global__ __launch_bounds__(THREADS) void alu_rows_counted(const uint32_t* __restrict__ events, const uint32_t* __restrict__ n_events, size_t height,
+                                                            uint32_t* __restrict__ out, uint32_t* counts, int tiles) {
+  alu_rows_body<CHIP>(events, (size_t)*n_events, height, out, counts, tiles);
+}
+
+// SyscallChip::generate_trace's filter for the Core table (crates/core/machine/src/syscall/chip.rs:252-259) on the device, for events that
+// are already in HBM: keeps, in order, the syscall events whose code (a_record.prev_value, word 7) has the send-to-table byte set or
+// names a Linux syscall. One block; per pass of blockDim.x events an ordered prefix count (wave ballots + one LDS pass over the waves).
+// *n_kept = how many were kept; *flags |= 1 when more were kept than `cap` rows hold (the caller's fixed height).
+__global__ __launch_bounds__(1024) void syscall_core_compact(const uint32_t* __restrict__ events, size_t n_events, uint32_t* __restrict__ kept,
+                                                             uint32_t* __restrict__ n_kept, size_t cap, uint32_t* __restrict__ flags) {
+  constexpr int EW = event_words(SYSCALL_CORE);
+  __shared__ uint32_t wave_count[16];
+  __shared__ uint32_t base;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, waves = blockDim.x >> 6;
+  if (threadIdx.x == 0) base = 0;
+  __syncthreads();
+  for (size_t i0 = 0; i0 < n_events; i0 += blockDim.x) {
+    const size_t i = i0 + threadIdx.x;
+    bool keep = false;
+    if (i < n_events) {
+      const uint32_t code = events[i * EW + 7];
+      keep = ((code >> 16) & 0xff) == 1 || ((code >> 8) & 0xff) != 0;
+    }
+    const unsigned long long m = __ballot(keep);
+    if (lane == 0) wave_count[wave] = (uint32_t)__popcll(m);
+    __syncthreads();
+    uint32_t before = base;
+    for (int w = 0; w < wave; w++) before += wave_count[w];
+    const size_t dst = (size_t)before + __popcll(m & ((1ull << lane) - 1));
+    if (keep && dst < cap)
+      for (int k = 0; k < EW; k++) kept[dst * EW + k] = events[i * EW + k];
+    __syncthreads();
+    if (threadIdx.x == 0) { uint32_t t = base; for (int w = 0; w < waves; w++) t += wave_count[w]; base = t; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    if (base > cap) { atomicOr(flags, 1u); *n_kept = (uint32_t)cap; }
+    else *n_kept = base;
   }
 }
 
@@ -964,7 +1014,7 @@ __global__ __launch_bounds__(THREADS) void cpu_rows(const uint32_t* __restrict__
       const uint32_t clk = e[0], pc = e[1];
       const size_t idx = (size_t)(pc - pc_base) >> 2;   // Program::fetch
       const bool in_program = pc >= pc_base && idx < n_instr;
-      if (!in_program) *bad_pc = 1;
+      if (!in_program) atomicOr(bad_pc, 1);
       // the shard clock is range-checked as a 16-bit and an 8-bit limb (cpu/air/mod.rs:39,131-138): a clock of 2^24 or more would be
       // truncated into a trace that satisfies no verifier (the executor closes a shard long before: executor.rs:325,2423)
       if (clk >> 24) atomicOr(bad_pc, 2);
@@ -2786,7 +2836,7 @@ enum { MESSAGE = 0, KIND = 7, OFFSET_BITS = 8, X = 16, Y = 23, Y6_BITS = 30, RC_
        INITIAL = 64, SUM_CHECKER = 78, CUMULATIVE = 85 };
 }
 __constant__ uint32_t d_global_consts[28];   // start digest x, y (septic_digest.rs:9-14), dummy point x, y (septic_curve.rs:18-38); Montgomery
-enum : uint32_t { GLOBAL_ERR_NO_POINT = 1, GLOBAL_ERR_INFINITY = 2, GLOBAL_ERR_EQUAL_X = 4 };
+enum : uint32_t { GLOBAL_ERR_NO_POINT = 1, GLOBAL_ERR_INFINITY = 2, GLOBAL_ERR_EQUAL_X = 4, GLOBAL_ERR_NOT_U16 = 8 };
 __device__ __forceinline__ septic::Point load_point(const uint32_t* p) {
   septic::Point r;
 #pragma unroll
@@ -2818,6 +2868,7 @@ __global__ void global_point_rows(const uint32_t* __restrict__ events, size_t n_
   }
   const uint32_t* e = events + row * 8;
   const uint32_t is_receive = e[7] & 0xff, kind = (e[7] >> 8) & 0xff;
+  if (e[0] >> 16) atomicOr(err, GLOBAL_ERR_NOT_U16);     // message[0] is range-checked as a u16 (global/mod.rs): found here, the events may never have been on the host
   septic::S7 m;
   for (int k = 0; k < 7; k++) { m.c[k] = kb::to_monty(e[k]); put(MESSAGE + k, m.c[k]); }
   m.c[0] = kb::add(m.c[0], kb::to_monty(kind << 16));

@@ -26,6 +26,8 @@
 #include <string>
 #include <vector>
 
+#include <sched.h>
+
 #include "kb31.cuh"
 #include "poseidon2.cuh"
 #include "lde.cuh"
@@ -61,6 +63,16 @@ static void launch_alu_rows(zkm_ctx* ctx, const uint32_t* d_events, size_t n_eve
 extern "C" {
 
 const char* zkm_last_error(void) { return g_err.c_str(); }
+
+#ifndef ZKM_SOURCES_DIGEST
+#define ZKM_SOURCES_DIGEST "unrecorded"
+#endif
+#ifndef ZKM_HIPCC_VERSION
+#define ZKM_HIPCC_VERSION "unknown"
+#endif
+// also found by reading the file's bytes (ziren_amd/build.py recorded_digest): the build script checks it without loading the library
+extern "C" const char zkm_build_info_string[] = "ZKM_SOURCES_DIGEST=" ZKM_SOURCES_DIGEST ";hipcc=" ZKM_HIPCC_VERSION ";arch=gfx950";
+const char* zkm_build_info(void) { return zkm_build_info_string; }
 
 int zkm_ctx_create(int device, zkm_ctx** out) {
   API_BEGIN
@@ -196,6 +208,7 @@ int zkm_ctx_kernel_timings(zkm_ctx* ctx, const char** names, float* ms, uint32_t
 }
 void zkm_ctx_set_kernel_timing(zkm_ctx* ctx, int mode) { ctx->kernel_timing = mode; }
 void zkm_ctx_set_kernel_timing_only(zkm_ctx* ctx, const char* name) { ctx->timing_only = name ? name : ""; ctx->kernel_timing = 3; }
+void zkm_ctx_set_lde_overlap(zkm_ctx* ctx, int on) { std::lock_guard<std::mutex> lk(ctx->mu); ctx->lde_overlap = on != 0; }
 
 int zkm_ctx_register_quotient_kernel(zkm_ctx* ctx, const uint32_t* program, uint32_t program_len, const void* code_object,
                                      size_t code_object_len) {

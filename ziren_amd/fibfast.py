@@ -13,6 +13,7 @@ between a branch and its delay slot), events/cpu.rs:46-77, events/instr.rs, even
 guest is crates/prover/scripts/fibonacci_sweep.rs:41-76."""
 import numpy as np
 
+from . import abi
 from . import events as E
 from . import miniexec as M
 
@@ -339,17 +340,39 @@ class DeviceShard:
     def prefetch(self, ctx):
         """Queue the copy of this shard's event vectors to the device (zkm_events_upload_async, the DMA stream) and return at once:
         {chip: DeviceEvents} for `traces`. Called right before the previous shard's proof, the transfer runs under that proof. The vectors
-        should be page-locked (`pin`). Global's and SyscallCore's events (a handful here) are read on the host and stay there."""
-        return {name: ctx.events_upload_async(ev) for name, ev, _, _ in self.work if len(ev) and name not in ("Global", "SyscallCore")}
+        should be page-locked (`pin`). SyscallCore reads SyscallInstrs' vector: one copy serves both."""
+        return {name: ctx.events_upload_async(ev) for name, ev, _, _ in self.work if len(ev) and name != "SyscallCore"}
 
-    def traces(self, ctx, prefetched=None):
+    _KIND = {"Cpu": abi.TG_CPU, "Branch": abi.TG_BRANCH, "Jump": abi.TG_JUMP, "MovCond": abi.TG_MOV_COND, "Mul": abi.TG_MUL, "DivRem": abi.TG_DIVREM,
+             "MemoryInstrs": abi.TG_MEMORY_INSTRS, "MiscInstrs": abi.TG_MISC_INSTRS, "SyscallInstrs": abi.TG_SYSCALL_INSTRS,
+             "SyscallCore": abi.TG_SYSCALL_CORE, "MemoryLocal": abi.TG_MEMORY_LOCAL, "Global": abi.TG_GLOBAL}
+
+    def traces(self, ctx, prefetched=None, one_call=True):
         """generate_traces on the device: one DeviceMatrix per chip of `self.chips`, in that order. `prefetched` = what `prefetch` returned
-        (freed here); without it every generator uploads its own events."""
+        (freed here); without it every generator uploads its own events. one_call (default): the whole shard in one zkm_tracegen_shard
+        call — every generator queued behind the copy of its events, one synchronisation; False: one entry point per chip, as the
+        chips' own tests call them (same traces: tests/test_fibfast.py)."""
+        pre = prefetched or {}
+        if one_call:
+            items = []
+            for name, ev, lh, _ in self.work:
+                ev = pre.get("SyscallInstrs" if name == "SyscallCore" else name, ev)
+                if name in _ALU:
+                    items.append((abi.TG_ALU, ev, lh, {"chip": _ALU[name]}))
+                elif name == "Cpu":
+                    items.append((abi.TG_CPU, ev, lh, {"program": self.machine.program, "pc_base": self.machine.pc_base, "shard": self.shard_no}))
+                else:
+                    items.append((self._KIND[name], ev, lh, None))
+            items.append((abi.TG_BYTE_MULTS, None, 16, None))
+            items.append((abi.TG_PROGRAM_MULTS, None, self.plh, None))
+            born = ctx.tracegen_shard(items)
+            for d in pre.values():
+                d.free()
+            return born
         blu = ctx.byte_lookups()
         born, program_mults = [], None
-        pre = prefetched or {}
         for name, ev, lh, _ in self.work:
-            ev = pre.get(name, ev)
+            ev = pre.get("SyscallInstrs" if name == "SyscallCore" else name, ev)
             if name == "Cpu":
                 cpu, program_mults = ctx.tracegen_cpu_and_program(ev, self.machine.program, self.machine.pc_base, self.shard_no, lh, self.plh, blu)
                 born.append(cpu)

@@ -490,6 +490,34 @@ class Context:
         lib.check(lib.load().zkm_tracegen_byte_table(self.h, C.byref(h)))
         return DeviceMatrix(self, h, 1 << 16, 12)
 
+    def tracegen_shard(self, items, blu: "ByteLookups" = None):
+        """generate_traces of a core shard in one call (zkm_tracegen_shard): `items` = [(kind, events, fixed_log2_rows, extra)] with kind one
+        of abi.TG_*, events a numpy array or a DeviceEvents (None for TG_BYTE_MULTS / TG_PROGRAM_MULTS), extra = {"chip": alu chip} for
+        TG_ALU, {"program", "pc_base", "shard"} for TG_CPU. Every generator is queued behind the copy of its events and the call
+        synchronises once. Returns one DeviceMatrix per item."""
+        from . import events as _ev, miniexec as _m
+        dtypes = {abi.TG_ALU: _ev.ALU_EVENT, abi.TG_CPU: _m.CPU_EVENT, abi.TG_BRANCH: _ev.JUMP_EVENT, abi.TG_JUMP: _ev.JUMP_EVENT,
+                  abi.TG_MOV_COND: _ev.MOV_COND_EVENT, abi.TG_MUL: _ev.COMP_ALU_EVENT, abi.TG_DIVREM: _ev.COMP_ALU_EVENT, abi.TG_MEMORY_INSTRS: _ev.MEM_INSTR_EVENT,
+                  abi.TG_MISC_INSTRS: _ev.MISC_EVENT, abi.TG_SYSCALL_INSTRS: _ev.SYSCALL_EVENT, abi.TG_SYSCALL_CORE: _ev.SYSCALL_EVENT,
+                  abi.TG_SYSCALL_PRECOMPILE: _ev.SYSCALL_EVENT, abi.TG_MEMORY_LOCAL: _m.MEMORY_LOCAL_EVENT, abi.TG_GLOBAL: _m.GLOBAL_LOOKUP_EVENT}
+        descs = (abi.TracegenDesc * len(items))()
+        keep = []
+        for d, (kind, events, lh, extra) in zip(descs, items):
+            d.kind, d.fixed_log2_rows, d.chip = kind, lh, -1
+            if kind in dtypes:
+                p_ev, n_ev, k = _evptr(events, dtypes[kind])
+                keep.append(k)
+                d.events, d.n_events = p_ev.value, n_ev
+            if kind == abi.TG_ALU:
+                d.chip = extra["chip"]
+            if kind == abi.TG_CPU:
+                prog = np.ascontiguousarray(extra["program"], dtype=_m.INSTRUCTION)
+                keep.append(prog)
+                d.program, d.n_instr, d.pc_base, d.shard = (prog.ctypes.data if len(prog) else None), len(prog), extra["pc_base"], extra["shard"]
+        out = (C.c_void_p * len(items))()
+        lib.check(lib.load().zkm_tracegen_shard(self.h, descs, C.c_size_t(len(items)), blu.h if blu is not None else None, out))
+        return [self._born(C.c_void_p(h)) for h in out]
+
     def tracegen_byte_mults(self, blu: "ByteLookups", extra_counts=None) -> DeviceMatrix:
         """`ByteChip::generate_trace` over the lookups counted in `blu` (+ optional (65536, 10) host counts)."""
         ex = np.ascontiguousarray(extra_counts, dtype=np.uint32) if extra_counts is not None else None

@@ -142,13 +142,18 @@ def executor_fits(shapes, clk, counts):
     return False
 
 
+# the largest `num_extra_cycles` of the default syscall map (SHA_EXTEND's 48: crates/core/executor/src/syscalls/precompiles/sha256/extend.rs:10-12;
+# every other syscall 0 or 1), executor.rs:303-305
+MAX_SYSCALL_CYCLES = 48
+
+
 def executor_shard_cycles(shard_size, counts_at, first_check=0):
     """Cycles the executor runs before it closes a shard whose estimated event counts after c cycles are `counts_at(c)`
     (estimate_mips_event_counts: opcode counts, Mul and Lt raised by the DivRem count, no other dependency — cost.rs:96-195): the smaller of
     the clock limit (`max_syscall_cycles + clk >= shard_size * 4`, executor.rs:325,2423; clk advances 5 per cycle) and the first shape check
     — made when the global clock is a multiple of 16, `first_check` being the shard's first such cycle — at which no maximal shape fits."""
     shapes = maximal_core_shapes(shard_size.bit_length() - 1)          # opts.shard_size.ilog2(), utils/prove.rs:147
-    limit = -(-4 * shard_size // 5)                       # first c with 5 c >= 4 shard_size
+    limit = -(-(4 * shard_size - MAX_SYSCALL_CYCLES) // 5)                       # first c with max_syscall_cycles + 5 c >= 4 shard_size
     lo, hi = 0, (limit - first_check) // SHAPE_CHECK_FREQUENCY + 1
     if executor_fits(shapes, 5 * limit, counts_at(limit)):
         return limit, "clock"
