@@ -1,21 +1,27 @@
 #!/usr/bin/env python3
 """Benchmark of the shard-prover hot path (BASELINE.json metric: shard-proofs/sec, fibonacci 2^22-row trace).
 
-A "step" is one full shard proof — MachineProver::commit + open (crates/stark/src/prover.rs:258-653), core FRI parameters (blowup 2,
-84 queries, 16 PoW bits) — of a shard whose traces are already resident in HBM. The default workload is BASELINE.json's own: a middle
-shard of the fibonacci guest as the reference cuts and shapes it (the executor's shape check closes the shard, `CoreShapeConfig::fix_shape`
-pads it: ziren_amd/shape.py) at SHARD_SIZE = 2^21 — 1 569 808 cycles in a Cpu trace of 2^22 rows, 16 core chips + Byte + Program.
+A "step" is one full shard proof per GPU — MachineProver::commit + open (crates/stark/src/prover.rs:258-653), core FRI parameters
+(blowup 2, 84 queries, 16 PoW bits). The workload is BASELINE.json's own: middle shards of the fibonacci guest as the reference cuts and
+shapes them (the executor's shape check closes the shard, `CoreShapeConfig::fix_shape` pads it: ziren_amd/shape.py) at SHARD_SIZE = 2^21 —
+1 569 808 cycles in a Cpu trace of 2^22 rows, 16 core chips + Byte + Program.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload fib|fib-tight|syn] [--log-rows 22]
+  python bench.py [--gpus N] [--steps K] [--warmup W]
 
-Every number this file prints belongs to a proof the restated verifier (oracle verify_shard, outside the timed region) accepted: a leg
-whose proof is rejected raises instead of printing.
+ONE experiment for every N (the 1 -> N curve compares like with like): one process per GPU (launched by the driver through
+torch.distributed.run, or by this script itself when WORLD_SIZE is not set: `python bench.py --gpus 8` starts 8 ranks); K N distinct
+shards are dealt from one claim queue to whichever lane is free (crates/core/machine/src/utils/prove.rs:484-497), two lanes (a context +
+host thread each) per GPU; per shard: the executor's events in page-locked host memory -> device traces (one zkm_tracegen_shard call) ->
+proof, the next shard's events crossing PCIe under the current proof; the proof streams are gathered to rank 0 inside the timed region (a
+no-op at N = 1); there is no data-path collective. Per-GPU work is fixed: scaling is weak, value = shards / max-over-ranks time. Every
+lane starts the timed region with its first shard's events resident in HBM (claimed and prefetched before the barrier).
 
-N > 1: one process per GPU (launched by the driver through torch.distributed.run, or by this script itself when WORLD_SIZE is not set:
-`python bench.py --gpus 8` starts 8 ranks). Shards are independent (crates/core/machine/src/utils/prove.rs:492-497): the ranks take
-distinct shards from one claim queue, each from the executor's events in page-locked host memory (events -> device traces -> proof, the
-next shard's events crossing PCIe under the current proof), the proof streams are gathered to rank 0 over RCCL inside the timed region;
-there is no data-path collective. Per-GPU work is fixed (--steps K shards per GPU, K N in the queue): scaling is weak, value = shards / max-over-ranks time.
+After the timed region (outside `value`) rank 0 runs the resident one-lane leg on the same shard — traces resident in HBM, one shard in
+flight — for the per-kernel figures: `roofline` (dominant kernel, HIP events), `valu`, `lde`, `kernels_ms` (a pass with the side-stream
+overlap off, so that the durations add up), `resident_one_lane`; and, at N = 1, the continuity legs and `cpu_baseline`.
+
+Every number this file prints belongs to proofs the restated verifier (oracle verify_shard, outside the timed region) accepted: a leg
+whose proof is rejected raises instead of printing. `--resident` prints the old resident-only line (profiling scripts use it).
 """
 import argparse
 import ctypes as C
@@ -34,7 +40,7 @@ os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")      # before anything initi
 
 HBM_PEAK_GBPS = 8000.0     # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 FP64_VECTOR_TFLOPS = 78.6  # MI355X FP64 vector peak: 256 CUs x 4 SIMDs x 16 lanes x 2 flop x 2.4 GHz (MI355X_MICROARCH.md)
-PROFILE_ROUND = "r04"
+PROFILE_ROUND = "r05"
 HASHING_KERNELS = ("compress_layer", "hash_leaves", "hash_leaves_tree", "hash_fri_leaves", "hash_fri_leaves_tree", "compress_small", "compress_tail")
 LDE_KERNELS = ("lde_rows", "lde_cols_forward", "lde_cols_inverse")
 ROCPROF_NAMES = {"compress_layer": "merkle::compress_layer", "hash_leaves": "merkle::hash_leaves", "hash_leaves_tree": "merkle::hash_leaves_tree",
@@ -60,7 +66,7 @@ def csrc_digest():
 def poseidon2_isa():
     """Dynamic VALU instructions per permutation as the hardware counts them (SQ_INSTS_VALU over tools/ubench_p2's kernels, written by
     tools/profile_r04.sh -> tools/pmc_poseidon2.py); the newest profile kept; None when there is none."""
-    for rnd in (PROFILE_ROUND, "r03"):
+    for rnd in (PROFILE_ROUND, "r04", "r03"):
         path = os.path.join(ROOT, "profiles", f"{rnd}_poseidon2_isa.json")
         if os.path.exists(path):
             return json.load(open(path)), f"profiles/{rnd}_poseidon2_isa.json"
@@ -237,7 +243,9 @@ def verify_or_die(wl, fri, ch0, proof, what):
     leg's last proof, outside every timed region. A rejected proof ends the run: no number is printed for it."""
     from ziren_amd import synth
     O = oracle()
-    rc = O.verify_shard(wl.oracle_pk(O, fri), wl.chips, fri, synth.NUM_PV_ELTS, ch0.copy(), np.ascontiguousarray(proof, dtype=np.uint32).copy())
+    if getattr(wl, "_opk", None) is None:
+        wl._opk = wl.oracle_pk(O, fri)          # the oracle's own commit of the preprocessed traces: once per workload
+    rc = O.verify_shard(wl._opk, wl.chips, fri, synth.NUM_PV_ELTS, ch0.copy(), np.ascontiguousarray(proof, dtype=np.uint32).copy())
     if rc != 0:
         raise SystemExit(f"bench.py: the verifier REJECTED the {what} proof (code {rc}); nothing is reported for it")
     return True
@@ -284,17 +292,24 @@ def resident_leg(farm, wl, hp, pk, ch0, traces, steps, warmup, kernel_timing):
         accumulate(kern_acc, ctx)
 
     elapsed = farm.timed(timed_step, steps=steps, warmup=0)
-    table, table_steps, table_ms = kern_acc, steps, elapsed / steps * 1e3
+    table, table_steps, table_ms, table_mode = kern_acc, steps, elapsed / steps * 1e3, "in the timed region (side-stream overlap on: concurrent kernels' durations overlap)"
     if dominant is not None:
+        # the per-kernel table: every launch >= 256 KiB timed, the side-stream LDE overlap OFF for this pass — each kernel then runs alone
+        # on the main stream and the HIP-event durations add up to (at most) the step
         L.zkm_ctx_set_kernel_timing(ctx.h, C.c_int(2))
+        L.zkm_ctx_set_lde_overlap(ctx.h, C.c_int(0))
+        step()                                   # the first serialised proof re-sizes the pool's scratch
         table, table_steps = {}, min(steps, 5)
+        ctx.synchronize()
         t0 = time.perf_counter()
         for _ in range(table_steps):
             step()
             accumulate(table, ctx)
         table_ms = (time.perf_counter() - t0) / table_steps * 1e3
+        table_mode = "serialised: side-stream overlap off (zkm_ctx_set_lde_overlap 0), every launch >= 256 KiB timed"
+        L.zkm_ctx_set_lde_overlap(ctx.h, C.c_int(1))
     return {"elapsed": elapsed, "phases": {n: v / steps for n, v in phase_acc.items()}, "kern_timed": kern_acc, "table": table,
-            "table_steps": table_steps, "table_ms": table_ms, "dominant": dominant, "proof": state["proof"].copy(), "out": out}
+            "table_steps": table_steps, "table_ms": table_ms, "table_mode": table_mode, "dominant": dominant, "proof": state["proof"].copy(), "out": out}
 
 
 def traffic_profile(tag):
@@ -329,6 +344,7 @@ def roofline_objects(wl, fri, leg, steps):
             traffic = int(tk["hbm_bytes_per_launch"]) if tk else None
         roofline = {"bound": "hbm", "kernel": name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": tsrc,
+                    "measured_in": "the resident one-lane leg (traces in HBM, one shard in flight), its timed steps, HIP events on the launch stream",
                     "launches_per_step": calls // steps, "avg_launch_ms": round(per_launch_ms, 4), "algorithmic_bytes_per_launch": int(kbytes),
                     "kernel_share_of_step": round(ms / steps / ms_per_step, 3),
                     "whole_shard": {"algorithmic_bytes": alg_bytes, "achieved": round(alg_bytes / (ms_per_step * 1e-3) / 1e9, 1),
@@ -366,11 +382,17 @@ def roofline_objects(wl, fri, leg, steps):
             tr = sum(tj["kernels"][ROCPROF_NAMES[n]]["hbm_bytes_total"] for n in LDE_KERNELS if ROCPROF_NAMES[n] in tj["kernels"]) / max(tj.get("steps", 1), 1)
         lde = {"ms": round(lde_ms, 3), "alg_GB": round(alg / 1e9, 3), "alg_GBps": round(alg / lde_ms / 1e6, 1), "frac_of_hbm_peak": round(alg / lde_ms / 1e6 / HBM_PEAK_GBPS, 4),
                "traffic_GB": round(tr / 1e9, 3) if tr else None, "ratio": round(tr / alg, 2) if tr else None,
+               "time_is": "serialised (side-stream overlap off): the three kernels' HIP-event durations, each running alone",
                "structural_floor": "36 n w: a two-level split reads and writes the column three times (strided inverse, rows, strided forward)"}
     kernels_ms = {n: {"ms": round(v[0] / table_steps, 3), "launches": v[1] // table_steps, "GBps": round(v[2] / max(v[0], 1e-9) / 1e6, 1)}
                   for n, v in sorted(table.items(), key=lambda kv: -kv[1][0])}
-    source = (f"a pass of {table_steps} steps after the timed region with every launch >= 256 KiB timed ({table_ms:.3f} ms per step); inside the timed "
-              f"region only {leg['dominant']} is timed, and the roofline is computed from those launches") if leg["dominant"] else "the timed region"
+    ksum = sum(v[0] for v in table.values()) / table_steps
+    if leg["dominant"] and ksum > table_ms * 1.001:
+        raise SystemExit(f"bench.py: the serialised per-kernel durations add up to {ksum:.3f} ms, more than the {table_ms:.3f} ms step they were measured in")
+    source = {"pass": f"{table_steps} proofs after the timed region, {leg['table_mode']}", "ms_per_step_of_that_pass": round(table_ms, 3),
+              "kernels_ms_sum": round(ksum, 3), "untimed_remainder_ms": round(table_ms - ksum, 3),
+              "note": "kernels_ms_sum <= the pass's step time is asserted; the remainder is launches below 256 KiB, copies, host round trips and idle gaps. "
+                      f"Inside the resident leg's timed region only {leg['dominant']} is timed, and the roofline is computed from those launches (overlap on: in situ)"}
     return roofline, valu, lde, kernels_ms, source
 
 
@@ -558,7 +580,7 @@ def cpu_baseline_leg(wl, fri, full, sample_log):
             "full_size_measurement": f"profiles/{PROFILE_ROUND}_cpu_baseline_full.json (bench.py --cpu-full)"}
 
 
-# ---- N > 1: the claim queue over events -> traces -> proof ---------------------------------------------------------------------------------
+# ---- the farm line (every N): the claim queue over events -> traces -> proof -----------------------------------------------------------------
 
 class StubLane:
     """tests/test_bench_cli.py only (ZKM_BENCH_STUB_PROVER=1, CPU, gloo): stands in for the GPU lane so that the launch / queue / gather /
@@ -567,6 +589,7 @@ class StubLane:
     def __init__(self, rank):
         self.rank = rank
         self.event_bytes = 1 << 20
+        self.last = None
 
     def prefetch(self, i):
         return ("events", i)
@@ -574,6 +597,7 @@ class StubLane:
     def prove(self, i, handle):
         assert handle == ("events", i)
         time.sleep(0.01)
+        self.last = i
         return np.array([0x5AFE, i, self.rank] + [i] * (8 + i % 3), dtype=np.uint32)
 
     def verify_last(self):
@@ -617,7 +641,7 @@ class FibQueueLane:
 
     def prove(self, i, handle):
         w = self.wls[i % len(self.wls)]
-        born = w.ds.traces(self.ctx, handle)
+        born = w.ds.traces(self.ctx, handle)          # one zkm_tracegen_shard call: every generator queued behind the events' copy
         proof = self.hp.prove_shard(self.pk, w.public_values, born, self.challenger(i), out=self.out)
         for t in born:
             t.free()
@@ -626,80 +650,210 @@ class FibQueueLane:
 
     def verify_last(self):
         i, w, proof = self.last
-        return verify_or_die(w, self.fri, self.challenger(i), proof, f"queue shard {i}")
+        ok = verify_or_die(w, self.fri, self.challenger(i), proof, f"queue shard {i}")
+        for other in self.wls:
+            other._opk = w._opk                   # one program, one key: the oracle commits the preprocessed traces once per rank
+        return ok
 
     def sync(self):
         self.ctx.synchronize()
 
 
-def queue_main(args, farm, fri):
+LINE_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "shards", "warmup", "ms_per_step", "ms_per_shard", "higher_is_better", "scaling", "vs_baseline", "dtype",
+             "verified", "verified_proofs", "stub", "data", "config", "roofline", "valu", "lde", "kernels_ms", "kernels_ms_source", "phases_ms", "resident_one_lane",
+             "two_in_flight", "events_to_proof", "other_workloads", "cpu_baseline", "host_ms_per_shard", "host_cpu_s_per_shard", "event_bytes_per_shard", "h2d_GBps_per_rank",
+             "shards_proved", "shards_proved_by_rank0", "fewest_shards_on_a_rank", "lib_digest", "wall_s")
+
+
+def farm_main(args, farm, fri):
+    """The one experiment behind every `--gpus N` (module docstring): K N shards through the claim queue, M lanes per GPU."""
+    t_start = time.perf_counter()
     rank, local_rank, world = farm.rank, farm.local_rank, farm.world
     stub = os.environ.get("ZKM_BENCH_STUB_PROVER") == "1"
+    specialize = not args.interpreter
     M = max(1, args.inflight)
-    lane = StubLane(rank) if stub else FibQueueLane(local_rank, rank, fri, args.shard_size_log, not args.interpreter)
-    lanes = [lane] + [StubLane(rank) if stub else FibQueueLane(local_rank, rank, fri, args.shard_size_log, not args.interpreter, share=lane) for _ in range(M - 1)]
+    lib_digest = None
+    if not stub:
+        from ziren_amd import lib
+        lib_digest = lib.check_build_identity()          # a library built from other sources than the tree's is refused here
+    lane = StubLane(rank) if stub else FibQueueLane(local_rank, rank, fri, args.shard_size_log, specialize)
+    lanes = [lane] + [StubLane(rank) if stub else FibQueueLane(local_rank, rank, fri, args.shard_size_log, specialize, share=lane) for _ in range(M - 1)]
 
     def sync_all():
         for l in lanes:
             l.sync()
     farm.device_sync = sync_all
-    # default (and --queue -1): --steps K shards per GPU, K N in the queue (weak scaling: per-GPU work fixed); --queue S: S shards in all
-    per_gpu = max(args.steps, 2 * M)
+    # default: exactly --steps K shards per GPU, K N in the queue (weak scaling: per-GPU work fixed); --queue S: S shards in all
+    per_gpu = max(1, args.steps)
     n_shards = args.queue if args.queue > 0 else per_gpu * world
-    for l in lanes:
-        for _ in range(max(1, args.warmup)):
-            l.prove(0, l.prefetch(0))
+    warm = max(1, args.warmup)
+    t_setup = time.perf_counter()
+    if len(lanes) > 1 and not stub:
+        import threading
+        ths = [threading.Thread(target=lambda l=l: [l.prove(0, l.prefetch(0)) for _ in range(warm)]) for l in lanes]   # warm the lanes the way they run: together
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+    else:
+        for l in lanes:
+            for _ in range(warm):
+                l.prove(0, l.prefetch(0))
+    t_warm = time.perf_counter()
+    pairs = [(l.prove, l.prefetch) for l in lanes]
+    farm.prime_queue(n_shards, pairs)         # every lane's first shard: claimed, its events queued for HBM — resident when the clock starts
     farm.barrier()
+    cpu0 = time.process_time()
     t0 = time.perf_counter()
-    ids, proofs = farm.run_queue(n_shards, lanes=[(l.prove, l.prefetch) for l in lanes])
+    ids, proofs = farm.run_queue(n_shards, lanes=pairs)
     gathered = farm.gather_proofs(ids, proofs, n_shards)
     farm.barrier()
     elapsed = farm.max_over_ranks(time.perf_counter() - t0)
+    cpu_s = time.process_time() - cpu0
+    t_timed = time.perf_counter()
     mine = float(np.mean(farm.host_ms)) if farm.host_ms else 0.0
     slowest = farm.max_over_ranks(mine)
+    cpu_per_shard = cpu_s / max(1, len(ids))
+    cpu_per_shard_max = farm.max_over_ranks(cpu_per_shard)
     proved = farm.sum_over_ranks(float(len(ids)))
     fewest = -farm.max_over_ranks(-float(len(ids)))
-    ok = 1.0
+    # verification, outside the timed region: at N = 1 every lane's last proof; at N > 1 one proof per rank (the last of its first lane
+    # that proved anything) — bounded: the CPU verifier of a 2^22-row shard takes seconds on a rank's share of the host cores
+    ok, checked = 1.0, 0
     for l in lanes:
-        if getattr(l, "last", True) is not None and ids:
-            ok = min(ok, 1.0 if l.verify_last() else 0.0)         # every lane of every rank checks the last proof it made (outside the timed region)
+        if l.last is not None and (world == 1 or checked == 0):
+            ok = min(ok, 1.0 if l.verify_last() else 0.0)
+            checked += 1
     all_ok = -farm.max_over_ranks(-ok)
+    verified_proofs = int(farm.sum_over_ranks(float(checked)))
+    t_verify = time.perf_counter()
     ranks_in_group = farm.dist.get_world_size() if farm.dist is not None else 1
     if all_ok != 1.0 or int(proved) != n_shards:
         raise SystemExit("bench.py: a rank's proof was rejected or a shard was proven by nobody")
+    line = dict.fromkeys(LINE_KEYS)
     if rank == 0:
         assert len(gathered) == n_shards and len({p.tobytes() for p in gathered}) == n_shards, "the gathered proofs are not distinct"
         ms = elapsed / n_shards * 1e3
-        cpu_log = 22 if stub else lane.wls[0].chips[0].log_height
-        if not stub:
-            from ziren_amd import synth
-            alg = synth.shard_algorithmic_bytes(lane.wls[0])
-        print(json.dumps({
+        backend = "none (one process)" if farm.dist is None else "gloo" if (stub or os.environ.get("ZKM_BENCH_ONE_DEVICE") == "1") else "nccl (RCCL)"
+        line.update({
             "metric": "shard-proofs/sec", "value": round(n_shards / elapsed, 4), "unit": "shard-proofs/s", "n_gpus": world,
             "steps": n_shards if args.queue > 0 else per_gpu, "shards": n_shards,
-            "warmup": max(1, args.warmup), "ms_per_step": round(ms if args.queue > 0 else elapsed / per_gpu * 1e3, 3), "ms_per_shard": round(ms, 3),
+            "warmup": warm, "ms_per_step": round(ms if args.queue > 0 else elapsed / per_gpu * 1e3, 3), "ms_per_shard": round(ms, 3),
             "higher_is_better": True, "scaling": "strong" if args.queue > 0 else "weak",
-            "vs_baseline": None, "dtype": "u32", "verified": True, "stub": stub or None,
-            "data": "synthetic (the fibonacci guest's events in closed form, ziren_amd/fibfast.py; two pool shards per rank, page-locked)",
-            "config": {"workload": (f"FIB-S{args.shard_size_log}: {n_shards} distinct shards ({'as given' if args.queue > 0 else str(per_gpu) + ' per GPU'}) of examples/fibonacci (cut and shaped as the reference does at SHARD_SIZE = 2^{args.shard_size_log}, "
-                                    f"Cpu 2^{cpu_log} rows) dealt from one claim queue; per shard: executor events in page-locked host memory -> device traces -> full shard "
+            "vs_baseline": None, "dtype": "u32", "verified": True, "verified_proofs": {"checked_by_the_verifier": verified_proofs, "of": n_shards,
+                                                                                    "which": "the last proof of every lane" if world == 1 else "one proof per rank (its first lane's last)",
+                                                                                    "all_gathered_streams_distinct": True},
+            "stub": stub or None,
+            "data": "synthetic (the fibonacci guest's events in closed form, ziren_amd/fibfast.py; no executor or ELF in this environment; two pool shards per rank, page-locked)",
+            "config": {"workload": (f"FIB-S{args.shard_size_log}: {n_shards} distinct shards ({'as given' if args.queue > 0 else str(per_gpu) + ' per GPU'}) of examples/fibonacci (cut and shaped as the reference does at "
+                                    f"SHARD_SIZE = 2^{args.shard_size_log}) dealt from one claim queue; per shard: executor events in page-locked host memory -> device traces -> full shard "
                                     f"proof (commit+open, blowup 2, 84 queries, 16 PoW bits); proof streams gathered to rank 0 inside the timed region"),
                        "parallelism": f"{world} GPU(s), one process each, {M} shard(s) in flight per GPU (a context + host thread each), claim queue (every lane claims one shard "
-                                      f"ahead: its events cross PCIe under the current proof), {'gloo' if stub else 'RCCL'} gather of {sum(len(p) for p in gathered) * 4} proof bytes, "
+                                      f"ahead: its events cross PCIe under the current proof), {backend} gather of {sum(len(p) for p in gathered) * 4} proof bytes to rank 0, "
                                       f"no data-path collective",
-                       "shards_in_flight_per_gpu": M, "ranks_in_process_group": ranks_in_group,
-                       "backend": "none (one process)" if farm.dist is None else "gloo" if (stub or os.environ.get("ZKM_BENCH_ONE_DEVICE") == "1") else "nccl (RCCL)"},
-            "roofline": None if stub else {
-                "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBPS * world,
-                "whole_shard": {"algorithmic_bytes_per_shard": alg, "achieved": round(alg * n_shards / elapsed / 1e9, 1),
-                                "frac": round(alg * n_shards / elapsed / 1e9 / (HBM_PEAK_GBPS * world), 4)},
-                "note": "SURVEY 8(d)'s algorithmic bytes of one shard x shards / time against N x 8 TB/s; the per-kernel roofline, counters and the CPU baseline "
-                        "are on the N = 1 line (this path runs with kernel timing off)"},
+                       "shards_in_flight_per_gpu": M, "ranks_in_process_group": ranks_in_group, "backend": backend},
             "host_ms_per_shard": {"rank0_mean": round(mine, 3), "max_over_ranks_of_means": round(slowest, 3)},
+            "host_cpu_s_per_shard": {"rank0": round(cpu_per_shard, 4), "max_over_ranks": round(cpu_per_shard_max, 4),
+                                     "note": "process CPU seconds (all threads: the lanes' Python + ctypes, root polling) per shard this rank proved, timed region only"},
             "event_bytes_per_shard": lane.event_bytes,
             "h2d_GBps_per_rank": round(lane.event_bytes * len(ids) / elapsed / 1e9, 2),      # rank 0's events over the timed region: what its PCIe link carried
-            "shards_proved": int(proved), "shards_proved_by_rank0": len(ids), "fewest_shards_on_a_rank": int(fewest)}))
+            "shards_proved": int(proved), "shards_proved_by_rank0": len(ids), "fewest_shards_on_a_rank": int(fewest), "lib_digest": lib_digest})
+    if rank == 0 and not stub:
+        farm_extras(args, fri, lane, lanes, line, world, elapsed, n_shards)
+    t_post = time.perf_counter()
+    if rank == 0:
+        line["wall_s"] = {"setup": round(t_setup - t_start, 2), "warmup": round(t_warm - t_setup, 2), "timed_region": round(elapsed, 3),
+                          "verification": round(t_verify - t_timed, 2), "resident_leg_and_extras": round(t_post - t_verify, 2)}
+        print(json.dumps(line), flush=True)
+    farm.barrier()          # the other ranks leave with rank 0
     farm.close()
+
+
+def farm_extras(args, fri, lane, lanes, line, world, elapsed, n_shards):
+    """Rank 0, after the timed region and outside `value`: the resident one-lane leg on the lane's first pool shard — `roofline`, `valu`,
+    `lde`, `kernels_ms`, `resident_one_lane` — and, at N = 1, the continuity legs and the CPU baseline."""
+    from ziren_amd import lib, prover, synth
+    L = lib.load()
+    wl = lane.wls[0]
+    hp, pk, ch0, ctx = lane.hp, lane.pk, lane.ch0, lane.ctx
+    for l in lanes[1:]:
+        l.ctx.trim()                    # the other lanes' pools go back to the driver: the legs below run on the first lane's context
+    alg = synth.shard_algorithmic_bytes(wl)
+    steps = max(3, min(args.steps, 10))
+    traces = wl.resident_traces(ctx)            # inputs resident in HBM before timing
+    leg = resident_leg(_LocalTimer(ctx), wl, hp, pk, ch0, traces, steps, 2, args.kernel_timing)
+    verify_or_die(wl, fri, ch0, leg["proof"], wl.tag + " resident")
+    roofline, valu, lde, kernels_ms, ksource = roofline_objects(wl, fri, leg, steps)
+    if roofline is not None:
+        roofline["whole_shard_in_the_timed_region"] = {
+            "algorithmic_bytes_per_shard": alg, "achieved": round(alg * n_shards / elapsed / 1e9, 1), "peak": HBM_PEAK_GBPS * world,
+            "frac": round(alg * n_shards / elapsed / 1e9 / (HBM_PEAK_GBPS * world), 4),
+            "note": "SURVEY 8(d)'s algorithmic bytes of one shard x shards / time of the timed region against N x 8 TB/s"}
+    rms = leg["elapsed"] / steps * 1e3
+    line.update({"roofline": roofline, "valu": valu, "lde": lde, "kernels_ms": kernels_ms, "kernels_ms_source": ksource,
+                 "phases_ms": {n: round(v, 3) for n, v in leg["phases"].items()},
+                 "resident_one_lane": {"value": round(steps / leg["elapsed"], 4), "unit": "shard-proofs/s", "ms_per_step": round(rms, 3), "steps": steps, "verified": True,
+                                       "note": "rounds 1-4's headline: traces resident in HBM, one shard in flight, one context; after the timed region, not `value`"}})
+    line["config"].update({"chips": {c.name: c.log_height for c in wl.chips},
+                           "committed_cells": int(sum((1 << c.log_height) * (c.prep_width + c.main_width + 4 * c.perm_ext_width + (4 << c.log_quotient_degree)) for c in wl.chips)),
+                           "proof_words": int(len(leg["proof"])), "cycles": wl.cycles,
+                           "shape": {"registered_under_log2_shard_size": wl.ds.shape_key[0], "cluster": wl.ds.shape_key[1], "shard_closed_by": wl.cut,
+                                     "reference": "crates/core/machine/src/shape/mod.rs:139-191, crates/core/executor/src/executor.rs:2429-2516"}})
+    if world > 1 or args.no_extra:
+        for t in traces:
+            t.free()
+        return
+    L.zkm_ctx_set_kernel_timing(ctx.h, C.c_int(0))
+    line["two_in_flight"] = two_in_flight_leg(wl, fri, lane.ctx.device, (hp, pk, ch0, traces, leg["out"]), not args.interpreter, steps)
+    for t in traces:
+        t.free()
+    ev, proof = events_leg(wl, hp, pk, ch0, leg["out"], min(steps, 6))
+    verify_or_die(wl, fri, ch0, proof, wl.tag + " events->proof")
+    ev["verified"] = True
+    ev["proof_identical_to_resident_leg"] = bool(np.array_equal(proof, leg["proof"]))     # same events, same transcript: the same words
+    if not ev["proof_identical_to_resident_leg"]:
+        raise SystemExit("bench.py: the proof made from prefetched events differs from the one made from resident traces")
+    line["events_to_proof"] = ev
+    also = [a for a in args.also.split(",") if a] + [f"fibc{wl.log_size}"] + ([] if args.no_syn else ["syn22"])
+    ctx.trim()
+    line["other_workloads"] = other_workload_legs(also, fri, lane.ctx.device, not args.interpreter, steps) or None
+    if not args.no_cpu_baseline:
+        sample = args.cpu_sample_log if args.cpu_sample_log is not None else 18
+        line["cpu_baseline"] = cpu_baseline_leg(wl, fri, args.cpu_full, sample)
+
+
+def other_workload_legs(also, fri, device, specialize, steps):
+    """Resident one-lane legs of other workloads, for continuity: fibc21 (the same record without the shape step), syn22 (rounds 1-3's
+    headline), fib21 / fibs20 / syn20 ... on request (--also)."""
+    from ziren_amd import prover
+    extra = {}
+    for name in also:
+        if name.startswith("syn"):
+            w2 = SynWorkload(int(name[3:]))
+        elif name.startswith("fibs"):
+            w2 = FibWorkload("shaped", int(name[4:]))
+        elif name.startswith("fibc"):
+            w2 = FibWorkload("cut", int(name[4:]))
+        else:
+            w2 = FibWorkload("tight", int(name[3:]))
+        ctx2 = prover.Context(device)
+        hp2, pk2, ch2 = w2.setup(ctx2, fri, specialize)
+        tr2 = w2.resident_traces(ctx2)
+        n2 = max(3, min(steps, 5))
+        leg2 = resident_leg(_LocalTimer(ctx2), w2, hp2, pk2, ch2, tr2, n2, 1, 2)
+        verify_or_die(w2, fri, ch2, leg2["proof"], w2.tag)
+        t = leg2["table"]
+        extra[name.upper()] = {
+            "workload": w2.label, "ms_per_step": round(leg2["elapsed"] / n2 * 1e3, 3), "value": round(n2 / leg2["elapsed"], 4), "unit": "shard-proofs/s", "steps": n2,
+            "verified": True, "chips": {c.name: c.log_height for c in w2.chips},
+            "committed_cells": int(sum((1 << c.log_height) * (c.prep_width + c.main_width + 4 * c.perm_ext_width + (4 << c.log_quotient_degree)) for c in w2.chips)),
+            "kernels_ms": {k: round(v[0] / leg2["table_steps"], 3) for k, v in sorted(t.items(), key=lambda kv: -kv[1][0])[:8]}}
+        for x in tr2:
+            x.free()
+        pk2.free()                     # before its context goes
+        del hp2, pk2, tr2, leg2, w2
+        ctx2.close()
+    return extra
 
 
 # ---- main ----------------------------------------------------------------------------------------------------------------------------------
@@ -708,27 +862,28 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--tracegen", action="store_true", help="benchmark device trace generation of the core chips instead of the shard proof (tools/bench_tracegen.py)")
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=10, help="shards per GPU in the timed region (K N in the queue)")
+    ap.add_argument("--warmup", type=int, default=2, help="untimed warm-up proofs per lane")
+    ap.add_argument("--resident", action="store_true", help="N = 1 only: print the resident-only line of rounds 1-4 (traces in HBM, one shard in flight, no queue): "
+                    "what the profiling scripts run; takes --workload / --log-rows")
     ap.add_argument("--workload", choices=["fib", "fib-tight", "syn"], default="fib",
-                    help="fib (default): the fibonacci shard as the reference cuts and shapes it at SHARD_SIZE = 2^--shard-size-log; fib-tight: 2^--log-rows cycles, "
+                    help="--resident only. fib (default): the fibonacci shard as the reference cuts and shapes it at SHARD_SIZE = 2^--shard-size-log; fib-tight: 2^--log-rows cycles, "
                          "tight heights; syn: SYN---log-rows")
-    ap.add_argument("--shard-size-log", type=int, default=21, help="log2 of the reference's SHARD_SIZE for --workload fib (MAX_SHARD_SIZE = 2^21, crates/stark/src/opts.rs:6; "
+    ap.add_argument("--shard-size-log", type=int, default=21, help="log2 of the reference's SHARD_SIZE (MAX_SHARD_SIZE = 2^21, crates/stark/src/opts.rs:6; "
                     "at 2^22 this guest's shard has no covering shape: fix_shape fails in the reference too)")
     ap.add_argument("--log-rows", type=int, default=None, help="fib-tight: log2 cycles (default 21, the most a shard's 24-bit clock holds); syn: log2 rows of the tallest chip (default 22)")
     ap.add_argument("--cpu-sample-log", type=int, default=None, help="size of the cpu_baseline sample (fib: log2 SHARD_SIZE, default 18; syn: log rows, default 20)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-full", action="store_true", help="time the CPU baseline on the benchmarked shard itself instead of a sample (minutes)")
-    ap.add_argument("--no-extra", action="store_true", help="only the timed region, its verification and the roofline objects (profiling runs)")
-    ap.add_argument("--no-syn", action="store_true", help="skip the SYN-22 continuity leg after a fib run")
-    ap.add_argument("--also", type=str, default="", help="comma-separated extra resident legs after the main one: fib21 (2^21 cycles, tight), fibs20 (shaped at SHARD_SIZE 2^20), fibc20 (the same record, tight), syn20 ...")
+    ap.add_argument("--no-extra", action="store_true", help="only the timed region, its verification and the resident leg's roofline objects")
+    ap.add_argument("--no-syn", action="store_true", help="skip the SYN-22 continuity leg")
+    ap.add_argument("--also", type=str, default="", help="comma-separated extra resident legs: fib21 (2^21 cycles, tight), fibs20 (shaped at SHARD_SIZE 2^20), fibc20 (the same record, tight), syn20 ...")
     ap.add_argument("--kernel-timing", type=int, default=3,
-                    help="0 off, 1 every launch, 2 launches >= 256 KiB, 3 (default): inside the timed region only the dominant kernel is timed")
+                    help="resident leg: 0 off, 1 every launch, 2 launches >= 256 KiB, 3 (default): inside its timed steps only the dominant kernel is timed")
     ap.add_argument("--interpreter", action="store_true", help="no generated kernels: the bytecode interpreter for the quotient, the generic kernel for the permutation traces")
-    ap.add_argument("--inflight", type=int, default=2, help="queue path: shards in flight per GPU (a context + host thread each); 2 fills one proof's transcript "
-                    "round trips and launch gaps with the other's kernels (the N = 1 resident line always keeps one in flight and reports two beside it)")
-    ap.add_argument("--queue", type=int, default=0, metavar="SHARDS", help="N = 1 too: deal SHARDS distinct shards through the claim queue (events -> traces -> proof); "
-                    "-1 (the default for N > 1): --steps per GPU.")
+    ap.add_argument("--inflight", type=int, default=2, help="shards in flight per GPU (a context + host thread each); 2 fills one proof's transcript "
+                    "round trips and launch gaps with the other's kernels")
+    ap.add_argument("--queue", type=int, default=0, metavar="SHARDS", help="deal SHARDS distinct shards in all through the claim queue (strong scaling) instead of --steps per GPU")
     args = ap.parse_args()
     if args.log_rows is None:
         args.log_rows = 21 if (args.workload == "fib-tight" or args.tracegen) else 22
@@ -740,28 +895,32 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args.gpus))
 
-    from ziren_amd import abi, farm as farm_mod, prover
+    from ziren_amd import abi, farm as farm_mod
     # tests only: ZKM_BENCH_STUB_PROVER=1 (no GPU at all: gloo, stub lanes) and ZKM_BENCH_ONE_DEVICE=1 (a 1-GPU box standing in for N: every
     # rank proves on device 0 and the process group runs over gloo — RCCL refuses two ranks on one device)
     one_device = os.environ.get("ZKM_BENCH_ONE_DEVICE") == "1"
     farm = farm_mod.Farm(backend="gloo" if (os.environ.get("ZKM_BENCH_STUB_PROVER") == "1" or one_device) else None)
-    rank, local_rank, world = farm.rank, farm.local_rank, farm.world
     if one_device:
-        farm.local_rank = local_rank = 0
-    if world != args.gpus:
+        farm.local_rank = 0
+    if farm.world != args.gpus:
         farm.close()
-        raise SystemExit(f"bench.py: --gpus {args.gpus} but the process group has {world} rank(s) (WORLD_SIZE): refusing to print a line for another N")
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the process group has {farm.world} rank(s) (WORLD_SIZE): refusing to print a line for another N")
     fri = abi.FriConfig(1, 84, 16)  # core config, crates/stark/src/kb31_poseidon2.rs:203-213
-    if world > 1 or args.queue:
-        return queue_main(args, farm, fri)
+    if args.resident:
+        if farm.world != 1:
+            raise SystemExit("bench.py: --resident is the one-GPU resident-trace line")
+        return resident_main(args, farm, fri)
+    return farm_main(args, farm, fri)
 
-    # ---- N = 1: the resident-trace line ------------------------------------------------------------------------------------------------
+
+def resident_main(args, farm, fri):
+    """`--resident`: rounds 1-4's N = 1 line — W warm-up + K timed proofs of one shard whose traces are resident in HBM, one in flight."""
+    from ziren_amd import lib, prover
     wl = {"fib": lambda: FibWorkload("shaped", args.shard_size_log), "fib-tight": lambda: FibWorkload("tight", args.log_rows),
           "syn": lambda: SynWorkload(args.log_rows)}[args.workload]()
-    ctx = prover.Context(local_rank)
+    ctx = prover.Context(farm.local_rank)
     farm.device_sync = ctx.synchronize
-    specialize = not args.interpreter
-    hp, pk, ch0 = wl.setup(ctx, fri, specialize)
+    hp, pk, ch0 = wl.setup(ctx, fri, not args.interpreter)
     traces = wl.resident_traces(ctx)            # inputs resident in HBM before timing
     leg = resident_leg(farm, wl, hp, pk, ch0, traces, args.steps, args.warmup, args.kernel_timing)
     verify_or_die(wl, fri, ch0, leg["proof"], wl.tag)
@@ -772,72 +931,14 @@ def main():
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": wl.data, "verified": True,
             "config": {"workload": wl.label, "chips": {c.name: c.log_height for c in wl.chips},
                        "committed_cells": int(sum((1 << c.log_height) * (c.prep_width + c.main_width + 4 * c.perm_ext_width + (4 << c.log_quotient_degree)) for c in wl.chips)),
-                       "proof_words": int(len(leg["proof"])), "parallelism": "1 GPU x 1 shard in flight"},
+                       "proof_words": int(len(leg["proof"])), "parallelism": "1 GPU x 1 shard in flight, traces resident (--resident)"},
             "phases_ms": {n: round(v, 3) for n, v in leg["phases"].items()}, "kernels_ms": kernels_ms, "kernels_ms_source": ksource,
-            "roofline": roofline, "valu": valu, "lde": lde}
+            "roofline": roofline, "valu": valu, "lde": lde, "lib_digest": lib.check_build_identity()}
     if wl.kind != "syn":
         line["config"]["cycles"] = wl.cycles
-        line["config"]["event_generation_s"] = round(wl.event_generation_s, 2)
-        if wl.kind == "shaped":
-            line["config"]["shape"] = {"registered_under_log2_shard_size": wl.ds.shape_key[0], "cluster": wl.ds.shape_key[1], "shard_closed_by": wl.cut,
-                                       "reference": "crates/core/machine/src/shape/mod.rs:139-191, crates/core/executor/src/executor.rs:2429-2516"}
-    if not args.no_extra:
-        from ziren_amd import lib
-        lib.load().zkm_ctx_set_kernel_timing(ctx.h, C.c_int(0))
-        line["two_in_flight"] = two_in_flight_leg(wl, fri, local_rank, (hp, pk, ch0, traces, leg["out"]), specialize, steps)
-        for t in traces:
-            t.free()
-        traces = None
-        if wl.kind == "syn":
-            line["pcie_inclusive"] = pcie_leg(wl, hp, pk, ch0, leg["out"], steps)
-        else:
-            ev, proof = events_leg(wl, hp, pk, ch0, leg["out"], min(steps, 6))
-            verify_or_die(wl, fri, ch0, proof, wl.tag + " events->proof")
-            ev["verified"] = True
-            ev["proof_identical_to_resident_leg"] = bool(np.array_equal(proof, leg["proof"]))     # same events, same transcript: the same words
-            if not ev["proof_identical_to_resident_leg"]:
-                raise SystemExit("bench.py: the proof made from prefetched events differs from the one made from resident traces")
-            line["events_to_proof"] = ev
-        extra = {}
-        also = [a for a in args.also.split(",") if a]
-        if wl.kind == "shaped":
-            also.append(f"fibc{wl.log_size}")          # the same record, tight: what the shape step costs
-        if wl.kind != "syn" and not args.no_syn:
-            also.append("syn22")
-        ctx.trim()
-        for name in also:
-            if name.startswith("syn"):
-                w2 = SynWorkload(int(name[3:]))
-            elif name.startswith("fibs"):
-                w2 = FibWorkload("shaped", int(name[4:]))
-            elif name.startswith("fibc"):
-                w2 = FibWorkload("cut", int(name[4:]))
-            else:
-                w2 = FibWorkload("tight", int(name[3:]))
-            ctx2 = prover.Context(local_rank)
-            hp2, pk2, ch2 = w2.setup(ctx2, fri, specialize)
-            tr2 = w2.resident_traces(ctx2)
-            n2 = max(3, min(steps, 5))
-            leg2 = resident_leg(_LocalTimer(ctx2), w2, hp2, pk2, ch2, tr2, n2, 1, 2)
-            verify_or_die(w2, fri, ch2, leg2["proof"], w2.tag)
-            t = leg2["table"]
-            extra[name.upper()] = {
-                "workload": w2.label, "ms_per_step": round(leg2["elapsed"] / n2 * 1e3, 3), "value": round(n2 / leg2["elapsed"], 4), "unit": "shard-proofs/s", "steps": n2,
-                "verified": True, "chips": {c.name: c.log_height for c in w2.chips},
-                "committed_cells": int(sum((1 << c.log_height) * (c.prep_width + c.main_width + 4 * c.perm_ext_width + (4 << c.log_quotient_degree)) for c in w2.chips)),
-                "kernels_ms": {k: round(v[0] / leg2["table_steps"], 3) for k, v in sorted(t.items(), key=lambda kv: -kv[1][0])[:8]}}
-            for x in tr2:
-                x.free()
-            pk2.free()                     # before its context goes
-            del hp2, pk2, tr2, leg2, w2
-            ctx2.close()
-        if extra:
-            line["other_workloads"] = extra
-    if not args.no_cpu_baseline:
-        sample = args.cpu_sample_log if args.cpu_sample_log is not None else (20 if wl.kind == "syn" else 18 if wl.kind == "shaped" else 18)
-        line["cpu_baseline"] = cpu_baseline_leg(wl, fri, args.cpu_full, sample)
-    else:
-        line["cpu_baseline"] = None
+    if wl.kind == "syn" and not args.no_extra:
+        line["pcie_inclusive"] = pcie_leg(wl, hp, pk, ch0, leg["out"], steps)
+    line["cpu_baseline"] = None if (args.no_cpu_baseline or args.no_extra) else cpu_baseline_leg(wl, fri, args.cpu_full, args.cpu_sample_log if args.cpu_sample_log is not None else (20 if wl.kind == "syn" else 18))
     print(json.dumps(line), flush=True)
     farm.close()
 

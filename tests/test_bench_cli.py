@@ -28,6 +28,37 @@ def test_gpus_2_without_a_launcher_starts_two_ranks_and_prints_one_line():
     assert "claim queue" in line["config"]["parallelism"]
 
 
+def test_n1_and_n2_lines_are_one_experiment_with_the_same_keys():
+    """`--gpus 1` runs the same claim-queue path as `--gpus N > 1` — same keys in the line, same config fields, two
+    shards in flight per GPU, --steps shards per GPU — so value(N) / (N value(1)) compares like with like."""
+    lines = {}
+    for n in (1, 2):
+        r = _run(["--gpus", str(n), "--steps", "6", "--warmup", "1"], {"ZKM_BENCH_STUB_PROVER": "1"})
+        assert r.returncode == 0, r.stderr[-2000:]
+        out = [l for l in r.stdout.splitlines() if l.strip()]
+        assert len(out) == 1, r.stdout
+        lines[n] = json.loads(out[0])
+    a, b = lines[1], lines[2]
+    assert list(a.keys()) == list(b.keys())
+    assert set(a["config"].keys()) == set(b["config"].keys())
+    for line, n in ((a, 1), (b, 2)):
+        assert line["n_gpus"] == n and line["steps"] == 6 and line["shards"] == 6 * n and line["shards_proved"] == 6 * n and line["warmup"] == 1
+        assert line["config"]["shards_in_flight_per_gpu"] == 2 and line["config"]["ranks_in_process_group"] == n
+        assert "claim queue" in line["config"]["parallelism"] and line["scaling"] == "weak"
+        assert abs(line["ms_per_step"] * line["steps"] / 1e3 - line["wall_s"]["timed_region"]) < 2e-3           # K steps fit the timed region exactly
+        for key in ("roofline", "cpu_baseline", "resident_one_lane", "kernels_ms", "lde", "valu", "verified_proofs"):
+            assert key in line
+    assert a["config"]["backend"] == "none (one process)" and b["config"]["backend"] == "gloo"
+    assert a["verified_proofs"]["of"] == 6 and b["verified_proofs"]["checked_by_the_verifier"] == 2     # one proof per rank at N > 1
+
+
+def test_steps_means_exactly_that_many_shards_per_gpu():
+    r = _run(["--gpus", "1", "--steps", "1", "--warmup", "1"], {"ZKM_BENCH_STUB_PROVER": "1"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["steps"] == 1 and line["shards"] == 1 and line["shards_proved"] == 1
+
+
 def test_gpus_must_agree_with_the_process_group():
     """A launcher that sets WORLD_SIZE=1 for a `--gpus 2` command gets an error, never a line that says n_gpus 1."""
     r = _run(["--gpus", "2"], {"ZKM_BENCH_STUB_PROVER": "1", "WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})

@@ -476,12 +476,23 @@ def test_gpu_global_tracegen_matches_oracle(hip_ctx, oracle, n):
     assert np.array_equal(F.from_monty(mults.to_host()), want_counts)
     mults.free()
     m.free()
+    if n in (5, 2500):
+        # the events already in HBM (zkm_events_upload_async): nothing of them is read on the host, the u16 check included
+        dev = hip_ctx.events_upload_async(ev)
+        blu2 = hip_ctx.byte_lookups()
+        m2 = hip_ctx.tracegen_global(dev, -1, blu2)
+        assert np.array_equal(m2.to_host(), want)
+        m2.free(); blu2.free(); dev.free()
     if n == 5:
         from ziren_amd import lib
         bad = ev.copy()
         bad["message"][2, 0] = 70000
         with pytest.raises(lib.ZkmError, match="not a u16"):
             hip_ctx.tracegen_global(bad, -1, blu)
+        dev = hip_ctx.events_upload_async(bad)
+        with pytest.raises(lib.ZkmError, match="not a u16"):
+            hip_ctx.tracegen_global(dev, -1, blu)
+        dev.free()
         with pytest.raises(lib.ZkmError, match="null byte lookups"):
             hip_ctx.tracegen_global(ev, -1, None)
     blu.free()

@@ -174,7 +174,7 @@ def test_gpu_bench_queue_mode_over_rccl():
     s.close()
     env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), ZKM_FORCE_DIST="1",
                HSA_ENABLE_IPC_MODE_LEGACY="0")
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--queue", "6", "--shard-size-log", "16", "--warmup", "1"], env=env,
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--queue", "6", "--shard-size-log", "16", "--warmup", "1", "--no-extra"], env=env,
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
@@ -183,6 +183,11 @@ def test_gpu_bench_queue_mode_over_rccl():
     assert d["verified"] is True and d["config"]["shards_in_flight_per_gpu"] == 2 and d["config"]["ranks_in_process_group"] == 1
     assert "nccl" in d["config"]["backend"] and d["event_bytes_per_shard"] > 0
     assert d["steps"] == 6 and d["shards_proved"] == 6 and d["value"] > 0 and d["host_ms_per_shard"]["rank0_mean"] > 0
+    # the resident one-lane leg after the timed region: the per-kernel objects of the same line
+    assert d["resident_one_lane"]["value"] > 0 and d["roofline"]["kernel"] and 0 < d["roofline"]["frac"] < 1
+    src = d["kernels_ms_source"]
+    assert src["kernels_ms_sum"] <= src["ms_per_step_of_that_pass"] and "overlap off" in src["pass"]
+    assert d["lib_digest"] and d["verified_proofs"]["checked_by_the_verifier"] == 2 and d["cpu_baseline"] is None
 
 
 @pytest.mark.gpu
@@ -201,3 +206,4 @@ def test_gpu_bench_two_ranks_on_one_device_share_the_queue():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["ranks_in_process_group"] == 2 and d["shards"] == 8 and d["shards_proved"] == 8 and d["steps"] == 4
     assert d["verified"] is True and d["fewest_shards_on_a_rank"] >= 1 and d["config"]["shards_in_flight_per_gpu"] == 2
+    assert d["verified_proofs"]["checked_by_the_verifier"] == 2 and d["resident_one_lane"]["value"] > 0 and d["roofline"]["kernel"] and d["cpu_baseline"] is None

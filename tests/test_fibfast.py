@@ -209,14 +209,84 @@ def test_gpu_shape_fixed_shard_bit_exact(hip_ctx, oracle, log_shard_size):
 
 
 @pytest.mark.gpu
-def test_gpu_benchmarked_shape_fixed_shard_is_accepted_by_the_verifier(hip_ctx, oracle):
-    """bench.py's default workload at full size: SHARD_SIZE = 2^21 -> 1 569 808 cycles, Cpu padded to 2^22 rows, 16 core chips + Byte +
-    Program(2^19): accepted by the restated verifier, rejected with one opened value changed."""
+def test_gpu_one_call_shard_trace_generation_equals_the_per_chip_calls(hip_ctx, oracle):
+    """zkm_tracegen_shard (every generator of the shard queued behind its events, one synchronisation) against the per-chip entry points
+    and the oracle's rows, for a shaped shard (zero-event chips included) and a tight one, from host pointers and from prefetched events."""
+    for m, shape in ((fibfast.shaped_shard(1 << 13)[0], "fix"), (fibfast.full_shard(12), None)):
+        ds = fibfast.DeviceShard(m, shape=shape)
+        ocs = _oracle_side_shaped(oracle, m, ds) if shape else _oracle_side(oracle, m)
+        per_chip = ds.traces(hip_ctx, one_call=False)
+        one_call = ds.traces(hip_ctx)
+        ds.pin(hip_ctx)
+        prefetched = ds.traces(hip_ctx, ds.prefetch(hip_ctx))
+        assert len(per_chip) == len(one_call) == len(prefetched) == len(ocs)
+        for a, b, c, o in zip(per_chip, one_call, prefetched, ocs):
+            want = o.trace
+            assert (b.height, b.width) == want.shape, o.name
+            assert np.array_equal(a.to_host(), want) and np.array_equal(b.to_host(), want) and np.array_equal(c.to_host(), want), o.name
+        for t in per_chip + one_call + prefetched:
+            t.free()
+
+
+@pytest.mark.gpu
+def test_gpu_shard_trace_generation_fails_as_a_whole(hip_ctx):
+    """A descriptor the device rejects (a Cpu event outside the program) fails the call and returns no matrix; a Program descriptor
+    without a Cpu one is refused before anything is queued."""
+    from ziren_amd import abi, lib
+    m = fibfast.full_shard(12)
+    rec = m.shards[0].record
+    ev = rec.cpu.copy()
+    ev["pc"][3] = 0x7FFF0000
+    items = [(abi.TG_CPU, ev, 12, {"program": m.program, "pc_base": m.pc_base, "shard": 2}), (abi.TG_BYTE_MULTS, None, 16, None)]
+    with pytest.raises(lib.ZkmError, match="outside the program"):
+        hip_ctx.tracegen_shard(items)
+    with pytest.raises(lib.ZkmError, match="there is none"):
+        hip_ctx.tracegen_shard([(abi.TG_PROGRAM_MULTS, None, 6, None)])
+    good = hip_ctx.tracegen_shard([(abi.TG_CPU, rec.cpu, 12, {"program": m.program, "pc_base": m.pc_base, "shard": 2})])
+    assert good[0].height == 1 << 12
+    good[0].free()
+
+
+@pytest.mark.gpu
+def test_gpu_benchmarked_shape_fixed_shard_bit_exact_at_full_size(hip_ctx, oracle):
+    """bench.py's workload at full size, word for word (BASELINE config 3 on the metric's own shard): SHARD_SIZE = 2^21 ->
+    1 569 808 cycles, Cpu padded to 2^22 rows, 16 core chips + Byte + Program(2^19) — the only place where Program 2^19 preprocessed,
+    eight zero-event chips at 2^17-2^19, `sponge_prefix` with Bitwise in front of Branch and the side-stream LDE meet at these heights.
+    All 18 device-born traces (one zkm_tracegen_shard call, from prefetched events) equal the oracle's rows; the whole proof stream and the
+    transcript state equal `oracle.prove_shard`'s (about 100 s on the box's 16 cores); the verifier accepts it and rejects it with one
+    opened value changed. crates/stark/src/prover.rs:258-653."""
+    from ziren_amd import abi, field as F, prover, synth
+    from test_machine import ZERO_DIGEST
     m, cycles, why = fibfast.shaped_shard(1 << 21)
     ds = fibfast.DeviceShard(m, shape="fix")
     assert why == "shape" and ds.shape["Cpu"] == 22 and len(ds.chips) == 18
-    fri, opk, start, _, proof, _ = _gpu_prove_fib(hip_ctx, oracle, m, ds)
-    _accepts_and_rejects(oracle, opk, ds.chips, fri, start, proof)
+    ocs = _oracle_side_shaped(oracle, m, ds)
+    assert [c.name for c in ds.chips] == [c.name for c in ocs] and [c.log_height for c in ds.chips] == [c.log_height for c in ocs]
+    fri = abi.FriConfig(1, 84, 16)
+    hp = prover.HipProver(ds.chips, fri, synth.NUM_PV_ELTS, ctx=hip_ctx)
+    hp.specialize_quotient_kernels(ds.chips)
+    pc_start = F.to_monty(m.pc_base)
+    prep = ds.preprocessed(hip_ctx)
+    pk = hp.setup(prep, [0, 0], pc_start, ZERO_DIGEST)
+    opk = oracle.Pk([p.to_host() for p in prep], [0, 0], pc_start, ZERO_DIGEST, fri.log_blowup)
+    assert np.array_equal(pk.commit, opk.commitment())
+    ch = prover.new_challenger()
+    pk.observe_into(ch)
+    start = ch.copy()
+    ds.pin(hip_ctx)
+    born = ds.traces(hip_ctx, ds.prefetch(hip_ctx))           # the way the farm's lanes make them
+    for t, o in zip(born, ocs):                               # one trace on the host at a time: Cpu alone is 2^22 rows
+        assert np.array_equal(t.to_host(), o.trace), o.name
+    proof = hp.prove_shard(pk, ds.public_values, born, ch).copy()
+    for t in born:
+        t.free()
+    hip_ctx.trim()
+    och = oracle.new_challenger()
+    opk.observe_into(och)
+    oproof, _ = oracle.prove_shard(opk, ocs, [c.trace for c in ocs], ds.public_values, fri, synth.NUM_PV_ELTS, och)
+    assert len(proof) == len(oproof) and np.array_equal(proof, oproof), "the GPU proof of the benchmarked shard differs from the oracle's"
+    assert ch.as_tuple() == och.as_tuple()
+    _accepts_and_rejects(oracle, opk, ocs, fri, start, proof)
 
 
 @pytest.mark.gpu

@@ -210,6 +210,23 @@ def test_gpu_new_chip_tracegen_matches_oracle(hip_ctx, oracle):
         assert (born.height, born.width) == want.shape and np.array_equal(born.to_host(), want), (precompile, len(ev))
         assert np.array_equal(F.from_monty(mults.to_host()), counts)
         born.free(); mults.free(); blu.free()
+        if len(ev):
+            # the same events already in HBM (zkm_events_upload_async): SyscallCore's filter runs on the device — with the shape's height
+            # the kept count never reaches the host, without one it costs a round trip — and the rows are the same
+            for fixed in (-1, int(np.log2(want.shape[0])), int(np.log2(want.shape[0])) + 2):
+                dev = hip_ctx.events_upload_async(np.ascontiguousarray(ev))
+                blu = hip_ctx.byte_lookups()
+                born = hip_ctx.tracegen_syscall(dev, precompile, fixed, blu)
+                mults = hip_ctx.tracegen_byte_mults(blu)
+                want_f = want if fixed < 0 else oracle.tracegen_syscall(ev, precompile, fixed)
+                assert (born.height, born.width) == want_f.shape and np.array_equal(born.to_host(), want_f), (precompile, len(ev), fixed)
+                assert np.array_equal(F.from_monty(mults.to_host()), counts)
+                born.free(); mults.free(); blu.free(); dev.free()
+    if len(cpu.syscall) > 4:
+        dev = hip_ctx.events_upload_async(np.ascontiguousarray(cpu.syscall))
+        with pytest.raises(lib.ZkmError, match="too small"):
+            hip_ctx.tracegen_syscall(dev, False, 2)         # five kept events do not fit four rows: found by the device-side filter
+        dev.free()
     assert int(F.from_monty(oracle.tracegen_syscall(cpu.syscall, False))[:, 10].sum()) == 5      # of 14 syscalls only the precompile calls go to the table
     for ev, fixed in ((pre.poseidon2_permute, -1), (pre.poseidon2_permute[:1], -1), (pre.poseidon2_permute[:0], -1), (np.tile(pre.poseidon2_permute, 70), 9)):
         counts = np.zeros((1 << 16, 10), dtype=np.uint32)

@@ -71,8 +71,8 @@ const char* zkm_last_error(void) { return g_err.c_str(); }
 #define ZKM_HIPCC_VERSION "unknown"
 #endif
 // also found by reading the file's bytes (ziren_amd/build.py recorded_digest): the build script checks it without loading the library
-extern "C" const char zkm_build_info_string[] = "ZKM_SOURCES_DIGEST=" ZKM_SOURCES_DIGEST ";hipcc=" ZKM_HIPCC_VERSION ";arch=gfx950";
-const char* zkm_build_info(void) { return zkm_build_info_string; }
+static const char build_info_string[] = "ZKM_SOURCES_DIGEST=" ZKM_SOURCES_DIGEST ";hipcc=" ZKM_HIPCC_VERSION ";arch=gfx950";
+const char* zkm_build_info(void) { return build_info_string; }
 
 int zkm_ctx_create(int device, zkm_ctx** out) {
   API_BEGIN

@@ -129,6 +129,17 @@ class Farm:
             store = self.dist.distributed_c10d._get_default_store()
             return int(store.add(key, 1)) - 1
 
+    def prime_queue(self, n_shards: int, lanes, queue: str = "shards"):
+        """Before a timed `run_queue`: every lane claims its first shard of the batch and queues its prefetch now, so that the batch starts
+        the way it continues — each lane's next input already crossing PCIe (or landed) when its proof starts. The caller synchronises
+        (barrier) between this and `run_queue`, which then begins with these claims instead of making its own."""
+        primed = []
+        for pv, pf in lanes:
+            cur = self.claim(queue)
+            primed.append((cur, pf(cur) if (pf is not None and cur < n_shards) else None))
+        self._primed = getattr(self, "_primed", {})
+        self._primed[self._queue_key(queue)] = primed
+
     def run_queue(self, n_shards: int, prove: Optional[Callable] = None, queue: str = "shards", prefetch: Optional[Callable] = None, lanes=None):
         """Prove shards of one batch until its queue is empty; returns ([shard ids this rank proved], [their proof streams]). Calling
         it again deals a new batch (a fresh counter). `self.host_ms` collects, per shard proven here, the wall-clock milliseconds of
@@ -147,14 +158,20 @@ class Farm:
         lanes = lanes or [(prove, prefetch)]
         results = [None] * len(lanes)
         errors = []
+        primed = getattr(self, "_primed", {}).pop(self._queue_key(queue), None)
+        if primed is not None and len(primed) != len(lanes):
+            raise ValueError("prime_queue was called with another number of lanes")
 
         def work(j):
             pv, pf = lanes[j]
             ids, proofs, ms = [], [], []
             results[j] = (ids, proofs, ms)
             try:
-                cur = self.claim(queue)
-                handle = pf(cur) if (pf is not None and cur < n_shards) else None
+                if primed is not None:
+                    cur, handle = primed[j]
+                else:
+                    cur = self.claim(queue)
+                    handle = pf(cur) if (pf is not None and cur < n_shards) else None
                 while cur < n_shards:
                     t0 = time.perf_counter()
                     nxt, nxt_handle = n_shards, None

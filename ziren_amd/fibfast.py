@@ -319,6 +319,8 @@ class DeviceShard:
     def pin(self, ctx):
         """Move the shard's event vectors into page-locked host memory (zkm_host_alloc): where a host that feeds a GPU keeps them, the
         upload inside every zkm_tracegen_* call is then plain DMA at PCIe rate. Returns the bytes pinned."""
+        if getattr(self, "_pinned_by", None) is ctx:
+            return 0                                  # already page-locked through this context
         total = 0
         pinned = []
         for name, ev, lh, record in self.work:
@@ -328,6 +330,7 @@ class DeviceShard:
             pinned.append((name, buf[:len(ev) * (ev.dtype.itemsize // 4)].view(ev.dtype), lh, record))
             total += ev.nbytes
         self.work = pinned
+        self._pinned_by = ctx
         return total
 
     def event_bytes(self):

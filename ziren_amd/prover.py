@@ -245,9 +245,9 @@ class Context:
     def tracegen_syscall(self, events: np.ndarray, precompile: bool, fixed_log2_rows: int = -1, blu: "ByteLookups" = None) -> DeviceMatrix:
         """`generate_trace` of the SyscallCore / SyscallPrecompile tables on the device (zkm_tracegen_syscall); dtype events.SYSCALL_EVENT."""
         from . import events as _ev
-        ev = np.ascontiguousarray(events, dtype=_ev.SYSCALL_EVENT)
+        p_ev, n_ev, _keep = _evptr(events, _ev.SYSCALL_EVENT)      # a DeviceEvents: SyscallCore's filter runs on the device
         h = C.c_void_p()
-        lib.check(lib.load().zkm_tracegen_syscall(self.h, C.c_void_p(ev.ctypes.data if len(ev) else None), C.c_size_t(len(ev)), C.c_int(int(precompile)),
+        lib.check(lib.load().zkm_tracegen_syscall(self.h, p_ev, C.c_size_t(n_ev), C.c_int(int(precompile)),
                                                   C.c_int(fixed_log2_rows), blu.h if blu is not None else None, C.byref(h)))
         return self._born(h)
 
@@ -427,9 +427,9 @@ class Context:
         """`generate_trace` of the Global chip on the device (zkm_tracegen_global); dtype miniexec.GLOBAL_LOOKUP_EVENT. The
         U16Range lookups of the messages' first words are counted into `blu`."""
         from . import miniexec as _m
-        ev = np.ascontiguousarray(events, dtype=_m.GLOBAL_LOOKUP_EVENT)
+        p_ev, n_ev, _keep = _evptr(events, _m.GLOBAL_LOOKUP_EVENT)
         h = C.c_void_p()
-        lib.check(lib.load().zkm_tracegen_global(self.h, C.c_void_p(ev.ctypes.data if len(ev) else None), C.c_size_t(len(ev)),
+        lib.check(lib.load().zkm_tracegen_global(self.h, p_ev, C.c_size_t(n_ev),
                                                  C.c_int(fixed_log2_rows), blu.h if blu is not None else None, C.byref(h)))
         return self._born(h)
 
