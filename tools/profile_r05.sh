@@ -1,0 +1,54 @@
+#!/bin/bash
+# Round-5 profiles of the benchmark command (default workload: the shaped fibonacci shard, tag fibs21), run on the GPU box from the repo root:
+#   gpurun --timeout 1500 -- 'bash tools/profile_r05.sh [quick] [syn]'
+# 1. the default line unprofiled                                                                    -> r05_fibs21_bench.json
+# 2. rocprofv3 --kernel-trace --stats of the resident leg (bench.py --resident), overlap on and off (per-kernel average durations, gaps)      -> r05_fibs21_kernel_stats.csv, r05_fibs21_idle_gaps.json
+# 3. PMC passes (separate runs, counters only): SQ wave-cycle breakdown + VALU busy (two passes)    -> r05_fibs21_sq_counters.csv
+#    FETCH_SIZE, WRITE_SIZE -> HBM bytes per launch                                                 -> r05_fibs21_hbm_traffic.json
+#    SQ_INSTS_VALU over the Poseidon2 microbenchmark                                                -> r05_poseidon2_isa.json
+# `quick` stops after the SQ passes; `syn` repeats 2-3 for --workload syn (tag syn22).
+set -u
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$R/gpurun_out/r05prof
+rm -rf "$OUT"; mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+db() { find "$1" -name '*_results.db' | head -1; }
+QUICK=0; SYN=0
+for a in "$@"; do [ "$a" = quick ] && QUICK=1; [ "$a" = syn ] && SYN=1; done
+python $R/bench.py > $OUT/r05_fibs21_bench.json 2> $OUT/bench.err          # the default line: the claim queue from events, two lanes + the resident leg
+profile() {   # tag, extra bench args
+  local T=$1; shift
+  local B="python $R/bench.py --resident $* --no-cpu-baseline --no-extra"      # the resident one-lane leg: what the per-kernel figures of the line are quoted on
+  cd /tmp
+  rocprofv3 --kernel-trace --stats -d $OUT/stats_$T -o stats -- $B --steps 5 --warmup 1 > $OUT/r05_${T}_bench_profiled.json 2> $OUT/stats_$T.err
+  # the same with the side-stream LDE overlap off: every kernel alone on the main stream (the mode of the line's kernels_ms table and of the PMC passes, which serialise)
+  ZKM_LDE_OVERLAP=0 rocprofv3 --kernel-trace --stats -d $OUT/statsser_$T -o stats -- $B --steps 5 --warmup 1 > $OUT/r05_${T}_bench_profiled_serialised.json 2> $OUT/statsser_$T.err
+  # counter passes: 1 warm-up + 1 timed proof, no per-kernel timing pass (2 proofs per run)
+  local P="$B --steps 1 --warmup 1 --kernel-timing 0"
+  rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS -d $OUT/sq_$T -o sq -- $P > /dev/null 2> $OUT/sq_$T.err
+  rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_VALU SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT -d $OUT/sq2_$T -o sq2 -- $P > /dev/null 2> $OUT/sq2_$T.err
+  cd $R
+  python tools/rocprof_summary.py "$(db $OUT/stats_$T)" $OUT/r05_${T}_kernel_stats.csv
+  python tools/rocprof_summary.py "$(db $OUT/statsser_$T)" $OUT/r05_${T}_kernel_stats_serialised.csv
+  python tools/rocprof_gaps.py "$(db $OUT/stats_$T)" $OUT/r05_${T}_idle_gaps.json > $OUT/gaps_$T.txt
+  python tools/pmc_sq_summary.py "$(db $OUT/sq_$T)" $OUT/r05_${T}_sq_counters.csv "$(db $OUT/sq2_$T)"
+  if [ $QUICK = 0 ]; then
+    cd /tmp
+    rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/f_$T -o f -- $P > /dev/null 2> $OUT/f_$T.err
+    rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/w_$T -o w -- $P > /dev/null 2> $OUT/w_$T.err
+    cd $R
+    python tools/pmc_traffic.py "$(db $OUT/f_$T)" "$(db $OUT/w_$T)" $OUT/r05_${T}_hbm_traffic.json "$T" 2
+  fi
+  find $OUT -name '*.db' -delete
+  rm -rf $OUT/stats_$T $OUT/statsser_$T $OUT/sq_$T $OUT/sq2_$T $OUT/f_$T $OUT/w_$T
+}
+profile fibs21
+[ $SYN = 1 ] && profile syn22 --workload syn
+if [ $QUICK = 0 ]; then
+  cd /tmp
+  rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_WAVES -d $OUT/p2 -o p2 -- $R/tools/ubench_p2 gpu > $OUT/r05_ubench_poseidon2_int_vs_f64.txt 2> $OUT/p2.err
+  cd $R
+  python tools/pmc_poseidon2.py "$(db $OUT/p2)" $OUT/r05_poseidon2_isa.json
+  find $OUT -name '*.db' -delete; rm -rf $OUT/p2
+fi
+ls -la $OUT

@@ -30,13 +30,14 @@ PART_INSTRS = int(os.environ.get("ZKM_Q_PART", "6000"))              # a long pr
 SINGLE_KERNEL_INSTRS = int(os.environ.get("ZKM_Q_SINGLE", "12000"))  # ... when it is longer than this (KeccakSponge: 114 324; every other recorded chip is below 10 000)
 
 
-TEMPLATE_VERSION = b"8"  # bump when emit_source changes
+TEMPLATE_VERSION = b"9"  # bump when emit_source changes
 
 
 # Experiment knobs (tools/ab_quotient.sh; unset in production): waves per SIMD the compiler is told to fit the kernel into, and where a
 # program is cut into several kernels. They are part of the cache key.
 Q_WAVES = int(os.environ.get("ZKM_Q_WAVES", "0"))
 Q_AHEAD = int(os.environ.get("ZKM_Q_AHEAD", "1"))           # how many groups ahead
+Q_TILE = int(os.environ.get("ZKM_Q_TILE", "1"))           # quotient_args.cuh: 1 = the 8 x 32 tile with staged vector stores, 0 = rounds 2-4's two half-tiles (A/B only)
 Q_PREFETCH = int(os.environ.get("ZKM_Q_PREFETCH", "4"))     # words of trace loads per group, issued Q_AHEAD groups ahead of their use (0: the compiler's
                                                             # order, which sinks every load to its first use; round 4: 5.35 -> 4.55 ms on the benchmarked shard)
 
@@ -46,7 +47,7 @@ def _template_key() -> bytes:
     the shared prologue (quotient_args.cuh) or the field arithmetic (kb31.cuh) can never leave a stale kernel behind."""
     h = hashlib.sha256(TEMPLATE_VERSION)
     h.update(f"{Q_WAVES},{SINGLE_KERNEL_INSTRS},{PART_INSTRS}".encode())
-    h.update(f",pf{Q_PREFETCH},{Q_AHEAD}".encode())
+    h.update(f",pf{Q_PREFETCH},{Q_AHEAD},tile{Q_TILE}".encode())
     for name in ("quotient_args.cuh", "kb31.cuh"):
         with open(os.path.join(CSRC, name), "rb") as f:
             h.update(f.read())
@@ -221,6 +222,7 @@ def _kernel_source(lines, n_instr, n_constraints, accumulate=False, part="") -> 
     body = "\n  ".join(lines)
     return f"""// GENERATED by ziren_amd/codegen.py from a chip's constraint bytecode ({n_instr} instructions,
 // {n_constraints} constraints{part}). Same arithmetic as stark::quotient_kernel (the interpreter), values in VGPRs.
+{"" if Q_TILE == 1 else f"#define ZKM_Q_TILE {Q_TILE}"}
 #include "quotient_args.cuh"
 
 extern "C" __global__ {f"__attribute__((amdgpu_waves_per_eu({Q_WAVES},{Q_WAVES}))) " if Q_WAVES else ""}__launch_bounds__({BLOCK}) void {KERNEL_NAME}(stark::QuotientArgs a) {{

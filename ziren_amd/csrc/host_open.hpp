@@ -472,9 +472,17 @@ struct ShardOpening {
         } else {
           ej.kind = m.n_points > 1 ? 3 : 2;
         }
+        ej.lead = 0;
+        if (ej.split >= 8 && ej.groups > 1) {
+          // row slices dealt to XCDs whole (open.cuh, EVAL_XCD_AWARE): a multiple of 8 slices, the job's first block on a multiple of 8
+          ej.split &= ~7;
+          const uint32_t lead = (8 - eblk % 8) % 8;
+          ej.lead = open::EVAL_XCD_AWARE | lead;
+          eblk += lead;
+        }
         ej.partials = (E4*)salloc((size_t)ej.split * m.width * 2 * sizeof(E4));
         eblk += (uint32_t)ej.groups * (uint32_t)ej.split;
-        ej.blk_end = eblk; ej.pad = 0;
+        ej.blk_end = eblk;
         ejobs.push_back(ej);
         ebytes += 4.0 * m.n * m.width + 16.0 * m.n;
         sblk += (uint32_t)(m.width * 2);

@@ -26,8 +26,10 @@ struct EvalJob {
   const uint32_t* mat; const kb::E4* weights; kb::E4* partials;
   size_t n;
   int width, groups, split, kind;   // kind 0: one point, 1: two points, 2: small one point, 3: small two points
-  uint32_t blk_end, pad;
+  uint32_t blk_end;
+  uint32_t lead;                    // XCD_AWARE | leading blocks of the job's range that do nothing (they align its first block to a multiple of 8)
 };
+constexpr uint32_t EVAL_XCD_AWARE = 0x100;
 struct SumJob { const kb::E4* partials; int split, count; uint32_t out0, blk_end; };
 template <class J>
 __device__ __forceinline__ const J& find_job(const J* __restrict__ jobs, uint32_t& local) {
@@ -173,7 +175,19 @@ __global__ __launch_bounds__(THREADS) void eval_columns_batch(const EvalJob* __r
   __shared__ uint32_t red[EVAL_WORDS * THREADS + EVAL_WORDS * 8];
   uint32_t local;
   const EvalJob& j = find_job(jobs, local);
-  const uint32_t bx = local % (uint32_t)j.groups, by = local / (uint32_t)j.groups;
+  uint32_t bx = local % (uint32_t)j.groups, by = local / (uint32_t)j.groups;
+  if (j.lead & EVAL_XCD_AWARE) {
+    // Every column group of a row slice reads the same weights (16 bytes per row against 4 per column and row): the `groups` blocks of a
+    // slice are dealt to ONE XCD, back to back in its queue, so that the slice's weights come through HBM once and out of that XCD's L2
+    // for the other groups. Workgroups go round-robin to the 8 XCDs: the job's first block is aligned to a multiple of 8 (`lead` idle
+    // blocks), split is a multiple of 8, and block 8 s + x of the job is the s-th block of XCD x: slice (s / groups) * 8 + x, group s % groups.
+    const uint32_t lead = j.lead & 0xff;
+    if (local < lead) return;
+    local -= lead;
+    const uint32_t x = local & 7, s = local >> 3;
+    bx = s % (uint32_t)j.groups;
+    by = (s / (uint32_t)j.groups) * 8 + x;
+  }
   if (j.kind == 0) eval_columns_body<false>(j.mat, j.n, j.width, j.weights, j.partials, red, bx, by, (uint32_t)j.split);
   else if (j.kind == 1) eval_columns_body<true>(j.mat, j.n, j.width, j.weights, j.partials, red, bx, by, (uint32_t)j.split);
   else eval_columns_small_body(j.mat, j.n, j.width, j.weights, j.kind == 3, j.partials, red, bx);
