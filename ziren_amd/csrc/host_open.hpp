@@ -367,7 +367,7 @@ struct ShardOpening {
     int bd = 256;
     while (per_thread * bd > 64 * 1024 && bd > 64) bd >>= 1;
     size_t lds = per_thread * bd;
-    if (lds > 160 * 1024) throw std::runtime_error(std::string("constraint program of chip ") + d->name + " needs too many registers");
+    if (lds > 152 * 1024) throw std::runtime_error(std::string("constraint program of chip ") + d->name + " needs too many registers");
     double qbytes = 4.0 * Q * (d->main_width + d->prep_width + 4.0 * c.perm_ext_w) + 16.0 * Q;
     auto fit = d->program_len ? ctx->quotient_fns.find(fnv1a(d->program, d->program_len)) : ctx->quotient_fns.end();
     const bool special = fit != ctx->quotient_fns.end();
