@@ -165,6 +165,37 @@ def test_gpu_generated_permutation_kernels_equal_the_generic_one_and_the_oracle(
         special.close()
 
 
+def test_pair_row_loads_puts_a_columns_two_reads_together_and_loses_nothing():
+    """codegen.pair_row_loads: every statement exactly once, every value declared before its use, every column that is read at both rows
+    has its two loads adjacent, and the next row's running sum is formed as the loads come (no pile of hoisted values left waiting)."""
+    from ziren_amd import chips
+    for prog in (chips.record_cpu_chip(10).program, chips.record_divrem_chip(10).program, chips.record_global_chip(10).program, shared_term_program()):
+        lines, meta = codegen._ssa_lines(np.asarray(prog, dtype=np.uint32))
+        out, meta2 = codegen.pair_row_loads(lines, meta)
+        assert sorted(out) == sorted(lines) and len(meta2) == len(out)
+        seen = set()
+        for ln, (v, uses) in zip(out, meta2):
+            assert all(u in seen for u in uses), ln
+            if v is not None:
+                seen.add(v)
+        keys = [codegen._load_key(ln) for ln in out]
+        where = {k: i for i, k in enumerate(keys) if k is not None}
+        pairs = [(i, where[(k[0], k[1], not k[2])]) for i, k in enumerate(keys) if k is not None and (k[0], k[1], not k[2]) in where]
+        assert all(abs(i - j) == 1 for i, j in pairs)
+        _check_defined_before_use("kb::FoldAcc acc;\n" + "\n".join(out))
+        # the hoisted values do not pile up: at no point are more than a few values that come from hoisted `next` loads waiting for their reader
+        last_use = {}
+        for i, (v, uses) in enumerate(meta2):
+            for u in uses:
+                last_use[u] = i
+        hoisted = [meta2[j][0] for i, j in pairs if j == i + 1 and keys[j][2]]
+        if hoisted:
+            defs = {v: i for i, (v, _) in enumerate(meta2) if v is not None}
+            peak = max(sum(1 for h in hoisted if defs[h] <= t < last_use.get(h, defs[h])) for t in range(len(out)))
+            n_perm = sum(1 for k in keys if k is not None and k[0] == "perm" and k[2])
+            assert peak <= max(8, len(hoisted) - n_perm + 3), (peak, len(hoisted), n_perm)
+
+
 def test_prefetch_order_moves_loads_up_and_loses_nothing():
     """codegen.prefetch_order: every statement of the program appears exactly once, no load moves down, every value is still declared
     before its first use, and group k + 1's loads sit in front of group k's first use."""

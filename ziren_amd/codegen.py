@@ -30,7 +30,7 @@ PART_INSTRS = int(os.environ.get("ZKM_Q_PART", "6000"))              # a long pr
 SINGLE_KERNEL_INSTRS = int(os.environ.get("ZKM_Q_SINGLE", "12000"))  # ... when it is longer than this (KeccakSponge: 114 324; every other recorded chip is below 10 000)
 
 
-TEMPLATE_VERSION = b"9"  # bump when emit_source changes
+TEMPLATE_VERSION = b"10"  # bump when emit_source changes
 
 
 # Experiment knobs (tools/ab_quotient.sh; unset in production): waves per SIMD the compiler is told to fit the kernel into, and where a
@@ -38,6 +38,7 @@ TEMPLATE_VERSION = b"9"  # bump when emit_source changes
 Q_WAVES = int(os.environ.get("ZKM_Q_WAVES", "0"))
 Q_AHEAD = int(os.environ.get("ZKM_Q_AHEAD", "1"))           # how many groups ahead
 Q_TILE = int(os.environ.get("ZKM_Q_TILE", "1"))           # quotient_args.cuh: 1 = the 8 x 32 tile with staged vector stores, 0 = rounds 2-4's two half-tiles (A/B only)
+Q_PAIR = int(os.environ.get("ZKM_Q_PAIR", "1"))           # pair_row_loads: a column's `next` load right behind its `local` load (0: where the program has them; A/B only)
 Q_PREFETCH = int(os.environ.get("ZKM_Q_PREFETCH", "4"))     # words of trace loads per group, issued Q_AHEAD groups ahead of their use (0: the compiler's
                                                             # order, which sinks every load to its first use; round 4: 5.35 -> 4.55 ms on the benchmarked shard)
 
@@ -47,7 +48,7 @@ def _template_key() -> bytes:
     the shared prologue (quotient_args.cuh) or the field arithmetic (kb31.cuh) can never leave a stale kernel behind."""
     h = hashlib.sha256(TEMPLATE_VERSION)
     h.update(f"{Q_WAVES},{SINGLE_KERNEL_INSTRS},{PART_INSTRS}".encode())
-    h.update(f",pf{Q_PREFETCH},{Q_AHEAD},tile{Q_TILE}".encode())
+    h.update(f",pf{Q_PREFETCH},{Q_AHEAD},tile{Q_TILE},pair{Q_PAIR}".encode())
     for name in ("quotient_args.cuh", "kb31.cuh"):
         with open(os.path.join(CSRC, name), "rb") as f:
             h.update(f.read())
@@ -274,10 +275,95 @@ def prefetch_order(lines, words_per_group: int):
     return out
 
 
+def _load_key(line: str):
+    """(array, column, is_next) of a trace-load statement, None for anything else."""
+    import re
+    m = re.search(r"= a\.(main|prep)_lde\[\(size_t\)(\d+) \* a\.\w+_stride \+ (q\.pn|q\.p)\];", line)
+    if m:
+        return m.group(1), int(m.group(2)), m.group(3) == "q.pn"
+    m = re.search(r"a\.perm_lde \+ \(size_t\)(\d+) \* a\.perm_stride \+ (q\.pn|q\.p)\)\[0\]", line)
+    if m:
+        return "perm", int(m.group(1)), m.group(2) == "q.pn"
+    return None
+
+
+def pair_row_loads(lines, meta):
+    """The same statements with every column's two row loads next to each other. A column read at `next` as well as at `local` (every
+    permutation column: the running-sum constraint adds up the whole next row, permutation.rs eval; a few main columns) is read twice
+    through the same cache lines — once by the thread that owns the row, once by the thread that owns the row before it, which the
+    quotient tile puts in the same wavefront or block (quotient_args.cuh). That only saves the second trip to HBM if the two reads are
+    close in TIME: in program order the `local` reads sit with the LogUp constraints and the `next` reads thousands of instructions
+    later with the cumulative-sum constraint, by when the line has left the L2 (round 5: 10.1 GB read per proof for 7.8 GB of rows,
+    whatever the tile). So the second load of a pair is moved up behind the first; and so that the hoisted values do not sit in
+    registers until the program reaches them (Cpu: 44 permutation words), every statement that only combines hoisted values — the
+    running sum of the next row, one extension addition per column — is moved up with them: four registers stay live instead."""
+    keys = [_load_key(ln) for ln in lines]
+    where = {k: i for i, k in enumerate(keys) if k is not None}
+    partner = {}
+    for i, k in enumerate(keys):
+        if k is None:
+            continue
+        j = where.get((k[0], k[1], not k[2]))
+        if j is not None and j > i:
+            partner[i] = j
+    if not partner:
+        return list(lines), list(meta)
+    hoisted_stmt = set(partner.values())
+    tainted = set()                 # values that depend on hoisted loads only
+    defined = set()
+    emitted = [False] * len(lines)
+    order = []
+    uniform_like = set()            # values with no operands that are not loads (constants, challenges, selectors): free to combine with
+
+    def emit(i):
+        emitted[i] = True
+        order.append(i)
+        v = meta[i][0]
+        if v is not None:
+            defined.add(v)
+
+    # consumers of each value, in program order
+    readers = {}
+    for i, (v, uses) in enumerate(meta):
+        for u in uses:
+            readers.setdefault(u, []).append(i)
+    for i, (v, uses) in enumerate(meta):
+        if v is not None and not uses and keys[i] is None:
+            uniform_like.add(v)
+
+    def close_over(start_values):
+        """Statements (not asserts) all of whose operands are hoisted-derived or operand-free values already defined: move them up now."""
+        work = list(start_values)
+        while work:
+            x = work.pop()
+            for r in readers.get(x, ()):
+                v, uses = meta[r]
+                if emitted[r] or v is None:
+                    continue
+                if all((u in tainted) or (u in uniform_like and u in defined) for u in uses) and any(u in tainted for u in uses):
+                    emit(r)
+                    tainted.add(v)
+                    work.append(v)
+
+    for i in range(len(lines)):
+        if emitted[i]:
+            continue
+        emit(i)
+        j = partner.get(i)
+        if j is not None and not emitted[j]:
+            emit(j)
+            tainted.add(meta[j][0])
+            close_over([meta[j][0]])
+    assert len(order) == len(lines)
+    return [lines[i] for i in order], [meta[i] for i in order]
+
+
 def emit_source(program: np.ndarray) -> str:
     """Straight-line HIP for one chip, one kernel."""
     prog = np.asarray(program, dtype=np.uint32)
-    lines, _ = _ssa_lines(prog)
+    lines, meta = _ssa_lines(prog)
+    if Q_PAIR:
+        lines, _ = pair_row_loads(lines, meta)
     if Q_PREFETCH:
         lines = prefetch_order(lines, Q_PREFETCH)
     return _kernel_source(lines, int(prog[0]), int(prog[2]))
@@ -291,6 +377,8 @@ def emit_part_sources(program: np.ndarray):
     it is recomputed by the later kernel (the statements that define it, transitively, are put in front of the part)."""
     prog = np.asarray(program, dtype=np.uint32)
     lines, meta = _ssa_lines(prog)
+    if Q_PAIR:
+        lines, meta = pair_row_loads(lines, meta)
     defined_at = {v: k for k, (v, _) in enumerate(meta) if v is not None}
     cuts, start = [], 0
     for k, (v, _) in enumerate(meta):

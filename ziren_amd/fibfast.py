@@ -356,7 +356,8 @@ class DeviceShard:
         call — every generator queued behind the copy of its events, one synchronisation; False: one entry point per chip, as the
         chips' own tests call them (same traces: tests/test_fibfast.py)."""
         pre = prefetched or {}
-        if one_call:
+        from . import lib as _lib
+        if one_call and hasattr(_lib.load(), "zkm_tracegen_shard"):      # (an older build under A/B comparison, ZKM_HIP_LIB, has the per-chip calls only)
             items = []
             for name, ev, lh, _ in self.work:
                 ev = pre.get("SyscallInstrs" if name == "SyscallCore" else name, ev)

@@ -387,6 +387,8 @@ def _execute(n_cycles: int, seed: int = 1, shard: int = 1, pc_base: int = 0x1000
         # ---- pick the instruction at pc (the program is written as it runs)
         if given is not None:
             if pc not in program:
+                if len(rec.cpu) or done_shards:
+                    break           # the run is done when the pc leaves the program (executor.rs:2172-2176), HALT or not: simple_program() ends so
                 raise RuntimeError(f"miniexec: pc {pc:#x} is outside the program")
             ins = program[pc]
         elif queued and not delay_slot and pending_jump_reg is None:
