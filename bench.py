@@ -621,6 +621,10 @@ class FibQueueLane:
         self.ctx = prover.Context(device)
         self.hp, self.pk, self.ch0 = self.wls[0].setup(self.ctx, fri, specialize)       # one program, one shape: one key for every shard
         lib.load().zkm_ctx_set_kernel_timing(self.ctx.h, C.c_int(0))
+        if hasattr(lib.load(), "zkm_ctx_set_host_wait") and os.environ.get("ZKM_BENCH_LANE_WAIT", "blocking") == "blocking":
+            # a farm lane sleeps while it waits for its GPU work: with two lanes per GPU the throughput is that of spinning lanes
+            # (profiles/r05_ab_host_wait.txt) at 1.2 host cores per rank instead of 3 — 8 ranks fit a 16-CPU host
+            lib.load().zkm_ctx_set_host_wait(self.ctx.h, C.c_int(1))
         if share is None:
             for w in self.wls:
                 w.prep_host, w.pc_start, w.zero_digest = self.wls[0].prep_host, self.wls[0].pc_start, self.wls[0].zero_digest     # one program: one key
@@ -713,6 +717,7 @@ def farm_main(args, farm, fri):
     farm.barrier()
     elapsed = farm.max_over_ranks(time.perf_counter() - t0)
     cpu_s = time.process_time() - cpu0
+    wall_local = time.perf_counter() - t0
     t_timed = time.perf_counter()
     mine = float(np.mean(farm.host_ms)) if farm.host_ms else 0.0
     slowest = farm.max_over_ranks(mine)
@@ -757,7 +762,10 @@ def farm_main(args, farm, fri):
                        "shards_in_flight_per_gpu": M, "ranks_in_process_group": ranks_in_group, "backend": backend},
             "host_ms_per_shard": {"rank0_mean": round(mine, 3), "max_over_ranks_of_means": round(slowest, 3)},
             "host_cpu_s_per_shard": {"rank0": round(cpu_per_shard, 4), "max_over_ranks": round(cpu_per_shard_max, 4),
-                                     "note": "process CPU seconds (all threads: the lanes' Python + ctypes, root polling) per shard this rank proved, timed region only"},
+                                     "cores_busy_rank0": round(cpu_s / max(wall_local, 1e-9), 2),
+                                     "lane_threads_cores_rank0": [round(c / max(wall_local, 1e-9), 2) for c in getattr(farm, "lane_cpu_s", [])],
+                                     "other_threads_cores_rank0": round((cpu_s - sum(getattr(farm, "lane_cpu_s", []))) / max(wall_local, 1e-9), 2),
+                                     "note": "process CPU seconds (all threads: the lanes' Python + ctypes, root polling, the HIP runtime's own threads) per shard this rank proved, timed region only"},
             "event_bytes_per_shard": lane.event_bytes,
             "h2d_GBps_per_rank": round(lane.event_bytes * len(ids) / elapsed / 1e9, 2),      # rank 0's events over the timed region: what its PCIe link carried
             "shards_proved": int(proved), "shards_proved_by_rank0": len(ids), "fewest_shards_on_a_rank": int(fewest), "lib_digest": lib_digest})
@@ -783,6 +791,8 @@ def farm_extras(args, fri, lane, lanes, line, world, elapsed, n_shards):
         l.ctx.trim()                    # the other lanes' pools go back to the driver: the legs below run on the first lane's context
     alg = synth.shard_algorithmic_bytes(wl)
     steps = max(3, min(args.steps, 10))
+    if hasattr(L, "zkm_ctx_set_host_wait"):
+        L.zkm_ctx_set_host_wait(ctx.h, C.c_int(0))          # one lane alone: the spinning wait (lowest latency), as in rounds 1-4
     traces = wl.resident_traces(ctx)            # inputs resident in HBM before timing
     leg = resident_leg(_LocalTimer(ctx), wl, hp, pk, ch0, traces, steps, 2, args.kernel_timing)
     verify_or_die(wl, fri, ch0, leg["proof"], wl.tag + " resident")

@@ -156,6 +156,12 @@ void zkm_ctx_set_kernel_timing_only(zkm_ctx* ctx, const char* name);
  * off: every kernel of a proof runs alone on the main stream, so per-kernel HIP-event durations add up to the proof's busy time
  * (a measurement mode: the proof is the same words, ~0.7 ms slower). The environment's ZKM_LDE_OVERLAP=0 sets the default to off. */
 void zkm_ctx_set_lde_overlap(zkm_ctx* ctx, int on);
+/* How the calling thread waits for this context's GPU work. 0 (default): it spins (hipStreamSynchronize, and the FRI layer roots are
+ * watched arriving in page-locked memory) — lowest latency, one host core per context for the length of a proof. 1: it sleeps on an
+ * interrupt-backed event — about a millisecond more per proof for a context alone, nothing measurable when two contexts share a GPU,
+ * a tenth of the CPU time: what a rank of a many-GPU host with few cores per GPU wants (the reference's GPU opts run one prover thread
+ * per device too, crates/stark/src/opts.rs:83-110). The environment's ZKM_HOST_WAIT=blocking makes 1 the default. */
+void zkm_ctx_set_host_wait(zkm_ctx* ctx, int blocking);
 /* Register a chip-specialised quotient kernel: a gfx950 code object exporting
  * `zkm_quotient_specialized(stark::QuotientArgs)` generated from exactly these program words
  * (ziren_amd/codegen.py; the Rust shim does this once per chip AIR). zkm_open uses it for chips whose

@@ -191,7 +191,7 @@ int zkm_tracegen_flat(zkm_ctx* ctx, const uint32_t* words, size_t n_words, size_
     hipLaunchKernelGGL(open::transpose_slab, dim3(div_up(width, 32), div_up(height, 32)), dim3(32, 8), 0, ctx->stream,
                        (const uint32_t*)stage, m->d, height, width, (size_t)0, height);
     LAUNCH_CHECK();
-    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    ctx->sync(ctx->stream);
   } catch (...) {
     if (stage) ctx->release(stage);
     if (m->d) ctx->release(m->d);
@@ -305,7 +305,7 @@ int zkm_tracegen_program(zkm_ctx* ctx, const zkm_instruction* program, size_t n_
     hipLaunchKernelGGL(tracegen::program_rows, dim3(div_up(height, 256)), dim3(256), 0, ctx->stream, (const uint32_t*)d_program, n_instr,
                        pc_base, height, m->d);
     LAUNCH_CHECK();
-    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    ctx->sync(ctx->stream);
   } catch (...) {
     if (d_program) ctx->release(d_program);
     if (m->d) ctx->release(m->d);
@@ -339,7 +339,7 @@ int zkm_tracegen_program_mults(zkm_ctx* ctx, const zkm_cpu_event* events, size_t
     }
     hipLaunchKernelGGL(tracegen::counts_to_field, dim3(div_up(height, 256)), dim3(256), 0, ctx->stream, m->d, height);
     LAUNCH_CHECK();
-    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    ctx->sync(ctx->stream);
   } catch (...) {
     if (d_events) ctx->release(d_events);
     if (m->d) ctx->release(m->d);
@@ -456,7 +456,7 @@ static zkm_matrix* enqueue_syscall(TraceBatch& b, const zkm_syscall_event* event
       // no shape: the trace's height is the next power of two of the kept count, which the host has to learn first (one round trip; a
       // shaped shard — the reference's default — fixes the height and takes the branch below)
       const uint32_t* h_n = ctx->download_async(d_n, 1);
-      HIP_CHECK(hipStreamSynchronize(ctx->stream));
+      ctx->sync(ctx->stream);
       return enqueue_rows(b, tracegen::SYSCALL_CORE, nullptr, *h_n, -1, blu, nullptr, d_kept);
     }
     // the kept count stays on the device: the row kernel reads it there
@@ -1250,7 +1250,7 @@ int zkm_tracegen_exp_reverse_bits(zkm_ctx* ctx, const uint32_t* bases, const uin
                          (const uint32_t*)d_bits, (const uint32_t*)d_off, n_events, height, m->d);
       LAUNCH_CHECK();
     }
-    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    ctx->sync(ctx->stream);
   } catch (...) {
     for (uint32_t* p : {d_bases, d_bits, d_off, m->d})
       if (p) ctx->release(p);
@@ -1308,7 +1308,7 @@ int zkm_tracegen_byte_table(zkm_ctx* ctx, zkm_matrix** out) {
     m->d = ctx->alloc_n<uint32_t>(m->h * m->w);
     hipLaunchKernelGGL(tracegen::byte_table, dim3(tracegen::BYTE_ROWS / 256), dim3(256), 0, ctx->stream, m->d);
     LAUNCH_CHECK();
-    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    ctx->sync(ctx->stream);
   } catch (...) {
     if (m->d) ctx->release(m->d);
     delete m;

@@ -132,6 +132,31 @@ struct zkm_ctx {
   bool lde_overlap = !(getenv("ZKM_LDE_OVERLAP") && atoi(getenv("ZKM_LDE_OVERLAP")) == 0);
   bool root_poll = !(getenv("ZKM_ROOT_POLL") && atoi(getenv("ZKM_ROOT_POLL")) == 0);   // wait_root; cleared for good by its first timeout
   int root_spin_before_yield = getenv("ZKM_ROOT_SPIN") ? atoi(getenv("ZKM_ROOT_SPIN")) : 4096;   // wait_root: spins before it starts yielding the core
+  int root_sleep_ns = getenv("ZKM_ROOT_SLEEP_NS") ? atoi(getenv("ZKM_ROOT_SLEEP_NS")) : 0;        // > 0: past the spins it sleeps this long between looks instead of yielding
+  // How this context's host thread waits for its stream (zkm_ctx_set_host_wait; ZKM_HOST_WAIT=blocking sets the default). Spinning
+  // (hipStreamSynchronize, and wait_root watching the root arrive) is the lowest latency and costs a core per lane for the whole proof;
+  // blocking sleeps on an interrupt-backed event: ~1 ms more per proof for one lane alone, nothing measurable with two lanes per GPU (the
+  // other lane's kernels fill the wake-up latency), a tenth of the CPU time. A farm rank runs its lanes blocking.
+  bool host_wait_blocking = getenv("ZKM_HOST_WAIT") && !strcmp(getenv("ZKM_HOST_WAIT"), "blocking");
+  int wait_sleep_ns = getenv("ZKM_WAIT_SLEEP_NS") ? atoi(getenv("ZKM_WAIT_SLEEP_NS")) : 20000;
+  // (an event created with hipEventBlockingSync does not make hipEventSynchronize sleep on this runtime — measured: the lane thread still
+  // burns a core; only the process-wide hipDeviceScheduleBlockingSync does, and that would bind every context of the process. So the
+  // blocking wait is a query of the stream between short sleeps: a few per cent of a core, ~40 us of wake-up latency per wait.)
+  static void sleep_ns(long ns) {
+    static thread_local bool slack_set = false;
+    if (!slack_set) { prctl(PR_SET_TIMERSLACK, 1000UL, 0, 0, 0); slack_set = true; }     // the default 50 us of timer slack would triple a 20 us sleep
+    timespec ts{0, ns};
+    nanosleep(&ts, nullptr);
+  }
+  void sync(hipStream_t s) {
+    if (!host_wait_blocking) { HIP_CHECK(hipStreamSynchronize(s)); return; }
+    for (int i = 0;; i++) {
+      const hipError_t e = hipStreamQuery(s);
+      if (e == hipSuccess) return;
+      if (e != hipErrorNotReady) HIP_CHECK(e);
+      if (i >= 4) sleep_ns(wait_sleep_ns);
+    }
+  }
   // per-chip specialised quotient kernels (ziren_amd/codegen.py), keyed by a hash of the program words
   std::map<uint64_t, std::vector<hipFunction_t>> quotient_fns;   // a program's specialised kernel(s), in launch order
   std::map<uint64_t, hipFunction_t> perm_fns;                    // a lookups blob's specialised permutation-trace kernel (key: perm_key)
@@ -164,8 +189,8 @@ struct zkm_ctx {
     return pin + off;
   }
   void begin_call() {
-    HIP_CHECK(hipStreamSynchronize(stream));
-    HIP_CHECK(hipStreamSynchronize(stream2));
+    sync(stream);
+    sync(stream2);
     cur = stream;
     side_join();               // both streams are idle here: only the deferred scratch is left to hand back
     pin_off = 0;
@@ -248,7 +273,7 @@ struct zkm_ctx {
       HIP_CHECK(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, cur));
     } else {
       HIP_CHECK(hipMemcpyAsync(d, src, bytes, hipMemcpyHostToDevice, cur));
-      HIP_CHECK(hipStreamSynchronize(cur));
+      sync(cur);
     }
     return d;
   }
@@ -299,8 +324,8 @@ struct zkm_ctx {
     mark("begin");
   }
   void end_timing(bool append) {
-    HIP_CHECK(hipStreamSynchronize(stream));
-    HIP_CHECK(hipStreamSynchronize(stream2));
+    sync(stream);
+    sync(stream2);
     if (!append) { timing_names.clear(); timing_ms.clear(); kstats.clear(); }
     for (auto& r : krecs) {
       float ms = 0;

@@ -498,7 +498,7 @@ struct ShardOpening {
       KLAUNCH(ctx, "reduce_partials", 0.0, open::reduce_partials_batch, dim3(sblk), dim3(64), 0, d_s, d_y);
     }
     const E4* hy = ctx->download_async(d_y, std::max<size_t>(total_y, 1));
-    HIP_CHECK(hipStreamSynchronize(st));
+    ctx->sync(st);
     ypos = 0;
     for (auto& r : rounds)
       for (auto& m : r.mats) {
@@ -614,7 +614,7 @@ struct ShardOpening {
   }
   const size_t nfin = (size_t)1 << lf;
   const E4* fin = ctx->download_async((const E4*)f, nfin);
-  HIP_CHECK(hipStreamSynchronize(st));
+  ctx->sync(st);
   for (size_t i = 1; i < nfin; i++)
     if (!kb::eq(fin[i], fin[0])) throw std::runtime_error("FRI final polynomial is not constant (internal error)");
   final_poly = fin[0];
@@ -636,7 +636,7 @@ struct ShardOpening {
       KLAUNCH(ctx, "grind", 0.0, merkle::grind, dim3(div_up(total, merkle::THREADS)), dim3(merkle::THREADS), 0, (const uint32_t*)d_state,
               (const uint32_t*)d_in, (int)ch->num_inputs, (int)fri->proof_of_work_bits, base, total, d_best);
       const unsigned int* h_best = ctx->download_async((const unsigned int*)d_best, 1);
-      HIP_CHECK(hipStreamSynchronize(st));
+      ctx->sync(st);
       found = *h_best;
       if (found != 0xffffffffu) break;
       base += total;
@@ -689,7 +689,7 @@ struct ShardOpening {
       HIP_CHECK(hipMemcpyAsync(gathered_big.data(), d_dst, n_gather * 4, hipMemcpyDeviceToHost, st));
       gathered = gathered_big.data();
     }
-    HIP_CHECK(hipStreamSynchronize(st));
+    ctx->sync(st);
   }
   ctx->mark("open: queries");
   }

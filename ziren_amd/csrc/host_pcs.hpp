@@ -175,7 +175,7 @@ static void wait_root(zkm_ctx* ctx, const uint32_t* h_root, bool pollable) {
       bool all = true;
       for (int k = 0; k < 8; k++) all &= v[k] != 0xffffffffu;
       if (all) { std::atomic_thread_fence(std::memory_order_acquire); return; }
-      if ((spins & 4095) == 4095 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(1)) {
+      if ((ctx->host_wait_blocking || (spins & 4095) == 4095) && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(1)) {
         // the stores of a running kernel are not visible to the host here (non-coherent host memory?): every further root would cost
         // the same second, so this context synchronises from now on, and says so once
         ctx->root_poll = false;
@@ -183,11 +183,14 @@ static void wait_root(zkm_ctx* ctx, const uint32_t* h_root, bool pollable) {
         break;
       }
       // after a short burst of spinning give the core away: a lane's host thread shares its CPUs with the other lanes and ranks of the node
-      if (spins >= ctx->root_spin_before_yield) sched_yield();
-      else cpu_relax();
+      // a blocking context looks at the root between short sleeps; a spinning one spins, and past a burst gives the core away when asked
+      if (ctx->host_wait_blocking) { if (spins >= 64) zkm_ctx::sleep_ns(std::min(ctx->wait_sleep_ns, 10000)); else cpu_relax(); }
+      else if (spins < ctx->root_spin_before_yield) cpu_relax();
+      else if (ctx->root_sleep_ns > 0) zkm_ctx::sleep_ns(ctx->root_sleep_ns);
+      else sched_yield();
     }
   }
-  HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  ctx->sync(ctx->stream);
 }
 
 // MerkleTreeMmcs::commit over column-major matrices of power-of-two heights.
@@ -385,7 +388,7 @@ static zkm_pcs_data* pcs_commit(zkm_ctx* ctx, const std::vector<zkm_matrix>& mat
     for (size_t i = 0; i < mats.size(); i++)
       if (!extended[i]) throw std::runtime_error("pcs_commit: a matrix was not reached by the tree (internal error)");
     const uint32_t* h_root = d->tree.h_root ? d->tree.h_root : ctx->download_async(d->tree.node(d->tree.log_max, 0), 8);
-    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    ctx->sync(ctx->stream);
     d->tree.h_root = nullptr;   // the pinned ring is rewound at the next top-level call
     memcpy(d->root, h_root, 32);
   } catch (...) {

@@ -27,6 +27,8 @@
 #include <vector>
 
 #include <sched.h>
+#include <time.h>
+#include <sys/prctl.h>
 
 #include "kb31.cuh"
 #include "poseidon2.cuh"
@@ -172,7 +174,7 @@ int zkm_ctx_trim(zkm_ctx* ctx) {
   API_BEGIN
   std::lock_guard<std::mutex> lk(ctx->mu);
   HIP_CHECK(hipSetDevice(ctx->device));
-  HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  ctx->sync(ctx->stream);
   for (auto& kv : ctx->free_list) HIP_CHECK(hipFree(kv.second));
   ctx->free_list.clear();
   ctx->drop_coset_tables();
@@ -187,8 +189,8 @@ int zkm_ctx_trim(zkm_ctx* ctx) {
 
 int zkm_ctx_synchronize(zkm_ctx* ctx) {
   API_BEGIN
-  HIP_CHECK(hipStreamSynchronize(ctx->stream));
-  if (ctx->ev_dma) HIP_CHECK(hipStreamSynchronize(ctx->ev_dma));   // and every event prefetch queued so far has landed
+  ctx->sync(ctx->stream);
+  if (ctx->ev_dma) ctx->sync(ctx->ev_dma);   // and every event prefetch queued so far has landed
   API_END
 }
 
@@ -208,6 +210,7 @@ int zkm_ctx_kernel_timings(zkm_ctx* ctx, const char** names, float* ms, uint32_t
 }
 void zkm_ctx_set_kernel_timing(zkm_ctx* ctx, int mode) { ctx->kernel_timing = mode; }
 void zkm_ctx_set_kernel_timing_only(zkm_ctx* ctx, const char* name) { ctx->timing_only = name ? name : ""; ctx->kernel_timing = 3; }
+void zkm_ctx_set_host_wait(zkm_ctx* ctx, int blocking) { std::lock_guard<std::mutex> lk(ctx->mu); ctx->host_wait_blocking = blocking != 0; }
 void zkm_ctx_set_lde_overlap(zkm_ctx* ctx, int on) { std::lock_guard<std::mutex> lk(ctx->mu); ctx->lde_overlap = on != 0; }
 
 int zkm_ctx_register_quotient_kernel(zkm_ctx* ctx, const uint32_t* program, uint32_t program_len, const void* code_object,
@@ -377,7 +380,7 @@ static void download_colmajor(zkm_ctx* ctx, const uint32_t* d, size_t h, size_t 
   hipLaunchKernelGGL(open::transpose, dim3(div_up(h, 32), div_up(w, 32)), dim3(32, 8), 0, ctx->stream, d, stage, w, h);
   LAUNCH_CHECK();
   HIP_CHECK(hipMemcpyAsync(host, stage, h * w * 4, hipMemcpyDeviceToHost, ctx->stream));
-  HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  ctx->sync(ctx->stream);
   ctx->release(stage);
 }
 
@@ -496,7 +499,7 @@ int zkm_pcs_open_batch(zkm_ctx* ctx, const zkm_pcs_data* d, size_t index, uint32
   LAUNCH_CHECK();
   std::vector<uint32_t> host(src.size());
   HIP_CHECK(hipMemcpyAsync(host.data(), d_dst, src.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
-  HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  ctx->sync(ctx->stream);
   memcpy(values_out, host.data(), nvals * 4);
   memcpy(proof_out, host.data() + nvals, (size_t)t.log_max * 32);
   ctx->release((void*)d_src);
@@ -635,7 +638,7 @@ int zkm_poseidon2_permute_batch(zkm_ctx* ctx, uint32_t* states, size_t n) {
   hipLaunchKernelGGL(merkle::permute_batch, dim3(div_up(n, merkle::THREADS)), dim3(merkle::THREADS), 0, ctx->stream, d, n);
   LAUNCH_CHECK();
   HIP_CHECK(hipMemcpyAsync(states, d, n * 64, hipMemcpyDeviceToHost, ctx->stream));
-  HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  ctx->sync(ctx->stream);
   ctx->release(d);
   API_END
 }
@@ -650,7 +653,7 @@ int zkm_poseidon2_permute_batch_int(zkm_ctx* ctx, uint32_t* states, size_t n) {
   hipLaunchKernelGGL(merkle::permute_batch_int, dim3(div_up(n, merkle::THREADS)), dim3(merkle::THREADS), 0, ctx->stream, d, n);
   LAUNCH_CHECK();
   HIP_CHECK(hipMemcpyAsync(states, d, n * 64, hipMemcpyDeviceToHost, ctx->stream));
-  HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  ctx->sync(ctx->stream);
   ctx->release(d);
   API_END
 }
@@ -704,7 +707,7 @@ int zkm_permutation_trace(zkm_ctx* ctx, const zkm_chip_desc* chip, const zkm_mat
       const uint32_t* last = pt->d + (size_t)(c.perm_ext_w - 1) * 4 * c.n;
       for (int e = 0; e < 4; e++) HIP_CHECK(hipMemcpyAsync(local_sum + e, last + (size_t)e * c.n + (c.n - 1), 4, hipMemcpyDeviceToHost, ctx->stream));
     }
-    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    ctx->sync(ctx->stream);
   } catch (...) {
     for (void* p : scratch) ctx->release(p);
     if (pt->d) ctx->release(pt->d);

@@ -157,6 +157,7 @@ class Farm:
         import threading
         lanes = lanes or [(prove, prefetch)]
         results = [None] * len(lanes)
+        lane_cpu = [0.0] * len(lanes)
         errors = []
         primed = getattr(self, "_primed", {}).pop(self._queue_key(queue), None)
         if primed is not None and len(primed) != len(lanes):
@@ -166,6 +167,7 @@ class Farm:
             pv, pf = lanes[j]
             ids, proofs, ms = [], [], []
             results[j] = (ids, proofs, ms)
+            cpu_start = time.thread_time()
             try:
                 if primed is not None:
                     cur, handle = primed[j]
@@ -187,6 +189,8 @@ class Farm:
                     cur, handle = nxt, nxt_handle
             except BaseException as e:  # noqa: BLE001  (re-raised on the calling thread)
                 errors.append(e)
+            finally:
+                lane_cpu[j] = time.thread_time() - cpu_start      # CPU seconds of this lane's host thread (Python, ctypes, waiting inside the library)
 
         try:
             if len(lanes) == 1:
@@ -202,6 +206,7 @@ class Farm:
         if errors:
             raise errors[0]
         self.host_ms = [m for r in results for m in r[2]]
+        self.lane_cpu_s = lane_cpu
         return [i for r in results for i in r[0]], [p for r in results for p in r[1]]
 
     def gather_proofs(self, shard_ids: Sequence[int], proofs: Sequence[np.ndarray], n_shards: int) -> Optional[List[np.ndarray]]:
