@@ -146,6 +146,70 @@ class Device:
         return self.ctx.tracegen_program_mults(cpu, len(prog), pc_base, lh)
 
 
+class _Pending:
+    def __init__(self, i):
+        self.i = i
+
+
+class DeviceOneCall(Device):
+    """Trace provider: the HIP library with a CPU shard's generators queued in ONE call (zkm_tracegen_shard) — what a farm lane does. `trace`
+    hands back placeholders; `flush(chips)` makes the call (optionally from events copied ahead with zkm_events_upload_async, so that
+    nothing is read on the host) and puts the device matrices in their place. Chips the shard call does not cover (the precompiles, the
+    memory tables) go through their own entry points at once, counting into the same byte-lookup table."""
+
+    def __init__(self, ctx, prefetch=False):
+        super().__init__(ctx)
+        self.items, self.prefetch = [], prefetch
+
+    def _defer(self, item):
+        self.items.append(item)
+        return _Pending(len(self.items) - 1)
+
+    def trace(self, what, *a):
+        from ziren_amd import abi
+        if what == "cpu":
+            ev, prog, pc_base, shard, lh = a
+            return self._defer((abi.TG_CPU, ev, lh, {"program": prog, "pc_base": pc_base, "shard": shard}))
+        if what == "alu":
+            return self._defer((abi.TG_ALU, a[1], a[2], {"chip": a[0]}))
+        simple = {"syscall_instrs": abi.TG_SYSCALL_INSTRS, "jump": abi.TG_JUMP, "mov_cond": abi.TG_MOV_COND, "memory_local": abi.TG_MEMORY_LOCAL,
+                  "branch": abi.TG_BRANCH, "memory_instrs": abi.TG_MEMORY_INSTRS, "misc_instrs": abi.TG_MISC_INSTRS, "mul": abi.TG_MUL, "divrem": abi.TG_DIVREM,
+                  "global": abi.TG_GLOBAL}
+        if what in simple:
+            return self._defer((simple[what], a[0], a[1], None))
+        if what == "syscall_table":
+            return self._defer((abi.TG_SYSCALL_PRECOMPILE if a[1] else abi.TG_SYSCALL_CORE, a[0], a[2], None))
+        return super().trace(what, *a)
+
+    def byte_trace(self, alu_streams):
+        from ziren_amd import abi
+        return self._defer((abi.TG_BYTE_MULTS, None, 16, None))
+
+    def program_mults(self, cpu, prog, pc_base, lh):
+        from ziren_amd import abi
+        if not any(it[0] == abi.TG_CPU for it in self.items):
+            return super().program_mults(cpu, prog, pc_base, lh)
+        return self._defer((abi.TG_PROGRAM_MULTS, None, lh, None))
+
+    def flush(self, chip_list):
+        items = self.items
+        held = []
+        if self.prefetch:
+            items = []
+            for kind, ev, lh, extra in self.items:
+                if ev is not None and len(ev):
+                    ev = self.ctx.events_upload_async(np.ascontiguousarray(ev))
+                    held.append(ev)
+                items.append((kind, ev, lh, extra))
+        born = self.ctx.tracegen_shard(items, self.blu) if items else []
+        for d in held:
+            d.free()
+        for c in chip_list:
+            if isinstance(c.trace, _Pending):
+                c.trace = born[c.trace.i]
+        self.items = []
+
+
 def build_shard(src, machine, k, shape=None):
     """The chips shard k includes (MachineAir::included: a chip with no events is left out; Program and Byte are always in) with their
     traces from `src`. Returns the RecordedChips in machine order, Byte and Program last (prep indices 0 and 1 of the key).

@@ -278,6 +278,26 @@ def gpu_prove_machine(hip_ctx, oracle, m, fri):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("prefetch", [False, True])
+def test_gpu_one_call_trace_generation_of_every_shard_kind(hip_ctx, oracle, prefetch):
+    """zkm_tracegen_shard over whole machines (every chip of a CPU shard: jumps, memory and misc instructions, syscalls with their Core table,
+    Global with the syscalls' messages; the deferred shards' syscall tables and Global next to their own entry points): every trace equal
+    to the oracle's rows, from host events and from events copied ahead (nothing read on the host: SyscallCore filtered on the device at
+    the height the shard fixes)."""
+    for m in (M.run_machine(5000, seed=21, shard_cycles=2048, poseidon2_calls=4), M.run_machine(program=fibonacci_program(150), shard_cycles=512)):
+        for k in range(len(m.shards)):
+            ocs = ML.build_shard(ML.Oracle(oracle), m, k)
+            dev = ML.DeviceOneCall(hip_ctx, prefetch)
+            dcs = ML.build_shard(dev, m, k)
+            dev.flush(dcs)
+            assert [c.name for c in dcs] == [c.name for c in ocs]
+            for d, o in zip(dcs, ocs):
+                assert np.array_equal(d.trace.to_host(), o.trace), (m.shards[k].kind, k, d.name, prefetch)
+                d.trace.free()
+            dev.blu.free()
+
+
+@pytest.mark.gpu
 def test_gpu_machine_with_precompile_proves_and_verifies(hip_ctx, oracle):
     """BASELINE config 4's shape at test size (a program with precompile calls, several shards): CPU shards, the precompile shard and the
     memory shard proven on the GPU from device-born traces, bit-identical to the oracle's proofs, accepted by the restated machine
