@@ -750,6 +750,10 @@ void zkm_host_ext_mul(const uint32_t a[4], const uint32_t b[4], uint32_t out[4])
 void zkm_host_ext_inv(const uint32_t a[4], uint32_t out[4]);
 uint32_t zkm_host_field_mul(uint32_t a, uint32_t b);
 uint32_t zkm_host_field_inv(uint32_t a);
+/* Host build of the reduction the generated quotient / permutation kernels finish a linear form with (csrc/kb31.cuh reduce96_bounded):
+ * (hi 2^64 + lo) / 2^32 mod p in [0, p), valid for hi 2^64 + lo < 127 * 2^63. Test hook (tests/test_host_abi.py holds it against
+ * Python integers at the bound's edges). */
+uint32_t zkm_host_reduce96_bounded(uint32_t hi, uint64_t lo);
 uint32_t zkm_host_two_adic_generator(uint32_t bits);
 
 #ifdef __cplusplus

@@ -285,3 +285,26 @@ def test_recorder_counts_and_widths():
     for c in sh.chips:
         if c.name in costs:
             assert c.main_width + 4 * c.perm_ext_width + 8 == costs[c.name]
+
+
+def test_bounded_reduction_of_linear_forms_is_exact():
+    """csrc/kb31.cuh reduce96_bounded — what the generated quotient / permutation kernels finish a linear form with — on the host build,
+    against Python integers: (hi 2^64 + lo) / 2^32 mod p for sums up to the documented bound 127 * 2^63, at its edges (the largest sum,
+    sums whose Montgomery step comes out negative, quotients -1, 0 and 126) and on what the forms are made of (products of reduced
+    words, a constant in the middle word)."""
+    L = lib.load()
+    P = F.P
+    rinv = pow(1 << 32, -1, P)
+    rng = np.random.default_rng(17)
+    top = 127 << 63
+    xs = [0, 1, P - 1, P, (1 << 32) - 1, 1 << 32, (P - 1) << 32, ((P - 1) << 32) + (1 << 32) - 1, (1 << 64) - 1, 1 << 64, top - 1, top - P, top - (1 << 32)]
+    xs += [126 * (P - 1) ** 2, 126 * (P - 1) ** 2 + ((P - 1) << 32), 4 * (P - 1) ** 2, 2 * (P - 1) ** 2 + ((P - 1) << 32)]
+    xs += [int(rng.integers(0, 1 << 32)) for _ in range(50)]                                                # a low word only: the step is negative
+    xs += [(int(rng.integers(0, 127)) << 63) + int(rng.integers(0, 1 << 63)) for _ in range(2000)]          # anywhere below the bound
+    xs += [sum(int(a) * int(b) for a, b in zip(rng.integers(0, P, t), rng.integers(0, P, t))) + (int(rng.integers(0, P)) << 32)
+           for t in list(range(1, 126)) * 4]                                                                # forms as the generator builds them
+    xs += [k * (1 << 63) + d for k in (1, 2, 63, 125, 126) for d in (-1, 0, 1)]
+    for x in xs:
+        assert 0 <= x < top
+        got = L.zkm_host_reduce96_bounded(x >> 64, x & ((1 << 64) - 1))
+        assert got == x * rinv % P, hex(x)

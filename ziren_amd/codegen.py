@@ -30,7 +30,7 @@ PART_INSTRS = int(os.environ.get("ZKM_Q_PART", "6000"))              # a long pr
 SINGLE_KERNEL_INSTRS = int(os.environ.get("ZKM_Q_SINGLE", "12000"))  # ... when it is longer than this (KeccakSponge: 114 324; every other recorded chip is below 10 000)
 
 
-TEMPLATE_VERSION = b"10"  # bump when emit_source changes
+TEMPLATE_VERSION = b"11"  # bump when emit_source changes
 
 
 # Experiment knobs (tools/ab_quotient.sh; unset in production): waves per SIMD the compiler is told to fit the kernel into, and where a
@@ -48,7 +48,7 @@ def _template_key() -> bytes:
     the shared prologue (quotient_args.cuh) or the field arithmetic (kb31.cuh) can never leave a stale kernel behind."""
     h = hashlib.sha256(TEMPLATE_VERSION)
     h.update(f"{Q_WAVES},{SINGLE_KERNEL_INSTRS},{PART_INSTRS}".encode())
-    h.update(f",pf{Q_PREFETCH},{Q_AHEAD},tile{Q_TILE},pair{Q_PAIR}".encode())
+    h.update(f",pf{Q_PREFETCH},{Q_AHEAD},tile{Q_TILE},pair{Q_PAIR},forms{Q_FORMS}".encode())
     for name in ("quotient_args.cuh", "kb31.cuh"):
         with open(os.path.join(CSRC, name), "rb") as f:
             h.update(f.read())
@@ -57,6 +57,47 @@ def _template_key() -> bytes:
 
 def program_hash(program: np.ndarray) -> str:
     return hashlib.sha256(_template_key() + np.ascontiguousarray(program, dtype=np.uint32).tobytes()).hexdigest()[:24]
+
+
+P = 0x7F000001
+MONTY_ONE = 0x01FFFFFE
+Q_FORMS = int(os.environ.get("ZKM_Q_FORMS", "1"))           # emit_form: 1 = bounded accumulators (round 5), 0 = rounds 3-4's fold_zero / fold_finish + modular additions (A/B only)
+
+
+def emit_form(name: str, consts, uterms, vterms, extras) -> str:
+    """Statements that define `const kb::E4 name` = sum(consts) + sum(u * b for uterms) + sum(e * b for vterms) + sum(extras): consts
+    and the u are wave-uniform extension values (challenges and their powers: SGPR operands), e and extras row values, b base-field row
+    values, every word reduced. The products go unreduced into one integer accumulator per coefficient and are reduced once. The
+    generator knows the form's bound — a product is below (p - 1)^2, the constant enters as c 2^32 (the accumulator starts there: no
+    addition afterwards), an extra as one product by R mod p — and picks the cheapest exact shape (csrc/kb31.cuh):
+      * below 2^32 p: 64-bit accumulators (one v_mad_u64_u32 per product and coefficient), an ordinary Montgomery reduction;
+      * below 2^64: 64-bit accumulators, reduce96_bounded;
+      * below 127 * 2^63: 96-bit accumulators (product + carry), reduce96_bounded (ten instructions instead of twenty-two);
+      * beyond (no recorded chip): rounds 3-4's shape — acc96_reduce and modular additions for the constant and the extras."""
+    n_prod = len(uterms) + len(vterms)
+    const = None
+    for c in consts:
+        const = c if const is None else f"kb::eadd({const}, {c})"
+    bound = n_prod * (P - 1) ** 2 + (0 if const is None else (P - 1) << 32) + len(extras) * (P - 1) * MONTY_ONE
+    acc = f"l_{name}"
+    if not Q_FORMS or bound >= 127 << 63:
+        stmts = [f"kb::FoldAcc {acc} = kb::fold_zero();"] + [f"kb::fold_base({acc}, {u}, {b});" for u, b in uterms]
+        stmts += [f"kb::fold_scaled({acc}, {e}, {b});" for e, b in vterms]
+        expr = f"kb::fold_finish({acc})"
+        for c in list(consts) + list(extras):
+            expr = f"kb::eadd({expr}, {c})"
+        return " ".join(stmts) + f" const kb::E4 {name} = {expr};"
+    if n_prod == 0 and not extras:
+        return f"const kb::E4 {name} = {const if const is not None else 'kb::ezero()'};"
+    if bound < 1 << 64:
+        stmts = [f"kb::FoldAcc64 {acc} = " + (f"kb::fold64_from({const});" if const is not None else "kb::fold64_zero();")]
+        stmts += [f"kb::fold64_scaled({acc}, {u}, {b});" for u, b in list(uterms) + list(vterms)]
+        stmts += [f"kb::fold64_add({acc}, {e});" for e in extras]
+        return " ".join(stmts) + f" const kb::E4 {name} = kb::fold64_finish<{'true' if bound < P << 32 else 'false'}>({acc});"
+    stmts = [f"kb::FoldAcc {acc} = " + (f"kb::fold_from({const});" if const is not None else "kb::fold_zero();")]
+    stmts += [f"kb::fold_base({acc}, {u}, {b});" for u, b in uterms] + [f"kb::fold_scaled({acc}, {e}, {b});" for e, b in vterms]
+    stmts += [f"kb::fold_add({acc}, {e});" for e in extras]
+    return " ".join(stmts) + f" const kb::E4 {name} = kb::fold_finish_bounded({acc});"
 
 
 def _ssa_lines(program: np.ndarray):
@@ -85,13 +126,8 @@ def _ssa_lines(program: np.ndarray):
         form = deferred.pop(name, None)
         if form is None:
             return name
-        acc = f"l_{name}"
-        stmts = [f"kb::FoldAcc {acc} = kb::fold_zero();"] + [f"kb::fold_base({acc}, {u}, {b});" for u, b in form["terms"]]
-        expr = f"kb::fold_finish({acc})"
-        for c in form["consts"] + form["extras"]:
-            expr = f"kb::eadd({expr}, {c})"
-        lines.append(" ".join(stmts) + f" const kb::E4 {name} = {expr};")
-        meta.append((name, tuple(x for t in form["terms"] for x in t) + tuple(form["consts"]) + tuple(form["extras"])))
+        lines.append(emit_form(name, form["consts"], form["terms"], form["vterms"], form["extras"]))
+        meta.append((name, tuple(x for t in form["terms"] + form["vterms"] for x in t) + tuple(form["consts"]) + tuple(form["extras"])))
         return name
 
     cidx = 0
@@ -163,7 +199,7 @@ def _ssa_lines(program: np.ndarray):
             x, y = cur_e[ra], cur_e[rb]
             if op == air.ADD_E and (x in deferred or y in deferred) and x != y:
                 # a sum with a linear form stays a linear form: the other side joins as more terms, as a uniform constant or as an extra addend
-                form = {"terms": [], "consts": [], "extras": []}
+                form = {"terms": [], "vterms": [], "consts": [], "extras": []}
                 for z in (x, y):
                     if z in deferred:
                         # copied, not taken: z stays a deferred form of its own, so a second reader of the same value (the same
@@ -196,9 +232,16 @@ def _ssa_lines(program: np.ndarray):
             x, y = cur_e[ra], cur_b[rb]
             if op == air.MUL_EB and x in uniform and x not in deferred and y not in uniform:
                 v = fresh("e"); cur_e[dst] = v
-                deferred[v] = {"terms": [(x, y)], "consts": [], "extras": []}      # uniform extension value x row value: a term
+                deferred[v] = {"terms": [(x, y)], "vterms": [], "consts": [], "extras": []}      # uniform extension value x row value: a term
                 continue
             x = use(x)
+            if Q_FORMS and op == air.MUL_EB and x not in uniform and y not in uniform:
+                # row extension value x row value (a LogUp batch's multiplicity-weighted denominators, m1 d2 + m2 d1): a term as well,
+                # so that the sum of two of them is two products per coefficient and ONE reduction instead of eight Montgomery products
+                # and four modular additions
+                v = fresh("e"); cur_e[dst] = v
+                deferred[v] = {"terms": [], "vterms": [(x, y)], "consts": [], "extras": []}
+                continue
             v = fresh("e"); cur_e[dst] = v
             lines.append(f"const kb::E4 {v} = kb::{fn}({x}, {y});")
             meta.append((v, (x, y)))
@@ -562,19 +605,28 @@ def emit_perm_source(blob, log_quotient_degree: int) -> str:
             first = True
             for k in range(b * batch, min((b + 1) * batch, n)):
                 kind, values, _ = lookups[k]
-                body.append(f"kb::E4 d{k} = kb::eadd_base(a.alpha, kb::to_monty({kind}u));")
-                if len(values) >= 4:
-                    body.append(f"kb::FoldAcc fa{k} = kb::fold_zero();")
+                if Q_FORMS:
+                    # alpha + kind + sum_v beta^(v+1) value_v as one bounded form: the accumulators start at the (uniform) constant
+                    terms = []
                     for v, f in enumerate(values):
                         lin = form(f, body)
                         if lin != "0u":
-                            body.append(f"kb::fold_base(fa{k}, a.beta_pows[{v + 1}], {lin});")
-                    body.append(f"d{k} = kb::eadd(d{k}, kb::fold_finish(fa{k}));")
+                            terms.append((f"a.beta_pows[{v + 1}]", lin))
+                    body.append(emit_form(f"d{k}", [f"kb::eadd_base(a.alpha, kb::to_monty({kind}u))"], terms, [], []))
                 else:
-                    for v, f in enumerate(values):
-                        lin = form(f, body)
-                        if lin != "0u":
-                            body.append(f"d{k} = kb::eadd(d{k}, kb::escale(a.beta_pows[{v + 1}], {lin}));")
+                    body.append(f"kb::E4 d{k} = kb::eadd_base(a.alpha, kb::to_monty({kind}u));")
+                    if len(values) >= 4:
+                        body.append(f"kb::FoldAcc fa{k} = kb::fold_zero();")
+                        for v, f in enumerate(values):
+                            lin = form(f, body)
+                            if lin != "0u":
+                                body.append(f"kb::fold_base(fa{k}, a.beta_pows[{v + 1}], {lin});")
+                        body.append(f"d{k} = kb::eadd(d{k}, kb::fold_finish(fa{k}));")
+                    else:
+                        for v, f in enumerate(values):
+                            lin = form(f, body)
+                            if lin != "0u":
+                                body.append(f"d{k} = kb::eadd(d{k}, kb::escale(a.beta_pows[{v + 1}], {lin}));")
                 if first:
                     body.append(f"kb::E4 num{b} = kb::efrom({mults[k]}); kb::E4 den{b} = d{k};")
                     first = False
@@ -605,7 +657,7 @@ extern "C" __global__ __launch_bounds__({BLOCK}) void {PERM_KERNEL_NAME}(stark::
 
 
 def perm_hash(blob, log_quotient_degree: int) -> str:
-    h = hashlib.sha256(_template_key() + b"perm1")
+    h = hashlib.sha256(_template_key() + b"perm2")
     with open(os.path.join(CSRC, "perm_args.cuh"), "rb") as f:
         h.update(f.read())
     h.update(np.ascontiguousarray(blob, dtype=np.uint32).tobytes() + bytes([log_quotient_degree]))

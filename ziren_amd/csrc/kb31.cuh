@@ -148,6 +148,27 @@ KB_HD uint32_t bitrev(uint32_t x, int bits) {
 #endif
 }
 
+// (hi 2^64 + lo64) / R mod p in [0, p) for a sum known to be below 127 * 2^63 — a linear form of up to 126 products of a word below
+// 2^32 by a reduced word, which is every linear form and folded constraint sum the generated kernels build (ziren_amd/codegen.py
+// computes the bound of each and falls back to acc96_reduce beyond it). One Montgomery step on the low word leaves
+// x1 = (x - t p) / 2^32 = (hi : mid) - mulhi(t, p), a signed value in (-p, 127 * 2^31); its quotient by 2^31, q in [-1, 126], is
+// also a good enough quotient by p: x1 - q p = (x1 mod 2^31) + q (2^24 - 1) lies in [0, 2p) (p = 2^31 - 2^24 + 1), one conditional
+// subtraction from the answer. Ten instructions against acc96_reduce's twenty-two (round 5).
+KB_HD uint32_t reduce96_bounded(uint32_t hi, uint64_t lo64) {
+  const uint32_t lo = (uint32_t)lo64, mid = (uint32_t)(lo64 >> 32);
+  const uint32_t t = lo + (lo << 24) + (lo << 31);  // lo * MU mod 2^32
+#if defined(__HIP_DEVICE_COMPILE__)
+  const uint32_t uhi = __umulhi(t, P);
+#else
+  const uint32_t uhi = (uint32_t)(((uint64_t)t * P) >> 32);
+#endif
+  const uint64_t x1 = ((((uint64_t)hi) << 32) | mid) - uhi;  // two's complement; the low words of x and t p coincide: no borrow from them
+  const uint32_t q = (uint32_t)(x1 >> 31);                   // floor(x1 / 2^31): 0xffffffff for a negative x1
+  const uint32_t low = (uint32_t)x1 & 0x7fffffffu;
+  const uint32_t x2 = low + (q << 24) - q;                   // x1 - q p
+  return umin32(x2, x2 - P);
+}
+
 // ---- long dot products: 96-bit accumulation, one reduction at the end ------------------------------------------------
 // sum_i a_i b_i with a_i, b_i < 2^32: each term is one v_mad_u64_u32 into the low 64 bits plus the carry into a third
 // word (two instructions per product instead of 3.5 with a Montgomery reduction every second product). Holds 2^32 terms.
@@ -315,6 +336,44 @@ __device__ __forceinline__ void fold_ext(FoldAcc& f, const E4& a /* uniform */, 
 }
 __device__ __forceinline__ E4 fold_finish(const FoldAcc& f) {
   return E4{{acc96_reduce(f.c[0]), acc96_reduce(f.c[1]), acc96_reduce(f.c[2]), acc96_reduce(f.c[3])}};
+}
+// What the generated kernels use for a linear form whose bound they know (codegen.emit_form): the accumulator starts at a constant
+// (c R sits in the middle word: no addition afterwards), takes row values as one product by R mod p, products of two row values
+// (the multiplicity-weighted denominators of a LogUp batch), and is reduced by reduce96_bounded.
+__device__ __forceinline__ FoldAcc fold_from(const E4& c) {
+  return FoldAcc{{Acc96{(uint64_t)c.c[0] << 32, 0}, Acc96{(uint64_t)c.c[1] << 32, 0}, Acc96{(uint64_t)c.c[2] << 32, 0}, Acc96{(uint64_t)c.c[3] << 32, 0}}};
+}
+__device__ __forceinline__ void fold_add(FoldAcc& f, const E4& e) {
+#pragma unroll
+  for (int i = 0; i < 4; i++) acc96_fma_uniform(f.c[i], ONE, e.c[i]);
+}
+__device__ __forceinline__ void fold_scaled(FoldAcc& f, const E4& e, uint32_t v) {
+#pragma unroll
+  for (int i = 0; i < 4; i++) acc96_fma(f.c[i], e.c[i], v);
+}
+__device__ __forceinline__ E4 fold_finish_bounded(const FoldAcc& f) {
+  return E4{{reduce96_bounded(f.c[0].hi, f.c[0].lo), reduce96_bounded(f.c[1].hi, f.c[1].lo), reduce96_bounded(f.c[2].hi, f.c[2].lo),
+             reduce96_bounded(f.c[3].hi, f.c[3].lo)}};
+}
+// The same in 64 bits, for a form whose bound is below 2^64 (no carry word: one v_mad_u64_u32 per product); `narrow`: the bound is
+// below 2^32 p as well, so the reduction is an ordinary Montgomery reduction.
+struct FoldAcc64 { uint64_t c[4]; };
+__device__ __forceinline__ FoldAcc64 fold64_zero() { return FoldAcc64{{0, 0, 0, 0}}; }
+__device__ __forceinline__ FoldAcc64 fold64_from(const E4& c) {
+  return FoldAcc64{{(uint64_t)c.c[0] << 32, (uint64_t)c.c[1] << 32, (uint64_t)c.c[2] << 32, (uint64_t)c.c[3] << 32}};
+}
+__device__ __forceinline__ void fold64_scaled(FoldAcc64& f, const E4& e, uint32_t v) {
+#pragma unroll
+  for (int i = 0; i < 4; i++) f.c[i] += (uint64_t)e.c[i] * v;
+}
+__device__ __forceinline__ void fold64_add(FoldAcc64& f, const E4& e) {
+#pragma unroll
+  for (int i = 0; i < 4; i++) f.c[i] += (uint64_t)e.c[i] * ONE;
+}
+template <bool NARROW>
+__device__ __forceinline__ E4 fold64_finish(const FoldAcc64& f) {
+  if (NARROW) return E4{{monty_reduce(f.c[0]), monty_reduce(f.c[1]), monty_reduce(f.c[2]), monty_reduce(f.c[3])}};
+  return E4{{reduce96_bounded(0, f.c[0]), reduce96_bounded(0, f.c[1]), reduce96_bounded(0, f.c[2]), reduce96_bounded(0, f.c[3])}};
 }
 #endif
 KB_HD E4 epow(E4 a, uint64_t e) {

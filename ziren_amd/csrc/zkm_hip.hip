@@ -748,6 +748,7 @@ void zkm_host_ext_inv(const uint32_t a[4], uint32_t out[4]) {
 }
 uint32_t zkm_host_field_mul(uint32_t a, uint32_t b) { return kb::mul(a, b); }
 uint32_t zkm_host_field_inv(uint32_t a) { return kb::inv(a); }
+uint32_t zkm_host_reduce96_bounded(uint32_t hi, uint64_t lo) { return kb::reduce96_bounded(hi, lo); }
 uint32_t zkm_host_two_adic_generator(uint32_t bits) { return kb::two_adic_generator((int)bits); }
 
 }  // extern "C"

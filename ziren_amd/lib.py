@@ -21,7 +21,7 @@ EXPORTS = [
     "zkm_poseidon2_permute_batch", "zkm_poseidon2_permute_batch_int", "zkm_coset_lde_batch", "zkm_permutation_trace",
     "zkm_challenger_init", "zkm_challenger_observe", "zkm_challenger_sample", "zkm_challenger_sample_bits",
     "zkm_host_poseidon2_permute", "zkm_host_poseidon2_permute_f64", "zkm_host_poseidon2_f64_sponge", "zkm_host_poseidon2_f64_compress_inject", "zkm_host_poseidon2_f64_audit",
-    "zkm_host_ext_mul", "zkm_host_ext_inv", "zkm_host_field_mul", "zkm_host_field_inv", "zkm_host_two_adic_generator",
+    "zkm_host_ext_mul", "zkm_host_ext_inv", "zkm_host_field_mul", "zkm_host_field_inv", "zkm_host_reduce96_bounded", "zkm_host_two_adic_generator",
 ]
 
 
@@ -90,6 +90,9 @@ def load():
     L.zkm_challenger_sample_bits.restype = C.c_uint32
     L.zkm_host_field_mul.restype = C.c_uint32
     L.zkm_host_field_inv.restype = C.c_uint32
+    if hasattr(L, "zkm_host_reduce96_bounded"):
+        L.zkm_host_reduce96_bounded.restype = C.c_uint32
+        L.zkm_host_reduce96_bounded.argtypes = [C.c_uint32, C.c_uint64]
     L.zkm_host_two_adic_generator.restype = C.c_uint32
     for name in ("zkm_ctx_destroy", "zkm_host_free", "zkm_events_free", "zkm_byte_lookups_free", "zkm_ctx_set_kernel_timing", "zkm_ctx_set_kernel_timing_only", "zkm_ctx_set_lde_overlap", "zkm_ctx_set_host_wait", "zkm_matrix_free", "zkm_pcs_data_free", "zkm_pk_free", "zkm_main_data_free",
                  "zkm_challenger_init", "zkm_challenger_observe", "zkm_host_poseidon2_permute", "zkm_host_poseidon2_permute_f64", "zkm_host_poseidon2_f64_sponge",
