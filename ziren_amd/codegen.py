@@ -30,7 +30,7 @@ PART_INSTRS = int(os.environ.get("ZKM_Q_PART", "6000"))              # a long pr
 SINGLE_KERNEL_INSTRS = int(os.environ.get("ZKM_Q_SINGLE", "12000"))  # ... when it is longer than this (KeccakSponge: 114 324; every other recorded chip is below 10 000)
 
 
-TEMPLATE_VERSION = b"11"  # bump when emit_source changes
+TEMPLATE_VERSION = b"12"  # bump when emit_source changes
 
 
 # Experiment knobs (tools/ab_quotient.sh; unset in production): waves per SIMD the compiler is told to fit the kernel into, and where a
@@ -39,6 +39,7 @@ Q_WAVES = int(os.environ.get("ZKM_Q_WAVES", "0"))
 Q_AHEAD = int(os.environ.get("ZKM_Q_AHEAD", "1"))           # how many groups ahead
 Q_TILE = int(os.environ.get("ZKM_Q_TILE", "1"))           # quotient_args.cuh: 1 = the 8 x 32 tile with staged vector stores, 0 = rounds 2-4's two half-tiles (A/B only)
 Q_PAIR = int(os.environ.get("ZKM_Q_PAIR", "1"))           # pair_row_loads: a column's `next` load right behind its `local` load (0: where the program has them; A/B only)
+P_GROUP = int(os.environ.get("ZKM_P_GROUP", "4"))       # emit_perm_source: fraction columns whose inversions share one base-field inversion (Montgomery's trick)
 Q_PREFETCH = int(os.environ.get("ZKM_Q_PREFETCH", "4"))     # words of trace loads per group, issued Q_AHEAD groups ahead of their use (0: the compiler's
                                                             # order, which sinks every load to its first use; round 4: 5.35 -> 4.55 ms on the benchmarked shard)
 
@@ -48,7 +49,7 @@ def _template_key() -> bytes:
     the shared prologue (quotient_args.cuh) or the field arithmetic (kb31.cuh) can never leave a stale kernel behind."""
     h = hashlib.sha256(TEMPLATE_VERSION)
     h.update(f"{Q_WAVES},{SINGLE_KERNEL_INSTRS},{PART_INSTRS}".encode())
-    h.update(f",pf{Q_PREFETCH},{Q_AHEAD},tile{Q_TILE},pair{Q_PAIR},forms{Q_FORMS}".encode())
+    h.update(f",pf{Q_PREFETCH},{Q_AHEAD},tile{Q_TILE},pair{Q_PAIR},forms{Q_FORMS},pg{P_GROUP},sums{Q_SUMS}".encode())
     for name in ("quotient_args.cuh", "kb31.cuh"):
         with open(os.path.join(CSRC, name), "rb") as f:
             h.update(f.read())
@@ -62,6 +63,107 @@ def program_hash(program: np.ndarray) -> str:
 P = 0x7F000001
 MONTY_ONE = 0x01FFFFFE
 Q_FORMS = int(os.environ.get("ZKM_Q_FORMS", "1"))           # emit_form: 1 = bounded accumulators (round 5), 0 = rounds 3-4's fold_zero / fold_finish + modular additions (A/B only)
+
+
+Q_SUMS = int(os.environ.get("ZKM_Q_SUMS", "1"))             # _ssa_lines: 1 = base-field sums of products reduced once (round 5), 0 = one modular operation per bytecode instruction (A/B only)
+MAX_SUM_TERMS = 48                                          # a deferred base-field sum is emitted when it reaches this many terms (its bound stays below 127 * 2^63)
+
+
+def _base_read_counts(prog: np.ndarray):
+    """How many instructions read each base-field SSA value (same renaming as _ssa_lines: one fresh name per defining instruction)."""
+    n_instr = int(prog[0])
+    cur_b, reads, nv = {}, {}, 0
+    base_defs = (air.LD_MAIN, air.LD_PREP, air.LD_CONST, air.LD_PV, air.LD_GLOBAL_SUM, air.LD_IS_FIRST, air.LD_IS_LAST, air.LD_IS_TRANS,
+                 air.ADD_B, air.SUB_B, air.MUL_B, air.NEG_B)
+    ext_defs = (air.LD_PERM, air.LD_CHALLENGE, air.LD_LOCAL_SUM, air.ADD_E, air.SUB_E, air.MUL_E, air.NEG_E, air.ADD_EB, air.SUB_EB, air.MUL_EB)
+    for k in range(n_instr):
+        w0 = int(prog[4 + 2 * k])
+        op, dst, ra, rb = w0 & 0xFF, (w0 >> 8) & 0xFF, (w0 >> 16) & 0xFF, w0 >> 24
+        if op in (air.ADD_B, air.SUB_B, air.MUL_B):
+            srcs = (cur_b[ra], cur_b[rb])
+        elif op in (air.NEG_B, air.ASSERT_B):
+            srcs = (cur_b[ra],)
+        elif op in (air.ADD_EB, air.SUB_EB, air.MUL_EB):
+            srcs = (cur_b[rb],)
+        else:
+            srcs = ()
+        for z in srcs:
+            reads[z] = reads.get(z, 0) + 1
+        if op in base_defs:
+            nv += 1
+            cur_b[dst] = f"b{nv}"
+        elif op in ext_defs:
+            nv += 1
+    return reads
+
+
+def emit_sum(name: str, prods, leaves, uniform=()) -> str:
+    """Statements that define `const uint32_t name` = sum(sign * x * y for prods) + sum(sign * z for leaves) as a reduced word, x, y, z
+    reduced words (row values or wave-uniform ones). Few terms: the modular operations the bytecode names. Otherwise every product and
+    leaf goes into one integer sum — a leaf as z * (R mod p) (or z * (p - R mod p) when subtracted), a subtracted product as (p - x) * y
+    — which is reduced once: an ordinary Montgomery reduction below 2^32 p, reduce96_bounded below 2^64, a 96-bit accumulator beyond.
+    Costs (cycles per wavefront, tools/ubench_int): a modular product 22.9, a modular addition 9.3, v_mad_u64_u32 5."""
+    k, m = len(prods), len(leaves)
+    pos = [z for sg, z in leaves if sg > 0]
+    neg = [z for sg, z in leaves if sg < 0]
+
+    def chain(first, first_negated):
+        expr = first
+        rest_pos, rest_neg = list(pos), list(neg)
+        if expr is None:
+            if rest_pos:
+                expr = rest_pos.pop(0)
+            else:
+                expr = f"kb::neg({rest_neg.pop(0)})" if len(rest_neg) == 1 else None
+                if expr is None:
+                    z = rest_neg.pop(0)
+                    expr = z
+                    for w in rest_neg:
+                        expr = f"kb::add({expr}, {w})"
+                    return f"kb::neg({expr})"
+        elif first_negated:
+            # -(x y) + ...: start from a positive leaf if there is one
+            if rest_pos:
+                expr = f"kb::sub({rest_pos.pop(0)}, {first})"
+            else:
+                expr = f"kb::neg({first})"
+        for w in rest_pos:
+            expr = f"kb::add({expr}, {w})"
+        for w in rest_neg:
+            expr = f"kb::sub({expr}, {w})"
+        return expr
+
+    if k == 0 and m < 6:
+        return f"const uint32_t {name} = {chain(None, False)};"
+    if k == 1 and m == 0:
+        sg, x, y = prods[0]
+        return f"const uint32_t {name} = " + (f"kb::mul({x}, {y});" if sg > 0 else f"kb::monty_reduce((uint64_t)(kb::P - {x}) * {y});")
+    terms, bound, extra = [], 0, 0.0
+    for sg, x, y in prods:
+        if sg > 0:
+            terms.append((x, y)); bound += (P - 1) ** 2
+        else:
+            if y in uniform and x not in uniform:
+                x, y = y, x
+            terms.append((f"(kb::P - {x})", y)); bound += P * (P - 1)
+            extra += 0.0 if x in uniform else 2.5
+    for z in pos:
+        terms.append((z, "kb::ONE")); bound += (P - 1) * MONTY_ONE
+    for z in neg:
+        terms.append((z, "(kb::P - kb::ONE)")); bound += (P - 1) * (P - MONTY_ONE)
+    n = len(terms)
+    cost_chain = 22.9 * k + 9.3 * (k + m - 1)
+    cost_sum = 5.0 * n + extra + (16.1 if bound < P << 32 else 30.0 if bound < 1 << 64 else 34.0 + 2.5 * n)
+    if k == 1 and cost_chain <= cost_sum:
+        sg, x, y = prods[0]
+        return f"const uint32_t {name} = {chain(f'kb::mul({x}, {y})', sg < 0)};"
+    assert bound < 127 << 63, "a deferred base-field sum beyond reduce96_bounded's bound (MAX_SUM_TERMS)"
+    if bound < 1 << 64:
+        total = " + ".join(f"(uint64_t){a} * {b}" for a, b in terms)
+        return f"const uint32_t {name} = " + (f"kb::monty_reduce({total});" if bound < P << 32 else f"kb::reduce96_bounded(0, {total});")
+    acc = f"s_{name}"
+    stmts = [f"kb::Acc96 {acc} = kb::acc96_zero();"] + [f"kb::acc96_fma({acc}, {a}, {b});" for a, b in terms]
+    return " ".join(stmts) + f" const uint32_t {name} = kb::reduce96_bounded({acc}.hi, {acc}.lo);"
 
 
 def emit_form(name: str, consts, uterms, vterms, extras) -> str:
@@ -130,6 +232,36 @@ def _ssa_lines(program: np.ndarray):
         meta.append((name, tuple(x for t in form["terms"] + form["vterms"] for x in t) + tuple(form["consts"]) + tuple(form["extras"])))
         return name
 
+    # Sums of products in the base field (round 5). ADD_B / SUB_B / NEG_B emit nothing: their value is kept as a signed list of products
+    # (of two emitted, reduced values) and leaves (emitted, reduced values), and a MUL_B as one product. When something needs the value
+    # as a reduced word — a multiplication, an assert, an extension operation — emit_sum writes it the cheapest exact way: a short chain
+    # of modular operations as before, or all products and leaves into one 64-bit sum (one v_mad_u64_u32 each; a leaf as a product by
+    # +-R mod p, a subtracted product with p - x on one side) and ONE reduction (a b - c: three instructions less than a product, a
+    # correction and a modular subtraction; a sum of k products: k - 1 reductions and k - 1 modular additions less).
+    reads = _base_read_counts(prog) if Q_SUMS else {}
+    bdef = {}                # SSA base value -> {"prods": [(sign, x, y)], "leaves": [(sign, z)]} not emitted yet
+
+    def buse(name):
+        """The name of a base value about to be read as a reduced word: a deferred sum is emitted first."""
+        f = bdef.pop(name, None)
+        if f is not None:
+            lines.append(emit_sum(name, f["prods"], f["leaves"], uniform))
+            meta.append((name, tuple(z for _, x, y in f["prods"] for z in (x, y)) + tuple(z for _, z in f["leaves"])))
+        return name
+
+    def bview(name, sign):
+        """A base value as (products, leaves) to be merged into a sum, with `sign` applied. A deferred sum with several readers is
+        emitted once if recomputing it in each reader would cost more than reading the word."""
+        f = bdef.get(name)
+        if f is not None and reads.get(name, 1) > 1 and len(f["prods"]) + len(f["leaves"]) > 2:
+            buse(name)
+            f = None
+        if f is None:
+            return [], [(sign, name)]
+        if reads.get(name, 1) <= 1:
+            del bdef[name]
+        return [(sign * sg, x, y) for sg, x, y in f["prods"]], [(sign * sg, z) for sg, z in f["leaves"]]
+
     cidx = 0
     for k in range(n_instr):
         w0, imm = int(prog[4 + 2 * k]), int(prog[5 + 2 * k])
@@ -183,6 +315,16 @@ def _ssa_lines(program: np.ndarray):
             fn = {air.ADD_B: "add", air.SUB_B: "sub", air.MUL_B: "mul"}[op]
             x, y = cur_b[ra], cur_b[rb]
             v = fresh("b"); cur_b[dst] = v
+            if Q_SUMS and not (x in uniform and y in uniform):
+                if op == air.MUL_B:
+                    bdef[v] = {"prods": [(1, buse(x), buse(y))], "leaves": []}
+                else:
+                    px, lx = bview(x, 1)
+                    py, ly = bview(y, 1 if op == air.ADD_B else -1)
+                    bdef[v] = {"prods": px + py, "leaves": lx + ly}
+                    if len(px) + len(py) + len(lx) + len(ly) > MAX_SUM_TERMS:
+                        buse(v)
+                continue
             lines.append(f"const uint32_t {v} = kb::{fn}({x}, {y});")
             meta.append((v, (x, y)))
             if x in uniform and y in uniform:
@@ -190,6 +332,10 @@ def _ssa_lines(program: np.ndarray):
         elif op == air.NEG_B:
             x = cur_b[ra]
             v = fresh("b"); cur_b[dst] = v
+            if Q_SUMS and x not in uniform:
+                px, lx = bview(x, -1)
+                bdef[v] = {"prods": px, "leaves": lx}
+                continue
             lines.append(f"const uint32_t {v} = kb::neg({x});")
             meta.append((v, (x,)))
             if x in uniform:
@@ -229,7 +375,7 @@ def _ssa_lines(program: np.ndarray):
                 uniform.add(v)
         elif op in (air.ADD_EB, air.SUB_EB, air.MUL_EB):
             fn = {air.ADD_EB: "eadd_base", air.SUB_EB: "esub_base", air.MUL_EB: "escale"}[op]
-            x, y = cur_e[ra], cur_b[rb]
+            x, y = cur_e[ra], buse(cur_b[rb])
             if op == air.MUL_EB and x in uniform and x not in deferred and y not in uniform:
                 v = fresh("e"); cur_e[dst] = v
                 deferred[v] = {"terms": [(x, y)], "vterms": [], "consts": [], "extras": []}      # uniform extension value x row value: a term
@@ -248,8 +394,9 @@ def _ssa_lines(program: np.ndarray):
             if x in uniform and y in uniform:
                 uniform.add(v)
         elif op == air.ASSERT_B:
-            lines.append(f"kb::fold_base(acc, a.alpha_pows[{cidx}], {cur_b[ra]});")
-            meta.append((None, (cur_b[ra],)))
+            x = buse(cur_b[ra])
+            lines.append(f"kb::fold_base(acc, a.alpha_pows[{cidx}], {x});")
+            meta.append((None, (x,)))
             cidx += 1
         elif op == air.ASSERT_E:
             x = use(cur_e[ra])
@@ -598,7 +745,7 @@ def emit_perm_source(blob, log_quotient_degree: int) -> str:
     zero_stores = " ".join(f"a.perm[(size_t){j} * a.n + r] = 0;" for j in range(4 * (ncols + 1)))
     exit_line = f"if (__all(({' | '.join(live) if live else '0u'}) == 0)) {{ {zero_stores} return; }}"
     body.append("kb::E4 rowsum = kb::ezero();")
-    G = 2
+    G = P_GROUP
     for b0 in range(0, ncols, G):
         cols_here = [b for b in range(b0, min(b0 + G, ncols))]
         for g, b in enumerate(cols_here):
