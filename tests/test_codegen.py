@@ -113,7 +113,7 @@ def test_perm_source_loads_every_column_once_and_parses_the_blob_back():
     src = codegen.emit_perm_source(c.lookups_blob, c.log_quotient_degree)
     loads = re.findall(r"const uint32_t ([mp]\d+) = a\.(?:main|prep)\[", src)
     assert len(loads) == len(set(loads)) > 10
-    assert src.count("kb::inv_batch<") == -(-(c.perm_ext_width - 1) // 2)
+    assert src.count("kb::inv_batch<") == -(-(c.perm_ext_width - 1) // codegen.P_GROUP)      # one base-field inversion per P_GROUP fraction columns
     assert codegen.specialize_perm(chips.record_keccak_sponge_chip(10).lookups_blob, 1) is None      # too many lookups: the generic kernel
 
 
@@ -213,3 +213,41 @@ def test_prefetch_order_moves_loads_up_and_loses_nothing():
             else:
                 seen_non_load += 1
         _check_defined_before_use("kb::FoldAcc acc;\n" + "\n".join(body))
+
+
+def test_split_uniform_moves_every_derived_uniform_value_into_the_table_kernel_and_loses_nothing():
+    """codegen.split_uniform: the kernel proper keeps every row statement and assert, declares every value before its use, computes no
+    wave-uniform value itself (it reads each from the table once), and the table kernel computes — from leaves only — exactly the values
+    it stores, one slot each, 16-byte slots for extension values, inside what the library allocates."""
+    from ziren_amd import chips
+    n_cut = 0
+    for prog in (chips.record_cpu_chip(10).program, chips.record_divrem_chip(10).program, chips.record_global_chip(10).program,
+                 chips.record_byte_chip().program, shared_term_program()):
+        lines, meta, uniform = codegen._ssa_lines(np.asarray(prog, dtype=np.uint32), with_uniform=True)
+        cut = codegen.split_uniform(lines, meta, uniform)
+        if cut is None:      # a program without wave-uniform arithmetic: nothing to move
+            assert not any(v is not None and v in uniform and uses for v, uses in meta if any(v in u for _, u in meta))
+            continue
+        n_cut += 1
+        main, main_meta, prologue = cut
+        row = [(ln, m) for ln, m in zip(lines, meta) if m[0] is None or m[0] not in uniform]
+        assert [ln for ln, m in zip(main, main_meta) if m[0] is None or m[0] not in uniform] == [ln for ln, _ in row]      # nothing lost, same order
+        seen = set()
+        for ln, (v, uses) in zip(main, main_meta):
+            assert all(u in seen for u in uses), ln
+            if v is not None:
+                seen.add(v)
+            if v is not None and v in uniform:
+                assert not uses and ("a.uniforms" in ln or not any(f in ln for f in ("kb::emul", "kb::mul(", "kb::eadd", "kb::escale"))), ln
+        _check_defined_before_use("kb::FoldAcc acc;\n" + "\n".join(main))
+        stores = prologue[-1]
+        slots = [(int(off), "e") for off in re.findall(r"\*\(kb::E4\*\)\(a\.uniforms \+ (\d+)\)", stores)] + \
+                [(int(off), "b") for off in re.findall(r"a\.uniforms\[(\d+)\] =", stores)]
+        used = sorted(w for off, kind in slots for w in range(off, off + (4 if kind == "e" else 1)))
+        assert used == list(range(len(used))) and len(used) <= codegen.UNIFORM_TABLE_WORDS and all(off % 4 == 0 for off, kind in slots if kind == "e")
+        loaded = re.findall(r"a\.uniforms(?: \+ |\[)(\d+)", "\n".join(main))
+        assert sorted(int(x) for x in loaded) == sorted(off for off, _ in slots)
+        _check_defined_before_use("kb::FoldAcc acc;\n" + "\n".join(prologue[:-1]))
+    assert n_cut >= 4
+    src = codegen.emit_source(chips.record_cpu_chip(10).program)
+    assert src.count("__global__") == 2 and codegen.UNIFORMS_KERNEL_NAME in src

@@ -25,12 +25,13 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 CACHE = os.path.join(HERE, "_jit")
 KERNEL_NAME = "zkm_quotient_specialized"
+UNIFORMS_KERNEL_NAME = "zkm_quotient_uniforms"
 BLOCK = 256
 PART_INSTRS = int(os.environ.get("ZKM_Q_PART", "6000"))              # a long program is cut into kernels of about this many statements
 SINGLE_KERNEL_INSTRS = int(os.environ.get("ZKM_Q_SINGLE", "12000"))  # ... when it is longer than this (KeccakSponge: 114 324; every other recorded chip is below 10 000)
 
 
-TEMPLATE_VERSION = b"12"  # bump when emit_source changes
+TEMPLATE_VERSION = b"13"  # bump when emit_source changes
 
 
 # Experiment knobs (tools/ab_quotient.sh; unset in production): waves per SIMD the compiler is told to fit the kernel into, and where a
@@ -49,7 +50,7 @@ def _template_key() -> bytes:
     the shared prologue (quotient_args.cuh) or the field arithmetic (kb31.cuh) can never leave a stale kernel behind."""
     h = hashlib.sha256(TEMPLATE_VERSION)
     h.update(f"{Q_WAVES},{SINGLE_KERNEL_INSTRS},{PART_INSTRS}".encode())
-    h.update(f",pf{Q_PREFETCH},{Q_AHEAD},tile{Q_TILE},pair{Q_PAIR},forms{Q_FORMS},pg{P_GROUP},sums{Q_SUMS}".encode())
+    h.update(f",pf{Q_PREFETCH},{Q_AHEAD},tile{Q_TILE},pair{Q_PAIR},forms{Q_FORMS},pg{P_GROUP},sums{Q_SUMS},ut{Q_UNITABLE}".encode() + (b",fakeuni" if Q_FAKEUNI else b""))
     for name in ("quotient_args.cuh", "kb31.cuh"):
         with open(os.path.join(CSRC, name), "rb") as f:
             h.update(f.read())
@@ -65,6 +66,8 @@ MONTY_ONE = 0x01FFFFFE
 Q_FORMS = int(os.environ.get("ZKM_Q_FORMS", "1"))           # emit_form: 1 = bounded accumulators (round 5), 0 = rounds 3-4's fold_zero / fold_finish + modular additions (A/B only)
 
 
+Q_UNITABLE = int(os.environ.get("ZKM_Q_UNITABLE", "1"))     # split_uniform: 1 = wave-uniform values computed once per launch into a table (round 5), 0 = by every wavefront (A/B only)
+Q_FAKEUNI = int(os.environ.get("ZKM_Q_FAKEUNI", "0"))       # EXPERIMENT ONLY: derived wave-uniform values loaded from a table (wrong values; timing of a uniform-table design)
 Q_SUMS = int(os.environ.get("ZKM_Q_SUMS", "1"))             # _ssa_lines: 1 = base-field sums of products reduced once (round 5), 0 = one modular operation per bytecode instruction (A/B only)
 MAX_SUM_TERMS = 48                                          # a deferred base-field sum is emitted when it reaches this many terms (its bound stays below 127 * 2^63)
 
@@ -202,9 +205,9 @@ def emit_form(name: str, consts, uterms, vterms, extras) -> str:
     return " ".join(stmts) + f" const kb::E4 {name} = kb::fold_finish_bounded({acc});"
 
 
-def _ssa_lines(program: np.ndarray):
+def _ssa_lines(program: np.ndarray, with_uniform: bool = False):
     """The program as straight-line HIP statements, every register write a fresh SSA value: (lines, meta) with meta[k] = (the value line
-    k defines — None for an assert —, the values it reads)."""
+    k defines — None for an assert —, the values it reads); with_uniform: and the set of values that are the same for every row."""
     prog = np.asarray(program, dtype=np.uint32)
     n_instr = int(prog[0])
     cur_b, cur_e = {}, {}   # register -> current variable name
@@ -406,7 +409,15 @@ def _ssa_lines(program: np.ndarray):
         else:
             raise ValueError(f"bad opcode {op}")
     assert cidx == int(prog[2]) and len(meta) == len(lines)
-    return lines, meta
+    if Q_FAKEUNI:
+        # EXPERIMENT ONLY (tools/ab_uniforms.sh; wrong values): every derived wave-uniform value read from a table instead of being
+        # computed by each wavefront's scalar unit — what a table of precomputed uniform values would cost the kernel
+        n_alpha = max(1, int(prog[2]))
+        for i, (v, uses) in enumerate(meta):
+            if v is not None and v in uniform and uses:
+                lines[i] = (f"const kb::E4 {v} = a.alpha_pows[{i % n_alpha}];" if v.startswith("e") else f"const uint32_t {v} = a.public_values[{i % 64}];")
+                meta[i] = (v, ())
+    return (lines, meta, uniform) if with_uniform else (lines, meta)
 
 
 def _kernel_source(lines, n_instr, n_constraints, accumulate=False, part="") -> str:
@@ -548,15 +559,80 @@ def pair_row_loads(lines, meta):
     return [lines[i] for i in order], [meta[i] for i in order]
 
 
+UNIFORM_TABLE_WORDS = 4096     # stark::QUOTIENT_UNIFORM_WORDS (csrc/quotient_args.cuh): what the library allocates per chip
+
+
+def split_uniform(lines, meta, uniform):
+    """The statements of a kernel without its wave-uniform arithmetic. A value that is the same for every row — the powers of beta, a
+    constant times a challenge, anything computed from challenges, constants and public values only — used to be computed by every
+    wavefront on its scalar unit: for the Cpu chip 4 400 scalar instructions beside 6 500 vector ones, 14 KiB of a 78 KiB kernel (the
+    instruction cache holds 64), and the wavefront issues nothing else meanwhile. Such values are now computed ONCE per launch by a
+    one-wavefront kernel (`zkm_quotient_uniforms`, launched in front) into a table, and the kernel proper reads the ones it needs
+    with scalar loads. Returns (main lines, main meta, prologue lines) or None when there is nothing to move or the table would not fit.
+    Leaves (a literal, a challenge, a public value) stay where they are read: they cost a move or one scalar load."""
+    defined_at = {v: i for i, (v, _) in enumerate(meta) if v is not None}
+    derived = {v for v, uses in meta if v is not None and v in uniform and uses}
+    frontier, seen = [], set()
+    for v, uses in meta:
+        if v is not None and v in uniform:
+            continue
+        for u in uses:
+            if u in derived and u not in seen:
+                seen.add(u)
+                frontier.append(u)
+    if not frontier:
+        return None
+    offsets, words = {}, 0
+    for v in [u for u in frontier if u.startswith("e")] + [u for u in frontier if not u.startswith("e")]:   # extension values first: 16-byte slots stay aligned
+        offsets[v] = words
+        words += 4 if v.startswith("e") else 1
+    if words > UNIFORM_TABLE_WORDS:
+        return None
+    need, stack = set(), list(frontier)
+    while stack:
+        u = stack.pop()
+        if u in need:
+            continue
+        need.add(u)
+        stack += list(meta[defined_at[u]][1])
+    prologue = [lines[i] for i in sorted(defined_at[u] for u in need)]
+    prologue.append("if (threadIdx.x == 0) { " + " ".join(
+        (f"*(kb::E4*)(a.uniforms + {off}) = {v};" if v.startswith("e") else f"a.uniforms[{off}] = {v};") for v, off in offsets.items()) + " }")
+    main_lines, main_meta = [], []
+    for ln, (v, uses) in zip(lines, meta):
+        if v is None or v not in uniform or not uses:
+            main_lines.append(ln); main_meta.append((v, uses))           # row arithmetic, asserts, uniform leaves
+        elif v in offsets:
+            off = offsets[v]
+            main_lines.append(f"const kb::E4 {v} = *(const kb::E4*)(a.uniforms + {off});" if v.startswith("e") else f"const uint32_t {v} = a.uniforms[{off}];")
+            main_meta.append((v, ()))
+    return main_lines, main_meta, prologue
+
+
 def emit_source(program: np.ndarray) -> str:
-    """Straight-line HIP for one chip, one kernel."""
+    """Straight-line HIP for one chip: one kernel, and in front of it (where the chip has wave-uniform arithmetic) the one-wavefront
+    kernel that fills its table of uniform values."""
     prog = np.asarray(program, dtype=np.uint32)
-    lines, meta = _ssa_lines(prog)
+    lines, meta, uniform = _ssa_lines(prog, with_uniform=True)
+    prologue = None
+    if Q_UNITABLE:
+        cut = split_uniform(lines, meta, uniform)
+        if cut is not None:
+            lines, meta, prologue = cut
     if Q_PAIR:
         lines, _ = pair_row_loads(lines, meta)
     if Q_PREFETCH:
         lines = prefetch_order(lines, Q_PREFETCH)
-    return _kernel_source(lines, int(prog[0]), int(prog[2]))
+    src = _kernel_source(lines, int(prog[0]), int(prog[2]))
+    if prologue is not None:
+        body = "\n  ".join(prologue)
+        src += f"""
+// The chip's wave-uniform values, once per launch (split_uniform): one wavefront, every lane the same arithmetic, lane 0 stores.
+extern "C" __global__ __launch_bounds__(64) void {UNIFORMS_KERNEL_NAME}(stark::QuotientArgs a) {{
+  {body}
+}}
+"""
+    return src
 
 
 

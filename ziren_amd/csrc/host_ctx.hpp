@@ -159,6 +159,7 @@ struct zkm_ctx {
   }
   // per-chip specialised quotient kernels (ziren_amd/codegen.py), keyed by a hash of the program words
   std::map<uint64_t, std::vector<hipFunction_t>> quotient_fns;   // a program's specialised kernel(s), in launch order
+  std::map<uint64_t, hipFunction_t> quotient_uniform_fns;         // ... and, where its code object has one, the kernel that fills QuotientArgs::uniforms
   std::map<uint64_t, hipFunction_t> perm_fns;                    // a lookups blob's specialised permutation-trace kernel (key: perm_key)
   std::vector<hipModule_t> modules;
   hipEvent_t get_event() {

@@ -372,12 +372,24 @@ struct ShardOpening {
     auto fit = d->program_len ? ctx->quotient_fns.find(fnv1a(d->program, d->program_len)) : ctx->quotient_fns.end();
     const bool special = fit != ctx->quotient_fns.end();
     const std::vector<hipFunction_t>* fns = special ? &fit->second : nullptr;
-    launches.push_back([this, a, fns, Q, bd, lds, qbytes]() mutable {
+    hipFunction_t uni_fn = nullptr;
+    a.uniforms = nullptr;
+    if (special) {
+      auto uit = ctx->quotient_uniform_fns.find(fit->first);
+      if (uit != ctx->quotient_uniform_fns.end()) {
+        uni_fn = uit->second;
+        a.uniforms = ctx->alloc_n<uint32_t>(stark::QUOTIENT_UNIFORM_WORDS);   // one table per chip: the kernels of a phase may follow each other closely
+        scratch.push_back(a.uniforms);
+      }
+    }
+    launches.push_back([this, a, fns, uni_fn, Q, bd, lds, qbytes]() mutable {
       if (fns) {
         // chip-specialised kernel: same arithmetic, values in VGPRs
         size_t arg_size = sizeof(a);
         void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &arg_size, HIP_LAUNCH_PARAM_END};
         ctx->flush_staged();
+        if (uni_fn)    // one wavefront computes the chip's wave-uniform values into a.uniforms; the kernel behind it on the stream reads them
+          HIP_CHECK(hipExtModuleLaunchKernel(uni_fn, 64, 1, 1, 64, 1, 1, 0, st, nullptr, config, nullptr, nullptr, 0));
         for (hipFunction_t fn : *fns) {       // several for a long program: the first stores, the others accumulate
           const bool timed = ctx->kbegin("quotient", qbytes);
           HIP_CHECK(hipExtModuleLaunchKernel(fn, div_up(Q, 256) * 256, 1, 1, 256, 1, 1, 0, st, nullptr, config,

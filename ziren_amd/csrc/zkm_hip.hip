@@ -257,7 +257,12 @@ int zkm_ctx_register_quotient_kernel(zkm_ctx* ctx, const uint32_t* program, uint
     throw;
   }
   for (hipModule_t m : mods) ctx->modules.push_back(m);
-  ctx->quotient_fns[fnv1a(program, program_len)] = fns;
+  const uint64_t key = fnv1a(program, program_len);
+  ctx->quotient_fns[key] = fns;
+  ctx->quotient_uniform_fns.erase(key);
+  hipFunction_t uni;
+  if (mods.size() == 1 && hipModuleGetFunction(&uni, mods[0], "zkm_quotient_uniforms") == hipSuccess) ctx->quotient_uniform_fns[key] = uni;
+  else (void)hipGetLastError();      // a code object without the table kernel (a program cut into parts, an older generator): not an error
   API_END
 }
 
