@@ -218,7 +218,7 @@ def test_prefetch_order_moves_loads_up_and_loses_nothing():
 def test_split_uniform_moves_every_derived_uniform_value_into_the_table_kernel_and_loses_nothing():
     """codegen.split_uniform: the kernel proper keeps every row statement and assert, declares every value before its use, computes no
     wave-uniform value itself (it reads each from the table once), and the table kernel computes — from leaves only — exactly the values
-    it stores, one slot each, 16-byte slots for extension values, inside what the library allocates."""
+    it stores, one slot for each distinct expression, 16-byte slots for extension values, inside what the library allocates."""
     from ziren_amd import chips
     n_cut = 0
     for prog in (chips.record_cpu_chip(10).program, chips.record_divrem_chip(10).program, chips.record_global_chip(10).program,
@@ -246,7 +246,7 @@ def test_split_uniform_moves_every_derived_uniform_value_into_the_table_kernel_a
         used = sorted(w for off, kind in slots for w in range(off, off + (4 if kind == "e" else 1)))
         assert used == list(range(len(used))) and len(used) <= codegen.UNIFORM_TABLE_WORDS and all(off % 4 == 0 for off, kind in slots if kind == "e")
         loaded = re.findall(r"a\.uniforms(?: \+ |\[)(\d+)", "\n".join(main))
-        assert sorted(int(x) for x in loaded) == sorted(off for off, _ in slots)
+        assert {int(x) for x in loaded} == {off for off, _ in slots}          # every slot is read; equal uniform expressions share one
         _check_defined_before_use("kb::FoldAcc acc;\n" + "\n".join(prologue[:-1]))
     assert n_cut >= 4
     src = codegen.emit_source(chips.record_cpu_chip(10).program)

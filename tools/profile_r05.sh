@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round-5 profiles of the benchmark command (default workload: the shaped fibonacci shard, tag fibs21), run on the GPU box from the repo root:
 #   gpurun --timeout 1500 -- 'bash tools/profile_r05.sh [quick] [syn]'
-# 1. the default line unprofiled                                                                    -> r05_fibs21_bench.json
+# 1. (last) the default line unprofiled, as the driver runs it (--steps 20 --warmup 5)              -> r05_fibs21_bench.json
 # 2. rocprofv3 --kernel-trace --stats of the resident leg (bench.py --resident), overlap on and off (per-kernel average durations, gaps)      -> r05_fibs21_kernel_stats.csv, r05_fibs21_idle_gaps.json
 # 3. PMC passes (separate runs, counters only): SQ wave-cycle breakdown + VALU busy (two passes)    -> r05_fibs21_sq_counters.csv
 #    FETCH_SIZE, WRITE_SIZE -> HBM bytes per launch                                                 -> r05_fibs21_hbm_traffic.json
@@ -15,7 +15,6 @@ cd /tmp && export TMPDIR=/tmp
 db() { find "$1" -name '*_results.db' | head -1; }
 QUICK=0; SYN=0
 for a in "$@"; do [ "$a" = quick ] && QUICK=1; [ "$a" = syn ] && SYN=1; done
-python $R/bench.py > $OUT/r05_fibs21_bench.json 2> $OUT/bench.err          # the default line: the claim queue from events, two lanes + the resident leg
 profile() {   # tag, extra bench args
   local T=$1; shift
   local B="python $R/bench.py --resident $* --no-cpu-baseline --no-extra"      # the resident one-lane leg: what the per-kernel figures of the line are quoted on
@@ -51,4 +50,9 @@ if [ $QUICK = 0 ]; then
   python tools/pmc_poseidon2.py "$(db $OUT/p2)" $OUT/r05_poseidon2_isa.json
   find $OUT -name '*.db' -delete; rm -rf $OUT/p2
 fi
+# the default line LAST (the claim queue from events, two lanes + the resident leg), with this run's counter traffic in place: bench.py quotes
+# roofline.traffic only from a profile whose csrc digest is the tree's
+cp $OUT/r05_fibs21_hbm_traffic.json $R/profiles/ 2>/dev/null
+cd $R
+python $R/bench.py --steps 20 --warmup 5 > $OUT/r05_fibs21_bench.json 2> $OUT/bench.err
 ls -la $OUT

@@ -31,7 +31,7 @@ PART_INSTRS = int(os.environ.get("ZKM_Q_PART", "6000"))              # a long pr
 SINGLE_KERNEL_INSTRS = int(os.environ.get("ZKM_Q_SINGLE", "12000"))  # ... when it is longer than this (KeccakSponge: 114 324; every other recorded chip is below 10 000)
 
 
-TEMPLATE_VERSION = b"13"  # bump when emit_source changes
+TEMPLATE_VERSION = b"14"  # bump when emit_source changes
 
 
 # Experiment knobs (tools/ab_quotient.sh; unset in production): waves per SIMD the compiler is told to fit the kernel into, and where a
@@ -570,16 +570,32 @@ def split_uniform(lines, meta, uniform):
     one-wavefront kernel (`zkm_quotient_uniforms`, launched in front) into a table, and the kernel proper reads the ones it needs
     with scalar loads. Returns (main lines, main meta, prologue lines) or None when there is nothing to move or the table would not fit.
     Leaves (a literal, a challenge, a public value) stay where they are read: they cost a move or one scalar load."""
+    import re
+    name_re = re.compile(r"\b[eb]\d+\b")
     defined_at = {v: i for i, (v, _) in enumerate(meta) if v is not None}
+    # equal uniform expressions get one representative (the bytecode builds the powers of beta again for every lookup): one slot, one
+    # computation in the table kernel
+    rep, by_expr, rep_line = {}, {}, {}
+    for ln, (v, uses) in zip(lines, meta):
+        if v is None or v not in uniform:
+            continue
+        head, expr = ln.split(" = ", 1)
+        expr = name_re.sub(lambda m: rep.get(m.group(0), m.group(0)), expr)
+        key = (v[0], expr)
+        if key in by_expr:
+            rep[v] = by_expr[key]
+        else:
+            by_expr[key] = rep[v] = v
+            rep_line[v] = f"{head} = {expr}"
     derived = {v for v, uses in meta if v is not None and v in uniform and uses}
     frontier, seen = [], set()
     for v, uses in meta:
         if v is not None and v in uniform:
             continue
         for u in uses:
-            if u in derived and u not in seen:
-                seen.add(u)
-                frontier.append(u)
+            if u in derived and rep[u] not in seen:
+                seen.add(rep[u])
+                frontier.append(rep[u])
     if not frontier:
         return None
     offsets, words = {}, 0
@@ -594,19 +610,29 @@ def split_uniform(lines, meta, uniform):
         if u in need:
             continue
         need.add(u)
-        stack += list(meta[defined_at[u]][1])
-    prologue = [lines[i] for i in sorted(defined_at[u] for u in need)]
+        stack += [rep[w] for w in meta[defined_at[u]][1]]
+    prologue = [rep_line[u] for u in sorted(need, key=lambda u: defined_at[u])]
     prologue.append("if (threadIdx.x == 0) { " + " ".join(
         (f"*(kb::E4*)(a.uniforms + {off}) = {v};" if v.startswith("e") else f"a.uniforms[{off}] = {v};") for v, off in offsets.items()) + " }")
     main_lines, main_meta = [], []
     for ln, (v, uses) in zip(lines, meta):
         if v is None or v not in uniform or not uses:
             main_lines.append(ln); main_meta.append((v, uses))           # row arithmetic, asserts, uniform leaves
-        elif v in offsets:
-            off = offsets[v]
+        elif rep[v] in offsets:
+            off = offsets[rep[v]]
             main_lines.append(f"const kb::E4 {v} = *(const kb::E4*)(a.uniforms + {off});" if v.startswith("e") else f"const uint32_t {v} = a.uniforms[{off}];")
             main_meta.append((v, ()))
     return main_lines, main_meta, prologue
+
+
+def _uniforms_kernel_source(prologue) -> str:
+    body = "\n  ".join(prologue)
+    return f"""
+// The chip's wave-uniform values, once per launch (split_uniform): one wavefront, every lane the same arithmetic, lane 0 stores.
+extern "C" __global__ __launch_bounds__(64) void {UNIFORMS_KERNEL_NAME}(stark::QuotientArgs a) {{
+  {body}
+}}
+"""
 
 
 def emit_source(program: np.ndarray) -> str:
@@ -625,13 +651,7 @@ def emit_source(program: np.ndarray) -> str:
         lines = prefetch_order(lines, Q_PREFETCH)
     src = _kernel_source(lines, int(prog[0]), int(prog[2]))
     if prologue is not None:
-        body = "\n  ".join(prologue)
-        src += f"""
-// The chip's wave-uniform values, once per launch (split_uniform): one wavefront, every lane the same arithmetic, lane 0 stores.
-extern "C" __global__ __launch_bounds__(64) void {UNIFORMS_KERNEL_NAME}(stark::QuotientArgs a) {{
-  {body}
-}}
-"""
+        src += _uniforms_kernel_source(prologue)
     return src
 
 
@@ -642,7 +662,12 @@ def emit_part_sources(program: np.ndarray):
     boundaries: the first kernel stores its partial quotient, the others add theirs to it. A value computed before a cut and used after
     it is recomputed by the later kernel (the statements that define it, transitively, are put in front of the part)."""
     prog = np.asarray(program, dtype=np.uint32)
-    lines, meta = _ssa_lines(prog)
+    lines, meta, uniform = _ssa_lines(prog, with_uniform=True)
+    prologue = None
+    if Q_UNITABLE:       # the wave-uniform values once per launch, for all parts: the table kernel rides in the first part's code object
+        cut = split_uniform(lines, meta, uniform)
+        if cut is not None:
+            lines, meta, prologue = cut
     if Q_PAIR:
         lines, meta = pair_row_loads(lines, meta)
     defined_at = {v: k for k, (v, _) in enumerate(meta) if v is not None}
@@ -668,6 +693,8 @@ def emit_part_sources(program: np.ndarray):
         prelude = [lines[k] for k in sorted(defined_at[u] for u in need)]
         sources.append(_kernel_source(prelude + lines[lo:hi], int(prog[0]), int(prog[2]), accumulate=n > 0,
                                       part=f"; part {n + 1} of {len(cuts)}: statements {lo}..{hi - 1}"))
+    if prologue is not None:
+        sources[0] += _uniforms_kernel_source(prologue)
     return sources
 
 

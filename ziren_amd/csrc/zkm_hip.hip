@@ -261,8 +261,8 @@ int zkm_ctx_register_quotient_kernel(zkm_ctx* ctx, const uint32_t* program, uint
   ctx->quotient_fns[key] = fns;
   ctx->quotient_uniform_fns.erase(key);
   hipFunction_t uni;
-  if (mods.size() == 1 && hipModuleGetFunction(&uni, mods[0], "zkm_quotient_uniforms") == hipSuccess) ctx->quotient_uniform_fns[key] = uni;
-  else (void)hipGetLastError();      // a code object without the table kernel (a program cut into parts, an older generator): not an error
+  if (hipModuleGetFunction(&uni, mods[0], "zkm_quotient_uniforms") == hipSuccess) ctx->quotient_uniform_fns[key] = uni;   // of a program cut into parts: in the first
+  else (void)hipGetLastError();      // a code object without the table kernel (no uniform arithmetic, an older generator): not an error
   API_END
 }
 
