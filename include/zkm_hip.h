@@ -168,7 +168,10 @@ void zkm_ctx_set_host_wait(zkm_ctx* ctx, int blocking);
  * program matches and the bytecode interpreter otherwise; both compute the same values. A long program
  * (KeccakSponge: 114 324 instructions) is cut into several kernels, handed over as one container: "ZKMQPART",
  * u32 count, u32 zero, count x u64 lengths, the code objects; the first stores its share of the quotient
- * values, the others add theirs. Registering a program again replaces its kernels. */
+ * values, the others add theirs. The (first) code object may also export `zkm_quotient_uniforms(stark::QuotientArgs)`: one
+ * wavefront that computes the chip's wave-uniform values (powers of the permutation challenges, constants times challenges) into
+ * QuotientArgs::uniforms; zkm_open launches it in front of the chip's kernel(s), which then read the table instead of every
+ * wavefront repeating that arithmetic (csrc/quotient_args.cuh). Registering a program again replaces its kernels. */
 int zkm_ctx_register_quotient_kernel(zkm_ctx* ctx, const uint32_t* program, uint32_t program_len,
                                      const void* code_object, size_t code_object_len);
 

@@ -31,7 +31,7 @@ PART_INSTRS = int(os.environ.get("ZKM_Q_PART", "6000"))              # a long pr
 SINGLE_KERNEL_INSTRS = int(os.environ.get("ZKM_Q_SINGLE", "12000"))  # ... when it is longer than this (KeccakSponge: 114 324; every other recorded chip is below 10 000)
 
 
-TEMPLATE_VERSION = b"14"  # bump when emit_source changes
+TEMPLATE_VERSION = b"15"  # bump when emit_source changes
 
 
 # Experiment knobs (tools/ab_quotient.sh; unset in production): waves per SIMD the compiler is told to fit the kernel into, and where a
@@ -50,7 +50,7 @@ def _template_key() -> bytes:
     the shared prologue (quotient_args.cuh) or the field arithmetic (kb31.cuh) can never leave a stale kernel behind."""
     h = hashlib.sha256(TEMPLATE_VERSION)
     h.update(f"{Q_WAVES},{SINGLE_KERNEL_INSTRS},{PART_INSTRS}".encode())
-    h.update(f",pf{Q_PREFETCH},{Q_AHEAD},tile{Q_TILE},pair{Q_PAIR},forms{Q_FORMS},pg{P_GROUP},sums{Q_SUMS},ut{Q_UNITABLE}".encode() + (b",fakeuni" if Q_FAKEUNI else b""))
+    h.update(f",pf{Q_PREFETCH},{Q_AHEAD},tile{Q_TILE},pair{Q_PAIR},forms{Q_FORMS},pg{P_GROUP},sums{Q_SUMS},ut{Q_UNITABLE},pt{Q_PARTS_TABLE}".encode() + (b",fakeuni" if Q_FAKEUNI else b""))
     for name in ("quotient_args.cuh", "kb31.cuh"):
         with open(os.path.join(CSRC, name), "rb") as f:
             h.update(f.read())
@@ -67,6 +67,7 @@ Q_FORMS = int(os.environ.get("ZKM_Q_FORMS", "1"))           # emit_form: 1 = bou
 
 
 Q_UNITABLE = int(os.environ.get("ZKM_Q_UNITABLE", "1"))     # split_uniform: 1 = wave-uniform values computed once per launch into a table (round 5), 0 = by every wavefront (A/B only)
+Q_PARTS_TABLE = int(os.environ.get("ZKM_Q_PARTS_TABLE", "0"))  # the table kernel for programs cut into parts as well (measured: no gain; A/B only)
 Q_FAKEUNI = int(os.environ.get("ZKM_Q_FAKEUNI", "0"))       # EXPERIMENT ONLY: derived wave-uniform values loaded from a table (wrong values; timing of a uniform-table design)
 Q_SUMS = int(os.environ.get("ZKM_Q_SUMS", "1"))             # _ssa_lines: 1 = base-field sums of products reduced once (round 5), 0 = one modular operation per bytecode instruction (A/B only)
 MAX_SUM_TERMS = 48                                          # a deferred base-field sum is emitted when it reaches this many terms (its bound stays below 127 * 2^63)
@@ -205,7 +206,7 @@ def emit_form(name: str, consts, uterms, vterms, extras) -> str:
     return " ".join(stmts) + f" const kb::E4 {name} = kb::fold_finish_bounded({acc});"
 
 
-def _ssa_lines(program: np.ndarray, with_uniform: bool = False):
+def _ssa_lines(program: np.ndarray, with_uniform: bool = False, sums: Optional[bool] = None):
     """The program as straight-line HIP statements, every register write a fresh SSA value: (lines, meta) with meta[k] = (the value line
     k defines — None for an assert —, the values it reads); with_uniform: and the set of values that are the same for every row."""
     prog = np.asarray(program, dtype=np.uint32)
@@ -241,7 +242,8 @@ def _ssa_lines(program: np.ndarray, with_uniform: bool = False):
     # of modular operations as before, or all products and leaves into one 64-bit sum (one v_mad_u64_u32 each; a leaf as a product by
     # +-R mod p, a subtracted product with p - x on one side) and ONE reduction (a b - c: three instructions less than a product, a
     # correction and a modular subtraction; a sum of k products: k - 1 reductions and k - 1 modular additions less).
-    reads = _base_read_counts(prog) if Q_SUMS else {}
+    sums = bool(Q_SUMS) if sums is None else sums
+    reads = _base_read_counts(prog) if sums else {}
     bdef = {}                # SSA base value -> {"prods": [(sign, x, y)], "leaves": [(sign, z)]} not emitted yet
 
     def buse(name):
@@ -318,7 +320,7 @@ def _ssa_lines(program: np.ndarray, with_uniform: bool = False):
             fn = {air.ADD_B: "add", air.SUB_B: "sub", air.MUL_B: "mul"}[op]
             x, y = cur_b[ra], cur_b[rb]
             v = fresh("b"); cur_b[dst] = v
-            if Q_SUMS and not (x in uniform and y in uniform):
+            if sums and not (x in uniform and y in uniform):
                 if op == air.MUL_B:
                     bdef[v] = {"prods": [(1, buse(x), buse(y))], "leaves": []}
                 else:
@@ -335,7 +337,7 @@ def _ssa_lines(program: np.ndarray, with_uniform: bool = False):
         elif op == air.NEG_B:
             x = cur_b[ra]
             v = fresh("b"); cur_b[dst] = v
-            if Q_SUMS and x not in uniform:
+            if sums and x not in uniform:
                 px, lx = bview(x, -1)
                 bdef[v] = {"prods": px, "leaves": lx}
                 continue
@@ -662,9 +664,13 @@ def emit_part_sources(program: np.ndarray):
     boundaries: the first kernel stores its partial quotient, the others add theirs to it. A value computed before a cut and used after
     it is recomputed by the later kernel (the statements that define it, transitively, are put in front of the part)."""
     prog = np.asarray(program, dtype=np.uint32)
-    lines, meta, uniform = _ssa_lines(prog, with_uniform=True)
+    # One modular operation per bytecode instruction here, and no table of uniform values: a value computed before a cut and read after it
+    # is recomputed by the later part, and a deferred sum of products (emit_sum) read in several parts is recomputed whole in each —
+    # KeccakSponge's quotient: 3.6 ms per shard this way, 5.9 ms with the sums (its XOR / AND terms are sums of products read again and
+    # again); the table kernel costs it 0.2 ms for a few scalar instructions saved (tools/ab_keccak_quotient.sh, EXPERIMENTS.md round 5).
+    lines, meta, uniform = _ssa_lines(prog, with_uniform=True, sums=False)
     prologue = None
-    if Q_UNITABLE:       # the wave-uniform values once per launch, for all parts: the table kernel rides in the first part's code object
+    if Q_UNITABLE and Q_PARTS_TABLE:
         cut = split_uniform(lines, meta, uniform)
         if cut is not None:
             lines, meta, prologue = cut
