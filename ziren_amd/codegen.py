@@ -27,7 +27,7 @@ CACHE = os.path.join(HERE, "_jit")
 KERNEL_NAME = "zkm_quotient_specialized"
 UNIFORMS_KERNEL_NAME = "zkm_quotient_uniforms"
 BLOCK = 256
-PART_INSTRS = int(os.environ.get("ZKM_Q_PART", "6000"))              # a long program is cut into kernels of about this many statements
+PART_INSTRS = int(os.environ.get("ZKM_Q_PART", "1500"))              # a long program is cut into kernels of about this many statements (KeccakSponge: 6000 -> 3.58 ms of quotient per shard, 3000 -> 3.12, 1500 -> 2.75, 800 -> 3.01: a 200 KiB kernel against a 64 KiB instruction cache)
 SINGLE_KERNEL_INSTRS = int(os.environ.get("ZKM_Q_SINGLE", "12000"))  # ... when it is longer than this (KeccakSponge: 114 324; every other recorded chip is below 10 000)
 
 
