@@ -11,17 +11,17 @@ OUT=$R/gpurun_out/shakeout; mkdir -p $OUT
 t0=$(date +%s.%N)
 ZKM_BENCH_ONE_DEVICE=1 python bench.py --gpus 8 --inflight 1 --shard-size-log 18 --steps 4 --warmup 1 > $OUT/eight_ranks.json 2> $OUT/eight_ranks.err
 rc=$?; t1=$(date +%s.%N)
-echo "eight ranks on one device: rc $rc, wall $(echo "$t1 - $t0" | bc) s"
+echo "eight ranks on one device: rc $rc, wall $(python3 -c "print(round($t1 - $t0, 1))") s"
 t0=$(date +%s.%N)
 ZKM_BENCH_ONE_DEVICE=1 python bench.py --gpus 8 --inflight 2 --shard-size-log 18 --steps 4 --warmup 1 > $OUT/eight_ranks_two_lanes.json 2> $OUT/eight_ranks_two_lanes.err
 rc2=$?; t2=$(date +%s.%N)
-echo "eight ranks x two lanes on one device: rc $rc2, wall $(echo "$t2 - $t0" | bc) s"
+echo "eight ranks x two lanes on one device: rc $rc2, wall $(python3 -c "print(round($t2 - $t0, 1))") s"
 for rep in 1 2; do
   python bench.py --steps 20 --warmup 3 --no-extra --no-cpu-baseline > $OUT/free_$rep.json 2> $OUT/free_$rep.err
   taskset -c 0-1 python bench.py --steps 20 --warmup 3 --no-extra --no-cpu-baseline > $OUT/two_cores_$rep.json 2> $OUT/two_cores_$rep.err
   taskset -c 0 python bench.py --steps 20 --warmup 3 --no-extra --no-cpu-baseline > $OUT/one_core_$rep.json 2> $OUT/one_core_$rep.err
 done
-python - "$OUT" "$(echo "$t1 - $t0" | bc)" <<'PY'
+python - "$OUT" "$(python3 -c "print(round($t1 - $t0, 1))")" <<'PY'
 import json, sys, os
 out = sys.argv[1]
 def line(name):
