@@ -43,7 +43,7 @@ profile() {   # tag, extra bench args
 }
 profile fibs21
 [ $SYN = 1 ] && profile syn22 --workload syn
-if [ $QUICK = 0 ]; then
+if [ $QUICK = 0 ] && [ -x $R/tools/ubench_p2 ]; then      # a build product (hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -I ziren_amd/csrc tools/ubench_p2.hip -o tools/ubench_p2)
   cd /tmp
   rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_WAVES -d $OUT/p2 -o p2 -- $R/tools/ubench_p2 gpu > $OUT/r05_ubench_poseidon2_int_vs_f64.txt 2> $OUT/p2.err
   cd $R
