@@ -1,3 +1,7 @@
+#!/bin/bash
+# A/B on ONE box (round 5): the generated quotient kernels capped at four waves per SIMD (ZKM_Q_WAVES=4: 128 registers, a few words
+# spilled) against the compiler's choice (134 registers, three waves): the resident leg's quotient time, then the default line.
+#   gpurun --timeout 1800 -- 'bash tools/ab_waves.sh'
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}; cd $R
 python -m pytest tests/test_codegen.py -m gpu -x -q 2>&1 | tail -2
@@ -13,4 +17,3 @@ for rep in 1 2; do
   run waves4 ZKM_Q_WAVES=4
 done
 bash tools/ab_default_line.sh ZKM_Q_WAVES 0 4 2 40
-python tools/bench_keccak_shard.py --steps 3 > gpurun_out/ab6/r05_keccak_shard.json 2> gpurun_out/ab6/keccak.err; tail -c 900 gpurun_out/ab6/r05_keccak_shard.json
