@@ -41,9 +41,9 @@ os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")      # before anything initi
 HBM_PEAK_GBPS = 8000.0     # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 FP64_VECTOR_TFLOPS = 78.6  # MI355X FP64 vector peak: 256 CUs x 4 SIMDs x 16 lanes x 2 flop x 2.4 GHz (MI355X_MICROARCH.md)
 PROFILE_ROUND = "r05"
-HASHING_KERNELS = ("compress_layer", "hash_leaves", "hash_leaves_tree", "hash_fri_leaves", "hash_fri_leaves_tree", "compress_small", "compress_tail")
+HASHING_KERNELS = ("compress_layer", "compress_layer_rowdig", "hash_leaves", "hash_rows", "hash_leaves_tree", "hash_fri_leaves", "hash_fri_leaves_tree", "compress_small", "compress_tail")
 LDE_KERNELS = ("lde_rows", "lde_cols_forward", "lde_cols_inverse")
-ROCPROF_NAMES = {"compress_layer": "merkle::compress_layer", "hash_leaves": "merkle::hash_leaves", "hash_leaves_tree": "merkle::hash_leaves_tree",
+ROCPROF_NAMES = {"compress_layer": "merkle::compress_layer", "hash_leaves": "merkle::hash_leaves", "hash_rows": "merkle::hash_rows", "hash_leaves_tree": "merkle::hash_leaves_tree",
                  "lde_rows": "lde::lde_rows_big", "lde_cols_forward": "lde::lde_cols<true>", "lde_cols_inverse": "lde::lde_cols<false>"}
 
 PROVER_SOURCES = ("kb31.cuh", "lde.cuh", "merkle.cuh", "open.cuh", "poseidon2.cuh", "poseidon2_constants.inc", "poseidon2_f64.cuh", "quotient_args.cuh",
@@ -263,7 +263,7 @@ def accumulate(acc, ctx):
 
 def resident_leg(farm, wl, hp, pk, ch0, traces, steps, warmup, kernel_timing):
     """W warm-up proofs, then exactly K timed proofs between barriers, traces resident in HBM. Inside the timed region only the dominant
-    kernel (the one the roofline is quoted on: the kernel with the most HIP-event time in the last warm-up proof) is timed; the per-kernel
+    kernel (the one the roofline is quoted on: the kernel with the most HIP-event time in a warm-up proof that runs every kernel alone) is timed; the per-kernel
     table comes from a pass after it (timing every launch >= 256 KiB costs ~2.5 % of a step)."""
     from ziren_amd import lib
     L = lib.load()
@@ -279,6 +279,14 @@ def resident_leg(farm, wl, hp, pk, ch0, traces, steps, warmup, kernel_timing):
         step()
     dominant = None
     if kernel_timing == 3:
+        # ranked on a proof with the side-stream LDE overlap off: with it on, a side-stream launch stretches under the leaf hashing it runs
+        # beside (lde_cols_inverse: 12.7 ms of HIP-event time for 1.9 ms of work) and would be picked for a duration that is not its own
+        if hasattr(L, "zkm_ctx_set_lde_overlap"):
+            env = os.environ.get("ZKM_LDE_OVERLAP")
+            was_on = not (env is not None and env.strip().lstrip("+-").isdigit() and int(env) == 0)     # the context's default (host_ctx.hpp)
+            L.zkm_ctx_set_lde_overlap(ctx.h, C.c_int(0))
+            step()
+            L.zkm_ctx_set_lde_overlap(ctx.h, C.c_int(1 if was_on else 0))
         last = ctx.kernel_timings()
         if last:
             dominant = max(last, key=lambda t: t[1])[0]
@@ -371,7 +379,7 @@ def roofline_objects(wl, fri, leg, steps):
         if os.path.exists(spath):
             import csv
             rows = {r["Name"]: r for r in csv.DictReader(open(spath))}
-            valu["valu_pipe_busy_pct_measured"] = {n: float(rows[n]["ValuPipeBusyPct(of SIMD time)"]) for n in ("merkle::compress_layer", "merkle::hash_leaves")
+            valu["valu_pipe_busy_pct_measured"] = {n: float(rows[n]["ValuPipeBusyPct(of SIMD time)"]) for n in ("merkle::compress_layer", "merkle::compress_layer_rowdig", "merkle::hash_leaves", "merkle::hash_rows")
                                                    if n in rows and rows[n].get("ValuPipeBusyPct(of SIMD time)")}
             valu["valu_pipe_busy_source"] = os.path.relpath(spath, ROOT)
     lde = None

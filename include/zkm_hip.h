@@ -156,6 +156,11 @@ void zkm_ctx_set_kernel_timing_only(zkm_ctx* ctx, const char* name);
  * off: every kernel of a proof runs alone on the main stream, so per-kernel HIP-event durations add up to the proof's busy time
  * (a measurement mode: the proof is the same words, ~0.7 ms slower). The environment's ZKM_LDE_OVERLAP=0 sets the default to off. */
 void zkm_ctx_set_lde_overlap(zkm_ctx* ctx, int on);
+/* on (default): a commit whose matrices are all on the device hashes the rows of every shorter height in ONE launch in front of the tree
+ * levels (merkle::hash_rows; a level with injection then takes two permutations per node). off: a level's kernel runs its node's whole
+ * row sponge itself (rounds 1-5; also what a commit does while a matrix is still crossing PCIe). Same digests either way. The
+ * environment's ZKM_ROWS_UP_FRONT=0 sets the default to off. */
+void zkm_ctx_set_rows_up_front(zkm_ctx* ctx, int on);
 /* How the calling thread waits for this context's GPU work. 0 (default): it spins (hipStreamSynchronize, and the FRI layer roots are
  * watched arriving in page-locked memory) — lowest latency, one host core per context for the length of a proof. 1: it sleeps on an
  * interrupt-backed event — about a millisecond more per proof for a context alone, nothing measurable when two contexts share a GPU,

@@ -294,6 +294,40 @@ def test_pcs_commit_rows_that_start_with_constant_columns(hip_ctx, oracle, bl):
         d.free()
 
 
+@pytest.mark.parametrize("bl", [1, 2])
+def test_rows_hashed_up_front_or_inside_the_tree_levels_same_commitment(hip_ctx, oracle, bl):
+    """build_tree hashes the rows of a commit's shorter heights in one launch in front of the tree levels (merkle::hash_rows, the default
+    when every matrix is on the device) or inside compress_layer (zkm_ctx_set_rows_up_front 0; also the path of a commit that is still
+    waiting for a matrix). Same root, same authentication paths, both equal to the oracle's: ragged widths (1, 7, 8, 9, 41 columns),
+    two matrices of one height, a height whose row is constant altogether, constant columns in front (sponge_prefix feeds both paths),
+    heights down to a single row, and a commit with nothing below the top (no hash_rows launch at all)."""
+    import ctypes as C
+    from ziren_amd import lib
+    rng = np.random.default_rng(991 + bl)
+    const = lambda h, w: np.repeat(rand(rng, (1, w)), h, axis=0)
+    cases = ([rand(rng, (1 << 15, 9)), rand(rng, (1 << 14, 41)), rand(rng, (1 << 14, 7)), const(1 << 13, 11), const(1 << 12, 16), rand(rng, (1 << 12, 1)),
+              rand(rng, (1 << 10, 8)), rand(rng, (64, 3)), rand(rng, (2, 5)), rand(rng, (1, 9))],
+             [rand(rng, (1 << 12, 5)), rand(rng, (1 << 12, 12))],
+             [rand(rng, (1 << 16, 2)), rand(rng, (1 << 15, 130))])
+    try:
+        for mats in cases:
+            mats = [np.ascontiguousarray(m) for m in mats]
+            root_o, _, _ = oracle.pcs_commit(mats, bl)
+            maxh = max(m.shape[0] for m in mats) << bl
+            got = []
+            for up_front in (1, 0):
+                lib.load().zkm_ctx_set_rows_up_front(hip_ctx.h, C.c_int(up_front))
+                d = prover.pcs_commit(hip_ctx, [hip_ctx.upload(m) for m in mats], bl)
+                assert np.array_equal(d.root, root_o), up_front
+                got.append([d.open_batch(idx) for idx in (0, 3, maxh // 2 + 1, maxh - 1)])
+                d.free()
+            for (v1, p1), (v0, p0), idx in zip(got[0], got[1], (0, 3, maxh // 2 + 1, maxh - 1)):
+                vo, po, ok = oracle.pcs_open_batch(mats, bl, idx)
+                assert ok and np.array_equal(v1, vo) and np.array_equal(p1, po) and np.array_equal(v0, vo) and np.array_equal(p0, po)
+    finally:
+        lib.load().zkm_ctx_set_rows_up_front(hip_ctx.h, C.c_int(1))
+
+
 def test_pcs_commit_shifted_domains(hip_ctx, oracle):
     rng = np.random.default_rng(77)
     mats = [rand(rng, (256, 4)), rand(rng, (256, 4))]
@@ -732,9 +766,10 @@ def test_kernel_timing_modes(hip_ctx, oracle):
     pk = hp.setup([], [], shard.pc_start, shard.initial_global_cumulative_sum)
     traces = hp.upload_traces([c.trace for c in shard.chips])
     seen, proofs = {}, []
-    for mode in ("only", 2, 0):
-        if mode == "only":
-            lib.load().zkm_ctx_set_kernel_timing_only(hip_ctx.h, b"compress_layer")
+    for mode in (2, "only", 0):
+        if mode == "only":      # the tree levels with injection: compress_layer_rowdig when the rows are hashed up front (the default), else compress_layer
+            target = "compress_layer_rowdig" if "compress_layer_rowdig" in seen[2] else "compress_layer"
+            lib.load().zkm_ctx_set_kernel_timing_only(hip_ctx.h, target.encode())
         else:
             lib.load().zkm_ctx_set_kernel_timing(hip_ctx.h, C.c_int(mode))
         ch = prover.new_challenger()
@@ -742,7 +777,7 @@ def test_kernel_timing_modes(hip_ctx, oracle):
         proofs.append(hp.prove_shard(pk, shard.public_values, traces, ch).copy())
         seen[mode] = {name for name, ms, calls, nbytes in hip_ctx.kernel_timings() if calls}
     lib.load().zkm_ctx_set_kernel_timing(hip_ctx.h, C.c_int(2))
-    assert seen["only"] == {"compress_layer"} and seen[0] == set() and {"compress_layer", "hash_leaves", "quotient"} <= seen[2]
+    assert seen["only"] == {target} and seen[0] == set() and {target, "hash_leaves", "quotient"} <= seen[2]
     assert np.array_equal(proofs[0], proofs[1]) and np.array_equal(proofs[0], proofs[2])
 
 

@@ -130,6 +130,9 @@ struct zkm_ctx {
   // ZKM_LDE_OVERLAP=0 turns it off for every context of the process). Off, every kernel of a proof runs alone on the main stream and
   // the per-kernel HIP-event durations add up to the busy time.
   bool lde_overlap = !(getenv("ZKM_LDE_OVERLAP") && atoi(getenv("ZKM_LDE_OVERLAP")) == 0);
+  // build_tree: the rows of a commit's shorter heights hashed by one launch in front of the tree levels (merkle::hash_rows) instead of
+  // inside compress_layer; ZKM_ROWS_UP_FRONT=0 for the A/B
+  bool rows_up_front = !(getenv("ZKM_ROWS_UP_FRONT") && atoi(getenv("ZKM_ROWS_UP_FRONT")) == 0);
   bool root_poll = !(getenv("ZKM_ROOT_POLL") && atoi(getenv("ZKM_ROOT_POLL")) == 0);   // wait_root; cleared for good by its first timeout
   int root_spin_before_yield = getenv("ZKM_ROOT_SPIN") ? atoi(getenv("ZKM_ROOT_SPIN")) : 4096;   // wait_root: spins before it starts yielding the core
   int root_sleep_ns = getenv("ZKM_ROOT_SLEEP_NS") ? atoi(getenv("ZKM_ROOT_SLEEP_NS")) : 0;        // > 0: past the spins it sleeps this long between looks instead of yielding

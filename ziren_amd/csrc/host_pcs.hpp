@@ -195,7 +195,11 @@ static void wait_root(zkm_ctx* ctx, const uint32_t* h_root, bool pollable) {
 
 // MerkleTreeMmcs::commit over column-major matrices of power-of-two heights.
 static void build_tree(zkm_ctx* ctx, const std::vector<zkm_matrix>& mats, Tree& t,
-                       const std::function<void(size_t)>& prepare_height = nullptr, const std::vector<const uint32_t*>* col_flags = nullptr) {
+                       const std::function<void(size_t)>& prepare_height = nullptr, const std::vector<const uint32_t*>* col_flags = nullptr,
+                       bool rows_up_front = false) {
+  // rows_up_front (pcs_commit, when every matrix is on the device already): the rows of all shorter heights are hashed by ONE launch
+  // (merkle::hash_rows) right after the leaves, and a layer with injection takes two permutations per node
+  // (merkle::compress_layer_rowdig) instead of running the row's sponge inside compress_layer.
   // col_flags (pcs_commit): per matrix the constant-column flags its LDE left (two words per column, lde::Mat::cflag), or null. Where
   // the row injected at a layer starts with constant columns, the sponge over them is computed once (merkle::sponge_prefix).
   // prepare_height(h), when given, is called right before the matrices of height h are first read: pcs_commit extends
@@ -277,10 +281,50 @@ static void build_tree(zkm_ctx* ctx, const std::vector<zkm_matrix>& mats, Tree& 
   // <= 64-node layers go in one launch
   size_t min_h = maxh;
   for (auto& m : mats) min_h = std::min(min_h, m.h);
+  // rows_up_front: every shorter height's row digests, one launch; groups ordered by permutations per row, longest first
+  std::map<size_t, uint32_t*> rowdig;
+  uint32_t* rowdig_buf = nullptr;
+  if (rows_up_front && min_h < maxh) {
+    std::vector<size_t> hs;
+    size_t rows = 0;
+    for (auto& kv : tables)
+      if (kv.first < maxh && kv.second.first) { hs.push_back(kv.first); rows += kv.first; }
+    std::sort(hs.begin(), hs.end(), [&](size_t a, size_t b) {
+      const size_t pa = (tables[a].second + 7) / 8, pb = (tables[b].second + 7) / 8;
+      return pa != pb ? pa > pb : a > b;
+    });
+    rowdig_buf = ctx->alloc_n<uint32_t>(rows * 8);
+    std::vector<merkle::RowGroup> groups;
+    size_t off = 0, blocks = 0;
+    double bytes = 0;
+    for (size_t h : hs) {
+      wait_height(h);
+      const uint32_t* prefix = nullptr;
+      if (flag_tables.count(h) && flag_tables[h]) {   // after wait_height: the flags are final once the matrices' LDE is queued
+        uint32_t* out = prefixes + 32 * prefix_no++;
+        KLAUNCH(ctx, "sponge_prefix", 0.0, merkle::sponge_prefix, dim3(1), dim3(64), 0, (const uint32_t* const*)flag_tables[h], (int)tables[h].second, out);
+        prefix = out;
+      }
+      rowdig[h] = rowdig_buf + off * 8;
+      groups.push_back(merkle::RowGroup{(const uint32_t* const*)tables[h].first, prefix, rowdig[h], (uint32_t)h, (int)tables[h].second, (uint32_t)blocks});
+      off += h;
+      blocks += div_up(h, merkle::THREADS);
+      bytes += 4.0 * h * tables[h].second + 32.0 * h;
+    }
+    const merkle::RowGroup* d_groups = (const merkle::RowGroup*)ctx->upload_staged(groups.data(), groups.size() * sizeof(merkle::RowGroup));
+    to_free.push_back((const uint32_t**)d_groups);
+    KLAUNCH(ctx, "hash_rows", bytes, merkle::hash_rows, dim3((unsigned)blocks), dim3(merkle::THREADS), 0, d_groups, (int)groups.size());
+  }
   int layer = fuse;
   for (size_t len = maxh >> (fuse + 1); len >= 1; len >>= 1, layer++) {
     if (min_h > len) {
       if (compress_small_layer(ctx, t, layer, len)) break;
+      continue;
+    }
+    if (rowdig.count(len)) {
+      KLAUNCH(ctx, "compress_layer_rowdig", 96.0 * len + 32.0 * len, merkle::compress_layer_rowdig, dim3(div_up(len, merkle::THREADS)), dim3(merkle::THREADS), 0,
+              (const uint32_t*)(t.digests + t.layer_off[layer] * 8), t.digests + t.layer_off[layer + 1] * 8, len, (const uint32_t*)rowdig[len]);
+      if (len == 1) break;
       continue;
     }
     const uint32_t** d = tables.count(len) ? tables[len].first : nullptr;
@@ -299,6 +343,7 @@ static void build_tree(zkm_ctx* ctx, const std::vector<zkm_matrix>& mats, Tree& 
   }
   for (auto d : to_free) ctx->release((void*)d);
   ctx->release(prefixes);
+  ctx->release(rowdig_buf);
 }
 
 static void free_pcs_data(zkm_ctx* ctx, zkm_pcs_data* d) {
@@ -381,7 +426,10 @@ static zkm_pcs_data* pcs_commit(zkm_ctx* ctx, const std::vector<zkm_matrix>& mat
       }
       lde_batch(ctx, jobs, log_blowup);
     };
-    build_tree(ctx, d->ldes, d->tree, extend_height, &col_flags);
+    // every matrix on the device and extended (or queued) already: the shorter heights' rows are hashed in one launch (ZKM_ROWS_UP_FRONT=0:
+    // inside compress_layer, as before round 5's last step); a matrix still crossing PCIe keeps the layer-by-layer order that waits for it late
+    const bool rows_up_front = ctx->rows_up_front && std::all_of(extended.begin(), extended.end(), [](char e) { return e != 0; });
+    build_tree(ctx, d->ldes, d->tree, extend_height, &col_flags, rows_up_front);
     ctx->side_join();
     ctx->release(cflags);
     cflags = nullptr;

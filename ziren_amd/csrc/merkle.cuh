@@ -115,6 +115,63 @@ __global__ __launch_bounds__(THREADS) void compress_layer(const uint32_t* __rest
   store_digest(next + 8 * i, s);
 }
 
+// ---- the rows of every shorter height hashed up front (round 5) --------------------------------------------------------------------
+// compress_layer with injection runs a node's whole sponge (up to ~60 permutations for the benchmarked shard's 2^19 layer) in the thread
+// that also compresses the node: 128 registers, four waves per SIMD, and a layer of 2^18 - 2^19 nodes is one or two rounds of waves that
+// live a millisecond — its launches run at 86 - 93 % VALU busy where hash_leaves (36 registers, 6.6 waves) runs at 96.5 %
+// (profiles/r05_compress_layer_dispatches.csv). The sponge of an injected row does not depend on the tree below it, only the last
+// compression does: hash_rows hashes the rows of ALL shorter heights of a commit in one launch (groups ordered longest row first, so
+// the launch's tail is made of the short rows), compress_layer_rowdig then takes two permutations per node.
+struct RowGroup {
+  const uint32_t* const* cols;  // the height's column pointers (all matrices of that height, in commit order)
+  const uint32_t* prefix;       // sponge_prefix's output for that height, or null
+  uint32_t* out;                // [height][8] row digests (Montgomery words)
+  uint32_t height;
+  int width;
+  uint32_t first_block;         // of this group in the launch's grid
+};
+__global__ __launch_bounds__(THREADS) void hash_rows(const RowGroup* __restrict__ groups, int n_groups) {
+  int gi = 0;
+  while (gi + 1 < n_groups && blockIdx.x >= gp::load(&groups[gi + 1].first_block)) gi++;
+  const RowGroup* g = groups + gi;
+  const size_t r = (size_t)(blockIdx.x - gp::load(&g->first_block)) * blockDim.x + threadIdx.x;
+  if (r >= gp::load(&g->height)) return;
+  const uint32_t* prefix = gp::load(&g->prefix);
+  const uint32_t* const* cols = gp::load(&g->cols);
+  int width = gp::load(&g->width);
+  double s[16];
+  if (prefix) {
+    const int skip = (int)gp::load(prefix + 16);
+#pragma unroll
+    for (int k = 0; k < 16; k++) s[k] = p2f::load_monty(gp::load(prefix + k));
+    cols += 8 * skip;
+    width -= 8 * skip;   // <= 0: every column of the row is constant, the prefix state is the row's sponge
+  } else {
+#pragma unroll
+    for (int k = 0; k < 16; k++) s[k] = 0.0;
+  }
+  absorb_row(s, cols, width, r);
+  store_digest(gp::load(&g->out) + r * 8, s);
+}
+// next[i] = compress(compress(prev[2i], prev[2i+1]), rowdig[i]); one call site of the permutation
+__global__ __launch_bounds__(THREADS) void compress_layer_rowdig(const uint32_t* __restrict__ prev, uint32_t* __restrict__ next, size_t m,
+                                                                 const uint32_t* __restrict__ rowdig) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m) return;
+  double s[16];
+  load_digest(s, prev + 16 * i);
+  load_digest(s + 8, prev + 16 * i + 8);
+  const uint4* rd = reinterpret_cast<const uint4*>(rowdig + 8 * i);
+  const uint4 a = rd[0], b = rd[1];   // requested a permutation ahead of their use
+  for (int ph = 0;; ph++) {
+    p2f::permute(s);
+    if (ph == 1) break;
+    s[8] = p2f::load_monty(a.x); s[9] = p2f::load_monty(a.y); s[10] = p2f::load_monty(a.z); s[11] = p2f::load_monty(a.w);
+    s[12] = p2f::load_monty(b.x); s[13] = p2f::load_monty(b.y); s[14] = p2f::load_monty(b.z); s[15] = p2f::load_monty(b.w);
+  }
+  store_digest(next + 8 * i, s);
+}
+
 // Top of the tree in one launch: starting from a layer of 2*len0 digests at `prev`, compress down to the
 // root; the layers are contiguous in memory (2*len0, len0, len0/2, ..., 1 digests). One block; a
 // barrier between levels makes the freshly written layer visible to the block.

@@ -212,6 +212,7 @@ void zkm_ctx_set_kernel_timing(zkm_ctx* ctx, int mode) { ctx->kernel_timing = mo
 void zkm_ctx_set_kernel_timing_only(zkm_ctx* ctx, const char* name) { ctx->timing_only = name ? name : ""; ctx->kernel_timing = 3; }
 void zkm_ctx_set_host_wait(zkm_ctx* ctx, int blocking) { std::lock_guard<std::mutex> lk(ctx->mu); ctx->host_wait_blocking = blocking != 0; }
 void zkm_ctx_set_lde_overlap(zkm_ctx* ctx, int on) { std::lock_guard<std::mutex> lk(ctx->mu); ctx->lde_overlap = on != 0; }
+void zkm_ctx_set_rows_up_front(zkm_ctx* ctx, int on) { std::lock_guard<std::mutex> lk(ctx->mu); ctx->rows_up_front = on != 0; }
 
 int zkm_ctx_register_quotient_kernel(zkm_ctx* ctx, const uint32_t* program, uint32_t program_len, const void* code_object,
                                      size_t code_object_len) {

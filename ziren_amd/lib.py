@@ -12,7 +12,7 @@ _LIB = None
 
 # every symbol include/zkm_hip.h declares
 EXPORTS = [
-    "zkm_last_error", "zkm_build_info", "zkm_ctx_create", "zkm_ctx_destroy", "zkm_ctx_synchronize", "zkm_ctx_trim", "zkm_ctx_last_timings", "zkm_ctx_kernel_timings", "zkm_ctx_set_kernel_timing", "zkm_ctx_set_kernel_timing_only", "zkm_ctx_set_lde_overlap", "zkm_ctx_set_host_wait", "zkm_ctx_register_quotient_kernel", "zkm_ctx_register_perm_kernel",
+    "zkm_last_error", "zkm_build_info", "zkm_ctx_create", "zkm_ctx_destroy", "zkm_ctx_synchronize", "zkm_ctx_trim", "zkm_ctx_last_timings", "zkm_ctx_kernel_timings", "zkm_ctx_set_kernel_timing", "zkm_ctx_set_kernel_timing_only", "zkm_ctx_set_lde_overlap", "zkm_ctx_set_rows_up_front", "zkm_ctx_set_host_wait", "zkm_ctx_register_quotient_kernel", "zkm_ctx_register_perm_kernel",
     "zkm_host_alloc", "zkm_host_free", "zkm_matrix_upload", "zkm_matrix_upload_async", "zkm_matrix_wait", "zkm_events_upload_async", "zkm_events_free", "zkm_matrix_download", "zkm_matrix_height", "zkm_matrix_width", "zkm_matrix_free",
     "zkm_pcs_commit", "zkm_pcs_data_free", "zkm_pcs_data_get_lde", "zkm_pcs_open_batch",
     "zkm_pk_setup", "zkm_pk_commitment", "zkm_pk_observe_into", "zkm_pk_free",
@@ -94,7 +94,7 @@ def load():
         L.zkm_host_reduce96_bounded.restype = C.c_uint32
         L.zkm_host_reduce96_bounded.argtypes = [C.c_uint32, C.c_uint64]
     L.zkm_host_two_adic_generator.restype = C.c_uint32
-    for name in ("zkm_ctx_destroy", "zkm_host_free", "zkm_events_free", "zkm_byte_lookups_free", "zkm_ctx_set_kernel_timing", "zkm_ctx_set_kernel_timing_only", "zkm_ctx_set_lde_overlap", "zkm_ctx_set_host_wait", "zkm_matrix_free", "zkm_pcs_data_free", "zkm_pk_free", "zkm_main_data_free",
+    for name in ("zkm_ctx_destroy", "zkm_host_free", "zkm_events_free", "zkm_byte_lookups_free", "zkm_ctx_set_kernel_timing", "zkm_ctx_set_kernel_timing_only", "zkm_ctx_set_lde_overlap", "zkm_ctx_set_rows_up_front", "zkm_ctx_set_host_wait", "zkm_matrix_free", "zkm_pcs_data_free", "zkm_pk_free", "zkm_main_data_free",
                  "zkm_challenger_init", "zkm_challenger_observe", "zkm_host_poseidon2_permute", "zkm_host_poseidon2_permute_f64", "zkm_host_poseidon2_f64_sponge",
                  "zkm_host_poseidon2_f64_compress_inject", "zkm_host_poseidon2_f64_audit", "zkm_host_ext_mul", "zkm_host_ext_inv"):
         if hasattr(L, name) or "ZKM_HIP_LIB" not in os.environ:   # an older build under A/B comparison may lack the newest entry points
