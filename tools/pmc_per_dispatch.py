@@ -22,17 +22,17 @@ def main(db_path, pattern, out_path):
                       f"where kernel_name like ? group by {ident}, counter_name", (f"%{pattern}%",)).fetchall()
     per = collections.OrderedDict()
     for did, k, c, v, dur, g, st in sorted(rows, key=lambda r: (r[6], r[0])):
-        d = per.setdefault(did, {"dur": dur, "grid": g})
+        d = per.setdefault(did, {"dur": dur, "grid": g, "name": k.split("(")[0].replace("void ", "")})
         d[c] = v
     with open(out_path, "w", newline="") as f:
         w = csv.writer(f)
-        w.writerow(["dispatch", "grid_work_items", "duration_us", "waves", "valu_insts_per_wave", "valu_pipe_busy_pct", "mean_waves_per_simd"])
+        w.writerow(["dispatch", "kernel", "grid_work_items", "duration_us", "waves", "valu_insts_per_wave", "valu_pipe_busy_pct", "mean_waves_per_simd"])
         for did, d in per.items():
             gui = d.get("GRBM_GUI_ACTIVE", 0)
             waves = max(d.get("SQ_WAVES", 0), 1)
             busy = round(100 * d.get("SQ_ACTIVE_INST_VALU", 0) * 4 / (gui / 8 * N_SIMD), 1) if gui else ""
             res = round(d.get("SQ_WAVE_CYCLES", 0) * 4 / (gui / 8 * N_SIMD), 2) if gui else ""
-            w.writerow([did, d["grid"], round(d["dur"] / 1e3, 1), int(d.get("SQ_WAVES", 0)), round(d.get("SQ_INSTS_VALU", 0) / waves), busy, res])
+            w.writerow([did, d["name"], d["grid"], round(d["dur"] / 1e3, 1), int(d.get("SQ_WAVES", 0)), round(d.get("SQ_INSTS_VALU", 0) / waves), busy, res])
     print("wrote", out_path, len(per), "dispatches; columns seen:", cols)
 
 

@@ -9,6 +9,7 @@ rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_ACTIVE_I
   python $R/bench.py --resident --no-cpu-baseline --no-extra --steps 1 --warmup 1 --kernel-timing 0 > /dev/null 2> $OUT/c.err
 cd $R
 DB=$(find $OUT/c -name '*_results.db' | head -1)
+python tools/pmc_per_dispatch.py "$DB" "" $R/gpurun_out/r05_all_dispatches.csv
 python tools/pmc_per_dispatch.py "$DB" compress_layer $R/gpurun_out/r05_compress_layer_dispatches.csv
 python tools/pmc_per_dispatch.py "$DB" hash_leaves $R/gpurun_out/r05_hash_leaves_dispatches.csv
 python tools/pmc_per_dispatch.py "$DB" hash_rows $R/gpurun_out/r05_hash_rows_dispatches.csv
