@@ -222,6 +222,9 @@ class Farm:
                 raise RuntimeError("a shard was proven by no rank")
             return out
         torch, dist = self.torch, self.dist
+        trace = os.environ.get("ZKM_FARM_TRACE") == "1"
+        marks = [("start", time.perf_counter())]
+        mark = (lambda name: marks.append((name, time.perf_counter()))) if trace else (lambda name: None)
         lens = np.zeros(n_shards + self.world, dtype=np.int64)     # [length of every shard's stream] ++ [words held per rank]
         for i, p in zip(shard_ids, proofs):
             lens[i] = len(p)
@@ -229,30 +232,57 @@ class Farm:
         t = torch.from_numpy(lens).to(self.device)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)           # disjoint entries: every rank learns every length
         lens = t.cpu().numpy()
+        mark("lengths all-reduced")
         if (lens[:n_shards] == 0).any():                   # known on every rank: nobody is left waiting in the gather
             raise RuntimeError("a shard was proven by no rank")
         cap = int(lens[n_shards:].max())
-        mine = np.zeros(cap + n_shards, dtype=np.uint32)    # [ids this rank holds (0xffffffff padded)] ++ [their words, concatenated]
+        # [ids this rank holds (0xffffffff padded)] ++ [their words, concatenated]; on a GPU the send buffer is page-locked and kept: a fresh
+        # pageable array of a few MB now and then takes 25 ms to cross PCIe (first-touch faults under the staging copy), inside the timed region
+        pinned = None
+        if self.device.type == "cuda":
+            pinned = getattr(self, "_send_pin", None)
+            if pinned is None or pinned.numel() < cap + n_shards:
+                pinned = self._send_pin = torch.empty(max(cap + n_shards, 1 << 20), dtype=torch.int32, pin_memory=True)
+            mine = pinned.numpy()[:cap + n_shards].view(np.uint32)      # what lies behind this rank's own words is never read
+        else:
+            mine = np.empty(cap + n_shards, dtype=np.uint32)
         mine[:n_shards] = 0xFFFFFFFF
         mine[:len(shard_ids)] = shard_ids
         off = n_shards
         for p in proofs:
             mine[off:off + len(p)] = np.asarray(p, dtype=np.uint32)
             off += len(p)
-        buf = torch.from_numpy(mine.view(np.int32)).to(self.device)
+        buf = (pinned[:cap + n_shards].to(self.device, non_blocking=True) if pinned is not None else torch.from_numpy(mine.view(np.int32)).to(self.device))
+        mark("packed, copy queued")
         bufs = [torch.empty_like(buf) for _ in range(self.world)] if self.rank == 0 else None
         dist.gather(buf, bufs, dst=0)
+        mark("gather queued")
         if self.rank != 0:
             return None
         out = [None] * n_shards
+        if self.device.type == "cuda":          # one page-locked landing buffer for all ranks' words, one synchronisation
+            need = sum(int(b.numel()) for b in bufs)
+            recv = getattr(self, "_recv_pin", None)
+            if recv is None or recv.numel() < need:
+                recv = self._recv_pin = torch.empty(max(need, 1 << 20), dtype=torch.int32, pin_memory=True)
+            views, o = [], 0
+            for b in bufs:
+                recv[o:o + b.numel()].copy_(b, non_blocking=True)
+                views.append(recv[o:o + b.numel()])
+                o += b.numel()
+            torch.cuda.current_stream().synchronize()
+            bufs = views
         for b in bufs:
-            b = b.cpu().numpy().view(np.uint32)
+            b = b.numpy().view(np.uint32)
             off = n_shards
             for i in b[:n_shards]:
                 if i == 0xFFFFFFFF:
                     break
                 out[int(i)] = b[off:off + int(lens[i])].copy()
                 off += int(lens[i])
+        mark("unpacked")
+        if trace:
+            print("gather_proofs: " + ", ".join(f"{b[0]} {1e3 * (b[1] - a[1]):.2f} ms" for a, b in zip(marks, marks[1:])), file=sys.stderr, flush=True)
         return out
 
     def timed(self, step: Callable[[], None], steps: int, warmup: int) -> float:
