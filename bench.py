@@ -728,7 +728,7 @@ def farm_main(args, farm, fri):
     t0 = time.perf_counter()
     ids, proofs = farm.run_queue(n_shards, lanes=pairs)
     t_g = time.perf_counter()
-    gathered = farm.gather_proofs(ids, proofs, n_shards)
+    gathered = farm.gather_proofs(ids, proofs, n_shards, copy=False)
     t_b = time.perf_counter()
     farm.barrier()
     gather_s = (t_b - t_g, time.perf_counter() - t_b)      # the gather (with this rank's wait for the slowest rank's last proof), the closing barrier
