@@ -680,10 +680,14 @@ LINE_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "shards", "warmup", "
              "shards_proved", "shards_proved_by_rank0", "fewest_shards_on_a_rank", "lib_digest", "wall_s")
 
 
-def farm_main(args, farm, fri):
-    """The one experiment behind every `--gpus N` (module docstring): K N shards through the claim queue, M lanes per GPU."""
+def build_and_warm_lanes(args, fri, rank, local_rank):
+    """A rank's lanes (contexts, key, page-locked event pool) and their warm-up proofs. bench.py runs this BEFORE the process group exists:
+    HIP deals a process's streams onto a few hardware queues in the order they are made (GPU_MAX_HW_QUEUES, four by default), and which
+    streams end up sharing one is worth up to 3 ms per shard (profiles/r05_ab_hw_queues.txt: 43.2 ms with the prover's streams made first,
+    44.4-45.0 when torch.cuda and RCCL made theirs first, 46-52 ms for the unlucky counts) — so every rank of every N makes the prover's
+    streams first, in the order the N = 1 line makes them, and torch / RCCL take what is left for streams that are idle while shards are
+    proven."""
     t_start = time.perf_counter()
-    rank, local_rank, world = farm.rank, farm.local_rank, farm.world
     stub = os.environ.get("ZKM_BENCH_STUB_PROVER") == "1"
     specialize = not args.interpreter
     M = max(1, args.inflight)
@@ -693,14 +697,6 @@ def farm_main(args, farm, fri):
         lib_digest = lib.check_build_identity()          # a library built from other sources than the tree's is refused here
     lane = StubLane(rank) if stub else FibQueueLane(local_rank, rank, fri, args.shard_size_log, specialize)
     lanes = [lane] + [StubLane(rank) if stub else FibQueueLane(local_rank, rank, fri, args.shard_size_log, specialize, share=lane) for _ in range(M - 1)]
-
-    def sync_all():
-        for l in lanes:
-            l.sync()
-    farm.device_sync = sync_all
-    # default: exactly --steps K shards per GPU, K N in the queue (weak scaling: per-GPU work fixed); --queue S: S shards in all
-    per_gpu = max(1, args.steps)
-    n_shards = args.queue if args.queue > 0 else per_gpu * world
     warm = max(1, args.warmup)
     t_setup = time.perf_counter()
     if len(lanes) > 1 and not stub:
@@ -714,6 +710,23 @@ def farm_main(args, farm, fri):
         for l in lanes:
             for _ in range(warm):
                 l.prove(0, l.prefetch(0))
+    return {"lanes": lanes, "lib_digest": lib_digest, "t_start": t_start, "t_setup": t_setup, "stub": stub, "warm": warm}
+
+
+def farm_main(args, farm, fri, built):
+    """The one experiment behind every `--gpus N` (module docstring): K N shards through the claim queue, M lanes per GPU."""
+    rank, local_rank, world = farm.rank, farm.local_rank, farm.world
+    lanes, lib_digest, t_start, t_setup, stub, warm = (built[k] for k in ("lanes", "lib_digest", "t_start", "t_setup", "stub", "warm"))
+    M = len(lanes)
+    lane = lanes[0]
+
+    def sync_all():
+        for l in lanes:
+            l.sync()
+    farm.device_sync = sync_all
+    # default: exactly --steps K shards per GPU, K N in the queue (weak scaling: per-GPU work fixed); --queue S: S shards in all
+    per_gpu = max(1, args.steps)
+    n_shards = args.queue if args.queue > 0 else per_gpu * world
     # the gather's first use (RCCL loads its kernels and sets its channels up on the first call of a collective: ~20 ms, a millisecond per
     # shard of a 20-shard timed region) belongs to the warm-up as well: streams of the benchmarked length, dealt round-robin, thrown away
     if farm.dist is not None:
@@ -929,18 +942,22 @@ def main():
     # tests only: ZKM_BENCH_STUB_PROVER=1 (no GPU at all: gloo, stub lanes) and ZKM_BENCH_ONE_DEVICE=1 (a 1-GPU box standing in for N: every
     # rank proves on device 0 and the process group runs over gloo — RCCL refuses two ranks on one device)
     one_device = os.environ.get("ZKM_BENCH_ONE_DEVICE") == "1"
+    fri = abi.FriConfig(1, 84, 16)  # core config, crates/stark/src/kb31_poseidon2.rs:203-213
+    built = None
+    if not args.resident:          # the lanes and their warm-up before torch.cuda / RCCL exist in this process: see build_and_warm_lanes
+        rank_env, local_env, _ = farm_mod.env_rank_world()
+        built = build_and_warm_lanes(args, fri, rank_env, 0 if one_device else local_env)
     farm = farm_mod.Farm(backend="gloo" if (os.environ.get("ZKM_BENCH_STUB_PROVER") == "1" or one_device) else None)
     if one_device:
         farm.local_rank = 0
     if farm.world != args.gpus:
         farm.close()
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the process group has {farm.world} rank(s) (WORLD_SIZE): refusing to print a line for another N")
-    fri = abi.FriConfig(1, 84, 16)  # core config, crates/stark/src/kb31_poseidon2.rs:203-213
     if args.resident:
         if farm.world != 1:
             raise SystemExit("bench.py: --resident is the one-GPU resident-trace line")
         return resident_main(args, farm, fri)
-    return farm_main(args, farm, fri)
+    return farm_main(args, farm, fri, built)
 
 
 def resident_main(args, farm, fri):
