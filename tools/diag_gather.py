@@ -1,3 +1,5 @@
+"""Times Farm.gather_proofs and its pieces under RCCL at world size 1 (forty proof streams of the benchmarked length):
+   gpurun -- 'python tools/diag_gather.py'   (EXPERIMENTS.md, round 5: the pageable send buffer that took 25 ms now and then)."""
 import os, sys, time
 os.environ.update(ZKM_FORCE_DIST="1", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29577")
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "."))

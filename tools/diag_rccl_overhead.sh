@@ -1,3 +1,6 @@
+#!/bin/bash
+# The default line plain, with torch.cuda initialised before the lanes, and on the N > 1 code path (RCCL, world size 1): ms per shard, gather s,
+# closing barrier s, host ms per proof.   gpurun -- 'bash tools/diag_rccl_overhead.sh'   (profiles/r05_rccl_world1_overhead.txt)
 cd $GRAFT_REPO_ROOT
 show() { python -c "
 import json,sys; l=json.loads(sys.stdin.read()); print('$1', l['ms_per_shard'], l['wall_s']['gather_inside_it'], l['wall_s']['closing_barrier_inside_it'], l['host_ms_per_shard']['rank0_mean'])"; }
