@@ -490,6 +490,10 @@ struct zkm_pcs_data {
   Tree tree;
   uint32_t root[8];
   int log_blowup = 1;
+  // lde::Mat::cflag of the four-step matrices, kept with the commitment (two words per column: [2c] = 0 while no two different words
+  // were seen, [2c + 1] = the column's first word): the opening kernels read a constant column's word instead of the column
+  uint32_t* cflags = nullptr;
+  std::vector<const uint32_t*> col_flags;   // per matrix: into cflags, or null
 };
 
 struct zkm_pk {

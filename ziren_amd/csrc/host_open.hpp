@@ -25,6 +25,7 @@ struct RoundMat {
   const zkm_matrix* lde;
   int n_points;  // 1 or 2
   std::vector<E4> y[2];
+  size_t col0 = 0;   // of this matrix in the opening's column tables (open::build_col_tables)
 };
 struct Round { const zkm_pcs_data* data; std::vector<RoundMat> mats; };
 
@@ -203,6 +204,9 @@ struct ShardOpening {
   std::vector<Round> rounds;
   int log_max = 0;
   std::vector<E4*> ro = std::vector<E4*>(32, nullptr);
+  const uint32_t** col_ptr_lde = nullptr;    // the opening's column tables (device; scratch of this opening)
+  const uint32_t** col_ptr_eval = nullptr;
+  uint32_t* col_mask = nullptr;
   // FRI
   std::vector<E4*> layers;      // f_t on device
   std::vector<Tree> ftrees;
@@ -442,6 +446,31 @@ struct ShardOpening {
       rq.mats.push_back(RoundMat{qchunks[i].d, qchunks[i].h, 4, qshifts[i], &quot_data->ldes[i], 1, {}});
     rounds.push_back(rq);
   }
+  // the column tables of this opening: per column of every matrix a pointer and a row mask — the column itself, or (mask 0) eight copies of
+  // the word of a column that never changes, from the flags its commitment kept (open.cuh: build_col_tables)
+  {
+    std::vector<open::ColJob> cjobs;
+    size_t total = 0;
+    for (auto& r : rounds)
+      for (auto& m : r.mats) {
+        m.col0 = total;
+        if (m.width == 0) continue;
+        const size_t idx = (size_t)(m.lde - r.data->ldes.data());
+        const uint32_t* cf = idx < r.data->col_flags.size() ? r.data->col_flags[idx] : nullptr;
+        cjobs.push_back(open::ColJob{m.lde->d, m.evals, cf, m.lde->h, m.n, (uint32_t)total, (uint32_t)m.width});
+        total += m.width;
+      }
+    const size_t tn = std::max<size_t>(total, 1);
+    col_ptr_lde = (const uint32_t**)salloc(tn * sizeof(void*));
+    col_ptr_eval = (const uint32_t**)salloc(tn * sizeof(void*));
+    col_mask = (uint32_t*)salloc(tn * sizeof(uint32_t));
+    uint32_t* cword = (uint32_t*)salloc(tn * 8 * sizeof(uint32_t));
+    if (total) {
+      const open::ColJob* d_c = (const open::ColJob*)ctx->upload_staged(cjobs.data(), cjobs.size() * sizeof(open::ColJob), &scratch);
+      KLAUNCH(ctx, "col_tables", 0.0, open::build_col_tables, dim3(div_up(total, 256)), dim3(256), 0, d_c, (int)cjobs.size(), (uint32_t)total, col_ptr_lde,
+              col_ptr_eval, col_mask, cword);
+    }
+  }
   // (i) evaluate every column at zeta (and zeta * g): barycentric weights shared per (height, shift)
   {
     std::map<std::pair<size_t, uint32_t>, E4*> wcache;
@@ -476,6 +505,7 @@ struct ShardOpening {
         } else wts = it->second;
         open::EvalJob ej;
         ej.mat = m.evals; ej.weights = wts; ej.n = m.n; ej.width = (int)m.width;
+        ej.colptr = col_ptr_eval + m.col0; ej.colmask = col_mask + m.col0;
         ej.groups = (int)div_up(m.width, open::EVAL_COLS);
         ej.split = 1;
         if (m.n >= 4 * open::THREADS) {
@@ -552,6 +582,7 @@ struct ShardOpening {
         int lh = log2_strict(m.lde->h);
         open::ReduceMat rm;
         rm.lde = m.lde->d; rm.width = (int)m.width; rm.n_points = m.n_points;
+        rm.colptr = col_ptr_lde + m.col0; rm.colmask = col_mask + m.col0;
         rm.apow_off = (uint32_t)off[lh]; rm.pad = 0;
         rm.A1 = fap[m.width];
         for (int pt = 0; pt < m.n_points; pt++) {

@@ -351,6 +351,7 @@ static void free_pcs_data(zkm_ctx* ctx, zkm_pcs_data* d) {
   for (auto& m : d->ldes) ctx->release(m.d);
   for (auto& m : d->owned_evals) ctx->release(m.d);
   ctx->release(d->tree.digests);
+  ctx->release(d->cflags);
   delete d;
 }
 
@@ -431,7 +432,8 @@ static zkm_pcs_data* pcs_commit(zkm_ctx* ctx, const std::vector<zkm_matrix>& mat
     const bool rows_up_front = ctx->rows_up_front && std::all_of(extended.begin(), extended.end(), [](char e) { return e != 0; });
     build_tree(ctx, d->ldes, d->tree, extend_height, &col_flags, rows_up_front);
     ctx->side_join();
-    ctx->release(cflags);
+    d->cflags = cflags;          // stay with the commitment: open reads them (host_open.hpp: column tables)
+    d->col_flags = col_flags;
     cflags = nullptr;
     for (size_t i = 0; i < mats.size(); i++)
       if (!extended[i]) throw std::runtime_error("pcs_commit: a matrix was not reached by the tree (internal error)");

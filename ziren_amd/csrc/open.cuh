@@ -21,9 +21,38 @@ constexpr int THREADS = 256;
 // The opening phase of a shard evaluates ~4 matrices per chip: one launch per kernel covers all of them (round 3; before, each matrix
 // had its own bary_weights / eval_columns / reduce_partials launches: ~80 dispatches per proof). A flat blockIdx.x is mapped to
 // (job, block inside the job) through the jobs' cumulative block counts; the job tables live in device memory, indices are wave-uniform.
+// Column tables (round 5): the opening kernels address a matrix's columns through a pointer and a row mask per column. A column that
+// never changes (lde::Mat::cflag, kept with the commitment) gets mask 0 and a pointer at eight copies of its canonical word, so every row
+// (and every 16-byte load) of it reads one cache line instead of the column: reduce_openings and eval_columns_batch run at the HBM read
+// ceiling, and a fifth to a quarter of the benchmarked shard's columns are constant. Any other column: the column itself, mask ~0.
+struct ColJob { const uint32_t* lde; const uint32_t* evals; const uint32_t* cflag; size_t N, n; uint32_t col0, width; };
+__global__ __launch_bounds__(256) void build_col_tables(const ColJob* __restrict__ jobs, int n_jobs, uint32_t total, const uint32_t** __restrict__ lde_ptr,
+                                                        const uint32_t** __restrict__ eval_ptr, uint32_t* __restrict__ mask, uint32_t* __restrict__ cword) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= total) return;
+  int j = 0;
+  while (j + 1 < n_jobs && t >= jobs[j + 1].col0) j++;
+  const ColJob J = jobs[j];
+  const uint32_t c = t - J.col0;
+  if (J.cflag && J.cflag[2 * c] == 0) {
+    const uint32_t w0 = J.cflag[2 * c + 1];
+    const uint32_t w = kb::umin32(w0, w0 - kb::P);   // what lde_cols<true> wrote into the LDE; the evaluations hold a word congruent to it
+#pragma unroll
+    for (int k = 0; k < 8; k++) cword[8 * (size_t)t + k] = w;
+    lde_ptr[t] = cword + 8 * (size_t)t;
+    eval_ptr[t] = cword + 8 * (size_t)t;
+    mask[t] = 0;
+  } else {
+    lde_ptr[t] = J.lde + (size_t)c * J.N;
+    eval_ptr[t] = J.evals + (size_t)c * J.n;
+    mask[t] = 0xffffffffu;
+  }
+}
+
 struct WeightJob { kb::E4 u, c; uint32_t w_n, blk_end; size_t n; kb::E4* out; };
 struct EvalJob {
   const uint32_t* mat; const kb::E4* weights; kb::E4* partials;
+  const uint32_t* const* colptr; const uint32_t* colmask;   // the matrix's window of the column tables
   size_t n;
   int width, groups, split, kind;   // kind 0: one point, 1: two points, 2: small one point, 3: small two points
   uint32_t blk_end;
@@ -112,12 +141,17 @@ __device__ __forceinline__ void block_reduce_store(kb::E4 (&acc)[EVAL_COLS][2], 
 }
 
 template <bool TWO>
-__device__ __forceinline__ void eval_columns_body(const uint32_t* __restrict__ mat, size_t n, int width, const kb::E4* __restrict__ weights,
+__device__ __forceinline__ void eval_columns_body(const uint32_t* const* __restrict__ colptr, const uint32_t* __restrict__ colmask, size_t n, int width,
+                                                  const kb::E4* __restrict__ weights,
                                                   kb::E4* __restrict__ partials, uint32_t* red, uint32_t bx, uint32_t by, uint32_t ny) {
   const int c0 = bx * EVAL_COLS;
   const uint32_t* cols[EVAL_COLS];
+  uint32_t msk[EVAL_COLS];
 #pragma unroll
-  for (int c = 0; c < EVAL_COLS; c++) cols[c] = mat + (size_t)min(c0 + c, width - 1) * n;  // clamp: duplicates are not stored
+  for (int c = 0; c < EVAL_COLS; c++) {   // clamp: duplicates are not stored
+    cols[c] = gp::load(colptr + min(c0 + c, width - 1));
+    msk[c] = gp::load(colmask + min(c0 + c, width - 1));
+  }
   kb::E4 acc[EVAL_COLS][2];
 #pragma unroll
   for (int c = 0; c < EVAL_COLS; c++) { acc[c][0] = kb::ezero(); acc[c][1] = kb::ezero(); }
@@ -131,8 +165,8 @@ __device__ __forceinline__ void eval_columns_body(const uint32_t* __restrict__ m
     for (int k = 0; k < 4; k++) w[k] = gp::load_e4(weights + r + k);
 #pragma unroll
     for (int c = 0; c < EVAL_COLS; c++) {
-      v[c] = gp::load(reinterpret_cast<const uint4*>(cols[c] + r));
-      if (TWO) vnext[c] = gp::load(cols[c] + rn);
+      v[c] = gp::load(reinterpret_cast<const uint4*>(cols[c] + ((uint32_t)r & msk[c])));
+      if (TWO) vnext[c] = gp::load(cols[c] + ((uint32_t)rn & msk[c]));
     }
 #pragma unroll
     for (int c = 0; c < EVAL_COLS; c++) {
@@ -153,7 +187,8 @@ __device__ __forceinline__ void eval_columns_body(const uint32_t* __restrict__ m
 }
 
 // Small matrices (n < 4 * THREADS): one block per column group, scalar loads.
-__device__ __forceinline__ void eval_columns_small_body(const uint32_t* __restrict__ mat, size_t n, int width, const kb::E4* __restrict__ weights,
+__device__ __forceinline__ void eval_columns_small_body(const uint32_t* const* __restrict__ colptr, const uint32_t* __restrict__ colmask, size_t n, int width,
+                                                        const kb::E4* __restrict__ weights,
                                                         int two_points, kb::E4* __restrict__ partials, uint32_t* red, uint32_t bx) {
   const int c0 = bx * EVAL_COLS;
   kb::E4 acc[EVAL_COLS][2];
@@ -164,9 +199,10 @@ __device__ __forceinline__ void eval_columns_small_body(const uint32_t* __restri
     size_t rn = r + 1 == n ? 0 : r + 1;
 #pragma unroll
     for (int c = 0; c < EVAL_COLS; c++) {
-      const uint32_t* col = mat + (size_t)min(c0 + c, width - 1) * n;
-      acc[c][0] = kb::eadd(acc[c][0], kb::escale(w, col[r]));
-      if (two_points) acc[c][1] = kb::eadd(acc[c][1], kb::escale(w, col[rn]));
+      const uint32_t* col = colptr[min(c0 + c, width - 1)];
+      const uint32_t mk = colmask[min(c0 + c, width - 1)];
+      acc[c][0] = kb::eadd(acc[c][0], kb::escale(w, col[(uint32_t)r & mk]));
+      if (two_points) acc[c][1] = kb::eadd(acc[c][1], kb::escale(w, col[(uint32_t)rn & mk]));
     }
   }
   block_reduce_store(acc, c0, width, partials, red, 0);
@@ -189,9 +225,9 @@ __global__ __launch_bounds__(THREADS) void eval_columns_batch(const EvalJob* __r
     bx = s % (uint32_t)j.groups;
     by = (s / (uint32_t)j.groups) * 8 + x;
   }
-  if (j.kind == 0) eval_columns_body<false>(j.mat, j.n, j.width, j.weights, j.partials, red, bx, by, (uint32_t)j.split);
-  else if (j.kind == 1) eval_columns_body<true>(j.mat, j.n, j.width, j.weights, j.partials, red, bx, by, (uint32_t)j.split);
-  else eval_columns_small_body(j.mat, j.n, j.width, j.weights, j.kind == 3, j.partials, red, bx);
+  if (j.kind == 0) eval_columns_body<false>(j.colptr, j.colmask, j.n, j.width, j.weights, j.partials, red, bx, by, (uint32_t)j.split);
+  else if (j.kind == 1) eval_columns_body<true>(j.colptr, j.colmask, j.n, j.width, j.weights, j.partials, red, bx, by, (uint32_t)j.split);
+  else eval_columns_small_body(j.colptr, j.colmask, j.n, j.width, j.weights, j.kind == 3, j.partials, red, bx);
 }
 
 // out[i] = sum_s partials[s * count + i]; one 64-lane block per output element
@@ -222,8 +258,17 @@ __global__ __launch_bounds__(64) void reduce_partials_batch(const SumJob* __rest
 // the point-1 terms as T1 = sum alpha^width S'_m (one extension product per two-point matrix), and
 //   ro[r] = (Y0 - T0) / (z0 - x) + (Y1 - T1) / (z1 - x)     with Y_pt = sum_m Yc[m][pt] (host).
 // x_r comes from the two-level power table of w_N (two loads and a product instead of a 23-step square-and-multiply).
+// word at byte offset `off` (a lane's 32-bit value) of a column whose base is wave-uniform: global_load with a scalar base and a vector offset
+__device__ __forceinline__ uint32_t load_row(const uint32_t* base, uint32_t off) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return *(const uint32_t __attribute__((address_space(1)))*)((const char __attribute__((address_space(1)))*)base + off);
+#else
+  return *(const uint32_t*)((const char*)base + off);
+#endif
+}
 struct ReduceMat {
   const uint32_t* lde;  // column-major, height N
+  const uint32_t* const* colptr; const uint32_t* colmask;   // the matrix's window of the column tables (row r of column c: colptr[c][r & colmask[c]])
   int width;
   int n_points;         // 1: zeta only, 2: zeta and zeta*g
   uint32_t apow_off;    // off(m, 0)
@@ -248,17 +293,28 @@ __global__ __launch_bounds__(THREADS) void reduce_openings(const ReduceMat* __re
   kb::E4 d1 = kb::emul(e01, e0);
   kb::E4 T0 = kb::ezero(), T1 = kb::ezero();
   bool two = false;
+  const uint32_t roff = (uint32_t)r * 4u;   // the row's byte offset in a column (N <= 2^30): one v_and with the column's mask, then a load with a scalar base
   for (int m = 0; m < n_mats; m++) {
     const ReduceMat& M = mats[m];
     const kb::E4* __restrict__ ap = alpha_pows + M.apow_off;
     // S' = sum_c alpha^(off + c) * L[r][c]: four base-field dot products over the matrix's columns, accumulated in 96 bits
     kb::Acc96 s0 = kb::acc96_zero(), s1 = kb::acc96_zero(), s2 = kb::acc96_zero(), s3 = kb::acc96_zero();
-    const uint32_t* col = M.lde + r;
+    // the tables through the constant address space: a wave-uniform index then is a scalar load (as global memory the compiler cannot
+    // prove them unwritten and loads them per lane, one after the other: 2.55 ms instead of 1.75)
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef const uint32_t* __attribute__((address_space(4))) const* PtrTable;
+    typedef const uint32_t __attribute__((address_space(4)))* MaskTable;
+    const PtrTable cp = (PtrTable)(uint64_t)M.colptr;
+    const MaskTable cm = (MaskTable)(uint64_t)M.colmask;
+#else
+    const uint32_t* const* cp = M.colptr;
+    const uint32_t* cm = M.colmask;
+#endif
     int c = 0;
     for (; c + 8 <= M.width; c += 8) {
       uint32_t v[8];
 #pragma unroll
-      for (int k = 0; k < 8; k++) v[k] = gp::load(col + (size_t)(c + k) * N);
+      for (int k = 0; k < 8; k++) v[k] = load_row(cp[c + k], roff & cm[c + k]);
 #pragma unroll
       for (int k = 0; k < 8; k++) {
         const kb::E4 a = ap[c + k];
@@ -270,7 +326,7 @@ __global__ __launch_bounds__(THREADS) void reduce_openings(const ReduceMat* __re
     }
     for (; c < M.width; c++) {
       const kb::E4 a = ap[c];
-      const uint32_t v = gp::load(col + (size_t)c * N);
+      const uint32_t v = load_row(cp[c], roff & cm[c]);
       kb::acc96_fma_uniform(s0, a.c[0], v);
       kb::acc96_fma_uniform(s1, a.c[1], v);
       kb::acc96_fma_uniform(s2, a.c[2], v);
