@@ -40,7 +40,7 @@ os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")      # before anything initi
 
 HBM_PEAK_GBPS = 8000.0     # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 FP64_VECTOR_TFLOPS = 78.6  # MI355X FP64 vector peak: 256 CUs x 4 SIMDs x 16 lanes x 2 flop x 2.4 GHz (MI355X_MICROARCH.md)
-PROFILE_ROUND = "r05"
+PROFILE_ROUND = "r06"
 HASHING_KERNELS = ("compress_layer", "compress_layer_rowdig", "hash_leaves", "hash_rows", "hash_leaves_tree", "hash_fri_leaves", "hash_fri_leaves_tree", "compress_small", "compress_tail")
 LDE_KERNELS = ("lde_rows", "lde_cols_forward", "lde_cols_inverse")
 ROCPROF_NAMES = {"compress_layer": "merkle::compress_layer", "hash_leaves": "merkle::hash_leaves", "hash_rows": "merkle::hash_rows", "hash_leaves_tree": "merkle::hash_leaves_tree",
@@ -63,13 +63,22 @@ def csrc_digest():
     return h.hexdigest()[:16]
 
 
+def newest_profile(suffix):
+    """profiles/<round>_<suffix> of the newest round that has one (this round's first), relative to the repo; None when no round has."""
+    first = int(PROFILE_ROUND[1:])
+    for n in range(first, 0, -1):
+        rel = os.path.join("profiles", f"r{n:02d}_{suffix}")
+        if os.path.exists(os.path.join(ROOT, rel)):
+            return rel
+    return None
+
+
 def poseidon2_isa():
     """Dynamic VALU instructions per permutation as the hardware counts them (SQ_INSTS_VALU over tools/ubench_p2's kernels, written by
-    tools/profile_r04.sh -> tools/pmc_poseidon2.py); the newest profile kept; None when there is none."""
-    for rnd in (PROFILE_ROUND, "r04", "r03"):
-        path = os.path.join(ROOT, "profiles", f"{rnd}_poseidon2_isa.json")
-        if os.path.exists(path):
-            return json.load(open(path)), f"profiles/{rnd}_poseidon2_isa.json"
+    tools/profile_r06.sh -> tools/pmc_poseidon2.py); the newest profile kept; None when there is none."""
+    rel = newest_profile("poseidon2_isa.json")
+    if rel is not None:
+        return json.load(open(os.path.join(ROOT, rel))), rel
     return None, None
 
 
@@ -326,10 +335,10 @@ def resident_leg(farm, wl, hp, pk, ch0, traces, steps, warmup, kernel_timing):
 def traffic_profile(tag):
     """The rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE summary of this workload kept under profiles/ (tools/profile_r04.sh), only if it was
     taken on these very kernel sources (it records their digest); PMC counters cannot be read from inside this process."""
-    path = os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_{tag}_hbm_traffic.json")
-    rel = os.path.relpath(path, ROOT)
-    if not os.path.exists(path):
-        return None, {"file": rel, "missing": True}
+    rel = newest_profile(f"{tag}_hbm_traffic.json")
+    if rel is None:
+        return None, {"file": f"profiles/{PROFILE_ROUND}_{tag}_hbm_traffic.json", "missing": True}
+    path = os.path.join(ROOT, rel)
     tj = json.load(open(path))
     if tj.get("csrc_digest") != csrc_digest():
         return None, {"file": rel, "stale": True, "note": "taken on other kernel sources (csrc digest differs): not quoted"}
@@ -375,8 +384,9 @@ def roofline_objects(wl, fri, leg, steps):
                 "frac": round(perms / hms / 1e6 / peak, 3) if peak else None, "valu_instr_per_permutation": per_perm,
                 "valu_instr_source": (isa_src + " (SQ_INSTS_VALU / permutations, tools/ubench_p2)") if isa else None,
                 "share_of_step": round(hms / table_ms, 3)}
-        spath = os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_{wl.tag}_sq_counters.csv")
-        if os.path.exists(spath):
+        srel = newest_profile(f"{wl.tag}_sq_counters.csv")
+        spath = os.path.join(ROOT, srel) if srel else None
+        if spath:
             import csv
             rows = {r["Name"]: r for r in csv.DictReader(open(spath))}
             valu["valu_pipe_busy_pct_measured"] = {n: float(rows[n]["ValuPipeBusyPct(of SIMD time)"]) for n in ("merkle::compress_layer", "merkle::compress_layer_rowdig", "merkle::hash_leaves", "merkle::hash_rows")
@@ -588,7 +598,7 @@ def cpu_baseline_leg(wl, fri, full, sample_log):
             "sample": (f"oracle (CPU restatement, canonical `% p` arithmetic, OpenMP, {threads} threads) proving one {what} shard in {wall:.2f} s ({lde_s:.2f} s of it coset LDEs)"
                        + ("" if full else f"; scaled to the benchmarked shard by committed cells (x{ratio:.2f}), the LDEs by a further ({k_full} + 1) / ({k_s} + 1)")),
             "measured_at_full_size": bool(full), "sample_seconds": round(wall, 3), "estimated_seconds_full_size": round(est, 2),
-            "full_size_measurement": f"profiles/{PROFILE_ROUND}_cpu_baseline_full.json (bench.py --cpu-full)"}
+            "full_size_measurement": (newest_profile("cpu_baseline_full.json") or "none kept under profiles/") + " (bench.py --cpu-full: the benchmarked shard itself on the CPU)"}
 
 
 # ---- the farm line (every N): the claim queue over events -> traces -> proof -----------------------------------------------------------------
@@ -860,9 +870,26 @@ def farm_extras(args, fri, lane, lanes, line, world, elapsed, n_shards):
     also = [a for a in args.also.split(",") if a] + [f"fibc{wl.log_size}"] + ([] if args.no_syn else ["syn22"])
     ctx.trim()
     line["other_workloads"] = other_workload_legs(also, fri, lane.ctx.device, not args.interpreter, steps) or None
+    if not args.no_reduce:
+        # the recursion-tree reduce over this run's shards (ziren_amd/reduce.py; stand-in programs at the reference's compress shapes): per-shape
+        # ms, an 8-leaf tree through the farm's queue, and its share of core + reduce time at this line's ms per core shard
+        ctx.trim()
+        line["other_workloads"] = dict(line["other_workloads"] or {}, REDUCE=reduce_leg(lane.ctx.device, (8,), 3, elapsed / n_shards * 1e3))
     if not args.no_cpu_baseline:
         sample = args.cpu_sample_log if args.cpu_sample_log is not None else 18
         line["cpu_baseline"] = cpu_baseline_leg(wl, fri, args.cpu_full, sample)
+
+
+def reduce_leg(device, leaves, steps, core_ms_per_shard):
+    """tools/bench_reduce_tree.py's measurement, trimmed to what a line carries."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench_reduce_tree
+    r = bench_reduce_tree.reduce_bench(leaves=leaves, steps=steps, core_ms_per_shard=core_ms_per_shard, device=device)
+    for leg in r["per_shape"].values():
+        leg["kernels_ms"] = {k: v["ms"] for k, v in list(leg["kernels_ms"].items())[:6]}
+        leg.pop("shape", None), leg.pop("fill", None)
+    r["full_measurement"] = f"profiles/{PROFILE_ROUND}_reduce_tree.json (tools/bench_reduce_tree.py --leaves 8,16,32)"
+    return r
 
 
 def other_workload_legs(also, fri, device, specialize, steps):
@@ -909,7 +936,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2, help="untimed warm-up proofs per lane")
     ap.add_argument("--resident", action="store_true", help="N = 1 only: print the resident-only line of rounds 1-4 (traces in HBM, one shard in flight, no queue): "
                     "what the profiling scripts run; takes --workload / --log-rows")
-    ap.add_argument("--workload", choices=["fib", "fib-tight", "syn"], default="fib",
+    ap.add_argument("--no-reduce", action="store_true", help="skip the recursion-tree reduce leg (other_workloads.REDUCE)")
+    ap.add_argument("--leaves", type=str, default="8,16,32", help="--workload reduce-tree: core proofs under the trees that are timed")
+    ap.add_argument("--workload", choices=["fib", "fib-tight", "syn", "reduce-tree"], default="fib",
                     help="--resident only. fib (default): the fibonacci shard as the reference cuts and shapes it at SHARD_SIZE = 2^--shard-size-log; fib-tight: 2^--log-rows cycles, "
                          "tight heights; syn: SYN---log-rows")
     ap.add_argument("--shard-size-log", type=int, default=21, help="log2 of the reference's SHARD_SIZE (MAX_SHARD_SIZE = 2^21, crates/stark/src/opts.rs:6; "
@@ -935,6 +964,19 @@ def main():
         import bench_tracegen
         return bench_tracegen.tracegen_bench(args)
 
+    if args.workload == "reduce-tree":
+        # the recursion-tree reduce on its own (one GPU): first layer + reduce layers + shrink over stand-in programs at the reference's
+        # compress shapes, through the farm's queue; one JSON line, `value` = recursion shards per second of the largest tree
+        if args.gpus != 1:
+            raise SystemExit("bench.py --workload reduce-tree measures one GPU (the tree's layers are dealt by Farm.run_queue: tests/test_reduce.py covers world 2)")
+        r = reduce_leg(0, tuple(int(x) for x in args.leaves.split(",") if x), max(3, min(args.steps, 10)), None)
+        t = r["trees"][-1]
+        print(json.dumps({"metric": "recursion-shard-proofs/sec (reduce tree)", "value": round(t["recursion_shards"] / t["wall_ms"] * 1e3, 3), "unit": "shard-proofs/s", "n_gpus": 1,
+                          "steps": t["recursion_shards"], "warmup": 1, "ms_per_step": t["ms_per_recursion_shard"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                          "dtype": "u32", "data": "synthetic (stand-in recursion programs, ziren_amd/reduce.py)", "verified": True,
+                          "config": {"workload": f"reduce tree over {t['leaves']} core proofs: first layer + {len(t['layers']) - 2} reduce layers + shrink, compress-machine shards at the reference's shapes"},
+                          "reduce": r}), flush=True)
+        return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args.gpus))
 

@@ -151,7 +151,7 @@ def test_every_column_of_every_recursion_chip_is_bound(oracle):
     from test_recursion_chips import all_chips_shard, wrap_machine_shard, recursion_public_values, tally_of
     rec_of = {"BaseAlu": lambda: R.record_constraints(False), "ExtAlu": lambda: R.record_constraints(True),
               "MemoryConst": lambda: R.record_mem_const(constraints_only=True), "MemoryVar": lambda: R.record_mem_var(constraints_only=True),
-              "Select": lambda: R.record_select(constraints_only=True), "Poseidon2Wide": lambda: R.record_poseidon2_wide(constraints_only=True),
+              "Select": lambda: R.record_select(constraints_only=True), "Poseidon2WideDeg3": lambda: R.record_poseidon2_wide(constraints_only=True),
               "ExpReverseBitsLen": lambda: R.record_exp_reverse_bits(constraints_only=True), "BatchFRI": lambda: R.record_batch_fri(constraints_only=True),
               "PublicValues": lambda: R.record_public_values(constraints_only=True), "FriFold": lambda: R.record_fri_fold(constraints_only=True),
               "Poseidon2SkinnyDeg9": lambda: R.record_poseidon2_skinny(constraints_only=True)}

@@ -377,7 +377,7 @@ def test_gpu_core_proofs_feed_a_compress_shaped_shard(hip_ctx, oracle):
     ch = prover.new_challenger()
     pk.observe_into(ch)
     start = ch.copy()
-    born = [hip_ctx.tracegen_poseidon2_wide(ev, r.log_height) if r.name == "Poseidon2Wide" else
+    born = [hip_ctx.tracegen_poseidon2_wide(ev, r.log_height) if r.name == "Poseidon2WideDeg3" else
             hip_ctx.tracegen_exp_reverse_bits(*ev, r.log_height) if r.name == "ExpReverseBitsLen" else
             hip_ctx.tracegen_flat(ev, r.trace.shape[1], r.log_height) if ev is not None else hip_ctx.upload(r.trace)
             for (_, ev), r in zip(streams, recs)]

@@ -139,7 +139,7 @@ def test_fri_fold_and_all_chips_machine(oracle):
     cells caught, and the ten-chip machine's lookups cancel; the oracle's proof verifies."""
     from ziren_amd import synth
     recs, streams, digest = all_chips_shard(oracle)
-    assert [r.name for r in recs] == ["BaseAlu", "ExtAlu", "MemoryConst", "MemoryVar", "Select", "Poseidon2Wide", "ExpReverseBitsLen", "BatchFRI",
+    assert [r.name for r in recs] == ["BaseAlu", "ExtAlu", "MemoryConst", "MemoryVar", "Select", "Poseidon2WideDeg3", "ExpReverseBitsLen", "BatchFRI",
                                       "FriFold", "PublicValues"]
     ff = recs[8]
     rec = R.record_fri_fold(constraints_only=True)
@@ -213,7 +213,7 @@ def test_compress_machine_is_complete(oracle):
     with the committed digest as public values — verifies; a different claimed digest does not."""
     from ziren_amd import synth
     recs, streams, digest = compress_machine_shard(oracle)
-    assert [r.name for r in recs] == ["BaseAlu", "ExtAlu", "MemoryConst", "MemoryVar", "Select", "Poseidon2Wide", "ExpReverseBitsLen", "BatchFRI",
+    assert [r.name for r in recs] == ["BaseAlu", "ExtAlu", "MemoryConst", "MemoryVar", "Select", "Poseidon2WideDeg3", "ExpReverseBitsLen", "BatchFRI",
                                       "PublicValues"]
     pv = recursion_public_values(digest)
     by = {r.name: r for r in recs}
@@ -349,7 +349,7 @@ def test_poseidon2_wide(oracle):
         wrong[0, 20] += 1
         oracle.tracegen_poseidon2_wide(F.to_monty(wrong))
     recs, _ = balanced_shard(300, 150, 40, seed=21, n_var=60, n_select=80, n_poseidon2=40, oracle=oracle)
-    assert recs[-1].name == "Poseidon2Wide" and recs[-1].main_width == 313
+    assert recs[-1].name == "Poseidon2WideDeg3" and recs[-1].main_width == 313
     t = tally_of(recs)
     assert t and not any(t.values())
 
@@ -409,7 +409,7 @@ def test_gpu_recursion_alu_shard(hip_ctx, oracle, log_blowup, queries):
     ch = prover.new_challenger()
     pk.observe_into(ch)
     start = ch.copy()
-    born = [hip_ctx.tracegen_poseidon2_wide(ev, r.log_height) if r.name == "Poseidon2Wide" else
+    born = [hip_ctx.tracegen_poseidon2_wide(ev, r.log_height) if r.name == "Poseidon2WideDeg3" else
             hip_ctx.tracegen_exp_reverse_bits(*ev, r.log_height) if r.name == "ExpReverseBitsLen" else
             hip_ctx.tracegen_flat(ev, r.trace.shape[1], r.log_height) if ev is not None else hip_ctx.upload(r.trace)
             for (_, ev), r in zip(streams, recs)]

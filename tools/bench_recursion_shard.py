@@ -77,7 +77,7 @@ def main():
         t0 = time.perf_counter()
         born = []
         for (ev_key, mw, lh), r in zip(mains, recs):
-            if r.name == "Poseidon2Wide":
+            if r.name == "Poseidon2WideDeg3":
                 born.append(ctx.tracegen_poseidon2_wide(prog[ev_key], lh))
             elif r.name.startswith("Poseidon2Skinny"):
                 born.append(ctx.tracegen_poseidon2_skinny(prog[ev_key], lh))

@@ -99,17 +99,22 @@ class Farm:
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
         return float(t.item())
 
-    def gather_commitments(self, shard_ids: Sequence[int], commits: Sequence[np.ndarray], n_shards: int):
-        """All ranks contribute (shard id, 24-word commitment triple); returns on every rank the table in
-        shard order. A few hundred bytes per shard — point-to-point over xGMI would be equally fine."""
-        table = np.zeros((n_shards, 24), dtype=np.int64)
-        for i, c in zip(shard_ids, commits):
-            table[i] = np.asarray(c, dtype=np.int64)[:24]
+    def gather_words(self, shard_ids: Sequence[int], rows: Sequence[np.ndarray], n_shards: int, words: int) -> np.ndarray:
+        """All ranks contribute (shard id, `words` 32-bit words); returns on every rank the (n_shards, words) table in shard order. A few
+        hundred bytes per shard (one small all-reduce): what the next layer of the recursion tree witnesses of this one
+        (ziren_amd/reduce.py) — point-to-point over xGMI would be equally fine."""
+        table = np.zeros((n_shards, words), dtype=np.int64)
+        for i, c in zip(shard_ids, rows):
+            table[i] = np.asarray(c, dtype=np.int64)[:words]
         if self.dist is None:
             return table.astype(np.uint32)
         t = self.torch.from_numpy(table).to(self.device)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)  # disjoint rows: sum == union
         return t.cpu().numpy().astype(np.uint32)
+
+    def gather_commitments(self, shard_ids: Sequence[int], commits: Sequence[np.ndarray], n_shards: int):
+        """The (main, permutation, quotient) commitment triple of every shard, on every rank."""
+        return self.gather_words(shard_ids, commits, n_shards, 24)
 
     # ---- dealing shards to the next free rank (prove.rs:484) ---------------------------------------------------------------
     def _queue_key(self, queue: str) -> str:

@@ -261,7 +261,7 @@ def record_poseidon2_wide(log_height: int = 10, prep_index: int = 0, constraints
             b.assert_eq(s0[rd], state[0])
     for i in range(16):
         b.assert_eq(ext_state[4][i], state[i])
-    return r if constraints_only else _finish_rec(r, "Poseidon2Wide", log_height, POSEIDON2_WIDE_WIDTH, prep_index)
+    return r if constraints_only else _finish_rec(r, "Poseidon2WideDeg3", log_height, POSEIDON2_WIDE_WIDTH, prep_index)
 
 
 EXP_REVERSE_BITS_COLS, EXP_REVERSE_BITS_PREP_COLS = 7, 10
