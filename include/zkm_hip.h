@@ -141,6 +141,13 @@ int zkm_ctx_synchronize(zkm_ctx* ctx);
 /* Device buffers are recycled through an exact-size pool; trim returns the idle ones to the driver, and drops the per-height tables
  * (coset twiddles, quotient selectors, row twiddles) a long-lived prover accumulates: they are rebuilt on the next use of a height. */
 int zkm_ctx_trim(zkm_ctx* ctx);
+/* A cap on what the context's pool may hold from the driver (handed out + cached), in bytes; 0 = none (the default; ZKM_POOL_LIMIT_MB sets
+ * it for every context of the process). A request that would cross it first returns the cached buffers to the driver and then fails
+ * with "out of device memory ..." in zkm_last_error(): the failing call gives back what it had taken and the context stays usable —
+ * where the reference's prover would abort the process on an allocation failure (crates/stark/src/prover.rs:206-208: callers unwrap()).
+ * A real hipMalloc failure is handled the same way. zkm_ctx_memory_held: the bytes the pool holds right now. */
+int zkm_ctx_set_memory_limit(zkm_ctx* ctx, size_t bytes);
+size_t zkm_ctx_memory_held(zkm_ctx* ctx);
 /* per-phase GPU time of the last zkm_commit/zkm_open on this context, in milliseconds (HIP
  * events on the context's stream). names/values arrays of capacity cap; returns the count. */
 int zkm_ctx_last_timings(zkm_ctx* ctx, const char** names, float* ms, int cap);
@@ -162,10 +169,12 @@ void zkm_ctx_set_lde_overlap(zkm_ctx* ctx, int on);
  * environment's ZKM_ROWS_UP_FRONT=0 sets the default to off. */
 void zkm_ctx_set_rows_up_front(zkm_ctx* ctx, int on);
 /* How the calling thread waits for this context's GPU work. 0 (default): it spins (hipStreamSynchronize, and the FRI layer roots are
- * watched arriving in page-locked memory) — lowest latency, one host core per context for the length of a proof. 1: it sleeps on an
- * interrupt-backed event — about a millisecond more per proof for a context alone, nothing measurable when two contexts share a GPU,
- * a tenth of the CPU time: what a rank of a many-GPU host with few cores per GPU wants (the reference's GPU opts run one prover thread
- * per device too, crates/stark/src/opts.rs:83-110). The environment's ZKM_HOST_WAIT=blocking makes 1 the default. */
+ * watched arriving in page-locked memory) — lowest latency, one host core per context for the length of a proof. 1: it queries the
+ * stream between 20 us sleeps (not a kernel-level blocking wait: this runtime has none per stream) — about a millisecond more per proof
+ * for a context alone, nothing measurable when two contexts share a GPU, a tenth of the CPU time: what a rank of a many-GPU host with
+ * few cores per GPU wants (the reference's GPU opts run one prover thread per device too, crates/stark/src/opts.rs:83-110). While such a
+ * wait sleeps, the calling thread's timer slack is 1 us (PR_SET_TIMERSLACK); it is put back to what the caller had when the wait ends.
+ * The environment's ZKM_HOST_WAIT=blocking makes 1 the default. */
 void zkm_ctx_set_host_wait(zkm_ctx* ctx, int blocking);
 /* Register a chip-specialised quotient kernel: a gfx950 code object exporting
  * `zkm_quotient_specialized(stark::QuotientArgs)` generated from exactly these program words
@@ -191,7 +200,10 @@ int zkm_ctx_register_perm_kernel(zkm_ctx* ctx, const uint32_t* lookups, uint32_t
  * zkm_matrix_upload from such a buffer is pure DMA at PCIe rate. Pageable buffers work too, slower. */
 void* zkm_host_alloc(zkm_ctx* ctx, size_t bytes);
 void zkm_host_free(zkm_ctx* ctx, void* p);
-/* Upload a row-major host matrix (height a power of two) and lay it out column-major in HBM. */
+/* Upload a row-major host matrix (height a power of two) and lay it out column-major in HBM. Words are Montgomery-form field elements
+ * as Plonky3 keeps them (< p = 0x7f000001); a word >= p cannot occur in a RowMajorMatrix<KoalaBear> and is reduced mod p on the way in
+ * (same for zkm_matrix_upload_async and zkm_tracegen_flat), so the device always holds canonical words — the kernels' accumulator
+ * bounds assume it. */
 int zkm_matrix_upload(zkm_ctx* ctx, const uint32_t* host_row_major, size_t height, size_t width,
                       zkm_matrix** out);
 /* The same without waiting: the copy and the transposition are queued on the context's upload streams and the call

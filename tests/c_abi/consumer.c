@@ -7,7 +7,12 @@
  *   consumer prove      on a GPU, the whole hot path as the Rust shim would drive it: zkm_chip_desc of the AddSub chip (constraint bytecode and
  *                       lookups from a header the test generates with the recorder: tests/c_abi/addsub_desc.h), forty AluEvents -> device trace,
  *                       zkm_pk_setup (no preprocessed trace) -> zkm_challenger_init + zkm_pk_observe_into -> zkm_commit -> zkm_open with the
- *                       too-small-buffer retry -> prints "proof <words> <fnv1a of the stream> <main commitment word 0> <transcript word>" */
+ *                       too-small-buffer retry -> prints "proof <words> <fnv1a of the stream> <main commitment word 0> <transcript word>"
+ *   consumer fail       on a GPU, three failures driven through the ABI — a freed trace handle handed to zkm_commit, zkm_open with a chip list
+ *                       that disagrees with the commit, an allocation refused by a capped pool (zkm_ctx_set_memory_limit) — each must return
+ *                       non-zero with its message in zkm_last_error() and leave the transcript alone; the SAME context then proves the shard:
+ *                       the line printed at the end equals `consumer prove`'s (crates/stark/src/prover.rs:206-208: the reference's callers
+ *                       unwrap(); across a C ABI a failure has to be a status, never an unwind, and must not poison the context) */
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -15,7 +20,7 @@
 #ifdef ZKM_HAVE_ADDSUB_DESC
 #include "addsub_desc.h"   /* ADDSUB_PROGRAM[], ADDSUB_LOOKUPS[], ADDSUB_NUM_CONSTRAINTS, ADDSUB_LQD, N_PUBLIC_VALUES, NUM_PV_ELTS */
 
-static int prove(zkm_ctx* ctx) {
+static int prove(zkm_ctx* ctx, int with_failures) {
   enum { N = 40 };
   zkm_alu_event ev[N];
   memset(ev, 0, sizeof ev);
@@ -27,6 +32,36 @@ static int prove(zkm_ctx* ctx) {
   }
   zkm_matrix* trace = NULL;
   if (zkm_tracegen_alu(ctx, ZKM_CHIP_ADD_SUB, ev, N, -1, NULL, &trace) != 0) { printf("tracegen: %s\n", zkm_last_error()); return 20; }
+  if (with_failures) {
+    /* (1) a handle that was freed: refused by name, nothing dereferenced */
+    zkm_matrix* gone = NULL;
+    if (zkm_tracegen_alu(ctx, ZKM_CHIP_ADD_SUB, ev, N, -1, NULL, &gone) != 0) return 40;
+    zkm_matrix_free(ctx, gone);
+    zkm_matrix_free(ctx, gone);                               /* a double free is ignored */
+    const char* nm[1] = {"AddSub"};
+    const zkm_matrix* dead[1] = {gone};
+    uint32_t c8[ZKM_DIGEST_ELEMS], ord[1];
+    static uint32_t pv0[N_PUBLIC_VALUES];
+    zkm_main_data* none = NULL;
+    if (zkm_commit(ctx, 1, nm, dead, pv0, N_PUBLIC_VALUES, 1, c8, ord, &none) == 0 || none != NULL) return 41;
+    if (!strstr(zkm_last_error(), "not a live handle")) { printf("freed handle: %s\n", zkm_last_error()); return 42; }
+    printf("refused: %s\n", zkm_last_error());
+    /* (3) a capped pool: the traces of 2^20 events do not fit 8 MiB; the failing call gives back what it took */
+    const size_t held = zkm_ctx_memory_held(ctx);
+    if (zkm_ctx_set_memory_limit(ctx, held + ((size_t)8 << 20)) != 0) return 43;
+    enum { BIG = 1 << 20 };
+    zkm_alu_event* many = (zkm_alu_event*)calloc(BIG, sizeof *many);
+    for (int i = 0; i < BIG; i++) { many[i].opcode = 0; many[i].b = (uint32_t)i; many[i].c = 1; many[i].a = (uint32_t)i + 1; many[i].pc = 4 * (uint32_t)i; many[i].next_pc = many[i].pc + 4; }
+    zkm_matrix* big = NULL;
+    if (zkm_tracegen_alu(ctx, ZKM_CHIP_ADD_SUB, many, BIG, -1, NULL, &big) == 0 || big != NULL) return 44;
+    if (!strstr(zkm_last_error(), "out of device memory")) { printf("capped pool: %s\n", zkm_last_error()); return 45;}
+    printf("refused: %s\n", zkm_last_error());
+    if (zkm_ctx_memory_held(ctx) > held + ((size_t)8 << 20)) return 46;
+    if (zkm_ctx_set_memory_limit(ctx, 0) != 0) return 47;
+    if (zkm_tracegen_alu(ctx, ZKM_CHIP_ADD_SUB, many, BIG, -1, NULL, &big) != 0) { printf("after the cap: %s\n", zkm_last_error()); return 48; }
+    zkm_matrix_free(ctx, big);
+    free(many);
+  }
   zkm_chip_desc chip;
   memset(&chip, 0, sizeof chip);
   chip.name = "AddSub";
@@ -58,6 +93,19 @@ static int prove(zkm_ctx* ctx) {
   if (need <= 8 || memcmp(&before, &ch, sizeof ch) != 0 || !strstr(zkm_last_error(), "too small")) return 25;
   uint32_t* proof = (uint32_t*)malloc(need * 4);
   size_t len = 0;
+  if (with_failures) {
+    /* (2) a chip list that disagrees with what was committed: refused, the commitment and the transcript untouched */
+    zkm_chip_desc wrong = chip;
+    wrong.main_width = chip.main_width + 1;
+    if (zkm_open(ctx, pk, data, &wrong, &fri, NUM_PV_ELTS, &ch, proof, need, &len) == 0) return 50;
+    if (!strstr(zkm_last_error(), "does not match") || memcmp(&before, &ch, sizeof ch) != 0) { printf("chip list: %s\n", zkm_last_error()); return 51; }
+    printf("refused: %s\n", zkm_last_error());
+    /* and a proving key that was freed */
+    zkm_pk* pk2 = NULL;
+    if (zkm_pk_setup(ctx, 0, NULL, NULL, 0, igcs, fri.log_blowup, &pk2) != 0) return 52;
+    zkm_pk_free(ctx, pk2);
+    if (zkm_open(ctx, pk2, data, &chip, &fri, NUM_PV_ELTS, &ch, proof, need, &len) == 0 || !strstr(zkm_last_error(), "not a live handle")) return 53;
+  }
   if (zkm_open(ctx, pk, data, &chip, &fri, NUM_PV_ELTS, &ch, proof, need, &len) != 0) { printf("open: %s\n", zkm_last_error()); return 26; }
   if (len != need || memcmp(proof, main_commit, 32) != 0) return 27;
   uint32_t h = 2166136261u;
@@ -80,7 +128,8 @@ int main(int argc, char** argv) {
   }
   if (rc != 0) { printf("ctx: %s\n", zkm_last_error()); return 3; }
 #ifdef ZKM_HAVE_ADDSUB_DESC
-  if (!strcmp(argv[1], "prove")) { rc = prove(ctx); zkm_ctx_destroy(ctx); return rc; }
+  if (!strcmp(argv[1], "prove")) { rc = prove(ctx, 0); zkm_ctx_destroy(ctx); return rc; }
+  if (!strcmp(argv[1], "fail")) { rc = prove(ctx, 1); zkm_ctx_destroy(ctx); return rc; }
 #endif
   zkm_alu_event ev;
   memset(&ev, 0, sizeof ev);

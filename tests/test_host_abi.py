@@ -138,6 +138,29 @@ def test_gpu_plain_c_consumer_proves_a_shard(tmp_path, oracle):
     assert sample == oracle.lib().orc_challenger_sample(C.byref(ch))
 
 
+@pytest.mark.gpu
+def test_gpu_plain_c_consumer_survives_failures(tmp_path):
+    """SURVEY 8(b) "Errors": a freed handle reused, a chip list that disagrees with the commit, an allocation a capped pool refuses — each a
+    non-zero status with its message, none an unwind or a crash — and the same context then produces the very proof `consumer prove`
+    prints (which test_gpu_plain_c_consumer_proves_a_shard holds against the oracle)."""
+    import subprocess
+    exe = _build_c_consumer(tmp_path, with_desc=True)
+    good = subprocess.run([exe, "prove"], capture_output=True, text=True)
+    out = subprocess.run([exe, "fail"], capture_output=True, text=True)
+    assert out.returncode == 0, (out.returncode, out.stdout, out.stderr)
+    lines = out.stdout.strip().splitlines()
+    refused = [l for l in lines if l.startswith("refused: ")]
+    assert len(refused) == 3 and "not a live handle" in refused[0] and "out of device memory" in refused[1] and "does not match" in refused[2], lines
+    assert lines[-1].startswith("proof ") and lines[-1] == good.stdout.strip().splitlines()[-1]
+
+
+def test_api_never_unwinds_whatever_is_thrown():
+    """API_END catches everything (csrc/zkm_hip.hip): the macro has a catch (...) arm behind the std::exception one."""
+    src = open(os.path.join(ROOT, "ziren_amd", "csrc", "zkm_hip.hip")).read()
+    macro = src[src.index("#define API_END"):src.index("return 0;", src.index("#define API_END"))]
+    assert "catch (const std::exception& e)" in macro and "catch (...)" in macro
+
+
 def test_host_field_ext_poseidon2_match_oracle(oracle):
     L = lib.load()
     rng = np.random.default_rng(1)

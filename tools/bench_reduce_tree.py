@@ -112,6 +112,49 @@ def shard_leg(lane, prog, shape_idx, fri, steps, O=None):
     return out
 
 
+def two_lane_leg(lanes, prog, shape_idx, fri, steps):
+    """Both lanes of the GPU proving the same program back to back (a host thread each): ms per shard from events, and with the traces
+    resident — what the tree's wide layers can reach, and how much of it the events' path costs."""
+    import threading
+    inputs = (np.arange(prog.n_inputs, dtype=np.uint64) * 977 + 5) % np.uint64(0x7F000001)
+    pid = ("two", shape_idx, prog.n_inputs)
+    for l in lanes:
+        l.prove(pid, prog, shape_idx, fri, inputs)
+    res = {}
+
+    def timed(fn):
+        for l in lanes:
+            l.ctx.synchronize()
+        t0 = time.perf_counter()
+        ths = [threading.Thread(target=fn, args=(l,)) for l in lanes]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        for l in lanes:
+            l.ctx.synchronize()
+        return (time.perf_counter() - t0) / (steps * len(lanes)) * 1e3
+
+    res["from_events_ms_per_shard"] = round(timed(lambda l: [l.prove(pid, prog, shape_idx, fri, inputs) for _ in range(steps)]), 3)
+    state = {}
+    for l in lanes:
+        hp, recs, pk, ch0 = l.key_for(pid, prog, shape_idx, fri)
+        w = prog.witness(inputs)
+        state[id(l)] = (hp, pk, ch0, l.traces(prog, recs, w), prog.public_values(w["digest"]))
+
+    def resident(l):
+        hp, pk, ch0, born, pv = state[id(l)]
+        for _ in range(steps):
+            hp.prove_shard(pk, pv, born, ch0.copy(), out=l.out)
+
+    resident(lanes[0]); resident(lanes[1])
+    res["traces_resident_ms_per_shard"] = round(timed(resident), 3)
+    for hp, pk, ch0, born, pv in state.values():
+        for t in born:
+            t.free()
+    return res
+
+
 def tree_leg(tree, farm, lanes, n_leaves, O=None, repeat=2):
     """K leaves -> one shrink proof, layer by layer through the farm's queue; the best of `repeat` runs (the first builds the keys)."""
     from ziren_amd import field as F, reduce as RD
@@ -165,8 +208,10 @@ def reduce_bench(leaves=(8, 16, 32), leaf_shape=1, reduce_shape=0, shrink_shape=
         prog = tree.program(si, 2 if si == reduce_shape else 1)
         per_shape[f"shape{si}_compress_1_84"] = shard_leg(lanes[0], prog, si, RD.COMPRESS_FRI, steps, O)
     per_shape[f"shape{shrink_shape}_shrink_2_42"] = shard_leg(lanes[0], tree.program(shrink_shape, 1), shrink_shape, RD.SHRINK_FRI, steps, O)
-    lanes[0].close()
-    ctxs[0].trim()
+    two = {f"shape{si}": two_lane_leg(lanes, tree.program(si, 2 if si == reduce_shape else 1), si, RD.COMPRESS_FRI, steps) for si in shapes_to_time}
+    for l in lanes:
+        l.close()
+        l.ctx.trim()
     gen_s = time.perf_counter() - t0
     f = farm_mod.Farm()
     trees = [tree_leg(tree, f, lanes, k, O) for k in leaves]
@@ -175,7 +220,7 @@ def reduce_bench(leaves=(8, 16, 32), leaf_shape=1, reduce_shape=0, shrink_shape=
                       "the children's commitments + digests witnessed and absorbed into the committed digest; not a verifier of its children (that program comes out of the Rust recursion compiler)",
            "plan": {"first_layer_shape": leaf_shape, "reduce_layers_shape": reduce_shape, "shrink_shape": shrink_shape,
                     "note": "which allowed shape a first-layer / reduce / shrink program lands in is the recursion compiler's output: an assumption here; ms per shard is given for all three"},
-           "per_shape": per_shape, "trees": trees,
+           "per_shape": per_shape, "two_lanes": two, "trees": trees,
            "tree_mode": "two lanes (a context + host thread each) on the one GPU claim nodes from the layer's queue (Farm.run_queue); after each layer gather_words + gather_proofs; proving keys kept per program",
            "lib_digest": lib.check_build_identity(), "seconds_of_program_generation_and_shape_legs": round(gen_s, 1)}
     if core_ms_per_shard:

@@ -135,6 +135,7 @@ static int tracegen_single(zkm_ctx* ctx, zkm_matrix** out, const std::function<z
   API_BEGIN
   std::lock_guard<std::mutex> lk(ctx->mu);
   HIP_CHECK(hipSetDevice(ctx->device));
+  CallScope call_scope(ctx);
   ctx->begin_timing();
   TraceBatch b(ctx);
   zkm_matrix* m = nullptr;
@@ -168,6 +169,7 @@ int zkm_tracegen_flat(zkm_ctx* ctx, const uint32_t* words, size_t n_words, size_
   API_BEGIN
   std::lock_guard<std::mutex> lk(ctx->mu);
   HIP_CHECK(hipSetDevice(ctx->device));
+  CallScope call_scope(ctx);
   if (width == 0) throw std::runtime_error("zkm_tracegen_flat: zero width");
   if (n_words && !words) throw std::runtime_error("zkm_tracegen_flat: null records");
   const size_t rows = (n_words + width - 1) / width;
@@ -292,6 +294,7 @@ int zkm_tracegen_program(zkm_ctx* ctx, const zkm_instruction* program, size_t n_
   API_BEGIN
   std::lock_guard<std::mutex> lk(ctx->mu);
   HIP_CHECK(hipSetDevice(ctx->device));
+  CallScope call_scope(ctx);
   if (n_instr && !program) throw std::runtime_error("zkm_tracegen_program: null program");
   const size_t height = padded_trace_rows(n_instr, fixed_log2_rows, "zkm_tracegen_program");
   ctx->begin_call();
@@ -322,6 +325,7 @@ int zkm_tracegen_program_mults(zkm_ctx* ctx, const zkm_cpu_event* events, size_t
   API_BEGIN
   std::lock_guard<std::mutex> lk(ctx->mu);
   HIP_CHECK(hipSetDevice(ctx->device));
+  CallScope call_scope(ctx);
   if (n_events && !events) throw std::runtime_error("zkm_tracegen_program_mults: null events");
   const size_t height = padded_trace_rows(n_instr, fixed_log2_rows, "zkm_tracegen_program_mults");
   ctx->begin_call();
@@ -411,6 +415,7 @@ int zkm_tracegen_poseidon2_wide(zkm_ctx* ctx, const uint32_t* events, size_t n_e
   API_BEGIN
   std::lock_guard<std::mutex> lk(ctx->mu);
   HIP_CHECK(hipSetDevice(ctx->device));
+  CallScope call_scope(ctx);
   if (n_events && !events) throw std::runtime_error("zkm_tracegen_poseidon2_wide: null events");
   const size_t height = padded_trace_rows(n_events, fixed_log2_rows, "zkm_tracegen_poseidon2_wide");
   ctx->begin_timing();
@@ -482,6 +487,7 @@ int zkm_tracegen_memory_global(zkm_ctx* ctx, const zkm_memory_init_finalize_even
   static_assert(sizeof(zkm_memory_init_finalize_event) == 16, "event records mirror the #[repr(C)] executor structs");
   std::lock_guard<std::mutex> lk(ctx->mu);
   HIP_CHECK(hipSetDevice(ctx->device));
+  CallScope call_scope(ctx);
   if (n_events && !events) throw std::runtime_error("zkm_tracegen_memory_global: null events");
   const size_t height = padded_trace_rows(n_events, fixed_log2_rows, "zkm_tracegen_memory_global");
   // generate_trace sorts the events by address first (memory/global.rs:131)
@@ -524,6 +530,7 @@ int zkm_tracegen_poseidon2_permute(zkm_ctx* ctx, const zkm_poseidon2_permute_eve
   static_assert(sizeof(zkm_poseidon2_permute_event) == 4 * tracegen::POSEIDON2_PERMUTE_EVENT_WORDS, "flattened Poseidon2PermuteEvent is 99 words");
   std::lock_guard<std::mutex> lk(ctx->mu);
   HIP_CHECK(hipSetDevice(ctx->device));
+  CallScope call_scope(ctx);
   if (n_events && !events) throw std::runtime_error("zkm_tracegen_poseidon2_permute: null events");
   const size_t height = padded_trace_rows(n_events, fixed_log2_rows, "zkm_tracegen_poseidon2_permute");
   ctx->begin_timing();
@@ -566,6 +573,7 @@ int zkm_tracegen_keccak_sponge(zkm_ctx* ctx, const zkm_keccak_sponge_block* bloc
   static_assert(sizeof(zkm_keccak_sponge_block) == 4 * tracegen::KECCAK_SPONGE_BLOCK_WORDS, "a KeccakSpongeEvent block is 337 words");
   std::lock_guard<std::mutex> lk(ctx->mu);
   HIP_CHECK(hipSetDevice(ctx->device));
+  CallScope call_scope(ctx);
   if (n_blocks && !blocks) throw std::runtime_error("zkm_tracegen_keccak_sponge: null blocks");
   const size_t height = padded_trace_rows(24 * n_blocks, fixed_log2_rows, "zkm_tracegen_keccak_sponge");
   ctx->begin_timing();
@@ -610,6 +618,7 @@ int zkm_tracegen_sha_extend(zkm_ctx* ctx, const zkm_sha_extend_event* events, si
   static_assert(sizeof(zkm_sha_extend_event) == 4 * tracegen::SHA_EXTEND_EVENT_WORDS, "flattened EVENTsha_extend");
   std::lock_guard<std::mutex> lk(ctx->mu);
   HIP_CHECK(hipSetDevice(ctx->device));
+  CallScope call_scope(ctx);
   if (n_events && !events) throw std::runtime_error("zkm_tracegen_sha_extend: null events");
   const size_t height = padded_trace_rows(48 * n_events, fixed_log2_rows, "zkm_tracegen_sha_extend");
   ctx->begin_timing();
@@ -650,6 +659,7 @@ int zkm_tracegen_sha_compress(zkm_ctx* ctx, const zkm_sha_compress_event* events
   static_assert(sizeof(zkm_sha_compress_event) == 4 * tracegen::SHA_COMPRESS_EVENT_WORDS, "flattened EVENTsha_compress");
   std::lock_guard<std::mutex> lk(ctx->mu);
   HIP_CHECK(hipSetDevice(ctx->device));
+  CallScope call_scope(ctx);
   if (n_events && !events) throw std::runtime_error("zkm_tracegen_sha_compress: null events");
   const size_t height = padded_trace_rows(80 * n_events, fixed_log2_rows, "zkm_tracegen_sha_compress");
   ctx->begin_timing();
@@ -716,6 +726,7 @@ int zkm_tracegen_ed_add(zkm_ctx* ctx, const zkm_ed_add_event* events, size_t n_e
   static_assert(sizeof(zkm_ed_add_event) == 4 * tracegen::ED_ADD_EVENT_WORDS, "flattened EllipticCurveAddEvent is 180 words");
   std::lock_guard<std::mutex> lk(ctx->mu);
   HIP_CHECK(hipSetDevice(ctx->device));
+  CallScope call_scope(ctx);
   if (n_events && !events) throw std::runtime_error("zkm_tracegen_ed_add: null events");
   const size_t height = padded_trace_rows(n_events, fixed_log2_rows, "zkm_tracegen_ed_add");
   ctx->begin_timing();
@@ -757,6 +768,7 @@ int zkm_tracegen_ed_decompress(zkm_ctx* ctx, const zkm_ed_decompress_event* even
   static_assert(sizeof(zkm_ed_decompress_event) == 4 * tracegen::ED_DECOMPRESS_EVENT_WORDS, "flattened EdDecompressEvent is 92 words");
   std::lock_guard<std::mutex> lk(ctx->mu);
   HIP_CHECK(hipSetDevice(ctx->device));
+  CallScope call_scope(ctx);
   if (n_events && !events) throw std::runtime_error("zkm_tracegen_ed_decompress: null events");
   const size_t height = padded_trace_rows(n_events, fixed_log2_rows, "zkm_tracegen_ed_decompress");
   ctx->begin_timing();
@@ -802,6 +814,7 @@ int zkm_tracegen_uint256_mul(zkm_ctx* ctx, const zkm_uint256_mul_event* events, 
   static_assert(sizeof(zkm_uint256_mul_event) == 4 * tracegen::UINT256_MUL_EVENT_WORDS, "flattened Uint256MulEvent is 132 words");
   std::lock_guard<std::mutex> lk(ctx->mu);
   HIP_CHECK(hipSetDevice(ctx->device));
+  CallScope call_scope(ctx);
   if (n_events && !events) throw std::runtime_error("zkm_tracegen_uint256_mul: null events");
   const size_t height = padded_trace_rows(n_events, fixed_log2_rows, "zkm_tracegen_uint256_mul");
   ctx->begin_timing();
@@ -845,6 +858,7 @@ int zkm_tracegen_u256x2048_mul(zkm_ctx* ctx, const zkm_u256x2048_mul_event* even
   static_assert(sizeof(zkm_u256x2048_mul_event) == 4 * tracegen::U256X2048_MUL_EVENT_WORDS, "flattened U256xU2048MulEvent is 808 words");
   std::lock_guard<std::mutex> lk(ctx->mu);
   HIP_CHECK(hipSetDevice(ctx->device));
+  CallScope call_scope(ctx);
   if (n_events && !events) throw std::runtime_error("zkm_tracegen_u256x2048_mul: null events");
   const size_t height = padded_trace_rows(n_events, fixed_log2_rows, "zkm_tracegen_u256x2048_mul");
   ctx->begin_timing();
@@ -889,6 +903,7 @@ int zkm_tracegen_boolean_circuit_garble(zkm_ctx* ctx, const zkm_garble_row* rows
   static_assert(sizeof(zkm_garble_row) == 4 * tracegen::GARBLE_ROW_WORDS, "a BooleanCircuitGarble row record is 103 words");
   std::lock_guard<std::mutex> lk(ctx->mu);
   HIP_CHECK(hipSetDevice(ctx->device));
+  CallScope call_scope(ctx);
   if (n_rows && !rows) throw std::runtime_error("zkm_tracegen_boolean_circuit_garble: null rows");
   const size_t height = padded_trace_rows(n_rows, fixed_log2_rows, "zkm_tracegen_boolean_circuit_garble");
   ctx->begin_timing();
@@ -931,6 +946,7 @@ int zkm_tracegen_sys_linux(zkm_ctx* ctx, const zkm_linux_event* events, size_t n
   static_assert(sizeof(zkm_linux_event) == 4 * tracegen::LINUX_EVENT_WORDS, "flattened LinuxEvent is 23 words");
   std::lock_guard<std::mutex> lk(ctx->mu);
   HIP_CHECK(hipSetDevice(ctx->device));
+  CallScope call_scope(ctx);
   if (n_events && !events) throw std::runtime_error("zkm_tracegen_sys_linux: null events");
   const size_t height = padded_trace_rows(n_events, fixed_log2_rows, "zkm_tracegen_sys_linux");
   ctx->begin_timing();
@@ -995,6 +1011,7 @@ static int tracegen_weierstrass(zkm_ctx* ctx, int curve, bool dbl, const void* e
   API_BEGIN
   std::lock_guard<std::mutex> lk(ctx->mu);
   HIP_CHECK(hipSetDevice(ctx->device));
+  CallScope call_scope(ctx);
   if (curve < 0 || curve > 3) throw std::runtime_error(std::string(who) + ": unknown curve");
   if (n_events && !events) throw std::runtime_error(std::string(who) + ": null events");
   const int nl = curve == 3 ? 12 : 8, W = 2 * nl, G = 6 * 4 * nl - 4;
@@ -1093,6 +1110,7 @@ int zkm_tracegen_weierstrass_decompress(zkm_ctx* ctx, int curve, const void* eve
   const char* who = "zkm_tracegen_weierstrass_decompress";
   std::lock_guard<std::mutex> lk(ctx->mu);
   HIP_CHECK(hipSetDevice(ctx->device));
+  CallScope call_scope(ctx);
   if (curve != 0 && curve != 1 && curve != 3) throw std::runtime_error(std::string(who) + ": the curve is ZKM_CURVE_SECP256K1, ZKM_CURVE_SECP256R1 or ZKM_CURVE_BLS12381");
   if (n_events && !events) throw std::runtime_error(std::string(who) + ": null events");
   const int nl = curve == 3 ? 12 : 8, N = 4 * nl, W = nl, G = 6 * N - 4;
@@ -1158,6 +1176,7 @@ static int tracegen_fp_tower(zkm_ctx* ctx, int field, int kind, const void* even
   API_BEGIN
   std::lock_guard<std::mutex> lk(ctx->mu);
   HIP_CHECK(hipSetDevice(ctx->device));
+  CallScope call_scope(ctx);
   if (field != 2 && field != 3) throw std::runtime_error(std::string(who) + ": the field is ZKM_CURVE_BN254 or ZKM_CURVE_BLS12381");
   if (n_events && !events) throw std::runtime_error(std::string(who) + ": null events");
   const int nl = field == 3 ? 12 : 8, W = kind == 0 ? nl : 2 * nl, G = 6 * 4 * nl - 4;
@@ -1227,6 +1246,7 @@ int zkm_tracegen_exp_reverse_bits(zkm_ctx* ctx, const uint32_t* bases, const uin
   API_BEGIN
   std::lock_guard<std::mutex> lk(ctx->mu);
   HIP_CHECK(hipSetDevice(ctx->device));
+  CallScope call_scope(ctx);
   if (n_events && (!bases || !bits || !offsets)) throw std::runtime_error("zkm_tracegen_exp_reverse_bits: null events");
   const size_t rows = n_events ? offsets[n_events] : 0;
   for (size_t e = 0; e < n_events; e++)
@@ -1268,6 +1288,7 @@ int zkm_tracegen_poseidon2_skinny(zkm_ctx* ctx, const uint32_t* events, size_t n
   API_BEGIN
   std::lock_guard<std::mutex> lk(ctx->mu);
   HIP_CHECK(hipSetDevice(ctx->device));
+  CallScope call_scope(ctx);
   if (n_events && !events) throw std::runtime_error("zkm_tracegen_poseidon2_skinny: null events");
   const size_t height = padded_trace_rows(n_events * tracegen::SKINNY_ROWS, fixed_log2_rows, "zkm_tracegen_poseidon2_skinny");
   ctx->begin_timing();
@@ -1301,6 +1322,7 @@ int zkm_tracegen_byte_table(zkm_ctx* ctx, zkm_matrix** out) {
   API_BEGIN
   std::lock_guard<std::mutex> lk(ctx->mu);
   HIP_CHECK(hipSetDevice(ctx->device));
+  CallScope call_scope(ctx);
   ctx->begin_call();
   zkm_matrix* m = new zkm_matrix();
   m->h = tracegen::BYTE_ROWS; m->w = tracegen::BYTE_PREP_COLS;
@@ -1322,6 +1344,7 @@ int zkm_byte_lookups_create(zkm_ctx* ctx, zkm_byte_lookups** out) {
   API_BEGIN
   std::lock_guard<std::mutex> lk(ctx->mu);
   HIP_CHECK(hipSetDevice(ctx->device));
+  CallScope call_scope(ctx);
   const size_t cells = (size_t)tracegen::BYTE_ROWS * tracegen::NUM_BYTE_OPS;
   zkm_byte_lookups* b = new zkm_byte_lookups();
   try {
@@ -1370,6 +1393,7 @@ int zkm_tracegen_shard(zkm_ctx* ctx, const zkm_tracegen_desc* descs, size_t n, z
   API_BEGIN
   std::lock_guard<std::mutex> lk(ctx->mu);
   HIP_CHECK(hipSetDevice(ctx->device));
+  CallScope call_scope(ctx);
   if (n && (!descs || !out)) throw std::runtime_error("zkm_tracegen_shard: null descriptors");
   ctx->begin_timing();
   TraceBatch b(ctx);

@@ -77,6 +77,31 @@ static uint32_t sample_bits(zkm_challenger* c, uint32_t bits) {
 }
 }  // namespace chal
 
+// ---- live handles --------------------------------------------------------------------------------
+// Every object the C ABI hands out as an opaque pointer (zkm_matrix, zkm_pcs_data, zkm_pk, zkm_main_data) enters this table when it is
+// made and leaves it when it is destroyed, so that an entry point can tell a live handle from one that was freed (or never was one)
+// WITHOUT dereferencing it: a freed handle reused is an error message, not undefined behaviour (SURVEY 8b "Errors").
+enum HandleKind { H_MATRIX = 1, H_PCS_DATA = 2, H_PK = 3, H_MAIN_DATA = 4 };
+struct HandleTable {
+  std::mutex mu;
+  std::unordered_map<const void*, int> live;
+  static HandleTable& get() { static HandleTable t; return t; }
+  void add(const void* p, int kind) { std::lock_guard<std::mutex> lk(mu); live[p] = kind; }
+  void drop(const void* p) { std::lock_guard<std::mutex> lk(mu); live.erase(p); }
+  bool is_live(const void* p, int kind) { std::lock_guard<std::mutex> lk(mu); auto it = live.find(p); return it != live.end() && it->second == kind; }
+};
+template <int KIND>
+struct Handle {
+  Handle() { HandleTable::get().add(this, KIND); }
+  Handle(const Handle&) { HandleTable::get().add(this, KIND); }
+  Handle& operator=(const Handle&) { return *this; }
+  ~Handle() { HandleTable::get().drop(this); }
+};
+static inline void check_handle(const void* p, int kind, const char* fn, const char* what) {
+  if (!p) throw std::runtime_error(std::string(fn) + ": null " + what);
+  if (!HandleTable::get().is_live(p, kind)) throw std::runtime_error(std::string(fn) + ": " + what + " is not a live handle (freed, or never returned by this library)");
+}
+
 // ---- context -----------------------------------------------------------------------------------
 struct zkm_ctx {
   int device = 0;
@@ -133,7 +158,7 @@ struct zkm_ctx {
   // build_tree: the rows of a commit's shorter heights hashed by one launch in front of the tree levels (merkle::hash_rows) instead of
   // inside compress_layer; ZKM_ROWS_UP_FRONT=0 for the A/B
   bool rows_up_front = !(getenv("ZKM_ROWS_UP_FRONT") && atoi(getenv("ZKM_ROWS_UP_FRONT")) == 0);
-  bool root_poll = !(getenv("ZKM_ROOT_POLL") && atoi(getenv("ZKM_ROOT_POLL")) == 0);   // wait_root; cleared for good by its first timeout
+  bool root_poll = !(getenv("ZKM_ROOT_POLL") && atoi(getenv("ZKM_ROOT_POLL")) == 0);   // wait_root; cleared only when a FINISHED launch's root is still not visible
   int root_spin_before_yield = getenv("ZKM_ROOT_SPIN") ? atoi(getenv("ZKM_ROOT_SPIN")) : 4096;   // wait_root: spins before it starts yielding the core
   int root_sleep_ns = getenv("ZKM_ROOT_SLEEP_NS") ? atoi(getenv("ZKM_ROOT_SLEEP_NS")) : 0;        // > 0: past the spins it sleeps this long between looks instead of yielding
   // How this context's host thread waits for its stream (zkm_ctx_set_host_wait; ZKM_HOST_WAIT=blocking sets the default). Spinning
@@ -145,19 +170,32 @@ struct zkm_ctx {
   // (an event created with hipEventBlockingSync does not make hipEventSynchronize sleep on this runtime — measured: the lane thread still
   // burns a core; only the process-wide hipDeviceScheduleBlockingSync does, and that would bind every context of the process. So the
   // blocking wait is a query of the stream between short sleeps: a few per cent of a core, ~40 us of wake-up latency per wait.)
-  static void sleep_ns(long ns) {
-    static thread_local bool slack_set = false;
-    if (!slack_set) { prctl(PR_SET_TIMERSLACK, 1000UL, 0, 0, 0); slack_set = true; }     // the default 50 us of timer slack would triple a 20 us sleep
+  // The sleeping waits need a timer slack of ~1 us (the default 50 us would triple a 20 us sleep). The slack belongs to the CALLER's
+  // thread — a Rust prover thread, a Python lane — so it is tightened only while one of this library's waits is actually sleeping and put
+  // back when that wait ends: an embedding application's own timers are never left changed.
+  struct TimerSlack {
+    long saved = -1;
+    void tighten() {
+      if (saved >= 0) return;
+      saved = prctl(PR_GET_TIMERSLACK, 0, 0, 0, 0);
+      if (saved >= 0) prctl(PR_SET_TIMERSLACK, 1000UL, 0, 0, 0);
+    }
+    ~TimerSlack() { if (saved >= 0) prctl(PR_SET_TIMERSLACK, (unsigned long)saved, 0, 0, 0); }
+  };
+  static void sleep_ns(long ns, TimerSlack& slack) {
+    slack.tighten();
     timespec ts{0, ns};
     nanosleep(&ts, nullptr);
   }
+  // host_wait_blocking: not a kernel-level blocking wait (see above: this runtime has none per stream) but a stream query between short sleeps
   void sync(hipStream_t s) {
     if (!host_wait_blocking) { HIP_CHECK(hipStreamSynchronize(s)); return; }
+    TimerSlack slack;
     for (int i = 0;; i++) {
       const hipError_t e = hipStreamQuery(s);
       if (e == hipSuccess) return;
       if (e != hipErrorNotReady) HIP_CHECK(e);
-      if (i >= 4) sleep_ns(wait_sleep_ns);
+      if (i >= 4) sleep_ns(wait_sleep_ns, slack);
     }
   }
   // per-chip specialised quotient kernels (ziren_amd/codegen.py), keyed by a hash of the program words
@@ -290,6 +328,21 @@ struct zkm_ctx {
     return h;
   }
 
+  // Pool accounting and its cap: `pool_bytes` = everything this pool holds from hipMalloc (handed out + cached). `pool_limit` (0: none;
+  // zkm_ctx_set_memory_limit, or ZKM_POOL_LIMIT_MB for every context of the process) bounds it: a request that would cross it first gives the
+  // cached blocks back to the driver and, if that is not enough, fails with an error the caller can act on — the context stays usable.
+  size_t pool_bytes = 0;
+  size_t pool_limit = getenv("ZKM_POOL_LIMIT_MB") ? (size_t)atoll(getenv("ZKM_POOL_LIMIT_MB")) << 20 : 0;
+  // buffers handed out since the outermost API call on this context began (CallScope): what a failing call gives back
+  std::vector<void*> call_allocs;
+  int call_depth = 0;
+  void drop_cached() {            // stream-ordered reuse is over for these: wait for the work that may still touch them
+    if (free_list.empty()) return;
+    (void)hipStreamSynchronize(stream);
+    if (stream2) (void)hipStreamSynchronize(stream2);
+    for (auto& kv : free_list) { (void)hipFree(kv.second); pool_bytes -= kv.first; }
+    free_list.clear();
+  }
   void* alloc(size_t bytes) {
     if (bytes == 0) bytes = 4;
     bytes = (bytes + 255) & ~(size_t)255;
@@ -299,9 +352,25 @@ struct zkm_ctx {
       p = it->second;
       free_list.erase(it);
     } else {
-      HIP_CHECK(hipMalloc(&p, bytes));
+      if (pool_limit && pool_bytes + bytes > pool_limit) drop_cached();
+      if (pool_limit && pool_bytes + bytes > pool_limit)
+        throw std::runtime_error("out of device memory: " + std::to_string(bytes) + " bytes on top of " + std::to_string(pool_bytes) +
+                                 " held would cross the context's pool limit of " + std::to_string(pool_limit) + " bytes");
+      hipError_t e = hipMalloc(&p, bytes);
+      if (e != hipSuccess) {        // the device is full: hand the cached blocks back and try once more
+        (void)hipGetLastError();
+        drop_cached();
+        e = hipMalloc(&p, bytes);
+      }
+      if (e != hipSuccess) {
+        (void)hipGetLastError();
+        throw std::runtime_error(std::string("out of device memory: hipMalloc of ") + std::to_string(bytes) + " bytes failed (" + hipGetErrorString(e) + "), " +
+                                 std::to_string(pool_bytes) + " bytes held by this context's pool");
+      }
+      pool_bytes += bytes;
     }
     live[p] = bytes;
+    if (call_depth > 0) call_allocs.push_back(p);
     return p;
   }
   template <class T>
@@ -456,7 +525,7 @@ struct zkm_ctx {
   }
 };
 
-struct zkm_matrix {
+struct zkm_matrix : Handle<H_MATRIX> {
   uint32_t* d = nullptr;  // column-major: column c at d + c * h
   size_t h = 0, w = 0;
   bool owned = true;
@@ -481,7 +550,7 @@ struct Tree {
   const uint32_t* node(int layer, size_t i) const { return digests + (layer_off[layer] + i) * 8; }
 };
 
-struct zkm_pcs_data {
+struct zkm_pcs_data : Handle<H_PCS_DATA> {
   std::vector<zkm_matrix> ldes;           // owned; bit-reversed rows, height = h << log_blowup
   std::vector<const uint32_t*> evals;     // borrowed: the committed evaluations (column-major, natural order)
   std::vector<size_t> eval_heights;
@@ -496,7 +565,7 @@ struct zkm_pcs_data {
   std::vector<const uint32_t*> col_flags;   // per matrix: into cflags, or null
 };
 
-struct zkm_pk {
+struct zkm_pk : Handle<H_PK> {
   std::vector<zkm_matrix> prep;  // borrowed device matrices
   std::vector<uint32_t> local_only;
   zkm_pcs_data* data = nullptr;
@@ -505,7 +574,7 @@ struct zkm_pk {
   uint32_t igcs[14];
 };
 
-struct zkm_main_data {
+struct zkm_main_data : Handle<H_MAIN_DATA> {
   std::vector<size_t> order;             // sorted position -> caller index
   std::vector<zkm_matrix> traces;        // borrowed, sorted order
   zkm_pcs_data* data = nullptr;

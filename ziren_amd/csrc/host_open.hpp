@@ -615,10 +615,24 @@ struct ShardOpening {
   }
 
   // (iv) FRI commit phase (fri.rs:257-358): per layer a tree over the pairs, its root into the transcript, beta out, fold
+  // fri.rs:34-69. Per layer: commit to the pairs (leaf kernel + tree levels), observe the root, sample beta, fold (+ beta^2 ro of the new
+  // length). The transcript step runs ON THE DEVICE, in the launch that finishes the layer's tree (merkle::observe_root_sample_beta over a
+  // device copy of the challenger), and the fold reads beta from memory: all layers are queued back to back with no host round trip
+  // between them (before: one per layer, 22 for the benchmarked shard — most of a small shard's commit phase was waiting). Afterwards the
+  // host replays the same steps from the roots the launches left in page-locked memory — it remains the source of truth: the betas the
+  // device used must be the ones the host transcript samples, or the proof is refused here.
   void fri_commit_phase() {
+  static_assert(sizeof(merkle::DevChallenger) == sizeof(zkm_challenger), "the device challenger is the ABI's challenger");
   E4* f = ro[log_max];
   int lf = log_max;
   uint32_t neg_half = kb::neg(kb::inv(kb::to_monty(2)));
+  const int n_layers = log_max - bl;
+  merkle::DevChallenger* d_ch = (merkle::DevChallenger*)ctx->upload(ch, sizeof(zkm_challenger), &scratch);    // its own buffer: the launches write it
+  E4* d_betas = (E4*)salloc((size_t)std::max(n_layers, 1) * 2 * sizeof(E4));
+  uint32_t* h_roots = (uint32_t*)ctx->pin_alloc((size_t)std::max(n_layers, 1) * 32);
+  if (!h_roots) throw std::runtime_error("pinned staging ring exhausted");
+  for (int i = 0; i < n_layers * 8; i++) ((volatile uint32_t*)h_roots)[i] = 0xffffffffu;
+  int li = 0;
   while (lf > bl) {
     size_t len = (size_t)1 << lf, half = len / 2;
     Tree t;
@@ -635,29 +649,37 @@ struct ShardOpening {
       KLAUNCH(ctx, "hash_fri_leaves", 64.0 * half, merkle::hash_fri_leaves, dim3(div_up(half, merkle::THREADS)), dim3(merkle::THREADS), 0,
               (const E4*)f, half, t.digests);
     int layer = fuse;
+    bool tail = false;
     for (size_t l = half >> (fuse + 1); l >= 1; l >>= 1, layer++)
-      if (compress_small_layer(ctx, t, layer, l)) break;
-    std::array<uint32_t, 8> root;
-    const bool pollable = t.h_root != nullptr;
-    const uint32_t* h_root = t.h_root ? t.h_root : ctx->download_async(t.node(t.log_max, 0), 8);
-    wait_root(ctx, h_root, pollable);
+      if (compress_small_layer(ctx, t, layer, l, d_ch, d_betas + 2 * li, h_roots + 8 * li)) { tail = true; break; }
+    if (!tail)      // a tree of one leaf (or one whose levels all ran inside the leaf kernel): the root is in the tree already
+      KLAUNCH(ctx, "fri_root_challenge", 0.0, merkle::fri_root_challenge, dim3(1), dim3(64), 0, t.node(t.log_max, 0), h_roots + 8 * li, d_ch, d_betas + 2 * li);
     t.h_root = nullptr;
-    memcpy(root.data(), h_root, 32);
-    chal::observe_slice(ch, root.data(), 8);
-    commits.push_back(root);
-    E4 beta = chal::sample_ext(ch);
     E4* g = (E4*)salloc(half * sizeof(E4));
     KLAUNCH(ctx, "fri_fold", 48.0 * half + (ro[lf - 1] ? 16.0 * half : 0.0), open::fri_fold, dim3(div_up(half, open::THREADS)),
-            dim3(open::THREADS), 0, (const E4*)f, lf, beta, kb::esqr(beta), kb::two_adic_generator(lf),
+            dim3(open::THREADS), 0, (const E4*)f, lf, (const E4*)(d_betas + 2 * li), kb::two_adic_generator(lf),
             kb::inv(kb::two_adic_generator(lf)), neg_half, (const E4*)ro[lf - 1], g);
     layers.push_back(f);
     ftrees.push_back(t);
     f = g;
     lf--;
+    li++;
   }
   const size_t nfin = (size_t)1 << lf;
   const E4* fin = ctx->download_async((const E4*)f, nfin);
+  const E4* used = n_layers > 0 ? ctx->download_async((const E4*)d_betas, (size_t)n_layers * 2) : nullptr;
   ctx->sync(st);
+  // the host's transcript, from the roots: observe, sample — and hold the device's betas against it
+  for (int i = 0; i < n_layers; i++) {
+    std::array<uint32_t, 8> root;
+    memcpy(root.data(), h_roots + 8 * i, 32);
+    for (int k = 0; k < 8; k++)
+      if (root[k] == 0xffffffffu) throw std::runtime_error("an FRI layer's root did not arrive in page-locked memory (internal error)");
+    chal::observe_slice(ch, root.data(), 8);
+    commits.push_back(root);
+    const E4 beta = chal::sample_ext(ch);
+    if (!kb::eq(beta, used[2 * i])) throw std::runtime_error("the device transcript of the FRI commit phase diverged from the host's (internal error)");
+  }
   for (size_t i = 1; i < nfin; i++)
     if (!kb::eq(fin[i], fin[0])) throw std::runtime_error("FRI final polynomial is not constant (internal error)");
   final_poly = fin[0];

@@ -134,7 +134,8 @@ static const uint32_t** upload_ptrs(zkm_ctx* ctx, const std::vector<const uint32
 // Layers of at most LANES_MAX nodes without injection: lane-parallel compression; returns true when it
 // finished the tree (tail launch, which also writes the root to pinned host memory: t.h_root, valid after the next stream
 // synchronisation), false when the caller should go on with the next layer.
-static bool compress_small_layer(zkm_ctx* ctx, Tree& t, int layer, size_t len) {
+static bool compress_small_layer(zkm_ctx* ctx, Tree& t, int layer, size_t len, merkle::DevChallenger* d_ch = nullptr, kb::E4* d_beta = nullptr,
+                                 uint32_t* h_root_slot = nullptr) {
   const size_t LANES_MAX = 4096, TAIL = 64;
   if (len > LANES_MAX) {
     KLAUNCH(ctx, "compress_layer", 96.0 * len, merkle::compress_layer, dim3(div_up(len, merkle::THREADS)), dim3(merkle::THREADS), 0,
@@ -143,9 +144,10 @@ static bool compress_small_layer(zkm_ctx* ctx, Tree& t, int layer, size_t len) {
     return false;
   }
   if (len <= TAIL) {
-    uint32_t* h_root = (uint32_t*)ctx->pin_alloc(32);
+    // d_ch (an FRI commit-phase tree): the tail observes the root into the device challenger and samples beta (merkle.cuh)
+    uint32_t* h_root = h_root_slot ? h_root_slot : (uint32_t*)ctx->pin_alloc(32);
     if (h_root) for (int k = 0; k < 8; k++) ((volatile uint32_t*)h_root)[k] = 0xffffffffu;   // not a field word: wait_root can watch the root arrive
-    KLAUNCH(ctx, "compress_tail", 96.0 * len, merkle::compress_tail_lanes, dim3(1), dim3(1024), 0, t.digests + t.layer_off[layer] * 8, len, h_root);
+    KLAUNCH(ctx, "compress_tail", 96.0 * len, merkle::compress_tail_lanes, dim3(1), dim3(1024), 0, t.digests + t.layer_off[layer] * 8, len, h_root, d_ch, d_beta);
     t.h_root = h_root;
     return true;
   }
@@ -170,23 +172,32 @@ static inline void cpu_relax() {
 static void wait_root(zkm_ctx* ctx, const uint32_t* h_root, bool pollable) {
   if (ctx->root_poll && pollable) {
     const volatile uint32_t* v = h_root;
-    const auto t0 = std::chrono::steady_clock::now();
+    auto t0 = std::chrono::steady_clock::now();
+    zkm_ctx::TimerSlack slack;
     for (int spins = 0;; spins++) {
       bool all = true;
       for (int k = 0; k < 8; k++) all &= v[k] != 0xffffffffu;
       if (all) { std::atomic_thread_fence(std::memory_order_acquire); return; }
       if ((ctx->host_wait_blocking || (spins & 4095) == 4095) && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(1)) {
-        // the stores of a running kernel are not visible to the host here (non-coherent host memory?): every further root would cost
-        // the same second, so this context synchronises from now on, and says so once
+        // a second without the root. "Not finished yet" and "finished but not visible" are different things: on an oversubscribed device
+        // (eight ranks sharing one GPU, a tail launch queued behind seconds of another lane's work) the launch may simply not have run.
+        // Only a stream that HAS completed while the words are still 0xffffffff means the stores do not reach the host here (non-coherent
+        // host memory): then every further root would cost the same wait, and this context synchronises from now on.
+        const hipError_t q = hipStreamQuery(ctx->stream);
+        if (q == hipErrorNotReady) { t0 = std::chrono::steady_clock::now(); continue; }     // still running or queued: keep watching
+        if (q != hipSuccess) HIP_CHECK(q);                                                  // a failed launch surfaces here
+        bool now = true;
+        for (int k = 0; k < 8; k++) now &= v[k] != 0xffffffffu;
+        if (now) { std::atomic_thread_fence(std::memory_order_acquire); return; }
         ctx->root_poll = false;
-        fprintf(stderr, "libzkm_hip: a tree root did not become visible in page-locked memory within 1 s; root polling is off for this context (stream synchronisation instead)\n");
+        g_err = "a finished launch's tree root is not visible in page-locked memory: root polling is off for this context (stream synchronisation instead)";
         break;
       }
       // after a short burst of spinning give the core away: a lane's host thread shares its CPUs with the other lanes and ranks of the node
       // a blocking context looks at the root between short sleeps; a spinning one spins, and past a burst gives the core away when asked
-      if (ctx->host_wait_blocking) { if (spins >= 64) zkm_ctx::sleep_ns(std::min(ctx->wait_sleep_ns, 10000)); else cpu_relax(); }
+      if (ctx->host_wait_blocking) { if (spins >= 64) zkm_ctx::sleep_ns(std::min(ctx->wait_sleep_ns, 10000), slack); else cpu_relax(); }
       else if (spins < ctx->root_spin_before_yield) cpu_relax();
-      else if (ctx->root_sleep_ns > 0) zkm_ctx::sleep_ns(ctx->root_sleep_ns);
+      else if (ctx->root_sleep_ns > 0) zkm_ctx::sleep_ns(ctx->root_sleep_ns, slack);
       else sched_yield();
     }
   }

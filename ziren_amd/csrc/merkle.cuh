@@ -358,16 +358,71 @@ __global__ __launch_bounds__(THREADS) void compress_layer_lanes(const uint32_t* 
   if (e < 8) next[8 * node + e] = x;
 }
 
+// ---- the duplex challenger on the device: the FRI commit phase without host round trips ---------------------------------------------
+// DuplexChallenger<KoalaBear, Perm, 16, 8> (crates/recursion/circuit/src/challenger.rs:90-114,201-233; host twin: chal:: in host_ctx.hpp)
+// over the same state the ABI carries (zkm_challenger), kept in device memory while the commit phase runs: the launch that finishes a
+// layer's tree observes the root and samples beta right there (fri.rs:34-69: observe the commitment, sample_ext), the fold reads beta from
+// memory, and the host queues all layers back to back — it replays the transcript from the roots afterwards and stays the source of truth
+// (host_open.hpp fri_commit_phase). Sixteen lanes of one DPP row: lane e holds sponge word e, input word e, output word e.
+struct DevChallenger {
+  uint32_t sponge_state[16];
+  uint32_t num_inputs;
+  uint32_t input_buffer[16];
+  uint32_t num_outputs;
+  uint32_t output_buffer[16];
+};
+// rw: lane e < 8 holds root word e. Writes beta_out[0] = beta, beta_out[1] = beta^2, and the advanced state back to *ch.
+__device__ __forceinline__ void observe_root_sample_beta(uint32_t rw, int e, const lanes::LaneConsts& k, DevChallenger* ch, kb::E4* beta_out) {
+  uint32_t x = ch->sponge_state[e];
+  uint32_t inb = ch->input_buffer[e], outb = ch->output_buffer[e];
+  uint32_t ni = ch->num_inputs, no = ch->num_outputs;      // the same in every lane
+  auto duplexing = [&]() {                                 // challenger.rs:90-103: overwrite the first num_inputs words, permute, eight outputs
+    x = (uint32_t)e < ni ? inb : x;
+    ni = 0;
+    x = lanes::permute(x, k);
+    outb = x;
+    no = 8;
+  };
+#pragma unroll 1
+  for (int i = 0; i < 8; i++) {                            // observe(root[i]) (:105-114)
+    const uint32_t ri = (uint32_t)__shfl((int)rw, i, 16);
+    no = 0;
+    inb = (uint32_t)e == ni ? ri : inb;
+    ni++;
+    if (ni == 8) duplexing();
+  }
+  uint32_t b[4];
+#pragma unroll 1
+  for (int j = 0; j < 4; j++) {                            // sample_ext = four samples, each popped from the back (:201-233)
+    if (ni != 0 || no == 0) duplexing();
+    no--;
+    b[j] = (uint32_t)__shfl((int)outb, (int)no, 16);
+  }
+  ch->sponge_state[e] = x;
+  ch->input_buffer[e] = inb;
+  ch->output_buffer[e] = outb;
+  if (e == 0) {
+    ch->num_inputs = ni;
+    ch->num_outputs = no;
+    const kb::E4 beta{{b[0], b[1], b[2], b[3]}};
+    beta_out[0] = beta;
+    beta_out[1] = kb::esqr(beta);
+  }
+}
+
 // Root of the tree in one launch, 16 lanes per node: from 2*len0 digests at `prev` (len0 <= 64) down to 1. The root also goes straight
 // to `root_host` (page-locked host memory, may be null): the transcript reads it after the stream synchronisation, no copy dispatch.
+// With `ch` (an FRI commit-phase tree): the root is observed into the device challenger and beta sampled here (observe_root_sample_beta).
 // (Tried and removed, round 3: ONE launch from 4096 nodes down, len0 / 64 blocks with grid barriers between levels — 72 dispatches fewer
 // per proof, bit-exact, but 0.8 ms slower per SYN-22 proof: an agent-scope release is a whole-L2 write-back on gfx950, and a level is
 // latency-bound at ~3 us either way.)
-__global__ __launch_bounds__(1024) void compress_tail_lanes(uint32_t* __restrict__ prev, size_t len0, uint32_t* root_host) {
+__global__ __launch_bounds__(1024) void compress_tail_lanes(uint32_t* __restrict__ prev, size_t len0, uint32_t* root_host, DevChallenger* ch,
+                                                            kb::E4* beta_out) {
   const int e = threadIdx.x & 15;
   lanes::LaneConsts k = lanes::load_consts(e);
   uint32_t* p = prev;
   uint32_t* nx = prev + 16 * len0;
+  uint32_t root_word = 0;
   for (size_t len = len0; len >= 1; len >>= 1) {
     const size_t node = threadIdx.x >> 4;
     if (node < len) {
@@ -376,12 +431,24 @@ __global__ __launch_bounds__(1024) void compress_tail_lanes(uint32_t* __restrict
         nx[8 * node + e] = x;
         if (len == 1 && root_host) root_host[e] = x;
       }
+      if (len == 1) root_word = x;
     }
     __syncthreads();
     p = nx;
     nx += 8 * len;
     if (len == 1) break;
   }
+  if (ch && threadIdx.x < 16) observe_root_sample_beta(root_word, e, k, ch, beta_out);
+}
+
+// The same step for a tree whose root was produced by another launch (a layer of one or two leaves has no tail launch): one row of lanes.
+__global__ __launch_bounds__(64) void fri_root_challenge(const uint32_t* __restrict__ root_dev, uint32_t* root_host, DevChallenger* ch, kb::E4* beta_out) {
+  if (threadIdx.x >= 16) return;
+  const int e = threadIdx.x;
+  lanes::LaneConsts k = lanes::load_consts(e);
+  const uint32_t rw = e < 8 ? root_dev[e] : 0;
+  if (e < 8 && root_host) root_host[e] = rw;
+  observe_root_sample_beta(rw, e, k, ch, beta_out);
 }
 
 // The part of an injected row's sponge that is the same for every row (round 4). The shape step pads a shard with chips that have no

@@ -348,13 +348,16 @@ __global__ __launch_bounds__(THREADS) void reduce_openings(const ReduceMat* __re
 
 // FRI fold (fri.rs:257-358): g[j] = e0 + (beta - x)(e1 - e0)/(-2x) [+ beta^2 * ro_next[j]],
 // (e0, e1) = (f[2j], f[2j+1]), x = w_len^bitrev(2j).
-__global__ __launch_bounds__(THREADS) void fri_fold(const kb::E4* __restrict__ f, int log_len, kb::E4 beta, kb::E4 beta_sq,
+// beta and beta^2 are read from memory (betas[0], betas[1]): the launch that finished this layer's tree sampled them on the device
+// (merkle::observe_root_sample_beta), so the fold is queued right behind it without the host seeing the root first.
+__global__ __launch_bounds__(THREADS) void fri_fold(const kb::E4* __restrict__ f, int log_len, const kb::E4* __restrict__ betas,
                                                     uint32_t w_len, uint32_t w_len_inv, uint32_t neg_half,
                                                     const kb::E4* __restrict__ ro_next,
                                                     kb::E4* __restrict__ g) {
   size_t half = (size_t)1 << (log_len - 1);
   size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= half) return;
+  const kb::E4 beta = betas[0], beta_sq = betas[1];
   kb::E4 e0 = f[2 * j], e1 = f[2 * j + 1];
   uint32_t e = kb::bitrev((uint32_t)(2 * j), log_len);
   uint32_t xinv = kb::pow(w_len_inv, (uint64_t)e);
@@ -405,14 +408,22 @@ __global__ void transpose(const uint32_t* __restrict__ in, uint32_t* __restrict_
   }
 }
 
-// rows [r0, r0 + rows) of a row-major [.][cols] slab -> column-major matrix of `height` rows
+// rows [r0, r0 + rows) of a row-major [.][cols] slab -> column-major matrix of `height` rows. This is where host words enter the
+// prover (zkm_matrix_upload, zkm_matrix_upload_async, zkm_tracegen_flat): every kernel behind it sizes its accumulators for canonical
+// Montgomery words (< p: what a RowMajorMatrix<KoalaBear> holds — MontyField31 keeps its value reduced), so a word >= p is reduced here
+// (3p > 2^32: two conditional subtractions cover every u32) instead of silently computing with a wrong bound.
 __global__ void transpose_slab(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, size_t rows, size_t cols, size_t r0,
                                size_t height) {
   __shared__ uint32_t tile[32][33];
   size_t bx = (size_t)blockIdx.x * 32, by = (size_t)blockIdx.y * 32;
   for (int j = threadIdx.y; j < 32; j += blockDim.y) {
     size_t r = by + j, c = bx + threadIdx.x;
-    if (r < rows && c < cols) tile[j][threadIdx.x] = in[r * cols + c];
+    if (r < rows && c < cols) {
+      uint32_t w = in[r * cols + c];
+      w = w >= kb::P ? w - kb::P : w;
+      w = w >= kb::P ? w - kb::P : w;
+      tile[j][threadIdx.x] = w;
+    }
   }
   __syncthreads();
   for (int j = threadIdx.y; j < 32; j += blockDim.y) {

@@ -24,6 +24,8 @@
 #include <numeric>
 #include <stdexcept>
 #include <string>
+#include <unordered_map>
+#include <exception>
 #include <vector>
 
 #include <sched.h>
@@ -53,6 +55,8 @@ static void launch_alu_rows(zkm_ctx* ctx, const uint32_t* d_events, size_t n_eve
           counts ? tracegen::TILES_PER_BLOCK : 1);
 }
 
+// Nothing unwinds across the C ABI (SURVEY 8b "Errors"): every entry point that can fail returns a status and leaves the message in
+// zkm_last_error(); whatever is thrown — a std::exception or anything else — ends here.
 #define API_BEGIN try {
 #define API_END                              \
   }                                          \
@@ -60,7 +64,38 @@ static void launch_alu_rows(zkm_ctx* ctx, const uint32_t* d_events, size_t n_eve
     g_err = e.what();                        \
     return -1;                               \
   }                                          \
+  catch (...) {                              \
+    g_err = "unknown exception (not derived from std::exception)"; \
+    return -1;                               \
+  }                                          \
   return 0;
+
+// The outermost API call on a context that ends in an exception gives back every pool buffer it took and still holds: a call that fails
+// returns no handle, so whatever it allocated is garbage (objects it already destroyed while unwinding released theirs: a second release
+// is ignored). The streams are drained first — the pool reuses buffers in stream order, and the failing call's kernels may still be
+// running. After that the context proves again as if the call had not been made (tests/c_abi/consumer.c `fail`).
+struct CallScope {
+  zkm_ctx* c;
+  int exceptions;
+  explicit CallScope(zkm_ctx* ctx) : c(ctx), exceptions(std::uncaught_exceptions()) {
+    if (c->call_depth++ == 0) c->call_allocs.clear();
+  }
+  ~CallScope() {
+    if (--c->call_depth > 0) return;
+    if (std::uncaught_exceptions() > exceptions) {
+      (void)hipStreamSynchronize(c->stream);
+      (void)hipStreamSynchronize(c->stream2);
+      if (c->ev_dma) (void)hipStreamSynchronize(c->ev_dma);
+      (void)hipGetLastError();
+      c->cur = c->stream;
+      c->side_pending = false;
+      for (void* p : c->side_deferred) c->release(p);
+      c->side_deferred.clear();
+      for (void* p : c->call_allocs) c->release(p);
+    }
+    c->call_allocs.clear();
+  }
+};
 
 extern "C" {
 
@@ -176,8 +211,9 @@ int zkm_ctx_trim(zkm_ctx* ctx) {
   API_BEGIN
   std::lock_guard<std::mutex> lk(ctx->mu);
   HIP_CHECK(hipSetDevice(ctx->device));
+  CallScope call_scope(ctx);
   ctx->sync(ctx->stream);
-  for (auto& kv : ctx->free_list) HIP_CHECK(hipFree(kv.second));
+  for (auto& kv : ctx->free_list) { HIP_CHECK(hipFree(kv.second)); ctx->pool_bytes -= kv.first; }
   ctx->free_list.clear();
   ctx->drop_coset_tables();
   // per-height tables a long-lived prover accumulates (12 B per quotient-domain row per (height, degree); n words per height): rebuilt on
@@ -187,6 +223,19 @@ int zkm_ctx_trim(zkm_ctx* ctx) {
   for (auto& kv : ctx->row_tabs) HIP_CHECK(hipFree(kv.second));
   ctx->row_tabs.clear();
   API_END
+}
+
+int zkm_ctx_set_memory_limit(zkm_ctx* ctx, size_t bytes) {
+  API_BEGIN
+  if (!ctx) throw std::runtime_error("zkm_ctx_set_memory_limit: null context");
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  ctx->pool_limit = bytes;
+  API_END
+}
+size_t zkm_ctx_memory_held(zkm_ctx* ctx) {
+  if (!ctx) return 0;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  return ctx->pool_bytes;
 }
 
 int zkm_ctx_synchronize(zkm_ctx* ctx) {
@@ -221,6 +270,7 @@ int zkm_ctx_register_quotient_kernel(zkm_ctx* ctx, const uint32_t* program, uint
   API_BEGIN
   std::lock_guard<std::mutex> lk(ctx->mu);
   HIP_CHECK(hipSetDevice(ctx->device));
+  CallScope call_scope(ctx);
   if (!program_len || !code_object_len) throw std::runtime_error("empty program or code object");
   // one gfx950 code object, or — for a program long enough to be cut into several kernels (ziren_amd/codegen.py) — a container of them:
   // "ZKMQPART", u32 count, u32 zero, count x u64 lengths, then the code objects back to back. The first kernel stores its share of the
@@ -274,6 +324,7 @@ int zkm_ctx_register_perm_kernel(zkm_ctx* ctx, const uint32_t* lookups, uint32_t
   API_BEGIN
   std::lock_guard<std::mutex> lk(ctx->mu);
   HIP_CHECK(hipSetDevice(ctx->device));
+  CallScope call_scope(ctx);
   if (lookups_len < 2 || !code_object_len) throw std::runtime_error("empty lookups blob or code object");
   std::vector<char> copy((const char*)code_object, (const char*)code_object + code_object_len);   // an aligned allocation of its own
   hipModule_t mod;
@@ -362,6 +413,7 @@ int zkm_matrix_upload_async(zkm_ctx* ctx, const uint32_t* host, size_t height, s
   API_BEGIN
   std::lock_guard<std::mutex> lk(ctx->mu);
   HIP_CHECK(hipSetDevice(ctx->device));
+  CallScope call_scope(ctx);
   *out = upload_async(ctx, host, height, width);
   API_END
 }
@@ -369,6 +421,7 @@ int zkm_matrix_wait(zkm_ctx* ctx, const zkm_matrix* m) {
   API_BEGIN
   std::lock_guard<std::mutex> lk(ctx->mu);
   HIP_CHECK(hipSetDevice(ctx->device));
+  CallScope call_scope(ctx);
   if (m->ready) HIP_CHECK(hipEventSynchronize(m->ready));
   API_END
 }
@@ -376,6 +429,7 @@ int zkm_matrix_upload(zkm_ctx* ctx, const uint32_t* host, size_t height, size_t 
   API_BEGIN
   std::lock_guard<std::mutex> lk(ctx->mu);
   HIP_CHECK(hipSetDevice(ctx->device));
+  CallScope call_scope(ctx);
   zkm_matrix* m = upload_async(ctx, host, height, width);
   HIP_CHECK(hipEventSynchronize(m->ready));  // the host buffer is free again when this returns
   *out = m;
@@ -396,6 +450,7 @@ int zkm_matrix_download(zkm_ctx* ctx, const zkm_matrix* m, uint32_t* host) {
   API_BEGIN
   std::lock_guard<std::mutex> lk(ctx->mu);
   HIP_CHECK(hipSetDevice(ctx->device));
+  CallScope call_scope(ctx);
   wait_ready(ctx->stream, *m);
   download_colmajor(ctx, m->d, m->h, m->w, host);
   API_END
@@ -403,7 +458,7 @@ int zkm_matrix_download(zkm_ctx* ctx, const zkm_matrix* m, uint32_t* host) {
 size_t zkm_matrix_height(const zkm_matrix* m) { return m->h; }
 size_t zkm_matrix_width(const zkm_matrix* m) { return m->w; }
 void zkm_matrix_free(zkm_ctx* ctx, zkm_matrix* m) {
-  if (!m) return;
+  if (!m || !HandleTable::get().is_live(m, H_MATRIX)) return;      // a second free of the same handle is ignored, not a double delete
   std::lock_guard<std::mutex> lk(ctx->mu);
   if (m->ready) {
     (void)hipEventSynchronize(m->ready);  // never hand a buffer back to the pool while its upload is in flight
@@ -421,6 +476,7 @@ int zkm_events_upload_async(zkm_ctx* ctx, const void* host, size_t bytes, void**
   API_BEGIN
   std::lock_guard<std::mutex> lk(ctx->mu);
   HIP_CHECK(hipSetDevice(ctx->device));
+  CallScope call_scope(ctx);
   if (bytes && !host) throw std::runtime_error("zkm_events_upload_async: null events");
   if (!ctx->ev_dma) HIP_CHECK(hipStreamCreateWithFlags(&ctx->ev_dma, hipStreamNonBlocking));
   void* d = ctx->alloc(std::max<size_t>(bytes, 4));
@@ -459,6 +515,7 @@ int zkm_pcs_commit(zkm_ctx* ctx, size_t n_mats, const zkm_matrix* const* mats, c
   API_BEGIN
   std::lock_guard<std::mutex> lk(ctx->mu);
   HIP_CHECK(hipSetDevice(ctx->device));
+  CallScope call_scope(ctx);
   if (n_mats == 0) throw std::runtime_error("zkm_pcs_commit: empty batch");
   std::vector<zkm_matrix> ms;
   std::vector<uint32_t> sh;
@@ -480,6 +537,7 @@ int zkm_pcs_data_get_lde(zkm_ctx* ctx, const zkm_pcs_data* d, size_t idx, uint32
   API_BEGIN
   std::lock_guard<std::mutex> lk(ctx->mu);
   HIP_CHECK(hipSetDevice(ctx->device));
+  CallScope call_scope(ctx);
   if (idx >= d->ldes.size()) throw std::runtime_error("matrix index out of range");
   download_colmajor(ctx, d->ldes[idx].d, d->ldes[idx].h, d->ldes[idx].w, host);
   API_END
@@ -488,6 +546,7 @@ int zkm_pcs_open_batch(zkm_ctx* ctx, const zkm_pcs_data* d, size_t index, uint32
   API_BEGIN
   std::lock_guard<std::mutex> lk(ctx->mu);
   HIP_CHECK(hipSetDevice(ctx->device));
+  CallScope call_scope(ctx);
   const Tree& t = d->tree;
   if (index >= t.max_height) throw std::runtime_error("open_batch index out of range");
   std::vector<const uint32_t*> src;
@@ -520,6 +579,9 @@ int zkm_pk_setup(zkm_ctx* ctx, size_t n_prep, const zkm_matrix* const* prep_trac
   API_BEGIN
   std::lock_guard<std::mutex> lk(ctx->mu);
   HIP_CHECK(hipSetDevice(ctx->device));
+  CallScope call_scope(ctx);
+  for (size_t i = 0; i < n_prep; i++) check_handle(prep_traces ? prep_traces[i] : nullptr, H_MATRIX, "zkm_pk_setup", "preprocessed trace");
+  if (!igcs || !out) throw std::runtime_error("zkm_pk_setup: null argument");
   ctx->begin_call();
   zkm_pk* pk = new zkm_pk();
   pk->pc_start = pc_start;
@@ -542,7 +604,7 @@ int zkm_pk_observe_into(const zkm_pk* pk, zkm_challenger* c) {
   return 0;
 }
 void zkm_pk_free(zkm_ctx* ctx, zkm_pk* pk) {
-  if (!pk) return;
+  if (!pk || !HandleTable::get().is_live(pk, H_PK)) return;
   std::lock_guard<std::mutex> lk(ctx->mu);
   free_pcs_data(ctx, pk->data);
   delete pk;
@@ -571,6 +633,9 @@ int zkm_commit(zkm_ctx* ctx, size_t n_chips, const char* const* names, const zkm
   API_BEGIN
   std::lock_guard<std::mutex> lk(ctx->mu);
   HIP_CHECK(hipSetDevice(ctx->device));
+  CallScope call_scope(ctx);
+  if (!names || !main_traces || !out || !main_commit_out) throw std::runtime_error("zkm_commit: null argument");
+  for (size_t i = 0; i < n_chips; i++) check_handle(main_traces[i], H_MATRIX, "zkm_commit", "main trace");
   ctx->begin_timing();
   zkm_main_data* md = commit_impl(ctx, n_chips, names, main_traces, public_values, n_pv, log_blowup);
   ctx->mark("commit main");
@@ -581,7 +646,7 @@ int zkm_commit(zkm_ctx* ctx, size_t n_chips, const char* const* names, const zkm
   API_END
 }
 void zkm_main_data_free(zkm_ctx* ctx, zkm_main_data* d) {
-  if (!d) return;
+  if (!d || !HandleTable::get().is_live(d, H_MAIN_DATA)) return;
   std::lock_guard<std::mutex> lk(ctx->mu);
   free_pcs_data(ctx, d->data);
   delete d;
@@ -592,6 +657,10 @@ int zkm_open(zkm_ctx* ctx, const zkm_pk* pk, zkm_main_data* data, const zkm_chip
   API_BEGIN
   std::lock_guard<std::mutex> lk(ctx->mu);
   HIP_CHECK(hipSetDevice(ctx->device));
+  CallScope call_scope(ctx);
+  check_handle(pk, H_PK, "zkm_open", "proving key");
+  check_handle(data, H_MAIN_DATA, "zkm_open", "main data");
+  if (!chips || !fri || !challenger || !proof_len) throw std::runtime_error("zkm_open: null argument");
   if (num_pv_elts > data->public_values.size()) throw std::runtime_error("num_pv_elts exceeds public_values length");
   Writer w(proof_out, proof_cap);
   ctx->begin_timing();
@@ -612,6 +681,10 @@ int zkm_prove_shard(zkm_ctx* ctx, const zkm_pk* pk, size_t n_chips, const zkm_ch
   API_BEGIN
   std::lock_guard<std::mutex> lk(ctx->mu);
   HIP_CHECK(hipSetDevice(ctx->device));
+  CallScope call_scope(ctx);
+  check_handle(pk, H_PK, "zkm_prove_shard", "proving key");
+  if (!chips || !main_traces || !fri || !challenger || !proof_len) throw std::runtime_error("zkm_prove_shard: null argument");
+  for (size_t i = 0; i < n_chips; i++) check_handle(main_traces[i], H_MATRIX, "zkm_prove_shard", "main trace");
   if (num_pv_elts > n_pv) throw std::runtime_error("num_pv_elts exceeds public_values length");
   std::vector<const char*> names;
   for (size_t i = 0; i < n_chips; i++) names.push_back(chips[i].name);
@@ -640,6 +713,7 @@ int zkm_poseidon2_permute_batch(zkm_ctx* ctx, uint32_t* states, size_t n) {
   API_BEGIN
   std::lock_guard<std::mutex> lk(ctx->mu);
   HIP_CHECK(hipSetDevice(ctx->device));
+  CallScope call_scope(ctx);
   if (n == 0) return 0;
   uint32_t* d = ctx->alloc_n<uint32_t>(n * 16);
   HIP_CHECK(hipMemcpyAsync(d, states, n * 64, hipMemcpyHostToDevice, ctx->stream));
@@ -655,6 +729,7 @@ int zkm_poseidon2_permute_batch_int(zkm_ctx* ctx, uint32_t* states, size_t n) {
   API_BEGIN
   std::lock_guard<std::mutex> lk(ctx->mu);
   HIP_CHECK(hipSetDevice(ctx->device));
+  CallScope call_scope(ctx);
   if (n == 0) return 0;
   uint32_t* d = ctx->alloc_n<uint32_t>(n * 16);
   HIP_CHECK(hipMemcpyAsync(d, states, n * 64, hipMemcpyHostToDevice, ctx->stream));
@@ -691,6 +766,7 @@ int zkm_permutation_trace(zkm_ctx* ctx, const zkm_chip_desc* chip, const zkm_mat
   if (!chip || !main || !challenges || !out || !local_sum) throw std::runtime_error("zkm_permutation_trace: null argument");
   std::lock_guard<std::mutex> lk(ctx->mu);
   HIP_CHECK(hipSetDevice(ctx->device));
+  CallScope call_scope(ctx);
   if (main->w != chip->main_width) throw std::runtime_error("zkm_permutation_trace: chip main_width does not match its trace");
   if (chip->prep_width && (!prep || prep->w != chip->prep_width || prep->h != main->h)) throw std::runtime_error("zkm_permutation_trace: the chip's preprocessed trace is missing or of another shape");
   const ChipMeta c = chip_meta(chip, main->h, (size_t)-1);

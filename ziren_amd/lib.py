@@ -12,7 +12,7 @@ _LIB = None
 
 # every symbol include/zkm_hip.h declares
 EXPORTS = [
-    "zkm_last_error", "zkm_build_info", "zkm_ctx_create", "zkm_ctx_destroy", "zkm_ctx_synchronize", "zkm_ctx_trim", "zkm_ctx_last_timings", "zkm_ctx_kernel_timings", "zkm_ctx_set_kernel_timing", "zkm_ctx_set_kernel_timing_only", "zkm_ctx_set_lde_overlap", "zkm_ctx_set_rows_up_front", "zkm_ctx_set_host_wait", "zkm_ctx_register_quotient_kernel", "zkm_ctx_register_perm_kernel",
+    "zkm_last_error", "zkm_build_info", "zkm_ctx_create", "zkm_ctx_destroy", "zkm_ctx_synchronize", "zkm_ctx_trim", "zkm_ctx_set_memory_limit", "zkm_ctx_memory_held", "zkm_ctx_last_timings", "zkm_ctx_kernel_timings", "zkm_ctx_set_kernel_timing", "zkm_ctx_set_kernel_timing_only", "zkm_ctx_set_lde_overlap", "zkm_ctx_set_rows_up_front", "zkm_ctx_set_host_wait", "zkm_ctx_register_quotient_kernel", "zkm_ctx_register_perm_kernel",
     "zkm_host_alloc", "zkm_host_free", "zkm_matrix_upload", "zkm_matrix_upload_async", "zkm_matrix_wait", "zkm_events_upload_async", "zkm_events_free", "zkm_matrix_download", "zkm_matrix_height", "zkm_matrix_width", "zkm_matrix_free",
     "zkm_pcs_commit", "zkm_pcs_data_free", "zkm_pcs_data_get_lde", "zkm_pcs_open_batch",
     "zkm_pk_setup", "zkm_pk_commitment", "zkm_pk_observe_into", "zkm_pk_free",
@@ -75,6 +75,9 @@ def load():
         L.zkm_build_info.restype = C.c_char_p
     L.zkm_host_alloc.restype = C.c_void_p
     L.zkm_matrix_height.restype = C.c_size_t
+    if hasattr(L, "zkm_ctx_memory_held"):
+        L.zkm_ctx_memory_held.restype = C.c_size_t
+        L.zkm_ctx_set_memory_limit.argtypes = [C.c_void_p, C.c_size_t]
     L.zkm_matrix_width.restype = C.c_size_t
     L.zkm_tracegen_alu_width.restype = C.c_size_t
     L.zkm_tracegen_jump_width.restype = C.c_size_t
