@@ -697,7 +697,11 @@ enum zkm_tracegen_kind {
   ZKM_TG_BRANCH = 2, ZKM_TG_JUMP = 3, ZKM_TG_MOV_COND = 4, ZKM_TG_MUL = 5, ZKM_TG_DIVREM = 6, ZKM_TG_MEMORY_INSTRS = 7, ZKM_TG_MISC_INSTRS = 8,
   ZKM_TG_SYSCALL_INSTRS = 9, ZKM_TG_SYSCALL_CORE = 10, ZKM_TG_SYSCALL_PRECOMPILE = 11, ZKM_TG_MEMORY_LOCAL = 12, ZKM_TG_GLOBAL = 13,
   ZKM_TG_BYTE_MULTS = 14,    /* no events */
-  ZKM_TG_PROGRAM_MULTS = 15  /* no events: needs a ZKM_TG_CPU descriptor in the same call */
+  ZKM_TG_PROGRAM_MULTS = 15, /* no events: needs a ZKM_TG_CPU descriptor in the same call */
+  /* the recursion machine's chips (crates/recursion/core/src/chips): a compress / shrink shard's traces in one call as well */
+  ZKM_TG_FLAT = 16,              /* zkm_tracegen_flat: events = the records' words, n_events = their number, `chip` = the trace width */
+  ZKM_TG_POSEIDON2_WIDE = 17,    /* zkm_tracegen_poseidon2_wide: n_events permutations of 32 words */
+  ZKM_TG_EXP_REVERSE_BITS = 18   /* events = one buffer [bases (n_events) | offsets (n_events + 1) | bits (n_instr)], n_instr = offsets[n_events] = the rows */
 };
 typedef struct zkm_tracegen_desc {
   uint32_t kind;             /* enum zkm_tracegen_kind */

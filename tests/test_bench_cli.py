@@ -49,7 +49,8 @@ def test_n1_and_n2_lines_are_one_experiment_with_the_same_keys():
         for key in ("roofline", "cpu_baseline", "resident_one_lane", "kernels_ms", "lde", "valu", "verified_proofs"):
             assert key in line
     assert a["config"]["backend"] == "none (one process)" and b["config"]["backend"] == "gloo"
-    assert a["verified_proofs"]["of"] == 6 and b["verified_proofs"]["checked_by_the_verifier"] == 2     # one proof per rank at N > 1
+    assert a["verified_proofs"]["of"] == 6 and a["verified_proofs"]["checked_by_the_verifier"] == 6        # N = 1: every gathered proof
+    assert b["verified_proofs"]["checked_by_the_verifier"] == 4                                            # N > 1: every lane's last proof on every rank
 
 
 def test_steps_means_exactly_that_many_shards_per_gpu():

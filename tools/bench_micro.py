@@ -32,9 +32,14 @@ def main():
     ap.add_argument("--width", type=int, default=64)
     ap.add_argument("--reps", type=int, default=5)
     args = ap.parse_args()
-    ctx = prover.Context(0)
+    print(json.dumps(micro_bench(prover.Context(0), args.log_rows, args.width, args.reps), indent=1))
+
+
+def micro_bench(ctx, log_rows=(20, 21, 22), width=64, reps=5, config2=True):
+    """{"micro": [per 2^k x width matrix: LDE and Merkle separately], "config2": SYN-20 commit only} on `ctx` (bench.py carries it as `micro`)."""
     from ziren_amd import lib
     import ctypes as C
+    args = argparse.Namespace(log_rows=list(log_rows), width=width, reps=reps)
     lib.load().zkm_ctx_set_kernel_timing(ctx.h, C.c_int(1))
     out = []
     rng = F.SplitMix64(0xC0FFEE)
@@ -48,7 +53,7 @@ def main():
             d = prover.pcs_commit(ctx, [dm], 1)
             wall.append((time.perf_counter() - t0) * 1e3)
             lde_ms.append(kernel_ms(ctx, ["lde_rows", "lde_cols_inverse", "lde_cols_forward"]))
-            tree_ms.append(kernel_ms(ctx, ["hash_leaves", "hash_leaves_tree", "compress_layer", "compress_small", "compress_tail"]))
+            tree_ms.append(kernel_ms(ctx, ["hash_leaves", "hash_leaves_tree", "hash_rows", "compress_layer", "compress_layer_rowdig", "compress_small", "compress_tail"]))
             d.free()
         lde, tree = float(np.median(lde_ms[1:])), float(np.median(tree_ms[1:]))
         lde_bytes, tree_bytes = 12.0 * n * w, 8.0 * n * w + 128.0 * n
@@ -62,6 +67,9 @@ def main():
         out.append(rec)
         dm.free()
         ctx.trim()
+    if not config2:
+        lib.load().zkm_ctx_set_kernel_timing(ctx.h, C.c_int(2))
+        return {"micro": out}
     # BASELINE config 2: SYN-20 main traces, commit only
     sh = synth.syn_shard(20)
     hp = prover.HipProver(sh.chips, __import__("ziren_amd.abi", fromlist=["abi"]).FriConfig(1, 84, 16), synth.NUM_PV_ELTS, ctx=ctx)
@@ -78,7 +86,13 @@ def main():
             "commit_ms": round(float(np.median(walls[1:])), 3), "cells": cells,
             "algorithmic_bytes": int(20 * cells + 128 * rows),
             "GBps": round((20 * cells + 128 * rows) / float(np.median(walls[1:])) / 1e6, 1)}
-    print(json.dumps({"micro": out, "config2": cfg2}, indent=1))
+    for t in traces:
+        t.free()
+    ctx.trim()
+    lib.load().zkm_ctx_set_kernel_timing(ctx.h, C.c_int(2))
+    return {"micro": out, "config2": cfg2,
+            "note": "one matrix resident in HBM, blow-up 2, medians of per-kernel HIP-event time (LDE = the three LDE kernels, Merkle = leaves + every tree level); "
+                    "algorithmic bytes LDE 12 n w, Merkle 8 n w + 128 n (SURVEY 8d)"}
 
 
 if __name__ == "__main__":

@@ -57,6 +57,18 @@ def shard_leg(lane, prog, shape_idx, fri, steps, O=None):
     for _ in range(steps):
         lane.prove(pid, prog, shape_idx, fri, inputs)
     ctx.synchronize()
+    serial_ms = (time.perf_counter() - t0) / steps * 1e3
+    # pipelined, as the tree's lanes run: the next node's events are queued on the DMA stream right before the current node's proof
+    h = lane.prefetch(prog, inputs)
+    lane.prove(pid, prog, shape_idx, fri, inputs, handle=h)
+    h = lane.prefetch(prog, inputs)
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        nxt = lane.prefetch(prog, inputs) if i + 1 < steps else None
+        lane.prove(pid, prog, shape_idx, fri, inputs, handle=h)
+        h = nxt
+    ctx.synchronize()
     ms = (time.perf_counter() - t0) / steps * 1e3
     # the same with the traces resident: what the proof alone takes
     hp, recs, pk, ch0 = lane.key_for(pid, prog, shape_idx, fri)
@@ -96,7 +108,7 @@ def shard_leg(lane, prog, shape_idx, fri, steps, O=None):
     dom = max(table.items(), key=lambda kv: kv[1][0])
     out = {"shape": {c: prog.shape[c] for c in RD.CHIP_ORDER}, "fri": {"log_blowup": fri[0], "queries": fri[1], "pow_bits": fri[2]},
            "fill": prog.fill(), "committed_cells": cells, "proof_words": int(len(proof)), "event_bytes": event_bytes,
-           "ms_per_shard_from_events": round(ms, 3), "ms_per_shard_traces_resident": round(resident_ms, 3),
+           "ms_per_shard_from_events": round(ms, 3), "ms_per_shard_from_events_unpipelined": round(serial_ms, 3), "ms_per_shard_traces_resident": round(resident_ms, 3),
            "setup_ms_once_per_program": round(lane.setup_ms[(pid, tuple(fri))], 3),
            "phases_ms": {k: round(v, 3) for k, v in phases.items()},
            "kernels_ms": {k: {"ms": round(v[0] / n, 3), "launches": v[1] // n, "GBps": round(v[2] / max(v[0], 1e-9) / 1e6, 1)} for k, v in sorted(table.items(), key=lambda kv: -kv[1][0])},
@@ -135,7 +147,14 @@ def two_lane_leg(lanes, prog, shape_idx, fri, steps):
             l.ctx.synchronize()
         return (time.perf_counter() - t0) / (steps * len(lanes)) * 1e3
 
-    res["from_events_ms_per_shard"] = round(timed(lambda l: [l.prove(pid, prog, shape_idx, fri, inputs) for _ in range(steps)]), 3)
+    def from_events(l):
+        h = l.prefetch(prog, inputs)
+        for i in range(steps):
+            nxt = l.prefetch(prog, inputs) if i + 1 < steps else None
+            l.prove(pid, prog, shape_idx, fri, inputs, handle=h)
+            h = nxt
+
+    res["from_events_ms_per_shard"] = round(timed(from_events), 3)
     state = {}
     for l in lanes:
         hp, recs, pk, ch0 = l.key_for(pid, prog, shape_idx, fri)

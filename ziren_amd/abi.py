@@ -36,7 +36,7 @@ class ChipDesc(C.Structure):
 
 # enum zkm_tracegen_kind
 (TG_ALU, TG_CPU, TG_BRANCH, TG_JUMP, TG_MOV_COND, TG_MUL, TG_DIVREM, TG_MEMORY_INSTRS, TG_MISC_INSTRS, TG_SYSCALL_INSTRS, TG_SYSCALL_CORE,
- TG_SYSCALL_PRECOMPILE, TG_MEMORY_LOCAL, TG_GLOBAL, TG_BYTE_MULTS, TG_PROGRAM_MULTS) = range(16)
+ TG_SYSCALL_PRECOMPILE, TG_MEMORY_LOCAL, TG_GLOBAL, TG_BYTE_MULTS, TG_PROGRAM_MULTS, TG_FLAT, TG_POSEIDON2_WIDE, TG_EXP_REVERSE_BITS) = range(19)
 
 
 class TracegenDesc(C.Structure):

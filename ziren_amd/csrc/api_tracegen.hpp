@@ -98,6 +98,9 @@ static zkm_matrix* enqueue_rows(TraceBatch& b, int chip, const void* events, siz
   const size_t height = height_given ? height_given : padded_trace_rows(n_events, fixed_log2_rows, "zkm_tracegen_alu");
   const size_t w = (size_t)tracegen::chip_width(chip);
   zkm_matrix* m = b.matrix(height, w);
+  // no events: every row is padding_row<CHIP> (tracegen::alu_rows_body), the same on every row — the shape step adds such chips to every
+  // shard (eight of the benchmarked shard's eighteen); the commitment's LDE then skips the pass that would find that out by reading them
+  m->uniform_rows = n_events == 0 && !n_dev && !dev_events_given;
   const size_t event_bytes = 4 * (size_t)tracegen::event_words(chip);
   const uint32_t* dev_events = dev_events_given ? dev_events_given : b.events(events, n_events * event_bytes);
   uint32_t* counts = blu ? blu->counts : nullptr;
@@ -165,11 +168,10 @@ int zkm_tracegen_jump(zkm_ctx* ctx, const zkm_jump_event* events, size_t n_event
   return tracegen_events(ctx, tracegen::JUMP, events, n_events, fixed_log2_rows, nullptr, out);
 }
 
-int zkm_tracegen_flat(zkm_ctx* ctx, const uint32_t* words, size_t n_words, size_t width, int fixed_log2_rows, zkm_matrix** out) {
-  API_BEGIN
-  std::lock_guard<std::mutex> lk(ctx->mu);
-  HIP_CHECK(hipSetDevice(ctx->device));
-  CallScope call_scope(ctx);
+// A recursion chip whose trace is its records end to end (zkm_tracegen_flat): the words — a host pointer, or an address
+// zkm_events_upload_async returned — transposed into the padded column-major matrix, zero rows behind them.
+static zkm_matrix* enqueue_flat(TraceBatch& b, const uint32_t* words, size_t n_words, size_t width, int fixed_log2_rows) {
+  zkm_ctx* ctx = b.ctx;
   if (width == 0) throw std::runtime_error("zkm_tracegen_flat: zero width");
   if (n_words && !words) throw std::runtime_error("zkm_tracegen_flat: null records");
   const size_t rows = (n_words + width - 1) / width;
@@ -181,28 +183,16 @@ int zkm_tracegen_flat(zkm_ctx* ctx, const uint32_t* words, size_t n_words, size_
   } else {
     while (height < rows) height <<= 1;
   }
-  ctx->begin_call();
-  zkm_matrix* m = new zkm_matrix();
-  m->h = height; m->w = width;
-  uint32_t* stage = nullptr;
-  try {
-    m->d = ctx->alloc_n<uint32_t>(height * width);
-    stage = ctx->alloc_n<uint32_t>(height * width);
-    HIP_CHECK(hipMemsetAsync(stage, 0, height * width * 4, ctx->stream));
-    if (n_words) HIP_CHECK(hipMemcpyAsync(stage, words, n_words * 4, hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(open::transpose_slab, dim3(div_up(width, 32), div_up(height, 32)), dim3(32, 8), 0, ctx->stream,
-                       (const uint32_t*)stage, m->d, height, width, (size_t)0, height);
-    LAUNCH_CHECK();
-    ctx->sync(ctx->stream);
-  } catch (...) {
-    if (stage) ctx->release(stage);
-    if (m->d) ctx->release(m->d);
-    delete m;
-    throw;
-  }
-  ctx->release(stage);
-  *out = m;
-  API_END
+  zkm_matrix* m = b.matrix(height, width);
+  m->uniform_rows = n_words == 0;
+  const uint32_t* dev = n_words ? b.events(words, n_words * 4) : nullptr;
+  ctx->flush_staged();
+  hipLaunchKernelGGL(open::flat_rows, dim3(div_up(width, 32), div_up(height, 32)), dim3(32, 8), 0, ctx->stream, dev, n_words, m->d, width, height);
+  LAUNCH_CHECK();
+  return m;
+}
+int zkm_tracegen_flat(zkm_ctx* ctx, const uint32_t* words, size_t n_words, size_t width, int fixed_log2_rows, zkm_matrix** out) {
+  return tracegen_single(ctx, out, [&](TraceBatch& b) { return enqueue_flat(b, words, n_words, width, fixed_log2_rows); });
 }
 
 size_t zkm_tracegen_branch_width(void) { return (size_t)tracegen::chip_width(tracegen::BRANCH); }
@@ -411,34 +401,18 @@ int zkm_tracegen_global(zkm_ctx* ctx, const zkm_global_lookup_event* events, siz
   return tracegen_single(ctx, out, [&](TraceBatch& b) { return enqueue_global(b, events, n_events, fixed_log2_rows, blu); });
 }
 
-int zkm_tracegen_poseidon2_wide(zkm_ctx* ctx, const uint32_t* events, size_t n_events, int fixed_log2_rows, zkm_matrix** out) {
-  API_BEGIN
-  std::lock_guard<std::mutex> lk(ctx->mu);
-  HIP_CHECK(hipSetDevice(ctx->device));
-  CallScope call_scope(ctx);
+static zkm_matrix* enqueue_poseidon2_wide(TraceBatch& b, const uint32_t* events, size_t n_events, int fixed_log2_rows) {
+  zkm_ctx* ctx = b.ctx;
   if (n_events && !events) throw std::runtime_error("zkm_tracegen_poseidon2_wide: null events");
   const size_t height = padded_trace_rows(n_events, fixed_log2_rows, "zkm_tracegen_poseidon2_wide");
-  ctx->begin_timing();
-  zkm_matrix* m = new zkm_matrix();
-  m->h = height; m->w = tracegen::POSEIDON2_WIDE_WIDTH;
-  uint32_t* d_events = nullptr;
-  try {
-    m->d = ctx->alloc_n<uint32_t>(height * m->w);
-    d_events = (uint32_t*)ctx->alloc(std::max<size_t>(n_events * 128, 4));
-    if (n_events) HIP_CHECK(hipMemcpyAsync(d_events, events, n_events * 128, hipMemcpyHostToDevice, ctx->stream));
-    KLAUNCH(ctx, "tracegen_poseidon2_wide", 128.0 * n_events + 4.0 * height * tracegen::POSEIDON2_WIDE_WIDTH, tracegen::poseidon2_wide_rows,
-            dim3(div_up(height, (size_t)tracegen::THREADS)), dim3(tracegen::THREADS), 0, (const uint32_t*)d_events, n_events, height, m->d);
-    ctx->mark("trace generation");
-    ctx->end_timing(false);
-  } catch (...) {
-    if (d_events) ctx->release(d_events);
-    if (m->d) ctx->release(m->d);
-    delete m;
-    throw;
-  }
-  ctx->release(d_events);
-  *out = m;
-  API_END
+  zkm_matrix* m = b.matrix(height, tracegen::POSEIDON2_WIDE_WIDTH);
+  const uint32_t* d_events = n_events ? b.events(events, n_events * 128) : (const uint32_t*)b.temp(4);
+  KLAUNCH(ctx, "tracegen_poseidon2_wide", 128.0 * n_events + 4.0 * height * tracegen::POSEIDON2_WIDE_WIDTH, tracegen::poseidon2_wide_rows,
+          dim3(div_up(height, (size_t)tracegen::THREADS)), dim3(tracegen::THREADS), 0, d_events, n_events, height, m->d);
+  return m;
+}
+int zkm_tracegen_poseidon2_wide(zkm_ctx* ctx, const uint32_t* events, size_t n_events, int fixed_log2_rows, zkm_matrix** out) {
+  return tracegen_single(ctx, out, [&](TraceBatch& b) { return enqueue_poseidon2_wide(b, events, n_events, fixed_log2_rows); });
 }
 
 // SyscallCore keeps the events whose code has the send-to-table byte set or names a Linux syscall (syscall/chip.rs:252-259): host events are
@@ -1267,7 +1241,7 @@ int zkm_tracegen_exp_reverse_bits(zkm_ctx* ctx, const uint32_t* bases, const uin
       if (rows) HIP_CHECK(hipMemcpyAsync(d_bits, bits, rows * 4, hipMemcpyHostToDevice, ctx->stream));
       HIP_CHECK(hipMemcpyAsync(d_off, offsets, (n_events + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
       hipLaunchKernelGGL(tracegen::exp_reverse_bits_rows, dim3(div_up(n_events, (size_t)256)), dim3(256), 0, ctx->stream, (const uint32_t*)d_bases,
-                         (const uint32_t*)d_bits, (const uint32_t*)d_off, n_events, height, m->d);
+                         (const uint32_t*)d_bits, (const uint32_t*)d_off, n_events, rows, height, m->d);
       LAUNCH_CHECK();
     }
     ctx->sync(ctx->stream);
@@ -1282,6 +1256,26 @@ int zkm_tracegen_exp_reverse_bits(zkm_ctx* ctx, const uint32_t* bases, const uin
   ctx->release(d_off);
   *out = m;
   API_END
+}
+
+// ExpReverseBitsLen inside a batch (ZKM_TG_EXP_REVERSE_BITS): one buffer [bases (n) | offsets (n + 1) | bits (rows)] — a host pointer or
+// a prefetched address; `rows` = offsets[n], given by the caller (the offsets may already be in HBM). The kernel bounds every row it
+// writes by the height, so offsets that disagree with `rows` cannot write outside the matrix.
+static zkm_matrix* enqueue_exp_reverse_bits(TraceBatch& b, const uint32_t* packed, size_t n_events, size_t rows, int fixed_log2_rows) {
+  zkm_ctx* ctx = b.ctx;
+  if (n_events && !packed) throw std::runtime_error("zkm_tracegen_exp_reverse_bits: null events");
+  const size_t height = padded_trace_rows(rows, fixed_log2_rows, "zkm_tracegen_exp_reverse_bits");
+  zkm_matrix* m = b.matrix(height, tracegen::EXP_REVERSE_BITS_WIDTH);
+  HIP_CHECK(hipMemsetAsync(m->d, 0, height * m->w * 4, ctx->stream));
+  m->uniform_rows = n_events == 0;
+  if (n_events) {
+    const uint32_t* d = b.events(packed, (2 * n_events + 1 + rows) * 4);
+    ctx->flush_staged();
+    hipLaunchKernelGGL(tracegen::exp_reverse_bits_rows, dim3(div_up(n_events, (size_t)256)), dim3(256), 0, ctx->stream, d, d + 2 * n_events + 1,
+                       d + n_events, n_events, rows, height, m->d);
+    LAUNCH_CHECK();
+  }
+  return m;
 }
 
 int zkm_tracegen_poseidon2_skinny(zkm_ctx* ctx, const uint32_t* events, size_t n_events, int fixed_log2_rows, zkm_matrix** out) {
@@ -1436,6 +1430,12 @@ int zkm_tracegen_shard(zkm_ctx* ctx, const zkm_tracegen_desc* descs, size_t n, z
           out[i] = enqueue_cpu(b, (const zkm_cpu_event*)d.events, d.n_events, d.program, d.n_instr, d.pc_base, d.shard, d.fixed_log2_rows,
                                pm_at >= 0 ? descs[pm_at].fixed_log2_rows : -1, use, pm_at >= 0 ? &out[pm_at] : nullptr);
           break;
+        case ZKM_TG_FLAT:
+          if (d.chip <= 0) throw std::runtime_error("zkm_tracegen_shard: a flat descriptor carries the trace width in `chip`");
+          out[i] = enqueue_flat(b, (const uint32_t*)d.events, d.n_events, (size_t)d.chip, d.fixed_log2_rows);
+          break;
+        case ZKM_TG_POSEIDON2_WIDE: out[i] = enqueue_poseidon2_wide(b, (const uint32_t*)d.events, d.n_events, d.fixed_log2_rows); break;
+        case ZKM_TG_EXP_REVERSE_BITS: out[i] = enqueue_exp_reverse_bits(b, (const uint32_t*)d.events, d.n_events, d.n_instr, d.fixed_log2_rows); break;
         case ZKM_TG_PROGRAM_MULTS: case ZKM_TG_BYTE_MULTS: break;
         default: throw std::runtime_error("zkm_tracegen_shard: unknown descriptor kind");
       }

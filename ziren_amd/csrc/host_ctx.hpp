@@ -529,6 +529,7 @@ struct zkm_matrix : Handle<H_MATRIX> {
   uint32_t* d = nullptr;  // column-major: column c at d + c * h
   size_t h = 0, w = 0;
   bool owned = true;
+  bool uniform_rows = false;   // set by a trace generator that had no events: every row is the chip's padding row (lde::Mat::uniform)
   hipEvent_t ready = nullptr;  // set by zkm_matrix_upload_async: fires when the matrix is complete in HBM
 };
 

@@ -6,6 +6,8 @@ struct LdeJob {
   const uint32_t* in; size_t n, w; uint32_t lde_shift; uint32_t* out;
   uint32_t* cflag = nullptr;   // optional: 2 w words, zeroed by the caller, that keep the constant-column flags (lde::Mat::cflag) after the batch — written
                                // only for four-step matrices (n > 2^LOG_ROW_MAX); without it the batch uses scratch of its own
+  bool uniform = false;        // zkm_matrix::uniform_rows: the trace generator made every row the same (a chip without events): the strided inverse pass
+                               // does not read the matrix to find that out
 };
 
 static void lde_batch_chunk(zkm_ctx* ctx, const std::vector<LdeJob>& jobs, int bl) {
@@ -57,7 +59,7 @@ static void lde_batch_chunk(zkm_ctx* ctx, const std::vector<LdeJob>& jobs, int b
     for (; p < order.size() && jobs[order[p]].n == n; p++) {
       const LdeJob& j = jobs[order[p]];
       lde::Mat& m = b.m[nm++];
-      m.in = j.in; m.out = j.out; m.col0 = cols; m.w = (uint32_t)j.w; m.shift = j.lde_shift;
+      m.in = j.in; m.out = j.out; m.col0 = cols; m.w = (uint32_t)j.w; m.shift = j.lde_shift; m.uniform = j.uniform ? 1u : 0u;
       if (la) {
         m.tmp1 = tmp1 + t1; t1 += n * j.w;
         m.tmp2 = tmp2 + t2; t2 += (n * j.w) << bl;
@@ -78,6 +80,7 @@ static void lde_batch_chunk(zkm_ctx* ctx, const std::vector<LdeJob>& jobs, int b
       blk[lde::K_COLS_FWD] += (uint32_t)(per_col * cols * cosets);
       lds_cols = std::max(lds_cols, ((size_t)1 << la) * (((size_t)1 << g.logT) + 1) * 4);
       bytes_inv += 8.0 * cells; bytes_rows += 4.0 * cells * (1 + cosets); bytes_fwd += 8.0 * cells * cosets;
+      for (int mi = (int)g.first_mat; mi < nm; mi++) if (b.m[mi].uniform) bytes_inv -= 8.0 * (double)n * b.m[mi].w;
     } else {
       blk[lde::K_ROWS_SMALL] += cols;
       const size_t B = (size_t)1 << lb;
@@ -399,7 +402,7 @@ static zkm_pcs_data* pcs_commit(zkm_ctx* ctx, const std::vector<zkm_matrix>& mat
       for (size_t i = 0; i < mats.size(); i++)
         if (mats[i].h > ((size_t)1 << lde::LOG_ROW_MAX)) { col_flags[i] = cflags + off; off += 2 * mats[i].w; }
     }
-    auto job_of = [&](size_t i) { return LdeJob{mats[i].d, mats[i].h, mats[i].w, shift_of(i), d->ldes[i].d, const_cast<uint32_t*>(col_flags[i])}; };
+    auto job_of = [&](size_t i) { return LdeJob{mats[i].d, mats[i].h, mats[i].w, shift_of(i), d->ldes[i].d, const_cast<uint32_t*>(col_flags[i]), mats[i].uniform_rows}; };
     std::vector<char> extended(mats.size(), 0);
     size_t top = 0;
     for (auto& l : d->ldes) top = std::max(top, l.h);

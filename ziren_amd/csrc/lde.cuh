@@ -233,7 +233,9 @@ struct Mat {
                         //         (cosets x B words, see fill_scaled_stage_twiddles); la == 0: unused
   const uint32_t* cs;   // la > 0: cs[j A + k1] = shift_j^k1 / n
   uint32_t col0, w;     // first column inside the group, width
-  uint32_t shift, pad;  // shift of coset 0 (shift_j = shift w_N^j)
+  uint32_t shift;       // shift of coset 0 (shift_j = shift w_N^j)
+  uint32_t uniform;     // != 0: the producer says every row of `in` is the same (a trace generator without events, zkm_matrix::uniform_rows):
+                        //       every column is constant and lde_cols<false> only records its first word
   uint32_t* cflag;      // la > 0: per column two words, zeroed before the batch: [2c] != 0 once some tile of column c was seen to hold two
                         //         different values (lde_cols<false>), [2c + 1] = the column's first word. A column whose words are all equal
                         //         is the constant polynomial: its LDE is that word on every row of every coset, so the two later passes do
@@ -298,6 +300,11 @@ __global__ __launch_bounds__(THREADS) void lde_cols(const Batch* __restrict__ d)
   // 16-byte global accesses (T >= 8), four in flight per thread
   const int logTq = logT - 2;
   const int quads = (A << logT) >> 2;
+  if (!FORWARD && m.uniform) {
+    // nothing to find out: the column's word for the two later passes, the "differs" word stays zero
+    if (xb == 0 && threadIdx.x == 0) gp::store(m.cflag + 2 * c + 1, gp::load(m.in + c * n));
+    return;
+  }
   if (FORWARD && gp::load(m.cflag + 2 * c) == 0) {
     // a constant column (see Mat::cflag): every word of this block's output tile is the column's word
     const uint32_t v0 = gp::load(m.cflag + 2 * c + 1);

@@ -432,4 +432,27 @@ __global__ void transpose_slab(const uint32_t* __restrict__ in, uint32_t* __rest
   }
 }
 
+// zkm_tracegen_flat's rows: `in` holds n_words words, records end to end (row-major, `cols` per row); rows behind them are zero. The
+// same tile transpose as transpose_slab, reading past the records as zero: no staging buffer, no memset, and the source may be an
+// address zkm_events_upload_async returned. Host words are reduced to canonical form on the way in, as in transpose_slab.
+__global__ void flat_rows(const uint32_t* __restrict__ in, size_t n_words, uint32_t* __restrict__ out, size_t cols, size_t height) {
+  __shared__ uint32_t tile[32][33];
+  size_t bx = (size_t)blockIdx.x * 32, by = (size_t)blockIdx.y * 32;
+  for (int j = threadIdx.y; j < 32; j += blockDim.y) {
+    size_t r = by + j, c = bx + threadIdx.x;
+    uint32_t w = 0;
+    if (r < height && c < cols && r * cols + c < n_words) {
+      w = in[r * cols + c];
+      w = w >= kb::P ? w - kb::P : w;
+      w = w >= kb::P ? w - kb::P : w;
+    }
+    tile[j][threadIdx.x] = w;
+  }
+  __syncthreads();
+  for (int j = threadIdx.y; j < 32; j += blockDim.y) {
+    size_t c = bx + j, r = by + threadIdx.x;
+    if (r < height && c < cols) out[c * height + r] = tile[threadIdx.x][j];
+  }
+}
+
 }  // namespace open

@@ -2747,12 +2747,15 @@ __global__ __launch_bounds__(bf_threads(NL)) void fp_tower_rows(const uint32_t* 
 // multiplier); Montgomery words in and out. offsets[e] .. offsets[e + 1] are event e's rows; the rest of the matrix is zeroed first.
 constexpr int EXP_REVERSE_BITS_WIDTH = 7;
 __global__ void exp_reverse_bits_rows(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ bits, const uint32_t* __restrict__ offsets,
-                                      size_t n_events, size_t height, uint32_t* __restrict__ out) {
+                                      size_t n_events, size_t rows, size_t height, uint32_t* __restrict__ out) {
   const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= n_events) return;
   const uint32_t x = bases[e];
   uint32_t accum = kb::ONE;
-  for (uint32_t i = offsets[e]; i < offsets[e + 1]; i++) {
+  // `rows` bits were handed over and the matrix has `height` rows: offsets that say otherwise (they may come straight from HBM, unread by
+  // the host) neither read nor write outside
+  const size_t end = offsets[e + 1] < rows ? offsets[e + 1] : rows;
+  for (size_t i = offsets[e]; i < end && i < height; i++) {
     const uint32_t bit = bits[i], prev_sq = kb::mul(accum, accum), mult = bit == kb::ONE ? x : kb::ONE;
     accum = kb::mul(prev_sq, mult);
     const uint32_t r[EXP_REVERSE_BITS_WIDTH] = {x, bit, prev_sq, accum, accum, kb::mul(accum, accum), mult};

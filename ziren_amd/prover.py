@@ -508,6 +508,22 @@ class Context:
                 p_ev, n_ev, k = _evptr(events, dtypes[kind])
                 keep.append(k)
                 d.events, d.n_events = p_ev.value, n_ev
+            if kind in (abi.TG_FLAT, abi.TG_POSEIDON2_WIDE, abi.TG_EXP_REVERSE_BITS):
+                # the recursion machine's chips: plain words. TG_FLAT: extra = {"width"}; TG_POSEIDON2_WIDE: 32 words per permutation;
+                # TG_EXP_REVERSE_BITS: one buffer [bases | offsets | bits], extra = {"n": instructions, "rows": offsets[n]}
+                if isinstance(events, DeviceEvents):
+                    p_ev, n_words, k = C.c_void_p(events.ptr), len(events.host), events
+                else:
+                    k = np.ascontiguousarray(events if events is not None else np.zeros(0, dtype=np.uint32), dtype=np.uint32).reshape(-1)
+                    p_ev, n_words = C.c_void_p(k.ctypes.data if len(k) else None), len(k)
+                keep.append(k)
+                d.events = p_ev.value
+                if kind == abi.TG_FLAT:
+                    d.n_events, d.chip = n_words, extra["width"]
+                elif kind == abi.TG_POSEIDON2_WIDE:
+                    d.n_events = n_words // 32
+                else:
+                    d.n_events, d.n_instr = extra["n"], extra["rows"]
             if kind == abi.TG_ALU:
                 d.chip = extra["chip"]
             if kind == abi.TG_CPU:

@@ -444,18 +444,30 @@ class ReduceLane:
             self.provers[key] = (hp, recs)
         return self.provers[key]
 
+    PATCHED = ("var_values", "poseidon2_events", "pv_main")
+
     def _pinned(self, prog: StandinProgram):
-        """This lane's own copy of the program's main-event streams, in page-locked memory (once per program and lane): H2D at the link's
-        rate instead of a pageable copy's, and a node's witness is written into it without touching another lane's."""
+        """This lane's own page-locked copies of the program's main-event streams (once per program and lane): H2D at the link's rate
+        instead of a pageable copy's. The streams a node's witness is written into have TWO copies, used alternately: node i + 1's words
+        are written (and its copy queued) while node i's copy may still be in flight."""
         pins = self._pins.setdefault(id(prog), {})
         if not pins:
+            alloc = (lambda n: self.ctx.host_alloc((n,))) if self.pin else (lambda n: np.empty(n, dtype=np.uint32))
             for name, spec in zip(CHIP_ORDER, chip_specs()):
                 ek = spec[1]
-                if ek is None or name == "ExpReverseBitsLen":
+                if ek is None:
                     continue
-                src = prog.streams[ek]
-                pins[ek] = self.ctx.host_alloc((len(src),)) if self.pin else np.empty(len(src), dtype=np.uint32)
-                pins[ek][:] = src
+                if name == "ExpReverseBitsLen":       # one buffer [bases | offsets | bits] (ZKM_TG_EXP_REVERSE_BITS)
+                    src = np.concatenate([prog.streams["exp_bases"], prog.streams["exp_offsets"], prog.streams["exp_bits"]]).astype(np.uint32)
+                else:
+                    src = prog.streams[ek]
+                copies = []
+                for _ in range(2 if ek in self.PATCHED else 1):
+                    buf = alloc(len(src))
+                    buf[:] = src
+                    copies.append(buf)
+                pins[ek] = copies
+            pins["_turn"] = 0
         return pins
 
     def key_for(self, prog_id, prog: StandinProgram, shape_idx: int, fri):
@@ -465,7 +477,7 @@ class ReduceLane:
         if k not in self.keys:
             hp, recs = self.prover_for(shape_idx, prog.shape, fri)
             t0 = time.perf_counter()
-            preps = [self.ctx.tracegen_flat(prog.streams[spec[0]], spec[2], r.log_height) for spec, r in zip(chip_specs(), recs)]
+            preps = self.ctx.tracegen_shard([(abi.TG_FLAT, prog.streams[spec[0]], r.log_height, {"width": spec[2]}) for spec, r in zip(chip_specs(), recs)])
             pk = hp.setup(preps, [int(r.local_only) for r in recs], F.to_monty(0), F.to_monty(np.zeros(14, dtype=np.uint64)))
             self.ctx.synchronize()
             self.setup_ms[k] = 1e3 * (time.perf_counter() - t0)
@@ -474,31 +486,55 @@ class ReduceLane:
             self.keys[k] = (hp, recs, pk, ch0)
         return self.keys[k]
 
-    def traces(self, prog: StandinProgram, recs, witness=None):
-        """The nine main traces born on the device from the program's event streams (`witness`: a node's input-dependent words)."""
-        ev = self._pinned(prog)
-        if witness is not None:
-            for k in ("var_values", "poseidon2_events", "pv_main"):
-                ev[k][:len(witness[k])] = witness[k]
-        born = []
+    def prefetch(self, prog: StandinProgram, inputs):
+        """A node's events on their way to HBM (zkm_events_upload_async on the context's DMA stream: under whatever this lane is proving):
+        the witness is written into this turn's page-locked copies, every stream's copy queued. Returns the handle `prove` takes."""
+        w = prog.witness(inputs)
+        pins = self._pinned(prog)
+        turn = pins["_turn"]
+        pins["_turn"] = turn ^ 1
+        dev = {}
+        for ek, copies in pins.items():
+            if ek == "_turn":
+                continue
+            buf = copies[turn % len(copies)]
+            if ek in self.PATCHED:
+                buf[:len(w[ek])] = w[ek]
+            dev[ek] = self.ctx.events_upload_async(buf)
+        return (w, dev)
+
+    def traces(self, prog: StandinProgram, recs, witness=None, handle=None):
+        """The nine main traces born on the device from the program's event streams — one zkm_tracegen_shard call: every generator queued
+        behind the copy of its events (already in HBM with `handle`, else copied now from the page-locked streams), one synchronisation."""
+        if handle is None:
+            pins = self._pinned(prog)
+            ev = {ek: copies[0] for ek, copies in pins.items() if ek != "_turn"}
+            if witness is not None:
+                for k in self.PATCHED:
+                    ev[k][:len(witness[k])] = witness[k]
+        else:
+            ev = handle[1]
+        n_exp = len(prog.streams["exp_bases"])
+        items = []
         for name, spec, r in zip(CHIP_ORDER, chip_specs(), recs):
             ek, mw = spec[1], spec[3]
             if name == "Poseidon2WideDeg3":
-                born.append(self.ctx.tracegen_poseidon2_wide(ev[ek], r.log_height))
+                items.append((abi.TG_POSEIDON2_WIDE, ev[ek], r.log_height, None))
             elif name == "ExpReverseBitsLen":
-                born.append(self.ctx.tracegen_exp_reverse_bits(prog.streams["exp_bases"], prog.streams["exp_bits"], prog.streams["exp_offsets"], r.log_height))
+                items.append((abi.TG_EXP_REVERSE_BITS, ev[ek], r.log_height, {"n": n_exp, "rows": int(prog.streams["exp_offsets"][-1]) if n_exp else 0}))
             elif ek is None:
-                born.append(self.ctx.tracegen_flat(np.zeros(0, dtype=np.uint32), mw, r.log_height))
+                items.append((abi.TG_FLAT, None, r.log_height, {"width": mw}))
             else:
-                born.append(self.ctx.tracegen_flat(ev[ek], mw, r.log_height))
-        return born
+                items.append((abi.TG_FLAT, ev[ek], r.log_height, {"width": mw}))
+        return self.ctx.tracegen_shard(items)
 
-    def prove(self, prog_id, prog: StandinProgram, shape_idx: int, fri, inputs, salt: int = 0) -> np.ndarray:
-        """One recursion shard: witness `inputs`, events -> device traces -> commit + open. `salt` (the node's index in the tree) is
-        observed into the transcript after the key, as bench.py's queue does for core shards."""
+    def prove(self, prog_id, prog: StandinProgram, shape_idx: int, fri, inputs, salt: int = 0, handle=None) -> np.ndarray:
+        """One recursion shard: witness `inputs`, events -> device traces -> commit + open. `handle` = what `prefetch` returned for these
+        inputs (the events are in HBM or on their way), else they are copied now. `salt` (the node's index in the tree) is observed into
+        the transcript after the key, as bench.py's queue does for core shards."""
         hp, recs, pk, ch0 = self.key_for(prog_id, prog, shape_idx, fri)
-        w = prog.witness(inputs)
-        born = self.traces(prog, recs, w)
+        w = handle[0] if handle is not None else prog.witness(inputs)
+        born = self.traces(prog, recs, w, handle)
         ch = ch0.copy()
         if salt:
             from . import lib
@@ -507,6 +543,9 @@ class ReduceLane:
         proof = hp.prove_shard(pk, prog.public_values(w["digest"]), born, ch, out=self.out)
         for t in born:
             t.free()
+        if handle is not None:
+            for d in handle[1].values():
+                d.free()
         return proof
 
     def close(self):
@@ -515,8 +554,10 @@ class ReduceLane:
         self.keys.clear()
         if self.pin:
             for pins in self._pins.values():
-                for arr in pins.values():
-                    self.ctx.host_free(arr)
+                for ek, copies in pins.items():
+                    if ek != "_turn":
+                        for arr in copies:
+                            self.ctx.host_free(arr)
         self._pins.clear()
 
 
@@ -566,14 +607,20 @@ class ReduceTree:
         for name, shape_idx, fri, nodes in self.layers(len(below)):
             progs = {nc: self.program(shape_idx, nc) for nc in {len(ch) for ch in nodes}}
 
-            def prove_with(lane, _nodes=nodes, _progs=progs, _below=below, _salt0=salt0, _si=shape_idx, _fri=fri):
-                def prove(i):
+            def lane_pair(lane, _nodes=nodes, _progs=progs, _below=below, _salt0=salt0, _si=shape_idx, _fri=fri):
+                inputs_of = lambda i: np.concatenate([_below[c] for c in _nodes[i]])   # noqa: E731
+
+                def prefetch(i):          # node i's events start crossing PCIe while this lane proves the node before it
+                    return lane.prefetch(_progs[len(_nodes[i])], inputs_of(i)) if hasattr(lane, "prefetch") else None
+
+                def prove(i, handle):
                     ch = _nodes[i]
-                    return lane.prove((_si, len(ch)), _progs[len(ch)], _si, _fri, np.concatenate([_below[c] for c in ch]), salt=_salt0 + i).copy()
-                return prove
+                    kw = {"handle": handle} if handle is not None else {}
+                    return lane.prove((_si, len(ch)), _progs[len(ch)], _si, _fri, inputs_of(i), salt=_salt0 + i, **kw).copy()
+                return prove, prefetch
 
             t0 = time.perf_counter()
-            ids, proofs = farm.run_queue(len(nodes), queue="reduce", lanes=[(prove_with(l), None) for l in lanes])
+            ids, proofs = farm.run_queue(len(nodes), queue="reduce", lanes=[lane_pair(l) for l in lanes])
             mine = np.stack([child_words(p, True) for p in proofs]) if proofs else np.zeros((0, CHILD_WORDS), dtype=np.uint64)
             below = farm.gather_words(ids, mine, len(nodes), CHILD_WORDS).astype(np.uint64)
             gathered = farm.gather_proofs(ids, proofs, len(nodes))
