@@ -41,7 +41,7 @@ os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")      # before anything initi
 HBM_PEAK_GBPS = 8000.0     # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 FP64_VECTOR_TFLOPS = 78.6  # MI355X FP64 vector peak: 256 CUs x 4 SIMDs x 16 lanes x 2 flop x 2.4 GHz (MI355X_MICROARCH.md)
 PROFILE_ROUND = "r06"
-HASHING_KERNELS = ("compress_layer", "compress_layer_rowdig", "hash_leaves", "hash_rows", "hash_leaves_tree", "hash_fri_leaves", "hash_fri_leaves_tree", "compress_small", "compress_tail")
+HASHING_KERNELS = ("compress_layer", "compress_layer_rowdig", "hash_leaves", "hash_rows", "hash_leaves_tree", "hash_fri_leaves", "hash_fri_leaves_lanes", "hash_fri_leaves_tree", "compress_small", "compress_tail")
 LDE_KERNELS = ("lde_rows", "lde_cols_forward", "lde_cols_inverse")
 ROCPROF_NAMES = {"compress_layer": "merkle::compress_layer", "hash_leaves": "merkle::hash_leaves", "hash_rows": "merkle::hash_rows", "hash_leaves_tree": "merkle::hash_leaves_tree",
                  "lde_rows": "lde::lde_rows_big", "lde_cols_forward": "lde::lde_cols<true>", "lde_cols_inverse": "lde::lde_cols<false>"}
@@ -1005,7 +1005,7 @@ def main():
         print(json.dumps({"metric": "recursion-shard-proofs/sec (reduce tree)", "value": round(t["recursion_shards"] / t["wall_ms"] * 1e3, 3), "unit": "shard-proofs/s", "n_gpus": 1,
                           "steps": t["recursion_shards"], "warmup": 1, "ms_per_step": t["ms_per_recursion_shard"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                           "dtype": "u32", "data": "synthetic (stand-in recursion programs, ziren_amd/reduce.py)", "verified": True,
-                          "config": {"workload": f"reduce tree over {t['leaves']} core proofs: first layer + {len(t['layers']) - 2} reduce layers + shrink, compress-machine shards at the reference's shapes"},
+                          "config": {"workload": f"reduce tree over {t['leaves']} core proofs: first layer + {len(t['layers']) - 2} reduce layers + shrink, compress-machine shards at the reference's shapes, pipelined"},
                           "reduce": r}), flush=True)
         return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:

@@ -16,6 +16,12 @@
 //!    (crates/core/executor/src/programs.rs:15-22) through `run_test_core` without a shape config (utils/prove.rs:628-656), as the flat
 //!    stream of INTEGRATION.md section 3 with `caller index := position` and the chip names beside it. Pins the transcript, LogUp,
 //!    quotient, openings, FRI betas / query indices / proof-of-work and the stream order — fri.rs:626-815's checks are contained in it.
+//! 3. airs.txt — for every chip of the core machine (`MipsAir`) and of the compress machine (`RecursionAir<_, 3>`): widths, lookup counts by
+//!    kind, and the value of EVERY main constraint, in evaluation order, at one fixed point (`get_symbolic_constraints`,
+//!    crates/stark/src/machine.rs:377-390, chip.rs:65-90; variables by the formula above: main local / next = value(7, 0 / 1, c),
+//!    preprocessed = value(11, 0 / 1, c), public value i = value(13, 0, i), is_first_row / is_last_row / is_transition = value(17, 0, 0 / 1 / 2)).
+//!    Pins the hand-transcribed AIRs of ziren_amd/chips.py and recursion.py: a missing, extra, reordered or altered constraint changes the
+//!    list (the order fixes the powers of alpha, prover.rs:447-456). tests/test_reference_goldens.py::test_recorded_airs_equal_the_references.
 use std::{fmt::Write as _, fs, path::PathBuf};
 
 use p3_commit::{Mmcs, Pcs};
@@ -120,10 +126,46 @@ fn stream(p: &ShardProof<KoalaBearPoseidon2>) -> (Vec<u32>, Vec<String>) {
     (w, names)
 }
 
+/// A symbolic constraint at the fixed point (p3-uni-stark `SymbolicExpression`, `Entry`: as read from the fork's symbolic_builder).
+fn at_point(e: &p3_uni_stark::SymbolicExpression<F>) -> F {
+    use p3_uni_stark::{Entry, SymbolicExpression as E};
+    match e {
+        E::Variable(v) => match v.entry {
+            Entry::Main { offset } => value(7, offset as u32, v.index as u32),
+            Entry::Preprocessed { offset } => value(11, offset as u32, v.index as u32),
+            Entry::Public => value(13, 0, v.index as u32),
+            _ => panic!("a main constraint reads the permutation trace or a challenge"),
+        },
+        E::IsFirstRow => value(17, 0, 0),
+        E::IsLastRow => value(17, 0, 1),
+        E::IsTransition => value(17, 0, 2),
+        E::Constant(c) => *c,
+        E::Add { x, y, .. } => at_point(x) + at_point(y),
+        E::Sub { x, y, .. } => at_point(x) - at_point(y),
+        E::Neg { x, .. } => -at_point(x),
+        E::Mul { x, y, .. } => at_point(x) * at_point(y),
+    }
+}
+
+fn airs<A>(out: &mut String, machine: &str, chips: &[zkm_stark::Chip<F, A>])
+where A: zkm_stark::air::MachineAir<F> + for<'a> p3_air::Air<p3_uni_stark::SymbolicAirBuilder<F>> {
+    for chip in chips {
+        let cs = p3_uni_stark::get_symbolic_constraints(chip.air(), chip.preprocessed_width(), zkm_stark::PROOF_MAX_NUM_PVS);
+        let kinds = |ls: &[zkm_stark::lookup::Lookup<F>]| { let mut k: Vec<String> = ls.iter().map(|l| format!("{:?}", l.kind)).collect(); k.sort(); k.join(",") };
+        writeln!(out, "chip {machine} {} prep {} main {} lqd {} constraints {} sends [{}] receives [{}]", chip.name(), chip.preprocessed_width(), chip.width(),
+                 chip.log_quotient_degree(), cs.len(), kinds(chip.sends()), kinds(chip.receives())).unwrap();
+        record(out, &format!("values_{machine}_{}", chip.name()), cs.iter().map(|c| word(at_point(c))));
+    }
+}
+
 fn main() {
     let dir = PathBuf::from(std::env::args().nth(1).expect("usage: dump_golden <out dir>"));
     fs::create_dir_all(&dir).unwrap();
     fs::write(dir.join("pcs_size_gaps.txt"), pcs_size_gaps()).unwrap();
+    let mut a = String::new();
+    airs(&mut a, "core", MipsAir::<F>::machine(KoalaBearPoseidon2::new()).chips());                                   // crates/core/machine/src/mips/mod.rs
+    airs(&mut a, "compress", zkm_recursion_core::machine::RecursionAir::<F, 3>::compress_machine(KoalaBearPoseidon2::new()).chips());   // recursion/core/src/machine.rs:112-132
+    fs::write(dir.join("airs.txt"), a).unwrap();
     let mut runtime = Executor::new(simple_program(), ZKMCoreOpts::default());
     runtime.run().unwrap();
     let proof = run_test_core::<CpuProver<KoalaBearPoseidon2, MipsAir<F>>>(runtime, ZKMStdin::new(), None).unwrap();   // proves and verifies

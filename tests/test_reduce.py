@@ -282,3 +282,59 @@ def test_gpu_eight_leaf_tree_through_the_farm(hip_ctx, oracle):
     for l in lanes:
         l.close()
     ctx2.close()
+
+
+TREE_WORKER = """
+import sys, json, os
+import numpy as np
+sys.path.insert(0, %r)
+sys.path.insert(0, %r)
+from ziren_amd import farm, field as F, prover, reduce as RD
+f = farm.Farm(backend="gloo")                      # two processes on ONE device: RCCL refuses that, the collectives are the same calls
+ctx = prover.Context(0)
+permute = lambda v: F.from_monty(prover.poseidon2_permute_batch(ctx, F.to_monty(np.asarray(v, dtype=np.uint64))))
+tree = RD.ReduceTree(RD.TreePlan(0, 0, 0), permute)
+core = (np.arange(6 * 32, dtype=np.uint64).reshape(6, 32) * 104729 + 3) %% F.P
+lane = RD.ReduceLane(ctx)
+streams, words = tree.run(f, [lane], core)
+mine = sorted(k[0] for k in lane.keys)             # the programs this rank proved nodes of
+out = {"rank": f.rank, "layers": [len(w) for w in words], "digests": [w[:, 24:].tolist() for w in words],
+       "streams": None if streams[0] is None else [[int(p[0]) for p in s] for s in streams], "nodes_proved_here": len(lane.setup_ms)}
+if f.rank == 0:
+    import oracle_lib as O
+    from test_reduce import host_shard, oracle_key
+    from ziren_amd import abi, synth
+    prog = tree.program(0, 1)
+    recs = host_shard(prog, O, words[-2][0].astype(np.uint64))             # the shrink node witnesses the root of the reduce layers
+    opk, och = oracle_key(O, recs, RD.SHRINK_FRI[0])
+    O.challenger_observe(och, np.array([sum(len(w) for w in words)], dtype=np.uint32))      # its salt: the last node of the tree
+    out["shrink_verified"] = O.verify_shard(opk, recs, abi.FriConfig(*RD.SHRINK_FRI), synth.NUM_PV_ELTS, och, streams[-1][0]) == 0
+print("RESULT " + json.dumps(out), flush=True)
+lane.close()
+f.close()
+"""
+
+
+@pytest.mark.gpu
+def test_gpu_tree_over_two_real_ranks_sharing_the_device(tmp_path):
+    """The N > 1 path of the reduce tree with real lanes: two processes (gloo), both proving on this box's one GPU, claim the nodes of every
+    layer from the shared queue; both end with the same witnessed words, rank 0 with every layer's streams, and the shrink proof — made by
+    whichever rank claimed it — is accepted by the restated verifier."""
+    import json
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    script = tmp_path / "tree_worker.py"
+    script.write_text(TREE_WORKER % (ROOT, os.path.join(ROOT, "tests")))
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=600) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [o[1][-1500:] for o in outs]
+    res = sorted((json.loads(next(l for l in o[0].splitlines() if l.startswith("RESULT "))[7:]) for o in outs), key=lambda d: d["rank"])
+    assert res[0]["layers"] == res[1]["layers"] == [6, 3, 2, 1, 1]
+    assert res[0]["digests"] == res[1]["digests"]
+    assert res[1]["streams"] is None and [len(s) for s in res[0]["streams"]] == [6, 3, 2, 1, 1]
+    assert res[0]["shrink_verified"] is True

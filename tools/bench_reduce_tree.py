@@ -179,7 +179,7 @@ def tree_leg(tree, farm, lanes, n_leaves, O=None, repeat=2):
     from ziren_amd import field as F, reduce as RD
     rng = np.random.default_rng(n_leaves)
     core = rng.integers(0, F.P, (n_leaves, RD.CHILD_WORDS), dtype=np.uint64)
-    best = None
+    best, best_layered = None, None
     for _ in range(repeat + 1):
         for l in lanes:
             l.ctx.synchronize()
@@ -188,10 +188,21 @@ def tree_leg(tree, farm, lanes, n_leaves, O=None, repeat=2):
         dt = time.perf_counter() - t0
         if best is None or dt < best[0]:
             best = (dt, list(tree.layer_seconds), streams, words)
+        for l in lanes:
+            l.ctx.synchronize()
+        t0 = time.perf_counter()
+        s2, w2 = tree.run(farm, lanes, core, pipelined=False)
+        dt2 = time.perf_counter() - t0
+        if best_layered is None or dt2 < best_layered[0]:
+            best_layered = (dt2, list(tree.layer_seconds))
+        assert all(np.array_equal(a, b) for a, b in zip(words, w2)) and all(np.array_equal(p, q) for x, y in zip(streams, s2) for p, q in zip(x, y)), "the two schedules made different proofs"
     dt, layers, streams, words = best
     n_proofs = sum(len(s) for s in streams)
     res = {"leaves": n_leaves, "recursion_shards": n_proofs, "wall_ms": round(dt * 1e3, 2), "ms_per_recursion_shard": round(dt * 1e3 / n_proofs, 3),
-           "layers": [{"layer": nm, "nodes": n, "ms": round(s * 1e3, 2)} for nm, n, s in layers],
+           "schedule": "pipelined: one queue over all nodes in layer order, a node waits only for its own children (as the reference's channels do, lib.rs:655-915); one gather at the end",
+           "layers": [{"layer": nm, "nodes": n, "last_node_finished_at_ms": round(s * 1e3, 2)} for nm, n, s in layers],
+           "layer_by_layer": {"wall_ms": round(best_layered[0] * 1e3, 2), "layers": [{"layer": nm, "nodes": n, "ms": round(s * 1e3, 2)} for nm, n, s in best_layered[1]],
+                              "note": "the same nodes with a barrier, an all-reduce of the witnessed words and a gather per layer (ReduceTree.run_layers): same proofs, word for word"},
            "proof_bytes_gathered": int(4 * sum(len(p) for s in streams for p in s))}
     if O is not None:      # the shrink proof (the tree's output) and the root of the reduce layers through the verifier
         specs = tree.layers(n_leaves)
@@ -240,7 +251,7 @@ def reduce_bench(leaves=(8, 16, 32), leaf_shape=1, reduce_shape=0, shrink_shape=
            "plan": {"first_layer_shape": leaf_shape, "reduce_layers_shape": reduce_shape, "shrink_shape": shrink_shape,
                     "note": "which allowed shape a first-layer / reduce / shrink program lands in is the recursion compiler's output: an assumption here; ms per shard is given for all three"},
            "per_shape": per_shape, "two_lanes": two, "trees": trees,
-           "tree_mode": "two lanes (a context + host thread each) on the one GPU claim nodes from the layer's queue (Farm.run_queue); after each layer gather_words + gather_proofs; proving keys kept per program",
+           "tree_mode": "two lanes (a context + host thread each) on the one GPU claim nodes from the tree's queue; children's words through the board (a dictionary in one process, the process group's store across ranks); one gather_proofs at the end; proving keys kept per program",
            "lib_digest": lib.check_build_identity(), "seconds_of_program_generation_and_shape_legs": round(gen_s, 1)}
     if core_ms_per_shard:
         out["share_of_a_fibonacci_run"] = [{"core_shards": t["leaves"], "core_ms": round(core_ms_per_shard * t["leaves"], 1), "reduce_tree_ms": t["wall_ms"],

@@ -27,10 +27,12 @@ def main(fetch_db, write_db, out_path, tag="syn22", proofs=1):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, root)
     import bench              # the same digest bench.py checks before it quotes a figure from this file
-    try:
-        commit = subprocess.run(["git", "-C", root, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or None
-    except OSError:
-        commit = None
+    commit = os.environ.get("ZKM_COMMIT") or None       # the GPU box's snapshot has no .git: the caller passes the commit it snapshotted
+    if commit is None:
+        try:
+            commit = subprocess.run(["git", "-C", root, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or None
+        except OSError:
+            commit = None
     proofs = int(proofs)
     out = {"workload": f"{tag}: {proofs} shard proof(s) of bench.py's workload of that tag (tools/profile_r04.sh)", "steps": proofs, "csrc_digest": bench.csrc_digest(), "commit": commit,
            "correction": "read bytes = 2 * FETCH_SIZE * 1024, write bytes = WRITE_SIZE * 1024", "kernels": {}}

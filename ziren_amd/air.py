@@ -533,6 +533,49 @@ def _constraint_values(b: "AirBuilder", main: np.ndarray, public_values=None, pr
             memo.clear()
 
 
+def constraint_values_at_point(b: "AirBuilder", n_public_values: int = 231) -> List[int]:
+    """Every recorded base-field constraint, in evaluation order, at the fixed point integration/zkm-hip/examples/dump_golden.rs evaluates the
+    reference's symbolic constraints at (its `airs.txt`): main local / next column c = value(7, 0 / 1, c), preprocessed = value(11, 0 / 1, c),
+    public value i = value(13, 0, i), is_first_row / is_last_row / is_transition = value(17, 0, 0 / 1 / 2), with
+    value(seed, r, c) = ((seed * 2654435761 + r * 40503 + c * 9973 + 12345) mod 2^32) mod p. Canonical integers."""
+    val = lambda seed, r, c: ((seed * 2654435761 + r * 40503 + c * 9973 + 12345) % (1 << 32)) % F.P   # noqa: E731
+    main = np.array([[val(7, r, c) for c in range(b.main_width)] for r in range(2)], dtype=np.uint64)
+    prep = np.array([[val(11, r, c) for c in range(max(b.prep_width, 1))] for r in range(2)], dtype=np.uint64)
+    pv = [val(13, 0, i) for i in range(n_public_values)]
+    sel = {LD_IS_FIRST: val(17, 0, 0), LD_IS_LAST: val(17, 0, 1), LD_IS_TRANS: val(17, 0, 2)}
+    memo = {}
+
+    def ev(x):
+        k = id(x)
+        if k not in memo:
+            if x.op == LD_MAIN:
+                v = int(main[1 if x.a else 0, x.imm])
+            elif x.op == LD_PREP:
+                v = int(prep[1 if x.a else 0, x.imm])
+            elif x.op == LD_CONST:
+                v = int(F.from_monty(np.uint32(x.imm)))
+            elif x.op == LD_PV:
+                v = pv[x.imm]
+            elif x.op in sel:
+                v = sel[x.op]
+            elif x.op == ADD_B:
+                v = (ev(x.a) + ev(x.c)) % F.P
+            elif x.op == SUB_B:
+                v = (ev(x.a) - ev(x.c)) % F.P
+            elif x.op == MUL_B:
+                v = ev(x.a) * ev(x.c) % F.P
+            elif x.op == NEG_B:
+                v = -ev(x.a) % F.P
+            else:
+                raise ValueError(f"opcode {x.op} in a main constraint")
+            memo[k] = v
+        return memo[k]
+
+    import sys
+    sys.setrecursionlimit(max(sys.getrecursionlimit(), 20000))
+    return [ev(a) for a in b.asserts if not a.ext]
+
+
 def debug_constraints(b: "AirBuilder", main: np.ndarray, public_values=None, prep: np.ndarray = None) -> List[Tuple[int, int]]:
     """Evaluate the recorded base-field constraints on every row of a trace (canonical values, row-major),
     row i against row (i + 1) mod n as crates/stark/src/debug.rs:30-120 does. Returns [(constraint, first failing

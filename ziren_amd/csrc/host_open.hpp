@@ -641,8 +641,11 @@ struct ShardOpening {
     for (size_t l = half; l >= 1; l >>= 1) { t.layer_off.push_back(off); off += l; if (l == 1) break; }
     t.digests = (uint32_t*)salloc(off * 8 * 4);
     int fuse = 0;   // FRI trees have one matrix: the first levels are reduced inside the leaf kernel's blocks
-    if (half >= (size_t)merkle::FRI_FUSE_LEAVES) fuse = std::min(merkle::FRI_FUSE_MAX_LEVELS, lf - 1);
-    if (fuse > 0)
+    if (half > 4096 && half >= (size_t)merkle::FRI_FUSE_LEAVES) fuse = std::min(merkle::FRI_FUSE_MAX_LEVELS, lf - 1);
+    if (half <= 4096)      // a latency-bound layer: sixteen lanes per leaf, then the lane-parallel levels (compress_small_layer)
+      KLAUNCH(ctx, "hash_fri_leaves_lanes", 64.0 * half, merkle::hash_fri_leaves_lanes, dim3(div_up(half * 16, merkle::THREADS)), dim3(merkle::THREADS), 0,
+              (const E4*)f, half, t.digests);
+    else if (fuse > 0)
       KLAUNCH(ctx, "hash_fri_leaves_tree", 32.0 * half + 32.0 * half * (2.0 - 1.0 / (1 << fuse)), merkle::hash_fri_leaves_tree,
               dim3(half / merkle::FRI_FUSE_LEAVES), dim3(merkle::FRI_FUSE_LEAVES), merkle::FRI_FUSE_LEAVES * 12 * sizeof(uint32_t), (const E4*)f, half, t.digests, fuse);
     else

@@ -410,6 +410,18 @@ __device__ __forceinline__ void observe_root_sample_beta(uint32_t rw, int e, con
   }
 }
 
+// FRI commit-phase leaves with 16 lanes per leaf (row j = (f[2j], f[2j+1]): the eight words at f + 8 j; the capacity lanes start at zero): a
+// layer of a few thousand leaves cannot fill the chip with one thread per leaf and pays a serial permutation's ~11 us; this way ~4 us.
+__global__ __launch_bounds__(THREADS) void hash_fri_leaves_lanes(const kb::E4* __restrict__ f, size_t m, uint32_t* __restrict__ digests) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t j = t >> 4;
+  const int e = threadIdx.x & 15;
+  if (j >= m) return;
+  lanes::LaneConsts k = lanes::load_consts(e);
+  const uint32_t x = lanes::permute(e < 8 ? reinterpret_cast<const uint32_t*>(f)[8 * j + e] : 0u, k);
+  if (e < 8) digests[8 * j + e] = x;
+}
+
 // Root of the tree in one launch, 16 lanes per node: from 2*len0 digests at `prev` (len0 <= 64) down to 1. The root also goes straight
 // to `root_host` (page-locked host memory, may be null): the transcript reads it after the stream synchronisation, no copy dispatch.
 // With `ch` (an FRI commit-phase tree): the root is observed into the device challenger and beta sampled here (observe_root_sample_beta).

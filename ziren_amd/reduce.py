@@ -573,6 +573,68 @@ class TreePlan:
         self.leaf_shape, self.reduce_shape, self.shrink_shape = leaf_shape, reduce_shape, shrink_shape
 
 
+class _Board:
+    """Where the nodes of a pipelined tree publish the 32 words their parents witness: the process group's key-value store across ranks
+    (c10d `Store.set / check / get`), a dictionary under a condition variable inside one process. A store client is one connection:
+    a blocking `get` would hold it against this process's other lanes (whose `set` may be the very thing it waits for), so waiting is
+    `check` (non-blocking) between short sleeps, and every store call of the process goes through the farm's one lock."""
+
+    def __init__(self, farm, prefix):
+        import threading
+        self.prefix, self.local, self.cv, self.failed = prefix, {}, threading.Condition(), False
+        self.store = farm.dist.distributed_c10d._get_default_store() if farm.dist is not None else None
+        self.lock = farm._claim_lock
+
+    def publish(self, g, words):
+        w = np.ascontiguousarray(words, dtype=np.uint64)
+        with self.cv:
+            self.local[g] = w
+            self.cv.notify_all()
+        if self.store is not None:
+            with self.lock:
+                self.store.set(f"{self.prefix}_{g}", w.tobytes())
+
+    def ready(self, g):
+        with self.cv:
+            if g in self.local:
+                return True
+        if self.store is None:
+            return False
+        with self.lock:
+            return bool(self.store.check([f"{self.prefix}_{g}"]))
+
+    def wait(self, g, timeout_s: float = 600.0):
+        import time
+        t0 = time.perf_counter()
+        while True:
+            with self.cv:
+                if g in self.local:
+                    return self.local[g]
+                if self.failed:
+                    raise RuntimeError("another lane of the tree failed")
+                if self.store is None:
+                    self.cv.wait(timeout=0.05)
+                    continue
+            with self.lock:
+                have = bool(self.store.check([f"{self.prefix}_{g}"]))
+                w = np.frombuffer(self.store.get(f"{self.prefix}_{g}"), dtype=np.uint64).copy() if have else None
+            if w is not None:
+                with self.cv:
+                    self.local[g] = w
+                return w
+            if time.perf_counter() - t0 > timeout_s:
+                raise RuntimeError(f"node {g} of the tree was not published within {timeout_s:.0f} s (a rank failed?)")
+            time.sleep(0.0002)
+
+    def fail(self):
+        with self.cv:
+            self.failed = True
+            self.cv.notify_all()
+
+    def close(self):
+        self.local.clear()
+
+
 class ReduceTree:
     """The programs of a tree (one per (shape, children) pair: every node of a layer runs the same program on its own inputs) and the
     level-by-level driver over a `Farm`."""
@@ -596,10 +658,102 @@ class ReduceTree:
         out.append(("shrink", self.plan.shrink_shape, SHRINK_FRI, [(0,)]))
         return out
 
-    def run(self, farm, lanes: Sequence[ReduceLane], core_words: np.ndarray, on_layer=None):
+    def run(self, farm, lanes: Sequence[ReduceLane], core_words: np.ndarray, pipelined: bool = True):
         """Prove the whole tree over `core_words` ((n_core, 32) canonical: `child_words` of the gathered core proofs, known on every rank).
         Returns (per layer the gathered proof streams — rank 0 only, None elsewhere —, per layer the (n, 32) witnessed words of its
-        nodes). Every rank calls this with the same arguments; lanes of all ranks claim nodes from the layer's queue."""
+        nodes). Every rank calls this with the same arguments.
+
+        `pipelined` (default), as the reference runs it (lib.rs:655-915: inputs, traces and proofs flow through channels, a layer-r node is
+        generated as soon as its two children are proven): all nodes of the tree are ONE queue in layer order; a free lane of any rank
+        claims the next node, waits — only if it has to — for its children's 32 words (published through the process group's key-value store,
+        128 bytes per node; a dictionary inside one process), proves it and publishes its own. A node only waits for nodes in front of it in
+        the queue, which somebody has already claimed: no deadlock, and no barrier between layers — the narrow top of the tree overlaps with
+        the wide layers' tails. The proof streams go to rank 0 in ONE gather at the end (`Farm.gather_proofs`): the tree's only collective.
+        `pipelined=False`: layer by layer (`run_layers`), a queue, an all-reduce of the words and a gather per layer."""
+        if not pipelined:
+            return self.run_layers(farm, lanes, core_words)
+        import threading
+        import time
+        core = np.asarray(core_words, dtype=np.uint64)
+        layers = self.layers(len(core))
+        offs = np.concatenate([[0], np.cumsum([len(nodes) for *_, nodes in layers])]).astype(int)
+        n_total = int(offs[-1])
+        layer_of = np.repeat(np.arange(len(layers)), [len(nodes) for *_, nodes in layers])
+        progs = [{nc: self.program(si, nc) for nc in {len(ch) for ch in nodes}} for _, si, _, nodes in layers]
+        epoch = farm._epochs.get("reduce_tree", 0)
+        board = _Board(farm, f"zkm_tree_{epoch}")
+
+        def inputs_of(g):             # blocks until the children's words are published
+            L = int(layer_of[g])
+            ch = layers[L][3][g - offs[L]]
+            if L == 0:
+                return np.concatenate([core[c] for c in ch])
+            return np.concatenate([board.wait(int(offs[L - 1]) + c) for c in ch])
+
+        def children_ready(g):
+            L = int(layer_of[g])
+            return L == 0 or all(board.ready(int(offs[L - 1]) + c) for c in layers[L][3][g - offs[L]])
+
+        results = [([], [], []) for _ in lanes]
+        errors = []
+        t_start = time.perf_counter()
+
+        def work(j):
+            lane = lanes[j]
+            ids, proofs, done_at = results[j]
+            try:
+                cur, handle = farm.claim("reduce_tree"), None
+                while cur < n_total:
+                    nxt = farm.claim("reduce_tree")
+                    L = int(layer_of[cur])
+                    _, si, fri, nodes = layers[L]
+                    ch = nodes[cur - offs[L]]
+                    inputs = inputs_of(cur)
+                    if handle is None and hasattr(lane, "prefetch"):
+                        handle = lane.prefetch(progs[L][len(ch)], inputs)
+                    nxt_handle = None
+                    if nxt < n_total and hasattr(lane, "prefetch") and children_ready(nxt):      # its events cross PCIe under this proof
+                        Ln = int(layer_of[nxt])
+                        nxt_handle = lane.prefetch(progs[Ln][len(layers[Ln][3][nxt - offs[Ln]])], inputs_of(nxt))
+                    kw = {"handle": handle} if handle is not None else {}
+                    proof = lane.prove((si, len(ch)), progs[L][len(ch)], si, fri, inputs, salt=cur + 1, **kw).copy()
+                    board.publish(cur, child_words(proof, True))
+                    ids.append(cur)
+                    proofs.append(proof)
+                    done_at.append(time.perf_counter() - t_start)
+                    cur, handle = nxt, nxt_handle
+            except BaseException as e:  # noqa: BLE001  (re-raised on the calling thread)
+                errors.append(e)
+                board.fail()
+
+        try:
+            if len(lanes) == 1:
+                work(0)
+            else:
+                ts = [threading.Thread(target=work, args=(j,)) for j in range(len(lanes))]
+                for t in ts:
+                    t.start()
+                for t in ts:
+                    t.join()
+        finally:
+            farm._epochs["reduce_tree"] = epoch + 1
+        if errors:
+            raise errors[0]
+        ids = [i for r in results for i in r[0]]
+        proofs = [p for r in results for p in r[1]]
+        gathered = farm.gather_proofs(ids, proofs, n_total)
+        all_words = np.stack([board.wait(g) for g in range(n_total)])
+        # when each layer's last node finished on this rank (seconds from the start): the layers overlap, so these are not durations
+        self.layer_seconds = [(layers[L][0], len(layers[L][3]), max([t for r in results for g, t in zip(r[0], r[2]) if layer_of[g] == L], default=0.0)) for L in range(len(layers))]
+        self.layer_seconds_are = "finish times (pipelined: layers overlap)"
+        streams = [None if gathered is None else gathered[offs[L]:offs[L + 1]] for L in range(len(layers))]
+        words = [all_words[offs[L]:offs[L + 1]] for L in range(len(layers))]
+        board.close()
+        return streams, words
+
+    def run_layers(self, farm, lanes: Sequence[ReduceLane], core_words: np.ndarray, on_layer=None):
+        """The tree layer by layer: every layer a claim queue (`Farm.run_queue`), then `gather_words` (every rank learns what the next layer
+        witnesses) and `gather_proofs` (rank 0 receives the streams). Node salts as in `run`: the node's position in the tree + 1."""
         import time
         below = np.asarray(core_words, dtype=np.uint64)
         streams, words, salt0 = [], [], 1
@@ -625,6 +779,7 @@ class ReduceTree:
             below = farm.gather_words(ids, mine, len(nodes), CHILD_WORDS).astype(np.uint64)
             gathered = farm.gather_proofs(ids, proofs, len(nodes))
             self.layer_seconds.append((name, len(nodes), time.perf_counter() - t0))
+            self.layer_seconds_are = "durations (layer by layer)"
             streams.append(gathered)
             words.append(below)
             salt0 += len(nodes)
