@@ -166,7 +166,7 @@ def test_gpu_run_with_every_chip_through_the_farm(tmp_path):
 def test_gpu_bench_queue_mode_over_rccl():
     """`bench.py --gpus N --queue`: the benchmark's multi-GPU line through the code path the farm tests cover (claim queue with one shard
     claimed ahead per lane, two lanes, events prefetched, RCCL gather to rank 0), here with world size 1 on RCCL: six distinct shaped
-    fibonacci shards (SHARD_SIZE 2^16), one JSON line, every lane's last proof verified."""
+    fibonacci shards (SHARD_SIZE 2^16), one JSON line, every gathered proof verified."""
     import json
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -187,7 +187,7 @@ def test_gpu_bench_queue_mode_over_rccl():
     assert d["resident_one_lane"]["value"] > 0 and d["roofline"]["kernel"] and 0 < d["roofline"]["frac"] < 1
     src = d["kernels_ms_source"]
     assert src["kernels_ms_sum"] <= src["ms_per_step_of_that_pass"] and "overlap off" in src["pass"]
-    assert d["lib_digest"] and d["verified_proofs"]["checked_by_the_verifier"] == 2 and d["cpu_baseline"] is None
+    assert d["lib_digest"] and d["verified_proofs"]["checked_by_the_verifier"] == 6 and d["cpu_baseline"] is None      # N = 1: every gathered proof
 
 
 @pytest.mark.gpu
@@ -206,4 +206,4 @@ def test_gpu_bench_two_ranks_on_one_device_share_the_queue():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["ranks_in_process_group"] == 2 and d["shards"] == 8 and d["shards_proved"] == 8 and d["steps"] == 4
     assert d["verified"] is True and d["fewest_shards_on_a_rank"] >= 1 and d["config"]["shards_in_flight_per_gpu"] == 2
-    assert d["verified_proofs"]["checked_by_the_verifier"] == 2 and d["resident_one_lane"]["value"] > 0 and d["roofline"]["kernel"] and d["cpu_baseline"] is None
+    assert 2 <= d["verified_proofs"]["checked_by_the_verifier"] <= 4 and d["resident_one_lane"]["value"] > 0 and d["roofline"]["kernel"] and d["cpu_baseline"] is None    # every lane that proved something
