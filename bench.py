@@ -598,7 +598,7 @@ def cpu_baseline_leg(wl, fri, full, sample_log):
             "sample": (f"oracle (CPU restatement, canonical `% p` arithmetic, OpenMP, {threads} threads) proving one {what} shard in {wall:.2f} s ({lde_s:.2f} s of it coset LDEs)"
                        + ("" if full else f"; scaled to the benchmarked shard by committed cells (x{ratio:.2f}), the LDEs by a further ({k_full} + 1) / ({k_s} + 1)")),
             "measured_at_full_size": bool(full), "sample_seconds": round(wall, 3), "estimated_seconds_full_size": round(est, 2),
-            "full_size_measurement": (newest_profile("cpu_baseline_full.json") or "none kept under profiles/") + " (bench.py --cpu-full: the benchmarked shard itself on the CPU)"}
+            "full_size_measurement": ("this run: the benchmarked shard itself on the CPU; kept per round as " if full else "") + (newest_profile("cpu_baseline_full.json") or "none kept under profiles/") + " (bench.py's default since round 6; --cpu-sample scales a smaller shard instead)"}
 
 
 # ---- the farm line (every N): the claim queue over events -> traces -> proof -----------------------------------------------------------------
