@@ -154,7 +154,11 @@ def two_lane_leg(lanes, prog, shape_idx, fri, steps):
             l.prove(pid, prog, shape_idx, fri, inputs, handle=h)
             h = nxt
 
+    for l in lanes:
+        l.host_s = {k: 0.0 for k in l.host_s}
     res["from_events_ms_per_shard"] = round(timed(from_events), 3)
+    n = max(1, sum(l.host_s["nodes"] for l in lanes))
+    res["from_events_host_ms_per_node"] = {k: round(1e3 * sum(l.host_s[k] for l in lanes) / n, 3) for k in ("prefetch", "traces", "prove_shard", "free")}
     state = {}
     for l in lanes:
         hp, recs, pk, ch0 = l.key_for(pid, prog, shape_idx, fri)
@@ -221,14 +225,14 @@ def tree_leg(tree, farm, lanes, n_leaves, O=None, repeat=2):
     return res
 
 
-def reduce_bench(leaves=(8, 16, 32), leaf_shape=1, reduce_shape=0, shrink_shape=0, steps=5, core_ms_per_shard=None, device=0, check=True, shapes_to_time=(0, 1, 2)):
+def reduce_bench(leaves=(8, 16, 32), leaf_shape=1, reduce_shape=0, shrink_shape=0, steps=5, core_ms_per_shard=None, device=0, check=True, shapes_to_time=(0, 1, 2), n_lanes=2):
     from ziren_amd import farm as farm_mod, lib, prover, reduce as RD
     lib.check_build_identity()
     O = None
     if check:
         import bench
         O = bench.oracle()
-    ctxs = [prover.Context(device), prover.Context(device)]
+    ctxs = [prover.Context(device) for _ in range(max(2, n_lanes))]
     lanes = [RD.ReduceLane(c) for c in ctxs]
     shapes = RD.load_shapes()
     tree = RD.ReduceTree(RD.TreePlan(leaf_shape, reduce_shape, shrink_shape), device_permute(ctxs[0]))
@@ -251,7 +255,7 @@ def reduce_bench(leaves=(8, 16, 32), leaf_shape=1, reduce_shape=0, shrink_shape=
            "plan": {"first_layer_shape": leaf_shape, "reduce_layers_shape": reduce_shape, "shrink_shape": shrink_shape,
                     "note": "which allowed shape a first-layer / reduce / shrink program lands in is the recursion compiler's output: an assumption here; ms per shard is given for all three"},
            "per_shape": per_shape, "two_lanes": two, "trees": trees,
-           "tree_mode": "two lanes (a context + host thread each) on the one GPU claim nodes from the tree's queue; children's words through the board (a dictionary in one process, the process group's store across ranks); one gather_proofs at the end; proving keys kept per program",
+           "lanes": len(lanes), "tree_mode": "lanes (a context + host thread each) on the one GPU claim nodes from the tree's queue; children's words through the board (a dictionary in one process, the process group's store across ranks); one gather_proofs at the end; proving keys kept per program",
            "lib_digest": lib.check_build_identity(), "seconds_of_program_generation_and_shape_legs": round(gen_s, 1)}
     if core_ms_per_shard:
         out["share_of_a_fibonacci_run"] = [{"core_shards": t["leaves"], "core_ms": round(core_ms_per_shard * t["leaves"], 1), "reduce_tree_ms": t["wall_ms"],
@@ -271,9 +275,10 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--core-ms", type=float, default=None, help="ms per core shard (bench.py's ms_per_shard on this box) for the share figure")
     ap.add_argument("--no-check", action="store_true")
+    ap.add_argument("--lanes", type=int, default=2, help="contexts (+ host threads) on the GPU claiming nodes")
     ap.add_argument("--out", type=str, default=None)
     args = ap.parse_args()
-    res = reduce_bench([int(x) for x in args.leaves.split(",") if x], args.leaf_shape, args.reduce_shape, args.shrink_shape, args.steps, args.core_ms, check=not args.no_check)
+    res = reduce_bench([int(x) for x in args.leaves.split(",") if x], args.leaf_shape, args.reduce_shape, args.shrink_shape, args.steps, args.core_ms, check=not args.no_check, n_lanes=args.lanes)
     txt = json.dumps(res, indent=1)
     if args.out:
         with open(args.out, "w") as f:

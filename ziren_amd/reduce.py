@@ -434,6 +434,7 @@ class ReduceLane:
         self.provers, self.keys = {}, {}
         self.out = np.zeros(1 << 23, dtype=np.uint32)
         self.setup_ms, self._pins = {}, {}
+        self.host_s = {"prefetch": 0.0, "traces": 0.0, "prove_shard": 0.0, "free": 0.0, "nodes": 0}     # wall seconds of this lane's host thread per phase
 
     def prover_for(self, shape_idx: int, shape, fri):
         key = (shape_idx, tuple(fri))
@@ -489,6 +490,8 @@ class ReduceLane:
     def prefetch(self, prog: StandinProgram, inputs):
         """A node's events on their way to HBM (zkm_events_upload_async on the context's DMA stream: under whatever this lane is proving):
         the witness is written into this turn's page-locked copies, every stream's copy queued. Returns the handle `prove` takes."""
+        import time
+        t0 = time.perf_counter()
         w = prog.witness(inputs)
         pins = self._pinned(prog)
         turn = pins["_turn"]
@@ -501,6 +504,7 @@ class ReduceLane:
             if ek in self.PATCHED:
                 buf[:len(w[ek])] = w[ek]
             dev[ek] = self.ctx.events_upload_async(buf)
+        self.host_s["prefetch"] += time.perf_counter() - t0
         return (w, dev)
 
     def traces(self, prog: StandinProgram, recs, witness=None, handle=None):
@@ -533,19 +537,28 @@ class ReduceLane:
         inputs (the events are in HBM or on their way), else they are copied now. `salt` (the node's index in the tree) is observed into
         the transcript after the key, as bench.py's queue does for core shards."""
         hp, recs, pk, ch0 = self.key_for(prog_id, prog, shape_idx, fri)
+        import time
+        t0 = time.perf_counter()
         w = handle[0] if handle is not None else prog.witness(inputs)
         born = self.traces(prog, recs, w, handle)
+        t1 = time.perf_counter()
         ch = ch0.copy()
         if salt:
             from . import lib
             idx = np.array([salt], dtype=np.uint32)
             lib.load().zkm_challenger_observe(C.byref(ch), abi.as_u32p(idx), C.c_size_t(1))
         proof = hp.prove_shard(pk, prog.public_values(w["digest"]), born, ch, out=self.out)
+        t2 = time.perf_counter()
         for t in born:
             t.free()
         if handle is not None:
             for d in handle[1].values():
                 d.free()
+        t3 = time.perf_counter()
+        self.host_s["traces"] += t1 - t0
+        self.host_s["prove_shard"] += t2 - t1
+        self.host_s["free"] += t3 - t2
+        self.host_s["nodes"] += 1
         return proof
 
     def close(self):
