@@ -264,6 +264,8 @@ def test_gpu_eight_leaf_tree_through_the_farm(hip_ctx, oracle):
     streams, words = tree.run(f, lanes, core)
     assert [len(s) for s in streams] == [8, 4, 2, 1, 1]
     assert len({p.tobytes() for s in streams for p in s}) == 16
+    layered, lwords = tree.run(f, lanes, core, pipelined=False)       # the layer-by-layer schedule: the same proofs, word for word
+    assert all(np.array_equal(a, b) for x, y in zip(streams, layered) for a, b in zip(x, y)) and all(np.array_equal(a, b) for a, b in zip(words, lwords))
     below = core
     structure = [[(i,) for i in range(8)]] + RD.tree_levels(8) + [[(0,)]]
     salt = 1

@@ -187,11 +187,12 @@ def tree_leg(tree, farm, lanes, n_leaves, O=None, repeat=2):
     for _ in range(repeat + 1):
         for l in lanes:
             l.ctx.synchronize()
-        t0 = time.perf_counter()
+        t0, c0 = time.perf_counter(), time.process_time()
         streams, words = tree.run(farm, lanes, core)
         dt = time.perf_counter() - t0
+        cores = (time.process_time() - c0) / dt
         if best is None or dt < best[0]:
-            best = (dt, list(tree.layer_seconds), streams, words)
+            best = (dt, list(tree.layer_seconds), streams, words, cores)
         for l in lanes:
             l.ctx.synchronize()
         t0 = time.perf_counter()
@@ -200,9 +201,9 @@ def tree_leg(tree, farm, lanes, n_leaves, O=None, repeat=2):
         if best_layered is None or dt2 < best_layered[0]:
             best_layered = (dt2, list(tree.layer_seconds))
         assert all(np.array_equal(a, b) for a, b in zip(words, w2)) and all(np.array_equal(p, q) for x, y in zip(streams, s2) for p, q in zip(x, y)), "the two schedules made different proofs"
-    dt, layers, streams, words = best
+    dt, layers, streams, words, cores = best
     n_proofs = sum(len(s) for s in streams)
-    res = {"leaves": n_leaves, "recursion_shards": n_proofs, "wall_ms": round(dt * 1e3, 2), "ms_per_recursion_shard": round(dt * 1e3 / n_proofs, 3),
+    res = {"cores_busy": round(cores, 2), "leaves": n_leaves, "recursion_shards": n_proofs, "wall_ms": round(dt * 1e3, 2), "ms_per_recursion_shard": round(dt * 1e3 / n_proofs, 3),
            "schedule": "pipelined: one queue over all nodes in layer order, a node waits only for its own children (as the reference's channels do, lib.rs:655-915); one gather at the end",
            "layers": [{"layer": nm, "nodes": n, "last_node_finished_at_ms": round(s * 1e3, 2)} for nm, n, s in layers],
            "layer_by_layer": {"wall_ms": round(best_layered[0] * 1e3, 2), "layers": [{"layer": nm, "nodes": n, "ms": round(s * 1e3, 2)} for nm, n, s in best_layered[1]],
@@ -247,14 +248,19 @@ def reduce_bench(leaves=(8, 16, 32), leaf_shape=1, reduce_shape=0, shrink_shape=
         l.close()
         l.ctx.trim()
     gen_s = time.perf_counter() - t0
+    # the tree's lanes sleep between stream queries, as the core farm's do (zkm_ctx_set_host_wait 1): 0.05 CPU-seconds per shard instead of a
+    # spinning core per lane, same wall time (alternated on one box: 104.3 / 368.8 ms spinning, 103.8 / 367.8 sleeping for 8 / 32 leaves)
+    for l in lanes:
+        lib.load().zkm_ctx_set_host_wait(l.ctx.h, C.c_int(1))
     f = farm_mod.Farm()
     trees = [tree_leg(tree, f, lanes, k, O) for k in leaves]
+    host = {"lanes_wait": "sleeping between stream queries (zkm_ctx_set_host_wait 1)", "cores_busy_while_a_tree_runs": [t.pop("cores_busy") for t in trees]}
     out = {"what": "the recursion-tree reduce (crates/prover/src/lib.rs:617-957) at the reference's compress shapes (crates/recursion/core/src/shape.rs:134-171), one MI355X",
            "program": "STAND-IN (ziren_amd/reduce.py): the reference's nine chips, heights and widths, events filling 3/4 of every height, balanced memory lookups, "
                       "the children's commitments + digests witnessed and absorbed into the committed digest; not a verifier of its children (that program comes out of the Rust recursion compiler)",
            "plan": {"first_layer_shape": leaf_shape, "reduce_layers_shape": reduce_shape, "shrink_shape": shrink_shape,
                     "note": "which allowed shape a first-layer / reduce / shrink program lands in is the recursion compiler's output: an assumption here; ms per shard is given for all three"},
-           "per_shape": per_shape, "two_lanes": two, "trees": trees,
+           "per_shape": per_shape, "two_lanes": two, "trees": trees, "host": host,
            "lanes": len(lanes), "tree_mode": "lanes (a context + host thread each) on the one GPU claim nodes from the tree's queue; children's words through the board (a dictionary in one process, the process group's store across ranks); one gather_proofs at the end; proving keys kept per program",
            "lib_digest": lib.check_build_identity(), "seconds_of_program_generation_and_shape_legs": round(gen_s, 1)}
     if core_ms_per_shard:
