@@ -154,6 +154,42 @@ def test_gpu_plain_c_consumer_survives_failures(tmp_path):
     assert lines[-1].startswith("proof ") and lines[-1] == good.stdout.strip().splitlines()[-1]
 
 
+@pytest.mark.gpu
+def test_gpu_out_of_memory_in_the_middle_of_a_proof_leaves_the_context_usable(oracle):
+    """A pool capped at half of what a shard proof needs: zkm_prove_shard fails somewhere inside commit / open with "out of device memory",
+    the caller's transcript has not moved, the failing call has given back what it took (the pool is no larger than the cap), and with the
+    cap lifted the same context makes the very proof it made before."""
+    from ziren_amd import prover
+    ctx = prover.Context(0)
+    sh = synth.syn_shard(14)
+    fri = abi.FriConfig(1, 84, 16)
+    hp = prover.HipProver(sh.chips, fri, synth.NUM_PV_ELTS, ctx=ctx)
+    pk = hp.setup([], [], sh.pc_start, sh.initial_global_cumulative_sum)
+    ch0 = prover.new_challenger()
+    pk.observe_into(ch0)
+    traces = hp.upload_traces([c.trace for c in sh.chips])
+    ctx.trim()
+    held0 = ctx.memory_held()
+    good = hp.prove_shard(pk, sh.public_values, traces, ch0.copy()).copy()
+    need = ctx.memory_held() - held0
+    assert need > (8 << 20)
+    ctx.trim()
+    for frac in (0.5, 0.15, 0.3):
+        ctx.set_memory_limit(held0 + int(frac * need))
+        ch = ch0.copy()
+        with pytest.raises(lib.ZkmError, match="out of device memory"):
+            hp.prove_shard(pk, sh.public_values, traces, ch)
+        assert bytes(ch) == bytes(ch0)                                  # the transcript only advances with a delivered proof
+        assert ctx.memory_held() <= held0 + int(frac * need)
+    ctx.set_memory_limit(0)
+    again = hp.prove_shard(pk, sh.public_values, traces, ch0.copy()).copy()
+    assert np.array_equal(again, good)
+    for t in traces:
+        t.free()
+    pk.free()
+    ctx.close()
+
+
 def test_api_never_unwinds_whatever_is_thrown():
     """API_END catches everything (csrc/zkm_hip.hip): the macro has a catch (...) arm behind the std::exception one."""
     src = open(os.path.join(ROOT, "ziren_amd", "csrc", "zkm_hip.hip")).read()

@@ -230,6 +230,10 @@ int zkm_ctx_set_memory_limit(zkm_ctx* ctx, size_t bytes) {
   if (!ctx) throw std::runtime_error("zkm_ctx_set_memory_limit: null context");
   std::lock_guard<std::mutex> lk(ctx->mu);
   ctx->pool_limit = bytes;
+  if (bytes && ctx->pool_bytes > bytes) {      // a cap below what the pool holds: the cached (idle) buffers go back to the driver now
+    HIP_CHECK(hipSetDevice(ctx->device));
+    ctx->drop_cached();
+  }
   API_END
 }
 size_t zkm_ctx_memory_held(zkm_ctx* ctx) {

@@ -560,6 +560,13 @@ class Context:
     def synchronize(self):
         lib.check(lib.load().zkm_ctx_synchronize(self.h))
 
+    def set_memory_limit(self, nbytes: int):
+        """zkm_ctx_set_memory_limit: cap what the context's pool may hold (0: none); over it a call fails with "out of device memory"."""
+        lib.check(lib.load().zkm_ctx_set_memory_limit(self.h, C.c_size_t(int(nbytes))))
+
+    def memory_held(self) -> int:
+        return int(lib.load().zkm_ctx_memory_held(self.h))
+
     def trim(self):
         lib.check(lib.load().zkm_ctx_trim(self.h))
 
