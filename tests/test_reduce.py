@@ -340,3 +340,23 @@ def test_gpu_tree_over_two_real_ranks_sharing_the_device(tmp_path):
     assert res[0]["digests"] == res[1]["digests"]
     assert res[1]["streams"] is None and [len(s) for s in res[0]["streams"]] == [6, 3, 2, 1, 1]
     assert res[0]["shrink_verified"] is True
+
+
+@pytest.mark.gpu
+def test_gpu_bench_reduce_tree_line():
+    """`bench.py --workload reduce-tree`: one JSON line — per-shape legs (each proof through the restated verifier), a 4-leaf tree under both
+    schedules with the same proofs, recursion shards per second as `value`."""
+    import json
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "reduce-tree", "--leaves", "4", "--steps", "3"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["metric"].startswith("recursion-shard-proofs/sec") and d["value"] > 0 and d["verified"] is True and d["n_gpus"] == 1
+    red = d["reduce"]
+    assert set(red["per_shape"]) == {"shape0_compress_1_84", "shape1_compress_1_84", "shape2_compress_1_84", "shape0_shrink_2_42"}
+    for leg in red["per_shape"].values():
+        assert leg["verified"] is True and 0 < leg["roofline"]["frac"] < 1 and leg["ms_per_shard_traces_resident"] <= leg["ms_per_shard_from_events_unpipelined"] * 1.05
+    t = red["trees"][0]
+    assert t["leaves"] == 4 and t["recursion_shards"] == 4 + 2 + 1 + 1 and t["wall_ms"] > 0 and t["layer_by_layer"]["wall_ms"] > 0
+    assert "STAND-IN" in red["program"]
