@@ -641,8 +641,9 @@ struct ShardOpening {
     for (size_t l = half; l >= 1; l >>= 1) { t.layer_off.push_back(off); off += l; if (l == 1) break; }
     t.digests = (uint32_t*)salloc(off * 8 * 4);
     int fuse = 0;   // FRI trees have one matrix: the first levels are reduced inside the leaf kernel's blocks
-    if (half > 4096 && half >= (size_t)merkle::FRI_FUSE_LEAVES) fuse = std::min(merkle::FRI_FUSE_MAX_LEVELS, lf - 1);
-    if (half <= 4096)      // a latency-bound layer: sixteen lanes per leaf, then the lane-parallel levels (compress_small_layer)
+    static const size_t FRI_LANES_MAX = getenv("ZKM_FRI_LANES_MAX") ? (size_t)atol(getenv("ZKM_FRI_LANES_MAX")) : 4096;     // A/B knob
+    if (half > FRI_LANES_MAX && half >= (size_t)merkle::FRI_FUSE_LEAVES) fuse = std::min(merkle::FRI_FUSE_MAX_LEVELS, lf - 1);
+    if (half <= FRI_LANES_MAX)      // a latency-bound layer: sixteen lanes per leaf, then the lane-parallel levels (compress_small_layer)
       KLAUNCH(ctx, "hash_fri_leaves_lanes", 64.0 * half, merkle::hash_fri_leaves_lanes, dim3(div_up(half * 16, merkle::THREADS)), dim3(merkle::THREADS), 0,
               (const E4*)f, half, t.digests);
     else if (fuse > 0)

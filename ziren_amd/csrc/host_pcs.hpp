@@ -139,7 +139,10 @@ static const uint32_t** upload_ptrs(zkm_ctx* ctx, const std::vector<const uint32
 // synchronisation), false when the caller should go on with the next layer.
 static bool compress_small_layer(zkm_ctx* ctx, Tree& t, int layer, size_t len, merkle::DevChallenger* d_ch = nullptr, kb::E4* d_beta = nullptr,
                                  uint32_t* h_root_slot = nullptr) {
-  const size_t LANES_MAX = 4096, TAIL = 64;
+  // ZKM_LANES_MAX: the largest layer the lane-parallel kernel takes (A/B knob; 4096 is the measured crossover: at 8192 nodes two waves per
+  // SIMD share the issue slots and the level is no faster than the thread-per-node kernel's serial permutation)
+  static const size_t LANES_MAX = getenv("ZKM_LANES_MAX") ? (size_t)atol(getenv("ZKM_LANES_MAX")) : 4096;
+  const size_t TAIL = 64;
   if (len > LANES_MAX) {
     KLAUNCH(ctx, "compress_layer", 96.0 * len, merkle::compress_layer, dim3(div_up(len, merkle::THREADS)), dim3(merkle::THREADS), 0,
             (const uint32_t*)(t.digests + t.layer_off[layer] * 8), t.digests + t.layer_off[layer + 1] * 8, len,
