@@ -134,6 +134,18 @@ class Farm:
             store = self.dist.distributed_c10d._get_default_store()
             return int(store.add(key, 1)) - 1
 
+    def store(self):
+        """(the process group's key-value store or None, the lock every store call of this process goes through). A c10d store client is one
+        connection: calls from several lanes are serialised, and nothing may block inside one (ziren_amd/reduce.py's board polls `check`)."""
+        return (self.dist.distributed_c10d._get_default_store() if self.dist is not None else None), self._claim_lock
+
+    def open_epoch(self, queue: str) -> int:
+        """The number of the batch `queue` is in (every rank calls run_queue / a tree the same number of times, so the numbers agree)."""
+        return self._epochs.get(queue, 0)
+
+    def close_epoch(self, queue: str):
+        self._epochs[queue] = self._epochs.get(queue, 0) + 1
+
     def prime_queue(self, n_shards: int, lanes, queue: str = "shards"):
         """Before a timed `run_queue`: every lane claims its first shard of the batch and queues its prefetch now, so that the batch starts
         the way it continues — each lane's next input already crossing PCIe (or landed) when its proof starts. The caller synchronises

@@ -595,8 +595,7 @@ class _Board:
     def __init__(self, farm, prefix):
         import threading
         self.prefix, self.local, self.cv, self.failed = prefix, {}, threading.Condition(), False
-        self.store = farm.dist.distributed_c10d._get_default_store() if farm.dist is not None else None
-        self.lock = farm._claim_lock
+        self.store, self.lock = farm.store()
 
     def publish(self, g, words):
         w = np.ascontiguousarray(words, dtype=np.uint64)
@@ -693,7 +692,7 @@ class ReduceTree:
         n_total = int(offs[-1])
         layer_of = np.repeat(np.arange(len(layers)), [len(nodes) for *_, nodes in layers])
         progs = [{nc: self.program(si, nc) for nc in {len(ch) for ch in nodes}} for _, si, _, nodes in layers]
-        epoch = farm._epochs.get("reduce_tree", 0)
+        epoch = farm.open_epoch("reduce_tree")
         board = _Board(farm, f"zkm_tree_{epoch}")
 
         def inputs_of(g):             # blocks until the children's words are published
@@ -749,7 +748,7 @@ class ReduceTree:
                 for t in ts:
                     t.join()
         finally:
-            farm._epochs["reduce_tree"] = epoch + 1
+            farm.close_epoch("reduce_tree")
         if errors:
             raise errors[0]
         ids = [i for r in results for i in r[0]]
