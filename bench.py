@@ -995,11 +995,9 @@ def main():
         import bench_tracegen
         return bench_tracegen.tracegen_bench(args)
 
-    if args.workload == "reduce-tree":
-        # the recursion-tree reduce on its own (one GPU): first layer + reduce layers + shrink over stand-in programs at the reference's
-        # compress shapes, through the farm's queue; one JSON line, `value` = recursion shards per second of the largest tree
-        if args.gpus != 1:
-            raise SystemExit("bench.py --workload reduce-tree measures one GPU (the tree's layers are dealt by Farm.run_queue: tests/test_reduce.py covers world 2)")
+    if args.workload == "reduce-tree" and args.gpus == 1 and "WORLD_SIZE" not in os.environ:
+        # the recursion-tree reduce on its own, one GPU, with everything measured: per-shape legs + trees under both schedules; one JSON line,
+        # `value` = recursion shards per second of the largest tree
         r = reduce_leg(0, tuple(int(x) for x in args.leaves.split(",") if x), max(3, min(args.steps, 10)), None)
         t = r["trees"][-1]
         print(json.dumps({"metric": "recursion-shard-proofs/sec (reduce tree)", "value": round(t["recursion_shards"] / t["wall_ms"] * 1e3, 3), "unit": "shard-proofs/s", "n_gpus": 1,
@@ -1010,6 +1008,8 @@ def main():
         return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args.gpus))
+    if args.workload == "reduce-tree":
+        return reduce_tree_main(args)
 
     from ziren_amd import abi, farm as farm_mod
     # tests only: ZKM_BENCH_STUB_PROVER=1 (no GPU at all: gloo, stub lanes) and ZKM_BENCH_ONE_DEVICE=1 (a 1-GPU box standing in for N: every
@@ -1031,6 +1031,77 @@ def main():
             raise SystemExit("bench.py: --resident is the one-GPU resident-trace line")
         return resident_main(args, farm, fri)
     return farm_main(args, farm, fri, built)
+
+
+def reduce_tree_main(args):
+    """`--workload reduce-tree --gpus N` (N > 1, or under a launcher): the reduce tree over N ranks — one process per GPU, two lanes each, all
+    nodes of the tree one claim queue in the process group's store, children's words through the store, ONE gather of the proof streams to
+    rank 0 at the end (RCCL on GPUs: `north_star`'s "RCCL/xGMI only for the final recursion-tree reduce"). `--leaves K` (the last of the list):
+    K N leaves — K first-layer proofs per GPU, so the work per GPU is fixed as N grows (weak scaling; the tree gains log2 N reduce layers).
+    W untimed trees (they build the keys), then `--steps` timed trees between barriers, max over ranks; rank 0 verifies the shrink proof and
+    the root of the reduce layers of the last tree and prints one line: `value` = recursion shards per second of the whole job."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench_reduce_tree as BRT
+    from ziren_amd import farm as farm_mod, field as F, lib, prover, reduce as RD
+    one_device = os.environ.get("ZKM_BENCH_ONE_DEVICE") == "1"
+    rank_env, local_env, world_env = farm_mod.env_rank_world()
+    device = 0 if one_device else local_env
+    lib_digest = lib.check_build_identity()
+    ctxs = [prover.Context(device) for _ in range(max(1, args.inflight))]        # the prover's streams before torch / RCCL make theirs
+    lanes = [RD.ReduceLane(c) for c in ctxs]
+    for c in ctxs:
+        lib.load().zkm_ctx_set_host_wait(c.h, C.c_int(1))
+    tree = RD.ReduceTree(RD.TreePlan(1, 0, 0), BRT.device_permute(ctxs[0]))
+    per_gpu = [int(x) for x in args.leaves.split(",") if x][-1]
+    n_leaves = per_gpu * world_env
+    for nc in (1, 2):                    # every rank generates the same programs (seeded) before the clock
+        tree.program(0, nc)
+    tree.program(1, 1)
+    farm = farm_mod.Farm(backend="gloo" if one_device else None)
+    if one_device:
+        farm.local_rank = 0
+    if farm.world != args.gpus:
+        farm.close()
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the process group has {farm.world} rank(s)")
+    farm.device_sync = lambda: [c.synchronize() for c in ctxs]
+    core = np.random.default_rng(7).integers(0, F.P, (n_leaves, RD.CHILD_WORDS), dtype=np.uint64)      # the same on every rank: child_words of the gathered core proofs
+    for _ in range(max(1, args.warmup)):
+        tree.run(farm, lanes, core)
+    steps = max(1, min(args.steps, 5))
+    farm.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        streams, words = tree.run(farm, lanes, core)
+    farm.barrier()
+    elapsed = farm.max_over_ranks(time.perf_counter() - t0)
+    proved = farm.sum_over_ranks(float(sum(l.host_s["nodes"] for l in lanes)))
+    fewest = -farm.max_over_ranks(-float(sum(l.host_s["nodes"] for l in lanes)))
+    if farm.rank == 0:
+        layers = tree.layers(n_leaves)
+        n_nodes = sum(len(nodes) for *_, nodes in layers)
+        O = oracle()
+        below = [core] + [w.astype(np.uint64) for w in words]
+        salt, ok = 1, True
+        for li, (nm, si, fri_cfg, nodes) in enumerate(layers):
+            if li >= len(layers) - 2:
+                i = len(nodes) - 1
+                ok = ok and BRT.verify(O, tree.program(si, len(nodes[i])), fri_cfg, np.concatenate([below[li][c] for c in nodes[i]]), streams[li][i], salt=salt + i)
+            salt += len(nodes)
+        if not ok:
+            raise SystemExit("bench.py: the verifier REJECTED a proof of the tree; nothing is reported for it")
+        backend = "none (one process)" if farm.dist is None else "gloo" if one_device else "nccl (RCCL)"
+        print(json.dumps({"metric": "recursion-shard-proofs/sec (reduce tree)", "value": round(n_nodes * steps / elapsed, 3), "unit": "shard-proofs/s", "n_gpus": farm.world,
+                          "steps": steps, "warmup": max(1, args.warmup), "ms_per_step": round(elapsed / steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                          "dtype": "u32", "data": "synthetic (stand-in recursion programs, ziren_amd/reduce.py)", "verified": True,
+                          "config": {"workload": f"reduce tree over {n_leaves} core proofs ({per_gpu} per GPU): first layer (shape 1) + {len(layers) - 2} reduce layers + shrink (shape 0), "
+                                                 f"{n_nodes} compress-machine shards at the reference's shapes per tree, pipelined; a step = one tree",
+                                     "parallelism": f"{farm.world} GPU(s), one process each, {len(lanes)} lane(s) per GPU, one claim queue over all nodes, children's words through the store, "
+                                                    f"{backend} gather of {4 * sum(len(p) for s in streams for p in s)} proof bytes to rank 0 at the end of every tree",
+                                     "backend": backend, "ranks_in_process_group": farm.dist.get_world_size() if farm.dist is not None else 1},
+                          "tree_ms": round(elapsed / steps * 1e3, 2), "recursion_shards_per_tree": n_nodes, "nodes_proved_in_all_warmup_included": int(proved), "fewest_nodes_on_a_rank_warmup_included": int(fewest),
+                          "verified_proofs": "the root of the reduce layers and the shrink proof of the last tree", "lib_digest": lib_digest}), flush=True)
+    farm.barrier()
+    farm.close()
 
 
 def resident_main(args, farm, fri):

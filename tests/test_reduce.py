@@ -360,3 +360,22 @@ def test_gpu_bench_reduce_tree_line():
     t = red["trees"][0]
     assert t["leaves"] == 4 and t["recursion_shards"] == 4 + 2 + 1 + 1 and t["wall_ms"] > 0 and t["layer_by_layer"]["wall_ms"] > 0
     assert "STAND-IN" in red["program"]
+
+
+@pytest.mark.gpu
+def test_gpu_bench_reduce_tree_over_two_ranks_on_one_device():
+    """`bench.py --workload reduce-tree --gpus 2` self-launching two ranks that share this box's GPU (ZKM_BENCH_ONE_DEVICE: gloo): one claim
+    queue over all nodes, words through the store, one gather per tree, the last tree's root and shrink proofs verified, one line with
+    n_gpus = 2 and the whole job's recursion shards per second."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(ZKM_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "reduce-tree", "--gpus", "2", "--leaves", "3", "--steps", "2", "--warmup", "1"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["ranks_in_process_group"] == 2 and d["verified"] is True and d["value"] > 0
+    assert d["recursion_shards_per_tree"] == 6 + 3 + 2 + 1 + 1 and d["steps"] == 2 and abs(d["value"] - 13 * 2 / (d["ms_per_step"] * 2 / 1e3)) < 0.5
+    assert d["fewest_nodes_on_a_rank_warmup_included"] >= 1
